@@ -1,0 +1,281 @@
+"""fp64 autograd oracle for the batched augmented-ODE hot path.  TEST INFRASTRUCTURE ONLY.
+
+PARITY UNPINNED BY THE REFERENCE: impICNF/ContinuousNormalizingFlows.jl v0.31.0 is pure
+Julia, there is no Julia in the build container or on the GPU box, and the reference's own
+tests hold no golden vectors for this path (test/ci_tests/smoke_tests.jl:69-156 only check
+`!isnothing`; regression_tests.jl:28 is `@test true`).  This file is therefore an
+*independent second implementation* written from the reference's source text, not the
+reference itself.  It is deliberately built on different machinery than the product
+(torch.autograd VJPs, torch.func JVPs/Jacobians, float64) so that an error in the
+hand-written backward pass of the C restatement / HIP kernels cannot hide in it.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
+
+What it restates (all citations relative to /root/reference):
+  * MLP input rows [z; t; ys]            src/layers/cond_layer.jl:7-31, src/core/icnf.jl:147-153,
+                                         src/core/base_icnf.jl:49-60
+  * Dense chain  h = act(W h + b)        src/core/icnf.jl:67-71 (Lux.Chain of Lux.Dense)
+  * Hutchinson VJP dynamics              src/core/icnf.jl:517-559, src/core/utils.jl:150-159
+  * Hutchinson JVP dynamics              src/core/icnf.jl:561-603, src/core/utils.jl:161-170
+  * exact-trace dynamics (TestMode)      src/core/icnf.jl:297-339, src/core/utils.jl:79-88
+  * regularisers  |zdot|_2, |eps^T J|_2  src/core/icnf.jl:184-205, 229-251
+  * state assembly u0=[x;0], logp        src/core/base_icnf.jl:247-296, 158-172
+  * |z_aug|_2                            src/core/base_icnf.jl:106-132
+  * loss                                 src/core/icnf.jl:628-649
+  * fixed-step RK4 / Tsit5               user-supplied sol_kwargs in the reference
+                                         (src/core/base_icnf.jl:138); tableaux from SURVEY.md §8 A4.
+
+Array convention: every matrix argument is shaped like its Julia counterpart, (rows, B)
+with one column per sample.  Flat parameter vector `p` uses the Lux/ComponentArrays layout:
+layer_1.weight (out x in, column-major), layer_1.bias, layer_2.weight, ...
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+ACT_IDENTITY, ACT_TANH, ACT_SOFTPLUS = 0, 1, 2
+MODE_HUTCH_VJP, MODE_HUTCH_JVP, MODE_EXACT = 0, 1, 2
+ALG_RK4, ALG_TSIT5 = 0, 1
+
+# Tsitouras 2011 5(4) tableau.
+TSIT5_C = (0.0, 0.161, 0.327, 0.9, 0.9800255409045097, 1.0)
+TSIT5_A = (
+    (),
+    (0.161,),
+    (-0.008480655492356989, 0.335480655492357),
+    (2.8971530571054935, -6.359448489975075, 4.3622954328695815),
+    (5.325864828439257, -11.748883564062828, 7.4955393428898365, -0.09249506636175525),
+    (5.86145544294642, -12.92096931784711, 8.159367898576159, -0.071584973281401,
+     -0.028269050394068383),
+)
+TSIT5_B = (0.09646076681806523, 0.01, 0.4798896504144996, 1.379008574103742,
+           -3.290069515436081, 2.324710524099774)
+
+RK4_C = (0.0, 0.5, 0.5, 1.0)
+RK4_A = ((), (0.5,), (0.0, 0.5), (0.0, 0.0, 1.0))
+RK4_B = (1.0 / 6.0, 1.0 / 3.0, 1.0 / 3.0, 1.0 / 6.0)
+
+
+def tableau(alg: int):
+    if alg == ALG_RK4:
+        return RK4_C, RK4_A, RK4_B
+    if alg == ALG_TSIT5:
+        return TSIT5_C, TSIT5_A, TSIT5_B
+    raise ValueError(f"unknown alg {alg}")
+
+
+@dataclass
+class Spec:
+    """Configuration carrier; mirrors the fields of ICNF that reach the hot path
+    (src/core/icnf.jl:16-141)."""
+    nvars: int
+    naug: int = 0
+    ncond: int = 0
+    autonomous: bool = False
+    widths: Sequence[int] = ()      # [n_in, h1, ..., D]
+    acts: Sequence[int] = ()        # one per Dense layer
+    mode: int = MODE_HUTCH_VJP
+    nprobes: int = 1
+    reg_z: bool = False             # NORM_Z  and TrainMode{true}
+    reg_j: bool = False             # NORM_J  and TrainMode{true}
+    reg_aug: bool = False           # NORM_Z_AUG and AUGMENTED and TrainMode{true}
+
+    @property
+    def D(self) -> int:
+        return self.nvars + self.naug
+
+    @property
+    def n_in(self) -> int:
+        return self.D + (0 if self.autonomous else 1) + self.ncond
+
+    @property
+    def S(self) -> int:
+        return self.D + 3
+
+    def check(self):
+        assert len(self.widths) == len(self.acts) + 1
+        assert self.widths[0] == self.n_in, (self.widths, self.n_in)
+        assert self.widths[-1] == self.D
+
+    def param_offsets(self) -> Tuple[List[int], List[int], int]:
+        w_off, b_off, o = [], [], 0
+        for l in range(len(self.acts)):
+            fin, fout = self.widths[l], self.widths[l + 1]
+            w_off.append(o)
+            o += fin * fout
+            b_off.append(o)
+            o += fout
+        return w_off, b_off, o
+
+
+def unpack_params(spec: Spec, p: np.ndarray, dtype=torch.float64):
+    """Flat Lux blob -> [(W (out,in), b (out))]; weight stored column-major (out x in)."""
+    w_off, b_off, n = spec.param_offsets()
+    assert p.shape == (n,), (p.shape, n)
+    out = []
+    for l in range(len(spec.acts)):
+        fin, fout = spec.widths[l], spec.widths[l + 1]
+        W = np.asarray(p[w_off[l]:w_off[l] + fin * fout]).reshape(fin, fout).T  # (out,in)
+        b = np.asarray(p[b_off[l]:b_off[l] + fout])
+        out.append((torch.tensor(np.ascontiguousarray(W), dtype=dtype),
+                    torch.tensor(b, dtype=dtype)))
+    return out
+
+
+def _act(a: torch.Tensor, kind: int) -> torch.Tensor:
+    if kind == ACT_IDENTITY:
+        return a
+    if kind == ACT_TANH:
+        return torch.tanh(a)
+    if kind == ACT_SOFTPLUS:
+        return torch.nn.functional.softplus(a)
+    raise ValueError(kind)
+
+
+def _net(spec: Spec, layers, z: torch.Tensor, t: float, ys: Optional[torch.Tensor]):
+    """z: (D,B) -> zdot (D,B).  Input rows [z; t; ys] (cond_layer.jl:7-31)."""
+    rows = [z]
+    if not spec.autonomous:
+        rows.append(torch.full((1, z.shape[1]), float(t), dtype=z.dtype))
+    if spec.ncond:
+        rows.append(ys)
+    h = torch.cat(rows, dim=0)
+    for (W, b), kind in zip(layers, spec.acts):
+        h = _act(W @ h + b[:, None], kind)
+    return h
+
+
+def aug_f(spec: Spec, p: np.ndarray, u: np.ndarray, t: float, eps: Optional[np.ndarray],
+          ys: Optional[np.ndarray]) -> np.ndarray:
+    """One dynamics call: u (S,B) -> du (S,B) = [zdot; ldot; Edot; ndot]
+    (src/core/icnf.jl:517-536 Hutchinson, :297-316 exact).  eps is (K*D, B): probe k
+    occupies rows k*D:(k+1)*D.  K>1 is the build-defined extension of SURVEY.md §8(a0):
+    ldot = -(1/K) sum_k <eps_k^T J, eps_k>,  ndot = (1/K) sum_k |eps_k^T J|_2."""
+    spec.check()
+    layers = unpack_params(spec, np.asarray(p, dtype=np.float64))
+    D, B = spec.D, u.shape[1]
+    z = torch.tensor(np.asarray(u[:D], dtype=np.float64), requires_grad=True)
+    yt = None if ys is None else torch.tensor(np.asarray(ys, dtype=np.float64))
+    f = lambda zz: _net(spec, layers, zz, t, yt)
+    zdot = f(z)
+    ldot = torch.zeros(B, dtype=torch.float64)
+    ndot = torch.zeros(B, dtype=torch.float64)
+    if spec.mode == MODE_EXACT:
+        # full per-sample Jacobian, then trace (utils.jl:79-88, icnf.jl:312)
+        tr = torch.zeros(B, dtype=torch.float64)
+        for i in range(D):
+            seed = torch.zeros_like(zdot)
+            seed[i] = 1.0
+            (gi,) = torch.autograd.grad(zdot, z, seed, retain_graph=True)
+            tr = tr + gi[i]
+        ldot = -tr
+    else:
+        K = spec.nprobes
+        e = torch.tensor(np.asarray(eps, dtype=np.float64))
+        assert e.shape == (K * D, B)
+        for k in range(K):
+            ek = e[k * D:(k + 1) * D]
+            if spec.mode == MODE_HUTCH_VJP:
+                (g,) = torch.autograd.grad(zdot, z, ek, retain_graph=True)   # eps^T J
+            else:
+                _, g = torch.func.jvp(f, (z.detach(),), (ek,))             # J eps
+            ldot = ldot - (g * ek).sum(0) / K
+            if spec.reg_j:
+                ndot = ndot + torch.linalg.vector_norm(g, dim=0) / K
+    Edot = torch.linalg.vector_norm(zdot, dim=0) if spec.reg_z and spec.mode != MODE_EXACT \
+        else torch.zeros(B, dtype=torch.float64)
+    if spec.mode == MODE_EXACT:
+        ndot = torch.zeros(B, dtype=torch.float64)
+    du = torch.cat([zdot.detach(), ldot[None], Edot.detach()[None], ndot[None]], dim=0)
+    return du.detach().numpy()
+
+
+def integrate_fixed(spec: Spec, p, u0: np.ndarray, t0: float, t1: float, nsteps: int, alg: int,
+                    eps, ys) -> np.ndarray:
+    """base_sol with a fixed-step explicit RK method (src/core/base_icnf.jl:134-140 with
+    sol_kwargs=(alg, adaptive=false, dt)).  Stage time t_n + c_i dt, t_n = t0 + n dt."""
+    c, a, b = tableau(alg)
+    dt = (t1 - t0) / nsteps
+    u = np.asarray(u0, dtype=np.float64).copy()
+    for n in range(nsteps):
+        tn = t0 + n * dt
+        ks = []
+        for i in range(len(c)):
+            ui = u.copy()
+            for j, aij in enumerate(a[i]):
+                if aij != 0.0:
+                    ui += dt * aij * ks[j]
+            ks.append(aug_f(spec, p, ui, tn + c[i] * dt, eps, ys))
+        for bi, ki in zip(b, ks):
+            u += dt * bi * ki
+    return u
+
+
+def std_normal_logpdf(z: np.ndarray) -> np.ndarray:
+    """logpdf of MvNormal(Zeros(d), Eye(d)) per column (src/core/icnf.jl:76-79)."""
+    d = z.shape[0]
+    return -0.5 * d * math.log(2.0 * math.pi) - 0.5 * (z * z).sum(0)
+
+
+def inference_fixed(spec: Spec, p, xs: np.ndarray, t0, t1, nsteps, alg, eps, ys=None):
+    """inference_prob + inference_sol for MatrixMode (src/core/base_icnf.jl:247-296,158-172).
+    Returns logp (B,), (Edot, ndot, Adot) each (B,), u_final (S,B)."""
+    B = xs.shape[1]
+    u0 = np.concatenate([np.asarray(xs, dtype=np.float64),
+                         np.zeros((spec.naug + 3, B))], axis=0)
+    u1 = integrate_fixed(spec, p, u0, t0, t1, nsteps, alg, eps, ys)
+    D = spec.D
+    z, dlogp = u1[:D], u1[D]
+    logp = std_normal_logpdf(z) - dlogp
+    if spec.reg_aug and spec.naug > 0:
+        Adot = np.sqrt((z[spec.nvars:] ** 2).sum(0))
+    else:
+        Adot = np.zeros(B)
+    return logp, (u1[D + 1].copy(), u1[D + 2].copy(), Adot), u1
+
+
+def loss(spec: Spec, p, xs, t0, t1, nsteps, alg, eps, ys=None, lambdas=(0.0, 0.0, 0.0)):
+    """mean(-logp + l1 E + l2 n + l3 A)  (src/core/icnf.jl:628-649)."""
+    logp, (E, n, A), _ = inference_fixed(spec, p, xs, t0, t1, nsteps, alg, eps, ys)
+    return float(np.mean(-logp + lambdas[0] * E + lambdas[1] * n + lambdas[2] * A))
+
+
+# ----------------------------------------------------------------------------------------
+# deterministic synthetic inputs
+# ----------------------------------------------------------------------------------------
+def make_spec(nvars, hidden: Sequence[int], act=ACT_TANH, naug=0, ncond=0, autonomous=False,
+              **kw) -> Spec:
+    D = nvars + naug
+    n_in = D + (0 if autonomous else 1) + ncond
+    widths = [n_in, *hidden, D]
+    acts = [act] * len(hidden) + [ACT_IDENTITY]
+    s = Spec(nvars=nvars, naug=naug, ncond=ncond, autonomous=autonomous, widths=widths,
+             acts=acts, **kw)
+    s.check()
+    return s
+
+
+def glorot_params(spec: Spec, rng: np.random.Generator, bias_scale: float = 0.0) -> np.ndarray:
+    """W ~ U(-sqrt(6/(in+out)), +), b = bias_scale*N(0,1); flat Lux layout, float32."""
+    parts = []
+    for l in range(len(spec.acts)):
+        fin, fout = spec.widths[l], spec.widths[l + 1]
+        lim = math.sqrt(6.0 / (fin + fout))
+        W = rng.uniform(-lim, lim, size=(fout, fin))
+        parts.append(W.T.reshape(-1))                 # column-major (out x in)
+        parts.append(bias_scale * rng.standard_normal(fout))
+    return np.concatenate(parts).astype(np.float32)
+
+
+def synth_inputs(spec: Spec, B: int, seed: int, bias_scale: float = 0.0):
+    rng = np.random.default_rng(seed)
+    p = glorot_params(spec, rng, bias_scale)
+    xs = rng.standard_normal((spec.nvars, B)).astype(np.float32)
+    eps = rng.standard_normal((spec.nprobes * spec.D, B)).astype(np.float32)
+    ys = rng.standard_normal((spec.ncond, B)).astype(np.float32) if spec.ncond else None
+    return p, xs, eps, ys
