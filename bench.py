@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""bench.py — throughput of the batched log-density hot path on MI355X.
+
+A "step" is one pass of the hot path over one batch: `loss(icnf, mode, xs, ps, st)` =
+cnf_inference_fixed (fused fixed-step solve + log-density epilogue) + cnf_loss_sums (+ the
+RCCL all-reduce of the loss scalars when N > 1), with inputs already resident in HBM.
+Metric (BASELINE.json): log-density evaluations counted as samples·steps per second.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg2|cfg2p|cfg3|cfg5|cfg1]
+
+N > 1 is launched by the driver as `python -m torch.distributed.run --nproc-per-node N ...`;
+the batch columns are sharded by rank (weak scaling: 65 536 columns per GPU), no data-path
+collective, one all-reduce of five scalars per step.
+
+The JSON line also carries
+  roofline     — the fused solve kernel against the f32 MFMA peak (the path is compute-bound:
+                 ≥ 97 flop/B); its HBM figure is reported beside it.
+  cpu_baseline — the CPU fp32 restatement (oracle/, "port") timed on this host's cores on a
+                 bounded sample of the same workload (rank 0, N = 1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as entry  # noqa: E402
+
+# workload table: SURVEY.md §8(d).  flop / bytes are ALGORITHMIC figures per sample·step.
+CONFIGS = {
+    # name: (make_spec kwargs, alg, B per GPU, flop per sample·step, per-call-ABI bytes per sample·step,
+    #        fused bytes per sample per solve, description)
+    "cfg1": (dict(nvars=2, hidden=[32, 32]), 1, 1024, 28032, 288, 20,
+             "FFJORD nvars=2, MLP 2x32 tanh, Tsit5 40 fixed steps, batch=1024, Hutchinson(1)"),
+    "cfg2": (dict(nvars=8, hidden=[64, 64, 64]), 0, 65536, 147968, 480, 68,
+             "FFJORD nvars=8, MLP 3x64 tanh, RK4 40 steps, batch=65536, Hutchinson(1)"),
+    "cfg2p": (dict(nvars=8, hidden=[64, 64, 64]), 1, 65536, 221952, 720, 68,
+              "FFJORD nvars=8, MLP 3x64 tanh, Tsit5 40 steps, batch=65536, Hutchinson(1)"),
+    "cfg3": (dict(nvars=8, hidden=[64, 64, 64], nprobes=4, reg_z=True, reg_j=True), 1, 65536,
+             553728, 1296, 164,
+             "RNODE nvars=8, MLP 3x64 tanh, Tsit5 40 steps, batch=65536, Hutchinson(4)"),
+    "cfg4": (dict(nvars=32, hidden=[256, 256, 256]), 0, 32768, 2361344, 1632, 260,
+             "FFJORD nvars=32, MLP 3x256 tanh, RK4 40 steps, batch=32768 per GPU, Hutchinson(1)"),
+    "cfg5": (dict(nvars=8, ncond=8, hidden=[128, 128, 128], mode=2), 0, 16384, 2393088, 480, 68,
+             "CondFFJORD nvars=8+8 cond, MLP 3x128 tanh, exact trace, RK4 40 steps, batch=16384"),
+}
+NSTEPS = 40
+F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 = f32 vector rate
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
+    ap.add_argument("--batch", type=int, default=0, help="override columns per GPU")
+    ap.add_argument("--path", type=int, default=0, help="0 auto, 1 SIMT, 2 MFMA")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    return ap.parse_args()
+
+
+def cpu_baseline(o64, oc, spec, alg, p, xs, eps, ys, target_s):
+    """Time the CPU restatement on all host cores on a bounded column sample."""
+    nt = os.cpu_count() or 1
+    nt = min(nt, oc.max_threads()) if oc.max_threads() > 0 else nt
+    B0 = 64 * nt
+    t = time.perf_counter()
+    oc.inference_fixed(spec, p, xs[:, :B0], 0.0, 1.0, NSTEPS, alg, eps[:, :B0],
+                       None if ys is None else ys[:, :B0], nthreads=nt)
+    dt0 = time.perf_counter() - t
+    rate0 = B0 * NSTEPS / dt0
+    Bs = int(min(xs.shape[1], max(B0, rate0 * target_s / NSTEPS)))
+    Bs = max(B0, Bs // (64 * nt) * (64 * nt))
+    t = time.perf_counter()
+    oc.inference_fixed(spec, p, xs[:, :Bs], 0.0, 1.0, NSTEPS, alg, eps[:, :Bs],
+                       None if ys is None else ys[:, :Bs], nthreads=nt)
+    dt = time.perf_counter() - t
+    return dict(value=Bs * NSTEPS / dt, unit="samples*steps/s", cores=nt, kind="port",
+                sample=f"{Bs} of the workload's columns, one full {NSTEPS}-step solve, "
+                       f"{dt:.1f} s, oracle/cnf_oracle.c (gcc -O3 -march=x86-64-v3 -fopenmp)")
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus > 1 and world == 1:
+        print(f"bench.py --gpus {a.gpus} must be launched with torch.distributed.run", file=sys.stderr)
+        sys.exit(2)
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    pkg = entry.load_package()
+    o64, oc = entry.load_oracle()
+    kw, alg, Bdef, flop_ss, bytes_call_ss, bytes_fused, desc = CONFIGS[a.config]
+    B = a.batch or Bdef
+    spec = o64.make_spec(**kw)
+    # weights are shared by all ranks; the batch is generated per global column block so an
+    # N-GPU run evaluates N different shards (weak scaling).
+    p = o64.glorot_params(spec, np.random.default_rng(20240612))
+    rng = np.random.default_rng(20240612 + 1000 * (rank + 1))
+    xs = rng.standard_normal((spec.nvars, B)).astype(np.float32)
+    eps = rng.standard_normal((spec.nprobes * spec.D, B)).astype(np.float32)
+    ys = rng.standard_normal((spec.ncond, B)).astype(np.float32) if spec.ncond else None
+
+    acts = {0: "identity", 1: "tanh", 2: "softplus"}
+    layers = [pkg.Dense(spec.widths[i], spec.widths[i + 1], acts[spec.acts[i]])
+              for i in range(len(spec.acts))]
+    reg = bool(spec.reg_z or spec.reg_j)
+    icnf = pkg.ICNF(nvariables=spec.nvars, naugments=spec.naug, nconditions=spec.ncond,
+                    nn=pkg.Chain(*layers), compute_mode=pkg.HIPVecJacMatrixMode(kernel_path=a.path),
+                    steer_rate=0.0, lambda1=0.01 if spec.reg_z else 0.0,
+                    lambda2=0.01 if spec.reg_j else 0.0, lambda3=0.0, nprobes=spec.nprobes,
+                    device=dev, sol_kwargs=dict(alg=pkg.Tsit5() if alg == 1 else pkg.RK4(),
+                                                adaptive=False, nsteps=NSTEPS))
+    mode = pkg.TestMode() if spec.mode == 2 else pkg.TrainMode(reg)
+    # inputs resident in HBM, already in the column-major layout the ABI takes
+    X = torch.tensor(xs.T.copy(), device=dev).t()
+    E = torch.tensor(eps.T.copy(), device=dev).t()
+    Y = torch.tensor(ys.T.copy(), device=dev).t() if ys is not None else None
+    P = torch.tensor(p, device=dev)
+    args = (X,) + ((Y,) if Y is not None else ()) + (P, {})
+
+    def step():
+        return pkg.loss(icnf, mode, *args, eps=E)
+
+    def sync():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    for _ in range(a.warmup):
+        step()
+    sync()
+    # kernel-only timing with events on the launching stream (solve kernel = dominant kernel)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+          for _ in range(a.steps)]
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        ev[i][0].record()
+        logp, regs = pkg.inference(icnf, mode, *args, eps=E)
+        ev[i][1].record()
+        sums = pkg.loss_sums(icnf, mode, logp, torch.stack(list(regs)))
+        lossv = pkg.reduce_loss(sums, B, (icnf.lambda1, icnf.lambda2, icnf.lambda3))
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    kern_ms = float(np.mean([s.elapsed_time(e) for s, e in ev]))
+
+    if rank == 0:
+        value = world * B * NSTEPS * a.steps / elapsed
+        path = icnf.kernel_path(mode)
+        flops_launch = float(flop_ss) * B * NSTEPS
+        ach_tflops = flops_launch / (kern_ms * 1e-3) / 1e12
+        stages = 4 if alg == 0 else 6
+        out = {
+            "metric": "log-density evals (samples*steps)/sec",
+            "value": value, "unit": "samples*steps/s", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": desc, "name": a.config, "columns_per_gpu": B,
+                       "global_columns": world * B, "nsteps": NSTEPS,
+                       "integrator": "RK4" if alg == 0 else "Tsit5",
+                       "kernel_path": {1: "simt", 2: "mfma"}.get(path, str(path)),
+                       "parallelism": f"column-shard x{world}, loss all-reduce (5 scalars)"},
+            "loss": float(lossv),
+            "roofline": {
+                "bound": "mfma", "achieved": ach_tflops, "peak": F32_MFMA_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": ach_tflops / F32_MFMA_PEAK_TFLOPS, "traffic": None,
+                "kernel_ms": kern_ms, "flop_per_sample_step": flop_ss,
+                "hbm_model": {
+                    "fused_bytes_per_launch": bytes_fused * B,
+                    "fused_GBps": bytes_fused * B / (kern_ms * 1e-3) / 1e9,
+                    "per_call_abi_bytes_per_launch": bytes_call_ss * B * NSTEPS,
+                    "per_call_abi_GBps": bytes_call_ss * B * NSTEPS / (kern_ms * 1e-3) / 1e9,
+                    "per_call_abi_frac_of_8TBps": bytes_call_ss * B * NSTEPS / (kern_ms * 1e-3) / 1e9
+                    / HBM_PEAK_GBS,
+                    "stages_per_step": stages},
+            },
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(o64, oc, spec, alg, p, xs, eps, ys, a.cpu_seconds)
+            out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

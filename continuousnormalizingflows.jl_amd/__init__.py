@@ -1,0 +1,11 @@
+"""MI355X-native hot path of impICNF/ContinuousNormalizingFlows.jl: hand-written HIP kernels
+behind a C ABI (include/cnf.h, csrc/), plus the host-side mirror of the reference's
+ICNF / inference / generate / loss interface (icnf.py) and the column-sharding helper.
+
+The directory name follows the repository contract (`continuousnormalizingflows.jl_amd`) and is
+not a valid Python identifier; `__graft_entry__.load_package()` registers it as `cnf_amd`.
+"""
+from . import _lib
+from .icnf import *  # noqa: F401,F403
+from .icnf import loss_sums  # noqa: F401
+from .sharding import reduce_loss, shard_columns  # noqa: F401

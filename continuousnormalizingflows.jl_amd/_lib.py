@@ -1,0 +1,90 @@
+"""ctypes binding of libcnf_hip.so — the C ABI declared in include/cnf.h.
+
+The product path has no CPU fallback: if the shared library is missing or cannot be loaded
+this module raises, and every compute entry point of the library itself returns an error when
+no gfx950 device is visible.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libcnf_hip.so")
+CSRC = os.path.join(_PKG, "csrc")
+MAX_LAYERS = 8
+
+OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_NO_PARAMS, ERR_HIP, ERR_NO_DEVICE = 0, -1, -2, -3, -4, -5
+ACT_IDENTITY, ACT_TANH, ACT_SOFTPLUS = 0, 1, 2
+MODE_HUTCH_VJP, MODE_HUTCH_JVP, MODE_EXACT = 0, 1, 2
+ALG_RK4, ALG_TSIT5 = 0, 1
+PATH_AUTO, PATH_SIMT, PATH_MFMA = 0, 1, 2
+
+EXPORTS = ("cnf_version", "cnf_last_error", "cnf_create", "cnf_destroy", "cnf_set_params",
+           "cnf_kernel_path", "cnf_aug_f", "cnf_integrate_fixed", "cnf_inference_fixed",
+           "cnf_loss_sums")
+
+
+class CnfConfig(C.Structure):
+    _fields_ = [("nvars", C.c_int32), ("naug", C.c_int32), ("ncond", C.c_int32),
+                ("autonomous", C.c_int32), ("n_layers", C.c_int32),
+                ("widths", C.c_int32 * (MAX_LAYERS + 1)), ("acts", C.c_int32 * MAX_LAYERS),
+                ("mode", C.c_int32), ("nprobes", C.c_int32),
+                ("reg_z", C.c_int32), ("reg_j", C.c_int32), ("reg_aug", C.c_int32),
+                ("device_id", C.c_int32), ("kernel_path", C.c_int32)]
+
+
+class CnfError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"libcnf_hip error {code}: {msg}")
+        self.code = code
+
+
+def build(verbose: bool = False) -> str:
+    """Compile every HIP source for gfx950 into continuousnormalizingflows.jl_amd/libcnf_hip.so."""
+    out = None if verbose else subprocess.DEVNULL
+    subprocess.check_call(["make", "-C", CSRC, "-j4", "all"], stdout=out)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the product path.")
+    # torch ships its own libamdhip64.so.7; import it first so both sides share one HIP runtime
+    # (device pointers and streams are then interchangeable).
+    try:
+        import torch  # noqa: F401
+    except Exception:  # pragma: no cover
+        pass
+    lib = C.CDLL(LIB_PATH)
+    vp, fp, szp = C.c_void_p, C.c_void_p, C.POINTER(C.c_size_t)
+    lib.cnf_version.restype = C.c_int
+    lib.cnf_last_error.restype = C.c_char_p
+    lib.cnf_create.argtypes = [C.POINTER(vp), C.POINTER(CnfConfig)]
+    lib.cnf_destroy.argtypes = [vp]
+    lib.cnf_set_params.argtypes = [vp, fp, C.c_size_t, szp, szp, C.c_int, vp]
+    lib.cnf_kernel_path.argtypes = [vp]
+    lib.cnf_aug_f.argtypes = [vp, fp, fp, C.c_float, fp, fp, C.c_int64, vp]
+    lib.cnf_integrate_fixed.argtypes = [vp, C.c_int, C.c_int, C.c_float, C.c_float, fp, fp, fp,
+                                        C.c_int64, fp, vp]
+    lib.cnf_inference_fixed.argtypes = [vp, C.c_int, C.c_int, C.c_float, C.c_float, fp, fp, fp,
+                                        C.c_int64, fp, fp, fp, vp]
+    lib.cnf_loss_sums.argtypes = [vp, fp, fp, C.c_int64, fp, vp]
+    for name in EXPORTS:
+        getattr(lib, name)  # AttributeError if the ABI is incomplete
+    _lib = lib
+    return lib
+
+
+def check(rc: int):
+    if rc != 0:
+        raise CnfError(rc, load().cnf_last_error().decode())

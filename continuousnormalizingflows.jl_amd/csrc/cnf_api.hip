@@ -1,0 +1,338 @@
+// cnf_api.hip — the C ABI of libcnf_hip.so (see include/cnf.h for the contract).
+//
+// Host-side only: handle lifetime, validation, parameter repacking, workspace management and
+// dispatch to the kernel families (cnf_mfma.hip: fused whole-solve MFMA kernels;
+// cnf_simt.hip: generic per-call kernels).  There is no CPU fallback: without a gfx950 device
+// every entry point that would compute returns CNF_ERR_NO_DEVICE / CNF_ERR_HIP.
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "cnf_internal.h"
+
+using namespace cnf;
+
+namespace {
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                       \
+    do {                                                                                    \
+        hipError_t _e = (expr);                                                             \
+        if (_e != hipSuccess)                                                               \
+            return fail(CNF_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));    \
+    } while (0)
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = false;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        ok = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+}  // namespace
+
+struct cnf_handle {
+    cnf_config cfg{};
+    int D = 0, S = 0;
+    NetDev net{};
+    size_t nparams = 0;
+    bool have_params = false;
+    int path = CNF_PATH_SIMT;
+    // device copies of the parameters
+    float* P_dev = nullptr;       // Lux layout (SIMT path)
+    MfmaPlan* plan = nullptr;
+    float* packed_dev = nullptr;  // MFMA operand image
+    // SIMT workspaces, grown on demand
+    float* ws = nullptr;
+    int64_t ws_B = 0;
+    float* kbuf = nullptr;        // 6 stage derivatives + 1 state, each S x kbuf_B
+    int64_t kbuf_B = 0;
+    float* loss_partial = nullptr;
+};
+
+static int ensure_ws(cnf_handle* h, int64_t B) {
+    if (B <= h->ws_B) return CNF_OK;
+    if (h->ws) HIP_TRY(hipFree(h->ws));
+    h->ws = nullptr;
+    h->ws_B = 0;
+    const int64_t Bp = (B + 255) / 256 * 256;
+    HIP_TRY(hipMalloc((void**)&h->ws, simt_ws_rows(h->net) * (size_t)Bp * sizeof(float)));
+    h->ws_B = Bp;
+    return CNF_OK;
+}
+
+static int ensure_kbuf(cnf_handle* h, int64_t B) {
+    if (B <= h->kbuf_B) return CNF_OK;
+    if (h->kbuf) HIP_TRY(hipFree(h->kbuf));
+    h->kbuf = nullptr;
+    h->kbuf_B = 0;
+    HIP_TRY(hipMalloc((void**)&h->kbuf, 7 * (size_t)h->S * (size_t)B * sizeof(float)));
+    h->kbuf_B = B;
+    return CNF_OK;
+}
+
+extern "C" {
+
+int cnf_version(void) { return CNF_ABI_VERSION; }
+
+const char* cnf_last_error(void) { return g_err.c_str(); }
+
+int cnf_create(cnf_handle** out, const cnf_config* cfg) {
+    if (!out || !cfg) return fail(CNF_ERR_INVALID, "cnf_create: null argument");
+    *out = nullptr;
+    const cnf_config& c = *cfg;
+    if (c.nvars < 1 || c.naug < 0 || c.ncond < 0)
+        return fail(CNF_ERR_INVALID, "cnf_create: nvars >= 1, naug >= 0, ncond >= 0 required");
+    if (c.n_layers < 1 || c.n_layers > CNF_MAX_LAYERS)
+        return fail(CNF_ERR_INVALID, "cnf_create: n_layers out of range");
+    const int D = c.nvars + c.naug;
+    const int n_in = D + (c.autonomous ? 0 : 1) + c.ncond;  // src/core/icnf.jl:64
+    if (c.widths[0] != n_in)
+        return fail(CNF_ERR_INVALID, "cnf_create: widths[0] must equal nvars+naug+!autonomous+ncond");
+    if (c.widths[c.n_layers] != D)
+        return fail(CNF_ERR_INVALID, "cnf_create: last width must equal nvars+naug");
+    for (int l = 0; l <= c.n_layers; ++l)
+        if (c.widths[l] < 1) return fail(CNF_ERR_INVALID, "cnf_create: widths must be positive");
+    for (int l = 0; l < c.n_layers; ++l)
+        if (c.acts[l] < CNF_ACT_IDENTITY || c.acts[l] > CNF_ACT_SOFTPLUS)
+            return fail(CNF_ERR_INVALID, "cnf_create: unknown activation id");
+    if (c.mode < CNF_MODE_HUTCH_VJP || c.mode > CNF_MODE_EXACT)
+        return fail(CNF_ERR_INVALID, "cnf_create: unknown mode");
+    if (c.nprobes < 1) return fail(CNF_ERR_INVALID, "cnf_create: nprobes >= 1 required");
+    if (c.kernel_path < CNF_PATH_AUTO || c.kernel_path > CNF_PATH_MFMA)
+        return fail(CNF_ERR_INVALID, "cnf_create: unknown kernel_path");
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(CNF_ERR_NO_DEVICE, "cnf_create: no HIP device visible (libcnf_hip has no CPU fallback)");
+    if (c.device_id < 0 || c.device_id >= ndev)
+        return fail(CNF_ERR_INVALID, "cnf_create: device_id out of range");
+
+    cnf_handle* h = new cnf_handle();
+    h->cfg = c;
+    h->D = D;
+    h->S = D + 3;
+    NetDev& n = h->net;
+    n.D = D; n.C = c.ncond; n.autonomous = c.autonomous; n.n_layers = c.n_layers;
+    n.maxw = 0;
+    for (int l = 0; l <= c.n_layers; ++l) {
+        n.widths[l] = c.widths[l];
+        if (c.widths[l] > n.maxw) n.maxw = c.widths[l];
+    }
+    for (int l = 0; l < c.n_layers; ++l) n.acts[l] = c.acts[l];
+    n.mode = c.mode; n.K = c.nprobes; n.reg_z = c.reg_z; n.reg_j = c.reg_j;
+
+    h->path = CNF_PATH_SIMT;
+    if (c.kernel_path != CNF_PATH_SIMT) {
+        h->plan = mfma_plan_create(c);
+        if (h->plan) {
+            h->path = CNF_PATH_MFMA;
+        } else if (c.kernel_path == CNF_PATH_MFMA) {
+            delete h;
+            return fail(CNF_ERR_UNSUPPORTED, "cnf_create: configuration not covered by the MFMA kernels");
+        }
+    }
+    *out = h;
+    return CNF_OK;
+}
+
+int cnf_destroy(cnf_handle* h) {
+    if (!h) return CNF_OK;
+    DeviceGuard g(h->cfg.device_id);
+    if (h->P_dev) (void)hipFree(h->P_dev);
+    if (h->packed_dev) (void)hipFree(h->packed_dev);
+    if (h->ws) (void)hipFree(h->ws);
+    if (h->kbuf) (void)hipFree(h->kbuf);
+    if (h->loss_partial) (void)hipFree(h->loss_partial);
+    if (h->plan) mfma_plan_destroy(h->plan);
+    delete h;
+    return CNF_OK;
+}
+
+int cnf_kernel_path(const cnf_handle* h) { return h ? h->path : CNF_ERR_INVALID; }
+
+int cnf_set_params(cnf_handle* h, const float* p, size_t n, const size_t* w_off,
+                   const size_t* b_off, int p_is_device, void* stream) {
+    if (!h || !p || !w_off || !b_off) return fail(CNF_ERR_INVALID, "cnf_set_params: null argument");
+    const cnf_config& c = h->cfg;
+    for (int l = 0; l < c.n_layers; ++l) {
+        const size_t wn = (size_t)c.widths[l] * (size_t)c.widths[l + 1];
+        if (w_off[l] + wn > n || b_off[l] + (size_t)c.widths[l + 1] > n)
+            return fail(CNF_ERR_INVALID, "cnf_set_params: layer offsets exceed the parameter vector");
+    }
+    DeviceGuard g(c.device_id);
+    if (!g.ok) return fail(CNF_ERR_HIP, "cnf_set_params: hipSetDevice failed");
+    hipStream_t st = (hipStream_t)stream;
+    // host copy (needed for repacking)
+    std::vector<float> host(n);
+    if (p_is_device) {
+        HIP_TRY(hipMemcpyAsync(host.data(), p, n * sizeof(float), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    } else {
+        std::memcpy(host.data(), p, n * sizeof(float));
+    }
+    if (h->path == CNF_PATH_MFMA) {
+        const size_t bytes = mfma_packed_bytes(h->plan);
+        if (!h->packed_dev) HIP_TRY(hipMalloc((void**)&h->packed_dev, bytes));
+        std::vector<float> packed(bytes / sizeof(float), 0.f);
+        mfma_pack(h->plan, host.data(), w_off, b_off, packed.data());
+        HIP_TRY(hipMemcpyAsync(h->packed_dev, packed.data(), bytes, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    } else {
+        if (h->P_dev && h->nparams != n) {
+            HIP_TRY(hipFree(h->P_dev));
+            h->P_dev = nullptr;
+        }
+        if (!h->P_dev) HIP_TRY(hipMalloc((void**)&h->P_dev, n * sizeof(float)));
+        HIP_TRY(hipMemcpyAsync(h->P_dev, host.data(), n * sizeof(float), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        for (int l = 0; l < c.n_layers; ++l) {
+            h->net.w_off[l] = (int)w_off[l];
+            h->net.b_off[l] = (int)b_off[l];
+        }
+    }
+    h->nparams = n;
+    h->have_params = true;
+    return CNF_OK;
+}
+
+static int check_call(cnf_handle* h, const float* eps, const float* ys, int64_t B, const char* who) {
+    if (!h) return fail(CNF_ERR_INVALID, std::string(who) + ": null handle");
+    if (!h->have_params) return fail(CNF_ERR_NO_PARAMS, std::string(who) + ": cnf_set_params not called");
+    if (B < 0) return fail(CNF_ERR_INVALID, std::string(who) + ": negative batch");
+    if (h->cfg.mode != CNF_MODE_EXACT && !eps && B > 0)
+        return fail(CNF_ERR_INVALID, std::string(who) + ": eps is required in Hutchinson modes");
+    if (h->cfg.ncond > 0 && !ys && B > 0)
+        return fail(CNF_ERR_INVALID, std::string(who) + ": ys is required when ncond > 0");
+    return CNF_OK;
+}
+
+int cnf_aug_f(cnf_handle* h, float* du, const float* u, float t, const float* eps,
+              const float* ys, int64_t B, void* stream) {
+    int rc = check_call(h, eps, ys, B, "cnf_aug_f");
+    if (rc) return rc;
+    if (B == 0) return CNF_OK;
+    if (!du || !u) return fail(CNF_ERR_INVALID, "cnf_aug_f: null u/du");
+    if (du == u) return fail(CNF_ERR_INVALID, "cnf_aug_f: du may not alias u");
+    DeviceGuard g(h->cfg.device_id);
+    hipStream_t st = (hipStream_t)stream;
+    if (h->path == CNF_PATH_MFMA) {
+        SolveArgs a{};
+        a.u0 = u; a.eps = eps; a.ys = ys; a.B = B; a.nsteps = 0; a.alg = 0; a.t0 = t; a.t1 = t;
+        a.u_out = du; a.nvars = h->cfg.nvars; a.reg_aug = 0;
+        HIP_TRY(mfma_solve(h->plan, h->packed_dev, a, st));
+        return CNF_OK;
+    }
+    rc = ensure_ws(h, B);
+    if (rc) return rc;
+    StageIn in{};
+    in.u = u; in.nprev = 0; in.dt = 0.f;
+    HIP_TRY(simt_aug_f(h->net, h->P_dev, in, t, eps, ys, B, du, h->ws, h->ws_B, st));
+    return CNF_OK;
+}
+
+static int simt_integrate(cnf_handle* h, int alg, int nsteps, float t0, float t1, float* u,
+                          const float* eps, const float* ys, int64_t B, hipStream_t st) {
+    // u is integrated in place.  Unfused structure: one launch per stage + one per step.
+    int rc = ensure_ws(h, B);
+    if (rc) return rc;
+    rc = ensure_kbuf(h, B);
+    if (rc) return rc;
+    const Tableau T = make_tableau(alg);
+    const size_t n = (size_t)h->S * (size_t)B;
+    float* k[6];
+    for (int i = 0; i < 6; ++i) k[i] = h->kbuf + (size_t)i * n;
+    const float dt = (t1 - t0) / (float)nsteps;
+    for (int step = 0; step < nsteps; ++step) {
+        const float tn = t0 + (float)step * dt;
+        for (int i = 0; i < T.ns; ++i) {
+            StageIn in{};
+            in.u = u; in.nprev = i; in.dt = dt;
+            for (int j = 0; j < i; ++j) { in.k[j] = k[j]; in.coef[j] = T.a[i][j]; }
+            HIP_TRY(simt_aug_f(h->net, h->P_dev, in, tn + T.c[i] * dt, eps, ys, B, k[i], h->ws,
+                               h->ws_B, st));
+        }
+        StageIn fin{};
+        fin.u = u; fin.nprev = T.ns; fin.dt = dt;
+        for (int j = 0; j < T.ns; ++j) { fin.k[j] = k[j]; fin.coef[j] = T.b[j]; }
+        HIP_TRY(rk_update(u, fin, (int64_t)n, st));
+    }
+    return CNF_OK;
+}
+
+int cnf_integrate_fixed(cnf_handle* h, int alg, int nsteps, float t0, float t1, const float* u0,
+                        const float* eps, const float* ys, int64_t B, float* u1, void* stream) {
+    int rc = check_call(h, eps, ys, B, "cnf_integrate_fixed");
+    if (rc) return rc;
+    if (nsteps < 1) return fail(CNF_ERR_INVALID, "cnf_integrate_fixed: nsteps >= 1 required");
+    if (alg != CNF_ALG_RK4 && alg != CNF_ALG_TSIT5)
+        return fail(CNF_ERR_INVALID, "cnf_integrate_fixed: unknown alg");
+    if (B == 0) return CNF_OK;
+    if (!u0 || !u1) return fail(CNF_ERR_INVALID, "cnf_integrate_fixed: null u0/u1");
+    DeviceGuard g(h->cfg.device_id);
+    hipStream_t st = (hipStream_t)stream;
+    if (h->path == CNF_PATH_MFMA) {
+        SolveArgs a{};
+        a.u0 = u0; a.eps = eps; a.ys = ys; a.B = B; a.nsteps = nsteps; a.alg = alg;
+        a.t0 = t0; a.t1 = t1; a.u_out = u1; a.nvars = h->cfg.nvars; a.reg_aug = 0;
+        HIP_TRY(mfma_solve(h->plan, h->packed_dev, a, st));
+        return CNF_OK;
+    }
+    if (u1 != u0)
+        HIP_TRY(hipMemcpyAsync(u1, u0, (size_t)h->S * (size_t)B * sizeof(float),
+                               hipMemcpyDeviceToDevice, st));
+    return simt_integrate(h, alg, nsteps, t0, t1, u1, eps, ys, B, st);
+}
+
+int cnf_inference_fixed(cnf_handle* h, int alg, int nsteps, float t0, float t1, const float* x,
+                        const float* eps, const float* ys, int64_t B, float* logp, float* regs,
+                        float* u_final, void* stream) {
+    int rc = check_call(h, eps, ys, B, "cnf_inference_fixed");
+    if (rc) return rc;
+    if (nsteps < 1) return fail(CNF_ERR_INVALID, "cnf_inference_fixed: nsteps >= 1 required");
+    if (alg != CNF_ALG_RK4 && alg != CNF_ALG_TSIT5)
+        return fail(CNF_ERR_INVALID, "cnf_inference_fixed: unknown alg");
+    if (B == 0) return CNF_OK;
+    if (!x || !logp) return fail(CNF_ERR_INVALID, "cnf_inference_fixed: null x/logp");
+    DeviceGuard g(h->cfg.device_id);
+    hipStream_t st = (hipStream_t)stream;
+    const int reg_aug = (h->cfg.reg_aug && h->cfg.naug > 0 && h->cfg.mode != CNF_MODE_EXACT) ? 1 : 0;
+    if (h->path == CNF_PATH_MFMA) {
+        SolveArgs a{};
+        a.x = x; a.eps = eps; a.ys = ys; a.B = B; a.nsteps = nsteps; a.alg = alg;
+        a.t0 = t0; a.t1 = t1; a.u_out = u_final; a.logp = logp; a.regs = regs;
+        a.nvars = h->cfg.nvars; a.reg_aug = reg_aug;
+        HIP_TRY(mfma_solve(h->plan, h->packed_dev, a, st));
+        return CNF_OK;
+    }
+    rc = ensure_kbuf(h, B);
+    if (rc) return rc;
+    float* u = u_final ? u_final : h->kbuf + 6 * (size_t)h->S * (size_t)h->kbuf_B;
+    HIP_TRY(assemble_u0(x, h->cfg.nvars, h->S, B, u, st));
+    rc = simt_integrate(h, alg, nsteps, t0, t1, u, eps, ys, B, st);
+    if (rc) return rc;
+    HIP_TRY(epilogue(u, h->cfg.nvars, h->D, reg_aug, B, logp, regs, st));
+    return CNF_OK;
+}
+
+int cnf_loss_sums(cnf_handle* h, const float* logp, const float* regs, int64_t B, float* sums4,
+                  void* stream) {
+    if (!h || !logp || !sums4) return fail(CNF_ERR_INVALID, "cnf_loss_sums: null argument");
+    if (B < 0) return fail(CNF_ERR_INVALID, "cnf_loss_sums: negative batch");
+    DeviceGuard g(h->cfg.device_id);
+    if (!h->loss_partial) HIP_TRY(hipMalloc((void**)&h->loss_partial, 256 * 4 * sizeof(float)));
+    HIP_TRY(loss_sums(logp, regs, B, h->loss_partial, sums4, (hipStream_t)stream));
+    return CNF_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,70 @@
+// cnf_internal.h — internal interfaces between the C-ABI layer and the kernel files.
+#pragma once
+#include "cnf_common.h"
+
+namespace cnf {
+
+// Device-side description of the Dense chain (passed by value as a kernel argument).
+struct NetDev {
+    int D, C, autonomous, n_layers, maxw;
+    int widths[CNF_MAX_LAYERS + 1];
+    int acts[CNF_MAX_LAYERS];
+    int w_off[CNF_MAX_LAYERS];  // offsets into the device copy of the Lux parameter blob
+    int b_off[CNF_MAX_LAYERS];
+    int mode, K, reg_z, reg_j;
+};
+
+// Runge-Kutta stage combination folded into a kernel prologue:
+//   value = u + dt * sum_{j<nprev} coef[j] * k[j]
+struct StageIn {
+    const float* u;
+    const float* k[6];
+    float coef[6];
+    int nprev;
+    float dt;
+};
+
+// ---- generic SIMT path (cnf_simt.hip) ----
+size_t simt_ws_rows(const NetDev& net);
+hipError_t simt_aug_f(const NetDev& net, const float* P, const StageIn& in, float t,
+                      const float* eps, const float* ys, int64_t B, float* du, float* ws,
+                      int64_t ld, hipStream_t st);
+hipError_t rk_update(float* u, const StageIn& in, int64_t n, hipStream_t st);
+hipError_t assemble_u0(const float* x, int nvars, int S, int64_t B, float* u, hipStream_t st);
+hipError_t epilogue(const float* u, int nvars, int D, int reg_aug, int64_t B, float* logp,
+                    float* regs, hipStream_t st);
+hipError_t loss_sums(const float* logp, const float* regs, int64_t B, float* partial,
+                     float* sums4, hipStream_t st);
+
+// ---- fused MFMA path (cnf_mfma.hip) ----
+struct MfmaPlan;  // opaque: packed-weight layout + kernel selection for one config
+
+// Returns nullptr if the configuration is outside what the MFMA kernels cover.
+MfmaPlan* mfma_plan_create(const cnf_config& cfg);
+void mfma_plan_destroy(MfmaPlan* p);
+// bytes of the packed weight image (device buffer the plan needs)
+size_t mfma_packed_bytes(const MfmaPlan* p);
+// host-side repack of the Lux blob into the MFMA operand image
+void mfma_pack(const MfmaPlan* p, const float* lux, const size_t* w_off, const size_t* b_off,
+               float* packed);
+const char* mfma_plan_name(const MfmaPlan* p);
+
+struct SolveArgs {
+    // exactly one of x (nvars x B, u0 = [x;0]) or u0 (S x B) is non-null
+    const float* x;
+    const float* u0;
+    const float* eps;
+    const float* ys;
+    int64_t B;
+    int nsteps;      // 0 = single dynamics call (aug_f): du written to u_out, evaluated at t0
+    int alg;
+    float t0, t1;
+    float* u_out;    // S x B or null
+    float* logp;     // B or null
+    float* regs;     // 3B or null
+    int nvars, reg_aug;
+};
+hipError_t mfma_solve(const MfmaPlan* p, const float* packed_dev, const SolveArgs& a,
+                      hipStream_t st);
+
+}  // namespace cnf

@@ -1,0 +1,513 @@
+"""Host-side mirror of the reference's AbstractICNF interface for the batched (MatrixMode)
+fixed-step path, sitting directly on the C ABI of libcnf_hip.so.
+
+The reference is Julia (no Julia toolchain in this image), so this module plays the role the
+`HIPMatrixMode` glue of INTEGRATION.md plays there: same names, argument order, array shapes
+((rows, B), one column per sample) and error behaviour as the reference's `ICNF`, `inference`,
+`generate`, `loss`, `TrainMode`/`TestMode` and ComputeMode types, so the parity tests read like
+the reference's smoke tests (test/ci_tests/smoke_tests.jl).  torch is used only for device
+memory, streams, RNG and torch.distributed.
+
+Reference map (relative to the reference repo):
+  ICNF(; ...)                      src/core/icnf.jl:53-141
+  TrainMode / TestMode             src/core/types.jl:1-7
+  *MatrixMode compute modes        src/core/types.jl:9-35
+  inference / generate             src/core/base_icnf.jl:406-465
+  loss                             src/core/icnf.jl:628-649
+  (icnf)(xs, ps, st)               src/core/base_icnf.jl:509-523
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass
+from typing import Callable, Dict, Optional, Sequence, Tuple, Union
+
+import torch
+
+from . import _lib
+
+__all__ = [
+    "ICNF", "TrainMode", "TestMode", "Dense", "Chain", "tanh", "softplus", "identity",
+    "HIPVecJacMatrixMode", "HIPJacVecMatrixMode", "LuxVecJacMatrixMode", "LuxJacVecMatrixMode",
+    "DIVecJacMatrixMode", "DIJacVecMatrixMode", "Tsit5", "RK4", "setup", "inference", "generate",
+    "loss", "augmented_f",
+]
+
+
+# ---------------------------------------------------------------------------------------
+# modes (src/core/types.jl)
+# ---------------------------------------------------------------------------------------
+class Mode:
+    pass
+
+
+class TestMode(Mode):
+    __test__ = False  # not a pytest class
+
+    def __repr__(self):
+        return "TestMode()"
+
+
+class TrainMode(Mode):
+    """TrainMode{REG}; TrainMode() == TrainMode{true}() (src/core/types.jl:5-7)."""
+
+    def __init__(self, reg: bool = True):
+        self.reg = bool(reg)
+
+    def __repr__(self):
+        return f"TrainMode{{{str(self.reg).lower()}}}()"
+
+
+class ComputeMode:
+    jacvec = False
+
+
+class MatrixMode(ComputeMode):
+    """Whole batch in one solve.  `kernel_path` is PATH_AUTO / PATH_SIMT / PATH_MFMA."""
+
+    def __init__(self, adback=None, kernel_path: int = _lib.PATH_AUTO):
+        self.adback = adback  # accepted for signature parity; AD is hand-written in the kernels
+        self.kernel_path = kernel_path
+
+
+class HIPVecJacMatrixMode(MatrixMode):
+    jacvec = False
+
+
+class HIPJacVecMatrixMode(MatrixMode):
+    jacvec = True
+
+
+# The reference's MatrixMode names select the same estimators; they resolve to the HIP kernels.
+LuxVecJacMatrixMode = DIVecJacMatrixMode = HIPVecJacMatrixMode
+LuxJacVecMatrixMode = DIJacVecMatrixMode = HIPJacVecMatrixMode
+
+
+# ---------------------------------------------------------------------------------------
+# network description (Lux.Chain of Lux.Dense, src/core/icnf.jl:67-71)
+# ---------------------------------------------------------------------------------------
+def identity(x):
+    return x
+
+
+def tanh(x):
+    return torch.tanh(x)
+
+
+def softplus(x):
+    return torch.nn.functional.softplus(x)
+
+
+_ACT_IDS = {identity: _lib.ACT_IDENTITY, tanh: _lib.ACT_TANH, softplus: _lib.ACT_SOFTPLUS,
+            None: _lib.ACT_IDENTITY, "identity": _lib.ACT_IDENTITY, "tanh": _lib.ACT_TANH,
+            "softplus": _lib.ACT_SOFTPLUS}
+
+
+@dataclass
+class Dense:
+    """Dense(in => out, activation)."""
+    n_in: int
+    n_out: int
+    activation: Union[Callable, str, None] = identity
+
+    @property
+    def act_id(self) -> int:
+        try:
+            return _ACT_IDS[self.activation]
+        except KeyError:
+            raise TypeError(f"MethodError: no HIP kernel for activation {self.activation!r} "
+                            "(supported: identity, tanh, softplus)") from None
+
+
+class Chain:
+    def __init__(self, *layers: Dense):
+        if not layers:
+            raise ValueError("Chain needs at least one Dense layer")
+        for a, b in zip(layers[:-1], layers[1:]):
+            if a.n_out != b.n_in:
+                raise ValueError(f"DimensionMismatch: Dense({a.n_in}=>{a.n_out}) followed by "
+                                 f"Dense({b.n_in}=>{b.n_out})")
+        self.layers = tuple(layers)
+
+    @property
+    def widths(self):
+        return [self.layers[0].n_in] + [l.n_out for l in self.layers]
+
+    def param_offsets(self):
+        """ComponentArray layout: layer_k.weight (out x in, column-major), layer_k.bias."""
+        w_off, b_off, o = [], [], 0
+        for l in self.layers:
+            w_off.append(o)
+            o += l.n_in * l.n_out
+            b_off.append(o)
+            o += l.n_out
+        return w_off, b_off, o
+
+
+# ---------------------------------------------------------------------------------------
+# solver selection (sol_kwargs.alg)
+# ---------------------------------------------------------------------------------------
+class Tsit5:
+    alg_id = _lib.ALG_TSIT5
+
+
+class RK4:
+    alg_id = _lib.ALG_RK4
+
+
+# ---------------------------------------------------------------------------------------
+# ICNF
+# ---------------------------------------------------------------------------------------
+class _Handle:
+    """Owns one cnf_handle (one trace mode / regulariser combination)."""
+
+    def __init__(self, cfg: _lib.CnfConfig):
+        self.lib = _lib.load()
+        self.ptr = C.c_void_p()
+        _lib.check(self.lib.cnf_create(C.byref(self.ptr), C.byref(cfg)))
+        self.params_key = None
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                self.lib.cnf_destroy(self.ptr)
+                self.ptr = None
+        except Exception:
+            pass
+
+
+def _stream_ptr(device) -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _ptr(t: Optional[torch.Tensor]) -> C.c_void_p:
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+class ICNF:
+    """Keyword constructor mirroring `ICNF(; ...)` (src/core/icnf.jl:53-103).
+
+    Differences forced by the fixed-step HIP path (all raise instead of silently falling back):
+      * `sol_kwargs` must select a fixed-step method: alg in {Tsit5(), RK4()}, adaptive=False,
+        and either `dt` or `nsteps`.  The reference default (adaptive VCABM) is not implemented.
+      * `nn` must be a Chain of Dense layers with identity/tanh/softplus activations.
+      * data_type is Float32.
+    """
+
+    def __init__(self, *, data_type=torch.float32, compute_mode: Optional[ComputeMode] = None,
+                 inplace: bool = False, autonomous: bool = False, device=None, rng=None,
+                 tspan: Tuple[float, float] = (0.0, 1.0), nvariables: int = 1,
+                 naugments: Optional[int] = None, nconditions: int = 0, n_in: Optional[int] = None,
+                 n_out: Optional[int] = None, n_hidden: Optional[int] = None,
+                 nn: Optional[Chain] = None, steer_rate: float = 0.1, lambda1: float = 0.01,
+                 lambda2: float = 0.01, lambda3: float = 0.01, nprobes: int = 1,
+                 sol_kwargs: Optional[dict] = None, **aliases):
+        # accept the reference's unicode keyword names too
+        lambda1 = aliases.pop("λ₁", lambda1)
+        lambda2 = aliases.pop("λ₂", lambda2)
+        lambda3 = aliases.pop("λ₃", lambda3)
+        if aliases:
+            raise TypeError(f"MethodError: unknown keyword(s) {sorted(aliases)}")
+        if data_type is not torch.float32:
+            raise TypeError("MethodError: the HIP path computes in Float32 only")
+        self.data_type = data_type
+        self.compute_mode = compute_mode if compute_mode is not None else HIPVecJacMatrixMode()
+        if not isinstance(self.compute_mode, MatrixMode):
+            raise TypeError("MethodError: only MatrixMode compute modes are implemented "
+                            "(VectorMode solves one sample at a time and is out of scope)")
+        self.inplace = bool(inplace)
+        self.autonomous = bool(autonomous)
+        self.device = torch.device(device if device is not None else "cuda:0")
+        if self.device.type != "cuda":
+            raise TypeError("MethodError: HIPMatrixMode needs a cuda (ROCm) device; "
+                            "there is no CPU fallback")
+        self.tspan = (float(tspan[0]), float(tspan[1]))
+        self.nvariables = int(nvariables)
+        self.naugments = int(nvariables + 1 if naugments is None else naugments)  # icnf.jl:62
+        self.nconditions = int(nconditions)
+        D = self.nvariables + self.naugments
+        n_in = D + (0 if autonomous else 1) + self.nconditions if n_in is None else n_in
+        n_out = D if n_out is None else n_out
+        n_hidden = 4 * n_in if n_hidden is None else n_hidden
+        if nn is None:  # icnf.jl:67-71
+            nn = Chain(Dense(n_in, n_hidden, softplus), Dense(n_hidden, n_hidden, softplus),
+                       Dense(n_hidden, n_out))
+        if not isinstance(nn, Chain):
+            raise TypeError("MethodError: nn must be a Chain of Dense layers")
+        self.nn = nn
+        self.steer_rate = float(steer_rate)
+        self.lambda1, self.lambda2, self.lambda3 = float(lambda1), float(lambda2), float(lambda3)
+        self.nprobes = int(nprobes)
+        self.rng = rng
+        if self.rng is None and torch.cuda.is_available():
+            self.rng = torch.Generator(device=self.device)
+            self.rng.manual_seed(0)
+        self.sol_kwargs = dict(sol_kwargs or {})
+        self._handles: Dict[tuple, _Handle] = {}
+        w = nn.widths
+        if w[0] != D + (0 if autonomous else 1) + self.nconditions or w[-1] != D:
+            raise ValueError(
+                f"DimensionMismatch: nn maps {w[0]} => {w[-1]} but the flow needs "
+                f"{D + (0 if autonomous else 1) + self.nconditions} => {D}")
+        if len(nn.layers) > _lib.MAX_LAYERS:
+            raise ValueError(f"at most {_lib.MAX_LAYERS} Dense layers are supported")
+
+    # -- type-parameter style flags (src/core/icnf.jl:105-125) --
+    @property
+    def D(self) -> int:
+        return self.nvariables + self.naugments
+
+    @property
+    def S(self) -> int:
+        return self.D + 3  # n_augments == 2 always (icnf.jl:143-145) plus dlogp
+
+    @property
+    def conditioned(self) -> bool:
+        return self.nconditions != 0
+
+    @property
+    def augmented(self) -> bool:
+        return self.naugments != 0
+
+    def _solver(self):
+        kw = self.sol_kwargs
+        alg = kw.get("alg")
+        if alg is None or not hasattr(alg, "alg_id"):
+            raise NotImplementedError(
+                "sol_kwargs.alg must be Tsit5() or RK4(); the reference's adaptive default "
+                "(VCABM, reltol=abstol=1e-4) couples samples through its step controller and is "
+                "not implemented by the fixed-step HIP path")
+        if kw.get("adaptive", True):
+            raise NotImplementedError("sol_kwargs.adaptive must be False (fixed-step path)")
+        return alg.alg_id
+
+    def _nsteps(self, t0: float, t1: float) -> int:
+        kw = self.sol_kwargs
+        if "nsteps" in kw:
+            return int(kw["nsteps"])
+        if "dt" not in kw:
+            raise NotImplementedError("sol_kwargs needs dt (or nsteps) with adaptive=False")
+        n = abs(t1 - t0) / float(kw["dt"])
+        return max(1, int(round(n)))
+
+    def _steer_tspan(self, mode: Mode) -> Tuple[float, float]:
+        """steer_tspan (src/core/base_icnf.jl:23-43)."""
+        t0, t1 = self.tspan
+        if self.steer_rate != 0.0 and isinstance(mode, TrainMode) and mode.reg:
+            r = (torch.rand((), generator=self.rng, device=self.device).item() * 2.0 - 1.0) \
+                * self.steer_rate
+            t1 = t1 + abs(t1 - t0) * r
+        return t0, t1
+
+    def _handle(self, mode: Mode) -> _Handle:
+        train = isinstance(mode, TrainMode)
+        if not train and not isinstance(mode, TestMode):
+            raise TypeError(f"MethodError: no method for mode {mode!r}")
+        reg = train and mode.reg
+        if not train:
+            tmode = _lib.MODE_EXACT
+        else:
+            tmode = _lib.MODE_HUTCH_JVP if self.compute_mode.jacvec else _lib.MODE_HUTCH_VJP
+        key = (tmode, reg)
+        h = self._handles.get(key)
+        if h is None:
+            cfg = _lib.CnfConfig()
+            cfg.nvars, cfg.naug, cfg.ncond = self.nvariables, self.naugments, self.nconditions
+            cfg.autonomous = int(self.autonomous)
+            cfg.n_layers = len(self.nn.layers)
+            for i, wd in enumerate(self.nn.widths):
+                cfg.widths[i] = wd
+            for i, l in enumerate(self.nn.layers):
+                cfg.acts[i] = l.act_id
+            cfg.mode = tmode
+            cfg.nprobes = self.nprobes if train else 1
+            cfg.reg_z = int(reg and self.lambda1 != 0.0)       # NORM_Z   (icnf.jl:113)
+            cfg.reg_j = int(reg and self.lambda2 != 0.0)       # NORM_J   (icnf.jl:114)
+            cfg.reg_aug = int(reg and self.lambda3 != 0.0 and self.augmented)  # NORM_Z_AUG
+            cfg.device_id = self.device.index or 0
+            cfg.kernel_path = self.compute_mode.kernel_path
+            h = _Handle(cfg)
+            self._handles[key] = h
+        return h
+
+    def _bind_params(self, h: _Handle, ps: torch.Tensor):
+        w_off, b_off, n = self.nn.param_offsets()
+        if ps.dtype != torch.float32 or ps.dim() != 1 or ps.numel() != n:
+            raise ValueError(f"DimensionMismatch: ps must be a Float32 vector of length {n}")
+        key = (ps.data_ptr(), ps._version, str(ps.device))
+        if h.params_key == key:
+            return
+        ps_c = ps.contiguous()
+        wo = (C.c_size_t * len(w_off))(*w_off)
+        bo = (C.c_size_t * len(b_off))(*b_off)
+        _lib.check(h.lib.cnf_set_params(h.ptr, _ptr(ps_c), n, wo, bo, int(ps_c.is_cuda),
+                                        _stream_ptr(self.device)))
+        h.params_key = key
+
+    def kernel_path(self, mode: Mode) -> int:
+        h = self._handle(mode)
+        return int(h.lib.cnf_kernel_path(h.ptr))
+
+    # Lux-layer call (src/core/base_icnf.jl:509-523)
+    def __call__(self, xs, ps, st):
+        if self.conditioned:
+            x, y = xs
+            return inference(self, TrainMode(False), x, y, ps, st)[0], st
+        return inference(self, TrainMode(False), xs, ps, st)[0], st
+
+
+# ---------------------------------------------------------------------------------------
+# helpers
+# ---------------------------------------------------------------------------------------
+def setup(rng: Optional[torch.Generator], icnf: ICNF):
+    """LuxCore.setup + ComponentArray: flat Float32 parameter vector (glorot-uniform weights,
+    zero biases — Lux.Dense defaults) and an empty state."""
+    parts = []
+    for l in icnf.nn.layers:
+        lim = math.sqrt(6.0 / (l.n_in + l.n_out))
+        W = (torch.rand(l.n_out, l.n_in, generator=rng, dtype=torch.float64) * 2 - 1) * lim
+        parts.append(W.t().reshape(-1))  # column-major (out x in)
+        parts.append(torch.zeros(l.n_out, dtype=torch.float64))
+    return torch.cat(parts).to(torch.float32), {}
+
+
+def _colmajor(a: torch.Tensor, rows: int, name: str, device) -> torch.Tensor:
+    """(rows, B) tensor -> Julia memory layout (B x rows contiguous), on the device."""
+    if a.dim() != 2 or a.shape[0] != rows:
+        raise ValueError(f"DimensionMismatch: {name} must be ({rows}, B), got {tuple(a.shape)}")
+    if a.device != device:
+        raise ValueError(f"{name} must live on {device} (got {a.device})")
+    return a.to(torch.float32).t().contiguous()
+
+
+def _draw_eps(icnf: ICNF, K: int, B: int) -> torch.Tensor:
+    """rand!(rng, epsdist, eps): standard normal (src/core/base_icnf.jl:258-259)."""
+    return torch.randn(B, K * icnf.D, generator=icnf.rng, device=icnf.device, dtype=torch.float32)
+
+
+def _split_args(icnf: ICNF, args, what: str):
+    """(xs, ps, st) or (xs, ys, ps, st) as in the reference's method table."""
+    if icnf.conditioned:
+        if len(args) != 4:
+            raise TypeError(f"MethodError: {what}(icnf, mode, xs, ys, ps, st) expected for a "
+                            "conditioned ICNF")
+        return args
+    if len(args) != 3:
+        raise TypeError(f"MethodError: {what}(icnf, mode, xs, ps, st) expected")
+    return args[0], None, args[1], args[2]
+
+
+def inference(icnf: ICNF, mode: Mode, *args, eps: Optional[torch.Tensor] = None,
+              return_state: bool = False):
+    """inference(icnf, mode, xs[, ys], ps, st) -> (logp̂x (B,), (Ė, ṅ, Ȧ)).
+
+    `eps` ((K*D, B)) pins the Hutchinson probes; by default they are drawn from icnf.rng as
+    the reference does.  xs is (nvariables, B), ys (nconditions, B)."""
+    xs, ys, ps, st = _split_args(icnf, args, "inference")
+    h = icnf._handle(mode)
+    icnf._bind_params(h, ps)
+    dev = icnf.device
+    x = _colmajor(xs, icnf.nvariables, "xs", dev)
+    B = x.shape[0]
+    y = _colmajor(ys, icnf.nconditions, "ys", dev) if icnf.conditioned else None
+    if y is not None and y.shape[0] != B:
+        raise ValueError("DimensionMismatch: xs and ys must have the same number of columns")
+    train = isinstance(mode, TrainMode)
+    K = icnf.nprobes if train else 1
+    if eps is None:
+        e = _draw_eps(icnf, K, B)  # drawn (and unused) in TestMode too, like base_icnf.jl:258
+    else:
+        e = _colmajor(eps, K * icnf.D, "eps", dev)
+        if e.shape[0] != B:
+            raise ValueError("DimensionMismatch: eps must have B columns")
+    t0, t1 = icnf._steer_tspan(mode)
+    alg = icnf._solver()
+    nsteps = icnf._nsteps(t0, t1)
+    logp = torch.empty(B, device=dev, dtype=torch.float32)
+    regs = torch.empty(3, B, device=dev, dtype=torch.float32)
+    uf = torch.empty(B, icnf.S, device=dev, dtype=torch.float32) if return_state else None
+    _lib.check(h.lib.cnf_inference_fixed(h.ptr, alg, nsteps, t0, t1, _ptr(x), _ptr(e), _ptr(y), B,
+                                         _ptr(logp), _ptr(regs), _ptr(uf), _stream_ptr(dev)))
+    out = (logp, (regs[0], regs[1], regs[2]))
+    if return_state:
+        return out + (uf.t(),)
+    return out
+
+
+def generate(icnf: ICNF, mode: Mode, *args, z0: Optional[torch.Tensor] = None,
+             eps: Optional[torch.Tensor] = None):
+    """generate(icnf, mode, [ys,] ps, st, n) -> (nvariables, n) samples: integrate the base
+    sample backwards over the reversed tspan (src/core/base_icnf.jl:351-404, 185-194)."""
+    if icnf.conditioned:
+        if len(args) != 4:
+            raise TypeError("MethodError: generate(icnf, mode, ys, ps, st, n) expected")
+        ys, ps, st, n = args
+    else:
+        if len(args) != 3:
+            raise TypeError("MethodError: generate(icnf, mode, ps, st, n) expected")
+        ps, st, n = args
+        ys = None
+    h = icnf._handle(mode)
+    icnf._bind_params(h, ps)
+    dev = icnf.device
+    D, S = icnf.D, icnf.S
+    if z0 is None:
+        z = torch.randn(n, D, generator=icnf.rng, device=dev, dtype=torch.float32)
+    else:
+        z = _colmajor(z0, D, "z0", dev)
+    train = isinstance(mode, TrainMode)
+    K = icnf.nprobes if train else 1
+    e = _draw_eps(icnf, K, n) if eps is None else _colmajor(eps, K * D, "eps", dev)
+    y = _colmajor(ys, icnf.nconditions, "ys", dev) if icnf.conditioned else None
+    u0 = torch.zeros(n, S, device=dev, dtype=torch.float32)
+    u0[:, :D] = z
+    t0, t1 = icnf._steer_tspan(mode)
+    alg = icnf._solver()
+    nsteps = icnf._nsteps(t0, t1)
+    u1 = torch.empty_like(u0)
+    _lib.check(h.lib.cnf_integrate_fixed(h.ptr, alg, nsteps, t1, t0, _ptr(u0), _ptr(e), _ptr(y), n,
+                                         _ptr(u1), _stream_ptr(dev)))
+    return u1[:, :icnf.nvariables].t()
+
+
+def augmented_f(icnf: ICNF, mode: Mode, u: torch.Tensor, ps: torch.Tensor, t: float,
+                eps: Optional[torch.Tensor], ys: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """One dynamics call du = f(u, p, t): the closure of make_ode_func
+    (src/core/base_icnf.jl:62-78; src/core/icnf.jl:517-536).  u: (S, B)."""
+    h = icnf._handle(mode)
+    icnf._bind_params(h, ps)
+    dev = icnf.device
+    um = _colmajor(u, icnf.S, "u", dev)
+    B = um.shape[0]
+    train = isinstance(mode, TrainMode)
+    K = icnf.nprobes if train else 1
+    e = None if eps is None else _colmajor(eps, K * icnf.D, "eps", dev)
+    y = _colmajor(ys, icnf.nconditions, "ys", dev) if icnf.conditioned else None
+    du = torch.empty_like(um)
+    _lib.check(h.lib.cnf_aug_f(h.ptr, _ptr(du), _ptr(um), float(t), _ptr(e), _ptr(y), B,
+                               _stream_ptr(dev)))
+    return du.t()
+
+
+def loss_sums(icnf: ICNF, mode: Mode, logp: torch.Tensor, regs) -> torch.Tensor:
+    """Device-side partial sums [Σ-logp, ΣĖ, Σṅ, ΣȦ] of this rank's columns."""
+    h = icnf._handle(mode)
+    B = logp.numel()
+    r = torch.stack(list(regs)).contiguous() if not (
+        isinstance(regs, torch.Tensor) and regs.is_contiguous()) else regs
+    sums = torch.empty(4, device=icnf.device, dtype=torch.float32)
+    _lib.check(h.lib.cnf_loss_sums(h.ptr, _ptr(logp.contiguous()), _ptr(r), B, _ptr(sums),
+                                   _stream_ptr(icnf.device)))
+    return sums
+
+
+def loss(icnf: ICNF, mode: Mode, *args, eps: Optional[torch.Tensor] = None, group=None):
+    """loss(icnf, mode, xs[, ys], ps, st) = mean(-logp̂x + λ₁Ė + λ₂ṅ + λ₃Ȧ)
+    (src/core/icnf.jl:628-649).  When torch.distributed is initialised the batch columns are
+    taken to be sharded over the ranks of `group`: the four partial sums and the column count
+    are all-reduced (RCCL over xGMI on GPUs) and every rank returns the global mean."""
+    from .sharding import reduce_loss
+    logp, (E, n, A) = inference(icnf, mode, *args, eps=eps)
+    sums = loss_sums(icnf, mode, logp, torch.stack([E, n, A]))
+    return reduce_loss(sums, logp.numel(), (icnf.lambda1, icnf.lambda2, icnf.lambda3), group=group)

@@ -1,0 +1,137 @@
+/* cnf.h — C ABI of libcnf_hip.so: the MI355X (gfx950) implementation of the batched
+ * augmented-ODE hot path of impICNF/ContinuousNormalizingFlows.jl v0.31.0.
+ *
+ * The reference has no FFI: its extension point is Julia dispatch on a ComputeMode subtype
+ * (src/core/types.jl:9-35).  A `HIPMatrixMode <: MatrixMode` binds the entry
+ * points below with `ccall`; each one names the reference method it replaces.  Citations are
+ * relative to the reference repository root.
+ *
+ * Conventions
+ *   - plain C: pointers, sizes, scalars; no C++/torch types; nothing throws across the ABI.
+ *   - every function returns 0 on success or a negative cnf_status; cnf_last_error() gives the
+ *     message of the last failure on the calling thread.
+ *   - all matrices are Float32 in the reference's Julia layout: column-major, one column per
+ *     sample (a sample's rows contiguous, stride between samples = row count).
+ *   - D = nvars + naug, S = D + 3 state rows [z (D); dlogp; E; n]  (src/core/icnf.jl:143-145,
+ *     535; src/core/base_icnf.jl:165-167).
+ *   - u, du, x, eps, ys, logp, regs, u_final, sums4 are DEVICE pointers (hipMalloc or a torch /
+ *     ROCArray allocation on the handle's device).  p in cnf_set_params may be host or device.
+ *   - work is enqueued on the caller's HIP stream (`stream` is a hipStream_t passed as void*;
+ *     NULL = the null stream) and is asynchronous with respect to the host.
+ *   - the caller owns every array; the library keeps no caller pointer after a call returns
+ *     (cnf_set_params copies and repacks the weights).  A handle is bound to one device and is
+ *     not thread-safe; distinct handles are independent.
+ *   - NaN/Inf in outputs is not an error (the reference ignores the solver retcode,
+ *     src/core/base_icnf.jl:138-139).
+ */
+#ifndef CNF_H
+#define CNF_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CNF_ABI_VERSION 1
+#define CNF_MAX_LAYERS 8
+
+typedef enum {
+    CNF_OK = 0,
+    CNF_ERR_INVALID = -1,      /* bad argument / inconsistent config (Julia: MethodError/DimensionMismatch) */
+    CNF_ERR_UNSUPPORTED = -2,  /* configuration outside what the kernels implement */
+    CNF_ERR_NO_PARAMS = -3,    /* cnf_set_params has not been called */
+    CNF_ERR_HIP = -4,          /* HIP runtime error (message in cnf_last_error) */
+    CNF_ERR_NO_DEVICE = -5     /* no gfx950 device visible */
+} cnf_status;
+
+/* activation ids of Lux.Dense layers (src/core/icnf.jl:67-71) */
+enum { CNF_ACT_IDENTITY = 0, CNF_ACT_TANH = 1, CNF_ACT_SOFTPLUS = 2 };
+
+/* trace estimator = ComputeMode x Mode of the reference:
+ *   HUTCH_VJP  LuxVecJacMatrixMode / DIVecJacMatrixMode + TrainMode   (src/core/utils.jl:150-159)
+ *   HUTCH_JVP  LuxJacVecMatrixMode / DIJacVecMatrixMode + TrainMode   (src/core/utils.jl:161-170)
+ *   EXACT      any MatrixMode + TestMode                              (src/core/utils.jl:79-88) */
+enum { CNF_MODE_HUTCH_VJP = 0, CNF_MODE_HUTCH_JVP = 1, CNF_MODE_EXACT = 2 };
+
+/* fixed-step integrators a user selects through sol_kwargs=(alg, adaptive=false, dt)
+ * (src/core/base_icnf.jl:138) */
+enum { CNF_ALG_RK4 = 0, CNF_ALG_TSIT5 = 1 };
+
+/* kernel families (cnf_kernel_path) */
+enum { CNF_PATH_AUTO = 0, CNF_PATH_SIMT = 1, CNF_PATH_MFMA = 2 };
+
+/* Configuration = the ICNF fields and type parameters that reach the hot path
+ * (src/core/icnf.jl:16-141). */
+typedef struct {
+    int32_t nvars;                        /* nvariables */
+    int32_t naug;                         /* naugments (AUGMENTED = naug != 0) */
+    int32_t ncond;                        /* nconditions (CONDITIONED = ncond != 0) */
+    int32_t autonomous;                   /* 1: no time row in the MLP input */
+    int32_t n_layers;                     /* Dense layers in the Chain */
+    int32_t widths[CNF_MAX_LAYERS + 1];   /* widths[0]=n_in=D+!autonomous+ncond, ..., widths[n_layers]=D */
+    int32_t acts[CNF_MAX_LAYERS];         /* CNF_ACT_* per layer */
+    int32_t mode;                         /* CNF_MODE_* */
+    int32_t nprobes;                      /* K Hutchinson probes (reference: 1) */
+    int32_t reg_z;                        /* Edot=|zdot|_2 on: NORM_Z and TrainMode{true} (icnf.jl:184-199) */
+    int32_t reg_j;                        /* ndot=|eps^T J|_2 on: NORM_J and TrainMode{true} (icnf.jl:229-245) */
+    int32_t reg_aug;                      /* Adot=|z_aug|_2 on: NORM_Z_AUG, AUGMENTED, TrainMode{true} (base_icnf.jl:106-122) */
+    int32_t device_id;                    /* HIP device ordinal */
+    int32_t kernel_path;                  /* CNF_PATH_*; AUTO picks MFMA when the shape is supported */
+} cnf_config;
+
+typedef struct cnf_handle cnf_handle;
+
+int cnf_version(void);
+const char* cnf_last_error(void);
+
+/* ICNF(; ...) constructor (src/core/icnf.jl:53-141): validates and binds a config to a device. */
+int cnf_create(cnf_handle** out, const cnf_config* cfg);
+int cnf_destroy(cnf_handle* h);
+
+/* Parameters `ps`: the ComponentArray of LuxCore.setup (test/ci_tests/smoke_tests.jl:61-62) —
+ * a flat Float32 vector holding, per Dense layer, weight (out x in, column-major: W(o,i) at
+ * w_off[l] + o + out*i) and bias (out, at b_off[l]).  n = length(p).  The library copies and
+ * repacks; call again whenever ps changes.  p_is_device: 1 if p is a device pointer. */
+int cnf_set_params(cnf_handle* h, const float* p, size_t n, const size_t* w_off,
+                   const size_t* b_off, int p_is_device, void* stream);
+
+/* Which kernel family the handle resolved to (CNF_PATH_SIMT or CNF_PATH_MFMA). */
+int cnf_kernel_path(const cnf_handle* h);
+
+/* augmented_f(u,p,t, icnf, mode, nn, st, eps) / augmented_f(du,u,p,t, ...) for MatrixMode:
+ * src/core/icnf.jl:517-559 (VecJac), :561-603 (JacVec), :297-339 (TestMode) — the callable
+ * make_ode_func hands to the ODE solver (src/core/base_icnf.jl:62-78).
+ *   u, du : S x B      eps : (K*D) x B (probe k = rows k*D..k*D+D-1; NULL in EXACT mode)
+ *   ys    : C x B or NULL      t : scalar time.  du may not alias u. */
+int cnf_aug_f(cnf_handle* h, float* du, const float* u, float t, const float* eps,
+              const float* ys, int64_t B, void* stream);
+
+/* base_sol(icnf, prob) = last(solve(prob; alg, adaptive=false, dt=(t1-t0)/nsteps).u):
+ * src/core/base_icnf.jl:134-140.  u0, u1: S x B (u1 may alias u0).  Stage i of step n is
+ * evaluated at t0 + n*dt + c_i*dt.  t1 < t0 integrates backwards (generate_prob's reversed
+ * tspan, src/core/base_icnf.jl:351-376). */
+int cnf_integrate_fixed(cnf_handle* h, int alg, int nsteps, float t0, float t1, const float* u0,
+                        const float* eps, const float* ys, int64_t B, float* u1, void* stream);
+
+/* inference(icnf, mode, xs[, ys], ps, st) for MatrixMode with a fixed-step solver, fused:
+ * inference_prob (u0 = [x; 0]) + base_sol + inference_sol (logp = logpdf(N(0,I), z) - dlogp):
+ * src/core/base_icnf.jl:247-296, 134-140, 158-172, 406-425.  eps is an explicit input (the
+ * reference draws it from icnf.rng at :258-259).
+ *   x: nvars x B.  logp: B.  regs: 3*B laid out [Edot (B) | ndot (B) | Adot (B)] or NULL.
+ *   u_final: S x B or NULL. */
+int cnf_inference_fixed(cnf_handle* h, int alg, int nsteps, float t0, float t1, const float* x,
+                        const float* eps, const float* ys, int64_t B, float* logp, float* regs,
+                        float* u_final, void* stream);
+
+/* The reduction of loss(icnf, mode, xs[, ys], ps, st) (src/core/icnf.jl:628-649) before the
+ * mean: sums4 (device, 4 floats) = [sum(-logp), sum(Edot), sum(ndot), sum(Adot)] over the B
+ * columns given.  loss = (s0 + l1*s1 + l2*s2 + l3*s3) / B_global after the caller's
+ * all-reduce of these four scalars.  Deterministic (fixed-order tree, no float atomics). */
+int cnf_loss_sums(cnf_handle* h, const float* logp, const float* regs, int64_t B, float* sums4,
+                  void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CNF_H */

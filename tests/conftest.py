@@ -1,0 +1,48 @@
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+import __graft_entry__ as entry  # noqa: E402
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def pkg():
+    return entry.load_package()
+
+
+@pytest.fixture(scope="session")
+def oracles():
+    return entry.load_oracle()
+
+
+def golden_index():
+    with open(os.path.join(GOLDEN, "index.json")) as f:
+        return json.load(f)
+
+
+def load_golden(name):
+    o64, _ = entry.load_oracle()
+    meta = golden_index()[name]
+    spec = o64.Spec(nvars=meta["nvars"], naug=meta["naug"], ncond=meta["ncond"],
+                    autonomous=meta["autonomous"], widths=meta["widths"], acts=meta["acts"],
+                    mode=meta["mode"], nprobes=meta["nprobes"], reg_z=meta["reg_z"],
+                    reg_j=meta["reg_j"], reg_aug=meta["reg_aug"])
+    spec.check()
+    data = dict(np.load(os.path.join(GOLDEN, name + ".npz")))
+    data.setdefault("ys", None)
+    return spec, meta, data
+
+
+GOLDEN_NAMES = sorted(golden_index().keys())

@@ -1,0 +1,79 @@
+"""CPU: the C-ABI library loads, exports every symbol include/cnf.h declares, validates
+configurations, and fails loudly (no CPU fallback) when no GPU is present."""
+import ctypes as C
+import os
+import re
+
+import pytest
+import torch
+
+from conftest import ROOT
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "cnf.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(cnf_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_header_declares_expected_entry_points():
+    syms = declared_symbols()
+    for s in ("cnf_create", "cnf_destroy", "cnf_set_params", "cnf_aug_f", "cnf_integrate_fixed",
+              "cnf_inference_fixed", "cnf_loss_sums", "cnf_last_error", "cnf_version",
+              "cnf_kernel_path"):
+        assert s in syms
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    lib = pkg._lib.load()
+    for s in declared_symbols():
+        assert hasattr(lib, s), s
+    assert set(pkg._lib.EXPORTS) == set(declared_symbols())
+    assert lib.cnf_version() == 1
+
+
+def test_config_struct_matches_header(pkg):
+    # 5 + 9 + 8 + 7 int32 fields
+    assert C.sizeof(pkg._lib.CnfConfig) == 4 * (5 + 9 + 8 + 7)
+
+
+def _cfg(pkg, **kw):
+    c = pkg._lib.CnfConfig()
+    c.nvars, c.naug, c.ncond, c.autonomous, c.n_layers = 2, 0, 0, 0, 2
+    c.widths[0], c.widths[1], c.widths[2] = 3, 16, 2
+    c.acts[0], c.acts[1] = 1, 0
+    c.mode, c.nprobes = 0, 1
+    for k, v in kw.items():
+        setattr(c, k, v)
+    return c
+
+
+@pytest.mark.parametrize("bad", [dict(nvars=0), dict(n_layers=0), dict(n_layers=9), dict(mode=7),
+                                 dict(nprobes=0), dict(naug=1), dict(kernel_path=5)])
+def test_create_rejects_inconsistent_config(pkg, bad):
+    lib = pkg._lib.load()
+    h = C.c_void_p()
+    rc = lib.cnf_create(C.byref(h), C.byref(_cfg(pkg, **bad)))
+    assert rc == pkg._lib.ERR_INVALID
+    assert lib.cnf_last_error().decode().startswith("cnf_create")
+    assert not h.value
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="CPU-only behaviour")
+def test_no_gpu_means_loud_failure_not_fallback(pkg):
+    lib = pkg._lib.load()
+    h = C.c_void_p()
+    rc = lib.cnf_create(C.byref(h), C.byref(_cfg(pkg)))
+    assert rc == pkg._lib.ERR_NO_DEVICE
+    assert "no CPU fallback" in lib.cnf_last_error().decode()
+    with pytest.raises(pkg._lib.CnfError):
+        pkg._lib.check(rc)
+
+
+def test_null_arguments_are_errors_not_crashes(pkg):
+    lib = pkg._lib.load()
+    assert lib.cnf_create(None, None) == pkg._lib.ERR_INVALID
+    assert lib.cnf_destroy(None) == 0
+    assert lib.cnf_aug_f(None, None, None, 0.0, None, None, 4, None) == pkg._lib.ERR_INVALID
+    assert lib.cnf_inference_fixed(None, 0, 1, 0.0, 1.0, None, None, None, 4, None, None, None,
+                                   None) == pkg._lib.ERR_INVALID

@@ -1,0 +1,81 @@
+"""CPU: the host-side mirror of the reference interface — constructor defaults
+(src/core/icnf.jl:53-103), parameter layout, method-table errors, column sharding."""
+import numpy as np
+import pytest
+import torch
+
+
+def test_constructor_defaults_follow_the_reference(pkg):
+    icnf = pkg.ICNF(nvariables=1)
+    assert icnf.naugments == 2                      # naugments = nvariables + 1
+    assert icnf.nn.widths == [4, 16, 16, 3]         # n_in = 1+2+1, n_hidden = 4 n_in, n_out = 3
+    assert [l.act_id for l in icnf.nn.layers] == [2, 2, 0]   # softplus, softplus, identity
+    assert (icnf.lambda1, icnf.lambda2, icnf.lambda3) == (0.01, 0.01, 0.01)
+    assert icnf.steer_rate == 0.1 and icnf.tspan == (0.0, 1.0)
+    assert icnf.S == icnf.D + 3
+
+
+def test_unicode_keyword_aliases(pkg):
+    icnf = pkg.ICNF(nvariables=2, **{"λ₁": 0.0, "λ₂": 0.5, "λ₃": 0.0})
+    assert (icnf.lambda1, icnf.lambda2, icnf.lambda3) == (0.0, 0.5, 0.0)
+    with pytest.raises(TypeError):
+        pkg.ICNF(nvariables=2, bogus=1)
+
+
+def test_param_layout_matches_oracle(pkg, oracles):
+    o64, _ = oracles
+    nn = pkg.Chain(pkg.Dense(9, 64, pkg.tanh), pkg.Dense(64, 64, pkg.tanh), pkg.Dense(64, 8))
+    spec = o64.make_spec(8, [64, 64])
+    assert nn.param_offsets() == tuple(spec.param_offsets())
+    icnf = pkg.ICNF(nvariables=8, naugments=0, nn=nn)
+    ps, st = pkg.setup(torch.Generator().manual_seed(0), icnf)
+    assert ps.dtype == torch.float32 and ps.shape == (spec.param_offsets()[2],) and st == {}
+    w_off, b_off, _ = nn.param_offsets()
+    assert torch.all(ps[b_off[0]:b_off[0] + 64] == 0)
+    assert float(ps[:w_off[1]].abs().max()) <= (6.0 / (9 + 64)) ** 0.5 + 1e-6
+
+
+def test_dimension_and_method_errors(pkg):
+    with pytest.raises(ValueError, match="DimensionMismatch"):
+        pkg.Chain(pkg.Dense(3, 8), pkg.Dense(9, 2))
+    with pytest.raises(ValueError, match="DimensionMismatch"):
+        pkg.ICNF(nvariables=2, naugments=0, nn=pkg.Chain(pkg.Dense(4, 8), pkg.Dense(8, 2)))
+    with pytest.raises(TypeError, match="MethodError"):
+        pkg.Dense(3, 3, activation=torch.relu).act_id
+    with pytest.raises(TypeError, match="MethodError"):
+        pkg.ICNF(nvariables=2, compute_mode=object())
+    with pytest.raises(TypeError, match="no CPU fallback"):
+        pkg.ICNF(nvariables=2, device="cpu")
+    icnf = pkg.ICNF(nvariables=2)
+    with pytest.raises(NotImplementedError, match="VCABM"):
+        icnf._solver()
+    icnf = pkg.ICNF(nvariables=2, sol_kwargs=dict(alg=pkg.Tsit5(), adaptive=True))
+    with pytest.raises(NotImplementedError):
+        icnf._solver()
+    icnf = pkg.ICNF(nvariables=2, sol_kwargs=dict(alg=pkg.RK4(), adaptive=False, dt=1 / 40))
+    assert icnf._solver() == 0 and icnf._nsteps(0.0, 1.0) == 40
+    with pytest.raises(TypeError, match="MethodError"):
+        pkg.inference(icnf, pkg.TrainMode(), 1, 2, 3, 4)   # unconditioned takes (xs, ps, st)
+
+
+def test_reference_compute_mode_names_resolve(pkg):
+    assert pkg.LuxVecJacMatrixMode is pkg.HIPVecJacMatrixMode
+    assert pkg.DIJacVecMatrixMode().jacvec and not pkg.DIVecJacMatrixMode().jacvec
+    assert repr(pkg.TrainMode()) == "TrainMode{true}()" and repr(pkg.TrainMode(False)) == "TrainMode{false}()"
+
+
+def test_shard_columns_partition(pkg):
+    for B, G in [(65536, 8), (262144, 8), (10, 4), (3, 8), (0, 2)]:
+        spans = [pkg.shard_columns(B, r, G) for r in range(G)]
+        assert spans[0][0] == 0 and spans[-1][1] == B
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        sizes = [hi - lo for lo, hi in spans]
+        assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        pkg.shard_columns(8, 2, 2)
+
+
+def test_reduce_loss_single_process(pkg):
+    sums = torch.tensor([10.0, 2.0, 4.0, 6.0])
+    out = pkg.reduce_loss(sums, 4, (0.5, 0.25, 0.0))
+    assert np.isclose(float(out), (10 + 1 + 1) / 4)

@@ -1,0 +1,140 @@
+"""CPU: analytic known-answer tests that pin the oracles without the reference
+(SURVEY.md §8(c)): closed-form linear flow, convergence orders of the integrators,
+VJP/JVP agreement, exact trace vs one-hot probes vs finite differences, zero weights,
+K-probe mean, column independence."""
+import math
+
+import numpy as np
+import pytest
+from scipy.linalg import expm
+
+
+def linear_spec(o64, D, mode):
+    s = o64.Spec(nvars=D, autonomous=True, widths=[D, D], acts=[o64.ACT_IDENTITY], mode=mode)
+    s.check()
+    return s
+
+
+def linear_problem(D, seed):
+    rng = np.random.default_rng(seed)
+    A = rng.standard_normal((D, D)) * 0.4
+    b = rng.standard_normal(D) * 0.2
+    p = np.concatenate([A.T.reshape(-1), b])
+    xs = rng.standard_normal((D, 6))
+    M = np.zeros((D + 1, D + 1)); M[:D, :D] = A; M[:D, D] = b
+    E = expm(M)
+    z1 = E[:D, :D] @ xs + E[:D, D:]
+    logp = -0.5 * D * math.log(2 * math.pi) - 0.5 * (z1 ** 2).sum(0) + np.trace(A)
+    return A, p, xs, z1, logp
+
+
+@pytest.mark.parametrize("which", ["fp64", "c"])
+def test_linear_field_closed_form(which, oracles):
+    o64, oc = oracles
+    D = 3
+    spec = linear_spec(o64, D, o64.MODE_EXACT)
+    A, p, xs, z1, logp_ref = linear_problem(D, 0)
+    if which == "fp64":
+        logp, _, u1 = o64.inference_fixed(spec, p, xs, 0.0, 1.0, 40, o64.ALG_TSIT5, None)
+        tol = 1e-9
+    else:
+        logp, _, u1 = oc.inference_fixed(spec, p.astype(np.float32), xs.astype(np.float32), 0.0, 1.0,
+                                         40, o64.ALG_TSIT5, None)
+        tol = 2e-5
+    assert np.max(np.abs(u1[:D] - z1)) < tol
+    assert np.max(np.abs(u1[D] + np.trace(A))) < tol       # dlogp = -tr(A) (t1 - t0)
+    assert np.max(np.abs(logp - logp_ref)) < 10 * tol
+
+
+@pytest.mark.parametrize("alg,order", [(0, 4), (1, 5)])
+def test_integrator_convergence_order(alg, order, oracles):
+    o64, _ = oracles
+    D = 3
+    spec = linear_spec(o64, D, o64.MODE_EXACT)
+    A, p, xs, z1, _ = linear_problem(D, 1)
+    errs = []
+    for n in (2, 4, 8):
+        u1 = o64.integrate_fixed(spec, p, np.concatenate([xs, np.zeros((3, xs.shape[1]))]), 0.0, 1.0,
+                                 n, alg, None, None)
+        errs.append(np.max(np.abs(u1[:D] - z1)))
+    slopes = [math.log2(errs[i] / errs[i + 1]) for i in range(2)]
+    assert all(abs(s - order) < 0.6 for s in slopes), (errs, slopes)
+
+
+def test_vjp_and_jvp_give_the_same_trace_scalar(oracles):
+    o64, oc = oracles
+    kw = dict(nvars=4, hidden=[16, 16], ncond=2, reg_z=True, reg_j=True)
+    sv = o64.make_spec(mode=o64.MODE_HUTCH_VJP, **kw)
+    sj = o64.make_spec(mode=o64.MODE_HUTCH_JVP, **kw)
+    p, xs, eps, ys = o64.synth_inputs(sv, 9, 5, bias_scale=0.2)
+    u = np.concatenate([xs, np.zeros((3, 9), np.float32)])
+    for f, tol in ((o64.aug_f, 1e-12), (oc.aug_f, 2e-6)):
+        dv = f(sv, p, u, 0.2, eps, ys)
+        dj = f(sj, p, u, 0.2, eps, ys)
+        D = sv.D
+        assert np.max(np.abs(dv[:D + 2] - dj[:D + 2])) < tol     # zdot, ldot, Edot agree
+        assert np.max(np.abs(dv[D + 2] - dj[D + 2])) > 1e-3      # |eps^T J| != |J eps|
+
+
+def test_exact_trace_equals_onehot_probes_and_finite_differences(oracles):
+    o64, oc = oracles
+    D = 5
+    se = o64.make_spec(nvars=D, hidden=[24, 24], mode=o64.MODE_EXACT)
+    sk = o64.make_spec(nvars=D, hidden=[24, 24], nprobes=D)
+    p, xs, _, _ = o64.synth_inputs(se, 7, 6, bias_scale=0.2)
+    u = np.concatenate([xs, np.zeros((3, 7), np.float32)]).astype(np.float64)
+    onehot = np.tile(np.eye(D).reshape(D * D, 1), (1, 7))       # probe k = e_k
+    ex = o64.aug_f(se, p, u, 0.4, None, None)
+    hk = o64.aug_f(sk, p, u, 0.4, onehot, None)
+    assert np.max(np.abs(ex[D] - D * hk[D])) < 1e-12              # mean over K=D probes -> x D
+    h = 1e-6
+    tr = np.zeros(7)
+    for i in range(D):
+        up, um = u.copy(), u.copy()
+        up[i] += h; um[i] -= h
+        tr += (o64.aug_f(se, p, up, 0.4, None, None)[i] - o64.aug_f(se, p, um, 0.4, None, None)[i]) / (2 * h)
+    assert np.max(np.abs(ex[D] + tr)) < 1e-7
+    exc = oc.aug_f(se, p, u.astype(np.float32), 0.4, None, None)
+    assert np.max(np.abs(exc[D] - ex[D])) < 5e-6
+
+
+def test_zero_weights_translate_by_bias(oracles):
+    o64, oc = oracles
+    spec = o64.make_spec(nvars=3, hidden=[8])
+    _, _, n = spec.param_offsets()
+    p = np.zeros(n, np.float32)
+    _, b_off, _ = spec.param_offsets()
+    bN = np.array([0.3, -0.2, 0.1], np.float32)
+    p[b_off[-1]:b_off[-1] + 3] = bN
+    rng = np.random.default_rng(2)
+    xs = rng.standard_normal((3, 5)).astype(np.float32)
+    eps = rng.standard_normal((3, 5)).astype(np.float32)
+    ref = -1.5 * math.log(2 * math.pi) - 0.5 * ((xs + bN[:, None]) ** 2).sum(0)
+    for f, tol in ((o64.inference_fixed, 1e-6), (oc.inference_fixed, 1e-5)):
+        logp = f(spec, p, xs, 0.0, 1.0, 8, o64.ALG_RK4, eps)[0]
+        assert np.max(np.abs(logp - ref)) < tol
+
+
+def test_k_probe_result_is_mean_of_single_probe_runs(oracles):
+    o64, oc = oracles
+    K = 3
+    sk = o64.make_spec(nvars=4, hidden=[16, 16], nprobes=K, reg_z=True, reg_j=True)
+    s1 = o64.make_spec(nvars=4, hidden=[16, 16], nprobes=1, reg_z=True, reg_j=True)
+    p, xs, eps, _ = o64.synth_inputs(sk, 6, 11, bias_scale=0.1)
+    lk, (Ek, nk, _), _ = oc.inference_fixed(sk, p, xs, 0.0, 1.0, 6, o64.ALG_TSIT5, eps)
+    runs = [oc.inference_fixed(s1, p, xs, 0.0, 1.0, 6, o64.ALG_TSIT5, eps[k * 4:(k + 1) * 4]) for k in range(K)]
+    assert np.max(np.abs(lk - np.mean([r[0] for r in runs], 0))) < 1e-5
+    assert np.max(np.abs(nk - np.mean([r[1][1] for r in runs], 0))) < 1e-5
+    assert np.max(np.abs(Ek - runs[0][1][0])) < 1e-6
+
+
+def test_columns_are_independent(oracles):
+    """Fixed-step integration keeps samples independent: permuting the
+    columns permutes the outputs bit-for-bit."""
+    o64, oc = oracles
+    spec = o64.make_spec(nvars=8, hidden=[64, 64, 64])
+    p, xs, eps, _ = o64.synth_inputs(spec, 70, 12)
+    perm = np.random.default_rng(0).permutation(70)
+    a = oc.inference_fixed(spec, p, xs, 0.0, 1.0, 3, o64.ALG_TSIT5, eps)[0]
+    b = oc.inference_fixed(spec, p, xs[:, perm], 0.0, 1.0, 3, o64.ALG_TSIT5, eps[:, perm])[0]
+    assert np.array_equal(a[perm], b)

@@ -1,0 +1,206 @@
+"""GPU: parity of the HIP path (called through the C ABI) with the oracles.
+
+Tolerances (float32 arithmetic, stated by north_star: log-density max abs error < 1e-4):
+  * one dynamics call vs fp64 fixtures: 2e-5 relative-ish (|err| / (1+|ref|))
+  * fixed-step solve vs fp64 fixtures / C restatement: 1e-4 absolute on logp, regs, state
+  * structural properties (column independence, shard concatenation, SIMT-vs-MFMA agreement,
+    determinism) are bit-exact where the same kernel runs on the same column."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN_NAMES, load_golden
+
+pytestmark = pytest.mark.gpu
+
+ACTS = {0: "identity", 1: "tanh", 2: "softplus"}
+TOL_CALL = 2e-5
+TOL_SOLVE = 1e-4
+
+
+def make_icnf(pkg, spec, alg, nsteps, path=0, lambdas=(0.01, 0.01, 0.01)):
+    layers = [pkg.Dense(spec.widths[i], spec.widths[i + 1], ACTS[spec.acts[i]])
+              for i in range(len(spec.acts))]
+    cm = (pkg.HIPJacVecMatrixMode if spec.mode == 1 else pkg.HIPVecJacMatrixMode)(kernel_path=path)
+    l1 = lambdas[0] if spec.reg_z else 0.0
+    l2 = lambdas[1] if spec.reg_j else 0.0
+    l3 = lambdas[2] if spec.reg_aug else 0.0
+    return pkg.ICNF(nvariables=spec.nvars, naugments=spec.naug, nconditions=spec.ncond,
+                    autonomous=spec.autonomous, nn=pkg.Chain(*layers), compute_mode=cm,
+                    steer_rate=0.0, lambda1=l1, lambda2=l2, lambda3=l3, nprobes=spec.nprobes,
+                    device="cuda:0",
+                    sol_kwargs=dict(alg=pkg.Tsit5() if alg == 1 else pkg.RK4(), adaptive=False,
+                                    nsteps=nsteps))
+
+
+def mode_of(pkg, spec):
+    if spec.mode == 2:
+        return pkg.TestMode()
+    return pkg.TrainMode(bool(spec.reg_z or spec.reg_j or spec.reg_aug))
+
+
+def dev(a):
+    return None if a is None else torch.tensor(np.asarray(a, dtype=np.float32), device="cuda:0")
+
+
+def run_inference(pkg, icnf, spec, p, xs, eps, ys, **kw):
+    args = (dev(xs),) + ((dev(ys),) if spec.ncond else ()) + (dev(p), {})
+    return pkg.inference(icnf, mode_of(pkg, spec), *args, eps=dev(eps), **kw)
+
+
+def paths_for(pkg, spec, alg, nsteps):
+    """SIMT always; MFMA when the library says the configuration is covered."""
+    out = [1]
+    try:
+        icnf = make_icnf(pkg, spec, alg, nsteps, path=2)
+        icnf.kernel_path(mode_of(pkg, spec))
+        out.append(2)
+    except pkg._lib.CnfError as e:
+        assert e.code == pkg._lib.ERR_UNSUPPORTED
+    return out
+
+
+@pytest.mark.parametrize("name", GOLDEN_NAMES)
+def test_aug_f_matches_golden(name, pkg):
+    spec, meta, g = load_golden(name)
+    for path in paths_for(pkg, spec, meta["alg"], meta["nsteps"]):
+        icnf = make_icnf(pkg, spec, meta["alg"], meta["nsteps"], path)
+        du = pkg.augmented_f(icnf, mode_of(pkg, spec), dev(g["u"]), dev(g["p"]), float(g["t"]),
+                             dev(g["eps"]), dev(g["ys"])).cpu().numpy()
+        err = np.max(np.abs(du - g["du"]) / (1.0 + np.abs(g["du"])))
+        assert err < TOL_CALL, (name, path, err)
+
+
+@pytest.mark.parametrize("name", GOLDEN_NAMES)
+def test_inference_matches_golden(name, pkg):
+    spec, meta, g = load_golden(name)
+    for path in paths_for(pkg, spec, meta["alg"], meta["nsteps"]):
+        icnf = make_icnf(pkg, spec, meta["alg"], meta["nsteps"], path)
+        logp, (E, n, A), u1 = run_inference(pkg, icnf, spec, g["p"], g["xs"], g["eps"], g["ys"],
+                                            return_state=True)
+        assert icnf.kernel_path(mode_of(pkg, spec)) == path
+        assert np.max(np.abs(logp.cpu().numpy() - g["logp"])) < TOL_SOLVE, (name, path)
+        assert np.max(np.abs(E.cpu().numpy() - g["E"])) < TOL_SOLVE
+        assert np.max(np.abs(n.cpu().numpy() - g["n"])) < TOL_SOLVE
+        assert np.max(np.abs(A.cpu().numpy() - g["A"])) < TOL_SOLVE
+        assert np.max(np.abs(u1.cpu().numpy() - g["u1"])) < TOL_SOLVE
+
+
+CASES = [
+    # (make_spec kwargs, B, alg, nsteps)
+    (dict(nvars=8, hidden=[64, 64, 64]), 1000, 1, 40),                 # headline shape, ragged B
+    (dict(nvars=8, hidden=[64, 64, 64]), 1, 0, 40),                    # single column
+    (dict(nvars=8, hidden=[64, 64, 64], nprobes=4, reg_z=True, reg_j=True), 300, 1, 40),
+    (dict(nvars=2, hidden=[32, 32]), 1024, 1, 40),
+    (dict(nvars=8, ncond=8, hidden=[128, 128, 128], mode=2), 130, 0, 40),
+    (dict(nvars=1, naug=2, hidden=[16, 16], act=2, reg_z=True, reg_j=True, reg_aug=True), 257, 1, 20),
+    (dict(nvars=3, hidden=[16, 16], autonomous=True, mode=1, reg_z=True, reg_j=True), 77, 0, 10),
+    (dict(nvars=32, hidden=[256, 256, 256]), 48, 0, 10),
+]
+
+
+@pytest.mark.parametrize("kw,B,alg,nsteps", CASES)
+def test_inference_matches_c_restatement(kw, B, alg, nsteps, pkg, oracles):
+    o64, oc = oracles
+    spec = o64.make_spec(**kw)
+    p, xs, eps, ys = o64.synth_inputs(spec, B, 20240612, bias_scale=0.1)
+    ref_logp, ref_regs, ref_u = oc.inference_fixed(spec, p, xs, 0.0, 1.0, nsteps, alg, eps, ys, nthreads=4)
+    for path in paths_for(pkg, spec, alg, nsteps):
+        icnf = make_icnf(pkg, spec, alg, nsteps, path)
+        logp, regs, u1 = run_inference(pkg, icnf, spec, p, xs, eps, ys, return_state=True)
+        assert np.max(np.abs(logp.cpu().numpy() - ref_logp)) < TOL_SOLVE, (kw, path)
+        for a, b in zip(regs, ref_regs):
+            assert np.max(np.abs(a.cpu().numpy() - b)) < TOL_SOLVE
+        assert np.max(np.abs(u1.cpu().numpy() - ref_u)) < TOL_SOLVE
+
+
+def test_empty_batch_is_a_no_op(pkg, oracles):
+    o64, _ = oracles
+    spec = o64.make_spec(nvars=8, hidden=[64, 64, 64])
+    p, xs, eps, _ = o64.synth_inputs(spec, 4, 1)
+    icnf = make_icnf(pkg, spec, 1, 40)
+    logp, regs = run_inference(pkg, icnf, spec, p, xs[:, :0], eps[:, :0], None)
+    assert logp.shape == (0,) and all(r.shape == (0,) for r in regs)
+
+
+def test_shard_concatenation_is_bit_identical_and_deterministic(pkg, oracles):
+    """Sharding invariance at the headline shape: evaluating column blocks
+    separately — as the ranks of a multi-GPU run do — reproduces the unsharded bits."""
+    o64, _ = oracles
+    spec = o64.make_spec(nvars=8, hidden=[64, 64, 64])
+    B = 4096 + 37
+    p, xs, eps, _ = o64.synth_inputs(spec, B, 5)
+    icnf = make_icnf(pkg, spec, 1, 40)
+    full = run_inference(pkg, icnf, spec, p, xs, eps, None)[0].cpu().numpy()
+    again = run_inference(pkg, icnf, spec, p, xs, eps, None)[0].cpu().numpy()
+    assert np.array_equal(full, again)
+    parts = []
+    for r in range(8):
+        lo, hi = pkg.shard_columns(B, r, 8)
+        parts.append(run_inference(pkg, icnf, spec, p, xs[:, lo:hi], eps[:, lo:hi], None)[0].cpu().numpy())
+    assert np.array_equal(np.concatenate(parts), full)
+
+
+def test_full_size_headline_properties(pkg, oracles):
+    """BASELINE headline size (D=8, 3x64, Tsit5x40, B=65536): checks that do not need a CPU
+    reference at that size — agreement with the C restatement on a random column subset,
+    finiteness, and the loss reduction against a float64 host sum."""
+    o64, oc = oracles
+    spec = o64.make_spec(nvars=8, hidden=[64, 64, 64])
+    B = 65536
+    p, xs, eps, _ = o64.synth_inputs(spec, B, 20240614)
+    icnf = make_icnf(pkg, spec, 1, 40)
+    logp, regs = run_inference(pkg, icnf, spec, p, xs, eps, None)
+    lp = logp.cpu().numpy()
+    assert np.all(np.isfinite(lp))
+    idx = np.random.default_rng(0).choice(B, 512, replace=False)
+    ref = oc.inference_fixed(spec, p, xs[:, idx], 0.0, 1.0, 40, 1, eps[:, idx], nthreads=4)[0]
+    assert np.max(np.abs(lp[idx] - ref)) < TOL_SOLVE
+    sums = pkg.loss_sums(icnf, pkg.TrainMode(False), logp, torch.stack(list(regs))).cpu().numpy()
+    assert abs(sums[0] + lp.astype(np.float64).sum()) < 1e-6 * abs(lp.astype(np.float64).sum()) + 1e-2
+    loss = float(pkg.loss(icnf, pkg.TrainMode(False), dev(xs), dev(p), {}, eps=dev(eps)))
+    assert abs(loss + lp.astype(np.float64).mean()) < 1e-4
+
+
+def test_generate_inverts_inference(pkg, oracles):
+    """generate integrates the reversed tspan (src/core/base_icnf.jl:372): pushing x forward
+    to z and pulling z back must return x (integrator error only)."""
+    o64, _ = oracles
+    spec = o64.make_spec(nvars=8, hidden=[64, 64, 64])
+    p, xs, eps, _ = o64.synth_inputs(spec, 256, 9, bias_scale=0.1)
+    icnf = make_icnf(pkg, spec, 1, 40)
+    _, _, u1 = run_inference(pkg, icnf, spec, p, xs, eps, None, return_state=True)
+    back = pkg.generate(icnf, pkg.TrainMode(False), dev(p), {}, 256, z0=u1[:8].contiguous(), eps=dev(eps))
+    assert np.max(np.abs(back.cpu().numpy() - xs)) < 1e-4
+    samples = pkg.generate(icnf, pkg.TrainMode(False), dev(p), {}, 100)
+    assert samples.shape == (8, 100) and bool(torch.isfinite(samples).all())
+
+
+def test_layer_call_and_drawn_probes(pkg, oracles):
+    """(icnf)(xs, ps, st) uses TrainMode{false} and draws eps from icnf.rng
+    (src/core/base_icnf.jl:509-515, 258-259): two calls give different Hutchinson estimates
+    whose mean error against the exact trace shrinks; TestMode is deterministic."""
+    o64, _ = oracles
+    spec = o64.make_spec(nvars=2, hidden=[32, 32])
+    p, xs, _, _ = o64.synth_inputs(spec, 64, 3, bias_scale=0.1)
+    icnf = make_icnf(pkg, spec, 1, 20)
+    a, st = icnf(dev(xs), dev(p), {})
+    b, _ = icnf(dev(xs), dev(p), {})
+    assert st == {} and not torch.equal(a, b)
+    e1 = pkg.inference(icnf, pkg.TestMode(), dev(xs), dev(p), {})[0]
+    e2 = pkg.inference(icnf, pkg.TestMode(), dev(xs), dev(p), {})[0]
+    assert torch.equal(e1, e2)
+    assert float((a - e1).abs().max()) < 5.0
+
+
+def test_errors_surface_as_exceptions(pkg, oracles):
+    o64, _ = oracles
+    spec = o64.make_spec(nvars=8, hidden=[64, 64, 64])
+    p, xs, eps, _ = o64.synth_inputs(spec, 8, 1)
+    icnf = make_icnf(pkg, spec, 1, 40)
+    with pytest.raises(ValueError, match="DimensionMismatch"):
+        pkg.inference(icnf, pkg.TrainMode(), dev(xs[:5]), dev(p), {})
+    with pytest.raises(ValueError, match="DimensionMismatch"):
+        pkg.inference(icnf, pkg.TrainMode(), dev(xs), dev(p[:-1]), {})
+    with pytest.raises(ValueError):
+        pkg.inference(icnf, pkg.TrainMode(), torch.tensor(xs), dev(p), {})      # host tensor
