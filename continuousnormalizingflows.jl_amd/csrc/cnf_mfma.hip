@@ -1,11 +1,515 @@
-// placeholder until the fused MFMA kernels land
+// cnf_mfma.hip — fused whole-solve kernels for gfx950: the Dense chain, its pullback
+// (Hutchinson eps^T J) and the fixed-step Runge-Kutta loop in ONE launch per solve.
+//
+// Replaces, for MatrixMode + a fixed-step solver, the reference's
+//   inference_prob -> solve(ODEProblem) { augmented_f -> icnf_jacobian -> Lux Chain + Zygote } -> inference_sol
+// (src/core/base_icnf.jl:247-296,134-172; src/core/icnf.jl:517-559; src/core/utils.jl:150-159).
+//
+// Design:
+//   * one wave owns a tile of 16 samples for the whole solve: state z, dlogp, E, n and the RK
+//     stage derivatives stay in registers; HBM is touched once at the start (x, eps, ys) and
+//     once at the end (logp, regs, optional final state).
+//   * every weight product runs on v_mfma_f32_16x16x4_f32 (exact f32, = fmaf chain) with the
+//     sample tile on N; an accumulator tile is the next product's B operand with no data
+//     movement (row permutation explained in cnf_mfma_layout.h).
+//   * weights (forward and transposed images) are staged once per workgroup into LDS in
+//     MFMA-operand order and read with conflict-free ds_read_b128 (one read per 4 MFMAs).
+//   * eps^T J eps, |zdot|, |eps^T J| are reduced over the 4 lane groups that share a sample with
+//     two cross-lane exchanges.
+#include <cstring>
+#include <vector>
+
 #include "cnf_internal.h"
+#include "cnf_mfma_layout.h"
+
 namespace cnf {
-struct MfmaPlan { int dummy; };
-MfmaPlan* mfma_plan_create(const cnf_config&) { return nullptr; }
-void mfma_plan_destroy(MfmaPlan* p) { delete p; }
-size_t mfma_packed_bytes(const MfmaPlan*) { return 0; }
-void mfma_pack(const MfmaPlan*, const float*, const size_t*, const size_t*, float*) {}
-const char* mfma_plan_name(const MfmaPlan*) { return "none"; }
-hipError_t mfma_solve(const MfmaPlan*, const float*, const SolveArgs&, hipStream_t) { return hipErrorNotSupported; }
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct KArgs {
+    const float* packed;
+    const float* x;     // nvars x B, or null
+    const float* u0;    // S x B, or null
+    const float* eps;   // (K D) x B
+    const float* ys;    // C x B
+    float* u_out;       // S x B or null
+    float* logp;        // B or null
+    float* regs;        // 3B or null
+    long long B;
+    int nsteps;         // 0: single dynamics call at t0, du -> u_out
+    float t0, dt;
+    int nvars, D, C, reg_z, reg_j, reg_aug, autonomous;
+    Tableau T;
+};
+
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
+
+// sum over the 4 lane groups (lanes l, l^16, l^32, l^48) that hold one sample
+__device__ __forceinline__ float group_sum(float v) {
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
+
+// Out[MT tiles] += A(image at smem+img)[MT x KS k-steps] * In   where In register s is k-step s.
+// `in` is indexed [s]; KS live k-steps (KG = ceil(KS/4) groups in the image).
+template <int MT, int KS, typename InT>
+__device__ __forceinline__ void gemm_tiles(const float* __restrict__ img, int lane, const InT& in,
+                                           f32x4 (&acc)[MT]) {
+    constexpr int KG = (KS + 3) / 4;
+    const f32x4* A = reinterpret_cast<const f32x4*>(img) + lane;
+#pragma unroll
+    for (int kg = 0; kg < KG; ++kg) {
+        f32x4 a[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) a[mt] = A[(mt * KG + kg) * 64];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (kg * 4 + j < KS) {
+                const float b = in(kg * 4 + j);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acc[mt] = mfma4(a[mt][j], b, acc[mt]);
+            }
+        }
+    }
+}
+
+template <int N>
+struct RegIn {  // flat register array as k-step source
+    const float (&v)[N];
+    __device__ __forceinline__ float operator()(int s) const { return v[s]; }
+};
+template <int MT>
+struct TileIn {  // accumulator tiles as k-step source: k-step s = tile s/4, register s%4
+    const f32x4 (&v)[MT];
+    __device__ __forceinline__ float operator()(int s) const { return v[s >> 2][s & 3]; }
+};
+
+template <int MT>
+__device__ __forceinline__ void load_cvec(const float* __restrict__ vec, int g, f32x4 (&out)[MT]) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) out[mt] = *reinterpret_cast<const f32x4*>(vec + (mt * 4 + g) * 4);
+}
+
+// One dynamics evaluation for a 16-sample tile (VJP engine).
+template <int HT, int L, int ZR, int CR, int ACT, int KP>
+__device__ __forceinline__ void dyn_eval_vjp(const float* __restrict__ smem, int lane, float t,
+                                             bool autonomous, bool reg_z, bool reg_j,
+                                             const float (&z)[ZR], const float (&y)[CR > 0 ? CR : 1],
+                                             const float (&eps)[KP][ZR], float (&zd)[ZR], float& ld,
+                                             float& ed, float& nd) {
+    constexpr MfmaLayout LAY(HT, L, ZR, CR, true);
+    constexpr int DT = (ZR + 3) / 4;
+    const int g = lane >> 4;
+    f32x4 h[HT];
+    f32x4 d[L][HT];  // act' of every hidden layer, kept for the pullback
+
+    // ---- layer 1: a = W1z z + w1t t + W1y y + b1 ----
+    {
+        f32x4 acc[HT];
+        load_cvec<HT>(smem + LAY.v_b1, g, acc);
+        if (!autonomous) {
+            f32x4 wt[HT];
+            load_cvec<HT>(smem + LAY.v_w1t, g, wt);
+#pragma unroll
+            for (int mt = 0; mt < HT; ++mt) acc[mt] += wt[mt] * t;
+        }
+        gemm_tiles<HT, ZR>(smem + LAY.f1z, lane, RegIn<ZR>{z}, acc);
+        if constexpr (CR > 0) gemm_tiles<HT, CR>(smem + LAY.f1y, lane, RegIn<CR>{y}, acc);
+#pragma unroll
+        for (int mt = 0; mt < HT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float dd;
+                h[mt][r] = act_fwd<ACT>(acc[mt][r], dd);
+                d[0][mt][r] = dd;
+            }
+    }
+    // ---- hidden layers 2..L ----
+#pragma unroll
+    for (int l = 1; l < L; ++l) {
+        f32x4 acc[HT];
+        load_cvec<HT>(smem + LAY.v_bh + (l - 1) * MfmaLayout::vecC(HT), g, acc);
+        gemm_tiles<HT, 4 * HT>(smem + LAY.fh + (l - 1) * MfmaLayout::imgA(HT, HT), lane, TileIn<HT>{h}, acc);
+#pragma unroll
+        for (int mt = 0; mt < HT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float dd;
+                h[mt][r] = act_fwd<ACT>(acc[mt][r], dd);
+                d[l][mt][r] = dd;
+            }
+    }
+    // ---- last layer (identity): zdot ----
+    {
+        f32x4 acc[DT];
+        load_cvec<DT>(smem + LAY.v_bN, g, acc);
+        gemm_tiles<DT, 4 * HT>(smem + LAY.fN, lane, TileIn<HT>{h}, acc);
+#pragma unroll
+        for (int s = 0; s < ZR; ++s) zd[s] = acc[s >> 2][s & 3];
+    }
+    ed = 0.f;
+    if (reg_z) {
+        float e2 = 0.f;
+#pragma unroll
+        for (int s = 0; s < ZR; ++s) e2 = fmaf(zd[s], zd[s], e2);
+        ed = sqrtf(group_sum(e2));   // Edot = |zdot|_2   (src/core/icnf.jl:184-199)
+    }
+    // ---- pullback per probe: g = eps^T J ----
+    ld = 0.f;
+    nd = 0.f;
+    constexpr float invK = 1.f / (float)KP;
+    // probes run one after the other (rolled loop): the transposed images are re-read from LDS
+    // per probe, which costs LDS bandwidth the kernel has to spare and keeps registers flat.
+#pragma clang loop unroll(disable)
+    for (int p = 0; p < KP; ++p) {
+        float ep[ZR];
+#pragma unroll
+        for (int s = 0; s < ZR; ++s) {
+            ep[s] = eps[0][s];
+#pragma unroll
+            for (int q = 1; q < KP; ++q) ep[s] = (p == q) ? eps[q][s] : ep[s];
+        }
+        int opq = 0;
+        if constexpr (KP > 1) asm volatile("" : "+v"(opq));
+        const float* __restrict__ sm = smem + opq;
+        f32x4 dl[HT];
+        {
+            f32x4 acc[HT];
+#pragma unroll
+            for (int mt = 0; mt < HT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            gemm_tiles<HT, ZR>(sm + LAY.bN, lane, RegIn<ZR>{ep}, acc);   // W_N^T eps
+#pragma unroll
+            for (int mt = 0; mt < HT; ++mt) dl[mt] = acc[mt] * d[L - 1][mt];
+        }
+#pragma unroll
+        for (int l = L - 1; l >= 1; --l) {  // W_{l+1}^T delta, times act'(a_l)
+            f32x4 acc[HT];
+#pragma unroll
+            for (int mt = 0; mt < HT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            gemm_tiles<HT, 4 * HT>(sm + LAY.bh + (l - 1) * MfmaLayout::imgA(HT, HT), lane, TileIn<HT>{dl}, acc);
+#pragma unroll
+            for (int mt = 0; mt < HT; ++mt) dl[mt] = acc[mt] * d[l - 1][mt];
+        }
+        f32x4 gacc[DT];
+#pragma unroll
+        for (int dt_ = 0; dt_ < DT; ++dt_) gacc[dt_] = f32x4{0.f, 0.f, 0.f, 0.f};
+        gemm_tiles<DT, 4 * HT>(sm + LAY.b1, lane, TileIn<HT>{dl}, gacc);       // W_1[:,0:D]^T delta_1
+        float dot = 0.f, n2 = 0.f;
+#pragma unroll
+        for (int s = 0; s < ZR; ++s) {
+            const float gv = gacc[s >> 2][s & 3];
+            dot = fmaf(gv, ep[s], dot);     // ldot = -sum(eJ .* eps)   (icnf.jl:532)
+            n2 = fmaf(gv, gv, n2);
+        }
+        ld -= invK * group_sum(dot);
+        if (reg_j) nd += invK * sqrtf(group_sum(n2));   // ndot = |eps^T J|_2 (icnf.jl:229-245)
+    }
+}
+
+template <int HT, int L, int ZR, int CR, int ACT, int KP, int NTHREADS>
+__global__ void __launch_bounds__(NTHREADS)
+mfma_vjp_solve_kernel(KArgs a) {
+    constexpr MfmaLayout LAY(HT, L, ZR, CR, true);
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    // stage the packed weight image: global (L2) -> LDS, 16 B per lane, coalesced
+    {
+        const f32x4* src = reinterpret_cast<const f32x4*>(a.packed);
+        f32x4* dst = reinterpret_cast<f32x4*>(smem);
+        for (int i = threadIdx.x; i < LAY.total / 4; i += NTHREADS) dst[i] = src[i];
+    }
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const int g = lane >> 4, n = lane & 15;
+    const int wave = threadIdx.x >> 6;
+    constexpr int WPB = NTHREADS / 64;
+    const long long ntiles = (a.B + 15) / 16;
+    const int D = a.D, S = D + 3, C = a.C;
+    const int Kd = KP * D;
+    const bool reg_z = a.reg_z, reg_j = a.reg_j, autonomous = a.autonomous;
+
+    for (long long tile = (long long)blockIdx.x * WPB + wave; tile < ntiles;
+         tile += (long long)gridDim.x * WPB) {
+        const long long smp = tile * 16 + n;
+        const bool valid = smp < a.B;
+        const long long sc = valid ? smp : a.B - 1;   // clamp loads, mask stores
+        float z[ZR], eps[KP][ZR], y[CR > 0 ? CR : 1];
+        float lacc = 0.f, eacc = 0.f, nacc = 0.f;
+#pragma unroll
+        for (int s = 0; s < ZR; ++s) {
+            const int f = 4 * s + g;
+            if (a.x) z[s] = f < a.nvars ? a.x[sc * a.nvars + f] : 0.f;   // u0 = [x; 0]
+            else z[s] = f < D ? a.u0[sc * S + f] : 0.f;
+#pragma unroll
+            for (int p = 0; p < KP; ++p) eps[p][s] = f < D ? a.eps[sc * Kd + p * D + f] : 0.f;
+        }
+        if (!a.x) { lacc = a.u0[sc * S + D]; eacc = a.u0[sc * S + D + 1]; nacc = a.u0[sc * S + D + 2]; }
+        y[0] = 0.f;
+        if constexpr (CR > 0) {
+#pragma unroll
+            for (int s = 0; s < CR; ++s) { const int f = 4 * s + g; y[s] = f < C ? a.ys[sc * C + f] : 0.f; }
+        }
+
+        // ---- fixed-step explicit RK, stage loop rolled (one copy of the dynamics code) ----
+        float kz[6][ZR], kl[6], ke[6], kn[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            kl[j] = ke[j] = kn[j] = 0.f;
+#pragma unroll
+            for (int s = 0; s < ZR; ++s) kz[j][s] = 0.f;
+        }
+        const float dt = a.dt;
+        const bool single = a.nsteps == 0;      // one dynamics call: du = f(u, p, t0)
+        const int ns = single ? 1 : a.T.ns;
+        const int nsteps = single ? 1 : a.nsteps;
+#pragma clang loop unroll(disable)
+        for (int step = 0; step < nsteps; ++step) {
+            const float tn = a.t0 + (float)step * dt;
+#pragma clang loop unroll(disable)
+            for (int st = 0; st < ns; ++st) {
+                float zs[ZR];
+#pragma unroll
+                for (int s = 0; s < ZR; ++s) {
+                    float acc = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 5; ++j) acc = fmaf(a.T.a[st][j], kz[j][s], acc);
+                    zs[s] = fmaf(dt, acc, z[s]);
+                }
+                float zd[ZR], ld, ed, nd;
+                // The weight image is loop-invariant, and LLVM would hoist all ~300 operand reads out
+                // of the RK loops (and spill them).  An opaque zero offset pins the reads per stage.
+                int opaque = 0;
+                asm volatile("" : "+v"(opaque));
+                dyn_eval_vjp<HT, L, ZR, CR, ACT, KP>(smem + opaque, lane, tn + a.T.c[st] * dt, autonomous, reg_z,
+                                                     reg_j, zs, y, eps, zd, ld, ed, nd);
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    const bool hit = (j == st);
+                    kl[j] = hit ? ld : kl[j];
+                    ke[j] = hit ? ed : ke[j];
+                    kn[j] = hit ? nd : kn[j];
+#pragma unroll
+                    for (int s = 0; s < ZR; ++s) kz[j][s] = hit ? zd[s] : kz[j][s];
+                }
+            }
+            if (single) break;
+            float sl = 0.f, se = 0.f, sn = 0.f;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const float bj = a.T.b[j];
+                sl = fmaf(bj, kl[j], sl); se = fmaf(bj, ke[j], se); sn = fmaf(bj, kn[j], sn);
+            }
+            lacc = fmaf(dt, sl, lacc); eacc = fmaf(dt, se, eacc); nacc = fmaf(dt, sn, nacc);
+#pragma unroll
+            for (int s = 0; s < ZR; ++s) {
+                float acc = 0.f;
+#pragma unroll
+                for (int j = 0; j < 6; ++j) acc = fmaf(a.T.b[j], kz[j][s], acc);
+                z[s] = fmaf(dt, acc, z[s]);
+            }
+        }
+
+        if (single) {
+            if (valid) {
+#pragma unroll
+                for (int s = 0; s < ZR; ++s) { const int f = 4 * s + g; if (f < D) a.u_out[smp * S + f] = kz[0][s]; }
+                if (g == 0) { a.u_out[smp * S + D] = kl[0]; a.u_out[smp * S + D + 1] = ke[0]; a.u_out[smp * S + D + 2] = kn[0]; }
+            }
+            continue;
+        }
+        // ---- epilogue: inference_sol (src/core/base_icnf.jl:158-172) ----
+        float ss = 0.f, sa = 0.f;
+#pragma unroll
+        for (int s = 0; s < ZR; ++s) {
+            const int f = 4 * s + g;
+            const float v2 = z[s] * z[s];
+            ss += v2;
+            if (f >= a.nvars) sa += v2;
+        }
+        ss = group_sum(ss);
+        sa = group_sum(sa);
+        if (valid) {
+            if (a.u_out) {
+#pragma unroll
+                for (int s = 0; s < ZR; ++s) { const int f = 4 * s + g; if (f < D) a.u_out[smp * S + f] = z[s]; }
+                if (g == 0) { a.u_out[smp * S + D] = lacc; a.u_out[smp * S + D + 1] = eacc; a.u_out[smp * S + D + 2] = nacc; }
+            }
+            if (g == 0) {
+                if (a.logp) a.logp[smp] = (-0.5f * (float)D * kLog2Pi - 0.5f * ss) - lacc;
+                if (a.regs) {
+                    a.regs[smp] = eacc;
+                    a.regs[a.B + smp] = nacc;
+                    a.regs[2 * a.B + smp] = a.reg_aug ? sqrtf(sa) : 0.f;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// plan: which instantiation serves a configuration, and how to pack its weights
+// ---------------------------------------------------------------------------------------
+typedef hipError_t (*LaunchFn)(const KArgs&, int lds_bytes, int nblocks, hipStream_t);
+
+struct MfmaPlan {
+    int HT, L, ZR, CR, ACT, KP;
+    bool with_bwd;
+    MfmaLayout lay;
+    LaunchFn launch;
+    cnf_config cfg;
+    int nthreads;
+    int num_cus;
+    char name[96];
+    MfmaPlan() : lay(1, 2, 1, 0, true) {}
+};
+
+template <int HT, int L, int ZR, int CR, int ACT, int KP, int NTHREADS>
+static hipError_t launch_vjp(const KArgs& a, int lds_bytes, int nblocks, hipStream_t st) {
+    auto kern = mfma_vjp_solve_kernel<HT, L, ZR, CR, ACT, KP, NTHREADS>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(NTHREADS), lds_bytes, st, a);
+    return hipGetLastError();
+}
+
+struct Inst {
+    int HT, L, ZR, CR, ACT, KP;
+    LaunchFn fn;
+    int nthreads;
+};
+
+#define VJP_INST(HT, L, ZR, CR, ACT, KP, NT) \
+    Inst { HT, L, ZR, CR, ACT, KP, &launch_vjp<HT, L, ZR, CR, ACT, KP, NT>, NT }
+
+static const Inst kVjpInsts[] = {
+    VJP_INST(4, 3, 2, 0, CNF_ACT_TANH, 1, 512),      // cfg2 / cfg2': D=8, 3x64, K=1
+    VJP_INST(4, 3, 2, 0, CNF_ACT_TANH, 4, 512),      // cfg3: RNODE K=4
+    VJP_INST(2, 2, 1, 0, CNF_ACT_TANH, 1, 512),      // cfg1: D=2, 2x32
+    VJP_INST(1, 2, 1, 0, CNF_ACT_SOFTPLUS, 1, 512),  // reference default net at nvariables=1
+};
+
+MfmaPlan* mfma_plan_create(const cnf_config& c) {
+    if (c.mode != CNF_MODE_HUTCH_VJP) return nullptr;
+    const int N = c.n_layers, L = N - 1;
+    if (L < 1) return nullptr;
+    const int H = c.widths[1];
+    for (int l = 1; l <= L; ++l)
+        if (c.widths[l] != H || c.acts[l - 1] != c.acts[0]) return nullptr;
+    if (c.acts[N - 1] != CNF_ACT_IDENTITY) return nullptr;
+    const int D = c.nvars + c.naug;
+    const int HT = (H + 15) / 16, ZR = (D + 3) / 4, CR = (c.ncond + 3) / 4;
+    for (const Inst& in : kVjpInsts) {
+        if (in.HT == HT && in.L == L && in.ZR == ZR && in.CR == CR && in.ACT == c.acts[0] && in.KP == c.nprobes) {
+            MfmaPlan* p = new MfmaPlan();
+            p->HT = HT; p->L = L; p->ZR = ZR; p->CR = CR; p->ACT = in.ACT; p->KP = in.KP;
+            p->with_bwd = true;
+            p->lay = MfmaLayout(HT, L, ZR, CR, true);
+            p->launch = in.fn;
+            p->cfg = c;
+            p->nthreads = in.nthreads;
+            p->num_cus = 0;
+            snprintf(p->name, sizeof(p->name), "mfma_vjp<HT=%d,L=%d,ZR=%d,CR=%d,act=%d,K=%d>", HT, L, ZR, CR, in.ACT, in.KP);
+            return p;
+        }
+    }
+    return nullptr;
+}
+
+void mfma_plan_destroy(MfmaPlan* p) { delete p; }
+size_t mfma_packed_bytes(const MfmaPlan* p) { return (size_t)p->lay.total * sizeof(float); }
+const char* mfma_plan_name(const MfmaPlan* p) { return p->name; }
+
+// A image: out[(mt*KG + kg)*256 + lane*4 + j] = A(rowmap(mt, lane&15), 16 kg + 4 j + (lane>>4))
+template <typename F>
+static void pack_imgA(float* out, int MT, int KG, int M, int K, F A) {
+    for (int mt = 0; mt < MT; ++mt)
+        for (int kg = 0; kg < KG; ++kg)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 4; ++j) {
+                    const int row = mfma_rowmap(mt, lane & 15);
+                    const int k = 16 * kg + 4 * j + (lane >> 4);
+                    out[((mt * KG + kg) * 64 + lane) * 4 + j] = (row < M && k < K) ? A(row, k) : 0.f;
+                }
+}
+
+// C vector: out[(mt*4 + g)*4 + r] = v(16 mt + 4 r + g)
+template <typename F>
+static void pack_vecC(float* out, int MT, int M, F v) {
+    for (int mt = 0; mt < MT; ++mt)
+        for (int g = 0; g < 4; ++g)
+            for (int r = 0; r < 4; ++r) {
+                const int f = 16 * mt + 4 * r + g;
+                out[(mt * 4 + g) * 4 + r] = f < M ? v(f) : 0.f;
+            }
+}
+
+void mfma_pack(const MfmaPlan* p, const float* lux, const size_t* w_off, const size_t* b_off, float* packed) {
+    const cnf_config& c = p->cfg;
+    const MfmaLayout& Y = p->lay;
+    const int N = c.n_layers, L = N - 1, H = c.widths[1], D = c.nvars + c.naug, C = c.ncond;
+    const int n_in = c.widths[0];
+    const int tcol = D;                           // time column of W1 (if !autonomous)
+    const int ycol = D + (c.autonomous ? 0 : 1);  // first cond column
+    (void)n_in;
+    // Lux Dense weight (out x in) column-major: W(o,i) = lux[w_off + o + out*i]
+    auto W = [&](int l, int o, int i) { return lux[w_off[l] + (size_t)o + (size_t)c.widths[l + 1] * i]; };
+    auto Bv = [&](int l, int o) { return lux[b_off[l] + o]; };
+    pack_imgA(packed + Y.f1z, Y.HT, Y.KGZ, H, D, [&](int r, int k) { return W(0, r, k); });
+    if (Y.CR > 0) pack_imgA(packed + Y.f1y, Y.HT, Y.KGC, H, C, [&](int r, int k) { return W(0, r, ycol + k); });
+    for (int l = 1; l < L; ++l)
+        pack_imgA(packed + Y.fh + (l - 1) * MfmaLayout::imgA(Y.HT, Y.HT), Y.HT, Y.HT, H, H,
+                  [&](int r, int k) { return W(l, r, k); });
+    pack_imgA(packed + Y.fN, Y.DT, Y.HT, D, H, [&](int r, int k) { return W(L, r, k); });
+    if (p->with_bwd) {
+        pack_imgA(packed + Y.bN, Y.HT, Y.KGZ, H, D, [&](int r, int k) { return W(L, k, r); });   // W_N^T
+        for (int l = 1; l < L; ++l)
+            pack_imgA(packed + Y.bh + (l - 1) * MfmaLayout::imgA(Y.HT, Y.HT), Y.HT, Y.HT, H, H,
+                      [&](int r, int k) { return W(l, k, r); });                                    // W_l^T
+        pack_imgA(packed + Y.b1, Y.DT, Y.HT, D, H, [&](int r, int k) { return W(0, k, r); });     // W_1[:,0:D]^T
+    }
+    pack_vecC(packed + Y.v_b1, Y.HT, H, [&](int f) { return Bv(0, f); });
+    pack_vecC(packed + Y.v_w1t, Y.HT, H, [&](int f) { return c.autonomous ? 0.f : W(0, f, tcol); });
+    for (int l = 1; l < L; ++l)
+        pack_vecC(packed + Y.v_bh + (l - 1) * MfmaLayout::vecC(Y.HT), Y.HT, H, [&](int f) { return Bv(l, f); });
+    pack_vecC(packed + Y.v_bN, Y.DT, D, [&](int f) { return Bv(L, f); });
+}
+
+hipError_t mfma_solve(const MfmaPlan* p, const float* packed_dev, const SolveArgs& s, hipStream_t st) {
+    if (s.B == 0) return hipSuccess;
+    MfmaPlan* mp = const_cast<MfmaPlan*>(p);
+    if (mp->num_cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return e;
+        e = hipGetDeviceProperties(&prop, dev);
+        if (e != hipSuccess) return e;
+        mp->num_cus = prop.multiProcessorCount;
+    }
+    KArgs a{};
+    a.packed = packed_dev;
+    a.x = s.x; a.u0 = s.u0; a.eps = s.eps; a.ys = s.ys;
+    a.u_out = s.u_out; a.logp = s.logp; a.regs = s.regs;
+    a.B = s.B; a.nsteps = s.nsteps; a.t0 = s.t0;
+    a.dt = s.nsteps > 0 ? (s.t1 - s.t0) / (float)s.nsteps : 0.f;
+    a.nvars = s.nvars; a.D = p->cfg.nvars + p->cfg.naug; a.C = p->cfg.ncond;
+    a.reg_z = p->cfg.reg_z; a.reg_j = p->cfg.reg_j; a.reg_aug = s.reg_aug; a.autonomous = p->cfg.autonomous;
+    a.T = make_tableau(s.alg);
+    const long long ntiles = (s.B + 15) / 16;
+    const int wpb = p->nthreads / 64;
+    long long want = (ntiles + wpb - 1) / wpb;
+    const int lds = (int)mfma_packed_bytes(p);
+    const int per_cu = lds > 80 * 1024 ? 1 : 2;
+    const long long cap = (long long)mp->num_cus * per_cu;
+    const int nblocks = (int)(want < cap ? want : cap);
+    return p->launch(a, lds, nblocks, st);
+}
+
+}  // namespace cnf

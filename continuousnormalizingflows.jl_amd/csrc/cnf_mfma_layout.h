@@ -1,0 +1,67 @@
+// cnf_mfma_layout.h — LDS image of the Dense chain for the fused MFMA solve kernels.
+//
+// Every product of the MLP and of its pullback is computed as  Out[M x 16 samples] =
+// A[M x K] * In[K x 16 samples]  with v_mfma_f32_16x16x4_f32: samples on the N axis (one
+// 16-sample tile per wave), features on M, and the *accumulator tile of one layer fed straight
+// back as the B operand of the next* — no LDS round trip, no cross-lane movement.
+//
+// That works because of one row permutation.  The C/D layout of the 16x16 MFMA puts row i of
+// the M-tile in lane group g = i>>2 (lanes 16g..16g+15), register r = i&3; the B operand of
+// k-step s wants k = 4s + g from lane group g.  If M-tile row i of tile mt is made to compute
+// feature  f = 16 mt + 4 (i&3) + (i>>2)  then register r of accumulator tile mt holds, in lane
+// group g, feature 4 (4 mt + r) + g — exactly the B operand of k-step s = 4 mt + r in natural k
+// order.  So the A images below are stored with permuted rows and natural columns.
+//
+// "dense layout" of a D-row quantity (z, eps, zdot, eps^T J): register s (s < ZR = ceil(D/4)),
+// lane group g holds row 4 s + g of the lane's sample — D = 8 uses 2 registers on all 64 lanes.
+//
+// An "A image" for a product with MT M-tiles and KG k-groups (4 k-steps each) is
+// [mt][kg][lane 0..63][j 0..3] floats: lane l, component j = A[rowmap(mt, l&15)][16 kg + 4 j + (l>>4)]
+// read with one conflict-free ds_read_b128 per 4 MFMAs.
+// A "C vector" (bias, time column) for MT tiles is [mt][g][r]: value of feature 16 mt + 4 r + g.
+#pragma once
+#include "cnf.h"
+
+namespace cnf {
+
+struct MfmaLayout {
+    int HT, L, ZR, CR;   // hidden tiles (H_pad = 16 HT), hidden layers, k-steps of D and of C
+    int DT, KGZ, KGC;    // M-tiles of D, k-groups of D and C
+    // A images (float offsets)
+    int f1z, f1y;        // layer 1, z columns / cond columns          M = H, K = D_pad / C_pad
+    int fh;              // hidden layers 2..L, consecutive             M = H, K = H
+    int fN;              // last layer                                  M = D, K = H
+    int bN;              // W_N^T                                       M = H, K = D_pad
+    int bh;              // W_l^T for l = 2..L (stored in forward order) M = H, K = H
+    int b1;              // W_1[:, 0:D]^T                               M = D, K = H
+    // C vectors
+    int v_b1, v_w1t, v_bh, v_bN;
+    int total;           // floats
+
+    static constexpr int imgA(int MT, int KG) { return MT * KG * 256; }
+    static constexpr int vecC(int MT) { return MT * 16; }
+
+    constexpr MfmaLayout(int HT_, int L_, int ZR_, int CR_, bool with_bwd)
+        : HT(HT_), L(L_), ZR(ZR_), CR(CR_), DT((ZR_ + 3) / 4), KGZ((ZR_ + 3) / 4), KGC((CR_ + 3) / 4),
+          f1z(0), f1y(0), fh(0), fN(0), bN(0), bh(0), b1(0), v_b1(0), v_w1t(0), v_bh(0), v_bN(0),
+          total(0) {
+        int o = 0;
+        f1z = o; o += imgA(HT, KGZ);
+        f1y = o; o += imgA(HT, KGC);
+        fh = o;  o += (L - 1) * imgA(HT, HT);
+        fN = o;  o += imgA(DT, HT);
+        bN = o;  if (with_bwd) o += imgA(HT, KGZ);
+        bh = o;  if (with_bwd) o += (L - 1) * imgA(HT, HT);
+        b1 = o;  if (with_bwd) o += imgA(DT, HT);
+        v_b1 = o;  o += vecC(HT);
+        v_w1t = o; o += vecC(HT);
+        v_bh = o;  o += (L - 1) * vecC(HT);
+        v_bN = o;  o += vecC(DT);
+        total = (o + 3) / 4 * 4;
+    }
+};
+
+// feature computed by M-tile row i of tile mt
+constexpr int mfma_rowmap(int mt, int i) { return 16 * mt + 4 * (i & 3) + (i >> 2); }
+
+}  // namespace cnf
