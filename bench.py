@@ -72,6 +72,7 @@ def cpu_baseline(o64, oc, spec, alg, p, xs, eps, ys, target_s):
     """Time the CPU restatement on all host cores on a bounded column sample."""
     nt = os.cpu_count() or 1
     nt = min(nt, oc.max_threads()) if oc.max_threads() > 0 else nt
+    oc.set_fast_tanh(True)   # the arithmetic Lux's CPU path runs (NNlib.tanh_fast); vectorises
     B0 = 64 * nt
     t = time.perf_counter()
     oc.inference_fixed(spec, p, xs[:, :B0], 0.0, 1.0, NSTEPS, alg, eps[:, :B0],
@@ -86,7 +87,7 @@ def cpu_baseline(o64, oc, spec, alg, p, xs, eps, ys, target_s):
     dt = time.perf_counter() - t
     return dict(value=Bs * NSTEPS / dt, unit="samples*steps/s", cores=nt, kind="port",
                 sample=f"{Bs} of the workload's columns, one full {NSTEPS}-step solve, "
-                       f"{dt:.1f} s, oracle/cnf_oracle.c (gcc -O3 -march=x86-64-v3 -fopenmp)")
+                       f"{dt:.1f} s, oracle/cnf_oracle.c (gcc -O3 -march=x86-64-v3 -fopenmp, tanh_fast)")
 
 
 def main():

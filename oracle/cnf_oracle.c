@@ -40,6 +40,20 @@ static int check_cfg(const cnf_oracle_cfg* c) {
     return 0;
 }
 
+/* Lux swaps tanh -> NNlib.tanh_fast on CPU Float32 arrays (upstream): a rational
+ * approximation, max abs error 3.3e-7 (checked against tanh in float64).  The parity checks use
+ * libm tanhf (default); bench.py's cpu_baseline switches this on so the timed CPU path does the
+ * arithmetic the reference's CPU path does (and vectorises). */
+static int g_fast_tanh = 0;
+void cnf_oracle_set_fast_tanh(int on) { g_fast_tanh = on; }
+static inline float tanh_fast_f(float x) {
+    const float x2 = x * x;
+    const float n = 1.0f + x2 * (0.1346604f + x2 * (0.0035974074f + x2 * (2.2332108e-5f + x2 * 1.587199e-8f)));
+    const float d = 1.0f + x2 * (0.4679937f + x2 * (0.026262015f + x2 * (0.0003453992f + x2 * 8.7767893e-7f)));
+    const float r = x * (n / d);
+    return x2 < 66.f ? r : (x > 0.f ? 1.f : -1.f);
+}
+
 /* NNlib.softplus(x) = log1p(exp(-|x|)) + relu(x) */
 static inline float softplusf(float x) { return log1pf(expf(-fabsf(x))) + (x > 0.f ? x : 0.f); }
 static inline float sigmoidf(float x) { return 1.f / (1.f + expf(-x)); }
@@ -95,7 +109,12 @@ static void dense_fwd(const float* W, const float* b, int fin, int fout, int act
     if (act == ACT_ID) {
         memcpy(h, a, n * sizeof(float));
     } else if (act == ACT_TANH) {
-        for (size_t k = 0; k < n; ++k) h[k] = tanhf(a[k]);
+        if (g_fast_tanh) {
+#pragma omp simd
+            for (size_t k = 0; k < n; ++k) h[k] = tanh_fast_f(a[k]);
+        } else {
+            for (size_t k = 0; k < n; ++k) h[k] = tanhf(a[k]);
+        }
     } else {
         for (size_t k = 0; k < n; ++k) h[k] = softplusf(a[k]);
     }
@@ -243,6 +262,19 @@ static void aug_f_block(const cnf_oracle_cfg* c, const float* p, const size_t* w
     }
 }
 
+/* worksharing body: must be called by every thread of an enclosing parallel region */
+static void aug_f_ws(const cnf_oracle_cfg* cfg, const float* p, const size_t* w_off,
+                     const size_t* b_off, const float* u, float t, const float* eps,
+                     const float* ys, int64_t B, float* du, scratch* s) {
+    const int64_t nblk = (B + CB - 1) / CB;
+#pragma omp for schedule(static)
+    for (int64_t blk = 0; blk < nblk; ++blk) {
+        const int64_t col0 = blk * CB;
+        const int ncols = (int)((B - col0) < CB ? (B - col0) : CB);
+        aug_f_block(cfg, p, w_off, b_off, u, t, eps, ys, col0, ncols, du, s);
+    }
+}
+
 int cnf_oracle_aug_f(const cnf_oracle_cfg* cfg, const float* p, const size_t* w_off,
                      const size_t* b_off, const float* u, float t, const float* eps,
                      const float* ys, int64_t B, float* du, int nthreads) {
@@ -250,24 +282,19 @@ int cnf_oracle_aug_f(const cnf_oracle_cfg* cfg, const float* p, const size_t* w_
     if (rc) return rc;
     if (cfg->mode != MODE_EXACT && !eps) return -4;
     if (cfg->ncond && !ys) return -5;
-    const int64_t nblk = (B + CB - 1) / CB;
     int err = 0;
     if (nthreads < 1) nthreads = 1;
 #pragma omp parallel num_threads(nthreads)
     {
         scratch s;
-        if (scratch_init(&s, cfg)) {
+        const int bad = scratch_init(&s, cfg);
+        if (bad) {
 #pragma omp atomic write
             err = -6;
-        } else {
-#pragma omp for schedule(static)
-            for (int64_t blk = 0; blk < nblk; ++blk) {
-                const int64_t col0 = blk * CB;
-                const int ncols = (int)((B - col0) < CB ? (B - col0) : CB);
-                aug_f_block(cfg, p, w_off, b_off, u, t, eps, ys, col0, ncols, du, &s);
-            }
-            free(s.base);
         }
+#pragma omp barrier
+        if (!err) aug_f_ws(cfg, p, w_off, b_off, u, t, eps, ys, B, du, &s);
+        if (!bad) free(s.base);
     }
     return err;
 }
@@ -307,26 +334,44 @@ int cnf_oracle_integrate_fixed(const cnf_oracle_cfg* cfg, const float* p, const 
     if (u1 != u0) memcpy(u1, u0, n * sizeof(float));
     const float dt = (t1 - t0) / (float)nsteps;
     if (nthreads < 1) nthreads = 1;
-    for (int step = 0; step < nsteps && !rc; ++step) {
-        const float tn = t0 + (float)step * dt;
-        for (int i = 0; i < ns && !rc; ++i) {
-            const float* Ai = alg == 0 ? RK4_A[i] : T5_A[i];
-#pragma omp parallel for num_threads(nthreads) schedule(static)
-            for (int64_t e = 0; e < (int64_t)n; ++e) {
-                float acc = 0.f;
-                for (int j = 0; j < i; ++j) acc += Ai[j] * k[j][e];
-                us[e] = u1[e] + dt * acc;
+    if (cfg->mode != MODE_EXACT && !eps) rc = -4;
+    if (cfg->ncond && !ys) rc = -5;
+    int err = rc;
+    /* one parallel region per solve; inside it the reference's structure is kept: per stage a
+     * whole-state axpy, then one dynamics call over the whole batch (implicit barriers) */
+#pragma omp parallel num_threads(nthreads)
+    {
+        scratch s;
+        const int bad = scratch_init(&s, cfg);
+        if (bad) {
+#pragma omp atomic write
+            err = -6;
+        }
+#pragma omp barrier
+        if (!err) {
+            for (int step = 0; step < nsteps; ++step) {
+                const float tn = t0 + (float)step * dt;
+                for (int i = 0; i < ns; ++i) {
+                    const float* Ai = alg == 0 ? RK4_A[i] : T5_A[i];
+#pragma omp for schedule(static)
+                    for (int64_t e = 0; e < (int64_t)n; ++e) {
+                        float acc = 0.f;
+                        for (int j = 0; j < i; ++j) acc += Ai[j] * k[j][e];
+                        us[e] = u1[e] + dt * acc;
+                    }
+                    aug_f_ws(cfg, p, w_off, b_off, us, tn + Cc[i] * dt, eps, ys, B, k[i], &s);
+                }
+#pragma omp for schedule(static)
+                for (int64_t e = 0; e < (int64_t)n; ++e) {
+                    float acc = 0.f;
+                    for (int i = 0; i < ns; ++i) acc += Bc[i] * k[i][e];
+                    u1[e] += dt * acc;
+                }
             }
-            rc = cnf_oracle_aug_f(cfg, p, w_off, b_off, us, tn + Cc[i] * dt, eps, ys, B, k[i], nthreads);
         }
-        if (rc) break;
-#pragma omp parallel for num_threads(nthreads) schedule(static)
-        for (int64_t e = 0; e < (int64_t)n; ++e) {
-            float acc = 0.f;
-            for (int i = 0; i < ns; ++i) acc += Bc[i] * k[i][e];
-            u1[e] += dt * acc;
-        }
+        if (!bad) free(s.base);
     }
+    rc = err;
     free(us);
     for (int i = 0; i < ns; ++i) free(k[i]);
     return rc;

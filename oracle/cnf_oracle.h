@@ -56,6 +56,9 @@ int cnf_oracle_inference_fixed(const cnf_oracle_cfg* cfg, const float* p, const 
 
 int cnf_oracle_max_threads(void);
 
+/* 1: use NNlib.tanh_fast's rational approximation (what Lux runs on CPU Float32); 0: libm tanhf */
+void cnf_oracle_set_fast_tanh(int on);
+
 #ifdef __cplusplus
 }
 #endif

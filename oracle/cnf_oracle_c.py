@@ -53,6 +53,10 @@ def lib():
     return _lib
 
 
+def set_fast_tanh(on: bool) -> None:
+    lib().cnf_oracle_set_fast_tanh(int(bool(on)))
+
+
 def max_threads() -> int:
     return int(lib().cnf_oracle_max_threads())
 
