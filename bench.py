@@ -51,6 +51,20 @@ CONFIGS = {
              "CondFFJORD nvars=8+8 cond, MLP 3x128 tanh, exact trace, RK4 40 steps, batch=16384"),
 }
 NSTEPS = 40
+
+
+def measured_traffic(name):
+    """HBM bytes per launch of the solve kernel from the PMC passes of profiles/collect.sh
+    (FETCH_SIZE and WRITE_SIZE in separate runs; FETCH_SIZE doubled per the gfx950 note in
+    MI355X_MICROARCH.md §HBM).  bench.py cannot run rocprofv3 on itself, so the figure is read
+    from the committed summary; null when the configuration has not been profiled."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            return json.load(f).get(name)
+    except Exception:
+        return None
+
+
 F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 = f32 vector rate
 HBM_PEAK_GBS = 8000.0
 
@@ -188,7 +202,8 @@ def main():
             "loss": float(lossv),
             "roofline": {
                 "bound": "mfma", "achieved": ach_tflops, "peak": F32_MFMA_PEAK_TFLOPS,
-                "unit": "TFLOP/s", "frac": ach_tflops / F32_MFMA_PEAK_TFLOPS, "traffic": None,
+                "unit": "TFLOP/s", "frac": ach_tflops / F32_MFMA_PEAK_TFLOPS,
+                "traffic": measured_traffic(a.config),
                 "kernel_ms": kern_ms, "flop_per_sample_step": flop_ss,
                 "hbm_model": {
                     "fused_bytes_per_launch": bytes_fused * B,

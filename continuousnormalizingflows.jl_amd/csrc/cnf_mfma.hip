@@ -16,6 +16,8 @@
 //     MFMA-operand order and read with conflict-free ds_read_b128 (one read per 4 MFMAs).
 //   * eps^T J eps, |zdot|, |eps^T J| are reduced over the 4 lane groups that share a sample with
 //     two cross-lane exchanges.
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -39,6 +41,9 @@ struct KArgs {
     int nsteps;         // 0: single dynamics call at t0, du -> u_out
     float t0, dt;
     int nvars, D, C, reg_z, reg_j, reg_aug, autonomous;
+    int exact;          // tangent engine only: seeds are the D unit vectors, ldot = -tr J
+    int prio_mode;      // 0 none, 1 waves 0..3 high, 2 waves 4.. high (SIMD partners = w, w+4)
+    int* queue;         // dynamic tile queue (zeroed before the launch) or null = static stride
     Tableau T;
 };
 
@@ -93,18 +98,26 @@ __device__ __forceinline__ void load_cvec(const float* __restrict__ vec, int g, 
     for (int mt = 0; mt < MT; ++mt) out[mt] = *reinterpret_cast<const f32x4*>(vec + (mt * 4 + g) * 4);
 }
 
-// One dynamics evaluation for a 16-sample tile (VJP engine).
-template <int HT, int L, int ZR, int CR, int ACT, int KP>
-__device__ __forceinline__ void dyn_eval_vjp(const float* __restrict__ smem, int lane, float t,
-                                             bool autonomous, bool reg_z, bool reg_j,
-                                             const float (&z)[ZR], const float (&y)[CR > 0 ? CR : 1],
-                                             const float (&eps)[KP][ZR], float (&zd)[ZR], float& ld,
-                                             float& ed, float& nd) {
-    constexpr MfmaLayout LAY(HT, L, ZR, CR, true);
+enum { ENG_VJP = 0, ENG_TAN = 1 };
+
+// One dynamics evaluation for a 16-sample tile.
+//   forward pass (shared), then
+//   ENG_VJP: pullback of KP probes with the transposed images  (g = eps^T J;  src/core/utils.jl:150-159)
+//   ENG_TAN: pushforward of tangents with the forward images only:
+//            Hutchinson JVP (g = J eps; src/core/utils.jl:161-170) or, with `exact`, the D unit
+//            tangents whose i-th output row is J_ii (trace of src/core/utils.jl:79-88, icnf.jl:312)
+template <int HT, int L, int ZR, int CR, int ACT, int ENGINE, int KP, int PRE>
+__device__ __forceinline__ void dyn_eval(const float* __restrict__ smem, int lane, float t,
+                                         bool autonomous, bool reg_z, bool reg_j, bool exact, int D,
+                                         const float (&z)[ZR], const float (&y)[CR > 0 ? CR : 1],
+                                         const float (&eps)[KP][ZR], const f32x4 (&pre_c)[HT],
+                                         const f32x4 (&pre_q)[HT], float (&zd)[ZR], float& ld,
+                                         float& ed, float& nd) {
+    constexpr MfmaLayout LAY(HT, L, ZR, CR, ENGINE == ENG_VJP);
     constexpr int DT = (ZR + 3) / 4;
     const int g = lane >> 4;
     f32x4 h[HT];
-    f32x4 d[L][HT];  // act' of every hidden layer, kept for the pullback
+    f32x4 d[L][HT];  // act' of every hidden layer, kept for the pullback / pushforward
 
     // ---- layer 1: a = W1z z + w1t t + W1y y + b1 ----
     {
@@ -157,62 +170,102 @@ __device__ __forceinline__ void dyn_eval_vjp(const float* __restrict__ smem, int
         for (int s = 0; s < ZR; ++s) e2 = fmaf(zd[s], zd[s], e2);
         ed = sqrtf(group_sum(e2));   // Edot = |zdot|_2   (src/core/icnf.jl:184-199)
     }
-    // ---- pullback per probe: g = eps^T J ----
     ld = 0.f;
     nd = 0.f;
-    constexpr float invK = 1.f / (float)KP;
-    // probes run one after the other (rolled loop): the transposed images are re-read from LDS
-    // per probe, which costs LDS bandwidth the kernel has to spare and keeps registers flat.
+    // Probes / tangents run one after the other (rolled loop): the operand images are re-read
+    // from LDS each time, which costs LDS bandwidth the kernel has to spare and keeps the
+    // register footprint flat.
+    const int nseed = (ENGINE == ENG_TAN && exact) ? D : KP;
+    const float scale = (ENGINE == ENG_TAN && exact) ? 1.f : 1.f / (float)KP;
 #pragma clang loop unroll(disable)
-    for (int p = 0; p < KP; ++p) {
+    for (int p = 0; p < nseed; ++p) {
         float ep[ZR];
 #pragma unroll
         for (int s = 0; s < ZR; ++s) {
             ep[s] = eps[0][s];
 #pragma unroll
             for (int q = 1; q < KP; ++q) ep[s] = (p == q) ? eps[q][s] : ep[s];
+            if (ENGINE == ENG_TAN && exact) ep[s] = (4 * s + g == p) ? 1.f : 0.f;   // unit vector e_p
         }
         int opq = 0;
-        if constexpr (KP > 1) asm volatile("" : "+v"(opq));
+        if (KP > 1 || ENGINE == ENG_TAN) asm volatile("" : "+v"(opq));
         const float* __restrict__ sm = smem + opq;
-        f32x4 dl[HT];
-        {
-            f32x4 acc[HT];
-#pragma unroll
-            for (int mt = 0; mt < HT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-            gemm_tiles<HT, ZR>(sm + LAY.bN, lane, RegIn<ZR>{ep}, acc);   // W_N^T eps
-#pragma unroll
-            for (int mt = 0; mt < HT; ++mt) dl[mt] = acc[mt] * d[L - 1][mt];
-        }
-#pragma unroll
-        for (int l = L - 1; l >= 1; --l) {  // W_{l+1}^T delta, times act'(a_l)
-            f32x4 acc[HT];
-#pragma unroll
-            for (int mt = 0; mt < HT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-            gemm_tiles<HT, 4 * HT>(sm + LAY.bh + (l - 1) * MfmaLayout::imgA(HT, HT), lane, TileIn<HT>{dl}, acc);
-#pragma unroll
-            for (int mt = 0; mt < HT; ++mt) dl[mt] = acc[mt] * d[l - 1][mt];
-        }
         f32x4 gacc[DT];
 #pragma unroll
         for (int dt_ = 0; dt_ < DT; ++dt_) gacc[dt_] = f32x4{0.f, 0.f, 0.f, 0.f};
-        gemm_tiles<DT, 4 * HT>(sm + LAY.b1, lane, TileIn<HT>{dl}, gacc);       // W_1[:,0:D]^T delta_1
+        if constexpr (ENGINE == ENG_VJP) {
+            f32x4 dl[HT];
+            if constexpr (PRE) {   // W_N^T eps does not change during the solve: hoisted by the caller
+#pragma unroll
+                for (int mt = 0; mt < HT; ++mt) dl[mt] = pre_c[mt] * d[L - 1][mt];
+            } else {
+                f32x4 acc[HT];
+#pragma unroll
+                for (int mt = 0; mt < HT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                gemm_tiles<HT, ZR>(sm + LAY.bN, lane, RegIn<ZR>{ep}, acc);   // W_N^T eps
+#pragma unroll
+                for (int mt = 0; mt < HT; ++mt) dl[mt] = acc[mt] * d[L - 1][mt];
+            }
+#pragma unroll
+            for (int l = L - 1; l >= 1; --l) {  // W_{l+1}^T delta, times act'(a_l)
+                f32x4 acc[HT];
+#pragma unroll
+                for (int mt = 0; mt < HT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                gemm_tiles<HT, 4 * HT>(sm + LAY.bh + (l - 1) * MfmaLayout::imgA(HT, HT), lane, TileIn<HT>{dl}, acc);
+#pragma unroll
+                for (int mt = 0; mt < HT; ++mt) dl[mt] = acc[mt] * d[l - 1][mt];
+            }
+            if constexpr (PRE == 2) {
+                // without the |eps^T J| regulariser only <eps^T J, eps> = <delta_1, W_1[:,0:D] eps> is
+                // needed: a dot product with the hoisted q = W_1[:,0:D] eps replaces the last product
+                float qd = 0.f;
+#pragma unroll
+                for (int mt = 0; mt < HT; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) qd = fmaf(dl[mt][r], pre_q[mt][r], qd);
+                ld -= scale * group_sum(qd);
+                continue;
+            }
+            gemm_tiles<DT, 4 * HT>(sm + LAY.b1, lane, TileIn<HT>{dl}, gacc);   // W_1[:,0:D]^T delta_1
+        } else {
+            f32x4 tau[HT];
+            {
+                f32x4 acc[HT];
+#pragma unroll
+                for (int mt = 0; mt < HT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                gemm_tiles<HT, ZR>(sm + LAY.f1z, lane, RegIn<ZR>{ep}, acc);  // W_1[:,0:D] v
+#pragma unroll
+                for (int mt = 0; mt < HT; ++mt) tau[mt] = acc[mt] * d[0][mt];
+            }
+#pragma unroll
+            for (int l = 1; l < L; ++l) {  // act'(a_{l+1}) .* (W_{l+1} tau)
+                f32x4 acc[HT];
+#pragma unroll
+                for (int mt = 0; mt < HT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                gemm_tiles<HT, 4 * HT>(sm + LAY.fh + (l - 1) * MfmaLayout::imgA(HT, HT), lane, TileIn<HT>{tau}, acc);
+#pragma unroll
+                for (int mt = 0; mt < HT; ++mt) tau[mt] = acc[mt] * d[l][mt];
+            }
+            gemm_tiles<DT, 4 * HT>(sm + LAY.fN, lane, TileIn<HT>{tau}, gacc);  // W_N tau = J v
+        }
         float dot = 0.f, n2 = 0.f;
 #pragma unroll
         for (int s = 0; s < ZR; ++s) {
             const float gv = gacc[s >> 2][s & 3];
-            dot = fmaf(gv, ep[s], dot);     // ldot = -sum(eJ .* eps)   (icnf.jl:532)
+            dot = fmaf(gv, ep[s], dot);     // ldot = -sum(eJ .* eps) / -sum(eps .* Jeps) / -J_pp
             n2 = fmaf(gv, gv, n2);
         }
-        ld -= invK * group_sum(dot);
-        if (reg_j) nd += invK * sqrtf(group_sum(n2));   // ndot = |eps^T J|_2 (icnf.jl:229-245)
+        ld -= scale * group_sum(dot);
+        if (reg_j) nd += scale * sqrtf(group_sum(n2));   // ndot = |eps^T J|_2 or |J eps|_2 (icnf.jl:229-245)
     }
 }
 
-template <int HT, int L, int ZR, int CR, int ACT, int KP, int NTHREADS>
+// PRE: 0 none; 1 hoist c = W_N^T eps; 2 also hoist q = W_1[:,0:D] eps and skip the last pullback
+// product (valid only without reg_j).  PRE > 0 needs ENGINE == ENG_VJP and KP == 1.
+template <int HT, int L, int ZR, int CR, int ACT, int ENGINE, int KP, int PRE, int NTHREADS>
 __global__ void __launch_bounds__(NTHREADS)
-mfma_vjp_solve_kernel(KArgs a) {
-    constexpr MfmaLayout LAY(HT, L, ZR, CR, true);
+mfma_solve_kernel(KArgs a) {
+    constexpr MfmaLayout LAY(HT, L, ZR, CR, ENGINE == ENG_VJP);
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // stage the packed weight image: global (L2) -> LDS, 16 B per lane, coalesced
     {
@@ -229,10 +282,30 @@ mfma_vjp_solve_kernel(KArgs a) {
     const long long ntiles = (a.B + 15) / 16;
     const int D = a.D, S = D + 3, C = a.C;
     const int Kd = KP * D;
-    const bool reg_z = a.reg_z, reg_j = a.reg_j, autonomous = a.autonomous;
+    const bool reg_z = a.reg_z, reg_j = a.reg_j, autonomous = a.autonomous, exact = a.exact;
 
-    for (long long tile = (long long)blockIdx.x * WPB + wave; tile < ntiles;
-         tile += (long long)gridDim.x * WPB) {
+    // SIMD partners (waves w and w+4 of a workgroup) run the same program; left alone they fall
+    // into lockstep, their activation phases coincide and the matrix pipe idles (measured: 72 %
+    // MFMA-busy).  A static priority split makes one partner the pole wave and lets the other
+    // fill its VALU phases; the dynamic tile queue then balances the uneven progress.
+    if (a.prio_mode == 1) { if (__builtin_amdgcn_readfirstlane(wave) < 4) __builtin_amdgcn_s_setprio(1); }
+    else if (a.prio_mode == 2) { if (__builtin_amdgcn_readfirstlane(wave) >= 4) __builtin_amdgcn_s_setprio(1); }
+    else if (a.prio_mode == 3) {   // graded: wave quad 0 highest
+        const int q = __builtin_amdgcn_readfirstlane(wave) >> 2;
+        if (q == 0) __builtin_amdgcn_s_setprio(3);
+        else if (q == 1) __builtin_amdgcn_s_setprio(2);
+        else if (q == 2) __builtin_amdgcn_s_setprio(1);
+    }
+    const long long total_waves = (long long)gridDim.x * WPB;
+
+    for (long long tile = (long long)blockIdx.x * WPB + wave; tile < ntiles;) {
+        // next tile: static stride, or one returning atomic per tile on the launch's queue word
+        long long next_tile = tile + total_waves;
+        if (a.queue) {
+            int tk = 0;
+            if (lane == 0) tk = atomicAdd(a.queue, 1);
+            next_tile = total_waves + (long long)__builtin_amdgcn_readfirstlane(tk);
+        }
         const long long smp = tile * 16 + n;
         const bool valid = smp < a.B;
         const long long sc = valid ? smp : a.B - 1;   // clamp loads, mask stores
@@ -244,7 +317,7 @@ mfma_vjp_solve_kernel(KArgs a) {
             if (a.x) z[s] = f < a.nvars ? a.x[sc * a.nvars + f] : 0.f;   // u0 = [x; 0]
             else z[s] = f < D ? a.u0[sc * S + f] : 0.f;
 #pragma unroll
-            for (int p = 0; p < KP; ++p) eps[p][s] = f < D ? a.eps[sc * Kd + p * D + f] : 0.f;
+            for (int p = 0; p < KP; ++p) eps[p][s] = (f < D && a.eps) ? a.eps[sc * Kd + p * D + f] : 0.f;
         }
         if (!a.x) { lacc = a.u0[sc * S + D]; eacc = a.u0[sc * S + D + 1]; nacc = a.u0[sc * S + D + 2]; }
         y[0] = 0.f;
@@ -261,6 +334,11 @@ mfma_vjp_solve_kernel(KArgs a) {
 #pragma unroll
             for (int s = 0; s < ZR; ++s) kz[j][s] = 0.f;
         }
+        f32x4 pre_c[HT], pre_q[HT];
+#pragma unroll
+        for (int mt = 0; mt < HT; ++mt) pre_c[mt] = pre_q[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (PRE >= 1) gemm_tiles<HT, ZR>(smem + LAY.bN, lane, RegIn<ZR>{eps[0]}, pre_c);
+        if constexpr (PRE >= 2) gemm_tiles<HT, ZR>(smem + LAY.f1z, lane, RegIn<ZR>{eps[0]}, pre_q);
         const float dt = a.dt;
         const bool single = a.nsteps == 0;      // one dynamics call: du = f(u, p, t0)
         const int ns = single ? 1 : a.T.ns;
@@ -283,8 +361,9 @@ mfma_vjp_solve_kernel(KArgs a) {
                 // of the RK loops (and spill them).  An opaque zero offset pins the reads per stage.
                 int opaque = 0;
                 asm volatile("" : "+v"(opaque));
-                dyn_eval_vjp<HT, L, ZR, CR, ACT, KP>(smem + opaque, lane, tn + a.T.c[st] * dt, autonomous, reg_z,
-                                                     reg_j, zs, y, eps, zd, ld, ed, nd);
+                dyn_eval<HT, L, ZR, CR, ACT, ENGINE, KP, PRE>(smem + opaque, lane, tn + a.T.c[st] * dt, autonomous,
+                                                              reg_z, reg_j, exact, D, zs, y, eps, pre_c, pre_q, zd,
+                                                              ld, ed, nd);
 #pragma unroll
                 for (int j = 0; j < 6; ++j) {
                     const bool hit = (j == st);
@@ -318,6 +397,7 @@ mfma_vjp_solve_kernel(KArgs a) {
                 for (int s = 0; s < ZR; ++s) { const int f = 4 * s + g; if (f < D) a.u_out[smp * S + f] = kz[0][s]; }
                 if (g == 0) { a.u_out[smp * S + D] = kl[0]; a.u_out[smp * S + D + 1] = ke[0]; a.u_out[smp * S + D + 2] = kn[0]; }
             }
+            tile = next_tile;
             continue;
         }
         // ---- epilogue: inference_sol (src/core/base_icnf.jl:158-172) ----
@@ -346,6 +426,7 @@ mfma_vjp_solve_kernel(KArgs a) {
                 }
             }
         }
+        tile = next_tile;
     }
 }
 
@@ -355,20 +436,23 @@ mfma_vjp_solve_kernel(KArgs a) {
 typedef hipError_t (*LaunchFn)(const KArgs&, int lds_bytes, int nblocks, hipStream_t);
 
 struct MfmaPlan {
-    int HT, L, ZR, CR, ACT, KP;
+    int HT, L, ZR, CR, ACT, ENGINE, KP;
     bool with_bwd;
     MfmaLayout lay;
     LaunchFn launch;
     cnf_config cfg;
     int nthreads;
     int num_cus;
-    char name[96];
+    int prio_mode;      // see KArgs
+    int use_queue;
+    int* queue_dev;     // one int per plan, zeroed on the stream before every launch
+    char name[128];
     MfmaPlan() : lay(1, 2, 1, 0, true) {}
 };
 
-template <int HT, int L, int ZR, int CR, int ACT, int KP, int NTHREADS>
-static hipError_t launch_vjp(const KArgs& a, int lds_bytes, int nblocks, hipStream_t st) {
-    auto kern = mfma_vjp_solve_kernel<HT, L, ZR, CR, ACT, KP, NTHREADS>;
+template <int HT, int L, int ZR, int CR, int ACT, int ENGINE, int KP, int PRE, int NTHREADS>
+static hipError_t launch_inst(const KArgs& a, int lds_bytes, int nblocks, hipStream_t st) {
+    auto kern = mfma_solve_kernel<HT, L, ZR, CR, ACT, ENGINE, KP, PRE, NTHREADS>;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
@@ -380,23 +464,44 @@ static hipError_t launch_vjp(const KArgs& a, int lds_bytes, int nblocks, hipStre
 }
 
 struct Inst {
-    int HT, L, ZR, CR, ACT, KP;
+    int HT, L, ZR, CR, ACT, ENGINE, KP;
+    int PRE;   // 2 requires !reg_j
     LaunchFn fn;
     int nthreads;
 };
 
-#define VJP_INST(HT, L, ZR, CR, ACT, KP, NT) \
-    Inst { HT, L, ZR, CR, ACT, KP, &launch_vjp<HT, L, ZR, CR, ACT, KP, NT>, NT }
+#define MFMA_INST(HT, L, ZR, CR, ACT, ENG, KP, PRE, NT) \
+    Inst { HT, L, ZR, CR, ACT, ENG, KP, PRE, &launch_inst<HT, L, ZR, CR, ACT, ENG, KP, PRE, NT>, NT }
 
-static const Inst kVjpInsts[] = {
-    VJP_INST(4, 3, 2, 0, CNF_ACT_TANH, 1, 512),      // cfg2 / cfg2': D=8, 3x64, K=1
-    VJP_INST(4, 3, 2, 0, CNF_ACT_TANH, 4, 512),      // cfg3: RNODE K=4
-    VJP_INST(2, 2, 1, 0, CNF_ACT_TANH, 1, 512),      // cfg1: D=2, 2x32
-    VJP_INST(1, 2, 1, 0, CNF_ACT_SOFTPLUS, 1, 512),  // reference default net at nvariables=1
+// Instantiations.  The first entry that matches (shape, engine, K) and the requested thread count
+// (CNF_MFMA_NT, default: first match) serves the configuration; everything else runs on the
+// generic SIMT path.
+static const Inst kInsts[] = {
+    // --- Hutchinson VJP (LuxVecJacMatrixMode + TrainMode) ---
+    MFMA_INST(4, 3, 2, 0, CNF_ACT_TANH, ENG_VJP, 1, 2, 512),      // cfg2 / cfg2': D=8, 3x64, K=1, FFJORD
+    MFMA_INST(4, 3, 2, 0, CNF_ACT_TANH, ENG_VJP, 1, 1, 512),      // same shape with reg_j (RNODE, K=1)
+    MFMA_INST(4, 3, 2, 0, CNF_ACT_TANH, ENG_VJP, 1, 0, 512),      // no hoisting (A/B reference)
+    MFMA_INST(4, 3, 2, 0, CNF_ACT_TANH, ENG_VJP, 1, 2, 1024),
+    MFMA_INST(4, 3, 2, 0, CNF_ACT_TANH, ENG_VJP, 1, 2, 256),
+    MFMA_INST(4, 3, 2, 0, CNF_ACT_TANH, ENG_VJP, 4, 0, 512),      // cfg3: RNODE K=4
+    MFMA_INST(2, 2, 1, 0, CNF_ACT_TANH, ENG_VJP, 1, 2, 512),      // cfg1: D=2, 2x32
+    MFMA_INST(2, 2, 1, 0, CNF_ACT_TANH, ENG_VJP, 1, 1, 512),
+    MFMA_INST(1, 2, 1, 0, CNF_ACT_SOFTPLUS, ENG_VJP, 1, 1, 512),  // reference default net, nvariables=1
+    // --- tangent engine: Hutchinson JVP (LuxJacVecMatrixMode) and exact trace (TestMode) ---
+    MFMA_INST(8, 3, 2, 2, CNF_ACT_TANH, ENG_TAN, 1, 0, 256),      // cfg5: D=8, C=8, 3x128 (200 VGPR, 1 wave/SIMD:
+    MFMA_INST(8, 3, 2, 2, CNF_ACT_TANH, ENG_TAN, 1, 0, 512),      //  13.1 ms; the 512-thread build spills: 23.7 ms)
+    MFMA_INST(4, 3, 2, 0, CNF_ACT_TANH, ENG_TAN, 1, 0, 512),      // D=8, 3x64 exact / JVP
+    MFMA_INST(2, 2, 1, 0, CNF_ACT_TANH, ENG_TAN, 1, 0, 512),      // D<=4, 2x32 exact / JVP
+    MFMA_INST(1, 2, 1, 0, CNF_ACT_SOFTPLUS, ENG_TAN, 1, 0, 512),  // reference default net, TestMode
+    MFMA_INST(1, 2, 1, 0, CNF_ACT_TANH, ENG_TAN, 1, 0, 512),
 };
 
+static int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return (v && *v) ? atoi(v) : dflt;
+}
+
 MfmaPlan* mfma_plan_create(const cnf_config& c) {
-    if (c.mode != CNF_MODE_HUTCH_VJP) return nullptr;
     const int N = c.n_layers, L = N - 1;
     if (L < 1) return nullptr;
     const int H = c.widths[1];
@@ -405,24 +510,38 @@ MfmaPlan* mfma_plan_create(const cnf_config& c) {
     if (c.acts[N - 1] != CNF_ACT_IDENTITY) return nullptr;
     const int D = c.nvars + c.naug;
     const int HT = (H + 15) / 16, ZR = (D + 3) / 4, CR = (c.ncond + 3) / 4;
-    for (const Inst& in : kVjpInsts) {
-        if (in.HT == HT && in.L == L && in.ZR == ZR && in.CR == CR && in.ACT == c.acts[0] && in.KP == c.nprobes) {
+    const int engine = c.mode == CNF_MODE_HUTCH_VJP ? ENG_VJP : ENG_TAN;
+    const int KP = c.mode == CNF_MODE_EXACT ? 1 : c.nprobes;
+    const int want_nt = env_int("CNF_MFMA_NT", 0);
+    const int want_pre = env_int("CNF_MFMA_PRE", -1);
+    for (const Inst& in : kInsts) {
+        if (in.PRE == 2 && c.reg_j) continue;   // the dot-product shortcut needs no |eps^T J|
+        if (in.HT == HT && in.L == L && in.ZR == ZR && in.CR == CR && in.ACT == c.acts[0] &&
+            in.ENGINE == engine && in.KP == KP && (want_nt == 0 || want_nt == in.nthreads) &&
+            (want_pre < 0 || want_pre == in.PRE)) {
             MfmaPlan* p = new MfmaPlan();
-            p->HT = HT; p->L = L; p->ZR = ZR; p->CR = CR; p->ACT = in.ACT; p->KP = in.KP;
-            p->with_bwd = true;
-            p->lay = MfmaLayout(HT, L, ZR, CR, true);
+            p->HT = HT; p->L = L; p->ZR = ZR; p->CR = CR; p->ACT = in.ACT; p->ENGINE = engine; p->KP = KP;
+            p->with_bwd = engine == ENG_VJP;
+            p->lay = MfmaLayout(HT, L, ZR, CR, p->with_bwd);
             p->launch = in.fn;
             p->cfg = c;
             p->nthreads = in.nthreads;
             p->num_cus = 0;
-            snprintf(p->name, sizeof(p->name), "mfma_vjp<HT=%d,L=%d,ZR=%d,CR=%d,act=%d,K=%d>", HT, L, ZR, CR, in.ACT, in.KP);
+            p->prio_mode = env_int("CNF_MFMA_PRIO", 0);
+            p->use_queue = env_int("CNF_MFMA_QUEUE", 0);
+            p->queue_dev = nullptr;
+            snprintf(p->name, sizeof(p->name), "mfma_%s<HT=%d,L=%d,ZR=%d,CR=%d,act=%d,K=%d,pre=%d,nt=%d>",
+                     engine == ENG_VJP ? "vjp" : "tan", HT, L, ZR, CR, in.ACT, KP, in.PRE, in.nthreads);
             return p;
         }
     }
     return nullptr;
 }
 
-void mfma_plan_destroy(MfmaPlan* p) { delete p; }
+void mfma_plan_destroy(MfmaPlan* p) {
+    if (p && p->queue_dev) (void)hipFree(p->queue_dev);
+    delete p;
+}
 size_t mfma_packed_bytes(const MfmaPlan* p) { return (size_t)p->lay.total * sizeof(float); }
 const char* mfma_plan_name(const MfmaPlan* p) { return p->name; }
 
@@ -502,6 +621,18 @@ hipError_t mfma_solve(const MfmaPlan* p, const float* packed_dev, const SolveArg
     a.nvars = s.nvars; a.D = p->cfg.nvars + p->cfg.naug; a.C = p->cfg.ncond;
     a.reg_z = p->cfg.reg_z; a.reg_j = p->cfg.reg_j; a.reg_aug = s.reg_aug; a.autonomous = p->cfg.autonomous;
     a.T = make_tableau(s.alg);
+    a.exact = p->cfg.mode == CNF_MODE_EXACT;
+    a.prio_mode = p->prio_mode;
+    a.queue = nullptr;
+    if (mp->use_queue) {
+        if (!mp->queue_dev) {
+            hipError_t e = hipMalloc((void**)&mp->queue_dev, sizeof(int));
+            if (e != hipSuccess) return e;
+        }
+        hipError_t e = hipMemsetAsync(mp->queue_dev, 0, sizeof(int), st);
+        if (e != hipSuccess) return e;
+        a.queue = mp->queue_dev;
+    }
     const long long ntiles = (s.B + 15) / 16;
     const int wpb = p->nthreads / 64;
     long long want = (ntiles + wpb - 1) / wpb;
