@@ -79,6 +79,8 @@ def parse():
     ap.add_argument("--path", type=int, default=0, help="0 auto, 1 SIMT, 2 MFMA")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--backend", default="nccl", help="process-group backend (nccl = RCCL; gloo for "
+                    "the single-GPU launch-contract test, where all ranks share device 0)")
     return ap.parse_args()
 
 
@@ -116,11 +118,16 @@ def main():
         print(f"bench.py --gpus {a.gpus} must be launched with torch.distributed.run", file=sys.stderr)
         sys.exit(2)
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    if a.backend != "nccl":
+        local = local % torch.cuda.device_count()   # contract test: ranks may share a device
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(a.backend, rank=rank, world_size=world)
 
     pkg = entry.load_package()
     o64, oc = entry.load_oracle()
