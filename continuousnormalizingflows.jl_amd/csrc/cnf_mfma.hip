@@ -21,42 +21,9 @@
 #include <cstring>
 #include <vector>
 
-#include "cnf_internal.h"
-#include "cnf_mfma_layout.h"
+#include "cnf_mfma_dev.h"
 
 namespace cnf {
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-struct KArgs {
-    const float* packed;
-    const float* x;     // nvars x B, or null
-    const float* u0;    // S x B, or null
-    const float* eps;   // (K D) x B
-    const float* ys;    // C x B
-    float* u_out;       // S x B or null
-    float* logp;        // B or null
-    float* regs;        // 3B or null
-    long long B;
-    int nsteps;         // 0: single dynamics call at t0, du -> u_out
-    float t0, dt;
-    int nvars, D, C, reg_z, reg_j, reg_aug, autonomous;
-    int exact;          // tangent engine only: seeds are the D unit vectors, ldot = -tr J
-    int prio_mode;      // 0 none, 1 waves 0..3 high, 2 waves 4.. high (SIMD partners = w, w+4)
-    int* queue;         // dynamic tile queue (zeroed before the launch) or null = static stride
-    Tableau T;
-};
-
-__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
-}
-
-// sum over the 4 lane groups (lanes l, l^16, l^32, l^48) that hold one sample
-__device__ __forceinline__ float group_sum(float v) {
-    v += __shfl_xor(v, 16, 64);
-    v += __shfl_xor(v, 32, 64);
-    return v;
-}
 
 // Out[MT tiles] += A(image at smem+img)[MT x KS k-steps] * In   where In register s is k-step s.
 // `in` is indexed [s]; KS live k-steps (KG = ceil(KS/4) groups in the image).
@@ -92,13 +59,7 @@ struct TileIn {  // accumulator tiles as k-step source: k-step s = tile s/4, reg
     __device__ __forceinline__ float operator()(int s) const { return v[s >> 2][s & 3]; }
 };
 
-template <int MT>
-__device__ __forceinline__ void load_cvec(const float* __restrict__ vec, int g, f32x4 (&out)[MT]) {
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) out[mt] = *reinterpret_cast<const f32x4*>(vec + (mt * 4 + g) * 4);
-}
 
-enum { ENG_VJP = 0, ENG_TAN = 1 };
 
 // One dynamics evaluation for a 16-sample tile.
 //   forward pass (shared), then
@@ -443,6 +404,7 @@ struct MfmaPlan {
     cnf_config cfg;
     int nthreads;
     int num_cus;
+    int kind;           // 0: per-wave LDS-resident kernel, 1: cooperative wide-layer kernel
     int prio_mode;      // see KArgs
     int use_queue;
     int* queue_dev;     // one int per plan, zeroed on the stream before every launch
@@ -514,6 +476,23 @@ MfmaPlan* mfma_plan_create(const cnf_config& c) {
     const int KP = c.mode == CNF_MODE_EXACT ? 1 : c.nprobes;
     const int want_nt = env_int("CNF_MFMA_NT", 0);
     const int want_pre = env_int("CNF_MFMA_PRE", -1);
+    const bool force_coop = env_int("CNF_MFMA_COOP", 0) != 0;
+    auto make_coop = [&]() -> MfmaPlan* {
+        if (!coop_supported(HT, L, ZR, CR, c.acts[0], engine, KP)) return nullptr;
+        MfmaPlan* p = new MfmaPlan();
+        p->HT = HT; p->L = L; p->ZR = ZR; p->CR = CR; p->ACT = c.acts[0]; p->ENGINE = engine; p->KP = KP;
+        p->with_bwd = true;
+        p->lay = MfmaLayout(HT, L, ZR, CR, true);
+        p->launch = nullptr;
+        p->cfg = c;
+        p->nthreads = 256;
+        p->num_cus = 0;
+        p->prio_mode = 0; p->use_queue = 0; p->queue_dev = nullptr;
+        p->kind = 1;
+        snprintf(p->name, sizeof(p->name), "coop_vjp<HT=%d,L=%d,ZR=%d,act=%d>", HT, L, ZR, c.acts[0]);
+        return p;
+    };
+    if (force_coop) return make_coop();
     for (const Inst& in : kInsts) {
         if (in.PRE == 2 && c.reg_j) continue;   // the dot-product shortcut needs no |eps^T J|
         if (in.HT == HT && in.L == L && in.ZR == ZR && in.CR == CR && in.ACT == c.acts[0] &&
@@ -530,12 +509,13 @@ MfmaPlan* mfma_plan_create(const cnf_config& c) {
             p->prio_mode = env_int("CNF_MFMA_PRIO", 0);
             p->use_queue = env_int("CNF_MFMA_QUEUE", 0);
             p->queue_dev = nullptr;
+            p->kind = 0;
             snprintf(p->name, sizeof(p->name), "mfma_%s<HT=%d,L=%d,ZR=%d,CR=%d,act=%d,K=%d,pre=%d,nt=%d>",
                      engine == ENG_VJP ? "vjp" : "tan", HT, L, ZR, CR, in.ACT, KP, in.PRE, in.nthreads);
             return p;
         }
     }
-    return nullptr;
+    return make_coop();
 }
 
 void mfma_plan_destroy(MfmaPlan* p) {
@@ -633,6 +613,7 @@ hipError_t mfma_solve(const MfmaPlan* p, const float* packed_dev, const SolveArg
         if (e != hipSuccess) return e;
         a.queue = mp->queue_dev;
     }
+    if (p->kind == 1) return coop_launch(p->HT, p->L, p->ZR, p->ACT, a, mp->num_cus, st);
     const long long ntiles = (s.B + 15) / 16;
     const int wpb = p->nthreads / 64;
     long long want = (ntiles + wpb - 1) / wpb;

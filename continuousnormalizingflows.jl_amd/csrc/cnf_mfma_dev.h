@@ -1,0 +1,54 @@
+// cnf_mfma_dev.h — device-side helpers shared by the MFMA kernel files.
+#pragma once
+#include "cnf_internal.h"
+#include "cnf_mfma_layout.h"
+
+namespace cnf {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct KArgs {
+    const float* packed;
+    const float* x;     // nvars x B, or null
+    const float* u0;    // S x B, or null
+    const float* eps;   // (K D) x B
+    const float* ys;    // C x B
+    float* u_out;       // S x B or null
+    float* logp;        // B or null
+    float* regs;        // 3B or null
+    long long B;
+    int nsteps;         // 0: single dynamics call at t0, du -> u_out
+    float t0, dt;
+    int nvars, D, C, reg_z, reg_j, reg_aug, autonomous;
+    int exact;          // tangent engine only: seeds are the D unit vectors, ldot = -tr J
+    int prio_mode;      // 0 none, 1 waves 0..3 high, 2 waves 4.. high (SIMD partners = w, w+4)
+    int* queue;         // dynamic tile queue (zeroed before the launch) or null = static stride
+    Tableau T;
+};
+
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// sum over the 4 lane groups (lanes l, l^16, l^32, l^48) that hold one sample
+__device__ __forceinline__ float group_sum(float v) {
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
+
+
+enum { ENG_VJP = 0, ENG_TAN = 1 };
+
+// C vector (bias, time column): the f32x4 of lane group g in tile mt
+template <int MT>
+__device__ __forceinline__ void load_cvec(const float* __restrict__ vec, int g, f32x4 (&out)[MT]) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) out[mt] = *reinterpret_cast<const f32x4*>(vec + (mt * 4 + g) * 4);
+}
+
+// cooperative wide-layer kernel (cnf_coop.hip)
+bool coop_supported(int HT, int L, int ZR, int CR, int ACT, int engine, int KP);
+hipError_t coop_launch(int HT, int L, int ZR, int ACT, const KArgs& a, int num_cus, hipStream_t st);
+
+}  // namespace cnf

@@ -96,6 +96,8 @@ CASES = [
     (dict(nvars=1, naug=2, hidden=[16, 16], act=2, reg_z=True, reg_j=True, reg_aug=True), 257, 1, 20),
     (dict(nvars=3, hidden=[16, 16], autonomous=True, mode=1, reg_z=True, reg_j=True), 77, 0, 10),
     (dict(nvars=32, hidden=[256, 256, 256]), 48, 0, 10),
+    (dict(nvars=32, hidden=[256, 256, 256], reg_z=True, reg_j=True), 200, 1, 40),   # cfg4 shape, cooperative kernel
+    (dict(nvars=8, hidden=[128, 128, 128]), 100, 1, 40),                            # 3x128 Hutchinson VJP (cooperative)
 ]
 
 
@@ -112,6 +114,25 @@ def test_inference_matches_c_restatement(kw, B, alg, nsteps, pkg, oracles):
         for a, b in zip(regs, ref_regs):
             assert np.max(np.abs(a.cpu().numpy() - b)) < TOL_SOLVE
         assert np.max(np.abs(u1.cpu().numpy() - ref_u)) < TOL_SOLVE
+
+
+def test_cooperative_wide_layer_kernel_matches_per_wave_kernel(pkg, oracles, monkeypatch):
+    """The workgroup-cooperative kernel (csrc/cnf_coop.hip, used when the operand images do not
+    fit LDS) forced onto the headline shape must reproduce the per-wave kernel and the oracle."""
+    o64, oc = oracles
+    spec = o64.make_spec(nvars=8, hidden=[64, 64, 64], reg_z=True, reg_j=True)
+    B = 1000                                        # ragged: 15 full super-tiles + 40 columns
+    p, xs, eps, _ = o64.synth_inputs(spec, B, 77, bias_scale=0.1)
+    base = run_inference(pkg, make_icnf(pkg, spec, 1, 40, path=2), spec, p, xs, eps, None, return_state=True)
+    monkeypatch.setenv("CNF_MFMA_COOP", "1")
+    coop = run_inference(pkg, make_icnf(pkg, spec, 1, 40, path=2), spec, p, xs, eps, None, return_state=True)
+    monkeypatch.delenv("CNF_MFMA_COOP")
+    ref = oc.inference_fixed(spec, p, xs, 0.0, 1.0, 40, 1, eps, nthreads=4)
+    assert np.max(np.abs(coop[0].cpu().numpy() - ref[0])) < TOL_SOLVE
+    assert np.max(np.abs(coop[0].cpu().numpy() - base[0].cpu().numpy())) < 2e-5
+    for a, b in zip(coop[1], base[1]):
+        assert np.max(np.abs(a.cpu().numpy() - b.cpu().numpy())) < 2e-5
+    assert np.max(np.abs(coop[2].cpu().numpy() - ref[2])) < TOL_SOLVE
 
 
 def test_empty_batch_is_a_no_op(pkg, oracles):
