@@ -1,0 +1,31 @@
+// cnf_mfma_generic.hip — zero-padded instantiations of the per-wave fused solve kernel.
+//
+// The specialised table in cnf_mfma.hip matches (D, C) exactly (BASELINE shapes).  These cover
+// every other uniform-width Dense chain with H <= 128, L in {2,3}, D <= 16, C in {0} or <= 16,
+// tanh or softplus, K = 1: the state/condition k-steps are padded to 4 (zero rows in the operand
+// images, zero registers in the state), which costs at most 2-3 wasted MFMAs per product against
+// the 40x the generic SIMT path would cost.  E.g. the reference's default net for nvariables = 2
+// (D = 5, n_in = 6, hidden 24, softplus) runs on <HT=2, L=2, ZR=4, CR=0, softplus>.
+#include "cnf_mfma_kernel.h"
+
+namespace cnf {
+
+#define GEN4(HT, L, ACT, NT)                                   \
+    MFMA_INST(HT, L, 4, 0, ACT, ENG_VJP, 1, 1, NT),            \
+    MFMA_INST(HT, L, 4, 4, ACT, ENG_VJP, 1, 1, NT),            \
+    MFMA_INST(HT, L, 4, 0, ACT, ENG_TAN, 1, 0, NT),            \
+    MFMA_INST(HT, L, 4, 4, ACT, ENG_TAN, 1, 0, NT)
+#define GEN_ACT(HT, NT)                                                          \
+    GEN4(HT, 2, CNF_ACT_TANH, NT), GEN4(HT, 3, CNF_ACT_TANH, NT),                \
+    GEN4(HT, 2, CNF_ACT_SOFTPLUS, NT), GEN4(HT, 3, CNF_ACT_SOFTPLUS, NT)
+
+static const Inst kGeneric[] = {
+    GEN_ACT(1, 512), GEN_ACT(2, 512), GEN_ACT(3, 512), GEN_ACT(4, 512), GEN_ACT(6, 256), GEN_ACT(8, 256),
+};
+
+const Inst* mfma_generic_insts(int* count) {
+    *count = (int)(sizeof(kGeneric) / sizeof(kGeneric[0]));
+    return kGeneric;
+}
+
+}  // namespace cnf

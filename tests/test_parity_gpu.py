@@ -98,7 +98,23 @@ CASES = [
     (dict(nvars=32, hidden=[256, 256, 256]), 48, 0, 10),
     (dict(nvars=32, hidden=[256, 256, 256], reg_z=True, reg_j=True), 200, 1, 40),   # cfg4 shape, cooperative kernel
     (dict(nvars=8, hidden=[128, 128, 128]), 100, 1, 40),                            # 3x128 Hutchinson VJP (cooperative)
+    # generic zero-padded MFMA instances (csrc/cnf_mfma_generic.hip)
+    (dict(nvars=2, naug=3, hidden=[24, 24], act=2, reg_z=True, reg_j=True, reg_aug=True), 333, 1, 20),  # default net, nvariables=2
+    (dict(nvars=4, ncond=3, hidden=[48, 48, 48], reg_z=True, reg_j=True), 130, 1, 20),     # conditioned Hutchinson VJP
+    (dict(nvars=6, ncond=16, hidden=[64, 64], mode=1, reg_j=True), 90, 0, 20),             # conditioned JVP
+    (dict(nvars=10, hidden=[96, 96], act=2, mode=2), 70, 0, 20),                           # exact trace, D=10, softplus
+    (dict(nvars=16, hidden=[128, 128, 128], mode=2, autonomous=True), 40, 0, 10),          # exact trace, D=16, 3x128
 ]
+GENERIC_MFMA_CASES = CASES[-5:]
+
+
+@pytest.mark.parametrize("kw,B,alg,nsteps", GENERIC_MFMA_CASES)
+def test_generic_instances_resolve_to_the_mfma_path(kw, B, alg, nsteps, pkg, oracles):
+    o64, _ = oracles
+    spec = o64.make_spec(**kw)
+    assert 2 in paths_for(pkg, spec, alg, nsteps)
+    icnf = make_icnf(pkg, spec, alg, nsteps, path=0)          # AUTO must pick it too
+    assert icnf.kernel_path(mode_of(pkg, spec)) == 2
 
 
 @pytest.mark.parametrize("kw,B,alg,nsteps", CASES)
