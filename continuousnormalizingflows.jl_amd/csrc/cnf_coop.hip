@@ -19,31 +19,46 @@
 
 namespace cnf {
 
-// acc[m][q] += A(global image; M-tile mt0+m) * B(LDS image; sample tile nt0+q), over KG k-groups
+// acc[m][q] += A(global image; M-tile mt0+m) * B(LDS image; sample tile nt0+q), over KG k-groups.
+// Two fragment sets ping-pong (k-loop unrolled by 2): the loads of k-group kg+1 — A from L2, B from
+// LDS — are issued before the 16 M NQ MFMAs of k-group kg, so both latencies hide behind them and
+// no register copies are needed.
+template <int M, int NQ>
+__device__ __forceinline__ void coop_frag_load(const f32x4* __restrict__ A, int mt0, int KG, int kg,
+                                               const f32x4* __restrict__ bimg, int nt0, int lane,
+                                               f32x4 (&a)[M], f32x4 (&b)[NQ]) {
+#pragma unroll
+    for (int m = 0; m < M; ++m) a[m] = A[((mt0 + m) * KG + kg) * 64];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) b[q] = bimg[(kg * 4 + nt0 + q) * 64 + lane];
+}
+
+template <int M, int NQ>
+__device__ __forceinline__ void coop_frag_mfma(const f32x4 (&a)[M], const f32x4 (&b)[NQ], f32x4 (&acc)[M][NQ]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int m = 0; m < M; ++m)
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) acc[m][q] = mfma4(a[m][j], b[q][j], acc[m][q]);
+}
+
 template <int M, int NQ>
 __device__ __forceinline__ void coop_gemm(const float* __restrict__ gimg, int mt0, int KG,
                                           const f32x4* __restrict__ bimg, int nt0, int lane,
                                           f32x4 (&acc)[M][NQ]) {
     const f32x4* __restrict__ A = reinterpret_cast<const f32x4*>(gimg) + lane;
-    f32x4 a_cur[M], a_nxt[M];
-#pragma unroll
-    for (int m = 0; m < M; ++m) a_cur[m] = A[((mt0 + m) * KG) * 64];
+    f32x4 a0[M], a1[M], b0[NQ], b1[NQ];
+    coop_frag_load<M, NQ>(A, mt0, KG, 0, bimg, nt0, lane, a0, b0);
 #pragma clang loop unroll(disable)
-    for (int kg = 0; kg < KG; ++kg) {
-        const int kn = kg + 1 < KG ? kg + 1 : kg;   // prefetch the next k-group's fragments from L2
-#pragma unroll
-        for (int m = 0; m < M; ++m) a_nxt[m] = A[((mt0 + m) * KG + kn) * 64];
-        f32x4 b[NQ];
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) b[q] = bimg[(kg * 4 + nt0 + q) * 64 + lane];
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int m = 0; m < M; ++m)
-#pragma unroll
-                for (int q = 0; q < NQ; ++q) acc[m][q] = mfma4(a_cur[m][j], b[q][j], acc[m][q]);
-#pragma unroll
-        for (int m = 0; m < M; ++m) a_cur[m] = a_nxt[m];
+    for (int kg = 0; kg < KG; kg += 2) {
+        const bool has1 = kg + 1 < KG, has2 = kg + 2 < KG;   // wave-uniform
+        if (has1) coop_frag_load<M, NQ>(A, mt0, KG, kg + 1, bimg, nt0, lane, a1, b1);
+        coop_frag_mfma<M, NQ>(a0, b0, acc);
+        if (has1) {
+            if (has2) coop_frag_load<M, NQ>(A, mt0, KG, kg + 2, bimg, nt0, lane, a0, b0);
+            coop_frag_mfma<M, NQ>(a1, b1, acc);
+        }
     }
 }
 
@@ -174,7 +189,8 @@ __device__ __forceinline__ void coop_eval(const float* __restrict__ P, f32x4* __
     }
 }
 
-template <int HT, int L, int ZR, int ACT>
+// NS: Runge-Kutta stage derivatives kept (4 for RK4, 6 for Tsit5)
+template <int HT, int L, int ZR, int ACT, int NS>
 __global__ void __launch_bounds__(256)
 coop_vjp_solve_kernel(KArgs a) {
     constexpr int DT = (ZR + 3) / 4, XB = HT * 4 * 64;
@@ -211,16 +227,16 @@ coop_vjp_solve_kernel(KArgs a) {
             ebuf[(kg * 4 + wave) * 64 + lane] = v;
         }
 
-        float kz[6][ZR], kl[6], ke[6], kn[6];
+        float kz[NS][ZR], kl[NS], ke[NS], kn[NS];
 #pragma unroll
-        for (int j = 0; j < 6; ++j) {
+        for (int j = 0; j < NS; ++j) {
             kl[j] = ke[j] = kn[j] = 0.f;
 #pragma unroll
             for (int s = 0; s < ZR; ++s) kz[j][s] = 0.f;
         }
         const float dt = a.dt;
         const bool single = a.nsteps == 0;
-        const int ns = single ? 1 : a.T.ns;
+        const int ns = single ? 1 : (a.T.ns < NS ? a.T.ns : NS);
         const int nsteps = single ? 1 : a.nsteps;
 #pragma clang loop unroll(disable)
         for (int step = 0; step < nsteps; ++step) {
@@ -232,14 +248,14 @@ coop_vjp_solve_kernel(KArgs a) {
                 for (int s = 0; s < ZR; ++s) {
                     float acc = 0.f;
 #pragma unroll
-                    for (int j = 0; j < 5; ++j) acc = fmaf(a.T.a[sg][j], kz[j][s], acc);
+                    for (int j = 0; j < NS - 1; ++j) acc = fmaf(a.T.a[sg][j], kz[j][s], acc);
                     zs[s] = fmaf(dt, acc, z[s]);
                 }
                 float zd[ZR], ld, ed, nd;
                 coop_eval<HT, L, ZR, ACT>(a.packed, xbuf, zbuf, ebuf, lane, wave, tn + a.T.c[sg] * dt, autonomous,
                                           reg_z, reg_j, zs, eps, zd, ld, ed, nd);
 #pragma unroll
-                for (int j = 0; j < 6; ++j) {
+                for (int j = 0; j < NS; ++j) {
                     const bool hit = (j == sg);
                     kl[j] = hit ? ld : kl[j];
                     ke[j] = hit ? ed : ke[j];
@@ -251,7 +267,7 @@ coop_vjp_solve_kernel(KArgs a) {
             if (single) break;
             float sl = 0.f, se = 0.f, sn = 0.f;
 #pragma unroll
-            for (int j = 0; j < 6; ++j) {
+            for (int j = 0; j < NS; ++j) {
                 const float bj = a.T.b[j];
                 sl = fmaf(bj, kl[j], sl); se = fmaf(bj, ke[j], se); sn = fmaf(bj, kn[j], sn);
             }
@@ -260,7 +276,7 @@ coop_vjp_solve_kernel(KArgs a) {
             for (int s = 0; s < ZR; ++s) {
                 float acc = 0.f;
 #pragma unroll
-                for (int j = 0; j < 6; ++j) acc = fmaf(a.T.b[j], kz[j][s], acc);
+                for (int j = 0; j < NS; ++j) acc = fmaf(a.T.b[j], kz[j][s], acc);
                 z[s] = fmaf(dt, acc, z[s]);
             }
         }
@@ -303,11 +319,11 @@ coop_vjp_solve_kernel(KArgs a) {
 // ---------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------
-template <int HT, int L, int ZR, int ACT>
+template <int HT, int L, int ZR, int ACT, int NS>
 static hipError_t launch_coop(const KArgs& a, int nblocks, hipStream_t st) {
     constexpr int DT = (ZR + 3) / 4;
     constexpr int lds = (2 * HT * 4 * 64 + 2 * DT * 4 * 64) * 16;
-    auto kern = coop_vjp_solve_kernel<HT, L, ZR, ACT>;
+    auto kern = coop_vjp_solve_kernel<HT, L, ZR, ACT, NS>;
     static unsigned long long done_mask = 0;
     int dev = 0;
     hipError_t e0 = hipGetDevice(&dev);
@@ -323,12 +339,15 @@ static hipError_t launch_coop(const KArgs& a, int nblocks, hipStream_t st) {
 
 struct CoopInst {
     int HT, L, ZR, ACT;
-    hipError_t (*fn)(const KArgs&, int, hipStream_t);
+    hipError_t (*fn4)(const KArgs&, int, hipStream_t);   // RK4 (4 stage derivatives kept)
+    hipError_t (*fn6)(const KArgs&, int, hipStream_t);   // Tsit5
 };
+#define COOP_INST(HT, L, ZR, ACT) \
+    CoopInst { HT, L, ZR, ACT, &launch_coop<HT, L, ZR, ACT, 4>, &launch_coop<HT, L, ZR, ACT, 6> }
 static const CoopInst kCoop[] = {
-    {16, 3, 8, CNF_ACT_TANH, &launch_coop<16, 3, 8, CNF_ACT_TANH>},   // cfg4: D=32, 3x256
-    {8, 3, 2, CNF_ACT_TANH, &launch_coop<8, 3, 2, CNF_ACT_TANH>},     // D=8, 3x128 Hutchinson VJP
-    {4, 3, 2, CNF_ACT_TANH, &launch_coop<4, 3, 2, CNF_ACT_TANH>},     // D=8, 3x64 (cross-check of the per-wave kernel)
+    COOP_INST(16, 3, 8, CNF_ACT_TANH),   // cfg4: D=32, 3x256
+    COOP_INST(8, 3, 2, CNF_ACT_TANH),    // D=8, 3x128 Hutchinson VJP
+    COOP_INST(4, 3, 2, CNF_ACT_TANH),    // D=8, 3x64 (cross-check of the per-wave kernel)
 };
 
 bool coop_supported(int HT, int L, int ZR, int CR, int ACT, int engine, int KP) {
@@ -343,7 +362,7 @@ hipError_t coop_launch(int HT, int L, int ZR, int ACT, const KArgs& a, int num_c
         if (c.HT == HT && c.L == L && c.ZR == ZR && c.ACT == ACT) {
             const long long nst = (a.B + 63) / 64;
             const int nblocks = (int)(nst < num_cus ? nst : num_cus);
-            return c.fn(a, nblocks, st);
+            return (a.T.ns <= 4 ? c.fn4 : c.fn6)(a, nblocks, st);
         }
     return hipErrorNotSupported;
 }
