@@ -199,6 +199,73 @@ def test_full_size_headline_properties(pkg, oracles):
     assert abs(loss + lp.astype(np.float64).mean()) < 1e-4
 
 
+def test_full_size_cfg3_k_probe_result_is_mean_of_single_probe_solves(pkg, oracles):
+    """cfg3 at full size (RNODE, K=4, B=65536): l̇ and ṅ are linear in the per-probe terms while z's
+    trajectory is probe-independent, so the K=4 solve must equal the mean of the
+    four single-probe solves — a size-independent check of the K-probe extension."""
+    o64, _ = oracles
+    B, D, K = 65536, 8, 4
+    sk = o64.make_spec(nvars=D, hidden=[64, 64, 64], nprobes=K, reg_z=True, reg_j=True)
+    s1 = o64.make_spec(nvars=D, hidden=[64, 64, 64], nprobes=1, reg_z=True, reg_j=True)
+    p, xs, eps, _ = o64.synth_inputs(sk, B, 20240615)
+    lk, (Ek, nk, _) = run_inference(pkg, make_icnf(pkg, sk, 1, 40), sk, p, xs, eps, None)
+    i1 = make_icnf(pkg, s1, 1, 40)
+    runs = [run_inference(pkg, i1, s1, p, xs, eps[k * D:(k + 1) * D], None) for k in range(K)]
+    lm = torch.stack([r[0] for r in runs]).mean(0)
+    nm = torch.stack([r[1][1] for r in runs]).mean(0)
+    assert float((lk - lm).abs().max()) < 5e-5
+    assert float((nk - nm).abs().max()) < 5e-5
+    assert float((Ek - runs[0][1][0]).abs().max()) < 5e-5
+    assert bool(torch.isfinite(lk).all())
+
+
+def test_full_size_cfg4_shards_concatenate_bit_identically(pkg, oracles):
+    """cfg4 per-GPU size (D=32, 3x256, RK4x40, B=32768, cooperative kernel): two half-batches —
+    what two ranks would evaluate — reproduce the unsharded bits; a column subset agrees with the
+    C restatement."""
+    o64, oc = oracles
+    spec = o64.make_spec(nvars=32, hidden=[256, 256, 256])
+    B = 32768
+    p, xs, eps, _ = o64.synth_inputs(spec, B, 20240616)
+    icnf = make_icnf(pkg, spec, 0, 40)
+    assert icnf.kernel_path(pkg.TrainMode(False)) == 2
+    full = run_inference(pkg, icnf, spec, p, xs, eps, None)[0]
+    h = B // 2
+    a = run_inference(pkg, icnf, spec, p, xs[:, :h], eps[:, :h], None)[0]
+    b = run_inference(pkg, icnf, spec, p, xs[:, h:], eps[:, h:], None)[0]
+    assert torch.equal(torch.cat([a, b]), full)
+    idx = np.random.default_rng(1).choice(B, 96, replace=False)
+    ref = oc.inference_fixed(spec, p, xs[:, idx], 0.0, 1.0, 40, 0, eps[:, idx], nthreads=4)[0]
+    assert np.max(np.abs(full.cpu().numpy()[idx] - ref)) < TOL_SOLVE
+
+
+def test_full_size_cfg5_exact_trace_equals_unit_probe_hutchinson(pkg, oracles):
+    """cfg5 at full size (cond D=8+8, 3x128, exact trace, B=16384): the exact trace is the sum of
+    the D unit-vector probes, i.e. D times the K=D Hutchinson mean with probes e_1..e_D — checked
+    through two different code paths (tangent engine, exact seeds vs generic SIMT K-probe VJP) on a
+    slice, plus the C restatement on a column subset."""
+    o64, oc = oracles
+    D, C, B = 8, 8, 16384
+    se = o64.make_spec(nvars=D, ncond=C, hidden=[128, 128, 128], mode=2)
+    p, xs, _, ys = o64.synth_inputs(se, B, 20240617)
+    icnf = make_icnf(pkg, se, 0, 40)
+    assert icnf.kernel_path(pkg.TestMode()) == 2
+    full = run_inference(pkg, icnf, se, p, xs, None, ys)[0].cpu().numpy()
+    assert np.all(np.isfinite(full))
+    idx = np.random.default_rng(2).choice(B, 128, replace=False)
+    ref = oc.inference_fixed(se, p, xs[:, idx], 0.0, 1.0, 40, 0, None, ys[:, idx], nthreads=4)[0]
+    assert np.max(np.abs(full[idx] - ref)) < TOL_SOLVE
+    # K = D unit probes through the Hutchinson VJP path: dlogp_exact = D * dlogp_K
+    sk = o64.make_spec(nvars=D, ncond=C, hidden=[128, 128, 128], nprobes=D)
+    n = 256
+    onehot = np.tile(np.eye(D, dtype=np.float32).reshape(D * D, 1), (1, n))
+    ik = make_icnf(pkg, sk, 0, 40)
+    _, _, uk = run_inference(pkg, ik, sk, p, xs[:, :n], onehot, ys[:, :n], return_state=True)
+    _, _, ue = run_inference(pkg, icnf, se, p, xs[:, :n], None, ys[:, :n], return_state=True)
+    assert float((ue[:D] - uk[:D]).abs().max()) < 2e-5
+    assert float((ue[D] - D * uk[D]).abs().max()) < 1e-4
+
+
 def test_generate_inverts_inference(pkg, oracles):
     """generate integrates the reversed tspan (src/core/base_icnf.jl:372): pushing x forward
     to z and pulling z back must return x (integrator error only)."""
