@@ -79,6 +79,8 @@ def parse():
     ap.add_argument("--path", type=int, default=0, help="0 auto, 1 SIMT, 2 MFMA")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--arith", default="f32", choices=["f32", "bf16x6"],
+                    help="hidden-product arithmetic: exact f32 MFMA (default) or split-bf16 (opt-in)")
     ap.add_argument("--backend", default="nccl", help="process-group backend (nccl = RCCL; gloo for "
                     "the single-GPU launch-contract test, where all ranks share device 0)")
     return ap.parse_args()
@@ -147,7 +149,8 @@ def main():
               for i in range(len(spec.acts))]
     reg = bool(spec.reg_z or spec.reg_j)
     icnf = pkg.ICNF(nvariables=spec.nvars, naugments=spec.naug, nconditions=spec.ncond,
-                    nn=pkg.Chain(*layers), compute_mode=pkg.HIPVecJacMatrixMode(kernel_path=a.path),
+                    nn=pkg.Chain(*layers),
+                    compute_mode=pkg.HIPVecJacMatrixMode(kernel_path=a.path, arith=1 if a.arith == "bf16x6" else 0),
                     steer_rate=0.0, lambda1=0.01 if spec.reg_z else 0.0,
                     lambda2=0.01 if spec.reg_j else 0.0, lambda3=0.0, nprobes=spec.nprobes,
                     device=dev, sol_kwargs=dict(alg=pkg.Tsit5() if alg == 1 else pkg.RK4(),
@@ -200,7 +203,9 @@ def main():
             "metric": "log-density evals (samples*steps)/sec",
             "value": value, "unit": "samples*steps/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if a.arith == "f32" else "f32 via 3-way bf16 split (6 bf16 MFMAs per hidden product)",
+            "data": "synthetic",
             "config": {"workload": desc, "name": a.config, "columns_per_gpu": B,
                        "global_columns": world * B, "nsteps": NSTEPS,
                        "integrator": "RK4" if alg == 0 else "Tsit5",

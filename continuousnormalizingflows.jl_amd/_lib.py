@@ -20,6 +20,7 @@ ACT_IDENTITY, ACT_TANH, ACT_SOFTPLUS = 0, 1, 2
 MODE_HUTCH_VJP, MODE_HUTCH_JVP, MODE_EXACT = 0, 1, 2
 ALG_RK4, ALG_TSIT5 = 0, 1
 PATH_AUTO, PATH_SIMT, PATH_MFMA = 0, 1, 2
+ARITH_F32, ARITH_BF16X6 = 0, 1
 
 EXPORTS = ("cnf_version", "cnf_last_error", "cnf_create", "cnf_destroy", "cnf_set_params",
            "cnf_kernel_path", "cnf_aug_f", "cnf_integrate_fixed", "cnf_inference_fixed",
@@ -32,7 +33,7 @@ class CnfConfig(C.Structure):
                 ("widths", C.c_int32 * (MAX_LAYERS + 1)), ("acts", C.c_int32 * MAX_LAYERS),
                 ("mode", C.c_int32), ("nprobes", C.c_int32),
                 ("reg_z", C.c_int32), ("reg_j", C.c_int32), ("reg_aug", C.c_int32),
-                ("device_id", C.c_int32), ("kernel_path", C.c_int32)]
+                ("device_id", C.c_int32), ("kernel_path", C.c_int32), ("arith", C.c_int32)]
 
 
 class CnfError(RuntimeError):

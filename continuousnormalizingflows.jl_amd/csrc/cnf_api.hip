@@ -111,6 +111,10 @@ int cnf_create(cnf_handle** out, const cnf_config* cfg) {
     if (c.nprobes < 1) return fail(CNF_ERR_INVALID, "cnf_create: nprobes >= 1 required");
     if (c.kernel_path < CNF_PATH_AUTO || c.kernel_path > CNF_PATH_MFMA)
         return fail(CNF_ERR_INVALID, "cnf_create: unknown kernel_path");
+    if (c.arith < CNF_ARITH_F32 || c.arith > CNF_ARITH_BF16X6)
+        return fail(CNF_ERR_INVALID, "cnf_create: unknown arith");
+    if (c.arith != CNF_ARITH_F32 && c.kernel_path == CNF_PATH_SIMT)
+        return fail(CNF_ERR_INVALID, "cnf_create: arith = BF16X6 is an MFMA-path option");
 
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
@@ -137,7 +141,7 @@ int cnf_create(cnf_handle** out, const cnf_config* cfg) {
         h->plan = mfma_plan_create(c);
         if (h->plan) {
             h->path = CNF_PATH_MFMA;
-        } else if (c.kernel_path == CNF_PATH_MFMA) {
+        } else if (c.kernel_path == CNF_PATH_MFMA || c.arith != CNF_ARITH_F32) {
             delete h;
             return fail(CNF_ERR_UNSUPPORTED, "cnf_create: configuration not covered by the MFMA kernels");
         }

@@ -37,6 +37,7 @@ struct MfmaPlan {
     int nthreads;
     int num_cus;
     int kind;           // 0: per-wave LDS-resident kernel, 1: cooperative wide-layer kernel
+    int arith;          // CNF_ARITH_* of the hidden products
     int prio_mode;      // see KArgs
     int use_queue;
     int* queue_dev;     // one int per plan, zeroed on the stream before every launch
@@ -58,6 +59,11 @@ static const Inst kInsts[] = {
     MFMA_INST(2, 2, 1, 0, CNF_ACT_TANH, ENG_VJP, 1, 2, 512),      // cfg1: D=2, 2x32
     MFMA_INST(2, 2, 1, 0, CNF_ACT_TANH, ENG_VJP, 1, 1, 512),
     MFMA_INST(1, 2, 1, 0, CNF_ACT_SOFTPLUS, ENG_VJP, 1, 1, 512),  // reference default net, nvariables=1
+    // --- split-bf16 hidden products (cnf_config.arith = CNF_ARITH_BF16X6), headline shape ---
+    MFMA_INST_BF16X6(4, 3, 2, 0, CNF_ACT_TANH, ENG_VJP, 1, 2, 512),
+    MFMA_INST_BF16X6(4, 3, 2, 0, CNF_ACT_TANH, ENG_VJP, 1, 1, 512),
+    MFMA_INST_BF16X6(4, 3, 2, 0, CNF_ACT_TANH, ENG_VJP, 4, 0, 512),
+    MFMA_INST_BF16X6(4, 3, 2, 0, CNF_ACT_TANH, ENG_TAN, 1, 0, 512),
     // --- tangent engine: Hutchinson JVP (LuxJacVecMatrixMode) and exact trace (TestMode) ---
     MFMA_INST(8, 3, 2, 2, CNF_ACT_TANH, ENG_TAN, 1, 0, 256),      // cfg5: D=8, C=8, 3x128 (200 VGPR, 1 wave/SIMD:
     MFMA_INST(8, 3, 2, 2, CNF_ACT_TANH, ENG_TAN, 1, 0, 512),      //  13.1 ms; the 512-thread build spills: 23.7 ms)
@@ -98,16 +104,18 @@ MfmaPlan* mfma_plan_create(const cnf_config& c) {
         p->num_cus = 0;
         p->prio_mode = 0; p->use_queue = 0; p->queue_dev = nullptr;
         p->kind = 1;
+        p->arith = 0;
         snprintf(p->name, sizeof(p->name), "coop_vjp<HT=%d,L=%d,ZR=%d,act=%d>", HT, L, ZR, c.acts[0]);
         return p;
     };
-    if (force_coop) return make_coop();
+    if (force_coop) return c.arith == CNF_ARITH_F32 ? make_coop() : nullptr;
     constexpr size_t kMaxLds = 160 * 1024;
     auto make = [&](const Inst& in) -> MfmaPlan* {
         MfmaPlan* p = new MfmaPlan();
         p->HT = HT; p->L = L; p->ZR = in.ZR; p->CR = in.CR; p->ACT = in.ACT; p->ENGINE = engine; p->KP = KP;
         p->with_bwd = engine == ENG_VJP;
-        p->lay = MfmaLayout(HT, L, in.ZR, in.CR, p->with_bwd);
+        p->arith = in.arith;
+        p->lay = MfmaLayout(HT, L, in.ZR, in.CR, p->with_bwd, in.arith);
         p->launch = in.fn;
         p->cfg = c;
         p->nthreads = in.nthreads;
@@ -116,18 +124,20 @@ MfmaPlan* mfma_plan_create(const cnf_config& c) {
         p->use_queue = env_int("CNF_MFMA_QUEUE", 0);
         p->queue_dev = nullptr;
         p->kind = 0;
-        snprintf(p->name, sizeof(p->name), "mfma_%s<HT=%d,L=%d,ZR=%d,CR=%d,act=%d,K=%d,pre=%d,nt=%d>",
-                 engine == ENG_VJP ? "vjp" : "tan", HT, L, in.ZR, in.CR, in.ACT, KP, in.PRE, in.nthreads);
+        snprintf(p->name, sizeof(p->name), "mfma_%s<HT=%d,L=%d,ZR=%d,CR=%d,act=%d,K=%d,pre=%d,nt=%d,%s>",
+                 engine == ENG_VJP ? "vjp" : "tan", HT, L, in.ZR, in.CR, in.ACT, KP, in.PRE, in.nthreads,
+                 in.arith ? "bf16x6" : "f32");
         return p;
     };
     // 1. specialised instances: exact state / condition k-steps
     for (const Inst& in : kInsts) {
         if (in.PRE == 2 && c.reg_j) continue;   // the dot-product shortcut needs no |eps^T J|
         if (in.HT == HT && in.L == L && in.ZR == ZR && in.CR == CR && in.ACT == c.acts[0] &&
-            in.ENGINE == engine && in.KP == KP && (want_nt == 0 || want_nt == in.nthreads) &&
-            (want_pre < 0 || want_pre == in.PRE))
+            in.ENGINE == engine && in.KP == KP && in.arith == c.arith &&
+            (want_nt == 0 || want_nt == in.nthreads) && (want_pre < 0 || want_pre == in.PRE))
             return make(in);
     }
+    if (c.arith != CNF_ARITH_F32) return nullptr;   // split-bf16: specialised instances only
     // 2. generic zero-padded instances whose images fit LDS
     if (want_nt == 0 && want_pre < 0) {
         int ng = 0;
@@ -164,6 +174,41 @@ static void pack_imgA(float* out, int MT, int KG, int M, int K, F A) {
                 }
 }
 
+// split-bf16 hidden image (see gemm_hidden_bf16x6): three bf16 parts of every weight, RNE at each level
+static inline unsigned short bf16_rne(float x) {
+    unsigned u;
+    std::memcpy(&u, &x, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);   // NaN stays NaN
+    return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+static inline float bf16_val(unsigned short b) {
+    const unsigned u = (unsigned)b << 16;
+    float f;
+    std::memcpy(&f, &u, 4);
+    return f;
+}
+template <typename F>
+static void pack_imgH16(float* out, int HT, int H, F A) {
+    unsigned short* o = reinterpret_cast<unsigned short*>(out);
+    const int NC = HT / 2;
+    for (int mt = 0; mt < HT; ++mt)
+        for (int c = 0; c < NC; ++c)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 8; ++j) {
+                    const int row = mfma_rowmap(mt, lane & 15);
+                    const int k = 16 * (2 * c + (j >> 2)) + 4 * (j & 3) + (lane >> 4);
+                    const float w = (row < H && k < H) ? A(row, k) : 0.f;
+                    unsigned short part[3];
+                    part[0] = bf16_rne(w);
+                    const float r1 = w - bf16_val(part[0]);
+                    part[1] = bf16_rne(r1);
+                    const float r2 = r1 - bf16_val(part[1]);
+                    part[2] = bf16_rne(r2);
+                    for (int sp = 0; sp < 3; ++sp)
+                        o[((((size_t)sp * HT + mt) * NC + c) * 64 + lane) * 8 + j] = part[sp];
+                }
+}
+
 // C vector: out[(mt*4 + g)*4 + r] = v(16 mt + 4 r + g)
 template <typename F>
 static void pack_vecC(float* out, int MT, int M, F v) {
@@ -188,15 +233,17 @@ void mfma_pack(const MfmaPlan* p, const float* lux, const size_t* w_off, const s
     auto Bv = [&](int l, int o) { return lux[b_off[l] + o]; };
     pack_imgA(packed + Y.f1z, Y.HT, Y.KGZ, H, D, [&](int r, int k) { return W(0, r, k); });
     if (Y.CR > 0) pack_imgA(packed + Y.f1y, Y.HT, Y.KGC, H, C, [&](int r, int k) { return W(0, r, ycol + k); });
-    for (int l = 1; l < L; ++l)
-        pack_imgA(packed + Y.fh + (l - 1) * MfmaLayout::imgA(Y.HT, Y.HT), Y.HT, Y.HT, H, H,
-                  [&](int r, int k) { return W(l, r, k); });
+    for (int l = 1; l < L; ++l) {
+        if (Y.arith) pack_imgH16(packed + Y.fh + (l - 1) * Y.imgHid(), Y.HT, H, [&](int r, int k) { return W(l, r, k); });
+        else pack_imgA(packed + Y.fh + (l - 1) * Y.imgHid(), Y.HT, Y.HT, H, H, [&](int r, int k) { return W(l, r, k); });
+    }
     pack_imgA(packed + Y.fN, Y.DT, Y.HT, D, H, [&](int r, int k) { return W(L, r, k); });
     if (p->with_bwd) {
         pack_imgA(packed + Y.bN, Y.HT, Y.KGZ, H, D, [&](int r, int k) { return W(L, k, r); });   // W_N^T
-        for (int l = 1; l < L; ++l)
-            pack_imgA(packed + Y.bh + (l - 1) * MfmaLayout::imgA(Y.HT, Y.HT), Y.HT, Y.HT, H, H,
-                      [&](int r, int k) { return W(l, k, r); });                                    // W_l^T
+        for (int l = 1; l < L; ++l) {                                                                 // W_l^T
+            if (Y.arith) pack_imgH16(packed + Y.bh + (l - 1) * Y.imgHid(), Y.HT, H, [&](int r, int k) { return W(l, k, r); });
+            else pack_imgA(packed + Y.bh + (l - 1) * Y.imgHid(), Y.HT, Y.HT, H, H, [&](int r, int k) { return W(l, k, r); });
+        }
         pack_imgA(packed + Y.b1, Y.DT, Y.HT, D, H, [&](int r, int k) { return W(0, k, r); });     // W_1[:,0:D]^T
     }
     pack_vecC(packed + Y.v_b1, Y.HT, H, [&](int f) { return Bv(0, f); });

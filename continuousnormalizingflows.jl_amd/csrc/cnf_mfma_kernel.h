@@ -44,20 +44,101 @@ struct TileIn {  // accumulator tiles as k-step source: k-step s = tile s/4, reg
 
 
 
+// ---------------------------------------------------------------------------------------
+// split-bf16 hidden product (ARITH = 1): Out[HT tiles] += W (H x H) * In, with both operands split
+// exactly into three bf16 parts (x = hi + mid + lo, 8 + 8 + 8 significant bits) and six bf16
+// MFMAs per (tile, 32-deep k-chunk): lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi — every term
+// down to 2^-24 relative is kept, accumulation stays f32, so the result is f32-equivalent
+// (simulation + parity tests), at 16x the f32 MFMA rate per instruction.
+// v_mfma_f32_16x16x32_bf16: lane l holds A[row l&15][k = 8 (l>>4) + j] and B[k = 8 (l>>4) + j][col l&15],
+// j = 0..7; C/D as the f32 form.  The 8 k-values lane group g supplies for chunk c are the two
+// accumulator tiles 2c, 2c+1 (4 registers each): k-slot j <-> feature 16 (2c + (j>>2)) + 4 (j&3) + g;
+// the image packer (mfma_pack) stores W columns in that order, so chaining needs no data movement.
+// ---------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {   // lo16 = bf16(a), hi16 = bf16(b), RNE
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// x[0..7] -> three packed bf16x8 fragments
+__device__ __forceinline__ void split3_bf16(const float (&x)[8], u32x4& hi, u32x4& mid, u32x4& lo) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float x0 = x[2 * i], x1 = x[2 * i + 1];
+        const unsigned h = cvt_pk_bf16(x0, x1);
+        const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xffff0000u);
+        const unsigned m = cvt_pk_bf16(r0, r1);
+        const float s0 = r0 - __uint_as_float(m << 16), s1 = r1 - __uint_as_float(m & 0xffff0000u);
+        hi[i] = h; mid[i] = m; lo[i] = cvt_pk_bf16(s0, s1);
+    }
+}
+
+__device__ __forceinline__ f32x4 mfma_bf16(u32x4 a, u32x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+template <int HT>
+__device__ __forceinline__ void gemm_hidden_bf16x6(const float* __restrict__ img, int lane,
+                                                   const f32x4 (&in)[HT], f32x4 (&acc)[HT]) {
+    static_assert(HT % 2 == 0, "split-bf16 hidden products need an even number of 16-row tiles");
+    constexpr int NC = HT / 2;
+    const u32x4* __restrict__ A = reinterpret_cast<const u32x4*>(img) + lane;   // [split][mt][chunk][lane]
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        float x[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { x[j] = in[2 * c][j]; x[4 + j] = in[2 * c + 1][j]; }
+        u32x4 bh, bm, bl;
+        split3_bf16(x, bh, bm, bl);
+        u32x4 ah[HT], am[HT], al[HT];
+#pragma unroll
+        for (int mt = 0; mt < HT; ++mt) {
+            ah[mt] = A[((0 * HT + mt) * NC + c) * 64];
+            am[mt] = A[((1 * HT + mt) * NC + c) * 64];
+            al[mt] = A[((2 * HT + mt) * NC + c) * 64];
+        }
+        // small terms first; consecutive MFMAs go to different accumulators
+#pragma unroll
+        for (int mt = 0; mt < HT; ++mt) acc[mt] = mfma_bf16(al[mt], bh, acc[mt]);
+#pragma unroll
+        for (int mt = 0; mt < HT; ++mt) acc[mt] = mfma_bf16(ah[mt], bl, acc[mt]);
+#pragma unroll
+        for (int mt = 0; mt < HT; ++mt) acc[mt] = mfma_bf16(am[mt], bm, acc[mt]);
+#pragma unroll
+        for (int mt = 0; mt < HT; ++mt) acc[mt] = mfma_bf16(am[mt], bh, acc[mt]);
+#pragma unroll
+        for (int mt = 0; mt < HT; ++mt) acc[mt] = mfma_bf16(ah[mt], bm, acc[mt]);
+#pragma unroll
+        for (int mt = 0; mt < HT; ++mt) acc[mt] = mfma_bf16(ah[mt], bh, acc[mt]);
+    }
+}
+
+// hidden H x H product in the arithmetic of the instance
+template <int HT, int ARITH>
+__device__ __forceinline__ void gemm_hidden(const float* __restrict__ img, int lane, const f32x4 (&in)[HT],
+                                            f32x4 (&acc)[HT]) {
+    if constexpr (ARITH == 1) gemm_hidden_bf16x6<HT>(img, lane, in, acc);
+    else gemm_tiles<HT, 4 * HT>(img, lane, TileIn<HT>{in}, acc);
+}
+
 // One dynamics evaluation for a 16-sample tile.
 //   forward pass (shared), then
 //   ENG_VJP: pullback of KP probes with the transposed images  (g = eps^T J;  src/core/utils.jl:150-159)
 //   ENG_TAN: pushforward of tangents with the forward images only:
 //            Hutchinson JVP (g = J eps; src/core/utils.jl:161-170) or, with `exact`, the D unit
 //            tangents whose i-th output row is J_ii (trace of src/core/utils.jl:79-88, icnf.jl:312)
-template <int HT, int L, int ZR, int CR, int ACT, int ENGINE, int KP, int PRE>
+template <int HT, int L, int ZR, int CR, int ACT, int ENGINE, int KP, int PRE, int ARITH>
 __device__ __forceinline__ void dyn_eval(const float* __restrict__ smem, int lane, float t,
                                          bool autonomous, bool reg_z, bool reg_j, bool exact, int D,
                                          const float (&z)[ZR], const float (&y)[CR > 0 ? CR : 1],
                                          const float (&eps)[KP][ZR], const f32x4 (&pre_c)[HT],
                                          const f32x4 (&pre_q)[HT], float (&zd)[ZR], float& ld,
                                          float& ed, float& nd) {
-    constexpr MfmaLayout LAY(HT, L, ZR, CR, ENGINE == ENG_VJP);
+    constexpr MfmaLayout LAY(HT, L, ZR, CR, ENGINE == ENG_VJP, ARITH);
     constexpr int DT = (ZR + 3) / 4;
     const int g = lane >> 4;
     f32x4 h[HT];
@@ -89,7 +170,7 @@ __device__ __forceinline__ void dyn_eval(const float* __restrict__ smem, int lan
     for (int l = 1; l < L; ++l) {
         f32x4 acc[HT];
         load_cvec<HT>(smem + LAY.v_bh + (l - 1) * MfmaLayout::vecC(HT), g, acc);
-        gemm_tiles<HT, 4 * HT>(smem + LAY.fh + (l - 1) * MfmaLayout::imgA(HT, HT), lane, TileIn<HT>{h}, acc);
+        gemm_hidden<HT, ARITH>(smem + LAY.fh + (l - 1) * LAY.imgHid(), lane, h, acc);
 #pragma unroll
         for (int mt = 0; mt < HT; ++mt)
 #pragma unroll
@@ -155,7 +236,7 @@ __device__ __forceinline__ void dyn_eval(const float* __restrict__ smem, int lan
                 f32x4 acc[HT];
 #pragma unroll
                 for (int mt = 0; mt < HT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-                gemm_tiles<HT, 4 * HT>(sm + LAY.bh + (l - 1) * MfmaLayout::imgA(HT, HT), lane, TileIn<HT>{dl}, acc);
+                gemm_hidden<HT, ARITH>(sm + LAY.bh + (l - 1) * LAY.imgHid(), lane, dl, acc);
 #pragma unroll
                 for (int mt = 0; mt < HT; ++mt) dl[mt] = acc[mt] * d[l - 1][mt];
             }
@@ -186,7 +267,7 @@ __device__ __forceinline__ void dyn_eval(const float* __restrict__ smem, int lan
                 f32x4 acc[HT];
 #pragma unroll
                 for (int mt = 0; mt < HT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-                gemm_tiles<HT, 4 * HT>(sm + LAY.fh + (l - 1) * MfmaLayout::imgA(HT, HT), lane, TileIn<HT>{tau}, acc);
+                gemm_hidden<HT, ARITH>(sm + LAY.fh + (l - 1) * LAY.imgHid(), lane, tau, acc);
 #pragma unroll
                 for (int mt = 0; mt < HT; ++mt) tau[mt] = acc[mt] * d[l][mt];
             }
@@ -206,10 +287,10 @@ __device__ __forceinline__ void dyn_eval(const float* __restrict__ smem, int lan
 
 // PRE: 0 none; 1 hoist c = W_N^T eps; 2 also hoist q = W_1[:,0:D] eps and skip the last pullback
 // product (valid only without reg_j).  PRE > 0 needs ENGINE == ENG_VJP and KP == 1.
-template <int HT, int L, int ZR, int CR, int ACT, int ENGINE, int KP, int PRE, int NTHREADS>
+template <int HT, int L, int ZR, int CR, int ACT, int ENGINE, int KP, int PRE, int NTHREADS, int ARITH = 0>
 __global__ void __launch_bounds__(NTHREADS)
 mfma_solve_kernel(KArgs a) {
-    constexpr MfmaLayout LAY(HT, L, ZR, CR, ENGINE == ENG_VJP);
+    constexpr MfmaLayout LAY(HT, L, ZR, CR, ENGINE == ENG_VJP, ARITH);
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // stage the packed weight image: global (L2) -> LDS, 16 B per lane, coalesced
     {
@@ -305,7 +386,7 @@ mfma_solve_kernel(KArgs a) {
                 // of the RK loops (and spill them).  An opaque zero offset pins the reads per stage.
                 int opaque = 0;
                 asm volatile("" : "+v"(opaque));
-                dyn_eval<HT, L, ZR, CR, ACT, ENGINE, KP, PRE>(smem + opaque, lane, tn + a.T.c[st] * dt, autonomous,
+                dyn_eval<HT, L, ZR, CR, ACT, ENGINE, KP, PRE, ARITH>(smem + opaque, lane, tn + a.T.c[st] * dt, autonomous,
                                                               reg_z, reg_j, exact, D, zs, y, eps, pre_c, pre_q, zd,
                                                               ld, ed, nd);
 #pragma unroll
@@ -376,9 +457,9 @@ mfma_solve_kernel(KArgs a) {
 
 typedef hipError_t (*LaunchFn)(const KArgs&, int lds_bytes, int nblocks, hipStream_t);
 
-template <int HT, int L, int ZR, int CR, int ACT, int ENGINE, int KP, int PRE, int NTHREADS>
+template <int HT, int L, int ZR, int CR, int ACT, int ENGINE, int KP, int PRE, int NTHREADS, int ARITH = 0>
 inline hipError_t launch_inst(const KArgs& a, int lds_bytes, int nblocks, hipStream_t st) {
-    auto kern = mfma_solve_kernel<HT, L, ZR, CR, ACT, ENGINE, KP, PRE, NTHREADS>;
+    auto kern = mfma_solve_kernel<HT, L, ZR, CR, ACT, ENGINE, KP, PRE, NTHREADS, ARITH>;
     // > 64 KB of dynamic LDS has to be enabled once per device for this kernel
     static unsigned long long done_mask = 0;
     int dev = 0;
@@ -398,10 +479,13 @@ struct Inst {
     int PRE;   // 2 requires !reg_j
     LaunchFn fn;
     int nthreads;
+    int arith; // CNF_ARITH_*
 };
 
 #define MFMA_INST(HT, L, ZR, CR, ACT, ENG, KP, PRE, NT) \
-    Inst { HT, L, ZR, CR, ACT, ENG, KP, PRE, &launch_inst<HT, L, ZR, CR, ACT, ENG, KP, PRE, NT>, NT }
+    Inst { HT, L, ZR, CR, ACT, ENG, KP, PRE, &launch_inst<HT, L, ZR, CR, ACT, ENG, KP, PRE, NT>, NT, 0 }
+#define MFMA_INST_BF16X6(HT, L, ZR, CR, ACT, ENG, KP, PRE, NT) \
+    Inst { HT, L, ZR, CR, ACT, ENG, KP, PRE, &launch_inst<HT, L, ZR, CR, ACT, ENG, KP, PRE, NT, 1>, NT, 1 }
 
 // generic zero-padded instances (cnf_mfma_generic.hip): D <= 16 and C <= 16 or C = 0
 const Inst* mfma_generic_insts(int* count);

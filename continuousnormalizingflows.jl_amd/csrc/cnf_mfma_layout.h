@@ -26,6 +26,7 @@ namespace cnf {
 
 struct MfmaLayout {
     int HT, L, ZR, CR;   // hidden tiles (H_pad = 16 HT), hidden layers, k-steps of D and of C
+    int arith;           // 0: f32 hidden images; 1: split-bf16 hidden images (cnf_mfma_kernel.h)
     int DT, KGZ, KGC;    // M-tiles of D, k-groups of D and C
     // A images (float offsets)
     int f1z, f1y;        // layer 1, z columns / cond columns          M = H, K = D_pad / C_pad
@@ -39,19 +40,23 @@ struct MfmaLayout {
     int total;           // floats
 
     static constexpr int imgA(int MT, int KG) { return MT * KG * 256; }
+    // hidden H x H image in split-bf16 form: [split 3][mt HT][chunk HT/2][lane 64][8 bf16] = 16 B per
+    // lane per (split, mt, chunk); in float units
+    static constexpr int imgH16(int HT) { return 3 * HT * (HT / 2) * 256; }
+    constexpr int imgHid() const { return arith ? imgH16(HT) : imgA(HT, HT); }
     static constexpr int vecC(int MT) { return MT * 16; }
 
-    constexpr MfmaLayout(int HT_, int L_, int ZR_, int CR_, bool with_bwd)
-        : HT(HT_), L(L_), ZR(ZR_), CR(CR_), DT((ZR_ + 3) / 4), KGZ((ZR_ + 3) / 4), KGC((CR_ + 3) / 4),
+    constexpr MfmaLayout(int HT_, int L_, int ZR_, int CR_, bool with_bwd, int arith_ = 0)
+        : HT(HT_), L(L_), ZR(ZR_), CR(CR_), arith(arith_), DT((ZR_ + 3) / 4), KGZ((ZR_ + 3) / 4), KGC((CR_ + 3) / 4),
           f1z(0), f1y(0), fh(0), fN(0), bN(0), bh(0), b1(0), v_b1(0), v_w1t(0), v_bh(0), v_bN(0),
           total(0) {
         int o = 0;
         f1z = o; o += imgA(HT, KGZ);
         f1y = o; o += imgA(HT, KGC);
-        fh = o;  o += (L - 1) * imgA(HT, HT);
+        fh = o;  o += (L - 1) * (arith_ ? imgH16(HT_) : imgA(HT_, HT_));
         fN = o;  o += imgA(DT, HT);
         bN = o;  if (with_bwd) o += imgA(HT, KGZ);
-        bh = o;  if (with_bwd) o += (L - 1) * imgA(HT, HT);
+        bh = o;  if (with_bwd) o += (L - 1) * (arith_ ? imgH16(HT_) : imgA(HT_, HT_));
         b1 = o;  if (with_bwd) o += imgA(DT, HT);
         v_b1 = o;  o += vecC(HT);
         v_w1t = o; o += vecC(HT);

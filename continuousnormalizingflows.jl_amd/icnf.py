@@ -66,9 +66,10 @@ class ComputeMode:
 class MatrixMode(ComputeMode):
     """Whole batch in one solve.  `kernel_path` is PATH_AUTO / PATH_SIMT / PATH_MFMA."""
 
-    def __init__(self, adback=None, kernel_path: int = _lib.PATH_AUTO):
+    def __init__(self, adback=None, kernel_path: int = _lib.PATH_AUTO, arith: int = _lib.ARITH_F32):
         self.adback = adback  # accepted for signature parity; AD is hand-written in the kernels
         self.kernel_path = kernel_path
+        self.arith = arith    # ARITH_F32 (exact, default) or ARITH_BF16X6 (split-bf16 MFMA)
 
 
 class HIPVecJacMatrixMode(MatrixMode):
@@ -327,6 +328,7 @@ class ICNF:
             cfg.reg_aug = int(reg and self.lambda3 != 0.0 and self.augmented)  # NORM_Z_AUG
             cfg.device_id = self.device.index or 0
             cfg.kernel_path = self.compute_mode.kernel_path
+            cfg.arith = getattr(self.compute_mode, "arith", _lib.ARITH_F32)
             h = _Handle(cfg)
             self._handles[key] = h
         return h

@@ -58,6 +58,14 @@ enum { CNF_MODE_HUTCH_VJP = 0, CNF_MODE_HUTCH_JVP = 1, CNF_MODE_EXACT = 2 };
  * (src/core/base_icnf.jl:138) */
 enum { CNF_ALG_RK4 = 0, CNF_ALG_TSIT5 = 1 };
 
+/* arithmetic of the hidden-layer products (cnf_config.arith).  Both accumulate in f32.
+ *   F32       exact f32 MFMA (v_mfma_f32_16x16x4_f32 = fmaf chain) — default, the validated path
+ *   BF16X6    each f32 operand split exactly into three bf16 parts, six bf16 MFMAs per product
+ *             (hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid; dropped terms <= 2^-24 relative):
+ *             f32-equivalent accuracy at a higher MFMA rate.  Only shapes the per-wave MFMA
+ *             kernel covers; cnf_create fails with CNF_ERR_UNSUPPORTED otherwise. */
+enum { CNF_ARITH_F32 = 0, CNF_ARITH_BF16X6 = 1 };
+
 /* kernel families (cnf_kernel_path) */
 enum { CNF_PATH_AUTO = 0, CNF_PATH_SIMT = 1, CNF_PATH_MFMA = 2 };
 
@@ -78,6 +86,7 @@ typedef struct {
     int32_t reg_aug;                      /* Adot=|z_aug|_2 on: NORM_Z_AUG, AUGMENTED, TrainMode{true} (base_icnf.jl:106-122) */
     int32_t device_id;                    /* HIP device ordinal */
     int32_t kernel_path;                  /* CNF_PATH_*; AUTO picks MFMA when the shape is supported */
+    int32_t arith;                        /* CNF_ARITH_* */
 } cnf_config;
 
 typedef struct cnf_handle cnf_handle;

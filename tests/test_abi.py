@@ -33,8 +33,8 @@ def test_library_exports_every_declared_symbol(pkg):
 
 
 def test_config_struct_matches_header(pkg):
-    # 5 + 9 + 8 + 7 int32 fields
-    assert C.sizeof(pkg._lib.CnfConfig) == 4 * (5 + 9 + 8 + 7)
+    # 5 + 9 + 8 + 8 int32 fields
+    assert C.sizeof(pkg._lib.CnfConfig) == 4 * (5 + 9 + 8 + 8)
 
 
 def _cfg(pkg, **kw):

@@ -151,6 +151,54 @@ def test_cooperative_wide_layer_kernel_matches_per_wave_kernel(pkg, oracles, mon
     assert np.max(np.abs(coop[2].cpu().numpy() - ref[2])) < TOL_SOLVE
 
 
+def make_icnf_bf16x6(pkg, spec, alg, nsteps):
+    icnf = make_icnf(pkg, spec, alg, nsteps, path=2)
+    icnf.compute_mode.arith = pkg._lib.ARITH_BF16X6
+    return icnf
+
+
+@pytest.mark.parametrize("name", ["cfg2_ffjord_d8_3x64_rk4", "cfg2p_ffjord_d8_3x64_tsit5",
+                                  "cfg3_rnode_d8_3x64_tsit5_k4"])
+def test_split_bf16_arithmetic_matches_golden(name, pkg):
+    """Opt-in CNF_ARITH_BF16X6: hidden products as six bf16 MFMAs on an exact 3-way split of both
+    operands.  Must meet the same tolerances as the exact-f32 kernel against the fp64 fixtures."""
+    spec, meta, g = load_golden(name)
+    icnf = make_icnf_bf16x6(pkg, spec, meta["alg"], meta["nsteps"])
+    du = pkg.augmented_f(icnf, mode_of(pkg, spec), dev(g["u"]), dev(g["p"]), float(g["t"]),
+                         dev(g["eps"]), None).cpu().numpy()
+    assert np.max(np.abs(du - g["du"]) / (1.0 + np.abs(g["du"]))) < TOL_CALL
+    logp, (E, n, A), u1 = run_inference(pkg, icnf, spec, g["p"], g["xs"], g["eps"], None, return_state=True)
+    assert np.max(np.abs(logp.cpu().numpy() - g["logp"])) < TOL_SOLVE
+    assert np.max(np.abs(n.cpu().numpy() - g["n"])) < TOL_SOLVE
+    assert np.max(np.abs(u1.cpu().numpy() - g["u1"])) < TOL_SOLVE
+
+
+def test_split_bf16_is_as_accurate_as_f32_on_stiffer_weights(pkg, oracles):
+    """A 2-way split (3 products) loses 2 decimal digits on stiffer nets; the 3-way
+    split must stay within a small factor of the exact-f32 kernel's own error against float64."""
+    o64, _ = oracles
+    spec = o64.make_spec(nvars=8, hidden=[64, 64, 64])
+    B = 512
+    p, xs, eps, _ = o64.synth_inputs(spec, B, 20240614)
+    p = (p * 2.5).astype(np.float32)
+    ref = o64.inference_fixed(spec, p, xs[:, :64], 0.0, 1.0, 40, 1, eps[:, :64])[0]
+    f32 = run_inference(pkg, make_icnf(pkg, spec, 1, 40, path=2), spec, p, xs, eps, None)[0].cpu().numpy()
+    b16 = run_inference(pkg, make_icnf_bf16x6(pkg, spec, 1, 40), spec, p, xs, eps, None)[0].cpu().numpy()
+    e32 = np.max(np.abs(f32[:64] - ref))
+    e16 = np.max(np.abs(b16[:64] - ref))
+    assert e16 < max(3.0 * e32, 2e-4), (e16, e32)
+    assert np.max(np.abs(b16 - f32)) < 1e-3
+
+
+def test_split_bf16_is_refused_where_not_implemented(pkg, oracles):
+    o64, _ = oracles
+    spec = o64.make_spec(nvars=32, hidden=[256, 256, 256])
+    icnf = make_icnf_bf16x6(pkg, spec, 0, 10)
+    with pytest.raises(pkg._lib.CnfError) as e:
+        icnf.kernel_path(pkg.TrainMode(False))
+    assert e.value.code == pkg._lib.ERR_UNSUPPORTED
+
+
 def test_empty_batch_is_a_no_op(pkg, oracles):
     o64, _ = oracles
     spec = o64.make_spec(nvars=8, hidden=[64, 64, 64])
