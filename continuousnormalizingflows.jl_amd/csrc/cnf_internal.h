@@ -64,7 +64,6 @@ struct SolveArgs {
     float* regs;     // 3B or null
     int nvars, reg_aug;
 };
-hipError_t mfma_solve(const MfmaPlan* p, const float* packed_dev, const SolveArgs& a,
-                      hipStream_t st);
+hipError_t mfma_solve(MfmaPlan* p, const float* packed_dev, const SolveArgs& a, hipStream_t st);
 
 }  // namespace cnf

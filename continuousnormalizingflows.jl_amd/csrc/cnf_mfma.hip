@@ -253,9 +253,9 @@ void mfma_pack(const MfmaPlan* p, const float* lux, const size_t* w_off, const s
     pack_vecC(packed + Y.v_bN, Y.DT, D, [&](int f) { return Bv(L, f); });
 }
 
-hipError_t mfma_solve(const MfmaPlan* p, const float* packed_dev, const SolveArgs& s, hipStream_t st) {
+hipError_t mfma_solve(MfmaPlan* p, const float* packed_dev, const SolveArgs& s, hipStream_t st) {
     if (s.B == 0) return hipSuccess;
-    MfmaPlan* mp = const_cast<MfmaPlan*>(p);
+    MfmaPlan* mp = p;   // caches the CU count and owns the optional queue word
     if (mp->num_cus == 0) {
         int dev = 0;
         hipDeviceProp_t prop;

@@ -279,3 +279,67 @@ def synth_inputs(spec: Spec, B: int, seed: int, bias_scale: float = 0.0):
     eps = rng.standard_normal((spec.nprobes * spec.D, B)).astype(np.float32)
     ys = rng.standard_normal((spec.ncond, B)).astype(np.float32) if spec.ncond else None
     return p, xs, eps, ys
+
+
+# ----------------------------------------------------------------------------------------
+# Groundwork for SURVEY.md §8(f) rank 2 — parameter gradient of the loss (training).
+# The reference differentiates `loss` through SciMLBase.solve with QuadratureAdjoint
+# (src/core/icnf.jl:90-99; src/exts/mlj_ext/core_icnf.jl:42-51).  With a fixed-step solver the
+# exact gradient of the *discrete* loss is obtained by reverse-mode through the RK steps
+# (discretise-then-optimise); this fp64 autograd version is the oracle a future HIP backward
+# kernel will be checked against.  Hutchinson VJP mode only.
+# ----------------------------------------------------------------------------------------
+def loss_and_grad(spec: Spec, p, xs, t0, t1, nsteps, alg, eps, ys=None, lambdas=(0.0, 0.0, 0.0)):
+    """Returns (loss, dloss/dp) with p in the flat Lux layout, all in float64."""
+    spec.check()
+    assert spec.mode == MODE_HUTCH_VJP, "gradient oracle: Hutchinson VJP mode"
+    D, K = spec.D, spec.nprobes
+    pt = torch.tensor(np.asarray(p, dtype=np.float64), requires_grad=True)
+    w_off, b_off, _ = spec.param_offsets()
+    layers = []
+    for l in range(len(spec.acts)):
+        fin, fout = spec.widths[l], spec.widths[l + 1]
+        W = pt[w_off[l]:w_off[l] + fin * fout].reshape(fin, fout).t()
+        layers.append((W, pt[b_off[l]:b_off[l] + fout]))
+    x = torch.tensor(np.asarray(xs, dtype=np.float64))
+    B = x.shape[1]
+    e = torch.tensor(np.asarray(eps, dtype=np.float64))
+    yt = None if ys is None else torch.tensor(np.asarray(ys, dtype=np.float64))
+
+    def f_aug(u, t):
+        z = u[:D]
+        if not z.requires_grad:
+            z = z.clone().requires_grad_(True)
+        zdot = _net(spec, layers, z, t, yt)
+        ldot = torch.zeros(B, dtype=torch.float64)
+        ndot = torch.zeros(B, dtype=torch.float64)
+        for k in range(K):
+            ek = e[k * D:(k + 1) * D]
+            (g,) = torch.autograd.grad(zdot, z, ek, create_graph=True)
+            ldot = ldot - (g * ek).sum(0) / K
+            if spec.reg_j:
+                ndot = ndot + torch.sqrt((g * g).sum(0)) / K
+        Edot = torch.sqrt((zdot * zdot).sum(0)) if spec.reg_z else torch.zeros(B, dtype=torch.float64)
+        return torch.cat([zdot, ldot[None], Edot[None], ndot[None]], dim=0)
+
+    c, a, b = tableau(alg)
+    dt = (t1 - t0) / nsteps
+    u = torch.cat([x, torch.zeros(spec.naug + 3, B, dtype=torch.float64)], dim=0)
+    for n in range(nsteps):
+        tn = t0 + n * dt
+        ks = []
+        for i in range(len(c)):
+            ui = u
+            for j, aij in enumerate(a[i]):
+                if aij != 0.0:
+                    ui = ui + dt * aij * ks[j]
+            ks.append(f_aug(ui, tn + c[i] * dt))
+        for bi, ki in zip(b, ks):
+            u = u + dt * bi * ki
+    z, dlogp = u[:D], u[D]
+    logp = -0.5 * D * math.log(2.0 * math.pi) - 0.5 * (z * z).sum(0) - dlogp
+    A = torch.sqrt((z[spec.nvars:] ** 2).sum(0)) if (spec.reg_aug and spec.naug > 0) \
+        else torch.zeros(B, dtype=torch.float64)
+    L = (-logp + lambdas[0] * u[D + 1] + lambdas[1] * u[D + 2] + lambdas[2] * A).mean()
+    (gp,) = torch.autograd.grad(L, pt)
+    return float(L.detach()), gp.detach().numpy()

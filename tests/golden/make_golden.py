@@ -74,3 +74,17 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+def make_gradient_fixture():
+    """Groundwork for the parameter-gradient row: dloss/dp of the discrete loss (cfg2 shape, B = 8,
+    Tsit5 x 10) from oracle/cnf_oracle64.py::loss_and_grad."""
+    spec = o.make_spec(nvars=8, hidden=[64, 64, 64])
+    p, xs, eps, _ = o.synth_inputs(spec, 8, 20240618, bias_scale=0.1)
+    L, g = o.loss_and_grad(spec, p, xs, 0.0, 1.0, 10, o.ALG_TSIT5, eps)
+    np.savez_compressed(os.path.join(OUT, "grad_cfg2_d8_3x64_tsit5.npz"), p=p, xs=xs, eps=eps, nsteps=10,
+                        loss=L, grad=g)
+
+
+if __name__ == "__main__":
+    make_gradient_fixture()
