@@ -57,9 +57,20 @@ inline Tableau make_tableau(int alg) {
 __device__ __forceinline__ float fast_exp(float x) { return __expf(x); }
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 
+// internal: tanh whose pre-activation arrives already multiplied by -2 log2(e) (the factor is folded
+// into the forward weight images and biases by mfma_pack), so exp(-2a) is a bare v_exp_f32
+constexpr int CNF_ACT_TANH_PRESCALED = 3;
+constexpr float kTanhPrescale = -2.8853900817779268f;
+
 template <int ACT>
 __device__ __forceinline__ float act_fwd(float a, float& d) {
-    if constexpr (ACT == CNF_ACT_TANH) {
+    if constexpr (ACT == CNF_ACT_TANH_PRESCALED) {
+        const float e = __builtin_amdgcn_exp2f(a);
+        const float r = fast_rcp(1.f + e);
+        const float h = fmaf(2.f, r, -1.f);
+        d = fmaf(-h, h, 1.f);
+        return h;
+    } else if constexpr (ACT == CNF_ACT_TANH) {
         // tanh(a) = 2 sigmoid(2a) - 1: one v_mul, v_exp, v_add, v_rcp, two v_fma.  Saturates
         // correctly (e -> inf gives r = 0, h = -1; e -> 0 gives h = 1); |error| <= 2e-7.
         const float e = __builtin_amdgcn_exp2f(a * -2.8853900817779268f);   // exp(-2a)

@@ -345,21 +345,23 @@ struct CoopInst {
 #define COOP_INST(HT, L, ZR, ACT) \
     CoopInst { HT, L, ZR, ACT, &launch_coop<HT, L, ZR, ACT, 4>, &launch_coop<HT, L, ZR, ACT, 6> }
 static const CoopInst kCoop[] = {
-    COOP_INST(16, 3, 8, CNF_ACT_TANH),   // cfg4: D=32, 3x256
-    COOP_INST(8, 3, 2, CNF_ACT_TANH),    // D=8, 3x128 Hutchinson VJP
-    COOP_INST(4, 3, 2, CNF_ACT_TANH),    // D=8, 3x64 (cross-check of the per-wave kernel)
+    // tanh instances are compiled for pre-scaled pre-activations (mfma_pack folds -2 log2 e into the
+    // forward images); they are matched against CNF_ACT_TANH configurations
+    COOP_INST(16, 3, 8, CNF_ACT_TANH_PRESCALED),   // cfg4: D=32, 3x256
+    COOP_INST(8, 3, 2, CNF_ACT_TANH_PRESCALED),    // D=8, 3x128 Hutchinson VJP
+    COOP_INST(4, 3, 2, CNF_ACT_TANH_PRESCALED),    // D=8, 3x64 (cross-check of the per-wave kernel)
 };
 
 bool coop_supported(int HT, int L, int ZR, int CR, int ACT, int engine, int KP) {
     if (engine != ENG_VJP || KP != 1 || CR != 0) return false;
     for (const CoopInst& c : kCoop)
-        if (c.HT == HT && c.L == L && c.ZR == ZR && c.ACT == ACT) return true;
+        if (c.HT == HT && c.L == L && c.ZR == ZR && (c.ACT == ACT || (c.ACT == CNF_ACT_TANH_PRESCALED && ACT == CNF_ACT_TANH))) return true;
     return false;
 }
 
 hipError_t coop_launch(int HT, int L, int ZR, int ACT, const KArgs& a, int num_cus, hipStream_t st) {
     for (const CoopInst& c : kCoop)
-        if (c.HT == HT && c.L == L && c.ZR == ZR && c.ACT == ACT) {
+        if (c.HT == HT && c.L == L && c.ZR == ZR && (c.ACT == ACT || (c.ACT == CNF_ACT_TANH_PRESCALED && ACT == CNF_ACT_TANH))) {
             const long long nst = (a.B + 63) / 64;
             const int nblocks = (int)(nst < num_cus ? nst : num_cus);
             return (a.T.ns <= 4 ? c.fn4 : c.fn6)(a, nblocks, st);

@@ -38,6 +38,7 @@ struct MfmaPlan {
     int num_cus;
     int kind;           // 0: per-wave LDS-resident kernel, 1: cooperative wide-layer kernel
     int arith;          // CNF_ARITH_* of the hidden products
+    float fwd_scale;    // factor folded into the forward hidden-layer images/biases (pre-scaled tanh)
     int prio_mode;      // see KArgs
     int use_queue;
     int* queue_dev;     // one int per plan, zeroed on the stream before every launch
@@ -50,19 +51,19 @@ struct MfmaPlan {
 // generic SIMT path.
 static const Inst kInsts[] = {
     // --- Hutchinson VJP (LuxVecJacMatrixMode + TrainMode) ---
-    MFMA_INST(4, 3, 2, 0, CNF_ACT_TANH, ENG_VJP, 1, 2, 512),      // cfg2 / cfg2': D=8, 3x64, K=1, FFJORD
-    MFMA_INST(4, 3, 2, 0, CNF_ACT_TANH, ENG_VJP, 1, 1, 512),      // same shape with reg_j (RNODE, K=1)
-    MFMA_INST(4, 3, 2, 0, CNF_ACT_TANH, ENG_VJP, 1, 0, 512),      // no hoisting (A/B reference)
-    MFMA_INST(4, 3, 2, 0, CNF_ACT_TANH, ENG_VJP, 1, 2, 1024),
-    MFMA_INST(4, 3, 2, 0, CNF_ACT_TANH, ENG_VJP, 1, 2, 256),
-    MFMA_INST(4, 3, 2, 0, CNF_ACT_TANH, ENG_VJP, 4, 0, 512),      // cfg3: RNODE K=4
-    MFMA_INST(2, 2, 1, 0, CNF_ACT_TANH, ENG_VJP, 1, 2, 512),      // cfg1: D=2, 2x32
-    MFMA_INST(2, 2, 1, 0, CNF_ACT_TANH, ENG_VJP, 1, 1, 512),
+    MFMA_INST(4, 3, 2, 0, CNF_ACT_TANH_PRESCALED, ENG_VJP, 1, 2, 512),      // cfg2 / cfg2': D=8, 3x64, K=1, FFJORD
+    MFMA_INST(4, 3, 2, 0, CNF_ACT_TANH_PRESCALED, ENG_VJP, 1, 1, 512),      // same shape with reg_j (RNODE, K=1)
+    MFMA_INST(4, 3, 2, 0, CNF_ACT_TANH_PRESCALED, ENG_VJP, 1, 0, 512),      // no hoisting (A/B reference)
+    MFMA_INST(4, 3, 2, 0, CNF_ACT_TANH_PRESCALED, ENG_VJP, 1, 2, 1024),
+    MFMA_INST(4, 3, 2, 0, CNF_ACT_TANH_PRESCALED, ENG_VJP, 1, 2, 256),
+    MFMA_INST(4, 3, 2, 0, CNF_ACT_TANH_PRESCALED, ENG_VJP, 4, 0, 512),      // cfg3: RNODE K=4
+    MFMA_INST(2, 2, 1, 0, CNF_ACT_TANH_PRESCALED, ENG_VJP, 1, 2, 512),      // cfg1: D=2, 2x32
+    MFMA_INST(2, 2, 1, 0, CNF_ACT_TANH_PRESCALED, ENG_VJP, 1, 1, 512),
     MFMA_INST(1, 2, 1, 0, CNF_ACT_SOFTPLUS, ENG_VJP, 1, 1, 512),  // reference default net, nvariables=1
     // --- split-bf16 hidden products (cnf_config.arith = CNF_ARITH_BF16X6), headline shape ---
-    MFMA_INST_BF16X6(4, 3, 2, 0, CNF_ACT_TANH, ENG_VJP, 1, 2, 512),
-    MFMA_INST_BF16X6(4, 3, 2, 0, CNF_ACT_TANH, ENG_VJP, 1, 1, 512),
-    MFMA_INST_BF16X6(4, 3, 2, 0, CNF_ACT_TANH, ENG_VJP, 4, 0, 512),
+    MFMA_INST_BF16X6(4, 3, 2, 0, CNF_ACT_TANH_PRESCALED, ENG_VJP, 1, 2, 512),
+    MFMA_INST_BF16X6(4, 3, 2, 0, CNF_ACT_TANH_PRESCALED, ENG_VJP, 1, 1, 512),
+    MFMA_INST_BF16X6(4, 3, 2, 0, CNF_ACT_TANH_PRESCALED, ENG_VJP, 4, 0, 512),
     MFMA_INST_BF16X6(4, 3, 2, 0, CNF_ACT_TANH, ENG_TAN, 1, 0, 512),
     // --- tangent engine: Hutchinson JVP (LuxJacVecMatrixMode) and exact trace (TestMode) ---
     MFMA_INST(8, 3, 2, 2, CNF_ACT_TANH, ENG_TAN, 1, 0, 256),      // cfg5: D=8, C=8, 3x128 (200 VGPR, 1 wave/SIMD:
@@ -72,6 +73,11 @@ static const Inst kInsts[] = {
     MFMA_INST(1, 2, 1, 0, CNF_ACT_SOFTPLUS, ENG_TAN, 1, 0, 512),  // reference default net, TestMode
     MFMA_INST(1, 2, 1, 0, CNF_ACT_TANH, ENG_TAN, 1, 0, 512),
 };
+
+// an instance compiled for pre-scaled tanh serves a tanh configuration
+static bool act_matches(int inst_act, int cfg_act) {
+    return inst_act == cfg_act || (inst_act == CNF_ACT_TANH_PRESCALED && cfg_act == CNF_ACT_TANH);
+}
 
 static int env_int(const char* name, int dflt) {
     const char* v = getenv(name);
@@ -105,6 +111,7 @@ MfmaPlan* mfma_plan_create(const cnf_config& c) {
         p->prio_mode = 0; p->use_queue = 0; p->queue_dev = nullptr;
         p->kind = 1;
         p->arith = 0;
+        p->fwd_scale = c.acts[0] == CNF_ACT_TANH ? kTanhPrescale : 1.f;   // cnf_coop.hip runs pre-scaled tanh
         snprintf(p->name, sizeof(p->name), "coop_vjp<HT=%d,L=%d,ZR=%d,act=%d>", HT, L, ZR, c.acts[0]);
         return p;
     };
@@ -115,6 +122,7 @@ MfmaPlan* mfma_plan_create(const cnf_config& c) {
         p->HT = HT; p->L = L; p->ZR = in.ZR; p->CR = in.CR; p->ACT = in.ACT; p->ENGINE = engine; p->KP = KP;
         p->with_bwd = engine == ENG_VJP;
         p->arith = in.arith;
+        p->fwd_scale = in.ACT == CNF_ACT_TANH_PRESCALED ? kTanhPrescale : 1.f;
         p->lay = MfmaLayout(HT, L, in.ZR, in.CR, p->with_bwd, in.arith);
         p->launch = in.fn;
         p->cfg = c;
@@ -132,7 +140,7 @@ MfmaPlan* mfma_plan_create(const cnf_config& c) {
     // 1. specialised instances: exact state / condition k-steps
     for (const Inst& in : kInsts) {
         if (in.PRE == 2 && c.reg_j) continue;   // the dot-product shortcut needs no |eps^T J|
-        if (in.HT == HT && in.L == L && in.ZR == ZR && in.CR == CR && in.ACT == c.acts[0] &&
+        if (in.HT == HT && in.L == L && in.ZR == ZR && in.CR == CR && act_matches(in.ACT, c.acts[0]) &&
             in.ENGINE == engine && in.KP == KP && in.arith == c.arith &&
             (want_nt == 0 || want_nt == in.nthreads) && (want_pre < 0 || want_pre == in.PRE))
             return make(in);
@@ -145,7 +153,7 @@ MfmaPlan* mfma_plan_create(const cnf_config& c) {
         for (int i = 0; i < ng; ++i) {
             const Inst& in = gen[i];
             if (in.HT == HT && in.L == L && in.ZR >= ZR && in.CR >= CR && (CR > 0 || in.CR == 0) &&
-                in.ACT == c.acts[0] && in.ENGINE == engine && in.KP == KP &&
+                act_matches(in.ACT, c.acts[0]) && in.ENGINE == engine && in.KP == KP &&
                 (size_t)MfmaLayout(HT, L, in.ZR, in.CR, engine == ENG_VJP).total * sizeof(float) <= kMaxLds)
                 return make(in);
         }
@@ -231,11 +239,12 @@ void mfma_pack(const MfmaPlan* p, const float* lux, const size_t* w_off, const s
     // Lux Dense weight (out x in) column-major: W(o,i) = lux[w_off + o + out*i]
     auto W = [&](int l, int o, int i) { return lux[w_off[l] + (size_t)o + (size_t)c.widths[l + 1] * i]; };
     auto Bv = [&](int l, int o) { return lux[b_off[l] + o]; };
-    pack_imgA(packed + Y.f1z, Y.HT, Y.KGZ, H, D, [&](int r, int k) { return W(0, r, k); });
-    if (Y.CR > 0) pack_imgA(packed + Y.f1y, Y.HT, Y.KGC, H, C, [&](int r, int k) { return W(0, r, ycol + k); });
+    const float fs = p->fwd_scale;   // hidden-layer pre-activations are produced pre-scaled (forward images only)
+    pack_imgA(packed + Y.f1z, Y.HT, Y.KGZ, H, D, [&](int r, int k) { return fs * W(0, r, k); });
+    if (Y.CR > 0) pack_imgA(packed + Y.f1y, Y.HT, Y.KGC, H, C, [&](int r, int k) { return fs * W(0, r, ycol + k); });
     for (int l = 1; l < L; ++l) {
-        if (Y.arith) pack_imgH16(packed + Y.fh + (l - 1) * Y.imgHid(), Y.HT, H, [&](int r, int k) { return W(l, r, k); });
-        else pack_imgA(packed + Y.fh + (l - 1) * Y.imgHid(), Y.HT, Y.HT, H, H, [&](int r, int k) { return W(l, r, k); });
+        if (Y.arith) pack_imgH16(packed + Y.fh + (l - 1) * Y.imgHid(), Y.HT, H, [&](int r, int k) { return fs * W(l, r, k); });
+        else pack_imgA(packed + Y.fh + (l - 1) * Y.imgHid(), Y.HT, Y.HT, H, H, [&](int r, int k) { return fs * W(l, r, k); });
     }
     pack_imgA(packed + Y.fN, Y.DT, Y.HT, D, H, [&](int r, int k) { return W(L, r, k); });
     if (p->with_bwd) {
@@ -246,10 +255,10 @@ void mfma_pack(const MfmaPlan* p, const float* lux, const size_t* w_off, const s
         }
         pack_imgA(packed + Y.b1, Y.DT, Y.HT, D, H, [&](int r, int k) { return W(0, k, r); });     // W_1[:,0:D]^T
     }
-    pack_vecC(packed + Y.v_b1, Y.HT, H, [&](int f) { return Bv(0, f); });
-    pack_vecC(packed + Y.v_w1t, Y.HT, H, [&](int f) { return c.autonomous ? 0.f : W(0, f, tcol); });
+    pack_vecC(packed + Y.v_b1, Y.HT, H, [&](int f) { return fs * Bv(0, f); });
+    pack_vecC(packed + Y.v_w1t, Y.HT, H, [&](int f) { return c.autonomous ? 0.f : fs * W(0, f, tcol); });
     for (int l = 1; l < L; ++l)
-        pack_vecC(packed + Y.v_bh + (l - 1) * MfmaLayout::vecC(Y.HT), Y.HT, H, [&](int f) { return Bv(l, f); });
+        pack_vecC(packed + Y.v_bh + (l - 1) * MfmaLayout::vecC(Y.HT), Y.HT, H, [&](int f) { return fs * Bv(l, f); });
     pack_vecC(packed + Y.v_bN, Y.DT, D, [&](int f) { return Bv(L, f); });
 }
 

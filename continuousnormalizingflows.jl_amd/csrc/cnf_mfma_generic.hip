@@ -10,9 +10,11 @@
 
 namespace cnf {
 
+// VJP instances of tanh nets run the pre-scaled tanh (forward images carry the -2 log2 e factor)
+#define VJP_ACT(ACT) ((ACT) == CNF_ACT_TANH ? CNF_ACT_TANH_PRESCALED : (ACT))
 #define GEN4(HT, L, ACT, NT)                                   \
-    MFMA_INST(HT, L, 4, 0, ACT, ENG_VJP, 1, 1, NT),            \
-    MFMA_INST(HT, L, 4, 4, ACT, ENG_VJP, 1, 1, NT),            \
+    MFMA_INST(HT, L, 4, 0, VJP_ACT(ACT), ENG_VJP, 1, 1, NT),   \
+    MFMA_INST(HT, L, 4, 4, VJP_ACT(ACT), ENG_VJP, 1, 1, NT),   \
     MFMA_INST(HT, L, 4, 0, ACT, ENG_TAN, 1, 0, NT),            \
     MFMA_INST(HT, L, 4, 4, ACT, ENG_TAN, 1, 0, NT)
 #define GEN_ACT(HT, NT)                                                          \

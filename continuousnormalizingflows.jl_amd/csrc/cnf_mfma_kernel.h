@@ -363,7 +363,13 @@ mfma_solve_kernel(KArgs a) {
 #pragma unroll
         for (int mt = 0; mt < HT; ++mt) pre_c[mt] = pre_q[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
         if constexpr (PRE >= 1) gemm_tiles<HT, ZR>(smem + LAY.bN, lane, RegIn<ZR>{eps[0]}, pre_c);
-        if constexpr (PRE >= 2) gemm_tiles<HT, ZR>(smem + LAY.f1z, lane, RegIn<ZR>{eps[0]}, pre_q);
+        if constexpr (PRE >= 2) {
+            gemm_tiles<HT, ZR>(smem + LAY.f1z, lane, RegIn<ZR>{eps[0]}, pre_q);
+            if constexpr (ACT == CNF_ACT_TANH_PRESCALED) {   // the forward image carries the tanh pre-scale
+#pragma unroll
+                for (int mt = 0; mt < HT; ++mt) pre_q[mt] *= (1.f / kTanhPrescale);
+            }
+        }
         const float dt = a.dt;
         const bool single = a.nsteps == 0;      // one dynamics call: du = f(u, p, t0)
         const int ns = single ? 1 : a.T.ns;
