@@ -24,7 +24,7 @@ ARITH_F32, ARITH_BF16X6 = 0, 1
 
 EXPORTS = ("cnf_version", "cnf_last_error", "cnf_create", "cnf_destroy", "cnf_set_params",
            "cnf_kernel_path", "cnf_aug_f", "cnf_integrate_fixed", "cnf_inference_fixed",
-           "cnf_loss_sums")
+           "cnf_loss_sums", "cnf_loss_grad_fixed")
 
 
 class CnfConfig(C.Structure):
@@ -80,6 +80,8 @@ def load():
     lib.cnf_inference_fixed.argtypes = [vp, C.c_int, C.c_int, C.c_float, C.c_float, fp, fp, fp,
                                         C.c_int64, fp, fp, fp, vp]
     lib.cnf_loss_sums.argtypes = [vp, fp, fp, C.c_int64, fp, vp]
+    lib.cnf_loss_grad_fixed.argtypes = [vp, C.c_int, C.c_int, C.c_float, C.c_float, fp, fp, fp, C.c_int64,
+                                        fp, fp, vp]
     for name in EXPORTS:
         getattr(lib, name)  # AttributeError if the ABI is incomplete
     _lib = lib

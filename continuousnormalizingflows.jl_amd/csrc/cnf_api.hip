@@ -58,6 +58,12 @@ struct cnf_handle {
     float* kbuf = nullptr;        // 6 stage derivatives + 1 state, each S x kbuf_B
     int64_t kbuf_B = 0;
     float* loss_partial = nullptr;
+    // parameter gradient (cnf_loss_grad_fixed)
+    std::vector<size_t> w_off, b_off;   // Lux offsets given to cnf_set_params
+    float* grad_packed = nullptr;        // plain f32 operand image for the reverse sweep
+    float* grad_ws = nullptr;            // checkpoints + logp + regs
+    size_t grad_ws_bytes = 0;
+    int num_cus = 0;
 };
 
 static int ensure_ws(cnf_handle* h, int64_t B) {
@@ -158,6 +164,8 @@ int cnf_destroy(cnf_handle* h) {
     if (h->ws) (void)hipFree(h->ws);
     if (h->kbuf) (void)hipFree(h->kbuf);
     if (h->loss_partial) (void)hipFree(h->loss_partial);
+    if (h->grad_packed) (void)hipFree(h->grad_packed);
+    if (h->grad_ws) (void)hipFree(h->grad_ws);
     if (h->plan) mfma_plan_destroy(h->plan);
     delete h;
     return CNF_OK;
@@ -204,6 +212,16 @@ int cnf_set_params(cnf_handle* h, const float* p, size_t n, const size_t* w_off,
             h->net.w_off[l] = (int)w_off[l];
             h->net.b_off[l] = (int)b_off[l];
         }
+    }
+    h->w_off.assign(w_off, w_off + c.n_layers);
+    h->b_off.assign(b_off, b_off + c.n_layers);
+    if (h->path == CNF_PATH_MFMA && grad_supported(c)) {
+        const size_t gb = grad_packed_bytes();
+        if (!h->grad_packed) HIP_TRY(hipMalloc((void**)&h->grad_packed, gb));
+        std::vector<float> gp(gb / sizeof(float), 0.f);
+        grad_pack(c, host.data(), w_off, b_off, gp.data());
+        HIP_TRY(hipMemcpyAsync(h->grad_packed, gp.data(), gb, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipStreamSynchronize(st));
     }
     h->nparams = n;
     h->have_params = true;
@@ -336,6 +354,56 @@ int cnf_loss_sums(cnf_handle* h, const float* logp, const float* regs, int64_t B
     DeviceGuard g(h->cfg.device_id);
     if (!h->loss_partial) HIP_TRY(hipMalloc((void**)&h->loss_partial, 256 * 4 * sizeof(float)));
     HIP_TRY(loss_sums(logp, regs, B, h->loss_partial, sums4, (hipStream_t)stream));
+    return CNF_OK;
+}
+
+int cnf_loss_grad_fixed(cnf_handle* h, int alg, int nsteps, float t0, float t1, const float* x,
+                        const float* eps, const float* ys, int64_t B, float* grad, float* sums4,
+                        void* stream) {
+    int rc = check_call(h, eps, ys, B, "cnf_loss_grad_fixed");
+    if (rc) return rc;
+    if (nsteps < 1) return fail(CNF_ERR_INVALID, "cnf_loss_grad_fixed: nsteps >= 1 required");
+    if (alg != CNF_ALG_RK4 && alg != CNF_ALG_TSIT5) return fail(CNF_ERR_INVALID, "cnf_loss_grad_fixed: unknown alg");
+    if (!x || !grad) return fail(CNF_ERR_INVALID, "cnf_loss_grad_fixed: null x/grad");
+    if (h->path != CNF_PATH_MFMA || !grad_supported(h->cfg) || !h->grad_packed)
+        return fail(CNF_ERR_UNSUPPORTED, "cnf_loss_grad_fixed: configuration not covered by the gradient kernel "
+                                         "(Hutchinson VJP, K=1, no regularisers/conditions, 3 tanh layers of 49..64, D 5..8)");
+    DeviceGuard g(h->cfg.device_id);
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipMemsetAsync(grad, 0, h->nparams * sizeof(float), st));
+    if (B == 0) {
+        if (sums4) HIP_TRY(hipMemsetAsync(sums4, 0, 4 * sizeof(float), st));
+        return CNF_OK;
+    }
+    if (h->num_cus == 0) {
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, h->cfg.device_id));
+        h->num_cus = prop.multiProcessorCount;
+    }
+    const long long ntiles = (B + 15) / 16;
+    const size_t ckpt_floats = (size_t)(nsteps + 1) * (size_t)ntiles * 64 * 2;   // ZR = 2
+    const size_t slab_floats = grad_slab_floats(h->num_cus);
+    const size_t need = (ckpt_floats + 4 * (size_t)B + slab_floats) * sizeof(float);
+    if (need > h->grad_ws_bytes) {
+        if (h->grad_ws) HIP_TRY(hipFree(h->grad_ws));
+        h->grad_ws = nullptr; h->grad_ws_bytes = 0;
+        HIP_TRY(hipMalloc((void**)&h->grad_ws, need));
+        h->grad_ws_bytes = need;
+    }
+    float* ckpt = h->grad_ws;
+    float* logp = ckpt + ckpt_floats;
+    float* regs = logp + B;
+    float* slab = regs + 3 * (size_t)B;
+    SolveArgs a{};
+    a.x = x; a.eps = eps; a.ys = ys; a.B = B; a.nsteps = nsteps; a.alg = alg; a.t0 = t0; a.t1 = t1;
+    a.logp = logp; a.regs = regs; a.nvars = h->cfg.nvars; a.reg_aug = 0; a.ckpt = ckpt;
+    HIP_TRY(mfma_solve(h->plan, h->packed_dev, a, st));
+    if (sums4) {
+        if (!h->loss_partial) HIP_TRY(hipMalloc((void**)&h->loss_partial, 256 * 4 * sizeof(float)));
+        HIP_TRY(loss_sums(logp, regs, B, h->loss_partial, sums4, st));
+    }
+    HIP_TRY(grad_launch(h->cfg, h->grad_packed, ckpt, eps, h->w_off.data(), h->b_off.data(), alg, nsteps, t0, t1,
+                        B, slab, grad, h->num_cus, st));
     return CNF_OK;
 }
 

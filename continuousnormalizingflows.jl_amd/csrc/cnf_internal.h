@@ -63,7 +63,17 @@ struct SolveArgs {
     float* logp;     // B or null
     float* regs;     // 3B or null
     int nvars, reg_aug;
+    float* ckpt;     // optional checkpoint buffer (see KArgs::ckpt)
 };
 hipError_t mfma_solve(MfmaPlan* p, const float* packed_dev, const SolveArgs& a, hipStream_t st);
+
+// ---- parameter gradient (cnf_grad.hip) ----
+bool grad_supported(const cnf_config& c);
+size_t grad_packed_bytes();
+size_t grad_slab_floats(int num_cus);
+void grad_pack(const cnf_config& c, const float* lux, const size_t* w_off, const size_t* b_off, float* packed);
+hipError_t grad_launch(const cnf_config& c, const float* packed_dev, const float* ckpt, const float* eps,
+                       const size_t* w_off, const size_t* b_off, int alg, int nsteps, float t0, float t1,
+                       long long B, float* slab, float* grad, int num_cus, hipStream_t st);
 
 }  // namespace cnf

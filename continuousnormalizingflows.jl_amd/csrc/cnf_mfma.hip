@@ -262,6 +262,15 @@ void mfma_pack(const MfmaPlan* p, const float* lux, const size_t* w_off, const s
     pack_vecC(packed + Y.v_bN, Y.DT, D, [&](int f) { return Bv(L, f); });
 }
 
+// operand image for the gradient kernel: f32, no tanh pre-scale, forward + transposed (HT=4, L=3, ZR=2)
+void grad_pack(const cnf_config& c, const float* lux, const size_t* w_off, const size_t* b_off, float* packed) {
+    MfmaPlan p;
+    p.HT = 4; p.L = 3; p.ZR = 2; p.CR = 0; p.with_bwd = true; p.arith = 0; p.fwd_scale = 1.f;
+    p.lay = MfmaLayout(4, 3, 2, 0, true, 0);
+    p.cfg = c;
+    mfma_pack(&p, lux, w_off, b_off, packed);
+}
+
 hipError_t mfma_solve(MfmaPlan* p, const float* packed_dev, const SolveArgs& s, hipStream_t st) {
     if (s.B == 0) return hipSuccess;
     MfmaPlan* mp = p;   // caches the CU count and owns the optional queue word
@@ -277,7 +286,7 @@ hipError_t mfma_solve(MfmaPlan* p, const float* packed_dev, const SolveArgs& s, 
     KArgs a{};
     a.packed = packed_dev;
     a.x = s.x; a.u0 = s.u0; a.eps = s.eps; a.ys = s.ys;
-    a.u_out = s.u_out; a.logp = s.logp; a.regs = s.regs;
+    a.u_out = s.u_out; a.logp = s.logp; a.regs = s.regs; a.ckpt = s.ckpt;
     a.B = s.B; a.nsteps = s.nsteps; a.t0 = s.t0;
     a.dt = s.nsteps > 0 ? (s.t1 - s.t0) / (float)s.nsteps : 0.f;
     a.nvars = s.nvars; a.D = p->cfg.nvars + p->cfg.naug; a.C = p->cfg.ncond;

@@ -377,6 +377,10 @@ mfma_solve_kernel(KArgs a) {
 #pragma clang loop unroll(disable)
         for (int step = 0; step < nsteps; ++step) {
             const float tn = a.t0 + (float)step * dt;
+            if (a.ckpt) {
+#pragma unroll
+                for (int s = 0; s < ZR; ++s) a.ckpt[(((long long)step * ntiles + tile) * 64 + lane) * ZR + s] = z[s];
+            }
 #pragma clang loop unroll(disable)
             for (int st = 0; st < ns; ++st) {
                 float zs[ZR];
@@ -430,6 +434,10 @@ mfma_solve_kernel(KArgs a) {
             }
             tile = next_tile;
             continue;
+        }
+        if (a.ckpt) {
+#pragma unroll
+            for (int s = 0; s < ZR; ++s) a.ckpt[(((long long)a.nsteps * ntiles + tile) * 64 + lane) * ZR + s] = z[s];
         }
         // ---- epilogue: inference_sol (src/core/base_icnf.jl:158-172) ----
         float ss = 0.f, sa = 0.f;

@@ -31,7 +31,7 @@ __all__ = [
     "ICNF", "TrainMode", "TestMode", "Dense", "Chain", "tanh", "softplus", "identity",
     "HIPVecJacMatrixMode", "HIPJacVecMatrixMode", "LuxVecJacMatrixMode", "LuxJacVecMatrixMode",
     "DIVecJacMatrixMode", "DIJacVecMatrixMode", "Tsit5", "RK4", "setup", "inference", "generate",
-    "loss", "augmented_f",
+    "loss", "augmented_f", "loss_and_gradient",
 ]
 
 
@@ -513,3 +513,33 @@ def loss(icnf: ICNF, mode: Mode, *args, eps: Optional[torch.Tensor] = None, grou
     logp, (E, n, A) = inference(icnf, mode, *args, eps=eps)
     sums = loss_sums(icnf, mode, logp, torch.stack([E, n, A]))
     return reduce_loss(sums, logp.numel(), (icnf.lambda1, icnf.lambda2, icnf.lambda3), group=group)
+
+
+def loss_and_gradient(icnf: ICNF, mode: Mode, *args, eps: Optional[torch.Tensor] = None, group=None):
+    """(loss, dloss/dps) for `loss(icnf, mode, xs, ps, st)` — what `Zygote.gradient` of the
+    reference's training objective returns (src/exts/mlj_ext/core_icnf.jl:42-51), here the exact
+    gradient of the discrete fixed-step loss, computed by the reverse-sweep HIP kernel.  With
+    torch.distributed initialised the column shards' gradients (nparams floats) and loss sums are
+    all-reduced (RCCL over xGMI) and every rank returns the global mean and its gradient."""
+    from .sharding import reduce_loss
+    xs, ys, ps, st = _split_args(icnf, args, "loss_and_gradient")
+    h = icnf._handle(mode)
+    icnf._bind_params(h, ps)
+    dev = icnf.device
+    x = _colmajor(xs, icnf.nvariables, "xs", dev)
+    B = x.shape[0]
+    e = _draw_eps(icnf, icnf.nprobes, B) if eps is None else _colmajor(eps, icnf.nprobes * icnf.D, "eps", dev)
+    t0, t1 = icnf._steer_tspan(mode)
+    grad = torch.empty(ps.numel(), device=dev, dtype=torch.float32)
+    sums = torch.empty(4, device=dev, dtype=torch.float32)
+    _lib.check(h.lib.cnf_loss_grad_fixed(h.ptr, icnf._solver(), icnf._nsteps(t0, t1), t0, t1, _ptr(x), _ptr(e),
+                                         None, B, _ptr(grad), _ptr(sums), _stream_ptr(dev)))
+    import torch.distributed as dist
+    Bg = float(B)
+    if dist.is_available() and dist.is_initialized():
+        cnt = torch.tensor([Bg], device=dev, dtype=torch.float64)
+        dist.all_reduce(grad, op=dist.ReduceOp.SUM, group=group)
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM, group=group)
+        Bg = float(cnt.item())
+    value = reduce_loss(sums, B, (icnf.lambda1, icnf.lambda2, icnf.lambda3), group=group)
+    return value, grad / Bg

@@ -140,6 +140,20 @@ int cnf_inference_fixed(cnf_handle* h, int alg, int nsteps, float t0, float t1, 
 int cnf_loss_sums(cnf_handle* h, const float* logp, const float* regs, int64_t B, float* sums4,
                   void* stream);
 
+/* Gradient of the summed negative log-density with respect to the parameters, through the
+ * fixed-step solve (discretise-then-optimise reverse mode):
+ *     grad[k] = d/dp_k  sum_j ( -logp_j )        over the B columns given,
+ * the quantity Zygote obtains for `loss` via QuadratureAdjoint + ZygoteVJP in the reference's
+ * training loop (src/core/icnf.jl:90-99; src/exts/mlj_ext/core_icnf.jl:42-51), here exact for the
+ * discrete solve.  grad: device, n floats in the layout of cnf_set_params' p (overwritten).
+ * sums4 (device, may be NULL): as cnf_loss_sums.  The caller all-reduces grad and sums4 across
+ * column shards and divides by the global column count.
+ * First implementation: Hutchinson VJP, K = 1, no regularisers, no conditions, 3 tanh hidden
+ * layers of width 49..64, 5 <= D <= 8 (the headline shape); CNF_ERR_UNSUPPORTED otherwise. */
+int cnf_loss_grad_fixed(cnf_handle* h, int alg, int nsteps, float t0, float t1, const float* x,
+                        const float* eps, const float* ys, int64_t B, float* grad, float* sums4,
+                        void* stream);
+
 #ifdef __cplusplus
 }
 #endif

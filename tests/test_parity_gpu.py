@@ -199,6 +199,62 @@ def test_split_bf16_is_refused_where_not_implemented(pkg, oracles):
     assert e.value.code == pkg._lib.ERR_UNSUPPORTED
 
 
+def grad_icnf(pkg, spec, alg, nsteps):
+    icnf = make_icnf(pkg, spec, alg, nsteps, path=2)
+    icnf.lambda1 = icnf.lambda2 = icnf.lambda3 = 0.0
+    return icnf
+
+
+def test_parameter_gradient_matches_golden_fixture(pkg, oracles):
+    """dloss/dp of the discrete loss (reverse-sweep kernel, csrc/cnf_grad.hip) against the committed
+    fp64 autograd fixture: cfg2 shape, B = 8, Tsit5 x 10.  Tolerance: float32 accumulation of a
+    sum over 8 samples x 60 stages, relative to the gradient's scale."""
+    import os
+    from conftest import GOLDEN
+    o64, _ = oracles
+    f = np.load(os.path.join(GOLDEN, "grad_cfg2_d8_3x64_tsit5.npz"))
+    spec = o64.make_spec(nvars=8, hidden=[64, 64, 64])
+    icnf = grad_icnf(pkg, spec, 1, int(f["nsteps"]))
+    val, g = pkg.loss_and_gradient(icnf, pkg.TrainMode(False), dev(f["xs"]), dev(f["p"]), {}, eps=dev(f["eps"]))
+    g = g.cpu().numpy().astype(np.float64)
+    assert abs(float(val) - float(f["loss"])) < 1e-4
+    scale = np.abs(f["grad"]).max()
+    assert np.max(np.abs(g - f["grad"])) < 2e-5 * scale + 1e-6, np.max(np.abs(g - f["grad"])) / scale
+
+
+@pytest.mark.parametrize("D,H,B,alg,nsteps", [(8, 64, 100, 0, 6), (6, 56, 37, 1, 4)])
+def test_parameter_gradient_matches_autograd_oracle(D, H, B, alg, nsteps, pkg, oracles):
+    """Ragged batches (partial tiles), RK4 and Tsit5, padded D and H: gradient vs the fp64 oracle,
+    plus the bias rows and the time column explicitly."""
+    o64, _ = oracles
+    spec = o64.make_spec(nvars=D, hidden=[H, H, H])
+    p, xs, eps, _ = o64.synth_inputs(spec, B, 5 + D, bias_scale=0.2)
+    L, gref = o64.loss_and_grad(spec, p, xs, 0.0, 1.0, nsteps, alg, eps)
+    icnf = grad_icnf(pkg, spec, alg, nsteps)
+    val, g = pkg.loss_and_gradient(icnf, pkg.TrainMode(False), dev(xs), dev(p), {}, eps=dev(eps))
+    g = g.cpu().numpy().astype(np.float64)
+    assert abs(float(val) - L) < 1e-4
+    scale = np.abs(gref).max()
+    err = np.abs(g - gref)
+    assert err.max() < 5e-5 * scale + 1e-6, (err.max() / scale, int(err.argmax()))
+    w_off, b_off, _ = spec.param_offsets()
+    tcol = slice(w_off[0] + H * D, w_off[0] + H * (D + 1))       # d/dW_1[:, time column]
+    assert np.abs(gref[tcol]).max() > 0 and err[tcol].max() < 5e-5 * scale + 1e-6
+    for l in range(4):
+        bs = slice(b_off[l], b_off[l] + spec.widths[l + 1])
+        assert err[bs].max() < 5e-5 * scale + 1e-6
+
+
+def test_parameter_gradient_is_refused_outside_its_shape(pkg, oracles):
+    o64, _ = oracles
+    spec = o64.make_spec(nvars=2, hidden=[32, 32])
+    p, xs, eps, _ = o64.synth_inputs(spec, 16, 1)
+    icnf = grad_icnf(pkg, spec, 1, 10)
+    with pytest.raises(pkg._lib.CnfError) as e:
+        pkg.loss_and_gradient(icnf, pkg.TrainMode(False), dev(xs), dev(p), {}, eps=dev(eps))
+    assert e.value.code == pkg._lib.ERR_UNSUPPORTED
+
+
 def test_empty_batch_is_a_no_op(pkg, oracles):
     o64, _ = oracles
     spec = o64.make_spec(nvars=8, hidden=[64, 64, 64])
