@@ -8,4 +8,5 @@ not a valid Python identifier; `__graft_entry__.load_package()` registers it as 
 from . import _lib
 from .icnf import *  # noqa: F401,F403
 from .icnf import loss_sums  # noqa: F401
-from .sharding import reduce_loss, shard_columns  # noqa: F401
+from .icnf import loss_and_gradient  # noqa: F401
+from .sharding import reduce_gradient, reduce_loss, shard_columns  # noqa: F401

@@ -521,7 +521,7 @@ def loss_and_gradient(icnf: ICNF, mode: Mode, *args, eps: Optional[torch.Tensor]
     gradient of the discrete fixed-step loss, computed by the reverse-sweep HIP kernel.  With
     torch.distributed initialised the column shards' gradients (nparams floats) and loss sums are
     all-reduced (RCCL over xGMI) and every rank returns the global mean and its gradient."""
-    from .sharding import reduce_loss
+    from .sharding import reduce_gradient, reduce_loss
     xs, ys, ps, st = _split_args(icnf, args, "loss_and_gradient")
     h = icnf._handle(mode)
     icnf._bind_params(h, ps)
@@ -534,12 +534,5 @@ def loss_and_gradient(icnf: ICNF, mode: Mode, *args, eps: Optional[torch.Tensor]
     sums = torch.empty(4, device=dev, dtype=torch.float32)
     _lib.check(h.lib.cnf_loss_grad_fixed(h.ptr, icnf._solver(), icnf._nsteps(t0, t1), t0, t1, _ptr(x), _ptr(e),
                                          None, B, _ptr(grad), _ptr(sums), _stream_ptr(dev)))
-    import torch.distributed as dist
-    Bg = float(B)
-    if dist.is_available() and dist.is_initialized():
-        cnt = torch.tensor([Bg], device=dev, dtype=torch.float64)
-        dist.all_reduce(grad, op=dist.ReduceOp.SUM, group=group)
-        dist.all_reduce(cnt, op=dist.ReduceOp.SUM, group=group)
-        Bg = float(cnt.item())
     value = reduce_loss(sums, B, (icnf.lambda1, icnf.lambda2, icnf.lambda3), group=group)
-    return value, grad / Bg
+    return value, reduce_gradient(grad, B, group=group)

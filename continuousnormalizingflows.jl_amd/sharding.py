@@ -36,3 +36,15 @@ def reduce_loss(sums4: torch.Tensor, B_local: int, lambdas: Sequence[float],
         dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
     lam = torch.tensor([1.0, *[float(l) for l in lambdas]], device=buf.device, dtype=torch.float64)
     return ((buf[:4] * lam).sum() / buf[4]).to(torch.float32)
+
+
+def reduce_gradient(grad_sum: torch.Tensor, B_local: int, group=None) -> torch.Tensor:
+    """Summed per-shard gradient (nparams floats) -> gradient of the global mean loss on every
+    rank: the one collective of the training path whose size is not a handful of scalars
+    (37-580 KiB over xGMI; one all-reduce, no bucketing needed at this size)."""
+    import torch.distributed as dist
+    cnt = torch.tensor([float(B_local)], device=grad_sum.device, dtype=torch.float64)
+    if dist.is_available() and dist.is_initialized():
+        dist.all_reduce(grad_sum, op=dist.ReduceOp.SUM, group=group)
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM, group=group)
+    return grad_sum / cnt.to(grad_sum.dtype)

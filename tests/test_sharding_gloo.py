@@ -36,7 +36,16 @@ def _worker(rank, world, port, q):
         full = oc.inference_fixed(spec, p, xs, 0.0, 1.0, 8, o64.ALG_TSIT5, eps)
         same = bool(np.array_equal(full[0][lo:hi], logp))
         ref = float(np.mean(-full[0].astype(np.float64) + lam[0] * full[1][0] + lam[1] * full[1][1]))
-        q.put((rank, got, ref, same))
+        # gradient path: per-shard summed gradients (fp64 autograd oracle standing in for the
+        # reverse-sweep kernel) all-reduced to the gradient of the global mean loss
+        s1 = o64.make_spec(4, [16, 16])
+        p1, x1, e1, _ = o64.synth_inputs(s1, 11, 22, bias_scale=0.1)
+        l1, h1 = pkg.shard_columns(11, rank, world)
+        _, gs = o64.loss_and_grad(s1, p1, x1[:, l1:h1], 0.0, 1.0, 3, o64.ALG_RK4, e1[:, l1:h1])
+        gred = pkg.reduce_gradient(torch.tensor(gs * (h1 - l1)), h1 - l1).numpy()
+        _, gfull = o64.loss_and_grad(s1, p1, x1, 0.0, 1.0, 3, o64.ALG_RK4, e1)
+        gerr = float(np.max(np.abs(gred - gfull)))
+        q.put((rank, got, ref, same, gerr))
     finally:
         dist.destroy_process_group()
 
@@ -53,7 +62,8 @@ def test_two_rank_sharded_loss_matches_unsharded():
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    for rank, got, ref, same in res:
+    for rank, got, ref, same, gerr in res:
         assert same, "sharded columns differ from the unsharded run"
         assert abs(got - ref) < 1e-5 * max(1.0, abs(ref)), (rank, got, ref)
+        assert gerr < 1e-12, gerr
     assert res[0][1] == res[1][1]                    # every rank returns the same global mean
