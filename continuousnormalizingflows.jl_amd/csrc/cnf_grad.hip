@@ -71,36 +71,42 @@ __device__ __forceinline__ void frags_B(float* __restrict__ scr, int lane, const
 __device__ __forceinline__ f32x4 slab_load(const float* p) {
     return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
 }
+// The old tile values are fetched PD tiles ahead of their MFMA chains (the L2 round trip is ~700
+// cycles; a chain is 128-256), so only the first PD loads of a matrix are exposed.
+template <int MT, int NT, bool TWO>
+__device__ __forceinline__ void outer_rmw_impl(float* __restrict__ img, int lane, const float (&af1)[MT][4],
+                                               const float (&bf1)[NT][4], const float (&af2)[MT][4],
+                                               const float (&bf2)[NT][4]) {
+    constexpr int NTILE = MT * NT;
+    constexpr int PD = NTILE < 4 ? NTILE : 4;
+    float* base = img + lane * 4;
+    f32x4 old[PD];
+#pragma unroll
+    for (int t = 0; t < PD; ++t) old[t] = slab_load(base + t * 256);
+#pragma unroll
+    for (int t = 0; t < NTILE; ++t) {
+        const int mt = t / NT, nt = t % NT;
+        f32x4 acc = old[t % PD];
+        if (t + PD < NTILE) old[t % PD] = slab_load(base + (t + PD) * 256);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc = mfma4(af1[mt][s], bf1[nt][s], acc);
+        if constexpr (TWO) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) acc = mfma4(af2[mt][s], bf2[nt][s], acc);
+        }
+        *reinterpret_cast<f32x4*>(base + t * 256) = acc;
+    }
+}
 template <int MT, int NT>
 __device__ __forceinline__ void outer_rmw(float* __restrict__ img, int lane, const float (&af)[MT][4],
                                           const float (&bf)[NT][4]) {
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            float* p = img + ((mt * NT + nt) * 64 + lane) * 4;
-            f32x4 acc = slab_load(p);
-#pragma unroll
-            for (int s = 0; s < 4; ++s) acc = mfma4(af[mt][s], bf[nt][s], acc);
-            *reinterpret_cast<f32x4*>(p) = acc;
-        }
+    outer_rmw_impl<MT, NT, false>(img, lane, af, bf, af, bf);
 }
 template <int MT, int NT>
 __device__ __forceinline__ void outer_rmw2(float* __restrict__ img, int lane, const float (&af1)[MT][4],
                                            const float (&bf1)[NT][4], const float (&af2)[MT][4],
                                            const float (&bf2)[NT][4]) {
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            float* p = img + ((mt * NT + nt) * 64 + lane) * 4;
-            f32x4 acc = slab_load(p);
-#pragma unroll
-            for (int s = 0; s < 4; ++s) acc = mfma4(af1[mt][s], bf1[nt][s], acc);
-#pragma unroll
-            for (int s = 0; s < 4; ++s) acc = mfma4(af2[mt][s], bf2[nt][s], acc);
-            *reinterpret_cast<f32x4*>(p) = acc;
-        }
+    outer_rmw_impl<MT, NT, true>(img, lane, af1, bf1, af2, bf2);
 }
 
 template <int MT>
