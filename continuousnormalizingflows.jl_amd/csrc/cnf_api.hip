@@ -358,16 +358,16 @@ int cnf_loss_sums(cnf_handle* h, const float* logp, const float* regs, int64_t B
 }
 
 int cnf_loss_grad_fixed(cnf_handle* h, int alg, int nsteps, float t0, float t1, const float* x,
-                        const float* eps, const float* ys, int64_t B, float* grad, float* sums4,
-                        void* stream) {
+                        const float* eps, const float* ys, int64_t B, const float* lambdas,
+                        float* grad, float* sums4, void* stream) {
     int rc = check_call(h, eps, ys, B, "cnf_loss_grad_fixed");
     if (rc) return rc;
     if (nsteps < 1) return fail(CNF_ERR_INVALID, "cnf_loss_grad_fixed: nsteps >= 1 required");
     if (alg != CNF_ALG_RK4 && alg != CNF_ALG_TSIT5) return fail(CNF_ERR_INVALID, "cnf_loss_grad_fixed: unknown alg");
-    if (!x || !grad) return fail(CNF_ERR_INVALID, "cnf_loss_grad_fixed: null x/grad");
+    if (!x || !grad || !lambdas) return fail(CNF_ERR_INVALID, "cnf_loss_grad_fixed: null x/grad/lambdas");
     if (h->path != CNF_PATH_MFMA || !grad_supported(h->cfg) || !h->grad_packed)
         return fail(CNF_ERR_UNSUPPORTED, "cnf_loss_grad_fixed: configuration not covered by the gradient kernel "
-                                         "(Hutchinson VJP, K=1, no regularisers/conditions, 3 tanh layers of 49..64, D 5..8)");
+                                         "(Hutchinson VJP, K=1, no conditions, 3 tanh layers of 49..64, D 5..8)");
     DeviceGuard g(h->cfg.device_id);
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(hipMemsetAsync(grad, 0, h->nparams * sizeof(float), st));
@@ -396,14 +396,16 @@ int cnf_loss_grad_fixed(cnf_handle* h, int alg, int nsteps, float t0, float t1, 
     float* slab = regs + 3 * (size_t)B;
     SolveArgs a{};
     a.x = x; a.eps = eps; a.ys = ys; a.B = B; a.nsteps = nsteps; a.alg = alg; a.t0 = t0; a.t1 = t1;
-    a.logp = logp; a.regs = regs; a.nvars = h->cfg.nvars; a.reg_aug = 0; a.ckpt = ckpt;
+    const int reg_aug = (h->cfg.reg_aug && h->cfg.naug > 0) ? 1 : 0;
+    a.logp = logp; a.regs = regs; a.nvars = h->cfg.nvars; a.reg_aug = reg_aug; a.ckpt = ckpt;
     HIP_TRY(mfma_solve(h->plan, h->packed_dev, a, st));
     if (sums4) {
         if (!h->loss_partial) HIP_TRY(hipMalloc((void**)&h->loss_partial, 256 * 4 * sizeof(float)));
         HIP_TRY(loss_sums(logp, regs, B, h->loss_partial, sums4, st));
     }
+    const float lam[3] = {h->cfg.reg_z ? lambdas[0] : 0.f, h->cfg.reg_j ? lambdas[1] : 0.f, reg_aug ? lambdas[2] : 0.f};
     HIP_TRY(grad_launch(h->cfg, h->grad_packed, ckpt, eps, h->w_off.data(), h->b_off.data(), alg, nsteps, t0, t1,
-                        B, slab, grad, h->num_cus, st));
+                        B, lam, slab, grad, h->num_cus, st));
     return CNF_OK;
 }
 

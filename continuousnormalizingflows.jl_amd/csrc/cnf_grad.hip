@@ -5,6 +5,10 @@
 // With a fixed-step solver the exact gradient of the discrete loss is reverse mode through the RK
 // steps (discretise-then-optimise): grad = sum_j d(-logp_j)/dp over the batch columns given.
 //
+// Regularised objective (TrainMode{true}: + l1 |zdot| + l2 |eps^T J| + l3 |z_aug|, icnf.jl:184-251,628-637):
+//   kbar += c_E zdot/|zdot|;  gbar = c_n g/|g| - c_l eps with g = W_1[:,0:D]^T delta_1;  dbar_1 = W_1[:,0:D] gbar
+//   (the hoisted-q shortcut is the special case c_n = 0);  lambda_N += l3 z_aug/|z_aug|.
+//
 // Two launches per gradient: the forward solve kernel (cnf_mfma_kernel.h) with step checkpoints
 // z_n, then this reverse sweep.  Per wave: one 16-sample tile, steps in reverse; per stage
 //   recompute   h_l, act'_l                                   (forward images)
@@ -35,7 +39,8 @@ struct GArgs {
     long long B;
     int nsteps;
     float t0, dt;
-    int D, H, n_in, autonomous;
+    int D, H, n_in, autonomous, nvars;
+    float lam1, lam2, lam3;   // weights of Edot, ndot, Adot in the objective (0 = term off)
     int w_off[4], b_off[4];   // Lux offsets of the L+1 <= 4 Dense layers
     Tableau T;
 };
@@ -210,6 +215,15 @@ mfma_grad_kernel(GArgs a) {
             // dL/dz_N = z_N  (L = sum_j -logp_j, -log N(z) = |z|^2/2 + const); zero for padding columns
             lam[s] = valid ? a.ckpt[(((long long)a.nsteps * ntiles + tile) * 64 + lane) * ZR + s] : 0.f;
         }
+        if (a.lam3 != 0.f) {   // + l3 |z_aug|_2 at the final time (src/core/base_icnf.jl:106-122)
+            float sa = 0.f;
+#pragma unroll
+            for (int s = 0; s < ZR; ++s) { const int f = 4 * s + g; if (f >= a.nvars && f < D) sa = fmaf(lam[s], lam[s], sa); }
+            sa = group_sum(sa);
+            const float inv = sa > 0.f ? a.lam3 * rsqrtf(sa) : 0.f;
+#pragma unroll
+            for (int s = 0; s < ZR; ++s) { const int f = 4 * s + g; if (f >= a.nvars && f < D) lam[s] = fmaf(inv, lam[s], lam[s]); }
+        }
         f32x4 cvec[HT], qvec[HT];   // c = W_N^T eps, q = W_1[:,0:D] eps: constant over the solve
         zero_tiles<HT>(cvec);
         zero_tiles<HT>(qvec);
@@ -276,6 +290,8 @@ mfma_grad_kernel(GArgs a) {
                     kbar[s] = dt * kb;
                 }
                 const float cl = valid ? dt * bi : 0.f;   // cotangent of ldot: dL/d(dlogp) = +1
+                const float cE = cl * a.lam1, cn = cl * a.lam2;   // cotangents of Edot, ndot
+                const bool regz = a.lam1 != 0.f, regj = a.lam2 != 0.f;   // wave-uniform
                 const float tt = tn + a.T.c[st] * dt;
                 int opaque = 0;
                 asm volatile("" : "+v"(opaque));
@@ -294,9 +310,43 @@ mfma_grad_kernel(GArgs a) {
                     for (int mt = 0; mt < HT; ++mt) dl[l - 1][mt] = u[l - 1][mt] * d[l - 1][mt];
                 }
                 // (3) bottom-up through the pullback: dbar, second-order terms, Wbar_{l+1} += delta_{l+1} ubar_l^T
-                f32x4 db[HT], a2[L][HT];   // a2_l = dbar_l .* u_l  (multiplies act''_l later)
+                if (regz) {   // Edot = |zdot|: kbar += c_E zdot / |zdot|
+                    f32x4 zacc[DT];
+                    load_cvec<DT>(sm + LAY.v_bN, g, zacc);
+                    gemm_tiles<DT, 4 * HT>(sm + LAY.fN, lane, TileIn<HT>{h[L - 1]}, zacc);
+                    float e2 = 0.f;
 #pragma unroll
-                for (int mt = 0; mt < HT; ++mt) db[mt] = qvec[mt] * (-cl);
+                    for (int s = 0; s < ZR; ++s) e2 = fmaf(zacc[s >> 2][s & 3], zacc[s >> 2][s & 3], e2);
+                    e2 = group_sum(e2);
+                    const float inv = e2 > 0.f ? cE * rsqrtf(e2) : 0.f;
+#pragma unroll
+                    for (int s = 0; s < ZR; ++s) kbar[s] = fmaf(inv, zacc[s >> 2][s & 3], kbar[s]);
+                }
+                // gbar = cotangent of g = eps^T J (dense layout): -c_l eps (+ c_n g/|g|)
+                float gbar[ZR];
+#pragma unroll
+                for (int s = 0; s < ZR; ++s) gbar[s] = -cl * eps[s];
+                f32x4 db[HT], a2[L][HT];   // a2_l = dbar_l .* u_l  (multiplies act''_l later)
+                if (regj) {
+                    f32x4 gacc[DT];
+                    zero_tiles<DT>(gacc);
+                    gemm_tiles<DT, 4 * HT>(sm + LAY.b1, lane, TileIn<HT>{dl[0]}, gacc);   // g = W_1[:,0:D]^T delta_1
+                    float n2 = 0.f;
+#pragma unroll
+                    for (int s = 0; s < ZR; ++s) n2 = fmaf(gacc[s >> 2][s & 3], gacc[s >> 2][s & 3], n2);
+                    n2 = group_sum(n2);
+                    const float inv = n2 > 0.f ? cn * rsqrtf(n2) : 0.f;
+#pragma unroll
+                    for (int s = 0; s < ZR; ++s) gbar[s] = fmaf(inv, gacc[s >> 2][s & 3], gbar[s]);
+                    zero_tiles<HT>(db);
+                    gemm_tiles<HT, ZR>(sm + LAY.f1z, lane, RegIn<ZR>{gbar}, db);              // dbar_1 = W_1[:,0:D] gbar
+                } else {
+#pragma unroll
+                    for (int mt = 0; mt < HT; ++mt) db[mt] = qvec[mt] * (-cl);                // = W_1[:,0:D] (-c_l eps)
+                }
+                f32x4 gb_tile[1];
+                gb_tile[0] = f32x4{gbar[0], ZR > 1 ? gbar[ZR > 1 ? 1 : 0] : 0.f, ZR > 2 ? gbar[ZR > 2 ? 2 : 0] : 0.f,
+                                   ZR > 3 ? gbar[ZR > 3 ? 3 : 0] : 0.f};
                 f32x4 ubs[L > 1 ? L - 1 : 1][HT];   // ubar_l kept: its outer product is merged with the top-down one
 #pragma unroll
                 for (int l = 0; l < L - 1; ++l) {
@@ -357,14 +407,11 @@ mfma_grad_kernel(GArgs a) {
                             if (4 * r + g == 15) v = 1.f;
                             in_tile[0][r] = v;
                         }
-                        // Wbar_1 += abar_1 [z; t; 1]^T + qbar [eps; 0]^T with qbar = -c_l delta_1
-                        f32x4 qb[HT];
-#pragma unroll
-                        for (int mt = 0; mt < HT; ++mt) qb[mt] = dl[0][mt] * (-cl);
+                        // Wbar_1 += abar_1 [z; t; 1]^T + delta_1 [gbar; 0]^T   (g = W_1[:,0:D]^T delta_1)
                         float bf[1][4], af2[HT][4], bf2[1][4];
                         frags_B<1>(scrB, lane, in_tile, bf);
-                        frags_A<HT>(scrC, lane, qb, af2);
-                        frags_B<1>(scrB + 256, lane, eps_tile, bf2);
+                        frags_A<HT>(scrC, lane, dl[0], af2);
+                        frags_B<1>(scrB + 256, lane, gb_tile, bf2);
                         outer_rmw2<HT, 1>(slab + SL::W1, lane, af, bf, af2, bf2);
                         f32x4 zb[DT];
                         zero_tiles<DT>(zb);
@@ -430,7 +477,7 @@ grad_reduce_kernel(const float* __restrict__ slab, int nwaves, GArgs a, float* _
 // host side
 // ---------------------------------------------------------------------------------------
 bool grad_supported(const cnf_config& c) {
-    if (c.mode != CNF_MODE_HUTCH_VJP || c.nprobes != 1 || c.ncond != 0 || c.reg_z || c.reg_j || c.reg_aug) return false;
+    if (c.mode != CNF_MODE_HUTCH_VJP || c.nprobes != 1 || c.ncond != 0) return false;
     if (c.n_layers != 4 || c.acts[3] != CNF_ACT_IDENTITY) return false;
     for (int l = 0; l < 3; ++l)
         if (c.acts[l] != CNF_ACT_TANH || c.widths[l + 1] != c.widths[1]) return false;
@@ -443,7 +490,7 @@ size_t grad_slab_floats(int num_cus) { return (size_t)num_cus * 4 * GradSlab<4, 
 
 hipError_t grad_launch(const cnf_config& c, const float* packed_dev, const float* ckpt, const float* eps,
                        const size_t* w_off, const size_t* b_off, int alg, int nsteps, float t0, float t1,
-                       long long B, float* slab, float* grad, int num_cus, hipStream_t st) {
+                       long long B, const float lam[3], float* slab, float* grad, int num_cus, hipStream_t st) {
     using G = GradLds<4, 3, 2, CNF_ACT_TANH>;
     using SL = GradSlab<4, 3, 2>;
     auto kern = mfma_grad_kernel<4, 3, 2, CNF_ACT_TANH>;
@@ -460,7 +507,8 @@ hipError_t grad_launch(const cnf_config& c, const float* packed_dev, const float
     GArgs a{};
     a.packed = packed_dev; a.ckpt = ckpt; a.eps = eps; a.slab = slab; a.B = B;
     a.nsteps = nsteps; a.t0 = t0; a.dt = (t1 - t0) / (float)nsteps;
-    a.D = c.nvars + c.naug; a.H = c.widths[1]; a.n_in = c.widths[0]; a.autonomous = c.autonomous;
+    a.D = c.nvars + c.naug; a.H = c.widths[1]; a.n_in = c.widths[0]; a.autonomous = c.autonomous; a.nvars = c.nvars;
+    a.lam1 = lam[0]; a.lam2 = lam[1]; a.lam3 = lam[2];
     for (int l = 0; l < 4; ++l) { a.w_off[l] = (int)w_off[l]; a.b_off[l] = (int)b_off[l]; }
     a.T = make_tableau(alg);
     const long long ntiles = (B + 15) / 16;

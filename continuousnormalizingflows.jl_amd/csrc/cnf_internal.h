@@ -74,6 +74,6 @@ size_t grad_slab_floats(int num_cus);
 void grad_pack(const cnf_config& c, const float* lux, const size_t* w_off, const size_t* b_off, float* packed);
 hipError_t grad_launch(const cnf_config& c, const float* packed_dev, const float* ckpt, const float* eps,
                        const size_t* w_off, const size_t* b_off, int alg, int nsteps, float t0, float t1,
-                       long long B, float* slab, float* grad, int num_cus, hipStream_t st);
+                       long long B, const float lam[3], float* slab, float* grad, int num_cus, hipStream_t st);
 
 }  // namespace cnf

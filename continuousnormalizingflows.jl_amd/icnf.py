@@ -532,7 +532,8 @@ def loss_and_gradient(icnf: ICNF, mode: Mode, *args, eps: Optional[torch.Tensor]
     t0, t1 = icnf._steer_tspan(mode)
     grad = torch.empty(ps.numel(), device=dev, dtype=torch.float32)
     sums = torch.empty(4, device=dev, dtype=torch.float32)
+    lam = (C.c_float * 3)(icnf.lambda1, icnf.lambda2, icnf.lambda3)
     _lib.check(h.lib.cnf_loss_grad_fixed(h.ptr, icnf._solver(), icnf._nsteps(t0, t1), t0, t1, _ptr(x), _ptr(e),
-                                         None, B, _ptr(grad), _ptr(sums), _stream_ptr(dev)))
+                                         None, B, lam, _ptr(grad), _ptr(sums), _stream_ptr(dev)))
     value = reduce_loss(sums, B, (icnf.lambda1, icnf.lambda2, icnf.lambda3), group=group)
     return value, reduce_gradient(grad, B, group=group)

@@ -142,17 +142,19 @@ int cnf_loss_sums(cnf_handle* h, const float* logp, const float* regs, int64_t B
 
 /* Gradient of the summed negative log-density with respect to the parameters, through the
  * fixed-step solve (discretise-then-optimise reverse mode):
- *     grad[k] = d/dp_k  sum_j ( -logp_j )        over the B columns given,
+ *     grad[k] = d/dp_k  sum_j ( -logp_j + l1 Edot_j + l2 ndot_j + l3 Adot_j )    over the B columns given
+ * (lambdas = {l1, l2, l3}, host pointer; a term is active only if the handle's reg_z / reg_j /
+ * reg_aug flag is set, i.e. for TrainMode{true} with a non-zero lambda, src/core/icnf.jl:628-637),
  * the quantity Zygote obtains for `loss` via QuadratureAdjoint + ZygoteVJP in the reference's
  * training loop (src/core/icnf.jl:90-99; src/exts/mlj_ext/core_icnf.jl:42-51), here exact for the
  * discrete solve.  grad: device, n floats in the layout of cnf_set_params' p (overwritten).
  * sums4 (device, may be NULL): as cnf_loss_sums.  The caller all-reduces grad and sums4 across
  * column shards and divides by the global column count.
- * First implementation: Hutchinson VJP, K = 1, no regularisers, no conditions, 3 tanh hidden
- * layers of width 49..64, 5 <= D <= 8 (the headline shape); CNF_ERR_UNSUPPORTED otherwise. */
+ * First implementation: Hutchinson VJP, K = 1, no conditions, 3 tanh hidden layers of width
+ * 49..64, 5 <= D <= 8 (the headline shape, FFJORD and RNODE losses); CNF_ERR_UNSUPPORTED otherwise. */
 int cnf_loss_grad_fixed(cnf_handle* h, int alg, int nsteps, float t0, float t1, const float* x,
-                        const float* eps, const float* ys, int64_t B, float* grad, float* sums4,
-                        void* stream);
+                        const float* eps, const float* ys, int64_t B, const float* lambdas,
+                        float* grad, float* sums4, void* stream);
 
 #ifdef __cplusplus
 }
