@@ -215,8 +215,8 @@ int cnf_set_params(cnf_handle* h, const float* p, size_t n, const size_t* w_off,
     }
     h->w_off.assign(w_off, w_off + c.n_layers);
     h->b_off.assign(b_off, b_off + c.n_layers);
-    if (h->path == CNF_PATH_MFMA && grad_supported(c)) {
-        const size_t gb = grad_packed_bytes();
+    if (h->path == CNF_PATH_MFMA && mfma_plan_is_per_wave(h->plan) && grad_supported(c)) {
+        const size_t gb = grad_packed_bytes(c);
         if (!h->grad_packed) HIP_TRY(hipMalloc((void**)&h->grad_packed, gb));
         std::vector<float> gp(gb / sizeof(float), 0.f);
         grad_pack(c, host.data(), w_off, b_off, gp.data());
@@ -367,7 +367,7 @@ int cnf_loss_grad_fixed(cnf_handle* h, int alg, int nsteps, float t0, float t1, 
     if (!x || !grad || !lambdas) return fail(CNF_ERR_INVALID, "cnf_loss_grad_fixed: null x/grad/lambdas");
     if (h->path != CNF_PATH_MFMA || !grad_supported(h->cfg) || !h->grad_packed)
         return fail(CNF_ERR_UNSUPPORTED, "cnf_loss_grad_fixed: configuration not covered by the gradient kernel "
-                                         "(Hutchinson VJP, K=1, no conditions, 3 tanh layers of 49..64, D 5..8)");
+                                         "(Hutchinson VJP, K=1, no conditions, 2-3 equal tanh/softplus hidden layers of width <= 64, D <= 14)");
     DeviceGuard g(h->cfg.device_id);
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(hipMemsetAsync(grad, 0, h->nparams * sizeof(float), st));
@@ -381,8 +381,9 @@ int cnf_loss_grad_fixed(cnf_handle* h, int alg, int nsteps, float t0, float t1, 
         h->num_cus = prop.multiProcessorCount;
     }
     const long long ntiles = (B + 15) / 16;
-    const size_t ckpt_floats = (size_t)(nsteps + 1) * (size_t)ntiles * 64 * 2;   // ZR = 2
-    const size_t slab_floats = grad_slab_floats(h->num_cus);
+    const int ckpt_zr = mfma_plan_zr(h->plan);
+    const size_t ckpt_floats = (size_t)(nsteps + 1) * (size_t)ntiles * 64 * (size_t)ckpt_zr;
+    const size_t slab_floats = grad_slab_floats(h->cfg, h->num_cus);
     const size_t need = (ckpt_floats + 4 * (size_t)B + slab_floats) * sizeof(float);
     if (need > h->grad_ws_bytes) {
         if (h->grad_ws) HIP_TRY(hipFree(h->grad_ws));
@@ -404,7 +405,7 @@ int cnf_loss_grad_fixed(cnf_handle* h, int alg, int nsteps, float t0, float t1, 
         HIP_TRY(loss_sums(logp, regs, B, h->loss_partial, sums4, st));
     }
     const float lam[3] = {h->cfg.reg_z ? lambdas[0] : 0.f, h->cfg.reg_j ? lambdas[1] : 0.f, reg_aug ? lambdas[2] : 0.f};
-    HIP_TRY(grad_launch(h->cfg, h->grad_packed, ckpt, eps, h->w_off.data(), h->b_off.data(), alg, nsteps, t0, t1,
+    HIP_TRY(grad_launch(h->cfg, h->grad_packed, ckpt, ckpt_zr, eps, h->w_off.data(), h->b_off.data(), alg, nsteps, t0, t1,
                         B, lam, slab, grad, h->num_cus, st));
     return CNF_OK;
 }

@@ -33,7 +33,8 @@ namespace cnf {
 
 struct GArgs {
     const float* packed;   // operand image: f32, no tanh pre-scale, forward + transposed
-    const float* ckpt;     // [nsteps+1][ntiles][64][ZR]
+    const float* ckpt;     // [nsteps+1][ntiles][64][ckpt_zr]  (ckpt_zr = state k-steps of the forward instance)
+    int ckpt_zr;
     const float* eps;      // D x B
     float* slab;           // [waves][GradSlab::TOTAL] floats, zeroed by the host
     long long B;
@@ -114,6 +115,16 @@ __device__ __forceinline__ void outer_rmw2(float* __restrict__ img, int lane, co
     outer_rmw_impl<MT, NT, true>(img, lane, af1, bf1, af2, bf2);
 }
 
+// dense-layout D-vector (register s, lane group g <-> feature 4s+g) as one accumulator-layout tile
+template <int ZR>
+__device__ __forceinline__ f32x4 dense_tile(const float (&v)[ZR]) {
+    static_assert(ZR <= 4, "gradient kernel: D <= 16");
+    f32x4 t = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < ZR; ++s) t[s] = v[s];
+    return t;
+}
+
 template <int MT>
 __device__ __forceinline__ void zero_tiles(f32x4 (&t)[MT]) {
 #pragma unroll
@@ -177,7 +188,6 @@ mfma_grad_kernel(GArgs a) {
     using G = GradLds<HT, L, ZR, ACT>;
     constexpr MfmaLayout LAY(HT, L, ZR, 0, true, 0);
     constexpr int DT = G::DT;
-    static_assert(ACT == CNF_ACT_TANH, "gradient kernel: tanh hidden activations");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     {
         const f32x4* src = reinterpret_cast<const f32x4*>(a.packed);
@@ -213,7 +223,7 @@ mfma_grad_kernel(GArgs a) {
             const int f = 4 * s + g;
             eps[s] = f < D ? a.eps[sc * D + f] : 0.f;
             // dL/dz_N = z_N  (L = sum_j -logp_j, -log N(z) = |z|^2/2 + const); zero for padding columns
-            lam[s] = valid ? a.ckpt[(((long long)a.nsteps * ntiles + tile) * 64 + lane) * ZR + s] : 0.f;
+            lam[s] = valid ? a.ckpt[(((long long)a.nsteps * ntiles + tile) * 64 + lane) * a.ckpt_zr + s] : 0.f;
         }
         if (a.lam3 != 0.f) {   // + l3 |z_aug|_2 at the final time (src/core/base_icnf.jl:106-122)
             float sa = 0.f;
@@ -231,15 +241,14 @@ mfma_grad_kernel(GArgs a) {
         gemm_tiles<HT, ZR>(smem + LAY.f1z, lane, RegIn<ZR>{eps}, qvec);
         // eps as an accumulator-layout pseudo tile (rows = state features)
         f32x4 eps_tile[1];
-        eps_tile[0] = f32x4{eps[0], ZR > 1 ? eps[ZR > 1 ? 1 : 0] : 0.f, ZR > 2 ? eps[ZR > 2 ? 2 : 0] : 0.f,
-                            ZR > 3 ? eps[ZR > 3 ? 3 : 0] : 0.f};
+        eps_tile[0] = dense_tile<ZR>(eps);
 
 #pragma clang loop unroll(disable)
         for (int step = a.nsteps - 1; step >= 0; --step) {
             const float tn = a.t0 + (float)step * dt;
             float zn[ZR];
 #pragma unroll
-            for (int s = 0; s < ZR; ++s) zn[s] = a.ckpt[(((long long)step * ntiles + tile) * 64 + lane) * ZR + s];
+            for (int s = 0; s < ZR; ++s) zn[s] = a.ckpt[(((long long)step * ntiles + tile) * 64 + lane) * a.ckpt_zr + s];
             // ---- forward sweep of the step: stage derivatives kz_i (z rows only) ----
             float kz[6][ZR];
 #pragma unroll
@@ -345,8 +354,7 @@ mfma_grad_kernel(GArgs a) {
                     for (int mt = 0; mt < HT; ++mt) db[mt] = qvec[mt] * (-cl);                // = W_1[:,0:D] (-c_l eps)
                 }
                 f32x4 gb_tile[1];
-                gb_tile[0] = f32x4{gbar[0], ZR > 1 ? gbar[ZR > 1 ? 1 : 0] : 0.f, ZR > 2 ? gbar[ZR > 2 ? 2 : 0] : 0.f,
-                                   ZR > 3 ? gbar[ZR > 3 ? 3 : 0] : 0.f};
+                gb_tile[0] = dense_tile<ZR>(gbar);
                 f32x4 ubs[L > 1 ? L - 1 : 1][HT];   // ubar_l kept: its outer product is merged with the top-down one
 #pragma unroll
                 for (int l = 0; l < L - 1; ++l) {
@@ -360,8 +368,7 @@ mfma_grad_kernel(GArgs a) {
                 for (int mt = 0; mt < HT; ++mt) { cb[mt] = db[mt] * d[L - 1][mt]; a2[L - 1][mt] = db[mt] * cvec[mt]; }
                 // (4) top-down through the forward chain
                 f32x4 kb_tile[1];
-                kb_tile[0] = f32x4{kbar[0], ZR > 1 ? kbar[ZR > 1 ? 1 : 0] : 0.f, ZR > 2 ? kbar[ZR > 2 ? 2 : 0] : 0.f,
-                                   ZR > 3 ? kbar[ZR > 3 ? 3 : 0] : 0.f};
+                kb_tile[0] = dense_tile<ZR>(kbar);
                 {   // Wbar_N += eps cbar^T + kbar h_L^T (one chain per tile);  bbar_N = kbar x ones
                     float af1[1][4], bf1[HT][4], af2[1][4], bf2[HT][4];
                     frags_A<1>(scrA, lane, eps_tile, af1);
@@ -380,7 +387,8 @@ mfma_grad_kernel(GArgs a) {
                     f32x4 ab[HT];
 #pragma unroll
                     for (int mt = 0; mt < HT; ++mt) {
-                        const f32x4 d2 = h[l][mt] * d[l][mt] * -2.f;          // tanh'' = -2 h (1 - h^2)
+                        // act'': tanh -> -2 h (1 - h^2);  softplus -> s (1 - s) with s = act' = sigmoid(a)
+                        const f32x4 d2 = ACT == CNF_ACT_TANH ? h[l][mt] * d[l][mt] * -2.f : d[l][mt] * (1.f - d[l][mt]);
                         ab[mt] = hb[mt] * d[l][mt] + a2[l][mt] * d2;
                     }
                     float af[HT][4];
@@ -476,51 +484,79 @@ grad_reduce_kernel(const float* __restrict__ slab, int nwaves, GArgs a, float* _
 // ---------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------
-bool grad_supported(const cnf_config& c) {
-    if (c.mode != CNF_MODE_HUTCH_VJP || c.nprobes != 1 || c.ncond != 0) return false;
-    if (c.n_layers != 4 || c.acts[3] != CNF_ACT_IDENTITY) return false;
-    for (int l = 0; l < 3; ++l)
-        if (c.acts[l] != CNF_ACT_TANH || c.widths[l + 1] != c.widths[1]) return false;
-    const int D = c.nvars + c.naug, H = c.widths[1];
-    return H > 48 && H <= 64 && D > 4 && D <= 8;   // HT = 4, ZR = 2: the headline shape
+struct GradInst {
+    int HT, L, ZR, ACT;
+    int lds_bytes, slab_total, packed_floats;
+    void (*kern)(GArgs);
+    void (*reduce)(const float*, int, GArgs, float*);
+};
+#define GRAD_INST(HT, L, ZR, ACT)                                                                       \
+    GradInst { HT, L, ZR, ACT, GradLds<HT, L, ZR, ACT>::TOTAL * 4, GradSlab<HT, L, ZR>::TOTAL,          \
+               MfmaLayout(HT, L, ZR, 0, true, 0).total, &mfma_grad_kernel<HT, L, ZR, ACT>,            \
+               &grad_reduce_kernel<HT, L, ZR> }
+#define GRAD_SHAPES(ACT)                                                                                \
+    GRAD_INST(4, 3, 2, ACT), GRAD_INST(4, 2, 2, ACT), GRAD_INST(2, 3, 2, ACT), GRAD_INST(2, 2, 2, ACT), \
+    GRAD_INST(1, 3, 2, ACT), GRAD_INST(1, 2, 2, ACT), GRAD_INST(4, 3, 4, ACT), GRAD_INST(4, 2, 4, ACT), \
+    GRAD_INST(2, 3, 4, ACT), GRAD_INST(2, 2, 4, ACT), GRAD_INST(3, 3, 2, ACT), GRAD_INST(3, 2, 2, ACT), \
+    GRAD_INST(3, 3, 4, ACT), GRAD_INST(3, 2, 4, ACT)
+static const GradInst kGrad[] = {GRAD_SHAPES(CNF_ACT_TANH), GRAD_SHAPES(CNF_ACT_SOFTPLUS)};
+
+static const GradInst* grad_find(const cnf_config& c) {
+    if (c.mode != CNF_MODE_HUTCH_VJP || c.nprobes != 1 || c.ncond != 0) return nullptr;
+    const int N = c.n_layers, L = N - 1;
+    if (L < 2 || L > 3 || c.acts[N - 1] != CNF_ACT_IDENTITY) return nullptr;
+    const int H = c.widths[1];
+    for (int l = 0; l < L; ++l)
+        if (c.acts[l] != c.acts[0] || c.widths[l + 1] != H) return nullptr;
+    const int D = c.nvars + c.naug, HT = (H + 15) / 16, ZR = (D + 3) / 4;
+    if (D + (c.autonomous ? 0 : 1) > 15) return nullptr;   // input tile: 16 columns, the last one is the bias column
+    const GradInst* best = nullptr;
+    for (const GradInst& g : kGrad)
+        if (g.HT == HT && g.L == L && g.ACT == c.acts[0] && g.ZR >= ZR && (!best || g.ZR < best->ZR)) best = &g;
+    return best;
 }
 
-size_t grad_packed_bytes() { return (size_t)MfmaLayout(4, 3, 2, 0, true, 0).total * sizeof(float); }
-size_t grad_slab_floats(int num_cus) { return (size_t)num_cus * 4 * GradSlab<4, 3, 2>::TOTAL; }
+bool grad_supported(const cnf_config& c) { return grad_find(c) != nullptr; }
+size_t grad_packed_bytes(const cnf_config& c) { return (size_t)grad_find(c)->packed_floats * sizeof(float); }
+size_t grad_slab_floats(const cnf_config& c, int num_cus) { return (size_t)num_cus * 4 * grad_find(c)->slab_total; }
+void grad_shape(const cnf_config& c, int* HT, int* L, int* ZR) {
+    const GradInst* g = grad_find(c);
+    *HT = g->HT; *L = g->L; *ZR = g->ZR;
+}
 
-hipError_t grad_launch(const cnf_config& c, const float* packed_dev, const float* ckpt, const float* eps,
+hipError_t grad_launch(const cnf_config& c, const float* packed_dev, const float* ckpt, int ckpt_zr, const float* eps,
                        const size_t* w_off, const size_t* b_off, int alg, int nsteps, float t0, float t1,
                        long long B, const float lam[3], float* slab, float* grad, int num_cus, hipStream_t st) {
-    using G = GradLds<4, 3, 2, CNF_ACT_TANH>;
-    using SL = GradSlab<4, 3, 2>;
-    auto kern = mfma_grad_kernel<4, 3, 2, CNF_ACT_TANH>;
-    constexpr int lds = G::TOTAL * (int)sizeof(float);
-    static unsigned long long done_mask = 0;
+    const GradInst* gi = grad_find(c);
+    if (!gi) return hipErrorNotSupported;
+    // > 64 KB of dynamic LDS has to be enabled once per device and kernel
+    static unsigned long long done_mask[sizeof(kGrad) / sizeof(kGrad[0])] = {};
+    const int idx = (int)(gi - kGrad);
     int dev = 0;
     hipError_t e0 = hipGetDevice(&dev);
     if (e0 != hipSuccess) return e0;
-    if (!(done_mask >> (dev & 63) & 1ull)) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (!(done_mask[idx] >> (dev & 63) & 1ull)) {
+        hipError_t e = hipFuncSetAttribute((const void*)gi->kern, hipFuncAttributeMaxDynamicSharedMemorySize, gi->lds_bytes);
         if (e != hipSuccess) return e;
-        done_mask |= 1ull << (dev & 63);
+        done_mask[idx] |= 1ull << (dev & 63);
     }
     GArgs a{};
-    a.packed = packed_dev; a.ckpt = ckpt; a.eps = eps; a.slab = slab; a.B = B;
+    a.packed = packed_dev; a.ckpt = ckpt; a.ckpt_zr = ckpt_zr; a.eps = eps; a.slab = slab; a.B = B;
     a.nsteps = nsteps; a.t0 = t0; a.dt = (t1 - t0) / (float)nsteps;
     a.D = c.nvars + c.naug; a.H = c.widths[1]; a.n_in = c.widths[0]; a.autonomous = c.autonomous; a.nvars = c.nvars;
     a.lam1 = lam[0]; a.lam2 = lam[1]; a.lam3 = lam[2];
-    for (int l = 0; l < 4; ++l) { a.w_off[l] = (int)w_off[l]; a.b_off[l] = (int)b_off[l]; }
+    for (int l = 0; l < c.n_layers; ++l) { a.w_off[l] = (int)w_off[l]; a.b_off[l] = (int)b_off[l]; }
     a.T = make_tableau(alg);
     const long long ntiles = (B + 15) / 16;
     const long long want = (ntiles + 3) / 4;
     const int nblocks = (int)(want < num_cus ? want : num_cus);
     const int nwaves = nblocks * 4;
-    hipError_t e = hipMemsetAsync(slab, 0, (size_t)nwaves * SL::TOTAL * sizeof(float), st);
+    hipError_t e = hipMemsetAsync(slab, 0, (size_t)nwaves * gi->slab_total * sizeof(float), st);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(256), lds, st, a);
+    hipLaunchKernelGGL(gi->kern, dim3(nblocks), dim3(256), gi->lds_bytes, st, a);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((grad_reduce_kernel<4, 3, 2>), dim3((SL::TOTAL + 255) / 256), dim3(256), 0, st, slab, nwaves, a, grad);
+    hipLaunchKernelGGL(gi->reduce, dim3((gi->slab_total + 255) / 256), dim3(256), 0, st, slab, nwaves, a, grad);
     return hipGetLastError();
 }
 

@@ -262,11 +262,16 @@ void mfma_pack(const MfmaPlan* p, const float* lux, const size_t* w_off, const s
     pack_vecC(packed + Y.v_bN, Y.DT, D, [&](int f) { return Bv(L, f); });
 }
 
-// operand image for the gradient kernel: f32, no tanh pre-scale, forward + transposed (HT=4, L=3, ZR=2)
+// operand image for the gradient kernel: f32, no tanh pre-scale, forward + transposed
+int mfma_plan_zr(const MfmaPlan* p) { return p->ZR; }
+bool mfma_plan_is_per_wave(const MfmaPlan* p) { return p->kind == 0; }
+
 void grad_pack(const cnf_config& c, const float* lux, const size_t* w_off, const size_t* b_off, float* packed) {
+    int HT, L, ZR;
+    grad_shape(c, &HT, &L, &ZR);
     MfmaPlan p;
-    p.HT = 4; p.L = 3; p.ZR = 2; p.CR = 0; p.with_bwd = true; p.arith = 0; p.fwd_scale = 1.f;
-    p.lay = MfmaLayout(4, 3, 2, 0, true, 0);
+    p.HT = HT; p.L = L; p.ZR = ZR; p.CR = 0; p.with_bwd = true; p.arith = 0; p.fwd_scale = 1.f;
+    p.lay = MfmaLayout(HT, L, ZR, 0, true, 0);
     p.cfg = c;
     mfma_pack(&p, lux, w_off, b_off, packed);
 }

@@ -266,6 +266,31 @@ def test_parameter_gradient_of_the_regularised_objective(alg, nsteps, pkg, oracl
     assert np.max(np.abs(g0 - gref)) > 1e-3 * scale
 
 
+GRAD_SHAPES = [
+    # (make_spec kwargs, lambdas, B, alg, nsteps)
+    (dict(nvars=1, naug=2, hidden=[16, 16], act=2, reg_z=True, reg_j=True, reg_aug=True), (0.01, 0.01, 0.01), 50, 1, 4),  # reference default ICNF(nvariables=1), TrainMode{true}
+    (dict(nvars=2, hidden=[32, 32]), (0.0, 0.0, 0.0), 33, 1, 5),                                # cfg1 shape
+    (dict(nvars=2, naug=3, hidden=[24, 24], act=2, reg_z=True, reg_j=True), (0.02, 0.03, 0.0), 20, 0, 4),  # default net, nvariables=2
+    (dict(nvars=12, hidden=[48, 48, 48]), (0.0, 0.0, 0.0), 19, 0, 3),                           # D = 12 (padded state k-steps)
+    (dict(nvars=5, hidden=[64, 64], autonomous=True, act=2), (0.0, 0.0, 0.0), 17, 1, 3),        # autonomous, softplus, L = 2
+]
+
+
+@pytest.mark.parametrize("kw,lam,B,alg,nsteps", GRAD_SHAPES)
+def test_parameter_gradient_other_shapes_and_softplus(kw, lam, B, alg, nsteps, pkg, oracles):
+    o64, _ = oracles
+    spec = o64.make_spec(**kw)
+    p, xs, eps, _ = o64.synth_inputs(spec, B, 77, bias_scale=0.2)
+    L, gref = o64.loss_and_grad(spec, p, xs, 0.0, 1.0, nsteps, alg, eps, None, lam)
+    icnf = make_icnf(pkg, spec, alg, nsteps, path=2, lambdas=lam)
+    mode = pkg.TrainMode(bool(spec.reg_z or spec.reg_j or spec.reg_aug))
+    val, g = pkg.loss_and_gradient(icnf, mode, dev(xs), dev(p), {}, eps=dev(eps))
+    g = g.cpu().numpy().astype(np.float64)
+    assert abs(float(val) - L) < 1e-4
+    scale = np.abs(gref).max()
+    assert np.max(np.abs(g - gref)) < 5e-5 * scale + 1e-6, np.max(np.abs(g - gref)) / scale
+
+
 def test_gradient_descent_on_the_gradient_kernel_reduces_the_loss(pkg, oracles):
     """End-to-end use of the training path: a few Adam steps driven by loss_and_gradient lower the
     NLL of a shifted, scaled Gaussian (the role MLJ `fit` plays around the reference's loss)."""
@@ -294,7 +319,7 @@ def test_gradient_descent_on_the_gradient_kernel_reduces_the_loss(pkg, oracles):
 
 def test_parameter_gradient_is_refused_outside_its_shape(pkg, oracles):
     o64, _ = oracles
-    spec = o64.make_spec(nvars=2, hidden=[32, 32])
+    spec = o64.make_spec(nvars=32, hidden=[256, 256, 256])       # cooperative-kernel shape: no gradient yet
     p, xs, eps, _ = o64.synth_inputs(spec, 16, 1)
     icnf = grad_icnf(pkg, spec, 1, 10)
     with pytest.raises(pkg._lib.CnfError) as e:
