@@ -382,7 +382,10 @@ int cnf_loss_grad_fixed(cnf_handle* h, int alg, int nsteps, float t0, float t1, 
     }
     const long long ntiles = (B + 15) / 16;
     const int ckpt_zr = mfma_plan_zr(h->plan);
-    const size_t ckpt_floats = (size_t)(nsteps + 1) * (size_t)ntiles * 64 * (size_t)ckpt_zr;
+    const int nstages = alg == CNF_ALG_RK4 ? 4 : 6;
+    const size_t ckpt_z_floats = (size_t)(nsteps + 1) * (size_t)ntiles * 64 * (size_t)ckpt_zr;
+    const size_t ckpt_k_floats = (size_t)nsteps * nstages * (size_t)ntiles * 64 * (size_t)ckpt_zr;
+    const size_t ckpt_floats = ckpt_z_floats + ckpt_k_floats;
     const size_t slab_floats = grad_slab_floats(h->cfg, h->num_cus);
     const size_t need = (ckpt_floats + 4 * (size_t)B + slab_floats) * sizeof(float);
     if (need > h->grad_ws_bytes) {
@@ -392,20 +395,21 @@ int cnf_loss_grad_fixed(cnf_handle* h, int alg, int nsteps, float t0, float t1, 
         h->grad_ws_bytes = need;
     }
     float* ckpt = h->grad_ws;
+    float* ckpt_k = ckpt + ckpt_z_floats;
     float* logp = ckpt + ckpt_floats;
     float* regs = logp + B;
     float* slab = regs + 3 * (size_t)B;
     SolveArgs a{};
     a.x = x; a.eps = eps; a.ys = ys; a.B = B; a.nsteps = nsteps; a.alg = alg; a.t0 = t0; a.t1 = t1;
     const int reg_aug = (h->cfg.reg_aug && h->cfg.naug > 0) ? 1 : 0;
-    a.logp = logp; a.regs = regs; a.nvars = h->cfg.nvars; a.reg_aug = reg_aug; a.ckpt = ckpt;
+    a.logp = logp; a.regs = regs; a.nvars = h->cfg.nvars; a.reg_aug = reg_aug; a.ckpt = ckpt; a.ckpt_k = ckpt_k;
     HIP_TRY(mfma_solve(h->plan, h->packed_dev, a, st));
     if (sums4) {
         if (!h->loss_partial) HIP_TRY(hipMalloc((void**)&h->loss_partial, 256 * 4 * sizeof(float)));
         HIP_TRY(loss_sums(logp, regs, B, h->loss_partial, sums4, st));
     }
     const float lam[3] = {h->cfg.reg_z ? lambdas[0] : 0.f, h->cfg.reg_j ? lambdas[1] : 0.f, reg_aug ? lambdas[2] : 0.f};
-    HIP_TRY(grad_launch(h->cfg, h->grad_packed, ckpt, ckpt_zr, eps, h->w_off.data(), h->b_off.data(), alg, nsteps, t0, t1,
+    HIP_TRY(grad_launch(h->cfg, h->grad_packed, ckpt, ckpt_k, ckpt_zr, eps, h->w_off.data(), h->b_off.data(), alg, nsteps, t0, t1,
                         B, lam, slab, grad, h->num_cus, st));
     return CNF_OK;
 }

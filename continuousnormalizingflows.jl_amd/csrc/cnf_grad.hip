@@ -35,6 +35,7 @@ struct GArgs {
     const float* packed;   // operand image: f32, no tanh pre-scale, forward + transposed
     const float* ckpt;     // [nsteps+1][ntiles][64][ckpt_zr]  (ckpt_zr = state k-steps of the forward instance)
     int ckpt_zr;
+    const float* ckpt_k;   // stage derivatives [step * ns + stage][ntiles][64][ckpt_zr] or null (re-sweep)
     const float* eps;      // D x B
     float* slab;           // [waves][GradSlab::TOTAL] floats, zeroed by the host
     long long B;
@@ -255,6 +256,16 @@ mfma_grad_kernel(GArgs a) {
             for (int j = 0; j < 6; ++j)
 #pragma unroll
                 for (int s = 0; s < ZR; ++s) kz[j][s] = 0.f;
+            if (a.ckpt_k) {
+                // stage derivatives were checkpointed by the forward kernel
+#pragma unroll
+                for (int j = 0; j < 6; ++j)
+                    if (j < ns) {
+#pragma unroll
+                        for (int s = 0; s < ZR; ++s)
+                            kz[j][s] = a.ckpt_k[((((long long)step * ns + j) * ntiles + tile) * 64 + lane) * a.ckpt_zr + s];
+                    }
+            } else {
 #pragma clang loop unroll(disable)
             for (int st = 0; st < ns; ++st) {
                 float zs[ZR];
@@ -277,6 +288,7 @@ mfma_grad_kernel(GArgs a) {
                 for (int j = 0; j < 6; ++j)
 #pragma unroll
                     for (int s = 0; s < ZR; ++s) kz[j][s] = (j == st) ? zacc[s >> 2][s & 3] : kz[j][s];
+            }
             }
             // ---- reverse sweep over the stages ----
             float Zb[6][ZR];
@@ -524,7 +536,8 @@ void grad_shape(const cnf_config& c, int* HT, int* L, int* ZR) {
     *HT = g->HT; *L = g->L; *ZR = g->ZR;
 }
 
-hipError_t grad_launch(const cnf_config& c, const float* packed_dev, const float* ckpt, int ckpt_zr, const float* eps,
+hipError_t grad_launch(const cnf_config& c, const float* packed_dev, const float* ckpt, const float* ckpt_k,
+                       int ckpt_zr, const float* eps,
                        const size_t* w_off, const size_t* b_off, int alg, int nsteps, float t0, float t1,
                        long long B, const float lam[3], float* slab, float* grad, int num_cus, hipStream_t st) {
     const GradInst* gi = grad_find(c);
@@ -541,7 +554,7 @@ hipError_t grad_launch(const cnf_config& c, const float* packed_dev, const float
         done_mask[idx] |= 1ull << (dev & 63);
     }
     GArgs a{};
-    a.packed = packed_dev; a.ckpt = ckpt; a.ckpt_zr = ckpt_zr; a.eps = eps; a.slab = slab; a.B = B;
+    a.packed = packed_dev; a.ckpt = ckpt; a.ckpt_k = ckpt_k; a.ckpt_zr = ckpt_zr; a.eps = eps; a.slab = slab; a.B = B;
     a.nsteps = nsteps; a.t0 = t0; a.dt = (t1 - t0) / (float)nsteps;
     a.D = c.nvars + c.naug; a.H = c.widths[1]; a.n_in = c.widths[0]; a.autonomous = c.autonomous; a.nvars = c.nvars;
     a.lam1 = lam[0]; a.lam2 = lam[1]; a.lam3 = lam[2];

@@ -399,6 +399,11 @@ mfma_solve_kernel(KArgs a) {
                 dyn_eval<HT, L, ZR, CR, ACT, ENGINE, KP, PRE, ARITH>(smem + opaque, lane, tn + a.T.c[st] * dt, autonomous,
                                                               reg_z, reg_j, exact, D, zs, y, eps, pre_c, pre_q, zd,
                                                               ld, ed, nd);
+                if (a.ckpt_k) {
+#pragma unroll
+                    for (int s = 0; s < ZR; ++s)
+                        a.ckpt_k[((((long long)step * ns + st) * ntiles + tile) * 64 + lane) * ZR + s] = zd[s];
+                }
 #pragma unroll
                 for (int j = 0; j < 6; ++j) {
                     const bool hit = (j == st);
