@@ -327,6 +327,40 @@ def test_parameter_gradient_is_refused_outside_its_shape(pkg, oracles):
     assert e.value.code == pkg._lib.ERR_UNSUPPORTED
 
 
+def test_randomised_shapes_fused_vs_generic_kernels(pkg, oracles):
+    """60 random configurations (D, C, H, L, activation, trace mode, regularisers, integrator, ragged
+    B): wherever the library picks a fused MFMA instance, its result must agree with the generic
+    SIMT kernels — two independent GPU implementations of the same math."""
+    o64, _ = oracles
+    rng = np.random.default_rng(20240620)
+    checked = 0
+    for it in range(60):
+        D = int(rng.integers(1, 15))
+        naug = int(rng.integers(0, min(3, D)))
+        C = int(rng.choice([0, 0, 0, 3, 8, 13]))
+        H = int(rng.choice([8, 16, 24, 32, 40, 48, 64, 72, 96, 128]))
+        L = int(rng.choice([2, 3]))
+        act = int(rng.choice([1, 2]))
+        mode = int(rng.choice([0, 0, 1, 2]))
+        reg = bool(rng.integers(0, 2)) and mode != 2
+        kw = dict(nvars=D - naug, naug=naug, ncond=C, hidden=[H] * L, act=act, mode=mode,
+                  autonomous=bool(rng.integers(0, 4) == 0), reg_z=reg, reg_j=reg, reg_aug=reg and naug > 0)
+        spec = o64.make_spec(**kw)
+        alg, nsteps, B = int(rng.integers(0, 2)), int(rng.integers(2, 6)), int(rng.integers(1, 90))
+        if 2 not in paths_for(pkg, spec, alg, nsteps):
+            continue
+        p, xs, eps, ys = o64.synth_inputs(spec, B, 1000 + it, bias_scale=0.2)
+        a = run_inference(pkg, make_icnf(pkg, spec, alg, nsteps, path=2), spec, p, xs, eps, ys, return_state=True)
+        b = run_inference(pkg, make_icnf(pkg, spec, alg, nsteps, path=1), spec, p, xs, eps, ys, return_state=True)
+        err = float((a[0] - b[0]).abs().max())
+        assert err < 5e-5, (kw, alg, nsteps, B, err)
+        assert float((a[2] - b[2]).abs().max()) < 5e-5, kw
+        for u, v in zip(a[1], b[1]):
+            assert float((u - v).abs().max()) < 5e-5, kw
+        checked += 1
+    assert checked >= 30, checked
+
+
 def test_empty_batch_is_a_no_op(pkg, oracles):
     o64, _ = oracles
     spec = o64.make_spec(nvars=8, hidden=[64, 64, 64])
