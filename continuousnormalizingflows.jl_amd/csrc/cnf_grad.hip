@@ -37,6 +37,8 @@ struct GArgs {
     int ckpt_zr;
     const float* ckpt_k;   // stage derivatives [step * ns + stage][ntiles][64][ckpt_zr] or null (re-sweep)
     const float* eps;      // D x B
+    const float* ys;       // C x B or null
+    int C;
     float* slab;           // [waves][GradSlab::TOTAL] floats, zeroed by the host
     long long B;
     int nsteps;
@@ -132,19 +134,20 @@ __device__ __forceinline__ void zero_tiles(f32x4 (&t)[MT]) {
     for (int m = 0; m < MT; ++m) t[m] = f32x4{0.f, 0.f, 0.f, 0.f};
 }
 
-template <int HT, int L, int ZR, int ACT>
+template <int HT, int L, int ZR, int CR, int ACT>
 struct GradLds {   // float offsets inside dynamic LDS: operand image, then per-wave transpose scratch
-    static constexpr MfmaLayout LAY = MfmaLayout(HT, L, ZR, 0, true, 0);
+    static constexpr MfmaLayout LAY = MfmaLayout(HT, L, ZR, CR, true, 0);
     static constexpr int DT = (ZR + 3) / 4;
     static constexpr int SCR = (LAY.total + 3) / 4 * 4;
-    static constexpr int SCR_W = 3 * HT * 256;          // A tiles, B tiles, second B set
+    static constexpr int SCR_W = (3 * HT + 3) * 256;    // three HT-tile slots + three single-tile slots
     static constexpr int TOTAL = SCR + 4 * SCR_W;
 };
-template <int HT, int L, int ZR>
+template <int HT, int L, int ZR, int CR>
 struct GradSlab {  // float offsets inside one wave's slab; every image is [mt][nt][lane][4] (accumulator layout)
     static constexpr int DT = (ZR + 3) / 4;
-    static constexpr int W1 = 0;                                   // [HT][1]: H x 16 input columns (col 15 = bias 1)
-    static constexpr int WH = W1 + HT * 256;                       // (L-1) x [HT][HT]
+    static constexpr int NT1 = CR > 0 ? 2 : 1;                     // input tiles: [z; t; ...; 1@15] and [y (<= 16)]
+    static constexpr int W1 = 0;                                   // [HT][NT1]: H x 16 NT1 input columns
+    static constexpr int WH = W1 + HT * NT1 * 256;                       // (L-1) x [HT][HT]
     static constexpr int WN = WH + (L - 1) * HT * HT * 256;        // [DT][HT]
     static constexpr int BH = WN + DT * HT * 256;                  // (L-1) x [HT][1]: column 0 = bias of hidden layer l+1
     static constexpr int BN = BH + (L - 1) * HT * 256;             // [DT][1]: column 0 = bias of the last layer
@@ -152,10 +155,11 @@ struct GradSlab {  // float offsets inside one wave's slab; every image is [mt][
 };
 
 // forward chain: h_l, act'_l for every hidden layer
-template <int HT, int L, int ZR, int ACT>
+template <int HT, int L, int ZR, int CR, int ACT>
 __device__ __forceinline__ void grad_forward(const float* __restrict__ smem, int lane, float t, bool autonomous,
-                                             const float (&z)[ZR], f32x4 (&h)[L][HT], f32x4 (&d)[L][HT]) {
-    constexpr MfmaLayout LAY(HT, L, ZR, 0, true, 0);
+                                             const float (&z)[ZR], const float (&y)[CR > 0 ? CR : 1],
+                                             f32x4 (&h)[L][HT], f32x4 (&d)[L][HT]) {
+    constexpr MfmaLayout LAY(HT, L, ZR, CR, true, 0);
     const int g = lane >> 4;
     f32x4 acc[HT];
     load_cvec<HT>(smem + LAY.v_b1, g, acc);
@@ -166,6 +170,7 @@ __device__ __forceinline__ void grad_forward(const float* __restrict__ smem, int
         for (int mt = 0; mt < HT; ++mt) acc[mt] += wt[mt] * t;
     }
     gemm_tiles<HT, ZR>(smem + LAY.f1z, lane, RegIn<ZR>{z}, acc);
+    if constexpr (CR > 0) gemm_tiles<HT, CR>(smem + LAY.f1y, lane, RegIn<CR>{y}, acc);
 #pragma unroll
     for (int l = 0; l < L; ++l) {
         if (l > 0) {
@@ -183,11 +188,11 @@ __device__ __forceinline__ void grad_forward(const float* __restrict__ smem, int
     }
 }
 
-template <int HT, int L, int ZR, int ACT>
+template <int HT, int L, int ZR, int CR, int ACT>
 __global__ void __launch_bounds__(256)
 mfma_grad_kernel(GArgs a) {
-    using G = GradLds<HT, L, ZR, ACT>;
-    constexpr MfmaLayout LAY(HT, L, ZR, 0, true, 0);
+    using G = GradLds<HT, L, ZR, CR, ACT>;
+    constexpr MfmaLayout LAY(HT, L, ZR, CR, true, 0);
     constexpr int DT = G::DT;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     {
@@ -198,10 +203,13 @@ mfma_grad_kernel(GArgs a) {
     __syncthreads();
     const int lane = threadIdx.x & 63, g = lane >> 4, n = lane & 15;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    using SL = GradSlab<HT, L, ZR>;
+    using SL = GradSlab<HT, L, ZR, CR>;
     float* scrA = smem + G::SCR + wave * G::SCR_W;
     float* scrB = scrA + HT * 256;
     float* scrC = scrB + HT * 256;
+    float* scrS1 = scrC + HT * 256;   // single-tile slots (pseudo tiles: eps, kbar, gbar, inputs, y)
+    float* scrS2 = scrS1 + 256;
+    float* scrS3 = scrS2 + 256;
     float* slab = a.slab + ((long long)blockIdx.x * 4 + wave) * SL::TOTAL;
     // ones pseudo tile: feature 0 = 1 (bias columns); layer-1 input tile carries its ones at feature 15
     f32x4 ones_tile[1];
@@ -235,6 +243,14 @@ mfma_grad_kernel(GArgs a) {
 #pragma unroll
             for (int s = 0; s < ZR; ++s) { const int f = 4 * s + g; if (f >= a.nvars && f < D) lam[s] = fmaf(inv, lam[s], lam[s]); }
         }
+        float y[CR > 0 ? CR : 1];
+        y[0] = 0.f;
+        if constexpr (CR > 0) {
+#pragma unroll
+            for (int s = 0; s < CR; ++s) { const int f = 4 * s + g; y[s] = f < a.C ? a.ys[sc * a.C + f] : 0.f; }
+        }
+        f32x4 y_tile[1];
+        y_tile[0] = dense_tile<(CR > 0 ? CR : 1)>(y);   // condition rows as an accumulator-layout tile
         f32x4 cvec[HT], qvec[HT];   // c = W_N^T eps, q = W_1[:,0:D] eps: constant over the solve
         zero_tiles<HT>(cvec);
         zero_tiles<HT>(qvec);
@@ -280,7 +296,7 @@ mfma_grad_kernel(GArgs a) {
                 asm volatile("" : "+v"(opaque));
                 const float* sm = smem + opaque;
                 f32x4 h[L][HT], d[L][HT];
-                grad_forward<HT, L, ZR, ACT>(sm, lane, tn + a.T.c[st] * dt, autonomous, zs, h, d);
+                grad_forward<HT, L, ZR, CR, ACT>(sm, lane, tn + a.T.c[st] * dt, autonomous, zs, y, h, d);
                 f32x4 zacc[DT];
                 load_cvec<DT>(sm + LAY.v_bN, g, zacc);
                 gemm_tiles<DT, 4 * HT>(sm + LAY.fN, lane, TileIn<HT>{h[L - 1]}, zacc);
@@ -320,7 +336,7 @@ mfma_grad_kernel(GArgs a) {
 
                 // (1) recompute, (2) first-order pullback
                 f32x4 h[L][HT], d[L][HT], dl[L][HT], u[L][HT];
-                grad_forward<HT, L, ZR, ACT>(sm, lane, tt, autonomous, zs, h, d);
+                grad_forward<HT, L, ZR, CR, ACT>(sm, lane, tt, autonomous, zs, y, h, d);
 #pragma unroll
                 for (int mt = 0; mt < HT; ++mt) { u[L - 1][mt] = cvec[mt]; dl[L - 1][mt] = cvec[mt] * d[L - 1][mt]; }
 #pragma unroll
@@ -385,7 +401,7 @@ mfma_grad_kernel(GArgs a) {
                     float af1[1][4], bf1[HT][4], af2[1][4], bf2[HT][4];
                     frags_A<1>(scrA, lane, eps_tile, af1);
                     frags_B<HT>(scrB, lane, cb, bf1);
-                    frags_A<1>(scrA + 256, lane, kb_tile, af2);
+                    frags_A<1>(scrS1, lane, kb_tile, af2);
                     frags_B<HT>(scrC, lane, h[L - 1], bf2);
                     outer_rmw2<1, HT>(slab + SL::WN, lane, af1, bf1, af2, bf2);
                     outer_rmw<1, 1>(slab + SL::BN, lane, af2, onesf);
@@ -431,8 +447,22 @@ mfma_grad_kernel(GArgs a) {
                         float bf[1][4], af2[HT][4], bf2[1][4];
                         frags_B<1>(scrB, lane, in_tile, bf);
                         frags_A<HT>(scrC, lane, dl[0], af2);
-                        frags_B<1>(scrB + 256, lane, gb_tile, bf2);
-                        outer_rmw2<HT, 1>(slab + SL::W1, lane, af, bf, af2, bf2);
+                        frags_B<1>(scrS2, lane, gb_tile, bf2);
+                        if constexpr (CR > 0) {
+                            // image [HT][2]: column tile 0 (merged chain) and column tile 1 = abar_1 y^T
+                            float bfy[1][4];
+                            frags_B<1>(scrS3, lane, y_tile, bfy);
+#pragma unroll
+                            for (int mt = 0; mt < HT; ++mt) {
+                                float a1[1][4], a2f[1][4];
+#pragma unroll
+                                for (int q4 = 0; q4 < 4; ++q4) { a1[0][q4] = af[mt][q4]; a2f[0][q4] = af2[mt][q4]; }
+                                outer_rmw2<1, 1>(slab + SL::W1 + (mt * 2 + 0) * 256, lane, a1, bf, a2f, bf2);
+                                outer_rmw<1, 1>(slab + SL::W1 + (mt * 2 + 1) * 256, lane, a1, bfy);
+                            }
+                        } else {
+                            outer_rmw2<HT, 1>(slab + SL::W1, lane, af, bf, af2, bf2);
+                        }
                         f32x4 zb[DT];
                         zero_tiles<DT>(zb);
                         gemm_tiles<DT, 4 * HT>(sm + LAY.b1, lane, TileIn<HT>{ab}, zb);   // W_1[:,0:D]^T abar_1
@@ -459,21 +489,23 @@ mfma_grad_kernel(GArgs a) {
 
 // Sum the waves' slabs in a fixed order and scatter into the Lux-layout gradient (every parameter is
 // written by exactly one thread: no atomics).
-template <int HT, int L, int ZR>
+template <int HT, int L, int ZR, int CR>
 __global__ void __launch_bounds__(256)
 grad_reduce_kernel(const float* __restrict__ slab, int nwaves, GArgs a, float* __restrict__ grad) {
-    using SL = GradSlab<HT, L, ZR>;
+    using SL = GradSlab<HT, L, ZR, CR>;
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= SL::TOTAL) return;
     float sum = 0.f;
     for (int w = 0; w < nwaves; ++w) sum += slab[(long long)w * SL::TOTAL + e];
     const int H = a.H, D = a.D;
     const int ln = (e >> 2) & 63, r = e & 3, n = ln & 15, gg = ln >> 4;
-    if (e < SL::WH) {                                   // W_1 image: [mt][lane][r]
-        const int mt = (e - SL::W1) / 256;
+    if (e < SL::WH) {                                   // W_1 image: [mt][input tile][lane][r]
+        const int tl = (e - SL::W1) / 256, mt = tl / SL::NT1, it = tl % SL::NT1;
         const int out = 16 * mt + 4 * r + gg;
-        if (out < H && n < a.n_in) grad[a.w_off[0] + out + H * n] = sum;
-        if (out < H && n == 15) grad[a.b_off[0] + out] = sum;                  // ones column
+        const int ncore = D + (a.autonomous ? 0 : 1);   // z and time columns live in input tile 0
+        if (out < H && it == 0 && n < ncore) grad[a.w_off[0] + out + H * n] = sum;
+        if (out < H && it == 0 && n == 15) grad[a.b_off[0] + out] = sum;       // ones column
+        if (out < H && it == 1 && n < a.C) grad[a.w_off[0] + out + H * (ncore + n)] = sum;   // condition columns
     } else if (e < SL::WN) {                            // hidden images
         const int rel = e - SL::WH, l = rel / (HT * HT * 256), tl = (rel / 256) % (HT * HT);
         const int out = 16 * (tl / HT) + 4 * r + gg, in = 16 * (tl % HT) + n;
@@ -497,24 +529,23 @@ grad_reduce_kernel(const float* __restrict__ slab, int nwaves, GArgs a, float* _
 // host side
 // ---------------------------------------------------------------------------------------
 struct GradInst {
-    int HT, L, ZR, ACT;
+    int HT, L, ZR, CR, ACT;
     int lds_bytes, slab_total, packed_floats;
     void (*kern)(GArgs);
     void (*reduce)(const float*, int, GArgs, float*);
 };
-#define GRAD_INST(HT, L, ZR, ACT)                                                                       \
-    GradInst { HT, L, ZR, ACT, GradLds<HT, L, ZR, ACT>::TOTAL * 4, GradSlab<HT, L, ZR>::TOTAL,          \
-               MfmaLayout(HT, L, ZR, 0, true, 0).total, &mfma_grad_kernel<HT, L, ZR, ACT>,            \
-               &grad_reduce_kernel<HT, L, ZR> }
-#define GRAD_SHAPES(ACT)                                                                                \
-    GRAD_INST(4, 3, 2, ACT), GRAD_INST(4, 2, 2, ACT), GRAD_INST(2, 3, 2, ACT), GRAD_INST(2, 2, 2, ACT), \
-    GRAD_INST(1, 3, 2, ACT), GRAD_INST(1, 2, 2, ACT), GRAD_INST(4, 3, 4, ACT), GRAD_INST(4, 2, 4, ACT), \
-    GRAD_INST(2, 3, 4, ACT), GRAD_INST(2, 2, 4, ACT), GRAD_INST(3, 3, 2, ACT), GRAD_INST(3, 2, 2, ACT), \
-    GRAD_INST(3, 3, 4, ACT), GRAD_INST(3, 2, 4, ACT)
-static const GradInst kGrad[] = {GRAD_SHAPES(CNF_ACT_TANH), GRAD_SHAPES(CNF_ACT_SOFTPLUS)};
+#define GRAD_INST(HT, L, ZR, CR, ACT)                                                                        \
+    GradInst { HT, L, ZR, CR, ACT, GradLds<HT, L, ZR, CR, ACT>::TOTAL * 4, GradSlab<HT, L, ZR, CR>::TOTAL,   \
+               MfmaLayout(HT, L, ZR, CR, true, 0).total, &mfma_grad_kernel<HT, L, ZR, CR, ACT>,            \
+               &grad_reduce_kernel<HT, L, ZR, CR> }
+#define GRAD_HT(HT, CR, ACT)                                                                                 \
+    GRAD_INST(HT, 3, 2, CR, ACT), GRAD_INST(HT, 2, 2, CR, ACT), GRAD_INST(HT, 3, 4, CR, ACT), GRAD_INST(HT, 2, 4, CR, ACT)
+#define GRAD_SHAPES(CR, ACT) GRAD_HT(1, CR, ACT), GRAD_HT(2, CR, ACT), GRAD_HT(3, CR, ACT), GRAD_HT(4, CR, ACT)
+static const GradInst kGrad[] = {GRAD_SHAPES(0, CNF_ACT_TANH), GRAD_SHAPES(0, CNF_ACT_SOFTPLUS),
+                                 GRAD_SHAPES(4, CNF_ACT_TANH), GRAD_SHAPES(4, CNF_ACT_SOFTPLUS)};
 
 static const GradInst* grad_find(const cnf_config& c) {
-    if (c.mode != CNF_MODE_HUTCH_VJP || c.nprobes != 1 || c.ncond != 0) return nullptr;
+    if (c.mode != CNF_MODE_HUTCH_VJP || c.nprobes != 1 || c.ncond > 16) return nullptr;
     const int N = c.n_layers, L = N - 1;
     if (L < 2 || L > 3 || c.acts[N - 1] != CNF_ACT_IDENTITY) return nullptr;
     const int H = c.widths[1];
@@ -524,20 +555,22 @@ static const GradInst* grad_find(const cnf_config& c) {
     if (D + (c.autonomous ? 0 : 1) > 15) return nullptr;   // input tile: 16 columns, the last one is the bias column
     const GradInst* best = nullptr;
     for (const GradInst& g : kGrad)
-        if (g.HT == HT && g.L == L && g.ACT == c.acts[0] && g.ZR >= ZR && (!best || g.ZR < best->ZR)) best = &g;
+        if (g.HT == HT && g.L == L && g.ACT == c.acts[0] && g.ZR >= ZR && (g.CR > 0) == (c.ncond > 0) &&
+            (!best || g.ZR < best->ZR))
+            best = &g;
     return best;
 }
 
 bool grad_supported(const cnf_config& c) { return grad_find(c) != nullptr; }
 size_t grad_packed_bytes(const cnf_config& c) { return (size_t)grad_find(c)->packed_floats * sizeof(float); }
 size_t grad_slab_floats(const cnf_config& c, int num_cus) { return (size_t)num_cus * 4 * grad_find(c)->slab_total; }
-void grad_shape(const cnf_config& c, int* HT, int* L, int* ZR) {
+void grad_shape(const cnf_config& c, int* HT, int* L, int* ZR, int* CR) {
     const GradInst* g = grad_find(c);
-    *HT = g->HT; *L = g->L; *ZR = g->ZR;
+    *HT = g->HT; *L = g->L; *ZR = g->ZR; *CR = g->CR;
 }
 
 hipError_t grad_launch(const cnf_config& c, const float* packed_dev, const float* ckpt, const float* ckpt_k,
-                       int ckpt_zr, const float* eps,
+                       int ckpt_zr, const float* eps, const float* ys,
                        const size_t* w_off, const size_t* b_off, int alg, int nsteps, float t0, float t1,
                        long long B, const float lam[3], float* slab, float* grad, int num_cus, hipStream_t st) {
     const GradInst* gi = grad_find(c);
@@ -554,7 +587,7 @@ hipError_t grad_launch(const cnf_config& c, const float* packed_dev, const float
         done_mask[idx] |= 1ull << (dev & 63);
     }
     GArgs a{};
-    a.packed = packed_dev; a.ckpt = ckpt; a.ckpt_k = ckpt_k; a.ckpt_zr = ckpt_zr; a.eps = eps; a.slab = slab; a.B = B;
+    a.packed = packed_dev; a.ckpt = ckpt; a.ckpt_k = ckpt_k; a.ckpt_zr = ckpt_zr; a.eps = eps; a.ys = ys; a.C = c.ncond; a.slab = slab; a.B = B;
     a.nsteps = nsteps; a.t0 = t0; a.dt = (t1 - t0) / (float)nsteps;
     a.D = c.nvars + c.naug; a.H = c.widths[1]; a.n_in = c.widths[0]; a.autonomous = c.autonomous; a.nvars = c.nvars;
     a.lam1 = lam[0]; a.lam2 = lam[1]; a.lam3 = lam[2];

@@ -72,10 +72,10 @@ hipError_t mfma_solve(MfmaPlan* p, const float* packed_dev, const SolveArgs& a, 
 bool grad_supported(const cnf_config& c);
 size_t grad_packed_bytes(const cnf_config& c);
 size_t grad_slab_floats(const cnf_config& c, int num_cus);
-void grad_shape(const cnf_config& c, int* HT, int* L, int* ZR);
+void grad_shape(const cnf_config& c, int* HT, int* L, int* ZR, int* CR);
 void grad_pack(const cnf_config& c, const float* lux, const size_t* w_off, const size_t* b_off, float* packed);
 hipError_t grad_launch(const cnf_config& c, const float* packed_dev, const float* ckpt, const float* ckpt_k,
-                       int ckpt_zr, const float* eps,
+                       int ckpt_zr, const float* eps, const float* ys,
                        const size_t* w_off, const size_t* b_off, int alg, int nsteps, float t0, float t1,
                        long long B, const float lam[3], float* slab, float* grad, int num_cus, hipStream_t st);
 int mfma_plan_zr(const MfmaPlan* p);   // state k-steps of the forward instance (checkpoint stride)

@@ -267,11 +267,11 @@ int mfma_plan_zr(const MfmaPlan* p) { return p->ZR; }
 bool mfma_plan_is_per_wave(const MfmaPlan* p) { return p->kind == 0; }
 
 void grad_pack(const cnf_config& c, const float* lux, const size_t* w_off, const size_t* b_off, float* packed) {
-    int HT, L, ZR;
-    grad_shape(c, &HT, &L, &ZR);
+    int HT, L, ZR, CR;
+    grad_shape(c, &HT, &L, &ZR, &CR);
     MfmaPlan p;
-    p.HT = HT; p.L = L; p.ZR = ZR; p.CR = 0; p.with_bwd = true; p.arith = 0; p.fwd_scale = 1.f;
-    p.lay = MfmaLayout(HT, L, ZR, 0, true, 0);
+    p.HT = HT; p.L = L; p.ZR = ZR; p.CR = CR; p.with_bwd = true; p.arith = 0; p.fwd_scale = 1.f;
+    p.lay = MfmaLayout(HT, L, ZR, CR, true, 0);
     p.cfg = c;
     mfma_pack(&p, lux, w_off, b_off, packed);
 }

@@ -528,12 +528,13 @@ def loss_and_gradient(icnf: ICNF, mode: Mode, *args, eps: Optional[torch.Tensor]
     dev = icnf.device
     x = _colmajor(xs, icnf.nvariables, "xs", dev)
     B = x.shape[0]
+    y = _colmajor(ys, icnf.nconditions, "ys", dev) if icnf.conditioned else None
     e = _draw_eps(icnf, icnf.nprobes, B) if eps is None else _colmajor(eps, icnf.nprobes * icnf.D, "eps", dev)
     t0, t1 = icnf._steer_tspan(mode)
     grad = torch.empty(ps.numel(), device=dev, dtype=torch.float32)
     sums = torch.empty(4, device=dev, dtype=torch.float32)
     lam = (C.c_float * 3)(icnf.lambda1, icnf.lambda2, icnf.lambda3)
     _lib.check(h.lib.cnf_loss_grad_fixed(h.ptr, icnf._solver(), icnf._nsteps(t0, t1), t0, t1, _ptr(x), _ptr(e),
-                                         None, B, lam, _ptr(grad), _ptr(sums), _stream_ptr(dev)))
+                                         _ptr(y), B, lam, _ptr(grad), _ptr(sums), _stream_ptr(dev)))
     value = reduce_loss(sums, B, (icnf.lambda1, icnf.lambda2, icnf.lambda3), group=group)
     return value, reduce_gradient(grad, B, group=group)

@@ -273,6 +273,9 @@ GRAD_SHAPES = [
     (dict(nvars=2, naug=3, hidden=[24, 24], act=2, reg_z=True, reg_j=True), (0.02, 0.03, 0.0), 20, 0, 4),  # default net, nvariables=2
     (dict(nvars=12, hidden=[48, 48, 48]), (0.0, 0.0, 0.0), 19, 0, 3),                           # D = 12 (padded state k-steps)
     (dict(nvars=5, hidden=[64, 64], autonomous=True, act=2), (0.0, 0.0, 0.0), 17, 1, 3),        # autonomous, softplus, L = 2
+    (dict(nvars=8, ncond=8, hidden=[64, 64, 64], reg_z=True, reg_j=True), (0.01, 0.01, 0.0), 40, 1, 3),   # conditioned RNODE
+    (dict(nvars=2, ncond=2, naug=3, hidden=[32, 32], act=2, reg_z=True, reg_j=True, reg_aug=True), (0.01, 0.01, 0.01), 21, 0, 4),  # default CondICNF net (nvariables=2, nconditions=2)
+    (dict(nvars=3, ncond=13, hidden=[16, 16, 16]), (0.0, 0.0, 0.0), 9, 0, 3),                   # many conditions, one hidden tile
 ]
 
 
@@ -280,11 +283,12 @@ GRAD_SHAPES = [
 def test_parameter_gradient_other_shapes_and_softplus(kw, lam, B, alg, nsteps, pkg, oracles):
     o64, _ = oracles
     spec = o64.make_spec(**kw)
-    p, xs, eps, _ = o64.synth_inputs(spec, B, 77, bias_scale=0.2)
-    L, gref = o64.loss_and_grad(spec, p, xs, 0.0, 1.0, nsteps, alg, eps, None, lam)
+    p, xs, eps, ys = o64.synth_inputs(spec, B, 77, bias_scale=0.2)
+    L, gref = o64.loss_and_grad(spec, p, xs, 0.0, 1.0, nsteps, alg, eps, ys, lam)
     icnf = make_icnf(pkg, spec, alg, nsteps, path=2, lambdas=lam)
     mode = pkg.TrainMode(bool(spec.reg_z or spec.reg_j or spec.reg_aug))
-    val, g = pkg.loss_and_gradient(icnf, mode, dev(xs), dev(p), {}, eps=dev(eps))
+    args = (dev(xs),) + ((dev(ys),) if spec.ncond else ()) + (dev(p), {})
+    val, g = pkg.loss_and_gradient(icnf, mode, *args, eps=dev(eps))
     g = g.cpu().numpy().astype(np.float64)
     assert abs(float(val) - L) < 1e-4
     scale = np.abs(gref).max()
