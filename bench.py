@@ -79,6 +79,9 @@ def parse():
     ap.add_argument("--path", type=int, default=0, help="0 auto, 1 SIMT, 2 MFMA")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--mode", default="infer", choices=["infer", "grad"],
+                    help="infer: loss (default, the BASELINE metric); grad: loss_and_gradient — forward with "
+                         "checkpoints + reverse sweep + all-reduce of nparams floats")
     ap.add_argument("--arith", default="f32", choices=["f32", "bf16x6"],
                     help="hidden-product arithmetic: exact f32 MFMA (default) or split-bf16 (opt-in)")
     ap.add_argument("--backend", default="nccl", help="process-group backend (nccl = RCCL; gloo for "
@@ -164,6 +167,8 @@ def main():
     args = (X,) + ((Y,) if Y is not None else ()) + (P, {})
 
     def step():
+        if a.mode == "grad":
+            return pkg.loss_and_gradient(icnf, mode, *args, eps=E)[0]
         return pkg.loss(icnf, mode, *args, eps=E)
 
     def sync():
@@ -181,6 +186,10 @@ def main():
     t0 = time.perf_counter()
     for i in range(a.steps):
         ev[i][0].record()
+        if a.mode == "grad":
+            lossv, gradv = pkg.loss_and_gradient(icnf, mode, *args, eps=E)
+            ev[i][1].record()
+            continue
         logp, regs = pkg.inference(icnf, mode, *args, eps=E)
         ev[i][1].record()
         sums = pkg.loss_sums(icnf, mode, logp, torch.stack(list(regs)))
@@ -199,8 +208,16 @@ def main():
         flops_launch = float(flop_ss) * B * NSTEPS
         ach_tflops = flops_launch / (kern_ms * 1e-3) / 1e12
         stages = 4 if alg == 0 else 6
+        if a.mode == "grad":
+            # executed MFMA work of forward + reverse sweep per sample*step, not an
+            # algorithmic figure: (280 + 1016) MFMAs of 2048 flop per stage per 16-sample tile (cfg2 shape)
+            stages_ = 4 if alg == 0 else 6
+            flop_ss = (280 + 1016) * 2048 / 16 * stages_
+            flops_launch = float(flop_ss) * B * NSTEPS
+            ach_tflops = flops_launch / (kern_ms * 1e-3) / 1e12
         out = {
-            "metric": "log-density evals (samples*steps)/sec",
+            "metric": "log-density evals (samples*steps)/sec" if a.mode == "infer"
+            else "training-step evals (samples*steps)/sec: loss + dloss/dp",
             "value": value, "unit": "samples*steps/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
@@ -210,7 +227,9 @@ def main():
                        "global_columns": world * B, "nsteps": NSTEPS,
                        "integrator": "RK4" if alg == 0 else "Tsit5",
                        "kernel_path": {1: "simt", 2: "mfma"}.get(path, str(path)),
-                       "parallelism": f"column-shard x{world}, loss all-reduce (5 scalars)"},
+                       "mode": a.mode,
+                       "parallelism": f"column-shard x{world}, loss all-reduce (5 scalars)"
+                       + (" + gradient all-reduce (nparams floats)" if a.mode == "grad" else "")},
             "loss": float(lossv),
             "roofline": {
                 "bound": "mfma", "achieved": ach_tflops, "peak": F32_MFMA_PEAK_TFLOPS,
