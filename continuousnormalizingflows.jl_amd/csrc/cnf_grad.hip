@@ -92,18 +92,30 @@ __device__ __forceinline__ void outer_rmw_impl(float* __restrict__ img, int lane
     f32x4 old[PD];
 #pragma unroll
     for (int t = 0; t < PD; ++t) old[t] = slab_load(base + t * 256);
+    // two tiles per iteration: their accumulation chains are independent, so the dependent-MFMA
+    // latency (40 cycles vs 32 issue) of one hides behind the other
 #pragma unroll
-    for (int t = 0; t < NTILE; ++t) {
-        const int mt = t / NT, nt = t % NT;
-        f32x4 acc = old[t % PD];
+    for (int t = 0; t < NTILE; t += 2) {
+        const bool two = t + 1 < NTILE;
+        const int mt0 = t / NT, nt0 = t % NT, mt1 = (t + 1) / NT, nt1 = (t + 1) % NT;
+        f32x4 acc0 = old[t % PD];
+        f32x4 acc1 = two ? old[(t + 1) % PD] : f32x4{0.f, 0.f, 0.f, 0.f};
         if (t + PD < NTILE) old[t % PD] = slab_load(base + (t + PD) * 256);
+        if (two && t + 1 + PD < NTILE) old[(t + 1) % PD] = slab_load(base + (t + 1 + PD) * 256);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) acc = mfma4(af1[mt][s], bf1[nt][s], acc);
+        for (int s = 0; s < 4; ++s) {
+            acc0 = mfma4(af1[mt0][s], bf1[nt0][s], acc0);
+            if (two) acc1 = mfma4(af1[mt1 < MT ? mt1 : 0][s], bf1[nt1][s], acc1);
+        }
         if constexpr (TWO) {
 #pragma unroll
-            for (int s = 0; s < 4; ++s) acc = mfma4(af2[mt][s], bf2[nt][s], acc);
+            for (int s = 0; s < 4; ++s) {
+                acc0 = mfma4(af2[mt0][s], bf2[nt0][s], acc0);
+                if (two) acc1 = mfma4(af2[mt1 < MT ? mt1 : 0][s], bf2[nt1][s], acc1);
+            }
         }
-        *reinterpret_cast<f32x4*>(base + t * 256) = acc;
+        *reinterpret_cast<f32x4*>(base + t * 256) = acc0;
+        if (two) *reinterpret_cast<f32x4*>(base + (t + 1) * 256) = acc1;
     }
 }
 template <int MT, int NT>
@@ -493,10 +505,17 @@ template <int HT, int L, int ZR, int CR>
 __global__ void __launch_bounds__(256)
 grad_reduce_kernel(const float* __restrict__ slab, int nwaves, GArgs a, float* __restrict__ grad) {
     using SL = GradSlab<HT, L, ZR, CR>;
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= SL::TOTAL) return;
-    float sum = 0.f;
-    for (int w = 0; w < nwaves; ++w) sum += slab[(long long)w * SL::TOTAL + e];
+    // 64 elements per block, 4 slab groups per element (fixed partition, fixed combine order)
+    __shared__ float part[4][64];
+    const int el = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + el;
+    float acc = 0.f;
+    if (e < SL::TOTAL)
+        for (int w = grp; w < nwaves; w += 4) acc += slab[(long long)w * SL::TOTAL + e];
+    part[grp][el] = acc;
+    __syncthreads();
+    if (grp != 0 || e >= SL::TOTAL) return;
+    const float sum = (part[0][el] + part[1][el]) + (part[2][el] + part[3][el]);
     const int H = a.H, D = a.D;
     const int ln = (e >> 2) & 63, r = e & 3, n = ln & 15, gg = ln >> 4;
     if (e < SL::WH) {                                   // W_1 image: [mt][input tile][lane][r]
@@ -602,7 +621,7 @@ hipError_t grad_launch(const cnf_config& c, const float* packed_dev, const float
     hipLaunchKernelGGL(gi->kern, dim3(nblocks), dim3(256), gi->lds_bytes, st, a);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(gi->reduce, dim3((gi->slab_total + 255) / 256), dim3(256), 0, st, slab, nwaves, a, grad);
+    hipLaunchKernelGGL(gi->reduce, dim3((gi->slab_total + 63) / 64), dim3(256), 0, st, slab, nwaves, a, grad);
     return hipGetLastError();
 }
 

@@ -295,6 +295,29 @@ def test_parameter_gradient_other_shapes_and_softplus(kw, lam, B, alg, nsteps, p
     assert np.max(np.abs(g - gref)) < 5e-5 * scale + 1e-6, np.max(np.abs(g - gref)) / scale
 
 
+def test_full_size_gradient_is_additive_over_column_shards(pkg, oracles):
+    """Headline size (B = 65536, Tsit5 x 40): the summed gradient of the whole batch equals the sum of
+    the gradients of two column shards — the identity the multi-GPU all-reduce relies on — and the
+    training loss equals the inference loss."""
+    o64, _ = oracles
+    spec = o64.make_spec(nvars=8, hidden=[64, 64, 64])
+    B = 65536
+    p, xs, eps, _ = o64.synth_inputs(spec, B, 20240621)
+    icnf = grad_icnf(pkg, spec, 1, 40)
+    m = pkg.TrainMode(False)
+    X, E, P = dev(xs), dev(eps), dev(p)
+    vf, gf = pkg.loss_and_gradient(icnf, m, X, P, {}, eps=E)
+    h = 40000                                             # uneven split, partial tiles on neither side
+    v1, g1 = pkg.loss_and_gradient(icnf, m, X[:, :h], P, {}, eps=E[:, :h])
+    v2, g2 = pkg.loss_and_gradient(icnf, m, X[:, h:], P, {}, eps=E[:, h:])
+    gs = (g1.double() * h + g2.double() * (B - h)) / B
+    scale = float(gf.abs().max())
+    assert float((gf.double() - gs).abs().max()) < 2e-5 * scale
+    assert abs(float(vf) - (float(v1) * h + float(v2) * (B - h)) / B) < 1e-5
+    assert abs(float(vf) - float(pkg.loss(icnf, m, X, P, {}, eps=E))) < 1e-5
+    assert bool(torch.isfinite(gf).all())
+
+
 def test_gradient_descent_on_the_gradient_kernel_reduces_the_loss(pkg, oracles):
     """End-to-end use of the training path: a few Adam steps driven by loss_and_gradient lower the
     NLL of a shifted, scaled Gaussian (the role MLJ `fit` plays around the reference's loss)."""
