@@ -190,9 +190,9 @@ def main():
             lossv, gradv = pkg.loss_and_gradient(icnf, mode, *args, eps=E)
             ev[i][1].record()
             continue
-        logp, regs = pkg.inference(icnf, mode, *args, eps=E)
+        logp, regs = pkg.inference(icnf, mode, *args, eps=E, _raw=True)
         ev[i][1].record()
-        sums = pkg.loss_sums(icnf, mode, logp, torch.stack(list(regs)))
+        sums = pkg.loss_sums(icnf, mode, logp, regs)
         lossv = pkg.reduce_loss(sums, B, (icnf.lambda1, icnf.lambda2, icnf.lambda3))
     sync()
     elapsed = time.perf_counter() - t0

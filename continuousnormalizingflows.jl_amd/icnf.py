@@ -401,7 +401,7 @@ def _split_args(icnf: ICNF, args, what: str):
 
 
 def inference(icnf: ICNF, mode: Mode, *args, eps: Optional[torch.Tensor] = None,
-              return_state: bool = False):
+              return_state: bool = False, _raw: bool = False):
     """inference(icnf, mode, xs[, ys], ps, st) -> (logp̂x (B,), (Ė, ṅ, Ȧ)).
 
     `eps` ((K*D, B)) pins the Hutchinson probes; by default they are drawn from icnf.rng as
@@ -431,6 +431,8 @@ def inference(icnf: ICNF, mode: Mode, *args, eps: Optional[torch.Tensor] = None,
     uf = torch.empty(B, icnf.S, device=dev, dtype=torch.float32) if return_state else None
     _lib.check(h.lib.cnf_inference_fixed(h.ptr, alg, nsteps, t0, t1, _ptr(x), _ptr(e), _ptr(y), B,
                                          _ptr(logp), _ptr(regs), _ptr(uf), _stream_ptr(dev)))
+    if _raw:   # internal: the (3, B) regulariser block as one tensor (no copies on the loss path)
+        return logp, regs
     out = (logp, (regs[0], regs[1], regs[2]))
     if return_state:
         return out + (uf.t(),)
@@ -510,8 +512,8 @@ def loss(icnf: ICNF, mode: Mode, *args, eps: Optional[torch.Tensor] = None, grou
     taken to be sharded over the ranks of `group`: the four partial sums and the column count
     are all-reduced (RCCL over xGMI on GPUs) and every rank returns the global mean."""
     from .sharding import reduce_loss
-    logp, (E, n, A) = inference(icnf, mode, *args, eps=eps)
-    sums = loss_sums(icnf, mode, logp, torch.stack([E, n, A]))
+    logp, regs = inference(icnf, mode, *args, eps=eps, _raw=True)
+    sums = loss_sums(icnf, mode, logp, regs)
     return reduce_loss(sums, logp.numel(), (icnf.lambda1, icnf.lambda2, icnf.lambda3), group=group)
 
 

@@ -24,18 +24,31 @@ def shard_columns(B: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, lo + q + (1 if rank < r else 0)
 
 
+_const_cache = {}
+
+
+def _const(device, values) -> torch.Tensor:
+    """Small float64 device constants, created once per (device, values) — not per step."""
+    key = (str(device), tuple(float(v) for v in values))
+    t = _const_cache.get(key)
+    if t is None:
+        t = torch.tensor(key[1], device=device, dtype=torch.float64)
+        _const_cache[key] = t
+    return t
+
+
 def reduce_loss(sums4: torch.Tensor, B_local: int, lambdas: Sequence[float],
                 group=None) -> torch.Tensor:
     """(Σ-logp, ΣĖ, Σṅ, ΣȦ) of this rank's columns -> global mean loss on every rank.
     Partial sums are combined in float64 so the result does not depend on the rank count
     beyond fp32 rounding of the per-rank sums."""
     import torch.distributed as dist
-    buf = torch.cat([sums4.to(torch.float64),
-                     torch.tensor([float(B_local)], device=sums4.device, dtype=torch.float64)])
+    lam = _const(sums4.device, (1.0, *lambdas))
     if dist.is_available() and dist.is_initialized():
+        buf = torch.cat([sums4.to(torch.float64), _const(sums4.device, (float(B_local),))])
         dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
-    lam = torch.tensor([1.0, *[float(l) for l in lambdas]], device=buf.device, dtype=torch.float64)
-    return ((buf[:4] * lam).sum() / buf[4]).to(torch.float32)
+        return (torch.dot(buf[:4], lam) / buf[4]).to(torch.float32)
+    return (torch.dot(sums4.to(torch.float64), lam) / float(B_local)).to(torch.float32)
 
 
 def reduce_gradient(grad_sum: torch.Tensor, B_local: int, group=None) -> torch.Tensor:
