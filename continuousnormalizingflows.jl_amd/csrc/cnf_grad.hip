@@ -20,13 +20,14 @@
 //                Wbar_l += abar_l h_{l-1}^T; bbar_l += abar_l; hbar_{l-1} = W_l^T abar_l;  Zbar = W_1[:,0:D]^T abar_1
 // Weight cotangents are outer products summed over the tile's 16 samples: MFMAs with the SAMPLE
 // index on K, so each operand tile is transposed once through wave-private LDS scratch
-// (ds_write_b128 + 4 ds_read_b32).  Accumulation: every wave owns a private slab (50 KB, L2/MALL
-// resident) holding its cotangent tiles; a tile update is load (L1-bypassing) -> MFMA chain with the
-// old value as C operand -> store, both contributions to a matrix merged into one chain so a tile is
-// touched once per stage, biases obtained as outer products with a ones column.  A second kernel
-// sums the slabs in a fixed order into the Lux-layout gradient: no atomics, bit-reproducible.
-// (First version used LDS float atomics: ds_add_f32 retires ~1 lane per 3.4 cycles per CU and made
-// the sweep 10x slower than its MFMA time.)
+// (ds_write_b128 into a padded tile + 4 conflict-free ds_read_b32).  Accumulation: the cotangent tiles
+// live in registers for the whole launch, partitioned over the workgroup's four waves (wave w owns row
+// block w of every hidden matrix and of W_1, column tile w of W_N); the waves run in lockstep and
+// publish their operand tiles through an LDS exchange buffer once per matrix per stage; biases are
+// outer products with a ones column.  At the end each wave deposits its tiles in a slab and a second
+// kernel sums the slabs in a fixed order into the Lux-layout gradient: no atomics, bit-reproducible.
+// (History: LDS float atomics - ds_add_f32 retires ~1 lane per 3.4 cycles per CU - 89 ms at cfg2;
+// wave-private slabs updated by load/MFMA/store - 64 GB of fabric traffic per gradient - 19 ms.)
 #include "cnf_mfma_kernel.h"
 
 namespace cnf {
@@ -49,85 +50,34 @@ struct GArgs {
     Tableau T;
 };
 
-// ---- transposed fragments of accumulator-layout tiles: sample index onto K ----
-// A side: lane (i = lane&15, g = lane>>4) gets, for k-step s, feature rowmap(mt, i) of sample 4s+g
+// Cross-wave exchange of accumulator-layout tiles through LDS.  A tile is stored with 8 dwords of
+// padding per 16-lane group (TS = 280 floats), which makes both transposed fragment reads below
+// bank-conflict-free (bank = 8 (lane group) + 4 (k lane group) + register, distinct over a 32-lane half).
+constexpr int TS = 280;
+__device__ __forceinline__ void tile_store(float* __restrict__ slot, int lane, f32x4 t) {
+    *reinterpret_cast<f32x4*>(slot + lane * 4 + (lane >> 4) * 8) = t;
+}
 template <int MT>
-__device__ __forceinline__ void frags_A(float* __restrict__ scr, int lane, const f32x4 (&t)[MT], float (&f)[MT][4]) {
-    f32x4* S = reinterpret_cast<f32x4*>(scr);
+__device__ __forceinline__ void tiles_store(float* __restrict__ dst, int lane, const f32x4 (&t)[MT]) {
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) S[mt * 64 + lane] = t[mt];
+    for (int mt = 0; mt < MT; ++mt) tile_store(dst + mt * TS, lane, t[mt]);
+}
+// A side: lane (i = lane&15, g = lane>>4) gets, for k-step s, feature rowmap(mt, i) of sample 4s+g
+__device__ __forceinline__ void read_frag_A(const float* __restrict__ tile, int lane, float (&f)[4]) {
     const int i = lane & 15, g = lane >> 4;
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int s = 0; s < 4; ++s) f[mt][s] = scr[(mt * 64 + ((i >> 2) * 16 + 4 * s + g)) * 4 + (i & 3)];
+    for (int s = 0; s < 4; ++s) f[s] = tile[(i >> 2) * 72 + 16 * s + 4 * g + (i & 3)];
 }
 // B side: lane (j = lane&15, g) gets, for k-step s, feature 16 nt + j (natural order) of sample 4s+g
-template <int NT>
-__device__ __forceinline__ void frags_B(float* __restrict__ scr, int lane, const f32x4 (&t)[NT], float (&f)[NT][4]) {
-    f32x4* S = reinterpret_cast<f32x4*>(scr);
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) S[nt * 64 + lane] = t[nt];
+__device__ __forceinline__ void read_frag_B(const float* __restrict__ tile, int lane, float (&f)[4]) {
     const int j = lane & 15, g = lane >> 4;
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int s = 0; s < 4; ++s) f[nt][s] = scr[(nt * 64 + ((j & 3) * 16 + 4 * s + g)) * 4 + (j >> 2)];
+    for (int s = 0; s < 4; ++s) f[s] = tile[(j & 3) * 72 + 16 * s + 4 * g + (j >> 2)];
 }
-
-// slab tile update: acc = old; acc += sum_s A1_s B1_s (+ A2_s B2_s); store.  The load bypasses L1
-// (nontemporal) so it always sees this wave's own store of the previous stage.
-__device__ __forceinline__ f32x4 slab_load(const float* p) {
-    return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
-}
-// The old tile values are fetched PD tiles ahead of their MFMA chains (the L2 round trip is ~700
-// cycles; a chain is 128-256), so only the first PD loads of a matrix are exposed.
-template <int MT, int NT, bool TWO>
-__device__ __forceinline__ void outer_rmw_impl(float* __restrict__ img, int lane, const float (&af1)[MT][4],
-                                               const float (&bf1)[NT][4], const float (&af2)[MT][4],
-                                               const float (&bf2)[NT][4]) {
-    constexpr int NTILE = MT * NT;
-    constexpr int PD = NTILE < 4 ? NTILE : 4;
-    float* base = img + lane * 4;
-    f32x4 old[PD];
+__device__ __forceinline__ f32x4 outer4(const float (&a)[4], const float (&b)[4], f32x4 acc) {
 #pragma unroll
-    for (int t = 0; t < PD; ++t) old[t] = slab_load(base + t * 256);
-    // two tiles per iteration: their accumulation chains are independent, so the dependent-MFMA
-    // latency (40 cycles vs 32 issue) of one hides behind the other
-#pragma unroll
-    for (int t = 0; t < NTILE; t += 2) {
-        const bool two = t + 1 < NTILE;
-        const int mt0 = t / NT, nt0 = t % NT, mt1 = (t + 1) / NT, nt1 = (t + 1) % NT;
-        f32x4 acc0 = old[t % PD];
-        f32x4 acc1 = two ? old[(t + 1) % PD] : f32x4{0.f, 0.f, 0.f, 0.f};
-        if (t + PD < NTILE) old[t % PD] = slab_load(base + (t + PD) * 256);
-        if (two && t + 1 + PD < NTILE) old[(t + 1) % PD] = slab_load(base + (t + 1 + PD) * 256);
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            acc0 = mfma4(af1[mt0][s], bf1[nt0][s], acc0);
-            if (two) acc1 = mfma4(af1[mt1 < MT ? mt1 : 0][s], bf1[nt1][s], acc1);
-        }
-        if constexpr (TWO) {
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                acc0 = mfma4(af2[mt0][s], bf2[nt0][s], acc0);
-                if (two) acc1 = mfma4(af2[mt1 < MT ? mt1 : 0][s], bf2[nt1][s], acc1);
-            }
-        }
-        *reinterpret_cast<f32x4*>(base + t * 256) = acc0;
-        if (two) *reinterpret_cast<f32x4*>(base + (t + 1) * 256) = acc1;
-    }
-}
-template <int MT, int NT>
-__device__ __forceinline__ void outer_rmw(float* __restrict__ img, int lane, const float (&af)[MT][4],
-                                          const float (&bf)[NT][4]) {
-    outer_rmw_impl<MT, NT, false>(img, lane, af, bf, af, bf);
-}
-template <int MT, int NT>
-__device__ __forceinline__ void outer_rmw2(float* __restrict__ img, int lane, const float (&af1)[MT][4],
-                                           const float (&bf1)[NT][4], const float (&af2)[MT][4],
-                                           const float (&bf2)[NT][4]) {
-    outer_rmw_impl<MT, NT, true>(img, lane, af1, bf1, af2, bf2);
+    for (int s = 0; s < 4; ++s) acc = mfma4(a[s], b[s], acc);
+    return acc;
 }
 
 // dense-layout D-vector (register s, lane group g <-> feature 4s+g) as one accumulator-layout tile
@@ -151,8 +101,12 @@ struct GradLds {   // float offsets inside dynamic LDS: operand image, then per-
     static constexpr MfmaLayout LAY = MfmaLayout(HT, L, ZR, CR, true, 0);
     static constexpr int DT = (ZR + 3) / 4;
     static constexpr int SCR = (LAY.total + 3) / 4 * 4;
-    static constexpr int SCR_W = (3 * HT + 3) * 256;    // three HT-tile slots + three single-tile slots
-    static constexpr int TOTAL = SCR + 4 * SCR_W;
+    // exchange region per wave: operand tiles published for the other waves (padded tiles of TS floats);
+    // the largest exchange is the hidden-matrix one [A1 | B1 | A2 | B2] x HT tiles
+    static constexpr int XCH = SCR;
+    static constexpr int XCH_TILES = 4 * HT > 2 * HT + 3 ? 4 * HT : 2 * HT + 3;
+    static constexpr int XCH_W = XCH_TILES * TS;
+    static constexpr int TOTAL = XCH + 4 * XCH_W;
 };
 template <int HT, int L, int ZR, int CR>
 struct GradSlab {  // float offsets inside one wave's slab; every image is [mt][nt][lane][4] (accumulator layout)
@@ -216,28 +170,37 @@ mfma_grad_kernel(GArgs a) {
     const int lane = threadIdx.x & 63, g = lane >> 4, n = lane & 15;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     using SL = GradSlab<HT, L, ZR, CR>;
-    float* scrA = smem + G::SCR + wave * G::SCR_W;
-    float* scrB = scrA + HT * 256;
-    float* scrC = scrB + HT * 256;
-    float* scrS1 = scrC + HT * 256;   // single-tile slots (pseudo tiles: eps, kbar, gbar, inputs, y)
-    float* scrS2 = scrS1 + 256;
-    float* scrS3 = scrS2 + 256;
     float* slab = a.slab + ((long long)blockIdx.x * 4 + wave) * SL::TOTAL;
-    // ones pseudo tile: feature 0 = 1 (bias columns); layer-1 input tile carries its ones at feature 15
-    f32x4 ones_tile[1];
-    ones_tile[0] = f32x4{(lane >> 4) == 0 ? 1.f : 0.f, 0.f, 0.f, 0.f};
-    float onesf[1][4];
-    frags_B<1>(scrB, lane, ones_tile, onesf);
+    // B fragment of the ones column (feature 0 = 1 for every sample): bias cotangents as outer products
+    float onesf[4];
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) onesf[q4] = (lane & 15) == 0 ? 1.f : 0.f;
     const long long ntiles = (a.B + 15) / 16;
     const int D = a.D;
     const bool autonomous = a.autonomous;
     const float dt = a.dt;
     const int ns = a.T.ns;
 
-    for (long long tile = (long long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long long)gridDim.x * 4) {
+    // Hidden-matrix cotangents live in registers for the whole launch: wave w owns row block w
+    // (W̄[16w .. 16w+15][:]) of every hidden matrix and accumulates the outer products of ALL four
+    // waves' sample tiles for it; the operand tiles travel through the LDS exchange buffer once per
+    // hidden matrix per stage.  (Slab read-modify-write of these tiles cost 64 GB of fabric traffic
+    // per gradient at cfg2.)  The four waves therefore run the tile loop in lockstep.
+    f32x4 Wh[L > 1 ? L - 1 : 1][HT], Bh[L > 1 ? L - 1 : 1], W1acc[SL::NT1], WNacc, BNacc;
+#pragma unroll
+    for (int l = 0; l < (L > 1 ? L - 1 : 1); ++l) { zero_tiles<HT>(Wh[l]); Bh[l] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    zero_tiles<SL::NT1>(W1acc);
+    WNacc = BNacc = f32x4{0.f, 0.f, 0.f, 0.f};
+    float* xch = smem + G::XCH;
+    float* xmine = xch + wave * G::XCH_W;
+    const long long ngroups = (ntiles + 3) / 4;
+    for (long long tg = blockIdx.x; tg < ngroups; tg += gridDim.x) {
+        const long long tile_raw = tg * 4 + wave;
+        const bool tile_ok = tile_raw < ntiles;
+        const long long tile = tile_ok ? tile_raw : ntiles - 1;   // idle waves replay the last tile with zero cotangents
         const long long smp = tile * 16 + n;
-        const bool valid = smp < a.B;
-        const long long sc = valid ? smp : a.B - 1;
+        const bool valid = tile_ok && smp < a.B;
+        const long long sc = smp < a.B ? smp : a.B - 1;
         float eps[ZR], lam[ZR];
 #pragma unroll
         for (int s = 0; s < ZR; ++s) {
@@ -409,14 +372,27 @@ mfma_grad_kernel(GArgs a) {
                 // (4) top-down through the forward chain
                 f32x4 kb_tile[1];
                 kb_tile[0] = dense_tile<ZR>(kbar);
-                {   // Wbar_N += eps cbar^T + kbar h_L^T (one chain per tile);  bbar_N = kbar x ones
-                    float af1[1][4], bf1[HT][4], af2[1][4], bf2[HT][4];
-                    frags_A<1>(scrA, lane, eps_tile, af1);
-                    frags_B<HT>(scrB, lane, cb, bf1);
-                    frags_A<1>(scrS1, lane, kb_tile, af2);
-                    frags_B<HT>(scrC, lane, h[L - 1], bf2);
-                    outer_rmw2<1, HT>(slab + SL::WN, lane, af1, bf1, af2, bf2);
-                    outer_rmw<1, 1>(slab + SL::BN, lane, af2, onesf);
+                {   // Wbar_N += eps cbar^T + kbar h_L^T;  bbar_N += kbar x ones.  Wave w owns column tile w.
+                    tile_store(xmine + 0 * TS, lane, eps_tile[0]);
+                    tile_store(xmine + 1 * TS, lane, kb_tile[0]);
+                    tiles_store<HT>(xmine + 2 * TS, lane, cb);
+                    tiles_store<HT>(xmine + (2 + HT) * TS, lane, h[L - 1]);
+                    __syncthreads();
+                    if (wave < HT) {
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) {
+                            const float* xv = xch + v * G::XCH_W;
+                            float a1[4], a2f[4], b1[4], b2[4];
+                            read_frag_A(xv + 0 * TS, lane, a1);
+                            read_frag_A(xv + 1 * TS, lane, a2f);
+                            read_frag_B(xv + (2 + wave) * TS, lane, b1);
+                            read_frag_B(xv + (2 + HT + wave) * TS, lane, b2);
+                            WNacc = outer4(a1, b1, WNacc);
+                            WNacc = outer4(a2f, b2, WNacc);
+                            if (wave == 0) BNacc = outer4(a2f, onesf, BNacc);
+                        }
+                    }
+                    __syncthreads();
                 }
                 f32x4 hb[HT];
                 zero_tiles<HT>(hb);
@@ -431,50 +407,72 @@ mfma_grad_kernel(GArgs a) {
                         const f32x4 d2 = ACT == CNF_ACT_TANH ? h[l][mt] * d[l][mt] * -2.f : d[l][mt] * (1.f - d[l][mt]);
                         ab[mt] = hb[mt] * d[l][mt] + a2[l][mt] * d2;
                     }
-                    float af[HT][4];
-                    frags_A<HT>(scrA, lane, ab, af);
                     if (l > 0) {
-                        // Wbar_{l+1} += abar_l h_{l-1}^T + delta_l ubar_{l-1}^T ;  bbar_{l+1} = abar_l x ones
-                        float bf[HT][4], af2[HT][4], bf2[HT][4];
-                        frags_B<HT>(scrB, lane, h[l - 1], bf);
-                        frags_A<HT>(scrC, lane, dl[l], af2);
-                        outer_rmw<HT, 1>(slab + SL::BH + (l - 1) * HT * 256, lane, af, onesf);
-                        // scrA/scrB are free again once their fragments are in registers
-                        frags_B<HT>(scrA, lane, ubs[l - 1], bf2);
-                        outer_rmw2<HT, HT>(slab + SL::WH + (l - 1) * HT * HT * 256, lane, af, bf, af2, bf2);
+                        // Wbar_{l+1} += abar_l h_{l-1}^T + delta_l ubar_{l-1}^T ;  bbar_{l+1} += abar_l x ones.
+                        // Publish this wave's operand tiles; wave w accumulates row block w over all 4 waves.
+                        tiles_store<HT>(xmine + 0 * HT * TS, lane, ab);           // A1 = abar_l
+                        tiles_store<HT>(xmine + 1 * HT * TS, lane, h[l - 1]);     // B1 = h_{l-1}
+                        tiles_store<HT>(xmine + 2 * HT * TS, lane, dl[l]);        // A2 = delta_l
+                        tiles_store<HT>(xmine + 3 * HT * TS, lane, ubs[l - 1]);   // B2 = ubar_{l-1}
+                        __syncthreads();
+                        if (wave < HT) {
+#pragma unroll
+                            for (int v = 0; v < 4; ++v) {
+                                const float* xv = xch + v * G::XCH_W;
+                                float a1[4], a2f[4];
+                                read_frag_A(xv + (0 * HT + wave) * TS, lane, a1);
+                                read_frag_A(xv + (2 * HT + wave) * TS, lane, a2f);
+                                Bh[l - 1] = outer4(a1, onesf, Bh[l - 1]);
+#pragma unroll
+                                for (int nt = 0; nt < HT; ++nt) {
+                                    float b1[4], b2[4];
+                                    read_frag_B(xv + (1 * HT + nt) * TS, lane, b1);
+                                    read_frag_B(xv + (3 * HT + nt) * TS, lane, b2);
+                                    Wh[l - 1][nt] = outer4(a1, b1, Wh[l - 1][nt]);
+                                    Wh[l - 1][nt] = outer4(a2f, b2, Wh[l - 1][nt]);
+                                }
+                            }
+                        }
+                        __syncthreads();   // exchange buffer is reused by the next hidden matrix / stage
                         zero_tiles<HT>(hb);
                         gemm_tiles<HT, 4 * HT>(sm + LAY.bh + (l - 1) * MfmaLayout::imgA(HT, HT), lane, TileIn<HT>{ab}, hb);   // W_{l+1}^T abar
                     } else {
                         // input pseudo tile [z (D rows); t; ...; 1 at feature 15]: feature j <-> (register j>>2, lane group j&3)
-                        f32x4 in_tile[1];
+                        f32x4 in_tile;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             float v = r < ZR ? zs[r < ZR ? r : 0] : 0.f;
                             if (!autonomous && 4 * r + g == D) v = tt;
                             if (4 * r + g > D || (autonomous && 4 * r + g == D)) v = 0.f;
                             if (4 * r + g == 15) v = 1.f;
-                            in_tile[0][r] = v;
+                            in_tile[r] = v;
                         }
-                        // Wbar_1 += abar_1 [z; t; 1]^T + delta_1 [gbar; 0]^T   (g = W_1[:,0:D]^T delta_1)
-                        float bf[1][4], af2[HT][4], bf2[1][4];
-                        frags_B<1>(scrB, lane, in_tile, bf);
-                        frags_A<HT>(scrC, lane, dl[0], af2);
-                        frags_B<1>(scrS2, lane, gb_tile, bf2);
-                        if constexpr (CR > 0) {
-                            // image [HT][2]: column tile 0 (merged chain) and column tile 1 = abar_1 y^T
-                            float bfy[1][4];
-                            frags_B<1>(scrS3, lane, y_tile, bfy);
+                        // Wbar_1 += abar_1 [z; t; 1]^T + delta_1 [gbar; 0]^T (+ abar_1 y^T);  wave w owns row block w
+                        tiles_store<HT>(xmine + 0 * HT * TS, lane, ab);
+                        tiles_store<HT>(xmine + 1 * HT * TS, lane, dl[0]);
+                        tile_store(xmine + (2 * HT + 0) * TS, lane, in_tile);
+                        tile_store(xmine + (2 * HT + 1) * TS, lane, gb_tile[0]);
+                        if constexpr (CR > 0) tile_store(xmine + (2 * HT + 2) * TS, lane, y_tile[0]);
+                        __syncthreads();
+                        if (wave < HT) {
 #pragma unroll
-                            for (int mt = 0; mt < HT; ++mt) {
-                                float a1[1][4], a2f[1][4];
-#pragma unroll
-                                for (int q4 = 0; q4 < 4; ++q4) { a1[0][q4] = af[mt][q4]; a2f[0][q4] = af2[mt][q4]; }
-                                outer_rmw2<1, 1>(slab + SL::W1 + (mt * 2 + 0) * 256, lane, a1, bf, a2f, bf2);
-                                outer_rmw<1, 1>(slab + SL::W1 + (mt * 2 + 1) * 256, lane, a1, bfy);
+                            for (int v = 0; v < 4; ++v) {
+                                const float* xv = xch + v * G::XCH_W;
+                                float a1[4], a2f[4], b1[4], b2[4];
+                                read_frag_A(xv + (0 * HT + wave) * TS, lane, a1);
+                                read_frag_A(xv + (1 * HT + wave) * TS, lane, a2f);
+                                read_frag_B(xv + (2 * HT + 0) * TS, lane, b1);
+                                read_frag_B(xv + (2 * HT + 1) * TS, lane, b2);
+                                W1acc[0] = outer4(a1, b1, W1acc[0]);
+                                W1acc[0] = outer4(a2f, b2, W1acc[0]);
+                                if constexpr (CR > 0) {
+                                    float by[4];
+                                    read_frag_B(xv + (2 * HT + 2) * TS, lane, by);
+                                    W1acc[SL::NT1 - 1] = outer4(a1, by, W1acc[SL::NT1 - 1]);
+                                }
                             }
-                        } else {
-                            outer_rmw2<HT, 1>(slab + SL::W1, lane, af, bf, af2, bf2);
                         }
+                        __syncthreads();
                         f32x4 zb[DT];
                         zero_tiles<DT>(zb);
                         gemm_tiles<DT, 4 * HT>(sm + LAY.b1, lane, TileIn<HT>{ab}, zb);   // W_1[:,0:D]^T abar_1
@@ -482,7 +480,6 @@ mfma_grad_kernel(GArgs a) {
                         for (int s = 0; s < ZR; ++s) Zbar[s] = zb[s >> 2][s & 3];
                     }
                 }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // slab stores of this stage are done before its tiles are re-read
 #pragma unroll
                 for (int j = 0; j < 6; ++j)
 #pragma unroll
@@ -496,6 +493,21 @@ mfma_grad_kernel(GArgs a) {
                 lam[s] = acc;
             }
         }
+    }
+    // every wave deposits the tiles it owns in its own (zeroed) slab; grad_reduce_kernel sums the slabs
+    if (wave < HT) {
+#pragma unroll
+        for (int l = 0; l < L - 1; ++l) {
+#pragma unroll
+            for (int nt = 0; nt < HT; ++nt)
+                *reinterpret_cast<f32x4*>(slab + SL::WH + l * HT * HT * 256 + ((wave * HT + nt) * 64 + lane) * 4) = Wh[l][nt];
+            *reinterpret_cast<f32x4*>(slab + SL::BH + l * HT * 256 + (wave * 64 + lane) * 4) = Bh[l];
+        }
+#pragma unroll
+        for (int it = 0; it < SL::NT1; ++it)
+            *reinterpret_cast<f32x4*>(slab + SL::W1 + ((wave * SL::NT1 + it) * 64 + lane) * 4) = W1acc[it];
+        *reinterpret_cast<f32x4*>(slab + SL::WN + (wave * 64 + lane) * 4) = WNacc;
+        if (wave == 0) *reinterpret_cast<f32x4*>(slab + SL::BN + lane * 4) = BNacc;
     }
 }
 
