@@ -1,7 +1,7 @@
 // cnf_mfma_generic.hip — zero-padded instantiations of the per-wave fused solve kernel.
 //
 // The specialised table in cnf_mfma.hip matches (D, C) exactly (BASELINE shapes).  These cover
-// every other uniform-width Dense chain with H <= 128, L in {2,3}, D <= 16, C in {0} or <= 16,
+// every other uniform-width Dense chain with H <= 128 and L in {2,3} (H <= 64 for L in {1,4}), D <= 16, C = 0 or <= 16,
 // tanh or softplus, K = 1: the state/condition k-steps are padded to 4 (zero rows in the operand
 // images, zero registers in the state), which costs at most 2-3 wasted MFMAs per product against
 // the 40x the generic SIMT path would cost.  E.g. the reference's default net for nvariables = 2
@@ -21,8 +21,14 @@ namespace cnf {
     GEN4(HT, 2, CNF_ACT_TANH, NT), GEN4(HT, 3, CNF_ACT_TANH, NT),                \
     GEN4(HT, 2, CNF_ACT_SOFTPLUS, NT), GEN4(HT, 3, CNF_ACT_SOFTPLUS, NT)
 
+// 1 and 4 hidden layers (H <= 64)
+#define GEN_L14(HT, NT)                                                          \
+    GEN4(HT, 1, CNF_ACT_TANH, NT), GEN4(HT, 4, CNF_ACT_TANH, NT),                \
+    GEN4(HT, 1, CNF_ACT_SOFTPLUS, NT), GEN4(HT, 4, CNF_ACT_SOFTPLUS, NT)
+
 static const Inst kGeneric[] = {
     GEN_ACT(1, 512), GEN_ACT(2, 512), GEN_ACT(3, 512), GEN_ACT(4, 512), GEN_ACT(6, 256), GEN_ACT(8, 256),
+    GEN_L14(1, 512), GEN_L14(2, 512), GEN_L14(3, 512), GEN_L14(4, 512),
 };
 
 const Inst* mfma_generic_insts(int* count) {
