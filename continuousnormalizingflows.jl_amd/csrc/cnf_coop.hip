@@ -344,29 +344,41 @@ struct CoopInst {
 };
 #define COOP_INST(HT, L, ZR, ACT) \
     CoopInst { HT, L, ZR, ACT, &launch_coop<HT, L, ZR, ACT, 4>, &launch_coop<HT, L, ZR, ACT, 6> }
+// tanh instances are compiled for pre-scaled pre-activations (mfma_pack folds -2 log2 e into the
+// forward images); they are matched against CNF_ACT_TANH configurations.  First the exact shapes,
+// then zero-padded ones (state k-steps padded to 8: D <= 32).
+#define COOP_GEN(HT)                                                                              \
+    COOP_INST(HT, 3, 8, CNF_ACT_TANH_PRESCALED), COOP_INST(HT, 2, 8, CNF_ACT_TANH_PRESCALED),     \
+    COOP_INST(HT, 3, 8, CNF_ACT_SOFTPLUS), COOP_INST(HT, 2, 8, CNF_ACT_SOFTPLUS)
 static const CoopInst kCoop[] = {
-    // tanh instances are compiled for pre-scaled pre-activations (mfma_pack folds -2 log2 e into the
-    // forward images); they are matched against CNF_ACT_TANH configurations
     COOP_INST(16, 3, 8, CNF_ACT_TANH_PRESCALED),   // cfg4: D=32, 3x256
     COOP_INST(8, 3, 2, CNF_ACT_TANH_PRESCALED),    // D=8, 3x128 Hutchinson VJP
     COOP_INST(4, 3, 2, CNF_ACT_TANH_PRESCALED),    // D=8, 3x64 (cross-check of the per-wave kernel)
+    COOP_GEN(16), COOP_GEN(12), COOP_GEN(8),
 };
 
-bool coop_supported(int HT, int L, int ZR, int CR, int ACT, int engine, int KP) {
+static const CoopInst* coop_find(int HT, int L, int ZR, int ACT) {
+    const CoopInst* best = nullptr;
+    for (const CoopInst& c : kCoop) {
+        const bool act_ok = c.ACT == ACT || (c.ACT == CNF_ACT_TANH_PRESCALED && ACT == CNF_ACT_TANH);
+        if (c.HT == HT && c.L == L && c.ZR >= ZR && act_ok && (!best || c.ZR < best->ZR)) best = &c;
+    }
+    return best;
+}
+
+bool coop_supported(int HT, int L, int ZR, int CR, int ACT, int engine, int KP, int* ZR_inst) {
     if (engine != ENG_VJP || KP != 1 || CR != 0) return false;
-    for (const CoopInst& c : kCoop)
-        if (c.HT == HT && c.L == L && c.ZR == ZR && (c.ACT == ACT || (c.ACT == CNF_ACT_TANH_PRESCALED && ACT == CNF_ACT_TANH))) return true;
-    return false;
+    const CoopInst* c = coop_find(HT, L, ZR, ACT);
+    if (c && ZR_inst) *ZR_inst = c->ZR;
+    return c != nullptr;
 }
 
 hipError_t coop_launch(int HT, int L, int ZR, int ACT, const KArgs& a, int num_cus, hipStream_t st) {
-    for (const CoopInst& c : kCoop)
-        if (c.HT == HT && c.L == L && c.ZR == ZR && (c.ACT == ACT || (c.ACT == CNF_ACT_TANH_PRESCALED && ACT == CNF_ACT_TANH))) {
-            const long long nst = (a.B + 63) / 64;
-            const int nblocks = (int)(nst < num_cus ? nst : num_cus);
-            return (a.T.ns <= 4 ? c.fn4 : c.fn6)(a, nblocks, st);
-        }
-    return hipErrorNotSupported;
+    const CoopInst* c = coop_find(HT, L, ZR, ACT);
+    if (!c) return hipErrorNotSupported;
+    const long long nst = (a.B + 63) / 64;
+    const int nblocks = (int)(nst < num_cus ? nst : num_cus);
+    return (a.T.ns <= 4 ? c->fn4 : c->fn6)(a, nblocks, st);
 }
 
 }  // namespace cnf

@@ -99,11 +99,12 @@ MfmaPlan* mfma_plan_create(const cnf_config& c) {
     const int want_pre = env_int("CNF_MFMA_PRE", -1);
     const bool force_coop = env_int("CNF_MFMA_COOP", 0) != 0;
     auto make_coop = [&]() -> MfmaPlan* {
-        if (!coop_supported(HT, L, ZR, CR, c.acts[0], engine, KP)) return nullptr;
+        int zr_inst = ZR;
+        if (!coop_supported(HT, L, ZR, CR, c.acts[0], engine, KP, &zr_inst)) return nullptr;
         MfmaPlan* p = new MfmaPlan();
-        p->HT = HT; p->L = L; p->ZR = ZR; p->CR = CR; p->ACT = c.acts[0]; p->ENGINE = engine; p->KP = KP;
+        p->HT = HT; p->L = L; p->ZR = zr_inst; p->CR = CR; p->ACT = c.acts[0]; p->ENGINE = engine; p->KP = KP;
         p->with_bwd = true;
-        p->lay = MfmaLayout(HT, L, ZR, CR, true);
+        p->lay = MfmaLayout(HT, L, zr_inst, CR, true);
         p->launch = nullptr;
         p->cfg = c;
         p->nthreads = 256;
@@ -112,7 +113,7 @@ MfmaPlan* mfma_plan_create(const cnf_config& c) {
         p->kind = 1;
         p->arith = 0;
         p->fwd_scale = c.acts[0] == CNF_ACT_TANH ? kTanhPrescale : 1.f;   // cnf_coop.hip runs pre-scaled tanh
-        snprintf(p->name, sizeof(p->name), "coop_vjp<HT=%d,L=%d,ZR=%d,act=%d>", HT, L, ZR, c.acts[0]);
+        snprintf(p->name, sizeof(p->name), "coop_vjp<HT=%d,L=%d,ZR=%d,act=%d>", HT, L, zr_inst, c.acts[0]);
         return p;
     };
     if (force_coop) return c.arith == CNF_ARITH_F32 ? make_coop() : nullptr;

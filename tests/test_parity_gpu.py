@@ -104,8 +104,12 @@ CASES = [
     (dict(nvars=6, ncond=16, hidden=[64, 64], mode=1, reg_j=True), 90, 0, 20),             # conditioned JVP
     (dict(nvars=10, hidden=[96, 96], act=2, mode=2), 70, 0, 20),                           # exact trace, D=10, softplus
     (dict(nvars=16, hidden=[128, 128, 128], mode=2, autonomous=True), 40, 0, 10),          # exact trace, D=16, 3x128
+    # zero-padded cooperative wide-layer instances (csrc/cnf_coop.hip)
+    (dict(nvars=20, hidden=[192, 192], act=2, reg_z=True, reg_j=True), 70, 1, 8),          # D=20, 2x192 softplus
+    (dict(nvars=6, naug=2, hidden=[256, 256, 256], reg_z=True, reg_j=True, reg_aug=True), 100, 0, 8),  # D=8, 3x256
+    (dict(nvars=30, hidden=[128, 128], autonomous=True), 65, 1, 6),                         # D=30, 2x128 autonomous
 ]
-GENERIC_MFMA_CASES = CASES[-5:]
+GENERIC_MFMA_CASES = CASES[-8:]
 
 
 @pytest.mark.parametrize("kw,B,alg,nsteps", GENERIC_MFMA_CASES)
