@@ -507,6 +507,36 @@ def test_full_size_cfg5_exact_trace_equals_unit_probe_hutchinson(pkg, oracles):
     assert float((ue[D] - D * uk[D]).abs().max()) < 1e-4
 
 
+FULL_SIZE = [
+    # BASELINE.json configs at their full batch sizes: (name, make_spec kwargs, B, alg)
+    ("cfg2p", dict(nvars=8, hidden=[64, 64, 64]), 65536, 1),
+    ("cfg3", dict(nvars=8, hidden=[64, 64, 64], nprobes=4, reg_z=True, reg_j=True), 65536, 1),
+    ("cfg4", dict(nvars=32, hidden=[256, 256, 256]), 32768, 0),
+    ("cfg5", dict(nvars=8, ncond=8, hidden=[128, 128, 128], mode=2), 16384, 0),
+]
+
+
+@pytest.mark.parametrize("name,kw,B,alg", FULL_SIZE)
+def test_full_size_every_column_matches_the_c_restatement(name, kw, B, alg, pkg, oracles):
+    """All B columns of the full-size solve (40 steps) against oracle/cnf_oracle.c on every host core:
+    max |dlogp| < 1e-4 (north_star), plus the regulariser rows and the final state."""
+    import os
+    o64, oc = oracles
+    spec = o64.make_spec(**kw)
+    p, xs, eps, ys = o64.synth_inputs(spec, B, 20240700 + len(name))
+    icnf = make_icnf(pkg, spec, alg, 40)
+    logp, regs, u1 = run_inference(pkg, icnf, spec, p, xs, eps, ys, return_state=True)
+    assert icnf.kernel_path(mode_of(pkg, spec)) == 2
+    nt = max(1, min(os.cpu_count() or 1, oc.max_threads()))
+    ref_logp, ref_regs, ref_u = oc.inference_fixed(spec, p, xs, 0.0, 1.0, 40, alg, eps, ys, nthreads=nt)
+    err = np.abs(logp.cpu().numpy() - ref_logp)
+    assert err.max() < TOL_SOLVE, (name, float(err.max()), int(err.argmax()))
+    for a, b in zip(regs, ref_regs):
+        assert np.max(np.abs(a.cpu().numpy() - b)) < TOL_SOLVE
+    assert np.max(np.abs(u1.cpu().numpy() - ref_u)) < TOL_SOLVE
+    print(f"{name}: B={B} max|dlogp|={err.max():.2e} mean={err.mean():.2e} ({nt} CPU threads)")
+
+
 def test_generate_inverts_inference(pkg, oracles):
     """generate integrates the reversed tspan (src/core/base_icnf.jl:372): pushing x forward
     to z and pulling z back must return x (integrator error only)."""
