@@ -87,9 +87,13 @@ static int env_int(const char* name, int dflt) {
 MfmaPlan* mfma_plan_create(const cnf_config& c) {
     const int N = c.n_layers, L = N - 1;
     if (L < 1) return nullptr;
-    const int H = c.widths[1];
-    for (int l = 1; l <= L; ++l)
-        if (c.widths[l] != H || c.acts[l - 1] != c.acts[0]) return nullptr;
+    // hidden layers may have different widths: every one is zero-padded to the widest (act(0) of a padded
+    // feature only ever meets zero weights), so only the activation has to be common
+    int H = 0;
+    for (int l = 1; l <= L; ++l) {
+        if (c.acts[l - 1] != c.acts[0]) return nullptr;
+        if (c.widths[l] > H) H = c.widths[l];
+    }
     if (c.acts[N - 1] != CNF_ACT_IDENTITY) return nullptr;
     const int D = c.nvars + c.naug;
     const int HT = (H + 15) / 16, ZR = (D + 3) / 4, CR = (c.ncond + 3) / 4;
@@ -197,7 +201,7 @@ static inline float bf16_val(unsigned short b) {
     return f;
 }
 template <typename F>
-static void pack_imgH16(float* out, int HT, int H, F A) {
+static void pack_imgH16(float* out, int HT, int M, int K, F A) {
     unsigned short* o = reinterpret_cast<unsigned short*>(out);
     const int NC = HT / 2;
     for (int mt = 0; mt < HT; ++mt)
@@ -206,7 +210,7 @@ static void pack_imgH16(float* out, int HT, int H, F A) {
                 for (int j = 0; j < 8; ++j) {
                     const int row = mfma_rowmap(mt, lane & 15);
                     const int k = 16 * (2 * c + (j >> 2)) + 4 * (j & 3) + (lane >> 4);
-                    const float w = (row < H && k < H) ? A(row, k) : 0.f;
+                    const float w = (row < M && k < K) ? A(row, k) : 0.f;
                     unsigned short part[3];
                     part[0] = bf16_rne(w);
                     const float r1 = w - bf16_val(part[0]);
@@ -232,7 +236,8 @@ static void pack_vecC(float* out, int MT, int M, F v) {
 void mfma_pack(const MfmaPlan* p, const float* lux, const size_t* w_off, const size_t* b_off, float* packed) {
     const cnf_config& c = p->cfg;
     const MfmaLayout& Y = p->lay;
-    const int N = c.n_layers, L = N - 1, H = c.widths[1], D = c.nvars + c.naug, C = c.ncond;
+    const int N = c.n_layers, L = N - 1, D = c.nvars + c.naug, C = c.ncond;
+    auto Hl = [&](int l) { return c.widths[l]; };   // width of hidden layer l (1-based); padded to 16 HT
     const int n_in = c.widths[0];
     const int tcol = D;                           // time column of W1 (if !autonomous)
     const int ycol = D + (c.autonomous ? 0 : 1);  // first cond column
@@ -241,25 +246,25 @@ void mfma_pack(const MfmaPlan* p, const float* lux, const size_t* w_off, const s
     auto W = [&](int l, int o, int i) { return lux[w_off[l] + (size_t)o + (size_t)c.widths[l + 1] * i]; };
     auto Bv = [&](int l, int o) { return lux[b_off[l] + o]; };
     const float fs = p->fwd_scale;   // hidden-layer pre-activations are produced pre-scaled (forward images only)
-    pack_imgA(packed + Y.f1z, Y.HT, Y.KGZ, H, D, [&](int r, int k) { return fs * W(0, r, k); });
-    if (Y.CR > 0) pack_imgA(packed + Y.f1y, Y.HT, Y.KGC, H, C, [&](int r, int k) { return fs * W(0, r, ycol + k); });
+    pack_imgA(packed + Y.f1z, Y.HT, Y.KGZ, Hl(1), D, [&](int r, int k) { return fs * W(0, r, k); });
+    if (Y.CR > 0) pack_imgA(packed + Y.f1y, Y.HT, Y.KGC, Hl(1), C, [&](int r, int k) { return fs * W(0, r, ycol + k); });
     for (int l = 1; l < L; ++l) {
-        if (Y.arith) pack_imgH16(packed + Y.fh + (l - 1) * Y.imgHid(), Y.HT, H, [&](int r, int k) { return fs * W(l, r, k); });
-        else pack_imgA(packed + Y.fh + (l - 1) * Y.imgHid(), Y.HT, Y.HT, H, H, [&](int r, int k) { return fs * W(l, r, k); });
+        if (Y.arith) pack_imgH16(packed + Y.fh + (l - 1) * Y.imgHid(), Y.HT, Hl(l + 1), Hl(l), [&](int r, int k) { return fs * W(l, r, k); });
+        else pack_imgA(packed + Y.fh + (l - 1) * Y.imgHid(), Y.HT, Y.HT, Hl(l + 1), Hl(l), [&](int r, int k) { return fs * W(l, r, k); });
     }
-    pack_imgA(packed + Y.fN, Y.DT, Y.HT, D, H, [&](int r, int k) { return W(L, r, k); });
+    pack_imgA(packed + Y.fN, Y.DT, Y.HT, D, Hl(L), [&](int r, int k) { return W(L, r, k); });
     if (p->with_bwd) {
-        pack_imgA(packed + Y.bN, Y.HT, Y.KGZ, H, D, [&](int r, int k) { return W(L, k, r); });   // W_N^T
+        pack_imgA(packed + Y.bN, Y.HT, Y.KGZ, Hl(L), D, [&](int r, int k) { return W(L, k, r); });   // W_N^T
         for (int l = 1; l < L; ++l) {                                                                 // W_l^T
-            if (Y.arith) pack_imgH16(packed + Y.bh + (l - 1) * Y.imgHid(), Y.HT, H, [&](int r, int k) { return W(l, k, r); });
-            else pack_imgA(packed + Y.bh + (l - 1) * Y.imgHid(), Y.HT, Y.HT, H, H, [&](int r, int k) { return W(l, k, r); });
+            if (Y.arith) pack_imgH16(packed + Y.bh + (l - 1) * Y.imgHid(), Y.HT, Hl(l), Hl(l + 1), [&](int r, int k) { return W(l, k, r); });
+            else pack_imgA(packed + Y.bh + (l - 1) * Y.imgHid(), Y.HT, Y.HT, Hl(l), Hl(l + 1), [&](int r, int k) { return W(l, k, r); });
         }
-        pack_imgA(packed + Y.b1, Y.DT, Y.HT, D, H, [&](int r, int k) { return W(0, k, r); });     // W_1[:,0:D]^T
+        pack_imgA(packed + Y.b1, Y.DT, Y.HT, D, Hl(1), [&](int r, int k) { return W(0, k, r); });     // W_1[:,0:D]^T
     }
-    pack_vecC(packed + Y.v_b1, Y.HT, H, [&](int f) { return fs * Bv(0, f); });
-    pack_vecC(packed + Y.v_w1t, Y.HT, H, [&](int f) { return c.autonomous ? 0.f : fs * W(0, f, tcol); });
+    pack_vecC(packed + Y.v_b1, Y.HT, Hl(1), [&](int f) { return fs * Bv(0, f); });
+    pack_vecC(packed + Y.v_w1t, Y.HT, Hl(1), [&](int f) { return c.autonomous ? 0.f : fs * W(0, f, tcol); });
     for (int l = 1; l < L; ++l)
-        pack_vecC(packed + Y.v_bh + (l - 1) * MfmaLayout::vecC(Y.HT), Y.HT, H, [&](int f) { return fs * Bv(l, f); });
+        pack_vecC(packed + Y.v_bh + (l - 1) * MfmaLayout::vecC(Y.HT), Y.HT, Hl(l + 1), [&](int f) { return fs * Bv(l, f); });
     pack_vecC(packed + Y.v_bN, Y.DT, D, [&](int f) { return Bv(L, f); });
 }
 

@@ -374,7 +374,10 @@ def test_randomised_shapes_fused_vs_generic_kernels(pkg, oracles):
         act = int(rng.choice([1, 2]))
         mode = int(rng.choice([0, 0, 1, 2]))
         reg = bool(rng.integers(0, 2)) and mode != 2
-        kw = dict(nvars=D - naug, naug=naug, ncond=C, hidden=[H] * L, act=act, mode=mode,
+        hidden = [H] * L
+        if rng.integers(0, 3) == 0:                           # non-uniform widths: padded to the widest layer
+            hidden = [int(rng.choice([8, 12, 16, 24, 32, 40, 48, 64])) for _ in range(L)]
+        kw = dict(nvars=D - naug, naug=naug, ncond=C, hidden=hidden, act=act, mode=mode,
                   autonomous=bool(rng.integers(0, 4) == 0), reg_z=reg, reg_j=reg, reg_aug=reg and naug > 0)
         spec = o64.make_spec(**kw)
         alg, nsteps, B = int(rng.integers(0, 2)), int(rng.integers(2, 6)), int(rng.integers(1, 90))
