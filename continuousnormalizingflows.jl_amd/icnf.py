@@ -28,7 +28,7 @@ import torch
 from . import _lib
 
 __all__ = [
-    "ICNF", "TrainMode", "TestMode", "Dense", "Chain", "tanh", "softplus", "identity",
+    "ICNF", "TrainMode", "TestMode", "Dense", "Chain", "PlanarLayer", "tanh", "softplus", "identity",
     "HIPVecJacMatrixMode", "HIPJacVecMatrixMode", "LuxVecJacMatrixMode", "LuxJacVecMatrixMode",
     "DIVecJacMatrixMode", "DIJacVecMatrixMode", "Tsit5", "RK4", "setup", "inference", "generate",
     "loss", "augmented_f", "loss_and_gradient",
@@ -121,10 +121,30 @@ class Dense:
                             "(supported: identity, tanh, softplus)") from None
 
 
+@dataclass
+class PlanarLayer:
+    """PlanarLayer(in => out, activation): z -> u * activation(w' z + b)  (src/layers/planar_layer.jl:6-77).
+    It is the Dense chain Dense(in => 1, activation) -> Dense(1 => out) with the second bias pinned to zero,
+    so it runs on the same kernels; only the parameter order differs: ps = (u (out), w (in), b (1))
+    (src/layers/planar_layer.jl:36-50).  Use it as `nn=Chain(PlanarLayer(...))` like the reference's tests
+    (test/ci_tests/smoke_tests.jl:32-46)."""
+    n_in: int
+    n_out: int
+    activation: Union[Callable, str, None] = identity
+    use_bias: bool = True
+
+
 class Chain:
-    def __init__(self, *layers: Dense):
+    def __init__(self, *layers):
         if not layers:
             raise ValueError("Chain needs at least one Dense layer")
+        self.planar = None
+        if len(layers) == 1 and isinstance(layers[0], PlanarLayer):
+            pl = layers[0]
+            self.planar = pl
+            layers = (Dense(pl.n_in, 1, pl.activation), Dense(1, pl.n_out, identity))
+        elif any(isinstance(l, PlanarLayer) for l in layers):
+            raise TypeError("MethodError: PlanarLayer is supported as the only layer of the Chain")
         for a, b in zip(layers[:-1], layers[1:]):
             if a.n_out != b.n_in:
                 raise ValueError(f"DimensionMismatch: Dense({a.n_in}=>{a.n_out}) followed by "
@@ -136,7 +156,14 @@ class Chain:
         return [self.layers[0].n_in] + [l.n_out for l in self.layers]
 
     def param_offsets(self):
-        """ComponentArray layout: layer_k.weight (out x in, column-major), layer_k.bias."""
+        """ComponentArray layout: layer_k.weight (out x in, column-major), layer_k.bias.
+        For a PlanarLayer: (u, w, b); the ABI view appends the pinned zero bias (and a zero b when
+        use_bias = false) behind the user's vector — see abi_params."""
+        if self.planar is not None:
+            pl = self.planar
+            n_user = pl.n_out + pl.n_in + (1 if pl.use_bias else 0)
+            b0 = pl.n_out + pl.n_in if pl.use_bias else n_user + pl.n_out   # b, or an appended zero
+            return [pl.n_out, 0], [b0, n_user], n_user
         w_off, b_off, o = [], [], 0
         for l in self.layers:
             w_off.append(o)
@@ -144,6 +171,14 @@ class Chain:
             b_off.append(o)
             o += l.n_out
         return w_off, b_off, o
+
+    def abi_params(self, ps: torch.Tensor) -> torch.Tensor:
+        """The vector handed to cnf_set_params: ps itself for Dense chains; for a PlanarLayer ps followed
+        by the zeros that stand for the absent biases."""
+        if self.planar is None:
+            return ps
+        pad = self.planar.n_out + (0 if self.planar.use_bias else 1)
+        return torch.cat([ps, torch.zeros(pad, dtype=ps.dtype, device=ps.device)])
 
 
 # ---------------------------------------------------------------------------------------
@@ -340,10 +375,10 @@ class ICNF:
         key = (ps.data_ptr(), ps._version, str(ps.device))
         if h.params_key == key:
             return
-        ps_c = ps.contiguous()
+        ps_c = self.nn.abi_params(ps).contiguous()
         wo = (C.c_size_t * len(w_off))(*w_off)
         bo = (C.c_size_t * len(b_off))(*b_off)
-        _lib.check(h.lib.cnf_set_params(h.ptr, _ptr(ps_c), n, wo, bo, int(ps_c.is_cuda),
+        _lib.check(h.lib.cnf_set_params(h.ptr, _ptr(ps_c), ps_c.numel(), wo, bo, int(ps_c.is_cuda),
                                         _stream_ptr(self.device)))
         h.params_key = key
 
@@ -365,6 +400,12 @@ class ICNF:
 def setup(rng: Optional[torch.Generator], icnf: ICNF):
     """LuxCore.setup + ComponentArray: flat Float32 parameter vector (glorot-uniform weights,
     zero biases — Lux.Dense defaults) and an empty state."""
+    if icnf.nn.planar is not None:   # (u, w, b): glorot-uniform vectors, zero bias (planar_layer.jl:36-50)
+        pl = icnf.nn.planar
+        u = (torch.rand(pl.n_out, generator=rng, dtype=torch.float64) * 2 - 1) * math.sqrt(6.0 / (pl.n_out + 1))
+        w = (torch.rand(pl.n_in, generator=rng, dtype=torch.float64) * 2 - 1) * math.sqrt(6.0 / (pl.n_in + 1))
+        b = torch.zeros(1 if pl.use_bias else 0, dtype=torch.float64)
+        return torch.cat([u, w, b]).to(torch.float32), {}
     parts = []
     for l in icnf.nn.layers:
         lim = math.sqrt(6.0 / (l.n_in + l.n_out))
@@ -525,6 +566,8 @@ def loss_and_gradient(icnf: ICNF, mode: Mode, *args, eps: Optional[torch.Tensor]
     all-reduced (RCCL over xGMI) and every rank returns the global mean and its gradient."""
     from .sharding import reduce_gradient, reduce_loss
     xs, ys, ps, st = _split_args(icnf, args, "loss_and_gradient")
+    if icnf.nn.planar is not None:
+        raise NotImplementedError("loss_and_gradient: PlanarLayer nets are not covered by the gradient kernel")
     h = icnf._handle(mode)
     icnf._bind_params(h, ps)
     dev = icnf.device

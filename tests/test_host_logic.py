@@ -79,3 +79,23 @@ def test_reduce_loss_single_process(pkg):
     sums = torch.tensor([10.0, 2.0, 4.0, 6.0])
     out = pkg.reduce_loss(sums, 4, (0.5, 0.25, 0.0))
     assert np.isclose(float(out), (10 + 1 + 1) / 4)
+
+
+def test_planar_layer_maps_onto_a_dense_chain(pkg):
+    """PlanarLayer(in => out, act) = Dense(in => 1, act) -> Dense(1 => out) with a zero second bias; its
+    ComponentArray order is (u, w, b) (src/layers/planar_layer.jl:36-50)."""
+    nn = pkg.Chain(pkg.PlanarLayer(6, 5, pkg.tanh))
+    assert nn.widths == [6, 1, 5] and [l.act_id for l in nn.layers] == [1, 0]
+    w_off, b_off, n = nn.param_offsets()
+    assert (w_off, b_off, n) == ([5, 0], [11, 12], 12)          # w after u; b; u; appended zero bias
+    ps = torch.arange(1, 13, dtype=torch.float32)
+    ext = nn.abi_params(ps)
+    assert ext.shape == (17,) and torch.all(ext[12:] == 0) and torch.equal(ext[:12], ps)
+    nb = pkg.Chain(pkg.PlanarLayer(6, 5, pkg.tanh, use_bias=False))
+    w_off, b_off, n = nb.param_offsets()
+    assert n == 11 and b_off == [16, 11] and nb.abi_params(torch.ones(11)).shape == (17,)
+    icnf = pkg.ICNF(nvariables=2, nn=nn)                      # the reference's smoke-test shape: 2*2+2 => 2*2+1
+    ps, st = pkg.setup(torch.Generator().manual_seed(1), icnf)
+    assert ps.shape == (12,) and float(ps[11]) == 0.0
+    with pytest.raises(TypeError, match="MethodError"):
+        pkg.Chain(pkg.PlanarLayer(6, 5), pkg.Dense(5, 5))

@@ -578,6 +578,38 @@ def test_layer_call_and_drawn_probes(pkg, oracles):
     assert float((a - e1).abs().max()) < 5.0
 
 
+@pytest.mark.parametrize("use_bias,conditioned", [(True, False), (False, False), (True, True)])
+def test_planar_layer_net_matches_the_equivalent_dense_chain(use_bias, conditioned, pkg, oracles):
+    """The reference's alternative nn (test/ci_tests/smoke_tests.jl:32-46): ICNF(nn = Chain(PlanarLayer(...))),
+    inference in TrainMode{true} and TestMode, against the oracle run on the equivalent Dense chain."""
+    o64, oc = oracles
+    nv, C = 2, (2 if conditioned else 0)
+    D = 2 * nv + 1                                           # nvariables + naugments (default nvariables + 1)
+    n_in = D + 1 + C
+    rng = np.random.default_rng(5)
+    u, w = rng.uniform(-0.7, 0.7, D), rng.uniform(-0.7, 0.7, n_in)
+    b = rng.uniform(-0.3, 0.3, 1) if use_bias else np.zeros(0)
+    ps = np.concatenate([u, w, b]).astype(np.float32)
+    B = 50
+    xs = rng.standard_normal((nv, B)).astype(np.float32)
+    eps = rng.standard_normal((D, B)).astype(np.float32)
+    ys = rng.standard_normal((C, B)).astype(np.float32) if C else None
+    for mode_id, mode in ((0, pkg.TrainMode(True)), (2, pkg.TestMode())):
+        spec = o64.Spec(nvars=nv, naug=nv + 1, ncond=C, widths=[n_in, 1, D], acts=[1, 0], mode=mode_id,
+                        reg_z=mode_id == 0, reg_j=mode_id == 0, reg_aug=mode_id == 0)
+        p_dense = np.concatenate([w, b if use_bias else np.zeros(1), u, np.zeros(D)]).astype(np.float32)
+        ref = oc.inference_fixed(spec, p_dense, xs, 0.0, 1.0, 20, 1, eps, ys, nthreads=2)
+        icnf = pkg.ICNF(nvariables=nv, nconditions=C, nn=pkg.Chain(pkg.PlanarLayer(n_in, D, pkg.tanh, use_bias=use_bias)),
+                        steer_rate=0.0, device="cuda:0", sol_kwargs=dict(alg=pkg.Tsit5(), adaptive=False, nsteps=20))
+        args = (dev(xs),) + ((dev(ys),) if C else ()) + (dev(ps), {})
+        logp, (E, n, A) = pkg.inference(icnf, mode, *args, eps=dev(eps))
+        assert np.max(np.abs(logp.cpu().numpy() - ref[0])) < TOL_SOLVE
+        for a_, b_ in zip((E, n, A), ref[1]):
+            assert np.max(np.abs(a_.cpu().numpy() - b_)) < TOL_SOLVE
+    samples = pkg.generate(icnf, pkg.TestMode(), *(((dev(ys),) if C else ()) + (dev(ps), {}, B)))
+    assert samples.shape == (nv, B) and bool(torch.isfinite(samples).all())
+
+
 def test_errors_surface_as_exceptions(pkg, oracles):
     o64, _ = oracles
     spec = o64.make_spec(nvars=8, hidden=[64, 64, 64])
