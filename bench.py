@@ -69,6 +69,31 @@ F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 = f
 HBM_PEAK_GBS = 8000.0
 
 
+def grad_mfma_per_stage(spec):
+    """MFMA instructions one wave executes per RK stage for loss + gradient (forward solve kernel + reverse
+    sweep), counted from the kernels' loops (csrc/cnf_mfma_kernel.h, cnf_grad.hip, cnf_grad_probes.hip):
+    a product with MT output tiles and KS k-steps is MT*KS instructions; an outer-product update of one
+    16x16 tile over the workgroup's 4 sample tiles is 4 x 4."""
+    H, L, K = max(spec.widths[1:-1]), len(spec.acts) - 1, spec.nprobes
+    HT, ZR, CR = -(-H // 16), -(-spec.D // 4), -(-spec.ncond // 4)
+    DT = -(-ZR // 4)
+    hid, first, last = (L - 1) * 4 * HT * HT, HT * (ZR + CR), DT * 4 * HT
+    # forward solve kernel: chain, then the pullback per probe (one probe: c = W_N^T eps hoisted, and
+    # without |eps^T J| the last product is a dot with the hoisted q = W_1 eps)
+    fwd = first + hid + last
+    fwd += hid + (last if spec.reg_j else 0) if K == 1 else K * (HT * ZR + hid + last)
+    chain = first + hid + (last if spec.reg_z else 0)          # recompute of h_l, act'_l (+ zdot for |zdot|)
+    top = HT * ZR + hid + last                                 # W_N^T kbar, W_l^T abar_l, W_1^T abar_1
+    if K == 1:
+        rev = chain + hid + ((last + HT * ZR) if spec.reg_j else 0) + hid + top
+        rev += 4 * 8 + (L - 1) * 4 * (4 + 8 * HT) + 4 * (8 + (4 if CR else 0))
+    else:
+        per_probe = HT * ZR + hid + (last if spec.reg_j else 0) + HT * ZR + hid + (L - 1) * 16 * HT + 4 * 8
+        rev = chain + K * per_probe + top
+        rev += 4 * 4 + (L - 1) * 4 * (4 + 4 * HT) + 4 * (4 + (4 if CR else 0))
+    return fwd + rev
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -210,9 +235,8 @@ def main():
         stages = 4 if alg == 0 else 6
         if a.mode == "grad":
             # executed MFMA work of forward + reverse sweep per sample*step, not an
-            # algorithmic figure: (280 + 1016) MFMAs of 2048 flop per stage per 16-sample tile (cfg2 shape)
-            stages_ = 4 if alg == 0 else 6
-            flop_ss = (280 + 1016) * 2048 / 16 * stages_
+            # algorithmic figure: v_mfma_f32_16x16x4_f32 instructions (2048 flop) per stage per 16-sample tile
+            flop_ss = grad_mfma_per_stage(spec) * 2048 / 16 * stages
             flops_launch = float(flop_ss) * B * NSTEPS
             ach_tflops = flops_launch / (kern_ms * 1e-3) / 1e12
         out = {

@@ -367,7 +367,7 @@ int cnf_loss_grad_fixed(cnf_handle* h, int alg, int nsteps, float t0, float t1, 
     if (!x || !grad || !lambdas) return fail(CNF_ERR_INVALID, "cnf_loss_grad_fixed: null x/grad/lambdas");
     if (h->path != CNF_PATH_MFMA || !grad_supported(h->cfg) || !h->grad_packed)
         return fail(CNF_ERR_UNSUPPORTED, "cnf_loss_grad_fixed: configuration not covered by the gradient kernel "
-                                         "(Hutchinson VJP, K=1, <= 16 conditions, 2-3 equal tanh/softplus hidden layers of width <= 64, D <= 14)");
+                                         "(Hutchinson VJP, <= 16 conditions, 2-3 equal tanh/softplus hidden layers of width <= 64, D <= 14)");
     DeviceGuard g(h->cfg.device_id);
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(hipMemsetAsync(grad, 0, h->nparams * sizeof(float), st));

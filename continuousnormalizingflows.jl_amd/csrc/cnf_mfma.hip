@@ -162,6 +162,17 @@ MfmaPlan* mfma_plan_create(const cnf_config& c) {
                 (size_t)MfmaLayout(HT, L, in.ZR, in.CR, engine == ENG_VJP).total * sizeof(float) <= kMaxLds)
                 return make(in);
         }
+        // several probes: instances with a register capacity of KP >= K probes, K passed at run time
+        if (KP > 1) {
+            gen = mfma_generic_probe_insts(&ng);
+            for (int i = 0; i < ng; ++i) {
+                const Inst& in = gen[i];
+                if (in.HT == HT && in.L == L && in.ZR >= ZR && in.CR >= CR && (CR > 0 || in.CR == 0) &&
+                    act_matches(in.ACT, c.acts[0]) && in.ENGINE == engine && in.KP >= KP &&
+                    (size_t)MfmaLayout(HT, L, in.ZR, in.CR, engine == ENG_VJP).total * sizeof(float) <= kMaxLds)
+                    return make(in);
+            }
+        }
     }
     // 3. cooperative wide-layer kernel
     return make_coop();
@@ -304,6 +315,7 @@ hipError_t mfma_solve(MfmaPlan* p, const float* packed_dev, const SolveArgs& s, 
     a.reg_z = p->cfg.reg_z; a.reg_j = p->cfg.reg_j; a.reg_aug = s.reg_aug; a.autonomous = p->cfg.autonomous;
     a.T = make_tableau(s.alg);
     a.exact = p->cfg.mode == CNF_MODE_EXACT;
+    a.K = p->KP;
     a.prio_mode = p->prio_mode;
     a.queue = nullptr;
     if (mp->use_queue) {

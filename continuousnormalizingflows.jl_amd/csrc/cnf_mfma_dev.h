@@ -20,6 +20,7 @@ struct KArgs {
     int nsteps;         // 0: single dynamics call at t0, du -> u_out
     float t0, dt;
     int nvars, D, C, reg_z, reg_j, reg_aug, autonomous;
+    int K;              // live Hutchinson probes (<= the instance's capacity KP)
     int exact;          // tangent engine only: seeds are the D unit vectors, ldot = -tr J
     int prio_mode;      // 0 none, 1 waves 0..3 high, 2 waves 4.. high (SIMD partners = w, w+4)
     int* queue;         // dynamic tile queue (zeroed before the launch) or null = static stride

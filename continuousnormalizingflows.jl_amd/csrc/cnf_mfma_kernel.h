@@ -133,7 +133,7 @@ __device__ __forceinline__ void gemm_hidden(const float* __restrict__ img, int l
 //            tangents whose i-th output row is J_ii (trace of src/core/utils.jl:79-88, icnf.jl:312)
 template <int HT, int L, int ZR, int CR, int ACT, int ENGINE, int KP, int PRE, int ARITH>
 __device__ __forceinline__ void dyn_eval(const float* __restrict__ smem, int lane, float t,
-                                         bool autonomous, bool reg_z, bool reg_j, bool exact, int D,
+                                         bool autonomous, bool reg_z, bool reg_j, bool exact, int D, int K,
                                          const float (&z)[ZR], const float (&y)[CR > 0 ? CR : 1],
                                          const float (&eps)[KP][ZR], const f32x4 (&pre_c)[HT],
                                          const f32x4 (&pre_q)[HT], float (&zd)[ZR], float& ld,
@@ -200,8 +200,9 @@ __device__ __forceinline__ void dyn_eval(const float* __restrict__ smem, int lan
     // Probes / tangents run one after the other (rolled loop): the operand images are re-read
     // from LDS each time, which costs LDS bandwidth the kernel has to spare and keeps the
     // register footprint flat.
-    const int nseed = (ENGINE == ENG_TAN && exact) ? D : KP;
-    const float scale = (ENGINE == ENG_TAN && exact) ? 1.f : 1.f / (float)KP;
+    // K <= KP probes are live (KP is the instance's register capacity; K == KP == 1 for the hoisting instances)
+    const int nseed = (ENGINE == ENG_TAN && exact) ? D : K;
+    const float scale = (ENGINE == ENG_TAN && exact) ? 1.f : 1.f / (float)K;
 #pragma clang loop unroll(disable)
     for (int p = 0; p < nseed; ++p) {
         float ep[ZR];
@@ -306,7 +307,8 @@ mfma_solve_kernel(KArgs a) {
     constexpr int WPB = NTHREADS / 64;
     const long long ntiles = (a.B + 15) / 16;
     const int D = a.D, S = D + 3, C = a.C;
-    const int Kd = KP * D;
+    const int K = KP == 1 ? 1 : a.K;   // live probes (<= KP)
+    const int Kd = K * D;
     const bool reg_z = a.reg_z, reg_j = a.reg_j, autonomous = a.autonomous, exact = a.exact;
 
     // SIMD partners (waves w and w+4 of a workgroup) run the same program; left alone they fall
@@ -342,7 +344,7 @@ mfma_solve_kernel(KArgs a) {
             if (a.x) z[s] = f < a.nvars ? a.x[sc * a.nvars + f] : 0.f;   // u0 = [x; 0]
             else z[s] = f < D ? a.u0[sc * S + f] : 0.f;
 #pragma unroll
-            for (int p = 0; p < KP; ++p) eps[p][s] = (f < D && a.eps) ? a.eps[sc * Kd + p * D + f] : 0.f;
+            for (int p = 0; p < KP; ++p) eps[p][s] = (f < D && p < K && a.eps) ? a.eps[sc * Kd + p * D + f] : 0.f;
         }
         if (!a.x) { lacc = a.u0[sc * S + D]; eacc = a.u0[sc * S + D + 1]; nacc = a.u0[sc * S + D + 2]; }
         y[0] = 0.f;
@@ -397,7 +399,7 @@ mfma_solve_kernel(KArgs a) {
                 int opaque = 0;
                 asm volatile("" : "+v"(opaque));
                 dyn_eval<HT, L, ZR, CR, ACT, ENGINE, KP, PRE, ARITH>(smem + opaque, lane, tn + a.T.c[st] * dt, autonomous,
-                                                              reg_z, reg_j, exact, D, zs, y, eps, pre_c, pre_q, zd,
+                                                              reg_z, reg_j, exact, D, K, zs, y, eps, pre_c, pre_q, zd,
                                                               ld, ed, nd);
                 if (a.ckpt_k) {
 #pragma unroll
@@ -508,6 +510,8 @@ struct Inst {
 
 // generic zero-padded instances (cnf_mfma_generic.hip): D <= 16 and C <= 16 or C = 0
 const Inst* mfma_generic_insts(int* count);
+// the same shapes with a capacity of several Hutchinson probes (cnf_mfma_generic_probes.hip): VJP, K <= KP
+const Inst* mfma_generic_probe_insts(int* count);
 
 
 }  // namespace cnf

@@ -150,7 +150,7 @@ int cnf_loss_sums(cnf_handle* h, const float* logp, const float* regs, int64_t B
  * discrete solve.  grad: device, n floats in the layout of cnf_set_params' p (overwritten).
  * sums4 (device, may be NULL): as cnf_loss_sums.  The caller all-reduces grad and sums4 across
  * column shards and divides by the global column count.
- * First implementation: Hutchinson VJP, K = 1, <= 16 conditions, 2 or 3 equal hidden layers (tanh or
+ * Covered: Hutchinson VJP with 1 <= K <= 8 probes, <= 16 conditions, 2 or 3 equal hidden layers (tanh or
  * softplus) of width <= 64, D + !autonomous <= 15; FFJORD and RNODE losses; CNF_ERR_UNSUPPORTED otherwise. */
 int cnf_loss_grad_fixed(cnf_handle* h, int alg, int nsteps, float t0, float t1, const float* x,
                         const float* eps, const float* ys, int64_t B, const float* lambdas,

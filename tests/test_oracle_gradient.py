@@ -8,9 +8,13 @@ import numpy as np
 from conftest import GOLDEN
 
 
-def test_loss_gradient_matches_finite_differences(oracles):
+import pytest
+
+
+@pytest.mark.parametrize("nprobes", [1, 3])
+def test_loss_gradient_matches_finite_differences(nprobes, oracles):
     o64, _ = oracles
-    spec = o64.make_spec(nvars=3, hidden=[8, 8], reg_z=True, reg_j=True)
+    spec = o64.make_spec(nvars=3, hidden=[8, 8], reg_z=True, reg_j=True, nprobes=nprobes)
     p, xs, eps, _ = o64.synth_inputs(spec, 5, 31, bias_scale=0.2)
     lam = (0.01, 0.02, 0.0)
     L, g = o64.loss_and_grad(spec, p, xs, 0.0, 1.0, 4, o64.ALG_RK4, eps, None, lam)

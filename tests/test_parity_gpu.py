@@ -299,6 +299,55 @@ def test_parameter_gradient_other_shapes_and_softplus(kw, lam, B, alg, nsteps, p
     assert np.max(np.abs(g - gref)) < 5e-5 * scale + 1e-6, np.max(np.abs(g - gref)) / scale
 
 
+PROBE_GRAD_SHAPES = [
+    # (make_spec kwargs, lambdas, B, alg, nsteps): several Hutchinson probes (csrc/cnf_grad_probes.hip)
+    (dict(nvars=8, hidden=[64, 64, 64], nprobes=4, reg_z=True, reg_j=True), (0.01, 0.01, 0.0), 70, 1, 3),   # BASELINE cfg3 shape (RNODE, K = 4)
+    (dict(nvars=8, hidden=[64, 64, 64], nprobes=2), (0.0, 0.0, 0.0), 37, 0, 4),                              # FFJORD, K = 2, no regularisers
+    (dict(nvars=2, naug=3, hidden=[24, 24], act=2, nprobes=3, reg_z=True, reg_j=True, reg_aug=True), (0.02, 0.03, 0.01), 21, 1, 3),
+    (dict(nvars=6, ncond=5, hidden=[40, 40, 40], nprobes=2, reg_j=True), (0.0, 0.05, 0.0), 18, 0, 3),        # conditioned, padded hidden width
+    (dict(nvars=11, hidden=[16, 16], nprobes=5, autonomous=True), (0.0, 0.0, 0.0), 9, 1, 2),
+]
+
+
+@pytest.mark.parametrize("kw,lam,B,alg,nsteps", PROBE_GRAD_SHAPES)
+def test_parameter_gradient_with_several_probes(kw, lam, B, alg, nsteps, pkg, oracles):
+    """K > 1 probes: ldot and ndot are probe means (1/K sum_k), the gradient kernel runs the pullback
+    and its reverse once per probe.  Checked against the fp64 autograd oracle."""
+    o64, _ = oracles
+    spec = o64.make_spec(**kw)
+    p, xs, eps, ys = o64.synth_inputs(spec, B, 91, bias_scale=0.2)
+    L, gref = o64.loss_and_grad(spec, p, xs, 0.0, 1.0, nsteps, alg, eps, ys, lam)
+    icnf = make_icnf(pkg, spec, alg, nsteps, path=2, lambdas=lam)
+    args = (dev(xs),) + ((dev(ys),) if spec.ncond else ()) + (dev(p), {})
+    val, g = pkg.loss_and_gradient(icnf, pkg.TrainMode(True), *args, eps=dev(eps))
+    g = g.cpu().numpy().astype(np.float64)
+    assert abs(float(val) - L) < 1e-4
+    scale = np.abs(gref).max()
+    assert np.max(np.abs(g - gref)) < 5e-5 * scale + 1e-6, np.max(np.abs(g - gref)) / scale
+    # the probes matter: one probe alone gives a measurably different gradient
+    kw1 = dict(kw, nprobes=1)
+    _, g1 = o64.loss_and_grad(o64.make_spec(**kw1), p, xs, 0.0, 1.0, nsteps, alg, eps[:spec.D], ys, lam)
+    assert np.max(np.abs(g1 - gref)) > 1e-3 * scale
+
+
+def test_probe_gradient_kernel_agrees_with_the_single_probe_kernel(pkg, oracles):
+    """K identical probes have the same loss and gradient as one probe: the two gradient kernels
+    (cnf_grad.hip, cnf_grad_probes.hip) are independent implementations of the reverse sweep."""
+    o64, _ = oracles
+    kw = dict(nvars=8, hidden=[64, 64, 64], reg_z=True, reg_j=True)
+    lam = (0.02, 0.03, 0.0)
+    s1, s3 = o64.make_spec(**kw), o64.make_spec(nprobes=3, **kw)
+    B = 2000
+    p, xs, eps, _ = o64.synth_inputs(s1, B, 17, bias_scale=0.1)
+    i1 = make_icnf(pkg, s1, 1, 8, path=2, lambdas=lam)
+    i3 = make_icnf(pkg, s3, 1, 8, path=2, lambdas=lam)
+    v1, g1 = pkg.loss_and_gradient(i1, pkg.TrainMode(True), dev(xs), dev(p), {}, eps=dev(eps))
+    v3, g3 = pkg.loss_and_gradient(i3, pkg.TrainMode(True), dev(xs), dev(p), {}, eps=dev(np.tile(eps, (3, 1))))
+    assert abs(float(v1) - float(v3)) < 2e-5
+    scale = float(g1.abs().max())
+    assert float((g1 - g3).abs().max()) < 2e-5 * scale
+
+
 def test_full_size_gradient_is_additive_over_column_shards(pkg, oracles):
     """Headline size (B = 65536, Tsit5 x 40): the summed gradient of the whole batch equals the sum of
     the gradients of two column shards — the identity the multi-GPU all-reduce relies on — and the
@@ -364,7 +413,8 @@ def test_randomised_shapes_fused_vs_generic_kernels(pkg, oracles):
     SIMT kernels — two independent GPU implementations of the same math."""
     o64, _ = oracles
     rng = np.random.default_rng(20240620)
-    checked = 0
+    rng_k = np.random.default_rng(7)                          # probe counts from their own stream (shapes unchanged)
+    checked = probes_checked = 0
     for it in range(90):
         D = int(rng.integers(1, 15))
         naug = int(rng.integers(0, min(3, D)))
@@ -377,7 +427,8 @@ def test_randomised_shapes_fused_vs_generic_kernels(pkg, oracles):
         hidden = [H] * L
         if rng.integers(0, 3) == 0:                           # non-uniform widths: padded to the widest layer
             hidden = [int(rng.choice([8, 12, 16, 24, 32, 40, 48, 64])) for _ in range(L)]
-        kw = dict(nvars=D - naug, naug=naug, ncond=C, hidden=hidden, act=act, mode=mode,
+        K = int(rng_k.choice([1, 1, 2, 3, 4, 8])) if mode == 0 else 1
+        kw = dict(nvars=D - naug, naug=naug, ncond=C, hidden=hidden, act=act, mode=mode, nprobes=K,
                   autonomous=bool(rng.integers(0, 4) == 0), reg_z=reg, reg_j=reg, reg_aug=reg and naug > 0)
         spec = o64.make_spec(**kw)
         alg, nsteps, B = int(rng.integers(0, 2)), int(rng.integers(2, 6)), int(rng.integers(1, 90))
@@ -392,7 +443,8 @@ def test_randomised_shapes_fused_vs_generic_kernels(pkg, oracles):
         for u, v in zip(a[1], b[1]):
             assert float((u - v).abs().max()) < 5e-5, kw
         checked += 1
-    assert checked >= 45, checked
+        probes_checked += K > 1
+    assert checked >= 45 and probes_checked >= 8, (checked, probes_checked)
 
 
 def test_empty_batch_is_a_no_op(pkg, oracles):
