@@ -4,8 +4,10 @@
 // dispatch to the kernel families (cnf_mfma.hip: fused whole-solve MFMA kernels;
 // cnf_simt.hip: generic per-call kernels).  There is no CPU fallback: without a gfx950 device
 // every entry point that would compute returns CNF_ERR_NO_DEVICE / CNF_ERR_HIP.
+#include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -27,6 +29,76 @@ int fail(int code, const std::string& msg) {
         if (_e != hipSuccess)                                                               \
             return fail(CNF_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));    \
     } while (0)
+
+// Device-side repacking.  Every element of an operand image is either zero padding or ONE Lux parameter
+// times a constant (1, or the tanh pre-scale folded into the forward images), so an image is a gather:
+// packed[j] = p[idx[j]] * scale[j].  The map is derived from the host packer itself (pack a vector of
+// ones -> scale, pack the ramp 1, 2, 3, ... -> idx) and verified bit-for-bit against it on a random vector; an
+// image that is not a gather (the split-bf16 hidden images) fails the check and keeps the host path.
+// With a map, cnf_set_params on a device pointer is one kernel on the caller's stream: no host round
+// trip and no synchronisation in a training loop that updates ps on the device every step.
+struct PackMap {
+    int* idx = nullptr;       // device, source parameter or -1 (zero padding)
+    float* scale = nullptr;   // device
+    size_t n = 0;
+    bool valid = false;
+};
+
+__global__ void gather_pack_kernel(const float* __restrict__ p, const int* __restrict__ idx,
+                                   const float* __restrict__ scale, float* __restrict__ out, size_t n) {
+    const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const int i = idx[j];
+    out[j] = i >= 0 ? p[i] * scale[j] : 0.f;
+}
+
+// returns false (map left invalid) when the image is not a verified gather of the parameters
+bool build_pack_map(PackMap& m, size_t nparams, size_t npacked,
+                    const std::function<void(const float*, float*)>& pack) {
+    m.valid = false;
+    if (nparams == 0 || nparams >= (1u << 20)) return false;   // the ramp must stay exact after scaling
+    std::vector<float> ones(nparams, 1.f), ramp(nparams), rnd(nparams);
+    for (size_t i = 0; i < nparams; ++i) {
+        ramp[i] = (float)(i + 1);
+        rnd[i] = (float)((double)((i * 2654435761u) & 0xffffu) / 65536.0 - 0.5) * 1.7f;
+    }
+    std::vector<float> p1(npacked, 0.f), p2(npacked, 0.f), p3(npacked, 0.f);
+    pack(ones.data(), p1.data());
+    pack(ramp.data(), p2.data());
+    pack(rnd.data(), p3.data());
+    std::vector<int> idx(npacked);
+    for (size_t j = 0; j < npacked; ++j) {
+        if (p1[j] == 0.f) {
+            if (p2[j] != 0.f || p3[j] != 0.f) return false;
+            idx[j] = -1;
+            continue;
+        }
+        const double q = (double)p2[j] / (double)p1[j];
+        const long long i = llround(q) - 1;
+        if (!(i >= 0 && (size_t)i < nparams) || std::fabs(q - (double)(i + 1)) > 0.25) return false;
+        idx[j] = (int)i;
+        const float want = rnd[(size_t)i] * p1[j];   // what the kernel will compute
+        if (std::memcmp(&want, &p3[j], sizeof(float)) != 0) return false;
+    }
+    if (m.n != npacked) {
+        if (m.idx) (void)hipFree(m.idx);
+        if (m.scale) (void)hipFree(m.scale);
+        m.idx = nullptr; m.scale = nullptr; m.n = 0;
+        if (hipMalloc((void**)&m.idx, npacked * sizeof(int)) != hipSuccess) return false;
+        if (hipMalloc((void**)&m.scale, npacked * sizeof(float)) != hipSuccess) return false;
+        m.n = npacked;
+    }
+    if (hipMemcpy(m.idx, idx.data(), npacked * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) return false;
+    if (hipMemcpy(m.scale, p1.data(), npacked * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return false;
+    m.valid = true;
+    return true;
+}
+
+void free_pack_map(PackMap& m) {
+    if (m.idx) (void)hipFree(m.idx);
+    if (m.scale) (void)hipFree(m.scale);
+    m = PackMap{};
+}
 
 struct DeviceGuard {
     int prev = -1;
@@ -64,6 +136,13 @@ struct cnf_handle {
     float* grad_ws = nullptr;            // checkpoints + logp + regs
     size_t grad_ws_bytes = 0;
     int num_cus = 0;
+    // device-side repacking (see PackMap): maps for the solve image and the gradient image, rebuilt
+    // when the layout handed to cnf_set_params changes; p_stage holds host-supplied parameters
+    PackMap map_fwd, map_grad;
+    bool maps_built = false;
+    bool repack_on_device = false;
+    float* p_stage = nullptr;
+    size_t p_stage_n = 0;
 };
 
 static int ensure_ws(cnf_handle* h, int64_t B) {
@@ -166,12 +245,21 @@ int cnf_destroy(cnf_handle* h) {
     if (h->loss_partial) (void)hipFree(h->loss_partial);
     if (h->grad_packed) (void)hipFree(h->grad_packed);
     if (h->grad_ws) (void)hipFree(h->grad_ws);
+    if (h->p_stage) (void)hipFree(h->p_stage);
+    free_pack_map(h->map_fwd);
+    free_pack_map(h->map_grad);
     if (h->plan) mfma_plan_destroy(h->plan);
     delete h;
     return CNF_OK;
 }
 
 int cnf_kernel_path(const cnf_handle* h) { return h ? h->path : CNF_ERR_INVALID; }
+
+int cnf_repack_on_device(const cnf_handle* h) {
+    if (!h) return CNF_ERR_INVALID;
+    if (!h->have_params) return CNF_ERR_NO_PARAMS;
+    return h->repack_on_device ? 1 : 0;
+}
 
 int cnf_set_params(cnf_handle* h, const float* p, size_t n, const size_t* w_off,
                    const size_t* b_off, int p_is_device, void* stream) {
@@ -185,43 +273,87 @@ int cnf_set_params(cnf_handle* h, const float* p, size_t n, const size_t* w_off,
     DeviceGuard g(c.device_id);
     if (!g.ok) return fail(CNF_ERR_HIP, "cnf_set_params: hipSetDevice failed");
     hipStream_t st = (hipStream_t)stream;
-    // host copy (needed for repacking)
-    std::vector<float> host(n);
-    if (p_is_device) {
-        HIP_TRY(hipMemcpyAsync(host.data(), p, n * sizeof(float), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-    } else {
-        std::memcpy(host.data(), p, n * sizeof(float));
+    const bool mfma = h->path == CNF_PATH_MFMA;
+    const bool want_grad = mfma && mfma_plan_is_per_wave(h->plan) && grad_supported(c);
+    const bool same_layout = h->have_params && h->nparams == n &&
+                             std::equal(w_off, w_off + c.n_layers, h->w_off.begin()) &&
+                             std::equal(b_off, b_off + c.n_layers, h->b_off.begin());
+    if (!same_layout) {
+        h->w_off.assign(w_off, w_off + c.n_layers);
+        h->b_off.assign(b_off, b_off + c.n_layers);
+        h->maps_built = false;
     }
-    if (h->path == CNF_PATH_MFMA) {
-        const size_t bytes = mfma_packed_bytes(h->plan);
-        if (!h->packed_dev) HIP_TRY(hipMalloc((void**)&h->packed_dev, bytes));
-        std::vector<float> packed(bytes / sizeof(float), 0.f);
-        mfma_pack(h->plan, host.data(), w_off, b_off, packed.data());
-        HIP_TRY(hipMemcpyAsync(h->packed_dev, packed.data(), bytes, hipMemcpyHostToDevice, st));
-        HIP_TRY(hipStreamSynchronize(st));
-    } else {
-        if (h->P_dev && h->nparams != n) {
-            HIP_TRY(hipFree(h->P_dev));
-            h->P_dev = nullptr;
-        }
-        if (!h->P_dev) HIP_TRY(hipMalloc((void**)&h->P_dev, n * sizeof(float)));
-        HIP_TRY(hipMemcpyAsync(h->P_dev, host.data(), n * sizeof(float), hipMemcpyHostToDevice, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        for (int l = 0; l < c.n_layers; ++l) {
-            h->net.w_off[l] = (int)w_off[l];
-            h->net.b_off[l] = (int)b_off[l];
-        }
+    if (mfma && !h->packed_dev) HIP_TRY(hipMalloc((void**)&h->packed_dev, mfma_packed_bytes(h->plan)));
+    if (want_grad && !h->grad_packed) HIP_TRY(hipMalloc((void**)&h->grad_packed, grad_packed_bytes(c)));
+    if (mfma && !h->maps_built) {
+        // one-time (per layout): derive and verify the gather maps from the host packers
+        build_pack_map(h->map_fwd, n, mfma_packed_bytes(h->plan) / sizeof(float),
+                       [&](const float* src, float* dst) { mfma_pack(h->plan, src, w_off, b_off, dst); });
+        if (want_grad)
+            build_pack_map(h->map_grad, n, grad_packed_bytes(c) / sizeof(float),
+                           [&](const float* src, float* dst) { grad_pack(c, src, w_off, b_off, dst); });
+        h->maps_built = true;
     }
-    h->w_off.assign(w_off, w_off + c.n_layers);
-    h->b_off.assign(b_off, b_off + c.n_layers);
-    if (h->path == CNF_PATH_MFMA && mfma_plan_is_per_wave(h->plan) && grad_supported(c)) {
-        const size_t gb = grad_packed_bytes(c);
-        if (!h->grad_packed) HIP_TRY(hipMalloc((void**)&h->grad_packed, gb));
-        std::vector<float> gp(gb / sizeof(float), 0.f);
-        grad_pack(c, host.data(), w_off, b_off, gp.data());
-        HIP_TRY(hipMemcpyAsync(h->grad_packed, gp.data(), gb, hipMemcpyHostToDevice, st));
-        HIP_TRY(hipStreamSynchronize(st));
+    const bool dev_pack = mfma && h->map_fwd.valid && (!want_grad || h->map_grad.valid);
+    h->repack_on_device = dev_pack;
+    if (mfma && dev_pack) {
+        // device path: (host p: one H2D copy into the staging buffer, then) gather kernels on `stream`
+        const float* src = p;
+        if (!p_is_device) {
+            if (h->p_stage_n < n) {
+                if (h->p_stage) HIP_TRY(hipFree(h->p_stage));
+                h->p_stage = nullptr; h->p_stage_n = 0;
+                HIP_TRY(hipMalloc((void**)&h->p_stage, n * sizeof(float)));
+                h->p_stage_n = n;
+            }
+            HIP_TRY(hipMemcpyAsync(h->p_stage, p, n * sizeof(float), hipMemcpyHostToDevice, st));
+            HIP_TRY(hipStreamSynchronize(st));   // the caller may reuse its host buffer on return
+            src = h->p_stage;
+        }
+        const PackMap* maps[2] = {&h->map_fwd, want_grad ? &h->map_grad : nullptr};
+        float* outs[2] = {h->packed_dev, h->grad_packed};
+        for (int i = 0; i < 2; ++i) {
+            if (!maps[i]) continue;
+            const size_t np = maps[i]->n;
+            hipLaunchKernelGGL(gather_pack_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, st, src,
+                               maps[i]->idx, maps[i]->scale, outs[i], np);
+            HIP_TRY(hipGetLastError());
+        }
+    } else {
+        // host path: SIMT parameters (plain copy) and images that are not a gather (split-bf16)
+        std::vector<float> host(n);
+        if (p_is_device) {
+            HIP_TRY(hipMemcpyAsync(host.data(), p, n * sizeof(float), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+        } else {
+            std::memcpy(host.data(), p, n * sizeof(float));
+        }
+        if (mfma) {
+            const size_t bytes = mfma_packed_bytes(h->plan);
+            std::vector<float> packed(bytes / sizeof(float), 0.f);
+            mfma_pack(h->plan, host.data(), w_off, b_off, packed.data());
+            HIP_TRY(hipMemcpyAsync(h->packed_dev, packed.data(), bytes, hipMemcpyHostToDevice, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            if (want_grad) {
+                const size_t gb = grad_packed_bytes(c);
+                std::vector<float> gp(gb / sizeof(float), 0.f);
+                grad_pack(c, host.data(), w_off, b_off, gp.data());
+                HIP_TRY(hipMemcpyAsync(h->grad_packed, gp.data(), gb, hipMemcpyHostToDevice, st));
+                HIP_TRY(hipStreamSynchronize(st));
+            }
+        } else {
+            if (h->P_dev && h->nparams != n) {
+                HIP_TRY(hipFree(h->P_dev));
+                h->P_dev = nullptr;
+            }
+            if (!h->P_dev) HIP_TRY(hipMalloc((void**)&h->P_dev, n * sizeof(float)));
+            HIP_TRY(hipMemcpyAsync(h->P_dev, host.data(), n * sizeof(float), hipMemcpyHostToDevice, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            for (int l = 0; l < c.n_layers; ++l) {
+                h->net.w_off[l] = (int)w_off[l];
+                h->net.b_off[l] = (int)b_off[l];
+            }
+        }
     }
     h->nparams = n;
     h->have_params = true;

@@ -386,6 +386,15 @@ class ICNF:
         h = self._handle(mode)
         return int(h.lib.cnf_kernel_path(h.ptr))
 
+    def repack_on_device(self, mode: Mode) -> bool:
+        """True when the last parameter binding of this mode's handle was repacked by the device gather
+        kernels (no host round trip) — cnf_repack_on_device."""
+        h = self._handle(mode)
+        rc = int(h.lib.cnf_repack_on_device(h.ptr))
+        if rc < 0:
+            _lib.check(rc)
+        return bool(rc)
+
     # Lux-layer call (src/core/base_icnf.jl:509-523)
     def __call__(self, xs, ps, st):
         if self.conditioned:

@@ -101,12 +101,21 @@ int cnf_destroy(cnf_handle* h);
 /* Parameters `ps`: the ComponentArray of LuxCore.setup (test/ci_tests/smoke_tests.jl:61-62) —
  * a flat Float32 vector holding, per Dense layer, weight (out x in, column-major: W(o,i) at
  * w_off[l] + o + out*i) and bias (out, at b_off[l]).  n = length(p).  The library copies and
- * repacks; call again whenever ps changes.  p_is_device: 1 if p is a device pointer. */
+ * repacks; call again whenever ps changes.  p_is_device: 1 if p is a device pointer.
+ * Ordering: the repack is enqueued on `stream` (for a device pointer on the fused path it is one
+ * gather kernel per operand image, no host round trip and no synchronisation, so a training loop
+ * that updates ps on the device can call this every step); later calls on the same stream see the
+ * new parameters, calls on other streams must be ordered after it by the caller.  A host p may be
+ * reused as soon as the call returns. */
 int cnf_set_params(cnf_handle* h, const float* p, size_t n, const size_t* w_off,
                    const size_t* b_off, int p_is_device, void* stream);
 
 /* Which kernel family the handle resolved to (CNF_PATH_SIMT or CNF_PATH_MFMA). */
 int cnf_kernel_path(const cnf_handle* h);
+
+/* How the last cnf_set_params repacked: 1 = gather kernels on the device (fused path, f32 images),
+ * 0 = on the host (SIMT parameter copy, split-bf16 images).  CNF_ERR_NO_PARAMS before the first call. */
+int cnf_repack_on_device(const cnf_handle* h);
 
 /* augmented_f(u,p,t, icnf, mode, nn, st, eps) / augmented_f(du,u,p,t, ...) for MatrixMode:
  * src/core/icnf.jl:517-559 (VecJac), :561-603 (JacVec), :297-339 (TestMode) — the callable

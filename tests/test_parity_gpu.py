@@ -447,6 +447,39 @@ def test_randomised_shapes_fused_vs_generic_kernels(pkg, oracles):
     assert checked >= 45 and probes_checked >= 8, (checked, probes_checked)
 
 
+@pytest.mark.parametrize("kw", [dict(nvars=8, hidden=[64, 64, 64]),                       # exact-shape instance + gradient image
+                                dict(nvars=5, ncond=3, hidden=[40, 24, 40], act=2),        # padded generic instance
+                                dict(nvars=32, hidden=[256, 256, 256]),                    # cooperative kernel
+                                dict(nvars=3, hidden=[16, 16], mode=2)])                   # tangent engine
+def test_device_side_repack_equals_host_repack(kw, pkg, oracles):
+    """cnf_set_params on a device pointer runs a gather kernel (no host round trip); on a host pointer
+    the same gather after one copy.  Both must give the bits the host packer gives, here observed
+    through the solve: device-ps, host-ps and the C oracle's answer."""
+    o64, oc = oracles
+    spec = o64.make_spec(**kw)
+    B = 33
+    p, xs, eps, ys = o64.synth_inputs(spec, B, 12, bias_scale=0.3)
+    icnf = make_icnf(pkg, spec, 0, 4, path=2)
+    mode = mode_of(pkg, spec)
+    args_d = (dev(xs),) + ((dev(ys),) if spec.ncond else ()) + (dev(p), {})
+    args_h = (dev(xs),) + ((dev(ys),) if spec.ncond else ()) + (torch.tensor(p), {})
+    a = pkg.inference(icnf, mode, *args_d, eps=dev(eps))[0]
+    b = pkg.inference(icnf, mode, *args_h, eps=dev(eps))[0]
+    assert torch.equal(a, b)
+    assert icnf.repack_on_device(mode)
+    ref = oc.inference_fixed(spec, p, xs, 0.0, 1.0, 4, 0, eps, ys)[0]
+    assert np.max(np.abs(a.cpu().numpy() - ref)) < TOL_SOLVE
+    # in-place update on the device is picked up (stream-ordered, no synchronisation needed)
+    P = dev(p)
+    args = (dev(xs),) + ((dev(ys),) if spec.ncond else ()) + (P, {})
+    pkg.inference(icnf, mode, *args, eps=dev(eps))
+    P.mul_(0.5)
+    c = pkg.inference(icnf, mode, *args, eps=dev(eps))[0]
+    ref2 = oc.inference_fixed(spec, (p * np.float32(0.5)).astype(np.float32), xs, 0.0, 1.0, 4, 0, eps, ys)[0]
+    assert np.max(np.abs(c.cpu().numpy() - ref2)) < TOL_SOLVE
+    assert not torch.equal(a, c)
+
+
 def test_empty_batch_is_a_no_op(pkg, oracles):
     o64, _ = oracles
     spec = o64.make_spec(nvars=8, hidden=[64, 64, 64])
