@@ -94,6 +94,22 @@ def grad_mfma_per_stage(spec):
     return fwd + rev
 
 
+def layered_flop_per_stage(spec):
+    """GEMM flop per sample per RK stage of the layer-wise gradient path (csrc/cnf_grad_layered.hip): forward
+    chain (recompute at the stage point; the stage derivatives themselves are checkpointed), per probe the
+    pullback and its bottom-up reverse with the probe's weight cotangents, then the top-down pass with
+    weight cotangents.  Plus the forward sweep (one chain per stage) and the fused solve for the loss."""
+    w, K, D = spec.widths, spec.nprobes, spec.D
+    N = len(w) - 1
+    fwd = sum(2 * w[l + 1] * (w[l] + 1) for l in range(N))
+    hid = sum(2 * w[l + 1] * w[l] for l in range(1, N))
+    pull = hid + 2 * D * w[1]
+    per_probe = pull + 2 * (2 * w[1] * D) + 2 * hid
+    top = fwd + pull
+    solve = sum(2 * w[l + 1] * w[l] for l in range(N)) + (K * pull)       # the regular fused solve for the loss
+    return 2 * fwd + K * per_probe + top + solve      # forward sweep + recompute = 2 chains per stage
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -236,7 +252,8 @@ def main():
         if a.mode == "grad":
             # executed MFMA work of forward + reverse sweep per sample*step, not an
             # algorithmic figure: v_mfma_f32_16x16x4_f32 instructions (2048 flop) per stage per 16-sample tile
-            flop_ss = grad_mfma_per_stage(spec) * 2048 / 16 * stages
+            gpath = icnf.grad_path(mode)
+            flop_ss = (grad_mfma_per_stage(spec) * 2048 / 16 if gpath == 1 else layered_flop_per_stage(spec)) * stages
             flops_launch = float(flop_ss) * B * NSTEPS
             ach_tflops = flops_launch / (kern_ms * 1e-3) / 1e12
         out = {
@@ -252,6 +269,8 @@ def main():
                        "integrator": "RK4" if alg == 0 else "Tsit5",
                        "kernel_path": {1: "simt", 2: "mfma"}.get(path, str(path)),
                        "mode": a.mode,
+                       **({"gradient_path": {1: "fused reverse-sweep kernel", 2: "layer-wise (rocBLAS GEMMs)"}.get(
+                           icnf.grad_path(mode), "none")} if a.mode == "grad" else {}),
                        "parallelism": f"column-shard x{world}, loss all-reduce (5 scalars)"
                        + (" + gradient all-reduce (nparams floats)" if a.mode == "grad" else "")},
             "loss": float(lossv),

@@ -24,7 +24,7 @@ ARITH_F32, ARITH_BF16X6 = 0, 1
 
 EXPORTS = ("cnf_version", "cnf_last_error", "cnf_create", "cnf_destroy", "cnf_set_params",
            "cnf_kernel_path", "cnf_repack_on_device", "cnf_aug_f", "cnf_integrate_fixed", "cnf_inference_fixed",
-           "cnf_loss_sums", "cnf_loss_grad_fixed")
+           "cnf_loss_sums", "cnf_loss_grad_fixed", "cnf_grad_path")
 
 
 class CnfConfig(C.Structure):
@@ -75,6 +75,7 @@ def load():
     lib.cnf_set_params.argtypes = [vp, fp, C.c_size_t, szp, szp, C.c_int, vp]
     lib.cnf_kernel_path.argtypes = [vp]
     lib.cnf_repack_on_device.argtypes = [vp]
+    lib.cnf_grad_path.argtypes = [vp]
     lib.cnf_aug_f.argtypes = [vp, fp, fp, C.c_float, fp, fp, C.c_int64, vp]
     lib.cnf_integrate_fixed.argtypes = [vp, C.c_int, C.c_int, C.c_float, C.c_float, fp, fp, fp,
                                         C.c_int64, fp, vp]

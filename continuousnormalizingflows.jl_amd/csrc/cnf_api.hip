@@ -6,6 +6,7 @@
 // every entry point that would compute returns CNF_ERR_NO_DEVICE / CNF_ERR_HIP.
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <string>
@@ -139,6 +140,7 @@ struct cnf_handle {
     // device-side repacking (see PackMap): maps for the solve image and the gradient image, rebuilt
     // when the layout handed to cnf_set_params changes; p_stage holds host-supplied parameters
     PackMap map_fwd, map_grad;
+    LayeredGrad* layered = nullptr;      // rocBLAS context + workspace of the layer-wise gradient
     bool maps_built = false;
     bool repack_on_device = false;
     float* p_stage = nullptr;
@@ -246,6 +248,7 @@ int cnf_destroy(cnf_handle* h) {
     if (h->grad_packed) (void)hipFree(h->grad_packed);
     if (h->grad_ws) (void)hipFree(h->grad_ws);
     if (h->p_stage) (void)hipFree(h->p_stage);
+    layered_grad_destroy(h->layered);
     free_pack_map(h->map_fwd);
     free_pack_map(h->map_grad);
     if (h->plan) mfma_plan_destroy(h->plan);
@@ -310,6 +313,13 @@ int cnf_set_params(cnf_handle* h, const float* p, size_t n, const size_t* w_off,
             HIP_TRY(hipStreamSynchronize(st));   // the caller may reuse its host buffer on return
             src = h->p_stage;
         }
+        // Lux-layout device copy (the layer-wise gradient reads the plain parameters)
+        if (h->P_dev && h->nparams != n) {
+            HIP_TRY(hipFree(h->P_dev));
+            h->P_dev = nullptr;
+        }
+        if (!h->P_dev) HIP_TRY(hipMalloc((void**)&h->P_dev, n * sizeof(float)));
+        HIP_TRY(hipMemcpyAsync(h->P_dev, src, n * sizeof(float), hipMemcpyDeviceToDevice, st));
         const PackMap* maps[2] = {&h->map_fwd, want_grad ? &h->map_grad : nullptr};
         float* outs[2] = {h->packed_dev, h->grad_packed};
         for (int i = 0; i < 2; ++i) {
@@ -329,6 +339,12 @@ int cnf_set_params(cnf_handle* h, const float* p, size_t n, const size_t* w_off,
             std::memcpy(host.data(), p, n * sizeof(float));
         }
         if (mfma) {
+            if (h->P_dev && h->nparams != n) {
+                HIP_TRY(hipFree(h->P_dev));
+                h->P_dev = nullptr;
+            }
+            if (!h->P_dev) HIP_TRY(hipMalloc((void**)&h->P_dev, n * sizeof(float)));
+            HIP_TRY(hipMemcpyAsync(h->P_dev, host.data(), n * sizeof(float), hipMemcpyHostToDevice, st));
             const size_t bytes = mfma_packed_bytes(h->plan);
             std::vector<float> packed(bytes / sizeof(float), 0.f);
             mfma_pack(h->plan, host.data(), w_off, b_off, packed.data());
@@ -489,6 +505,19 @@ int cnf_loss_sums(cnf_handle* h, const float* logp, const float* regs, int64_t B
     return CNF_OK;
 }
 
+// fused reverse-sweep kernel, unless CNF_GRAD_LAYERED=1 forces the layer-wise path (tests, A/B timing)
+static bool grad_is_fused(const cnf_handle* h) {
+    const char* force = getenv("CNF_GRAD_LAYERED");
+    return h->path == CNF_PATH_MFMA && grad_supported(h->cfg) && mfma_plan_is_per_wave(h->plan) &&
+           !(force && *force && *force != '0');
+}
+
+int cnf_grad_path(const cnf_handle* h) {
+    if (!h) return CNF_ERR_INVALID;
+    if (grad_is_fused(h)) return 1;
+    return layered_grad_supported(h->cfg) ? 2 : 0;
+}
+
 int cnf_loss_grad_fixed(cnf_handle* h, int alg, int nsteps, float t0, float t1, const float* x,
                         const float* eps, const float* ys, int64_t B, const float* lambdas,
                         float* grad, float* sums4, void* stream) {
@@ -497,14 +526,42 @@ int cnf_loss_grad_fixed(cnf_handle* h, int alg, int nsteps, float t0, float t1, 
     if (nsteps < 1) return fail(CNF_ERR_INVALID, "cnf_loss_grad_fixed: nsteps >= 1 required");
     if (alg != CNF_ALG_RK4 && alg != CNF_ALG_TSIT5) return fail(CNF_ERR_INVALID, "cnf_loss_grad_fixed: unknown alg");
     if (!x || !grad || !lambdas) return fail(CNF_ERR_INVALID, "cnf_loss_grad_fixed: null x/grad/lambdas");
-    if (h->path != CNF_PATH_MFMA || !grad_supported(h->cfg) || !h->grad_packed)
-        return fail(CNF_ERR_UNSUPPORTED, "cnf_loss_grad_fixed: configuration not covered by the gradient kernel "
-                                         "(Hutchinson VJP, <= 16 conditions, 2-3 equal tanh/softplus hidden layers of width <= 64, D <= 14)");
+    const bool fused = grad_is_fused(h) && h->grad_packed;
+    if (!fused && !layered_grad_supported(h->cfg))
+        return fail(CNF_ERR_UNSUPPORTED, "cnf_loss_grad_fixed: the gradient is implemented for the Hutchinson VJP mode "
+                                         "(fused kernels: <= 8 probes, <= 16 conditions, 2-3 equal tanh/softplus hidden layers of "
+                                         "width <= 64, D <= 14; every other VJP configuration: layer-wise path)");
     DeviceGuard g(h->cfg.device_id);
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(hipMemsetAsync(grad, 0, h->nparams * sizeof(float), st));
     if (B == 0) {
         if (sums4) HIP_TRY(hipMemsetAsync(sums4, 0, 4 * sizeof(float), st));
+        return CNF_OK;
+    }
+    if (!fused) {
+        // layer-wise reverse sweep (cnf_grad_layered.hip); the loss sums come from the regular solve
+        if (sums4) {
+            const size_t need = 4 * (size_t)B * sizeof(float);
+            if (need > h->grad_ws_bytes) {
+                if (h->grad_ws) HIP_TRY(hipFree(h->grad_ws));
+                h->grad_ws = nullptr; h->grad_ws_bytes = 0;
+                HIP_TRY(hipMalloc((void**)&h->grad_ws, need));
+                h->grad_ws_bytes = need;
+            }
+            float* logp = h->grad_ws;
+            float* regs = logp + B;
+            rc = cnf_inference_fixed(h, alg, nsteps, t0, t1, x, eps, ys, B, logp, regs, nullptr, stream);
+            if (rc) return rc;
+            if (!h->loss_partial) HIP_TRY(hipMalloc((void**)&h->loss_partial, 256 * 4 * sizeof(float)));
+            HIP_TRY(loss_sums(logp, regs, B, h->loss_partial, sums4, st));
+        }
+        const int ra = (h->cfg.reg_aug && h->cfg.naug > 0) ? 1 : 0;
+        const float lam[3] = {h->cfg.reg_z ? lambdas[0] : 0.f, h->cfg.reg_j ? lambdas[1] : 0.f, ra ? lambdas[2] : 0.f};
+        std::string msg;
+        hipError_t e = layered_grad(&h->layered, h->cfg, h->P_dev, h->w_off.data(), h->b_off.data(), x, eps, ys, alg, nsteps,
+                                    t0, t1, B, lam, grad, st, &msg);
+        if (e == hipErrorNotSupported) return fail(CNF_ERR_UNSUPPORTED, "cnf_loss_grad_fixed: " + msg);
+        if (e != hipSuccess) return fail(CNF_ERR_HIP, "cnf_loss_grad_fixed: " + msg);
         return CNF_OK;
     }
     if (h->num_cus == 0) {

@@ -1,0 +1,488 @@
+// cnf_grad_layered.hip — parameter gradient for every Hutchinson-VJP configuration the fused
+// reverse-sweep kernels (cnf_grad.hip, cnf_grad_probes.hip) do not cover: wide layers (BASELINE cfg4,
+// 3x256), more than three hidden layers, unequal widths, mixed activations, D > 14.
+//
+// Same mathematics as cnf_grad.hip (discretise-then-optimise reverse sweep through the fixed-step RK
+// solve; reference: Zygote through SciMLBase.solve, src/core/icnf.jl:90-99, objective icnf.jl:184-251,
+// 628-637), organised LAYER-WISE over the whole column shard instead of tile-wise: every product is a
+// plain GEMM [features x B] on rocBLAS (f32 MFMA), the elementwise pieces are small HIP kernels below.
+// With wide layers the arithmetic intensity of these GEMMs is high (256 x 256 x B), so the layer-wise
+// form is compute-bound on the matrix cores; the activations of one stage (a_l, act'_l, the pullback
+// v_l, ...) live in HBM (cfg4: ~0.6 GB).
+//
+// Layout: all matrices are column-major [rows x B] = one contiguous column per sample, the layout of
+// the ABI's x / eps / ys.  a_l carries an extra row of ones (ld = H_l + 1) and the parameters are kept
+// in an augmented copy PA_l = [W_l | b_l] (H_l x (H_{l-1} + 1)), so the bias add is part of the forward
+// GEMM and the bias cotangent is the last column of  Wbar_l += sbar_l [a_{l-1}; 1]^T.
+//
+// Weight cotangents have K = B (tens of thousands) and a small output: they are computed as strided-
+// batched GEMMs over column chunks, each chunk accumulating (beta = 1) into its own slab for the whole
+// solve; one kernel sums the slabs in a fixed order at the end (no atomics: bit-reproducible).
+//
+// rocBLAS is resolved with dlopen at first use, so libcnf_hip.so has no link-time dependency on it and
+// every other entry point works without it.
+#include <dlfcn.h>
+
+#include <cstdlib>
+
+#include <string>
+#include <vector>
+
+#include <rocblas/rocblas.h>
+
+#include "cnf_internal.h"
+
+namespace cnf {
+
+namespace {
+
+struct Blas {
+    void* lib = nullptr;
+    decltype(&rocblas_create_handle) create = nullptr;
+    decltype(&rocblas_destroy_handle) destroy = nullptr;
+    decltype(&rocblas_set_stream) set_stream = nullptr;
+    decltype(&rocblas_sgemm) sgemm = nullptr;
+    decltype(&rocblas_sgemm_strided_batched) sgemm_sb = nullptr;
+    bool ok = false;
+};
+
+Blas load_blas() {
+    Blas b;
+    for (const char* name : {"librocblas.so.5", "librocblas.so", "/opt/rocm/lib/librocblas.so.5", "/opt/rocm/lib/librocblas.so"}) {
+        b.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        if (b.lib) break;
+    }
+    if (!b.lib) return b;
+    b.create = (decltype(b.create))dlsym(b.lib, "rocblas_create_handle");
+    b.destroy = (decltype(b.destroy))dlsym(b.lib, "rocblas_destroy_handle");
+    b.set_stream = (decltype(b.set_stream))dlsym(b.lib, "rocblas_set_stream");
+    b.sgemm = (decltype(b.sgemm))dlsym(b.lib, "rocblas_sgemm");
+    b.sgemm_sb = (decltype(b.sgemm_sb))dlsym(b.lib, "rocblas_sgemm_strided_batched");
+    b.ok = b.create && b.destroy && b.set_stream && b.sgemm && b.sgemm_sb;
+    return b;
+}
+
+Blas& blas() {
+    static Blas b = load_blas();
+    return b;
+}
+
+struct LDesc {              // the Dense chain, by value in kernel arguments
+    int n_layers;
+    int win[CNF_MAX_LAYERS], wout[CNF_MAX_LAYERS], act[CNF_MAX_LAYERS];
+    long long pa_off[CNF_MAX_LAYERS];   // [W_l | b_l] inside the augmented parameter buffer
+    long long w_off[CNF_MAX_LAYERS], b_off[CNF_MAX_LAYERS];   // Lux offsets
+    long long npa;
+};
+
+constexpr int TPB = 256;
+inline dim3 grid_for(long long n) { return dim3((unsigned)((n + TPB - 1) / TPB)); }
+
+// PA_l = [W_l | b_l] gathered from the Lux vector
+__global__ void aug_params_kernel(const float* __restrict__ P, float* __restrict__ PA, LDesc L) {
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= L.npa) return;
+    int l = 0;
+    while (l + 1 < L.n_layers && e >= L.pa_off[l + 1]) ++l;
+    const long long r = e - L.pa_off[l];
+    const int o = (int)(r % L.wout[l]), i = (int)(r / L.wout[l]);
+    PA[e] = i < L.win[l] ? P[L.w_off[l] + o + (long long)L.wout[l] * i] : P[L.b_off[l] + o];
+}
+
+// grad (Lux layout) = sum of the chunk slabs, fixed order
+__global__ void reduce_slabs_kernel(const float* __restrict__ slabs, int nslab, long long stride, LDesc L,
+                                    float* __restrict__ grad) {
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= L.npa) return;
+    float acc = 0.f;
+    for (int s = 0; s < nslab; ++s) acc += slabs[(long long)s * stride + e];
+    int l = 0;
+    while (l + 1 < L.n_layers && e >= L.pa_off[l + 1]) ++l;
+    const long long r = e - L.pa_off[l];
+    const int o = (int)(r % L.wout[l]), i = (int)(r / L.wout[l]);
+    grad[i < L.win[l] ? L.w_off[l] + o + (long long)L.wout[l] * i : L.b_off[l] + o] = acc;
+}
+
+// z0 = [x; 0]  (src/core/base_icnf.jl:165-167)
+__global__ void init_state_kernel(const float* __restrict__ x, float* __restrict__ z, int nvars, int D, long long B) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)D * B) return;
+    const long long j = i / D;
+    const int f = (int)(i % D);
+    z[i] = f < nvars ? x[j * nvars + f] : 0.f;
+}
+
+struct Comb { const float* k[6]; float coef[6]; int nk; };
+// out = base + sum_j coef_j k_j   (out may alias base)
+__global__ void combine_kernel(float* __restrict__ out, const float* __restrict__ base, Comb c, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float acc = 0.f;
+    for (int j = 0; j < c.nk; ++j) acc = fmaf(c.coef[j], c.k[j][i], acc);
+    out[i] = base[i] + acc;
+}
+
+// a_0 = [z; t; y; 1]  (CondLayer row order, src/layers/cond_layer.jl:12-23), ld = n_in + 1
+__global__ void build_input_kernel(const float* __restrict__ zs, float t, const float* __restrict__ ys,
+                                   float* __restrict__ a0, int D, int C, int autonomous, long long B) {
+    const int nin = D + (autonomous ? 0 : 1) + C, ld = nin + 1;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)ld * B) return;
+    const long long j = i / ld;
+    const int f = (int)(i % ld);
+    float v;
+    if (f < D) v = zs[j * D + f];
+    else if (f == nin) v = 1.f;
+    else if (!autonomous && f == D) v = t;
+    else v = ys[j * C + (f - D - (autonomous ? 0 : 1))];
+    a0[i] = v;
+}
+
+// in place on a (ld = H + 1): a = act(s), d = act'(s), ones row
+__global__ void act_kernel(float* __restrict__ a, float* __restrict__ d, int act, int H, long long B) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)(H + 1) * B) return;
+    const long long j = i / (H + 1);
+    const int f = (int)(i % (H + 1));
+    if (f == H) { a[i] = 1.f; return; }
+    float dd;
+    a[i] = act_fwd_rt(act, a[i], dd);
+    d[j * H + f] = dd;
+}
+
+// dst[rows x B, ld rows] = src[rows x B, ld lds] (first `rows` rows, row offset roff)
+__global__ void copy_rows_kernel(float* __restrict__ dst, const float* __restrict__ src, int rows, int lds, int roff, long long B) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)rows * B) return;
+    const long long j = i / rows;
+    const int f = (int)(i % rows);
+    dst[i] = src[j * lds + roff + f];
+}
+
+__global__ void mul_kernel(float* __restrict__ out, const float* __restrict__ x, const float* __restrict__ y, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = x[i] * y[i];
+}
+
+// kbar = dt (b lam + sum_j a_j Zb_j)  (+ cE zdot / |zdot|: Edot = |zdot|, src/core/icnf.jl:184-199)
+__global__ void kbar_kernel(float* __restrict__ kbar, const float* __restrict__ lam, Comb zb, float dtb, float dt,
+                            const float* __restrict__ aN, float cE, int D, long long B) {
+    const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= B) return;
+    float inv = 0.f;
+    if (cE != 0.f) {
+        float e2 = 0.f;
+        for (int f = 0; f < D; ++f) { const float v = aN[j * (D + 1) + f]; e2 = fmaf(v, v, e2); }
+        inv = e2 > 0.f ? cE * rsqrtf(e2) : 0.f;
+    }
+    for (int f = 0; f < D; ++f) {
+        float acc = 0.f;
+        for (int q = 0; q < zb.nk; ++q) acc = fmaf(zb.coef[q], zb.k[q][j * D + f], acc);
+        float v = fmaf(dtb, lam[j * D + f], dt * acc);
+        if (cE != 0.f) v = fmaf(inv, aN[j * (D + 1) + f], v);
+        kbar[j * D + f] = v;
+    }
+}
+
+// gbar = -c_l eps_k + c_n g / |g|   (cotangent of g = eps^T J; ldot = -<eps, g>/K, ndot = |g|/K)
+__global__ void gbar_kernel(float* __restrict__ gbar, const float* __restrict__ g, const float* __restrict__ epsk,
+                            float cl, float cn, int D, long long B) {
+    const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= B) return;
+    float inv = 0.f;
+    if (cn != 0.f) {
+        float n2 = 0.f;
+        for (int f = 0; f < D; ++f) { const float v = g[j * D + f]; n2 = fmaf(v, v, n2); }
+        inv = n2 > 0.f ? cn * rsqrtf(n2) : 0.f;
+    }
+    for (int f = 0; f < D; ++f) gbar[j * D + f] = fmaf(inv, g[j * D + f], -cl * epsk[j * D + f]);
+}
+
+// vbar = dbar .* act';  acc2 += dbar .* v
+__global__ void bottom_kernel(const float* __restrict__ db, const float* __restrict__ d, const float* __restrict__ v,
+                              float* __restrict__ vbar, float* __restrict__ acc2, int first, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float x = db[i];
+    vbar[i] = x * d[i];
+    acc2[i] = first ? x * v[i] : fmaf(x, v[i], acc2[i]);   // the first probe initialises the sum
+}
+
+// sbar = abar .* act' + acc2 .* act''   (tanh: act'' = -2 a act';  softplus: act'' = act' (1 - act'))
+__global__ void sbar_kernel(float* __restrict__ sbar, const float* __restrict__ abar, const float* __restrict__ d,
+                            const float* __restrict__ acc2, const float* __restrict__ a, int act, int H, long long B) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)H * B) return;
+    const long long j = i / H;
+    const int f = (int)(i % H);
+    const float dd = d[i];
+    float e = 0.f;
+    if (act == CNF_ACT_TANH) e = -2.f * a[j * (H + 1) + f] * dd;
+    else if (act == CNF_ACT_SOFTPLUS) e = dd * (1.f - dd);
+    sbar[i] = fmaf(acc2[i], e, abar[i] * dd);
+}
+
+// lam_N = dL/dz_N = z_N (+ l3 z_aug / |z_aug|, src/core/base_icnf.jl:106-122)
+__global__ void lam_init_kernel(float* __restrict__ lam, const float* __restrict__ zN, float lam3, int nvars, int D, long long B) {
+    const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= B) return;
+    float inv = 0.f;
+    if (lam3 != 0.f) {
+        float s = 0.f;
+        for (int f = nvars; f < D; ++f) { const float v = zN[j * D + f]; s = fmaf(v, v, s); }
+        inv = s > 0.f ? lam3 * rsqrtf(s) : 0.f;
+    }
+    for (int f = 0; f < D; ++f) {
+        const float v = zN[j * D + f];
+        lam[j * D + f] = f >= nvars ? fmaf(inv, v, v) : v;
+    }
+}
+
+}  // namespace
+
+struct LayeredGrad {
+    rocblas_handle rb = nullptr;
+    float* ws = nullptr;
+    size_t ws_floats = 0;
+};
+
+void layered_grad_destroy(LayeredGrad* g) {
+    if (!g) return;
+    if (g->rb && blas().ok) (void)blas().destroy(g->rb);
+    if (g->ws) (void)hipFree(g->ws);
+    delete g;
+}
+
+bool layered_grad_supported(const cnf_config& c) { return c.mode == CNF_MODE_HUTCH_VJP && c.nprobes >= 1; }
+
+#define LG_HIP(expr)                                                                    \
+    do {                                                                                \
+        hipError_t _e = (expr);                                                         \
+        if (_e != hipSuccess) { *err = std::string(#expr) + ": " + hipGetErrorString(_e); return _e; } \
+    } while (0)
+#define LG_BLAS(expr)                                                                   \
+    do {                                                                                \
+        rocblas_status _s = (expr);                                                     \
+        if (_s != rocblas_status_success) { *err = std::string(#expr) + ": rocblas status " + std::to_string((int)_s); return hipErrorUnknown; } \
+    } while (0)
+
+hipError_t layered_grad(LayeredGrad** ctx, const cnf_config& c, const float* P_dev, const size_t* w_off,
+                        const size_t* b_off, const float* x, const float* eps, const float* ys, int alg,
+                        int nsteps, float t0, float t1, long long B, const float lam[3], float* grad,
+                        hipStream_t st, std::string* err) {
+    Blas& bl = blas();
+    if (!bl.ok) {
+        *err = "layered gradient: librocblas.so.5 could not be loaded (dlopen)";
+        return hipErrorNotSupported;
+    }
+    if (!*ctx) *ctx = new LayeredGrad();
+    LayeredGrad& G = **ctx;
+    if (!G.rb) LG_BLAS(bl.create(&G.rb));
+    LG_BLAS(bl.set_stream(G.rb, st));
+
+    const int N = c.n_layers, D = c.nvars + c.naug, C = c.ncond, K = c.nprobes;
+    LDesc L{};
+    L.n_layers = N;
+    long long npa = 0;
+    int maxw = D;
+    for (int l = 0; l < N; ++l) {
+        L.win[l] = c.widths[l]; L.wout[l] = c.widths[l + 1]; L.act[l] = c.acts[l];
+        L.pa_off[l] = npa; L.w_off[l] = (long long)w_off[l]; L.b_off[l] = (long long)b_off[l];
+        npa += (long long)L.wout[l] * (L.win[l] + 1);
+        if (L.wout[l] > maxw) maxw = L.wout[l];
+    }
+    L.npa = npa;
+    const long long npa_pad = (npa + 63) / 64 * 64;
+    // column chunks of the weight-cotangent GEMMs (K = B split for parallelism; one slab per chunk)
+    // (cfg4, B = 32768, measured: 256 columns per chunk 237 ms per gradient; 128: 246; 512: 263; 2048: 282)
+    long long kc = (B + 255) / 256;
+    kc = (kc + 63) / 64 * 64;
+    if (kc < 256) kc = 256;
+    if (const char* e = getenv("CNF_LAYERED_KC")) { if (atoll(e) >= 16) kc = atoll(e); }   // tuning knob
+    const int nbf = (int)(B / kc);
+    const long long tail = B - (long long)nbf * kc;
+    const int nslab = nbf + (tail > 0 ? 1 : 0);
+
+    // ---- workspace ----
+    const long long DB = (long long)D * B;
+    long long off = 0;
+    auto take = [&](long long n) { const long long o = off; off += (n + 63) / 64 * 64; return o; };
+    const long long o_PA = take(npa_pad), o_slab = take(npa_pad * nslab), o_zck = take(DB * (nsteps + 1));
+    // stage derivatives of every step are kept when they fit 4 GiB, otherwise recomputed in the reverse sweep
+    const int nst = alg == CNF_ALG_RK4 ? 4 : 6;
+    const bool keep_k = (double)DB * nst * nsteps * sizeof(float) <= 4.0 * 1024 * 1024 * 1024 && !getenv("CNF_LAYERED_NO_KCKPT");
+    const long long o_kck = keep_k ? take(DB * nst * nsteps) : 0;
+    long long o_kz[6], o_zb[6];
+    for (int j = 0; j < 6; ++j) o_kz[j] = take(DB);
+    for (int j = 0; j < 6; ++j) o_zb[j] = take(DB);
+    const long long o_lam = take(DB), o_kbar = take(DB), o_zs = take(DB), o_g = take(DB), o_gbar = take(DB), o_vN = take(DB);
+    long long o_a[CNF_MAX_LAYERS + 1], o_d[CNF_MAX_LAYERS], o_v[CNF_MAX_LAYERS], o_acc2[CNF_MAX_LAYERS], o_dl[CNF_MAX_LAYERS];
+    o_a[0] = take((long long)(c.widths[0] + 1) * B);
+    for (int l = 0; l < N; ++l) {
+        const long long HB = (long long)L.wout[l] * B;
+        o_a[l + 1] = take((long long)(L.wout[l] + 1) * B);
+        o_d[l] = take(HB); o_v[l] = take(HB); o_acc2[l] = take(HB); o_dl[l] = take(HB);
+    }
+    const long long WB = (long long)maxw * B;
+    const long long o_t0 = take(WB), o_t1 = take(WB), o_t2 = take(WB), o_t3 = take(WB), o_t4 = take(WB);
+    if ((size_t)off > G.ws_floats) {
+        if (G.ws) LG_HIP(hipFree(G.ws));
+        G.ws = nullptr; G.ws_floats = 0;
+        LG_HIP(hipMalloc((void**)&G.ws, (size_t)off * sizeof(float)));
+        G.ws_floats = (size_t)off;
+    }
+    float* W = G.ws;
+    float* PA = W + o_PA;
+    float* slabs = W + o_slab;
+    float *kz[6], *Zb[6], *a[CNF_MAX_LAYERS + 1], *d[CNF_MAX_LAYERS], *v[CNF_MAX_LAYERS], *acc2[CNF_MAX_LAYERS], *dl[CNF_MAX_LAYERS];
+    for (int j = 0; j < 6; ++j) { kz[j] = W + o_kz[j]; Zb[j] = W + o_zb[j]; }
+    for (int l = 0; l <= N; ++l) a[l] = W + o_a[l];
+    for (int l = 0; l < N; ++l) { d[l] = W + o_d[l]; v[l] = W + o_v[l]; acc2[l] = W + o_acc2[l]; dl[l] = W + o_dl[l]; }
+    float *lamv = W + o_lam, *kbar = W + o_kbar, *zs = W + o_zs, *gk = W + o_g, *gbar = W + o_gbar, *vN = W + o_vN;
+    float *tdb = W + o_t0, *tdb2 = W + o_t1, *tvb = W + o_t2, *tsb = W + o_t3, *tab = W + o_t4;
+
+    LG_HIP(hipMemsetAsync(slabs, 0, (size_t)npa_pad * nslab * sizeof(float), st));
+    hipLaunchKernelGGL(aug_params_kernel, grid_for(npa), dim3(TPB), 0, st, P_dev, PA, L);
+
+    const float one = 1.f, zero = 0.f;
+    auto gemm = [&](rocblas_operation ta, rocblas_operation tb, int m, long long n, int k, const float* A, int lda,
+                    const float* Bm, int ldb, float* Cm, int ldc) -> rocblas_status {
+        return bl.sgemm(G.rb, ta, tb, m, (rocblas_int)n, k, &one, A, lda, Bm, ldb, &zero, Cm, ldc);
+    };
+    const rocblas_operation OPN = rocblas_operation_none, OPT = rocblas_operation_transpose;
+    // Wbar_l[:, 0:ncols] += X Y^T over the column chunks
+    auto wgrad = [&](int l, const float* X, int ldx, const float* Y, int ldy, int ncols) -> rocblas_status {
+        const int m = L.wout[l];
+        float* Cm = slabs + L.pa_off[l];
+        if (nbf > 0) {
+            rocblas_status s = bl.sgemm_sb(G.rb, OPN, OPT, m, ncols, (rocblas_int)kc, &one, X, ldx, (rocblas_stride)(kc * ldx),
+                                           Y, ldy, (rocblas_stride)(kc * ldy), &one, Cm, m, (rocblas_stride)npa_pad, nbf);
+            if (s != rocblas_status_success) return s;
+        }
+        if (tail > 0)
+            return bl.sgemm(G.rb, OPN, OPT, m, ncols, (rocblas_int)tail, &one, X + (long long)nbf * kc * ldx, ldx,
+                            Y + (long long)nbf * kc * ldy, ldy, &one, Cm + (long long)nbf * npa_pad, m);
+        return rocblas_status_success;
+    };
+    // forward chain at (zs, t): a_l, act'_l for every layer; zdot = a_N
+    auto forward = [&](const float* zin, float t) -> rocblas_status {
+        hipLaunchKernelGGL(build_input_kernel, grid_for((long long)(c.widths[0] + 1) * B), dim3(TPB), 0, st, zin, t, ys, a[0],
+                           D, C, c.autonomous, B);
+        for (int l = 0; l < N; ++l) {
+            rocblas_status s = gemm(OPN, OPN, L.wout[l], B, L.win[l] + 1, PA + L.pa_off[l], L.wout[l], a[l], L.win[l] + 1,
+                                    a[l + 1], L.wout[l] + 1);
+            if (s != rocblas_status_success) return s;
+            hipLaunchKernelGGL(act_kernel, grid_for((long long)(L.wout[l] + 1) * B), dim3(TPB), 0, st, a[l + 1], d[l], L.act[l],
+                               L.wout[l], B);
+        }
+        return rocblas_status_success;
+    };
+
+    const Tableau T = make_tableau(alg);
+    const float dt = (t1 - t0) / (float)nsteps;
+    const int ns = T.ns;
+    // stage derivatives of one step from z_n (z rows only: the gradient needs no trace here)
+    auto stage_derivs = [&](const float* zn, float tn) -> rocblas_status {
+        for (int i = 0; i < ns; ++i) {
+            Comb cb{};
+            cb.nk = 0;
+            for (int j = 0; j < i; ++j)
+                if (T.a[i][j] != 0.f) { cb.k[cb.nk] = kz[j]; cb.coef[cb.nk] = dt * T.a[i][j]; ++cb.nk; }
+            hipLaunchKernelGGL(combine_kernel, grid_for(DB), dim3(TPB), 0, st, zs, zn, cb, DB);
+            rocblas_status s = forward(zs, tn + T.c[i] * dt);
+            if (s != rocblas_status_success) return s;
+            hipLaunchKernelGGL(copy_rows_kernel, grid_for(DB), dim3(TPB), 0, st, kz[i], a[N], D, D + 1, 0, B);
+        }
+        return rocblas_status_success;
+    };
+
+    // ---- forward sweep: checkpoints z_n ----
+    float* zck = W + o_zck;
+    hipLaunchKernelGGL(init_state_kernel, grid_for(DB), dim3(TPB), 0, st, x, zck, c.nvars, D, B);
+    float* kck = W + o_kck;
+    for (int n = 0; n < nsteps; ++n) {
+        LG_BLAS(stage_derivs(zck + (long long)n * DB, t0 + (float)n * dt));
+        if (keep_k)
+            for (int j = 0; j < ns; ++j)
+                LG_HIP(hipMemcpyAsync(kck + ((long long)n * ns + j) * DB, kz[j], (size_t)DB * sizeof(float), hipMemcpyDeviceToDevice, st));
+        Comb cb{};
+        cb.nk = ns;
+        for (int j = 0; j < ns; ++j) { cb.k[j] = kz[j]; cb.coef[j] = dt * T.b[j]; }
+        hipLaunchKernelGGL(combine_kernel, grid_for(DB), dim3(TPB), 0, st, zck + (long long)(n + 1) * DB, zck + (long long)n * DB, cb, DB);
+    }
+    hipLaunchKernelGGL(lam_init_kernel, grid_for(B), dim3(TPB), 0, st, lamv, zck + (long long)nsteps * DB, lam[2], c.nvars, D, B);
+
+    // ---- reverse sweep ----
+    const float invK = 1.f / (float)K;
+    for (int n = nsteps - 1; n >= 0; --n) {
+        const float* zn = zck + (long long)n * DB;
+        const float tn = t0 + (float)n * dt;
+        if (keep_k) { for (int j = 0; j < ns; ++j) kz[j] = kck + ((long long)n * ns + j) * DB; }
+        else LG_BLAS(stage_derivs(zn, tn));
+        for (int i = ns - 1; i >= 0; --i) {
+            Comb cb{};
+            cb.nk = 0;
+            for (int j = 0; j < i; ++j)
+                if (T.a[i][j] != 0.f) { cb.k[cb.nk] = kz[j]; cb.coef[cb.nk] = dt * T.a[i][j]; ++cb.nk; }
+            hipLaunchKernelGGL(combine_kernel, grid_for(DB), dim3(TPB), 0, st, zs, zn, cb, DB);
+            LG_BLAS(forward(zs, tn + T.c[i] * dt));
+            const float cl = dt * T.b[i];          // cotangent of ldot (dL/d dlogp = +1 per column)
+            Comb zb{};
+            zb.nk = 0;
+            for (int j = i + 1; j < ns; ++j)
+                if (T.a[j][i] != 0.f) { zb.k[zb.nk] = Zb[j]; zb.coef[zb.nk] = T.a[j][i]; ++zb.nk; }
+            hipLaunchKernelGGL(kbar_kernel, grid_for(B), dim3(TPB), 0, st, kbar, lamv, zb, dt * T.b[i], dt, a[N], cl * lam[0], D, B);
+
+            for (int k = 0; k < K; ++k) {
+                // pullback of probe k: v_N = eps_k, delta_l = v_l .* act'_l, v_{l-1} = W_l^T delta_l, g = W_1[:,0:D]^T delta_1
+                hipLaunchKernelGGL(copy_rows_kernel, grid_for(DB), dim3(TPB), 0, st, vN, eps, D, K * D, k * D, B);
+                for (int l = N - 1; l >= 0; --l) {
+                    const float* vl = l == N - 1 ? vN : v[l];
+                    const long long HB = (long long)L.wout[l] * B;
+                    hipLaunchKernelGGL(mul_kernel, grid_for(HB), dim3(TPB), 0, st, dl[l], vl, d[l], HB);
+                    if (l > 0) LG_BLAS(gemm(OPT, OPN, L.win[l], B, L.wout[l], PA + L.pa_off[l], L.wout[l], dl[l], L.wout[l], v[l - 1], L.win[l]));
+                    else LG_BLAS(gemm(OPT, OPN, D, B, L.wout[0], PA, L.wout[0], dl[0], L.wout[0], gk, D));
+                }
+                hipLaunchKernelGGL(gbar_kernel, grid_for(B), dim3(TPB), 0, st, gbar, gk, vN, cl * invK, cl * lam[1] * invK, D, B);
+                // bottom-up through the pullback
+                LG_BLAS(gemm(OPN, OPN, L.wout[0], B, D, PA, L.wout[0], gbar, D, tdb, L.wout[0]));     // dbar_1 = W_1[:,0:D] gbar
+                LG_BLAS(wgrad(0, dl[0], L.wout[0], gbar, D, D));                                       // Wbar_1[:,0:D] += delta_1 gbar^T
+                float *db = tdb, *dbn = tdb2;
+                for (int l = 0; l < N; ++l) {
+                    const float* vl = l == N - 1 ? vN : v[l];
+                    const long long HB = (long long)L.wout[l] * B;
+                    hipLaunchKernelGGL(bottom_kernel, grid_for(HB), dim3(TPB), 0, st, db, d[l], vl, tvb, acc2[l], k == 0 ? 1 : 0, HB);
+                    if (l + 1 < N) {
+                        LG_BLAS(wgrad(l + 1, dl[l + 1], L.wout[l + 1], tvb, L.wout[l], L.wout[l]));    // Wbar_{l+1} += delta_{l+1} vbar_l^T
+                        LG_BLAS(gemm(OPN, OPN, L.wout[l + 1], B, L.wout[l], PA + L.pa_off[l + 1], L.wout[l + 1], tvb, L.wout[l], dbn, L.wout[l + 1]));
+                        float* tmp = db; db = dbn; dbn = tmp;
+                    }
+                }
+            }
+            // top-down through the forward chain
+            const float* ab = kbar;
+            float *abn = tab, *abn2 = tdb;   // tdb/tdb2 are free again
+            for (int l = N - 1; l >= 0; --l) {
+                hipLaunchKernelGGL(sbar_kernel, grid_for((long long)L.wout[l] * B), dim3(TPB), 0, st, tsb, ab, d[l], acc2[l], a[l + 1],
+                                   L.act[l], L.wout[l], B);
+                LG_BLAS(wgrad(l, tsb, L.wout[l], a[l], L.win[l] + 1, L.win[l] + 1));                   // [Wbar_l | bbar_l] += sbar_l [a_{l-1}; 1]^T
+                if (l > 0) {
+                    LG_BLAS(gemm(OPT, OPN, L.win[l], B, L.wout[l], PA + L.pa_off[l], L.wout[l], tsb, L.wout[l], abn, L.win[l]));
+                    ab = abn;
+                    float* tmp = abn; abn = abn2; abn2 = tmp;
+                } else {
+                    LG_BLAS(gemm(OPT, OPN, D, B, L.wout[0], PA, L.wout[0], tsb, L.wout[0], Zb[i], D));   // Zbar_i = W_1[:,0:D]^T sbar_1
+                }
+            }
+        }
+        Comb cb{};
+        cb.nk = ns;
+        for (int j = 0; j < ns; ++j) { cb.k[j] = Zb[j]; cb.coef[j] = 1.f; }
+        hipLaunchKernelGGL(combine_kernel, grid_for(DB), dim3(TPB), 0, st, lamv, lamv, cb, DB);
+    }
+    hipLaunchKernelGGL(reduce_slabs_kernel, grid_for(npa), dim3(TPB), 0, st, slabs, nslab, npa_pad, L, grad);
+    LG_HIP(hipGetLastError());
+    return hipSuccess;
+}
+
+}  // namespace cnf

@@ -1,5 +1,7 @@
 // cnf_internal.h — internal interfaces between the C-ABI layer and the kernel files.
 #pragma once
+#include <string>
+
 #include "cnf_common.h"
 
 namespace cnf {
@@ -78,6 +80,14 @@ hipError_t grad_launch(const cnf_config& c, const float* packed_dev, const float
                        int ckpt_zr, const float* eps, const float* ys,
                        const size_t* w_off, const size_t* b_off, int alg, int nsteps, float t0, float t1,
                        long long B, const float lam[3], float* slab, float* grad, int num_cus, hipStream_t st);
+// layer-wise gradient on rocBLAS GEMMs for everything the fused kernels do not cover (cnf_grad_layered.hip)
+struct LayeredGrad;
+bool layered_grad_supported(const cnf_config& c);
+void layered_grad_destroy(LayeredGrad* g);
+hipError_t layered_grad(LayeredGrad** ctx, const cnf_config& c, const float* P_dev, const size_t* w_off,
+                        const size_t* b_off, const float* x, const float* eps, const float* ys, int alg,
+                        int nsteps, float t0, float t1, long long B, const float lam[3], float* grad,
+                        hipStream_t st, std::string* err);
 int mfma_plan_zr(const MfmaPlan* p);   // state k-steps of the forward instance (checkpoint stride)
 bool mfma_plan_is_per_wave(const MfmaPlan* p);
 

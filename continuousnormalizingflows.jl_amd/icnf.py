@@ -386,6 +386,11 @@ class ICNF:
         h = self._handle(mode)
         return int(h.lib.cnf_kernel_path(h.ptr))
 
+    def grad_path(self, mode: Mode) -> int:
+        """0: no gradient for this mode; 1: fused reverse-sweep kernel; 2: layer-wise path (cnf_grad_path)."""
+        h = self._handle(mode)
+        return int(h.lib.cnf_grad_path(h.ptr))
+
     def repack_on_device(self, mode: Mode) -> bool:
         """True when the last parameter binding of this mode's handle was repacked by the device gather
         kernels (no host round trip) — cnf_repack_on_device."""

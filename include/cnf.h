@@ -159,11 +159,18 @@ int cnf_loss_sums(cnf_handle* h, const float* logp, const float* regs, int64_t B
  * discrete solve.  grad: device, n floats in the layout of cnf_set_params' p (overwritten).
  * sums4 (device, may be NULL): as cnf_loss_sums.  The caller all-reduces grad and sums4 across
  * column shards and divides by the global column count.
- * Covered: Hutchinson VJP with 1 <= K <= 8 probes, <= 16 conditions, 2 or 3 equal hidden layers (tanh or
- * softplus) of width <= 64, D + !autonomous <= 15; FFJORD and RNODE losses; CNF_ERR_UNSUPPORTED otherwise. */
+ * Every Hutchinson-VJP configuration is covered.  Fused reverse-sweep kernels: 1 <= K <= 8 probes,
+ * <= 16 conditions, 2 or 3 equal hidden layers (tanh or softplus) of width <= 64, D + !autonomous <= 15;
+ * every other shape (wide layers, more layers, unequal widths, mixed activations, larger D): layer-wise
+ * reverse sweep on rocBLAS GEMMs.  FFJORD and RNODE losses.  JVP / exact modes: CNF_ERR_UNSUPPORTED. */
 int cnf_loss_grad_fixed(cnf_handle* h, int alg, int nsteps, float t0, float t1, const float* x,
                         const float* eps, const float* ys, int64_t B, const float* lambdas,
                         float* grad, float* sums4, void* stream);
+
+/* Which implementation cnf_loss_grad_fixed uses for this handle: 0 = none (CNF_ERR_UNSUPPORTED),
+ * 1 = fused reverse-sweep kernel (cnf_grad.hip / cnf_grad_probes.hip), 2 = layer-wise reverse sweep on
+ * rocBLAS GEMMs (cnf_grad_layered.hip; librocblas.so.5 is loaded with dlopen at first use). */
+int cnf_grad_path(const cnf_handle* h);
 
 #ifdef __cplusplus
 }

@@ -397,11 +397,59 @@ def test_gradient_descent_on_the_gradient_kernel_reduces_the_loss(pkg, oracles):
     assert torch.equal(a, b)
 
 
-def test_parameter_gradient_is_refused_outside_its_shape(pkg, oracles):
+LAYERED_GRAD_SHAPES = [
+    # (make_spec kwargs, lambdas, B, alg, nsteps): outside the fused gradient kernels -> layer-wise path (csrc/cnf_grad_layered.hip)
+    (dict(nvars=32, hidden=[256, 256, 256]), (0.0, 0.0, 0.0), 40, 0, 2),                                   # BASELINE cfg4 shape (cooperative forward kernel)
+    (dict(nvars=8, ncond=8, hidden=[128, 128, 128], reg_z=True, reg_j=True), (0.02, 0.03, 0.0), 300, 1, 2),  # cfg5 widths, conditioned RNODE, chunked weight cotangents
+    (dict(nvars=3, naug=2, hidden=[24, 40, 16, 32, 24], act=2, reg_z=True, reg_j=True, reg_aug=True), (0.01, 0.02, 0.03), 50, 1, 3),  # five unequal hidden layers (SIMT forward)
+    (dict(nvars=20, hidden=[64, 64], nprobes=3, reg_j=True), (0.0, 0.05, 0.0), 33, 0, 3),                 # D = 20, three probes
+    (dict(nvars=4, hidden=[96], autonomous=True), (0.0, 0.0, 0.0), 25, 1, 2),                              # one hidden layer
+]
+
+
+@pytest.mark.parametrize("kw,lam,B,alg,nsteps", LAYERED_GRAD_SHAPES)
+def test_parameter_gradient_layerwise_path(kw, lam, B, alg, nsteps, pkg, oracles):
+    """Every Hutchinson-VJP configuration has a gradient: what the fused reverse-sweep kernels do not
+    cover runs layer-wise on rocBLAS GEMMs.  Checked against the fp64 autograd oracle."""
     o64, _ = oracles
-    spec = o64.make_spec(nvars=32, hidden=[256, 256, 256])       # cooperative-kernel shape: no gradient yet
+    spec = o64.make_spec(**kw)
+    p, xs, eps, ys = o64.synth_inputs(spec, B, 123, bias_scale=0.2)
+    L, gref = o64.loss_and_grad(spec, p, xs, 0.0, 1.0, nsteps, alg, eps, ys, lam)
+    icnf = make_icnf(pkg, spec, alg, nsteps, path=0, lambdas=lam)
+    mode = pkg.TrainMode(bool(spec.reg_z or spec.reg_j or spec.reg_aug))
+    args = (dev(xs),) + ((dev(ys),) if spec.ncond else ()) + (dev(p), {})
+    val, g = pkg.loss_and_gradient(icnf, mode, *args, eps=dev(eps))
+    g = g.cpu().numpy().astype(np.float64)
+    assert abs(float(val) - L) < 1e-4
+    scale = np.abs(gref).max()
+    assert np.max(np.abs(g - gref)) < 5e-5 * scale + 1e-6, np.max(np.abs(g - gref)) / scale
+
+
+def test_layerwise_gradient_agrees_with_the_fused_kernel(pkg, oracles, monkeypatch):
+    """cfg2 shape, B = 5000 (several column chunks + a ragged tail): the layer-wise path forced with
+    CNF_GRAD_LAYERED=1 against the fused reverse-sweep kernel - two independent implementations."""
+    o64, _ = oracles
+    spec = o64.make_spec(nvars=8, hidden=[64, 64, 64], reg_z=True, reg_j=True)
+    lam = (0.02, 0.03, 0.0)
+    B = 5000
+    p, xs, eps, _ = o64.synth_inputs(spec, B, 9, bias_scale=0.1)
+    icnf = make_icnf(pkg, spec, 1, 6, path=2, lambdas=lam)
+    v1, g1 = pkg.loss_and_gradient(icnf, pkg.TrainMode(True), dev(xs), dev(p), {}, eps=dev(eps))
+    monkeypatch.setenv("CNF_GRAD_LAYERED", "1")
+    v2, g2 = pkg.loss_and_gradient(icnf, pkg.TrainMode(True), dev(xs), dev(p), {}, eps=dev(eps))
+    g2b = pkg.loss_and_gradient(icnf, pkg.TrainMode(True), dev(xs), dev(p), {}, eps=dev(eps))[1]
+    monkeypatch.delenv("CNF_GRAD_LAYERED")
+    assert abs(float(v1) - float(v2)) < 1e-5
+    scale = float(g1.abs().max())
+    assert float((g1 - g2).abs().max()) < 2e-5 * scale
+    assert torch.equal(g2, g2b)                                    # chunk slabs, fixed order: reproducible
+
+
+def test_parameter_gradient_is_refused_outside_the_vjp_mode(pkg, oracles):
+    o64, _ = oracles
+    spec = o64.make_spec(nvars=8, hidden=[64, 64, 64], mode=1)   # Hutchinson JVP: no gradient yet
     p, xs, eps, _ = o64.synth_inputs(spec, 16, 1)
-    icnf = grad_icnf(pkg, spec, 1, 10)
+    icnf = make_icnf(pkg, spec, 1, 10, path=2, lambdas=(0.0, 0.0, 0.0))
     with pytest.raises(pkg._lib.CnfError) as e:
         pkg.loss_and_gradient(icnf, pkg.TrainMode(False), dev(xs), dev(p), {}, eps=dev(eps))
     assert e.value.code == pkg._lib.ERR_UNSUPPORTED
