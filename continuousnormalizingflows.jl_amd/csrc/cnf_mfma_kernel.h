@@ -125,6 +125,36 @@ __device__ __forceinline__ void gemm_hidden(const float* __restrict__ img, int l
     else gemm_tiles<HT, 4 * HT>(img, lane, TileIn<HT>{in}, acc);
 }
 
+// Activation of one accumulator tile.  For tanh the non-transcendental steps are written on 2-wide
+// vectors so they select the packed VALU forms (v_pk_add_f32 / v_pk_fma_f32: two lanes' worth per issue
+// slot, same issue cost as the scalar form — profiles/ubench/pk_f32_cost.result.txt); on gfx950 f32 VALU
+// time adds to f32 MFMA time, so every issue slot saved is wall time.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <int ACT>
+__device__ __forceinline__ void act_tile(const f32x4& a, f32x4& h, f32x4& d) {
+    if constexpr (ACT == CNF_ACT_TANH_PRESCALED || ACT == CNF_ACT_TANH) {
+        f32x2 x0 = {a[0], a[1]}, x1 = {a[2], a[3]};
+        if constexpr (ACT == CNF_ACT_TANH) { x0 = x0 * kTanhPrescale; x1 = x1 * kTanhPrescale; }
+        f32x2 e0 = {__builtin_amdgcn_exp2f(x0[0]), __builtin_amdgcn_exp2f(x0[1])};
+        f32x2 e1 = {__builtin_amdgcn_exp2f(x1[0]), __builtin_amdgcn_exp2f(x1[1])};
+        e0 = e0 + 1.f;
+        e1 = e1 + 1.f;
+        const f32x2 r0 = {fast_rcp(e0[0]), fast_rcp(e0[1])}, r1 = {fast_rcp(e1[0]), fast_rcp(e1[1])};
+        const f32x2 two = {2.f, 2.f}, one = {1.f, 1.f};
+        const f32x2 h0 = __builtin_elementwise_fma(r0, two, -one), h1 = __builtin_elementwise_fma(r1, two, -one);
+        const f32x2 d0 = __builtin_elementwise_fma(-h0, h0, one), d1 = __builtin_elementwise_fma(-h1, h1, one);
+        h = f32x4{h0[0], h0[1], h1[0], h1[1]};
+        d = f32x4{d0[0], d0[1], d1[0], d1[1]};
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float dd;
+            h[r] = act_fwd<ACT>(a[r], dd);
+            d[r] = dd;
+        }
+    }
+}
+
 // One dynamics evaluation for a 16-sample tile.
 //   forward pass (shared), then
 //   ENG_VJP: pullback of KP probes with the transposed images  (g = eps^T J;  src/core/utils.jl:150-159)
@@ -157,13 +187,7 @@ __device__ __forceinline__ void dyn_eval(const float* __restrict__ smem, int lan
         gemm_tiles<HT, ZR>(smem + LAY.f1z, lane, RegIn<ZR>{z}, acc);
         if constexpr (CR > 0) gemm_tiles<HT, CR>(smem + LAY.f1y, lane, RegIn<CR>{y}, acc);
 #pragma unroll
-        for (int mt = 0; mt < HT; ++mt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float dd;
-                h[mt][r] = act_fwd<ACT>(acc[mt][r], dd);
-                d[0][mt][r] = dd;
-            }
+        for (int mt = 0; mt < HT; ++mt) act_tile<ACT>(acc[mt], h[mt], d[0][mt]);
     }
     // ---- hidden layers 2..L ----
 #pragma unroll
@@ -172,13 +196,7 @@ __device__ __forceinline__ void dyn_eval(const float* __restrict__ smem, int lan
         load_cvec<HT>(smem + LAY.v_bh + (l - 1) * MfmaLayout::vecC(HT), g, acc);
         gemm_hidden<HT, ARITH>(smem + LAY.fh + (l - 1) * LAY.imgHid(), lane, h, acc);
 #pragma unroll
-        for (int mt = 0; mt < HT; ++mt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float dd;
-                h[mt][r] = act_fwd<ACT>(acc[mt][r], dd);
-                d[l][mt][r] = dd;
-            }
+        for (int mt = 0; mt < HT; ++mt) act_tile<ACT>(acc[mt], h[mt], d[l][mt]);
     }
     // ---- last layer (identity): zdot ----
     {
