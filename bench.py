@@ -95,7 +95,7 @@ def grad_mfma_per_stage(spec):
 
 
 def layered_flop_per_stage(spec):
-    """GEMM flop per sample per RK stage of the layer-wise gradient path (csrc/cnf_grad_layered.hip): forward
+    """GEMM flop per sample per RK stage of the layer-wise gradient path (csrc/cnf_layered.hip): forward
     chain (recompute at the stage point; the stage derivatives themselves are checkpointed), per probe the
     pullback and its bottom-up reverse with the probe's weight cotangents, then the top-down pass with
     weight cotangents.  Plus the forward sweep (one chain per stage) and the fused solve for the loss."""

@@ -19,7 +19,7 @@ OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_NO_PARAMS, ERR_HIP, ERR_NO_DEVICE = 0, -1,
 ACT_IDENTITY, ACT_TANH, ACT_SOFTPLUS = 0, 1, 2
 MODE_HUTCH_VJP, MODE_HUTCH_JVP, MODE_EXACT = 0, 1, 2
 ALG_RK4, ALG_TSIT5 = 0, 1
-PATH_AUTO, PATH_SIMT, PATH_MFMA = 0, 1, 2
+PATH_AUTO, PATH_SIMT, PATH_MFMA, PATH_LAYERED = 0, 1, 2, 3
 ARITH_F32, ARITH_BF16X6 = 0, 1
 
 EXPORTS = ("cnf_version", "cnf_last_error", "cnf_create", "cnf_destroy", "cnf_set_params",

@@ -140,7 +140,8 @@ struct cnf_handle {
     // device-side repacking (see PackMap): maps for the solve image and the gradient image, rebuilt
     // when the layout handed to cnf_set_params changes; p_stage holds host-supplied parameters
     PackMap map_fwd, map_grad;
-    LayeredGrad* layered = nullptr;      // rocBLAS context + workspace of the layer-wise gradient
+    LayeredGrad* layered = nullptr;      // rocBLAS context + workspaces of the layer-wise evaluation / gradient
+    bool layered_forced = false;         // kernel_path = CNF_PATH_LAYERED given explicitly: GEMM path for every batch
     bool maps_built = false;
     bool repack_on_device = false;
     float* p_stage = nullptr;
@@ -196,11 +197,11 @@ int cnf_create(cnf_handle** out, const cnf_config* cfg) {
     if (c.mode < CNF_MODE_HUTCH_VJP || c.mode > CNF_MODE_EXACT)
         return fail(CNF_ERR_INVALID, "cnf_create: unknown mode");
     if (c.nprobes < 1) return fail(CNF_ERR_INVALID, "cnf_create: nprobes >= 1 required");
-    if (c.kernel_path < CNF_PATH_AUTO || c.kernel_path > CNF_PATH_MFMA)
+    if (c.kernel_path < CNF_PATH_AUTO || c.kernel_path > CNF_PATH_LAYERED)
         return fail(CNF_ERR_INVALID, "cnf_create: unknown kernel_path");
     if (c.arith < CNF_ARITH_F32 || c.arith > CNF_ARITH_BF16X6)
         return fail(CNF_ERR_INVALID, "cnf_create: unknown arith");
-    if (c.arith != CNF_ARITH_F32 && c.kernel_path == CNF_PATH_SIMT)
+    if (c.arith != CNF_ARITH_F32 && (c.kernel_path == CNF_PATH_SIMT || c.kernel_path == CNF_PATH_LAYERED))
         return fail(CNF_ERR_INVALID, "cnf_create: arith = BF16X6 is an MFMA-path option");
 
     int ndev = 0;
@@ -224,13 +225,22 @@ int cnf_create(cnf_handle** out, const cnf_config* cfg) {
     n.mode = c.mode; n.K = c.nprobes; n.reg_z = c.reg_z; n.reg_j = c.reg_j;
 
     h->path = CNF_PATH_SIMT;
-    if (c.kernel_path != CNF_PATH_SIMT) {
+    if (c.kernel_path == CNF_PATH_LAYERED) {
+        if (!layered_available()) {
+            delete h;
+            return fail(CNF_ERR_UNSUPPORTED, "cnf_create: CNF_PATH_LAYERED needs librocblas.so.5 (dlopen failed)");
+        }
+        h->path = CNF_PATH_LAYERED;
+        h->layered_forced = true;
+    } else if (c.kernel_path != CNF_PATH_SIMT) {
         h->plan = mfma_plan_create(c);
         if (h->plan) {
             h->path = CNF_PATH_MFMA;
         } else if (c.kernel_path == CNF_PATH_MFMA || c.arith != CNF_ARITH_F32) {
             delete h;
             return fail(CNF_ERR_UNSUPPORTED, "cnf_create: configuration not covered by the MFMA kernels");
+        } else if (layered_available()) {
+            h->path = CNF_PATH_LAYERED;
         }
     }
     *out = h;
@@ -376,6 +386,29 @@ int cnf_set_params(cnf_handle* h, const float* p, size_t n, const size_t* w_off,
     return CNF_OK;
 }
 
+// One dynamics evaluation on the generic families: layer-wise GEMMs (cnf_layered.hip) for a LAYERED handle
+// (CNF_LAYERED_MIN_B=n sends batches below n to the SIMT kernels instead), the thread-per-sample kernels
+// (cnf_simt.hip) otherwise.
+static int64_t layered_min_batch() {
+    const char* e = getenv("CNF_LAYERED_MIN_B");
+    return (e && *e) ? atoll(e) : 0;   // measured: the GEMM path wins at every batch size (profiles/r1h_generic_small.json)
+}
+static int generic_aug_f(cnf_handle* h, const StageIn& in, float t, const float* eps, const float* ys, int64_t B,
+                         float* du, bool first_of_solve, hipStream_t st) {
+    if (h->path == CNF_PATH_LAYERED && (h->layered_forced || B >= layered_min_batch())) {
+        std::string msg;
+        hipError_t e = layered_aug_f(&h->layered, h->cfg, h->P_dev, h->w_off.data(), h->b_off.data(), first_of_solve, in, t,
+                                     eps, ys, B, du, st, &msg);
+        if (e == hipErrorNotSupported) return fail(CNF_ERR_UNSUPPORTED, msg);
+        if (e != hipSuccess) return fail(CNF_ERR_HIP, msg);
+        return CNF_OK;
+    }
+    int rc = ensure_ws(h, B);
+    if (rc) return rc;
+    HIP_TRY(simt_aug_f(h->net, h->P_dev, in, t, eps, ys, B, du, h->ws, h->ws_B, st));
+    return CNF_OK;
+}
+
 static int check_call(cnf_handle* h, const float* eps, const float* ys, int64_t B, const char* who) {
     if (!h) return fail(CNF_ERR_INVALID, std::string(who) + ": null handle");
     if (!h->have_params) return fail(CNF_ERR_NO_PARAMS, std::string(who) + ": cnf_set_params not called");
@@ -403,20 +436,15 @@ int cnf_aug_f(cnf_handle* h, float* du, const float* u, float t, const float* ep
         HIP_TRY(mfma_solve(h->plan, h->packed_dev, a, st));
         return CNF_OK;
     }
-    rc = ensure_ws(h, B);
-    if (rc) return rc;
     StageIn in{};
     in.u = u; in.nprev = 0; in.dt = 0.f;
-    HIP_TRY(simt_aug_f(h->net, h->P_dev, in, t, eps, ys, B, du, h->ws, h->ws_B, st));
-    return CNF_OK;
+    return generic_aug_f(h, in, t, eps, ys, B, du, true, st);
 }
 
 static int simt_integrate(cnf_handle* h, int alg, int nsteps, float t0, float t1, float* u,
                           const float* eps, const float* ys, int64_t B, hipStream_t st) {
-    // u is integrated in place.  Unfused structure: one launch per stage + one per step.
-    int rc = ensure_ws(h, B);
-    if (rc) return rc;
-    rc = ensure_kbuf(h, B);
+    // u is integrated in place.  Unfused structure: one evaluation per stage + one update per step.
+    int rc = ensure_kbuf(h, B);
     if (rc) return rc;
     const Tableau T = make_tableau(alg);
     const size_t n = (size_t)h->S * (size_t)B;
@@ -429,8 +457,8 @@ static int simt_integrate(cnf_handle* h, int alg, int nsteps, float t0, float t1
             StageIn in{};
             in.u = u; in.nprev = i; in.dt = dt;
             for (int j = 0; j < i; ++j) { in.k[j] = k[j]; in.coef[j] = T.a[i][j]; }
-            HIP_TRY(simt_aug_f(h->net, h->P_dev, in, tn + T.c[i] * dt, eps, ys, B, k[i], h->ws,
-                               h->ws_B, st));
+            rc = generic_aug_f(h, in, tn + T.c[i] * dt, eps, ys, B, k[i], step == 0 && i == 0, st);
+            if (rc) return rc;
         }
         StageIn fin{};
         fin.u = u; fin.nprev = T.ns; fin.dt = dt;
@@ -539,7 +567,7 @@ int cnf_loss_grad_fixed(cnf_handle* h, int alg, int nsteps, float t0, float t1, 
         return CNF_OK;
     }
     if (!fused) {
-        // layer-wise reverse sweep (cnf_grad_layered.hip); the loss sums come from the regular solve
+        // layer-wise reverse sweep (cnf_layered.hip); the loss sums come from the regular solve
         if (sums4) {
             const size_t need = 4 * (size_t)B * sizeof(float);
             if (need > h->grad_ws_bytes) {

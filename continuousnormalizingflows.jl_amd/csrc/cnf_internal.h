@@ -80,8 +80,12 @@ hipError_t grad_launch(const cnf_config& c, const float* packed_dev, const float
                        int ckpt_zr, const float* eps, const float* ys,
                        const size_t* w_off, const size_t* b_off, int alg, int nsteps, float t0, float t1,
                        long long B, const float lam[3], float* slab, float* grad, int num_cus, hipStream_t st);
-// layer-wise gradient on rocBLAS GEMMs for everything the fused kernels do not cover (cnf_grad_layered.hip)
+// layer-wise gradient on rocBLAS GEMMs for everything the fused kernels do not cover (cnf_layered.hip)
 struct LayeredGrad;
+bool layered_available();   // librocblas.so.5 loadable
+hipError_t layered_aug_f(LayeredGrad** ctx, const cnf_config& c, const float* P_dev, const size_t* w_off,
+                         const size_t* b_off, bool rebuild_params, const StageIn& in, float t, const float* eps,
+                         const float* ys, long long B, float* du, hipStream_t st, std::string* err);
 bool layered_grad_supported(const cnf_config& c);
 void layered_grad_destroy(LayeredGrad* g);
 hipError_t layered_grad(LayeredGrad** ctx, const cnf_config& c, const float* P_dev, const size_t* w_off,

@@ -1,6 +1,12 @@
-// cnf_grad_layered.hip — parameter gradient for every Hutchinson-VJP configuration the fused
-// reverse-sweep kernels (cnf_grad.hip, cnf_grad_probes.hip) do not cover: wide layers (BASELINE cfg4,
-// 3x256), more than three hidden layers, unequal widths, mixed activations, D > 14.
+// cnf_layered.hip — layer-wise evaluation on library GEMMs for what the fused kernels do not cover.
+//
+// (1) layered_aug_f: the augmented dynamics (SURVEY.md §8 boundary A; src/core/icnf.jl:184-322) for ANY
+//     Dense chain — more than four hidden layers, widths above 256, mixed activations, D > 16, several
+//     JVP probes — in all three trace modes.  It has the signature of simt_aug_f and plugs into the same
+//     RK driver (cnf_api.hip), replacing the thread-per-sample kernels when the batch is large.
+// (2) layered_grad: the parameter gradient for every Hutchinson-VJP configuration the fused
+//     reverse-sweep kernels (cnf_grad.hip, cnf_grad_probes.hip) do not cover: wide layers (BASELINE cfg4,
+//     3x256), more than three hidden layers, unequal widths, mixed activations, D > 14.
 //
 // Same mathematics as cnf_grad.hip (discretise-then-optimise reverse sweep through the fixed-step RK
 // solve; reference: Zygote through SciMLBase.solve, src/core/icnf.jl:90-99, objective icnf.jl:184-251,
@@ -238,18 +244,100 @@ __global__ void lam_init_kernel(float* __restrict__ lam, const float* __restrict
     }
 }
 
+
+// ---- forward evaluation (layered_aug_f) ----
+
+// a_0 = [z; t; y; 1] with z = rows 0..D-1 of  u + dt sum_j coef_j k_j  (state layout S x B)
+__global__ void build_input_stage_kernel(StageIn in, int S, float t, const float* __restrict__ ys, float* __restrict__ a0,
+                                         int D, int C, int autonomous, long long B) {
+    const int nin = D + (autonomous ? 0 : 1) + C, ld = nin + 1;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)ld * B) return;
+    const long long j = i / ld;
+    const int f = (int)(i % ld);
+    float v;
+    if (f < D) {
+        float acc = 0.f;
+        for (int q = 0; q < in.nprev; ++q) acc = fmaf(in.coef[q], in.k[q][j * S + f], acc);
+        v = fmaf(in.dt, acc, in.u[j * S + f]);
+    } else if (f == nin) v = 1.f;
+    else if (!autonomous && f == D) v = t;
+    else v = ys[j * C + (f - D - (autonomous ? 0 : 1))];
+    a0[i] = v;
+}
+
+// out[rows x B] = x[rows roff.. of ld ldx] .* y[rows x B]
+__global__ void mul_rows_kernel(float* __restrict__ out, const float* __restrict__ x, int ldx, int roff,
+                                const float* __restrict__ y, int rows, long long B) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)rows * B) return;
+    const long long j = i / rows;
+    const int f = (int)(i % rows);
+    out[i] = x[j * ldx + roff + f] * y[i];
+}
+
+// Hutchinson accumulation for one probe: ldot -= scale <g, eps_k>;  ndot += scale |g|   (icnf.jl:229-245)
+__global__ void trace_kernel(const float* __restrict__ g, const float* __restrict__ eps, int lde, int roff,
+                             float* __restrict__ ld, float* __restrict__ nd, float scale, int reg_j, int D, long long B) {
+    const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= B) return;
+    float dot = 0.f, n2 = 0.f;
+    for (int f = 0; f < D; ++f) {
+        const float gv = g[j * D + f];
+        dot = fmaf(gv, eps[j * lde + roff + f], dot);
+        n2 = fmaf(gv, gv, n2);
+    }
+    ld[j] -= scale * dot;
+    if (reg_j) nd[j] += scale * sqrtf(n2);
+}
+
+// exact trace, unit tangent e_i: tau_1 = W_1[:, i] .* act'_1
+__global__ void exact_seed_kernel(float* __restrict__ tau, const float* __restrict__ w1col, const float* __restrict__ d1,
+                                  int H, long long B) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)H * B) return;
+    tau[i] = w1col[i % H] * d1[i];
+}
+
+// ldot -= act'_N[i] * (W_N[i, :] tau)   (J_ii)
+__global__ void exact_diag_kernel(const float* __restrict__ row, const float* __restrict__ dN, int D, int i,
+                                  float* __restrict__ ld, long long B) {
+    const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < B) ld[j] -= row[j] * dN[j * D + i];
+}
+
+// du = [zdot; ldot; |zdot| (reg_z); ndot]
+__global__ void finish_kernel(float* __restrict__ du, const float* __restrict__ aN, const float* __restrict__ ld,
+                              const float* __restrict__ nd, int reg_z, int D, long long B) {
+    const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= B) return;
+    const int S = D + 3;
+    float e2 = 0.f;
+    for (int f = 0; f < D; ++f) {
+        const float v = aN[j * (D + 1) + f];
+        du[j * S + f] = v;
+        e2 = fmaf(v, v, e2);
+    }
+    du[j * S + D] = ld[j];
+    du[j * S + D + 1] = reg_z ? sqrtf(e2) : 0.f;
+    du[j * S + D + 2] = nd[j];
+}
+
 }  // namespace
 
 struct LayeredGrad {
     rocblas_handle rb = nullptr;
-    float* ws = nullptr;
+    float* ws = nullptr;          // gradient workspace
     size_t ws_floats = 0;
+    float* ws_fwd = nullptr;      // forward-evaluation workspace (the gradient calls the forward for the loss)
+    size_t ws_fwd_floats = 0;
 };
 
 void layered_grad_destroy(LayeredGrad* g) {
     if (!g) return;
     if (g->rb && blas().ok) (void)blas().destroy(g->rb);
     if (g->ws) (void)hipFree(g->ws);
+    if (g->ws_fwd) (void)hipFree(g->ws_fwd);
     delete g;
 }
 
@@ -265,6 +353,130 @@ bool layered_grad_supported(const cnf_config& c) { return c.mode == CNF_MODE_HUT
         rocblas_status _s = (expr);                                                     \
         if (_s != rocblas_status_success) { *err = std::string(#expr) + ": rocblas status " + std::to_string((int)_s); return hipErrorUnknown; } \
     } while (0)
+
+bool layered_available() { return blas().ok; }
+
+// du = augmented_f(u + dt sum coef k, p, t): forward chain, then the trace estimator of the handle's mode
+hipError_t layered_aug_f(LayeredGrad** ctx, const cnf_config& c, const float* P_dev, const size_t* w_off,
+                         const size_t* b_off, bool rebuild_params, const StageIn& in, float t, const float* eps,
+                         const float* ys, long long B, float* du, hipStream_t st, std::string* err) {
+    Blas& bl = blas();
+    if (!bl.ok) {
+        *err = "layered evaluation: librocblas.so.5 could not be loaded (dlopen)";
+        return hipErrorNotSupported;
+    }
+    if (!*ctx) *ctx = new LayeredGrad();
+    LayeredGrad& G = **ctx;
+    if (!G.rb) LG_BLAS(bl.create(&G.rb));
+    LG_BLAS(bl.set_stream(G.rb, st));
+    const int N = c.n_layers, D = c.nvars + c.naug, C = c.ncond, S = D + 3;
+    const int K = c.mode == CNF_MODE_EXACT ? 1 : c.nprobes;
+    LDesc L{};
+    L.n_layers = N;
+    long long npa = 0;
+    int maxw = D;
+    for (int l = 0; l < N; ++l) {
+        L.win[l] = c.widths[l]; L.wout[l] = c.widths[l + 1]; L.act[l] = c.acts[l];
+        L.pa_off[l] = npa; L.w_off[l] = (long long)w_off[l]; L.b_off[l] = (long long)b_off[l];
+        npa += (long long)L.wout[l] * (L.win[l] + 1);
+        if (L.wout[l] > maxw) maxw = L.wout[l];
+    }
+    L.npa = npa;
+    long long off = 0;
+    auto take = [&](long long n) { const long long o = off; off += (n + 63) / 64 * 64; return o; };
+    const long long o_PA = take(npa);
+    long long o_a[CNF_MAX_LAYERS + 1], o_d[CNF_MAX_LAYERS];
+    o_a[0] = take((long long)(c.widths[0] + 1) * B);
+    for (int l = 0; l < N; ++l) { o_a[l + 1] = take((long long)(L.wout[l] + 1) * B); o_d[l] = take((long long)L.wout[l] * B); }
+    const long long WB = (long long)maxw * B;
+    const long long o_t0 = take(WB), o_t1 = take(WB), o_ld = take(B), o_nd = take(B), o_row = take(B);
+    const bool grown = (size_t)off > G.ws_fwd_floats;
+    if (grown) {
+        if (G.ws_fwd) LG_HIP(hipFree(G.ws_fwd));
+        G.ws_fwd = nullptr; G.ws_fwd_floats = 0;
+        LG_HIP(hipMalloc((void**)&G.ws_fwd, (size_t)off * sizeof(float)));
+        G.ws_fwd_floats = (size_t)off;
+    }
+    float* W = G.ws_fwd;
+    float* PA = W + o_PA;
+    float *a[CNF_MAX_LAYERS + 1], *d[CNF_MAX_LAYERS];
+    for (int l = 0; l <= N; ++l) a[l] = W + o_a[l];
+    for (int l = 0; l < N; ++l) d[l] = W + o_d[l];
+    float *tA = W + o_t0, *tB = W + o_t1, *ldacc = W + o_ld, *ndacc = W + o_nd, *row = W + o_row;
+    if (rebuild_params || grown)
+        hipLaunchKernelGGL(aug_params_kernel, grid_for(npa), dim3(TPB), 0, st, P_dev, PA, L);
+
+    const float one = 1.f, zero = 0.f;
+    auto gemm = [&](rocblas_operation ta, rocblas_operation tb, int m, long long n, int k, const float* A, int lda,
+                    const float* Bm, int ldb, float* Cm, int ldc) -> rocblas_status {
+        return bl.sgemm(G.rb, ta, tb, m, (rocblas_int)n, k, &one, A, lda, Bm, ldb, &zero, Cm, ldc);
+    };
+    const rocblas_operation OPN = rocblas_operation_none, OPT = rocblas_operation_transpose;
+
+    // forward chain
+    hipLaunchKernelGGL(build_input_stage_kernel, grid_for((long long)(c.widths[0] + 1) * B), dim3(TPB), 0, st, in, S, t, ys, a[0],
+                       D, C, c.autonomous, B);
+    for (int l = 0; l < N; ++l) {
+        LG_BLAS(gemm(OPN, OPN, L.wout[l], B, L.win[l] + 1, PA + L.pa_off[l], L.wout[l], a[l], L.win[l] + 1, a[l + 1], L.wout[l] + 1));
+        hipLaunchKernelGGL(act_kernel, grid_for((long long)(L.wout[l] + 1) * B), dim3(TPB), 0, st, a[l + 1], d[l], L.act[l], L.wout[l], B);
+    }
+    LG_HIP(hipMemsetAsync(ldacc, 0, (size_t)B * sizeof(float), st));
+    LG_HIP(hipMemsetAsync(ndacc, 0, (size_t)B * sizeof(float), st));
+
+    if (c.mode == CNF_MODE_HUTCH_VJP) {
+        // g = eps^T J: delta_N = eps .* act'_N, delta_{l-1} = (W_l^T delta_l) .* act'_{l-1}, g = W_1[:,0:D]^T delta_1
+        for (int k = 0; k < K; ++k) {
+            float *dl = tA, *vv = tB;
+            hipLaunchKernelGGL(mul_rows_kernel, grid_for((long long)D * B), dim3(TPB), 0, st, dl, eps, K * D, k * D, d[N - 1], D, B);
+            for (int l = N - 1; l >= 1; --l) {
+                LG_BLAS(gemm(OPT, OPN, L.win[l], B, L.wout[l], PA + L.pa_off[l], L.wout[l], dl, L.wout[l], vv, L.win[l]));
+                const long long HB = (long long)L.win[l] * B;
+                hipLaunchKernelGGL(mul_kernel, grid_for(HB), dim3(TPB), 0, st, vv, vv, d[l - 1], HB);
+                float* tmp = dl; dl = vv; vv = tmp;
+            }
+            LG_BLAS(gemm(OPT, OPN, D, B, L.wout[0], PA, L.wout[0], dl, L.wout[0], vv, D));
+            hipLaunchKernelGGL(trace_kernel, grid_for(B), dim3(TPB), 0, st, vv, eps, K * D, k * D, ldacc, ndacc, 1.f / (float)K,
+                               c.reg_j, D, B);
+        }
+    } else if (c.mode == CNF_MODE_HUTCH_JVP) {
+        // g = J eps: tau_1 = (W_1[:,0:D] eps) .* act'_1, tau_{l+1} = (W_{l+1} tau_l) .* act'_{l+1}
+        for (int k = 0; k < K; ++k) {
+            float *tau = tA, *nx = tB;
+            LG_BLAS(gemm(OPN, OPN, L.wout[0], B, D, PA, L.wout[0], eps + (long long)k * D, K * D, tau, L.wout[0]));
+            hipLaunchKernelGGL(mul_kernel, grid_for((long long)L.wout[0] * B), dim3(TPB), 0, st, tau, tau, d[0], (long long)L.wout[0] * B);
+            for (int l = 1; l < N; ++l) {
+                LG_BLAS(gemm(OPN, OPN, L.wout[l], B, L.win[l], PA + L.pa_off[l], L.wout[l], tau, L.win[l], nx, L.wout[l]));
+                hipLaunchKernelGGL(mul_kernel, grid_for((long long)L.wout[l] * B), dim3(TPB), 0, st, nx, nx, d[l], (long long)L.wout[l] * B);
+                float* tmp = tau; tau = nx; nx = tmp;
+            }
+            hipLaunchKernelGGL(trace_kernel, grid_for(B), dim3(TPB), 0, st, tau, eps, K * D, k * D, ldacc, ndacc, 1.f / (float)K,
+                               c.reg_j, D, B);
+        }
+    } else {
+        // exact trace: unit tangents e_i pushed forward, J_ii read off the i-th output row (icnf.jl:312)
+        for (int i = 0; i < D; ++i) {
+            float *tau = tA, *nx = tB;
+            if (N == 1) {
+                // single layer: J_ii = act'_1[i] W_1[i, i]
+                hipLaunchKernelGGL(copy_rows_kernel, grid_for(B), dim3(TPB), 0, st, row, PA + i + (long long)L.wout[0] * i, 1, 0, 0, B);
+            } else {
+                hipLaunchKernelGGL(exact_seed_kernel, grid_for((long long)L.wout[0] * B), dim3(TPB), 0, st, tau,
+                                   PA + (long long)L.wout[0] * i, d[0], L.wout[0], B);
+                for (int l = 1; l < N - 1; ++l) {
+                    LG_BLAS(gemm(OPN, OPN, L.wout[l], B, L.win[l], PA + L.pa_off[l], L.wout[l], tau, L.win[l], nx, L.wout[l]));
+                    hipLaunchKernelGGL(mul_kernel, grid_for((long long)L.wout[l] * B), dim3(TPB), 0, st, nx, nx, d[l], (long long)L.wout[l] * B);
+                    float* tmp = tau; tau = nx; nx = tmp;
+                }
+                // row i of W_N tau: a 1 x B product
+                LG_BLAS(gemm(OPN, OPN, 1, B, L.win[N - 1], PA + L.pa_off[N - 1] + i, L.wout[N - 1], tau, L.win[N - 1], row, 1));
+            }
+            hipLaunchKernelGGL(exact_diag_kernel, grid_for(B), dim3(TPB), 0, st, row, d[N - 1], D, i, ldacc, B);
+        }
+    }
+    hipLaunchKernelGGL(finish_kernel, grid_for(B), dim3(TPB), 0, st, du, a[N], ldacc, ndacc, c.reg_z, D, B);
+    LG_HIP(hipGetLastError());
+    return hipSuccess;
+}
 
 hipError_t layered_grad(LayeredGrad** ctx, const cnf_config& c, const float* P_dev, const size_t* w_off,
                         const size_t* b_off, const float* x, const float* eps, const float* ys, int alg,

@@ -66,8 +66,12 @@ enum { CNF_ALG_RK4 = 0, CNF_ALG_TSIT5 = 1 };
  *             kernel covers; cnf_create fails with CNF_ERR_UNSUPPORTED otherwise. */
 enum { CNF_ARITH_F32 = 0, CNF_ARITH_BF16X6 = 1 };
 
-/* kernel families (cnf_kernel_path) */
-enum { CNF_PATH_AUTO = 0, CNF_PATH_SIMT = 1, CNF_PATH_MFMA = 2 };
+/* kernel families (cnf_kernel_path).  AUTO resolves to MFMA (fused whole-solve kernels) when an
+ * instance covers the configuration, else to LAYERED (layer-wise evaluation on rocBLAS GEMMs + HIP
+ * elementwise kernels, any Dense chain) when librocblas.so.5 can be loaded, else to SIMT (thread-per-
+ * sample kernels, any Dense chain; 4-100x slower than LAYERED at every batch size measured, kept as the
+ * dependency-free fallback and as an independent implementation for the tests). */
+enum { CNF_PATH_AUTO = 0, CNF_PATH_SIMT = 1, CNF_PATH_MFMA = 2, CNF_PATH_LAYERED = 3 };
 
 /* Configuration = the ICNF fields and type parameters that reach the hot path
  * (src/core/icnf.jl:16-141). */
@@ -110,7 +114,7 @@ int cnf_destroy(cnf_handle* h);
 int cnf_set_params(cnf_handle* h, const float* p, size_t n, const size_t* w_off,
                    const size_t* b_off, int p_is_device, void* stream);
 
-/* Which kernel family the handle resolved to (CNF_PATH_SIMT or CNF_PATH_MFMA). */
+/* Which kernel family the handle resolved to (CNF_PATH_SIMT, CNF_PATH_MFMA or CNF_PATH_LAYERED). */
 int cnf_kernel_path(const cnf_handle* h);
 
 /* How the last cnf_set_params repacked: 1 = gather kernels on the device (fused path, f32 images),
@@ -169,7 +173,7 @@ int cnf_loss_grad_fixed(cnf_handle* h, int alg, int nsteps, float t0, float t1, 
 
 /* Which implementation cnf_loss_grad_fixed uses for this handle: 0 = none (CNF_ERR_UNSUPPORTED),
  * 1 = fused reverse-sweep kernel (cnf_grad.hip / cnf_grad_probes.hip), 2 = layer-wise reverse sweep on
- * rocBLAS GEMMs (cnf_grad_layered.hip; librocblas.so.5 is loaded with dlopen at first use). */
+ * rocBLAS GEMMs (cnf_layered.hip; librocblas.so.5 is loaded with dlopen at first use). */
 int cnf_grad_path(const cnf_handle* h);
 
 #ifdef __cplusplus

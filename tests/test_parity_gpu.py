@@ -49,8 +49,8 @@ def run_inference(pkg, icnf, spec, p, xs, eps, ys, **kw):
 
 
 def paths_for(pkg, spec, alg, nsteps):
-    """SIMT always; MFMA when the library says the configuration is covered."""
-    out = [1]
+    """SIMT and the layer-wise GEMM path always; MFMA when the library says the configuration is covered."""
+    out = [1, 3]
     try:
         icnf = make_icnf(pkg, spec, alg, nsteps, path=2)
         icnf.kernel_path(mode_of(pkg, spec))
@@ -398,7 +398,7 @@ def test_gradient_descent_on_the_gradient_kernel_reduces_the_loss(pkg, oracles):
 
 
 LAYERED_GRAD_SHAPES = [
-    # (make_spec kwargs, lambdas, B, alg, nsteps): outside the fused gradient kernels -> layer-wise path (csrc/cnf_grad_layered.hip)
+    # (make_spec kwargs, lambdas, B, alg, nsteps): outside the fused gradient kernels -> layer-wise path (csrc/cnf_layered.hip)
     (dict(nvars=32, hidden=[256, 256, 256]), (0.0, 0.0, 0.0), 40, 0, 2),                                   # BASELINE cfg4 shape (cooperative forward kernel)
     (dict(nvars=8, ncond=8, hidden=[128, 128, 128], reg_z=True, reg_j=True), (0.02, 0.03, 0.0), 300, 1, 2),  # cfg5 widths, conditioned RNODE, chunked weight cotangents
     (dict(nvars=3, naug=2, hidden=[24, 40, 16, 32, 24], act=2, reg_z=True, reg_j=True, reg_aug=True), (0.01, 0.02, 0.03), 50, 1, 3),  # five unequal hidden layers (SIMT forward)
@@ -526,6 +526,54 @@ def test_device_side_repack_equals_host_repack(kw, pkg, oracles):
     ref2 = oc.inference_fixed(spec, (p * np.float32(0.5)).astype(np.float32), xs, 0.0, 1.0, 4, 0, eps, ys)[0]
     assert np.max(np.abs(c.cpu().numpy() - ref2)) < TOL_SOLVE
     assert not torch.equal(a, c)
+
+
+def test_randomised_shapes_layerwise_vs_generic_kernels(pkg, oracles):
+    """The layer-wise GEMM path (csrc/cnf_layered.hip, CNF_PATH_LAYERED) against the thread-per-sample kernels
+    on 40 random configurations, including everything the fused kernels do not take: up to 6 hidden layers
+    of unequal width up to 300, D up to 40, several JVP probes, all three trace modes, conditions."""
+    o64, _ = oracles
+    rng = np.random.default_rng(20240702)
+    for it in range(40):
+        D = int(rng.integers(1, 41))
+        naug = int(rng.integers(0, min(3, D)))
+        C = int(rng.choice([0, 0, 5, 19]))
+        L = int(rng.integers(1, 7))
+        hidden = [int(rng.choice([7, 16, 33, 64, 100, 128, 200, 300])) for _ in range(L)]
+        mode = int(rng.choice([0, 0, 1, 2]))
+        if mode == 2:
+            D = min(D, 12)                                        # exact trace: D tangents per evaluation
+            naug = min(naug, D - 1)
+        K = int(rng.choice([1, 1, 2, 3])) if mode != 2 else 1
+        reg = bool(rng.integers(0, 2)) and mode != 2
+        kw = dict(nvars=D - naug, naug=naug, ncond=C, hidden=hidden, act=int(rng.choice([1, 2])), mode=mode, nprobes=K,
+                  autonomous=bool(rng.integers(0, 4) == 0), reg_z=reg, reg_j=reg, reg_aug=reg and naug > 0)
+        spec = o64.make_spec(**kw)
+        alg, nsteps, B = int(rng.integers(0, 2)), int(rng.integers(1, 4)), int(rng.integers(1, 70))
+        p, xs, eps, ys = o64.synth_inputs(spec, B, 3000 + it, bias_scale=0.2)
+        a = run_inference(pkg, make_icnf(pkg, spec, alg, nsteps, path=3), spec, p, xs, eps, ys, return_state=True)
+        b = run_inference(pkg, make_icnf(pkg, spec, alg, nsteps, path=1), spec, p, xs, eps, ys, return_state=True)
+        assert float((a[0] - b[0]).abs().max()) < 1e-4, (kw, alg, nsteps, B)
+        assert float((a[2] - b[2]).abs().max()) < 1e-4, kw
+        for u, v in zip(a[1], b[1]):
+            assert float((u - v).abs().max()) < 1e-4, kw
+
+
+def test_auto_path_prefers_fused_then_layerwise(pkg, oracles):
+    """AUTO: fused MFMA instance when one covers the configuration, else the layer-wise GEMM path."""
+    o64, oc = oracles
+    fused = make_icnf(pkg, o64.make_spec(nvars=8, hidden=[64, 64, 64]), 0, 4, path=0)
+    assert fused.kernel_path(pkg.TrainMode(False)) == pkg._lib.PATH_MFMA
+    spec = o64.make_spec(nvars=8, hidden=[64, 64, 64, 64, 64, 64])            # six hidden layers: no fused instance
+    icnf = make_icnf(pkg, spec, 1, 3, path=0)
+    assert icnf.kernel_path(pkg.TrainMode(False)) == pkg._lib.PATH_LAYERED
+    B = 2500
+    p, xs, eps, _ = o64.synth_inputs(spec, B, 8, bias_scale=0.2)
+    big = run_inference(pkg, icnf, spec, p, xs, eps, None)[0].cpu().numpy()
+    small = run_inference(pkg, icnf, spec, p, xs[:, :100], eps[:, :100], None)[0].cpu().numpy()
+    ref = oc.inference_fixed(spec, p, xs, 0.0, 1.0, 3, 1, eps, None)[0]
+    assert np.max(np.abs(big - ref)) < TOL_SOLVE
+    assert np.max(np.abs(small - ref[:100])) < TOL_SOLVE
 
 
 def test_empty_batch_is_a_no_op(pkg, oracles):
