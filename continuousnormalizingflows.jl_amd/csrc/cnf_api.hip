@@ -556,9 +556,8 @@ int cnf_loss_grad_fixed(cnf_handle* h, int alg, int nsteps, float t0, float t1, 
     if (!x || !grad || !lambdas) return fail(CNF_ERR_INVALID, "cnf_loss_grad_fixed: null x/grad/lambdas");
     const bool fused = grad_is_fused(h) && h->grad_packed;
     if (!fused && !layered_grad_supported(h->cfg))
-        return fail(CNF_ERR_UNSUPPORTED, "cnf_loss_grad_fixed: the gradient is implemented for the Hutchinson VJP mode "
-                                         "(fused kernels: <= 8 probes, <= 16 conditions, 2-3 equal tanh/softplus hidden layers of "
-                                         "width <= 64, D <= 14; every other VJP configuration: layer-wise path)");
+        return fail(CNF_ERR_UNSUPPORTED, "cnf_loss_grad_fixed: the gradient is implemented for the Hutchinson modes (TrainMode); "
+                                         "the exact-trace mode is not a training mode");
     DeviceGuard g(h->cfg.device_id);
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(hipMemsetAsync(grad, 0, h->nparams * sizeof(float), st));

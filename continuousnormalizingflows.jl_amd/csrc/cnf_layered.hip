@@ -341,7 +341,9 @@ void layered_grad_destroy(LayeredGrad* g) {
     delete g;
 }
 
-bool layered_grad_supported(const cnf_config& c) { return c.mode == CNF_MODE_HUTCH_VJP && c.nprobes >= 1; }
+bool layered_grad_supported(const cnf_config& c) {
+    return (c.mode == CNF_MODE_HUTCH_VJP || c.mode == CNF_MODE_HUTCH_JVP) && c.nprobes >= 1;
+}
 
 #define LG_HIP(expr)                                                                    \
     do {                                                                                \
@@ -646,8 +648,35 @@ hipError_t layered_grad(LayeredGrad** ctx, const cnf_config& c, const float* P_d
             hipLaunchKernelGGL(kbar_kernel, grid_for(B), dim3(TPB), 0, st, kbar, lamv, zb, dt * T.b[i], dt, a[N], cl * lam[0], D, B);
 
             for (int k = 0; k < K; ++k) {
-                // pullback of probe k: v_N = eps_k, delta_l = v_l .* act'_l, v_{l-1} = W_l^T delta_l, g = W_1[:,0:D]^T delta_1
                 hipLaunchKernelGGL(copy_rows_kernel, grid_for(DB), dim3(TPB), 0, st, vN, eps, D, K * D, k * D, B);
+                if (c.mode == CNF_MODE_HUTCH_JVP) {
+                    // g = J eps_k by pushforward: r_l = W_l tau_{l-1} (tau_0 = eps on the z columns), tau_l = r_l .* act'_l;
+                    // reverse: rbar_l = taubar_l .* act'_l, acc2_l += taubar_l .* r_l, Wbar_l += rbar_l tau_{l-1}^T,
+                    // taubar_{l-1} = W_l^T rbar_l.  (r_l is kept in v[l], tau_l in dl[l].)
+                    for (int l = 0; l < N; ++l) {
+                        if (l == 0) LG_BLAS(gemm(OPN, OPN, L.wout[0], B, D, PA, L.wout[0], vN, D, v[0], L.wout[0]));
+                        else LG_BLAS(gemm(OPN, OPN, L.wout[l], B, L.win[l], PA + L.pa_off[l], L.wout[l], dl[l - 1], L.win[l], v[l], L.wout[l]));
+                        const long long HB = (long long)L.wout[l] * B;
+                        hipLaunchKernelGGL(mul_kernel, grid_for(HB), dim3(TPB), 0, st, dl[l], v[l], d[l], HB);
+                    }
+                    hipLaunchKernelGGL(gbar_kernel, grid_for(B), dim3(TPB), 0, st, gbar, dl[N - 1], vN, cl * invK, cl * lam[1] * invK, D, B);
+                    const float* tb = gbar;
+                    float *tbn = tdb, *tbn2 = tdb2;
+                    for (int l = N - 1; l >= 0; --l) {
+                        const long long HB = (long long)L.wout[l] * B;
+                        hipLaunchKernelGGL(bottom_kernel, grid_for(HB), dim3(TPB), 0, st, tb, d[l], v[l], tvb, acc2[l], k == 0 ? 1 : 0, HB);
+                        if (l > 0) {
+                            LG_BLAS(wgrad(l, tvb, L.wout[l], dl[l - 1], L.win[l], L.win[l]));
+                            LG_BLAS(gemm(OPT, OPN, L.win[l], B, L.wout[l], PA + L.pa_off[l], L.wout[l], tvb, L.wout[l], tbn, L.win[l]));
+                            tb = tbn;
+                            float* tmp = tbn; tbn = tbn2; tbn2 = tmp;
+                        } else {
+                            LG_BLAS(wgrad(0, tvb, L.wout[0], vN, D, D));   // Wbar_1[:,0:D] += rbar_1 eps_k^T
+                        }
+                    }
+                    continue;
+                }
+                // pullback of probe k: v_N = eps_k, delta_l = v_l .* act'_l, v_{l-1} = W_l^T delta_l, g = W_1[:,0:D]^T delta_1
                 for (int l = N - 1; l >= 0; --l) {
                     const float* vl = l == N - 1 ? vN : v[l];
                     const long long HB = (long long)L.wout[l] * B;

@@ -163,10 +163,11 @@ int cnf_loss_sums(cnf_handle* h, const float* logp, const float* regs, int64_t B
  * discrete solve.  grad: device, n floats in the layout of cnf_set_params' p (overwritten).
  * sums4 (device, may be NULL): as cnf_loss_sums.  The caller all-reduces grad and sums4 across
  * column shards and divides by the global column count.
- * Every Hutchinson-VJP configuration is covered.  Fused reverse-sweep kernels: 1 <= K <= 8 probes,
+ * Every Hutchinson (VJP or JVP) configuration is covered.  Fused reverse-sweep kernels: 1 <= K <= 8 probes,
  * <= 16 conditions, 2 or 3 equal hidden layers (tanh or softplus) of width <= 64, D + !autonomous <= 15;
  * every other shape (wide layers, more layers, unequal widths, mixed activations, larger D): layer-wise
- * reverse sweep on rocBLAS GEMMs.  FFJORD and RNODE losses.  JVP / exact modes: CNF_ERR_UNSUPPORTED. */
+ * reverse sweep on rocBLAS GEMMs, which also serves the Hutchinson JVP mode.  FFJORD and RNODE losses.
+ * Exact-trace mode (TestMode): CNF_ERR_UNSUPPORTED. */
 int cnf_loss_grad_fixed(cnf_handle* h, int alg, int nsteps, float t0, float t1, const float* x,
                         const float* eps, const float* ys, int64_t B, const float* lambdas,
                         float* grad, float* sums4, void* stream);

@@ -287,12 +287,12 @@ def synth_inputs(spec: Spec, B: int, seed: int, bias_scale: float = 0.0):
 # (src/core/icnf.jl:90-99; src/exts/mlj_ext/core_icnf.jl:42-51).  With a fixed-step solver the
 # exact gradient of the *discrete* loss is obtained by reverse-mode through the RK steps
 # (discretise-then-optimise); this fp64 autograd version is the oracle a future HIP backward
-# kernel will be checked against.  Hutchinson VJP mode only.
+# kernel will be checked against.  Hutchinson VJP and JVP modes.
 # ----------------------------------------------------------------------------------------
 def loss_and_grad(spec: Spec, p, xs, t0, t1, nsteps, alg, eps, ys=None, lambdas=(0.0, 0.0, 0.0)):
     """Returns (loss, dloss/dp) with p in the flat Lux layout, all in float64."""
     spec.check()
-    assert spec.mode == MODE_HUTCH_VJP, "gradient oracle: Hutchinson VJP mode"
+    assert spec.mode in (MODE_HUTCH_VJP, MODE_HUTCH_JVP), "gradient oracle: Hutchinson modes"
     D, K = spec.D, spec.nprobes
     pt = torch.tensor(np.asarray(p, dtype=np.float64), requires_grad=True)
     w_off, b_off, _ = spec.param_offsets()
@@ -315,7 +315,13 @@ def loss_and_grad(spec: Spec, p, xs, t0, t1, nsteps, alg, eps, ys=None, lambdas=
         ndot = torch.zeros(B, dtype=torch.float64)
         for k in range(K):
             ek = e[k * D:(k + 1) * D]
-            (g,) = torch.autograd.grad(zdot, z, ek, create_graph=True)
+            if spec.mode == MODE_HUTCH_VJP:
+                (g,) = torch.autograd.grad(zdot, z, ek, create_graph=True)          # eps^T J
+            else:
+                # J eps by the double-backward identity: v -> J^T v is linear, its derivative applied to eps is J eps
+                v = torch.zeros_like(zdot, requires_grad=True)
+                (jt,) = torch.autograd.grad(zdot, z, v, create_graph=True)
+                (g,) = torch.autograd.grad(jt, v, ek, create_graph=True)
             ldot = ldot - (g * ek).sum(0) / K
             if spec.reg_j:
                 ndot = ndot + torch.sqrt((g * g).sum(0)) / K

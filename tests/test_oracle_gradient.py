@@ -11,10 +11,10 @@ from conftest import GOLDEN
 import pytest
 
 
-@pytest.mark.parametrize("nprobes", [1, 3])
-def test_loss_gradient_matches_finite_differences(nprobes, oracles):
+@pytest.mark.parametrize("nprobes,mode", [(1, 0), (3, 0), (2, 1)])
+def test_loss_gradient_matches_finite_differences(nprobes, mode, oracles):
     o64, _ = oracles
-    spec = o64.make_spec(nvars=3, hidden=[8, 8], reg_z=True, reg_j=True, nprobes=nprobes)
+    spec = o64.make_spec(nvars=3, hidden=[8, 8], reg_z=True, reg_j=True, nprobes=nprobes, mode=mode)
     p, xs, eps, _ = o64.synth_inputs(spec, 5, 31, bias_scale=0.2)
     lam = (0.01, 0.02, 0.0)
     L, g = o64.loss_and_grad(spec, p, xs, 0.0, 1.0, 4, o64.ALG_RK4, eps, None, lam)

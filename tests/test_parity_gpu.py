@@ -445,13 +445,42 @@ def test_layerwise_gradient_agrees_with_the_fused_kernel(pkg, oracles, monkeypat
     assert torch.equal(g2, g2b)                                    # chunk slabs, fixed order: reproducible
 
 
-def test_parameter_gradient_is_refused_outside_the_vjp_mode(pkg, oracles):
+JVP_GRAD_SHAPES = [
+    # Hutchinson JVP mode (LuxJacVecMatrixMode): ldot = -<eps, J eps>/K, ndot = |J eps|/K
+    (dict(nvars=8, hidden=[64, 64, 64], mode=1), (0.0, 0.0, 0.0), 60, 1, 3),
+    (dict(nvars=8, hidden=[64, 64, 64], mode=1, reg_z=True, reg_j=True), (0.02, 0.05, 0.0), 60, 0, 3),
+    (dict(nvars=5, naug=2, ncond=4, hidden=[48, 96], act=2, mode=1, nprobes=2, reg_z=True, reg_j=True, reg_aug=True), (0.01, 0.03, 0.02), 41, 1, 2),
+    (dict(nvars=32, hidden=[256, 256, 256], mode=1, reg_j=True), (0.0, 0.04, 0.0), 24, 0, 2),
+]
+
+
+@pytest.mark.parametrize("kw,lam,B,alg,nsteps", JVP_GRAD_SHAPES)
+def test_parameter_gradient_in_jvp_mode(kw, lam, B, alg, nsteps, pkg, oracles):
+    """The gradient in Hutchinson JVP mode (layer-wise path: pushforward, its reverse, shared top-down
+    pass) against the fp64 autograd oracle."""
     o64, _ = oracles
-    spec = o64.make_spec(nvars=8, hidden=[64, 64, 64], mode=1)   # Hutchinson JVP: no gradient yet
-    p, xs, eps, _ = o64.synth_inputs(spec, 16, 1)
+    spec = o64.make_spec(**kw)
+    p, xs, eps, ys = o64.synth_inputs(spec, B, 321, bias_scale=0.2)
+    L, gref = o64.loss_and_grad(spec, p, xs, 0.0, 1.0, nsteps, alg, eps, ys, lam)
+    icnf = make_icnf(pkg, spec, alg, nsteps, path=0, lambdas=lam)
+    mode = pkg.TrainMode(bool(spec.reg_z or spec.reg_j or spec.reg_aug))
+    assert icnf.grad_path(mode) == 2
+    args = (dev(xs),) + ((dev(ys),) if spec.ncond else ()) + (dev(p), {})
+    val, g = pkg.loss_and_gradient(icnf, mode, *args, eps=dev(eps))
+    g = g.cpu().numpy().astype(np.float64)
+    assert abs(float(val) - L) < 1e-4
+    scale = np.abs(gref).max()
+    assert np.max(np.abs(g - gref)) < 5e-5 * scale + 1e-6, np.max(np.abs(g - gref)) / scale
+
+
+def test_parameter_gradient_is_refused_in_exact_trace_mode(pkg, oracles):
+    o64, _ = oracles
+    spec = o64.make_spec(nvars=8, hidden=[64, 64, 64], mode=2)   # TestMode (exact trace) is not a training mode
+    p, xs, _, _ = o64.synth_inputs(spec, 16, 1)
     icnf = make_icnf(pkg, spec, 1, 10, path=2, lambdas=(0.0, 0.0, 0.0))
+    assert icnf.grad_path(pkg.TestMode()) == 0
     with pytest.raises(pkg._lib.CnfError) as e:
-        pkg.loss_and_gradient(icnf, pkg.TrainMode(False), dev(xs), dev(p), {}, eps=dev(eps))
+        pkg.loss_and_gradient(icnf, pkg.TestMode(), dev(xs), dev(p), {})
     assert e.value.code == pkg._lib.ERR_UNSUPPORTED
 
 
