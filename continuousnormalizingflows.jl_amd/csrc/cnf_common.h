@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "cnf.h"
 
 namespace cnf {
@@ -97,5 +99,13 @@ __device__ __forceinline__ float act_fwd_rt(int act, float a, float& d) {
 }
 
 constexpr float kLog2Pi = 1.8378770664093453f;
+
+// "dynamic LDS above 64 KB enabled for this kernel" flag, one bit per device; host threads may race on
+// the first launch (the attribute call is idempotent, the flag updates are atomic)
+struct DeviceOnce {
+    std::atomic<unsigned long long> mask{0};
+    bool done(int dev) const { return (mask.load(std::memory_order_acquire) >> (dev & 63)) & 1ull; }
+    void set(int dev) { mask.fetch_or(1ull << (dev & 63), std::memory_order_release); }
+};
 
 }  // namespace cnf

@@ -324,14 +324,14 @@ static hipError_t launch_coop(const KArgs& a, int nblocks, hipStream_t st) {
     constexpr int DT = (ZR + 3) / 4;
     constexpr int lds = (2 * HT * 4 * 64 + 2 * DT * 4 * 64) * 16;
     auto kern = coop_vjp_solve_kernel<HT, L, ZR, ACT, NS>;
-    static unsigned long long done_mask = 0;
+    static DeviceOnce once;
     int dev = 0;
     hipError_t e0 = hipGetDevice(&dev);
     if (e0 != hipSuccess) return e0;
-    if (!(done_mask >> (dev & 63) & 1ull)) {
+    if (!once.done(dev)) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return e;
-        done_mask |= 1ull << (dev & 63);
+        once.set(dev);
     }
     hipLaunchKernelGGL(kern, dim3(nblocks), dim3(256), lds, st, a);
     return hipGetLastError();

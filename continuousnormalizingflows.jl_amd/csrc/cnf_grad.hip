@@ -485,7 +485,7 @@ hipError_t grad_launch(const cnf_config& c, const float* packed_dev, const float
     const GradInst* gi = grad_find(c);
     if (!gi) return hipErrorNotSupported;
     // > 64 KB of dynamic LDS has to be enabled once per device and kernel
-    static unsigned long long done_mask[sizeof(kGrad) / sizeof(kGrad[0])] = {};
+    static DeviceOnce done_mask[sizeof(kGrad) / sizeof(kGrad[0])];
     const int idx = (int)(gi - kGrad);
     int dev = 0;
     hipError_t e0 = hipGetDevice(&dev);
@@ -496,12 +496,12 @@ hipError_t grad_launch(const cnf_config& c, const float* packed_dev, const float
         kern = grad_probes_kernel(gi->HT, gi->L, gi->ZR, gi->CR, gi->ACT);
         if (!kern || !ckpt_k) return hipErrorNotSupported;
     }
-    static unsigned long long done_probes[sizeof(kGrad) / sizeof(kGrad[0])] = {};
-    unsigned long long& done = (c.nprobes > 1 ? done_probes : done_mask)[idx];
-    if (!(done >> (dev & 63) & 1ull)) {
+    static DeviceOnce done_probes[sizeof(kGrad) / sizeof(kGrad[0])];
+    DeviceOnce& done = (c.nprobes > 1 ? done_probes : done_mask)[idx];
+    if (!done.done(dev)) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, gi->lds_bytes);
         if (e != hipSuccess) return e;
-        done |= 1ull << (dev & 63);
+        done.set(dev);
     }
     GArgs a{};
     a.packed = packed_dev; a.ckpt = ckpt; a.ckpt_k = ckpt_k; a.ckpt_zr = ckpt_zr; a.eps = eps; a.K = c.nprobes; a.ys = ys; a.C = c.ncond; a.slab = slab; a.B = B;

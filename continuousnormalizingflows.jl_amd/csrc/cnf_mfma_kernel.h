@@ -500,14 +500,14 @@ template <int HT, int L, int ZR, int CR, int ACT, int ENGINE, int KP, int PRE, i
 inline hipError_t launch_inst(const KArgs& a, int lds_bytes, int nblocks, hipStream_t st) {
     auto kern = mfma_solve_kernel<HT, L, ZR, CR, ACT, ENGINE, KP, PRE, NTHREADS, ARITH>;
     // > 64 KB of dynamic LDS has to be enabled once per device for this kernel
-    static unsigned long long done_mask = 0;
+    static DeviceOnce once;
     int dev = 0;
     hipError_t e0 = hipGetDevice(&dev);
     if (e0 != hipSuccess) return e0;
-    if (!(done_mask >> (dev & 63) & 1ull)) {
+    if (!once.done(dev)) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (e != hipSuccess) return e;
-        done_mask |= 1ull << (dev & 63);
+        once.set(dev);
     }
     hipLaunchKernelGGL(kern, dim3(nblocks), dim3(NTHREADS), lds_bytes, st, a);
     return hipGetLastError();
