@@ -820,6 +820,35 @@ def test_planar_layer_net_matches_the_equivalent_dense_chain(use_bias, condition
     assert samples.shape == (nv, B) and bool(torch.isfinite(samples).all())
 
 
+@pytest.mark.parametrize("mode", ["infer", "grad"])
+def test_bench_contract_with_two_ranks_on_one_gpu(mode):
+    """The N > 1 path of bench.py end to end, as the driver launches it (torch.distributed.run, one process
+    per rank, barrier + max-over-ranks timing, one JSON line from rank 0) — here two ranks sharing the one
+    GPU with the gloo backend, since RCCL refuses two ranks on one device.  Checks the contract fields
+    and that the job-wide loss is the mean over both ranks' different column blocks."""
+    import json, os, socket, subprocess, sys
+    from conftest import ROOT
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--backend", "gloo", "--no-cpu-baseline", "--batch", "4096", "--mode", mode]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["warmup"] == 1 and out["scaling"] == "weak"
+    assert out["config"]["global_columns"] == 2 * 4096 and out["config"]["columns_per_gpu"] == 4096
+    assert out["value"] > 0 and abs(out["value"] - 2 * 4096 * 40 * 2 / (out["ms_per_step"] * 2e-3)) < 1e-6 * out["value"]
+    single = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--no-cpu-baseline",
+                             "--batch", "4096", "--mode", mode], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    one = json.loads([l for l in single.stdout.splitlines() if l.startswith("{")][0])
+    # rank 0's block is the single-process block; the two-rank mean differs from it (rank 1 holds other columns)
+    assert abs(out["loss"] - one["loss"]) > 1e-6 and abs(out["loss"] - one["loss"]) < 0.5
+
+
 def test_errors_surface_as_exceptions(pkg, oracles):
     o64, _ = oracles
     spec = o64.make_spec(nvars=8, hidden=[64, 64, 64])
