@@ -10,3 +10,5 @@ from .icnf import *  # noqa: F401,F403
 from .icnf import loss_sums  # noqa: F401
 from .icnf import loss_and_gradient  # noqa: F401
 from .sharding import reduce_gradient, reduce_loss, shard_columns  # noqa: F401
+from .adapters import *  # noqa: F401,F403
+from .adapters import epoch_batches  # noqa: F401

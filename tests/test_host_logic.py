@@ -99,3 +99,24 @@ def test_planar_layer_maps_onto_a_dense_chain(pkg):
     assert ps.shape == (12,) and float(ps[11]) == 0.0
     with pytest.raises(TypeError, match="MethodError"):
         pkg.Chain(pkg.PlanarLayer(6, 5), pkg.Dense(5, 5))
+
+
+def test_epoch_batches_follow_the_dataloader_contract(pkg):
+    """MLUtils.DataLoader(...; shuffle = true, partial = true): every column once per epoch, batches of
+    `batchsize` with a shorter last one, batchsize 0 = one full batch, new order each epoch."""
+    import torch
+    g = torch.Generator().manual_seed(0)
+    b1 = list(pkg.epoch_batches(10, 4, g))
+    assert [len(b) for b in b1] == [4, 4, 2]
+    assert sorted(torch.cat(b1).tolist()) == list(range(10))
+    b2 = list(pkg.epoch_batches(10, 4, g))
+    assert torch.cat(b1).tolist() != torch.cat(b2).tolist()
+    full = list(pkg.epoch_batches(7, 0, g))
+    assert len(full) == 1 and sorted(full[0].tolist()) == list(range(7))
+
+
+def test_opt_callback_prints_like_the_reference(pkg, capsys):
+    cb = pkg.make_opt_callback(64)
+    assert cb(1, 3.5) is False and cb(2, 3.0) is False and cb(65, 2.5) is False
+    out = capsys.readouterr().out.splitlines()
+    assert out == ["Iteration: 1 | Loss: 3.5", "Iteration: 65 | Loss: 2.5"]

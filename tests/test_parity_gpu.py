@@ -849,6 +849,63 @@ def test_bench_contract_with_two_ranks_on_one_gpu(mode):
     assert abs(out["loss"] - one["loss"]) > 1e-6 and abs(out["loss"] - one["loss"]) < 0.5
 
 
+def _fit_icnf(pkg, nvars, ncond=0, naug=0):
+    return pkg.ICNF(nvariables=nvars, naugments=naug, nconditions=ncond, steer_rate=0.0, lambda1=0.0, lambda2=0.0, lambda3=0.0,
+                    device="cuda:0", sol_kwargs=dict(alg=pkg.Tsit5(), adaptive=False, nsteps=8))
+
+
+def test_mlj_style_fit_transform_and_distribution_wrapper(pkg):
+    """ICNFModel.fit (shuffled mini-batches, WeightDecay + Adam on loss(TrainMode{true}), every step one
+    loss_and_gradient call) learns a shifted, scaled 1-D Gaussian; transform returns densities; the
+    ICNFDist wrapper's pdf integrates to 1 in TestMode (exact trace: a CNF is a normalised density) and its
+    samples have the data's moments (src/exts/mlj_ext/core_icnf.jl, src/exts/dist_ext/core_icnf.jl)."""
+    g = torch.Generator().manual_seed(5)
+    X = 2.0 + 0.5 * torch.randn(4096, 1, generator=g)
+    icnf = _fit_icnf(pkg, 1)
+    seen = []
+    model = pkg.ICNFModel(icnf=icnf, batchsize=1024, epochs=60, eta=5e-3, callback=lambda it, l: seen.append(l) or False,
+                          shuffle_rng=torch.Generator().manual_seed(1))
+    fitresult, cache, report = model.fit(X)
+    assert cache is None and report["stats"]["iterations"] == 60 * 4 == len(seen)
+    entropy = 0.5 * np.log(2 * np.pi * np.e * 0.25)                      # NLL of the true density: 0.726
+    assert seen[0] > 2.0 and np.mean(seen[-8:]) < entropy + 0.08, (seen[0], np.mean(seen[-8:]))
+    px = model.transform(fitresult, X[:100])
+    assert list(px.columns) == ["px"] and len(px) == 100 and (px["px"] > 0).all()
+    d = pkg.ICNFDist.from_fit(model, fitresult, pkg.TestMode())
+    assert len(d) == 1
+    grid = torch.linspace(-2.0, 6.0, 4001)[None, :]
+    p = d.pdf(grid).double().cpu()
+    integral = float(torch.trapezoid(p, grid[0].double()))
+    assert abs(integral - 1.0) < 2e-3, integral
+    assert abs(float(d.logpdf(torch.tensor([2.0]))) - float(d.logpdf(torch.tensor([[2.0]]))[0])) < 1e-6
+    s = d.rand(20000)
+    assert s.shape == (1, 20000) and d.rand().shape == (1,)
+    assert abs(float(s.mean()) - 2.0) < 0.05 and abs(float(s.std()) - 0.5) < 0.05
+    assert set(model.fitted_params(fitresult)) == {"learned_parameters", "states"}
+
+
+def test_conditioned_fit_and_distribution_wrapper(pkg):
+    """CondICNFModel: x | y ~ N(y, 0.3^2); after a short fit the conditional density peaks near y, and
+    CondICNFDist uses the first n condition columns for n points (src/exts/dist_ext/core_cond_icnf.jl:45)."""
+    g = torch.Generator().manual_seed(6)
+    Y = torch.rand(4096, 1, generator=g) * 4 - 2
+    X = Y + 0.3 * torch.randn(4096, 1, generator=g)
+    icnf = _fit_icnf(pkg, 1, ncond=1)
+    model = pkg.CondICNFModel(icnf=icnf, batchsize=0, epochs=150, eta=5e-3, callback=None)
+    fitresult, _, report = model.fit((X, Y))
+    assert report["stats"]["iterations"] == 150                            # batchsize 0 = full batch
+    px = model.transform(fitresult, (X[:64], Y[:64]))
+    assert (px["px"] > 0).all()
+    ys = torch.tensor([[-1.0, 1.0]])
+    d = pkg.CondICNFDist.from_fit(model, fitresult, pkg.TestMode(), ys)
+    at_own = d.logpdf(torch.tensor([[-1.0, 1.0]]))                         # x = y for both columns
+    swapped = d.logpdf(torch.tensor([[1.0, -1.0]]))                        # x = -y
+    assert float(at_own.min()) > float(swapped.max()) + 2.0, (at_own, swapped)
+    assert d.rand(2).shape == (1, 2)
+    with pytest.raises(IndexError):
+        d.logpdf(torch.zeros(1, 3))
+
+
 def test_errors_surface_as_exceptions(pkg, oracles):
     o64, _ = oracles
     spec = o64.make_spec(nvars=8, hidden=[64, 64, 64])
