@@ -83,7 +83,7 @@ def load():
                                         C.c_int64, fp, fp, fp, vp]
     lib.cnf_loss_sums.argtypes = [vp, fp, fp, C.c_int64, fp, vp]
     lib.cnf_loss_grad_fixed.argtypes = [vp, C.c_int, C.c_int, C.c_float, C.c_float, fp, fp, fp, C.c_int64,
-                                        C.POINTER(C.c_float), fp, fp, vp]
+                                        C.POINTER(C.c_float), fp, fp, fp, vp]
     for name in EXPORTS:
         getattr(lib, name)  # AttributeError if the ABI is incomplete
     _lib = lib

@@ -74,6 +74,7 @@ class _MLJICNF:
     beta: Tuple[float, float] = (0.9, 0.999)
     epsilon: float = 1.0e-8
     shuffle_rng: Optional[torch.Generator] = None
+    init_rng: Optional[torch.Generator] = None   # CPU generator for the initial parameters (LuxCore.setup(icnf.rng, icnf))
 
     _conditioned = False
 
@@ -83,7 +84,7 @@ class _MLJICNF:
             raise TypeError("MethodError: ICNFModel needs an unconditioned flow, CondICNFModel a conditioned one")
         if self.loss is not None and self.loss is not _icnf.loss:
             raise NotImplementedError("a custom loss has no gradient kernel; fit optimises the package's `loss`")
-        ps, st = _icnf.setup(None, ic)
+        ps, st = _icnf.setup(self.init_rng, ic)
         ps = ps.to(ic.device)
         # Optimisers.OptimiserChain(WeightDecay(lambda), Adam(eta, beta, epsilon)): the decay term lambda * p is
         # added to the gradient before Adam sees it = torch's (non-decoupled) Adam weight_decay

@@ -548,7 +548,7 @@ int cnf_grad_path(const cnf_handle* h) {
 
 int cnf_loss_grad_fixed(cnf_handle* h, int alg, int nsteps, float t0, float t1, const float* x,
                         const float* eps, const float* ys, int64_t B, const float* lambdas,
-                        float* grad, float* sums4, void* stream) {
+                        float* grad, float* grad_x, float* sums4, void* stream) {
     int rc = check_call(h, eps, ys, B, "cnf_loss_grad_fixed");
     if (rc) return rc;
     if (nsteps < 1) return fail(CNF_ERR_INVALID, "cnf_loss_grad_fixed: nsteps >= 1 required");
@@ -586,7 +586,7 @@ int cnf_loss_grad_fixed(cnf_handle* h, int alg, int nsteps, float t0, float t1, 
         const float lam[3] = {h->cfg.reg_z ? lambdas[0] : 0.f, h->cfg.reg_j ? lambdas[1] : 0.f, ra ? lambdas[2] : 0.f};
         std::string msg;
         hipError_t e = layered_grad(&h->layered, h->cfg, h->P_dev, h->w_off.data(), h->b_off.data(), x, eps, ys, alg, nsteps,
-                                    t0, t1, B, lam, grad, st, &msg);
+                                    t0, t1, B, lam, grad, grad_x, st, &msg);
         if (e == hipErrorNotSupported) return fail(CNF_ERR_UNSUPPORTED, "cnf_loss_grad_fixed: " + msg);
         if (e != hipSuccess) return fail(CNF_ERR_HIP, "cnf_loss_grad_fixed: " + msg);
         return CNF_OK;
@@ -626,7 +626,7 @@ int cnf_loss_grad_fixed(cnf_handle* h, int alg, int nsteps, float t0, float t1, 
     }
     const float lam[3] = {h->cfg.reg_z ? lambdas[0] : 0.f, h->cfg.reg_j ? lambdas[1] : 0.f, reg_aug ? lambdas[2] : 0.f};
     HIP_TRY(grad_launch(h->cfg, h->grad_packed, ckpt, ckpt_k, ckpt_zr, eps, ys, h->w_off.data(), h->b_off.data(), alg, nsteps, t0, t1,
-                        B, lam, slab, grad, h->num_cus, st));
+                        B, lam, slab, grad, grad_x, h->num_cus, st));
     return CNF_OK;
 }
 

@@ -371,6 +371,13 @@ mfma_grad_kernel(GArgs a) {
                 lam[s] = acc;
             }
         }
+        if (a.grad_x && valid) {   // costate at t0 = dL/dz_0; its first nvars rows are dL/dx
+#pragma unroll
+            for (int s = 0; s < ZR; ++s) {
+                const int f = 4 * s + g;
+                if (f < a.nvars) a.grad_x[smp * a.nvars + f] = lam[s];
+            }
+        }
     }
     // every wave deposits the tiles it owns in its own (zeroed) slab; grad_reduce_kernel sums the slabs
     if (wave < HT) {
@@ -481,7 +488,7 @@ void grad_shape(const cnf_config& c, int* HT, int* L, int* ZR, int* CR) {
 hipError_t grad_launch(const cnf_config& c, const float* packed_dev, const float* ckpt, const float* ckpt_k,
                        int ckpt_zr, const float* eps, const float* ys,
                        const size_t* w_off, const size_t* b_off, int alg, int nsteps, float t0, float t1,
-                       long long B, const float lam[3], float* slab, float* grad, int num_cus, hipStream_t st) {
+                       long long B, const float lam[3], float* slab, float* grad, float* grad_x, int num_cus, hipStream_t st) {
     const GradInst* gi = grad_find(c);
     if (!gi) return hipErrorNotSupported;
     // > 64 KB of dynamic LDS has to be enabled once per device and kernel
@@ -504,7 +511,7 @@ hipError_t grad_launch(const cnf_config& c, const float* packed_dev, const float
         done.set(dev);
     }
     GArgs a{};
-    a.packed = packed_dev; a.ckpt = ckpt; a.ckpt_k = ckpt_k; a.ckpt_zr = ckpt_zr; a.eps = eps; a.K = c.nprobes; a.ys = ys; a.C = c.ncond; a.slab = slab; a.B = B;
+    a.packed = packed_dev; a.ckpt = ckpt; a.ckpt_k = ckpt_k; a.ckpt_zr = ckpt_zr; a.eps = eps; a.K = c.nprobes; a.ys = ys; a.C = c.ncond; a.slab = slab; a.grad_x = grad_x; a.B = B;
     a.nsteps = nsteps; a.t0 = t0; a.dt = (t1 - t0) / (float)nsteps;
     a.D = c.nvars + c.naug; a.H = c.widths[1]; a.n_in = c.widths[0]; a.autonomous = c.autonomous; a.nvars = c.nvars;
     a.lam1 = lam[0]; a.lam2 = lam[1]; a.lam3 = lam[2];

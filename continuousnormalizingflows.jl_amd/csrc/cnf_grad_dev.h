@@ -16,6 +16,7 @@ struct GArgs {
     const float* ys;       // C x B or null
     int C;
     float* slab;           // [waves][GradSlab::TOTAL] floats, zeroed by the host
+    float* grad_x;         // optional: dL/dx (nvars x B) = rows 0..nvars-1 of the costate at t0, or null
     long long B;
     int nsteps;
     float t0, dt;

@@ -353,6 +353,13 @@ mfma_grad_probes_kernel(GArgs a) {
                 lam[s] = acc;
             }
         }
+        if (a.grad_x && valid) {   // costate at t0 = dL/dz_0; its first nvars rows are dL/dx
+#pragma unroll
+            for (int s = 0; s < ZR; ++s) {
+                const int f = 4 * s + g;
+                if (f < a.nvars) a.grad_x[smp * a.nvars + f] = lam[s];
+            }
+        }
     }
     if (wave < HT) {
 #pragma unroll

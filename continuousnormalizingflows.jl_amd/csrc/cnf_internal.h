@@ -79,7 +79,7 @@ void grad_pack(const cnf_config& c, const float* lux, const size_t* w_off, const
 hipError_t grad_launch(const cnf_config& c, const float* packed_dev, const float* ckpt, const float* ckpt_k,
                        int ckpt_zr, const float* eps, const float* ys,
                        const size_t* w_off, const size_t* b_off, int alg, int nsteps, float t0, float t1,
-                       long long B, const float lam[3], float* slab, float* grad, int num_cus, hipStream_t st);
+                       long long B, const float lam[3], float* slab, float* grad, float* grad_x, int num_cus, hipStream_t st);
 // layer-wise gradient on rocBLAS GEMMs for everything the fused kernels do not cover (cnf_layered.hip)
 struct LayeredGrad;
 bool layered_available();   // librocblas.so.5 loadable
@@ -90,7 +90,7 @@ bool layered_grad_supported(const cnf_config& c);
 void layered_grad_destroy(LayeredGrad* g);
 hipError_t layered_grad(LayeredGrad** ctx, const cnf_config& c, const float* P_dev, const size_t* w_off,
                         const size_t* b_off, const float* x, const float* eps, const float* ys, int alg,
-                        int nsteps, float t0, float t1, long long B, const float lam[3], float* grad,
+                        int nsteps, float t0, float t1, long long B, const float lam[3], float* grad, float* grad_x,
                         hipStream_t st, std::string* err);
 int mfma_plan_zr(const MfmaPlan* p);   // state k-steps of the forward instance (checkpoint stride)
 bool mfma_plan_is_per_wave(const MfmaPlan* p);

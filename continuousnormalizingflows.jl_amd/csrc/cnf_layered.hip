@@ -482,7 +482,7 @@ hipError_t layered_aug_f(LayeredGrad** ctx, const cnf_config& c, const float* P_
 
 hipError_t layered_grad(LayeredGrad** ctx, const cnf_config& c, const float* P_dev, const size_t* w_off,
                         const size_t* b_off, const float* x, const float* eps, const float* ys, int alg,
-                        int nsteps, float t0, float t1, long long B, const float lam[3], float* grad,
+                        int nsteps, float t0, float t1, long long B, const float lam[3], float* grad, float* grad_x,
                         hipStream_t st, std::string* err) {
     Blas& bl = blas();
     if (!bl.ok) {
@@ -722,6 +722,8 @@ hipError_t layered_grad(LayeredGrad** ctx, const cnf_config& c, const float* P_d
         hipLaunchKernelGGL(combine_kernel, grid_for(DB), dim3(TPB), 0, st, lamv, lamv, cb, DB);
     }
     hipLaunchKernelGGL(reduce_slabs_kernel, grid_for(npa), dim3(TPB), 0, st, slabs, nslab, npa_pad, L, grad);
+    if (grad_x)   // costate at t0: dL/dx = its first nvars rows
+        hipLaunchKernelGGL(copy_rows_kernel, grid_for((long long)c.nvars * B), dim3(TPB), 0, st, grad_x, lamv, c.nvars, D, 0, B);
     LG_HIP(hipGetLastError());
     return hipSuccess;
 }

@@ -572,12 +572,15 @@ def loss(icnf: ICNF, mode: Mode, *args, eps: Optional[torch.Tensor] = None, grou
     return reduce_loss(sums, logp.numel(), (icnf.lambda1, icnf.lambda2, icnf.lambda3), group=group)
 
 
-def loss_and_gradient(icnf: ICNF, mode: Mode, *args, eps: Optional[torch.Tensor] = None, group=None):
+def loss_and_gradient(icnf: ICNF, mode: Mode, *args, eps: Optional[torch.Tensor] = None, group=None,
+                      wrt_x: bool = False):
     """(loss, dloss/dps) for `loss(icnf, mode, xs, ps, st)` — what `Zygote.gradient` of the
     reference's training objective returns (src/exts/mlj_ext/core_icnf.jl:42-51), here the exact
     gradient of the discrete fixed-step loss, computed by the reverse-sweep HIP kernel.  With
     torch.distributed initialised the column shards' gradients (nparams floats) and loss sums are
-    all-reduced (RCCL over xGMI) and every rank returns the global mean and its gradient."""
+    all-reduced (RCCL over xGMI) and every rank returns the global mean and its gradient.
+    `wrt_x=True` also returns dloss/dxs, (nvariables, B) for this rank's columns (`DI.gradient` with respect
+    to the data in test/ci_tests/smoke_tests.jl): the costate at t0, a by-product of the same sweep."""
     from .sharding import reduce_gradient, reduce_loss
     xs, ys, ps, st = _split_args(icnf, args, "loss_and_gradient")
     if icnf.nn.planar is not None:
@@ -591,9 +594,19 @@ def loss_and_gradient(icnf: ICNF, mode: Mode, *args, eps: Optional[torch.Tensor]
     e = _draw_eps(icnf, icnf.nprobes, B) if eps is None else _colmajor(eps, icnf.nprobes * icnf.D, "eps", dev)
     t0, t1 = icnf._steer_tspan(mode)
     grad = torch.empty(ps.numel(), device=dev, dtype=torch.float32)
+    gx = torch.zeros(B, icnf.nvariables, device=dev, dtype=torch.float32) if wrt_x else None
     sums = torch.empty(4, device=dev, dtype=torch.float32)
     lam = (C.c_float * 3)(icnf.lambda1, icnf.lambda2, icnf.lambda3)
     _lib.check(h.lib.cnf_loss_grad_fixed(h.ptr, icnf._solver(), icnf._nsteps(t0, t1), t0, t1, _ptr(x), _ptr(e),
-                                         _ptr(y), B, lam, _ptr(grad), _ptr(sums), _stream_ptr(dev)))
+                                         _ptr(y), B, lam, _ptr(grad), _ptr(gx), _ptr(sums), _stream_ptr(dev)))
     value = reduce_loss(sums, B, (icnf.lambda1, icnf.lambda2, icnf.lambda3), group=group)
-    return value, reduce_gradient(grad, B, group=group)
+    gps = reduce_gradient(grad, B, group=group)
+    if not wrt_x:
+        return value, gps
+    import torch.distributed as dist
+    Bg = B
+    if dist.is_available() and dist.is_initialized():
+        n = torch.tensor([B], dtype=torch.int64, device=dev if dist.get_backend(group) == "nccl" else "cpu")
+        dist.all_reduce(n, group=group)
+        Bg = int(n.item())
+    return value, gps, (gx / Bg).t()

@@ -161,6 +161,8 @@ int cnf_loss_sums(cnf_handle* h, const float* logp, const float* regs, int64_t B
  * the quantity Zygote obtains for `loss` via QuadratureAdjoint + ZygoteVJP in the reference's
  * training loop (src/core/icnf.jl:90-99; src/exts/mlj_ext/core_icnf.jl:42-51), here exact for the
  * discrete solve.  grad: device, n floats in the layout of cnf_set_params' p (overwritten).
+ * grad_x (device, may be NULL): nvars x B, the gradient of the same sum with respect to the data columns
+ * (DI.gradient wrt x in test/ci_tests/smoke_tests.jl) - the costate at t0, free in the reverse sweep.
  * sums4 (device, may be NULL): as cnf_loss_sums.  The caller all-reduces grad and sums4 across
  * column shards and divides by the global column count.
  * Every Hutchinson (VJP or JVP) configuration is covered.  Fused reverse-sweep kernels: 1 <= K <= 8 probes,
@@ -170,7 +172,7 @@ int cnf_loss_sums(cnf_handle* h, const float* logp, const float* regs, int64_t B
  * Exact-trace mode (TestMode): CNF_ERR_UNSUPPORTED. */
 int cnf_loss_grad_fixed(cnf_handle* h, int alg, int nsteps, float t0, float t1, const float* x,
                         const float* eps, const float* ys, int64_t B, const float* lambdas,
-                        float* grad, float* sums4, void* stream);
+                        float* grad, float* grad_x, float* sums4, void* stream);
 
 /* Which implementation cnf_loss_grad_fixed uses for this handle: 0 = none (CNF_ERR_UNSUPPORTED),
  * 1 = fused reverse-sweep kernel (cnf_grad.hip / cnf_grad_probes.hip), 2 = layer-wise reverse sweep on

@@ -289,8 +289,8 @@ def synth_inputs(spec: Spec, B: int, seed: int, bias_scale: float = 0.0):
 # (discretise-then-optimise); this fp64 autograd version is the oracle a future HIP backward
 # kernel will be checked against.  Hutchinson VJP and JVP modes.
 # ----------------------------------------------------------------------------------------
-def loss_and_grad(spec: Spec, p, xs, t0, t1, nsteps, alg, eps, ys=None, lambdas=(0.0, 0.0, 0.0)):
-    """Returns (loss, dloss/dp) with p in the flat Lux layout, all in float64."""
+def loss_and_grad(spec: Spec, p, xs, t0, t1, nsteps, alg, eps, ys=None, lambdas=(0.0, 0.0, 0.0), wrt_x=False):
+    """Returns (loss, dloss/dp) with p in the flat Lux layout, all in float64; with wrt_x also dloss/dxs."""
     spec.check()
     assert spec.mode in (MODE_HUTCH_VJP, MODE_HUTCH_JVP), "gradient oracle: Hutchinson modes"
     D, K = spec.D, spec.nprobes
@@ -301,7 +301,7 @@ def loss_and_grad(spec: Spec, p, xs, t0, t1, nsteps, alg, eps, ys=None, lambdas=
         fin, fout = spec.widths[l], spec.widths[l + 1]
         W = pt[w_off[l]:w_off[l] + fin * fout].reshape(fin, fout).t()
         layers.append((W, pt[b_off[l]:b_off[l] + fout]))
-    x = torch.tensor(np.asarray(xs, dtype=np.float64))
+    x = torch.tensor(np.asarray(xs, dtype=np.float64), requires_grad=bool(wrt_x))
     B = x.shape[1]
     e = torch.tensor(np.asarray(eps, dtype=np.float64))
     yt = None if ys is None else torch.tensor(np.asarray(ys, dtype=np.float64))
@@ -347,5 +347,8 @@ def loss_and_grad(spec: Spec, p, xs, t0, t1, nsteps, alg, eps, ys=None, lambdas=
     A = torch.sqrt((z[spec.nvars:] ** 2).sum(0)) if (spec.reg_aug and spec.naug > 0) \
         else torch.zeros(B, dtype=torch.float64)
     L = (-logp + lambdas[0] * u[D + 1] + lambdas[1] * u[D + 2] + lambdas[2] * A).mean()
+    if wrt_x:
+        gp, gx = torch.autograd.grad(L, (pt, x))
+        return float(L.detach()), gp.detach().numpy(), gx.detach().numpy()
     (gp,) = torch.autograd.grad(L, pt)
     return float(L.detach()), gp.detach().numpy()

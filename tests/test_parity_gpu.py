@@ -473,6 +473,31 @@ def test_parameter_gradient_in_jvp_mode(kw, lam, B, alg, nsteps, pkg, oracles):
     assert np.max(np.abs(g - gref)) < 5e-5 * scale + 1e-6, np.max(np.abs(g - gref)) / scale
 
 
+@pytest.mark.parametrize("kw,lam", [
+    (dict(nvars=8, hidden=[64, 64, 64]), (0.0, 0.0, 0.0)),                                                  # fused kernel, one probe
+    (dict(nvars=6, naug=2, hidden=[64, 64, 64], nprobes=3, reg_z=True, reg_j=True, reg_aug=True), (0.02, 0.03, 0.01)),   # fused probes kernel, augmented
+    (dict(nvars=5, ncond=3, hidden=[32, 48, 32, 16], act=2, reg_z=True), (0.02, 0.0, 0.0)),                 # layer-wise path
+    (dict(nvars=4, hidden=[40, 40], mode=1, reg_j=True), (0.0, 0.04, 0.0)),                                 # layer-wise path, JVP mode
+])
+def test_gradient_with_respect_to_the_data(kw, lam, pkg, oracles):
+    """dloss/dxs (DI.gradient wrt x in the reference's smoke tests): the costate at t0, written by the same
+    reverse sweep — all four gradient implementations against fp64 autograd, ragged batch."""
+    o64, _ = oracles
+    spec = o64.make_spec(**kw)
+    B = 37
+    p, xs, eps, ys = o64.synth_inputs(spec, B, 55, bias_scale=0.2)
+    L, gref, gxref = o64.loss_and_grad(spec, p, xs, 0.0, 1.0, 3, 1, eps, ys, lam, wrt_x=True)
+    icnf = make_icnf(pkg, spec, 1, 3, path=0, lambdas=lam)
+    mode = pkg.TrainMode(bool(spec.reg_z or spec.reg_j or spec.reg_aug))
+    args = (dev(xs),) + ((dev(ys),) if spec.ncond else ()) + (dev(p), {})
+    val, g, gx = pkg.loss_and_gradient(icnf, mode, *args, eps=dev(eps), wrt_x=True)
+    assert gx.shape == (spec.nvars, B)
+    assert abs(float(val) - L) < 1e-4
+    assert np.max(np.abs(g.cpu().numpy() - gref)) < 5e-5 * np.abs(gref).max() + 1e-6
+    sx = np.abs(gxref).max()
+    assert np.max(np.abs(gx.cpu().numpy().astype(np.float64) - gxref)) < 5e-5 * sx + 1e-7, np.max(np.abs(gx.cpu().numpy() - gxref)) / sx
+
+
 def test_parameter_gradient_is_refused_in_exact_trace_mode(pkg, oracles):
     o64, _ = oracles
     spec = o64.make_spec(nvars=8, hidden=[64, 64, 64], mode=2)   # TestMode (exact trace) is not a training mode
@@ -864,11 +889,11 @@ def test_mlj_style_fit_transform_and_distribution_wrapper(pkg):
     icnf = _fit_icnf(pkg, 1)
     seen = []
     model = pkg.ICNFModel(icnf=icnf, batchsize=1024, epochs=60, eta=5e-3, callback=lambda it, l: seen.append(l) or False,
-                          shuffle_rng=torch.Generator().manual_seed(1))
+                          shuffle_rng=torch.Generator().manual_seed(1), init_rng=torch.Generator().manual_seed(2))
     fitresult, cache, report = model.fit(X)
     assert cache is None and report["stats"]["iterations"] == 60 * 4 == len(seen)
     entropy = 0.5 * np.log(2 * np.pi * np.e * 0.25)                      # NLL of the true density: 0.726
-    assert seen[0] > 2.0 and np.mean(seen[-8:]) < entropy + 0.08, (seen[0], np.mean(seen[-8:]))
+    assert seen[0] > np.mean(seen[-8:]) + 0.3 and np.mean(seen[-8:]) < entropy + 0.08, (seen[0], np.mean(seen[-8:]))
     px = model.transform(fitresult, X[:100])
     assert list(px.columns) == ["px"] and len(px) == 100 and (px["px"] > 0).all()
     d = pkg.ICNFDist.from_fit(model, fitresult, pkg.TestMode())
@@ -891,7 +916,7 @@ def test_conditioned_fit_and_distribution_wrapper(pkg):
     Y = torch.rand(4096, 1, generator=g) * 4 - 2
     X = Y + 0.3 * torch.randn(4096, 1, generator=g)
     icnf = _fit_icnf(pkg, 1, ncond=1)
-    model = pkg.CondICNFModel(icnf=icnf, batchsize=0, epochs=150, eta=5e-3, callback=None)
+    model = pkg.CondICNFModel(icnf=icnf, batchsize=0, epochs=150, eta=5e-3, callback=None, init_rng=torch.Generator().manual_seed(3))
     fitresult, _, report = model.fit((X, Y))
     assert report["stats"]["iterations"] == 150                            # batchsize 0 = full batch
     px = model.transform(fitresult, (X[:64], Y[:64]))
