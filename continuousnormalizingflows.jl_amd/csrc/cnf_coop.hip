@@ -357,19 +357,23 @@ static const CoopInst kCoop[] = {
     COOP_GEN(16), COOP_GEN(12), COOP_GEN(8),
 };
 
+// smallest instance that holds the shape: hidden tiles (zero-padded, e.g. 7 -> 8), then state k-steps
 static const CoopInst* coop_find(int HT, int L, int ZR, int ACT) {
     const CoopInst* best = nullptr;
     for (const CoopInst& c : kCoop) {
         const bool act_ok = c.ACT == ACT || (c.ACT == CNF_ACT_TANH_PRESCALED && ACT == CNF_ACT_TANH);
-        if (c.HT == HT && c.L == L && c.ZR >= ZR && act_ok && (!best || c.ZR < best->ZR)) best = &c;
+        if (c.HT >= HT && c.L == L && c.ZR >= ZR && act_ok &&
+            (!best || c.HT < best->HT || (c.HT == best->HT && c.ZR < best->ZR)))
+            best = &c;
     }
     return best;
 }
 
-bool coop_supported(int HT, int L, int ZR, int CR, int ACT, int engine, int KP, int* ZR_inst) {
+bool coop_supported(int HT, int L, int ZR, int CR, int ACT, int engine, int KP, int* ZR_inst, int* HT_inst) {
     if (engine != ENG_VJP || KP != 1 || CR != 0) return false;
     const CoopInst* c = coop_find(HT, L, ZR, ACT);
     if (c && ZR_inst) *ZR_inst = c->ZR;
+    if (c && HT_inst) *HT_inst = c->HT;
     return c != nullptr;
 }
 

@@ -103,9 +103,10 @@ MfmaPlan* mfma_plan_create(const cnf_config& c) {
     const int want_pre = env_int("CNF_MFMA_PRE", -1);
     const bool force_coop = env_int("CNF_MFMA_COOP", 0) != 0;
     auto make_coop = [&]() -> MfmaPlan* {
-        int zr_inst = ZR;
-        if (!coop_supported(HT, L, ZR, CR, c.acts[0], engine, KP, &zr_inst)) return nullptr;
+        int zr_inst = ZR, ht_inst = HT;
+        if (!coop_supported(HT, L, ZR, CR, c.acts[0], engine, KP, &zr_inst, &ht_inst)) return nullptr;
         MfmaPlan* p = new MfmaPlan();
+        const int HT = ht_inst;   // the instance's hidden tiles (zero-padded)
         p->HT = HT; p->L = L; p->ZR = zr_inst; p->CR = CR; p->ACT = c.acts[0]; p->ENGINE = engine; p->KP = KP;
         p->with_bwd = true;
         p->lay = MfmaLayout(HT, L, zr_inst, CR, true);
@@ -124,6 +125,7 @@ MfmaPlan* mfma_plan_create(const cnf_config& c) {
     constexpr size_t kMaxLds = 160 * 1024;
     auto make = [&](const Inst& in) -> MfmaPlan* {
         MfmaPlan* p = new MfmaPlan();
+        const int HT = in.HT;   // the instance's hidden tiles (>= the configuration's: zero-padded)
         p->HT = HT; p->L = L; p->ZR = in.ZR; p->CR = in.CR; p->ACT = in.ACT; p->ENGINE = engine; p->KP = KP;
         p->with_bwd = engine == ENG_VJP;
         p->arith = in.arith;
@@ -153,25 +155,30 @@ MfmaPlan* mfma_plan_create(const cnf_config& c) {
     if (c.arith != CNF_ARITH_F32) return nullptr;   // split-bf16: specialised instances only
     // 2. generic zero-padded instances whose images fit LDS
     if (want_nt == 0 && want_pre < 0) {
-        int ng = 0;
-        const Inst* gen = mfma_generic_insts(&ng);
-        for (int i = 0; i < ng; ++i) {
-            const Inst& in = gen[i];
-            if (in.HT == HT && in.L == L && in.ZR >= ZR && in.CR >= CR && (CR > 0 || in.CR == 0) &&
-                act_matches(in.ACT, c.acts[0]) && in.ENGINE == engine && in.KP == KP &&
-                (size_t)MfmaLayout(HT, L, in.ZR, in.CR, engine == ENG_VJP).total * sizeof(float) <= kMaxLds)
-                return make(in);
-        }
-        // several probes: instances with a register capacity of KP >= K probes, K passed at run time
-        if (KP > 1) {
-            gen = mfma_generic_probe_insts(&ng);
+        // smallest instance that holds the configuration: hidden tiles, then state k-steps (zero padding
+        // costs MFMAs, so the tightest fit wins); K = 1 tables first, then the probe-capacity table
+        auto pick = [&](const Inst* gen, int ng, bool probes) -> const Inst* {
+            const Inst* best = nullptr;
             for (int i = 0; i < ng; ++i) {
                 const Inst& in = gen[i];
-                if (in.HT == HT && in.L == L && in.ZR >= ZR && in.CR >= CR && (CR > 0 || in.CR == 0) &&
-                    act_matches(in.ACT, c.acts[0]) && in.ENGINE == engine && in.KP >= KP &&
-                    (size_t)MfmaLayout(HT, L, in.ZR, in.CR, engine == ENG_VJP).total * sizeof(float) <= kMaxLds)
-                    return make(in);
+                if (in.HT >= HT && in.L == L && in.ZR >= ZR && in.CR >= CR && (CR > 0 || in.CR == 0) &&
+                    act_matches(in.ACT, c.acts[0]) && in.ENGINE == engine && (probes ? in.KP >= KP : in.KP == KP) &&
+                    (size_t)MfmaLayout(in.HT, L, in.ZR, in.CR, engine == ENG_VJP).total * sizeof(float) <= kMaxLds &&
+                    (!best || in.HT < best->HT || (in.HT == best->HT && in.ZR < best->ZR)))
+                    best = &in;
             }
+            return best;
+        };
+        int ng = 0, ng8 = 0, ngp = 0;
+        const Inst* gen = mfma_generic_insts(&ng);
+        const Inst* gen8 = mfma_generic_zr8_insts(&ng8);
+        const Inst* a4 = pick(gen, ng, false);
+        const Inst* a8 = pick(gen8, ng8, false);
+        if (a4 && (!a8 || a4->HT <= a8->HT)) return make(*a4);
+        if (a8) return make(*a8);
+        if (KP > 1) {
+            const Inst* genp = mfma_generic_probe_insts(&ngp);
+            if (const Inst* ap = pick(genp, ngp, true)) return make(*ap);
         }
     }
     // 3. cooperative wide-layer kernel

@@ -51,7 +51,7 @@ __device__ __forceinline__ void load_cvec(const float* __restrict__ vec, int g, 
 }
 
 // cooperative wide-layer kernel (cnf_coop.hip)
-bool coop_supported(int HT, int L, int ZR, int CR, int ACT, int engine, int KP, int* ZR_inst);
+bool coop_supported(int HT, int L, int ZR, int CR, int ACT, int engine, int KP, int* ZR_inst, int* HT_inst);
 hipError_t coop_launch(int HT, int L, int ZR, int ACT, const KArgs& a, int num_cus, hipStream_t st);
 
 }  // namespace cnf

@@ -1,7 +1,7 @@
 // cnf_mfma_generic.hip — zero-padded instantiations of the per-wave fused solve kernel.
 //
 // The specialised table in cnf_mfma.hip matches (D, C) exactly (BASELINE shapes).  These cover
-// every other uniform-width Dense chain with H <= 128 and L in {2,3} (H <= 64 for L in {1,4}), D <= 16, C = 0 or <= 16,
+// every other Dense chain with H <= 128 and L in {2,3} (H <= 64 for L in {1,4}), D <= 16 (D <= 32: cnf_mfma_generic_zr8.hip), C = 0 or <= 16,
 // tanh or softplus, K = 1: the state/condition k-steps are padded to 4 (zero rows in the operand
 // images, zero registers in the state), which costs at most 2-3 wasted MFMAs per product against
 // the 40x the generic SIMT path would cost.  E.g. the reference's default net for nvariables = 2

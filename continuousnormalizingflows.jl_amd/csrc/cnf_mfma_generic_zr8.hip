@@ -1,0 +1,31 @@
+// cnf_mfma_generic_zr8.hip — zero-padded per-wave solve instances with 8 state k-steps (16 < D <= 32).
+//
+// The reference's default constructor builds D = 2 n + 1 state rows and hidden width 8 n + 8 for
+// nvariables = n (src/core/icnf.jl:62-71): n = 8 .. 15 gives D = 17 .. 31 and H = 72 .. 128 — beyond the
+// 4 state k-steps of cnf_mfma_generic.hip, below the cooperative kernel's widths.  These instances keep
+// such flows (and any other chain with D <= 32, H <= 128) on the fused path: z, eps and the RK stage
+// derivatives use 8 registers per lane each, the D-row products two M-tiles.
+#include "cnf_mfma_kernel.h"
+
+namespace cnf {
+
+#define VJP_ACT(ACT) ((ACT) == CNF_ACT_TANH ? CNF_ACT_TANH_PRESCALED : (ACT))
+#define GEN8(HT, L, ACT, NT)                                   \
+    MFMA_INST(HT, L, 8, 0, VJP_ACT(ACT), ENG_VJP, 1, 1, NT),   \
+    MFMA_INST(HT, L, 8, 4, VJP_ACT(ACT), ENG_VJP, 1, 1, NT),   \
+    MFMA_INST(HT, L, 8, 0, ACT, ENG_TAN, 1, 0, NT),            \
+    MFMA_INST(HT, L, 8, 4, ACT, ENG_TAN, 1, 0, NT)
+#define GEN8_ACT(HT, NT)                                                         \
+    GEN8(HT, 2, CNF_ACT_TANH, NT), GEN8(HT, 3, CNF_ACT_TANH, NT),                \
+    GEN8(HT, 2, CNF_ACT_SOFTPLUS, NT), GEN8(HT, 3, CNF_ACT_SOFTPLUS, NT)
+
+static const Inst kGenericZr8[] = {
+    GEN8_ACT(2, 512), GEN8_ACT(4, 256), GEN8_ACT(6, 256), GEN8_ACT(8, 256),   // HT = 4 spills at 2 waves/SIMD (8 state k-steps)
+};
+
+const Inst* mfma_generic_zr8_insts(int* count) {
+    *count = (int)(sizeof(kGenericZr8) / sizeof(kGenericZr8[0]));
+    return kGenericZr8;
+}
+
+}  // namespace cnf

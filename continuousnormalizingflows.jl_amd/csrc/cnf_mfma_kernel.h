@@ -530,6 +530,8 @@ struct Inst {
 const Inst* mfma_generic_insts(int* count);
 // the same shapes with a capacity of several Hutchinson probes (cnf_mfma_generic_probes.hip): VJP, K <= KP
 const Inst* mfma_generic_probe_insts(int* count);
+// state k-steps padded to 8 (D <= 32): the reference's default nets for nvariables 8..15 (cnf_mfma_generic_zr8.hip)
+const Inst* mfma_generic_zr8_insts(int* count);
 
 
 }  // namespace cnf

@@ -4,7 +4,7 @@ import __graft_entry__ as entry
 pkg = entry.load_package(); o64, oc = entry.load_oracle()
 dev = torch.device("cuda:0")
 out = {}
-for nv in (1, 2, 4):
+for nv in (1, 2, 4, 8, 12, 15):
     icnf = pkg.ICNF(nvariables=nv, device=dev, steer_rate=0.0, sol_kwargs=dict(alg=pkg.Tsit5(), adaptive=False, nsteps=40))
     ps, st = pkg.setup(torch.Generator().manual_seed(0), icnf)
     B = 65536
@@ -26,4 +26,4 @@ for nv in (1, 2, 4):
         for _ in range(3): pkg.loss_and_gradient(icnf, m, X, P, st, eps=E)
         t1.record(); torch.cuda.synchronize()
         out[f"nv{nv}_grad"] = dict(ms=t0.elapsed_time(t1) / 3)
-print(json.dumps(out, indent=1))
+print(json.dumps(out))
