@@ -678,6 +678,35 @@ def test_auto_path_prefers_fused_then_layerwise(pkg, oracles):
     assert np.max(np.abs(small - ref[:100])) < TOL_SOLVE
 
 
+def test_million_column_batch(pkg, oracles):
+    """B = 1 000 003 (64-bit column indexing, a ragged last tile, several tile rounds per CU): head, middle and
+    tail columns against the C restatement; the gradient at B = 300 007 is additive over a split."""
+    o64, oc = oracles
+    spec = o64.make_spec(nvars=8, hidden=[64, 64, 64])
+    B = 1_000_003
+    rng = np.random.default_rng(12)
+    p = o64.glorot_params(spec, rng)
+    xs = rng.standard_normal((8, B)).astype(np.float32)
+    eps = rng.standard_normal((8, B)).astype(np.float32)
+    icnf = make_icnf(pkg, spec, 1, 10)
+    logp = run_inference(pkg, icnf, spec, p, xs, eps, None)[0].cpu().numpy()
+    assert np.isfinite(logp).all()
+    for lo in (0, 499_968, B - 67):
+        sl = slice(lo, lo + 67)
+        ref = oc.inference_fixed(spec, p, xs[:, sl], 0.0, 1.0, 10, 1, eps[:, sl], None)[0]
+        assert np.max(np.abs(logp[sl] - ref)) < TOL_SOLVE, lo
+    Bg = 300_007
+    g_icnf = grad_icnf(pkg, spec, 0, 4)
+    X, E, P = dev(xs[:, :Bg]), dev(eps[:, :Bg]), dev(p)
+    vf, gf = pkg.loss_and_gradient(g_icnf, pkg.TrainMode(False), X, P, {}, eps=E)
+    h = 123_457
+    v1, g1 = pkg.loss_and_gradient(g_icnf, pkg.TrainMode(False), X[:, :h], P, {}, eps=E[:, :h])
+    v2, g2 = pkg.loss_and_gradient(g_icnf, pkg.TrainMode(False), X[:, h:], P, {}, eps=E[:, h:])
+    gs = (g1.double() * h + g2.double() * (Bg - h)) / Bg
+    assert float((gf.double() - gs).abs().max()) < 3e-5 * float(gf.abs().max())
+    assert abs(float(vf) - (float(v1) * h + float(v2) * (Bg - h)) / Bg) < 2e-5
+
+
 def test_empty_batch_is_a_no_op(pkg, oracles):
     o64, _ = oracles
     spec = o64.make_spec(nvars=8, hidden=[64, 64, 64])
