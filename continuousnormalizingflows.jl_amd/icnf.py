@@ -238,7 +238,7 @@ class ICNF:
                  n_out: Optional[int] = None, n_hidden: Optional[int] = None,
                  nn: Optional[Chain] = None, steer_rate: float = 0.1, lambda1: float = 0.01,
                  lambda2: float = 0.01, lambda3: float = 0.01, nprobes: int = 1,
-                 sol_kwargs: Optional[dict] = None, **aliases):
+                 basedist=None, epsdist=None, sol_kwargs: Optional[dict] = None, **aliases):
         # accept the reference's unicode keyword names too
         lambda1 = aliases.pop("λ₁", lambda1)
         lambda2 = aliases.pop("λ₂", lambda2)
@@ -275,6 +275,18 @@ class ICNF:
         self.steer_rate = float(steer_rate)
         self.lambda1, self.lambda2, self.lambda3 = float(lambda1), float(lambda2), float(lambda3)
         self.nprobes = int(nprobes)
+        # basedist / epsdist (src/core/icnf.jl:76-83): None = MvNormal(0, I), the case the kernels fuse
+        # (log N(z) in the epilogue, z ~ N(0, I) in generate, Gaussian probes).  basedist may be any object with
+        # `log_prob(z)` and `sample((n,))` on (n, D) tensors (torch.distributions style): logpdf(basedist, z) is
+        # then evaluated on the host from the final state (base_icnf.jl:168), and the parameter gradient,
+        # whose terminal costate assumes the Gaussian, is refused.  epsdist: None, "rademacher", or a callable
+        # (generator, (B, K*D), device) -> tensor.
+        self.basedist = basedist
+        self.epsdist = epsdist
+        if basedist is not None and not (hasattr(basedist, "log_prob") and hasattr(basedist, "sample")):
+            raise TypeError("MethodError: basedist needs log_prob(z) and sample((n,))")
+        if epsdist is not None and epsdist != "rademacher" and not callable(epsdist):
+            raise TypeError("MethodError: epsdist is None, 'rademacher' or a callable")
         self.rng = rng
         if self.rng is None and torch.cuda.is_available():
             self.rng = torch.Generator(device=self.device)
@@ -439,8 +451,17 @@ def _colmajor(a: torch.Tensor, rows: int, name: str, device) -> torch.Tensor:
 
 
 def _draw_eps(icnf: ICNF, K: int, B: int) -> torch.Tensor:
-    """rand!(rng, epsdist, eps): standard normal (src/core/base_icnf.jl:258-259)."""
-    return torch.randn(B, K * icnf.D, generator=icnf.rng, device=icnf.device, dtype=torch.float32)
+    """rand!(rng, epsdist, eps) (src/core/base_icnf.jl:258-259): standard normal unless icnf.epsdist says otherwise."""
+    shape = (B, K * icnf.D)
+    if icnf.epsdist is None:
+        return torch.randn(shape, generator=icnf.rng, device=icnf.device, dtype=torch.float32)
+    if icnf.epsdist == "rademacher":
+        r = torch.randint(0, 2, shape, generator=icnf.rng, device=icnf.device)
+        return (2 * r - 1).to(torch.float32)
+    e = icnf.epsdist(icnf.rng, shape, icnf.device)
+    if tuple(e.shape) != shape:
+        raise ValueError(f"DimensionMismatch: epsdist must return a {shape} tensor")
+    return e.to(device=icnf.device, dtype=torch.float32).contiguous()
 
 
 def _split_args(icnf: ICNF, args, what: str):
@@ -483,9 +504,12 @@ def inference(icnf: ICNF, mode: Mode, *args, eps: Optional[torch.Tensor] = None,
     nsteps = icnf._nsteps(t0, t1)
     logp = torch.empty(B, device=dev, dtype=torch.float32)
     regs = torch.empty(3, B, device=dev, dtype=torch.float32)
-    uf = torch.empty(B, icnf.S, device=dev, dtype=torch.float32) if return_state else None
+    want_state = return_state or icnf.basedist is not None
+    uf = torch.empty(B, icnf.S, device=dev, dtype=torch.float32) if want_state else None
     _lib.check(h.lib.cnf_inference_fixed(h.ptr, alg, nsteps, t0, t1, _ptr(x), _ptr(e), _ptr(y), B,
                                          _ptr(logp), _ptr(regs), _ptr(uf), _stream_ptr(dev)))
+    if icnf.basedist is not None:   # logp̂x = logpdf(basedist, z) - Δlogp (base_icnf.jl:168-169)
+        logp = (icnf.basedist.log_prob(uf[:, :icnf.D]) - uf[:, icnf.D]).to(torch.float32)
     if _raw:   # internal: the (3, B) regulariser block as one tensor (no copies on the loss path)
         return logp, regs
     out = (logp, (regs[0], regs[1], regs[2]))
@@ -511,7 +535,9 @@ def generate(icnf: ICNF, mode: Mode, *args, z0: Optional[torch.Tensor] = None,
     icnf._bind_params(h, ps)
     dev = icnf.device
     D, S = icnf.D, icnf.S
-    if z0 is None:
+    if z0 is None and icnf.basedist is not None:
+        z = icnf.basedist.sample((n,)).to(device=dev, dtype=torch.float32).reshape(n, D)
+    elif z0 is None:
         z = torch.randn(n, D, generator=icnf.rng, device=dev, dtype=torch.float32)
     else:
         z = _colmajor(z0, D, "z0", dev)
@@ -585,6 +611,8 @@ def loss_and_gradient(icnf: ICNF, mode: Mode, *args, eps: Optional[torch.Tensor]
     xs, ys, ps, st = _split_args(icnf, args, "loss_and_gradient")
     if icnf.nn.planar is not None:
         raise NotImplementedError("loss_and_gradient: PlanarLayer nets are not covered by the gradient kernel")
+    if icnf.basedist is not None:
+        raise NotImplementedError("loss_and_gradient: the terminal costate assumes basedist = MvNormal(0, I)")
     h = icnf._handle(mode)
     icnf._bind_params(h, ps)
     dev = icnf.device

@@ -1008,6 +1008,47 @@ def test_conditioned_fit_and_distribution_wrapper(pkg):
         d.logpdf(torch.zeros(1, 3))
 
 
+def test_custom_base_and_probe_distributions(pkg, oracles):
+    """ICNF(; basedist, epsdist) (src/core/icnf.jl:76-83): a non-default base density is evaluated on the host
+    from the final state (logp̂x = logpdf(basedist, z) - Δlogp, base_icnf.jl:168) and sampled in generate;
+    Rademacher / callable probe distributions feed the same kernels."""
+    o64, _ = oracles
+    spec = o64.make_spec(nvars=3, hidden=[32, 32])
+    p, xs, eps, _ = o64.synth_inputs(spec, 50, 4, bias_scale=0.2)
+    std = make_icnf(pkg, spec, 1, 6)
+    loc = torch.tensor([0.5, -1.0, 2.0], device="cuda:0")
+    base = torch.distributions.MultivariateNormal(loc, covariance_matrix=torch.diag(torch.tensor([0.25, 1.0, 4.0], device="cuda:0")))
+    cus = make_icnf(pkg, spec, 1, 6)
+    cus.basedist = base
+    m = pkg.TestMode()
+    lp0, _, u1 = pkg.inference(std, m, dev(xs), dev(p), {}, return_state=True)
+    lp1 = pkg.inference(cus, m, dev(xs), dev(p), {})[0]
+    z = u1[:3].t()
+    expect = base.log_prob(z) - u1[3]
+    assert float((lp1 - expect).abs().max()) < 1e-5
+    assert float((lp1 - lp0).abs().max()) > 0.1
+    assert abs(float(pkg.loss(cus, m, dev(xs), dev(p), {})) + float(lp1.mean())) < 1e-5
+    tight = torch.distributions.MultivariateNormal(loc, covariance_matrix=1e-10 * torch.eye(3, device="cuda:0"))
+    cus.basedist = tight
+    g = pkg.generate(cus, m, dev(p), {}, 5)
+    one = pkg.generate(std, m, dev(p), {}, 1, z0=loc[:, None])
+    assert float((g - one).abs().max()) < 1e-3                       # every sample starts at loc
+    with pytest.raises(NotImplementedError):
+        pkg.loss_and_gradient(cus, pkg.TrainMode(False), dev(xs), dev(p), {})
+    rad = make_icnf(pkg, spec, 1, 6)
+    rad.epsdist = "rademacher"
+    from importlib import import_module
+    draw = import_module(pkg.__name__ + ".icnf")._draw_eps
+    e = draw(rad, 2, 1000)
+    assert e.shape == (1000, 6) and set(e.unique().tolist()) == {-1.0, 1.0}
+    a = pkg.inference(rad, pkg.TrainMode(False), dev(xs), dev(p), {})[0]
+    assert bool(torch.isfinite(a).all())
+    rad.epsdist = lambda gen, shape, device: torch.full(shape, 0.5, device=device)
+    b = pkg.inference(rad, pkg.TrainMode(False), dev(xs), dev(p), {})[0]
+    c = pkg.inference(std, pkg.TrainMode(False), dev(xs), dev(p), {}, eps=torch.full((3, 50), 0.5, device="cuda:0"))[0]
+    assert torch.equal(b, c)
+
+
 def test_errors_surface_as_exceptions(pkg, oracles):
     o64, _ = oracles
     spec = o64.make_spec(nvars=8, hidden=[64, 64, 64])
