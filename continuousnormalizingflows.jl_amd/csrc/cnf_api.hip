@@ -141,6 +141,11 @@ struct cnf_handle {
     // when the layout handed to cnf_set_params changes; p_stage holds host-supplied parameters
     PackMap map_fwd, map_grad;
     LayeredGrad* layered = nullptr;      // rocBLAS context + workspaces of the layer-wise evaluation / gradient
+    // embedded-step workspace (cnf_step_embedded): 7 stage derivatives + 1 stage state, each S x ebuf_B
+    float* ebuf = nullptr;
+    int64_t ebuf_B = 0;
+    int ek[7] = {0, 1, 2, 3, 4, 5, 6};   // which slot holds k_1 .. k_7 (first-same-as-last swaps slots 0 and 6)
+    double* err_partial = nullptr;
     bool layered_forced = false;         // kernel_path = CNF_PATH_LAYERED given explicitly: GEMM path for every batch
     bool maps_built = false;
     bool repack_on_device = false;
@@ -258,6 +263,8 @@ int cnf_destroy(cnf_handle* h) {
     if (h->grad_packed) (void)hipFree(h->grad_packed);
     if (h->grad_ws) (void)hipFree(h->grad_ws);
     if (h->p_stage) (void)hipFree(h->p_stage);
+    if (h->ebuf) (void)hipFree(h->ebuf);
+    if (h->err_partial) (void)hipFree(h->err_partial);
     layered_grad_destroy(h->layered);
     free_pack_map(h->map_fwd);
     free_pack_map(h->map_grad);
@@ -520,6 +527,101 @@ int cnf_inference_fixed(cnf_handle* h, int alg, int nsteps, float t0, float t1, 
     rc = simt_integrate(h, alg, nsteps, t0, t1, u, eps, ys, B, st);
     if (rc) return rc;
     HIP_TRY(epilogue(u, h->cfg.nvars, h->D, reg_aug, B, logp, regs, st));
+    return CNF_OK;
+}
+
+// f(u + dt sum coef k, t) on whichever family serves the handle; `stage` is scratch for the fused path, whose
+// single-call kernel takes the stage state itself
+static int eval_dynamics(cnf_handle* h, const StageIn& in, float t, const float* eps, const float* ys, int64_t B, float* du,
+                         float* stage, bool first, hipStream_t st) {
+    if (h->path == CNF_PATH_MFMA) {
+        const float* uin = in.u;
+        if (in.nprev > 0) {
+            HIP_TRY(rk_update(stage, in, (int64_t)h->S * B, st));
+            uin = stage;
+        }
+        SolveArgs a{};
+        a.u0 = uin; a.eps = eps; a.ys = ys; a.B = B; a.nsteps = 0; a.alg = 0; a.t0 = t; a.t1 = t;
+        a.u_out = du; a.nvars = h->cfg.nvars; a.reg_aug = 0;
+        HIP_TRY(mfma_solve(h->plan, h->packed_dev, a, st));
+        return CNF_OK;
+    }
+    return generic_aug_f(h, in, t, eps, ys, B, du, first, st);
+}
+
+int cnf_step_embedded(cnf_handle* h, int alg, int flags, float t, float dt, const float* u, const float* eps,
+                      const float* ys, int64_t B, float abstol, float reltol, float* u_new, double* err_sumsq,
+                      void* stream) {
+    int rc = check_call(h, eps, ys, B, "cnf_step_embedded");
+    if (rc) return rc;
+    if (alg != CNF_ALG_TSIT5) return fail(CNF_ERR_INVALID, "cnf_step_embedded: the embedded pair is Tsit5 (alg = CNF_ALG_TSIT5)");
+    if (!(abstol >= 0.f) || !(reltol >= 0.f) || (abstol == 0.f && reltol == 0.f))
+        return fail(CNF_ERR_INVALID, "cnf_step_embedded: tolerances must be non-negative and not both zero");
+    if (B == 0) return CNF_OK;
+    if (!u || !u_new || !err_sumsq) return fail(CNF_ERR_INVALID, "cnf_step_embedded: null u/u_new/err_sumsq");
+    if (u == u_new) return fail(CNF_ERR_INVALID, "cnf_step_embedded: u_new may not alias u");
+    DeviceGuard g(h->cfg.device_id);
+    hipStream_t st = (hipStream_t)stream;
+    const size_t n = (size_t)h->S * (size_t)B;
+    if (B > h->ebuf_B) {
+        if (h->ebuf) HIP_TRY(hipFree(h->ebuf));
+        h->ebuf = nullptr; h->ebuf_B = 0;
+        HIP_TRY(hipMalloc((void**)&h->ebuf, 8 * n * sizeof(float)));
+        h->ebuf_B = B;
+        flags = 0;   // the cached stages went with the old buffer
+    }
+    if (!h->err_partial) HIP_TRY(hipMalloc((void**)&h->err_partial, kErrBlocks * sizeof(double)));
+    const size_t slot = (size_t)h->S * (size_t)h->ebuf_B;
+    float* stage = h->ebuf + 7 * slot;
+    if (flags & CNF_STEP_FSAL) { const int tmp = h->ek[0]; h->ek[0] = h->ek[6]; h->ek[6] = tmp; }
+    float* k[7];
+    for (int i = 0; i < 7; ++i) k[i] = h->ebuf + (size_t)h->ek[i] * slot;
+    const Tableau T = make_tableau(CNF_ALG_TSIT5);
+    if (!(flags & (CNF_STEP_FSAL | CNF_STEP_RETRY))) {
+        StageIn in{};
+        in.u = u; in.nprev = 0; in.dt = 0.f;
+        rc = eval_dynamics(h, in, t, eps, ys, B, k[0], stage, true, st);
+        if (rc) return rc;
+    }
+    for (int i = 1; i < 6; ++i) {
+        StageIn in{};
+        in.u = u; in.nprev = i; in.dt = dt;
+        for (int j = 0; j < i; ++j) { in.k[j] = k[j]; in.coef[j] = T.a[i][j]; }
+        rc = eval_dynamics(h, in, t + T.c[i] * dt, eps, ys, B, k[i], stage, false, st);
+        if (rc) return rc;
+    }
+    StageIn fin{};
+    fin.u = u; fin.nprev = 6; fin.dt = dt;
+    for (int j = 0; j < 6; ++j) { fin.k[j] = k[j]; fin.coef[j] = T.b[j]; }
+    HIP_TRY(rk_update(u_new, fin, (int64_t)n, st));
+    StageIn last{};
+    last.u = u_new; last.nprev = 0; last.dt = 0.f;
+    rc = eval_dynamics(h, last, t + dt, eps, ys, B, k[6], stage, false, st);   // 7th stage = first stage of the next step
+    if (rc) return rc;
+    // b - bhat of the embedded 4th-order solution (Tsitouras 2011); satisfies the order-4 conditions to 1e-15
+    static const float btilde[7] = {-0.00178001105222577714f, -0.0008164344596567469f, 0.007880878010261995f,
+                                    -0.1447110071732629f, 0.5823571654525552f, -0.45808210592918697f,
+                                    0.015151515151515152f};
+    HIP_TRY(embedded_error(u, u_new, k, btilde, 7, dt, abstol, reltol, (int64_t)n, h->err_partial, err_sumsq, st));
+    return CNF_OK;
+}
+
+int cnf_assemble_u0(cnf_handle* h, const float* x, int64_t B, float* u0, void* stream) {
+    if (!h || B < 0) return fail(CNF_ERR_INVALID, "cnf_assemble_u0: null handle or negative batch");
+    if (B == 0) return CNF_OK;
+    if (!x || !u0) return fail(CNF_ERR_INVALID, "cnf_assemble_u0: null x/u0");
+    DeviceGuard g(h->cfg.device_id);
+    HIP_TRY(assemble_u0(x, h->cfg.nvars, h->S, B, u0, (hipStream_t)stream));
+    return CNF_OK;
+}
+
+int cnf_epilogue(cnf_handle* h, const float* u, int64_t B, float* logp, float* regs, void* stream) {
+    if (!h || B < 0) return fail(CNF_ERR_INVALID, "cnf_epilogue: null handle or negative batch");
+    if (B == 0) return CNF_OK;
+    if (!u || !logp) return fail(CNF_ERR_INVALID, "cnf_epilogue: null u/logp");
+    DeviceGuard g(h->cfg.device_id);
+    const int reg_aug = (h->cfg.reg_aug && h->cfg.naug > 0 && h->cfg.mode != CNF_MODE_EXACT) ? 1 : 0;
+    HIP_TRY(epilogue(u, h->cfg.nvars, h->D, reg_aug, B, logp, regs, (hipStream_t)stream));
     return CNF_OK;
 }
 

@@ -37,6 +37,9 @@ hipError_t epilogue(const float* u, int nvars, int D, int reg_aug, int64_t B, fl
                     float* regs, hipStream_t st);
 hipError_t loss_sums(const float* logp, const float* regs, int64_t B, float* partial,
                      float* sums4, hipStream_t st);
+constexpr int kErrBlocks = 256;   // partial sums of embedded_error (= LOSS_BLOCKS in cnf_simt.hip)
+hipError_t embedded_error(const float* u, const float* unew, const float* const* k, const float* btilde, int nk, float dt,
+                          float abstol, float reltol, int64_t n, double* partial, double* out, hipStream_t st);
 
 // ---- fused MFMA path (cnf_mfma.hip) ----
 struct MfmaPlan;  // opaque: packed-weight layout + kernel selection for one config

@@ -326,6 +326,55 @@ hipError_t epilogue(const float* u, int nvars, int D, int reg_aug, int64_t B, fl
     return hipGetLastError();
 }
 
+// Embedded error estimate of one step (OrdinaryDiffEq: utilde = dt sum_i btilde_i k_i, atmp = utilde ./ (abstol +
+// max(|uprev|, |u|) reltol), EEst = sqrt(sum(atmp^2) / length)): squared scaled residuals summed in double,
+// fixed partition and combine order (no atomics).
+struct ErrIn { const float* k[7]; float coef[7]; int nk; };
+
+__global__ void __launch_bounds__(256)
+err_partial_kernel(const float* __restrict__ u, const float* __restrict__ unew, ErrIn in, float dt, float abstol,
+                   float reltol, int64_t n, double* __restrict__ partial /* LOSS_BLOCKS */) {
+    double acc = 0.0;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+        float ut = 0.f;
+        for (int j = 0; j < in.nk; ++j) ut = fmaf(in.coef[j], in.k[j][e], ut);
+        const float r = dt * ut / fmaf(fmaxf(fabsf(u[e]), fabsf(unew[e])), reltol, abstol);
+        acc += (double)r * (double)r;
+    }
+    __shared__ double sm[256];
+    sm[threadIdx.x] = acc;
+    __syncthreads();
+    for (int st = 128; st >= 1; st >>= 1) {
+        if ((int)threadIdx.x < st) sm[threadIdx.x] += sm[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = sm[0];
+}
+
+__global__ void __launch_bounds__(256)
+err_final_kernel(const double* __restrict__ partial, double* __restrict__ out) {
+    __shared__ double sm[256];
+    double v = 0.0;
+    for (int b = threadIdx.x; b < LOSS_BLOCKS; b += 256) v += partial[b];
+    sm[threadIdx.x] = v;
+    __syncthreads();
+    for (int st = 128; st >= 1; st >>= 1) {
+        if ((int)threadIdx.x < st) sm[threadIdx.x] += sm[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = sm[0];
+}
+
+hipError_t embedded_error(const float* u, const float* unew, const float* const* k, const float* btilde, int nk, float dt,
+                          float abstol, float reltol, int64_t n, double* partial, double* out, hipStream_t st) {
+    ErrIn in{};
+    in.nk = nk;
+    for (int j = 0; j < nk; ++j) { in.k[j] = k[j]; in.coef[j] = btilde[j]; }
+    hipLaunchKernelGGL(err_partial_kernel, dim3(LOSS_BLOCKS), dim3(256), 0, st, u, unew, in, dt, abstol, reltol, n, partial);
+    hipLaunchKernelGGL(err_final_kernel, dim3(1), dim3(256), 0, st, partial, out);
+    return hipGetLastError();
+}
+
 hipError_t loss_sums(const float* logp, const float* regs, int64_t B, float* partial,
                      float* sums4, hipStream_t st) {
     hipLaunchKernelGGL(loss_partial_kernel, dim3(LOSS_BLOCKS), dim3(256), 0, st, logp, regs, B, partial);

@@ -225,8 +225,10 @@ class ICNF:
     """Keyword constructor mirroring `ICNF(; ...)` (src/core/icnf.jl:53-103).
 
     Differences forced by the fixed-step HIP path (all raise instead of silently falling back):
-      * `sol_kwargs` must select a fixed-step method: alg in {Tsit5(), RK4()}, adaptive=False,
-        and either `dt` or `nsteps`.  The reference default (adaptive VCABM) is not implemented.
+      * `sol_kwargs.alg` is Tsit5() or RK4().  With adaptive=False (and `dt` or `nsteps`) the whole solve is one
+        fused launch; Tsit5() with adaptive=True (OrdinaryDiffEq's default for it; reltol/abstol default 1e-4 as in
+        the reference) steps under a PI controller on the host with one device attempt per step
+        (`_adaptive_integrate`).  The reference's own default algorithm (VCABM) is not implemented.
       * `nn` must be a Chain of Dense layers with identity/tanh/softplus activations.
       * data_type is Float32.
     """
@@ -326,9 +328,15 @@ class ICNF:
                 "sol_kwargs.alg must be Tsit5() or RK4(); the reference's adaptive default "
                 "(VCABM, reltol=abstol=1e-4) couples samples through its step controller and is "
                 "not implemented by the fixed-step HIP path")
-        if kw.get("adaptive", True):
-            raise NotImplementedError("sol_kwargs.adaptive must be False (fixed-step path)")
+        if kw.get("adaptive", True) and alg.alg_id != _lib.ALG_TSIT5:
+            raise NotImplementedError("adaptive stepping is implemented for Tsit5() only; use adaptive=False with RK4()")
         return alg.alg_id
+
+    @property
+    def adaptive(self) -> bool:
+        """OrdinaryDiffEq's default: an algorithm with an embedded pair steps adaptively unless adaptive=false."""
+        self._solver()
+        return bool(self.sol_kwargs.get("adaptive", True))
 
     def _nsteps(self, t0: float, t1: float) -> int:
         kw = self.sol_kwargs
@@ -476,6 +484,96 @@ def _split_args(icnf: ICNF, args, what: str):
     return args[0], None, args[1], args[2]
 
 
+def _adaptive_integrate(icnf: ICNF, h: "_Handle", u0: torch.Tensor, t0: float, t1: float,
+                        e: Optional[torch.Tensor], y: Optional[torch.Tensor], group=None) -> torch.Tensor:
+    """Adaptive Tsit5 from t0 to t1 (either direction) on the (B, S) state u0: what `SciMLBase.solve(prob, Tsit5();
+    reltol, abstol)` does in `base_sol` (src/core/base_icnf.jl:134-140), restated from OrdinaryDiffEq's documented
+    algorithm — Hairer's initial step, embedded 4th-order error estimate scaled by `abstol + reltol max(|u_prev|, |u|)`
+    under the RMS norm over the WHOLE state, PI controller (beta1 = 7/50, beta2 = 2/25, gamma = 9/10, qmin = 1/5,
+    qmax = 10, qoldinit = 1e-4), first-same-as-last.  Every attempt is one `cnf_step_embedded` call; the host only
+    handles the controller's scalars.  The error norm couples all columns, so with torch.distributed initialised
+    the squared sum and the element count are all-reduced and every rank takes the same steps.  The step sequence
+    of the Julia implementation cannot be checked here (no Julia); parity is against the fp64 oracle's restatement
+    of the same algorithm and against fine fixed-step solves."""
+    import torch.distributed as dist
+    kw = icnf.sol_kwargs
+    reltol, abstol = float(kw.get("reltol", 1e-4)), float(kw.get("abstol", 1e-4))
+    maxiters = int(kw.get("maxiters", 100000))
+    dev = icnf.device
+    B, S = u0.shape
+    lib, st = h.lib, _stream_ptr(dev)
+    sharded = dist.is_available() and dist.is_initialized()
+    tdir = 1.0 if t1 >= t0 else -1.0
+    span = abs(t1 - t0)
+    stats = {"naccept": 0, "nreject": 0, "nf": 0, "dts": []}
+    icnf.last_solve_stats = stats
+    if B == 0 or span == 0.0:
+        return u0.clone()
+
+    def allsum(vals):
+        t = torch.tensor(vals, dtype=torch.float64, device=dev if (sharded and dist.get_backend(group) == "nccl") else "cpu")
+        if sharded:
+            dist.all_reduce(t, group=group)
+        return [float(v) for v in t]
+
+    def f(u, t):
+        du = torch.empty_like(u)
+        _lib.check(lib.cnf_aug_f(h.ptr, _ptr(du), _ptr(u), t, _ptr(e), _ptr(y), B, st))
+        stats["nf"] += 1
+        return du
+
+    if "dt" in kw:
+        dt = min(abs(float(kw["dt"])), span)
+    else:   # ode_determine_initdt (Hairer, Noersett, Wanner I, II.4) with the RMS norm over all S*B entries
+        sk = abstol + u0.abs() * reltol
+        f0 = f(u0, t0)
+        s0, s1, n = allsum([float(((u0 / sk).double() ** 2).sum()), float(((f0 / sk).double() ** 2).sum()), float(B * S)])
+        d0, d1 = math.sqrt(s0 / n), math.sqrt(s1 / n)
+        dt0 = 1e-6 if (d0 < 1e-5 or d1 < 1e-5) else 0.01 * d0 / d1
+        dt0 = min(dt0, span)
+        f1 = f(u0 + tdir * dt0 * f0, t0 + tdir * dt0)
+        (s2,) = allsum([float((((f1 - f0) / sk).double() ** 2).sum())])
+        d2 = math.sqrt(s2 / n) / dt0
+        dmax = max(d1, d2)
+        dt1 = max(1e-6, dt0 * 1e-3) if dmax <= 1e-15 else 10.0 ** (-(2.0 + math.log10(dmax)) / 5.0)
+        dt = min(100.0 * dt0, dt1, span)
+    beta1, beta2, gamma, qmin, qmax, qold = 7.0 / 50.0, 2.0 / 25.0, 0.9, 0.2, 10.0, 1e-4
+    u = u0.contiguous().clone()
+    un = torch.empty_like(u)
+    err = torch.zeros(1, dtype=torch.float64, device=dev)
+    t, flags = t0, 0
+    ntot = allsum([float(B * S)])[0] if sharded else float(B * S)
+    for _ in range(maxiters):
+        if abs(t1 - t) <= 1e-7 * max(1.0, span):
+            break
+        last = dt >= abs(t1 - t) * (1.0 - 1e-6)
+        step = abs(t1 - t) if last else dt          # tstop: never step over t1
+        _lib.check(lib.cnf_step_embedded(h.ptr, _lib.ALG_TSIT5, flags, t, tdir * step, _ptr(u), _ptr(e), _ptr(y), B,
+                                         abstol, reltol, _ptr(un), _ptr(err), st))
+        stats["nf"] += 6 if flags else 7
+        (ssq,) = allsum([float(err.item())])
+        eest = math.sqrt(ssq / ntot)
+        if not math.isfinite(eest):
+            raise FloatingPointError("adaptive solve: non-finite error estimate (unstable dynamics)")
+        q11 = eest ** beta1 if eest > 0.0 else 0.0
+        q = 1.0 / qmax if eest == 0.0 else max(1.0 / qmax, min(1.0 / qmin, (q11 / qold ** beta2) / gamma))
+        if eest <= 1.0:   # accept
+            t = t1 if last else t + tdir * step
+            u, un = un, u
+            stats["naccept"] += 1
+            stats["dts"].append(tdir * step)
+            qold = max(eest, 1e-4)
+            dt = step / q
+            flags = _lib.STEP_FSAL
+        else:             # reject: same (t, u), smaller step
+            stats["nreject"] += 1
+            dt = step / min(1.0 / qmin, q11 / gamma)
+            flags = _lib.STEP_RETRY
+    else:
+        raise RuntimeError("adaptive solve: maxiters reached")
+    return u
+
+
 def inference(icnf: ICNF, mode: Mode, *args, eps: Optional[torch.Tensor] = None,
               return_state: bool = False, _raw: bool = False):
     """inference(icnf, mode, xs[, ys], ps, st) -> (logp̂x (B,), (Ė, ṅ, Ȧ)).
@@ -501,13 +599,19 @@ def inference(icnf: ICNF, mode: Mode, *args, eps: Optional[torch.Tensor] = None,
             raise ValueError("DimensionMismatch: eps must have B columns")
     t0, t1 = icnf._steer_tspan(mode)
     alg = icnf._solver()
-    nsteps = icnf._nsteps(t0, t1)
     logp = torch.empty(B, device=dev, dtype=torch.float32)
     regs = torch.empty(3, B, device=dev, dtype=torch.float32)
     want_state = return_state or icnf.basedist is not None
-    uf = torch.empty(B, icnf.S, device=dev, dtype=torch.float32) if want_state else None
-    _lib.check(h.lib.cnf_inference_fixed(h.ptr, alg, nsteps, t0, t1, _ptr(x), _ptr(e), _ptr(y), B,
-                                         _ptr(logp), _ptr(regs), _ptr(uf), _stream_ptr(dev)))
+    if icnf.adaptive:
+        u0 = torch.empty(B, icnf.S, device=dev, dtype=torch.float32)
+        _lib.check(h.lib.cnf_assemble_u0(h.ptr, _ptr(x), B, _ptr(u0), _stream_ptr(dev)))
+        uf = _adaptive_integrate(icnf, h, u0, t0, t1, e, y)
+        _lib.check(h.lib.cnf_epilogue(h.ptr, _ptr(uf), B, _ptr(logp), _ptr(regs), _stream_ptr(dev)))
+    else:
+        nsteps = icnf._nsteps(t0, t1)
+        uf = torch.empty(B, icnf.S, device=dev, dtype=torch.float32) if want_state else None
+        _lib.check(h.lib.cnf_inference_fixed(h.ptr, alg, nsteps, t0, t1, _ptr(x), _ptr(e), _ptr(y), B,
+                                             _ptr(logp), _ptr(regs), _ptr(uf), _stream_ptr(dev)))
     if icnf.basedist is not None:   # logp̂x = logpdf(basedist, z) - Δlogp (base_icnf.jl:168-169)
         logp = (icnf.basedist.log_prob(uf[:, :icnf.D]) - uf[:, icnf.D]).to(torch.float32)
     if _raw:   # internal: the (3, B) regulariser block as one tensor (no copies on the loss path)
@@ -549,10 +653,13 @@ def generate(icnf: ICNF, mode: Mode, *args, z0: Optional[torch.Tensor] = None,
     u0[:, :D] = z
     t0, t1 = icnf._steer_tspan(mode)
     alg = icnf._solver()
-    nsteps = icnf._nsteps(t0, t1)
-    u1 = torch.empty_like(u0)
-    _lib.check(h.lib.cnf_integrate_fixed(h.ptr, alg, nsteps, t1, t0, _ptr(u0), _ptr(e), _ptr(y), n,
-                                         _ptr(u1), _stream_ptr(dev)))
+    if icnf.adaptive:
+        u1 = _adaptive_integrate(icnf, h, u0, t1, t0, e, y)
+    else:
+        nsteps = icnf._nsteps(t0, t1)
+        u1 = torch.empty_like(u0)
+        _lib.check(h.lib.cnf_integrate_fixed(h.ptr, alg, nsteps, t1, t0, _ptr(u0), _ptr(e), _ptr(y), n,
+                                             _ptr(u1), _stream_ptr(dev)))
     return u1[:, :icnf.nvariables].t()
 
 
@@ -613,6 +720,8 @@ def loss_and_gradient(icnf: ICNF, mode: Mode, *args, eps: Optional[torch.Tensor]
         raise NotImplementedError("loss_and_gradient: PlanarLayer nets are not covered by the gradient kernel")
     if icnf.basedist is not None:
         raise NotImplementedError("loss_and_gradient: the terminal costate assumes basedist = MvNormal(0, I)")
+    if icnf.adaptive:
+        raise NotImplementedError("loss_and_gradient differentiates the fixed-step solve: use adaptive=False")
     h = icnf._handle(mode)
     icnf._bind_params(h, ps)
     dev = icnf.device

@@ -114,6 +114,29 @@ int cnf_destroy(cnf_handle* h);
 int cnf_set_params(cnf_handle* h, const float* p, size_t n, const size_t* w_off,
                    const size_t* b_off, int p_is_device, void* stream);
 
+/* ---- adaptive stepping: the caller drives an embedded Runge-Kutta solve -------------
+ * base_sol with an adaptive `alg` (src/core/base_icnf.jl:134-140) lets OrdinaryDiffEq choose the steps from an
+ * error norm over the WHOLE S x B state, so samples (and column shards) are coupled through the step-size
+ * controller.  The library provides the per-attempt device work; the controller (a few scalars per attempt, and
+ * an all-reduce of err_sumsq when the columns are sharded) stays with the caller.
+ *
+ * cnf_step_embedded: one attempt of Tsit5 from (t, u) with step dt:
+ *     u_new = u + dt sum_i b_i k_i                                   (5th order)
+ *     err_sumsq[0] = sum over all S*B entries of (dt sum_i btilde_i k_i / (abstol + reltol max(|u|, |u_new|)))^2
+ * (OrdinaryDiffEq's calculate_residuals + ODE_DEFAULT_NORM before the division by the length and the root).
+ * u, u_new: device S x B, must not alias.  err_sumsq: device double.  flags: CNF_STEP_FSAL = this attempt starts
+ * where the previous (accepted) attempt of this handle ended, so its first stage is that attempt's last one;
+ * CNF_STEP_RETRY = same (t, u) as the previous (rejected) attempt, the first stage is reused.  0 = evaluate it. */
+enum { CNF_STEP_FSAL = 1, CNF_STEP_RETRY = 2 };
+int cnf_step_embedded(cnf_handle* h, int alg, int flags, float t, float dt, const float* u, const float* eps,
+                      const float* ys, int64_t B, float abstol, float reltol, float* u_new, double* err_sumsq,
+                      void* stream);
+
+/* u0 = [x; 0] (S x B) for an integration driven by the caller (inference_prob, src/core/base_icnf.jl:247-270), and
+ * the inference_sol epilogue on a final state: logp (B), regs (3B, may be NULL) (src/core/base_icnf.jl:158-172). */
+int cnf_assemble_u0(cnf_handle* h, const float* x, int64_t B, float* u0, void* stream);
+int cnf_epilogue(cnf_handle* h, const float* u, int64_t B, float* logp, float* regs, void* stream);
+
 /* Which kernel family the handle resolved to (CNF_PATH_SIMT, CNF_PATH_MFMA or CNF_PATH_LAYERED). */
 int cnf_kernel_path(const cnf_handle* h);
 

@@ -216,6 +216,81 @@ def integrate_fixed(spec: Spec, p, u0: np.ndarray, t0: float, t1: float, nsteps:
     return u
 
 
+TSIT5_BTILDE = (-0.00178001105222577714, -0.0008164344596567469, 0.007880878010261995, -0.1447110071732629,
+                0.5823571654525552, -0.45808210592918697, 1.0 / 66.0)
+
+
+def integrate_adaptive_tsit5(spec: Spec, p, u0: np.ndarray, t0: float, t1: float, reltol: float, abstol: float,
+                             eps=None, ys=None, dt0: Optional[float] = None, maxiters: int = 100000):
+    """base_sol with Tsit5(), adaptive (src/core/base_icnf.jl:134-140), restated in float64 from OrdinaryDiffEq's
+    documented algorithm: Hairer's initial step, embedded 4th-order estimate dt sum btilde_i k_i scaled by
+    abstol + reltol max(|u_prev|, |u|), RMS norm over the whole S x B state, PI controller (beta1 = 7/50, beta2 = 2/25,
+    gamma = 9/10, qmin = 1/5, qmax = 10, qoldinit = 1e-4), first-same-as-last.  Returns (u1, stats).
+    The Julia package is not available here, so its exact step sequence is unverified: this is the oracle the HIP
+    path's adaptive mode is compared with, itself checked against fine fixed-step solves."""
+    c, a, b = tableau(ALG_TSIT5)
+    bt = TSIT5_BTILDE
+    f = lambda u, t: aug_f(spec, p, u, t, eps, ys).astype(np.float64)
+    u = np.asarray(u0, dtype=np.float64).copy()
+    n = u.size
+    tdir = 1.0 if t1 >= t0 else -1.0
+    span = abs(t1 - t0)
+    rms = lambda x: math.sqrt(float((x * x).sum()) / n)
+    k1 = f(u, t0)
+    nf = 1
+    if dt0 is None:
+        sk = abstol + np.abs(u) * reltol
+        d0, d1 = rms(u / sk), rms(k1 / sk)
+        h0 = 1e-6 if (d0 < 1e-5 or d1 < 1e-5) else 0.01 * d0 / d1
+        h0 = min(h0, span)
+        f1 = f(u + tdir * h0 * k1, t0 + tdir * h0)
+        nf += 1
+        d2 = rms((f1 - k1) / sk) / h0
+        dm = max(d1, d2)
+        h1 = max(1e-6, h0 * 1e-3) if dm <= 1e-15 else 10.0 ** (-(2.0 + math.log10(dm)) / 5.0)
+        dt = min(100.0 * h0, h1, span)
+    else:
+        dt = min(abs(dt0), span)
+    beta1, beta2, gamma, qmin, qmax, qold = 7.0 / 50.0, 2.0 / 25.0, 0.9, 0.2, 10.0, 1e-4
+    t = t0
+    stats = {"naccept": 0, "nreject": 0, "dts": []}
+    for _ in range(maxiters):
+        if abs(t1 - t) <= 1e-12 * max(1.0, span):
+            break
+        last = dt >= abs(t1 - t) * (1.0 - 1e-12)
+        h = tdir * (abs(t1 - t) if last else dt)
+        ks = [k1]
+        for i in range(1, 6):
+            ui = u.copy()
+            for j, aij in enumerate(a[i]):
+                if aij != 0.0:
+                    ui = ui + h * aij * ks[j]
+            ks.append(f(ui, t + c[i] * h))
+        un = u.copy()
+        for bi, ki in zip(b, ks):
+            un = un + h * bi * ki
+        k7 = f(un, t + h)
+        nf += 6
+        ut = h * sum(bti * ki for bti, ki in zip(bt, ks + [k7]))
+        eest = rms(ut / (abstol + np.maximum(np.abs(u), np.abs(un)) * reltol))
+        q11 = eest ** beta1 if eest > 0 else 0.0
+        q = 1.0 / qmax if eest == 0 else max(1.0 / qmax, min(1.0 / qmin, (q11 / qold ** beta2) / gamma))
+        if eest <= 1.0:
+            t = t1 if last else t + h
+            u, k1 = un, k7
+            qold = max(eest, 1e-4)
+            stats["naccept"] += 1
+            stats["dts"].append(h)
+            dt = abs(h) / q
+        else:
+            stats["nreject"] += 1
+            dt = abs(h) / min(1.0 / qmin, q11 / gamma)
+    else:
+        raise RuntimeError("maxiters")
+    stats["nf"] = nf
+    return u, stats
+
+
 def std_normal_logpdf(z: np.ndarray) -> np.ndarray:
     """logpdf of MvNormal(Zeros(d), Eye(d)) per column (src/core/icnf.jl:76-79)."""
     d = z.shape[0]

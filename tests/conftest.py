@@ -24,6 +24,10 @@ def pkg():
 
 @pytest.fixture(scope="session")
 def oracles():
+    # the fp64 oracle issues thousands of tiny autograd calls; on a many-core host torch's default intra-op
+    # thread count makes each of them crawl (measured on the 128-core GPU box: 0.25 s per call vs 2 ms at 8)
+    import torch
+    torch.set_num_threads(min(8, torch.get_num_threads()))
     return entry.load_oracle()
 
 

@@ -49,8 +49,10 @@ def test_dimension_and_method_errors(pkg):
     icnf = pkg.ICNF(nvariables=2)
     with pytest.raises(NotImplementedError, match="VCABM"):
         icnf._solver()
-    icnf = pkg.ICNF(nvariables=2, sol_kwargs=dict(alg=pkg.Tsit5(), adaptive=True))
-    with pytest.raises(NotImplementedError):
+    icnf = pkg.ICNF(nvariables=2, sol_kwargs=dict(alg=pkg.Tsit5()))          # OrdinaryDiffEq default: adaptive
+    assert icnf._solver() == 1 and icnf.adaptive
+    icnf = pkg.ICNF(nvariables=2, sol_kwargs=dict(alg=pkg.RK4()))            # no embedded pair on this path
+    with pytest.raises(NotImplementedError, match="adaptive"):
         icnf._solver()
     icnf = pkg.ICNF(nvariables=2, sol_kwargs=dict(alg=pkg.RK4(), adaptive=False, dt=1 / 40))
     assert icnf._solver() == 0 and icnf._nsteps(0.0, 1.0) == 40

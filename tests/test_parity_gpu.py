@@ -1049,6 +1049,74 @@ def test_custom_base_and_probe_distributions(pkg, oracles):
     assert torch.equal(b, c)
 
 
+def _adaptive_icnf(pkg, spec, tol, path=0, **kw):
+    icnf = make_icnf(pkg, spec, 1, 1, path=path)
+    icnf.sol_kwargs = dict(alg=pkg.Tsit5(), reltol=tol, abstol=tol, **kw)       # adaptive by default, as in OrdinaryDiffEq
+    return icnf
+
+
+@pytest.mark.parametrize("kw,tol", [
+    (dict(nvars=8, hidden=[64, 64, 64]), 1e-4),                                             # fused kernel, the reference's default tolerances
+    (dict(nvars=8, hidden=[64, 64, 64], reg_z=True, reg_j=True), 1e-6),
+    (dict(nvars=3, ncond=2, hidden=[24, 24], act=2, mode=2), 1e-5),                         # exact trace, conditioned
+    (dict(nvars=4, hidden=[32, 32, 32, 32, 32]), 1e-5),                                     # layer-wise path (five hidden layers)
+])
+def test_adaptive_tsit5_follows_the_oracle_restatement(kw, tol, pkg, oracles):
+    """Adaptive Tsit5 (PI controller on the host, one cnf_step_embedded attempt per step) against the fp64 oracle's
+    restatement of the same algorithm: same accepted / rejected counts, the same step sizes to 1e-3, the same
+    final state; and against a fine fixed-step solve to within the tolerance."""
+    o64, _ = oracles
+    spec = o64.make_spec(**kw)
+    B = 40
+    p, xs, eps, ys = o64.synth_inputs(spec, B, 77, bias_scale=0.3)
+    p = (p * 2.0).astype(np.float32)                                                        # stiffer field: a dozen steps
+    icnf = _adaptive_icnf(pkg, spec, tol)
+    logp, regs, u1 = run_inference(pkg, icnf, spec, p, xs, eps, ys, return_state=True)
+    st = icnf.last_solve_stats
+    u0 = np.vstack([xs.astype(np.float64), np.zeros((spec.naug + 3, B))])
+    uref, sref = o64.integrate_adaptive_tsit5(spec, p, u0, 0.0, 1.0, tol, tol, eps, ys)
+    # the controller sees a float32 error estimate: at the reference's tolerance (1e-4) the step sequence is the
+    # oracle's; near float32's noise floor (1e-6) an accept/size decision may differ by a step
+    # (the embedded estimate is a small difference of O(1) stage derivatives, so below ~1e-5 its float32 rounding
+    # noise moves the PI controller's step sizes; the solution stays within the tolerance)
+    assert abs(st["naccept"] - sref["naccept"]) <= (0 if tol >= 1e-4 else 3), (st, sref)
+    assert abs(st["nreject"] - sref["nreject"]) <= (0 if tol >= 1e-4 else 3), (st, sref)
+    assert st["naccept"] >= 5
+    if tol >= 1e-4:
+        assert np.allclose(st["dts"], sref["dts"], rtol=1e-2), (st["dts"], sref["dts"])
+    else:
+        assert abs(st["dts"][0] - sref["dts"][0]) < 1e-2 * sref["dts"][0]                    # Hairer's initial step
+    assert st["nf"] == 2 + 7 + 6 * (st["naccept"] + st["nreject"] - 1)                     # first-same-as-last / retry reuse
+    assert np.max(np.abs(u1.cpu().numpy() - uref)) < 2e-4
+    fine = o64.integrate_fixed(spec, p, u0, 0.0, 1.0, 40, 1, eps, ys)
+    assert np.max(np.abs(u1.cpu().numpy() - fine)) < 50 * tol + 2e-4
+    z = uref[:spec.D]
+    lp = -0.5 * spec.D * np.log(2 * np.pi) - 0.5 * (z * z).sum(0) - uref[spec.D]
+    assert np.max(np.abs(logp.cpu().numpy() - lp)) < 2e-4
+
+
+def test_adaptive_solve_couples_the_batch_and_round_trips(pkg, oracles):
+    """The error norm runs over the whole S x B state (OrdinaryDiffEq's default norm), so the step sequence - and the
+    last digits of every column - depend on the batch composition, unlike the fixed-step solve; generate with the
+    adaptive solver inverts inference to the tolerance."""
+    o64, _ = oracles
+    spec = o64.make_spec(nvars=8, hidden=[64, 64, 64])
+    p, xs, eps, _ = o64.synth_inputs(spec, 3000, 5, bias_scale=0.3)
+    p = (p * 2.0).astype(np.float32)
+    xs[:, 2000:] *= 3.0                                                                     # harder columns at the end
+    icnf = _adaptive_icnf(pkg, spec, 1e-5)
+    full = run_inference(pkg, icnf, spec, p, xs, eps, None, return_state=True)
+    steps_full = list(icnf.last_solve_stats["dts"])
+    head = run_inference(pkg, icnf, spec, p, xs[:, :2000], eps[:, :2000], None)
+    steps_head = list(icnf.last_solve_stats["dts"])
+    assert steps_full != steps_head
+    assert float((full[0][:2000] - head[0]).abs().max()) < 5e-3                             # same solution to the tolerance (RMS-controlled)
+    m = pkg.TrainMode(False)
+    z1 = full[2][:8]
+    back = pkg.generate(icnf, m, dev(p), {}, 3000, z0=z1, eps=dev(eps))
+    assert float((back - dev(xs)).abs().max()) < 5e-3
+
+
 def test_errors_surface_as_exceptions(pkg, oracles):
     o64, _ = oracles
     spec = o64.make_spec(nvars=8, hidden=[64, 64, 64])
