@@ -1,0 +1,85 @@
+"""GPU, world_size 2 (gloo; both ranks share the one device, RCCL would refuse that): the sharded product path.
+Each rank runs the HIP kernels on its contiguous column block; loss and gradient are all-reduced inside
+`loss` / `loss_and_gradient`, and the adaptive solve all-reduces its error sum so both ranks take the steps of the
+unsharded solve."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _build(pkg, o64, spec, sol_kwargs):
+    acts = ["identity", "tanh", "softplus"]
+    layers = [pkg.Dense(spec.widths[i], spec.widths[i + 1], acts[spec.acts[i]]) for i in range(len(spec.acts))]
+    return pkg.ICNF(nvariables=spec.nvars, naugments=spec.naug, nn=pkg.Chain(*layers), steer_rate=0.0,
+                    lambda1=0.02 if spec.reg_z else 0.0, lambda2=0.03 if spec.reg_j else 0.0, lambda3=0.0,
+                    device="cuda:0", sol_kwargs=sol_kwargs)
+
+
+def _case(pkg, o64):
+    spec = o64.make_spec(8, [64, 64, 64], reg_z=True, reg_j=True)
+    B = 1001                                                   # ragged: 501 + 500
+    p, xs, eps, _ = o64.synth_inputs(spec, B, 33, bias_scale=0.2)
+    return spec, B, (p * 1.5).astype(np.float32), xs, eps
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as entry
+    pkg = entry.load_package()
+    o64, _ = entry.load_oracle()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        spec, B, p, xs, eps = _case(pkg, o64)
+        lo, hi = pkg.shard_columns(B, rank, world)
+        dev = lambda a: torch.tensor(np.ascontiguousarray(a), device="cuda:0")
+        m = pkg.TrainMode(True)
+        fixed = _build(pkg, o64, spec, dict(alg=pkg.Tsit5(), adaptive=False, nsteps=10))
+        val, g = pkg.loss_and_gradient(fixed, m, dev(xs[:, lo:hi]), dev(p), {}, eps=dev(eps[:, lo:hi]))
+        lval = pkg.loss(fixed, m, dev(xs[:, lo:hi]), dev(p), {}, eps=dev(eps[:, lo:hi]))
+        adap = _build(pkg, o64, spec, dict(alg=pkg.Tsit5(), reltol=1e-4, abstol=1e-4))
+        logp = pkg.inference(adap, m, dev(xs[:, lo:hi]), dev(p), {}, eps=dev(eps[:, lo:hi]))[0]
+        q.put((rank, float(val), float(lval), g.cpu().numpy(), logp.cpu().numpy(), list(adap.last_solve_stats["dts"])))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_ranks_on_the_gpu_reproduce_the_unsharded_results(pkg, oracles):
+    o64, _ = oracles
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29700 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    res = sorted((q.get(timeout=500) for _ in procs), key=lambda r: r[0])
+    for pr in procs:
+        pr.join(60)
+        assert pr.exitcode == 0
+    # unsharded reference in this process (no process group here)
+    spec, B, p, xs, eps = _case(pkg, o64)
+    dev = lambda a: torch.tensor(np.ascontiguousarray(a), device="cuda:0")
+    m = pkg.TrainMode(True)
+    fixed = _build(pkg, o64, spec, dict(alg=pkg.Tsit5(), adaptive=False, nsteps=10))
+    val, g = pkg.loss_and_gradient(fixed, m, dev(xs), dev(p), {}, eps=dev(eps))
+    adap = _build(pkg, o64, spec, dict(alg=pkg.Tsit5(), reltol=1e-4, abstol=1e-4))
+    logp = pkg.inference(adap, m, dev(xs), dev(p), {}, eps=dev(eps))[0].cpu().numpy()
+    dts = list(adap.last_solve_stats["dts"])
+    assert len(dts) >= 4
+    for rank, v, lv, gr, lp, d in res:
+        assert abs(v - float(val)) < 1e-5 and abs(lv - float(val)) < 1e-5          # global mean on every rank
+        assert np.max(np.abs(gr - g.cpu().numpy())) < 2e-5 * float(g.abs().max())  # all-reduced gradient = unsharded gradient
+        assert np.allclose(d, dts, rtol=1e-6), (d, dts)                            # the unsharded solve's steps
+        lo, hi = pkg.shard_columns(B, rank, 2)
+        assert np.max(np.abs(lp - logp[lo:hi])) < 1e-5
+    assert res[0][5] == res[1][5]                                                  # both ranks took identical steps
