@@ -147,9 +147,30 @@ def cpu_baseline(o64, oc, spec, alg, p, xs, eps, ys, target_s):
     oc.inference_fixed(spec, p, xs[:, :Bs], 0.0, 1.0, NSTEPS, alg, eps[:, :Bs],
                        None if ys is None else ys[:, :Bs], nthreads=nt)
     dt = time.perf_counter() - t
-    return dict(value=Bs * NSTEPS / dt, unit="samples*steps/s", cores=nt, kind="port",
-                sample=f"{Bs} of the workload's columns, one full {NSTEPS}-step solve, "
-                       f"{dt:.1f} s, oracle/cnf_oracle.c (gcc -O3 -march=x86-64-v3 -fopenmp, tanh_fast)")
+    out = dict(value=Bs * NSTEPS / dt, unit="samples*steps/s", cores=nt, kind="port",
+               sample=f"{Bs} of the workload's columns, one full {NSTEPS}-step solve, "
+                      f"{dt:.1f} s, oracle/cnf_oracle.c (gcc -O3 -march=x86-64-v3 -fopenmp, tanh_fast)")
+    # CPU-favourable cross-check: the same unfused algorithm with every product a library
+    # GEMM (torch.mm, MKL/oneDNN, float32), Hutchinson-VJP configurations only; a few seconds of work
+    if spec.mode == 0:
+        try:
+            import torch
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            import cnf_oracle_torch32 as t32
+            nthr0 = torch.get_num_threads()
+            torch.set_num_threads(min(16, nthr0))   # small GEMMs: more threads than this only add overhead
+            Bt = int(min(xs.shape[1], 8192))
+            yt = None if ys is None else ys[:, :Bt]
+            t32.inference_fixed(spec, p, xs[:, :256], 0.0, 1.0, 2, alg, eps[:, :256], None if ys is None else ys[:, :256])
+            t = time.perf_counter()
+            t32.inference_fixed(spec, p, xs[:, :Bt], 0.0, 1.0, NSTEPS, alg, eps[:, :Bt], yt)
+            dtt = time.perf_counter() - t
+            out["torch_f32_gemm"] = dict(value=Bt * NSTEPS / dtt, threads=torch.get_num_threads(),
+                                         sample=f"{Bt} columns, {dtt:.1f} s, oracle/cnf_oracle_torch32.py")
+            torch.set_num_threads(nthr0)
+        except Exception as ex:  # pragma: no cover - the cross-check is optional
+            out["torch_f32_gemm"] = dict(error=str(ex)[:200])
+    return out
 
 
 def main():

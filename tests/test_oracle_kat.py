@@ -138,3 +138,17 @@ def test_columns_are_independent(oracles):
     a = oc.inference_fixed(spec, p, xs, 0.0, 1.0, 3, o64.ALG_TSIT5, eps)[0]
     b = oc.inference_fixed(spec, p, xs[:, perm], 0.0, 1.0, 3, o64.ALG_TSIT5, eps[:, perm])[0]
     assert np.array_equal(a[perm], b)
+
+
+def test_torch_f32_gemm_restatement_matches_the_fp64_oracle(oracles):
+    """oracle/cnf_oracle_torch32.py (bench.py's CPU-favourable timing cross-check): RNODE, two probes, conditioned."""
+    import os, sys
+    from conftest import ROOT
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import cnf_oracle_torch32 as t32
+    o64, _ = oracles
+    spec = o64.make_spec(nvars=5, naug=1, ncond=3, hidden=[32, 32], act=2, nprobes=2, reg_z=True, reg_j=True)
+    p, xs, eps, ys = o64.synth_inputs(spec, 33, 9, bias_scale=0.2)
+    ref = o64.inference_fixed(spec, p, xs, 0.0, 1.0, 8, o64.ALG_TSIT5, eps, ys)[0]
+    got = t32.inference_fixed(spec, p, xs, 0.0, 1.0, 8, o64.ALG_TSIT5, eps, ys)
+    assert np.max(np.abs(got - ref)) < 5e-5
