@@ -25,7 +25,7 @@ ARITH_F32, ARITH_BF16X6 = 0, 1
 
 EXPORTS = ("cnf_version", "cnf_last_error", "cnf_create", "cnf_destroy", "cnf_set_params",
            "cnf_kernel_path", "cnf_repack_on_device", "cnf_aug_f", "cnf_integrate_fixed", "cnf_inference_fixed",
-           "cnf_loss_sums", "cnf_loss_grad_fixed", "cnf_grad_path", "cnf_step_embedded", "cnf_assemble_u0",
+           "cnf_loss_sums", "cnf_loss_grad_fixed", "cnf_loss_grad_grid", "cnf_grad_path", "cnf_step_embedded", "cnf_assemble_u0",
            "cnf_epilogue")
 
 
@@ -78,6 +78,8 @@ def load():
     lib.cnf_kernel_path.argtypes = [vp]
     lib.cnf_repack_on_device.argtypes = [vp]
     lib.cnf_grad_path.argtypes = [vp]
+    lib.cnf_loss_grad_grid.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_float), fp, fp, fp, C.c_int64,
+                                       C.POINTER(C.c_float), fp, fp, fp, vp]
     lib.cnf_step_embedded.argtypes = [vp, C.c_int, C.c_int, C.c_float, C.c_float, fp, fp, fp, C.c_int64, C.c_float,
                                       C.c_float, fp, fp, vp]
     lib.cnf_assemble_u0.argtypes = [vp, fp, C.c_int64, fp, vp]

@@ -530,6 +530,55 @@ int cnf_inference_fixed(cnf_handle* h, int alg, int nsteps, float t0, float t1, 
     return CNF_OK;
 }
 
+// fixed steps on a given grid: u advanced in place, 6 (Tsit5) or 4 (RK4) evaluations per step on the handle's family
+static int integrate_grid(cnf_handle* h, int alg, int nsteps, const float* tgrid, float* u, const float* eps, const float* ys,
+                          int64_t B, hipStream_t st);
+
+int cnf_loss_grad_grid(cnf_handle* h, int alg, int nsteps, const float* tgrid, const float* x, const float* eps,
+                       const float* ys, int64_t B, const float* lambdas, float* grad, float* grad_x, float* sums4,
+                       void* stream) {
+    int rc = check_call(h, eps, ys, B, "cnf_loss_grad_grid");
+    if (rc) return rc;
+    if (nsteps < 1 || !tgrid) return fail(CNF_ERR_INVALID, "cnf_loss_grad_grid: nsteps >= 1 and a grid of nsteps + 1 times required");
+    if (alg != CNF_ALG_RK4 && alg != CNF_ALG_TSIT5) return fail(CNF_ERR_INVALID, "cnf_loss_grad_grid: unknown alg");
+    if (!x || !grad || !lambdas) return fail(CNF_ERR_INVALID, "cnf_loss_grad_grid: null x/grad/lambdas");
+    if (!layered_grad_supported(h->cfg))
+        return fail(CNF_ERR_UNSUPPORTED, "cnf_loss_grad_grid: the gradient is implemented for the Hutchinson modes (TrainMode)");
+    DeviceGuard g(h->cfg.device_id);
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipMemsetAsync(grad, 0, h->nparams * sizeof(float), st));
+    if (B == 0) {
+        if (sums4) HIP_TRY(hipMemsetAsync(sums4, 0, 4 * sizeof(float), st));
+        return CNF_OK;
+    }
+    const int ra = (h->cfg.reg_aug && h->cfg.naug > 0) ? 1 : 0;
+    if (sums4) {   // the loss of the same discrete solve: augmented state advanced over the grid, then the epilogue
+        const size_t need = ((size_t)h->S + 4) * (size_t)B * sizeof(float);
+        if (need > h->grad_ws_bytes) {
+            if (h->grad_ws) HIP_TRY(hipFree(h->grad_ws));
+            h->grad_ws = nullptr; h->grad_ws_bytes = 0;
+            HIP_TRY(hipMalloc((void**)&h->grad_ws, need));
+            h->grad_ws_bytes = need;
+        }
+        float* u = h->grad_ws;
+        float* logp = u + (size_t)h->S * B;
+        float* regs = logp + B;
+        HIP_TRY(assemble_u0(x, h->cfg.nvars, h->S, B, u, st));
+        rc = integrate_grid(h, alg, nsteps, tgrid, u, eps, ys, B, st);
+        if (rc) return rc;
+        HIP_TRY(epilogue(u, h->cfg.nvars, h->D, ra, B, logp, regs, st));
+        if (!h->loss_partial) HIP_TRY(hipMalloc((void**)&h->loss_partial, 256 * 4 * sizeof(float)));
+        HIP_TRY(loss_sums(logp, regs, B, h->loss_partial, sums4, st));
+    }
+    const float lam[3] = {h->cfg.reg_z ? lambdas[0] : 0.f, h->cfg.reg_j ? lambdas[1] : 0.f, ra ? lambdas[2] : 0.f};
+    std::string msg;
+    hipError_t e = layered_grad(&h->layered, h->cfg, h->P_dev, h->w_off.data(), h->b_off.data(), x, eps, ys, alg, nsteps,
+                                tgrid[0], tgrid[nsteps], tgrid, B, lam, grad, grad_x, st, &msg);
+    if (e == hipErrorNotSupported) return fail(CNF_ERR_UNSUPPORTED, "cnf_loss_grad_grid: " + msg);
+    if (e != hipSuccess) return fail(CNF_ERR_HIP, "cnf_loss_grad_grid: " + msg);
+    return CNF_OK;
+}
+
 // f(u + dt sum coef k, t) on whichever family serves the handle; `stage` is scratch for the fused path, whose
 // single-call kernel takes the stage state itself
 static int eval_dynamics(cnf_handle* h, const StageIn& in, float t, const float* eps, const float* ys, int64_t B, float* du,
@@ -547,6 +596,37 @@ static int eval_dynamics(cnf_handle* h, const StageIn& in, float t, const float*
         return CNF_OK;
     }
     return generic_aug_f(h, in, t, eps, ys, B, du, first, st);
+}
+
+static int integrate_grid(cnf_handle* h, int alg, int nsteps, const float* tgrid, float* u, const float* eps, const float* ys,
+                          int64_t B, hipStream_t st) {
+    const size_t n = (size_t)h->S * (size_t)B;
+    if (B > h->ebuf_B) {
+        if (h->ebuf) HIP_TRY(hipFree(h->ebuf));
+        h->ebuf = nullptr; h->ebuf_B = 0;
+        HIP_TRY(hipMalloc((void**)&h->ebuf, 8 * n * sizeof(float)));
+        h->ebuf_B = B;
+    }
+    const size_t slot = (size_t)h->S * (size_t)h->ebuf_B;
+    float* stage = h->ebuf + 7 * slot;
+    float* k[6];
+    for (int i = 0; i < 6; ++i) k[i] = h->ebuf + (size_t)i * slot;
+    const Tableau T = make_tableau(alg);
+    for (int s = 0; s < nsteps; ++s) {
+        const float tn = tgrid[s], dt = tgrid[s + 1] - tgrid[s];
+        for (int i = 0; i < T.ns; ++i) {
+            StageIn in{};
+            in.u = u; in.nprev = i; in.dt = dt;
+            for (int j = 0; j < i; ++j) { in.k[j] = k[j]; in.coef[j] = T.a[i][j]; }
+            int rc = eval_dynamics(h, in, tn + T.c[i] * dt, eps, ys, B, k[i], stage, s == 0 && i == 0, st);
+            if (rc) return rc;
+        }
+        StageIn fin{};
+        fin.u = u; fin.nprev = T.ns; fin.dt = dt;
+        for (int j = 0; j < T.ns; ++j) { fin.k[j] = k[j]; fin.coef[j] = T.b[j]; }
+        HIP_TRY(rk_update(u, fin, (int64_t)n, st));
+    }
+    return CNF_OK;
 }
 
 int cnf_step_embedded(cnf_handle* h, int alg, int flags, float t, float dt, const float* u, const float* eps,
@@ -688,7 +768,7 @@ int cnf_loss_grad_fixed(cnf_handle* h, int alg, int nsteps, float t0, float t1, 
         const float lam[3] = {h->cfg.reg_z ? lambdas[0] : 0.f, h->cfg.reg_j ? lambdas[1] : 0.f, ra ? lambdas[2] : 0.f};
         std::string msg;
         hipError_t e = layered_grad(&h->layered, h->cfg, h->P_dev, h->w_off.data(), h->b_off.data(), x, eps, ys, alg, nsteps,
-                                    t0, t1, B, lam, grad, grad_x, st, &msg);
+                                    t0, t1, nullptr, B, lam, grad, grad_x, st, &msg);
         if (e == hipErrorNotSupported) return fail(CNF_ERR_UNSUPPORTED, "cnf_loss_grad_fixed: " + msg);
         if (e != hipSuccess) return fail(CNF_ERR_HIP, "cnf_loss_grad_fixed: " + msg);
         return CNF_OK;

@@ -93,8 +93,8 @@ bool layered_grad_supported(const cnf_config& c);
 void layered_grad_destroy(LayeredGrad* g);
 hipError_t layered_grad(LayeredGrad** ctx, const cnf_config& c, const float* P_dev, const size_t* w_off,
                         const size_t* b_off, const float* x, const float* eps, const float* ys, int alg,
-                        int nsteps, float t0, float t1, long long B, const float lam[3], float* grad, float* grad_x,
-                        hipStream_t st, std::string* err);
+                        int nsteps, float t0, float t1, const float* tgrid, long long B, const float lam[3], float* grad,
+                        float* grad_x, hipStream_t st, std::string* err);
 int mfma_plan_zr(const MfmaPlan* p);   // state k-steps of the forward instance (checkpoint stride)
 bool mfma_plan_is_per_wave(const MfmaPlan* p);
 

@@ -482,8 +482,8 @@ hipError_t layered_aug_f(LayeredGrad** ctx, const cnf_config& c, const float* P_
 
 hipError_t layered_grad(LayeredGrad** ctx, const cnf_config& c, const float* P_dev, const size_t* w_off,
                         const size_t* b_off, const float* x, const float* eps, const float* ys, int alg,
-                        int nsteps, float t0, float t1, long long B, const float lam[3], float* grad, float* grad_x,
-                        hipStream_t st, std::string* err) {
+                        int nsteps, float t0, float t1, const float* tgrid, long long B, const float lam[3], float* grad,
+                        float* grad_x, hipStream_t st, std::string* err) {
     Blas& bl = blas();
     if (!bl.ok) {
         *err = "layered gradient: librocblas.so.5 could not be loaded (dlopen)";
@@ -593,7 +593,10 @@ hipError_t layered_grad(LayeredGrad** ctx, const cnf_config& c, const float* P_d
     };
 
     const Tableau T = make_tableau(alg);
-    const float dt = (t1 - t0) / (float)nsteps;
+    // step n runs from tgrid[n] to tgrid[n+1] when a grid is given (frozen steps of an adaptive solve), else uniform
+    float dt = (t1 - t0) / (float)nsteps;
+    auto step_t = [&](int n) { return tgrid ? tgrid[n] : t0 + (float)n * ((t1 - t0) / (float)nsteps); };
+    auto step_dt = [&](int n) { return tgrid ? tgrid[n + 1] - tgrid[n] : (t1 - t0) / (float)nsteps; };
     const int ns = T.ns;
     // stage derivatives of one step from z_n (z rows only: the gradient needs no trace here)
     auto stage_derivs = [&](const float* zn, float tn) -> rocblas_status {
@@ -615,7 +618,8 @@ hipError_t layered_grad(LayeredGrad** ctx, const cnf_config& c, const float* P_d
     hipLaunchKernelGGL(init_state_kernel, grid_for(DB), dim3(TPB), 0, st, x, zck, c.nvars, D, B);
     float* kck = W + o_kck;
     for (int n = 0; n < nsteps; ++n) {
-        LG_BLAS(stage_derivs(zck + (long long)n * DB, t0 + (float)n * dt));
+        dt = step_dt(n);
+        LG_BLAS(stage_derivs(zck + (long long)n * DB, step_t(n)));
         if (keep_k)
             for (int j = 0; j < ns; ++j)
                 LG_HIP(hipMemcpyAsync(kck + ((long long)n * ns + j) * DB, kz[j], (size_t)DB * sizeof(float), hipMemcpyDeviceToDevice, st));
@@ -630,7 +634,8 @@ hipError_t layered_grad(LayeredGrad** ctx, const cnf_config& c, const float* P_d
     const float invK = 1.f / (float)K;
     for (int n = nsteps - 1; n >= 0; --n) {
         const float* zn = zck + (long long)n * DB;
-        const float tn = t0 + (float)n * dt;
+        dt = step_dt(n);
+        const float tn = step_t(n);
         if (keep_k) { for (int j = 0; j < ns; ++j) kz[j] = kck + ((long long)n * ns + j) * DB; }
         else LG_BLAS(stage_derivs(zn, tn));
         for (int i = ns - 1; i >= 0; --i) {

@@ -720,8 +720,6 @@ def loss_and_gradient(icnf: ICNF, mode: Mode, *args, eps: Optional[torch.Tensor]
         raise NotImplementedError("loss_and_gradient: PlanarLayer nets are not covered by the gradient kernel")
     if icnf.basedist is not None:
         raise NotImplementedError("loss_and_gradient: the terminal costate assumes basedist = MvNormal(0, I)")
-    if icnf.adaptive:
-        raise NotImplementedError("loss_and_gradient differentiates the fixed-step solve: use adaptive=False")
     h = icnf._handle(mode)
     icnf._bind_params(h, ps)
     dev = icnf.device
@@ -734,8 +732,23 @@ def loss_and_gradient(icnf: ICNF, mode: Mode, *args, eps: Optional[torch.Tensor]
     gx = torch.zeros(B, icnf.nvariables, device=dev, dtype=torch.float32) if wrt_x else None
     sums = torch.empty(4, device=dev, dtype=torch.float32)
     lam = (C.c_float * 3)(icnf.lambda1, icnf.lambda2, icnf.lambda3)
-    _lib.check(h.lib.cnf_loss_grad_fixed(h.ptr, icnf._solver(), icnf._nsteps(t0, t1), t0, t1, _ptr(x), _ptr(e),
-                                         _ptr(y), B, lam, _ptr(grad), _ptr(gx), _ptr(sums), _stream_ptr(dev)))
+    if icnf.adaptive:
+        # differentiate the discrete solve on the steps the adaptive solver accepted (frozen grid; the dependence
+        # of the step sizes on ps is ignored - the discretise-then-optimise convention)
+        u0 = torch.empty(B, icnf.S, device=dev, dtype=torch.float32)
+        _lib.check(h.lib.cnf_assemble_u0(h.ptr, _ptr(x), B, _ptr(u0), _stream_ptr(dev)))
+        _adaptive_integrate(icnf, h, u0, t0, t1, e, y, group=group)
+        ts = [t0]
+        for d in icnf.last_solve_stats["dts"]:
+            ts.append(ts[-1] + d)
+        ts[-1] = t1
+        grid = (C.c_float * len(ts))(*ts)
+        icnf.last_solve_stats["tgrid"] = ts
+        _lib.check(h.lib.cnf_loss_grad_grid(h.ptr, icnf._solver(), len(ts) - 1, grid, _ptr(x), _ptr(e), _ptr(y), B, lam,
+                                            _ptr(grad), _ptr(gx), _ptr(sums), _stream_ptr(dev)))
+    else:
+        _lib.check(h.lib.cnf_loss_grad_fixed(h.ptr, icnf._solver(), icnf._nsteps(t0, t1), t0, t1, _ptr(x), _ptr(e),
+                                             _ptr(y), B, lam, _ptr(grad), _ptr(gx), _ptr(sums), _stream_ptr(dev)))
     value = reduce_loss(sums, B, (icnf.lambda1, icnf.lambda2, icnf.lambda3), group=group)
     gps = reduce_gradient(grad, B, group=group)
     if not wrt_x:

@@ -197,6 +197,15 @@ int cnf_loss_grad_fixed(cnf_handle* h, int alg, int nsteps, float t0, float t1, 
                         const float* eps, const float* ys, int64_t B, const float* lambdas,
                         float* grad, float* grad_x, float* sums4, void* stream);
 
+/* The same sum and gradients on a NON-UNIFORM grid of fixed steps: step n runs from tgrid[n] to tgrid[n+1]
+ * (tgrid: HOST array of nsteps + 1 times).  This is how a loss evaluated with the adaptive solver is
+ * differentiated: the accepted steps are frozen and the discrete solve on that grid is reversed (the dependence
+ * of the step sizes on the parameters is ignored, the usual discretise-then-optimise convention).  Layer-wise
+ * gradient path for every shape; the loss sums come from the same grid solve. */
+int cnf_loss_grad_grid(cnf_handle* h, int alg, int nsteps, const float* tgrid, const float* x, const float* eps,
+                       const float* ys, int64_t B, const float* lambdas, float* grad, float* grad_x, float* sums4,
+                       void* stream);
+
 /* Which implementation cnf_loss_grad_fixed uses for this handle: 0 = none (CNF_ERR_UNSUPPORTED),
  * 1 = fused reverse-sweep kernel (cnf_grad.hip / cnf_grad_probes.hip), 2 = layer-wise reverse sweep on
  * rocBLAS GEMMs (cnf_layered.hip; librocblas.so.5 is loaded with dlopen at first use). */

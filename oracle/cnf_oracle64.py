@@ -364,8 +364,9 @@ def synth_inputs(spec: Spec, B: int, seed: int, bias_scale: float = 0.0):
 # (discretise-then-optimise); this fp64 autograd version is the oracle a future HIP backward
 # kernel will be checked against.  Hutchinson VJP and JVP modes.
 # ----------------------------------------------------------------------------------------
-def loss_and_grad(spec: Spec, p, xs, t0, t1, nsteps, alg, eps, ys=None, lambdas=(0.0, 0.0, 0.0), wrt_x=False):
-    """Returns (loss, dloss/dp) with p in the flat Lux layout, all in float64; with wrt_x also dloss/dxs."""
+def loss_and_grad(spec: Spec, p, xs, t0, t1, nsteps, alg, eps, ys=None, lambdas=(0.0, 0.0, 0.0), wrt_x=False, tgrid=None):
+    """Returns (loss, dloss/dp) with p in the flat Lux layout, all in float64; with wrt_x also dloss/dxs.
+    tgrid (nsteps + 1 times) replaces the uniform grid: fixed steps frozen from an adaptive solve."""
     spec.check()
     assert spec.mode in (MODE_HUTCH_VJP, MODE_HUTCH_JVP), "gradient oracle: Hutchinson modes"
     D, K = spec.D, spec.nprobes
@@ -408,6 +409,8 @@ def loss_and_grad(spec: Spec, p, xs, t0, t1, nsteps, alg, eps, ys=None, lambdas=
     u = torch.cat([x, torch.zeros(spec.naug + 3, B, dtype=torch.float64)], dim=0)
     for n in range(nsteps):
         tn = t0 + n * dt
+        if tgrid is not None:
+            tn, dt = float(tgrid[n]), float(tgrid[n + 1]) - float(tgrid[n])
         ks = []
         for i in range(len(c)):
             ui = u

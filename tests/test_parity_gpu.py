@@ -1095,6 +1095,33 @@ def test_adaptive_tsit5_follows_the_oracle_restatement(kw, tol, pkg, oracles):
     assert np.max(np.abs(logp.cpu().numpy() - lp)) < 2e-4
 
 
+@pytest.mark.parametrize("kw,lam", [
+    (dict(nvars=8, hidden=[64, 64, 64], reg_z=True, reg_j=True), (0.02, 0.03, 0.0)),
+    (dict(nvars=3, naug=2, ncond=2, hidden=[24, 48, 24], act=2, nprobes=2, reg_aug=True), (0.0, 0.0, 0.05)),
+])
+def test_gradient_of_the_adaptive_solve_on_its_frozen_grid(kw, lam, pkg, oracles):
+    """loss_and_gradient with the adaptive solver: the accepted steps are frozen and the discrete solve on that
+    non-uniform grid is reversed (cnf_loss_grad_grid) - against fp64 autograd on the same grid."""
+    o64, _ = oracles
+    spec = o64.make_spec(**kw)
+    B = 45
+    p, xs, eps, ys = o64.synth_inputs(spec, B, 88, bias_scale=0.3)
+    p = (p * 2.0).astype(np.float32)
+    icnf = _adaptive_icnf(pkg, spec, 1e-4)
+    icnf.lambda1, icnf.lambda2, icnf.lambda3 = lam
+    mode = pkg.TrainMode(True)
+    args = (dev(xs),) + ((dev(ys),) if spec.ncond else ()) + (dev(p), {})
+    val, g, gx = pkg.loss_and_gradient(icnf, mode, *args, eps=dev(eps), wrt_x=True)
+    ts = icnf.last_solve_stats["tgrid"]
+    assert len(ts) >= 5 and ts[0] == 0.0 and ts[-1] == 1.0 and len(set(np.round(np.diff(ts), 6))) > 1   # non-uniform
+    L, gref, gxref = o64.loss_and_grad(spec, p, xs, 0.0, 1.0, len(ts) - 1, 1, eps, ys, lam, wrt_x=True, tgrid=ts)
+    assert abs(float(val) - L) < 1e-4
+    assert np.max(np.abs(g.cpu().numpy() - gref)) < 5e-5 * np.abs(gref).max() + 1e-6
+    assert np.max(np.abs(gx.cpu().numpy() - gxref)) < 5e-5 * np.abs(gxref).max() + 1e-7
+    # and the loss of the grid solve is the loss the adaptive inference reports
+    assert abs(float(val) - float(pkg.loss(icnf, mode, *args, eps=dev(eps)))) < 1e-4
+
+
 def test_adaptive_solve_couples_the_batch_and_round_trips(pkg, oracles):
     """The error norm runs over the whole S x B state (OrdinaryDiffEq's default norm), so the step sequence - and the
     last digits of every column - depend on the batch composition, unlike the fixed-step solve; generate with the
