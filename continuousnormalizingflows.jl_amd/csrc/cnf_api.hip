@@ -657,6 +657,26 @@ int cnf_step_embedded(cnf_handle* h, int alg, int flags, float t, float dt, cons
     float* k[7];
     for (int i = 0; i < 7; ++i) k[i] = h->ebuf + (size_t)h->ek[i] * slot;
     const Tableau T = make_tableau(CNF_ALG_TSIT5);
+    // b - bhat of the embedded 4th-order solution (Tsitouras 2011); satisfies the order-4 conditions to 1e-15
+    static const float btilde[7] = {-0.00178001105222577714f, -0.0008164344596567469f, 0.007880878010261995f,
+                                    -0.1447110071732629f, 0.5823571654525552f, -0.45808210592918697f,
+                                    0.015151515151515152f};
+    if (h->path == CNF_PATH_MFMA && mfma_plan_is_per_wave(h->plan)) {
+        // fused attempt: the six stages and the update in ONE launch of the solve kernel (nsteps = 1), which also
+        // writes every stage derivative; then the 7th stage at u_new and the error reduction.  (The fused step
+        // evaluates its own first stage, so the FSAL / RETRY hints save nothing here; 3 launches instead of 14.)
+        for (int i = 0; i < 7; ++i) k[i] = h->ebuf + (size_t)i * n;   // [stage][B][S], packed for this B
+        SolveArgs a{};
+        a.u0 = u; a.eps = eps; a.ys = ys; a.B = B; a.nsteps = 1; a.alg = CNF_ALG_TSIT5; a.t0 = t; a.t1 = t + dt;
+        a.u_out = u_new; a.nvars = h->cfg.nvars; a.reg_aug = 0; a.kfull = h->ebuf;
+        HIP_TRY(mfma_solve(h->plan, h->packed_dev, a, st));
+        StageIn last{};
+        last.u = u_new; last.nprev = 0; last.dt = 0.f;
+        rc = eval_dynamics(h, last, t + dt, eps, ys, B, k[6], stage, false, st);
+        if (rc) return rc;
+        HIP_TRY(embedded_error(u, u_new, k, btilde, 7, dt, abstol, reltol, (int64_t)n, h->err_partial, err_sumsq, st));
+        return CNF_OK;
+    }
     if (!(flags & (CNF_STEP_FSAL | CNF_STEP_RETRY))) {
         StageIn in{};
         in.u = u; in.nprev = 0; in.dt = 0.f;
@@ -678,10 +698,6 @@ int cnf_step_embedded(cnf_handle* h, int alg, int flags, float t, float dt, cons
     last.u = u_new; last.nprev = 0; last.dt = 0.f;
     rc = eval_dynamics(h, last, t + dt, eps, ys, B, k[6], stage, false, st);   // 7th stage = first stage of the next step
     if (rc) return rc;
-    // b - bhat of the embedded 4th-order solution (Tsitouras 2011); satisfies the order-4 conditions to 1e-15
-    static const float btilde[7] = {-0.00178001105222577714f, -0.0008164344596567469f, 0.007880878010261995f,
-                                    -0.1447110071732629f, 0.5823571654525552f, -0.45808210592918697f,
-                                    0.015151515151515152f};
     HIP_TRY(embedded_error(u, u_new, k, btilde, 7, dt, abstol, reltol, (int64_t)n, h->err_partial, err_sumsq, st));
     return CNF_OK;
 }

@@ -68,8 +68,9 @@ struct SolveArgs {
     float* logp;     // B or null
     float* regs;     // 3B or null
     int nvars, reg_aug;
-    float* ckpt;     // optional checkpoint buffers (see KArgs::ckpt, ckpt_k)
+    float* ckpt;     // optional checkpoint buffers (see KArgs::ckpt, ckpt_k, kfull)
     float* ckpt_k;
+    float* kfull;
 };
 hipError_t mfma_solve(MfmaPlan* p, const float* packed_dev, const SolveArgs& a, hipStream_t st);
 

@@ -25,6 +25,7 @@ struct KArgs {
     int prio_mode;      // 0 none, 1 waves 0..3 high, 2 waves 4.. high (SIMD partners = w, w+4)
     int* queue;         // dynamic tile queue (zeroed before the launch) or null = static stride
     float* ckpt;        // optional: z at the start of every step + final, [step][tile][lane][ZR] (gradient)
+    float* kfull;       // optional: all S rows of every stage derivative of ONE step, [stage][B][S] (adaptive attempts)
     float* ckpt_k;      // optional: stage derivatives zdot_i, [step * ns + stage][tile][lane][ZR] (gradient)
     Tableau T;
 };

@@ -435,6 +435,22 @@ mfma_solve_kernel(KArgs a) {
                 }
             }
             if (single) break;
+#ifndef CNF_NO_KFULL   // (A/B switch: the cost of this block on the metric kernel is measured with -DCNF_NO_KFULL)
+            if (a.kfull && valid) {
+                // all S rows of the step's stage derivatives in the ABI's layout, [stage][sample][row]: the embedded
+                // error estimate of an adaptive attempt (cnf_step_embedded, nsteps = 1).  Once per step, outside
+                // the stage loop, so the metric path pays one untaken branch per step.
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    if (j < ns) {
+                        float* kf = a.kfull + ((long long)j * a.B + smp) * S;
+#pragma unroll
+                        for (int s = 0; s < ZR; ++s) { const int f = 4 * s + g; if (f < D) kf[f] = kz[j][s]; }
+                        if (g == 0) { kf[D] = kl[j]; kf[D + 1] = ke[j]; kf[D + 2] = kn[j]; }
+                    }
+                }
+            }
+#endif
             float sl = 0.f, se = 0.f, sn = 0.f;
 #pragma unroll
             for (int j = 0; j < 6; ++j) {
