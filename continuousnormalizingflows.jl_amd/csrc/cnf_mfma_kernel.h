@@ -141,6 +141,9 @@ __device__ __forceinline__ void act_tile(const f32x4& a, f32x4& h, f32x4& d) {
         e1 = e1 + 1.f;
         const f32x2 r0 = {fast_rcp(e0[0]), fast_rcp(e0[1])}, r1 = {fast_rcp(e1[0]), fast_rcp(e1[1])};
         const f32x2 two = {2.f, 2.f}, one = {1.f, 1.f};
+        // (Do not name the packed instructions in inline asm here: the compiler inserts the MFMA -> VALU wait states
+        // (s_nop) only for instructions it selected itself, and an asm statement reading an accumulator tile
+        // right after the MFMAs returns garbage.  Measured anyway on values that were safe: no gain.)
         const f32x2 h0 = __builtin_elementwise_fma(r0, two, -one), h1 = __builtin_elementwise_fma(r1, two, -one);
         const f32x2 d0 = __builtin_elementwise_fma(-h0, h0, one), d1 = __builtin_elementwise_fma(-h1, h1, one);
         h = f32x4{h0[0], h0[1], h1[0], h1[1]};
