@@ -1155,3 +1155,43 @@ def test_errors_surface_as_exceptions(pkg, oracles):
         pkg.inference(icnf, pkg.TrainMode(), dev(xs), dev(p[:-1]), {})
     with pytest.raises(ValueError):
         pkg.inference(icnf, pkg.TrainMode(), torch.tensor(xs), dev(p), {})      # host tensor
+
+
+def test_abi_level_errors_and_grid_gradient(pkg, oracles):
+    """Direct C-ABI calls: status codes of the stepping / gradient entry points, and cnf_loss_grad_grid on a UNIFORM
+    RK4 grid against cnf_loss_grad_fixed (layer-wise grid path vs fused reverse-sweep kernel)."""
+    import ctypes as C
+    o64, _ = oracles
+    L = pkg._lib
+    spec = o64.make_spec(nvars=8, hidden=[64, 64, 64])
+    B = 300
+    p, xs, eps, _ = o64.synth_inputs(spec, B, 2, bias_scale=0.2)
+    icnf = make_icnf(pkg, spec, 0, 5, path=2, lambdas=(0.0, 0.0, 0.0))
+    mode = pkg.TrainMode(False)
+    h = icnf._handle(mode)
+    P = dev(p)
+    icnf._bind_params(h, P)
+    ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+    X = dev(xs.T.copy()); E = dev(eps.T.copy())                         # (B, rows) contiguous = column-major (rows, B)
+    lam = (C.c_float * 3)(0.0, 0.0, 0.0)
+    g1 = torch.empty(p.size, device="cuda:0"); g2 = torch.empty_like(g1)
+    s1 = torch.empty(4, device="cuda:0"); s2 = torch.empty_like(s1)
+    L.check(h.lib.cnf_loss_grad_fixed(h.ptr, 0, 5, 0.0, 1.0, ptr(X), ptr(E), None, B, lam, ptr(g1), None, ptr(s1), None))
+    grid = (C.c_float * 6)(*[i / 5 for i in range(6)])
+    L.check(h.lib.cnf_loss_grad_grid(h.ptr, 0, 5, grid, ptr(X), ptr(E), None, B, lam, ptr(g2), None, ptr(s2), None))
+    assert float((g1 - g2).abs().max()) < 2e-5 * float(g1.abs().max())
+    assert float((s1 - s2).abs().max()) < 1e-3 * float(s1.abs().max())
+    # status codes
+    u = torch.zeros(B, 11, device="cuda:0"); un = torch.empty_like(u); err = torch.zeros(1, dtype=torch.float64, device="cuda:0")
+    step = lambda alg, dtv, uu, unn, at, rt: h.lib.cnf_step_embedded(h.ptr, alg, 0, 0.0, dtv, ptr(uu), ptr(E), None, B, at, rt,
+                                                                   ptr(unn), ptr(err), None)
+    assert step(1, 0.1, u, un, 1e-4, 1e-4) == L.OK
+    assert step(0, 0.1, u, un, 1e-4, 1e-4) == L.ERR_INVALID              # RK4 has no embedded pair here
+    assert step(1, 0.1, u, u, 1e-4, 1e-4) == L.ERR_INVALID               # aliasing
+    assert step(1, 0.1, u, un, 0.0, 0.0) == L.ERR_INVALID                # both tolerances zero
+    assert b"tolerances" in h.lib.cnf_last_error()
+    assert h.lib.cnf_loss_grad_grid(h.ptr, 1, 0, grid, ptr(X), ptr(E), None, B, lam, ptr(g2), None, None, None) == L.ERR_INVALID
+    assert h.lib.cnf_loss_grad_grid(h.ptr, 1, 5, None, ptr(X), ptr(E), None, B, lam, ptr(g2), None, None, None) == L.ERR_INVALID
+    assert h.lib.cnf_epilogue(h.ptr, None, B, ptr(g2), None, None) == L.ERR_INVALID
+    assert h.lib.cnf_assemble_u0(h.ptr, ptr(X), -1, ptr(u), None) == L.ERR_INVALID
+    assert h.lib.cnf_grad_path(None) == L.ERR_INVALID and h.lib.cnf_repack_on_device(h.ptr) == 1
