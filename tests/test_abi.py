@@ -77,3 +77,14 @@ def test_null_arguments_are_errors_not_crashes(pkg):
     assert lib.cnf_aug_f(None, None, None, 0.0, None, None, 4, None) == pkg._lib.ERR_INVALID
     assert lib.cnf_inference_fixed(None, 0, 1, 0.0, 1.0, None, None, None, 4, None, None, None,
                                    None) == pkg._lib.ERR_INVALID
+
+
+def test_cpp_host_example_compiles_against_the_header(tmp_path):
+    """examples/abi_demo.cpp (a torch-free C++/HIP host on the C ABI) must keep compiling against include/cnf.h."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    subprocess.run([hipcc, "-O1", "--offload-arch=gfx950", "-I", os.path.join(ROOT, "include"), "-c",
+                    os.path.join(ROOT, "examples", "abi_demo.cpp"), "-o", str(tmp_path / "abi_demo.o")], check=True, timeout=300)

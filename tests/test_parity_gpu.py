@@ -1195,3 +1195,32 @@ def test_abi_level_errors_and_grid_gradient(pkg, oracles):
     assert h.lib.cnf_epilogue(h.ptr, None, B, ptr(g2), None, None) == L.ERR_INVALID
     assert h.lib.cnf_assemble_u0(h.ptr, ptr(X), -1, ptr(u), None) == L.ERR_INVALID
     assert h.lib.cnf_grad_path(None) == L.ERR_INVALID and h.lib.cnf_repack_on_device(h.ptr) == 1
+
+
+def test_plain_cpp_host_on_the_c_abi(pkg, oracles, tmp_path):
+    """examples/abi_demo.cpp: a C++/HIP host with no Python or torch in the process drives the library through
+    include/cnf.h (the call sequence of INTEGRATION.md's Julia glue) and reproduces the Python mirror's log-densities."""
+    import os, shutil, struct, subprocess
+    from conftest import ROOT
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    libdir = os.path.join(ROOT, "continuousnormalizingflows.jl_amd")
+    exe = str(tmp_path / "abi_demo")
+    subprocess.run([hipcc, "-O2", "--offload-arch=gfx950", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "abi_demo.cpp"),
+                    "-o", exe, "-L", libdir, "-lcnf_hip", f"-Wl,-rpath,{libdir}"], check=True, timeout=300)
+    o64, _ = oracles
+    spec = o64.make_spec(nvars=8, hidden=[64, 64, 64])
+    B, nsteps = 5000, 20
+    p, xs, eps, _ = o64.synth_inputs(spec, B, 14, bias_scale=0.2)
+    fin, fout = tmp_path / "in.bin", tmp_path / "out.bin"
+    with open(fin, "wb") as f:
+        f.write(struct.pack("6i", 8, 64, 3, B, nsteps, 1))
+        f.write(p.astype(np.float32).tobytes())
+        f.write(np.ascontiguousarray(xs.T, dtype=np.float32).tobytes())       # column-major (rows, B)
+        f.write(np.ascontiguousarray(eps.T, dtype=np.float32).tobytes())
+    r = subprocess.run([exe, str(fin), str(fout)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert "kernel_path=2" in r.stdout, r.stdout
+    got = np.fromfile(fout, dtype=np.float32)
+    icnf = make_icnf(pkg, spec, 1, nsteps)
+    ref = run_inference(pkg, icnf, spec, p, xs, eps, None)[0].cpu().numpy()
+    assert got.shape == ref.shape and np.array_equal(got, ref)              # same library, same inputs: same bits
