@@ -23,6 +23,14 @@
  *     not thread-safe; distinct handles are independent.
  *   - NaN/Inf in outputs is not an error (the reference ignores the solver retcode,
  *     src/core/base_icnf.jl:138-139).
+ *
+ * Entry points
+ *   lifetime / parameters    cnf_create, cnf_destroy, cnf_set_params
+ *   boundary A (per call)    cnf_aug_f                      du = augmented_f(u, p, t)
+ *   boundary B (whole solve) cnf_integrate_fixed, cnf_inference_fixed, cnf_loss_sums
+ *   caller-driven solves     cnf_assemble_u0, cnf_step_embedded (adaptive Tsit5 attempt), cnf_epilogue
+ *   training                 cnf_loss_grad_fixed, cnf_loss_grad_grid  (dloss/dps, optionally dloss/dxs)
+ *   introspection            cnf_version, cnf_last_error, cnf_kernel_path, cnf_grad_path, cnf_repack_on_device
  */
 #ifndef CNF_H
 #define CNF_H
