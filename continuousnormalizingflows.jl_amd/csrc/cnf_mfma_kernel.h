@@ -295,6 +295,19 @@ __device__ __forceinline__ void dyn_eval(const float* __restrict__ smem, int lan
 #pragma unroll
                 for (int mt = 0; mt < HT; ++mt) tau[mt] = acc[mt] * d[l][mt];
             }
+            if (LAY.v_wNr >= 0 && exact) {
+                // only J_pp = <W_N[p, :], tau> is needed: a dot with row p of W_N (kept in accumulator layout in the
+                // image) instead of a full 16-row last-layer product: DT * 4 HT MFMAs -> 4 HT fmas + one reduction
+                f32x4 wr[HT];
+                load_cvec<HT>(sm + LAY.v_wNr + p * MfmaLayout::vecC(HT), g, wr);
+                float jd = 0.f;
+#pragma unroll
+                for (int mt = 0; mt < HT; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) jd = fmaf(tau[mt][r], wr[mt][r], jd);
+                ld -= group_sum(jd);
+                continue;
+            }
             gemm_tiles<DT, 4 * HT>(sm + LAY.fN, lane, TileIn<HT>{tau}, gacc);  // W_N tau = J v
         }
         float dot = 0.f, n2 = 0.f;
