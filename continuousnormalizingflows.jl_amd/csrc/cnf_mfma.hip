@@ -284,6 +284,9 @@ void mfma_pack(const MfmaPlan* p, const float* lux, const size_t* w_off, const s
     for (int l = 1; l < L; ++l)
         pack_vecC(packed + Y.v_bh + (l - 1) * MfmaLayout::vecC(Y.HT), Y.HT, Hl(l + 1), [&](int f) { return fs * Bv(l, f); });
     pack_vecC(packed + Y.v_bN, Y.DT, D, [&](int f) { return Bv(L, f); });
+    if (Y.v_w1c >= 0)   // columns of W_1[:, 0:D] in accumulator layout (first-layer tangent of a unit seed = a column load)
+        for (int i = 0; i < D; ++i)
+            pack_vecC(packed + Y.v_w1c + i * MfmaLayout::vecC(Y.HT), Y.HT, Hl(1), [&](int f) { return fs * W(0, f, i); });
     if (Y.v_wNr >= 0)   // rows of W_N in accumulator layout (exact trace reads J_ii off a dot product instead of a last-layer product)
         for (int i = 0; i < D; ++i)
             pack_vecC(packed + Y.v_wNr + i * MfmaLayout::vecC(Y.HT), Y.HT, Hl(L), [&](int f) { return W(L, i, f); });

@@ -282,7 +282,8 @@ __device__ __forceinline__ void dyn_eval(const float* __restrict__ smem, int lan
                 f32x4 acc[HT];
 #pragma unroll
                 for (int mt = 0; mt < HT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-                gemm_tiles<HT, ZR>(sm + LAY.f1z, lane, RegIn<ZR>{ep}, acc);  // W_1[:,0:D] v
+                if (LAY.v_w1c >= 0 && exact) load_cvec<HT>(sm + LAY.v_w1c + p * MfmaLayout::vecC(HT), g, acc);   // W_1[:, p]: no product
+                else gemm_tiles<HT, ZR>(sm + LAY.f1z, lane, RegIn<ZR>{ep}, acc);  // W_1[:,0:D] v
 #pragma unroll
                 for (int mt = 0; mt < HT; ++mt) tau[mt] = acc[mt] * d[0][mt];
             }
