@@ -55,7 +55,7 @@ __global__ void gather_pack_kernel(const float* __restrict__ p, const int* __res
 
 // returns false (map left invalid) when the image is not a verified gather of the parameters
 bool build_pack_map(PackMap& m, size_t nparams, size_t npacked,
-                    const std::function<void(const float*, float*)>& pack) {
+                    const std::function<void(const float*, float*)>& pack, size_t skip_off = 0, size_t skip_len = 0) {
     m.valid = false;
     if (nparams == 0 || nparams >= (1u << 20)) return false;   // the ramp must stay exact after scaling
     std::vector<float> ones(nparams, 1.f), ramp(nparams), rnd(nparams);
@@ -69,6 +69,10 @@ bool build_pack_map(PackMap& m, size_t nparams, size_t npacked,
     pack(rnd.data(), p3.data());
     std::vector<int> idx(npacked);
     for (size_t j = 0; j < npacked; ++j) {
+        if (j >= skip_off && j < skip_off + skip_len) {   // region filled by its own device packer (not a gather)
+            idx[j] = -1; p1[j] = 0.f;
+            continue;
+        }
         if (p1[j] == 0.f) {
             if (p2[j] != 0.f || p3[j] != 0.f) return false;
             idx[j] = -1;
@@ -307,8 +311,10 @@ int cnf_set_params(cnf_handle* h, const float* p, size_t n, const size_t* w_off,
     if (want_grad && !h->grad_packed) HIP_TRY(hipMalloc((void**)&h->grad_packed, grad_packed_bytes(c)));
     if (mfma && !h->maps_built) {
         // one-time (per layout): derive and verify the gather maps from the host packers
+        size_t qo = 0, ql = 0;
+        (void)mfma_plan_q_region(h->plan, &qo, &ql);
         build_pack_map(h->map_fwd, n, mfma_packed_bytes(h->plan) / sizeof(float),
-                       [&](const float* src, float* dst) { mfma_pack(h->plan, src, w_off, b_off, dst); });
+                       [&](const float* src, float* dst) { mfma_pack(h->plan, src, w_off, b_off, dst); }, qo, ql);
         if (want_grad)
             build_pack_map(h->map_grad, n, grad_packed_bytes(c) / sizeof(float),
                            [&](const float* src, float* dst) { grad_pack(c, src, w_off, b_off, dst); });
@@ -346,6 +352,8 @@ int cnf_set_params(cnf_handle* h, const float* p, size_t n, const size_t* w_off,
                                maps[i]->idx, maps[i]->scale, outs[i], np);
             HIP_TRY(hipGetLastError());
         }
+        size_t qo = 0, ql = 0;
+        if (mfma_plan_q_region(h->plan, &qo, &ql)) HIP_TRY(mfma_pack_q_device(h->plan, src, w_off, h->packed_dev, st));
     } else {
         // host path: SIMT parameters (plain copy) and images that are not a gather (split-bf16)
         std::vector<float> host(n);

@@ -53,6 +53,9 @@ size_t mfma_packed_bytes(const MfmaPlan* p);
 void mfma_pack(const MfmaPlan* p, const float* lux, const size_t* w_off, const size_t* b_off,
                float* packed);
 const char* mfma_plan_name(const MfmaPlan* p);
+// the one image region that is not a gather of the parameters (Q of the two-hidden-layer exact trace), and its device packer
+bool mfma_plan_q_region(const MfmaPlan* p, size_t* off, size_t* len);
+hipError_t mfma_pack_q_device(const MfmaPlan* p, const float* lux_dev, const size_t* w_off, float* packed_dev, hipStream_t st);
 
 struct SolveArgs {
     // exactly one of x (nvars x B, u0 = [x;0]) or u0 (S x B) is non-null

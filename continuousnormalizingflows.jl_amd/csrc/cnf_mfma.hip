@@ -284,6 +284,18 @@ void mfma_pack(const MfmaPlan* p, const float* lux, const size_t* w_off, const s
     for (int l = 1; l < L; ++l)
         pack_vecC(packed + Y.v_bh + (l - 1) * MfmaLayout::vecC(Y.HT), Y.HT, Hl(l + 1), [&](int f) { return fs * Bv(l, f); });
     pack_vecC(packed + Y.v_bN, Y.DT, D, [&](int f) { return Bv(L, f); });
+    if (Y.qtr >= 0) {
+        // Q[a][b] = W_2[a][b] * (W_1[:,0:D] W_3)[b][a]: with two hidden layers tr J = sum_ab act'_2[a] Q[a][b] act'_1[b]
+        const int H1 = Hl(1), H2 = Hl(2);
+        std::vector<double> P((size_t)H1 * H2, 0.0);
+        for (int b = 0; b < H1; ++b)
+            for (int a = 0; a < H2; ++a) {
+                double acc = 0.0;
+                for (int i = 0; i < D; ++i) acc += (double)W(0, b, i) * (double)W(2, i, a);
+                P[(size_t)b * H2 + a] = acc;
+            }
+        pack_imgA(packed + Y.qtr, Y.HT, Y.HT, H2, H1, [&](int r, int k) { return (float)((double)W(1, r, k) * P[(size_t)k * H2 + r]); });
+    }
     if (Y.v_w1c >= 0)   // columns of W_1[:, 0:D] in accumulator layout (first-layer tangent of a unit seed = a column load)
         for (int i = 0; i < D; ++i)
             pack_vecC(packed + Y.v_w1c + i * MfmaLayout::vecC(Y.HT), Y.HT, Hl(1), [&](int f) { return fs * W(0, f, i); });
@@ -293,6 +305,39 @@ void mfma_pack(const MfmaPlan* p, const float* lux, const size_t* w_off, const s
 }
 
 // operand image for the gradient kernel: f32, no tanh pre-scale, forward + transposed
+// Device-side pack of the Q image (see mfma_pack): every element is W_2[a][b] * sum_i W_1[b][i] W_3[i][a] in the A-image
+// slot of (row a, column b); same arithmetic as the host packer (double accumulation, one rounding).
+__global__ void pack_q_kernel(const float* __restrict__ lux, float* __restrict__ img, int HT, int H1, int H2, int D,
+                              long long w0, long long w1, long long w2) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= HT * HT * 256) return;
+    const int j = e & 3, lane = (e >> 2) & 63, tile = e >> 8, kg = tile % HT, mt = tile / HT;
+    const int a = mfma_rowmap(mt, lane & 15), b = 16 * kg + 4 * j + (lane >> 4);
+    float v = 0.f;
+    if (a < H2 && b < H1) {
+        double acc = 0.0;
+        for (int i = 0; i < D; ++i) acc += (double)lux[w0 + b + (long long)H1 * i] * (double)lux[w2 + i + (long long)D * a];
+        v = (float)((double)lux[w1 + a + (long long)H2 * b] * acc);
+    }
+    img[e] = v;
+}
+
+bool mfma_plan_q_region(const MfmaPlan* p, size_t* off, size_t* len) {
+    if (!p || p->kind != 0 || p->lay.qtr < 0) return false;
+    *off = (size_t)p->lay.qtr;
+    *len = (size_t)MfmaLayout::imgA(p->lay.HT, p->lay.HT);
+    return true;
+}
+
+hipError_t mfma_pack_q_device(const MfmaPlan* p, const float* lux_dev, const size_t* w_off, float* packed_dev, hipStream_t st) {
+    const cnf_config& c = p->cfg;
+    const int D = c.nvars + c.naug, H1 = c.widths[1], H2 = c.widths[2], HT = p->lay.HT;
+    const int n = HT * HT * 256;
+    hipLaunchKernelGGL(pack_q_kernel, dim3((n + 255) / 256), dim3(256), 0, st, lux_dev, packed_dev + p->lay.qtr, HT, H1, H2, D,
+                       (long long)w_off[0], (long long)w_off[1], (long long)w_off[2]);
+    return hipGetLastError();
+}
+
 int mfma_plan_zr(const MfmaPlan* p) { return p->ZR; }
 bool mfma_plan_is_per_wave(const MfmaPlan* p) { return p->kind == 0; }
 

@@ -224,7 +224,25 @@ __device__ __forceinline__ void dyn_eval(const float* __restrict__ smem, int lan
     // from LDS each time, which costs LDS bandwidth the kernel has to spare and keeps the
     // register footprint flat.
     // K <= KP probes are live (KP is the instance's register capacity; K == KP == 1 for the hoisting instances)
-    const int nseed = (ENGINE == ENG_TAN && exact) ? D : K;
+    int nseed = (ENGINE == ENG_TAN && exact) ? D : K;
+    if constexpr (ENGINE == ENG_TAN && L == 2) {
+        if (LAY.qtr >= 0 && exact) {
+            // Two hidden layers: tr J = sum_ab act'_2[a] W_2[a][b] act'_1[b] (W_1[:,0:D] W_3)[b][a] = act'_2^T Q act'_1 with the
+            // constant Q = W_2 .* (W_1[:,0:D] W_3)^T packed beside the weights: ONE H x H product and a dot, instead of D
+            // tangent passes (the batched-Jacobian trace of src/core/utils.jl:79-88, icnf.jl:312, for the default architecture).
+            f32x4 qd[HT];
+#pragma unroll
+            for (int mt = 0; mt < HT; ++mt) qd[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            gemm_tiles<HT, 4 * HT>(smem + LAY.qtr, lane, TileIn<HT>{d[0]}, qd);
+            float tr = 0.f;
+#pragma unroll
+            for (int mt = 0; mt < HT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) tr = fmaf(qd[mt][r], d[1][mt][r], tr);
+            ld = -group_sum(tr);
+            nseed = 0;
+        }
+    }
     const float scale = (ENGINE == ENG_TAN && exact) ? 1.f : 1.f / (float)K;
 #pragma clang loop unroll(disable)
     for (int p = 0; p < nseed; ++p) {

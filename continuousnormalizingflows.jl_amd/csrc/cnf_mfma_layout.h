@@ -37,6 +37,7 @@ struct MfmaLayout {
     int b1;              // W_1[:, 0:D]^T                               M = D, K = H
     // C vectors
     int v_b1, v_w1t, v_bh, v_bN;
+    int qtr;             // tangent-engine layouts with L = 2: image of Q = W_2 .* (W_1[:,0:D] W_3)^T (exact trace = act'_2^T Q act'_1)
     int v_w1c;           // tangent-engine layouts only: column i of W_1[:, 0:D] as a C vector (exact trace: tau_1 = W_1 e_i)
     int v_wNr;           // tangent-engine layouts only: row i of W_N as a C vector, i < 4 ZR (exact trace: J_ii = <W_N[i,:], tau>)
     int total;           // floats
@@ -50,7 +51,7 @@ struct MfmaLayout {
 
     constexpr MfmaLayout(int HT_, int L_, int ZR_, int CR_, bool with_bwd, int arith_ = 0)
         : HT(HT_), L(L_), ZR(ZR_), CR(CR_), arith(arith_), DT((ZR_ + 3) / 4), KGZ((ZR_ + 3) / 4), KGC((CR_ + 3) / 4),
-          f1z(0), f1y(0), fh(0), fN(0), bN(0), bh(0), b1(0), v_b1(0), v_w1t(0), v_bh(0), v_bN(0), v_w1c(-1), v_wNr(-1),
+          f1z(0), f1y(0), fh(0), fN(0), bN(0), bh(0), b1(0), v_b1(0), v_w1t(0), v_bh(0), v_bN(0), qtr(-1), v_w1c(-1), v_wNr(-1),
           total(0) {
         int o = 0;
         f1z = o; o += imgA(HT, KGZ);
@@ -67,6 +68,9 @@ struct MfmaLayout {
         // (only where it still fits the 160 KB of LDS: the conditioned 3x128 instances with 4 state k-steps do not)
         v_wNr = -1;
         if (!with_bwd && (o + 4 * ZR_ * vecC(HT_)) * 4 <= 160 * 1024) { v_wNr = o; o += 4 * ZR_ * vecC(HT_); }
+        // two hidden layers (the reference's default architecture): tr J = act'_2^T Q act'_1 needs one H x H product
+        qtr = -1;
+        if (!with_bwd && L_ == 2 && arith_ == 0 && (o + imgA(HT_, HT_)) * 4 <= 160 * 1024) { qtr = o; o += imgA(HT_, HT_); }
         v_w1c = -1;
         if (!with_bwd && (o + 4 * ZR_ * vecC(HT_)) * 4 <= 160 * 1024) { v_w1c = o; o += 4 * ZR_ * vecC(HT_); }
         total = (o + 3) / 4 * 4;

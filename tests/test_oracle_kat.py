@@ -152,3 +152,26 @@ def test_torch_f32_gemm_restatement_matches_the_fp64_oracle(oracles):
     ref = o64.inference_fixed(spec, p, xs, 0.0, 1.0, 8, o64.ALG_TSIT5, eps, ys)[0]
     got = t32.inference_fixed(spec, p, xs, 0.0, 1.0, 8, o64.ALG_TSIT5, eps, ys)
     assert np.max(np.abs(got - ref)) < 5e-5
+
+
+def test_two_hidden_layer_trace_identity(oracles):
+    """The identity behind the fused exact-trace shortcut for the reference's default architecture (two hidden layers):
+    tr J = act'_2^T Q act'_1 with the constant Q = W_2 .* (W_1[:,0:D] W_3)^T  (csrc/cnf_mfma_kernel.h, mfma_pack)."""
+    o64, _ = oracles
+    spec = o64.make_spec(nvars=5, naug=2, ncond=3, hidden=[24, 40], act=2, mode=2)
+    p, xs, _, ys = o64.synth_inputs(spec, 9, 4, bias_scale=0.3)
+    u = np.vstack([xs.astype(np.float64), np.zeros((spec.naug + 3, 9))])
+    u[:spec.D] += 0.1 * np.random.default_rng(0).standard_normal((spec.D, 9))
+    t = 0.37
+    du = o64.aug_f(spec, p, u, t, None, ys)
+    layers = [(np.asarray(W, dtype=np.float64), np.asarray(b, dtype=np.float64)) for W, b in o64.unpack_params(spec, p)]
+    (W1, b1), (W2, b2), (W3, b3) = layers
+    D = spec.D
+    x = np.vstack([u[:D], np.full((1, 9), t), ys.astype(np.float64)])
+    sig = lambda a: 1.0 / (1.0 + np.exp(-a))
+    a1 = W1 @ x + b1[:, None]
+    h1 = np.log1p(np.exp(a1))
+    a2 = W2 @ h1 + b2[:, None]
+    Q = W2 * (W1[:, :D] @ W3).T
+    tr = np.einsum("aj,ab,bj->j", sig(a2), Q, sig(a1))
+    assert np.max(np.abs(du[D] + tr)) < 1e-12
