@@ -19,7 +19,12 @@ namespace cnf {
     GEN8(HT, 2, CNF_ACT_TANH, NT), GEN8(HT, 3, CNF_ACT_TANH, NT),                \
     GEN8(HT, 2, CNF_ACT_SOFTPLUS, NT), GEN8(HT, 3, CNF_ACT_SOFTPLUS, NT)
 
+// 7 hidden tiles, two hidden layers, tangent engine: H = 104 / 112 (default nets for nvariables = 12, 13) on the 8-tile instance
+// would not fit the Q image of the exact-trace shortcut in LDS; on 7 tiles it does
+#define GEN8_TAN7(ACT) MFMA_INST(7, 2, 8, 0, ACT, ENG_TAN, 1, 0, 256), MFMA_INST(7, 2, 8, 4, ACT, ENG_TAN, 1, 0, 256)
+
 static const Inst kGenericZr8[] = {
+    GEN8_TAN7(CNF_ACT_TANH), GEN8_TAN7(CNF_ACT_SOFTPLUS),
     GEN8_ACT(2, 512), GEN8_ACT(4, 256), GEN8_ACT(6, 256), GEN8_ACT(8, 256),   // HT = 4 spills at 2 waves/SIMD (8 state k-steps)
 };
 

@@ -65,14 +65,15 @@ struct MfmaLayout {
         v_w1t = o; o += vecC(HT);
         v_bh = o;  o += (L - 1) * vecC(HT);
         v_bN = o;  o += vecC(DT);
-        // (only where it still fits the 160 KB of LDS: the conditioned 3x128 instances with 4 state k-steps do not)
-        v_wNr = -1;
-        if (!with_bwd && (o + 4 * ZR_ * vecC(HT_)) * 4 <= 160 * 1024) { v_wNr = o; o += 4 * ZR_ * vecC(HT_); }
         // two hidden layers (the reference's default architecture): tr J = act'_2^T Q act'_1 needs one H x H product
         qtr = -1;
         if (!with_bwd && L_ == 2 && arith_ == 0 && (o + imgA(HT_, HT_)) * 4 <= 160 * 1024) { qtr = o; o += imgA(HT_, HT_); }
+        // otherwise the exact trace pushes D unit tangents: column p of W_1 and row p of W_N in accumulator layout save the
+        // first and last product of each (only where they still fit the 160 KB of LDS)
+        v_wNr = -1;
+        if (!with_bwd && qtr < 0 && (o + 4 * ZR_ * vecC(HT_)) * 4 <= 160 * 1024) { v_wNr = o; o += 4 * ZR_ * vecC(HT_); }
         v_w1c = -1;
-        if (!with_bwd && (o + 4 * ZR_ * vecC(HT_)) * 4 <= 160 * 1024) { v_w1c = o; o += 4 * ZR_ * vecC(HT_); }
+        if (!with_bwd && qtr < 0 && (o + 4 * ZR_ * vecC(HT_)) * 4 <= 160 * 1024) { v_w1c = o; o += 4 * ZR_ * vecC(HT_); }
         total = (o + 3) / 4 * 4;
     }
 };
