@@ -306,6 +306,29 @@ __global__ void exact_diag_kernel(const float* __restrict__ row, const float* __
     if (j < B) ld[j] -= row[j] * dN[j * D + i];
 }
 
+// Two hidden layers: Q[a][b] = W_2[a][b] * sum_i W_1[b][i] W_3[i][a]  (tr J = act'_2^T Q act'_1; see mfma_pack / pack_q_kernel)
+__global__ void layered_q_kernel(const float* __restrict__ PA, float* __restrict__ Q, LDesc L, int D) {
+    const int H1 = L.wout[0], H2 = L.wout[1];
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (long long)H1 * H2) return;
+    const int a = (int)(e % H2), b = (int)(e / H2);      // Q column-major (H2 x H1)
+    const float* W1 = PA + L.pa_off[0];
+    const float* W2 = PA + L.pa_off[1];
+    const float* W3 = PA + L.pa_off[2];
+    double acc = 0.0;
+    for (int i = 0; i < D; ++i) acc += (double)W1[b + (long long)H1 * i] * (double)W3[i + (long long)D * a];
+    Q[e] = (float)((double)W2[a + (long long)H2 * b] * acc);
+}
+
+// ldot = -<q_j, act'_2[:, j]> per column
+__global__ void neg_coldot_kernel(const float* __restrict__ x, const float* __restrict__ y, int rows, float* __restrict__ ld, long long B) {
+    const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= B) return;
+    float acc = 0.f;
+    for (int f = 0; f < rows; ++f) acc = fmaf(x[j * rows + f], y[j * rows + f], acc);
+    ld[j] = -acc;
+}
+
 // du = [zdot; ldot; |zdot| (reg_z); ndot]
 __global__ void finish_kernel(float* __restrict__ du, const float* __restrict__ aN, const float* __restrict__ ld,
                               const float* __restrict__ nd, int reg_z, int D, long long B) {
@@ -387,6 +410,8 @@ hipError_t layered_aug_f(LayeredGrad** ctx, const cnf_config& c, const float* P_
     long long off = 0;
     auto take = [&](long long n) { const long long o = off; off += (n + 63) / 64 * 64; return o; };
     const long long o_PA = take(npa);
+    const bool use_q = c.mode == CNF_MODE_EXACT && N == 3 && c.acts[2] == CNF_ACT_IDENTITY;   // two hidden layers
+    const long long o_Q = take(use_q ? (long long)L.wout[0] * L.wout[1] : 0);
     long long o_a[CNF_MAX_LAYERS + 1], o_d[CNF_MAX_LAYERS];
     o_a[0] = take((long long)(c.widths[0] + 1) * B);
     for (int l = 0; l < N; ++l) { o_a[l + 1] = take((long long)(L.wout[l] + 1) * B); o_d[l] = take((long long)L.wout[l] * B); }
@@ -405,8 +430,11 @@ hipError_t layered_aug_f(LayeredGrad** ctx, const cnf_config& c, const float* P_
     for (int l = 0; l <= N; ++l) a[l] = W + o_a[l];
     for (int l = 0; l < N; ++l) d[l] = W + o_d[l];
     float *tA = W + o_t0, *tB = W + o_t1, *ldacc = W + o_ld, *ndacc = W + o_nd, *row = W + o_row;
-    if (rebuild_params || grown)
+    float* Qm = W + o_Q;
+    if (rebuild_params || grown) {
         hipLaunchKernelGGL(aug_params_kernel, grid_for(npa), dim3(TPB), 0, st, P_dev, PA, L);
+        if (use_q) hipLaunchKernelGGL(layered_q_kernel, grid_for((long long)L.wout[0] * L.wout[1]), dim3(TPB), 0, st, PA, Qm, L, D);
+    }
 
     const float one = 1.f, zero = 0.f;
     auto gemm = [&](rocblas_operation ta, rocblas_operation tb, int m, long long n, int k, const float* A, int lda,
@@ -454,6 +482,10 @@ hipError_t layered_aug_f(LayeredGrad** ctx, const cnf_config& c, const float* P_
             hipLaunchKernelGGL(trace_kernel, grid_for(B), dim3(TPB), 0, st, tau, eps, K * D, k * D, ldacc, ndacc, 1.f / (float)K,
                                c.reg_j, D, B);
         }
+    } else if (use_q) {
+        // two hidden layers: tr J = act'_2^T Q act'_1 - one GEMM and a column dot instead of D tangent passes
+        LG_BLAS(gemm(OPN, OPN, L.wout[1], B, L.wout[0], Qm, L.wout[1], d[0], L.wout[0], tA, L.wout[1]));
+        hipLaunchKernelGGL(neg_coldot_kernel, grid_for(B), dim3(TPB), 0, st, tA, d[1], L.wout[1], ldacc, B);
     } else {
         // exact trace: unit tangents e_i pushed forward, J_ii read off the i-th output row (icnf.jl:312)
         for (int i = 0; i < D; ++i) {

@@ -174,8 +174,15 @@ MfmaPlan* mfma_plan_create(const cnf_config& c) {
         const Inst* gen8 = mfma_generic_zr8_insts(&ng8);
         const Inst* a4 = pick(gen, ng, false);
         const Inst* a8 = pick(gen8, ng8, false);
-        if (a4 && (!a8 || a4->HT <= a8->HT)) return make(*a4);
-        if (a8) return make(*a8);
+        const Inst* pickd = (a4 && (!a8 || a4->HT <= a8->HT)) ? a4 : a8;
+        if (pickd) {
+            // exact trace of a two-hidden-layer net whose Q image does not fit LDS beside this instance's images (8 hidden
+            // tiles with 8 state k-steps): D tangent passes here would lose to the layer-wise path's single Q GEMM
+            if (c.mode == CNF_MODE_EXACT && L == 2 && MfmaLayout(pickd->HT, L, pickd->ZR, pickd->CR, false).qtr < 0 &&
+                c.kernel_path == CNF_PATH_AUTO && layered_available())
+                return nullptr;
+            return make(*pickd);
+        }
         if (KP > 1) {
             const Inst* genp = mfma_generic_probe_insts(&ngp);
             if (const Inst* ap = pick(genp, ngp, true)) return make(*ap);
