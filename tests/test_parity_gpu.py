@@ -588,10 +588,11 @@ def test_randomised_shapes_fused_vs_generic_kernels(pkg, oracles):
         a = run_inference(pkg, make_icnf(pkg, spec, alg, nsteps, path=2), spec, p, xs, eps, ys, return_state=True)
         b = run_inference(pkg, make_icnf(pkg, spec, alg, nsteps, path=1), spec, p, xs, eps, ys, return_state=True)
         err = float((a[0] - b[0]).abs().max())
-        assert err < 5e-5, (kw, alg, nsteps, B, err)
-        assert float((a[2] - b[2]).abs().max()) < 5e-5, kw
+        tol = 5e-5 * max(1.0, float(b[0].abs().max()) / 64.0)          # float32: a few ulp of the largest |logp|
+        assert err < tol, (kw, alg, nsteps, B, err, tol)
+        assert float((a[2] - b[2]).abs().max()) < 5e-5 * max(1.0, float(b[2].abs().max()) / 64.0), kw
         for u, v in zip(a[1], b[1]):
-            assert float((u - v).abs().max()) < 5e-5, kw
+            assert float((u - v).abs().max()) < 5e-5 * max(1.0, float(v.abs().max()) / 64.0), kw
         checked += 1
         probes_checked += K > 1
     assert checked >= 45 and probes_checked >= 8, (checked, probes_checked)
