@@ -542,7 +542,8 @@ def test_randomised_gradient_shapes(pkg, oracles):
         assert np.max(np.abs(g.cpu().numpy() - gref)) < 5e-5 * sc + 1e-6, (kw, alg, nsteps, B)
         sx = np.abs(gxref).max()
         assert np.max(np.abs(gx.cpu().numpy() - gxref)) < 5e-5 * sx + 1e-7, (kw, alg, nsteps, B)
-    assert seen == {1, 2}, seen
+    if "CNF_FUZZ_SEED" not in os.environ:                              # the default seed exercises both implementations
+        assert seen == {1, 2}, seen
 
 
 def test_parameter_gradient_is_refused_in_exact_trace_mode(pkg, oracles):
