@@ -143,7 +143,10 @@ struct cnf_handle {
     int num_cus = 0;
     // device-side repacking (see PackMap): maps for the solve image and the gradient image, rebuilt
     // when the layout handed to cnf_set_params changes; p_stage holds host-supplied parameters
-    PackMap map_fwd, map_grad;
+    PackMap map_fwd, map_grad, map_slab;
+    float* slab_packed = nullptr;        // operand image of the slab-accumulator gradient kernel (cnf_grad_slab.hip)
+    float* slab_ws = nullptr;            // its checkpoints + slabs
+    size_t slab_ws_floats = 0;
     LayeredGrad* layered = nullptr;      // rocBLAS context + workspaces of the layer-wise evaluation / gradient
     // embedded-step workspace (cnf_step_embedded): 7 stage derivatives + 1 stage state, each S x ebuf_B
     float* ebuf = nullptr;
@@ -272,6 +275,9 @@ int cnf_destroy(cnf_handle* h) {
     layered_grad_destroy(h->layered);
     free_pack_map(h->map_fwd);
     free_pack_map(h->map_grad);
+    free_pack_map(h->map_slab);
+    if (h->slab_packed) (void)hipFree(h->slab_packed);
+    if (h->slab_ws) (void)hipFree(h->slab_ws);
     if (h->plan) mfma_plan_destroy(h->plan);
     delete h;
     return CNF_OK;
@@ -394,6 +400,23 @@ int cnf_set_params(cnf_handle* h, const float* p, size_t n, const size_t* w_off,
                 h->net.w_off[l] = (int)w_off[l];
                 h->net.b_off[l] = (int)b_off[l];
             }
+        }
+    }
+    // image of the slab-accumulator gradient kernel: a gather from the Lux-layout device copy kept above
+    if (grad_slab_supported(c) && !(mfma && want_grad)) {
+        const size_t sb = grad_slab_packed_bytes(c);
+        if (!h->slab_packed) HIP_TRY(hipMalloc((void**)&h->slab_packed, sb));
+        if (!h->map_slab.valid || !same_layout)
+            build_pack_map(h->map_slab, n, sb / sizeof(float),
+                           [&](const float* src, float* dst) { grad_slab_pack(c, src, w_off, b_off, dst); });
+        if (h->map_slab.valid) {
+            const size_t np = h->map_slab.n;
+            hipLaunchKernelGGL(gather_pack_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, st, h->P_dev,
+                               h->map_slab.idx, h->map_slab.scale, h->slab_packed, np);
+            HIP_TRY(hipGetLastError());
+        } else {
+            HIP_TRY(hipFree(h->slab_packed));
+            h->slab_packed = nullptr;
         }
     }
     h->nparams = n;
@@ -746,9 +769,15 @@ static bool grad_is_fused(const cnf_handle* h) {
            !(force && *force && *force != '0');
 }
 
+// slab-accumulator kernel for the mid-width two-hidden-layer nets (CNF_GRAD_LAYERED=1 skips it too)
+static bool grad_uses_slab(const cnf_handle* h) {
+    const char* force = getenv("CNF_GRAD_LAYERED");
+    return (h->slab_packed || !h->have_params) && grad_slab_supported(h->cfg) && !(force && *force && *force != '0');
+}
+
 int cnf_grad_path(const cnf_handle* h) {
     if (!h) return CNF_ERR_INVALID;
-    if (grad_is_fused(h)) return 1;
+    if (grad_is_fused(h) || grad_uses_slab(h)) return 1;
     return layered_grad_supported(h->cfg) ? 2 : 0;
 }
 
@@ -772,7 +801,7 @@ int cnf_loss_grad_fixed(cnf_handle* h, int alg, int nsteps, float t0, float t1, 
         return CNF_OK;
     }
     if (!fused) {
-        // layer-wise reverse sweep (cnf_layered.hip); the loss sums come from the regular solve
+        // the loss sums come from the regular solve on whichever family serves the handle
         if (sums4) {
             const size_t need = 4 * (size_t)B * sizeof(float);
             if (need > h->grad_ws_bytes) {
@@ -790,6 +819,24 @@ int cnf_loss_grad_fixed(cnf_handle* h, int alg, int nsteps, float t0, float t1, 
         }
         const int ra = (h->cfg.reg_aug && h->cfg.naug > 0) ? 1 : 0;
         const float lam[3] = {h->cfg.reg_z ? lambdas[0] : 0.f, h->cfg.reg_j ? lambdas[1] : 0.f, ra ? lambdas[2] : 0.f};
+        if (grad_uses_slab(h)) {
+            // two-hidden-layer nets of 4..7 hidden tiles: tile-fused reverse sweep with slab accumulators (cnf_grad_slab.hip)
+            if (h->num_cus == 0) {
+                hipDeviceProp_t prop;
+                HIP_TRY(hipGetDeviceProperties(&prop, h->cfg.device_id));
+                h->num_cus = prop.multiProcessorCount;
+            }
+            const size_t need = grad_slab_ws_floats(h->cfg, alg, nsteps, B, h->num_cus);
+            if (need > h->slab_ws_floats) {
+                if (h->slab_ws) HIP_TRY(hipFree(h->slab_ws));
+                h->slab_ws = nullptr; h->slab_ws_floats = 0;
+                HIP_TRY(hipMalloc((void**)&h->slab_ws, need * sizeof(float)));
+                h->slab_ws_floats = need;
+            }
+            HIP_TRY(grad_slab_launch(h->cfg, h->slab_packed, x, eps, h->w_off.data(), h->b_off.data(), alg, nsteps, t0, t1, B, lam,
+                                     h->slab_ws, grad, grad_x, h->num_cus, st));
+            return CNF_OK;
+        }
         std::string msg;
         hipError_t e = layered_grad(&h->layered, h->cfg, h->P_dev, h->w_off.data(), h->b_off.data(), x, eps, ys, alg, nsteps,
                                     t0, t1, nullptr, B, lam, grad, grad_x, st, &msg);

@@ -1,0 +1,493 @@
+// cnf_grad_slab.hip — parameter gradient for two-hidden-layer nets of 4..7 hidden tiles and up to 30 state rows:
+// the reference's default architecture for nvariables = 7 .. 11 (D = 2 n + 1, H = 8 n + 8, src/core/icnf.jl:62-71).
+//
+// Between the register-accumulator kernel (cnf_grad.hip: H <= 64, D <= 14) and the layer-wise path (cnf_layered.hip,
+// memory-bound and launch-bound at these widths: 64 ms per step at B = 1024, 170-240 ms at B = 65536).  Same reverse
+// sweep per 16-sample tile (see cnf_grad.hip for the mathematics), with two differences:
+//   * the weight cotangents do not fit the register file beside the per-stage quantities, so every wave keeps a
+//     PRIVATE slab in global memory (L2 / MALL resident) and updates a tile by load -> MFMA chain with the old value as
+//     the C operand -> store, a few tiles prefetched ahead; no cross-wave exchange, no barriers in the sweep.  One kernel
+//     sums the slabs in a fixed order at the end (no atomics, bit-reproducible);
+//   * the kernel is self-contained: it runs its own forward sweep from x first (checkpointing z_n and the stage
+//     derivatives in its tile layout), so it does not depend on which kernel family serves the forward solve.
+// Hutchinson VJP, one probe, no conditions; FFJORD and RNODE objectives incl. the augmented-dimension term.
+// The layer-1 input pseudo tile(s) are [z (D rows); t; 0 ..; 1 in the last column]: one tile for D <= 14, two for D <= 30.
+#include "cnf_grad_dev.h"
+
+namespace cnf {
+
+template <int HT, int ZR>
+struct SlabLay {   // float offsets inside one wave's slab; every image is [mt][nt][lane][4] (accumulator layout)
+    static constexpr int DT = (ZR + 3) / 4;
+    static constexpr int NT1 = DT;                                 // input tiles of layer 1
+    static constexpr int W1 = 0;                                   // [HT][NT1]
+    static constexpr int WH = W1 + HT * NT1 * 256;                 // [HT][HT]
+    static constexpr int WN = WH + HT * HT * 256;                  // [DT][HT]
+    static constexpr int BH = WN + DT * HT * 256;                  // [HT][1]: column 0 = bias of the second hidden layer
+    static constexpr int BN = BH + HT * 256;                       // [DT][1]: column 0 = bias of the last layer
+    static constexpr int TOTAL = BN + DT * 256;
+};
+
+__device__ __forceinline__ f32x4 slab_load(const float* p) {       // bypasses L1: always sees this wave's previous store
+    return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+}
+
+// transposed fragments of accumulator-layout tiles through ONE wave-private padded LDS slot (LDS operations of a
+// wave execute in order, so the slot is reused tile after tile)
+template <int MT>
+__device__ __forceinline__ void frags_A(float* __restrict__ slot, int lane, const f32x4 (&t)[MT], float (&f)[MT][4]) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) { tile_store(slot, lane, t[mt]); read_frag_A(slot, lane, f[mt]); }
+}
+template <int NT>
+__device__ __forceinline__ void frags_B(float* __restrict__ slot, int lane, const f32x4 (&t)[NT], float (&f)[NT][4]) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) { tile_store(slot, lane, t[nt]); read_frag_B(slot, lane, f[nt]); }
+}
+
+// slab tiles [MT][NT] += A1 B1^T (+ A2 B2^T): old values fetched PD tiles ahead of their MFMA chains
+template <int MT, int NT, bool TWO>
+__device__ __forceinline__ void outer_rmw(float* __restrict__ img, int lane, const float (&af1)[MT][4],
+                                          const float (&bf1)[NT][4], const float (&af2)[MT][4], const float (&bf2)[NT][4]) {
+    constexpr int NTILE = MT * NT;
+    constexpr int PD = NTILE < 4 ? NTILE : 4;
+    float* base = img + lane * 4;
+    f32x4 old[PD];
+#pragma unroll
+    for (int t = 0; t < PD; ++t) old[t] = slab_load(base + t * 256);
+#pragma unroll
+    for (int t = 0; t < NTILE; ++t) {
+        const int mt = t / NT, nt = t % NT;
+        f32x4 acc = old[t % PD];
+        if (t + PD < NTILE) old[t % PD] = slab_load(base + (t + PD) * 256);
+        acc = outer4(af1[mt], bf1[nt], acc);
+        if constexpr (TWO) acc = outer4(af2[mt], bf2[nt], acc);
+        *reinterpret_cast<f32x4*>(base + t * 256) = acc;
+    }
+}
+
+// dense-layout vector (register s, lane group g <-> row 4 s + g) -> accumulator-layout pseudo tile `it` (rows 16 it ..)
+template <int ZR>
+__device__ __forceinline__ f32x4 dense_tile_at(const float (&v)[ZR], int it) {
+    f32x4 t = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int s = 0; s < ZR; ++s) t[r] = (s == 4 * it + r) ? v[s] : t[r];
+    return t;
+}
+
+template <int HT, int ZR, int ACT>
+__global__ void __launch_bounds__(256)
+grad_slab_kernel(GArgs a, const float* __restrict__ x, float* __restrict__ ckz, float* __restrict__ ckk) {
+    constexpr int L = 2, CR = 0;
+    constexpr MfmaLayout LAY(HT, L, ZR, CR, true, 0);
+    using SL = SlabLay<HT, ZR>;
+    constexpr int DT = SL::DT, NT1 = SL::NT1;
+    constexpr int ONES = 16 * NT1 - 1;                              // bias column of the layer-1 input tiles
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    {
+        const f32x4* src = reinterpret_cast<const f32x4*>(a.packed);
+        f32x4* dst = reinterpret_cast<f32x4*>(smem);
+        for (int i = threadIdx.x; i < LAY.total / 4; i += 256) dst[i] = src[i];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, g = lane >> 4, n = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float* slot = smem + (LAY.total + 3) / 4 * 4 + wave * TS;
+    float* slab = a.slab + ((long long)blockIdx.x * 4 + wave) * SL::TOTAL;
+    float onesf[1][4];
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) onesf[0][q4] = (lane & 15) == 0 ? 1.f : 0.f;   // B fragment of the column e_0
+    const long long ntiles = (a.B + 15) / 16;
+    const int D = a.D;
+    const bool autonomous = a.autonomous;
+    const float dt = a.dt;
+    const int ns = a.T.ns;
+    const float y[1] = {0.f};
+
+    for (long long tile = (long long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long long)gridDim.x * 4) {
+        const long long smp = tile * 16 + n;
+        const bool valid = smp < a.B;
+        const long long sc = valid ? smp : a.B - 1;
+        float eps[ZR], lam[ZR];
+        // ---------------- forward sweep: checkpoints z_n and the stage derivatives ----------------
+        {
+            float z[ZR];
+#pragma unroll
+            for (int s = 0; s < ZR; ++s) {
+                const int f = 4 * s + g;
+                eps[s] = f < D ? a.eps[sc * D + f] : 0.f;
+                z[s] = f < a.nvars ? x[sc * a.nvars + f] : 0.f;     // u0 = [x; 0]
+            }
+#pragma clang loop unroll(disable)
+            for (int step = 0; step < a.nsteps; ++step) {
+                const float tn = a.t0 + (float)step * dt;
+#pragma unroll
+                for (int s = 0; s < ZR; ++s) ckz[(((long long)step * ntiles + tile) * 64 + lane) * ZR + s] = z[s];
+                float kz[6][ZR];
+#pragma unroll
+                for (int j = 0; j < 6; ++j)
+#pragma unroll
+                    for (int s = 0; s < ZR; ++s) kz[j][s] = 0.f;
+#pragma clang loop unroll(disable)
+                for (int st = 0; st < ns; ++st) {
+                    float zs[ZR];
+#pragma unroll
+                    for (int s = 0; s < ZR; ++s) {
+                        float acc = 0.f;
+#pragma unroll
+                        for (int j = 0; j < 5; ++j) acc = fmaf(a.T.a[st][j], kz[j][s], acc);
+                        zs[s] = fmaf(dt, acc, z[s]);
+                    }
+                    int opaque = 0;
+                    asm volatile("" : "+v"(opaque));
+                    const float* sm = smem + opaque;
+                    f32x4 h[L][HT], d[L][HT];
+                    grad_forward<HT, L, ZR, CR, ACT>(sm, lane, tn + a.T.c[st] * dt, autonomous, zs, y, h, d);
+                    f32x4 zacc[DT];
+                    load_cvec<DT>(sm + LAY.v_bN, g, zacc);
+                    gemm_tiles<DT, 4 * HT>(sm + LAY.fN, lane, TileIn<HT>{h[L - 1]}, zacc);
+#pragma unroll
+                    for (int s = 0; s < ZR; ++s) {
+                        const float v = zacc[s >> 2][s & 3];
+                        ckk[((((long long)step * ns + st) * ntiles + tile) * 64 + lane) * ZR + s] = v;
+#pragma unroll
+                        for (int j = 0; j < 6; ++j) kz[j][s] = (j == st) ? v : kz[j][s];
+                    }
+                }
+#pragma unroll
+                for (int s = 0; s < ZR; ++s) {
+                    float acc = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) acc = fmaf(a.T.b[j], kz[j][s], acc);
+                    z[s] = fmaf(dt, acc, z[s]);
+                }
+            }
+            // dL/dz_N = z_N  (L = sum_j -logp_j, -log N(z) = |z|^2/2 + const); zero for padding columns
+#pragma unroll
+            for (int s = 0; s < ZR; ++s) lam[s] = valid ? z[s] : 0.f;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the checkpoints written above are read back below by the same lanes
+        if (a.lam3 != 0.f) {   // + l3 |z_aug|_2 at the final time (src/core/base_icnf.jl:106-122)
+            float sa = 0.f;
+#pragma unroll
+            for (int s = 0; s < ZR; ++s) { const int f = 4 * s + g; if (f >= a.nvars && f < D) sa = fmaf(lam[s], lam[s], sa); }
+            sa = group_sum(sa);
+            const float inv = sa > 0.f ? a.lam3 * rsqrtf(sa) : 0.f;
+#pragma unroll
+            for (int s = 0; s < ZR; ++s) { const int f = 4 * s + g; if (f >= a.nvars && f < D) lam[s] = fmaf(inv, lam[s], lam[s]); }
+        }
+        f32x4 cvec[HT], qvec[HT];   // c = W_N^T eps, q = W_1[:,0:D] eps: constant over the solve
+        zero_tiles<HT>(cvec);
+        zero_tiles<HT>(qvec);
+        gemm_tiles<HT, ZR>(smem + LAY.bN, lane, RegIn<ZR>{eps}, cvec);
+        gemm_tiles<HT, ZR>(smem + LAY.f1z, lane, RegIn<ZR>{eps}, qvec);
+
+        // ---------------- reverse sweep ----------------
+#pragma clang loop unroll(disable)
+        for (int step = a.nsteps - 1; step >= 0; --step) {
+            const float tn = a.t0 + (float)step * dt;
+            float zn[ZR], kz[6][ZR], Zb[6][ZR];
+#pragma unroll
+            for (int s = 0; s < ZR; ++s) zn[s] = ckz[(((long long)step * ntiles + tile) * 64 + lane) * ZR + s];
+#pragma unroll
+            for (int j = 0; j < 6; ++j)
+#pragma unroll
+                for (int s = 0; s < ZR; ++s) {
+                    kz[j][s] = j < ns ? ckk[((((long long)step * ns + j) * ntiles + tile) * 64 + lane) * ZR + s] : 0.f;
+                    Zb[j][s] = 0.f;
+                }
+#pragma clang loop unroll(disable)
+            for (int st = ns - 1; st >= 0; --st) {
+                float zs[ZR], kbar[ZR];
+                const float bi = a.T.b[st];
+#pragma unroll
+                for (int s = 0; s < ZR; ++s) {
+                    float acc = 0.f, kb = bi * lam[s];
+#pragma unroll
+                    for (int j = 0; j < 5; ++j) acc = fmaf(a.T.a[st][j], kz[j][s], acc);
+#pragma unroll
+                    for (int j = 1; j < 6; ++j) kb = fmaf(a.T.a[j][st], Zb[j][s], kb);
+                    zs[s] = fmaf(dt, acc, zn[s]);
+                    kbar[s] = dt * kb;
+                }
+                const float cl = valid ? dt * bi : 0.f;
+                const float cE = cl * a.lam1, cn = cl * a.lam2;
+                const bool regz = a.lam1 != 0.f, regj = a.lam2 != 0.f;
+                const float tt = tn + a.T.c[st] * dt;
+                int opaque = 0;
+                asm volatile("" : "+v"(opaque));
+                const float* sm = smem + opaque;
+
+                // recompute and first-order pullback
+                f32x4 h[L][HT], d[L][HT], dl[L][HT], u0[HT];
+                grad_forward<HT, L, ZR, CR, ACT>(sm, lane, tt, autonomous, zs, y, h, d);
+#pragma unroll
+                for (int mt = 0; mt < HT; ++mt) dl[1][mt] = cvec[mt] * d[1][mt];
+                zero_tiles<HT>(u0);
+                gemm_tiles<HT, 4 * HT>(sm + LAY.bh, lane, TileIn<HT>{dl[1]}, u0);
+#pragma unroll
+                for (int mt = 0; mt < HT; ++mt) dl[0][mt] = u0[mt] * d[0][mt];
+                if (regz) {   // Edot = |zdot|: kbar += c_E zdot / |zdot|
+                    f32x4 zacc[DT];
+                    load_cvec<DT>(sm + LAY.v_bN, g, zacc);
+                    gemm_tiles<DT, 4 * HT>(sm + LAY.fN, lane, TileIn<HT>{h[1]}, zacc);
+                    float e2 = 0.f;
+#pragma unroll
+                    for (int s = 0; s < ZR; ++s) e2 = fmaf(zacc[s >> 2][s & 3], zacc[s >> 2][s & 3], e2);
+                    e2 = group_sum(e2);
+                    const float inv = e2 > 0.f ? cE * rsqrtf(e2) : 0.f;
+#pragma unroll
+                    for (int s = 0; s < ZR; ++s) kbar[s] = fmaf(inv, zacc[s >> 2][s & 3], kbar[s]);
+                }
+                float gbar[ZR];
+#pragma unroll
+                for (int s = 0; s < ZR; ++s) gbar[s] = -cl * eps[s];
+                f32x4 db[HT], a2[L][HT], ubs[HT];
+                if (regj) {
+                    f32x4 gacc[DT];
+                    zero_tiles<DT>(gacc);
+                    gemm_tiles<DT, 4 * HT>(sm + LAY.b1, lane, TileIn<HT>{dl[0]}, gacc);   // g = W_1[:,0:D]^T delta_1
+                    float n2 = 0.f;
+#pragma unroll
+                    for (int s = 0; s < ZR; ++s) n2 = fmaf(gacc[s >> 2][s & 3], gacc[s >> 2][s & 3], n2);
+                    n2 = group_sum(n2);
+                    const float inv = n2 > 0.f ? cn * rsqrtf(n2) : 0.f;
+#pragma unroll
+                    for (int s = 0; s < ZR; ++s) gbar[s] = fmaf(inv, gacc[s >> 2][s & 3], gbar[s]);
+                    zero_tiles<HT>(db);
+                    gemm_tiles<HT, ZR>(sm + LAY.f1z, lane, RegIn<ZR>{gbar}, db);          // dbar_1 = W_1[:,0:D] gbar
+                } else {
+#pragma unroll
+                    for (int mt = 0; mt < HT; ++mt) db[mt] = qvec[mt] * (-cl);
+                }
+#pragma unroll
+                for (int mt = 0; mt < HT; ++mt) { ubs[mt] = db[mt] * d[0][mt]; a2[0][mt] = db[mt] * u0[mt]; }
+                zero_tiles<HT>(db);
+                gemm_tiles<HT, 4 * HT>(sm + LAY.fh, lane, TileIn<HT>{ubs}, db);          // W_2 ubar_1
+                f32x4 cb[HT];
+#pragma unroll
+                for (int mt = 0; mt < HT; ++mt) { cb[mt] = db[mt] * d[1][mt]; a2[1][mt] = db[mt] * cvec[mt]; }
+
+                // Wbar_N += eps cbar^T + kbar h_2^T;  bbar_N += kbar x e_0
+                {
+                    f32x4 et[DT], kt[DT];
+#pragma unroll
+                    for (int it = 0; it < DT; ++it) { et[it] = dense_tile_at<ZR>(eps, it); kt[it] = dense_tile_at<ZR>(kbar, it); }
+                    float af1[DT][4], af2[DT][4], bf1[HT][4], bf2[HT][4];
+                    frags_A<DT>(slot, lane, et, af1);
+                    frags_A<DT>(slot, lane, kt, af2);
+                    frags_B<HT>(slot, lane, cb, bf1);
+                    frags_B<HT>(slot, lane, h[1], bf2);
+                    outer_rmw<DT, HT, true>(slab + SL::WN, lane, af1, bf1, af2, bf2);
+                    outer_rmw<DT, 1, false>(slab + SL::BN, lane, af2, onesf, af2, onesf);
+                }
+                f32x4 hb[HT];
+                zero_tiles<HT>(hb);
+                gemm_tiles<HT, ZR>(sm + LAY.bN, lane, RegIn<ZR>{kbar}, hb);               // W_N^T kbar
+                float Zbar[ZR];
+                {   // second hidden layer: Wbar_2 += abar_2 h_1^T + delta_2 ubar_1^T;  bbar_2 += abar_2 x e_0
+                    f32x4 ab[HT];
+#pragma unroll
+                    for (int mt = 0; mt < HT; ++mt) {
+                        const f32x4 d2 = ACT == CNF_ACT_TANH ? h[1][mt] * d[1][mt] * -2.f : d[1][mt] * (1.f - d[1][mt]);
+                        ab[mt] = hb[mt] * d[1][mt] + a2[1][mt] * d2;
+                    }
+                    float af[HT][4], bf[HT][4], af2[HT][4], bf2[HT][4];
+                    frags_A<HT>(slot, lane, ab, af);
+                    frags_B<HT>(slot, lane, h[0], bf);
+                    frags_A<HT>(slot, lane, dl[1], af2);
+                    frags_B<HT>(slot, lane, ubs, bf2);
+                    outer_rmw<HT, 1, false>(slab + SL::BH, lane, af, onesf, af, onesf);
+                    outer_rmw<HT, HT, true>(slab + SL::WH, lane, af, bf, af2, bf2);
+                    zero_tiles<HT>(hb);
+                    gemm_tiles<HT, 4 * HT>(sm + LAY.bh, lane, TileIn<HT>{ab}, hb);       // W_2^T abar_2
+                }
+                {   // first hidden layer: Wbar_1 += abar_1 [z; t; 1]^T + delta_1 [gbar; 0]^T
+                    f32x4 ab[HT];
+#pragma unroll
+                    for (int mt = 0; mt < HT; ++mt) {
+                        const f32x4 d2 = ACT == CNF_ACT_TANH ? h[0][mt] * d[0][mt] * -2.f : d[0][mt] * (1.f - d[0][mt]);
+                        ab[mt] = hb[mt] * d[0][mt] + a2[0][mt] * d2;
+                    }
+                    f32x4 in_t[NT1], gb_t[NT1];
+#pragma unroll
+                    for (int it = 0; it < NT1; ++it) {
+                        in_t[it] = dense_tile_at<ZR>(zs, it);          // rows >= D of zs are zero
+                        gb_t[it] = dense_tile_at<ZR>(gbar, it);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int f = 16 * it + 4 * r + g;
+                            if (!autonomous && f == D) in_t[it][r] = tt;
+                            if (f == ONES) in_t[it][r] = 1.f;
+                        }
+                    }
+                    float af[HT][4], af2[HT][4], bf[NT1][4], bf2[NT1][4];
+                    frags_A<HT>(slot, lane, ab, af);
+                    frags_A<HT>(slot, lane, dl[0], af2);
+                    frags_B<NT1>(slot, lane, in_t, bf);
+                    frags_B<NT1>(slot, lane, gb_t, bf2);
+                    outer_rmw<HT, NT1, true>(slab + SL::W1, lane, af, bf, af2, bf2);
+                    f32x4 zb[DT];
+                    zero_tiles<DT>(zb);
+                    gemm_tiles<DT, 4 * HT>(sm + LAY.b1, lane, TileIn<HT>{ab}, zb);       // W_1[:,0:D]^T abar_1
+#pragma unroll
+                    for (int s = 0; s < ZR; ++s) Zbar[s] = zb[s >> 2][s & 3];
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this stage's slab stores land before the tiles are re-read
+#pragma unroll
+                for (int j = 0; j < 6; ++j)
+#pragma unroll
+                    for (int s = 0; s < ZR; ++s) Zb[j][s] = (j == st) ? Zbar[s] : Zb[j][s];
+            }
+#pragma unroll
+            for (int s = 0; s < ZR; ++s) {
+                float acc = lam[s];
+#pragma unroll
+                for (int j = 0; j < 6; ++j) acc += Zb[j][s];
+                lam[s] = acc;
+            }
+        }
+        if (a.grad_x && valid) {
+#pragma unroll
+            for (int s = 0; s < ZR; ++s) {
+                const int f = 4 * s + g;
+                if (f < a.nvars) a.grad_x[smp * a.nvars + f] = lam[s];
+            }
+        }
+    }
+}
+
+// Sum the waves' slabs in a fixed order and scatter into the Lux-layout gradient (no atomics).
+template <int HT, int ZR>
+__global__ void __launch_bounds__(256)
+grad_slab_reduce_kernel(const float* __restrict__ slab, int nwaves, GArgs a, float* __restrict__ grad) {
+    using SL = SlabLay<HT, ZR>;
+    constexpr int ONES = 16 * SL::NT1 - 1;
+    __shared__ float part[4][64];
+    const int el = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + el;
+    float acc = 0.f;
+    if (e < SL::TOTAL)
+        for (int w = grp; w < nwaves; w += 4) acc += slab[(long long)w * SL::TOTAL + e];
+    part[grp][el] = acc;
+    __syncthreads();
+    if (grp != 0 || e >= SL::TOTAL) return;
+    const float sum = (part[0][el] + part[1][el]) + (part[2][el] + part[3][el]);
+    const int H1 = a.H, H2 = a.n_in /* second hidden width, see grad_slab_launch */, D = a.D;
+    const int ln = (e >> 2) & 63, r = e & 3, n = ln & 15, gg = ln >> 4;
+    const int ncore = D + (a.autonomous ? 0 : 1);
+    if (e < SL::WH) {                                   // W_1 image [mt][input tile]
+        const int tl = (e - SL::W1) / 256, mt = tl / SL::NT1, it = tl % SL::NT1;
+        const int out = 16 * mt + 4 * r + gg, col = 16 * it + n;
+        if (out < H1 && col < ncore) grad[a.w_off[0] + out + H1 * col] = sum;
+        if (out < H1 && col == ONES) grad[a.b_off[0] + out] = sum;
+    } else if (e < SL::WN) {                            // W_2 image [mt][nt]
+        const int tl = (e - SL::WH) / 256;
+        const int out = 16 * (tl / HT) + 4 * r + gg, in = 16 * (tl % HT) + n;
+        if (out < H2 && in < H1) grad[a.w_off[1] + out + H2 * in] = sum;
+    } else if (e < SL::BH) {                            // W_3 image [dt][nt]: rows = state features
+        const int tl = (e - SL::WN) / 256;
+        const int out = 16 * (tl / HT) + 4 * r + gg, in = 16 * (tl % HT) + n;
+        if (out < D && in < H2) grad[a.w_off[2] + out + D * in] = sum;
+    } else if (e < SL::BN) {
+        const int mt = (e - SL::BH) / 256;
+        const int out = 16 * mt + 4 * r + gg;
+        if (out < H2 && n == 0) grad[a.b_off[1] + out] = sum;
+    } else {
+        const int mt = (e - SL::BN) / 256;
+        const int out = 16 * mt + 4 * r + gg;
+        if (out < D && n == 0) grad[a.b_off[2] + out] = sum;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------
+struct SlabInst {
+    int HT, ZR, ACT, lds_bytes, slab_total, packed_floats;
+    void (*kern)(GArgs, const float*, float*, float*);
+    void (*reduce)(const float*, int, GArgs, float*);
+};
+#define SLAB_INST(HT, ZR, ACT)                                                                                   \
+    SlabInst { HT, ZR, ACT, (MfmaLayout(HT, 2, ZR, 0, true, 0).total + 4 * TS + 8) * 4, SlabLay<HT, ZR>::TOTAL,    \
+               MfmaLayout(HT, 2, ZR, 0, true, 0).total, &grad_slab_kernel<HT, ZR, ACT>, &grad_slab_reduce_kernel<HT, ZR> }
+#define SLAB_ACT(HT, ZR) SLAB_INST(HT, ZR, CNF_ACT_TANH), SLAB_INST(HT, ZR, CNF_ACT_SOFTPLUS)
+static const SlabInst kSlab[] = {
+    SLAB_ACT(4, 8),                                   // D = 15 .. 30 with H <= 64 (ICNF(nvariables = 7): D = 15, H = 64)
+    SLAB_ACT(5, 4), SLAB_ACT(5, 8), SLAB_ACT(6, 4), SLAB_ACT(6, 8), SLAB_ACT(7, 4),
+};
+
+static const SlabInst* slab_find(const cnf_config& c) {
+    if (c.mode != CNF_MODE_HUTCH_VJP || c.nprobes != 1 || c.ncond != 0 || c.n_layers != 3) return nullptr;
+    if (c.acts[2] != CNF_ACT_IDENTITY || c.acts[0] != c.acts[1] || (c.acts[0] != CNF_ACT_TANH && c.acts[0] != CNF_ACT_SOFTPLUS)) return nullptr;
+    const int D = c.nvars + c.naug, H = c.widths[1] > c.widths[2] ? c.widths[1] : c.widths[2];
+    const int HT = (H + 15) / 16;
+    const int ZR = D + (c.autonomous ? 0 : 1) <= 15 ? 4 : 8;           // one input tile holds D + time + the bias column
+    if (D + (c.autonomous ? 0 : 1) > 31) return nullptr;
+    const SlabInst* best = nullptr;
+    for (const SlabInst& s : kSlab)
+        if (s.HT >= HT && s.ZR >= ZR && s.ACT == c.acts[0] && s.lds_bytes <= 160 * 1024 &&
+            (!best || s.HT < best->HT || (s.HT == best->HT && s.ZR < best->ZR)))
+            best = &s;
+    return best;
+}
+
+bool grad_slab_supported(const cnf_config& c) { return slab_find(c) != nullptr; }
+size_t grad_slab_packed_bytes(const cnf_config& c) { return (size_t)slab_find(c)->packed_floats * sizeof(float); }
+
+void grad_slab_pack(const cnf_config& c, const float* lux, const size_t* w_off, const size_t* b_off, float* packed) {
+    const SlabInst* s = slab_find(c);
+    mfma_pack_layout(c, s->HT, 2, s->ZR, 0, lux, w_off, b_off, packed);
+}
+
+// workspace floats: checkpoints z_n, stage derivatives, slabs
+size_t grad_slab_ws_floats(const cnf_config& c, int alg, int nsteps, long long B, int num_cus) {
+    const SlabInst* s = slab_find(c);
+    const long long ntiles = (B + 15) / 16;
+    const int ns = alg == CNF_ALG_RK4 ? 4 : 6;
+    return (size_t)(nsteps + 1) * ntiles * 64 * s->ZR + (size_t)nsteps * ns * ntiles * 64 * s->ZR + (size_t)num_cus * 4 * s->slab_total;
+}
+
+hipError_t grad_slab_launch(const cnf_config& c, const float* packed_dev, const float* x, const float* eps,
+                            const size_t* w_off, const size_t* b_off, int alg, int nsteps, float t0, float t1, long long B,
+                            const float lam[3], float* ws, float* grad, float* grad_x, int num_cus, hipStream_t st) {
+    const SlabInst* si = slab_find(c);
+    if (!si) return hipErrorNotSupported;
+    static DeviceOnce once[sizeof(kSlab) / sizeof(kSlab[0])];
+    const int idx = (int)(si - kSlab);
+    int dev = 0;
+    hipError_t e0 = hipGetDevice(&dev);
+    if (e0 != hipSuccess) return e0;
+    if (!once[idx].done(dev)) {
+        hipError_t e = hipFuncSetAttribute((const void*)si->kern, hipFuncAttributeMaxDynamicSharedMemorySize, si->lds_bytes);
+        if (e != hipSuccess) return e;
+        once[idx].set(dev);
+    }
+    const long long ntiles = (B + 15) / 16;
+    const int ns = alg == CNF_ALG_RK4 ? 4 : 6;
+    float* ckz = ws;
+    float* ckk = ckz + (size_t)(nsteps + 1) * ntiles * 64 * si->ZR;
+    float* slab = ckk + (size_t)nsteps * ns * ntiles * 64 * si->ZR;
+    GArgs a{};
+    a.packed = packed_dev; a.eps = eps; a.K = 1; a.ys = nullptr; a.C = 0; a.slab = slab; a.grad_x = grad_x; a.B = B;
+    a.nsteps = nsteps; a.t0 = t0; a.dt = (t1 - t0) / (float)nsteps;
+    a.D = c.nvars + c.naug; a.H = c.widths[1]; a.n_in = c.widths[2] /* second hidden width for the reduce kernel */;
+    a.autonomous = c.autonomous; a.nvars = c.nvars;
+    a.lam1 = lam[0]; a.lam2 = lam[1]; a.lam3 = lam[2];
+    for (int l = 0; l < 3; ++l) { a.w_off[l] = (int)w_off[l]; a.b_off[l] = (int)b_off[l]; }
+    a.T = make_tableau(alg);
+    const long long want = (ntiles + 3) / 4;
+    const int nblocks = (int)(want < num_cus ? want : num_cus);
+    const int nwaves = nblocks * 4;
+    hipError_t e = hipMemsetAsync(slab, 0, (size_t)nwaves * si->slab_total * sizeof(float), st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(si->kern, dim3(nblocks), dim3(256), si->lds_bytes, st, a, x, ckz, ckk);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(si->reduce, dim3((si->slab_total + 63) / 64), dim3(256), 0, st, slab, nwaves, a, grad);
+    return hipGetLastError();
+}
+
+}  // namespace cnf

@@ -99,6 +99,16 @@ hipError_t layered_grad(LayeredGrad** ctx, const cnf_config& c, const float* P_d
                         const size_t* b_off, const float* x, const float* eps, const float* ys, int alg,
                         int nsteps, float t0, float t1, const float* tgrid, long long B, const float lam[3], float* grad,
                         float* grad_x, hipStream_t st, std::string* err);
+void mfma_pack_layout(const cnf_config& c, int HT, int L, int ZR, int CR, const float* lux, const size_t* w_off,
+                      const size_t* b_off, float* packed);
+// slab-accumulator gradient kernel for two-hidden-layer nets of 4..7 hidden tiles (cnf_grad_slab.hip)
+bool grad_slab_supported(const cnf_config& c);
+size_t grad_slab_packed_bytes(const cnf_config& c);
+void grad_slab_pack(const cnf_config& c, const float* lux, const size_t* w_off, const size_t* b_off, float* packed);
+size_t grad_slab_ws_floats(const cnf_config& c, int alg, int nsteps, long long B, int num_cus);
+hipError_t grad_slab_launch(const cnf_config& c, const float* packed_dev, const float* x, const float* eps,
+                            const size_t* w_off, const size_t* b_off, int alg, int nsteps, float t0, float t1, long long B,
+                            const float lam[3], float* ws, float* grad, float* grad_x, int num_cus, hipStream_t st);
 int mfma_plan_zr(const MfmaPlan* p);   // state k-steps of the forward instance (checkpoint stride)
 bool mfma_plan_is_per_wave(const MfmaPlan* p);
 

@@ -348,14 +348,20 @@ hipError_t mfma_pack_q_device(const MfmaPlan* p, const float* lux_dev, const siz
 int mfma_plan_zr(const MfmaPlan* p) { return p->ZR; }
 bool mfma_plan_is_per_wave(const MfmaPlan* p) { return p->kind == 0; }
 
-void grad_pack(const cnf_config& c, const float* lux, const size_t* w_off, const size_t* b_off, float* packed) {
-    int HT, L, ZR, CR;
-    grad_shape(c, &HT, &L, &ZR, &CR);
+// plain f32 image (forward + transposed, no tanh pre-scale) for a given layout: the gradient kernels' operand image
+void mfma_pack_layout(const cnf_config& c, int HT, int L, int ZR, int CR, const float* lux, const size_t* w_off,
+                      const size_t* b_off, float* packed) {
     MfmaPlan p;
     p.HT = HT; p.L = L; p.ZR = ZR; p.CR = CR; p.with_bwd = true; p.arith = 0; p.fwd_scale = 1.f;
     p.lay = MfmaLayout(HT, L, ZR, CR, true, 0);
     p.cfg = c;
     mfma_pack(&p, lux, w_off, b_off, packed);
+}
+
+void grad_pack(const cnf_config& c, const float* lux, const size_t* w_off, const size_t* b_off, float* packed) {
+    int HT, L, ZR, CR;
+    grad_shape(c, &HT, &L, &ZR, &CR);
+    mfma_pack_layout(c, HT, L, ZR, CR, lux, w_off, b_off, packed);
 }
 
 hipError_t mfma_solve(MfmaPlan* p, const float* packed_dev, const SolveArgs& s, hipStream_t st) {

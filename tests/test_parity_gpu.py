@@ -434,6 +434,40 @@ def test_parameter_gradient_layerwise_path(kw, lam, B, alg, nsteps, pkg, oracles
     assert np.max(np.abs(g - gref)) < 5e-5 * scale + 1e-6, np.max(np.abs(g - gref)) / scale
 
 
+SLAB_GRAD_SHAPES = [
+    # two hidden layers, 4..7 hidden tiles: tile-fused reverse sweep with slab accumulators (csrc/cnf_grad_slab.hip)
+    (dict(nvars=7, naug=8, hidden=[64, 64], act=2, reg_z=True, reg_j=True, reg_aug=True), (0.01, 0.01, 0.01), 45, 1, 3),   # ICNF(nvariables=7): D=15, two input tiles
+    (dict(nvars=8, naug=9, hidden=[72, 72], act=2, reg_z=True, reg_j=True, reg_aug=True), (0.01, 0.01, 0.01), 70, 1, 3),   # ICNF(nvariables=8): D=17, H=72
+    (dict(nvars=10, naug=11, hidden=[88, 88], act=2, reg_z=True, reg_j=True, reg_aug=True), (0.01, 0.02, 0.03), 33, 0, 3), # ICNF(nvariables=10): D=21, H=88
+    (dict(nvars=10, hidden=[80, 96]), (0.0, 0.0, 0.0), 50, 1, 2),                                                         # FFJORD, unequal widths, one input tile
+    (dict(nvars=15, hidden=[112, 100], autonomous=True, reg_j=True), (0.0, 0.05, 0.0), 21, 0, 2),                         # 7 tiles, autonomous, D=15 in one tile
+]
+
+
+@pytest.mark.parametrize("kw,lam,B,alg,nsteps", SLAB_GRAD_SHAPES)
+def test_parameter_gradient_slab_kernel(kw, lam, B, alg, nsteps, pkg, oracles, monkeypatch):
+    """The mid-width two-hidden-layer nets (the reference's default architecture for 7..11 variables): parameters and
+    data gradients against fp64 autograd, and against the layer-wise path on the same inputs."""
+    o64, _ = oracles
+    spec = o64.make_spec(**kw)
+    p, xs, eps, _ = o64.synth_inputs(spec, B, 222, bias_scale=0.2)
+    L, gref, gxref = o64.loss_and_grad(spec, p, xs, 0.0, 1.0, nsteps, alg, eps, None, lam, wrt_x=True)
+    icnf = make_icnf(pkg, spec, alg, nsteps, path=0, lambdas=lam)
+    mode = pkg.TrainMode(bool(spec.reg_z or spec.reg_j or spec.reg_aug))
+    assert icnf.grad_path(mode) == 1
+    val, g, gx = pkg.loss_and_gradient(icnf, mode, dev(xs), dev(p), {}, eps=dev(eps), wrt_x=True)
+    assert abs(float(val) - L) < 1e-4
+    sc = np.abs(gref).max()
+    assert np.max(np.abs(g.cpu().numpy() - gref)) < 5e-5 * sc + 1e-6, np.max(np.abs(g.cpu().numpy() - gref)) / sc
+    assert np.max(np.abs(gx.cpu().numpy() - gxref)) < 5e-5 * np.abs(gxref).max() + 1e-7
+    again = pkg.loss_and_gradient(icnf, mode, dev(xs), dev(p), {}, eps=dev(eps))[1]
+    assert torch.equal(g, again)                                                                      # no atomics
+    monkeypatch.setenv("CNF_GRAD_LAYERED", "1")
+    g2 = pkg.loss_and_gradient(icnf, mode, dev(xs), dev(p), {}, eps=dev(eps))[1]
+    monkeypatch.delenv("CNF_GRAD_LAYERED")
+    assert float((g - g2).abs().max()) < 5e-5 * float(g.abs().max())
+
+
 def test_layerwise_gradient_agrees_with_the_fused_kernel(pkg, oracles, monkeypatch):
     """cfg2 shape, B = 5000 (several column chunks + a ragged tail): the layer-wise path forced with
     CNF_GRAD_LAYERED=1 against the fused reverse-sweep kernel - two independent implementations."""
