@@ -77,24 +77,85 @@ __device__ __forceinline__ f32x4 dense_tile_at(const float (&v)[ZR], int it) {
     return t;
 }
 
-template <int HT, int ZR, int ACT>
+// Operand pointers of one stage.  GS = 0: the whole image sits in LDS.  GS = 1 (7-8 hidden tiles with 8 state k-steps, whose
+// image exceeds LDS): only the two H x H images and the bias vectors are staged; the four D-sized images (f1z, fN, bN, b1) are
+// read from the packed image in global memory (L2 resident, same layout) - they feed 6 of the ~25 products of a stage.
+template <int HT, int ZR, int GS>
+struct SlabPtr {
+    static constexpr MfmaLayout LAY = MfmaLayout(HT, 2, ZR, 0, true, 0);
+    static constexpr int IMG = MfmaLayout::imgA(HT, HT);
+    static constexpr int LDS_FLOATS = GS ? 2 * IMG + (LAY.total - LAY.v_b1) : LAY.total;
+    const float *f1z, *fN, *bN, *b1, *fh, *bh, *vec;   // vec + LAY.v_xx addresses a C vector
+    __device__ __forceinline__ SlabPtr(const float* sm, const float* gp) {
+        if (GS) {
+            f1z = gp + LAY.f1z; fN = gp + LAY.fN; bN = gp + LAY.bN; b1 = gp + LAY.b1;
+            fh = sm; bh = sm + IMG; vec = sm + 2 * IMG - LAY.v_b1;
+        } else {
+            f1z = sm + LAY.f1z; fN = sm + LAY.fN; bN = sm + LAY.bN; b1 = sm + LAY.b1;
+            fh = sm + LAY.fh; bh = sm + LAY.bh; vec = sm;
+        }
+    }
+};
+
+// forward chain of the two hidden layers: h_l, act'_l
+template <int HT, int ZR, int ACT, int GS>
+__device__ __forceinline__ void slab_forward(const SlabPtr<HT, ZR, GS>& P, int lane, float t, bool autonomous, const float (&z)[ZR],
+                                             f32x4 (&h)[2][HT], f32x4 (&d)[2][HT]) {
+    constexpr MfmaLayout LAY(HT, 2, ZR, 0, true, 0);
+    const int g = lane >> 4;
+    f32x4 acc[HT];
+    load_cvec<HT>(P.vec + LAY.v_b1, g, acc);
+    if (!autonomous) {
+        f32x4 wt[HT];
+        load_cvec<HT>(P.vec + LAY.v_w1t, g, wt);
+#pragma unroll
+        for (int mt = 0; mt < HT; ++mt) acc[mt] += wt[mt] * t;
+    }
+    gemm_tiles<HT, ZR>(P.f1z, lane, RegIn<ZR>{z}, acc);
+#pragma unroll
+    for (int l = 0; l < 2; ++l) {
+        if (l > 0) {
+            load_cvec<HT>(P.vec + LAY.v_bh, g, acc);
+            gemm_tiles<HT, 4 * HT>(P.fh, lane, TileIn<HT>{h[0]}, acc);
+        }
+#pragma unroll
+        for (int mt = 0; mt < HT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float dd;
+                h[l][mt][r] = act_fwd<ACT>(acc[mt][r], dd);
+                d[l][mt][r] = dd;
+            }
+    }
+}
+
+template <int HT, int ZR, int ACT, int GS>
 __global__ void __launch_bounds__(256)
 grad_slab_kernel(GArgs a, const float* __restrict__ x, float* __restrict__ ckz, float* __restrict__ ckk) {
-    constexpr int L = 2, CR = 0;
-    constexpr MfmaLayout LAY(HT, L, ZR, CR, true, 0);
+    constexpr int L = 2;
+    constexpr MfmaLayout LAY(HT, L, ZR, 0, true, 0);
     using SL = SlabLay<HT, ZR>;
+    using SP = SlabPtr<HT, ZR, GS>;
     constexpr int DT = SL::DT, NT1 = SL::NT1;
     constexpr int ONES = 16 * NT1 - 1;                              // bias column of the layer-1 input tiles
     extern __shared__ __attribute__((aligned(16))) float smem[];
     {
         const f32x4* src = reinterpret_cast<const f32x4*>(a.packed);
         f32x4* dst = reinterpret_cast<f32x4*>(smem);
-        for (int i = threadIdx.x; i < LAY.total / 4; i += 256) dst[i] = src[i];
+        if (GS) {
+            for (int i = threadIdx.x; i < SP::IMG / 4; i += 256) {
+                dst[i] = src[LAY.fh / 4 + i];
+                dst[SP::IMG / 4 + i] = src[LAY.bh / 4 + i];
+            }
+            for (int i = threadIdx.x; i < (LAY.total - LAY.v_b1) / 4; i += 256) dst[2 * SP::IMG / 4 + i] = src[LAY.v_b1 / 4 + i];
+        } else {
+            for (int i = threadIdx.x; i < LAY.total / 4; i += 256) dst[i] = src[i];
+        }
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, g = lane >> 4, n = lane & 15;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    float* slot = smem + (LAY.total + 3) / 4 * 4 + wave * TS;
+    float* slot = smem + (SP::LDS_FLOATS + 3) / 4 * 4 + wave * TS;
     float* slab = a.slab + ((long long)blockIdx.x * 4 + wave) * SL::TOTAL;
     float onesf[1][4];
 #pragma unroll
@@ -104,7 +165,6 @@ grad_slab_kernel(GArgs a, const float* __restrict__ x, float* __restrict__ ckz, 
     const bool autonomous = a.autonomous;
     const float dt = a.dt;
     const int ns = a.T.ns;
-    const float y[1] = {0.f};
 
     for (long long tile = (long long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long long)gridDim.x * 4) {
         const long long smp = tile * 16 + n;
@@ -142,12 +202,12 @@ grad_slab_kernel(GArgs a, const float* __restrict__ x, float* __restrict__ ckz, 
                     }
                     int opaque = 0;
                     asm volatile("" : "+v"(opaque));
-                    const float* sm = smem + opaque;
+                    const SP P(smem + opaque, a.packed + opaque);
                     f32x4 h[L][HT], d[L][HT];
-                    grad_forward<HT, L, ZR, CR, ACT>(sm, lane, tn + a.T.c[st] * dt, autonomous, zs, y, h, d);
+                    slab_forward<HT, ZR, ACT, GS>(P, lane, tn + a.T.c[st] * dt, autonomous, zs, h, d);
                     f32x4 zacc[DT];
-                    load_cvec<DT>(sm + LAY.v_bN, g, zacc);
-                    gemm_tiles<DT, 4 * HT>(sm + LAY.fN, lane, TileIn<HT>{h[L - 1]}, zacc);
+                    load_cvec<DT>(P.vec + LAY.v_bN, g, zacc);
+                    gemm_tiles<DT, 4 * HT>(P.fN, lane, TileIn<HT>{h[L - 1]}, zacc);
 #pragma unroll
                     for (int s = 0; s < ZR; ++s) {
                         const float v = zacc[s >> 2][s & 3];
@@ -181,8 +241,11 @@ grad_slab_kernel(GArgs a, const float* __restrict__ x, float* __restrict__ ckz, 
         f32x4 cvec[HT], qvec[HT];   // c = W_N^T eps, q = W_1[:,0:D] eps: constant over the solve
         zero_tiles<HT>(cvec);
         zero_tiles<HT>(qvec);
-        gemm_tiles<HT, ZR>(smem + LAY.bN, lane, RegIn<ZR>{eps}, cvec);
-        gemm_tiles<HT, ZR>(smem + LAY.f1z, lane, RegIn<ZR>{eps}, qvec);
+        {
+            const SP P0(smem, a.packed);
+            gemm_tiles<HT, ZR>(P0.bN, lane, RegIn<ZR>{eps}, cvec);
+            gemm_tiles<HT, ZR>(P0.f1z, lane, RegIn<ZR>{eps}, qvec);
+        }
 
         // ---------------- reverse sweep ----------------
 #pragma clang loop unroll(disable)
@@ -218,21 +281,21 @@ grad_slab_kernel(GArgs a, const float* __restrict__ x, float* __restrict__ ckz, 
                 const float tt = tn + a.T.c[st] * dt;
                 int opaque = 0;
                 asm volatile("" : "+v"(opaque));
-                const float* sm = smem + opaque;
+                const SP P(smem + opaque, a.packed + opaque);
 
                 // recompute and first-order pullback
                 f32x4 h[L][HT], d[L][HT], dl[L][HT], u0[HT];
-                grad_forward<HT, L, ZR, CR, ACT>(sm, lane, tt, autonomous, zs, y, h, d);
+                slab_forward<HT, ZR, ACT, GS>(P, lane, tt, autonomous, zs, h, d);
 #pragma unroll
                 for (int mt = 0; mt < HT; ++mt) dl[1][mt] = cvec[mt] * d[1][mt];
                 zero_tiles<HT>(u0);
-                gemm_tiles<HT, 4 * HT>(sm + LAY.bh, lane, TileIn<HT>{dl[1]}, u0);
+                gemm_tiles<HT, 4 * HT>(P.bh, lane, TileIn<HT>{dl[1]}, u0);
 #pragma unroll
                 for (int mt = 0; mt < HT; ++mt) dl[0][mt] = u0[mt] * d[0][mt];
                 if (regz) {   // Edot = |zdot|: kbar += c_E zdot / |zdot|
                     f32x4 zacc[DT];
-                    load_cvec<DT>(sm + LAY.v_bN, g, zacc);
-                    gemm_tiles<DT, 4 * HT>(sm + LAY.fN, lane, TileIn<HT>{h[1]}, zacc);
+                    load_cvec<DT>(P.vec + LAY.v_bN, g, zacc);
+                    gemm_tiles<DT, 4 * HT>(P.fN, lane, TileIn<HT>{h[1]}, zacc);
                     float e2 = 0.f;
 #pragma unroll
                     for (int s = 0; s < ZR; ++s) e2 = fmaf(zacc[s >> 2][s & 3], zacc[s >> 2][s & 3], e2);
@@ -248,7 +311,7 @@ grad_slab_kernel(GArgs a, const float* __restrict__ x, float* __restrict__ ckz, 
                 if (regj) {
                     f32x4 gacc[DT];
                     zero_tiles<DT>(gacc);
-                    gemm_tiles<DT, 4 * HT>(sm + LAY.b1, lane, TileIn<HT>{dl[0]}, gacc);   // g = W_1[:,0:D]^T delta_1
+                    gemm_tiles<DT, 4 * HT>(P.b1, lane, TileIn<HT>{dl[0]}, gacc);   // g = W_1[:,0:D]^T delta_1
                     float n2 = 0.f;
 #pragma unroll
                     for (int s = 0; s < ZR; ++s) n2 = fmaf(gacc[s >> 2][s & 3], gacc[s >> 2][s & 3], n2);
@@ -257,7 +320,7 @@ grad_slab_kernel(GArgs a, const float* __restrict__ x, float* __restrict__ ckz, 
 #pragma unroll
                     for (int s = 0; s < ZR; ++s) gbar[s] = fmaf(inv, gacc[s >> 2][s & 3], gbar[s]);
                     zero_tiles<HT>(db);
-                    gemm_tiles<HT, ZR>(sm + LAY.f1z, lane, RegIn<ZR>{gbar}, db);          // dbar_1 = W_1[:,0:D] gbar
+                    gemm_tiles<HT, ZR>(P.f1z, lane, RegIn<ZR>{gbar}, db);          // dbar_1 = W_1[:,0:D] gbar
                 } else {
 #pragma unroll
                     for (int mt = 0; mt < HT; ++mt) db[mt] = qvec[mt] * (-cl);
@@ -265,7 +328,7 @@ grad_slab_kernel(GArgs a, const float* __restrict__ x, float* __restrict__ ckz, 
 #pragma unroll
                 for (int mt = 0; mt < HT; ++mt) { ubs[mt] = db[mt] * d[0][mt]; a2[0][mt] = db[mt] * u0[mt]; }
                 zero_tiles<HT>(db);
-                gemm_tiles<HT, 4 * HT>(sm + LAY.fh, lane, TileIn<HT>{ubs}, db);          // W_2 ubar_1
+                gemm_tiles<HT, 4 * HT>(P.fh, lane, TileIn<HT>{ubs}, db);          // W_2 ubar_1
                 f32x4 cb[HT];
 #pragma unroll
                 for (int mt = 0; mt < HT; ++mt) { cb[mt] = db[mt] * d[1][mt]; a2[1][mt] = db[mt] * cvec[mt]; }
@@ -285,7 +348,7 @@ grad_slab_kernel(GArgs a, const float* __restrict__ x, float* __restrict__ ckz, 
                 }
                 f32x4 hb[HT];
                 zero_tiles<HT>(hb);
-                gemm_tiles<HT, ZR>(sm + LAY.bN, lane, RegIn<ZR>{kbar}, hb);               // W_N^T kbar
+                gemm_tiles<HT, ZR>(P.bN, lane, RegIn<ZR>{kbar}, hb);               // W_N^T kbar
                 float Zbar[ZR];
                 {   // second hidden layer: Wbar_2 += abar_2 h_1^T + delta_2 ubar_1^T;  bbar_2 += abar_2 x e_0
                     f32x4 ab[HT];
@@ -302,7 +365,7 @@ grad_slab_kernel(GArgs a, const float* __restrict__ x, float* __restrict__ ckz, 
                     outer_rmw<HT, 1, false>(slab + SL::BH, lane, af, onesf, af, onesf);
                     outer_rmw<HT, HT, true>(slab + SL::WH, lane, af, bf, af2, bf2);
                     zero_tiles<HT>(hb);
-                    gemm_tiles<HT, 4 * HT>(sm + LAY.bh, lane, TileIn<HT>{ab}, hb);       // W_2^T abar_2
+                    gemm_tiles<HT, 4 * HT>(P.bh, lane, TileIn<HT>{ab}, hb);       // W_2^T abar_2
                 }
                 {   // first hidden layer: Wbar_1 += abar_1 [z; t; 1]^T + delta_1 [gbar; 0]^T
                     f32x4 ab[HT];
@@ -331,7 +394,7 @@ grad_slab_kernel(GArgs a, const float* __restrict__ x, float* __restrict__ ckz, 
                     outer_rmw<HT, NT1, true>(slab + SL::W1, lane, af, bf, af2, bf2);
                     f32x4 zb[DT];
                     zero_tiles<DT>(zb);
-                    gemm_tiles<DT, 4 * HT>(sm + LAY.b1, lane, TileIn<HT>{ab}, zb);       // W_1[:,0:D]^T abar_1
+                    gemm_tiles<DT, 4 * HT>(P.b1, lane, TileIn<HT>{ab}, zb);       // W_1[:,0:D]^T abar_1
 #pragma unroll
                     for (int s = 0; s < ZR; ++s) Zbar[s] = zb[s >> 2][s & 3];
                 }
@@ -410,13 +473,14 @@ struct SlabInst {
     void (*kern)(GArgs, const float*, float*, float*);
     void (*reduce)(const float*, int, GArgs, float*);
 };
-#define SLAB_INST(HT, ZR, ACT)                                                                                   \
-    SlabInst { HT, ZR, ACT, (MfmaLayout(HT, 2, ZR, 0, true, 0).total + 4 * TS + 8) * 4, SlabLay<HT, ZR>::TOTAL,    \
-               MfmaLayout(HT, 2, ZR, 0, true, 0).total, &grad_slab_kernel<HT, ZR, ACT>, &grad_slab_reduce_kernel<HT, ZR> }
-#define SLAB_ACT(HT, ZR) SLAB_INST(HT, ZR, CNF_ACT_TANH), SLAB_INST(HT, ZR, CNF_ACT_SOFTPLUS)
+#define SLAB_INST(HT, ZR, ACT, GS)                                                                               \
+    SlabInst { HT, ZR, ACT, (SlabPtr<HT, ZR, GS>::LDS_FLOATS + 4 * TS + 8) * 4, SlabLay<HT, ZR>::TOTAL,               \
+               MfmaLayout(HT, 2, ZR, 0, true, 0).total, &grad_slab_kernel<HT, ZR, ACT, GS>, &grad_slab_reduce_kernel<HT, ZR> }
+#define SLAB_ACT(HT, ZR, GS) SLAB_INST(HT, ZR, CNF_ACT_TANH, GS), SLAB_INST(HT, ZR, CNF_ACT_SOFTPLUS, GS)
 static const SlabInst kSlab[] = {
-    SLAB_ACT(4, 8),                                   // D = 15 .. 30 with H <= 64 (ICNF(nvariables = 7): D = 15, H = 64)
-    SLAB_ACT(5, 4), SLAB_ACT(5, 8), SLAB_ACT(6, 4), SLAB_ACT(6, 8), SLAB_ACT(7, 4),
+    SLAB_ACT(4, 8, 0),                                // D = 15 .. 30 with H <= 64 (ICNF(nvariables = 7): D = 15, H = 64)
+    SLAB_ACT(5, 4, 0), SLAB_ACT(5, 8, 0), SLAB_ACT(6, 4, 0), SLAB_ACT(6, 8, 0), SLAB_ACT(7, 4, 0),
+    SLAB_ACT(7, 8, 1), SLAB_ACT(8, 4, 1), SLAB_ACT(8, 8, 1),   // D-sized images read from global memory (nvariables = 12 .. 14)
 };
 
 static const SlabInst* slab_find(const cnf_config& c) {

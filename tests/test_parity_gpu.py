@@ -441,6 +441,9 @@ SLAB_GRAD_SHAPES = [
     (dict(nvars=10, naug=11, hidden=[88, 88], act=2, reg_z=True, reg_j=True, reg_aug=True), (0.01, 0.02, 0.03), 33, 0, 3), # ICNF(nvariables=10): D=21, H=88
     (dict(nvars=10, hidden=[80, 96]), (0.0, 0.0, 0.0), 50, 1, 2),                                                         # FFJORD, unequal widths, one input tile
     (dict(nvars=15, hidden=[112, 100], autonomous=True, reg_j=True), (0.0, 0.05, 0.0), 21, 0, 2),                         # 7 tiles, autonomous, D=15 in one tile
+    (dict(nvars=12, naug=13, hidden=[104, 104], act=2, reg_z=True, reg_j=True, reg_aug=True), (0.01, 0.01, 0.01), 40, 1, 2), # ICNF(nvariables=12): 7 tiles, D-sized images from global memory
+    (dict(nvars=14, naug=15, hidden=[120, 120], act=2, reg_z=True, reg_j=True, reg_aug=True), (0.01, 0.02, 0.01), 19, 0, 2), # ICNF(nvariables=14): D=29, 8 tiles
+    (dict(nvars=6, hidden=[128, 128], reg_z=True), (0.03, 0.0, 0.0), 35, 1, 2),                                           # 8 tiles, D=6
 ]
 
 
