@@ -163,7 +163,7 @@ MfmaPlan* mfma_plan_create(const cnf_config& c) {
                 const Inst& in = gen[i];
                 if (in.HT >= HT && in.L == L && in.ZR >= ZR && in.CR >= CR && (CR > 0 || in.CR == 0) &&
                     act_matches(in.ACT, c.acts[0]) && in.ENGINE == engine && (probes ? in.KP >= KP : in.KP == KP) &&
-                    (size_t)MfmaLayout(in.HT, L, in.ZR, in.CR, engine == ENG_VJP).total * sizeof(float) <= kMaxLds &&
+                    (size_t)MfmaLayout(in.HT, L, in.ZR, in.CR, engine == ENG_VJP).lds_total * sizeof(float) <= kMaxLds &&
                     (!best || in.HT < best->HT || (in.HT == best->HT && in.ZR < best->ZR)))
                     best = &in;
             }
@@ -402,7 +402,7 @@ hipError_t mfma_solve(MfmaPlan* p, const float* packed_dev, const SolveArgs& s, 
     const long long ntiles = (s.B + 15) / 16;
     const int wpb = p->nthreads / 64;
     long long want = (ntiles + wpb - 1) / wpb;
-    const int lds = (int)mfma_packed_bytes(p);
+    const int lds = p->lay.lds_total * (int)sizeof(float);
     const int per_cu = lds > 80 * 1024 ? 1 : 2;
     const long long cap = (long long)mp->num_cus * per_cu;
     const int nblocks = (int)(want < cap ? want : cap);

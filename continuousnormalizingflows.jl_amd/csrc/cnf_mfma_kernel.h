@@ -167,7 +167,7 @@ __device__ __forceinline__ void act_tile(const f32x4& a, f32x4& h, f32x4& d) {
 //            Hutchinson JVP (g = J eps; src/core/utils.jl:161-170) or, with `exact`, the D unit
 //            tangents whose i-th output row is J_ii (trace of src/core/utils.jl:79-88, icnf.jl:312)
 template <int HT, int L, int ZR, int CR, int ACT, int ENGINE, int KP, int PRE, int ARITH>
-__device__ __forceinline__ void dyn_eval(const float* __restrict__ smem, int lane, float t,
+__device__ __forceinline__ void dyn_eval(const float* __restrict__ smem, const float* __restrict__ gimg, int lane, float t,
                                          bool autonomous, bool reg_z, bool reg_j, bool exact, int D, int K,
                                          const float (&z)[ZR], const float (&y)[CR > 0 ? CR : 1],
                                          const float (&eps)[KP][ZR], const f32x4 (&pre_c)[HT],
@@ -207,7 +207,7 @@ __device__ __forceinline__ void dyn_eval(const float* __restrict__ smem, int lan
     {
         f32x4 acc[DT];
         load_cvec<DT>(smem + LAY.v_bN, g, acc);
-        gemm_tiles<DT, 4 * HT>(smem + LAY.fN, lane, TileIn<HT>{h}, acc);
+        gemm_tiles<DT, 4 * HT>((LAY.fN_global ? gimg : smem) + LAY.fN, lane, TileIn<HT>{h}, acc);
 #pragma unroll
         for (int s = 0; s < ZR; ++s) zd[s] = acc[s >> 2][s & 3];
     }
@@ -327,7 +327,7 @@ __device__ __forceinline__ void dyn_eval(const float* __restrict__ smem, int lan
                 ld -= group_sum(jd);
                 continue;
             }
-            gemm_tiles<DT, 4 * HT>(sm + LAY.fN, lane, TileIn<HT>{tau}, gacc);  // W_N tau = J v
+            gemm_tiles<DT, 4 * HT>((LAY.fN_global ? gimg + opq : sm) + LAY.fN, lane, TileIn<HT>{tau}, gacc);  // W_N tau = J v
         }
         float dot = 0.f, n2 = 0.f;
 #pragma unroll
@@ -352,7 +352,7 @@ mfma_solve_kernel(KArgs a) {
     {
         const f32x4* src = reinterpret_cast<const f32x4*>(a.packed);
         f32x4* dst = reinterpret_cast<f32x4*>(smem);
-        for (int i = threadIdx.x; i < LAY.total / 4; i += NTHREADS) dst[i] = src[i];
+        for (int i = threadIdx.x; i < LAY.lds_total / 4; i += NTHREADS) dst[i] = src[i];
     }
     __syncthreads();
 
@@ -453,7 +453,7 @@ mfma_solve_kernel(KArgs a) {
                 // of the RK loops (and spill them).  An opaque zero offset pins the reads per stage.
                 int opaque = 0;
                 asm volatile("" : "+v"(opaque));
-                dyn_eval<HT, L, ZR, CR, ACT, ENGINE, KP, PRE, ARITH>(smem + opaque, lane, tn + a.T.c[st] * dt, autonomous,
+                dyn_eval<HT, L, ZR, CR, ACT, ENGINE, KP, PRE, ARITH>(smem + opaque, a.packed + opaque, lane, tn + a.T.c[st] * dt, autonomous,
                                                               reg_z, reg_j, exact, D, K, zs, y, eps, pre_c, pre_q, zd,
                                                               ld, ed, nd);
                 if (a.ckpt_k) {

@@ -40,7 +40,9 @@ struct MfmaLayout {
     int qtr;             // tangent-engine layouts with L = 2: image of Q = W_2 .* (W_1[:,0:D] W_3)^T (exact trace = act'_2^T Q act'_1)
     int v_w1c;           // tangent-engine layouts only: column i of W_1[:, 0:D] as a C vector (exact trace: tau_1 = W_1 e_i)
     int v_wNr;           // tangent-engine layouts only: row i of W_N as a C vector, i < 4 ZR (exact trace: J_ii = <W_N[i,:], tau>)
-    int total;           // floats
+    int total;           // floats of the packed image (global memory)
+    int lds_total;       // floats staged into LDS (= total unless fN_global)
+    bool fN_global;      // the last-layer image sits behind the LDS part and is read from global memory
 
     static constexpr int imgA(int MT, int KG) { return MT * KG * 256; }
     // hidden H x H image in split-bf16 form: [split 3][mt HT][chunk HT/2][lane 64][8 bf16] = 16 B per
@@ -52,29 +54,42 @@ struct MfmaLayout {
     constexpr MfmaLayout(int HT_, int L_, int ZR_, int CR_, bool with_bwd, int arith_ = 0)
         : HT(HT_), L(L_), ZR(ZR_), CR(CR_), arith(arith_), DT((ZR_ + 3) / 4), KGZ((ZR_ + 3) / 4), KGC((CR_ + 3) / 4),
           f1z(0), f1y(0), fh(0), fN(0), bN(0), bh(0), b1(0), v_b1(0), v_w1t(0), v_bh(0), v_bN(0), qtr(-1), v_w1c(-1), v_wNr(-1),
-          total(0) {
-        int o = 0;
-        f1z = o; o += imgA(HT, KGZ);
-        f1y = o; o += imgA(HT, KGC);
-        fh = o;  o += (L - 1) * (arith_ ? imgH16(HT_) : imgA(HT_, HT_));
-        fN = o;  o += imgA(DT, HT);
-        bN = o;  if (with_bwd) o += imgA(HT, KGZ);
-        bh = o;  if (with_bwd) o += (L - 1) * (arith_ ? imgH16(HT_) : imgA(HT_, HT_));
-        b1 = o;  if (with_bwd) o += imgA(DT, HT);
-        v_b1 = o;  o += vecC(HT);
-        v_w1t = o; o += vecC(HT);
-        v_bh = o;  o += (L - 1) * vecC(HT);
-        v_bN = o;  o += vecC(DT);
-        // two hidden layers (the reference's default architecture): tr J = act'_2^T Q act'_1 needs one H x H product
-        qtr = -1;
-        if (!with_bwd && L_ == 2 && arith_ == 0 && (o + imgA(HT_, HT_)) * 4 <= 160 * 1024) { qtr = o; o += imgA(HT_, HT_); }
-        // otherwise the exact trace pushes D unit tangents: column p of W_1 and row p of W_N in accumulator layout save the
-        // first and last product of each (only where they still fit the 160 KB of LDS)
-        v_wNr = -1;
-        if (!with_bwd && qtr < 0 && (o + 4 * ZR_ * vecC(HT_)) * 4 <= 160 * 1024) { v_wNr = o; o += 4 * ZR_ * vecC(HT_); }
-        v_w1c = -1;
-        if (!with_bwd && qtr < 0 && (o + 4 * ZR_ * vecC(HT_)) * 4 <= 160 * 1024) { v_w1c = o; o += 4 * ZR_ * vecC(HT_); }
-        total = (o + 3) / 4 * 4;
+          total(0), lds_total(0), fN_global(false) {
+        // Pass 0 lays every image out in LDS.  If the Q image of the two-hidden-layer exact trace does not fit that way
+        // (8 hidden tiles with 8 state k-steps), pass 1 moves the last-layer image fN behind the LDS part: the kernel stages
+        // [0, lds_total) and reads fN from the packed image in global memory (one D-row product per evaluation).
+        for (int pass = 0; pass < 2; ++pass) {
+            const bool fN_out = pass == 1;
+            int o = 0;
+            f1z = o; o += imgA(HT, KGZ);
+            f1y = o; o += imgA(HT, KGC);
+            fh = o;  o += (L - 1) * (arith_ ? imgH16(HT_) : imgA(HT_, HT_));
+            fN = o;  if (!fN_out) o += imgA(DT, HT);
+            bN = o;  if (with_bwd) o += imgA(HT, KGZ);
+            bh = o;  if (with_bwd) o += (L - 1) * (arith_ ? imgH16(HT_) : imgA(HT_, HT_));
+            b1 = o;  if (with_bwd) o += imgA(DT, HT);
+            v_b1 = o;  o += vecC(HT);
+            v_w1t = o; o += vecC(HT);
+            v_bh = o;  o += (L - 1) * vecC(HT);
+            v_bN = o;  o += vecC(DT);
+            const int o_fixed = o;   // everything that must be in LDS besides the optional sections below
+            // two hidden layers (the reference's default architecture): tr J = act'_2^T Q act'_1 needs one H x H product
+            qtr = -1;
+            if (!with_bwd && L_ == 2 && arith_ == 0 && (o + imgA(HT_, HT_)) * 4 <= 160 * 1024) { qtr = o; o += imgA(HT_, HT_); }
+            // otherwise the exact trace pushes D unit tangents: column p of W_1 and row p of W_N in accumulator layout save the
+            // first and last product of each (only where they still fit the 160 KB of LDS)
+            v_wNr = -1;
+            if (!with_bwd && qtr < 0 && (o + 4 * ZR_ * vecC(HT_)) * 4 <= 160 * 1024) { v_wNr = o; o += 4 * ZR_ * vecC(HT_); }
+            v_w1c = -1;
+            if (!with_bwd && qtr < 0 && (o + 4 * ZR_ * vecC(HT_)) * 4 <= 160 * 1024) { v_w1c = o; o += 4 * ZR_ * vecC(HT_); }
+            lds_total = (o + 3) / 4 * 4;
+            fN_global = fN_out;
+            if (fN_out) { fN = lds_total; o = lds_total + imgA(DT, HT); }
+            total = (o + 3) / 4 * 4;
+            const bool want_retry = pass == 0 && !with_bwd && L_ == 2 && arith_ == 0 && qtr < 0 &&
+                                    (o_fixed - imgA(DT, HT) + imgA(HT_, HT_)) * 4 <= 160 * 1024;
+            if (!want_retry) break;
+        }
     }
 };
 

@@ -98,7 +98,7 @@ CASES = [
     (dict(nvars=32, hidden=[256, 256, 256]), 48, 0, 10),
     (dict(nvars=32, hidden=[256, 256, 256], reg_z=True, reg_j=True), 200, 1, 40),   # cfg4 shape, cooperative kernel
     (dict(nvars=8, hidden=[128, 128, 128]), 100, 1, 40),                            # 3x128 Hutchinson VJP (cooperative)
-    (dict(nvars=15, naug=16, hidden=[128, 128], act=2, mode=2), 37, 1, 5),                  # ICNF(nvariables=15) in TestMode: two hidden layers, Q on the layer-wise path
+    (dict(nvars=15, naug=16, hidden=[128, 128], act=2, mode=2), 37, 1, 5),                  # ICNF(nvariables=15) in TestMode: two hidden layers, Q shortcut (fused: last-layer image read from global memory; layer-wise: one Q GEMM)
     # generic zero-padded MFMA instances (csrc/cnf_mfma_generic.hip)
     (dict(nvars=2, naug=3, hidden=[24, 24], act=2, reg_z=True, reg_j=True, reg_aug=True), 333, 1, 20),  # default net, nvariables=2
     (dict(nvars=4, ncond=3, hidden=[48, 48, 48], reg_z=True, reg_j=True), 130, 1, 20),     # conditioned Hutchinson VJP
