@@ -1,5 +1,5 @@
-// cnf_grad_slab.hip — parameter gradient for two-hidden-layer nets of 4..7 hidden tiles and up to 30 state rows:
-// the reference's default architecture for nvariables = 7 .. 11 (D = 2 n + 1, H = 8 n + 8, src/core/icnf.jl:62-71).
+// cnf_grad_slab.hip — parameter gradient for two-hidden-layer nets of 4..8 hidden tiles and up to 31 state rows:
+// the reference's default architecture for nvariables = 7 .. 15 (D = 2 n + 1, H = 8 n + 8, src/core/icnf.jl:62-71).
 //
 // Between the register-accumulator kernel (cnf_grad.hip: H <= 64, D <= 14) and the layer-wise path (cnf_layered.hip,
 // memory-bound and launch-bound at these widths: 64 ms per step at B = 1024, 170-240 ms at B = 65536).  Same reverse
@@ -11,7 +11,8 @@
 //   * the kernel is self-contained: it runs its own forward sweep from x first (checkpointing z_n and the stage
 //     derivatives in its tile layout), so it does not depend on which kernel family serves the forward solve.
 // Hutchinson VJP, one probe, no conditions; FFJORD and RNODE objectives incl. the augmented-dimension term.
-// The layer-1 input pseudo tile(s) are [z (D rows); t; 0 ..; 1 in the last column]: one tile for D <= 14, two for D <= 30.
+// The layer-1 input pseudo tile(s) are [z (D rows); t; 0 ..]: one tile for D <= 15, two for D <= 31; biases are outer
+// products with the column e_0.
 #include "cnf_grad_dev.h"
 
 namespace cnf {
@@ -25,7 +26,8 @@ struct SlabLay {   // float offsets inside one wave's slab; every image is [mt][
     static constexpr int WN = WH + HT * HT * 256;                  // [DT][HT]
     static constexpr int BH = WN + DT * HT * 256;                  // [HT][1]: column 0 = bias of the second hidden layer
     static constexpr int BN = BH + HT * 256;                       // [DT][1]: column 0 = bias of the last layer
-    static constexpr int TOTAL = BN + DT * 256;
+    static constexpr int B1 = BN + DT * 256;                       // [HT][1]: column 0 = bias of the first hidden layer
+    static constexpr int TOTAL = B1 + HT * 256;
 };
 
 __device__ __forceinline__ f32x4 slab_load(const float* p) {       // bypasses L1: always sees this wave's previous store
@@ -137,7 +139,6 @@ grad_slab_kernel(GArgs a, const float* __restrict__ x, float* __restrict__ ckz, 
     using SL = SlabLay<HT, ZR>;
     using SP = SlabPtr<HT, ZR, GS>;
     constexpr int DT = SL::DT, NT1 = SL::NT1;
-    constexpr int ONES = 16 * NT1 - 1;                              // bias column of the layer-1 input tiles
     extern __shared__ __attribute__((aligned(16))) float smem[];
     {
         const f32x4* src = reinterpret_cast<const f32x4*>(a.packed);
@@ -367,7 +368,7 @@ grad_slab_kernel(GArgs a, const float* __restrict__ x, float* __restrict__ ckz, 
                     zero_tiles<HT>(hb);
                     gemm_tiles<HT, 4 * HT>(P.bh, lane, TileIn<HT>{ab}, hb);       // W_2^T abar_2
                 }
-                {   // first hidden layer: Wbar_1 += abar_1 [z; t; 1]^T + delta_1 [gbar; 0]^T
+                {   // first hidden layer: Wbar_1 += abar_1 [z; t]^T + delta_1 [gbar; 0]^T
                     f32x4 ab[HT];
 #pragma unroll
                     for (int mt = 0; mt < HT; ++mt) {
@@ -383,7 +384,6 @@ grad_slab_kernel(GArgs a, const float* __restrict__ x, float* __restrict__ ckz, 
                         for (int r = 0; r < 4; ++r) {
                             const int f = 16 * it + 4 * r + g;
                             if (!autonomous && f == D) in_t[it][r] = tt;
-                            if (f == ONES) in_t[it][r] = 1.f;
                         }
                     }
                     float af[HT][4], af2[HT][4], bf[NT1][4], bf2[NT1][4];
@@ -392,6 +392,7 @@ grad_slab_kernel(GArgs a, const float* __restrict__ x, float* __restrict__ ckz, 
                     frags_B<NT1>(slot, lane, in_t, bf);
                     frags_B<NT1>(slot, lane, gb_t, bf2);
                     outer_rmw<HT, NT1, true>(slab + SL::W1, lane, af, bf, af2, bf2);
+                    outer_rmw<HT, 1, false>(slab + SL::B1, lane, af, onesf, af, onesf);   // bbar_1 += abar_1 x e_0
                     f32x4 zb[DT];
                     zero_tiles<DT>(zb);
                     gemm_tiles<DT, 4 * HT>(P.b1, lane, TileIn<HT>{ab}, zb);       // W_1[:,0:D]^T abar_1
@@ -427,7 +428,6 @@ template <int HT, int ZR>
 __global__ void __launch_bounds__(256)
 grad_slab_reduce_kernel(const float* __restrict__ slab, int nwaves, GArgs a, float* __restrict__ grad) {
     using SL = SlabLay<HT, ZR>;
-    constexpr int ONES = 16 * SL::NT1 - 1;
     __shared__ float part[4][64];
     const int el = threadIdx.x & 63, grp = threadIdx.x >> 6;
     const int e = blockIdx.x * 64 + el;
@@ -445,7 +445,6 @@ grad_slab_reduce_kernel(const float* __restrict__ slab, int nwaves, GArgs a, flo
         const int tl = (e - SL::W1) / 256, mt = tl / SL::NT1, it = tl % SL::NT1;
         const int out = 16 * mt + 4 * r + gg, col = 16 * it + n;
         if (out < H1 && col < ncore) grad[a.w_off[0] + out + H1 * col] = sum;
-        if (out < H1 && col == ONES) grad[a.b_off[0] + out] = sum;
     } else if (e < SL::WN) {                            // W_2 image [mt][nt]
         const int tl = (e - SL::WH) / 256;
         const int out = 16 * (tl / HT) + 4 * r + gg, in = 16 * (tl % HT) + n;
@@ -458,10 +457,14 @@ grad_slab_reduce_kernel(const float* __restrict__ slab, int nwaves, GArgs a, flo
         const int mt = (e - SL::BH) / 256;
         const int out = 16 * mt + 4 * r + gg;
         if (out < H2 && n == 0) grad[a.b_off[1] + out] = sum;
-    } else {
+    } else if (e < SL::B1) {
         const int mt = (e - SL::BN) / 256;
         const int out = 16 * mt + 4 * r + gg;
         if (out < D && n == 0) grad[a.b_off[2] + out] = sum;
+    } else {
+        const int mt = (e - SL::B1) / 256;
+        const int out = 16 * mt + 4 * r + gg;
+        if (out < H1 && n == 0) grad[a.b_off[0] + out] = sum;
     }
 }
 
@@ -488,8 +491,8 @@ static const SlabInst* slab_find(const cnf_config& c) {
     if (c.acts[2] != CNF_ACT_IDENTITY || c.acts[0] != c.acts[1] || (c.acts[0] != CNF_ACT_TANH && c.acts[0] != CNF_ACT_SOFTPLUS)) return nullptr;
     const int D = c.nvars + c.naug, H = c.widths[1] > c.widths[2] ? c.widths[1] : c.widths[2];
     const int HT = (H + 15) / 16;
-    const int ZR = D + (c.autonomous ? 0 : 1) <= 15 ? 4 : 8;           // one input tile holds D + time + the bias column
-    if (D + (c.autonomous ? 0 : 1) > 31) return nullptr;
+    const int ZR = D + (c.autonomous ? 0 : 1) <= 16 ? 4 : 8;           // one input tile holds the D state columns and the time column
+    if (D + (c.autonomous ? 0 : 1) > 32) return nullptr;
     const SlabInst* best = nullptr;
     for (const SlabInst& s : kSlab)
         if (s.HT >= HT && s.ZR >= ZR && s.ACT == c.acts[0] && s.lds_bytes <= 160 * 1024 &&

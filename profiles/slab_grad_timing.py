@@ -5,7 +5,7 @@ pkg = entry.load_package()
 dev = torch.device("cuda:0")
 out = {}
 torch.manual_seed(0)
-for nv in (7, 8, 10, 11, 12, 14):
+for nv in (7, 8, 10, 12, 15):
     for B in (1024, 65536):
         icnf = pkg.ICNF(nvariables=nv, device=dev, steer_rate=0.0, sol_kwargs=dict(alg=pkg.Tsit5(), adaptive=False, nsteps=40))
         ps, st = pkg.setup(torch.Generator().manual_seed(0), icnf)

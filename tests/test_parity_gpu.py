@@ -444,6 +444,8 @@ SLAB_GRAD_SHAPES = [
     (dict(nvars=12, naug=13, hidden=[104, 104], act=2, reg_z=True, reg_j=True, reg_aug=True), (0.01, 0.01, 0.01), 40, 1, 2), # ICNF(nvariables=12): 7 tiles, D-sized images from global memory
     (dict(nvars=14, naug=15, hidden=[120, 120], act=2, reg_z=True, reg_j=True, reg_aug=True), (0.01, 0.02, 0.01), 19, 0, 2), # ICNF(nvariables=14): D=29, 8 tiles
     (dict(nvars=6, hidden=[128, 128], reg_z=True), (0.03, 0.0, 0.0), 35, 1, 2),                                           # 8 tiles, D=6
+    (dict(nvars=15, naug=16, hidden=[128, 128], act=2, reg_z=True, reg_j=True, reg_aug=True), (0.01, 0.01, 0.01), 22, 1, 2), # ICNF(nvariables=15): D=31 + time = 32 input columns
+    (dict(nvars=15, hidden=[64, 48]), (0.0, 0.0, 0.0), 30, 0, 2),                                                         # D=15 + time = 16 columns in one input tile
 ]
 
 
