@@ -833,7 +833,7 @@ int cnf_loss_grad_fixed(cnf_handle* h, int alg, int nsteps, float t0, float t1, 
                 HIP_TRY(hipMalloc((void**)&h->slab_ws, need * sizeof(float)));
                 h->slab_ws_floats = need;
             }
-            HIP_TRY(grad_slab_launch(h->cfg, h->slab_packed, x, eps, h->w_off.data(), h->b_off.data(), alg, nsteps, t0, t1, B, lam,
+            HIP_TRY(grad_slab_launch(h->cfg, h->slab_packed, x, eps, ys, h->w_off.data(), h->b_off.data(), alg, nsteps, t0, t1, B, lam,
                                      h->slab_ws, grad, grad_x, h->num_cus, st));
             return CNF_OK;
         }

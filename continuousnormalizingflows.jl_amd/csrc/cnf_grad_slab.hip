@@ -10,14 +10,14 @@
 //     sums the slabs in a fixed order at the end (no atomics, bit-reproducible);
 //   * the kernel is self-contained: it runs its own forward sweep from x first (checkpointing z_n and the stage
 //     derivatives in its tile layout), so it does not depend on which kernel family serves the forward solve.
-// Hutchinson VJP, one probe, no conditions; FFJORD and RNODE objectives incl. the augmented-dimension term.
+// Hutchinson VJP, one probe, up to 16 conditions; FFJORD and RNODE objectives incl. the augmented-dimension term.
 // The layer-1 input pseudo tile(s) are [z (D rows); t; 0 ..]: one tile for D <= 15, two for D <= 31; biases are outer
 // products with the column e_0.
 #include "cnf_grad_dev.h"
 
 namespace cnf {
 
-template <int HT, int ZR>
+template <int HT, int ZR, int CR = 0>
 struct SlabLay {   // float offsets inside one wave's slab; every image is [mt][nt][lane][4] (accumulator layout)
     static constexpr int DT = (ZR + 3) / 4;
     static constexpr int NT1 = DT;                                 // input tiles of layer 1
@@ -27,7 +27,8 @@ struct SlabLay {   // float offsets inside one wave's slab; every image is [mt][
     static constexpr int BH = WN + DT * HT * 256;                  // [HT][1]: column 0 = bias of the second hidden layer
     static constexpr int BN = BH + HT * 256;                       // [DT][1]: column 0 = bias of the last layer
     static constexpr int B1 = BN + DT * 256;                       // [HT][1]: column 0 = bias of the first hidden layer
-    static constexpr int TOTAL = B1 + HT * 256;
+    static constexpr int W1Y = B1 + HT * 256;                      // [HT][1]: the condition columns of W_1 (<= 16), conditioned flows only
+    static constexpr int TOTAL = W1Y + (CR > 0 ? HT * 256 : 0);
 };
 
 __device__ __forceinline__ f32x4 slab_load(const float* p) {       // bypasses L1: always sees this wave's previous store
@@ -82,28 +83,28 @@ __device__ __forceinline__ f32x4 dense_tile_at(const float (&v)[ZR], int it) {
 // Operand pointers of one stage.  GS = 0: the whole image sits in LDS.  GS = 1 (7-8 hidden tiles with 8 state k-steps, whose
 // image exceeds LDS): only the two H x H images and the bias vectors are staged; the four D-sized images (f1z, fN, bN, b1) are
 // read from the packed image in global memory (L2 resident, same layout) - they feed 6 of the ~25 products of a stage.
-template <int HT, int ZR, int GS>
+template <int HT, int ZR, int GS, int CR = 0>
 struct SlabPtr {
-    static constexpr MfmaLayout LAY = MfmaLayout(HT, 2, ZR, 0, true, 0);
+    static constexpr MfmaLayout LAY = MfmaLayout(HT, 2, ZR, CR, true, 0);
     static constexpr int IMG = MfmaLayout::imgA(HT, HT);
     static constexpr int LDS_FLOATS = GS ? 2 * IMG + (LAY.total - LAY.v_b1) : LAY.total;
-    const float *f1z, *fN, *bN, *b1, *fh, *bh, *vec;   // vec + LAY.v_xx addresses a C vector
+    const float *f1z, *f1y, *fN, *bN, *b1, *fh, *bh, *vec;   // vec + LAY.v_xx addresses a C vector
     __device__ __forceinline__ SlabPtr(const float* sm, const float* gp) {
         if (GS) {
-            f1z = gp + LAY.f1z; fN = gp + LAY.fN; bN = gp + LAY.bN; b1 = gp + LAY.b1;
+            f1z = gp + LAY.f1z; f1y = gp + LAY.f1y; fN = gp + LAY.fN; bN = gp + LAY.bN; b1 = gp + LAY.b1;
             fh = sm; bh = sm + IMG; vec = sm + 2 * IMG - LAY.v_b1;
         } else {
-            f1z = sm + LAY.f1z; fN = sm + LAY.fN; bN = sm + LAY.bN; b1 = sm + LAY.b1;
+            f1z = sm + LAY.f1z; f1y = sm + LAY.f1y; fN = sm + LAY.fN; bN = sm + LAY.bN; b1 = sm + LAY.b1;
             fh = sm + LAY.fh; bh = sm + LAY.bh; vec = sm;
         }
     }
 };
 
 // forward chain of the two hidden layers: h_l, act'_l
-template <int HT, int ZR, int ACT, int GS>
-__device__ __forceinline__ void slab_forward(const SlabPtr<HT, ZR, GS>& P, int lane, float t, bool autonomous, const float (&z)[ZR],
-                                             f32x4 (&h)[2][HT], f32x4 (&d)[2][HT]) {
-    constexpr MfmaLayout LAY(HT, 2, ZR, 0, true, 0);
+template <int HT, int ZR, int ACT, int GS, int CR>
+__device__ __forceinline__ void slab_forward(const SlabPtr<HT, ZR, GS, CR>& P, int lane, float t, bool autonomous, const float (&z)[ZR],
+                                             const float (&y)[CR > 0 ? CR : 1], f32x4 (&h)[2][HT], f32x4 (&d)[2][HT]) {
+    constexpr MfmaLayout LAY(HT, 2, ZR, CR, true, 0);
     const int g = lane >> 4;
     f32x4 acc[HT];
     load_cvec<HT>(P.vec + LAY.v_b1, g, acc);
@@ -114,6 +115,7 @@ __device__ __forceinline__ void slab_forward(const SlabPtr<HT, ZR, GS>& P, int l
         for (int mt = 0; mt < HT; ++mt) acc[mt] += wt[mt] * t;
     }
     gemm_tiles<HT, ZR>(P.f1z, lane, RegIn<ZR>{z}, acc);
+    if constexpr (CR > 0) gemm_tiles<HT, CR>(P.f1y, lane, RegIn<CR>{y}, acc);
 #pragma unroll
     for (int l = 0; l < 2; ++l) {
         if (l > 0) {
@@ -131,13 +133,13 @@ __device__ __forceinline__ void slab_forward(const SlabPtr<HT, ZR, GS>& P, int l
     }
 }
 
-template <int HT, int ZR, int ACT, int GS>
+template <int HT, int ZR, int ACT, int GS, int CR>
 __global__ void __launch_bounds__(256)
 grad_slab_kernel(GArgs a, const float* __restrict__ x, float* __restrict__ ckz, float* __restrict__ ckk) {
     constexpr int L = 2;
-    constexpr MfmaLayout LAY(HT, L, ZR, 0, true, 0);
-    using SL = SlabLay<HT, ZR>;
-    using SP = SlabPtr<HT, ZR, GS>;
+    constexpr MfmaLayout LAY(HT, L, ZR, CR, true, 0);
+    using SL = SlabLay<HT, ZR, CR>;
+    using SP = SlabPtr<HT, ZR, GS, CR>;
     constexpr int DT = SL::DT, NT1 = SL::NT1;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     {
@@ -171,7 +173,12 @@ grad_slab_kernel(GArgs a, const float* __restrict__ x, float* __restrict__ ckz, 
         const long long smp = tile * 16 + n;
         const bool valid = smp < a.B;
         const long long sc = valid ? smp : a.B - 1;
-        float eps[ZR], lam[ZR];
+        float eps[ZR], lam[ZR], y[CR > 0 ? CR : 1];
+        y[0] = 0.f;
+        if constexpr (CR > 0) {
+#pragma unroll
+            for (int s = 0; s < CR; ++s) { const int f = 4 * s + g; y[s] = f < a.C ? a.ys[sc * a.C + f] : 0.f; }
+        }
         // ---------------- forward sweep: checkpoints z_n and the stage derivatives ----------------
         {
             float z[ZR];
@@ -205,7 +212,7 @@ grad_slab_kernel(GArgs a, const float* __restrict__ x, float* __restrict__ ckz, 
                     asm volatile("" : "+v"(opaque));
                     const SP P(smem + opaque, a.packed + opaque);
                     f32x4 h[L][HT], d[L][HT];
-                    slab_forward<HT, ZR, ACT, GS>(P, lane, tn + a.T.c[st] * dt, autonomous, zs, h, d);
+                    slab_forward<HT, ZR, ACT, GS, CR>(P, lane, tn + a.T.c[st] * dt, autonomous, zs, y, h, d);
                     f32x4 zacc[DT];
                     load_cvec<DT>(P.vec + LAY.v_bN, g, zacc);
                     gemm_tiles<DT, 4 * HT>(P.fN, lane, TileIn<HT>{h[L - 1]}, zacc);
@@ -286,7 +293,7 @@ grad_slab_kernel(GArgs a, const float* __restrict__ x, float* __restrict__ ckz, 
 
                 // recompute and first-order pullback
                 f32x4 h[L][HT], d[L][HT], dl[L][HT], u0[HT];
-                slab_forward<HT, ZR, ACT, GS>(P, lane, tt, autonomous, zs, h, d);
+                slab_forward<HT, ZR, ACT, GS, CR>(P, lane, tt, autonomous, zs, y, h, d);
 #pragma unroll
                 for (int mt = 0; mt < HT; ++mt) dl[1][mt] = cvec[mt] * d[1][mt];
                 zero_tiles<HT>(u0);
@@ -393,6 +400,13 @@ grad_slab_kernel(GArgs a, const float* __restrict__ x, float* __restrict__ ckz, 
                     frags_B<NT1>(slot, lane, gb_t, bf2);
                     outer_rmw<HT, NT1, true>(slab + SL::W1, lane, af, bf, af2, bf2);
                     outer_rmw<HT, 1, false>(slab + SL::B1, lane, af, onesf, af, onesf);   // bbar_1 += abar_1 x e_0
+                    if constexpr (CR > 0) {                                               // Wbar_1[:, condition columns] += abar_1 y^T
+                        f32x4 yt[1];
+                        yt[0] = dense_tile_at<CR>(y, 0);
+                        float bfy[1][4];
+                        frags_B<1>(slot, lane, yt, bfy);
+                        outer_rmw<HT, 1, false>(slab + SL::W1Y, lane, af, bfy, af, bfy);
+                    }
                     f32x4 zb[DT];
                     zero_tiles<DT>(zb);
                     gemm_tiles<DT, 4 * HT>(P.b1, lane, TileIn<HT>{ab}, zb);       // W_1[:,0:D]^T abar_1
@@ -424,10 +438,10 @@ grad_slab_kernel(GArgs a, const float* __restrict__ x, float* __restrict__ ckz, 
 }
 
 // Sum the waves' slabs in a fixed order and scatter into the Lux-layout gradient (no atomics).
-template <int HT, int ZR>
+template <int HT, int ZR, int CR>
 __global__ void __launch_bounds__(256)
 grad_slab_reduce_kernel(const float* __restrict__ slab, int nwaves, GArgs a, float* __restrict__ grad) {
-    using SL = SlabLay<HT, ZR>;
+    using SL = SlabLay<HT, ZR, CR>;
     __shared__ float part[4][64];
     const int el = threadIdx.x & 63, grp = threadIdx.x >> 6;
     const int e = blockIdx.x * 64 + el;
@@ -461,10 +475,14 @@ grad_slab_reduce_kernel(const float* __restrict__ slab, int nwaves, GArgs a, flo
         const int mt = (e - SL::BN) / 256;
         const int out = 16 * mt + 4 * r + gg;
         if (out < D && n == 0) grad[a.b_off[2] + out] = sum;
-    } else {
+    } else if (e < SL::W1Y) {
         const int mt = (e - SL::B1) / 256;
         const int out = 16 * mt + 4 * r + gg;
         if (out < H1 && n == 0) grad[a.b_off[0] + out] = sum;
+    } else {                                            // condition columns of W_1
+        const int mt = (e - SL::W1Y) / 256;
+        const int out = 16 * mt + 4 * r + gg;
+        if (out < H1 && n < a.C) grad[a.w_off[0] + out + H1 * (ncore + n)] = sum;
     }
 }
 
@@ -472,14 +490,16 @@ grad_slab_reduce_kernel(const float* __restrict__ slab, int nwaves, GArgs a, flo
 // host side
 // ---------------------------------------------------------------------------------------
 struct SlabInst {
-    int HT, ZR, ACT, lds_bytes, slab_total, packed_floats;
+    int HT, ZR, ACT, CR, lds_bytes, slab_total, packed_floats;
     void (*kern)(GArgs, const float*, float*, float*);
     void (*reduce)(const float*, int, GArgs, float*);
 };
-#define SLAB_INST(HT, ZR, ACT, GS)                                                                               \
-    SlabInst { HT, ZR, ACT, (SlabPtr<HT, ZR, GS>::LDS_FLOATS + 4 * TS + 8) * 4, SlabLay<HT, ZR>::TOTAL,               \
-               MfmaLayout(HT, 2, ZR, 0, true, 0).total, &grad_slab_kernel<HT, ZR, ACT, GS>, &grad_slab_reduce_kernel<HT, ZR> }
-#define SLAB_ACT(HT, ZR, GS) SLAB_INST(HT, ZR, CNF_ACT_TANH, GS), SLAB_INST(HT, ZR, CNF_ACT_SOFTPLUS, GS)
+#define SLAB_INST(HT, ZR, ACT, GS, CR)                                                                                          \
+    SlabInst { HT, ZR, ACT, CR, (SlabPtr<HT, ZR, GS, CR>::LDS_FLOATS + 4 * TS + 8) * 4, SlabLay<HT, ZR, CR>::TOTAL,                  \
+               MfmaLayout(HT, 2, ZR, CR, true, 0).total, &grad_slab_kernel<HT, ZR, ACT, GS, CR>, &grad_slab_reduce_kernel<HT, ZR, CR> }
+#define SLAB_ACT(HT, ZR, GS)                                                                  \
+    SLAB_INST(HT, ZR, CNF_ACT_TANH, GS, 0), SLAB_INST(HT, ZR, CNF_ACT_SOFTPLUS, GS, 0),       \
+    SLAB_INST(HT, ZR, CNF_ACT_TANH, GS, 4), SLAB_INST(HT, ZR, CNF_ACT_SOFTPLUS, GS, 4)
 static const SlabInst kSlab[] = {
     SLAB_ACT(4, 8, 0),                                // D = 15 .. 30 with H <= 64 (ICNF(nvariables = 7): D = 15, H = 64)
     SLAB_ACT(5, 4, 0), SLAB_ACT(5, 8, 0), SLAB_ACT(6, 4, 0), SLAB_ACT(6, 8, 0), SLAB_ACT(7, 4, 0),
@@ -487,7 +507,7 @@ static const SlabInst kSlab[] = {
 };
 
 static const SlabInst* slab_find(const cnf_config& c) {
-    if (c.mode != CNF_MODE_HUTCH_VJP || c.nprobes != 1 || c.ncond != 0 || c.n_layers != 3) return nullptr;
+    if (c.mode != CNF_MODE_HUTCH_VJP || c.nprobes != 1 || c.ncond > 16 || c.n_layers != 3) return nullptr;
     if (c.acts[2] != CNF_ACT_IDENTITY || c.acts[0] != c.acts[1] || (c.acts[0] != CNF_ACT_TANH && c.acts[0] != CNF_ACT_SOFTPLUS)) return nullptr;
     const int D = c.nvars + c.naug, H = c.widths[1] > c.widths[2] ? c.widths[1] : c.widths[2];
     const int HT = (H + 15) / 16;
@@ -495,7 +515,7 @@ static const SlabInst* slab_find(const cnf_config& c) {
     if (D + (c.autonomous ? 0 : 1) > 32) return nullptr;
     const SlabInst* best = nullptr;
     for (const SlabInst& s : kSlab)
-        if (s.HT >= HT && s.ZR >= ZR && s.ACT == c.acts[0] && s.lds_bytes <= 160 * 1024 &&
+        if (s.HT >= HT && s.ZR >= ZR && s.ACT == c.acts[0] && (s.CR > 0) == (c.ncond > 0) && s.lds_bytes <= 160 * 1024 &&
             (!best || s.HT < best->HT || (s.HT == best->HT && s.ZR < best->ZR)))
             best = &s;
     return best;
@@ -506,7 +526,7 @@ size_t grad_slab_packed_bytes(const cnf_config& c) { return (size_t)slab_find(c)
 
 void grad_slab_pack(const cnf_config& c, const float* lux, const size_t* w_off, const size_t* b_off, float* packed) {
     const SlabInst* s = slab_find(c);
-    mfma_pack_layout(c, s->HT, 2, s->ZR, 0, lux, w_off, b_off, packed);
+    mfma_pack_layout(c, s->HT, 2, s->ZR, s->CR, lux, w_off, b_off, packed);
 }
 
 // workspace floats: checkpoints z_n, stage derivatives, slabs
@@ -517,7 +537,7 @@ size_t grad_slab_ws_floats(const cnf_config& c, int alg, int nsteps, long long B
     return (size_t)(nsteps + 1) * ntiles * 64 * s->ZR + (size_t)nsteps * ns * ntiles * 64 * s->ZR + (size_t)num_cus * 4 * s->slab_total;
 }
 
-hipError_t grad_slab_launch(const cnf_config& c, const float* packed_dev, const float* x, const float* eps,
+hipError_t grad_slab_launch(const cnf_config& c, const float* packed_dev, const float* x, const float* eps, const float* ys,
                             const size_t* w_off, const size_t* b_off, int alg, int nsteps, float t0, float t1, long long B,
                             const float lam[3], float* ws, float* grad, float* grad_x, int num_cus, hipStream_t st) {
     const SlabInst* si = slab_find(c);
@@ -538,7 +558,7 @@ hipError_t grad_slab_launch(const cnf_config& c, const float* packed_dev, const 
     float* ckk = ckz + (size_t)(nsteps + 1) * ntiles * 64 * si->ZR;
     float* slab = ckk + (size_t)nsteps * ns * ntiles * 64 * si->ZR;
     GArgs a{};
-    a.packed = packed_dev; a.eps = eps; a.K = 1; a.ys = nullptr; a.C = 0; a.slab = slab; a.grad_x = grad_x; a.B = B;
+    a.packed = packed_dev; a.eps = eps; a.K = 1; a.ys = ys; a.C = c.ncond; a.slab = slab; a.grad_x = grad_x; a.B = B;
     a.nsteps = nsteps; a.t0 = t0; a.dt = (t1 - t0) / (float)nsteps;
     a.D = c.nvars + c.naug; a.H = c.widths[1]; a.n_in = c.widths[2] /* second hidden width for the reduce kernel */;
     a.autonomous = c.autonomous; a.nvars = c.nvars;

@@ -106,7 +106,7 @@ bool grad_slab_supported(const cnf_config& c);
 size_t grad_slab_packed_bytes(const cnf_config& c);
 void grad_slab_pack(const cnf_config& c, const float* lux, const size_t* w_off, const size_t* b_off, float* packed);
 size_t grad_slab_ws_floats(const cnf_config& c, int alg, int nsteps, long long B, int num_cus);
-hipError_t grad_slab_launch(const cnf_config& c, const float* packed_dev, const float* x, const float* eps,
+hipError_t grad_slab_launch(const cnf_config& c, const float* packed_dev, const float* x, const float* eps, const float* ys,
                             const size_t* w_off, const size_t* b_off, int alg, int nsteps, float t0, float t1, long long B,
                             const float lam[3], float* ws, float* grad, float* grad_x, int num_cus, hipStream_t st);
 int mfma_plan_zr(const MfmaPlan* p);   // state k-steps of the forward instance (checkpoint stride)

@@ -446,6 +446,8 @@ SLAB_GRAD_SHAPES = [
     (dict(nvars=6, hidden=[128, 128], reg_z=True), (0.03, 0.0, 0.0), 35, 1, 2),                                           # 8 tiles, D=6
     (dict(nvars=15, naug=16, hidden=[128, 128], act=2, reg_z=True, reg_j=True, reg_aug=True), (0.01, 0.01, 0.01), 22, 1, 2), # ICNF(nvariables=15): D=31 + time = 32 input columns
     (dict(nvars=15, hidden=[64, 48]), (0.0, 0.0, 0.0), 30, 0, 2),                                                         # D=15 + time = 16 columns in one input tile
+    (dict(nvars=8, naug=9, ncond=4, hidden=[88, 88], act=2, reg_z=True, reg_j=True, reg_aug=True), (0.01, 0.01, 0.01), 41, 1, 2), # CondICNF(nvariables=8, nconditions=4) default net
+    (dict(nvars=6, ncond=16, hidden=[128, 112], reg_j=True), (0.0, 0.04, 0.0), 23, 0, 2),                                 # 16 conditions, 8 tiles (D-sized images from global memory)
 ]
 
 
@@ -455,20 +457,21 @@ def test_parameter_gradient_slab_kernel(kw, lam, B, alg, nsteps, pkg, oracles, m
     data gradients against fp64 autograd, and against the layer-wise path on the same inputs."""
     o64, _ = oracles
     spec = o64.make_spec(**kw)
-    p, xs, eps, _ = o64.synth_inputs(spec, B, 222, bias_scale=0.2)
-    L, gref, gxref = o64.loss_and_grad(spec, p, xs, 0.0, 1.0, nsteps, alg, eps, None, lam, wrt_x=True)
+    p, xs, eps, ys = o64.synth_inputs(spec, B, 222, bias_scale=0.2)
+    L, gref, gxref = o64.loss_and_grad(spec, p, xs, 0.0, 1.0, nsteps, alg, eps, ys, lam, wrt_x=True)
     icnf = make_icnf(pkg, spec, alg, nsteps, path=0, lambdas=lam)
     mode = pkg.TrainMode(bool(spec.reg_z or spec.reg_j or spec.reg_aug))
     assert icnf.grad_path(mode) == 1
-    val, g, gx = pkg.loss_and_gradient(icnf, mode, dev(xs), dev(p), {}, eps=dev(eps), wrt_x=True)
+    cargs = (dev(xs),) + ((dev(ys),) if spec.ncond else ()) + (dev(p), {})
+    val, g, gx = pkg.loss_and_gradient(icnf, mode, *cargs, eps=dev(eps), wrt_x=True)
     assert abs(float(val) - L) < 1e-4
     sc = np.abs(gref).max()
     assert np.max(np.abs(g.cpu().numpy() - gref)) < 5e-5 * sc + 1e-6, np.max(np.abs(g.cpu().numpy() - gref)) / sc
     assert np.max(np.abs(gx.cpu().numpy() - gxref)) < 5e-5 * np.abs(gxref).max() + 1e-7
-    again = pkg.loss_and_gradient(icnf, mode, dev(xs), dev(p), {}, eps=dev(eps))[1]
+    again = pkg.loss_and_gradient(icnf, mode, *cargs, eps=dev(eps))[1]
     assert torch.equal(g, again)                                                                      # no atomics
     monkeypatch.setenv("CNF_GRAD_LAYERED", "1")
-    g2 = pkg.loss_and_gradient(icnf, mode, dev(xs), dev(p), {}, eps=dev(eps))[1]
+    g2 = pkg.loss_and_gradient(icnf, mode, *cargs, eps=dev(eps))[1]
     monkeypatch.delenv("CNF_GRAD_LAYERED")
     assert float((g - g2).abs().max()) < 5e-5 * float(g.abs().max())
 
