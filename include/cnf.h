@@ -198,7 +198,8 @@ int cnf_loss_sums(cnf_handle* h, const float* logp, const float* regs, int64_t B
  * column shards and divides by the global column count.
  * Every Hutchinson (VJP or JVP) configuration is covered.  Fused reverse-sweep kernels: 1 <= K <= 8 probes,
  * <= 16 conditions, 2 or 3 equal hidden layers (tanh or softplus) of width <= 64, D + !autonomous <= 15;
- * every other shape (wide layers, more layers, unequal widths, mixed activations, larger D): layer-wise
+ * slab-accumulator kernel: two hidden layers of width <= 128, D + !autonomous <= 32, <= 16 conditions, one probe (the
+ * reference's default nets for 7..15 variables); every other shape (wider or more layers, mixed activations, larger D): layer-wise
  * reverse sweep on rocBLAS GEMMs, which also serves the Hutchinson JVP mode.  FFJORD and RNODE losses.
  * Exact-trace mode (TestMode): CNF_ERR_UNSUPPORTED. */
 int cnf_loss_grad_fixed(cnf_handle* h, int alg, int nsteps, float t0, float t1, const float* x,
@@ -215,7 +216,7 @@ int cnf_loss_grad_grid(cnf_handle* h, int alg, int nsteps, const float* tgrid, c
                        void* stream);
 
 /* Which implementation cnf_loss_grad_fixed uses for this handle: 0 = none (CNF_ERR_UNSUPPORTED),
- * 1 = fused reverse-sweep kernel (cnf_grad.hip / cnf_grad_probes.hip), 2 = layer-wise reverse sweep on
+ * 1 = fused reverse-sweep kernel (cnf_grad.hip / cnf_grad_probes.hip / cnf_grad_slab.hip), 2 = layer-wise reverse sweep on
  * rocBLAS GEMMs (cnf_layered.hip; librocblas.so.5 is loaded with dlopen at first use). */
 int cnf_grad_path(const cnf_handle* h);
 
