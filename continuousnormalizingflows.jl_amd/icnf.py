@@ -195,6 +195,9 @@ class RK4:
 # ---------------------------------------------------------------------------------------
 # ICNF
 # ---------------------------------------------------------------------------------------
+_warned_default_alg = False
+
+
 class _Handle:
     """Owns one cnf_handle (one trace mode / regulariser combination)."""
 
@@ -323,11 +326,21 @@ class ICNF:
     def _solver(self):
         kw = self.sol_kwargs
         alg = kw.get("alg")
-        if alg is None or not hasattr(alg, "alg_id"):
-            raise NotImplementedError(
-                "sol_kwargs.alg must be Tsit5() or RK4(); the reference's adaptive default "
-                "(VCABM, reltol=abstol=1e-4) couples samples through its step controller and is "
-                "not implemented by the fixed-step HIP path")
+        if alg is None:
+            # The reference's default is sol_kwargs = (alg = VCABM(), reltol = abstol = 1e-4, ...) (src/core/icnf.jl:84-89).
+            # VCABM is not implemented; an ICNF built without `alg` solves with adaptive Tsit5 at the same tolerances
+            # (same accuracy target, different step sequence) and says so once, like the reference's `@warn maxlog = 1`.
+            global _warned_default_alg
+            if not _warned_default_alg:
+                import warnings
+                warnings.warn("sol_kwargs has no `alg`: the reference's default VCABM() is not implemented; using adaptive "
+                              "Tsit5() with reltol = abstol = 1e-4", stacklevel=3)
+                _warned_default_alg = True
+            alg = Tsit5()
+            kw["alg"] = alg
+        if not hasattr(alg, "alg_id"):
+            raise NotImplementedError("sol_kwargs.alg must be Tsit5() or RK4() (VCABM and other OrdinaryDiffEq algorithms "
+                                      "are not implemented)")
         if kw.get("adaptive", True) and alg.alg_id != _lib.ALG_TSIT5:
             raise NotImplementedError("adaptive stepping is implemented for Tsit5() only; use adaptive=False with RK4()")
         return alg.alg_id

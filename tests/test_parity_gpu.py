@@ -1269,3 +1269,46 @@ def test_plain_cpp_host_on_the_c_abi(pkg, oracles, tmp_path):
     icnf = make_icnf(pkg, spec, 1, nsteps)
     ref = run_inference(pkg, icnf, spec, p, xs, eps, None)[0].cpu().numpy()
     assert got.shape == ref.shape and np.array_equal(got, ref)              # same library, same inputs: same bits
+
+
+@pytest.mark.parametrize("conditioned", [False, True])
+def test_reference_smoke_flow_with_all_defaults(conditioned, pkg):
+    """test/ci_tests/smoke_tests.jl:69-156 with nothing but the defaults: ICNF(; nvariables, [nconditions]) - default net,
+    default (adaptive) solver at the reference's tolerances, default lambdas and steer rate - through inference, generate,
+    loss, the layer call, the gradients with respect to ps and x, and the MLJ / Distributions adapters.  The reference only
+    checks `!isnothing`; here also shapes, finiteness and that a short fit lowers the loss."""
+    import warnings
+    g = torch.Generator().manual_seed(11)
+    r = torch.distributions.Beta(2.0, 4.0).sample((2, 64)).float()           # Beta(2, 4) data, ndimensions = 2 (smoke_tests.jl:10-13)
+    r2 = torch.distributions.Beta(2.0, 4.0).sample((2, 64)).float()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        icnf = pkg.ICNF(nvariables=2, nconditions=2 if conditioned else 0, device="cuda:0")
+        ps, st = pkg.setup(g, icnf)
+        ps = ps.cuda()
+        cond = (r2.cuda(),) if conditioned else ()
+        for mode in (pkg.TrainMode(True), pkg.TestMode()):
+            logp, (E, n, A) = pkg.inference(icnf, mode, r.cuda(), *cond, ps, st)
+            assert logp.shape == (64,) and bool(torch.isfinite(logp).all()) and E.shape == n.shape == A.shape == (64,)
+            x = pkg.generate(icnf, mode, *cond, ps, st, 64)
+            assert x.shape == (2, 64) and bool(torch.isfinite(x).all())
+            assert np.isfinite(float(pkg.loss(icnf, mode, r.cuda(), *cond, ps, st)))
+            out = icnf((r.cuda(),) + cond if conditioned else r.cuda(), ps, st)
+            assert out is not None
+        val, gps, gx = pkg.loss_and_gradient(icnf, pkg.TrainMode(True), r.cuda(), *cond, ps, st, wrt_x=True)
+        assert gps.shape == ps.shape and gx.shape == (2, 64) and bool(torch.isfinite(gps).all()) and bool(torch.isfinite(gx).all())
+        Model = pkg.CondICNFModel if conditioned else pkg.ICNFModel
+        model = Model(icnf=icnf, batchsize=32, epochs=8, callback=None, init_rng=torch.Generator().manual_seed(3))
+        data = (r.t(), r2.t()) if conditioned else r.t()
+        l0 = float(pkg.loss(icnf, pkg.TestMode(), r.cuda(), *cond, pkg.setup(torch.Generator().manual_seed(3), icnf)[0].cuda(), st))
+        fitresult, _, report = model.fit(data)
+        assert report["stats"]["iterations"] == 16
+        l1 = float(pkg.loss(icnf, pkg.TestMode(), r.cuda(), *cond, fitresult[0], st))
+        assert l1 < l0
+        px = model.transform(fitresult, data)
+        assert len(px) == 64 and (px["px"] > 0).all()
+        if conditioned:
+            d = pkg.CondICNFDist.from_fit(model, fitresult, pkg.TestMode(), r2)
+        else:
+            d = pkg.ICNFDist.from_fit(model, fitresult, pkg.TestMode())
+        assert d.logpdf(r).shape == (64,) and d.pdf(r[:, 0]).dim() == 0 and d.rand(5).shape == (2, 5) and d.rand().shape == (2,)
