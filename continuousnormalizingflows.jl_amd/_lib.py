@@ -19,6 +19,8 @@ OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_NO_PARAMS, ERR_HIP, ERR_NO_DEVICE = 0, -1,
 ACT_IDENTITY, ACT_TANH, ACT_SOFTPLUS = 0, 1, 2
 MODE_HUTCH_VJP, MODE_HUTCH_JVP, MODE_EXACT = 0, 1, 2
 ALG_RK4, ALG_TSIT5 = 0, 1
+ALG_VCABM = 2   # host-side id only: the multistep solve has its own entry points (cnf_vcabm_*)
+VCABM_MAX_ORDER = 12
 PATH_AUTO, PATH_SIMT, PATH_MFMA, PATH_LAYERED = 0, 1, 2, 3
 STEP_FSAL, STEP_RETRY = 1, 2
 ARITH_F32, ARITH_BF16X6 = 0, 1
@@ -26,7 +28,7 @@ ARITH_F32, ARITH_BF16X6 = 0, 1
 EXPORTS = ("cnf_version", "cnf_last_error", "cnf_create", "cnf_destroy", "cnf_set_params",
            "cnf_kernel_path", "cnf_repack_on_device", "cnf_aug_f", "cnf_integrate_fixed", "cnf_inference_fixed",
            "cnf_loss_sums", "cnf_loss_grad_fixed", "cnf_loss_grad_grid", "cnf_grad_path", "cnf_step_embedded", "cnf_assemble_u0",
-           "cnf_epilogue")
+           "cnf_epilogue", "cnf_vcabm_begin", "cnf_vcabm_attempt", "cnf_vcabm_accept", "cnf_vcabm_state")
 
 
 class CnfConfig(C.Structure):
@@ -84,6 +86,10 @@ def load():
                                       C.c_float, fp, fp, vp]
     lib.cnf_assemble_u0.argtypes = [vp, fp, C.c_int64, fp, vp]
     lib.cnf_epilogue.argtypes = [vp, fp, C.c_int64, fp, fp, vp]
+    lib.cnf_vcabm_begin.argtypes = [vp, C.c_float, fp, fp, fp, C.c_int64, vp]
+    lib.cnf_vcabm_attempt.argtypes = [vp, C.c_int, C.c_float, fp, fp, C.c_int64, C.c_float, C.c_float, fp, vp]
+    lib.cnf_vcabm_accept.argtypes = [vp, fp, fp, C.c_int64, C.c_float, C.c_float, fp, vp]
+    lib.cnf_vcabm_state.argtypes = [vp, C.c_int64, fp, C.POINTER(C.c_double), vp]
     lib.cnf_aug_f.argtypes = [vp, fp, fp, C.c_float, fp, fp, C.c_int64, vp]
     lib.cnf_integrate_fixed.argtypes = [vp, C.c_int, C.c_int, C.c_float, C.c_float, fp, fp, fp,
                                         C.c_int64, fp, vp]

@@ -153,6 +153,14 @@ struct cnf_handle {
     int64_t ebuf_B = 0;
     int ek[7] = {0, 1, 2, 3, 4, 5, 6};   // which slot holds k_1 .. k_7 (first-same-as-last swaps slots 0 and 6)
     double* err_partial = nullptr;
+    // multistep solve (cnf_vcabm_*): 6 state-size vectors + 2 x kVcSlots difference vectors, each S x vc_B
+    float* vc_buf = nullptr;
+    double* vc_partial = nullptr;
+    int64_t vc_B = -1;
+    int vc_iu = 0, vc_iun = 2, vc_if = 3, vc_ifn = 5, vc_cur = 0;   // which vector holds u, u_new, f_n, f_{n+1}; live difference half
+    int vc_nhist = 0, vc_k = 0;          // accepted steps since begin; order of the pending attempt (0 = none)
+    double vc_hist[kVcSlots + 1] = {};   // signed sizes of the accepted steps, newest first
+    double vc_t = 0.0, vc_dt = 0.0;
     bool layered_forced = false;         // kernel_path = CNF_PATH_LAYERED given explicitly: GEMM path for every batch
     bool maps_built = false;
     bool repack_on_device = false;
@@ -272,6 +280,8 @@ int cnf_destroy(cnf_handle* h) {
     if (h->p_stage) (void)hipFree(h->p_stage);
     if (h->ebuf) (void)hipFree(h->ebuf);
     if (h->err_partial) (void)hipFree(h->err_partial);
+    if (h->vc_buf) (void)hipFree(h->vc_buf);
+    if (h->vc_partial) (void)hipFree(h->vc_partial);
     layered_grad_destroy(h->layered);
     free_pack_map(h->map_fwd);
     free_pack_map(h->map_grad);
@@ -730,6 +740,159 @@ int cnf_step_embedded(cnf_handle* h, int alg, int flags, float t, float dt, cons
     rc = eval_dynamics(h, last, t + dt, eps, ys, B, k[6], stage, false, st);   // 7th stage = first stage of the next step
     if (rc) return rc;
     HIP_TRY(embedded_error(u, u_new, k, btilde, 7, dt, abstol, reltol, (int64_t)n, h->err_partial, err_sumsq, st));
+    return CNF_OK;
+}
+
+// ---- variable-step variable-order Adams PECE: the reference's default alg = VCABM() ----
+
+static inline float* vc_vec(cnf_handle* h, int i) { return h->vc_buf + (size_t)i * (size_t)h->S * (size_t)h->vc_B; }
+static inline float* vc_diffs(cnf_handle* h, int half) { return vc_vec(h, 6 + half * kVcSlots); }
+
+static int vc_check(cnf_handle* h, const float* eps, const float* ys, int64_t B, const char* who) {
+    int rc = check_call(h, eps, ys, B, who);
+    if (rc) return rc;
+    if (h->vc_B < 0 || B != h->vc_B) return fail(CNF_ERR_INVALID, std::string(who) + ": cnf_vcabm_begin was not called for this batch");
+    return CNF_OK;
+}
+
+int cnf_vcabm_begin(cnf_handle* h, float t0, const float* u0, const float* eps, const float* ys, int64_t B, void* stream) {
+    int rc = check_call(h, eps, ys, B, "cnf_vcabm_begin");
+    if (rc) return rc;
+    if (B > 0 && !u0) return fail(CNF_ERR_INVALID, "cnf_vcabm_begin: null u0");
+    DeviceGuard g(h->cfg.device_id);
+    hipStream_t st = (hipStream_t)stream;
+    if (B != h->vc_B) {
+        if (h->vc_buf) HIP_TRY(hipFree(h->vc_buf));
+        h->vc_buf = nullptr; h->vc_B = -1;
+        const size_t n = (size_t)h->S * (size_t)B;
+        if (n) HIP_TRY(hipMalloc((void**)&h->vc_buf, (6 + 2 * kVcSlots) * n * sizeof(float)));
+        h->vc_B = B;
+    }
+    if (!h->vc_partial) HIP_TRY(hipMalloc((void**)&h->vc_partial, vcabm_partial_doubles() * sizeof(double)));
+    h->vc_iu = 0; h->vc_iun = 2; h->vc_if = 3; h->vc_ifn = 5; h->vc_cur = 0;
+    h->vc_nhist = 0; h->vc_k = 0; h->vc_t = t0; h->vc_dt = 0.0;
+    for (double& d : h->vc_hist) d = 0.0;
+    if (B == 0) return CNF_OK;
+    const size_t n = (size_t)h->S * (size_t)B;
+    HIP_TRY(hipMemcpyAsync(vc_vec(h, h->vc_iu), u0, n * sizeof(float), hipMemcpyDeviceToDevice, st));
+    StageIn in{};
+    in.u = vc_vec(h, h->vc_iu); in.nprev = 0; in.dt = 0.f;
+    return eval_dynamics(h, in, t0, eps, ys, B, vc_vec(h, h->vc_if), nullptr, true, st);
+}
+
+int cnf_vcabm_attempt(cnf_handle* h, int order, float dt, const float* eps, const float* ys, int64_t B, float abstol,
+                      float reltol, double* err3, void* stream) {
+    int rc = vc_check(h, eps, ys, B, "cnf_vcabm_attempt");
+    if (rc) return rc;
+    if (order < 1 || order > CNF_VCABM_MAX_ORDER || order > h->vc_nhist + 1)
+        return fail(CNF_ERR_INVALID, "cnf_vcabm_attempt: order must be in 1..12 and at most one more than the accepted steps");
+    if (!(abstol >= 0.f) || !(reltol >= 0.f) || (abstol == 0.f && reltol == 0.f))
+        return fail(CNF_ERR_INVALID, "cnf_vcabm_attempt: tolerances must be non-negative and not both zero");
+    if (dt == 0.f || !(dt == dt)) return fail(CNF_ERR_INVALID, "cnf_vcabm_attempt: dt must be non-zero");
+    if (B == 0) return CNF_OK;
+    if (!err3) return fail(CNF_ERR_INVALID, "cnf_vcabm_attempt: null err3");
+    DeviceGuard g(h->cfg.device_id);
+    hipStream_t st = (hipStream_t)stream;
+    const int k = order;
+    const int m = std::min(k + 1, h->vc_nhist + 1);
+    // step sizes newest first, the candidate in front (Hairer, Noersett, Wanner I, III.5: t_{n+1} - t_{n-j+1} = sum of the j newest)
+    double dts[kVcSlots + 2];
+    dts[0] = dt;
+    for (int i = 0; i <= kVcSlots; ++i) dts[i + 1] = h->vc_hist[i];
+    VcCoef c{};
+    c.ps_old = vc_diffs(h, h->vc_cur);
+    c.ps_new = vc_diffs(h, h->vc_cur ^ 1);
+    c.ld = (size_t)h->S * (size_t)B;
+    c.k = k; c.m = m; c.dt = dt;
+    double beta = 1.0, num = 0.0, den = 0.0;
+    c.beta[0] = 1.f;
+    for (int j = 1; j < m; ++j) {       // beta_j = beta_{j-1} (t_{n+1} - t_{n-j+1}) / (t_n - t_{n-j})
+        num += dts[j - 1];
+        den += dts[j];
+        beta *= num / den;
+        c.beta[j] = (float)beta;
+    }
+    // g_j = c_{j,1};  c_{0,q} = 1/q,  c_{1,q} = 1/(q(q+1)),  c_{j,q} = c_{j-1,q} - c_{j-1,q+1} dt / (t_{n+1} - t_{n-j+1})
+    double cq[kVcSlots + 3], gd[kVcSlots + 1];
+    const int ng = k + 1;
+    gd[0] = 1.0;
+    for (int q = 1; q <= ng; ++q) cq[q - 1] = 1.0 / ((double)q * (double)(q + 1));
+    double xi = dts[0];
+    for (int j = 1; j < ng; ++j) {
+        if (j > 1) {
+            xi += dts[j - 1];
+            for (int q = 0; q < ng - j + 1; ++q) cq[q] = cq[q] - cq[q + 1] * (double)dt / xi;
+        }
+        gd[j] = cq[0];
+    }
+    for (int j = 0; j < ng; ++j) c.g[j] = (float)gd[j];
+    c.e0 = (float)((double)dt * (gd[k] - gd[k - 1]));
+    c.e1 = k >= 2 ? (float)((double)dt * (gd[k - 1] - gd[k - 2])) : 0.f;
+    c.e2 = k >= 3 ? (float)((double)dt * (gd[k - 2] - gd[k - 3])) : 0.f;
+    const int64_t n = (int64_t)c.ld;
+    float *u = vc_vec(h, h->vc_iu), *p = vc_vec(h, 1), *un = vc_vec(h, h->vc_iun), *d = vc_vec(h, 4);
+    HIP_TRY(vcabm_predict(vc_vec(h, h->vc_if), u, c, n, p, st));                                    // P
+    StageIn in{};
+    in.u = p; in.nprev = 0; in.dt = 0.f;
+    rc = eval_dynamics(h, in, (float)(h->vc_t + (double)dt), eps, ys, B, d, nullptr, false, st);   // E
+    if (rc) return rc;
+    HIP_TRY(vcabm_correct(d, p, u, c, abstol, reltol, n, un, h->vc_partial, err3, st));             // C
+    h->vc_k = k; h->vc_dt = dt;
+    return CNF_OK;
+}
+
+int cnf_vcabm_accept(cnf_handle* h, const float* eps, const float* ys, int64_t B, float abstol, float reltol,
+                     double* err_up, void* stream) {
+    int rc = vc_check(h, eps, ys, B, "cnf_vcabm_accept");
+    if (rc) return rc;
+    if (B == 0) return CNF_OK;
+    if (h->vc_k == 0) return fail(CNF_ERR_INVALID, "cnf_vcabm_accept: no pending attempt");
+    const int k = h->vc_k;
+    if (err_up && (k >= CNF_VCABM_MAX_ORDER || h->vc_nhist < k))
+        return fail(CNF_ERR_INVALID, "cnf_vcabm_accept: the order k+1 estimate needs k accepted steps and k < 12");
+    DeviceGuard g(h->cfg.device_id);
+    hipStream_t st = (hipStream_t)stream;
+    const size_t n = (size_t)h->S * (size_t)B;
+    float *u = vc_vec(h, h->vc_iu), *un = vc_vec(h, h->vc_iun), *fnew = vc_vec(h, h->vc_ifn);
+    StageIn in{};
+    in.u = un; in.nprev = 0; in.dt = 0.f;
+    rc = eval_dynamics(h, in, (float)(h->vc_t + h->vc_dt), eps, ys, B, fnew, nullptr, false, st);   // E
+    if (rc) return rc;
+    if (err_up) {
+        // gamma*_j of the Adams-Moulton family: sum_{i<=j} gamma*_i / (j - i + 1) = [j == 0]
+        double gs[kVcSlots + 2];
+        gs[0] = 1.0;
+        for (int j = 1; j <= k + 1; ++j) {
+            double a = 0.0;
+            for (int i = 0; i < j; ++i) a += gs[i] / (double)(j - i + 1);
+            gs[j] = -a;
+        }
+        VcCoef c{};
+        c.ps_new = vc_diffs(h, h->vc_cur ^ 1);
+        c.ld = n; c.k = k;
+        c.e0 = (float)(h->vc_dt * gs[k + 1]);
+        HIP_TRY(vcabm_errup(fnew, u, un, c, abstol, reltol, (int64_t)n, h->vc_partial, err_up, st));
+    }
+    std::swap(h->vc_iu, h->vc_iun);
+    std::swap(h->vc_if, h->vc_ifn);
+    h->vc_cur ^= 1;
+    for (int i = kVcSlots; i > 0; --i) h->vc_hist[i] = h->vc_hist[i - 1];
+    h->vc_hist[0] = h->vc_dt;
+    h->vc_t += h->vc_dt;
+    h->vc_nhist += 1;
+    h->vc_k = 0;
+    return CNF_OK;
+}
+
+int cnf_vcabm_state(cnf_handle* h, int64_t B, float* u_out, double* t_out, void* stream) {
+    if (!h) return fail(CNF_ERR_INVALID, "cnf_vcabm_state: null handle");
+    if (h->vc_B < 0 || B != h->vc_B) return fail(CNF_ERR_INVALID, "cnf_vcabm_state: cnf_vcabm_begin was not called for this batch");
+    if (t_out) *t_out = h->vc_t;
+    if (u_out && B > 0) {
+        DeviceGuard g(h->cfg.device_id);
+        HIP_TRY(hipMemcpyAsync(u_out, vc_vec(h, h->vc_iu), (size_t)h->S * (size_t)B * sizeof(float), hipMemcpyDeviceToDevice,
+                               (hipStream_t)stream));
+    }
     return CNF_OK;
 }
 

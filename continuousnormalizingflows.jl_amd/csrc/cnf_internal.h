@@ -112,4 +112,23 @@ hipError_t grad_slab_launch(const cnf_config& c, const float* packed_dev, const 
 int mfma_plan_zr(const MfmaPlan* p);   // state k-steps of the forward instance (checkpoint stride)
 bool mfma_plan_is_per_wave(const MfmaPlan* p);
 
+// ---- variable-coefficient Adams PECE (cnf_vcabm.hip): elementwise passes of one step attempt ----
+constexpr int kVcSlots = 13;   // Phi*_0 .. Phi*_12: orders 1..12 plus the difference the order-raising estimate needs
+struct VcCoef {
+    const float* ps_old;   // Phi*_j(n-1): kVcSlots vectors, stride ld
+    float* ps_new;         // Phi*_j(n)
+    size_t ld;
+    int k, m;              // order (predictor terms); differences the history supports (m <= k + 1)
+    float dt;
+    float beta[kVcSlots];
+    float g[kVcSlots + 1];
+    float e0, e1, e2;      // dt (g_k - g_{k-1}), dt (g_{k-1} - g_{k-2}), dt (g_{k-2} - g_{k-3});  errup: e0 = dt gamma*_{k+1}
+};
+size_t vcabm_partial_doubles();
+hipError_t vcabm_predict(const float* f, const float* u, const VcCoef& c, int64_t n, float* p, hipStream_t st);
+hipError_t vcabm_correct(const float* d, const float* p, const float* u, const VcCoef& c, float abstol, float reltol,
+                         int64_t n, float* unew, double* partial, double* err3, hipStream_t st);
+hipError_t vcabm_errup(const float* fnew, const float* u, const float* unew, const VcCoef& c, float abstol, float reltol,
+                       int64_t n, double* partial, double* err1, hipStream_t st);
+
 }  // namespace cnf

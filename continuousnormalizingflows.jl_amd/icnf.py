@@ -30,7 +30,7 @@ from . import _lib
 __all__ = [
     "ICNF", "TrainMode", "TestMode", "Dense", "Chain", "PlanarLayer", "tanh", "softplus", "identity",
     "HIPVecJacMatrixMode", "HIPJacVecMatrixMode", "LuxVecJacMatrixMode", "LuxJacVecMatrixMode",
-    "DIVecJacMatrixMode", "DIJacVecMatrixMode", "Tsit5", "RK4", "setup", "inference", "generate",
+    "DIVecJacMatrixMode", "DIJacVecMatrixMode", "Tsit5", "RK4", "VCABM", "setup", "inference", "generate",
     "loss", "augmented_f", "loss_and_gradient",
 ]
 
@@ -192,12 +192,15 @@ class RK4:
     alg_id = _lib.ALG_RK4
 
 
+class VCABM:
+    """The reference's default algorithm (src/core/icnf.jl:84-89): adaptive order (1..12), adaptive step Adams
+    predictor-corrector (OrdinaryDiffEqAdamsBashforthMoulton.VCABM).  Always adaptive here."""
+    alg_id = _lib.ALG_VCABM
+
+
 # ---------------------------------------------------------------------------------------
 # ICNF
 # ---------------------------------------------------------------------------------------
-_warned_default_alg = False
-
-
 class _Handle:
     """Owns one cnf_handle (one trace mode / regulariser combination)."""
 
@@ -228,10 +231,10 @@ class ICNF:
     """Keyword constructor mirroring `ICNF(; ...)` (src/core/icnf.jl:53-103).
 
     Differences forced by the fixed-step HIP path (all raise instead of silently falling back):
-      * `sol_kwargs.alg` is Tsit5() or RK4().  With adaptive=False (and `dt` or `nsteps`) the whole solve is one
-        fused launch; Tsit5() with adaptive=True (OrdinaryDiffEq's default for it; reltol/abstol default 1e-4 as in
-        the reference) steps under a PI controller on the host with one device attempt per step
-        (`_adaptive_integrate`).  The reference's own default algorithm (VCABM) is not implemented.
+      * `sol_kwargs.alg` is VCABM() (the reference's default when none is given), Tsit5() or RK4().  Tsit5 / RK4 with
+        adaptive=False (and `dt` or `nsteps`): the whole solve is one fused launch.  VCABM() and Tsit5() with
+        adaptive=True (OrdinaryDiffEq's default; reltol/abstol default 1e-4 as in the reference) step under the
+        solver's controller on the host with one device attempt per step (`_vcabm_integrate`, `_adaptive_integrate`).
       * `nn` must be a Chain of Dense layers with identity/tanh/softplus activations.
       * data_type is Float32.
     """
@@ -326,23 +329,16 @@ class ICNF:
     def _solver(self):
         kw = self.sol_kwargs
         alg = kw.get("alg")
-        if alg is None:
-            # The reference's default is sol_kwargs = (alg = VCABM(), reltol = abstol = 1e-4, ...) (src/core/icnf.jl:84-89).
-            # VCABM is not implemented; an ICNF built without `alg` solves with adaptive Tsit5 at the same tolerances
-            # (same accuracy target, different step sequence) and says so once, like the reference's `@warn maxlog = 1`.
-            global _warned_default_alg
-            if not _warned_default_alg:
-                import warnings
-                warnings.warn("sol_kwargs has no `alg`: the reference's default VCABM() is not implemented; using adaptive "
-                              "Tsit5() with reltol = abstol = 1e-4", stacklevel=3)
-                _warned_default_alg = True
-            alg = Tsit5()
+        if alg is None:   # the reference's default: sol_kwargs = (alg = VCABM(), reltol = abstol = 1e-4, ...) (src/core/icnf.jl:84-89)
+            alg = VCABM()
             kw["alg"] = alg
         if not hasattr(alg, "alg_id"):
-            raise NotImplementedError("sol_kwargs.alg must be Tsit5() or RK4() (VCABM and other OrdinaryDiffEq algorithms "
+            raise NotImplementedError("sol_kwargs.alg must be VCABM(), Tsit5() or RK4() (other OrdinaryDiffEq algorithms "
                                       "are not implemented)")
-        if kw.get("adaptive", True) and alg.alg_id != _lib.ALG_TSIT5:
-            raise NotImplementedError("adaptive stepping is implemented for Tsit5() only; use adaptive=False with RK4()")
+        if kw.get("adaptive", True) and alg.alg_id == _lib.ALG_RK4:
+            raise NotImplementedError("adaptive stepping is implemented for VCABM() and Tsit5(); use adaptive=False with RK4()")
+        if not kw.get("adaptive", True) and alg.alg_id == _lib.ALG_VCABM:
+            raise NotImplementedError("VCABM() is implemented as an adaptive solver only; use Tsit5() or RK4() with adaptive=False")
         return alg.alg_id
 
     @property
@@ -498,7 +494,7 @@ def _split_args(icnf: ICNF, args, what: str):
 
 
 def _adaptive_integrate(icnf: ICNF, h: "_Handle", u0: torch.Tensor, t0: float, t1: float,
-                        e: Optional[torch.Tensor], y: Optional[torch.Tensor], group=None) -> torch.Tensor:
+                        e: Optional[torch.Tensor], y: Optional[torch.Tensor], group=None, _tsit5: bool = False) -> torch.Tensor:
     """Adaptive Tsit5 from t0 to t1 (either direction) on the (B, S) state u0: what `SciMLBase.solve(prob, Tsit5();
     reltol, abstol)` does in `base_sol` (src/core/base_icnf.jl:134-140), restated from OrdinaryDiffEq's documented
     algorithm — Hairer's initial step, embedded 4th-order error estimate scaled by `abstol + reltol max(|u_prev|, |u|)`
@@ -509,6 +505,8 @@ def _adaptive_integrate(icnf: ICNF, h: "_Handle", u0: torch.Tensor, t0: float, t
     of the Julia implementation cannot be checked here (no Julia); parity is against the fp64 oracle's restatement
     of the same algorithm and against fine fixed-step solves."""
     import torch.distributed as dist
+    if icnf._solver() == _lib.ALG_VCABM and not _tsit5:
+        return _vcabm_integrate(icnf, h, u0, t0, t1, e, y, group=group)
     kw = icnf.sol_kwargs
     reltol, abstol = float(kw.get("reltol", 1e-4)), float(kw.get("abstol", 1e-4))
     maxiters = int(kw.get("maxiters", 100000))
@@ -585,6 +583,112 @@ def _adaptive_integrate(icnf: ICNF, h: "_Handle", u0: torch.Tensor, t0: float, t
     else:
         raise RuntimeError("adaptive solve: maxiters reached")
     return u
+
+
+def _vcabm_integrate(icnf: ICNF, h: "_Handle", u0: torch.Tensor, t0: float, t1: float,
+                     e: Optional[torch.Tensor], y: Optional[torch.Tensor], group=None) -> torch.Tensor:
+    """`SciMLBase.solve(prob, VCABM(); reltol, abstol)` of `base_sol` (src/core/base_icnf.jl:134-140) - the reference's
+    default solver - from t0 to t1 (either direction) on the (B, S) state u0.  The device keeps the multistep state and
+    does the PECE passes (`cnf_vcabm_*`, csrc/cnf_vcabm.hip); this loop is the host side of the solver: order ramp
+    1 -> 3 over the first steps, then Shampine-Gordon order selection from the error estimates of orders k-2 .. k+1, the
+    integral step-size controller dt / clamp(EEst^(1/(k+1)) / gamma, 1/qmax, 1/qmin) (gamma = 9/10, qmin = 1/5,
+    qmax = 10; the same factor after a rejection) and Hairer's initial step.  Restated from the published algorithm
+    (see oracle/cnf_oracle64.py::integrate_vcabm, the fp64 oracle this is tested against); the Julia package's exact
+    step / order sequence cannot be checked here.  The error norms run over the whole S x B state, so a sharded
+    solve all-reduces the squared sums and every rank takes the same steps."""
+    import torch.distributed as dist
+    kw = icnf.sol_kwargs
+    reltol, abstol = float(kw.get("reltol", 1e-4)), float(kw.get("abstol", 1e-4))
+    maxiters = int(kw.get("maxiters", 100000))
+    dev = icnf.device
+    B, S = u0.shape
+    lib, st = h.lib, _stream_ptr(dev)
+    sharded = dist.is_available() and dist.is_initialized()
+    tdir = 1.0 if t1 >= t0 else -1.0
+    span = abs(t1 - t0)
+    stats = {"naccept": 0, "nreject": 0, "nf": 0, "dts": [], "orders": []}
+    icnf.last_solve_stats = stats
+    if B == 0 or span == 0.0:
+        return u0.clone()
+
+    def allsum(vals):
+        t = torch.tensor(vals, dtype=torch.float64, device=dev if (sharded and dist.get_backend(group) == "nccl") else "cpu")
+        if sharded:
+            dist.all_reduce(t, group=group)
+        return [float(v) for v in t]
+
+    u0 = u0.contiguous()
+    _lib.check(lib.cnf_vcabm_begin(h.ptr, t0, _ptr(u0), _ptr(e), _ptr(y), B, st))
+    stats["nf"] += 1
+    ntot = allsum([float(B * S)])[0] if sharded else float(B * S)
+    if "dt" in kw:
+        dt = min(abs(float(kw["dt"])), span)
+    else:   # ode_determine_initdt (Hairer, Noersett, Wanner I, II.4) with the algorithm order 7
+        du = torch.empty_like(u0)
+
+        def f(u, t):
+            _lib.check(lib.cnf_aug_f(h.ptr, _ptr(du), _ptr(u), t, _ptr(e), _ptr(y), B, st))
+            stats["nf"] += 1
+            return du.clone()
+
+        sk = abstol + u0.abs() * reltol
+        f0 = f(u0, t0)
+        s0, s1 = allsum([float(((u0 / sk).double() ** 2).sum()), float(((f0 / sk).double() ** 2).sum())])
+        d0, d1 = math.sqrt(s0 / ntot), math.sqrt(s1 / ntot)
+        dt0 = 1e-6 if (d0 < 1e-5 or d1 < 1e-5) else 0.01 * d0 / d1
+        dt0 = min(dt0, span)
+        f1 = f(u0 + tdir * dt0 * f0, t0 + tdir * dt0)
+        (s2,) = allsum([float((((f1 - f0) / sk).double() ** 2).sum())])
+        d2 = math.sqrt(s2 / ntot) / dt0
+        dmax = max(d1, d2)
+        dt1 = max(1e-6, dt0 * 1e-3) if dmax <= 1e-15 else 10.0 ** (-(2.0 + math.log10(dmax)) / 8.0)
+        dt = min(100.0 * dt0, dt1, span)
+    gamma, qmin, qmax = 0.9, 0.2, 10.0
+    err3 = torch.zeros(3, dtype=torch.float64, device=dev)
+    errp = torch.zeros(1, dtype=torch.float64, device=dev)
+    t, k, step = t0, 1, 1
+    for _ in range(maxiters):
+        if abs(t1 - t) <= 1e-7 * max(1.0, span):
+            break
+        last = dt >= abs(t1 - t) * (1.0 - 1e-6)
+        hstep = abs(t1 - t) if last else dt          # tstop: never step over t1
+        _lib.check(lib.cnf_vcabm_attempt(h.ptr, k, tdir * hstep, _ptr(e), _ptr(y), B, abstol, reltol, _ptr(err3), st))
+        stats["nf"] += 1
+        s_k, s_km1, s_km2 = allsum(err3.tolist())
+        eest = math.sqrt(s_k / ntot)
+        if not math.isfinite(eest):
+            raise FloatingPointError("adaptive solve: non-finite error estimate (unstable dynamics)")
+        if eest > 1.0:    # reject: same state, smaller step, same order
+            stats["nreject"] += 1
+            dt = hstep / max(1.0 / qmax, min(1.0 / qmin, eest ** (1.0 / (k + 1)) / gamma))
+            continue
+        select = step > 4 and k >= 3
+        lower = select and max(math.sqrt(s_km2 / ntot), math.sqrt(s_km1 / ntot)) <= eest
+        want_up = select and not lower and k < _lib.VCABM_MAX_ORDER
+        _lib.check(lib.cnf_vcabm_accept(h.ptr, _ptr(e), _ptr(y), B, abstol, reltol, _ptr(errp) if want_up else None, st))
+        stats["nf"] += 1
+        knew = k
+        if not select:
+            knew = min(k + 1, 3)
+        elif lower:
+            knew = k - 1
+        elif want_up:
+            (s_kp1,) = allsum(errp.tolist())
+            if math.sqrt(s_kp1 / ntot) < eest:
+                knew = k + 1
+                eest = 1.0     # keeps the step size (up to the safety factor) across the order change
+        q = 1.0 / qmax if eest == 0.0 else max(1.0 / qmax, min(1.0 / qmin, eest ** (1.0 / (knew + 1)) / gamma))
+        t = t1 if last else t + tdir * hstep
+        stats["naccept"] += 1
+        stats["dts"].append(tdir * hstep)
+        stats["orders"].append(k)
+        k, step = knew, step + 1
+        dt = hstep / q
+    else:
+        raise RuntimeError("adaptive solve: maxiters reached")
+    out = torch.empty_like(u0)
+    _lib.check(lib.cnf_vcabm_state(h.ptr, B, _ptr(out), None, st))
+    return out
 
 
 def inference(icnf: ICNF, mode: Mode, *args, eps: Optional[torch.Tensor] = None,
@@ -750,14 +854,17 @@ def loss_and_gradient(icnf: ICNF, mode: Mode, *args, eps: Optional[torch.Tensor]
         # of the step sizes on ps is ignored - the discretise-then-optimise convention)
         u0 = torch.empty(B, icnf.S, device=dev, dtype=torch.float32)
         _lib.check(h.lib.cnf_assemble_u0(h.ptr, _ptr(x), B, _ptr(u0), _stream_ptr(dev)))
-        _adaptive_integrate(icnf, h, u0, t0, t1, e, y, group=group)
+        # (also under VCABM: a multistep recurrence has no one-step discrete adjoint here, so training differentiates
+        # the adaptive Tsit5 discretisation at the same tolerances - the reference's own QuadratureAdjoint gradient is
+        # likewise a separate solve that matches the forward pass only to tolerance)
+        _adaptive_integrate(icnf, h, u0, t0, t1, e, y, group=group, _tsit5=True)
         ts = [t0]
         for d in icnf.last_solve_stats["dts"]:
             ts.append(ts[-1] + d)
         ts[-1] = t1
         grid = (C.c_float * len(ts))(*ts)
         icnf.last_solve_stats["tgrid"] = ts
-        _lib.check(h.lib.cnf_loss_grad_grid(h.ptr, icnf._solver(), len(ts) - 1, grid, _ptr(x), _ptr(e), _ptr(y), B, lam,
+        _lib.check(h.lib.cnf_loss_grad_grid(h.ptr, _lib.ALG_TSIT5, len(ts) - 1, grid, _ptr(x), _ptr(e), _ptr(y), B, lam,
                                             _ptr(grad), _ptr(gx), _ptr(sums), _stream_ptr(dev)))
     else:
         _lib.check(h.lib.cnf_loss_grad_fixed(h.ptr, icnf._solver(), icnf._nsteps(t0, t1), t0, t1, _ptr(x), _ptr(e),

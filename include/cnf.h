@@ -28,7 +28,8 @@
  *   lifetime / parameters    cnf_create, cnf_destroy, cnf_set_params
  *   boundary A (per call)    cnf_aug_f                      du = augmented_f(u, p, t)
  *   boundary B (whole solve) cnf_integrate_fixed, cnf_inference_fixed, cnf_loss_sums
- *   caller-driven solves     cnf_assemble_u0, cnf_step_embedded (adaptive Tsit5 attempt), cnf_epilogue
+ *   caller-driven solves     cnf_assemble_u0, cnf_step_embedded (adaptive Tsit5 attempt), cnf_epilogue,
+ *                            cnf_vcabm_begin / _attempt / _accept / _state (the reference's default alg VCABM)
  *   training                 cnf_loss_grad_fixed, cnf_loss_grad_grid  (dloss/dps, optionally dloss/dxs)
  *   introspection            cnf_version, cnf_last_error, cnf_kernel_path, cnf_grad_path, cnf_repack_on_device
  */
@@ -144,6 +145,34 @@ int cnf_step_embedded(cnf_handle* h, int alg, int flags, float t, float dt, cons
  * the inference_sol epilogue on a final state: logp (B), regs (3B, may be NULL) (src/core/base_icnf.jl:158-172). */
 int cnf_assemble_u0(cnf_handle* h, const float* x, int64_t B, float* u0, void* stream);
 int cnf_epilogue(cnf_handle* h, const float* u, int64_t B, float* logp, float* regs, void* stream);
+
+/* The reference's DEFAULT solver: `alg = VCABM()`, reltol = abstol = 1e-4 (src/core/icnf.jl:84-89), run by
+ * SciMLBase.solve in base_sol (src/core/base_icnf.jl:134-140).  VCABM lives in OrdinaryDiffEqAdamsBashforthMoulton
+ * (compat "2", not vendored): the variable-step variable-order Adams predictor-corrector in divided-difference form
+ * (Hairer, Noersett, Wanner I, III.5; Shampine & Gordon's PECE step).  The library keeps the multistep state - u_n, f_n,
+ * the modified divided differences Phi*_j(n-1), the accepted step sizes - on the device; the caller drives the step-size
+ * and order policy (the host side of the reference's solver), reading one to three error sums per step:
+ *
+ *   cnf_vcabm_begin    u_0 (S x B, device) at t0; evaluates f_0; forgets any earlier history.
+ *   cnf_vcabm_attempt  one PEC pass of order k (= number of predictor terms, 1 <= k <= min(12, accepted steps + 1)) with
+ *                      step dt (either sign): p = u_n + dt sum_{j<k} g_j Phi*_j(n), f(p, t_n + dt),
+ *                      u_{n+1} = p + dt g_k Phi_k(n+1).  err3 (device, 3 doubles) receives the sums over the whole S x B
+ *                      state of the squared local error estimates of orders k, k-1, k-2, each scaled by
+ *                      abstol + reltol max(|u_n|, |u_{n+1}|):  dt (g_j - g_{j-1}) Phi_j(n+1), j = k, k-1, k-2 (0 where
+ *                      k is too small).  The state is unchanged: a rejected attempt is simply repeated with another dt / k.
+ *   cnf_vcabm_accept   commits the pending attempt: f_{n+1} = f(u_{n+1}, t_{n+1}) (the final E), history rotation.
+ *                      err_up (device, 1 double, or NULL): squared sum of the order k+1 estimate
+ *                      dt gamma*_{k+1} Phi_{k+1}(n+1) from the re-evaluated derivative (needs k accepted steps, k < 12).
+ *   cnf_vcabm_state    copies the current state into u_out (S x B, device; may be NULL), current time into *t_out (host).
+ *
+ * eps / ys as in cnf_aug_f, the same arrays on every call of one solve.  Sharded solves all-reduce the sums. */
+#define CNF_VCABM_MAX_ORDER 12
+int cnf_vcabm_begin(cnf_handle* h, float t0, const float* u0, const float* eps, const float* ys, int64_t B, void* stream);
+int cnf_vcabm_attempt(cnf_handle* h, int order, float dt, const float* eps, const float* ys, int64_t B, float abstol,
+                      float reltol, double* err3, void* stream);
+int cnf_vcabm_accept(cnf_handle* h, const float* eps, const float* ys, int64_t B, float abstol, float reltol,
+                     double* err_up, void* stream);
+int cnf_vcabm_state(cnf_handle* h, int64_t B, float* u_out, double* t_out, void* stream);
 
 /* Which kernel family the handle resolved to (CNF_PATH_SIMT, CNF_PATH_MFMA or CNF_PATH_LAYERED). */
 int cnf_kernel_path(const cnf_handle* h);

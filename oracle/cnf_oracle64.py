@@ -291,6 +291,168 @@ def integrate_adaptive_tsit5(spec: Spec, p, u0: np.ndarray, t0: float, t1: float
     return u, stats
 
 
+def adams_moulton_gammas(n: int):
+    """gamma*_0 .. gamma*_{n-1} of the Adams-Moulton family: sum_{m=0}^{j} gamma*_m / (j - m + 1) = [j == 0]
+    (Hairer, Noersett, Wanner I, III.1 eq. 1.9'): 1, -1/2, -1/12, -1/24, -19/720, -3/160, ..."""
+    from fractions import Fraction
+    gs = [Fraction(1)]
+    for j in range(1, n):
+        gs.append(-sum(gs[m] / (j - m + 1) for m in range(j)))
+    return [float(x) for x in gs]
+
+
+class VcabmStepper:
+    """The multistep state and the PECE passes of the variable-coefficient Adams method (Hairer, Noersett, Wanner I, III.5,
+    eqs. 5.7-5.10; Shampine & Gordon's error estimates), one attempt at a time so a test can drive the HIP entry points
+    and this with the same (order, dt) script.  Orders / indices as in the text: order k = number of predictor terms."""
+
+    def __init__(self, f, u0, t0, abstol, reltol, max_order: int = 12):
+        self.f, self.u, self.t = f, np.asarray(u0, dtype=np.float64).copy(), t0
+        self.abstol, self.reltol, self.max_order = abstol, reltol, max_order
+        self.fn = f(self.u, t0)
+        self.hist, self.phistar_prev, self.pending = [], [], None
+        self.gstar = adams_moulton_gammas(max_order + 3)
+        self.n = self.u.size
+
+    def _rms_sq(self, x):
+        return float((x * x).sum())
+
+    def attempt(self, k: int, h: float):
+        """-> (u_new, [sum of squared scaled errors of orders k, k-1, k-2])"""
+        assert 1 <= k <= min(self.max_order, len(self.hist) + 1)
+        dts = [h] + self.hist
+        m = min(k + 1, len(self.hist) + 1)          # differences the history supports
+        # beta_j(n) = prod_{i<j} (t_{n+1} - t_{n-i}) / (t_n - t_{n-1-i});  Phi_j(n) = Phi_{j-1}(n) - Phi*_{j-1}(n-1)
+        beta = [1.0]
+        for j in range(1, m):
+            beta.append(beta[-1] * sum(dts[:j]) / sum(dts[1:j + 1]))
+        phi = [self.fn]
+        for j in range(1, m):
+            phi.append(phi[-1] - self.phistar_prev[j - 1])
+        phistar = [bj * pj for bj, pj in zip(beta, phi)]
+        # g_j(n) = c_{j,1}: c_{0,q} = 1/q, c_{1,q} = 1/(q(q+1)), c_{j,q} = c_{j-1,q} - c_{j-1,q+1} h / (t_{n+1} - t_{n-j+1})
+        ng = k + 1
+        c = [1.0 / q for q in range(1, ng + 2)]
+        g = [c[0]]
+        for j in range(1, ng):
+            if j == 1:
+                c = [1.0 / (q * (q + 1)) for q in range(1, ng + 1)]
+            else:
+                xi = sum(dts[:j])
+                c = [c[q] - c[q + 1] * h / xi for q in range(len(c) - 1)]
+            g.append(c[0])
+        up = self.u + h * sum(g[j] * phistar[j] for j in range(k))                # P
+        dp = self.f(up, self.t + h)                                               # E
+        pn = self._diffs(dp, k, phistar)
+        un = up + h * g[k] * pn[k]                                                # C
+        sc = self.abstol + np.maximum(np.abs(self.u), np.abs(un)) * self.reltol
+        errs = [self._rms_sq(h * (g[k] - g[k - 1]) * pn[k] / sc),
+                self._rms_sq(h * (g[k - 1] - g[k - 2]) * pn[k - 1] / sc) if k >= 2 else 0.0,
+                self._rms_sq(h * (g[k - 2] - g[k - 3]) * pn[k - 2] / sc) if k >= 3 else 0.0]
+        self.pending = (k, h, phistar, un, sc)
+        self.last_g, self.last_beta = g, beta
+        return un, errs
+
+    @staticmethod
+    def _diffs(d, upto, phistar):   # Phi_j(n+1), j = 0 .. upto, from a derivative at t_{n+1}
+        out = [d]
+        for j in range(1, upto + 1):
+            out.append(out[-1] - phistar[j - 1])
+        return out
+
+    def accept(self, want_up: bool = False):
+        """commit the pending attempt (final E); -> sum of squared scaled errors of order k+1, or None"""
+        k, h, phistar, un, sc = self.pending
+        fnew = self.f(un, self.t + h)                                             # E
+        up = None
+        if want_up:
+            assert k < self.max_order and len(self.hist) >= k
+            up = self._rms_sq(h * self.gstar[k + 1] * self._diffs(fnew, k + 1, phistar)[k + 1] / sc)
+        self.u, self.fn, self.t = un, fnew, self.t + h
+        self.hist = [h] + self.hist[:self.max_order]
+        self.phistar_prev, self.pending = phistar, None
+        return up
+
+
+def integrate_vcabm(spec: Spec, p, u0: np.ndarray, t0: float, t1: float, reltol: float, abstol: float,
+                    eps=None, ys=None, dt0: Optional[float] = None, maxiters: int = 100000, max_order: int = 12):
+    """base_sol with the reference's DEFAULT algorithm VCABM() (src/core/icnf.jl:84-89, base_icnf.jl:134-140): the
+    variable-step, variable-order Adams predictor-corrector in variable-coefficient (divided-difference) form, restated in
+    float64 from the published algorithm - Hairer, Noersett, Wanner I, III.5 (beta_j, Phi_j, Phi*_j, g_j recurrences)
+    with Shampine & Gordon's PECE step, error estimate and order selection - in the arrangement
+    OrdinaryDiffEqAdamsBashforthMoulton uses as far as it can be recalled without the package: order k starts at 1 and
+    rises by one per accepted step up to 3 during the first 4 steps; predictor with k terms, corrector adds the
+    (k+1)-th, error estimate dt (g_k - g_{k-1}) Phi_k(n+1) scaled by abstol + reltol max(|u_prev|, |u|) under the
+    RMS norm over the WHOLE state; after that the estimates for orders k-1, k-2 (from the predictor differences) and
+    k+1 (dt gamma*_{k+1} Phi_{k+1}(n+1) from the re-evaluated derivative) lower the order when max(err_{k-2}, err_{k-1})
+    <= err_k, or raise it when err_{k+1} < err_k (the step-size error is then set to 1); integral step-size controller
+    dt / clamp(EEst^(1/(k+1)) / gamma, 1/qmax, 1/qmin), gamma = 9/10, qmin = 1/5, qmax = 10, same factor on a rejection;
+    Hairer's initial step with the algorithm order 7.  PARITY UNPINNED: the Julia package is absent, so its exact
+    step and order sequence is unverified; this is the oracle the HIP path's VCABM mode is compared with, itself
+    checked against fine fixed-step solves and on a linear field.  Returns (u1, stats)."""
+    f = lambda u, t: aug_f(spec, p, u, t, eps, ys).astype(np.float64)
+    n = np.asarray(u0).size
+    tdir = 1.0 if t1 >= t0 else -1.0
+    span = abs(t1 - t0)
+    rms = lambda x: math.sqrt(float((x * x).sum()) / n)
+    s = VcabmStepper(f, u0, t0, abstol, reltol, max_order)
+    nf = 1
+    if dt0 is None:
+        u, fn = s.u, s.fn
+        sk = abstol + np.abs(u) * reltol
+        d0, d1 = rms(u / sk), rms(fn / sk)
+        h0 = 1e-6 if (d0 < 1e-5 or d1 < 1e-5) else 0.01 * d0 / d1
+        h0 = min(h0, span)
+        f1 = f(u + tdir * h0 * fn, t0 + tdir * h0)
+        nf += 1
+        d2 = rms((f1 - fn) / sk) / h0
+        dm = max(d1, d2)
+        h1 = max(1e-6, h0 * 1e-3) if dm <= 1e-15 else 10.0 ** (-(2.0 + math.log10(dm)) / 8.0)
+        dt = min(100.0 * h0, h1, span)
+    else:
+        dt = min(abs(dt0), span)
+    gamma, qmin, qmax = 0.9, 0.2, 10.0
+    t, k, step = t0, 1, 1
+    stats = {"naccept": 0, "nreject": 0, "dts": [], "orders": []}
+    for _ in range(maxiters):
+        if abs(t1 - t) <= 1e-12 * max(1.0, span):
+            break
+        last = dt >= abs(t1 - t) * (1.0 - 1e-12)
+        h = tdir * (abs(t1 - t) if last else dt)
+        _, errs = s.attempt(k, h)
+        nf += 1
+        eest = math.sqrt(errs[0] / n)
+        if not eest <= 1.0:
+            stats["nreject"] += 1
+            dt = abs(h) / max(1.0 / qmax, min(1.0 / qmin, eest ** (1.0 / (k + 1)) / gamma))
+            continue
+        select = step > 4 and k >= 3
+        lower = select and max(math.sqrt(errs[2] / n), math.sqrt(errs[1] / n)) <= eest
+        want_up = select and not lower and k < max_order
+        up = s.accept(want_up)
+        nf += 1
+        knew = k
+        if not select:
+            knew = min(k + 1, 3)
+        elif lower:
+            knew = k - 1
+        elif want_up and math.sqrt(up / n) < eest:
+            knew = k + 1
+            eest = 1.0
+        q = 1.0 / qmax if eest == 0 else max(1.0 / qmax, min(1.0 / qmin, eest ** (1.0 / (knew + 1)) / gamma))
+        t = t1 if last else t + h
+        s.t = t
+        stats["naccept"] += 1
+        stats["dts"].append(h)
+        stats["orders"].append(k)
+        k, step = knew, step + 1
+        dt = abs(h) / q
+    else:
+        raise RuntimeError("maxiters")
+    stats["nf"] = nf
+    return s.u, stats
+
+
 def std_normal_logpdf(z: np.ndarray) -> np.ndarray:
     """logpdf of MvNormal(Zeros(d), Eye(d)) per column (src/core/icnf.jl:76-79)."""
     d = z.shape[0]

@@ -1,4 +1,5 @@
-"""Adaptive Tsit5 (reltol = abstol = 1e-4, the reference's defaults) against the fixed 40-step solve at cfg2 scale."""
+"""Adaptive solves (reltol = abstol = 1e-4, the reference's defaults; Tsit5 and the reference's default VCABM) against the
+fixed 40-step solve at cfg2 scale."""
 import json, os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -12,7 +13,9 @@ X = torch.tensor(xs.T.copy(), device=dev).t(); E = torch.tensor(eps.T.copy(), de
 out = {}
 for name, kw in (("fixed_tsit5_40", dict(alg=pkg.Tsit5(), adaptive=False, nsteps=40)),
                  ("adaptive_1e-4", dict(alg=pkg.Tsit5(), reltol=1e-4, abstol=1e-4)),
-                 ("adaptive_1e-6", dict(alg=pkg.Tsit5(), reltol=1e-6, abstol=1e-6))):
+                 ("adaptive_1e-6", dict(alg=pkg.Tsit5(), reltol=1e-6, abstol=1e-6)),
+                 ("vcabm_1e-4", dict(alg=pkg.VCABM(), reltol=1e-4, abstol=1e-4)),
+                 ("vcabm_1e-6", dict(alg=pkg.VCABM(), reltol=1e-6, abstol=1e-6))):
     layers = [pkg.Dense(spec.widths[i], spec.widths[i + 1], ["identity", "tanh", "softplus"][spec.acts[i]]) for i in range(4)]
     icnf = pkg.ICNF(nvariables=8, naugments=0, nn=pkg.Chain(*layers), steer_rate=0.0, lambda1=0.0, lambda2=0.0, lambda3=0.0,
                     device=dev, sol_kwargs=kw)
@@ -26,6 +29,7 @@ for name, kw in (("fixed_tsit5_40", dict(alg=pkg.Tsit5(), adaptive=False, nsteps
     if icnf.adaptive:
         st = icnf.last_solve_stats
         r.update(naccept=st["naccept"], nreject=st["nreject"], nf=st["nf"])
+        if "orders" in st: r["orders"] = st["orders"]
     out[name] = r
     if name == "fixed_tsit5_40": base = lp
     else: r["max_abs_dlogp_vs_fixed40"] = float((lp - base).abs().max())

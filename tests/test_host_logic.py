@@ -46,9 +46,10 @@ def test_dimension_and_method_errors(pkg):
         pkg.ICNF(nvariables=2, compute_mode=object())
     with pytest.raises(TypeError, match="no CPU fallback"):
         pkg.ICNF(nvariables=2, device="cpu")
-    icnf = pkg.ICNF(nvariables=2)                                            # reference default alg (VCABM) -> adaptive Tsit5, warned once
-    with pytest.warns(UserWarning, match="VCABM"):
-        assert icnf._solver() == 1 and icnf.adaptive
+    icnf = pkg.ICNF(nvariables=2)                                            # the reference's default: alg = VCABM(), adaptive
+    assert icnf._solver() == pkg._lib.ALG_VCABM and icnf.adaptive and isinstance(icnf.sol_kwargs["alg"], pkg.VCABM)
+    with pytest.raises(NotImplementedError, match="adaptive"):
+        pkg.ICNF(nvariables=2, sol_kwargs=dict(alg=pkg.VCABM(), adaptive=False, dt=0.1))._solver()
     with pytest.raises(NotImplementedError):
         pkg.ICNF(nvariables=2, sol_kwargs=dict(alg=object()))._solver()
     icnf = pkg.ICNF(nvariables=2, sol_kwargs=dict(alg=pkg.Tsit5()))          # OrdinaryDiffEq default: adaptive

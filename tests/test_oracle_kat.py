@@ -175,3 +175,73 @@ def test_two_hidden_layer_trace_identity(oracles):
     Q = W2 * (W1[:, :D] @ W3).T
     tr = np.einsum("aj,ab,bj->j", sig(a2), Q, sig(a1))
     assert np.max(np.abs(du[D] + tr)) < 1e-12
+
+
+# ---- the restatement of the reference's default solver (VCABM) ----
+
+def test_adams_moulton_gammas_known_values(oracles):
+    o64, _ = oracles
+    g = o64.adams_moulton_gammas(8)   # Hairer, Noersett, Wanner I, table III.1.2
+    want = [1, -1 / 2, -1 / 12, -1 / 24, -19 / 720, -3 / 160, -863 / 60480, -275 / 24192]
+    assert np.allclose(g, want, rtol=0, atol=1e-15)
+
+
+def test_variable_coefficient_adams_is_exact_on_polynomials(oracles):
+    """u' = (q + 1) t^q with arbitrary step sizes: an order-k attempt (k predictor terms + one corrector term = the
+    interpolation polynomial of degree k through k + 1 derivative values) integrates degree q <= k exactly whatever the
+    step ratios, its order-k error estimate - a k-th divided difference - vanishes for q < k, and with constant steps
+    the g_j are the classical Adams-Bashforth gammas.  Pins the beta / Phi / g recurrences of the restatement."""
+    o64, _ = oracles
+    rng = np.random.default_rng(4)
+    for q in range(0, 9):
+        f = lambda u, t, q=q: np.full_like(u, (q + 1) * t ** q)
+        s = o64.VcabmStepper(f, np.zeros((1, 3)), 0.3, 1.0, 0.0)
+        for n in range(14):
+            h = float(rng.uniform(0.02, 0.2))
+            k = min(n + 1, 12)
+            t_old, u_old = s.t, s.u.copy()
+            un, errs = s.attempt(k, h)
+            exact = (t_old + h) ** (q + 1) - t_old ** (q + 1)
+            if q <= k:
+                assert np.max(np.abs(un - u_old - exact)) < 1e-11, (q, n, k)
+            else:
+                assert np.max(np.abs(un - u_old - exact)) > 1e-13
+            if q < k:
+                assert errs[0] < 1e-20, (q, n, k, errs)
+            up = s.accept(want_up=(k < 12 and len(s.hist) >= k))
+            if up is not None and q < k + 1:
+                assert up < 1e-20
+    # constant steps: g_j = gamma_j = 1, 1/2, 5/12, 3/8, 251/720 (Adams-Bashforth)
+    s = o64.VcabmStepper(lambda u, t: np.ones_like(u), np.zeros((1, 1)), 0.0, 1.0, 0.0)
+    for n in range(6):
+        s.attempt(min(n + 1, 5), 0.1)
+        s.accept()
+    un, _ = s.attempt(5, 0.1)
+    assert abs(float(un.ravel()[0]) - 0.7) < 1e-14
+    assert np.allclose(s.last_g, [1, 1 / 2, 5 / 12, 3 / 8, 251 / 720, 95 / 288], rtol=0, atol=1e-14)
+    assert np.allclose(s.last_beta, 1.0, rtol=0, atol=1e-14)
+
+
+def test_vcabm_restatement_on_the_linear_field(oracles):
+    """Closed form e^{A} z0: the adaptive solve lands within a small multiple of the tolerance at every tolerance, uses
+    fewer derivative evaluations than adaptive Tsit5 at tight tolerances, climbs to high order, and runs backwards."""
+    o64, _ = oracles
+    D = 3
+    spec = linear_spec(o64, D, o64.MODE_EXACT)
+    A, p, xs, z1, _ = linear_problem(D, 2)
+    u0 = np.concatenate([xs, np.zeros((3, xs.shape[1]))])
+    prev = None
+    for tol in (1e-4, 1e-6, 1e-8, 1e-10):
+        u1, st = o64.integrate_vcabm(spec, p, u0, 0.0, 1.0, tol, tol)
+        err = np.max(np.abs(u1[:D] - z1))
+        assert err < 50 * tol, (tol, err)
+        assert np.max(np.abs(u1[D] + np.trace(A))) < 50 * tol
+        assert st["nf"] == 2 + 2 * st["naccept"] + st["nreject"]                 # f0, Hairer's probe, PECE
+        assert st["orders"][:4] == [1, 2, 3, 3]
+        if prev is not None:
+            assert err < prev
+        prev = err
+    _, ts = o64.integrate_adaptive_tsit5(spec, p, u0, 0.0, 1.0, 1e-10, 1e-10)
+    assert st["nf"] < ts["nf"] and max(st["orders"]) >= 8
+    back, sb = o64.integrate_vcabm(spec, p, u1, 1.0, 0.0, 1e-10, 1e-10)
+    assert sb["dts"][0] < 0 and np.max(np.abs(back[:D] - xs)) < 1e-7

@@ -1312,3 +1312,141 @@ def test_reference_smoke_flow_with_all_defaults(conditioned, pkg):
         else:
             d = pkg.ICNFDist.from_fit(model, fitresult, pkg.TestMode())
         assert d.logpdf(r).shape == (64,) and d.pdf(r[:, 0]).dim() == 0 and d.rand(5).shape == (2, 5) and d.rand().shape == (2,)
+
+
+# ---- the reference's default solver: VCABM (variable-order, variable-step Adams PECE) ----
+
+def _vcabm_handle(pkg, icnf, spec, p):
+    h = icnf._handle(mode_of(pkg, spec))
+    icnf._bind_params(h, dev(p))
+    return h
+
+
+@pytest.mark.parametrize("kw,path", [
+    (dict(nvars=8, hidden=[64, 64, 64], reg_z=True, reg_j=True), 0),                        # fused single-call kernel
+    (dict(nvars=3, ncond=2, hidden=[24, 24], act=2), 1),                                    # SIMT family, conditioned
+])
+def test_vcabm_passes_follow_a_scripted_order_and_step_sequence(kw, path, pkg, oracles):
+    """cnf_vcabm_begin / _attempt / _accept / _state driven with a fixed script of (order, dt) - orders up to 12, steps
+    growing, shrinking, a rejected (repeated) attempt, the order k+1 estimate where the history allows it - against the
+    fp64 stepper on the same script: u_{n+1} after every attempt and all four error sums.  No controller involved, so
+    every pass (differences, beta / g coefficients, predictor, corrector, error estimates) is compared one to one."""
+    import ctypes as C
+    o64, _ = oracles
+    L = pkg._lib
+    spec = o64.make_spec(**kw)
+    B = 37
+    p, xs, eps, ys = o64.synth_inputs(spec, B, 21, bias_scale=0.3)
+    icnf = make_icnf(pkg, spec, 1, 1, path=path)
+    h = _vcabm_handle(pkg, icnf, spec, p)
+    S = spec.D + 3
+    u0 = np.vstack([xs.astype(np.float64), np.zeros((spec.naug + 3, B))])
+    abstol, reltol = 1e-5, 1e-4
+    f = lambda u, t: o64.aug_f(spec, p, u, t, eps, ys).astype(np.float64)
+    ref = o64.VcabmStepper(f, u0, 0.1, abstol, reltol)
+    colmajor = lambda a: dev(np.ascontiguousarray(a.T))                                     # (rows, B) -> B x rows = column-major rows x B
+    d_u0, d_eps, d_ys = colmajor(u0), colmajor(eps), (colmajor(ys) if spec.ncond else None)
+    ptr = lambda t: C.c_void_p(0 if t is None else t.data_ptr())
+    st = C.c_void_p(0)
+    L.check(h.lib.cnf_vcabm_begin(h.ptr, 0.1, ptr(d_u0), ptr(d_eps), ptr(d_ys), B, st))
+    err3 = torch.zeros(3, dtype=torch.float64, device="cuda:0")
+    errp = torch.zeros(1, dtype=torch.float64, device="cuda:0")
+    out = torch.empty(B, S, device="cuda:0")
+    script = [(1, 0.01), (2, 0.012), (3, 0.02), (3, 0.02), (4, 0.015), (5, 0.03), (6, 0.03), (7, 0.025), (8, 0.04),
+              (9, 0.03), (10, 0.03), (11, 0.035), (12, 0.03), (12, 0.05), (11, 0.02), (7, 0.06), (3, 0.03), (4, 0.03)]
+    worst = 0.0
+    for i, (k, dt) in enumerate(script):
+        if i == 6:   # a rejected attempt: tried with a larger step first, then repeated - the state must be untouched
+            L.check(h.lib.cnf_vcabm_attempt(h.ptr, k, 3 * dt, ptr(d_eps), ptr(d_ys), B, abstol, reltol, ptr(err3), st))
+        L.check(h.lib.cnf_vcabm_attempt(h.ptr, k, dt, ptr(d_eps), ptr(d_ys), B, abstol, reltol, ptr(err3), st))
+        un, errs = ref.attempt(k, dt)
+        want_up = k < 12 and len(ref.hist) >= k
+        L.check(h.lib.cnf_vcabm_accept(h.ptr, ptr(d_eps), ptr(d_ys), B, abstol, reltol, ptr(errp) if want_up else None, st))
+        up = ref.accept(want_up)
+        tt = C.c_double(0)
+        L.check(h.lib.cnf_vcabm_state(h.ptr, B, ptr(out), C.byref(tt), st))
+        torch.cuda.synchronize()
+        assert abs(tt.value - ref.t) < 1e-6
+        worst = max(worst, float(np.max(np.abs(out.cpu().numpy().T - un))))
+        got = err3.cpu().numpy()
+        # the estimates are high-order differences of float32 derivatives: compare relative to the sum's own size with
+        # the float32 noise floor of a k-th difference (~2^k ulp of |f|) scaled like the estimate itself
+        for j, (a, b) in enumerate(zip(got, errs)):
+            if j < k:   # orders k, k-1, k-2 exist
+                noise = ref.n * (abs(dt) * 2.0 ** (k - j) * 1e-6 / abstol) ** 2
+                assert abs(a - b) <= 2e-2 * b + noise, (i, k, j, a, b, noise)
+            else:
+                assert a == 0.0
+        if want_up:
+            noise = ref.n * (abs(dt) * 2.0 ** (k + 1) * 1e-6 / abstol) ** 2
+            assert abs(float(errp) - up) <= 2e-2 * up + noise, (i, k, float(errp), up, noise)
+    assert worst < 2e-5, worst
+    # misuse surfaces as status codes
+    assert h.lib.cnf_vcabm_accept(h.ptr, ptr(d_eps), ptr(d_ys), B, abstol, reltol, None, st) == L.ERR_INVALID      # no pending attempt
+    assert h.lib.cnf_vcabm_attempt(h.ptr, 13, 0.01, ptr(d_eps), ptr(d_ys), B, abstol, reltol, ptr(err3), st) == L.ERR_INVALID
+    assert h.lib.cnf_vcabm_attempt(h.ptr, 3, 0.01, ptr(d_eps), ptr(d_ys), B + 1, abstol, reltol, ptr(err3), st) == L.ERR_INVALID
+    L.check(h.lib.cnf_vcabm_begin(h.ptr, 0.0, ptr(d_u0), ptr(d_eps), ptr(d_ys), B, st))
+    assert h.lib.cnf_vcabm_attempt(h.ptr, 2, 0.01, ptr(d_eps), ptr(d_ys), B, abstol, reltol, ptr(err3), st) == L.ERR_INVALID  # no history yet
+
+
+@pytest.mark.parametrize("kw,tol", [
+    (dict(nvars=8, hidden=[64, 64, 64]), 1e-4),                                             # the reference's default tolerances
+    (dict(nvars=8, hidden=[64, 64, 64], reg_z=True, reg_j=True), 1e-6),
+    (dict(nvars=3, ncond=2, hidden=[24, 24], act=2, mode=2), 1e-5),                         # exact trace, conditioned
+])
+def test_vcabm_solve_follows_the_oracle_restatement(kw, tol, pkg, oracles):
+    """The default solver end to end (`ICNF` without sol_kwargs.alg): host controller + order selection over the device
+    passes against the fp64 restatement - accepted / rejected counts, the order history, the final state - and against
+    a fine fixed-step solve to within a multiple of the tolerance."""
+    o64, _ = oracles
+    spec = o64.make_spec(**kw)
+    B = 40
+    p, xs, eps, ys = o64.synth_inputs(spec, B, 78, bias_scale=0.3)
+    p = (p * 2.0).astype(np.float32)
+    icnf = make_icnf(pkg, spec, 1, 1)
+    icnf.sol_kwargs = dict(reltol=tol, abstol=tol)                                          # alg defaults to VCABM()
+    logp, regs, u1 = run_inference(pkg, icnf, spec, p, xs, eps, ys, return_state=True)
+    assert isinstance(icnf.sol_kwargs["alg"], pkg.VCABM) and icnf.adaptive
+    st = icnf.last_solve_stats
+    u0 = np.vstack([xs.astype(np.float64), np.zeros((spec.naug + 3, B))])
+    uref, sref = o64.integrate_vcabm(spec, p, u0, 0.0, 1.0, tol, tol, eps, ys)
+    slack = 1 if tol >= 1e-4 else 4
+    assert abs(st["naccept"] - sref["naccept"]) <= slack and abs(st["nreject"] - sref["nreject"]) <= slack, (st, sref)
+    assert st["orders"][:4] == [1, 2, 3, 3] and max(st["orders"]) >= 4
+    if tol >= 1e-4:
+        assert st["orders"] == sref["orders"], (st["orders"], sref["orders"])
+        assert np.allclose(st["dts"], sref["dts"], rtol=2e-2), (st["dts"], sref["dts"])
+    assert abs(st["dts"][0] - sref["dts"][0]) < 1e-2 * sref["dts"][0]                        # Hairer's initial step, order 7
+    assert st["nf"] == 3 + 2 * st["naccept"] + st["nreject"]                                # PECE: two evaluations per accepted step
+    fine = o64.integrate_fixed(spec, p, u0, 0.0, 1.0, 400, 1, eps, ys)
+    assert np.max(np.abs(uref - fine)) < 100 * tol                                          # the restatement itself
+    assert np.max(np.abs(u1.cpu().numpy() - uref)) < (20 * tol + 2e-5 if tol >= 1e-4 else 100 * tol)   # float32 differences move the step sequence below 1e-5
+    assert np.max(np.abs(u1.cpu().numpy() - fine)) < 100 * tol
+    z = u1.cpu().numpy()[:spec.D]
+    lp = -0.5 * spec.D * np.log(2 * np.pi) - 0.5 * (z * z).sum(0) - u1.cpu().numpy()[spec.D]
+    assert np.max(np.abs(logp.cpu().numpy() - lp) / (1.0 + np.abs(lp))) < 1e-6               # the epilogue on that state (float32 rounding of logp)
+
+
+def test_vcabm_round_trip_large_batch_and_training(pkg, oracles):
+    """generate inverts inference under the default solver (negative steps), a 65 536-column solve agrees with Tsit5 at
+    the same tolerance, and loss_and_gradient under VCABM differentiates the adaptive Tsit5 discretisation (value
+    within the tolerance of the VCABM loss)."""
+    o64, _ = oracles
+    spec = o64.make_spec(nvars=8, hidden=[64, 64, 64])
+    B = 65536
+    p, xs, eps, _ = o64.synth_inputs(spec, B, 6, bias_scale=0.3)
+    p = (p * 2.0).astype(np.float32)
+    icnf = make_icnf(pkg, spec, 1, 1)
+    icnf.sol_kwargs = dict(alg=pkg.VCABM(), reltol=1e-5, abstol=1e-5)
+    full = run_inference(pkg, icnf, spec, p, xs, eps, None, return_state=True)
+    st = dict(icnf.last_solve_stats)
+    assert st["naccept"] >= 6 and max(st["orders"]) >= 4
+    ts = _adaptive_icnf(pkg, spec, 1e-5)
+    other = run_inference(pkg, ts, spec, p, xs, eps, None)
+    assert float((full[0] - other[0]).abs().max()) < 5e-3
+    m = pkg.TrainMode(False)
+    back = pkg.generate(icnf, m, dev(p), {}, B, z0=full[2][:8], eps=dev(eps))
+    assert icnf.last_solve_stats["dts"][0] < 0
+    assert float((back - dev(xs)).abs().max()) < 5e-3
+    val, g = pkg.loss_and_gradient(icnf, pkg.TrainMode(True), dev(xs), dev(p), {}, eps=dev(eps))
+    assert bool(torch.isfinite(g).all()) and abs(float(val) - float(-full[0].mean())) < 1e-3

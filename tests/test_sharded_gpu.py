@@ -1,7 +1,7 @@
 """GPU, world_size 2 (gloo; both ranks share the one device, RCCL would refuse that): the sharded product path.
 Each rank runs the HIP kernels on its contiguous column block; loss and gradient are all-reduced inside
 `loss` / `loss_and_gradient`, and the adaptive solve all-reduces its error sum so both ranks take the steps of the
-unsharded solve."""
+unsharded solve (Tsit5 and the reference's default VCABM, whose order selection reads three more all-reduced sums)."""
 import os
 import sys
 
@@ -48,7 +48,11 @@ def _worker(rank, world, port, q):
         lval = pkg.loss(fixed, m, dev(xs[:, lo:hi]), dev(p), {}, eps=dev(eps[:, lo:hi]))
         adap = _build(pkg, o64, spec, dict(alg=pkg.Tsit5(), reltol=1e-4, abstol=1e-4))
         logp = pkg.inference(adap, m, dev(xs[:, lo:hi]), dev(p), {}, eps=dev(eps[:, lo:hi]))[0]
-        q.put((rank, float(val), float(lval), g.cpu().numpy(), logp.cpu().numpy(), list(adap.last_solve_stats["dts"])))
+        dflt = _build(pkg, o64, spec, dict(reltol=1e-4, abstol=1e-4))          # the reference's default solver, VCABM
+        logp_v = pkg.inference(dflt, m, dev(xs[:, lo:hi]), dev(p), {}, eps=dev(eps[:, lo:hi]))[0]
+        vst = dflt.last_solve_stats
+        q.put((rank, float(val), float(lval), g.cpu().numpy(), logp.cpu().numpy(), list(adap.last_solve_stats["dts"]),
+               logp_v.cpu().numpy(), list(vst["dts"]), list(vst["orders"])))
     finally:
         dist.destroy_process_group()
 
@@ -76,10 +80,16 @@ def test_two_ranks_on_the_gpu_reproduce_the_unsharded_results(pkg, oracles):
     logp = pkg.inference(adap, m, dev(xs), dev(p), {}, eps=dev(eps))[0].cpu().numpy()
     dts = list(adap.last_solve_stats["dts"])
     assert len(dts) >= 4
-    for rank, v, lv, gr, lp, d in res:
+    dflt = _build(pkg, o64, spec, dict(reltol=1e-4, abstol=1e-4))
+    logp_v = pkg.inference(dflt, m, dev(xs), dev(p), {}, eps=dev(eps))[0].cpu().numpy()
+    vdts, vorders = list(dflt.last_solve_stats["dts"]), list(dflt.last_solve_stats["orders"])
+    assert isinstance(dflt.sol_kwargs["alg"], pkg.VCABM) and len(vdts) >= 5
+    for rank, v, lv, gr, lp, d, lpv, dv, ov in res:
         assert abs(v - float(val)) < 1e-5 and abs(lv - float(val)) < 1e-5          # global mean on every rank
         assert np.max(np.abs(gr - g.cpu().numpy())) < 2e-5 * float(g.abs().max())  # all-reduced gradient = unsharded gradient
         assert np.allclose(d, dts, rtol=1e-6), (d, dts)                            # the unsharded solve's steps
         lo, hi = pkg.shard_columns(B, rank, 2)
         assert np.max(np.abs(lp - logp[lo:hi])) < 1e-5
+        assert ov == vorders and np.allclose(dv, vdts, rtol=1e-5), (dv, vdts, ov, vorders)   # VCABM: same orders, same steps
+        assert np.max(np.abs(lpv - logp_v[lo:hi])) < 1e-4
     assert res[0][5] == res[1][5]                                                  # both ranks took identical steps
