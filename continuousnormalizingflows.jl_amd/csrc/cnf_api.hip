@@ -584,7 +584,7 @@ int cnf_loss_grad_grid(cnf_handle* h, int alg, int nsteps, const float* tgrid, c
     if (alg != CNF_ALG_RK4 && alg != CNF_ALG_TSIT5) return fail(CNF_ERR_INVALID, "cnf_loss_grad_grid: unknown alg");
     if (!x || !grad || !lambdas) return fail(CNF_ERR_INVALID, "cnf_loss_grad_grid: null x/grad/lambdas");
     if (!layered_grad_supported(h->cfg))
-        return fail(CNF_ERR_UNSUPPORTED, "cnf_loss_grad_grid: the gradient is implemented for the Hutchinson modes (TrainMode)");
+        return fail(CNF_ERR_UNSUPPORTED, "cnf_loss_grad_grid: no gradient path for this configuration");
     DeviceGuard g(h->cfg.device_id);
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(hipMemsetAsync(grad, 0, h->nparams * sizeof(float), st));
@@ -592,7 +592,8 @@ int cnf_loss_grad_grid(cnf_handle* h, int alg, int nsteps, const float* tgrid, c
         if (sums4) HIP_TRY(hipMemsetAsync(sums4, 0, 4 * sizeof(float), st));
         return CNF_OK;
     }
-    const int ra = (h->cfg.reg_aug && h->cfg.naug > 0) ? 1 : 0;
+    const bool hutch = h->cfg.mode != CNF_MODE_EXACT;
+    const int ra = (hutch && h->cfg.reg_aug && h->cfg.naug > 0) ? 1 : 0;
     if (sums4) {   // the loss of the same discrete solve: augmented state advanced over the grid, then the epilogue
         const size_t need = ((size_t)h->S + 4) * (size_t)B * sizeof(float);
         if (need > h->grad_ws_bytes) {
@@ -611,7 +612,7 @@ int cnf_loss_grad_grid(cnf_handle* h, int alg, int nsteps, const float* tgrid, c
         if (!h->loss_partial) HIP_TRY(hipMalloc((void**)&h->loss_partial, 256 * 4 * sizeof(float)));
         HIP_TRY(loss_sums(logp, regs, B, h->loss_partial, sums4, st));
     }
-    const float lam[3] = {h->cfg.reg_z ? lambdas[0] : 0.f, h->cfg.reg_j ? lambdas[1] : 0.f, ra ? lambdas[2] : 0.f};
+    const float lam[3] = {hutch && h->cfg.reg_z ? lambdas[0] : 0.f, hutch && h->cfg.reg_j ? lambdas[1] : 0.f, ra ? lambdas[2] : 0.f};
     std::string msg;
     hipError_t e = layered_grad(&h->layered, h->cfg, h->P_dev, h->w_off.data(), h->b_off.data(), x, eps, ys, alg, nsteps,
                                 tgrid[0], tgrid[nsteps], tgrid, B, lam, grad, grad_x, st, &msg);
@@ -954,8 +955,7 @@ int cnf_loss_grad_fixed(cnf_handle* h, int alg, int nsteps, float t0, float t1, 
     if (!x || !grad || !lambdas) return fail(CNF_ERR_INVALID, "cnf_loss_grad_fixed: null x/grad/lambdas");
     const bool fused = grad_is_fused(h) && h->grad_packed;
     if (!fused && !layered_grad_supported(h->cfg))
-        return fail(CNF_ERR_UNSUPPORTED, "cnf_loss_grad_fixed: the gradient is implemented for the Hutchinson modes (TrainMode); "
-                                         "the exact-trace mode is not a training mode");
+        return fail(CNF_ERR_UNSUPPORTED, "cnf_loss_grad_fixed: no gradient path for this configuration");
     DeviceGuard g(h->cfg.device_id);
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(hipMemsetAsync(grad, 0, h->nparams * sizeof(float), st));
@@ -980,8 +980,9 @@ int cnf_loss_grad_fixed(cnf_handle* h, int alg, int nsteps, float t0, float t1, 
             if (!h->loss_partial) HIP_TRY(hipMalloc((void**)&h->loss_partial, 256 * 4 * sizeof(float)));
             HIP_TRY(loss_sums(logp, regs, B, h->loss_partial, sums4, st));
         }
-        const int ra = (h->cfg.reg_aug && h->cfg.naug > 0) ? 1 : 0;
-        const float lam[3] = {h->cfg.reg_z ? lambdas[0] : 0.f, h->cfg.reg_j ? lambdas[1] : 0.f, ra ? lambdas[2] : 0.f};
+        const bool hutch = h->cfg.mode != CNF_MODE_EXACT;   // the exact-trace dynamics carry no regularisers (icnf.jl:297-339)
+        const int ra = (hutch && h->cfg.reg_aug && h->cfg.naug > 0) ? 1 : 0;
+        const float lam[3] = {hutch && h->cfg.reg_z ? lambdas[0] : 0.f, hutch && h->cfg.reg_j ? lambdas[1] : 0.f, ra ? lambdas[2] : 0.f};
         if (grad_uses_slab(h)) {
             // two-hidden-layer nets of 4..7 hidden tiles: tile-fused reverse sweep with slab accumulators (cnf_grad_slab.hip)
             if (h->num_cus == 0) {

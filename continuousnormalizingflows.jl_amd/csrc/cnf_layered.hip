@@ -165,6 +165,12 @@ __global__ void copy_rows_kernel(float* __restrict__ dst, const float* __restric
     dst[i] = src[j * lds + roff + f];
 }
 
+// seed of the exact trace: the unit vector e_k in every column (tr J = sum_k e_k^T J e_k)
+__global__ void onehot_kernel(float* __restrict__ dst, int k, int D, long long B) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < (long long)D * B) dst[i] = (int)(i % D) == k ? 1.f : 0.f;
+}
+
 __global__ void mul_kernel(float* __restrict__ out, const float* __restrict__ x, const float* __restrict__ y, long long n) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = x[i] * y[i];
@@ -365,7 +371,7 @@ void layered_grad_destroy(LayeredGrad* g) {
 }
 
 bool layered_grad_supported(const cnf_config& c) {
-    return (c.mode == CNF_MODE_HUTCH_VJP || c.mode == CNF_MODE_HUTCH_JVP) && c.nprobes >= 1;
+    return c.mode == CNF_MODE_EXACT || ((c.mode == CNF_MODE_HUTCH_VJP || c.mode == CNF_MODE_HUTCH_JVP) && c.nprobes >= 1);
 }
 
 #define LG_HIP(expr)                                                                    \
@@ -526,7 +532,10 @@ hipError_t layered_grad(LayeredGrad** ctx, const cnf_config& c, const float* P_d
     if (!G.rb) LG_BLAS(bl.create(&G.rb));
     LG_BLAS(bl.set_stream(G.rb, st));
 
-    const int N = c.n_layers, D = c.nvars + c.naug, C = c.ncond, K = c.nprobes;
+    // TestMode (icnf.jl:297-339): ldot = -tr J = -sum_k e_k^T J e_k - the pullback below with the D unit vectors as
+    // probes, each with weight 1 (what the reference's AD does through its D one-hot passes)
+    const bool exact = c.mode == CNF_MODE_EXACT;
+    const int N = c.n_layers, D = c.nvars + c.naug, C = c.ncond, K = exact ? D : c.nprobes;
     LDesc L{};
     L.n_layers = N;
     long long npa = 0;
@@ -663,7 +672,7 @@ hipError_t layered_grad(LayeredGrad** ctx, const cnf_config& c, const float* P_d
     hipLaunchKernelGGL(lam_init_kernel, grid_for(B), dim3(TPB), 0, st, lamv, zck + (long long)nsteps * DB, lam[2], c.nvars, D, B);
 
     // ---- reverse sweep ----
-    const float invK = 1.f / (float)K;
+    const float invK = exact ? 1.f : 1.f / (float)K;
     for (int n = nsteps - 1; n >= 0; --n) {
         const float* zn = zck + (long long)n * DB;
         dt = step_dt(n);
@@ -685,7 +694,8 @@ hipError_t layered_grad(LayeredGrad** ctx, const cnf_config& c, const float* P_d
             hipLaunchKernelGGL(kbar_kernel, grid_for(B), dim3(TPB), 0, st, kbar, lamv, zb, dt * T.b[i], dt, a[N], cl * lam[0], D, B);
 
             for (int k = 0; k < K; ++k) {
-                hipLaunchKernelGGL(copy_rows_kernel, grid_for(DB), dim3(TPB), 0, st, vN, eps, D, K * D, k * D, B);
+                if (exact) hipLaunchKernelGGL(onehot_kernel, grid_for(DB), dim3(TPB), 0, st, vN, k, D, B);
+                else hipLaunchKernelGGL(copy_rows_kernel, grid_for(DB), dim3(TPB), 0, st, vN, eps, D, K * D, k * D, B);
                 if (c.mode == CNF_MODE_HUTCH_JVP) {
                     // g = J eps_k by pushforward: r_l = W_l tau_{l-1} (tau_0 = eps on the z columns), tau_l = r_l .* act'_l;
                     // reverse: rbar_l = taubar_l .* act'_l, acc2_l += taubar_l .* r_l, Wbar_l += rbar_l tau_{l-1}^T,

@@ -833,8 +833,6 @@ def loss_and_gradient(icnf: ICNF, mode: Mode, *args, eps: Optional[torch.Tensor]
     to the data in test/ci_tests/smoke_tests.jl): the costate at t0, a by-product of the same sweep."""
     from .sharding import reduce_gradient, reduce_loss
     xs, ys, ps, st = _split_args(icnf, args, "loss_and_gradient")
-    if icnf.nn.planar is not None:
-        raise NotImplementedError("loss_and_gradient: PlanarLayer nets are not covered by the gradient kernel")
     if icnf.basedist is not None:
         raise NotImplementedError("loss_and_gradient: the terminal costate assumes basedist = MvNormal(0, I)")
     h = icnf._handle(mode)
@@ -845,7 +843,10 @@ def loss_and_gradient(icnf: ICNF, mode: Mode, *args, eps: Optional[torch.Tensor]
     y = _colmajor(ys, icnf.nconditions, "ys", dev) if icnf.conditioned else None
     e = _draw_eps(icnf, icnf.nprobes, B) if eps is None else _colmajor(eps, icnf.nprobes * icnf.D, "eps", dev)
     t0, t1 = icnf._steer_tspan(mode)
-    grad = torch.empty(ps.numel(), device=dev, dtype=torch.float32)
+    # the library differentiates with respect to the vector it was given (Chain.abi_params): ps itself, or for a PlanarLayer ps
+    # followed by the pinned zero biases, whose gradient entries are dropped below
+    n_abi = ps.numel() if icnf.nn.planar is None else icnf.nn.abi_params(ps).numel()
+    grad = torch.empty(n_abi, device=dev, dtype=torch.float32)
     gx = torch.zeros(B, icnf.nvariables, device=dev, dtype=torch.float32) if wrt_x else None
     sums = torch.empty(4, device=dev, dtype=torch.float32)
     lam = (C.c_float * 3)(icnf.lambda1, icnf.lambda2, icnf.lambda3)
@@ -870,7 +871,7 @@ def loss_and_gradient(icnf: ICNF, mode: Mode, *args, eps: Optional[torch.Tensor]
         _lib.check(h.lib.cnf_loss_grad_fixed(h.ptr, icnf._solver(), icnf._nsteps(t0, t1), t0, t1, _ptr(x), _ptr(e),
                                              _ptr(y), B, lam, _ptr(grad), _ptr(gx), _ptr(sums), _stream_ptr(dev)))
     value = reduce_loss(sums, B, (icnf.lambda1, icnf.lambda2, icnf.lambda3), group=group)
-    gps = reduce_gradient(grad, B, group=group)
+    gps = reduce_gradient(grad[:ps.numel()], B, group=group)
     if not wrt_x:
         return value, gps
     import torch.distributed as dist

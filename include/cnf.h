@@ -225,12 +225,13 @@ int cnf_loss_sums(cnf_handle* h, const float* logp, const float* regs, int64_t B
  * (DI.gradient wrt x in test/ci_tests/smoke_tests.jl) - the costate at t0, free in the reverse sweep.
  * sums4 (device, may be NULL): as cnf_loss_sums.  The caller all-reduces grad and sums4 across
  * column shards and divides by the global column count.
- * Every Hutchinson (VJP or JVP) configuration is covered.  Fused reverse-sweep kernels: 1 <= K <= 8 probes,
+ * Every configuration is covered.  Fused reverse-sweep kernels: 1 <= K <= 8 probes,
  * <= 16 conditions, 2 or 3 equal hidden layers (tanh or softplus) of width <= 64, D + !autonomous <= 15;
  * slab-accumulator kernel: two hidden layers of width <= 128, D + !autonomous <= 32, <= 16 conditions, one probe (the
  * reference's default nets for 7..15 variables); every other shape (wider or more layers, mixed activations, larger D): layer-wise
- * reverse sweep on rocBLAS GEMMs, which also serves the Hutchinson JVP mode.  FFJORD and RNODE losses.
- * Exact-trace mode (TestMode): CNF_ERR_UNSUPPORTED. */
+ * reverse sweep on rocBLAS GEMMs, which also serves the Hutchinson JVP mode and the exact-trace mode (TestMode:
+ * -tr J = -sum_k e_k^T J e_k, the pullback with the D unit vectors as probes; eps is ignored, no regularisers).
+ * FFJORD and RNODE losses. */
 int cnf_loss_grad_fixed(cnf_handle* h, int alg, int nsteps, float t0, float t1, const float* x,
                         const float* eps, const float* ys, int64_t B, const float* lambdas,
                         float* grad, float* grad_x, float* sums4, void* stream);

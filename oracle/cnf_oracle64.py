@@ -530,7 +530,6 @@ def loss_and_grad(spec: Spec, p, xs, t0, t1, nsteps, alg, eps, ys=None, lambdas=
     """Returns (loss, dloss/dp) with p in the flat Lux layout, all in float64; with wrt_x also dloss/dxs.
     tgrid (nsteps + 1 times) replaces the uniform grid: fixed steps frozen from an adaptive solve."""
     spec.check()
-    assert spec.mode in (MODE_HUTCH_VJP, MODE_HUTCH_JVP), "gradient oracle: Hutchinson modes"
     D, K = spec.D, spec.nprobes
     pt = torch.tensor(np.asarray(p, dtype=np.float64), requires_grad=True)
     w_off, b_off, _ = spec.param_offsets()
@@ -541,7 +540,7 @@ def loss_and_grad(spec: Spec, p, xs, t0, t1, nsteps, alg, eps, ys=None, lambdas=
         layers.append((W, pt[b_off[l]:b_off[l] + fout]))
     x = torch.tensor(np.asarray(xs, dtype=np.float64), requires_grad=bool(wrt_x))
     B = x.shape[1]
-    e = torch.tensor(np.asarray(eps, dtype=np.float64))
+    e = None if spec.mode == MODE_EXACT else torch.tensor(np.asarray(eps, dtype=np.float64))
     yt = None if ys is None else torch.tensor(np.asarray(ys, dtype=np.float64))
 
     def f_aug(u, t):
@@ -551,6 +550,13 @@ def loss_and_grad(spec: Spec, p, xs, t0, t1, nsteps, alg, eps, ys=None, lambdas=
         zdot = _net(spec, layers, z, t, yt)
         ldot = torch.zeros(B, dtype=torch.float64)
         ndot = torch.zeros(B, dtype=torch.float64)
+        if spec.mode == MODE_EXACT:   # TestMode: ldot = -tr J, no regularisers (src/core/icnf.jl:297-339)
+            for i in range(D):
+                seed = torch.zeros_like(zdot)
+                seed[i] = 1.0
+                (gi,) = torch.autograd.grad(zdot, z, seed, create_graph=True)
+                ldot = ldot - gi[i]
+            return torch.cat([zdot, ldot[None], torch.zeros(2, B, dtype=torch.float64)], dim=0)
         for k in range(K):
             ek = e[k * D:(k + 1) * D]
             if spec.mode == MODE_HUTCH_VJP:

@@ -588,17 +588,6 @@ def test_randomised_gradient_shapes(pkg, oracles):
         assert seen == {1, 2}, seen
 
 
-def test_parameter_gradient_is_refused_in_exact_trace_mode(pkg, oracles):
-    o64, _ = oracles
-    spec = o64.make_spec(nvars=8, hidden=[64, 64, 64], mode=2)   # TestMode (exact trace) is not a training mode
-    p, xs, _, _ = o64.synth_inputs(spec, 16, 1)
-    icnf = make_icnf(pkg, spec, 1, 10, path=2, lambdas=(0.0, 0.0, 0.0))
-    assert icnf.grad_path(pkg.TestMode()) == 0
-    with pytest.raises(pkg._lib.CnfError) as e:
-        pkg.loss_and_gradient(icnf, pkg.TestMode(), dev(xs), dev(p), {})
-    assert e.value.code == pkg._lib.ERR_UNSUPPORTED
-
-
 def test_randomised_shapes_fused_vs_generic_kernels(pkg, oracles):
     """90 random configurations (D, C, H, L in 1..4, activation, trace mode, regularisers, integrator, ragged
     B): wherever the library picks a fused MFMA instance, its result must agree with the generic
@@ -1271,8 +1260,9 @@ def test_plain_cpp_host_on_the_c_abi(pkg, oracles, tmp_path):
     assert got.shape == ref.shape and np.array_equal(got, ref)              # same library, same inputs: same bits
 
 
+@pytest.mark.parametrize("planar", [False, True])
 @pytest.mark.parametrize("conditioned", [False, True])
-def test_reference_smoke_flow_with_all_defaults(conditioned, pkg):
+def test_reference_smoke_flow_with_all_defaults(conditioned, planar, pkg):
     """test/ci_tests/smoke_tests.jl:69-156 with nothing but the defaults: ICNF(; nvariables, [nconditions]) - default net,
     default (adaptive) solver at the reference's tolerances, default lambdas and steer rate - through inference, generate,
     loss, the layer call, the gradients with respect to ps and x, and the MLJ / Distributions adapters.  The reference only
@@ -1283,7 +1273,11 @@ def test_reference_smoke_flow_with_all_defaults(conditioned, pkg):
     r2 = torch.distributions.Beta(2.0, 4.0).sample((2, 64)).float()
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        icnf = pkg.ICNF(nvariables=2, nconditions=2 if conditioned else 0, device="cuda:0")
+        nnkw = {}
+        if planar:   # smoke_tests.jl:32-46
+            nnkw["nn"] = pkg.Chain(pkg.PlanarLayer(2 * (3 if conditioned else 2) + 2, 2 * 2 + 1, pkg.tanh))
+        icnf = pkg.ICNF(nvariables=2, nconditions=2 if conditioned else 0, device="cuda:0", **nnkw)
+        assert isinstance(icnf.sol_kwargs.get("alg", pkg.VCABM()), pkg.VCABM)                  # the reference's default solver
         ps, st = pkg.setup(g, icnf)
         ps = ps.cuda()
         cond = (r2.cuda(),) if conditioned else ()
@@ -1295,8 +1289,10 @@ def test_reference_smoke_flow_with_all_defaults(conditioned, pkg):
             assert np.isfinite(float(pkg.loss(icnf, mode, r.cuda(), *cond, ps, st)))
             out = icnf((r.cuda(),) + cond if conditioned else r.cuda(), ps, st)
             assert out is not None
-        val, gps, gx = pkg.loss_and_gradient(icnf, pkg.TrainMode(True), r.cuda(), *cond, ps, st, wrt_x=True)
-        assert gps.shape == ps.shape and gx.shape == (2, 64) and bool(torch.isfinite(gps).all()) and bool(torch.isfinite(gx).all())
+        for mode in (pkg.TrainMode(True), pkg.TestMode()):                                     # DI.gradient of diff_loss / diff2_loss, both omodes
+            val, gps, gx = pkg.loss_and_gradient(icnf, mode, r.cuda(), *cond, ps, st, wrt_x=True)
+            assert gps.shape == ps.shape and gx.shape == (2, 64) and bool(torch.isfinite(gps).all()) and bool(torch.isfinite(gx).all())
+            assert float(gps.abs().max()) > 0 and float(gx.abs().max()) > 0
         Model = pkg.CondICNFModel if conditioned else pkg.ICNFModel
         model = Model(icnf=icnf, batchsize=32, epochs=8, callback=None, init_rng=torch.Generator().manual_seed(3))
         data = (r.t(), r2.t()) if conditioned else r.t()
@@ -1450,3 +1446,73 @@ def test_vcabm_round_trip_large_batch_and_training(pkg, oracles):
     assert float((back - dev(xs)).abs().max()) < 5e-3
     val, g = pkg.loss_and_gradient(icnf, pkg.TrainMode(True), dev(xs), dev(p), {}, eps=dev(eps))
     assert bool(torch.isfinite(g).all()) and abs(float(val) - float(-full[0].mean())) < 1e-3
+
+
+# ---- the remaining cells of the reference's smoke matrix for the gradient: TestMode and PlanarLayer nets ----
+
+@pytest.mark.parametrize("kw,alg,nsteps", [
+    (dict(nvars=3, ncond=2, hidden=[24, 24], act=2, mode=2), 1, 8),                         # default-style softplus net, conditioned
+    (dict(nvars=8, hidden=[64, 64, 64], mode=2), 0, 6),
+    (dict(nvars=2, naug=3, hidden=[20], act=1, mode=2), 1, 8),                              # augmented, one hidden layer
+])
+def test_gradient_of_the_test_mode_loss(kw, alg, nsteps, pkg, oracles):
+    """`DI.gradient` of `loss(icnf, TestMode(), ...)` with respect to ps and to xs (test/ci_tests/smoke_tests.jl:85-90 with
+    omode = TestMode()): the exact trace -tr J = -sum_k e_k^T J e_k reversed with the D unit vectors as probes on the
+    layer-wise path, against fp64 autograd through the exact-trace solve."""
+    o64, _ = oracles
+    spec = o64.make_spec(**kw)
+    B = 41
+    p, xs, eps, ys = o64.synth_inputs(spec, B, 52, bias_scale=0.3)
+    icnf = make_icnf(pkg, spec, alg, nsteps)
+    mode = pkg.TestMode()
+    assert icnf.grad_path(mode) == 2
+    args = (dev(xs),) + ((dev(ys),) if spec.ncond else ()) + (dev(p), {})
+    val, g, gx = pkg.loss_and_gradient(icnf, mode, *args, wrt_x=True)
+    L, gref, gxref = o64.loss_and_grad(spec, p, xs, 0.0, 1.0, nsteps, alg, None, ys, (0.0, 0.0, 0.0), wrt_x=True)
+    assert abs(float(val) - L) < 2e-5 * (1 + abs(L))
+    assert abs(float(val) - float(pkg.loss(icnf, mode, *args))) < 1e-5 * (1 + abs(L))
+    assert np.max(np.abs(g.cpu().numpy() - gref)) < 5e-5 * np.abs(gref).max() + 1e-6
+    assert np.max(np.abs(gx.cpu().numpy() - gxref)) < 5e-5 * np.abs(gxref).max() + 1e-7
+
+
+@pytest.mark.parametrize("use_bias", [True, False])
+@pytest.mark.parametrize("conditioned", [False, True])
+def test_gradient_of_a_planar_layer_net(use_bias, conditioned, pkg, oracles):
+    """planar = true in the reference's smoke matrix (test/ci_tests/smoke_tests.jl:32-46, 130-134): the gradient with respect
+    to the PlanarLayer's own parameter vector (u, w, b) and to xs, TrainMode{true} and TestMode, against fp64 autograd on the
+    equivalent Dense chain (the pinned zero bias carries no gradient entry)."""
+    o64, _ = oracles
+    nv, C = 2, (2 if conditioned else 0)
+    D = 2 * nv + 1
+    n_in = D + 1 + C
+    rng = np.random.default_rng(9)
+    u, w = rng.uniform(-0.7, 0.7, D), rng.uniform(-0.7, 0.7, n_in)
+    b = rng.uniform(-0.3, 0.3, 1) if use_bias else np.zeros(0)
+    ps = np.concatenate([u, w, b]).astype(np.float32)
+    B = 33
+    xs = rng.standard_normal((nv, B)).astype(np.float32)
+    eps = rng.standard_normal((D, B)).astype(np.float32)
+    ys = rng.standard_normal((C, B)).astype(np.float32) if C else None
+    lam = (0.01, 0.01, 0.01)
+    for mode_id, mode in ((0, pkg.TrainMode(True)), (2, pkg.TestMode())):
+        tr = mode_id == 0
+        spec = o64.Spec(nvars=nv, naug=nv + 1, ncond=C, widths=[n_in, 1, D], acts=[1, 0], mode=mode_id,
+                        reg_z=tr, reg_j=tr, reg_aug=tr)
+        p_dense = np.concatenate([w, b if use_bias else np.zeros(1), u, np.zeros(D)])
+        L, gd, gxref = o64.loss_and_grad(spec, p_dense, xs, 0.0, 1.0, 12, 1, eps, ys, lam if tr else (0.0, 0.0, 0.0), wrt_x=True)
+        gw, gb, gu = gd[:n_in], gd[n_in:n_in + 1], gd[n_in + 1:n_in + 1 + D]
+        gref = np.concatenate([gu, gw, gb if use_bias else np.zeros(0)])
+        icnf = pkg.ICNF(nvariables=nv, nconditions=C, nn=pkg.Chain(pkg.PlanarLayer(n_in, D, pkg.tanh, use_bias=use_bias)),
+                        steer_rate=0.0, device="cuda:0", sol_kwargs=dict(alg=pkg.Tsit5(), adaptive=False, nsteps=12))
+        args = (dev(xs),) + ((dev(ys),) if C else ()) + (dev(ps), {})
+        val, g, gx = pkg.loss_and_gradient(icnf, mode, *args, eps=dev(eps), wrt_x=True)
+        assert g.shape == (ps.size,)
+        assert abs(float(val) - L) < 2e-5 * (1 + abs(L))
+        assert np.max(np.abs(g.cpu().numpy() - gref)) < 5e-5 * np.abs(gref).max() + 1e-6, (mode_id, g.cpu().numpy(), gref)
+        assert np.max(np.abs(gx.cpu().numpy() - gxref)) < 5e-5 * np.abs(gxref).max() + 1e-7
+    # and the MLJ-style fit runs on it, as in the reference's smoke test
+    model = pkg.ICNFModel(icnf=icnf, batchsize=16, epochs=3, callback=None) if not conditioned else \
+        pkg.CondICNFModel(icnf=icnf, batchsize=16, epochs=3, callback=None)
+    data = (xs.T, ys.T) if conditioned else xs.T
+    fitresult, _, report = model.fit(data)
+    assert report["stats"]["iterations"] == 9 and np.isfinite(report["stats"]["final_loss"])
