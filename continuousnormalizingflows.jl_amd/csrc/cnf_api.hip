@@ -161,12 +161,36 @@ struct cnf_handle {
     int vc_nhist = 0, vc_k = 0;          // accepted steps since begin; order of the pending attempt (0 = none)
     double vc_hist[kVcSlots + 1] = {};   // signed sizes of the accepted steps, newest first
     double vc_t = 0.0, vc_dt = 0.0;
+    float* tgrid_dev = nullptr;          // step times of a non-uniform grid for the fused gradient kernels
+    size_t tgrid_cap = 0;
     bool layered_forced = false;         // kernel_path = CNF_PATH_LAYERED given explicitly: GEMM path for every batch
     bool maps_built = false;
     bool repack_on_device = false;
     float* p_stage = nullptr;
     size_t p_stage_n = 0;
 };
+
+// The configuration the fused gradient kernels are selected and packed for.  TestMode (exact trace): -tr J is the sum over
+// the D unit vectors e_k of -e_k^T J e_k, i.e. the several-probe reverse sweep with K = D one-hot probes of weight 1 and no
+// regularisers (up to the kernel's probe capacity; wider states take the layer-wise path).
+static cnf_config grad_cfg(const cnf_handle* h) {
+    cnf_config c = h->cfg;
+    if (c.mode == CNF_MODE_EXACT) {
+        c.mode = CNF_MODE_HUTCH_VJP;
+        c.nprobes = h->D;
+        c.reg_z = c.reg_j = c.reg_aug = 0;
+        if (h->D > 8) c.nprobes = 0;   // no fused instance: grad_supported() rejects nprobes < 1
+    }
+    return c;
+}
+
+__global__ void unit_probes_kernel(float* __restrict__ eps, int D, long long B) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long DD = (long long)D * D;
+    if (i >= DD * B) return;
+    const int r = (int)(i % DD);
+    eps[i] = (r / D) == (r % D) ? 1.f : 0.f;   // probe k = rows k D .. k D + D - 1 of the column: e_k
+}
 
 static int ensure_ws(cnf_handle* h, int64_t B) {
     if (B <= h->ws_B) return CNF_OK;
@@ -281,6 +305,7 @@ int cnf_destroy(cnf_handle* h) {
     if (h->ebuf) (void)hipFree(h->ebuf);
     if (h->err_partial) (void)hipFree(h->err_partial);
     if (h->vc_buf) (void)hipFree(h->vc_buf);
+    if (h->tgrid_dev) (void)hipFree(h->tgrid_dev);
     if (h->vc_partial) (void)hipFree(h->vc_partial);
     layered_grad_destroy(h->layered);
     free_pack_map(h->map_fwd);
@@ -314,7 +339,8 @@ int cnf_set_params(cnf_handle* h, const float* p, size_t n, const size_t* w_off,
     if (!g.ok) return fail(CNF_ERR_HIP, "cnf_set_params: hipSetDevice failed");
     hipStream_t st = (hipStream_t)stream;
     const bool mfma = h->path == CNF_PATH_MFMA;
-    const bool want_grad = mfma && mfma_plan_is_per_wave(h->plan) && grad_supported(c);
+    const cnf_config gc = grad_cfg(h);
+    const bool want_grad = mfma && mfma_plan_is_per_wave(h->plan) && grad_supported(gc);
     const bool same_layout = h->have_params && h->nparams == n &&
                              std::equal(w_off, w_off + c.n_layers, h->w_off.begin()) &&
                              std::equal(b_off, b_off + c.n_layers, h->b_off.begin());
@@ -324,7 +350,7 @@ int cnf_set_params(cnf_handle* h, const float* p, size_t n, const size_t* w_off,
         h->maps_built = false;
     }
     if (mfma && !h->packed_dev) HIP_TRY(hipMalloc((void**)&h->packed_dev, mfma_packed_bytes(h->plan)));
-    if (want_grad && !h->grad_packed) HIP_TRY(hipMalloc((void**)&h->grad_packed, grad_packed_bytes(c)));
+    if (want_grad && !h->grad_packed) HIP_TRY(hipMalloc((void**)&h->grad_packed, grad_packed_bytes(gc)));
     if (mfma && !h->maps_built) {
         // one-time (per layout): derive and verify the gather maps from the host packers
         size_t qo = 0, ql = 0;
@@ -332,8 +358,8 @@ int cnf_set_params(cnf_handle* h, const float* p, size_t n, const size_t* w_off,
         build_pack_map(h->map_fwd, n, mfma_packed_bytes(h->plan) / sizeof(float),
                        [&](const float* src, float* dst) { mfma_pack(h->plan, src, w_off, b_off, dst); }, qo, ql);
         if (want_grad)
-            build_pack_map(h->map_grad, n, grad_packed_bytes(c) / sizeof(float),
-                           [&](const float* src, float* dst) { grad_pack(c, src, w_off, b_off, dst); });
+            build_pack_map(h->map_grad, n, grad_packed_bytes(gc) / sizeof(float),
+                           [&](const float* src, float* dst) { grad_pack(gc, src, w_off, b_off, dst); });
         h->maps_built = true;
     }
     const bool dev_pack = mfma && h->map_fwd.valid && (!want_grad || h->map_grad.valid);
@@ -392,9 +418,9 @@ int cnf_set_params(cnf_handle* h, const float* p, size_t n, const size_t* w_off,
             HIP_TRY(hipMemcpyAsync(h->packed_dev, packed.data(), bytes, hipMemcpyHostToDevice, st));
             HIP_TRY(hipStreamSynchronize(st));
             if (want_grad) {
-                const size_t gb = grad_packed_bytes(c);
+                const size_t gb = grad_packed_bytes(gc);
                 std::vector<float> gp(gb / sizeof(float), 0.f);
-                grad_pack(c, host.data(), w_off, b_off, gp.data());
+                grad_pack(gc, host.data(), w_off, b_off, gp.data());
                 HIP_TRY(hipMemcpyAsync(h->grad_packed, gp.data(), gb, hipMemcpyHostToDevice, st));
                 HIP_TRY(hipStreamSynchronize(st));
             }
@@ -574,52 +600,6 @@ int cnf_inference_fixed(cnf_handle* h, int alg, int nsteps, float t0, float t1, 
 // fixed steps on a given grid: u advanced in place, 6 (Tsit5) or 4 (RK4) evaluations per step on the handle's family
 static int integrate_grid(cnf_handle* h, int alg, int nsteps, const float* tgrid, float* u, const float* eps, const float* ys,
                           int64_t B, hipStream_t st);
-
-int cnf_loss_grad_grid(cnf_handle* h, int alg, int nsteps, const float* tgrid, const float* x, const float* eps,
-                       const float* ys, int64_t B, const float* lambdas, float* grad, float* grad_x, float* sums4,
-                       void* stream) {
-    int rc = check_call(h, eps, ys, B, "cnf_loss_grad_grid");
-    if (rc) return rc;
-    if (nsteps < 1 || !tgrid) return fail(CNF_ERR_INVALID, "cnf_loss_grad_grid: nsteps >= 1 and a grid of nsteps + 1 times required");
-    if (alg != CNF_ALG_RK4 && alg != CNF_ALG_TSIT5) return fail(CNF_ERR_INVALID, "cnf_loss_grad_grid: unknown alg");
-    if (!x || !grad || !lambdas) return fail(CNF_ERR_INVALID, "cnf_loss_grad_grid: null x/grad/lambdas");
-    if (!layered_grad_supported(h->cfg))
-        return fail(CNF_ERR_UNSUPPORTED, "cnf_loss_grad_grid: no gradient path for this configuration");
-    DeviceGuard g(h->cfg.device_id);
-    hipStream_t st = (hipStream_t)stream;
-    HIP_TRY(hipMemsetAsync(grad, 0, h->nparams * sizeof(float), st));
-    if (B == 0) {
-        if (sums4) HIP_TRY(hipMemsetAsync(sums4, 0, 4 * sizeof(float), st));
-        return CNF_OK;
-    }
-    const bool hutch = h->cfg.mode != CNF_MODE_EXACT;
-    const int ra = (hutch && h->cfg.reg_aug && h->cfg.naug > 0) ? 1 : 0;
-    if (sums4) {   // the loss of the same discrete solve: augmented state advanced over the grid, then the epilogue
-        const size_t need = ((size_t)h->S + 4) * (size_t)B * sizeof(float);
-        if (need > h->grad_ws_bytes) {
-            if (h->grad_ws) HIP_TRY(hipFree(h->grad_ws));
-            h->grad_ws = nullptr; h->grad_ws_bytes = 0;
-            HIP_TRY(hipMalloc((void**)&h->grad_ws, need));
-            h->grad_ws_bytes = need;
-        }
-        float* u = h->grad_ws;
-        float* logp = u + (size_t)h->S * B;
-        float* regs = logp + B;
-        HIP_TRY(assemble_u0(x, h->cfg.nvars, h->S, B, u, st));
-        rc = integrate_grid(h, alg, nsteps, tgrid, u, eps, ys, B, st);
-        if (rc) return rc;
-        HIP_TRY(epilogue(u, h->cfg.nvars, h->D, ra, B, logp, regs, st));
-        if (!h->loss_partial) HIP_TRY(hipMalloc((void**)&h->loss_partial, 256 * 4 * sizeof(float)));
-        HIP_TRY(loss_sums(logp, regs, B, h->loss_partial, sums4, st));
-    }
-    const float lam[3] = {hutch && h->cfg.reg_z ? lambdas[0] : 0.f, hutch && h->cfg.reg_j ? lambdas[1] : 0.f, ra ? lambdas[2] : 0.f};
-    std::string msg;
-    hipError_t e = layered_grad(&h->layered, h->cfg, h->P_dev, h->w_off.data(), h->b_off.data(), x, eps, ys, alg, nsteps,
-                                tgrid[0], tgrid[nsteps], tgrid, B, lam, grad, grad_x, st, &msg);
-    if (e == hipErrorNotSupported) return fail(CNF_ERR_UNSUPPORTED, "cnf_loss_grad_grid: " + msg);
-    if (e != hipSuccess) return fail(CNF_ERR_HIP, "cnf_loss_grad_grid: " + msg);
-    return CNF_OK;
-}
 
 // f(u + dt sum coef k, t) on whichever family serves the handle; `stage` is scratch for the fused path, whose
 // single-call kernel takes the stage state itself
@@ -929,7 +909,7 @@ int cnf_loss_sums(cnf_handle* h, const float* logp, const float* regs, int64_t B
 // fused reverse-sweep kernel, unless CNF_GRAD_LAYERED=1 forces the layer-wise path (tests, A/B timing)
 static bool grad_is_fused(const cnf_handle* h) {
     const char* force = getenv("CNF_GRAD_LAYERED");
-    return h->path == CNF_PATH_MFMA && grad_supported(h->cfg) && mfma_plan_is_per_wave(h->plan) &&
+    return h->path == CNF_PATH_MFMA && grad_supported(grad_cfg(h)) && mfma_plan_is_per_wave(h->plan) &&
            !(force && *force && *force != '0');
 }
 
@@ -945,17 +925,22 @@ int cnf_grad_path(const cnf_handle* h) {
     return layered_grad_supported(h->cfg) ? 2 : 0;
 }
 
-int cnf_loss_grad_fixed(cnf_handle* h, int alg, int nsteps, float t0, float t1, const float* x,
-                        const float* eps, const float* ys, int64_t B, const float* lambdas,
-                        float* grad, float* grad_x, float* sums4, void* stream) {
-    int rc = check_call(h, eps, ys, B, "cnf_loss_grad_fixed");
+}  // extern "C"
+
+// loss sums + gradient on a uniform grid (tgrid == nullptr: nsteps steps from t0 to t1) or on the caller's non-uniform
+// grid (tgrid: host, nsteps + 1 times; t0 / t1 ignored).  The same three gradient implementations serve both.
+static int loss_grad_impl(cnf_handle* h, const char* who, int alg, int nsteps, float t0, float t1, const float* tgrid,
+                          const float* x, const float* eps, const float* ys, int64_t B, const float* lambdas,
+                          float* grad, float* grad_x, float* sums4, void* stream) {
+    int rc = check_call(h, eps, ys, B, who);
     if (rc) return rc;
-    if (nsteps < 1) return fail(CNF_ERR_INVALID, "cnf_loss_grad_fixed: nsteps >= 1 required");
-    if (alg != CNF_ALG_RK4 && alg != CNF_ALG_TSIT5) return fail(CNF_ERR_INVALID, "cnf_loss_grad_fixed: unknown alg");
-    if (!x || !grad || !lambdas) return fail(CNF_ERR_INVALID, "cnf_loss_grad_fixed: null x/grad/lambdas");
+    const std::string w(who);
+    if (nsteps < 1) return fail(CNF_ERR_INVALID, w + ": nsteps >= 1 required");
+    if (alg != CNF_ALG_RK4 && alg != CNF_ALG_TSIT5) return fail(CNF_ERR_INVALID, w + ": unknown alg");
+    if (!x || !grad || !lambdas) return fail(CNF_ERR_INVALID, w + ": null x/grad/lambdas");
     const bool fused = grad_is_fused(h) && h->grad_packed;
     if (!fused && !layered_grad_supported(h->cfg))
-        return fail(CNF_ERR_UNSUPPORTED, "cnf_loss_grad_fixed: no gradient path for this configuration");
+        return fail(CNF_ERR_UNSUPPORTED, w + ": no gradient path for this configuration");
     DeviceGuard g(h->cfg.device_id);
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(hipMemsetAsync(grad, 0, h->nparams * sizeof(float), st));
@@ -963,10 +948,23 @@ int cnf_loss_grad_fixed(cnf_handle* h, int alg, int nsteps, float t0, float t1, 
         if (sums4) HIP_TRY(hipMemsetAsync(sums4, 0, 4 * sizeof(float), st));
         return CNF_OK;
     }
+    const float* tgrid_dev = nullptr;
+    if (tgrid) {   // the fused kernels read the step times from device memory (uniform loads, once per step)
+        t0 = tgrid[0]; t1 = tgrid[nsteps];
+        if ((size_t)nsteps + 1 > h->tgrid_cap) {
+            if (h->tgrid_dev) HIP_TRY(hipFree(h->tgrid_dev));
+            h->tgrid_dev = nullptr; h->tgrid_cap = 0;
+            const size_t cap = ((size_t)nsteps + 1 + 63) / 64 * 64;
+            HIP_TRY(hipMalloc((void**)&h->tgrid_dev, cap * sizeof(float)));
+            h->tgrid_cap = cap;
+        }
+        HIP_TRY(hipMemcpyAsync(h->tgrid_dev, tgrid, ((size_t)nsteps + 1) * sizeof(float), hipMemcpyHostToDevice, st));
+        tgrid_dev = h->tgrid_dev;
+    }
     if (!fused) {
         // the loss sums come from the regular solve on whichever family serves the handle
         if (sums4) {
-            const size_t need = 4 * (size_t)B * sizeof(float);
+            const size_t need = ((size_t)h->S + 4) * (size_t)B * sizeof(float);
             if (need > h->grad_ws_bytes) {
                 if (h->grad_ws) HIP_TRY(hipFree(h->grad_ws));
                 h->grad_ws = nullptr; h->grad_ws_bytes = 0;
@@ -975,8 +973,17 @@ int cnf_loss_grad_fixed(cnf_handle* h, int alg, int nsteps, float t0, float t1, 
             }
             float* logp = h->grad_ws;
             float* regs = logp + B;
-            rc = cnf_inference_fixed(h, alg, nsteps, t0, t1, x, eps, ys, B, logp, regs, nullptr, stream);
-            if (rc) return rc;
+            if (tgrid) {   // the loss of the same discrete solve: augmented state advanced over the grid, then the epilogue
+                float* u = regs + 3 * (size_t)B;
+                const int ra0 = (h->cfg.mode != CNF_MODE_EXACT && h->cfg.reg_aug && h->cfg.naug > 0) ? 1 : 0;
+                HIP_TRY(assemble_u0(x, h->cfg.nvars, h->S, B, u, st));
+                rc = integrate_grid(h, alg, nsteps, tgrid, u, eps, ys, B, st);
+                if (rc) return rc;
+                HIP_TRY(epilogue(u, h->cfg.nvars, h->D, ra0, B, logp, regs, st));
+            } else {
+                rc = cnf_inference_fixed(h, alg, nsteps, t0, t1, x, eps, ys, B, logp, regs, nullptr, stream);
+                if (rc) return rc;
+            }
             if (!h->loss_partial) HIP_TRY(hipMalloc((void**)&h->loss_partial, 256 * 4 * sizeof(float)));
             HIP_TRY(loss_sums(logp, regs, B, h->loss_partial, sums4, st));
         }
@@ -997,15 +1004,15 @@ int cnf_loss_grad_fixed(cnf_handle* h, int alg, int nsteps, float t0, float t1, 
                 HIP_TRY(hipMalloc((void**)&h->slab_ws, need * sizeof(float)));
                 h->slab_ws_floats = need;
             }
-            HIP_TRY(grad_slab_launch(h->cfg, h->slab_packed, x, eps, ys, h->w_off.data(), h->b_off.data(), alg, nsteps, t0, t1, B, lam,
+            HIP_TRY(grad_slab_launch(h->cfg, h->slab_packed, x, eps, ys, h->w_off.data(), h->b_off.data(), alg, nsteps, t0, t1, tgrid_dev, B, lam,
                                      h->slab_ws, grad, grad_x, h->num_cus, st));
             return CNF_OK;
         }
         std::string msg;
         hipError_t e = layered_grad(&h->layered, h->cfg, h->P_dev, h->w_off.data(), h->b_off.data(), x, eps, ys, alg, nsteps,
-                                    t0, t1, nullptr, B, lam, grad, grad_x, st, &msg);
-        if (e == hipErrorNotSupported) return fail(CNF_ERR_UNSUPPORTED, "cnf_loss_grad_fixed: " + msg);
-        if (e != hipSuccess) return fail(CNF_ERR_HIP, "cnf_loss_grad_fixed: " + msg);
+                                    t0, t1, tgrid, B, lam, grad, grad_x, st, &msg);
+        if (e == hipErrorNotSupported) return fail(CNF_ERR_UNSUPPORTED, w + ": " + msg);
+        if (e != hipSuccess) return fail(CNF_ERR_HIP, w + ": " + msg);
         return CNF_OK;
     }
     if (h->num_cus == 0) {
@@ -1019,8 +1026,12 @@ int cnf_loss_grad_fixed(cnf_handle* h, int alg, int nsteps, float t0, float t1, 
     const size_t ckpt_z_floats = (size_t)(nsteps + 1) * (size_t)ntiles * 64 * (size_t)ckpt_zr;
     const size_t ckpt_k_floats = (size_t)nsteps * nstages * (size_t)ntiles * 64 * (size_t)ckpt_zr;
     const size_t ckpt_floats = ckpt_z_floats + ckpt_k_floats;
-    const size_t slab_floats = grad_slab_floats(h->cfg, h->num_cus);
-    const size_t need = (ckpt_floats + 4 * (size_t)B + slab_floats) * sizeof(float);
+    const cnf_config gc = grad_cfg(h);
+    const bool exact = h->cfg.mode == CNF_MODE_EXACT;
+    const size_t slab_floats = grad_slab_floats(gc, h->num_cus);
+    const size_t state_floats = tgrid ? 2 * (size_t)h->S * (size_t)B : 0;   // ping-pong states of the step-by-step forward pass
+    const size_t unit_floats = exact ? (size_t)h->D * (size_t)h->D * (size_t)B : 0;   // the D unit probes of every column
+    const size_t need = (ckpt_floats + 4 * (size_t)B + slab_floats + state_floats + unit_floats) * sizeof(float);
     if (need > h->grad_ws_bytes) {
         if (h->grad_ws) HIP_TRY(hipFree(h->grad_ws));
         h->grad_ws = nullptr; h->grad_ws_bytes = 0;
@@ -1032,19 +1043,61 @@ int cnf_loss_grad_fixed(cnf_handle* h, int alg, int nsteps, float t0, float t1, 
     float* logp = ckpt + ckpt_floats;
     float* regs = logp + B;
     float* slab = regs + 3 * (size_t)B;
-    SolveArgs a{};
-    a.x = x; a.eps = eps; a.ys = ys; a.B = B; a.nsteps = nsteps; a.alg = alg; a.t0 = t0; a.t1 = t1;
-    const int reg_aug = (h->cfg.reg_aug && h->cfg.naug > 0) ? 1 : 0;
-    a.logp = logp; a.regs = regs; a.nvars = h->cfg.nvars; a.reg_aug = reg_aug; a.ckpt = ckpt; a.ckpt_k = ckpt_k;
-    HIP_TRY(mfma_solve(h->plan, h->packed_dev, a, st));
+    const int reg_aug = (!exact && h->cfg.reg_aug && h->cfg.naug > 0) ? 1 : 0;
+    if (!tgrid) {
+        SolveArgs a{};
+        a.x = x; a.eps = eps; a.ys = ys; a.B = B; a.nsteps = nsteps; a.alg = alg; a.t0 = t0; a.t1 = t1;
+        a.logp = logp; a.regs = regs; a.nvars = h->cfg.nvars; a.reg_aug = reg_aug; a.ckpt = ckpt; a.ckpt_k = ckpt_k;
+        HIP_TRY(mfma_solve(h->plan, h->packed_dev, a, st));
+    } else {
+        // non-uniform grid: the checkpointing forward pass is one launch of the (unchanged) solve kernel per step - the metric
+        // kernel keeps its loop-invariant step size; step n writes checkpoint slots n and n + 1 and its stage derivatives
+        float* ua = slab + slab_floats;
+        float* ub = ua + (size_t)h->S * (size_t)B;
+        HIP_TRY(assemble_u0(x, h->cfg.nvars, h->S, B, ua, st));
+        const size_t zslot = (size_t)ntiles * 64 * (size_t)ckpt_zr;
+        for (int n = 0; n < nsteps; ++n) {
+            SolveArgs a{};
+            a.u0 = ua; a.u_out = ub; a.eps = eps; a.ys = ys; a.B = B; a.nsteps = 1; a.alg = alg; a.t0 = tgrid[n]; a.t1 = tgrid[n + 1];
+            a.nvars = h->cfg.nvars; a.reg_aug = reg_aug;
+            a.ckpt = ckpt + (size_t)n * zslot; a.ckpt_k = ckpt_k + (size_t)n * nstages * zslot;
+            if (n == nsteps - 1) { a.logp = logp; a.regs = regs; }
+            HIP_TRY(mfma_solve(h->plan, h->packed_dev, a, st));
+            float* tmp = ua; ua = ub; ub = tmp;
+        }
+    }
     if (sums4) {
         if (!h->loss_partial) HIP_TRY(hipMalloc((void**)&h->loss_partial, 256 * 4 * sizeof(float)));
         HIP_TRY(loss_sums(logp, regs, B, h->loss_partial, sums4, st));
     }
-    const float lam[3] = {h->cfg.reg_z ? lambdas[0] : 0.f, h->cfg.reg_j ? lambdas[1] : 0.f, reg_aug ? lambdas[2] : 0.f};
-    HIP_TRY(grad_launch(h->cfg, h->grad_packed, ckpt, ckpt_k, ckpt_zr, eps, ys, h->w_off.data(), h->b_off.data(), alg, nsteps, t0, t1,
-                        B, lam, slab, grad, grad_x, h->num_cus, st));
+    const float lam[3] = {gc.reg_z ? lambdas[0] : 0.f, gc.reg_j ? lambdas[1] : 0.f, reg_aug ? lambdas[2] : 0.f};
+    const float* probes = eps;
+    if (exact) {
+        float* unit = slab + slab_floats + state_floats;
+        const long long nunit = (long long)unit_floats;
+        hipLaunchKernelGGL(unit_probes_kernel, dim3((unsigned)((nunit + 255) / 256)), dim3(256), 0, st, unit, h->D, (long long)B);
+        HIP_TRY(hipGetLastError());
+        probes = unit;
+    }
+    HIP_TRY(grad_launch(gc, h->grad_packed, ckpt, ckpt_k, ckpt_zr, probes, ys, h->w_off.data(), h->b_off.data(), alg, nsteps, t0, t1,
+                        tgrid_dev, exact ? 1.f : 0.f, B, lam, slab, grad, grad_x, h->num_cus, st));
     return CNF_OK;
+}
+
+
+extern "C" {
+
+int cnf_loss_grad_fixed(cnf_handle* h, int alg, int nsteps, float t0, float t1, const float* x,
+                        const float* eps, const float* ys, int64_t B, const float* lambdas,
+                        float* grad, float* grad_x, float* sums4, void* stream) {
+    return loss_grad_impl(h, "cnf_loss_grad_fixed", alg, nsteps, t0, t1, nullptr, x, eps, ys, B, lambdas, grad, grad_x, sums4, stream);
+}
+
+int cnf_loss_grad_grid(cnf_handle* h, int alg, int nsteps, const float* tgrid, const float* x, const float* eps,
+                       const float* ys, int64_t B, const float* lambdas, float* grad, float* grad_x, float* sums4,
+                       void* stream) {
+    if (nsteps < 1 || !tgrid) return fail(CNF_ERR_INVALID, "cnf_loss_grad_grid: nsteps >= 1 and a grid of nsteps + 1 times required");
+    return loss_grad_impl(h, "cnf_loss_grad_grid", alg, nsteps, 0.f, 0.f, tgrid, x, eps, ys, B, lambdas, grad, grad_x, sums4, stream);
 }
 
 }  // extern "C"

@@ -56,7 +56,7 @@ mfma_grad_kernel(GArgs a) {
     const long long ntiles = (a.B + 15) / 16;
     const int D = a.D;
     const bool autonomous = a.autonomous;
-    const float dt = a.dt;
+    const float dt0 = a.dt;
     const int ns = a.T.ns;
 
     // Hidden-matrix cotangents live in registers for the whole launch: wave w owns row block w
@@ -115,7 +115,8 @@ mfma_grad_kernel(GArgs a) {
 
 #pragma clang loop unroll(disable)
         for (int step = a.nsteps - 1; step >= 0; --step) {
-            const float tn = a.t0 + (float)step * dt;
+            float tn = a.t0 + (float)step * dt0, dt = dt0;
+            if (a.tgrid) { tn = a.tgrid[step]; dt = a.tgrid[step + 1] - tn; }
             float zn[ZR];
 #pragma unroll
             for (int s = 0; s < ZR; ++s) zn[s] = a.ckpt[(((long long)step * ntiles + tile) * 64 + lane) * a.ckpt_zr + s];
@@ -487,8 +488,8 @@ void grad_shape(const cnf_config& c, int* HT, int* L, int* ZR, int* CR) {
 
 hipError_t grad_launch(const cnf_config& c, const float* packed_dev, const float* ckpt, const float* ckpt_k,
                        int ckpt_zr, const float* eps, const float* ys,
-                       const size_t* w_off, const size_t* b_off, int alg, int nsteps, float t0, float t1,
-                       long long B, const float lam[3], float* slab, float* grad, float* grad_x, int num_cus, hipStream_t st) {
+                       const size_t* w_off, const size_t* b_off, int alg, int nsteps, float t0, float t1, const float* tgrid_dev,
+                       float probe_w, long long B, const float lam[3], float* slab, float* grad, float* grad_x, int num_cus, hipStream_t st) {
     const GradInst* gi = grad_find(c);
     if (!gi) return hipErrorNotSupported;
     // > 64 KB of dynamic LDS has to be enabled once per device and kernel
@@ -512,7 +513,7 @@ hipError_t grad_launch(const cnf_config& c, const float* packed_dev, const float
     }
     GArgs a{};
     a.packed = packed_dev; a.ckpt = ckpt; a.ckpt_k = ckpt_k; a.ckpt_zr = ckpt_zr; a.eps = eps; a.K = c.nprobes; a.ys = ys; a.C = c.ncond; a.slab = slab; a.grad_x = grad_x; a.B = B;
-    a.nsteps = nsteps; a.t0 = t0; a.dt = (t1 - t0) / (float)nsteps;
+    a.nsteps = nsteps; a.t0 = t0; a.dt = (t1 - t0) / (float)nsteps; a.tgrid = tgrid_dev; a.probe_w = probe_w;
     a.D = c.nvars + c.naug; a.H = c.widths[1]; a.n_in = c.widths[0]; a.autonomous = c.autonomous; a.nvars = c.nvars;
     a.lam1 = lam[0]; a.lam2 = lam[1]; a.lam3 = lam[2];
     for (int l = 0; l < c.n_layers; ++l) { a.w_off[l] = (int)w_off[l]; a.b_off[l] = (int)b_off[l]; }

@@ -20,6 +20,8 @@ struct GArgs {
     long long B;
     int nsteps;
     float t0, dt;
+    float probe_w;         // weight of each probe's trace term; 0 = 1 / K (Hutchinson mean), 1 = exact trace from the D unit probes
+    const float* tgrid;    // optional (device): nsteps + 1 step times of a non-uniform grid; null = t0 + n dt
     int D, H, n_in, autonomous, nvars;
     float lam1, lam2, lam3;   // weights of Edot, ndot, Adot in the objective (0 = term off)
     int w_off[4], b_off[4];   // Lux offsets of the L+1 <= 4 Dense layers

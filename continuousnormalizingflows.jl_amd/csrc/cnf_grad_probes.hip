@@ -65,9 +65,9 @@ mfma_grad_probes_kernel(GArgs a) {
     for (int q4 = 0; q4 < 4; ++q4) onesf[q4] = (lane & 15) == 0 ? 1.f : 0.f;
     const long long ntiles = (a.B + 15) / 16;
     const int D = a.D, K = a.K;
-    const float invK = 1.f / (float)K;
+    const float invK = a.probe_w > 0.f ? a.probe_w : 1.f / (float)K;
     const bool autonomous = a.autonomous;
-    const float dt = a.dt;
+    const float dt0 = a.dt;
     const int ns = a.T.ns;
 
     f32x4 Wh[L > 1 ? L - 1 : 1][HT], Bh[L > 1 ? L - 1 : 1], W1acc[SL::NT1], WNacc, BNacc;
@@ -109,7 +109,8 @@ mfma_grad_probes_kernel(GArgs a) {
 
 #pragma clang loop unroll(disable)
         for (int step = a.nsteps - 1; step >= 0; --step) {
-            const float tn = a.t0 + (float)step * dt;
+            float tn = a.t0 + (float)step * dt0, dt = dt0;
+            if (a.tgrid) { tn = a.tgrid[step]; dt = a.tgrid[step + 1] - tn; }
             float zn[ZR];
 #pragma unroll
             for (int s = 0; s < ZR; ++s) zn[s] = a.ckpt[(((long long)step * ntiles + tile) * 64 + lane) * a.ckpt_zr + s];

@@ -166,7 +166,7 @@ grad_slab_kernel(GArgs a, const float* __restrict__ x, float* __restrict__ ckz, 
     const long long ntiles = (a.B + 15) / 16;
     const int D = a.D;
     const bool autonomous = a.autonomous;
-    const float dt = a.dt;
+    const float dt0 = a.dt;
     const int ns = a.T.ns;
 
     for (long long tile = (long long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long long)gridDim.x * 4) {
@@ -190,7 +190,8 @@ grad_slab_kernel(GArgs a, const float* __restrict__ x, float* __restrict__ ckz, 
             }
 #pragma clang loop unroll(disable)
             for (int step = 0; step < a.nsteps; ++step) {
-                const float tn = a.t0 + (float)step * dt;
+                float tn = a.t0 + (float)step * dt0, dt = dt0;
+                if (a.tgrid) { tn = a.tgrid[step]; dt = a.tgrid[step + 1] - tn; }
 #pragma unroll
                 for (int s = 0; s < ZR; ++s) ckz[(((long long)step * ntiles + tile) * 64 + lane) * ZR + s] = z[s];
                 float kz[6][ZR];
@@ -258,7 +259,8 @@ grad_slab_kernel(GArgs a, const float* __restrict__ x, float* __restrict__ ckz, 
         // ---------------- reverse sweep ----------------
 #pragma clang loop unroll(disable)
         for (int step = a.nsteps - 1; step >= 0; --step) {
-            const float tn = a.t0 + (float)step * dt;
+            float tn = a.t0 + (float)step * dt0, dt = dt0;
+            if (a.tgrid) { tn = a.tgrid[step]; dt = a.tgrid[step + 1] - tn; }
             float zn[ZR], kz[6][ZR], Zb[6][ZR];
 #pragma unroll
             for (int s = 0; s < ZR; ++s) zn[s] = ckz[(((long long)step * ntiles + tile) * 64 + lane) * ZR + s];
@@ -538,8 +540,8 @@ size_t grad_slab_ws_floats(const cnf_config& c, int alg, int nsteps, long long B
 }
 
 hipError_t grad_slab_launch(const cnf_config& c, const float* packed_dev, const float* x, const float* eps, const float* ys,
-                            const size_t* w_off, const size_t* b_off, int alg, int nsteps, float t0, float t1, long long B,
-                            const float lam[3], float* ws, float* grad, float* grad_x, int num_cus, hipStream_t st) {
+                            const size_t* w_off, const size_t* b_off, int alg, int nsteps, float t0, float t1,
+                            const float* tgrid_dev, long long B, const float lam[3], float* ws, float* grad, float* grad_x, int num_cus, hipStream_t st) {
     const SlabInst* si = slab_find(c);
     if (!si) return hipErrorNotSupported;
     static DeviceOnce once[sizeof(kSlab) / sizeof(kSlab[0])];
@@ -559,7 +561,7 @@ hipError_t grad_slab_launch(const cnf_config& c, const float* packed_dev, const 
     float* slab = ckk + (size_t)nsteps * ns * ntiles * 64 * si->ZR;
     GArgs a{};
     a.packed = packed_dev; a.eps = eps; a.K = 1; a.ys = ys; a.C = c.ncond; a.slab = slab; a.grad_x = grad_x; a.B = B;
-    a.nsteps = nsteps; a.t0 = t0; a.dt = (t1 - t0) / (float)nsteps;
+    a.nsteps = nsteps; a.t0 = t0; a.dt = (t1 - t0) / (float)nsteps; a.tgrid = tgrid_dev;
     a.D = c.nvars + c.naug; a.H = c.widths[1]; a.n_in = c.widths[2] /* second hidden width for the reduce kernel */;
     a.autonomous = c.autonomous; a.nvars = c.nvars;
     a.lam1 = lam[0]; a.lam2 = lam[1]; a.lam3 = lam[2];

@@ -85,8 +85,8 @@ void grad_shape(const cnf_config& c, int* HT, int* L, int* ZR, int* CR);
 void grad_pack(const cnf_config& c, const float* lux, const size_t* w_off, const size_t* b_off, float* packed);
 hipError_t grad_launch(const cnf_config& c, const float* packed_dev, const float* ckpt, const float* ckpt_k,
                        int ckpt_zr, const float* eps, const float* ys,
-                       const size_t* w_off, const size_t* b_off, int alg, int nsteps, float t0, float t1,
-                       long long B, const float lam[3], float* slab, float* grad, float* grad_x, int num_cus, hipStream_t st);
+                       const size_t* w_off, const size_t* b_off, int alg, int nsteps, float t0, float t1, const float* tgrid_dev,
+                       float probe_w, long long B, const float lam[3], float* slab, float* grad, float* grad_x, int num_cus, hipStream_t st);
 // layer-wise gradient on rocBLAS GEMMs for everything the fused kernels do not cover (cnf_layered.hip)
 struct LayeredGrad;
 bool layered_available();   // librocblas.so.5 loadable
@@ -107,8 +107,8 @@ size_t grad_slab_packed_bytes(const cnf_config& c);
 void grad_slab_pack(const cnf_config& c, const float* lux, const size_t* w_off, const size_t* b_off, float* packed);
 size_t grad_slab_ws_floats(const cnf_config& c, int alg, int nsteps, long long B, int num_cus);
 hipError_t grad_slab_launch(const cnf_config& c, const float* packed_dev, const float* x, const float* eps, const float* ys,
-                            const size_t* w_off, const size_t* b_off, int alg, int nsteps, float t0, float t1, long long B,
-                            const float lam[3], float* ws, float* grad, float* grad_x, int num_cus, hipStream_t st);
+                            const size_t* w_off, const size_t* b_off, int alg, int nsteps, float t0, float t1,
+                            const float* tgrid_dev, long long B, const float lam[3], float* ws, float* grad, float* grad_x, int num_cus, hipStream_t st);
 int mfma_plan_zr(const MfmaPlan* p);   // state k-steps of the forward instance (checkpoint stride)
 bool mfma_plan_is_per_wave(const MfmaPlan* p);
 

@@ -229,8 +229,9 @@ int cnf_loss_sums(cnf_handle* h, const float* logp, const float* regs, int64_t B
  * <= 16 conditions, 2 or 3 equal hidden layers (tanh or softplus) of width <= 64, D + !autonomous <= 15;
  * slab-accumulator kernel: two hidden layers of width <= 128, D + !autonomous <= 32, <= 16 conditions, one probe (the
  * reference's default nets for 7..15 variables); every other shape (wider or more layers, mixed activations, larger D): layer-wise
- * reverse sweep on rocBLAS GEMMs, which also serves the Hutchinson JVP mode and the exact-trace mode (TestMode:
- * -tr J = -sum_k e_k^T J e_k, the pullback with the D unit vectors as probes; eps is ignored, no regularisers).
+ * reverse sweep on rocBLAS GEMMs, which also serves the Hutchinson JVP mode.  Exact-trace mode (TestMode):
+ * -tr J = -sum_k e_k^T J e_k, the pullback with the D unit vectors as probes of weight 1 (eps is ignored, no
+ * regularisers) - on the several-probe fused kernel for D <= 8, layer-wise beyond.
  * FFJORD and RNODE losses. */
 int cnf_loss_grad_fixed(cnf_handle* h, int alg, int nsteps, float t0, float t1, const float* x,
                         const float* eps, const float* ys, int64_t B, const float* lambdas,
@@ -239,13 +240,15 @@ int cnf_loss_grad_fixed(cnf_handle* h, int alg, int nsteps, float t0, float t1, 
 /* The same sum and gradients on a NON-UNIFORM grid of fixed steps: step n runs from tgrid[n] to tgrid[n+1]
  * (tgrid: HOST array of nsteps + 1 times).  This is how a loss evaluated with the adaptive solver is
  * differentiated: the accepted steps are frozen and the discrete solve on that grid is reversed (the dependence
- * of the step sizes on the parameters is ignored, the usual discretise-then-optimise convention).  Layer-wise
- * gradient path for every shape; the loss sums come from the same grid solve. */
+ * of the step sizes on the parameters is ignored, the usual discretise-then-optimise convention).  Served by the same
+ * implementations as cnf_loss_grad_fixed (cnf_grad_path): the fused reverse-sweep kernels read the step times from device
+ * memory (their checkpointing forward pass is one launch of the solve kernel per step), the layer-wise path takes them
+ * from the host; the loss sums come from the same grid solve. */
 int cnf_loss_grad_grid(cnf_handle* h, int alg, int nsteps, const float* tgrid, const float* x, const float* eps,
                        const float* ys, int64_t B, const float* lambdas, float* grad, float* grad_x, float* sums4,
                        void* stream);
 
-/* Which implementation cnf_loss_grad_fixed uses for this handle: 0 = none (CNF_ERR_UNSUPPORTED),
+/* Which implementation cnf_loss_grad_fixed / cnf_loss_grad_grid use for this handle: 0 = none (CNF_ERR_UNSUPPORTED),
  * 1 = fused reverse-sweep kernel (cnf_grad.hip / cnf_grad_probes.hip / cnf_grad_slab.hip), 2 = layer-wise reverse sweep on
  * rocBLAS GEMMs (cnf_layered.hip; librocblas.so.5 is loaded with dlopen at first use). */
 int cnf_grad_path(const cnf_handle* h);

@@ -30,6 +30,13 @@ for name, kw in (("fixed_tsit5_40", dict(alg=pkg.Tsit5(), adaptive=False, nsteps
         st = icnf.last_solve_stats
         r.update(naccept=st["naccept"], nreject=st["nreject"], nf=st["nf"])
         if "orders" in st: r["orders"] = st["orders"]
+    g = lambda: pkg.loss_and_gradient(icnf, m, X, P, {}, eps=E)[1]
+    g(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5): g()
+    torch.cuda.synchronize()
+    r["loss_and_gradient_ms"] = 1e3 * (time.perf_counter() - t0) / 5
+    r["grad_path"] = icnf.grad_path(m)
     out[name] = r
     if name == "fixed_tsit5_40": base = lp
     else: r["max_abs_dlogp_vs_fixed40"] = float((lp - base).abs().max())

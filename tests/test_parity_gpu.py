@@ -1129,15 +1129,20 @@ def test_adaptive_tsit5_follows_the_oracle_restatement(kw, tol, pkg, oracles):
     assert np.max(np.abs(logp.cpu().numpy() - lp)) < 2e-4
 
 
-@pytest.mark.parametrize("kw,lam", [
-    (dict(nvars=8, hidden=[64, 64, 64], reg_z=True, reg_j=True), (0.02, 0.03, 0.0)),
-    (dict(nvars=3, naug=2, ncond=2, hidden=[24, 48, 24], act=2, nprobes=2, reg_aug=True), (0.0, 0.0, 0.05)),
+@pytest.mark.parametrize("kw,lam,gpath", [
+    (dict(nvars=8, hidden=[64, 64, 64], reg_z=True, reg_j=True), (0.02, 0.03, 0.0), 1),     # register-accumulator kernel
+    (dict(nvars=8, hidden=[64, 64, 64], nprobes=3, reg_j=True), (0.0, 0.03, 0.0), 1),       # several-probe kernel
+    (dict(nvars=4, naug=5, ncond=2, hidden=[40, 40], act=2, reg_z=True), (0.02, 0.0, 0.0), 1),   # default-style net, conditioned
+    (dict(nvars=10, hidden=[72, 72], act=2, reg_z=True, reg_j=True), (0.02, 0.03, 0.0), 1),  # slab-accumulator kernel
+    (dict(nvars=3, naug=2, ncond=2, hidden=[24, 48, 24], act=2, nprobes=2, reg_aug=True), (0.0, 0.0, 0.05), 2),   # layer-wise path
 ])
-def test_gradient_of_the_adaptive_solve_on_its_frozen_grid(kw, lam, pkg, oracles):
+def test_gradient_of_the_adaptive_solve_on_its_frozen_grid(kw, lam, gpath, pkg, oracles):
     """loss_and_gradient with the adaptive solver: the accepted steps are frozen and the discrete solve on that
-    non-uniform grid is reversed (cnf_loss_grad_grid) - against fp64 autograd on the same grid."""
+    non-uniform grid is reversed (cnf_loss_grad_grid; the fused reverse-sweep kernels read the step times from device
+    memory, the layer-wise path takes them from the host) - against fp64 autograd on the same grid."""
     o64, _ = oracles
     spec = o64.make_spec(**kw)
+    assert _adaptive_icnf(pkg, spec, 1e-4).grad_path(pkg.TrainMode(True)) == gpath
     B = 45
     p, xs, eps, ys = o64.synth_inputs(spec, B, 88, bias_scale=0.3)
     p = (p * 2.0).astype(np.float32)
@@ -1450,22 +1455,25 @@ def test_vcabm_round_trip_large_batch_and_training(pkg, oracles):
 
 # ---- the remaining cells of the reference's smoke matrix for the gradient: TestMode and PlanarLayer nets ----
 
-@pytest.mark.parametrize("kw,alg,nsteps", [
-    (dict(nvars=3, ncond=2, hidden=[24, 24], act=2, mode=2), 1, 8),                         # default-style softplus net, conditioned
-    (dict(nvars=8, hidden=[64, 64, 64], mode=2), 0, 6),
-    (dict(nvars=2, naug=3, hidden=[20], act=1, mode=2), 1, 8),                              # augmented, one hidden layer
+@pytest.mark.parametrize("kw,alg,nsteps,gpath", [
+    (dict(nvars=3, ncond=2, hidden=[24, 24], act=2, mode=2), 1, 8, 1),                      # default-style softplus net, conditioned
+    (dict(nvars=8, hidden=[64, 64, 64], mode=2), 0, 6, 1),                                  # 8 unit probes: the probe kernel's capacity
+    (dict(nvars=1, naug=2, hidden=[16, 16], act=2, mode=2), 1, 8, 1),                       # ICNF(; nvariables = 1): the reference's benchmark net
+    (dict(nvars=1, hidden=[16, 16], act=1, mode=2), 1, 8, 1),                               # D = 1: the one-probe kernel
+    (dict(nvars=9, hidden=[32, 32], act=1, mode=2), 1, 6, 2),                               # more than 8 state rows: layer-wise path
+    (dict(nvars=2, naug=3, hidden=[20], act=1, mode=2), 1, 8, 2),                           # augmented, one hidden layer: layer-wise path
 ])
-def test_gradient_of_the_test_mode_loss(kw, alg, nsteps, pkg, oracles):
+def test_gradient_of_the_test_mode_loss(kw, alg, nsteps, gpath, pkg, oracles):
     """`DI.gradient` of `loss(icnf, TestMode(), ...)` with respect to ps and to xs (test/ci_tests/smoke_tests.jl:85-90 with
     omode = TestMode()): the exact trace -tr J = -sum_k e_k^T J e_k reversed with the D unit vectors as probes on the
-    layer-wise path, against fp64 autograd through the exact-trace solve."""
+    several-probe fused kernel (D <= 8) or the layer-wise path, against fp64 autograd through the exact-trace solve."""
     o64, _ = oracles
     spec = o64.make_spec(**kw)
     B = 41
     p, xs, eps, ys = o64.synth_inputs(spec, B, 52, bias_scale=0.3)
     icnf = make_icnf(pkg, spec, alg, nsteps)
     mode = pkg.TestMode()
-    assert icnf.grad_path(mode) == 2
+    assert icnf.grad_path(mode) == gpath
     args = (dev(xs),) + ((dev(ys),) if spec.ncond else ()) + (dev(p), {})
     val, g, gx = pkg.loss_and_gradient(icnf, mode, *args, wrt_x=True)
     L, gref, gxref = o64.loss_and_grad(spec, p, xs, 0.0, 1.0, nsteps, alg, None, ys, (0.0, 0.0, 0.0), wrt_x=True)
