@@ -749,7 +749,7 @@ int cnf_vcabm_begin(cnf_handle* h, float t0, const float* u0, const float* eps, 
         if (n) HIP_TRY(hipMalloc((void**)&h->vc_buf, (6 + 2 * kVcSlots) * n * sizeof(float)));
         h->vc_B = B;
     }
-    if (!h->vc_partial) HIP_TRY(hipMalloc((void**)&h->vc_partial, vcabm_partial_doubles() * sizeof(double)));
+    if (!h->vc_partial) HIP_TRY(hipMalloc((void**)&h->vc_partial, (vcabm_partial_doubles() + 8) * sizeof(double)));   // + result slots of cnf_solve_vcabm
     h->vc_iu = 0; h->vc_iun = 2; h->vc_if = 3; h->vc_ifn = 5; h->vc_cur = 0;
     h->vc_nhist = 0; h->vc_k = 0; h->vc_t = t0; h->vc_dt = 0.0;
     for (double& d : h->vc_hist) d = 0.0;
@@ -875,6 +875,112 @@ int cnf_vcabm_state(cnf_handle* h, int64_t B, float* u_out, double* t_out, void*
                                (hipStream_t)stream));
     }
     return CNF_OK;
+}
+
+// The whole default solve in one call: cnf_vcabm_begin / _attempt / _accept driven by the step-size and order policy of
+// icnf._vcabm_integrate (the host side of the reference's solver), restated here so that a single-process caller pays one
+// library call per solve instead of two per step.  Synchronises `stream` (the policy reads the error sums).
+int cnf_solve_vcabm(cnf_handle* h, float t0, float t1, const float* u0, const float* eps, const float* ys, int64_t B,
+                    float abstol, float reltol, float dt_init, int maxiters, float* u1, cnf_solve_stats* stats,
+                    float* dts_out, int32_t* orders_out, int32_t record_cap, void* stream) {
+    if (stats) *stats = cnf_solve_stats{};
+    int rc = cnf_vcabm_begin(h, t0, u0, eps, ys, B, stream);
+    if (rc) return rc;
+    if (!(abstol >= 0.f) || !(reltol >= 0.f) || (abstol == 0.f && reltol == 0.f))
+        return fail(CNF_ERR_INVALID, "cnf_solve_vcabm: tolerances must be non-negative and not both zero");
+    if (B > 0 && !u1) return fail(CNF_ERR_INVALID, "cnf_solve_vcabm: null u1");
+    if (maxiters < 1) return fail(CNF_ERR_INVALID, "cnf_solve_vcabm: maxiters >= 1 required");
+    int nf = B > 0 ? 1 : 0, naccept = 0, nreject = 0, max_order = 0;
+    const double span = std::fabs((double)t1 - (double)t0), tdir = t1 >= t0 ? 1.0 : -1.0;
+    if (B == 0 || span == 0.0) {
+        if (B > 0) return cnf_vcabm_state(h, B, u1, nullptr, stream);
+        return CNF_OK;
+    }
+    DeviceGuard g(h->cfg.device_id);
+    hipStream_t st = (hipStream_t)stream;
+    const size_t n = (size_t)h->S * (size_t)B;
+    const double ntot = (double)n;
+    double* res = h->vc_partial + vcabm_partial_doubles();   // device result slots
+    double host[4];
+    auto fetch = [&](int cnt) -> int {
+        HIP_TRY(hipMemcpyAsync(host, res, cnt * sizeof(double), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        return CNF_OK;
+    };
+    double dt;
+    if (dt_init != 0.f) {
+        dt = std::min((double)std::fabs(dt_init), span);
+    } else {   // ode_determine_initdt (Hairer, Noersett, Wanner I, II.4) with the algorithm order 7, RMS norm over all S*B entries
+        float *u = vc_vec(h, h->vc_iu), *f0 = vc_vec(h, h->vc_if), *ue = vc_vec(h, 1), *f1 = vc_vec(h, 4);
+        HIP_TRY(vcabm_scaled_sumsq(u, nullptr, u, abstol, reltol, (int64_t)n, h->vc_partial, res, st));
+        HIP_TRY(vcabm_scaled_sumsq(f0, nullptr, u, abstol, reltol, (int64_t)n, h->vc_partial, res + 1, st));
+        rc = fetch(2);
+        if (rc) return rc;
+        const double d0 = std::sqrt(host[0] / ntot), d1 = std::sqrt(host[1] / ntot);
+        double h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
+        h0 = std::min(h0, span);
+        StageIn eu{};
+        eu.u = u; eu.nprev = 1; eu.k[0] = f0; eu.coef[0] = 1.f; eu.dt = (float)(tdir * h0);
+        HIP_TRY(rk_update(ue, eu, (int64_t)n, st));
+        StageIn in{};
+        in.u = ue; in.nprev = 0; in.dt = 0.f;
+        rc = eval_dynamics(h, in, (float)((double)t0 + tdir * h0), eps, ys, B, f1, nullptr, false, st);
+        if (rc) return rc;
+        ++nf;
+        HIP_TRY(vcabm_scaled_sumsq(f1, f0, u, abstol, reltol, (int64_t)n, h->vc_partial, res, st));
+        rc = fetch(1);
+        if (rc) return rc;
+        const double d2 = std::sqrt(host[0] / ntot) / h0, dmax = std::max(d1, d2);
+        const double h1 = dmax <= 1e-15 ? std::max(1e-6, h0 * 1e-3) : std::pow(10.0, -(2.0 + std::log10(dmax)) / 8.0);
+        dt = std::min(std::min(100.0 * h0, h1), span);
+    }
+    const double gamma = 0.9, qmin = 0.2, qmax = 10.0;
+    double t = t0;
+    int k = 1, step = 1, it = 0;
+    for (; it < maxiters; ++it) {
+        if (std::fabs((double)t1 - t) <= 1e-7 * std::max(1.0, span)) break;
+        const bool last = dt >= std::fabs((double)t1 - t) * (1.0 - 1e-6);
+        const double hstep = last ? std::fabs((double)t1 - t) : dt;     // tstop: never step over t1
+        rc = cnf_vcabm_attempt(h, k, (float)(tdir * hstep), eps, ys, B, abstol, reltol, res, stream);
+        if (rc) return rc;
+        ++nf;
+        rc = fetch(3);
+        if (rc) return rc;
+        double eest = std::sqrt(host[0] / ntot);
+        if (!std::isfinite(eest)) return fail(CNF_ERR_INVALID, "cnf_solve_vcabm: non-finite error estimate (unstable dynamics)");
+        if (eest > 1.0) {   // reject: same state, smaller step, same order
+            ++nreject;
+            dt = hstep / std::max(1.0 / qmax, std::min(1.0 / qmin, std::pow(eest, 1.0 / (k + 1)) / gamma));
+            continue;
+        }
+        const bool select = step > 4 && k >= 3;
+        const bool lower = select && std::max(std::sqrt(host[2] / ntot), std::sqrt(host[1] / ntot)) <= eest;
+        const bool want_up = select && !lower && k < CNF_VCABM_MAX_ORDER;
+        rc = cnf_vcabm_accept(h, eps, ys, B, abstol, reltol, want_up ? res : nullptr, stream);
+        if (rc) return rc;
+        ++nf;
+        int knew = k;
+        if (!select) knew = std::min(k + 1, 3);
+        else if (lower) knew = k - 1;
+        else if (want_up) {
+            rc = fetch(1);
+            if (rc) return rc;
+            if (std::sqrt(host[0] / ntot) < eest) { knew = k + 1; eest = 1.0; }
+        }
+        const double q = eest == 0.0 ? 1.0 / qmax : std::max(1.0 / qmax, std::min(1.0 / qmin, std::pow(eest, 1.0 / (knew + 1)) / gamma));
+        t = last ? (double)t1 : t + tdir * hstep;
+        if (naccept < record_cap) {
+            if (dts_out) dts_out[naccept] = (float)(tdir * hstep);
+            if (orders_out) orders_out[naccept] = k;
+        }
+        ++naccept;
+        if (k > max_order) max_order = k;
+        k = knew; ++step;
+        dt = hstep / q;
+    }
+    if (stats) { stats->naccept = naccept; stats->nreject = nreject; stats->nf = nf; stats->max_order = max_order; }
+    if (it == maxiters) return fail(CNF_ERR_INVALID, "cnf_solve_vcabm: maxiters reached");
+    return cnf_vcabm_state(h, B, u1, nullptr, stream);
 }
 
 int cnf_assemble_u0(cnf_handle* h, const float* x, int64_t B, float* u0, void* stream) {

@@ -125,6 +125,8 @@ struct VcCoef {
     float e0, e1, e2;      // dt (g_k - g_{k-1}), dt (g_{k-1} - g_{k-2}), dt (g_{k-2} - g_{k-3});  errup: e0 = dt gamma*_{k+1}
 };
 size_t vcabm_partial_doubles();
+hipError_t vcabm_scaled_sumsq(const float* a, const float* b, const float* u, float abstol, float reltol, int64_t n,
+                              double* partial, double* out1, hipStream_t st);
 hipError_t vcabm_predict(const float* f, const float* u, const VcCoef& c, int64_t n, float* p, hipStream_t st);
 hipError_t vcabm_correct(const float* d, const float* p, const float* u, const VcCoef& c, float abstol, float reltol,
                          int64_t n, float* unew, double* partial, double* err3, hipStream_t st);

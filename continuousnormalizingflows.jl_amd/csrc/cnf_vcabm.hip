@@ -84,6 +84,18 @@ vc_errup_kernel(const float* __restrict__ fnew, const float* __restrict__ u, con
     block_sum3(a0, 0.0, 0.0, partial);
 }
 
+// sum over the state of ((a - b) / (abstol + reltol |u|))^2 (b may be null): the norms of Hairer's initial-step heuristic
+__global__ void __launch_bounds__(256)
+vc_norm_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ u, float abstol, float reltol,
+               int64_t n, double* __restrict__ partial) {
+    double a0 = 0.0;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+        const float r = (b ? a[e] - b[e] : a[e]) / fmaf(fabsf(u[e]), reltol, abstol);
+        a0 += (double)r * (double)r;
+    }
+    block_sum3(a0, 0.0, 0.0, partial);
+}
+
 __global__ void __launch_bounds__(256)
 vc_final_kernel(const double* __restrict__ partial, int nout, double* __restrict__ out) {
     __shared__ double sm[256];
@@ -121,6 +133,13 @@ hipError_t vcabm_errup(const float* fnew, const float* u, const float* unew, con
                        int64_t n, double* partial, double* err1, hipStream_t st) {
     hipLaunchKernelGGL(vc_errup_kernel, dim3(VC_BLOCKS), dim3(256), 0, st, fnew, u, unew, c, abstol, reltol, n, partial);
     hipLaunchKernelGGL(vc_final_kernel, dim3(1), dim3(256), 0, st, partial, 1, err1);
+    return hipGetLastError();
+}
+
+hipError_t vcabm_scaled_sumsq(const float* a, const float* b, const float* u, float abstol, float reltol, int64_t n,
+                              double* partial, double* out1, hipStream_t st) {
+    hipLaunchKernelGGL(vc_norm_kernel, dim3(VC_BLOCKS), dim3(256), 0, st, a, b, u, abstol, reltol, n, partial);
+    hipLaunchKernelGGL(vc_final_kernel, dim3(1), dim3(256), 0, st, partial, 1, out1);
     return hipGetLastError();
 }
 

@@ -594,7 +594,9 @@ def _vcabm_integrate(icnf: ICNF, h: "_Handle", u0: torch.Tensor, t0: float, t1: 
     integral step-size controller dt / clamp(EEst^(1/(k+1)) / gamma, 1/qmax, 1/qmin) (gamma = 9/10, qmin = 1/5,
     qmax = 10; the same factor after a rejection) and Hairer's initial step.  Restated from the published algorithm
     (see oracle/cnf_oracle64.py::integrate_vcabm, the fp64 oracle this is tested against); the Julia package's exact
-    step / order sequence cannot be checked here.  The error norms run over the whole S x B state, so a sharded
+    step / order sequence cannot be checked here.  A single-process solve runs the same policy inside the library
+    (`cnf_solve_vcabm`, one call per solve; `icnf.vcabm_policy = "python"` keeps this loop - the two are tested to take
+    identical steps).  The error norms run over the whole S x B state, so a sharded
     solve all-reduces the squared sums and every rank takes the same steps."""
     import torch.distributed as dist
     kw = icnf.sol_kwargs
@@ -618,11 +620,21 @@ def _vcabm_integrate(icnf: ICNF, h: "_Handle", u0: torch.Tensor, t0: float, t1: 
         return [float(v) for v in t]
 
     u0 = u0.contiguous()
+    if not sharded and getattr(icnf, "vcabm_policy", "library") == "library":
+        # single process: the same policy restated inside the library (cnf_solve_vcabm), one call per solve
+        cap = 4096
+        ss, dts, orders = _lib.SolveStats(), (C.c_float * cap)(), (C.c_int32 * cap)()
+        out = torch.empty_like(u0)
+        _lib.check(lib.cnf_solve_vcabm(h.ptr, t0, t1, _ptr(u0), _ptr(e), _ptr(y), B, abstol, reltol,
+                                       float(kw["dt"]) if "dt" in kw else 0.0, maxiters, _ptr(out), C.byref(ss), dts, orders, cap, st))
+        m = min(ss.naccept, cap)
+        stats.update(naccept=ss.naccept, nreject=ss.nreject, nf=ss.nf, dts=[float(v) for v in dts[:m]], orders=[int(v) for v in orders[:m]])
+        return out
     _lib.check(lib.cnf_vcabm_begin(h.ptr, t0, _ptr(u0), _ptr(e), _ptr(y), B, st))
     stats["nf"] += 1
     ntot = allsum([float(B * S)])[0] if sharded else float(B * S)
     if "dt" in kw:
-        dt = min(abs(float(kw["dt"])), span)
+        dt = min(abs(C.c_float(float(kw["dt"])).value), span)      # Float32, as the library entry takes it
     else:   # ode_determine_initdt (Hairer, Noersett, Wanner I, II.4) with the algorithm order 7
         du = torch.empty_like(u0)
 

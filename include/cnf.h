@@ -29,7 +29,7 @@
  *   boundary A (per call)    cnf_aug_f                      du = augmented_f(u, p, t)
  *   boundary B (whole solve) cnf_integrate_fixed, cnf_inference_fixed, cnf_loss_sums
  *   caller-driven solves     cnf_assemble_u0, cnf_step_embedded (adaptive Tsit5 attempt), cnf_epilogue,
- *                            cnf_vcabm_begin / _attempt / _accept / _state (the reference's default alg VCABM)
+ *                            cnf_vcabm_begin / _attempt / _accept / _state, cnf_solve_vcabm (the reference's default alg VCABM)
  *   training                 cnf_loss_grad_fixed, cnf_loss_grad_grid  (dloss/dps, optionally dloss/dxs)
  *   introspection            cnf_version, cnf_last_error, cnf_kernel_path, cnf_grad_path, cnf_repack_on_device
  */
@@ -173,6 +173,17 @@ int cnf_vcabm_attempt(cnf_handle* h, int order, float dt, const float* eps, cons
 int cnf_vcabm_accept(cnf_handle* h, const float* eps, const float* ys, int64_t B, float abstol, float reltol,
                      double* err_up, void* stream);
 int cnf_vcabm_state(cnf_handle* h, int64_t B, float* u_out, double* t_out, void* stream);
+
+/* The whole default solve in one call: u1 = solve(u' = augmented_f, u0, (t0, t1), VCABM(); abstol, reltol) - the passes above
+ * under the solver's own policy (order ramp 1 -> 3, then order selection from the four error estimates; integral step-size
+ * controller, gamma = 9/10, q in [1/5, 10]; Hairer's initial step unless dt_init != 0), run on the host inside the library.
+ * For single-process callers (a sharded solve must all-reduce the sums between the passes and drives them itself).
+ * u0, u1: S x B device arrays (may alias).  stats (host, may be NULL) and the first record_cap accepted step sizes / orders
+ * (host arrays, may be NULL) are filled in; the call synchronises `stream`. */
+typedef struct cnf_solve_stats { int32_t naccept, nreject, nf, max_order; } cnf_solve_stats;
+int cnf_solve_vcabm(cnf_handle* h, float t0, float t1, const float* u0, const float* eps, const float* ys, int64_t B,
+                    float abstol, float reltol, float dt_init, int maxiters, float* u1, cnf_solve_stats* stats,
+                    float* dts_out, int32_t* orders_out, int32_t record_cap, void* stream);
 
 /* Which kernel family the handle resolved to (CNF_PATH_SIMT, CNF_PATH_MFMA or CNF_PATH_LAYERED). */
 int cnf_kernel_path(const cnf_handle* h);
