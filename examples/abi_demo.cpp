@@ -8,7 +8,8 @@
 //          (FFJORD: Dense(nvars+1 => H, tanh), (L-1) x Dense(H => H, tanh), Dense(H => nvars); column-major arrays,
 //          one column per sample, exactly what the Julia side would hand over)
 // out.bin: float32 logp[B];  stdout: mean log-density and the time of one solve.
-// This is the call sequence INTEGRATION.md's Julia glue makes: cnf_create -> cnf_set_params -> cnf_inference_fixed.
+// This is the call sequence INTEGRATION.md's Julia glue makes: cnf_create -> cnf_set_params -> cnf_inference_fixed, then the
+// default solver: cnf_assemble_u0 -> cnf_solve_vcabm -> cnf_epilogue.  The output file holds both log-density vectors.
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -72,7 +73,23 @@ int main(int argc, char** argv) {
     FILE* g = fopen(argv[2], "wb");
     if (!g) { perror(argv[2]); return 1; }
     fwrite(logp.data(), 4, B, g);
+
+    // the reference's default sol_kwargs (alg = VCABM(), reltol = abstol = 1e-4): u0 = [x; 0] -> one cnf_solve_vcabm -> epilogue
+    const int S = nvars + 3;
+    float *du0, *du1;
+    HIP_OK(hipMalloc((void**)&du0, (size_t)S * B * 4)); HIP_OK(hipMalloc((void**)&du1, (size_t)S * B * 4));
+    CNF_OK_(cnf_assemble_u0(h, dx, B, du0, st));
+    cnf_solve_stats stats{};
+    std::vector<float> dts(256);
+    std::vector<int32_t> orders(256);
+    CNF_OK_(cnf_solve_vcabm(h, 0.f, 1.f, du0, de, nullptr, B, 1e-4f, 1e-4f, 0.f, 100000, du1, &stats, dts.data(), orders.data(), 256, st));
+    CNF_OK_(cnf_epilogue(h, du1, B, dl, nullptr, st));
+    HIP_OK(hipStreamSynchronize(st));
+    HIP_OK(hipMemcpy(logp.data(), dl, B * 4, hipMemcpyDeviceToHost));
+    printf("vcabm naccept=%d nreject=%d nf=%d max_order=%d first_dt=%.6g\n", stats.naccept, stats.nreject, stats.nf, stats.max_order, dts[0]);
+    fwrite(logp.data(), 4, B, g);
     fclose(g);
+    hipFree(du0); hipFree(du1);
     CNF_OK_(cnf_destroy(h));
     hipFree(dx); hipFree(de); hipFree(dl);
     return 0;

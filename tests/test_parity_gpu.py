@@ -1262,7 +1262,12 @@ def test_plain_cpp_host_on_the_c_abi(pkg, oracles, tmp_path):
     got = np.fromfile(fout, dtype=np.float32)
     icnf = make_icnf(pkg, spec, 1, nsteps)
     ref = run_inference(pkg, icnf, spec, p, xs, eps, None)[0].cpu().numpy()
-    assert got.shape == ref.shape and np.array_equal(got, ref)              # same library, same inputs: same bits
+    assert got.shape == (2 * B,) and np.array_equal(got[:B], ref)          # same library, same inputs: same bits
+    icnf.sol_kwargs = {}                                                    # the reference's defaults: VCABM at 1e-4
+    ref_v = run_inference(pkg, icnf, spec, p, xs, eps, None)[0].cpu().numpy()
+    st = icnf.last_solve_stats
+    assert np.array_equal(got[B:], ref_v)
+    assert f"vcabm naccept={st['naccept']} nreject={st['nreject']} nf={st['nf']} max_order={max(st['orders'])}" in r.stdout, r.stdout
 
 
 @pytest.mark.parametrize("planar", [False, True])
