@@ -933,6 +933,7 @@ int cnf_solve_vcabm(cnf_handle* h, float t0, float t1, const float* u0, const fl
         const double d2 = std::sqrt(host[0] / ntot) / h0, dmax = std::max(d1, d2);
         const double h1 = dmax <= 1e-15 ? std::max(1e-6, h0 * 1e-3) : std::pow(10.0, -(2.0 + std::log10(dmax)) / 8.0);
         dt = std::min(std::min(100.0 * h0, h1), span);
+        if (!(std::isfinite(dt) && dt > 0.0)) return fail(CNF_ERR_INVALID, "cnf_solve_vcabm: non-finite state or dynamics at t0 (no initial step)");
     }
     const double gamma = 0.9, qmin = 0.2, qmax = 10.0;
     double t = t0;

@@ -20,6 +20,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import weakref
 from dataclasses import dataclass
 from typing import Callable, Dict, Optional, Sequence, Tuple, Union
 
@@ -209,6 +210,7 @@ class _Handle:
         self.ptr = C.c_void_p()
         _lib.check(self.lib.cnf_create(C.byref(self.ptr), C.byref(cfg)))
         self.params_key = None
+        self.params_ref = None
 
     def __del__(self):
         try:
@@ -401,8 +403,11 @@ class ICNF:
         w_off, b_off, n = self.nn.param_offsets()
         if ps.dtype != torch.float32 or ps.dim() != 1 or ps.numel() != n:
             raise ValueError(f"DimensionMismatch: ps must be a Float32 vector of length {n}")
+        # skip the repack only for the SAME tensor object at the same version: a data_ptr alone can be a freed
+        # tensor's address handed out again by the caching allocator
         key = (ps.data_ptr(), ps._version, str(ps.device))
-        if h.params_key == key:
+        same = h.params_ref is not None and h.params_ref() is ps
+        if same and h.params_key == key:
             return
         ps_c = self.nn.abi_params(ps).contiguous()
         wo = (C.c_size_t * len(w_off))(*w_off)
@@ -410,6 +415,7 @@ class ICNF:
         _lib.check(h.lib.cnf_set_params(h.ptr, _ptr(ps_c), ps_c.numel(), wo, bo, int(ps_c.is_cuda),
                                         _stream_ptr(self.device)))
         h.params_key = key
+        h.params_ref = weakref.ref(ps)
 
     def kernel_path(self, mode: Mode) -> int:
         h = self._handle(mode)
@@ -542,12 +548,16 @@ def _adaptive_integrate(icnf: ICNF, h: "_Handle", u0: torch.Tensor, t0: float, t
         d0, d1 = math.sqrt(s0 / n), math.sqrt(s1 / n)
         dt0 = 1e-6 if (d0 < 1e-5 or d1 < 1e-5) else 0.01 * d0 / d1
         dt0 = min(dt0, span)
+        if not (math.isfinite(dt0) and dt0 > 0.0):
+            raise FloatingPointError("adaptive solve: non-finite state or dynamics at t0 (no initial step)")
         f1 = f(u0 + tdir * dt0 * f0, t0 + tdir * dt0)
         (s2,) = allsum([float((((f1 - f0) / sk).double() ** 2).sum())])
         d2 = math.sqrt(s2 / n) / dt0
         dmax = max(d1, d2)
         dt1 = max(1e-6, dt0 * 1e-3) if dmax <= 1e-15 else 10.0 ** (-(2.0 + math.log10(dmax)) / 5.0)
         dt = min(100.0 * dt0, dt1, span)
+        if not (math.isfinite(dt) and dt > 0.0):
+            raise FloatingPointError("adaptive solve: non-finite state or dynamics at t0 (no initial step)")
     beta1, beta2, gamma, qmin, qmax, qold = 7.0 / 50.0, 2.0 / 25.0, 0.9, 0.2, 10.0, 1e-4
     u = u0.contiguous().clone()
     un = torch.empty_like(u)
@@ -625,8 +635,15 @@ def _vcabm_integrate(icnf: ICNF, h: "_Handle", u0: torch.Tensor, t0: float, t1: 
         cap = 4096
         ss, dts, orders = _lib.SolveStats(), (C.c_float * cap)(), (C.c_int32 * cap)()
         out = torch.empty_like(u0)
-        _lib.check(lib.cnf_solve_vcabm(h.ptr, t0, t1, _ptr(u0), _ptr(e), _ptr(y), B, abstol, reltol,
-                                       float(kw["dt"]) if "dt" in kw else 0.0, maxiters, _ptr(out), C.byref(ss), dts, orders, cap, st))
+        try:
+            _lib.check(lib.cnf_solve_vcabm(h.ptr, t0, t1, _ptr(u0), _ptr(e), _ptr(y), B, abstol, reltol,
+                                           float(kw["dt"]) if "dt" in kw else 0.0, maxiters, _ptr(out), C.byref(ss), dts, orders, cap, st))
+        except _lib.CnfError as err:   # the same exceptions as the host loop below
+            if "maxiters" in str(err):
+                raise RuntimeError("adaptive solve: maxiters reached") from None
+            if "non-finite" in str(err):
+                raise FloatingPointError("adaptive solve: non-finite error estimate (unstable dynamics)") from None
+            raise
         m = min(ss.naccept, cap)
         stats.update(naccept=ss.naccept, nreject=ss.nreject, nf=ss.nf, dts=[float(v) for v in dts[:m]], orders=[int(v) for v in orders[:m]])
         return out
@@ -649,12 +666,16 @@ def _vcabm_integrate(icnf: ICNF, h: "_Handle", u0: torch.Tensor, t0: float, t1: 
         d0, d1 = math.sqrt(s0 / ntot), math.sqrt(s1 / ntot)
         dt0 = 1e-6 if (d0 < 1e-5 or d1 < 1e-5) else 0.01 * d0 / d1
         dt0 = min(dt0, span)
+        if not (math.isfinite(dt0) and dt0 > 0.0):
+            raise FloatingPointError("adaptive solve: non-finite state or dynamics at t0 (no initial step)")
         f1 = f(u0 + tdir * dt0 * f0, t0 + tdir * dt0)
         (s2,) = allsum([float((((f1 - f0) / sk).double() ** 2).sum())])
         d2 = math.sqrt(s2 / ntot) / dt0
         dmax = max(d1, d2)
         dt1 = max(1e-6, dt0 * 1e-3) if dmax <= 1e-15 else 10.0 ** (-(2.0 + math.log10(dmax)) / 8.0)
         dt = min(100.0 * dt0, dt1, span)
+        if not (math.isfinite(dt) and dt > 0.0):
+            raise FloatingPointError("adaptive solve: non-finite state or dynamics at t0 (no initial step)")
     gamma, qmin, qmax = 0.9, 0.2, 10.0
     err3 = torch.zeros(3, dtype=torch.float64, device=dev)
     errp = torch.zeros(1, dtype=torch.float64, device=dev)

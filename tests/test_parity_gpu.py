@@ -1540,3 +1540,46 @@ def test_gradient_of_a_planar_layer_net(use_bias, conditioned, pkg, oracles):
     data = (xs.T, ys.T) if conditioned else xs.T
     fitresult, _, report = model.fit(data)
     assert report["stats"]["iterations"] == 9 and np.isfinite(report["stats"]["final_loss"])
+
+
+@pytest.mark.parametrize("alg,policy", [("tsit5", None), ("vcabm", "library"), ("vcabm", "python")])
+def test_adaptive_solves_fail_loudly(alg, policy, pkg, oracles):
+    """SciML reports maxiters / instability through the retcode, which the reference ignores (src/core/base_icnf.jl:138-139);
+    here they are exceptions, the same ones from the host loops and from the library's own policy loop."""
+    o64, _ = oracles
+    spec = o64.make_spec(nvars=3, hidden=[16, 16])
+    p, xs, eps, _ = o64.synth_inputs(spec, 20, 4, bias_scale=0.3)
+    icnf = make_icnf(pkg, spec, 1, 1)
+    icnf.sol_kwargs = dict(alg=pkg.Tsit5() if alg == "tsit5" else pkg.VCABM(), reltol=1e-6, abstol=1e-6, maxiters=3)
+    if policy:
+        icnf.vcabm_policy = policy
+    with pytest.raises(RuntimeError, match="maxiters"):
+        run_inference(pkg, icnf, spec, p, xs, eps, None)
+    icnf.sol_kwargs["maxiters"] = 100000
+    bad = p.copy()
+    bad[-3:] = np.inf                                                                       # a bias at infinity: non-finite dynamics
+    with pytest.raises(FloatingPointError, match="non-finite"):
+        run_inference(pkg, icnf, spec, bad, xs, eps, None)
+
+
+def test_parameters_are_rebound_when_a_new_tensor_reuses_the_address(pkg, oracles):
+    """The handle skips the repack only for the same tensor object at the same version: a fresh tensor that the caching
+    allocator places at a freed tensor's address must not be mistaken for it."""
+    o64, _ = oracles
+    spec = o64.make_spec(nvars=3, hidden=[16, 16])
+    p, xs, eps, _ = o64.synth_inputs(spec, 20, 4, bias_scale=0.3)
+    icnf = make_icnf(pkg, spec, 1, 10)
+    a = run_inference(pkg, icnf, spec, p, xs, eps, None)[0].clone()
+    ptrs = set()
+    for k in range(4):                                   # same size, allocated right after the previous one was freed
+        t = dev(p * (1.0 + 0.1 * (k + 1)))
+        ptrs.add(t.data_ptr())
+        b = pkg.inference(icnf, mode_of(pkg, spec), dev(xs), t, {}, eps=dev(eps))[0]
+        ref = run_inference(pkg, make_icnf(pkg, spec, 1, 10), spec, p * (1.0 + 0.1 * (k + 1)), xs, eps, None)[0]
+        assert torch.equal(b, ref) and not torch.equal(a, b)
+        del t
+    t = dev(p)
+    v0 = pkg.inference(icnf, mode_of(pkg, spec), dev(xs), t, {}, eps=dev(eps))[0]
+    t.mul_(1.5)                                          # in-place update of the same object: the version changes
+    v1 = pkg.inference(icnf, mode_of(pkg, spec), dev(xs), t, {}, eps=dev(eps))[0]
+    assert torch.equal(v0, a) and not torch.equal(v1, v0)
