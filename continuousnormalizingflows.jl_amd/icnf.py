@@ -376,7 +376,13 @@ class ICNF:
             tmode = _lib.MODE_EXACT
         else:
             tmode = _lib.MODE_HUTCH_JVP if self.compute_mode.jacvec else _lib.MODE_HUTCH_VJP
-        key = (tmode, reg)
+        reg_z = int(reg and self.lambda1 != 0.0)               # NORM_Z   (icnf.jl:113)
+        reg_j = int(reg and self.lambda2 != 0.0)               # NORM_J   (icnf.jl:114)
+        reg_aug = int(reg and self.lambda3 != 0.0 and self.augmented)  # NORM_Z_AUG
+        nprobes = self.nprobes if train else 1
+        arith = getattr(self.compute_mode, "arith", _lib.ARITH_F32)
+        # everything the library bakes into the handle (the reference's ICNF is immutable; here fields may be reassigned)
+        key = (tmode, reg_z, reg_j, reg_aug, nprobes, self.compute_mode.kernel_path, arith)
         h = self._handles.get(key)
         if h is None:
             cfg = _lib.CnfConfig()
@@ -388,13 +394,11 @@ class ICNF:
             for i, l in enumerate(self.nn.layers):
                 cfg.acts[i] = l.act_id
             cfg.mode = tmode
-            cfg.nprobes = self.nprobes if train else 1
-            cfg.reg_z = int(reg and self.lambda1 != 0.0)       # NORM_Z   (icnf.jl:113)
-            cfg.reg_j = int(reg and self.lambda2 != 0.0)       # NORM_J   (icnf.jl:114)
-            cfg.reg_aug = int(reg and self.lambda3 != 0.0 and self.augmented)  # NORM_Z_AUG
+            cfg.nprobes = nprobes
+            cfg.reg_z, cfg.reg_j, cfg.reg_aug = reg_z, reg_j, reg_aug
             cfg.device_id = self.device.index or 0
             cfg.kernel_path = self.compute_mode.kernel_path
-            cfg.arith = getattr(self.compute_mode, "arith", _lib.ARITH_F32)
+            cfg.arith = arith
             h = _Handle(cfg)
             self._handles[key] = h
         return h

@@ -1583,3 +1583,20 @@ def test_parameters_are_rebound_when_a_new_tensor_reuses_the_address(pkg, oracle
     t.mul_(1.5)                                          # in-place update of the same object: the version changes
     v1 = pkg.inference(icnf, mode_of(pkg, spec), dev(xs), t, {}, eps=dev(eps))[0]
     assert torch.equal(v0, a) and not torch.equal(v1, v0)
+
+
+def test_reassigned_fields_reach_the_library(pkg, oracles):
+    """The regulariser switches are baked into a handle (NORM_Z / NORM_J are type parameters in the reference,
+    src/core/icnf.jl:109-115); reassigning lambda / nprobes on the Python object selects another handle."""
+    o64, _ = oracles
+    spec = o64.make_spec(nvars=3, hidden=[16, 16])
+    p, xs, eps, _ = o64.synth_inputs(spec, 20, 4, bias_scale=0.3)
+    icnf = make_icnf(pkg, spec, 1, 10)
+    m = pkg.TrainMode(True)
+    E0 = pkg.inference(icnf, m, dev(xs), dev(p), {}, eps=dev(eps))[1][0]
+    assert float(E0.abs().max()) == 0.0                                     # lambda1 = 0: no kinetic term
+    icnf.lambda1 = 0.05
+    lp, (E1, n1, _) = pkg.inference(icnf, m, dev(xs), dev(p), {}, eps=dev(eps))
+    spec_z = o64.make_spec(nvars=3, hidden=[16, 16], reg_z=True)
+    ref = o64.inference_fixed(spec_z, p, xs, 0.0, 1.0, 10, 1, eps)
+    assert float(n1.abs().max()) == 0.0 and np.max(np.abs(E1.cpu().numpy() - ref[1][0])) < TOL_SOLVE
