@@ -1328,11 +1328,12 @@ def _vcabm_handle(pkg, icnf, spec, p):
     return h
 
 
-@pytest.mark.parametrize("kw,path", [
-    (dict(nvars=8, hidden=[64, 64, 64], reg_z=True, reg_j=True), 0),                        # fused single-call kernel
-    (dict(nvars=3, ncond=2, hidden=[24, 24], act=2), 1),                                    # SIMT family, conditioned
+@pytest.mark.parametrize("kw,path,B", [
+    (dict(nvars=8, hidden=[64, 64, 64], reg_z=True, reg_j=True), 0, 37),                    # fused single-call kernel; S B odd: scalar passes
+    (dict(nvars=8, hidden=[64, 64, 64], reg_z=True, reg_j=True), 0, 36),                    # S B a multiple of 4: 16-byte passes
+    (dict(nvars=3, ncond=2, hidden=[24, 24], act=2), 1, 38),                                # SIMT family, conditioned
 ])
-def test_vcabm_passes_follow_a_scripted_order_and_step_sequence(kw, path, pkg, oracles):
+def test_vcabm_passes_follow_a_scripted_order_and_step_sequence(kw, path, B, pkg, oracles):
     """cnf_vcabm_begin / _attempt / _accept / _state driven with a fixed script of (order, dt) - orders up to 12, steps
     growing, shrinking, a rejected (repeated) attempt, the order k+1 estimate where the history allows it - against the
     fp64 stepper on the same script: u_{n+1} after every attempt and all four error sums.  No controller involved, so
@@ -1341,7 +1342,6 @@ def test_vcabm_passes_follow_a_scripted_order_and_step_sequence(kw, path, pkg, o
     o64, _ = oracles
     L = pkg._lib
     spec = o64.make_spec(**kw)
-    B = 37
     p, xs, eps, ys = o64.synth_inputs(spec, B, 21, bias_scale=0.3)
     icnf = make_icnf(pkg, spec, 1, 1, path=path)
     h = _vcabm_handle(pkg, icnf, spec, p)
