@@ -28,7 +28,7 @@ ARITH_F32, ARITH_BF16X6 = 0, 1
 EXPORTS = ("cnf_version", "cnf_last_error", "cnf_create", "cnf_destroy", "cnf_set_params",
            "cnf_kernel_path", "cnf_repack_on_device", "cnf_aug_f", "cnf_integrate_fixed", "cnf_inference_fixed",
            "cnf_loss_sums", "cnf_loss_grad_fixed", "cnf_loss_grad_grid", "cnf_grad_path", "cnf_step_embedded", "cnf_assemble_u0",
-           "cnf_epilogue", "cnf_vcabm_begin", "cnf_vcabm_attempt", "cnf_vcabm_accept", "cnf_vcabm_state", "cnf_solve_vcabm")
+           "cnf_epilogue", "cnf_vcabm_begin", "cnf_vcabm_attempt", "cnf_vcabm_accept", "cnf_vcabm_state", "cnf_solve_vcabm", "cnf_solve_tsit5", "cnf_loss_grad_adaptive")
 
 
 class CnfConfig(C.Structure):
@@ -95,6 +95,10 @@ def load():
     lib.cnf_vcabm_attempt.argtypes = [vp, C.c_int, C.c_float, fp, fp, C.c_int64, C.c_float, C.c_float, fp, vp]
     lib.cnf_vcabm_accept.argtypes = [vp, fp, fp, C.c_int64, C.c_float, C.c_float, fp, vp]
     lib.cnf_vcabm_state.argtypes = [vp, C.c_int64, fp, C.POINTER(C.c_double), vp]
+    lib.cnf_solve_tsit5.argtypes = [vp, C.c_float, C.c_float, fp, fp, fp, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_int,
+                                    fp, C.POINTER(SolveStats), C.POINTER(C.c_float), C.c_int32, vp]
+    lib.cnf_loss_grad_adaptive.argtypes = [vp, C.c_float, C.c_float, fp, fp, fp, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_int,
+                                           C.POINTER(C.c_float), fp, fp, fp, C.POINTER(SolveStats), C.POINTER(C.c_float), C.c_int32, vp]
     lib.cnf_solve_vcabm.argtypes = [vp, C.c_float, C.c_float, fp, fp, fp, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_int,
                                     fp, C.POINTER(SolveStats), C.POINTER(C.c_float), C.POINTER(C.c_int32), C.c_int32, vp]
     lib.cnf_aug_f.argtypes = [vp, fp, fp, C.c_float, fp, fp, C.c_int64, vp]

@@ -161,6 +161,8 @@ struct cnf_handle {
     int vc_nhist = 0, vc_k = 0;          // accepted steps since begin; order of the pending attempt (0 = none)
     double vc_hist[kVcSlots + 1] = {};   // signed sizes of the accepted steps, newest first
     double vc_t = 0.0, vc_dt = 0.0;
+    float* ad_buf = nullptr;             // adaptive Tsit5 whole solve (cnf_solve_tsit5): two states + two derivative scratch vectors
+    int64_t ad_B = 0;
     float* tgrid_dev = nullptr;          // step times of a non-uniform grid for the fused gradient kernels
     size_t tgrid_cap = 0;
     bool layered_forced = false;         // kernel_path = CNF_PATH_LAYERED given explicitly: GEMM path for every batch
@@ -306,6 +308,7 @@ int cnf_destroy(cnf_handle* h) {
     if (h->err_partial) (void)hipFree(h->err_partial);
     if (h->vc_buf) (void)hipFree(h->vc_buf);
     if (h->tgrid_dev) (void)hipFree(h->tgrid_dev);
+    if (h->ad_buf) (void)hipFree(h->ad_buf);
     if (h->vc_partial) (void)hipFree(h->vc_partial);
     layered_grad_destroy(h->layered);
     free_pack_map(h->map_fwd);
@@ -984,6 +987,129 @@ int cnf_solve_vcabm(cnf_handle* h, float t0, float t1, const float* u0, const fl
     return cnf_vcabm_state(h, B, u1, nullptr, stream);
 }
 
+// Adaptive Tsit5 from t0 to t1 in one call: cnf_step_embedded attempts under OrdinaryDiffEq's PI controller - the loop of
+// icnf._adaptive_integrate restated inside the library (single process).  Synchronises `stream`.
+static int ensure_adaptive_buf(cnf_handle* h, int64_t B) {
+    if (B <= h->ad_B) return CNF_OK;
+    if (h->ad_buf) HIP_TRY(hipFree(h->ad_buf));
+    h->ad_buf = nullptr; h->ad_B = 0;
+    HIP_TRY(hipMalloc((void**)&h->ad_buf, 6 * (size_t)h->S * (size_t)B * sizeof(float)));   // 4 for the solve, 2 for cnf_loss_grad_adaptive
+    h->ad_B = B;
+    return CNF_OK;
+}
+
+static int solve_tsit5_impl(cnf_handle* h, float t0, float t1, const float* u0, const float* eps, const float* ys, int64_t B,
+                            float abstol, float reltol, float dt_init, int maxiters, float* u1, cnf_solve_stats* stats,
+                            std::vector<double>* steps, void* stream) {
+    if (stats) *stats = cnf_solve_stats{};
+    int rc = check_call(h, eps, ys, B, "cnf_solve_tsit5");
+    if (rc) return rc;
+    if (!(abstol >= 0.f) || !(reltol >= 0.f) || (abstol == 0.f && reltol == 0.f))
+        return fail(CNF_ERR_INVALID, "cnf_solve_tsit5: tolerances must be non-negative and not both zero");
+    if (B > 0 && (!u0 || !u1)) return fail(CNF_ERR_INVALID, "cnf_solve_tsit5: null u0/u1");
+    if (maxiters < 1) return fail(CNF_ERR_INVALID, "cnf_solve_tsit5: maxiters >= 1 required");
+    if (B == 0) return CNF_OK;
+    DeviceGuard g(h->cfg.device_id);
+    hipStream_t st = (hipStream_t)stream;
+    const size_t n = (size_t)h->S * (size_t)B;
+    const double span = std::fabs((double)t1 - (double)t0), tdir = t1 >= t0 ? 1.0 : -1.0, ntot = (double)n;
+    if (span == 0.0) {
+        if (u1 != u0) HIP_TRY(hipMemcpyAsync(u1, u0, n * sizeof(float), hipMemcpyDeviceToDevice, st));
+        return CNF_OK;
+    }
+    rc = ensure_adaptive_buf(h, B);
+    if (rc) return rc;
+    if (!h->vc_partial) HIP_TRY(hipMalloc((void**)&h->vc_partial, (vcabm_partial_doubles() + 8) * sizeof(double)));
+    const size_t slot = (size_t)h->S * (size_t)h->ad_B;
+    float *ua = h->ad_buf, *ub = ua + slot, *f0 = ub + slot, *f1 = f0 + slot;
+    HIP_TRY(hipMemcpyAsync(ua, u0, n * sizeof(float), hipMemcpyDeviceToDevice, st));
+    double* res = h->vc_partial + vcabm_partial_doubles();
+    double host[2];
+    auto fetch = [&](int cnt) -> int {
+        HIP_TRY(hipMemcpyAsync(host, res, cnt * sizeof(double), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        return CNF_OK;
+    };
+    int nf = 0, naccept = 0, nreject = 0;
+    double dt;
+    if (dt_init != 0.f) {
+        dt = std::min((double)std::fabs(dt_init), span);
+    } else {   // ode_determine_initdt (Hairer, Noersett, Wanner I, II.4), order 5
+        StageIn in{};
+        in.u = ua; in.nprev = 0; in.dt = 0.f;
+        rc = eval_dynamics(h, in, t0, eps, ys, B, f0, nullptr, true, st);
+        if (rc) return rc;
+        ++nf;
+        HIP_TRY(vcabm_scaled_sumsq(ua, nullptr, ua, abstol, reltol, (int64_t)n, h->vc_partial, res, st));
+        HIP_TRY(vcabm_scaled_sumsq(f0, nullptr, ua, abstol, reltol, (int64_t)n, h->vc_partial, res + 1, st));
+        rc = fetch(2);
+        if (rc) return rc;
+        const double d0 = std::sqrt(host[0] / ntot), d1 = std::sqrt(host[1] / ntot);
+        double h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
+        h0 = std::min(h0, span);
+        if (!(std::isfinite(h0) && h0 > 0.0)) return fail(CNF_ERR_INVALID, "cnf_solve_tsit5: non-finite state or dynamics at t0 (no initial step)");
+        StageIn eu{};
+        eu.u = ua; eu.nprev = 1; eu.k[0] = f0; eu.coef[0] = 1.f; eu.dt = (float)(tdir * h0);
+        HIP_TRY(rk_update(ub, eu, (int64_t)n, st));
+        StageIn in1{};
+        in1.u = ub; in1.nprev = 0; in1.dt = 0.f;
+        rc = eval_dynamics(h, in1, (float)((double)t0 + tdir * h0), eps, ys, B, f1, nullptr, false, st);
+        if (rc) return rc;
+        ++nf;
+        HIP_TRY(vcabm_scaled_sumsq(f1, f0, ua, abstol, reltol, (int64_t)n, h->vc_partial, res, st));
+        rc = fetch(1);
+        if (rc) return rc;
+        const double d2 = std::sqrt(host[0] / ntot) / h0, dmax = std::max(d1, d2);
+        const double h1 = dmax <= 1e-15 ? std::max(1e-6, h0 * 1e-3) : std::pow(10.0, -(2.0 + std::log10(dmax)) / 5.0);
+        dt = std::min(std::min(100.0 * h0, h1), span);
+        if (!(std::isfinite(dt) && dt > 0.0)) return fail(CNF_ERR_INVALID, "cnf_solve_tsit5: non-finite state or dynamics at t0 (no initial step)");
+    }
+    const double beta1 = 7.0 / 50.0, beta2 = 2.0 / 25.0, gamma = 0.9, qmin = 0.2, qmax = 10.0;
+    double qold = 1e-4, t = t0;
+    int flags = 0, it = 0;
+    for (; it < maxiters; ++it) {
+        if (std::fabs((double)t1 - t) <= 1e-7 * std::max(1.0, span)) break;
+        const bool last = dt >= std::fabs((double)t1 - t) * (1.0 - 1e-6);
+        const double step = last ? std::fabs((double)t1 - t) : dt;     // tstop: never step over t1
+        rc = cnf_step_embedded(h, CNF_ALG_TSIT5, flags, (float)t, (float)(tdir * step), ua, eps, ys, B, abstol, reltol, ub, res, stream);
+        if (rc) return rc;
+        nf += flags ? 6 : 7;
+        rc = fetch(1);
+        if (rc) return rc;
+        const double eest = std::sqrt(host[0] / ntot);
+        if (!std::isfinite(eest)) return fail(CNF_ERR_INVALID, "cnf_solve_tsit5: non-finite error estimate (unstable dynamics)");
+        const double q11 = eest > 0.0 ? std::pow(eest, beta1) : 0.0;
+        const double q = eest == 0.0 ? 1.0 / qmax : std::max(1.0 / qmax, std::min(1.0 / qmin, (q11 / std::pow(qold, beta2)) / gamma));
+        if (eest <= 1.0) {   // accept
+            t = last ? (double)t1 : t + tdir * step;
+            std::swap(ua, ub);
+            if (steps) steps->push_back(tdir * step);
+            ++naccept;
+            qold = std::max(eest, 1e-4);
+            dt = step / q;
+            flags = CNF_STEP_FSAL;
+        } else {             // reject: same (t, u), smaller step
+            ++nreject;
+            dt = step / std::min(1.0 / qmin, q11 / gamma);
+            flags = CNF_STEP_RETRY;
+        }
+    }
+    if (stats) { stats->naccept = naccept; stats->nreject = nreject; stats->nf = nf; stats->max_order = 5; }
+    if (it == maxiters) return fail(CNF_ERR_INVALID, "cnf_solve_tsit5: maxiters reached");
+    HIP_TRY(hipMemcpyAsync(u1, ua, n * sizeof(float), hipMemcpyDeviceToDevice, st));
+    return CNF_OK;
+}
+
+int cnf_solve_tsit5(cnf_handle* h, float t0, float t1, const float* u0, const float* eps, const float* ys, int64_t B,
+                    float abstol, float reltol, float dt_init, int maxiters, float* u1, cnf_solve_stats* stats,
+                    float* dts_out, int32_t record_cap, void* stream) {
+    std::vector<double> steps;
+    const int rc = solve_tsit5_impl(h, t0, t1, u0, eps, ys, B, abstol, reltol, dt_init, maxiters, u1, stats, &steps, stream);
+    if (dts_out)
+        for (size_t i = 0; i < steps.size() && (int64_t)i < record_cap; ++i) dts_out[i] = (float)steps[i];
+    return rc;
+}
+
 int cnf_assemble_u0(cnf_handle* h, const float* x, int64_t B, float* u0, void* stream) {
     if (!h || B < 0) return fail(CNF_ERR_INVALID, "cnf_assemble_u0: null handle or negative batch");
     if (B == 0) return CNF_OK;
@@ -1205,6 +1331,40 @@ int cnf_loss_grad_grid(cnf_handle* h, int alg, int nsteps, const float* tgrid, c
                        void* stream) {
     if (nsteps < 1 || !tgrid) return fail(CNF_ERR_INVALID, "cnf_loss_grad_grid: nsteps >= 1 and a grid of nsteps + 1 times required");
     return loss_grad_impl(h, "cnf_loss_grad_grid", alg, nsteps, 0.f, 0.f, tgrid, x, eps, ys, B, lambdas, grad, grad_x, sums4, stream);
+}
+
+int cnf_loss_grad_adaptive(cnf_handle* h, float t0, float t1, const float* x, const float* eps, const float* ys, int64_t B,
+                           float abstol, float reltol, float dt_init, int maxiters, const float* lambdas, float* grad,
+                           float* grad_x, float* sums4, cnf_solve_stats* stats, float* tgrid_out, int32_t grid_cap,
+                           void* stream) {
+    if (stats) *stats = cnf_solve_stats{};
+    int rc = check_call(h, eps, ys, B, "cnf_loss_grad_adaptive");
+    if (rc) return rc;
+    if (!x || !grad || !lambdas) return fail(CNF_ERR_INVALID, "cnf_loss_grad_adaptive: null x/grad/lambdas");
+    if (t0 == t1) return fail(CNF_ERR_INVALID, "cnf_loss_grad_adaptive: empty time span");
+    std::vector<float> grid;
+    if (B == 0) {   // nothing to step over: the fixed entry zeroes grad / sums4
+        return loss_grad_impl(h, "cnf_loss_grad_adaptive", CNF_ALG_TSIT5, 1, t0, t1, nullptr, x, eps, ys, B, lambdas, grad, grad_x, sums4, stream);
+    }
+    {
+        DeviceGuard g(h->cfg.device_id);
+        rc = ensure_adaptive_buf(h, B);
+        if (rc) return rc;
+        const size_t slot = (size_t)h->S * (size_t)h->ad_B;
+        float* u = h->ad_buf + 4 * slot;
+        HIP_TRY(assemble_u0(x, h->cfg.nvars, h->S, B, u, (hipStream_t)stream));
+        std::vector<double> steps;
+        rc = solve_tsit5_impl(h, t0, t1, u, eps, ys, B, abstol, reltol, dt_init, maxiters, u + slot, stats, &steps, stream);
+        if (rc) return rc;
+        double t = t0;
+        grid.push_back(t0);
+        for (double d : steps) { t += d; grid.push_back((float)t); }
+        grid.back() = t1;
+    }
+    if (tgrid_out)
+        for (size_t i = 0; i < grid.size() && (int64_t)i < grid_cap; ++i) tgrid_out[i] = grid[i];
+    return loss_grad_impl(h, "cnf_loss_grad_adaptive", CNF_ALG_TSIT5, (int)grid.size() - 1, 0.f, 0.f, grid.data(), x, eps, ys, B,
+                          lambdas, grad, grad_x, sums4, stream);
 }
 
 }  // extern "C"

@@ -503,6 +503,18 @@ def _split_args(icnf: ICNF, args, what: str):
     return args[0], None, args[1], args[2]
 
 
+def _solve_errors(call):
+    """Run a whole-solve library call; its status codes become the exceptions of the host loops."""
+    try:
+        _lib.check(call())
+    except _lib.CnfError as err:
+        if "maxiters" in str(err):
+            raise RuntimeError("adaptive solve: maxiters reached") from None
+        if "non-finite" in str(err):
+            raise FloatingPointError("adaptive solve: " + str(err).split(": ", 2)[-1]) from None
+        raise
+
+
 def _adaptive_integrate(icnf: ICNF, h: "_Handle", u0: torch.Tensor, t0: float, t1: float,
                         e: Optional[torch.Tensor], y: Optional[torch.Tensor], group=None, _tsit5: bool = False) -> torch.Tensor:
     """Adaptive Tsit5 from t0 to t1 (either direction) on the (B, S) state u0: what `SciMLBase.solve(prob, Tsit5();
@@ -530,6 +542,16 @@ def _adaptive_integrate(icnf: ICNF, h: "_Handle", u0: torch.Tensor, t0: float, t
     icnf.last_solve_stats = stats
     if B == 0 or span == 0.0:
         return u0.clone()
+    if not sharded and getattr(icnf, "adaptive_policy", "library") == "library":
+        # single process: the same controller restated inside the library (cnf_solve_tsit5), one call per solve
+        cap = 4096
+        ss, dts = _lib.SolveStats(), (C.c_float * cap)()
+        u0 = u0.contiguous()
+        out = torch.empty_like(u0)
+        _solve_errors(lambda: lib.cnf_solve_tsit5(h.ptr, t0, t1, _ptr(u0), _ptr(e), _ptr(y), B, abstol, reltol,
+                                                  float(kw["dt"]) if "dt" in kw else 0.0, maxiters, _ptr(out), C.byref(ss), dts, cap, st))
+        stats.update(naccept=ss.naccept, nreject=ss.nreject, nf=ss.nf, dts=[float(v) for v in dts[:min(ss.naccept, cap)]])
+        return out
 
     def allsum(vals):
         t = torch.tensor(vals, dtype=torch.float64, device=dev if (sharded and dist.get_backend(group) == "nccl") else "cpu")
@@ -609,7 +631,7 @@ def _vcabm_integrate(icnf: ICNF, h: "_Handle", u0: torch.Tensor, t0: float, t1: 
     qmax = 10; the same factor after a rejection) and Hairer's initial step.  Restated from the published algorithm
     (see oracle/cnf_oracle64.py::integrate_vcabm, the fp64 oracle this is tested against); the Julia package's exact
     step / order sequence cannot be checked here.  A single-process solve runs the same policy inside the library
-    (`cnf_solve_vcabm`, one call per solve; `icnf.vcabm_policy = "python"` keeps this loop - the two are tested to take
+    (`cnf_solve_vcabm`, one call per solve; `icnf.adaptive_policy = "python"` keeps this loop - the two are tested to take
     identical steps).  The error norms run over the whole S x B state, so a sharded
     solve all-reduces the squared sums and every rank takes the same steps."""
     import torch.distributed as dist
@@ -634,20 +656,13 @@ def _vcabm_integrate(icnf: ICNF, h: "_Handle", u0: torch.Tensor, t0: float, t1: 
         return [float(v) for v in t]
 
     u0 = u0.contiguous()
-    if not sharded and getattr(icnf, "vcabm_policy", "library") == "library":
+    if not sharded and getattr(icnf, "adaptive_policy", "library") == "library":
         # single process: the same policy restated inside the library (cnf_solve_vcabm), one call per solve
         cap = 4096
         ss, dts, orders = _lib.SolveStats(), (C.c_float * cap)(), (C.c_int32 * cap)()
         out = torch.empty_like(u0)
-        try:
-            _lib.check(lib.cnf_solve_vcabm(h.ptr, t0, t1, _ptr(u0), _ptr(e), _ptr(y), B, abstol, reltol,
-                                           float(kw["dt"]) if "dt" in kw else 0.0, maxiters, _ptr(out), C.byref(ss), dts, orders, cap, st))
-        except _lib.CnfError as err:   # the same exceptions as the host loop below
-            if "maxiters" in str(err):
-                raise RuntimeError("adaptive solve: maxiters reached") from None
-            if "non-finite" in str(err):
-                raise FloatingPointError("adaptive solve: non-finite error estimate (unstable dynamics)") from None
-            raise
+        _solve_errors(lambda: lib.cnf_solve_vcabm(h.ptr, t0, t1, _ptr(u0), _ptr(e), _ptr(y), B, abstol, reltol,
+                                                  float(kw["dt"]) if "dt" in kw else 0.0, maxiters, _ptr(out), C.byref(ss), dts, orders, cap, st))
         m = min(ss.naccept, cap)
         stats.update(naccept=ss.naccept, nreject=ss.nreject, nf=ss.nf, dts=[float(v) for v in dts[:m]], orders=[int(v) for v in orders[:m]])
         return out
@@ -887,7 +902,20 @@ def loss_and_gradient(icnf: ICNF, mode: Mode, *args, eps: Optional[torch.Tensor]
     gx = torch.zeros(B, icnf.nvariables, device=dev, dtype=torch.float32) if wrt_x else None
     sums = torch.empty(4, device=dev, dtype=torch.float32)
     lam = (C.c_float * 3)(icnf.lambda1, icnf.lambda2, icnf.lambda3)
-    if icnf.adaptive:
+    import torch.distributed as _dist
+    if icnf.adaptive and not (_dist.is_available() and _dist.is_initialized()) and getattr(icnf, "adaptive_policy", "library") == "library":
+        # single process: adaptive Tsit5 solve + frozen-grid gradient in one library call (cnf_loss_grad_adaptive)
+        kw = icnf.sol_kwargs
+        cap = 4096
+        ss, tg = _lib.SolveStats(), (C.c_float * cap)()
+        _solve_errors(lambda: h.lib.cnf_loss_grad_adaptive(
+            h.ptr, t0, t1, _ptr(x), _ptr(e), _ptr(y), B, float(kw.get("abstol", 1e-4)), float(kw.get("reltol", 1e-4)),
+            float(kw["dt"]) if "dt" in kw else 0.0, int(kw.get("maxiters", 100000)), lam, _ptr(grad), _ptr(gx), _ptr(sums),
+            C.byref(ss), tg, cap, _stream_ptr(dev)))
+        ts = [float(v) for v in tg[:min(ss.naccept + 1, cap)]]
+        icnf.last_solve_stats = {"naccept": ss.naccept, "nreject": ss.nreject, "nf": ss.nf, "tgrid": ts,
+                                 "dts": [b - a for a, b in zip(ts, ts[1:])]}
+    elif icnf.adaptive:
         # differentiate the discrete solve on the steps the adaptive solver accepted (frozen grid; the dependence
         # of the step sizes on ps is ignored - the discretise-then-optimise convention)
         u0 = torch.empty(B, icnf.S, device=dev, dtype=torch.float32)

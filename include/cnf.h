@@ -29,8 +29,8 @@
  *   boundary A (per call)    cnf_aug_f                      du = augmented_f(u, p, t)
  *   boundary B (whole solve) cnf_integrate_fixed, cnf_inference_fixed, cnf_loss_sums
  *   caller-driven solves     cnf_assemble_u0, cnf_step_embedded (adaptive Tsit5 attempt), cnf_epilogue,
- *                            cnf_vcabm_begin / _attempt / _accept / _state, cnf_solve_vcabm (the reference's default alg VCABM)
- *   training                 cnf_loss_grad_fixed, cnf_loss_grad_grid  (dloss/dps, optionally dloss/dxs)
+ *                            cnf_vcabm_begin / _attempt / _accept / _state, cnf_solve_vcabm (the reference's default alg VCABM), cnf_solve_tsit5
+ *   training                 cnf_loss_grad_fixed, cnf_loss_grad_grid, cnf_loss_grad_adaptive  (dloss/dps, optionally dloss/dxs)
  *   introspection            cnf_version, cnf_last_error, cnf_kernel_path, cnf_grad_path, cnf_repack_on_device
  */
 #ifndef CNF_H
@@ -185,6 +185,13 @@ int cnf_solve_vcabm(cnf_handle* h, float t0, float t1, const float* u0, const fl
                     float abstol, float reltol, float dt_init, int maxiters, float* u1, cnf_solve_stats* stats,
                     float* dts_out, int32_t* orders_out, int32_t record_cap, void* stream);
 
+/* Adaptive Tsit5 (OrdinaryDiffEq's PI controller: beta1 = 7/50, beta2 = 2/25, gamma = 9/10, q in [1/5, 10]; Hairer's initial
+ * step unless dt_init != 0) from t0 to t1 in one call - cnf_step_embedded attempts driven inside the library; arguments as
+ * cnf_solve_vcabm (max_order is reported as 5).  Single process; synchronises `stream`. */
+int cnf_solve_tsit5(cnf_handle* h, float t0, float t1, const float* u0, const float* eps, const float* ys, int64_t B,
+                    float abstol, float reltol, float dt_init, int maxiters, float* u1, cnf_solve_stats* stats,
+                    float* dts_out, int32_t record_cap, void* stream);
+
 /* Which kernel family the handle resolved to (CNF_PATH_SIMT, CNF_PATH_MFMA or CNF_PATH_LAYERED). */
 int cnf_kernel_path(const cnf_handle* h);
 
@@ -258,6 +265,17 @@ int cnf_loss_grad_fixed(cnf_handle* h, int alg, int nsteps, float t0, float t1, 
 int cnf_loss_grad_grid(cnf_handle* h, int alg, int nsteps, const float* tgrid, const float* x, const float* eps,
                        const float* ys, int64_t B, const float* lambdas, float* grad, float* grad_x, float* sums4,
                        void* stream);
+
+/* The training step under an adaptive solver in one call: the adaptive Tsit5 solve from x (cnf_solve_tsit5), its accepted
+ * steps frozen into a grid, then cnf_loss_grad_grid on that grid.  This is what serves `Zygote.gradient` of a loss evaluated
+ * with the reference's default sol_kwargs (VCABM at 1e-4: a multistep recurrence has no one-step discrete adjoint, so the
+ * adaptive Tsit5 discretisation at the same tolerances is differentiated; the reference's own QuadratureAdjoint gradient is
+ * likewise a separate solve that matches the forward pass to tolerance).  tgrid_out (host, may be NULL): the first grid_cap
+ * grid times; stats (host, may be NULL).  Single process; synchronises `stream`. */
+int cnf_loss_grad_adaptive(cnf_handle* h, float t0, float t1, const float* x, const float* eps, const float* ys, int64_t B,
+                           float abstol, float reltol, float dt_init, int maxiters, const float* lambdas, float* grad,
+                           float* grad_x, float* sums4, cnf_solve_stats* stats, float* tgrid_out, int32_t grid_cap,
+                           void* stream);
 
 /* Which implementation cnf_loss_grad_fixed / cnf_loss_grad_grid use for this handle: 0 = none (CNF_ERR_UNSUPPORTED),
  * 1 = fused reverse-sweep kernel (cnf_grad.hip / cnf_grad_probes.hip / cnf_grad_slab.hip), 2 = layer-wise reverse sweep on

@@ -1416,7 +1416,7 @@ def test_vcabm_solve_follows_the_oracle_restatement(kw, tol, pkg, oracles):
     icnf.sol_kwargs["dt"] = 2.0 ** -7          # exactly representable in float32: the step controller amplifies a 1e-8 difference 1000-fold over a solve
     runs = {}
     for pol in ("python", "library"):
-        icnf.vcabm_policy = pol
+        icnf.adaptive_policy = pol
         runs[pol] = (run_inference(pkg, icnf, spec, p, xs, eps, ys, return_state=True)[2], dict(icnf.last_solve_stats))
     (u_py, st_py), (u_lib, st_lib) = runs["python"], runs["library"]
     assert st_lib["orders"] == st_py["orders"] and (st_lib["naccept"], st_lib["nreject"]) == (st_py["naccept"], st_py["nreject"])
@@ -1552,7 +1552,7 @@ def test_adaptive_solves_fail_loudly(alg, policy, pkg, oracles):
     icnf = make_icnf(pkg, spec, 1, 1)
     icnf.sol_kwargs = dict(alg=pkg.Tsit5() if alg == "tsit5" else pkg.VCABM(), reltol=1e-6, abstol=1e-6, maxiters=3)
     if policy:
-        icnf.vcabm_policy = policy
+        icnf.adaptive_policy = policy
     with pytest.raises(RuntimeError, match="maxiters"):
         run_inference(pkg, icnf, spec, p, xs, eps, None)
     icnf.sol_kwargs["maxiters"] = 100000
@@ -1600,3 +1600,38 @@ def test_reassigned_fields_reach_the_library(pkg, oracles):
     spec_z = o64.make_spec(nvars=3, hidden=[16, 16], reg_z=True)
     ref = o64.inference_fixed(spec_z, p, xs, 0.0, 1.0, 10, 1, eps)
     assert float(n1.abs().max()) == 0.0 and np.max(np.abs(E1.cpu().numpy() - ref[1][0])) < TOL_SOLVE
+
+
+def test_adaptive_tsit5_library_policy_is_the_host_loop(pkg, oracles):
+    """cnf_solve_tsit5 / cnf_loss_grad_adaptive (the PI controller inside the library, one call per solve / training step)
+    against the Python host loop that sharded solves run: from a common, exactly representable initial step the same
+    accepted steps, state, loss and gradient bit for bit; with Hairer's initial step the same counts and a gradient
+    within 1e-5 (the two initial-step computations round differently)."""
+    o64, _ = oracles
+    spec = o64.make_spec(nvars=8, hidden=[64, 64, 64], reg_z=True, reg_j=True)
+    B = 48
+    p, xs, eps, _ = o64.synth_inputs(spec, B, 91, bias_scale=0.3)
+    p = (p * 2.0).astype(np.float32)
+    icnf = _adaptive_icnf(pkg, spec, 1e-5, dt=2.0 ** -6)
+    icnf.lambda1, icnf.lambda2 = 0.02, 0.03
+    mode = pkg.TrainMode(True)
+    out = {}
+    for pol in ("python", "library"):
+        icnf.adaptive_policy = pol
+        lp, _, u1 = pkg.inference(icnf, mode, dev(xs), dev(p), {}, eps=dev(eps), return_state=True)
+        st = dict(icnf.last_solve_stats)
+        val, g, gx = pkg.loss_and_gradient(icnf, mode, dev(xs), dev(p), {}, eps=dev(eps), wrt_x=True)
+        out[pol] = (u1, st, float(val), g, gx, list(icnf.last_solve_stats["tgrid"]))
+    a, b = out["python"], out["library"]
+    assert (a[1]["naccept"], a[1]["nreject"], a[1]["nf"]) == (b[1]["naccept"], b[1]["nreject"], b[1]["nf"]) and a[1]["naccept"] >= 6
+    assert np.array_equal(np.float32(a[1]["dts"]), np.float32(b[1]["dts"])) and torch.equal(a[0], b[0])
+    assert np.array_equal(np.float32(a[5]), np.float32(b[5])) and a[2] == b[2] and torch.equal(a[3], b[3]) and torch.equal(a[4], b[4])
+    del icnf.sol_kwargs["dt"]
+    res = {}
+    for pol in ("python", "library"):
+        icnf.adaptive_policy = pol
+        val, g = pkg.loss_and_gradient(icnf, mode, dev(xs), dev(p), {}, eps=dev(eps))
+        res[pol] = (float(val), g, dict(icnf.last_solve_stats))
+    assert res["python"][2]["naccept"] == res["library"][2]["naccept"]
+    assert abs(res["python"][0] - res["library"][0]) < 1e-5
+    assert float((res["python"][1] - res["library"][1]).abs().max()) < 1e-5 * float(res["python"][1].abs().max()) + 1e-7

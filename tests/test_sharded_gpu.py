@@ -81,7 +81,7 @@ def test_two_ranks_on_the_gpu_reproduce_the_unsharded_results(pkg, oracles):
     dts = list(adap.last_solve_stats["dts"])
     assert len(dts) >= 4
     dflt = _build(pkg, o64, spec, dict(reltol=1e-4, abstol=1e-4))
-    dflt.vcabm_policy = "python"                       # the host loop the ranks run (the library's single-call policy is its twin)
+    dflt.adaptive_policy = "python"                       # the host loop the ranks run (the library's single-call policy is its twin)
     logp_v = pkg.inference(dflt, m, dev(xs), dev(p), {}, eps=dev(eps))[0].cpu().numpy()
     vdts, vorders = list(dflt.last_solve_stats["dts"]), list(dflt.last_solve_stats["orders"])
     assert isinstance(dflt.sol_kwargs["alg"], pkg.VCABM) and len(vdts) >= 5
