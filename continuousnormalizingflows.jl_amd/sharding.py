@@ -56,8 +56,9 @@ def reduce_gradient(grad_sum: torch.Tensor, B_local: int, group=None) -> torch.T
     rank: the one collective of the training path whose size is not a handful of scalars
     (37-580 KiB over xGMI; one all-reduce, no bucketing needed at this size)."""
     import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return grad_sum / float(B_local)                  # single process: no device-side count, no collective
     cnt = torch.tensor([float(B_local)], device=grad_sum.device, dtype=torch.float64)
-    if dist.is_available() and dist.is_initialized():
-        dist.all_reduce(grad_sum, op=dist.ReduceOp.SUM, group=group)
-        dist.all_reduce(cnt, op=dist.ReduceOp.SUM, group=group)
+    dist.all_reduce(grad_sum, op=dist.ReduceOp.SUM, group=group)
+    dist.all_reduce(cnt, op=dist.ReduceOp.SUM, group=group)
     return grad_sum / cnt.to(grad_sum.dtype)

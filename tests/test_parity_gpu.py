@@ -1635,3 +1635,18 @@ def test_adaptive_tsit5_library_policy_is_the_host_loop(pkg, oracles):
     assert res["python"][2]["naccept"] == res["library"][2]["naccept"]
     assert abs(res["python"][0] - res["library"][0]) < 1e-5
     assert float((res["python"][1] - res["library"][1]).abs().max()) < 1e-5 * float(res["python"][1].abs().max()) + 1e-7
+
+
+def test_usage_example_runs_end_to_end():
+    """examples/usage.py - the reference's examples/usage.jl on the HIP path (data, ICNF, ICNFModel fit for 300 epochs with the
+    default VCABM solver and STEER, ICNFDist pdf / rand) - as its own process."""
+    import json, os, subprocess, sys
+    from conftest import ROOT
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "examples", "usage.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = r.stdout.strip().splitlines()
+    res = json.loads(lines[-1])
+    assert lines[0].startswith("Iteration: 1 | Loss: ") and len(lines) == 6             # iterations 1, 65, 129, 193, 257
+    first = float(lines[0].split("Loss: ")[1])
+    assert res["fit_iterations"] == 300 and res["final_loss"] < first - 1.0
+    assert abs(res["new_data_mean"] - res["true_mean"]) < 0.2 and all(np.isfinite(v) for v in res.values())
