@@ -159,6 +159,7 @@ struct cnf_handle {
     int64_t vc_B = -1;
     int vc_iu = 0, vc_iun = 2, vc_if = 3, vc_ifn = 5, vc_cur = 0;   // which vector holds u, u_new, f_n, f_{n+1}; live difference half
     int vc_nhist = 0, vc_k = 0;          // accepted steps since begin; order of the pending attempt (0 = none)
+    int vc_avail = 0, vc_m = 0;          // differences Phi*_j(n-1) the last accepted step stored; those the pending attempt stores
     double vc_hist[kVcSlots + 1] = {};   // signed sizes of the accepted steps, newest first
     double vc_t = 0.0, vc_dt = 0.0;
     float* ad_buf = nullptr;             // adaptive Tsit5 whole solve (cnf_solve_tsit5): two states + two derivative scratch vectors
@@ -754,7 +755,7 @@ int cnf_vcabm_begin(cnf_handle* h, float t0, const float* u0, const float* eps, 
     }
     if (!h->vc_partial) HIP_TRY(hipMalloc((void**)&h->vc_partial, (vcabm_partial_doubles() + 8) * sizeof(double)));   // + result slots of cnf_solve_vcabm
     h->vc_iu = 0; h->vc_iun = 2; h->vc_if = 3; h->vc_ifn = 5; h->vc_cur = 0;
-    h->vc_nhist = 0; h->vc_k = 0; h->vc_t = t0; h->vc_dt = 0.0;
+    h->vc_nhist = 0; h->vc_k = 0; h->vc_avail = 0; h->vc_m = 0; h->vc_t = t0; h->vc_dt = 0.0;
     for (double& d : h->vc_hist) d = 0.0;
     if (B == 0) return CNF_OK;
     const size_t n = (size_t)h->S * (size_t)B;
@@ -770,6 +771,8 @@ int cnf_vcabm_attempt(cnf_handle* h, int order, float dt, const float* eps, cons
     if (rc) return rc;
     if (order < 1 || order > CNF_VCABM_MAX_ORDER || order > h->vc_nhist + 1)
         return fail(CNF_ERR_INVALID, "cnf_vcabm_attempt: order must be in 1..12 and at most one more than the accepted steps");
+    if (std::min(order, h->vc_nhist) > h->vc_avail)
+        return fail(CNF_ERR_INVALID, "cnf_vcabm_attempt: the order can rise by at most one per accepted step (the stored differences end there)");
     if (!(abstol >= 0.f) || !(reltol >= 0.f) || (abstol == 0.f && reltol == 0.f))
         return fail(CNF_ERR_INVALID, "cnf_vcabm_attempt: tolerances must be non-negative and not both zero");
     if (dt == 0.f || !(dt == dt)) return fail(CNF_ERR_INVALID, "cnf_vcabm_attempt: dt must be non-zero");
@@ -821,7 +824,7 @@ int cnf_vcabm_attempt(cnf_handle* h, int order, float dt, const float* eps, cons
     rc = eval_dynamics(h, in, (float)(h->vc_t + (double)dt), eps, ys, B, d, nullptr, false, st);   // E
     if (rc) return rc;
     HIP_TRY(vcabm_correct(d, p, u, c, abstol, reltol, n, un, h->vc_partial, err3, st));             // C
-    h->vc_k = k; h->vc_dt = dt;
+    h->vc_k = k; h->vc_m = m; h->vc_dt = dt;
     return CNF_OK;
 }
 
@@ -864,6 +867,7 @@ int cnf_vcabm_accept(cnf_handle* h, const float* eps, const float* ys, int64_t B
     h->vc_hist[0] = h->vc_dt;
     h->vc_t += h->vc_dt;
     h->vc_nhist += 1;
+    h->vc_avail = h->vc_m;
     h->vc_k = 0;
     return CNF_OK;
 }

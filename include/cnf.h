@@ -154,7 +154,8 @@ int cnf_epilogue(cnf_handle* h, const float* u, int64_t B, float* logp, float* r
  * and order policy (the host side of the reference's solver), reading one to three error sums per step:
  *
  *   cnf_vcabm_begin    u_0 (S x B, device) at t0; evaluates f_0; forgets any earlier history.
- *   cnf_vcabm_attempt  one PEC pass of order k (= number of predictor terms, 1 <= k <= min(12, accepted steps + 1)) with
+ *   cnf_vcabm_attempt  one PEC pass of order k (= number of predictor terms, 1 <= k <= min(12, accepted steps + 1), and at most
+ *                      one more than the order of the last accepted step: the stored differences end there) with
  *                      step dt (either sign): p = u_n + dt sum_{j<k} g_j Phi*_j(n), f(p, t_n + dt),
  *                      u_{n+1} = p + dt g_k Phi_k(n+1).  err3 (device, 3 doubles) receives the sums over the whole S x B
  *                      state of the squared local error estimates of orders k, k-1, k-2, each scaled by

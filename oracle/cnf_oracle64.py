@@ -320,6 +320,7 @@ class VcabmStepper:
     def attempt(self, k: int, h: float):
         """-> (u_new, [sum of squared scaled errors of orders k, k-1, k-2])"""
         assert 1 <= k <= min(self.max_order, len(self.hist) + 1)
+        assert min(k, len(self.hist)) <= len(self.phistar_prev), "the order can rise by at most one per accepted step"
         dts = [h] + self.hist
         m = min(k + 1, len(self.hist) + 1)          # differences the history supports
         # beta_j(n) = prod_{i<j} (t_{n+1} - t_{n-i}) / (t_n - t_{n-1-i});  Phi_j(n) = Phi_{j-1}(n) - Phi*_{j-1}(n-1)

@@ -1328,12 +1328,15 @@ def _vcabm_handle(pkg, icnf, spec, p):
     return h
 
 
-@pytest.mark.parametrize("kw,path,B", [
-    (dict(nvars=8, hidden=[64, 64, 64], reg_z=True, reg_j=True), 0, 37),                    # fused single-call kernel; S B odd: scalar passes
-    (dict(nvars=8, hidden=[64, 64, 64], reg_z=True, reg_j=True), 0, 36),                    # S B a multiple of 4: 16-byte passes
-    (dict(nvars=3, ncond=2, hidden=[24, 24], act=2), 1, 38),                                # SIMT family, conditioned
+@pytest.mark.parametrize("kw,path,B,rand", [
+    (dict(nvars=8, hidden=[64, 64, 64], reg_z=True, reg_j=True), 0, 37, None),              # fused single-call kernel; S B odd: scalar passes
+    (dict(nvars=8, hidden=[64, 64, 64], reg_z=True, reg_j=True), 0, 36, None),              # S B a multiple of 4: 16-byte passes
+    (dict(nvars=3, ncond=2, hidden=[24, 24], act=2), 1, 38, None),                          # SIMT family, conditioned
+    (dict(nvars=8, hidden=[64, 64, 64]), 0, 64, (1, +1.0)),                                 # random orders and step sizes
+    (dict(nvars=8, hidden=[64, 64, 64]), 0, 52, (2, -1.0)),                                 # ... stepping backwards (generate)
+    (dict(nvars=4, naug=2, hidden=[32, 32, 32, 32], act=2), 3, 40, (3, +1.0)),              # ... layer-wise dynamics
 ])
-def test_vcabm_passes_follow_a_scripted_order_and_step_sequence(kw, path, B, pkg, oracles):
+def test_vcabm_passes_follow_a_scripted_order_and_step_sequence(kw, path, B, rand, pkg, oracles):
     """cnf_vcabm_begin / _attempt / _accept / _state driven with a fixed script of (order, dt) - orders up to 12, steps
     growing, shrinking, a rejected (repeated) attempt, the order k+1 estimate where the history allows it - against the
     fp64 stepper on the same script: u_{n+1} after every attempt and all four error sums.  No controller involved, so
@@ -1360,6 +1363,14 @@ def test_vcabm_passes_follow_a_scripted_order_and_step_sequence(kw, path, B, pkg
     out = torch.empty(B, S, device="cuda:0")
     script = [(1, 0.01), (2, 0.012), (3, 0.02), (3, 0.02), (4, 0.015), (5, 0.03), (6, 0.03), (7, 0.025), (8, 0.04),
               (9, 0.03), (10, 0.03), (11, 0.035), (12, 0.03), (12, 0.05), (11, 0.02), (7, 0.06), (3, 0.03), (4, 0.03)]
+    if rand is not None:
+        rs = np.random.default_rng(rand[0])
+        script, avail = [], 0
+        for i in range(24):   # any order the stored differences allow: down freely, up by at most one per accepted step
+            ok = [k for k in range(1, min(12, i + 1) + 1) if min(k, i) <= avail]
+            k = int(rs.choice(ok[-3:])) if rs.uniform() < 0.7 else int(rs.choice(ok))
+            script.append((k, rand[1] * float(rs.uniform(0.005, 0.05))))
+            avail = min(k + 1, i + 1)
     worst = 0.0
     for i, (k, dt) in enumerate(script):
         if i == 6:   # a rejected attempt: tried with a larger step first, then repeated - the state must be untouched
@@ -1393,6 +1404,12 @@ def test_vcabm_passes_follow_a_scripted_order_and_step_sequence(kw, path, B, pkg
     assert h.lib.cnf_vcabm_attempt(h.ptr, 3, 0.01, ptr(d_eps), ptr(d_ys), B + 1, abstol, reltol, ptr(err3), st) == L.ERR_INVALID
     L.check(h.lib.cnf_vcabm_begin(h.ptr, 0.0, ptr(d_u0), ptr(d_eps), ptr(d_ys), B, st))
     assert h.lib.cnf_vcabm_attempt(h.ptr, 2, 0.01, ptr(d_eps), ptr(d_ys), B, abstol, reltol, ptr(err3), st) == L.ERR_INVALID  # no history yet
+    for k in (1, 1, 1):                                                                    # three steps at order 1 ...
+        L.check(h.lib.cnf_vcabm_attempt(h.ptr, k, 0.01, ptr(d_eps), ptr(d_ys), B, abstol, reltol, ptr(err3), st))
+        L.check(h.lib.cnf_vcabm_accept(h.ptr, ptr(d_eps), ptr(d_ys), B, abstol, reltol, None, st))
+    assert h.lib.cnf_vcabm_attempt(h.ptr, 3, 0.01, ptr(d_eps), ptr(d_ys), B, abstol, reltol, ptr(err3), st) == L.ERR_INVALID  # ... then 3: two orders up
+    assert b"at most one" in h.lib.cnf_last_error()
+    assert h.lib.cnf_vcabm_attempt(h.ptr, 2, 0.01, ptr(d_eps), ptr(d_ys), B, abstol, reltol, ptr(err3), st) == L.OK
 
 
 @pytest.mark.parametrize("kw,tol", [
