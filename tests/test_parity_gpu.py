@@ -1667,3 +1667,54 @@ def test_usage_example_runs_end_to_end():
     first = float(lines[0].split("Loss: ")[1])
     assert res["fit_iterations"] == 300 and res["final_loss"] < first - 1.0
     assert abs(res["new_data_mean"] - res["true_mean"]) < 0.2 and all(np.isfinite(v) for v in res.values())
+
+
+def test_randomised_shapes_under_the_adaptive_solvers(pkg, oracles):
+    """30 random configurations (state size, conditions, widths, depth, activation, trace mode, probes, regularisers, ragged B,
+    either time direction) through the default solver VCABM, adaptive Tsit5 and - where a gradient exists - the one-call
+    adaptive training step, each against a fine fixed-step solve / the frozen-grid gradient of the same library: every
+    dynamics family (fused, cooperative-free generic, layer-wise, SIMT) under every solver loop."""
+    import os
+    o64, _ = oracles
+    rng = np.random.default_rng(int(os.environ.get("CNF_FUZZ_SEED", 20240703)) + 17)
+    tol = 1e-5
+    kinds = set()
+    for it in range(30):
+        D = int(rng.integers(1, 12))
+        naug = int(rng.integers(0, min(3, D)))
+        C = int(rng.choice([0, 0, 2, 5]))
+        L = int(rng.choice([1, 2, 2, 3, 4]))
+        hidden = [int(rng.choice([8, 16, 24, 32, 48, 64]))] * L
+        if rng.integers(0, 3) == 0:
+            hidden = [int(rng.choice([8, 12, 16, 24, 32, 40])) for _ in range(L)]
+        mode = int(rng.choice([0, 0, 1, 2]))
+        reg = bool(rng.integers(0, 2)) and mode != 2
+        K = int(rng.choice([1, 1, 2, 3])) if mode == 0 else 1
+        kw = dict(nvars=D - naug, naug=naug, ncond=C, hidden=hidden, act=int(rng.choice([1, 2])), mode=mode, nprobes=K,
+                  autonomous=bool(rng.integers(0, 4) == 0), reg_z=reg, reg_j=reg, reg_aug=reg and naug > 0)
+        spec = o64.make_spec(**kw)
+        B = int(rng.integers(1, 70))
+        p, xs, eps, ys = o64.synth_inputs(spec, B, 3000 + it, bias_scale=0.3)
+        p = (p * 1.5).astype(np.float32)
+        fine = run_inference(pkg, make_icnf(pkg, spec, 1, 200), spec, p, xs, eps, ys, return_state=True)
+        scale = max(1.0, float(fine[2].abs().max()))
+        path = int(rng.choice([0, 0, 1, 3]))                   # the library's choice, or the SIMT / layer-wise family forced
+        for alg in (pkg.VCABM(), pkg.Tsit5()):
+            icnf = make_icnf(pkg, spec, 1, 1, path=path)
+            icnf.sol_kwargs = dict(alg=alg, reltol=tol, abstol=tol)
+            got = run_inference(pkg, icnf, spec, p, xs, eps, ys, return_state=True)
+            st = icnf.last_solve_stats
+            assert st["naccept"] >= 2 and float((got[2] - fine[2]).abs().max()) < 300 * tol * scale, (kw, B, type(alg).__name__, st)
+            kinds.add((icnf.kernel_path(mode_of(pkg, spec)), type(alg).__name__))
+        # the adaptive training step (Tsit5 grid): one library call vs the host loop + cnf_loss_grad_grid
+        mode_obj = mode_of(pkg, spec)
+        args = (dev(xs),) + ((dev(ys),) if spec.ncond else ()) + (dev(p), {})
+        icnf.sol_kwargs["dt"] = 2.0 ** -5
+        res = {}
+        for pol in ("library", "python"):
+            icnf.adaptive_policy = pol
+            res[pol] = pkg.loss_and_gradient(icnf, mode_obj, *args, eps=dev(eps), wrt_x=True)
+        for a, b in zip(res["library"], res["python"]):
+            assert torch.equal(torch.as_tensor(a), torch.as_tensor(b)), (kw, B)
+        assert bool(torch.isfinite(res["library"][1]).all())
+    assert len(kinds) >= 4, kinds
