@@ -25,7 +25,7 @@ import torch
 from . import icnf as _icnf
 from .icnf import ICNF, Mode, TestMode, TrainMode
 
-__all__ = ["ICNFModel", "CondICNFModel", "ICNFDist", "CondICNFDist", "make_opt_callback"]
+__all__ = ["ICNFModel", "CondICNFModel", "ICNFDist", "CondICNFDist", "make_opt_callback", "save_machine", "load_machine"]
 
 
 def make_opt_callback(n: int) -> Callable[[int, float], bool]:
@@ -207,3 +207,62 @@ class CondICNFDist(ICNFDist):
         if n > self.ys.shape[1]:
             raise IndexError(f"BoundsError: {n} columns requested, the distribution holds {self.ys.shape[1]} conditions")
         return (self.ys[:, :n],)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# MLJBase.save(file, mach) / machine(file) (examples/usage.jl:96-98): the fitted model as one file
+# ---------------------------------------------------------------------------------------------------------------
+_ALG_NAMES = {"VCABM": _icnf.VCABM, "Tsit5": _icnf.Tsit5, "RK4": _icnf.RK4}
+_ACT_NAMES = {_icnf._lib.ACT_IDENTITY: "identity", _icnf._lib.ACT_TANH: "tanh", _icnf._lib.ACT_SOFTPLUS: "softplus"}
+
+
+def save_machine(path: str, model: _MLJICNF, fitresult) -> None:
+    """Everything needed to rebuild the machine: the flow's configuration (plain numbers and names), the model's
+    hyper-parameters and the learned parameter vector.  Custom basedist / epsdist objects and callbacks are not stored."""
+    ic = model.icnf
+    if ic.basedist is not None or callable(ic.epsdist):
+        raise NotImplementedError("save_machine: custom basedist / epsdist objects are not serialised")
+    nn = ic.nn
+    if nn.planar is not None:
+        net = {"planar": [nn.planar.n_in, nn.planar.n_out, _ACT_NAMES[nn.layers[0].act_id], bool(nn.planar.use_bias)]}
+    else:
+        net = {"dense": [[l.n_in, l.n_out, _ACT_NAMES[l.act_id]] for l in nn.layers]}
+    sol = {k: v for k, v in ic.sol_kwargs.items() if isinstance(v, (int, float, bool))}
+    ic._solver()
+    sol["alg"] = type(ic.sol_kwargs["alg"]).__name__
+    ps, st = fitresult
+    torch.save({
+        "format": "cnf_amd.machine.v1", "conditioned": bool(model._conditioned),
+        "icnf": {"nvariables": ic.nvariables, "naugments": ic.naugments, "nconditions": ic.nconditions,
+                 "autonomous": ic.autonomous, "inplace": ic.inplace, "tspan": list(ic.tspan), "steer_rate": ic.steer_rate,
+                 "lambda1": ic.lambda1, "lambda2": ic.lambda2, "lambda3": ic.lambda3, "nprobes": ic.nprobes,
+                 "epsdist": ic.epsdist, "jacvec": bool(ic.compute_mode.jacvec), "net": net, "sol_kwargs": sol},
+        "model": {"batchsize": model.batchsize, "epochs": model.epochs, "weight_decay": model.weight_decay, "eta": model.eta,
+                  "beta": list(model.beta), "epsilon": model.epsilon},
+        "ps": ps.detach().cpu(), "st": dict(st)}, path)
+
+
+def load_machine(path: str, device="cuda:0"):
+    """-> (model, fitresult) as `fit` returned them; the flow is rebuilt on `device`."""
+    blob = torch.load(path, map_location="cpu", weights_only=True)
+    if blob.get("format") != "cnf_amd.machine.v1":
+        raise ValueError("load_machine: not a machine file of this package")
+    c = dict(blob["icnf"])
+    net = c.pop("net")
+    if "planar" in net:
+        n_in, n_out, act, use_bias = net["planar"]
+        nn = _icnf.Chain(_icnf.PlanarLayer(n_in, n_out, act, use_bias=use_bias))
+    else:
+        nn = _icnf.Chain(*[_icnf.Dense(a, b, act) for a, b, act in net["dense"]])
+    sol = dict(c.pop("sol_kwargs"))
+    sol["alg"] = _ALG_NAMES[sol["alg"]]()
+    cm = (_icnf.HIPJacVecMatrixMode if c.pop("jacvec") else _icnf.HIPVecJacMatrixMode)()
+    c["tspan"] = tuple(c["tspan"])
+    icnf = ICNF(nn=nn, compute_mode=cm, sol_kwargs=sol, device=device, **c)
+    m = dict(blob["model"])
+    m["beta"] = tuple(m["beta"])
+    model = (CondICNFModel if blob["conditioned"] else ICNFModel)(icnf=icnf, **m)
+    ps = blob["ps"]
+    if torch.cuda.is_available():        # (a box without a GPU can still inspect the file; ps then stays on the host)
+        ps = ps.to(icnf.device)
+    return model, (ps, dict(blob["st"]))

@@ -50,6 +50,10 @@ fitresult, _, report = model.fit(df)
 torch.cuda.synchronize()
 t_fit = time.perf_counter() - t0
 
+icnf_mach_fn = os.path.join(os.environ.get("TMPDIR", "/tmp"), "icnf-machine.pt")
+pkg.save_machine(icnf_mach_fn, model, fitresult)   # MLJBase.save(icnf_mach_fn, mach)  # save it
+model, fitresult = pkg.load_machine(icnf_mach_fn)  # mach = machine(icnf_mach_fn)  # load it
+
 # ## Use It
 d = pkg.ICNFDist.from_fit(model, fitresult, pkg.TestMode())
 actual_pdf = data_dist.log_prob(r[0].clamp(1e-6, 1 - 1e-6)).exp()

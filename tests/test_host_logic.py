@@ -125,3 +125,38 @@ def test_opt_callback_prints_like_the_reference(pkg, capsys):
     assert cb(1, 3.5) is False and cb(2, 3.0) is False and cb(65, 2.5) is False
     out = capsys.readouterr().out.splitlines()
     assert out == ["Iteration: 1 | Loss: 3.5", "Iteration: 65 | Loss: 2.5"]
+
+
+@pytest.mark.parametrize("kind", ["default", "planar_cond", "fixed_jvp"])
+def test_machine_file_round_trip(kind, pkg, tmp_path):
+    """MLJBase.save(file, mach) / machine(file) of the reference's usage example: the fitted machine as one file of plain
+    numbers, names and the parameter vector; loading rebuilds an equal flow and model."""
+    if kind == "default":
+        icnf = pkg.ICNF(nvariables=2, lambda1=0.02)
+        model = pkg.ICNFModel(icnf=icnf, batchsize=128, epochs=7)
+    elif kind == "planar_cond":
+        icnf = pkg.ICNF(nvariables=2, nconditions=2, nn=pkg.Chain(pkg.PlanarLayer(8, 5, pkg.tanh, use_bias=False)), steer_rate=0.0)
+        model = pkg.CondICNFModel(icnf=icnf, eta=0.01)
+    else:
+        icnf = pkg.ICNF(nvariables=3, naugments=0, autonomous=True, compute_mode=pkg.LuxJacVecMatrixMode(), nprobes=2, epsdist="rademacher",
+                        nn=pkg.Chain(pkg.Dense(3, 8, pkg.tanh), pkg.Dense(8, 3)), tspan=(0.0, 2.0),
+                        sol_kwargs=dict(alg=pkg.Tsit5(), adaptive=False, dt=0.05))
+        model = pkg.ICNFModel(icnf=icnf)
+    ps, st = pkg.setup(torch.Generator().manual_seed(3), icnf)
+    f = str(tmp_path / "icnf-machine.pt")
+    pkg.save_machine(f, model, (ps, st))
+    model2, (ps2, st2) = pkg.load_machine(f, device="cuda:0")
+    assert type(model2) is type(model) and torch.equal(ps2.cpu(), ps) and st2 == st
+    for name in ("batchsize", "epochs", "weight_decay", "eta", "beta", "epsilon"):
+        assert getattr(model2, name) == getattr(model, name), name
+    a, b = model.icnf, model2.icnf
+    for name in ("nvariables", "naugments", "nconditions", "autonomous", "tspan", "steer_rate", "lambda1", "lambda2", "lambda3",
+                 "nprobes", "epsdist"):
+        assert getattr(a, name) == getattr(b, name), name
+    assert a.nn.widths == b.nn.widths and [l.act_id for l in a.nn.layers] == [l.act_id for l in b.nn.layers]
+    assert (a.nn.planar is None) == (b.nn.planar is None) and a.nn.param_offsets() == b.nn.param_offsets()
+    assert a.compute_mode.jacvec == b.compute_mode.jacvec and a._solver() == b._solver() and a.adaptive == b.adaptive
+    assert {k: v for k, v in a.sol_kwargs.items() if k != "alg"} == {k: v for k, v in b.sol_kwargs.items() if k != "alg"}
+    with pytest.raises(NotImplementedError):
+        bad = pkg.ICNF(nvariables=2, basedist=torch.distributions.Normal(0.0, 1.0))
+        pkg.save_machine(f, pkg.ICNFModel(icnf=bad), (ps, st))
