@@ -1,49 +1,25 @@
-// cnf_api.hip — the C ABI of libcnf_hip.so (see include/cnf.h for the contract).
+// cnf_api.hip — the C ABI of libcnf_hip.so (see include/cnf.h for the contract): handles, parameters and the
+// fixed-step entry points.  (cnf_api_adaptive.hip: adaptive solves; cnf_api_grad.hip: gradients; cnf_handle.h: shared.)
 //
 // Host-side only: handle lifetime, validation, parameter repacking, workspace management and
 // dispatch to the kernel families (cnf_mfma.hip: fused whole-solve MFMA kernels;
 // cnf_simt.hip: generic per-call kernels).  There is no CPU fallback: without a gfx950 device
 // every entry point that would compute returns CNF_ERR_NO_DEVICE / CNF_ERR_HIP.
-#include <cmath>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <functional>
-#include <string>
-#include <vector>
-
-#include "cnf_internal.h"
+#include "cnf_handle.h"
 
 using namespace cnf;
 
 namespace {
 thread_local std::string g_err;
+int fail(int code, const std::string& msg) { return cnf::api_fail(code, msg); }
+}  // namespace
 
-int fail(int code, const std::string& msg) {
+int cnf::api_fail(int code, const std::string& msg) {
     g_err = msg;
     return code;
 }
 
-#define HIP_TRY(expr)                                                                       \
-    do {                                                                                    \
-        hipError_t _e = (expr);                                                             \
-        if (_e != hipSuccess)                                                               \
-            return fail(CNF_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));    \
-    } while (0)
-
-// Device-side repacking.  Every element of an operand image is either zero padding or ONE Lux parameter
-// times a constant (1, or the tanh pre-scale folded into the forward images), so an image is a gather:
-// packed[j] = p[idx[j]] * scale[j].  The map is derived from the host packer itself (pack a vector of
-// ones -> scale, pack the ramp 1, 2, 3, ... -> idx) and verified bit-for-bit against it on a random vector; an
-// image that is not a gather (the split-bf16 hidden images) fails the check and keeps the host path.
-// With a map, cnf_set_params on a device pointer is one kernel on the caller's stream: no host round
-// trip and no synchronisation in a training loop that updates ps on the device every step.
-struct PackMap {
-    int* idx = nullptr;       // device, source parameter or -1 (zero padding)
-    float* scale = nullptr;   // device
-    size_t n = 0;
-    bool valid = false;
-};
+namespace {
 
 __global__ void gather_pack_kernel(const float* __restrict__ p, const int* __restrict__ idx,
                                    const float* __restrict__ scale, float* __restrict__ out, size_t n) {
@@ -105,95 +81,8 @@ void free_pack_map(PackMap& m) {
     m = PackMap{};
 }
 
-struct DeviceGuard {
-    int prev = -1;
-    bool ok = false;
-    explicit DeviceGuard(int dev) {
-        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
-        ok = hipSetDevice(dev) == hipSuccess;
-    }
-    ~DeviceGuard() {
-        if (prev >= 0) (void)hipSetDevice(prev);
-    }
-};
 }  // namespace
 
-struct cnf_handle {
-    cnf_config cfg{};
-    int D = 0, S = 0;
-    NetDev net{};
-    size_t nparams = 0;
-    bool have_params = false;
-    int path = CNF_PATH_SIMT;
-    // device copies of the parameters
-    float* P_dev = nullptr;       // Lux layout (SIMT path)
-    MfmaPlan* plan = nullptr;
-    float* packed_dev = nullptr;  // MFMA operand image
-    // SIMT workspaces, grown on demand
-    float* ws = nullptr;
-    int64_t ws_B = 0;
-    float* kbuf = nullptr;        // 6 stage derivatives + 1 state, each S x kbuf_B
-    int64_t kbuf_B = 0;
-    float* loss_partial = nullptr;
-    // parameter gradient (cnf_loss_grad_fixed)
-    std::vector<size_t> w_off, b_off;   // Lux offsets given to cnf_set_params
-    float* grad_packed = nullptr;        // plain f32 operand image for the reverse sweep
-    float* grad_ws = nullptr;            // checkpoints + logp + regs
-    size_t grad_ws_bytes = 0;
-    int num_cus = 0;
-    // device-side repacking (see PackMap): maps for the solve image and the gradient image, rebuilt
-    // when the layout handed to cnf_set_params changes; p_stage holds host-supplied parameters
-    PackMap map_fwd, map_grad, map_slab;
-    float* slab_packed = nullptr;        // operand image of the slab-accumulator gradient kernel (cnf_grad_slab.hip)
-    float* slab_ws = nullptr;            // its checkpoints + slabs
-    size_t slab_ws_floats = 0;
-    LayeredGrad* layered = nullptr;      // rocBLAS context + workspaces of the layer-wise evaluation / gradient
-    // embedded-step workspace (cnf_step_embedded): 7 stage derivatives + 1 stage state, each S x ebuf_B
-    float* ebuf = nullptr;
-    int64_t ebuf_B = 0;
-    int ek[7] = {0, 1, 2, 3, 4, 5, 6};   // which slot holds k_1 .. k_7 (first-same-as-last swaps slots 0 and 6)
-    double* err_partial = nullptr;
-    // multistep solve (cnf_vcabm_*): 6 state-size vectors + 2 x kVcSlots difference vectors, each S x vc_B
-    float* vc_buf = nullptr;
-    double* vc_partial = nullptr;
-    int64_t vc_B = -1;
-    int vc_iu = 0, vc_iun = 2, vc_if = 3, vc_ifn = 5, vc_cur = 0;   // which vector holds u, u_new, f_n, f_{n+1}; live difference half
-    int vc_nhist = 0, vc_k = 0;          // accepted steps since begin; order of the pending attempt (0 = none)
-    int vc_avail = 0, vc_m = 0;          // differences Phi*_j(n-1) the last accepted step stored; those the pending attempt stores
-    double vc_hist[kVcSlots + 1] = {};   // signed sizes of the accepted steps, newest first
-    double vc_t = 0.0, vc_dt = 0.0;
-    float* ad_buf = nullptr;             // adaptive Tsit5 whole solve (cnf_solve_tsit5): two states + two derivative scratch vectors
-    int64_t ad_B = 0;
-    float* tgrid_dev = nullptr;          // step times of a non-uniform grid for the fused gradient kernels
-    size_t tgrid_cap = 0;
-    bool layered_forced = false;         // kernel_path = CNF_PATH_LAYERED given explicitly: GEMM path for every batch
-    bool maps_built = false;
-    bool repack_on_device = false;
-    float* p_stage = nullptr;
-    size_t p_stage_n = 0;
-};
-
-// The configuration the fused gradient kernels are selected and packed for.  TestMode (exact trace): -tr J is the sum over
-// the D unit vectors e_k of -e_k^T J e_k, i.e. the several-probe reverse sweep with K = D one-hot probes of weight 1 and no
-// regularisers (up to the kernel's probe capacity; wider states take the layer-wise path).
-static cnf_config grad_cfg(const cnf_handle* h) {
-    cnf_config c = h->cfg;
-    if (c.mode == CNF_MODE_EXACT) {
-        c.mode = CNF_MODE_HUTCH_VJP;
-        c.nprobes = h->D;
-        c.reg_z = c.reg_j = c.reg_aug = 0;
-        if (h->D > 8) c.nprobes = 0;   // no fused instance: grad_supported() rejects nprobes < 1
-    }
-    return c;
-}
-
-__global__ void unit_probes_kernel(float* __restrict__ eps, int D, long long B) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long long DD = (long long)D * D;
-    if (i >= DD * B) return;
-    const int r = (int)(i % DD);
-    eps[i] = (r / D) == (r % D) ? 1.f : 0.f;   // probe k = rows k D .. k D + D - 1 of the column: e_k
-}
 
 static int ensure_ws(cnf_handle* h, int64_t B) {
     if (B <= h->ws_B) return CNF_OK;
@@ -343,7 +232,7 @@ int cnf_set_params(cnf_handle* h, const float* p, size_t n, const size_t* w_off,
     if (!g.ok) return fail(CNF_ERR_HIP, "cnf_set_params: hipSetDevice failed");
     hipStream_t st = (hipStream_t)stream;
     const bool mfma = h->path == CNF_PATH_MFMA;
-    const cnf_config gc = grad_cfg(h);
+    const cnf_config gc = api_grad_cfg(h);
     const bool want_grad = mfma && mfma_plan_is_per_wave(h->plan) && grad_supported(gc);
     const bool same_layout = h->have_params && h->nparams == n &&
                              std::equal(w_off, w_off + c.n_layers, h->w_off.begin()) &&
@@ -487,7 +376,8 @@ static int generic_aug_f(cnf_handle* h, const StageIn& in, float t, const float*
     return CNF_OK;
 }
 
-static int check_call(cnf_handle* h, const float* eps, const float* ys, int64_t B, const char* who) {
+extern "C++" {
+int cnf::api_check_call(cnf_handle* h, const float* eps, const float* ys, int64_t B, const char* who) {
     if (!h) return fail(CNF_ERR_INVALID, std::string(who) + ": null handle");
     if (!h->have_params) return fail(CNF_ERR_NO_PARAMS, std::string(who) + ": cnf_set_params not called");
     if (B < 0) return fail(CNF_ERR_INVALID, std::string(who) + ": negative batch");
@@ -497,10 +387,11 @@ static int check_call(cnf_handle* h, const float* eps, const float* ys, int64_t 
         return fail(CNF_ERR_INVALID, std::string(who) + ": ys is required when ncond > 0");
     return CNF_OK;
 }
+}  // extern "C++"
 
 int cnf_aug_f(cnf_handle* h, float* du, const float* u, float t, const float* eps,
               const float* ys, int64_t B, void* stream) {
-    int rc = check_call(h, eps, ys, B, "cnf_aug_f");
+    int rc = api_check_call(h, eps, ys, B, "cnf_aug_f");
     if (rc) return rc;
     if (B == 0) return CNF_OK;
     if (!du || !u) return fail(CNF_ERR_INVALID, "cnf_aug_f: null u/du");
@@ -548,7 +439,7 @@ static int simt_integrate(cnf_handle* h, int alg, int nsteps, float t0, float t1
 
 int cnf_integrate_fixed(cnf_handle* h, int alg, int nsteps, float t0, float t1, const float* u0,
                         const float* eps, const float* ys, int64_t B, float* u1, void* stream) {
-    int rc = check_call(h, eps, ys, B, "cnf_integrate_fixed");
+    int rc = api_check_call(h, eps, ys, B, "cnf_integrate_fixed");
     if (rc) return rc;
     if (nsteps < 1) return fail(CNF_ERR_INVALID, "cnf_integrate_fixed: nsteps >= 1 required");
     if (alg != CNF_ALG_RK4 && alg != CNF_ALG_TSIT5)
@@ -573,7 +464,7 @@ int cnf_integrate_fixed(cnf_handle* h, int alg, int nsteps, float t0, float t1, 
 int cnf_inference_fixed(cnf_handle* h, int alg, int nsteps, float t0, float t1, const float* x,
                         const float* eps, const float* ys, int64_t B, float* logp, float* regs,
                         float* u_final, void* stream) {
-    int rc = check_call(h, eps, ys, B, "cnf_inference_fixed");
+    int rc = api_check_call(h, eps, ys, B, "cnf_inference_fixed");
     if (rc) return rc;
     if (nsteps < 1) return fail(CNF_ERR_INVALID, "cnf_inference_fixed: nsteps >= 1 required");
     if (alg != CNF_ALG_RK4 && alg != CNF_ALG_TSIT5)
@@ -601,14 +492,11 @@ int cnf_inference_fixed(cnf_handle* h, int alg, int nsteps, float t0, float t1, 
     return CNF_OK;
 }
 
-// fixed steps on a given grid: u advanced in place, 6 (Tsit5) or 4 (RK4) evaluations per step on the handle's family
-static int integrate_grid(cnf_handle* h, int alg, int nsteps, const float* tgrid, float* u, const float* eps, const float* ys,
-                          int64_t B, hipStream_t st);
-
 // f(u + dt sum coef k, t) on whichever family serves the handle; `stage` is scratch for the fused path, whose
 // single-call kernel takes the stage state itself
-static int eval_dynamics(cnf_handle* h, const StageIn& in, float t, const float* eps, const float* ys, int64_t B, float* du,
-                         float* stage, bool first, hipStream_t st) {
+extern "C++" {
+int cnf::api_eval_dynamics(cnf_handle* h, const StageIn& in, float t, const float* eps, const float* ys, int64_t B, float* du,
+                           float* stage, bool first, hipStream_t st) {
     if (h->path == CNF_PATH_MFMA) {
         const float* uin = in.u;
         if (in.nprev > 0) {
@@ -623,9 +511,11 @@ static int eval_dynamics(cnf_handle* h, const StageIn& in, float t, const float*
     }
     return generic_aug_f(h, in, t, eps, ys, B, du, first, st);
 }
+}  // extern "C++"
 
-static int integrate_grid(cnf_handle* h, int alg, int nsteps, const float* tgrid, float* u, const float* eps, const float* ys,
-                          int64_t B, hipStream_t st) {
+extern "C++" {
+int cnf::api_integrate_grid(cnf_handle* h, int alg, int nsteps, const float* tgrid, float* u, const float* eps, const float* ys,
+                            int64_t B, hipStream_t st) {
     const size_t n = (size_t)h->S * (size_t)B;
     if (B > h->ebuf_B) {
         if (h->ebuf) HIP_TRY(hipFree(h->ebuf));
@@ -644,7 +534,7 @@ static int integrate_grid(cnf_handle* h, int alg, int nsteps, const float* tgrid
             StageIn in{};
             in.u = u; in.nprev = i; in.dt = dt;
             for (int j = 0; j < i; ++j) { in.k[j] = k[j]; in.coef[j] = T.a[i][j]; }
-            int rc = eval_dynamics(h, in, tn + T.c[i] * dt, eps, ys, B, k[i], stage, s == 0 && i == 0, st);
+            int rc = api_eval_dynamics(h, in, tn + T.c[i] * dt, eps, ys, B, k[i], stage, s == 0 && i == 0, st);
             if (rc) return rc;
         }
         StageIn fin{};
@@ -654,465 +544,7 @@ static int integrate_grid(cnf_handle* h, int alg, int nsteps, const float* tgrid
     }
     return CNF_OK;
 }
-
-int cnf_step_embedded(cnf_handle* h, int alg, int flags, float t, float dt, const float* u, const float* eps,
-                      const float* ys, int64_t B, float abstol, float reltol, float* u_new, double* err_sumsq,
-                      void* stream) {
-    int rc = check_call(h, eps, ys, B, "cnf_step_embedded");
-    if (rc) return rc;
-    if (alg != CNF_ALG_TSIT5) return fail(CNF_ERR_INVALID, "cnf_step_embedded: the embedded pair is Tsit5 (alg = CNF_ALG_TSIT5)");
-    if (!(abstol >= 0.f) || !(reltol >= 0.f) || (abstol == 0.f && reltol == 0.f))
-        return fail(CNF_ERR_INVALID, "cnf_step_embedded: tolerances must be non-negative and not both zero");
-    if (B == 0) return CNF_OK;
-    if (!u || !u_new || !err_sumsq) return fail(CNF_ERR_INVALID, "cnf_step_embedded: null u/u_new/err_sumsq");
-    if (u == u_new) return fail(CNF_ERR_INVALID, "cnf_step_embedded: u_new may not alias u");
-    DeviceGuard g(h->cfg.device_id);
-    hipStream_t st = (hipStream_t)stream;
-    const size_t n = (size_t)h->S * (size_t)B;
-    if (B > h->ebuf_B) {
-        if (h->ebuf) HIP_TRY(hipFree(h->ebuf));
-        h->ebuf = nullptr; h->ebuf_B = 0;
-        HIP_TRY(hipMalloc((void**)&h->ebuf, 8 * n * sizeof(float)));
-        h->ebuf_B = B;
-        flags = 0;   // the cached stages went with the old buffer
-    }
-    if (!h->err_partial) HIP_TRY(hipMalloc((void**)&h->err_partial, kErrBlocks * sizeof(double)));
-    const size_t slot = (size_t)h->S * (size_t)h->ebuf_B;
-    float* stage = h->ebuf + 7 * slot;
-    if (flags & CNF_STEP_FSAL) { const int tmp = h->ek[0]; h->ek[0] = h->ek[6]; h->ek[6] = tmp; }
-    float* k[7];
-    for (int i = 0; i < 7; ++i) k[i] = h->ebuf + (size_t)h->ek[i] * slot;
-    const Tableau T = make_tableau(CNF_ALG_TSIT5);
-    // b - bhat of the embedded 4th-order solution (Tsitouras 2011); satisfies the order-4 conditions to 1e-15
-    static const float btilde[7] = {-0.00178001105222577714f, -0.0008164344596567469f, 0.007880878010261995f,
-                                    -0.1447110071732629f, 0.5823571654525552f, -0.45808210592918697f,
-                                    0.015151515151515152f};
-    if (h->path == CNF_PATH_MFMA && mfma_plan_is_per_wave(h->plan)) {
-        // fused attempt: the six stages and the update in ONE launch of the solve kernel (nsteps = 1), which also
-        // writes every stage derivative; then the 7th stage at u_new and the error reduction.  (The fused step
-        // evaluates its own first stage, so the FSAL / RETRY hints save nothing here; 3 launches instead of 14.)
-        for (int i = 0; i < 7; ++i) k[i] = h->ebuf + (size_t)i * n;   // [stage][B][S], packed for this B
-        SolveArgs a{};
-        a.u0 = u; a.eps = eps; a.ys = ys; a.B = B; a.nsteps = 1; a.alg = CNF_ALG_TSIT5; a.t0 = t; a.t1 = t + dt;
-        a.u_out = u_new; a.nvars = h->cfg.nvars; a.reg_aug = 0; a.kfull = h->ebuf;
-        HIP_TRY(mfma_solve(h->plan, h->packed_dev, a, st));
-        StageIn last{};
-        last.u = u_new; last.nprev = 0; last.dt = 0.f;
-        rc = eval_dynamics(h, last, t + dt, eps, ys, B, k[6], stage, false, st);
-        if (rc) return rc;
-        HIP_TRY(embedded_error(u, u_new, k, btilde, 7, dt, abstol, reltol, (int64_t)n, h->err_partial, err_sumsq, st));
-        return CNF_OK;
-    }
-    if (!(flags & (CNF_STEP_FSAL | CNF_STEP_RETRY))) {
-        StageIn in{};
-        in.u = u; in.nprev = 0; in.dt = 0.f;
-        rc = eval_dynamics(h, in, t, eps, ys, B, k[0], stage, true, st);
-        if (rc) return rc;
-    }
-    for (int i = 1; i < 6; ++i) {
-        StageIn in{};
-        in.u = u; in.nprev = i; in.dt = dt;
-        for (int j = 0; j < i; ++j) { in.k[j] = k[j]; in.coef[j] = T.a[i][j]; }
-        rc = eval_dynamics(h, in, t + T.c[i] * dt, eps, ys, B, k[i], stage, false, st);
-        if (rc) return rc;
-    }
-    StageIn fin{};
-    fin.u = u; fin.nprev = 6; fin.dt = dt;
-    for (int j = 0; j < 6; ++j) { fin.k[j] = k[j]; fin.coef[j] = T.b[j]; }
-    HIP_TRY(rk_update(u_new, fin, (int64_t)n, st));
-    StageIn last{};
-    last.u = u_new; last.nprev = 0; last.dt = 0.f;
-    rc = eval_dynamics(h, last, t + dt, eps, ys, B, k[6], stage, false, st);   // 7th stage = first stage of the next step
-    if (rc) return rc;
-    HIP_TRY(embedded_error(u, u_new, k, btilde, 7, dt, abstol, reltol, (int64_t)n, h->err_partial, err_sumsq, st));
-    return CNF_OK;
-}
-
-// ---- variable-step variable-order Adams PECE: the reference's default alg = VCABM() ----
-
-static inline float* vc_vec(cnf_handle* h, int i) { return h->vc_buf + (size_t)i * (size_t)h->S * (size_t)h->vc_B; }
-static inline float* vc_diffs(cnf_handle* h, int half) { return vc_vec(h, 6 + half * kVcSlots); }
-
-static int vc_check(cnf_handle* h, const float* eps, const float* ys, int64_t B, const char* who) {
-    int rc = check_call(h, eps, ys, B, who);
-    if (rc) return rc;
-    if (h->vc_B < 0 || B != h->vc_B) return fail(CNF_ERR_INVALID, std::string(who) + ": cnf_vcabm_begin was not called for this batch");
-    return CNF_OK;
-}
-
-int cnf_vcabm_begin(cnf_handle* h, float t0, const float* u0, const float* eps, const float* ys, int64_t B, void* stream) {
-    int rc = check_call(h, eps, ys, B, "cnf_vcabm_begin");
-    if (rc) return rc;
-    if (B > 0 && !u0) return fail(CNF_ERR_INVALID, "cnf_vcabm_begin: null u0");
-    DeviceGuard g(h->cfg.device_id);
-    hipStream_t st = (hipStream_t)stream;
-    if (B != h->vc_B) {
-        if (h->vc_buf) HIP_TRY(hipFree(h->vc_buf));
-        h->vc_buf = nullptr; h->vc_B = -1;
-        const size_t n = (size_t)h->S * (size_t)B;
-        if (n) HIP_TRY(hipMalloc((void**)&h->vc_buf, (6 + 2 * kVcSlots) * n * sizeof(float)));
-        h->vc_B = B;
-    }
-    if (!h->vc_partial) HIP_TRY(hipMalloc((void**)&h->vc_partial, (vcabm_partial_doubles() + 8) * sizeof(double)));   // + result slots of cnf_solve_vcabm
-    h->vc_iu = 0; h->vc_iun = 2; h->vc_if = 3; h->vc_ifn = 5; h->vc_cur = 0;
-    h->vc_nhist = 0; h->vc_k = 0; h->vc_avail = 0; h->vc_m = 0; h->vc_t = t0; h->vc_dt = 0.0;
-    for (double& d : h->vc_hist) d = 0.0;
-    if (B == 0) return CNF_OK;
-    const size_t n = (size_t)h->S * (size_t)B;
-    HIP_TRY(hipMemcpyAsync(vc_vec(h, h->vc_iu), u0, n * sizeof(float), hipMemcpyDeviceToDevice, st));
-    StageIn in{};
-    in.u = vc_vec(h, h->vc_iu); in.nprev = 0; in.dt = 0.f;
-    return eval_dynamics(h, in, t0, eps, ys, B, vc_vec(h, h->vc_if), nullptr, true, st);
-}
-
-int cnf_vcabm_attempt(cnf_handle* h, int order, float dt, const float* eps, const float* ys, int64_t B, float abstol,
-                      float reltol, double* err3, void* stream) {
-    int rc = vc_check(h, eps, ys, B, "cnf_vcabm_attempt");
-    if (rc) return rc;
-    if (order < 1 || order > CNF_VCABM_MAX_ORDER || order > h->vc_nhist + 1)
-        return fail(CNF_ERR_INVALID, "cnf_vcabm_attempt: order must be in 1..12 and at most one more than the accepted steps");
-    if (std::min(order, h->vc_nhist) > h->vc_avail)
-        return fail(CNF_ERR_INVALID, "cnf_vcabm_attempt: the order can rise by at most one per accepted step (the stored differences end there)");
-    if (!(abstol >= 0.f) || !(reltol >= 0.f) || (abstol == 0.f && reltol == 0.f))
-        return fail(CNF_ERR_INVALID, "cnf_vcabm_attempt: tolerances must be non-negative and not both zero");
-    if (dt == 0.f || !(dt == dt)) return fail(CNF_ERR_INVALID, "cnf_vcabm_attempt: dt must be non-zero");
-    if (B == 0) return CNF_OK;
-    if (!err3) return fail(CNF_ERR_INVALID, "cnf_vcabm_attempt: null err3");
-    DeviceGuard g(h->cfg.device_id);
-    hipStream_t st = (hipStream_t)stream;
-    const int k = order;
-    const int m = std::min(k + 1, h->vc_nhist + 1);
-    // step sizes newest first, the candidate in front (Hairer, Noersett, Wanner I, III.5: t_{n+1} - t_{n-j+1} = sum of the j newest)
-    double dts[kVcSlots + 2];
-    dts[0] = dt;
-    for (int i = 0; i <= kVcSlots; ++i) dts[i + 1] = h->vc_hist[i];
-    VcCoef c{};
-    c.ps_old = vc_diffs(h, h->vc_cur);
-    c.ps_new = vc_diffs(h, h->vc_cur ^ 1);
-    c.ld = (size_t)h->S * (size_t)B;
-    c.k = k; c.m = m; c.dt = dt;
-    double beta = 1.0, num = 0.0, den = 0.0;
-    c.beta[0] = 1.f;
-    for (int j = 1; j < m; ++j) {       // beta_j = beta_{j-1} (t_{n+1} - t_{n-j+1}) / (t_n - t_{n-j})
-        num += dts[j - 1];
-        den += dts[j];
-        beta *= num / den;
-        c.beta[j] = (float)beta;
-    }
-    // g_j = c_{j,1};  c_{0,q} = 1/q,  c_{1,q} = 1/(q(q+1)),  c_{j,q} = c_{j-1,q} - c_{j-1,q+1} dt / (t_{n+1} - t_{n-j+1})
-    double cq[kVcSlots + 3], gd[kVcSlots + 1];
-    const int ng = k + 1;
-    gd[0] = 1.0;
-    for (int q = 1; q <= ng; ++q) cq[q - 1] = 1.0 / ((double)q * (double)(q + 1));
-    double xi = dts[0];
-    for (int j = 1; j < ng; ++j) {
-        if (j > 1) {
-            xi += dts[j - 1];
-            for (int q = 0; q < ng - j + 1; ++q) cq[q] = cq[q] - cq[q + 1] * (double)dt / xi;
-        }
-        gd[j] = cq[0];
-    }
-    for (int j = 0; j < ng; ++j) c.g[j] = (float)gd[j];
-    c.e0 = (float)((double)dt * (gd[k] - gd[k - 1]));
-    c.e1 = k >= 2 ? (float)((double)dt * (gd[k - 1] - gd[k - 2])) : 0.f;
-    c.e2 = k >= 3 ? (float)((double)dt * (gd[k - 2] - gd[k - 3])) : 0.f;
-    const int64_t n = (int64_t)c.ld;
-    float *u = vc_vec(h, h->vc_iu), *p = vc_vec(h, 1), *un = vc_vec(h, h->vc_iun), *d = vc_vec(h, 4);
-    HIP_TRY(vcabm_predict(vc_vec(h, h->vc_if), u, c, n, p, st));                                    // P
-    StageIn in{};
-    in.u = p; in.nprev = 0; in.dt = 0.f;
-    rc = eval_dynamics(h, in, (float)(h->vc_t + (double)dt), eps, ys, B, d, nullptr, false, st);   // E
-    if (rc) return rc;
-    HIP_TRY(vcabm_correct(d, p, u, c, abstol, reltol, n, un, h->vc_partial, err3, st));             // C
-    h->vc_k = k; h->vc_m = m; h->vc_dt = dt;
-    return CNF_OK;
-}
-
-int cnf_vcabm_accept(cnf_handle* h, const float* eps, const float* ys, int64_t B, float abstol, float reltol,
-                     double* err_up, void* stream) {
-    int rc = vc_check(h, eps, ys, B, "cnf_vcabm_accept");
-    if (rc) return rc;
-    if (B == 0) return CNF_OK;
-    if (h->vc_k == 0) return fail(CNF_ERR_INVALID, "cnf_vcabm_accept: no pending attempt");
-    const int k = h->vc_k;
-    if (err_up && (k >= CNF_VCABM_MAX_ORDER || h->vc_nhist < k))
-        return fail(CNF_ERR_INVALID, "cnf_vcabm_accept: the order k+1 estimate needs k accepted steps and k < 12");
-    DeviceGuard g(h->cfg.device_id);
-    hipStream_t st = (hipStream_t)stream;
-    const size_t n = (size_t)h->S * (size_t)B;
-    float *u = vc_vec(h, h->vc_iu), *un = vc_vec(h, h->vc_iun), *fnew = vc_vec(h, h->vc_ifn);
-    StageIn in{};
-    in.u = un; in.nprev = 0; in.dt = 0.f;
-    rc = eval_dynamics(h, in, (float)(h->vc_t + h->vc_dt), eps, ys, B, fnew, nullptr, false, st);   // E
-    if (rc) return rc;
-    if (err_up) {
-        // gamma*_j of the Adams-Moulton family: sum_{i<=j} gamma*_i / (j - i + 1) = [j == 0]
-        double gs[kVcSlots + 2];
-        gs[0] = 1.0;
-        for (int j = 1; j <= k + 1; ++j) {
-            double a = 0.0;
-            for (int i = 0; i < j; ++i) a += gs[i] / (double)(j - i + 1);
-            gs[j] = -a;
-        }
-        VcCoef c{};
-        c.ps_new = vc_diffs(h, h->vc_cur ^ 1);
-        c.ld = n; c.k = k;
-        c.e0 = (float)(h->vc_dt * gs[k + 1]);
-        HIP_TRY(vcabm_errup(fnew, u, un, c, abstol, reltol, (int64_t)n, h->vc_partial, err_up, st));
-    }
-    std::swap(h->vc_iu, h->vc_iun);
-    std::swap(h->vc_if, h->vc_ifn);
-    h->vc_cur ^= 1;
-    for (int i = kVcSlots; i > 0; --i) h->vc_hist[i] = h->vc_hist[i - 1];
-    h->vc_hist[0] = h->vc_dt;
-    h->vc_t += h->vc_dt;
-    h->vc_nhist += 1;
-    h->vc_avail = h->vc_m;
-    h->vc_k = 0;
-    return CNF_OK;
-}
-
-int cnf_vcabm_state(cnf_handle* h, int64_t B, float* u_out, double* t_out, void* stream) {
-    if (!h) return fail(CNF_ERR_INVALID, "cnf_vcabm_state: null handle");
-    if (h->vc_B < 0 || B != h->vc_B) return fail(CNF_ERR_INVALID, "cnf_vcabm_state: cnf_vcabm_begin was not called for this batch");
-    if (t_out) *t_out = h->vc_t;
-    if (u_out && B > 0) {
-        DeviceGuard g(h->cfg.device_id);
-        HIP_TRY(hipMemcpyAsync(u_out, vc_vec(h, h->vc_iu), (size_t)h->S * (size_t)B * sizeof(float), hipMemcpyDeviceToDevice,
-                               (hipStream_t)stream));
-    }
-    return CNF_OK;
-}
-
-// The whole default solve in one call: cnf_vcabm_begin / _attempt / _accept driven by the step-size and order policy of
-// icnf._vcabm_integrate (the host side of the reference's solver), restated here so that a single-process caller pays one
-// library call per solve instead of two per step.  Synchronises `stream` (the policy reads the error sums).
-int cnf_solve_vcabm(cnf_handle* h, float t0, float t1, const float* u0, const float* eps, const float* ys, int64_t B,
-                    float abstol, float reltol, float dt_init, int maxiters, float* u1, cnf_solve_stats* stats,
-                    float* dts_out, int32_t* orders_out, int32_t record_cap, void* stream) {
-    if (stats) *stats = cnf_solve_stats{};
-    int rc = cnf_vcabm_begin(h, t0, u0, eps, ys, B, stream);
-    if (rc) return rc;
-    if (!(abstol >= 0.f) || !(reltol >= 0.f) || (abstol == 0.f && reltol == 0.f))
-        return fail(CNF_ERR_INVALID, "cnf_solve_vcabm: tolerances must be non-negative and not both zero");
-    if (B > 0 && !u1) return fail(CNF_ERR_INVALID, "cnf_solve_vcabm: null u1");
-    if (maxiters < 1) return fail(CNF_ERR_INVALID, "cnf_solve_vcabm: maxiters >= 1 required");
-    int nf = B > 0 ? 1 : 0, naccept = 0, nreject = 0, max_order = 0;
-    const double span = std::fabs((double)t1 - (double)t0), tdir = t1 >= t0 ? 1.0 : -1.0;
-    if (B == 0 || span == 0.0) {
-        if (B > 0) return cnf_vcabm_state(h, B, u1, nullptr, stream);
-        return CNF_OK;
-    }
-    DeviceGuard g(h->cfg.device_id);
-    hipStream_t st = (hipStream_t)stream;
-    const size_t n = (size_t)h->S * (size_t)B;
-    const double ntot = (double)n;
-    double* res = h->vc_partial + vcabm_partial_doubles();   // device result slots
-    double host[4];
-    auto fetch = [&](int cnt) -> int {
-        HIP_TRY(hipMemcpyAsync(host, res, cnt * sizeof(double), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        return CNF_OK;
-    };
-    double dt;
-    if (dt_init != 0.f) {
-        dt = std::min((double)std::fabs(dt_init), span);
-    } else {   // ode_determine_initdt (Hairer, Noersett, Wanner I, II.4) with the algorithm order 7, RMS norm over all S*B entries
-        float *u = vc_vec(h, h->vc_iu), *f0 = vc_vec(h, h->vc_if), *ue = vc_vec(h, 1), *f1 = vc_vec(h, 4);
-        HIP_TRY(vcabm_scaled_sumsq(u, nullptr, u, abstol, reltol, (int64_t)n, h->vc_partial, res, st));
-        HIP_TRY(vcabm_scaled_sumsq(f0, nullptr, u, abstol, reltol, (int64_t)n, h->vc_partial, res + 1, st));
-        rc = fetch(2);
-        if (rc) return rc;
-        const double d0 = std::sqrt(host[0] / ntot), d1 = std::sqrt(host[1] / ntot);
-        double h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
-        h0 = std::min(h0, span);
-        StageIn eu{};
-        eu.u = u; eu.nprev = 1; eu.k[0] = f0; eu.coef[0] = 1.f; eu.dt = (float)(tdir * h0);
-        HIP_TRY(rk_update(ue, eu, (int64_t)n, st));
-        StageIn in{};
-        in.u = ue; in.nprev = 0; in.dt = 0.f;
-        rc = eval_dynamics(h, in, (float)((double)t0 + tdir * h0), eps, ys, B, f1, nullptr, false, st);
-        if (rc) return rc;
-        ++nf;
-        HIP_TRY(vcabm_scaled_sumsq(f1, f0, u, abstol, reltol, (int64_t)n, h->vc_partial, res, st));
-        rc = fetch(1);
-        if (rc) return rc;
-        const double d2 = std::sqrt(host[0] / ntot) / h0, dmax = std::max(d1, d2);
-        const double h1 = dmax <= 1e-15 ? std::max(1e-6, h0 * 1e-3) : std::pow(10.0, -(2.0 + std::log10(dmax)) / 8.0);
-        dt = std::min(std::min(100.0 * h0, h1), span);
-        if (!(std::isfinite(dt) && dt > 0.0)) return fail(CNF_ERR_INVALID, "cnf_solve_vcabm: non-finite state or dynamics at t0 (no initial step)");
-    }
-    const double gamma = 0.9, qmin = 0.2, qmax = 10.0;
-    double t = t0;
-    int k = 1, step = 1, it = 0;
-    for (; it < maxiters; ++it) {
-        if (std::fabs((double)t1 - t) <= 1e-7 * std::max(1.0, span)) break;
-        const bool last = dt >= std::fabs((double)t1 - t) * (1.0 - 1e-6);
-        const double hstep = last ? std::fabs((double)t1 - t) : dt;     // tstop: never step over t1
-        rc = cnf_vcabm_attempt(h, k, (float)(tdir * hstep), eps, ys, B, abstol, reltol, res, stream);
-        if (rc) return rc;
-        ++nf;
-        rc = fetch(3);
-        if (rc) return rc;
-        double eest = std::sqrt(host[0] / ntot);
-        if (!std::isfinite(eest)) return fail(CNF_ERR_INVALID, "cnf_solve_vcabm: non-finite error estimate (unstable dynamics)");
-        if (eest > 1.0) {   // reject: same state, smaller step, same order
-            ++nreject;
-            dt = hstep / std::max(1.0 / qmax, std::min(1.0 / qmin, std::pow(eest, 1.0 / (k + 1)) / gamma));
-            continue;
-        }
-        const bool select = step > 4 && k >= 3;
-        const bool lower = select && std::max(std::sqrt(host[2] / ntot), std::sqrt(host[1] / ntot)) <= eest;
-        const bool want_up = select && !lower && k < CNF_VCABM_MAX_ORDER;
-        rc = cnf_vcabm_accept(h, eps, ys, B, abstol, reltol, want_up ? res : nullptr, stream);
-        if (rc) return rc;
-        ++nf;
-        int knew = k;
-        if (!select) knew = std::min(k + 1, 3);
-        else if (lower) knew = k - 1;
-        else if (want_up) {
-            rc = fetch(1);
-            if (rc) return rc;
-            if (std::sqrt(host[0] / ntot) < eest) { knew = k + 1; eest = 1.0; }
-        }
-        const double q = eest == 0.0 ? 1.0 / qmax : std::max(1.0 / qmax, std::min(1.0 / qmin, std::pow(eest, 1.0 / (knew + 1)) / gamma));
-        t = last ? (double)t1 : t + tdir * hstep;
-        if (naccept < record_cap) {
-            if (dts_out) dts_out[naccept] = (float)(tdir * hstep);
-            if (orders_out) orders_out[naccept] = k;
-        }
-        ++naccept;
-        if (k > max_order) max_order = k;
-        k = knew; ++step;
-        dt = hstep / q;
-    }
-    if (stats) { stats->naccept = naccept; stats->nreject = nreject; stats->nf = nf; stats->max_order = max_order; }
-    if (it == maxiters) return fail(CNF_ERR_INVALID, "cnf_solve_vcabm: maxiters reached");
-    return cnf_vcabm_state(h, B, u1, nullptr, stream);
-}
-
-// Adaptive Tsit5 from t0 to t1 in one call: cnf_step_embedded attempts under OrdinaryDiffEq's PI controller - the loop of
-// icnf._adaptive_integrate restated inside the library (single process).  Synchronises `stream`.
-static int ensure_adaptive_buf(cnf_handle* h, int64_t B) {
-    if (B <= h->ad_B) return CNF_OK;
-    if (h->ad_buf) HIP_TRY(hipFree(h->ad_buf));
-    h->ad_buf = nullptr; h->ad_B = 0;
-    HIP_TRY(hipMalloc((void**)&h->ad_buf, 6 * (size_t)h->S * (size_t)B * sizeof(float)));   // 4 for the solve, 2 for cnf_loss_grad_adaptive
-    h->ad_B = B;
-    return CNF_OK;
-}
-
-static int solve_tsit5_impl(cnf_handle* h, float t0, float t1, const float* u0, const float* eps, const float* ys, int64_t B,
-                            float abstol, float reltol, float dt_init, int maxiters, float* u1, cnf_solve_stats* stats,
-                            std::vector<double>* steps, void* stream) {
-    if (stats) *stats = cnf_solve_stats{};
-    int rc = check_call(h, eps, ys, B, "cnf_solve_tsit5");
-    if (rc) return rc;
-    if (!(abstol >= 0.f) || !(reltol >= 0.f) || (abstol == 0.f && reltol == 0.f))
-        return fail(CNF_ERR_INVALID, "cnf_solve_tsit5: tolerances must be non-negative and not both zero");
-    if (B > 0 && (!u0 || !u1)) return fail(CNF_ERR_INVALID, "cnf_solve_tsit5: null u0/u1");
-    if (maxiters < 1) return fail(CNF_ERR_INVALID, "cnf_solve_tsit5: maxiters >= 1 required");
-    if (B == 0) return CNF_OK;
-    DeviceGuard g(h->cfg.device_id);
-    hipStream_t st = (hipStream_t)stream;
-    const size_t n = (size_t)h->S * (size_t)B;
-    const double span = std::fabs((double)t1 - (double)t0), tdir = t1 >= t0 ? 1.0 : -1.0, ntot = (double)n;
-    if (span == 0.0) {
-        if (u1 != u0) HIP_TRY(hipMemcpyAsync(u1, u0, n * sizeof(float), hipMemcpyDeviceToDevice, st));
-        return CNF_OK;
-    }
-    rc = ensure_adaptive_buf(h, B);
-    if (rc) return rc;
-    if (!h->vc_partial) HIP_TRY(hipMalloc((void**)&h->vc_partial, (vcabm_partial_doubles() + 8) * sizeof(double)));
-    const size_t slot = (size_t)h->S * (size_t)h->ad_B;
-    float *ua = h->ad_buf, *ub = ua + slot, *f0 = ub + slot, *f1 = f0 + slot;
-    HIP_TRY(hipMemcpyAsync(ua, u0, n * sizeof(float), hipMemcpyDeviceToDevice, st));
-    double* res = h->vc_partial + vcabm_partial_doubles();
-    double host[2];
-    auto fetch = [&](int cnt) -> int {
-        HIP_TRY(hipMemcpyAsync(host, res, cnt * sizeof(double), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        return CNF_OK;
-    };
-    int nf = 0, naccept = 0, nreject = 0;
-    double dt;
-    if (dt_init != 0.f) {
-        dt = std::min((double)std::fabs(dt_init), span);
-    } else {   // ode_determine_initdt (Hairer, Noersett, Wanner I, II.4), order 5
-        StageIn in{};
-        in.u = ua; in.nprev = 0; in.dt = 0.f;
-        rc = eval_dynamics(h, in, t0, eps, ys, B, f0, nullptr, true, st);
-        if (rc) return rc;
-        ++nf;
-        HIP_TRY(vcabm_scaled_sumsq(ua, nullptr, ua, abstol, reltol, (int64_t)n, h->vc_partial, res, st));
-        HIP_TRY(vcabm_scaled_sumsq(f0, nullptr, ua, abstol, reltol, (int64_t)n, h->vc_partial, res + 1, st));
-        rc = fetch(2);
-        if (rc) return rc;
-        const double d0 = std::sqrt(host[0] / ntot), d1 = std::sqrt(host[1] / ntot);
-        double h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
-        h0 = std::min(h0, span);
-        if (!(std::isfinite(h0) && h0 > 0.0)) return fail(CNF_ERR_INVALID, "cnf_solve_tsit5: non-finite state or dynamics at t0 (no initial step)");
-        StageIn eu{};
-        eu.u = ua; eu.nprev = 1; eu.k[0] = f0; eu.coef[0] = 1.f; eu.dt = (float)(tdir * h0);
-        HIP_TRY(rk_update(ub, eu, (int64_t)n, st));
-        StageIn in1{};
-        in1.u = ub; in1.nprev = 0; in1.dt = 0.f;
-        rc = eval_dynamics(h, in1, (float)((double)t0 + tdir * h0), eps, ys, B, f1, nullptr, false, st);
-        if (rc) return rc;
-        ++nf;
-        HIP_TRY(vcabm_scaled_sumsq(f1, f0, ua, abstol, reltol, (int64_t)n, h->vc_partial, res, st));
-        rc = fetch(1);
-        if (rc) return rc;
-        const double d2 = std::sqrt(host[0] / ntot) / h0, dmax = std::max(d1, d2);
-        const double h1 = dmax <= 1e-15 ? std::max(1e-6, h0 * 1e-3) : std::pow(10.0, -(2.0 + std::log10(dmax)) / 5.0);
-        dt = std::min(std::min(100.0 * h0, h1), span);
-        if (!(std::isfinite(dt) && dt > 0.0)) return fail(CNF_ERR_INVALID, "cnf_solve_tsit5: non-finite state or dynamics at t0 (no initial step)");
-    }
-    const double beta1 = 7.0 / 50.0, beta2 = 2.0 / 25.0, gamma = 0.9, qmin = 0.2, qmax = 10.0;
-    double qold = 1e-4, t = t0;
-    int flags = 0, it = 0;
-    for (; it < maxiters; ++it) {
-        if (std::fabs((double)t1 - t) <= 1e-7 * std::max(1.0, span)) break;
-        const bool last = dt >= std::fabs((double)t1 - t) * (1.0 - 1e-6);
-        const double step = last ? std::fabs((double)t1 - t) : dt;     // tstop: never step over t1
-        rc = cnf_step_embedded(h, CNF_ALG_TSIT5, flags, (float)t, (float)(tdir * step), ua, eps, ys, B, abstol, reltol, ub, res, stream);
-        if (rc) return rc;
-        nf += flags ? 6 : 7;
-        rc = fetch(1);
-        if (rc) return rc;
-        const double eest = std::sqrt(host[0] / ntot);
-        if (!std::isfinite(eest)) return fail(CNF_ERR_INVALID, "cnf_solve_tsit5: non-finite error estimate (unstable dynamics)");
-        const double q11 = eest > 0.0 ? std::pow(eest, beta1) : 0.0;
-        const double q = eest == 0.0 ? 1.0 / qmax : std::max(1.0 / qmax, std::min(1.0 / qmin, (q11 / std::pow(qold, beta2)) / gamma));
-        if (eest <= 1.0) {   // accept
-            t = last ? (double)t1 : t + tdir * step;
-            std::swap(ua, ub);
-            if (steps) steps->push_back(tdir * step);
-            ++naccept;
-            qold = std::max(eest, 1e-4);
-            dt = step / q;
-            flags = CNF_STEP_FSAL;
-        } else {             // reject: same (t, u), smaller step
-            ++nreject;
-            dt = step / std::min(1.0 / qmin, q11 / gamma);
-            flags = CNF_STEP_RETRY;
-        }
-    }
-    if (stats) { stats->naccept = naccept; stats->nreject = nreject; stats->nf = nf; stats->max_order = 5; }
-    if (it == maxiters) return fail(CNF_ERR_INVALID, "cnf_solve_tsit5: maxiters reached");
-    HIP_TRY(hipMemcpyAsync(u1, ua, n * sizeof(float), hipMemcpyDeviceToDevice, st));
-    return CNF_OK;
-}
-
-int cnf_solve_tsit5(cnf_handle* h, float t0, float t1, const float* u0, const float* eps, const float* ys, int64_t B,
-                    float abstol, float reltol, float dt_init, int maxiters, float* u1, cnf_solve_stats* stats,
-                    float* dts_out, int32_t record_cap, void* stream) {
-    std::vector<double> steps;
-    const int rc = solve_tsit5_impl(h, t0, t1, u0, eps, ys, B, abstol, reltol, dt_init, maxiters, u1, stats, &steps, stream);
-    if (dts_out)
-        for (size_t i = 0; i < steps.size() && (int64_t)i < record_cap; ++i) dts_out[i] = (float)steps[i];
-    return rc;
-}
+}  // extern "C++"
 
 int cnf_assemble_u0(cnf_handle* h, const float* x, int64_t B, float* u0, void* stream) {
     if (!h || B < 0) return fail(CNF_ERR_INVALID, "cnf_assemble_u0: null handle or negative batch");
@@ -1141,234 +573,6 @@ int cnf_loss_sums(cnf_handle* h, const float* logp, const float* regs, int64_t B
     if (!h->loss_partial) HIP_TRY(hipMalloc((void**)&h->loss_partial, 256 * 4 * sizeof(float)));
     HIP_TRY(loss_sums(logp, regs, B, h->loss_partial, sums4, (hipStream_t)stream));
     return CNF_OK;
-}
-
-// fused reverse-sweep kernel, unless CNF_GRAD_LAYERED=1 forces the layer-wise path (tests, A/B timing)
-static bool grad_is_fused(const cnf_handle* h) {
-    const char* force = getenv("CNF_GRAD_LAYERED");
-    return h->path == CNF_PATH_MFMA && grad_supported(grad_cfg(h)) && mfma_plan_is_per_wave(h->plan) &&
-           !(force && *force && *force != '0');
-}
-
-// slab-accumulator kernel for the mid-width two-hidden-layer nets (CNF_GRAD_LAYERED=1 skips it too)
-static bool grad_uses_slab(const cnf_handle* h) {
-    const char* force = getenv("CNF_GRAD_LAYERED");
-    return (h->slab_packed || !h->have_params) && grad_slab_supported(h->cfg) && !(force && *force && *force != '0');
-}
-
-int cnf_grad_path(const cnf_handle* h) {
-    if (!h) return CNF_ERR_INVALID;
-    if (grad_is_fused(h) || grad_uses_slab(h)) return 1;
-    return layered_grad_supported(h->cfg) ? 2 : 0;
-}
-
-}  // extern "C"
-
-// loss sums + gradient on a uniform grid (tgrid == nullptr: nsteps steps from t0 to t1) or on the caller's non-uniform
-// grid (tgrid: host, nsteps + 1 times; t0 / t1 ignored).  The same three gradient implementations serve both.
-static int loss_grad_impl(cnf_handle* h, const char* who, int alg, int nsteps, float t0, float t1, const float* tgrid,
-                          const float* x, const float* eps, const float* ys, int64_t B, const float* lambdas,
-                          float* grad, float* grad_x, float* sums4, void* stream) {
-    int rc = check_call(h, eps, ys, B, who);
-    if (rc) return rc;
-    const std::string w(who);
-    if (nsteps < 1) return fail(CNF_ERR_INVALID, w + ": nsteps >= 1 required");
-    if (alg != CNF_ALG_RK4 && alg != CNF_ALG_TSIT5) return fail(CNF_ERR_INVALID, w + ": unknown alg");
-    if (!x || !grad || !lambdas) return fail(CNF_ERR_INVALID, w + ": null x/grad/lambdas");
-    const bool fused = grad_is_fused(h) && h->grad_packed;
-    if (!fused && !layered_grad_supported(h->cfg))
-        return fail(CNF_ERR_UNSUPPORTED, w + ": no gradient path for this configuration");
-    DeviceGuard g(h->cfg.device_id);
-    hipStream_t st = (hipStream_t)stream;
-    HIP_TRY(hipMemsetAsync(grad, 0, h->nparams * sizeof(float), st));
-    if (B == 0) {
-        if (sums4) HIP_TRY(hipMemsetAsync(sums4, 0, 4 * sizeof(float), st));
-        return CNF_OK;
-    }
-    const float* tgrid_dev = nullptr;
-    if (tgrid) {   // the fused kernels read the step times from device memory (uniform loads, once per step)
-        t0 = tgrid[0]; t1 = tgrid[nsteps];
-        if ((size_t)nsteps + 1 > h->tgrid_cap) {
-            if (h->tgrid_dev) HIP_TRY(hipFree(h->tgrid_dev));
-            h->tgrid_dev = nullptr; h->tgrid_cap = 0;
-            const size_t cap = ((size_t)nsteps + 1 + 63) / 64 * 64;
-            HIP_TRY(hipMalloc((void**)&h->tgrid_dev, cap * sizeof(float)));
-            h->tgrid_cap = cap;
-        }
-        HIP_TRY(hipMemcpyAsync(h->tgrid_dev, tgrid, ((size_t)nsteps + 1) * sizeof(float), hipMemcpyHostToDevice, st));
-        tgrid_dev = h->tgrid_dev;
-    }
-    if (!fused) {
-        // the loss sums come from the regular solve on whichever family serves the handle
-        if (sums4) {
-            const size_t need = ((size_t)h->S + 4) * (size_t)B * sizeof(float);
-            if (need > h->grad_ws_bytes) {
-                if (h->grad_ws) HIP_TRY(hipFree(h->grad_ws));
-                h->grad_ws = nullptr; h->grad_ws_bytes = 0;
-                HIP_TRY(hipMalloc((void**)&h->grad_ws, need));
-                h->grad_ws_bytes = need;
-            }
-            float* logp = h->grad_ws;
-            float* regs = logp + B;
-            if (tgrid) {   // the loss of the same discrete solve: augmented state advanced over the grid, then the epilogue
-                float* u = regs + 3 * (size_t)B;
-                const int ra0 = (h->cfg.mode != CNF_MODE_EXACT && h->cfg.reg_aug && h->cfg.naug > 0) ? 1 : 0;
-                HIP_TRY(assemble_u0(x, h->cfg.nvars, h->S, B, u, st));
-                rc = integrate_grid(h, alg, nsteps, tgrid, u, eps, ys, B, st);
-                if (rc) return rc;
-                HIP_TRY(epilogue(u, h->cfg.nvars, h->D, ra0, B, logp, regs, st));
-            } else {
-                rc = cnf_inference_fixed(h, alg, nsteps, t0, t1, x, eps, ys, B, logp, regs, nullptr, stream);
-                if (rc) return rc;
-            }
-            if (!h->loss_partial) HIP_TRY(hipMalloc((void**)&h->loss_partial, 256 * 4 * sizeof(float)));
-            HIP_TRY(loss_sums(logp, regs, B, h->loss_partial, sums4, st));
-        }
-        const bool hutch = h->cfg.mode != CNF_MODE_EXACT;   // the exact-trace dynamics carry no regularisers (icnf.jl:297-339)
-        const int ra = (hutch && h->cfg.reg_aug && h->cfg.naug > 0) ? 1 : 0;
-        const float lam[3] = {hutch && h->cfg.reg_z ? lambdas[0] : 0.f, hutch && h->cfg.reg_j ? lambdas[1] : 0.f, ra ? lambdas[2] : 0.f};
-        if (grad_uses_slab(h)) {
-            // two-hidden-layer nets of 4..7 hidden tiles: tile-fused reverse sweep with slab accumulators (cnf_grad_slab.hip)
-            if (h->num_cus == 0) {
-                hipDeviceProp_t prop;
-                HIP_TRY(hipGetDeviceProperties(&prop, h->cfg.device_id));
-                h->num_cus = prop.multiProcessorCount;
-            }
-            const size_t need = grad_slab_ws_floats(h->cfg, alg, nsteps, B, h->num_cus);
-            if (need > h->slab_ws_floats) {
-                if (h->slab_ws) HIP_TRY(hipFree(h->slab_ws));
-                h->slab_ws = nullptr; h->slab_ws_floats = 0;
-                HIP_TRY(hipMalloc((void**)&h->slab_ws, need * sizeof(float)));
-                h->slab_ws_floats = need;
-            }
-            HIP_TRY(grad_slab_launch(h->cfg, h->slab_packed, x, eps, ys, h->w_off.data(), h->b_off.data(), alg, nsteps, t0, t1, tgrid_dev, B, lam,
-                                     h->slab_ws, grad, grad_x, h->num_cus, st));
-            return CNF_OK;
-        }
-        std::string msg;
-        hipError_t e = layered_grad(&h->layered, h->cfg, h->P_dev, h->w_off.data(), h->b_off.data(), x, eps, ys, alg, nsteps,
-                                    t0, t1, tgrid, B, lam, grad, grad_x, st, &msg);
-        if (e == hipErrorNotSupported) return fail(CNF_ERR_UNSUPPORTED, w + ": " + msg);
-        if (e != hipSuccess) return fail(CNF_ERR_HIP, w + ": " + msg);
-        return CNF_OK;
-    }
-    if (h->num_cus == 0) {
-        hipDeviceProp_t prop;
-        HIP_TRY(hipGetDeviceProperties(&prop, h->cfg.device_id));
-        h->num_cus = prop.multiProcessorCount;
-    }
-    const long long ntiles = (B + 15) / 16;
-    const int ckpt_zr = mfma_plan_zr(h->plan);
-    const int nstages = alg == CNF_ALG_RK4 ? 4 : 6;
-    const size_t ckpt_z_floats = (size_t)(nsteps + 1) * (size_t)ntiles * 64 * (size_t)ckpt_zr;
-    const size_t ckpt_k_floats = (size_t)nsteps * nstages * (size_t)ntiles * 64 * (size_t)ckpt_zr;
-    const size_t ckpt_floats = ckpt_z_floats + ckpt_k_floats;
-    const cnf_config gc = grad_cfg(h);
-    const bool exact = h->cfg.mode == CNF_MODE_EXACT;
-    const size_t slab_floats = grad_slab_floats(gc, h->num_cus);
-    const size_t state_floats = tgrid ? 2 * (size_t)h->S * (size_t)B : 0;   // ping-pong states of the step-by-step forward pass
-    const size_t unit_floats = exact ? (size_t)h->D * (size_t)h->D * (size_t)B : 0;   // the D unit probes of every column
-    const size_t need = (ckpt_floats + 4 * (size_t)B + slab_floats + state_floats + unit_floats) * sizeof(float);
-    if (need > h->grad_ws_bytes) {
-        if (h->grad_ws) HIP_TRY(hipFree(h->grad_ws));
-        h->grad_ws = nullptr; h->grad_ws_bytes = 0;
-        HIP_TRY(hipMalloc((void**)&h->grad_ws, need));
-        h->grad_ws_bytes = need;
-    }
-    float* ckpt = h->grad_ws;
-    float* ckpt_k = ckpt + ckpt_z_floats;
-    float* logp = ckpt + ckpt_floats;
-    float* regs = logp + B;
-    float* slab = regs + 3 * (size_t)B;
-    const int reg_aug = (!exact && h->cfg.reg_aug && h->cfg.naug > 0) ? 1 : 0;
-    if (!tgrid) {
-        SolveArgs a{};
-        a.x = x; a.eps = eps; a.ys = ys; a.B = B; a.nsteps = nsteps; a.alg = alg; a.t0 = t0; a.t1 = t1;
-        a.logp = logp; a.regs = regs; a.nvars = h->cfg.nvars; a.reg_aug = reg_aug; a.ckpt = ckpt; a.ckpt_k = ckpt_k;
-        HIP_TRY(mfma_solve(h->plan, h->packed_dev, a, st));
-    } else {
-        // non-uniform grid: the checkpointing forward pass is one launch of the (unchanged) solve kernel per step - the metric
-        // kernel keeps its loop-invariant step size; step n writes checkpoint slots n and n + 1 and its stage derivatives
-        float* ua = slab + slab_floats;
-        float* ub = ua + (size_t)h->S * (size_t)B;
-        HIP_TRY(assemble_u0(x, h->cfg.nvars, h->S, B, ua, st));
-        const size_t zslot = (size_t)ntiles * 64 * (size_t)ckpt_zr;
-        for (int n = 0; n < nsteps; ++n) {
-            SolveArgs a{};
-            a.u0 = ua; a.u_out = ub; a.eps = eps; a.ys = ys; a.B = B; a.nsteps = 1; a.alg = alg; a.t0 = tgrid[n]; a.t1 = tgrid[n + 1];
-            a.nvars = h->cfg.nvars; a.reg_aug = reg_aug;
-            a.ckpt = ckpt + (size_t)n * zslot; a.ckpt_k = ckpt_k + (size_t)n * nstages * zslot;
-            if (n == nsteps - 1) { a.logp = logp; a.regs = regs; }
-            HIP_TRY(mfma_solve(h->plan, h->packed_dev, a, st));
-            float* tmp = ua; ua = ub; ub = tmp;
-        }
-    }
-    if (sums4) {
-        if (!h->loss_partial) HIP_TRY(hipMalloc((void**)&h->loss_partial, 256 * 4 * sizeof(float)));
-        HIP_TRY(loss_sums(logp, regs, B, h->loss_partial, sums4, st));
-    }
-    const float lam[3] = {gc.reg_z ? lambdas[0] : 0.f, gc.reg_j ? lambdas[1] : 0.f, reg_aug ? lambdas[2] : 0.f};
-    const float* probes = eps;
-    if (exact) {
-        float* unit = slab + slab_floats + state_floats;
-        const long long nunit = (long long)unit_floats;
-        hipLaunchKernelGGL(unit_probes_kernel, dim3((unsigned)((nunit + 255) / 256)), dim3(256), 0, st, unit, h->D, (long long)B);
-        HIP_TRY(hipGetLastError());
-        probes = unit;
-    }
-    HIP_TRY(grad_launch(gc, h->grad_packed, ckpt, ckpt_k, ckpt_zr, probes, ys, h->w_off.data(), h->b_off.data(), alg, nsteps, t0, t1,
-                        tgrid_dev, exact ? 1.f : 0.f, B, lam, slab, grad, grad_x, h->num_cus, st));
-    return CNF_OK;
-}
-
-
-extern "C" {
-
-int cnf_loss_grad_fixed(cnf_handle* h, int alg, int nsteps, float t0, float t1, const float* x,
-                        const float* eps, const float* ys, int64_t B, const float* lambdas,
-                        float* grad, float* grad_x, float* sums4, void* stream) {
-    return loss_grad_impl(h, "cnf_loss_grad_fixed", alg, nsteps, t0, t1, nullptr, x, eps, ys, B, lambdas, grad, grad_x, sums4, stream);
-}
-
-int cnf_loss_grad_grid(cnf_handle* h, int alg, int nsteps, const float* tgrid, const float* x, const float* eps,
-                       const float* ys, int64_t B, const float* lambdas, float* grad, float* grad_x, float* sums4,
-                       void* stream) {
-    if (nsteps < 1 || !tgrid) return fail(CNF_ERR_INVALID, "cnf_loss_grad_grid: nsteps >= 1 and a grid of nsteps + 1 times required");
-    return loss_grad_impl(h, "cnf_loss_grad_grid", alg, nsteps, 0.f, 0.f, tgrid, x, eps, ys, B, lambdas, grad, grad_x, sums4, stream);
-}
-
-int cnf_loss_grad_adaptive(cnf_handle* h, float t0, float t1, const float* x, const float* eps, const float* ys, int64_t B,
-                           float abstol, float reltol, float dt_init, int maxiters, const float* lambdas, float* grad,
-                           float* grad_x, float* sums4, cnf_solve_stats* stats, float* tgrid_out, int32_t grid_cap,
-                           void* stream) {
-    if (stats) *stats = cnf_solve_stats{};
-    int rc = check_call(h, eps, ys, B, "cnf_loss_grad_adaptive");
-    if (rc) return rc;
-    if (!x || !grad || !lambdas) return fail(CNF_ERR_INVALID, "cnf_loss_grad_adaptive: null x/grad/lambdas");
-    if (t0 == t1) return fail(CNF_ERR_INVALID, "cnf_loss_grad_adaptive: empty time span");
-    std::vector<float> grid;
-    if (B == 0) {   // nothing to step over: the fixed entry zeroes grad / sums4
-        return loss_grad_impl(h, "cnf_loss_grad_adaptive", CNF_ALG_TSIT5, 1, t0, t1, nullptr, x, eps, ys, B, lambdas, grad, grad_x, sums4, stream);
-    }
-    {
-        DeviceGuard g(h->cfg.device_id);
-        rc = ensure_adaptive_buf(h, B);
-        if (rc) return rc;
-        const size_t slot = (size_t)h->S * (size_t)h->ad_B;
-        float* u = h->ad_buf + 4 * slot;
-        HIP_TRY(assemble_u0(x, h->cfg.nvars, h->S, B, u, (hipStream_t)stream));
-        std::vector<double> steps;
-        rc = solve_tsit5_impl(h, t0, t1, u, eps, ys, B, abstol, reltol, dt_init, maxiters, u + slot, stats, &steps, stream);
-        if (rc) return rc;
-        double t = t0;
-        grid.push_back(t0);
-        for (double d : steps) { t += d; grid.push_back((float)t); }
-        grid.back() = t1;
-    }
-    if (tgrid_out)
-        for (size_t i = 0; i < grid.size() && (int64_t)i < grid_cap; ++i) tgrid_out[i] = grid[i];
-    return loss_grad_impl(h, "cnf_loss_grad_adaptive", CNF_ALG_TSIT5, (int)grid.size() - 1, 0.f, 0.f, grid.data(), x, eps, ys, B,
-                          lambdas, grad, grad_x, sums4, stream);
 }
 
 }  // extern "C"

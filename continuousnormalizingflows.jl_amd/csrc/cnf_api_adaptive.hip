@@ -1,0 +1,477 @@
+// cnf_api_adaptive.hip — the adaptive solves of the C ABI (include/cnf.h): cnf_step_embedded (one Tsit5 attempt),
+// cnf_vcabm_begin / _attempt / _accept / _state (the passes of the reference's default solver), and the whole solves
+// cnf_solve_vcabm / cnf_solve_tsit5 with the solvers' step-size (and order) policies restated on the host side.
+#include "cnf_handle.h"
+
+using namespace cnf;
+
+namespace {
+int fail(int code, const std::string& msg) { return cnf::api_fail(code, msg); }
+}  // namespace
+
+extern "C" {
+
+int cnf_step_embedded(cnf_handle* h, int alg, int flags, float t, float dt, const float* u, const float* eps,
+                      const float* ys, int64_t B, float abstol, float reltol, float* u_new, double* err_sumsq,
+                      void* stream) {
+    int rc = api_check_call(h, eps, ys, B, "cnf_step_embedded");
+    if (rc) return rc;
+    if (alg != CNF_ALG_TSIT5) return fail(CNF_ERR_INVALID, "cnf_step_embedded: the embedded pair is Tsit5 (alg = CNF_ALG_TSIT5)");
+    if (!(abstol >= 0.f) || !(reltol >= 0.f) || (abstol == 0.f && reltol == 0.f))
+        return fail(CNF_ERR_INVALID, "cnf_step_embedded: tolerances must be non-negative and not both zero");
+    if (B == 0) return CNF_OK;
+    if (!u || !u_new || !err_sumsq) return fail(CNF_ERR_INVALID, "cnf_step_embedded: null u/u_new/err_sumsq");
+    if (u == u_new) return fail(CNF_ERR_INVALID, "cnf_step_embedded: u_new may not alias u");
+    DeviceGuard g(h->cfg.device_id);
+    hipStream_t st = (hipStream_t)stream;
+    const size_t n = (size_t)h->S * (size_t)B;
+    if (B > h->ebuf_B) {
+        if (h->ebuf) HIP_TRY(hipFree(h->ebuf));
+        h->ebuf = nullptr; h->ebuf_B = 0;
+        HIP_TRY(hipMalloc((void**)&h->ebuf, 8 * n * sizeof(float)));
+        h->ebuf_B = B;
+        flags = 0;   // the cached stages went with the old buffer
+    }
+    if (!h->err_partial) HIP_TRY(hipMalloc((void**)&h->err_partial, kErrBlocks * sizeof(double)));
+    const size_t slot = (size_t)h->S * (size_t)h->ebuf_B;
+    float* stage = h->ebuf + 7 * slot;
+    if (flags & CNF_STEP_FSAL) { const int tmp = h->ek[0]; h->ek[0] = h->ek[6]; h->ek[6] = tmp; }
+    float* k[7];
+    for (int i = 0; i < 7; ++i) k[i] = h->ebuf + (size_t)h->ek[i] * slot;
+    const Tableau T = make_tableau(CNF_ALG_TSIT5);
+    // b - bhat of the embedded 4th-order solution (Tsitouras 2011); satisfies the order-4 conditions to 1e-15
+    static const float btilde[7] = {-0.00178001105222577714f, -0.0008164344596567469f, 0.007880878010261995f,
+                                    -0.1447110071732629f, 0.5823571654525552f, -0.45808210592918697f,
+                                    0.015151515151515152f};
+    if (h->path == CNF_PATH_MFMA && mfma_plan_is_per_wave(h->plan)) {
+        // fused attempt: the six stages and the update in ONE launch of the solve kernel (nsteps = 1), which also
+        // writes every stage derivative; then the 7th stage at u_new and the error reduction.  (The fused step
+        // evaluates its own first stage, so the FSAL / RETRY hints save nothing here; 3 launches instead of 14.)
+        for (int i = 0; i < 7; ++i) k[i] = h->ebuf + (size_t)i * n;   // [stage][B][S], packed for this B
+        SolveArgs a{};
+        a.u0 = u; a.eps = eps; a.ys = ys; a.B = B; a.nsteps = 1; a.alg = CNF_ALG_TSIT5; a.t0 = t; a.t1 = t + dt;
+        a.u_out = u_new; a.nvars = h->cfg.nvars; a.reg_aug = 0; a.kfull = h->ebuf;
+        HIP_TRY(mfma_solve(h->plan, h->packed_dev, a, st));
+        StageIn last{};
+        last.u = u_new; last.nprev = 0; last.dt = 0.f;
+        rc = api_eval_dynamics(h, last, t + dt, eps, ys, B, k[6], stage, false, st);
+        if (rc) return rc;
+        HIP_TRY(embedded_error(u, u_new, k, btilde, 7, dt, abstol, reltol, (int64_t)n, h->err_partial, err_sumsq, st));
+        return CNF_OK;
+    }
+    if (!(flags & (CNF_STEP_FSAL | CNF_STEP_RETRY))) {
+        StageIn in{};
+        in.u = u; in.nprev = 0; in.dt = 0.f;
+        rc = api_eval_dynamics(h, in, t, eps, ys, B, k[0], stage, true, st);
+        if (rc) return rc;
+    }
+    for (int i = 1; i < 6; ++i) {
+        StageIn in{};
+        in.u = u; in.nprev = i; in.dt = dt;
+        for (int j = 0; j < i; ++j) { in.k[j] = k[j]; in.coef[j] = T.a[i][j]; }
+        rc = api_eval_dynamics(h, in, t + T.c[i] * dt, eps, ys, B, k[i], stage, false, st);
+        if (rc) return rc;
+    }
+    StageIn fin{};
+    fin.u = u; fin.nprev = 6; fin.dt = dt;
+    for (int j = 0; j < 6; ++j) { fin.k[j] = k[j]; fin.coef[j] = T.b[j]; }
+    HIP_TRY(rk_update(u_new, fin, (int64_t)n, st));
+    StageIn last{};
+    last.u = u_new; last.nprev = 0; last.dt = 0.f;
+    rc = api_eval_dynamics(h, last, t + dt, eps, ys, B, k[6], stage, false, st);   // 7th stage = first stage of the next step
+    if (rc) return rc;
+    HIP_TRY(embedded_error(u, u_new, k, btilde, 7, dt, abstol, reltol, (int64_t)n, h->err_partial, err_sumsq, st));
+    return CNF_OK;
+}
+
+// ---- variable-step variable-order Adams PECE: the reference's default alg = VCABM() ----
+
+static inline float* vc_vec(cnf_handle* h, int i) { return h->vc_buf + (size_t)i * (size_t)h->S * (size_t)h->vc_B; }
+static inline float* vc_diffs(cnf_handle* h, int half) { return vc_vec(h, 6 + half * kVcSlots); }
+
+static int vc_check(cnf_handle* h, const float* eps, const float* ys, int64_t B, const char* who) {
+    int rc = api_check_call(h, eps, ys, B, who);
+    if (rc) return rc;
+    if (h->vc_B < 0 || B != h->vc_B) return fail(CNF_ERR_INVALID, std::string(who) + ": cnf_vcabm_begin was not called for this batch");
+    return CNF_OK;
+}
+
+int cnf_vcabm_begin(cnf_handle* h, float t0, const float* u0, const float* eps, const float* ys, int64_t B, void* stream) {
+    int rc = api_check_call(h, eps, ys, B, "cnf_vcabm_begin");
+    if (rc) return rc;
+    if (B > 0 && !u0) return fail(CNF_ERR_INVALID, "cnf_vcabm_begin: null u0");
+    DeviceGuard g(h->cfg.device_id);
+    hipStream_t st = (hipStream_t)stream;
+    if (B != h->vc_B) {
+        if (h->vc_buf) HIP_TRY(hipFree(h->vc_buf));
+        h->vc_buf = nullptr; h->vc_B = -1;
+        const size_t n = (size_t)h->S * (size_t)B;
+        if (n) HIP_TRY(hipMalloc((void**)&h->vc_buf, (6 + 2 * kVcSlots) * n * sizeof(float)));
+        h->vc_B = B;
+    }
+    if (!h->vc_partial) HIP_TRY(hipMalloc((void**)&h->vc_partial, (vcabm_partial_doubles() + 8) * sizeof(double)));   // + result slots of cnf_solve_vcabm
+    h->vc_iu = 0; h->vc_iun = 2; h->vc_if = 3; h->vc_ifn = 5; h->vc_cur = 0;
+    h->vc_nhist = 0; h->vc_k = 0; h->vc_avail = 0; h->vc_m = 0; h->vc_t = t0; h->vc_dt = 0.0;
+    for (double& d : h->vc_hist) d = 0.0;
+    if (B == 0) return CNF_OK;
+    const size_t n = (size_t)h->S * (size_t)B;
+    HIP_TRY(hipMemcpyAsync(vc_vec(h, h->vc_iu), u0, n * sizeof(float), hipMemcpyDeviceToDevice, st));
+    StageIn in{};
+    in.u = vc_vec(h, h->vc_iu); in.nprev = 0; in.dt = 0.f;
+    return api_eval_dynamics(h, in, t0, eps, ys, B, vc_vec(h, h->vc_if), nullptr, true, st);
+}
+
+int cnf_vcabm_attempt(cnf_handle* h, int order, float dt, const float* eps, const float* ys, int64_t B, float abstol,
+                      float reltol, double* err3, void* stream) {
+    int rc = vc_check(h, eps, ys, B, "cnf_vcabm_attempt");
+    if (rc) return rc;
+    if (order < 1 || order > CNF_VCABM_MAX_ORDER || order > h->vc_nhist + 1)
+        return fail(CNF_ERR_INVALID, "cnf_vcabm_attempt: order must be in 1..12 and at most one more than the accepted steps");
+    if (std::min(order, h->vc_nhist) > h->vc_avail)
+        return fail(CNF_ERR_INVALID, "cnf_vcabm_attempt: the order can rise by at most one per accepted step (the stored differences end there)");
+    if (!(abstol >= 0.f) || !(reltol >= 0.f) || (abstol == 0.f && reltol == 0.f))
+        return fail(CNF_ERR_INVALID, "cnf_vcabm_attempt: tolerances must be non-negative and not both zero");
+    if (dt == 0.f || !(dt == dt)) return fail(CNF_ERR_INVALID, "cnf_vcabm_attempt: dt must be non-zero");
+    if (B == 0) return CNF_OK;
+    if (!err3) return fail(CNF_ERR_INVALID, "cnf_vcabm_attempt: null err3");
+    DeviceGuard g(h->cfg.device_id);
+    hipStream_t st = (hipStream_t)stream;
+    const int k = order;
+    const int m = std::min(k + 1, h->vc_nhist + 1);
+    // step sizes newest first, the candidate in front (Hairer, Noersett, Wanner I, III.5: t_{n+1} - t_{n-j+1} = sum of the j newest)
+    double dts[kVcSlots + 2];
+    dts[0] = dt;
+    for (int i = 0; i <= kVcSlots; ++i) dts[i + 1] = h->vc_hist[i];
+    VcCoef c{};
+    c.ps_old = vc_diffs(h, h->vc_cur);
+    c.ps_new = vc_diffs(h, h->vc_cur ^ 1);
+    c.ld = (size_t)h->S * (size_t)B;
+    c.k = k; c.m = m; c.dt = dt;
+    double beta = 1.0, num = 0.0, den = 0.0;
+    c.beta[0] = 1.f;
+    for (int j = 1; j < m; ++j) {       // beta_j = beta_{j-1} (t_{n+1} - t_{n-j+1}) / (t_n - t_{n-j})
+        num += dts[j - 1];
+        den += dts[j];
+        beta *= num / den;
+        c.beta[j] = (float)beta;
+    }
+    // g_j = c_{j,1};  c_{0,q} = 1/q,  c_{1,q} = 1/(q(q+1)),  c_{j,q} = c_{j-1,q} - c_{j-1,q+1} dt / (t_{n+1} - t_{n-j+1})
+    double cq[kVcSlots + 3], gd[kVcSlots + 1];
+    const int ng = k + 1;
+    gd[0] = 1.0;
+    for (int q = 1; q <= ng; ++q) cq[q - 1] = 1.0 / ((double)q * (double)(q + 1));
+    double xi = dts[0];
+    for (int j = 1; j < ng; ++j) {
+        if (j > 1) {
+            xi += dts[j - 1];
+            for (int q = 0; q < ng - j + 1; ++q) cq[q] = cq[q] - cq[q + 1] * (double)dt / xi;
+        }
+        gd[j] = cq[0];
+    }
+    for (int j = 0; j < ng; ++j) c.g[j] = (float)gd[j];
+    c.e0 = (float)((double)dt * (gd[k] - gd[k - 1]));
+    c.e1 = k >= 2 ? (float)((double)dt * (gd[k - 1] - gd[k - 2])) : 0.f;
+    c.e2 = k >= 3 ? (float)((double)dt * (gd[k - 2] - gd[k - 3])) : 0.f;
+    const int64_t n = (int64_t)c.ld;
+    float *u = vc_vec(h, h->vc_iu), *p = vc_vec(h, 1), *un = vc_vec(h, h->vc_iun), *d = vc_vec(h, 4);
+    HIP_TRY(vcabm_predict(vc_vec(h, h->vc_if), u, c, n, p, st));                                    // P
+    StageIn in{};
+    in.u = p; in.nprev = 0; in.dt = 0.f;
+    rc = api_eval_dynamics(h, in, (float)(h->vc_t + (double)dt), eps, ys, B, d, nullptr, false, st);   // E
+    if (rc) return rc;
+    HIP_TRY(vcabm_correct(d, p, u, c, abstol, reltol, n, un, h->vc_partial, err3, st));             // C
+    h->vc_k = k; h->vc_m = m; h->vc_dt = dt;
+    return CNF_OK;
+}
+
+int cnf_vcabm_accept(cnf_handle* h, const float* eps, const float* ys, int64_t B, float abstol, float reltol,
+                     double* err_up, void* stream) {
+    int rc = vc_check(h, eps, ys, B, "cnf_vcabm_accept");
+    if (rc) return rc;
+    if (B == 0) return CNF_OK;
+    if (h->vc_k == 0) return fail(CNF_ERR_INVALID, "cnf_vcabm_accept: no pending attempt");
+    const int k = h->vc_k;
+    if (err_up && (k >= CNF_VCABM_MAX_ORDER || h->vc_nhist < k))
+        return fail(CNF_ERR_INVALID, "cnf_vcabm_accept: the order k+1 estimate needs k accepted steps and k < 12");
+    DeviceGuard g(h->cfg.device_id);
+    hipStream_t st = (hipStream_t)stream;
+    const size_t n = (size_t)h->S * (size_t)B;
+    float *u = vc_vec(h, h->vc_iu), *un = vc_vec(h, h->vc_iun), *fnew = vc_vec(h, h->vc_ifn);
+    StageIn in{};
+    in.u = un; in.nprev = 0; in.dt = 0.f;
+    rc = api_eval_dynamics(h, in, (float)(h->vc_t + h->vc_dt), eps, ys, B, fnew, nullptr, false, st);   // E
+    if (rc) return rc;
+    if (err_up) {
+        // gamma*_j of the Adams-Moulton family: sum_{i<=j} gamma*_i / (j - i + 1) = [j == 0]
+        double gs[kVcSlots + 2];
+        gs[0] = 1.0;
+        for (int j = 1; j <= k + 1; ++j) {
+            double a = 0.0;
+            for (int i = 0; i < j; ++i) a += gs[i] / (double)(j - i + 1);
+            gs[j] = -a;
+        }
+        VcCoef c{};
+        c.ps_new = vc_diffs(h, h->vc_cur ^ 1);
+        c.ld = n; c.k = k;
+        c.e0 = (float)(h->vc_dt * gs[k + 1]);
+        HIP_TRY(vcabm_errup(fnew, u, un, c, abstol, reltol, (int64_t)n, h->vc_partial, err_up, st));
+    }
+    std::swap(h->vc_iu, h->vc_iun);
+    std::swap(h->vc_if, h->vc_ifn);
+    h->vc_cur ^= 1;
+    for (int i = kVcSlots; i > 0; --i) h->vc_hist[i] = h->vc_hist[i - 1];
+    h->vc_hist[0] = h->vc_dt;
+    h->vc_t += h->vc_dt;
+    h->vc_nhist += 1;
+    h->vc_avail = h->vc_m;
+    h->vc_k = 0;
+    return CNF_OK;
+}
+
+int cnf_vcabm_state(cnf_handle* h, int64_t B, float* u_out, double* t_out, void* stream) {
+    if (!h) return fail(CNF_ERR_INVALID, "cnf_vcabm_state: null handle");
+    if (h->vc_B < 0 || B != h->vc_B) return fail(CNF_ERR_INVALID, "cnf_vcabm_state: cnf_vcabm_begin was not called for this batch");
+    if (t_out) *t_out = h->vc_t;
+    if (u_out && B > 0) {
+        DeviceGuard g(h->cfg.device_id);
+        HIP_TRY(hipMemcpyAsync(u_out, vc_vec(h, h->vc_iu), (size_t)h->S * (size_t)B * sizeof(float), hipMemcpyDeviceToDevice,
+                               (hipStream_t)stream));
+    }
+    return CNF_OK;
+}
+
+// The whole default solve in one call: cnf_vcabm_begin / _attempt / _accept driven by the step-size and order policy of
+// icnf._vcabm_integrate (the host side of the reference's solver), restated here so that a single-process caller pays one
+// library call per solve instead of two per step.  Synchronises `stream` (the policy reads the error sums).
+int cnf_solve_vcabm(cnf_handle* h, float t0, float t1, const float* u0, const float* eps, const float* ys, int64_t B,
+                    float abstol, float reltol, float dt_init, int maxiters, float* u1, cnf_solve_stats* stats,
+                    float* dts_out, int32_t* orders_out, int32_t record_cap, void* stream) {
+    if (stats) *stats = cnf_solve_stats{};
+    int rc = cnf_vcabm_begin(h, t0, u0, eps, ys, B, stream);
+    if (rc) return rc;
+    if (!(abstol >= 0.f) || !(reltol >= 0.f) || (abstol == 0.f && reltol == 0.f))
+        return fail(CNF_ERR_INVALID, "cnf_solve_vcabm: tolerances must be non-negative and not both zero");
+    if (B > 0 && !u1) return fail(CNF_ERR_INVALID, "cnf_solve_vcabm: null u1");
+    if (maxiters < 1) return fail(CNF_ERR_INVALID, "cnf_solve_vcabm: maxiters >= 1 required");
+    int nf = B > 0 ? 1 : 0, naccept = 0, nreject = 0, max_order = 0;
+    const double span = std::fabs((double)t1 - (double)t0), tdir = t1 >= t0 ? 1.0 : -1.0;
+    if (B == 0 || span == 0.0) {
+        if (B > 0) return cnf_vcabm_state(h, B, u1, nullptr, stream);
+        return CNF_OK;
+    }
+    DeviceGuard g(h->cfg.device_id);
+    hipStream_t st = (hipStream_t)stream;
+    const size_t n = (size_t)h->S * (size_t)B;
+    const double ntot = (double)n;
+    double* res = h->vc_partial + vcabm_partial_doubles();   // device result slots
+    double host[4];
+    auto fetch = [&](int cnt) -> int {
+        HIP_TRY(hipMemcpyAsync(host, res, cnt * sizeof(double), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        return CNF_OK;
+    };
+    double dt;
+    if (dt_init != 0.f) {
+        dt = std::min((double)std::fabs(dt_init), span);
+    } else {   // ode_determine_initdt (Hairer, Noersett, Wanner I, II.4) with the algorithm order 7, RMS norm over all S*B entries
+        float *u = vc_vec(h, h->vc_iu), *f0 = vc_vec(h, h->vc_if), *ue = vc_vec(h, 1), *f1 = vc_vec(h, 4);
+        HIP_TRY(vcabm_scaled_sumsq(u, nullptr, u, abstol, reltol, (int64_t)n, h->vc_partial, res, st));
+        HIP_TRY(vcabm_scaled_sumsq(f0, nullptr, u, abstol, reltol, (int64_t)n, h->vc_partial, res + 1, st));
+        rc = fetch(2);
+        if (rc) return rc;
+        const double d0 = std::sqrt(host[0] / ntot), d1 = std::sqrt(host[1] / ntot);
+        double h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
+        h0 = std::min(h0, span);
+        StageIn eu{};
+        eu.u = u; eu.nprev = 1; eu.k[0] = f0; eu.coef[0] = 1.f; eu.dt = (float)(tdir * h0);
+        HIP_TRY(rk_update(ue, eu, (int64_t)n, st));
+        StageIn in{};
+        in.u = ue; in.nprev = 0; in.dt = 0.f;
+        rc = api_eval_dynamics(h, in, (float)((double)t0 + tdir * h0), eps, ys, B, f1, nullptr, false, st);
+        if (rc) return rc;
+        ++nf;
+        HIP_TRY(vcabm_scaled_sumsq(f1, f0, u, abstol, reltol, (int64_t)n, h->vc_partial, res, st));
+        rc = fetch(1);
+        if (rc) return rc;
+        const double d2 = std::sqrt(host[0] / ntot) / h0, dmax = std::max(d1, d2);
+        const double h1 = dmax <= 1e-15 ? std::max(1e-6, h0 * 1e-3) : std::pow(10.0, -(2.0 + std::log10(dmax)) / 8.0);
+        dt = std::min(std::min(100.0 * h0, h1), span);
+        if (!(std::isfinite(dt) && dt > 0.0)) return fail(CNF_ERR_INVALID, "cnf_solve_vcabm: non-finite state or dynamics at t0 (no initial step)");
+    }
+    const double gamma = 0.9, qmin = 0.2, qmax = 10.0;
+    double t = t0;
+    int k = 1, step = 1, it = 0;
+    for (; it < maxiters; ++it) {
+        if (std::fabs((double)t1 - t) <= 1e-7 * std::max(1.0, span)) break;
+        const bool last = dt >= std::fabs((double)t1 - t) * (1.0 - 1e-6);
+        const double hstep = last ? std::fabs((double)t1 - t) : dt;     // tstop: never step over t1
+        rc = cnf_vcabm_attempt(h, k, (float)(tdir * hstep), eps, ys, B, abstol, reltol, res, stream);
+        if (rc) return rc;
+        ++nf;
+        rc = fetch(3);
+        if (rc) return rc;
+        double eest = std::sqrt(host[0] / ntot);
+        if (!std::isfinite(eest)) return fail(CNF_ERR_INVALID, "cnf_solve_vcabm: non-finite error estimate (unstable dynamics)");
+        if (eest > 1.0) {   // reject: same state, smaller step, same order
+            ++nreject;
+            dt = hstep / std::max(1.0 / qmax, std::min(1.0 / qmin, std::pow(eest, 1.0 / (k + 1)) / gamma));
+            continue;
+        }
+        const bool select = step > 4 && k >= 3;
+        const bool lower = select && std::max(std::sqrt(host[2] / ntot), std::sqrt(host[1] / ntot)) <= eest;
+        const bool want_up = select && !lower && k < CNF_VCABM_MAX_ORDER;
+        rc = cnf_vcabm_accept(h, eps, ys, B, abstol, reltol, want_up ? res : nullptr, stream);
+        if (rc) return rc;
+        ++nf;
+        int knew = k;
+        if (!select) knew = std::min(k + 1, 3);
+        else if (lower) knew = k - 1;
+        else if (want_up) {
+            rc = fetch(1);
+            if (rc) return rc;
+            if (std::sqrt(host[0] / ntot) < eest) { knew = k + 1; eest = 1.0; }
+        }
+        const double q = eest == 0.0 ? 1.0 / qmax : std::max(1.0 / qmax, std::min(1.0 / qmin, std::pow(eest, 1.0 / (knew + 1)) / gamma));
+        t = last ? (double)t1 : t + tdir * hstep;
+        if (naccept < record_cap) {
+            if (dts_out) dts_out[naccept] = (float)(tdir * hstep);
+            if (orders_out) orders_out[naccept] = k;
+        }
+        ++naccept;
+        if (k > max_order) max_order = k;
+        k = knew; ++step;
+        dt = hstep / q;
+    }
+    if (stats) { stats->naccept = naccept; stats->nreject = nreject; stats->nf = nf; stats->max_order = max_order; }
+    if (it == maxiters) return fail(CNF_ERR_INVALID, "cnf_solve_vcabm: maxiters reached");
+    return cnf_vcabm_state(h, B, u1, nullptr, stream);
+}
+
+// Adaptive Tsit5 from t0 to t1 in one call: cnf_step_embedded attempts under OrdinaryDiffEq's PI controller - the loop of
+// icnf._adaptive_integrate restated inside the library (single process).  Synchronises `stream`.
+extern "C++" {
+int cnf::api_ensure_adaptive_buf(cnf_handle* h, int64_t B) {
+    if (B <= h->ad_B) return CNF_OK;
+    if (h->ad_buf) HIP_TRY(hipFree(h->ad_buf));
+    h->ad_buf = nullptr; h->ad_B = 0;
+    HIP_TRY(hipMalloc((void**)&h->ad_buf, 6 * (size_t)h->S * (size_t)B * sizeof(float)));   // 4 for the solve, 2 for cnf_loss_grad_adaptive
+    h->ad_B = B;
+    return CNF_OK;
+}
+}  // extern "C++"
+
+extern "C++" {
+int cnf::api_solve_tsit5(cnf_handle* h, float t0, float t1, const float* u0, const float* eps, const float* ys, int64_t B,
+                         float abstol, float reltol, float dt_init, int maxiters, float* u1, cnf_solve_stats* stats,
+                         std::vector<double>* steps, void* stream) {
+    if (stats) *stats = cnf_solve_stats{};
+    int rc = api_check_call(h, eps, ys, B, "cnf_solve_tsit5");
+    if (rc) return rc;
+    if (!(abstol >= 0.f) || !(reltol >= 0.f) || (abstol == 0.f && reltol == 0.f))
+        return fail(CNF_ERR_INVALID, "cnf_solve_tsit5: tolerances must be non-negative and not both zero");
+    if (B > 0 && (!u0 || !u1)) return fail(CNF_ERR_INVALID, "cnf_solve_tsit5: null u0/u1");
+    if (maxiters < 1) return fail(CNF_ERR_INVALID, "cnf_solve_tsit5: maxiters >= 1 required");
+    if (B == 0) return CNF_OK;
+    DeviceGuard g(h->cfg.device_id);
+    hipStream_t st = (hipStream_t)stream;
+    const size_t n = (size_t)h->S * (size_t)B;
+    const double span = std::fabs((double)t1 - (double)t0), tdir = t1 >= t0 ? 1.0 : -1.0, ntot = (double)n;
+    if (span == 0.0) {
+        if (u1 != u0) HIP_TRY(hipMemcpyAsync(u1, u0, n * sizeof(float), hipMemcpyDeviceToDevice, st));
+        return CNF_OK;
+    }
+    rc = api_ensure_adaptive_buf(h, B);
+    if (rc) return rc;
+    if (!h->vc_partial) HIP_TRY(hipMalloc((void**)&h->vc_partial, (vcabm_partial_doubles() + 8) * sizeof(double)));
+    const size_t slot = (size_t)h->S * (size_t)h->ad_B;
+    float *ua = h->ad_buf, *ub = ua + slot, *f0 = ub + slot, *f1 = f0 + slot;
+    HIP_TRY(hipMemcpyAsync(ua, u0, n * sizeof(float), hipMemcpyDeviceToDevice, st));
+    double* res = h->vc_partial + vcabm_partial_doubles();
+    double host[2];
+    auto fetch = [&](int cnt) -> int {
+        HIP_TRY(hipMemcpyAsync(host, res, cnt * sizeof(double), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        return CNF_OK;
+    };
+    int nf = 0, naccept = 0, nreject = 0;
+    double dt;
+    if (dt_init != 0.f) {
+        dt = std::min((double)std::fabs(dt_init), span);
+    } else {   // ode_determine_initdt (Hairer, Noersett, Wanner I, II.4), order 5
+        StageIn in{};
+        in.u = ua; in.nprev = 0; in.dt = 0.f;
+        rc = api_eval_dynamics(h, in, t0, eps, ys, B, f0, nullptr, true, st);
+        if (rc) return rc;
+        ++nf;
+        HIP_TRY(vcabm_scaled_sumsq(ua, nullptr, ua, abstol, reltol, (int64_t)n, h->vc_partial, res, st));
+        HIP_TRY(vcabm_scaled_sumsq(f0, nullptr, ua, abstol, reltol, (int64_t)n, h->vc_partial, res + 1, st));
+        rc = fetch(2);
+        if (rc) return rc;
+        const double d0 = std::sqrt(host[0] / ntot), d1 = std::sqrt(host[1] / ntot);
+        double h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
+        h0 = std::min(h0, span);
+        if (!(std::isfinite(h0) && h0 > 0.0)) return fail(CNF_ERR_INVALID, "cnf_solve_tsit5: non-finite state or dynamics at t0 (no initial step)");
+        StageIn eu{};
+        eu.u = ua; eu.nprev = 1; eu.k[0] = f0; eu.coef[0] = 1.f; eu.dt = (float)(tdir * h0);
+        HIP_TRY(rk_update(ub, eu, (int64_t)n, st));
+        StageIn in1{};
+        in1.u = ub; in1.nprev = 0; in1.dt = 0.f;
+        rc = api_eval_dynamics(h, in1, (float)((double)t0 + tdir * h0), eps, ys, B, f1, nullptr, false, st);
+        if (rc) return rc;
+        ++nf;
+        HIP_TRY(vcabm_scaled_sumsq(f1, f0, ua, abstol, reltol, (int64_t)n, h->vc_partial, res, st));
+        rc = fetch(1);
+        if (rc) return rc;
+        const double d2 = std::sqrt(host[0] / ntot) / h0, dmax = std::max(d1, d2);
+        const double h1 = dmax <= 1e-15 ? std::max(1e-6, h0 * 1e-3) : std::pow(10.0, -(2.0 + std::log10(dmax)) / 5.0);
+        dt = std::min(std::min(100.0 * h0, h1), span);
+        if (!(std::isfinite(dt) && dt > 0.0)) return fail(CNF_ERR_INVALID, "cnf_solve_tsit5: non-finite state or dynamics at t0 (no initial step)");
+    }
+    const double beta1 = 7.0 / 50.0, beta2 = 2.0 / 25.0, gamma = 0.9, qmin = 0.2, qmax = 10.0;
+    double qold = 1e-4, t = t0;
+    int flags = 0, it = 0;
+    for (; it < maxiters; ++it) {
+        if (std::fabs((double)t1 - t) <= 1e-7 * std::max(1.0, span)) break;
+        const bool last = dt >= std::fabs((double)t1 - t) * (1.0 - 1e-6);
+        const double step = last ? std::fabs((double)t1 - t) : dt;     // tstop: never step over t1
+        rc = cnf_step_embedded(h, CNF_ALG_TSIT5, flags, (float)t, (float)(tdir * step), ua, eps, ys, B, abstol, reltol, ub, res, stream);
+        if (rc) return rc;
+        nf += flags ? 6 : 7;
+        rc = fetch(1);
+        if (rc) return rc;
+        const double eest = std::sqrt(host[0] / ntot);
+        if (!std::isfinite(eest)) return fail(CNF_ERR_INVALID, "cnf_solve_tsit5: non-finite error estimate (unstable dynamics)");
+        const double q11 = eest > 0.0 ? std::pow(eest, beta1) : 0.0;
+        const double q = eest == 0.0 ? 1.0 / qmax : std::max(1.0 / qmax, std::min(1.0 / qmin, (q11 / std::pow(qold, beta2)) / gamma));
+        if (eest <= 1.0) {   // accept
+            t = last ? (double)t1 : t + tdir * step;
+            std::swap(ua, ub);
+            if (steps) steps->push_back(tdir * step);
+            ++naccept;
+            qold = std::max(eest, 1e-4);
+            dt = step / q;
+            flags = CNF_STEP_FSAL;
+        } else {             // reject: same (t, u), smaller step
+            ++nreject;
+            dt = step / std::min(1.0 / qmin, q11 / gamma);
+            flags = CNF_STEP_RETRY;
+        }
+    }
+    if (stats) { stats->naccept = naccept; stats->nreject = nreject; stats->nf = nf; stats->max_order = 5; }
+    if (it == maxiters) return fail(CNF_ERR_INVALID, "cnf_solve_tsit5: maxiters reached");
+    HIP_TRY(hipMemcpyAsync(u1, ua, n * sizeof(float), hipMemcpyDeviceToDevice, st));
+    return CNF_OK;
+}
+}  // extern "C++"
+
+int cnf_solve_tsit5(cnf_handle* h, float t0, float t1, const float* u0, const float* eps, const float* ys, int64_t B,
+                    float abstol, float reltol, float dt_init, int maxiters, float* u1, cnf_solve_stats* stats,
+                    float* dts_out, int32_t record_cap, void* stream) {
+    std::vector<double> steps;
+    const int rc = api_solve_tsit5(h, t0, t1, u0, eps, ys, B, abstol, reltol, dt_init, maxiters, u1, stats, &steps, stream);
+    if (dts_out)
+        for (size_t i = 0; i < steps.size() && (int64_t)i < record_cap; ++i) dts_out[i] = (float)steps[i];
+    return rc;
+}
+
+}  // extern "C"

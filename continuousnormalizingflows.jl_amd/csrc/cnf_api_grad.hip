@@ -1,0 +1,268 @@
+// cnf_api_grad.hip — the gradient entry points of the C ABI (include/cnf.h): cnf_loss_grad_fixed / _grid / _adaptive and
+// cnf_grad_path, over the three implementations (register-accumulator and several-probe kernels, slab-accumulator kernel,
+// layer-wise path) - which one serves a handle, their workspaces, the checkpointing forward pass.
+#include "cnf_handle.h"
+
+using namespace cnf;
+
+namespace {
+int fail(int code, const std::string& msg) { return cnf::api_fail(code, msg); }
+}  // namespace
+
+// The configuration the fused gradient kernels are selected and packed for.  TestMode (exact trace): -tr J is the sum over
+// the D unit vectors e_k of -e_k^T J e_k, i.e. the several-probe reverse sweep with K = D one-hot probes of weight 1 and no
+// regularisers (up to the kernel's probe capacity; wider states take the layer-wise path).
+cnf_config cnf::api_grad_cfg(const cnf_handle* h) {
+    cnf_config c = h->cfg;
+    if (c.mode == CNF_MODE_EXACT) {
+        c.mode = CNF_MODE_HUTCH_VJP;
+        c.nprobes = h->D;
+        c.reg_z = c.reg_j = c.reg_aug = 0;
+        if (h->D > 8) c.nprobes = 0;   // no fused instance: grad_supported() rejects nprobes < 1
+    }
+    return c;
+}
+
+__global__ void unit_probes_kernel(float* __restrict__ eps, int D, long long B) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long DD = (long long)D * D;
+    if (i >= DD * B) return;
+    const int r = (int)(i % DD);
+    eps[i] = (r / D) == (r % D) ? 1.f : 0.f;   // probe k = rows k D .. k D + D - 1 of the column: e_k
+}
+
+extern "C" {
+
+// fused reverse-sweep kernel, unless CNF_GRAD_LAYERED=1 forces the layer-wise path (tests, A/B timing)
+extern "C++" {
+bool cnf::api_grad_is_fused(const cnf_handle* h) {
+    const char* force = getenv("CNF_GRAD_LAYERED");
+    return h->path == CNF_PATH_MFMA && grad_supported(api_grad_cfg(h)) && mfma_plan_is_per_wave(h->plan) &&
+           !(force && *force && *force != '0');
+}
+}  // extern "C++"
+
+// slab-accumulator kernel for the mid-width two-hidden-layer nets (CNF_GRAD_LAYERED=1 skips it too)
+extern "C++" {
+bool cnf::api_grad_uses_slab(const cnf_handle* h) {
+    const char* force = getenv("CNF_GRAD_LAYERED");
+    return (h->slab_packed || !h->have_params) && grad_slab_supported(h->cfg) && !(force && *force && *force != '0');
+}
+}  // extern "C++"
+
+int cnf_grad_path(const cnf_handle* h) {
+    if (!h) return CNF_ERR_INVALID;
+    if (api_grad_is_fused(h) || api_grad_uses_slab(h)) return 1;
+    return layered_grad_supported(h->cfg) ? 2 : 0;
+}
+
+}  // extern "C"
+
+// loss sums + gradient on a uniform grid (tgrid == nullptr: nsteps steps from t0 to t1) or on the caller's non-uniform
+// grid (tgrid: host, nsteps + 1 times; t0 / t1 ignored).  The same three gradient implementations serve both.
+static int loss_grad_impl(cnf_handle* h, const char* who, int alg, int nsteps, float t0, float t1, const float* tgrid,
+                          const float* x, const float* eps, const float* ys, int64_t B, const float* lambdas,
+                          float* grad, float* grad_x, float* sums4, void* stream) {
+    int rc = api_check_call(h, eps, ys, B, who);
+    if (rc) return rc;
+    const std::string w(who);
+    if (nsteps < 1) return fail(CNF_ERR_INVALID, w + ": nsteps >= 1 required");
+    if (alg != CNF_ALG_RK4 && alg != CNF_ALG_TSIT5) return fail(CNF_ERR_INVALID, w + ": unknown alg");
+    if (!x || !grad || !lambdas) return fail(CNF_ERR_INVALID, w + ": null x/grad/lambdas");
+    const bool fused = api_grad_is_fused(h) && h->grad_packed;
+    if (!fused && !layered_grad_supported(h->cfg))
+        return fail(CNF_ERR_UNSUPPORTED, w + ": no gradient path for this configuration");
+    DeviceGuard g(h->cfg.device_id);
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipMemsetAsync(grad, 0, h->nparams * sizeof(float), st));
+    if (B == 0) {
+        if (sums4) HIP_TRY(hipMemsetAsync(sums4, 0, 4 * sizeof(float), st));
+        return CNF_OK;
+    }
+    const float* tgrid_dev = nullptr;
+    if (tgrid) {   // the fused kernels read the step times from device memory (uniform loads, once per step)
+        t0 = tgrid[0]; t1 = tgrid[nsteps];
+        if ((size_t)nsteps + 1 > h->tgrid_cap) {
+            if (h->tgrid_dev) HIP_TRY(hipFree(h->tgrid_dev));
+            h->tgrid_dev = nullptr; h->tgrid_cap = 0;
+            const size_t cap = ((size_t)nsteps + 1 + 63) / 64 * 64;
+            HIP_TRY(hipMalloc((void**)&h->tgrid_dev, cap * sizeof(float)));
+            h->tgrid_cap = cap;
+        }
+        HIP_TRY(hipMemcpyAsync(h->tgrid_dev, tgrid, ((size_t)nsteps + 1) * sizeof(float), hipMemcpyHostToDevice, st));
+        tgrid_dev = h->tgrid_dev;
+    }
+    if (!fused) {
+        // the loss sums come from the regular solve on whichever family serves the handle
+        if (sums4) {
+            const size_t need = ((size_t)h->S + 4) * (size_t)B * sizeof(float);
+            if (need > h->grad_ws_bytes) {
+                if (h->grad_ws) HIP_TRY(hipFree(h->grad_ws));
+                h->grad_ws = nullptr; h->grad_ws_bytes = 0;
+                HIP_TRY(hipMalloc((void**)&h->grad_ws, need));
+                h->grad_ws_bytes = need;
+            }
+            float* logp = h->grad_ws;
+            float* regs = logp + B;
+            if (tgrid) {   // the loss of the same discrete solve: augmented state advanced over the grid, then the epilogue
+                float* u = regs + 3 * (size_t)B;
+                const int ra0 = (h->cfg.mode != CNF_MODE_EXACT && h->cfg.reg_aug && h->cfg.naug > 0) ? 1 : 0;
+                HIP_TRY(assemble_u0(x, h->cfg.nvars, h->S, B, u, st));
+                rc = api_integrate_grid(h, alg, nsteps, tgrid, u, eps, ys, B, st);
+                if (rc) return rc;
+                HIP_TRY(epilogue(u, h->cfg.nvars, h->D, ra0, B, logp, regs, st));
+            } else {
+                rc = cnf_inference_fixed(h, alg, nsteps, t0, t1, x, eps, ys, B, logp, regs, nullptr, stream);
+                if (rc) return rc;
+            }
+            if (!h->loss_partial) HIP_TRY(hipMalloc((void**)&h->loss_partial, 256 * 4 * sizeof(float)));
+            HIP_TRY(loss_sums(logp, regs, B, h->loss_partial, sums4, st));
+        }
+        const bool hutch = h->cfg.mode != CNF_MODE_EXACT;   // the exact-trace dynamics carry no regularisers (icnf.jl:297-339)
+        const int ra = (hutch && h->cfg.reg_aug && h->cfg.naug > 0) ? 1 : 0;
+        const float lam[3] = {hutch && h->cfg.reg_z ? lambdas[0] : 0.f, hutch && h->cfg.reg_j ? lambdas[1] : 0.f, ra ? lambdas[2] : 0.f};
+        if (api_grad_uses_slab(h)) {
+            // two-hidden-layer nets of 4..7 hidden tiles: tile-fused reverse sweep with slab accumulators (cnf_grad_slab.hip)
+            if (h->num_cus == 0) {
+                hipDeviceProp_t prop;
+                HIP_TRY(hipGetDeviceProperties(&prop, h->cfg.device_id));
+                h->num_cus = prop.multiProcessorCount;
+            }
+            const size_t need = grad_slab_ws_floats(h->cfg, alg, nsteps, B, h->num_cus);
+            if (need > h->slab_ws_floats) {
+                if (h->slab_ws) HIP_TRY(hipFree(h->slab_ws));
+                h->slab_ws = nullptr; h->slab_ws_floats = 0;
+                HIP_TRY(hipMalloc((void**)&h->slab_ws, need * sizeof(float)));
+                h->slab_ws_floats = need;
+            }
+            HIP_TRY(grad_slab_launch(h->cfg, h->slab_packed, x, eps, ys, h->w_off.data(), h->b_off.data(), alg, nsteps, t0, t1, tgrid_dev, B, lam,
+                                     h->slab_ws, grad, grad_x, h->num_cus, st));
+            return CNF_OK;
+        }
+        std::string msg;
+        hipError_t e = layered_grad(&h->layered, h->cfg, h->P_dev, h->w_off.data(), h->b_off.data(), x, eps, ys, alg, nsteps,
+                                    t0, t1, tgrid, B, lam, grad, grad_x, st, &msg);
+        if (e == hipErrorNotSupported) return fail(CNF_ERR_UNSUPPORTED, w + ": " + msg);
+        if (e != hipSuccess) return fail(CNF_ERR_HIP, w + ": " + msg);
+        return CNF_OK;
+    }
+    if (h->num_cus == 0) {
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, h->cfg.device_id));
+        h->num_cus = prop.multiProcessorCount;
+    }
+    const long long ntiles = (B + 15) / 16;
+    const int ckpt_zr = mfma_plan_zr(h->plan);
+    const int nstages = alg == CNF_ALG_RK4 ? 4 : 6;
+    const size_t ckpt_z_floats = (size_t)(nsteps + 1) * (size_t)ntiles * 64 * (size_t)ckpt_zr;
+    const size_t ckpt_k_floats = (size_t)nsteps * nstages * (size_t)ntiles * 64 * (size_t)ckpt_zr;
+    const size_t ckpt_floats = ckpt_z_floats + ckpt_k_floats;
+    const cnf_config gc = api_grad_cfg(h);
+    const bool exact = h->cfg.mode == CNF_MODE_EXACT;
+    const size_t slab_floats = grad_slab_floats(gc, h->num_cus);
+    const size_t state_floats = tgrid ? 2 * (size_t)h->S * (size_t)B : 0;   // ping-pong states of the step-by-step forward pass
+    const size_t unit_floats = exact ? (size_t)h->D * (size_t)h->D * (size_t)B : 0;   // the D unit probes of every column
+    const size_t need = (ckpt_floats + 4 * (size_t)B + slab_floats + state_floats + unit_floats) * sizeof(float);
+    if (need > h->grad_ws_bytes) {
+        if (h->grad_ws) HIP_TRY(hipFree(h->grad_ws));
+        h->grad_ws = nullptr; h->grad_ws_bytes = 0;
+        HIP_TRY(hipMalloc((void**)&h->grad_ws, need));
+        h->grad_ws_bytes = need;
+    }
+    float* ckpt = h->grad_ws;
+    float* ckpt_k = ckpt + ckpt_z_floats;
+    float* logp = ckpt + ckpt_floats;
+    float* regs = logp + B;
+    float* slab = regs + 3 * (size_t)B;
+    const int reg_aug = (!exact && h->cfg.reg_aug && h->cfg.naug > 0) ? 1 : 0;
+    if (!tgrid) {
+        SolveArgs a{};
+        a.x = x; a.eps = eps; a.ys = ys; a.B = B; a.nsteps = nsteps; a.alg = alg; a.t0 = t0; a.t1 = t1;
+        a.logp = logp; a.regs = regs; a.nvars = h->cfg.nvars; a.reg_aug = reg_aug; a.ckpt = ckpt; a.ckpt_k = ckpt_k;
+        HIP_TRY(mfma_solve(h->plan, h->packed_dev, a, st));
+    } else {
+        // non-uniform grid: the checkpointing forward pass is one launch of the (unchanged) solve kernel per step - the metric
+        // kernel keeps its loop-invariant step size; step n writes checkpoint slots n and n + 1 and its stage derivatives
+        float* ua = slab + slab_floats;
+        float* ub = ua + (size_t)h->S * (size_t)B;
+        HIP_TRY(assemble_u0(x, h->cfg.nvars, h->S, B, ua, st));
+        const size_t zslot = (size_t)ntiles * 64 * (size_t)ckpt_zr;
+        for (int n = 0; n < nsteps; ++n) {
+            SolveArgs a{};
+            a.u0 = ua; a.u_out = ub; a.eps = eps; a.ys = ys; a.B = B; a.nsteps = 1; a.alg = alg; a.t0 = tgrid[n]; a.t1 = tgrid[n + 1];
+            a.nvars = h->cfg.nvars; a.reg_aug = reg_aug;
+            a.ckpt = ckpt + (size_t)n * zslot; a.ckpt_k = ckpt_k + (size_t)n * nstages * zslot;
+            if (n == nsteps - 1) { a.logp = logp; a.regs = regs; }
+            HIP_TRY(mfma_solve(h->plan, h->packed_dev, a, st));
+            float* tmp = ua; ua = ub; ub = tmp;
+        }
+    }
+    if (sums4) {
+        if (!h->loss_partial) HIP_TRY(hipMalloc((void**)&h->loss_partial, 256 * 4 * sizeof(float)));
+        HIP_TRY(loss_sums(logp, regs, B, h->loss_partial, sums4, st));
+    }
+    const float lam[3] = {gc.reg_z ? lambdas[0] : 0.f, gc.reg_j ? lambdas[1] : 0.f, reg_aug ? lambdas[2] : 0.f};
+    const float* probes = eps;
+    if (exact) {
+        float* unit = slab + slab_floats + state_floats;
+        const long long nunit = (long long)unit_floats;
+        hipLaunchKernelGGL(unit_probes_kernel, dim3((unsigned)((nunit + 255) / 256)), dim3(256), 0, st, unit, h->D, (long long)B);
+        HIP_TRY(hipGetLastError());
+        probes = unit;
+    }
+    HIP_TRY(grad_launch(gc, h->grad_packed, ckpt, ckpt_k, ckpt_zr, probes, ys, h->w_off.data(), h->b_off.data(), alg, nsteps, t0, t1,
+                        tgrid_dev, exact ? 1.f : 0.f, B, lam, slab, grad, grad_x, h->num_cus, st));
+    return CNF_OK;
+}
+
+
+extern "C" {
+
+int cnf_loss_grad_fixed(cnf_handle* h, int alg, int nsteps, float t0, float t1, const float* x,
+                        const float* eps, const float* ys, int64_t B, const float* lambdas,
+                        float* grad, float* grad_x, float* sums4, void* stream) {
+    return loss_grad_impl(h, "cnf_loss_grad_fixed", alg, nsteps, t0, t1, nullptr, x, eps, ys, B, lambdas, grad, grad_x, sums4, stream);
+}
+
+int cnf_loss_grad_grid(cnf_handle* h, int alg, int nsteps, const float* tgrid, const float* x, const float* eps,
+                       const float* ys, int64_t B, const float* lambdas, float* grad, float* grad_x, float* sums4,
+                       void* stream) {
+    if (nsteps < 1 || !tgrid) return fail(CNF_ERR_INVALID, "cnf_loss_grad_grid: nsteps >= 1 and a grid of nsteps + 1 times required");
+    return loss_grad_impl(h, "cnf_loss_grad_grid", alg, nsteps, 0.f, 0.f, tgrid, x, eps, ys, B, lambdas, grad, grad_x, sums4, stream);
+}
+
+int cnf_loss_grad_adaptive(cnf_handle* h, float t0, float t1, const float* x, const float* eps, const float* ys, int64_t B,
+                           float abstol, float reltol, float dt_init, int maxiters, const float* lambdas, float* grad,
+                           float* grad_x, float* sums4, cnf_solve_stats* stats, float* tgrid_out, int32_t grid_cap,
+                           void* stream) {
+    if (stats) *stats = cnf_solve_stats{};
+    int rc = api_check_call(h, eps, ys, B, "cnf_loss_grad_adaptive");
+    if (rc) return rc;
+    if (!x || !grad || !lambdas) return fail(CNF_ERR_INVALID, "cnf_loss_grad_adaptive: null x/grad/lambdas");
+    if (t0 == t1) return fail(CNF_ERR_INVALID, "cnf_loss_grad_adaptive: empty time span");
+    std::vector<float> grid;
+    if (B == 0) {   // nothing to step over: the fixed entry zeroes grad / sums4
+        return loss_grad_impl(h, "cnf_loss_grad_adaptive", CNF_ALG_TSIT5, 1, t0, t1, nullptr, x, eps, ys, B, lambdas, grad, grad_x, sums4, stream);
+    }
+    {
+        DeviceGuard g(h->cfg.device_id);
+        rc = api_ensure_adaptive_buf(h, B);
+        if (rc) return rc;
+        const size_t slot = (size_t)h->S * (size_t)h->ad_B;
+        float* u = h->ad_buf + 4 * slot;
+        HIP_TRY(assemble_u0(x, h->cfg.nvars, h->S, B, u, (hipStream_t)stream));
+        std::vector<double> steps;
+        rc = api_solve_tsit5(h, t0, t1, u, eps, ys, B, abstol, reltol, dt_init, maxiters, u + slot, stats, &steps, stream);
+        if (rc) return rc;
+        double t = t0;
+        grid.push_back(t0);
+        for (double d : steps) { t += d; grid.push_back((float)t); }
+        grid.back() = t1;
+    }
+    if (tgrid_out)
+        for (size_t i = 0; i < grid.size() && (int64_t)i < grid_cap; ++i) tgrid_out[i] = grid[i];
+    return loss_grad_impl(h, "cnf_loss_grad_adaptive", CNF_ALG_TSIT5, (int)grid.size() - 1, 0.f, 0.f, grid.data(), x, eps, ys, B,
+                          lambdas, grad, grad_x, sums4, stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,130 @@
+// cnf_handle.h — private to the C-ABI layer (cnf_api.hip: handles, parameters, fixed-step entry points;
+// cnf_api_adaptive.hip: caller-driven and whole adaptive solves; cnf_api_grad.hip: the gradient entry points).
+#pragma once
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <string>
+#include <vector>
+
+#include "cnf_internal.h"
+
+namespace cnf {
+
+// records the message cnf_last_error() returns (thread-local) and hands the status code back
+int api_fail(int code, const std::string& msg);
+
+#define HIP_TRY(expr)                                                                               \
+    do {                                                                                            \
+        hipError_t _e = (expr);                                                                     \
+        if (_e != hipSuccess)                                                                       \
+            return ::cnf::api_fail(CNF_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+    } while (0)
+
+// Device-side repacking.  Every element of an operand image is either zero padding or ONE Lux parameter
+// times a constant (1, or the tanh pre-scale folded into the forward images), so an image is a gather:
+// packed[j] = p[idx[j]] * scale[j].  The map is derived from the host packer itself (pack a vector of
+// ones -> scale, pack the ramp 1, 2, 3, ... -> idx) and verified bit-for-bit against it on a random vector; an
+// image that is not a gather (the split-bf16 hidden images) fails the check and keeps the host path.
+// With a map, cnf_set_params on a device pointer is one kernel on the caller's stream: no host round
+// trip and no synchronisation in a training loop that updates ps on the device every step.
+struct PackMap {
+    int* idx = nullptr;       // device, source parameter or -1 (zero padding)
+    float* scale = nullptr;   // device
+    size_t n = 0;
+    bool valid = false;
+};
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = false;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        ok = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+}  // namespace cnf
+
+struct cnf_handle {
+    cnf_config cfg{};
+    int D = 0, S = 0;
+    cnf::NetDev net{};
+    size_t nparams = 0;
+    bool have_params = false;
+    int path = CNF_PATH_SIMT;
+    // device copies of the parameters
+    float* P_dev = nullptr;       // Lux layout (SIMT path)
+    cnf::MfmaPlan* plan = nullptr;
+    float* packed_dev = nullptr;  // MFMA operand image
+    // SIMT workspaces, grown on demand
+    float* ws = nullptr;
+    int64_t ws_B = 0;
+    float* kbuf = nullptr;        // 6 stage derivatives + 1 state, each S x kbuf_B
+    int64_t kbuf_B = 0;
+    float* loss_partial = nullptr;
+    // parameter gradient (cnf_loss_grad_fixed)
+    std::vector<size_t> w_off, b_off;   // Lux offsets given to cnf_set_params
+    float* grad_packed = nullptr;        // plain f32 operand image for the reverse sweep
+    float* grad_ws = nullptr;            // checkpoints + logp + regs
+    size_t grad_ws_bytes = 0;
+    int num_cus = 0;
+    // device-side repacking (see PackMap): maps for the solve image and the gradient image, rebuilt
+    // when the layout handed to cnf_set_params changes; p_stage holds host-supplied parameters
+    cnf::PackMap map_fwd, map_grad, map_slab;
+    float* slab_packed = nullptr;        // operand image of the slab-accumulator gradient kernel (cnf_grad_slab.hip)
+    float* slab_ws = nullptr;            // its checkpoints + slabs
+    size_t slab_ws_floats = 0;
+    cnf::LayeredGrad* layered = nullptr;      // rocBLAS context + workspaces of the layer-wise evaluation / gradient
+    // embedded-step workspace (cnf_step_embedded): 7 stage derivatives + 1 stage state, each S x ebuf_B
+    float* ebuf = nullptr;
+    int64_t ebuf_B = 0;
+    int ek[7] = {0, 1, 2, 3, 4, 5, 6};   // which slot holds k_1 .. k_7 (first-same-as-last swaps slots 0 and 6)
+    double* err_partial = nullptr;
+    // multistep solve (cnf_vcabm_*): 6 state-size vectors + 2 x cnf::kVcSlots difference vectors, each S x vc_B
+    float* vc_buf = nullptr;
+    double* vc_partial = nullptr;
+    int64_t vc_B = -1;
+    int vc_iu = 0, vc_iun = 2, vc_if = 3, vc_ifn = 5, vc_cur = 0;   // which vector holds u, u_new, f_n, f_{n+1}; live difference half
+    int vc_nhist = 0, vc_k = 0;          // accepted steps since begin; order of the pending attempt (0 = none)
+    int vc_avail = 0, vc_m = 0;          // differences Phi*_j(n-1) the last accepted step stored; those the pending attempt stores
+    double vc_hist[cnf::kVcSlots + 1] = {};   // signed sizes of the accepted steps, newest first
+    double vc_t = 0.0, vc_dt = 0.0;
+    float* ad_buf = nullptr;             // adaptive Tsit5 whole solve (cnf_solve_tsit5): two states + two derivative scratch vectors
+    int64_t ad_B = 0;
+    float* tgrid_dev = nullptr;          // step times of a non-uniform grid for the fused gradient kernels
+    size_t tgrid_cap = 0;
+    bool layered_forced = false;         // kernel_path = CNF_PATH_LAYERED given explicitly: GEMM path for every batch
+    bool maps_built = false;
+    bool repack_on_device = false;
+    float* p_stage = nullptr;
+    size_t p_stage_n = 0;
+};
+
+namespace cnf {
+
+// shared helpers of the three files
+int api_check_call(cnf_handle* h, const float* eps, const float* ys, int64_t B, const char* who);
+// f(u + dt sum coef k, t) on whichever family serves the handle; `stage` is scratch for the fused path, whose single-call
+// kernel takes the stage state itself
+int api_eval_dynamics(cnf_handle* h, const StageIn& in, float t, const float* eps, const float* ys, int64_t B, float* du,
+                      float* stage, bool first, hipStream_t st);
+// fixed steps on a given grid: u advanced in place, 6 (Tsit5) or 4 (RK4) evaluations per step on the handle's family
+int api_integrate_grid(cnf_handle* h, int alg, int nsteps, const float* tgrid, float* u, const float* eps, const float* ys,
+                       int64_t B, hipStream_t st);
+// cnf_api_grad.hip
+cnf_config api_grad_cfg(const cnf_handle* h);
+bool api_grad_is_fused(const cnf_handle* h);
+bool api_grad_uses_slab(const cnf_handle* h);
+// cnf_api_adaptive.hip
+int api_ensure_adaptive_buf(cnf_handle* h, int64_t B);
+int api_solve_tsit5(cnf_handle* h, float t0, float t1, const float* u0, const float* eps, const float* ys, int64_t B,
+                    float abstol, float reltol, float dt_init, int maxiters, float* u1, cnf_solve_stats* stats,
+                    std::vector<double>* steps, void* stream);
+
+}  // namespace cnf
