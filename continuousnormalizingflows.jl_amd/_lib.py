@@ -118,3 +118,14 @@ def load():
 def check(rc: int):
     if rc != 0:
         raise CnfError(rc, load().cnf_last_error().decode())
+
+
+def stream_ptr(device) -> C.c_void_p:
+    """hipStream_t of torch's current stream on `device`, as the void* the ABI takes."""
+    import torch
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def ptr(t) -> C.c_void_p:
+    """Device (or host) address of a tensor; None -> NULL."""
+    return C.c_void_p(0 if t is None else t.data_ptr())

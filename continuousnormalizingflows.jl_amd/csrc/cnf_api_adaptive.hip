@@ -241,7 +241,7 @@ int cnf_vcabm_state(cnf_handle* h, int64_t B, float* u_out, double* t_out, void*
 }
 
 // The whole default solve in one call: cnf_vcabm_begin / _attempt / _accept driven by the step-size and order policy of
-// icnf._vcabm_integrate (the host side of the reference's solver), restated here so that a single-process caller pays one
+// solvers._vcabm_integrate (the host side of the reference's solver), restated here so that a single-process caller pays one
 // library call per solve instead of two per step.  Synchronises `stream` (the policy reads the error sums).
 int cnf_solve_vcabm(cnf_handle* h, float t0, float t1, const float* u0, const float* eps, const float* ys, int64_t B,
                     float abstol, float reltol, float dt_init, int maxiters, float* u1, cnf_solve_stats* stats,
@@ -348,7 +348,7 @@ int cnf_solve_vcabm(cnf_handle* h, float t0, float t1, const float* u0, const fl
 }
 
 // Adaptive Tsit5 from t0 to t1 in one call: cnf_step_embedded attempts under OrdinaryDiffEq's PI controller - the loop of
-// icnf._adaptive_integrate restated inside the library (single process).  Synchronises `stream`.
+// solvers._adaptive_integrate restated inside the library (single process).  Synchronises `stream`.
 extern "C++" {
 int cnf::api_ensure_adaptive_buf(cnf_handle* h, int64_t B) {
     if (B <= h->ad_B) return CNF_OK;
