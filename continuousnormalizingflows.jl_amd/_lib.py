@@ -129,3 +129,8 @@ def stream_ptr(device) -> C.c_void_p:
 def ptr(t) -> C.c_void_p:
     """Device (or host) address of a tensor; None -> NULL."""
     return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def clamp_maxiters(sol_kwargs) -> int:
+    """sol_kwargs.maxiters as the C int the ABI takes (the reference's usage example passes typemax(Int))."""
+    return min(int(sol_kwargs.get("maxiters", 100000)), 2 ** 31 - 1)

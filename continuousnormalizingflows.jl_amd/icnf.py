@@ -664,7 +664,7 @@ def loss_and_gradient(icnf: ICNF, mode: Mode, *args, eps: Optional[torch.Tensor]
         ss, tg = _lib.SolveStats(), (C.c_float * cap)()
         _solve_errors(lambda: h.lib.cnf_loss_grad_adaptive(
             h.ptr, t0, t1, _ptr(x), _ptr(e), _ptr(y), B, float(kw.get("abstol", 1e-4)), float(kw.get("reltol", 1e-4)),
-            float(kw["dt"]) if "dt" in kw else 0.0, int(kw.get("maxiters", 100000)), lam, _ptr(grad), _ptr(gx), _ptr(sums),
+            float(kw["dt"]) if "dt" in kw else 0.0, _lib.clamp_maxiters(kw), lam, _ptr(grad), _ptr(gx), _ptr(sums),
             C.byref(ss), tg, cap, _stream_ptr(dev)))
         ts = [float(v) for v in tg[:min(ss.naccept + 1, cap)]]
         icnf.last_solve_stats = {"naccept": ss.naccept, "nreject": ss.nreject, "nf": ss.nf, "tgrid": ts,

@@ -43,7 +43,7 @@ def _adaptive_integrate(icnf, h, u0: torch.Tensor, t0: float, t1: float,
         return _vcabm_integrate(icnf, h, u0, t0, t1, e, y, group=group)
     kw = icnf.sol_kwargs
     reltol, abstol = float(kw.get("reltol", 1e-4)), float(kw.get("abstol", 1e-4))
-    maxiters = int(kw.get("maxiters", 100000))
+    maxiters = _lib.clamp_maxiters(kw)
     dev = icnf.device
     B, S = u0.shape
     lib, st = h.lib, _stream_ptr(dev)
@@ -149,7 +149,7 @@ def _vcabm_integrate(icnf, h, u0: torch.Tensor, t0: float, t1: float,
     import torch.distributed as dist
     kw = icnf.sol_kwargs
     reltol, abstol = float(kw.get("reltol", 1e-4)), float(kw.get("abstol", 1e-4))
-    maxiters = int(kw.get("maxiters", 100000))
+    maxiters = _lib.clamp_maxiters(kw)
     dev = icnf.device
     B, S = u0.shape
     lib, st = h.lib, _stream_ptr(dev)

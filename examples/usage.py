@@ -37,7 +37,7 @@ icnf = pkg.ICNF(
     nvariables=nvariables, naugments=naugments, nconditions=0,
     lambda1=0.01, lambda2=0.01, lambda3=0.01, steer_rate=0.1, tspan=(0.0, 1.0),
     device="cuda:0", autonomous=False, inplace=False, compute_mode=pkg.LuxVecJacMatrixMode(),
-    sol_kwargs=dict(maxiters=2 ** 31 - 1, reltol=1e-4, abstol=1e-4, alg=pkg.VCABM()))
+    sol_kwargs=dict(maxiters=2 ** 63 - 1, reltol=1e-4, abstol=1e-4, alg=pkg.VCABM()))
 
 # ## Fit It
 model = pkg.ICNFModel(icnf=icnf, batchsize=1024, epochs=300, callback=pkg.make_opt_callback(64),
