@@ -11,14 +11,14 @@ int fail(int code, const std::string& msg) { return cnf::api_fail(code, msg); }
 
 // The configuration the fused gradient kernels are selected and packed for.  TestMode (exact trace): -tr J is the sum over
 // the D unit vectors e_k of -e_k^T J e_k, i.e. the several-probe reverse sweep with K = D one-hot probes of weight 1 and no
-// regularisers (up to the kernel's probe capacity; wider states take the layer-wise path).
+// regularisers (the probe loop of cnf_grad_probes.hip has no capacity limit; shapes outside the fused kernels take the
+// layer-wise path).
 cnf_config cnf::api_grad_cfg(const cnf_handle* h) {
     cnf_config c = h->cfg;
     if (c.mode == CNF_MODE_EXACT) {
         c.mode = CNF_MODE_HUTCH_VJP;
         c.nprobes = h->D;
         c.reg_z = c.reg_j = c.reg_aug = 0;
-        if (h->D > 8) c.nprobes = 0;   // no fused instance: grad_supported() rejects nprobes < 1
     }
     return c;
 }

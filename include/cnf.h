@@ -250,7 +250,7 @@ int cnf_loss_sums(cnf_handle* h, const float* logp, const float* regs, int64_t B
  * reference's default nets for 7..15 variables); every other shape (wider or more layers, mixed activations, larger D): layer-wise
  * reverse sweep on rocBLAS GEMMs, which also serves the Hutchinson JVP mode.  Exact-trace mode (TestMode):
  * -tr J = -sum_k e_k^T J e_k, the pullback with the D unit vectors as probes of weight 1 (eps is ignored, no
- * regularisers) - on the several-probe fused kernel for D <= 8, layer-wise beyond.
+ * regularisers) - on the several-probe fused kernel where the shape has one, layer-wise otherwise.
  * FFJORD and RNODE losses. */
 int cnf_loss_grad_fixed(cnf_handle* h, int alg, int nsteps, float t0, float t1, const float* x,
                         const float* eps, const float* ys, int64_t B, const float* lambdas,

@@ -1490,10 +1490,12 @@ def test_vcabm_round_trip_large_batch_and_training(pkg, oracles):
 
 @pytest.mark.parametrize("kw,alg,nsteps,gpath", [
     (dict(nvars=3, ncond=2, hidden=[24, 24], act=2, mode=2), 1, 8, 1),                      # default-style softplus net, conditioned
-    (dict(nvars=8, hidden=[64, 64, 64], mode=2), 0, 6, 1),                                  # 8 unit probes: the probe kernel's capacity
+    (dict(nvars=8, hidden=[64, 64, 64], mode=2), 0, 6, 1),                                  # 8 unit probes, three hidden layers
     (dict(nvars=1, naug=2, hidden=[16, 16], act=2, mode=2), 1, 8, 1),                       # ICNF(; nvariables = 1): the reference's benchmark net
     (dict(nvars=1, hidden=[16, 16], act=1, mode=2), 1, 8, 1),                               # D = 1: the one-probe kernel
-    (dict(nvars=9, hidden=[32, 32], act=1, mode=2), 1, 6, 2),                               # more than 8 state rows: layer-wise path
+    (dict(nvars=4, naug=5, hidden=[40, 40], act=2, mode=2), 1, 6, 1),                       # ICNF(; nvariables = 4): 9 unit probes
+    (dict(nvars=13, hidden=[56, 56], act=1, mode=2), 1, 5, 1),                              # 13 unit probes, 4 hidden tiles
+    (dict(nvars=15, hidden=[32, 32], act=1, mode=2), 1, 5, 2),                              # state + time column beyond one input tile: layer-wise path
     (dict(nvars=2, naug=3, hidden=[20], act=1, mode=2), 1, 8, 2),                           # augmented, one hidden layer: layer-wise path
 ])
 def test_gradient_of_the_test_mode_loss(kw, alg, nsteps, gpath, pkg, oracles):
