@@ -88,3 +88,23 @@ def make_gradient_fixture():
 
 if __name__ == "__main__":
     make_gradient_fixture()
+
+
+def make_vcabm_fixture():
+    """The reference's default solver on a small flow (default-style softplus net, nvariables = 2, naugments = 3, RNODE terms on,
+    B = 24, tolerances 1e-4 - the defaults - and 1e-6): final state, accepted / rejected counts, order history and steps of
+    oracle/cnf_oracle64.py::integrate_vcabm."""
+    spec = o.make_spec(nvars=2, naug=3, hidden=[24, 24], act=2, reg_z=True, reg_j=True)
+    p, xs, eps, _ = o.synth_inputs(spec, 24, 20240704, bias_scale=0.3)
+    p = (p * 2.0).astype(np.float32)
+    u0 = np.vstack([xs.astype(np.float64), np.zeros((spec.naug + 3, 24))])
+    out = dict(p=p, xs=xs, eps=eps)
+    for tag, tol in (("a", 1e-4), ("b", 1e-6)):
+        u1, st = o.integrate_vcabm(spec, p, u0, 0.0, 1.0, tol, tol, eps)
+        out.update({f"tol_{tag}": tol, f"u1_{tag}": u1, f"naccept_{tag}": st["naccept"], f"nreject_{tag}": st["nreject"],
+                    f"orders_{tag}": np.array(st["orders"]), f"dts_{tag}": np.array(st["dts"])})
+    np.savez_compressed(os.path.join(OUT, "vcabm_default_softplus_aug.npz"), **out)
+
+
+if __name__ == "__main__":
+    make_vcabm_fixture()

@@ -245,3 +245,20 @@ def test_vcabm_restatement_on_the_linear_field(oracles):
     assert st["nf"] < ts["nf"] and max(st["orders"]) >= 8
     back, sb = o64.integrate_vcabm(spec, p, u1, 1.0, 0.0, 1e-10, 1e-10)
     assert sb["dts"][0] < 0 and np.max(np.abs(back[:D] - xs)) < 1e-7
+
+
+def test_vcabm_restatement_reproduces_its_fixture(oracles):
+    """tests/golden/vcabm_default_softplus_aug.npz (tests/golden/make_golden.py::make_vcabm_fixture): the restatement of the
+    default solver is pinned against accidental change - same accepted / rejected counts, order history, steps and state."""
+    import os
+    from conftest import GOLDEN
+    o64, _ = oracles
+    f = np.load(os.path.join(GOLDEN, "vcabm_default_softplus_aug.npz"))
+    spec = o64.make_spec(nvars=2, naug=3, hidden=[24, 24], act=2, reg_z=True, reg_j=True)
+    u0 = np.vstack([f["xs"].astype(np.float64), np.zeros((spec.naug + 3, f["xs"].shape[1]))])
+    for tag in ("a", "b"):
+        tol = float(f[f"tol_{tag}"])
+        u1, st = o64.integrate_vcabm(spec, f["p"], u0, 0.0, 1.0, tol, tol, f["eps"])
+        assert (st["naccept"], st["nreject"]) == (int(f[f"naccept_{tag}"]), int(f[f"nreject_{tag}"]))
+        assert st["orders"] == f[f"orders_{tag}"].tolist()
+        assert np.allclose(st["dts"], f[f"dts_{tag}"], rtol=1e-9, atol=0) and np.allclose(u1, f[f"u1_{tag}"], rtol=0, atol=1e-10)

@@ -1720,3 +1720,26 @@ def test_randomised_shapes_under_the_adaptive_solvers(pkg, oracles):
             assert torch.equal(torch.as_tensor(a), torch.as_tensor(b)), (kw, B)
         assert bool(torch.isfinite(res["library"][1]).all())
     assert len(kinds) >= 4, kinds
+
+
+def test_vcabm_against_the_committed_fixture(pkg):
+    """The default solver against tests/golden/vcabm_default_softplus_aug.npz (fp64 restatement, generated by
+    tests/golden/make_golden.py): at the reference's tolerance the same accepted / rejected counts and order history, steps
+    within 2 %, state within 20 tol; at 1e-6 counts within 4 and the state within 100 tol.  No oracle code runs here."""
+    import os
+    from conftest import GOLDEN
+    f = np.load(os.path.join(GOLDEN, "vcabm_default_softplus_aug.npz"))
+    nn = pkg.Chain(pkg.Dense(6, 24, pkg.softplus), pkg.Dense(24, 24, pkg.softplus), pkg.Dense(24, 5))
+    for tag in ("a", "b"):
+        tol = float(f[f"tol_{tag}"])
+        icnf = pkg.ICNF(nvariables=2, naugments=3, nn=nn, steer_rate=0.0, lambda1=0.01, lambda2=0.01, lambda3=0.0, device="cuda:0",
+                        sol_kwargs=dict(reltol=tol, abstol=tol))
+        _, _, u1 = pkg.inference(icnf, pkg.TrainMode(True), dev(f["xs"]), dev(f["p"]), {}, eps=dev(f["eps"]), return_state=True)
+        st = icnf.last_solve_stats
+        err = float(np.max(np.abs(u1.cpu().numpy() - f[f"u1_{tag}"])))
+        if tag == "a":
+            assert (st["naccept"], st["nreject"]) == (int(f["naccept_a"]), int(f["nreject_a"])) and st["orders"] == f["orders_a"].tolist()
+            assert np.allclose(st["dts"], f["dts_a"], rtol=2e-2) and err < 20 * tol, err
+        else:
+            assert abs(st["naccept"] - int(f["naccept_b"])) <= 4 and abs(st["nreject"] - int(f["nreject_b"])) <= 4, st
+            assert max(st["orders"]) >= 8 and err < 100 * tol, err
