@@ -68,7 +68,7 @@ static int loss_grad_impl(cnf_handle* h, const char* who, int alg, int nsteps, f
     const std::string w(who);
     if (nsteps < 1) return fail(CNF_ERR_INVALID, w + ": nsteps >= 1 required");
     if (alg != CNF_ALG_RK4 && alg != CNF_ALG_TSIT5) return fail(CNF_ERR_INVALID, w + ": unknown alg");
-    if (!x || !grad || !lambdas) return fail(CNF_ERR_INVALID, w + ": null x/grad/lambdas");
+    if ((B > 0 && !x) || !grad || !lambdas) return fail(CNF_ERR_INVALID, w + ": null x/grad/lambdas");
     const bool fused = api_grad_is_fused(h) && h->grad_packed;
     if (!fused && !layered_grad_supported(h->cfg))
         return fail(CNF_ERR_UNSUPPORTED, w + ": no gradient path for this configuration");
@@ -238,7 +238,7 @@ int cnf_loss_grad_adaptive(cnf_handle* h, float t0, float t1, const float* x, co
     if (stats) *stats = cnf_solve_stats{};
     int rc = api_check_call(h, eps, ys, B, "cnf_loss_grad_adaptive");
     if (rc) return rc;
-    if (!x || !grad || !lambdas) return fail(CNF_ERR_INVALID, "cnf_loss_grad_adaptive: null x/grad/lambdas");
+    if ((B > 0 && !x) || !grad || !lambdas) return fail(CNF_ERR_INVALID, "cnf_loss_grad_adaptive: null x/grad/lambdas");
     if (t0 == t1) return fail(CNF_ERR_INVALID, "cnf_loss_grad_adaptive: empty time span");
     std::vector<float> grid;
     if (B == 0) {   // nothing to step over: the fixed entry zeroes grad / sums4

@@ -748,6 +748,16 @@ def test_empty_batch_is_a_no_op(pkg, oracles):
     icnf = make_icnf(pkg, spec, 1, 40)
     logp, regs = run_inference(pkg, icnf, spec, p, xs[:, :0], eps[:, :0], None)
     assert logp.shape == (0,) and all(r.shape == (0,) for r in regs)
+    for kw in (dict(), dict(alg=pkg.Tsit5())):               # the default solver (VCABM) and adaptive Tsit5: empty and one-column batches
+        icnf = make_icnf(pkg, spec, 1, 40)
+        icnf.sol_kwargs = dict(reltol=1e-5, abstol=1e-5, **kw)
+        logp, regs = run_inference(pkg, icnf, spec, p, xs[:, :0], eps[:, :0], None)
+        assert logp.shape == (0,) and all(r.shape == (0,) for r in regs)
+        val, g = pkg.loss_and_gradient(icnf, pkg.TrainMode(False), dev(xs[:, :0]), dev(p), {}, eps=dev(eps[:, :0]))
+        assert g.shape == (p.size,) and bool(torch.isnan(g).all()) and bool(torch.isnan(val))   # a mean over zero columns (Statistics.mean of nothing)
+        one = run_inference(pkg, icnf, spec, p, xs[:, :1], eps[:, :1], None)[0]
+        ref = run_inference(pkg, make_icnf(pkg, spec, 1, 200), spec, p, xs[:, :1], eps[:, :1], None)[0]
+        assert one.shape == (1,) and abs(float(one - ref)) < 1e-3
 
 
 def test_shard_concatenation_is_bit_identical_and_deterministic(pkg, oracles):
