@@ -331,15 +331,36 @@ hipError_t epilogue(const float* u, int nvars, int D, int reg_aug, int64_t B, fl
 // fixed partition and combine order (no atomics).
 struct ErrIn { const float* k[7]; float coef[7]; int nk; };
 
+// V consecutive elements per thread (V = 4: 16-byte loads when the state size allows), kErrBlocks blocks
+template <int V>
 __global__ void __launch_bounds__(256)
 err_partial_kernel(const float* __restrict__ u, const float* __restrict__ unew, ErrIn in, float dt, float abstol,
-                   float reltol, int64_t n, double* __restrict__ partial /* LOSS_BLOCKS */) {
+                   float reltol, int64_t n, double* __restrict__ partial /* kErrBlocks */) {
     double acc = 0.0;
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
-        float ut = 0.f;
-        for (int j = 0; j < in.nk; ++j) ut = fmaf(in.coef[j], in.k[j][e], ut);
-        const float r = dt * ut / fmaf(fmaxf(fabsf(u[e]), fabsf(unew[e])), reltol, abstol);
-        acc += (double)r * (double)r;
+    for (int64_t e = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * V; e < n; e += (int64_t)gridDim.x * blockDim.x * V) {
+        float ut[V], a[V], b[V];
+#pragma unroll
+        for (int i = 0; i < V; ++i) ut[i] = 0.f;
+        for (int j = 0; j < in.nk; ++j) {
+            if constexpr (V == 4) {
+                const float4 k = *reinterpret_cast<const float4*>(in.k[j] + e);
+                ut[0] = fmaf(in.coef[j], k.x, ut[0]); ut[1] = fmaf(in.coef[j], k.y, ut[1]);
+                ut[2] = fmaf(in.coef[j], k.z, ut[2]); ut[3] = fmaf(in.coef[j], k.w, ut[3]);
+            } else {
+                ut[0] = fmaf(in.coef[j], in.k[j][e], ut[0]);
+            }
+        }
+        if constexpr (V == 4) {
+            const float4 x = *reinterpret_cast<const float4*>(u + e), y = *reinterpret_cast<const float4*>(unew + e);
+            a[0] = x.x; a[1] = x.y; a[2] = x.z; a[3] = x.w; b[0] = y.x; b[1] = y.y; b[2] = y.z; b[3] = y.w;
+        } else {
+            a[0] = u[e]; b[0] = unew[e];
+        }
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            const float r = dt * ut[i] / fmaf(fmaxf(fabsf(a[i]), fabsf(b[i])), reltol, abstol);
+            acc += (double)r * (double)r;
+        }
     }
     __shared__ double sm[256];
     sm[threadIdx.x] = acc;
@@ -355,7 +376,7 @@ __global__ void __launch_bounds__(256)
 err_final_kernel(const double* __restrict__ partial, double* __restrict__ out) {
     __shared__ double sm[256];
     double v = 0.0;
-    for (int b = threadIdx.x; b < LOSS_BLOCKS; b += 256) v += partial[b];
+    for (int b = threadIdx.x; b < kErrBlocks; b += 256) v += partial[b];
     sm[threadIdx.x] = v;
     __syncthreads();
     for (int st = 128; st >= 1; st >>= 1) {
@@ -369,8 +390,10 @@ hipError_t embedded_error(const float* u, const float* unew, const float* const*
                           float abstol, float reltol, int64_t n, double* partial, double* out, hipStream_t st) {
     ErrIn in{};
     in.nk = nk;
-    for (int j = 0; j < nk; ++j) { in.k[j] = k[j]; in.coef[j] = btilde[j]; }
-    hipLaunchKernelGGL(err_partial_kernel, dim3(LOSS_BLOCKS), dim3(256), 0, st, u, unew, in, dt, abstol, reltol, n, partial);
+    bool vec = n % 4 == 0 && ((uintptr_t)u % 16 == 0) && ((uintptr_t)unew % 16 == 0);
+    for (int j = 0; j < nk; ++j) { in.k[j] = k[j]; in.coef[j] = btilde[j]; vec = vec && ((uintptr_t)k[j] % 16 == 0); }
+    if (vec) hipLaunchKernelGGL(err_partial_kernel<4>, dim3(kErrBlocks), dim3(256), 0, st, u, unew, in, dt, abstol, reltol, n, partial);
+    else hipLaunchKernelGGL(err_partial_kernel<1>, dim3(kErrBlocks), dim3(256), 0, st, u, unew, in, dt, abstol, reltol, n, partial);
     hipLaunchKernelGGL(err_final_kernel, dim3(1), dim3(256), 0, st, partial, out);
     return hipGetLastError();
 }
