@@ -102,13 +102,13 @@ int cnf_vcabm_begin(cnf_handle* h, float t0, const float* u0, const float* eps, 
     if (B > 0 && !u0) return fail(CNF_ERR_INVALID, "cnf_vcabm_begin: null u0");
     DeviceGuard g(h->cfg.device_id);
     hipStream_t st = (hipStream_t)stream;
-    if (B != h->vc_B) {
+    if (B > h->vc_cap) {   // grown on demand only: alternating batch sizes (a shorter last mini-batch) reuse the allocation
         if (h->vc_buf) HIP_TRY(hipFree(h->vc_buf));
-        h->vc_buf = nullptr; h->vc_B = -1;
-        const size_t n = (size_t)h->S * (size_t)B;
-        if (n) HIP_TRY(hipMalloc((void**)&h->vc_buf, (6 + 2 * kVcSlots) * n * sizeof(float)));
-        h->vc_B = B;
+        h->vc_buf = nullptr; h->vc_cap = 0; h->vc_B = -1;
+        HIP_TRY(hipMalloc((void**)&h->vc_buf, (6 + 2 * kVcSlots) * (size_t)h->S * (size_t)B * sizeof(float)));
+        h->vc_cap = B;
     }
+    h->vc_B = B;   // the vectors of this solve are packed at stride S x B inside the allocation
     if (!h->vc_partial) HIP_TRY(hipMalloc((void**)&h->vc_partial, (vcabm_partial_doubles() + 8) * sizeof(double)));   // + result slots of cnf_solve_vcabm
     h->vc_iu = 0; h->vc_iun = 2; h->vc_if = 3; h->vc_ifn = 5; h->vc_cur = 0;
     h->vc_nhist = 0; h->vc_k = 0; h->vc_avail = 0; h->vc_m = 0; h->vc_t = t0; h->vc_dt = 0.0;

@@ -89,7 +89,7 @@ struct cnf_handle {
     // multistep solve (cnf_vcabm_*): 6 state-size vectors + 2 x cnf::kVcSlots difference vectors, each S x vc_B
     float* vc_buf = nullptr;
     double* vc_partial = nullptr;
-    int64_t vc_B = -1;
+    int64_t vc_B = -1, vc_cap = 0;       // columns of the solve in progress; columns the allocation holds
     int vc_iu = 0, vc_iun = 2, vc_if = 3, vc_ifn = 5, vc_cur = 0;   // which vector holds u, u_new, f_n, f_{n+1}; live difference half
     int vc_nhist = 0, vc_k = 0;          // accepted steps since begin; order of the pending attempt (0 = none)
     int vc_avail = 0, vc_m = 0;          // differences Phi*_j(n-1) the last accepted step stored; those the pending attempt stores
