@@ -49,6 +49,11 @@ t0 = time.perf_counter()
 fitresult, _, report = model.fit(df)
 torch.cuda.synchronize()
 t_fit = time.perf_counter() - t0
+warm = pkg.ICNFModel(icnf=icnf, batchsize=1024, epochs=100, callback=None, init_rng=torch.Generator().manual_seed(1))
+t0 = time.perf_counter()
+warm.fit(df)                                      # the same loop again, library and kernels already loaded
+torch.cuda.synchronize()
+t_warm = (time.perf_counter() - t0) / 100
 
 icnf_mach_fn = os.path.join(os.environ.get("TMPDIR", "/tmp"), "icnf-machine.pt")
 pkg.save_machine(icnf_mach_fn, model, fitresult)   # MLJBase.save(icnf_mach_fn, mach)  # save it
@@ -66,7 +71,7 @@ t_use = time.perf_counter() - t0
 # ## Evaluate It
 diff = estimated_pdf - actual_pdf
 res = {"mad": float(diff.abs().mean()), "msd": float((diff ** 2).mean()), "tv_dis": float(0.5 * diff.abs().sum() / ndata),
-       "fit_s": t_fit, "fit_iterations": report["stats"]["iterations"], "ms_per_iteration": 1e3 * t_fit / report["stats"]["iterations"],
+       "fit_s": t_fit, "fit_iterations": report["stats"]["iterations"], "ms_per_iteration": 1e3 * t_fit / report["stats"]["iterations"], "ms_per_iteration_warm": 1e3 * t_warm,
        "final_loss": report["stats"]["final_loss"], "pdf_and_rand_ms": 1e3 * t_use,
        "new_data_mean": float(new_data.mean()), "true_mean": 2.0 / 6.0, "new_data_std": float(new_data.std()),
        "true_std": (2.0 * 4.0 / (36.0 * 7.0)) ** 0.5}
