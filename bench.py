@@ -12,17 +12,36 @@ N > 1 is launched by the driver as `python -m torch.distributed.run --nproc-per-
 the batch columns are sharded by rank (weak scaling: 65 536 columns per GPU), no data-path
 collective, one all-reduce of five scalars per step.
 
+Timing protocol (the 63 ms window of 20 launches ran at boost clock and the rocprof
+summaries could not reproduce it):
+  1. W warm-up steps (untimed);
+  2. an untimed PRE-ROLL of the same step until >= --preroll-seconds (default 2 s) of back-to-back
+     launches have run, so DVFS has settled to the clock the chip sustains under this load; every
+     launch is bracketed by HIP events and every 16th is followed by a shader-clock probe
+     (profiles/ubench/clockprobe.hip), so the drift is visible: `sustained.first_quarter_ms`,
+     `last_quarter_ms`, `median_ms`, `clock_mhz`;
+  3. EXACTLY K timed steps between barrier + synchronize on both sides -> `value`, `ms_per_step`;
+     the solve kernel's mean / median launch duration over those K steps -> `roofline`.
+`rocprofv3 --kernel-trace --stats` of the same command (profiles/collect.sh) therefore averages over
+the same steady state, and `roofline.frac` = flop_per_launch / (CSV average) reproduces.
+
 The JSON line also carries
   roofline     — the fused solve kernel against the f32 MFMA peak (the path is compute-bound:
                  ≥ 97 flop/B); its HBM figure is reported beside it.
-  cpu_baseline — the CPU fp32 restatement (oracle/, "port") timed on this host's cores on a
-                 bounded sample of the same workload (rank 0, N = 1 only).
+  secondary    — the north_star's target configuration (cfg2p: the same flow under Tsit5 x 40)
+                 measured by the same protocol in the same process, with its own roofline.
+  cpu_baseline — CPU fp32 restatements of the same algorithm on this host's cores (rank 0, N = 1):
+                 the C port (oracle/cnf_oracle.c, cache-blocked register-tiled products, AVX-512 when
+                 the CPU has it) and a whole-batch BLAS leg (torch.mm on every host thread at the full
+                 batch — the structure of the reference's CPU path); `value` is the faster one.
 """
 from __future__ import annotations
 
 import argparse
+import ctypes as C
 import json
 import os
+import shutil
 import sys
 import time
 
@@ -113,13 +132,18 @@ def layered_flop_per_stage(spec):
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
     ap.add_argument("--batch", type=int, default=0, help="override columns per GPU")
     ap.add_argument("--path", type=int, default=0, help="0 auto, 1 SIMT, 2 MFMA")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--preroll-seconds", type=float, default=2.0,
+                    help="untimed back-to-back launches before the timed steps so the clock has settled (0 = none)")
+    ap.add_argument("--secondary", default="auto",
+                    help="second workload measured by the same protocol and reported under 'secondary' "
+                         "(auto = cfg2p, the north_star's Tsit5 target, when --config cfg2 --mode infer; none = off)")
     ap.add_argument("--mode", default="infer", choices=["infer", "grad"],
                     help="infer: loss (default, the BASELINE metric); grad: loss_and_gradient — forward with "
                          "checkpoints + reverse sweep + all-reduce of nparams floats")
@@ -130,8 +154,11 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(o64, oc, spec, alg, p, xs, eps, ys, target_s):
-    """Time the CPU restatement on all host cores on a bounded column sample."""
+# ---------------------------------------------------------------------------------------------------
+# CPU baseline legs (rank 0, N = 1): test infrastructure timed beside the GPU path, never on it
+# ---------------------------------------------------------------------------------------------------
+def _cpu_leg_c_port(oc, spec, alg, p, xs, eps, ys, target_s):
+    """oracle/cnf_oracle.c on every host thread, a bounded column sample, one full 40-step solve."""
     nt = os.cpu_count() or 1
     nt = min(nt, oc.max_threads()) if oc.max_threads() > 0 else nt
     oc.set_fast_tanh(True)   # the arithmetic Lux's CPU path runs (NNlib.tanh_fast); vectorises
@@ -147,58 +174,100 @@ def cpu_baseline(o64, oc, spec, alg, p, xs, eps, ys, target_s):
     oc.inference_fixed(spec, p, xs[:, :Bs], 0.0, 1.0, NSTEPS, alg, eps[:, :Bs],
                        None if ys is None else ys[:, :Bs], nthreads=nt)
     dt = time.perf_counter() - t
-    out = dict(value=Bs * NSTEPS / dt, unit="samples*steps/s", cores=nt, kind="port",
-               sample=f"{Bs} of the workload's columns, one full {NSTEPS}-step solve, "
-                      f"{dt:.1f} s, oracle/cnf_oracle.c (gcc -O3 -march=x86-64-v3 -fopenmp, tanh_fast)")
-    # CPU-favourable cross-check: the same unfused algorithm with every product a library
-    # GEMM (torch.mm, MKL/oneDNN, float32), Hutchinson-VJP configurations only; a few seconds of work
+    oc.set_fast_tanh(False)
+    return dict(value=Bs * NSTEPS / dt, threads=nt, isa=oc.isa() if hasattr(oc, "isa") else "avx2",
+                sample=f"{Bs} of the workload's columns, one full {NSTEPS}-step solve, {dt:.1f} s, "
+                       f"oracle/cnf_oracle.c (gcc -O3 -fopenmp, tanh_fast)")
+
+
+def _cpu_leg_blas(spec, alg, p, xs, eps, ys, target_s):
+    """The reference's CPU structure: per dynamics call whole-batch sgemm per Dense layer (forward, pullback)
+    on every host thread — torch.mm (MKL / oneDNN), float32, the FULL batch; the bounded sample is a number
+    of RK steps of the 40 (the rate per step does not depend on the step index).  Hutchinson-VJP only."""
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import cnf_oracle_torch32 as t32
+    nthr0 = torch.get_num_threads()
+    nt = os.cpu_count() or nthr0
+    best = None
+    try:
+        for threads in sorted({nt, max(1, nt // 2)}, reverse=True):   # SMT siblings rarely help a GEMM
+            torch.set_num_threads(threads)
+            B = xs.shape[1]
+            t = time.perf_counter()
+            t32.inference_fixed(spec, p, xs, 0.0, 1.0 / NSTEPS, 1, alg, eps, ys)     # one step: warm-up + estimate
+            dt1 = time.perf_counter() - t
+            ns = int(max(1, min(NSTEPS, (target_s / 2) / max(dt1, 1e-3))))
+            t = time.perf_counter()
+            t32.inference_fixed(spec, p, xs, 0.0, ns / NSTEPS, ns, alg, eps, ys)
+            dt = time.perf_counter() - t
+            leg = dict(value=B * ns / dt, threads=threads,
+                       sample=f"all {B} columns, {ns} of the {NSTEPS} steps, {dt:.1f} s, "
+                              f"oracle/cnf_oracle_torch32.py (torch.mm float32)")
+            if best is None or leg["value"] > best["value"]:
+                best = leg
+    finally:
+        torch.set_num_threads(nthr0)
+    return best
+
+
+def cpu_baseline(o64, oc, spec, alg, p, xs, eps, ys, target_s):
+    legs = {"c_port": _cpu_leg_c_port(oc, spec, alg, p, xs, eps, ys, target_s)}
     if spec.mode == 0:
         try:
-            import torch
-            sys.path.insert(0, os.path.join(ROOT, "oracle"))
-            import cnf_oracle_torch32 as t32
-            nthr0 = torch.get_num_threads()
-            torch.set_num_threads(min(16, nthr0))   # small GEMMs: more threads than this only add overhead
-            Bt = int(min(xs.shape[1], 8192))
-            yt = None if ys is None else ys[:, :Bt]
-            t32.inference_fixed(spec, p, xs[:, :256], 0.0, 1.0, 2, alg, eps[:, :256], None if ys is None else ys[:, :256])
-            t = time.perf_counter()
-            t32.inference_fixed(spec, p, xs[:, :Bt], 0.0, 1.0, NSTEPS, alg, eps[:, :Bt], yt)
-            dtt = time.perf_counter() - t
-            out["torch_f32_gemm"] = dict(value=Bt * NSTEPS / dtt, threads=torch.get_num_threads(),
-                                         sample=f"{Bt} columns, {dtt:.1f} s, oracle/cnf_oracle_torch32.py")
-            torch.set_num_threads(nthr0)
-        except Exception as ex:  # pragma: no cover - the cross-check is optional
-            out["torch_f32_gemm"] = dict(error=str(ex)[:200])
-    return out
+            legs["blas_whole_batch"] = _cpu_leg_blas(spec, alg, p, xs, eps, ys, target_s)
+        except Exception as ex:  # pragma: no cover
+            legs["blas_whole_batch"] = dict(error=str(ex)[:200])
+    name, bestleg = max(((k, v) for k, v in legs.items() if "value" in v), key=lambda kv: kv[1]["value"])
+    return dict(value=bestleg["value"], unit="samples*steps/s", cores=bestleg["threads"], kind="port",
+                sample=f"[{name}] " + bestleg["sample"], host_threads=os.cpu_count(),
+                julia_available=bool(shutil.which("julia")), legs=legs)
 
 
-def main():
-    a = parse()
-    import torch
-    import torch.distributed as dist
+# ---------------------------------------------------------------------------------------------------
+# shader-clock probe (measurement helper, profiles/ubench/clockprobe.hip)
+# ---------------------------------------------------------------------------------------------------
+class ClockProbe:
+    def __init__(self, torch, dev):
+        self.ok = False
+        path = os.path.join(ROOT, "profiles", "ubench", "libclockprobe.so")
+        if not os.path.exists(path):
+            return
+        try:
+            self.lib = C.CDLL(path)
+            self.lib.clockprobe_launch.argtypes = [C.c_int64, C.c_void_p, C.c_void_p]
+            khz = int(self.lib.clockprobe_ref_khz(dev.index or 0))
+            self.ref_mhz = khz / 1e3 if khz > 0 else 100.0
+            self.torch, self.dev, self.bufs = torch, dev, []
+            self.ok = True
+        except Exception:
+            self.ok = False
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if a.gpus > 1 and world == 1:
-        print(f"bench.py --gpus {a.gpus} must be launched with torch.distributed.run", file=sys.stderr)
-        sys.exit(2)
-    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
-    if a.backend != "nccl":
-        local = local % torch.cuda.device_count()   # contract test: ranks may share a device
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if a.backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group(a.backend, rank=rank, world_size=world)
+    def sample(self):
+        """Enqueue one ~20 us probe behind whatever was launched last on the current stream."""
+        if not self.ok:
+            return
+        buf = self.torch.zeros(2, dtype=self.torch.int64, device=self.dev)
+        self.lib.clockprobe_launch(int(20e-6 * self.ref_mhz * 1e6), C.c_void_p(buf.data_ptr()),
+                                   C.c_void_p(self.torch.cuda.current_stream(self.dev).cuda_stream))
+        self.bufs.append(buf)
 
-    pkg = entry.load_package()
-    o64, oc = entry.load_oracle()
-    kw, alg, Bdef, flop_ss, bytes_call_ss, bytes_fused, desc = CONFIGS[a.config]
+    def drain(self):
+        """MHz of every probe since the last drain (call after a synchronize)."""
+        out = []
+        for b in self.bufs:
+            c, r = (int(v) for v in b.tolist())
+            if r > 0:
+                out.append(c / r * self.ref_mhz)
+        self.bufs = []
+        return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# workloads
+# ---------------------------------------------------------------------------------------------------
+def make_workload(pkg, o64, name, a, rank, dev, torch):
+    kw, alg, Bdef, flop_ss, bytes_call_ss, bytes_fused, desc = CONFIGS[name]
     B = a.batch or Bdef
     spec = o64.make_spec(**kw)
     # weights are shared by all ranks; the batch is generated per global column block so an
@@ -227,11 +296,38 @@ def main():
     Y = torch.tensor(ys.T.copy(), device=dev).t() if ys is not None else None
     P = torch.tensor(p, device=dev)
     args = (X,) + ((Y,) if Y is not None else ()) + (P, {})
+    return dict(name=name, spec=spec, alg=alg, B=B, flop_ss=flop_ss, bytes_call_ss=bytes_call_ss,
+                bytes_fused=bytes_fused, desc=desc, icnf=icnf, mode=mode, args=args, E=E,
+                host=(p, xs, eps, ys))
 
-    def step():
-        if a.mode == "grad":
-            return pkg.loss_and_gradient(icnf, mode, *args, eps=E)[0]
-        return pkg.loss(icnf, mode, *args, eps=E)
+
+def _quarters(ms):
+    n = len(ms)
+    q = max(1, n // 4)
+    return float(np.mean(ms[:q])), float(np.mean(ms[-q:])), float(np.median(ms))
+
+
+def measure(w, a, steps, warmup, preroll_s, pkg, torch, dist, world, dev, probe):
+    """Warm-up, pre-roll to the sustained clock, then exactly `steps` timed steps.  Returns timings."""
+    icnf, mode, args, E, B = w["icnf"], w["mode"], w["args"], w["E"], w["B"]
+    grad = a.mode == "grad"
+    state = {}
+
+    def launch(ev=None):
+        """One step; the event pair brackets the dominant kernel's launch (the solve; for --mode grad the
+        whole loss + gradient) on the launching stream."""
+        if ev is not None:
+            ev[0].record()
+        if grad:
+            state["loss"], _ = pkg.loss_and_gradient(icnf, mode, *args, eps=E)
+            if ev is not None:
+                ev[1].record()
+            return
+        logp, regs = pkg.inference(icnf, mode, *args, eps=E, _raw=True)
+        if ev is not None:
+            ev[1].record()
+        sums = pkg.loss_sums(icnf, mode, logp, regs)
+        state["loss"] = pkg.reduce_loss(sums, B, (icnf.lambda1, icnf.lambda2, icnf.lambda3))
 
     def sync():
         torch.cuda.synchronize(dev)
@@ -239,80 +335,181 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
-    for _ in range(a.warmup):
-        step()
+    def events(n):
+        return [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+
+    for _ in range(max(1, warmup)):
+        launch()
     sync()
-    # kernel-only timing with events on the launching stream (solve kernel = dominant kernel)
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-          for _ in range(a.steps)]
+    # estimate the step time from a short synchronised burst, then pre-roll
+    t = time.perf_counter()
+    for _ in range(3):
+        launch()
+    sync()
+    est = max((time.perf_counter() - t) / 3, 1e-5)
+    n_pre = int(min(20000, max(0, np.ceil(preroll_s / est)))) if preroll_s > 0 else 0
+    if world > 1:   # every rank must run the same number of steps (the loss all-reduce is a collective)
+        tt = torch.tensor([n_pre], device=dev, dtype=torch.int64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        n_pre = int(tt.item())
+    sustained = None
+    if n_pre > 0:
+        ev = events(n_pre)
+        t = time.perf_counter()
+        for i in range(n_pre):
+            launch(ev[i])
+            if i % 16 == 15:
+                probe.sample()
+        sync()
+        pre_wall = time.perf_counter() - t
+        ms = [s.elapsed_time(e) for s, e in ev]
+        fq, lq, med = _quarters(ms)
+        mhz = probe.drain()
+        sustained = dict(launches=n_pre, seconds=pre_wall, first_quarter_ms=fq, last_quarter_ms=lq, median_ms=med,
+                         clock_mhz=(dict(first_quarter=float(np.mean(mhz[:max(1, len(mhz) // 4)])),
+                                         last_quarter=float(np.mean(mhz[-max(1, len(mhz) // 4):])),
+                                         min=float(np.min(mhz)), max=float(np.max(mhz)), probes=len(mhz))
+                                    if mhz else None))
+    # ---- the timed region: exactly `steps` steps ----
+    ev = events(steps)
+    sync()
     t0 = time.perf_counter()
-    for i in range(a.steps):
-        ev[i][0].record()
-        if a.mode == "grad":
-            lossv, gradv = pkg.loss_and_gradient(icnf, mode, *args, eps=E)
-            ev[i][1].record()
-            continue
-        logp, regs = pkg.inference(icnf, mode, *args, eps=E, _raw=True)
-        ev[i][1].record()
-        sums = pkg.loss_sums(icnf, mode, logp, regs)
-        lossv = pkg.reduce_loss(sums, B, (icnf.lambda1, icnf.lambda2, icnf.lambda3))
+    for i in range(steps):
+        launch(ev[i])
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    kern_ms = float(np.mean([s.elapsed_time(e) for s, e in ev]))
+    ms = [s.elapsed_time(e) for s, e in ev]
+    probe.sample()
+    torch.cuda.synchronize(dev)
+    mhz_end = probe.drain()
+    return dict(elapsed=elapsed, kern_ms=float(np.mean(ms)), kern_ms_median=float(np.median(ms)),
+                kern_ms_min=float(np.min(ms)), kern_ms_max=float(np.max(ms)), sustained=sustained,
+                clock_mhz_after_timed=(mhz_end[0] if mhz_end else None), loss=float(state["loss"]))
+
+
+def report(w, m, a, steps, warmup, world):
+    """The JSON fields of one measured workload."""
+    spec, alg, B, icnf, mode = w["spec"], w["alg"], w["B"], w["icnf"], w["mode"]
+    flop_ss = w["flop_ss"]
+    stages = 4 if alg == 0 else 6
+    value = world * B * NSTEPS * steps / m["elapsed"]
+    path = icnf.kernel_path(mode)
+    extra = {}
+    if a.mode == "grad":
+        # (i) executed MFMA work of forward + reverse sweep per sample*step (DESIGN.md section 8): v_mfma_f32_16x16x4_f32
+        # instructions (2048 flop) per stage per 16-sample tile, recomputation included; (ii) the algorithmic figure:
+        # reverse mode of a function costing F is 2F on top of F (each product once forwards, twice backwards) = 3 F
+        gpath = icnf.grad_path(mode)
+        exec_ss = (grad_mfma_per_stage(spec) * 2048 / 16 if gpath == 1 else layered_flop_per_stage(spec)) * stages
+        extra["executed_flop_per_sample_step"] = exec_ss
+        extra["executed_frac"] = exec_ss * B * NSTEPS / (m["kern_ms"] * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS
+        flop_ss = 3 * flop_ss
+    flops_launch = float(flop_ss) * B * NSTEPS
+    ach = flops_launch / (m["kern_ms"] * 1e-3) / 1e12
+    roof = {
+        "bound": "mfma", "achieved": ach, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+        "frac": ach / F32_MFMA_PEAK_TFLOPS, "traffic": measured_traffic(w["name"]),
+        "kernel_ms": m["kern_ms"], "kernel_ms_median": m["kern_ms_median"], "kernel_ms_min": m["kern_ms_min"],
+        "kernel_ms_max": m["kern_ms_max"], "flop_per_sample_step": flop_ss, "flop_per_launch": flops_launch,
+        **extra,
+        "hbm_model": {
+            "fused_bytes_per_launch": w["bytes_fused"] * B,
+            "fused_GBps": w["bytes_fused"] * B / (m["kern_ms"] * 1e-3) / 1e9,
+            "per_call_abi_bytes_per_launch": w["bytes_call_ss"] * B * NSTEPS,
+            "per_call_abi_GBps": w["bytes_call_ss"] * B * NSTEPS / (m["kern_ms"] * 1e-3) / 1e9,
+            "per_call_abi_frac_of_8TBps": w["bytes_call_ss"] * B * NSTEPS / (m["kern_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "stages_per_step": stages},
+    }
+    s = m["sustained"]
+    if s:
+        s = dict(s)
+        s["frac_last_quarter"] = flops_launch / (s["last_quarter_ms"] * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS
+        s["frac_first_quarter"] = flops_launch / (s["first_quarter_ms"] * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS
+        if s.get("clock_mhz"):
+            # the f32 MFMA peak at the clock the chip actually held: 256 CUs x 256 flop/cycle
+            pk = 256 * 256 * s["clock_mhz"]["last_quarter"] * 1e6 / 1e12
+            s["peak_at_measured_clock_TFLOPs"] = pk
+            s["frac_of_peak_at_measured_clock"] = flops_launch / (s["last_quarter_ms"] * 1e-3) / 1e12 / pk
+        roof["sustained"] = s
+    roof["clock_mhz_after_timed"] = m["clock_mhz_after_timed"]
+    return {
+        "value": value, "ms_per_step": 1e3 * m["elapsed"] / steps,
+        "config": {"workload": w["desc"], "name": w["name"], "columns_per_gpu": B,
+                   "global_columns": world * B, "nsteps": NSTEPS,
+                   "integrator": "RK4" if alg == 0 else "Tsit5",
+                   "kernel_path": {1: "simt", 2: "mfma", 3: "layered"}.get(path, str(path)),
+                   "mode": a.mode,
+                   **({"gradient_path": {1: "fused reverse-sweep kernel", 2: "layer-wise (rocBLAS GEMMs)"}.get(
+                       icnf.grad_path(mode), "none")} if a.mode == "grad" else {}),
+                   "parallelism": f"column-shard x{world}, loss all-reduce (5 scalars)"
+                   + (" + gradient all-reduce (nparams floats)" if a.mode == "grad" else "")},
+        "loss": m["loss"], "roofline": roof,
+    }
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus > 1 and world == 1:
+        print(f"bench.py --gpus {a.gpus} must be launched with torch.distributed.run", file=sys.stderr)
+        sys.exit(2)
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    if a.backend != "nccl":
+        local = local % torch.cuda.device_count()   # contract test: ranks may share a device
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(a.backend, rank=rank, world_size=world)
+
+    pkg = entry.load_package()
+    o64, oc = entry.load_oracle()      # input generation and the cpu_baseline leg only (outside the timed regions)
+    probe = ClockProbe(torch, dev)
+
+    w = make_workload(pkg, o64, a.config, a, rank, dev, torch)
+    m = measure(w, a, a.steps, a.warmup, a.preroll_seconds, pkg, torch, dist, world, dev, probe)
+    sec_name = ("cfg2p" if (a.config == "cfg2" and a.mode == "infer" and not a.batch) else "none") \
+        if a.secondary == "auto" else a.secondary
+    sec = None
+    if sec_name != "none":
+        w2 = make_workload(pkg, o64, sec_name, a, rank, dev, torch)
+        m2 = measure(w2, a, a.steps, a.warmup, min(a.preroll_seconds, 1.5), pkg, torch, dist, world, dev, probe)
+        sec = (w2, m2)
 
     if rank == 0:
-        value = world * B * NSTEPS * a.steps / elapsed
-        path = icnf.kernel_path(mode)
-        flops_launch = float(flop_ss) * B * NSTEPS
-        ach_tflops = flops_launch / (kern_ms * 1e-3) / 1e12
-        stages = 4 if alg == 0 else 6
-        if a.mode == "grad":
-            # executed MFMA work of forward + reverse sweep per sample*step, not an
-            # algorithmic figure: v_mfma_f32_16x16x4_f32 instructions (2048 flop) per stage per 16-sample tile
-            gpath = icnf.grad_path(mode)
-            flop_ss = (grad_mfma_per_stage(spec) * 2048 / 16 if gpath == 1 else layered_flop_per_stage(spec)) * stages
-            flops_launch = float(flop_ss) * B * NSTEPS
-            ach_tflops = flops_launch / (kern_ms * 1e-3) / 1e12
+        r = report(w, m, a, a.steps, a.warmup, world)
         out = {
             "metric": "log-density evals (samples*steps)/sec" if a.mode == "infer"
             else "training-step evals (samples*steps)/sec: loss + dloss/dp",
-            "value": value, "unit": "samples*steps/s", "n_gpus": world, "steps": a.steps,
-            "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True,
+            "value": r["value"], "unit": "samples*steps/s", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": r["ms_per_step"], "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if a.arith == "f32" else "f32 via 3-way bf16 split (6 bf16 MFMAs per hidden product)",
-            "data": "synthetic",
-            "config": {"workload": desc, "name": a.config, "columns_per_gpu": B,
-                       "global_columns": world * B, "nsteps": NSTEPS,
-                       "integrator": "RK4" if alg == 0 else "Tsit5",
-                       "kernel_path": {1: "simt", 2: "mfma"}.get(path, str(path)),
-                       "mode": a.mode,
-                       **({"gradient_path": {1: "fused reverse-sweep kernel", 2: "layer-wise (rocBLAS GEMMs)"}.get(
-                           icnf.grad_path(mode), "none")} if a.mode == "grad" else {}),
-                       "parallelism": f"column-shard x{world}, loss all-reduce (5 scalars)"
-                       + (" + gradient all-reduce (nparams floats)" if a.mode == "grad" else "")},
-            "loss": float(lossv),
-            "roofline": {
-                "bound": "mfma", "achieved": ach_tflops, "peak": F32_MFMA_PEAK_TFLOPS,
-                "unit": "TFLOP/s", "frac": ach_tflops / F32_MFMA_PEAK_TFLOPS,
-                "traffic": measured_traffic(a.config),
-                "kernel_ms": kern_ms, "flop_per_sample_step": flop_ss,
-                "hbm_model": {
-                    "fused_bytes_per_launch": bytes_fused * B,
-                    "fused_GBps": bytes_fused * B / (kern_ms * 1e-3) / 1e9,
-                    "per_call_abi_bytes_per_launch": bytes_call_ss * B * NSTEPS,
-                    "per_call_abi_GBps": bytes_call_ss * B * NSTEPS / (kern_ms * 1e-3) / 1e9,
-                    "per_call_abi_frac_of_8TBps": bytes_call_ss * B * NSTEPS / (kern_ms * 1e-3) / 1e9
-                    / HBM_PEAK_GBS,
-                    "stages_per_step": stages},
-            },
+            "data": "synthetic", "config": r["config"], "loss": r["loss"], "roofline": r["roofline"],
+            "protocol": {"preroll_seconds": a.preroll_seconds,
+                         "note": "W warm-up steps, an untimed pre-roll to the sustained clock, then exactly K timed "
+                                 "steps between barrier+synchronize; roofline from HIP events around each solve launch"},
         }
+        if sec is not None:
+            r2 = report(sec[0], sec[1], a, a.steps, a.warmup, world)
+            out["secondary"] = {"metric": out["metric"], "unit": out["unit"], "steps": a.steps,
+                                "why": "the north_star's target configuration (Tsit5 x 40) by the same protocol", **r2}
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(o64, oc, spec, alg, p, xs, eps, ys, a.cpu_seconds)
-            out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+            p, xs, eps, ys = w["host"]
+            out["cpu_baseline"] = cpu_baseline(o64, oc, w["spec"], w["alg"], p, xs, eps, ys, a.cpu_seconds)
+            out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -1,17 +1,24 @@
 #!/bin/bash
 # Profile recipe (run on the GPU box through gpurun from the repo root):
 #   bash profiles/collect.sh <round-tag> <config> [extra bench args]
-# 1. kernel trace + stats of the default bench command
+# 1. kernel trace + stats of the bench command.  bench.py pre-rolls >= 2 s of back-to-back launches before its
+#    timed steps (several hundred launches of the solve kernel), so the CSV average IS the sustained-clock
+#    duration and roofline.frac = flop_per_launch / (CSV average) reproduces the printed line.
+#    A second stats file restricted to the launches of the timed region + the last quarter of the pre-roll
+#    (warm-ups excluded) is derived from the kernel trace: <config>_kernel_stats_steady.json
 # 2. PMC passes in their own runs (no tracing domains besides --kernel-trace), one small
-#    counter group per pass: SQ issue/wait, MFMA busy, LDS, clock, HBM read, HBM write.
+#    counter group per pass: SQ issue/wait, MFMA busy, LDS, clock, HBM read, HBM write; the clock each
+#    launch ran at = GRBM_GUI_ACTIVE / 8 XCDs / duration is written next to the times.
 set -u
-TAG=${1:-r1}; CFG=${2:-cfg2}; shift 2 || true
+TAG=${1:-r2}; CFG=${2:-cfg2}; shift 2 || true
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_${TAG}_${CFG}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $ROOT/bench.py --config $CFG --steps 5 --warmup 2 --no-cpu-baseline $*"
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/trace.log 2>&1
+BENCH="python3 $ROOT/bench.py --config $CFG --steps 40 --warmup 3 --no-cpu-baseline --secondary none $*"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/trace.log 2>&1
+# PMC passes: a short pre-roll is enough (counters are per launch), 24 launches each
+PBENCH="python3 $ROOT/bench.py --config $CFG --steps 20 --warmup 2 --preroll-seconds 0.5 --no-cpu-baseline --secondary none $*"
 i=0
 for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVES" \
            "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_VALU" \
@@ -20,23 +27,6 @@ for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
            "FETCH_SIZE" \
            "WRITE_SIZE"; do
   i=$((i+1))
-  timeout 300 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $OUT/pmc$i -- $BENCH > $OUT/pmc$i.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $OUT/pmc$i -- $PBENCH > $OUT/pmc$i.log 2>&1
 done
-python3 - <<PY
-import csv, glob, collections, os
-out = "$OUT"
-agg = collections.defaultdict(lambda: collections.defaultdict(list))
-for f in glob.glob(out + "/pmc*/**/*counter_collection.csv", recursive=True):
-    for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"]
-        if "cnf::" not in k: continue
-        agg[k.split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
-with open(out + "/pmc_summary.txt", "w") as fo:
-    for k, cs in agg.items():
-        fo.write(k + "\n")
-        for c, v in sorted(cs.items()):
-            fo.write(f"  {c:32s} launches={len(v):3d} mean={sum(v)/len(v):.6g} min={min(v):.6g} max={max(v):.6g}\n")
-print(open(out + "/pmc_summary.txt").read())
-PY
-find $OUT -name "*kernel_stats.csv" | head -1 | xargs -I{} sh -c 'head -4 {} | cut -c1-200'
-rocprofv3 -L 2>/dev/null | grep -E "^\s*(Name|gpu)" | head -0
+python3 $ROOT/profiles/summarise.py $OUT $CFG

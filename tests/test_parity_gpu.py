@@ -979,7 +979,7 @@ def test_bench_contract_with_two_ranks_on_one_gpu(mode):
         port = sk.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--backend", "gloo", "--no-cpu-baseline", "--batch", "4096", "--mode", mode]
+           "--backend", "gloo", "--no-cpu-baseline", "--batch", "4096", "--mode", mode, "--preroll-seconds", "0.2"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -989,7 +989,7 @@ def test_bench_contract_with_two_ranks_on_one_gpu(mode):
     assert out["config"]["global_columns"] == 2 * 4096 and out["config"]["columns_per_gpu"] == 4096
     assert out["value"] > 0 and abs(out["value"] - 2 * 4096 * 40 * 2 / (out["ms_per_step"] * 2e-3)) < 1e-6 * out["value"]
     single = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--no-cpu-baseline",
-                             "--batch", "4096", "--mode", mode], capture_output=True, text=True, timeout=600, cwd=ROOT)
+                             "--batch", "4096", "--mode", mode, "--preroll-seconds", "0"], capture_output=True, text=True, timeout=600, cwd=ROOT)
     one = json.loads([l for l in single.stdout.splitlines() if l.startswith("{")][0])
     # rank 0's block is the single-process block; the two-rank mean differs from it (rank 1 holds other columns)
     assert abs(out["loss"] - one["loss"]) > 1e-6 and abs(out["loss"] - one["loss"]) < 0.5
