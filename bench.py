@@ -149,6 +149,10 @@ def parse():
                          "checkpoints + reverse sweep + all-reduce of nparams floats")
     ap.add_argument("--arith", default="f32", choices=["f32", "bf16x6"],
                     help="hidden-product arithmetic: exact f32 MFMA (default) or split-bf16 (opt-in)")
+    ap.add_argument("--collective", default="abi", choices=["abi", "torch"],
+                    help="N > 1 on the nccl backend: 'abi' = the library's own RCCL communicator (cnf_comm_init / "
+                         "cnf_allreduce_loss, include/cnf.h; falls back to torch.distributed if it cannot be formed), "
+                         "'torch' = torch.distributed all_reduce")
     ap.add_argument("--backend", default="nccl", help="process-group backend (nccl = RCCL; gloo for "
                     "the single-GPU launch-contract test, where all ranks share device 0)")
     return ap.parse_args()
@@ -445,6 +449,7 @@ def report(w, m, a, steps, warmup, world):
                    "mode": a.mode,
                    **({"gradient_path": {1: "fused reverse-sweep kernel", 2: "layer-wise (rocBLAS GEMMs)"}.get(
                        icnf.grad_path(mode), "none")} if a.mode == "grad" else {}),
+                   "collective": w.get("collective", ""),
                    "parallelism": f"column-shard x{world}, loss all-reduce (5 scalars)"
                    + (" + gradient all-reduce (nparams floats)" if a.mode == "grad" else "")},
         "loss": m["loss"], "roofline": roof,
@@ -477,14 +482,42 @@ def main():
     pkg = entry.load_package()
     o64, oc = entry.load_oracle()      # input generation and the cpu_baseline leg only (outside the timed regions)
     probe = ClockProbe(torch, dev)
+    collective, hung = "none (one GPU)", False
+    if world > 1:
+        collective = f"torch.distributed all_reduce ({a.backend})"
+        if a.backend == "nccl" and a.collective == "abi":
+            # the library's own RCCL communicator; formed in a helper thread so that a rendezvous problem becomes a
+            # fall-back to torch.distributed after 90 s instead of a hung job
+            import threading
+            box = {}
+
+            def form():
+                try:
+                    box["comm"] = pkg.Comm.from_process_group(dev)
+                except Exception as ex:   # pragma: no cover
+                    box["err"] = str(ex)[:300]
+
+            th = threading.Thread(target=form, daemon=True)
+            th.start()
+            th.join(90.0)
+            hung = th.is_alive()
+            ok = torch.tensor([1 if "comm" in box else 0], device=dev, dtype=torch.int32)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 1:
+                pkg.set_comm(box["comm"])
+                collective = "cnf_allreduce_loss: RCCL ncclAllReduce of 5 doubles through the C ABI (include/cnf.h)"
+            else:
+                collective += f" [cnf_comm_init unavailable: {box.get('err', 'timed out')}]"
 
     w = make_workload(pkg, o64, a.config, a, rank, dev, torch)
+    w["collective"] = collective
     m = measure(w, a, a.steps, a.warmup, a.preroll_seconds, pkg, torch, dist, world, dev, probe)
     sec_name = ("cfg2p" if (a.config == "cfg2" and a.mode == "infer" and not a.batch) else "none") \
         if a.secondary == "auto" else a.secondary
     sec = None
     if sec_name != "none":
         w2 = make_workload(pkg, o64, sec_name, a, rank, dev, torch)
+        w2["collective"] = collective
         m2 = measure(w2, a, a.steps, a.warmup, min(a.preroll_seconds, 1.5), pkg, torch, dist, world, dev, probe)
         sec = (w2, m2)
 
@@ -512,7 +545,14 @@ def main():
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out))
     if world > 1:
+        c = pkg.get_comm()
+        pkg.set_comm(None)
+        if c is not None:
+            c.destroy()
         dist.destroy_process_group()
+    if hung:                       # a helper thread is still inside ncclCommInitRank: do not wait for it at exit
+        sys.stdout.flush()
+        os._exit(0)
 
 
 if __name__ == "__main__":

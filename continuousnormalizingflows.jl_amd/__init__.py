@@ -9,6 +9,6 @@ from . import _lib
 from .icnf import *  # noqa: F401,F403
 from .icnf import loss_sums  # noqa: F401
 from .icnf import loss_and_gradient  # noqa: F401
-from .sharding import reduce_gradient, reduce_loss, shard_columns  # noqa: F401
+from .sharding import Comm, get_comm, reduce_gradient, reduce_loss, set_comm, shard_columns  # noqa: F401
 from .adapters import *  # noqa: F401,F403
 from .adapters import epoch_batches  # noqa: F401

@@ -24,11 +24,16 @@ VCABM_MAX_ORDER = 12
 PATH_AUTO, PATH_SIMT, PATH_MFMA, PATH_LAYERED = 0, 1, 2, 3
 STEP_FSAL, STEP_RETRY = 1, 2
 ARITH_F32, ARITH_BF16X6 = 0, 1
+ERR_COMM = -6
+COMM_ID_BYTES = 128
+DTYPE_F32, DTYPE_F64 = 0, 1
 
 EXPORTS = ("cnf_version", "cnf_last_error", "cnf_create", "cnf_destroy", "cnf_set_params",
            "cnf_kernel_path", "cnf_repack_on_device", "cnf_aug_f", "cnf_integrate_fixed", "cnf_inference_fixed",
            "cnf_loss_sums", "cnf_loss_grad_fixed", "cnf_loss_grad_grid", "cnf_grad_path", "cnf_step_embedded", "cnf_assemble_u0",
-           "cnf_epilogue", "cnf_vcabm_begin", "cnf_vcabm_attempt", "cnf_vcabm_accept", "cnf_vcabm_state", "cnf_solve_vcabm", "cnf_solve_tsit5", "cnf_loss_grad_adaptive")
+           "cnf_epilogue", "cnf_vcabm_begin", "cnf_vcabm_attempt", "cnf_vcabm_accept", "cnf_vcabm_state", "cnf_solve_vcabm", "cnf_solve_tsit5", "cnf_loss_grad_adaptive",
+           "cnf_comm_unique_id", "cnf_comm_init", "cnf_comm_init_all", "cnf_comm_destroy", "cnf_comm_rank", "cnf_comm_size",
+           "cnf_comm_group_start", "cnf_comm_group_end", "cnf_allreduce_loss", "cnf_allreduce_sum")
 
 
 class CnfConfig(C.Structure):
@@ -109,6 +114,14 @@ def load():
     lib.cnf_loss_sums.argtypes = [vp, fp, fp, C.c_int64, fp, vp]
     lib.cnf_loss_grad_fixed.argtypes = [vp, C.c_int, C.c_int, C.c_float, C.c_float, fp, fp, fp, C.c_int64,
                                         C.POINTER(C.c_float), fp, fp, fp, vp]
+    lib.cnf_comm_unique_id.argtypes = [vp]
+    lib.cnf_comm_init.argtypes = [C.POINTER(vp), C.c_int, C.c_int, vp, C.c_int]
+    lib.cnf_comm_init_all.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(C.c_int)]
+    lib.cnf_comm_destroy.argtypes = [vp]
+    lib.cnf_comm_rank.argtypes = [vp]
+    lib.cnf_comm_size.argtypes = [vp]
+    lib.cnf_allreduce_loss.argtypes = [vp, fp, C.c_int64, fp, vp]
+    lib.cnf_allreduce_sum.argtypes = [vp, fp, C.c_size_t, C.c_int, vp]
     for name in EXPORTS:
         getattr(lib, name)  # AttributeError if the ABI is incomplete
     _lib = lib

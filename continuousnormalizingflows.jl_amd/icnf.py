@@ -291,10 +291,26 @@ class ICNF:
             raise TypeError("MethodError: basedist needs log_prob(z) and sample((n,))")
         if epsdist is not None and epsdist != "rademacher" and not callable(epsdist):
             raise TypeError("MethodError: epsdist is None, 'rademacher' or a callable")
+        # icnf.rng draws the Hutchinson probes (base_icnf.jl:258-259).  When the columns are sharded over ranks each
+        # rank must draw DIFFERENT probes for its columns, so the default generator is seeded with the rank; the STEER
+        # end time (one draw per call for the whole batch, base_icnf.jl:23-43) comes from a second generator that is
+        # seeded identically on every rank, so all shards integrate the same span (drawing it from the
+        # per-rank stream desynchronises the ranks).  `sharded=False` makes every call of this ICNF rank-local (no
+        # collectives even though a process group exists); None = follow torch.distributed / the installed Comm.
         self.rng = rng
+        self.sharded: Optional[bool] = None
+        rank = 0
+        try:
+            import torch.distributed as _d
+            if _d.is_available() and _d.is_initialized():
+                rank = _d.get_rank()
+        except Exception:
+            rank = 0
         if self.rng is None and torch.cuda.is_available():
             self.rng = torch.Generator(device=self.device)
-            self.rng.manual_seed(0)
+            self.rng.manual_seed(rank)
+        self.steer_rng = torch.Generator(device="cpu")
+        self.steer_rng.manual_seed(0)
         self.sol_kwargs = dict(sol_kwargs or {})
         self._handles: Dict[tuple, _Handle] = {}
         w = nn.widths
@@ -356,10 +372,21 @@ class ICNF:
         """steer_tspan (src/core/base_icnf.jl:23-43)."""
         t0, t1 = self.tspan
         if self.steer_rate != 0.0 and isinstance(mode, TrainMode) and mode.reg:
-            r = (torch.rand((), generator=self.rng, device=self.device).item() * 2.0 - 1.0) \
-                * self.steer_rate
+            r = (torch.rand((), generator=self.steer_rng, dtype=torch.float32).item() * 2.0 - 1.0) * self.steer_rate
             t1 = t1 + abs(t1 - t0) * r
         return t0, t1
+
+    def _group(self, group):
+        """The `group` argument the reductions and adaptive loops receive: False (rank-local) when this ICNF opted out."""
+        return False if self.sharded is False else group
+
+    def invalidate_params(self) -> None:
+        """Force the next call to repack `ps` (cnf_set_params).  The binding is skipped only for the SAME tensor object
+        at an unchanged `ps._version`; writes that bypass autograd's version counter (through `ps.data`, a raw pointer,
+        another library's kernel) must be followed by this call."""
+        for h in self._handles.values():
+            h.params_key = None
+            h.params_ref = None
 
     def _handle(self, mode: Mode) -> _Handle:
         train = isinstance(mode, TrainMode)
@@ -401,6 +428,8 @@ class ICNF:
         w_off, b_off, n = self.nn.param_offsets()
         if ps.dtype != torch.float32 or ps.dim() != 1 or ps.numel() != n:
             raise ValueError(f"DimensionMismatch: ps must be a Float32 vector of length {n}")
+        if ps.is_cuda and ps.device != self.device:
+            raise ValueError(f"ps lives on {ps.device} but this ICNF is bound to {self.device}")
         # skip the repack only for the SAME tensor object at the same version: a data_ptr alone can be a freed
         # tensor's address handed out again by the caching allocator
         key = (ps.data_ptr(), ps._version, str(ps.device))
@@ -498,12 +527,17 @@ def _split_args(icnf: ICNF, args, what: str):
 
 
 def inference(icnf: ICNF, mode: Mode, *args, eps: Optional[torch.Tensor] = None,
-              return_state: bool = False, _raw: bool = False):
+              return_state: bool = False, _raw: bool = False, group=None):
     """inference(icnf, mode, xs[, ys], ps, st) -> (logp̂x (B,), (Ė, ṅ, Ȧ)).
 
     `eps` ((K*D, B)) pins the Hutchinson probes; by default they are drawn from icnf.rng as
-    the reference does.  xs is (nvariables, B), ys (nconditions, B)."""
+    the reference does.  xs is (nvariables, B), ys (nconditions, B).
+    `group`: under an ADAPTIVE solver the error norm couples all columns, so when the batch is sharded over ranks the
+    solve all-reduces its error sums over `group` (None = the default group / the installed Comm) and every rank must
+    make this call; `group=False` (or `icnf.sharded = False`) runs a rank-local solve with no collectives.  Fixed-step
+    solves never communicate."""
     xs, ys, ps, st = _split_args(icnf, args, "inference")
+    group = icnf._group(group)
     h = icnf._handle(mode)
     icnf._bind_params(h, ps)
     dev = icnf.device
@@ -527,14 +561,17 @@ def inference(icnf: ICNF, mode: Mode, *args, eps: Optional[torch.Tensor] = None,
     want_state = return_state or icnf.basedist is not None
     if icnf.adaptive:
         u0 = torch.empty(B, icnf.S, device=dev, dtype=torch.float32)
-        _lib.check(h.lib.cnf_assemble_u0(h.ptr, _ptr(x), B, _ptr(u0), _stream_ptr(dev)))
-        uf = _adaptive_integrate(icnf, h, u0, t0, t1, e, y)
-        _lib.check(h.lib.cnf_epilogue(h.ptr, _ptr(uf), B, _ptr(logp), _ptr(regs), _stream_ptr(dev)))
+        if B:
+            _lib.check(h.lib.cnf_assemble_u0(h.ptr, _ptr(x), B, _ptr(u0), _stream_ptr(dev)))
+        uf = _adaptive_integrate(icnf, h, u0, t0, t1, e, y, group=group)
+        if B:
+            _lib.check(h.lib.cnf_epilogue(h.ptr, _ptr(uf), B, _ptr(logp), _ptr(regs), _stream_ptr(dev)))
     else:
         nsteps = icnf._nsteps(t0, t1)
         uf = torch.empty(B, icnf.S, device=dev, dtype=torch.float32) if want_state else None
-        _lib.check(h.lib.cnf_inference_fixed(h.ptr, alg, nsteps, t0, t1, _ptr(x), _ptr(e), _ptr(y), B,
-                                             _ptr(logp), _ptr(regs), _ptr(uf), _stream_ptr(dev)))
+        if B:
+            _lib.check(h.lib.cnf_inference_fixed(h.ptr, alg, nsteps, t0, t1, _ptr(x), _ptr(e), _ptr(y), B,
+                                                 _ptr(logp), _ptr(regs), _ptr(uf), _stream_ptr(dev)))
     if icnf.basedist is not None:   # logp̂x = logpdf(basedist, z) - Δlogp (base_icnf.jl:168-169)
         logp = (icnf.basedist.log_prob(uf[:, :icnf.D]) - uf[:, icnf.D]).to(torch.float32)
     if _raw:   # internal: the (3, B) regulariser block as one tensor (no copies on the loss path)
@@ -546,7 +583,7 @@ def inference(icnf: ICNF, mode: Mode, *args, eps: Optional[torch.Tensor] = None,
 
 
 def generate(icnf: ICNF, mode: Mode, *args, z0: Optional[torch.Tensor] = None,
-             eps: Optional[torch.Tensor] = None):
+             eps: Optional[torch.Tensor] = None, group=None):
     """generate(icnf, mode, [ys,] ps, st, n) -> (nvariables, n) samples: integrate the base
     sample backwards over the reversed tspan (src/core/base_icnf.jl:351-404, 185-194)."""
     if icnf.conditioned:
@@ -577,7 +614,7 @@ def generate(icnf: ICNF, mode: Mode, *args, z0: Optional[torch.Tensor] = None,
     t0, t1 = icnf._steer_tspan(mode)
     alg = icnf._solver()
     if icnf.adaptive:
-        u1 = _adaptive_integrate(icnf, h, u0, t1, t0, e, y)
+        u1 = _adaptive_integrate(icnf, h, u0, t1, t0, e, y, group=icnf._group(group))
     else:
         nsteps = icnf._nsteps(t0, t1)
         u1 = torch.empty_like(u0)
@@ -611,9 +648,10 @@ def loss_sums(icnf: ICNF, mode: Mode, logp: torch.Tensor, regs) -> torch.Tensor:
     B = logp.numel()
     r = torch.stack(list(regs)).contiguous() if not (
         isinstance(regs, torch.Tensor) and regs.is_contiguous()) else regs
-    sums = torch.empty(4, device=icnf.device, dtype=torch.float32)
-    _lib.check(h.lib.cnf_loss_sums(h.ptr, _ptr(logp.contiguous()), _ptr(r), B, _ptr(sums),
-                                   _stream_ptr(icnf.device)))
+    sums = torch.zeros(4, device=icnf.device, dtype=torch.float32)
+    if B:
+        _lib.check(h.lib.cnf_loss_sums(h.ptr, _ptr(logp.contiguous()), _ptr(r), B, _ptr(sums),
+                                       _stream_ptr(icnf.device)))
     return sums
 
 
@@ -623,7 +661,8 @@ def loss(icnf: ICNF, mode: Mode, *args, eps: Optional[torch.Tensor] = None, grou
     taken to be sharded over the ranks of `group`: the four partial sums and the column count
     are all-reduced (RCCL over xGMI on GPUs) and every rank returns the global mean."""
     from .sharding import reduce_loss
-    logp, regs = inference(icnf, mode, *args, eps=eps, _raw=True)
+    group = icnf._group(group)
+    logp, regs = inference(icnf, mode, *args, eps=eps, _raw=True, group=group)
     sums = loss_sums(icnf, mode, logp, regs)
     return reduce_loss(sums, logp.numel(), (icnf.lambda1, icnf.lambda2, icnf.lambda3), group=group)
 
@@ -636,8 +675,17 @@ def loss_and_gradient(icnf: ICNF, mode: Mode, *args, eps: Optional[torch.Tensor]
     torch.distributed initialised the column shards' gradients (nparams floats) and loss sums are
     all-reduced (RCCL over xGMI) and every rank returns the global mean and its gradient.
     `wrt_x=True` also returns dloss/dxs, (nvariables, B) for this rank's columns (`DI.gradient` with respect
-    to the data in test/ci_tests/smoke_tests.jl): the costate at t0, a by-product of the same sweep."""
-    from .sharding import reduce_gradient, reduce_loss
+    to the data in test/ci_tests/smoke_tests.jl): the costate at t0, a by-product of the same sweep.
+
+    Solver substitution (recorded in `icnf.last_solve_stats["alg_used"]` / `["gradient_of"]`): with a fixed-step
+    solver the value and gradient are those of exactly the discretisation `loss()` evaluates.  With an ADAPTIVE solver
+    the accepted steps of an adaptive *Tsit5* solve are frozen and the discrete solve on that grid is reversed — also
+    when `sol_kwargs.alg` is VCABM (the reference's default), whose multistep recurrence has no one-step discrete
+    adjoint here.  So under VCABM the returned value is the Tsit5-grid loss, which agrees with `loss()` (VCABM) only
+    to the solver tolerance (tests/test_parity_gpu.py bounds the difference); the reference's own gradient
+    (QuadratureAdjoint, icnf.jl:90-99) is likewise a separate solve that matches its forward pass to tolerance."""
+    from .sharding import global_count, is_sharded, reduce_gradient, reduce_loss
+    group = icnf._group(group)
     xs, ys, ps, st = _split_args(icnf, args, "loss_and_gradient")
     if icnf.basedist is not None:
         raise NotImplementedError("loss_and_gradient: the terminal costate assumes basedist = MvNormal(0, I)")
@@ -647,7 +695,8 @@ def loss_and_gradient(icnf: ICNF, mode: Mode, *args, eps: Optional[torch.Tensor]
     x = _colmajor(xs, icnf.nvariables, "xs", dev)
     B = x.shape[0]
     y = _colmajor(ys, icnf.nconditions, "ys", dev) if icnf.conditioned else None
-    e = _draw_eps(icnf, icnf.nprobes, B) if eps is None else _colmajor(eps, icnf.nprobes * icnf.D, "eps", dev)
+    K = icnf.nprobes if isinstance(mode, TrainMode) else 1      # as `inference`: TestMode ignores the probes
+    e = _draw_eps(icnf, K, B) if eps is None else _colmajor(eps, K * icnf.D, "eps", dev)
     t0, t1 = icnf._steer_tspan(mode)
     # the library differentiates with respect to the vector it was given (Chain.abi_params): ps itself, or for a PlanarLayer ps
     # followed by the pinned zero biases, whose gradient entries are dropped below
@@ -656,8 +705,7 @@ def loss_and_gradient(icnf: ICNF, mode: Mode, *args, eps: Optional[torch.Tensor]
     gx = torch.zeros(B, icnf.nvariables, device=dev, dtype=torch.float32) if wrt_x else None
     sums = torch.empty(4, device=dev, dtype=torch.float32)
     lam = (C.c_float * 3)(icnf.lambda1, icnf.lambda2, icnf.lambda3)
-    import torch.distributed as _dist
-    if icnf.adaptive and not (_dist.is_available() and _dist.is_initialized()) and getattr(icnf, "adaptive_policy", "library") == "library":
+    if icnf.adaptive and not is_sharded(group) and getattr(icnf, "adaptive_policy", "library") == "library":
         # single process: adaptive Tsit5 solve + frozen-grid gradient in one library call (cnf_loss_grad_adaptive)
         kw = icnf.sol_kwargs
         cap = 4096
@@ -668,7 +716,8 @@ def loss_and_gradient(icnf: ICNF, mode: Mode, *args, eps: Optional[torch.Tensor]
             C.byref(ss), tg, cap, _stream_ptr(dev)))
         ts = [float(v) for v in tg[:min(ss.naccept + 1, cap)]]
         icnf.last_solve_stats = {"naccept": ss.naccept, "nreject": ss.nreject, "nf": ss.nf, "tgrid": ts,
-                                 "dts": [b - a for a, b in zip(ts, ts[1:])]}
+                                 "dts": [b - a for a, b in zip(ts, ts[1:])], "alg_used": "Tsit5",
+                                 "gradient_of": "adaptive Tsit5 solve, accepted steps frozen (discrete adjoint on that grid)"}
     elif icnf.adaptive:
         # differentiate the discrete solve on the steps the adaptive solver accepted (frozen grid; the dependence
         # of the step sizes on ps is ignored - the discretise-then-optimise convention)
@@ -684,19 +733,17 @@ def loss_and_gradient(icnf: ICNF, mode: Mode, *args, eps: Optional[torch.Tensor]
         ts[-1] = t1
         grid = (C.c_float * len(ts))(*ts)
         icnf.last_solve_stats["tgrid"] = ts
+        icnf.last_solve_stats["gradient_of"] = "adaptive Tsit5 solve, accepted steps frozen (discrete adjoint on that grid)"
         _lib.check(h.lib.cnf_loss_grad_grid(h.ptr, _lib.ALG_TSIT5, len(ts) - 1, grid, _ptr(x), _ptr(e), _ptr(y), B, lam,
                                             _ptr(grad), _ptr(gx), _ptr(sums), _stream_ptr(dev)))
     else:
+        icnf.last_solve_stats = {"alg_used": "Tsit5" if icnf._solver() == _lib.ALG_TSIT5 else "RK4",
+                                 "gradient_of": "the fixed-step solve loss() evaluates (exact discrete adjoint)"}
         _lib.check(h.lib.cnf_loss_grad_fixed(h.ptr, icnf._solver(), icnf._nsteps(t0, t1), t0, t1, _ptr(x), _ptr(e),
                                              _ptr(y), B, lam, _ptr(grad), _ptr(gx), _ptr(sums), _stream_ptr(dev)))
     value = reduce_loss(sums, B, (icnf.lambda1, icnf.lambda2, icnf.lambda3), group=group)
     gps = reduce_gradient(grad[:ps.numel()], B, group=group)
     if not wrt_x:
         return value, gps
-    import torch.distributed as dist
-    Bg = B
-    if dist.is_available() and dist.is_initialized():
-        n = torch.tensor([B], dtype=torch.int64, device=dev if dist.get_backend(group) == "nccl" else "cpu")
-        dist.all_reduce(n, group=group)
-        Bg = int(n.item())
+    Bg = global_count(B, dev, group)
     return value, gps, (gx / Bg).t()

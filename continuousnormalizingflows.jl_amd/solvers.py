@@ -38,7 +38,7 @@ def _adaptive_integrate(icnf, h, u0: torch.Tensor, t0: float, t1: float,
     the squared sum and the element count are all-reduced and every rank takes the same steps.  The step sequence
     of the Julia implementation cannot be checked here (no Julia); parity is against the fp64 oracle's restatement
     of the same algorithm and against fine fixed-step solves."""
-    import torch.distributed as dist
+    from .sharding import allsum as _allsum, is_sharded
     if icnf._solver() == _lib.ALG_VCABM and not _tsit5:
         return _vcabm_integrate(icnf, h, u0, t0, t1, e, y, group=group)
     kw = icnf.sol_kwargs
@@ -47,12 +47,14 @@ def _adaptive_integrate(icnf, h, u0: torch.Tensor, t0: float, t1: float,
     dev = icnf.device
     B, S = u0.shape
     lib, st = h.lib, _stream_ptr(dev)
-    sharded = dist.is_available() and dist.is_initialized()
+    sharded = is_sharded(group)     # group=False: a rank-local solve, no collectives
     tdir = 1.0 if t1 >= t0 else -1.0
     span = abs(t1 - t0)
-    stats = {"naccept": 0, "nreject": 0, "nf": 0, "dts": []}
+    stats = {"naccept": 0, "nreject": 0, "nf": 0, "dts": [], "alg_used": "Tsit5"}
     icnf.last_solve_stats = stats
-    if B == 0 or span == 0.0:
+    # an EMPTY shard of a sharded solve must still take part in every all-reduce (it contributes zeros and follows
+    # the other ranks' steps); only an unsharded empty batch returns at once
+    if span == 0.0 or (B == 0 and not sharded):
         return u0.clone()
     if not sharded and getattr(icnf, "adaptive_policy", "library") == "library":
         # single process: the same controller restated inside the library (cnf_solve_tsit5), one call per solve
@@ -66,14 +68,12 @@ def _adaptive_integrate(icnf, h, u0: torch.Tensor, t0: float, t1: float,
         return out
 
     def allsum(vals):
-        t = torch.tensor(vals, dtype=torch.float64, device=dev if (sharded and dist.get_backend(group) == "nccl") else "cpu")
-        if sharded:
-            dist.all_reduce(t, group=group)
-        return [float(v) for v in t]
+        return _allsum(vals, dev, group if sharded else False)
 
     def f(u, t):
         du = torch.empty_like(u)
-        _lib.check(lib.cnf_aug_f(h.ptr, _ptr(du), _ptr(u), t, _ptr(e), _ptr(y), B, st))
+        if B:
+            _lib.check(lib.cnf_aug_f(h.ptr, _ptr(du), _ptr(u), t, _ptr(e), _ptr(y), B, st))
         stats["nf"] += 1
         return du
 
@@ -107,8 +107,9 @@ def _adaptive_integrate(icnf, h, u0: torch.Tensor, t0: float, t1: float,
             break
         last = dt >= abs(t1 - t) * (1.0 - 1e-6)
         step = abs(t1 - t) if last else dt          # tstop: never step over t1
-        _lib.check(lib.cnf_step_embedded(h.ptr, _lib.ALG_TSIT5, flags, t, tdir * step, _ptr(u), _ptr(e), _ptr(y), B,
-                                         abstol, reltol, _ptr(un), _ptr(err), st))
+        if B:
+            _lib.check(lib.cnf_step_embedded(h.ptr, _lib.ALG_TSIT5, flags, t, tdir * step, _ptr(u), _ptr(e), _ptr(y), B,
+                                             abstol, reltol, _ptr(un), _ptr(err), st))
         stats["nf"] += 6 if flags else 7
         (ssq,) = allsum([float(err.item())])
         eest = math.sqrt(ssq / ntot)
@@ -146,26 +147,24 @@ def _vcabm_integrate(icnf, h, u0: torch.Tensor, t0: float, t1: float,
     (`cnf_solve_vcabm`, one call per solve; `icnf.adaptive_policy = "python"` keeps this loop - the two are tested to take
     identical steps).  The error norms run over the whole S x B state, so a sharded
     solve all-reduces the squared sums and every rank takes the same steps."""
-    import torch.distributed as dist
+    from .sharding import allsum as _allsum, is_sharded
     kw = icnf.sol_kwargs
     reltol, abstol = float(kw.get("reltol", 1e-4)), float(kw.get("abstol", 1e-4))
     maxiters = _lib.clamp_maxiters(kw)
     dev = icnf.device
     B, S = u0.shape
     lib, st = h.lib, _stream_ptr(dev)
-    sharded = dist.is_available() and dist.is_initialized()
+    sharded = is_sharded(group)     # group=False: a rank-local solve, no collectives
     tdir = 1.0 if t1 >= t0 else -1.0
     span = abs(t1 - t0)
-    stats = {"naccept": 0, "nreject": 0, "nf": 0, "dts": [], "orders": []}
+    stats = {"naccept": 0, "nreject": 0, "nf": 0, "dts": [], "orders": [], "alg_used": "VCABM"}
     icnf.last_solve_stats = stats
-    if B == 0 or span == 0.0:
+    # an empty shard of a sharded solve still joins every all-reduce (zeros) and follows the other ranks' steps
+    if span == 0.0 or (B == 0 and not sharded):
         return u0.clone()
 
     def allsum(vals):
-        t = torch.tensor(vals, dtype=torch.float64, device=dev if (sharded and dist.get_backend(group) == "nccl") else "cpu")
-        if sharded:
-            dist.all_reduce(t, group=group)
-        return [float(v) for v in t]
+        return _allsum(vals, dev, group if sharded else False)
 
     u0 = u0.contiguous()
     if not sharded and getattr(icnf, "adaptive_policy", "library") == "library":
@@ -178,7 +177,8 @@ def _vcabm_integrate(icnf, h, u0: torch.Tensor, t0: float, t1: float,
         m = min(ss.naccept, cap)
         stats.update(naccept=ss.naccept, nreject=ss.nreject, nf=ss.nf, dts=[float(v) for v in dts[:m]], orders=[int(v) for v in orders[:m]])
         return out
-    _lib.check(lib.cnf_vcabm_begin(h.ptr, t0, _ptr(u0), _ptr(e), _ptr(y), B, st))
+    if B:
+        _lib.check(lib.cnf_vcabm_begin(h.ptr, t0, _ptr(u0), _ptr(e), _ptr(y), B, st))
     stats["nf"] += 1
     ntot = allsum([float(B * S)])[0] if sharded else float(B * S)
     if "dt" in kw:
@@ -187,7 +187,8 @@ def _vcabm_integrate(icnf, h, u0: torch.Tensor, t0: float, t1: float,
         du = torch.empty_like(u0)
 
         def f(u, t):
-            _lib.check(lib.cnf_aug_f(h.ptr, _ptr(du), _ptr(u), t, _ptr(e), _ptr(y), B, st))
+            if B:
+                _lib.check(lib.cnf_aug_f(h.ptr, _ptr(du), _ptr(u), t, _ptr(e), _ptr(y), B, st))
             stats["nf"] += 1
             return du.clone()
 
@@ -216,7 +217,8 @@ def _vcabm_integrate(icnf, h, u0: torch.Tensor, t0: float, t1: float,
             break
         last = dt >= abs(t1 - t) * (1.0 - 1e-6)
         hstep = abs(t1 - t) if last else dt          # tstop: never step over t1
-        _lib.check(lib.cnf_vcabm_attempt(h.ptr, k, tdir * hstep, _ptr(e), _ptr(y), B, abstol, reltol, _ptr(err3), st))
+        if B:
+            _lib.check(lib.cnf_vcabm_attempt(h.ptr, k, tdir * hstep, _ptr(e), _ptr(y), B, abstol, reltol, _ptr(err3), st))
         stats["nf"] += 1
         s_k, s_km1, s_km2 = allsum(err3.tolist())
         eest = math.sqrt(s_k / ntot)
@@ -229,7 +231,8 @@ def _vcabm_integrate(icnf, h, u0: torch.Tensor, t0: float, t1: float,
         select = step > 4 and k >= 3
         lower = select and max(math.sqrt(s_km2 / ntot), math.sqrt(s_km1 / ntot)) <= eest
         want_up = select and not lower and k < _lib.VCABM_MAX_ORDER
-        _lib.check(lib.cnf_vcabm_accept(h.ptr, _ptr(e), _ptr(y), B, abstol, reltol, _ptr(errp) if want_up else None, st))
+        if B:
+            _lib.check(lib.cnf_vcabm_accept(h.ptr, _ptr(e), _ptr(y), B, abstol, reltol, _ptr(errp) if want_up else None, st))
         stats["nf"] += 1
         knew = k
         if not select:
@@ -251,5 +254,6 @@ def _vcabm_integrate(icnf, h, u0: torch.Tensor, t0: float, t1: float,
     else:
         raise RuntimeError("adaptive solve: maxiters reached")
     out = torch.empty_like(u0)
-    _lib.check(lib.cnf_vcabm_state(h.ptr, B, _ptr(out), None, st))
+    if B:
+        _lib.check(lib.cnf_vcabm_state(h.ptr, B, _ptr(out), None, st))
     return out

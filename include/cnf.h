@@ -31,6 +31,8 @@
  *   caller-driven solves     cnf_assemble_u0, cnf_step_embedded (adaptive Tsit5 attempt), cnf_epilogue,
  *                            cnf_vcabm_begin / _attempt / _accept / _state, cnf_solve_vcabm (the reference's default alg VCABM), cnf_solve_tsit5
  *   training                 cnf_loss_grad_fixed, cnf_loss_grad_grid, cnf_loss_grad_adaptive  (dloss/dps, optionally dloss/dxs)
+ *   column shards (RCCL)     cnf_comm_unique_id, cnf_comm_init, cnf_comm_init_all, cnf_comm_destroy, cnf_comm_rank, cnf_comm_size,
+ *                            cnf_allreduce_loss (the mean in `loss`), cnf_allreduce_sum, cnf_comm_group_start / _end
  *   introspection            cnf_version, cnf_last_error, cnf_kernel_path, cnf_grad_path, cnf_repack_on_device
  */
 #ifndef CNF_H
@@ -51,7 +53,8 @@ typedef enum {
     CNF_ERR_UNSUPPORTED = -2,  /* configuration outside what the kernels implement */
     CNF_ERR_NO_PARAMS = -3,    /* cnf_set_params has not been called */
     CNF_ERR_HIP = -4,          /* HIP runtime error (message in cnf_last_error) */
-    CNF_ERR_NO_DEVICE = -5     /* no gfx950 device visible */
+    CNF_ERR_NO_DEVICE = -5,    /* no gfx950 device visible */
+    CNF_ERR_COMM = -6          /* RCCL error, or librccl.so.1 could not be loaded (message in cnf_last_error) */
 } cnf_status;
 
 /* activation ids of Lux.Dense layers (src/core/icnf.jl:67-71) */
@@ -282,6 +285,38 @@ int cnf_loss_grad_adaptive(cnf_handle* h, float t0, float t1, const float* x, co
  * 1 = fused reverse-sweep kernel (cnf_grad.hip / cnf_grad_probes.hip / cnf_grad_slab.hip), 2 = layer-wise reverse sweep on
  * rocBLAS GEMMs (cnf_layered.hip; librocblas.so.5 is loaded with dlopen at first use). */
 int cnf_grad_path(const cnf_handle* h);
+
+/* ---- column shards: the one exchange step of the path -----------------------------------------
+ * Under fixed-step integration every column (sample) is independent (src/core/icnf.jl:530-535 is column-wise), so rank r
+ * of G evaluates a contiguous column block with a full weight replica and no data-path collective.  The only exchange is
+ * the mean in `loss` (src/core/icnf.jl:636): an all-reduce of the four partial sums of cnf_loss_sums and the column
+ * count.  The reference has no multi-device path; these entries are what a sharded Julia host calls in its place.
+ * RCCL (ncclAllReduce, ncclSum) over xGMI; librccl.so.1 is resolved with dlopen at first use (CNF_ERR_COMM if absent).
+ *
+ *   cnf_comm_unique_id   rank 0 obtains the 128-byte RCCL id (ncclGetUniqueId) and ships it to the other ranks by whatever
+ *                        channel the host has (MPI, a file, a TCP store).
+ *   cnf_comm_init        one rank per process: ncclCommInitRank(nranks, id, rank) on device_id (collective over the ranks).
+ *   cnf_comm_init_all    one process driving ndev devices: ncclCommInitAll; out receives ndev communicators (rank i on devs[i]).
+ *                        Calls on several of them from one thread must be bracketed by cnf_comm_group_start / _end.
+ *   cnf_allreduce_loss   out5 (device, 5 doubles) = sum over ranks of [sums4[0..3] (as double), B_local]: enqueued on
+ *                        `stream` behind the cnf_loss_sums that produced sums4 (device, 4 floats).  Every rank then has
+ *                        loss = (out5[0] + l1 out5[1] + l2 out5[2] + l3 out5[3]) / out5[4].  40 bytes: latency-bound.
+ *   cnf_allreduce_sum    in-place sum of `count` elements (CNF_DTYPE_F32 / CNF_DTYPE_F64) of a device buffer: the gradient of
+ *                        cnf_loss_grad_* (nparams floats) and the squared error sums of the adaptive solvers (doubles), which
+ *                        couple the shards through the step-size controller. */
+#define CNF_COMM_ID_BYTES 128
+enum { CNF_DTYPE_F32 = 0, CNF_DTYPE_F64 = 1 };
+typedef struct cnf_comm cnf_comm;
+int cnf_comm_unique_id(void* id_out /* CNF_COMM_ID_BYTES, host */);
+int cnf_comm_init(cnf_comm** out, int rank, int nranks, const void* id /* CNF_COMM_ID_BYTES, host */, int device_id);
+int cnf_comm_init_all(cnf_comm** out /* ndev entries */, int ndev, const int* devs);
+int cnf_comm_destroy(cnf_comm* c);
+int cnf_comm_rank(const cnf_comm* c);
+int cnf_comm_size(const cnf_comm* c);
+int cnf_comm_group_start(void);
+int cnf_comm_group_end(void);
+int cnf_allreduce_loss(cnf_comm* c, const float* sums4, int64_t B_local, double* out5, void* stream);
+int cnf_allreduce_sum(cnf_comm* c, void* buf, size_t count, int dtype, void* stream);
 
 #ifdef __cplusplus
 }

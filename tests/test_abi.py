@@ -79,6 +79,24 @@ def test_null_arguments_are_errors_not_crashes(pkg):
                                    None) == pkg._lib.ERR_INVALID
 
 
+def test_comm_entry_points_fail_cleanly_without_a_device(pkg):
+    """The RCCL entry points validate their arguments and report through status codes (no GPU here: cnf_comm_init must
+    fail with NO_DEVICE or COMM, never crash); the unique id is 128 bytes as include/cnf.h says."""
+    lib = pkg._lib.load()
+    hdr = open(os.path.join(ROOT, "include", "cnf.h")).read()
+    assert "#define CNF_COMM_ID_BYTES 128" in hdr and pkg._lib.COMM_ID_BYTES == 128
+    assert lib.cnf_comm_unique_id(None) == pkg._lib.ERR_INVALID
+    assert lib.cnf_comm_destroy(None) == 0
+    assert lib.cnf_allreduce_loss(None, None, 0, None, None) == pkg._lib.ERR_INVALID
+    assert lib.cnf_allreduce_sum(None, None, 0, 0, None) == pkg._lib.ERR_INVALID
+    c = C.c_void_p()
+    buf = (C.c_char * 128)()
+    assert lib.cnf_comm_init(C.byref(c), 2, 2, buf, 0) == pkg._lib.ERR_INVALID      # rank out of range
+    if not torch.cuda.is_available():
+        assert lib.cnf_comm_init(C.byref(c), 0, 1, buf, 0) in (pkg._lib.ERR_NO_DEVICE, pkg._lib.ERR_COMM)
+        assert not c.value
+
+
 def test_cpp_host_example_compiles_against_the_header(tmp_path):
     """examples/abi_demo.cpp (a torch-free C++/HIP host on the C ABI) must keep compiling against include/cnf.h."""
     import shutil

@@ -1753,3 +1753,85 @@ def test_vcabm_against_the_committed_fixture(pkg):
         else:
             assert abs(st["naccept"] - int(f["naccept_b"])) <= 4 and abs(st["nreject"] - int(f["nreject_b"])) <= 4, st
             assert max(st["orders"]) >= 8 and err < 100 * tol, err
+
+
+# ---------------------------------------------------------------------------------------------------
+# the collective behind the C ABI: RCCL executed on the MI355X with one rank
+# ---------------------------------------------------------------------------------------------------
+def test_rccl_allreduce_through_the_abi_with_one_rank(pkg):
+    """cnf_comm_unique_id + cnf_comm_init (ncclCommInitRank) + cnf_allreduce_loss / cnf_allreduce_sum (ncclAllReduce) on
+    the caller's stream.  A 1-GPU lease cannot form a larger communicator (RCCL refuses two ranks on one device), so this
+    pins the dlopen, the init and the enqueue order; N = 2 semantics are covered by the gloo tests."""
+    dev = torch.device("cuda:0")
+    comm = pkg.Comm(0, 1, pkg.Comm.unique_id(), dev)
+    assert comm.lib.cnf_comm_rank(comm.ptr) == 0 and comm.lib.cnf_comm_size(comm.ptr) == 1
+    sums = torch.tensor([3.5, 0.25, -1.0, 2.0], device=dev)
+    out5 = comm.allreduce_loss(sums, 1234)
+    torch.cuda.synchronize()
+    assert out5.dtype == torch.float64 and out5.tolist() == [3.5, 0.25, -1.0, 2.0, 1234.0]
+    # stream order: the reduction is enqueued behind the kernel that produces sums4 on the same (non-default) stream
+    s = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(s):
+        big = torch.randn(1 << 22, device=dev)
+        sums2 = torch.stack([big.sum(), big.abs().sum(), (big * big).sum(), big.max()])
+        out = comm.allreduce_loss(sums2, 7).clone()
+    s.synchronize()
+    assert torch.allclose(out[:4], sums2.double()) and out[4].item() == 7.0
+    g32 = torch.arange(9480, device=dev, dtype=torch.float32)
+    g64 = torch.tensor([1e-30, 2.0, 3e30], device=dev, dtype=torch.float64)
+    comm.allreduce_sum(g32)
+    comm.allreduce_sum(g64)
+    torch.cuda.synchronize()
+    assert torch.equal(g32, torch.arange(9480, device=dev, dtype=torch.float32)) and g64.tolist() == [1e-30, 2.0, 3e30]
+    with pytest.raises(ValueError):
+        comm.allreduce_sum(torch.zeros(4, device=dev, dtype=torch.int32))
+    # the host reductions route through the installed communicator and agree with the local formula
+    pkg.set_comm(comm)
+    try:
+        lam = (0.01, 0.02, 0.03)
+        got = float(pkg.reduce_loss(sums, 100, lam))
+        assert abs(got - (3.5 + 0.01 * 0.25 - 0.02 * 1.0 + 0.03 * 2.0) / 100) < 1e-7
+        gr = pkg.reduce_gradient(torch.full((64,), 50.0, device=dev), 100)
+        assert torch.allclose(gr, torch.full((64,), 0.5, device=dev))
+        # group=False opts out even though a communicator is installed
+        assert abs(float(pkg.reduce_loss(sums, 100, lam, group=False)) - got) < 1e-7
+    finally:
+        pkg.set_comm(None)
+        comm.destroy()
+
+
+def test_loss_through_the_library_communicator_matches_the_local_loss(pkg, oracles):
+    """loss / loss_and_gradient / the adaptive solvers with a Comm installed (one rank): same numbers as without."""
+    o64, _ = oracles
+    spec = o64.make_spec(8, [64, 64, 64], reg_z=True, reg_j=True)
+    B = 777
+    p, xs, eps, _ = o64.synth_inputs(spec, B, 91, bias_scale=0.2)
+    dev = lambda a: torch.tensor(np.ascontiguousarray(a), device="cuda:0")
+    mk = lambda kw: pkg.ICNF(nvariables=8, naugments=0, nn=pkg.Chain(pkg.Dense(9, 64, "tanh"), pkg.Dense(64, 64, "tanh"),
+                                                                     pkg.Dense(64, 64, "tanh"), pkg.Dense(64, 8)),
+                             steer_rate=0.0, lambda1=0.02, lambda2=0.03, lambda3=0.0, device="cuda:0", sol_kwargs=kw)
+    m = pkg.TrainMode(True)
+    res = {}
+    for tag in ("local", "comm"):
+        comm = None
+        if tag == "comm":
+            comm = pkg.Comm(0, 1, pkg.Comm.unique_id(), torch.device("cuda:0"))
+            pkg.set_comm(comm)
+        try:
+            fixed = mk(dict(alg=pkg.Tsit5(), adaptive=False, nsteps=10))
+            v, g = pkg.loss_and_gradient(fixed, m, dev(xs), dev(p), {}, eps=dev(eps))
+            lv = pkg.loss(fixed, m, dev(xs), dev(p), {}, eps=dev(eps))
+            adap = mk(dict(alg=pkg.Tsit5(), reltol=1e-4, abstol=1e-4))
+            la = pkg.inference(adap, m, dev(xs), dev(p), {}, eps=dev(eps))[0]
+            dflt = mk(dict(reltol=1e-4, abstol=1e-4))
+            lvc = pkg.inference(dflt, m, dev(xs), dev(p), {}, eps=dev(eps))[0]
+            res[tag] = (float(v), g.cpu().numpy(), float(lv), la.cpu().numpy(), list(adap.last_solve_stats["dts"]),
+                        lvc.cpu().numpy(), list(dflt.last_solve_stats["orders"]))
+        finally:
+            if comm is not None:
+                pkg.set_comm(None)
+                comm.destroy()
+    a, b = res["local"], res["comm"]
+    assert abs(a[0] - b[0]) < 1e-6 and abs(a[2] - b[2]) < 1e-6 and np.allclose(a[1], b[1], rtol=1e-6, atol=1e-8)
+    assert np.allclose(a[4], b[4], rtol=1e-6) and np.max(np.abs(a[3] - b[3])) < 1e-5      # same adaptive steps
+    assert a[6] == b[6] and np.max(np.abs(a[5] - b[5])) < 1e-4                              # VCABM: same orders

@@ -51,8 +51,27 @@ def _worker(rank, world, port, q):
         dflt = _build(pkg, o64, spec, dict(reltol=1e-4, abstol=1e-4))          # the reference's default solver, VCABM
         logp_v = pkg.inference(dflt, m, dev(xs[:, lo:hi]), dev(p), {}, eps=dev(eps[:, lo:hi]))[0]
         vst = dflt.last_solve_stats
+        # --- (a) STEER with rng-drawn probes: every rank must integrate the same drawn t1 although the
+        # probe generators differ per rank; (b) an EMPTY shard (B = 1 over 2 ranks) must join every all-reduce of the
+        # adaptive solvers instead of returning early; (c) group=False: a rank-local adaptive solve on ONE rank only
+        steer = pkg.ICNF(nvariables=spec.nvars, naugments=0, nn=fixed.nn, steer_rate=0.3, lambda1=0.02, lambda2=0.03, lambda3=0.0,
+                         device="cuda:0", sol_kwargs=dict(reltol=1e-4, abstol=1e-4))       # default solver (VCABM), STEER on
+        t1s, seeds = [], int(steer.rng.initial_seed())
+        for _ in range(3):
+            pkg.loss(steer, m, dev(xs[:, lo:hi]), dev(p), {})                              # probes drawn from icnf.rng
+            t1s.append(round(sum(steer.last_solve_stats["dts"]), 6))
+        l1, h1 = pkg.shard_columns(1, rank, world)                                         # rank 0: one column, rank 1: none
+        tiny = []
+        for kw in (dict(alg=pkg.Tsit5(), reltol=1e-4, abstol=1e-4), dict(reltol=1e-4, abstol=1e-4),
+                   dict(alg=pkg.Tsit5(), adaptive=False, nsteps=6)):
+            ic = _build(pkg, o64, spec, kw)
+            tiny.append(float(pkg.loss(ic, m, dev(xs[:, l1:h1]), dev(p), {}, eps=dev(eps[:, l1:h1]))))
+        local = None
+        if rank == 0:
+            local = pkg.inference(adap, m, dev(xs[:, :64]), dev(p), {}, eps=dev(eps[:, :64]), group=False)[0].cpu().numpy()
+        dist.barrier()
         q.put((rank, float(val), float(lval), g.cpu().numpy(), logp.cpu().numpy(), list(adap.last_solve_stats["dts"]),
-               logp_v.cpu().numpy(), list(vst["dts"]), list(vst["orders"])))
+               logp_v.cpu().numpy(), list(vst["dts"]), list(vst["orders"]), t1s, seeds, tiny, local))
     finally:
         dist.destroy_process_group()
 
@@ -85,6 +104,19 @@ def test_two_ranks_on_the_gpu_reproduce_the_unsharded_results(pkg, oracles):
     logp_v = pkg.inference(dflt, m, dev(xs), dev(p), {}, eps=dev(eps))[0].cpu().numpy()
     vdts, vorders = list(dflt.last_solve_stats["dts"]), list(dflt.last_solve_stats["orders"])
     assert isinstance(dflt.sol_kwargs["alg"], pkg.VCABM) and len(vdts) >= 5
+    # the extra checks first (they do not need the unsharded numbers computed above)
+    assert res[0][9] == res[1][9] and len(set(res[0][9])) == 3        # STEER: same t1 on both ranks, a new draw per call
+    assert all(abs(t - 1.0) <= 0.3 + 1e-6 and abs(t - 1.0) > 1e-4 for t in res[0][9])
+    assert res[0][10] != res[1][10]                                   # probe generators are seeded per rank
+    assert res[0][11] == res[1][11]                                   # empty shard: both ranks return the global mean ...
+    one = []
+    for kw in (dict(alg=pkg.Tsit5(), reltol=1e-4, abstol=1e-4), dict(reltol=1e-4, abstol=1e-4), dict(alg=pkg.Tsit5(), adaptive=False, nsteps=6)):
+        ic = _build(pkg, o64, spec, kw)
+        one.append(float(pkg.loss(ic, m, dev(xs[:, :1]), dev(p), {}, eps=dev(eps[:, :1]))))
+    assert np.allclose(res[0][11], one, rtol=1e-5, atol=1e-5), (res[0][11], one)   # ... of the one column
+    loc = pkg.inference(adap, m, dev(xs[:, :64]), dev(p), {}, eps=dev(eps[:, :64]))[0].cpu().numpy()
+    assert res[1][12] is None and np.max(np.abs(res[0][12] - loc)) < 1e-5          # rank-local solve while a group exists
+    res = [r[:9] for r in res]
     for rank, v, lv, gr, lp, d, lpv, dv, ov in res:
         assert abs(v - float(val)) < 1e-5 and abs(lv - float(val)) < 1e-5          # global mean on every rank
         assert np.max(np.abs(gr - g.cpu().numpy())) < 2e-5 * float(g.abs().max())  # all-reduced gradient = unsharded gradient
