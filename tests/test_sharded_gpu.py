@@ -48,6 +48,7 @@ def _worker(rank, world, port, q):
         lval = pkg.loss(fixed, m, dev(xs[:, lo:hi]), dev(p), {}, eps=dev(eps[:, lo:hi]))
         adap = _build(pkg, o64, spec, dict(alg=pkg.Tsit5(), reltol=1e-4, abstol=1e-4))
         logp = pkg.inference(adap, m, dev(xs[:, lo:hi]), dev(p), {}, eps=dev(eps[:, lo:hi]))[0]
+        adap_dts = list(adap.last_solve_stats["dts"])
         dflt = _build(pkg, o64, spec, dict(reltol=1e-4, abstol=1e-4))          # the reference's default solver, VCABM
         logp_v = pkg.inference(dflt, m, dev(xs[:, lo:hi]), dev(p), {}, eps=dev(eps[:, lo:hi]))[0]
         vst = dflt.last_solve_stats
@@ -70,7 +71,7 @@ def _worker(rank, world, port, q):
         if rank == 0:
             local = pkg.inference(adap, m, dev(xs[:, :64]), dev(p), {}, eps=dev(eps[:, :64]), group=False)[0].cpu().numpy()
         dist.barrier()
-        q.put((rank, float(val), float(lval), g.cpu().numpy(), logp.cpu().numpy(), list(adap.last_solve_stats["dts"]),
+        q.put((rank, float(val), float(lval), g.cpu().numpy(), logp.cpu().numpy(), adap_dts,
                logp_v.cpu().numpy(), list(vst["dts"]), list(vst["orders"]), t1s, seeds, tiny, local))
     finally:
         dist.destroy_process_group()
