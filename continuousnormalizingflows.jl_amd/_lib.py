@@ -32,6 +32,7 @@ EXPORTS = ("cnf_version", "cnf_last_error", "cnf_create", "cnf_destroy", "cnf_se
            "cnf_kernel_path", "cnf_repack_on_device", "cnf_aug_f", "cnf_integrate_fixed", "cnf_inference_fixed",
            "cnf_loss_sums", "cnf_loss_grad_fixed", "cnf_loss_grad_grid", "cnf_grad_path", "cnf_step_embedded", "cnf_assemble_u0",
            "cnf_epilogue", "cnf_vcabm_begin", "cnf_vcabm_attempt", "cnf_vcabm_accept", "cnf_vcabm_state", "cnf_solve_vcabm", "cnf_solve_tsit5", "cnf_loss_grad_adaptive",
+           "cnf_integrate_fixed_dt", "cnf_inference_fixed_dt",
            "cnf_comm_unique_id", "cnf_comm_init", "cnf_comm_init_all", "cnf_comm_destroy", "cnf_comm_rank", "cnf_comm_size",
            "cnf_comm_group_start", "cnf_comm_group_end", "cnf_allreduce_loss", "cnf_allreduce_sum")
 
@@ -111,6 +112,8 @@ def load():
                                         C.c_int64, fp, vp]
     lib.cnf_inference_fixed.argtypes = [vp, C.c_int, C.c_int, C.c_float, C.c_float, fp, fp, fp,
                                         C.c_int64, fp, fp, fp, vp]
+    lib.cnf_integrate_fixed_dt.argtypes = [vp, C.c_int, C.c_float, C.c_float, C.c_float, fp, fp, fp, C.c_int64, fp, vp]
+    lib.cnf_inference_fixed_dt.argtypes = [vp, C.c_int, C.c_float, C.c_float, C.c_float, fp, fp, fp, C.c_int64, fp, fp, fp, vp]
     lib.cnf_loss_sums.argtypes = [vp, fp, fp, C.c_int64, fp, vp]
     lib.cnf_loss_grad_fixed.argtypes = [vp, C.c_int, C.c_int, C.c_float, C.c_float, fp, fp, fp, C.c_int64,
                                         C.POINTER(C.c_float), fp, fp, fp, vp]

@@ -492,6 +492,77 @@ int cnf_inference_fixed(cnf_handle* h, int alg, int nsteps, float t0, float t1, 
     return CNF_OK;
 }
 
+// OrdinaryDiffEq's fixed-dt stepping on (t0, t1): n_full steps of |dt|, then a shorter tail step that lands on t1 (a tstop);
+// a remainder within 100 eps(Float32) of the larger end point counts as having reached it (fixed_t_for_floatingpoint_error!).
+struct FixedDtPlan { int n_full; bool tail; float t_mid; };
+static FixedDtPlan fixed_dt_plan(float t0, float t1, float dt) {
+    const double span = std::fabs((double)t1 - (double)t0), adt = std::fabs((double)dt);
+    const double tdir = t1 >= t0 ? 1.0 : -1.0;
+    FixedDtPlan p{};
+    p.n_full = (int)std::floor(span / adt + 1e-9);
+    const double tol = 100.0 * 1.1920928955078125e-7 * std::fmax(std::fabs((double)t0), std::fabs((double)t1));
+    p.tail = span - p.n_full * adt > tol;
+    p.t_mid = p.tail ? (float)((double)t0 + tdir * p.n_full * adt) : t1;
+    return p;
+}
+
+int cnf_integrate_fixed_dt(cnf_handle* h, int alg, float dt, float t0, float t1, const float* u0, const float* eps,
+                           const float* ys, int64_t B, float* u1, void* stream) {
+    int rc = api_check_call(h, eps, ys, B, "cnf_integrate_fixed_dt");
+    if (rc) return rc;
+    if (!(std::fabs(dt) > 0.f) || !std::isfinite(dt) || !std::isfinite(t0) || !std::isfinite(t1))
+        return fail(CNF_ERR_INVALID, "cnf_integrate_fixed_dt: dt must be non-zero and finite, t0 / t1 finite");
+    if (std::fabs((double)t1 - t0) / std::fabs((double)dt) > 1e8) return fail(CNF_ERR_INVALID, "cnf_integrate_fixed_dt: more than 1e8 steps");
+    if (B == 0) return CNF_OK;
+    if (!u0 || !u1) return fail(CNF_ERR_INVALID, "cnf_integrate_fixed_dt: null u0/u1");
+    const FixedDtPlan p = fixed_dt_plan(t0, t1, dt);
+    if (p.n_full == 0 && !p.tail) {       // nothing to integrate
+        DeviceGuard g(h->cfg.device_id);
+        if (u1 != u0) HIP_TRY(hipMemcpyAsync(u1, u0, (size_t)h->S * (size_t)B * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+        return CNF_OK;
+    }
+    const float* from = u0;
+    if (p.n_full > 0) {
+        rc = cnf_integrate_fixed(h, alg, p.n_full, t0, p.t_mid, u0, eps, ys, B, u1, stream);
+        if (rc) return rc;
+        from = u1;
+    }
+    if (p.tail) return cnf_integrate_fixed(h, alg, 1, p.t_mid, t1, from, eps, ys, B, u1, stream);
+    return CNF_OK;
+}
+
+int cnf_inference_fixed_dt(cnf_handle* h, int alg, float dt, float t0, float t1, const float* x, const float* eps,
+                           const float* ys, int64_t B, float* logp, float* regs, float* u_final, void* stream) {
+    int rc = api_check_call(h, eps, ys, B, "cnf_inference_fixed_dt");
+    if (rc) return rc;
+    if (!(std::fabs(dt) > 0.f) || !std::isfinite(dt) || !std::isfinite(t0) || !std::isfinite(t1))
+        return fail(CNF_ERR_INVALID, "cnf_inference_fixed_dt: dt must be non-zero and finite, t0 / t1 finite");
+    if (std::fabs((double)t1 - t0) / std::fabs((double)dt) > 1e8) return fail(CNF_ERR_INVALID, "cnf_inference_fixed_dt: more than 1e8 steps");
+    if (B == 0) return CNF_OK;
+    if (!x || !logp) return fail(CNF_ERR_INVALID, "cnf_inference_fixed_dt: null x/logp");
+    const FixedDtPlan p = fixed_dt_plan(t0, t1, dt);
+    if (!p.tail && p.n_full > 0) return cnf_inference_fixed(h, alg, p.n_full, t0, t1, x, eps, ys, B, logp, regs, u_final, stream);
+    // a state buffer between the two launches (or for the degenerate empty span): the caller's u_final, else the embedded-step scratch
+    DeviceGuard g(h->cfg.device_id);
+    hipStream_t st = (hipStream_t)stream;
+    float* u = u_final;
+    if (!u) {
+        rc = api_ensure_adaptive_buf(h, B);
+        if (rc) return rc;
+        u = h->ad_buf;
+    }
+    HIP_TRY(assemble_u0(x, h->cfg.nvars, h->S, B, u, st));
+    if (p.n_full > 0) {
+        rc = cnf_integrate_fixed(h, alg, p.n_full, t0, p.t_mid, u, eps, ys, B, u, stream);
+        if (rc) return rc;
+    }
+    if (p.tail) {
+        rc = cnf_integrate_fixed(h, alg, 1, p.t_mid, t1, u, eps, ys, B, u, stream);
+        if (rc) return rc;
+    }
+    return cnf_epilogue(h, u, B, logp, regs, stream);
+}
+
 // f(u + dt sum coef k, t) on whichever family serves the handle; `stage` is scratch for the fused path, whose
 // single-call kernel takes the stage state itself
 extern "C++" {

@@ -360,6 +360,8 @@ class ICNF:
         return bool(self.sol_kwargs.get("adaptive", True))
 
     def _nsteps(self, t0: float, t1: float) -> int:
+        """`nsteps` equal steps (an extension of this host: sol_kwargs.nsteps); with `dt` the solve goes through the
+        `*_fixed_dt` entries instead (see _fixed_dt)."""
         kw = self.sol_kwargs
         if "nsteps" in kw:
             return int(kw["nsteps"])
@@ -367,6 +369,26 @@ class ICNF:
             raise NotImplementedError("sol_kwargs needs dt (or nsteps) with adaptive=False")
         n = abs(t1 - t0) / float(kw["dt"])
         return max(1, int(round(n)))
+
+    def _fixed_dt(self) -> Optional[float]:
+        """sol_kwargs = (alg, adaptive = false, dt): OrdinaryDiffEq's fixed-dt stepping — steps of dt and a shorter last
+        step onto t1 (what a STEER-drawn t1 meets, base_icnf.jl:23-43) — served by cnf_inference_fixed_dt /
+        cnf_integrate_fixed_dt.  None when the user gave `nsteps` (equal steps) instead."""
+        kw = self.sol_kwargs
+        if "nsteps" in kw or "dt" not in kw:
+            return None
+        return abs(float(kw["dt"]))
+
+    @staticmethod
+    def fixed_dt_grid(t0: float, t1: float, dt: float):
+        """The times of those steps, [t0, ..., t1] (the plan of cnf_integrate_fixed_dt; include/cnf.h)."""
+        span, adt = abs(t1 - t0), abs(dt)
+        tdir = 1.0 if t1 >= t0 else -1.0
+        n = int(math.floor(span / adt + 1e-9))
+        tol = 100.0 * 1.1920928955078125e-7 * max(abs(t0), abs(t1))
+        if span - n * adt <= tol:
+            return [t0] if n == 0 else [t0 + (t1 - t0) * i / n for i in range(n)] + [t1]
+        return [t0 + tdir * adt * i for i in range(n + 1)] + [t1]
 
     def _steer_tspan(self, mode: Mode) -> Tuple[float, float]:
         """steer_tspan (src/core/base_icnf.jl:23-43)."""
@@ -567,10 +589,13 @@ def inference(icnf: ICNF, mode: Mode, *args, eps: Optional[torch.Tensor] = None,
         if B:
             _lib.check(h.lib.cnf_epilogue(h.ptr, _ptr(uf), B, _ptr(logp), _ptr(regs), _stream_ptr(dev)))
     else:
-        nsteps = icnf._nsteps(t0, t1)
         uf = torch.empty(B, icnf.S, device=dev, dtype=torch.float32) if want_state else None
-        if B:
-            _lib.check(h.lib.cnf_inference_fixed(h.ptr, alg, nsteps, t0, t1, _ptr(x), _ptr(e), _ptr(y), B,
+        dt = icnf._fixed_dt()
+        if dt is not None:
+            _lib.check(h.lib.cnf_inference_fixed_dt(h.ptr, alg, dt, t0, t1, _ptr(x), _ptr(e), _ptr(y), B,
+                                                    _ptr(logp), _ptr(regs), _ptr(uf), _stream_ptr(dev)))
+        else:
+            _lib.check(h.lib.cnf_inference_fixed(h.ptr, alg, icnf._nsteps(t0, t1), t0, t1, _ptr(x), _ptr(e), _ptr(y), B,
                                                  _ptr(logp), _ptr(regs), _ptr(uf), _stream_ptr(dev)))
     if icnf.basedist is not None:   # logp̂x = logpdf(basedist, z) - Δlogp (base_icnf.jl:168-169)
         logp = (icnf.basedist.log_prob(uf[:, :icnf.D]) - uf[:, icnf.D]).to(torch.float32)
@@ -616,10 +641,14 @@ def generate(icnf: ICNF, mode: Mode, *args, z0: Optional[torch.Tensor] = None,
     if icnf.adaptive:
         u1 = _adaptive_integrate(icnf, h, u0, t1, t0, e, y, group=icnf._group(group))
     else:
-        nsteps = icnf._nsteps(t0, t1)
         u1 = torch.empty_like(u0)
-        _lib.check(h.lib.cnf_integrate_fixed(h.ptr, alg, nsteps, t1, t0, _ptr(u0), _ptr(e), _ptr(y), n,
-                                             _ptr(u1), _stream_ptr(dev)))
+        dt = icnf._fixed_dt()
+        if dt is not None:
+            _lib.check(h.lib.cnf_integrate_fixed_dt(h.ptr, alg, dt, t1, t0, _ptr(u0), _ptr(e), _ptr(y), n,
+                                                    _ptr(u1), _stream_ptr(dev)))
+        else:
+            _lib.check(h.lib.cnf_integrate_fixed(h.ptr, alg, icnf._nsteps(t0, t1), t1, t0, _ptr(u0), _ptr(e), _ptr(y), n,
+                                                 _ptr(u1), _stream_ptr(dev)))
     return u1[:, :icnf.nvariables].t()
 
 
@@ -739,8 +768,18 @@ def loss_and_gradient(icnf: ICNF, mode: Mode, *args, eps: Optional[torch.Tensor]
     else:
         icnf.last_solve_stats = {"alg_used": "Tsit5" if icnf._solver() == _lib.ALG_TSIT5 else "RK4",
                                  "gradient_of": "the fixed-step solve loss() evaluates (exact discrete adjoint)"}
-        _lib.check(h.lib.cnf_loss_grad_fixed(h.ptr, icnf._solver(), icnf._nsteps(t0, t1), t0, t1, _ptr(x), _ptr(e),
-                                             _ptr(y), B, lam, _ptr(grad), _ptr(gx), _ptr(sums), _stream_ptr(dev)))
+        dt = icnf._fixed_dt()
+        ts = icnf.fixed_dt_grid(t0, t1, dt) if dt is not None else None
+        if ts is not None and len(ts) >= 2 and abs((ts[-1] - ts[-2]) - (ts[1] - ts[0])) > 1e-7 * abs(t1 - t0):
+            # fixed dt with a shorter last step (a STEER-drawn t1): the same grid as cnf_inference_fixed_dt, reversed exactly
+            grid = (C.c_float * len(ts))(*ts)
+            icnf.last_solve_stats["tgrid"] = ts
+            _lib.check(h.lib.cnf_loss_grad_grid(h.ptr, icnf._solver(), len(ts) - 1, grid, _ptr(x), _ptr(e), _ptr(y), B, lam,
+                                                _ptr(grad), _ptr(gx), _ptr(sums), _stream_ptr(dev)))
+        else:
+            nsteps = (len(ts) - 1) if ts is not None and len(ts) >= 2 else icnf._nsteps(t0, t1)
+            _lib.check(h.lib.cnf_loss_grad_fixed(h.ptr, icnf._solver(), nsteps, t0, t1, _ptr(x), _ptr(e),
+                                                 _ptr(y), B, lam, _ptr(grad), _ptr(gx), _ptr(sums), _stream_ptr(dev)))
     value = reduce_loss(sums, B, (icnf.lambda1, icnf.lambda2, icnf.lambda3), group=group)
     gps = reduce_gradient(grad[:ps.numel()], B, group=group)
     if not wrt_x:

@@ -27,7 +27,7 @@
  * Entry points
  *   lifetime / parameters    cnf_create, cnf_destroy, cnf_set_params
  *   boundary A (per call)    cnf_aug_f                      du = augmented_f(u, p, t)
- *   boundary B (whole solve) cnf_integrate_fixed, cnf_inference_fixed, cnf_loss_sums
+ *   boundary B (whole solve) cnf_integrate_fixed, cnf_inference_fixed, cnf_integrate_fixed_dt, cnf_inference_fixed_dt, cnf_loss_sums
  *   caller-driven solves     cnf_assemble_u0, cnf_step_embedded (adaptive Tsit5 attempt), cnf_epilogue,
  *                            cnf_vcabm_begin / _attempt / _accept / _state, cnf_solve_vcabm (the reference's default alg VCABM), cnf_solve_tsit5
  *   training                 cnf_loss_grad_fixed, cnf_loss_grad_grid, cnf_loss_grad_adaptive  (dloss/dps, optionally dloss/dxs)
@@ -217,6 +217,17 @@ int cnf_aug_f(cnf_handle* h, float* du, const float* u, float t, const float* ep
  * tspan, src/core/base_icnf.jl:351-376). */
 int cnf_integrate_fixed(cnf_handle* h, int alg, int nsteps, float t0, float t1, const float* u0,
                         const float* eps, const float* ys, int64_t B, float* u1, void* stream);
+
+/* The same solve as the user states it to OrdinaryDiffEq: sol_kwargs = (alg, adaptive = false, dt) on tspan (t0, t1) —
+ * steps of |dt| towards t1 and a SHORTER LAST STEP that lands on t1 (t1 is a tstop of the integrator); when what remains
+ * after the full steps is within 100 eps(Float32) max(|t0|, |t1|) — OrdinaryDiffEq's floating-point fix-up for tstops —
+ * the span is divided equally instead.  This is what STEER needs: steer_tspan (src/core/base_icnf.jl:23-43) draws t1 per
+ * call, so |t1 - t0| is not a multiple of dt.  Two launches of the fused solve kernel (full steps, then the tail).
+ * |t1 - t0| < tolerance copies u0 to u1.  cnf_inference_fixed_dt is cnf_inference_fixed on that grid. */
+int cnf_integrate_fixed_dt(cnf_handle* h, int alg, float dt, float t0, float t1, const float* u0, const float* eps,
+                           const float* ys, int64_t B, float* u1, void* stream);
+int cnf_inference_fixed_dt(cnf_handle* h, int alg, float dt, float t0, float t1, const float* x, const float* eps,
+                           const float* ys, int64_t B, float* logp, float* regs, float* u_final, void* stream);
 
 /* inference(icnf, mode, xs[, ys], ps, st) for MatrixMode with a fixed-step solver, fused:
  * inference_prob (u0 = [x; 0]) + base_sol + inference_sol (logp = logpdf(N(0,I), z) - dlogp):

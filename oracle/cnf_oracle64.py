@@ -216,6 +216,38 @@ def integrate_fixed(spec: Spec, p, u0: np.ndarray, t0: float, t1: float, nsteps:
     return u
 
 
+def fixed_dt_grid(t0: float, t1: float, dt: float):
+    """The step times OrdinaryDiffEq takes with `adaptive = false, dt` on tspan (t0, t1) (base_sol,
+    src/core/base_icnf.jl:134-140; what STEER's drawn t1 meets, base_icnf.jl:23-43): steps of |dt| towards t1 and a
+    SHORTER LAST STEP that lands on t1 (t1 is a tstop) — unless what remains is within 100 eps(Float32) of the larger
+    end point, which its floating-point fix-up treats as already being t1 (then the steps are the equal division).
+    Returns the list [t0, ..., t1]."""
+    span, adt = abs(t1 - t0), abs(dt)
+    assert adt > 0.0
+    tdir = 1.0 if t1 >= t0 else -1.0
+    n = int(math.floor(span / adt + 1e-9))
+    tol = 100.0 * float(np.finfo(np.float32).eps) * max(abs(t0), abs(t1))
+    rem = span - n * adt
+    if rem <= tol:
+        if n == 0:
+            return [t0]
+        return [t0 + (t1 - t0) * i / n for i in range(n)] + [t1]
+    return [t0 + tdir * adt * i for i in range(n + 1)] + [t1]
+
+
+def integrate_grid(spec: Spec, p, u0: np.ndarray, tgrid, alg: int, eps, ys) -> np.ndarray:
+    """Fixed steps on a given grid of times (either direction): step n runs from tgrid[n] to tgrid[n+1]."""
+    u = np.asarray(u0, dtype=np.float64).copy()
+    for ta, tb in zip(tgrid[:-1], tgrid[1:]):
+        u = integrate_fixed(spec, p, u, ta, tb, 1, alg, eps, ys)
+    return u
+
+
+def integrate_fixed_dt(spec: Spec, p, u0: np.ndarray, t0: float, t1: float, dt: float, alg: int, eps, ys) -> np.ndarray:
+    """base_sol with sol_kwargs = (alg, adaptive = false, dt): steps of dt and a shorter last step (fixed_dt_grid)."""
+    return integrate_grid(spec, p, u0, fixed_dt_grid(t0, t1, dt), alg, eps, ys)
+
+
 TSIT5_BTILDE = (-0.00178001105222577714, -0.0008164344596567469, 0.007880878010261995, -0.1447110071732629,
                 0.5823571654525552, -0.45808210592918697, 1.0 / 66.0)
 
@@ -460,13 +492,17 @@ def std_normal_logpdf(z: np.ndarray) -> np.ndarray:
     return -0.5 * d * math.log(2.0 * math.pi) - 0.5 * (z * z).sum(0)
 
 
-def inference_fixed(spec: Spec, p, xs: np.ndarray, t0, t1, nsteps, alg, eps, ys=None):
+def inference_fixed(spec: Spec, p, xs: np.ndarray, t0, t1, nsteps, alg, eps, ys=None, dt=None):
     """inference_prob + inference_sol for MatrixMode (src/core/base_icnf.jl:247-296,158-172).
-    Returns logp (B,), (Edot, ndot, Adot) each (B,), u_final (S,B)."""
+    Returns logp (B,), (Edot, ndot, Adot) each (B,), u_final (S,B).  With `dt` given, nsteps is ignored and the solve
+    takes OrdinaryDiffEq's fixed-dt steps (integrate_fixed_dt)."""
     B = xs.shape[1]
     u0 = np.concatenate([np.asarray(xs, dtype=np.float64),
                          np.zeros((spec.naug + 3, B))], axis=0)
-    u1 = integrate_fixed(spec, p, u0, t0, t1, nsteps, alg, eps, ys)
+    if dt is not None:
+        u1 = integrate_fixed_dt(spec, p, u0, t0, t1, dt, alg, eps, ys)
+    else:
+        u1 = integrate_fixed(spec, p, u0, t0, t1, nsteps, alg, eps, ys)
     D = spec.D
     z, dlogp = u1[:D], u1[D]
     logp = std_normal_logpdf(z) - dlogp

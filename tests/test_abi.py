@@ -106,42 +106,3 @@ def test_cpp_host_example_compiles_against_the_header(tmp_path):
         pytest.skip("hipcc not available")
     subprocess.run([hipcc, "-O1", "--offload-arch=gfx950", "-I", os.path.join(ROOT, "include"), "-c",
                     os.path.join(ROOT, "examples", "abi_demo.cpp"), "-o", str(tmp_path / "abi_demo.o")], check=True, timeout=300)
-
-
-def test_julia_glue_ccalls_match_the_header():
-    """INTEGRATION.md's Julia glue cannot be executed here (no Julia): at least every `ccall((:name, libcnf), Cint, (types...), ...)`
-    in it must name an entry point of include/cnf.h with the same number of parameters and compatible scalar types."""
-    import os, re
-    from conftest import ROOT
-    md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
-    blocks = re.findall(r"```julia\n(.*?)```", md, flags=re.S)
-    assert blocks
-    hdr = open(os.path.join(ROOT, "include", "cnf.h")).read()
-    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
-    protos = {m.group(1): [a.strip() for a in m.group(2).split(",")] for m in re.finditer(r"\bint\s+(cnf_\w+)\s*\(([^;{]*?)\)\s*;", hdr)}
-    protos["cnf_last_error"] = ["void"]
-    seen = set()
-    for code in blocks:
-        for m in re.finditer(r"ccall\(\(:(\w+),\s*libcnf\),\s*(\w+),\s*\(", code):
-            name, start = m.group(1), m.end()
-            depth, i = 1, start
-            while depth:                                   # the matching parenthesis of the type tuple
-                depth += {"(": 1, ")": -1}.get(code[i], 0)
-                i += 1
-            types = [t.strip() for t in re.split(r",(?![^{]*})", code[start:i - 1]) if t.strip()]
-            assert name in protos, f"ccall of an unknown entry point: {name}"
-            params = [] if protos[name] == ["void"] else protos[name]
-            assert len(types) == len(params), (name, types, params)
-            for jt, cp in zip(types, params):              # scalar kinds must agree
-                if jt in ("Cint", "Int32"):
-                    assert re.match(r"(int|int32_t)\s+\w+$", cp), (name, jt, cp)
-                elif jt == "Int64":
-                    assert cp.startswith("int64_t "), (name, jt, cp)
-                elif jt == "Cfloat":
-                    assert cp.startswith("float ") and "*" not in cp, (name, jt, cp)
-                elif jt == "Csize_t":
-                    assert cp.startswith("size_t "), (name, jt, cp)
-                else:                                      # Ptr{...} / Ref{...}
-                    assert "*" in cp, (name, jt, cp)
-            seen.add(name)
-    assert {"cnf_create", "cnf_set_params", "cnf_aug_f", "cnf_inference_fixed", "cnf_loss_grad_fixed", "cnf_solve_vcabm"} <= seen, seen
