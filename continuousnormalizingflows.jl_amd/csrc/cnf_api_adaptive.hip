@@ -273,7 +273,7 @@ int cnf_solve_vcabm(cnf_handle* h, float t0, float t1, const float* u0, const fl
     double dt;
     if (dt_init != 0.f) {
         dt = std::min((double)std::fabs(dt_init), span);
-    } else {   // ode_determine_initdt (Hairer, Noersett, Wanner I, II.4) with the algorithm order 7, RMS norm over all S*B entries
+    } else {   // ode_determine_initdt (Hairer, Noersett, Wanner I, II.4), RMS norm over all S*B entries; the exponent is 1 / get_current_alg_order = 1 / (the cache's current order) = 1 at the start of a VCABM solve (recalled, not read)
         float *u = vc_vec(h, h->vc_iu), *f0 = vc_vec(h, h->vc_if), *ue = vc_vec(h, 1), *f1 = vc_vec(h, 4);
         HIP_TRY(vcabm_scaled_sumsq(u, nullptr, u, abstol, reltol, (int64_t)n, h->vc_partial, res, st));
         HIP_TRY(vcabm_scaled_sumsq(f0, nullptr, u, abstol, reltol, (int64_t)n, h->vc_partial, res + 1, st));
@@ -294,7 +294,7 @@ int cnf_solve_vcabm(cnf_handle* h, float t0, float t1, const float* u0, const fl
         rc = fetch(1);
         if (rc) return rc;
         const double d2 = std::sqrt(host[0] / ntot) / h0, dmax = std::max(d1, d2);
-        const double h1 = dmax <= 1e-15 ? std::max(1e-6, h0 * 1e-3) : std::pow(10.0, -(2.0 + std::log10(dmax)) / 8.0);
+        const double h1 = dmax <= 1e-15 ? std::max(1e-6, h0 * 1e-3) : std::pow(10.0, -(2.0 + std::log10(dmax)) / 1.0);
         dt = std::min(std::min(100.0 * h0, h1), span);
         if (!(std::isfinite(dt) && dt > 0.0)) return fail(CNF_ERR_INVALID, "cnf_solve_vcabm: non-finite state or dynamics at t0 (no initial step)");
     }

@@ -15,6 +15,10 @@ from . import _lib
 from ._lib import ptr as _ptr, stream_ptr as _stream_ptr
 
 
+# get_current_alg_order(VCABM(), cache) when the initial step is chosen: the cache starts at order 1
+VCABM_INITDT_ORDER = 1.0
+
+
 def _solve_errors(call):
     """Run a whole-solve library call; its status codes become the exceptions of the host loops."""
     try:
@@ -183,7 +187,7 @@ def _vcabm_integrate(icnf, h, u0: torch.Tensor, t0: float, t1: float,
     ntot = allsum([float(B * S)])[0] if sharded else float(B * S)
     if "dt" in kw:
         dt = min(abs(C.c_float(float(kw["dt"])).value), span)      # Float32, as the library entry takes it
-    else:   # ode_determine_initdt (Hairer, Noersett, Wanner I, II.4) with the algorithm order 7
+    else:   # ode_determine_initdt (Hairer, Noersett, Wanner I, II.4); its last step divides by get_current_alg_order(alg, cache), which for the variable-order Adams family is the CURRENT order of the cache = 1 at the start (the +1 / 'order 7' of round 1 had no source; recalled, not read - no Julia here)
         du = torch.empty_like(u0)
 
         def f(u, t):
@@ -204,7 +208,7 @@ def _vcabm_integrate(icnf, h, u0: torch.Tensor, t0: float, t1: float,
         (s2,) = allsum([float((((f1 - f0) / sk).double() ** 2).sum())])
         d2 = math.sqrt(s2 / ntot) / dt0
         dmax = max(d1, d2)
-        dt1 = max(1e-6, dt0 * 1e-3) if dmax <= 1e-15 else 10.0 ** (-(2.0 + math.log10(dmax)) / 8.0)
+        dt1 = max(1e-6, dt0 * 1e-3) if dmax <= 1e-15 else 10.0 ** (-(2.0 + math.log10(dmax)) / VCABM_INITDT_ORDER)
         dt = min(100.0 * dt0, dt1, span)
         if not (math.isfinite(dt) and dt > 0.0):
             raise FloatingPointError("adaptive solve: non-finite state or dynamics at t0 (no initial step)")

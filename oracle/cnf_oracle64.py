@@ -420,7 +420,7 @@ def integrate_vcabm(spec: Spec, p, u0: np.ndarray, t0: float, t1: float, reltol:
     k+1 (dt gamma*_{k+1} Phi_{k+1}(n+1) from the re-evaluated derivative) lower the order when max(err_{k-2}, err_{k-1})
     <= err_k, or raise it when err_{k+1} < err_k (the step-size error is then set to 1); integral step-size controller
     dt / clamp(EEst^(1/(k+1)) / gamma, 1/qmax, 1/qmin), gamma = 9/10, qmin = 1/5, qmax = 10, same factor on a rejection;
-    Hairer's initial step with the algorithm order 7.  PARITY UNPINNED: the Julia package is absent, so its exact
+    Hairer's initial step with the exponent 1 / get_current_alg_order = 1 / (current order of the cache) = 1.  PARITY UNPINNED: the Julia package is absent, so its exact
     step and order sequence is unverified; this is the oracle the HIP path's VCABM mode is compared with, itself
     checked against fine fixed-step solves and on a linear field.  Returns (u1, stats)."""
     f = lambda u, t: aug_f(spec, p, u, t, eps, ys).astype(np.float64)
@@ -440,7 +440,7 @@ def integrate_vcabm(spec: Spec, p, u0: np.ndarray, t0: float, t1: float, reltol:
         nf += 1
         d2 = rms((f1 - fn) / sk) / h0
         dm = max(d1, d2)
-        h1 = max(1e-6, h0 * 1e-3) if dm <= 1e-15 else 10.0 ** (-(2.0 + math.log10(dm)) / 8.0)
+        h1 = max(1e-6, h0 * 1e-3) if dm <= 1e-15 else 10.0 ** (-(2.0 + math.log10(dm)) / 1.0)
         dt = min(100.0 * h0, h1, span)
     else:
         dt = min(abs(dt0), span)

