@@ -385,6 +385,8 @@ hipError_t mfma_solve(MfmaPlan* p, const float* packed_dev, const SolveArgs& s, 
     a.nvars = s.nvars; a.D = p->cfg.nvars + p->cfg.naug; a.C = p->cfg.ncond;
     a.reg_z = p->cfg.reg_z; a.reg_j = p->cfg.reg_j; a.reg_aug = s.reg_aug; a.autonomous = p->cfg.autonomous;
     a.T = make_tableau(s.alg);
+    for (int st = 0; st < 6; ++st)
+        for (int i = 0; i < 5; ++i) a.acol[st][i] = (st + 1 + i < a.T.ns && st < a.T.ns) ? a.T.a[st + 1 + i][st] : 0.f;
     a.exact = p->cfg.mode == CNF_MODE_EXACT;
     a.K = p->KP;
     a.prio_mode = p->prio_mode;

@@ -28,6 +28,7 @@ struct KArgs {
     float* kfull;       // optional: all S rows of every stage derivative of ONE step, [stage][B][S] (adaptive attempts)
     float* ckpt_k;      // optional: stage derivatives zdot_i, [step * ns + stage][tile][lane][ZR] (gradient)
     Tableau T;
+    float acol[6][5];   // acol[st][i] = T.a[st + 1 + i][st] (0 beyond the last stage): what stage st contributes to the stages after it
 };
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {

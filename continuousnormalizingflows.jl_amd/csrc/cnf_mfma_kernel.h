@@ -132,22 +132,116 @@ __device__ __forceinline__ void gemm_hidden(const float* __restrict__ img, int l
 // slot, same issue cost as the scalar form — profiles/ubench/pk_f32_cost.result.txt); on gfx950 f32 VALU
 // time adds to f32 MFMA time, so every issue slot saved is wall time.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// Packed f32 VALU (v_pk_add_f32 / v_pk_fma_f32 / v_pk_mul_f32: two values per issue slot at the scalar forms' issue cost,
+// profiles/ubench/pk_f32_cost.result.txt).  On gfx950 f32 VALU time ADDS to f32 MFMA time, so every issue slot is wall time.
+// The compiler cannot be trusted with them here: LLVM's pre-emit peephole UNPACKS packed f32 instructions that sit behind an
+// MFMA (43 of the 97 in this kernel: "co-issue in the MFMA shadow" - which v_mfma_f32_16x16x4_f32 does not offer), so the hot
+// ones are written as inline asm.  The hazard recogniser does not look inside asm, so each statement carries its own wait
+// states (MI300/MI350 ISA, "manually inserted wait states"):
+//   * trans (v_exp / v_rcp) result read by a non-trans VALU: 1 wait state            -> leading s_nop 0
+//   * MFMA (8-pass) result read by VALU, or its SrcC overwritten by VALU: 11         -> leading s_nop 7 + s_nop 3 (PK_AFTER_MFMA)
+//   * VALU result read by an MFMA as SrcA/B: the asm result is consumed by compiler-selected instructions that do not know
+//     the asm is a VALU                                                              -> trailing s_nop 1 (PK_BEFORE_MFMA)
+// -DCNF_NO_PK_ASM falls back to the plain vector expressions (A/B switch).
+#ifndef CNF_NO_PK_ASM
+__device__ __forceinline__ void pk_add1(f32x2& a, f32x2& b) {          // a += 1, b += 1; inputs written by v_exp_f32
+    asm volatile("s_nop 0\n\tv_pk_add_f32 %0, %0, 1.0 op_sel_hi:[1,0]\n\tv_pk_add_f32 %1, %1, 1.0 op_sel_hi:[1,0]" : "+v"(a), "+v"(b));
+}
+// h = 2 r - 1, d = 1 - h^2 for two value pairs; r written by v_rcp_f32 (each d follows the OTHER pair's h: no back-to-back dependence)
+__device__ __forceinline__ void pk_tanh_from_r(f32x2& ha, f32x2& hb, f32x2& da, f32x2& db, const f32x2& ra, const f32x2& rb) {
+    asm volatile("s_nop 0\n\t"
+                 "v_pk_fma_f32 %0, %4, 2.0, -1.0 op_sel_hi:[1,0,0]\n\t"
+                 "v_pk_fma_f32 %1, %5, 2.0, -1.0 op_sel_hi:[1,0,0]\n\t"
+                 "v_pk_fma_f32 %2, %0, %0, 1.0 op_sel_hi:[1,1,0] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+                 "v_pk_fma_f32 %3, %1, %1, 1.0 op_sel_hi:[1,1,0] neg_lo:[1,0,0] neg_hi:[1,0,0]"
+                 : "=&v"(ha), "=&v"(hb), "=&v"(da), "=&v"(db) : "v"(ra), "v"(rb));
+}
+// c[i] = a[i] .* b[i] for N accumulator tiles in ONE statement (one set of wait states per layer, not per tile);
+// `a` may be MFMA results, c feeds MFMAs
+#define CNF_PKMUL(o, x, y) "v_pk_mul_f32 %" #o ", %" #x ", %" #y "\n\t"
+template <int N>
+__device__ __forceinline__ void tiles_mul_block(const f32x4* a, const f32x4* b, f32x4* c) {
+    static_assert(N >= 1 && N <= 4, "at most 4 tiles (24 asm operands) per statement");
+    f32x2 x[2 * N], y[2 * N], o[2 * N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        x[2 * i] = f32x2{a[i][0], a[i][1]}; x[2 * i + 1] = f32x2{a[i][2], a[i][3]};
+        y[2 * i] = f32x2{b[i][0], b[i][1]}; y[2 * i + 1] = f32x2{b[i][2], b[i][3]};
+    }
+    if constexpr (N == 1) {
+        asm volatile("s_nop 7\n\ts_nop 3\n\t" CNF_PKMUL(0, 2, 4) CNF_PKMUL(1, 3, 5) "s_nop 1"
+            : "=&v"(o[0]), "=&v"(o[1]) : "v"(x[0]), "v"(x[1]), "v"(y[0]), "v"(y[1]));
+    } else if constexpr (N == 2) {
+        asm volatile("s_nop 7\n\ts_nop 3\n\t" CNF_PKMUL(0, 4, 8) CNF_PKMUL(1, 5, 9) CNF_PKMUL(2, 6, 10) CNF_PKMUL(3, 7, 11) "s_nop 1"
+            : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3])
+            : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]));
+    } else if constexpr (N == 3) {
+        asm volatile("s_nop 7\n\ts_nop 3\n\t" CNF_PKMUL(0, 6, 12) CNF_PKMUL(1, 7, 13) CNF_PKMUL(2, 8, 14) CNF_PKMUL(3, 9, 15) CNF_PKMUL(4, 10, 16)
+            CNF_PKMUL(5, 11, 17) "s_nop 1"
+            : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5])
+            : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]), "v"(y[4]), "v"(y[5]));
+    } else {
+        asm volatile("s_nop 7\n\ts_nop 3\n\t" CNF_PKMUL(0, 8, 16) CNF_PKMUL(1, 9, 17) CNF_PKMUL(2, 10, 18) CNF_PKMUL(3, 11, 19) CNF_PKMUL(4, 12, 20)
+            CNF_PKMUL(5, 13, 21) CNF_PKMUL(6, 14, 22) CNF_PKMUL(7, 15, 23) "s_nop 1"
+            : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7])
+            : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]),
+              "v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]), "v"(y[4]), "v"(y[5]), "v"(y[6]), "v"(y[7]));
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) c[i] = f32x4{o[2 * i][0], o[2 * i][1], o[2 * i + 1][0], o[2 * i + 1][1]};
+}
+#else
+__device__ __forceinline__ void pk_add1(f32x2& a, f32x2& b) { a = a + 1.f; b = b + 1.f; }
+__device__ __forceinline__ void pk_tanh_from_r(f32x2& ha, f32x2& hb, f32x2& da, f32x2& db, const f32x2& ra, const f32x2& rb) {
+    const f32x2 two = {2.f, 2.f}, one = {1.f, 1.f};
+    ha = __builtin_elementwise_fma(ra, two, -one); hb = __builtin_elementwise_fma(rb, two, -one);
+    da = __builtin_elementwise_fma(-ha, ha, one); db = __builtin_elementwise_fma(-hb, hb, one);
+}
+template <int N>
+__device__ __forceinline__ void tiles_mul_block(const f32x4* a, const f32x4* b, f32x4* c) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) c[i] = a[i] * b[i];
+}
+#endif
+// c = a .* b over MT accumulator tiles, in statements of up to 4 tiles
+template <int MT>
+__device__ __forceinline__ void tiles_mul(const f32x4 (&a)[MT], const f32x4 (&b)[MT], f32x4 (&c)[MT]) {
+    constexpr int FULL = MT / 4, REM = MT % 4;
+#pragma unroll
+    for (int q = 0; q < FULL; ++q) tiles_mul_block<4>(&a[4 * q], &b[4 * q], &c[4 * q]);
+    if constexpr (REM > 0) tiles_mul_block<REM>(&a[4 * FULL], &b[4 * FULL], &c[4 * FULL]);
+}
+__device__ __forceinline__ f32x4 tile_fma(const f32x4& a, float s, const f32x4& c) {   // a * s + c
+    const f32x2 a0 = {a[0], a[1]}, a1 = {a[2], a[3]}, c0 = {c[0], c[1]}, c1 = {c[2], c[3]}, ss = {s, s};
+    const f32x2 r0 = __builtin_elementwise_fma(a0, ss, c0), r1 = __builtin_elementwise_fma(a1, ss, c1);
+    return f32x4{r0[0], r0[1], r1[0], r1[1]};
+}
+// sum over the tiles of <a, b>, accumulated two lanes' worth per issue
+template <int MT>
+__device__ __forceinline__ float tiles_dot(const f32x4 (&a)[MT], const f32x4 (&b)[MT]) {
+    f32x2 acc = {0.f, 0.f};
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const f32x2 a0 = {a[mt][0], a[mt][1]}, a1 = {a[mt][2], a[mt][3]}, b0 = {b[mt][0], b[mt][1]}, b1 = {b[mt][2], b[mt][3]};
+        acc = __builtin_elementwise_fma(a0, b0, acc);
+        acc = __builtin_elementwise_fma(a1, b1, acc);
+    }
+    return acc[0] + acc[1];
+}
+
 template <int ACT>
 __device__ __forceinline__ void act_tile(const f32x4& a, f32x4& h, f32x4& d) {
     if constexpr (ACT == CNF_ACT_TANH_PRESCALED || ACT == CNF_ACT_TANH) {
+        // tanh(a) = 2 / (1 + exp(-2a)) - 1, tanh' = 1 - tanh^2: v_exp and v_rcp per value, the rest two values per issue
         f32x2 x0 = {a[0], a[1]}, x1 = {a[2], a[3]};
         if constexpr (ACT == CNF_ACT_TANH) { x0 = x0 * kTanhPrescale; x1 = x1 * kTanhPrescale; }
         f32x2 e0 = {__builtin_amdgcn_exp2f(x0[0]), __builtin_amdgcn_exp2f(x0[1])};
         f32x2 e1 = {__builtin_amdgcn_exp2f(x1[0]), __builtin_amdgcn_exp2f(x1[1])};
-        e0 = e0 + 1.f;
-        e1 = e1 + 1.f;
+        pk_add1(e0, e1);
         const f32x2 r0 = {fast_rcp(e0[0]), fast_rcp(e0[1])}, r1 = {fast_rcp(e1[0]), fast_rcp(e1[1])};
-        const f32x2 two = {2.f, 2.f}, one = {1.f, 1.f};
-        // (Do not name the packed instructions in inline asm here: the compiler inserts the MFMA -> VALU wait states
-        // (s_nop) only for instructions it selected itself, and an asm statement reading an accumulator tile
-        // right after the MFMAs returns garbage.  Measured anyway on values that were safe: no gain.)
-        const f32x2 h0 = __builtin_elementwise_fma(r0, two, -one), h1 = __builtin_elementwise_fma(r1, two, -one);
-        const f32x2 d0 = __builtin_elementwise_fma(-h0, h0, one), d1 = __builtin_elementwise_fma(-h1, h1, one);
+        f32x2 h0, h1, d0, d1;
+        pk_tanh_from_r(h0, h1, d0, d1, r0, r1);
         h = f32x4{h0[0], h0[1], h1[0], h1[1]};
         d = f32x4{d0[0], d0[1], d1[0], d1[1]};
     } else {
@@ -158,6 +252,17 @@ __device__ __forceinline__ void act_tile(const f32x4& a, f32x4& h, f32x4& d) {
             d[r] = dd;
         }
     }
+}
+
+// Phase fence for the instruction schedulers: MFMA, VALU and transcendental instructions stay on their side, LDS reads and
+// scalar instructions may still cross (operand prefetch).  On gfx950 every MFMA -> VALU -> MFMA round trip costs ~9 issue
+// cycles on top of the instructions themselves (profiles/ubench/mfma_valu_overlap.result.txt: 32.0 -> 45.3 cycles for one
+// v_fma behind an MFMA, +4.4 per further one), and f32 MFMAs hide no VALU work, so interleaving the two - which LLVM does
+// eagerly (39 round trips per dynamics call at cfg2) - only costs.  -DCNF_NO_PHASE_FENCE is the A/B switch.
+__device__ __forceinline__ void phase_fence() {
+#ifndef CNF_NO_PHASE_FENCE
+    __builtin_amdgcn_sched_barrier(0x0104);
+#endif
 }
 
 // One dynamics evaluation for a 16-sample tile.
@@ -187,12 +292,15 @@ __device__ __forceinline__ void dyn_eval(const float* __restrict__ smem, const f
             f32x4 wt[HT];
             load_cvec<HT>(smem + LAY.v_w1t, g, wt);
 #pragma unroll
-            for (int mt = 0; mt < HT; ++mt) acc[mt] += wt[mt] * t;
+            for (int mt = 0; mt < HT; ++mt) acc[mt] = tile_fma(wt[mt], t, acc[mt]);
         }
+        phase_fence();
         gemm_tiles<HT, ZR>(smem + LAY.f1z, lane, RegIn<ZR>{z}, acc);
         if constexpr (CR > 0) gemm_tiles<HT, CR>(smem + LAY.f1y, lane, RegIn<CR>{y}, acc);
+        phase_fence();
 #pragma unroll
         for (int mt = 0; mt < HT; ++mt) act_tile<ACT>(acc[mt], h[mt], d[0][mt]);
+        phase_fence();
     }
     // ---- hidden layers 2..L ----
 #pragma unroll
@@ -200,14 +308,17 @@ __device__ __forceinline__ void dyn_eval(const float* __restrict__ smem, const f
         f32x4 acc[HT];
         load_cvec<HT>(smem + LAY.v_bh + (l - 1) * MfmaLayout::vecC(HT), g, acc);
         gemm_hidden<HT, ARITH>(smem + LAY.fh + (l - 1) * LAY.imgHid(), lane, h, acc);
+        phase_fence();
 #pragma unroll
         for (int mt = 0; mt < HT; ++mt) act_tile<ACT>(acc[mt], h[mt], d[l][mt]);
+        phase_fence();
     }
     // ---- last layer (identity): zdot ----
     {
         f32x4 acc[DT];
         load_cvec<DT>(smem + LAY.v_bN, g, acc);
         gemm_tiles<DT, 4 * HT>((LAY.fN_global ? gimg : smem) + LAY.fN, lane, TileIn<HT>{h}, acc);
+        phase_fence();
 #pragma unroll
         for (int s = 0; s < ZR; ++s) zd[s] = acc[s >> 2][s & 3];
     }
@@ -263,33 +374,28 @@ __device__ __forceinline__ void dyn_eval(const float* __restrict__ smem, const f
         if constexpr (ENGINE == ENG_VJP) {
             f32x4 dl[HT];
             if constexpr (PRE) {   // W_N^T eps does not change during the solve: hoisted by the caller
-#pragma unroll
-                for (int mt = 0; mt < HT; ++mt) dl[mt] = pre_c[mt] * d[L - 1][mt];
+                tiles_mul<HT>(pre_c, d[L - 1], dl);
             } else {
                 f32x4 acc[HT];
 #pragma unroll
                 for (int mt = 0; mt < HT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
                 gemm_tiles<HT, ZR>(sm + LAY.bN, lane, RegIn<ZR>{ep}, acc);   // W_N^T eps
-#pragma unroll
-                for (int mt = 0; mt < HT; ++mt) dl[mt] = acc[mt] * d[L - 1][mt];
+                tiles_mul<HT>(acc, d[L - 1], dl);
             }
 #pragma unroll
             for (int l = L - 1; l >= 1; --l) {  // W_{l+1}^T delta, times act'(a_l)
                 f32x4 acc[HT];
 #pragma unroll
                 for (int mt = 0; mt < HT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                phase_fence();
                 gemm_hidden<HT, ARITH>(sm + LAY.bh + (l - 1) * LAY.imgHid(), lane, dl, acc);
-#pragma unroll
-                for (int mt = 0; mt < HT; ++mt) dl[mt] = acc[mt] * d[l - 1][mt];
+                phase_fence();
+                tiles_mul<HT>(acc, d[l - 1], dl);
             }
             if constexpr (PRE == 2) {
                 // without the |eps^T J| regulariser only <eps^T J, eps> = <delta_1, W_1[:,0:D] eps> is
                 // needed: a dot product with the hoisted q = W_1[:,0:D] eps replaces the last product
-                float qd = 0.f;
-#pragma unroll
-                for (int mt = 0; mt < HT; ++mt)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) qd = fmaf(dl[mt][r], pre_q[mt][r], qd);
+                const float qd = tiles_dot<HT>(dl, pre_q);
                 ld -= scale * group_sum(qd);
                 continue;
             }
@@ -302,17 +408,17 @@ __device__ __forceinline__ void dyn_eval(const float* __restrict__ smem, const f
                 for (int mt = 0; mt < HT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
                 if (LAY.v_w1c >= 0 && exact) load_cvec<HT>(sm + LAY.v_w1c + p * MfmaLayout::vecC(HT), g, acc);   // W_1[:, p]: no product
                 else gemm_tiles<HT, ZR>(sm + LAY.f1z, lane, RegIn<ZR>{ep}, acc);  // W_1[:,0:D] v
-#pragma unroll
-                for (int mt = 0; mt < HT; ++mt) tau[mt] = acc[mt] * d[0][mt];
+                tiles_mul<HT>(acc, d[0], tau);
             }
 #pragma unroll
             for (int l = 1; l < L; ++l) {  // act'(a_{l+1}) .* (W_{l+1} tau)
                 f32x4 acc[HT];
 #pragma unroll
                 for (int mt = 0; mt < HT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                phase_fence();
                 gemm_hidden<HT, ARITH>(sm + LAY.fh + (l - 1) * LAY.imgHid(), lane, tau, acc);
-#pragma unroll
-                for (int mt = 0; mt < HT; ++mt) tau[mt] = acc[mt] * d[l][mt];
+                phase_fence();
+                tiles_mul<HT>(acc, d[l], tau);
             }
             if (LAY.v_wNr >= 0 && exact) {
                 // only J_pp = <W_N[p, :], tau> is needed: a dot with row p of W_N (kept in accumulator layout in the
@@ -344,7 +450,7 @@ __device__ __forceinline__ void dyn_eval(const float* __restrict__ smem, const f
 // PRE: 0 none; 1 hoist c = W_N^T eps; 2 also hoist q = W_1[:,0:D] eps and skip the last pullback
 // product (valid only without reg_j).  PRE > 0 needs ENGINE == ENG_VJP and KP == 1.
 template <int HT, int L, int ZR, int CR, int ACT, int ENGINE, int KP, int PRE, int NTHREADS, int ARITH = 0>
-__global__ void __launch_bounds__(NTHREADS)
+__global__ void __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(1, (NTHREADS + 255) / 256)))
 mfma_solve_kernel(KArgs a) {
     constexpr MfmaLayout LAY(HT, L, ZR, CR, ENGINE == ENG_VJP, ARITH);
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -409,13 +515,15 @@ mfma_solve_kernel(KArgs a) {
         }
 
         // ---- fixed-step explicit RK, stage loop rolled (one copy of the dynamics code) ----
-        float kz[6][ZR], kl[6], ke[6], kn[6];
+        // No stage derivative is stored.  Each one is folded at once into (i) the running sums of the step update
+        // (sum_j b_j k_j for z, dlogp, E, n) and (ii) the partial sums P[i] of the state increments of the stages still to
+        // come: P[i] holds sum_{j <= st} a[st+1+i][j] kz_j, so after stage st   P[i] <- P[i+1] + a[st+2+i][st] * zdot   (the
+        // shift is the fma's own operand choice - no moves, no predicated selects), and the next stage starts from
+        // z + dt P[0].  Same fma chains in the same order as summing stored derivatives: bit-identical results.
+        float P[5][ZR], zsum[ZR], lsum, esum, nsum;
+        float zd[ZR], ld = 0.f, ed = 0.f, nd = 0.f;
 #pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            kl[j] = ke[j] = kn[j] = 0.f;
-#pragma unroll
-            for (int s = 0; s < ZR; ++s) kz[j][s] = 0.f;
-        }
+        for (int s = 0; s < ZR; ++s) zd[s] = 0.f;
         f32x4 pre_c[HT], pre_q[HT];
 #pragma unroll
         for (int mt = 0; mt < HT; ++mt) pre_c[mt] = pre_q[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -438,17 +546,18 @@ mfma_solve_kernel(KArgs a) {
 #pragma unroll
                 for (int s = 0; s < ZR; ++s) a.ckpt[(((long long)step * ntiles + tile) * 64 + lane) * ZR + s] = z[s];
             }
+            lsum = esum = nsum = 0.f;
+#pragma unroll
+            for (int s = 0; s < ZR; ++s) {
+                zsum[s] = 0.f;
+#pragma unroll
+                for (int i = 0; i < 5; ++i) P[i][s] = 0.f;
+            }
 #pragma clang loop unroll(disable)
             for (int st = 0; st < ns; ++st) {
                 float zs[ZR];
 #pragma unroll
-                for (int s = 0; s < ZR; ++s) {
-                    float acc = 0.f;
-#pragma unroll
-                    for (int j = 0; j < 5; ++j) acc = fmaf(a.T.a[st][j], kz[j][s], acc);
-                    zs[s] = fmaf(dt, acc, z[s]);
-                }
-                float zd[ZR], ld, ed, nd;
+                for (int s = 0; s < ZR; ++s) zs[s] = fmaf(dt, P[0][s], z[s]);
                 // The weight image is loop-invariant, and LLVM would hoist all ~300 operand reads out
                 // of the RK loops (and spill them).  An opaque zero offset pins the reads per stage.
                 int opaque = 0;
@@ -461,54 +570,37 @@ mfma_solve_kernel(KArgs a) {
                     for (int s = 0; s < ZR; ++s)
                         a.ckpt_k[((((long long)step * ns + st) * ntiles + tile) * 64 + lane) * ZR + s] = zd[s];
                 }
+#ifndef CNF_NO_KFULL   // (A/B switch: the cost of this block on the metric kernel is measured with -DCNF_NO_KFULL)
+                if (a.kfull && valid) {
+                    // all S rows of this stage's derivative in the ABI's layout, [stage][sample][row]: the embedded error
+                    // estimate of an adaptive attempt (cnf_step_embedded, nsteps = 1); the metric path pays one untaken branch
+                    float* kf = a.kfull + ((long long)st * a.B + smp) * S;
 #pragma unroll
-                for (int j = 0; j < 6; ++j) {
-                    const bool hit = (j == st);
-                    kl[j] = hit ? ld : kl[j];
-                    ke[j] = hit ? ed : ke[j];
-                    kn[j] = hit ? nd : kn[j];
+                    for (int s = 0; s < ZR; ++s) { const int f = 4 * s + g; if (f < D) kf[f] = zd[s]; }
+                    if (g == 0) { kf[D] = ld; kf[D + 1] = ed; kf[D + 2] = nd; }
+                }
+#endif
+                const float bst = a.T.b[st];
+                lsum = fmaf(bst, ld, lsum); esum = fmaf(bst, ed, esum); nsum = fmaf(bst, nd, nsum);
 #pragma unroll
-                    for (int s = 0; s < ZR; ++s) kz[j][s] = hit ? zd[s] : kz[j][s];
+                for (int s = 0; s < ZR; ++s) {
+                    zsum[s] = fmaf(bst, zd[s], zsum[s]);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) P[i][s] = fmaf(a.acol[st][i], zd[s], P[i + 1][s]);
+                    P[4][s] = a.acol[st][4] * zd[s];
                 }
             }
             if (single) break;
-#ifndef CNF_NO_KFULL   // (A/B switch: the cost of this block on the metric kernel is measured with -DCNF_NO_KFULL)
-            if (a.kfull && valid) {
-                // all S rows of the step's stage derivatives in the ABI's layout, [stage][sample][row]: the embedded
-                // error estimate of an adaptive attempt (cnf_step_embedded, nsteps = 1).  Once per step, outside
-                // the stage loop, so the metric path pays one untaken branch per step.
+            lacc = fmaf(dt, lsum, lacc); eacc = fmaf(dt, esum, eacc); nacc = fmaf(dt, nsum, nacc);
 #pragma unroll
-                for (int j = 0; j < 6; ++j) {
-                    if (j < ns) {
-                        float* kf = a.kfull + ((long long)j * a.B + smp) * S;
-#pragma unroll
-                        for (int s = 0; s < ZR; ++s) { const int f = 4 * s + g; if (f < D) kf[f] = kz[j][s]; }
-                        if (g == 0) { kf[D] = kl[j]; kf[D + 1] = ke[j]; kf[D + 2] = kn[j]; }
-                    }
-                }
-            }
-#endif
-            float sl = 0.f, se = 0.f, sn = 0.f;
-#pragma unroll
-            for (int j = 0; j < 6; ++j) {
-                const float bj = a.T.b[j];
-                sl = fmaf(bj, kl[j], sl); se = fmaf(bj, ke[j], se); sn = fmaf(bj, kn[j], sn);
-            }
-            lacc = fmaf(dt, sl, lacc); eacc = fmaf(dt, se, eacc); nacc = fmaf(dt, sn, nacc);
-#pragma unroll
-            for (int s = 0; s < ZR; ++s) {
-                float acc = 0.f;
-#pragma unroll
-                for (int j = 0; j < 6; ++j) acc = fmaf(a.T.b[j], kz[j][s], acc);
-                z[s] = fmaf(dt, acc, z[s]);
-            }
+            for (int s = 0; s < ZR; ++s) z[s] = fmaf(dt, zsum[s], z[s]);
         }
 
         if (single) {
             if (valid) {
 #pragma unroll
-                for (int s = 0; s < ZR; ++s) { const int f = 4 * s + g; if (f < D) a.u_out[smp * S + f] = kz[0][s]; }
-                if (g == 0) { a.u_out[smp * S + D] = kl[0]; a.u_out[smp * S + D + 1] = ke[0]; a.u_out[smp * S + D + 2] = kn[0]; }
+                for (int s = 0; s < ZR; ++s) { const int f = 4 * s + g; if (f < D) a.u_out[smp * S + f] = zd[s]; }
+                if (g == 0) { a.u_out[smp * S + D] = ld; a.u_out[smp * S + D + 1] = ed; a.u_out[smp * S + D + 2] = nd; }
             }
             tile = next_tile;
             continue;
