@@ -35,11 +35,19 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
-// sum over the 4 lane groups (lanes l, l^16, l^32, l^48) that hold one sample
+// sum over the 4 lane groups (lanes l, l^16, l^32, l^48) that hold one sample.  gfx950's row / half swaps do each exchange
+// in one VALU instruction: v_permlane16_swap(a, b) exchanges the odd 16-lane rows of a with the even rows of b, so with
+// a = b = v the two results are [r0 r0 r2 r2] and [r1 r1 r3 r3] and their sum is v + v(lane ^ 16); v_permlane32_swap does the
+// same with the 32-lane halves.  (__shfl_xor compiles to address arithmetic + ds_bpermute_b32 + an LDS round trip per stage:
+// ~7 VALU instructions and ~130 cycles of latency for each of the two stages.)
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float group_sum(float v) {
-    v += __shfl_xor(v, 16, 64);
-    v += __shfl_xor(v, 32, 64);
-    return v;
+    const unsigned u = __float_as_uint(v);
+    const u32x2_t r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    const float s = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    const unsigned w = __float_as_uint(s);
+    const u32x2_t q = __builtin_amdgcn_permlane32_swap(w, w, false, false);
+    return __uint_as_float(q[0]) + __uint_as_float(q[1]);
 }
 
 
