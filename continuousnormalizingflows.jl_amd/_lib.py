@@ -11,7 +11,8 @@ import os
 import subprocess
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libcnf_hip.so")
+# CNF_HIP_LIB overrides the library path (same variable as the Julia binding, julia/hip_ext/libcnf.jl): A/B builds
+LIB_PATH = os.environ.get("CNF_HIP_LIB") or os.path.join(_PKG, "libcnf_hip.so")
 CSRC = os.path.join(_PKG, "csrc")
 MAX_LAYERS = 8
 

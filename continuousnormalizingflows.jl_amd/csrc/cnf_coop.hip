@@ -15,22 +15,39 @@
 //     XCD) with 16-byte-per-lane coalesced loads, each reused by 4 sample tiles (16 MFMAs per
 //     load instruction), prefetched one k-group ahead.
 // Same math and same reference map as cnf_mfma.hip (src/core/icnf.jl:517-559, utils.jl:150-159).
-#include "cnf_mfma_dev.h"
+// With ONE wave per SIMD the packed-f32 asm statements (each carries its own wait states and is volatile) and the MFMA / VALU
+// phase fences of the per-wave kernel cost more than they save here (same-box A/B at cfg4: 29.0 ms with both, 28.5 / 29.1 with
+// one, 28.1 with neither): nothing else can issue while this wave sits in an s_nop, and the k-loops need the scheduler's freedom
+// to place the L2 / LDS fragment loads.  This translation unit takes the plain forms.
+#define CNF_NO_PK_ASM 1
+#define CNF_NO_PHASE_FENCE 1
+#include "cnf_mfma_kernel.h"   // act_tile, tiles_mul, tile_fma: shared with the per-wave kernel
 
 namespace cnf {
 
-// acc[m][q] += A(global image; M-tile mt0+m) * B(LDS image; sample tile nt0+q), over KG k-groups.
-// Two fragment sets ping-pong (k-loop unrolled by 2): the loads of k-group kg+1 — A from L2, B from
-// LDS — are issued before the 16 M NQ MFMAs of k-group kg, so both latencies hide behind them and
-// no register copies are needed.
-template <int M, int NQ>
-__device__ __forceinline__ void coop_frag_load(const f32x4* __restrict__ A, int mt0, int KG, int kg,
-                                               const f32x4* __restrict__ bimg, int nt0, int lane,
-                                               f32x4 (&a)[M], f32x4 (&b)[NQ]) {
+// One wave per SIMD means nothing hides a stall, so the structure below is about never waiting:
+//   * the FIRST weight fragment of every product (an L2 read, 1-2 k cycles) is requested before the activation / exchange /
+//     barrier phase that precedes the product, not after it (the A images do not depend on the barrier); biases likewise;
+//   * no stage derivative is stored: running sums, as in the per-wave kernel; act' of the last hidden layer is rebuilt from the
+//     activations still sitting in the exchange buffer instead of being held in 64 registers.
+// (Tried and dropped: hoisting the solve-invariant products c = W_N^T eps and q = W_1[:,0:D] eps out of the RK loop, as the
+// per-wave kernel does, through a per-workgroup global workspace - LDS and registers are full.  5.5 % fewer MFMAs, but 128 KB per
+// workgroup per dynamics call does not stay in the 4 MB L2 of an XCD beside the weight image (PMC: 10 GB of HBM reads per launch
+// when streamed), and because vmcnt retires in order the reads cannot hide under the product they are issued before: its own
+// fragment loads wait for them.  cfg4: 25.7 ms without, 28.7 ms with c alone, 27.6 - 29.0 ms with both.)
+
+// A fragments of k-group kg for M-tiles mt0 .. mt0 + M - 1 (global image, 16 B per lane, coalesced); A already points at the lane
+template <int M>
+__device__ __forceinline__ void coop_load_a(const f32x4* __restrict__ A, int mt0, int KG, int kg, f32x4 (&a)[M]) {
 #pragma unroll
     for (int m = 0; m < M; ++m) a[m] = A[((mt0 + m) * KG + kg) * 64];
+}
+// B fragments of k-group kg for sample tiles nt0 .. nt0 + NQ - 1 (LDS exchange image, conflict-free ds_read_b128)
+// (NT = sample tiles of the super-tile = tiles per k-group in the image)
+template <int NQ, int NT>
+__device__ __forceinline__ void coop_load_b(const f32x4* __restrict__ bimg, int nt0, int kg, int lane, f32x4 (&b)[NQ]) {
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) b[q] = bimg[(kg * 4 + nt0 + q) * 64 + lane];
+    for (int q = 0; q < NQ; ++q) b[q] = bimg[(kg * NT + nt0 + q) * 64 + lane];
 }
 
 template <int M, int NQ>
@@ -43,20 +60,22 @@ __device__ __forceinline__ void coop_frag_mfma(const f32x4 (&a)[M], const f32x4 
             for (int q = 0; q < NQ; ++q) acc[m][q] = mfma4(a[m][j], b[q][j], acc[m][q]);
 }
 
-template <int M, int NQ>
-__device__ __forceinline__ void coop_gemm(const float* __restrict__ gimg, int mt0, int KG,
+// acc[m][q] += A(global image; M-tile mt0+m) * B(LDS image; sample tile nt0+q), over KG k-groups.  `a0` arrives holding the A
+// fragments of k-group 0 (requested by the caller one phase earlier).  Two fragment sets ping-pong (k-loop unrolled by 2): the
+// loads of k-group kg+1 - A from L2, B from LDS - are issued before the 16 M NQ MFMAs of k-group kg.
+template <int M, int NQ, int NT>
+__device__ __forceinline__ void coop_gemm(const f32x4* __restrict__ A, int mt0, int KG,
                                           const f32x4* __restrict__ bimg, int nt0, int lane,
-                                          f32x4 (&acc)[M][NQ]) {
-    const f32x4* __restrict__ A = reinterpret_cast<const f32x4*>(gimg) + lane;
-    f32x4 a0[M], a1[M], b0[NQ], b1[NQ];
-    coop_frag_load<M, NQ>(A, mt0, KG, 0, bimg, nt0, lane, a0, b0);
+                                          f32x4 (&a0)[M], f32x4 (&acc)[M][NQ]) {
+    f32x4 a1[M], b0[NQ], b1[NQ];
+    coop_load_b<NQ, NT>(bimg, nt0, 0, lane, b0);
 #pragma clang loop unroll(disable)
     for (int kg = 0; kg < KG; kg += 2) {
         const bool has1 = kg + 1 < KG, has2 = kg + 2 < KG;   // wave-uniform
-        if (has1) coop_frag_load<M, NQ>(A, mt0, KG, kg + 1, bimg, nt0, lane, a1, b1);
+        if (has1) { coop_load_a<M>(A, mt0, KG, kg + 1, a1); coop_load_b<NQ, NT>(bimg, nt0, kg + 1, lane, b1); }
         coop_frag_mfma<M, NQ>(a0, b0, acc);
         if (has1) {
-            if (has2) coop_frag_load<M, NQ>(A, mt0, KG, kg + 2, bimg, nt0, lane, a0, b0);
+            if (has2) { coop_load_a<M>(A, mt0, KG, kg + 2, a0); coop_load_b<NQ, NT>(bimg, nt0, kg + 2, lane, b0); }
             coop_frag_mfma<M, NQ>(a1, b1, acc);
         }
     }
@@ -68,120 +87,176 @@ __device__ __forceinline__ void gload_cvec(const float* __restrict__ vec, int mt
     for (int m = 0; m < MT; ++m) out[m] = *reinterpret_cast<const f32x4*>(vec + ((mt0 + m) * 4 + g) * 4);
 }
 
-template <int HT, int L, int ZR, int ACT>
+// NT: sample tiles per super-tile (4: one workgroup per CU owns 64 samples; 2: two workgroups per CU own 32 samples each - half
+// the exchange buffers and half the accumulators per wave, so two waves share each SIMD and fill each other's stalls, at the
+// price of each weight fragment feeding 2 sample tiles instead of 4).  Waves 0 .. NT-1 own the ODE state of one sample tile.
+template <int HT, int L, int ZR, int ACT, int NT>
 __device__ __forceinline__ void coop_eval(const float* __restrict__ P, f32x4* __restrict__ xbuf,
                                           f32x4* __restrict__ zbuf, const f32x4* __restrict__ ebuf,
                                           int lane, int wave, float t, bool autonomous, bool reg_z,
-                                          bool reg_j, const float (&zs)[ZR], const float (&eps)[ZR],
+                                          bool reg_j, const float (&zs)[ZR],
                                           float (&zd)[ZR], float& ld, float& ed, float& nd) {
     constexpr MfmaLayout LAY(HT, L, ZR, 0, true);
-    constexpr int MTW = HT / 4, DT = (ZR + 3) / 4, XB = HT * 4 * 64;   // XB: f32x4 per exchange buffer
+    constexpr int MTW = HT / 4, DT = (ZR + 3) / 4, XB = HT * NT * 64;   // XB: f32x4 per exchange buffer
+    const bool owner = wave < NT;                                        // this wave integrates sample tile `wave`
     const int g = lane >> 4;
     const int mt0 = wave * MTW;
-    // publish this wave's stage state as the B image of sample tile `wave`
-#pragma unroll
-    for (int kg = 0; kg < DT; ++kg) {
-        f32x4 v;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = (4 * kg + j < ZR) ? zs[(4 * kg + j) < ZR ? 4 * kg + j : 0] : 0.f;
-        zbuf[(kg * 4 + wave) * 64 + lane] = v;
-    }
-    __syncthreads();
-
-    f32x4 d[L][MTW][4];
-    f32x4 acc[MTW][4];
+    const f32x4* __restrict__ Pq = reinterpret_cast<const f32x4*>(P) + lane;   // image offsets are multiples of 4 floats
+    f32x4 afr[MTW];                      // first A fragments of the next H-row product, requested one phase ahead
+    f32x4 afd[DT];                       // ... of the next D-row product (last layer, W_1^T)
+    // act' of this wave's features, kept for the pullback - except the LAST hidden layer's when it can be rebuilt from the
+    // activations themselves, which stay in the exchange buffer until delta_{L-1} replaces them (tanh: 1 - h^2): 64 registers
+    constexpr bool D_FROM_H = (ACT == CNF_ACT_TANH_PRESCALED || ACT == CNF_ACT_TANH);
+    constexpr int LD = D_FROM_H ? (L > 1 ? L - 1 : 1) : L;
+    f32x4 d[LD][MTW][NT];
+    f32x4 acc[MTW][NT];
     // ---- layer 1 ----
     {
         f32x4 bias[MTW], wt[MTW];
+        coop_load_a<MTW>(Pq + LAY.f1z / 4, mt0, DT, 0, afr);
         gload_cvec<MTW>(P + LAY.v_b1, mt0, g, bias);
         gload_cvec<MTW>(P + LAY.v_w1t, mt0, g, wt);
+        // publish this wave's stage state as the B image of sample tile `wave`
+        if (owner) {
 #pragma unroll
-        for (int m = 0; m < MTW; ++m)
+            for (int kg = 0; kg < DT; ++kg) {
+                f32x4 v;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) acc[m][q] = autonomous ? bias[m] : bias[m] + wt[m] * t;
-        coop_gemm<MTW, 4>(P + LAY.f1z, mt0, DT, zbuf, 0, lane, acc);
+                for (int j = 0; j < 4; ++j) v[j] = (4 * kg + j < ZR) ? zs[(4 * kg + j) < ZR ? 4 * kg + j : 0] : 0.f;
+                zbuf[(kg * NT + wave) * 64 + lane] = v;
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < MTW; ++m) {
+            const f32x4 b0 = autonomous ? bias[m] : tile_fma(wt[m], t, bias[m]);
+#pragma unroll
+            for (int q = 0; q < NT; ++q) acc[m][q] = b0;
+        }
+        __syncthreads();
+        phase_fence();
+        coop_gemm<MTW, NT, NT>(Pq + LAY.f1z / 4, mt0, DT, zbuf, 0, lane, afr, acc);
+        phase_fence();
     }
     // cur = exchange buffer holding the current layer's activations (compile-time after unrolling)
 #pragma unroll
     for (int l = 0; l < L; ++l) {
         const int cur = l & 1;
-        if (l > 0) {
-            f32x4 bias[MTW];
-            gload_cvec<MTW>(P + LAY.v_bh + (l - 1) * MfmaLayout::vecC(HT), mt0, g, bias);
-#pragma unroll
-            for (int m = 0; m < MTW; ++m)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) acc[m][q] = bias[m];
-            coop_gemm<MTW, 4>(P + LAY.fh + (l - 1) * MfmaLayout::imgA(HT, HT), mt0, HT, xbuf + (cur ^ 1) * XB, 0,
-                              lane, acc);
-        }
+        // request what the NEXT product needs before this layer's activation / exchange / barrier phase
+        if (l + 1 < L) coop_load_a<MTW>(Pq + (LAY.fh + l * MfmaLayout::imgA(HT, HT)) / 4, mt0, HT, 0, afr);
+        else if (owner) coop_load_a<DT>(Pq + LAY.fN / 4, 0, HT, 0, afd);
 #pragma unroll
         for (int m = 0; m < MTW; ++m)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                f32x4 h;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float dd;
-                    h[r] = act_fwd<ACT>(acc[m][q][r], dd);
-                    d[l][m][q][r] = dd;
-                }
-                xbuf[cur * XB + ((mt0 + m) * 4 + q) * 64 + lane] = h;
+            for (int q = 0; q < NT; ++q) {
+                f32x4 h, dd;
+                act_tile<ACT>(acc[m][q], h, dd);
+                if (!(D_FROM_H && l == L - 1 && L > 1)) d[l < LD ? l : 0][m][q] = dd;
+                xbuf[cur * XB + ((mt0 + m) * NT + q) * 64 + lane] = h;
             }
+        if (l + 1 < L) {
+            // the next layer's bias goes straight into the accumulators (dead now); the request overlaps the barrier
+            f32x4 bnx[MTW];
+            gload_cvec<MTW>(P + LAY.v_bh + l * MfmaLayout::vecC(HT), mt0, g, bnx);
+#pragma unroll
+            for (int m = 0; m < MTW; ++m)
+#pragma unroll
+                for (int q = 0; q < NT; ++q) acc[m][q] = bnx[m];
+        }
         __syncthreads();
+        if (l + 1 < L) {
+            phase_fence();
+            coop_gemm<MTW, NT, NT>(Pq + (LAY.fh + l * MfmaLayout::imgA(HT, HT)) / 4, mt0, HT, xbuf + cur * XB, 0, lane, afr, acc);
+            phase_fence();
+        }
     }
     constexpr int hbuf = (L - 1) & 1;   // buffer holding h_L
     // ---- last layer (identity) for this wave's own sample tile: zdot ----
-    {
+    if (owner) {
         f32x4 zacc[DT][1];
         f32x4 bias[DT];
         gload_cvec<DT>(P + LAY.v_bN, 0, g, bias);
 #pragma unroll
         for (int m = 0; m < DT; ++m) zacc[m][0] = bias[m];
-        coop_gemm<DT, 1>(P + LAY.fN, 0, HT, xbuf + hbuf * XB, wave, lane, zacc);
+        phase_fence();
+        coop_gemm<DT, 1, NT>(Pq + LAY.fN / 4, 0, HT, xbuf + hbuf * XB, wave, lane, afd, zacc);
+        phase_fence();
 #pragma unroll
         for (int s = 0; s < ZR; ++s) zd[s] = zacc[s >> 2][0][s & 3];
     }
     ed = 0.f;
-    if (reg_z) {
+    if (reg_z && owner) {
         float e2 = 0.f;
 #pragma unroll
         for (int s = 0; s < ZR; ++s) e2 = fmaf(zd[s], zd[s], e2);
         ed = sqrtf(group_sum(e2));
     }
-    // ---- pullback: delta_L = (W_N^T eps) .* act'_L, written to the buffer h_{L-1} occupied ----
-#pragma unroll
-    for (int m = 0; m < MTW; ++m)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) acc[m][q] = f32x4{0.f, 0.f, 0.f, 0.f};
-    coop_gemm<MTW, 4>(P + LAY.bN, mt0, DT, ebuf, 0, lane, acc);
-#pragma unroll
-    for (int l = L - 1; l >= 0; --l) {
-        // acc holds W_{l+2}^T delta_{l+2} (or W_N^T eps): multiply by act'_{l+1}, publish, next product
-        const int wbuf = ((L - 1 - l) & 1) ^ hbuf ^ 1;   // alternate, starting opposite to hbuf
+    // ---- pullback: delta_L = c .* act'_L into the buffer h_{L-1} occupied, then W_l^T delta_l .* act'_{l-1} downwards ----
+    nd = 0.f;
+    {   // c = W_N^T eps
 #pragma unroll
         for (int m = 0; m < MTW; ++m)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) xbuf[wbuf * XB + ((mt0 + m) * 4 + q) * 64 + lane] = acc[m][q] * d[l][m][q];
+            for (int q = 0; q < NT; ++q) acc[m][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        coop_load_a<MTW>(Pq + LAY.bN / 4, mt0, DT, 0, afr);
+        coop_gemm<MTW, NT, NT>(Pq + LAY.bN / 4, mt0, DT, ebuf, 0, lane, afr, acc);
+        if (L > 1) coop_load_a<MTW>(Pq + (LAY.bh + (L - 2) * MfmaLayout::imgA(HT, HT)) / 4, mt0, HT, 0, afr);
+    }
+#pragma unroll
+    for (int l = L - 1; l >= 0; --l) {
+        // acc holds W_{l+2}^T delta_{l+2} (or c): multiply by act'_{l+1}; publish it for the next product
+        const int wbuf = ((L - 1 - l) & 1) ^ hbuf ^ 1;   // alternate, starting opposite to hbuf
+#pragma unroll
+        for (int m = 0; m < MTW; ++m) {
+            f32x4 dm[NT], dl[NT];
+            if (D_FROM_H && L > 1 && l == L - 1) {
+                // act'_L = 1 - h_L^2 from this wave's own tiles of h_L, still in the exchange buffer
+#pragma unroll
+                for (int q = 0; q < NT; ++q) {
+                    const f32x4 h = xbuf[hbuf * XB + ((mt0 + m) * NT + q) * 64 + lane];
+                    const f32x2 h0 = {h[0], h[1]}, h1 = {h[2], h[3]}, one = {1.f, 1.f};
+                    const f32x2 d0 = __builtin_elementwise_fma(-h0, h0, one), d1 = __builtin_elementwise_fma(-h1, h1, one);
+                    dm[q] = f32x4{d0[0], d0[1], d1[0], d1[1]};
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < NT; ++q) dm[q] = d[l < LD ? l : 0][m][q];
+            }
+            tiles_mul<NT>(acc[m], dm, dl);
+#pragma unroll
+            for (int q = 0; q < NT; ++q) xbuf[wbuf * XB + ((mt0 + m) * NT + q) * 64 + lane] = dl[q];
+        }
+        if (l == 0 && owner) coop_load_a<DT>(Pq + LAY.b1 / 4, 0, HT, 0, afd);
         __syncthreads();
         if (l > 0) {
 #pragma unroll
             for (int m = 0; m < MTW; ++m)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) acc[m][q] = f32x4{0.f, 0.f, 0.f, 0.f};
-            coop_gemm<MTW, 4>(P + LAY.bh + (l - 1) * MfmaLayout::imgA(HT, HT), mt0, HT, xbuf + wbuf * XB, 0, lane, acc);
-        } else {
-            // g = W_1[:,0:D]^T delta_1 for this wave's own sample tile
+                for (int q = 0; q < NT; ++q) acc[m][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+            phase_fence();
+            coop_gemm<MTW, NT, NT>(Pq + (LAY.bh + (l - 1) * MfmaLayout::imgA(HT, HT)) / 4, mt0, HT, xbuf + wbuf * XB, 0, lane, afr, acc);
+            phase_fence();
+            if (l > 1) coop_load_a<MTW>(Pq + (LAY.bh + (l - 2) * MfmaLayout::imgA(HT, HT)) / 4, mt0, HT, 0, afr);
+        } else if (owner) {
+            // g = W_1[:,0:D]^T delta_1 for this wave's own sample tile (needed for |eps^T J|)
             f32x4 gacc[DT][1];
 #pragma unroll
             for (int m = 0; m < DT; ++m) gacc[m][0] = f32x4{0.f, 0.f, 0.f, 0.f};
-            coop_gemm<DT, 1>(P + LAY.b1, 0, HT, xbuf + wbuf * XB, wave, lane, gacc);
+            phase_fence();
+            coop_gemm<DT, 1, NT>(Pq + LAY.b1 / 4, 0, HT, xbuf + wbuf * XB, wave, lane, afd, gacc);
+            phase_fence();
+            // this lane's probe values sit in the B image of eps (k-group kg, own sample tile): no registers held for them
             float dot = 0.f, n2 = 0.f;
 #pragma unroll
-            for (int s = 0; s < ZR; ++s) {
-                const float gv = gacc[s >> 2][0][s & 3];
-                dot = fmaf(gv, eps[s], dot);
-                n2 = fmaf(gv, gv, n2);
+            for (int kg = 0; kg < DT; ++kg) {
+                const f32x4 ev = ebuf[(kg * NT + wave) * 64 + lane];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (4 * kg + j < ZR) {
+                        const float gv = gacc[kg][0][j];
+                        dot = fmaf(gv, ev[j], dot);
+                        n2 = fmaf(gv, gv, n2);
+                    }
+                }
             }
             ld = -group_sum(dot);
             nd = reg_j ? sqrtf(group_sum(n2)) : 0.f;
@@ -189,24 +264,26 @@ __device__ __forceinline__ void coop_eval(const float* __restrict__ P, f32x4* __
     }
 }
 
-// NS: Runge-Kutta stage derivatives kept (4 for RK4, 6 for Tsit5)
-template <int HT, int L, int ZR, int ACT, int NS>
-__global__ void __launch_bounds__(256)
+// NS: Runge-Kutta stages of the instance (4: RK4, 6: Tsit5) - the partial sums of the later stages' increments take NS - 1 rows
+template <int HT, int L, int ZR, int ACT, int NS, int NT>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NT == 4 ? 1 : 2, NT == 4 ? 1 : 2)))
 coop_vjp_solve_kernel(KArgs a) {
-    constexpr int DT = (ZR + 3) / 4, XB = HT * 4 * 64;
+    constexpr int DT = (ZR + 3) / 4, XB = HT * NT * 64;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    f32x4* xbuf = reinterpret_cast<f32x4*>(smem);   // [2][HT][4 sample tiles][64 lanes]
-    f32x4* zbuf = xbuf + 2 * XB;                     // [DT][4][64]
-    f32x4* ebuf = zbuf + DT * 4 * 64;                // [DT][4][64]
+    f32x4* xbuf = reinterpret_cast<f32x4*>(smem);   // [2][HT][NT sample tiles][64 lanes]
+    f32x4* zbuf = xbuf + 2 * XB;                     // [DT][NT][64]
+    f32x4* ebuf = zbuf + DT * NT * 64;               // [DT][NT][64]
     const int lane = threadIdx.x & 63, g = lane >> 4, n = lane & 15;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int D = a.D, S = D + 3;
     const bool reg_z = a.reg_z, reg_j = a.reg_j, autonomous = a.autonomous;
-    const long long nst = (a.B + 63) / 64;
+    constexpr int SUP = 16 * NT;                      // samples per super-tile
+    const long long nst = (a.B + SUP - 1) / SUP;
+    const bool owner = wave < NT;
 
     for (long long st = blockIdx.x; st < nst; st += gridDim.x) {
-        const long long smp = st * 64 + wave * 16 + n;
-        const bool valid = smp < a.B;
+        const long long smp = st * SUP + (owner ? wave : 0) * 16 + n;
+        const bool valid = owner && smp < a.B;
         const long long sc = valid ? smp : a.B - 1;
         float z[ZR], eps[ZR];
         float lacc = 0.f, eacc = 0.f, nacc = 0.f;
@@ -218,22 +295,24 @@ coop_vjp_solve_kernel(KArgs a) {
             eps[s] = f < D ? a.eps[sc * D + f] : 0.f;
         }
         if (!a.x) { lacc = a.u0[sc * S + D]; eacc = a.u0[sc * S + D + 1]; nacc = a.u0[sc * S + D + 2]; }
-        __syncthreads();   // previous super-tile's readers of ebuf are done
+        __syncthreads();   // previous super-tile's readers of the exchange buffers are done
+        if (owner) {
 #pragma unroll
-        for (int kg = 0; kg < DT; ++kg) {
-            f32x4 v;
+            for (int kg = 0; kg < DT; ++kg) {
+                f32x4 v;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = (4 * kg + j < ZR) ? eps[(4 * kg + j) < ZR ? 4 * kg + j : 0] : 0.f;
-            ebuf[(kg * 4 + wave) * 64 + lane] = v;
+                for (int j = 0; j < 4; ++j) v[j] = (4 * kg + j < ZR) ? eps[(4 * kg + j) < ZR ? 4 * kg + j : 0] : 0.f;
+                ebuf[(kg * NT + wave) * 64 + lane] = v;
+            }
         }
 
-        float kz[NS][ZR], kl[NS], ke[NS], kn[NS];
+        // ---- fixed-step explicit RK, stage loop rolled; running sums instead of stored stage derivatives (see
+        // mfma_solve_kernel in cnf_mfma_kernel.h: same fma chains in the same order) ----
+        constexpr int NP = NS - 1;
+        float Pz[NP][ZR], zsum[ZR], lsum, esum, nsum;
+        float zd[ZR], ld = 0.f, ed = 0.f, nd = 0.f;
 #pragma unroll
-        for (int j = 0; j < NS; ++j) {
-            kl[j] = ke[j] = kn[j] = 0.f;
-#pragma unroll
-            for (int s = 0; s < ZR; ++s) kz[j][s] = 0.f;
-        }
+        for (int s = 0; s < ZR; ++s) zd[s] = 0.f;
         const float dt = a.dt;
         const bool single = a.nsteps == 0;
         const int ns = single ? 1 : (a.T.ns < NS ? a.T.ns : NS);
@@ -241,50 +320,40 @@ coop_vjp_solve_kernel(KArgs a) {
 #pragma clang loop unroll(disable)
         for (int step = 0; step < nsteps; ++step) {
             const float tn = a.t0 + (float)step * dt;
+            lsum = esum = nsum = 0.f;
+#pragma unroll
+            for (int s = 0; s < ZR; ++s) {
+                zsum[s] = 0.f;
+#pragma unroll
+                for (int i = 0; i < NP; ++i) Pz[i][s] = 0.f;
+            }
 #pragma clang loop unroll(disable)
             for (int sg = 0; sg < ns; ++sg) {
                 float zs[ZR];
 #pragma unroll
+                for (int s = 0; s < ZR; ++s) zs[s] = fmaf(dt, Pz[0][s], z[s]);
+                coop_eval<HT, L, ZR, ACT, NT>(a.packed, xbuf, zbuf, ebuf, lane, wave, tn + a.T.c[sg] * dt, autonomous,
+                                          reg_z, reg_j, zs, zd, ld, ed, nd);
+                const float bst = a.T.b[sg];
+                lsum = fmaf(bst, ld, lsum); esum = fmaf(bst, ed, esum); nsum = fmaf(bst, nd, nsum);
+#pragma unroll
                 for (int s = 0; s < ZR; ++s) {
-                    float acc = 0.f;
+                    zsum[s] = fmaf(bst, zd[s], zsum[s]);
 #pragma unroll
-                    for (int j = 0; j < NS - 1; ++j) acc = fmaf(a.T.a[sg][j], kz[j][s], acc);
-                    zs[s] = fmaf(dt, acc, z[s]);
-                }
-                float zd[ZR], ld, ed, nd;
-                coop_eval<HT, L, ZR, ACT>(a.packed, xbuf, zbuf, ebuf, lane, wave, tn + a.T.c[sg] * dt, autonomous,
-                                          reg_z, reg_j, zs, eps, zd, ld, ed, nd);
-#pragma unroll
-                for (int j = 0; j < NS; ++j) {
-                    const bool hit = (j == sg);
-                    kl[j] = hit ? ld : kl[j];
-                    ke[j] = hit ? ed : ke[j];
-                    kn[j] = hit ? nd : kn[j];
-#pragma unroll
-                    for (int s = 0; s < ZR; ++s) kz[j][s] = hit ? zd[s] : kz[j][s];
+                    for (int i = 0; i < NP - 1; ++i) Pz[i][s] = fmaf(a.acol[sg][i], zd[s], Pz[i + 1][s]);
+                    Pz[NP - 1][s] = a.acol[sg][NP - 1] * zd[s];
                 }
             }
             if (single) break;
-            float sl = 0.f, se = 0.f, sn = 0.f;
+            lacc = fmaf(dt, lsum, lacc); eacc = fmaf(dt, esum, eacc); nacc = fmaf(dt, nsum, nacc);
 #pragma unroll
-            for (int j = 0; j < NS; ++j) {
-                const float bj = a.T.b[j];
-                sl = fmaf(bj, kl[j], sl); se = fmaf(bj, ke[j], se); sn = fmaf(bj, kn[j], sn);
-            }
-            lacc = fmaf(dt, sl, lacc); eacc = fmaf(dt, se, eacc); nacc = fmaf(dt, sn, nacc);
-#pragma unroll
-            for (int s = 0; s < ZR; ++s) {
-                float acc = 0.f;
-#pragma unroll
-                for (int j = 0; j < NS; ++j) acc = fmaf(a.T.b[j], kz[j][s], acc);
-                z[s] = fmaf(dt, acc, z[s]);
-            }
+            for (int s = 0; s < ZR; ++s) z[s] = fmaf(dt, zsum[s], z[s]);
         }
         if (single) {
             if (valid) {
 #pragma unroll
-                for (int s = 0; s < ZR; ++s) { const int f = 4 * s + g; if (f < D) a.u_out[smp * S + f] = kz[0][s]; }
-                if (g == 0) { a.u_out[smp * S + D] = kl[0]; a.u_out[smp * S + D + 1] = ke[0]; a.u_out[smp * S + D + 2] = kn[0]; }
+                for (int s = 0; s < ZR; ++s) { const int f = 4 * s + g; if (f < D) a.u_out[smp * S + f] = zd[s]; }
+                if (g == 0) { a.u_out[smp * S + D] = ld; a.u_out[smp * S + D + 1] = ed; a.u_out[smp * S + D + 2] = nd; }
             }
             continue;
         }
@@ -319,11 +388,11 @@ coop_vjp_solve_kernel(KArgs a) {
 // ---------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------
-template <int HT, int L, int ZR, int ACT, int NS>
+template <int HT, int L, int ZR, int ACT, int NS, int NT>
 static hipError_t launch_coop(const KArgs& a, int nblocks, hipStream_t st) {
     constexpr int DT = (ZR + 3) / 4;
-    constexpr int lds = (2 * HT * 4 * 64 + 2 * DT * 4 * 64) * 16;
-    auto kern = coop_vjp_solve_kernel<HT, L, ZR, ACT, NS>;
+    constexpr int lds = (2 * HT * NT * 64 + 2 * DT * NT * 64) * 16;
+    auto kern = coop_vjp_solve_kernel<HT, L, ZR, ACT, NS, NT>;
     static DeviceOnce once;
     int dev = 0;
     hipError_t e0 = hipGetDevice(&dev);
@@ -339,11 +408,20 @@ static hipError_t launch_coop(const KArgs& a, int nblocks, hipStream_t st) {
 
 struct CoopInst {
     int HT, L, ZR, ACT;
-    hipError_t (*fn4)(const KArgs&, int, hipStream_t);   // RK4 (4 stage derivatives kept)
-    hipError_t (*fn6)(const KArgs&, int, hipStream_t);   // Tsit5
+    // [0] RK4, [1] Tsit5 with 64-sample super-tiles (one workgroup per CU); with -DCNF_COOP_NT2 also [2], [3]: the same with
+    // 32-sample super-tiles (two workgroups per CU, two waves per SIMD; CNF_COOP_NT=2 selects them).  Measured at cfg4 on one
+    // box: 28.8 ms against 25.4 ms - each weight fragment then feeds 2 sample tiles instead of 4 and the second wave on the
+    // SIMD hides less than that costs - so the default build does not carry them.
+    hipError_t (*fn[4])(const KArgs&, int, hipStream_t);
 };
+#ifdef CNF_COOP_NT2
+#define COOP_INST(HT, L, ZR, ACT)                                                                        \
+    CoopInst { HT, L, ZR, ACT, { &launch_coop<HT, L, ZR, ACT, 4, 4>, &launch_coop<HT, L, ZR, ACT, 6, 4>,  \
+                                 &launch_coop<HT, L, ZR, ACT, 4, 2>, &launch_coop<HT, L, ZR, ACT, 6, 2> } }
+#else
 #define COOP_INST(HT, L, ZR, ACT) \
-    CoopInst { HT, L, ZR, ACT, &launch_coop<HT, L, ZR, ACT, 4>, &launch_coop<HT, L, ZR, ACT, 6> }
+    CoopInst { HT, L, ZR, ACT, { &launch_coop<HT, L, ZR, ACT, 4, 4>, &launch_coop<HT, L, ZR, ACT, 6, 4>, nullptr, nullptr } }
+#endif
 // tanh instances are compiled for pre-scaled pre-activations (mfma_pack folds -2 log2 e into the
 // forward images); they are matched against CNF_ACT_TANH configurations.  First the exact shapes,
 // then zero-padded ones (state k-steps padded to 8: D <= 32).
@@ -380,9 +458,13 @@ bool coop_supported(int HT, int L, int ZR, int CR, int ACT, int engine, int KP, 
 hipError_t coop_launch(int HT, int L, int ZR, int ACT, const KArgs& a, int num_cus, hipStream_t st) {
     const CoopInst* c = coop_find(HT, L, ZR, ACT);
     if (!c) return hipErrorNotSupported;
-    const long long nst = (a.B + 63) / 64;
-    const int nblocks = (int)(nst < num_cus ? nst : num_cus);
-    return (a.T.ns <= 4 ? c->fn4 : c->fn6)(a, nblocks, st);
+    // sample tiles per super-tile: 4 (one workgroup per CU); CNF_COOP_NT=2 in a -DCNF_COOP_NT2 build picks the two-workgroup form
+    static const int nt_env = [] { const char* e = getenv("CNF_COOP_NT"); return (e && *e) ? atoi(e) : 0; }();
+    const int NT = (nt_env == 2 && c->fn[2]) ? 2 : 4;
+    const long long nst = (a.B + 16 * NT - 1) / (16 * NT);
+    const long long cap = (long long)num_cus * (NT == 4 ? 1 : 2);
+    const int nblocks = (int)(nst < cap ? nst : cap);
+    return c->fn[(a.T.ns <= 4 ? 0 : 1) + (NT == 4 ? 0 : 2)](a, nblocks, st);
 }
 
 }  // namespace cnf

@@ -42,6 +42,7 @@ struct MfmaPlan {
     int prio_mode;      // see KArgs
     int use_queue;
     int* queue_dev;     // one int per plan, zeroed on the stream before every launch
+
     char name[128];
     MfmaPlan() : lay(1, 2, 1, 0, true) {}
 };
