@@ -59,6 +59,9 @@ int cnf_oracle_max_threads(void);
 /* 1: use NNlib.tanh_fast's rational approximation (what Lux runs on CPU Float32); 0: libm tanhf */
 void cnf_oracle_set_fast_tanh(int on);
 
+/* which ISA clone of the block products the loader selected from cpuid: 2 = AVX-512, 1 = the build's baseline (AVX2 + FMA) */
+int cnf_oracle_isa(void);
+
 #ifdef __cplusplus
 }
 #endif

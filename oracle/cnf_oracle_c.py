@@ -57,6 +57,11 @@ def set_fast_tanh(on: bool) -> None:
     lib().cnf_oracle_set_fast_tanh(int(bool(on)))
 
 
+def isa() -> str:
+    """The vector ISA the block products run on (selected at load time from cpuid)."""
+    return {2: "avx512", 1: "avx2"}.get(int(lib().cnf_oracle_isa()), "scalar")
+
+
 def max_threads() -> int:
     return int(lib().cnf_oracle_max_threads())
 
