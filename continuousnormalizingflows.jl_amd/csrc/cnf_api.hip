@@ -162,9 +162,9 @@ int cnf_create(cnf_handle** out, const cnf_config* cfg) {
 
     h->path = CNF_PATH_SIMT;
     if (c.kernel_path == CNF_PATH_LAYERED) {
-        if (!layered_available()) {
+        if (!layered_supports(c)) {
             delete h;
-            return fail(CNF_ERR_UNSUPPORTED, "cnf_create: CNF_PATH_LAYERED needs librocblas.so.5 (dlopen failed)");
+            return fail(CNF_ERR_UNSUPPORTED, "cnf_create: CNF_PATH_LAYERED covers layers of up to 512 outputs and 639 inputs");
         }
         h->path = CNF_PATH_LAYERED;
         h->layered_forced = true;
@@ -175,7 +175,7 @@ int cnf_create(cnf_handle** out, const cnf_config* cfg) {
         } else if (c.kernel_path == CNF_PATH_MFMA || c.arith != CNF_ARITH_F32) {
             delete h;
             return fail(CNF_ERR_UNSUPPORTED, "cnf_create: configuration not covered by the MFMA kernels");
-        } else if (layered_available()) {
+        } else if (layered_supports(c)) {
             h->path = CNF_PATH_LAYERED;
         }
     }

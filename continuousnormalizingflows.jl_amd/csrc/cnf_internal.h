@@ -87,9 +87,10 @@ hipError_t grad_launch(const cnf_config& c, const float* packed_dev, const float
                        int ckpt_zr, const float* eps, const float* ys,
                        const size_t* w_off, const size_t* b_off, int alg, int nsteps, float t0, float t1, const float* tgrid_dev,
                        float probe_w, long long B, const float lam[3], float* slab, float* grad, float* grad_x, int num_cus, hipStream_t st);
-// layer-wise gradient on rocBLAS GEMMs for everything the fused kernels do not cover (cnf_layered.hip)
+// layer-wise evaluation / gradient on the product kernels of cnf_lgemm.hip for everything the fused kernels do not cover (cnf_layered.hip)
 struct LayeredGrad;
-bool layered_available();   // librocblas.so.5 loadable
+bool layered_available();   // always: the products are the library's own kernels (cnf_lgemm.hip)
+bool layered_supports(const cnf_config& c);   // every layer within the product kernels' limits (512 outputs, 639 inputs)
 hipError_t layered_aug_f(LayeredGrad** ctx, const cnf_config& c, const float* P_dev, const size_t* w_off,
                          const size_t* b_off, bool rebuild_params, const StageIn& in, float t, const float* eps,
                          const float* ys, long long B, float* du, hipStream_t st, std::string* err);

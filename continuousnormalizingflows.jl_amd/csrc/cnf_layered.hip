@@ -25,53 +25,33 @@
 // batched GEMMs over column chunks, each chunk accumulating (beta = 1) into its own slab for the whole
 // solve; one kernel sums the slabs in a fixed order at the end (no atomics: bit-reproducible).
 //
-// rocBLAS is resolved with dlopen at first use, so libcnf_hip.so has no link-time dependency on it and
-// every other entry point works without it.
-#include <dlfcn.h>
-
+// The products run on the hand-written MFMA kernels of cnf_lgemm.hip (weights pre-packed into operand images once per parameter
+// set; activation / act' / the pullback's elementwise product fused into their epilogues); the library has no dependency on a
+// vendor BLAS.
+#include <algorithm>
 #include <cstdlib>
 
 #include <string>
 #include <vector>
 
-#include <rocblas/rocblas.h>
-
 #include "cnf_internal.h"
 
 namespace cnf {
 
+// cnf_lgemm.hip
+enum { LG_EPI_PLAIN = 0, LG_EPI_ACT = 1, LG_EPI_MUL = 2, LG_EPI_MUL2 = 3, LG_EPI_BOTTOM = 4, LG_EPI_SBAR = 5 };
+hipError_t lg_pack_image(const float* src, long long sm, long long sk, int M, int K, float* img, hipStream_t st);
+size_t lg_image_floats(int M, int K);
+bool lg_gemm_supported(int M, int K);
+hipError_t lg_gemm(const float* img, int M, int K, const float* in, int ldb, float* out, int ldc, long long N, int epi,
+                   const float* e, int lde, float* dout, int ldd, int act, hipStream_t st, const float* e2 = nullptr,
+                   const float* a3 = nullptr, int ld3 = 0, int first = 0);
+bool lg_wgrad_supported(int M, int Nc);
+int lg_wgrad_chunks(int M, long long B, int num_cus, long long* chunk_out);
+hipError_t lg_wgrad(float* slabs, long long slab_stride, long long chunk, int nchunks, int M, int Nc, const float* x, int ldx,
+                    const float* y, int ldy, long long B, hipStream_t st);
+
 namespace {
-
-struct Blas {
-    void* lib = nullptr;
-    decltype(&rocblas_create_handle) create = nullptr;
-    decltype(&rocblas_destroy_handle) destroy = nullptr;
-    decltype(&rocblas_set_stream) set_stream = nullptr;
-    decltype(&rocblas_sgemm) sgemm = nullptr;
-    decltype(&rocblas_sgemm_strided_batched) sgemm_sb = nullptr;
-    bool ok = false;
-};
-
-Blas load_blas() {
-    Blas b;
-    for (const char* name : {"librocblas.so.5", "librocblas.so", "/opt/rocm/lib/librocblas.so.5", "/opt/rocm/lib/librocblas.so"}) {
-        b.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
-        if (b.lib) break;
-    }
-    if (!b.lib) return b;
-    b.create = (decltype(b.create))dlsym(b.lib, "rocblas_create_handle");
-    b.destroy = (decltype(b.destroy))dlsym(b.lib, "rocblas_destroy_handle");
-    b.set_stream = (decltype(b.set_stream))dlsym(b.lib, "rocblas_set_stream");
-    b.sgemm = (decltype(b.sgemm))dlsym(b.lib, "rocblas_sgemm");
-    b.sgemm_sb = (decltype(b.sgemm_sb))dlsym(b.lib, "rocblas_sgemm_strided_batched");
-    b.ok = b.create && b.destroy && b.set_stream && b.sgemm && b.sgemm_sb;
-    return b;
-}
-
-Blas& blas() {
-    static Blas b = load_blas();
-    return b;
-}
 
 struct LDesc {              // the Dense chain, by value in kernel arguments
     int n_layers;
@@ -142,18 +122,6 @@ __global__ void build_input_kernel(const float* __restrict__ zs, float t, const 
     else if (!autonomous && f == D) v = t;
     else v = ys[j * C + (f - D - (autonomous ? 0 : 1))];
     a0[i] = v;
-}
-
-// in place on a (ld = H + 1): a = act(s), d = act'(s), ones row
-__global__ void act_kernel(float* __restrict__ a, float* __restrict__ d, int act, int H, long long B) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (long long)(H + 1) * B) return;
-    const long long j = i / (H + 1);
-    const int f = (int)(i % (H + 1));
-    if (f == H) { a[i] = 1.f; return; }
-    float dd;
-    a[i] = act_fwd_rt(act, a[i], dd);
-    d[j * H + f] = dd;
 }
 
 // dst[rows x B, ld rows] = src[rows x B, ld lds] (first `rows` rows, row offset roff)
@@ -305,6 +273,22 @@ __global__ void exact_seed_kernel(float* __restrict__ tau, const float* __restri
     tau[i] = w1col[i % H] * d1[i];
 }
 
+// row[j] = <w (stride ws), tau[:, j]>: row i of W_N applied to one tangent per column (a 1 x B product: one wave per column,
+// lanes over the H entries, so the loads of a column are coalesced; an MFMA tile would waste 15 of its 16 rows)
+__global__ void rowdot_kernel(const float* __restrict__ w, long long ws, const float* __restrict__ tau, int H, float* __restrict__ row,
+                              long long B) {
+    const int lane = threadIdx.x & 63;
+    const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+    for (long long j = wave; j < B; j += nwaves) {
+        float acc = 0.f;
+        for (int k = lane; k < H; k += 64) acc = fmaf(w[(long long)k * ws], tau[j * H + k], acc);
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o, 64);
+        if (lane == 0) row[j] = acc;
+    }
+}
+
 // ldot -= act'_N[i] * (W_N[i, :] tau)   (J_ii)
 __global__ void exact_diag_kernel(const float* __restrict__ row, const float* __restrict__ dN, int D, int i,
                                   float* __restrict__ ld, long long B) {
@@ -354,8 +338,18 @@ __global__ void finish_kernel(float* __restrict__ du, const float* __restrict__ 
 
 }  // namespace
 
+// an operand image of A(m, k) = PA[rel + m * sm + k * sk] (M x K), repacked whenever the parameters change
+struct LgImage {
+    long long rel, sm, sk;
+    int M, K;
+    float* img = nullptr;
+    unsigned epoch = 0;
+};
+
 struct LayeredGrad {
-    rocblas_handle rb = nullptr;
+    std::vector<LgImage> images;
+    unsigned epoch = 1;           // bumped whenever PA is rebuilt: stale images are repacked at their next use
+    int num_cus = 0;
     float* ws = nullptr;          // gradient workspace
     size_t ws_floats = 0;
     float* ws_fwd = nullptr;      // forward-evaluation workspace (the gradient calls the forward for the loss)
@@ -364,7 +358,8 @@ struct LayeredGrad {
 
 void layered_grad_destroy(LayeredGrad* g) {
     if (!g) return;
-    if (g->rb && blas().ok) (void)blas().destroy(g->rb);
+    for (LgImage& im : g->images)
+        if (im.img) (void)hipFree(im.img);
     if (g->ws) (void)hipFree(g->ws);
     if (g->ws_fwd) (void)hipFree(g->ws_fwd);
     delete g;
@@ -379,27 +374,69 @@ bool layered_grad_supported(const cnf_config& c) {
         hipError_t _e = (expr);                                                         \
         if (_e != hipSuccess) { *err = std::string(#expr) + ": " + hipGetErrorString(_e); return _e; } \
     } while (0)
-#define LG_BLAS(expr)                                                                   \
-    do {                                                                                \
-        rocblas_status _s = (expr);                                                     \
-        if (_s != rocblas_status_success) { *err = std::string(#expr) + ": rocblas status " + std::to_string((int)_s); return hipErrorUnknown; } \
-    } while (0)
+#define LG_BLAS(expr) LG_HIP(expr)
 
-bool layered_available() { return blas().ok; }
+// every product of the chain (forward, transposed, weight cotangent) fits one launch of the kernels in cnf_lgemm.hip
+bool layered_available() { return true; }
+bool layered_supports(const cnf_config& c) {
+    for (int l = 0; l < c.n_layers; ++l) {
+        const int win = c.widths[l], wout = c.widths[l + 1];
+        if (!lg_gemm_supported(wout, win + 1) || !lg_gemm_supported(win, wout) || !lg_wgrad_supported(wout, win + 1)) return false;
+    }
+    return true;
+}
+
+// the image of A(m, k) = PA[rel + m sm + k sk], packed on first use and again after every parameter rebuild
+static hipError_t lg_image(LayeredGrad& G, const float* PA, long long rel, long long sm, long long sk, int M, int K,
+                           const float** out, hipStream_t st) {
+    for (LgImage& im : G.images) {
+        if (im.rel == rel && im.sm == sm && im.sk == sk && im.M == M && im.K == K) {
+            if (im.epoch != G.epoch) {
+                hipError_t e = lg_pack_image(PA + rel, sm, sk, M, K, im.img, st);
+                if (e != hipSuccess) return e;
+                im.epoch = G.epoch;
+            }
+            *out = im.img;
+            return hipSuccess;
+        }
+    }
+    LgImage im;
+    im.rel = rel; im.sm = sm; im.sk = sk; im.M = M; im.K = K;
+    hipError_t e = hipMalloc((void**)&im.img, lg_image_floats(M, K) * sizeof(float));
+    if (e != hipSuccess) return e;
+    e = lg_pack_image(PA + rel, sm, sk, M, K, im.img, st);
+    if (e != hipSuccess) { (void)hipFree(im.img); return e; }
+    im.epoch = G.epoch;
+    G.images.push_back(im);
+    *out = im.img;
+    return hipSuccess;
+}
+
+// C (ldc) = op(A) Bm: A = PA + rel (column-major m x k with lda, or its transpose) - the call shape of the BLAS routine this
+// replaces; epi / e / dout select the fused epilogue (LG_EPI_*)
+enum { OPN = 0, OPT = 1 };
+static hipError_t lg_product(LayeredGrad& G, const float* PA, int ta, int m, long long n, int k, const float* A, int lda,
+                             const float* Bm, int ldb, float* Cm, int ldc, int epi, const float* e, int lde, float* dout, int ldd,
+                             int act, hipStream_t st, const float* e2 = nullptr, const float* a3 = nullptr, int ld3 = 0,
+                             int first = 0) {
+    if (!lg_gemm_supported(m, k)) return hipErrorNotSupported;
+    const float* img = nullptr;
+    const long long rel = A - PA;
+    hipError_t er = ta == OPN ? lg_image(G, PA, rel, 1, lda, m, k, &img, st) : lg_image(G, PA, rel, lda, 1, m, k, &img, st);
+    if (er != hipSuccess) return er;
+    return lg_gemm(img, m, k, Bm, ldb, Cm, ldc, n, epi, e, lde, dout, ldd, act, st, e2, a3, ld3, first);
+}
 
 // du = augmented_f(u + dt sum coef k, p, t): forward chain, then the trace estimator of the handle's mode
 hipError_t layered_aug_f(LayeredGrad** ctx, const cnf_config& c, const float* P_dev, const size_t* w_off,
                          const size_t* b_off, bool rebuild_params, const StageIn& in, float t, const float* eps,
                          const float* ys, long long B, float* du, hipStream_t st, std::string* err) {
-    Blas& bl = blas();
-    if (!bl.ok) {
-        *err = "layered evaluation: librocblas.so.5 could not be loaded (dlopen)";
+    if (!layered_supports(c)) {
+        *err = "layered evaluation: a layer is wider than the product kernels cover (512 outputs, 639 inputs)";
         return hipErrorNotSupported;
     }
     if (!*ctx) *ctx = new LayeredGrad();
     LayeredGrad& G = **ctx;
-    if (!G.rb) LG_BLAS(bl.create(&G.rb));
-    LG_BLAS(bl.set_stream(G.rb, st));
     const int N = c.n_layers, D = c.nvars + c.naug, C = c.ncond, S = D + 3;
     const int K = c.mode == CNF_MODE_EXACT ? 1 : c.nprobes;
     LDesc L{};
@@ -440,22 +477,25 @@ hipError_t layered_aug_f(LayeredGrad** ctx, const cnf_config& c, const float* P_
     if (rebuild_params || grown) {
         hipLaunchKernelGGL(aug_params_kernel, grid_for(npa), dim3(TPB), 0, st, P_dev, PA, L);
         if (use_q) hipLaunchKernelGGL(layered_q_kernel, grid_for((long long)L.wout[0] * L.wout[1]), dim3(TPB), 0, st, PA, Qm, L, D);
+        ++G.epoch;   // operand images of the old parameters are repacked at their next use
     }
 
-    const float one = 1.f, zero = 0.f;
-    auto gemm = [&](rocblas_operation ta, rocblas_operation tb, int m, long long n, int k, const float* A, int lda,
-                    const float* Bm, int ldb, float* Cm, int ldc) -> rocblas_status {
-        return bl.sgemm(G.rb, ta, tb, m, (rocblas_int)n, k, &one, A, lda, Bm, ldb, &zero, Cm, ldc);
+    // C = op(A) Bm (plain), and the two fused forms: .* e, and activation (h, act', ones row)
+    auto gemm = [&](int ta, int, int m, long long n, int k, const float* A, int lda, const float* Bm, int ldb, float* Cm,
+                    int ldc) -> hipError_t {
+        return lg_product(G, PA, ta, m, n, k, A, lda, Bm, ldb, Cm, ldc, LG_EPI_PLAIN, nullptr, 0, nullptr, 0, 0, st);
     };
-    const rocblas_operation OPN = rocblas_operation_none, OPT = rocblas_operation_transpose;
+    auto gemm_mul = [&](int ta, int m, long long n, int k, const float* A, int lda, const float* Bm, int ldb, float* Cm, int ldc,
+                        const float* e, int lde) -> hipError_t {
+        return lg_product(G, PA, ta, m, n, k, A, lda, Bm, ldb, Cm, ldc, LG_EPI_MUL, e, lde, nullptr, 0, 0, st);
+    };
 
     // forward chain
     hipLaunchKernelGGL(build_input_stage_kernel, grid_for((long long)(c.widths[0] + 1) * B), dim3(TPB), 0, st, in, S, t, ys, a[0],
                        D, C, c.autonomous, B);
-    for (int l = 0; l < N; ++l) {
-        LG_BLAS(gemm(OPN, OPN, L.wout[l], B, L.win[l] + 1, PA + L.pa_off[l], L.wout[l], a[l], L.win[l] + 1, a[l + 1], L.wout[l] + 1));
-        hipLaunchKernelGGL(act_kernel, grid_for((long long)(L.wout[l] + 1) * B), dim3(TPB), 0, st, a[l + 1], d[l], L.act[l], L.wout[l], B);
-    }
+    for (int l = 0; l < N; ++l)   // a_{l+1} = act(W_l a_l + b_l) with act' and the ones row, one launch
+        LG_BLAS(lg_product(G, PA, OPN, L.wout[l], B, L.win[l] + 1, PA + L.pa_off[l], L.wout[l], a[l], L.win[l] + 1, a[l + 1],
+                           L.wout[l] + 1, LG_EPI_ACT, nullptr, 0, d[l], L.wout[l], L.act[l], st));
     LG_HIP(hipMemsetAsync(ldacc, 0, (size_t)B * sizeof(float), st));
     LG_HIP(hipMemsetAsync(ndacc, 0, (size_t)B * sizeof(float), st));
 
@@ -465,9 +505,7 @@ hipError_t layered_aug_f(LayeredGrad** ctx, const cnf_config& c, const float* P_
             float *dl = tA, *vv = tB;
             hipLaunchKernelGGL(mul_rows_kernel, grid_for((long long)D * B), dim3(TPB), 0, st, dl, eps, K * D, k * D, d[N - 1], D, B);
             for (int l = N - 1; l >= 1; --l) {
-                LG_BLAS(gemm(OPT, OPN, L.win[l], B, L.wout[l], PA + L.pa_off[l], L.wout[l], dl, L.wout[l], vv, L.win[l]));
-                const long long HB = (long long)L.win[l] * B;
-                hipLaunchKernelGGL(mul_kernel, grid_for(HB), dim3(TPB), 0, st, vv, vv, d[l - 1], HB);
+                LG_BLAS(gemm_mul(OPT, L.win[l], B, L.wout[l], PA + L.pa_off[l], L.wout[l], dl, L.wout[l], vv, L.win[l], d[l - 1], L.win[l]));
                 float* tmp = dl; dl = vv; vv = tmp;
             }
             LG_BLAS(gemm(OPT, OPN, D, B, L.wout[0], PA, L.wout[0], dl, L.wout[0], vv, D));
@@ -478,11 +516,9 @@ hipError_t layered_aug_f(LayeredGrad** ctx, const cnf_config& c, const float* P_
         // g = J eps: tau_1 = (W_1[:,0:D] eps) .* act'_1, tau_{l+1} = (W_{l+1} tau_l) .* act'_{l+1}
         for (int k = 0; k < K; ++k) {
             float *tau = tA, *nx = tB;
-            LG_BLAS(gemm(OPN, OPN, L.wout[0], B, D, PA, L.wout[0], eps + (long long)k * D, K * D, tau, L.wout[0]));
-            hipLaunchKernelGGL(mul_kernel, grid_for((long long)L.wout[0] * B), dim3(TPB), 0, st, tau, tau, d[0], (long long)L.wout[0] * B);
+            LG_BLAS(gemm_mul(OPN, L.wout[0], B, D, PA, L.wout[0], eps + (long long)k * D, K * D, tau, L.wout[0], d[0], L.wout[0]));
             for (int l = 1; l < N; ++l) {
-                LG_BLAS(gemm(OPN, OPN, L.wout[l], B, L.win[l], PA + L.pa_off[l], L.wout[l], tau, L.win[l], nx, L.wout[l]));
-                hipLaunchKernelGGL(mul_kernel, grid_for((long long)L.wout[l] * B), dim3(TPB), 0, st, nx, nx, d[l], (long long)L.wout[l] * B);
+                LG_BLAS(gemm_mul(OPN, L.wout[l], B, L.win[l], PA + L.pa_off[l], L.wout[l], tau, L.win[l], nx, L.wout[l], d[l], L.wout[l]));
                 float* tmp = tau; tau = nx; nx = tmp;
             }
             hipLaunchKernelGGL(trace_kernel, grid_for(B), dim3(TPB), 0, st, tau, eps, K * D, k * D, ldacc, ndacc, 1.f / (float)K,
@@ -503,12 +539,12 @@ hipError_t layered_aug_f(LayeredGrad** ctx, const cnf_config& c, const float* P_
                 hipLaunchKernelGGL(exact_seed_kernel, grid_for((long long)L.wout[0] * B), dim3(TPB), 0, st, tau,
                                    PA + (long long)L.wout[0] * i, d[0], L.wout[0], B);
                 for (int l = 1; l < N - 1; ++l) {
-                    LG_BLAS(gemm(OPN, OPN, L.wout[l], B, L.win[l], PA + L.pa_off[l], L.wout[l], tau, L.win[l], nx, L.wout[l]));
-                    hipLaunchKernelGGL(mul_kernel, grid_for((long long)L.wout[l] * B), dim3(TPB), 0, st, nx, nx, d[l], (long long)L.wout[l] * B);
+                    LG_BLAS(gemm_mul(OPN, L.wout[l], B, L.win[l], PA + L.pa_off[l], L.wout[l], tau, L.win[l], nx, L.wout[l], d[l], L.wout[l]));
                     float* tmp = tau; tau = nx; nx = tmp;
                 }
                 // row i of W_N tau: a 1 x B product
-                LG_BLAS(gemm(OPN, OPN, 1, B, L.win[N - 1], PA + L.pa_off[N - 1] + i, L.wout[N - 1], tau, L.win[N - 1], row, 1));
+                hipLaunchKernelGGL(rowdot_kernel, dim3((unsigned)std::min<long long>((B + 3) / 4, 4096)), dim3(TPB), 0, st,
+                                   PA + L.pa_off[N - 1] + i, (long long)L.wout[N - 1], tau, L.win[N - 1], row, B);
             }
             hipLaunchKernelGGL(exact_diag_kernel, grid_for(B), dim3(TPB), 0, st, row, d[N - 1], D, i, ldacc, B);
         }
@@ -522,15 +558,19 @@ hipError_t layered_grad(LayeredGrad** ctx, const cnf_config& c, const float* P_d
                         const size_t* b_off, const float* x, const float* eps, const float* ys, int alg,
                         int nsteps, float t0, float t1, const float* tgrid, long long B, const float lam[3], float* grad,
                         float* grad_x, hipStream_t st, std::string* err) {
-    Blas& bl = blas();
-    if (!bl.ok) {
-        *err = "layered gradient: librocblas.so.5 could not be loaded (dlopen)";
+    if (!layered_supports(c)) {
+        *err = "layered gradient: a layer is wider than the product kernels cover (512 outputs, 639 inputs)";
         return hipErrorNotSupported;
     }
     if (!*ctx) *ctx = new LayeredGrad();
     LayeredGrad& G = **ctx;
-    if (!G.rb) LG_BLAS(bl.create(&G.rb));
-    LG_BLAS(bl.set_stream(G.rb, st));
+    if (G.num_cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        LG_HIP(hipGetDevice(&dev));
+        LG_HIP(hipGetDeviceProperties(&prop, dev));
+        G.num_cus = prop.multiProcessorCount;
+    }
 
     // TestMode (icnf.jl:297-339): ldot = -tr J = -sum_k e_k^T J e_k - the pullback below with the D unit vectors as
     // probes, each with weight 1 (what the reference's AD does through its D one-hot passes)
@@ -548,15 +588,13 @@ hipError_t layered_grad(LayeredGrad** ctx, const cnf_config& c, const float* P_d
     }
     L.npa = npa;
     const long long npa_pad = (npa + 63) / 64 * 64;
-    // column chunks of the weight-cotangent GEMMs (K = B split for parallelism; one slab per chunk)
-    // (cfg4, B = 32768, measured: 256 columns per chunk 237 ms per gradient; 128: 246; 512: 263; 2048: 282)
-    long long kc = (B + 255) / 256;
-    kc = (kc + 63) / 64 * 64;
-    if (kc < 256) kc = 256;
-    if (const char* e = getenv("CNF_LAYERED_KC")) { if (atoll(e) >= 16) kc = atoll(e); }   // tuning knob
-    const int nbf = (int)(B / kc);
-    const long long tail = B - (long long)nbf * kc;
-    const int nslab = nbf + (tail > 0 ? 1 : 0);
+    // sample chunks of the weight-cotangent products: one slab per chunk, each chunk's strip of C accumulated in registers
+    // (cnf_lgemm.hip); CNF_LAYERED_KC overrides the chunk length
+    long long kc = 0;
+    int nslab = lg_wgrad_chunks(maxw, B, G.num_cus, &kc);
+    if (const char* e = getenv("CNF_LAYERED_KC")) {
+        if (atoll(e) >= 16) { kc = (atoll(e) + 3) / 4 * 4; nslab = (int)((B + kc - 1) / kc); }
+    }
 
     // ---- workspace ----
     const long long DB = (long long)D * B;
@@ -599,38 +637,25 @@ hipError_t layered_grad(LayeredGrad** ctx, const cnf_config& c, const float* P_d
     LG_HIP(hipMemsetAsync(slabs, 0, (size_t)npa_pad * nslab * sizeof(float), st));
     hipLaunchKernelGGL(aug_params_kernel, grid_for(npa), dim3(TPB), 0, st, P_dev, PA, L);
 
-    const float one = 1.f, zero = 0.f;
-    auto gemm = [&](rocblas_operation ta, rocblas_operation tb, int m, long long n, int k, const float* A, int lda,
-                    const float* Bm, int ldb, float* Cm, int ldc) -> rocblas_status {
-        return bl.sgemm(G.rb, ta, tb, m, (rocblas_int)n, k, &one, A, lda, Bm, ldb, &zero, Cm, ldc);
+    ++G.epoch;   // PA was just rebuilt: operand images are repacked at their next use
+    auto gemm = [&](int ta, int, int m, long long n, int k, const float* A, int lda, const float* Bm, int ldb, float* Cm,
+                    int ldc) -> hipError_t {
+        return lg_product(G, PA, ta, m, n, k, A, lda, Bm, ldb, Cm, ldc, LG_EPI_PLAIN, nullptr, 0, nullptr, 0, 0, st);
     };
-    const rocblas_operation OPN = rocblas_operation_none, OPT = rocblas_operation_transpose;
-    // Wbar_l[:, 0:ncols] += X Y^T over the column chunks
-    auto wgrad = [&](int l, const float* X, int ldx, const float* Y, int ldy, int ncols) -> rocblas_status {
-        const int m = L.wout[l];
-        float* Cm = slabs + L.pa_off[l];
-        if (nbf > 0) {
-            rocblas_status s = bl.sgemm_sb(G.rb, OPN, OPT, m, ncols, (rocblas_int)kc, &one, X, ldx, (rocblas_stride)(kc * ldx),
-                                           Y, ldy, (rocblas_stride)(kc * ldy), &one, Cm, m, (rocblas_stride)npa_pad, nbf);
-            if (s != rocblas_status_success) return s;
-        }
-        if (tail > 0)
-            return bl.sgemm(G.rb, OPN, OPT, m, ncols, (rocblas_int)tail, &one, X + (long long)nbf * kc * ldx, ldx,
-                            Y + (long long)nbf * kc * ldy, ldy, &one, Cm + (long long)nbf * npa_pad, m);
-        return rocblas_status_success;
+    // Wbar_l[:, 0:ncols] += X Y^T, chunk by chunk into the slabs
+    auto wgrad = [&](int l, const float* X, int ldx, const float* Y, int ldy, int ncols) -> hipError_t {
+        return lg_wgrad(slabs + L.pa_off[l], npa_pad, kc, nslab, L.wout[l], ncols, X, ldx, Y, ldy, B, st);
     };
     // forward chain at (zs, t): a_l, act'_l for every layer; zdot = a_N
-    auto forward = [&](const float* zin, float t) -> rocblas_status {
+    auto forward = [&](const float* zin, float t) -> hipError_t {
         hipLaunchKernelGGL(build_input_kernel, grid_for((long long)(c.widths[0] + 1) * B), dim3(TPB), 0, st, zin, t, ys, a[0],
                            D, C, c.autonomous, B);
         for (int l = 0; l < N; ++l) {
-            rocblas_status s = gemm(OPN, OPN, L.wout[l], B, L.win[l] + 1, PA + L.pa_off[l], L.wout[l], a[l], L.win[l] + 1,
-                                    a[l + 1], L.wout[l] + 1);
-            if (s != rocblas_status_success) return s;
-            hipLaunchKernelGGL(act_kernel, grid_for((long long)(L.wout[l] + 1) * B), dim3(TPB), 0, st, a[l + 1], d[l], L.act[l],
-                               L.wout[l], B);
+            hipError_t s = lg_product(G, PA, OPN, L.wout[l], B, L.win[l] + 1, PA + L.pa_off[l], L.wout[l], a[l], L.win[l] + 1,
+                                      a[l + 1], L.wout[l] + 1, LG_EPI_ACT, nullptr, 0, d[l], L.wout[l], L.act[l], st);
+            if (s != hipSuccess) return s;
         }
-        return rocblas_status_success;
+        return hipSuccess;
     };
 
     const Tableau T = make_tableau(alg);
@@ -640,18 +665,18 @@ hipError_t layered_grad(LayeredGrad** ctx, const cnf_config& c, const float* P_d
     auto step_dt = [&](int n) { return tgrid ? tgrid[n + 1] - tgrid[n] : (t1 - t0) / (float)nsteps; };
     const int ns = T.ns;
     // stage derivatives of one step from z_n (z rows only: the gradient needs no trace here)
-    auto stage_derivs = [&](const float* zn, float tn) -> rocblas_status {
+    auto stage_derivs = [&](const float* zn, float tn) -> hipError_t {
         for (int i = 0; i < ns; ++i) {
             Comb cb{};
             cb.nk = 0;
             for (int j = 0; j < i; ++j)
                 if (T.a[i][j] != 0.f) { cb.k[cb.nk] = kz[j]; cb.coef[cb.nk] = dt * T.a[i][j]; ++cb.nk; }
             hipLaunchKernelGGL(combine_kernel, grid_for(DB), dim3(TPB), 0, st, zs, zn, cb, DB);
-            rocblas_status s = forward(zs, tn + T.c[i] * dt);
-            if (s != rocblas_status_success) return s;
+            hipError_t s = forward(zs, tn + T.c[i] * dt);
+            if (s != hipSuccess) return s;
             hipLaunchKernelGGL(copy_rows_kernel, grid_for(DB), dim3(TPB), 0, st, kz[i], a[N], D, D + 1, 0, B);
         }
-        return rocblas_status_success;
+        return hipSuccess;
     };
 
     // ---- forward sweep: checkpoints z_n ----
@@ -723,43 +748,41 @@ hipError_t layered_grad(LayeredGrad** ctx, const cnf_config& c, const float* P_d
                     }
                     continue;
                 }
-                // pullback of probe k: v_N = eps_k, delta_l = v_l .* act'_l, v_{l-1} = W_l^T delta_l, g = W_1[:,0:D]^T delta_1
-                for (int l = N - 1; l >= 0; --l) {
-                    const float* vl = l == N - 1 ? vN : v[l];
-                    const long long HB = (long long)L.wout[l] * B;
-                    hipLaunchKernelGGL(mul_kernel, grid_for(HB), dim3(TPB), 0, st, dl[l], vl, d[l], HB);
-                    if (l > 0) LG_BLAS(gemm(OPT, OPN, L.win[l], B, L.wout[l], PA + L.pa_off[l], L.wout[l], dl[l], L.wout[l], v[l - 1], L.win[l]));
-                    else LG_BLAS(gemm(OPT, OPN, D, B, L.wout[0], PA, L.wout[0], dl[0], L.wout[0], gk, D));
-                }
+                // pullback of probe k: v_N = eps_k, delta_l = v_l .* act'_l, v_{l-1} = W_l^T delta_l, g = W_1[:,0:D]^T delta_1;
+                // every product also writes delta_{l-1} = v_{l-1} .* act'_{l-1} (fused epilogue)
+                hipLaunchKernelGGL(mul_kernel, grid_for(DB), dim3(TPB), 0, st, dl[N - 1], vN, d[N - 1], DB);
+                for (int l = N - 1; l >= 1; --l)
+                    LG_BLAS(lg_product(G, PA, OPT, L.win[l], B, L.wout[l], PA + L.pa_off[l], L.wout[l], dl[l], L.wout[l], v[l - 1], L.win[l],
+                                       LG_EPI_MUL2, d[l - 1], L.win[l], dl[l - 1], L.win[l], 0, st));
+                LG_BLAS(gemm(OPT, OPN, D, B, L.wout[0], PA, L.wout[0], dl[0], L.wout[0], gk, D));
                 hipLaunchKernelGGL(gbar_kernel, grid_for(B), dim3(TPB), 0, st, gbar, gk, vN, cl * invK, cl * lam[1] * invK, D, B);
-                // bottom-up through the pullback
-                LG_BLAS(gemm(OPN, OPN, L.wout[0], B, D, PA, L.wout[0], gbar, D, tdb, L.wout[0]));     // dbar_1 = W_1[:,0:D] gbar
+                // bottom-up through the pullback: dbar_1 = W_1[:,0:D] gbar, vbar_l = dbar_l .* act'_l, acc2_l += dbar_l .* v_l
+                // (both in the epilogue of the product that makes dbar_l), dbar_{l+1} = W_{l+1} vbar_l
+                float *cur = tvb, *nxt = tdb;
+                LG_BLAS(lg_product(G, PA, OPN, L.wout[0], B, D, PA, L.wout[0], gbar, D, cur, L.wout[0], LG_EPI_BOTTOM, d[0], L.wout[0],
+                                   acc2[0], L.wout[0], 0, st, N == 1 ? vN : v[0], nullptr, 0, k == 0 ? 1 : 0));
                 LG_BLAS(wgrad(0, dl[0], L.wout[0], gbar, D, D));                                       // Wbar_1[:,0:D] += delta_1 gbar^T
-                float *db = tdb, *dbn = tdb2;
-                for (int l = 0; l < N; ++l) {
-                    const float* vl = l == N - 1 ? vN : v[l];
-                    const long long HB = (long long)L.wout[l] * B;
-                    hipLaunchKernelGGL(bottom_kernel, grid_for(HB), dim3(TPB), 0, st, db, d[l], vl, tvb, acc2[l], k == 0 ? 1 : 0, HB);
-                    if (l + 1 < N) {
-                        LG_BLAS(wgrad(l + 1, dl[l + 1], L.wout[l + 1], tvb, L.wout[l], L.wout[l]));    // Wbar_{l+1} += delta_{l+1} vbar_l^T
-                        LG_BLAS(gemm(OPN, OPN, L.wout[l + 1], B, L.wout[l], PA + L.pa_off[l + 1], L.wout[l + 1], tvb, L.wout[l], dbn, L.wout[l + 1]));
-                        float* tmp = db; db = dbn; dbn = tmp;
-                    }
+                for (int l = 0; l + 1 < N; ++l) {
+                    LG_BLAS(wgrad(l + 1, dl[l + 1], L.wout[l + 1], cur, L.wout[l], L.wout[l]));        // Wbar_{l+1} += delta_{l+1} vbar_l^T
+                    LG_BLAS(lg_product(G, PA, OPN, L.wout[l + 1], B, L.wout[l], PA + L.pa_off[l + 1], L.wout[l + 1], cur, L.wout[l], nxt,
+                                       L.wout[l + 1], LG_EPI_BOTTOM, d[l + 1], L.wout[l + 1], acc2[l + 1], L.wout[l + 1], 0, st,
+                                       l + 1 == N - 1 ? vN : v[l + 1], nullptr, 0, k == 0 ? 1 : 0));
+                    float* tmp = cur; cur = nxt; nxt = tmp;
                 }
             }
-            // top-down through the forward chain
-            const float* ab = kbar;
-            float *abn = tab, *abn2 = tdb;   // tdb/tdb2 are free again
+            // top-down through the forward chain: sbar_l = abar_l .* act'_l + acc2_l .* act''_l (in the epilogue of the product
+            // that makes abar_l), [Wbar_l | bbar_l] += sbar_l [a_{l-1}; 1]^T, abar_{l-1} = W_l^T sbar_l
+            float *scur = tsb, *snxt = tab;
+            hipLaunchKernelGGL(sbar_kernel, grid_for((long long)L.wout[N - 1] * B), dim3(TPB), 0, st, scur, kbar, d[N - 1], acc2[N - 1],
+                               a[N], L.act[N - 1], L.wout[N - 1], B);
             for (int l = N - 1; l >= 0; --l) {
-                hipLaunchKernelGGL(sbar_kernel, grid_for((long long)L.wout[l] * B), dim3(TPB), 0, st, tsb, ab, d[l], acc2[l], a[l + 1],
-                                   L.act[l], L.wout[l], B);
-                LG_BLAS(wgrad(l, tsb, L.wout[l], a[l], L.win[l] + 1, L.win[l] + 1));                   // [Wbar_l | bbar_l] += sbar_l [a_{l-1}; 1]^T
+                LG_BLAS(wgrad(l, scur, L.wout[l], a[l], L.win[l] + 1, L.win[l] + 1));
                 if (l > 0) {
-                    LG_BLAS(gemm(OPT, OPN, L.win[l], B, L.wout[l], PA + L.pa_off[l], L.wout[l], tsb, L.wout[l], abn, L.win[l]));
-                    ab = abn;
-                    float* tmp = abn; abn = abn2; abn2 = tmp;
+                    LG_BLAS(lg_product(G, PA, OPT, L.win[l], B, L.wout[l], PA + L.pa_off[l], L.wout[l], scur, L.wout[l], snxt, L.win[l],
+                                       LG_EPI_SBAR, d[l - 1], L.win[l], nullptr, 0, L.act[l - 1], st, acc2[l - 1], a[l], L.win[l] + 1, 0));
+                    float* tmp = scur; scur = snxt; snxt = tmp;
                 } else {
-                    LG_BLAS(gemm(OPT, OPN, D, B, L.wout[0], PA, L.wout[0], tsb, L.wout[0], Zb[i], D));   // Zbar_i = W_1[:,0:D]^T sbar_1
+                    LG_BLAS(gemm(OPT, OPN, D, B, L.wout[0], PA, L.wout[0], scur, L.wout[0], Zb[i], D));   // Zbar_i = W_1[:,0:D]^T sbar_1
                 }
             }
         }

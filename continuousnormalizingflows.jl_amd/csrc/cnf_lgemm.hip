@@ -1,0 +1,419 @@
+// cnf_lgemm.hip — the products of the layer-wise path (cnf_layered.hip) as hand-written gfx950 kernels.
+//
+// The layer-wise path serves every Dense chain the fused kernels do not (wide layers such as BASELINE config 4's gradient,
+// unequal widths, mixed activations, many probes): one dynamics evaluation / one reverse-sweep stage is a sequence of
+// [features x B] products with elementwise work between them (src/core/icnf.jl:517-559, src/core/utils.jl:150-170 unfused, as the
+// reference's Lux + Zygote path is).  Round 1 sent the products to rocBLAS and ran the elementwise pieces as separate launches;
+// here both kinds of product are v_mfma_f32_16x16x4_f32 kernels with the elementwise work fused into their epilogues:
+//
+//   lg_gemm   Out[M x B] = A[M x K] In[K x B]  - A a weight matrix (or its transpose, or Q) pre-packed once per parameter set
+//             into MFMA operand order, In / Out column-major with one column per sample (the ABI's layout).  A 256-thread
+//             workgroup owns 64 samples: their input columns are staged once into LDS as the B-operand image (16 B per lane,
+//             conflict-free), wave w computes every fourth 16-row tile for all four 16-sample tiles, weight fragments stream
+//             from L2 (16 B per lane, each feeding 16 MFMAs).  Epilogues: plain store; activation (h and act' in one pass, plus
+//             the ones row the next product's bias rides on); product with another [M x B] array (the pullback's .* act').
+//   lg_wgrad  C[M x Nc] += X[M x B] Y[Nc x B]^T (weight cotangents: samples on the MFMA K axis).  A workgroup owns 64 rows of C
+//             and one chunk of samples; wave w keeps one 16-row strip of C - up to 17 accumulator tiles - in registers for its
+//             whole chunk and adds it to the chunk's slab once, so the slab traffic is (#chunks x |C|) per call instead of per
+//             256 columns.  Slabs are summed in a fixed order at the end (no atomics: bit-reproducible).
+//
+// Contraction order is a fixed function of the shapes, so results are deterministic and independent of B's partition into
+// workgroups (each output element is one fmaf chain over k in image order).
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+
+#include "cnf_mfma_dev.h"
+
+namespace cnf {
+
+// ---- A-operand image: [mt][kq][lane = 16 g + i][j] = A(16 mt + i, 16 kq + 4 g + j), A(m, k) = src[m * sm + k * sk] ----
+// (natural row order, so accumulator register r of lane group g is output row 16 mt + 4 g + r: four consecutive rows per
+// lane = one 16-byte store; the k order inside a 16-group is permuted, which a contraction does not see as long as the B
+// operand uses the same map: component j of lane group g <-> k = 16 kq + 4 g + j, four consecutive input rows = one 16-byte load)
+__global__ void lg_pack_kernel(const float* __restrict__ src, long long sm, long long sk, int M, int K, int KQ,
+                               float* __restrict__ img, long long n) {
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const int j = (int)(e & 3), lane = (int)((e >> 2) & 63);
+    const long long tile = e >> 8;
+    const int kq = (int)(tile % KQ), mt = (int)(tile / KQ);
+    const int row = 16 * mt + (lane & 15), k = 16 * kq + 4 * (lane >> 4) + j;
+    img[e] = (row < M && k < K) ? src[(long long)row * sm + (long long)k * sk] : 0.f;
+}
+
+hipError_t lg_pack_image(const float* src, long long sm, long long sk, int M, int K, float* img, hipStream_t st) {
+    const int MT = (M + 15) / 16, KQ = (K + 15) / 16;
+    const long long n = (long long)MT * KQ * 256;
+    hipLaunchKernelGGL(lg_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, sm, sk, M, K, KQ, img, n);
+    return hipGetLastError();
+}
+size_t lg_image_floats(int M, int K) { return (size_t)((M + 15) / 16) * ((K + 15) / 16) * 256; }
+
+// epilogues (x = the product):
+//   PLAIN   out = x
+//   ACT     out = act(x), dout = act'(x), ones row behind out
+//   MUL     out = x .* e
+//   MUL2    out = x, dout = x .* e                                   (pullback: v_l and delta_l = v_l .* act'_l)
+//   BOTTOM  out = x .* e, dout (+)= x .* e2  (first: =)              (reverse of the pullback: vbar_l, acc2_l)
+//   SBAR    out = x .* e + e2 .* act''  (act'' from e = act' and the activations a3)   (reverse of the forward chain)
+enum { LG_EPI_PLAIN = 0, LG_EPI_ACT = 1, LG_EPI_MUL = 2, LG_EPI_MUL2 = 3, LG_EPI_BOTTOM = 4, LG_EPI_SBAR = 5 };
+
+// four consecutive floats of a column whose stride (H + 1 for the arrays that carry a ones row) is not a multiple of four:
+// one 16-byte access with 4-byte alignment (gfx950 global memory accesses need dword alignment only)
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+
+struct LgGemmArgs {
+    const float* img;      // A image
+    const float* in;       // [K x N], column stride ldb
+    float* out;            // [M x N], column stride ldc
+    const float* e;        // MUL / MUL2 / BOTTOM / SBAR: [M x N] factor (act'), column stride lde
+    float* dout;           // ACT: act'; MUL2: x .* e; BOTTOM: acc2;  [M x N], column stride ldd
+    const float* e2;       // BOTTOM: v; SBAR: acc2;  [M x N], column stride lde
+    const float* a3;       // SBAR: the layer's activations [M x N], column stride ld3 (tanh: act'' = -2 a act')
+    long long N;
+    int M, K, MT, KQ, ldb, ldc, lde, ldd, ld3, act, first;
+    int mts;               // M-tiles per workgroup row (blockIdx.y picks the group): wide outputs are split over several workgroups
+};
+
+// MTW: 16-row tiles per wave (MT <= 4 MTW); NQ: 16-sample tiles per workgroup (each weight fragment feeds NQ sample tiles)
+template <int MTW, int NQ, int EPI>
+__global__ void __launch_bounds__(256)
+lg_gemm_kernel(LgGemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    f32x4* bimg = reinterpret_cast<f32x4*>(smem);                 // [KQ][NQ sample tiles][64 lanes]
+    const int lane = threadIdx.x & 63, g = lane >> 4, n = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long long s0 = (long long)blockIdx.x * (16 * NQ);
+    // stage the input columns: lane (g, n) holds rows 16 kq + 4 g .. + 3 of column s0 + 16 q + n; wave w stages tiles w, w + 4, ...
+#pragma unroll
+    for (int qq = 0; qq < NQ / 4; ++qq) {
+        const int q = wave + 4 * qq;
+        const long long col = s0 + 16 * q + n;
+        const bool cv = col < a.N;
+        const float* src = a.in + (cv ? col : 0) * (long long)a.ldb;
+        for (int kq = 0; kq < a.KQ; ++kq) {
+            const int k0 = 16 * kq + 4 * g;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (cv) {
+                if (k0 + 3 < a.K) {
+                    const f32x4u t = *reinterpret_cast<const f32x4u*>(src + k0);
+                    v = f32x4{t[0], t[1], t[2], t[3]};
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) if (k0 + j < a.K) v[j] = src[k0 + j];
+                }
+            }
+            bimg[(kq * NQ + q) * 64 + lane] = v;
+        }
+    }
+    __syncthreads();
+    const f32x4* __restrict__ A = reinterpret_cast<const f32x4*>(a.img) + lane;
+    f32x4 acc[MTW][NQ];
+#pragma unroll
+    for (int m = 0; m < MTW; ++m)
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) acc[m][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // M-tiles of this wave: wave, wave + 4, ...; tiles past MT read a clamped (valid) image tile and are never stored
+    const int mt_lo = blockIdx.y * a.mts;
+    const int mt_hi = mt_lo + a.mts < a.MT ? mt_lo + a.mts : a.MT;
+    int mts[MTW];
+#pragma unroll
+    for (int m = 0; m < MTW; ++m) { const int t = mt_lo + wave + 4 * m; mts[m] = t < mt_hi ? t : mt_hi - 1; }
+    f32x4 a0[MTW], a1[MTW], b0[NQ], b1[NQ];
+#pragma unroll
+    for (int m = 0; m < MTW; ++m) a0[m] = A[((long long)mts[m] * a.KQ + 0) * 64];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) b0[q] = bimg[(0 * NQ + q) * 64 + lane];
+#pragma clang loop unroll(disable)
+    for (int kq = 0; kq < a.KQ; kq += 2) {
+        const bool has1 = kq + 1 < a.KQ, has2 = kq + 2 < a.KQ;
+        if (has1) {
+#pragma unroll
+            for (int m = 0; m < MTW; ++m) a1[m] = A[((long long)mts[m] * a.KQ + kq + 1) * 64];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) b1[q] = bimg[((kq + 1) * NQ + q) * 64 + lane];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int m = 0; m < MTW; ++m)
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) acc[m][q] = mfma4(a0[m][j], b0[q][j], acc[m][q]);
+        if (has1) {
+            if (has2) {
+#pragma unroll
+                for (int m = 0; m < MTW; ++m) a0[m] = A[((long long)mts[m] * a.KQ + kq + 2) * 64];
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) b0[q] = bimg[((kq + 2) * NQ + q) * 64 + lane];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int m = 0; m < MTW; ++m)
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) acc[m][q] = mfma4(a1[m][j], b1[q][j], acc[m][q]);
+        }
+    }
+    // epilogue: lane (g, n) of tile (mt, q) holds rows 16 mt + 4 g .. + 3 of column s0 + 16 q + n
+#pragma unroll
+    for (int m = 0; m < MTW; ++m) {
+        const int mt = mt_lo + wave + 4 * m;
+        if (mt >= mt_hi) continue;
+        const int r0 = 16 * mt + 4 * g;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const long long col = s0 + 16 * q + n;
+            if (col >= a.N) continue;
+            f32x4 v = acc[m][q], dv = {0.f, 0.f, 0.f, 0.f};
+            const bool full = r0 + 3 < a.M;
+            if (EPI == LG_EPI_ACT) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { float dd; v[r] = act_fwd_rt(a.act, v[r], dd); dv[r] = dd; }
+            }
+            if (EPI == LG_EPI_MUL || EPI == LG_EPI_MUL2 || EPI == LG_EPI_BOTTOM || EPI == LG_EPI_SBAR) {
+                // elementwise operands of this lane's four rows (row-guarded scalar loads at the ragged edge)
+                auto load4 = [&](const float* base, int ld) -> f32x4 {
+                    const float* p = base + col * (long long)ld + r0;
+                    if (full) { const f32x4u t = *reinterpret_cast<const f32x4u*>(p); return f32x4{t[0], t[1], t[2], t[3]}; }
+                    f32x4 t = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) if (r0 + r < a.M) t[r] = p[r];
+                    return t;
+                };
+                const f32x4 ev = load4(a.e, a.lde);
+                if (EPI == LG_EPI_MUL) v *= ev;
+                if (EPI == LG_EPI_MUL2) dv = v * ev;
+                if (EPI == LG_EPI_BOTTOM) {
+                    const f32x4 vv = load4(a.e2, a.lde);
+                    f32x4 prev = {0.f, 0.f, 0.f, 0.f};
+                    if (!a.first) prev = load4(a.dout, a.ldd);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dv[r] = a.first ? v[r] * vv[r] : fmaf(v[r], vv[r], prev[r]);
+                    v *= ev;
+                }
+                if (EPI == LG_EPI_SBAR) {
+                    const f32x4 c2 = load4(a.e2, a.lde);
+                    f32x4 e2v = {0.f, 0.f, 0.f, 0.f};
+                    if (a.act == CNF_ACT_TANH) {
+                        const f32x4 av = load4(a.a3, a.ld3);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) e2v[r] = -2.f * av[r] * ev[r];
+                    } else if (a.act == CNF_ACT_SOFTPLUS) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) e2v[r] = ev[r] * (1.f - ev[r]);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = fmaf(c2[r], e2v[r], v[r] * ev[r]);
+                }
+            }
+            float* op = a.out + col * (long long)a.ldc + r0;
+            if (full) {
+                *reinterpret_cast<f32x4u*>(op) = f32x4u{v[0], v[1], v[2], v[3]};
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) if (r0 + r < a.M) op[r] = v[r];
+            }
+            if (EPI == LG_EPI_ACT || EPI == LG_EPI_MUL2 || EPI == LG_EPI_BOTTOM) {
+                float* dp = a.dout + col * (long long)a.ldd + r0;
+                if (full) {
+                    *reinterpret_cast<f32x4u*>(dp) = f32x4u{dv[0], dv[1], dv[2], dv[3]};
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) if (r0 + r < a.M) dp[r] = dv[r];
+                }
+                // the ones row behind the activations (row M of a column of ldc = M + 1 floats: the next product's bias rides on
+                // it), written by the lane that owns the last valid row
+                if (EPI == LG_EPI_ACT && a.ldc > a.M && r0 <= a.M - 1 && a.M - 1 < r0 + 4) a.out[col * (long long)a.ldc + a.M] = 1.f;
+            }
+        }
+    }
+}
+
+template <int MTW, int NQ, int EPI>
+static hipError_t lg_gemm_launch(const LgGemmArgs& a, hipStream_t st) {
+    const int lds = a.KQ * NQ * 64 * 16;
+    auto kern = lg_gemm_kernel<MTW, NQ, EPI>;
+    static DeviceOnce once;
+    int dev = 0;
+    hipError_t e0 = hipGetDevice(&dev);
+    if (e0 != hipSuccess) return e0;
+    if (lds > 64 * 1024 && !once.done(dev)) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        once.set(dev);
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)((a.N + 16 * NQ - 1) / (16 * NQ)), (unsigned)((a.MT + a.mts - 1) / a.mts)), dim3(256), lds, st, a);
+    return hipGetLastError();
+}
+
+// largest shapes one launch covers: 32 row tiles (M <= 512), the 64-sample B panel in 160 KB of LDS (K <= 640)
+bool lg_gemm_supported(int M, int K) { return M >= 1 && M <= 512 && K >= 1 && ((K + 15) / 16) * 4096 <= 160 * 1024; }
+
+template <int EPI>
+static hipError_t lg_gemm_dispatch(LgGemmArgs a, hipStream_t st) {
+    // Outputs wider than 16 row tiles are split evenly over several workgroups per sample panel (at most 16 tiles = 4 per wave
+    // each); 128-sample panels (every weight fragment feeds 8 sample tiles: half the L2 traffic of the images) when the panel
+    // fits LDS and there are enough samples to fill the chip that way
+    const int splits = (a.MT + 15) / 16;
+    a.mts = (a.MT + splits - 1) / splits;
+    const bool wide = a.KQ * 8 * 1024 <= 160 * 1024 && a.N * splits >= 128 * 192;
+    if (a.mts <= 4) return wide ? lg_gemm_launch<1, 8, EPI>(a, st) : lg_gemm_launch<1, 4, EPI>(a, st);
+    if (a.mts <= 8) return wide ? lg_gemm_launch<2, 8, EPI>(a, st) : lg_gemm_launch<2, 4, EPI>(a, st);
+    return wide ? lg_gemm_launch<4, 8, EPI>(a, st) : lg_gemm_launch<4, 4, EPI>(a, st);
+}
+
+hipError_t lg_gemm(const float* img, int M, int K, const float* in, int ldb, float* out, int ldc, long long N, int epi,
+                   const float* e, int lde, float* dout, int ldd, int act, hipStream_t st, const float* e2, const float* a3, int ld3,
+                   int first) {
+    if (N <= 0) return hipSuccess;
+    LgGemmArgs a{};
+    a.img = img; a.in = in; a.out = out; a.e = e; a.dout = dout; a.e2 = e2; a.a3 = a3; a.N = N;
+    a.M = M; a.K = K; a.MT = (M + 15) / 16; a.KQ = (K + 15) / 16; a.ldb = ldb; a.ldc = ldc; a.lde = lde; a.ldd = ldd; a.ld3 = ld3;
+    a.act = act; a.first = first;
+    switch (epi) {
+        case LG_EPI_ACT: return lg_gemm_dispatch<LG_EPI_ACT>(a, st);
+        case LG_EPI_MUL: return lg_gemm_dispatch<LG_EPI_MUL>(a, st);
+        case LG_EPI_MUL2: return lg_gemm_dispatch<LG_EPI_MUL2>(a, st);
+        case LG_EPI_BOTTOM: return lg_gemm_dispatch<LG_EPI_BOTTOM>(a, st);
+        case LG_EPI_SBAR: return lg_gemm_dispatch<LG_EPI_SBAR>(a, st);
+        default: return lg_gemm_dispatch<LG_EPI_PLAIN>(a, st);
+    }
+}
+
+// ---- weight cotangents: C[M x Nc] (column-major, ld = M) += X[M x samples] Y[Nc x samples]^T over one chunk of samples ----
+struct LgWgradArgs {
+    float* slabs;            // slab c at slabs + c * slab_stride; C at its start
+    long long slab_stride;
+    const float* x; const float* y;
+    long long B, chunk;      // samples in total, samples per chunk (multiple of 4)
+    int M, Nc, ldx, ldy;
+};
+
+// NTN: 16-column tiles of C a wave keeps (Nc <= 16 NTN).  The four waves of a workgroup own four 16-row strips of C and share
+// every slice of Y (and of X): 16 samples at a time are fetched with coalesced loads (each sample's rows are contiguous) into
+// registers while the previous slice is being multiplied, then parked in LDS as [row tile][lane group g][row n][k-step u] so
+// that ONE lane-linear ds_read_b128 hands a lane its B operands of all four k-steps of a tile (sample 4 u + g, row 16 t + n).
+// (Reading the operands straight from global memory made every wave fetch all of Y: 670 MB of L2 traffic per call at cfg4.)
+template <int NTN>
+__global__ void __launch_bounds__(256)
+lg_wgrad_kernel(LgWgradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int RY = (NTN * 16 + 63) / 64;                     // loads per lane per sample for the Y slice
+    constexpr int YS = NTN * 256, XS = 4 * 256;                  // floats per staged slice
+    // slice buffer b: Y part at smem + b (YS + XS), X part behind it
+    const int lane = threadIdx.x & 63, g = lane >> 4, n = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int row0 = blockIdx.x * 64;                             // this workgroup's 64 rows of C; wave w: rows row0 + 16 w ..
+    const int chunk = blockIdx.y;
+    const long long c0 = (long long)chunk * a.chunk;
+    const long long c1 = c0 + a.chunk < a.B ? c0 + a.chunk : a.B;
+    f32x4 acc[NTN];
+#pragma unroll
+    for (int t = 0; t < NTN; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float ry[4][RY], rx[4];
+    // wave w fetches the samples of k-step u = w of a slice (sample 4 w + q, q = lane group it will serve): lane l takes rows
+    // l, l + 64, ... of Y and row row0 + l of X
+    auto fetch = [&](long long s) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const long long gs = s + 4 * wave + q;
+            const bool sv = gs < c1;
+            const float* yp = a.y + (sv ? gs : 0) * (long long)a.ldy;
+#pragma unroll
+            for (int i = 0; i < RY; ++i) { const int r = lane + 64 * i; ry[q][i] = (sv && r < a.Nc) ? yp[r] : 0.f; }
+            rx[q] = (sv && row0 + lane < a.M) ? a.x[(sv ? gs : 0) * (long long)a.ldx + row0 + lane] : 0.f;
+        }
+    };
+    auto park = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+            for (int i = 0; i < RY; ++i) {
+                const int r = lane + 64 * i;                        // row 16 t + nn of Y
+                if (r < NTN * 16) smem[buf * (YS + XS) + (((r >> 4) * 4 + q) * 16 + (r & 15)) * 4 + wave] = ry[q][i];
+            }
+            smem[buf * (YS + XS) + YS + (((lane >> 4) * 4 + q) * 16 + (lane & 15)) * 4 + wave] = rx[q];
+        }
+    };
+    fetch(c0);
+    park(0);
+    __syncthreads();
+    int buf = 0;
+    for (long long s = c0; s < c1; s += 16) {
+        const bool more = s + 16 < c1;
+        if (more) fetch(s + 16);
+        const f32x4* y4 = reinterpret_cast<const f32x4*>(smem + buf * (YS + XS)) + lane;
+        const f32x4 av = reinterpret_cast<const f32x4*>(smem + buf * (YS + XS) + YS)[wave * 64 + lane];
+        f32x4 bv[NTN];
+#pragma unroll
+        for (int t = 0; t < NTN; ++t) bv[t] = y4[t * 64];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int t = 0; t < NTN; ++t) acc[t] = mfma4(av[u], bv[t][u], acc[t]);
+        if (more) park(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+    // C rows 16 mt + 4 g + r (natural row order of the accumulator), column 16 t + n
+    const int mt = blockIdx.x * 4 + wave;
+    if (16 * mt >= a.M) return;
+    float* C = a.slabs + (long long)chunk * a.slab_stride;
+    const int r0 = 16 * mt + 4 * g;
+#pragma unroll
+    for (int t = 0; t < NTN; ++t) {
+        const int col = 16 * t + n;
+        if (col >= a.Nc) continue;
+        float* cp = C + (long long)col * a.M + r0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) if (r0 + r < a.M) cp[r] += acc[t][r];
+    }
+}
+
+bool lg_wgrad_supported(int M, int Nc) { return M >= 1 && Nc >= 1 && Nc <= 16 * 33; }
+
+// number of sample chunks (= slabs) a wgrad call uses for this (M, B): enough workgroups to fill the chip, chunks of >= 64 samples
+int lg_wgrad_chunks(int M, long long B, int num_cus, long long* chunk_out) {
+    const int RB = ((M + 15) / 16 + 3) / 4;
+    long long want = (2LL * num_cus + RB - 1) / RB;   // two workgroups per CU (measured at cfg4: 82 us per call; one per CU: 88 us)
+    if (want < 1) want = 1;
+    long long chunk = (B + want - 1) / want;
+    chunk = (chunk + 63) / 64 * 64;
+    if (chunk < 64) chunk = 64;
+    const long long nch = (B + chunk - 1) / chunk;
+    if (chunk_out) *chunk_out = chunk;
+    return (int)(nch < 1 ? 1 : nch);
+}
+
+hipError_t lg_wgrad(float* slabs, long long slab_stride, long long chunk, int nchunks, int M, int Nc, const float* x, int ldx,
+                    const float* y, int ldy, long long B, hipStream_t st) {
+    if (B <= 0) return hipSuccess;
+    LgWgradArgs a{};
+    a.slabs = slabs; a.slab_stride = slab_stride; a.x = x; a.y = y; a.B = B; a.chunk = chunk;
+    a.M = M; a.Nc = Nc; a.ldx = ldx; a.ldy = ldy;
+    const int MT = (M + 15) / 16, NTN = (Nc + 15) / 16;
+    const dim3 grid((unsigned)((MT + 3) / 4), (unsigned)nchunks);
+    const int ntn = NTN <= 1 ? 1 : NTN <= 3 ? 3 : NTN <= 5 ? 5 : NTN <= 9 ? 9 : NTN <= 17 ? 17 : 33;
+    const int lds = 2 * (ntn * 256 + 4 * 256) * (int)sizeof(float);          // <= 2 * 37 * 1 KB = 74 KB
+    if (lds > 64 * 1024) {
+        static DeviceOnce once;
+        int dev = 0;
+        hipError_t e0 = hipGetDevice(&dev);
+        if (e0 != hipSuccess) return e0;
+        if (!once.done(dev)) {
+            hipError_t e = hipFuncSetAttribute((const void*)lg_wgrad_kernel<33>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;
+            once.set(dev);
+        }
+    }
+    if (NTN <= 1) hipLaunchKernelGGL(lg_wgrad_kernel<1>, grid, dim3(256), lds, st, a);
+    else if (NTN <= 3) hipLaunchKernelGGL(lg_wgrad_kernel<3>, grid, dim3(256), lds, st, a);
+    else if (NTN <= 5) hipLaunchKernelGGL(lg_wgrad_kernel<5>, grid, dim3(256), lds, st, a);
+    else if (NTN <= 9) hipLaunchKernelGGL(lg_wgrad_kernel<9>, grid, dim3(256), lds, st, a);
+    else if (NTN <= 17) hipLaunchKernelGGL(lg_wgrad_kernel<17>, grid, dim3(256), lds, st, a);
+    else hipLaunchKernelGGL(lg_wgrad_kernel<33>, grid, dim3(256), lds, st, a);
+    return hipGetLastError();
+}
+
+}  // namespace cnf

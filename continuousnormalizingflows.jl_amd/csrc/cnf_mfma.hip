@@ -180,7 +180,7 @@ MfmaPlan* mfma_plan_create(const cnf_config& c) {
             // exact trace of a two-hidden-layer net whose Q image does not fit LDS beside this instance's images (8 hidden
             // tiles with 8 state k-steps): D tangent passes here would lose to the layer-wise path's single Q GEMM
             if (c.mode == CNF_MODE_EXACT && L == 2 && MfmaLayout(pickd->HT, L, pickd->ZR, pickd->CR, false).qtr < 0 &&
-                c.kernel_path == CNF_PATH_AUTO && layered_available())
+                c.kernel_path == CNF_PATH_AUTO && layered_supports(c))
                 return nullptr;
             return make(*pickd);
         }
