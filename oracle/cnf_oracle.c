@@ -1,13 +1,13 @@
 /* cnf_oracle.c — CPU fp32 restatement of the reference hot path.  See cnf_oracle.h.
  * TEST INFRASTRUCTURE ONLY; parity unpinned by the reference (no Julia, no golden vectors).
  *
- * Structure follows the reference, not the fused GPU design: one call of aug_f evaluates
- * the whole S x B state (per-layer "GEMMs" over the batch columns, then a hand-written
- * pullback / pushforward of the Dense chain), and the Runge-Kutta stage loop lives outside
- * it, calling it 4 (RK4) or 6 (Tsit5) times per step with whole-matrix axpys in between —
- * the shape of SciMLBase.solve driving make_ode_func's closure (src/core/base_icnf.jl:62-78,
- * 134-140).  The only departure: the reference evaluates the forward pass twice per call
- * (src/core/utils.jl:157-158); here it is evaluated once (same numbers, favours the CPU).
+ * One dynamics call (cnf_oracle_aug_f) has the reference's structure: per-layer products over the batch columns, then a
+ * hand-written pullback / pushforward of the Dense chain (src/core/icnf.jl:517-559, src/core/utils.jl:150-170), with the one
+ * departure that the forward pass is evaluated once per call, not twice (src/core/utils.jl:157-158; same numbers, favours the
+ * CPU).  The fixed-step solve (cnf_oracle_integrate_fixed) calls it 4 (RK4) or 6 (Tsit5) times per step with the RK axpys in
+ * between - the shape of SciMLBase.solve driving make_ode_func's closure (src/core/base_icnf.jl:62-78, 134-140) - but runs that
+ * loop per chunk of 256 columns inside each thread (columns are independent under fixed steps), which is what a CPU needs to
+ * keep the stage data in cache; the numbers are the same as a whole-batch loop's, bit for bit.
  */
 #include "cnf_oracle.h"
 
@@ -355,53 +355,70 @@ int cnf_oracle_integrate_fixed(const cnf_oracle_cfg* cfg, const float* p, const 
     const float* Cc = alg == 0 ? RK4_C : T5_C;
     const float* Bc = alg == 0 ? RK4_B : T5_B;
     const int S = cfg->nvars + cfg->naug + 3;
+    const int C = cfg->ncond, KD = cfg->nprobes * (cfg->nvars + cfg->naug);
     const size_t n = (size_t)S * (size_t)B;
-    float* k[6] = {0};
-    float* us = (float*)malloc(n * sizeof(float));
-    for (int i = 0; i < ns; ++i) k[i] = (float*)malloc(n * sizeof(float));
     if (u1 != u0) memcpy(u1, u0, n * sizeof(float));
     const float dt = (t1 - t0) / (float)nsteps;
     if (nthreads < 1) nthreads = 1;
     if (cfg->mode != MODE_EXACT && !eps) rc = -4;
     if (cfg->ncond && !ys) rc = -5;
     int err = rc;
-    /* one parallel region per solve; inside it the reference's structure is kept: per stage a
-     * whole-state axpy, then one dynamics call over the whole batch (implicit barriers) */
+    /* Columns are independent under fixed-step integration (every operation of augmented_f is column-wise,
+     * src/core/icnf.jl:530-535), so each thread takes chunks of CHUNK columns through ALL steps with chunk-local stage
+     * buffers: per stage a dynamics call over the chunk (the reference's per-call structure, block by block) and the RK
+     * axpys on data that stays in the core's L2.  No barriers, no shared whole-state arrays (round 1 kept the whole state
+     * and six stage arrays shared and synchronised every stage: 2 GFLOP/s per core on a 128-core, two-socket host whose
+     * block products alone run at ~30). */
+    enum { CHUNK = 4 * CB };
+    const int64_t nchunks = (B + CHUNK - 1) / CHUNK;
 #pragma omp parallel num_threads(nthreads)
     {
         scratch s;
         const int bad = scratch_init(&s, cfg);
-        if (bad) {
+        float* loc = (float*)aligned_alloc(64, (size_t)(8 * S * CHUNK) * sizeof(float));
+        if (bad || !loc) {
 #pragma omp atomic write
             err = -6;
         }
 #pragma omp barrier
         if (!err) {
-            for (int step = 0; step < nsteps; ++step) {
-                const float tn = t0 + (float)step * dt;
-                for (int i = 0; i < ns; ++i) {
-                    const float* Ai = alg == 0 ? RK4_A[i] : T5_A[i];
-#pragma omp for schedule(static)
-                    for (int64_t e = 0; e < (int64_t)n; ++e) {
-                        float acc = 0.f;
-                        for (int j = 0; j < i; ++j) acc += Ai[j] * k[j][e];
-                        us[e] = u1[e] + dt * acc;
+            float* ul = loc;                       /* the chunk's state, S x CHUNK (column-major like the ABI) */
+            float* us = loc + (size_t)S * CHUNK;   /* stage state */
+            float* kl[6];
+            for (int i = 0; i < 6; ++i) kl[i] = loc + (size_t)(2 + i) * S * CHUNK;
+#pragma omp for schedule(dynamic, 1)
+            for (int64_t ch = 0; ch < nchunks; ++ch) {
+                const int64_t c0 = ch * CHUNK;
+                const int nc = (int)((B - c0) < CHUNK ? (B - c0) : CHUNK);
+                const size_t nl = (size_t)S * (size_t)nc;
+                memcpy(ul, u1 + (size_t)c0 * S, nl * sizeof(float));
+                const float* epsl = eps ? eps + (size_t)c0 * KD : NULL;
+                const float* ysl = ys ? ys + (size_t)c0 * C : NULL;
+                for (int step = 0; step < nsteps; ++step) {
+                    const float tn = t0 + (float)step * dt;
+                    for (int i = 0; i < ns; ++i) {
+                        const float* Ai = alg == 0 ? RK4_A[i] : T5_A[i];
+                        for (size_t e = 0; e < nl; ++e) {
+                            float acc = 0.f;
+                            for (int j = 0; j < i; ++j) acc += Ai[j] * kl[j][e];
+                            us[e] = ul[e] + dt * acc;
+                        }
+                        for (int b0 = 0; b0 < nc; b0 += CB)
+                            aug_f_block(cfg, p, w_off, b_off, us, tn + Cc[i] * dt, epsl, ysl, b0, nc - b0 < CB ? nc - b0 : CB, kl[i], &s);
                     }
-                    aug_f_ws(cfg, p, w_off, b_off, us, tn + Cc[i] * dt, eps, ys, B, k[i], &s);
+                    for (size_t e = 0; e < nl; ++e) {
+                        float acc = 0.f;
+                        for (int i = 0; i < ns; ++i) acc += Bc[i] * kl[i][e];
+                        ul[e] += dt * acc;
+                    }
                 }
-#pragma omp for schedule(static)
-                for (int64_t e = 0; e < (int64_t)n; ++e) {
-                    float acc = 0.f;
-                    for (int i = 0; i < ns; ++i) acc += Bc[i] * k[i][e];
-                    u1[e] += dt * acc;
-                }
+                memcpy(u1 + (size_t)c0 * S, ul, nl * sizeof(float));
             }
         }
         if (!bad) free(s.base);
+        free(loc);
     }
     rc = err;
-    free(us);
-    for (int i = 0; i < ns; ++i) free(k[i]);
     return rc;
 }
 
