@@ -447,7 +447,7 @@ def report(w, m, a, steps, warmup, world):
                    "integrator": "RK4" if alg == 0 else "Tsit5",
                    "kernel_path": {1: "simt", 2: "mfma", 3: "layered"}.get(path, str(path)),
                    "mode": a.mode,
-                   **({"gradient_path": {1: "fused reverse-sweep kernel", 2: "layer-wise (rocBLAS GEMMs)"}.get(
+                   **({"gradient_path": {1: "fused reverse-sweep kernel", 2: "layer-wise (hand-written MFMA product kernels)"}.get(
                        icnf.grad_path(mode), "none")} if a.mode == "grad" else {}),
                    "collective": w.get("collective", ""),
                    "parallelism": f"column-shard x{world}, loss all-reduce (5 scalars)"

@@ -79,10 +79,11 @@ enum { CNF_ALG_RK4 = 0, CNF_ALG_TSIT5 = 1 };
 enum { CNF_ARITH_F32 = 0, CNF_ARITH_BF16X6 = 1 };
 
 /* kernel families (cnf_kernel_path).  AUTO resolves to MFMA (fused whole-solve kernels) when an
- * instance covers the configuration, else to LAYERED (layer-wise evaluation on rocBLAS GEMMs + HIP
- * elementwise kernels, any Dense chain) when librocblas.so.5 can be loaded, else to SIMT (thread-per-
- * sample kernels, any Dense chain; 4-100x slower than LAYERED at every batch size measured, kept as the
- * dependency-free fallback and as an independent implementation for the tests). */
+ * instance covers the configuration, else to LAYERED (layer-wise evaluation: every product of the chain a
+ * hand-written MFMA kernel with the elementwise work in its epilogue, csrc/cnf_lgemm.hip; any Dense chain
+ * whose layers have at most 512 outputs and 639 inputs), else to SIMT (thread-per-sample kernels, any Dense
+ * chain; 4-100x slower than LAYERED at every batch size measured, kept as the fallback for wider layers and
+ * as an independent implementation for the tests). */
 enum { CNF_PATH_AUTO = 0, CNF_PATH_SIMT = 1, CNF_PATH_MFMA = 2, CNF_PATH_LAYERED = 3 };
 
 /* Configuration = the ICNF fields and type parameters that reach the hot path
@@ -262,7 +263,7 @@ int cnf_loss_sums(cnf_handle* h, const float* logp, const float* regs, int64_t B
  * <= 16 conditions, 2 or 3 equal hidden layers (tanh or softplus) of width <= 64, D + !autonomous <= 15;
  * slab-accumulator kernel: two hidden layers of width <= 128, D + !autonomous <= 32, <= 16 conditions, one probe (the
  * reference's default nets for 7..15 variables); every other shape (wider or more layers, mixed activations, larger D): layer-wise
- * reverse sweep on rocBLAS GEMMs, which also serves the Hutchinson JVP mode.  Exact-trace mode (TestMode):
+ * reverse sweep on the library's own product kernels (csrc/cnf_lgemm.hip), which also serves the Hutchinson JVP mode.  Exact-trace mode (TestMode):
  * -tr J = -sum_k e_k^T J e_k, the pullback with the D unit vectors as probes of weight 1 (eps is ignored, no
  * regularisers) - on the several-probe fused kernel where the shape has one, layer-wise otherwise.
  * FFJORD and RNODE losses. */
@@ -294,7 +295,7 @@ int cnf_loss_grad_adaptive(cnf_handle* h, float t0, float t1, const float* x, co
 
 /* Which implementation cnf_loss_grad_fixed / cnf_loss_grad_grid use for this handle: 0 = none (CNF_ERR_UNSUPPORTED),
  * 1 = fused reverse-sweep kernel (cnf_grad.hip / cnf_grad_probes.hip / cnf_grad_slab.hip), 2 = layer-wise reverse sweep on
- * rocBLAS GEMMs (cnf_layered.hip; librocblas.so.5 is loaded with dlopen at first use). */
+ * the product kernels of cnf_lgemm.hip (cnf_layered.hip). */
 int cnf_grad_path(const cnf_handle* h);
 
 /* ---- column shards: the one exchange step of the path -----------------------------------------
