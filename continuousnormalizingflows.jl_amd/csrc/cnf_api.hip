@@ -199,6 +199,7 @@ int cnf_destroy(cnf_handle* h) {
     if (h->vc_buf) (void)hipFree(h->vc_buf);
     if (h->tgrid_dev) (void)hipFree(h->tgrid_dev);
     if (h->ad_buf) (void)hipFree(h->ad_buf);
+    if (h->dc_buf) (void)hipFree(h->dc_buf);
     if (h->vc_partial) (void)hipFree(h->vc_partial);
     layered_grad_destroy(h->layered);
     free_pack_map(h->map_fwd);

@@ -51,6 +51,7 @@ int cnf_step_embedded(cnf_handle* h, int alg, int flags, float t, float dt, cons
         SolveArgs a{};
         a.u0 = u; a.eps = eps; a.ys = ys; a.B = B; a.nsteps = 1; a.alg = CNF_ALG_TSIT5; a.t0 = t; a.t1 = t + dt;
         a.u_out = u_new; a.nvars = h->cfg.nvars; a.reg_aug = 0; a.kfull = h->ebuf;
+        a.dt_exact = dt;   // the step the error estimate is scaled with, not fl(fl(t + dt) - t)
         HIP_TRY(mfma_solve(h->plan, h->packed_dev, a, st));
         StageIn last{};
         last.u = u_new; last.nprev = 0; last.dt = 0.f;
@@ -378,6 +379,49 @@ int cnf::api_solve_tsit5(cnf_handle* h, float t0, float t1, const float* u0, con
     const double span = std::fabs((double)t1 - (double)t0), tdir = t1 >= t0 ? 1.0 : -1.0, ntot = (double)n;
     if (span == 0.0) {
         if (u1 != u0) HIP_TRY(hipMemcpyAsync(u1, u0, n * sizeof(float), hipMemcpyDeviceToDevice, st));
+        return CNF_OK;
+    }
+    if (h->path == CNF_PATH_MFMA && h->plan && B <= mfma_adaptive_capacity(h->plan)) {
+        // the batch fits the chip's wave slots: the whole solve, step controller included, in one launch
+        const int dts_cap = maxiters < (1 << 20) ? maxiters : (1 << 20);
+        const size_t need = mfma_adaptive_scratch_bytes(B, dts_cap);
+        if (need > h->dc_bytes) {
+            if (h->dc_buf) HIP_TRY(hipFree(h->dc_buf));
+            h->dc_buf = nullptr; h->dc_bytes = 0;
+            HIP_TRY(hipMalloc(&h->dc_buf, need));
+            h->dc_bytes = need;
+        }
+        SolveArgs a{};
+        a.u0 = u0; a.eps = eps; a.ys = ys; a.B = B; a.nsteps = 1; a.alg = CNF_ALG_TSIT5; a.t0 = t0; a.t1 = t1;
+        a.u_out = u1; a.nvars = h->cfg.nvars; a.reg_aug = 0;
+        int* stats_dev = nullptr;
+        float* dts_dev = nullptr;
+        const hipError_t le = mfma_solve_adaptive(h->plan, h->packed_dev, a, abstol, reltol, dt_init, maxiters, h->dc_buf, dts_cap, &stats_dev, &dts_dev, st);
+        if (le != hipSuccess) {
+            (void)hipGetLastError();   // not sticky: nothing was launched
+            return fail(CNF_ERR_HIP, std::string("cnf_solve_tsit5: launch of the device-controlled solve failed: ") + hipGetErrorString(le));
+        }
+        // stats and the first accepted steps sit side by side: one copy serves the usual solve
+        constexpr int kInline = 60;
+        int host[4 + kInline];
+        const int first = dts_cap < kInline ? dts_cap : kInline;
+        HIP_TRY(hipMemcpyAsync(host, stats_dev, (4 + first) * sizeof(int), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        if (stats) { stats->naccept = host[0]; stats->nreject = host[1]; stats->nf = host[2]; stats->max_order = 5; }
+        if (host[3] == 1) return fail(CNF_ERR_INVALID, "cnf_solve_tsit5: non-finite error estimate (unstable dynamics)");
+        if (host[3] == 2) return fail(CNF_ERR_INVALID, "cnf_solve_tsit5: maxiters reached");
+        if (host[3] == 3) return fail(CNF_ERR_INVALID, "cnf_solve_tsit5: non-finite state or dynamics at t0 (no initial step)");
+        if (steps) {
+            const int na = host[0] < dts_cap ? host[0] : dts_cap;
+            std::vector<float> all((size_t)na);
+            const float* inl = reinterpret_cast<const float*>(host + 4);
+            for (int i = 0; i < na && i < first; ++i) all[i] = inl[i];
+            if (na > first) {
+                HIP_TRY(hipMemcpyAsync(all.data() + first, dts_dev + first, (size_t)(na - first) * sizeof(float), hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipStreamSynchronize(st));
+            }
+            for (int i = 0; i < na; ++i) steps->push_back((double)all[i]);
+        }
         return CNF_OK;
     }
     rc = api_ensure_adaptive_buf(h, B);

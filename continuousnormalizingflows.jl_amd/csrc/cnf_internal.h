@@ -74,8 +74,14 @@ struct SolveArgs {
     float* ckpt;     // optional checkpoint buffers (see KArgs::ckpt, ckpt_k, kfull)
     float* ckpt_k;
     float* kfull;
+    float dt_exact;  // != 0: the step itself (nsteps = 1 attempts: (t0 + dt) - t0 is not dt in float32); 0: (t1 - t0) / nsteps
 };
 hipError_t mfma_solve(MfmaPlan* p, const float* packed_dev, const SolveArgs& a, hipStream_t st);
+// adaptive Tsit5 with the step controller on the device (cnf_mfma_kernel.h: mfma_adaptive_kernel): u0 -> u_out over [t0, t1]
+int64_t mfma_adaptive_capacity(MfmaPlan* p);
+size_t mfma_adaptive_scratch_bytes(int64_t B, int dts_cap);
+hipError_t mfma_solve_adaptive(MfmaPlan* p, const float* packed_dev, const SolveArgs& s, float abstol, float reltol, float dt_init,
+                               int maxiters, void* scratch, int dts_cap, int** stats_dev, float** dts_dev, hipStream_t st);
 
 // ---- parameter gradient (cnf_grad.hip) ----
 bool grad_supported(const cnf_config& c);

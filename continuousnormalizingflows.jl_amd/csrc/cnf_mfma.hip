@@ -21,6 +21,7 @@
 #include <cstring>
 #include <vector>
 
+#define CNF_WITH_DEVICE_CONTROLLER 1
 #include "cnf_mfma_kernel.h"
 
 namespace cnf {
@@ -33,6 +34,8 @@ struct MfmaPlan {
     bool with_bwd;
     MfmaLayout lay;
     LaunchFn launch;
+    LaunchAdaptFn launch_adapt;   // adaptive Tsit5 with the step controller on the device, or null
+    int adapt_per_cu = -1;        // workgroups of that kernel per compute unit (occupancy query, cached)
     cnf_config cfg;
     int nthreads;
     int num_cus;
@@ -52,26 +55,26 @@ struct MfmaPlan {
 // generic SIMT path.
 static const Inst kInsts[] = {
     // --- Hutchinson VJP (LuxVecJacMatrixMode + TrainMode) ---
-    MFMA_INST(4, 3, 2, 0, CNF_ACT_TANH_PRESCALED, ENG_VJP, 1, 2, 512),      // cfg2 / cfg2': D=8, 3x64, K=1, FFJORD
-    MFMA_INST(4, 3, 2, 0, CNF_ACT_TANH_PRESCALED, ENG_VJP, 1, 1, 512),      // same shape with reg_j (RNODE, K=1)
+    MFMA_INST_AD(4, 3, 2, 0, CNF_ACT_TANH_PRESCALED, ENG_VJP, 1, 2, 512),      // cfg2 / cfg2': D=8, 3x64, K=1, FFJORD
+    MFMA_INST_AD(4, 3, 2, 0, CNF_ACT_TANH_PRESCALED, ENG_VJP, 1, 1, 512),      // same shape with reg_j (RNODE, K=1)
     MFMA_INST(4, 3, 2, 0, CNF_ACT_TANH_PRESCALED, ENG_VJP, 1, 0, 512),      // no hoisting (A/B reference)
     MFMA_INST(4, 3, 2, 0, CNF_ACT_TANH_PRESCALED, ENG_VJP, 1, 2, 1024),
     MFMA_INST(4, 3, 2, 0, CNF_ACT_TANH_PRESCALED, ENG_VJP, 1, 2, 256),
     MFMA_INST(4, 3, 2, 0, CNF_ACT_TANH_PRESCALED, ENG_VJP, 4, 0, 512),      // cfg3: RNODE K=4
-    MFMA_INST(2, 2, 1, 0, CNF_ACT_TANH_PRESCALED, ENG_VJP, 1, 2, 512),      // cfg1: D=2, 2x32
-    MFMA_INST(2, 2, 1, 0, CNF_ACT_TANH_PRESCALED, ENG_VJP, 1, 1, 512),
-    MFMA_INST(1, 2, 1, 0, CNF_ACT_SOFTPLUS, ENG_VJP, 1, 1, 512),  // reference default net, nvariables=1
+    MFMA_INST_AD(2, 2, 1, 0, CNF_ACT_TANH_PRESCALED, ENG_VJP, 1, 2, 512),      // cfg1: D=2, 2x32
+    MFMA_INST_AD(2, 2, 1, 0, CNF_ACT_TANH_PRESCALED, ENG_VJP, 1, 1, 512),
+    MFMA_INST_AD(1, 2, 1, 0, CNF_ACT_SOFTPLUS, ENG_VJP, 1, 1, 512),  // reference default net, nvariables=1
     // --- split-bf16 hidden products (cnf_config.arith = CNF_ARITH_BF16X6), headline shape ---
     MFMA_INST_BF16X6(4, 3, 2, 0, CNF_ACT_TANH_PRESCALED, ENG_VJP, 1, 2, 512),
     MFMA_INST_BF16X6(4, 3, 2, 0, CNF_ACT_TANH_PRESCALED, ENG_VJP, 1, 1, 512),
     MFMA_INST_BF16X6(4, 3, 2, 0, CNF_ACT_TANH_PRESCALED, ENG_VJP, 4, 0, 512),
     MFMA_INST_BF16X6(4, 3, 2, 0, CNF_ACT_TANH, ENG_TAN, 1, 0, 512),
     // --- tangent engine: Hutchinson JVP (LuxJacVecMatrixMode) and exact trace (TestMode) ---
-    MFMA_INST(8, 3, 2, 2, CNF_ACT_TANH, ENG_TAN, 1, 0, 256),      // cfg5: D=8, C=8, 3x128 (200 VGPR, 1 wave/SIMD:
+    MFMA_INST_AD(8, 3, 2, 2, CNF_ACT_TANH, ENG_TAN, 1, 0, 256),      // cfg5: D=8, C=8, 3x128 (200 VGPR, 1 wave/SIMD:
     MFMA_INST(8, 3, 2, 2, CNF_ACT_TANH, ENG_TAN, 1, 0, 512),      //  13.1 ms; the 512-thread build spills: 23.7 ms)
-    MFMA_INST(4, 3, 2, 0, CNF_ACT_TANH, ENG_TAN, 1, 0, 512),      // D=8, 3x64 exact / JVP
-    MFMA_INST(2, 2, 1, 0, CNF_ACT_TANH, ENG_TAN, 1, 0, 512),      // D<=4, 2x32 exact / JVP
-    MFMA_INST(1, 2, 1, 0, CNF_ACT_SOFTPLUS, ENG_TAN, 1, 0, 512),  // reference default net, TestMode
+    MFMA_INST_AD(4, 3, 2, 0, CNF_ACT_TANH, ENG_TAN, 1, 0, 512),      // D=8, 3x64 exact / JVP
+    MFMA_INST_AD(2, 2, 1, 0, CNF_ACT_TANH, ENG_TAN, 1, 0, 512),      // D<=4, 2x32 exact / JVP
+    MFMA_INST_AD(1, 2, 1, 0, CNF_ACT_SOFTPLUS, ENG_TAN, 1, 0, 512),  // reference default net, TestMode
     MFMA_INST(1, 2, 1, 0, CNF_ACT_TANH, ENG_TAN, 1, 0, 512),
 };
 
@@ -112,6 +115,7 @@ MfmaPlan* mfma_plan_create(const cnf_config& c) {
         p->with_bwd = true;
         p->lay = MfmaLayout(HT, L, zr_inst, CR, true);
         p->launch = nullptr;
+        p->launch_adapt = nullptr;
         p->cfg = c;
         p->nthreads = 256;
         p->num_cus = 0;
@@ -133,6 +137,7 @@ MfmaPlan* mfma_plan_create(const cnf_config& c) {
         p->fwd_scale = in.ACT == CNF_ACT_TANH_PRESCALED ? kTanhPrescale : 1.f;
         p->lay = MfmaLayout(HT, L, in.ZR, in.CR, p->with_bwd, in.arith);
         p->launch = in.fn;
+        p->launch_adapt = in.fn_adapt;
         p->cfg = c;
         p->nthreads = in.nthreads;
         p->num_cus = 0;
@@ -382,7 +387,7 @@ hipError_t mfma_solve(MfmaPlan* p, const float* packed_dev, const SolveArgs& s, 
     a.x = s.x; a.u0 = s.u0; a.eps = s.eps; a.ys = s.ys;
     a.u_out = s.u_out; a.logp = s.logp; a.regs = s.regs; a.ckpt = s.ckpt; a.ckpt_k = s.ckpt_k; a.kfull = s.kfull;
     a.B = s.B; a.nsteps = s.nsteps; a.t0 = s.t0;
-    a.dt = s.nsteps > 0 ? (s.t1 - s.t0) / (float)s.nsteps : 0.f;
+    a.dt = s.nsteps > 0 ? (s.dt_exact != 0.f ? s.dt_exact : (s.t1 - s.t0) / (float)s.nsteps) : 0.f;
     a.nvars = s.nvars; a.D = p->cfg.nvars + p->cfg.naug; a.C = p->cfg.ncond;
     a.reg_z = p->cfg.reg_z; a.reg_j = p->cfg.reg_j; a.reg_aug = s.reg_aug; a.autonomous = p->cfg.autonomous;
     a.T = make_tableau(s.alg);
@@ -404,12 +409,85 @@ hipError_t mfma_solve(MfmaPlan* p, const float* packed_dev, const SolveArgs& s, 
     if (p->kind == 1) return coop_launch(p->HT, p->L, p->ZR, p->ACT, a, mp->num_cus, st);
     const long long ntiles = (s.B + 15) / 16;
     const int wpb = p->nthreads / 64;
-    long long want = (ntiles + wpb - 1) / wpb;
+    long long want = ntiles;   // tile t runs on workgroup t % nblocks (cnf_mfma_kernel.h): small batches spread over the CUs
+    (void)wpb;
     const int lds = p->lay.lds_total * (int)sizeof(float);
     const int per_cu = lds > 80 * 1024 ? 1 : 2;
     const long long cap = (long long)mp->num_cus * per_cu;
     const int nblocks = (int)(want < cap ? want : cap);
     return p->launch(a, lds, nblocks, st);
+}
+
+
+// Largest batch the device-controlled adaptive kernel takes (one tile of 16 samples per resident wave), 0 if the plan has
+// no such kernel.
+int64_t mfma_adaptive_capacity(MfmaPlan* p) {
+    if (!p || p->kind != 0 || !p->launch_adapt) return 0;
+    if (env_int("CNF_DEVICE_CONTROLLER", 1) == 0) return 0;
+    if (p->num_cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+        p->num_cus = prop.multiProcessorCount;
+    }
+    if (p->adapt_per_cu < 0) {
+        int occ = 0;
+        const hipError_t e = p->launch_adapt(KArgs{}, AArgs{}, p->lay.lds_total * (int)sizeof(float), 0, nullptr, &occ);
+        if (e != hipSuccess) { (void)hipGetLastError(); occ = 0; }
+        p->adapt_per_cu = occ;
+    }
+    return (int64_t)p->num_cus * p->adapt_per_cu * (p->nthreads / 64) * 16;
+}
+
+// scratch of one device-controlled solve: [2][2][ntiles] doubles, then counter + 4 stats (8 ints), then dts_cap floats
+size_t mfma_adaptive_scratch_bytes(int64_t B, int dts_cap) {
+    const size_t ntiles = (size_t)((B + 15) / 16);
+    return 4 * ntiles * sizeof(double) + 8 * sizeof(int) + (size_t)dts_cap * sizeof(float);
+}
+
+hipError_t mfma_solve_adaptive(MfmaPlan* p, const float* packed_dev, const SolveArgs& s, float abstol, float reltol, float dt_init,
+                               int maxiters, void* scratch, int dts_cap, int** stats_dev, float** dts_dev, hipStream_t st) {
+    const long long ntiles = (s.B + 15) / 16;
+    KArgs a{};
+    a.packed = packed_dev;
+    a.u0 = s.u0; a.eps = s.eps; a.ys = s.ys; a.u_out = s.u_out;
+    a.B = s.B; a.nsteps = 1; a.t0 = s.t0; a.dt = 0.f;
+    a.nvars = s.nvars; a.D = p->cfg.nvars + p->cfg.naug; a.C = p->cfg.ncond;
+    a.reg_z = p->cfg.reg_z; a.reg_j = p->cfg.reg_j; a.reg_aug = s.reg_aug; a.autonomous = p->cfg.autonomous;
+    a.exact = p->cfg.mode == CNF_MODE_EXACT;
+    a.K = p->KP;
+    AArgs q{};
+    q.abstol = abstol; q.reltol = reltol; q.t1 = s.t1; q.dt_init = dt_init; q.maxiters = maxiters; q.dts_cap = dts_cap;
+    const Tableau T = make_tableau(CNF_ALG_TSIT5);
+    // b - bhat of the embedded 4th-order solution (Tsitouras 2011); the same constants as cnf_step_embedded
+    static const float btilde[7] = {-0.00178001105222577714f, -0.0008164344596567469f, 0.007880878010261995f,
+                                    -0.1447110071732629f, 0.5823571654525552f, -0.45808210592918697f,
+                                    0.015151515151515152f};
+    for (int i = 0; i < 7; ++i) { q.bt[i] = btilde[i]; q.c[i] = i < 6 ? T.c[i] : 1.f; }
+    for (int j = 0; j < 6; ++j) {
+        q.b[j] = T.b[j];
+        for (int i = 0; i < 6; ++i) {
+            const int row = j + 1 + i;   // the stage that receives stage j's derivative
+            q.acol[j][i] = row < 6 ? T.a[row][j] : (row == 6 ? T.b[j] : 0.f);
+        }
+    }
+    char* base = (char*)scratch;
+    q.slots = (double*)base;
+    int* ints = (int*)(base + 4 * (size_t)ntiles * sizeof(double));
+    q.counter = (unsigned*)ints;
+    q.stats = ints + 4;
+    q.dts = (float*)(ints + 8);
+    *stats_dev = q.stats;
+    *dts_dev = q.dts;
+    hipError_t e = hipMemsetAsync(ints, 0, 8 * sizeof(int), st);
+    if (e != hipSuccess) return e;
+    const int wpb = p->nthreads / 64;
+    const int lds = p->lay.lds_total * (int)sizeof(float);
+    const long long cap = (long long)p->num_cus * (p->adapt_per_cu > 0 ? p->adapt_per_cu : 0);
+    // tile t runs on workgroup t % nblocks, wave t / nblocks: spread over the CUs first
+    long long nblocks = ntiles < cap ? ntiles : cap;
+    if (nblocks * wpb < ntiles) return hipErrorInvalidValue;
+    return p->launch_adapt(a, q, lds, (int)nblocks, st, nullptr);
 }
 
 }  // namespace cnf

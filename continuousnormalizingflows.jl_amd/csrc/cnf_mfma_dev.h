@@ -31,6 +31,23 @@ struct KArgs {
     float acol[6][5];   // acol[st][i] = T.a[st + 1 + i][st] (0 beyond the last stage): what stage st contributes to the stages after it
 };
 
+// Device-side step controller (mfma_adaptive_kernel): the whole adaptive Tsit5 solve of a batch that fits the chip's wave
+// slots in ONE launch.  Every wave owns one tile of 16 samples; the error norm of an attempt is a grid-wide sum (per-workgroup
+// partials in `slots`, an arrival counter, every workgroup re-sums the partials in the same order), after which every wave runs
+// the same PI controller on the same number and takes the same accept / reject decision.
+struct AArgs {
+    float abstol, reltol, t1, dt_init;
+    int maxiters, dts_cap;
+    float acol[6][6];   // acol[st][i] = A7[st + 1 + i][st], A7 = Tsit5's stage matrix with the FSAL row 6 = b (0 beyond it)
+    float b[6];         // weights of the 5th-order solution
+    float bt[7];        // b - bhat: the embedded error estimate
+    float c[7];
+    double* slots;      // [2 (round parity)][2][workgroups]
+    unsigned* counter;  // arrivals, zeroed on the stream before the launch
+    float* dts;         // accepted steps, dts_cap entries
+    int* stats;         // naccept, nreject, nf, status (0 ok, 1 non-finite error estimate, 2 maxiters, 3 no initial step)
+};
+
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }

@@ -2,10 +2,11 @@
 //
 // The specialised table in cnf_mfma.hip matches (D, C) exactly (BASELINE shapes).  These cover
 // every other Dense chain with H <= 128 and L in {2,3} (H <= 64 for L in {1,4}), D <= 16 (D <= 32: cnf_mfma_generic_zr8.hip), C = 0 or <= 16,
-// tanh or softplus, K = 1: the state/condition k-steps are padded to 4 (zero rows in the operand
+// tanh or softplus, K = 1 (the unconditioned ones with their device-controlled adaptive twins, MFMA_INST_AD): the state/condition k-steps are padded to 4 (zero rows in the operand
 // images, zero registers in the state), which costs at most 2-3 wasted MFMAs per product against
 // the 40x the generic SIMT path would cost.  E.g. the reference's default net for nvariables = 2
 // (D = 5, n_in = 6, hidden 24, softplus) runs on <HT=2, L=2, ZR=4, CR=0, softplus>.
+#define CNF_WITH_DEVICE_CONTROLLER 1
 #include "cnf_mfma_kernel.h"
 
 namespace cnf {
@@ -13,9 +14,9 @@ namespace cnf {
 // VJP instances of tanh nets run the pre-scaled tanh (forward images carry the -2 log2 e factor)
 #define VJP_ACT(ACT) ((ACT) == CNF_ACT_TANH ? CNF_ACT_TANH_PRESCALED : (ACT))
 #define GEN4(HT, L, ACT, NT)                                   \
-    MFMA_INST(HT, L, 4, 0, VJP_ACT(ACT), ENG_VJP, 1, 1, NT),   \
+    MFMA_INST_AD(HT, L, 4, 0, VJP_ACT(ACT), ENG_VJP, 1, 1, NT),   \
     MFMA_INST(HT, L, 4, 4, VJP_ACT(ACT), ENG_VJP, 1, 1, NT),   \
-    MFMA_INST(HT, L, 4, 0, ACT, ENG_TAN, 1, 0, NT),            \
+    MFMA_INST_AD(HT, L, 4, 0, ACT, ENG_TAN, 1, 0, NT),            \
     MFMA_INST(HT, L, 4, 4, ACT, ENG_TAN, 1, 0, NT)
 #define GEN_ACT(HT, NT)                                                          \
     GEN4(HT, 2, CNF_ACT_TANH, NT), GEN4(HT, 3, CNF_ACT_TANH, NT),                \

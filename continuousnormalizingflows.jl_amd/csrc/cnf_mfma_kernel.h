@@ -486,7 +486,9 @@ mfma_solve_kernel(KArgs a) {
     }
     const long long total_waves = (long long)gridDim.x * WPB;
 
-    for (long long tile = (long long)blockIdx.x * WPB + wave; tile < ntiles;) {
+    // tiles go to workgroups first, then to the waves of a workgroup: a batch of fewer tiles than the chip has wave slots
+    // spreads over the compute units (one latency-bound wave per SIMD) instead of filling a few of them
+    for (long long tile = (long long)blockIdx.x + (long long)gridDim.x * wave; tile < ntiles;) {
         // next tile: static stride, or one returning atomic per tile on the launch's queue word
         long long next_tile = tile + total_waves;
         if (a.queue) {
@@ -561,6 +563,9 @@ mfma_solve_kernel(KArgs a) {
                 // The weight image is loop-invariant, and LLVM would hoist all ~300 operand reads out
                 // of the RK loops (and spill them).  An opaque zero offset pins the reads per stage.
                 int opaque = 0;
+#ifdef CNF_HOIST_SMALL
+                if constexpr (!(HT <= 2 && KP == 1))
+#endif
                 asm volatile("" : "+v"(opaque));
                 dyn_eval<HT, L, ZR, CR, ACT, ENGINE, KP, PRE, ARITH>(smem + opaque, a.packed + opaque, lane, tn + a.T.c[st] * dt, autonomous,
                                                               reg_z, reg_j, exact, D, K, zs, y, eps, pre_c, pre_q, zd,
@@ -639,6 +644,315 @@ mfma_solve_kernel(KArgs a) {
     }
 }
 
+#ifdef CNF_WITH_DEVICE_CONTROLLER
+// ---- adaptive Tsit5 with the step controller on the device: one launch per solve ----
+// OrdinaryDiffEq's adaptive loop as cnf_api_adaptive.hip::api_solve_tsit5 restates it on the host (Hairer's initial step,
+// embedded estimate dt sum btilde_i k_i scaled by abstol + reltol max(|u|, |u_new|), RMS over the whole S x B state, PI
+// controller, first-same-as-last), for batches of at most one tile per resident wave.  The host loop pays 3-4 launches and
+// a device-to-host round trip per attempt (~70 us); here an attempt costs its six dynamics calls and one grid-wide sum.
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// Grid-wide sums of two per-lane values over all tiles, in two levels: the waves of a workgroup meet in LDS, wave 0 of every
+// workgroup publishes the workgroup's partial, arrives at the counter, waits for the other workgroups, and adds the
+// partials up in workgroup order.  Every wave ends with the same two doubles (same partials, same order).  `round` counts
+// the calls (the same in every wave): its parity picks the slot set, its value the arrival target.  One poller per
+// workgroup: with a poller per wave the 1024 pollers of a 16 K batch cost ~70 us per sum on one counter word.
+// (Spare waves of a workgroup have left the kernel; the hardware barrier counts the waves still running.)
+__device__ __forceinline__ void grid_sum2(const AArgs& q, unsigned& round, int wave, int nact, int lane, double& v0, double& v1) {
+    __shared__ double wg_part[2][16];
+    __shared__ double wg_tot[2];
+    v0 = wave_sum_f64(v0);
+    v1 = wave_sum_f64(v1);
+    if (lane == 0) { wg_part[0][wave] = v0; wg_part[1][wave] = v1; }
+    __syncthreads();
+    if (wave == 0) {
+        const unsigned nb = gridDim.x;
+        double* sl = q.slots + (size_t)(round & 1u) * 2u * (size_t)nb;
+        if (lane == 0) {
+            double a0 = 0.0, a1 = 0.0;
+            for (int w = 0; w < nact; ++w) { a0 += wg_part[0][w]; a1 += wg_part[1][w]; }
+            sl[blockIdx.x] = a0;
+            sl[nb + blockIdx.x] = a1;
+            __hip_atomic_fetch_add(q.counter, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned target = (round + 1u) * nb;
+            while (__hip_atomic_load(q.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        double a0 = 0.0, a1 = 0.0;
+        for (unsigned i = lane; i < nb; i += 64) { a0 += sl[i]; a1 += sl[nb + i]; }
+        a0 = wave_sum_f64(a0);
+        a1 = wave_sum_f64(a1);
+        if (lane == 0) { wg_tot[0] = a0; wg_tot[1] = a1; }
+    }
+    __syncthreads();
+    v0 = wg_tot[0];
+    v1 = wg_tot[1];
+    ++round;
+}
+
+template <int HT, int L, int ZR, int CR, int ACT, int ENGINE, int KP, int PRE, int NTHREADS, int ARITH = 0>
+__global__ void __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(1, (NTHREADS + 255) / 256)))
+mfma_adaptive_kernel(KArgs a, AArgs q) {
+    constexpr MfmaLayout LAY(HT, L, ZR, CR, ENGINE == ENG_VJP, ARITH);
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    {
+        const f32x4* src = reinterpret_cast<const f32x4*>(a.packed);
+        f32x4* dst = reinterpret_cast<f32x4*>(smem);
+        for (int i = threadIdx.x; i < LAY.lds_total / 4; i += NTHREADS) dst[i] = src[i];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int g = lane >> 4, n = lane & 15;
+    const int wave = threadIdx.x >> 6;
+    const long long ntiles = (a.B + 15) / 16;
+    const long long tile = (long long)blockIdx.x + (long long)gridDim.x * wave;
+    if (tile >= ntiles) return;   // the host sizes the grid so that every tile has a wave; spare waves leave
+    // waves of this workgroup that own a tile (wave w owns tile blockIdx + gridDim w): they meet in grid_sum2
+    const int nact = (int)((ntiles - 1 - (long long)blockIdx.x) / (long long)gridDim.x) + 1 < NTHREADS / 64
+                         ? (int)((ntiles - 1 - (long long)blockIdx.x) / (long long)gridDim.x) + 1 : NTHREADS / 64;
+    const int D = a.D, S = D + 3, C = a.C;
+    const int K = KP == 1 ? 1 : a.K;
+    const int Kd = K * D;
+    const bool reg_z = a.reg_z, reg_j = a.reg_j, autonomous = a.autonomous, exact = a.exact;
+    const long long smp = tile * 16 + n;
+    const bool valid = smp < a.B;
+    const long long sc = valid ? smp : a.B - 1;
+    float z[ZR], eps[KP][ZR], y[CR > 0 ? CR : 1];
+#pragma unroll
+    for (int s = 0; s < ZR; ++s) {
+        const int f = 4 * s + g;
+        z[s] = f < D ? a.u0[sc * S + f] : 0.f;
+#pragma unroll
+        for (int p = 0; p < KP; ++p) eps[p][s] = (f < D && p < K && a.eps) ? a.eps[sc * Kd + p * D + f] : 0.f;
+    }
+    float la = a.u0[sc * S + D], ea = a.u0[sc * S + D + 1], na = a.u0[sc * S + D + 2];
+    y[0] = 0.f;
+    if constexpr (CR > 0) {
+#pragma unroll
+        for (int s = 0; s < CR; ++s) { const int f = 4 * s + g; y[s] = f < C ? a.ys[sc * C + f] : 0.f; }
+    }
+    f32x4 pre_c[HT], pre_q[HT];
+#pragma unroll
+    for (int mt = 0; mt < HT; ++mt) pre_c[mt] = pre_q[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (PRE >= 1) gemm_tiles<HT, ZR>(smem + LAY.bN, lane, RegIn<ZR>{eps[0]}, pre_c);
+    if constexpr (PRE >= 2) {
+        gemm_tiles<HT, ZR>(smem + LAY.f1z, lane, RegIn<ZR>{eps[0]}, pre_q);
+        if constexpr (ACT == CNF_ACT_TANH_PRESCALED) {
+#pragma unroll
+            for (int mt = 0; mt < HT; ++mt) pre_q[mt] *= (1.f / kTanhPrescale);
+        }
+    }
+
+    const double t0 = (double)a.t0, t1 = (double)q.t1;
+    const double span = fabs(t1 - t0), tdir = t1 >= t0 ? 1.0 : -1.0, ntot = (double)S * (double)a.B;
+    const float abstol = q.abstol, reltol = q.reltol;
+    // a lane's share of the state: its ZR rows of z, and - in lane group 0 - the three scalar rows
+    auto row_live = [&](int s) { return valid && 4 * s + g < D; };
+    const bool scal_live = valid && g == 0;
+
+    float k1z[ZR], k1l = 0.f, k1e = 0.f, k1n = 0.f;      // derivative at (z, t): first stage of the next attempt
+    float P[6][ZR], erz[ZR], lsum = 0.f, esum = 0.f, nsum = 0.f, erl = 0.f, ere = 0.f, ern = 0.f;
+    float zs[ZR], zd[ZR], ld = 0.f, ed = 0.f, nd = 0.f;
+#pragma unroll
+    for (int s = 0; s < ZR; ++s) {
+        zs[s] = z[s]; zd[s] = 0.f; k1z[s] = 0.f; erz[s] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) P[i][s] = 0.f;
+    }
+    double t = t0, dt = 0.0, qold = 1e-4, step = 0.0, h0 = 0.0, d1 = 0.0;
+    float tf = 0.f, dtf = 0.f, tcur = a.t0;
+    bool last = false;
+    int phase = 0, st = 0, it = 0, naccept = 0, nreject = 0, nf = 0, status = 0;
+    unsigned round = 0;
+
+    for (;;) {
+        // one dynamics call per trip: at (u0, t0) first, at the Euler point of Hairer's rule second, then the stages
+        int opaque = 0;
+        asm volatile("" : "+v"(opaque));
+        dyn_eval<HT, L, ZR, CR, ACT, ENGINE, KP, PRE, ARITH>(smem + opaque, a.packed + opaque, lane, tcur, autonomous, reg_z, reg_j, exact,
+                                                      D, K, zs, y, eps, pre_c, pre_q, zd, ld, ed, nd);
+        ++nf;
+        bool begin = false;
+        if (phase == 0) {
+#pragma unroll
+            for (int s = 0; s < ZR; ++s) k1z[s] = zd[s];
+            k1l = ld; k1e = ed; k1n = nd;
+            if (q.dt_init != 0.f) {
+                dt = fmin((double)fabsf(q.dt_init), span);
+                begin = true;
+            } else {   // ode_determine_initdt (Hairer, Noersett, Wanner I, II.4), order 5
+                double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+                for (int s = 0; s < ZR; ++s) {
+                    if (row_live(s)) {
+                        const float sk = fmaf(fabsf(z[s]), reltol, abstol), r0 = z[s] / sk, r1 = k1z[s] / sk;
+                        s0 += (double)r0 * (double)r0; s1 += (double)r1 * (double)r1;
+                    }
+                }
+                if (scal_live) {
+                    const float u3[3] = {la, ea, na}, f3[3] = {k1l, k1e, k1n};
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) {
+                        const float sk = fmaf(fabsf(u3[i]), reltol, abstol), r0 = u3[i] / sk, r1 = f3[i] / sk;
+                        s0 += (double)r0 * (double)r0; s1 += (double)r1 * (double)r1;
+                    }
+                }
+                grid_sum2(q, round, wave, nact, lane, s0, s1);
+                const double d0 = sqrt(s0 / ntot);
+                d1 = sqrt(s1 / ntot);
+                h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
+                h0 = fmin(h0, span);
+                if (!(isfinite(h0) && h0 > 0.0)) { status = 3; break; }
+                const float hf = (float)(tdir * h0);
+#pragma unroll
+                for (int s = 0; s < ZR; ++s) zs[s] = fmaf(hf, k1z[s], z[s]);
+                tcur = (float)(t0 + tdir * h0);
+                phase = 1;
+                continue;
+            }
+        } else if (phase == 1) {
+            double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+            for (int s = 0; s < ZR; ++s) {
+                if (row_live(s)) {
+                    const float r = (zd[s] - k1z[s]) / fmaf(fabsf(z[s]), reltol, abstol);
+                    s0 += (double)r * (double)r;
+                }
+            }
+            if (scal_live) {
+                const float u3[3] = {la, ea, na}, f3[3] = {k1l, k1e, k1n}, g3[3] = {ld, ed, nd};
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const float r = (g3[i] - f3[i]) / fmaf(fabsf(u3[i]), reltol, abstol);
+                    s0 += (double)r * (double)r;
+                }
+            }
+            grid_sum2(q, round, wave, nact, lane, s0, s1);
+            const double d2 = sqrt(s0 / ntot) / h0, dmax = fmax(d1, d2);
+            const double h1 = dmax <= 1e-15 ? fmax(1e-6, h0 * 1e-3) : pow(10.0, -(2.0 + log10(dmax)) / 5.0);
+            dt = fmin(fmin(100.0 * h0, h1), span);
+            if (!(isfinite(dt) && dt > 0.0)) { status = 3; break; }
+            begin = true;
+        } else {
+            // stage st (1..6) of the attempt has been evaluated
+            erl = fmaf(q.bt[st], ld, erl); ere = fmaf(q.bt[st], ed, ere); ern = fmaf(q.bt[st], nd, ern);
+#pragma unroll
+            for (int s = 0; s < ZR; ++s) erz[s] = fmaf(q.bt[st], zd[s], erz[s]);
+            if (st < 6) {
+                const float bst = q.b[st];
+                lsum = fmaf(bst, ld, lsum); esum = fmaf(bst, ed, esum); nsum = fmaf(bst, nd, nsum);
+#pragma unroll
+                for (int s = 0; s < ZR; ++s) {
+#pragma unroll
+                    for (int i = 0; i < 5; ++i) P[i][s] = fmaf(q.acol[st][i], zd[s], P[i + 1][s]);
+                    P[5][s] = q.acol[st][5] * zd[s];
+                    zs[s] = fmaf(dtf, P[0][s], z[s]);     // the next stage's state; for st + 1 = 6 the new state itself
+                }
+                ++st;
+                tcur = tf + q.c[st] * dtf;
+                continue;
+            }
+            // the attempt is complete: zs = z_new, (zd, ld, ed, nd) = the derivative there
+            const float ln = fmaf(dtf, lsum, la), en = fmaf(dtf, esum, ea), nn = fmaf(dtf, nsum, na);
+            double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+            for (int s = 0; s < ZR; ++s) {
+                if (row_live(s)) {
+                    const float r = dtf * erz[s] / fmaf(fmaxf(fabsf(z[s]), fabsf(zs[s])), reltol, abstol);
+                    s0 += (double)r * (double)r;
+                }
+            }
+            if (scal_live) {
+                const float u3[3] = {la, ea, na}, v3[3] = {ln, en, nn}, e3[3] = {erl, ere, ern};
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const float r = dtf * e3[i] / fmaf(fmaxf(fabsf(u3[i]), fabsf(v3[i])), reltol, abstol);
+                    s0 += (double)r * (double)r;
+                }
+            }
+            grid_sum2(q, round, wave, nact, lane, s0, s1);
+            const double eest = sqrt(s0 / ntot);
+            if (!isfinite(eest)) { status = 1; break; }
+            const double beta1 = 7.0 / 50.0, beta2 = 2.0 / 25.0, gamma = 0.9, qmin = 0.2, qmax = 10.0;
+            const double q11 = eest > 0.0 ? pow(eest, beta1) : 0.0;
+            const double qq = eest == 0.0 ? 1.0 / qmax : fmax(1.0 / qmax, fmin(1.0 / qmin, (q11 / pow(qold, beta2)) / gamma));
+            if (eest <= 1.0) {   // accept
+                t = last ? t1 : t + tdir * step;
+#pragma unroll
+                for (int s = 0; s < ZR; ++s) { z[s] = zs[s]; k1z[s] = zd[s]; }
+                la = ln; ea = en; na = nn;
+                k1l = ld; k1e = ed; k1n = nd;
+                if (tile == 0 && lane == 0 && naccept < q.dts_cap) q.dts[naccept] = (float)(tdir * step);
+                ++naccept;
+                qold = fmax(eest, 1e-4);
+                dt = step / qq;
+            } else {             // reject: same (t, z, k1), smaller step
+                ++nreject;
+                dt = step / fmin(1.0 / qmin, q11 / gamma);
+            }
+            begin = true;
+        }
+        if (begin) {
+            if (fabs(t1 - t) <= 1e-7 * fmax(1.0, span)) break;
+            if (it >= q.maxiters) { status = 2; break; }
+            ++it;
+            last = dt >= fabs(t1 - t) * (1.0 - 1e-6);
+            step = last ? fabs(t1 - t) : dt;     // tstop: never step over t1
+            tf = (float)t;
+            dtf = (float)(tdir * step);
+            lsum = q.b[0] * k1l; esum = q.b[0] * k1e; nsum = q.b[0] * k1n;
+            erl = q.bt[0] * k1l; ere = q.bt[0] * k1e; ern = q.bt[0] * k1n;
+#pragma unroll
+            for (int s = 0; s < ZR; ++s) {
+                erz[s] = q.bt[0] * k1z[s];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) P[i][s] = q.acol[0][i] * k1z[s];
+                zs[s] = fmaf(dtf, P[0][s], z[s]);
+            }
+            st = 1;
+            phase = 2;
+            tcur = tf + q.c[1] * dtf;
+        }
+    }
+
+    if (valid && a.u_out) {
+#pragma unroll
+        for (int s = 0; s < ZR; ++s) { const int f = 4 * s + g; if (f < D) a.u_out[smp * S + f] = z[s]; }
+        if (g == 0) { a.u_out[smp * S + D] = la; a.u_out[smp * S + D + 1] = ea; a.u_out[smp * S + D + 2] = na; }
+    }
+    if (tile == 0 && lane == 0) { q.stats[0] = naccept; q.stats[1] = nreject; q.stats[2] = nf; q.stats[3] = status; }
+}
+
+// occ_out != null: only report how many workgroups of this kernel one compute unit holds (registers and LDS considered)
+typedef hipError_t (*LaunchAdaptFn)(const KArgs&, const AArgs&, int lds_bytes, int nblocks, hipStream_t, int* occ_out);
+
+template <int HT, int L, int ZR, int CR, int ACT, int ENGINE, int KP, int PRE, int NTHREADS, int ARITH = 0>
+inline hipError_t launch_adapt_inst(const KArgs& a, const AArgs& q, int lds_bytes, int nblocks, hipStream_t st, int* occ_out) {
+    auto kern = mfma_adaptive_kernel<HT, L, ZR, CR, ACT, ENGINE, KP, PRE, NTHREADS, ARITH>;
+    static DeviceOnce once;
+    int dev = 0;
+    hipError_t e0 = hipGetDevice(&dev);
+    if (e0 != hipSuccess) return e0;
+    if (!once.done(dev)) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        if (e != hipSuccess) return e;
+        once.set(dev);
+    }
+    if (occ_out) return hipOccupancyMaxActiveBlocksPerMultiprocessor(occ_out, (const void*)kern, NTHREADS, (size_t)lds_bytes);
+    // cooperative launch: the runtime refuses a grid whose workgroups cannot all be resident, which the grid-wide sums need
+    KArgs ka = a;
+    AArgs qa = q;
+    void* params[2] = {&ka, &qa};
+    return hipLaunchCooperativeKernel((const void*)kern, dim3(nblocks), dim3(NTHREADS), params, (unsigned)lds_bytes, st);
+}
+#else
+typedef hipError_t (*LaunchAdaptFn)(const KArgs&, const AArgs&, int lds_bytes, int nblocks, hipStream_t, int* occ_out);
+#endif
+
 typedef hipError_t (*LaunchFn)(const KArgs&, int lds_bytes, int nblocks, hipStream_t);
 
 template <int HT, int L, int ZR, int CR, int ACT, int ENGINE, int KP, int PRE, int NTHREADS, int ARITH = 0>
@@ -664,12 +978,19 @@ struct Inst {
     LaunchFn fn;
     int nthreads;
     int arith; // CNF_ARITH_*
+    LaunchAdaptFn fn_adapt;   // adaptive Tsit5 with the device-side step controller, or null (host loop)
 };
 
 #define MFMA_INST(HT, L, ZR, CR, ACT, ENG, KP, PRE, NT) \
-    Inst { HT, L, ZR, CR, ACT, ENG, KP, PRE, &launch_inst<HT, L, ZR, CR, ACT, ENG, KP, PRE, NT>, NT, 0 }
+    Inst { HT, L, ZR, CR, ACT, ENG, KP, PRE, &launch_inst<HT, L, ZR, CR, ACT, ENG, KP, PRE, NT>, NT, 0, nullptr }
 #define MFMA_INST_BF16X6(HT, L, ZR, CR, ACT, ENG, KP, PRE, NT) \
-    Inst { HT, L, ZR, CR, ACT, ENG, KP, PRE, &launch_inst<HT, L, ZR, CR, ACT, ENG, KP, PRE, NT, 1>, NT, 1 }
+    Inst { HT, L, ZR, CR, ACT, ENG, KP, PRE, &launch_inst<HT, L, ZR, CR, ACT, ENG, KP, PRE, NT, 1>, NT, 1, nullptr }
+#ifdef CNF_WITH_DEVICE_CONTROLLER
+// the same instance with its device-controlled adaptive twin
+#define MFMA_INST_AD(HT, L, ZR, CR, ACT, ENG, KP, PRE, NT) \
+    Inst { HT, L, ZR, CR, ACT, ENG, KP, PRE, &launch_inst<HT, L, ZR, CR, ACT, ENG, KP, PRE, NT>, NT, 0, \
+           &launch_adapt_inst<HT, L, ZR, CR, ACT, ENG, KP, PRE, NT> }
+#endif
 
 // generic zero-padded instances (cnf_mfma_generic.hip): D <= 16 and C <= 16 or C = 0
 const Inst* mfma_generic_insts(int* count);

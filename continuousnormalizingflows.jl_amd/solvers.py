@@ -24,7 +24,7 @@ def _solve_errors(call):
     try:
         _lib.check(call())
     except _lib.CnfError as err:
-        if "maxiters" in str(err):
+        if "maxiters reached" in str(err):
             raise RuntimeError("adaptive solve: maxiters reached") from None
         if "non-finite" in str(err):
             raise FloatingPointError("adaptive solve: " + str(err).split(": ", 2)[-1]) from None

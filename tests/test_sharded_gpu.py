@@ -97,6 +97,7 @@ def test_two_ranks_on_the_gpu_reproduce_the_unsharded_results(pkg, oracles):
     fixed = _build(pkg, o64, spec, dict(alg=pkg.Tsit5(), adaptive=False, nsteps=10))
     val, g = pkg.loss_and_gradient(fixed, m, dev(xs), dev(p), {}, eps=dev(eps))
     adap = _build(pkg, o64, spec, dict(alg=pkg.Tsit5(), reltol=1e-4, abstol=1e-4))
+    adap.adaptive_policy = "python"                       # the host loop the ranks run (a single process would get the one-launch solve)
     logp = pkg.inference(adap, m, dev(xs), dev(p), {}, eps=dev(eps))[0].cpu().numpy()
     dts = list(adap.last_solve_stats["dts"])
     assert len(dts) >= 4
@@ -115,6 +116,7 @@ def test_two_ranks_on_the_gpu_reproduce_the_unsharded_results(pkg, oracles):
         ic = _build(pkg, o64, spec, kw)
         one.append(float(pkg.loss(ic, m, dev(xs[:, :1]), dev(p), {}, eps=dev(eps[:, :1]))))
     assert np.allclose(res[0][11], one, rtol=1e-5, atol=1e-5), (res[0][11], one)   # ... of the one column
+    adap.adaptive_policy = "library"                      # a rank-local solve is a single-process solve: the library's own policy
     loc = pkg.inference(adap, m, dev(xs[:, :64]), dev(p), {}, eps=dev(eps[:, :64]))[0].cpu().numpy()
     assert res[1][12] is None and np.max(np.abs(res[0][12] - loc)) < 1e-5          # rank-local solve while a group exists
     res = [r[:9] for r in res]
