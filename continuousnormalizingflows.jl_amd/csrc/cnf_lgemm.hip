@@ -74,6 +74,7 @@ struct LgGemmArgs {
     long long N;
     int M, K, MT, KQ, ldb, ldc, lde, ldd, ld3, act, first;
     int mts;               // M-tiles per workgroup row (blockIdx.y picks the group): wide outputs are split over several workgroups
+    int spw;               // pipelined kernel: 32-sample sub-panels per workgroup
 };
 
 // MTW: 16-row tiles per wave (MT <= 4 MTW); NQ: 16-sample tiles per workgroup (each weight fragment feeds NQ sample tiles)
@@ -230,6 +231,204 @@ lg_gemm_kernel(LgGemmArgs a) {
     }
 }
 
+// ---- pipelined variant: a workgroup walks over several 32-sample sub-panels; while the MFMAs of one sub-panel run, the input
+// columns of the next are in flight (global -> registers, parked in the other LDS buffer after the epilogue).  The fused
+// products of the reverse sweep move ~130 MB for 4.3 GFLOP at cfg4's shapes - HBM time ~ MFMA time - so the one-panel kernel
+// above (stage, then multiply, then epilogue, one workgroup per CU) runs at the SUM of the two; this one at their maximum.
+// 68 KB of LDS (K <= 272) and <= 256 registers: two workgroups per CU, whose epilogue stalls overlap the other's MFMAs.
+template <int MTW, int EPI>
+__device__ __forceinline__ void lg_epilogue_tile(const LgGemmArgs& a, f32x4 v, int r0, long long col) {
+    f32x4 dv = {0.f, 0.f, 0.f, 0.f};
+    const bool full = r0 + 3 < a.M;
+    if (EPI == LG_EPI_ACT) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { float dd; v[r] = act_fwd_rt(a.act, v[r], dd); dv[r] = dd; }
+    }
+    if (EPI == LG_EPI_MUL || EPI == LG_EPI_MUL2 || EPI == LG_EPI_BOTTOM || EPI == LG_EPI_SBAR) {
+        auto load4 = [&](const float* base, int ld) -> f32x4 {
+            const float* p = base + col * (long long)ld + r0;
+            if (full) { const f32x4u t = *reinterpret_cast<const f32x4u*>(p); return f32x4{t[0], t[1], t[2], t[3]}; }
+            f32x4 t = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (r0 + r < a.M) t[r] = p[r];
+            return t;
+        };
+        const f32x4 ev = load4(a.e, a.lde);
+        if (EPI == LG_EPI_MUL) v *= ev;
+        if (EPI == LG_EPI_MUL2) dv = v * ev;
+        if (EPI == LG_EPI_BOTTOM) {
+            const f32x4 vv = load4(a.e2, a.lde);
+            f32x4 prev = {0.f, 0.f, 0.f, 0.f};
+            if (!a.first) prev = load4(a.dout, a.ldd);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dv[r] = a.first ? v[r] * vv[r] : fmaf(v[r], vv[r], prev[r]);
+            v *= ev;
+        }
+        if (EPI == LG_EPI_SBAR) {
+            const f32x4 c2 = load4(a.e2, a.lde);
+            f32x4 e2v = {0.f, 0.f, 0.f, 0.f};
+            if (a.act == CNF_ACT_TANH) {
+                const f32x4 av = load4(a.a3, a.ld3);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) e2v[r] = -2.f * av[r] * ev[r];
+            } else if (a.act == CNF_ACT_SOFTPLUS) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) e2v[r] = ev[r] * (1.f - ev[r]);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = fmaf(c2[r], e2v[r], v[r] * ev[r]);
+        }
+    }
+    float* op = a.out + col * (long long)a.ldc + r0;
+    if (full) {
+        *reinterpret_cast<f32x4u*>(op) = f32x4u{v[0], v[1], v[2], v[3]};
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) if (r0 + r < a.M) op[r] = v[r];
+    }
+    if (EPI == LG_EPI_ACT || EPI == LG_EPI_MUL2 || EPI == LG_EPI_BOTTOM) {
+        float* dp = a.dout + col * (long long)a.ldd + r0;
+        if (full) {
+            *reinterpret_cast<f32x4u*>(dp) = f32x4u{dv[0], dv[1], dv[2], dv[3]};
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (r0 + r < a.M) dp[r] = dv[r];
+        }
+        if (EPI == LG_EPI_ACT && a.ldc > a.M && r0 <= a.M - 1 && a.M - 1 < r0 + 4) a.out[col * (long long)a.ldc + a.M] = 1.f;
+    }
+}
+
+constexpr int LG2_KQ_MAX = 17;                        // K <= 272: 2 buffers x 17 x 2 KB = 68 KB of LDS
+constexpr int LG2_UNITS = (2 * LG2_KQ_MAX + 3) / 4;   // staging units (1 KB: one (kq, q) tile) per wave and sub-panel
+
+template <int MTW, int EPI>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+lg_gemm2_kernel(LgGemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    f32x4* bimg = reinterpret_cast<f32x4*>(smem);                 // [2 buffers][KQ][2 sample tiles][64 lanes]
+    const int lane = threadIdx.x & 63, g = lane >> 4, n = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int KQ = a.KQ, nunits = 2 * KQ, bufsz = nunits * 64;
+    const long long nsub = (a.N + 31) / 32;
+    const long long sp0 = (long long)blockIdx.x * a.spw;
+    const int cnt = (int)(sp0 + a.spw <= nsub ? a.spw : nsub - sp0);
+    f32x4 stage[LG2_UNITS];
+    // unit u = 2 kq + q: lane (g, n) holds rows 16 kq + 4 g .. + 3 of column 32 sp + 16 q + n; wave w takes units w, w + 4, ...
+    auto fetch = [&](long long sp) {
+#pragma unroll
+        for (int i = 0; i < LG2_UNITS; ++i) {
+            const int u = wave + 4 * i;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (u < nunits) {
+                const int kq = u >> 1, q = u & 1, k0 = 16 * kq + 4 * g;
+                const long long col = sp * 32 + 16 * q + n;
+                if (col < a.N) {
+                    const float* src = a.in + col * (long long)a.ldb + k0;
+                    if (k0 + 3 < a.K) {
+                        const f32x4u t = *reinterpret_cast<const f32x4u*>(src);
+                        v = f32x4{t[0], t[1], t[2], t[3]};
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) if (k0 + j < a.K) v[j] = src[j];
+                    }
+                }
+            }
+            stage[i] = v;
+        }
+    };
+    auto park = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < LG2_UNITS; ++i) {
+            const int u = wave + 4 * i;
+            if (u < nunits) bimg[buf * bufsz + u * 64 + lane] = stage[i];
+        }
+    };
+    const f32x4* __restrict__ A = reinterpret_cast<const f32x4*>(a.img) + lane;
+    const int mt_lo = blockIdx.y * a.mts;
+    const int mt_hi = mt_lo + a.mts < a.MT ? mt_lo + a.mts : a.MT;
+    int mts[MTW];
+#pragma unroll
+    for (int m = 0; m < MTW; ++m) { const int t = mt_lo + wave + 4 * m; mts[m] = t < mt_hi ? t : mt_hi - 1; }
+    if (cnt <= 0) return;
+    fetch(sp0);
+    park(0);
+    __syncthreads();
+#pragma clang loop unroll(disable)
+    for (int it = 0; it < cnt; ++it) {
+        const long long sp = sp0 + it;
+        const bool more = it + 1 < cnt;
+        if (more) fetch(sp + 1);
+        const f32x4* bb = bimg + (it & 1) * bufsz + lane;
+        f32x4 acc[MTW][2];
+#pragma unroll
+        for (int m = 0; m < MTW; ++m) acc[m][0] = acc[m][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 a0[MTW], a1[MTW], b0[2], b1[2];
+#pragma unroll
+        for (int m = 0; m < MTW; ++m) a0[m] = A[((long long)mts[m] * KQ + 0) * 64];
+        b0[0] = bb[0]; b0[1] = bb[64];
+#pragma clang loop unroll(disable)
+        for (int kq = 0; kq < KQ; kq += 2) {
+            const bool has1 = kq + 1 < KQ, has2 = kq + 2 < KQ;
+            if (has1) {
+#pragma unroll
+                for (int m = 0; m < MTW; ++m) a1[m] = A[((long long)mts[m] * KQ + kq + 1) * 64];
+                b1[0] = bb[(2 * (kq + 1)) * 64]; b1[1] = bb[(2 * (kq + 1) + 1) * 64];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int m = 0; m < MTW; ++m) {
+                    acc[m][0] = mfma4(a0[m][j], b0[0][j], acc[m][0]);
+                    acc[m][1] = mfma4(a0[m][j], b0[1][j], acc[m][1]);
+                }
+            if (has1) {
+                if (has2) {
+#pragma unroll
+                    for (int m = 0; m < MTW; ++m) a0[m] = A[((long long)mts[m] * KQ + kq + 2) * 64];
+                    b0[0] = bb[(2 * (kq + 2)) * 64]; b0[1] = bb[(2 * (kq + 2) + 1) * 64];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int m = 0; m < MTW; ++m) {
+                        acc[m][0] = mfma4(a1[m][j], b1[0][j], acc[m][0]);
+                        acc[m][1] = mfma4(a1[m][j], b1[1][j], acc[m][1]);
+                    }
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < MTW; ++m) {
+            const int mt = mt_lo + wave + 4 * m;
+            if (mt >= mt_hi) continue;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const long long col = sp * 32 + 16 * q + n;
+                if (col < a.N) lg_epilogue_tile<MTW, EPI>(a, acc[m][q], 16 * mt + 4 * g, col);
+            }
+        }
+        if (more) park((it + 1) & 1);
+        __syncthreads();
+    }
+}
+
+template <int MTW, int EPI>
+static hipError_t lg_gemm2_launch(const LgGemmArgs& a, hipStream_t st) {
+    const int lds = 2 * a.KQ * 2 * 64 * 16;
+    auto kern = lg_gemm2_kernel<MTW, EPI>;
+    static DeviceOnce once;
+    int dev = 0;
+    hipError_t e0 = hipGetDevice(&dev);
+    if (e0 != hipSuccess) return e0;
+    if (lds > 64 * 1024 && !once.done(dev)) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        if (e != hipSuccess) return e;
+        once.set(dev);
+    }
+    const long long nsub = (a.N + 31) / 32;
+    hipLaunchKernelGGL(kern, dim3((unsigned)((nsub + a.spw - 1) / a.spw), (unsigned)((a.MT + a.mts - 1) / a.mts)), dim3(256), lds, st, a);
+    return hipGetLastError();
+}
+
 template <int MTW, int NQ, int EPI>
 static hipError_t lg_gemm_launch(const LgGemmArgs& a, hipStream_t st) {
     const int lds = a.KQ * NQ * 64 * 16;
@@ -257,6 +456,20 @@ static hipError_t lg_gemm_dispatch(LgGemmArgs a, hipStream_t st) {
     // fits LDS and there are enough samples to fill the chip that way
     const int splits = (a.MT + 15) / 16;
     a.mts = (a.MT + splits - 1) / splits;
+    static const int variant = [] { const char* v = getenv("CNF_LG_GEMM"); return v && *v ? atoi(v) : 2; }();
+    if (variant == 2 && a.KQ <= LG2_KQ_MAX) {
+        // enough sub-panels per workgroup for the pipeline to pay (>= 4 where the batch allows), at least ~2 workgroups per CU
+        static const int spw_env = [] { const char* v = getenv("CNF_LG_SPW"); return v && *v ? atoi(v) : 0; }();
+        const long long nsub = (a.N + 31) / 32;
+        long long spw = nsub * splits / 512;
+        if (spw < 1) spw = 1;
+        if (spw > 8) spw = 8;
+        if (spw_env > 0) spw = spw_env;
+        a.spw = (int)spw;
+        if (a.mts <= 4) return lg_gemm2_launch<1, EPI>(a, st);
+        if (a.mts <= 8) return lg_gemm2_launch<2, EPI>(a, st);
+        return lg_gemm2_launch<4, EPI>(a, st);
+    }
     const bool wide = a.KQ * 8 * 1024 <= 160 * 1024 && a.N * splits >= 128 * 192;
     if (a.mts <= 4) return wide ? lg_gemm_launch<1, 8, EPI>(a, st) : lg_gemm_launch<1, 4, EPI>(a, st);
     if (a.mts <= 8) return wide ? lg_gemm_launch<2, 8, EPI>(a, st) : lg_gemm_launch<2, 4, EPI>(a, st);
@@ -288,6 +501,7 @@ struct LgWgradArgs {
     const float* x; const float* y;
     long long B, chunk;      // samples in total, samples per chunk (multiple of 4)
     int M, Nc, ldx, ldy;
+    int nchunks, rblocks, groups;   // grid decomposition (see the kernel)
 };
 
 // NTN: 16-column tiles of C a wave keeps (Nc <= 16 NTN).  The four waves of a workgroup own four 16-row strips of C and share
@@ -296,7 +510,7 @@ struct LgWgradArgs {
 // that ONE lane-linear ds_read_b128 hands a lane its B operands of all four k-steps of a tile (sample 4 u + g, row 16 t + n).
 // (Reading the operands straight from global memory made every wave fetch all of Y: 670 MB of L2 traffic per call at cfg4.)
 template <int NTN>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3)))
 lg_wgrad_kernel(LgWgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int RY = (NTN * 16 + 63) / 64;                     // loads per lane per sample for the Y slice
@@ -304,79 +518,161 @@ lg_wgrad_kernel(LgWgradArgs a) {
     // slice buffer b: Y part at smem + b (YS + XS), X part behind it
     const int lane = threadIdx.x & 63, g = lane >> 4, n = lane & 15;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int row0 = blockIdx.x * 64;                             // this workgroup's 64 rows of C; wave w: rows row0 + 16 w ..
-    const int chunk = blockIdx.y;
+    // Workgroup -> (sample chunk, row block, column group).  The row blocks and column groups of ONE chunk read the same
+    // samples of X and Y; workgroups b and b + 8 share an XCD (and its L2) under the observed round-robin placement, so the
+    // sharers of a chunk are given ids that are equal mod 8: X and Y then come from HBM once and from that L2 afterwards
+    // (with the sharers dealt over the XCDs every one of them pulled its own copy: ~200 MB per call at cfg4 instead of 66).
+    // Placement is a speed matter only; the result does not depend on it.
+    const int sharers = a.rblocks * a.groups;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int chunk = (slot / sharers) * 8 + xcd, sub = slot % sharers;
+    if (chunk >= a.nchunks) return;
+    const int rblock = sub % a.rblocks;
+    const int row0 = rblock * 64;                                 // this workgroup's 64 rows of C; wave w: rows row0 + 16 w ..
+    // column group: C wider than NTN tiles is covered by several workgroups, each with its own columns of Y
+    const int col_lo = (sub / a.rblocks) * (NTN * 16);
+    const int Nc = a.Nc - col_lo < NTN * 16 ? a.Nc - col_lo : NTN * 16;
+    const float* __restrict__ Y = a.y + col_lo;
     const long long c0 = (long long)chunk * a.chunk;
     const long long c1 = c0 + a.chunk < a.B ? c0 + a.chunk : a.B;
+    // The slab's current values are requested before the chunk's last slice is multiplied and added after it: the read half
+    // of the read-modify-write is in flight during those MFMAs instead of being waited for after them (measured at cfg4:
+    // 29 of 82 us per call went to the flush).
+    // C rows 16 mt + 4 g + r (natural row order of the accumulator), column 16 t + n: four consecutive floats per lane.
+    const int mt = rblock * 4 + wave;
+    const int r0 = 16 * mt + 4 * g;
+    float* C = a.slabs + (long long)chunk * a.slab_stride + (long long)col_lo * a.M;
+    const bool rows4 = r0 + 3 < a.M;
+    f32x4 prev[NTN];
+    const int voff = n * a.M + r0;
+    auto load_prev = [&]() {
+#pragma unroll
+        for (int t = 0; t < NTN; ++t) {
+            const int col = 16 * t + n;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (col < Nc && 16 * mt < a.M) {
+                const float* cp = (C + (long long)(16 * t) * a.M) + voff;   // uniform tile base + one per-lane offset
+                if (rows4) { const f32x4u q = *reinterpret_cast<const f32x4u*>(cp); v = f32x4{q[0], q[1], q[2], q[3]}; }
+                else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) if (r0 + r < a.M) v[r] = cp[r];
+                }
+            }
+            prev[t] = v;
+        }
+    };
     f32x4 acc[NTN];
 #pragma unroll
     for (int t = 0; t < NTN; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float ry[4][RY], rx[4];
-    // wave w fetches the samples of k-step u = w of a slice (sample 4 w + q, q = lane group it will serve): lane l takes rows
-    // l, l + 64, ... of Y and row row0 + l of X
-    auto fetch = [&](long long s) {
+    // A slice in flight: component u of yv[i] / xv is row (lane + 64 i) of sample 4 u + wave - the four k-steps one reader lane
+    // wants, in the four registers of ONE 16-byte LDS write (lane-linear, conflict-free).  (Fetching by k-step instead - sample
+    // 4 w + q - scattered them as 4-byte writes with an 8-way bank conflict.)
+    struct Slice { f32x4 yv[RY]; f32x4 xv; };
+    Slice slA, slB;
+    // f32 MFMAs and VALU instructions share the issue slot, so the loop carries no per-lane address arithmetic: a sample's
+    // column starts at a wave-uniform address (scalar registers, 32-bit offsets from the chunk's first sample), the lane's
+    // row offsets are loop invariants, and rows past the operand's end are clamped instead of masked (they only reach rows /
+    // columns of C that are never stored).
+    unsigned yoff[RY];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const long long gs = s + 4 * wave + q;
-            const bool sv = gs < c1;
-            const float* yp = a.y + (sv ? gs : 0) * (long long)a.ldy;
-#pragma unroll
-            for (int i = 0; i < RY; ++i) { const int r = lane + 64 * i; ry[q][i] = (sv && r < a.Nc) ? yp[r] : 0.f; }
-            rx[q] = (sv && row0 + lane < a.M) ? a.x[(sv ? gs : 0) * (long long)a.ldx + row0 + lane] : 0.f;
-        }
+    for (int i = 0; i < RY; ++i) { const int r = lane + 64 * i; yoff[i] = 4u * (unsigned)(r < Nc ? r : Nc - 1); }   // bytes
+    const unsigned xoff = 4u * (unsigned)(row0 + lane < a.M ? row0 + lane : a.M - 1);
+    const float* __restrict__ Yc = Y + c0 * (long long)a.ldy;     // wave-uniform bases of the chunk
+    const float* __restrict__ Xc = a.x + c0 * (long long)a.ldx;
+    const int nrem = (int)(c1 - c0);
+    // (buffer loads: lane byte offset in a VGPR that never changes, the sample's byte offset in an SGPR - no address VALU)
+    const __amdgpu_buffer_rsrc_t rY = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Yc), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Xc), 0, 0x7fffffff, 0x00020000);
+    auto at = [](__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+        return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
     };
-    auto park = [&](int buf) {
+    auto fetch = [&](int s, Slice& sl) {                          // s: first sample of the slice, relative to c0
+        if (s + 16 <= nrem) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+            for (int u = 0; u < 4; ++u) {
+                const unsigned ys = 4u * (unsigned)(s + 4 * u + wave) * (unsigned)a.ldy;   // wave-uniform byte offsets
+                const unsigned xs = 4u * (unsigned)(s + 4 * u + wave) * (unsigned)a.ldx;
 #pragma unroll
-            for (int i = 0; i < RY; ++i) {
-                const int r = lane + 64 * i;                        // row 16 t + nn of Y
-                if (r < NTN * 16) smem[buf * (YS + XS) + (((r >> 4) * 4 + q) * 16 + (r & 15)) * 4 + wave] = ry[q][i];
+                for (int i = 0; i < RY; ++i) sl.yv[i][u] = at(rY, yoff[i], ys);
+                sl.xv[u] = at(rX, xoff, xs);
             }
-            smem[buf * (YS + XS) + YS + (((lane >> 4) * 4 + q) * 16 + (lane & 15)) * 4 + wave] = rx[q];
+        } else {                                                  // ragged end of the batch, or past the chunk: zeros
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int gs = s + 4 * u + wave;
+                const bool sv = gs < nrem;
+                const unsigned ys = 4u * (unsigned)(sv ? gs : 0) * (unsigned)a.ldy;
+                const unsigned xs = 4u * (unsigned)(sv ? gs : 0) * (unsigned)a.ldx;
+#pragma unroll
+                for (int i = 0; i < RY; ++i) sl.yv[i][u] = sv ? at(rY, yoff[i], ys) : 0.f;
+                sl.xv[u] = sv ? at(rX, xoff, xs) : 0.f;
+            }
         }
     };
-    fetch(c0);
-    park(0);
-    __syncthreads();
-    int buf = 0;
-    for (long long s = c0; s < c1; s += 16) {
-        const bool more = s + 16 < c1;
-        if (more) fetch(s + 16);
+    auto park = [&](int buf, const Slice& sl) {
+        f32x4* yb = reinterpret_cast<f32x4*>(smem + buf * (YS + XS));
+        f32x4* xb = reinterpret_cast<f32x4*>(smem + buf * (YS + XS) + YS);
+#pragma unroll
+        for (int i = 0; i < RY; ++i) {
+            const int r = lane + 64 * i;                            // row 16 t + nn of Y -> [t][g' = wave][nn][u]
+            if (r < NTN * 16) yb[((r >> 4) * 4 + wave) * 16 + (r & 15)] = sl.yv[i];
+        }
+        xb[((lane >> 4) * 4 + wave) * 16 + (lane & 15)] = sl.xv;
+    };
+    auto multiply = [&](int buf) {
         const f32x4* y4 = reinterpret_cast<const f32x4*>(smem + buf * (YS + XS)) + lane;
         const f32x4 av = reinterpret_cast<const f32x4*>(smem + buf * (YS + XS) + YS)[wave * 64 + lane];
         f32x4 bv[NTN];
 #pragma unroll
         for (int t = 0; t < NTN; ++t) bv[t] = y4[t * 64];
+        // k-step outermost: consecutive MFMAs go to different accumulators (no dependent back-to-back pairs)
 #pragma unroll
         for (int u = 0; u < 4; ++u)
 #pragma unroll
             for (int t = 0; t < NTN; ++t) acc[t] = mfma4(av[u], bv[t][u], acc[t]);
-        if (more) park(buf ^ 1);
+    };
+    // Slices of 16 samples.  A slice is fetched TWO slices ahead of its use (two register sets, alternating) and parked in
+    // the LDS buffer the previous multiply has just left: ~2 slice times of memory latency are covered.
+    fetch(0, slA);
+    park(0, slA);
+    fetch(16, slA);
+    fetch(32, slB);
+    __syncthreads();
+    for (int s = 0; s < nrem; s += 32) {
+        if (s + 16 >= nrem) { load_prev(); multiply(0); break; }
+        multiply(0);                                  // slice s; set A holds s + 16, set B s + 32
+        park(1, slA);
+        fetch(s + 48, slA);
         __syncthreads();
-        buf ^= 1;
+        if (s + 32 >= nrem) { load_prev(); multiply(1); break; }
+        multiply(1);                                  // slice s + 16; set B holds s + 32, set A s + 48
+        park(0, slB);
+        fetch(s + 64, slB);
+        __syncthreads();
     }
-    // C rows 16 mt + 4 g + r (natural row order of the accumulator), column 16 t + n
-    const int mt = blockIdx.x * 4 + wave;
     if (16 * mt >= a.M) return;
-    float* C = a.slabs + (long long)chunk * a.slab_stride;
-    const int r0 = 16 * mt + 4 * g;
 #pragma unroll
     for (int t = 0; t < NTN; ++t) {
         const int col = 16 * t + n;
-        if (col >= a.Nc) continue;
-        float* cp = C + (long long)col * a.M + r0;
+        if (col >= Nc) continue;
+        float* cp = (C + (long long)(16 * t) * a.M) + voff;
+        const f32x4 v = prev[t] + acc[t];
+        if (rows4) *reinterpret_cast<f32x4u*>(cp) = f32x4u{v[0], v[1], v[2], v[3]};
+        else {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) if (r0 + r < a.M) cp[r] += acc[t][r];
+            for (int r = 0; r < 4; ++r) if (r0 + r < a.M) cp[r] = v[r];
+        }
     }
 }
 
-bool lg_wgrad_supported(int M, int Nc) { return M >= 1 && Nc >= 1 && Nc <= 16 * 33; }
+bool lg_wgrad_supported(int M, int Nc) { return M >= 1 && Nc >= 1 && Nc <= 16 * 9 * 65535; }
 
 // number of sample chunks (= slabs) a wgrad call uses for this (M, B): enough workgroups to fill the chip, chunks of >= 64 samples
 int lg_wgrad_chunks(int M, long long B, int num_cus, long long* chunk_out) {
     const int RB = ((M + 15) / 16 + 3) / 4;
-    long long want = (2LL * num_cus + RB - 1) / RB;   // two workgroups per CU (measured at cfg4: 82 us per call; one per CU: 88 us)
+    const int groups = ((M + 1 + 15) / 16 + 8) / 9;   // column groups of a square layer's cotangent (lg_wgrad)
+    static const int per_cu = [] { const char* v = getenv("CNF_LG_WGRAD_PER_CU"); return v && *v ? atoi(v) : 2; }();
+    long long want = ((long long)per_cu * num_cus + RB * groups - 1) / (RB * groups);   // workgroups per CU
     if (want < 1) want = 1;
     long long chunk = (B + want - 1) / want;
     chunk = (chunk + 63) / 64 * 64;
@@ -393,26 +689,17 @@ hipError_t lg_wgrad(float* slabs, long long slab_stride, long long chunk, int nc
     a.slabs = slabs; a.slab_stride = slab_stride; a.x = x; a.y = y; a.B = B; a.chunk = chunk;
     a.M = M; a.Nc = Nc; a.ldx = ldx; a.ldy = ldy;
     const int MT = (M + 15) / 16, NTN = (Nc + 15) / 16;
-    const dim3 grid((unsigned)((MT + 3) / 4), (unsigned)nchunks);
-    const int ntn = NTN <= 1 ? 1 : NTN <= 3 ? 3 : NTN <= 5 ? 5 : NTN <= 9 ? 9 : NTN <= 17 ? 17 : 33;
-    const int lds = 2 * (ntn * 256 + 4 * 256) * (int)sizeof(float);          // <= 2 * 37 * 1 KB = 74 KB
-    if (lds > 64 * 1024) {
-        static DeviceOnce once;
-        int dev = 0;
-        hipError_t e0 = hipGetDevice(&dev);
-        if (e0 != hipSuccess) return e0;
-        if (!once.done(dev)) {
-            hipError_t e = hipFuncSetAttribute((const void*)lg_wgrad_kernel<33>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e != hipSuccess) return e;
-            once.set(dev);
-        }
-    }
+    // strips wider than 9 tiles go to several workgroups (column groups of 9 tiles): 36 accumulator registers leave room for
+    // the two-slice prefetch and three waves per SIMD; a 17-tile strip has neither (measured at cfg4: 67 us vs NN us per call)
+    const int groups = (NTN + 8) / 9;
+    a.nchunks = nchunks; a.rblocks = (MT + 3) / 4; a.groups = groups;
+    const dim3 grid((unsigned)(((nchunks + 7) / 8) * 8 * a.rblocks * a.groups));
+    const int ntn = NTN <= 1 ? 1 : NTN <= 3 ? 3 : NTN <= 5 ? 5 : 9;
+    const int lds = 2 * (ntn * 256 + 4 * 256) * (int)sizeof(float);          // <= 2 * 13 * 1 KB = 26 KB
     if (NTN <= 1) hipLaunchKernelGGL(lg_wgrad_kernel<1>, grid, dim3(256), lds, st, a);
     else if (NTN <= 3) hipLaunchKernelGGL(lg_wgrad_kernel<3>, grid, dim3(256), lds, st, a);
     else if (NTN <= 5) hipLaunchKernelGGL(lg_wgrad_kernel<5>, grid, dim3(256), lds, st, a);
-    else if (NTN <= 9) hipLaunchKernelGGL(lg_wgrad_kernel<9>, grid, dim3(256), lds, st, a);
-    else if (NTN <= 17) hipLaunchKernelGGL(lg_wgrad_kernel<17>, grid, dim3(256), lds, st, a);
-    else hipLaunchKernelGGL(lg_wgrad_kernel<33>, grid, dim3(256), lds, st, a);
+    else hipLaunchKernelGGL(lg_wgrad_kernel<9>, grid, dim3(256), lds, st, a);
     return hipGetLastError();
 }
 
