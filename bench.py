@@ -174,13 +174,18 @@ def _cpu_leg_c_port(oc, spec, alg, p, xs, eps, ys, target_s):
     rate0 = B0 * NSTEPS / dt0
     Bs = int(min(xs.shape[1], max(B0, rate0 * target_s / NSTEPS)))
     Bs = max(B0, Bs // (64 * nt) * (64 * nt))
+    # a fast host finishes the whole batch in well under the target: repeat the solve until the sample is ~target_s long
+    reps = int(max(1, min(64, round(rate0 * target_s / (Bs * NSTEPS)))))
+    run = lambda: oc.inference_fixed(spec, p, xs[:, :Bs], 0.0, 1.0, NSTEPS, alg, eps[:, :Bs],
+                                     None if ys is None else ys[:, :Bs], nthreads=nt)
+    run()                                                    # page in the sample, spin the threads up
     t = time.perf_counter()
-    oc.inference_fixed(spec, p, xs[:, :Bs], 0.0, 1.0, NSTEPS, alg, eps[:, :Bs],
-                       None if ys is None else ys[:, :Bs], nthreads=nt)
+    for _ in range(reps):
+        run()
     dt = time.perf_counter() - t
     oc.set_fast_tanh(False)
-    return dict(value=Bs * NSTEPS / dt, threads=nt, isa=oc.isa() if hasattr(oc, "isa") else "avx2",
-                sample=f"{Bs} of the workload's columns, one full {NSTEPS}-step solve, {dt:.1f} s, "
+    return dict(value=reps * Bs * NSTEPS / dt, threads=nt, isa=oc.isa() if hasattr(oc, "isa") else "avx2",
+                sample=f"{Bs} of the workload's columns, {reps} full {NSTEPS}-step solve(s), {dt:.1f} s, "
                        f"oracle/cnf_oracle.c (gcc -O3 -fopenmp, tanh_fast)")
 
 
