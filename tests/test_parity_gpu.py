@@ -203,6 +203,84 @@ def test_split_bf16_is_as_accurate_as_f32_on_stiffer_weights(pkg, oracles):
     assert np.max(np.abs(b16 - f32)) < 1e-3
 
 
+def _forward_error_bound(spec, p, u, t, c_hidden, c_edge, c_act):
+    """First-order, entry-wise bound on the error of zdot = MLP([z; t]) evaluated in finite precision, computed in
+    float64: every product W_l h_{l-1} carries an error <= c_l (|W_l| |h_{l-1}|), every activation value a relative
+    error <= c_act, and an error e in a layer's input reaches its output as <= |W_l| e (|tanh'| <= 1).  Returns
+    (zdot64, bound), both (D, B)."""
+    w_off, b_off, _ = spec.param_offsets()
+    D, B = spec.D, u.shape[1]
+    h = np.vstack([u[:D].astype(np.float64), np.full((1, B), float(t))])
+    err = np.zeros_like(h)
+    N = len(spec.acts)
+    for l in range(N):
+        fin, fout = spec.widths[l], spec.widths[l + 1]
+        W = np.asarray(p[w_off[l]:w_off[l] + fin * fout], dtype=np.float64).reshape(fin, fout).T
+        b = np.asarray(p[b_off[l]:b_off[l] + fout], dtype=np.float64)[:, None]
+        pre = W @ h + b
+        c = c_hidden if 0 < l < N - 1 else c_edge
+        e_pre = np.abs(W) @ err + c * (np.abs(W) @ np.abs(h) + np.abs(b))
+        if spec.acts[l] == 1:
+            h = np.tanh(pre)
+            err = e_pre + c_act * np.abs(h)          # |tanh'| <= 1
+        else:
+            h, err = pre, e_pre
+    return h, err
+
+
+def test_split_bf16_error_bound_holds_on_adversarial_products(pkg, oracles):
+    """the six-term split-bf16 product obeys |err| <= (4 u + gamma_{6K}) sum_k |a_k| |b_k| (u = 2^-24, K the
+    contraction length; gamma_n = n u / (1 - n u)) under ANY accumulation order inside v_mfma_f32_16x16x32_bf16, against
+    gamma_K for the exact-f32 chain.  Adversarial hidden layers: rows of alternating +-c weights on nearly equal
+    activations, so a pre-activation is a difference of terms 10^2..10^3 times its own size and the products' rounding
+    errors are not masked - across magnitudes c, with weights on both sides of bf16's rounding boundaries.  Both
+    arithmetics must stay inside their bound against the float64 evaluation; the measured constants are asserted too:
+    the split arithmetic's observed error must be within 4x of the exact kernel's (it is usually smaller: bf16 x bf16
+    products are exact and the instruction rounds less often than a 64-term fma chain)."""
+    o64, _ = oracles
+    spec = o64.make_spec(nvars=8, hidden=[64, 64, 64])
+    w_off, b_off, n = spec.param_offsets()
+    u24 = 2.0 ** -24
+    gam = lambda k: k * u24 / (1 - k * u24)
+    worst = {}
+    for trial, cmag in enumerate((1.0, 8.0, 40.0, 200.0, 1000.0, -0.05)):
+        rng = np.random.default_rng(50 + trial)
+        B = 256
+        p, xs, eps, _ = o64.synth_inputs(spec, B, 900 + trial, bias_scale=0.3)
+        p = p.astype(np.float32)
+        # layer 1: nearly equal activations around 0.5 (small weights, common bias), closer together the larger c is, so that
+        # layer 2's pre-activations - differences of 64 terms of size c / 2 - stay O(1) and nothing saturates
+        exact_inputs = cmag < 0          # last case: layer 1 saturated to exactly +-1, so the product's inputs carry no error
+        cmag = abs(cmag)
+        jit = min(0.01, 0.08 / cmag)
+        p[w_off[0]:b_off[0]] *= 2.0 * jit
+        p[b_off[0]:b_off[0] + 64] = 0.55 + jit * rng.standard_normal(64)
+        if exact_inputs:
+            p[b_off[0]:b_off[0] + 64] = 15.0 * rng.choice([1.0, -1.0], 64)
+        # layer 2 (hidden, split arithmetic): alternating-sign rows, magnitudes jittered in the last bf16-visible bits and below;
+        # layer 3 (hidden, split arithmetic): benign Glorot weights; layer 4 as drawn
+        W = (cmag * (1.0 + 2.0 ** -9 * rng.integers(-7, 8, (64, 64)) + 1e-6 * rng.standard_normal((64, 64)))
+             * np.where(np.arange(64)[None, :] % 2 == 0, 1.0, -1.0) * rng.choice([1.0, -1.0], (64, 1)))
+        p[w_off[1]:w_off[1] + 64 * 64] = W.T.reshape(-1).astype(np.float32)
+        p[b_off[1]:b_off[1] + 64] = 0.05 * rng.standard_normal(64)
+        u = np.vstack([xs.astype(np.float32), np.zeros((3, B), np.float32)])
+        t = 0.37
+        ref, _ = _forward_error_bound(spec, p, u, t, 0.0, 0.0, 0.0)
+        res = {}
+        for name, icnf, c_hidden in (("f32", make_icnf(pkg, spec, 1, 40, path=2), gam(64 + 1)),
+                                     ("bf16x6", make_icnf_bf16x6(pkg, spec, 1, 40), 4 * u24 + gam(6 * 64 + 1))):
+            du = pkg.augmented_f(icnf, mode_of(pkg, spec), dev(u), dev(p), t, dev(eps), None).cpu().numpy().astype(np.float64)
+            _, bound = _forward_error_bound(spec, p, u, t, c_hidden, gam(64 + 1), 8 * u24)
+            err = np.abs(du[:8] - ref)
+            assert np.all(err <= bound + 1e-30), (name, cmag, float((err / bound).max()))
+            res[name] = (float(err.max()), float((err / bound).max()))
+        worst[-cmag if exact_inputs else cmag] = res
+        # the cancellation is real: the bound is far above float32 resolution of the result itself
+        assert res["bf16x6"][0] <= 4.0 * res["f32"][0] + 1e-7, (cmag, res)
+    assert all(np.isfinite(v[k][0]) for v in worst.values() for k in v), worst
+    print("split-bf16 vs f32, (max |err|, max err / bound) per weight magnitude:", worst)
+
+
 def test_split_bf16_is_refused_where_not_implemented(pkg, oracles):
     o64, _ = oracles
     spec = o64.make_spec(nvars=32, hidden=[256, 256, 256])
