@@ -30,7 +30,7 @@ COMM_ID_BYTES = 128
 DTYPE_F32, DTYPE_F64 = 0, 1
 
 EXPORTS = ("cnf_version", "cnf_last_error", "cnf_create", "cnf_destroy", "cnf_set_params",
-           "cnf_kernel_path", "cnf_repack_on_device", "cnf_aug_f", "cnf_integrate_fixed", "cnf_inference_fixed",
+           "cnf_kernel_path", "cnf_solve_controller", "cnf_repack_on_device", "cnf_aug_f", "cnf_integrate_fixed", "cnf_inference_fixed",
            "cnf_loss_sums", "cnf_loss_grad_fixed", "cnf_loss_grad_grid", "cnf_grad_path", "cnf_step_embedded", "cnf_assemble_u0",
            "cnf_epilogue", "cnf_vcabm_begin", "cnf_vcabm_attempt", "cnf_vcabm_accept", "cnf_vcabm_state", "cnf_solve_vcabm", "cnf_solve_tsit5", "cnf_loss_grad_adaptive",
            "cnf_integrate_fixed_dt", "cnf_inference_fixed_dt",
@@ -90,6 +90,7 @@ def load():
     lib.cnf_destroy.argtypes = [vp]
     lib.cnf_set_params.argtypes = [vp, fp, C.c_size_t, szp, szp, C.c_int, vp]
     lib.cnf_kernel_path.argtypes = [vp]
+    lib.cnf_solve_controller.argtypes = [vp]
     lib.cnf_repack_on_device.argtypes = [vp]
     lib.cnf_grad_path.argtypes = [vp]
     lib.cnf_loss_grad_grid.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_float), fp, fp, fp, C.c_int64,

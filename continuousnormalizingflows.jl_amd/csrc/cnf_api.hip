@@ -213,6 +213,7 @@ int cnf_destroy(cnf_handle* h) {
 }
 
 int cnf_kernel_path(const cnf_handle* h) { return h ? h->path : CNF_ERR_INVALID; }
+int cnf_solve_controller(const cnf_handle* h) { return (h && h->last_controller >= 0) ? h->last_controller : CNF_ERR_INVALID; }
 
 int cnf_repack_on_device(const cnf_handle* h) {
     if (!h) return CNF_ERR_INVALID;

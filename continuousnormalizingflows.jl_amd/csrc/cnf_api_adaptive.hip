@@ -248,12 +248,53 @@ int cnf_solve_vcabm(cnf_handle* h, float t0, float t1, const float* u0, const fl
                     float abstol, float reltol, float dt_init, int maxiters, float* u1, cnf_solve_stats* stats,
                     float* dts_out, int32_t* orders_out, int32_t record_cap, void* stream) {
     if (stats) *stats = cnf_solve_stats{};
-    int rc = cnf_vcabm_begin(h, t0, u0, eps, ys, B, stream);
+    int rc = api_check_call(h, eps, ys, B, "cnf_solve_vcabm");
     if (rc) return rc;
     if (!(abstol >= 0.f) || !(reltol >= 0.f) || (abstol == 0.f && reltol == 0.f))
         return fail(CNF_ERR_INVALID, "cnf_solve_vcabm: tolerances must be non-negative and not both zero");
-    if (B > 0 && !u1) return fail(CNF_ERR_INVALID, "cnf_solve_vcabm: null u1");
+    if (B > 0 && (!u0 || !u1)) return fail(CNF_ERR_INVALID, "cnf_solve_vcabm: null u0/u1");
     if (maxiters < 1) return fail(CNF_ERR_INVALID, "cnf_solve_vcabm: maxiters >= 1 required");
+    if (B > 0 && t1 != t0 && h->path == CNF_PATH_MFMA && h->plan && B <= mfma_vcabm_capacity(h->plan)) {
+        // the batch fits the chip's wave slots: passes, error norms and the step / order policy in one launch
+        h->last_controller = 1;
+        DeviceGuard g(h->cfg.device_id);
+        hipStream_t st = (hipStream_t)stream;
+        const int dts_cap = maxiters < (1 << 20) ? maxiters : (1 << 20);
+        const size_t need = mfma_adaptive_scratch_bytes(B, dts_cap);
+        if (need > h->dc_bytes) {
+            if (h->dc_buf) HIP_TRY(hipFree(h->dc_buf));
+            h->dc_buf = nullptr; h->dc_bytes = 0;
+            HIP_TRY(hipMalloc(&h->dc_buf, need));
+            h->dc_bytes = need;
+        }
+        SolveArgs a{};
+        a.u0 = u0; a.eps = eps; a.ys = ys; a.B = B; a.nsteps = 1; a.alg = CNF_ALG_TSIT5; a.t0 = t0; a.t1 = t1;
+        a.u_out = u1; a.nvars = h->cfg.nvars; a.reg_aug = 0;
+        int *stats_dev = nullptr, *orders_dev = nullptr;
+        float* dts_dev = nullptr;
+        const hipError_t le = mfma_solve_vcabm(h->plan, h->packed_dev, a, abstol, reltol, dt_init, maxiters, h->dc_buf, dts_cap,
+                                               &stats_dev, &dts_dev, &orders_dev, st);
+        if (le != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(CNF_ERR_HIP, std::string("cnf_solve_vcabm: launch of the device-resident solve failed: ") + hipGetErrorString(le));
+        }
+        int hs[8];
+        HIP_TRY(hipMemcpyAsync(hs, stats_dev, sizeof(hs), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        if (stats) { stats->naccept = hs[0]; stats->nreject = hs[1]; stats->nf = hs[2]; stats->max_order = hs[4]; }
+        if (hs[3] == 1) return fail(CNF_ERR_INVALID, "cnf_solve_vcabm: non-finite error estimate (unstable dynamics)");
+        if (hs[3] == 2) return fail(CNF_ERR_INVALID, "cnf_solve_vcabm: maxiters reached");
+        if (hs[3] == 3) return fail(CNF_ERR_INVALID, "cnf_solve_vcabm: non-finite state or dynamics at t0 (no initial step)");
+        const int na = std::min(std::min(hs[0], dts_cap), (int)record_cap);
+        if (na > 0 && dts_out) HIP_TRY(hipMemcpyAsync(dts_out, dts_dev, (size_t)na * sizeof(float), hipMemcpyDeviceToHost, st));
+        if (na > 0 && orders_out) HIP_TRY(hipMemcpyAsync(orders_out, orders_dev, (size_t)na * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        if (na > 0 && (dts_out || orders_out)) HIP_TRY(hipStreamSynchronize(st));
+        h->vc_B = -1;   // the step-wise entry points have no state from this solve
+        return CNF_OK;
+    }
+    h->last_controller = 0;
+    rc = cnf_vcabm_begin(h, t0, u0, eps, ys, B, stream);
+    if (rc) return rc;
     int nf = B > 0 ? 1 : 0, naccept = 0, nreject = 0, max_order = 0;
     const double span = std::fabs((double)t1 - (double)t0), tdir = t1 >= t0 ? 1.0 : -1.0;
     if (B == 0 || span == 0.0) {
@@ -383,6 +424,7 @@ int cnf::api_solve_tsit5(cnf_handle* h, float t0, float t1, const float* u0, con
     }
     if (h->path == CNF_PATH_MFMA && h->plan && B <= mfma_adaptive_capacity(h->plan)) {
         // the batch fits the chip's wave slots: the whole solve, step controller included, in one launch
+        h->last_controller = 1;
         const int dts_cap = maxiters < (1 << 20) ? maxiters : (1 << 20);
         const size_t need = mfma_adaptive_scratch_bytes(B, dts_cap);
         if (need > h->dc_bytes) {
@@ -402,10 +444,10 @@ int cnf::api_solve_tsit5(cnf_handle* h, float t0, float t1, const float* u0, con
             return fail(CNF_ERR_HIP, std::string("cnf_solve_tsit5: launch of the device-controlled solve failed: ") + hipGetErrorString(le));
         }
         // stats and the first accepted steps sit side by side: one copy serves the usual solve
-        constexpr int kInline = 60;
-        int host[4 + kInline];
+        constexpr int kInline = 56;
+        int host[8 + kInline];
         const int first = dts_cap < kInline ? dts_cap : kInline;
-        HIP_TRY(hipMemcpyAsync(host, stats_dev, (4 + first) * sizeof(int), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(host, stats_dev, (8 + first) * sizeof(int), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         if (stats) { stats->naccept = host[0]; stats->nreject = host[1]; stats->nf = host[2]; stats->max_order = 5; }
         if (host[3] == 1) return fail(CNF_ERR_INVALID, "cnf_solve_tsit5: non-finite error estimate (unstable dynamics)");
@@ -414,7 +456,7 @@ int cnf::api_solve_tsit5(cnf_handle* h, float t0, float t1, const float* u0, con
         if (steps) {
             const int na = host[0] < dts_cap ? host[0] : dts_cap;
             std::vector<float> all((size_t)na);
-            const float* inl = reinterpret_cast<const float*>(host + 4);
+            const float* inl = reinterpret_cast<const float*>(host + 8);
             for (int i = 0; i < na && i < first; ++i) all[i] = inl[i];
             if (na > first) {
                 HIP_TRY(hipMemcpyAsync(all.data() + first, dts_dev + first, (size_t)(na - first) * sizeof(float), hipMemcpyDeviceToHost, st));
@@ -424,6 +466,7 @@ int cnf::api_solve_tsit5(cnf_handle* h, float t0, float t1, const float* u0, con
         }
         return CNF_OK;
     }
+    h->last_controller = 0;
     rc = api_ensure_adaptive_buf(h, B);
     if (rc) return rc;
     if (!h->vc_partial) HIP_TRY(hipMalloc((void**)&h->vc_partial, (vcabm_partial_doubles() + 8) * sizeof(double)));

@@ -95,6 +95,7 @@ struct cnf_handle {
     int vc_avail = 0, vc_m = 0;          // differences Phi*_j(n-1) the last accepted step stored; those the pending attempt stores
     double vc_hist[cnf::kVcSlots + 1] = {};   // signed sizes of the accepted steps, newest first
     double vc_t = 0.0, vc_dt = 0.0;
+    int last_controller = -1;            // cnf_solve_controller
     void* dc_buf = nullptr;              // device-controlled adaptive solve: slots, counter, stats, accepted steps
     size_t dc_bytes = 0;
     float* ad_buf = nullptr;             // adaptive Tsit5 whole solve (cnf_solve_tsit5): two states + two derivative scratch vectors

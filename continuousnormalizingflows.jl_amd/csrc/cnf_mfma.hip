@@ -36,6 +36,8 @@ struct MfmaPlan {
     LaunchFn launch;
     LaunchAdaptFn launch_adapt;   // adaptive Tsit5 with the step controller on the device, or null
     int adapt_per_cu = -1;        // workgroups of that kernel per compute unit (occupancy query, cached)
+    LaunchAdaptFn launch_vcabm;   // the default solver VCABM on the device (256-thread workgroups), or null
+    int vcabm_per_cu = -1;
     cnf_config cfg;
     int nthreads;
     int num_cus;
@@ -116,6 +118,7 @@ MfmaPlan* mfma_plan_create(const cnf_config& c) {
         p->lay = MfmaLayout(HT, L, zr_inst, CR, true);
         p->launch = nullptr;
         p->launch_adapt = nullptr;
+        p->launch_vcabm = nullptr;
         p->cfg = c;
         p->nthreads = 256;
         p->num_cus = 0;
@@ -138,6 +141,7 @@ MfmaPlan* mfma_plan_create(const cnf_config& c) {
         p->lay = MfmaLayout(HT, L, in.ZR, in.CR, p->with_bwd, in.arith);
         p->launch = in.fn;
         p->launch_adapt = in.fn_adapt;
+        p->launch_vcabm = in.fn_vcabm;
         p->cfg = c;
         p->nthreads = in.nthreads;
         p->num_cus = 0;
@@ -439,16 +443,13 @@ int64_t mfma_adaptive_capacity(MfmaPlan* p) {
     return (int64_t)p->num_cus * p->adapt_per_cu * (p->nthreads / 64) * 16;
 }
 
-// scratch of one device-controlled solve: [2][2][ntiles] doubles, then counter + 4 stats (8 ints), then dts_cap floats
+// scratch of one device-controlled solve: [2][3][ntiles] doubles, then counter (4 ints) + 8 stats, dts_cap floats, dts_cap orders
 size_t mfma_adaptive_scratch_bytes(int64_t B, int dts_cap) {
     const size_t ntiles = (size_t)((B + 15) / 16);
-    return 4 * ntiles * sizeof(double) + 8 * sizeof(int) + (size_t)dts_cap * sizeof(float);
+    return 6 * ntiles * sizeof(double) + 12 * sizeof(int) + (size_t)dts_cap * (sizeof(float) + sizeof(int));
 }
 
-hipError_t mfma_solve_adaptive(MfmaPlan* p, const float* packed_dev, const SolveArgs& s, float abstol, float reltol, float dt_init,
-                               int maxiters, void* scratch, int dts_cap, int** stats_dev, float** dts_dev, hipStream_t st) {
-    const long long ntiles = (s.B + 15) / 16;
-    KArgs a{};
+static void fill_kargs_adaptive(const MfmaPlan* p, const float* packed_dev, const SolveArgs& s, KArgs& a) {
     a.packed = packed_dev;
     a.u0 = s.u0; a.eps = s.eps; a.ys = s.ys; a.u_out = s.u_out;
     a.B = s.B; a.nsteps = 1; a.t0 = s.t0; a.dt = 0.f;
@@ -456,6 +457,28 @@ hipError_t mfma_solve_adaptive(MfmaPlan* p, const float* packed_dev, const Solve
     a.reg_z = p->cfg.reg_z; a.reg_j = p->cfg.reg_j; a.reg_aug = s.reg_aug; a.autonomous = p->cfg.autonomous;
     a.exact = p->cfg.mode == CNF_MODE_EXACT;
     a.K = p->KP;
+}
+
+static hipError_t fill_aargs_scratch(AArgs& q, void* scratch, long long ntiles, int dts_cap, int** stats_dev, float** dts_dev,
+                                     int** orders_dev, hipStream_t st) {
+    char* base = (char*)scratch;
+    q.slots = (double*)base;
+    int* ints = (int*)(base + 6 * (size_t)ntiles * sizeof(double));
+    q.counter = (unsigned*)ints;
+    q.stats = ints + 4;
+    q.dts = (float*)(ints + 12);
+    q.orders = ints + 12 + dts_cap;
+    *stats_dev = q.stats;
+    *dts_dev = q.dts;
+    if (orders_dev) *orders_dev = q.orders;
+    return hipMemsetAsync(ints, 0, 12 * sizeof(int), st);
+}
+
+hipError_t mfma_solve_adaptive(MfmaPlan* p, const float* packed_dev, const SolveArgs& s, float abstol, float reltol, float dt_init,
+                               int maxiters, void* scratch, int dts_cap, int** stats_dev, float** dts_dev, hipStream_t st) {
+    const long long ntiles = (s.B + 15) / 16;
+    KArgs a{};
+    fill_kargs_adaptive(p, packed_dev, s, a);
     AArgs q{};
     q.abstol = abstol; q.reltol = reltol; q.t1 = s.t1; q.dt_init = dt_init; q.maxiters = maxiters; q.dts_cap = dts_cap;
     const Tableau T = make_tableau(CNF_ALG_TSIT5);
@@ -471,15 +494,7 @@ hipError_t mfma_solve_adaptive(MfmaPlan* p, const float* packed_dev, const Solve
             q.acol[j][i] = row < 6 ? T.a[row][j] : (row == 6 ? T.b[j] : 0.f);
         }
     }
-    char* base = (char*)scratch;
-    q.slots = (double*)base;
-    int* ints = (int*)(base + 4 * (size_t)ntiles * sizeof(double));
-    q.counter = (unsigned*)ints;
-    q.stats = ints + 4;
-    q.dts = (float*)(ints + 8);
-    *stats_dev = q.stats;
-    *dts_dev = q.dts;
-    hipError_t e = hipMemsetAsync(ints, 0, 8 * sizeof(int), st);
+    hipError_t e = fill_aargs_scratch(q, scratch, ntiles, dts_cap, stats_dev, dts_dev, nullptr, st);
     if (e != hipSuccess) return e;
     const int wpb = p->nthreads / 64;
     const int lds = p->lay.lds_total * (int)sizeof(float);
@@ -488,6 +503,41 @@ hipError_t mfma_solve_adaptive(MfmaPlan* p, const float* packed_dev, const Solve
     long long nblocks = ntiles < cap ? ntiles : cap;
     if (nblocks * wpb < ntiles) return hipErrorInvalidValue;
     return p->launch_adapt(a, q, lds, (int)nblocks, st, nullptr);
+}
+
+// Largest batch the device-resident VCABM kernel takes (256-thread workgroups, one tile per wave), 0 if the plan has none.
+int64_t mfma_vcabm_capacity(MfmaPlan* p) {
+    if (!p || p->kind != 0 || !p->launch_vcabm) return 0;
+    if (env_int("CNF_DEVICE_CONTROLLER", 1) == 0) return 0;
+    if (p->num_cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+        p->num_cus = prop.multiProcessorCount;
+    }
+    if (p->vcabm_per_cu < 0) {
+        int occ = 0;
+        const hipError_t e = p->launch_vcabm(KArgs{}, AArgs{}, p->lay.lds_total * (int)sizeof(float), 0, nullptr, &occ);
+        if (e != hipSuccess) { (void)hipGetLastError(); occ = 0; }
+        p->vcabm_per_cu = occ;
+    }
+    return (int64_t)p->num_cus * p->vcabm_per_cu * 4 * 16;
+}
+
+hipError_t mfma_solve_vcabm(MfmaPlan* p, const float* packed_dev, const SolveArgs& s, float abstol, float reltol, float dt_init,
+                            int maxiters, void* scratch, int dts_cap, int** stats_dev, float** dts_dev, int** orders_dev, hipStream_t st) {
+    const long long ntiles = (s.B + 15) / 16;
+    KArgs a{};
+    fill_kargs_adaptive(p, packed_dev, s, a);
+    AArgs q{};
+    q.abstol = abstol; q.reltol = reltol; q.t1 = s.t1; q.dt_init = dt_init; q.maxiters = maxiters; q.dts_cap = dts_cap;
+    hipError_t e = fill_aargs_scratch(q, scratch, ntiles, dts_cap, stats_dev, dts_dev, orders_dev, st);
+    if (e != hipSuccess) return e;
+    const int lds = p->lay.lds_total * (int)sizeof(float);
+    const long long cap = (long long)p->num_cus * (p->vcabm_per_cu > 0 ? p->vcabm_per_cu : 0);
+    long long nblocks = ntiles < cap ? ntiles : cap;
+    if (nblocks * 4 < ntiles) return hipErrorInvalidValue;
+    return p->launch_vcabm(a, q, lds, (int)nblocks, st, nullptr);
 }
 
 }  // namespace cnf

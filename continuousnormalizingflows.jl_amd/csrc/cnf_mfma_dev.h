@@ -42,10 +42,11 @@ struct AArgs {
     float b[6];         // weights of the 5th-order solution
     float bt[7];        // b - bhat: the embedded error estimate
     float c[7];
-    double* slots;      // [2 (round parity)][2][workgroups]
+    double* slots;      // [2 (round parity)][3][workgroups]
     unsigned* counter;  // arrivals, zeroed on the stream before the launch
     float* dts;         // accepted steps, dts_cap entries
-    int* stats;         // naccept, nreject, nf, status (0 ok, 1 non-finite error estimate, 2 maxiters, 3 no initial step)
+    int* stats;         // naccept, nreject, nf, status (0 ok, 1 non-finite error estimate, 2 maxiters, 3 no initial step), max order
+    int* orders;        // VCABM: order of every accepted step, dts_cap entries
 };
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {

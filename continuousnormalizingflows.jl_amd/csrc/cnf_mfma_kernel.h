@@ -656,42 +656,50 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
     return v;
 }
 
-// Grid-wide sums of two per-lane values over all tiles, in two levels: the waves of a workgroup meet in LDS, wave 0 of every
+// Grid-wide sums of three per-lane values over all tiles, in two levels: the waves of a workgroup meet in LDS, wave 0 of every
 // workgroup publishes the workgroup's partial, arrives at the counter, waits for the other workgroups, and adds the
-// partials up in workgroup order.  Every wave ends with the same two doubles (same partials, same order).  `round` counts
+// partials up in workgroup order.  Every wave ends with the same three doubles (same partials, same order).  `round` counts
 // the calls (the same in every wave): its parity picks the slot set, its value the arrival target.  One poller per
 // workgroup: with a poller per wave the 1024 pollers of a 16 K batch cost ~70 us per sum on one counter word.
 // (Spare waves of a workgroup have left the kernel; the hardware barrier counts the waves still running.)
-__device__ __forceinline__ void grid_sum2(const AArgs& q, unsigned& round, int wave, int nact, int lane, double& v0, double& v1) {
-    __shared__ double wg_part[2][16];
-    __shared__ double wg_tot[2];
+__device__ __forceinline__ void grid_sum3(const AArgs& q, unsigned& round, int wave, int nact, int lane, double& v0, double& v1, double& v2) {
+    __shared__ double wg_part[3][16];
+    __shared__ double wg_tot[3];
     v0 = wave_sum_f64(v0);
     v1 = wave_sum_f64(v1);
-    if (lane == 0) { wg_part[0][wave] = v0; wg_part[1][wave] = v1; }
+    v2 = wave_sum_f64(v2);
+    if (lane == 0) { wg_part[0][wave] = v0; wg_part[1][wave] = v1; wg_part[2][wave] = v2; }
     __syncthreads();
     if (wave == 0) {
         const unsigned nb = gridDim.x;
-        double* sl = q.slots + (size_t)(round & 1u) * 2u * (size_t)nb;
+        double* sl = q.slots + (size_t)(round & 1u) * 3u * (size_t)nb;
         if (lane == 0) {
-            double a0 = 0.0, a1 = 0.0;
-            for (int w = 0; w < nact; ++w) { a0 += wg_part[0][w]; a1 += wg_part[1][w]; }
+            double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+            for (int w = 0; w < nact; ++w) { a0 += wg_part[0][w]; a1 += wg_part[1][w]; a2 += wg_part[2][w]; }
             sl[blockIdx.x] = a0;
             sl[nb + blockIdx.x] = a1;
+            sl[2 * nb + blockIdx.x] = a2;
             __hip_atomic_fetch_add(q.counter, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
             const unsigned target = (round + 1u) * nb;
             while (__hip_atomic_load(q.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        double a0 = 0.0, a1 = 0.0;
-        for (unsigned i = lane; i < nb; i += 64) { a0 += sl[i]; a1 += sl[nb + i]; }
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+        for (unsigned i = lane; i < nb; i += 64) { a0 += sl[i]; a1 += sl[nb + i]; a2 += sl[2 * nb + i]; }
         a0 = wave_sum_f64(a0);
         a1 = wave_sum_f64(a1);
-        if (lane == 0) { wg_tot[0] = a0; wg_tot[1] = a1; }
+        a2 = wave_sum_f64(a2);
+        if (lane == 0) { wg_tot[0] = a0; wg_tot[1] = a1; wg_tot[2] = a2; }
     }
     __syncthreads();
     v0 = wg_tot[0];
     v1 = wg_tot[1];
+    v2 = wg_tot[2];
     ++round;
+}
+__device__ __forceinline__ void grid_sum2(const AArgs& q, unsigned& round, int wave, int nact, int lane, double& v0, double& v1) {
+    double v2 = 0.0;
+    grid_sum3(q, round, wave, nact, lane, v0, v1, v2);
 }
 
 template <int HT, int L, int ZR, int CR, int ACT, int ENGINE, int KP, int PRE, int NTHREADS, int ARITH = 0>
@@ -924,7 +932,7 @@ mfma_adaptive_kernel(KArgs a, AArgs q) {
         for (int s = 0; s < ZR; ++s) { const int f = 4 * s + g; if (f < D) a.u_out[smp * S + f] = z[s]; }
         if (g == 0) { a.u_out[smp * S + D] = la; a.u_out[smp * S + D + 1] = ea; a.u_out[smp * S + D + 2] = na; }
     }
-    if (tile == 0 && lane == 0) { q.stats[0] = naccept; q.stats[1] = nreject; q.stats[2] = nf; q.stats[3] = status; }
+    if (tile == 0 && lane == 0) { q.stats[0] = naccept; q.stats[1] = nreject; q.stats[2] = nf; q.stats[3] = status; q.stats[4] = 5; }
 }
 
 // occ_out != null: only report how many workgroups of this kernel one compute unit holds (registers and LDS considered)
@@ -944,6 +952,324 @@ inline hipError_t launch_adapt_inst(const KArgs& a, const AArgs& q, int lds_byte
     }
     if (occ_out) return hipOccupancyMaxActiveBlocksPerMultiprocessor(occ_out, (const void*)kern, NTHREADS, (size_t)lds_bytes);
     // cooperative launch: the runtime refuses a grid whose workgroups cannot all be resident, which the grid-wide sums need
+    KArgs ka = a;
+    AArgs qa = q;
+    void* params[2] = {&ka, &qa};
+    return hipLaunchCooperativeKernel((const void*)kern, dim3(nblocks), dim3(NTHREADS), params, (unsigned)lds_bytes, st);
+}
+
+// ---- the reference's default solver VCABM (variable-step variable-order Adams PECE) in one launch ----
+// The device passes of cnf_vcabm.hip and the host policy of cnf_api_adaptive.hip::cnf_solve_vcabm, per tile in registers:
+// a lane keeps its rows of u_n, f_n and the thirteen modified divided differences Phi*_j(n-1) (HNW I, III.5).  Nothing is
+// double-buffered: Phi*_j(n) = beta_j Phi_j(n) is a short chain from f_n and Phi*(n-1), recomputed where the corrector and
+// the order-raising estimate need it and committed in place when a step is accepted - a rejected attempt has stored
+// nothing.  The step coefficients (beta, g, the error constants) are computed in double by every wave from the step-size
+// history, through a per-wave LDS scratch (run-time indexed loops).  One dynamics call site serves all four kinds of
+// evaluation (f at t0, Hairer's Euler point, the predictor, the corrected state).  256-thread workgroups: one wave per SIMD,
+// the whole register file (the difference table alone is 13 x (ZR + 3) registers).
+template <int HT, int L, int ZR, int CR, int ACT, int ENGINE, int KP, int PRE, int NTHREADS, int ARITH = 0>
+__global__ void __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(1, (NTHREADS + 255) / 256)))
+mfma_vcabm_kernel(KArgs a, AArgs q) {
+    constexpr MfmaLayout LAY(HT, L, ZR, CR, ENGINE == ENG_VJP, ARITH);
+    constexpr int NR = ZR + 3;        // rows of the state a lane holds: ZR of z, then dlogp, E, n
+    constexpr int KS = 13;            // Phi*_0 .. Phi*_12
+    constexpr int WPB = NTHREADS / 64;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __shared__ double sc_hist[WPB][KS + 1];   // signed sizes of the accepted steps, newest first
+    __shared__ double sc_dts[WPB][KS + 3], sc_cq[WPB][KS + 3], sc_gd[WPB][KS + 1], sc_gs[WPB][KS + 2];
+    __shared__ float sc_beta[WPB][KS], sc_g[WPB][KS + 1];
+    {
+        const f32x4* src = reinterpret_cast<const f32x4*>(a.packed);
+        f32x4* dst = reinterpret_cast<f32x4*>(smem);
+        for (int i = threadIdx.x; i < LAY.lds_total / 4; i += NTHREADS) dst[i] = src[i];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int g = lane >> 4, n = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long long ntiles = (a.B + 15) / 16;
+    const long long tile = (long long)blockIdx.x + (long long)gridDim.x * wave;
+    if (tile >= ntiles) return;
+    const int nact = (int)((ntiles - 1 - (long long)blockIdx.x) / (long long)gridDim.x) + 1 < WPB
+                         ? (int)((ntiles - 1 - (long long)blockIdx.x) / (long long)gridDim.x) + 1 : WPB;
+    const int D = a.D, S = D + 3, C = a.C;
+    const int K = KP == 1 ? 1 : a.K;
+    const int Kd = K * D;
+    const bool reg_z = a.reg_z, reg_j = a.reg_j, autonomous = a.autonomous, exact = a.exact;
+    const long long smp = tile * 16 + n;
+    const bool valid = smp < a.B;
+    const long long sc = valid ? smp : a.B - 1;
+    float U[NR], F[NR], PS[KS][NR], Pp[NR], UN[NR], X[NR];
+    float eps[KP][ZR], y[CR > 0 ? CR : 1];
+    bool live[NR];                    // the entries of the S x B state this lane answers for in a norm
+#pragma unroll
+    for (int s = 0; s < ZR; ++s) {
+        const int f = 4 * s + g;
+        U[s] = f < D ? a.u0[sc * S + f] : 0.f;
+        live[s] = valid && f < D;
+#pragma unroll
+        for (int p = 0; p < KP; ++p) eps[p][s] = (f < D && p < K && a.eps) ? a.eps[sc * Kd + p * D + f] : 0.f;
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) { U[ZR + r] = a.u0[sc * S + D + r]; live[ZR + r] = valid && g == 0; }
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        F[r] = Pp[r] = UN[r] = X[r] = 0.f;
+#pragma unroll
+        for (int j = 0; j < KS; ++j) PS[j][r] = 0.f;
+    }
+    y[0] = 0.f;
+    if constexpr (CR > 0) {
+#pragma unroll
+        for (int s = 0; s < CR; ++s) { const int f = 4 * s + g; y[s] = f < C ? a.ys[sc * C + f] : 0.f; }
+    }
+    f32x4 pre_c[HT], pre_q[HT];
+#pragma unroll
+    for (int mt = 0; mt < HT; ++mt) pre_c[mt] = pre_q[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (PRE >= 1) gemm_tiles<HT, ZR>(smem + LAY.bN, lane, RegIn<ZR>{eps[0]}, pre_c);
+    if constexpr (PRE >= 2) {
+        gemm_tiles<HT, ZR>(smem + LAY.f1z, lane, RegIn<ZR>{eps[0]}, pre_q);
+        if constexpr (ACT == CNF_ACT_TANH_PRESCALED) {
+#pragma unroll
+            for (int mt = 0; mt < HT; ++mt) pre_q[mt] *= (1.f / kTanhPrescale);
+        }
+    }
+    double* hist = sc_hist[wave];
+    double *dtsv = sc_dts[wave], *cq = sc_cq[wave], *gd = sc_gd[wave], *gs = sc_gs[wave];
+    float *beta = sc_beta[wave], *gg = sc_g[wave];
+    for (int i = 0; i <= KS; ++i) hist[i] = 0.0;
+
+    const double t0 = (double)a.t0, t1 = (double)q.t1;
+    const double span = fabs(t1 - t0), tdir = t1 >= t0 ? 1.0 : -1.0, ntot = (double)S * (double)a.B;
+    const float abstol = q.abstol, reltol = q.reltol;
+    const double gamma = 0.9, qmin = 0.2, qmax = 10.0;
+    double tpol = t0, tvc = t0, dt = 0.0, hstep = 0.0, h0 = 0.0, d1 = 0.0, eest = 0.0;
+    float dtf = 0.f, tcur = a.t0, e0 = 0.f, e1 = 0.f, e2 = 0.f;
+    int k = 1, m = 0, step = 1, nhist = 0, it = 0, naccept = 0, nreject = 0, nf = 0, status = 0, max_order = 0;
+    bool last = false, select = false, lower = false, want_up = false;
+    int phase = 0;                    // 0: f(u0, t0); 1: Hairer's Euler point; 2: predictor; 3: corrected state
+    unsigned round = 0;
+    float zs[ZR], zd[ZR], ld = 0.f, ed = 0.f, nd = 0.f;
+#pragma unroll
+    for (int s = 0; s < ZR; ++s) { zs[s] = U[s]; zd[s] = 0.f; }
+
+    // scaled squared norm pieces: r = v / (abstol + |ref| reltol)
+    auto sk_of = [&](float ref) { return fmaf(fabsf(ref), reltol, abstol); };
+
+    for (;;) {
+        int opaque = 0;
+        asm volatile("" : "+v"(opaque));
+        dyn_eval<HT, L, ZR, CR, ACT, ENGINE, KP, PRE, ARITH>(smem + opaque, a.packed + opaque, lane, tcur, autonomous, reg_z, reg_j, exact,
+                                                      D, K, zs, y, eps, pre_c, pre_q, zd, ld, ed, nd);
+        ++nf;
+#pragma unroll
+        for (int s = 0; s < ZR; ++s) X[s] = zd[s];
+        X[ZR] = ld; X[ZR + 1] = ed; X[ZR + 2] = nd;
+        bool begin = false;
+        if (phase == 0) {
+#pragma unroll
+            for (int r = 0; r < NR; ++r) F[r] = X[r];
+            if (q.dt_init != 0.f) {
+                dt = fmin((double)fabsf(q.dt_init), span);
+                begin = true;
+            } else {   // ode_determine_initdt, RMS norm over all S B entries; exponent 1 / (current order) = 1 at the start
+                double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+#pragma unroll
+                for (int r = 0; r < NR; ++r) {
+                    if (live[r]) {
+                        const float sk = sk_of(U[r]), r0 = U[r] / sk, r1 = F[r] / sk;
+                        s0 += (double)r0 * (double)r0; s1 += (double)r1 * (double)r1;
+                    }
+                }
+                grid_sum3(q, round, wave, nact, lane, s0, s1, s2);
+                const double d0 = sqrt(s0 / ntot);
+                d1 = sqrt(s1 / ntot);
+                h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
+                h0 = fmin(h0, span);
+                const float hf = (float)(tdir * h0);
+#pragma unroll
+                for (int s = 0; s < ZR; ++s) zs[s] = fmaf(hf, F[s], U[s]);
+                tcur = (float)(t0 + tdir * h0);
+                phase = 1;
+                continue;
+            }
+        } else if (phase == 1) {
+            double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                if (live[r]) { const float rr = (X[r] - F[r]) / sk_of(U[r]); s0 += (double)rr * (double)rr; }
+            }
+            grid_sum3(q, round, wave, nact, lane, s0, s1, s2);
+            const double d2 = sqrt(s0 / ntot) / h0, dmax = fmax(d1, d2);
+            const double h1 = dmax <= 1e-15 ? fmax(1e-6, h0 * 1e-3) : pow(10.0, -(2.0 + log10(dmax)) / 1.0);
+            dt = fmin(fmin(100.0 * h0, h1), span);
+            if (!(isfinite(dt) && dt > 0.0)) { status = 3; break; }
+            begin = true;
+        } else if (phase == 2) {
+            // C: Phi_j(n+1) from d = f(p, t + dt); u_new = p + dt g_k Phi_k(n+1); error sums of orders k, k-1, k-2
+            double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+            const float dg = dtf * gg[k];
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                float phiF = F[r], psn = phiF, phi = X[r], phim1 = 0.f, phim2 = 0.f;
+#pragma unroll
+                for (int j = 1; j < KS; ++j) {
+                    if (j <= k) {
+                        phim2 = phim1; phim1 = phi; phi -= psn;                   // psn = Phi*_{j-1}(n)
+                        if (j < m) { phiF -= PS[j - 1][r]; psn = beta[j] * phiF; }
+                    }
+                }
+                UN[r] = fmaf(dg, phi, Pp[r]);
+                if (live[r]) {
+                    const float inv = 1.f / fmaf(fmaxf(fabsf(U[r]), fabsf(UN[r])), reltol, abstol);
+                    const float r0 = e0 * phi * inv, r1 = e1 * phim1 * inv, r2 = e2 * phim2 * inv;
+                    s0 += (double)r0 * (double)r0; s1 += (double)r1 * (double)r1; s2 += (double)r2 * (double)r2;
+                }
+            }
+            grid_sum3(q, round, wave, nact, lane, s0, s1, s2);
+            eest = sqrt(s0 / ntot);
+            if (!isfinite(eest)) { status = 1; break; }
+            if (eest > 1.0) {   // reject: same state, smaller step, same order (nothing was stored)
+                ++nreject;
+                dt = hstep / fmax(1.0 / qmax, fmin(1.0 / qmin, pow(eest, 1.0 / (double)(k + 1)) / gamma));
+                begin = true;
+            } else {
+                select = step > 4 && k >= 3;
+                lower = select && fmax(sqrt(s2 / ntot), sqrt(s1 / ntot)) <= eest;
+                want_up = select && !lower && k < 12;
+#pragma unroll
+                for (int s = 0; s < ZR; ++s) zs[s] = UN[s];
+                tcur = (float)(tvc + (double)dtf);
+                phase = 3;
+                continue;
+            }
+        } else {
+            // accepted: X = f(u_new, t + dt).  Order k + 1 estimate, then commit Phi*(n), u, f, the history
+            int knew = k;
+            if (!select) knew = k + 1 < 3 ? k + 1 : 3;
+            else if (lower) knew = k - 1;
+            else if (want_up) {
+                gs[0] = 1.0;
+                for (int j = 1; j <= k + 1; ++j) {
+                    double acc = 0.0;
+                    for (int i = 0; i < j; ++i) acc += gs[i] / (double)(j - i + 1);
+                    gs[j] = -acc;
+                }
+                const float eu = (float)((double)dtf * gs[k + 1]);
+                double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+#pragma unroll
+                for (int r = 0; r < NR; ++r) {
+                    float phiF = F[r], psn = phiF, phi = X[r];
+#pragma unroll
+                    for (int j = 0; j < KS; ++j) {
+                        if (j <= k) {
+                            phi -= psn;                                          // psn = Phi*_j(n)
+                            if (j + 1 < m) { phiF -= PS[j][r]; psn = beta[j + 1] * phiF; }
+                        }
+                    }
+                    if (live[r]) {
+                        const float rr = eu * phi / fmaf(fmaxf(fabsf(U[r]), fabsf(UN[r])), reltol, abstol);
+                        s0 += (double)rr * (double)rr;
+                    }
+                }
+                grid_sum3(q, round, wave, nact, lane, s0, s1, s2);
+                if (sqrt(s0 / ntot) < eest) { knew = k + 1; eest = 1.0; }
+            }
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                float phi = F[r], keep = PS[0][r];
+                PS[0][r] = phi;
+#pragma unroll
+                for (int j = 1; j < KS; ++j) {
+                    if (j < m) { phi -= keep; keep = PS[j][r]; PS[j][r] = beta[j] * phi; }
+                }
+                U[r] = UN[r];
+                F[r] = X[r];
+            }
+            for (int i = KS; i > 0; --i) hist[i] = hist[i - 1];
+            hist[0] = (double)dtf;
+            tvc += (double)dtf;
+            nhist += 1;
+            const double qq = eest == 0.0 ? 1.0 / qmax : fmax(1.0 / qmax, fmin(1.0 / qmin, pow(eest, 1.0 / (double)(knew + 1)) / gamma));
+            tpol = last ? t1 : tpol + tdir * hstep;
+            if (tile == 0 && lane == 0 && naccept < q.dts_cap) { q.dts[naccept] = dtf; q.orders[naccept] = k; }
+            ++naccept;
+            if (k > max_order) max_order = k;
+            k = knew; ++step;
+            dt = hstep / qq;
+            begin = true;
+        }
+        if (begin) {
+            if (fabs(t1 - tpol) <= 1e-7 * fmax(1.0, span)) break;
+            if (it >= q.maxiters) { status = 2; break; }
+            ++it;
+            last = dt >= fabs(t1 - tpol) * (1.0 - 1e-6);
+            hstep = last ? fabs(t1 - tpol) : dt;      // tstop: never step over t1
+            dtf = (float)(tdir * hstep);
+            m = k + 1 < nhist + 1 ? k + 1 : nhist + 1;
+            // step sizes newest first, the candidate in front
+            dtsv[0] = (double)dtf;
+            for (int i = 0; i <= KS; ++i) dtsv[i + 1] = hist[i];
+            double bb = 1.0, num = 0.0, den = 0.0;
+            beta[0] = 1.f;
+            for (int j = 1; j < m; ++j) { num += dtsv[j - 1]; den += dtsv[j]; bb *= num / den; beta[j] = (float)bb; }
+            const int ng = k + 1;
+            gd[0] = 1.0;
+            for (int qi = 1; qi <= ng; ++qi) cq[qi - 1] = 1.0 / ((double)qi * (double)(qi + 1));
+            double xi = dtsv[0];
+            for (int j = 1; j < ng; ++j) {
+                if (j > 1) {
+                    xi += dtsv[j - 1];
+                    for (int qi = 0; qi < ng - j + 1; ++qi) cq[qi] = cq[qi] - cq[qi + 1] * (double)dtf / xi;
+                }
+                gd[j] = cq[0];
+            }
+            for (int j = 0; j < ng; ++j) gg[j] = (float)gd[j];
+            e0 = (float)((double)dtf * (gd[k] - gd[k - 1]));
+            e1 = k >= 2 ? (float)((double)dtf * (gd[k - 1] - gd[k - 2])) : 0.f;
+            e2 = k >= 3 ? (float)((double)dtf * (gd[k - 2] - gd[k - 3])) : 0.f;
+            // P: p = u + dt sum_{j<k} g_j Phi*_j(n)
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                float phi = F[r], acc = gg[0] * phi;
+#pragma unroll
+                for (int j = 1; j < KS; ++j) {
+                    if (j < m) {
+                        phi -= PS[j - 1][r];
+                        const float sj = beta[j] * phi;
+                        if (j < k) acc = fmaf(gg[j], sj, acc);
+                    }
+                }
+                Pp[r] = fmaf(dtf, acc, U[r]);
+            }
+#pragma unroll
+            for (int s = 0; s < ZR; ++s) zs[s] = Pp[s];
+            tcur = (float)(tvc + (double)dtf);
+            phase = 2;
+        }
+    }
+
+    if (valid && a.u_out) {
+#pragma unroll
+        for (int s = 0; s < ZR; ++s) { const int f = 4 * s + g; if (f < D) a.u_out[smp * S + f] = U[s]; }
+        if (g == 0) { a.u_out[smp * S + D] = U[ZR]; a.u_out[smp * S + D + 1] = U[ZR + 1]; a.u_out[smp * S + D + 2] = U[ZR + 2]; }
+    }
+    if (tile == 0 && lane == 0) { q.stats[0] = naccept; q.stats[1] = nreject; q.stats[2] = nf; q.stats[3] = status; q.stats[4] = max_order; }
+}
+
+template <int HT, int L, int ZR, int CR, int ACT, int ENGINE, int KP, int PRE, int NTHREADS, int ARITH = 0>
+inline hipError_t launch_vcabm_inst(const KArgs& a, const AArgs& q, int lds_bytes, int nblocks, hipStream_t st, int* occ_out) {
+    auto kern = mfma_vcabm_kernel<HT, L, ZR, CR, ACT, ENGINE, KP, PRE, NTHREADS, ARITH>;
+    static DeviceOnce once;
+    int dev = 0;
+    hipError_t e0 = hipGetDevice(&dev);
+    if (e0 != hipSuccess) return e0;
+    if (!once.done(dev)) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        if (e != hipSuccess) return e;
+        once.set(dev);
+    }
+    if (occ_out) return hipOccupancyMaxActiveBlocksPerMultiprocessor(occ_out, (const void*)kern, NTHREADS, (size_t)lds_bytes);
     KArgs ka = a;
     AArgs qa = q;
     void* params[2] = {&ka, &qa};
@@ -979,17 +1305,18 @@ struct Inst {
     int nthreads;
     int arith; // CNF_ARITH_*
     LaunchAdaptFn fn_adapt;   // adaptive Tsit5 with the device-side step controller, or null (host loop)
+    LaunchAdaptFn fn_vcabm;   // the default solver VCABM with policy and passes on the device (256-thread workgroups), or null
 };
 
 #define MFMA_INST(HT, L, ZR, CR, ACT, ENG, KP, PRE, NT) \
-    Inst { HT, L, ZR, CR, ACT, ENG, KP, PRE, &launch_inst<HT, L, ZR, CR, ACT, ENG, KP, PRE, NT>, NT, 0, nullptr }
+    Inst { HT, L, ZR, CR, ACT, ENG, KP, PRE, &launch_inst<HT, L, ZR, CR, ACT, ENG, KP, PRE, NT>, NT, 0, nullptr, nullptr }
 #define MFMA_INST_BF16X6(HT, L, ZR, CR, ACT, ENG, KP, PRE, NT) \
-    Inst { HT, L, ZR, CR, ACT, ENG, KP, PRE, &launch_inst<HT, L, ZR, CR, ACT, ENG, KP, PRE, NT, 1>, NT, 1, nullptr }
+    Inst { HT, L, ZR, CR, ACT, ENG, KP, PRE, &launch_inst<HT, L, ZR, CR, ACT, ENG, KP, PRE, NT, 1>, NT, 1, nullptr, nullptr }
 #ifdef CNF_WITH_DEVICE_CONTROLLER
 // the same instance with its device-controlled adaptive twin
 #define MFMA_INST_AD(HT, L, ZR, CR, ACT, ENG, KP, PRE, NT) \
     Inst { HT, L, ZR, CR, ACT, ENG, KP, PRE, &launch_inst<HT, L, ZR, CR, ACT, ENG, KP, PRE, NT>, NT, 0, \
-           &launch_adapt_inst<HT, L, ZR, CR, ACT, ENG, KP, PRE, NT> }
+           &launch_adapt_inst<HT, L, ZR, CR, ACT, ENG, KP, PRE, NT>, &launch_vcabm_inst<HT, L, ZR, CR, ACT, ENG, KP, PRE, 256> }
 #endif
 
 // generic zero-padded instances (cnf_mfma_generic.hip): D <= 16 and C <= 16 or C = 0

@@ -68,7 +68,8 @@ def _adaptive_integrate(icnf, h, u0: torch.Tensor, t0: float, t1: float,
         out = torch.empty_like(u0)
         _solve_errors(lambda: lib.cnf_solve_tsit5(h.ptr, t0, t1, _ptr(u0), _ptr(e), _ptr(y), B, abstol, reltol,
                                                   float(kw["dt"]) if "dt" in kw else 0.0, maxiters, _ptr(out), C.byref(ss), dts, cap, st))
-        stats.update(naccept=ss.naccept, nreject=ss.nreject, nf=ss.nf, dts=[float(v) for v in dts[:min(ss.naccept, cap)]])
+        stats.update(naccept=ss.naccept, nreject=ss.nreject, nf=ss.nf, dts=[float(v) for v in dts[:min(ss.naccept, cap)]],
+                     controller="device" if lib.cnf_solve_controller(h.ptr) == 1 else "host")
         return out
 
     def allsum(vals):
@@ -179,7 +180,8 @@ def _vcabm_integrate(icnf, h, u0: torch.Tensor, t0: float, t1: float,
         _solve_errors(lambda: lib.cnf_solve_vcabm(h.ptr, t0, t1, _ptr(u0), _ptr(e), _ptr(y), B, abstol, reltol,
                                                   float(kw["dt"]) if "dt" in kw else 0.0, maxiters, _ptr(out), C.byref(ss), dts, orders, cap, st))
         m = min(ss.naccept, cap)
-        stats.update(naccept=ss.naccept, nreject=ss.nreject, nf=ss.nf, dts=[float(v) for v in dts[:m]], orders=[int(v) for v in orders[:m]])
+        stats.update(naccept=ss.naccept, nreject=ss.nreject, nf=ss.nf, dts=[float(v) for v in dts[:m]], orders=[int(v) for v in orders[:m]],
+                     controller="device" if lib.cnf_solve_controller(h.ptr) == 1 else "host")
         return out
     if B:
         _lib.check(lib.cnf_vcabm_begin(h.ptr, t0, _ptr(u0), _ptr(e), _ptr(y), B, st))

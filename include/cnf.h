@@ -33,7 +33,7 @@
  *   training                 cnf_loss_grad_fixed, cnf_loss_grad_grid, cnf_loss_grad_adaptive  (dloss/dps, optionally dloss/dxs)
  *   column shards (RCCL)     cnf_comm_unique_id, cnf_comm_init, cnf_comm_init_all, cnf_comm_destroy, cnf_comm_rank, cnf_comm_size,
  *                            cnf_allreduce_loss (the mean in `loss`), cnf_allreduce_sum, cnf_comm_group_start / _end
- *   introspection            cnf_version, cnf_last_error, cnf_kernel_path, cnf_grad_path, cnf_repack_on_device
+ *   introspection            cnf_version, cnf_last_error, cnf_kernel_path, cnf_grad_path, cnf_repack_on_device, cnf_solve_controller
  */
 #ifndef CNF_H
 #define CNF_H
@@ -191,14 +191,21 @@ int cnf_solve_vcabm(cnf_handle* h, float t0, float t1, const float* u0, const fl
                     float* dts_out, int32_t* orders_out, int32_t record_cap, void* stream);
 
 /* Adaptive Tsit5 (OrdinaryDiffEq's PI controller: beta1 = 7/50, beta2 = 2/25, gamma = 9/10, q in [1/5, 10]; Hairer's initial
- * step unless dt_init != 0) from t0 to t1 in one call - cnf_step_embedded attempts driven inside the library; arguments as
- * cnf_solve_vcabm (max_order is reported as 5).  Single process; synchronises `stream`. */
+ * step unless dt_init != 0) from t0 to t1 in one call - cnf_step_embedded attempts driven inside the library, or, for batches
+ * that fit the chip's wave slots on a fused kernel, the whole solve with the controller on the device in one launch
+ * (cnf_solve_controller); arguments as cnf_solve_vcabm (max_order is reported as 5).  Single process; synchronises `stream`. */
 int cnf_solve_tsit5(cnf_handle* h, float t0, float t1, const float* u0, const float* eps, const float* ys, int64_t B,
                     float abstol, float reltol, float dt_init, int maxiters, float* u1, cnf_solve_stats* stats,
                     float* dts_out, int32_t record_cap, void* stream);
 
 /* Which kernel family the handle resolved to (CNF_PATH_SIMT, CNF_PATH_MFMA or CNF_PATH_LAYERED). */
 int cnf_kernel_path(const cnf_handle* h);
+
+/* Where the step (and order) policy of the handle's last cnf_solve_vcabm / cnf_solve_tsit5 / cnf_loss_grad_adaptive ran:
+ * 1 = on the device, the whole solve in one cooperative launch (fused per-wave kernels, batches of at most one 16-sample tile
+ * per resident wave); 0 = the host loop over per-attempt launches (any other case, or CNF_DEVICE_CONTROLLER=0 in the
+ * environment); CNF_ERR_INVALID before the first such call. */
+int cnf_solve_controller(const cnf_handle* h);
 
 /* How the last cnf_set_params repacked: 1 = gather kernels on the device (fused path, f32 images),
  * 0 = on the host (SIMT parameter copy, split-bf16 images).  CNF_ERR_NO_PARAMS before the first call. */

@@ -1962,6 +1962,7 @@ def test_device_side_step_controller_is_the_host_loop(kw, B, tol, dt0, pkg, orac
     dev_st, host_st = res["1"][2], res["0"][2]
     natt = dev_st["naccept"] + dev_st["nreject"]
     assert dev_st["nf"] == (1 if dt0 is not None else 2) + 6 * natt, dev_st                 # the one-launch path ran
+    assert dev_st["controller"] == "device" and host_st["controller"] == "host"
     auto = bool(kw.get("autonomous", False))
     slack = 0 if (auto or tol >= 1e-4) else 2
     assert abs(dev_st["naccept"] - host_st["naccept"]) <= slack and abs(dev_st["nreject"] - host_st["nreject"]) <= slack, (dev_st, host_st)
@@ -1981,6 +1982,42 @@ def test_device_side_step_controller_is_the_host_loop(kw, B, tol, dt0, pkg, orac
         uref, sref = o64.integrate_adaptive_tsit5(spec, p, u0, 0.0, 1.0, tol, tol, eps, ys, dt0=dt0)
         assert abs(dev_st["naccept"] - sref["naccept"]) <= (1 if tol >= 1e-4 else 3)
         assert np.max(np.abs(res["1"][1].cpu().numpy() - uref)) < 2e-4
+
+
+@pytest.mark.parametrize("kw,B,tol,dt0", [
+    (dict(nvars=8, hidden=[64, 64, 64], reg_z=True, reg_j=True), 48, 1e-5, 2.0 ** -7),      # cfg2's kernel, RNODE rows live
+    (dict(nvars=8, hidden=[64, 64, 64]), 1000, 1e-4, None),                                 # ragged last tile, Hairer's initial step
+    (dict(nvars=1, hidden=[8, 8], act=2), 1024, 1e-4, None),                                # the reference's benchmark net (nvariables = 1)
+    (dict(nvars=5, naug=2, hidden=[24, 24], act=2), 16, 1e-7, None),                        # orders up to 8+, one tile
+    (dict(nvars=3, hidden=[24, 24], act=2, mode=2), 200, 1e-5, None),                       # exact trace (TestMode)
+    (dict(nvars=8, hidden=[64, 64, 64], autonomous=True), 16379, 1e-4, None),               # every wave slot of the 256-thread kernel
+])
+def test_default_solver_on_the_device_is_the_host_policy(kw, B, tol, dt0, pkg, oracles, monkeypatch):
+    """The reference's default solver VCABM in ONE launch (mfma_vcabm_kernel: predictor, corrector and order-raising passes per
+    tile in registers, grid-wide error norms, the step-size and order policy in every wave) against cnf_solve_vcabm's host loop
+    over the device passes of cnf_vcabm.hip: the same evaluations at the same arguments and the same float32 arithmetic per
+    element, so the same orders, accepted / rejected counts and step sizes (the error norms are summed in a different order, in
+    double: decisions could differ only on a knife edge) and states equal to a few ulp."""
+    o64, _ = oracles
+    spec = o64.make_spec(**kw)
+    p, xs, eps, ys = o64.synth_inputs(spec, B, 6, bias_scale=0.3)
+    p = (p * 2.0).astype(np.float32)
+    icnf = make_icnf(pkg, spec, 1, 1)
+    icnf.sol_kwargs = dict(reltol=tol, abstol=tol, **({} if dt0 is None else dict(dt=dt0)))   # alg defaults to VCABM()
+    res = {}
+    for ctl in ("1", "0"):
+        monkeypatch.setenv("CNF_DEVICE_CONTROLLER", ctl)
+        logp, regs, u1 = run_inference(pkg, icnf, spec, p, xs, eps, ys, return_state=True)
+        res[ctl] = (logp, u1, dict(icnf.last_solve_stats))
+    d, h = res["1"][2], res["0"][2]
+    assert d["controller"] == "device" and h["controller"] == "host" and d["alg_used"] == "VCABM"
+    assert d["orders"] == h["orders"] and (d["naccept"], d["nreject"], d["nf"]) == (h["naccept"], h["nreject"], h["nf"]), (d, h)
+    assert d["naccept"] >= 5 and np.allclose(d["dts"], h["dts"], rtol=1e-6), (d["dts"], h["dts"])
+    scale = max(1.0, float(res["0"][1].abs().max()))
+    assert float((res["1"][1] - res["0"][1]).abs().max()) < 5e-6 * scale
+    assert float((res["1"][0] - res["0"][0]).abs().max()) < 5e-6 * max(1.0, float(res["0"][0].abs().max()))
+    if tol <= 1e-7:
+        assert max(d["orders"]) >= 6, d["orders"]
 
 
 def test_device_side_step_controller_reports_failures(pkg, oracles):
