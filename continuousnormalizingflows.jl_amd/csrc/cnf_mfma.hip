@@ -180,7 +180,7 @@ MfmaPlan* mfma_plan_create(const cnf_config& c) {
             return best;
         };
         int ng = 0, ng8 = 0, ngp = 0;
-        const Inst* gen = mfma_generic_insts(&ng);
+        const Inst* gen = c.acts[0] == CNF_ACT_SOFTPLUS ? mfma_generic_softplus_insts(&ng) : mfma_generic_insts(&ng);
         const Inst* gen8 = mfma_generic_zr8_insts(&ng8);
         const Inst* a4 = pick(gen, ng, false);
         const Inst* a8 = pick(gen8, ng8, false);

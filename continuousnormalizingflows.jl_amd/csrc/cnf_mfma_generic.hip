@@ -9,6 +9,13 @@
 #define CNF_WITH_DEVICE_CONTROLLER 1
 #include "cnf_mfma_kernel.h"
 
+// This file is compiled twice - tanh here, softplus through cnf_mfma_generic_softplus.hip - so that the two halves of the
+// table (each instance with its adaptive-Tsit5 and VCABM twins) build in parallel.
+#ifndef GEN_ACTIVATION
+#define GEN_ACTIVATION CNF_ACT_TANH
+#define GEN_TABLE_FN mfma_generic_insts
+#endif
+
 namespace cnf {
 
 // VJP instances of tanh nets run the pre-scaled tanh (forward images carry the -2 log2 e factor)
@@ -18,21 +25,17 @@ namespace cnf {
     MFMA_INST(HT, L, 4, 4, VJP_ACT(ACT), ENG_VJP, 1, 1, NT),   \
     MFMA_INST_AD(HT, L, 4, 0, ACT, ENG_TAN, 1, 0, NT),            \
     MFMA_INST(HT, L, 4, 4, ACT, ENG_TAN, 1, 0, NT)
-#define GEN_ACT(HT, NT)                                                          \
-    GEN4(HT, 2, CNF_ACT_TANH, NT), GEN4(HT, 3, CNF_ACT_TANH, NT),                \
-    GEN4(HT, 2, CNF_ACT_SOFTPLUS, NT), GEN4(HT, 3, CNF_ACT_SOFTPLUS, NT)
+#define GEN_ACT(HT, NT) GEN4(HT, 2, GEN_ACTIVATION, NT), GEN4(HT, 3, GEN_ACTIVATION, NT)
 
 // 1 and 4 hidden layers (H <= 64)
-#define GEN_L14(HT, NT)                                                          \
-    GEN4(HT, 1, CNF_ACT_TANH, NT), GEN4(HT, 4, CNF_ACT_TANH, NT),                \
-    GEN4(HT, 1, CNF_ACT_SOFTPLUS, NT), GEN4(HT, 4, CNF_ACT_SOFTPLUS, NT)
+#define GEN_L14(HT, NT) GEN4(HT, 1, GEN_ACTIVATION, NT), GEN4(HT, 4, GEN_ACTIVATION, NT)
 
 static const Inst kGeneric[] = {
     GEN_ACT(1, 512), GEN_ACT(2, 512), GEN_ACT(3, 512), GEN_ACT(4, 512), GEN_ACT(6, 256), GEN_ACT(8, 256),
     GEN_L14(1, 512), GEN_L14(2, 512), GEN_L14(3, 512), GEN_L14(4, 512),
 };
 
-const Inst* mfma_generic_insts(int* count) {
+const Inst* GEN_TABLE_FN(int* count) {
     *count = (int)(sizeof(kGeneric) / sizeof(kGeneric[0]));
     return kGeneric;
 }

@@ -1320,7 +1320,8 @@ struct Inst {
 #endif
 
 // generic zero-padded instances (cnf_mfma_generic.hip): D <= 16 and C <= 16 or C = 0
-const Inst* mfma_generic_insts(int* count);
+const Inst* mfma_generic_insts(int* count);            // tanh nets
+const Inst* mfma_generic_softplus_insts(int* count);   // softplus nets (cnf_mfma_generic_softplus.hip)
 // the same shapes with a capacity of several Hutchinson probes (cnf_mfma_generic_probes.hip): VJP, K <= KP
 const Inst* mfma_generic_probe_insts(int* count);
 // state k-steps padded to 8 (D <= 32): the reference's default nets for nvariables 8..15 (cnf_mfma_generic_zr8.hip)
