@@ -25,7 +25,17 @@ namespace cnf {
     MFMA_INST(HT, L, 4, 4, VJP_ACT(ACT), ENG_VJP, 1, 1, NT),   \
     MFMA_INST_AD(HT, L, 4, 0, ACT, ENG_TAN, 1, 0, NT),            \
     MFMA_INST(HT, L, 4, 4, ACT, ENG_TAN, 1, 0, NT)
+// two hidden layers of softplus are the reference's default nets (conditioned ones included): all four get the twins
+#define GEN4_ALL_AD(HT, L, ACT, NT)                               \
+    MFMA_INST_AD(HT, L, 4, 0, VJP_ACT(ACT), ENG_VJP, 1, 1, NT),   \
+    MFMA_INST_AD(HT, L, 4, 4, VJP_ACT(ACT), ENG_VJP, 1, 1, NT),   \
+    MFMA_INST_AD(HT, L, 4, 0, ACT, ENG_TAN, 1, 0, NT),            \
+    MFMA_INST_AD(HT, L, 4, 4, ACT, ENG_TAN, 1, 0, NT)
+#ifdef GEN_DEFAULT_NETS
+#define GEN_ACT(HT, NT) GEN4_ALL_AD(HT, 2, GEN_ACTIVATION, NT), GEN4(HT, 3, GEN_ACTIVATION, NT)
+#else
 #define GEN_ACT(HT, NT) GEN4(HT, 2, GEN_ACTIVATION, NT), GEN4(HT, 3, GEN_ACTIVATION, NT)
+#endif
 
 // 1 and 4 hidden layers (H <= 64)
 #define GEN_L14(HT, NT) GEN4(HT, 1, GEN_ACTIVATION, NT), GEN4(HT, 4, GEN_ACTIVATION, NT)

@@ -5,6 +5,7 @@
 // 4 state k-steps of cnf_mfma_generic.hip, below the cooperative kernel's widths.  These instances keep
 // such flows (and any other chain with D <= 32, H <= 128) on the fused path: z, eps and the RK stage
 // derivatives use 8 registers per lane each, the D-row products two M-tiles.
+#define CNF_WITH_DEVICE_CONTROLLER 1
 #include "cnf_mfma_kernel.h"
 
 namespace cnf {
@@ -15,16 +16,23 @@ namespace cnf {
     MFMA_INST(HT, L, 8, 4, VJP_ACT(ACT), ENG_VJP, 1, 1, NT),   \
     MFMA_INST(HT, L, 8, 0, ACT, ENG_TAN, 1, 0, NT),            \
     MFMA_INST(HT, L, 8, 4, ACT, ENG_TAN, 1, 0, NT)
+// the reference's default nets (two hidden layers of softplus, nvariables 8..15), unconditioned: with the one-launch adaptive twins
+#define GEN8_DEF(HT, L, ACT, NT)                                  \
+    MFMA_INST_AD(HT, L, 8, 0, VJP_ACT(ACT), ENG_VJP, 1, 1, NT),   \
+    MFMA_INST(HT, L, 8, 4, VJP_ACT(ACT), ENG_VJP, 1, 1, NT),      \
+    MFMA_INST_AD(HT, L, 8, 0, ACT, ENG_TAN, 1, 0, NT),            \
+    MFMA_INST(HT, L, 8, 4, ACT, ENG_TAN, 1, 0, NT)
 #define GEN8_ACT(HT, NT)                                                         \
     GEN8(HT, 2, CNF_ACT_TANH, NT), GEN8(HT, 3, CNF_ACT_TANH, NT),                \
-    GEN8(HT, 2, CNF_ACT_SOFTPLUS, NT), GEN8(HT, 3, CNF_ACT_SOFTPLUS, NT)
+    GEN8_DEF(HT, 2, CNF_ACT_SOFTPLUS, NT), GEN8(HT, 3, CNF_ACT_SOFTPLUS, NT)
 
 // 7 hidden tiles, two hidden layers, tangent engine: H = 104 / 112 (default nets for nvariables = 12, 13) on the 8-tile instance
 // would not fit the Q image of the exact-trace shortcut in LDS; on 7 tiles it does
 #define GEN8_TAN7(ACT) MFMA_INST(7, 2, 8, 0, ACT, ENG_TAN, 1, 0, 256), MFMA_INST(7, 2, 8, 4, ACT, ENG_TAN, 1, 0, 256)
+#define GEN8_TAN7_DEF(ACT) MFMA_INST_AD(7, 2, 8, 0, ACT, ENG_TAN, 1, 0, 256), MFMA_INST(7, 2, 8, 4, ACT, ENG_TAN, 1, 0, 256)
 
 static const Inst kGenericZr8[] = {
-    GEN8_TAN7(CNF_ACT_TANH), GEN8_TAN7(CNF_ACT_SOFTPLUS),
+    GEN8_TAN7(CNF_ACT_TANH), GEN8_TAN7_DEF(CNF_ACT_SOFTPLUS),
     GEN8_ACT(2, 512), GEN8_ACT(4, 256), GEN8_ACT(6, 256), GEN8_ACT(8, 256),   // HT = 4 spills at 2 waves/SIMD (8 state k-steps)
 };
 
