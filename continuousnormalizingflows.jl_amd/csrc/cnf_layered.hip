@@ -605,6 +605,15 @@ hipError_t layered_grad(LayeredGrad** ctx, const cnf_config& c, const float* P_d
     const int nst = alg == CNF_ALG_RK4 ? 4 : 6;
     const bool keep_k = (double)DB * nst * nsteps * sizeof(float) <= 4.0 * 1024 * 1024 * 1024 && !getenv("CNF_LAYERED_NO_KCKPT");
     const long long o_kck = keep_k ? take(DB * nst * nsteps) : 0;
+    // the activations of every stage (a_l with its ones row, act'_l) are kept too when they fit the budget (default 48 GiB of
+    // the 288; CNF_LAYERED_ACT_GIB): the reverse sweep then reads them instead of recomputing the forward chain of the stage
+    long long act_stage = (long long)(c.widths[0] + 1) * B;
+    for (int l = 0; l < N; ++l) act_stage += (long long)(L.wout[l] + 1) * B + (long long)L.wout[l] * B;
+    act_stage = (act_stage + 63) / 64 * 64 + 64 * (N + 2) * 2;
+    double act_gib = 48.0;
+    if (const char* e = getenv("CNF_LAYERED_ACT_GIB")) act_gib = atof(e);
+    const bool keep_act = keep_k && (double)act_stage * nst * nsteps * sizeof(float) <= act_gib * 1024.0 * 1024.0 * 1024.0;
+    const long long o_actck = keep_act ? take(act_stage * nst * nsteps) : 0;
     long long o_kz[6], o_zb[6];
     for (int j = 0; j < 6; ++j) o_kz[j] = take(DB);
     for (int j = 0; j < 6; ++j) o_zb[j] = take(DB);
@@ -631,6 +640,13 @@ hipError_t layered_grad(LayeredGrad** ctx, const cnf_config& c, const float* P_d
     for (int j = 0; j < 6; ++j) { kz[j] = W + o_kz[j]; Zb[j] = W + o_zb[j]; }
     for (int l = 0; l <= N; ++l) a[l] = W + o_a[l];
     for (int l = 0; l < N; ++l) { d[l] = W + o_d[l]; v[l] = W + o_v[l]; acc2[l] = W + o_acc2[l]; dl[l] = W + o_dl[l]; }
+    // where stage s (= step * ns + stage) keeps its activations: a[] / d[] are pointed there before the stage's forward chain
+    auto point_act = [&](long long stage) {
+        float* q = W + o_actck + stage * act_stage;
+        auto grab = [&](long long nfl) { float* r = q; q += (nfl + 63) / 64 * 64; return r; };
+        a[0] = grab((long long)(c.widths[0] + 1) * B);
+        for (int l = 0; l < N; ++l) { a[l + 1] = grab((long long)(L.wout[l] + 1) * B); d[l] = grab((long long)L.wout[l] * B); }
+    };
     float *lamv = W + o_lam, *kbar = W + o_kbar, *zs = W + o_zs, *gk = W + o_g, *gbar = W + o_gbar, *vN = W + o_vN;
     float *tdb = W + o_t0, *tdb2 = W + o_t1, *tvb = W + o_t2, *tsb = W + o_t3, *tab = W + o_t4;
 
@@ -664,6 +680,7 @@ hipError_t layered_grad(LayeredGrad** ctx, const cnf_config& c, const float* P_d
     auto step_t = [&](int n) { return tgrid ? tgrid[n] : t0 + (float)n * ((t1 - t0) / (float)nsteps); };
     auto step_dt = [&](int n) { return tgrid ? tgrid[n + 1] - tgrid[n] : (t1 - t0) / (float)nsteps; };
     const int ns = T.ns;
+    int cur_step = 0;
     // stage derivatives of one step from z_n (z rows only: the gradient needs no trace here)
     auto stage_derivs = [&](const float* zn, float tn) -> hipError_t {
         for (int i = 0; i < ns; ++i) {
@@ -672,6 +689,7 @@ hipError_t layered_grad(LayeredGrad** ctx, const cnf_config& c, const float* P_d
             for (int j = 0; j < i; ++j)
                 if (T.a[i][j] != 0.f) { cb.k[cb.nk] = kz[j]; cb.coef[cb.nk] = dt * T.a[i][j]; ++cb.nk; }
             hipLaunchKernelGGL(combine_kernel, grid_for(DB), dim3(TPB), 0, st, zs, zn, cb, DB);
+            if (keep_act) point_act((long long)cur_step * ns + i);
             hipError_t s = forward(zs, tn + T.c[i] * dt);
             if (s != hipSuccess) return s;
             hipLaunchKernelGGL(copy_rows_kernel, grid_for(DB), dim3(TPB), 0, st, kz[i], a[N], D, D + 1, 0, B);
@@ -685,6 +703,7 @@ hipError_t layered_grad(LayeredGrad** ctx, const cnf_config& c, const float* P_d
     float* kck = W + o_kck;
     for (int n = 0; n < nsteps; ++n) {
         dt = step_dt(n);
+        cur_step = n;
         LG_BLAS(stage_derivs(zck + (long long)n * DB, step_t(n)));
         if (keep_k)
             for (int j = 0; j < ns; ++j)
@@ -709,8 +728,12 @@ hipError_t layered_grad(LayeredGrad** ctx, const cnf_config& c, const float* P_d
             cb.nk = 0;
             for (int j = 0; j < i; ++j)
                 if (T.a[i][j] != 0.f) { cb.k[cb.nk] = kz[j]; cb.coef[cb.nk] = dt * T.a[i][j]; ++cb.nk; }
-            hipLaunchKernelGGL(combine_kernel, grid_for(DB), dim3(TPB), 0, st, zs, zn, cb, DB);
-            LG_BLAS(forward(zs, tn + T.c[i] * dt));
+            if (keep_act) {
+                point_act((long long)n * ns + i);      // a_l, act'_l of this stage as the forward sweep left them
+            } else {
+                hipLaunchKernelGGL(combine_kernel, grid_for(DB), dim3(TPB), 0, st, zs, zn, cb, DB);
+                LG_BLAS(forward(zs, tn + T.c[i] * dt));
+            }
             const float cl = dt * T.b[i];          // cotangent of ldot (dL/d dlogp = +1 per column)
             Comb zb{};
             zb.nk = 0;
