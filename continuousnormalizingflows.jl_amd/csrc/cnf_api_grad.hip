@@ -94,6 +94,7 @@ static int loss_grad_impl(cnf_handle* h, const char* who, int alg, int nsteps, f
     }
     if (!fused) {
         // the loss sums come from the regular solve on whichever family serves the handle
+        const bool loss_in_sweep = sums4 && !api_grad_uses_slab(h) && !getenv("CNF_LAYERED_LOSS_BY_SOLVE");
         if (sums4) {
             const size_t need = ((size_t)h->S + 4) * (size_t)B * sizeof(float);
             if (need > h->grad_ws_bytes) {
@@ -104,7 +105,9 @@ static int loss_grad_impl(cnf_handle* h, const char* who, int alg, int nsteps, f
             }
             float* logp = h->grad_ws;
             float* regs = logp + B;
-            if (tgrid) {   // the loss of the same discrete solve: augmented state advanced over the grid, then the epilogue
+            if (loss_in_sweep) {
+                // the layer-wise reverse sweep accumulates the loss terms of the solve it differentiates (below)
+            } else if (tgrid) {   // the loss of the same discrete solve: augmented state advanced over the grid, then the epilogue
                 float* u = regs + 3 * (size_t)B;
                 const int ra0 = (h->cfg.mode != CNF_MODE_EXACT && h->cfg.reg_aug && h->cfg.naug > 0) ? 1 : 0;
                 HIP_TRY(assemble_u0(x, h->cfg.nvars, h->S, B, u, st));
@@ -116,7 +119,7 @@ static int loss_grad_impl(cnf_handle* h, const char* who, int alg, int nsteps, f
                 if (rc) return rc;
             }
             if (!h->loss_partial) HIP_TRY(hipMalloc((void**)&h->loss_partial, 256 * 4 * sizeof(float)));
-            HIP_TRY(loss_sums(logp, regs, B, h->loss_partial, sums4, st));
+            if (!loss_in_sweep) HIP_TRY(loss_sums(logp, regs, B, h->loss_partial, sums4, st));
         }
         const bool hutch = h->cfg.mode != CNF_MODE_EXACT;   // the exact-trace dynamics carry no regularisers (icnf.jl:297-339)
         const int ra = (hutch && h->cfg.reg_aug && h->cfg.naug > 0) ? 1 : 0;
@@ -140,10 +143,12 @@ static int loss_grad_impl(cnf_handle* h, const char* who, int alg, int nsteps, f
             return CNF_OK;
         }
         std::string msg;
+        float* lg_logp = loss_in_sweep ? h->grad_ws : nullptr;
         hipError_t e = layered_grad(&h->layered, h->cfg, h->P_dev, h->w_off.data(), h->b_off.data(), x, eps, ys, alg, nsteps,
-                                    t0, t1, tgrid, B, lam, grad, grad_x, st, &msg);
+                                    t0, t1, tgrid, B, lam, grad, grad_x, st, &msg, lg_logp, lg_logp ? lg_logp + B : nullptr);
         if (e == hipErrorNotSupported) return fail(CNF_ERR_UNSUPPORTED, w + ": " + msg);
         if (e != hipSuccess) return fail(CNF_ERR_HIP, w + ": " + msg);
+        if (loss_in_sweep) HIP_TRY(loss_sums(lg_logp, lg_logp + B, B, h->loss_partial, sums4, st));
         return CNF_OK;
     }
     if (h->num_cus == 0) {

@@ -109,7 +109,9 @@ void layered_grad_destroy(LayeredGrad* g);
 hipError_t layered_grad(LayeredGrad** ctx, const cnf_config& c, const float* P_dev, const size_t* w_off,
                         const size_t* b_off, const float* x, const float* eps, const float* ys, int alg,
                         int nsteps, float t0, float t1, const float* tgrid, long long B, const float lam[3], float* grad,
-                        float* grad_x, hipStream_t st, std::string* err);
+                        float* grad_x, hipStream_t st, std::string* err, float* logp_out = nullptr, float* regs_out = nullptr);
+// logp_out (B) / regs_out (3 B): when both are given the reverse sweep also accumulates the loss terms of the same discrete
+// solve (dlogp, E, n per column) and runs the epilogue - no separate forward solve for the loss
 void mfma_pack_layout(const cnf_config& c, int HT, int L, int ZR, int CR, const float* lux, const size_t* w_off,
                       const size_t* b_off, float* packed);
 // slab-accumulator gradient kernel for two-hidden-layer nets of 4..7 hidden tiles (cnf_grad_slab.hip)

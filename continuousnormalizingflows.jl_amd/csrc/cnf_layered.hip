@@ -178,6 +178,90 @@ __global__ void gbar_kernel(float* __restrict__ gbar, const float* __restrict__ 
     for (int f = 0; f < D; ++f) gbar[j * D + f] = fmaf(inv, g[j * D + f], -cl * epsk[j * D + f]);
 }
 
+// The loss of the same discrete solve, accumulated stage by stage in the reverse sweep (the stage's zdot and eps^T J are at
+// hand there): E += w |zdot|;  dlogp += wl <eps_k, g_k>;  n += wn |g_k|
+__global__ void loss_acc_z_kernel(float* __restrict__ eacc, const float* __restrict__ aN, int ldn, float w, int D, long long B) {
+    const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= B) return;
+    float n2 = 0.f;
+    for (int f = 0; f < D; ++f) { const float v = aN[j * ldn + f]; n2 = fmaf(v, v, n2); }
+    eacc[j] = fmaf(w, sqrtf(n2), eacc[j]);
+}
+__global__ void loss_acc_g_kernel(float* __restrict__ lacc, float* __restrict__ nacc, const float* __restrict__ g,
+                                  const float* __restrict__ epsk, float wl, float wn, int D, long long B) {
+    const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= B) return;
+    float dot = 0.f, n2 = 0.f;
+    for (int f = 0; f < D; ++f) { const float v = g[j * D + f]; dot = fmaf(epsk[j * D + f], v, dot); n2 = fmaf(v, v, n2); }
+    lacc[j] = fmaf(wl, dot, lacc[j]);
+    if (wn != 0.f) nacc[j] = fmaf(wn, sqrtf(n2), nacc[j]);
+}
+// u = [z; dlogp; E; n] per column
+__global__ void pack_final_kernel(float* __restrict__ u, const float* __restrict__ z, const float* __restrict__ lacc,
+                                  const float* __restrict__ eacc, const float* __restrict__ nacc, int D, long long B) {
+    const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= B) return;
+    const int S = D + 3;
+    for (int f = 0; f < D; ++f) u[j * S + f] = z[j * D + f];
+    u[j * S + D] = lacc[j]; u[j * S + D + 1] = eacc[j]; u[j * S + D + 2] = nacc[j];
+}
+
+// ---- the same per-column kernels with one lane per (column, feature): G = the power of two >= D (<= 64) lanes share a
+// column, loads and stores are coalesced (the thread-per-column forms above walk a column with stride-D accesses and
+// occupy half the chip at B = 32 K: 12-20 us each, five of them per stage), norms and dots are butterfly sums over the group
+__device__ __forceinline__ float group_sum_w(float v, int G) {
+    for (int o = G >> 1; o >= 1; o >>= 1) v += __shfl_xor(v, o, G);
+    return v;
+}
+__global__ void kbar_grp_kernel(float* __restrict__ kbar, const float* __restrict__ lam, Comb zb, float dtb, float dt,
+                                const float* __restrict__ aN, float cE, int D, int G, long long B) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long j = i / G;
+    const int f = (int)(i % G);
+    const bool ok = j < B && f < D;
+    float z = ok ? aN[j * (D + 1) + f] : 0.f;
+    float inv = 0.f;
+    if (cE != 0.f) {
+        const float e2 = group_sum_w(z * z, G);
+        inv = e2 > 0.f ? cE * rsqrtf(e2) : 0.f;
+    }
+    if (!ok) return;
+    float acc = 0.f;
+    for (int q = 0; q < zb.nk; ++q) acc = fmaf(zb.coef[q], zb.k[q][j * D + f], acc);
+    float v = fmaf(dtb, lam[j * D + f], dt * acc);
+    if (cE != 0.f) v = fmaf(inv, z, v);
+    kbar[j * D + f] = v;
+}
+__global__ void gbar_grp_kernel(float* __restrict__ gbar, const float* __restrict__ g, const float* __restrict__ epsk,
+                                float cl, float cn, float* __restrict__ lacc, float* __restrict__ nacc, float wl, float wn,
+                                int D, int G, long long B) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long j = i / G;
+    const int f = (int)(i % G);
+    const bool ok = j < B && f < D;
+    const float gv = ok ? g[j * D + f] : 0.f, ev = ok ? epsk[j * D + f] : 0.f;
+    float inv = 0.f, n2 = 0.f;
+    if (cn != 0.f || (lacc && wn != 0.f)) n2 = group_sum_w(gv * gv, G);
+    if (cn != 0.f) inv = n2 > 0.f ? cn * rsqrtf(n2) : 0.f;
+    if (lacc) {     // the loss terms of this stage and probe ride along: dlogp += wl <eps, g>, n += wn |g|
+        const float dot = group_sum_w(ev * gv, G);
+        if (ok && f == 0) {
+            lacc[j] = fmaf(wl, dot, lacc[j]);
+            if (wn != 0.f) nacc[j] = fmaf(wn, sqrtf(n2), nacc[j]);
+        }
+    }
+    if (ok) gbar[j * D + f] = fmaf(inv, gv, -cl * ev);
+}
+__global__ void loss_acc_z_grp_kernel(float* __restrict__ eacc, const float* __restrict__ aN, int ldn, float w, int D, int G, long long B) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long j = i / G;
+    const int f = (int)(i % G);
+    const bool ok = j < B && f < D;
+    const float v = ok ? aN[j * ldn + f] : 0.f;
+    const float n2 = group_sum_w(v * v, G);
+    if (ok && f == 0) eacc[j] = fmaf(w, sqrtf(n2), eacc[j]);
+}
+
 // vbar = dbar .* act';  acc2 += dbar .* v
 __global__ void bottom_kernel(const float* __restrict__ db, const float* __restrict__ d, const float* __restrict__ v,
                               float* __restrict__ vbar, float* __restrict__ acc2, int first, long long n) {
@@ -557,7 +641,7 @@ hipError_t layered_aug_f(LayeredGrad** ctx, const cnf_config& c, const float* P_
 hipError_t layered_grad(LayeredGrad** ctx, const cnf_config& c, const float* P_dev, const size_t* w_off,
                         const size_t* b_off, const float* x, const float* eps, const float* ys, int alg,
                         int nsteps, float t0, float t1, const float* tgrid, long long B, const float lam[3], float* grad,
-                        float* grad_x, hipStream_t st, std::string* err) {
+                        float* grad_x, hipStream_t st, std::string* err, float* logp_out, float* regs_out) {
     if (!layered_supports(c)) {
         *err = "layered gradient: a layer is wider than the product kernels cover (512 outputs, 639 inputs)";
         return hipErrorNotSupported;
@@ -617,6 +701,7 @@ hipError_t layered_grad(LayeredGrad** ctx, const cnf_config& c, const float* P_d
     long long o_kz[6], o_zb[6];
     for (int j = 0; j < 6; ++j) o_kz[j] = take(DB);
     for (int j = 0; j < 6; ++j) o_zb[j] = take(DB);
+    const long long o_lacc = take(3 * B), o_ufin = take((long long)(D + 3) * B);
     const long long o_lam = take(DB), o_kbar = take(DB), o_zs = take(DB), o_g = take(DB), o_gbar = take(DB), o_vN = take(DB);
     long long o_a[CNF_MAX_LAYERS + 1], o_d[CNF_MAX_LAYERS], o_v[CNF_MAX_LAYERS], o_acc2[CNF_MAX_LAYERS], o_dl[CNF_MAX_LAYERS];
     o_a[0] = take((long long)(c.widths[0] + 1) * B);
@@ -717,6 +802,14 @@ hipError_t layered_grad(LayeredGrad** ctx, const cnf_config& c, const float* P_d
 
     // ---- reverse sweep ----
     const float invK = exact ? 1.f : 1.f / (float)K;
+    // the loss of this solve is accumulated on the way (no separate forward solve for it): per column dlogp, E, n
+    const bool want_loss = logp_out != nullptr && regs_out != nullptr;
+    float *lacc = W + o_lacc, *eacc = lacc + B, *nacc = eacc + B;
+    if (want_loss) LG_HIP(hipMemsetAsync(lacc, 0, 3 * (size_t)B * sizeof(float), st));
+    const bool hutch = !exact;
+    int Gw = 1;                      // lanes per column of the grouped per-column kernels (0: D > 64, thread-per-column forms)
+    while (Gw < D) Gw <<= 1;
+    if (Gw > 64) Gw = 0;
     for (int n = nsteps - 1; n >= 0; --n) {
         const float* zn = zck + (long long)n * DB;
         dt = step_dt(n);
@@ -739,7 +832,12 @@ hipError_t layered_grad(LayeredGrad** ctx, const cnf_config& c, const float* P_d
             zb.nk = 0;
             for (int j = i + 1; j < ns; ++j)
                 if (T.a[j][i] != 0.f) { zb.k[zb.nk] = Zb[j]; zb.coef[zb.nk] = T.a[j][i]; ++zb.nk; }
-            hipLaunchKernelGGL(kbar_kernel, grid_for(B), dim3(TPB), 0, st, kbar, lamv, zb, dt * T.b[i], dt, a[N], cl * lam[0], D, B);
+            if (Gw) hipLaunchKernelGGL(kbar_grp_kernel, grid_for(B * Gw), dim3(TPB), 0, st, kbar, lamv, zb, dt * T.b[i], dt, a[N], cl * lam[0], D, Gw, B);
+            else hipLaunchKernelGGL(kbar_kernel, grid_for(B), dim3(TPB), 0, st, kbar, lamv, zb, dt * T.b[i], dt, a[N], cl * lam[0], D, B);
+            if (want_loss && hutch && c.reg_z) {
+                if (Gw) hipLaunchKernelGGL(loss_acc_z_grp_kernel, grid_for(B * Gw), dim3(TPB), 0, st, eacc, a[N], D + 1, cl, D, Gw, B);
+                else hipLaunchKernelGGL(loss_acc_z_kernel, grid_for(B), dim3(TPB), 0, st, eacc, a[N], D + 1, cl, D, B);
+            }
 
             for (int k = 0; k < K; ++k) {
                 if (exact) hipLaunchKernelGGL(onehot_kernel, grid_for(DB), dim3(TPB), 0, st, vN, k, D, B);
@@ -754,7 +852,15 @@ hipError_t layered_grad(LayeredGrad** ctx, const cnf_config& c, const float* P_d
                         const long long HB = (long long)L.wout[l] * B;
                         hipLaunchKernelGGL(mul_kernel, grid_for(HB), dim3(TPB), 0, st, dl[l], v[l], d[l], HB);
                     }
-                    hipLaunchKernelGGL(gbar_kernel, grid_for(B), dim3(TPB), 0, st, gbar, dl[N - 1], vN, cl * invK, cl * lam[1] * invK, D, B);
+                    if (Gw) {
+                        hipLaunchKernelGGL(gbar_grp_kernel, grid_for(B * Gw), dim3(TPB), 0, st, gbar, dl[N - 1], vN, cl * invK, cl * lam[1] * invK,
+                                           want_loss ? lacc : nullptr, nacc, -cl * invK, c.reg_j ? cl * invK : 0.f, D, Gw, B);
+                    } else {
+                        hipLaunchKernelGGL(gbar_kernel, grid_for(B), dim3(TPB), 0, st, gbar, dl[N - 1], vN, cl * invK, cl * lam[1] * invK, D, B);
+                        if (want_loss)
+                            hipLaunchKernelGGL(loss_acc_g_kernel, grid_for(B), dim3(TPB), 0, st, lacc, nacc, dl[N - 1], vN, -cl * invK,
+                                               c.reg_j ? cl * invK : 0.f, D, B);
+                    }
                     const float* tb = gbar;
                     float *tbn = tdb, *tbn2 = tdb2;
                     for (int l = N - 1; l >= 0; --l) {
@@ -778,7 +884,15 @@ hipError_t layered_grad(LayeredGrad** ctx, const cnf_config& c, const float* P_d
                     LG_BLAS(lg_product(G, PA, OPT, L.win[l], B, L.wout[l], PA + L.pa_off[l], L.wout[l], dl[l], L.wout[l], v[l - 1], L.win[l],
                                        LG_EPI_MUL2, d[l - 1], L.win[l], dl[l - 1], L.win[l], 0, st));
                 LG_BLAS(gemm(OPT, OPN, D, B, L.wout[0], PA, L.wout[0], dl[0], L.wout[0], gk, D));
-                hipLaunchKernelGGL(gbar_kernel, grid_for(B), dim3(TPB), 0, st, gbar, gk, vN, cl * invK, cl * lam[1] * invK, D, B);
+                if (Gw) {
+                    hipLaunchKernelGGL(gbar_grp_kernel, grid_for(B * Gw), dim3(TPB), 0, st, gbar, gk, vN, cl * invK, cl * lam[1] * invK,
+                                       want_loss ? lacc : nullptr, nacc, -cl * invK, (hutch && c.reg_j) ? cl * invK : 0.f, D, Gw, B);
+                } else {
+                    hipLaunchKernelGGL(gbar_kernel, grid_for(B), dim3(TPB), 0, st, gbar, gk, vN, cl * invK, cl * lam[1] * invK, D, B);
+                    if (want_loss)
+                        hipLaunchKernelGGL(loss_acc_g_kernel, grid_for(B), dim3(TPB), 0, st, lacc, nacc, gk, vN, -cl * invK,
+                                           (hutch && c.reg_j) ? cl * invK : 0.f, D, B);
+                }
                 // bottom-up through the pullback: dbar_1 = W_1[:,0:D] gbar, vbar_l = dbar_l .* act'_l, acc2_l += dbar_l .* v_l
                 // (both in the epilogue of the product that makes dbar_l), dbar_{l+1} = W_{l+1} vbar_l
                 float *cur = tvb, *nxt = tdb;
@@ -817,6 +931,12 @@ hipError_t layered_grad(LayeredGrad** ctx, const cnf_config& c, const float* P_d
     hipLaunchKernelGGL(reduce_slabs_kernel, grid_for(npa), dim3(TPB), 0, st, slabs, nslab, npa_pad, L, grad);
     if (grad_x)   // costate at t0: dL/dx = its first nvars rows
         hipLaunchKernelGGL(copy_rows_kernel, grid_for((long long)c.nvars * B), dim3(TPB), 0, st, grad_x, lamv, c.nvars, D, 0, B);
+    if (want_loss) {   // inference_sol on [z(t1); dlogp; E; n] (src/core/base_icnf.jl:158-172)
+        float* ufin = W + o_ufin;
+        hipLaunchKernelGGL(pack_final_kernel, grid_for(B), dim3(TPB), 0, st, ufin, zck + (long long)nsteps * DB, lacc, eacc, nacc, D, B);
+        const int ra = (hutch && c.reg_aug && c.naug > 0) ? 1 : 0;
+        LG_HIP(epilogue(ufin, c.nvars, D, ra, B, logp_out, regs_out, st));
+    }
     LG_HIP(hipGetLastError());
     return hipSuccess;
 }
