@@ -696,7 +696,13 @@ hipError_t layered_grad(LayeredGrad** ctx, const cnf_config& c, const float* P_d
     act_stage = (act_stage + 63) / 64 * 64 + 64 * (N + 2) * 2;
     double act_gib = 48.0;
     if (const char* e = getenv("CNF_LAYERED_ACT_GIB")) act_gib = atof(e);
-    const bool keep_act = keep_k && (double)act_stage * nst * nsteps * sizeof(float) <= act_gib * 1024.0 * 1024.0 * 1024.0;
+    bool keep_act = keep_k && (double)act_stage * nst * nsteps * sizeof(float) <= act_gib * 1024.0 * 1024.0 * 1024.0;
+    if (keep_act) {   // ... and half of what the device has free (counting the workspace this context already holds)
+        size_t mfree = 0, mtotal = 0;
+        if (hipMemGetInfo(&mfree, &mtotal) != hipSuccess) { (void)hipGetLastError(); mfree = 0; }
+        const double avail = (double)mfree + (double)G.ws_floats * sizeof(float);
+        if ((double)act_stage * nst * nsteps * sizeof(float) > 0.5 * avail) keep_act = false;
+    }
     const long long o_actck = keep_act ? take(act_stage * nst * nsteps) : 0;
     long long o_kz[6], o_zb[6];
     for (int j = 0; j < 6; ++j) o_kz[j] = take(DB);
