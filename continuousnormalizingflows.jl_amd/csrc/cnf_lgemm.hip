@@ -126,28 +126,25 @@ lg_gemm_kernel(LgGemmArgs a) {
     for (int m = 0; m < MTW; ++m) a0[m] = A[((long long)mts[m] * a.KQ + 0) * 64];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) b0[q] = bimg[(0 * NQ + q) * 64 + lane];
+    // (prefetch loads unconditional, k-group index clamped at the end: see lg_gemm2_kernel)
 #pragma clang loop unroll(disable)
     for (int kq = 0; kq < a.KQ; kq += 2) {
-        const bool has1 = kq + 1 < a.KQ, has2 = kq + 2 < a.KQ;
-        if (has1) {
+        const int k1 = kq + 1 < a.KQ ? kq + 1 : a.KQ - 1, k2 = kq + 2 < a.KQ ? kq + 2 : a.KQ - 1;
 #pragma unroll
-            for (int m = 0; m < MTW; ++m) a1[m] = A[((long long)mts[m] * a.KQ + kq + 1) * 64];
+        for (int m = 0; m < MTW; ++m) a1[m] = A[((long long)mts[m] * a.KQ + k1) * 64];
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) b1[q] = bimg[((kq + 1) * NQ + q) * 64 + lane];
-        }
+        for (int q = 0; q < NQ; ++q) b1[q] = bimg[(k1 * NQ + q) * 64 + lane];
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int m = 0; m < MTW; ++m)
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) acc[m][q] = mfma4(a0[m][j], b0[q][j], acc[m][q]);
-        if (has1) {
-            if (has2) {
 #pragma unroll
-                for (int m = 0; m < MTW; ++m) a0[m] = A[((long long)mts[m] * a.KQ + kq + 2) * 64];
+        for (int m = 0; m < MTW; ++m) a0[m] = A[((long long)mts[m] * a.KQ + k2) * 64];
 #pragma unroll
-                for (int q = 0; q < NQ; ++q) b0[q] = bimg[((kq + 2) * NQ + q) * 64 + lane];
-            }
+        for (int q = 0; q < NQ; ++q) b0[q] = bimg[(k2 * NQ + q) * 64 + lane];
+        if (kq + 1 < a.KQ) {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -299,11 +296,13 @@ __device__ __forceinline__ void lg_epilogue_tile(const LgGemmArgs& a, f32x4 v, i
 }
 
 constexpr int LG2_KQ_MAX = 17;                        // K <= 272: 2 buffers x 17 x 2 KB = 68 KB of LDS
-constexpr int LG2_UNITS = (2 * LG2_KQ_MAX + 3) / 4;   // staging units (1 KB: one (kq, q) tile) per wave and sub-panel
 
-template <int MTW, int EPI>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+// NW waves per workgroup (4 or 8): with 8, a wave owns half as many row tiles, needs ~110 registers, and four waves share a
+// SIMD (two workgroups per CU) - twice the memory latency covered per SIMD
+template <int MTW, int EPI, int NW>
+__global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 2, NW / 2)))
 lg_gemm2_kernel(LgGemmArgs a) {
+    constexpr int LG2_UNITS = (2 * LG2_KQ_MAX + NW - 1) / NW;   // staging units (1 KB: one (kq, q) tile) per wave and sub-panel
     extern __shared__ __attribute__((aligned(16))) float smem[];
     f32x4* bimg = reinterpret_cast<f32x4*>(smem);                 // [2 buffers][KQ][2 sample tiles][64 lanes]
     const int lane = threadIdx.x & 63, g = lane >> 4, n = lane & 15;
@@ -317,7 +316,7 @@ lg_gemm2_kernel(LgGemmArgs a) {
     auto fetch = [&](long long sp) {
 #pragma unroll
         for (int i = 0; i < LG2_UNITS; ++i) {
-            const int u = wave + 4 * i;
+            const int u = wave + NW * i;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (u < nunits) {
                 const int kq = u >> 1, q = u & 1, k0 = 16 * kq + 4 * g;
@@ -339,7 +338,7 @@ lg_gemm2_kernel(LgGemmArgs a) {
     auto park = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < LG2_UNITS; ++i) {
-            const int u = wave + 4 * i;
+            const int u = wave + NW * i;
             if (u < nunits) bimg[buf * bufsz + u * 64 + lane] = stage[i];
         }
     };
@@ -348,7 +347,7 @@ lg_gemm2_kernel(LgGemmArgs a) {
     const int mt_hi = mt_lo + a.mts < a.MT ? mt_lo + a.mts : a.MT;
     int mts[MTW];
 #pragma unroll
-    for (int m = 0; m < MTW; ++m) { const int t = mt_lo + wave + 4 * m; mts[m] = t < mt_hi ? t : mt_hi - 1; }
+    for (int m = 0; m < MTW; ++m) { const int t = mt_lo + wave + NW * m; mts[m] = t < mt_hi ? t : mt_hi - 1; }
     if (cnt <= 0) return;
     fetch(sp0);
     park(0);
@@ -366,14 +365,15 @@ lg_gemm2_kernel(LgGemmArgs a) {
 #pragma unroll
         for (int m = 0; m < MTW; ++m) a0[m] = A[((long long)mts[m] * KQ + 0) * 64];
         b0[0] = bb[0]; b0[1] = bb[64];
+        // The prefetch loads are UNCONDITIONAL (k-group index clamped at the end): a load inside an `if` makes a control-flow
+        // join at which the compiler's wait-count insertion assumes the worst and waits for everything outstanding
+        // (`s_waitcnt vmcnt(0) lgkmcnt(0)` right after the prefetch was issued - measured: no overlap at all, 57 us per product)
 #pragma clang loop unroll(disable)
         for (int kq = 0; kq < KQ; kq += 2) {
-            const bool has1 = kq + 1 < KQ, has2 = kq + 2 < KQ;
-            if (has1) {
+            const int k1 = kq + 1 < KQ ? kq + 1 : KQ - 1, k2 = kq + 2 < KQ ? kq + 2 : KQ - 1;
 #pragma unroll
-                for (int m = 0; m < MTW; ++m) a1[m] = A[((long long)mts[m] * KQ + kq + 1) * 64];
-                b1[0] = bb[(2 * (kq + 1)) * 64]; b1[1] = bb[(2 * (kq + 1) + 1) * 64];
-            }
+            for (int m = 0; m < MTW; ++m) a1[m] = A[((long long)mts[m] * KQ + k1) * 64];
+            b1[0] = bb[(2 * k1) * 64]; b1[1] = bb[(2 * k1 + 1) * 64];
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -381,12 +381,10 @@ lg_gemm2_kernel(LgGemmArgs a) {
                     acc[m][0] = mfma4(a0[m][j], b0[0][j], acc[m][0]);
                     acc[m][1] = mfma4(a0[m][j], b0[1][j], acc[m][1]);
                 }
-            if (has1) {
-                if (has2) {
 #pragma unroll
-                    for (int m = 0; m < MTW; ++m) a0[m] = A[((long long)mts[m] * KQ + kq + 2) * 64];
-                    b0[0] = bb[(2 * (kq + 2)) * 64]; b0[1] = bb[(2 * (kq + 2) + 1) * 64];
-                }
+            for (int m = 0; m < MTW; ++m) a0[m] = A[((long long)mts[m] * KQ + k2) * 64];
+            b0[0] = bb[(2 * k2) * 64]; b0[1] = bb[(2 * k2 + 1) * 64];
+            if (kq + 1 < KQ) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -398,7 +396,7 @@ lg_gemm2_kernel(LgGemmArgs a) {
         }
 #pragma unroll
         for (int m = 0; m < MTW; ++m) {
-            const int mt = mt_lo + wave + 4 * m;
+            const int mt = mt_lo + wave + NW * m;
             if (mt >= mt_hi) continue;
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
@@ -411,10 +409,10 @@ lg_gemm2_kernel(LgGemmArgs a) {
     }
 }
 
-template <int MTW, int EPI>
+template <int MTW, int EPI, int NW = 4>
 static hipError_t lg_gemm2_launch(const LgGemmArgs& a, hipStream_t st) {
     const int lds = 2 * a.KQ * 2 * 64 * 16;
-    auto kern = lg_gemm2_kernel<MTW, EPI>;
+    auto kern = lg_gemm2_kernel<MTW, EPI, NW>;
     static DeviceOnce once;
     int dev = 0;
     hipError_t e0 = hipGetDevice(&dev);
@@ -425,7 +423,7 @@ static hipError_t lg_gemm2_launch(const LgGemmArgs& a, hipStream_t st) {
         once.set(dev);
     }
     const long long nsub = (a.N + 31) / 32;
-    hipLaunchKernelGGL(kern, dim3((unsigned)((nsub + a.spw - 1) / a.spw), (unsigned)((a.MT + a.mts - 1) / a.mts)), dim3(256), lds, st, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)((nsub + a.spw - 1) / a.spw), (unsigned)((a.MT + a.mts - 1) / a.mts)), dim3(64 * NW), lds, st, a);
     return hipGetLastError();
 }
 
@@ -466,11 +464,13 @@ static hipError_t lg_gemm_dispatch(LgGemmArgs a, hipStream_t st) {
         if (spw > 8) spw = 8;
         if (spw_env > 0) spw = spw_env;
         a.spw = (int)spw;
+        static const int nw = [] { const char* v = getenv("CNF_LG_NW"); return v && *v ? atoi(v) : 4; }();
+        if (nw == 8 && a.mts > 8) return lg_gemm2_launch<2, EPI, 8>(a, st);   // 9..16 row tiles over 8 waves
         if (a.mts <= 4) return lg_gemm2_launch<1, EPI>(a, st);
         if (a.mts <= 8) return lg_gemm2_launch<2, EPI>(a, st);
         return lg_gemm2_launch<4, EPI>(a, st);
     }
-    const bool wide = a.KQ * 8 * 1024 <= 160 * 1024 && a.N * splits >= 128 * 192;
+    const bool wide = variant != 3 && a.KQ * 8 * 1024 <= 160 * 1024 && a.N * splits >= 128 * 192;
     if (a.mts <= 4) return wide ? lg_gemm_launch<1, 8, EPI>(a, st) : lg_gemm_launch<1, 4, EPI>(a, st);
     if (a.mts <= 8) return wide ? lg_gemm_launch<2, 8, EPI>(a, st) : lg_gemm_launch<2, 4, EPI>(a, st);
     return wide ? lg_gemm_launch<4, 8, EPI>(a, st) : lg_gemm_launch<4, 4, EPI>(a, st);
