@@ -37,10 +37,17 @@ namespace cnf {
 // fragment loads wait for them.  cfg4: 25.7 ms without, 28.7 ms with c alone, 27.6 - 29.0 ms with both.)
 
 // A fragments of k-group kg for M-tiles mt0 .. mt0 + M - 1 (global image, 16 B per lane, coalesced); A already points at the lane
+// (buffer loads: the image offset of the fragment is wave-uniform and rides in an SGPR, the lane's 16-byte slot in a VGPR
+// that never changes - no address VALU in the loop; f32 MFMAs and VALU instructions share the issue slot)
+struct AImg { __amdgpu_buffer_rsrc_t r; unsigned off; unsigned lane16; };
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 template <int M>
-__device__ __forceinline__ void coop_load_a(const f32x4* __restrict__ A, int mt0, int KG, int kg, f32x4 (&a)[M]) {
+__device__ __forceinline__ void coop_load_a(const AImg& A, int mt0, int KG, int kg, f32x4 (&a)[M]) {
 #pragma unroll
-    for (int m = 0; m < M; ++m) a[m] = A[((mt0 + m) * KG + kg) * 64];
+    for (int m = 0; m < M; ++m) {
+        const unsigned so = A.off + (unsigned)(((mt0 + m) * KG + kg) * 1024);
+        a[m] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(A.r, (int)A.lane16, (int)so, 0));
+    }
 }
 // B fragments of k-group kg for sample tiles nt0 .. nt0 + NQ - 1 (LDS exchange image, conflict-free ds_read_b128)
 // (NT = sample tiles of the super-tile = tiles per k-group in the image)
@@ -64,7 +71,7 @@ __device__ __forceinline__ void coop_frag_mfma(const f32x4 (&a)[M], const f32x4 
 // fragments of k-group 0 (requested by the caller one phase earlier).  Two fragment sets ping-pong (k-loop unrolled by 2): the
 // loads of k-group kg+1 - A from L2, B from LDS - are issued before the 16 M NQ MFMAs of k-group kg.
 template <int M, int NQ, int NT>
-__device__ __forceinline__ void coop_gemm(const f32x4* __restrict__ A, int mt0, int KG,
+__device__ __forceinline__ void coop_gemm(const AImg& A, int mt0, int KG,
                                           const f32x4* __restrict__ bimg, int nt0, int lane,
                                           f32x4 (&a0)[M], f32x4 (&acc)[M][NQ]) {
     f32x4 a1[M], b0[NQ], b1[NQ];
@@ -101,7 +108,10 @@ __device__ __forceinline__ void coop_eval(const float* __restrict__ P, f32x4* __
     const bool owner = wave < NT;                                        // this wave integrates sample tile `wave`
     const int g = lane >> 4;
     const int mt0 = wave * MTW;
-    const f32x4* __restrict__ Pq = reinterpret_cast<const f32x4*>(P) + lane;   // image offsets are multiples of 4 floats
+    // image offsets are multiples of 4 floats; fragment loads go through a buffer resource over the packed image
+    const __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P), 0, 0x7fffffff, 0x00020000);
+    const unsigned lane16 = (unsigned)lane * 16u;
+#define AIMG(X) AImg{rP, (unsigned)(X) * 4u, lane16}
     f32x4 afr[MTW];                      // first A fragments of the next H-row product, requested one phase ahead
     f32x4 afd[DT];                       // ... of the next D-row product (last layer, W_1^T)
     // act' of this wave's features, kept for the pullback - except the LAST hidden layer's when it can be rebuilt from the
@@ -113,7 +123,7 @@ __device__ __forceinline__ void coop_eval(const float* __restrict__ P, f32x4* __
     // ---- layer 1 ----
     {
         f32x4 bias[MTW], wt[MTW];
-        coop_load_a<MTW>(Pq + LAY.f1z / 4, mt0, DT, 0, afr);
+        coop_load_a<MTW>(AIMG(LAY.f1z), mt0, DT, 0, afr);
         gload_cvec<MTW>(P + LAY.v_b1, mt0, g, bias);
         gload_cvec<MTW>(P + LAY.v_w1t, mt0, g, wt);
         // publish this wave's stage state as the B image of sample tile `wave`
@@ -134,7 +144,7 @@ __device__ __forceinline__ void coop_eval(const float* __restrict__ P, f32x4* __
         }
         __syncthreads();
         phase_fence();
-        coop_gemm<MTW, NT, NT>(Pq + LAY.f1z / 4, mt0, DT, zbuf, 0, lane, afr, acc);
+        coop_gemm<MTW, NT, NT>(AIMG(LAY.f1z), mt0, DT, zbuf, 0, lane, afr, acc);
         phase_fence();
     }
     // cur = exchange buffer holding the current layer's activations (compile-time after unrolling)
@@ -142,8 +152,8 @@ __device__ __forceinline__ void coop_eval(const float* __restrict__ P, f32x4* __
     for (int l = 0; l < L; ++l) {
         const int cur = l & 1;
         // request what the NEXT product needs before this layer's activation / exchange / barrier phase
-        if (l + 1 < L) coop_load_a<MTW>(Pq + (LAY.fh + l * MfmaLayout::imgA(HT, HT)) / 4, mt0, HT, 0, afr);
-        else if (owner) coop_load_a<DT>(Pq + LAY.fN / 4, 0, HT, 0, afd);
+        if (l + 1 < L) coop_load_a<MTW>(AIMG(LAY.fh + l * MfmaLayout::imgA(HT, HT)), mt0, HT, 0, afr);
+        else if (owner) coop_load_a<DT>(AIMG(LAY.fN), 0, HT, 0, afd);
 #pragma unroll
         for (int m = 0; m < MTW; ++m)
 #pragma unroll
@@ -165,7 +175,7 @@ __device__ __forceinline__ void coop_eval(const float* __restrict__ P, f32x4* __
         __syncthreads();
         if (l + 1 < L) {
             phase_fence();
-            coop_gemm<MTW, NT, NT>(Pq + (LAY.fh + l * MfmaLayout::imgA(HT, HT)) / 4, mt0, HT, xbuf + cur * XB, 0, lane, afr, acc);
+            coop_gemm<MTW, NT, NT>(AIMG(LAY.fh + l * MfmaLayout::imgA(HT, HT)), mt0, HT, xbuf + cur * XB, 0, lane, afr, acc);
             phase_fence();
         }
     }
@@ -178,7 +188,7 @@ __device__ __forceinline__ void coop_eval(const float* __restrict__ P, f32x4* __
 #pragma unroll
         for (int m = 0; m < DT; ++m) zacc[m][0] = bias[m];
         phase_fence();
-        coop_gemm<DT, 1, NT>(Pq + LAY.fN / 4, 0, HT, xbuf + hbuf * XB, wave, lane, afd, zacc);
+        coop_gemm<DT, 1, NT>(AIMG(LAY.fN), 0, HT, xbuf + hbuf * XB, wave, lane, afd, zacc);
         phase_fence();
 #pragma unroll
         for (int s = 0; s < ZR; ++s) zd[s] = zacc[s >> 2][0][s & 3];
@@ -197,9 +207,9 @@ __device__ __forceinline__ void coop_eval(const float* __restrict__ P, f32x4* __
         for (int m = 0; m < MTW; ++m)
 #pragma unroll
             for (int q = 0; q < NT; ++q) acc[m][q] = f32x4{0.f, 0.f, 0.f, 0.f};
-        coop_load_a<MTW>(Pq + LAY.bN / 4, mt0, DT, 0, afr);
-        coop_gemm<MTW, NT, NT>(Pq + LAY.bN / 4, mt0, DT, ebuf, 0, lane, afr, acc);
-        if (L > 1) coop_load_a<MTW>(Pq + (LAY.bh + (L - 2) * MfmaLayout::imgA(HT, HT)) / 4, mt0, HT, 0, afr);
+        coop_load_a<MTW>(AIMG(LAY.bN), mt0, DT, 0, afr);
+        coop_gemm<MTW, NT, NT>(AIMG(LAY.bN), mt0, DT, ebuf, 0, lane, afr, acc);
+        if (L > 1) coop_load_a<MTW>(AIMG(LAY.bh + (L - 2) * MfmaLayout::imgA(HT, HT)), mt0, HT, 0, afr);
     }
 #pragma unroll
     for (int l = L - 1; l >= 0; --l) {
@@ -225,7 +235,7 @@ __device__ __forceinline__ void coop_eval(const float* __restrict__ P, f32x4* __
 #pragma unroll
             for (int q = 0; q < NT; ++q) xbuf[wbuf * XB + ((mt0 + m) * NT + q) * 64 + lane] = dl[q];
         }
-        if (l == 0 && owner) coop_load_a<DT>(Pq + LAY.b1 / 4, 0, HT, 0, afd);
+        if (l == 0 && owner) coop_load_a<DT>(AIMG(LAY.b1), 0, HT, 0, afd);
         __syncthreads();
         if (l > 0) {
 #pragma unroll
@@ -233,16 +243,16 @@ __device__ __forceinline__ void coop_eval(const float* __restrict__ P, f32x4* __
 #pragma unroll
                 for (int q = 0; q < NT; ++q) acc[m][q] = f32x4{0.f, 0.f, 0.f, 0.f};
             phase_fence();
-            coop_gemm<MTW, NT, NT>(Pq + (LAY.bh + (l - 1) * MfmaLayout::imgA(HT, HT)) / 4, mt0, HT, xbuf + wbuf * XB, 0, lane, afr, acc);
+            coop_gemm<MTW, NT, NT>(AIMG(LAY.bh + (l - 1) * MfmaLayout::imgA(HT, HT)), mt0, HT, xbuf + wbuf * XB, 0, lane, afr, acc);
             phase_fence();
-            if (l > 1) coop_load_a<MTW>(Pq + (LAY.bh + (l - 2) * MfmaLayout::imgA(HT, HT)) / 4, mt0, HT, 0, afr);
+            if (l > 1) coop_load_a<MTW>(AIMG(LAY.bh + (l - 2) * MfmaLayout::imgA(HT, HT)), mt0, HT, 0, afr);
         } else if (owner) {
             // g = W_1[:,0:D]^T delta_1 for this wave's own sample tile (needed for |eps^T J|)
             f32x4 gacc[DT][1];
 #pragma unroll
             for (int m = 0; m < DT; ++m) gacc[m][0] = f32x4{0.f, 0.f, 0.f, 0.f};
             phase_fence();
-            coop_gemm<DT, 1, NT>(Pq + LAY.b1 / 4, 0, HT, xbuf + wbuf * XB, wave, lane, afd, gacc);
+            coop_gemm<DT, 1, NT>(AIMG(LAY.b1), 0, HT, xbuf + wbuf * XB, wave, lane, afd, gacc);
             phase_fence();
             // this lane's probe values sit in the B image of eps (k-group kg, own sample tile): no registers held for them
             float dot = 0.f, n2 = 0.f;
