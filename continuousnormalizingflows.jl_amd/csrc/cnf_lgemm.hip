@@ -342,7 +342,13 @@ lg_gemm2_kernel(LgGemmArgs a) {
             if (u < nunits) bimg[buf * bufsz + u * 64 + lane] = stage[i];
         }
     };
-    const f32x4* __restrict__ A = reinterpret_cast<const f32x4*>(a.img) + lane;
+    // weight fragments: buffer loads, the fragment's image offset wave-uniform in an SGPR, the lane's 16-byte slot in a VGPR
+    // that never changes (no address VALU in the loop)
+    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.img), 0, 0x7fffffff, 0x00020000);
+    const int lane16 = lane * 16;
+    auto ldA = [&](int mt, int kq) {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rA, lane16, (mt * KQ + kq) * 1024, 0));
+    };
     const int mt_lo = blockIdx.y * a.mts;
     const int mt_hi = mt_lo + a.mts < a.MT ? mt_lo + a.mts : a.MT;
     int mts[MTW];
@@ -363,7 +369,7 @@ lg_gemm2_kernel(LgGemmArgs a) {
         for (int m = 0; m < MTW; ++m) acc[m][0] = acc[m][1] = f32x4{0.f, 0.f, 0.f, 0.f};
         f32x4 a0[MTW], a1[MTW], b0[2], b1[2];
 #pragma unroll
-        for (int m = 0; m < MTW; ++m) a0[m] = A[((long long)mts[m] * KQ + 0) * 64];
+        for (int m = 0; m < MTW; ++m) a0[m] = ldA(mts[m], 0);
         b0[0] = bb[0]; b0[1] = bb[64];
         // The prefetch loads are UNCONDITIONAL (k-group index clamped at the end): a load inside an `if` makes a control-flow
         // join at which the compiler's wait-count insertion assumes the worst and waits for everything outstanding
@@ -372,7 +378,7 @@ lg_gemm2_kernel(LgGemmArgs a) {
         for (int kq = 0; kq < KQ; kq += 2) {
             const int k1 = kq + 1 < KQ ? kq + 1 : KQ - 1, k2 = kq + 2 < KQ ? kq + 2 : KQ - 1;
 #pragma unroll
-            for (int m = 0; m < MTW; ++m) a1[m] = A[((long long)mts[m] * KQ + k1) * 64];
+            for (int m = 0; m < MTW; ++m) a1[m] = ldA(mts[m], k1);
             b1[0] = bb[(2 * k1) * 64]; b1[1] = bb[(2 * k1 + 1) * 64];
 #pragma unroll
             for (int j = 0; j < 4; ++j)
@@ -382,7 +388,7 @@ lg_gemm2_kernel(LgGemmArgs a) {
                     acc[m][1] = mfma4(a0[m][j], b0[1][j], acc[m][1]);
                 }
 #pragma unroll
-            for (int m = 0; m < MTW; ++m) a0[m] = A[((long long)mts[m] * KQ + k2) * 64];
+            for (int m = 0; m < MTW; ++m) a0[m] = ldA(mts[m], k2);
             b0[0] = bb[(2 * k2) * 64]; b0[1] = bb[(2 * k2 + 1) * 64];
             if (kq + 1 < KQ) {
 #pragma unroll
