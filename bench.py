@@ -361,27 +361,24 @@ def measure(w, a, steps, warmup, preroll_s, pkg, torch, dist, world, dev, probe)
         tt = torch.tensor([n_pre], device=dev, dtype=torch.int64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         n_pre = int(tt.item())
-    sustained = None
+    # Everything the timed region needs is allocated BEFORE the pre-roll, and the pre-roll's statistics are read out AFTER the
+    # timed region: between the pre-roll's synchronize and the first timed launch the GPU idles for one host round trip only.
+    # (Reading several hundred event pairs and clock probes in between left it idle for milliseconds - long enough for DVFS
+    # to drop the clock: the first of K = 20 timed launches then took 3.4 ms instead of 2.96 and moved the mean by 1.5 %.)
+    ev_pre = events(n_pre) if n_pre > 0 else []
+    ev = events(steps)
+    pre_wall = 0.0
     if n_pre > 0:
-        ev = events(n_pre)
         t = time.perf_counter()
         for i in range(n_pre):
-            launch(ev[i])
+            launch(ev_pre[i])
             if i % 16 == 15:
                 probe.sample()
         sync()
         pre_wall = time.perf_counter() - t
-        ms = [s.elapsed_time(e) for s, e in ev]
-        fq, lq, med = _quarters(ms)
-        mhz = probe.drain()
-        sustained = dict(launches=n_pre, seconds=pre_wall, first_quarter_ms=fq, last_quarter_ms=lq, median_ms=med,
-                         clock_mhz=(dict(first_quarter=float(np.mean(mhz[:max(1, len(mhz) // 4)])),
-                                         last_quarter=float(np.mean(mhz[-max(1, len(mhz) // 4):])),
-                                         min=float(np.min(mhz)), max=float(np.max(mhz)), probes=len(mhz))
-                                    if mhz else None))
+    else:
+        sync()
     # ---- the timed region: exactly `steps` steps ----
-    ev = events(steps)
-    sync()
     t0 = time.perf_counter()
     for i in range(steps):
         launch(ev[i])
@@ -391,6 +388,16 @@ def measure(w, a, steps, warmup, preroll_s, pkg, torch, dist, world, dev, probe)
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+    sustained = None
+    if n_pre > 0:
+        ms_pre = [s.elapsed_time(e) for s, e in ev_pre]
+        fq, lq, med = _quarters(ms_pre)
+        mhz = probe.drain()
+        sustained = dict(launches=n_pre, seconds=pre_wall, first_quarter_ms=fq, last_quarter_ms=lq, median_ms=med,
+                         clock_mhz=(dict(first_quarter=float(np.mean(mhz[:max(1, len(mhz) // 4)])),
+                                         last_quarter=float(np.mean(mhz[-max(1, len(mhz) // 4):])),
+                                         min=float(np.min(mhz)), max=float(np.max(mhz)), probes=len(mhz))
+                                    if mhz else None))
     ms = [s.elapsed_time(e) for s, e in ev]
     probe.sample()
     torch.cuda.synchronize(dev)
