@@ -2,7 +2,7 @@
 """bench.py — throughput of the batched log-density hot path on MI355X.
 
 A "step" is one pass of the hot path over one batch: `loss(icnf, mode, xs, ps, st)` =
-cnf_inference_fixed (fused fixed-step solve + log-density epilogue) + cnf_loss_sums (+ the
+cnf_inference_fixed (fused fixed-step solve + log-density epilogue) + cnf_loss_mean (N = 1; cnf_loss_sums + the
 RCCL all-reduce of the loss scalars when N > 1), with inputs already resident in HBM.
 Metric (BASELINE.json): log-density evaluations counted as samples·steps per second.
 
@@ -335,8 +335,11 @@ def measure(w, a, steps, warmup, preroll_s, pkg, torch, dist, world, dev, probe)
         logp, regs = pkg.inference(icnf, mode, *args, eps=E, _raw=True)
         if ev is not None:
             ev[1].record()
-        sums = pkg.loss_sums(icnf, mode, logp, regs)
-        state["loss"] = pkg.reduce_loss(sums, B, (icnf.lambda1, icnf.lambda2, icnf.lambda3))
+        if world == 1:     # one process: the mean comes out of the library's two reduction kernels (cnf_loss_mean), as in pkg.loss
+            state["loss"] = pkg.loss_mean(icnf, mode, logp, regs)
+        else:
+            sums = pkg.loss_sums(icnf, mode, logp, regs)
+            state["loss"] = pkg.reduce_loss(sums, B, (icnf.lambda1, icnf.lambda2, icnf.lambda3))
 
     def sync():
         torch.cuda.synchronize(dev)

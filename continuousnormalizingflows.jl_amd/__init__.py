@@ -7,7 +7,7 @@ not a valid Python identifier; `__graft_entry__.load_package()` registers it as 
 """
 from . import _lib
 from .icnf import *  # noqa: F401,F403
-from .icnf import loss_sums  # noqa: F401
+from .icnf import loss_sums, loss_mean  # noqa: F401
 from .icnf import loss_and_gradient  # noqa: F401
 from .sharding import Comm, get_comm, reduce_gradient, reduce_loss, set_comm, shard_columns  # noqa: F401
 from .adapters import *  # noqa: F401,F403

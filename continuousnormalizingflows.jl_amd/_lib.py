@@ -31,7 +31,7 @@ DTYPE_F32, DTYPE_F64 = 0, 1
 
 EXPORTS = ("cnf_version", "cnf_last_error", "cnf_create", "cnf_destroy", "cnf_set_params",
            "cnf_kernel_path", "cnf_solve_controller", "cnf_repack_on_device", "cnf_aug_f", "cnf_integrate_fixed", "cnf_inference_fixed",
-           "cnf_loss_sums", "cnf_loss_grad_fixed", "cnf_loss_grad_grid", "cnf_grad_path", "cnf_step_embedded", "cnf_assemble_u0",
+           "cnf_loss_sums", "cnf_loss_mean", "cnf_loss_grad_fixed", "cnf_loss_grad_grid", "cnf_grad_path", "cnf_step_embedded", "cnf_assemble_u0",
            "cnf_epilogue", "cnf_vcabm_begin", "cnf_vcabm_attempt", "cnf_vcabm_accept", "cnf_vcabm_state", "cnf_solve_vcabm", "cnf_solve_tsit5", "cnf_loss_grad_adaptive",
            "cnf_integrate_fixed_dt", "cnf_inference_fixed_dt",
            "cnf_comm_unique_id", "cnf_comm_init", "cnf_comm_init_all", "cnf_comm_destroy", "cnf_comm_rank", "cnf_comm_size",
@@ -117,6 +117,7 @@ def load():
     lib.cnf_integrate_fixed_dt.argtypes = [vp, C.c_int, C.c_float, C.c_float, C.c_float, fp, fp, fp, C.c_int64, fp, vp]
     lib.cnf_inference_fixed_dt.argtypes = [vp, C.c_int, C.c_float, C.c_float, C.c_float, fp, fp, fp, C.c_int64, fp, fp, fp, vp]
     lib.cnf_loss_sums.argtypes = [vp, fp, fp, C.c_int64, fp, vp]
+    lib.cnf_loss_mean.argtypes = [vp, fp, fp, C.c_int64, C.POINTER(C.c_double), fp, fp, vp]
     lib.cnf_loss_grad_fixed.argtypes = [vp, C.c_int, C.c_int, C.c_float, C.c_float, fp, fp, fp, C.c_int64,
                                         C.POINTER(C.c_float), fp, fp, fp, vp]
     lib.cnf_comm_unique_id.argtypes = [vp]

@@ -648,4 +648,14 @@ int cnf_loss_sums(cnf_handle* h, const float* logp, const float* regs, int64_t B
     return CNF_OK;
 }
 
+int cnf_loss_mean(cnf_handle* h, const float* logp, const float* regs, int64_t B, const double* lambdas, float* sums4,
+                  float* loss, void* stream) {
+    if (!h || !logp || !lambdas || !loss) return fail(CNF_ERR_INVALID, "cnf_loss_mean: null argument");
+    if (B < 1) return fail(CNF_ERR_INVALID, "cnf_loss_mean: the mean of an empty batch is undefined (use cnf_loss_sums on shards)");
+    DeviceGuard g(h->cfg.device_id);
+    if (!h->loss_partial) HIP_TRY(hipMalloc((void**)&h->loss_partial, 256 * 4 * sizeof(float)));
+    HIP_TRY(loss_mean(logp, regs, B, h->loss_partial, sums4, loss, lambdas, (hipStream_t)stream));
+    return CNF_OK;
+}
+
 }  // extern "C"

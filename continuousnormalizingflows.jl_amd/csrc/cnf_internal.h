@@ -37,6 +37,8 @@ hipError_t epilogue(const float* u, int nvars, int D, int reg_aug, int64_t B, fl
                     float* regs, hipStream_t st);
 hipError_t loss_sums(const float* logp, const float* regs, int64_t B, float* partial,
                      float* sums4, hipStream_t st);
+hipError_t loss_mean(const float* logp, const float* regs, int64_t B, float* partial, float* sums4, float* mean_out,
+                     const double lam[3], hipStream_t st);
 constexpr int kErrBlocks = 1024;  // partial sums of embedded_error
 hipError_t embedded_error(const float* u, const float* unew, const float* const* k, const float* btilde, int nk, float dt,
                           float abstol, float reltol, int64_t n, double* partial, double* out, hipStream_t st);

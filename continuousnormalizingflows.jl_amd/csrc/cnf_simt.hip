@@ -270,8 +270,11 @@ loss_partial_kernel(const float* __restrict__ logp, const float* __restrict__ re
             (sm[0][threadIdx.x] + sm[1][threadIdx.x]) + (sm[2][threadIdx.x] + sm[3][threadIdx.x]);
 }
 
+// mean_out (may be null): (s0 + l1 s1 + l2 s2 + l3 s3) / B in double - the scalar `loss` of an unsharded batch, so that a
+// single-process caller needs no further device work after the two reduction kernels
 __global__ void __launch_bounds__(256)
-loss_final_kernel(const float* __restrict__ partial, float* __restrict__ sums4) {
+loss_final_kernel(const float* __restrict__ partial, float* __restrict__ sums4, float* __restrict__ mean_out, double l1, double l2,
+                  double l3, double B) {
     // 256 threads: thread t sums column q = t&3 over blocks t>>2, t>>2 + 64, ...
     const int q = threadIdx.x & 3;
     float v = 0.f;
@@ -283,7 +286,14 @@ loss_final_kernel(const float* __restrict__ partial, float* __restrict__ sums4) 
         if ((int)threadIdx.x < st) sm[threadIdx.x] += sm[threadIdx.x + st];
         __syncthreads();
     }
-    if (threadIdx.x < 4) sums4[threadIdx.x] = sm[threadIdx.x];
+    if (threadIdx.x < 4 && sums4) sums4[threadIdx.x] = sm[threadIdx.x];
+    if (threadIdx.x == 0 && mean_out) {
+        double acc = (double)sm[0];
+        acc += (double)sm[1] * l1;
+        acc += (double)sm[2] * l2;
+        acc += (double)sm[3] * l3;
+        mean_out[0] = (float)(acc / B);
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -401,7 +411,14 @@ hipError_t embedded_error(const float* u, const float* unew, const float* const*
 hipError_t loss_sums(const float* logp, const float* regs, int64_t B, float* partial,
                      float* sums4, hipStream_t st) {
     hipLaunchKernelGGL(loss_partial_kernel, dim3(LOSS_BLOCKS), dim3(256), 0, st, logp, regs, B, partial);
-    hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(256), 0, st, partial, sums4);
+    hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(256), 0, st, partial, sums4, (float*)nullptr, 0.0, 0.0, 0.0, 1.0);
+    return hipGetLastError();
+}
+
+hipError_t loss_mean(const float* logp, const float* regs, int64_t B, float* partial, float* sums4, float* mean_out,
+                     const double lam[3], hipStream_t st) {
+    hipLaunchKernelGGL(loss_partial_kernel, dim3(LOSS_BLOCKS), dim3(256), 0, st, logp, regs, B, partial);
+    hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(256), 0, st, partial, sums4, mean_out, lam[0], lam[1], lam[2], (double)B);
     return hipGetLastError();
 }
 

@@ -684,6 +684,22 @@ def loss_sums(icnf: ICNF, mode: Mode, logp: torch.Tensor, regs) -> torch.Tensor:
     return sums
 
 
+def loss_mean(icnf: ICNF, mode: Mode, logp: torch.Tensor, regs) -> torch.Tensor:
+    """The scalar loss of an UNSHARDED batch from (logp, regs) in the library's two reduction kernels
+    (`cnf_loss_mean`): mean(-logp + λ₁Ė + λ₂ṅ + λ₃Ȧ), combined in float64, returned as a 0-dim float32 tensor."""
+    import ctypes as C
+    h = icnf._handle(mode)
+    B = logp.numel()
+    if B == 0:
+        return torch.full((), float("nan"), device=icnf.device, dtype=torch.float32)
+    r = torch.stack(list(regs)).contiguous() if not (
+        isinstance(regs, torch.Tensor) and regs.is_contiguous()) else regs
+    out = torch.empty(1, device=icnf.device, dtype=torch.float32)
+    lam = (C.c_double * 3)(float(icnf.lambda1), float(icnf.lambda2), float(icnf.lambda3))
+    _lib.check(h.lib.cnf_loss_mean(h.ptr, _ptr(logp.contiguous()), _ptr(r), B, lam, None, _ptr(out), _stream_ptr(icnf.device)))
+    return out[0]
+
+
 def loss(icnf: ICNF, mode: Mode, *args, eps: Optional[torch.Tensor] = None, group=None):
     """loss(icnf, mode, xs[, ys], ps, st) = mean(-logp̂x + λ₁Ė + λ₂ṅ + λ₃Ȧ)
     (src/core/icnf.jl:628-649).  When torch.distributed is initialised the batch columns are
@@ -691,7 +707,10 @@ def loss(icnf: ICNF, mode: Mode, *args, eps: Optional[torch.Tensor] = None, grou
     are all-reduced (RCCL over xGMI on GPUs) and every rank returns the global mean."""
     from .sharding import reduce_loss
     group = icnf._group(group)
+    from .sharding import is_sharded
     logp, regs = inference(icnf, mode, *args, eps=eps, _raw=True, group=group)
+    if not is_sharded(group) and logp.numel():
+        return loss_mean(icnf, mode, logp, regs)       # one process: the mean comes out of the reduction kernels themselves
     sums = loss_sums(icnf, mode, logp, regs)
     return reduce_loss(sums, logp.numel(), (icnf.lambda1, icnf.lambda2, icnf.lambda3), group=group)
 

@@ -27,7 +27,7 @@
  * Entry points
  *   lifetime / parameters    cnf_create, cnf_destroy, cnf_set_params
  *   boundary A (per call)    cnf_aug_f                      du = augmented_f(u, p, t)
- *   boundary B (whole solve) cnf_integrate_fixed, cnf_inference_fixed, cnf_integrate_fixed_dt, cnf_inference_fixed_dt, cnf_loss_sums
+ *   boundary B (whole solve) cnf_integrate_fixed, cnf_inference_fixed, cnf_integrate_fixed_dt, cnf_inference_fixed_dt, cnf_loss_sums, cnf_loss_mean
  *   caller-driven solves     cnf_assemble_u0, cnf_step_embedded (adaptive Tsit5 attempt), cnf_epilogue,
  *                            cnf_vcabm_begin / _attempt / _accept / _state, cnf_solve_vcabm (the reference's default alg VCABM), cnf_solve_tsit5
  *   training                 cnf_loss_grad_fixed, cnf_loss_grad_grid, cnf_loss_grad_adaptive  (dloss/dps, optionally dloss/dxs)
@@ -253,6 +253,12 @@ int cnf_inference_fixed(cnf_handle* h, int alg, int nsteps, float t0, float t1, 
  * all-reduce of these four scalars.  Deterministic (fixed-order tree, no float atomics). */
 int cnf_loss_sums(cnf_handle* h, const float* logp, const float* regs, int64_t B, float* sums4,
                   void* stream);
+
+/* The scalar loss(icnf, mode, xs[, ys], ps, st) of an UNSHARDED batch in the same two reduction kernels:
+ * loss[0] (device) = (s0 + l1 s1 + l2 s2 + l3 s3) / B, combined in double; lambdas = {l1, l2, l3} (host doubles);
+ * sums4 (device, may be NULL) as cnf_loss_sums.  B >= 1. */
+int cnf_loss_mean(cnf_handle* h, const float* logp, const float* regs, int64_t B, const double* lambdas, float* sums4,
+                  float* loss, void* stream);
 
 /* Gradient of the summed negative log-density with respect to the parameters, through the
  * fixed-step solve (discretise-then-optimise reverse mode):

@@ -228,6 +228,26 @@ def _forward_error_bound(spec, p, u, t, c_hidden, c_edge, c_act):
     return h, err
 
 
+def test_loss_mean_equals_the_mean_of_the_partial_sums(pkg, oracles):
+    """cnf_loss_mean (the scalar loss of an unsharded batch out of the two reduction kernels) against cnf_loss_sums + the
+    float64 combination a sharded caller performs after its all-reduce: the same bits; and against a float64 host mean."""
+    o64, _ = oracles
+    spec = o64.make_spec(nvars=8, hidden=[64, 64, 64], reg_z=True, reg_j=True)
+    B = 777
+    p, xs, eps, _ = o64.synth_inputs(spec, B, 31, bias_scale=0.3)
+    icnf = make_icnf(pkg, spec, 1, 10)
+    icnf.lambda1, icnf.lambda2 = 0.02, 0.03
+    m = pkg.TrainMode(True)
+    logp, regs = pkg.inference(icnf, m, dev(xs), dev(p), {}, eps=dev(eps), _raw=True)
+    a = pkg.loss_mean(icnf, m, logp, regs)
+    sums = pkg.loss_sums(icnf, m, logp, regs)
+    b = pkg.reduce_loss(sums, B, (icnf.lambda1, icnf.lambda2, icnf.lambda3), group=False)
+    assert a.shape == () and torch.equal(a, b)
+    host = float((-logp.double() + 0.02 * regs[0].double() + 0.03 * regs[1].double()).mean())
+    assert abs(float(a) - host) < 2e-6 * max(1.0, abs(host))
+    assert abs(float(pkg.loss(icnf, m, dev(xs), dev(p), {}, eps=dev(eps))) - float(a)) == 0.0
+
+
 def test_split_bf16_error_bound_holds_on_adversarial_products(pkg, oracles):
     """the six-term split-bf16 product obeys |err| <= (4 u + gamma_{6K}) sum_k |a_k| |b_k| (u = 2^-24, K the
     contraction length; gamma_n = n u / (1 - n u)) under ANY accumulation order inside v_mfma_f32_16x16x32_bf16, against
