@@ -586,33 +586,25 @@ lg_wgrad_kernel(LgWgradArgs a) {
     const float* __restrict__ Yc = Y + c0 * (long long)a.ldy;     // wave-uniform bases of the chunk
     const float* __restrict__ Xc = a.x + c0 * (long long)a.ldx;
     const int nrem = (int)(c1 - c0);
-    // (buffer loads: lane byte offset in a VGPR that never changes, the sample's byte offset in an SGPR - no address VALU)
-    const __amdgpu_buffer_rsrc_t rY = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Yc), 0, 0x7fffffff, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Xc), 0, 0x7fffffff, 0x00020000);
+    // (buffer loads: lane byte offset in a VGPR that never changes, the sample's byte offset in an SGPR - no address VALU.
+    // The resources end exactly behind the chunk's last sample, so a slice that reaches past the chunk reads zeros there and
+    // the fetch needs NO branch: a load inside an `if` makes a control-flow join at which the compiler's wait-count
+    // insertion waits for everything outstanding - which would shorten the two-slice prefetch to one.)
+    const __amdgpu_buffer_rsrc_t rY =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Yc), 0, (int)((((long long)nrem - 1) * a.ldy + Nc) * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rX =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Xc), 0, (int)((((long long)nrem - 1) * a.ldx + a.M) * 4), 0x00020000);
     auto at = [](__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
         return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
     };
     auto fetch = [&](int s, Slice& sl) {                          // s: first sample of the slice, relative to c0
-        if (s + 16 <= nrem) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const unsigned ys = 4u * (unsigned)(s + 4 * u + wave) * (unsigned)a.ldy;   // wave-uniform byte offsets
-                const unsigned xs = 4u * (unsigned)(s + 4 * u + wave) * (unsigned)a.ldx;
+        for (int u = 0; u < 4; ++u) {
+            const unsigned ys = 4u * (unsigned)(s + 4 * u + wave) * (unsigned)a.ldy;   // wave-uniform byte offsets
+            const unsigned xs = 4u * (unsigned)(s + 4 * u + wave) * (unsigned)a.ldx;
 #pragma unroll
-                for (int i = 0; i < RY; ++i) sl.yv[i][u] = at(rY, yoff[i], ys);
-                sl.xv[u] = at(rX, xoff, xs);
-            }
-        } else {                                                  // ragged end of the batch, or past the chunk: zeros
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int gs = s + 4 * u + wave;
-                const bool sv = gs < nrem;
-                const unsigned ys = 4u * (unsigned)(sv ? gs : 0) * (unsigned)a.ldy;
-                const unsigned xs = 4u * (unsigned)(sv ? gs : 0) * (unsigned)a.ldx;
-#pragma unroll
-                for (int i = 0; i < RY; ++i) sl.yv[i][u] = sv ? at(rY, yoff[i], ys) : 0.f;
-                sl.xv[u] = sv ? at(rX, xoff, xs) : 0.f;
-            }
+            for (int i = 0; i < RY; ++i) sl.yv[i][u] = at(rY, yoff[i], ys);
+            sl.xv[u] = at(rX, xoff, xs);
         }
     };
     auto park = [&](int buf, const Slice& sl) {
