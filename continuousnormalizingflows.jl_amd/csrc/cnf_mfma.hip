@@ -438,7 +438,10 @@ int64_t mfma_adaptive_capacity(MfmaPlan* p) {
         int occ = 0;
         const hipError_t e = p->launch_adapt(KArgs{}, AArgs{}, p->lay.lds_total * (int)sizeof(float), 0, nullptr, &occ);
         if (e != hipSuccess) { (void)hipGetLastError(); occ = 0; }
-        p->adapt_per_cu = occ;
+        // one workgroup per CU: what the kernel is compiled for (waves_per_eu) and what the tests cover; a second resident
+        // workgroup (possible when the register count happens to allow it) only halves the active waves per workgroup
+        const int cap_env = env_int("CNF_DC_PER_CU", 1);
+        p->adapt_per_cu = occ < cap_env ? occ : cap_env;
     }
     return (int64_t)p->num_cus * p->adapt_per_cu * (p->nthreads / 64) * 16;
 }
@@ -519,7 +522,8 @@ int64_t mfma_vcabm_capacity(MfmaPlan* p) {
         int occ = 0;
         const hipError_t e = p->launch_vcabm(KArgs{}, AArgs{}, p->lay.lds_total * (int)sizeof(float), 0, nullptr, &occ);
         if (e != hipSuccess) { (void)hipGetLastError(); occ = 0; }
-        p->vcabm_per_cu = occ;
+        const int cap_env = env_int("CNF_DC_PER_CU", 1);
+        p->vcabm_per_cu = occ < cap_env ? occ : cap_env;
     }
     return (int64_t)p->num_cus * p->vcabm_per_cu * 4 * 16;
 }

@@ -650,11 +650,47 @@ mfma_solve_kernel(KArgs a) {
 // embedded estimate dt sum btilde_i k_i scaled by abstol + reltol max(|u|, |u_new|), RMS over the whole S x B state, PI
 // controller, first-same-as-last), for batches of at most one tile per resident wave.  The host loop pays 3-4 launches and
 // a device-to-host round trip per attempt (~70 us); here an attempt costs its six dynamics calls and one grid-wide sum.
+// Sum of a double over the 64 lanes, the same bits in every lane (each step adds a lane's value to its partner's, and the
+// partner does the mirror-image addition).  Within a row of 16 lanes the partners come from DPP modifiers (quad permutes,
+// half-row and row mirrors), across rows from the gfx950 row / half swaps - all VALU-speed; the shuffle form
+// (`__shfl_xor` on a double = two ds_bpermute_b32 + an LDS round trip per step, six steps) cost ~2 us per call, and a
+// grid-wide sum makes two calls for each of its three values.
+#ifdef CNF_WAVE_SUM_SHFL
 __device__ __forceinline__ double wave_sum_f64(double v) {
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
     return v;
 }
+#else
+__device__ __forceinline__ double wave_sum_f64(double v) {
+    auto halves = [](double x, unsigned& lo, unsigned& hi) {
+        const unsigned long long b = __builtin_bit_cast(unsigned long long, x);
+        lo = (unsigned)b; hi = (unsigned)(b >> 32);
+    };
+    auto whole = [](unsigned lo, unsigned hi) { return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo); };
+    unsigned lo, hi;
+#define CNF_DPP_STEP(CTRL)                                                                       \
+    halves(v, lo, hi);                                                                           \
+    v += whole((unsigned)__builtin_amdgcn_update_dpp(0, (int)lo, CTRL, 0xf, 0xf, false),        \
+               (unsigned)__builtin_amdgcn_update_dpp(0, (int)hi, CTRL, 0xf, 0xf, false));
+    CNF_DPP_STEP(0xB1)    // quad_perm [1,0,3,2]: lane ^ 1
+    CNF_DPP_STEP(0x4E)    // quad_perm [2,3,0,1]: lane ^ 2
+    CNF_DPP_STEP(0x141)   // row_half_mirror: i <-> 7 - i (the other quad of the 8)
+    CNF_DPP_STEP(0x140)   // row_mirror: i <-> 15 - i (the other 8 of the row)
+#undef CNF_DPP_STEP
+    halves(v, lo, hi);
+    {   // rows 16 apart
+        const u32x2_t a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false), b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+        v = whole(a[0], b[0]) + whole(a[1], b[1]);
+    }
+    halves(v, lo, hi);
+    {   // halves 32 apart
+        const u32x2_t a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false), b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+        v = whole(a[0], b[0]) + whole(a[1], b[1]);
+    }
+    return v;
+}
+#endif
 
 // Grid-wide sums of three per-lane values over all tiles, in two levels: the waves of a workgroup meet in LDS, wave 0 of every
 // workgroup publishes the workgroup's partial, arrives at the counter, waits for the other workgroups, and adds the

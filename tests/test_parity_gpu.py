@@ -1966,6 +1966,8 @@ def test_adaptive_tsit5_library_policy_is_the_host_loop(pkg, oracles, monkeypatc
     (dict(nvars=8, hidden=[64, 64, 64], autonomous=True), 32763, 1e-4, None),               # every wave slot of the chip, ragged last tile
     (dict(nvars=9, naug=10, hidden=[80, 80], act=2, autonomous=True), 100, 1e-4, None),     # reference default net for nvariables = 9
     (dict(nvars=2, naug=3, ncond=2, hidden=[32, 32], act=2, autonomous=True), 300, 1e-4, None),   # conditioned default-style net
+    (dict(nvars=2, hidden=[32, 32], autonomous=True), 6000, 1e-4, None),                    # 375 tiles on 256 workgroups: one or two of the eight waves own a tile
+    (dict(nvars=2, hidden=[32, 32], autonomous=True), 16384, 1e-4, None),                   # four of the eight
 ])
 def test_device_side_step_controller_is_the_host_loop(kw, B, tol, dt0, pkg, oracles, monkeypatch):
     """Adaptive Tsit5 in ONE launch (mfma_adaptive_kernel: grid-wide error norm, PI controller in every wave) against the
@@ -2021,6 +2023,8 @@ def test_device_side_step_controller_is_the_host_loop(kw, B, tol, dt0, pkg, orac
     (dict(nvars=9, naug=10, hidden=[80, 80], act=2), 100, 1e-4, None),                      # reference default net for nvariables = 9 (8 state k-steps)
     (dict(nvars=2, naug=3, ncond=2, hidden=[32, 32], act=2), 300, 1e-4, None),              # conditioned default-style net
     (dict(nvars=2, naug=3, ncond=2, hidden=[32, 32], act=2, mode=2), 64, 1e-5, None),       # ... TestMode
+    (dict(nvars=2, hidden=[32, 32]), 6000, 1e-4, None),                                     # 375 tiles on 256 workgroups: one or two of the four waves own a tile
+    (dict(nvars=2, hidden=[32, 32]), 16384, 1e-4, None),                                    # a small net at the kernel's capacity (one workgroup per CU)
 ])
 def test_default_solver_on_the_device_is_the_host_policy(kw, B, tol, dt0, pkg, oracles, monkeypatch):
     """The reference's default solver VCABM in ONE launch (mfma_vcabm_kernel: predictor, corrector and order-raising passes per
