@@ -45,7 +45,8 @@ struct AArgs {
     double* slots;      // [2 (round parity)][3][workgroups]
     unsigned* counter;  // arrivals, zeroed on the stream before the launch
     float* dts;         // accepted steps, dts_cap entries
-    int* stats;         // naccept, nreject, nf, status (0 ok, 1 non-finite error estimate, 2 maxiters, 3 no initial step), max order
+    int* stats;         // naccept, nreject, nf, status (0 ok, 1 non-finite error estimate, 2 maxiters, 3 no initial step, 4 grid sum
+                        // timed out), max order, [5] = abort flag raised by the first workgroup whose wait timed out
     int* orders;        // VCABM: order of every accepted step, dts_cap entries
 };
 

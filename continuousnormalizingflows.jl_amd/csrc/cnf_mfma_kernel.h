@@ -698,9 +698,13 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
 // the calls (the same in every wave): its parity picks the slot set, its value the arrival target.  One poller per
 // workgroup: with a poller per wave the 1024 pollers of a 16 K batch cost ~70 us per sum on one counter word.
 // (Spare waves of a workgroup have left the kernel; the hardware barrier counts the waves still running.)
-__device__ __forceinline__ void grid_sum3(const AArgs& q, unsigned& round, int wave, int nact, int lane, double& v0, double& v1, double& v2) {
+// Returns false when the other workgroups did not arrive within ~2^22 polls (seconds): a safety net, not a code path - a
+// grid whose workgroups are not all resident would otherwise spin for ever (and take the GPU with it).  The first workgroup
+// to give up raises q.stats[5]; every poller watches that word too, so the whole grid leaves within one poll.
+__device__ __forceinline__ bool grid_sum3(const AArgs& q, unsigned& round, int wave, int nact, int lane, double& v0, double& v1, double& v2) {
     __shared__ double wg_part[3][16];
     __shared__ double wg_tot[3];
+    __shared__ int wg_ok;
     v0 = wave_sum_f64(v0);
     v1 = wave_sum_f64(v1);
     v2 = wave_sum_f64(v2);
@@ -709,6 +713,7 @@ __device__ __forceinline__ void grid_sum3(const AArgs& q, unsigned& round, int w
     if (wave == 0) {
         const unsigned nb = gridDim.x;
         double* sl = q.slots + (size_t)(round & 1u) * 3u * (size_t)nb;
+        int ok = 1;
         if (lane == 0) {
             double a0 = 0.0, a1 = 0.0, a2 = 0.0;
             for (int w = 0; w < nact; ++w) { a0 += wg_part[0][w]; a1 += wg_part[1][w]; a2 += wg_part[2][w]; }
@@ -717,25 +722,36 @@ __device__ __forceinline__ void grid_sum3(const AArgs& q, unsigned& round, int w
             sl[2 * nb + blockIdx.x] = a2;
             __hip_atomic_fetch_add(q.counter, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
             const unsigned target = (round + 1u) * nb;
-            while (__hip_atomic_load(q.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
+            unsigned polls = 0;
+            while (__hip_atomic_load(q.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                __builtin_amdgcn_s_sleep(1);
+                if ((++polls & 63u) == 0u &&
+                    (polls > (1u << 22) || __hip_atomic_load(q.stats + 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                    __hip_atomic_store(q.stats + 5, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ok = 0;
+                    break;
+                }
+            }
         }
+        ok = __builtin_amdgcn_readfirstlane(ok);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         double a0 = 0.0, a1 = 0.0, a2 = 0.0;
         for (unsigned i = lane; i < nb; i += 64) { a0 += sl[i]; a1 += sl[nb + i]; a2 += sl[2 * nb + i]; }
         a0 = wave_sum_f64(a0);
         a1 = wave_sum_f64(a1);
         a2 = wave_sum_f64(a2);
-        if (lane == 0) { wg_tot[0] = a0; wg_tot[1] = a1; wg_tot[2] = a2; }
+        if (lane == 0) { wg_tot[0] = a0; wg_tot[1] = a1; wg_tot[2] = a2; wg_ok = ok; }
     }
     __syncthreads();
     v0 = wg_tot[0];
     v1 = wg_tot[1];
     v2 = wg_tot[2];
     ++round;
+    return wg_ok != 0;
 }
-__device__ __forceinline__ void grid_sum2(const AArgs& q, unsigned& round, int wave, int nact, int lane, double& v0, double& v1) {
+__device__ __forceinline__ bool grid_sum2(const AArgs& q, unsigned& round, int wave, int nact, int lane, double& v0, double& v1) {
     double v2 = 0.0;
-    grid_sum3(q, round, wave, nact, lane, v0, v1, v2);
+    return grid_sum3(q, round, wave, nact, lane, v0, v1, v2);
 }
 
 template <int HT, int L, int ZR, int CR, int ACT, int ENGINE, int KP, int PRE, int NTHREADS, int ARITH = 0>
@@ -845,7 +861,7 @@ mfma_adaptive_kernel(KArgs a, AArgs q) {
                         s0 += (double)r0 * (double)r0; s1 += (double)r1 * (double)r1;
                     }
                 }
-                grid_sum2(q, round, wave, nact, lane, s0, s1);
+                if (!grid_sum2(q, round, wave, nact, lane, s0, s1)) { status = 4; break; }
                 const double d0 = sqrt(s0 / ntot);
                 d1 = sqrt(s1 / ntot);
                 h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
@@ -875,7 +891,7 @@ mfma_adaptive_kernel(KArgs a, AArgs q) {
                     s0 += (double)r * (double)r;
                 }
             }
-            grid_sum2(q, round, wave, nact, lane, s0, s1);
+            if (!grid_sum2(q, round, wave, nact, lane, s0, s1)) { status = 4; break; }
             const double d2 = sqrt(s0 / ntot) / h0, dmax = fmax(d1, d2);
             const double h1 = dmax <= 1e-15 ? fmax(1e-6, h0 * 1e-3) : pow(10.0, -(2.0 + log10(dmax)) / 5.0);
             dt = fmin(fmin(100.0 * h0, h1), span);
@@ -918,7 +934,7 @@ mfma_adaptive_kernel(KArgs a, AArgs q) {
                     s0 += (double)r * (double)r;
                 }
             }
-            grid_sum2(q, round, wave, nact, lane, s0, s1);
+            if (!grid_sum2(q, round, wave, nact, lane, s0, s1)) { status = 4; break; }
             const double eest = sqrt(s0 / ntot);
             if (!isfinite(eest)) { status = 1; break; }
             const double beta1 = 7.0 / 50.0, beta2 = 2.0 / 25.0, gamma = 0.9, qmin = 0.2, qmax = 10.0;
@@ -1117,7 +1133,7 @@ mfma_vcabm_kernel(KArgs a, AArgs q) {
                         s0 += (double)r0 * (double)r0; s1 += (double)r1 * (double)r1;
                     }
                 }
-                grid_sum3(q, round, wave, nact, lane, s0, s1, s2);
+                if (!grid_sum3(q, round, wave, nact, lane, s0, s1, s2)) { status = 4; break; }
                 const double d0 = sqrt(s0 / ntot);
                 d1 = sqrt(s1 / ntot);
                 h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
@@ -1135,7 +1151,7 @@ mfma_vcabm_kernel(KArgs a, AArgs q) {
             for (int r = 0; r < NR; ++r) {
                 if (live[r]) { const float rr = (X[r] - F[r]) / sk_of(U[r]); s0 += (double)rr * (double)rr; }
             }
-            grid_sum3(q, round, wave, nact, lane, s0, s1, s2);
+            if (!grid_sum3(q, round, wave, nact, lane, s0, s1, s2)) { status = 4; break; }
             const double d2 = sqrt(s0 / ntot) / h0, dmax = fmax(d1, d2);
             const double h1 = dmax <= 1e-15 ? fmax(1e-6, h0 * 1e-3) : pow(10.0, -(2.0 + log10(dmax)) / 1.0);
             dt = fmin(fmin(100.0 * h0, h1), span);
@@ -1162,7 +1178,7 @@ mfma_vcabm_kernel(KArgs a, AArgs q) {
                     s0 += (double)r0 * (double)r0; s1 += (double)r1 * (double)r1; s2 += (double)r2 * (double)r2;
                 }
             }
-            grid_sum3(q, round, wave, nact, lane, s0, s1, s2);
+            if (!grid_sum3(q, round, wave, nact, lane, s0, s1, s2)) { status = 4; break; }
             eest = sqrt(s0 / ntot);
             if (!isfinite(eest)) { status = 1; break; }
             if (eest > 1.0) {   // reject: same state, smaller step, same order (nothing was stored)
@@ -1208,7 +1224,7 @@ mfma_vcabm_kernel(KArgs a, AArgs q) {
                         s0 += (double)rr * (double)rr;
                     }
                 }
-                grid_sum3(q, round, wave, nact, lane, s0, s1, s2);
+                if (!grid_sum3(q, round, wave, nact, lane, s0, s1, s2)) { status = 4; break; }
                 if (sqrt(s0 / ntot) < eest) { knew = k + 1; eest = 1.0; }
             }
 #pragma unroll
