@@ -79,9 +79,12 @@ def measured_traffic(name):
     from the committed summary; null when the configuration has not been profiled."""
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            return json.load(f).get(name)
+            e = json.load(f).get(name)
     except Exception:
-        return None
+        return None, None
+    if isinstance(e, dict):
+        return e.get("bytes"), e.get("source")
+    return e, None
 
 
 F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 = f32 vector rate
@@ -153,6 +156,11 @@ def parse():
                     help="N > 1 on the nccl backend: 'abi' = the library's own RCCL communicator (cnf_comm_init / "
                          "cnf_allreduce_loss, include/cnf.h; falls back to torch.distributed if it cannot be formed), "
                          "'torch' = torch.distributed all_reduce")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="take the N > 1 code path (process group, RCCL communicator, loss all-reduce inside the timed "
+                         "loop, teardown) even with one rank: the rehearsal of a multi-GPU launch on a 1-GPU box")
+    ap.add_argument("--comm-timeout", type=float, default=90.0,
+                    help="seconds to wait for ncclCommInitRank of the library's communicator before giving up (exit 3)")
     ap.add_argument("--backend", default="nccl", help="process-group backend (nccl = RCCL; gloo for "
                     "the single-GPU launch-contract test, where all ranks share device 0)")
     return ap.parse_args()
@@ -317,9 +325,12 @@ def _quarters(ms):
 
 
 def measure(w, a, steps, warmup, preroll_s, pkg, torch, dist, world, dev, probe):
-    """Warm-up, pre-roll to the sustained clock, then exactly `steps` timed steps.  Returns timings."""
+    """Warm-up, pre-roll to the sustained clock, then exactly `steps` timed steps.  Returns timings.
+    `sharded` (N > 1, or --force-dist with one rank) selects the column-shard form of the step: cnf_loss_sums + the
+    all-reduce of the loss scalars instead of cnf_loss_mean, and the barrier / max-over-ranks timing."""
     icnf, mode, args, E, B = w["icnf"], w["mode"], w["args"], w["E"], w["B"]
     grad = a.mode == "grad"
+    sharded = world > 1 or a.force_dist
     state = {}
 
     def launch(ev=None):
@@ -335,7 +346,7 @@ def measure(w, a, steps, warmup, preroll_s, pkg, torch, dist, world, dev, probe)
         logp, regs = pkg.inference(icnf, mode, *args, eps=E, _raw=True)
         if ev is not None:
             ev[1].record()
-        if world == 1:     # one process: the mean comes out of the library's two reduction kernels (cnf_loss_mean), as in pkg.loss
+        if not sharded:    # one process: the mean comes out of the library's two reduction kernels (cnf_loss_mean), as in pkg.loss
             state["loss"] = pkg.loss_mean(icnf, mode, logp, regs)
         else:
             sums = pkg.loss_sums(icnf, mode, logp, regs)
@@ -343,7 +354,7 @@ def measure(w, a, steps, warmup, preroll_s, pkg, torch, dist, world, dev, probe)
 
     def sync():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if sharded:
             dist.barrier()
             torch.cuda.synchronize(dev)
 
@@ -360,7 +371,7 @@ def measure(w, a, steps, warmup, preroll_s, pkg, torch, dist, world, dev, probe)
     sync()
     est = max((time.perf_counter() - t) / 3, 1e-5)
     n_pre = int(min(20000, max(0, np.ceil(preroll_s / est)))) if preroll_s > 0 else 0
-    if world > 1:   # every rank must run the same number of steps (the loss all-reduce is a collective)
+    if sharded:     # every rank must run the same number of steps (the loss all-reduce is a collective)
         tt = torch.tensor([n_pre], device=dev, dtype=torch.int64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         n_pre = int(tt.item())
@@ -387,7 +398,7 @@ def measure(w, a, steps, warmup, preroll_s, pkg, torch, dist, world, dev, probe)
         launch(ev[i])
     sync()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if sharded:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -431,7 +442,9 @@ def report(w, m, a, steps, warmup, world):
     ach = flops_launch / (m["kern_ms"] * 1e-3) / 1e12
     roof = {
         "bound": "mfma", "achieved": ach, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-        "frac": ach / F32_MFMA_PEAK_TFLOPS, "traffic": measured_traffic(w["name"]),
+        "frac": ach / F32_MFMA_PEAK_TFLOPS, "traffic": measured_traffic(w["name"])[0],
+        "traffic_source": (f"committed PMC pass {measured_traffic(w['name'])[1]} (not collected by this run: bench.py "
+                           "cannot run rocprofv3 on itself)" if measured_traffic(w["name"])[1] else None),
         "kernel_ms": m["kern_ms"], "kernel_ms_median": m["kern_ms_median"], "kernel_ms_min": m["kern_ms_min"],
         "kernel_ms_max": m["kern_ms_max"], "flop_per_sample_step": flop_ss, "flop_per_launch": flops_launch,
         **extra,
@@ -471,6 +484,49 @@ def report(w, m, a, steps, warmup, world):
     }
 
 
+def form_library_comm(pkg, torch, dist, dev, rank, world, timeout_s, fallback_name):
+    """The library's own RCCL communicator (cnf_comm_init, include/cnf.h) over the ranks of the process group.
+    Every torch.distributed collective of the set-up is issued by THIS (the main) thread, whose current device is the
+    rank's: the unique id travels as a device tensor (no object collective, which would land on the calling thread's
+    current device).  Only ncclCommInitRank itself runs in a helper thread - it takes the device as an argument
+    (DeviceGuard in csrc/cnf_comm.hip) - so that a rendezvous that never completes becomes `exit 3` with a message after
+    `timeout_s` instead of a job that hangs until the launcher's own timeout.  An init that FAILS (an error code, on any
+    rank) falls back to torch.distributed's all_reduce on every rank, and the JSON line says so."""
+    import threading
+    n = pkg._lib.COMM_ID_BYTES
+    uid = torch.zeros(n, dtype=torch.uint8, device=dev)
+    if rank == 0:
+        uid.copy_(torch.frombuffer(bytearray(pkg.Comm.unique_id()), dtype=torch.uint8))
+    dist.broadcast(uid, src=0)
+    uid_bytes = bytes(uid.cpu().numpy().tobytes())
+    box = {}
+
+    def init_rank():
+        try:
+            torch.cuda.set_device(dev)         # the current device is per thread
+            box["comm"] = pkg.Comm(rank, world, uid_bytes, dev)
+        except Exception as ex:   # pragma: no cover
+            box["err"] = str(ex)[:300]
+
+    th = threading.Thread(target=init_rank, daemon=True)
+    th.start()
+    th.join(timeout_s)
+    if th.is_alive():
+        print(f"bench.py: rank {rank}: ncclCommInitRank of the library communicator did not return within {timeout_s:.0f} s; "
+              f"re-run with --collective torch", file=sys.stderr, flush=True)
+        os._exit(3)                            # the helper thread is inside RCCL: no orderly teardown is possible
+    ok = torch.tensor([1 if "comm" in box else 0], device=dev, dtype=torch.int32)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if int(ok.item()) == 1:
+        pkg.set_comm(box["comm"])
+        return "cnf_allreduce_loss: RCCL ncclAllReduce of 5 doubles through the C ABI (include/cnf.h)"
+    if "comm" in box:
+        box["comm"].destroy()
+    print(f"bench.py: rank {rank}: cnf_comm_init unavailable ({box.get('err', 'failed on another rank')}); "
+          f"using {fallback_name}", file=sys.stderr, flush=True)
+    return fallback_name + f" [cnf_comm_init unavailable: {box.get('err', 'failed on another rank')}]"
+
+
 def main():
     a = parse()
     import torch
@@ -487,8 +543,10 @@ def main():
         local = local % torch.cuda.device_count()   # contract test: ranks may share a device
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    sharded = world > 1 or a.force_dist
+    if sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")      # only reached by a bare `python bench.py --force-dist`
         if a.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -497,32 +555,11 @@ def main():
     pkg = entry.load_package()
     o64, oc = entry.load_oracle()      # input generation and the cpu_baseline leg only (outside the timed regions)
     probe = ClockProbe(torch, dev)
-    collective, hung = "none (one GPU)", False
-    if world > 1:
+    collective = "none (one GPU)"
+    if sharded:
         collective = f"torch.distributed all_reduce ({a.backend})"
         if a.backend == "nccl" and a.collective == "abi":
-            # the library's own RCCL communicator; formed in a helper thread so that a rendezvous problem becomes a
-            # fall-back to torch.distributed after 90 s instead of a hung job
-            import threading
-            box = {}
-
-            def form():
-                try:
-                    box["comm"] = pkg.Comm.from_process_group(dev)
-                except Exception as ex:   # pragma: no cover
-                    box["err"] = str(ex)[:300]
-
-            th = threading.Thread(target=form, daemon=True)
-            th.start()
-            th.join(90.0)
-            hung = th.is_alive()
-            ok = torch.tensor([1 if "comm" in box else 0], device=dev, dtype=torch.int32)
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-            if int(ok.item()) == 1:
-                pkg.set_comm(box["comm"])
-                collective = "cnf_allreduce_loss: RCCL ncclAllReduce of 5 doubles through the C ABI (include/cnf.h)"
-            else:
-                collective += f" [cnf_comm_init unavailable: {box.get('err', 'timed out')}]"
+            collective = form_library_comm(pkg, torch, dist, dev, rank, world, a.comm_timeout, collective)
 
     w = make_workload(pkg, o64, a.config, a, rank, dev, torch)
     w["collective"] = collective
@@ -554,20 +591,17 @@ def main():
             r2 = report(sec[0], sec[1], a, a.steps, a.warmup, world)
             out["secondary"] = {"metric": out["metric"], "unit": out["unit"], "steps": a.steps,
                                 "why": "the north_star's target configuration (Tsit5 x 40) by the same protocol", **r2}
-        if world == 1 and not a.no_cpu_baseline:
+        if world == 1 and not a.no_cpu_baseline and not a.force_dist:
             p, xs, eps, ys = w["host"]
             out["cpu_baseline"] = cpu_baseline(o64, oc, w["spec"], w["alg"], p, xs, eps, ys, a.cpu_seconds)
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out))
-    if world > 1:
+    if sharded:
         c = pkg.get_comm()
         pkg.set_comm(None)
         if c is not None:
             c.destroy()
         dist.destroy_process_group()
-    if hung:                       # a helper thread is still inside ncclCommInitRank: do not wait for it at exit
-        sys.stdout.flush()
-        os._exit(0)
 
 
 if __name__ == "__main__":

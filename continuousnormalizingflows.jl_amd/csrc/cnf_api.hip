@@ -503,6 +503,9 @@ static FixedDtPlan fixed_dt_plan(float t0, float t1, float dt) {
     FixedDtPlan p{};
     p.n_full = (int)std::floor(span / adt + 1e-9);
     const double tol = 100.0 * 1.1920928955078125e-7 * std::fmax(std::fabs((double)t0), std::fabs((double)t1));
+    // a Float32 dt a hair above span / n (0.1f on (0, 1)) leaves a "remainder" of one whole step less that hair: the stepper
+    // snaps that step onto t1 (same tolerance), so it is the last of n_full + 1 equal steps, not a tail
+    if (span - p.n_full * adt > tol && adt - (span - p.n_full * adt) <= tol) ++p.n_full;
     p.tail = span - p.n_full * adt > tol;
     p.t_mid = p.tail ? (float)((double)t0 + tdir * p.n_full * adt) : t1;
     return p;

@@ -285,7 +285,7 @@ int cnf_solve_vcabm(cnf_handle* h, float t0, float t1, const float* u0, const fl
         if (hs[3] == 1) return fail(CNF_ERR_INVALID, "cnf_solve_vcabm: non-finite error estimate (unstable dynamics)");
         if (hs[3] == 2) return fail(CNF_ERR_INVALID, "cnf_solve_vcabm: maxiters reached");
         if (hs[3] == 3) return fail(CNF_ERR_INVALID, "cnf_solve_vcabm: non-finite state or dynamics at t0 (no initial step)");
-        if (hs[3] == 4) return fail(CNF_ERR_HIP, "cnf_solve_vcabm: the grid-wide sum of the one-launch solve timed out (workgroups not all resident); CNF_DEVICE_CONTROLLER=0 selects the host loop");
+        if (hs[3] == 4 || hs[5] != 0) return fail(CNF_ERR_HIP, "cnf_solve_vcabm: the grid-wide sum of the one-launch solve timed out (workgroups not all resident); CNF_DEVICE_CONTROLLER=0 selects the host loop");
         const int na = std::min(std::min(hs[0], dts_cap), (int)record_cap);
         if (na > 0 && dts_out) HIP_TRY(hipMemcpyAsync(dts_out, dts_dev, (size_t)na * sizeof(float), hipMemcpyDeviceToHost, st));
         if (na > 0 && orders_out) HIP_TRY(hipMemcpyAsync(orders_out, orders_dev, (size_t)na * sizeof(int32_t), hipMemcpyDeviceToHost, st));
@@ -454,7 +454,7 @@ int cnf::api_solve_tsit5(cnf_handle* h, float t0, float t1, const float* u0, con
         if (host[3] == 1) return fail(CNF_ERR_INVALID, "cnf_solve_tsit5: non-finite error estimate (unstable dynamics)");
         if (host[3] == 2) return fail(CNF_ERR_INVALID, "cnf_solve_tsit5: maxiters reached");
         if (host[3] == 3) return fail(CNF_ERR_INVALID, "cnf_solve_tsit5: non-finite state or dynamics at t0 (no initial step)");
-        if (host[3] == 4) return fail(CNF_ERR_HIP, "cnf_solve_tsit5: the grid-wide sum of the one-launch solve timed out (workgroups not all resident); CNF_DEVICE_CONTROLLER=0 selects the host loop");
+        if (host[3] == 4 || host[5] != 0) return fail(CNF_ERR_HIP, "cnf_solve_tsit5: the grid-wide sum of the one-launch solve timed out (workgroups not all resident); CNF_DEVICE_CONTROLLER=0 selects the host loop");
         if (steps) {
             const int na = host[0] < dts_cap ? host[0] : dts_cap;
             std::vector<float> all((size_t)na);

@@ -124,6 +124,15 @@ int cnf_comm_init(cnf_comm** out, int rank, int nranks, const void* id, int devi
 int cnf_comm_init_all(cnf_comm** out, int ndev, const int* devs) {
     if (!out || ndev < 1 || !devs) return cnf::api_fail(CNF_ERR_INVALID, "cnf_comm_init_all: bad arguments");
     if (int rc = need_rccl()) return rc;
+    int have = 0;
+    if (hipGetDeviceCount(&have) != hipSuccess || have < 1)
+        return cnf::api_fail(CNF_ERR_NO_DEVICE, "cnf_comm_init_all: no HIP device");
+    for (int i = 0; i < ndev; ++i) {
+        if (devs[i] < 0 || devs[i] >= have)
+            return cnf::api_fail(CNF_ERR_INVALID, "cnf_comm_init_all: device index out of range");
+        for (int j = 0; j < i; ++j)
+            if (devs[j] == devs[i]) return cnf::api_fail(CNF_ERR_INVALID, "cnf_comm_init_all: a device is listed twice");
+    }
     std::vector<ncclComm_t> comms((size_t)ndev);
     RCCL_TRY(cnf::rccl().init_all(comms.data(), ndev, devs));
     for (int i = 0; i < ndev; ++i) {

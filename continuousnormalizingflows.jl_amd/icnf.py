@@ -377,15 +377,19 @@ class ICNF:
         kw = self.sol_kwargs
         if "nsteps" in kw or "dt" not in kw:
             return None
-        return abs(float(kw["dt"]))
+        return C.c_float(abs(float(kw["dt"]))).value       # the Float32 the ABI receives: one plan on both sides
 
     @staticmethod
     def fixed_dt_grid(t0: float, t1: float, dt: float):
-        """The times of those steps, [t0, ..., t1] (the plan of cnf_integrate_fixed_dt; include/cnf.h)."""
+        """The times of those steps, [t0, ..., t1]: the plan of cnf_integrate_fixed_dt (fixed_dt_plan, csrc/cnf_api.hip),
+        computed like there in double from the Float32 values of t0, t1 and dt that cross the ABI."""
+        t0, t1, dt = (C.c_float(float(v)).value for v in (t0, t1, dt))
         span, adt = abs(t1 - t0), abs(dt)
         tdir = 1.0 if t1 >= t0 else -1.0
         n = int(math.floor(span / adt + 1e-9))
         tol = 100.0 * 1.1920928955078125e-7 * max(abs(t0), abs(t1))
+        if span - n * adt > tol and adt - (span - n * adt) <= tol:
+            n += 1                       # a Float32 dt a hair above span / n: the last step is snapped onto t1, no tail
         if span - n * adt <= tol:
             return [t0] if n == 0 else [t0 + (t1 - t0) * i / n for i in range(n)] + [t1]
         return [t0 + tdir * adt * i for i in range(n + 1)] + [t1]

@@ -20,7 +20,7 @@ end
 mutable struct Handle
     ptr::Ptr{Cvoid}
     params_id::UInt                      # objectid of the parameter vector bound last
-    params_hash::UInt                    # and a cheap content check (first/last/sum) so in-place updates rebind
+    params_hash::UInt                    # unused since parameters are bound on every call (kept for layout stability)
     w_off::Vector{Csize_t}
     b_off::Vector{Csize_t}
     function Handle(cfg::CnfConfig)
@@ -119,11 +119,11 @@ function bind_params!(h::Handle, icnf::ICNF, ps::Any)
     ps isa ComponentArrays.ComponentArray || error("HIPMatrixMode: ps must be the ComponentArray of LuxCore.setup (got $(typeof(ps)))")
     p = ComponentArrays.getdata(ps)
     n = length(p)
+    # Bound on EVERY call, host vectors too: an in-place update (an optimiser step, a finite-difference probe) keeps the
+    # vector's identity, and no cheap signature of its contents is safe (Base.hash of a large array samples it).  The cost is
+    # one copy of a few KiB to 580 KiB and the device-side gather into the operand images (DESIGN.md section 3).
     id = objectid(p)
-    sig = is_device_array(p) ? UInt(0) : hash((p[1], p[end], sum(p)))
-    if h.params_id == id && h.params_hash == sig && !is_device_array(p)
-        return nothing                                                    # same host vector, unchanged
-    end
+    sig = UInt(0)
     if isempty(h.w_off)
         h.w_off, h.b_off = param_offsets(icnf, ps)
     end

@@ -6,6 +6,12 @@
 # The rules cover `loss` for MatrixMode, unconditioned (src/core/icnf.jl:628-637) and conditioned (:639-649).
 
 function hip_loss_and_gradient(icnf::ICNF{T, <:HIPMatrixMode}, mode::Mode, xs::AbstractMatrix{<:Real}, ys::Union{Nothing, AbstractMatrix{<:Real}}, ps::Any) where {T <: AbstractFloat}
+    # the reverse-sweep kernels start from the terminal costate of the standard normal the forward epilogue fuses; any other
+    # `basedist` would get the gradient (and value) of the wrong density - loud failure, as the Python host raises
+    is_std_normal(icnf.basedist) || error(
+        "HIPMatrixMode: the gradient kernels cover basedist = MvNormal(0, I) (the constructor's default, src/core/icnf.jl:76-79); " *
+        "use a reference compute_mode to train with another base distribution",
+    )
     h = cached_handle(icnf, mode, ps)
     B = size(xs, 2)
     n_aug_input = n_augments_input(icnf)
@@ -63,6 +69,9 @@ function fixed_dt_grid(t0::Float32, t1::Float32, dt::Float32)
     tdir = t1 >= t0 ? 1.0 : -1.0
     n = floor(Int, span / adt + 1.0e-9)
     tol = 100 * Float64(eps(Float32)) * max(abs(Float64(t0)), abs(Float64(t1)))
+    if span - n * adt > tol && adt - (span - n * adt) <= tol
+        n += 1          # a Float32 dt a hair above span / n: the last step is snapped onto t1 (fixed_dt_plan, csrc/cnf_api.hip)
+    end
     if span - n * adt <= tol
         n == 0 && return Float32[t0, t1]
         return Float32[[Float64(t0) + (Float64(t1) - Float64(t0)) * i / n for i in 0:(n - 1)]; t1]

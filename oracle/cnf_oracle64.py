@@ -221,12 +221,18 @@ def fixed_dt_grid(t0: float, t1: float, dt: float):
     src/core/base_icnf.jl:134-140; what STEER's drawn t1 meets, base_icnf.jl:23-43): steps of |dt| towards t1 and a
     SHORTER LAST STEP that lands on t1 (t1 is a tstop) — unless what remains is within 100 eps(Float32) of the larger
     end point, which its floating-point fix-up treats as already being t1 (then the steps are the equal division).
+    The reference's tspan and dt are Float32 (`tspan::NTuple{2, T}`, src/core/icnf.jl:22; T = Float32), so the plan is made
+    from their Float32 values; a Float32 dt a hair above span / n (0.1f0 on (0, 1)) makes the n-th step overshoot t1 by less
+    than that tolerance, and the same fix-up snaps it onto t1: n equal steps, not n - 1 and a tail.
     Returns the list [t0, ..., t1]."""
+    t0, t1, dt = (float(np.float32(v)) for v in (t0, t1, dt))
     span, adt = abs(t1 - t0), abs(dt)
     assert adt > 0.0
     tdir = 1.0 if t1 >= t0 else -1.0
     n = int(math.floor(span / adt + 1e-9))
     tol = 100.0 * float(np.finfo(np.float32).eps) * max(abs(t0), abs(t1))
+    if span - n * adt > tol and adt - (span - n * adt) <= tol:
+        n += 1
     rem = span - n * adt
     if rem <= tol:
         if n == 0:

@@ -160,3 +160,21 @@ def test_machine_file_round_trip(kind, pkg, tmp_path):
     with pytest.raises(NotImplementedError):
         bad = pkg.ICNF(nvariables=2, basedist=torch.distributions.Normal(0.0, 1.0))
         pkg.save_machine(f, pkg.ICNFModel(icnf=bad), (ps, st))
+
+
+def test_fixed_dt_plan_is_made_from_the_float32_values_that_cross_the_abi(pkg, oracles):
+    """sol_kwargs.dt = 0.1 on (0, 1): Float32(0.1) is a hair above 1/10, so a plan made in double from the Float32 value sees
+    9 whole steps and a "remainder" of almost one step.  OrdinaryDiffEq's floating-point fix-up snaps that step onto t1:
+    ten equal steps, the same on the host (loss_and_gradient's grid), in the oracle and in the library (fixed_dt_plan)."""
+    o64, _ = oracles
+    for dt in (0.1, 1.0 / 40, 0.05, 1.0 / 3):
+        g = pkg.ICNF.fixed_dt_grid(0.0, 1.0, dt)
+        n = round(1.0 / dt)
+        assert len(g) == n + 1 and np.allclose(np.diff(g), 1.0 / n, rtol=0, atol=1e-12), (dt, g)
+        assert np.allclose(g, o64.fixed_dt_grid(0.0, 1.0, dt), rtol=0, atol=0)
+    # a genuine tail survives: dt = 0.3 -> 0.3, 0.6, 0.9 and a last step of 0.1 (from the Float32 value of dt)
+    g = pkg.ICNF.fixed_dt_grid(0.0, 1.0, 0.3)
+    assert len(g) == 5 and abs(g[1] - float(np.float32(0.3))) < 1e-15 and abs((g[4] - g[3]) - 0.1) < 1e-6
+    assert g == o64.fixed_dt_grid(0.0, 1.0, 0.3)
+    icnf = pkg.ICNF(nvariables=2, sol_kwargs=dict(alg=pkg.Tsit5(), adaptive=False, dt=0.1))
+    assert icnf._fixed_dt() == float(np.float32(0.1))

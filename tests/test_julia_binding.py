@@ -236,6 +236,21 @@ def test_conditioned_loss_has_an_rrule_and_helpers_are_defined():
     assert "icnf_inplace_view" not in text                                # the r1 sketch's undefined helper is gone, not renamed
 
 
+def test_gradient_rule_refuses_a_base_distribution_the_kernels_do_not_fuse():
+    """the reverse-sweep kernels hard-code the terminal costate of MvNormal(0, I); `inference_sol` falls back for
+    another `basedist`, so the rrule's body must not return a silently wrong gradient - it errors before any ccall."""
+    text = open(os.path.join(ROOT, "julia", "hip_ext", "rrule.jl")).read()
+    body = text[text.index("function hip_loss_and_gradient"):]
+    body = body[:body.index("\nend\n")]
+    guard, first_ccall = body.find("is_std_normal(icnf.basedist) || error("), body.find("ccall(")
+    assert 0 <= guard < first_ccall and guard < body.find("cached_handle(")
+    # and parameters are bound on every call (no content signature that an in-place update can defeat)
+    h = open(os.path.join(ROOT, "julia", "hip_ext", "handle.jl")).read()
+    bind = h[h.index("function bind_params!"):]
+    bind = bind[:bind.index("\nend\n")]
+    assert "return nothing" not in bind[:bind.index("ccall(")] and "sum(p)" not in bind
+
+
 def test_reference_signature_fixture_is_current():
     ref_root = os.environ.get("CNF_REFERENCE", "/root/reference")
     if not os.path.isdir(os.path.join(ref_root, "src", "core")):

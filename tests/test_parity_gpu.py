@@ -2218,6 +2218,82 @@ def test_rccl_allreduce_through_the_abi_with_one_rank(pkg):
         comm.destroy()
 
 
+def test_comm_init_all_with_one_device_and_grouped_reductions(pkg):
+    """cnf_comm_init_all (ncclCommInitAll: one host process driving several devices - the shape a Julia host without
+    MPI uses, julia/hip_ext/comm.jl) with the one device a lease has, and the grouped form of the reductions
+    (cnf_comm_group_start / _end around the per-device calls, which RCCL requires when one thread drives several ranks)."""
+    import ctypes as C
+    lib = pkg._lib.load()
+    dev = torch.device("cuda:0")
+    comms = (C.c_void_p * 1)()
+    devs = (C.c_int * 1)(0)
+    pkg._lib.check(lib.cnf_comm_init_all(comms, 1, devs))
+    c = C.c_void_p(comms[0])
+    try:
+        assert lib.cnf_comm_rank(c) == 0 and lib.cnf_comm_size(c) == 1
+        sums = torch.tensor([1.5, -2.0, 0.125, 8.0], device=dev)
+        out5 = torch.zeros(5, dtype=torch.float64, device=dev)
+        g = torch.arange(1000, device=dev, dtype=torch.float32)
+        st = pkg._lib.stream_ptr(dev)
+        pkg._lib.check(lib.cnf_comm_group_start())
+        pkg._lib.check(lib.cnf_allreduce_loss(c, pkg._lib.ptr(sums), 321, pkg._lib.ptr(out5), st))
+        pkg._lib.check(lib.cnf_allreduce_sum(c, pkg._lib.ptr(g), g.numel(), pkg._lib.DTYPE_F32, st))
+        pkg._lib.check(lib.cnf_comm_group_end())
+        torch.cuda.synchronize()
+        assert out5.tolist() == [1.5, -2.0, 0.125, 8.0, 321.0]
+        assert torch.equal(g, torch.arange(1000, device=dev, dtype=torch.float32))
+    finally:
+        lib.cnf_comm_destroy(c)
+    bad = (C.c_int * 1)(99)
+    assert lib.cnf_comm_init_all(comms, 1, bad) != 0          # a device that does not exist: a status code, not a crash
+    assert lib.cnf_comm_init_all(comms, 0, devs) == pkg._lib.ERR_INVALID
+
+
+@pytest.mark.parametrize("launcher", ["torchrun", "bare"])
+@pytest.mark.parametrize("mode", ["infer", "grad"])
+def test_bench_nccl_launch_path_rehearsed_with_one_rank(launcher, mode):
+    """Every line a multi-GPU `bench.py --gpus N` run executes, executed on the one GPU a lease has: launched by
+    torch.distributed.run exactly as the driver launches N > 1 (or bare, with --force-dist supplying the rendezvous),
+    init_process_group("nccl"), the library's RCCL communicator formed over the group (unique id broadcast as a device tensor
+    from the main thread; ncclCommInitRank in the watchdog thread), cnf_loss_sums + cnf_allreduce_loss INSIDE the timed loop,
+    the all-reduced pre-roll count and max-over-ranks time, comm destroy + destroy_process_group.  The one exchange is
+    the mean of src/core/icnf.jl:636."""
+    import json, os, socket, subprocess, sys
+    from conftest import ROOT
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    tail = [os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist", "--steps", "3", "--warmup", "1", "--batch", "4096",
+            "--mode", mode, "--preroll-seconds", "0.2", "--no-cpu-baseline"]
+    if launcher == "torchrun":
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+               "--master-port", str(port)] + tail
+        env = dict(os.environ)
+    else:
+        cmd = [sys.executable] + tail
+        env = dict(os.environ, MASTER_PORT=str(port))
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["config"]["collective"].startswith("cnf_allreduce_loss"), out["config"]["collective"]
+    assert out["n_gpus"] == 1 and out["steps"] == 3 and out["scaling"] == "weak" and out["value"] > 0
+    # the same numbers as the unsharded step on the same columns (one rank: the all-reduce is the identity)
+    single = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--no-cpu-baseline",
+                             "--batch", "4096", "--mode", mode, "--preroll-seconds", "0", "--secondary", "none"],
+                            capture_output=True, text=True, timeout=600, cwd=ROOT)
+    one = json.loads([l for l in single.stdout.splitlines() if l.startswith("{")][0])
+    assert abs(out["loss"] - one["loss"]) < 2e-6 * max(1.0, abs(one["loss"])), (out["loss"], one["loss"])
+    # and the torch.distributed transport, selected explicitly, on the same path
+    r2 = subprocess.run(cmd + ["--collective", "torch", "--secondary", "none"], capture_output=True, text=True, timeout=600,
+                        cwd=ROOT, env=env)
+    assert r2.returncode == 0, r2.stderr[-3000:]
+    out2 = json.loads([l for l in r2.stdout.splitlines() if l.startswith("{")][0])
+    assert out2["config"]["collective"].startswith("torch.distributed all_reduce (nccl)")
+    assert abs(out2["loss"] - one["loss"]) < 2e-6 * max(1.0, abs(one["loss"]))
+
+
 def test_loss_through_the_library_communicator_matches_the_local_loss(pkg, oracles):
     """loss / loss_and_gradient / the adaptive solvers with a Comm installed (one rank): same numbers as without."""
     o64, _ = oracles
