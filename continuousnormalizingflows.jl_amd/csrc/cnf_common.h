@@ -58,6 +58,9 @@ inline Tableau make_tableau(int alg) {
 // ---------------------------------------------------------------------------------------
 __device__ __forceinline__ float fast_exp(float x) { return __expf(x); }
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+// v_sqrt_f32 alone (1 ulp; a denormal argument gives 0): sqrtf expands to a scaled, Newton-corrected sequence of ~12 VALU
+// instructions, and the RNODE regularisers take K + 1 square roots per dynamics call
+__device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 
 // internal: tanh whose pre-activation arrives already multiplied by -2 log2(e) (the factor is folded
 // into the forward weight images and biases by mfma_pack), so exp(-2a) is a bare v_exp_f32

@@ -62,7 +62,8 @@ static const Inst kInsts[] = {
     MFMA_INST(4, 3, 2, 0, CNF_ACT_TANH_PRESCALED, ENG_VJP, 1, 0, 512),      // no hoisting (A/B reference)
     MFMA_INST(4, 3, 2, 0, CNF_ACT_TANH_PRESCALED, ENG_VJP, 1, 2, 1024),
     MFMA_INST(4, 3, 2, 0, CNF_ACT_TANH_PRESCALED, ENG_VJP, 1, 2, 256),
-    MFMA_INST(4, 3, 2, 0, CNF_ACT_TANH_PRESCALED, ENG_VJP, 4, 0, 512),      // cfg3: RNODE K=4
+    MFMA_INST(4, 3, 2, 0, CNF_ACT_TANH_PRESCALED, ENG_VJP, 4, 1, 512),      // cfg3: RNODE K=4, c_k = W_N^T eps_k hoisted, probes unrolled
+    MFMA_INST(4, 3, 2, 0, CNF_ACT_TANH_PRESCALED, ENG_VJP, 4, 0, 512),      // the same with the rolled probe loop, no hoisting (A/B: CNF_MFMA_PRE=0)
     MFMA_INST_AD(2, 2, 1, 0, CNF_ACT_TANH_PRESCALED, ENG_VJP, 1, 2, 512),      // cfg1: D=2, 2x32
     MFMA_INST_AD(2, 2, 1, 0, CNF_ACT_TANH_PRESCALED, ENG_VJP, 1, 1, 512),
     MFMA_INST_AD(1, 2, 1, 0, CNF_ACT_SOFTPLUS, ENG_VJP, 1, 1, 512),  // reference default net, nvariables=1

@@ -3,6 +3,7 @@
 #pragma once
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 
 #include "cnf_mfma_dev.h"
 
@@ -28,6 +29,17 @@ __device__ __forceinline__ void gemm_tiles(const float* __restrict__ img, int la
                 for (int mt = 0; mt < MT; ++mt) acc[mt] = mfma4(a[mt][j], b, acc[mt]);
             }
         }
+    }
+}
+
+// compile-time loop: f(integral_constant<int, I>) for I = 0 .. N-1.  Unlike `#pragma unroll`, every index is a constant
+// when the IR is generated, so arrays indexed by it are split into registers by the first SROA run (a pragma-unrolled loop
+// over pre_c[p] left the array in scratch: 13 scratch loads per dynamics call).
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
     }
 }
 
@@ -191,6 +203,46 @@ __device__ __forceinline__ void tiles_mul_block(const f32x4* a, const f32x4* b, 
 #pragma unroll
     for (int i = 0; i < N; ++i) c[i] = f32x4{o[2 * i][0], o[2 * i][1], o[2 * i + 1][0], o[2 * i + 1][1]};
 }
+// tiles_mul_block with the operands as named halves of whole tiles (no local operand arrays), for tiles that live in a
+// [KP][HT] array (vjp_probe_hoisted): an array of f32x2 operands is vector-promoted to a
+// <16 x float>, the tile loads that feed it become "widen to 16 lanes" shuffles, and the early VectorCombine turns those into
+// 64-byte loads that straddle the tiles of a [KP][HT] array - which then cannot be split into registers and stays in scratch.
+#define CNF_LO(t) __builtin_shufflevector(t, t, 0, 1)
+#define CNF_HI(t) __builtin_shufflevector(t, t, 2, 3)
+#define CNF_TILE(lo, hi) __builtin_shufflevector(lo, hi, 0, 1, 2, 3)
+template <int N>
+__device__ __forceinline__ void tiles_mul_block_named(const f32x4* a, const f32x4* b, f32x4* c) {
+    static_assert(N >= 1 && N <= 4, "at most 4 tiles (24 asm operands) per statement");
+    f32x2 o0, o1, o2, o3, o4, o5, o6, o7;
+    if constexpr (N == 1) {
+        const f32x4 a0 = a[0], b0 = b[0];
+        asm volatile("s_nop 7\n\ts_nop 3\n\t" CNF_PKMUL(0, 2, 4) CNF_PKMUL(1, 3, 5) "s_nop 1"
+            : "=&v"(o0), "=&v"(o1) : "v"(CNF_LO(a0)), "v"(CNF_HI(a0)), "v"(CNF_LO(b0)), "v"(CNF_HI(b0)));
+        c[0] = CNF_TILE(o0, o1);
+    } else if constexpr (N == 2) {
+        const f32x4 a0 = a[0], a1 = a[1], b0 = b[0], b1 = b[1];
+        asm volatile("s_nop 7\n\ts_nop 3\n\t" CNF_PKMUL(0, 4, 8) CNF_PKMUL(1, 5, 9) CNF_PKMUL(2, 6, 10) CNF_PKMUL(3, 7, 11) "s_nop 1"
+            : "=&v"(o0), "=&v"(o1), "=&v"(o2), "=&v"(o3)
+            : "v"(CNF_LO(a0)), "v"(CNF_HI(a0)), "v"(CNF_LO(a1)), "v"(CNF_HI(a1)), "v"(CNF_LO(b0)), "v"(CNF_HI(b0)), "v"(CNF_LO(b1)), "v"(CNF_HI(b1)));
+        c[0] = CNF_TILE(o0, o1); c[1] = CNF_TILE(o2, o3);
+    } else if constexpr (N == 3) {
+        const f32x4 a0 = a[0], a1 = a[1], a2 = a[2], b0 = b[0], b1 = b[1], b2 = b[2];
+        asm volatile("s_nop 7\n\ts_nop 3\n\t" CNF_PKMUL(0, 6, 12) CNF_PKMUL(1, 7, 13) CNF_PKMUL(2, 8, 14) CNF_PKMUL(3, 9, 15) CNF_PKMUL(4, 10, 16)
+            CNF_PKMUL(5, 11, 17) "s_nop 1"
+            : "=&v"(o0), "=&v"(o1), "=&v"(o2), "=&v"(o3), "=&v"(o4), "=&v"(o5)
+            : "v"(CNF_LO(a0)), "v"(CNF_HI(a0)), "v"(CNF_LO(a1)), "v"(CNF_HI(a1)), "v"(CNF_LO(a2)), "v"(CNF_HI(a2)),
+              "v"(CNF_LO(b0)), "v"(CNF_HI(b0)), "v"(CNF_LO(b1)), "v"(CNF_HI(b1)), "v"(CNF_LO(b2)), "v"(CNF_HI(b2)));
+        c[0] = CNF_TILE(o0, o1); c[1] = CNF_TILE(o2, o3); c[2] = CNF_TILE(o4, o5);
+    } else {
+        const f32x4 a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3], b0 = b[0], b1 = b[1], b2 = b[2], b3 = b[3];
+        asm volatile("s_nop 7\n\ts_nop 3\n\t" CNF_PKMUL(0, 8, 16) CNF_PKMUL(1, 9, 17) CNF_PKMUL(2, 10, 18) CNF_PKMUL(3, 11, 19) CNF_PKMUL(4, 12, 20)
+            CNF_PKMUL(5, 13, 21) CNF_PKMUL(6, 14, 22) CNF_PKMUL(7, 15, 23) "s_nop 1"
+            : "=&v"(o0), "=&v"(o1), "=&v"(o2), "=&v"(o3), "=&v"(o4), "=&v"(o5), "=&v"(o6), "=&v"(o7)
+            : "v"(CNF_LO(a0)), "v"(CNF_HI(a0)), "v"(CNF_LO(a1)), "v"(CNF_HI(a1)), "v"(CNF_LO(a2)), "v"(CNF_HI(a2)), "v"(CNF_LO(a3)), "v"(CNF_HI(a3)),
+              "v"(CNF_LO(b0)), "v"(CNF_HI(b0)), "v"(CNF_LO(b1)), "v"(CNF_HI(b1)), "v"(CNF_LO(b2)), "v"(CNF_HI(b2)), "v"(CNF_LO(b3)), "v"(CNF_HI(b3)));
+        c[0] = CNF_TILE(o0, o1); c[1] = CNF_TILE(o2, o3); c[2] = CNF_TILE(o4, o5); c[3] = CNF_TILE(o6, o7);
+    }
+}
 #else
 __device__ __forceinline__ void pk_add1(f32x2& a, f32x2& b) { a = a + 1.f; b = b + 1.f; }
 __device__ __forceinline__ void pk_tanh_from_r(f32x2& ha, f32x2& hb, f32x2& da, f32x2& db, const f32x2& ra, const f32x2& rb) {
@@ -203,6 +255,8 @@ __device__ __forceinline__ void tiles_mul_block(const f32x4* a, const f32x4* b, 
 #pragma unroll
     for (int i = 0; i < N; ++i) c[i] = a[i] * b[i];
 }
+template <int N>
+__device__ __forceinline__ void tiles_mul_block_named(const f32x4* a, const f32x4* b, f32x4* c) { tiles_mul_block<N>(a, b, c); }
 #endif
 // c = a .* b over MT accumulator tiles, in statements of up to 4 tiles
 template <int MT>
@@ -211,6 +265,13 @@ __device__ __forceinline__ void tiles_mul(const f32x4 (&a)[MT], const f32x4 (&b)
 #pragma unroll
     for (int q = 0; q < FULL; ++q) tiles_mul_block<4>(&a[4 * q], &b[4 * q], &c[4 * q]);
     if constexpr (REM > 0) tiles_mul_block<REM>(&a[4 * FULL], &b[4 * FULL], &c[4 * FULL]);
+}
+template <int MT>
+__device__ __forceinline__ void tiles_mul_named(const f32x4 (&a)[MT], const f32x4 (&b)[MT], f32x4 (&c)[MT]) {
+    constexpr int FULL = MT / 4, REM = MT % 4;
+#pragma unroll
+    for (int q = 0; q < FULL; ++q) tiles_mul_block_named<4>(&a[4 * q], &b[4 * q], &c[4 * q]);
+    if constexpr (REM > 0) tiles_mul_block_named<REM>(&a[4 * FULL], &b[4 * FULL], &c[4 * FULL]);
 }
 __device__ __forceinline__ f32x4 tile_fma(const f32x4& a, float s, const f32x4& c) {   // a * s + c
     const f32x2 a0 = {a[0], a[1]}, a1 = {a[2], a[3]}, c0 = {c[0], c[1]}, c1 = {c[2], c[3]}, ss = {s, s};
@@ -265,6 +326,48 @@ __device__ __forceinline__ void phase_fence() {
 #endif
 }
 
+// Pullback of ONE Hutchinson probe whose solve-invariant c = W_N^T eps has been hoisted, for the instances that carry
+// several probes (PRE = 1, KP > 1: cfg3).  Called KP times from a compile-time loop, so probe k's c_k and eps_k are named
+// registers (a rolled probe loop would pick them with a v_cndmask per register per probe) and c_k is not recomputed on every
+// dynamics call (8 of the 152 MFMAs of a probe at cfg3).  Every copy reads the operand images through its own opaque
+// offset, so the copies' LDS reads are not merged (and spilled).  The K = 1 kernels keep their own (older) text in dyn_eval:
+// their schedules are sensitive to any change of it (+-1.5 % from semantically neutral edits).
+template <int HT, int L, int ZR, int CR, int ARITH>
+__device__ __forceinline__ void vjp_probe_hoisted(const float* __restrict__ smem, int lane, bool reg_j, float scale,
+                                                  const float (&ep)[ZR], const f32x4 (&pc)[HT], const f32x4 (&d)[L][HT],
+                                                  float& ld, float& nd) {
+    constexpr MfmaLayout LAY(HT, L, ZR, CR, true, ARITH);
+    constexpr int DT = (ZR + 3) / 4;
+    int opq = 0;
+    asm volatile("" : "+v"(opq));
+    const float* __restrict__ sm = smem + opq;
+    f32x4 dl[HT];
+    tiles_mul_named<HT>(pc, d[L - 1], dl);
+#pragma unroll
+    for (int l = L - 1; l >= 1; --l) {  // W_{l+1}^T delta, times act'(a_l)
+        f32x4 acc[HT];
+#pragma unroll
+        for (int mt = 0; mt < HT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        phase_fence();
+        gemm_hidden<HT, ARITH>(sm + LAY.bh + (l - 1) * LAY.imgHid(), lane, dl, acc);
+        phase_fence();
+        tiles_mul_named<HT>(acc, d[l - 1], dl);
+    }
+    f32x4 gacc[DT];
+#pragma unroll
+    for (int dt_ = 0; dt_ < DT; ++dt_) gacc[dt_] = f32x4{0.f, 0.f, 0.f, 0.f};
+    gemm_tiles<DT, 4 * HT>(sm + LAY.b1, lane, TileIn<HT>{dl}, gacc);   // W_1[:,0:D]^T delta_1
+    float dot = 0.f, n2 = 0.f;
+#pragma unroll
+    for (int s = 0; s < ZR; ++s) {
+        const float gv = gacc[s >> 2][s & 3];
+        dot = fmaf(gv, ep[s], dot);
+        n2 = fmaf(gv, gv, n2);
+    }
+    ld -= scale * group_sum(dot);
+    if (reg_j) nd += scale * fast_sqrt(group_sum(n2));   // ndot = |eps^T J|_2 (icnf.jl:229-245)
+}
+
 // One dynamics evaluation for a 16-sample tile.
 //   forward pass (shared), then
 //   ENG_VJP: pullback of KP probes with the transposed images  (g = eps^T J;  src/core/utils.jl:150-159)
@@ -277,7 +380,7 @@ __device__ __forceinline__ void dyn_eval(const float* __restrict__ smem, const f
                                          const float (&z)[ZR], const float (&y)[CR > 0 ? CR : 1],
                                          const float (&eps)[KP][ZR], const f32x4 (&pre_c)[HT],
                                          const f32x4 (&pre_q)[HT], float (&zd)[ZR], float& ld,
-                                         float& ed, float& nd) {
+                                         float& ed, float& nd, const f32x4 (&pre_ck)[(PRE >= 1 && KP > 1) ? KP : 1][HT]) {
     constexpr MfmaLayout LAY(HT, L, ZR, CR, ENGINE == ENG_VJP, ARITH);
     constexpr int DT = (ZR + 3) / 4;
     const int g = lane >> 4;
@@ -327,7 +430,9 @@ __device__ __forceinline__ void dyn_eval(const float* __restrict__ smem, const f
         float e2 = 0.f;
 #pragma unroll
         for (int s = 0; s < ZR; ++s) e2 = fmaf(zd[s], zd[s], e2);
-        ed = sqrtf(group_sum(e2));   // Edot = |zdot|_2   (src/core/icnf.jl:184-199)
+        // Edot = |zdot|_2   (src/core/icnf.jl:184-199); the several-probe instances take v_sqrt_f32 alone
+        if constexpr (PRE >= 1 && KP > 1) ed = fast_sqrt(group_sum(e2));
+        else ed = sqrtf(group_sum(e2));
     }
     ld = 0.f;
     nd = 0.f;
@@ -355,6 +460,14 @@ __device__ __forceinline__ void dyn_eval(const float* __restrict__ smem, const f
         }
     }
     const float scale = (ENGINE == ENG_TAN && exact) ? 1.f : 1.f / (float)K;
+    if constexpr (ENGINE == ENG_VJP && PRE >= 1 && KP > 1) {
+        // K == KP exactly (the plan picks such an instance only for nprobes == KP)
+        static_for<0, KP>([&](auto pi) {
+            constexpr int p = decltype(pi)::value;
+            vjp_probe_hoisted<HT, L, ZR, CR, ARITH>(smem, lane, reg_j, scale, eps[p], pre_ck[p], d, ld, nd);
+        });
+        return;
+    }
 #pragma clang loop unroll(disable)
     for (int p = 0; p < nseed; ++p) {
         float ep[ZR];
@@ -529,7 +642,18 @@ mfma_solve_kernel(KArgs a) {
         f32x4 pre_c[HT], pre_q[HT];
 #pragma unroll
         for (int mt = 0; mt < HT; ++mt) pre_c[mt] = pre_q[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if constexpr (PRE >= 1) gemm_tiles<HT, ZR>(smem + LAY.bN, lane, RegIn<ZR>{eps[0]}, pre_c);
+        if constexpr (PRE >= 1 && KP == 1) gemm_tiles<HT, ZR>(smem + LAY.bN, lane, RegIn<ZR>{eps[0]}, pre_c);
+        // several probes: c_k = W_N^T eps_k of every probe, once per tile (see vjp_probe_hoisted)
+        static_assert(PRE == 0 || ENGINE == ENG_VJP, "hoisting is a VJP-engine feature");
+        static_assert(PRE < 2 || KP == 1, "the dot-product shortcut (PRE = 2) is instantiated for one probe");
+        f32x4 pre_ck[(PRE >= 1 && KP > 1) ? KP : 1][HT];
+        if constexpr (PRE >= 1 && KP > 1)
+            static_for<0, KP>([&](auto pi) {
+                constexpr int p = decltype(pi)::value;
+#pragma unroll
+                for (int mt = 0; mt < HT; ++mt) pre_ck[p][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                gemm_tiles<HT, ZR>(smem + LAY.bN, lane, RegIn<ZR>{eps[p]}, pre_ck[p]);
+            });
         if constexpr (PRE >= 2) {
             gemm_tiles<HT, ZR>(smem + LAY.f1z, lane, RegIn<ZR>{eps[0]}, pre_q);
             if constexpr (ACT == CNF_ACT_TANH_PRESCALED) {   // the forward image carries the tanh pre-scale
@@ -569,7 +693,7 @@ mfma_solve_kernel(KArgs a) {
                 asm volatile("" : "+v"(opaque));
                 dyn_eval<HT, L, ZR, CR, ACT, ENGINE, KP, PRE, ARITH>(smem + opaque, a.packed + opaque, lane, tn + a.T.c[st] * dt, autonomous,
                                                               reg_z, reg_j, exact, D, K, zs, y, eps, pre_c, pre_q, zd,
-                                                              ld, ed, nd);
+                                                              ld, ed, nd, pre_ck);
                 if (a.ckpt_k) {
 #pragma unroll
                     for (int s = 0; s < ZR; ++s)
@@ -798,7 +922,18 @@ mfma_adaptive_kernel(KArgs a, AArgs q) {
     f32x4 pre_c[HT], pre_q[HT];
 #pragma unroll
     for (int mt = 0; mt < HT; ++mt) pre_c[mt] = pre_q[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if constexpr (PRE >= 1) gemm_tiles<HT, ZR>(smem + LAY.bN, lane, RegIn<ZR>{eps[0]}, pre_c);
+    if constexpr (PRE >= 1 && KP == 1) gemm_tiles<HT, ZR>(smem + LAY.bN, lane, RegIn<ZR>{eps[0]}, pre_c);
+    // several probes: c_k = W_N^T eps_k of every probe, once per tile (see vjp_probe_hoisted)
+    static_assert(PRE == 0 || ENGINE == ENG_VJP, "hoisting is a VJP-engine feature");
+    static_assert(PRE < 2 || KP == 1, "the dot-product shortcut (PRE = 2) is instantiated for one probe");
+    f32x4 pre_ck[(PRE >= 1 && KP > 1) ? KP : 1][HT];
+    if constexpr (PRE >= 1 && KP > 1)
+        static_for<0, KP>([&](auto pi) {
+            constexpr int p = decltype(pi)::value;
+#pragma unroll
+            for (int mt = 0; mt < HT; ++mt) pre_ck[p][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            gemm_tiles<HT, ZR>(smem + LAY.bN, lane, RegIn<ZR>{eps[p]}, pre_ck[p]);
+        });
     if constexpr (PRE >= 2) {
         gemm_tiles<HT, ZR>(smem + LAY.f1z, lane, RegIn<ZR>{eps[0]}, pre_q);
         if constexpr (ACT == CNF_ACT_TANH_PRESCALED) {
@@ -834,7 +969,7 @@ mfma_adaptive_kernel(KArgs a, AArgs q) {
         int opaque = 0;
         asm volatile("" : "+v"(opaque));
         dyn_eval<HT, L, ZR, CR, ACT, ENGINE, KP, PRE, ARITH>(smem + opaque, a.packed + opaque, lane, tcur, autonomous, reg_z, reg_j, exact,
-                                                      D, K, zs, y, eps, pre_c, pre_q, zd, ld, ed, nd);
+                                                      D, K, zs, y, eps, pre_c, pre_q, zd, ld, ed, nd, pre_ck);
         ++nf;
         bool begin = false;
         if (phase == 0) {
@@ -1078,7 +1213,18 @@ mfma_vcabm_kernel(KArgs a, AArgs q) {
     f32x4 pre_c[HT], pre_q[HT];
 #pragma unroll
     for (int mt = 0; mt < HT; ++mt) pre_c[mt] = pre_q[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if constexpr (PRE >= 1) gemm_tiles<HT, ZR>(smem + LAY.bN, lane, RegIn<ZR>{eps[0]}, pre_c);
+    if constexpr (PRE >= 1 && KP == 1) gemm_tiles<HT, ZR>(smem + LAY.bN, lane, RegIn<ZR>{eps[0]}, pre_c);
+    // several probes: c_k = W_N^T eps_k of every probe, once per tile (see vjp_probe_hoisted)
+    static_assert(PRE == 0 || ENGINE == ENG_VJP, "hoisting is a VJP-engine feature");
+    static_assert(PRE < 2 || KP == 1, "the dot-product shortcut (PRE = 2) is instantiated for one probe");
+    f32x4 pre_ck[(PRE >= 1 && KP > 1) ? KP : 1][HT];
+    if constexpr (PRE >= 1 && KP > 1)
+        static_for<0, KP>([&](auto pi) {
+            constexpr int p = decltype(pi)::value;
+#pragma unroll
+            for (int mt = 0; mt < HT; ++mt) pre_ck[p][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            gemm_tiles<HT, ZR>(smem + LAY.bN, lane, RegIn<ZR>{eps[p]}, pre_ck[p]);
+        });
     if constexpr (PRE >= 2) {
         gemm_tiles<HT, ZR>(smem + LAY.f1z, lane, RegIn<ZR>{eps[0]}, pre_q);
         if constexpr (ACT == CNF_ACT_TANH_PRESCALED) {
@@ -1112,7 +1258,7 @@ mfma_vcabm_kernel(KArgs a, AArgs q) {
         int opaque = 0;
         asm volatile("" : "+v"(opaque));
         dyn_eval<HT, L, ZR, CR, ACT, ENGINE, KP, PRE, ARITH>(smem + opaque, a.packed + opaque, lane, tcur, autonomous, reg_z, reg_j, exact,
-                                                      D, K, zs, y, eps, pre_c, pre_q, zd, ld, ed, nd);
+                                                      D, K, zs, y, eps, pre_c, pre_q, zd, ld, ed, nd, pre_ck);
         ++nf;
 #pragma unroll
         for (int s = 0; s < ZR; ++s) X[s] = zd[s];

@@ -1,10 +1,24 @@
 #!/usr/bin/env python3
-"""One-line summary of a bench.py JSON line read from stdin (optionally prefixed by a tag given as argv[1])."""
+"""One-line summary of bench.py JSON lines: `brief.py FILE...` (the file name is the tag), or from stdin with an optional tag
+as argv[1].  An argument that names an existing file is always read as a file (never waits on stdin)."""
 import json
+import os
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else ""
-for line in sys.stdin:
+
+def lines():
+    files = [a for a in sys.argv[1:] if os.path.isfile(a)]
+    if files:
+        for f in files:
+            for line in open(f):
+                yield os.path.basename(f), line
+    else:
+        t = sys.argv[1] if len(sys.argv) > 1 else ""
+        for line in sys.stdin:
+            yield t, line
+
+
+for tag, line in lines():
     if not line.startswith("{"):
         continue
     d = json.loads(line)

@@ -1443,7 +1443,7 @@ def test_gradient_of_the_adaptive_solve_on_its_frozen_grid(kw, lam, gpath, pkg, 
     ts = icnf.last_solve_stats["tgrid"]
     assert len(ts) >= 5 and ts[0] == 0.0 and ts[-1] == 1.0 and len(set(np.round(np.diff(ts), 6))) > 1   # non-uniform
     L, gref, gxref = o64.loss_and_grad(spec, p, xs, 0.0, 1.0, len(ts) - 1, 1, eps, ys, lam, wrt_x=True, tgrid=ts)
-    assert abs(float(val) - L) < 1e-4
+    assert abs(float(val) - L) < 1e-4 + 2e-6 * abs(L)       # (a loss of 300 has a Float32 ulp of 3e-5)
     assert np.max(np.abs(g.cpu().numpy() - gref)) < 5e-5 * np.abs(gref).max() + 1e-6
     assert np.max(np.abs(gx.cpu().numpy() - gxref)) < 5e-5 * np.abs(gxref).max() + 1e-7
     # and the loss of the grid solve is the loss the adaptive inference reports
