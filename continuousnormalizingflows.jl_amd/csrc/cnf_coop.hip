@@ -39,14 +39,17 @@ namespace cnf {
 // A fragments of k-group kg for M-tiles mt0 .. mt0 + M - 1 (global image, 16 B per lane, coalesced); A already points at the lane
 // (buffer loads: the image offset of the fragment is wave-uniform and rides in an SGPR, the lane's 16-byte slot in a VGPR
 // that never changes - no address VALU in the loop; f32 MFMAs and VALU instructions share the issue slot)
-struct AImg { __amdgpu_buffer_rsrc_t r; unsigned off; unsigned lane16; };
+// `wl` != nullptr: the packed image has been staged into LDS (the tile-split small-batch form, NT = 1: with one sample tile a
+// k-group is 4 MFMAs per M-tile, far too little to hide an L2 round trip per fragment) and fragments are ds_read_b128.
+struct AImg { __amdgpu_buffer_rsrc_t r; unsigned off; unsigned lane16; const float* wl; };
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 template <int M>
 __device__ __forceinline__ void coop_load_a(const AImg& A, int mt0, int KG, int kg, f32x4 (&a)[M]) {
 #pragma unroll
     for (int m = 0; m < M; ++m) {
         const unsigned so = A.off + (unsigned)(((mt0 + m) * KG + kg) * 1024);
-        a[m] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(A.r, (int)A.lane16, (int)so, 0));
+        if (A.wl) a[m] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(A.wl) + so + A.lane16);
+        else a[m] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(A.r, (int)A.lane16, (int)so, 0));
     }
 }
 // B fragments of k-group kg for sample tiles nt0 .. nt0 + NQ - 1 (LDS exchange image, conflict-free ds_read_b128)
@@ -97,9 +100,10 @@ __device__ __forceinline__ void gload_cvec(const float* __restrict__ vec, int mt
 // NT: sample tiles per super-tile (4: one workgroup per CU owns 64 samples; 2: two workgroups per CU own 32 samples each - half
 // the exchange buffers and half the accumulators per wave, so two waves share each SIMD and fill each other's stalls, at the
 // price of each weight fragment feeding 2 sample tiles instead of 4).  Waves 0 .. NT-1 own the ODE state of one sample tile.
-template <int HT, int L, int ZR, int ACT, int NT>
-__device__ __forceinline__ void coop_eval(const float* __restrict__ P, f32x4* __restrict__ xbuf,
-                                          f32x4* __restrict__ zbuf, const f32x4* __restrict__ ebuf,
+// WL: the packed image sits in LDS at `wl` (see AImg); P is then only the global copy it was staged from
+template <int HT, int L, int ZR, int ACT, int NT, bool WL = false>
+__device__ __forceinline__ void coop_eval(const float* __restrict__ P, const float* __restrict__ wl, f32x4* __restrict__ xbuf,
+                                          f32x4* __restrict__ zbuf, const f32x4* __restrict__ ebuf, f32x4* __restrict__ pbuf,
                                           int lane, int wave, float t, bool autonomous, bool reg_z,
                                           bool reg_j, const float (&zs)[ZR],
                                           float (&zd)[ZR], float& ld, float& ed, float& nd) {
@@ -111,12 +115,17 @@ __device__ __forceinline__ void coop_eval(const float* __restrict__ P, f32x4* __
     // image offsets are multiples of 4 floats; fragment loads go through a buffer resource over the packed image
     const __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P), 0, 0x7fffffff, 0x00020000);
     const unsigned lane16 = (unsigned)lane * 16u;
-#define AIMG(X) AImg{rP, (unsigned)(X) * 4u, lane16}
+    const float* __restrict__ PV = WL ? wl : P;   // bias / time-column vectors
+#define AIMG(X) AImg{rP, (unsigned)(X) * 4u, lane16, WL ? wl : nullptr}
     f32x4 afr[MTW];                      // first A fragments of the next H-row product, requested one phase ahead
     f32x4 afd[DT];                       // ... of the next D-row product (last layer, W_1^T)
     // act' of this wave's features, kept for the pullback - except the LAST hidden layer's when it can be rebuilt from the
     // activations themselves, which stay in the exchange buffer until delta_{L-1} replaces them (tanh: 1 - h^2): 64 registers
-    constexpr bool D_FROM_H = (ACT == CNF_ACT_TANH_PRESCALED || ACT == CNF_ACT_TANH);
+    // NT == 1 (tile-split form): the two D-row products (zdot = W_N h_L and g = W_1[:,0:D]^T delta_1) are split over the waves
+    // along K - wave w multiplies the k-groups of its OWN features straight from its registers and publishes a partial tile,
+    // the owner adds the four partials in wave order - instead of the owner running all HT k-groups while three SIMDs wait
+    constexpr bool SPLITK = NT == 1;
+    constexpr bool D_FROM_H = (ACT == CNF_ACT_TANH_PRESCALED || ACT == CNF_ACT_TANH) && !SPLITK;
     constexpr int LD = D_FROM_H ? (L > 1 ? L - 1 : 1) : L;
     f32x4 d[LD][MTW][NT];
     f32x4 acc[MTW][NT];
@@ -124,8 +133,8 @@ __device__ __forceinline__ void coop_eval(const float* __restrict__ P, f32x4* __
     {
         f32x4 bias[MTW], wt[MTW];
         coop_load_a<MTW>(AIMG(LAY.f1z), mt0, DT, 0, afr);
-        gload_cvec<MTW>(P + LAY.v_b1, mt0, g, bias);
-        gload_cvec<MTW>(P + LAY.v_w1t, mt0, g, wt);
+        gload_cvec<MTW>(PV + LAY.v_b1, mt0, g, bias);
+        gload_cvec<MTW>(PV + LAY.v_w1t, mt0, g, wt);
         // publish this wave's stage state as the B image of sample tile `wave`
         if (owner) {
 #pragma unroll
@@ -153,7 +162,9 @@ __device__ __forceinline__ void coop_eval(const float* __restrict__ P, f32x4* __
         const int cur = l & 1;
         // request what the NEXT product needs before this layer's activation / exchange / barrier phase
         if (l + 1 < L) coop_load_a<MTW>(AIMG(LAY.fh + l * MfmaLayout::imgA(HT, HT)), mt0, HT, 0, afr);
+        else if (SPLITK) coop_load_a<DT>(AIMG(LAY.fN), 0, HT, mt0, afd);
         else if (owner) coop_load_a<DT>(AIMG(LAY.fN), 0, HT, 0, afd);
+        f32x4 hown[SPLITK ? MTW : 1];
 #pragma unroll
         for (int m = 0; m < MTW; ++m)
 #pragma unroll
@@ -161,12 +172,28 @@ __device__ __forceinline__ void coop_eval(const float* __restrict__ P, f32x4* __
                 f32x4 h, dd;
                 act_tile<ACT>(acc[m][q], h, dd);
                 if (!(D_FROM_H && l == L - 1 && L > 1)) d[l < LD ? l : 0][m][q] = dd;
-                xbuf[cur * XB + ((mt0 + m) * NT + q) * 64 + lane] = h;
+                if (SPLITK && l == L - 1) hown[SPLITK ? m : 0] = h;
+                else xbuf[cur * XB + ((mt0 + m) * NT + q) * 64 + lane] = h;
             }
+        if constexpr (SPLITK) {
+            if (l == L - 1) {   // partial of zdot over this wave's own k-groups
+                f32x4 zp[DT][1];
+#pragma unroll
+                for (int dt_ = 0; dt_ < DT; ++dt_) zp[dt_][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int m = 0; m < MTW; ++m) {
+                    if (m > 0) coop_load_a<DT>(AIMG(LAY.fN), 0, HT, mt0 + m, afd);
+                    f32x4 hb[1] = {hown[m]};
+                    coop_frag_mfma<DT, 1>(afd, hb, zp);
+                }
+#pragma unroll
+                for (int dt_ = 0; dt_ < DT; ++dt_) pbuf[(wave * DT + dt_) * 64 + lane] = zp[dt_][0];
+            }
+        }
         if (l + 1 < L) {
             // the next layer's bias goes straight into the accumulators (dead now); the request overlaps the barrier
             f32x4 bnx[MTW];
-            gload_cvec<MTW>(P + LAY.v_bh + l * MfmaLayout::vecC(HT), mt0, g, bnx);
+            gload_cvec<MTW>(PV + LAY.v_bh + l * MfmaLayout::vecC(HT), mt0, g, bnx);
 #pragma unroll
             for (int m = 0; m < MTW; ++m)
 #pragma unroll
@@ -184,12 +211,19 @@ __device__ __forceinline__ void coop_eval(const float* __restrict__ P, f32x4* __
     if (owner) {
         f32x4 zacc[DT][1];
         f32x4 bias[DT];
-        gload_cvec<DT>(P + LAY.v_bN, 0, g, bias);
+        gload_cvec<DT>(PV + LAY.v_bN, 0, g, bias);
 #pragma unroll
         for (int m = 0; m < DT; ++m) zacc[m][0] = bias[m];
-        phase_fence();
-        coop_gemm<DT, 1, NT>(AIMG(LAY.fN), 0, HT, xbuf + hbuf * XB, wave, lane, afd, zacc);
-        phase_fence();
+        if constexpr (SPLITK) {
+#pragma unroll
+            for (int w = 0; w < 4; ++w)
+#pragma unroll
+                for (int m = 0; m < DT; ++m) zacc[m][0] += pbuf[(w * DT + m) * 64 + lane];
+        } else {
+            phase_fence();
+            coop_gemm<DT, 1, NT>(AIMG(LAY.fN), 0, HT, xbuf + hbuf * XB, wave, lane, afd, zacc);
+            phase_fence();
+        }
 #pragma unroll
         for (int s = 0; s < ZR; ++s) zd[s] = zacc[s >> 2][0][s & 3];
     }
@@ -232,10 +266,23 @@ __device__ __forceinline__ void coop_eval(const float* __restrict__ P, f32x4* __
                 for (int q = 0; q < NT; ++q) dm[q] = d[l < LD ? l : 0][m][q];
             }
             tiles_mul<NT>(acc[m], dm, dl);
+            if constexpr (SPLITK) {
+                if (l == 0) {   // partial of g = W_1[:,0:D]^T delta_1 over this wave's own k-groups (accumulated in acc[0][0..])
+                    f32x4 gp[DT][1];
+                    coop_load_a<DT>(AIMG(LAY.b1), 0, HT, mt0 + m, afd);
+#pragma unroll
+                    for (int dt_ = 0; dt_ < DT; ++dt_) gp[dt_][0] = m == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : pbuf[(wave * DT + dt_) * 64 + lane];
+                    f32x4 db[1] = {dl[0]};
+                    coop_frag_mfma<DT, 1>(afd, db, gp);
+#pragma unroll
+                    for (int dt_ = 0; dt_ < DT; ++dt_) pbuf[(wave * DT + dt_) * 64 + lane] = gp[dt_][0];
+                    continue;
+                }
+            }
 #pragma unroll
             for (int q = 0; q < NT; ++q) xbuf[wbuf * XB + ((mt0 + m) * NT + q) * 64 + lane] = dl[q];
         }
-        if (l == 0 && owner) coop_load_a<DT>(AIMG(LAY.b1), 0, HT, 0, afd);
+        if (l == 0 && owner && !SPLITK) coop_load_a<DT>(AIMG(LAY.b1), 0, HT, 0, afd);
         __syncthreads();
         if (l > 0) {
 #pragma unroll
@@ -251,9 +298,16 @@ __device__ __forceinline__ void coop_eval(const float* __restrict__ P, f32x4* __
             f32x4 gacc[DT][1];
 #pragma unroll
             for (int m = 0; m < DT; ++m) gacc[m][0] = f32x4{0.f, 0.f, 0.f, 0.f};
-            phase_fence();
-            coop_gemm<DT, 1, NT>(AIMG(LAY.b1), 0, HT, xbuf + wbuf * XB, wave, lane, afd, gacc);
-            phase_fence();
+            if constexpr (SPLITK) {
+#pragma unroll
+                for (int w = 0; w < 4; ++w)
+#pragma unroll
+                    for (int m = 0; m < DT; ++m) gacc[m][0] += pbuf[(w * DT + m) * 64 + lane];
+            } else {
+                phase_fence();
+                coop_gemm<DT, 1, NT>(AIMG(LAY.b1), 0, HT, xbuf + wbuf * XB, wave, lane, afd, gacc);
+                phase_fence();
+            }
             // this lane's probe values sit in the B image of eps (k-group kg, own sample tile): no registers held for them
             float dot = 0.f, n2 = 0.f;
 #pragma unroll
@@ -275,14 +329,28 @@ __device__ __forceinline__ void coop_eval(const float* __restrict__ P, f32x4* __
 }
 
 // NS: Runge-Kutta stages of the instance (4: RK4, 6: Tsit5) - the partial sums of the later stages' increments take NS - 1 rows
-template <int HT, int L, int ZR, int ACT, int NS, int NT>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NT == 4 ? 1 : 2, NT == 4 ? 1 : 2)))
+// WL (with NT = 1): the tile-split form for small batches - one 16-sample tile per workgroup, its hidden width split over the
+// four waves (one per SIMD), the operand images staged into LDS once per workgroup.  A batch of <= one tile per compute unit
+// otherwise runs on one wave per tile at ~40 % MFMA utilisation with three SIMDs of every CU idle.
+template <int HT, int L, int ZR, int ACT, int NS, int NT, bool WL = false>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, NT == 4 ? 1 : 2)))
 coop_vjp_solve_kernel(KArgs a) {
     constexpr int DT = (ZR + 3) / 4, XB = HT * NT * 64;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     f32x4* xbuf = reinterpret_cast<f32x4*>(smem);   // [2][HT][NT sample tiles][64 lanes]
     f32x4* zbuf = xbuf + 2 * XB;                     // [DT][NT][64]
     f32x4* ebuf = zbuf + DT * NT * 64;               // [DT][NT][64]
+    f32x4* pbuf = ebuf + DT * NT * 64;               // NT == 1: [4 waves][DT][64] partial tiles of the D-row products
+    constexpr int PB = NT == 1 ? 4 * DT * 64 : 0;
+    const float* wl = nullptr;
+    if constexpr (WL) {
+        constexpr MfmaLayout LAYW(HT, L, ZR, 0, true);
+        f32x4* dst = pbuf + PB;
+        const f32x4* src = reinterpret_cast<const f32x4*>(a.packed);
+        for (int i = threadIdx.x; i < LAYW.lds_total / 4; i += 256) dst[i] = src[i];
+        wl = reinterpret_cast<const float*>(dst);
+        // (the first __syncthreads of the super-tile loop orders these writes before any fragment read)
+    }
     const int lane = threadIdx.x & 63, g = lane >> 4, n = lane & 15;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int D = a.D, S = D + 3;
@@ -342,7 +410,7 @@ coop_vjp_solve_kernel(KArgs a) {
                 float zs[ZR];
 #pragma unroll
                 for (int s = 0; s < ZR; ++s) zs[s] = fmaf(dt, Pz[0][s], z[s]);
-                coop_eval<HT, L, ZR, ACT, NT>(a.packed, xbuf, zbuf, ebuf, lane, wave, tn + a.T.c[sg] * dt, autonomous,
+                coop_eval<HT, L, ZR, ACT, NT, WL>(a.packed, wl, xbuf, zbuf, ebuf, pbuf, lane, wave, tn + a.T.c[sg] * dt, autonomous,
                                           reg_z, reg_j, zs, zd, ld, ed, nd);
                 const float bst = a.T.b[sg];
                 lsum = fmaf(bst, ld, lsum); esum = fmaf(bst, ed, esum); nsum = fmaf(bst, nd, nsum);
@@ -398,11 +466,13 @@ coop_vjp_solve_kernel(KArgs a) {
 // ---------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------
-template <int HT, int L, int ZR, int ACT, int NS, int NT>
+template <int HT, int L, int ZR, int ACT, int NS, int NT, bool WL = false>
 static hipError_t launch_coop(const KArgs& a, int nblocks, hipStream_t st) {
     constexpr int DT = (ZR + 3) / 4;
-    constexpr int lds = (2 * HT * NT * 64 + 2 * DT * NT * 64) * 16;
-    auto kern = coop_vjp_solve_kernel<HT, L, ZR, ACT, NS, NT>;
+    constexpr int lds = (2 * HT * NT * 64 + 2 * DT * NT * 64 + (NT == 1 ? 4 * DT * 64 : 0)) * 16 +
+                        (WL ? MfmaLayout(HT, L, ZR, 0, true).lds_total * 4 : 0);
+    static_assert(lds <= 160 * 1024, "exchange buffers + staged image exceed LDS");
+    auto kern = coop_vjp_solve_kernel<HT, L, ZR, ACT, NS, NT, WL>;
     static DeviceOnce once;
     int dev = 0;
     hipError_t e0 = hipGetDevice(&dev);
@@ -455,6 +525,35 @@ static const CoopInst* coop_find(int HT, int L, int ZR, int ACT) {
             best = &c;
     }
     return best;
+}
+
+// ---- the tile-split small-batch form: exact shapes only (it shares the per-wave instance's packed image) ----
+struct SplitInst {
+    int HT, L, ZR, ACT;
+    hipError_t (*fn[2])(const KArgs&, int, hipStream_t);   // [0] <= 4 stages (RK4), [1] <= 6 stages (Tsit5)
+};
+#define SPLIT_INST(HT, L, ZR, ACT) \
+    SplitInst { HT, L, ZR, ACT, { &launch_coop<HT, L, ZR, ACT, 4, 1, true>, &launch_coop<HT, L, ZR, ACT, 6, 1, true> } }
+static const SplitInst kSplit[] = {
+    SPLIT_INST(4, 3, 2, CNF_ACT_TANH_PRESCALED),   // D <= 8, 3x64 tanh (cfg2 / cfg2' at small batches)
+    SPLIT_INST(4, 2, 2, CNF_ACT_TANH_PRESCALED),
+    SPLIT_INST(4, 3, 2, CNF_ACT_SOFTPLUS),
+    SPLIT_INST(4, 2, 2, CNF_ACT_SOFTPLUS),
+    // the generic zero-padded per-wave instances (cnf_mfma_generic.hip) pad the state to 4 k-steps: D <= 16
+    SPLIT_INST(4, 3, 4, CNF_ACT_TANH_PRESCALED), SPLIT_INST(4, 2, 4, CNF_ACT_TANH_PRESCALED),
+    SPLIT_INST(4, 3, 4, CNF_ACT_SOFTPLUS), SPLIT_INST(4, 2, 4, CNF_ACT_SOFTPLUS),
+};
+static const SplitInst* split_find(int HT, int L, int ZR, int ACT) {
+    for (const SplitInst& c : kSplit)
+        if (c.HT == HT && c.L == L && c.ZR == ZR && (c.ACT == ACT || (c.ACT == CNF_ACT_TANH_PRESCALED && ACT == CNF_ACT_TANH))) return &c;
+    return nullptr;
+}
+bool coop_split_supported(int HT, int L, int ZR, int ACT) { return split_find(HT, L, ZR, ACT) != nullptr; }
+hipError_t coop_split_launch(int HT, int L, int ZR, int ACT, const KArgs& a, hipStream_t st) {
+    const SplitInst* c = split_find(HT, L, ZR, ACT);
+    if (!c) return hipErrorNotSupported;
+    const long long ntiles = (a.B + 15) / 16;
+    return c->fn[a.T.ns <= 4 ? 0 : 1](a, (int)ntiles, st);
 }
 
 bool coop_supported(int HT, int L, int ZR, int CR, int ACT, int engine, int KP, int* ZR_inst, int* HT_inst) {

@@ -413,6 +413,17 @@ hipError_t mfma_solve(MfmaPlan* p, const float* packed_dev, const SolveArgs& s, 
     }
     if (p->kind == 1) return coop_launch(p->HT, p->L, p->ZR, p->ACT, a, mp->num_cus, st);
     const long long ntiles = (s.B + 15) / 16;
+    // Small batches (at most one 16-sample tile per compute unit): the tile-split form - the tile's hidden width over the four
+    // SIMDs of a CU (cnf_coop.hip, NT = 1) - instead of one wave per tile with three SIMDs of its CU idle.  Same packed image
+    // (the layouts coincide: forward + transposed images, pre-scaled tanh), same arithmetic per product; the sums over a
+    // sample's lane groups are taken in the same order.  Whole fixed-step solves only: single dynamics calls (boundary A, the
+    // attempts of the adaptive host loops) stay on the per-wave kernel, whose arithmetic the one-launch adaptive kernels share
+    // bit for bit.  CNF_TILE_SPLIT=0 keeps the per-wave kernel everywhere, =2 forces the split form at any batch size.
+    const int split_env = env_int("CNF_TILE_SPLIT", 1);   // read per call: tests and A/B runs switch it inside one process
+    if (split_env > 0 && s.nsteps > 0 && p->ENGINE == ENG_VJP && p->KP == 1 && p->CR == 0 && p->arith == 0 && p->with_bwd && !s.ckpt && !s.ckpt_k &&
+        !s.kfull && !mp->use_queue && (split_env == 2 || ntiles <= mp->num_cus) && p->ZR * 4 >= a.D &&
+        coop_split_supported(p->HT, p->L, p->ZR, p->ACT))
+        return coop_split_launch(p->HT, p->L, p->ZR, p->ACT, a, st);
     const int wpb = p->nthreads / 64;
     long long want = ntiles;   // tile t runs on workgroup t % nblocks (cnf_mfma_kernel.h): small batches spread over the CUs
     (void)wpb;

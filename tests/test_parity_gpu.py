@@ -164,6 +164,53 @@ def test_cooperative_wide_layer_kernel_matches_per_wave_kernel(pkg, oracles, mon
     assert np.max(np.abs(coop[2].cpu().numpy() - ref[2])) < TOL_SOLVE
 
 
+@pytest.mark.parametrize("kw,alg", [
+    (dict(nvars=8, hidden=[64, 64, 64]), 1),                                  # cfg2' shape: the per-wave instance's hoisting form (PRE = 2)
+    (dict(nvars=8, hidden=[64, 64, 64], reg_z=True, reg_j=True), 0),          # RNODE, one probe, RK4
+    (dict(nvars=5, naug=2, hidden=[64, 64], act=2, reg_z=True, reg_aug=True), 1),   # softplus, two hidden layers, augmented
+    (dict(nvars=11, hidden=[50, 64, 40]), 1),                                 # generic zero-padded instance (4 state k-steps, ragged widths)
+])
+def test_tile_split_kernel_for_small_batches(kw, alg, pkg, oracles):
+    """Batches of at most one 16-sample tile per compute unit run on the tile-split form (cnf_coop.hip with one sample tile per
+    workgroup: the hidden width over the four SIMDs of a CU, images in LDS) instead of one wave per tile.  It is the same
+    augmented_f / solve (src/core/icnf.jl:517-559): checked against the C restatement, against the per-wave kernel on the
+    same inputs (CNF_TILE_SPLIT=0), for ragged batches, the final state, and generate."""
+    import os
+    o64, oc = oracles
+    spec = o64.make_spec(**kw)
+    nsteps = 12
+    icnf = make_icnf(pkg, spec, alg, nsteps, path=2)
+    mode = mode_of(pkg, spec)
+    old = os.environ.get("CNF_TILE_SPLIT")
+    try:
+        for B in (1, 16, 45, 1000, 4096):
+            p, xs, eps, ys = o64.synth_inputs(spec, B, 300 + B, bias_scale=0.2)
+            ref = oc.inference_fixed(spec, p, xs, 0.0, 1.0, nsteps, alg, eps, ys, nthreads=8)
+            out = {}
+            for tag, env in (("wave", "0"), ("split", "2")):
+                os.environ["CNF_TILE_SPLIT"] = env
+                logp, regs, u1 = run_inference(pkg, icnf, spec, p, xs, eps, ys, return_state=True)
+                out[tag] = (logp.cpu().numpy(), [r.cpu().numpy() for r in regs], u1.cpu().numpy())
+                assert np.max(np.abs(out[tag][0] - ref[0])) < TOL_SOLVE, (tag, B)
+                for a_, b_ in zip(out[tag][1], ref[1]):
+                    assert np.max(np.abs(a_ - b_)) < TOL_SOLVE, (tag, B)
+            assert np.max(np.abs(out["wave"][0] - out["split"][0])) < 2e-5
+            assert np.max(np.abs(out["wave"][2] - out["split"][2])) < 2e-5
+        # generate (the reversed solve) on the split form inverts the forward solve
+        os.environ["CNF_TILE_SPLIT"] = "2"
+        if not spec.ncond:
+            B = 333
+            p, xs, eps, ys = o64.synth_inputs(spec, B, 77, bias_scale=0.2)
+            _, _, u1 = run_inference(pkg, icnf, spec, p, xs, eps, ys, return_state=True)
+            back = pkg.generate(icnf, mode, dev(p), {}, B, z0=u1[:spec.D].contiguous(), eps=dev(eps))
+            assert np.max(np.abs(back.cpu().numpy() - xs)) < 5e-3          # 12 steps of RK4 / Tsit5 there and back
+    finally:
+        if old is None:
+            os.environ.pop("CNF_TILE_SPLIT", None)
+        else:
+            os.environ["CNF_TILE_SPLIT"] = old
+
+
 def make_icnf_bf16x6(pkg, spec, alg, nsteps):
     icnf = make_icnf(pkg, spec, alg, nsteps, path=2)
     icnf.compute_mode.arith = pkg._lib.ARITH_BF16X6
