@@ -346,8 +346,7 @@ coop_vjp_solve_kernel(KArgs a) {
     if constexpr (WL) {
         constexpr MfmaLayout LAYW(HT, L, ZR, 0, true);
         f32x4* dst = pbuf + PB;
-        const f32x4* src = reinterpret_cast<const f32x4*>(a.packed);
-        for (int i = threadIdx.x; i < LAYW.lds_total / 4; i += 256) dst[i] = src[i];
+        stage_image<256>(a.packed, reinterpret_cast<float*>(dst), LAYW.lds_total / 4);
         wl = reinterpret_cast<const float*>(dst);
         // (the first __syncthreads of the super-tile loop orders these writes before any fragment read)
     }

@@ -560,6 +560,31 @@ __device__ __forceinline__ void dyn_eval(const float* __restrict__ smem, const f
     }
 }
 
+// Stage `n4` f32x4 of the packed image from global memory (L2) into LDS with `NTHREADS` threads, 16 B per lane, coalesced.
+// Eight loads are in flight per lane before the first LDS write: the plain copy loop compiles to load - s_waitcnt vmcnt(0) -
+// ds_write per iteration, i.e. one full L2 round trip per 8 KB (cfg2: 83 KB = 11 serial round trips, 5 - 10 us per launch with
+// every workgroup of the chip reading the same lines) - nothing in a 3 ms solve, a third of a 29 us single dynamics call
+// (boundary A: cnf_aug_f).
+template <int NTHREADS>
+__device__ __forceinline__ void stage_image(const float* __restrict__ packed, float* __restrict__ smem, int n4) {
+    const f32x4* __restrict__ src = reinterpret_cast<const f32x4*>(packed);
+    f32x4* __restrict__ dst = reinterpret_cast<f32x4*>(smem);
+    constexpr int DEPTH = 8;
+    for (int base = threadIdx.x; base < n4; base += DEPTH * NTHREADS) {
+        f32x4 t[DEPTH];
+#pragma unroll
+        for (int k = 0; k < DEPTH; ++k) {
+            const int i = base + k * NTHREADS;
+            t[k] = src[i < n4 ? i : n4 - 1];      // clamped, not predicated: no control flow between the loads
+        }
+#pragma unroll
+        for (int k = 0; k < DEPTH; ++k) {
+            const int i = base + k * NTHREADS;
+            if (i < n4) dst[i] = t[k];
+        }
+    }
+}
+
 // PRE: 0 none; 1 hoist c = W_N^T eps; 2 also hoist q = W_1[:,0:D] eps and skip the last pullback
 // product (valid only without reg_j).  PRE > 0 needs ENGINE == ENG_VJP and KP == 1.
 template <int HT, int L, int ZR, int CR, int ACT, int ENGINE, int KP, int PRE, int NTHREADS, int ARITH = 0>
@@ -567,12 +592,8 @@ __global__ void __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(1
 mfma_solve_kernel(KArgs a) {
     constexpr MfmaLayout LAY(HT, L, ZR, CR, ENGINE == ENG_VJP, ARITH);
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    // stage the packed weight image: global (L2) -> LDS, 16 B per lane, coalesced
-    {
-        const f32x4* src = reinterpret_cast<const f32x4*>(a.packed);
-        f32x4* dst = reinterpret_cast<f32x4*>(smem);
-        for (int i = threadIdx.x; i < LAY.lds_total / 4; i += NTHREADS) dst[i] = src[i];
-    }
+    // stage the packed weight image: global (L2) -> LDS
+    stage_image<NTHREADS>(a.packed, smem, LAY.lds_total / 4);
     __syncthreads();
 
     const int lane = threadIdx.x & 63;
@@ -883,11 +904,7 @@ __global__ void __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(1
 mfma_adaptive_kernel(KArgs a, AArgs q) {
     constexpr MfmaLayout LAY(HT, L, ZR, CR, ENGINE == ENG_VJP, ARITH);
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    {
-        const f32x4* src = reinterpret_cast<const f32x4*>(a.packed);
-        f32x4* dst = reinterpret_cast<f32x4*>(smem);
-        for (int i = threadIdx.x; i < LAY.lds_total / 4; i += NTHREADS) dst[i] = src[i];
-    }
+    stage_image<NTHREADS>(a.packed, smem, LAY.lds_total / 4);
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const int g = lane >> 4, n = lane & 15;
@@ -1165,11 +1182,7 @@ mfma_vcabm_kernel(KArgs a, AArgs q) {
     __shared__ double sc_hist[WPB][KS + 1];   // signed sizes of the accepted steps, newest first
     __shared__ double sc_dts[WPB][KS + 3], sc_cq[WPB][KS + 3], sc_gd[WPB][KS + 1], sc_gs[WPB][KS + 2];
     __shared__ float sc_beta[WPB][KS], sc_g[WPB][KS + 1];
-    {
-        const f32x4* src = reinterpret_cast<const f32x4*>(a.packed);
-        f32x4* dst = reinterpret_cast<f32x4*>(smem);
-        for (int i = threadIdx.x; i < LAY.lds_total / 4; i += NTHREADS) dst[i] = src[i];
-    }
+    stage_image<NTHREADS>(a.packed, smem, LAY.lds_total / 4);
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const int g = lane >> 4, n = lane & 15;

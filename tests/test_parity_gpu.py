@@ -911,21 +911,52 @@ def test_empty_batch_is_a_no_op(pkg, oracles):
 
 
 def test_shard_concatenation_is_bit_identical_and_deterministic(pkg, oracles):
-    """Sharding invariance at the headline shape: evaluating column blocks
-    separately — as the ranks of a multi-GPU run do — reproduces the unsharded bits."""
+    """Sharding invariance ("bit-for-bit (fixed-step, same kernel)") at the headline shape: evaluating
+    column blocks separately - as the ranks of a multi-GPU run do - reproduces the unsharded bits when the shards run on the
+    kernel the full batch runs on: (i) shards above the tile-split threshold (more 16-sample tiles than compute units - every
+    BASELINE shard size), (ii) any shard size with the tile-split form switched off.  Shards small enough for the tile-split
+    kernel (<= 4096 columns) differ from the per-wave kernel's bits by rounding only (the D-row products are summed in a
+    different order): equal to 2e-5, and deterministic."""
+    import os
     o64, _ = oracles
     spec = o64.make_spec(nvars=8, hidden=[64, 64, 64])
-    B = 4096 + 37
-    p, xs, eps, _ = o64.synth_inputs(spec, B, 5)
     icnf = make_icnf(pkg, spec, 1, 40)
+    # (i) two shards of more than 4096 columns each
+    B = 2 * 4112 + 37
+    p, xs, eps, _ = o64.synth_inputs(spec, B, 5)
     full = run_inference(pkg, icnf, spec, p, xs, eps, None)[0].cpu().numpy()
     again = run_inference(pkg, icnf, spec, p, xs, eps, None)[0].cpu().numpy()
     assert np.array_equal(full, again)
     parts = []
-    for r in range(8):
-        lo, hi = pkg.shard_columns(B, r, 8)
+    for r in range(2):
+        lo, hi = pkg.shard_columns(B, r, 2)
+        assert hi - lo > 4096
         parts.append(run_inference(pkg, icnf, spec, p, xs[:, lo:hi], eps[:, lo:hi], None)[0].cpu().numpy())
     assert np.array_equal(np.concatenate(parts), full)
+    # (ii) eight small shards
+    B = 4096 + 37
+    p, xs, eps, _ = o64.synth_inputs(spec, B, 5)
+    full = run_inference(pkg, icnf, spec, p, xs, eps, None)[0].cpu().numpy()
+    old = os.environ.get("CNF_TILE_SPLIT")
+    try:
+        for env, exact in (("0", True), ("1", False)):
+            os.environ["CNF_TILE_SPLIT"] = env
+            parts = []
+            for r in range(8):
+                lo, hi = pkg.shard_columns(B, r, 8)
+                parts.append(run_inference(pkg, icnf, spec, p, xs[:, lo:hi], eps[:, lo:hi], None)[0].cpu().numpy())
+            got = np.concatenate(parts)
+            if exact:
+                assert np.array_equal(got, full)
+            else:
+                assert np.max(np.abs(got - full)) < 2e-5
+                lo, hi = pkg.shard_columns(B, 3, 8)
+                assert np.array_equal(parts[3], run_inference(pkg, icnf, spec, p, xs[:, lo:hi], eps[:, lo:hi], None)[0].cpu().numpy())
+    finally:
+        if old is None:
+            os.environ.pop("CNF_TILE_SPLIT", None)
+        else:
+            os.environ["CNF_TILE_SPLIT"] = old
 
 
 def test_full_size_headline_properties(pkg, oracles):
