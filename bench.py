@@ -132,6 +132,21 @@ def layered_flop_per_stage(spec):
     return 2 * fwd + K * per_probe + top + solve      # forward sweep + recompute = 2 chains per stage
 
 
+def coop_grad_flop_per_stage(spec):
+    """Product flop per sample per RK stage of the cooperative gradient (csrc/cnf_coop_grad.hip): the checkpointing forward solve
+    (chain + pullback), the reverse sweep's recomputed chain, pullback, bottom-up and top-down passes, and the deferred weight
+    cotangents (two terms per matrix, bias columns included)."""
+    w, D = spec.widths, spec.D
+    N = len(w) - 1
+    fwd = sum(2 * w[l + 1] * w[l] for l in range(N))
+    hid = sum(2 * w[l + 1] * w[l] for l in range(1, N - 1))            # H x H products of one pass
+    pull = hid + 2 * D * w[1]                                          # + W_N^T eps
+    solve = fwd + pull + 2 * D * w[1]                                  # forward solve: chain, pullback, g = W_1^T delta_1
+    chain = (fwd - 2 * w[N] * w[N - 1]) + pull + (2 * D * w[1] + hid) + (2 * D * w[1] + hid + 2 * D * w[1])
+    wgrad = sum(2 * 2 * w[l + 1] * (w[l] + 1) for l in range(N))
+    return solve + chain + wgrad
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -434,7 +449,8 @@ def report(w, m, a, steps, warmup, world):
         # instructions (2048 flop) per stage per 16-sample tile, recomputation included; (ii) the algorithmic figure:
         # reverse mode of a function costing F is 2F on top of F (each product once forwards, twice backwards) = 3 F
         gpath = icnf.grad_path(mode)
-        exec_ss = (grad_mfma_per_stage(spec) * 2048 / 16 if gpath == 1 else layered_flop_per_stage(spec)) * stages
+        exec_ss = (grad_mfma_per_stage(spec) * 2048 / 16 if gpath == 1 else coop_grad_flop_per_stage(spec) if gpath == 3
+                   else layered_flop_per_stage(spec)) * stages
         extra["executed_flop_per_sample_step"] = exec_ss
         extra["executed_frac"] = exec_ss * B * NSTEPS / (m["kern_ms"] * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS
         flop_ss = 3 * flop_ss
@@ -475,7 +491,8 @@ def report(w, m, a, steps, warmup, world):
                    "integrator": "RK4" if alg == 0 else "Tsit5",
                    "kernel_path": {1: "simt", 2: "mfma", 3: "layered"}.get(path, str(path)),
                    "mode": a.mode,
-                   **({"gradient_path": {1: "fused reverse-sweep kernel", 2: "layer-wise (hand-written MFMA product kernels)"}.get(
+                   **({"gradient_path": {1: "fused reverse-sweep kernel", 2: "layer-wise (hand-written MFMA product kernels)",
+                                              3: "cooperative reverse sweep + deferred weight-cotangent products"}.get(
                        icnf.grad_path(mode), "none")} if a.mode == "grad" else {}),
                    "collective": w.get("collective", ""),
                    "parallelism": f"column-shard x{world}, loss all-reduce (5 scalars)"

@@ -21,7 +21,8 @@
 // to place the L2 / LDS fragment loads.  This translation unit takes the plain forms.
 #define CNF_NO_PK_ASM 1
 #define CNF_NO_PHASE_FENCE 1
-#include "cnf_mfma_kernel.h"   // act_tile, tiles_mul, tile_fma: shared with the per-wave kernel
+#include "cnf_coop_dev.h"
+#include "cnf_coop_grad.h"
 
 namespace cnf {
 
@@ -35,67 +36,6 @@ namespace cnf {
 // workgroup per dynamics call does not stay in the 4 MB L2 of an XCD beside the weight image (PMC: 10 GB of HBM reads per launch
 // when streamed), and because vmcnt retires in order the reads cannot hide under the product they are issued before: its own
 // fragment loads wait for them.  cfg4: 25.7 ms without, 28.7 ms with c alone, 27.6 - 29.0 ms with both.)
-
-// A fragments of k-group kg for M-tiles mt0 .. mt0 + M - 1 (global image, 16 B per lane, coalesced); A already points at the lane
-// (buffer loads: the image offset of the fragment is wave-uniform and rides in an SGPR, the lane's 16-byte slot in a VGPR
-// that never changes - no address VALU in the loop; f32 MFMAs and VALU instructions share the issue slot)
-// `wl` != nullptr: the packed image has been staged into LDS (the tile-split small-batch form, NT = 1: with one sample tile a
-// k-group is 4 MFMAs per M-tile, far too little to hide an L2 round trip per fragment) and fragments are ds_read_b128.
-struct AImg { __amdgpu_buffer_rsrc_t r; unsigned off; unsigned lane16; const float* wl; };
-typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-template <int M>
-__device__ __forceinline__ void coop_load_a(const AImg& A, int mt0, int KG, int kg, f32x4 (&a)[M]) {
-#pragma unroll
-    for (int m = 0; m < M; ++m) {
-        const unsigned so = A.off + (unsigned)(((mt0 + m) * KG + kg) * 1024);
-        if (A.wl) a[m] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(A.wl) + so + A.lane16);
-        else a[m] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(A.r, (int)A.lane16, (int)so, 0));
-    }
-}
-// B fragments of k-group kg for sample tiles nt0 .. nt0 + NQ - 1 (LDS exchange image, conflict-free ds_read_b128)
-// (NT = sample tiles of the super-tile = tiles per k-group in the image)
-template <int NQ, int NT>
-__device__ __forceinline__ void coop_load_b(const f32x4* __restrict__ bimg, int nt0, int kg, int lane, f32x4 (&b)[NQ]) {
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) b[q] = bimg[(kg * NT + nt0 + q) * 64 + lane];
-}
-
-template <int M, int NQ>
-__device__ __forceinline__ void coop_frag_mfma(const f32x4 (&a)[M], const f32x4 (&b)[NQ], f32x4 (&acc)[M][NQ]) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int m = 0; m < M; ++m)
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) acc[m][q] = mfma4(a[m][j], b[q][j], acc[m][q]);
-}
-
-// acc[m][q] += A(global image; M-tile mt0+m) * B(LDS image; sample tile nt0+q), over KG k-groups.  `a0` arrives holding the A
-// fragments of k-group 0 (requested by the caller one phase earlier).  Two fragment sets ping-pong (k-loop unrolled by 2): the
-// loads of k-group kg+1 - A from L2, B from LDS - are issued before the 16 M NQ MFMAs of k-group kg.
-template <int M, int NQ, int NT>
-__device__ __forceinline__ void coop_gemm(const AImg& A, int mt0, int KG,
-                                          const f32x4* __restrict__ bimg, int nt0, int lane,
-                                          f32x4 (&a0)[M], f32x4 (&acc)[M][NQ]) {
-    f32x4 a1[M], b0[NQ], b1[NQ];
-    coop_load_b<NQ, NT>(bimg, nt0, 0, lane, b0);
-#pragma clang loop unroll(disable)
-    for (int kg = 0; kg < KG; kg += 2) {
-        const bool has1 = kg + 1 < KG, has2 = kg + 2 < KG;   // wave-uniform
-        if (has1) { coop_load_a<M>(A, mt0, KG, kg + 1, a1); coop_load_b<NQ, NT>(bimg, nt0, kg + 1, lane, b1); }
-        coop_frag_mfma<M, NQ>(a0, b0, acc);
-        if (has1) {
-            if (has2) { coop_load_a<M>(A, mt0, KG, kg + 2, a0); coop_load_b<NQ, NT>(bimg, nt0, kg + 2, lane, b0); }
-            coop_frag_mfma<M, NQ>(a1, b1, acc);
-        }
-    }
-}
-
-template <int MT>
-__device__ __forceinline__ void gload_cvec(const float* __restrict__ vec, int mt0, int g, f32x4 (&out)[MT]) {
-#pragma unroll
-    for (int m = 0; m < MT; ++m) out[m] = *reinterpret_cast<const f32x4*>(vec + ((mt0 + m) * 4 + g) * 4);
-}
 
 // NT: sample tiles per super-tile (4: one workgroup per CU owns 64 samples; 2: two workgroups per CU own 32 samples each - half
 // the exchange buffers and half the accumulators per wave, so two waves share each SIMD and fill each other's stalls, at the
@@ -332,7 +272,9 @@ __device__ __forceinline__ void coop_eval(const float* __restrict__ P, const flo
 // WL (with NT = 1): the tile-split form for small batches - one 16-sample tile per workgroup, its hidden width split over the
 // four waves (one per SIMD), the operand images staged into LDS once per workgroup.  A batch of <= one tile per compute unit
 // otherwise runs on one wave per tile at ~40 % MFMA utilisation with three SIMDs of every CU idle.
-template <int HT, int L, int ZR, int ACT, int NS, int NT, bool WL = false>
+// CK: the owner waves also checkpoint z at the start of every step (+ the final state) and every stage derivative, in tile
+// layout [..][16-sample tile][lane][ZR] (KArgs::ckpt / ckpt_k): the forward half of the cooperative gradient (cnf_coop_grad.hip)
+template <int HT, int L, int ZR, int ACT, int NS, int NT, bool WL = false, bool CK = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, NT == 4 ? 1 : 2)))
 coop_vjp_solve_kernel(KArgs a) {
     constexpr int DT = (ZR + 3) / 4, XB = HT * NT * 64;
@@ -397,6 +339,12 @@ coop_vjp_solve_kernel(KArgs a) {
 #pragma clang loop unroll(disable)
         for (int step = 0; step < nsteps; ++step) {
             const float tn = a.t0 + (float)step * dt;
+            if constexpr (CK) {
+                if (owner) {
+#pragma unroll
+                    for (int s = 0; s < ZR; ++s) a.ckpt[(((long long)step * nst * NT + st * NT + wave) * 64 + lane) * ZR + s] = z[s];
+                }
+            }
             lsum = esum = nsum = 0.f;
 #pragma unroll
             for (int s = 0; s < ZR; ++s) {
@@ -411,6 +359,13 @@ coop_vjp_solve_kernel(KArgs a) {
                 for (int s = 0; s < ZR; ++s) zs[s] = fmaf(dt, Pz[0][s], z[s]);
                 coop_eval<HT, L, ZR, ACT, NT, WL>(a.packed, wl, xbuf, zbuf, ebuf, pbuf, lane, wave, tn + a.T.c[sg] * dt, autonomous,
                                           reg_z, reg_j, zs, zd, ld, ed, nd);
+                if constexpr (CK) {
+                    if (owner) {
+#pragma unroll
+                        for (int s = 0; s < ZR; ++s)
+                            a.ckpt_k[((((long long)step * ns + sg) * nst * NT + st * NT + wave) * 64 + lane) * ZR + s] = zd[s];
+                    }
+                }
                 const float bst = a.T.b[sg];
                 lsum = fmaf(bst, ld, lsum); esum = fmaf(bst, ed, esum); nsum = fmaf(bst, nd, nsum);
 #pragma unroll
@@ -433,6 +388,12 @@ coop_vjp_solve_kernel(KArgs a) {
                 if (g == 0) { a.u_out[smp * S + D] = ld; a.u_out[smp * S + D + 1] = ed; a.u_out[smp * S + D + 2] = nd; }
             }
             continue;
+        }
+        if constexpr (CK) {
+            if (owner) {
+#pragma unroll
+                for (int s = 0; s < ZR; ++s) a.ckpt[(((long long)a.nsteps * nst * NT + st * NT + wave) * 64 + lane) * ZR + s] = z[s];
+            }
         }
         float ss = 0.f, sa = 0.f;
 #pragma unroll
@@ -465,13 +426,13 @@ coop_vjp_solve_kernel(KArgs a) {
 // ---------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------
-template <int HT, int L, int ZR, int ACT, int NS, int NT, bool WL = false>
+template <int HT, int L, int ZR, int ACT, int NS, int NT, bool WL = false, bool CK = false>
 static hipError_t launch_coop(const KArgs& a, int nblocks, hipStream_t st) {
     constexpr int DT = (ZR + 3) / 4;
     constexpr int lds = (2 * HT * NT * 64 + 2 * DT * NT * 64 + (NT == 1 ? 4 * DT * 64 : 0)) * 16 +
                         (WL ? MfmaLayout(HT, L, ZR, 0, true).lds_total * 4 : 0);
     static_assert(lds <= 160 * 1024, "exchange buffers + staged image exceed LDS");
-    auto kern = coop_vjp_solve_kernel<HT, L, ZR, ACT, NS, NT, WL>;
+    auto kern = coop_vjp_solve_kernel<HT, L, ZR, ACT, NS, NT, WL, CK>;
     static DeviceOnce once;
     int dev = 0;
     hipError_t e0 = hipGetDevice(&dev);
@@ -553,6 +514,26 @@ hipError_t coop_split_launch(int HT, int L, int ZR, int ACT, const KArgs& a, hip
     if (!c) return hipErrorNotSupported;
     const long long ntiles = (a.B + 15) / 16;
     return c->fn[a.T.ns <= 4 ? 0 : 1](a, (int)ntiles, st);
+}
+
+// ---- the checkpointing form: the forward half of the cooperative gradient, for the shapes cnf_coop_grad.hip instantiates ----
+struct CkInst {
+    int HT, L, ZR;
+    hipError_t (*fn[2])(const KArgs&, int, hipStream_t);
+};
+#define CK_INST(HT, L, ZR) \
+    CkInst { HT, L, ZR, { &launch_coop<HT, L, ZR, CNF_ACT_TANH_PRESCALED, 4, 4, false, true>, \
+                          &launch_coop<HT, L, ZR, CNF_ACT_TANH_PRESCALED, 6, 4, false, true> } }
+static const CkInst kCk[] = {CK_INST(16, 3, 8), CK_INST(8, 3, 2), CK_INST(4, 3, 2)};
+hipError_t coop_launch_ckpt(int HT, int L, int ZR, int ACT, const KArgs& a, int num_cus, hipStream_t st) {
+    if (ACT != CNF_ACT_TANH && ACT != CNF_ACT_TANH_PRESCALED) return hipErrorNotSupported;
+    for (const CkInst& c : kCk)
+        if (c.HT == HT && c.L == L && c.ZR == ZR) {
+            const long long nst = (a.B + 63) / 64;
+            const int nblocks = (int)(nst < num_cus ? nst : num_cus);
+            return c.fn[a.T.ns <= 4 ? 0 : 1](a, nblocks, st);
+        }
+    return hipErrorNotSupported;
 }
 
 bool coop_supported(int HT, int L, int ZR, int CR, int ACT, int engine, int KP, int* ZR_inst, int* HT_inst) {

@@ -1,0 +1,39 @@
+// cnf_coop_grad.h — interface of the cooperative reverse sweep (cnf_coop_grad.hip) and of the checkpointing form of the
+// cooperative forward solve (cnf_coop.hip) it pairs with.
+#pragma once
+#include "cnf_mfma_dev.h"
+
+namespace cnf {
+
+// One RK step of the reverse sweep over all column super-tiles (one launch).  Operand arrays of the deferred weight-cotangent
+// products are column-major, 2 * ns * B columns each: columns [i B, (i+1) B) of the first half belong to stage i's first term,
+// the same columns of the second half (offset ns * B) to its second term.
+struct CGArgs {
+    const float* packed;      // the cooperative plan's operand image (forward images carry the tanh pre-scale)
+    const float* eps;         // D x B
+    const float* ckpt;        // z at the start of every step and after the last: [step][tile][lane][ZR] (forward kernel, CK form)
+    const float* ckpt_k;      // stage derivatives: [step * ns + stage][tile][lane][ZR]
+    float* lam;               // costate, [tile][lane][ZR]: read (unless this is the last step), written
+    float* grad_x;            // nvars x B or null; written by step 0
+    float* scratch;           // per-workgroup scratch, `scratch_stride` floats apart
+    long long scratch_stride;
+    float* xh[3];             // X_l, l = 1 .. L: [delta_l | sbar_l], H rows, ld = H
+    float* yh[3];             // Y_l, l = 1 .. L: [vbar_l; 0 | h_l; 1] (l < L), [cbar; 0 | h_L; 1] (l = L), H + 1 rows, ld = H + 1
+    float* y1;                // [gbar; 0; 0 | z; t; 1]: the input side of Wbar_1, ld_y1 = n_in + 1 rows
+    float* xN;                // [eps | kbar]: D rows, ld = D
+    int ld_y1;
+    long long B;
+    int step, nsteps;
+    float tn, dt;             // this step's start time and length
+    int D, nvars, H, autonomous;
+    float lam3;
+    Tableau T;
+};
+
+bool coop_grad_supported(int HT, int L, int ZR, int ACT);
+int coop_grad_scratch_slots(int L);   // 64 x H floats each, per workgroup
+hipError_t coop_grad_step_launch(int HT, int L, int ZR, int ACT, const CGArgs& a, int num_cus, hipStream_t st);
+// the cooperative forward solve with step / stage checkpoints in tile layout (cnf_coop.hip)
+hipError_t coop_launch_ckpt(int HT, int L, int ZR, int ACT, const KArgs& a, int num_cus, hipStream_t st);
+
+}  // namespace cnf

@@ -1,0 +1,496 @@
+// cnf_coop_grad.hip — cooperative reverse sweep for wide hidden layers (gfx950): the parameter gradient of the FFJORD loss
+// through the fixed-step solve (reference: Zygote through SciMLBase.solve with QuadratureAdjoint +
+// ZygoteVJP, src/core/icnf.jl:90-99, driven by src/exts/mlj_ext/core_icnf.jl:42-51) for the shapes whose forward solve runs on
+// the cooperative kernel of cnf_coop.hip (BASELINE cfg4: D = 32, 3 x 256).
+//
+// Same mathematics as cnf_grad.hip (discretise-then-optimise; per stage: recompute the chain, first-order pullback, its
+// bottom-up reverse, the top-down pass, the RK adjoint recursion) organised like cnf_coop.hip: a 256-thread workgroup owns a
+// 64-sample super-tile, wave w the output features [w H/4, (w+1) H/4) of every product for all four sample tiles, operands
+// travel between the waves as B images in two LDS exchange buffers, weight fragments stream from the L2-resident packed image.
+// One launch per RK step (all its stages, in reverse); nothing of a stage's activation set ever makes a round trip through
+// HBM as a GEMM operand.  What does not fit the register file between its producer and its consumer (h_l, u_l, dbar_l .* u_l:
+// 64 registers per wave each) waits in a per-workgroup scratch in tile-native layout (one coalesced 1 KB store / load per tile).
+//
+// WEIGHT COTANGENTS ARE DEFERRED: with 256 x 256 matrices the cotangent accumulators (2 x 256 KB per workgroup) fit neither
+// registers nor LDS, and a product with the sample index on K wants all samples of a column chunk anyway.  The kernel writes
+// the operands of  Wbar_{l+1} += delta_{l+1} vbar_l^T + sbar_{l+1} [h_l; 1]^T  (and of Wbar_1, Wbar_N) for every stage of the
+// step into column-major arrays laid out so that ONE lg_wgrad launch per weight matrix per step (K = 2 x stages x B columns)
+// accumulates both terms and the bias column (cnf_lgemm.hip; slabs per column chunk, summed in a fixed order at the end).
+// A tile leaves for HBM through the exchange buffer it was published in: the lane that stores rows 4r .. 4r + 3 of a sample
+// reads its four values with conflict-free ds_read_b32 and issues one 16-byte store.
+//
+// Scope of this first version: Hutchinson VJP, one probe, no conditions, tanh, no |zdot| / |eps^T J| regularisers (FFJORD;
+// l3 |z_aug| is in), uniform steps, 2 or 3 hidden layers of one width: everything else stays on the layer-wise path.
+#define CNF_NO_PK_ASM 1
+#define CNF_NO_PHASE_FENCE 1
+#include "cnf_coop_dev.h"
+#include "cnf_coop_grad.h"
+
+namespace cnf {
+
+namespace {
+
+template <int MTW, int NT>
+struct TS {   // one wave's share of an [H x 64-sample] quantity: MTW x NT accumulator tiles
+    f32x4 t[MTW][NT];
+};
+
+// d = act'(a) from h = tanh(a)  (act''(a) = -2 h d)
+__device__ __forceinline__ f32x4 tanh_d(const f32x4& h) { return 1.f - h * h; }
+// 16-byte store to a 4-byte-aligned address (odd leading dimensions): one global_store_dwordx4, not four scattered dwords
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+
+}  // namespace
+
+template <int HT, int L, int ZR, int ACT, int NS>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+coop_grad_step_kernel(CGArgs a) {
+    static_assert(ACT == CNF_ACT_TANH_PRESCALED, "tanh nets only (act' and act'' are rebuilt from h)");
+    static_assert(L == 2 || L == 3, "two or three hidden layers");
+    constexpr int NT = 4;
+    constexpr MfmaLayout LAY(HT, L, ZR, 0, true);
+    constexpr int MTW = HT / 4, DT = (ZR + 3) / 4, XB = HT * NT * 64, DB = DT * NT * 64;
+    constexpr int IMG = MfmaLayout::imgA(HT, HT);
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    f32x4* xbuf = reinterpret_cast<f32x4*>(smem);   // [2][HT][NT][64]: exchange buffers
+    f32x4* zbuf = xbuf + 2 * XB;                     // [DT][NT][64]: stage state
+    f32x4* ebuf = zbuf + DB;                         // eps
+    f32x4* kbuf = ebuf + DB;                         // kbar
+    const int lane = threadIdx.x & 63, g = lane >> 4, n = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int mt0 = wave * MTW;
+    const int D = a.D, H = a.H;
+    const long long B = a.B;
+    const long long nst = (B + 63) / 64;
+    const float* P = a.packed;
+    const __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P), 0, 0x7fffffff, 0x00020000);
+    const unsigned lane16 = (unsigned)lane * 16u;
+#define AIMG(X) AImg{rP, (unsigned)(X) * 4u, lane16, nullptr}
+    const float inv_fs = 1.f / kTanhPrescale;        // the forward images carry the tanh pre-scale
+    const int ns = a.T.ns < NS ? a.T.ns : NS;
+    const float dt = a.dt, tn = a.tn;
+    const long long nsB = (long long)ns * B;
+    using T4 = f32x4[MTW][NT];
+
+    // own-tile helpers -------------------------------------------------------------------------------------------------
+    auto publish = [&](int buf, const T4& v) {
+#pragma unroll
+        for (int m = 0; m < MTW; ++m)
+#pragma unroll
+            for (int q = 0; q < NT; ++q) xbuf[buf * XB + ((mt0 + m) * NT + q) * 64 + lane] = v[m][q];
+    };
+    // this wave's tiles of exchange buffer `buf` -> rows [16 mt0, 16 (mt0 + MTW)) of the column-major array `arr` (leading
+    // dimension ld), columns col0 + (sample of the super-tile).  Lane (r = lane >> 4, n): rows 16 mt + 4 r .. + 3 of sample n.
+    auto gstore = [&](int buf, float* arr, int ld, long long col0, long long smp0) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // own ds_writes have landed; the reads below alias them
+        const float* xb = reinterpret_cast<const float*>(xbuf + buf * XB);
+#pragma unroll
+        for (int m = 0; m < MTW; ++m)
+#pragma unroll
+            for (int q = 0; q < NT; ++q) {
+                const int base = (((mt0 + m) * NT + q) * 64 + n) * 4 + g;   // + 64 * g' : lane group g' of the image
+                f32x4 v;
+                v[0] = xb[base]; v[1] = xb[base + 64]; v[2] = xb[base + 128]; v[3] = xb[base + 192];
+                const long long smp = smp0 + q * 16 + n;
+                const int row = 16 * (mt0 + m) + 4 * g;
+                if (smp < B && row < H) {
+                    float* dst = arr + (col0 + smp) * (long long)ld + row;
+                    if (row + 3 < H) *reinterpret_cast<f32x4u*>(dst) = v;
+                    else { for (int j = 0; j < 4; ++j) if (row + j < H) dst[j] = v[j]; }
+                }
+            }
+    };
+    float* scr = a.scratch + (long long)blockIdx.x * a.scratch_stride;
+    auto sstore = [&](int slot, const T4& v) {
+        f32x4* s4 = reinterpret_cast<f32x4*>(scr) + ((slot * 4 + wave) * MTW * NT) * 64 + lane;
+#pragma unroll
+        for (int m = 0; m < MTW; ++m)
+#pragma unroll
+            for (int q = 0; q < NT; ++q) s4[(m * NT + q) * 64] = v[m][q];
+    };
+    auto sload = [&](int slot, T4& v) {
+        const f32x4* s4 = reinterpret_cast<const f32x4*>(scr) + ((slot * 4 + wave) * MTW * NT) * 64 + lane;
+#pragma unroll
+        for (int m = 0; m < MTW; ++m)
+#pragma unroll
+            for (int q = 0; q < NT; ++q) v[m][q] = s4[(m * NT + q) * 64];
+    };
+    auto zero = [&](T4& v) {
+#pragma unroll
+        for (int m = 0; m < MTW; ++m)
+#pragma unroll
+            for (int q = 0; q < NT; ++q) v[m][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    // acc += A(image at float offset `img`; this wave's M-tiles) * B(LDS image `bimg` with KG k-groups)
+    auto product = [&](int img, int KG, const f32x4* bimg, T4& acc) {
+        f32x4 afr[MTW];
+        coop_load_a<MTW>(AIMG(img), mt0, KG, 0, afr);
+        coop_gemm<MTW, NT, NT>(AIMG(img), mt0, KG, bimg, 0, lane, afr, acc);
+    };
+    // dense D-row registers of this wave's sample tile -> B image
+    auto publish_dense = [&](f32x4* img, const float (&v)[ZR]) {
+#pragma unroll
+        for (int kg = 0; kg < DT; ++kg) {
+            f32x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = (4 * kg + j < ZR) ? v[(4 * kg + j) < ZR ? 4 * kg + j : 0] : 0.f;
+            img[(kg * NT + wave) * 64 + lane] = o;
+        }
+    };
+    // dense D-row registers -> rows [0, D) of column `col` of a column-major array
+    auto dense_store = [&](float* arr, int ld, long long col, const float (&v)[ZR]) {
+#pragma unroll
+        for (int s = 0; s < ZR; ++s) { const int f = 4 * s + g; if (f < D) arr[col * (long long)ld + f] = v[s]; }
+    };
+
+    // scratch slots (tile-native): H_l for l = 1 .. L-1, U_l for l = 2 .. L-1, A2_l for l = 1 .. L-1
+    constexpr int SLOT_H = 0, SLOT_U = L - 1, SLOT_A2 = SLOT_U + (L - 2);
+
+    for (long long st = blockIdx.x; st < nst; st += gridDim.x) {
+        const long long smp0 = st * 64;
+        const long long smp = smp0 + wave * 16 + n;                  // this wave's own sample tile (every wave owns one: NT = 4)
+        const bool valid = smp < B;
+        const long long sc = valid ? smp : B - 1;
+        const long long tile = st * NT + wave, ntp = nst * NT;
+        float eps[ZR], zn[ZR], lam[ZR], kz[NS][ZR], Zb[NS][ZR];
+#pragma unroll
+        for (int s = 0; s < ZR; ++s) {
+            const int f = 4 * s + g;
+            eps[s] = f < D ? a.eps[sc * D + f] : 0.f;
+            zn[s] = a.ckpt[(((long long)a.step * ntp + tile) * 64 + lane) * ZR + s];
+        }
+#pragma unroll
+        for (int j = 0; j < NS; ++j)
+#pragma unroll
+            for (int s = 0; s < ZR; ++s) {
+                kz[j][s] = j < ns ? a.ckpt_k[((((long long)a.step * ns + j) * ntp + tile) * 64 + lane) * ZR + s] : 0.f;
+                Zb[j][s] = 0.f;
+            }
+        if (a.step == a.nsteps - 1) {
+            // lambda_N = dL/dz_N = z_N (+ l3 z_aug / |z_aug|, src/core/base_icnf.jl:106-122); zero for padding columns
+#pragma unroll
+            for (int s = 0; s < ZR; ++s) lam[s] = valid ? a.ckpt[(((long long)a.nsteps * ntp + tile) * 64 + lane) * ZR + s] : 0.f;
+            if (a.lam3 != 0.f) {
+                float sa = 0.f;
+#pragma unroll
+                for (int s = 0; s < ZR; ++s) { const int f = 4 * s + g; if (f >= a.nvars && f < D) sa = fmaf(lam[s], lam[s], sa); }
+                sa = group_sum(sa);
+                const float inv = sa > 0.f ? a.lam3 * rsqrtf(sa) : 0.f;
+#pragma unroll
+                for (int s = 0; s < ZR; ++s) { const int f = 4 * s + g; if (f >= a.nvars && f < D) lam[s] = fmaf(inv, lam[s], lam[s]); }
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < ZR; ++s) lam[s] = a.lam[(tile * 64 + lane) * ZR + s];
+        }
+        __syncthreads();                 // the previous super-tile's readers of the LDS images are done
+        publish_dense(ebuf, eps);
+        // validity of the four sample tiles' column n (the weight of this lane's columns in every tile set)
+        float vq[NT];
+#pragma unroll
+        for (int q = 0; q < NT; ++q) vq[q] = (smp0 + q * 16 + n) < B ? 1.f : 0.f;
+
+#pragma clang loop unroll(disable)
+        for (int i = ns - 1; i >= 0; --i) {
+            // ---- this wave's sample tile: stage state, cotangent of the stage derivative ----
+            float zs[ZR], kbar[ZR];
+            const float bi = a.T.b[i];
+#pragma unroll
+            for (int s = 0; s < ZR; ++s) {
+                float acc = 0.f, kb = bi * lam[s];
+#pragma unroll
+                for (int j = 0; j < NS - 1; ++j) acc = fmaf(a.T.a[i][j], kz[j][s], acc);
+#pragma unroll
+                for (int j = 1; j < NS; ++j) kb = fmaf(a.T.a[j][i], Zb[j][s], kb);   // a[j][i] != 0 only for j > i
+                zs[s] = fmaf(dt, acc, zn[s]);
+                kbar[s] = valid ? dt * kb : 0.f;
+            }
+            const float cl = dt * bi;                                 // cotangent of ldot (dL/d dlogp = +1 per column)
+            const float tt = tn + a.T.c[i] * dt;
+            const long long c1 = (long long)i * B, c2 = nsB + (long long)i * B;   // first / second half of the operand arrays
+            publish_dense(zbuf, zs);
+            publish_dense(kbuf, kbar);
+            if (valid) {
+                // Wbar_1 operands: [gbar; 0; 0] with gbar = -c_l eps, and [z; t; 1];  Wbar_N operands: eps, kbar
+                float gb[ZR];
+#pragma unroll
+                for (int s = 0; s < ZR; ++s) gb[s] = -cl * eps[s];
+                dense_store(a.y1, a.ld_y1, c1 + smp, gb);
+                dense_store(a.y1, a.ld_y1, c2 + smp, zs);
+                if (g == 0) {
+                    float* col = a.y1 + (c2 + smp) * (long long)a.ld_y1;
+                    if (!a.autonomous) col[D] = tt;
+                    col[a.ld_y1 - 1] = 1.f;
+                }
+                dense_store(a.xN, D, c1 + smp, eps);
+                dense_store(a.xN, D, c2 + smp, kbar);
+            }
+            __syncthreads();
+
+            T4 acc, h3;   // h3: activations of the LAST hidden layer stay in registers
+            // ================= (1) recompute the chain: h_l (forward images carry the pre-scale) =================
+            {
+                f32x4 bias[MTW], wt[MTW];
+                gload_cvec<MTW>(P + LAY.v_b1, mt0, g, bias);
+                gload_cvec<MTW>(P + LAY.v_w1t, mt0, g, wt);
+#pragma unroll
+                for (int m = 0; m < MTW; ++m) {
+                    const f32x4 b0 = a.autonomous ? bias[m] : tile_fma(wt[m], tt, bias[m]);
+#pragma unroll
+                    for (int q = 0; q < NT; ++q) acc[m][q] = b0;
+                }
+                product(LAY.f1z, DT, zbuf, acc);
+            }
+            int cur = 0;
+#pragma unroll
+            for (int l = 0; l < L; ++l) {      // layer l + 1
+                T4 h;
+#pragma unroll
+                for (int m = 0; m < MTW; ++m)
+#pragma unroll
+                    for (int q = 0; q < NT; ++q) { f32x4 dd; act_tile<ACT>(acc[m][q], h[m][q], dd); }
+                publish(cur, h);
+                gstore(cur, a.yh[l], H + 1, c2, smp0);                       // [h_{l+1}; 1] half of Y_{l+1}
+                if (l + 1 < L) {
+                    sstore(SLOT_H + l, h);
+                    f32x4 bnx[MTW];
+                    gload_cvec<MTW>(P + LAY.v_bh + l * MfmaLayout::vecC(HT), mt0, g, bnx);
+#pragma unroll
+                    for (int m = 0; m < MTW; ++m)
+#pragma unroll
+                        for (int q = 0; q < NT; ++q) acc[m][q] = bnx[m];
+                    __syncthreads();
+                    product(LAY.fh + l * IMG, HT, xbuf + cur * XB, acc);
+                    cur ^= 1;
+                } else {
+#pragma unroll
+                    for (int m = 0; m < MTW; ++m)
+#pragma unroll
+                        for (int q = 0; q < NT; ++q) h3[m][q] = h[m][q];
+                }
+            }
+            // `cur` holds h_L (own tiles only matter from here on); the other buffer is free once every wave has left the last
+            // forward product: the barrier below (after delta_L is published into it) is preceded by one here
+            __syncthreads();
+            // ================= (2) first-order pullback: u_L = c, delta_l = u_l .* act'_l, u_{l-1} = W_l^T delta_l =================
+            T4 cvec;   // c = W_N^T eps (kept: a2_L = dbar_L .* c)
+            zero(cvec);
+            product(LAY.bN, DT, ebuf, cvec);
+            {
+                T4 dl;
+#pragma unroll
+                for (int m = 0; m < MTW; ++m)
+#pragma unroll
+                    for (int q = 0; q < NT; ++q) dl[m][q] = cvec[m][q] * tanh_d(h3[m][q]);
+                cur ^= 1;
+                publish(cur, dl);
+                gstore(cur, a.xh[L - 1], H, c1, smp0);                       // delta_L half of X_L
+                __syncthreads();
+            }
+            T4 u1;     // u_1 stays in registers until a2_1 is formed
+#pragma unroll
+            for (int l = L - 1; l >= 1; --l) {   // u_l = W_{l+1}^T delta_{l+1}; delta_l = u_l .* act'_l
+                T4 u, hl, dl;
+                zero(u);
+                product(LAY.bh + (l - 1) * IMG, HT, xbuf + cur * XB, u);
+                sload(SLOT_H + l - 1, hl);
+                if (l > 1) sstore(SLOT_U + l - 2, u);
+#pragma unroll
+                for (int m = 0; m < MTW; ++m)
+#pragma unroll
+                    for (int q = 0; q < NT; ++q) {
+                        dl[m][q] = u[m][q] * tanh_d(hl[m][q]);
+                        if (l == 1) u1[m][q] = u[m][q];
+                    }
+                cur ^= 1;
+                publish(cur, dl);
+                gstore(cur, a.xh[l - 1], H, c1, smp0);                       // delta_l half of X_l
+                if (l > 1) __syncthreads();
+            }
+            // `cur` holds delta_1 (for its store only); the other buffer (delta_2, or delta_L = c .* d for L == 1) may still be
+            // read by waves inside the last pullback product
+            // ================= (3) bottom-up: dbar_1 = W_1[:,0:D] gbar = -c_l q, vbar_l = dbar_l .* act'_l, dbar_{l+1} = W_{l+1} vbar_l ====
+            {
+                T4 db, hl, vb, a2;
+                zero(db);
+                product(LAY.f1z, DT, ebuf, db);                              // (pre-scaled) W_1[:,0:D] eps
+                sload(SLOT_H + 0, hl);
+#pragma unroll
+                for (int m = 0; m < MTW; ++m)
+#pragma unroll
+                    for (int q = 0; q < NT; ++q) {
+                        const f32x4 d1 = db[m][q] * (-cl * inv_fs * vq[q]);
+                        a2[m][q] = d1 * u1[m][q];
+                        vb[m][q] = d1 * tanh_d(hl[m][q]);
+                    }
+                sstore(SLOT_A2 + 0, a2);
+                // own tiles of `cur` (delta_1) have been stored by this wave: overwrite them with vbar_1
+                publish(cur, vb);
+                gstore(cur, a.yh[0], H + 1, c1, smp0);                       // [vbar_1; 0] half of Y_1
+                __syncthreads();
+            }
+            T4 a2L;    // a2_L = dbar_L .* c
+#pragma unroll
+            for (int l = 1; l < L; ++l) {        // dbar_{l+1} = W_{l+1} vbar_l
+                T4 db;
+                zero(db);
+                product(LAY.fh + (l - 1) * IMG, HT, xbuf + cur * XB, db);
+                if (l + 1 < L) {
+                    T4 hl, ul, vb, a2;
+                    sload(SLOT_H + l, hl);
+                    sload(SLOT_U + l - 1, ul);
+#pragma unroll
+                    for (int m = 0; m < MTW; ++m)
+#pragma unroll
+                        for (int q = 0; q < NT; ++q) {
+                            const f32x4 dd = db[m][q] * inv_fs;
+                            a2[m][q] = dd * ul[m][q];
+                            vb[m][q] = dd * tanh_d(hl[m][q]);
+                        }
+                    sstore(SLOT_A2 + l, a2);
+                    cur ^= 1;
+                    publish(cur, vb);
+                    gstore(cur, a.yh[l], H + 1, c1, smp0);                   // [vbar_{l+1}; 0] half of Y_{l+1}
+                    __syncthreads();
+                } else {
+                    T4 cb;   // cbar = dbar_L .* act'_L: Wbar_N += eps cbar^T
+#pragma unroll
+                    for (int m = 0; m < MTW; ++m)
+#pragma unroll
+                        for (int q = 0; q < NT; ++q) {
+                            const f32x4 dd = db[m][q] * inv_fs;
+                            a2L[m][q] = dd * cvec[m][q];
+                            cb[m][q] = dd * tanh_d(h3[m][q]);
+                        }
+                    cur ^= 1;
+                    publish(cur, cb);
+                    gstore(cur, a.yh[L - 1], H + 1, c1, smp0);               // [cbar; 0] half of Y_L
+                    __syncthreads();   // every wave has left the last bottom-up product: its operand buffer is free
+                }
+            }
+            if (L == 1) { /* not instantiated */ }
+            // ================= (4) top-down: hbar_L = W_N^T kbar, sbar_l = hbar_l .* act'_l + a2_l .* act''_l, hbar_{l-1} = W_l^T sbar_l ====
+            {
+                T4 hb;
+                zero(hb);
+                product(LAY.bN, DT, kbuf, hb);
+                T4 sb;
+#pragma unroll
+                for (int m = 0; m < MTW; ++m)
+#pragma unroll
+                    for (int q = 0; q < NT; ++q) {
+                        const f32x4 d = tanh_d(h3[m][q]);
+                        sb[m][q] = hb[m][q] * d + a2L[m][q] * (h3[m][q] * d * -2.f);
+                    }
+                cur ^= 1;
+                publish(cur, sb);
+                gstore(cur, a.xh[L - 1], H, c2, smp0);                       // sbar_L half of X_L
+                __syncthreads();
+            }
+#pragma unroll
+            for (int l = L - 1; l >= 1; --l) {   // hbar_l = W_{l+1}^T sbar_{l+1}
+                T4 hb, hl, a2, sb;
+                zero(hb);
+                product(LAY.bh + (l - 1) * IMG, HT, xbuf + cur * XB, hb);
+                sload(SLOT_H + l - 1, hl);
+                sload(SLOT_A2 + l - 1, a2);
+#pragma unroll
+                for (int m = 0; m < MTW; ++m)
+#pragma unroll
+                    for (int q = 0; q < NT; ++q) {
+                        const f32x4 d = tanh_d(hl[m][q]);
+                        sb[m][q] = hb[m][q] * d + a2[m][q] * (hl[m][q] * d * -2.f);
+                    }
+                cur ^= 1;
+                publish(cur, sb);
+                gstore(cur, a.xh[l - 1], H, c2, smp0);                       // sbar_l half of X_l
+                __syncthreads();
+            }
+            // Zbar_i = W_1[:,0:D]^T sbar_1 for this wave's own sample tile
+            {
+                f32x4 zacc[DT][1], afd[DT];
+#pragma unroll
+                for (int m = 0; m < DT; ++m) zacc[m][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+                coop_load_a<DT>(AIMG(LAY.b1), 0, HT, 0, afd);
+                coop_gemm<DT, 1, NT>(AIMG(LAY.b1), 0, HT, xbuf + cur * XB, wave, lane, afd, zacc);
+#pragma unroll
+                for (int j = 0; j < NS; ++j)
+#pragma unroll
+                    for (int s = 0; s < ZR; ++s) Zb[j][s] = (j == i) ? zacc[s >> 2][0][s & 3] : Zb[j][s];
+            }
+            __syncthreads();   // the next stage republishes zbuf / kbuf and reuses the exchange buffers
+        }
+        // lambda_n = lambda_{n+1} + sum_i Zbar_i
+#pragma unroll
+        for (int s = 0; s < ZR; ++s) {
+            float acc = lam[s];
+#pragma unroll
+            for (int j = 0; j < NS; ++j) acc += Zb[j][s];
+            lam[s] = acc;
+            a.lam[(tile * 64 + lane) * ZR + s] = acc;
+        }
+        if (a.step == 0 && a.grad_x && valid) {   // costate at t0 = dL/dz_0; its first nvars rows are dL/dx
+#pragma unroll
+            for (int s = 0; s < ZR; ++s) {
+                const int f = 4 * s + g;
+                if (f < a.nvars) a.grad_x[smp * a.nvars + f] = lam[s];
+            }
+        }
+    }
+#undef AIMG
+}
+
+// ---------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------
+template <int HT, int L, int ZR, int ACT, int NS>
+static hipError_t launch_grad_step(const CGArgs& a, int nblocks, hipStream_t st) {
+    constexpr int DT = (ZR + 3) / 4;
+    constexpr int lds = (2 * HT * 4 * 64 + 3 * DT * 4 * 64) * 16;
+    static_assert(lds <= 160 * 1024, "exchange buffers exceed LDS");
+    auto kern = coop_grad_step_kernel<HT, L, ZR, ACT, NS>;
+    static DeviceOnce once;
+    int dev = 0;
+    hipError_t e0 = hipGetDevice(&dev);
+    if (e0 != hipSuccess) return e0;
+    if (!once.done(dev)) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return e;
+        once.set(dev);
+    }
+    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(256), lds, st, a);
+    return hipGetLastError();
+}
+
+struct CoopGradInst {
+    int HT, L, ZR, ACT;
+    hipError_t (*fn[2])(const CGArgs&, int, hipStream_t);   // [0] RK4 (4 stages), [1] Tsit5 (6 stages)
+};
+#define CG_INST(HT, L, ZR) \
+    CoopGradInst { HT, L, ZR, CNF_ACT_TANH_PRESCALED, { &launch_grad_step<HT, L, ZR, CNF_ACT_TANH_PRESCALED, 4>, \
+                                                        &launch_grad_step<HT, L, ZR, CNF_ACT_TANH_PRESCALED, 6> } }
+// the same (HT, L, ZR) as the forward instances of cnf_coop.hip they pair with (the plan's packed image is shared)
+static const CoopGradInst kCoopGrad[] = {
+    CG_INST(16, 3, 8),   // cfg4: D = 32, 3 x 256
+    CG_INST(8, 3, 2),    // D <= 8, 3 x 128
+    CG_INST(4, 3, 2),    // D <= 8, 3 x 64: cross-check of the register-accumulator kernel (cnf_grad.hip)
+};
+
+static const CoopGradInst* cg_find(int HT, int L, int ZR, int ACT) {
+    for (const CoopGradInst& c : kCoopGrad)
+        if (c.HT == HT && c.L == L && c.ZR == ZR && (ACT == CNF_ACT_TANH || ACT == CNF_ACT_TANH_PRESCALED)) return &c;
+    return nullptr;
+}
+
+bool coop_grad_supported(int HT, int L, int ZR, int ACT) { return cg_find(HT, L, ZR, ACT) != nullptr; }
+int coop_grad_scratch_slots(int L) { return (L - 1) + (L - 2) + (L - 1); }
+
+hipError_t coop_grad_step_launch(int HT, int L, int ZR, int ACT, const CGArgs& a, int num_cus, hipStream_t st) {
+    const CoopGradInst* c = cg_find(HT, L, ZR, ACT);
+    if (!c) return hipErrorNotSupported;
+    const long long nst = (a.B + 63) / 64;
+    const int nblocks = (int)(nst < num_cus ? nst : num_cus);
+    return c->fn[a.T.ns <= 4 ? 0 : 1](a, nblocks, st);
+}
+
+}  // namespace cnf

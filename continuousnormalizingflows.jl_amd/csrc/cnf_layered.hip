@@ -35,6 +35,7 @@
 #include <vector>
 
 #include "cnf_internal.h"
+#include "cnf_coop_grad.h"
 
 namespace cnf {
 
@@ -943,6 +944,118 @@ hipError_t layered_grad(LayeredGrad** ctx, const cnf_config& c, const float* P_d
         const int ra = (hutch && c.reg_aug && c.naug > 0) ? 1 : 0;
         LG_HIP(epilogue(ufin, c.nvars, D, ra, B, logp_out, regs_out, st));
     }
+    LG_HIP(hipGetLastError());
+    return hipSuccess;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Cooperative gradient for wide hidden layers (cnf_coop_grad.hip): checkpointing forward solve, one reverse-sweep launch
+// per RK step, then one weight-cotangent product per weight matrix per step over the operands that launch left
+// ---------------------------------------------------------------------------------------------------------------------
+// rows [row0, rows) of columns [c0, c1) of a column-major array <- val
+__global__ void fill_rows_kernel(float* __restrict__ a, int ld, int row0, int rows, long long c0, long long c1, float val) {
+    const long long i = (long long)blockIdx.x * TPB + threadIdx.x;
+    const int nr = rows - row0;
+    if (i >= (c1 - c0) * nr) return;
+    a[(c0 + i / nr) * ld + row0 + (int)(i % nr)] = val;
+}
+
+bool coop_grad_eligible(const cnf_config& c, const MfmaPlan* plan, const float lam[3], const float* tgrid) {
+    int HT, L, ZR, ACT;
+    if (!mfma_plan_coop_shape(plan, &HT, &L, &ZR, &ACT)) return false;
+    if (const char* e = getenv("CNF_COOP_GRAD")) { if (*e == '0') return false; }
+    if (c.mode != CNF_MODE_HUTCH_VJP || c.nprobes != 1 || c.ncond != 0 || tgrid) return false;
+    if (lam[0] != 0.f || lam[1] != 0.f) return false;          // |zdot| / |eps^T J| cotangents: layer-wise path
+    if (c.n_layers != L + 1) return false;
+    for (int l = 0; l < L; ++l)
+        if (c.acts[l] != CNF_ACT_TANH || c.widths[l + 1] != c.widths[1]) return false;
+    if (c.acts[L] != CNF_ACT_IDENTITY) return false;
+    return coop_grad_supported(HT, L, ZR, ACT) && lg_wgrad_supported(c.widths[1], c.widths[1] + 1);
+}
+
+hipError_t coop_grad(LayeredGrad** ctx, const cnf_config& c, MfmaPlan* plan, const float* packed_dev, const size_t* w_off,
+                     const size_t* b_off, const float* x, const float* eps, int alg, int nsteps, float t0, float t1, long long B,
+                     float lam3, float* grad, float* grad_x, float* logp_out, float* regs_out, hipStream_t st, std::string* err) {
+    int HT, Lh, ZR, ACT;
+    if (!mfma_plan_coop_shape(plan, &HT, &Lh, &ZR, &ACT)) { *err = "coop_grad: not a cooperative plan"; return hipErrorNotSupported; }
+    if (!*ctx) *ctx = new LayeredGrad();
+    LayeredGrad& G = **ctx;
+    if (G.num_cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        LG_HIP(hipGetDevice(&dev));
+        LG_HIP(hipGetDeviceProperties(&prop, dev));
+        G.num_cus = prop.multiProcessorCount;
+    }
+    const int N = c.n_layers, D = c.nvars + c.naug, H = c.widths[1], n_in = c.widths[0];
+    LDesc L{};
+    L.n_layers = N;
+    long long npa = 0;
+    for (int l = 0; l < N; ++l) {
+        L.win[l] = c.widths[l]; L.wout[l] = c.widths[l + 1]; L.act[l] = c.acts[l];
+        L.pa_off[l] = npa; L.w_off[l] = (long long)w_off[l]; L.b_off[l] = (long long)b_off[l];
+        npa += (long long)L.wout[l] * (L.win[l] + 1);
+    }
+    L.npa = npa;
+    const long long npa_pad = (npa + 63) / 64 * 64;
+    const Tableau T = make_tableau(alg);
+    const int ns = T.ns;
+    const long long B2 = 2LL * ns * B;                      // columns of every operand array
+    long long kc = 0;
+    const int nslab = lg_wgrad_chunks(H, B2, G.num_cus, &kc);
+    const long long nst = (B + 63) / 64, ntp = nst * 4;
+    const int nblocks = (int)(nst < G.num_cus ? nst : G.num_cus);
+    const int slots = coop_grad_scratch_slots(Lh);
+    const long long scratch_stride = (long long)slots * HT * 1024;   // slots x (HT x 4 sample tiles x 64 lanes x 4) floats
+
+    long long off = 0;
+    auto take = [&](long long n) { const long long o = off; off += (n + 63) / 64 * 64; return o; };
+    const long long o_slab = take(npa_pad * nslab);
+    const long long o_zck = take((long long)(nsteps + 1) * ntp * 64 * ZR), o_kck = take((long long)nsteps * ns * ntp * 64 * ZR);
+    const long long o_lam = take(ntp * 64 * ZR), o_scr = take(scratch_stride * nblocks);
+    long long o_xh[3], o_yh[3];
+    for (int l = 0; l < Lh; ++l) { o_xh[l] = take((long long)H * B2); o_yh[l] = take((long long)(H + 1) * B2); }
+    const long long o_y1 = take((long long)(n_in + 1) * B2), o_xN = take((long long)D * B2);
+    if ((size_t)off > G.ws_floats) {
+        if (G.ws) LG_HIP(hipFree(G.ws));
+        G.ws = nullptr; G.ws_floats = 0;
+        LG_HIP(hipMalloc((void**)&G.ws, (size_t)off * sizeof(float)));
+        G.ws_floats = (size_t)off;
+    }
+    float* W = G.ws;
+    float* slabs = W + o_slab;
+    LG_HIP(hipMemsetAsync(slabs, 0, (size_t)npa_pad * nslab * sizeof(float), st));
+    // constant rows of the operand arrays: the zero / ones row of every Y_l, the zero rows under gbar
+    LG_HIP(hipMemsetAsync(W + o_y1, 0, (size_t)(n_in + 1) * B2 * sizeof(float), st));
+    for (int l = 0; l < Lh; ++l) {
+        hipLaunchKernelGGL(fill_rows_kernel, grid_for((long long)ns * B), dim3(TPB), 0, st, W + o_yh[l], H + 1, H, H + 1, 0LL, (long long)ns * B, 0.f);
+        hipLaunchKernelGGL(fill_rows_kernel, grid_for((long long)ns * B), dim3(TPB), 0, st, W + o_yh[l], H + 1, H, H + 1, (long long)ns * B, B2, 1.f);
+    }
+
+    // ---- forward: the cooperative solve, checkpointing z_n and the stage derivatives; it also delivers the loss terms ----
+    SolveArgs sa{};
+    sa.x = x; sa.eps = eps; sa.B = B; sa.nsteps = nsteps; sa.alg = alg; sa.t0 = t0; sa.t1 = t1;
+    sa.logp = logp_out; sa.regs = regs_out; sa.nvars = c.nvars; sa.reg_aug = (c.reg_aug && c.naug > 0) ? 1 : 0;
+    sa.ckpt = W + o_zck; sa.ckpt_k = W + o_kck;
+    LG_HIP(mfma_solve(plan, packed_dev, sa, st));
+
+    // ---- reverse: one launch per step, then the step's weight-cotangent products ----
+    CGArgs a{};
+    a.packed = packed_dev; a.eps = eps; a.ckpt = W + o_zck; a.ckpt_k = W + o_kck; a.lam = W + o_lam; a.grad_x = grad_x;
+    a.scratch = W + o_scr; a.scratch_stride = scratch_stride;
+    for (int l = 0; l < Lh; ++l) { a.xh[l] = W + o_xh[l]; a.yh[l] = W + o_yh[l]; }
+    a.y1 = W + o_y1; a.xN = W + o_xN; a.ld_y1 = n_in + 1;
+    a.B = B; a.nsteps = nsteps; a.D = D; a.nvars = c.nvars; a.H = H; a.autonomous = c.autonomous; a.lam3 = lam3; a.T = T;
+    const float dt = (t1 - t0) / (float)nsteps;
+    for (int n = nsteps - 1; n >= 0; --n) {
+        a.step = n; a.tn = t0 + (float)n * dt; a.dt = dt;
+        LG_HIP(coop_grad_step_launch(HT, Lh, ZR, ACT, a, G.num_cus, st));
+        LG_HIP(lg_wgrad(slabs + L.pa_off[0], npa_pad, kc, nslab, H, n_in + 1, a.xh[0], H, a.y1, n_in + 1, B2, st));
+        for (int l = 1; l < Lh; ++l)
+            LG_HIP(lg_wgrad(slabs + L.pa_off[l], npa_pad, kc, nslab, H, H + 1, a.xh[l], H, a.yh[l - 1], H + 1, B2, st));
+        LG_HIP(lg_wgrad(slabs + L.pa_off[Lh], npa_pad, kc, nslab, D, H + 1, a.xN, D, a.yh[Lh - 1], H + 1, B2, st));
+    }
+    hipLaunchKernelGGL(reduce_slabs_kernel, grid_for(npa), dim3(TPB), 0, st, slabs, nslab, npa_pad, L, grad);
     LG_HIP(hipGetLastError());
     return hipSuccess;
 }

@@ -23,6 +23,7 @@
 
 #define CNF_WITH_DEVICE_CONTROLLER 1
 #include "cnf_mfma_kernel.h"
+#include "cnf_coop_grad.h"
 
 namespace cnf {
 
@@ -357,6 +358,11 @@ hipError_t mfma_pack_q_device(const MfmaPlan* p, const float* lux_dev, const siz
 }
 
 int mfma_plan_zr(const MfmaPlan* p) { return p->ZR; }
+bool mfma_plan_coop_shape(const MfmaPlan* p, int* HT, int* L, int* ZR, int* ACT) {
+    if (!p || p->kind != 1) return false;
+    *HT = p->HT; *L = p->L; *ZR = p->ZR; *ACT = p->ACT;
+    return true;
+}
 bool mfma_plan_is_per_wave(const MfmaPlan* p) { return p->kind == 0; }
 
 // plain f32 image (forward + transposed, no tanh pre-scale) for a given layout: the gradient kernels' operand image
@@ -411,7 +417,11 @@ hipError_t mfma_solve(MfmaPlan* p, const float* packed_dev, const SolveArgs& s, 
         if (e != hipSuccess) return e;
         a.queue = mp->queue_dev;
     }
-    if (p->kind == 1) return coop_launch(p->HT, p->L, p->ZR, p->ACT, a, mp->num_cus, st);
+    if (p->kind == 1) {
+        // with checkpoint buffers: the checkpointing form of the cooperative solve (the forward half of cnf_coop_grad.hip)
+        if (s.ckpt) return coop_launch_ckpt(p->HT, p->L, p->ZR, p->ACT, a, mp->num_cus, st);
+        return coop_launch(p->HT, p->L, p->ZR, p->ACT, a, mp->num_cus, st);
+    }
     const long long ntiles = (s.B + 15) / 16;
     // Small batches (at most one 16-sample tile per compute unit): the tile-split form - the tile's hidden width over the four
     // SIMDs of a CU (cnf_coop.hip, NT = 1) - instead of one wave per tile with three SIMDs of its CU idle.  Same packed image

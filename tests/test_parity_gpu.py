@@ -579,6 +579,45 @@ def test_parameter_gradient_layerwise_path(kw, lam, B, alg, nsteps, pkg, oracles
     assert np.max(np.abs(g - gref)) < 5e-5 * scale + 1e-6, np.max(np.abs(g - gref)) / scale
 
 
+COOP_GRAD_SHAPES = [
+    # (make_spec kwargs, B, alg, nsteps, env): wide tanh FFJORD nets whose forward solve runs on the cooperative kernel
+    (dict(nvars=32, hidden=[256, 256, 256]), 40, 0, 2, {}),                       # BASELINE cfg4 shape, RK4, one ragged super-tile
+    (dict(nvars=32, hidden=[256, 256, 256]), 333, 1, 2, {}),                      # Tsit5 (6 stages), several super-tiles
+    (dict(nvars=20, naug=5, hidden=[200, 200, 200], reg_aug=True), 150, 0, 3, {}),   # zero-padded width (13 of 16 tiles), augmented, l3 |z_aug|
+    (dict(nvars=8, hidden=[128, 128, 128]), 200, 1, 2, {}),                       # 3 x 128 (8 hidden tiles, 2 state k-steps)
+    (dict(nvars=8, hidden=[64, 64, 64]), 130, 1, 3, {"CNF_MFMA_COOP": "1", "CNF_GRAD_LAYERED": "1"}),   # 3 x 64 forced onto it
+    (dict(nvars=7, hidden=[128, 128, 128], autonomous=True), 90, 0, 2, {}),       # no time column
+]
+
+
+@pytest.mark.parametrize("kw,B,alg,nsteps,env", COOP_GRAD_SHAPES)
+def test_parameter_gradient_cooperative_reverse_sweep(kw, B, alg, nsteps, env, pkg, oracles, monkeypatch):
+    """Wide hidden layers (the cooperative forward kernel's shapes): checkpointing forward solve + one cooperative reverse-sweep
+    launch per RK step + deferred weight-cotangent products (csrc/cnf_coop_grad.hip) - dloss/dps, dloss/dxs and the loss
+    against fp64 autograd through the same discrete solve (src/core/icnf.jl:90-99 differentiates `loss` through the solve),
+    and against the layer-wise path on the same inputs (CNF_COOP_GRAD=0)."""
+    o64, _ = oracles
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    spec = o64.make_spec(**kw)
+    lam = (0.0, 0.0, 0.03 if spec.reg_aug else 0.0)
+    p, xs, eps, ys = o64.synth_inputs(spec, B, 321, bias_scale=0.2)
+    L, gref, gxref = o64.loss_and_grad(spec, p, xs, 0.0, 1.0, nsteps, alg, eps, ys, lam, wrt_x=True)
+    mode = pkg.TrainMode(bool(spec.reg_aug))
+    out = {}
+    for tag, flag in (("coop", "1"), ("layered", "0")):
+        monkeypatch.setenv("CNF_COOP_GRAD", flag)
+        icnf = make_icnf(pkg, spec, alg, nsteps, path=0, lambdas=lam)
+        val, g, gx = pkg.loss_and_gradient(icnf, mode, dev(xs), dev(p), {}, eps=dev(eps), wrt_x=True)
+        assert icnf.grad_path(mode) == (3 if tag == "coop" else 2), (tag, icnf.grad_path(mode))
+        out[tag] = (float(val), g.cpu().numpy().astype(np.float64), gx.cpu().numpy().astype(np.float64))
+        assert abs(out[tag][0] - L) < 1e-4 + 2e-6 * abs(L), tag
+        scale = np.abs(gref).max()
+        assert np.max(np.abs(out[tag][1] - gref)) < 5e-5 * scale + 1e-6, (tag, np.max(np.abs(out[tag][1] - gref)) / scale)
+        assert np.max(np.abs(out[tag][2] - gxref)) < 5e-5 * np.abs(gxref).max() + 1e-7, tag
+    assert np.max(np.abs(out["coop"][1] - out["layered"][1])) < 2e-5 * np.abs(gref).max() + 1e-6
+
+
 SLAB_GRAD_SHAPES = [
     # two hidden layers, 4..7 hidden tiles: tile-fused reverse sweep with slab accumulators (csrc/cnf_grad_slab.hip)
     (dict(nvars=7, naug=8, hidden=[64, 64], act=2, reg_z=True, reg_j=True, reg_aug=True), (0.01, 0.01, 0.01), 45, 1, 3),   # ICNF(nvariables=7): D=15, two input tiles
