@@ -14,6 +14,7 @@ struct CGArgs {
     const float* ckpt;        // z at the start of every step and after the last: [step][tile][lane][ZR] (forward kernel, CK form)
     const float* ckpt_k;      // stage derivatives: [step * ns + stage][tile][lane][ZR]
     float* lam;               // costate, [tile][lane][ZR]: read (unless this is the last step), written
+    float* zb;                // Zbar_j of the running step's stages, [tile][lane][6][ZR] (scratch of the kernel)
     float* grad_x;            // nvars x B or null; written by step 0
     float* scratch;           // per-workgroup scratch, `scratch_stride` floats apart
     long long scratch_stride;
@@ -23,6 +24,7 @@ struct CGArgs {
     float* xN;                // [eps | kbar]: D rows, ld = D
     int ld_y1;
     long long B;
+    long long ntiles_pad;     // 16-sample tiles of the checkpoint arrays (the forward kernel's: 4 x ceil(B / 64))
     int step, nsteps;
     float tn, dt;             // this step's start time and length
     int D, nvars, H, autonomous;
@@ -31,7 +33,8 @@ struct CGArgs {
 };
 
 bool coop_grad_supported(int HT, int L, int ZR, int ACT);
-int coop_grad_scratch_slots(int L);   // 64 x H floats each, per workgroup
+int coop_grad_scratch_slots(int L);   // [HT x NT tiles] each, per workgroup
+int coop_grad_nt();                   // sample tiles per super-tile the reverse-sweep kernel runs with (4, or 2 by CNF_CG_NT)
 hipError_t coop_grad_step_launch(int HT, int L, int ZR, int ACT, const CGArgs& a, int num_cus, hipStream_t st);
 // the cooperative forward solve with step / stage checkpoints in tile layout (cnf_coop.hip)
 hipError_t coop_launch_ckpt(int HT, int L, int ZR, int ACT, const KArgs& a, int num_cus, hipStream_t st);

@@ -37,17 +37,29 @@ struct TS {   // one wave's share of an [H x 64-sample] quantity: MTW x NT accum
 
 // d = act'(a) from h = tanh(a)  (act''(a) = -2 h d)
 __device__ __forceinline__ f32x4 tanh_d(const f32x4& h) { return 1.f - h * h; }
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every outstanding GLOBAL access of the wave
+// (s_waitcnt vmcnt(0)): here that would put the round trip of the operand stores, the scratch stores and the prefetched scratch
+// loads (64 KB per wave per phase) on the critical path of every product.  The waves of a workgroup communicate through LDS
+// only - the global scratch is private to a wave - so the exchange needs no more than this.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
 // 16-byte store to a 4-byte-aligned address (odd leading dimensions): one global_store_dwordx4, not four scattered dwords
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 
 }  // namespace
 
-template <int HT, int L, int ZR, int ACT, int NS>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+// NT: sample tiles per super-tile.  4: one workgroup per CU, one wave per SIMD with up to 512 registers (every tile set of a
+// wave is 64 registers).  2: 32-sample super-tiles, two workgroups per CU, two waves per SIMD with 256 registers each (tile
+// sets of 32): half the reuse of every weight fragment, but a second wave on the SIMD to run while the first waits for its
+// scratch / operand traffic - which is where this kernel, unlike the forward solve, spends its stalls.
+template <int HT, int L, int ZR, int ACT, int NS, int NT = 4>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NT == 4 ? 1 : 2, NT == 4 ? 1 : 2)))
 coop_grad_step_kernel(CGArgs a) {
     static_assert(ACT == CNF_ACT_TANH_PRESCALED, "tanh nets only (act' and act'' are rebuilt from h)");
     static_assert(L == 2 || L == 3, "two or three hidden layers");
-    constexpr int NT = 4;
+    static_assert(NT == 4 || NT == 2, "64- or 32-sample super-tiles");
+    constexpr int SUP = 16 * NT;
     constexpr MfmaLayout LAY(HT, L, ZR, 0, true);
     constexpr int MTW = HT / 4, DT = (ZR + 3) / 4, XB = HT * NT * 64, DB = DT * NT * 64;
     constexpr int IMG = MfmaLayout::imgA(HT, HT);
@@ -61,7 +73,8 @@ coop_grad_step_kernel(CGArgs a) {
     const int mt0 = wave * MTW;
     const int D = a.D, H = a.H;
     const long long B = a.B;
-    const long long nst = (B + 63) / 64;
+    const long long nst = (B + SUP - 1) / SUP;
+    const bool owner = wave < NT;                     // this wave integrates sample tile `wave` of the super-tile
     const float* P = a.packed;
     const __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P), 0, 0x7fffffff, 0x00020000);
     const unsigned lane16 = (unsigned)lane * 16u;
@@ -79,26 +92,25 @@ coop_grad_step_kernel(CGArgs a) {
 #pragma unroll
             for (int q = 0; q < NT; ++q) xbuf[buf * XB + ((mt0 + m) * NT + q) * 64 + lane] = v[m][q];
     };
-    // this wave's tiles of exchange buffer `buf` -> rows [16 mt0, 16 (mt0 + MTW)) of the column-major array `arr` (leading
-    // dimension ld), columns col0 + (sample of the super-tile).  Lane (r = lane >> 4, n): rows 16 mt + 4 r .. + 3 of sample n.
-    auto gstore = [&](int buf, float* arr, int ld, long long col0, long long smp0) {
+    // this wave's tiles of exchange buffer `buf` -> rows [16 mt0, 16 (mt0 + MTW)) of a column-major operand array.  Lane
+    // (r = lane >> 4, n) stores rows 16 mt + 4 r .. + 3 of sample n: four conflict-free ds_read_b32 and one 16-byte buffer store
+    // (per-lane byte offset voff[q] precomputed per super-tile - 0xffffffff, i.e. out of range, for padding columns and rows -
+    // and the (column block, row tile) offset wave-uniform: no address arithmetic per tile).
+    auto gstore = [&](int buf, const __amdgpu_buffer_rsrc_t& rs, const unsigned (&voff)[NT], unsigned soff0, unsigned ldb) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // own ds_writes have landed; the reads below alias them
         const float* xb = reinterpret_cast<const float*>(xbuf + buf * XB);
 #pragma unroll
         for (int m = 0; m < MTW; ++m)
 #pragma unroll
             for (int q = 0; q < NT; ++q) {
-                const int base = (((mt0 + m) * NT + q) * 64 + n) * 4 + g;   // + 64 * g' : lane group g' of the image
+                const int base = (((mt0 + m) * NT + q) * 64 + n) * 4 + g;   // + 64 g': lane group g' of the image
                 f32x4 v;
                 v[0] = xb[base]; v[1] = xb[base + 64]; v[2] = xb[base + 128]; v[3] = xb[base + 192];
-                const long long smp = smp0 + q * 16 + n;
-                const int row = 16 * (mt0 + m) + 4 * g;
-                if (smp < B && row < H) {
-                    float* dst = arr + (col0 + smp) * (long long)ld + row;
-                    if (row + 3 < H) *reinterpret_cast<f32x4u*>(dst) = v;
-                    else { for (int j = 0; j < 4; ++j) if (row + j < H) dst[j] = v[j]; }
-                }
+                const unsigned so = soff0 + (unsigned)(16 * (mt0 + m)) * 4u;
+                const unsigned vo = (16 * (mt0 + m) + 4 * g < H) ? voff[q] : 0xffffffffu;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rs, (int)vo, (int)so, 0);
             }
+        (void)ldb;
     };
     float* scr = a.scratch + (long long)blockIdx.x * a.scratch_stride;
     auto sstore = [&](int slot, const T4& v) {
@@ -121,10 +133,10 @@ coop_grad_step_kernel(CGArgs a) {
 #pragma unroll
             for (int q = 0; q < NT; ++q) v[m][q] = f32x4{0.f, 0.f, 0.f, 0.f};
     };
-    // acc += A(image at float offset `img`; this wave's M-tiles) * B(LDS image `bimg` with KG k-groups)
-    auto product = [&](int img, int KG, const f32x4* bimg, T4& acc) {
-        f32x4 afr[MTW];
-        coop_load_a<MTW>(AIMG(img), mt0, KG, 0, afr);
+    // A product in two halves: its first weight fragments are requested BEFORE the elementwise / store / barrier phase that
+    // precedes it (an L2 round trip with nothing to hide behind otherwise), the k-loop runs after the barrier
+    auto pre_a = [&](int img, int KG, f32x4 (&afr)[MTW]) { coop_load_a<MTW>(AIMG(img), mt0, KG, 0, afr); };
+    auto run = [&](int img, int KG, const f32x4* bimg, f32x4 (&afr)[MTW], T4& acc) {
         coop_gemm<MTW, NT, NT>(AIMG(img), mt0, KG, bimg, 0, lane, afr, acc);
     };
     // dense D-row registers of this wave's sample tile -> B image
@@ -143,29 +155,31 @@ coop_grad_step_kernel(CGArgs a) {
         for (int s = 0; s < ZR; ++s) { const int f = 4 * s + g; if (f < D) arr[col * (long long)ld + f] = v[s]; }
     };
 
-    // scratch slots (tile-native): H_l for l = 1 .. L-1, U_l for l = 2 .. L-1, A2_l for l = 1 .. L-1
-    constexpr int SLOT_H = 0, SLOT_U = L - 1, SLOT_A2 = SLOT_U + (L - 2);
+    // scratch slots (tile-native): H_l (l = 1 .. L), U_l (l = 2 .. L-1), A2_l (l = 1 .. L-1), Q = W_1[:,0:D] eps, C = W_N^T eps
+    constexpr int SLOT_H = 0, SLOT_U = L, SLOT_A2 = SLOT_U + (L - 2), SLOT_Q = SLOT_A2 + (L - 1), SLOT_C = SLOT_Q + 1;
+    static_assert(SLOT_C + 1 == 3 * L - 1, "coop_grad_scratch_slots");
+    // operand arrays as buffer resources (byte sizes: 2 ns B columns)
+    const unsigned ldx = (unsigned)H * 4u, ldy = (unsigned)(H + 1) * 4u;
+    __amdgpu_buffer_rsrc_t rx[L], ry[L];
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+        rx[l] = __builtin_amdgcn_make_buffer_rsrc(a.xh[l], 0, (int)((long long)ldx * 2 * nsB), 0x00020000);
+        ry[l] = __builtin_amdgcn_make_buffer_rsrc(a.yh[l], 0, (int)((long long)ldy * 2 * nsB), 0x00020000);
+    }
 
     for (long long st = blockIdx.x; st < nst; st += gridDim.x) {
-        const long long smp0 = st * 64;
-        const long long smp = smp0 + wave * 16 + n;                  // this wave's own sample tile (every wave owns one: NT = 4)
-        const bool valid = smp < B;
-        const long long sc = valid ? smp : B - 1;
-        const long long tile = st * NT + wave, ntp = nst * NT;
-        float eps[ZR], zn[ZR], lam[ZR], kz[NS][ZR], Zb[NS][ZR];
+        const long long smp0 = st * SUP;
+        const long long smp = smp0 + (owner ? wave : 0) * 16 + n;    // the owner waves' own sample tile
+        const bool valid = owner && smp < B;
+        const long long sc = smp < B ? smp : B - 1;
+        const long long tile = st * NT + (owner ? wave : 0), ntp = a.ntiles_pad;
+        float eps[ZR], zn[ZR], lam[ZR];
 #pragma unroll
         for (int s = 0; s < ZR; ++s) {
             const int f = 4 * s + g;
             eps[s] = f < D ? a.eps[sc * D + f] : 0.f;
             zn[s] = a.ckpt[(((long long)a.step * ntp + tile) * 64 + lane) * ZR + s];
         }
-#pragma unroll
-        for (int j = 0; j < NS; ++j)
-#pragma unroll
-            for (int s = 0; s < ZR; ++s) {
-                kz[j][s] = j < ns ? a.ckpt_k[((((long long)a.step * ns + j) * ntp + tile) * 64 + lane) * ZR + s] : 0.f;
-                Zb[j][s] = 0.f;
-            }
         if (a.step == a.nsteps - 1) {
             // lambda_N = dL/dz_N = z_N (+ l3 z_aug / |z_aug|, src/core/base_icnf.jl:106-122); zero for padding columns
 #pragma unroll
@@ -183,33 +197,66 @@ coop_grad_step_kernel(CGArgs a) {
 #pragma unroll
             for (int s = 0; s < ZR; ++s) lam[s] = a.lam[(tile * 64 + lane) * ZR + s];
         }
-        __syncthreads();                 // the previous super-tile's readers of the LDS images are done
-        publish_dense(ebuf, eps);
-        // validity of the four sample tiles' column n (the weight of this lane's columns in every tile set)
+        // per-lane byte offsets of this lane's columns (sample q * 16 + n of the super-tile, rows 4 g ..) in the X / Y arrays;
+        // validity of those columns as a weight
+        unsigned vox[NT], voy[NT];
         float vq[NT];
 #pragma unroll
-        for (int q = 0; q < NT; ++q) vq[q] = (smp0 + q * 16 + n) < B ? 1.f : 0.f;
+        for (int q = 0; q < NT; ++q) {
+            const long long sq = smp0 + q * 16 + n;
+            vq[q] = sq < B ? 1.f : 0.f;
+            vox[q] = sq < B ? (unsigned)sq * ldx + 16u * (unsigned)g : 0xffffffffu;
+            voy[q] = sq < B ? (unsigned)sq * ldy + 16u * (unsigned)g : 0xffffffffu;
+        }
+        __syncthreads();                 // the previous super-tile's readers of the LDS images are done
+        if (owner) publish_dense(ebuf, eps);
+        __syncthreads();
+        {   // solve-invariant products of the super-tile: q = W_1[:,0:D] eps (un-scaled), c = W_N^T eps
+            f32x4 afr[MTW];
+            T4 t;
+            zero(t);
+            pre_a(LAY.f1z, DT, afr);
+            run(LAY.f1z, DT, ebuf, afr, t);
+#pragma unroll
+            for (int m = 0; m < MTW; ++m)
+#pragma unroll
+                for (int q = 0; q < NT; ++q) t[m][q] *= inv_fs;
+            sstore(SLOT_Q, t);
+            zero(t);
+            pre_a(LAY.bN, DT, afr);
+            run(LAY.bN, DT, ebuf, afr, t);
+            sstore(SLOT_C, t);
+        }
+        float* zbt = a.zb + (tile * 64 + lane) * (long long)(NS * ZR);   // Zbar_j of this step's stages, this lane
 
 #pragma clang loop unroll(disable)
         for (int i = ns - 1; i >= 0; --i) {
             // ---- this wave's sample tile: stage state, cotangent of the stage derivative ----
             float zs[ZR], kbar[ZR];
             const float bi = a.T.b[i];
+            {
+                float acc[ZR], kb[ZR];
 #pragma unroll
-            for (int s = 0; s < ZR; ++s) {
-                float acc = 0.f, kb = bi * lam[s];
+                for (int s = 0; s < ZR; ++s) { acc[s] = 0.f; kb[s] = bi * lam[s]; }
+                for (int j = 0; j < i; ++j) {
+                    const float aij = a.T.a[i][j];
+                    const float* kj = a.ckpt_k + ((((long long)a.step * ns + j) * ntp + tile) * 64 + lane) * ZR;
 #pragma unroll
-                for (int j = 0; j < NS - 1; ++j) acc = fmaf(a.T.a[i][j], kz[j][s], acc);
+                    for (int s = 0; s < ZR; ++s) acc[s] = fmaf(aij, kj[s], acc[s]);
+                }
+                for (int j = i + 1; j < ns; ++j) {
+                    const float aji = a.T.a[j][i];
 #pragma unroll
-                for (int j = 1; j < NS; ++j) kb = fmaf(a.T.a[j][i], Zb[j][s], kb);   // a[j][i] != 0 only for j > i
-                zs[s] = fmaf(dt, acc, zn[s]);
-                kbar[s] = valid ? dt * kb : 0.f;
+                    for (int s = 0; s < ZR; ++s) kb[s] = fmaf(aji, zbt[j * ZR + s], kb[s]);
+                }
+#pragma unroll
+                for (int s = 0; s < ZR; ++s) { zs[s] = fmaf(dt, acc[s], zn[s]); kbar[s] = valid ? dt * kb[s] : 0.f; }
             }
             const float cl = dt * bi;                                 // cotangent of ldot (dL/d dlogp = +1 per column)
             const float tt = tn + a.T.c[i] * dt;
             const long long c1 = (long long)i * B, c2 = nsB + (long long)i * B;   // first / second half of the operand arrays
-            publish_dense(zbuf, zs);
-            publish_dense(kbuf, kbar);
+            const unsigned sx1 = (unsigned)c1 * ldx, sx2 = (unsigned)c2 * ldx, sy1 = (unsigned)c1 * ldy, sy2 = (unsigned)c2 * ldy;
+            if (owner) { publish_dense(zbuf, zs); publish_dense(kbuf, kbar); }
             if (valid) {
                 // Wbar_1 operands: [gbar; 0; 0] with gbar = -c_l eps, and [z; t; 1];  Wbar_N operands: eps, kbar
                 float gb[ZR];
@@ -225,12 +272,12 @@ coop_grad_step_kernel(CGArgs a) {
                 dense_store(a.xN, D, c1 + smp, eps);
                 dense_store(a.xN, D, c2 + smp, kbar);
             }
-            __syncthreads();
-
-            T4 acc, h3;   // h3: activations of the LAST hidden layer stay in registers
-            // ================= (1) recompute the chain: h_l (forward images carry the pre-scale) =================
+            f32x4 afr[MTW];
+            T4 acc;
+            // ================= (1) recompute the chain (forward images carry the pre-scale) =================
             {
                 f32x4 bias[MTW], wt[MTW];
+                pre_a(LAY.f1z, DT, afr);
                 gload_cvec<MTW>(P + LAY.v_b1, mt0, g, bias);
                 gload_cvec<MTW>(P + LAY.v_w1t, mt0, g, wt);
 #pragma unroll
@@ -239,20 +286,23 @@ coop_grad_step_kernel(CGArgs a) {
 #pragma unroll
                     for (int q = 0; q < NT; ++q) acc[m][q] = b0;
                 }
-                product(LAY.f1z, DT, zbuf, acc);
+                __syncthreads();
+                run(LAY.f1z, DT, zbuf, afr, acc);
             }
             int cur = 0;
 #pragma unroll
             for (int l = 0; l < L; ++l) {      // layer l + 1
                 T4 h;
+                if (l + 1 < L) pre_a(LAY.fh + l * IMG, HT, afr);
+                else pre_a(LAY.bh + (L - 2) * IMG, HT, afr);                 // first pullback product
 #pragma unroll
                 for (int m = 0; m < MTW; ++m)
 #pragma unroll
                     for (int q = 0; q < NT; ++q) { f32x4 dd; act_tile<ACT>(acc[m][q], h[m][q], dd); }
                 publish(cur, h);
-                gstore(cur, a.yh[l], H + 1, c2, smp0);                       // [h_{l+1}; 1] half of Y_{l+1}
+                sstore(SLOT_H + l, h);
+                gstore(cur, ry[l], voy, sy2, ldy);                            // [h_{l+1}; 1] half of Y_{l+1}
                 if (l + 1 < L) {
-                    sstore(SLOT_H + l, h);
                     f32x4 bnx[MTW];
                     gload_cvec<MTW>(P + LAY.v_bh + l * MfmaLayout::vecC(HT), mt0, g, bnx);
 #pragma unroll
@@ -260,97 +310,95 @@ coop_grad_step_kernel(CGArgs a) {
 #pragma unroll
                         for (int q = 0; q < NT; ++q) acc[m][q] = bnx[m];
                     __syncthreads();
-                    product(LAY.fh + l * IMG, HT, xbuf + cur * XB, acc);
+                    run(LAY.fh + l * IMG, HT, xbuf + cur * XB, afr, acc);
                     cur ^= 1;
                 } else {
+                    // ===== (2) pullback starts here: delta_L = c .* act'_L while h_L is in registers =====
+                    T4 cv, dl;
+                    sload(SLOT_C, cv);
 #pragma unroll
                     for (int m = 0; m < MTW; ++m)
 #pragma unroll
-                        for (int q = 0; q < NT; ++q) h3[m][q] = h[m][q];
+                        for (int q = 0; q < NT; ++q) dl[m][q] = cv[m][q] * tanh_d(h[m][q]);
+                    cur ^= 1;
+                    publish(cur, dl);     // the other buffer: its last readers (the product of layer L) are behind the barrier of layer L - 1 ... see note
+                    gstore(cur, rx[L - 1], vox, sx1, ldx);                    // delta_L half of X_L
+                    __syncthreads();
                 }
             }
-            // `cur` holds h_L (own tiles only matter from here on); the other buffer is free once every wave has left the last
-            // forward product: the barrier below (after delta_L is published into it) is preceded by one here
-            __syncthreads();
-            // ================= (2) first-order pullback: u_L = c, delta_l = u_l .* act'_l, u_{l-1} = W_l^T delta_l =================
-            T4 cvec;   // c = W_N^T eps (kept: a2_L = dbar_L .* c)
-            zero(cvec);
-            product(LAY.bN, DT, ebuf, cvec);
-            {
-                T4 dl;
-#pragma unroll
-                for (int m = 0; m < MTW; ++m)
-#pragma unroll
-                    for (int q = 0; q < NT; ++q) dl[m][q] = cvec[m][q] * tanh_d(h3[m][q]);
-                cur ^= 1;
-                publish(cur, dl);
-                gstore(cur, a.xh[L - 1], H, c1, smp0);                       // delta_L half of X_L
-                __syncthreads();
-            }
-            T4 u1;     // u_1 stays in registers until a2_1 is formed
+            // note on that publish: buffer `cur` was read by the layer-L product of THIS wave and possibly still by slower waves;
+            // for L >= 2 the buffer written is the one layer L-1's product read, and every wave has passed the barrier that
+            // followed it.  (L == 1 is not instantiated.)
 #pragma unroll
             for (int l = L - 1; l >= 1; --l) {   // u_l = W_{l+1}^T delta_{l+1}; delta_l = u_l .* act'_l
-                T4 u, hl, dl;
-                zero(u);
-                product(LAY.bh + (l - 1) * IMG, HT, xbuf + cur * XB, u);
+                T4 u, hl, qv;
                 sload(SLOT_H + l - 1, hl);
-                if (l > 1) sstore(SLOT_U + l - 2, u);
-#pragma unroll
-                for (int m = 0; m < MTW; ++m)
-#pragma unroll
-                    for (int q = 0; q < NT; ++q) {
-                        dl[m][q] = u[m][q] * tanh_d(hl[m][q]);
-                        if (l == 1) u1[m][q] = u[m][q];
-                    }
+                zero(u);
+                run(LAY.bh + (l - 1) * IMG, HT, xbuf + cur * XB, afr, u);
+                if (l > 1) pre_a(LAY.bh + (l - 2) * IMG, HT, afr);
+                else pre_a(LAY.fh + 0 * IMG, HT, afr);                       // first bottom-up product
                 cur ^= 1;
-                publish(cur, dl);
-                gstore(cur, a.xh[l - 1], H, c1, smp0);                       // delta_l half of X_l
-                if (l > 1) __syncthreads();
-            }
-            // `cur` holds delta_1 (for its store only); the other buffer (delta_2, or delta_L = c .* d for L == 1) may still be
-            // read by waves inside the last pullback product
-            // ================= (3) bottom-up: dbar_1 = W_1[:,0:D] gbar = -c_l q, vbar_l = dbar_l .* act'_l, dbar_{l+1} = W_{l+1} vbar_l ====
-            {
-                T4 db, hl, vb, a2;
-                zero(db);
-                product(LAY.f1z, DT, ebuf, db);                              // (pre-scaled) W_1[:,0:D] eps
-                sload(SLOT_H + 0, hl);
+                if (l > 1) {
+                    T4 dl;
+                    sstore(SLOT_U + l - 2, u);
 #pragma unroll
-                for (int m = 0; m < MTW; ++m)
+                    for (int m = 0; m < MTW; ++m)
 #pragma unroll
-                    for (int q = 0; q < NT; ++q) {
-                        const f32x4 d1 = db[m][q] * (-cl * inv_fs * vq[q]);
-                        a2[m][q] = d1 * u1[m][q];
-                        vb[m][q] = d1 * tanh_d(hl[m][q]);
-                    }
-                sstore(SLOT_A2 + 0, a2);
-                // own tiles of `cur` (delta_1) have been stored by this wave: overwrite them with vbar_1
-                publish(cur, vb);
-                gstore(cur, a.yh[0], H + 1, c1, smp0);                       // [vbar_1; 0] half of Y_1
-                __syncthreads();
+                        for (int q = 0; q < NT; ++q) dl[m][q] = u[m][q] * tanh_d(hl[m][q]);
+                    publish(cur, dl);
+                    gstore(cur, rx[l - 1], vox, sx1, ldx);                    // delta_l half of X_l
+                    __syncthreads();
+                } else {
+                    // delta_1, and at once the bottom of the reverse pass: dbar_1 = W_1[:,0:D] gbar = -c_l q,
+                    // a2_1 = dbar_1 .* u_1, vbar_1 = dbar_1 .* act'_1
+                    T4 t;
+                    sload(SLOT_Q, qv);
+#pragma unroll
+                    for (int m = 0; m < MTW; ++m)
+#pragma unroll
+                        for (int q = 0; q < NT; ++q) t[m][q] = u[m][q] * tanh_d(hl[m][q]);
+                    publish(cur, t);
+                    gstore(cur, rx[0], vox, sx1, ldx);                        // delta_1 half of X_1
+#pragma unroll
+                    for (int m = 0; m < MTW; ++m)
+#pragma unroll
+                        for (int q = 0; q < NT; ++q) {
+                            const f32x4 d1 = qv[m][q] * (-cl * vq[q]);
+                            t[m][q] = d1 * u[m][q];
+                            qv[m][q] = d1 * tanh_d(hl[m][q]);
+                        }
+                    sstore(SLOT_A2 + 0, t);
+                    publish(cur, qv);     // own tiles of delta_1 have been stored by this wave: overwrite them with vbar_1
+                    gstore(cur, ry[0], voy, sy1, ldy);                        // [vbar_1; 0] half of Y_1
+                    __syncthreads();
+                }
             }
+            // ================= (3) bottom-up: dbar_{l+1} = W_{l+1} vbar_l, vbar_l = dbar_l .* act'_l =================
             T4 a2L;    // a2_L = dbar_L .* c
 #pragma unroll
-            for (int l = 1; l < L; ++l) {        // dbar_{l+1} = W_{l+1} vbar_l
-                T4 db;
+            for (int l = 1; l < L; ++l) {
+                T4 db, hl, x2;
+                sload(SLOT_H + l, hl);                                        // h_{l+1}
+                if (l + 1 < L) sload(SLOT_U + l - 1, x2);                     // u_{l+1}
+                else sload(SLOT_C, x2);                                       // u_L = c
                 zero(db);
-                product(LAY.fh + (l - 1) * IMG, HT, xbuf + cur * XB, db);
+                run(LAY.fh + (l - 1) * IMG, HT, xbuf + cur * XB, afr, db);
+                if (l + 1 < L) pre_a(LAY.fh + l * IMG, HT, afr);
+                else pre_a(LAY.bN, DT, afr);                                  // hbar_L = W_N^T kbar
+                cur ^= 1;
                 if (l + 1 < L) {
-                    T4 hl, ul, vb, a2;
-                    sload(SLOT_H + l, hl);
-                    sload(SLOT_U + l - 1, ul);
+                    T4 vb;
 #pragma unroll
                     for (int m = 0; m < MTW; ++m)
 #pragma unroll
                         for (int q = 0; q < NT; ++q) {
                             const f32x4 dd = db[m][q] * inv_fs;
-                            a2[m][q] = dd * ul[m][q];
+                            x2[m][q] = dd * x2[m][q];
                             vb[m][q] = dd * tanh_d(hl[m][q]);
                         }
-                    sstore(SLOT_A2 + l, a2);
-                    cur ^= 1;
+                    sstore(SLOT_A2 + l, x2);
                     publish(cur, vb);
-                    gstore(cur, a.yh[l], H + 1, c1, smp0);                   // [vbar_{l+1}; 0] half of Y_{l+1}
+                    gstore(cur, ry[l], voy, sy1, ldy);                        // [vbar_{l+1}; 0] half of Y_{l+1}
                     __syncthreads();
                 } else {
                     T4 cb;   // cbar = dbar_L .* act'_L: Wbar_N += eps cbar^T
@@ -359,41 +407,43 @@ coop_grad_step_kernel(CGArgs a) {
 #pragma unroll
                         for (int q = 0; q < NT; ++q) {
                             const f32x4 dd = db[m][q] * inv_fs;
-                            a2L[m][q] = dd * cvec[m][q];
-                            cb[m][q] = dd * tanh_d(h3[m][q]);
+                            a2L[m][q] = dd * x2[m][q];
+                            cb[m][q] = dd * tanh_d(hl[m][q]);
                         }
-                    cur ^= 1;
                     publish(cur, cb);
-                    gstore(cur, a.yh[L - 1], H + 1, c1, smp0);               // [cbar; 0] half of Y_L
+                    gstore(cur, ry[L - 1], voy, sy1, ldy);                    // [cbar; 0] half of Y_L
                     __syncthreads();   // every wave has left the last bottom-up product: its operand buffer is free
                 }
             }
-            if (L == 1) { /* not instantiated */ }
-            // ================= (4) top-down: hbar_L = W_N^T kbar, sbar_l = hbar_l .* act'_l + a2_l .* act''_l, hbar_{l-1} = W_l^T sbar_l ====
+            // ================= (4) top-down: sbar_l = hbar_l .* act'_l + a2_l .* act''_l, hbar_{l-1} = W_l^T sbar_l =================
             {
-                T4 hb;
+                T4 hb, hl, sb;
+                sload(SLOT_H + L - 1, hl);
                 zero(hb);
-                product(LAY.bN, DT, kbuf, hb);
-                T4 sb;
+                run(LAY.bN, DT, kbuf, afr, hb);
+                pre_a(LAY.bh + (L - 2) * IMG, HT, afr);
 #pragma unroll
                 for (int m = 0; m < MTW; ++m)
 #pragma unroll
                     for (int q = 0; q < NT; ++q) {
-                        const f32x4 d = tanh_d(h3[m][q]);
-                        sb[m][q] = hb[m][q] * d + a2L[m][q] * (h3[m][q] * d * -2.f);
+                        const f32x4 d = tanh_d(hl[m][q]);
+                        sb[m][q] = hb[m][q] * d + a2L[m][q] * (hl[m][q] * d * -2.f);
                     }
                 cur ^= 1;
                 publish(cur, sb);
-                gstore(cur, a.xh[L - 1], H, c2, smp0);                       // sbar_L half of X_L
+                gstore(cur, rx[L - 1], vox, sx2, ldx);                        // sbar_L half of X_L
                 __syncthreads();
             }
+            f32x4 afd[DT];
 #pragma unroll
             for (int l = L - 1; l >= 1; --l) {   // hbar_l = W_{l+1}^T sbar_{l+1}
                 T4 hb, hl, a2, sb;
-                zero(hb);
-                product(LAY.bh + (l - 1) * IMG, HT, xbuf + cur * XB, hb);
                 sload(SLOT_H + l - 1, hl);
                 sload(SLOT_A2 + l - 1, a2);
+                zero(hb);
+                run(LAY.bh + (l - 1) * IMG, HT, xbuf + cur * XB, afr, hb);
+                if (l > 1) pre_a(LAY.bh + (l - 2) * IMG, HT, afr);
+                else if (owner) coop_load_a<DT>(AIMG(LAY.b1), 0, HT, 0, afd);
 #pragma unroll
                 for (int m = 0; m < MTW; ++m)
 #pragma unroll
@@ -403,31 +453,29 @@ coop_grad_step_kernel(CGArgs a) {
                     }
                 cur ^= 1;
                 publish(cur, sb);
-                gstore(cur, a.xh[l - 1], H, c2, smp0);                       // sbar_l half of X_l
+                gstore(cur, rx[l - 1], vox, sx2, ldx);                        // sbar_l half of X_l
                 __syncthreads();
             }
             // Zbar_i = W_1[:,0:D]^T sbar_1 for this wave's own sample tile
-            {
-                f32x4 zacc[DT][1], afd[DT];
+            if (owner) {
+                f32x4 zacc[DT][1];
 #pragma unroll
                 for (int m = 0; m < DT; ++m) zacc[m][0] = f32x4{0.f, 0.f, 0.f, 0.f};
-                coop_load_a<DT>(AIMG(LAY.b1), 0, HT, 0, afd);
                 coop_gemm<DT, 1, NT>(AIMG(LAY.b1), 0, HT, xbuf + cur * XB, wave, lane, afd, zacc);
 #pragma unroll
-                for (int j = 0; j < NS; ++j)
-#pragma unroll
-                    for (int s = 0; s < ZR; ++s) Zb[j][s] = (j == i) ? zacc[s >> 2][0][s & 3] : Zb[j][s];
+                for (int s = 0; s < ZR; ++s) zbt[i * ZR + s] = zacc[s >> 2][0][s & 3];
             }
             __syncthreads();   // the next stage republishes zbuf / kbuf and reuses the exchange buffers
         }
         // lambda_n = lambda_{n+1} + sum_i Zbar_i
+        if (owner) {
 #pragma unroll
-        for (int s = 0; s < ZR; ++s) {
-            float acc = lam[s];
-#pragma unroll
-            for (int j = 0; j < NS; ++j) acc += Zb[j][s];
-            lam[s] = acc;
-            a.lam[(tile * 64 + lane) * ZR + s] = acc;
+            for (int s = 0; s < ZR; ++s) {
+                float acc = lam[s];
+                for (int j = 0; j < ns; ++j) acc += zbt[j * ZR + s];
+                lam[s] = acc;
+                a.lam[(tile * 64 + lane) * ZR + s] = acc;
+            }
         }
         if (a.step == 0 && a.grad_x && valid) {   // costate at t0 = dL/dz_0; its first nvars rows are dL/dx
 #pragma unroll
@@ -443,12 +491,15 @@ coop_grad_step_kernel(CGArgs a) {
 // ---------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------
-template <int HT, int L, int ZR, int ACT, int NS>
-static hipError_t launch_grad_step(const CGArgs& a, int nblocks, hipStream_t st) {
+template <int HT, int L, int ZR, int ACT, int NS, int NT>
+static hipError_t launch_grad_step(const CGArgs& a, int num_cus, hipStream_t st) {
     constexpr int DT = (ZR + 3) / 4;
-    constexpr int lds = (2 * HT * 4 * 64 + 3 * DT * 4 * 64) * 16;
-    static_assert(lds <= 160 * 1024, "exchange buffers exceed LDS");
-    auto kern = coop_grad_step_kernel<HT, L, ZR, ACT, NS>;
+    constexpr int lds = (2 * HT * NT * 64 + 3 * DT * NT * 64) * 16;
+    static_assert(lds * (NT == 4 ? 1 : 2) <= 160 * 1024, "exchange buffers exceed LDS");
+    const long long nst = (a.B + 16 * NT - 1) / (16 * NT);
+    const long long cap = (long long)num_cus * (NT == 4 ? 1 : 2);
+    const int nblocks = (int)(nst < cap ? nst : cap);
+    auto kern = coop_grad_step_kernel<HT, L, ZR, ACT, NS, NT>;
     static DeviceOnce once;
     int dev = 0;
     hipError_t e0 = hipGetDevice(&dev);
@@ -462,13 +513,16 @@ static hipError_t launch_grad_step(const CGArgs& a, int nblocks, hipStream_t st)
     return hipGetLastError();
 }
 
+int coop_grad_nt();
 struct CoopGradInst {
     int HT, L, ZR, ACT;
-    hipError_t (*fn[2])(const CGArgs&, int, hipStream_t);   // [0] RK4 (4 stages), [1] Tsit5 (6 stages)
+    hipError_t (*fn[4])(const CGArgs&, int, hipStream_t);   // [0] RK4 (4 stages), [1] Tsit5 (6 stages); [2], [3]: the same with NT = 2
 };
 #define CG_INST(HT, L, ZR) \
-    CoopGradInst { HT, L, ZR, CNF_ACT_TANH_PRESCALED, { &launch_grad_step<HT, L, ZR, CNF_ACT_TANH_PRESCALED, 4>, \
-                                                        &launch_grad_step<HT, L, ZR, CNF_ACT_TANH_PRESCALED, 6> } }
+    CoopGradInst { HT, L, ZR, CNF_ACT_TANH_PRESCALED, { &launch_grad_step<HT, L, ZR, CNF_ACT_TANH_PRESCALED, 4, 4>, \
+                                                        &launch_grad_step<HT, L, ZR, CNF_ACT_TANH_PRESCALED, 6, 4>, \
+                                                        &launch_grad_step<HT, L, ZR, CNF_ACT_TANH_PRESCALED, 4, 2>, \
+                                                        &launch_grad_step<HT, L, ZR, CNF_ACT_TANH_PRESCALED, 6, 2> } }
 // the same (HT, L, ZR) as the forward instances of cnf_coop.hip they pair with (the plan's packed image is shared)
 static const CoopGradInst kCoopGrad[] = {
     CG_INST(16, 3, 8),   // cfg4: D = 32, 3 x 256
@@ -483,14 +537,17 @@ static const CoopGradInst* cg_find(int HT, int L, int ZR, int ACT) {
 }
 
 bool coop_grad_supported(int HT, int L, int ZR, int ACT) { return cg_find(HT, L, ZR, ACT) != nullptr; }
-int coop_grad_scratch_slots(int L) { return (L - 1) + (L - 2) + (L - 1); }
+// sample tiles per super-tile of the reverse-sweep kernel (CNF_CG_NT = 2 | 4)
+int coop_grad_nt() {
+    static const int nt = [] { const char* e = getenv("CNF_CG_NT"); const int v = (e && *e) ? atoi(e) : 4; return v == 2 ? 2 : 4; }();
+    return nt;
+}
+int coop_grad_scratch_slots(int L) { return 3 * L - 1; }   // H_1..H_L, U_2..U_{L-1}, A2_1..A2_{L-1}, Q, C
 
 hipError_t coop_grad_step_launch(int HT, int L, int ZR, int ACT, const CGArgs& a, int num_cus, hipStream_t st) {
     const CoopGradInst* c = cg_find(HT, L, ZR, ACT);
     if (!c) return hipErrorNotSupported;
-    const long long nst = (a.B + 63) / 64;
-    const int nblocks = (int)(nst < num_cus ? nst : num_cus);
-    return c->fn[a.T.ns <= 4 ? 0 : 1](a, nblocks, st);
+    return c->fn[(a.T.ns <= 4 ? 0 : 1) + (coop_grad_nt() == 2 ? 2 : 0)](a, num_cus, st);
 }
 
 }  // namespace cnf

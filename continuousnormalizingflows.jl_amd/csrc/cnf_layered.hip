@@ -970,6 +970,7 @@ bool coop_grad_eligible(const cnf_config& c, const MfmaPlan* plan, const float l
     for (int l = 0; l < L; ++l)
         if (c.acts[l] != CNF_ACT_TANH || c.widths[l + 1] != c.widths[1]) return false;
     if (c.acts[L] != CNF_ACT_IDENTITY) return false;
+    if (c.widths[1] % 4 != 0) return false;                   // 16-byte row quads of the operand arrays
     return coop_grad_supported(HT, L, ZR, ACT) && lg_wgrad_supported(c.widths[1], c.widths[1] + 1);
 }
 
@@ -1004,7 +1005,9 @@ hipError_t coop_grad(LayeredGrad** ctx, const cnf_config& c, MfmaPlan* plan, con
     long long kc = 0;
     const int nslab = lg_wgrad_chunks(H, B2, G.num_cus, &kc);
     const long long nst = (B + 63) / 64, ntp = nst * 4;
-    const int nblocks = (int)(nst < G.num_cus ? nst : G.num_cus);
+    const int cgnt = coop_grad_nt();
+    const long long nst_g = (B + 16 * cgnt - 1) / (16 * cgnt), cap_g = (long long)G.num_cus * (cgnt == 4 ? 1 : 2);
+    const int nblocks = (int)(nst_g < cap_g ? nst_g : cap_g);
     const int slots = coop_grad_scratch_slots(Lh);
     const long long scratch_stride = (long long)slots * HT * 1024;   // slots x (HT x 4 sample tiles x 64 lanes x 4) floats
 
@@ -1012,7 +1015,7 @@ hipError_t coop_grad(LayeredGrad** ctx, const cnf_config& c, MfmaPlan* plan, con
     auto take = [&](long long n) { const long long o = off; off += (n + 63) / 64 * 64; return o; };
     const long long o_slab = take(npa_pad * nslab);
     const long long o_zck = take((long long)(nsteps + 1) * ntp * 64 * ZR), o_kck = take((long long)nsteps * ns * ntp * 64 * ZR);
-    const long long o_lam = take(ntp * 64 * ZR), o_scr = take(scratch_stride * nblocks);
+    const long long o_lam = take(ntp * 64 * ZR), o_zb = take(ntp * 64 * 6 * ZR), o_scr = take(scratch_stride * nblocks);
     long long o_xh[3], o_yh[3];
     for (int l = 0; l < Lh; ++l) { o_xh[l] = take((long long)H * B2); o_yh[l] = take((long long)(H + 1) * B2); }
     const long long o_y1 = take((long long)(n_in + 1) * B2), o_xN = take((long long)D * B2);
@@ -1041,11 +1044,11 @@ hipError_t coop_grad(LayeredGrad** ctx, const cnf_config& c, MfmaPlan* plan, con
 
     // ---- reverse: one launch per step, then the step's weight-cotangent products ----
     CGArgs a{};
-    a.packed = packed_dev; a.eps = eps; a.ckpt = W + o_zck; a.ckpt_k = W + o_kck; a.lam = W + o_lam; a.grad_x = grad_x;
+    a.packed = packed_dev; a.eps = eps; a.ckpt = W + o_zck; a.ckpt_k = W + o_kck; a.lam = W + o_lam; a.zb = W + o_zb; a.grad_x = grad_x;
     a.scratch = W + o_scr; a.scratch_stride = scratch_stride;
     for (int l = 0; l < Lh; ++l) { a.xh[l] = W + o_xh[l]; a.yh[l] = W + o_yh[l]; }
     a.y1 = W + o_y1; a.xN = W + o_xN; a.ld_y1 = n_in + 1;
-    a.B = B; a.nsteps = nsteps; a.D = D; a.nvars = c.nvars; a.H = H; a.autonomous = c.autonomous; a.lam3 = lam3; a.T = T;
+    a.B = B; a.ntiles_pad = ntp; a.nsteps = nsteps; a.D = D; a.nvars = c.nvars; a.H = H; a.autonomous = c.autonomous; a.lam3 = lam3; a.T = T;
     const float dt = (t1 - t0) / (float)nsteps;
     for (int n = nsteps - 1; n >= 0; --n) {
         a.step = n; a.tn = t0 + (float)n * dt; a.dt = dt;
