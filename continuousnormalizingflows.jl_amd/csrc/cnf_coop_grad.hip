@@ -37,13 +37,6 @@ struct TS {   // one wave's share of an [H x 64-sample] quantity: MTW x NT accum
 
 // d = act'(a) from h = tanh(a)  (act''(a) = -2 h d)
 __device__ __forceinline__ f32x4 tanh_d(const f32x4& h) { return 1.f - h * h; }
-// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every outstanding GLOBAL access of the wave
-// (s_waitcnt vmcnt(0)): here that would put the round trip of the operand stores, the scratch stores and the prefetched scratch
-// loads (64 KB per wave per phase) on the critical path of every product.  The waves of a workgroup communicate through LDS
-// only - the global scratch is private to a wave - so the exchange needs no more than this.
-__device__ __forceinline__ void lds_barrier() {
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
 // 16-byte store to a 4-byte-aligned address (odd leading dimensions): one global_store_dwordx4, not four scattered dwords
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 
@@ -98,7 +91,10 @@ coop_grad_step_kernel(CGArgs a) {
     // and the (column block, row tile) offset wave-uniform: no address arithmetic per tile).
     auto gstore = [&](int buf, const __amdgpu_buffer_rsrc_t& rs, const unsigned (&voff)[NT], unsigned soff0, unsigned ldb) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // own ds_writes have landed; the reads below alias them
-        const float* xb = reinterpret_cast<const float*>(xbuf + buf * XB);
+        // (float reads of memory written as f32x4: a may_alias type, and a compiler barrier behind the stores - type-based alias
+        // analysis would otherwise let a later publish() into the same tiles move ahead of the reads)
+        typedef float __attribute__((may_alias)) float_a;
+        const float_a* xb = reinterpret_cast<const float_a*>(xbuf + buf * XB);
 #pragma unroll
         for (int m = 0; m < MTW; ++m)
 #pragma unroll
@@ -110,6 +106,7 @@ coop_grad_step_kernel(CGArgs a) {
                 const unsigned vo = (16 * (mt0 + m) + 4 * g < H) ? voff[q] : 0xffffffffu;
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rs, (int)vo, (int)so, 0);
             }
+        asm volatile("" ::: "memory");
         (void)ldb;
     };
     float* scr = a.scratch + (long long)blockIdx.x * a.scratch_stride;
@@ -320,15 +317,15 @@ coop_grad_step_kernel(CGArgs a) {
                     for (int m = 0; m < MTW; ++m)
 #pragma unroll
                         for (int q = 0; q < NT; ++q) dl[m][q] = cv[m][q] * tanh_d(h[m][q]);
+                    // delta_L goes into the buffer the layer-L product has just read: slower waves may still be inside that
+                    // product (reading every wave's tiles), so this publish needs its own barrier in front
+                    __syncthreads();
                     cur ^= 1;
-                    publish(cur, dl);     // the other buffer: its last readers (the product of layer L) are behind the barrier of layer L - 1 ... see note
+                    publish(cur, dl);
                     gstore(cur, rx[L - 1], vox, sx1, ldx);                    // delta_L half of X_L
                     __syncthreads();
                 }
             }
-            // note on that publish: buffer `cur` was read by the layer-L product of THIS wave and possibly still by slower waves;
-            // for L >= 2 the buffer written is the one layer L-1's product read, and every wave has passed the barrier that
-            // followed it.  (L == 1 is not instantiated.)
 #pragma unroll
             for (int l = L - 1; l >= 1; --l) {   // u_l = W_{l+1}^T delta_{l+1}; delta_l = u_l .* act'_l
                 T4 u, hl, qv;
@@ -537,9 +534,10 @@ static const CoopGradInst* cg_find(int HT, int L, int ZR, int ACT) {
 }
 
 bool coop_grad_supported(int HT, int L, int ZR, int ACT) { return cg_find(HT, L, ZR, ACT) != nullptr; }
-// sample tiles per super-tile of the reverse-sweep kernel (CNF_CG_NT = 2 | 4)
+// sample tiles per super-tile of the reverse-sweep kernel: 2 (two workgroups per CU, two waves per SIMD: cfg4 loss + gradient
+// 143 ms) unless CNF_CG_NT=4 asks for the one-wave-per-SIMD form (153 ms)
 int coop_grad_nt() {
-    static const int nt = [] { const char* e = getenv("CNF_CG_NT"); const int v = (e && *e) ? atoi(e) : 4; return v == 2 ? 2 : 4; }();
+    static const int nt = [] { const char* e = getenv("CNF_CG_NT"); const int v = (e && *e) ? atoi(e) : 2; return v == 4 ? 4 : 2; }();
     return nt;
 }
 int coop_grad_scratch_slots(int L) { return 3 * L - 1; }   // H_1..H_L, U_2..U_{L-1}, A2_1..A2_{L-1}, Q, C

@@ -618,6 +618,28 @@ def test_parameter_gradient_cooperative_reverse_sweep(kw, B, alg, nsteps, env, p
     assert np.max(np.abs(out["coop"][1] - out["layered"][1])) < 2e-5 * np.abs(gref).max() + 1e-6
 
 
+def test_cooperative_gradient_at_full_size_agrees_with_the_layerwise_path(pkg, oracles, monkeypatch):
+    """BASELINE cfg4's shard (D = 32, 3 x 256, RK4 x 40, B = 32 768): loss, dloss/dps and dloss/dxs of the cooperative reverse
+    sweep against the layer-wise path on the same inputs - two independent implementations of the same discrete adjoint
+    (different products, different summation orders), both pinned to fp64 autograd at small sizes."""
+    o64, _ = oracles
+    spec = o64.make_spec(nvars=32, hidden=[256, 256, 256])
+    B = 32768
+    p, xs, eps, _ = o64.synth_inputs(spec, B, 20240615)
+    out = {}
+    for tag, flag in (("coop", "1"), ("layered", "0")):
+        monkeypatch.setenv("CNF_COOP_GRAD", flag)
+        icnf = make_icnf(pkg, spec, 0, 40, path=0, lambdas=(0.0, 0.0, 0.0))
+        val, g, gx = pkg.loss_and_gradient(icnf, pkg.TrainMode(False), dev(xs), dev(p), {}, eps=dev(eps), wrt_x=True)
+        assert icnf.grad_path(pkg.TrainMode(False)) == (3 if tag == "coop" else 2)
+        out[tag] = (float(val), g.cpu().numpy().astype(np.float64), gx.cpu().numpy().astype(np.float64))
+    a, b = out["coop"], out["layered"]
+    assert abs(a[0] - b[0]) < 2e-6 * abs(b[0]) + 1e-6
+    assert np.max(np.abs(a[1] - b[1])) < 2e-5 * np.abs(b[1]).max()
+    assert np.max(np.abs(a[2] - b[2])) < 2e-5 * np.abs(b[2]).max()
+    assert np.all(np.isfinite(a[1])) and np.all(np.isfinite(a[2]))
+
+
 SLAB_GRAD_SHAPES = [
     # two hidden layers, 4..7 hidden tiles: tile-fused reverse sweep with slab accumulators (csrc/cnf_grad_slab.hip)
     (dict(nvars=7, naug=8, hidden=[64, 64], act=2, reg_z=True, reg_j=True, reg_aug=True), (0.01, 0.01, 0.01), 45, 1, 3),   # ICNF(nvariables=7): D=15, two input tiles
