@@ -26,6 +26,19 @@
 #include "cnf_coop_dev.h"
 #include "cnf_coop_grad.h"
 
+// The operand arrays (read next by the weight-cotangent kernels) and the per-workgroup scratch move 5 GB per launch; written and
+// read with the non-temporal hint they stream past the L2 instead of evicting the 1.15 MB operand image every workgroup
+// re-reads for every product (-DCG_TEMPORAL restores plain accesses for an A/B).
+#ifndef CG_TEMPORAL
+#define CG_NT_AUX 2                                        // raw buffer store: nt
+#define CG_NT_STORE(v, p) __builtin_nontemporal_store((v), (p))
+#define CG_NT_LOAD(p) __builtin_nontemporal_load((p))
+#else
+#define CG_NT_AUX 0
+#define CG_NT_STORE(v, p) (*(p) = (v))
+#define CG_NT_LOAD(p) (*(p))
+#endif
+
 namespace cnf {
 
 namespace {
@@ -104,7 +117,7 @@ coop_grad_step_kernel(CGArgs a) {
                 v[0] = xb[base]; v[1] = xb[base + 64]; v[2] = xb[base + 128]; v[3] = xb[base + 192];
                 const unsigned so = soff0 + (unsigned)(16 * (mt0 + m)) * 4u;
                 const unsigned vo = (16 * (mt0 + m) + 4 * g < H) ? voff[q] : 0xffffffffu;
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rs, (int)vo, (int)so, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rs, (int)vo, (int)so, CG_NT_AUX);
             }
         asm volatile("" ::: "memory");
         (void)ldb;
@@ -115,14 +128,14 @@ coop_grad_step_kernel(CGArgs a) {
 #pragma unroll
         for (int m = 0; m < MTW; ++m)
 #pragma unroll
-            for (int q = 0; q < NT; ++q) s4[(m * NT + q) * 64] = v[m][q];
+            for (int q = 0; q < NT; ++q) CG_NT_STORE(v[m][q], &s4[(m * NT + q) * 64]);
     };
     auto sload = [&](int slot, T4& v) {
         const f32x4* s4 = reinterpret_cast<const f32x4*>(scr) + ((slot * 4 + wave) * MTW * NT) * 64 + lane;
 #pragma unroll
         for (int m = 0; m < MTW; ++m)
 #pragma unroll
-            for (int q = 0; q < NT; ++q) v[m][q] = s4[(m * NT + q) * 64];
+            for (int q = 0; q < NT; ++q) v[m][q] = CG_NT_LOAD(&s4[(m * NT + q) * 64]);
     };
     auto zero = [&](T4& v) {
 #pragma unroll

@@ -48,7 +48,7 @@ hipError_t lg_gemm(const float* img, int M, int K, const float* in, int ldb, flo
                    const float* e, int lde, float* dout, int ldd, int act, hipStream_t st, const float* e2 = nullptr,
                    const float* a3 = nullptr, int ld3 = 0, int first = 0);
 bool lg_wgrad_supported(int M, int Nc);
-int lg_wgrad_chunks(int M, long long B, int num_cus, long long* chunk_out);
+int lg_wgrad_chunks(int M, long long B, int num_cus, long long* chunk_out, int per_cu_dflt = 2);
 hipError_t lg_wgrad(float* slabs, long long slab_stride, long long chunk, int nchunks, int M, int Nc, const float* x, int ldx,
                     const float* y, int ldy, long long B, hipStream_t st);
 
@@ -1003,7 +1003,7 @@ hipError_t coop_grad(LayeredGrad** ctx, const cnf_config& c, MfmaPlan* plan, con
     const int ns = T.ns;
     const long long B2 = 2LL * ns * B;                      // columns of every operand array
     long long kc = 0;
-    const int nslab = lg_wgrad_chunks(H, B2, G.num_cus, &kc);
+    const int nslab = lg_wgrad_chunks(H, B2, G.num_cus, &kc, 4);
     const long long nst = (B + 63) / 64, ntp = nst * 4;
     const int cgnt = coop_grad_nt();
     const long long nst_g = (B + 16 * cgnt - 1) / (16 * cgnt), cap_g = (long long)G.num_cus * (cgnt == 4 ? 1 : 2);

@@ -666,10 +666,13 @@ lg_wgrad_kernel(LgWgradArgs a) {
 bool lg_wgrad_supported(int M, int Nc) { return M >= 1 && Nc >= 1 && Nc <= 16 * 9 * 65535; }
 
 // number of sample chunks (= slabs) a wgrad call uses for this (M, B): enough workgroups to fill the chip, chunks of >= 64 samples
-int lg_wgrad_chunks(int M, long long B, int num_cus, long long* chunk_out) {
+int lg_wgrad_chunks(int M, long long B, int num_cus, long long* chunk_out, int per_cu_dflt) {
     const int RB = ((M + 15) / 16 + 3) / 4;
     const int groups = ((M + 1 + 15) / 16 + 8) / 9;   // column groups of a square layer's cotangent (lg_wgrad)
-    static const int per_cu = [] { const char* v = getenv("CNF_LG_WGRAD_PER_CU"); return v && *v ? atoi(v) : 2; }();
+    // workgroups per CU: 2 for the per-stage calls of the layer-wise path (B columns), 4 for the per-step calls of the
+    // cooperative gradient (2 x stages x B columns: cfg4 loss + gradient 139.9 -> 133.3 ms; 1: 162, 3: 135, 8: 135)
+    static const int per_cu_env = [] { const char* v = getenv("CNF_LG_WGRAD_PER_CU"); return v && *v ? atoi(v) : 0; }();
+    const int per_cu = per_cu_env > 0 ? per_cu_env : per_cu_dflt;
     long long want = ((long long)per_cu * num_cus + RB * groups - 1) / (RB * groups);   // workgroups per CU
     if (want < 1) want = 1;
     long long chunk = (B + want - 1) / want;
