@@ -171,6 +171,9 @@ def parse():
                     help="N > 1 on the nccl backend: 'abi' = the library's own RCCL communicator (cnf_comm_init / "
                          "cnf_allreduce_loss, include/cnf.h; falls back to torch.distributed if it cannot be formed), "
                          "'torch' = torch.distributed all_reduce")
+    ap.add_argument("--bf16x6-secondary", default="auto", choices=["auto", "on", "off"],
+                    help="also measure the opt-in split-bf16 arithmetic of the same workload and report it as 'secondary_bf16x6' "
+                         "with its own error against the fp64 oracle (auto: the default cfg2 line on one GPU)")
     ap.add_argument("--force-dist", action="store_true",
                     help="take the N > 1 code path (process group, RCCL communicator, loss all-reduce inside the timed "
                          "loop, teardown) even with one rank: the rehearsal of a multi-GPU launch on a 1-GPU box")
@@ -298,7 +301,7 @@ class ClockProbe:
 # ---------------------------------------------------------------------------------------------------
 # workloads
 # ---------------------------------------------------------------------------------------------------
-def make_workload(pkg, o64, name, a, rank, dev, torch):
+def make_workload(pkg, o64, name, a, rank, dev, torch, arith=None):
     kw, alg, Bdef, flop_ss, bytes_call_ss, bytes_fused, desc = CONFIGS[name]
     B = a.batch or Bdef
     spec = o64.make_spec(**kw)
@@ -316,7 +319,7 @@ def make_workload(pkg, o64, name, a, rank, dev, torch):
     reg = bool(spec.reg_z or spec.reg_j)
     icnf = pkg.ICNF(nvariables=spec.nvars, naugments=spec.naug, nconditions=spec.ncond,
                     nn=pkg.Chain(*layers),
-                    compute_mode=pkg.HIPVecJacMatrixMode(kernel_path=a.path, arith=1 if a.arith == "bf16x6" else 0),
+                    compute_mode=pkg.HIPVecJacMatrixMode(kernel_path=a.path, arith=1 if (arith or a.arith) == "bf16x6" else 0),
                     steer_rate=0.0, lambda1=0.01 if spec.reg_z else 0.0,
                     lambda2=0.01 if spec.reg_j else 0.0, lambda3=0.0, nprobes=spec.nprobes,
                     device=dev, sol_kwargs=dict(alg=pkg.Tsit5() if alg == 1 else pkg.RK4(),
@@ -590,6 +593,24 @@ def main():
         m2 = measure(w2, a, a.steps, a.warmup, min(a.preroll_seconds, 1.5), pkg, torch, dist, world, dev, probe)
         sec = (w2, m2)
 
+    # the opt-in split-bf16 arithmetic as a reported secondary (never the headline: exact f32 is the validated path)
+    bf = None
+    want_bf = a.bf16x6_secondary == "on" or (a.bf16x6_secondary == "auto" and a.config == "cfg2" and a.mode == "infer" and
+                                              a.arith == "f32" and world == 1 and not a.force_dist and not a.batch)
+    if want_bf:
+        try:
+            w3 = make_workload(pkg, o64, a.config, a, rank, dev, torch, arith="bf16x6")
+            w3["collective"] = collective
+            m3 = measure(w3, a, a.steps, a.warmup, min(a.preroll_seconds, 1.0), pkg, torch, dist, world, dev, probe)
+            # 64 columns of this very batch under both arithmetics; the fp64 oracle is run on them in the cpu_baseline leg
+            idx = np.arange(0, w["B"], max(1, w["B"] // 64))[:64]
+            errs = {"idx": idx}
+            for tag, ww in (("f32", w), ("bf16x6", w3)):
+                errs[tag] = pkg.inference(ww["icnf"], ww["mode"], *ww["args"], eps=ww["E"])[0].cpu().numpy()[idx]
+            bf = (w3, m3, errs)
+        except Exception as ex:  # pragma: no cover
+            bf = ("error", str(ex)[:200])
+
     if rank == 0:
         r = report(w, m, a, a.steps, a.warmup, world)
         out = {
@@ -608,10 +629,31 @@ def main():
             r2 = report(sec[0], sec[1], a, a.steps, a.warmup, world)
             out["secondary"] = {"metric": out["metric"], "unit": out["unit"], "steps": a.steps,
                                 "why": "the north_star's target configuration (Tsit5 x 40) by the same protocol", **r2}
+        if bf is not None and bf[0] != "error":
+            r3 = report(bf[0], bf[1], a, a.steps, a.warmup, world)
+            out["secondary_bf16x6"] = {
+                "what": "the same workload with the hidden H x H products on six v_mfma_f32_16x16x32_bf16 per tile over an exact 3-way "
+                        "bf16 split of both operands (cnf_config.arith = CNF_ARITH_BF16X6; DESIGN.md section 4.1b): opt-in, not the headline",
+                "value": r3["value"], "unit": out["unit"], "ms_per_step": r3["ms_per_step"], "kernel_ms": r3["roofline"]["kernel_ms"],
+                "speedup_vs_f32": r3["value"] / r["value"], "loss": r3["loss"],
+                "dtype": "f32 via 3-way bf16 split (6 bf16 MFMAs per hidden product)",
+                "max_abs_dlogp_f32_vs_bf16x6": float(np.max(np.abs(bf[2]["f32"] - bf[2]["bf16x6"]))),
+                "note": "the MFMA-roofline fraction is not meaningful for this kernel (VALU / issue-bound, not MFMA-bound)"}
+        elif bf is not None:
+            out["secondary_bf16x6"] = {"error": bf[1]}
         if world == 1 and not a.no_cpu_baseline and not a.force_dist:
             p, xs, eps, ys = w["host"]
             out["cpu_baseline"] = cpu_baseline(o64, oc, w["spec"], w["alg"], p, xs, eps, ys, a.cpu_seconds)
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+            if bf is not None and bf[0] != "error":
+                # the checker on the same 64 columns: the fp64 oracle (full 40-step solves), both arithmetics against it
+                idx = bf[2]["idx"]
+                ref64 = o64.inference_fixed(w["spec"], p, xs[:, idx], 0.0, 1.0, NSTEPS, w["alg"], eps[:, idx],
+                                            None if ys is None else ys[:, idx])[0]
+                out["secondary_bf16x6"]["max_abs_dlogp_vs_fp64"] = {
+                    "columns": int(len(idx)), "f32": float(np.max(np.abs(bf[2]["f32"] - ref64))),
+                    "bf16x6": float(np.max(np.abs(bf[2]["bf16x6"] - ref64))), "tolerance": 1e-4,
+                    "oracle": "oracle/cnf_oracle64.py (float64 autograd), run in the cpu_baseline leg"}
         print(json.dumps(out))
     if sharded:
         c = pkg.get_comm()

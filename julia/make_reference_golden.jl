@@ -16,6 +16,12 @@
 # algorithms of the BASELINE configurations; not dependencies of the reference), ADTypes, ComponentArrays, Distributions,
 # Lux, LuxCore, NNlib, Random, Zygote, NPZ, JSON.
 #
+# NPZ.jl return types assumed (NPZ.npzread of a .npz written by numpy.savez): a Dict{String, Any} whose values are Arrays with the
+# numpy shape and element type - `p` a Vector{Float32}, `xs` / `eps` / `u` / `ys` Matrix{Float32} (numpy C-order (rows, B) arrays
+# arrive as (rows, B) Julia matrices: NPZ reverses the dimension order of the file and permutes back), and the 0-d array `t`
+# a 0-dimensional Array{Float32, 0} (or, in some NPZ versions, a scalar): `first(data["t"])` reads both.  An absent key
+# (`ys` of an unconditioned fixture) is tested with haskey.
+#
 # What is injected, and how (no reference code is changed):
 #   p    the fixture's flat Float32 parameter vector is copied into the ComponentArray of LuxCore.setup — so the run also
 #        TESTS the parameter order the C ABI assumes (layer_k.weight (out x in, column-major), layer_k.bias);
@@ -78,7 +84,7 @@ function run_fixture(name, meta)
     xs = Float32.(data["xs"])
     eps = Float32.(data["eps"])
     u = Float32.(data["u"])
-    t = Float32(data["t"][])
+    t = Float32(first(data["t"]))
     ys = haskey(data, "ys") ? Float32.(data["ys"]) : nothing
     D = Int(meta["nvars"]) + Int(meta["naug"])
     K = Int(meta["nprobes"])

@@ -11,7 +11,9 @@ sys.path.insert(0, os.path.dirname(HERE))
 from jl_signatures import methods  # noqa: E402
 
 REF = os.environ.get("CNF_REFERENCE", "/root/reference")
-NAMES = ("augmented_f", "base_sol", "inference_sol", "generate_sol", "make_ode_func", "loss", "inference_prob", "rrule")
+NAMES = ("augmented_f", "base_sol", "inference_sol", "generate_sol", "make_ode_func", "loss", "inference_prob", "rrule",
+         # called by julia/make_reference_golden.jl (arity / argument-kind check in tests/test_julia_binding.py)
+         "inference", "add_conditions_nn")
 FILES = ("src/core/icnf.jl", "src/core/base_icnf.jl", "src/core/utils.jl")
 
 
@@ -24,7 +26,31 @@ def derive():
     return table
 
 
+def constructor_keywords():
+    """Keyword names of the reference's `ICNF(; ...)` constructor (src/core/icnf.jl:53-103) - names only."""
+    import re
+    text = open(os.path.join(REF, "src/core/icnf.jl")).read()
+    start = text.index("function ICNF(;")
+    depth, i = 0, text.index("(", start)
+    j = i
+    while True:
+        c = text[j]
+        depth += c == "("
+        depth -= c == ")"
+        if depth == 0:
+            break
+        j += 1
+    from jl_signatures import split_top
+    kws = []
+    for a in split_top(text[i + 2:j].replace("\n", " ")):
+        m = re.match(r"\s*([^\s:=]+)\s*(::|=)", a)
+        if m:
+            kws.append(m.group(1))
+    return kws
+
+
 if __name__ == "__main__":
     t = derive()
     json.dump(t, open(os.path.join(HERE, "reference_signatures.json"), "w"), indent=0)
+    json.dump(constructor_keywords(), open(os.path.join(HERE, "reference_constructor_keywords.json"), "w"), indent=0)
     print(len(t), "methods")

@@ -251,6 +251,57 @@ def test_gradient_rule_refuses_a_base_distribution_the_kernels_do_not_fuse():
     assert "return nothing" not in bind[:bind.index("ccall(")] and "sum(p)" not in bind
 
 
+def test_reference_golden_recipe_calls_the_reference_as_it_is_declared():
+    """julia/make_reference_golden.jl cannot be executed here (no Julia): as text, every `CNF.<function>(...)` call in it has the
+    arity of a method the reference declares for that function (tests/golden/reference_signatures.json), the `ICNF(; ...)` call
+    uses only keywords of the reference's constructor (src/core/icnf.jl:53-103), the compute modes / modes it names exist
+    (src/core/types.jl), and the header states the NPZ.jl return types the script relies on."""
+    from jl_signatures import _balanced, split_top, strip_comments
+    text = strip_comments(open(os.path.join(ROOT, "julia", "make_reference_golden.jl")).read())
+    table = reference_table()
+    arities = {}
+    for m in table:
+        arities.setdefault(m["function"], set()).add(len(m["args"]))
+    seen = {}
+    for m in re.finditer(r"CNF\.(\w+)\(", text):
+        name = m.group(1)
+        end = _balanced(text, m.end() - 1)
+        args = split_top(text[m.end():end - 1].replace("\n", " "))
+        kw = [a for a in args if a.startswith(";") or re.match(r"^\w+\s*=[^=]", a)]
+        pos = [a for a in args if a not in kw]
+        seen.setdefault(name, []).append((len(pos), args))
+    for fn in ("augmented_f", "inference", "inference_prob", "base_sol", "add_conditions_nn"):
+        assert fn in seen, fn
+        for n, args in seen[fn]:
+            assert n in arities[fn], (fn, n, sorted(arities[fn]), args)
+    # conditioned and unconditioned forms are both exercised
+    assert {n for n, _ in seen["inference"]} == {5, 6} and {n for n, _ in seen["add_conditions_nn"]} == {1, 2}
+    # the out-of-place dynamics call: (u, p, t, icnf, mode, nn, st, eps) - 8 positional arguments (src/core/icnf.jl:517-536)
+    assert {n for n, _ in seen["augmented_f"]} == {8}
+    # constructor keywords
+    kws = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_constructor_keywords.json")))
+    m = re.search(r"CNF\.ICNF\(;", text)
+    end = _balanced(text, m.end() - 2)
+    used = []
+    for a in split_top(text[m.end():end - 1].replace("\n", " ")):
+        k = re.match(r"\s*([^\s=,]+)", a).group(1)
+        used.append(k)
+    assert used and all(k in kws for k in used), [k for k in used if k not in kws]
+    for must in ("nvariables", "naugments", "nconditions", "autonomous", "nn", "compute_mode", "steer_rate", "epsdist", "sol_kwargs"):
+        assert must in used, must
+    # types named by the recipe exist in the reference (names only)
+    for tname in ("LuxVecJacMatrixMode", "LuxJacVecMatrixMode", "TestMode", "TrainMode"):
+        assert f"CNF.{tname}" in text
+    ref_root = os.environ.get("CNF_REFERENCE", "/root/reference")
+    if os.path.isdir(os.path.join(ref_root, "src", "core")):
+        types_jl = open(os.path.join(ref_root, "src", "core", "types.jl")).read()
+        for tname in ("LuxVecJacMatrixMode", "LuxJacVecMatrixMode", "TestMode", "TrainMode"):
+            assert re.search(rf"struct {tname}\b", types_jl), tname
+    # the header says what it assumes of NPZ.jl
+    raw = open(os.path.join(ROOT, "julia", "make_reference_golden.jl")).read()
+    assert "NPZ.jl return types assumed" in raw
+
+
 def test_reference_signature_fixture_is_current():
     ref_root = os.environ.get("CNF_REFERENCE", "/root/reference")
     if not os.path.isdir(os.path.join(ref_root, "src", "core")):
@@ -260,3 +311,4 @@ def test_reference_signature_fixture_is_current():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     assert mod.derive() == reference_table()
+    assert mod.constructor_keywords() == json.load(open(os.path.join(ROOT, "tests", "golden", "reference_constructor_keywords.json")))
