@@ -80,7 +80,7 @@ struct cnf_handle {
     float* slab_packed = nullptr;        // operand image of the slab-accumulator gradient kernel (cnf_grad_slab.hip)
     float* slab_ws = nullptr;            // its checkpoints + slabs
     size_t slab_ws_floats = 0;
-    cnf::LayeredGrad* layered = nullptr;      // rocBLAS context + workspaces of the layer-wise evaluation / gradient
+    cnf::LayeredGrad* layered = nullptr;      // operand images + workspaces of the layer-wise evaluation / gradient and of the cooperative gradient
     // embedded-step workspace (cnf_step_embedded): 7 stage derivatives + 1 stage state, each S x ebuf_B
     float* ebuf = nullptr;
     int64_t ebuf_B = 0;

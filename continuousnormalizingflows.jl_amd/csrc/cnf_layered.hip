@@ -11,7 +11,8 @@
 // Same mathematics as cnf_grad.hip (discretise-then-optimise reverse sweep through the fixed-step RK
 // solve; reference: Zygote through SciMLBase.solve, src/core/icnf.jl:90-99, objective icnf.jl:184-251,
 // 628-637), organised LAYER-WISE over the whole column shard instead of tile-wise: every product is a
-// plain GEMM [features x B] on rocBLAS (f32 MFMA), the elementwise pieces are small HIP kernels below.
+// plain product [features x B] on the library's own MFMA kernels (cnf_lgemm.hip), the elementwise pieces ride in their epilogues
+// or are the small HIP kernels below.
 // With wide layers the arithmetic intensity of these GEMMs is high (256 x 256 x B), so the layer-wise
 // form is compute-bound on the matrix cores; the activations of one stage (a_l, act'_l, the pullback
 // v_l, ...) live in HBM (cfg4: ~0.6 GB).

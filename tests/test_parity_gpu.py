@@ -564,7 +564,8 @@ LAYERED_GRAD_SHAPES = [
 @pytest.mark.parametrize("kw,lam,B,alg,nsteps", LAYERED_GRAD_SHAPES)
 def test_parameter_gradient_layerwise_path(kw, lam, B, alg, nsteps, pkg, oracles):
     """Every Hutchinson-VJP configuration has a gradient: what the fused reverse-sweep kernels do not
-    cover runs layer-wise on rocBLAS GEMMs.  Checked against the fp64 autograd oracle."""
+    cover runs layer-wise on the library's own MFMA product kernels (csrc/cnf_lgemm.hip; the cfg4 shape on the cooperative
+    reverse sweep).  Checked against the fp64 autograd oracle."""
     o64, _ = oracles
     spec = o64.make_spec(**kw)
     p, xs, eps, ys = o64.synth_inputs(spec, B, 123, bias_scale=0.2)
