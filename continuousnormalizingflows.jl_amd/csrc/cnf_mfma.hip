@@ -42,7 +42,7 @@ struct MfmaPlan {
     cnf_config cfg;
     int nthreads;
     int num_cus;
-    int kind;           // 0: per-wave LDS-resident kernel, 1: cooperative wide-layer kernel
+    int kind;           // 0: per-wave LDS-resident kernel, 1: cooperative wide-layer kernel, 2: its extended form (cnf_coop_x.hip)
     int arith;          // CNF_ARITH_* of the hidden products
     float fwd_scale;    // factor folded into the forward hidden-layer images/biases (pre-scaled tanh)
     int prio_mode;      // see KArgs
@@ -200,8 +200,28 @@ MfmaPlan* mfma_plan_create(const cnf_config& c) {
             if (const Inst* ap = pick(genp, ngp, true)) return make(*ap);
         }
     }
-    // 3. cooperative wide-layer kernel
-    return make_coop();
+    // 3. cooperative wide-layer kernel (Hutchinson VJP, one probe, no conditions) ...
+    if (MfmaPlan* p = make_coop()) return p;
+    // 4. ... and its extended form: conditions, several probes, the exact trace as D unit probes (three hidden layers: with two
+    //    the layer-wise path's single Q product is cheaper than D pullbacks).  Hutchinson JVP stays layer-wise.
+    if (c.arith != CNF_ARITH_F32 || env_int("CNF_MFMA_COOPX", 1) == 0) return nullptr;
+    const bool exact = c.mode == CNF_MODE_EXACT;
+    if (!(c.mode == CNF_MODE_HUTCH_VJP || (exact && L == 3))) return nullptr;
+    if (!exact && (c.nprobes < 1 || c.nprobes > 64)) return nullptr;
+    int hti = HT, zri = ZR, cri = CR;
+    if (!coopx_supported(HT, L, ZR, CR, c.acts[0], &hti, &zri, &cri)) return nullptr;
+    MfmaPlan* p = new MfmaPlan();
+    p->HT = hti; p->L = L; p->ZR = zri; p->CR = cri; p->ACT = c.acts[0]; p->ENGINE = ENG_VJP; p->KP = exact ? 1 : c.nprobes;
+    p->with_bwd = true;
+    p->lay = MfmaLayout(hti, L, zri, cri, true);
+    p->launch = nullptr; p->launch_adapt = nullptr; p->launch_vcabm = nullptr;
+    p->cfg = c;
+    p->nthreads = 256; p->num_cus = 0; p->prio_mode = 0; p->use_queue = 0; p->queue_dev = nullptr;
+    p->kind = 2; p->arith = 0;
+    p->fwd_scale = c.acts[0] == CNF_ACT_TANH ? kTanhPrescale : 1.f;
+    snprintf(p->name, sizeof(p->name), "coopx<HT=%d,L=%d,ZR=%d,CR=%d,act=%d,%s>", hti, L, zri, cri, c.acts[0],
+             exact ? "exact (unit probes)" : "vjp");
+    return p;
 }
 
 void mfma_plan_destroy(MfmaPlan* p) {
@@ -417,6 +437,7 @@ hipError_t mfma_solve(MfmaPlan* p, const float* packed_dev, const SolveArgs& s, 
         if (e != hipSuccess) return e;
         a.queue = mp->queue_dev;
     }
+    if (p->kind == 2) return coopx_launch(p->HT, p->L, p->ZR, p->CR, p->ACT, a, mp->num_cus, st);
     if (p->kind == 1) {
         // with checkpoint buffers: the checkpointing form of the cooperative solve (the forward half of cnf_coop_grad.hip)
         if (s.ckpt) return coop_launch_ckpt(p->HT, p->L, p->ZR, p->ACT, a, mp->num_cus, st);

@@ -82,6 +82,9 @@ __device__ __forceinline__ void load_cvec(const float* __restrict__ vec, int g, 
 // cooperative wide-layer kernel (cnf_coop.hip)
 bool coop_supported(int HT, int L, int ZR, int CR, int ACT, int engine, int KP, int* ZR_inst, int* HT_inst);
 hipError_t coop_launch(int HT, int L, int ZR, int ACT, const KArgs& a, int num_cus, hipStream_t st);
+// the cooperative kernel extended to conditions, several probes and the exact trace as unit probes (cnf_coop_x.hip)
+bool coopx_supported(int HT, int L, int ZR, int CR, int ACT, int* HT_inst, int* ZR_inst, int* CR_inst);
+hipError_t coopx_launch(int HT, int L, int ZR, int CR, int ACT, const KArgs& a, int num_cus, hipStream_t st);
 // the same kernel with ONE sample tile per workgroup and the images in LDS: the tile-split form for small batches
 bool coop_split_supported(int HT, int L, int ZR, int ACT);
 hipError_t coop_split_launch(int HT, int L, int ZR, int ACT, const KArgs& a, hipStream_t st);

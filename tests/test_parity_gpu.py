@@ -5,6 +5,8 @@ Tolerances (float32 arithmetic, stated by north_star: log-density max abs error 
   * fixed-step solve vs fp64 fixtures / C restatement: 1e-4 absolute on logp, regs, state
   * structural properties (column independence, shard concatenation, SIMT-vs-MFMA agreement,
     determinism) are bit-exact where the same kernel runs on the same column."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -119,6 +121,39 @@ CASES = [
     (dict(nvars=8, hidden=[72, 72, 72]), 60, 0, 6),                                         # 5 hidden tiles -> the 6-tile instance
 ]
 GENERIC_MFMA_CASES = CASES[-15:]
+# the cooperative kernel extended to conditions, several probes and the exact trace as unit probes (csrc/cnf_coop_x.hip):
+# hidden widths 129 .. 256, which before round 3 ran layer-wise
+COOPX_CASES = [
+    (dict(nvars=8, ncond=8, hidden=[256, 256, 256], mode=2), 130, 0, 10),                   # cfg5's flow at H = 256: conditioned, exact trace (8 unit probes)
+    (dict(nvars=8, ncond=8, hidden=[192, 192, 192], mode=2), 75, 1, 6),                     # ... at H = 192 (12 of 16 tiles), Tsit5
+    (dict(nvars=8, ncond=8, hidden=[256, 256, 256], reg_z=True, reg_j=True), 100, 1, 8),    # conditioned RNODE, one probe
+    (dict(nvars=12, hidden=[192, 192, 192], nprobes=3, reg_z=True, reg_j=True), 70, 0, 8),  # three Hutchinson probes, wide
+    (dict(nvars=20, naug=4, ncond=5, hidden=[160, 160], act=2, nprobes=2, reg_z=True, reg_j=True, reg_aug=True), 45, 1, 6),   # softplus, two layers, augmented, 5 conditions
+    (dict(nvars=30, hidden=[256, 224, 256], mode=2, autonomous=True), 33, 0, 4),             # exact trace, D = 30 (30 unit probes), ragged widths, autonomous
+]
+CASES = CASES + COOPX_CASES
+
+
+@pytest.mark.parametrize("kw,B,alg,nsteps", COOPX_CASES)
+def test_wide_conditioned_probe_and_exact_flows_take_the_extended_cooperative_kernel(kw, B, alg, nsteps, pkg, oracles):
+    """These shapes resolve to the fused path (kernel_path 2) on their own, a single dynamics call (boundary A) agrees with the
+    fp64 oracle, and CNF_MFMA_COOPX=0 still serves them layer-wise (src/core/icnf.jl:297-339,517-559 on
+    src/core/base_icnf.jl:272-296 inputs)."""
+    o64, _ = oracles
+    spec = o64.make_spec(**kw)
+    icnf = make_icnf(pkg, spec, alg, nsteps, path=0)
+    mode = mode_of(pkg, spec)
+    assert icnf.kernel_path(mode) == 2
+    p, xs, eps, ys = o64.synth_inputs(spec, B, 99, bias_scale=0.2)
+    u = np.concatenate([xs, 0.3 * np.ones((spec.naug, B), np.float32), 0.1 * np.ones((3, B), np.float32)], axis=0).astype(np.float32)
+    du = pkg.augmented_f(icnf, mode, dev(u), dev(p), 0.41, dev(eps), dev(ys)).cpu().numpy()
+    ref = o64.aug_f(spec, p, u, 0.41, eps, ys)
+    assert np.max(np.abs(du - ref) / (1.0 + np.abs(ref))) < TOL_CALL
+    os.environ["CNF_MFMA_COOPX"] = "0"
+    try:
+        assert make_icnf(pkg, spec, alg, nsteps, path=0).kernel_path(mode) == 3
+    finally:
+        del os.environ["CNF_MFMA_COOPX"]
 
 
 @pytest.mark.parametrize("kw,B,alg,nsteps", GENERIC_MFMA_CASES)
@@ -143,6 +178,28 @@ def test_inference_matches_c_restatement(kw, B, alg, nsteps, pkg, oracles):
         for a, b in zip(regs, ref_regs):
             assert np.max(np.abs(a.cpu().numpy() - b)) < TOL_SOLVE
         assert np.max(np.abs(u1.cpu().numpy() - ref_u)) < TOL_SOLVE
+
+
+def test_extended_cooperative_kernel_at_full_size(pkg, oracles, monkeypatch):
+    """BASELINE cfg5's flow (CondFFJORD D = 8 + 8 conditions, exact trace, RK4 x 40, B = 16 384) at hidden width 256, where it
+    runs on the extended cooperative kernel: every column against the layer-wise path (an independent implementation), 128
+    columns against the C restatement, finiteness."""
+    o64, oc = oracles
+    spec = o64.make_spec(nvars=8, ncond=8, hidden=[256, 256, 256], mode=2)
+    B = 16384
+    p, xs, eps, ys = o64.synth_inputs(spec, B, 20240616)
+    icnf = make_icnf(pkg, spec, 0, 40, path=0)
+    assert icnf.kernel_path(mode_of(pkg, spec)) == 2
+    lp = run_inference(pkg, icnf, spec, p, xs, eps, ys)[0].cpu().numpy()
+    assert np.all(np.isfinite(lp))
+    monkeypatch.setenv("CNF_MFMA_COOPX", "0")
+    lay = make_icnf(pkg, spec, 0, 40, path=0)
+    assert lay.kernel_path(mode_of(pkg, spec)) == 3
+    lp2 = run_inference(pkg, lay, spec, p, xs, eps, ys)[0].cpu().numpy()
+    assert np.max(np.abs(lp - lp2)) < 5e-5
+    idx = np.random.default_rng(1).choice(B, 128, replace=False)
+    ref = oc.inference_fixed(spec, p, xs[:, idx], 0.0, 1.0, 40, 0, eps[:, idx], ys[:, idx], nthreads=8)[0]
+    assert np.max(np.abs(lp[idx] - ref)) < TOL_SOLVE
 
 
 def test_cooperative_wide_layer_kernel_matches_per_wave_kernel(pkg, oracles, monkeypatch):
