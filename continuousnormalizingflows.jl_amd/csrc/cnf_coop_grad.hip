@@ -50,6 +50,30 @@ struct TS {   // one wave's share of an [H x 64-sample] quantity: MTW x NT accum
 
 // d = act'(a) from h = tanh(a)  (act''(a) = -2 h d)
 __device__ __forceinline__ f32x4 tanh_d(const f32x4& h) { return 1.f - h * h; }
+// A product's k-loop in two parts, so that loads whose data is needed only AFTER the product (the scratch operands of the
+// elementwise phase that follows) can be requested behind the product's LAST fragment requests: they then return under its
+// final two k-groups instead of sitting in front of its fragment loads in the in-order vmcnt queue.
+//   head: k-groups 0 .. KG-3; on return a0 / b0 hold the (requested) fragments of k-group KG-2, a1 / b1 those of KG-1
+//   tail: the MFMAs of k-groups KG-2 and KG-1.        (KG even: 2 for the D-sized products, HT for the H x H ones)
+template <int M, int NQ, int NT>
+__device__ __forceinline__ void coop_gemm_head(const AImg& A, int mt0, int KG, const f32x4* __restrict__ bimg, int lane,
+                                               f32x4 (&a0)[M], f32x4 (&a1)[M], f32x4 (&b0)[NQ], f32x4 (&b1)[NQ], f32x4 (&acc)[M][NQ]) {
+    coop_load_b<NQ, NT>(bimg, 0, 0, lane, b0);
+#pragma clang loop unroll(disable)
+    for (int kg = 0; kg + 2 < KG; kg += 2) {
+        coop_load_a<M>(A, mt0, KG, kg + 1, a1); coop_load_b<NQ, NT>(bimg, 0, kg + 1, lane, b1);
+        coop_frag_mfma<M, NQ>(a0, b0, acc);
+        coop_load_a<M>(A, mt0, KG, kg + 2, a0); coop_load_b<NQ, NT>(bimg, 0, kg + 2, lane, b0);
+        coop_frag_mfma<M, NQ>(a1, b1, acc);
+    }
+    if (KG >= 2) { coop_load_a<M>(A, mt0, KG, KG - 1, a1); coop_load_b<NQ, NT>(bimg, 0, KG - 1, lane, b1); }
+}
+template <int M, int NQ>
+__device__ __forceinline__ void coop_gemm_tail(int KG, const f32x4 (&a0)[M], const f32x4 (&a1)[M], const f32x4 (&b0)[NQ],
+                                               const f32x4 (&b1)[NQ], f32x4 (&acc)[M][NQ]) {
+    coop_frag_mfma<M, NQ>(a0, b0, acc);
+    if (KG >= 2) coop_frag_mfma<M, NQ>(a1, b1, acc);      // (KG == 1: a D-sized product with D <= 16)
+}
 // 16-byte store to a 4-byte-aligned address (odd leading dimensions): one global_store_dwordx4, not four scattered dwords
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 
@@ -103,6 +127,9 @@ coop_grad_step_kernel(CGArgs a) {
     // (per-lane byte offset voff[q] precomputed per super-tile - 0xffffffff, i.e. out of range, for padding columns and rows -
     // and the (column block, row tile) offset wave-uniform: no address arithmetic per tile).
     auto gstore = [&](int buf, const __amdgpu_buffer_rsrc_t& rs, const unsigned (&voff)[NT], unsigned soff0, unsigned ldb) {
+#ifdef CG_EXP_NO_GSTORE
+        return;
+#endif
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // own ds_writes have landed; the reads below alias them
         // (float reads of memory written as f32x4: a may_alias type, and a compiler barrier behind the stores - type-based alias
         // analysis would otherwise let a later publish() into the same tiles move ahead of the reads)
@@ -124,6 +151,9 @@ coop_grad_step_kernel(CGArgs a) {
     };
     float* scr = a.scratch + (long long)blockIdx.x * a.scratch_stride;
     auto sstore = [&](int slot, const T4& v) {
+#ifdef CG_EXP_NO_SCRATCH
+        return;
+#endif
         f32x4* s4 = reinterpret_cast<f32x4*>(scr) + ((slot * 4 + wave) * MTW * NT) * 64 + lane;
 #pragma unroll
         for (int m = 0; m < MTW; ++m)
@@ -131,6 +161,10 @@ coop_grad_step_kernel(CGArgs a) {
             for (int q = 0; q < NT; ++q) CG_NT_STORE(v[m][q], &s4[(m * NT + q) * 64]);
     };
     auto sload = [&](int slot, T4& v) {
+#ifdef CG_EXP_NO_SCRATCH
+        for (int m = 0; m < MTW; ++m) for (int q = 0; q < NT; ++q) v[m][q] = f32x4{0.5f, 0.25f, 0.125f, 0.0625f};
+        return;
+#endif
         const f32x4* s4 = reinterpret_cast<const f32x4*>(scr) + ((slot * 4 + wave) * MTW * NT) * 64 + lane;
 #pragma unroll
         for (int m = 0; m < MTW; ++m)
@@ -149,6 +183,11 @@ coop_grad_step_kernel(CGArgs a) {
     auto run = [&](int img, int KG, const f32x4* bimg, f32x4 (&afr)[MTW], T4& acc) {
         coop_gemm<MTW, NT, NT>(AIMG(img), mt0, KG, bimg, 0, lane, afr, acc);
     };
+    f32x4 fa1[MTW], fb0[NT], fb1[NT];     // the split k-loop's second fragment set
+    auto head = [&](int img, int KG, const f32x4* bimg, f32x4 (&afr)[MTW], T4& acc) {
+        coop_gemm_head<MTW, NT, NT>(AIMG(img), mt0, KG, bimg, lane, afr, fa1, fb0, fb1, acc);
+    };
+    auto tail = [&](int KG, f32x4 (&afr)[MTW], T4& acc) { coop_gemm_tail<MTW, NT>(KG, afr, fa1, fb0, fb1, acc); };
     // dense D-row registers of this wave's sample tile -> B image
     auto publish_dense = [&](f32x4* img, const float (&v)[ZR]) {
 #pragma unroll
@@ -300,6 +339,7 @@ coop_grad_step_kernel(CGArgs a) {
                 run(LAY.f1z, DT, zbuf, afr, acc);
             }
             int cur = 0;
+            T4 cvL;
 #pragma unroll
             for (int l = 0; l < L; ++l) {      // layer l + 1
                 T4 h;
@@ -320,12 +360,18 @@ coop_grad_step_kernel(CGArgs a) {
 #pragma unroll
                         for (int q = 0; q < NT; ++q) acc[m][q] = bnx[m];
                     __syncthreads();
-                    run(LAY.fh + l * IMG, HT, xbuf + cur * XB, afr, acc);
+                    if (l + 2 == L) {   // the last forward product: c (for delta_L) is requested under its final k-groups
+                        head(LAY.fh + l * IMG, HT, xbuf + cur * XB, afr, acc);
+                        sload(SLOT_C, cvL);
+                        tail(HT, afr, acc);
+                    } else {
+                        run(LAY.fh + l * IMG, HT, xbuf + cur * XB, afr, acc);
+                    }
                     cur ^= 1;
                 } else {
                     // ===== (2) pullback starts here: delta_L = c .* act'_L while h_L is in registers =====
-                    T4 cv, dl;
-                    sload(SLOT_C, cv);
+                    T4 dl;
+                    T4& cv = cvL;
 #pragma unroll
                     for (int m = 0; m < MTW; ++m)
 #pragma unroll
@@ -342,9 +388,11 @@ coop_grad_step_kernel(CGArgs a) {
 #pragma unroll
             for (int l = L - 1; l >= 1; --l) {   // u_l = W_{l+1}^T delta_{l+1}; delta_l = u_l .* act'_l
                 T4 u, hl, qv;
-                sload(SLOT_H + l - 1, hl);
                 zero(u);
-                run(LAY.bh + (l - 1) * IMG, HT, xbuf + cur * XB, afr, u);
+                head(LAY.bh + (l - 1) * IMG, HT, xbuf + cur * XB, afr, u);
+                sload(SLOT_H + l - 1, hl);
+                if (l == 1) sload(SLOT_Q, qv);
+                tail(HT, afr, u);
                 if (l > 1) pre_a(LAY.bh + (l - 2) * IMG, HT, afr);
                 else pre_a(LAY.fh + 0 * IMG, HT, afr);                       // first bottom-up product
                 cur ^= 1;
@@ -362,7 +410,6 @@ coop_grad_step_kernel(CGArgs a) {
                     // delta_1, and at once the bottom of the reverse pass: dbar_1 = W_1[:,0:D] gbar = -c_l q,
                     // a2_1 = dbar_1 .* u_1, vbar_1 = dbar_1 .* act'_1
                     T4 t;
-                    sload(SLOT_Q, qv);
 #pragma unroll
                     for (int m = 0; m < MTW; ++m)
 #pragma unroll
@@ -388,11 +435,12 @@ coop_grad_step_kernel(CGArgs a) {
 #pragma unroll
             for (int l = 1; l < L; ++l) {
                 T4 db, hl, x2;
+                zero(db);
+                head(LAY.fh + (l - 1) * IMG, HT, xbuf + cur * XB, afr, db);
                 sload(SLOT_H + l, hl);                                        // h_{l+1}
                 if (l + 1 < L) sload(SLOT_U + l - 1, x2);                     // u_{l+1}
                 else sload(SLOT_C, x2);                                       // u_L = c
-                zero(db);
-                run(LAY.fh + (l - 1) * IMG, HT, xbuf + cur * XB, afr, db);
+                tail(HT, afr, db);
                 if (l + 1 < L) pre_a(LAY.fh + l * IMG, HT, afr);
                 else pre_a(LAY.bN, DT, afr);                                  // hbar_L = W_N^T kbar
                 cur ^= 1;
@@ -428,9 +476,10 @@ coop_grad_step_kernel(CGArgs a) {
             // ================= (4) top-down: sbar_l = hbar_l .* act'_l + a2_l .* act''_l, hbar_{l-1} = W_l^T sbar_l =================
             {
                 T4 hb, hl, sb;
-                sload(SLOT_H + L - 1, hl);
                 zero(hb);
-                run(LAY.bN, DT, kbuf, afr, hb);
+                head(LAY.bN, DT, kbuf, afr, hb);
+                sload(SLOT_H + L - 1, hl);
+                tail(DT, afr, hb);
                 pre_a(LAY.bh + (L - 2) * IMG, HT, afr);
 #pragma unroll
                 for (int m = 0; m < MTW; ++m)
@@ -448,10 +497,11 @@ coop_grad_step_kernel(CGArgs a) {
 #pragma unroll
             for (int l = L - 1; l >= 1; --l) {   // hbar_l = W_{l+1}^T sbar_{l+1}
                 T4 hb, hl, a2, sb;
+                zero(hb);
+                head(LAY.bh + (l - 1) * IMG, HT, xbuf + cur * XB, afr, hb);
                 sload(SLOT_H + l - 1, hl);
                 sload(SLOT_A2 + l - 1, a2);
-                zero(hb);
-                run(LAY.bh + (l - 1) * IMG, HT, xbuf + cur * XB, afr, hb);
+                tail(HT, afr, hb);
                 if (l > 1) pre_a(LAY.bh + (l - 2) * IMG, HT, afr);
                 else if (owner) coop_load_a<DT>(AIMG(LAY.b1), 0, HT, 0, afd);
 #pragma unroll
