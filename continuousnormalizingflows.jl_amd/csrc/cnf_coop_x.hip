@@ -3,6 +3,7 @@
 //   * several Hutchinson probes (this framework's nprobes extension; one forward pass, K pullbacks),
 //   * the exact trace (TestMode, src/core/icnf.jl:297-339, src/core/utils.jl:79-88) as the D unit probes e_1 .. e_D through the
 //     same pullback: tr J = sum_p (e_p^T J)_p - what the reference's DI variants do with one-hot seeds (utils.jl:35-77),
+//   * Hutchinson JVP (LuxJacVecMatrixMode, src/core/icnf.jl:561-603): the probes pushed through the forward images,
 // for hidden widths above the per-wave kernels' reach (129 .. 256: their forward + transposed images exceed LDS).  Before this
 // file those configurations ran layer-wise (cnf_layered.hip), every product a separate launch with its operands in HBM.
 //
@@ -21,7 +22,7 @@ namespace cnf {
 // other through the pullback; eps_p of the owner's sample tile is published per probe.
 template <int HT, int L, int ZR, int CR, int ACT>
 __device__ __forceinline__ void coopx_eval(const float* __restrict__ P, f32x4* xbuf, f32x4* zbuf, f32x4* ebuf, const f32x4* ybuf,
-                                           int lane, int wave, float t, bool autonomous, bool reg_z, bool reg_j, bool exact,
+                                           int lane, int wave, float t, bool autonomous, bool reg_z, bool reg_j, bool exact, bool jvp,
                                            int D, int K, const float* __restrict__ eps_col, const float (&zs)[ZR], float (&zd)[ZR],
                                            float& ld, float& ed, float& nd) {
     constexpr int NT = 2;
@@ -129,6 +130,53 @@ __device__ __forceinline__ void coopx_eval(const float* __restrict__ P, f32x4* x
                 ebuf[(kg * NT + wave) * 64 + lane] = v;
             }
         }
+        if (jvp) {
+            // Hutchinson JVP (LuxJacVecMatrixMode, src/core/icnf.jl:561-603, utils.jl:161-170): the tangent eps_p pushed through
+            // the FORWARD images - tau_1 = act'_1 .* (W_1[:,0:D] eps), tau_{l+1} = act'_{l+1} .* (W_{l+1} tau_l), J eps = W_N tau_L;
+            // ldot = -<eps, J eps> / K (the scalar the VJP form gives), ndot = |J eps|_2 / K.  The forward hidden-layer images
+            // carry the tanh pre-scale: undone per product.
+            constexpr float inv_fs = ACT == CNF_ACT_TANH_PRESCALED ? 1.f / kTanhPrescale : 1.f;
+            coop_load_a<MTW>(AIMG(LAY.f1z), mt0, DT, 0, afr);
+            __syncthreads();
+#pragma unroll
+            for (int m = 0; m < MTW; ++m)
+#pragma unroll
+                for (int q = 0; q < NT; ++q) acc[m][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+            coop_gemm<MTW, NT, NT>(AIMG(LAY.f1z), mt0, DT, ebuf, 0, lane, afr, acc);
+#pragma unroll
+            for (int l = 0; l < L; ++l) {
+                const int wbuf = (l & 1) ^ hbuf ^ 1;   // alternate, starting opposite to the buffer h_L sits in
+                if (l + 1 < L) coop_load_a<MTW>(AIMG(LAY.fh + l * IMG), mt0, HT, 0, afr);
+                else if (owner) coop_load_a<DT>(AIMG(LAY.fN), 0, HT, 0, afd);
+#pragma unroll
+                for (int m = 0; m < MTW; ++m)
+#pragma unroll
+                    for (int q = 0; q < NT; ++q) xbuf[wbuf * XB + ((mt0 + m) * NT + q) * 64 + lane] = acc[m][q] * d[l][m][q] * inv_fs;
+                __syncthreads();
+                if (l + 1 < L) {
+#pragma unroll
+                    for (int m = 0; m < MTW; ++m)
+#pragma unroll
+                        for (int q = 0; q < NT; ++q) acc[m][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    coop_gemm<MTW, NT, NT>(AIMG(LAY.fh + l * IMG), mt0, HT, xbuf + wbuf * XB, 0, lane, afr, acc);
+                } else if (owner) {
+                    f32x4 gacc[DT][1];   // J eps for this wave's own sample tile
+#pragma unroll
+                    for (int m = 0; m < DT; ++m) gacc[m][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    coop_gemm<DT, 1, NT>(AIMG(LAY.fN), 0, HT, xbuf + wbuf * XB, wave, lane, afd, gacc);
+                    float dot = 0.f, n2 = 0.f;
+#pragma unroll
+                    for (int s = 0; s < ZR; ++s) {
+                        const float gv = gacc[s >> 2][0][s & 3];
+                        dot = fmaf(gv, ep[s], dot);
+                        n2 = fmaf(gv, gv, n2);
+                    }
+                    ld -= scale * group_sum(dot);
+                    if (reg_j) nd += scale * sqrtf(group_sum(n2));   // ndot = |J eps|_2 (icnf.jl:229-245 on the JacVec twin)
+                }
+            }
+            continue;
+        }
         coop_load_a<MTW>(AIMG(LAY.bN), mt0, DT, 0, afr);
         __syncthreads();
         {   // c = W_N^T eps_p
@@ -191,7 +239,7 @@ coopx_solve_kernel(KArgs a) {
     const int lane = threadIdx.x & 63, g = lane >> 4, n = lane & 15;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int D = a.D, S = D + 3, C = a.C;
-    const bool exact = a.exact;
+    const bool exact = a.exact == 1, jvp = a.exact == 2;   // (KArgs::exact = 2: Hutchinson JVP, set for this kernel family only)
     const int K = exact ? 1 : a.K;
     const int Kd = K * D;
     const bool reg_z = a.reg_z, reg_j = a.reg_j, autonomous = a.autonomous;
@@ -254,7 +302,7 @@ coopx_solve_kernel(KArgs a) {
 #pragma unroll
                 for (int s = 0; s < ZR; ++s) zs[s] = fmaf(dt, Pz[0][s], z[s]);
                 coopx_eval<HT, L, ZR, CR, ACT>(a.packed, xbuf, zbuf, ebuf, ybuf, lane, wave, tn + a.T.c[sg] * dt, autonomous, reg_z, reg_j,
-                                                exact, D, K, eps_col, zs, zd, ld, ed, nd);
+                                                exact, jvp, D, K, eps_col, zs, zd, ld, ed, nd);
                 const float bst = a.T.b[sg];
                 lsum = fmaf(bst, ld, lsum); esum = fmaf(bst, ed, esum); nsum = fmaf(bst, nd, nsum);
 #pragma unroll

@@ -203,10 +203,10 @@ MfmaPlan* mfma_plan_create(const cnf_config& c) {
     // 3. cooperative wide-layer kernel (Hutchinson VJP, one probe, no conditions) ...
     if (MfmaPlan* p = make_coop()) return p;
     // 4. ... and its extended form: conditions, several probes, the exact trace as D unit probes (three hidden layers: with two
-    //    the layer-wise path's single Q product is cheaper than D pullbacks).  Hutchinson JVP stays layer-wise.
+    //    the layer-wise path's single Q product is cheaper than D pullbacks), Hutchinson JVP (probes pushed through the forward images).
     if (c.arith != CNF_ARITH_F32 || env_int("CNF_MFMA_COOPX", 1) == 0) return nullptr;
     const bool exact = c.mode == CNF_MODE_EXACT;
-    if (!(c.mode == CNF_MODE_HUTCH_VJP || (exact && L == 3))) return nullptr;
+    if (!(c.mode == CNF_MODE_HUTCH_VJP || c.mode == CNF_MODE_HUTCH_JVP || (exact && L == 3))) return nullptr;
     if (!exact && (c.nprobes < 1 || c.nprobes > 64)) return nullptr;
     int hti = HT, zri = ZR, cri = CR;
     if (!coopx_supported(HT, L, ZR, CR, c.acts[0], &hti, &zri, &cri)) return nullptr;
@@ -220,7 +220,7 @@ MfmaPlan* mfma_plan_create(const cnf_config& c) {
     p->kind = 2; p->arith = 0;
     p->fwd_scale = c.acts[0] == CNF_ACT_TANH ? kTanhPrescale : 1.f;
     snprintf(p->name, sizeof(p->name), "coopx<HT=%d,L=%d,ZR=%d,CR=%d,act=%d,%s>", hti, L, zri, cri, c.acts[0],
-             exact ? "exact (unit probes)" : "vjp");
+             exact ? "exact (unit probes)" : c.mode == CNF_MODE_HUTCH_JVP ? "jvp" : "vjp");
     return p;
 }
 
@@ -437,7 +437,10 @@ hipError_t mfma_solve(MfmaPlan* p, const float* packed_dev, const SolveArgs& s, 
         if (e != hipSuccess) return e;
         a.queue = mp->queue_dev;
     }
-    if (p->kind == 2) return coopx_launch(p->HT, p->L, p->ZR, p->CR, p->ACT, a, mp->num_cus, st);
+    if (p->kind == 2) {
+        if (p->cfg.mode == CNF_MODE_HUTCH_JVP) a.exact = 2;   // this kernel family's code for the JVP form (cnf_coop_x.hip)
+        return coopx_launch(p->HT, p->L, p->ZR, p->CR, p->ACT, a, mp->num_cus, st);
+    }
     if (p->kind == 1) {
         // with checkpoint buffers: the checkpointing form of the cooperative solve (the forward half of cnf_coop_grad.hip)
         if (s.ckpt) return coop_launch_ckpt(p->HT, p->L, p->ZR, p->ACT, a, mp->num_cus, st);

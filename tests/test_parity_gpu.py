@@ -130,6 +130,8 @@ COOPX_CASES = [
     (dict(nvars=12, hidden=[192, 192, 192], nprobes=3, reg_z=True, reg_j=True), 70, 0, 8),  # three Hutchinson probes, wide
     (dict(nvars=20, naug=4, ncond=5, hidden=[160, 160], act=2, nprobes=2, reg_z=True, reg_j=True, reg_aug=True), 45, 1, 6),   # softplus, two layers, augmented, 5 conditions
     (dict(nvars=30, hidden=[256, 224, 256], mode=2, autonomous=True), 33, 0, 4),             # exact trace, D = 30 (30 unit probes), ragged widths, autonomous
+    (dict(nvars=9, ncond=3, hidden=[176, 176, 176], mode=1, reg_z=True, reg_j=True), 60, 1, 6),   # Hutchinson JVP (|J eps|), conditioned, tanh (pre-scaled images undone)
+    (dict(nvars=24, hidden=[144, 144], act=2, mode=1, nprobes=2, reg_j=True), 40, 0, 5),     # Hutchinson JVP, softplus, two probes, two layers
 ]
 CASES = CASES + COOPX_CASES
 
