@@ -1,0 +1,24 @@
+#!/bin/bash
+# Round-end evidence on ONE box: bench lines of every BASELINE configuration (+ the gradient of cfg2 / cfg3 / cfg4) and the
+# rocprofv3 kernel-stats + PMC summaries of the metric kernels, copied where profiles/ keeps them.
+#   bash profiles/collect_all.sh <tag>      (from the repo root, on the GPU box)
+TAG=${1:-r3z}
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/$TAG
+mkdir -p $OUT
+cd $ROOT
+python bench.py > $OUT/${TAG}_bench_default.json 2> $OUT/bench_default.err
+for c in cfg1 cfg3 cfg4 cfg5; do python bench.py --config $c --steps 40 --no-cpu-baseline > $OUT/${TAG}_bench_$c.json 2>/dev/null; done
+for c in cfg2 cfg3 cfg4; do python bench.py --config $c --mode grad --steps 10 --warmup 2 --no-cpu-baseline > $OUT/${TAG}_bench_${c}_grad.json 2>/dev/null; done
+for c in cfg2 cfg2p cfg3 cfg4 cfg5; do
+  bash profiles/collect.sh $TAG $c > $OUT/collect_$c.log 2>&1
+  cp gpurun_out/prof_${TAG}_$c/trace/*/*_kernel_stats.csv $OUT/${TAG}_${c}_kernel_stats.csv 2>/dev/null
+  cp gpurun_out/prof_${TAG}_$c/pmc_summary.txt $OUT/${TAG}_${c}_pmc_summary.txt 2>/dev/null
+  cp gpurun_out/prof_${TAG}_$c/kernel_stats_steady.json $OUT/${TAG}_${c}_kernel_stats_steady.json 2>/dev/null
+done
+python profiles/percall_boundaryA.py > $OUT/${TAG}_percall_boundaryA.json 2>/dev/null
+python profiles/tile_split_timing.py > $OUT/${TAG}_tile_split.json 2>/dev/null
+python profiles/small_batch_latency.py > $OUT/${TAG}_small_batch_latency.json 2>/dev/null
+python profiles/reference_suite_timing.py > $OUT/${TAG}_reference_suite.json 2>/dev/null
+python profiles/coopx_timing.py > $OUT/${TAG}_coopx_timing.json 2>/dev/null
+python profiles/brief.py $OUT/${TAG}_bench_*.json
