@@ -23,6 +23,7 @@ struct CGArgs {
     float* y1;                // [gbar; 0; 0 | z; t; 1]: the input side of Wbar_1, ld_y1 = n_in + 1 rows
     float* xN;                // [eps | kbar]: D rows, ld = D
     int ld_y1;
+    int ldy;                  // leading dimension of every Y_l (>= H + 1; a multiple of 16 keeps the 16-byte stores line-aligned)
     long long B;
     long long ntiles_pad;     // 16-sample tiles of the checkpoint arrays (the forward kernel's: 4 x ceil(B / 64))
     int step, nsteps;
@@ -33,8 +34,8 @@ struct CGArgs {
 };
 
 bool coop_grad_supported(int HT, int L, int ZR, int ACT);
-int coop_grad_scratch_slots(int L);   // [HT x NT tiles] each, per workgroup
-int coop_grad_nt();                   // sample tiles per super-tile the reverse-sweep kernel runs with (4, or 2 by CNF_CG_NT)
+int coop_grad_scratch_slots(int L);   // one chain's tile set ([HT] tiles) each, per workgroup
+int coop_grad_nblocks(long long B, int num_cus);   // workgroups of a launch (each owns `scratch_stride` floats of scratch)
 hipError_t coop_grad_step_launch(int HT, int L, int ZR, int ACT, const CGArgs& a, int num_cus, hipStream_t st);
 // the cooperative forward solve with step / stage checkpoints in tile layout (cnf_coop.hip)
 hipError_t coop_launch_ckpt(int HT, int L, int ZR, int ACT, const KArgs& a, int num_cus, hipStream_t st);

@@ -5,28 +5,40 @@
 //
 // Same mathematics as cnf_grad.hip (discretise-then-optimise; per stage: recompute the chain, first-order pullback, its
 // bottom-up reverse, the top-down pass, the RK adjoint recursion) organised like cnf_coop.hip: a 256-thread workgroup owns a
-// 64-sample super-tile, wave w the output features [w H/4, (w+1) H/4) of every product for all four sample tiles, operands
-// travel between the waves as B images in two LDS exchange buffers, weight fragments stream from the L2-resident packed image.
-// One launch per RK step (all its stages, in reverse); nothing of a stage's activation set ever makes a round trip through
-// HBM as a GEMM operand.  What does not fit the register file between its producer and its consumer (h_l, u_l, dbar_l .* u_l:
-// 64 registers per wave each) waits in a per-workgroup scratch in tile-native layout (one coalesced 1 KB store / load per tile).
+// 16-sample super-tile, wave w the output features [w H/4, (w+1) H/4) of every product, operands travel between the waves as
+// B images in two LDS exchange buffers, weight fragments stream from the L2-resident packed image.  One launch per RK step (all
+// its stages, in reverse); nothing of a stage's activation set ever makes a round trip through HBM as a GEMM operand.
+//
+// TWO CHAINS PER PRODUCT.  The stage's four passes pair up: the bottom-up tangent pass (dbar_{l+1} = W_{l+1} vbar_l) needs only
+// act'_l of the forward recompute and multiplies with the SAME forward images; the top-down pass (hbar_l = W_{l+1}^T sbar_{l+1})
+// multiplies with the same transposed images as the pullback (u_l = W_{l+1}^T delta_{l+1}) and needs, at its level, exactly what
+// the pullback has just produced there (a2_l = dbar_l .* u_l).  So every product carries two chains side by side as two column
+// tiles - [h_l | vbar_l] on the way up, [delta_{l+1} | sbar_{l+1}] on the way down - and a stage is 2 L products instead of
+// 4 L - 2, with half the barriers.  What waits in the per-workgroup scratch (tile-native layout, one coalesced 1 KB store /
+// load per tile) between its producer and its consumer is h_l (l < L) and dbar_l (1 < l < L): 3 stores and 3 loads of a tile
+// set per stage at L = 3 (the four-pass organisation of this kernel's first version: 6 and 13); c = W_N^T eps and q = W_1 eps
+// ride along in the D-sized products ([eps | kbar] and [z | eps] as two-chain operands) instead of being kept.  The kernel is
+// bound by its HBM traffic (first version: 5.6 GB per launch at cfg4 against 0.98 ms of MFMA work, 1.75 ms per launch), and
+// this form moves ~40 % less: cfg4 loss + gradient 127 -> 117 ms.
 //
 // WEIGHT COTANGENTS ARE DEFERRED: with 256 x 256 matrices the cotangent accumulators (2 x 256 KB per workgroup) fit neither
 // registers nor LDS, and a product with the sample index on K wants all samples of a column chunk anyway.  The kernel writes
 // the operands of  Wbar_{l+1} += delta_{l+1} vbar_l^T + sbar_{l+1} [h_l; 1]^T  (and of Wbar_1, Wbar_N) for every stage of the
 // step into column-major arrays laid out so that ONE lg_wgrad launch per weight matrix per step (K = 2 x stages x B columns)
 // accumulates both terms and the bias column (cnf_lgemm.hip; slabs per column chunk, summed in a fixed order at the end).
-// A tile leaves for HBM through the exchange buffer it was published in: the lane that stores rows 4r .. 4r + 3 of a sample
-// reads its four values with conflict-free ds_read_b32 and issues one 16-byte store.
+// A tile leaves for HBM through the exchange buffer it was published in, as FULL 128-BYTE LINES: eight lanes cover 32
+// consecutive rows (two row tiles) of one sample - four conflict-free ds_read_b32 and one 16-byte store per lane (with 64-byte
+// runs, one row tile per sample, the same bytes cost 4 % more of the whole gradient), and the Y arrays' leading dimension is
+// padded to a multiple of 16 floats so that no store straddles a 64-byte block.
 //
-// Scope of this first version: Hutchinson VJP, one probe, no conditions, tanh, no |zdot| / |eps^T J| regularisers (FFJORD;
-// l3 |z_aug| is in), uniform steps, 2 or 3 hidden layers of one width: everything else stays on the layer-wise path.
+// Scope: Hutchinson VJP, one probe, no conditions, tanh, no |zdot| / |eps^T J| regularisers (FFJORD; l3 |z_aug| is in),
+// uniform steps, 2 or 3 hidden layers of one width: everything else stays on the layer-wise path.
 #define CNF_NO_PK_ASM 1
 #define CNF_NO_PHASE_FENCE 1
 #include "cnf_coop_dev.h"
 #include "cnf_coop_grad.h"
 
-// The operand arrays (read next by the weight-cotangent kernels) and the per-workgroup scratch move 5 GB per launch; written and
+// The operand arrays (read next by the weight-cotangent kernels) and the per-workgroup scratch are streams; written and
 // read with the non-temporal hint they stream past the L2 instead of evicting the 1.15 MB operand image every workgroup
 // re-reads for every product (-DCG_TEMPORAL restores plain accesses for an A/B).
 #ifndef CG_TEMPORAL
@@ -42,11 +54,6 @@
 namespace cnf {
 
 namespace {
-
-template <int MTW, int NT>
-struct TS {   // one wave's share of an [H x 64-sample] quantity: MTW x NT accumulator tiles
-    f32x4 t[MTW][NT];
-};
 
 // d = act'(a) from h = tanh(a)  (act''(a) = -2 h d)
 __device__ __forceinline__ f32x4 tanh_d(const f32x4& h) { return 1.f - h * h; }
@@ -74,141 +81,135 @@ __device__ __forceinline__ void coop_gemm_tail(int KG, const f32x4 (&a0)[M], con
     coop_frag_mfma<M, NQ>(a0, b0, acc);
     if (KG >= 2) coop_frag_mfma<M, NQ>(a1, b1, acc);      // (KG == 1: a D-sized product with D <= 16)
 }
-// 16-byte store to a 4-byte-aligned address (odd leading dimensions): one global_store_dwordx4, not four scattered dwords
-typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 
 }  // namespace
 
-// NT: sample tiles per super-tile.  4: one workgroup per CU, one wave per SIMD with up to 512 registers (every tile set of a
-// wave is 64 registers).  2: 32-sample super-tiles, two workgroups per CU, two waves per SIMD with 256 registers each (tile
-// sets of 32): half the reuse of every weight fragment, but a second wave on the SIMD to run while the first waits for its
-// scratch / operand traffic - which is where this kernel, unlike the forward solve, spends its stalls.
-template <int HT, int L, int ZR, int ACT, int NS, int NT = 4>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NT == 4 ? 1 : 2, NT == 4 ? 1 : 2)))
+// NT: sample tiles per super-tile (per chain); a product has CT = 2 NT column tiles
+template <int HT, int L, int ZR, int ACT, int NS, int NT>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 coop_grad_step_kernel(CGArgs a) {
     static_assert(ACT == CNF_ACT_TANH_PRESCALED, "tanh nets only (act' and act'' are rebuilt from h)");
     static_assert(L == 2 || L == 3, "two or three hidden layers");
-    static_assert(NT == 4 || NT == 2, "64- or 32-sample super-tiles");
-    constexpr int SUP = 16 * NT;
+    constexpr int SUP = 16 * NT, CT = 2 * NT;
     constexpr MfmaLayout LAY(HT, L, ZR, 0, true);
-    constexpr int MTW = HT / 4, DT = (ZR + 3) / 4, XB = HT * NT * 64, DB = DT * NT * 64;
+    constexpr int MTW = HT / 4, DT = (ZR + 3) / 4, XB = HT * CT * 64, DB2 = DT * CT * 64, DB1 = DT * NT * 64;
     constexpr int IMG = MfmaLayout::imgA(HT, HT);
+    constexpr bool GS = MTW % 2 == 0;                 // operand stores as full 128-byte lines (two row tiles x 8 samples)
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    f32x4* xbuf = reinterpret_cast<f32x4*>(smem);   // [2][HT][NT][64]: exchange buffers
-    f32x4* zbuf = xbuf + 2 * XB;                     // [DT][NT][64]: stage state
-    f32x4* ebuf = zbuf + DB;                         // eps
-    f32x4* kbuf = ebuf + DB;                         // kbar
+    f32x4* xbuf = reinterpret_cast<f32x4*>(smem);   // [2][HT][CT][64]: exchange buffers (column tile = chain * NT + sample tile)
+    f32x4* zebuf = xbuf + 2 * XB;                    // [DT][CT][64]: [z_stage | eps]
+    f32x4* ekbuf = zebuf + DB2;                      // [DT][CT][64]: [eps | kbar]
+    f32x4* ebuf = ekbuf + DB2;                       // [DT][NT][64]: eps
     const int lane = threadIdx.x & 63, g = lane >> 4, n = lane & 15;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int mt0 = wave * MTW;
     const int D = a.D, H = a.H;
     const long long B = a.B;
     const long long nst = (B + SUP - 1) / SUP;
-    const bool owner = wave < NT;                     // this wave integrates sample tile `wave` of the super-tile
+    const bool owner = wave < NT;
     const float* P = a.packed;
     const __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P), 0, 0x7fffffff, 0x00020000);
     const unsigned lane16 = (unsigned)lane * 16u;
 #define AIMG(X) AImg{rP, (unsigned)(X) * 4u, lane16, nullptr}
-    const float inv_fs = 1.f / kTanhPrescale;        // the forward images carry the tanh pre-scale
+    const float inv_fs = 1.f / kTanhPrescale;
     const int ns = a.T.ns < NS ? a.T.ns : NS;
     const float dt = a.dt, tn = a.tn;
     const long long nsB = (long long)ns * B;
-    using T4 = f32x4[MTW][NT];
+    using T1 = f32x4[MTW][NT];
+    using T2 = f32x4[MTW][CT];
 
-    // own-tile helpers -------------------------------------------------------------------------------------------------
-    auto publish = [&](int buf, const T4& v) {
-#pragma unroll
-        for (int m = 0; m < MTW; ++m)
-#pragma unroll
-            for (int q = 0; q < NT; ++q) xbuf[buf * XB + ((mt0 + m) * NT + q) * 64 + lane] = v[m][q];
-    };
-    // this wave's tiles of exchange buffer `buf` -> rows [16 mt0, 16 (mt0 + MTW)) of a column-major operand array.  Lane
-    // (r = lane >> 4, n) stores rows 16 mt + 4 r .. + 3 of sample n: four conflict-free ds_read_b32 and one 16-byte buffer store
-    // (per-lane byte offset voff[q] precomputed per super-tile - 0xffffffff, i.e. out of range, for padding columns and rows -
-    // and the (column block, row tile) offset wave-uniform: no address arithmetic per tile).
-    auto gstore = [&](int buf, const __amdgpu_buffer_rsrc_t& rs, const unsigned (&voff)[NT], unsigned soff0, unsigned ldb) {
-#ifdef CG_EXP_NO_GSTORE
-        return;
-#endif
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // own ds_writes have landed; the reads below alias them
-        // (float reads of memory written as f32x4: a may_alias type, and a compiler barrier behind the stores - type-based alias
-        // analysis would otherwise let a later publish() into the same tiles move ahead of the reads)
-        typedef float __attribute__((may_alias)) float_a;
-        const float_a* xb = reinterpret_cast<const float_a*>(xbuf + buf * XB);
+    auto publish2 = [&](int buf, const T1& c0, const T1& c1) {
 #pragma unroll
         for (int m = 0; m < MTW; ++m)
 #pragma unroll
             for (int q = 0; q < NT; ++q) {
-                const int base = (((mt0 + m) * NT + q) * 64 + n) * 4 + g;   // + 64 g': lane group g' of the image
-                f32x4 v;
-                v[0] = xb[base]; v[1] = xb[base + 64]; v[2] = xb[base + 128]; v[3] = xb[base + 192];
-                const unsigned so = soff0 + (unsigned)(16 * (mt0 + m)) * 4u;
-                const unsigned vo = (16 * (mt0 + m) + 4 * g < H) ? voff[q] : 0xffffffffu;
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rs, (int)vo, (int)so, CG_NT_AUX);
+                xbuf[buf * XB + ((mt0 + m) * CT + q) * 64 + lane] = c0[m][q];
+                xbuf[buf * XB + ((mt0 + m) * CT + NT + q) * 64 + lane] = c1[m][q];
             }
+    };
+    // this wave's tiles of chain `ch` in exchange buffer `buf` -> rows [16 mt0, 16 (mt0 + MTW)) of a column-major operand array
+    auto gstore = [&](int buf, int ch, const __amdgpu_buffer_rsrc_t& rs, const unsigned (&voff)[NT][2], unsigned soff0) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        typedef float __attribute__((may_alias)) float_a;
+        const float_a* xb = reinterpret_cast<const float_a*>(xbuf + buf * XB);
+        if constexpr (GS) {
+            const int s8 = lane >> 3, mm = (lane >> 2) & 1, gg = lane & 3;
+#pragma unroll
+            for (int m = 0; m < MTW; m += 2)
+#pragma unroll
+                for (int q = 0; q < NT; ++q)
+#pragma unroll
+                    for (int hf = 0; hf < 2; ++hf) {
+                        const int base = (((mt0 + m + mm) * CT + ch * NT + q) * 64 + s8 + 8 * hf) * 4 + gg;
+                        f32x4 v;
+                        v[0] = xb[base]; v[1] = xb[base + 64]; v[2] = xb[base + 128]; v[3] = xb[base + 192];
+                        const unsigned so = soff0 + (unsigned)(16 * (mt0 + m)) * 4u;
+                        const unsigned vo = (16 * (mt0 + m + mm) + 4 * gg < H) ? voff[q][hf] : 0xffffffffu;
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rs, (int)vo, (int)so, CG_NT_AUX);
+                    }
+        } else {
+#pragma unroll
+            for (int m = 0; m < MTW; ++m)
+#pragma unroll
+                for (int q = 0; q < NT; ++q) {
+                    const int base = (((mt0 + m) * CT + ch * NT + q) * 64 + n) * 4 + g;
+                    f32x4 v;
+                    v[0] = xb[base]; v[1] = xb[base + 64]; v[2] = xb[base + 128]; v[3] = xb[base + 192];
+                    const unsigned so = soff0 + (unsigned)(16 * (mt0 + m)) * 4u;
+                    const unsigned vo = (16 * (mt0 + m) + 4 * g < H) ? voff[q][0] : 0xffffffffu;
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rs, (int)vo, (int)so, CG_NT_AUX);
+                }
+        }
         asm volatile("" ::: "memory");
-        (void)ldb;
     };
     float* scr = a.scratch + (long long)blockIdx.x * a.scratch_stride;
-    auto sstore = [&](int slot, const T4& v) {
-#ifdef CG_EXP_NO_SCRATCH
-        return;
-#endif
+    auto sstore = [&](int slot, const T1& v) {
         f32x4* s4 = reinterpret_cast<f32x4*>(scr) + ((slot * 4 + wave) * MTW * NT) * 64 + lane;
 #pragma unroll
         for (int m = 0; m < MTW; ++m)
 #pragma unroll
             for (int q = 0; q < NT; ++q) CG_NT_STORE(v[m][q], &s4[(m * NT + q) * 64]);
     };
-    auto sload = [&](int slot, T4& v) {
-#ifdef CG_EXP_NO_SCRATCH
-        for (int m = 0; m < MTW; ++m) for (int q = 0; q < NT; ++q) v[m][q] = f32x4{0.5f, 0.25f, 0.125f, 0.0625f};
-        return;
-#endif
+    auto sload = [&](int slot, T1& v) {
         const f32x4* s4 = reinterpret_cast<const f32x4*>(scr) + ((slot * 4 + wave) * MTW * NT) * 64 + lane;
 #pragma unroll
         for (int m = 0; m < MTW; ++m)
 #pragma unroll
             for (int q = 0; q < NT; ++q) v[m][q] = CG_NT_LOAD(&s4[(m * NT + q) * 64]);
     };
-    auto zero = [&](T4& v) {
+    auto zero2 = [&](T2& v) {
 #pragma unroll
         for (int m = 0; m < MTW; ++m)
 #pragma unroll
-            for (int q = 0; q < NT; ++q) v[m][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int q = 0; q < CT; ++q) v[m][q] = f32x4{0.f, 0.f, 0.f, 0.f};
     };
-    // A product in two halves: its first weight fragments are requested BEFORE the elementwise / store / barrier phase that
-    // precedes it (an L2 round trip with nothing to hide behind otherwise), the k-loop runs after the barrier
     auto pre_a = [&](int img, int KG, f32x4 (&afr)[MTW]) { coop_load_a<MTW>(AIMG(img), mt0, KG, 0, afr); };
-    auto run = [&](int img, int KG, const f32x4* bimg, f32x4 (&afr)[MTW], T4& acc) {
-        coop_gemm<MTW, NT, NT>(AIMG(img), mt0, KG, bimg, 0, lane, afr, acc);
+    auto run2 = [&](int img, int KG, const f32x4* bimg, f32x4 (&afr)[MTW], T2& acc) {
+        coop_gemm<MTW, CT, CT>(AIMG(img), mt0, KG, bimg, 0, lane, afr, acc);
     };
-    f32x4 fa1[MTW], fb0[NT], fb1[NT];     // the split k-loop's second fragment set
-    auto head = [&](int img, int KG, const f32x4* bimg, f32x4 (&afr)[MTW], T4& acc) {
-        coop_gemm_head<MTW, NT, NT>(AIMG(img), mt0, KG, bimg, lane, afr, fa1, fb0, fb1, acc);
+    f32x4 fa1[MTW], fb0[CT], fb1[CT];
+    auto head2 = [&](int img, int KG, const f32x4* bimg, f32x4 (&afr)[MTW], T2& acc) {
+        coop_gemm_head<MTW, CT, CT>(AIMG(img), mt0, KG, bimg, lane, afr, fa1, fb0, fb1, acc);
     };
-    auto tail = [&](int KG, f32x4 (&afr)[MTW], T4& acc) { coop_gemm_tail<MTW, NT>(KG, afr, fa1, fb0, fb1, acc); };
-    // dense D-row registers of this wave's sample tile -> B image
-    auto publish_dense = [&](f32x4* img, const float (&v)[ZR]) {
+    auto tail2 = [&](int KG, f32x4 (&afr)[MTW], T2& acc) { coop_gemm_tail<MTW, CT>(KG, afr, fa1, fb0, fb1, acc); };
+    // dense D-row registers of this wave's sample tile -> column tile `ct` of a B image with `nct` column tiles per k-group
+    auto publish_dense = [&](f32x4* img, int nct, int ct, const float (&v)[ZR]) {
 #pragma unroll
         for (int kg = 0; kg < DT; ++kg) {
             f32x4 o;
 #pragma unroll
             for (int j = 0; j < 4; ++j) o[j] = (4 * kg + j < ZR) ? v[(4 * kg + j) < ZR ? 4 * kg + j : 0] : 0.f;
-            img[(kg * NT + wave) * 64 + lane] = o;
+            img[(kg * nct + ct) * 64 + lane] = o;
         }
     };
-    // dense D-row registers -> rows [0, D) of column `col` of a column-major array
     auto dense_store = [&](float* arr, int ld, long long col, const float (&v)[ZR]) {
 #pragma unroll
         for (int s = 0; s < ZR; ++s) { const int f = 4 * s + g; if (f < D) arr[col * (long long)ld + f] = v[s]; }
     };
 
-    // scratch slots (tile-native): H_l (l = 1 .. L), U_l (l = 2 .. L-1), A2_l (l = 1 .. L-1), Q = W_1[:,0:D] eps, C = W_N^T eps
-    constexpr int SLOT_H = 0, SLOT_U = L, SLOT_A2 = SLOT_U + (L - 2), SLOT_Q = SLOT_A2 + (L - 1), SLOT_C = SLOT_Q + 1;
-    static_assert(SLOT_C + 1 == 3 * L - 1, "coop_grad_scratch_slots");
-    // operand arrays as buffer resources (byte sizes: 2 ns B columns)
-    const unsigned ldx = (unsigned)H * 4u, ldy = (unsigned)(H + 1) * 4u;
+    // scratch slots (tile-native, one chain's tile set each): h_l (l = 1 .. L-1), dbar_l (l = 2 .. L-1)
+    constexpr int SLOT_H = 0, SLOT_DB = L - 1;
+    const unsigned ldx = (unsigned)H * 4u, ldy = (unsigned)a.ldy * 4u;
     __amdgpu_buffer_rsrc_t rx[L], ry[L];
 #pragma unroll
     for (int l = 0; l < L; ++l) {
@@ -218,7 +219,7 @@ coop_grad_step_kernel(CGArgs a) {
 
     for (long long st = blockIdx.x; st < nst; st += gridDim.x) {
         const long long smp0 = st * SUP;
-        const long long smp = smp0 + (owner ? wave : 0) * 16 + n;    // the owner waves' own sample tile
+        const long long smp = smp0 + (owner ? wave : 0) * 16 + n;
         const bool valid = owner && smp < B;
         const long long sc = smp < B ? smp : B - 1;
         const long long tile = st * NT + (owner ? wave : 0), ntp = a.ntiles_pad;
@@ -230,7 +231,6 @@ coop_grad_step_kernel(CGArgs a) {
             zn[s] = a.ckpt[(((long long)a.step * ntp + tile) * 64 + lane) * ZR + s];
         }
         if (a.step == a.nsteps - 1) {
-            // lambda_N = dL/dz_N = z_N (+ l3 z_aug / |z_aug|, src/core/base_icnf.jl:106-122); zero for padding columns
 #pragma unroll
             for (int s = 0; s < ZR; ++s) lam[s] = valid ? a.ckpt[(((long long)a.nsteps * ntp + tile) * 64 + lane) * ZR + s] : 0.f;
             if (a.lam3 != 0.f) {
@@ -246,41 +246,25 @@ coop_grad_step_kernel(CGArgs a) {
 #pragma unroll
             for (int s = 0; s < ZR; ++s) lam[s] = a.lam[(tile * 64 + lane) * ZR + s];
         }
-        // per-lane byte offsets of this lane's columns (sample q * 16 + n of the super-tile, rows 4 g ..) in the X / Y arrays;
-        // validity of those columns as a weight
-        unsigned vox[NT], voy[NT];
+        unsigned vox[NT][2], voy[NT][2];
         float vq[NT];
 #pragma unroll
         for (int q = 0; q < NT; ++q) {
-            const long long sq = smp0 + q * 16 + n;
-            vq[q] = sq < B ? 1.f : 0.f;
-            vox[q] = sq < B ? (unsigned)sq * ldx + 16u * (unsigned)g : 0xffffffffu;
-            voy[q] = sq < B ? (unsigned)sq * ldy + 16u * (unsigned)g : 0xffffffffu;
+            vq[q] = smp0 + q * 16 + n < B ? 1.f : 0.f;
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                const long long sq = GS ? smp0 + q * 16 + (lane >> 3) + 8 * hf : smp0 + q * 16 + n;
+                const unsigned ro = GS ? 16u * (unsigned)(lane & 3) + 64u * (unsigned)((lane >> 2) & 1) : 16u * (unsigned)g;
+                vox[q][hf] = sq < B ? (unsigned)sq * ldx + ro : 0xffffffffu;
+                voy[q][hf] = sq < B ? (unsigned)sq * ldy + ro : 0xffffffffu;
+            }
         }
         __syncthreads();                 // the previous super-tile's readers of the LDS images are done
-        if (owner) publish_dense(ebuf, eps);
-        __syncthreads();
-        {   // solve-invariant products of the super-tile: q = W_1[:,0:D] eps (un-scaled), c = W_N^T eps
-            f32x4 afr[MTW];
-            T4 t;
-            zero(t);
-            pre_a(LAY.f1z, DT, afr);
-            run(LAY.f1z, DT, ebuf, afr, t);
-#pragma unroll
-            for (int m = 0; m < MTW; ++m)
-#pragma unroll
-                for (int q = 0; q < NT; ++q) t[m][q] *= inv_fs;
-            sstore(SLOT_Q, t);
-            zero(t);
-            pre_a(LAY.bN, DT, afr);
-            run(LAY.bN, DT, ebuf, afr, t);
-            sstore(SLOT_C, t);
-        }
-        float* zbt = a.zb + (tile * 64 + lane) * (long long)(NS * ZR);   // Zbar_j of this step's stages, this lane
+        if (owner) publish_dense(ebuf, NT, wave, eps);
+        float* zbt = a.zb + (tile * 64 + lane) * (long long)(NS * ZR);
 
 #pragma clang loop unroll(disable)
         for (int i = ns - 1; i >= 0; --i) {
-            // ---- this wave's sample tile: stage state, cotangent of the stage derivative ----
             float zs[ZR], kbar[ZR];
             const float bi = a.T.b[i];
             {
@@ -301,13 +285,15 @@ coop_grad_step_kernel(CGArgs a) {
 #pragma unroll
                 for (int s = 0; s < ZR; ++s) { zs[s] = fmaf(dt, acc[s], zn[s]); kbar[s] = valid ? dt * kb[s] : 0.f; }
             }
-            const float cl = dt * bi;                                 // cotangent of ldot (dL/d dlogp = +1 per column)
+            const float cl = dt * bi;
             const float tt = tn + a.T.c[i] * dt;
-            const long long c1 = (long long)i * B, c2 = nsB + (long long)i * B;   // first / second half of the operand arrays
+            const long long c1 = (long long)i * B, c2 = nsB + (long long)i * B;
             const unsigned sx1 = (unsigned)c1 * ldx, sx2 = (unsigned)c2 * ldx, sy1 = (unsigned)c1 * ldy, sy2 = (unsigned)c2 * ldy;
-            if (owner) { publish_dense(zbuf, zs); publish_dense(kbuf, kbar); }
+            if (owner) {
+                publish_dense(zebuf, CT, wave, zs); publish_dense(zebuf, CT, NT + wave, eps);
+                publish_dense(ekbuf, CT, wave, eps); publish_dense(ekbuf, CT, NT + wave, kbar);
+            }
             if (valid) {
-                // Wbar_1 operands: [gbar; 0; 0] with gbar = -c_l eps, and [z; t; 1];  Wbar_N operands: eps, kbar
                 float gb[ZR];
 #pragma unroll
                 for (int s = 0; s < ZR; ++s) gb[s] = -cl * eps[s];
@@ -322,8 +308,8 @@ coop_grad_step_kernel(CGArgs a) {
                 dense_store(a.xN, D, c2 + smp, kbar);
             }
             f32x4 afr[MTW];
-            T4 acc;
-            // ================= (1) recompute the chain (forward images carry the pre-scale) =================
+            T2 acc;
+            // ================= up: [a_{l+1} | dbar_{l+1}] = W_{l+1} [h_l | vbar_l]  (forward images carry the pre-scale) =================
             {
                 f32x4 bias[MTW], wt[MTW];
                 pre_a(LAY.f1z, DT, afr);
@@ -333,187 +319,103 @@ coop_grad_step_kernel(CGArgs a) {
                 for (int m = 0; m < MTW; ++m) {
                     const f32x4 b0 = a.autonomous ? bias[m] : tile_fma(wt[m], tt, bias[m]);
 #pragma unroll
-                    for (int q = 0; q < NT; ++q) acc[m][q] = b0;
+                    for (int q = 0; q < NT; ++q) { acc[m][q] = b0; acc[m][NT + q] = f32x4{0.f, 0.f, 0.f, 0.f}; }
                 }
                 __syncthreads();
-                run(LAY.f1z, DT, zbuf, afr, acc);
+                run2(LAY.f1z, DT, zebuf, afr, acc);                          // [a_1 | q], q = W_1[:,0:D] eps
             }
             int cur = 0;
-            T4 cvL;
 #pragma unroll
             for (int l = 0; l < L; ++l) {      // layer l + 1
-                T4 h;
+                T1 h, vb, db;
                 if (l + 1 < L) pre_a(LAY.fh + l * IMG, HT, afr);
-                else pre_a(LAY.bh + (L - 2) * IMG, HT, afr);                 // first pullback product
+                else pre_a(LAY.bN, DT, afr);
 #pragma unroll
                 for (int m = 0; m < MTW; ++m)
 #pragma unroll
-                    for (int q = 0; q < NT; ++q) { f32x4 dd; act_tile<ACT>(acc[m][q], h[m][q], dd); }
-                publish(cur, h);
-                sstore(SLOT_H + l, h);
-                gstore(cur, ry[l], voy, sy2, ldy);                            // [h_{l+1}; 1] half of Y_{l+1}
+                    for (int q = 0; q < NT; ++q) {
+                        f32x4 dd;
+                        act_tile<ACT>(acc[m][q], h[m][q], dd);
+                        // dbar_1 = W_1[:,0:D] gbar = -c_l q (zero for padding columns); dbar_{l+1} = W_{l+1} vbar_l
+                        db[m][q] = acc[m][NT + q] * (l == 0 ? inv_fs * (-cl * vq[q]) : inv_fs);
+                        vb[m][q] = db[m][q] * tanh_d(h[m][q]);             // vbar_{l+1} (cbar at the top)
+                    }
+                publish2(cur, h, vb);
+                if (l + 1 < L) {
+                    sstore(SLOT_H + l, h);
+                    if (l > 0) sstore(SLOT_DB + l - 1, db);
+                }
+                gstore(cur, 0, ry[l], voy, sy2);                              // [h_{l+1}; 1] half of Y_{l+1}
+                gstore(cur, 1, ry[l], voy, sy1);                              // [vbar_{l+1}; 0] half
                 if (l + 1 < L) {
                     f32x4 bnx[MTW];
                     gload_cvec<MTW>(P + LAY.v_bh + l * MfmaLayout::vecC(HT), mt0, g, bnx);
 #pragma unroll
                     for (int m = 0; m < MTW; ++m)
 #pragma unroll
-                        for (int q = 0; q < NT; ++q) acc[m][q] = bnx[m];
+                        for (int q = 0; q < NT; ++q) { acc[m][q] = bnx[m]; acc[m][NT + q] = f32x4{0.f, 0.f, 0.f, 0.f}; }
                     __syncthreads();
-                    if (l + 2 == L) {   // the last forward product: c (for delta_L) is requested under its final k-groups
-                        head(LAY.fh + l * IMG, HT, xbuf + cur * XB, afr, acc);
-                        sload(SLOT_C, cvL);
-                        tail(HT, afr, acc);
-                    } else {
-                        run(LAY.fh + l * IMG, HT, xbuf + cur * XB, afr, acc);
-                    }
+                    run2(LAY.fh + l * IMG, HT, xbuf + cur * XB, afr, acc);
                     cur ^= 1;
                 } else {
-                    // ===== (2) pullback starts here: delta_L = c .* act'_L while h_L is in registers =====
-                    T4 dl;
-                    T4& cv = cvL;
-#pragma unroll
-                    for (int m = 0; m < MTW; ++m)
-#pragma unroll
-                        for (int q = 0; q < NT; ++q) dl[m][q] = cv[m][q] * tanh_d(h[m][q]);
-                    // delta_L goes into the buffer the layer-L product has just read: slower waves may still be inside that
-                    // product (reading every wave's tiles), so this publish needs its own barrier in front
-                    __syncthreads();
-                    cur ^= 1;
-                    publish(cur, dl);
-                    gstore(cur, rx[L - 1], vox, sx1, ldx);                    // delta_L half of X_L
-                    __syncthreads();
-                }
-            }
-#pragma unroll
-            for (int l = L - 1; l >= 1; --l) {   // u_l = W_{l+1}^T delta_{l+1}; delta_l = u_l .* act'_l
-                T4 u, hl, qv;
-                zero(u);
-                head(LAY.bh + (l - 1) * IMG, HT, xbuf + cur * XB, afr, u);
-                sload(SLOT_H + l - 1, hl);
-                if (l == 1) sload(SLOT_Q, qv);
-                tail(HT, afr, u);
-                if (l > 1) pre_a(LAY.bh + (l - 2) * IMG, HT, afr);
-                else pre_a(LAY.fh + 0 * IMG, HT, afr);                       // first bottom-up product
-                cur ^= 1;
-                if (l > 1) {
-                    T4 dl;
-                    sstore(SLOT_U + l - 2, u);
-#pragma unroll
-                    for (int m = 0; m < MTW; ++m)
-#pragma unroll
-                        for (int q = 0; q < NT; ++q) dl[m][q] = u[m][q] * tanh_d(hl[m][q]);
-                    publish(cur, dl);
-                    gstore(cur, rx[l - 1], vox, sx1, ldx);                    // delta_l half of X_l
-                    __syncthreads();
-                } else {
-                    // delta_1, and at once the bottom of the reverse pass: dbar_1 = W_1[:,0:D] gbar = -c_l q,
-                    // a2_1 = dbar_1 .* u_1, vbar_1 = dbar_1 .* act'_1
-                    T4 t;
-#pragma unroll
-                    for (int m = 0; m < MTW; ++m)
-#pragma unroll
-                        for (int q = 0; q < NT; ++q) t[m][q] = u[m][q] * tanh_d(hl[m][q]);
-                    publish(cur, t);
-                    gstore(cur, rx[0], vox, sx1, ldx);                        // delta_1 half of X_1
+                    // ===== the top: [c | hbar_L] = W_N^T [eps | kbar]; delta_L = c .* act'_L, a2_L = dbar_L .* c,
+                    //       sbar_L = hbar_L .* act'_L + a2_L .* act''_L - all while h_L and dbar_L are in registers =====
+                    T2 t;
+                    zero2(t);
+                    run2(LAY.bN, DT, ekbuf, afr, t);
+                    pre_a(LAY.bh + (L - 2) * IMG, HT, afr);
+                    T1 dl, sb;
 #pragma unroll
                     for (int m = 0; m < MTW; ++m)
 #pragma unroll
                         for (int q = 0; q < NT; ++q) {
-                            const f32x4 d1 = qv[m][q] * (-cl * vq[q]);
-                            t[m][q] = d1 * u[m][q];
-                            qv[m][q] = d1 * tanh_d(hl[m][q]);
+                            const f32x4 d = tanh_d(h[m][q]), c = t[m][q];
+                            dl[m][q] = c * d;
+                            sb[m][q] = t[m][NT + q] * d + (db[m][q] * c) * (h[m][q] * d * -2.f);
                         }
-                    sstore(SLOT_A2 + 0, t);
-                    publish(cur, qv);     // own tiles of delta_1 have been stored by this wave: overwrite them with vbar_1
-                    gstore(cur, ry[0], voy, sy1, ldy);                        // [vbar_1; 0] half of Y_1
+                    // own tiles of the Y_L pair have been stored by this wave (gstore waits for its LDS reads): overwrite them
+                    publish2(cur, dl, sb);
+                    gstore(cur, 0, rx[L - 1], vox, sx1);                      // delta_L half of X_L
+                    gstore(cur, 1, rx[L - 1], vox, sx2);                      // sbar_L half
                     __syncthreads();
                 }
             }
-            // ================= (3) bottom-up: dbar_{l+1} = W_{l+1} vbar_l, vbar_l = dbar_l .* act'_l =================
-            T4 a2L;    // a2_L = dbar_L .* c
-#pragma unroll
-            for (int l = 1; l < L; ++l) {
-                T4 db, hl, x2;
-                zero(db);
-                head(LAY.fh + (l - 1) * IMG, HT, xbuf + cur * XB, afr, db);
-                sload(SLOT_H + l, hl);                                        // h_{l+1}
-                if (l + 1 < L) sload(SLOT_U + l - 1, x2);                     // u_{l+1}
-                else sload(SLOT_C, x2);                                       // u_L = c
-                tail(HT, afr, db);
-                if (l + 1 < L) pre_a(LAY.fh + l * IMG, HT, afr);
-                else pre_a(LAY.bN, DT, afr);                                  // hbar_L = W_N^T kbar
-                cur ^= 1;
-                if (l + 1 < L) {
-                    T4 vb;
-#pragma unroll
-                    for (int m = 0; m < MTW; ++m)
-#pragma unroll
-                        for (int q = 0; q < NT; ++q) {
-                            const f32x4 dd = db[m][q] * inv_fs;
-                            x2[m][q] = dd * x2[m][q];
-                            vb[m][q] = dd * tanh_d(hl[m][q]);
-                        }
-                    sstore(SLOT_A2 + l, x2);
-                    publish(cur, vb);
-                    gstore(cur, ry[l], voy, sy1, ldy);                        // [vbar_{l+1}; 0] half of Y_{l+1}
-                    __syncthreads();
-                } else {
-                    T4 cb;   // cbar = dbar_L .* act'_L: Wbar_N += eps cbar^T
-#pragma unroll
-                    for (int m = 0; m < MTW; ++m)
-#pragma unroll
-                        for (int q = 0; q < NT; ++q) {
-                            const f32x4 dd = db[m][q] * inv_fs;
-                            a2L[m][q] = dd * x2[m][q];
-                            cb[m][q] = dd * tanh_d(hl[m][q]);
-                        }
-                    publish(cur, cb);
-                    gstore(cur, ry[L - 1], voy, sy1, ldy);                    // [cbar; 0] half of Y_L
-                    __syncthreads();   // every wave has left the last bottom-up product: its operand buffer is free
-                }
-            }
-            // ================= (4) top-down: sbar_l = hbar_l .* act'_l + a2_l .* act''_l, hbar_{l-1} = W_l^T sbar_l =================
-            {
-                T4 hb, hl, sb;
-                zero(hb);
-                head(LAY.bN, DT, kbuf, afr, hb);
-                sload(SLOT_H + L - 1, hl);
-                tail(DT, afr, hb);
-                pre_a(LAY.bh + (L - 2) * IMG, HT, afr);
-#pragma unroll
-                for (int m = 0; m < MTW; ++m)
-#pragma unroll
-                    for (int q = 0; q < NT; ++q) {
-                        const f32x4 d = tanh_d(hl[m][q]);
-                        sb[m][q] = hb[m][q] * d + a2L[m][q] * (hl[m][q] * d * -2.f);
-                    }
-                cur ^= 1;
-                publish(cur, sb);
-                gstore(cur, rx[L - 1], vox, sx2, ldx);                        // sbar_L half of X_L
-                __syncthreads();
-            }
+            // ================= down: [u_l | hbar_l] = W_{l+1}^T [delta_{l+1} | sbar_{l+1}] =================
             f32x4 afd[DT];
 #pragma unroll
-            for (int l = L - 1; l >= 1; --l) {   // hbar_l = W_{l+1}^T sbar_{l+1}
-                T4 hb, hl, a2, sb;
-                zero(hb);
-                head(LAY.bh + (l - 1) * IMG, HT, xbuf + cur * XB, afr, hb);
+            for (int l = L - 1; l >= 1; --l) {
+                T2 t;
+                T1 hl, dbl, dl, sb;
+                zero2(t);
+                if (l == 1) {
+                    // dbar_1 = -c_l q again: q = W_1[:,0:D] eps is a D-sized product, cheaper than a scratch round trip
+                    f32x4 afq[MTW];
+                    coop_load_a<MTW>(AIMG(LAY.f1z), mt0, DT, 0, afq);
+#pragma unroll
+                    for (int m = 0; m < MTW; ++m)
+#pragma unroll
+                        for (int q = 0; q < NT; ++q) dbl[m][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    coop_gemm<MTW, NT, NT>(AIMG(LAY.f1z), mt0, DT, ebuf, 0, lane, afq, dbl);
+                }
+                head2(LAY.bh + (l - 1) * IMG, HT, xbuf + cur * XB, afr, t);
                 sload(SLOT_H + l - 1, hl);
-                sload(SLOT_A2 + l - 1, a2);
-                tail(HT, afr, hb);
+                if (l > 1) sload(SLOT_DB + l - 2, dbl);
+                tail2(HT, afr, t);
                 if (l > 1) pre_a(LAY.bh + (l - 2) * IMG, HT, afr);
                 else if (owner) coop_load_a<DT>(AIMG(LAY.b1), 0, HT, 0, afd);
+                cur ^= 1;
 #pragma unroll
                 for (int m = 0; m < MTW; ++m)
 #pragma unroll
                     for (int q = 0; q < NT; ++q) {
-                        const f32x4 d = tanh_d(hl[m][q]);
-                        sb[m][q] = hb[m][q] * d + a2[m][q] * (hl[m][q] * d * -2.f);
+                        const f32x4 d = tanh_d(hl[m][q]), u = t[m][q];
+                        const f32x4 dbv = l == 1 ? dbl[m][q] * (inv_fs * (-cl * vq[q])) : dbl[m][q];
+                        dl[m][q] = u * d;
+                        sb[m][q] = t[m][NT + q] * d + (dbv * u) * (hl[m][q] * d * -2.f);
                     }
-                cur ^= 1;
-                publish(cur, sb);
-                gstore(cur, rx[l - 1], vox, sx2, ldx);                        // sbar_l half of X_l
+                publish2(cur, dl, sb);
+                gstore(cur, 0, rx[l - 1], vox, sx1);                          // delta_l half of X_l
+                gstore(cur, 1, rx[l - 1], vox, sx2);                          // sbar_l half
                 __syncthreads();
             }
             // Zbar_i = W_1[:,0:D]^T sbar_1 for this wave's own sample tile
@@ -521,13 +423,12 @@ coop_grad_step_kernel(CGArgs a) {
                 f32x4 zacc[DT][1];
 #pragma unroll
                 for (int m = 0; m < DT; ++m) zacc[m][0] = f32x4{0.f, 0.f, 0.f, 0.f};
-                coop_gemm<DT, 1, NT>(AIMG(LAY.b1), 0, HT, xbuf + cur * XB, wave, lane, afd, zacc);
+                coop_gemm<DT, 1, CT>(AIMG(LAY.b1), 0, HT, xbuf + cur * XB, NT + wave, lane, afd, zacc);
 #pragma unroll
                 for (int s = 0; s < ZR; ++s) zbt[i * ZR + s] = zacc[s >> 2][0][s & 3];
             }
-            __syncthreads();   // the next stage republishes zbuf / kbuf and reuses the exchange buffers
+            __syncthreads();
         }
-        // lambda_n = lambda_{n+1} + sum_i Zbar_i
         if (owner) {
 #pragma unroll
             for (int s = 0; s < ZR; ++s) {
@@ -537,7 +438,7 @@ coop_grad_step_kernel(CGArgs a) {
                 a.lam[(tile * 64 + lane) * ZR + s] = acc;
             }
         }
-        if (a.step == 0 && a.grad_x && valid) {   // costate at t0 = dL/dz_0; its first nvars rows are dL/dx
+        if (a.step == 0 && a.grad_x && valid) {
 #pragma unroll
             for (int s = 0; s < ZR; ++s) {
                 const int f = 4 * s + g;
@@ -553,11 +454,11 @@ coop_grad_step_kernel(CGArgs a) {
 // ---------------------------------------------------------------------------------------
 template <int HT, int L, int ZR, int ACT, int NS, int NT>
 static hipError_t launch_grad_step(const CGArgs& a, int num_cus, hipStream_t st) {
-    constexpr int DT = (ZR + 3) / 4;
-    constexpr int lds = (2 * HT * NT * 64 + 3 * DT * NT * 64) * 16;
-    static_assert(lds * (NT == 4 ? 1 : 2) <= 160 * 1024, "exchange buffers exceed LDS");
+    constexpr int DT = (ZR + 3) / 4, CT = 2 * NT;
+    constexpr int lds = (2 * HT * CT * 64 + (2 * DT * CT + DT * NT) * 64) * 16;
+    static_assert(lds * 2 <= 160 * 1024, "exchange buffers exceed LDS");
     const long long nst = (a.B + 16 * NT - 1) / (16 * NT);
-    const long long cap = (long long)num_cus * (NT == 4 ? 1 : 2);
+    const long long cap = (long long)num_cus * 2;
     const int nblocks = (int)(nst < cap ? nst : cap);
     auto kern = coop_grad_step_kernel<HT, L, ZR, ACT, NS, NT>;
     static DeviceOnce once;
@@ -573,16 +474,13 @@ static hipError_t launch_grad_step(const CGArgs& a, int num_cus, hipStream_t st)
     return hipGetLastError();
 }
 
-int coop_grad_nt();
 struct CoopGradInst {
     int HT, L, ZR, ACT;
-    hipError_t (*fn[4])(const CGArgs&, int, hipStream_t);   // [0] RK4 (4 stages), [1] Tsit5 (6 stages); [2], [3]: the same with NT = 2
+    hipError_t (*fn[2])(const CGArgs&, int, hipStream_t);   // [0] RK4 (4 stages), [1] Tsit5 (6 stages)
 };
 #define CG_INST(HT, L, ZR) \
-    CoopGradInst { HT, L, ZR, CNF_ACT_TANH_PRESCALED, { &launch_grad_step<HT, L, ZR, CNF_ACT_TANH_PRESCALED, 4, 4>, \
-                                                        &launch_grad_step<HT, L, ZR, CNF_ACT_TANH_PRESCALED, 6, 4>, \
-                                                        &launch_grad_step<HT, L, ZR, CNF_ACT_TANH_PRESCALED, 4, 2>, \
-                                                        &launch_grad_step<HT, L, ZR, CNF_ACT_TANH_PRESCALED, 6, 2> } }
+    CoopGradInst { HT, L, ZR, CNF_ACT_TANH_PRESCALED, { &launch_grad_step<HT, L, ZR, CNF_ACT_TANH_PRESCALED, 4, 1>, \
+                                                        &launch_grad_step<HT, L, ZR, CNF_ACT_TANH_PRESCALED, 6, 1> } }
 // the same (HT, L, ZR) as the forward instances of cnf_coop.hip they pair with (the plan's packed image is shared)
 static const CoopGradInst kCoopGrad[] = {
     CG_INST(16, 3, 8),   // cfg4: D = 32, 3 x 256
@@ -597,18 +495,17 @@ static const CoopGradInst* cg_find(int HT, int L, int ZR, int ACT) {
 }
 
 bool coop_grad_supported(int HT, int L, int ZR, int ACT) { return cg_find(HT, L, ZR, ACT) != nullptr; }
-// sample tiles per super-tile of the reverse-sweep kernel: 2 (two workgroups per CU, two waves per SIMD: cfg4 loss + gradient
-// 143 ms) unless CNF_CG_NT=4 asks for the one-wave-per-SIMD form (153 ms)
-int coop_grad_nt() {
-    static const int nt = [] { const char* e = getenv("CNF_CG_NT"); const int v = (e && *e) ? atoi(e) : 2; return v == 4 ? 4 : 2; }();
-    return nt;
+int coop_grad_scratch_slots(int L) { return 2 * L - 3; }   // h_1 .. h_{L-1}, dbar_2 .. dbar_{L-1}
+// workgroups of a launch (16-sample super-tiles, two workgroups per CU): the host sizes the per-workgroup scratch with it
+int coop_grad_nblocks(long long B, int num_cus) {
+    const long long nst = (B + 15) / 16, cap = (long long)num_cus * 2;
+    return (int)(nst < cap ? nst : cap);
 }
-int coop_grad_scratch_slots(int L) { return 3 * L - 1; }   // H_1..H_L, U_2..U_{L-1}, A2_1..A2_{L-1}, Q, C
 
 hipError_t coop_grad_step_launch(int HT, int L, int ZR, int ACT, const CGArgs& a, int num_cus, hipStream_t st) {
     const CoopGradInst* c = cg_find(HT, L, ZR, ACT);
     if (!c) return hipErrorNotSupported;
-    return c->fn[(a.T.ns <= 4 ? 0 : 1) + (coop_grad_nt() == 2 ? 2 : 0)](a, num_cus, st);
+    return c->fn[a.T.ns <= 4 ? 0 : 1](a, num_cus, st);
 }
 
 }  // namespace cnf

@@ -1006,19 +1006,20 @@ hipError_t coop_grad(LayeredGrad** ctx, const cnf_config& c, MfmaPlan* plan, con
     long long kc = 0;
     const int nslab = lg_wgrad_chunks(H, B2, G.num_cus, &kc, 4);
     const long long nst = (B + 63) / 64, ntp = nst * 4;
-    const int cgnt = coop_grad_nt();
-    const long long nst_g = (B + 16 * cgnt - 1) / (16 * cgnt), cap_g = (long long)G.num_cus * (cgnt == 4 ? 1 : 2);
-    const int nblocks = (int)(nst_g < cap_g ? nst_g : cap_g);
+    const int nblocks = coop_grad_nblocks(B, G.num_cus);
     const int slots = coop_grad_scratch_slots(Lh);
-    const long long scratch_stride = (long long)slots * HT * 1024;   // slots x (HT x 4 sample tiles x 64 lanes x 4) floats
+    const long long scratch_stride = (long long)(slots > 0 ? slots : 1) * HT * 256;   // slots x (HT tiles x 64 lanes x 4) floats
 
     long long off = 0;
     auto take = [&](long long n) { const long long o = off; off += (n + 63) / 64 * 64; return o; };
     const long long o_slab = take(npa_pad * nslab);
     const long long o_zck = take((long long)(nsteps + 1) * ntp * 64 * ZR), o_kck = take((long long)nsteps * ns * ntp * 64 * ZR);
     const long long o_lam = take(ntp * 64 * ZR), o_zb = take(ntp * 64 * 6 * ZR), o_scr = take(scratch_stride * nblocks);
+    // Y_l: H + 1 rows; a leading dimension that is a multiple of 16 floats keeps every 16-byte operand store inside one
+    // 64-byte block (H + 1 itself puts 15 of 16 samples' row quads across two)
+    const int ldy = (H + 1 + 15) / 16 * 16;
     long long o_xh[3], o_yh[3];
-    for (int l = 0; l < Lh; ++l) { o_xh[l] = take((long long)H * B2); o_yh[l] = take((long long)(H + 1) * B2); }
+    for (int l = 0; l < Lh; ++l) { o_xh[l] = take((long long)H * B2); o_yh[l] = take((long long)ldy * B2); }
     const long long o_y1 = take((long long)(n_in + 1) * B2), o_xN = take((long long)D * B2);
     if ((size_t)off > G.ws_floats) {
         if (G.ws) LG_HIP(hipFree(G.ws));
@@ -1032,8 +1033,8 @@ hipError_t coop_grad(LayeredGrad** ctx, const cnf_config& c, MfmaPlan* plan, con
     // constant rows of the operand arrays: the zero / ones row of every Y_l, the zero rows under gbar
     LG_HIP(hipMemsetAsync(W + o_y1, 0, (size_t)(n_in + 1) * B2 * sizeof(float), st));
     for (int l = 0; l < Lh; ++l) {
-        hipLaunchKernelGGL(fill_rows_kernel, grid_for((long long)ns * B), dim3(TPB), 0, st, W + o_yh[l], H + 1, H, H + 1, 0LL, (long long)ns * B, 0.f);
-        hipLaunchKernelGGL(fill_rows_kernel, grid_for((long long)ns * B), dim3(TPB), 0, st, W + o_yh[l], H + 1, H, H + 1, (long long)ns * B, B2, 1.f);
+        hipLaunchKernelGGL(fill_rows_kernel, grid_for((long long)ns * B), dim3(TPB), 0, st, W + o_yh[l], ldy, H, H + 1, 0LL, (long long)ns * B, 0.f);
+        hipLaunchKernelGGL(fill_rows_kernel, grid_for((long long)ns * B), dim3(TPB), 0, st, W + o_yh[l], ldy, H, H + 1, (long long)ns * B, B2, 1.f);
     }
 
     // ---- forward: the cooperative solve, checkpointing z_n and the stage derivatives; it also delivers the loss terms ----
@@ -1044,11 +1045,13 @@ hipError_t coop_grad(LayeredGrad** ctx, const cnf_config& c, MfmaPlan* plan, con
     LG_HIP(mfma_solve(plan, packed_dev, sa, st));
 
     // ---- reverse: one launch per step, then the step's weight-cotangent products ----
+    // (The products of step n on a second stream under the sweep of step n - 1, operand arrays double-buffered, was measured:
+    // cfg4 117 -> 131 ms.  Both kernels are bound by memory traffic and slow each other down by more than the overlap gains.)
     CGArgs a{};
     a.packed = packed_dev; a.eps = eps; a.ckpt = W + o_zck; a.ckpt_k = W + o_kck; a.lam = W + o_lam; a.zb = W + o_zb; a.grad_x = grad_x;
     a.scratch = W + o_scr; a.scratch_stride = scratch_stride;
     for (int l = 0; l < Lh; ++l) { a.xh[l] = W + o_xh[l]; a.yh[l] = W + o_yh[l]; }
-    a.y1 = W + o_y1; a.xN = W + o_xN; a.ld_y1 = n_in + 1;
+    a.y1 = W + o_y1; a.xN = W + o_xN; a.ld_y1 = n_in + 1; a.ldy = ldy;
     a.B = B; a.ntiles_pad = ntp; a.nsteps = nsteps; a.D = D; a.nvars = c.nvars; a.H = H; a.autonomous = c.autonomous; a.lam3 = lam3; a.T = T;
     const float dt = (t1 - t0) / (float)nsteps;
     for (int n = nsteps - 1; n >= 0; --n) {
@@ -1056,8 +1059,8 @@ hipError_t coop_grad(LayeredGrad** ctx, const cnf_config& c, MfmaPlan* plan, con
         LG_HIP(coop_grad_step_launch(HT, Lh, ZR, ACT, a, G.num_cus, st));
         LG_HIP(lg_wgrad(slabs + L.pa_off[0], npa_pad, kc, nslab, H, n_in + 1, a.xh[0], H, a.y1, n_in + 1, B2, st));
         for (int l = 1; l < Lh; ++l)
-            LG_HIP(lg_wgrad(slabs + L.pa_off[l], npa_pad, kc, nslab, H, H + 1, a.xh[l], H, a.yh[l - 1], H + 1, B2, st));
-        LG_HIP(lg_wgrad(slabs + L.pa_off[Lh], npa_pad, kc, nslab, D, H + 1, a.xN, D, a.yh[Lh - 1], H + 1, B2, st));
+            LG_HIP(lg_wgrad(slabs + L.pa_off[l], npa_pad, kc, nslab, H, H + 1, a.xh[l], H, a.yh[l - 1], ldy, B2, st));
+        LG_HIP(lg_wgrad(slabs + L.pa_off[Lh], npa_pad, kc, nslab, D, H + 1, a.xN, D, a.yh[Lh - 1], ldy, B2, st));
     }
     hipLaunchKernelGGL(reduce_slabs_kernel, grid_for(npa), dim3(TPB), 0, st, slabs, nslab, npa_pad, L, grad);
     LG_HIP(hipGetLastError());
