@@ -520,7 +520,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))
 lg_wgrad_kernel(LgWgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int RY = (NTN * 16 + 63) / 64;                     // loads per lane per sample for the Y slice
-    constexpr int YS = NTN * 256, XS = 4 * 256;                  // floats per staged slice
+    // floats per staged slice.  The Y part has room for all 64 RY fetched rows, not just the 16 NTN used ones: parking is then
+    // unconditional - a predicated ds_write is a control-flow join, at which the compiler's wait-count insertion waits for
+    // EVERY outstanding load (vmcnt(0)) and the two-slice prefetch shrinks to one
+    constexpr int YS = RY * 1024, XS = 4 * 256;
     // slice buffer b: Y part at smem + b (YS + XS), X part behind it
     const int lane = threadIdx.x & 63, g = lane >> 4, n = lane & 15;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -613,7 +616,7 @@ lg_wgrad_kernel(LgWgradArgs a) {
 #pragma unroll
         for (int i = 0; i < RY; ++i) {
             const int r = lane + 64 * i;                            // row 16 t + nn of Y -> [t][g' = wave][nn][u]
-            if (r < NTN * 16) yb[((r >> 4) * 4 + wave) * 16 + (r & 15)] = sl.yv[i];
+            yb[((r >> 4) * 4 + wave) * 16 + (r & 15)] = sl.yv[i];   // (rows >= 16 NTN: fetched clamped, parked, never read)
         }
         xb[((lane >> 4) * 4 + wave) * 16 + (lane & 15)] = sl.xv;
     };
@@ -634,19 +637,30 @@ lg_wgrad_kernel(LgWgradArgs a) {
     fetch(0, slA);
     park(0, slA);
     fetch(16, slA);
+    __builtin_amdgcn_sched_barrier(0);   // set A's requests in front of set B's, as the loop leaves them (its wait counts rely on one order)
     fetch(32, slB);
     __syncthreads();
-    for (int s = 0; s < nrem; s += 32) {
-        if (s + 16 >= nrem) { load_prev(); multiply(0); break; }
+    // (The steady-state loop has ONE exit, at its top: with the end-of-chunk tests inside the body, the exit path from the
+    // middle shared the latch block with the back edge, the wait-count insertion merged "A older than B" with "B older than A"
+    // there, and every park of set A waited for vmcnt(0) - the two-slice prefetch was one slice deep on every other slice.)
+    int s = 0;
+    for (; s + 32 < nrem; s += 32) {
         multiply(0);                                  // slice s; set A holds s + 16, set B s + 32
         park(1, slA);
         fetch(s + 48, slA);
         __syncthreads();
-        if (s + 32 >= nrem) { load_prev(); multiply(1); break; }
         multiply(1);                                  // slice s + 16; set B holds s + 32, set A s + 48
         park(0, slB);
         fetch(s + 64, slB);
         __syncthreads();
+    }
+    if (s + 16 >= nrem) { load_prev(); multiply(0); }   // one slice left
+    else {                                              // two
+        multiply(0);
+        park(1, slA);
+        __syncthreads();
+        load_prev();
+        multiply(1);
     }
     if (16 * mt >= a.M) return;
 #pragma unroll
@@ -696,7 +710,7 @@ hipError_t lg_wgrad(float* slabs, long long slab_stride, long long chunk, int nc
     a.nchunks = nchunks; a.rblocks = (MT + 3) / 4; a.groups = groups;
     const dim3 grid((unsigned)(((nchunks + 7) / 8) * 8 * a.rblocks * a.groups));
     const int ntn = NTN <= 1 ? 1 : NTN <= 3 ? 3 : NTN <= 5 ? 5 : 9;
-    const int lds = 2 * (ntn * 256 + 4 * 256) * (int)sizeof(float);          // <= 2 * 13 * 1 KB = 26 KB
+    const int lds = 2 * ((ntn * 16 + 63) / 64 * 1024 + 4 * 256) * (int)sizeof(float);   // <= 2 * 16 KB
     if (NTN <= 1) hipLaunchKernelGGL(lg_wgrad_kernel<1>, grid, dim3(256), lds, st, a);
     else if (NTN <= 3) hipLaunchKernelGGL(lg_wgrad_kernel<3>, grid, dim3(256), lds, st, a);
     else if (NTN <= 5) hipLaunchKernelGGL(lg_wgrad_kernel<5>, grid, dim3(256), lds, st, a);
