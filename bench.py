@@ -595,7 +595,7 @@ def main():
 
     # the opt-in split-bf16 arithmetic as a reported secondary (never the headline: exact f32 is the validated path)
     bf = None
-    want_bf = a.bf16x6_secondary == "on" or (a.bf16x6_secondary == "auto" and a.config == "cfg2" and a.mode == "infer" and
+    want_bf = a.bf16x6_secondary == "on" or (a.bf16x6_secondary == "auto" and a.config in ("cfg2", "cfg3") and a.mode == "infer" and
                                               a.arith == "f32" and world == 1 and not a.force_dist and not a.batch)
     if want_bf:
         try:

@@ -71,6 +71,7 @@ static const Inst kInsts[] = {
     // --- split-bf16 hidden products (cnf_config.arith = CNF_ARITH_BF16X6), headline shape ---
     MFMA_INST_BF16X6(4, 3, 2, 0, CNF_ACT_TANH_PRESCALED, ENG_VJP, 1, 2, 512),
     MFMA_INST_BF16X6(4, 3, 2, 0, CNF_ACT_TANH_PRESCALED, ENG_VJP, 1, 1, 512),
+    MFMA_INST_BF16X6(4, 3, 2, 0, CNF_ACT_TANH_PRESCALED, ENG_VJP, 4, 1, 512),   // cfg3 with c_k hoisted, probes unrolled
     MFMA_INST_BF16X6(4, 3, 2, 0, CNF_ACT_TANH_PRESCALED, ENG_VJP, 4, 0, 512),
     MFMA_INST_BF16X6(4, 3, 2, 0, CNF_ACT_TANH, ENG_TAN, 1, 0, 512),
     // --- tangent engine: Hutchinson JVP (LuxJacVecMatrixMode) and exact trace (TestMode) ---
