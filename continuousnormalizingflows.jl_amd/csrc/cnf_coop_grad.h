@@ -35,6 +35,7 @@ struct CGArgs {
 
 bool coop_grad_supported(int HT, int L, int ZR, int ACT);
 int coop_grad_scratch_slots(int L);   // one chain's tile set ([HT] tiles) each, per workgroup
+int coop_grad_nt();                   // sample tiles per super-tile (1; CNF_CG_NT=2: one workgroup per CU, one wave per SIMD)
 int coop_grad_nblocks(long long B, int num_cus);   // workgroups of a launch (each owns `scratch_stride` floats of scratch)
 hipError_t coop_grad_step_launch(int HT, int L, int ZR, int ACT, const CGArgs& a, int num_cus, hipStream_t st);
 // the cooperative forward solve with step / stage checkpoints in tile layout (cnf_coop.hip)

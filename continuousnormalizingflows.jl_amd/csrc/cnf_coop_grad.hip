@@ -51,6 +51,21 @@
 #define CG_NT_LOAD(p) (*(p))
 #endif
 
+// The kernel's barriers order LDS traffic only (the exchange images); no wave reads global memory another wave of the launch
+// wrote.  __syncthreads() also waits for every outstanding global store (vmcnt(0): the operand and scratch streams) at each of
+// the ~7 barriers of a stage; -DCG_LDS_SYNC waits for the LDS queue alone.  Measured at cfg4: no difference (112.7 vs 112.4 ms;
+// vmcnt retires in order, so the next product's first fragment wait drains the stores anyway) - the plain form stays.
+#ifdef CG_LDS_SYNC
+#define CG_SYNC()                                                     \
+    do {                                                              \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local"); \
+        __builtin_amdgcn_s_barrier();                                 \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local"); \
+    } while (0)
+#else
+#define CG_SYNC() __syncthreads()
+#endif
+
 namespace cnf {
 
 namespace {
@@ -86,7 +101,7 @@ __device__ __forceinline__ void coop_gemm_tail(int KG, const f32x4 (&a0)[M], con
 
 // NT: sample tiles per super-tile (per chain); a product has CT = 2 NT column tiles
 template <int HT, int L, int ZR, int ACT, int NS, int NT>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NT == 1 ? 2 : 1, NT == 1 ? 2 : 1)))
 coop_grad_step_kernel(CGArgs a) {
     static_assert(ACT == CNF_ACT_TANH_PRESCALED, "tanh nets only (act' and act'' are rebuilt from h)");
     static_assert(L == 2 || L == 3, "two or three hidden layers");
@@ -259,7 +274,7 @@ coop_grad_step_kernel(CGArgs a) {
                 voy[q][hf] = sq < B ? (unsigned)sq * ldy + ro : 0xffffffffu;
             }
         }
-        __syncthreads();                 // the previous super-tile's readers of the LDS images are done
+        CG_SYNC();                 // the previous super-tile's readers of the LDS images are done
         if (owner) publish_dense(ebuf, NT, wave, eps);
         float* zbt = a.zb + (tile * 64 + lane) * (long long)(NS * ZR);
 
@@ -321,7 +336,7 @@ coop_grad_step_kernel(CGArgs a) {
 #pragma unroll
                     for (int q = 0; q < NT; ++q) { acc[m][q] = b0; acc[m][NT + q] = f32x4{0.f, 0.f, 0.f, 0.f}; }
                 }
-                __syncthreads();
+                CG_SYNC();
                 run2(LAY.f1z, DT, zebuf, afr, acc);                          // [a_1 | q], q = W_1[:,0:D] eps
             }
             int cur = 0;
@@ -354,7 +369,7 @@ coop_grad_step_kernel(CGArgs a) {
                     for (int m = 0; m < MTW; ++m)
 #pragma unroll
                         for (int q = 0; q < NT; ++q) { acc[m][q] = bnx[m]; acc[m][NT + q] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-                    __syncthreads();
+                    CG_SYNC();
                     run2(LAY.fh + l * IMG, HT, xbuf + cur * XB, afr, acc);
                     cur ^= 1;
                 } else {
@@ -377,7 +392,7 @@ coop_grad_step_kernel(CGArgs a) {
                     publish2(cur, dl, sb);
                     gstore(cur, 0, rx[L - 1], vox, sx1);                      // delta_L half of X_L
                     gstore(cur, 1, rx[L - 1], vox, sx2);                      // sbar_L half
-                    __syncthreads();
+                    CG_SYNC();
                 }
             }
             // ================= down: [u_l | hbar_l] = W_{l+1}^T [delta_{l+1} | sbar_{l+1}] =================
@@ -416,7 +431,7 @@ coop_grad_step_kernel(CGArgs a) {
                 publish2(cur, dl, sb);
                 gstore(cur, 0, rx[l - 1], vox, sx1);                          // delta_l half of X_l
                 gstore(cur, 1, rx[l - 1], vox, sx2);                          // sbar_l half
-                __syncthreads();
+                CG_SYNC();
             }
             // Zbar_i = W_1[:,0:D]^T sbar_1 for this wave's own sample tile
             if (owner) {
@@ -427,7 +442,7 @@ coop_grad_step_kernel(CGArgs a) {
 #pragma unroll
                 for (int s = 0; s < ZR; ++s) zbt[i * ZR + s] = zacc[s >> 2][0][s & 3];
             }
-            __syncthreads();
+            CG_SYNC();
         }
         if (owner) {
 #pragma unroll
@@ -456,9 +471,9 @@ template <int HT, int L, int ZR, int ACT, int NS, int NT>
 static hipError_t launch_grad_step(const CGArgs& a, int num_cus, hipStream_t st) {
     constexpr int DT = (ZR + 3) / 4, CT = 2 * NT;
     constexpr int lds = (2 * HT * CT * 64 + (2 * DT * CT + DT * NT) * 64) * 16;
-    static_assert(lds * 2 <= 160 * 1024, "exchange buffers exceed LDS");
+    static_assert(lds * (NT == 1 ? 2 : 1) <= 160 * 1024, "exchange buffers exceed LDS");
     const long long nst = (a.B + 16 * NT - 1) / (16 * NT);
-    const long long cap = (long long)num_cus * 2;
+    const long long cap = (long long)num_cus * (NT == 1 ? 2 : 1);
     const int nblocks = (int)(nst < cap ? nst : cap);
     auto kern = coop_grad_step_kernel<HT, L, ZR, ACT, NS, NT>;
     static DeviceOnce once;
@@ -476,11 +491,13 @@ static hipError_t launch_grad_step(const CGArgs& a, int num_cus, hipStream_t st)
 
 struct CoopGradInst {
     int HT, L, ZR, ACT;
-    hipError_t (*fn[2])(const CGArgs&, int, hipStream_t);   // [0] RK4 (4 stages), [1] Tsit5 (6 stages)
+    hipError_t (*fn[4])(const CGArgs&, int, hipStream_t);   // [0] RK4 (4 stages), [1] Tsit5 (6 stages); [2], [3]: NT = 2
 };
 #define CG_INST(HT, L, ZR) \
     CoopGradInst { HT, L, ZR, CNF_ACT_TANH_PRESCALED, { &launch_grad_step<HT, L, ZR, CNF_ACT_TANH_PRESCALED, 4, 1>, \
-                                                        &launch_grad_step<HT, L, ZR, CNF_ACT_TANH_PRESCALED, 6, 1> } }
+                                                        &launch_grad_step<HT, L, ZR, CNF_ACT_TANH_PRESCALED, 6, 1>, \
+                                                        &launch_grad_step<HT, L, ZR, CNF_ACT_TANH_PRESCALED, 4, 2>, \
+                                                        &launch_grad_step<HT, L, ZR, CNF_ACT_TANH_PRESCALED, 6, 2> } }
 // the same (HT, L, ZR) as the forward instances of cnf_coop.hip they pair with (the plan's packed image is shared)
 static const CoopGradInst kCoopGrad[] = {
     CG_INST(16, 3, 8),   // cfg4: D = 32, 3 x 256
@@ -497,15 +514,20 @@ static const CoopGradInst* cg_find(int HT, int L, int ZR, int ACT) {
 bool coop_grad_supported(int HT, int L, int ZR, int ACT) { return cg_find(HT, L, ZR, ACT) != nullptr; }
 int coop_grad_scratch_slots(int L) { return 2 * L - 3; }   // h_1 .. h_{L-1}, dbar_2 .. dbar_{L-1}
 // workgroups of a launch (16-sample super-tiles, two workgroups per CU): the host sizes the per-workgroup scratch with it
+int coop_grad_nt() {
+    static const int nt = [] { const char* e = getenv("CNF_CG_NT"); return (e && atoi(e) == 2) ? 2 : 1; }();
+    return nt;
+}
 int coop_grad_nblocks(long long B, int num_cus) {
-    const long long nst = (B + 15) / 16, cap = (long long)num_cus * 2;
+    const int nt = coop_grad_nt();
+    const long long nst = (B + 16 * nt - 1) / (16 * nt), cap = (long long)num_cus * (nt == 1 ? 2 : 1);
     return (int)(nst < cap ? nst : cap);
 }
 
 hipError_t coop_grad_step_launch(int HT, int L, int ZR, int ACT, const CGArgs& a, int num_cus, hipStream_t st) {
     const CoopGradInst* c = cg_find(HT, L, ZR, ACT);
     if (!c) return hipErrorNotSupported;
-    return c->fn[a.T.ns <= 4 ? 0 : 1](a, num_cus, st);
+    return c->fn[(a.T.ns <= 4 ? 0 : 1) + (coop_grad_nt() == 2 ? 2 : 0)](a, num_cus, st);
 }
 
 }  // namespace cnf

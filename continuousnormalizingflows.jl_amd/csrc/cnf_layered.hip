@@ -1008,7 +1008,7 @@ hipError_t coop_grad(LayeredGrad** ctx, const cnf_config& c, MfmaPlan* plan, con
     const long long nst = (B + 63) / 64, ntp = nst * 4;
     const int nblocks = coop_grad_nblocks(B, G.num_cus);
     const int slots = coop_grad_scratch_slots(Lh);
-    const long long scratch_stride = (long long)(slots > 0 ? slots : 1) * HT * 256;   // slots x (HT tiles x 64 lanes x 4) floats
+    const long long scratch_stride = (long long)(slots > 0 ? slots : 1) * HT * 256 * coop_grad_nt();   // slots x (HT x NT tiles x 64 lanes x 4) floats
 
     long long off = 0;
     auto take = [&](long long n) { const long long o = off; off += (n + 63) / 64 * 64; return o; };
