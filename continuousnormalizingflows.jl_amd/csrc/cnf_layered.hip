@@ -49,7 +49,7 @@ hipError_t lg_gemm(const float* img, int M, int K, const float* in, int ldb, flo
                    const float* e, int lde, float* dout, int ldd, int act, hipStream_t st, const float* e2 = nullptr,
                    const float* a3 = nullptr, int ld3 = 0, int first = 0);
 bool lg_wgrad_supported(int M, int Nc);
-int lg_wgrad_chunks(int M, long long B, int num_cus, long long* chunk_out, int per_cu_dflt = 2);
+int lg_wgrad_chunks(int M, long long B, int num_cus, long long* chunk_out, int per_cu_dflt = 2, int Nc = 0);
 hipError_t lg_wgrad(float* slabs, long long slab_stride, long long chunk, int nchunks, int M, int Nc, const float* x, int ldx,
                     const float* y, int ldy, long long B, hipStream_t st);
 
@@ -953,6 +953,15 @@ hipError_t layered_grad(LayeredGrad** ctx, const cnf_config& c, const float* P_d
 // Cooperative gradient for wide hidden layers (cnf_coop_grad.hip): checkpointing forward solve, one reverse-sweep launch
 // per RK step, then one weight-cotangent product per weight matrix per step over the operands that launch left
 // ---------------------------------------------------------------------------------------------------------------------
+// dst[e] += sum of the n slabs src[c * sz + e], fixed order (the D-row cotangent's own, finer chunking folded into slab 0)
+__global__ void fold_slabs_kernel(float* __restrict__ dst, const float* __restrict__ src, int n, long long sz) {
+    const long long e = (long long)blockIdx.x * TPB + threadIdx.x;
+    if (e >= sz) return;
+    float acc = 0.f;
+    for (int c = 0; c < n; ++c) acc += src[(long long)c * sz + e];
+    dst[e] += acc;
+}
+
 // rows [row0, rows) of columns [c0, c1) of a column-major array <- val
 __global__ void fill_rows_kernel(float* __restrict__ a, int ld, int row0, int rows, long long c0, long long c1, float val) {
     const long long i = (long long)blockIdx.x * TPB + threadIdx.x;
@@ -1005,6 +1014,11 @@ hipError_t coop_grad(LayeredGrad** ctx, const cnf_config& c, MfmaPlan* plan, con
     const long long B2 = 2LL * ns * B;                      // columns of every operand array
     long long kc = 0;
     const int nslab = lg_wgrad_chunks(H, B2, G.num_cus, &kc, 4);
+    // The D-row cotangent (Wbar_N = [eps | kbar] Y_L^T: D x (H + 1)) is one row block: with the square layers' chunking it would
+    // run on a quarter of their workgroups (one per CU: 127 us for 270 MB).  It gets its own, finer chunks and slabs.
+    long long kcN = 0;
+    const int nslabN = lg_wgrad_chunks(D, B2, G.num_cus, &kcN, 4, H + 1);
+    const long long szN = (long long)D * (H + 1), szN_pad = (szN + 63) / 64 * 64;
     const long long nst = (B + 63) / 64, ntp = nst * 4;
     const int nblocks = coop_grad_nblocks(B, G.num_cus);
     const int slots = coop_grad_scratch_slots(Lh);
@@ -1012,7 +1026,7 @@ hipError_t coop_grad(LayeredGrad** ctx, const cnf_config& c, MfmaPlan* plan, con
 
     long long off = 0;
     auto take = [&](long long n) { const long long o = off; off += (n + 63) / 64 * 64; return o; };
-    const long long o_slab = take(npa_pad * nslab);
+    const long long o_slab = take(npa_pad * nslab), o_slabN = take(szN_pad * nslabN);
     const long long o_zck = take((long long)(nsteps + 1) * ntp * 64 * ZR), o_kck = take((long long)nsteps * ns * ntp * 64 * ZR);
     const long long o_lam = take(ntp * 64 * ZR), o_zb = take(ntp * 64 * 6 * ZR), o_scr = take(scratch_stride * nblocks);
     // Y_l: H + 1 rows; a leading dimension that is a multiple of 16 floats keeps every 16-byte operand store inside one
@@ -1030,6 +1044,7 @@ hipError_t coop_grad(LayeredGrad** ctx, const cnf_config& c, MfmaPlan* plan, con
     float* W = G.ws;
     float* slabs = W + o_slab;
     LG_HIP(hipMemsetAsync(slabs, 0, (size_t)npa_pad * nslab * sizeof(float), st));
+    LG_HIP(hipMemsetAsync(W + o_slabN, 0, (size_t)szN_pad * nslabN * sizeof(float), st));
     // constant rows of the operand arrays: the zero / ones row of every Y_l, the zero rows under gbar
     LG_HIP(hipMemsetAsync(W + o_y1, 0, (size_t)(n_in + 1) * B2 * sizeof(float), st));
     for (int l = 0; l < Lh; ++l) {
@@ -1060,8 +1075,9 @@ hipError_t coop_grad(LayeredGrad** ctx, const cnf_config& c, MfmaPlan* plan, con
         LG_HIP(lg_wgrad(slabs + L.pa_off[0], npa_pad, kc, nslab, H, n_in + 1, a.xh[0], H, a.y1, n_in + 1, B2, st));
         for (int l = 1; l < Lh; ++l)
             LG_HIP(lg_wgrad(slabs + L.pa_off[l], npa_pad, kc, nslab, H, H + 1, a.xh[l], H, a.yh[l - 1], ldy, B2, st));
-        LG_HIP(lg_wgrad(slabs + L.pa_off[Lh], npa_pad, kc, nslab, D, H + 1, a.xN, D, a.yh[Lh - 1], ldy, B2, st));
+        LG_HIP(lg_wgrad(W + o_slabN, szN_pad, kcN, nslabN, D, H + 1, a.xN, D, a.yh[Lh - 1], ldy, B2, st));
     }
+    hipLaunchKernelGGL(fold_slabs_kernel, grid_for(szN), dim3(TPB), 0, st, slabs + L.pa_off[Lh], W + o_slabN, nslabN, szN_pad);
     hipLaunchKernelGGL(reduce_slabs_kernel, grid_for(npa), dim3(TPB), 0, st, slabs, nslab, npa_pad, L, grad);
     LG_HIP(hipGetLastError());
     return hipSuccess;

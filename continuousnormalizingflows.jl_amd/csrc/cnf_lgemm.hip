@@ -516,7 +516,7 @@ struct LgWgradArgs {
 // that ONE lane-linear ds_read_b128 hands a lane its B operands of all four k-steps of a tile (sample 4 u + g, row 16 t + n).
 // (Reading the operands straight from global memory made every wave fetch all of Y: 670 MB of L2 traffic per call at cfg4.)
 template <int NTN>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3)))
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
 lg_wgrad_kernel(LgWgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int RY = (NTN * 16 + 63) / 64;                     // loads per lane per sample for the Y slice
@@ -620,6 +620,9 @@ lg_wgrad_kernel(LgWgradArgs a) {
         }
         xb[((lane >> 4) * 4 + wave) * 16 + (lane & 15)] = sl.xv;
     };
+    // The last column group of a strip may have one tile less than NTN (257 columns = 9 + 8 tiles): its waves skip that
+    // tile's MFMAs (wave-uniform branch) instead of multiplying padding - 1 / 18 of the 256 x 257 product.
+    const bool last_tile = (Nc + 15) / 16 >= NTN;
     auto multiply = [&](int buf) {
         const f32x4* y4 = reinterpret_cast<const f32x4*>(smem + buf * (YS + XS)) + lane;
         const f32x4 av = reinterpret_cast<const f32x4*>(smem + buf * (YS + XS) + YS)[wave * 64 + lane];
@@ -627,10 +630,17 @@ lg_wgrad_kernel(LgWgradArgs a) {
 #pragma unroll
         for (int t = 0; t < NTN; ++t) bv[t] = y4[t * 64];
         // k-step outermost: consecutive MFMAs go to different accumulators (no dependent back-to-back pairs)
+        constexpr int NTM = NTN > 1 ? NTN - 1 : NTN;
 #pragma unroll
         for (int u = 0; u < 4; ++u)
 #pragma unroll
-            for (int t = 0; t < NTN; ++t) acc[t] = mfma4(av[u], bv[t][u], acc[t]);
+            for (int t = 0; t < NTM; ++t) acc[t] = mfma4(av[u], bv[t][u], acc[t]);
+        if constexpr (NTN > 1) {
+            if (last_tile) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc[NTN - 1] = mfma4(av[u], bv[NTN - 1][u], acc[NTN - 1]);
+            }
+        }
     };
     // Slices of 16 samples.  A slice is fetched TWO slices ahead of its use (two register sets, alternating) and parked in
     // the LDS buffer the previous multiply has just left: ~2 slice times of memory latency are covered.
@@ -644,15 +654,31 @@ lg_wgrad_kernel(LgWgradArgs a) {
     // middle shared the latch block with the back edge, the wait-count insertion merged "A older than B" with "B older than A"
     // there, and every park of set A waited for vmcnt(0) - the two-slice prefetch was one slice deep on every other slice.)
     int s = 0;
+    // (-DLG_EXP_NOFETCH / _NOPARK / _NOSYNC: timing-only builds of profiles/ubench/wgrad_variants.hip - wrong results)
+#ifdef LG_EXP_NOFETCH
+#define LG_FETCH(a, b) ((void)0)
+#else
+#define LG_FETCH(a, b) fetch(a, b)
+#endif
+#ifdef LG_EXP_NOPARK
+#define LG_PARK(a, b) ((void)0)
+#else
+#define LG_PARK(a, b) park(a, b)
+#endif
+#ifdef LG_EXP_NOSYNC
+#define LG_SYNC() ((void)0)
+#else
+#define LG_SYNC() __syncthreads()
+#endif
     for (; s + 32 < nrem; s += 32) {
         multiply(0);                                  // slice s; set A holds s + 16, set B s + 32
-        park(1, slA);
-        fetch(s + 48, slA);
-        __syncthreads();
+        LG_PARK(1, slA);
+        LG_FETCH(s + 48, slA);
+        LG_SYNC();
         multiply(1);                                  // slice s + 16; set B holds s + 32, set A s + 48
-        park(0, slB);
-        fetch(s + 64, slB);
-        __syncthreads();
+        LG_PARK(0, slB);
+        LG_FETCH(s + 64, slB);
+        LG_SYNC();
     }
     if (s + 16 >= nrem) { load_prev(); multiply(0); }   // one slice left
     else {                                              // two
@@ -680,9 +706,10 @@ lg_wgrad_kernel(LgWgradArgs a) {
 bool lg_wgrad_supported(int M, int Nc) { return M >= 1 && Nc >= 1 && Nc <= 16 * 9 * 65535; }
 
 // number of sample chunks (= slabs) a wgrad call uses for this (M, B): enough workgroups to fill the chip, chunks of >= 64 samples
-int lg_wgrad_chunks(int M, long long B, int num_cus, long long* chunk_out, int per_cu_dflt) {
+int lg_wgrad_chunks(int M, long long B, int num_cus, long long* chunk_out, int per_cu_dflt, int Nc) {
     const int RB = ((M + 15) / 16 + 3) / 4;
-    const int groups = ((M + 1 + 15) / 16 + 8) / 9;   // column groups of a square layer's cotangent (lg_wgrad)
+    if (Nc <= 0) Nc = M + 1;                           // a square layer's cotangent with its bias column
+    const int groups = ((Nc + 15) / 16 + 8) / 9;      // column groups (lg_wgrad)
     // workgroups per CU: 2 for the per-stage calls of the layer-wise path (B columns), 4 for the per-step calls of the
     // cooperative gradient (2 x stages x B columns: cfg4 loss + gradient 139.9 -> 133.3 ms; 1: 162, 3: 135, 8: 135)
     static const int per_cu_env = [] { const char* v = getenv("CNF_LG_WGRAD_PER_CU"); return v && *v ? atoi(v) : 0; }();
