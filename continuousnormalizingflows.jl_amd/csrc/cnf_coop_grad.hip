@@ -107,7 +107,7 @@ coop_grad_step_kernel(CGArgs a) {
     static_assert(L == 2 || L == 3, "two or three hidden layers");
     constexpr int SUP = 16 * NT, CT = 2 * NT;
     constexpr MfmaLayout LAY(HT, L, ZR, 0, true);
-    constexpr int MTW = HT / 4, DT = (ZR + 3) / 4, XB = HT * CT * 64, DB2 = DT * CT * 64, DB1 = DT * NT * 64;
+    constexpr int MTW = HT / 4, DT = (ZR + 3) / 4, XB = HT * CT * 64, DB2 = DT * CT * 64;
     constexpr int IMG = MfmaLayout::imgA(HT, HT);
     constexpr bool GS = MTW % 2 == 0;                 // operand stores as full 128-byte lines (two row tiles x 8 samples)
     extern __shared__ __attribute__((aligned(16))) float smem[];

@@ -957,9 +957,15 @@ hipError_t layered_grad(LayeredGrad** ctx, const cnf_config& c, const float* P_d
 __global__ void fold_slabs_kernel(float* __restrict__ dst, const float* __restrict__ src, int n, long long sz) {
     const long long e = (long long)blockIdx.x * TPB + threadIdx.x;
     if (e >= sz) return;
-    float acc = 0.f;
-    for (int c = 0; c < n; ++c) acc += src[(long long)c * sz + e];
-    dst[e] += acc;
+    // eight independent partial sums (slabs c = k mod 8) keep eight loads in flight; combined in a fixed order
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int c = 0;
+    for (; c + 8 <= n; c += 8) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] += src[(long long)(c + k) * sz + e];
+    }
+    for (int k = 0; c < n; ++c, ++k) acc[k] += src[(long long)c * sz + e];
+    dst[e] += ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
 }
 
 // rows [row0, rows) of columns [c0, c1) of a column-major array <- val

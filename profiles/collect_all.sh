@@ -16,6 +16,9 @@ for c in cfg2 cfg2p cfg3 cfg4 cfg5; do
   cp gpurun_out/prof_${TAG}_$c/pmc_summary.txt $OUT/${TAG}_${c}_pmc_summary.txt 2>/dev/null
   cp gpurun_out/prof_${TAG}_$c/kernel_stats_steady.json $OUT/${TAG}_${c}_kernel_stats_steady.json 2>/dev/null
 done
+bash profiles/collect.sh ${TAG}g cfg4 --mode grad > $OUT/collect_cfg4_grad.log 2>&1
+cp gpurun_out/prof_${TAG}g_cfg4/trace/*/*_kernel_stats.csv $OUT/${TAG}_cfg4_grad_kernel_stats.csv 2>/dev/null
+cp gpurun_out/prof_${TAG}g_cfg4/pmc_summary.txt $OUT/${TAG}_cfg4_grad_pmc_summary.txt 2>/dev/null
 python profiles/percall_boundaryA.py > $OUT/${TAG}_percall_boundaryA.json 2>/dev/null
 python profiles/tile_split_timing.py > $OUT/${TAG}_tile_split.json 2>/dev/null
 python profiles/small_batch_latency.py > $OUT/${TAG}_small_batch_latency.json 2>/dev/null
