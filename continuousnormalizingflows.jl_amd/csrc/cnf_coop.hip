@@ -41,12 +41,12 @@ namespace cnf {
 // the exchange buffers and half the accumulators per wave, so two waves share each SIMD and fill each other's stalls, at the
 // price of each weight fragment feeding 2 sample tiles instead of 4).  Waves 0 .. NT-1 own the ODE state of one sample tile.
 // WL: the packed image sits in LDS at `wl` (see AImg); P is then only the global copy it was staged from
-template <int HT, int L, int ZR, int ACT, int NT, bool WL = false>
+template <int HT, int L, int ZR, int ACT, int NT, bool WL = false, bool GOUT = false>
 __device__ __forceinline__ void coop_eval(const float* __restrict__ P, const float* __restrict__ wl, f32x4* __restrict__ xbuf,
                                           f32x4* __restrict__ zbuf, const f32x4* __restrict__ ebuf, f32x4* __restrict__ pbuf,
                                           int lane, int wave, float t, bool autonomous, bool reg_z,
                                           bool reg_j, const float (&zs)[ZR],
-                                          float (&zd)[ZR], float& ld, float& ed, float& nd) {
+                                          float (&zd)[ZR], float& ld, float& ed, float& nd, float* __restrict__ gout = nullptr) {
     constexpr MfmaLayout LAY(HT, L, ZR, 0, true);
     constexpr int MTW = HT / 4, DT = (ZR + 3) / 4, XB = HT * NT * 64;   // XB: f32x4 per exchange buffer
     const bool owner = wave < NT;                                        // this wave integrates sample tile `wave`
@@ -264,6 +264,12 @@ __device__ __forceinline__ void coop_eval(const float* __restrict__ P, const flo
             }
             ld = -group_sum(dot);
             nd = reg_j ? sqrtf(group_sum(n2)) : 0.f;
+            if constexpr (GOUT) {   // g = eps^T J of this stage for the reverse sweep (cotangent of |eps^T J|)
+                if (gout) {
+#pragma unroll
+                    for (int s = 0; s < ZR; ++s) gout[s] = gacc[s >> 2][0][s & 3];
+                }
+            }
         }
     }
 }
@@ -357,8 +363,12 @@ coop_vjp_solve_kernel(KArgs a) {
                 float zs[ZR];
 #pragma unroll
                 for (int s = 0; s < ZR; ++s) zs[s] = fmaf(dt, Pz[0][s], z[s]);
-                coop_eval<HT, L, ZR, ACT, NT, WL>(a.packed, wl, xbuf, zbuf, ebuf, pbuf, lane, wave, tn + a.T.c[sg] * dt, autonomous,
-                                          reg_z, reg_j, zs, zd, ld, ed, nd);
+                float* gout = nullptr;
+                if constexpr (CK) {
+                    if (a.ckpt_g) gout = a.ckpt_g + ((((long long)step * ns + sg) * nst * NT + st * NT + wave) * 64 + lane) * ZR;
+                }
+                coop_eval<HT, L, ZR, ACT, NT, WL, CK>(a.packed, wl, xbuf, zbuf, ebuf, pbuf, lane, wave, tn + a.T.c[sg] * dt, autonomous,
+                                          reg_z, reg_j, zs, zd, ld, ed, nd, gout);
                 if constexpr (CK) {
                     if (owner) {
 #pragma unroll

@@ -13,6 +13,7 @@ struct CGArgs {
     const float* eps;         // D x B
     const float* ckpt;        // z at the start of every step and after the last: [step][tile][lane][ZR] (forward kernel, CK form)
     const float* ckpt_k;      // stage derivatives: [step * ns + stage][tile][lane][ZR]
+    const float* ckpt_g;      // g = eps^T J of every stage, same layout (read when lam2 != 0)
     float* lam;               // costate, [tile][lane][ZR]: read (unless this is the last step), written
     float* zb;                // Zbar_j of the running step's stages, [tile][lane][6][ZR] (scratch of the kernel)
     float* grad_x;            // nvars x B or null; written by step 0
@@ -29,7 +30,7 @@ struct CGArgs {
     int step, nsteps;
     float tn, dt;             // this step's start time and length
     int D, nvars, H, autonomous;
-    float lam3;
+    float lam1, lam2, lam3;   // weights of |zdot|, |eps^T J|, |z_aug| in the objective (src/core/icnf.jl:628-637)
     Tableau T;
 };
 

@@ -112,9 +112,9 @@ coop_grad_step_kernel(CGArgs a) {
     constexpr bool GS = MTW % 2 == 0;                 // operand stores as full 128-byte lines (two row tiles x 8 samples)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     f32x4* xbuf = reinterpret_cast<f32x4*>(smem);   // [2][HT][CT][64]: exchange buffers (column tile = chain * NT + sample tile)
-    f32x4* zebuf = xbuf + 2 * XB;                    // [DT][CT][64]: [z_stage | eps]
+    f32x4* zebuf = xbuf + 2 * XB;                    // [DT][CT][64]: [z_stage | gbar]
     f32x4* ekbuf = zebuf + DB2;                      // [DT][CT][64]: [eps | kbar]
-    f32x4* ebuf = ekbuf + DB2;                       // [DT][NT][64]: eps
+    f32x4* gbuf = ekbuf + DB2;                       // [DT][NT][64]: gbar (for the second dbar_1 product of the stage)
     const int lane = threadIdx.x & 63, g = lane >> 4, n = lane & 15;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int mt0 = wave * MTW;
@@ -262,10 +262,8 @@ coop_grad_step_kernel(CGArgs a) {
             for (int s = 0; s < ZR; ++s) lam[s] = a.lam[(tile * 64 + lane) * ZR + s];
         }
         unsigned vox[NT][2], voy[NT][2];
-        float vq[NT];
 #pragma unroll
         for (int q = 0; q < NT; ++q) {
-            vq[q] = smp0 + q * 16 + n < B ? 1.f : 0.f;
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf) {
                 const long long sq = GS ? smp0 + q * 16 + (lane >> 3) + 8 * hf : smp0 + q * 16 + n;
@@ -275,7 +273,6 @@ coop_grad_step_kernel(CGArgs a) {
             }
         }
         CG_SYNC();                 // the previous super-tile's readers of the LDS images are done
-        if (owner) publish_dense(ebuf, NT, wave, eps);
         float* zbt = a.zb + (tile * 64 + lane) * (long long)(NS * ZR);
 
 #pragma clang loop unroll(disable)
@@ -300,19 +297,42 @@ coop_grad_step_kernel(CGArgs a) {
 #pragma unroll
                 for (int s = 0; s < ZR; ++s) { zs[s] = fmaf(dt, acc[s], zn[s]); kbar[s] = valid ? dt * kb[s] : 0.f; }
             }
-            const float cl = dt * bi;
+            const float cl = valid ? dt * bi : 0.f;      // cotangent of ldot (dL/d dlogp = +1 per column); zero for padding columns
+            // gbar = cotangent of g = eps^T J: -c_l eps (+ c_n g / |g|);  kbar += c_E zdot / |zdot|  (src/core/icnf.jl:184-251: Edot =
+            // |zdot|, ndot = |eps^T J|; zdot_i and g_i of the stage are the forward solve's checkpoints)
+            float gbar[ZR];
+#pragma unroll
+            for (int s = 0; s < ZR; ++s) gbar[s] = -cl * eps[s];
+            if (a.lam1 != 0.f) {
+                const float* ki = a.ckpt_k + ((((long long)a.step * ns + i) * ntp + tile) * 64 + lane) * ZR;
+                float e2 = 0.f;
+#pragma unroll
+                for (int s = 0; s < ZR; ++s) e2 = fmaf(ki[s], ki[s], e2);
+                e2 = group_sum(e2);
+                const float inv = e2 > 0.f ? cl * a.lam1 * rsqrtf(e2) : 0.f;
+#pragma unroll
+                for (int s = 0; s < ZR; ++s) kbar[s] = fmaf(inv, ki[s], kbar[s]);
+            }
+            if (a.lam2 != 0.f) {
+                const float* gi = a.ckpt_g + ((((long long)a.step * ns + i) * ntp + tile) * 64 + lane) * ZR;
+                float n2 = 0.f;
+#pragma unroll
+                for (int s = 0; s < ZR; ++s) n2 = fmaf(gi[s], gi[s], n2);
+                n2 = group_sum(n2);
+                const float inv = n2 > 0.f ? cl * a.lam2 * rsqrtf(n2) : 0.f;
+#pragma unroll
+                for (int s = 0; s < ZR; ++s) gbar[s] = fmaf(inv, gi[s], gbar[s]);
+            }
             const float tt = tn + a.T.c[i] * dt;
             const long long c1 = (long long)i * B, c2 = nsB + (long long)i * B;
             const unsigned sx1 = (unsigned)c1 * ldx, sx2 = (unsigned)c2 * ldx, sy1 = (unsigned)c1 * ldy, sy2 = (unsigned)c2 * ldy;
             if (owner) {
-                publish_dense(zebuf, CT, wave, zs); publish_dense(zebuf, CT, NT + wave, eps);
+                publish_dense(zebuf, CT, wave, zs); publish_dense(zebuf, CT, NT + wave, gbar);
                 publish_dense(ekbuf, CT, wave, eps); publish_dense(ekbuf, CT, NT + wave, kbar);
+                publish_dense(gbuf, NT, wave, gbar);
             }
             if (valid) {
-                float gb[ZR];
-#pragma unroll
-                for (int s = 0; s < ZR; ++s) gb[s] = -cl * eps[s];
-                dense_store(a.y1, a.ld_y1, c1 + smp, gb);
+                dense_store(a.y1, a.ld_y1, c1 + smp, gbar);
                 dense_store(a.y1, a.ld_y1, c2 + smp, zs);
                 if (g == 0) {
                     float* col = a.y1 + (c2 + smp) * (long long)a.ld_y1;
@@ -337,7 +357,7 @@ coop_grad_step_kernel(CGArgs a) {
                     for (int q = 0; q < NT; ++q) { acc[m][q] = b0; acc[m][NT + q] = f32x4{0.f, 0.f, 0.f, 0.f}; }
                 }
                 CG_SYNC();
-                run2(LAY.f1z, DT, zebuf, afr, acc);                          // [a_1 | q], q = W_1[:,0:D] eps
+                run2(LAY.f1z, DT, zebuf, afr, acc);                          // [a_1 | dbar_1], dbar_1 = W_1[:,0:D] gbar
             }
             int cur = 0;
 #pragma unroll
@@ -351,8 +371,7 @@ coop_grad_step_kernel(CGArgs a) {
                     for (int q = 0; q < NT; ++q) {
                         f32x4 dd;
                         act_tile<ACT>(acc[m][q], h[m][q], dd);
-                        // dbar_1 = W_1[:,0:D] gbar = -c_l q (zero for padding columns); dbar_{l+1} = W_{l+1} vbar_l
-                        db[m][q] = acc[m][NT + q] * (l == 0 ? inv_fs * (-cl * vq[q]) : inv_fs);
+                        db[m][q] = acc[m][NT + q] * inv_fs;                   // dbar_{l+1} = W_{l+1} vbar_l (dbar_1 = W_1[:,0:D] gbar)
                         vb[m][q] = db[m][q] * tanh_d(h[m][q]);             // vbar_{l+1} (cbar at the top)
                     }
                 publish2(cur, h, vb);
@@ -403,14 +422,14 @@ coop_grad_step_kernel(CGArgs a) {
                 T1 hl, dbl, dl, sb;
                 zero2(t);
                 if (l == 1) {
-                    // dbar_1 = -c_l q again: q = W_1[:,0:D] eps is a D-sized product, cheaper than a scratch round trip
+                    // dbar_1 = W_1[:,0:D] gbar again: a D-sized product, cheaper than a scratch round trip
                     f32x4 afq[MTW];
                     coop_load_a<MTW>(AIMG(LAY.f1z), mt0, DT, 0, afq);
 #pragma unroll
                     for (int m = 0; m < MTW; ++m)
 #pragma unroll
                         for (int q = 0; q < NT; ++q) dbl[m][q] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    coop_gemm<MTW, NT, NT>(AIMG(LAY.f1z), mt0, DT, ebuf, 0, lane, afq, dbl);
+                    coop_gemm<MTW, NT, NT>(AIMG(LAY.f1z), mt0, DT, gbuf, 0, lane, afq, dbl);
                 }
                 head2(LAY.bh + (l - 1) * IMG, HT, xbuf + cur * XB, afr, t);
                 sload(SLOT_H + l - 1, hl);
@@ -424,7 +443,7 @@ coop_grad_step_kernel(CGArgs a) {
 #pragma unroll
                     for (int q = 0; q < NT; ++q) {
                         const f32x4 d = tanh_d(hl[m][q]), u = t[m][q];
-                        const f32x4 dbv = l == 1 ? dbl[m][q] * (inv_fs * (-cl * vq[q])) : dbl[m][q];
+                        const f32x4 dbv = l == 1 ? dbl[m][q] * inv_fs : dbl[m][q];
                         dl[m][q] = u * d;
                         sb[m][q] = t[m][NT + q] * d + (dbv * u) * (hl[m][q] * d * -2.f);
                     }

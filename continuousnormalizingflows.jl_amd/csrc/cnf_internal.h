@@ -77,6 +77,7 @@ struct SolveArgs {
     float* ckpt_k;
     float* kfull;
     float dt_exact;  // != 0: the step itself (nsteps = 1 attempts: (t0 + dt) - t0 is not dt in float32); 0: (t1 - t0) / nsteps
+    float* ckpt_g;   // optional, cooperative checkpointing solve only (KArgs::ckpt_g)
 };
 hipError_t mfma_solve(MfmaPlan* p, const float* packed_dev, const SolveArgs& a, hipStream_t st);
 // adaptive Tsit5 with the step controller on the device (cnf_mfma_kernel.h: mfma_adaptive_kernel): u0 -> u_out over [t0, t1]
@@ -132,7 +133,7 @@ bool mfma_plan_coop_shape(const MfmaPlan* p, int* HT, int* L, int* ZR, int* ACT)
 bool coop_grad_eligible(const cnf_config& c, const MfmaPlan* plan, const float lam[3], const float* tgrid);
 hipError_t coop_grad(LayeredGrad** ctx, const cnf_config& c, MfmaPlan* plan, const float* packed_dev, const size_t* w_off,
                      const size_t* b_off, const float* x, const float* eps, int alg, int nsteps, float t0, float t1, long long B,
-                     float lam3, float* grad, float* grad_x, float* logp_out, float* regs_out, hipStream_t st, std::string* err);
+                     const float lam[3], float* grad, float* grad_x, float* logp_out, float* regs_out, hipStream_t st, std::string* err);
 
 // ---- variable-coefficient Adams PECE (cnf_vcabm.hip): elementwise passes of one step attempt ----
 constexpr int kVcSlots = 13;   // Phi*_0 .. Phi*_12: orders 1..12 plus the difference the order-raising estimate needs

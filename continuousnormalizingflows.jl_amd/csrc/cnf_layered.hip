@@ -981,7 +981,6 @@ bool coop_grad_eligible(const cnf_config& c, const MfmaPlan* plan, const float l
     if (!mfma_plan_coop_shape(plan, &HT, &L, &ZR, &ACT)) return false;
     if (const char* e = getenv("CNF_COOP_GRAD")) { if (*e == '0') return false; }
     if (c.mode != CNF_MODE_HUTCH_VJP || c.nprobes != 1 || c.ncond != 0 || tgrid) return false;
-    if (lam[0] != 0.f || lam[1] != 0.f) return false;          // |zdot| / |eps^T J| cotangents: layer-wise path
     if (c.n_layers != L + 1) return false;
     for (int l = 0; l < L; ++l)
         if (c.acts[l] != CNF_ACT_TANH || c.widths[l + 1] != c.widths[1]) return false;
@@ -992,7 +991,7 @@ bool coop_grad_eligible(const cnf_config& c, const MfmaPlan* plan, const float l
 
 hipError_t coop_grad(LayeredGrad** ctx, const cnf_config& c, MfmaPlan* plan, const float* packed_dev, const size_t* w_off,
                      const size_t* b_off, const float* x, const float* eps, int alg, int nsteps, float t0, float t1, long long B,
-                     float lam3, float* grad, float* grad_x, float* logp_out, float* regs_out, hipStream_t st, std::string* err) {
+                     const float lam[3], float* grad, float* grad_x, float* logp_out, float* regs_out, hipStream_t st, std::string* err) {
     int HT, Lh, ZR, ACT;
     if (!mfma_plan_coop_shape(plan, &HT, &Lh, &ZR, &ACT)) { *err = "coop_grad: not a cooperative plan"; return hipErrorNotSupported; }
     if (!*ctx) *ctx = new LayeredGrad();
@@ -1034,6 +1033,7 @@ hipError_t coop_grad(LayeredGrad** ctx, const cnf_config& c, MfmaPlan* plan, con
     auto take = [&](long long n) { const long long o = off; off += (n + 63) / 64 * 64; return o; };
     const long long o_slab = take(npa_pad * nslab), o_slabN = take(szN_pad * nslabN);
     const long long o_zck = take((long long)(nsteps + 1) * ntp * 64 * ZR), o_kck = take((long long)nsteps * ns * ntp * 64 * ZR);
+    const long long o_gck = lam[1] != 0.f ? take((long long)nsteps * ns * ntp * 64 * ZR) : 0;
     const long long o_lam = take(ntp * 64 * ZR), o_zb = take(ntp * 64 * 6 * ZR), o_scr = take(scratch_stride * nblocks);
     // Y_l: H + 1 rows; a leading dimension that is a multiple of 16 floats keeps every 16-byte operand store inside one
     // 64-byte block (H + 1 itself puts 15 of 16 samples' row quads across two)
@@ -1062,18 +1062,18 @@ hipError_t coop_grad(LayeredGrad** ctx, const cnf_config& c, MfmaPlan* plan, con
     SolveArgs sa{};
     sa.x = x; sa.eps = eps; sa.B = B; sa.nsteps = nsteps; sa.alg = alg; sa.t0 = t0; sa.t1 = t1;
     sa.logp = logp_out; sa.regs = regs_out; sa.nvars = c.nvars; sa.reg_aug = (c.reg_aug && c.naug > 0) ? 1 : 0;
-    sa.ckpt = W + o_zck; sa.ckpt_k = W + o_kck;
+    sa.ckpt = W + o_zck; sa.ckpt_k = W + o_kck; sa.ckpt_g = lam[1] != 0.f ? W + o_gck : nullptr;
     LG_HIP(mfma_solve(plan, packed_dev, sa, st));
 
     // ---- reverse: one launch per step, then the step's weight-cotangent products ----
     // (The products of step n on a second stream under the sweep of step n - 1, operand arrays double-buffered, was measured:
     // cfg4 117 -> 131 ms.  Both kernels are bound by memory traffic and slow each other down by more than the overlap gains.)
     CGArgs a{};
-    a.packed = packed_dev; a.eps = eps; a.ckpt = W + o_zck; a.ckpt_k = W + o_kck; a.lam = W + o_lam; a.zb = W + o_zb; a.grad_x = grad_x;
+    a.packed = packed_dev; a.eps = eps; a.ckpt = W + o_zck; a.ckpt_k = W + o_kck; a.ckpt_g = sa.ckpt_g; a.lam = W + o_lam; a.zb = W + o_zb; a.grad_x = grad_x;
     a.scratch = W + o_scr; a.scratch_stride = scratch_stride;
     for (int l = 0; l < Lh; ++l) { a.xh[l] = W + o_xh[l]; a.yh[l] = W + o_yh[l]; }
     a.y1 = W + o_y1; a.xN = W + o_xN; a.ld_y1 = n_in + 1; a.ldy = ldy;
-    a.B = B; a.ntiles_pad = ntp; a.nsteps = nsteps; a.D = D; a.nvars = c.nvars; a.H = H; a.autonomous = c.autonomous; a.lam3 = lam3; a.T = T;
+    a.B = B; a.ntiles_pad = ntp; a.nsteps = nsteps; a.D = D; a.nvars = c.nvars; a.H = H; a.autonomous = c.autonomous; a.lam1 = lam[0]; a.lam2 = lam[1]; a.lam3 = lam[2]; a.T = T;
     const float dt = (t1 - t0) / (float)nsteps;
     for (int n = nsteps - 1; n >= 0; --n) {
         a.step = n; a.tn = t0 + (float)n * dt; a.dt = dt;

@@ -417,7 +417,7 @@ hipError_t mfma_solve(MfmaPlan* p, const float* packed_dev, const SolveArgs& s, 
     KArgs a{};
     a.packed = packed_dev;
     a.x = s.x; a.u0 = s.u0; a.eps = s.eps; a.ys = s.ys;
-    a.u_out = s.u_out; a.logp = s.logp; a.regs = s.regs; a.ckpt = s.ckpt; a.ckpt_k = s.ckpt_k; a.kfull = s.kfull;
+    a.u_out = s.u_out; a.logp = s.logp; a.regs = s.regs; a.ckpt = s.ckpt; a.ckpt_k = s.ckpt_k; a.kfull = s.kfull; a.ckpt_g = s.ckpt_g;
     a.B = s.B; a.nsteps = s.nsteps; a.t0 = s.t0;
     a.dt = s.nsteps > 0 ? (s.dt_exact != 0.f ? s.dt_exact : (s.t1 - s.t0) / (float)s.nsteps) : 0.f;
     a.nvars = s.nvars; a.D = p->cfg.nvars + p->cfg.naug; a.C = p->cfg.ncond;

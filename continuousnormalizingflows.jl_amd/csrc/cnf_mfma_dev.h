@@ -29,6 +29,7 @@ struct KArgs {
     float* ckpt_k;      // optional: stage derivatives zdot_i, [step * ns + stage][tile][lane][ZR] (gradient)
     Tableau T;
     float acol[6][5];   // acol[st][i] = T.a[st + 1 + i][st] (0 beyond the last stage): what stage st contributes to the stages after it
+    float* ckpt_g;      // optional (cooperative checkpointing solve): g = eps^T J of every stage, laid out like ckpt_k (gradient of |eps^T J|)
 };
 
 // Device-side step controller (mfma_adaptive_kernel): the whole adaptive Tsit5 solve of a batch that fits the chip's wave

@@ -647,6 +647,12 @@ COOP_GRAD_SHAPES = [
     (dict(nvars=8, hidden=[128, 128, 128]), 200, 1, 2, {}),                       # 3 x 128 (8 hidden tiles, 2 state k-steps)
     (dict(nvars=8, hidden=[64, 64, 64]), 130, 1, 3, {"CNF_MFMA_COOP": "1", "CNF_GRAD_LAYERED": "1"}),   # 3 x 64 forced onto it
     (dict(nvars=7, hidden=[128, 128, 128], autonomous=True), 90, 0, 2, {}),       # no time column
+    # the regularised objective (the reference's default lambdas are non-zero, src/core/icnf.jl:73-75): |zdot| and |eps^T J|
+    # cotangents from the forward solve's stage checkpoints
+    (dict(nvars=32, hidden=[256, 256, 256], reg_z=True, reg_j=True), 77, 0, 2, {"lam": (0.02, 0.03, 0.0)}),
+    (dict(nvars=20, naug=5, hidden=[200, 200, 200], reg_z=True, reg_j=True, reg_aug=True), 100, 1, 2, {"lam": (0.01, 0.01, 0.01)}),   # the reference's defaults
+    (dict(nvars=8, hidden=[128, 128, 128], reg_z=True), 70, 1, 2, {"lam": (0.05, 0.0, 0.0)}),        # |zdot| alone
+    (dict(nvars=8, hidden=[128, 128, 128], reg_j=True), 70, 0, 2, {"lam": (0.0, 0.05, 0.0)}),        # |eps^T J| alone
 ]
 
 
@@ -657,13 +663,16 @@ def test_parameter_gradient_cooperative_reverse_sweep(kw, B, alg, nsteps, env, p
     against fp64 autograd through the same discrete solve (src/core/icnf.jl:90-99 differentiates `loss` through the solve),
     and against the layer-wise path on the same inputs (CNF_COOP_GRAD=0)."""
     o64, _ = oracles
+    env = dict(env)
+    lam = env.pop("lam", None)
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     spec = o64.make_spec(**kw)
-    lam = (0.0, 0.0, 0.03 if spec.reg_aug else 0.0)
+    if lam is None:
+        lam = (0.0, 0.0, 0.03 if spec.reg_aug else 0.0)
     p, xs, eps, ys = o64.synth_inputs(spec, B, 321, bias_scale=0.2)
     L, gref, gxref = o64.loss_and_grad(spec, p, xs, 0.0, 1.0, nsteps, alg, eps, ys, lam, wrt_x=True)
-    mode = pkg.TrainMode(bool(spec.reg_aug))
+    mode = mode_of(pkg, spec)
     out = {}
     for tag, flag in (("coop", "1"), ("layered", "0")):
         monkeypatch.setenv("CNF_COOP_GRAD", flag)
