@@ -66,6 +66,9 @@ CONFIGS = {
              "RNODE nvars=8, MLP 3x64 tanh, Tsit5 40 steps, batch=65536, Hutchinson(4)"),
     "cfg4": (dict(nvars=32, hidden=[256, 256, 256]), 0, 32768, 2361344, 1632, 260,
              "FFJORD nvars=32, MLP 3x256 tanh, RK4 40 steps, batch=32768 per GPU, Hutchinson(1)"),
+    # (not a BASELINE configuration: cfg4's shape under the reference's default regularised objective, for the gradient timing)
+    "cfg4r": (dict(nvars=32, hidden=[256, 256, 256], reg_z=True, reg_j=True), 0, 32768, 2361344, 1632, 260,
+              "RNODE nvars=32, MLP 3x256 tanh, RK4 40 steps, batch=32768 per GPU, Hutchinson(1), |zdot| and |eps^T J| regularisers"),
     "cfg5": (dict(nvars=8, ncond=8, hidden=[128, 128, 128], mode=2), 0, 16384, 2393088, 480, 68,
              "CondFFJORD nvars=8+8 cond, MLP 3x128 tanh, exact trace, RK4 40 steps, batch=16384"),
 }
