@@ -31,8 +31,13 @@
 // runs, one row tile per sample, the same bytes cost 4 % more of the whole gradient), and the Y arrays' leading dimension is
 // padded to a multiple of 16 floats so that no store straddles a 64-byte block.
 //
-// Scope: Hutchinson VJP, one probe, no conditions, tanh, no |zdot| / |eps^T J| regularisers (FFJORD; l3 |z_aug| is in),
-// uniform steps, 2 or 3 hidden layers of one width: everything else stays on the layer-wise path.
+// REGULARISERS (the reference's default lambdas are non-zero, src/core/icnf.jl:73-75): the cotangents of Edot = |zdot| and
+// ndot = |eps^T J| need zdot_i and g_i = eps^T J of the stage - both are checkpoints of the forward solve (ckpt_k, ckpt_g) -
+// and enter as dense D-row operations of the owner wave: kbar += c_E zdot / |zdot|, gbar = -c_l eps + c_n g / |g|; the tangent
+// chain then starts from dbar_1 = W_1[:,0:D] gbar, the D-sized product the two-chain form runs anyway.
+//
+// Scope: Hutchinson VJP, one probe, no conditions, tanh, uniform steps, 2 or 3 hidden layers of one width: everything else
+// stays on the layer-wise path.
 #define CNF_NO_PK_ASM 1
 #define CNF_NO_PHASE_FENCE 1
 #include "cnf_coop_dev.h"
