@@ -362,7 +362,8 @@ template <int HT, int L, int ZR, int CR, int ACT, int NS>
 static hipError_t launch_coopx(const KArgs& a, int num_cus, hipStream_t st) {
     constexpr int DT = (ZR + 3) / 4, KGC = (CR + 3) / 4;
     constexpr int lds = (2 * HT * 2 * 64 + 2 * DT * 2 * 64 + KGC * 2 * 64) * 16;
-    static_assert(2 * lds <= 160 * 1024, "two workgroups per CU: exchange buffers exceed LDS");
+    // two workgroups per CU everywhere except HT = 16 with 16 state k-steps (82 KB: one workgroup per CU there)
+    static_assert(lds <= 160 * 1024 && (2 * lds <= 160 * 1024 || (HT == 16 && ZR == 16)), "exchange buffers exceed LDS");
     auto kern = coopx_solve_kernel<HT, L, ZR, CR, ACT, NS>;
     static DeviceOnce once;
     int dev = 0;
@@ -386,9 +387,11 @@ struct CoopXInst {
 };
 #define CX_INST(HT, L, ZR, CR, ACT) \
     CoopXInst { HT, L, ZR, CR, ACT, { &launch_coopx<HT, L, ZR, CR, ACT, 4>, &launch_coopx<HT, L, ZR, CR, ACT, 6> } }
-// zero-padded instances: hidden tiles 8 / 12 / 16 (H <= 128 / 192 / 256), 8 state k-steps (D <= 32), 0 or 4 condition k-steps
+// zero-padded instances: hidden tiles 8 / 12 / 16 (H <= 128 / 192 / 256), 8 or 16 state k-steps (D <= 32 / 64 - the reference's
+// default architecture has D = 2 nvariables + 1 and H = 4 (D + 1): nvariables 16 .. 30 land here), 0 or 4 condition k-steps
 // (C <= 16); tanh instances run pre-scaled pre-activations (mfma_pack folds -2 log2 e into the forward images)
-#define CX_SHAPES(HT, ACT) CX_INST(HT, 3, 8, 0, ACT), CX_INST(HT, 2, 8, 0, ACT), CX_INST(HT, 3, 8, 4, ACT), CX_INST(HT, 2, 8, 4, ACT)
+#define CX_SHAPES(HT, ACT) CX_INST(HT, 3, 8, 0, ACT), CX_INST(HT, 2, 8, 0, ACT), CX_INST(HT, 3, 8, 4, ACT), CX_INST(HT, 2, 8, 4, ACT), \
+                           CX_INST(HT, 3, 16, 0, ACT), CX_INST(HT, 2, 16, 0, ACT), CX_INST(HT, 3, 16, 4, ACT), CX_INST(HT, 2, 16, 4, ACT)
 static const CoopXInst kCoopX[] = {
     CX_SHAPES(8, CNF_ACT_TANH_PRESCALED), CX_SHAPES(12, CNF_ACT_TANH_PRESCALED), CX_SHAPES(16, CNF_ACT_TANH_PRESCALED),
     CX_SHAPES(8, CNF_ACT_SOFTPLUS), CX_SHAPES(12, CNF_ACT_SOFTPLUS), CX_SHAPES(16, CNF_ACT_SOFTPLUS),

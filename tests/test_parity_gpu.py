@@ -132,6 +132,12 @@ COOPX_CASES = [
     (dict(nvars=30, hidden=[256, 224, 256], mode=2, autonomous=True), 33, 0, 4),             # exact trace, D = 30 (30 unit probes), ragged widths, autonomous
     (dict(nvars=9, ncond=3, hidden=[176, 176, 176], mode=1, reg_z=True, reg_j=True), 60, 1, 6),   # Hutchinson JVP (|J eps|), conditioned, tanh (pre-scaled images undone)
     (dict(nvars=24, hidden=[144, 144], act=2, mode=1, nprobes=2, reg_j=True), 40, 0, 5),     # Hutchinson JVP, softplus, two probes, two layers
+    # 33 <= D <= 64 (16 state k-steps): the reference's default architecture for nvariables >= 16 (D = 2 nv + 1, H = 4 (D + 1), softplus)
+    (dict(nvars=16, naug=17, hidden=[136, 136], act=2, reg_z=True, reg_j=True, reg_aug=True), 70, 1, 6),   # ICNF(nvariables = 16)
+    (dict(nvars=24, naug=25, hidden=[200, 200], act=2, reg_z=True, reg_j=True, reg_aug=True), 40, 0, 6),   # ICNF(nvariables = 24): D = 49, H = 200
+    (dict(nvars=30, naug=31, ncond=6, hidden=[248, 248], act=2, reg_z=True, reg_j=True, reg_aug=True), 35, 1, 4),   # D = 61, H = 248, conditioned: 16 hidden tiles x 16 state k-steps (one workgroup per CU)
+    (dict(nvars=40, hidden=[192, 192, 192], reg_z=True, reg_j=True), 50, 0, 6),              # D = 40, tanh, three layers
+    (dict(nvars=36, hidden=[128, 128, 128], mode=1, reg_j=True), 40, 1, 4),                  # D = 36, Hutchinson JVP
 ]
 CASES = CASES + COOPX_CASES
 
