@@ -535,6 +535,12 @@ struct CkInst {
     CkInst { HT, L, ZR, { &launch_coop<HT, L, ZR, CNF_ACT_TANH_PRESCALED, 4, 4, false, true>, \
                           &launch_coop<HT, L, ZR, CNF_ACT_TANH_PRESCALED, 6, 4, false, true> } }
 static const CkInst kCk[] = {CK_INST(16, 3, 8), CK_INST(8, 3, 2), CK_INST(4, 3, 2)};
+bool coop_ckpt_supported(int HT, int L, int ZR, int ACT) {
+    if (ACT != CNF_ACT_TANH && ACT != CNF_ACT_TANH_PRESCALED) return false;
+    for (const CkInst& c : kCk)
+        if (c.HT == HT && c.L == L && c.ZR == ZR) return true;
+    return false;
+}
 hipError_t coop_launch_ckpt(int HT, int L, int ZR, int ACT, const KArgs& a, int num_cus, hipStream_t st) {
     if (ACT != CNF_ACT_TANH && ACT != CNF_ACT_TANH_PRESCALED) return hipErrorNotSupported;
     for (const CkInst& c : kCk)

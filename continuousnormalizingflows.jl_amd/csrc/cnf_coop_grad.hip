@@ -43,6 +43,16 @@
 #include "cnf_coop_dev.h"
 #include "cnf_coop_grad.h"
 
+// One translation unit per activation (compile time): this file builds the tanh instances and the shared host side;
+// cnf_coop_grad_softplus.hip includes it with CG_ACT_SOFTPLUS defined and contributes only its instance table.
+#ifdef CG_ACT_SOFTPLUS
+#define CG_ACT CNF_ACT_SOFTPLUS
+#define CG_TABLE_FN coop_grad_table_softplus
+#else
+#define CG_ACT CNF_ACT_TANH_PRESCALED
+#define CG_TABLE_FN coop_grad_table_tanh
+#endif
+
 // The operand arrays (read next by the weight-cotangent kernels) and the per-workgroup scratch are streams; written and
 // read with the non-temporal hint they stream past the L2 instead of evicting the 1.15 MB operand image every workgroup
 // re-reads for every product (-DCG_TEMPORAL restores plain accesses for an A/B).
@@ -75,8 +85,25 @@ namespace cnf {
 
 namespace {
 
-// d = act'(a) from h = tanh(a)  (act''(a) = -2 h d)
-__device__ __forceinline__ f32x4 tanh_d(const f32x4& h) { return 1.f - h * h; }
+// d = act'(a) from h = act(a):  tanh: 1 - h^2 (act'' = -2 h d);  softplus: h = log(1 + e^a), so e^-h = 1 / (1 + e^a) and
+// act' = sigmoid(a) = 1 - e^-h (act'' = d (1 - d))
+template <int ACT>
+__device__ __forceinline__ f32x4 act_d(const f32x4& h) {
+    if constexpr (ACT == CNF_ACT_SOFTPLUS) {
+        f32x4 d;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) d[j] = 1.f - __expf(-h[j]);
+        return d;
+    } else {
+        return 1.f - h * h;
+    }
+}
+// act''(a) from h and d = act'(a)
+template <int ACT>
+__device__ __forceinline__ f32x4 act_dd(const f32x4& h, const f32x4& d) {
+    if constexpr (ACT == CNF_ACT_SOFTPLUS) return d * (1.f - d);
+    else return h * d * -2.f;
+}
 // A product's k-loop in two parts, so that loads whose data is needed only AFTER the product (the scratch operands of the
 // elementwise phase that follows) can be requested behind the product's LAST fragment requests: they then return under its
 // final two k-groups instead of sitting in front of its fragment loads in the in-order vmcnt queue.
@@ -106,9 +133,9 @@ __device__ __forceinline__ void coop_gemm_tail(int KG, const f32x4 (&a0)[M], con
 
 // NT: sample tiles per super-tile (per chain); a product has CT = 2 NT column tiles
 template <int HT, int L, int ZR, int ACT, int NS, int NT>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NT == 1 ? 2 : 1, NT == 1 ? 2 : 1)))
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 coop_grad_step_kernel(CGArgs a) {
-    static_assert(ACT == CNF_ACT_TANH_PRESCALED, "tanh nets only (act' and act'' are rebuilt from h)");
+    static_assert(ACT == CNF_ACT_TANH_PRESCALED || ACT == CNF_ACT_SOFTPLUS, "act' and act'' are rebuilt from h: tanh and softplus");
     static_assert(L == 2 || L == 3, "two or three hidden layers");
     constexpr int SUP = 16 * NT, CT = 2 * NT;
     constexpr MfmaLayout LAY(HT, L, ZR, 0, true);
@@ -131,7 +158,7 @@ coop_grad_step_kernel(CGArgs a) {
     const __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P), 0, 0x7fffffff, 0x00020000);
     const unsigned lane16 = (unsigned)lane * 16u;
 #define AIMG(X) AImg{rP, (unsigned)(X) * 4u, lane16, nullptr}
-    const float inv_fs = 1.f / kTanhPrescale;
+    const float inv_fs = ACT == CNF_ACT_TANH_PRESCALED ? 1.f / kTanhPrescale : 1.f;   // the forward images of tanh nets carry the pre-scale
     const int ns = a.T.ns < NS ? a.T.ns : NS;
     const float dt = a.dt, tn = a.tn;
     const long long nsB = (long long)ns * B;
@@ -377,7 +404,7 @@ coop_grad_step_kernel(CGArgs a) {
                         f32x4 dd;
                         act_tile<ACT>(acc[m][q], h[m][q], dd);
                         db[m][q] = acc[m][NT + q] * inv_fs;                   // dbar_{l+1} = W_{l+1} vbar_l (dbar_1 = W_1[:,0:D] gbar)
-                        vb[m][q] = db[m][q] * tanh_d(h[m][q]);             // vbar_{l+1} (cbar at the top)
+                        vb[m][q] = db[m][q] * act_d<ACT>(h[m][q]);             // vbar_{l+1} (cbar at the top)
                     }
                 publish2(cur, h, vb);
                 if (l + 1 < L) {
@@ -408,9 +435,9 @@ coop_grad_step_kernel(CGArgs a) {
                     for (int m = 0; m < MTW; ++m)
 #pragma unroll
                         for (int q = 0; q < NT; ++q) {
-                            const f32x4 d = tanh_d(h[m][q]), c = t[m][q];
+                            const f32x4 d = act_d<ACT>(h[m][q]), c = t[m][q];
                             dl[m][q] = c * d;
-                            sb[m][q] = t[m][NT + q] * d + (db[m][q] * c) * (h[m][q] * d * -2.f);
+                            sb[m][q] = t[m][NT + q] * d + (db[m][q] * c) * act_dd<ACT>(h[m][q], d);
                         }
                     // own tiles of the Y_L pair have been stored by this wave (gstore waits for its LDS reads): overwrite them
                     publish2(cur, dl, sb);
@@ -447,10 +474,10 @@ coop_grad_step_kernel(CGArgs a) {
                 for (int m = 0; m < MTW; ++m)
 #pragma unroll
                     for (int q = 0; q < NT; ++q) {
-                        const f32x4 d = tanh_d(hl[m][q]), u = t[m][q];
+                        const f32x4 d = act_d<ACT>(hl[m][q]), u = t[m][q];
                         const f32x4 dbv = l == 1 ? dbl[m][q] * inv_fs : dbl[m][q];
                         dl[m][q] = u * d;
-                        sb[m][q] = t[m][NT + q] * d + (dbv * u) * (hl[m][q] * d * -2.f);
+                        sb[m][q] = t[m][NT + q] * d + (dbv * u) * act_dd<ACT>(hl[m][q], d);
                     }
                 publish2(cur, dl, sb);
                 gstore(cur, 0, rx[l - 1], vox, sx1);                          // delta_l half of X_l
@@ -493,12 +520,9 @@ coop_grad_step_kernel(CGArgs a) {
 // ---------------------------------------------------------------------------------------
 template <int HT, int L, int ZR, int ACT, int NS, int NT>
 static hipError_t launch_grad_step(const CGArgs& a, int num_cus, hipStream_t st) {
-    constexpr int DT = (ZR + 3) / 4, CT = 2 * NT;
-    constexpr int lds = (2 * HT * CT * 64 + (2 * DT * CT + DT * NT) * 64) * 16;
-    static_assert(lds * (NT == 1 ? 2 : 1) <= 160 * 1024, "exchange buffers exceed LDS");
-    const long long nst = (a.B + 16 * NT - 1) / (16 * NT);
-    const long long cap = (long long)num_cus * (NT == 1 ? 2 : 1);
-    const int nblocks = (int)(nst < cap ? nst : cap);
+    constexpr int lds = coop_grad_lds_bytes(HT, ZR, NT);
+    static_assert(lds <= 160 * 1024, "exchange buffers exceed LDS");
+    const int nblocks = coop_grad_nblocks(a.B, num_cus, HT, ZR);
     auto kern = coop_grad_step_kernel<HT, L, ZR, ACT, NS, NT>;
     static DeviceOnce once;
     int dev = 0;
@@ -513,45 +537,48 @@ static hipError_t launch_grad_step(const CGArgs& a, int num_cus, hipStream_t st)
     return hipGetLastError();
 }
 
-struct CoopGradInst {
-    int HT, L, ZR, ACT;
-    hipError_t (*fn[4])(const CGArgs&, int, hipStream_t);   // [0] RK4 (4 stages), [1] Tsit5 (6 stages); [2], [3]: NT = 2
-};
 #define CG_INST(HT, L, ZR) \
-    CoopGradInst { HT, L, ZR, CNF_ACT_TANH_PRESCALED, { &launch_grad_step<HT, L, ZR, CNF_ACT_TANH_PRESCALED, 4, 1>, \
-                                                        &launch_grad_step<HT, L, ZR, CNF_ACT_TANH_PRESCALED, 6, 1>, \
-                                                        &launch_grad_step<HT, L, ZR, CNF_ACT_TANH_PRESCALED, 4, 2>, \
-                                                        &launch_grad_step<HT, L, ZR, CNF_ACT_TANH_PRESCALED, 6, 2> } }
-// the same (HT, L, ZR) as the forward instances of cnf_coop.hip they pair with (the plan's packed image is shared)
-static const CoopGradInst kCoopGrad[] = {
-    CG_INST(16, 3, 8),   // cfg4: D = 32, 3 x 256
-    CG_INST(8, 3, 2),    // D <= 8, 3 x 128
-    CG_INST(4, 3, 2),    // D <= 8, 3 x 64: cross-check of the register-accumulator kernel (cnf_grad.hip)
-};
+    CoopGradInst { HT, L, ZR, CG_ACT, { &launch_grad_step<HT, L, ZR, CG_ACT, 4, 1>, &launch_grad_step<HT, L, ZR, CG_ACT, 6, 1> } }
+// the (HT, L, ZR) of the forward plans they pair with (the plan's packed image is shared): cnf_coop.hip's instances and the
+// unconditioned shapes of cnf_coop_x.hip (hidden tiles 8 / 12 / 16, 8 or 16 state k-steps)
+#define CG_XSHAPES(HT) CG_INST(HT, 3, 8), CG_INST(HT, 2, 8), CG_INST(HT, 3, 16), CG_INST(HT, 2, 16)
+const CoopGradInst* CG_TABLE_FN(int* n) {
+    static const CoopGradInst table[] = {
+#ifndef CG_ACT_SOFTPLUS
+        CG_INST(8, 3, 2),    // D <= 8, 3 x 128
+        CG_INST(4, 3, 2),    // D <= 8, 3 x 64: cross-check of the register-accumulator kernel (cnf_grad.hip)
+#endif
+        CG_XSHAPES(8), CG_XSHAPES(12), CG_XSHAPES(16),   // (16, 3, 8) is cfg4: D = 32, 3 x 256
+    };
+    *n = (int)(sizeof(table) / sizeof(table[0]));
+    return table;
+}
 
+#ifndef CG_ACT_SOFTPLUS
 static const CoopGradInst* cg_find(int HT, int L, int ZR, int ACT) {
-    for (const CoopGradInst& c : kCoopGrad)
-        if (c.HT == HT && c.L == L && c.ZR == ZR && (ACT == CNF_ACT_TANH || ACT == CNF_ACT_TANH_PRESCALED)) return &c;
+    int n = 0;
+    const bool sp = ACT == CNF_ACT_SOFTPLUS;
+    if (!sp && ACT != CNF_ACT_TANH && ACT != CNF_ACT_TANH_PRESCALED) return nullptr;
+    const CoopGradInst* t = sp ? coop_grad_table_softplus(&n) : coop_grad_table_tanh(&n);
+    for (int i = 0; i < n; ++i)
+        if (t[i].HT == HT && t[i].L == L && t[i].ZR == ZR) return &t[i];
     return nullptr;
 }
 
 bool coop_grad_supported(int HT, int L, int ZR, int ACT) { return cg_find(HT, L, ZR, ACT) != nullptr; }
 int coop_grad_scratch_slots(int L) { return 2 * L - 3; }   // h_1 .. h_{L-1}, dbar_2 .. dbar_{L-1}
-// workgroups of a launch (16-sample super-tiles, two workgroups per CU): the host sizes the per-workgroup scratch with it
-int coop_grad_nt() {
-    static const int nt = [] { const char* e = getenv("CNF_CG_NT"); return (e && atoi(e) == 2) ? 2 : 1; }();
-    return nt;
-}
-int coop_grad_nblocks(long long B, int num_cus) {
-    const int nt = coop_grad_nt();
-    const long long nst = (B + 16 * nt - 1) / (16 * nt), cap = (long long)num_cus * (nt == 1 ? 2 : 1);
+// workgroups of a launch (16-sample super-tiles; two workgroups per CU where two sets of exchange buffers fit): the host sizes
+// the per-workgroup scratch with it
+int coop_grad_nblocks(long long B, int num_cus, int HT, int ZR) {
+    const long long nst = (B + 15) / 16, cap = (long long)num_cus * (2 * coop_grad_lds_bytes(HT, ZR, 1) <= 160 * 1024 ? 2 : 1);
     return (int)(nst < cap ? nst : cap);
 }
 
 hipError_t coop_grad_step_launch(int HT, int L, int ZR, int ACT, const CGArgs& a, int num_cus, hipStream_t st) {
     const CoopGradInst* c = cg_find(HT, L, ZR, ACT);
     if (!c) return hipErrorNotSupported;
-    return c->fn[(a.T.ns <= 4 ? 0 : 1) + (coop_grad_nt() == 2 ? 2 : 0)](a, num_cus, st);
+    return c->fn[a.T.ns <= 4 ? 0 : 1](a, num_cus, st);
 }
+#endif
 
 }  // namespace cnf

@@ -24,7 +24,7 @@ template <int HT, int L, int ZR, int CR, int ACT>
 __device__ __forceinline__ void coopx_eval(const float* __restrict__ P, f32x4* xbuf, f32x4* zbuf, f32x4* ebuf, const f32x4* ybuf,
                                            int lane, int wave, float t, bool autonomous, bool reg_z, bool reg_j, bool exact, bool jvp,
                                            int D, int K, const float* __restrict__ eps_col, const float (&zs)[ZR], float (&zd)[ZR],
-                                           float& ld, float& ed, float& nd) {
+                                           float& ld, float& ed, float& nd, float* __restrict__ gout = nullptr) {
     constexpr int NT = 2;
     constexpr MfmaLayout LAY(HT, L, ZR, CR, true);
     constexpr int MTW = HT / 4, DT = (ZR + 3) / 4, KGC = (CR + 3) / 4, XB = HT * NT * 64;
@@ -220,6 +220,10 @@ __device__ __forceinline__ void coopx_eval(const float* __restrict__ P, f32x4* x
                 }
                 ld -= scale * group_sum(dot);
                 if (reg_j) nd += scale * sqrtf(group_sum(n2));   // ndot = |eps^T J|_2 (icnf.jl:229-245)
+                if (gout) {   // checkpointing solve (one probe): g = eps^T J of this stage for the reverse sweep
+#pragma unroll
+                    for (int s = 0; s < ZR; ++s) gout[s] = gacc[s >> 2][0][s & 3];
+                }
             }
         }
     }
@@ -286,9 +290,15 @@ coopx_solve_kernel(KArgs a) {
         const bool single = a.nsteps == 0;
         const int ns = single ? 1 : (a.T.ns < NS ? a.T.ns : NS);
         const int nsteps = single ? 1 : a.nsteps;
+        // checkpoints for the cooperative gradient (KArgs::ckpt / ckpt_k / ckpt_g; tile = 16-sample tile index, nst NT of them)
+        const long long cktile = st * NT + (owner ? wave : 0), ckntp = nst * NT;
 #pragma clang loop unroll(disable)
         for (int step = 0; step < nsteps; ++step) {
             const float tn = a.t0 + (float)step * dt;
+            if (a.ckpt && owner && !single) {
+#pragma unroll
+                for (int s = 0; s < ZR; ++s) a.ckpt[(((long long)step * ckntp + cktile) * 64 + lane) * ZR + s] = z[s];
+            }
             lsum = esum = nsum = 0.f;
 #pragma unroll
             for (int s = 0; s < ZR; ++s) {
@@ -301,8 +311,13 @@ coopx_solve_kernel(KArgs a) {
                 float zs[ZR];
 #pragma unroll
                 for (int s = 0; s < ZR; ++s) zs[s] = fmaf(dt, Pz[0][s], z[s]);
+                float* gout = (a.ckpt_g && owner && !single) ? a.ckpt_g + ((((long long)step * ns + sg) * ckntp + cktile) * 64 + lane) * ZR : nullptr;
                 coopx_eval<HT, L, ZR, CR, ACT>(a.packed, xbuf, zbuf, ebuf, ybuf, lane, wave, tn + a.T.c[sg] * dt, autonomous, reg_z, reg_j,
-                                                exact, jvp, D, K, eps_col, zs, zd, ld, ed, nd);
+                                                exact, jvp, D, K, eps_col, zs, zd, ld, ed, nd, gout);
+                if (a.ckpt_k && owner && !single) {
+#pragma unroll
+                    for (int s = 0; s < ZR; ++s) a.ckpt_k[((((long long)step * ns + sg) * ckntp + cktile) * 64 + lane) * ZR + s] = zd[s];
+                }
                 const float bst = a.T.b[sg];
                 lsum = fmaf(bst, ld, lsum); esum = fmaf(bst, ed, esum); nsum = fmaf(bst, nd, nsum);
 #pragma unroll
@@ -317,6 +332,10 @@ coopx_solve_kernel(KArgs a) {
             lacc = fmaf(dt, lsum, lacc); eacc = fmaf(dt, esum, eacc); nacc = fmaf(dt, nsum, nacc);
 #pragma unroll
             for (int s = 0; s < ZR; ++s) z[s] = fmaf(dt, zsum[s], z[s]);
+        }
+        if (a.ckpt && owner && !single) {
+#pragma unroll
+            for (int s = 0; s < ZR; ++s) a.ckpt[(((long long)nsteps * ckntp + cktile) * 64 + lane) * ZR + s] = z[s];
         }
         if (single) {
             if (valid) {

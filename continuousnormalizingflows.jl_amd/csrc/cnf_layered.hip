@@ -978,12 +978,12 @@ __global__ void fill_rows_kernel(float* __restrict__ a, int ld, int row0, int ro
 
 bool coop_grad_eligible(const cnf_config& c, const MfmaPlan* plan, const float lam[3], const float* tgrid) {
     int HT, L, ZR, ACT;
-    if (!mfma_plan_coop_shape(plan, &HT, &L, &ZR, &ACT)) return false;
+    if (!mfma_plan_coop_grad_shape(plan, &HT, &L, &ZR, &ACT)) return false;
     if (const char* e = getenv("CNF_COOP_GRAD")) { if (*e == '0') return false; }
     if (c.mode != CNF_MODE_HUTCH_VJP || c.nprobes != 1 || c.ncond != 0 || tgrid) return false;
     if (c.n_layers != L + 1) return false;
     for (int l = 0; l < L; ++l)
-        if (c.acts[l] != CNF_ACT_TANH || c.widths[l + 1] != c.widths[1]) return false;
+        if ((c.acts[l] != CNF_ACT_TANH && c.acts[l] != CNF_ACT_SOFTPLUS) || c.acts[l] != c.acts[0] || c.widths[l + 1] != c.widths[1]) return false;
     if (c.acts[L] != CNF_ACT_IDENTITY) return false;
     if (c.widths[1] % 4 != 0) return false;                   // 16-byte row quads of the operand arrays
     return coop_grad_supported(HT, L, ZR, ACT) && lg_wgrad_supported(c.widths[1], c.widths[1] + 1);
@@ -993,7 +993,7 @@ hipError_t coop_grad(LayeredGrad** ctx, const cnf_config& c, MfmaPlan* plan, con
                      const size_t* b_off, const float* x, const float* eps, int alg, int nsteps, float t0, float t1, long long B,
                      const float lam[3], float* grad, float* grad_x, float* logp_out, float* regs_out, hipStream_t st, std::string* err) {
     int HT, Lh, ZR, ACT;
-    if (!mfma_plan_coop_shape(plan, &HT, &Lh, &ZR, &ACT)) { *err = "coop_grad: not a cooperative plan"; return hipErrorNotSupported; }
+    if (!mfma_plan_coop_grad_shape(plan, &HT, &Lh, &ZR, &ACT)) { *err = "coop_grad: not a cooperative plan"; return hipErrorNotSupported; }
     if (!*ctx) *ctx = new LayeredGrad();
     LayeredGrad& G = **ctx;
     if (G.num_cus == 0) {
@@ -1024,10 +1024,10 @@ hipError_t coop_grad(LayeredGrad** ctx, const cnf_config& c, MfmaPlan* plan, con
     long long kcN = 0;
     const int nslabN = lg_wgrad_chunks(D, B2, G.num_cus, &kcN, 4, H + 1);
     const long long szN = (long long)D * (H + 1), szN_pad = (szN + 63) / 64 * 64;
-    const long long nst = (B + 63) / 64, ntp = nst * 4;
-    const int nblocks = coop_grad_nblocks(B, G.num_cus);
+    const long long ntp = mfma_plan_ckpt_tiles(plan, B);
+    const int nblocks = coop_grad_nblocks(B, G.num_cus, HT, ZR);
     const int slots = coop_grad_scratch_slots(Lh);
-    const long long scratch_stride = (long long)(slots > 0 ? slots : 1) * HT * 256 * coop_grad_nt();   // slots x (HT x NT tiles x 64 lanes x 4) floats
+    const long long scratch_stride = (long long)(slots > 0 ? slots : 1) * HT * 256;   // slots x (HT tiles x 64 lanes x 4) floats
 
     long long off = 0;
     auto take = [&](long long n) { const long long o = off; off += (n + 63) / 64 * 64; return o; };

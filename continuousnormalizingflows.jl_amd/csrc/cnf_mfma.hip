@@ -384,6 +384,19 @@ bool mfma_plan_coop_shape(const MfmaPlan* p, int* HT, int* L, int* ZR, int* ACT)
     *HT = p->HT; *L = p->L; *ZR = p->ZR; *ACT = p->ACT;
     return true;
 }
+// a plan whose forward solve can checkpoint for the cooperative gradient: the cooperative kernel, or its extended form in the
+// unconditioned one-probe VJP configuration (same layout family: MfmaLayout(HT, L, ZR, 0, true))
+bool mfma_plan_coop_grad_shape(const MfmaPlan* p, int* HT, int* L, int* ZR, int* ACT) {
+    if (mfma_plan_coop_shape(p, HT, L, ZR, ACT)) return true;
+    if (!p || p->kind != 2 || p->CR != 0 || p->KP != 1 || p->cfg.mode != CNF_MODE_HUTCH_VJP) return false;
+    *HT = p->HT; *L = p->L; *ZR = p->ZR; *ACT = p->ACT;
+    return true;
+}
+// 16-sample tiles of the checkpoint arrays such a solve writes (the kernel's super-tile count x its tiles per super-tile)
+long long mfma_plan_ckpt_tiles(const MfmaPlan* p, long long B) {
+    const bool x = p->kind == 2 || !coop_ckpt_supported(p->HT, p->L, p->ZR, p->ACT);   // which kernel checkpoints: see mfma_solve
+    return x ? (B + 31) / 32 * 2 : (B + 63) / 64 * 4;
+}
 bool mfma_plan_is_per_wave(const MfmaPlan* p) { return p->kind == 0; }
 
 // plain f32 image (forward + transposed, no tanh pre-scale) for a given layout: the gradient kernels' operand image
@@ -444,7 +457,10 @@ hipError_t mfma_solve(MfmaPlan* p, const float* packed_dev, const SolveArgs& s, 
     }
     if (p->kind == 1) {
         // with checkpoint buffers: the checkpointing form of the cooperative solve (the forward half of cnf_coop_grad.hip)
-        if (s.ckpt) return coop_launch_ckpt(p->HT, p->L, p->ZR, p->ACT, a, mp->num_cus, st);
+        // (shapes without a checkpointing instance of this kernel checkpoint through the extended kernel, which runs on the same
+        // packed image - MfmaLayout(HT, L, ZR, 0, true) - and checkpoints at run time)
+        if (s.ckpt) return coop_ckpt_supported(p->HT, p->L, p->ZR, p->ACT) ? coop_launch_ckpt(p->HT, p->L, p->ZR, p->ACT, a, mp->num_cus, st)
+                                                                            : coopx_launch(p->HT, p->L, p->ZR, 0, p->ACT, a, mp->num_cus, st);
         return coop_launch(p->HT, p->L, p->ZR, p->ACT, a, mp->num_cus, st);
     }
     const long long ntiles = (s.B + 15) / 16;

@@ -659,6 +659,13 @@ COOP_GRAD_SHAPES = [
     (dict(nvars=20, naug=5, hidden=[200, 200, 200], reg_z=True, reg_j=True, reg_aug=True), 100, 1, 2, {"lam": (0.01, 0.01, 0.01)}),   # the reference's defaults
     (dict(nvars=8, hidden=[128, 128, 128], reg_z=True), 70, 1, 2, {"lam": (0.05, 0.0, 0.0)}),        # |zdot| alone
     (dict(nvars=8, hidden=[128, 128, 128], reg_j=True), 70, 0, 2, {"lam": (0.0, 0.05, 0.0)}),        # |eps^T J| alone
+    # forward solve on the extended cooperative kernel in its checkpointing form: softplus, two hidden layers, 33 <= D <= 64 -
+    # the reference's default architecture for nvariables >= 16 under its default objective
+    (dict(nvars=16, naug=17, hidden=[136, 136], act=2, reg_z=True, reg_j=True, reg_aug=True), 70, 1, 2, {"lam": (0.01, 0.01, 0.01)}),   # ICNF(nvariables = 16)
+    (dict(nvars=24, naug=25, hidden=[200, 200], act=2, reg_z=True, reg_j=True, reg_aug=True), 45, 0, 2, {"lam": (0.01, 0.01, 0.01)}),   # ICNF(nvariables = 24): 16 x 16 tiles
+    (dict(nvars=40, hidden=[192, 192, 192]), 50, 0, 2, {}),                       # tanh, D = 40, three layers
+    (dict(nvars=12, hidden=[160, 160], act=2), 60, 1, 2, {}),                     # softplus, two layers, D <= 32
+    (dict(nvars=10, hidden=[176, 176]), 40, 0, 3, {}),                            # tanh, two layers
 ]
 
 
