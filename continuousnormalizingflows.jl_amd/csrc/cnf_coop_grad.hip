@@ -133,7 +133,10 @@ __device__ __forceinline__ void coop_gemm_tail(int KG, const f32x4 (&a0)[M], con
 
 // NT: sample tiles per super-tile (per chain); a product has CT = 2 NT column tiles
 template <int HT, int L, int ZR, int ACT, int NS, int NT>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+// (two workgroups per CU - two waves per SIMD, 256 registers each - where two sets of exchange buffers fit the LDS; one with the
+// whole register file otherwise: 16 hidden tiles x 16 state k-steps)
+__global__ void __launch_bounds__(256)
+    __attribute__((amdgpu_waves_per_eu(2 * coop_grad_lds_bytes(HT, ZR, NT) <= 160 * 1024 ? 2 : 1, 2 * coop_grad_lds_bytes(HT, ZR, NT) <= 160 * 1024 ? 2 : 1)))
 coop_grad_step_kernel(CGArgs a) {
     static_assert(ACT == CNF_ACT_TANH_PRESCALED || ACT == CNF_ACT_SOFTPLUS, "act' and act'' are rebuilt from h: tanh and softplus");
     static_assert(L == 2 || L == 3, "two or three hidden layers");

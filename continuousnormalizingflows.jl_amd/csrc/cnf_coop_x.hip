@@ -230,8 +230,12 @@ __device__ __forceinline__ void coopx_eval(const float* __restrict__ P, f32x4* x
 #undef AIMG
 }
 
+constexpr int coopx_lds_bytes(int HT, int ZR, int CR) { return (2 * HT * 2 * 64 + 2 * ((ZR + 3) / 4) * 2 * 64 + ((CR + 3) / 4) * 2 * 64) * 16; }
+// (two workgroups per CU, two waves per SIMD at 256 registers, where two sets of exchange buffers fit the LDS; otherwise - 16
+// hidden tiles x 16 state k-steps - one workgroup with the whole register file)
 template <int HT, int L, int ZR, int CR, int ACT, int NS>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+__global__ void __launch_bounds__(256)
+    __attribute__((amdgpu_waves_per_eu(2 * coopx_lds_bytes(HT, ZR, CR) <= 160 * 1024 ? 2 : 1, 2 * coopx_lds_bytes(HT, ZR, CR) <= 160 * 1024 ? 2 : 1)))
 coopx_solve_kernel(KArgs a) {
     constexpr int NT = 2;
     constexpr int DT = (ZR + 3) / 4, KGC = (CR + 3) / 4, XB = HT * NT * 64;
@@ -379,8 +383,7 @@ coopx_solve_kernel(KArgs a) {
 // ---------------------------------------------------------------------------------------
 template <int HT, int L, int ZR, int CR, int ACT, int NS>
 static hipError_t launch_coopx(const KArgs& a, int num_cus, hipStream_t st) {
-    constexpr int DT = (ZR + 3) / 4, KGC = (CR + 3) / 4;
-    constexpr int lds = (2 * HT * 2 * 64 + 2 * DT * 2 * 64 + KGC * 2 * 64) * 16;
+    constexpr int lds = coopx_lds_bytes(HT, ZR, CR);
     // two workgroups per CU everywhere except HT = 16 with 16 state k-steps (82 KB: one workgroup per CU there)
     static_assert(lds <= 160 * 1024 && (2 * lds <= 160 * 1024 || (HT == 16 && ZR == 16)), "exchange buffers exceed LDS");
     auto kern = coopx_solve_kernel<HT, L, ZR, CR, ACT, NS>;
