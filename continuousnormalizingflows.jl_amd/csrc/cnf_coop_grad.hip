@@ -552,6 +552,7 @@ const CoopGradInst* CG_TABLE_FN(int* n) {
         CG_INST(4, 3, 2),    // D <= 8, 3 x 64: cross-check of the register-accumulator kernel (cnf_grad.hip)
 #endif
         CG_XSHAPES(8), CG_XSHAPES(12), CG_XSHAPES(16),   // (16, 3, 8) is cfg4: D = 32, 3 x 256
+        CG_INST(20, 3, 24), CG_INST(20, 2, 24), CG_INST(24, 3, 24), CG_INST(24, 2, 24),   // H <= 320 / 384, D <= 96
     };
     *n = (int)(sizeof(table) / sizeof(table[0]));
     return table;

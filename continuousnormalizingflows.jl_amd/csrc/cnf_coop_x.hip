@@ -384,8 +384,7 @@ coopx_solve_kernel(KArgs a) {
 template <int HT, int L, int ZR, int CR, int ACT, int NS>
 static hipError_t launch_coopx(const KArgs& a, int num_cus, hipStream_t st) {
     constexpr int lds = coopx_lds_bytes(HT, ZR, CR);
-    // two workgroups per CU everywhere except HT = 16 with 16 state k-steps (82 KB: one workgroup per CU there)
-    static_assert(lds <= 160 * 1024 && (2 * lds <= 160 * 1024 || (HT == 16 && ZR == 16)), "exchange buffers exceed LDS");
+    static_assert(lds <= 160 * 1024, "exchange buffers exceed LDS");
     auto kern = coopx_solve_kernel<HT, L, ZR, CR, ACT, NS>;
     static DeviceOnce once;
     int dev = 0;
@@ -414,9 +413,13 @@ struct CoopXInst {
 // (C <= 16); tanh instances run pre-scaled pre-activations (mfma_pack folds -2 log2 e into the forward images)
 #define CX_SHAPES(HT, ACT) CX_INST(HT, 3, 8, 0, ACT), CX_INST(HT, 2, 8, 0, ACT), CX_INST(HT, 3, 8, 4, ACT), CX_INST(HT, 2, 8, 4, ACT), \
                            CX_INST(HT, 3, 16, 0, ACT), CX_INST(HT, 2, 16, 0, ACT), CX_INST(HT, 3, 16, 4, ACT), CX_INST(HT, 2, 16, 4, ACT)
+// beyond 256 hidden units / 64 state rows: 20 or 24 hidden tiles (H <= 320 / 384) x 24 state k-steps (D <= 96), unconditioned; one
+// workgroup per CU (120 KB of exchange buffers), one wave per SIMD with the whole register file
+#define CX_BIG(HT, ACT) CX_INST(HT, 3, 24, 0, ACT), CX_INST(HT, 2, 24, 0, ACT)
 static const CoopXInst kCoopX[] = {
     CX_SHAPES(8, CNF_ACT_TANH_PRESCALED), CX_SHAPES(12, CNF_ACT_TANH_PRESCALED), CX_SHAPES(16, CNF_ACT_TANH_PRESCALED),
     CX_SHAPES(8, CNF_ACT_SOFTPLUS), CX_SHAPES(12, CNF_ACT_SOFTPLUS), CX_SHAPES(16, CNF_ACT_SOFTPLUS),
+    CX_BIG(20, CNF_ACT_TANH_PRESCALED), CX_BIG(24, CNF_ACT_TANH_PRESCALED), CX_BIG(20, CNF_ACT_SOFTPLUS), CX_BIG(24, CNF_ACT_SOFTPLUS),
 };
 
 static const CoopXInst* cx_find(int HT, int L, int ZR, int CR, int ACT) {

@@ -138,6 +138,9 @@ COOPX_CASES = [
     (dict(nvars=30, naug=31, ncond=6, hidden=[248, 248], act=2, reg_z=True, reg_j=True, reg_aug=True), 35, 1, 4),   # D = 61, H = 248, conditioned: 16 hidden tiles x 16 state k-steps (one workgroup per CU)
     (dict(nvars=40, hidden=[192, 192, 192], reg_z=True, reg_j=True), 50, 0, 6),              # D = 40, tanh, three layers
     (dict(nvars=36, hidden=[128, 128, 128], mode=1, reg_j=True), 40, 1, 4),                  # D = 36, Hutchinson JVP
+    # beyond 256 hidden units / 64 state rows: 20 / 24 hidden tiles x 24 state k-steps
+    (dict(nvars=32, naug=33, hidden=[264, 264], act=2, reg_z=True, reg_j=True, reg_aug=True), 40, 1, 4),   # ICNF(nvariables = 32): D = 65, H = 264
+    (dict(nvars=70, hidden=[352, 352, 352], reg_z=True, reg_j=True), 33, 0, 4),              # tanh, three layers, D = 70, H = 352
 ]
 CASES = CASES + COOPX_CASES
 
@@ -666,6 +669,8 @@ COOP_GRAD_SHAPES = [
     (dict(nvars=40, hidden=[192, 192, 192]), 50, 0, 2, {}),                       # tanh, D = 40, three layers
     (dict(nvars=12, hidden=[160, 160], act=2), 60, 1, 2, {}),                     # softplus, two layers, D <= 32
     (dict(nvars=10, hidden=[176, 176]), 40, 0, 3, {}),                            # tanh, two layers
+    (dict(nvars=32, naug=33, hidden=[264, 264], act=2, reg_z=True, reg_j=True, reg_aug=True), 40, 1, 2, {"lam": (0.01, 0.01, 0.01)}),   # ICNF(nvariables = 32): 20 x 24 tiles
+    (dict(nvars=80, hidden=[384, 384, 384]), 36, 0, 2, {}),                       # tanh, D = 80, H = 384 (24 x 24 tiles)
 ]
 
 
