@@ -150,7 +150,7 @@ static int loss_grad_impl(cnf_handle* h, const char* who, int alg, int nsteps, f
             // wide hidden layers on the cooperative kernels: checkpointing forward solve (which also yields the loss terms),
             // one reverse-sweep launch per step, deferred weight-cotangent products (cnf_coop_grad.hip)
             float* cg_logp = sums4 ? h->grad_ws : nullptr;
-            hipError_t e = coop_grad(&h->layered, h->cfg, h->plan, h->packed_dev, h->w_off.data(), h->b_off.data(), x, eps, alg, nsteps,
+            hipError_t e = coop_grad(&h->layered, h->cfg, h->plan, h->packed_dev, h->w_off.data(), h->b_off.data(), x, eps, ys, alg, nsteps,
                                      t0, t1, B, lam, grad, grad_x, cg_logp, cg_logp ? cg_logp + B : nullptr, st, &msg);
             if (e != hipSuccess) return fail(CNF_ERR_HIP, w + ": " + msg);
             if (sums4) HIP_TRY(loss_sums(cg_logp, cg_logp + B, B, h->loss_partial, sums4, st));

@@ -11,6 +11,8 @@ namespace cnf {
 struct CGArgs {
     const float* packed;      // the cooperative plan's operand image (forward images carry the tanh pre-scale)
     const float* eps;         // D x B
+    const float* ys;          // C x B conditions or null
+    int C;
     const float* ckpt;        // z at the start of every step and after the last: [step][tile][lane][ZR] (forward kernel, CK form)
     const float* ckpt_k;      // stage derivatives: [step * ns + stage][tile][lane][ZR]
     const float* ckpt_g;      // g = eps^T J of every stage, same layout (read when lam2 != 0)
@@ -35,19 +37,19 @@ struct CGArgs {
 };
 
 // LDS of one workgroup: two exchange buffers [HT][2 NT column tiles][64 lanes] + [z | gbar], [eps | kbar] and gbar images
-constexpr int coop_grad_lds_bytes(int HT, int ZR, int NT) {
-    return (2 * HT * 2 * NT * 64 + (2 * ((ZR + 3) / 4) * 2 * NT + ((ZR + 3) / 4) * NT) * 64) * 16;
+constexpr int coop_grad_lds_bytes(int HT, int ZR, int NT, int CR = 0) {   // (+ the condition image)
+    return (2 * HT * 2 * NT * 64 + (2 * ((ZR + 3) / 4) * 2 * NT + ((ZR + 3) / 4) * NT + ((CR + 3) / 4) * NT) * 64) * 16;
 }
 struct CoopGradInst {
-    int HT, L, ZR, ACT;
+    int HT, L, ZR, CR, ACT;
     hipError_t (*fn[2])(const CGArgs&, int, hipStream_t);   // [0] RK4 (4 stages), [1] Tsit5 (6 stages)
 };
 const CoopGradInst* coop_grad_table_tanh(int* n);       // cnf_coop_grad.hip
 const CoopGradInst* coop_grad_table_softplus(int* n);   // cnf_coop_grad_softplus.hip
-bool coop_grad_supported(int HT, int L, int ZR, int ACT);
+bool coop_grad_supported(int HT, int L, int ZR, int CR, int ACT);
 int coop_grad_scratch_slots(int L);   // one chain's tile set ([HT] tiles) each, per workgroup
-int coop_grad_nblocks(long long B, int num_cus, int HT, int ZR);   // workgroups of a launch (each owns `scratch_stride` floats of scratch)
-hipError_t coop_grad_step_launch(int HT, int L, int ZR, int ACT, const CGArgs& a, int num_cus, hipStream_t st);
+int coop_grad_nblocks(long long B, int num_cus, int HT, int ZR, int CR = 0);   // workgroups of a launch (each owns `scratch_stride` floats of scratch)
+hipError_t coop_grad_step_launch(int HT, int L, int ZR, int CR, int ACT, const CGArgs& a, int num_cus, hipStream_t st);
 // the cooperative forward solve with step / stage checkpoints in tile layout (cnf_coop.hip)
 bool coop_ckpt_supported(int HT, int L, int ZR, int ACT);
 hipError_t coop_launch_ckpt(int HT, int L, int ZR, int ACT, const KArgs& a, int num_cus, hipStream_t st);

@@ -36,8 +36,9 @@
 // and enter as dense D-row operations of the owner wave: kbar += c_E zdot / |zdot|, gbar = -c_l eps + c_n g / |g|; the tangent
 // chain then starts from dbar_1 = W_1[:,0:D] gbar, the D-sized product the two-chain form runs anyway.
 //
-// Scope: Hutchinson VJP, one probe, no conditions, tanh, uniform steps, 2 or 3 hidden layers of one width: everything else
-// stays on the layer-wise path.
+// Scope: Hutchinson VJP, one probe, tanh or softplus, uniform steps, 2 or 3 hidden layers of one width, up to 16 conditions
+// (the condition rows of layer 1 are one more small product per stage; their cotangent rides in the W_1 operand array):
+// everything else stays on the layer-wise path.
 #define CNF_NO_PK_ASM 1
 #define CNF_NO_PHASE_FENCE 1
 #include "cnf_coop_dev.h"
@@ -132,17 +133,17 @@ __device__ __forceinline__ void coop_gemm_tail(int KG, const f32x4 (&a0)[M], con
 }  // namespace
 
 // NT: sample tiles per super-tile (per chain); a product has CT = 2 NT column tiles
-template <int HT, int L, int ZR, int ACT, int NS, int NT>
+template <int HT, int L, int ZR, int CR, int ACT, int NS, int NT>
 // (two workgroups per CU - two waves per SIMD, 256 registers each - where two sets of exchange buffers fit the LDS; one with the
 // whole register file otherwise: 16 hidden tiles x 16 state k-steps)
 __global__ void __launch_bounds__(256)
-    __attribute__((amdgpu_waves_per_eu(2 * coop_grad_lds_bytes(HT, ZR, NT) <= 160 * 1024 ? 2 : 1, 2 * coop_grad_lds_bytes(HT, ZR, NT) <= 160 * 1024 ? 2 : 1)))
+    __attribute__((amdgpu_waves_per_eu(2 * coop_grad_lds_bytes(HT, ZR, NT, CR) <= 160 * 1024 ? 2 : 1, 2 * coop_grad_lds_bytes(HT, ZR, NT, CR) <= 160 * 1024 ? 2 : 1)))
 coop_grad_step_kernel(CGArgs a) {
     static_assert(ACT == CNF_ACT_TANH_PRESCALED || ACT == CNF_ACT_SOFTPLUS, "act' and act'' are rebuilt from h: tanh and softplus");
     static_assert(L == 2 || L == 3, "two or three hidden layers");
     constexpr int SUP = 16 * NT, CT = 2 * NT;
-    constexpr MfmaLayout LAY(HT, L, ZR, 0, true);
-    constexpr int MTW = HT / 4, DT = (ZR + 3) / 4, XB = HT * CT * 64, DB2 = DT * CT * 64;
+    constexpr MfmaLayout LAY(HT, L, ZR, CR, true);
+    constexpr int MTW = HT / 4, DT = (ZR + 3) / 4, KGC = (CR + 3) / 4, XB = HT * CT * 64, DB2 = DT * CT * 64;
     constexpr int IMG = MfmaLayout::imgA(HT, HT);
     constexpr bool GS = MTW % 2 == 0;                 // operand stores as full 128-byte lines (two row tiles x 8 samples)
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -150,6 +151,7 @@ coop_grad_step_kernel(CGArgs a) {
     f32x4* zebuf = xbuf + 2 * XB;                    // [DT][CT][64]: [z_stage | gbar]
     f32x4* ekbuf = zebuf + DB2;                      // [DT][CT][64]: [eps | kbar]
     f32x4* gbuf = ekbuf + DB2;                       // [DT][NT][64]: gbar (for the second dbar_1 product of the stage)
+    f32x4* ybuf = gbuf + DT * NT * 64;               // [KGC][NT][64]: conditions (constant over the solve)
     const int lane = threadIdx.x & 63, g = lane >> 4, n = lane & 15;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int mt0 = wave * MTW;
@@ -308,6 +310,21 @@ coop_grad_step_kernel(CGArgs a) {
             }
         }
         CG_SYNC();                 // the previous super-tile's readers of the LDS images are done
+        float ycond[CR > 0 ? CR : 1];
+        ycond[0] = 0.f;
+        if constexpr (CR > 0) {
+#pragma unroll
+            for (int s = 0; s < CR; ++s) { const int f = 4 * s + g; ycond[s] = f < a.C ? a.ys[sc * a.C + f] : 0.f; }
+            if (owner) {
+#pragma unroll
+                for (int kg = 0; kg < KGC; ++kg) {
+                    f32x4 o;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = (4 * kg + j < CR) ? ycond[(4 * kg + j) < CR ? 4 * kg + j : 0] : 0.f;
+                    ybuf[(kg * NT + wave) * 64 + lane] = o;
+                }
+            }
+        }
         float* zbt = a.zb + (tile * 64 + lane) * (long long)(NS * ZR);
 
 #pragma clang loop unroll(disable)
@@ -374,6 +391,11 @@ coop_grad_step_kernel(CGArgs a) {
                     if (!a.autonomous) col[D] = tt;
                     col[a.ld_y1 - 1] = 1.f;
                 }
+                if constexpr (CR > 0) {   // [z; t; ys; 1]: the condition rows (src/core/base_icnf.jl:49-60, cond_layer.jl:7-31)
+                    float* col = a.y1 + (c2 + smp) * (long long)a.ld_y1 + D + (a.autonomous ? 0 : 1);
+#pragma unroll
+                    for (int s = 0; s < CR; ++s) { const int f = 4 * s + g; if (f < a.C) col[f] = ycond[s]; }
+                }
                 dense_store(a.xN, D, c1 + smp, eps);
                 dense_store(a.xN, D, c2 + smp, kbar);
             }
@@ -393,6 +415,20 @@ coop_grad_step_kernel(CGArgs a) {
                 }
                 CG_SYNC();
                 run2(LAY.f1z, DT, zebuf, afr, acc);                          // [a_1 | dbar_1], dbar_1 = W_1[:,0:D] gbar
+                if constexpr (CR > 0) {   // a_1 += W_1[:, conditions] ys (first chain only)
+                    T1 ya;
+#pragma unroll
+                    for (int m = 0; m < MTW; ++m)
+#pragma unroll
+                        for (int q = 0; q < NT; ++q) ya[m][q] = acc[m][q];
+                    f32x4 afy[MTW];
+                    coop_load_a<MTW>(AIMG(LAY.f1y), mt0, KGC, 0, afy);
+                    coop_gemm<MTW, NT, NT>(AIMG(LAY.f1y), mt0, KGC, ybuf, 0, lane, afy, ya);
+#pragma unroll
+                    for (int m = 0; m < MTW; ++m)
+#pragma unroll
+                        for (int q = 0; q < NT; ++q) acc[m][q] = ya[m][q];
+                }
             }
             int cur = 0;
 #pragma unroll
@@ -521,12 +557,12 @@ coop_grad_step_kernel(CGArgs a) {
 // ---------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------
-template <int HT, int L, int ZR, int ACT, int NS, int NT>
+template <int HT, int L, int ZR, int CR, int ACT, int NS, int NT>
 static hipError_t launch_grad_step(const CGArgs& a, int num_cus, hipStream_t st) {
-    constexpr int lds = coop_grad_lds_bytes(HT, ZR, NT);
+    constexpr int lds = coop_grad_lds_bytes(HT, ZR, NT, CR);
     static_assert(lds <= 160 * 1024, "exchange buffers exceed LDS");
-    const int nblocks = coop_grad_nblocks(a.B, num_cus, HT, ZR);
-    auto kern = coop_grad_step_kernel<HT, L, ZR, ACT, NS, NT>;
+    const int nblocks = coop_grad_nblocks(a.B, num_cus, HT, ZR, CR);
+    auto kern = coop_grad_step_kernel<HT, L, ZR, CR, ACT, NS, NT>;
     static DeviceOnce once;
     int dev = 0;
     hipError_t e0 = hipGetDevice(&dev);
@@ -540,11 +576,13 @@ static hipError_t launch_grad_step(const CGArgs& a, int num_cus, hipStream_t st)
     return hipGetLastError();
 }
 
-#define CG_INST(HT, L, ZR) \
-    CoopGradInst { HT, L, ZR, CG_ACT, { &launch_grad_step<HT, L, ZR, CG_ACT, 4, 1>, &launch_grad_step<HT, L, ZR, CG_ACT, 6, 1> } }
+#define CG_INSTC(HT, L, ZR, CR) \
+    CoopGradInst { HT, L, ZR, CR, CG_ACT, { &launch_grad_step<HT, L, ZR, CR, CG_ACT, 4, 1>, &launch_grad_step<HT, L, ZR, CR, CG_ACT, 6, 1> } }
+#define CG_INST(HT, L, ZR) CG_INSTC(HT, L, ZR, 0)
 // the (HT, L, ZR) of the forward plans they pair with (the plan's packed image is shared): cnf_coop.hip's instances and the
 // unconditioned shapes of cnf_coop_x.hip (hidden tiles 8 / 12 / 16, 8 or 16 state k-steps)
-#define CG_XSHAPES(HT) CG_INST(HT, 3, 8), CG_INST(HT, 2, 8), CG_INST(HT, 3, 16), CG_INST(HT, 2, 16)
+#define CG_XSHAPES(HT) CG_INST(HT, 3, 8), CG_INST(HT, 2, 8), CG_INST(HT, 3, 16), CG_INST(HT, 2, 16), \
+                       CG_INSTC(HT, 3, 8, 4), CG_INSTC(HT, 2, 8, 4), CG_INSTC(HT, 3, 16, 4), CG_INSTC(HT, 2, 16, 4)   /* <= 16 conditions */
 const CoopGradInst* CG_TABLE_FN(int* n) {
     static const CoopGradInst table[] = {
 #ifndef CG_ACT_SOFTPLUS
@@ -559,27 +597,27 @@ const CoopGradInst* CG_TABLE_FN(int* n) {
 }
 
 #ifndef CG_ACT_SOFTPLUS
-static const CoopGradInst* cg_find(int HT, int L, int ZR, int ACT) {
+static const CoopGradInst* cg_find(int HT, int L, int ZR, int CR, int ACT) {
     int n = 0;
     const bool sp = ACT == CNF_ACT_SOFTPLUS;
     if (!sp && ACT != CNF_ACT_TANH && ACT != CNF_ACT_TANH_PRESCALED) return nullptr;
     const CoopGradInst* t = sp ? coop_grad_table_softplus(&n) : coop_grad_table_tanh(&n);
     for (int i = 0; i < n; ++i)
-        if (t[i].HT == HT && t[i].L == L && t[i].ZR == ZR) return &t[i];
+        if (t[i].HT == HT && t[i].L == L && t[i].ZR == ZR && t[i].CR == CR) return &t[i];
     return nullptr;
 }
 
-bool coop_grad_supported(int HT, int L, int ZR, int ACT) { return cg_find(HT, L, ZR, ACT) != nullptr; }
+bool coop_grad_supported(int HT, int L, int ZR, int CR, int ACT) { return cg_find(HT, L, ZR, CR, ACT) != nullptr; }
 int coop_grad_scratch_slots(int L) { return 2 * L - 3; }   // h_1 .. h_{L-1}, dbar_2 .. dbar_{L-1}
 // workgroups of a launch (16-sample super-tiles; two workgroups per CU where two sets of exchange buffers fit): the host sizes
 // the per-workgroup scratch with it
-int coop_grad_nblocks(long long B, int num_cus, int HT, int ZR) {
-    const long long nst = (B + 15) / 16, cap = (long long)num_cus * (2 * coop_grad_lds_bytes(HT, ZR, 1) <= 160 * 1024 ? 2 : 1);
+int coop_grad_nblocks(long long B, int num_cus, int HT, int ZR, int CR) {
+    const long long nst = (B + 15) / 16, cap = (long long)num_cus * (2 * coop_grad_lds_bytes(HT, ZR, 1, CR) <= 160 * 1024 ? 2 : 1);
     return (int)(nst < cap ? nst : cap);
 }
 
-hipError_t coop_grad_step_launch(int HT, int L, int ZR, int ACT, const CGArgs& a, int num_cus, hipStream_t st) {
-    const CoopGradInst* c = cg_find(HT, L, ZR, ACT);
+hipError_t coop_grad_step_launch(int HT, int L, int ZR, int CR, int ACT, const CGArgs& a, int num_cus, hipStream_t st) {
+    const CoopGradInst* c = cg_find(HT, L, ZR, CR, ACT);
     if (!c) return hipErrorNotSupported;
     return c->fn[a.T.ns <= 4 ? 0 : 1](a, num_cus, st);
 }

@@ -128,14 +128,14 @@ hipError_t grad_slab_launch(const cnf_config& c, const float* packed_dev, const 
 int mfma_plan_zr(const MfmaPlan* p);   // state k-steps of the forward instance (checkpoint stride)
 bool mfma_plan_is_per_wave(const MfmaPlan* p);
 bool mfma_plan_coop_shape(const MfmaPlan* p, int* HT, int* L, int* ZR, int* ACT);   // true for a cooperative-kernel plan
-bool mfma_plan_coop_grad_shape(const MfmaPlan* p, int* HT, int* L, int* ZR, int* ACT);   // ... or an extended one that can checkpoint
+bool mfma_plan_coop_grad_shape(const MfmaPlan* p, int* HT, int* L, int* ZR, int* ACT, int* CR = nullptr);   // ... or an extended one that can checkpoint
 long long mfma_plan_ckpt_tiles(const MfmaPlan* p, long long B);
 // cooperative gradient for wide layers (cnf_coop_grad.hip + the deferred weight-cotangent products of cnf_lgemm.hip; host side in
 // cnf_layered.hip): loss terms from the checkpointing forward solve, gradient in the Lux layout, dL/dx
 bool coop_grad_eligible(const cnf_config& c, const MfmaPlan* plan, const float lam[3], const float* tgrid);
 hipError_t coop_grad(LayeredGrad** ctx, const cnf_config& c, MfmaPlan* plan, const float* packed_dev, const size_t* w_off,
-                     const size_t* b_off, const float* x, const float* eps, int alg, int nsteps, float t0, float t1, long long B,
-                     const float lam[3], float* grad, float* grad_x, float* logp_out, float* regs_out, hipStream_t st, std::string* err);
+                     const size_t* b_off, const float* x, const float* eps, const float* ys, int alg, int nsteps, float t0, float t1,
+                     long long B, const float lam[3], float* grad, float* grad_x, float* logp_out, float* regs_out, hipStream_t st, std::string* err);
 
 // ---- variable-coefficient Adams PECE (cnf_vcabm.hip): elementwise passes of one step attempt ----
 constexpr int kVcSlots = 13;   // Phi*_0 .. Phi*_12: orders 1..12 plus the difference the order-raising estimate needs

@@ -977,23 +977,23 @@ __global__ void fill_rows_kernel(float* __restrict__ a, int ld, int row0, int ro
 }
 
 bool coop_grad_eligible(const cnf_config& c, const MfmaPlan* plan, const float lam[3], const float* tgrid) {
-    int HT, L, ZR, ACT;
-    if (!mfma_plan_coop_grad_shape(plan, &HT, &L, &ZR, &ACT)) return false;
+    int HT, L, ZR, ACT, CR;
+    if (!mfma_plan_coop_grad_shape(plan, &HT, &L, &ZR, &ACT, &CR)) return false;
     if (const char* e = getenv("CNF_COOP_GRAD")) { if (*e == '0') return false; }
-    if (c.mode != CNF_MODE_HUTCH_VJP || c.nprobes != 1 || c.ncond != 0 || tgrid) return false;
+    if (c.mode != CNF_MODE_HUTCH_VJP || c.nprobes != 1 || (c.ncond != 0) != (CR != 0) || tgrid) return false;
     if (c.n_layers != L + 1) return false;
     for (int l = 0; l < L; ++l)
         if ((c.acts[l] != CNF_ACT_TANH && c.acts[l] != CNF_ACT_SOFTPLUS) || c.acts[l] != c.acts[0] || c.widths[l + 1] != c.widths[1]) return false;
     if (c.acts[L] != CNF_ACT_IDENTITY) return false;
     if (c.widths[1] % 4 != 0) return false;                   // 16-byte row quads of the operand arrays
-    return coop_grad_supported(HT, L, ZR, ACT) && lg_wgrad_supported(c.widths[1], c.widths[1] + 1);
+    return coop_grad_supported(HT, L, ZR, CR, ACT) && lg_wgrad_supported(c.widths[1], c.widths[1] + 1);
 }
 
 hipError_t coop_grad(LayeredGrad** ctx, const cnf_config& c, MfmaPlan* plan, const float* packed_dev, const size_t* w_off,
-                     const size_t* b_off, const float* x, const float* eps, int alg, int nsteps, float t0, float t1, long long B,
-                     const float lam[3], float* grad, float* grad_x, float* logp_out, float* regs_out, hipStream_t st, std::string* err) {
-    int HT, Lh, ZR, ACT;
-    if (!mfma_plan_coop_grad_shape(plan, &HT, &Lh, &ZR, &ACT)) { *err = "coop_grad: not a cooperative plan"; return hipErrorNotSupported; }
+                     const size_t* b_off, const float* x, const float* eps, const float* ys, int alg, int nsteps, float t0, float t1,
+                     long long B, const float lam[3], float* grad, float* grad_x, float* logp_out, float* regs_out, hipStream_t st, std::string* err) {
+    int HT, Lh, ZR, ACT, CR;
+    if (!mfma_plan_coop_grad_shape(plan, &HT, &Lh, &ZR, &ACT, &CR)) { *err = "coop_grad: not a cooperative plan"; return hipErrorNotSupported; }
     if (!*ctx) *ctx = new LayeredGrad();
     LayeredGrad& G = **ctx;
     if (G.num_cus == 0) {
@@ -1025,7 +1025,7 @@ hipError_t coop_grad(LayeredGrad** ctx, const cnf_config& c, MfmaPlan* plan, con
     const int nslabN = lg_wgrad_chunks(D, B2, G.num_cus, &kcN, 4, H + 1);
     const long long szN = (long long)D * (H + 1), szN_pad = (szN + 63) / 64 * 64;
     const long long ntp = mfma_plan_ckpt_tiles(plan, B);
-    const int nblocks = coop_grad_nblocks(B, G.num_cus, HT, ZR);
+    const int nblocks = coop_grad_nblocks(B, G.num_cus, HT, ZR, CR);
     const int slots = coop_grad_scratch_slots(Lh);
     const long long scratch_stride = (long long)(slots > 0 ? slots : 1) * HT * 256;   // slots x (HT tiles x 64 lanes x 4) floats
 
@@ -1060,7 +1060,7 @@ hipError_t coop_grad(LayeredGrad** ctx, const cnf_config& c, MfmaPlan* plan, con
 
     // ---- forward: the cooperative solve, checkpointing z_n and the stage derivatives; it also delivers the loss terms ----
     SolveArgs sa{};
-    sa.x = x; sa.eps = eps; sa.B = B; sa.nsteps = nsteps; sa.alg = alg; sa.t0 = t0; sa.t1 = t1;
+    sa.x = x; sa.eps = eps; sa.ys = ys; sa.B = B; sa.nsteps = nsteps; sa.alg = alg; sa.t0 = t0; sa.t1 = t1;
     sa.logp = logp_out; sa.regs = regs_out; sa.nvars = c.nvars; sa.reg_aug = (c.reg_aug && c.naug > 0) ? 1 : 0;
     sa.ckpt = W + o_zck; sa.ckpt_k = W + o_kck; sa.ckpt_g = lam[1] != 0.f ? W + o_gck : nullptr;
     LG_HIP(mfma_solve(plan, packed_dev, sa, st));
@@ -1069,7 +1069,7 @@ hipError_t coop_grad(LayeredGrad** ctx, const cnf_config& c, MfmaPlan* plan, con
     // (The products of step n on a second stream under the sweep of step n - 1, operand arrays double-buffered, was measured:
     // cfg4 117 -> 131 ms.  Both kernels are bound by memory traffic and slow each other down by more than the overlap gains.)
     CGArgs a{};
-    a.packed = packed_dev; a.eps = eps; a.ckpt = W + o_zck; a.ckpt_k = W + o_kck; a.ckpt_g = sa.ckpt_g; a.lam = W + o_lam; a.zb = W + o_zb; a.grad_x = grad_x;
+    a.packed = packed_dev; a.eps = eps; a.ys = ys; a.C = c.ncond; a.ckpt = W + o_zck; a.ckpt_k = W + o_kck; a.ckpt_g = sa.ckpt_g; a.lam = W + o_lam; a.zb = W + o_zb; a.grad_x = grad_x;
     a.scratch = W + o_scr; a.scratch_stride = scratch_stride;
     for (int l = 0; l < Lh; ++l) { a.xh[l] = W + o_xh[l]; a.yh[l] = W + o_yh[l]; }
     a.y1 = W + o_y1; a.xN = W + o_xN; a.ld_y1 = n_in + 1; a.ldy = ldy;
@@ -1077,7 +1077,7 @@ hipError_t coop_grad(LayeredGrad** ctx, const cnf_config& c, MfmaPlan* plan, con
     const float dt = (t1 - t0) / (float)nsteps;
     for (int n = nsteps - 1; n >= 0; --n) {
         a.step = n; a.tn = t0 + (float)n * dt; a.dt = dt;
-        LG_HIP(coop_grad_step_launch(HT, Lh, ZR, ACT, a, G.num_cus, st));
+        LG_HIP(coop_grad_step_launch(HT, Lh, ZR, CR, ACT, a, G.num_cus, st));
         LG_HIP(lg_wgrad(slabs + L.pa_off[0], npa_pad, kc, nslab, H, n_in + 1, a.xh[0], H, a.y1, n_in + 1, B2, st));
         for (int l = 1; l < Lh; ++l)
             LG_HIP(lg_wgrad(slabs + L.pa_off[l], npa_pad, kc, nslab, H, H + 1, a.xh[l], H, a.yh[l - 1], ldy, B2, st));

@@ -385,11 +385,14 @@ bool mfma_plan_coop_shape(const MfmaPlan* p, int* HT, int* L, int* ZR, int* ACT)
     return true;
 }
 // a plan whose forward solve can checkpoint for the cooperative gradient: the cooperative kernel, or its extended form in the
-// unconditioned one-probe VJP configuration (same layout family: MfmaLayout(HT, L, ZR, 0, true))
-bool mfma_plan_coop_grad_shape(const MfmaPlan* p, int* HT, int* L, int* ZR, int* ACT) {
+// one-probe VJP configuration (layout family MfmaLayout(HT, L, ZR, CR, true); *CR = its condition k-steps)
+bool mfma_plan_coop_grad_shape(const MfmaPlan* p, int* HT, int* L, int* ZR, int* ACT, int* CR) {
+    if (CR) *CR = 0;
     if (mfma_plan_coop_shape(p, HT, L, ZR, ACT)) return true;
-    if (!p || p->kind != 2 || p->CR != 0 || p->KP != 1 || p->cfg.mode != CNF_MODE_HUTCH_VJP) return false;
+    if (!p || p->kind != 2 || p->KP != 1 || p->cfg.mode != CNF_MODE_HUTCH_VJP) return false;
+    if (p->CR != 0 && !CR) return false;
     *HT = p->HT; *L = p->L; *ZR = p->ZR; *ACT = p->ACT;
+    if (CR) *CR = p->CR;
     return true;
 }
 // 16-sample tiles of the checkpoint arrays such a solve writes (the kernel's super-tile count x its tiles per super-tile)

@@ -671,6 +671,10 @@ COOP_GRAD_SHAPES = [
     (dict(nvars=10, hidden=[176, 176]), 40, 0, 3, {}),                            # tanh, two layers
     (dict(nvars=32, naug=33, hidden=[264, 264], act=2, reg_z=True, reg_j=True, reg_aug=True), 40, 1, 2, {"lam": (0.01, 0.01, 0.01)}),   # ICNF(nvariables = 32): 20 x 24 tiles
     (dict(nvars=80, hidden=[384, 384, 384]), 36, 0, 2, {}),                       # tanh, D = 80, H = 384 (24 x 24 tiles)
+    # conditioned flows (CondICNF): the condition rows of layer 1 and of its cotangent
+    (dict(nvars=8, ncond=8, hidden=[256, 256, 256], reg_z=True, reg_j=True), 70, 1, 2, {"lam": (0.01, 0.01, 0.0)}),   # conditioned RNODE, tanh
+    (dict(nvars=16, naug=17, ncond=5, hidden=[156, 156], act=2, reg_z=True, reg_j=True, reg_aug=True), 50, 0, 2, {"lam": (0.01, 0.01, 0.01)}),   # default architecture (nvariables = 16) with 5 conditions
+    (dict(nvars=20, naug=21, ncond=16, hidden=[232, 232], act=2, autonomous=True), 40, 1, 2, {}),   # 16 conditions, D = 41, autonomous
 ]
 
 
@@ -695,7 +699,8 @@ def test_parameter_gradient_cooperative_reverse_sweep(kw, B, alg, nsteps, env, p
     for tag, flag in (("coop", "1"), ("layered", "0")):
         monkeypatch.setenv("CNF_COOP_GRAD", flag)
         icnf = make_icnf(pkg, spec, alg, nsteps, path=0, lambdas=lam)
-        val, g, gx = pkg.loss_and_gradient(icnf, mode, dev(xs), dev(p), {}, eps=dev(eps), wrt_x=True)
+        args = (dev(xs),) + ((dev(ys),) if spec.ncond else ()) + (dev(p), {})
+        val, g, gx = pkg.loss_and_gradient(icnf, mode, *args, eps=dev(eps), wrt_x=True)
         assert icnf.grad_path(mode) == (3 if tag == "coop" else 2), (tag, icnf.grad_path(mode))
         out[tag] = (float(val), g.cpu().numpy().astype(np.float64), gx.cpu().numpy().astype(np.float64))
         assert abs(out[tag][0] - L) < 1e-4 + 2e-6 * abs(L), tag
