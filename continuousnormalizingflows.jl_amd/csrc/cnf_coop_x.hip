@@ -24,7 +24,7 @@ template <int HT, int L, int ZR, int CR, int ACT>
 __device__ __forceinline__ void coopx_eval(const float* __restrict__ P, f32x4* xbuf, f32x4* zbuf, f32x4* ebuf, const f32x4* ybuf,
                                            int lane, int wave, float t, bool autonomous, bool reg_z, bool reg_j, bool exact, bool jvp,
                                            int D, int K, const float* __restrict__ eps_col, const float (&zs)[ZR], float (&zd)[ZR],
-                                           float& ld, float& ed, float& nd, float* __restrict__ gout = nullptr) {
+                                           float& ld, float& ed, float& nd, float* __restrict__ gout = nullptr, int q_off = 0) {
     constexpr int NT = 2;
     constexpr MfmaLayout LAY(HT, L, ZR, CR, true);
     constexpr int MTW = HT / 4, DT = (ZR + 3) / 4, KGC = (CR + 3) / 4, XB = HT * NT * 64;
@@ -109,7 +109,40 @@ __device__ __forceinline__ void coopx_eval(const float* __restrict__ P, f32x4* x
     }
     ld = 0.f;
     nd = 0.f;
-    const int nseed = exact ? D : K;
+    int nseed = exact ? D : K;
+    if constexpr (L == 2) {
+        if (exact && q_off > 0) {
+            // Two hidden layers: tr J = sum_ab act'_2[a] W_2[a][b] act'_1[b] (W_1[:,0:D] W_3)[b][a] = act'_2^T Q act'_1 with the constant
+            // Q = W_2 .* (W_1[:,0:D] W_3)^T packed behind the operand images: ONE H x H product and a dot instead of D pullbacks (the
+            // batched-Jacobian trace of src/core/utils.jl:79-88, icnf.jl:312, for the reference's default architecture).
+            // act'_1 goes out as a B image through buffer 0 (h_1's: every reader passed the barrier behind h_2's publish).
+            coop_load_a<MTW>(AIMG(q_off), mt0, HT, 0, afr);
+#pragma unroll
+            for (int m = 0; m < MTW; ++m)
+#pragma unroll
+                for (int q = 0; q < NT; ++q) {
+                    xbuf[((mt0 + m) * NT + q) * 64 + lane] = d[0][m][q];
+                    acc[m][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            __syncthreads();
+            coop_gemm<MTW, NT, NT>(AIMG(q_off), mt0, HT, xbuf, 0, lane, afr, acc);
+            // this wave's rows of Q act'_1 against its rows of act'_2; the four waves' partial traces meet in the probe image's LDS
+            float* red = reinterpret_cast<float*>(ebuf);
+#pragma unroll
+            for (int q = 0; q < NT; ++q) {
+                float tr = 0.f;
+#pragma unroll
+                for (int m = 0; m < MTW; ++m)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) tr = fmaf(acc[m][q][r], d[1][m][q][r], tr);
+                red[(wave * NT + q) * 64 + lane] = group_sum(tr);
+            }
+            __syncthreads();
+            if (owner) ld = -(red[(0 * NT + wave) * 64 + lane] + red[(1 * NT + wave) * 64 + lane] + red[(2 * NT + wave) * 64 + lane] +
+                              red[(3 * NT + wave) * 64 + lane]);
+            nseed = 0;
+        }
+    }
     const float scale = exact ? 1.f : 1.f / (float)K;
 #pragma clang loop unroll(disable)
     for (int p = 0; p < nseed; ++p) {
@@ -317,7 +350,7 @@ coopx_solve_kernel(KArgs a) {
                 for (int s = 0; s < ZR; ++s) zs[s] = fmaf(dt, Pz[0][s], z[s]);
                 float* gout = (a.ckpt_g && owner && !single) ? a.ckpt_g + ((((long long)step * ns + sg) * ckntp + cktile) * 64 + lane) * ZR : nullptr;
                 coopx_eval<HT, L, ZR, CR, ACT>(a.packed, xbuf, zbuf, ebuf, ybuf, lane, wave, tn + a.T.c[sg] * dt, autonomous, reg_z, reg_j,
-                                                exact, jvp, D, K, eps_col, zs, zd, ld, ed, nd, gout);
+                                                exact, jvp, D, K, eps_col, zs, zd, ld, ed, nd, gout, a.q_off);
                 if (a.ckpt_k && owner && !single) {
 #pragma unroll
                     for (int s = 0; s < ZR; ++s) a.ckpt_k[((((long long)step * ns + sg) * ckntp + cktile) * 64 + lane) * ZR + s] = zd[s];

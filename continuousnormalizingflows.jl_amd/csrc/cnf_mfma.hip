@@ -48,6 +48,8 @@ struct MfmaPlan {
     int prio_mode;      // see KArgs
     int use_queue;
     int* queue_dev;     // one int per plan, zeroed on the stream before every launch
+    int q_extra = 0;    // extended cooperative plans of two-hidden-layer exact-trace flows: float offset of the Q image appended
+                        // behind the layout (0 = none); per-wave plans carry theirs inside the layout (lay.qtr)
 
     char name[128];
     MfmaPlan() : lay(1, 2, 1, 0, true) {}
@@ -207,7 +209,7 @@ MfmaPlan* mfma_plan_create(const cnf_config& c) {
     //    the layer-wise path's single Q product is cheaper than D pullbacks), Hutchinson JVP (probes pushed through the forward images).
     if (c.arith != CNF_ARITH_F32 || env_int("CNF_MFMA_COOPX", 1) == 0) return nullptr;
     const bool exact = c.mode == CNF_MODE_EXACT;
-    if (!(c.mode == CNF_MODE_HUTCH_VJP || c.mode == CNF_MODE_HUTCH_JVP || (exact && L == 3))) return nullptr;
+    if (!(c.mode == CNF_MODE_HUTCH_VJP || c.mode == CNF_MODE_HUTCH_JVP || (exact && (L == 3 || L == 2)))) return nullptr;
     if (!exact && (c.nprobes < 1 || c.nprobes > 64)) return nullptr;
     int hti = HT, zri = ZR, cri = CR;
     if (!coopx_supported(HT, L, ZR, CR, c.acts[0], &hti, &zri, &cri)) return nullptr;
@@ -219,9 +221,11 @@ MfmaPlan* mfma_plan_create(const cnf_config& c) {
     p->cfg = c;
     p->nthreads = 256; p->num_cus = 0; p->prio_mode = 0; p->use_queue = 0; p->queue_dev = nullptr;
     p->kind = 2; p->arith = 0;
+    // two hidden layers, exact trace: tr J = act'_2^T Q act'_1 - ONE H x H product per evaluation (the Q image sits behind the layout)
+    p->q_extra = (exact && L == 2) ? p->lay.total : 0;
     p->fwd_scale = c.acts[0] == CNF_ACT_TANH ? kTanhPrescale : 1.f;
     snprintf(p->name, sizeof(p->name), "coopx<HT=%d,L=%d,ZR=%d,CR=%d,act=%d,%s>", hti, L, zri, cri, c.acts[0],
-             exact ? "exact (unit probes)" : c.mode == CNF_MODE_HUTCH_JVP ? "jvp" : "vjp");
+             exact ? (L == 2 ? "exact (Q product)" : "exact (unit probes)") : c.mode == CNF_MODE_HUTCH_JVP ? "jvp" : "vjp");
     return p;
 }
 
@@ -229,7 +233,11 @@ void mfma_plan_destroy(MfmaPlan* p) {
     if (p && p->queue_dev) (void)hipFree(p->queue_dev);
     delete p;
 }
-size_t mfma_packed_bytes(const MfmaPlan* p) { return (size_t)p->lay.total * sizeof(float); }
+size_t mfma_packed_bytes(const MfmaPlan* p) {
+    return ((size_t)p->lay.total + (p->q_extra ? (size_t)MfmaLayout::imgA(p->lay.HT, p->lay.HT) : 0)) * sizeof(float);
+}
+// float offset of the Q image of a two-hidden-layer exact-trace plan, or -1
+static long long plan_q_offset(const MfmaPlan* p) { return p->q_extra ? p->q_extra : (p->kind == 0 ? p->lay.qtr : -1); }
 const char* mfma_plan_name(const MfmaPlan* p) { return p->name; }
 
 // A image: out[(mt*KG + kg)*256 + lane*4 + j] = A(rowmap(mt, lane&15), 16 kg + 4 j + (lane>>4))
@@ -324,7 +332,7 @@ void mfma_pack(const MfmaPlan* p, const float* lux, const size_t* w_off, const s
     for (int l = 1; l < L; ++l)
         pack_vecC(packed + Y.v_bh + (l - 1) * MfmaLayout::vecC(Y.HT), Y.HT, Hl(l + 1), [&](int f) { return fs * Bv(l, f); });
     pack_vecC(packed + Y.v_bN, Y.DT, D, [&](int f) { return Bv(L, f); });
-    if (Y.qtr >= 0) {
+    if (plan_q_offset(p) >= 0) {
         // Q[a][b] = W_2[a][b] * (W_1[:,0:D] W_3)[b][a]: with two hidden layers tr J = sum_ab act'_2[a] Q[a][b] act'_1[b]
         const int H1 = Hl(1), H2 = Hl(2);
         std::vector<double> P((size_t)H1 * H2, 0.0);
@@ -334,7 +342,7 @@ void mfma_pack(const MfmaPlan* p, const float* lux, const size_t* w_off, const s
                 for (int i = 0; i < D; ++i) acc += (double)W(0, b, i) * (double)W(2, i, a);
                 P[(size_t)b * H2 + a] = acc;
             }
-        pack_imgA(packed + Y.qtr, Y.HT, Y.HT, H2, H1, [&](int r, int k) { return (float)((double)W(1, r, k) * P[(size_t)k * H2 + r]); });
+        pack_imgA(packed + plan_q_offset(p), Y.HT, Y.HT, H2, H1, [&](int r, int k) { return (float)((double)W(1, r, k) * P[(size_t)k * H2 + r]); });
     }
     if (Y.v_w1c >= 0)   // columns of W_1[:, 0:D] in accumulator layout (first-layer tangent of a unit seed = a column load)
         for (int i = 0; i < D; ++i)
@@ -363,8 +371,8 @@ __global__ void pack_q_kernel(const float* __restrict__ lux, float* __restrict__
 }
 
 bool mfma_plan_q_region(const MfmaPlan* p, size_t* off, size_t* len) {
-    if (!p || p->kind != 0 || p->lay.qtr < 0) return false;
-    *off = (size_t)p->lay.qtr;
+    if (!p || plan_q_offset(p) < 0) return false;
+    *off = (size_t)plan_q_offset(p);
     *len = (size_t)MfmaLayout::imgA(p->lay.HT, p->lay.HT);
     return true;
 }
@@ -373,7 +381,7 @@ hipError_t mfma_pack_q_device(const MfmaPlan* p, const float* lux_dev, const siz
     const cnf_config& c = p->cfg;
     const int D = c.nvars + c.naug, H1 = c.widths[1], H2 = c.widths[2], HT = p->lay.HT;
     const int n = HT * HT * 256;
-    hipLaunchKernelGGL(pack_q_kernel, dim3((n + 255) / 256), dim3(256), 0, st, lux_dev, packed_dev + p->lay.qtr, HT, H1, H2, D,
+    hipLaunchKernelGGL(pack_q_kernel, dim3((n + 255) / 256), dim3(256), 0, st, lux_dev, packed_dev + plan_q_offset(p), HT, H1, H2, D,
                        (long long)w_off[0], (long long)w_off[1], (long long)w_off[2]);
     return hipGetLastError();
 }
@@ -456,6 +464,7 @@ hipError_t mfma_solve(MfmaPlan* p, const float* packed_dev, const SolveArgs& s, 
     }
     if (p->kind == 2) {
         if (p->cfg.mode == CNF_MODE_HUTCH_JVP) a.exact = 2;   // this kernel family's code for the JVP form (cnf_coop_x.hip)
+        a.q_off = p->q_extra;
         return coopx_launch(p->HT, p->L, p->ZR, p->CR, p->ACT, a, mp->num_cus, st);
     }
     if (p->kind == 1) {

@@ -141,6 +141,11 @@ COOPX_CASES = [
     # beyond 256 hidden units / 64 state rows: 20 / 24 hidden tiles x 24 state k-steps
     (dict(nvars=32, naug=33, hidden=[264, 264], act=2, reg_z=True, reg_j=True, reg_aug=True), 40, 1, 4),   # ICNF(nvariables = 32): D = 65, H = 264
     (dict(nvars=70, hidden=[352, 352, 352], reg_z=True, reg_j=True), 33, 0, 4),              # tanh, three layers, D = 70, H = 352
+    # TestMode of two-hidden-layer flows: tr J = act'_2^T Q act'_1, one H x H product per evaluation
+    (dict(nvars=16, naug=17, hidden=[136, 136], act=2, mode=2), 70, 1, 6),                   # ICNF(nvariables = 16), TestMode
+    (dict(nvars=24, naug=25, ncond=4, hidden=[216, 216], act=2, mode=2), 40, 0, 5),          # conditioned, D = 49
+    (dict(nvars=12, hidden=[192, 192], mode=2, autonomous=True), 50, 1, 4),                  # tanh, autonomous
+    (dict(nvars=40, naug=41, hidden=[328, 328], act=2, mode=2), 33, 0, 3),                   # ICNF(nvariables = 40): 24 x 24 tiles
 ]
 CASES = CASES + COOPX_CASES
 
