@@ -55,7 +55,7 @@ int cnf_grad_path(const cnf_handle* h) {
     if (api_grad_is_fused(h) || api_grad_uses_slab(h)) return 1;
     const bool hutch = h->cfg.mode != CNF_MODE_EXACT;
     const float lamf[3] = {hutch && h->cfg.reg_z ? 1.f : 0.f, hutch && h->cfg.reg_j ? 1.f : 0.f, 0.f};
-    if (coop_grad_eligible(h->cfg, h->plan, lamf, nullptr) && h->packed_dev) return 3;   // uniform steps; frozen adaptive grids: 2
+    if (coop_grad_eligible(h->cfg, h->plan, lamf, nullptr) && h->packed_dev) return 3;   // uniform steps and frozen adaptive grids alike
     return layered_grad_supported(h->cfg) ? 2 : 0;
 }
 
@@ -146,12 +146,12 @@ static int loss_grad_impl(cnf_handle* h, const char* who, int alg, int nsteps, f
             return CNF_OK;
         }
         std::string msg;
-        if (!tgrid && coop_grad_eligible(h->cfg, h->plan, lam, tgrid) && h->packed_dev && !getenv("CNF_LAYERED_LOSS_BY_SOLVE")) {
+        if (coop_grad_eligible(h->cfg, h->plan, lam, tgrid) && h->packed_dev && !getenv("CNF_LAYERED_LOSS_BY_SOLVE")) {
             // wide hidden layers on the cooperative kernels: checkpointing forward solve (which also yields the loss terms),
             // one reverse-sweep launch per step, deferred weight-cotangent products (cnf_coop_grad.hip)
             float* cg_logp = sums4 ? h->grad_ws : nullptr;
             hipError_t e = coop_grad(&h->layered, h->cfg, h->plan, h->packed_dev, h->w_off.data(), h->b_off.data(), x, eps, ys, alg, nsteps,
-                                     t0, t1, B, lam, grad, grad_x, cg_logp, cg_logp ? cg_logp + B : nullptr, st, &msg);
+                                     t0, t1, tgrid, tgrid_dev, B, lam, grad, grad_x, cg_logp, cg_logp ? cg_logp + B : nullptr, st, &msg);
             if (e != hipSuccess) return fail(CNF_ERR_HIP, w + ": " + msg);
             if (sums4) HIP_TRY(loss_sums(cg_logp, cg_logp + B, B, h->loss_partial, sums4, st));
             return CNF_OK;

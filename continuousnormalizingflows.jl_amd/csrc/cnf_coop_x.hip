@@ -323,7 +323,7 @@ coopx_solve_kernel(KArgs a) {
         float zd[ZR], ld = 0.f, ed = 0.f, nd = 0.f;
 #pragma unroll
         for (int s = 0; s < ZR; ++s) zd[s] = 0.f;
-        const float dt = a.dt;
+        const float dt0 = a.dt;
         const bool single = a.nsteps == 0;
         const int ns = single ? 1 : (a.T.ns < NS ? a.T.ns : NS);
         const int nsteps = single ? 1 : a.nsteps;
@@ -331,7 +331,9 @@ coopx_solve_kernel(KArgs a) {
         const long long cktile = st * NT + (owner ? wave : 0), ckntp = nst * NT;
 #pragma clang loop unroll(disable)
         for (int step = 0; step < nsteps; ++step) {
-            const float tn = a.t0 + (float)step * dt;
+            // uniform steps, or the caller's grid (KArgs::tgrid: the frozen steps of an adaptive solve, for the gradient)
+            const float tn = a.tgrid ? a.tgrid[step] : a.t0 + (float)step * dt0;
+            const float dt = a.tgrid ? a.tgrid[step + 1] - tn : dt0;
             if (a.ckpt && owner && !single) {
 #pragma unroll
                 for (int s = 0; s < ZR; ++s) a.ckpt[(((long long)step * ckntp + cktile) * 64 + lane) * ZR + s] = z[s];

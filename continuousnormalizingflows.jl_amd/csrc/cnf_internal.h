@@ -78,6 +78,7 @@ struct SolveArgs {
     float* kfull;
     float dt_exact;  // != 0: the step itself (nsteps = 1 attempts: (t0 + dt) - t0 is not dt in float32); 0: (t1 - t0) / nsteps
     float* ckpt_g;   // optional, cooperative checkpointing solve only (KArgs::ckpt_g)
+    const float* tgrid_dev;   // optional, cooperative checkpointing solve only: nsteps + 1 step times on the device
 };
 hipError_t mfma_solve(MfmaPlan* p, const float* packed_dev, const SolveArgs& a, hipStream_t st);
 // adaptive Tsit5 with the step controller on the device (cnf_mfma_kernel.h: mfma_adaptive_kernel): u0 -> u_out over [t0, t1]
@@ -129,13 +130,13 @@ int mfma_plan_zr(const MfmaPlan* p);   // state k-steps of the forward instance 
 bool mfma_plan_is_per_wave(const MfmaPlan* p);
 bool mfma_plan_coop_shape(const MfmaPlan* p, int* HT, int* L, int* ZR, int* ACT);   // true for a cooperative-kernel plan
 bool mfma_plan_coop_grad_shape(const MfmaPlan* p, int* HT, int* L, int* ZR, int* ACT, int* CR = nullptr);   // ... or an extended one that can checkpoint
-long long mfma_plan_ckpt_tiles(const MfmaPlan* p, long long B);
+long long mfma_plan_ckpt_tiles(const MfmaPlan* p, long long B, bool on_grid = false);
 // cooperative gradient for wide layers (cnf_coop_grad.hip + the deferred weight-cotangent products of cnf_lgemm.hip; host side in
 // cnf_layered.hip): loss terms from the checkpointing forward solve, gradient in the Lux layout, dL/dx
 bool coop_grad_eligible(const cnf_config& c, const MfmaPlan* plan, const float lam[3], const float* tgrid);
 hipError_t coop_grad(LayeredGrad** ctx, const cnf_config& c, MfmaPlan* plan, const float* packed_dev, const size_t* w_off,
                      const size_t* b_off, const float* x, const float* eps, const float* ys, int alg, int nsteps, float t0, float t1,
-                     long long B, const float lam[3], float* grad, float* grad_x, float* logp_out, float* regs_out, hipStream_t st, std::string* err);
+                     const float* tgrid, const float* tgrid_dev, long long B, const float lam[3], float* grad, float* grad_x, float* logp_out, float* regs_out, hipStream_t st, std::string* err);
 
 // ---- variable-coefficient Adams PECE (cnf_vcabm.hip): elementwise passes of one step attempt ----
 constexpr int kVcSlots = 13;   // Phi*_0 .. Phi*_12: orders 1..12 plus the difference the order-raising estimate needs

@@ -980,7 +980,8 @@ bool coop_grad_eligible(const cnf_config& c, const MfmaPlan* plan, const float l
     int HT, L, ZR, ACT, CR;
     if (!mfma_plan_coop_grad_shape(plan, &HT, &L, &ZR, &ACT, &CR)) return false;
     if (const char* e = getenv("CNF_COOP_GRAD")) { if (*e == '0') return false; }
-    if (c.mode != CNF_MODE_HUTCH_VJP || c.nprobes != 1 || (c.ncond != 0) != (CR != 0) || tgrid) return false;
+    if (c.mode != CNF_MODE_HUTCH_VJP || c.nprobes != 1 || (c.ncond != 0) != (CR != 0)) return false;
+    (void)tgrid;   // a non-uniform grid (the frozen steps of an adaptive solve): the extended kernel checkpoints on it
     if (c.n_layers != L + 1) return false;
     for (int l = 0; l < L; ++l)
         if ((c.acts[l] != CNF_ACT_TANH && c.acts[l] != CNF_ACT_SOFTPLUS) || c.acts[l] != c.acts[0] || c.widths[l + 1] != c.widths[1]) return false;
@@ -991,7 +992,7 @@ bool coop_grad_eligible(const cnf_config& c, const MfmaPlan* plan, const float l
 
 hipError_t coop_grad(LayeredGrad** ctx, const cnf_config& c, MfmaPlan* plan, const float* packed_dev, const size_t* w_off,
                      const size_t* b_off, const float* x, const float* eps, const float* ys, int alg, int nsteps, float t0, float t1,
-                     long long B, const float lam[3], float* grad, float* grad_x, float* logp_out, float* regs_out, hipStream_t st, std::string* err) {
+                     const float* tgrid, const float* tgrid_dev, long long B, const float lam[3], float* grad, float* grad_x, float* logp_out, float* regs_out, hipStream_t st, std::string* err) {
     int HT, Lh, ZR, ACT, CR;
     if (!mfma_plan_coop_grad_shape(plan, &HT, &Lh, &ZR, &ACT, &CR)) { *err = "coop_grad: not a cooperative plan"; return hipErrorNotSupported; }
     if (!*ctx) *ctx = new LayeredGrad();
@@ -1024,7 +1025,7 @@ hipError_t coop_grad(LayeredGrad** ctx, const cnf_config& c, MfmaPlan* plan, con
     long long kcN = 0;
     const int nslabN = lg_wgrad_chunks(D, B2, G.num_cus, &kcN, 4, H + 1);
     const long long szN = (long long)D * (H + 1), szN_pad = (szN + 63) / 64 * 64;
-    const long long ntp = mfma_plan_ckpt_tiles(plan, B);
+    const long long ntp = mfma_plan_ckpt_tiles(plan, B, tgrid != nullptr);
     const int nblocks = coop_grad_nblocks(B, G.num_cus, HT, ZR, CR);
     const int slots = coop_grad_scratch_slots(Lh);
     const long long scratch_stride = (long long)(slots > 0 ? slots : 1) * HT * 256;   // slots x (HT tiles x 64 lanes x 4) floats
@@ -1063,6 +1064,7 @@ hipError_t coop_grad(LayeredGrad** ctx, const cnf_config& c, MfmaPlan* plan, con
     sa.x = x; sa.eps = eps; sa.ys = ys; sa.B = B; sa.nsteps = nsteps; sa.alg = alg; sa.t0 = t0; sa.t1 = t1;
     sa.logp = logp_out; sa.regs = regs_out; sa.nvars = c.nvars; sa.reg_aug = (c.reg_aug && c.naug > 0) ? 1 : 0;
     sa.ckpt = W + o_zck; sa.ckpt_k = W + o_kck; sa.ckpt_g = lam[1] != 0.f ? W + o_gck : nullptr;
+    sa.tgrid_dev = tgrid ? tgrid_dev : nullptr;
     LG_HIP(mfma_solve(plan, packed_dev, sa, st));
 
     // ---- reverse: one launch per step, then the step's weight-cotangent products ----
@@ -1077,6 +1079,7 @@ hipError_t coop_grad(LayeredGrad** ctx, const cnf_config& c, MfmaPlan* plan, con
     const float dt = (t1 - t0) / (float)nsteps;
     for (int n = nsteps - 1; n >= 0; --n) {
         a.step = n; a.tn = t0 + (float)n * dt; a.dt = dt;
+        if (tgrid) { a.tn = tgrid[n]; a.dt = tgrid[n + 1] - tgrid[n]; }
         LG_HIP(coop_grad_step_launch(HT, Lh, ZR, CR, ACT, a, G.num_cus, st));
         LG_HIP(lg_wgrad(slabs + L.pa_off[0], npa_pad, kc, nslab, H, n_in + 1, a.xh[0], H, a.y1, n_in + 1, B2, st));
         for (int l = 1; l < Lh; ++l)

@@ -404,8 +404,8 @@ bool mfma_plan_coop_grad_shape(const MfmaPlan* p, int* HT, int* L, int* ZR, int*
     return true;
 }
 // 16-sample tiles of the checkpoint arrays such a solve writes (the kernel's super-tile count x its tiles per super-tile)
-long long mfma_plan_ckpt_tiles(const MfmaPlan* p, long long B) {
-    const bool x = p->kind == 2 || !coop_ckpt_supported(p->HT, p->L, p->ZR, p->ACT);   // which kernel checkpoints: see mfma_solve
+long long mfma_plan_ckpt_tiles(const MfmaPlan* p, long long B, bool on_grid) {
+    const bool x = p->kind == 2 || on_grid || !coop_ckpt_supported(p->HT, p->L, p->ZR, p->ACT);   // which kernel checkpoints: see mfma_solve
     return x ? (B + 31) / 32 * 2 : (B + 63) / 64 * 4;
 }
 bool mfma_plan_is_per_wave(const MfmaPlan* p) { return p->kind == 0; }
@@ -441,7 +441,7 @@ hipError_t mfma_solve(MfmaPlan* p, const float* packed_dev, const SolveArgs& s, 
     KArgs a{};
     a.packed = packed_dev;
     a.x = s.x; a.u0 = s.u0; a.eps = s.eps; a.ys = s.ys;
-    a.u_out = s.u_out; a.logp = s.logp; a.regs = s.regs; a.ckpt = s.ckpt; a.ckpt_k = s.ckpt_k; a.kfull = s.kfull; a.ckpt_g = s.ckpt_g;
+    a.u_out = s.u_out; a.logp = s.logp; a.regs = s.regs; a.ckpt = s.ckpt; a.ckpt_k = s.ckpt_k; a.kfull = s.kfull; a.ckpt_g = s.ckpt_g; a.tgrid = s.tgrid_dev;
     a.B = s.B; a.nsteps = s.nsteps; a.t0 = s.t0;
     a.dt = s.nsteps > 0 ? (s.dt_exact != 0.f ? s.dt_exact : (s.t1 - s.t0) / (float)s.nsteps) : 0.f;
     a.nvars = s.nvars; a.D = p->cfg.nvars + p->cfg.naug; a.C = p->cfg.ncond;
@@ -471,7 +471,7 @@ hipError_t mfma_solve(MfmaPlan* p, const float* packed_dev, const SolveArgs& s, 
         // with checkpoint buffers: the checkpointing form of the cooperative solve (the forward half of cnf_coop_grad.hip)
         // (shapes without a checkpointing instance of this kernel checkpoint through the extended kernel, which runs on the same
         // packed image - MfmaLayout(HT, L, ZR, 0, true) - and checkpoints at run time)
-        if (s.ckpt) return coop_ckpt_supported(p->HT, p->L, p->ZR, p->ACT) ? coop_launch_ckpt(p->HT, p->L, p->ZR, p->ACT, a, mp->num_cus, st)
+        if (s.ckpt) return (coop_ckpt_supported(p->HT, p->L, p->ZR, p->ACT) && !s.tgrid_dev) ? coop_launch_ckpt(p->HT, p->L, p->ZR, p->ACT, a, mp->num_cus, st)
                                                                             : coopx_launch(p->HT, p->L, p->ZR, 0, p->ACT, a, mp->num_cus, st);
         return coop_launch(p->HT, p->L, p->ZR, p->ACT, a, mp->num_cus, st);
     }

@@ -31,6 +31,7 @@ struct KArgs {
     float acol[6][5];   // acol[st][i] = T.a[st + 1 + i][st] (0 beyond the last stage): what stage st contributes to the stages after it
     float* ckpt_g;      // optional (cooperative checkpointing solve): g = eps^T J of every stage, laid out like ckpt_k (gradient of |eps^T J|)
     int q_off;          // extended cooperative kernel, exact trace of a two-hidden-layer flow: float offset of the Q image in `packed` (0: none)
+    const float* tgrid; // extended cooperative kernel: nsteps + 1 step times on the device (non-uniform grid) or null
 };
 
 // Device-side step controller (mfma_adaptive_kernel): the whole adaptive Tsit5 solve of a batch that fits the chip's wave

@@ -309,8 +309,7 @@ int cnf_loss_grad_adaptive(cnf_handle* h, float t0, float t1, const float* x, co
 /* Which implementation cnf_loss_grad_fixed / cnf_loss_grad_grid use for this handle: 0 = none (CNF_ERR_UNSUPPORTED),
  * 1 = fused reverse-sweep kernel (cnf_grad.hip / cnf_grad_probes.hip / cnf_grad_slab.hip), 2 = layer-wise reverse sweep on
  * the product kernels of cnf_lgemm.hip (cnf_layered.hip), 3 = cooperative reverse sweep for wide tanh nets (FFJORD or the regularised objective) on uniform
- * steps (cnf_coop_grad.hip: one launch per RK step + deferred weight-cotangent products; cnf_loss_grad_grid with a non-uniform
- * grid takes 2 on such a handle). */
+ * steps or on the caller's grid (cnf_coop_grad.hip: one launch per RK step + deferred weight-cotangent products). */
 int cnf_grad_path(const cnf_handle* h);
 
 /* ---- column shards: the one exchange step of the path -----------------------------------------

@@ -1660,6 +1660,10 @@ def test_adaptive_tsit5_follows_the_oracle_restatement(kw, tol, pkg, oracles):
     (dict(nvars=4, naug=5, ncond=2, hidden=[40, 40], act=2, reg_z=True), (0.02, 0.0, 0.0), 1),   # default-style net, conditioned
     (dict(nvars=10, hidden=[72, 72], act=2, reg_z=True, reg_j=True), (0.02, 0.03, 0.0), 1),  # slab-accumulator kernel
     (dict(nvars=3, naug=2, ncond=2, hidden=[24, 48, 24], act=2, nprobes=2, reg_aug=True), (0.0, 0.0, 0.05), 2),   # layer-wise path
+    # the cooperative gradient on a frozen grid: the extended kernel checkpoints on the caller's step times
+    (dict(nvars=16, naug=17, hidden=[136, 136], act=2, reg_z=True, reg_j=True, reg_aug=True), (0.01, 0.01, 0.01), 3),   # ICNF(nvariables = 16), default lambdas
+    (dict(nvars=32, hidden=[256, 256, 256], reg_z=True, reg_j=True), (0.02, 0.03, 0.0), 3),   # cfg4's shape (its uniform-grid forward has a checkpointing instance of its own)
+    (dict(nvars=8, ncond=8, hidden=[192, 192], reg_z=True), (0.05, 0.0, 0.0), 3),            # conditioned
 ])
 def test_gradient_of_the_adaptive_solve_on_its_frozen_grid(kw, lam, gpath, pkg, oracles):
     """loss_and_gradient with the adaptive solver: the accepted steps are frozen and the discrete solve on that
@@ -1667,7 +1671,8 @@ def test_gradient_of_the_adaptive_solve_on_its_frozen_grid(kw, lam, gpath, pkg, 
     memory, the layer-wise path takes them from the host) - against fp64 autograd on the same grid."""
     o64, _ = oracles
     spec = o64.make_spec(**kw)
-    assert _adaptive_icnf(pkg, spec, 1e-4).grad_path(pkg.TrainMode(True)) == gpath
+    if gpath != 3:   # (the cooperative path answers once parameters are bound: checked behind the call below)
+        assert _adaptive_icnf(pkg, spec, 1e-4).grad_path(pkg.TrainMode(True)) == gpath
     B = 45
     p, xs, eps, ys = o64.synth_inputs(spec, B, 88, bias_scale=0.3)
     p = (p * 2.0).astype(np.float32)
@@ -1676,6 +1681,7 @@ def test_gradient_of_the_adaptive_solve_on_its_frozen_grid(kw, lam, gpath, pkg, 
     mode = pkg.TrainMode(True)
     args = (dev(xs),) + ((dev(ys),) if spec.ncond else ()) + (dev(p), {})
     val, g, gx = pkg.loss_and_gradient(icnf, mode, *args, eps=dev(eps), wrt_x=True)
+    assert icnf.grad_path(mode) == gpath
     ts = icnf.last_solve_stats["tgrid"]
     assert len(ts) >= 5 and ts[0] == 0.0 and ts[-1] == 1.0 and len(set(np.round(np.diff(ts), 6))) > 1   # non-uniform
     L, gref, gxref = o64.loss_and_grad(spec, p, xs, 0.0, 1.0, len(ts) - 1, 1, eps, ys, lam, wrt_x=True, tgrid=ts)
