@@ -61,6 +61,26 @@ __device__ __forceinline__ void coop_gemm(const AImg& A, int mt0, int KG,
     }
 }
 
+// The same product with a RUN-TIME k-group count KE (even, <= the image's row pitch KP): a hidden width that fills fewer tiles
+// than the instance has skips the zero ones (136 hidden units in a 12-tile instance: 10 of 12 k-groups).  Branch-free: the
+// prefetch index is clamped instead of guarded - a load under an `if` is a control-flow join at which the compiler's
+// wait-count insertion waits for everything outstanding.
+template <int M, int NQ, int NT>
+__device__ __forceinline__ void coop_gemm_rt(const AImg& A, int mt0, int KP, int KE,
+                                             const f32x4* __restrict__ bimg, int nt0, int lane,
+                                             f32x4 (&a0)[M], f32x4 (&acc)[M][NQ]) {
+    f32x4 a1[M], b0[NQ], b1[NQ];
+    coop_load_b<NQ, NT>(bimg, nt0, 0, lane, b0);
+#pragma clang loop unroll(disable)
+    for (int kg = 0; kg < KE; kg += 2) {
+        const int k2 = kg + 2 < KE ? kg + 2 : KE - 1;
+        coop_load_a<M>(A, mt0, KP, kg + 1, a1); coop_load_b<NQ, NT>(bimg, nt0, kg + 1, lane, b1);
+        coop_frag_mfma<M, NQ>(a0, b0, acc);
+        coop_load_a<M>(A, mt0, KP, k2, a0); coop_load_b<NQ, NT>(bimg, nt0, k2, lane, b0);
+        coop_frag_mfma<M, NQ>(a1, b1, acc);
+    }
+}
+
 template <int MT>
 __device__ __forceinline__ void gload_cvec(const float* __restrict__ vec, int mt0, int g, f32x4 (&out)[MT]) {
 #pragma unroll

@@ -110,18 +110,20 @@ __device__ __forceinline__ f32x4 act_dd(const f32x4& h, const f32x4& d) {
 // final two k-groups instead of sitting in front of its fragment loads in the in-order vmcnt queue.
 //   head: k-groups 0 .. KG-3; on return a0 / b0 hold the (requested) fragments of k-group KG-2, a1 / b1 those of KG-1
 //   tail: the MFMAs of k-groups KG-2 and KG-1.        (KG even: 2 for the D-sized products, HT for the H x H ones)
+//   KP: the image's row pitch in k-groups (the instance's HT for the H x H images), KG <= KP the (even) number multiplied - a
+//   hidden width that fills fewer tiles than the instance has skips the zero ones
 template <int M, int NQ, int NT>
-__device__ __forceinline__ void coop_gemm_head(const AImg& A, int mt0, int KG, const f32x4* __restrict__ bimg, int lane,
+__device__ __forceinline__ void coop_gemm_head(const AImg& A, int mt0, int KP, int KG, const f32x4* __restrict__ bimg, int lane,
                                                f32x4 (&a0)[M], f32x4 (&a1)[M], f32x4 (&b0)[NQ], f32x4 (&b1)[NQ], f32x4 (&acc)[M][NQ]) {
     coop_load_b<NQ, NT>(bimg, 0, 0, lane, b0);
 #pragma clang loop unroll(disable)
     for (int kg = 0; kg + 2 < KG; kg += 2) {
-        coop_load_a<M>(A, mt0, KG, kg + 1, a1); coop_load_b<NQ, NT>(bimg, 0, kg + 1, lane, b1);
+        coop_load_a<M>(A, mt0, KP, kg + 1, a1); coop_load_b<NQ, NT>(bimg, 0, kg + 1, lane, b1);
         coop_frag_mfma<M, NQ>(a0, b0, acc);
-        coop_load_a<M>(A, mt0, KG, kg + 2, a0); coop_load_b<NQ, NT>(bimg, 0, kg + 2, lane, b0);
+        coop_load_a<M>(A, mt0, KP, kg + 2, a0); coop_load_b<NQ, NT>(bimg, 0, kg + 2, lane, b0);
         coop_frag_mfma<M, NQ>(a1, b1, acc);
     }
-    if (KG >= 2) { coop_load_a<M>(A, mt0, KG, KG - 1, a1); coop_load_b<NQ, NT>(bimg, 0, KG - 1, lane, b1); }
+    if (KG >= 2) { coop_load_a<M>(A, mt0, KP, KG - 1, a1); coop_load_b<NQ, NT>(bimg, 0, KG - 1, lane, b1); }
 }
 template <int M, int NQ>
 __device__ __forceinline__ void coop_gemm_tail(int KG, const f32x4 (&a0)[M], const f32x4 (&a1)[M], const f32x4 (&b0)[NQ],
@@ -236,14 +238,17 @@ coop_grad_step_kernel(CGArgs a) {
             for (int q = 0; q < CT; ++q) v[m][q] = f32x4{0.f, 0.f, 0.f, 0.f};
     };
     auto pre_a = [&](int img, int KG, f32x4 (&afr)[MTW]) { coop_load_a<MTW>(AIMG(img), mt0, KG, 0, afr); };
-    auto run2 = [&](int img, int KG, const f32x4* bimg, f32x4 (&afr)[MTW], T2& acc) {
-        coop_gemm<MTW, CT, CT>(AIMG(img), mt0, KG, bimg, 0, lane, afr, acc);
+    // hidden k-groups that are not zero padding, rounded up to even (the k-loops run two k-groups per iteration)
+    const int KHE = (H + 15) / 16 < HT ? (((H + 15) / 16 + 1) & ~1) : HT;
+    auto run2 = [&](int img, int KG, const f32x4* bimg, f32x4 (&afr)[MTW], T2& acc) {   // KG == HT: an H x H image
+        if (KG == HT) coop_gemm_rt<MTW, CT, CT>(AIMG(img), mt0, HT, KHE, bimg, 0, lane, afr, acc);
+        else coop_gemm<MTW, CT, CT>(AIMG(img), mt0, KG, bimg, 0, lane, afr, acc);
     };
     f32x4 fa1[MTW], fb0[CT], fb1[CT];
     auto head2 = [&](int img, int KG, const f32x4* bimg, f32x4 (&afr)[MTW], T2& acc) {
-        coop_gemm_head<MTW, CT, CT>(AIMG(img), mt0, KG, bimg, lane, afr, fa1, fb0, fb1, acc);
+        coop_gemm_head<MTW, CT, CT>(AIMG(img), mt0, KG, KG == HT ? KHE : KG, bimg, lane, afr, fa1, fb0, fb1, acc);
     };
-    auto tail2 = [&](int KG, f32x4 (&afr)[MTW], T2& acc) { coop_gemm_tail<MTW, CT>(KG, afr, fa1, fb0, fb1, acc); };
+    auto tail2 = [&](int KG, f32x4 (&afr)[MTW], T2& acc) { coop_gemm_tail<MTW, CT>(KG == HT ? KHE : KG, afr, fa1, fb0, fb1, acc); };
     // dense D-row registers of this wave's sample tile -> column tile `ct` of a B image with `nct` column tiles per k-group
     auto publish_dense = [&](f32x4* img, int nct, int ct, const float (&v)[ZR]) {
 #pragma unroll
@@ -528,7 +533,7 @@ coop_grad_step_kernel(CGArgs a) {
                 f32x4 zacc[DT][1];
 #pragma unroll
                 for (int m = 0; m < DT; ++m) zacc[m][0] = f32x4{0.f, 0.f, 0.f, 0.f};
-                coop_gemm<DT, 1, CT>(AIMG(LAY.b1), 0, HT, xbuf + cur * XB, NT + wave, lane, afd, zacc);
+                coop_gemm_rt<DT, 1, CT>(AIMG(LAY.b1), 0, HT, KHE, xbuf + cur * XB, NT + wave, lane, afd, zacc);
 #pragma unroll
                 for (int s = 0; s < ZR; ++s) zbt[i * ZR + s] = zacc[s >> 2][0][s & 3];
             }

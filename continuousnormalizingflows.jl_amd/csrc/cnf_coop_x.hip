@@ -24,8 +24,9 @@ template <int HT, int L, int ZR, int CR, int ACT>
 __device__ __forceinline__ void coopx_eval(const float* __restrict__ P, f32x4* xbuf, f32x4* zbuf, f32x4* ebuf, const f32x4* ybuf,
                                            int lane, int wave, float t, bool autonomous, bool reg_z, bool reg_j, bool exact, bool jvp,
                                            int D, int K, const float* __restrict__ eps_col, const float (&zs)[ZR], float (&zd)[ZR],
-                                           float& ld, float& ed, float& nd, float* __restrict__ gout = nullptr, int q_off = 0) {
+                                           float& ld, float& ed, float& nd, float* __restrict__ gout = nullptr, int q_off = 0, int KHa = 0) {
     constexpr int NT = 2;
+    const int KH = (KHa > 0 && KHa < HT) ? ((KHa + 1) & ~1) : HT;   // hidden k-groups that are not zero padding (even: coop_gemm_rt)
     constexpr MfmaLayout LAY(HT, L, ZR, CR, true);
     constexpr int MTW = HT / 4, DT = (ZR + 3) / 4, KGC = (CR + 3) / 4, XB = HT * NT * 64;
     constexpr int IMG = MfmaLayout::imgA(HT, HT);
@@ -88,7 +89,7 @@ __device__ __forceinline__ void coopx_eval(const float* __restrict__ P, f32x4* x
                 for (int q = 0; q < NT; ++q) acc[m][q] = bnx[m];
         }
         __syncthreads();
-        if (l + 1 < L) coop_gemm<MTW, NT, NT>(AIMG(LAY.fh + l * IMG), mt0, HT, xbuf + cur * XB, 0, lane, afr, acc);
+        if (l + 1 < L) coop_gemm_rt<MTW, NT, NT>(AIMG(LAY.fh + l * IMG), mt0, HT, KH, xbuf + cur * XB, 0, lane, afr, acc);
     }
     constexpr int hbuf = (L - 1) & 1;   // buffer holding h_L
     if (owner) {   // zdot = W_N h_L + b_N for this wave's own sample tile
@@ -96,7 +97,7 @@ __device__ __forceinline__ void coopx_eval(const float* __restrict__ P, f32x4* x
         gload_cvec<DT>(P + LAY.v_bN, 0, g, bias);
 #pragma unroll
         for (int m = 0; m < DT; ++m) zacc[m][0] = bias[m];
-        coop_gemm<DT, 1, NT>(AIMG(LAY.fN), 0, HT, xbuf + hbuf * XB, wave, lane, afd, zacc);
+        coop_gemm_rt<DT, 1, NT>(AIMG(LAY.fN), 0, HT, KH, xbuf + hbuf * XB, wave, lane, afd, zacc);
 #pragma unroll
         for (int s = 0; s < ZR; ++s) zd[s] = zacc[s >> 2][0][s & 3];
     }
@@ -125,7 +126,7 @@ __device__ __forceinline__ void coopx_eval(const float* __restrict__ P, f32x4* x
                     acc[m][q] = f32x4{0.f, 0.f, 0.f, 0.f};
                 }
             __syncthreads();
-            coop_gemm<MTW, NT, NT>(AIMG(q_off), mt0, HT, xbuf, 0, lane, afr, acc);
+            coop_gemm_rt<MTW, NT, NT>(AIMG(q_off), mt0, HT, KH, xbuf, 0, lane, afr, acc);
             // this wave's rows of Q act'_1 against its rows of act'_2; the four waves' partial traces meet in the probe image's LDS
             float* red = reinterpret_cast<float*>(ebuf);
 #pragma unroll
@@ -191,12 +192,12 @@ __device__ __forceinline__ void coopx_eval(const float* __restrict__ P, f32x4* x
                     for (int m = 0; m < MTW; ++m)
 #pragma unroll
                         for (int q = 0; q < NT; ++q) acc[m][q] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    coop_gemm<MTW, NT, NT>(AIMG(LAY.fh + l * IMG), mt0, HT, xbuf + wbuf * XB, 0, lane, afr, acc);
+                    coop_gemm_rt<MTW, NT, NT>(AIMG(LAY.fh + l * IMG), mt0, HT, KH, xbuf + wbuf * XB, 0, lane, afr, acc);
                 } else if (owner) {
                     f32x4 gacc[DT][1];   // J eps for this wave's own sample tile
 #pragma unroll
                     for (int m = 0; m < DT; ++m) gacc[m][0] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    coop_gemm<DT, 1, NT>(AIMG(LAY.fN), 0, HT, xbuf + wbuf * XB, wave, lane, afd, gacc);
+                    coop_gemm_rt<DT, 1, NT>(AIMG(LAY.fN), 0, HT, KH, xbuf + wbuf * XB, wave, lane, afd, gacc);
                     float dot = 0.f, n2 = 0.f;
 #pragma unroll
                     for (int s = 0; s < ZR; ++s) {
@@ -237,13 +238,13 @@ __device__ __forceinline__ void coopx_eval(const float* __restrict__ P, f32x4* x
                 for (int m = 0; m < MTW; ++m)
 #pragma unroll
                     for (int q = 0; q < NT; ++q) acc[m][q] = f32x4{0.f, 0.f, 0.f, 0.f};
-                coop_gemm<MTW, NT, NT>(AIMG(LAY.bh + (l - 1) * IMG), mt0, HT, xbuf + wbuf * XB, 0, lane, afr, acc);
+                coop_gemm_rt<MTW, NT, NT>(AIMG(LAY.bh + (l - 1) * IMG), mt0, HT, KH, xbuf + wbuf * XB, 0, lane, afr, acc);
                 if (l > 1) coop_load_a<MTW>(AIMG(LAY.bh + (l - 2) * IMG), mt0, HT, 0, afr);
             } else if (owner) {
                 f32x4 gacc[DT][1];   // g = W_1[:,0:D]^T delta_1 = eps_p^T J for this wave's own sample tile
 #pragma unroll
                 for (int m = 0; m < DT; ++m) gacc[m][0] = f32x4{0.f, 0.f, 0.f, 0.f};
-                coop_gemm<DT, 1, NT>(AIMG(LAY.b1), 0, HT, xbuf + wbuf * XB, wave, lane, afd, gacc);
+                coop_gemm_rt<DT, 1, NT>(AIMG(LAY.b1), 0, HT, KH, xbuf + wbuf * XB, wave, lane, afd, gacc);
                 float dot = 0.f, n2 = 0.f;
 #pragma unroll
                 for (int s = 0; s < ZR; ++s) {
@@ -352,7 +353,7 @@ coopx_solve_kernel(KArgs a) {
                 for (int s = 0; s < ZR; ++s) zs[s] = fmaf(dt, Pz[0][s], z[s]);
                 float* gout = (a.ckpt_g && owner && !single) ? a.ckpt_g + ((((long long)step * ns + sg) * ckntp + cktile) * 64 + lane) * ZR : nullptr;
                 coopx_eval<HT, L, ZR, CR, ACT>(a.packed, xbuf, zbuf, ebuf, ybuf, lane, wave, tn + a.T.c[sg] * dt, autonomous, reg_z, reg_j,
-                                                exact, jvp, D, K, eps_col, zs, zd, ld, ed, nd, gout, a.q_off);
+                                                exact, jvp, D, K, eps_col, zs, zd, ld, ed, nd, gout, a.q_off, a.KH);
                 if (a.ckpt_k && owner && !single) {
 #pragma unroll
                     for (int s = 0; s < ZR; ++s) a.ckpt_k[((((long long)step * ns + sg) * ckntp + cktile) * 64 + lane) * ZR + s] = zd[s];

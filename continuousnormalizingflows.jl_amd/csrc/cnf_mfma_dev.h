@@ -32,6 +32,7 @@ struct KArgs {
     float* ckpt_g;      // optional (cooperative checkpointing solve): g = eps^T J of every stage, laid out like ckpt_k (gradient of |eps^T J|)
     int q_off;          // extended cooperative kernel, exact trace of a two-hidden-layer flow: float offset of the Q image in `packed` (0: none)
     const float* tgrid; // extended cooperative kernel: nsteps + 1 step times on the device (non-uniform grid) or null
+    int KH;             // extended cooperative kernel: 16-row tiles the widest hidden layer really fills (<= the instance's HT; 0: all)
 };
 
 // Device-side step controller (mfma_adaptive_kernel): the whole adaptive Tsit5 solve of a batch that fits the chip's wave
