@@ -142,7 +142,8 @@ __device__ __forceinline__ void coop_eval(const float* __restrict__ P, const flo
         __syncthreads();
         if (l + 1 < L) {
             phase_fence();
-            coop_gemm<MTW, NT, NT>(AIMG(LAY.fh + l * MfmaLayout::imgA(HT, HT)), mt0, HT, xbuf + cur * XB, 0, lane, afr, acc);
+            if constexpr (WL) coop_gemm<MTW, NT, NT>(AIMG(LAY.fh + l * MfmaLayout::imgA(HT, HT)), mt0, HT, xbuf + cur * XB, 0, lane, afr, acc);   // (fragments from LDS: the guarded loop is the faster one)
+            else coop_gemm_rt<MTW, NT, NT>(AIMG(LAY.fh + l * MfmaLayout::imgA(HT, HT)), mt0, HT, HT, xbuf + cur * XB, 0, lane, afr, acc);
             phase_fence();
         }
     }
@@ -161,7 +162,8 @@ __device__ __forceinline__ void coop_eval(const float* __restrict__ P, const flo
                 for (int m = 0; m < DT; ++m) zacc[m][0] += pbuf[(w * DT + m) * 64 + lane];
         } else {
             phase_fence();
-            coop_gemm<DT, 1, NT>(AIMG(LAY.fN), 0, HT, xbuf + hbuf * XB, wave, lane, afd, zacc);
+            if constexpr (WL) coop_gemm<DT, 1, NT>(AIMG(LAY.fN), 0, HT, xbuf + hbuf * XB, wave, lane, afd, zacc);   // (fragments from LDS: the guarded loop is the faster one)
+            else coop_gemm_rt<DT, 1, NT>(AIMG(LAY.fN), 0, HT, HT, xbuf + hbuf * XB, wave, lane, afd, zacc);
             phase_fence();
         }
 #pragma unroll
@@ -230,7 +232,8 @@ __device__ __forceinline__ void coop_eval(const float* __restrict__ P, const flo
 #pragma unroll
                 for (int q = 0; q < NT; ++q) acc[m][q] = f32x4{0.f, 0.f, 0.f, 0.f};
             phase_fence();
-            coop_gemm<MTW, NT, NT>(AIMG(LAY.bh + (l - 1) * MfmaLayout::imgA(HT, HT)), mt0, HT, xbuf + wbuf * XB, 0, lane, afr, acc);
+            if constexpr (WL) coop_gemm<MTW, NT, NT>(AIMG(LAY.bh + (l - 1) * MfmaLayout::imgA(HT, HT)), mt0, HT, xbuf + wbuf * XB, 0, lane, afr, acc);   // (fragments from LDS: the guarded loop is the faster one)
+            else coop_gemm_rt<MTW, NT, NT>(AIMG(LAY.bh + (l - 1) * MfmaLayout::imgA(HT, HT)), mt0, HT, HT, xbuf + wbuf * XB, 0, lane, afr, acc);
             phase_fence();
             if (l > 1) coop_load_a<MTW>(AIMG(LAY.bh + (l - 2) * MfmaLayout::imgA(HT, HT)), mt0, HT, 0, afr);
         } else if (owner) {
@@ -245,7 +248,8 @@ __device__ __forceinline__ void coop_eval(const float* __restrict__ P, const flo
                     for (int m = 0; m < DT; ++m) gacc[m][0] += pbuf[(w * DT + m) * 64 + lane];
             } else {
                 phase_fence();
-                coop_gemm<DT, 1, NT>(AIMG(LAY.b1), 0, HT, xbuf + wbuf * XB, wave, lane, afd, gacc);
+                if constexpr (WL) coop_gemm<DT, 1, NT>(AIMG(LAY.b1), 0, HT, xbuf + wbuf * XB, wave, lane, afd, gacc);   // (fragments from LDS: the guarded loop is the faster one)
+                else coop_gemm_rt<DT, 1, NT>(AIMG(LAY.b1), 0, HT, HT, xbuf + wbuf * XB, wave, lane, afd, gacc);
                 phase_fence();
             }
             // this lane's probe values sit in the B image of eps (k-group kg, own sample tile): no registers held for them
