@@ -146,7 +146,8 @@ static int loss_grad_impl(cnf_handle* h, const char* who, int alg, int nsteps, f
             return CNF_OK;
         }
         std::string msg;
-        if (coop_grad_eligible(h->cfg, h->plan, lam, tgrid) && h->packed_dev && !getenv("CNF_LAYERED_LOSS_BY_SOLVE")) {
+        if (coop_grad_eligible(h->cfg, h->plan, lam, tgrid) && h->packed_dev && B <= coop_grad_max_columns(h->cfg, alg) &&
+            !getenv("CNF_LAYERED_LOSS_BY_SOLVE")) {
             // wide hidden layers on the cooperative kernels: checkpointing forward solve (which also yields the loss terms),
             // one reverse-sweep launch per step, deferred weight-cotangent products (cnf_coop_grad.hip)
             float* cg_logp = sums4 ? h->grad_ws : nullptr;

@@ -976,6 +976,13 @@ __global__ void fill_rows_kernel(float* __restrict__ a, int ld, int row0, int ro
     a[(c0 + i / nr) * ld + row0 + (int)(i % nr)] = val;
 }
 
+// The sweep kernel addresses its operand arrays through 32-bit buffer resources and 32-bit byte offsets: the largest array
+// ((H + 1, padded) rows x 2 x stages x B columns of floats) has to stay below 2 GB.  Larger batches take the layer-wise path.
+long long coop_grad_max_columns(const cnf_config& c, int alg) {
+    const long long ldy = (c.widths[1] + 1 + 15) / 16 * 16, ns = make_tableau(alg).ns;
+    return 0x7fffffffLL / (ldy * 4 * 2 * ns);
+}
+
 bool coop_grad_eligible(const cnf_config& c, const MfmaPlan* plan, const float lam[3], const float* tgrid) {
     int HT, L, ZR, ACT, CR;
     if (!mfma_plan_coop_grad_shape(plan, &HT, &L, &ZR, &ACT, &CR)) return false;
