@@ -492,6 +492,7 @@ coop_grad_step_kernel(CGArgs a) {
             }
             // ================= down: [u_l | hbar_l] = W_{l+1}^T [delta_{l+1} | sbar_{l+1}] =================
             f32x4 afd[DT];
+            const int kq0z = wave * KHE / 4;      // this wave's first k-group of the Zbar product (split along K, below)
 #pragma unroll
             for (int l = L - 1; l >= 1; --l) {
                 T2 t;
@@ -512,7 +513,7 @@ coop_grad_step_kernel(CGArgs a) {
                 if (l > 1) sload(SLOT_DB + l - 2, dbl);
                 tail2(HT, afr, t);
                 if (l > 1) pre_a(LAY.bh + (l - 2) * IMG, HT, afr);
-                else if (owner) coop_load_a<DT>(AIMG(LAY.b1), 0, HT, 0, afd);
+                else coop_load_a<DT>(AIMG(LAY.b1), 0, HT, kq0z < HT ? kq0z : HT - 1, afd);   // first fragments of this wave's share of the Zbar product
                 cur ^= 1;
 #pragma unroll
                 for (int m = 0; m < MTW; ++m)
@@ -528,16 +529,47 @@ coop_grad_step_kernel(CGArgs a) {
                 gstore(cur, 1, rx[l - 1], vox, sx2);                          // sbar_l half
                 CG_SYNC();
             }
-            // Zbar_i = W_1[:,0:D]^T sbar_1 for this wave's own sample tile
-            if (owner) {
-                f32x4 zacc[DT][1];
+            // Zbar_i = W_1[:,0:D]^T sbar_1: D rows x the sample tiles, K = H.  SPLIT ALONG K over the four waves (wave w: k-groups
+            // [w KHE / 4, (w + 1) KHE / 4)) - run by the owner waves alone it is a quarter of a stage of the reference's default
+            // architecture (D ~ H / 4, two layers) during which the other waves wait.  The partial tiles meet in the exchange
+            // buffer no product reads any more; the owner adds them in wave order.
+            {
+                f32x4 zacc[DT][NT];
 #pragma unroll
-                for (int m = 0; m < DT; ++m) zacc[m][0] = f32x4{0.f, 0.f, 0.f, 0.f};
-                coop_gemm_rt<DT, 1, CT>(AIMG(LAY.b1), 0, HT, KHE, xbuf + cur * XB, NT + wave, lane, afd, zacc);
+                for (int m = 0; m < DT; ++m)
 #pragma unroll
-                for (int s = 0; s < ZR; ++s) zbt[i * ZR + s] = zacc[s >> 2][0][s & 3];
+                    for (int q = 0; q < NT; ++q) zacc[m][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+                const int kq1 = (wave + 1) * KHE / 4;
+                f32x4 bz[NT];
+                coop_load_b<NT, CT>(xbuf + cur * XB, NT, kq0z < HT ? kq0z : HT - 1, lane, bz);
+#pragma clang loop unroll(disable)
+                for (int kg = kq0z; kg < kq1; ++kg) {
+                    const int kn = kg + 1 < kq1 ? kg + 1 : kq1 - 1;   // clamped prefetch (no load under a branch)
+                    f32x4 an[DT], bn[NT];
+                    coop_load_a<DT>(AIMG(LAY.b1), 0, HT, kn, an);
+                    coop_load_b<NT, CT>(xbuf + cur * XB, NT, kn, lane, bn);
+                    coop_frag_mfma<DT, NT>(afd, bz, zacc);
+#pragma unroll
+                    for (int m = 0; m < DT; ++m) afd[m] = an[m];
+#pragma unroll
+                    for (int q = 0; q < NT; ++q) bz[q] = bn[q];
+                }
+                f32x4* pz = xbuf + (cur ^ 1) * XB;        // [wave][DT][NT][64] partial tiles
+#pragma unroll
+                for (int m = 0; m < DT; ++m)
+#pragma unroll
+                    for (int q = 0; q < NT; ++q) pz[((wave * DT + m) * NT + q) * 64 + lane] = zacc[m][q];
             }
             CG_SYNC();
+            if (owner) {
+#pragma unroll
+                for (int s = 0; s < ZR; ++s) {
+                    const f32x4* pz = xbuf + (cur ^ 1) * XB + (((s >> 2)) * NT + wave) * 64 + lane;
+                    zbt[i * ZR + s] = ((pz[0 * DT * NT * 64][s & 3] + pz[1 * DT * NT * 64][s & 3]) + pz[2 * DT * NT * 64][s & 3]) + pz[3 * DT * NT * 64][s & 3];
+                }
+            }
+            // (no barrier here: the next stage writes these buffers only behind its own first barrier, which the owner reaches
+            // after this sum; the super-tile loop starts with one)
         }
         if (owner) {
 #pragma unroll
