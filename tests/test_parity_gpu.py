@@ -146,6 +146,7 @@ COOPX_CASES = [
     (dict(nvars=24, naug=25, ncond=4, hidden=[216, 216], act=2, mode=2), 40, 0, 5),          # conditioned, D = 49
     (dict(nvars=12, hidden=[192, 192], mode=2, autonomous=True), 50, 1, 4),                  # tanh, autonomous
     (dict(nvars=40, naug=41, hidden=[328, 328], act=2, mode=2), 33, 0, 3),                   # ICNF(nvariables = 40): 24 x 24 tiles
+    (dict(nvars=6, naug=2, ncond=16, hidden=[200, 200], mode=2, autonomous=True), 40, 0, 4),  # 16 conditions, autonomous, tanh
 ]
 CASES = CASES + COOPX_CASES
 
@@ -680,6 +681,9 @@ COOP_GRAD_SHAPES = [
     (dict(nvars=8, ncond=8, hidden=[256, 256, 256], reg_z=True, reg_j=True), 70, 1, 2, {"lam": (0.01, 0.01, 0.0)}),   # conditioned RNODE, tanh
     (dict(nvars=16, naug=17, ncond=5, hidden=[156, 156], act=2, reg_z=True, reg_j=True, reg_aug=True), 50, 0, 2, {"lam": (0.01, 0.01, 0.01)}),   # default architecture (nvariables = 16) with 5 conditions
     (dict(nvars=20, naug=21, ncond=16, hidden=[232, 232], act=2, autonomous=True), 40, 1, 2, {}),   # 16 conditions, D = 41, autonomous
+    # edges: one column and one step; the largest instance (24 x 24 tiles) filled exactly
+    (dict(nvars=32, hidden=[256, 256, 256], reg_z=True, reg_j=True), 1, 0, 1, {"lam": (0.01, 0.01, 0.0)}),
+    (dict(nvars=47, naug=48, hidden=[384, 384], act=2, reg_z=True, reg_j=True, reg_aug=True), 20, 1, 2, {"lam": (0.01, 0.01, 0.01)}),   # ICNF(nvariables = 47)
 ]
 
 
