@@ -46,8 +46,10 @@ __device__ __forceinline__ void coop_eval(const float* __restrict__ P, const flo
                                           f32x4* __restrict__ zbuf, const f32x4* __restrict__ ebuf, f32x4* __restrict__ pbuf,
                                           int lane, int wave, float t, bool autonomous, bool reg_z,
                                           bool reg_j, const float (&zs)[ZR],
-                                          float (&zd)[ZR], float& ld, float& ed, float& nd, float* __restrict__ gout = nullptr) {
+                                          float (&zd)[ZR], float& ld, float& ed, float& nd, float* __restrict__ gout = nullptr, int KHa = 0) {
     constexpr MfmaLayout LAY(HT, L, ZR, 0, true);
+    // hidden k-groups that are not zero padding (even): a width that fills fewer 16-row tiles than the instance has skips the rest
+    const int KH = (KHa > 0 && KHa < HT) ? ((KHa + 1) & ~1) : HT;
     constexpr int MTW = HT / 4, DT = (ZR + 3) / 4, XB = HT * NT * 64;   // XB: f32x4 per exchange buffer
     const bool owner = wave < NT;                                        // this wave integrates sample tile `wave`
     const int g = lane >> 4;
@@ -143,7 +145,7 @@ __device__ __forceinline__ void coop_eval(const float* __restrict__ P, const flo
         if (l + 1 < L) {
             phase_fence();
             if constexpr (WL) coop_gemm<MTW, NT, NT>(AIMG(LAY.fh + l * MfmaLayout::imgA(HT, HT)), mt0, HT, xbuf + cur * XB, 0, lane, afr, acc);   // (fragments from LDS: the guarded loop is the faster one)
-            else coop_gemm_rt<MTW, NT, NT>(AIMG(LAY.fh + l * MfmaLayout::imgA(HT, HT)), mt0, HT, HT, xbuf + cur * XB, 0, lane, afr, acc);
+            else coop_gemm_rt<MTW, NT, NT>(AIMG(LAY.fh + l * MfmaLayout::imgA(HT, HT)), mt0, HT, KH, xbuf + cur * XB, 0, lane, afr, acc);
             phase_fence();
         }
     }
@@ -163,7 +165,7 @@ __device__ __forceinline__ void coop_eval(const float* __restrict__ P, const flo
         } else {
             phase_fence();
             if constexpr (WL) coop_gemm<DT, 1, NT>(AIMG(LAY.fN), 0, HT, xbuf + hbuf * XB, wave, lane, afd, zacc);   // (fragments from LDS: the guarded loop is the faster one)
-            else coop_gemm_rt<DT, 1, NT>(AIMG(LAY.fN), 0, HT, HT, xbuf + hbuf * XB, wave, lane, afd, zacc);
+            else coop_gemm_rt<DT, 1, NT>(AIMG(LAY.fN), 0, HT, KH, xbuf + hbuf * XB, wave, lane, afd, zacc);
             phase_fence();
         }
 #pragma unroll
@@ -233,7 +235,7 @@ __device__ __forceinline__ void coop_eval(const float* __restrict__ P, const flo
                 for (int q = 0; q < NT; ++q) acc[m][q] = f32x4{0.f, 0.f, 0.f, 0.f};
             phase_fence();
             if constexpr (WL) coop_gemm<MTW, NT, NT>(AIMG(LAY.bh + (l - 1) * MfmaLayout::imgA(HT, HT)), mt0, HT, xbuf + wbuf * XB, 0, lane, afr, acc);   // (fragments from LDS: the guarded loop is the faster one)
-            else coop_gemm_rt<MTW, NT, NT>(AIMG(LAY.bh + (l - 1) * MfmaLayout::imgA(HT, HT)), mt0, HT, HT, xbuf + wbuf * XB, 0, lane, afr, acc);
+            else coop_gemm_rt<MTW, NT, NT>(AIMG(LAY.bh + (l - 1) * MfmaLayout::imgA(HT, HT)), mt0, HT, KH, xbuf + wbuf * XB, 0, lane, afr, acc);
             phase_fence();
             if (l > 1) coop_load_a<MTW>(AIMG(LAY.bh + (l - 2) * MfmaLayout::imgA(HT, HT)), mt0, HT, 0, afr);
         } else if (owner) {
@@ -249,7 +251,7 @@ __device__ __forceinline__ void coop_eval(const float* __restrict__ P, const flo
             } else {
                 phase_fence();
                 if constexpr (WL) coop_gemm<DT, 1, NT>(AIMG(LAY.b1), 0, HT, xbuf + wbuf * XB, wave, lane, afd, gacc);   // (fragments from LDS: the guarded loop is the faster one)
-                else coop_gemm_rt<DT, 1, NT>(AIMG(LAY.b1), 0, HT, HT, xbuf + wbuf * XB, wave, lane, afd, gacc);
+                else coop_gemm_rt<DT, 1, NT>(AIMG(LAY.b1), 0, HT, KH, xbuf + wbuf * XB, wave, lane, afd, gacc);
                 phase_fence();
             }
             // this lane's probe values sit in the B image of eps (k-group kg, own sample tile): no registers held for them
@@ -372,7 +374,7 @@ coop_vjp_solve_kernel(KArgs a) {
                     if (a.ckpt_g) gout = a.ckpt_g + ((((long long)step * ns + sg) * nst * NT + st * NT + wave) * 64 + lane) * ZR;
                 }
                 coop_eval<HT, L, ZR, ACT, NT, WL, CK>(a.packed, wl, xbuf, zbuf, ebuf, pbuf, lane, wave, tn + a.T.c[sg] * dt, autonomous,
-                                          reg_z, reg_j, zs, zd, ld, ed, nd, gout);
+                                          reg_z, reg_j, zs, zd, ld, ed, nd, gout, a.KH);
                 if constexpr (CK) {
                     if (owner) {
 #pragma unroll

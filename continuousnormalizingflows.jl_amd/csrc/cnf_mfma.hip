@@ -462,10 +462,10 @@ hipError_t mfma_solve(MfmaPlan* p, const float* packed_dev, const SolveArgs& s, 
         if (e != hipSuccess) return e;
         a.queue = mp->queue_dev;
     }
+    if (p->kind != 0) { int hmax = 0; for (int l = 1; l < p->cfg.n_layers; ++l) hmax = p->cfg.widths[l] > hmax ? p->cfg.widths[l] : hmax; a.KH = (hmax + 15) / 16; }
     if (p->kind == 2) {
         if (p->cfg.mode == CNF_MODE_HUTCH_JVP) a.exact = 2;   // this kernel family's code for the JVP form (cnf_coop_x.hip)
         a.q_off = p->q_extra;
-        { int hmax = 0; for (int l = 1; l < p->cfg.n_layers; ++l) hmax = p->cfg.widths[l] > hmax ? p->cfg.widths[l] : hmax; a.KH = (hmax + 15) / 16; }
         return coopx_launch(p->HT, p->L, p->ZR, p->CR, p->ACT, a, mp->num_cus, st);
     }
     if (p->kind == 1) {
