@@ -207,6 +207,9 @@ int cnf_destroy(cnf_handle* h) {
     free_pack_map(h->map_slab);
     if (h->slab_packed) (void)hipFree(h->slab_packed);
     if (h->slab_ws) (void)hipFree(h->slab_ws);
+    free_pack_map(h->map_cg);
+    if (h->cg_packed) (void)hipFree(h->cg_packed);
+    if (h->plan_cg) mfma_plan_destroy(h->plan_cg);
     if (h->plan) mfma_plan_destroy(h->plan);
     delete h;
     return CNF_OK;
@@ -348,6 +351,31 @@ int cnf_set_params(cnf_handle* h, const float* p, size_t n, const size_t* w_off,
         } else {
             HIP_TRY(hipFree(h->slab_packed));
             h->slab_packed = nullptr;
+        }
+    }
+    // image of the auxiliary cooperative plan (see cnf_handle::plan_cg): wide two-layer slab shapes, one-probe VJP, no conditions
+    if (grad_slab_supported(c) && !(mfma && want_grad) && c.mode == CNF_MODE_HUTCH_VJP && c.nprobes == 1 && c.ncond == 0 &&
+        c.widths[1] > 96 && c.widths[1] == c.widths[2] && c.widths[1] % 4 == 0) {
+        if (!h->cg_tried) {
+            h->cg_tried = true;
+            const char* e = getenv("CNF_COOP_GRAD_MID");
+            if (!(e && *e == '0')) h->plan_cg = mfma_plan_create(c, true);
+        }
+        if (h->plan_cg) {
+            const size_t cb = mfma_packed_bytes(h->plan_cg);
+            if (!h->cg_packed) HIP_TRY(hipMalloc((void**)&h->cg_packed, cb));
+            if (!h->map_cg.valid || !same_layout)
+                build_pack_map(h->map_cg, n, cb / sizeof(float),
+                               [&](const float* src, float* dst) { mfma_pack(h->plan_cg, src, w_off, b_off, dst); });
+            if (h->map_cg.valid) {
+                const size_t np = h->map_cg.n;
+                hipLaunchKernelGGL(gather_pack_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, st, h->P_dev,
+                                   h->map_cg.idx, h->map_cg.scale, h->cg_packed, np);
+                HIP_TRY(hipGetLastError());
+            } else {
+                HIP_TRY(hipFree(h->cg_packed));
+                h->cg_packed = nullptr;
+            }
         }
     }
     h->nparams = n;

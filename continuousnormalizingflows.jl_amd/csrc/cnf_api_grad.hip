@@ -44,6 +44,10 @@ bool cnf::api_grad_is_fused(const cnf_handle* h) {
 
 // slab-accumulator kernel for the mid-width two-hidden-layer nets (CNF_GRAD_LAYERED=1 skips it too)
 extern "C++" {
+// batches from which the cooperative reverse sweep beats the slab kernel on the shapes that have both (86 -> 80 ms at 2 x 104,
+// 106 -> 84 ms at 2 x 128, B = 65 536; the sweep's 40 + 160 launches per gradient need columns to amortise)
+bool cnf::api_grad_uses_coop_aux(const cnf_handle* h, int64_t B) { return h->plan_cg && h->cg_packed && B >= 4096; }
+
 bool cnf::api_grad_uses_slab(const cnf_handle* h) {
     const char* force = getenv("CNF_GRAD_LAYERED");
     return (h->slab_packed || !h->have_params) && grad_slab_supported(h->cfg) && !(force && *force && *force != '0');
@@ -52,7 +56,7 @@ bool cnf::api_grad_uses_slab(const cnf_handle* h) {
 
 int cnf_grad_path(const cnf_handle* h) {
     if (!h) return CNF_ERR_INVALID;
-    if (api_grad_is_fused(h) || api_grad_uses_slab(h)) return 1;
+    if (api_grad_is_fused(h) || api_grad_uses_slab(h)) return 1;   // (slab shapes with an auxiliary cooperative plan: 3 from 4096 columns on)
     const bool hutch = h->cfg.mode != CNF_MODE_EXACT;
     const float lamf[3] = {hutch && h->cfg.reg_z ? 1.f : 0.f, hutch && h->cfg.reg_j ? 1.f : 0.f, 0.f};
     if (coop_grad_eligible(h->cfg, h->plan, lamf, nullptr) && h->packed_dev) return 3;   // uniform steps and frozen adaptive grids alike
@@ -97,7 +101,11 @@ static int loss_grad_impl(cnf_handle* h, const char* who, int alg, int nsteps, f
     }
     if (!fused) {
         // the loss sums come from the regular solve on whichever family serves the handle
-        const bool loss_in_sweep = sums4 && !api_grad_uses_slab(h) && !getenv("CNF_LAYERED_LOSS_BY_SOLVE");
+        const bool hutch0 = h->cfg.mode != CNF_MODE_EXACT;
+        const float lam0[3] = {hutch0 && h->cfg.reg_z ? lambdas[0] : 0.f, hutch0 && h->cfg.reg_j ? lambdas[1] : 0.f, 0.f};
+        const bool use_cg = api_grad_uses_coop_aux(h, B) && coop_grad_eligible(h->cfg, h->plan_cg, lam0, tgrid) &&
+                            B <= coop_grad_max_columns(h->cfg, alg);
+        const bool loss_in_sweep = sums4 && (use_cg || !api_grad_uses_slab(h)) && !getenv("CNF_LAYERED_LOSS_BY_SOLVE");
         if (sums4) {
             const size_t need = ((size_t)h->S + 4) * (size_t)B * sizeof(float);
             if (need > h->grad_ws_bytes) {
@@ -127,7 +135,7 @@ static int loss_grad_impl(cnf_handle* h, const char* who, int alg, int nsteps, f
         const bool hutch = h->cfg.mode != CNF_MODE_EXACT;   // the exact-trace dynamics carry no regularisers (icnf.jl:297-339)
         const int ra = (hutch && h->cfg.reg_aug && h->cfg.naug > 0) ? 1 : 0;
         const float lam[3] = {hutch && h->cfg.reg_z ? lambdas[0] : 0.f, hutch && h->cfg.reg_j ? lambdas[1] : 0.f, ra ? lambdas[2] : 0.f};
-        if (api_grad_uses_slab(h)) {
+        if (api_grad_uses_slab(h) && !use_cg) {
             // two-hidden-layer nets of 4..7 hidden tiles: tile-fused reverse sweep with slab accumulators (cnf_grad_slab.hip)
             if (h->num_cus == 0) {
                 hipDeviceProp_t prop;
@@ -146,12 +154,14 @@ static int loss_grad_impl(cnf_handle* h, const char* who, int alg, int nsteps, f
             return CNF_OK;
         }
         std::string msg;
-        if (coop_grad_eligible(h->cfg, h->plan, lam, tgrid) && h->packed_dev && B <= coop_grad_max_columns(h->cfg, alg) &&
-            !getenv("CNF_LAYERED_LOSS_BY_SOLVE")) {
+        MfmaPlan* cgp = use_cg ? h->plan_cg : h->plan;
+        const float* cgi = use_cg ? h->cg_packed : h->packed_dev;
+        if (coop_grad_eligible(h->cfg, cgp, lam, tgrid) && cgi && B <= coop_grad_max_columns(h->cfg, alg) &&
+            (use_cg || !getenv("CNF_LAYERED_LOSS_BY_SOLVE"))) {
             // wide hidden layers on the cooperative kernels: checkpointing forward solve (which also yields the loss terms),
             // one reverse-sweep launch per step, deferred weight-cotangent products (cnf_coop_grad.hip)
             float* cg_logp = sums4 ? h->grad_ws : nullptr;
-            hipError_t e = coop_grad(&h->layered, h->cfg, h->plan, h->packed_dev, h->w_off.data(), h->b_off.data(), x, eps, ys, alg, nsteps,
+            hipError_t e = coop_grad(&h->layered, h->cfg, cgp, cgi, h->w_off.data(), h->b_off.data(), x, eps, ys, alg, nsteps,
                                      t0, t1, tgrid, tgrid_dev, B, lam, grad, grad_x, cg_logp, cg_logp ? cg_logp + B : nullptr, st, &msg);
             if (e != hipSuccess) return fail(CNF_ERR_HIP, w + ": " + msg);
             if (sums4) HIP_TRY(loss_sums(cg_logp, cg_logp + B, B, h->loss_partial, sums4, st));

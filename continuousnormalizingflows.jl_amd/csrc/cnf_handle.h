@@ -78,6 +78,12 @@ struct cnf_handle {
     // when the layout handed to cnf_set_params changes; p_stage holds host-supplied parameters
     cnf::PackMap map_fwd, map_grad, map_slab;
     float* slab_packed = nullptr;        // operand image of the slab-accumulator gradient kernel (cnf_grad_slab.hip)
+    // Two-hidden-layer nets of 7 .. 8 hidden tiles keep their per-wave forward plan (the one-launch adaptive solvers hang off it),
+    // but at large batches their gradient is faster on the cooperative reverse sweep: a second, cooperative plan + image for it
+    cnf::MfmaPlan* plan_cg = nullptr;
+    float* cg_packed = nullptr;
+    cnf::PackMap map_cg;
+    bool cg_tried = false;
     float* slab_ws = nullptr;            // its checkpoints + slabs
     size_t slab_ws_floats = 0;
     cnf::LayeredGrad* layered = nullptr;      // operand images + workspaces of the layer-wise evaluation / gradient and of the cooperative gradient
@@ -124,6 +130,7 @@ int api_integrate_grid(cnf_handle* h, int alg, int nsteps, const float* tgrid, f
 cnf_config api_grad_cfg(const cnf_handle* h);
 bool api_grad_is_fused(const cnf_handle* h);
 bool api_grad_uses_slab(const cnf_handle* h);
+bool api_grad_uses_coop_aux(const cnf_handle* h, int64_t B);   // the auxiliary cooperative plan serves this batch size
 // cnf_api_adaptive.hip
 int api_ensure_adaptive_buf(cnf_handle* h, int64_t B);
 int api_solve_tsit5(cnf_handle* h, float t0, float t1, const float* u0, const float* eps, const float* ys, int64_t B,

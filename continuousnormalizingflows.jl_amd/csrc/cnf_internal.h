@@ -47,7 +47,7 @@ hipError_t embedded_error(const float* u, const float* unew, const float* const*
 struct MfmaPlan;  // opaque: packed-weight layout + kernel selection for one config
 
 // Returns nullptr if the configuration is outside what the MFMA kernels cover.
-MfmaPlan* mfma_plan_create(const cnf_config& cfg);
+MfmaPlan* mfma_plan_create(const cnf_config& cfg, bool coop_only = false);   // coop_only: the cooperative kernel's plan or null
 void mfma_plan_destroy(MfmaPlan* p);
 // bytes of the packed weight image (device buffer the plan needs)
 size_t mfma_packed_bytes(const MfmaPlan* p);

@@ -95,7 +95,7 @@ static int env_int(const char* name, int dflt) {
     return (v && *v) ? atoi(v) : dflt;
 }
 
-MfmaPlan* mfma_plan_create(const cnf_config& c) {
+MfmaPlan* mfma_plan_create(const cnf_config& c, bool coop_only) {
     const int N = c.n_layers, L = N - 1;
     if (L < 1) return nullptr;
     // hidden layers may have different widths: every one is zero-padded to the widest (act(0) of a padded
@@ -112,7 +112,7 @@ MfmaPlan* mfma_plan_create(const cnf_config& c) {
     const int KP = c.mode == CNF_MODE_EXACT ? 1 : c.nprobes;
     const int want_nt = env_int("CNF_MFMA_NT", 0);
     const int want_pre = env_int("CNF_MFMA_PRE", -1);
-    const bool force_coop = env_int("CNF_MFMA_COOP", 0) != 0;
+    const bool force_coop = coop_only || env_int("CNF_MFMA_COOP", 0) != 0;
     auto make_coop = [&]() -> MfmaPlan* {
         int zr_inst = ZR, ht_inst = HT;
         if (!coop_supported(HT, L, ZR, CR, c.acts[0], engine, KP, &zr_inst, &ht_inst)) return nullptr;

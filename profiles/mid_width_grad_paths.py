@@ -1,8 +1,7 @@
-"""Loss + gradient of the reference's default architecture at nvariables 12 / 15 (two softplus layers of 104 / 128) on the path the
-library picks (the fused register-accumulator kernel) and, with CNF_MFMA_COOP=1 CNF_GRAD_LAYERED=1, forced onto the cooperative
-forward plan + cooperative gradient.  One MI355X, B = 65 536, Tsit5 x 40: 86.4 / 105.9 ms fused, 79.9 / 83.9 ms cooperative -
-the cooperative gradient would win from ~100 hidden units on, but these shapes keep their per-wave forward plan (the one-launch
-adaptive solvers hang off it), and a second plan + packed image per handle just for the gradient is not built."""
+"""Loss + gradient of the reference's default architecture at nvariables 12 / 15 (two softplus layers of 104 / 128), B = 65 536,
+Tsit5 x 40.  These shapes keep their per-wave forward plan (the one-launch adaptive solvers hang off it); from 4096 columns on their
+gradient runs on the cooperative reverse sweep through an auxiliary cooperative plan + image (cnf_handle::plan_cg):
+86.4 / 105.9 ms on the slab-accumulator kernel (CNF_COOP_GRAD_MID=0) -> 77.3 / 79.8 ms."""
 import os, sys, torch
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import __graft_entry__ as entry

@@ -719,6 +719,43 @@ def test_parameter_gradient_cooperative_reverse_sweep(kw, B, alg, nsteps, env, p
     assert np.max(np.abs(out["coop"][1] - out["layered"][1])) < 2e-5 * np.abs(gref).max() + 1e-6
 
 
+@pytest.mark.parametrize("kw", [
+    dict(nvars=15, naug=16, hidden=[128, 128], act=2, reg_z=True, reg_j=True, reg_aug=True),    # ICNF(nvariables = 15): 8 hidden tiles
+    dict(nvars=12, naug=13, hidden=[104, 104], act=2, reg_z=True, reg_j=True, reg_aug=True),    # ICNF(nvariables = 12): 7
+    dict(nvars=6, hidden=[112, 112]),                                                            # tanh FFJORD
+])
+def test_mid_width_gradient_takes_the_cooperative_sweep_at_large_batches(kw, pkg, oracles, monkeypatch):
+    """Two-hidden-layer nets of 7 - 8 hidden tiles keep their per-wave forward plan; from 4096 columns on their gradient runs on
+    the cooperative reverse sweep through an auxiliary cooperative plan and image (cnf_handle::plan_cg) - against fp64 autograd
+    and against the slab-accumulator kernel they take below that size (CNF_COOP_GRAD_MID=0 keeps them there)."""
+    o64, _ = oracles
+    spec = o64.make_spec(**kw)
+    B, nsteps, alg = 4096, 2, 1
+    lam = (0.01, 0.01, 0.01) if spec.reg_z else (0.0, 0.0, 0.0)
+    p, xs, eps, ys = o64.synth_inputs(spec, B, 77, bias_scale=0.2)
+    L, gref, gxref = o64.loss_and_grad(spec, p, xs, 0.0, 1.0, nsteps, alg, eps, ys, lam, wrt_x=True)
+    mode = mode_of(pkg, spec)
+    out = {}
+    for tag, flag in (("aux", "1"), ("slab", "0")):
+        monkeypatch.setenv("CNF_COOP_GRAD_MID", flag)
+        icnf = make_icnf(pkg, spec, alg, nsteps, path=0, lambdas=lam)
+        val, g, gx = pkg.loss_and_gradient(icnf, mode, dev(xs), dev(p), {}, eps=dev(eps), wrt_x=True)
+        assert icnf.kernel_path(mode) == 2 and icnf.grad_path(mode) == 1
+        out[tag] = (float(val), g.cpu().numpy().astype(np.float64), gx.cpu().numpy().astype(np.float64))
+        assert abs(out[tag][0] - L) < 1e-4 + 2e-6 * abs(L), tag
+        assert np.max(np.abs(out[tag][1] - gref)) < 5e-5 * np.abs(gref).max() + 1e-6, tag
+        assert np.max(np.abs(out[tag][2] - gxref)) < 5e-5 * np.abs(gxref).max() + 1e-7, tag
+    assert np.max(np.abs(out["aux"][1] - out["slab"][1])) > 0.0      # two implementations, two summation orders
+    # below the threshold the same handle serves the slab kernel
+    monkeypatch.setenv("CNF_COOP_GRAD_MID", "1")
+    icnf = make_icnf(pkg, spec, alg, nsteps, path=0, lambdas=lam)
+    val, g = pkg.loss_and_gradient(icnf, mode, dev(xs[:, :300]), dev(p), {}, eps=dev(eps[:, :300]))
+    monkeypatch.setenv("CNF_COOP_GRAD_MID", "0")
+    icnf0 = make_icnf(pkg, spec, alg, nsteps, path=0, lambdas=lam)
+    val0, g0 = pkg.loss_and_gradient(icnf0, mode, dev(xs[:, :300]), dev(p), {}, eps=dev(eps[:, :300]))
+    assert float(val) == float(val0) and torch.equal(g, g0)
+
+
 def test_cooperative_gradient_at_full_size_agrees_with_the_layerwise_path(pkg, oracles, monkeypatch):
     """BASELINE cfg4's shard (D = 32, 3 x 256, RK4 x 40, B = 32 768): loss, dloss/dps and dloss/dxs of the cooperative reverse
     sweep against the layer-wise path on the same inputs - two independent implementations of the same discrete adjoint
