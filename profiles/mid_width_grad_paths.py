@@ -7,7 +7,7 @@ sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import __graft_entry__ as entry
 pkg = entry.load_package()
 dev = torch.device("cuda:0")
-for nv in (12, 15):
+for nv in tuple(int(v) for v in os.environ.get("NVS", "12,15").split(",")):
     icnf = pkg.ICNF(nvariables=nv, device=dev, steer_rate=0.0, sol_kwargs=dict(alg=pkg.Tsit5(), adaptive=False, nsteps=40))
     ps, st = pkg.setup(torch.Generator().manual_seed(0), icnf)
     B = 65536
