@@ -736,12 +736,21 @@ hipError_t lg_wgrad(float* slabs, long long slab_stride, long long chunk, int nc
     const int groups = (NTN + 8) / 9;
     a.nchunks = nchunks; a.rblocks = (MT + 3) / 4; a.groups = groups;
     const dim3 grid((unsigned)(((nchunks + 7) / 8) * 8 * a.rblocks * a.groups));
-    const int ntn = NTN <= 1 ? 1 : NTN <= 3 ? 3 : NTN <= 5 ? 5 : 9;
+    // tiles per column group: the strip's tiles dealt evenly over its groups (11 tiles = 6 + 5, 13 = 7 + 6, 21 = 3 x 7), on
+    // the instance of exactly that many tiles - with the 9-tile instance for every group a 168 x 169 cotangent multiplied
+    // 18 tiles for its 11 (the short last group skips the one tile it lacks)
+    const int ntn = NTN <= 3 ? (NTN <= 1 ? 1 : 3) : (NTN + groups - 1) / groups;
     const int lds = 2 * ((ntn * 16 + 63) / 64 * 1024 + 4 * 256) * (int)sizeof(float);   // <= 2 * 16 KB
-    if (NTN <= 1) hipLaunchKernelGGL(lg_wgrad_kernel<1>, grid, dim3(256), lds, st, a);
-    else if (NTN <= 3) hipLaunchKernelGGL(lg_wgrad_kernel<3>, grid, dim3(256), lds, st, a);
-    else if (NTN <= 5) hipLaunchKernelGGL(lg_wgrad_kernel<5>, grid, dim3(256), lds, st, a);
-    else hipLaunchKernelGGL(lg_wgrad_kernel<9>, grid, dim3(256), lds, st, a);
+    switch (ntn) {
+        case 1: hipLaunchKernelGGL(lg_wgrad_kernel<1>, grid, dim3(256), lds, st, a); break;
+        case 3: hipLaunchKernelGGL(lg_wgrad_kernel<3>, grid, dim3(256), lds, st, a); break;
+        case 4: hipLaunchKernelGGL(lg_wgrad_kernel<4>, grid, dim3(256), lds, st, a); break;
+        case 5: hipLaunchKernelGGL(lg_wgrad_kernel<5>, grid, dim3(256), lds, st, a); break;
+        case 6: hipLaunchKernelGGL(lg_wgrad_kernel<6>, grid, dim3(256), lds, st, a); break;
+        case 7: hipLaunchKernelGGL(lg_wgrad_kernel<7>, grid, dim3(256), lds, st, a); break;
+        case 8: hipLaunchKernelGGL(lg_wgrad_kernel<8>, grid, dim3(256), lds, st, a); break;
+        default: hipLaunchKernelGGL(lg_wgrad_kernel<9>, grid, dim3(256), lds, st, a); break;
+    }
     return hipGetLastError();
 }
 
