@@ -165,6 +165,11 @@ def parse():
     ap.add_argument("--secondary", default="auto",
                     help="second workload measured by the same protocol and reported under 'secondary' "
                          "(auto = cfg2p, the north_star's Tsit5 target, when --config cfg2 --mode infer; none = off)")
+    ap.add_argument("--secondaries", default="auto",
+                    help="further workloads measured by the same protocol in the same process and reported compactly under "
+                         "'secondaries' ({value, ms_per_step, roofline: {kernel_ms, frac}, loss}): a comma list of "
+                         "name[:grad] (e.g. cfg3,cfg4,cfg5,cfg2:grad,cfg4:grad), 'none', or 'auto' = exactly that list on the "
+                         "default one-GPU cfg2 line, so that every BASELINE configuration and the gradient are on the driver-run line")
     ap.add_argument("--mode", default="infer", choices=["infer", "grad"],
                     help="infer: loss (default, the BASELINE metric); grad: loss_and_gradient — forward with "
                          "checkpoints + reverse sweep + all-reduce of nparams floats")
@@ -304,9 +309,9 @@ class ClockProbe:
 # ---------------------------------------------------------------------------------------------------
 # workloads
 # ---------------------------------------------------------------------------------------------------
-def make_workload(pkg, o64, name, a, rank, dev, torch, arith=None):
+def make_workload(pkg, o64, name, a, rank, dev, torch, arith=None, grad=None, batch=None):
     kw, alg, Bdef, flop_ss, bytes_call_ss, bytes_fused, desc = CONFIGS[name]
-    B = a.batch or Bdef
+    B = batch or a.batch or Bdef
     spec = o64.make_spec(**kw)
     # weights are shared by all ranks; the batch is generated per global column block so an
     # N-GPU run evaluates N different shards (weak scaling).
@@ -336,7 +341,7 @@ def make_workload(pkg, o64, name, a, rank, dev, torch, arith=None):
     args = (X,) + ((Y,) if Y is not None else ()) + (P, {})
     return dict(name=name, spec=spec, alg=alg, B=B, flop_ss=flop_ss, bytes_call_ss=bytes_call_ss,
                 bytes_fused=bytes_fused, desc=desc, icnf=icnf, mode=mode, args=args, E=E,
-                host=(p, xs, eps, ys))
+                host=(p, xs, eps, ys), grad=(a.mode == "grad") if grad is None else bool(grad))
 
 
 def _quarters(ms):
@@ -350,7 +355,7 @@ def measure(w, a, steps, warmup, preroll_s, pkg, torch, dist, world, dev, probe)
     `sharded` (N > 1, or --force-dist with one rank) selects the column-shard form of the step: cnf_loss_sums + the
     all-reduce of the loss scalars instead of cnf_loss_mean, and the barrier / max-over-ranks timing."""
     icnf, mode, args, E, B = w["icnf"], w["mode"], w["args"], w["E"], w["B"]
-    grad = a.mode == "grad"
+    grad = w["grad"]
     sharded = world > 1 or a.force_dist
     state = {}
 
@@ -450,11 +455,12 @@ def report(w, m, a, steps, warmup, world):
     value = world * B * NSTEPS * steps / m["elapsed"]
     path = icnf.kernel_path(mode)
     extra = {}
-    if a.mode == "grad":
+    grad = w["grad"]
+    if grad:
         # (i) executed MFMA work of forward + reverse sweep per sample*step: v_mfma_f32_16x16x4_f32
         # instructions (2048 flop) per stage per 16-sample tile, recomputation included; (ii) the algorithmic figure:
         # reverse mode of a function costing F is 2F on top of F (each product once forwards, twice backwards) = 3 F
-        gpath = icnf.grad_path(mode)
+        gpath = icnf.grad_path(mode, B=B, alg=alg)      # the implementation THIS call took (cnf_grad_path_for), not the handle's hint
         exec_ss = (grad_mfma_per_stage(spec) * 2048 / 16 if gpath == 1 else coop_grad_flop_per_stage(spec) if gpath == 3
                    else layered_flop_per_stage(spec)) * stages
         extra["executed_flop_per_sample_step"] = exec_ss
@@ -496,13 +502,14 @@ def report(w, m, a, steps, warmup, world):
                    "global_columns": world * B, "nsteps": NSTEPS,
                    "integrator": "RK4" if alg == 0 else "Tsit5",
                    "kernel_path": {1: "simt", 2: "mfma", 3: "layered"}.get(path, str(path)),
-                   "mode": a.mode,
+                   "kernel_family": icnf.kernel_family(mode, B=B), "kernel": icnf.kernel_name(mode),
+                   "mode": "grad" if grad else "infer",
                    **({"gradient_path": {1: "fused reverse-sweep kernel", 2: "layer-wise (hand-written MFMA product kernels)",
                                               3: "cooperative reverse sweep + deferred weight-cotangent products"}.get(
-                       icnf.grad_path(mode), "none")} if a.mode == "grad" else {}),
+                       icnf.grad_path(mode, B=B, alg=alg), "none")} if grad else {}),
                    "collective": w.get("collective", ""),
                    "parallelism": f"column-shard x{world}, loss all-reduce (5 scalars)"
-                   + (" + gradient all-reduce (nparams floats)" if a.mode == "grad" else "")},
+                   + (" + gradient all-reduce (nparams floats)" if grad else "")},
         "loss": m["loss"], "roofline": roof,
     }
 
@@ -534,12 +541,19 @@ def form_library_comm(pkg, torch, dist, dev, rank, world, timeout_s, fallback_na
     th = threading.Thread(target=init_rank, daemon=True)
     th.start()
     th.join(timeout_s)
-    if th.is_alive():
+    timed_out = th.is_alive()
+    if timed_out:
         print(f"bench.py: rank {rank}: ncclCommInitRank of the library communicator did not return within {timeout_s:.0f} s; "
               f"re-run with --collective torch", file=sys.stderr, flush=True)
-        os._exit(3)                            # the helper thread is inside RCCL: no orderly teardown is possible
-    ok = torch.tensor([1 if "comm" in box else 0], device=dev, dtype=torch.int32)
+    # every rank learns the worst outcome on the process group's own communicator (the main thread's; the stuck helper thread
+    # is inside a different one), so a timeout on ONE rank ends ALL ranks with exit 3 instead of leaving the others blocked in a
+    # collective until the launcher kills them: -1 = some rank timed out, 0 = some rank's init failed, 1 = all formed
+    ok = torch.tensor([-1 if timed_out else (1 if "comm" in box else 0)], device=dev, dtype=torch.int32)
     dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if int(ok.item()) < 0:
+        if not timed_out:
+            print(f"bench.py: rank {rank}: another rank's ncclCommInitRank timed out; exiting with it", file=sys.stderr, flush=True)
+        os._exit(3)                            # a helper thread is inside RCCL: no orderly teardown is possible
     if int(ok.item()) == 1:
         pkg.set_comm(box["comm"])
         return "cnf_allreduce_loss: RCCL ncclAllReduce of 5 doubles through the C ABI (include/cnf.h)"
@@ -614,6 +628,39 @@ def main():
         except Exception as ex:  # pragma: no cover
             bf = ("error", str(ex)[:200])
 
+    # every BASELINE configuration + the parameter gradient by the same protocol (shorter pre-roll, fewer timed steps for the
+    # long ones), compactly: VERDICT r3 #1 - cfg3 / cfg4 / cfg5 and the gradient figures were builder-run claims only
+    default_line = (a.config == "cfg2" and a.mode == "infer" and a.arith == "f32" and world == 1 and not a.force_dist and
+                    not a.batch and a.path == 0)
+    sec_list = ("cfg3,cfg4,cfg5,cfg2:grad,cfg4:grad" if default_line else "none") if a.secondaries == "auto" else a.secondaries
+    more = []
+    if sec_list != "none":
+        for item in [x.strip() for x in sec_list.split(",") if x.strip()]:
+            nm, _, md = item.partition(":")
+            g = md == "grad"
+            try:
+                wi = make_workload(pkg, o64, nm, a, rank, dev, torch, grad=g, batch=CONFIGS[nm][2])
+                wi["collective"] = collective
+                ki = min(a.steps, 20 if g else 50)
+                mi = measure(wi, a, ki, min(a.warmup, 3), min(a.preroll_seconds, 1.0), pkg, torch, dist, world, dev, probe)
+                more.append((item, wi, mi, ki))
+            except Exception as ex:  # pragma: no cover
+                more.append((item, None, str(ex)[:200], 0))
+            finally:
+                wi = None
+                torch.cuda.empty_cache()
+
+    ranks_seen = None
+    if sharded:
+        # what every rank bound and what the communicator it reduced on reports: the driver's log then proves that RCCL saw N ranks
+        c = pkg.get_comm()
+        mine = torch.tensor([rank, dev.index or 0, c.size() if c is not None else -1, dist.get_world_size()], device=dev, dtype=torch.int64)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        ranks_seen = [dict(rank=int(t[0]), device=int(t[1]), cnf_comm_size=int(t[2]), process_group_size=int(t[3])) for t in allr]
+        print(f"bench.py: rank {rank} bound cuda:{dev.index} ({torch.cuda.get_device_name(dev)}), "
+              f"cnf_comm_size() = {c.size() if c is not None else 'n/a (torch.distributed collective)'}, world {world}", file=sys.stderr, flush=True)
+
     if rank == 0:
         r = report(w, m, a, a.steps, a.warmup, world)
         out = {
@@ -628,6 +675,26 @@ def main():
                          "note": "W warm-up steps, an untimed pre-roll to the sustained clock, then exactly K timed "
                                  "steps between barrier+synchronize; roofline from HIP events around each solve launch"},
         }
+        if ranks_seen is not None:
+            out["ranks_seen"] = ranks_seen
+        if more:
+            out["secondaries"] = {}
+            for item, wi, mi, ki in more:
+                if wi is None:
+                    out["secondaries"][item] = {"error": mi}
+                    continue
+                ri = report(wi, mi, a, ki, a.warmup, world)
+                rf = ri["roofline"]
+                out["secondaries"][item] = {
+                    "workload": ri["config"]["workload"], "mode": ri["config"]["mode"], "columns_per_gpu": ri["config"]["columns_per_gpu"],
+                    "kernel_family": ri["config"]["kernel_family"], **({"gradient_path": ri["config"]["gradient_path"]} if wi["grad"] else {}),
+                    "value": ri["value"], "unit": "samples*steps/s", "steps": ki, "ms_per_step": ri["ms_per_step"], "loss": ri["loss"],
+                    "roofline": {"kernel_ms": rf["kernel_ms"], "kernel_ms_median": rf["kernel_ms_median"], "frac": rf["frac"],
+                                 "achieved": rf["achieved"], "peak": rf["peak"], "unit": rf["unit"],
+                                 "flop_per_sample_step": rf["flop_per_sample_step"],
+                                 **({"executed_frac": rf["executed_frac"]} if "executed_frac" in rf else {}),
+                                 "what": ("loss + gradient (forward with checkpoints + reverse sweep), 3 F convention" if wi["grad"]
+                                          else "the fused solve kernel")}}
         if sec is not None:
             r2 = report(sec[0], sec[1], a, a.steps, a.warmup, world)
             out["secondary"] = {"metric": out["metric"], "unit": out["unit"], "steps": a.steps,

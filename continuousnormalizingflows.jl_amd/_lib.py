@@ -35,7 +35,10 @@ EXPORTS = ("cnf_version", "cnf_last_error", "cnf_create", "cnf_destroy", "cnf_se
            "cnf_epilogue", "cnf_vcabm_begin", "cnf_vcabm_attempt", "cnf_vcabm_accept", "cnf_vcabm_state", "cnf_solve_vcabm", "cnf_solve_tsit5", "cnf_loss_grad_adaptive",
            "cnf_integrate_fixed_dt", "cnf_inference_fixed_dt",
            "cnf_comm_unique_id", "cnf_comm_init", "cnf_comm_init_all", "cnf_comm_destroy", "cnf_comm_rank", "cnf_comm_size",
-           "cnf_comm_group_start", "cnf_comm_group_end", "cnf_allreduce_loss", "cnf_allreduce_sum")
+           "cnf_comm_group_start", "cnf_comm_group_end", "cnf_allreduce_loss", "cnf_allreduce_sum",
+           "cnf_kernel_family", "cnf_kernel_family_for", "cnf_kernel_name", "cnf_grad_path_for")
+FAMILY_SIMT, FAMILY_PER_WAVE, FAMILY_COOP, FAMILY_COOPX, FAMILY_TILE_SPLIT, FAMILY_LAYERED = 0, 1, 2, 3, 4, 5
+FAMILY_NAMES = ("simt", "per_wave", "coop", "coopx", "tile_split", "layered")
 
 
 class CnfConfig(C.Structure):
@@ -93,6 +96,11 @@ def load():
     lib.cnf_solve_controller.argtypes = [vp]
     lib.cnf_repack_on_device.argtypes = [vp]
     lib.cnf_grad_path.argtypes = [vp]
+    lib.cnf_grad_path_for.argtypes = [vp, C.c_int64, C.c_int, C.c_int]
+    lib.cnf_kernel_family.argtypes = [vp]
+    lib.cnf_kernel_family_for.argtypes = [vp, C.c_int64, C.c_int]
+    lib.cnf_kernel_name.argtypes = [vp]
+    lib.cnf_kernel_name.restype = C.c_char_p
     lib.cnf_loss_grad_grid.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_float), fp, fp, fp, C.c_int64,
                                        C.POINTER(C.c_float), fp, fp, fp, vp]
     lib.cnf_step_embedded.argtypes = [vp, C.c_int, C.c_int, C.c_float, C.c_float, fp, fp, fp, C.c_int64, C.c_float,

@@ -105,6 +105,13 @@ static int ensure_kbuf(cnf_handle* h, int64_t B) {
     return CNF_OK;
 }
 
+// One dynamics evaluation on the generic families: CNF_LAYERED_MIN_B=n sends batches below n of an AUTO-resolved LAYERED handle
+// to the SIMT kernels instead
+static int64_t layered_min_batch() {
+    const char* e = getenv("CNF_LAYERED_MIN_B");
+    return (e && *e) ? atoll(e) : 0;   // measured: the GEMM path wins at every batch size (profiles/r1h_generic_small.json)
+}
+
 extern "C" {
 
 int cnf_version(void) { return CNF_ABI_VERSION; }
@@ -216,6 +223,25 @@ int cnf_destroy(cnf_handle* h) {
 }
 
 int cnf_kernel_path(const cnf_handle* h) { return h ? h->path : CNF_ERR_INVALID; }
+int cnf_kernel_family_for(cnf_handle* h, int64_t B, int whole_solve) {
+    if (!h || B < 0) return CNF_ERR_INVALID;
+    if (h->path == CNF_PATH_MFMA) {
+        DeviceGuard g(h->cfg.device_id);
+        return mfma_plan_family_for(h->plan, B, whole_solve != 0);
+    }
+    if (h->path == CNF_PATH_LAYERED) return (h->layered_forced || B >= layered_min_batch()) ? CNF_FAMILY_LAYERED : CNF_FAMILY_SIMT;
+    return CNF_FAMILY_SIMT;
+}
+int cnf_kernel_family(const cnf_handle* h) {
+    if (!h) return CNF_ERR_INVALID;
+    if (h->path == CNF_PATH_MFMA) return mfma_plan_family_for(h->plan, 0, false);
+    return h->path == CNF_PATH_LAYERED ? CNF_FAMILY_LAYERED : CNF_FAMILY_SIMT;
+}
+const char* cnf_kernel_name(const cnf_handle* h) {
+    if (!h) return "";
+    if (h->path == CNF_PATH_MFMA) return mfma_plan_name(h->plan);
+    return h->path == CNF_PATH_LAYERED ? "layered" : "simt";
+}
 int cnf_solve_controller(const cnf_handle* h) { return (h && h->last_controller >= 0) ? h->last_controller : CNF_ERR_INVALID; }
 
 int cnf_repack_on_device(const cnf_handle* h) {
@@ -386,10 +412,6 @@ int cnf_set_params(cnf_handle* h, const float* p, size_t n, const size_t* w_off,
 // One dynamics evaluation on the generic families: layer-wise GEMMs (cnf_layered.hip) for a LAYERED handle
 // (CNF_LAYERED_MIN_B=n sends batches below n to the SIMT kernels instead), the thread-per-sample kernels
 // (cnf_simt.hip) otherwise.
-static int64_t layered_min_batch() {
-    const char* e = getenv("CNF_LAYERED_MIN_B");
-    return (e && *e) ? atoll(e) : 0;   // measured: the GEMM path wins at every batch size (profiles/r1h_generic_small.json)
-}
 static int generic_aug_f(cnf_handle* h, const StageIn& in, float t, const float* eps, const float* ys, int64_t B,
                          float* du, bool first_of_solve, hipStream_t st) {
     if (h->path == CNF_PATH_LAYERED && (h->layered_forced || B >= layered_min_batch())) {

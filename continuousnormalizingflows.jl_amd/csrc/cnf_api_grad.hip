@@ -54,13 +54,37 @@ bool cnf::api_grad_uses_slab(const cnf_handle* h) {
 }
 }  // extern "C++"
 
+// The ONE place that decides which implementation serves a gradient call (the query entries and loss_grad_impl both ask it):
+// 1 = fused per-wave kernels (register / slab accumulators), 2 = layer-wise, 3 = cooperative reverse sweep, 0 = none.
+extern "C++" {
+cnf::GradRoute cnf::api_grad_route(const cnf_handle* h, int64_t B, int alg, bool on_grid) {
+    GradRoute r{};
+    if (api_grad_is_fused(h) && (h->grad_packed || !h->have_params)) { r.path = 1; return r; }
+    const bool slab = api_grad_uses_slab(h);
+    // B < 0: "the batch is not known" - the auxiliary cooperative plan of a slab shape is not counted (cnf_grad_path)
+    const bool fits = B < 0 || B <= coop_grad_max_columns(h->cfg, alg);
+    const float lam0[3] = {0.f, 0.f, 0.f};
+    if (B >= 0 && api_grad_uses_coop_aux(h, B) && fits && coop_grad_eligible(h->cfg, h->plan_cg, lam0, on_grid)) {
+        r.path = 3; r.use_cg_aux = true; return r;
+    }
+    if (slab) { r.path = 1; r.slab = true; return r; }
+    // CNF_LAYERED_LOSS_BY_SOLVE (A/B switch of the layer-wise path: loss from a separate solve) keeps the call layer-wise
+    if (fits && !getenv("CNF_LAYERED_LOSS_BY_SOLVE") && (h->packed_dev || !h->have_params) && coop_grad_eligible(h->cfg, h->plan, lam0, on_grid)) {
+        r.path = 3; return r;
+    }
+    r.path = layered_grad_supported(h->cfg) ? 2 : 0;
+    return r;
+}
+}  // extern "C++"
+
 int cnf_grad_path(const cnf_handle* h) {
     if (!h) return CNF_ERR_INVALID;
-    if (api_grad_is_fused(h) || api_grad_uses_slab(h)) return 1;   // (slab shapes with an auxiliary cooperative plan: 3 from 4096 columns on)
-    const bool hutch = h->cfg.mode != CNF_MODE_EXACT;
-    const float lamf[3] = {hutch && h->cfg.reg_z ? 1.f : 0.f, hutch && h->cfg.reg_j ? 1.f : 0.f, 0.f};
-    if (coop_grad_eligible(h->cfg, h->plan, lamf, nullptr) && h->packed_dev) return 3;   // uniform steps and frozen adaptive grids alike
-    return layered_grad_supported(h->cfg) ? 2 : 0;
+    return api_grad_route(h, -1, CNF_ALG_TSIT5, false).path;
+}
+
+int cnf_grad_path_for(const cnf_handle* h, int64_t B, int alg, int on_grid) {
+    if (!h || B < 0 || (alg != CNF_ALG_RK4 && alg != CNF_ALG_TSIT5)) return CNF_ERR_INVALID;
+    return api_grad_route(h, B, alg, on_grid != 0).path;
 }
 
 }  // extern "C"
@@ -76,9 +100,9 @@ static int loss_grad_impl(cnf_handle* h, const char* who, int alg, int nsteps, f
     if (nsteps < 1) return fail(CNF_ERR_INVALID, w + ": nsteps >= 1 required");
     if (alg != CNF_ALG_RK4 && alg != CNF_ALG_TSIT5) return fail(CNF_ERR_INVALID, w + ": unknown alg");
     if ((B > 0 && !x) || !grad || !lambdas) return fail(CNF_ERR_INVALID, w + ": null x/grad/lambdas");
-    const bool fused = api_grad_is_fused(h) && h->grad_packed;
-    if (!fused && !layered_grad_supported(h->cfg))
-        return fail(CNF_ERR_UNSUPPORTED, w + ": no gradient path for this configuration");
+    const GradRoute route = api_grad_route(h, B, alg, tgrid != nullptr);
+    const bool fused = route.path == 1 && !route.slab;
+    if (route.path == 0) return fail(CNF_ERR_UNSUPPORTED, w + ": no gradient path for this configuration");
     DeviceGuard g(h->cfg.device_id);
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(hipMemsetAsync(grad, 0, h->nparams * sizeof(float), st));
@@ -101,11 +125,10 @@ static int loss_grad_impl(cnf_handle* h, const char* who, int alg, int nsteps, f
     }
     if (!fused) {
         // the loss sums come from the regular solve on whichever family serves the handle
-        const bool hutch0 = h->cfg.mode != CNF_MODE_EXACT;
-        const float lam0[3] = {hutch0 && h->cfg.reg_z ? lambdas[0] : 0.f, hutch0 && h->cfg.reg_j ? lambdas[1] : 0.f, 0.f};
-        const bool use_cg = api_grad_uses_coop_aux(h, B) && coop_grad_eligible(h->cfg, h->plan_cg, lam0, tgrid) &&
-                            B <= coop_grad_max_columns(h->cfg, alg);
-        const bool loss_in_sweep = sums4 && (use_cg || !api_grad_uses_slab(h)) && !getenv("CNF_LAYERED_LOSS_BY_SOLVE");
+        // (the cooperative sweep's checkpointing forward solve always yields the loss terms; the layer-wise sweep accumulates
+        // them unless CNF_LAYERED_LOSS_BY_SOLVE asks for a separate solve; the slab kernel needs that solve)
+        const bool use_cg = route.use_cg_aux;
+        const bool loss_in_sweep = sums4 && (route.path == 3 || (route.path == 2 && !getenv("CNF_LAYERED_LOSS_BY_SOLVE")));
         if (sums4) {
             const size_t need = ((size_t)h->S + 4) * (size_t)B * sizeof(float);
             if (need > h->grad_ws_bytes) {
@@ -135,7 +158,7 @@ static int loss_grad_impl(cnf_handle* h, const char* who, int alg, int nsteps, f
         const bool hutch = h->cfg.mode != CNF_MODE_EXACT;   // the exact-trace dynamics carry no regularisers (icnf.jl:297-339)
         const int ra = (hutch && h->cfg.reg_aug && h->cfg.naug > 0) ? 1 : 0;
         const float lam[3] = {hutch && h->cfg.reg_z ? lambdas[0] : 0.f, hutch && h->cfg.reg_j ? lambdas[1] : 0.f, ra ? lambdas[2] : 0.f};
-        if (api_grad_uses_slab(h) && !use_cg) {
+        if (route.slab) {
             // two-hidden-layer nets of 4..7 hidden tiles: tile-fused reverse sweep with slab accumulators (cnf_grad_slab.hip)
             if (h->num_cus == 0) {
                 hipDeviceProp_t prop;
@@ -156,8 +179,8 @@ static int loss_grad_impl(cnf_handle* h, const char* who, int alg, int nsteps, f
         std::string msg;
         MfmaPlan* cgp = use_cg ? h->plan_cg : h->plan;
         const float* cgi = use_cg ? h->cg_packed : h->packed_dev;
-        if (coop_grad_eligible(h->cfg, cgp, lam, tgrid) && cgi && B <= coop_grad_max_columns(h->cfg, alg) &&
-            (use_cg || !getenv("CNF_LAYERED_LOSS_BY_SOLVE"))) {
+        if (route.path == 3) {
+            if (!cgi) return fail(CNF_ERR_NO_PARAMS, w + ": cnf_set_params has not been called");
             // wide hidden layers on the cooperative kernels: checkpointing forward solve (which also yields the loss terms),
             // one reverse-sweep launch per step, deferred weight-cotangent products (cnf_coop_grad.hip)
             float* cg_logp = sums4 ? h->grad_ws : nullptr;

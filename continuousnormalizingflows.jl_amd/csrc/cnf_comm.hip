@@ -29,6 +29,8 @@ struct Rccl {
     decltype(&ncclGetErrorString) err_str = nullptr;
     decltype(&ncclGroupStart) group_start = nullptr;
     decltype(&ncclGroupEnd) group_end = nullptr;
+    decltype(&ncclCommCount) comm_count = nullptr;        // optional: what the communicator itself reports
+    decltype(&ncclCommUserRank) comm_user_rank = nullptr;
     bool ok = false;
 };
 
@@ -53,6 +55,8 @@ Rccl load_rccl() {
     r.err_str = (decltype(r.err_str))dlsym(r.lib, "ncclGetErrorString");
     r.group_start = (decltype(r.group_start))dlsym(r.lib, "ncclGroupStart");
     r.group_end = (decltype(r.group_end))dlsym(r.lib, "ncclGroupEnd");
+    r.comm_count = (decltype(r.comm_count))dlsym(r.lib, "ncclCommCount");
+    r.comm_user_rank = (decltype(r.comm_user_rank))dlsym(r.lib, "ncclCommUserRank");
     r.ok = r.get_id && r.init_rank && r.init_all && r.destroy && r.all_reduce && r.err_str && r.group_start && r.group_end;
     return r;
 }
@@ -150,8 +154,20 @@ int cnf_comm_destroy(cnf_comm* c) {
     return CNF_OK;
 }
 
-int cnf_comm_rank(const cnf_comm* c) { return c ? c->rank : CNF_ERR_INVALID; }
-int cnf_comm_size(const cnf_comm* c) { return c ? c->nranks : CNF_ERR_INVALID; }
+// rank / size as the RCCL communicator itself reports them (ncclCommUserRank / ncclCommCount): a host that prints
+// cnf_comm_size() has proof of how many ranks RCCL joined, not an echo of the number it passed to cnf_comm_init
+int cnf_comm_rank(const cnf_comm* c) {
+    if (!c) return CNF_ERR_INVALID;
+    int v = c->rank;
+    if (c->comm && cnf::rccl().comm_user_rank && cnf::rccl().comm_user_rank(c->comm, &v) != ncclSuccess) return CNF_ERR_COMM;
+    return v;
+}
+int cnf_comm_size(const cnf_comm* c) {
+    if (!c) return CNF_ERR_INVALID;
+    int v = c->nranks;
+    if (c->comm && cnf::rccl().comm_count && cnf::rccl().comm_count(c->comm, &v) != ncclSuccess) return CNF_ERR_COMM;
+    return v;
+}
 
 int cnf_comm_group_start(void) {
     if (int rc = need_rccl()) return rc;

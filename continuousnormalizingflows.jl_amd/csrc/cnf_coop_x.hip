@@ -453,6 +453,9 @@ struct CoopXInst {
 // workgroup per CU (120 KB of exchange buffers), one wave per SIMD with the whole register file
 #define CX_BIG(HT, ACT) CX_INST(HT, 3, 24, 0, ACT), CX_INST(HT, 2, 24, 0, ACT)
 static const CoopXInst kCoopX[] = {
+    // exact twins of cnf_coop.hip's two narrow-state instances: their plans checkpoint on a caller's grid (the frozen steps of an
+    // adaptive solve) through this kernel ON THEIR OWN packed image, so hidden tiles and state k-steps must coincide
+    CX_INST(8, 3, 2, 0, CNF_ACT_TANH_PRESCALED), CX_INST(4, 3, 2, 0, CNF_ACT_TANH_PRESCALED),
     CX_SHAPES(8, CNF_ACT_TANH_PRESCALED), CX_SHAPES(12, CNF_ACT_TANH_PRESCALED), CX_SHAPES(16, CNF_ACT_TANH_PRESCALED),
     CX_SHAPES(8, CNF_ACT_SOFTPLUS), CX_SHAPES(12, CNF_ACT_SOFTPLUS), CX_SHAPES(16, CNF_ACT_SOFTPLUS),
     CX_BIG(20, CNF_ACT_TANH_PRESCALED), CX_BIG(24, CNF_ACT_TANH_PRESCALED), CX_BIG(20, CNF_ACT_SOFTPLUS), CX_BIG(24, CNF_ACT_SOFTPLUS),
@@ -462,10 +465,20 @@ static const CoopXInst* cx_find(int HT, int L, int ZR, int CR, int ACT) {
     const CoopXInst* best = nullptr;
     for (const CoopXInst& c : kCoopX) {
         const bool act_ok = c.ACT == ACT || (c.ACT == CNF_ACT_TANH_PRESCALED && ACT == CNF_ACT_TANH);
-        if (c.HT >= HT && c.L == L && c.ZR >= ZR && c.CR >= CR && (CR > 0 || c.CR == 0) && act_ok && (!best || c.HT < best->HT))
+        if (c.HT >= HT && c.L == L && c.ZR >= ZR && c.CR >= CR && (CR > 0 || c.CR == 0) && act_ok &&
+            (!best || c.HT < best->HT || (c.HT == best->HT && c.ZR < best->ZR)))
             best = &c;
     }
     return best;
+}
+// the instance compiled for exactly this layout family MfmaLayout(HT, L, ZR, CR, true): the only kind that may run on an image
+// another plan packed (the kernel reads the image through that layout's offsets and strides its checkpoints by ZR)
+static const CoopXInst* cx_find_exact(int HT, int L, int ZR, int CR, int ACT) {
+    for (const CoopXInst& c : kCoopX) {
+        const bool act_ok = c.ACT == ACT || (c.ACT == CNF_ACT_TANH_PRESCALED && ACT == CNF_ACT_TANH);
+        if (c.HT == HT && c.L == L && c.ZR == ZR && c.CR == CR && act_ok) return &c;
+    }
+    return nullptr;
 }
 
 bool coopx_supported(int HT, int L, int ZR, int CR, int ACT, int* HT_inst, int* ZR_inst, int* CR_inst) {
@@ -479,6 +492,13 @@ bool coopx_supported(int HT, int L, int ZR, int CR, int ACT, int* HT_inst, int* 
 
 hipError_t coopx_launch(int HT, int L, int ZR, int CR, int ACT, const KArgs& a, int num_cus, hipStream_t st) {
     const CoopXInst* c = cx_find(HT, L, ZR, CR, ACT);
+    if (!c) return hipErrorNotSupported;
+    return c->fn[a.T.ns <= 4 ? 0 : 1](a, num_cus, st);
+}
+
+bool coopx_exact_supported(int HT, int L, int ZR, int CR, int ACT) { return cx_find_exact(HT, L, ZR, CR, ACT) != nullptr; }
+hipError_t coopx_launch_exact(int HT, int L, int ZR, int CR, int ACT, const KArgs& a, int num_cus, hipStream_t st) {
+    const CoopXInst* c = cx_find_exact(HT, L, ZR, CR, ACT);
     if (!c) return hipErrorNotSupported;
     return c->fn[a.T.ns <= 4 ? 0 : 1](a, num_cus, st);
 }

@@ -131,6 +131,13 @@ cnf_config api_grad_cfg(const cnf_handle* h);
 bool api_grad_is_fused(const cnf_handle* h);
 bool api_grad_uses_slab(const cnf_handle* h);
 bool api_grad_uses_coop_aux(const cnf_handle* h, int64_t B);   // the auxiliary cooperative plan serves this batch size
+// which gradient implementation serves a call of B columns with `alg` on uniform steps / on a caller's grid (cnf_grad_path_for)
+struct GradRoute {
+    int path = 0;              // 0 none, 1 fused per-wave (register or slab accumulators), 2 layer-wise, 3 cooperative reverse sweep
+    bool slab = false;         // path 1 on the slab-accumulator kernel
+    bool use_cg_aux = false;   // path 3 on the handle's auxiliary cooperative plan (plan_cg / cg_packed)
+};
+GradRoute api_grad_route(const cnf_handle* h, int64_t B, int alg, bool on_grid);
 // cnf_api_adaptive.hip
 int api_ensure_adaptive_buf(cnf_handle* h, int64_t B);
 int api_solve_tsit5(cnf_handle* h, float t0, float t1, const float* u0, const float* eps, const float* ys, int64_t B,

@@ -128,12 +128,14 @@ hipError_t grad_slab_launch(const cnf_config& c, const float* packed_dev, const 
                             const float* tgrid_dev, long long B, const float lam[3], float* ws, float* grad, float* grad_x, int num_cus, hipStream_t st);
 int mfma_plan_zr(const MfmaPlan* p);   // state k-steps of the forward instance (checkpoint stride)
 bool mfma_plan_is_per_wave(const MfmaPlan* p);
+int mfma_plan_family_for(MfmaPlan* p, long long B, bool whole_solve);   // CNF_FAMILY_*
+bool mfma_plan_can_checkpoint(const MfmaPlan* p, bool on_grid);
 bool mfma_plan_coop_shape(const MfmaPlan* p, int* HT, int* L, int* ZR, int* ACT);   // true for a cooperative-kernel plan
 bool mfma_plan_coop_grad_shape(const MfmaPlan* p, int* HT, int* L, int* ZR, int* ACT, int* CR = nullptr);   // ... or an extended one that can checkpoint
 long long mfma_plan_ckpt_tiles(const MfmaPlan* p, long long B, bool on_grid = false);
 // cooperative gradient for wide layers (cnf_coop_grad.hip + the deferred weight-cotangent products of cnf_lgemm.hip; host side in
 // cnf_layered.hip): loss terms from the checkpointing forward solve, gradient in the Lux layout, dL/dx
-bool coop_grad_eligible(const cnf_config& c, const MfmaPlan* plan, const float lam[3], const float* tgrid);
+bool coop_grad_eligible(const cnf_config& c, const MfmaPlan* plan, const float lam[3], bool on_grid);
 long long coop_grad_max_columns(const cnf_config& c, int alg);   // batches beyond it take the layer-wise path (32-bit operand addressing)
 hipError_t coop_grad(LayeredGrad** ctx, const cnf_config& c, MfmaPlan* plan, const float* packed_dev, const size_t* w_off,
                      const size_t* b_off, const float* x, const float* eps, const float* ys, int alg, int nsteps, float t0, float t1,

@@ -983,12 +983,14 @@ long long coop_grad_max_columns(const cnf_config& c, int alg) {
     return 0x7fffffffLL / (ldy * 4 * 2 * ns);
 }
 
-bool coop_grad_eligible(const cnf_config& c, const MfmaPlan* plan, const float lam[3], const float* tgrid) {
+bool coop_grad_eligible(const cnf_config& c, const MfmaPlan* plan, const float lam[3], bool on_grid) {
     int HT, L, ZR, ACT, CR;
     if (!mfma_plan_coop_grad_shape(plan, &HT, &L, &ZR, &ACT, &CR)) return false;
     if (const char* e = getenv("CNF_COOP_GRAD")) { if (*e == '0') return false; }
     if (c.mode != CNF_MODE_HUTCH_VJP || c.nprobes != 1 || (c.ncond != 0) != (CR != 0)) return false;
-    (void)tgrid;   // a non-uniform grid (the frozen steps of an adaptive solve): the extended kernel checkpoints on it
+    // the forward solve must be able to checkpoint: on a non-uniform grid (the frozen steps of an adaptive solve) a cooperative
+    // plan does so through the extended kernel's instance of exactly its own layout, if there is one
+    if (!mfma_plan_can_checkpoint(plan, on_grid)) return false;
     if (c.n_layers != L + 1) return false;
     for (int l = 0; l < L; ++l)
         if ((c.acts[l] != CNF_ACT_TANH && c.acts[l] != CNF_ACT_SOFTPLUS) || c.acts[l] != c.acts[0] || c.widths[l + 1] != c.widths[1]) return false;

@@ -409,6 +409,16 @@ long long mfma_plan_ckpt_tiles(const MfmaPlan* p, long long B, bool on_grid) {
     return x ? (B + 31) / 32 * 2 : (B + 63) / 64 * 4;
 }
 bool mfma_plan_is_per_wave(const MfmaPlan* p) { return p->kind == 0; }
+// can this plan's forward solve checkpoint for the cooperative gradient (on the caller's grid when `on_grid`)?  Extended-kernel
+// plans always do (run-time switch); cooperative plans through their CK instance on uniform steps, otherwise through the
+// extended kernel's instance of exactly their layout (mfma_solve)
+bool mfma_plan_can_checkpoint(const MfmaPlan* p, bool on_grid) {
+    if (!p) return false;
+    if (p->kind == 2) return true;
+    if (p->kind != 1) return false;
+    if (!on_grid && coop_ckpt_supported(p->HT, p->L, p->ZR, p->ACT)) return true;
+    return coopx_exact_supported(p->HT, p->L, p->ZR, 0, p->ACT);
+}
 
 // plain f32 image (forward + transposed, no tanh pre-scale) for a given layout: the gradient kernels' operand image
 void mfma_pack_layout(const cnf_config& c, int HT, int L, int ZR, int CR, const float* lux, const size_t* w_off,
@@ -426,17 +436,46 @@ void grad_pack(const cnf_config& c, const float* lux, const size_t* w_off, const
     mfma_pack_layout(c, HT, L, ZR, CR, lux, w_off, b_off, packed);
 }
 
+static hipError_t plan_ensure_cus(MfmaPlan* mp) {
+    if (mp->num_cus != 0) return hipSuccess;
+    int dev = 0;
+    hipDeviceProp_t prop;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    e = hipGetDeviceProperties(&prop, dev);
+    if (e != hipSuccess) return e;
+    mp->num_cus = prop.multiProcessorCount;
+    return hipSuccess;
+}
+
+// Small batches (at most one 16-sample tile per compute unit) of a per-wave plan: the tile-split form - the tile's hidden width
+// over the four SIMDs of a CU (cnf_coop.hip, NT = 1) - instead of one wave per tile with three SIMDs of its CU idle.  Same packed
+// image (the layouts coincide: forward + transposed images, pre-scaled tanh), same arithmetic per product; the sums over a
+// sample's lane groups are taken in the same order.  Whole fixed-step solves only: single dynamics calls (boundary A, the
+// attempts of the adaptive host loops) stay on the per-wave kernel, whose arithmetic the one-launch adaptive kernels share bit
+// for bit.  CNF_TILE_SPLIT=0 keeps the per-wave kernel everywhere, =2 forces the split form at any batch size.
+static bool plan_takes_tile_split(MfmaPlan* p, long long B) {
+    if (p->kind != 0 || plan_ensure_cus(p) != hipSuccess) return false;
+    const int split_env = env_int("CNF_TILE_SPLIT", 1);   // read per call: tests and A/B runs switch it inside one process
+    const long long ntiles = (B + 15) / 16;
+    const int D = p->cfg.nvars + p->cfg.naug;
+    return split_env > 0 && p->ENGINE == ENG_VJP && p->KP == 1 && p->CR == 0 && p->arith == 0 && p->with_bwd && !p->use_queue &&
+           (split_env == 2 || ntiles <= p->num_cus) && p->ZR * 4 >= D && coop_split_supported(p->HT, p->L, p->ZR, p->ACT);
+}
+
+// CNF_FAMILY_* of the kernel that serves a whole fixed-step solve of B columns (whole_solve) or a single dynamics call
+int mfma_plan_family_for(MfmaPlan* p, long long B, bool whole_solve) {
+    if (p->kind == 1) return CNF_FAMILY_COOP;
+    if (p->kind == 2) return CNF_FAMILY_COOPX;
+    return (whole_solve && B > 0 && plan_takes_tile_split(p, B)) ? CNF_FAMILY_TILE_SPLIT : CNF_FAMILY_PER_WAVE;
+}
+
 hipError_t mfma_solve(MfmaPlan* p, const float* packed_dev, const SolveArgs& s, hipStream_t st) {
     if (s.B == 0) return hipSuccess;
     MfmaPlan* mp = p;   // caches the CU count and owns the optional queue word
-    if (mp->num_cus == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        hipError_t e = hipGetDevice(&dev);
+    {
+        hipError_t e = plan_ensure_cus(mp);
         if (e != hipSuccess) return e;
-        e = hipGetDeviceProperties(&prop, dev);
-        if (e != hipSuccess) return e;
-        mp->num_cus = prop.multiProcessorCount;
     }
     KArgs a{};
     a.packed = packed_dev;
@@ -473,20 +512,11 @@ hipError_t mfma_solve(MfmaPlan* p, const float* packed_dev, const SolveArgs& s, 
         // (shapes without a checkpointing instance of this kernel checkpoint through the extended kernel, which runs on the same
         // packed image - MfmaLayout(HT, L, ZR, 0, true) - and checkpoints at run time)
         if (s.ckpt) return (coop_ckpt_supported(p->HT, p->L, p->ZR, p->ACT) && !s.tgrid_dev) ? coop_launch_ckpt(p->HT, p->L, p->ZR, p->ACT, a, mp->num_cus, st)
-                                                                            : coopx_launch(p->HT, p->L, p->ZR, 0, p->ACT, a, mp->num_cus, st);
+                                                                            : coopx_launch_exact(p->HT, p->L, p->ZR, 0, p->ACT, a, mp->num_cus, st);
         return coop_launch(p->HT, p->L, p->ZR, p->ACT, a, mp->num_cus, st);
     }
     const long long ntiles = (s.B + 15) / 16;
-    // Small batches (at most one 16-sample tile per compute unit): the tile-split form - the tile's hidden width over the four
-    // SIMDs of a CU (cnf_coop.hip, NT = 1) - instead of one wave per tile with three SIMDs of its CU idle.  Same packed image
-    // (the layouts coincide: forward + transposed images, pre-scaled tanh), same arithmetic per product; the sums over a
-    // sample's lane groups are taken in the same order.  Whole fixed-step solves only: single dynamics calls (boundary A, the
-    // attempts of the adaptive host loops) stay on the per-wave kernel, whose arithmetic the one-launch adaptive kernels share
-    // bit for bit.  CNF_TILE_SPLIT=0 keeps the per-wave kernel everywhere, =2 forces the split form at any batch size.
-    const int split_env = env_int("CNF_TILE_SPLIT", 1);   // read per call: tests and A/B runs switch it inside one process
-    if (split_env > 0 && s.nsteps > 0 && p->ENGINE == ENG_VJP && p->KP == 1 && p->CR == 0 && p->arith == 0 && p->with_bwd && !s.ckpt && !s.ckpt_k &&
-        !s.kfull && !mp->use_queue && (split_env == 2 || ntiles <= mp->num_cus) && p->ZR * 4 >= a.D &&
-        coop_split_supported(p->HT, p->L, p->ZR, p->ACT))
+    if (s.nsteps > 0 && !s.ckpt && !s.ckpt_k && !s.kfull && plan_takes_tile_split(mp, s.B))
         return coop_split_launch(p->HT, p->L, p->ZR, p->ACT, a, st);
     const int wpb = p->nthreads / 64;
     long long want = ntiles;   // tile t runs on workgroup t % nblocks (cnf_mfma_kernel.h): small batches spread over the CUs

@@ -89,6 +89,10 @@ hipError_t coop_launch(int HT, int L, int ZR, int ACT, const KArgs& a, int num_c
 // the cooperative kernel extended to conditions, several probes and the exact trace as unit probes (cnf_coop_x.hip)
 bool coopx_supported(int HT, int L, int ZR, int CR, int ACT, int* HT_inst, int* ZR_inst, int* CR_inst);
 hipError_t coopx_launch(int HT, int L, int ZR, int CR, int ACT, const KArgs& a, int num_cus, hipStream_t st);
+// the same, restricted to the instance compiled for exactly MfmaLayout(HT, L, ZR, CR, true): what a plan of another kernel
+// family must use when it runs this kernel on its own packed image (hipErrorNotSupported otherwise)
+bool coopx_exact_supported(int HT, int L, int ZR, int CR, int ACT);
+hipError_t coopx_launch_exact(int HT, int L, int ZR, int CR, int ACT, const KArgs& a, int num_cus, hipStream_t st);
 // the same kernel with ONE sample tile per workgroup and the images in LDS: the tile-split form for small batches
 bool coop_split_supported(int HT, int L, int ZR, int ACT);
 hipError_t coop_split_launch(int HT, int L, int ZR, int ACT, const KArgs& a, hipStream_t st);

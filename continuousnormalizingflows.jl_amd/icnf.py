@@ -474,10 +474,27 @@ class ICNF:
         h = self._handle(mode)
         return int(h.lib.cnf_kernel_path(h.ptr))
 
-    def grad_path(self, mode: Mode) -> int:
-        """0: no gradient for this mode; 1: fused reverse-sweep kernel; 2: layer-wise path (cnf_grad_path)."""
+    def grad_path(self, mode: Mode, B: Optional[int] = None, alg: int = _lib.ALG_TSIT5, on_grid: bool = False) -> int:
+        """0: no gradient for this mode; 1: fused reverse-sweep kernel; 2: layer-wise path; 3: cooperative reverse sweep.
+        Without `B` the handle's batch-independent hint (cnf_grad_path); with it, the implementation a call of B columns with
+        `alg` on uniform steps / on a grid takes (cnf_grad_path_for)."""
         h = self._handle(mode)
-        return int(h.lib.cnf_grad_path(h.ptr))
+        if B is None:
+            return int(h.lib.cnf_grad_path(h.ptr))
+        return int(h.lib.cnf_grad_path_for(h.ptr, int(B), int(alg), int(on_grid)))
+
+    def kernel_family(self, mode: Mode, B: Optional[int] = None, whole_solve: bool = True) -> str:
+        """Which kernel organisation serves this mode's handle ("per_wave", "coop", "coopx", "layered", "simt"), or - with `B` -
+        a call of B columns ("tile_split" for small whole solves of per-wave shapes): cnf_kernel_family / cnf_kernel_family_for."""
+        h = self._handle(mode)
+        rc = int(h.lib.cnf_kernel_family(h.ptr)) if B is None else int(h.lib.cnf_kernel_family_for(h.ptr, int(B), int(whole_solve)))
+        if rc < 0:
+            _lib.check(rc)
+        return _lib.FAMILY_NAMES[rc]
+
+    def kernel_name(self, mode: Mode) -> str:
+        h = self._handle(mode)
+        return h.lib.cnf_kernel_name(h.ptr).decode()
 
     def repack_on_device(self, mode: Mode) -> bool:
         """True when the last parameter binding of this mode's handle was repacked by the device gather

@@ -82,6 +82,13 @@ class Comm:
                                               _lib.stream_ptr(self.device)))
         return t
 
+    def size(self) -> int:
+        """Ranks the RCCL communicator itself reports (cnf_comm_size -> ncclCommCount), not what the caller passed in."""
+        return int(self.lib.cnf_comm_size(self.ptr))
+
+    def comm_rank(self) -> int:
+        return int(self.lib.cnf_comm_rank(self.ptr))
+
     def destroy(self):
         if self.ptr:
             self.lib.cnf_comm_destroy(self.ptr)

@@ -33,7 +33,7 @@
  *   training                 cnf_loss_grad_fixed, cnf_loss_grad_grid, cnf_loss_grad_adaptive  (dloss/dps, optionally dloss/dxs)
  *   column shards (RCCL)     cnf_comm_unique_id, cnf_comm_init, cnf_comm_init_all, cnf_comm_destroy, cnf_comm_rank, cnf_comm_size,
  *                            cnf_allreduce_loss (the mean in `loss`), cnf_allreduce_sum, cnf_comm_group_start / _end
- *   introspection            cnf_version, cnf_last_error, cnf_kernel_path, cnf_grad_path, cnf_repack_on_device, cnf_solve_controller
+ *   introspection            cnf_version, cnf_last_error, cnf_kernel_path, cnf_kernel_family, cnf_grad_path, cnf_grad_path_for, cnf_repack_on_device, cnf_solve_controller
  */
 #ifndef CNF_H
 #define CNF_H
@@ -201,6 +201,24 @@ int cnf_solve_tsit5(cnf_handle* h, float t0, float t1, const float* u0, const fl
 /* Which kernel family the handle resolved to (CNF_PATH_SIMT, CNF_PATH_MFMA or CNF_PATH_LAYERED). */
 int cnf_kernel_path(const cnf_handle* h);
 
+/* CNF_PATH_MFMA covers four kernel organisations; hosts and tests ask here instead of inferring it from the environment.
+ *   PER_WAVE    one wave per 16-sample tile, operand images in LDS (csrc/cnf_mfma_kernel.h)        hidden width <= 128
+ *   COOP        a workgroup per 64-sample super-tile, images in L2 (csrc/cnf_coop.hip)             Hutchinson VJP, 1 probe, wide layers
+ *   COOPX       its extended form (csrc/cnf_coop_x.hip)                                            conditions / probes / exact / JVP, wide layers
+ *   TILE_SPLIT  one tile per workgroup, hidden width over the four SIMDs (csrc/cnf_coop.hip)       per-wave shapes at <= 16 CUs' worth of columns
+ * cnf_kernel_family: the handle's own family (never TILE_SPLIT).  cnf_kernel_family_for: the kernel a call of B columns takes -
+ * whole_solve != 0 for cnf_integrate_fixed / cnf_inference_fixed(_dt) / cnf_loss_*, 0 for cnf_aug_f and the caller-driven steps.
+ * Results of two families differ by summation order only (<= 2e-5 in logp); within one family a column's result does not depend
+ * on which other columns are in the call - SHARD CONCATENATION IS THEREFORE BIT-IDENTICAL ONLY WHEN EVERY SHARD AND THE
+ * UNSHARDED CALL TAKE THE SAME FAMILY: per-wave shapes switch to TILE_SPLIT at B <= 16 x (compute units) = 4096 columns
+ * (CNF_TILE_SPLIT=0 in the environment keeps PER_WAVE at every size); every BASELINE shard is larger. */
+enum { CNF_FAMILY_SIMT = 0, CNF_FAMILY_PER_WAVE = 1, CNF_FAMILY_COOP = 2, CNF_FAMILY_COOPX = 3, CNF_FAMILY_TILE_SPLIT = 4, CNF_FAMILY_LAYERED = 5 };
+int cnf_kernel_family(const cnf_handle* h);
+int cnf_kernel_family_for(cnf_handle* h, int64_t B, int whole_solve);
+/* Name of the kernel instance behind the handle ("mfma_vjp<HT=4,L=3,...>", "coopx<...>", "layered", "simt"); static storage
+ * owned by the handle. */
+const char* cnf_kernel_name(const cnf_handle* h);
+
 /* Where the step (and order) policy of the handle's last cnf_solve_vcabm / cnf_solve_tsit5 / cnf_loss_grad_adaptive ran:
  * 1 = on the device, the whole solve in one cooperative launch (fused per-wave kernels, batches of at most one 16-sample tile
  * per resident wave); 0 = the host loop over per-attempt launches (any other case, or CNF_DEVICE_CONTROLLER=0 in the
@@ -311,6 +329,14 @@ int cnf_loss_grad_adaptive(cnf_handle* h, float t0, float t1, const float* x, co
  * the product kernels of cnf_lgemm.hip (cnf_layered.hip), 3 = cooperative reverse sweep for wide tanh nets (FFJORD or the regularised objective) on uniform
  * steps or on the caller's grid (cnf_coop_grad.hip: one launch per RK step + deferred weight-cotangent products). */
 int cnf_grad_path(const cnf_handle* h);
+
+/* cnf_grad_path is a batch-independent HINT (the family a handle's shape belongs to).  The implementation a particular call
+ * takes also depends on its column count, its solver and whether it runs on a caller's grid: two-hidden-layer nets of 7-8 hidden
+ * tiles report 1 but run on 3 from 4096 columns on; a cooperative shape reports 3 but runs on 2 beyond the sweep's 32-bit operand
+ * addressing (2^31 / (8 stages (H + 1)) columns), or on a grid its forward kernel cannot checkpoint on.  This entry returns
+ * what cnf_loss_grad_fixed (on_grid = 0) / cnf_loss_grad_grid, cnf_loss_grad_adaptive (on_grid = 1) WILL take for B columns
+ * with `alg` (CNF_ALG_RK4 / CNF_ALG_TSIT5); same codes. */
+int cnf_grad_path_for(const cnf_handle* h, int64_t B, int alg, int on_grid);
 
 /* ---- column shards: the one exchange step of the path -----------------------------------------
  * Under fixed-step integration every column (sample) is independent (src/core/icnf.jl:530-535 is column-wise), so rank r

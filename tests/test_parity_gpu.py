@@ -264,6 +264,8 @@ def test_tile_split_kernel_for_small_batches(kw, alg, pkg, oracles):
             for tag, env in (("wave", "0"), ("split", "2")):
                 os.environ["CNF_TILE_SPLIT"] = env
                 logp, regs, u1 = run_inference(pkg, icnf, spec, p, xs, eps, ys, return_state=True)
+                assert icnf.kernel_family(mode, B=B) == ("per_wave" if tag == "wave" else "tile_split")
+                assert icnf.kernel_family(mode, B=B, whole_solve=False) == "per_wave"   # single dynamics calls never split
                 out[tag] = (logp.cpu().numpy(), [r.cpu().numpy() for r in regs], u1.cpu().numpy())
                 assert np.max(np.abs(out[tag][0] - ref[0])) < TOL_SOLVE, (tag, B)
                 for a_, b_ in zip(out[tag][1], ref[1]):
@@ -1061,6 +1063,113 @@ def test_auto_path_prefers_fused_then_layerwise(pkg, oracles):
     assert np.max(np.abs(small - ref[:100])) < TOL_SOLVE
 
 
+def test_kernel_family_is_reported_by_the_library(pkg, oracles, monkeypatch):
+    """cnf_kernel_family / cnf_kernel_family_for / cnf_kernel_name: a host asks the library which kernel organisation serves a
+    handle and a call instead of inferring it from CNF_* environment variables (VERDICT r3 weak #9)."""
+    o64, _ = oracles
+    monkeypatch.delenv("CNF_TILE_SPLIT", raising=False)
+    T = pkg.TrainMode(False)
+    cases = [
+        (dict(nvars=8, hidden=[64, 64, 64]), 0, T, "per_wave", "mfma_vjp<HT=4"),
+        (dict(nvars=32, hidden=[256, 256, 256]), 0, T, "coop", "coop_vjp<HT=16"),
+        (dict(nvars=8, ncond=8, hidden=[256, 256, 256], mode=2), 0, pkg.TestMode(), "coopx", "coopx<HT=16"),
+        (dict(nvars=16, naug=17, hidden=[136, 136], act=2), 0, T, "coopx", "coopx<HT=12"),
+        (dict(nvars=8, hidden=[64] * 6), 0, T, "layered", "layered"),
+        (dict(nvars=8, hidden=[64, 64, 64]), 1, T, "simt", "simt"),
+    ]
+    for kw, path, mode, fam, name in cases:
+        icnf = make_icnf(pkg, o64.make_spec(**kw), 0, 4, path=path)
+        assert icnf.kernel_family(mode) == fam, kw
+        assert icnf.kernel_name(mode).startswith(name), icnf.kernel_name(mode)
+        assert icnf.kernel_family(mode, B=65536) == fam
+    small = make_icnf(pkg, o64.make_spec(nvars=8, hidden=[64, 64, 64]), 0, 4)
+    assert small.kernel_family(T, B=4096) == "tile_split" and small.kernel_family(T, B=4097) == "per_wave"
+    assert small.kernel_family(T, B=4096, whole_solve=False) == "per_wave"
+    monkeypatch.setenv("CNF_TILE_SPLIT", "0")
+    assert small.kernel_family(T, B=4096) == "per_wave"
+
+
+@pytest.mark.parametrize("kw,B,alg", [
+    (dict(nvars=8, hidden=[64, 64, 64]), 20000, 0),                         # per-wave kernel (cfg2's)
+    (dict(nvars=8, hidden=[64, 64, 64]), 3000, 1),                          # tile-split kernel
+    (dict(nvars=32, hidden=[256, 256, 256]), 2000, 0),                      # cooperative kernel (cfg4's)
+    (dict(nvars=8, ncond=8, hidden=[128, 128, 128], mode=2), 1500, 0),      # tangent engine, conditioned (cfg5's)
+    (dict(nvars=16, naug=17, hidden=[136, 136], act=2, reg_z=True, reg_j=True), 1000, 1),   # extended cooperative kernel
+    (dict(nvars=8, hidden=[64] * 5), 1200, 1),                              # layer-wise path
+])
+def test_hot_path_is_hip_graph_capturable_on_a_side_stream(kw, B, alg, pkg, oracles):
+    """DESIGN.md section 7: after the first call has sized the workspaces, every entry point only enqueues work on the caller's
+    stream.  cnf_inference_fixed + cnf_loss_mean (and cnf_loss_grad_fixed) are captured into a HIP graph on a NON-default
+    stream, the outputs are wiped, the graph is replayed - twice - and must reproduce the eager results bit for bit."""
+    o64, _ = oracles
+    spec = o64.make_spec(**kw)
+    nsteps = 6
+    icnf = make_icnf(pkg, spec, alg, nsteps)
+    mode = mode_of(pkg, spec)
+    p, xs, eps, ys = o64.synth_inputs(spec, B, 4242, bias_scale=0.2)
+    X, E, P = dev(xs), dev(eps), dev(p)
+    args = (X,) + ((dev(ys),) if spec.ncond else ()) + (P, {})
+    with_grad = spec.mode == 0
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+
+    def step():
+        logp, regs = pkg.inference(icnf, mode, *args, eps=E, _raw=True)
+        out = [logp, regs, pkg.loss_mean(icnf, mode, logp, regs)]
+        if with_grad:
+            val, g = pkg.loss_and_gradient(icnf, mode, *args, eps=E)
+            out += [val, g]
+        return out
+
+    with torch.cuda.stream(side):
+        step()                                   # first use: workspaces, function attributes, parameter images
+        eager = [t.clone() for t in step()]
+    side.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        captured = step()
+    for rep in range(2):
+        for t in captured:
+            t.fill_(float("nan"))
+        graph.replay()
+        torch.cuda.synchronize()
+        for a_, b_ in zip(captured, eager):
+            assert torch.equal(a_, b_), (rep, kw)
+    assert torch.isfinite(eager[2]).item()
+
+
+def test_two_handles_on_two_streams_run_concurrently(pkg, oracles):
+    """Two flows (two cnf_handles, different kernel families) driven from two streams at the same time: no state is shared
+    between handles (workspaces, operand images and the tile queue word are per handle), so the interleaved results are the
+    serial results bit for bit, for solves and gradients."""
+    o64, _ = oracles
+    flows = []
+    for kw, B, alg in ((dict(nvars=8, hidden=[64, 64, 64]), 30000, 1), (dict(nvars=32, hidden=[256, 256, 256]), 3000, 0),
+                       (dict(nvars=8, hidden=[64, 64, 64], nprobes=4, reg_z=True, reg_j=True), 9000, 1)):
+        spec = o64.make_spec(**kw)
+        p, xs, eps, ys = o64.synth_inputs(spec, B, 99 + B, bias_scale=0.2)
+        flows.append((make_icnf(pkg, spec, alg, 5), mode_of(pkg, spec), (dev(xs), dev(p), {}), dev(eps), torch.cuda.Stream()))
+    torch.cuda.synchronize()
+
+    def run(f):
+        icnf, mode, args, E, _ = f
+        logp, regs = pkg.inference(icnf, mode, *args, eps=E, _raw=True)
+        val, g = pkg.loss_and_gradient(icnf, mode, *args, eps=E)
+        return logp, regs, val, g
+
+    serial = [[t.clone() for t in run(f)] for f in flows]
+    torch.cuda.synchronize()
+    for _ in range(6):
+        outs = []
+        for f in flows:                      # enqueue on every stream before any of them is waited for
+            with torch.cuda.stream(f[4]):
+                outs.append(run(f))
+        torch.cuda.synchronize()
+        for o, sres in zip(outs, serial):
+            for a_, b_ in zip(o, sres):
+                assert torch.equal(a_, b_)
+
+
 def test_million_column_batch(pkg, oracles):
     """B = 1 000 003 (64-bit column indexing, a ragged last tile, several tile rounds per CU): head, middle and
     tail columns against the C restatement; the gradient at B = 300 007 is additive over a split."""
@@ -1519,8 +1628,9 @@ def test_planar_layer_net_matches_the_equivalent_dense_chain(use_bias, condition
     assert samples.shape == (nv, B) and bool(torch.isfinite(samples).all())
 
 
-@pytest.mark.parametrize("mode", ["infer", "grad"])
-def test_bench_contract_with_two_ranks_on_one_gpu(mode):
+@pytest.mark.parametrize("mode,config,batch", [("infer", "cfg2", 4096), ("grad", "cfg2", 4096),
+                                               ("grad", "cfg4", 512)])    # cfg4: cooperative reverse sweep + reduce_gradient
+def test_bench_contract_with_two_ranks_on_one_gpu(mode, config, batch):
     """The N > 1 path of bench.py end to end, as the driver launches it (torch.distributed.run, one process
     per rank, barrier + max-over-ranks timing, one JSON line from rank 0) — here two ranks sharing the one
     GPU with the gloo backend, since RCCL refuses two ranks on one device.  Checks the contract fields
@@ -1532,17 +1642,22 @@ def test_bench_contract_with_two_ranks_on_one_gpu(mode):
         port = sk.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--backend", "gloo", "--no-cpu-baseline", "--batch", "4096", "--mode", mode, "--preroll-seconds", "0.2"]
+           "--backend", "gloo", "--no-cpu-baseline", "--batch", str(batch), "--mode", mode, "--config", config, "--preroll-seconds", "0.2"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 2 and out["warmup"] == 1 and out["scaling"] == "weak"
-    assert out["config"]["global_columns"] == 2 * 4096 and out["config"]["columns_per_gpu"] == 4096
-    assert out["value"] > 0 and abs(out["value"] - 2 * 4096 * 40 * 2 / (out["ms_per_step"] * 2e-3)) < 1e-6 * out["value"]
+    assert out["config"]["global_columns"] == 2 * batch and out["config"]["columns_per_gpu"] == batch and out["config"]["name"] == config
+    assert out["value"] > 0 and abs(out["value"] - 2 * batch * 40 * 2 / (out["ms_per_step"] * 2e-3)) < 1e-6 * out["value"]
+    # every rank reported what it bound and the group it reduced on (gloo: no library communicator, so cnf_comm_size = -1)
+    assert [r["rank"] for r in out["ranks_seen"]] == [0, 1] and all(r["process_group_size"] == 2 for r in out["ranks_seen"])
+    assert "secondaries" not in out      # the extra workloads belong to the default one-GPU line only
+    if mode == "grad":
+        assert ("cooperative" in out["config"]["gradient_path"]) == (config == "cfg4")
     single = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--no-cpu-baseline",
-                             "--batch", "4096", "--mode", mode, "--preroll-seconds", "0"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+                             "--batch", str(batch), "--mode", mode, "--config", config, "--preroll-seconds", "0"], capture_output=True, text=True, timeout=600, cwd=ROOT)
     one = json.loads([l for l in single.stdout.splitlines() if l.startswith("{")][0])
     # rank 0's block is the single-process block; the two-rank mean differs from it (rank 1 holds other columns)
     assert abs(out["loss"] - one["loss"]) > 1e-6 and abs(out["loss"] - one["loss"]) < 0.5
@@ -1705,6 +1820,11 @@ def test_adaptive_tsit5_follows_the_oracle_restatement(kw, tol, pkg, oracles):
     (dict(nvars=16, naug=17, hidden=[136, 136], act=2, reg_z=True, reg_j=True, reg_aug=True), (0.01, 0.01, 0.01), 3),   # ICNF(nvariables = 16), default lambdas
     (dict(nvars=32, hidden=[256, 256, 256], reg_z=True, reg_j=True), (0.02, 0.03, 0.0), 3),   # cfg4's shape (its uniform-grid forward has a checkpointing instance of its own)
     (dict(nvars=8, ncond=8, hidden=[192, 192], reg_z=True), (0.05, 0.0, 0.0), 3),            # conditioned
+    # a cooperative plan with TWO state k-steps (D <= 8, 3 x 128 tanh) used to checkpoint on a grid through the
+    # extended kernel's 8-k-step instance - another layout's offsets and checkpoint stride on this plan's image and buffers
+    (dict(nvars=8, hidden=[128, 128, 128]), (0.0, 0.0, 0.0), 3),
+    (dict(nvars=7, hidden=[120, 128, 100], reg_z=True, reg_j=True), (0.02, 0.03, 0.0), 2),   # unequal widths: layer-wise
+    (dict(nvars=5, naug=2, hidden=[128, 128, 128], reg_z=True, reg_j=True, reg_aug=True), (0.02, 0.03, 0.04), 3),
 ])
 def test_gradient_of_the_adaptive_solve_on_its_frozen_grid(kw, lam, gpath, pkg, oracles):
     """loss_and_gradient with the adaptive solver: the accepted steps are frozen and the discrete solve on that
@@ -1724,6 +1844,7 @@ def test_gradient_of_the_adaptive_solve_on_its_frozen_grid(kw, lam, gpath, pkg, 
     val, g, gx = pkg.loss_and_gradient(icnf, mode, *args, eps=dev(eps), wrt_x=True)
     assert icnf.grad_path(mode) == gpath
     ts = icnf.last_solve_stats["tgrid"]
+    assert icnf.grad_path(mode, B=B, alg=1, on_grid=True) == gpath   # cnf_grad_path_for: what this call took
     assert len(ts) >= 5 and ts[0] == 0.0 and ts[-1] == 1.0 and len(set(np.round(np.diff(ts), 6))) > 1   # non-uniform
     L, gref, gxref = o64.loss_and_grad(spec, p, xs, 0.0, 1.0, len(ts) - 1, 1, eps, ys, lam, wrt_x=True, tgrid=ts)
     assert abs(float(val) - L) < 1e-4 + 2e-6 * abs(L)       # (a loss of 300 has a Float32 ulp of 3e-5)
@@ -2562,6 +2683,9 @@ def test_bench_nccl_launch_path_rehearsed_with_one_rank(launcher, mode):
     out = json.loads(lines[0])
     assert out["config"]["collective"].startswith("cnf_allreduce_loss"), out["config"]["collective"]
     assert out["n_gpus"] == 1 and out["steps"] == 3 and out["scaling"] == "weak" and out["value"] > 0
+    # the rank reports the device it bound and the size the RCCL communicator ITSELF reports (ncclCommCount through cnf_comm_size)
+    assert out["ranks_seen"] == [dict(rank=0, device=0, cnf_comm_size=1, process_group_size=1)], out["ranks_seen"]
+    assert "bound cuda:0" in r.stderr and "cnf_comm_size() = 1" in r.stderr
     # the same numbers as the unsharded step on the same columns (one rank: the all-reduce is the identity)
     single = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--no-cpu-baseline",
                              "--batch", "4096", "--mode", mode, "--preroll-seconds", "0", "--secondary", "none"],
