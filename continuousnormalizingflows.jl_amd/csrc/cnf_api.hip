@@ -508,8 +508,7 @@ int cnf_integrate_fixed(cnf_handle* h, int alg, int nsteps, float t0, float t1, 
         return CNF_OK;
     }
     if (u1 != u0)
-        HIP_TRY(hipMemcpyAsync(u1, u0, (size_t)h->S * (size_t)B * sizeof(float),
-                               hipMemcpyDeviceToDevice, st));
+        HIP_TRY(copy_async(u1, u0, (size_t)h->S * (size_t)B * sizeof(float), st));
     return simt_integrate(h, alg, nsteps, t0, t1, u1, eps, ys, B, st);
 }
 
@@ -573,7 +572,7 @@ int cnf_integrate_fixed_dt(cnf_handle* h, int alg, float dt, float t0, float t1,
     const FixedDtPlan p = fixed_dt_plan(t0, t1, dt);
     if (p.n_full == 0 && !p.tail) {       // nothing to integrate
         DeviceGuard g(h->cfg.device_id);
-        if (u1 != u0) HIP_TRY(hipMemcpyAsync(u1, u0, (size_t)h->S * (size_t)B * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+        if (u1 != u0) HIP_TRY(copy_async(u1, u0, (size_t)h->S * (size_t)B * sizeof(float), (hipStream_t)stream));
         return CNF_OK;
     }
     const float* from = u0;

@@ -105,9 +105,9 @@ static int loss_grad_impl(cnf_handle* h, const char* who, int alg, int nsteps, f
     if (route.path == 0) return fail(CNF_ERR_UNSUPPORTED, w + ": no gradient path for this configuration");
     DeviceGuard g(h->cfg.device_id);
     hipStream_t st = (hipStream_t)stream;
-    HIP_TRY(hipMemsetAsync(grad, 0, h->nparams * sizeof(float), st));
+    HIP_TRY(zero_async(grad, h->nparams * sizeof(float), st));
     if (B == 0) {
-        if (sums4) HIP_TRY(hipMemsetAsync(sums4, 0, 4 * sizeof(float), st));
+        if (sums4) HIP_TRY(zero_async(sums4, 4 * sizeof(float), st));
         return CNF_OK;
     }
     const float* tgrid_dev = nullptr;

@@ -522,7 +522,7 @@ hipError_t grad_launch(const cnf_config& c, const float* packed_dev, const float
     const long long want = (ntiles + 3) / 4;
     const int nblocks = (int)(want < num_cus ? want : num_cus);
     const int nwaves = nblocks * 4;
-    hipError_t e = hipMemsetAsync(slab, 0, (size_t)nwaves * gi->slab_total * sizeof(float), st);
+    hipError_t e = zero_async(slab, (size_t)nwaves * gi->slab_total * sizeof(float), st);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(nblocks), dim3(256), gi->lds_bytes, st, a);
     e = hipGetLastError();

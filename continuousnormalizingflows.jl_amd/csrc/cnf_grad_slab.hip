@@ -570,7 +570,7 @@ hipError_t grad_slab_launch(const cnf_config& c, const float* packed_dev, const 
     const long long want = (ntiles + 3) / 4;
     const int nblocks = (int)(want < num_cus ? want : num_cus);
     const int nwaves = nblocks * 4;
-    hipError_t e = hipMemsetAsync(slab, 0, (size_t)nwaves * si->slab_total * sizeof(float), st);
+    hipError_t e = zero_async(slab, (size_t)nwaves * si->slab_total * sizeof(float), st);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(si->kern, dim3(nblocks), dim3(256), si->lds_bytes, st, a, x, ckz, ckk);
     e = hipGetLastError();

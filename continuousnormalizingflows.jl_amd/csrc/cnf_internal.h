@@ -33,6 +33,13 @@ hipError_t simt_aug_f(const NetDev& net, const float* P, const StageIn& in, floa
                       int64_t ld, hipStream_t st);
 hipError_t rk_update(float* u, const StageIn& in, int64_t n, hipStream_t st);
 hipError_t assemble_u0(const float* x, int nvars, int S, int64_t B, float* u, hipStream_t st);
+// Zero `bytes` (a multiple of 4) at p with a KERNEL on the stream.  Used instead of hipMemsetAsync everywhere on the hot path:
+// inside a captured HIP graph a memset NODE on this stack is not reliably ordered with the kernel nodes around it (round 4:
+// a graph of cnf_loss_grad_fixed replayed behind other work on the stream returned a quarter of the gradient entries from a
+// slab the memset had not - or not yet - cleared; the same calls made eagerly, or with this kernel, are bit-identical).
+hipError_t zero_async(void* p, size_t bytes, hipStream_t st);
+// device-to-device copy of `bytes` (a multiple of 4, both pointers 4-byte aligned, no overlap) as a kernel, for the same reason
+hipError_t copy_async(void* dst, const void* src, size_t bytes, hipStream_t st);
 hipError_t epilogue(const float* u, int nvars, int D, int reg_aug, int64_t B, float* logp,
                     float* regs, hipStream_t st);
 hipError_t loss_sums(const float* logp, const float* regs, int64_t B, float* partial,

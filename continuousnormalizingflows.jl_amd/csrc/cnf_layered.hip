@@ -582,8 +582,8 @@ hipError_t layered_aug_f(LayeredGrad** ctx, const cnf_config& c, const float* P_
     for (int l = 0; l < N; ++l)   // a_{l+1} = act(W_l a_l + b_l) with act' and the ones row, one launch
         LG_BLAS(lg_product(G, PA, OPN, L.wout[l], B, L.win[l] + 1, PA + L.pa_off[l], L.wout[l], a[l], L.win[l] + 1, a[l + 1],
                            L.wout[l] + 1, LG_EPI_ACT, nullptr, 0, d[l], L.wout[l], L.act[l], st));
-    LG_HIP(hipMemsetAsync(ldacc, 0, (size_t)B * sizeof(float), st));
-    LG_HIP(hipMemsetAsync(ndacc, 0, (size_t)B * sizeof(float), st));
+    LG_HIP(zero_async(ldacc, (size_t)B * sizeof(float), st));
+    LG_HIP(zero_async(ndacc, (size_t)B * sizeof(float), st));
 
     if (c.mode == CNF_MODE_HUTCH_VJP) {
         // g = eps^T J: delta_N = eps .* act'_N, delta_{l-1} = (W_l^T delta_l) .* act'_{l-1}, g = W_1[:,0:D]^T delta_1
@@ -743,7 +743,7 @@ hipError_t layered_grad(LayeredGrad** ctx, const cnf_config& c, const float* P_d
     float *lamv = W + o_lam, *kbar = W + o_kbar, *zs = W + o_zs, *gk = W + o_g, *gbar = W + o_gbar, *vN = W + o_vN;
     float *tdb = W + o_t0, *tdb2 = W + o_t1, *tvb = W + o_t2, *tsb = W + o_t3, *tab = W + o_t4;
 
-    LG_HIP(hipMemsetAsync(slabs, 0, (size_t)npa_pad * nslab * sizeof(float), st));
+    LG_HIP(zero_async(slabs, (size_t)npa_pad * nslab * sizeof(float), st));
     hipLaunchKernelGGL(aug_params_kernel, grid_for(npa), dim3(TPB), 0, st, P_dev, PA, L);
 
     ++G.epoch;   // PA was just rebuilt: operand images are repacked at their next use
@@ -800,7 +800,7 @@ hipError_t layered_grad(LayeredGrad** ctx, const cnf_config& c, const float* P_d
         LG_BLAS(stage_derivs(zck + (long long)n * DB, step_t(n)));
         if (keep_k)
             for (int j = 0; j < ns; ++j)
-                LG_HIP(hipMemcpyAsync(kck + ((long long)n * ns + j) * DB, kz[j], (size_t)DB * sizeof(float), hipMemcpyDeviceToDevice, st));
+                LG_HIP(copy_async(kck + ((long long)n * ns + j) * DB, kz[j], (size_t)DB * sizeof(float), st));
         Comb cb{};
         cb.nk = ns;
         for (int j = 0; j < ns; ++j) { cb.k[j] = kz[j]; cb.coef[j] = dt * T.b[j]; }
@@ -813,7 +813,7 @@ hipError_t layered_grad(LayeredGrad** ctx, const cnf_config& c, const float* P_d
     // the loss of this solve is accumulated on the way (no separate forward solve for it): per column dlogp, E, n
     const bool want_loss = logp_out != nullptr && regs_out != nullptr;
     float *lacc = W + o_lacc, *eacc = lacc + B, *nacc = eacc + B;
-    if (want_loss) LG_HIP(hipMemsetAsync(lacc, 0, 3 * (size_t)B * sizeof(float), st));
+    if (want_loss) LG_HIP(zero_async(lacc, 3 * (size_t)B * sizeof(float), st));
     const bool hutch = !exact;
     int Gw = 1;                      // lanes per column of the grouped per-column kernels (0: D > 64, thread-per-column forms)
     while (Gw < D) Gw <<= 1;
@@ -1059,10 +1059,10 @@ hipError_t coop_grad(LayeredGrad** ctx, const cnf_config& c, MfmaPlan* plan, con
     }
     float* W = G.ws;
     float* slabs = W + o_slab;
-    LG_HIP(hipMemsetAsync(slabs, 0, (size_t)npa_pad * nslab * sizeof(float), st));
-    LG_HIP(hipMemsetAsync(W + o_slabN, 0, (size_t)szN_pad * nslabN * sizeof(float), st));
+    LG_HIP(zero_async(slabs, (size_t)npa_pad * nslab * sizeof(float), st));
+    LG_HIP(zero_async(W + o_slabN, (size_t)szN_pad * nslabN * sizeof(float), st));
     // constant rows of the operand arrays: the zero / ones row of every Y_l, the zero rows under gbar
-    LG_HIP(hipMemsetAsync(W + o_y1, 0, (size_t)(n_in + 1) * B2 * sizeof(float), st));
+    LG_HIP(zero_async(W + o_y1, (size_t)(n_in + 1) * B2 * sizeof(float), st));
     for (int l = 0; l < Lh; ++l) {
         hipLaunchKernelGGL(fill_rows_kernel, grid_for((long long)ns * B), dim3(TPB), 0, st, W + o_yh[l], ldy, H, H + 1, 0LL, (long long)ns * B, 0.f);
         hipLaunchKernelGGL(fill_rows_kernel, grid_for((long long)ns * B), dim3(TPB), 0, st, W + o_yh[l], ldy, H, H + 1, (long long)ns * B, B2, 1.f);

@@ -497,7 +497,7 @@ hipError_t mfma_solve(MfmaPlan* p, const float* packed_dev, const SolveArgs& s, 
             hipError_t e = hipMalloc((void**)&mp->queue_dev, sizeof(int));
             if (e != hipSuccess) return e;
         }
-        hipError_t e = hipMemsetAsync(mp->queue_dev, 0, sizeof(int), st);
+        hipError_t e = zero_async(mp->queue_dev, sizeof(int), st);
         if (e != hipSuccess) return e;
         a.queue = mp->queue_dev;
     }
@@ -580,7 +580,7 @@ static hipError_t fill_aargs_scratch(AArgs& q, void* scratch, long long ntiles, 
     *stats_dev = q.stats;
     *dts_dev = q.dts;
     if (orders_dev) *orders_dev = q.orders;
-    return hipMemsetAsync(ints, 0, 12 * sizeof(int), st);
+    return zero_async(ints, 12 * sizeof(int), st);
 }
 
 hipError_t mfma_solve_adaptive(MfmaPlan* p, const float* packed_dev, const SolveArgs& s, float abstol, float reltol, float dt_init,

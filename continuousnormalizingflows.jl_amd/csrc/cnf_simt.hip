@@ -408,6 +408,55 @@ hipError_t embedded_error(const float* u, const float* unew, const float* const*
     return hipGetLastError();
 }
 
+__global__ void __launch_bounds__(256) zero_words_kernel(unsigned* __restrict__ p, size_t nwords) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // 16-byte stores over the aligned body, single words at both ends
+    const size_t head = (size_t)((16 - ((uintptr_t)p & 15)) & 15) / 4;
+    const size_t h = head < nwords ? head : nwords;
+    if (i < h) p[i] = 0u;
+    uint4* q = reinterpret_cast<uint4*>(p + h);
+    const size_t nq = (nwords - h) / 4;
+    for (size_t k = i; k < nq; k += stride) q[k] = uint4{0u, 0u, 0u, 0u};
+    const size_t tail0 = h + 4 * nq;
+    if (i < nwords - tail0) p[tail0 + i] = 0u;
+}
+
+__global__ void __launch_bounds__(256) copy_words_kernel(unsigned* __restrict__ d, const unsigned* __restrict__ s, size_t nwords, int vec) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (vec) {   // both 16-byte aligned: 16-byte body, word tail
+        const size_t nq = nwords / 4;
+        for (size_t k = i; k < nq; k += stride) reinterpret_cast<uint4*>(d)[k] = reinterpret_cast<const uint4*>(s)[k];
+        if (i < nwords - 4 * nq) d[4 * nq + i] = s[4 * nq + i];
+    } else {
+        for (size_t k = i; k < nwords; k += stride) d[k] = s[k];
+    }
+}
+
+hipError_t copy_async(void* dst, const void* src, size_t bytes, hipStream_t st) {
+    if (bytes == 0 || dst == src) return hipSuccess;
+    if ((bytes & 3) || ((uintptr_t)dst & 3) || ((uintptr_t)src & 3)) return hipErrorInvalidValue;
+    const size_t nwords = bytes / 4;
+    const int vec = (((uintptr_t)dst | (uintptr_t)src) & 15) == 0;
+    size_t nb = ((vec ? nwords / 4 : nwords) + 255) / 256;
+    if (nb < 1) nb = 1;
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(copy_words_kernel, dim3((unsigned)nb), dim3(256), 0, st, (unsigned*)dst, (const unsigned*)src, nwords, vec);
+    return hipGetLastError();
+}
+
+hipError_t zero_async(void* p, size_t bytes, hipStream_t st) {
+    if (bytes == 0) return hipSuccess;
+    if ((bytes & 3) || ((uintptr_t)p & 3)) return hipErrorInvalidValue;
+    const size_t nwords = bytes / 4;
+    size_t nb = (nwords / 4 + 255) / 256;
+    if (nb < 1) nb = 1;
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)nb), dim3(256), 0, st, (unsigned*)p, nwords);
+    return hipGetLastError();
+}
+
 hipError_t loss_sums(const float* logp, const float* regs, int64_t B, float* partial,
                      float* sums4, hipStream_t st) {
     hipLaunchKernelGGL(loss_partial_kernel, dim3(LOSS_BLOCKS), dim3(256), 0, st, logp, regs, B, partial);
