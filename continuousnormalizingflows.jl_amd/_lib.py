@@ -37,8 +37,8 @@ EXPORTS = ("cnf_version", "cnf_last_error", "cnf_create", "cnf_destroy", "cnf_se
            "cnf_comm_unique_id", "cnf_comm_init", "cnf_comm_init_all", "cnf_comm_destroy", "cnf_comm_rank", "cnf_comm_size",
            "cnf_comm_group_start", "cnf_comm_group_end", "cnf_allreduce_loss", "cnf_allreduce_sum",
            "cnf_kernel_family", "cnf_kernel_family_for", "cnf_kernel_name", "cnf_grad_path_for")
-FAMILY_SIMT, FAMILY_PER_WAVE, FAMILY_COOP, FAMILY_COOPX, FAMILY_TILE_SPLIT, FAMILY_LAYERED = 0, 1, 2, 3, 4, 5
-FAMILY_NAMES = ("simt", "per_wave", "coop", "coopx", "tile_split", "layered")
+FAMILY_SIMT, FAMILY_PER_WAVE, FAMILY_COOP, FAMILY_COOPX, FAMILY_TILE_SPLIT, FAMILY_LAYERED, FAMILY_COOPD = 0, 1, 2, 3, 4, 5, 6
+FAMILY_NAMES = ("simt", "per_wave", "coop", "coopx", "tile_split", "layered", "coopd")
 
 
 class CnfConfig(C.Structure):

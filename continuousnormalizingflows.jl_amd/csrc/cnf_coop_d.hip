@@ -1,0 +1,704 @@
+// cnf_coop_d.hip — the cooperative solve kernel with its tiles DEALT over four owner waves (round 4).
+//
+// Serves the one-probe Hutchinson-VJP configuration of the plans of cnf_coop_x.hip - TrainMode inference / loss and the
+// checkpointing forward half of the cooperative gradient - i.e. what the reference's constructor-default architecture
+// (src/core/icnf.jl:53-103: D = 2 nvariables + 1, two softplus layers of 4 (D + 1), lambdas 0.01) runs for nvariables >= 16.
+// Same math and reference map as cnf_coop.hip / cnf_coop_x.hip (src/core/icnf.jl:517-559, src/core/utils.jl:150-159); same
+// packed operand image (MfmaLayout(HT_inst, L, ZR_inst, 0, true), read through RUN-TIME offsets and pitches, so the plan, its
+// device-side repacking and the reverse sweep that shares the image are untouched).
+//
+// What was wrong with the extended kernel on these shapes (profiles/r3/r3U_nv20_coopx_pmc.txt: 57 % MFMA-busy,
+// 0.28-0.54 of peak): it executes 1.7 x the MFMAs the shape needs.  (i) Its instances pad the hidden width to 8 / 12 / 16 / 20 / 24
+// tiles and the state to 8 / 16 / 24 k-steps, and only the K side of a product skips the padding: at nvariables = 16 (H = 136:
+// 9 tiles, D = 33: 9 k-steps) the M side runs 12 tiles - one wave of four multiplies nothing but zeros - and the state products
+// run 16 k-steps.  (ii) With 32-sample super-tiles only two of the four waves own a sample tile, and the two D-row products
+// (zdot = W_N h_L, g = W_1[:,0:D]^T delta_1: a third of a stage's MFMAs at D ~ H/4) run on those two.
+//
+// Here a workgroup owns a 64-sample super-tile (one wave per SIMD, as cnf_coop.hip) and EVERY wave owns one sample tile:
+//   * the HT = 4 A + b hidden M-tiles of a product are dealt exactly: wave w computes tiles [w A, (w+1) A) for all four sample
+//     tiles (each weight fragment feeds 16 MFMAs) and the b < 4 left-over tiles for its OWN sample tile only.  A is a template
+//     parameter, b a run-time count (wave-uniform branches around MFMA-only blocks), so nine hidden tiles cost nine tiles' worth
+//     of MFMAs on every wave;
+//   * k-loops run the real k-groups and the real k-steps of the last one (H = 136: 34 k-steps, not 36 or 48);
+//   * the D-row products are split along K by OWNERSHIP (the organisation of the tile-split form, cnf_coop.hip): wave w
+//     multiplies the k-groups of the features it has just produced - straight from its registers, before the barrier - for
+//     all four sample tiles and publishes partial tiles; the owner of a sample tile adds the four partials in wave order.  The
+//     activations of the last hidden layer and the cotangent of the first are never published, a weight fragment of W_N / W_1^T
+//     feeds 16 MFMAs instead of 4, and L = 2 needs ONE exchange buffer.
+#define CNF_NO_PK_ASM 1
+#define CNF_NO_PHASE_FENCE 1
+#include "cnf_coop_dev.h"
+
+namespace cnf {
+
+// run-time view of the plan's packed image (float offsets of MfmaLayout) and the real tile counts of the configuration
+struct DImg {
+    int f1z, fh, fN, bN, bh, b1, v_b1, v_w1t, v_bh, v_bN;
+    int KPZ;          // k-group pitch of the state-column images (f1z, bN)
+    int HTP;          // k-group pitch of the H-column images (fh, bh, fN, b1) = the layout's hidden tiles
+    int imgH, vecH;   // floats per hidden image / hidden C vector
+    int b;            // left-over hidden tiles: HT_real = 4 A + b
+    int KGH, remH;    // real hidden k-groups (= HT_real) and k-steps of the last one (1 .. 4)
+    int KGZ, remZ;    // real state k-groups and k-steps of the last one
+    int xalias;       // the partial tiles alias the exchange buffer (LDS is short): one more barrier per D-row product
+    int ckzr;         // floats per lane of the checkpoint arrays (the plan's ZR: what the reverse sweep strides by)
+    int cvn;          // floats of the C-vector section [v_b1, end of v_bN) of the image: staged into LDS once per workgroup
+};
+struct DArgs {
+    KArgs k;
+    DImg g;
+};
+
+struct DRs {
+    __amdgpu_buffer_rsrc_t r;
+    unsigned lane16;
+};
+__device__ __forceinline__ f32x4 dload(const DRs& R, unsigned byte_off) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(R.r, (int)R.lane16, (int)byte_off, 0));
+}
+
+// Explicit residency in the accumulation registers.  With one wave per SIMD a wave has 256 architectural + 256 accumulation
+// registers; every VALU / MFMA operand of this kernel must be architectural (-amdgpu-mfma-vgpr-form), and what the allocator
+// spills it spills by its own cost model - in the first builds an LDS ADDRESS used inside the k-loops went to scratch, and since
+// vmcnt retires in order its reload drained every outstanding fragment prefetch (s_waitcnt vmcnt(0) per k-group: +17 % run
+// time).  act' of every hidden layer (written once, read once per evaluation) and the Runge-Kutta running sums (touched once per
+// stage) are therefore parked by hand: a value constrained to class "a" costs one v_accvgpr_write and one v_accvgpr_read.
+__device__ __forceinline__ float park(float x) {
+    float a;
+    asm("v_accvgpr_write_b32 %0, %1" : "=a"(a) : "v"(x));
+    return a;
+}
+__device__ __forceinline__ float unpark(float a) {
+    float x;
+    asm("v_accvgpr_read_b32 %0, %1" : "=v"(x) : "a"(a));
+    return x;
+}
+__device__ __forceinline__ f32x4 park4(const f32x4& v) { return f32x4{park(v[0]), park(v[1]), park(v[2]), park(v[3])}; }
+__device__ __forceinline__ f32x4 unpark4(const f32x4& v) { return f32x4{unpark(v[0]), unpark(v[1]), unpark(v[2]), unpark(v[3])}; }
+
+template <int A>
+struct UAcc {
+    f32x4 S[A][4];   // tiles [w A, (w+1) A) x the four sample tiles
+    f32x4 R[3];      // left-over tiles 4 A + r (r < b) x this wave's own sample tile
+};
+template <int A>
+__device__ __forceinline__ void uacc_fill(UAcc<A>& u, const f32x4 (&vS)[A], const f32x4 (&vR)[3]) {
+#pragma unroll
+    for (int m = 0; m < A; ++m)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) u.S[m][q] = vS[m];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) u.R[r] = vR[r];
+}
+template <int A>
+__device__ __forceinline__ void uacc_zero(UAcc<A>& u) {
+#pragma unroll
+    for (int m = 0; m < A; ++m)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) u.S[m][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 3; ++r) u.R[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
+// A fragments of k-group kg for this wave's units of an H-row product: image `img` (byte offset), k-group pitch KP
+template <int A>
+__device__ __forceinline__ void dealt_load_a(const DRs& R, unsigned img, int KP, int mtS0, int mtR0, int mtRmax, int kg,
+                                             f32x4 (&aS)[A], f32x4 (&aR)[3]) {
+#pragma unroll
+    for (int m = 0; m < A; ++m) aS[m] = dload(R, img + (unsigned)(((mtS0 + m) * KP + kg) * 1024));
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const int mt = mtR0 + r < mtRmax ? mtR0 + r : mtRmax;   // clamped, not guarded: no control flow around a load
+        aR[r] = dload(R, img + (unsigned)((mt * KP + kg) * 1024));
+    }
+}
+__device__ __forceinline__ void dealt_load_b(const f32x4* __restrict__ bimg, int kg, int wave, int lane, f32x4 (&bq)[4], f32x4& bo) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) bq[q] = bimg[(kg * 4 + q) * 64 + lane];
+    bo = bimg[(kg * 4 + wave) * 64 + lane];
+}
+template <int A, int JN>
+__device__ __forceinline__ void dealt_mfma(const f32x4 (&aS)[A], const f32x4 (&aR)[3], const f32x4 (&bq)[4], const f32x4& bo, int b,
+                                           UAcc<A>& u) {
+#pragma unroll
+    for (int j = 0; j < JN; ++j)
+#pragma unroll
+        for (int m = 0; m < A; ++m)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) u.S[m][q] = mfma4(aS[m][j], bq[q][j], u.S[m][q]);
+    if (b > 0) {
+#pragma unroll
+        for (int j = 0; j < JN; ++j) u.R[0] = mfma4(aR[0][j], bo[j], u.R[0]);
+    }
+    if (b > 1) {
+#pragma unroll
+        for (int j = 0; j < JN; ++j) u.R[1] = mfma4(aR[1][j], bo[j], u.R[1]);
+    }
+    if (b > 2) {
+#pragma unroll
+        for (int j = 0; j < JN; ++j) u.R[2] = mfma4(aR[2][j], bo[j], u.R[2]);
+    }
+}
+// the last k-group of a product: `rem` (1 .. 4, wave-uniform) k-steps are real
+template <int A>
+__device__ __forceinline__ void dealt_mfma_rem(const f32x4 (&aS)[A], const f32x4 (&aR)[3], const f32x4 (&bq)[4], const f32x4& bo, int b,
+                                               int rem, UAcc<A>& u) {
+    if (rem == 4) dealt_mfma<A, 4>(aS, aR, bq, bo, b, u);
+    else if (rem == 3) dealt_mfma<A, 3>(aS, aR, bq, bo, b, u);
+    else if (rem == 2) dealt_mfma<A, 2>(aS, aR, bq, bo, b, u);
+    else dealt_mfma<A, 1>(aS, aR, bq, bo, b, u);
+}
+
+// u += A(image) * B(LDS image) over KG k-groups, the last one with `rem` k-steps.  aS0 / aR0 arrive holding the fragments of
+// k-group 0 (requested by the caller one phase earlier); two fragment sets ping-pong, the loads of k-group kg + 1 are issued
+// before the MFMAs of k-group kg.
+template <int A>
+__device__ __forceinline__ void dealt_gemm(const DRs& R, unsigned img, int KP, int KG, int rem, int mtS0, int mtR0, int mtRmax, int b,
+                                           const f32x4* __restrict__ bimg, int wave, int lane, f32x4 (&aS0)[A], f32x4 (&aR0)[3],
+                                           UAcc<A>& u) {
+    f32x4 aS1[A], aR1[3], bq0[4], bq1[4], bo0, bo1;
+    dealt_load_b(bimg, 0, wave, lane, bq0, bo0);
+    const int KGf = KG - 1;   // full k-groups
+    int kg = 0;
+#pragma clang loop unroll(disable)
+    for (; kg + 2 <= KGf; kg += 2) {
+        dealt_load_a<A>(R, img, KP, mtS0, mtR0, mtRmax, kg + 1, aS1, aR1);
+        dealt_load_b(bimg, kg + 1, wave, lane, bq1, bo1);
+        dealt_mfma<A, 4>(aS0, aR0, bq0, bo0, b, u);
+        dealt_load_a<A>(R, img, KP, mtS0, mtR0, mtRmax, kg + 2, aS0, aR0);
+        dealt_load_b(bimg, kg + 2, wave, lane, bq0, bo0);
+        dealt_mfma<A, 4>(aS1, aR1, bq1, bo1, b, u);
+    }
+    if (kg < KGf) {   // one full k-group and the last one
+        dealt_load_a<A>(R, img, KP, mtS0, mtR0, mtRmax, KG - 1, aS1, aR1);
+        dealt_load_b(bimg, KG - 1, wave, lane, bq1, bo1);
+        dealt_mfma<A, 4>(aS0, aR0, bq0, bo0, b, u);
+        dealt_mfma_rem<A>(aS1, aR1, bq1, bo1, b, rem, u);
+    } else {
+        dealt_mfma_rem<A>(aS0, aR0, bq0, bo0, b, rem, u);
+    }
+}
+
+// K-split D-row product by ownership: part[dm][q] = sum over this wave's shared k-groups of W(dm, k) x[k, q] (all four sample
+// tiles, B operands straight from the registers that hold x), own[dm] = the same over its left-over k-groups for its own sample
+// tile.  `img`: the D-row image (fN or b1), k-group pitch KP.  The k-group that is the configuration's last one runs `rem`
+// k-steps.
+template <int A, int DT>
+__device__ __forceinline__ void dealt_drow(const DRs& R, unsigned img, int KP, int kgS0, int kgR0, int KG, int rem, int b,
+                                           const UAcc<A>& x, f32x4 (&f0)[DT], f32x4 (&part)[DT][4], f32x4 (&own)[DT]) {
+    // f0 arrives holding the fragments of k-group kgS0 (dealt_drow_first: requested before the activation phase)
+    f32x4 f1[DT];
+#pragma unroll
+    for (int dm = 0; dm < DT; ++dm) {
+        own[dm] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) part[dm][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    // shared block: k-groups kgS0 .. kgS0 + A - 1, then the left-over k-groups (clamped loads), software-pipelined by one
+#pragma unroll
+    for (int m = 0; m < A + 3; ++m) {
+        f32x4(&cur)[DT] = (m & 1) ? f1 : f0;
+        f32x4(&nxt)[DT] = (m & 1) ? f0 : f1;
+        if (m + 1 < A + 3) {
+            const int raw = m + 1 < A ? kgS0 + m + 1 : kgR0 + (m + 1 - A);
+            const int kgn = raw < KG ? raw : KG - 1;
+#pragma unroll
+            for (int dm = 0; dm < DT; ++dm) nxt[dm] = dload(R, img + (unsigned)((dm * KP + kgn) * 1024));
+        }
+        if (m < A) {
+            const bool last = kgS0 + m == KG - 1;   // only when b == 0 and this is the last wave's last tile
+            if (!last || rem == 4) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int dm = 0; dm < DT; ++dm)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) part[dm][q] = mfma4(cur[dm][j], x.S[m][q][j], part[dm][q]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (j < rem) {
+#pragma unroll
+                        for (int dm = 0; dm < DT; ++dm)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) part[dm][q] = mfma4(cur[dm][j], x.S[m][q][j], part[dm][q]);
+                    }
+            }
+        } else {
+            const int r = m - A;
+            if (r < b) {
+                // (k-steps beyond the last real one multiply zero weights: run them rather than branch per k-step)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int dm = 0; dm < DT; ++dm) own[dm] = mfma4(cur[dm][j], x.R[r][j], own[dm]);
+            }
+        }
+    }
+}
+
+// softplus and its derivative on one accumulator tile: NNlib.softplus(a) = log1p(exp(-|a|)) + relu(a), d = sigmoid(a)
+// (cnf_common.h: act_fwd) with the bare transcendentals - e = v_exp(-|a| log2 e) lies in (0, 1], so 1 + e in (1, 2] needs none of
+// __expf's / __logf's range handling (those expand to ~16 VALU instructions per element; this is 8.5) - and the affine steps on
+// register pairs (v_pk_add / v_pk_fma / v_pk_mul).  Same formulas, |error| <= 2e-7 as before.
+__device__ __forceinline__ void softplus_tile(const f32x4& a, f32x4& h, f32x4& d) {
+    constexpr float kNegLog2e = -1.4426950408889634f, kLn2 = 0.6931471805599453f;
+    float e[4], r[4], lg[4], mx[4], sel[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) e[i] = __builtin_amdgcn_exp2f(__builtin_fabsf(a[i]) * kNegLog2e);
+    const f32x2 one = {1.f, 1.f};
+    const f32x2 s0 = f32x2{e[0], e[1]} + one, s1 = f32x2{e[2], e[3]} + one;
+    const float sv[4] = {s0[0], s0[1], s1[0], s1[1]};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        r[i] = __builtin_amdgcn_rcpf(sv[i]);
+        lg[i] = __builtin_amdgcn_logf(sv[i]);       // log2(1 + e)
+        mx[i] = __builtin_fmaxf(a[i], 0.f);
+        sel[i] = a[i] >= 0.f ? 1.f : e[i];
+    }
+    const f32x2 ln2 = {kLn2, kLn2};
+    const f32x2 h0 = __builtin_elementwise_fma(f32x2{lg[0], lg[1]}, ln2, f32x2{mx[0], mx[1]});
+    const f32x2 h1 = __builtin_elementwise_fma(f32x2{lg[2], lg[3]}, ln2, f32x2{mx[2], mx[3]});
+    const f32x2 d0 = f32x2{r[0], r[1]} * f32x2{sel[0], sel[1]}, d1 = f32x2{r[2], r[3]} * f32x2{sel[2], sel[3]};
+    h = f32x4{h0[0], h0[1], h1[0], h1[1]};
+    d = f32x4{d0[0], d0[1], d1[0], d1[1]};
+}
+template <int DT>
+__device__ __forceinline__ void dealt_drow_first(const DRs& R, unsigned img, int KP, int kgS0, f32x4 (&f0)[DT]) {
+#pragma unroll
+    for (int dm = 0; dm < DT; ++dm) f0[dm] = dload(R, img + (unsigned)((dm * KP + kgS0) * 1024));
+}
+
+template <int ACT>
+__device__ __forceinline__ void act_pair(const f32x4& a, f32x4& h, f32x4& d) {
+    if constexpr (ACT == CNF_ACT_SOFTPLUS) softplus_tile(a, h, d);
+    else act_tile<ACT>(a, h, d);
+}
+
+// One dynamics evaluation for a 64-sample super-tile; every wave owns sample tile `wave`.
+template <int A, int L, int ZR, int ACT>
+__device__ __forceinline__ void coopd_eval(const DRs& R, const float* __restrict__ CV, const DImg& Gin, f32x4* __restrict__ xbuf, int XB,
+                                           f32x4* __restrict__ zbuf, const f32x4* __restrict__ ebuf, f32x4* __restrict__ pbuf,
+                                           int lane, int wave, float t, bool autonomous, bool reg_z, bool reg_j,
+                                           const float (&zs)[ZR], float (&zd)[ZR], float& ld, float& ed, float& nd,
+                                           float* __restrict__ gout) {
+    constexpr int DT = ZR / 4;
+    static_assert(ZR % 4 == 0, "state registers in whole M-tiles");
+    // every image offset of this evaluation hangs off an opaque zero: the several hundred wave-uniform fragment addresses are
+    // then recomputed per evaluation (a few scalar instructions each) instead of being hoisted out of the stage and step loops,
+    // where they do not fit the scalar register file (241 scalar spills in the first build, v_readlane reloads inside the k-loops)
+    int opq = 0;
+    asm volatile("" : "+s"(opq));
+    DImg G = Gin;
+    G.f1z += opq; G.fh += opq; G.fN += opq; G.bN += opq; G.bh += opq; G.b1 += opq;
+    const float* __restrict__ P = CV - G.v_b1;   // C vectors: the LDS copy, addressed by their image offsets
+    const int g = lane >> 4;
+    const int b = G.b;
+    const int mtS0 = wave * A, mtR0 = 4 * A, mtRmax = 4 * A + b - 1;   // (b = 0: the clamped left-over loads re-read tile 4 A - 1)
+    const unsigned F1Z = (unsigned)G.f1z * 4u, FH = (unsigned)G.fh * 4u, FN = (unsigned)G.fN * 4u, BN = (unsigned)G.bN * 4u,
+                   BH = (unsigned)G.bh * 4u, B1 = (unsigned)G.b1 * 4u, IMGH = (unsigned)G.imgH * 4u;
+    UAcc<A> acc;
+    UAcc<A> d[L];      // act' of every hidden layer (this wave's units), kept for the pullback: PARKED (see park)
+    f32x4 aS[A], aR[3];
+    // C vector (bias, time column) of this wave's units
+    auto cvec_units = [&](const float* __restrict__ vec, f32x4 (&vS)[A], f32x4 (&vR)[3]) {
+#pragma unroll
+        for (int m = 0; m < A; ++m) vS[m] = *reinterpret_cast<const f32x4*>(vec + ((mtS0 + m) * 4 + g) * 4);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int mt = mtR0 + r < mtRmax ? mtR0 + r : mtRmax;
+            vR[r] = *reinterpret_cast<const f32x4*>(vec + (mt * 4 + g) * 4);
+        }
+    };
+    // ---- layer 1: a = W1z z + w1t t + b1 ----
+    {
+        f32x4 bS[A], bR[3], wS[A], wR[3];
+        dealt_load_a<A>(R, F1Z, G.KPZ, mtS0, mtR0, mtRmax, 0, aS, aR);
+        cvec_units(P + G.v_b1, bS, bR);
+        cvec_units(P + G.v_w1t, wS, wR);
+#pragma unroll
+        for (int kg = 0; kg < DT; ++kg) {   // this wave's stage state as the B image of sample tile `wave`
+            f32x4 v;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = zs[4 * kg + j];
+            zbuf[(kg * 4 + wave) * 64 + lane] = v;
+        }
+        if (!autonomous) {
+#pragma unroll
+            for (int m = 0; m < A; ++m) bS[m] = tile_fma(wS[m], t, bS[m]);
+#pragma unroll
+            for (int r = 0; r < 3; ++r) bR[r] = tile_fma(wR[r], t, bR[r]);
+        }
+        uacc_fill<A>(acc, bS, bR);
+        __syncthreads();
+        dealt_gemm<A>(R, F1Z, G.KPZ, G.KGZ, G.remZ, mtS0, mtR0, mtRmax, b, zbuf, wave, lane, aS, aR, acc);
+    }
+    f32x4 part[DT][4], own[DT], fd[DT];
+    UAcc<A> h;
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+        const int cur = l & 1;   // exchange buffer of layer l + 1's activations (L = 2 only ever uses buffer 0)
+        if (l + 1 < L) dealt_load_a<A>(R, FH + (unsigned)l * IMGH, G.HTP, mtS0, mtR0, mtRmax, 0, aS, aR);
+        else dealt_drow_first<DT>(R, FN, G.HTP, mtS0, fd);
+#pragma unroll
+        for (int m = 0; m < A; ++m)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4 dd;
+                act_pair<ACT>(acc.S[m][q], h.S[m][q], dd);
+                d[l].S[m][q] = park4(dd);
+            }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            f32x4 dd;
+            act_pair<ACT>(acc.R[r], h.R[r], dd);
+            d[l].R[r] = park4(dd);
+        }
+        if (l + 1 < L) {
+#pragma unroll
+            for (int m = 0; m < A; ++m)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) xbuf[cur * XB + ((mtS0 + m) * 4 + q) * 64 + lane] = h.S[m][q];
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+                if (r < b) xbuf[cur * XB + ((mtR0 + r) * 4 + wave) * 64 + lane] = h.R[r];
+            f32x4 bS[A], bR[3];
+            cvec_units(P + G.v_bh + l * G.vecH, bS, bR);
+            uacc_fill<A>(acc, bS, bR);
+            __syncthreads();
+            dealt_gemm<A>(R, FH + (unsigned)l * IMGH, G.HTP, G.KGH, G.remH, mtS0, mtR0, mtRmax, b, xbuf + cur * XB, wave, lane, aS, aR, acc);
+        }
+    }
+    // ---- zdot = W_N h_L + b_N: partials over this wave's own k-groups, from registers ----
+    dealt_drow<A, DT>(R, FN, G.HTP, mtS0, mtR0, G.KGH, G.remH, b, h, fd, part, own);
+    // the first fragments of c = W_N^T eps are requested before the barrier
+    dealt_load_a<A>(R, BN, G.KPZ, mtS0, mtR0, mtRmax, 0, aS, aR);
+    if (G.xalias) __syncthreads();   // the partial tiles share the exchange buffer: its readers (the last hidden product) are done
+#pragma unroll
+    for (int dm = 0; dm < DT; ++dm)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) pbuf[((wave * DT + dm) * 4 + q) * 64 + lane] = part[dm][q];
+    __syncthreads();
+    {
+        f32x4 zacc[DT];
+#pragma unroll
+        for (int dm = 0; dm < DT; ++dm) {
+            zacc[dm] = *reinterpret_cast<const f32x4*>(P + G.v_bN + (dm * 4 + g) * 4);   // (LDS)
+#pragma unroll
+            for (int w = 0; w < 4; ++w) zacc[dm] += pbuf[((w * DT + dm) * 4 + wave) * 64 + lane];
+            zacc[dm] += own[dm];
+        }
+#pragma unroll
+        for (int s = 0; s < ZR; ++s) zd[s] = zacc[s >> 2][s & 3];
+    }
+    ed = 0.f;
+    if (reg_z) {
+        float e2 = 0.f;
+#pragma unroll
+        for (int s = 0; s < ZR; ++s) e2 = fmaf(zd[s], zd[s], e2);
+        ed = sqrtf(group_sum(e2));   // Edot = |zdot|_2   (src/core/icnf.jl:184-199)
+    }
+    // ---- pullback: c = W_N^T eps, delta_l = (W_{l+1}^T delta_{l+1}) .* act'_l ----
+    uacc_zero<A>(acc);
+    dealt_gemm<A>(R, BN, G.KPZ, G.KGZ, G.remZ, mtS0, mtR0, mtRmax, b, ebuf, wave, lane, aS, aR, acc);
+#pragma unroll
+    for (int l = L - 1; l >= 0; --l) {
+        // delta_{l+1} (1-based) = acc .* act'_{l+1}
+        if (l == 0) dealt_drow_first<DT>(R, B1, G.HTP, mtS0, fd);
+#pragma unroll
+        for (int m = 0; m < A; ++m) {
+            f32x4 dd[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) dd[q] = unpark4(d[l].S[m][q]);
+            tiles_mul<4>(acc.S[m], dd, h.S[m]);
+        }
+        {
+            f32x4 dd[3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) dd[r] = unpark4(d[l].R[r]);
+            tiles_mul<3>(acc.R, dd, h.R);
+        }
+        if (l > 0) {
+            // exchange buffer: h_l sat in buffer (l - 1) & 1; every reader passed a barrier since.  L = 2: buffer 0 again.
+            const int wbuf = (L == 2) ? 0 : ((l - 1) & 1) ^ 1;
+            dealt_load_a<A>(R, BH + (unsigned)(l - 1) * IMGH, G.HTP, mtS0, mtR0, mtRmax, 0, aS, aR);
+            if (G.xalias) __syncthreads();   // the owners have read the zdot partials out of this buffer
+#pragma unroll
+            for (int m = 0; m < A; ++m)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) xbuf[wbuf * XB + ((mtS0 + m) * 4 + q) * 64 + lane] = h.S[m][q];
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+                if (r < b) xbuf[wbuf * XB + ((mtR0 + r) * 4 + wave) * 64 + lane] = h.R[r];
+            uacc_zero<A>(acc);
+            __syncthreads();
+            dealt_gemm<A>(R, BH + (unsigned)(l - 1) * IMGH, G.HTP, G.KGH, G.remH, mtS0, mtR0, mtRmax, b, xbuf + wbuf * XB, wave, lane, aS, aR, acc);
+        }
+    }
+    // ---- g = W_1[:,0:D]^T delta_1 = eps^T J: partials from registers ----
+    dealt_drow<A, DT>(R, B1, G.HTP, mtS0, mtR0, G.KGH, G.remH, b, h, fd, part, own);
+    if (G.xalias) __syncthreads();
+#pragma unroll
+    for (int dm = 0; dm < DT; ++dm)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) pbuf[((wave * DT + dm) * 4 + q) * 64 + lane] = part[dm][q];
+    __syncthreads();
+    {
+        float dot = 0.f, n2 = 0.f;
+#pragma unroll
+        for (int dm = 0; dm < DT; ++dm) {
+            f32x4 ga = pbuf[((0 * DT + dm) * 4 + wave) * 64 + lane];
+#pragma unroll
+            for (int w = 1; w < 4; ++w) ga += pbuf[((w * DT + dm) * 4 + wave) * 64 + lane];
+            ga += own[dm];
+            const f32x4 ev = ebuf[(dm * 4 + wave) * 64 + lane];   // this lane's probe values sit in the B image of eps: no registers held
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                dot = fmaf(ga[j], ev[j], dot);   // <eps^T J, eps>
+                n2 = fmaf(ga[j], ga[j], n2);
+                if (gout) gout[4 * dm + j] = ga[j];       // checkpointing solve: g of this stage for the reverse sweep
+            }
+        }
+        ld = -group_sum(dot);
+        nd = reg_j ? sqrtf(group_sum(n2)) : 0.f;   // ndot = |eps^T J|_2 (src/core/icnf.jl:229-245)
+    }
+    // (the next evaluation's first LDS write is the state image, whose last readers - layer 1 - passed several barriers ago;
+    //  pbuf is rewritten only behind the next evaluation's own barriers)
+}
+
+constexpr int coopd_lds_bytes(int HT, int L, int DT, bool alias, int cvn) {
+    return ((L == 2 ? 1 : 2) * HT * 4 * 64 + 2 * DT * 4 * 64 + (alias ? 0 : 4 * DT * 4 * 64)) * 16 + (cvn + 3) / 4 * 16;
+}
+
+// The Runge-Kutta running sums of the later stages' increments (P_i <- P_{i+1} + a_{s+1+i,s} zdot, as the other kernels keep them)
+// and the step sum - six rows of ZR registers, touched once per stage - are parked in accumulation registers (see park): the
+// same fma chains in the same order, so the numbers are the same; 72 - 96 of the 256 architectural registers stay free for the
+// 4 A + b accumulator tiles and two fragment sets of the k-loops.
+template <int A, int L, int ZR, int ACT>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+coopd_solve_kernel(DArgs da) {
+    const KArgs& a = da.k;
+    const DImg& G = da.g;
+    constexpr int DT = ZR / 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int HT = 4 * A + G.b;
+    const int XB = HT * 4 * 64;
+    f32x4* xbuf = reinterpret_cast<f32x4*>(smem);            // [1 or 2][HT][4 sample tiles][64 lanes]
+    f32x4* zbuf = xbuf + (L == 2 ? 1 : 2) * XB;               // [DT][4][64]
+    f32x4* ebuf = zbuf + DT * 4 * 64;                         // [DT][4][64]
+    f32x4* pbuf = G.xalias ? xbuf : ebuf + DT * 4 * 64;       // [4 waves][DT][4][64] partial tiles of the D-row products
+    float* cbuf = reinterpret_cast<float*>(ebuf + DT * 4 * 64 + (G.xalias ? 0 : 4 * DT * 4 * 64));   // C vectors (biases, time column)
+    for (int i = threadIdx.x; i < G.cvn; i += 256) cbuf[i] = a.packed[G.v_b1 + i];
+    // (the first __syncthreads of the super-tile loop orders these writes before any read)
+    const int lane = threadIdx.x & 63, g = lane >> 4, n = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int D = a.D, S = D + 3;
+    const bool reg_z = a.reg_z, reg_j = a.reg_j, autonomous = a.autonomous;
+    const long long nst = (a.B + 63) / 64;
+    DRs R{__builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.packed), 0, 0x7fffffff, 0x00020000), (unsigned)lane * 16u};
+
+    for (long long st = blockIdx.x; st < nst; st += gridDim.x) {
+        const long long smp = st * 64 + wave * 16 + n;
+        const bool valid = smp < a.B;
+        const long long sc = valid ? smp : a.B - 1;
+        float zs[ZR], zp[ZR], pk[5][ZR];   // stage state; z and the running sums, parked
+        float lacc = 0.f, eacc = 0.f, nacc = 0.f;
+        __syncthreads();   // the previous super-tile's readers of the LDS images are done
+#pragma unroll
+        for (int kg = 0; kg < DT; ++kg) {
+            f32x4 v;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int s = 4 * kg + j, f = 4 * s + g;
+                if (a.x) zs[s] = f < a.nvars ? a.x[sc * a.nvars + f] : 0.f;
+                else zs[s] = f < D ? a.u0[sc * S + f] : 0.f;
+                zp[s] = park(zs[s]);
+                v[j] = f < D ? a.eps[sc * D + f] : 0.f;
+            }
+            ebuf[(kg * 4 + wave) * 64 + lane] = v;   // the probe of this wave's sample tile as a B image, for the whole solve
+        }
+        if (!a.x) { lacc = a.u0[sc * S + D]; eacc = a.u0[sc * S + D + 1]; nacc = a.u0[sc * S + D + 2]; }
+
+        float zd[ZR], ld = 0.f, ed = 0.f, nd = 0.f;
+        const float dt0 = a.dt;
+        const bool single = a.nsteps == 0;
+        const int ns = single ? 1 : (a.T.ns < 6 ? a.T.ns : 6);
+        const int nsteps = single ? 1 : a.nsteps;
+        // checkpoints for the cooperative gradient: [..][16-sample tile][lane][ckzr]
+        const long long cktile = st * 4 + wave, ckntp = nst * 4;
+        const int ckzr = G.ckzr;
+#pragma clang loop unroll(disable)
+        for (int step = 0; step < nsteps; ++step) {
+            const float tn = a.tgrid ? a.tgrid[step] : a.t0 + (float)step * dt0;
+            const float dt = a.tgrid ? a.tgrid[step + 1] - tn : dt0;
+            if (a.ckpt && !single) {
+                float* c = a.ckpt + (((long long)step * ckntp + cktile) * 64 + lane) * ckzr;
+#pragma unroll
+                for (int s = 0; s < ZR; ++s) c[s] = zs[s];   // (at a step's start the stage state IS z)
+                for (int s = ZR; s < ckzr; ++s) c[s] = 0.f;
+            }
+            float lsum = 0.f, esum = 0.f, nsum = 0.f;
+#pragma clang loop unroll(disable)
+            for (int sg = 0; sg < ns; ++sg) {
+                const long long ckrow = ((((long long)step * ns + sg) * ckntp + cktile) * 64 + lane) * ckzr;
+                float* gout = (a.ckpt_g && !single) ? a.ckpt_g + ckrow : nullptr;
+                coopd_eval<A, L, ZR, ACT>(R, cbuf, G, xbuf, XB, zbuf, ebuf, pbuf, lane, wave, tn + a.T.c[sg] * dt, autonomous, reg_z, reg_j,
+                                          zs, zd, ld, ed, nd, gout);
+                if (gout)
+                    for (int s = ZR; s < ckzr; ++s) gout[s] = 0.f;
+                if (a.ckpt_k && !single) {
+                    float* c = a.ckpt_k + ckrow;
+#pragma unroll
+                    for (int s = 0; s < ZR; ++s) c[s] = zd[s];
+                    for (int s = ZR; s < ckzr; ++s) c[s] = 0.f;
+                }
+                const float bst = a.T.b[sg];
+                lsum = fmaf(bst, ld, lsum); esum = fmaf(bst, ed, esum); nsum = fmaf(bst, nd, nsum);
+                if (single) break;
+                // running sums (parked rows pk[0..3] = P_1 .. P_4, pk[4] = the step sum): P_i <- fma(acol[sg][i], zdot, P_{i+1}),
+                // P_4 <- acol[sg][4] zdot, step sum <- fma(b, zdot, step sum); the next stage state is z + dt P_0
+                const float c0 = a.acol[sg][0], c1 = a.acol[sg][1], c2 = a.acol[sg][2], c3 = a.acol[sg][3], c4 = a.acol[sg][4];
+                const bool first = sg == 0, lastst = sg == ns - 1;
+#pragma unroll
+                for (int s = 0; s < ZR; ++s) {
+                    const float k = zd[s];
+                    const float o1 = first ? 0.f : unpark(pk[0][s]), o2 = first ? 0.f : unpark(pk[1][s]),
+                                o3 = first ? 0.f : unpark(pk[2][s]), o4 = first ? 0.f : unpark(pk[3][s]),
+                                os = first ? 0.f : unpark(pk[4][s]);
+                    const float zz = unpark(zp[s]);
+                    const float p0 = fmaf(c0, k, o1);
+                    pk[0][s] = park(fmaf(c1, k, o2));
+                    pk[1][s] = park(fmaf(c2, k, o3));
+                    pk[2][s] = park(fmaf(c3, k, o4));
+                    pk[3][s] = park(c4 * k);
+                    const float nsu = fmaf(bst, k, os);
+                    pk[4][s] = park(nsu);
+                    zs[s] = fmaf(dt, p0, zz);
+                    if (lastst) { const float zn = fmaf(dt, nsu, zz); zp[s] = park(zn); zs[s] = zn; }
+                }
+            }
+            if (single) break;
+            lacc = fmaf(dt, lsum, lacc); eacc = fmaf(dt, esum, eacc); nacc = fmaf(dt, nsum, nacc);
+        }
+        if (a.ckpt && !single) {
+            float* c = a.ckpt + (((long long)nsteps * ckntp + cktile) * 64 + lane) * ckzr;
+#pragma unroll
+            for (int s = 0; s < ZR; ++s) c[s] = zs[s];
+            for (int s = ZR; s < ckzr; ++s) c[s] = 0.f;
+        }
+        if (single) {
+            if (valid) {
+#pragma unroll
+                for (int s = 0; s < ZR; ++s) { const int f = 4 * s + g; if (f < D) a.u_out[smp * S + f] = zd[s]; }
+                if (g == 0) { a.u_out[smp * S + D] = ld; a.u_out[smp * S + D + 1] = ed; a.u_out[smp * S + D + 2] = nd; }
+            }
+            continue;
+        }
+        // ---- epilogue: inference_sol (src/core/base_icnf.jl:158-172) ----
+        float ss = 0.f, sa = 0.f;
+#pragma unroll
+        for (int s = 0; s < ZR; ++s) {
+            const int f = 4 * s + g;
+            const float v2 = zs[s] * zs[s];
+            ss += v2;
+            if (f >= a.nvars) sa += v2;
+        }
+        ss = group_sum(ss);
+        sa = group_sum(sa);
+        if (valid) {
+            if (a.u_out) {
+#pragma unroll
+                for (int s = 0; s < ZR; ++s) { const int f = 4 * s + g; if (f < D) a.u_out[smp * S + f] = zs[s]; }
+                if (g == 0) { a.u_out[smp * S + D] = lacc; a.u_out[smp * S + D + 1] = eacc; a.u_out[smp * S + D + 2] = nacc; }
+            }
+            if (g == 0) {
+                if (a.logp) a.logp[smp] = (-0.5f * (float)D * kLog2Pi - 0.5f * ss) - lacc;
+                if (a.regs) {
+                    a.regs[smp] = eacc;
+                    a.regs[a.B + smp] = nacc;
+                    a.regs[2 * a.B + smp] = a.reg_aug ? sqrtf(sa) : 0.f;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------
+template <int A, int L, int ZR, int ACT>
+static hipError_t launch_coopd(const DArgs& a, int lds, int nblocks, hipStream_t st) {
+    auto kern = coopd_solve_kernel<A, L, ZR, ACT>;
+    static DeviceOnce once;
+    int dev = 0;
+    hipError_t e0 = hipGetDevice(&dev);
+    if (e0 != hipSuccess) return e0;
+    if (!once.done(dev)) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        once.set(dev);
+    }
+    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(256), lds, st, a);
+    return hipGetLastError();
+}
+
+struct CoopDInst {
+    int A, L, ZR, ACT;
+    hipError_t (*fn)(const DArgs&, int, int, hipStream_t);
+};
+#define CD_INST(A, L, ZR, ACT) CoopDInst { A, L, ZR, ACT, &launch_coopd<A, L, ZR, ACT> }
+// (A, ZR) pairs of the reference's default architecture H = 4 (D + 1): D <= 48 with 9 .. 12 hidden tiles (nvariables 16 .. 23),
+// D <= 64 with 13 .. 16 (nvariables 24 .. 31); the same pairs serve any flow of those sizes
+#define CD_SHAPES(L, ACT) CD_INST(2, L, 12, ACT)
+static const CoopDInst kCoopD[] = {
+    CD_SHAPES(2, CNF_ACT_SOFTPLUS),
+};
+
+static const CoopDInst* cd_find(int HT_real, int L, int KZ, int ACT) {
+    const int A = HT_real / 4;
+    const CoopDInst* best = nullptr;
+    for (const CoopDInst& c : kCoopD) {
+        const bool act_ok = c.ACT == ACT || (c.ACT == CNF_ACT_TANH_PRESCALED && ACT == CNF_ACT_TANH);
+        if (c.A == A && c.L == L && c.ZR >= KZ && act_ok && (!best || c.ZR < best->ZR)) best = &c;
+    }
+    return best;
+}
+
+// H = widest hidden layer, D = state rows of the configuration; (HT, ZR) = the plan's layout
+bool coopd_supported(int H, int D, int L, int ACT, int HT_lay, int ZR_lay) {
+    const int HT_real = (H + 15) / 16, KZ = (D + 3) / 4;
+    if (HT_real < 8 || HT_real > HT_lay || KZ > ZR_lay) return false;
+    const CoopDInst* c = cd_find(HT_real, L, KZ, ACT);
+    if (!c) return false;
+    // state registers beyond the plan's k-steps would read image k-groups that do not exist
+    if ((c->ZR + 3) / 4 > (ZR_lay + 3) / 4) return false;
+    return coopd_lds_bytes(HT_real, L, c->ZR / 4, true, (2 + L) * 16 * HT_lay) <= 160 * 1024;
+}
+
+hipError_t coopd_launch(int H, int D, int L, int ACT, int HT_lay, int ZR_lay, const KArgs& k, int num_cus, hipStream_t st) {
+    const int HT_real = (H + 15) / 16, KZ = (D + 3) / 4;
+    const CoopDInst* c = cd_find(HT_real, L, KZ, ACT);
+    if (!c) return hipErrorNotSupported;
+    const MfmaLayout Y(HT_lay, L, ZR_lay, 0, true);
+    DArgs a{};
+    a.k = k;
+    DImg& G = a.g;
+    G.f1z = Y.f1z; G.fh = Y.fh; G.fN = Y.fN; G.bN = Y.bN; G.bh = Y.bh; G.b1 = Y.b1;
+    G.v_b1 = Y.v_b1; G.v_w1t = Y.v_w1t; G.v_bh = Y.v_bh; G.v_bN = Y.v_bN;
+    G.KPZ = Y.KGZ; G.HTP = Y.HT; G.imgH = MfmaLayout::imgA(Y.HT, Y.HT); G.vecH = MfmaLayout::vecC(Y.HT);
+    G.b = HT_real - 4 * c->A;
+    const int ksH = (H + 3) / 4;
+    G.KGH = HT_real; G.remH = ksH - 4 * (HT_real - 1);
+    G.KGZ = (KZ + 3) / 4; G.remZ = KZ - 4 * (G.KGZ - 1);
+    G.ckzr = ZR_lay;
+    const int DT = c->ZR / 4;
+    G.cvn = Y.v_bN + MfmaLayout::vecC(Y.DT) - Y.v_b1;
+    G.xalias = coopd_lds_bytes(HT_real, L, DT, false, G.cvn) <= 160 * 1024 ? 0 : 1;
+    const int lds = coopd_lds_bytes(HT_real, L, DT, G.xalias != 0, G.cvn);
+    if (lds > 160 * 1024 || (G.xalias && 4 * DT * 4 > (L == 2 ? 1 : 2) * HT_real * 4)) return hipErrorNotSupported;
+    const long long nst = (k.B + 63) / 64;
+    const int nblocks = (int)(nst < num_cus ? nst : num_cus);
+    return c->fn(a, lds, nblocks, st);
+}
+
+}  // namespace cnf

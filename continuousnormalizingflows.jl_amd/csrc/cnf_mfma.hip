@@ -404,7 +404,17 @@ bool mfma_plan_coop_grad_shape(const MfmaPlan* p, int* HT, int* L, int* ZR, int*
     return true;
 }
 // 16-sample tiles of the checkpoint arrays such a solve writes (the kernel's super-tile count x its tiles per super-tile)
+// an extended-kernel plan whose one-probe VJP solves run on the dealt cooperative kernel (cnf_coop_d.hip); CNF_COOPD=0: never
+static bool plan_uses_coopd(const MfmaPlan* p) {
+    if (!p || p->kind != 2 || p->KP != 1 || p->CR != 0 || p->cfg.mode != CNF_MODE_HUTCH_VJP || p->cfg.ncond != 0) return false;
+    if (env_int("CNF_COOPD", 1) == 0) return false;
+    int hmax = 0;
+    for (int l = 1; l < p->cfg.n_layers; ++l) hmax = p->cfg.widths[l] > hmax ? p->cfg.widths[l] : hmax;
+    return coopd_supported(hmax, p->cfg.nvars + p->cfg.naug, p->L, p->ACT, p->HT, p->ZR);
+}
+
 long long mfma_plan_ckpt_tiles(const MfmaPlan* p, long long B, bool on_grid) {
+    if (plan_uses_coopd(p)) return (B + 63) / 64 * 4;
     const bool x = p->kind == 2 || on_grid || !coop_ckpt_supported(p->HT, p->L, p->ZR, p->ACT);   // which kernel checkpoints: see mfma_solve
     return x ? (B + 31) / 32 * 2 : (B + 63) / 64 * 4;
 }
@@ -466,7 +476,7 @@ static bool plan_takes_tile_split(MfmaPlan* p, long long B) {
 // CNF_FAMILY_* of the kernel that serves a whole fixed-step solve of B columns (whole_solve) or a single dynamics call
 int mfma_plan_family_for(MfmaPlan* p, long long B, bool whole_solve) {
     if (p->kind == 1) return CNF_FAMILY_COOP;
-    if (p->kind == 2) return CNF_FAMILY_COOPX;
+    if (p->kind == 2) return plan_uses_coopd(p) ? CNF_FAMILY_COOPD : CNF_FAMILY_COOPX;
     return (whole_solve && B > 0 && plan_takes_tile_split(p, B)) ? CNF_FAMILY_TILE_SPLIT : CNF_FAMILY_PER_WAVE;
 }
 
@@ -505,6 +515,11 @@ hipError_t mfma_solve(MfmaPlan* p, const float* packed_dev, const SolveArgs& s, 
     if (p->kind == 2) {
         if (p->cfg.mode == CNF_MODE_HUTCH_JVP) a.exact = 2;   // this kernel family's code for the JVP form (cnf_coop_x.hip)
         a.q_off = p->q_extra;
+        if (plan_uses_coopd(p)) {
+            int hmax = 0;
+            for (int l = 1; l < p->cfg.n_layers; ++l) hmax = p->cfg.widths[l] > hmax ? p->cfg.widths[l] : hmax;
+            return coopd_launch(hmax, a.D, p->L, p->ACT, p->HT, p->ZR, a, mp->num_cus, st);
+        }
         return coopx_launch(p->HT, p->L, p->ZR, p->CR, p->ACT, a, mp->num_cus, st);
     }
     if (p->kind == 1) {

@@ -205,6 +205,7 @@ int cnf_kernel_path(const cnf_handle* h);
  *   PER_WAVE    one wave per 16-sample tile, operand images in LDS (csrc/cnf_mfma_kernel.h)        hidden width <= 128
  *   COOP        a workgroup per 64-sample super-tile, images in L2 (csrc/cnf_coop.hip)             Hutchinson VJP, 1 probe, wide layers
  *   COOPX       its extended form (csrc/cnf_coop_x.hip)                                            conditions / probes / exact / JVP, wide layers
+ *   COOPD       the cooperative kernel with its tiles dealt exactly over four owner waves (csrc/cnf_coop_d.hip)   one-probe VJP, the reference's default architecture at nvariables >= 16
  *   TILE_SPLIT  one tile per workgroup, hidden width over the four SIMDs (csrc/cnf_coop.hip)       per-wave shapes at <= 16 CUs' worth of columns
  * cnf_kernel_family: the handle's own family (never TILE_SPLIT).  cnf_kernel_family_for: the kernel a call of B columns takes -
  * whole_solve != 0 for cnf_integrate_fixed / cnf_inference_fixed(_dt) / cnf_loss_*, 0 for cnf_aug_f and the caller-driven steps.
@@ -212,7 +213,8 @@ int cnf_kernel_path(const cnf_handle* h);
  * on which other columns are in the call - SHARD CONCATENATION IS THEREFORE BIT-IDENTICAL ONLY WHEN EVERY SHARD AND THE
  * UNSHARDED CALL TAKE THE SAME FAMILY: per-wave shapes switch to TILE_SPLIT at B <= 16 x (compute units) = 4096 columns
  * (CNF_TILE_SPLIT=0 in the environment keeps PER_WAVE at every size); every BASELINE shard is larger. */
-enum { CNF_FAMILY_SIMT = 0, CNF_FAMILY_PER_WAVE = 1, CNF_FAMILY_COOP = 2, CNF_FAMILY_COOPX = 3, CNF_FAMILY_TILE_SPLIT = 4, CNF_FAMILY_LAYERED = 5 };
+enum { CNF_FAMILY_SIMT = 0, CNF_FAMILY_PER_WAVE = 1, CNF_FAMILY_COOP = 2, CNF_FAMILY_COOPX = 3, CNF_FAMILY_TILE_SPLIT = 4, CNF_FAMILY_LAYERED = 5,
+       CNF_FAMILY_COOPD = 6 };
 int cnf_kernel_family(const cnf_handle* h);
 int cnf_kernel_family_for(cnf_handle* h, int64_t B, int whole_solve);
 /* Name of the kernel instance behind the handle ("mfma_vjp<HT=4,L=3,...>", "coopx<...>", "layered", "simt"); static storage
