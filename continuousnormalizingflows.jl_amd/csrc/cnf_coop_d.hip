@@ -56,6 +56,28 @@ struct DRs {
 __device__ __forceinline__ f32x4 dload(const DRs& R, unsigned byte_off) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(R.r, (int)R.lane16, (int)byte_off, 0));
 }
+// fragment load with the tile's offset in a VECTOR register (lane slot + tile row offset, made opaque so that it stays one) and
+// the image + k-group offset in ONE scalar: the k-loops then carry a single scalar add per k-group.  With every fragment's
+// offset in its own scalar the scalar file overflows (193 scalar spills) and each load in the k-loops was preceded by a
+// v_readlane (a VALU instruction between MFMAs) + s_add + s_nop.
+__device__ __forceinline__ f32x4 dloadv(const DRs& R, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(R.r, (int)voff, (int)soff, 0));
+}
+template <int A>
+struct TileOff { unsigned S[A]; unsigned Rr[3]; };
+template <int A>
+__device__ __forceinline__ TileOff<A> tile_offsets(const DRs& R, int KP, int mtS0, int mtR0, int mtRmax) {
+    TileOff<A> t;
+#pragma unroll
+    for (int m = 0; m < A; ++m) { t.S[m] = R.lane16 + (unsigned)((mtS0 + m) * KP) * 1024u; asm volatile("" : "+v"(t.S[m])); }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const int mt = mtR0 + r < mtRmax ? mtR0 + r : mtRmax;   // clamped, not guarded: no control flow around a load
+        t.Rr[r] = R.lane16 + (unsigned)(mt * KP) * 1024u;
+        asm volatile("" : "+v"(t.Rr[r]));
+    }
+    return t;
+}
 
 // Explicit residency in the accumulation registers.  With one wave per SIMD a wave has 256 architectural + 256 accumulation
 // registers; every VALU / MFMA operand of this kernel must be architectural (-amdgpu-mfma-vgpr-form), and what the allocator
@@ -102,20 +124,21 @@ __device__ __forceinline__ void uacc_zero(UAcc<A>& u) {
 
 // A fragments of k-group kg for this wave's units of an H-row product: image `img` (byte offset), k-group pitch KP
 template <int A>
-__device__ __forceinline__ void dealt_load_a(const DRs& R, unsigned img, int KP, int mtS0, int mtR0, int mtRmax, int kg,
-                                             f32x4 (&aS)[A], f32x4 (&aR)[3]) {
+__device__ __forceinline__ void dealt_load_a(const DRs& R, const TileOff<A>& T, unsigned img, int kg, f32x4 (&aS)[A], f32x4 (&aR)[3]) {
+    const unsigned so = img + (unsigned)kg * 1024u;
 #pragma unroll
-    for (int m = 0; m < A; ++m) aS[m] = dload(R, img + (unsigned)(((mtS0 + m) * KP + kg) * 1024));
+    for (int m = 0; m < A; ++m) aS[m] = dloadv(R, T.S[m], so);
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
-        const int mt = mtR0 + r < mtRmax ? mtR0 + r : mtRmax;   // clamped, not guarded: no control flow around a load
-        aR[r] = dload(R, img + (unsigned)((mt * KP + kg) * 1024));
-    }
+    for (int r = 0; r < 3; ++r) aR[r] = dloadv(R, T.Rr[r], so);
 }
 __device__ __forceinline__ void dealt_load_b(const f32x4* __restrict__ bimg, int kg, int wave, int lane, f32x4 (&bq)[4], f32x4& bo) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) bq[q] = bimg[(kg * 4 + q) * 64 + lane];
-    bo = bimg[(kg * 4 + wave) * 64 + lane];
+    // the own tile's address is rebuilt from the (opaque) scalar wave index on every call - one v_add - instead of living in a
+    // loop-invariant vector register of its own: that register is what the allocator spilled to scratch in two earlier builds
+    int wv = wave;
+    asm volatile("" : "+s"(wv));
+    bo = bimg[(kg * 4 + wv) * 64 + lane];
 }
 template <int A, int JN>
 __device__ __forceinline__ void dealt_mfma(const f32x4 (&aS)[A], const f32x4 (&aR)[3], const f32x4 (&bq)[4], const f32x4& bo, int b,
@@ -153,7 +176,7 @@ __device__ __forceinline__ void dealt_mfma_rem(const f32x4 (&aS)[A], const f32x4
 // k-group 0 (requested by the caller one phase earlier); two fragment sets ping-pong, the loads of k-group kg + 1 are issued
 // before the MFMAs of k-group kg.
 template <int A>
-__device__ __forceinline__ void dealt_gemm(const DRs& R, unsigned img, int KP, int KG, int rem, int mtS0, int mtR0, int mtRmax, int b,
+__device__ __forceinline__ void dealt_gemm(const DRs& R, const TileOff<A>& T, unsigned img, int KG, int rem, int b,
                                            const f32x4* __restrict__ bimg, int wave, int lane, f32x4 (&aS0)[A], f32x4 (&aR0)[3],
                                            UAcc<A>& u) {
     f32x4 aS1[A], aR1[3], bq0[4], bq1[4], bo0, bo1;
@@ -162,15 +185,15 @@ __device__ __forceinline__ void dealt_gemm(const DRs& R, unsigned img, int KP, i
     int kg = 0;
 #pragma clang loop unroll(disable)
     for (; kg + 2 <= KGf; kg += 2) {
-        dealt_load_a<A>(R, img, KP, mtS0, mtR0, mtRmax, kg + 1, aS1, aR1);
+        dealt_load_a<A>(R, T, img, kg + 1, aS1, aR1);
         dealt_load_b(bimg, kg + 1, wave, lane, bq1, bo1);
         dealt_mfma<A, 4>(aS0, aR0, bq0, bo0, b, u);
-        dealt_load_a<A>(R, img, KP, mtS0, mtR0, mtRmax, kg + 2, aS0, aR0);
+        dealt_load_a<A>(R, T, img, kg + 2, aS0, aR0);
         dealt_load_b(bimg, kg + 2, wave, lane, bq0, bo0);
         dealt_mfma<A, 4>(aS1, aR1, bq1, bo1, b, u);
     }
     if (kg < KGf) {   // one full k-group and the last one
-        dealt_load_a<A>(R, img, KP, mtS0, mtR0, mtRmax, KG - 1, aS1, aR1);
+        dealt_load_a<A>(R, T, img, KG - 1, aS1, aR1);
         dealt_load_b(bimg, KG - 1, wave, lane, bq1, bo1);
         dealt_mfma<A, 4>(aS0, aR0, bq0, bo0, b, u);
         dealt_mfma_rem<A>(aS1, aR1, bq1, bo1, b, rem, u);
@@ -184,7 +207,7 @@ __device__ __forceinline__ void dealt_gemm(const DRs& R, unsigned img, int KP, i
 // tile.  `img`: the D-row image (fN or b1), k-group pitch KP.  The k-group that is the configuration's last one runs `rem`
 // k-steps.
 template <int A, int DT>
-__device__ __forceinline__ void dealt_drow(const DRs& R, unsigned img, int KP, int kgS0, int kgR0, int KG, int rem, int b,
+__device__ __forceinline__ void dealt_drow(const DRs& R, const unsigned (&vd)[DT], unsigned img, int kgS0, int kgR0, int KG, int rem, int b,
                                            const UAcc<A>& x, f32x4 (&f0)[DT], f32x4 (&part)[DT][4], f32x4 (&own)[DT]) {
     // f0 arrives holding the fragments of k-group kgS0 (dealt_drow_first: requested before the activation phase)
     f32x4 f1[DT];
@@ -203,7 +226,7 @@ __device__ __forceinline__ void dealt_drow(const DRs& R, unsigned img, int KP, i
             const int raw = m + 1 < A ? kgS0 + m + 1 : kgR0 + (m + 1 - A);
             const int kgn = raw < KG ? raw : KG - 1;
 #pragma unroll
-            for (int dm = 0; dm < DT; ++dm) nxt[dm] = dload(R, img + (unsigned)((dm * KP + kgn) * 1024));
+            for (int dm = 0; dm < DT; ++dm) nxt[dm] = dloadv(R, vd[dm], img + (unsigned)kgn * 1024u);
         }
         if (m < A) {
             const bool last = kgS0 + m == KG - 1;   // only when b == 0 and this is the last wave's last tile
@@ -264,11 +287,50 @@ __device__ __forceinline__ void softplus_tile(const f32x4& a, f32x4& h, f32x4& d
     d = f32x4{d0[0], d0[1], d1[0], d1[1]};
 }
 template <int DT>
-__device__ __forceinline__ void dealt_drow_first(const DRs& R, unsigned img, int KP, int kgS0, f32x4 (&f0)[DT]) {
+__device__ __forceinline__ void dealt_drow_first(const DRs& R, const unsigned (&vd)[DT], unsigned img, int kgS0, f32x4 (&f0)[DT]) {
 #pragma unroll
-    for (int dm = 0; dm < DT; ++dm) f0[dm] = dload(R, img + (unsigned)((dm * KP + kgS0) * 1024));
+    for (int dm = 0; dm < DT; ++dm) f0[dm] = dloadv(R, vd[dm], img + (unsigned)kgS0 * 1024u);
 }
 
+// the last hidden layer: the activation alone now, its derivative FROM the activation after the D-row product has consumed it
+// (softplus: sigmoid(a) = 1 - exp(-softplus(a)); tanh: 1 - tanh^2) - nothing of that layer is kept across the product, and the
+// rebuild costs what computing it the first time would have (one transcendental).  |error| <= 1.2e-7 absolute, as everything else.
+template <int ACT>
+__device__ __forceinline__ f32x4 act_only(const f32x4& a) {
+    if constexpr (ACT == CNF_ACT_SOFTPLUS) {
+        constexpr float kNegLog2e = -1.4426950408889634f, kLn2 = 0.6931471805599453f;
+        float e[4], lg[4], mx[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) e[i] = __builtin_amdgcn_exp2f(__builtin_fabsf(a[i]) * kNegLog2e);
+        const f32x2 one = {1.f, 1.f};
+        const f32x2 s0 = f32x2{e[0], e[1]} + one, s1 = f32x2{e[2], e[3]} + one;
+        const float sv[4] = {s0[0], s0[1], s1[0], s1[1]};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { lg[i] = __builtin_amdgcn_logf(sv[i]); mx[i] = __builtin_fmaxf(a[i], 0.f); }
+        const f32x2 ln2 = {kLn2, kLn2};
+        const f32x2 h0 = __builtin_elementwise_fma(f32x2{lg[0], lg[1]}, ln2, f32x2{mx[0], mx[1]});
+        const f32x2 h1 = __builtin_elementwise_fma(f32x2{lg[2], lg[3]}, ln2, f32x2{mx[2], mx[3]});
+        return f32x4{h0[0], h0[1], h1[0], h1[1]};
+    } else {
+        f32x4 h, d;
+        act_tile<ACT>(a, h, d);
+        return h;
+    }
+}
+template <int ACT>
+__device__ __forceinline__ f32x4 dact_from_h(const f32x4& h) {
+    if constexpr (ACT == CNF_ACT_SOFTPLUS) {
+        constexpr float kNegLog2e = -1.4426950408889634f;
+        f32x4 d;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) d[i] = 1.f - __builtin_amdgcn_exp2f(h[i] * kNegLog2e);
+        return d;
+    } else {
+        const f32x2 h0 = {h[0], h[1]}, h1 = {h[2], h[3]}, one = {1.f, 1.f};
+        const f32x2 d0 = __builtin_elementwise_fma(-h0, h0, one), d1 = __builtin_elementwise_fma(-h1, h1, one);
+        return f32x4{d0[0], d0[1], d1[0], d1[1]};
+    }
+}
 template <int ACT>
 __device__ __forceinline__ void act_pair(const f32x4& a, f32x4& h, f32x4& d) {
     if constexpr (ACT == CNF_ACT_SOFTPLUS) softplus_tile(a, h, d);
@@ -281,7 +343,11 @@ __device__ __forceinline__ void coopd_eval(const DRs& R, const float* __restrict
                                            f32x4* __restrict__ zbuf, const f32x4* __restrict__ ebuf, f32x4* __restrict__ pbuf,
                                            int lane, int wave, float t, bool autonomous, bool reg_z, bool reg_j,
                                            const float (&zs)[ZR], float (&zd)[ZR], float& ld, float& ed, float& nd,
-                                           float* __restrict__ gout) {
+                                           float* __restrict__ gout, const UAcc<A>& cP, f32x4 (&aS)[A], f32x4 (&aR)[3]) {
+    // cP: c = W_N^T eps of this wave's units, PARKED - eps is fixed for the whole solve (src/core/base_icnf.jl:258-259), so the
+    //     product is taken once per super-tile (coopd_hoist_c), and delta_L = c .* act'_L falls out of the last activation pass;
+    // aS / aR arrive holding the layer-1 fragments of k-group 0 and leave holding them again for the next evaluation (requested
+    //     before the last barrier: the load is in flight across the Runge-Kutta update and the state publish)
     constexpr int DT = ZR / 4;
     static_assert(ZR % 4 == 0, "state registers in whole M-tiles");
     // every image offset of this evaluation hangs off an opaque zero: the several hundred wave-uniform fragment addresses are
@@ -298,8 +364,12 @@ __device__ __forceinline__ void coopd_eval(const DRs& R, const float* __restrict
     const unsigned F1Z = (unsigned)G.f1z * 4u, FH = (unsigned)G.fh * 4u, FN = (unsigned)G.fN * 4u, BN = (unsigned)G.bN * 4u,
                    BH = (unsigned)G.bh * 4u, B1 = (unsigned)G.b1 * 4u, IMGH = (unsigned)G.imgH * 4u;
     UAcc<A> acc;
-    UAcc<A> d[L];      // act' of every hidden layer (this wave's units), kept for the pullback: PARKED (see park)
-    f32x4 aS[A], aR[3];
+    UAcc<A> d[L];      // act' of the hidden layers below the last (this wave's units), kept for the pullback: PARKED (see park)
+    const TileOff<A> TZ = tile_offsets<A>(R, G.KPZ, mtS0, mtR0, mtRmax);   // state-column images (k-group pitch KPZ)
+    const TileOff<A> TH = tile_offsets<A>(R, G.HTP, mtS0, mtR0, mtRmax);   // H-column images
+    unsigned vd[DT];
+#pragma unroll
+    for (int dm = 0; dm < DT; ++dm) { vd[dm] = R.lane16 + (unsigned)(dm * G.HTP) * 1024u; asm volatile("" : "+v"(vd[dm])); }
     // C vector (bias, time column) of this wave's units
     auto cvec_units = [&](const float* __restrict__ vec, f32x4 (&vS)[A], f32x4 (&vR)[3]) {
 #pragma unroll
@@ -313,7 +383,6 @@ __device__ __forceinline__ void coopd_eval(const DRs& R, const float* __restrict
     // ---- layer 1: a = W1z z + w1t t + b1 ----
     {
         f32x4 bS[A], bR[3], wS[A], wR[3];
-        dealt_load_a<A>(R, F1Z, G.KPZ, mtS0, mtR0, mtRmax, 0, aS, aR);
         cvec_units(P + G.v_b1, bS, bR);
         cvec_units(P + G.v_w1t, wS, wR);
 #pragma unroll
@@ -331,28 +400,36 @@ __device__ __forceinline__ void coopd_eval(const DRs& R, const float* __restrict
         }
         uacc_fill<A>(acc, bS, bR);
         __syncthreads();
-        dealt_gemm<A>(R, F1Z, G.KPZ, G.KGZ, G.remZ, mtS0, mtR0, mtRmax, b, zbuf, wave, lane, aS, aR, acc);
+        dealt_gemm<A>(R, TZ, F1Z, G.KGZ, G.remZ, b, zbuf, wave, lane, aS, aR, acc);
     }
     f32x4 part[DT][4], own[DT], fd[DT];
     UAcc<A> h;
 #pragma unroll
     for (int l = 0; l < L; ++l) {
         const int cur = l & 1;   // exchange buffer of layer l + 1's activations (L = 2 only ever uses buffer 0)
-        if (l + 1 < L) dealt_load_a<A>(R, FH + (unsigned)l * IMGH, G.HTP, mtS0, mtR0, mtRmax, 0, aS, aR);
-        else dealt_drow_first<DT>(R, FN, G.HTP, mtS0, fd);
+        if (l + 1 < L) dealt_load_a<A>(R, TH, FH + (unsigned)l * IMGH, 0, aS, aR);
+        else dealt_drow_first<DT>(R, vd, FN, mtS0, fd);
 #pragma unroll
         for (int m = 0; m < A; ++m)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                f32x4 dd;
-                act_pair<ACT>(acc.S[m][q], h.S[m][q], dd);
-                d[l].S[m][q] = park4(dd);
+                if (l + 1 < L) {
+                    f32x4 dd;
+                    act_pair<ACT>(acc.S[m][q], h.S[m][q], dd);
+                    d[l].S[m][q] = park4(dd);
+                } else {
+                    h.S[m][q] = act_only<ACT>(acc.S[m][q]);
+                }
             }
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
-            f32x4 dd;
-            act_pair<ACT>(acc.R[r], h.R[r], dd);
-            d[l].R[r] = park4(dd);
+            if (l + 1 < L) {
+                f32x4 dd;
+                act_pair<ACT>(acc.R[r], h.R[r], dd);
+                d[l].R[r] = park4(dd);
+            } else {
+                h.R[r] = act_only<ACT>(acc.R[r]);
+            }
         }
         if (l + 1 < L) {
 #pragma unroll
@@ -366,13 +443,20 @@ __device__ __forceinline__ void coopd_eval(const DRs& R, const float* __restrict
             cvec_units(P + G.v_bh + l * G.vecH, bS, bR);
             uacc_fill<A>(acc, bS, bR);
             __syncthreads();
-            dealt_gemm<A>(R, FH + (unsigned)l * IMGH, G.HTP, G.KGH, G.remH, mtS0, mtR0, mtRmax, b, xbuf + cur * XB, wave, lane, aS, aR, acc);
+            dealt_gemm<A>(R, TH, FH + (unsigned)l * IMGH, G.KGH, G.remH, b, xbuf + cur * XB, wave, lane, aS, aR, acc);
         }
     }
     // ---- zdot = W_N h_L + b_N: partials over this wave's own k-groups, from registers ----
-    dealt_drow<A, DT>(R, FN, G.HTP, mtS0, mtR0, G.KGH, G.remH, b, h, fd, part, own);
-    // the first fragments of c = W_N^T eps are requested before the barrier
-    dealt_load_a<A>(R, BN, G.KPZ, mtS0, mtR0, mtRmax, 0, aS, aR);
+    dealt_drow<A, DT>(R, vd, FN, mtS0, mtR0, G.KGH, G.remH, b, h, fd, part, own);
+    // the first fragments of the pullback's first product are requested before the barrier
+    if (L > 1) dealt_load_a<A>(R, TH, BH + (unsigned)(L - 2) * IMGH, 0, aS, aR);
+    // delta_L = c .* act'_L, act'_L rebuilt from h_L (which the product above has consumed)
+#pragma unroll
+    for (int m = 0; m < A; ++m)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) h.S[m][q] = unpark4(cP.S[m][q]) * dact_from_h<ACT>(h.S[m][q]);
+#pragma unroll
+    for (int r = 0; r < 3; ++r) h.R[r] = unpark4(cP.R[r]) * dact_from_h<ACT>(h.R[r]);
     if (G.xalias) __syncthreads();   // the partial tiles share the exchange buffer: its readers (the last hidden product) are done
 #pragma unroll
     for (int dm = 0; dm < DT; ++dm)
@@ -398,21 +482,21 @@ __device__ __forceinline__ void coopd_eval(const DRs& R, const float* __restrict
         for (int s = 0; s < ZR; ++s) e2 = fmaf(zd[s], zd[s], e2);
         ed = sqrtf(group_sum(e2));   // Edot = |zdot|_2   (src/core/icnf.jl:184-199)
     }
-    // ---- pullback: c = W_N^T eps, delta_l = (W_{l+1}^T delta_{l+1}) .* act'_l ----
-    uacc_zero<A>(acc);
-    dealt_gemm<A>(R, BN, G.KPZ, G.KGZ, G.remZ, mtS0, mtR0, mtRmax, b, ebuf, wave, lane, aS, aR, acc);
+    // ---- pullback: delta_L = c .* act'_L (above), delta_l = (W_{l+1}^T delta_{l+1}) .* act'_l ----
 #pragma unroll
     for (int l = L - 1; l >= 0; --l) {
-        // delta_{l+1} (1-based) = acc .* act'_{l+1}
-        if (l == 0) dealt_drow_first<DT>(R, B1, G.HTP, mtS0, fd);
+        // delta_{l+1} (1-based)
+        if (l == 0) dealt_drow_first<DT>(R, vd, B1, mtS0, fd);
+        if (l == L - 1) {
+            // (h already holds delta_L)
+        } else {
 #pragma unroll
-        for (int m = 0; m < A; ++m) {
-            f32x4 dd[4];
+            for (int m = 0; m < A; ++m) {
+                f32x4 dd[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) dd[q] = unpark4(d[l].S[m][q]);
-            tiles_mul<4>(acc.S[m], dd, h.S[m]);
-        }
-        {
+                for (int q = 0; q < 4; ++q) dd[q] = unpark4(d[l].S[m][q]);
+                tiles_mul<4>(acc.S[m], dd, h.S[m]);
+            }
             f32x4 dd[3];
 #pragma unroll
             for (int r = 0; r < 3; ++r) dd[r] = unpark4(d[l].R[r]);
@@ -421,8 +505,8 @@ __device__ __forceinline__ void coopd_eval(const DRs& R, const float* __restrict
         if (l > 0) {
             // exchange buffer: h_l sat in buffer (l - 1) & 1; every reader passed a barrier since.  L = 2: buffer 0 again.
             const int wbuf = (L == 2) ? 0 : ((l - 1) & 1) ^ 1;
-            dealt_load_a<A>(R, BH + (unsigned)(l - 1) * IMGH, G.HTP, mtS0, mtR0, mtRmax, 0, aS, aR);
-            if (G.xalias) __syncthreads();   // the owners have read the zdot partials out of this buffer
+            if (l < L - 1) dealt_load_a<A>(R, TH, BH + (unsigned)(l - 1) * IMGH, 0, aS, aR);
+            if (G.xalias && l == L - 1) __syncthreads();   // the owners have read the zdot partials out of this buffer
 #pragma unroll
             for (int m = 0; m < A; ++m)
 #pragma unroll
@@ -432,11 +516,12 @@ __device__ __forceinline__ void coopd_eval(const DRs& R, const float* __restrict
                 if (r < b) xbuf[wbuf * XB + ((mtR0 + r) * 4 + wave) * 64 + lane] = h.R[r];
             uacc_zero<A>(acc);
             __syncthreads();
-            dealt_gemm<A>(R, BH + (unsigned)(l - 1) * IMGH, G.HTP, G.KGH, G.remH, mtS0, mtR0, mtRmax, b, xbuf + wbuf * XB, wave, lane, aS, aR, acc);
+            dealt_gemm<A>(R, TH, BH + (unsigned)(l - 1) * IMGH, G.KGH, G.remH, b, xbuf + wbuf * XB, wave, lane, aS, aR, acc);
         }
     }
     // ---- g = W_1[:,0:D]^T delta_1 = eps^T J: partials from registers ----
-    dealt_drow<A, DT>(R, B1, G.HTP, mtS0, mtR0, G.KGH, G.remH, b, h, fd, part, own);
+    dealt_drow<A, DT>(R, vd, B1, mtS0, mtR0, G.KGH, G.remH, b, h, fd, part, own);
+    dealt_load_a<A>(R, TZ, F1Z, 0, aS, aR);   // the next evaluation's layer-1 fragments
     if (G.xalias) __syncthreads();
 #pragma unroll
     for (int dm = 0; dm < DT; ++dm)
@@ -464,6 +549,26 @@ __device__ __forceinline__ void coopd_eval(const DRs& R, const float* __restrict
     }
     // (the next evaluation's first LDS write is the state image, whose last readers - layer 1 - passed several barriers ago;
     //  pbuf is rewritten only behind the next evaluation's own barriers)
+}
+
+// once per super-tile: c = W_N^T eps of this wave's units (B operand: the probe image ebuf, published and fenced by the caller),
+// parked; and the first evaluation's layer-1 fragments
+template <int A, int ZR>
+__device__ __forceinline__ void coopd_hoist_c(const DRs& R, const DImg& G, const f32x4* __restrict__ ebuf, int lane, int wave,
+                                              UAcc<A>& cP, f32x4 (&aS)[A], f32x4 (&aR)[3]) {
+    const int b = G.b, mtS0 = wave * A, mtR0 = 4 * A, mtRmax = 4 * A + b - 1;
+    const TileOff<A> TZ = tile_offsets<A>(R, G.KPZ, mtS0, mtR0, mtRmax);
+    UAcc<A> acc;
+    uacc_zero<A>(acc);
+    dealt_load_a<A>(R, TZ, (unsigned)G.bN * 4u, 0, aS, aR);
+    dealt_gemm<A>(R, TZ, (unsigned)G.bN * 4u, G.KGZ, G.remZ, b, ebuf, wave, lane, aS, aR, acc);
+#pragma unroll
+    for (int m = 0; m < A; ++m)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) cP.S[m][q] = park4(acc.S[m][q]);
+#pragma unroll
+    for (int r = 0; r < 3; ++r) cP.R[r] = park4(acc.R[r]);
+    dealt_load_a<A>(R, TZ, (unsigned)G.f1z * 4u, 0, aS, aR);
 }
 
 constexpr int coopd_lds_bytes(int HT, int L, int DT, bool alias, int cvn) {
@@ -518,6 +623,10 @@ coopd_solve_kernel(DArgs da) {
             ebuf[(kg * 4 + wave) * 64 + lane] = v;   // the probe of this wave's sample tile as a B image, for the whole solve
         }
         if (!a.x) { lacc = a.u0[sc * S + D]; eacc = a.u0[sc * S + D + 1]; nacc = a.u0[sc * S + D + 2]; }
+        __syncthreads();
+        UAcc<A> cP;
+        f32x4 aS[A], aR[3];
+        coopd_hoist_c<A, ZR>(R, G, ebuf, lane, wave, cP, aS, aR);
 
         float zd[ZR], ld = 0.f, ed = 0.f, nd = 0.f;
         const float dt0 = a.dt;
@@ -543,7 +652,7 @@ coopd_solve_kernel(DArgs da) {
                 const long long ckrow = ((((long long)step * ns + sg) * ckntp + cktile) * 64 + lane) * ckzr;
                 float* gout = (a.ckpt_g && !single) ? a.ckpt_g + ckrow : nullptr;
                 coopd_eval<A, L, ZR, ACT>(R, cbuf, G, xbuf, XB, zbuf, ebuf, pbuf, lane, wave, tn + a.T.c[sg] * dt, autonomous, reg_z, reg_j,
-                                          zs, zd, ld, ed, nd, gout);
+                                          zs, zd, ld, ed, nd, gout, cP, aS, aR);
                 if (gout)
                     for (int s = ZR; s < ckzr; ++s) gout[s] = 0.f;
                 if (a.ckpt_k && !single) {
