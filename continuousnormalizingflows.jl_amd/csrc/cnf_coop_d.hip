@@ -758,7 +758,7 @@ struct CoopDInst {
 #define CD_INST(A, L, ZR, ACT) CoopDInst { A, L, ZR, ACT, &launch_coopd<A, L, ZR, ACT> }
 // (A, ZR) pairs of the reference's default architecture H = 4 (D + 1): D <= 48 with 9 .. 12 hidden tiles (nvariables 16 .. 23),
 // D <= 64 with 13 .. 16 (nvariables 24 .. 31); the same pairs serve any flow of those sizes
-#define CD_SHAPES(L, ACT) CD_INST(2, L, 12, ACT)
+#define CD_SHAPES(L, ACT) CD_INST(2, L, 12, ACT), CD_INST(3, L, 12, ACT), CD_INST(3, L, 16, ACT)
 static const CoopDInst kCoopD[] = {
     CD_SHAPES(2, CNF_ACT_SOFTPLUS),
 };

@@ -27,8 +27,8 @@ def run(nv, B, alg, nsteps, check=True, reps=3):
     a, b = res["1"], res["0"]
     d = np.abs(a[3] - b[3]).max(); dr = max(np.abs(x - y).max() for x, y in zip(a[4], b[4]))
     print(f"nv={nv} B={B} alg={alg} nsteps={nsteps}: {a[0]} {a[1]:.2f} ms {a[2]:.1f} TF | {b[0]} {b[1]:.2f} ms {b[2]:.1f} TF | max|dlogp| {d:.2e} max|dregs| {dr:.2e}", flush=True)
-for nv, B in ((16, 100), (16, 64), (17, 333), (18, 200), (19, 77), (20, 129), (21, 50)):
+for nv, B in ((22, 100), (23, 77), (24, 130), (27, 64), (29, 50)):
     run(nv, B, 1, 3, reps=1)
     run(nv, B, 0, 2, reps=1)
-for nv in (16, 18, 20, 21):
+for nv in (16, 20, 22, 24, 28, 29):
     run(nv, 32768, 1, 40)
