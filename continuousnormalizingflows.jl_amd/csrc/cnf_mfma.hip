@@ -404,17 +404,34 @@ bool mfma_plan_coop_grad_shape(const MfmaPlan* p, int* HT, int* L, int* ZR, int*
     return true;
 }
 // 16-sample tiles of the checkpoint arrays such a solve writes (the kernel's super-tile count x its tiles per super-tile)
-// an extended-kernel plan whose one-probe VJP solves run on the dealt cooperative kernel (cnf_coop_d.hip); CNF_COOPD=0: never
-static bool plan_uses_coopd(const MfmaPlan* p) {
+static hipError_t plan_ensure_cus(MfmaPlan* mp) {
+    if (mp->num_cus != 0) return hipSuccess;
+    int dev = 0;
+    hipDeviceProp_t prop;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    e = hipGetDeviceProperties(&prop, dev);
+    if (e != hipSuccess) return e;
+    mp->num_cus = prop.multiProcessorCount;
+    return hipSuccess;
+}
+
+// an extended-kernel plan whose one-probe VJP solves of B columns run on the dealt cooperative kernel (cnf_coop_d.hip): from 16
+// columns per compute unit on (4096) - below that its 64-sample super-tiles leave CUs empty that the extended kernel's 32-sample
+// ones fill (measured at nvariables = 24: 9.7 against 9.0 ms at B <= 4096, 9.7 against 11.7 ms at 8192).  CNF_COOPD=0: never,
+// =2: at any batch size.
+static bool plan_uses_coopd(const MfmaPlan* p, long long B) {
     if (!p || p->kind != 2 || p->KP != 1 || p->CR != 0 || p->cfg.mode != CNF_MODE_HUTCH_VJP || p->cfg.ncond != 0) return false;
-    if (env_int("CNF_COOPD", 1) == 0) return false;
+    const int env = env_int("CNF_COOPD", 1);
+    if (env == 0 || (env != 2 && B <= 16LL * (p->num_cus > 0 ? p->num_cus : 256))) return false;
     int hmax = 0;
     for (int l = 1; l < p->cfg.n_layers; ++l) hmax = p->cfg.widths[l] > hmax ? p->cfg.widths[l] : hmax;
     return coopd_supported(hmax, p->cfg.nvars + p->cfg.naug, p->L, p->ACT, p->HT, p->ZR);
 }
 
 long long mfma_plan_ckpt_tiles(const MfmaPlan* p, long long B, bool on_grid) {
-    if (plan_uses_coopd(p)) return (B + 63) / 64 * 4;
+    (void)plan_ensure_cus(const_cast<MfmaPlan*>(p));   // (the batch threshold of the dealt kernel counts compute units)
+    if (plan_uses_coopd(p, B)) return (B + 63) / 64 * 4;
     const bool x = p->kind == 2 || on_grid || !coop_ckpt_supported(p->HT, p->L, p->ZR, p->ACT);   // which kernel checkpoints: see mfma_solve
     return x ? (B + 31) / 32 * 2 : (B + 63) / 64 * 4;
 }
@@ -446,17 +463,6 @@ void grad_pack(const cnf_config& c, const float* lux, const size_t* w_off, const
     mfma_pack_layout(c, HT, L, ZR, CR, lux, w_off, b_off, packed);
 }
 
-static hipError_t plan_ensure_cus(MfmaPlan* mp) {
-    if (mp->num_cus != 0) return hipSuccess;
-    int dev = 0;
-    hipDeviceProp_t prop;
-    hipError_t e = hipGetDevice(&dev);
-    if (e != hipSuccess) return e;
-    e = hipGetDeviceProperties(&prop, dev);
-    if (e != hipSuccess) return e;
-    mp->num_cus = prop.multiProcessorCount;
-    return hipSuccess;
-}
 
 // Small batches (at most one 16-sample tile per compute unit) of a per-wave plan: the tile-split form - the tile's hidden width
 // over the four SIMDs of a CU (cnf_coop.hip, NT = 1) - instead of one wave per tile with three SIMDs of its CU idle.  Same packed
@@ -476,7 +482,7 @@ static bool plan_takes_tile_split(MfmaPlan* p, long long B) {
 // CNF_FAMILY_* of the kernel that serves a whole fixed-step solve of B columns (whole_solve) or a single dynamics call
 int mfma_plan_family_for(MfmaPlan* p, long long B, bool whole_solve) {
     if (p->kind == 1) return CNF_FAMILY_COOP;
-    if (p->kind == 2) return plan_uses_coopd(p) ? CNF_FAMILY_COOPD : CNF_FAMILY_COOPX;
+    if (p->kind == 2) return (B > 0 && plan_ensure_cus(p) == hipSuccess && plan_uses_coopd(p, B)) ? CNF_FAMILY_COOPD : CNF_FAMILY_COOPX;
     return (whole_solve && B > 0 && plan_takes_tile_split(p, B)) ? CNF_FAMILY_TILE_SPLIT : CNF_FAMILY_PER_WAVE;
 }
 
@@ -515,7 +521,7 @@ hipError_t mfma_solve(MfmaPlan* p, const float* packed_dev, const SolveArgs& s, 
     if (p->kind == 2) {
         if (p->cfg.mode == CNF_MODE_HUTCH_JVP) a.exact = 2;   // this kernel family's code for the JVP form (cnf_coop_x.hip)
         a.q_off = p->q_extra;
-        if (plan_uses_coopd(p)) {
+        if (plan_uses_coopd(p, s.B)) {
             int hmax = 0;
             for (int l = 1; l < p->cfg.n_layers; ++l) hmax = p->cfg.widths[l] > hmax ? p->cfg.widths[l] : hmax;
             return coopd_launch(hmax, a.D, p->L, p->ACT, p->HT, p->ZR, a, mp->num_cus, st);

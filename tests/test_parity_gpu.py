@@ -173,6 +173,127 @@ def test_wide_conditioned_probe_and_exact_flows_take_the_extended_cooperative_ke
         del os.environ["CNF_MFMA_COOPX"]
 
 
+# the cooperative kernel with its tiles dealt exactly over four owner waves (csrc/cnf_coop_d.hip): one-probe VJP solves of two-layer
+# softplus flows with 8 .. 15 hidden tiles and D <= 64 - the reference's default architecture for nvariables = 16 .. 29.
+# (H, D) chosen to hit every left-over tile count b = HT - 4 A in {0, 1, 2, 3}, every last-k-group length and both state sizes.
+COOPD_CASES = [
+    (dict(nvars=16, naug=17, hidden=[136, 136], act=2, reg_z=True, reg_j=True, reg_aug=True), 200, 1, 6),   # ICNF(nvariables = 16): 9 tiles (b = 1), H = 136: 2 k-steps in the last k-group, D = 33: 1
+    (dict(nvars=18, naug=19, hidden=[152, 152], act=2, reg_z=True, reg_j=True, reg_aug=True), 77, 0, 6),    # nvariables = 18: 10 tiles (b = 2), RK4, ragged batch
+    (dict(nvars=20, naug=21, hidden=[168, 168], act=2), 130, 1, 5),                                          # nvariables = 20 as FFJORD: 11 tiles (b = 3), no regularisers
+    (dict(nvars=40, hidden=[128, 128], act=2, reg_j=True), 64, 0, 5),                                         # 8 tiles (b = 0), D = 40 with H = 128: full last k-groups
+    (dict(nvars=22, naug=23, hidden=[184, 184], act=2, reg_z=True, reg_j=True, reg_aug=True), 100, 1, 4),   # nvariables = 22: 12 tiles: A = 3, b = 0, D = 45
+    (dict(nvars=24, naug=25, hidden=[200, 200], act=2, reg_z=True, reg_j=True, reg_aug=True), 90, 0, 5),    # nvariables = 24: 13 tiles (A = 3, b = 1), D = 49: 16 state registers
+    (dict(nvars=29, naug=30, hidden=[240, 240], act=2, reg_z=True, reg_aug=True, autonomous=True), 70, 1, 4),   # nvariables = 29: 15 tiles (b = 3), D = 59, no time column
+    (dict(nvars=35, hidden=[150, 230], act=2, reg_z=True, reg_j=True), 45, 1, 4),                             # unequal widths (padded to the widest), D = 35
+    (dict(nvars=30, naug=3, hidden=[132, 132], act=2, reg_j=True), 1, 0, 3),                                  # one column
+]
+
+
+@pytest.mark.parametrize("kw,B,alg,nsteps", COOPD_CASES)
+def test_dealt_cooperative_kernel_matches_the_oracles(kw, B, alg, nsteps, pkg, oracles, monkeypatch):
+    """csrc/cnf_coop_d.hip (forced at these batch sizes with CNF_COOPD=2; it takes over on its own above 4096 columns) is the
+    same augmented_f / solve (src/core/icnf.jl:517-559, src/core/base_icnf.jl:158-172): whole solves against the C restatement,
+    logp / regularisers / final state; a single dynamics call against the fp64 oracle; and against the extended kernel
+    (CNF_COOPD=0) on the same inputs - the two differ by summation order only."""
+    o64, oc = oracles
+    spec = o64.make_spec(**kw)
+    mode = mode_of(pkg, spec)
+    p, xs, eps, ys = o64.synth_inputs(spec, B, 500 + B, bias_scale=0.2)
+    ref = oc.inference_fixed(spec, p, xs, 0.0, 1.0, nsteps, alg, eps, ys, nthreads=8)
+    out = {}
+    for tag, env in (("dealt", "2"), ("extended", "0")):
+        monkeypatch.setenv("CNF_COOPD", env)
+        icnf = make_icnf(pkg, spec, alg, nsteps, path=2)
+        assert icnf.kernel_family(mode, B=B) == ("coopd" if tag == "dealt" else "coopx")
+        logp, regs, u1 = run_inference(pkg, icnf, spec, p, xs, eps, ys, return_state=True)
+        out[tag] = (logp.cpu().numpy(), [r.cpu().numpy() for r in regs], u1.cpu().numpy())
+        assert np.max(np.abs(out[tag][0] - ref[0])) < TOL_SOLVE, tag
+        for a_, b_ in zip(out[tag][1], ref[1]):
+            assert np.max(np.abs(a_ - b_)) < TOL_SOLVE, tag
+        u = np.concatenate([xs, 0.3 * np.ones((spec.naug, B), np.float32), 0.1 * np.ones((3, B), np.float32)], axis=0).astype(np.float32)
+        du = pkg.augmented_f(icnf, mode, dev(u), dev(p), 0.37, dev(eps), dev(ys)).cpu().numpy()
+        assert np.max(np.abs(du - o64.aug_f(spec, p, u, 0.37, eps, ys)) / (1.0 + np.abs(o64.aug_f(spec, p, u, 0.37, eps, ys)))) < TOL_CALL, tag
+        # generate: the reversed solve from a given state (cnf_integrate_fixed: u0 in, u1 out)
+        gen = pkg.generate(icnf, mode, dev(p), {}, B, z0=dev(out[tag][2][:spec.D]), eps=dev(eps))
+        out[tag] += (gen.cpu().numpy(),)
+    assert np.max(np.abs(out["dealt"][0] - out["extended"][0])) < 5e-5
+    assert np.max(np.abs(out["dealt"][2] - out["extended"][2])) < 5e-5
+    assert np.max(np.abs(out["dealt"][3] - out["extended"][3])) < 5e-5
+
+
+def test_dealt_cooperative_kernel_at_full_size(pkg, oracles, monkeypatch):
+    """ICNF(nvariables = 16) and (nvariables = 24) with every default (two softplus layers of 4 (D + 1), lambdas 0.01), B = 32 768,
+    Tsit5 x 40: the dealt kernel serves it on its own, every column agrees with the extended kernel (summation order only) and a
+    sample of columns with the C restatement; column shards concatenate bit-identically within the kernel."""
+    o64, oc = oracles
+    monkeypatch.delenv("CNF_COOPD", raising=False)
+    for nv, H in ((16, 136), (24, 200)):
+        spec = o64.make_spec(nvars=nv, naug=nv + 1, hidden=[H, H], act=2, reg_z=True, reg_j=True, reg_aug=True)
+        B = 32768
+        p, xs, eps, _ = o64.synth_inputs(spec, B, 7 + nv, bias_scale=0.1)
+        mode = mode_of(pkg, spec)
+        icnf = make_icnf(pkg, spec, 1, 40)
+        assert icnf.kernel_family(mode) == "coopx" and icnf.kernel_family(mode, B=B) == "coopd" and icnf.kernel_family(mode, B=4096) == "coopx"
+        logp, regs = run_inference(pkg, icnf, spec, p, xs, eps, None)
+        logp = logp.cpu().numpy()
+        monkeypatch.setenv("CNF_COOPD", "0")
+        lx, rx = run_inference(pkg, icnf, spec, p, xs, eps, None)
+        monkeypatch.delenv("CNF_COOPD")
+        assert np.max(np.abs(logp - lx.cpu().numpy())) < 1e-4
+        for a_, b_ in zip(regs, rx):
+            assert np.max(np.abs(a_.cpu().numpy() - b_.cpu().numpy())) < 1e-4
+        idx = np.arange(0, B, 257)
+        ref = oc.inference_fixed(spec, p, xs[:, idx], 0.0, 1.0, 40, 1, eps[:, idx], None, nthreads=8)
+        assert np.max(np.abs(logp[idx] - ref[0])) < TOL_SOLVE
+        # two shards, both above the 4096-column threshold: the same kernel, the same bits
+        cut = 12288 + 64 * 3 + 5
+        la = run_inference(pkg, icnf, spec, p, xs[:, :cut], eps[:, :cut], None)[0].cpu().numpy()
+        lb = run_inference(pkg, icnf, spec, p, xs[:, cut:], eps[:, cut:], None)[0].cpu().numpy()
+        assert np.array_equal(np.concatenate([la, lb]), logp)
+
+
+@pytest.mark.parametrize("kw,lam,B,alg,nsteps,grid", [
+    (dict(nvars=16, naug=17, hidden=[136, 136], act=2, reg_z=True, reg_j=True, reg_aug=True), (0.01, 0.01, 0.01), 150, 1, 2, False),
+    (dict(nvars=20, naug=21, hidden=[168, 168], act=2, reg_z=True, reg_j=True, reg_aug=True), (0.01, 0.01, 0.01), 70, 0, 3, False),
+    (dict(nvars=24, naug=25, hidden=[200, 200], act=2, reg_z=True, reg_j=True, reg_aug=True), (0.01, 0.01, 0.01), 80, 1, 2, False),
+    (dict(nvars=18, naug=19, hidden=[152, 152], act=2), (0.0, 0.0, 0.0), 100, 1, 3, True),      # on a non-uniform grid (device-resident step times)
+])
+def test_cooperative_gradient_on_the_dealt_forward_solve(kw, lam, B, alg, nsteps, grid, pkg, oracles, monkeypatch):
+    """The checkpointing forward half of the cooperative gradient on the dealt kernel (z per step, zdot and g = eps^T J per stage in
+    the tile layout and stride the reverse sweep reads): loss, dloss/dps, dloss/dxs against fp64 autograd (CNF_COOPD=2 forces it
+    at this batch size; src/core/icnf.jl:90-99)."""
+    o64, _ = oracles
+    monkeypatch.setenv("CNF_COOPD", "2")
+    spec = o64.make_spec(**kw)
+    p, xs, eps, ys = o64.synth_inputs(spec, B, 77 + B, bias_scale=0.2)
+    mode = mode_of(pkg, spec)
+    icnf = make_icnf(pkg, spec, alg, nsteps, lambdas=lam)
+    tg = None
+    if grid:
+        tg = np.cumsum([0.0, 0.13, 0.31, 0.2, 0.36]).astype(np.float32)
+        tg[-1] = 1.0
+        nsteps = len(tg) - 1
+    L, gref, gxref = o64.loss_and_grad(spec, p, xs, 0.0, 1.0, nsteps, alg, eps, ys, lam, wrt_x=True, tgrid=None if tg is None else [float(v) for v in tg])
+    if grid:
+        import ctypes as C
+        h = icnf._handle(mode)
+        icnf._bind_params(h, dev(p))
+        P = dev(p); icnf._bind_params(h, P)
+        x, e = dev(xs).t().contiguous(), dev(eps).t().contiguous()
+        g = torch.empty(P.numel(), device="cuda"); gx = torch.zeros(B, spec.nvars, device="cuda"); sums = torch.empty(4, device="cuda")
+        pkg._lib.check(h.lib.cnf_loss_grad_grid(h.ptr, alg, nsteps, (C.c_float * len(tg))(*tg), x.data_ptr(), e.data_ptr(), None, B,
+                                                (C.c_float * 3)(*lam), g.data_ptr(), gx.data_ptr(), sums.data_ptr(), None))
+        torch.cuda.synchronize()
+        assert int(h.lib.cnf_grad_path_for(h.ptr, B, alg, 1)) == 3
+        val, g, gx = float(sums[0]) / B, g / B, (gx / B).t()
+    else:
+        val, g, gx = pkg.loss_and_gradient(icnf, mode, dev(xs), dev(p), {}, eps=dev(eps), wrt_x=True)
+        assert icnf.grad_path(mode, B=B, alg=alg) == 3
+    assert abs(float(val) - L) < 1e-4 + 2e-6 * abs(L)
+    assert np.max(np.abs(g.cpu().numpy() - gref)) < 5e-5 * np.abs(gref).max() + 1e-6
+    assert np.max(np.abs(gx.cpu().numpy() - gxref)) < 5e-5 * np.abs(gxref).max() + 1e-7
+
+
 @pytest.mark.parametrize("kw,B,alg,nsteps", GENERIC_MFMA_CASES)
 def test_generic_instances_resolve_to_the_mfma_path(kw, B, alg, nsteps, pkg, oracles):
     o64, _ = oracles
@@ -1081,7 +1202,9 @@ def test_kernel_family_is_reported_by_the_library(pkg, oracles, monkeypatch):
         icnf = make_icnf(pkg, o64.make_spec(**kw), 0, 4, path=path)
         assert icnf.kernel_family(mode) == fam, kw
         assert icnf.kernel_name(mode).startswith(name), icnf.kernel_name(mode)
-        assert icnf.kernel_family(mode, B=65536) == fam
+        # (one-probe VJP solves of the default architecture's shapes leave the extended kernel for the dealt one above 4096 columns)
+        assert icnf.kernel_family(mode, B=65536) == ("coopd" if kw.get("act") == 2 and fam == "coopx" else fam)
+        assert icnf.kernel_family(mode, B=4096) == ("tile_split" if fam == "per_wave" and path == 0 else fam)
     small = make_icnf(pkg, o64.make_spec(nvars=8, hidden=[64, 64, 64]), 0, 4)
     assert small.kernel_family(T, B=4096) == "tile_split" and small.kernel_family(T, B=4097) == "per_wave"
     assert small.kernel_family(T, B=4096, whole_solve=False) == "per_wave"
