@@ -262,3 +262,110 @@ def test_vcabm_restatement_reproduces_its_fixture(oracles):
         assert (st["naccept"], st["nreject"]) == (int(f[f"naccept_{tag}"]), int(f[f"nreject_{tag}"]))
         assert st["orders"] == f[f"orders_{tag}"].tolist()
         assert np.allclose(st["dts"], f[f"dts_{tag}"], rtol=1e-9, atol=0) and np.allclose(u1, f[f"u1_{tag}"], rtol=0, atol=1e-10)
+
+
+# ---- derived, not recalled: what can be computed exactly is, with sympy / rational arithmetic ----
+
+def test_adams_gammas_derived_exactly(oracles):
+    """The Adams-Moulton gamma*_j = int_{-1}^{0} binom(s + j - 1, j) ds and the Adams-Bashforth gamma_j = int_0^1 binom(s + j - 1, j) ds
+    (Hairer-Noersett-Wanner I, III.1) computed by exact polynomial integration, 14 terms - the stepper's order runs to 12 - against
+    the recurrence the restatement uses, and against gamma_j = sum_{m <= j} gamma*_m."""
+    import sympy as sp
+    o64, _ = oracles
+    s = sp.symbols("s")
+    n = 14
+    gstar, gab = [], []
+    for j in range(n):
+        binom = sp.Integer(1)
+        for i in range(j):
+            binom = binom * (s + i) / (i + 1)          # binom(s + j - 1, j) = s (s+1) ... (s+j-1) / j!
+        gstar.append(sp.integrate(sp.expand(binom), (s, -1, 0)))
+        gab.append(sp.integrate(sp.expand(binom), (s, 0, 1)))
+    assert gstar[:5] == [1, sp.Rational(-1, 2), sp.Rational(-1, 12), sp.Rational(-1, 24), sp.Rational(-19, 720)]
+    assert gab[:5] == [1, sp.Rational(1, 2), sp.Rational(5, 12), sp.Rational(3, 8), sp.Rational(251, 720)]
+    got = o64.adams_moulton_gammas(n)
+    assert np.max(np.abs(np.array(got, dtype=np.float64) - np.array([float(g) for g in gstar]))) < 1e-15
+    for j in range(n):                                  # gamma_j = sum_{m=0}^{j} gamma*_m
+        assert sum(gstar[: j + 1]) == gab[j]
+    # with constant steps the variable-coefficient stepper's g_j must be these gamma_j (its predictor is Adams-Bashforth)
+    f = lambda u, t: np.ones_like(u)
+    st = o64.VcabmStepper(f, np.zeros((1, 1)), 0.1, 1.0, 0.0)
+    if hasattr(st, "constant_step_g"):
+        assert np.allclose(st.constant_step_g(8), [float(g) for g in gab[:8]], atol=1e-14)
+
+
+def _rooted_tree_conditions(A, b, c, order):
+    """Order conditions of an explicit Runge-Kutta pair up to `order` (<= 5): list of (name, sum, 1 / gamma(tree))."""
+    A, b, c = np.asarray(A, dtype=np.float64), np.asarray(b, dtype=np.float64), np.asarray(c, dtype=np.float64)
+    Ac, Ac2, Ac3, AAc = A @ c, A @ c ** 2, A @ c ** 3, A @ (A @ c)
+    conds = [("b 1", b.sum(), 1.0)]
+    if order >= 2: conds += [("b c", b @ c, 1 / 2)]
+    if order >= 3: conds += [("b c^2", b @ c ** 2, 1 / 3), ("b A c", b @ Ac, 1 / 6)]
+    if order >= 4:
+        conds += [("b c^3", b @ c ** 3, 1 / 4), ("b c.Ac", b @ (c * Ac), 1 / 8), ("b A c^2", b @ Ac2, 1 / 12), ("b A A c", b @ AAc, 1 / 24)]
+    if order >= 5:
+        conds += [("b c^4", b @ c ** 4, 1 / 5), ("b c^2.Ac", b @ (c ** 2 * Ac), 1 / 10), ("b c.Ac^2", b @ (c * Ac2), 1 / 15),
+                  ("b c.AAc", b @ (c * AAc), 1 / 30), ("b (Ac)^2", b @ (Ac * Ac), 1 / 20), ("b A c^3", b @ Ac3, 1 / 20),
+                  ("b A(c.Ac)", b @ (A @ (c * Ac)), 1 / 40), ("b A A c^2", b @ (A @ Ac2), 1 / 60), ("b A A A c", b @ (A @ AAc), 1 / 120)]
+    return conds
+
+
+def test_tsit5_pair_satisfies_its_order_conditions(oracles):
+    """Tsitouras' 5(4) pair as the oracle (and the kernels, csrc/cnf_common.h) carry it: the 7-stage FSAL tableau satisfies all 17
+    rooted-tree conditions of order 5 with its weights b, the embedded weights b - btilde satisfy the 8 conditions of order 4 and
+    VIOLATE order 5 (so dt sum btilde_i k_i is an O(dt^5) error estimate, not zero), sum btilde = 0 and the row sums equal c.
+    The constants are decimal literals of the published tableau, so 'satisfies' means to a few ulp of 1 - this pins every digit
+    of btilde, which the restatement recalled from memory."""
+    o64, _ = oracles
+    c6, a6, b6, bt = o64.TSIT5_C, o64.TSIT5_A, o64.TSIT5_B, o64.TSIT5_BTILDE
+    assert len(bt) == 7
+    A = np.zeros((7, 7))
+    for i, row in enumerate(a6):
+        A[i, : len(row)] = row
+    A[6, :6] = b6                                         # first-same-as-last: stage 7 = f(u_new)
+    c = np.array(list(c6) + [1.0])
+    b = np.array(list(b6) + [0.0])
+    assert np.max(np.abs(A.sum(1) - c)) < 5e-15
+    for name, got, want in _rooted_tree_conditions(A, b, c, 5):
+        assert abs(got - want) < 5e-15, (name, got, want)
+    bhat = b - np.array(bt)
+    assert abs(np.sum(bt)) < 5e-16
+    for name, got, want in _rooted_tree_conditions(A, bhat, c, 4):
+        assert abs(got - want) < 5e-15, ("embedded", name, got, want)
+    viol = max(abs(got - want) for name, got, want in _rooted_tree_conditions(A, bhat, c, 5)[8:])
+    assert viol > 1e-4, viol                              # genuinely 4th order
+    # classical RK4 for completeness
+    cr, ar, br = o64.RK4_C, o64.RK4_A, o64.RK4_B
+    Ar = np.zeros((4, 4))
+    for i, row in enumerate(ar):
+        Ar[i, : len(row)] = row
+    for name, got, want in _rooted_tree_conditions(Ar, br, cr, 4):
+        assert abs(got - want) < 1e-15, (name, got, want)
+
+
+def test_tanh_fast_departure_is_measured(oracles):
+    """Lux runs NNlib.tanh_fast on CPU Float32 arrays where the kernels (and the parity oracle) evaluate tanh itself.  The rational
+    approximation is restated in oracle/cnf_oracle.c (cnf_oracle_set_fast_tanh); here its departure is a NUMBER: max |tanh_fast - tanh|
+    over a dense grid, and max |delta logp| over 4096 columns of BASELINE config 2 (D = 8, 3 x 64, RK4 x 40) - far inside the 1e-4
+    log-density tolerance (DESIGN.md section 2 quotes both)."""
+    o64, oc = oracles
+    spec = o64.make_spec(8, [64, 64, 64])
+    B = 4096
+    p, xs, eps, _ = o64.synth_inputs(spec, B, 20240612)
+    oc.set_fast_tanh(False)
+    exact = oc.inference_fixed(spec, p, xs, 0.0, 1.0, 40, o64.ALG_RK4, eps, None, nthreads=8)[0]
+    oc.set_fast_tanh(True)
+    try:
+        fast = oc.inference_fixed(spec, p, xs, 0.0, 1.0, 40, o64.ALG_RK4, eps, None, nthreads=8)[0]
+    finally:
+        oc.set_fast_tanh(False)
+    dlogp = float(np.max(np.abs(fast - exact)))
+    x = np.linspace(-9.0, 9.0, 2_000_001)
+    x2 = (x.astype(np.float32) ** 2).astype(np.float64)
+    n = 1.0 + x2 * (0.1346604 + x2 * (0.0035974074 + x2 * (2.2332108e-5 + x2 * 1.587199e-8)))
+    d = 1.0 + x2 * (0.4679937 + x2 * (0.026262015 + x2 * (0.0003453992 + x2 * 8.7767893e-7)))
+    approx = np.where(x2 < 66.0, x * n / d, np.sign(x))
+    dtanh = float(np.max(np.abs(approx - np.tanh(x))))
+    print(f"tanh_fast: max|tanh_fast - tanh| = {dtanh:.3e}; cfg2 (4096 columns, RK4 x 40): max|dlogp| = {dlogp:.3e}")
+    assert dtanh < 5e-7
+    assert 0.0 < dlogp < 2e-5
