@@ -187,7 +187,11 @@ coop_grad_step_kernel(CGArgs a) {
         typedef float __attribute__((may_alias)) float_a;
         const float_a* xb = reinterpret_cast<const float_a*>(xbuf + buf * XB);
         if constexpr (GS) {
-            const int s8 = lane >> 3, mm = (lane >> 2) & 1, gg = lane & 3;
+            // ds_read_b32 banks are (word % 32) per 32-lane half: a half's lanes hold 4 samples x 2 row tiles x 4 row quads, and two
+            // row tiles are a multiple of 32 words apart - the lanes of the second row tile therefore take the samples 4 further
+            // on (s8 ^ 4: banks + 16), which made 2-way conflicts of every one of these reads (22 % of the kernel's LDS cycles,
+            // profiles/r3/r3T_cfg4_grad_pmc_summary.txt); the store offsets vox / voy follow the same assignment
+            const int mm = (lane >> 2) & 1, gg = lane & 3, s8 = (lane >> 3) ^ (4 * mm);
 #pragma unroll
             for (int m = 0; m < MTW; m += 2)
 #pragma unroll
@@ -308,7 +312,7 @@ coop_grad_step_kernel(CGArgs a) {
         for (int q = 0; q < NT; ++q) {
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf) {
-                const long long sq = GS ? smp0 + q * 16 + (lane >> 3) + 8 * hf : smp0 + q * 16 + n;
+                const long long sq = GS ? smp0 + q * 16 + ((lane >> 3) ^ (4 * ((lane >> 2) & 1))) + 8 * hf : smp0 + q * 16 + n;
                 const unsigned ro = GS ? 16u * (unsigned)(lane & 3) + 64u * (unsigned)((lane >> 2) & 1) : 16u * (unsigned)g;
                 vox[q][hf] = sq < B ? (unsigned)sq * ldx + ro : 0xffffffffu;
                 voy[q][hf] = sq < B ? (unsigned)sq * ldy + ro : 0xffffffffu;
