@@ -109,7 +109,7 @@ static int ensure_kbuf(cnf_handle* h, int64_t B) {
 // to the SIMT kernels instead
 static int64_t layered_min_batch() {
     const char* e = getenv("CNF_LAYERED_MIN_B");
-    return (e && *e) ? atoll(e) : 0;   // measured: the GEMM path wins at every batch size (profiles/r1h_generic_small.json)
+    return (e && *e) ? atoll(e) : 0;   // measured: the GEMM path wins at every batch size (profiles/archive/r1h_generic_small.json)
 }
 
 extern "C" {
