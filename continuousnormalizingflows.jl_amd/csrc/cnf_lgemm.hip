@@ -516,7 +516,7 @@ struct LgWgradArgs {
 // that ONE lane-linear ds_read_b128 hands a lane its B operands of all four k-steps of a tile (sample 4 u + g, row 16 t + n).
 // (Reading the operands straight from global memory made every wave fetch all of Y: 670 MB of L2 traffic per call at cfg4.)
 template <int NTN>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NTN >= 9 ? 2 : 3, 3)))
 lg_wgrad_kernel(LgWgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int RY = (NTN * 16 + 63) / 64;                     // loads per lane per sample for the Y slice
