@@ -42,6 +42,7 @@ struct DImg {
     int KGZ, remZ;    // real state k-groups and k-steps of the last one
     int xalias;       // the partial tiles alias the exchange buffer (LDS is short): one more barrier per D-row product
     int ckzr;         // floats per lane of the checkpoint arrays (the plan's ZR: what the reverse sweep strides by)
+    int q_off;        // exact-trace instances: float offset of the Q image (two hidden layers: tr J = act'_2^T Q act'_1), else 0
     int cvn;          // floats of the C-vector section [v_b1, end of v_bN) of the image: staged into LDS once per workgroup
 };
 struct DArgs {
@@ -551,6 +552,163 @@ __device__ __forceinline__ void coopd_eval(const DRs& R, const float* __restrict
     //  pbuf is rewritten only behind the next evaluation's own barriers)
 }
 
+// One dynamics evaluation in TestMode (exact trace) for a two-hidden-layer flow - the reference's default architecture
+// (src/core/icnf.jl:297-339, src/core/utils.jl:79-88): ldot = -tr J with tr J = act'_2^T Q act'_1 and the constant
+// Q = W_2 .* (W_1[:,0:D] W_3)^T packed behind the operand images (cnf_mfma.hip: mfma_pack), i.e. the forward chain, ONE more H x H
+// product whose B operand is act'_1, and a dot - no pullback, no probe.  Same dealing as coopd_eval: every wave computes its
+// units of Q act'_1, multiplies them by its own act'_2 and sums over its features; the four waves' partial traces of a sample
+// tile meet in LDS.  The exact-trace dynamics carry no regularisers (Edot = ndot = 0).
+template <int A, int ZR, int ACT>
+__device__ __forceinline__ void coopd_eval_exact(const DRs& R, const float* __restrict__ CV, const DImg& Gin, f32x4* __restrict__ xbuf,
+                                                 f32x4* __restrict__ zbuf, f32x4* __restrict__ pbuf, float* __restrict__ red,
+                                                 int lane, int wave, float t, bool autonomous, const float (&zs)[ZR], float (&zd)[ZR],
+                                                 float& ld, f32x4 (&aS)[A], f32x4 (&aR)[3]) {
+    constexpr int DT = ZR / 4;
+    int opq = 0;
+    asm volatile("" : "+s"(opq));
+    DImg G = Gin;
+    G.f1z += opq; G.fh += opq; G.fN += opq; G.q_off += opq;
+    const float* __restrict__ P = CV - G.v_b1;
+    const int g = lane >> 4;
+    const int b = G.b;
+    const int mtS0 = wave * A, mtR0 = 4 * A, mtRmax = 4 * A + b - 1;
+    const unsigned F1Z = (unsigned)G.f1z * 4u, FH = (unsigned)G.fh * 4u, FN = (unsigned)G.fN * 4u, QI = (unsigned)G.q_off * 4u;
+    UAcc<A> acc, h, d1p, a2p;   // d1p: act'_1, a2p: the second layer's pre-activations of this wave's units - parked
+    const TileOff<A> TZ = tile_offsets<A>(R, G.KPZ, mtS0, mtR0, mtRmax);
+    const TileOff<A> TH = tile_offsets<A>(R, G.HTP, mtS0, mtR0, mtRmax);
+    unsigned vd[DT];
+#pragma unroll
+    for (int dm = 0; dm < DT; ++dm) { vd[dm] = R.lane16 + (unsigned)(dm * G.HTP) * 1024u; asm volatile("" : "+v"(vd[dm])); }
+    auto cvec_units = [&](const float* __restrict__ vec, f32x4 (&vS)[A], f32x4 (&vR)[3]) {
+#pragma unroll
+        for (int m = 0; m < A; ++m) vS[m] = *reinterpret_cast<const f32x4*>(vec + ((mtS0 + m) * 4 + g) * 4);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int mt = mtR0 + r < mtRmax ? mtR0 + r : mtRmax;
+            vR[r] = *reinterpret_cast<const f32x4*>(vec + (mt * 4 + g) * 4);
+        }
+    };
+    auto publish = [&](const UAcc<A>& v) {
+#pragma unroll
+        for (int m = 0; m < A; ++m)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) xbuf[((mtS0 + m) * 4 + q) * 64 + lane] = v.S[m][q];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+            if (r < b) xbuf[((mtR0 + r) * 4 + wave) * 64 + lane] = v.R[r];
+    };
+    // ---- layer 1 ----
+    {
+        f32x4 bS[A], bR[3], wS[A], wR[3];
+        cvec_units(P + G.v_b1, bS, bR);
+        cvec_units(P + G.v_w1t, wS, wR);
+#pragma unroll
+        for (int kg = 0; kg < DT; ++kg) {
+            f32x4 v;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = zs[4 * kg + j];
+            zbuf[(kg * 4 + wave) * 64 + lane] = v;
+        }
+        if (!autonomous) {
+#pragma unroll
+            for (int m = 0; m < A; ++m) bS[m] = tile_fma(wS[m], t, bS[m]);
+#pragma unroll
+            for (int r = 0; r < 3; ++r) bR[r] = tile_fma(wR[r], t, bR[r]);
+        }
+        uacc_fill<A>(acc, bS, bR);
+        __syncthreads();
+        dealt_gemm<A>(R, TZ, F1Z, G.KGZ, G.remZ, b, zbuf, wave, lane, aS, aR, acc);
+    }
+    // ---- hidden layer 1: publish h_1; act'_1 waits (parked) for the exchange buffer ----
+    dealt_load_a<A>(R, TH, FH, 0, aS, aR);
+#pragma unroll
+    for (int m = 0; m < A; ++m)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 dd;
+            act_pair<ACT>(acc.S[m][q], h.S[m][q], dd);
+            d1p.S[m][q] = park4(dd);
+        }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        f32x4 dd;
+        act_pair<ACT>(acc.R[r], h.R[r], dd);
+        d1p.R[r] = park4(dd);
+    }
+    publish(h);
+    {
+        f32x4 bS[A], bR[3];
+        cvec_units(P + G.v_bh, bS, bR);
+        uacc_fill<A>(acc, bS, bR);
+    }
+    __syncthreads();
+    dealt_gemm<A>(R, TH, FH, G.KGH, G.remH, b, xbuf, wave, lane, aS, aR, acc);   // a_2 = W_2 h_1 + b_2
+    // ---- Q act'_1 FIRST (act'_1 as the B image), the pre-activations a_2 parked meanwhile: the trace then meets act'_2 the
+    //      moment it is computed, and neither act' has to outlive a product ----
+    dealt_load_a<A>(R, TH, QI, 0, aS, aR);
+#pragma unroll
+    for (int m = 0; m < A; ++m)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { a2p.S[m][q] = park4(acc.S[m][q]); h.S[m][q] = unpark4(d1p.S[m][q]); }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) { a2p.R[r] = park4(acc.R[r]); h.R[r] = unpark4(d1p.R[r]); }
+    __syncthreads();   // every wave is done reading h_1
+    publish(h);
+    uacc_zero<A>(acc);
+    __syncthreads();
+    dealt_gemm<A>(R, TH, QI, G.KGH, G.remH, b, xbuf, wave, lane, aS, aR, acc);   // Q act'_1
+    // ---- hidden layer 2: h_2 feeds zdot from registers; act'_2 meets Q act'_1 ----
+    f32x4 part[DT][4], own[DT], fd[DT];
+    dealt_drow_first<DT>(R, vd, FN, mtS0, fd);
+    float tr[4], trown = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) tr[q] = 0.f;
+#pragma unroll
+    for (int m = 0; m < A; ++m)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 dd;
+            act_pair<ACT>(unpark4(a2p.S[m][q]), h.S[m][q], dd);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) tr[q] = fmaf(acc.S[m][q][r], dd[r], tr[q]);
+        }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        f32x4 dd;
+        act_pair<ACT>(unpark4(a2p.R[r]), h.R[r], dd);
+        if (r < b) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) trown = fmaf(acc.R[r][j], dd[j], trown);
+        }
+    }
+    dealt_drow<A, DT>(R, vd, FN, mtS0, mtR0, G.KGH, G.remH, b, h, fd, part, own);
+    dealt_load_a<A>(R, TZ, F1Z, 0, aS, aR);   // the next evaluation's layer-1 fragments
+    if (G.xalias) __syncthreads();            // the partial tiles share the exchange buffer: the Q product's readers are done
+#pragma unroll
+    for (int dm = 0; dm < DT; ++dm)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) pbuf[((wave * DT + dm) * 4 + q) * 64 + lane] = part[dm][q];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) red[(wave * 4 + q) * 64 + lane] = group_sum(tr[q]);
+    trown = group_sum(trown);
+    __syncthreads();
+    {
+        f32x4 zacc[DT];
+#pragma unroll
+        for (int dm = 0; dm < DT; ++dm) {
+            zacc[dm] = *reinterpret_cast<const f32x4*>(P + G.v_bN + (dm * 4 + g) * 4);
+#pragma unroll
+            for (int w = 0; w < 4; ++w) zacc[dm] += pbuf[((w * DT + dm) * 4 + wave) * 64 + lane];
+            zacc[dm] += own[dm];
+        }
+#pragma unroll
+        for (int s = 0; s < ZR; ++s) zd[s] = zacc[s >> 2][s & 3];
+        ld = -(((red[(0 * 4 + wave) * 64 + lane] + red[(1 * 4 + wave) * 64 + lane]) + red[(2 * 4 + wave) * 64 + lane]) +
+               red[(3 * 4 + wave) * 64 + lane] + trown);
+    }
+    // (xalias: the next evaluation's first write into the exchange buffer - h_1 - comes behind two barriers)
+}
+
 // once per super-tile: c = W_N^T eps of this wave's units (B operand: the probe image ebuf, published and fenced by the caller),
 // parked; and the first evaluation's layer-1 fragments
 template <int A, int ZR>
@@ -579,9 +737,11 @@ constexpr int coopd_lds_bytes(int HT, int L, int DT, bool alias, int cvn) {
 // and the step sum - six rows of ZR registers, touched once per stage - are parked in accumulation registers (see park): the
 // same fma chains in the same order, so the numbers are the same; 72 - 96 of the 256 architectural registers stay free for the
 // 4 A + b accumulator tiles and two fragment sets of the k-loops.
-template <int A, int L, int ZR, int ACT>
+// MODE 0: one Hutchinson probe, VJP (TrainMode); 1: exact trace through the Q product (TestMode, two hidden layers)
+template <int A, int L, int ZR, int ACT, int MODE>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 coopd_solve_kernel(DArgs da) {
+    static_assert(MODE == 0 || L == 2, "the exact-trace form is the two-hidden-layer Q product");
     const KArgs& a = da.k;
     const DImg& G = da.g;
     constexpr int DT = ZR / 4;
@@ -618,15 +778,21 @@ coopd_solve_kernel(DArgs da) {
                 if (a.x) zs[s] = f < a.nvars ? a.x[sc * a.nvars + f] : 0.f;
                 else zs[s] = f < D ? a.u0[sc * S + f] : 0.f;
                 zp[s] = park(zs[s]);
-                v[j] = f < D ? a.eps[sc * D + f] : 0.f;
+                v[j] = (MODE == 0 && f < D) ? a.eps[sc * D + f] : 0.f;
             }
-            ebuf[(kg * 4 + wave) * 64 + lane] = v;   // the probe of this wave's sample tile as a B image, for the whole solve
+            if constexpr (MODE == 0) ebuf[(kg * 4 + wave) * 64 + lane] = v;   // the probe of this wave's sample tile as a B image, for the whole solve
         }
         if (!a.x) { lacc = a.u0[sc * S + D]; eacc = a.u0[sc * S + D + 1]; nacc = a.u0[sc * S + D + 2]; }
-        __syncthreads();
         UAcc<A> cP;
         f32x4 aS[A], aR[3];
-        coopd_hoist_c<A, ZR>(R, G, ebuf, lane, wave, cP, aS, aR);
+        if constexpr (MODE == 0) {
+            __syncthreads();
+            coopd_hoist_c<A, ZR>(R, G, ebuf, lane, wave, cP, aS, aR);
+        } else {
+            const int b_ = G.b;
+            const TileOff<A> TZ = tile_offsets<A>(R, G.KPZ, wave * A, 4 * A, 4 * A + b_ - 1);
+            dealt_load_a<A>(R, TZ, (unsigned)G.f1z * 4u, 0, aS, aR);
+        }
 
         float zd[ZR], ld = 0.f, ed = 0.f, nd = 0.f;
         const float dt0 = a.dt;
@@ -651,8 +817,12 @@ coopd_solve_kernel(DArgs da) {
             for (int sg = 0; sg < ns; ++sg) {
                 const long long ckrow = ((((long long)step * ns + sg) * ckntp + cktile) * 64 + lane) * ckzr;
                 float* gout = (a.ckpt_g && !single) ? a.ckpt_g + ckrow : nullptr;
-                coopd_eval<A, L, ZR, ACT>(R, cbuf, G, xbuf, XB, zbuf, ebuf, pbuf, lane, wave, tn + a.T.c[sg] * dt, autonomous, reg_z, reg_j,
-                                          zs, zd, ld, ed, nd, gout, cP, aS, aR);
+                if constexpr (MODE == 0)
+                    coopd_eval<A, L, ZR, ACT>(R, cbuf, G, xbuf, XB, zbuf, ebuf, pbuf, lane, wave, tn + a.T.c[sg] * dt, autonomous, reg_z, reg_j,
+                                              zs, zd, ld, ed, nd, gout, cP, aS, aR);
+                else
+                    coopd_eval_exact<A, ZR, ACT>(R, cbuf, G, xbuf, zbuf, pbuf, reinterpret_cast<float*>(ebuf), lane, wave, tn + a.T.c[sg] * dt,
+                                                 autonomous, zs, zd, ld, aS, aR);   // (the probe image's LDS holds the partial traces)
                 if (gout)
                     for (int s = ZR; s < ckzr; ++s) gout[s] = 0.f;
                 if (a.ckpt_k && !single) {
@@ -735,9 +905,9 @@ coopd_solve_kernel(DArgs da) {
 // ---------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------
-template <int A, int L, int ZR, int ACT>
+template <int A, int L, int ZR, int ACT, int MODE>
 static hipError_t launch_coopd(const DArgs& a, int lds, int nblocks, hipStream_t st) {
-    auto kern = coopd_solve_kernel<A, L, ZR, ACT>;
+    auto kern = coopd_solve_kernel<A, L, ZR, ACT, MODE>;
     static DeviceOnce once;
     int dev = 0;
     hipError_t e0 = hipGetDevice(&dev);
@@ -752,32 +922,34 @@ static hipError_t launch_coopd(const DArgs& a, int lds, int nblocks, hipStream_t
 }
 
 struct CoopDInst {
-    int A, L, ZR, ACT;
+    int A, L, ZR, ACT, MODE;
     hipError_t (*fn)(const DArgs&, int, int, hipStream_t);
 };
-#define CD_INST(A, L, ZR, ACT) CoopDInst { A, L, ZR, ACT, &launch_coopd<A, L, ZR, ACT> }
+#define CD_INST(A, L, ZR, ACT) CoopDInst { A, L, ZR, ACT, 0, &launch_coopd<A, L, ZR, ACT, 0> }
+#define CD_EXACT(A, ZR, ACT) CoopDInst { A, 2, ZR, ACT, 1, &launch_coopd<A, 2, ZR, ACT, 1> }
 // (A, ZR) pairs of the reference's default architecture H = 4 (D + 1): D <= 48 with 9 .. 12 hidden tiles (nvariables 16 .. 23),
 // D <= 64 with 13 .. 16 (nvariables 24 .. 31); the same pairs serve any flow of those sizes
 #define CD_SHAPES(L, ACT) CD_INST(2, L, 12, ACT), CD_INST(3, L, 12, ACT), CD_INST(3, L, 16, ACT)
 static const CoopDInst kCoopD[] = {
     CD_SHAPES(2, CNF_ACT_SOFTPLUS),
+    CD_EXACT(2, 12, CNF_ACT_SOFTPLUS), CD_EXACT(3, 12, CNF_ACT_SOFTPLUS),   // TestMode of the same flows up to D = 48 (the 16-state-register form does not fit the accumulation registers)
 };
 
-static const CoopDInst* cd_find(int HT_real, int L, int KZ, int ACT) {
+static const CoopDInst* cd_find(int HT_real, int L, int KZ, int ACT, int MODE) {
     const int A = HT_real / 4;
     const CoopDInst* best = nullptr;
     for (const CoopDInst& c : kCoopD) {
         const bool act_ok = c.ACT == ACT || (c.ACT == CNF_ACT_TANH_PRESCALED && ACT == CNF_ACT_TANH);
-        if (c.A == A && c.L == L && c.ZR >= KZ && act_ok && (!best || c.ZR < best->ZR)) best = &c;
+        if (c.A == A && c.L == L && c.MODE == MODE && c.ZR >= KZ && act_ok && (!best || c.ZR < best->ZR)) best = &c;
     }
     return best;
 }
 
 // H = widest hidden layer, D = state rows of the configuration; (HT, ZR) = the plan's layout
-bool coopd_supported(int H, int D, int L, int ACT, int HT_lay, int ZR_lay) {
+bool coopd_supported(int H, int D, int L, int ACT, int HT_lay, int ZR_lay, int exact) {
     const int HT_real = (H + 15) / 16, KZ = (D + 3) / 4;
     if (HT_real < 8 || HT_real > HT_lay || KZ > ZR_lay) return false;
-    const CoopDInst* c = cd_find(HT_real, L, KZ, ACT);
+    const CoopDInst* c = cd_find(HT_real, L, KZ, ACT, exact ? 1 : 0);
     if (!c) return false;
     // state registers beyond the plan's k-steps would read image k-groups that do not exist
     if ((c->ZR + 3) / 4 > (ZR_lay + 3) / 4) return false;
@@ -786,7 +958,9 @@ bool coopd_supported(int H, int D, int L, int ACT, int HT_lay, int ZR_lay) {
 
 hipError_t coopd_launch(int H, int D, int L, int ACT, int HT_lay, int ZR_lay, const KArgs& k, int num_cus, hipStream_t st) {
     const int HT_real = (H + 15) / 16, KZ = (D + 3) / 4;
-    const CoopDInst* c = cd_find(HT_real, L, KZ, ACT);
+    const bool exact = k.exact == 1;
+    if (exact && k.q_off <= 0) return hipErrorNotSupported;
+    const CoopDInst* c = cd_find(HT_real, L, KZ, ACT, exact ? 1 : 0);
     if (!c) return hipErrorNotSupported;
     const MfmaLayout Y(HT_lay, L, ZR_lay, 0, true);
     DArgs a{};
@@ -800,6 +974,7 @@ hipError_t coopd_launch(int H, int D, int L, int ACT, int HT_lay, int ZR_lay, co
     G.KGH = HT_real; G.remH = ksH - 4 * (HT_real - 1);
     G.KGZ = (KZ + 3) / 4; G.remZ = KZ - 4 * (G.KGZ - 1);
     G.ckzr = ZR_lay;
+    G.q_off = exact ? k.q_off : 0;
     const int DT = c->ZR / 4;
     G.cvn = Y.v_bN + MfmaLayout::vecC(Y.DT) - Y.v_b1;
     G.xalias = coopd_lds_bytes(HT_real, L, DT, false, G.cvn) <= 160 * 1024 ? 0 : 1;

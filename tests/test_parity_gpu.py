@@ -186,6 +186,11 @@ COOPD_CASES = [
     (dict(nvars=29, naug=30, hidden=[240, 240], act=2, reg_z=True, reg_aug=True, autonomous=True), 70, 1, 4),   # nvariables = 29: 15 tiles (b = 3), D = 59, no time column
     (dict(nvars=35, hidden=[150, 230], act=2, reg_z=True, reg_j=True), 45, 1, 4),                             # unequal widths (padded to the widest), D = 35
     (dict(nvars=30, naug=3, hidden=[132, 132], act=2, reg_j=True), 1, 0, 3),                                  # one column
+    # TestMode (exact trace) of the same flows: tr J = act'_2^T Q act'_1, one more H x H product instead of the pullback
+    (dict(nvars=16, naug=17, hidden=[136, 136], act=2, mode=2), 150, 1, 5),                                   # ICNF(nvariables = 16), TestMode
+    (dict(nvars=19, naug=20, hidden=[160, 160], act=2, mode=2), 70, 0, 5),                                    # 10 tiles (b = 2), RK4
+    (dict(nvars=22, naug=23, hidden=[184, 184], act=2, mode=2, autonomous=True), 90, 1, 4),                   # 12 tiles: A = 3; no time column
+    (dict(nvars=40, hidden=[176, 176], act=2, mode=2), 33, 0, 4),                                             # 11 tiles (b = 3), D = 40
 ]
 
 
@@ -214,7 +219,7 @@ def test_dealt_cooperative_kernel_matches_the_oracles(kw, B, alg, nsteps, pkg, o
         du = pkg.augmented_f(icnf, mode, dev(u), dev(p), 0.37, dev(eps), dev(ys)).cpu().numpy()
         assert np.max(np.abs(du - o64.aug_f(spec, p, u, 0.37, eps, ys)) / (1.0 + np.abs(o64.aug_f(spec, p, u, 0.37, eps, ys)))) < TOL_CALL, tag
         # generate: the reversed solve from a given state (cnf_integrate_fixed: u0 in, u1 out)
-        gen = pkg.generate(icnf, mode, dev(p), {}, B, z0=dev(out[tag][2][:spec.D]), eps=dev(eps))
+        gen = pkg.generate(icnf, mode, dev(p), {}, B, z0=dev(out[tag][2][:spec.D]), eps=dev(eps)) if spec.mode == 0 else dev(xs)
         out[tag] += (gen.cpu().numpy(),)
     assert np.max(np.abs(out["dealt"][0] - out["extended"][0])) < 5e-5
     assert np.max(np.abs(out["dealt"][2] - out["extended"][2])) < 5e-5
