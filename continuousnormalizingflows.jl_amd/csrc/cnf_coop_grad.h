@@ -41,14 +41,15 @@ constexpr int coop_grad_lds_bytes(int HT, int ZR, int NT, int CR = 0) {   // (+ 
     return (2 * HT * 2 * NT * 64 + (2 * ((ZR + 3) / 4) * 2 * NT + ((ZR + 3) / 4) * NT + ((CR + 3) / 4) * NT) * 64) * 16;
 }
 struct CoopGradInst {
-    int HT, L, ZR, CR, ACT;
+    int HT, L, ZR, CR, ACT, NT;
     hipError_t (*fn[2])(const CGArgs&, int, hipStream_t);   // [0] RK4 (4 stages), [1] Tsit5 (6 stages)
 };
 const CoopGradInst* coop_grad_table_tanh(int* n);       // cnf_coop_grad.hip
 const CoopGradInst* coop_grad_table_softplus(int* n);   // cnf_coop_grad_softplus.hip
 bool coop_grad_supported(int HT, int L, int ZR, int CR, int ACT);
 int coop_grad_scratch_slots(int L);   // one chain's tile set ([HT] tiles) each, per workgroup
-int coop_grad_nblocks(long long B, int num_cus, int HT, int ZR, int CR = 0);   // workgroups of a launch (each owns `scratch_stride` floats of scratch)
+int coop_grad_nblocks(long long B, int num_cus, int HT, int ZR, int CR = 0, int NT = 1);
+int coop_grad_nt(int HT, int L, int ZR, int CR, int ACT);   // sample tiles per super-tile of the instance that serves the shape   // workgroups of a launch (each owns `scratch_stride` floats of scratch)
 hipError_t coop_grad_step_launch(int HT, int L, int ZR, int CR, int ACT, const CGArgs& a, int num_cus, hipStream_t st);
 // the cooperative forward solve with step / stage checkpoints in tile layout (cnf_coop.hip)
 bool coop_ckpt_supported(int HT, int L, int ZR, int ACT);

@@ -602,7 +602,7 @@ template <int HT, int L, int ZR, int CR, int ACT, int NS, int NT>
 static hipError_t launch_grad_step(const CGArgs& a, int num_cus, hipStream_t st) {
     constexpr int lds = coop_grad_lds_bytes(HT, ZR, NT, CR);
     static_assert(lds <= 160 * 1024, "exchange buffers exceed LDS");
-    const int nblocks = coop_grad_nblocks(a.B, num_cus, HT, ZR, CR);
+    const int nblocks = coop_grad_nblocks(a.B, num_cus, HT, ZR, CR, NT);
     auto kern = coop_grad_step_kernel<HT, L, ZR, CR, ACT, NS, NT>;
     static DeviceOnce once;
     int dev = 0;
@@ -618,7 +618,9 @@ static hipError_t launch_grad_step(const CGArgs& a, int num_cus, hipStream_t st)
 }
 
 #define CG_INSTC(HT, L, ZR, CR) \
-    CoopGradInst { HT, L, ZR, CR, CG_ACT, { &launch_grad_step<HT, L, ZR, CR, CG_ACT, 4, 1>, &launch_grad_step<HT, L, ZR, CR, CG_ACT, 6, 1> } }
+    CoopGradInst { HT, L, ZR, CR, CG_ACT, 1, { &launch_grad_step<HT, L, ZR, CR, CG_ACT, 4, 1>, &launch_grad_step<HT, L, ZR, CR, CG_ACT, 6, 1> } }
+// (NT = 2 - 32-sample super-tiles, one workgroup per CU, each weight fragment feeding four column tiles - was measured on the
+// default architecture at nvariables = 16 / 20: 66.6 / 75.2 ms against 66.0 / 74.5 ms with NT = 1; not instantiated)
 #define CG_INST(HT, L, ZR) CG_INSTC(HT, L, ZR, 0)
 // the (HT, L, ZR) of the forward plans they pair with (the plan's packed image is shared): cnf_coop.hip's instances and the
 // unconditioned shapes of cnf_coop_x.hip (hidden tiles 8 / 12 / 16, 8 or 16 state k-steps)
@@ -647,13 +649,17 @@ static const CoopGradInst* cg_find(int HT, int L, int ZR, int CR, int ACT) {
         if (t[i].HT == HT && t[i].L == L && t[i].ZR == ZR && t[i].CR == CR) return &t[i];
     return nullptr;
 }
+int coop_grad_nt(int HT, int L, int ZR, int CR, int ACT) {
+    const CoopGradInst* c = cg_find(HT, L, ZR, CR, ACT);
+    return c ? c->NT : 1;
+}
 
 bool coop_grad_supported(int HT, int L, int ZR, int CR, int ACT) { return cg_find(HT, L, ZR, CR, ACT) != nullptr; }
 int coop_grad_scratch_slots(int L) { return 2 * L - 3; }   // h_1 .. h_{L-1}, dbar_2 .. dbar_{L-1}
 // workgroups of a launch (16-sample super-tiles; two workgroups per CU where two sets of exchange buffers fit): the host sizes
 // the per-workgroup scratch with it
-int coop_grad_nblocks(long long B, int num_cus, int HT, int ZR, int CR) {
-    const long long nst = (B + 15) / 16, cap = (long long)num_cus * (2 * coop_grad_lds_bytes(HT, ZR, 1, CR) <= 160 * 1024 ? 2 : 1);
+int coop_grad_nblocks(long long B, int num_cus, int HT, int ZR, int CR, int NT) {
+    const long long nst = (B + 16 * NT - 1) / (16 * NT), cap = (long long)num_cus * (2 * coop_grad_lds_bytes(HT, ZR, NT, CR) <= 160 * 1024 ? 2 : 1);
     return (int)(nst < cap ? nst : cap);
 }
 

@@ -1035,9 +1035,10 @@ hipError_t coop_grad(LayeredGrad** ctx, const cnf_config& c, MfmaPlan* plan, con
     const int nslabN = lg_wgrad_chunks(D, B2, G.num_cus, &kcN, 4, H + 1);
     const long long szN = (long long)D * (H + 1), szN_pad = (szN + 63) / 64 * 64;
     const long long ntp = mfma_plan_ckpt_tiles(plan, B, tgrid != nullptr);
-    const int nblocks = coop_grad_nblocks(B, G.num_cus, HT, ZR, CR);
+    const int cg_nt = coop_grad_nt(HT, Lh, ZR, CR, ACT);   // sample tiles per super-tile of the sweep instance
+    const int nblocks = coop_grad_nblocks(B, G.num_cus, HT, ZR, CR, cg_nt);
     const int slots = coop_grad_scratch_slots(Lh);
-    const long long scratch_stride = (long long)(slots > 0 ? slots : 1) * HT * 256;   // slots x (HT tiles x 64 lanes x 4) floats
+    const long long scratch_stride = (long long)(slots > 0 ? slots : 1) * HT * 256 * cg_nt;   // slots x (HT tiles x NT sample tiles x 64 lanes x 4) floats
 
     long long off = 0;
     auto take = [&](long long n) { const long long o = off; off += (n + 63) / 64 * 64; return o; };
