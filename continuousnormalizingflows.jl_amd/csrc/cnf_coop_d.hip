@@ -203,90 +203,81 @@ __device__ __forceinline__ void dealt_gemm(const DRs& R, const TileOff<A>& T, un
     }
 }
 
-// K-split D-row product by ownership: part[dm][q] = sum over this wave's shared k-groups of W(dm, k) x[k, q] (all four sample
-// tiles, B operands straight from the registers that hold x), own[dm] = the same over its left-over k-groups for its own sample
-// tile.  `img`: the D-row image (fN or b1), k-group pitch KP.  The k-group that is the configuration's last one runs `rem`
-// k-steps.
-template <int A, int DT>
+// K-split D-row product by ownership: the partial tiles sum over this wave's shared k-groups of W(dm, k) x[k, q] go to
+// pbuf[wave][dm][q] (all four sample tiles, B operands straight from the registers that hold x), own[dm] = the same over its
+// left-over k-groups for its own sample tile.  `img`: the D-row image (fN or b1).  The k-group that is the configuration's last
+// one runs `rem` k-steps.  With QH = 2 the sample tiles are taken two at a time (the fragments are fetched twice): 32 instead of
+// 64 accumulator registers at DT = 4, which is what keeps the 16-state-register instances out of scratch.
+template <int A, int DT, int QH>
 __device__ __forceinline__ void dealt_drow(const DRs& R, const unsigned (&vd)[DT], unsigned img, int kgS0, int kgR0, int KG, int rem, int b,
-                                           const UAcc<A>& x, f32x4 (&f0)[DT], f32x4 (&part)[DT][4], f32x4 (&own)[DT]) {
+                                           const UAcc<A>& x, f32x4 (&f0)[DT], f32x4* __restrict__ pw, int lane, f32x4 (&own)[DT]) {
     // f0 arrives holding the fragments of k-group kgS0 (dealt_drow_first: requested before the activation phase)
+    constexpr int QN = 4 / QH;
     f32x4 f1[DT];
 #pragma unroll
-    for (int dm = 0; dm < DT; ++dm) {
-        own[dm] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int dm = 0; dm < DT; ++dm) own[dm] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int q = 0; q < 4; ++q) part[dm][q] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    // shared block: k-groups kgS0 .. kgS0 + A - 1, then the left-over k-groups (clamped loads), software-pipelined by one
+    for (int qh = 0; qh < QH; ++qh) {
+        f32x4 part[DT][QN];
 #pragma unroll
-    for (int m = 0; m < A + 3; ++m) {
-        f32x4(&cur)[DT] = (m & 1) ? f1 : f0;
-        f32x4(&nxt)[DT] = (m & 1) ? f0 : f1;
-        if (m + 1 < A + 3) {
-            const int raw = m + 1 < A ? kgS0 + m + 1 : kgR0 + (m + 1 - A);
-            const int kgn = raw < KG ? raw : KG - 1;
+        for (int dm = 0; dm < DT; ++dm)
 #pragma unroll
-            for (int dm = 0; dm < DT; ++dm) nxt[dm] = dloadv(R, vd[dm], img + (unsigned)kgn * 1024u);
+            for (int q = 0; q < QN; ++q) part[dm][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (qh > 0) {
+#pragma unroll
+            for (int dm = 0; dm < DT; ++dm) f0[dm] = dloadv(R, vd[dm], img + (unsigned)kgS0 * 1024u);
         }
-        if (m < A) {
-            const bool last = kgS0 + m == KG - 1;   // only when b == 0 and this is the last wave's last tile
-            if (!last || rem == 4) {
+        // shared block: k-groups kgS0 .. kgS0 + A - 1, then (first pass only) the left-over k-groups (clamped loads), pipelined by one
+        constexpr int MEND_FIRST = A + 3;
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+        for (int m = 0; m < MEND_FIRST; ++m) {
+            if (qh > 0 && m >= A) break;
+            f32x4(&cur)[DT] = (m & 1) ? f1 : f0;
+            f32x4(&nxt)[DT] = (m & 1) ? f0 : f1;
+            const int mend = qh > 0 ? A : A + 3;
+            if (m + 1 < mend) {
+                const int raw = m + 1 < A ? kgS0 + m + 1 : kgR0 + (m + 1 - A);
+                const int kgn = raw < KG ? raw : KG - 1;
 #pragma unroll
-                    for (int dm = 0; dm < DT; ++dm)
+                for (int dm = 0; dm < DT; ++dm) nxt[dm] = dloadv(R, vd[dm], img + (unsigned)kgn * 1024u);
+            }
+            if (m < A) {
+                const bool last = kgS0 + m == KG - 1;   // only when b == 0 and this is the last wave's last tile
+                if (!last || rem == 4) {
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) part[dm][q] = mfma4(cur[dm][j], x.S[m][q][j], part[dm][q]);
-            } else {
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (j < rem) {
+                    for (int j = 0; j < 4; ++j)
 #pragma unroll
                         for (int dm = 0; dm < DT; ++dm)
 #pragma unroll
-                            for (int q = 0; q < 4; ++q) part[dm][q] = mfma4(cur[dm][j], x.S[m][q][j], part[dm][q]);
-                    }
-            }
-        } else {
-            const int r = m - A;
-            if (r < b) {
-                // (k-steps beyond the last real one multiply zero weights: run them rather than branch per k-step)
+                            for (int q = 0; q < QN; ++q) part[dm][q] = mfma4(cur[dm][j], x.S[m][qh * QN + q][j], part[dm][q]);
+                } else {
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                    for (int j = 0; j < 4; ++j)
+                        if (j < rem) {
 #pragma unroll
-                    for (int dm = 0; dm < DT; ++dm) own[dm] = mfma4(cur[dm][j], x.R[r][j], own[dm]);
+                            for (int dm = 0; dm < DT; ++dm)
+#pragma unroll
+                                for (int q = 0; q < QN; ++q) part[dm][q] = mfma4(cur[dm][j], x.S[m][qh * QN + q][j], part[dm][q]);
+                        }
+                }
+            } else {
+                const int r = m - A;
+                if (r < b) {
+                    // (k-steps beyond the last real one multiply zero weights: run them rather than branch per k-step)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int dm = 0; dm < DT; ++dm) own[dm] = mfma4(cur[dm][j], x.R[r][j], own[dm]);
+                }
             }
         }
+#pragma unroll
+        for (int dm = 0; dm < DT; ++dm)
+#pragma unroll
+            for (int q = 0; q < QN; ++q) pw[(dm * 4 + qh * QN + q) * 64 + lane] = part[dm][q];
     }
 }
 
-// softplus and its derivative on one accumulator tile: NNlib.softplus(a) = log1p(exp(-|a|)) + relu(a), d = sigmoid(a)
-// (cnf_common.h: act_fwd) with the bare transcendentals - e = v_exp(-|a| log2 e) lies in (0, 1], so 1 + e in (1, 2] needs none of
-// __expf's / __logf's range handling (those expand to ~16 VALU instructions per element; this is 8.5) - and the affine steps on
-// register pairs (v_pk_add / v_pk_fma / v_pk_mul).  Same formulas, |error| <= 2e-7 as before.
-__device__ __forceinline__ void softplus_tile(const f32x4& a, f32x4& h, f32x4& d) {
-    constexpr float kNegLog2e = -1.4426950408889634f, kLn2 = 0.6931471805599453f;
-    float e[4], r[4], lg[4], mx[4], sel[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) e[i] = __builtin_amdgcn_exp2f(__builtin_fabsf(a[i]) * kNegLog2e);
-    const f32x2 one = {1.f, 1.f};
-    const f32x2 s0 = f32x2{e[0], e[1]} + one, s1 = f32x2{e[2], e[3]} + one;
-    const float sv[4] = {s0[0], s0[1], s1[0], s1[1]};
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        r[i] = __builtin_amdgcn_rcpf(sv[i]);
-        lg[i] = __builtin_amdgcn_logf(sv[i]);       // log2(1 + e)
-        mx[i] = __builtin_fmaxf(a[i], 0.f);
-        sel[i] = a[i] >= 0.f ? 1.f : e[i];
-    }
-    const f32x2 ln2 = {kLn2, kLn2};
-    const f32x2 h0 = __builtin_elementwise_fma(f32x2{lg[0], lg[1]}, ln2, f32x2{mx[0], mx[1]});
-    const f32x2 h1 = __builtin_elementwise_fma(f32x2{lg[2], lg[3]}, ln2, f32x2{mx[2], mx[3]});
-    const f32x2 d0 = f32x2{r[0], r[1]} * f32x2{sel[0], sel[1]}, d1 = f32x2{r[2], r[3]} * f32x2{sel[2], sel[3]};
-    h = f32x4{h0[0], h0[1], h1[0], h1[1]};
-    d = f32x4{d0[0], d0[1], d1[0], d1[1]};
-}
 template <int DT>
 __device__ __forceinline__ void dealt_drow_first(const DRs& R, const unsigned (&vd)[DT], unsigned img, int kgS0, f32x4 (&f0)[DT]) {
 #pragma unroll
@@ -333,10 +324,7 @@ __device__ __forceinline__ f32x4 dact_from_h(const f32x4& h) {
     }
 }
 template <int ACT>
-__device__ __forceinline__ void act_pair(const f32x4& a, f32x4& h, f32x4& d) {
-    if constexpr (ACT == CNF_ACT_SOFTPLUS) softplus_tile(a, h, d);
-    else act_tile<ACT>(a, h, d);
-}
+__device__ __forceinline__ void act_pair(const f32x4& a, f32x4& h, f32x4& d) { act_tile<ACT>(a, h, d); }
 
 // One dynamics evaluation for a 64-sample super-tile; every wave owns sample tile `wave`.
 template <int A, int L, int ZR, int ACT>
@@ -403,7 +391,7 @@ __device__ __forceinline__ void coopd_eval(const DRs& R, const float* __restrict
         __syncthreads();
         dealt_gemm<A>(R, TZ, F1Z, G.KGZ, G.remZ, b, zbuf, wave, lane, aS, aR, acc);
     }
-    f32x4 part[DT][4], own[DT], fd[DT];
+    f32x4 own[DT], fd[DT];
     UAcc<A> h;
 #pragma unroll
     for (int l = 0; l < L; ++l) {
@@ -448,7 +436,10 @@ __device__ __forceinline__ void coopd_eval(const DRs& R, const float* __restrict
         }
     }
     // ---- zdot = W_N h_L + b_N: partials over this wave's own k-groups, from registers ----
-    dealt_drow<A, DT>(R, vd, FN, mtS0, mtR0, G.KGH, G.remH, b, h, fd, part, own);
+    constexpr int QH = DT >= 4 ? 2 : 1;
+    f32x4* __restrict__ pw = pbuf + (wave * DT) * 4 * 64;   // this wave's partial tiles: [dm][q][lane]
+    if (G.xalias) __syncthreads();   // the partial tiles share the exchange buffer: its readers (the last hidden product) are done
+    dealt_drow<A, DT, QH>(R, vd, FN, mtS0, mtR0, G.KGH, G.remH, b, h, fd, pw, lane, own);
     // the first fragments of the pullback's first product are requested before the barrier
     if (L > 1) dealt_load_a<A>(R, TH, BH + (unsigned)(L - 2) * IMGH, 0, aS, aR);
     // delta_L = c .* act'_L, act'_L rebuilt from h_L (which the product above has consumed)
@@ -458,11 +449,6 @@ __device__ __forceinline__ void coopd_eval(const DRs& R, const float* __restrict
         for (int q = 0; q < 4; ++q) h.S[m][q] = unpark4(cP.S[m][q]) * dact_from_h<ACT>(h.S[m][q]);
 #pragma unroll
     for (int r = 0; r < 3; ++r) h.R[r] = unpark4(cP.R[r]) * dact_from_h<ACT>(h.R[r]);
-    if (G.xalias) __syncthreads();   // the partial tiles share the exchange buffer: its readers (the last hidden product) are done
-#pragma unroll
-    for (int dm = 0; dm < DT; ++dm)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) pbuf[((wave * DT + dm) * 4 + q) * 64 + lane] = part[dm][q];
     __syncthreads();
     {
         f32x4 zacc[DT];
@@ -521,13 +507,9 @@ __device__ __forceinline__ void coopd_eval(const DRs& R, const float* __restrict
         }
     }
     // ---- g = W_1[:,0:D]^T delta_1 = eps^T J: partials from registers ----
-    dealt_drow<A, DT>(R, vd, B1, mtS0, mtR0, G.KGH, G.remH, b, h, fd, part, own);
-    dealt_load_a<A>(R, TZ, F1Z, 0, aS, aR);   // the next evaluation's layer-1 fragments
     if (G.xalias) __syncthreads();
-#pragma unroll
-    for (int dm = 0; dm < DT; ++dm)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) pbuf[((wave * DT + dm) * 4 + q) * 64 + lane] = part[dm][q];
+    dealt_drow<A, DT, QH>(R, vd, B1, mtS0, mtR0, G.KGH, G.remH, b, h, fd, pw, lane, own);
+    dealt_load_a<A>(R, TZ, F1Z, 0, aS, aR);   // the next evaluation's layer-1 fragments
     __syncthreads();
     {
         float dot = 0.f, n2 = 0.f;
@@ -658,7 +640,7 @@ __device__ __forceinline__ void coopd_eval_exact(const DRs& R, const float* __re
     __syncthreads();
     dealt_gemm<A>(R, TH, QI, G.KGH, G.remH, b, xbuf, wave, lane, aS, aR, acc);   // Q act'_1
     // ---- hidden layer 2: h_2 feeds zdot from registers; act'_2 meets Q act'_1 ----
-    f32x4 part[DT][4], own[DT], fd[DT];
+    f32x4 own[DT], fd[DT];
     dealt_drow_first<DT>(R, vd, FN, mtS0, fd);
     float tr[4], trown = 0.f;
 #pragma unroll
@@ -681,13 +663,9 @@ __device__ __forceinline__ void coopd_eval_exact(const DRs& R, const float* __re
             for (int j = 0; j < 4; ++j) trown = fmaf(acc.R[r][j], dd[j], trown);
         }
     }
-    dealt_drow<A, DT>(R, vd, FN, mtS0, mtR0, G.KGH, G.remH, b, h, fd, part, own);
-    dealt_load_a<A>(R, TZ, F1Z, 0, aS, aR);   // the next evaluation's layer-1 fragments
     if (G.xalias) __syncthreads();            // the partial tiles share the exchange buffer: the Q product's readers are done
-#pragma unroll
-    for (int dm = 0; dm < DT; ++dm)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) pbuf[((wave * DT + dm) * 4 + q) * 64 + lane] = part[dm][q];
+    dealt_drow<A, DT, (DT >= 4 ? 2 : 1)>(R, vd, FN, mtS0, mtR0, G.KGH, G.remH, b, h, fd, pbuf + (wave * DT) * 4 * 64, lane, own);
+    dealt_load_a<A>(R, TZ, F1Z, 0, aS, aR);   // the next evaluation's layer-1 fragments
 #pragma unroll
     for (int q = 0; q < 4; ++q) red[(wave * 4 + q) * 64 + lane] = group_sum(tr[q]);
     trown = group_sum(trown);
@@ -932,7 +910,7 @@ struct CoopDInst {
 #define CD_SHAPES(L, ACT) CD_INST(2, L, 12, ACT), CD_INST(3, L, 12, ACT), CD_INST(3, L, 16, ACT)
 static const CoopDInst kCoopD[] = {
     CD_SHAPES(2, CNF_ACT_SOFTPLUS),
-    CD_EXACT(2, 12, CNF_ACT_SOFTPLUS), CD_EXACT(3, 12, CNF_ACT_SOFTPLUS),   // TestMode of the same flows up to D = 48 (the 16-state-register form does not fit the accumulation registers)
+    CD_EXACT(2, 12, CNF_ACT_SOFTPLUS), CD_EXACT(3, 12, CNF_ACT_SOFTPLUS), CD_EXACT(3, 16, CNF_ACT_SOFTPLUS),   // TestMode of the same flows
 };
 
 static const CoopDInst* cd_find(int HT_real, int L, int KZ, int ACT, int MODE) {
