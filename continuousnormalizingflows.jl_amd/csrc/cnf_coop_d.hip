@@ -42,6 +42,7 @@ struct DImg {
     int KGZ, remZ;    // real state k-groups and k-steps of the last one
     int xalias;       // the partial tiles alias the exchange buffer (LDS is short): one more barrier per D-row product
     int ckzr;         // floats per lane of the checkpoint arrays (the plan's ZR: what the reverse sweep strides by)
+    int f1y, KPC, remC;   // conditioned flows (C <= 16: one k-group): the condition columns' image of layer 1, its k-group pitch, real k-steps (0: none)
     int q_off;        // exact-trace instances: float offset of the Q image (two hidden layers: tr J = act'_2^T Q act'_1), else 0
     int cvn;          // floats of the C-vector section [v_b1, end of v_bN) of the image: staged into LDS once per workgroup
 };
@@ -330,7 +331,7 @@ __device__ __forceinline__ void act_pair(const f32x4& a, f32x4& h, f32x4& d) { a
 template <int A, int L, int ZR, int ACT>
 __device__ __forceinline__ void coopd_eval(const DRs& R, const float* __restrict__ CV, const DImg& Gin, f32x4* __restrict__ xbuf, int XB,
                                            f32x4* __restrict__ zbuf, const f32x4* __restrict__ ebuf, f32x4* __restrict__ pbuf,
-                                           int lane, int wave, float t, bool autonomous, bool reg_z, bool reg_j,
+                                           const f32x4* __restrict__ ybuf, int lane, int wave, float t, bool autonomous, bool reg_z, bool reg_j,
                                            const float (&zs)[ZR], float (&zd)[ZR], float& ld, float& ed, float& nd,
                                            float* __restrict__ gout, const UAcc<A>& cP, f32x4 (&aS)[A], f32x4 (&aR)[3]) {
     // cP: c = W_N^T eps of this wave's units, PARKED - eps is fixed for the whole solve (src/core/base_icnf.jl:258-259), so the
@@ -345,7 +346,7 @@ __device__ __forceinline__ void coopd_eval(const DRs& R, const float* __restrict
     int opq = 0;
     asm volatile("" : "+s"(opq));
     DImg G = Gin;
-    G.f1z += opq; G.fh += opq; G.fN += opq; G.bN += opq; G.bh += opq; G.b1 += opq;
+    G.f1z += opq; G.fh += opq; G.fN += opq; G.bN += opq; G.bh += opq; G.b1 += opq; G.f1y += opq;
     const float* __restrict__ P = CV - G.v_b1;   // C vectors: the LDS copy, addressed by their image offsets
     const int g = lane >> 4;
     const int b = G.b;
@@ -390,6 +391,11 @@ __device__ __forceinline__ void coopd_eval(const DRs& R, const float* __restrict
         uacc_fill<A>(acc, bS, bR);
         __syncthreads();
         dealt_gemm<A>(R, TZ, F1Z, G.KGZ, G.remZ, b, zbuf, wave, lane, aS, aR, acc);
+        if (G.remC > 0) {   // + W_1[:, condition columns] y  (CondLayer rows [z; t; ys], src/layers/cond_layer.jl:7-31): one k-group
+            const TileOff<A> TC = tile_offsets<A>(R, G.KPC, mtS0, mtR0, mtRmax);
+            dealt_load_a<A>(R, TC, (unsigned)G.f1y * 4u, 0, aS, aR);
+            dealt_gemm<A>(R, TC, (unsigned)G.f1y * 4u, 1, G.remC, b, ybuf, wave, lane, aS, aR, acc);
+        }
     }
     f32x4 own[DT], fd[DT];
     UAcc<A> h;
@@ -543,13 +549,13 @@ __device__ __forceinline__ void coopd_eval(const DRs& R, const float* __restrict
 template <int A, int ZR, int ACT>
 __device__ __forceinline__ void coopd_eval_exact(const DRs& R, const float* __restrict__ CV, const DImg& Gin, f32x4* __restrict__ xbuf,
                                                  f32x4* __restrict__ zbuf, f32x4* __restrict__ pbuf, float* __restrict__ red,
-                                                 int lane, int wave, float t, bool autonomous, const float (&zs)[ZR], float (&zd)[ZR],
+                                                 const f32x4* __restrict__ ybuf, int lane, int wave, float t, bool autonomous, const float (&zs)[ZR], float (&zd)[ZR],
                                                  float& ld, f32x4 (&aS)[A], f32x4 (&aR)[3]) {
     constexpr int DT = ZR / 4;
     int opq = 0;
     asm volatile("" : "+s"(opq));
     DImg G = Gin;
-    G.f1z += opq; G.fh += opq; G.fN += opq; G.q_off += opq;
+    G.f1z += opq; G.fh += opq; G.fN += opq; G.q_off += opq; G.f1y += opq;
     const float* __restrict__ P = CV - G.v_b1;
     const int g = lane >> 4;
     const int b = G.b;
@@ -600,6 +606,11 @@ __device__ __forceinline__ void coopd_eval_exact(const DRs& R, const float* __re
         uacc_fill<A>(acc, bS, bR);
         __syncthreads();
         dealt_gemm<A>(R, TZ, F1Z, G.KGZ, G.remZ, b, zbuf, wave, lane, aS, aR, acc);
+        if (G.remC > 0) {   // + W_1[:, condition columns] y  (CondLayer rows [z; t; ys], src/layers/cond_layer.jl:7-31): one k-group
+            const TileOff<A> TC = tile_offsets<A>(R, G.KPC, mtS0, mtR0, mtRmax);
+            dealt_load_a<A>(R, TC, (unsigned)G.f1y * 4u, 0, aS, aR);
+            dealt_gemm<A>(R, TC, (unsigned)G.f1y * 4u, 1, G.remC, b, ybuf, wave, lane, aS, aR, acc);
+        }
     }
     // ---- hidden layer 1: publish h_1; act'_1 waits (parked) for the exchange buffer ----
     dealt_load_a<A>(R, TH, FH, 0, aS, aR);
@@ -707,8 +718,8 @@ __device__ __forceinline__ void coopd_hoist_c(const DRs& R, const DImg& G, const
     dealt_load_a<A>(R, TZ, (unsigned)G.f1z * 4u, 0, aS, aR);
 }
 
-constexpr int coopd_lds_bytes(int HT, int L, int DT, bool alias, int cvn) {
-    return ((L == 2 ? 1 : 2) * HT * 4 * 64 + 2 * DT * 4 * 64 + (alias ? 0 : 4 * DT * 4 * 64)) * 16 + (cvn + 3) / 4 * 16;
+constexpr int coopd_lds_bytes(int HT, int L, int DT, bool alias, int cvn, bool cond = false) {
+    return ((L == 2 ? 1 : 2) * HT * 4 * 64 + 2 * DT * 4 * 64 + (alias ? 0 : 4 * DT * 4 * 64) + (cond ? 4 * 64 : 0)) * 16 + (cvn + 3) / 4 * 16;
 }
 
 // The Runge-Kutta running sums of the later stages' increments (P_i <- P_{i+1} + a_{s+1+i,s} zdot, as the other kernels keep them)
@@ -730,7 +741,8 @@ coopd_solve_kernel(DArgs da) {
     f32x4* zbuf = xbuf + (L == 2 ? 1 : 2) * XB;               // [DT][4][64]
     f32x4* ebuf = zbuf + DT * 4 * 64;                         // [DT][4][64]
     f32x4* pbuf = G.xalias ? xbuf : ebuf + DT * 4 * 64;       // [4 waves][DT][4][64] partial tiles of the D-row products
-    float* cbuf = reinterpret_cast<float*>(ebuf + DT * 4 * 64 + (G.xalias ? 0 : 4 * DT * 4 * 64));   // C vectors (biases, time column)
+    f32x4* ybuf = ebuf + DT * 4 * 64 + (G.xalias ? 0 : 4 * DT * 4 * 64);   // [1][4][64]: conditions (constant over the solve)
+    float* cbuf = reinterpret_cast<float*>(ybuf + (G.remC > 0 ? 4 * 64 : 0));   // C vectors (biases, time column)
     for (int i = threadIdx.x; i < G.cvn; i += 256) cbuf[i] = a.packed[G.v_b1 + i];
     // (the first __syncthreads of the super-tile loop orders these writes before any read)
     const int lane = threadIdx.x & 63, g = lane >> 4, n = lane & 15;
@@ -759,6 +771,12 @@ coopd_solve_kernel(DArgs da) {
                 v[j] = (MODE == 0 && f < D) ? a.eps[sc * D + f] : 0.f;
             }
             if constexpr (MODE == 0) ebuf[(kg * 4 + wave) * 64 + lane] = v;   // the probe of this wave's sample tile as a B image, for the whole solve
+        }
+        if (G.remC > 0) {
+            f32x4 v;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const int f = 4 * j + g; v[j] = f < a.C ? a.ys[sc * a.C + f] : 0.f; }
+            ybuf[wave * 64 + lane] = v;
         }
         if (!a.x) { lacc = a.u0[sc * S + D]; eacc = a.u0[sc * S + D + 1]; nacc = a.u0[sc * S + D + 2]; }
         UAcc<A> cP;
@@ -796,10 +814,10 @@ coopd_solve_kernel(DArgs da) {
                 const long long ckrow = ((((long long)step * ns + sg) * ckntp + cktile) * 64 + lane) * ckzr;
                 float* gout = (a.ckpt_g && !single) ? a.ckpt_g + ckrow : nullptr;
                 if constexpr (MODE == 0)
-                    coopd_eval<A, L, ZR, ACT>(R, cbuf, G, xbuf, XB, zbuf, ebuf, pbuf, lane, wave, tn + a.T.c[sg] * dt, autonomous, reg_z, reg_j,
+                    coopd_eval<A, L, ZR, ACT>(R, cbuf, G, xbuf, XB, zbuf, ebuf, pbuf, ybuf, lane, wave, tn + a.T.c[sg] * dt, autonomous, reg_z, reg_j,
                                               zs, zd, ld, ed, nd, gout, cP, aS, aR);
                 else
-                    coopd_eval_exact<A, ZR, ACT>(R, cbuf, G, xbuf, zbuf, pbuf, reinterpret_cast<float*>(ebuf), lane, wave, tn + a.T.c[sg] * dt,
+                    coopd_eval_exact<A, ZR, ACT>(R, cbuf, G, xbuf, zbuf, pbuf, reinterpret_cast<float*>(ebuf), ybuf, lane, wave, tn + a.T.c[sg] * dt,
                                                  autonomous, zs, zd, ld, aS, aR);   // (the probe image's LDS holds the partial traces)
                 if (gout)
                     for (int s = ZR; s < ckzr; ++s) gout[s] = 0.f;
@@ -924,23 +942,28 @@ static const CoopDInst* cd_find(int HT_real, int L, int KZ, int ACT, int MODE) {
 }
 
 // H = widest hidden layer, D = state rows of the configuration; (HT, ZR) = the plan's layout
-bool coopd_supported(int H, int D, int L, int ACT, int HT_lay, int ZR_lay, int exact) {
+bool coopd_supported(int H, int D, int L, int ACT, int HT_lay, int ZR_lay, int exact, int C) {
+    if (C < 0 || C > 16) return false;   // (conditions: one k-group of layer 1)
     const int HT_real = (H + 15) / 16, KZ = (D + 3) / 4;
     if (HT_real < 8 || HT_real > HT_lay || KZ > ZR_lay) return false;
     const CoopDInst* c = cd_find(HT_real, L, KZ, ACT, exact ? 1 : 0);
     if (!c) return false;
     // state registers beyond the plan's k-steps would read image k-groups that do not exist
     if ((c->ZR + 3) / 4 > (ZR_lay + 3) / 4) return false;
-    return coopd_lds_bytes(HT_real, L, c->ZR / 4, true, (2 + L) * 16 * HT_lay) <= 160 * 1024;
+    // LDS: exchange buffer(s) + state / probe images + partial tiles (+ conditions) + C vectors; when that exceeds 160 KB the partial
+    // tiles alias the exchange buffer, which they must then fit (coopd_launch makes the same decision)
+    const int DT = c->ZR / 4, cvn = (1 + L) * 16 * HT_lay + 16 * ((ZR_lay + 3) / 4);   // b_1, w_1t, b_2 .. b_L, b_N
+    if (coopd_lds_bytes(HT_real, L, DT, false, cvn, C > 0) <= 160 * 1024) return true;
+    return coopd_lds_bytes(HT_real, L, DT, true, cvn, C > 0) <= 160 * 1024 && 4 * DT * 4 <= (L == 2 ? 1 : 2) * HT_real * 4;
 }
 
-hipError_t coopd_launch(int H, int D, int L, int ACT, int HT_lay, int ZR_lay, const KArgs& k, int num_cus, hipStream_t st) {
+hipError_t coopd_launch(int H, int D, int L, int ACT, int HT_lay, int ZR_lay, int CR_lay, const KArgs& k, int num_cus, hipStream_t st) {
     const int HT_real = (H + 15) / 16, KZ = (D + 3) / 4;
     const bool exact = k.exact == 1;
     if (exact && k.q_off <= 0) return hipErrorNotSupported;
     const CoopDInst* c = cd_find(HT_real, L, KZ, ACT, exact ? 1 : 0);
     if (!c) return hipErrorNotSupported;
-    const MfmaLayout Y(HT_lay, L, ZR_lay, 0, true);
+    const MfmaLayout Y(HT_lay, L, ZR_lay, CR_lay, true);
     DArgs a{};
     a.k = k;
     DImg& G = a.g;
@@ -953,10 +976,12 @@ hipError_t coopd_launch(int H, int D, int L, int ACT, int HT_lay, int ZR_lay, co
     G.KGZ = (KZ + 3) / 4; G.remZ = KZ - 4 * (G.KGZ - 1);
     G.ckzr = ZR_lay;
     G.q_off = exact ? k.q_off : 0;
+    G.f1y = Y.f1y; G.KPC = Y.KGC > 0 ? Y.KGC : 1; G.remC = (k.C + 3) / 4;   // condition k-steps (<= 4)
+    if (k.C > 16 || (k.C > 0 && CR_lay < G.remC)) return hipErrorNotSupported;
     const int DT = c->ZR / 4;
     G.cvn = Y.v_bN + MfmaLayout::vecC(Y.DT) - Y.v_b1;
-    G.xalias = coopd_lds_bytes(HT_real, L, DT, false, G.cvn) <= 160 * 1024 ? 0 : 1;
-    const int lds = coopd_lds_bytes(HT_real, L, DT, G.xalias != 0, G.cvn);
+    G.xalias = coopd_lds_bytes(HT_real, L, DT, false, G.cvn, k.C > 0) <= 160 * 1024 ? 0 : 1;
+    const int lds = coopd_lds_bytes(HT_real, L, DT, G.xalias != 0, G.cvn, k.C > 0);
     if (lds > 160 * 1024 || (G.xalias && 4 * DT * 4 > (L == 2 ? 1 : 2) * HT_real * 4)) return hipErrorNotSupported;
     const long long nst = (k.B + 63) / 64;
     const int nblocks = (int)(nst < num_cus ? nst : num_cus);

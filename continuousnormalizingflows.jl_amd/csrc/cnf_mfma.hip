@@ -421,14 +421,14 @@ static hipError_t plan_ensure_cus(MfmaPlan* mp) {
 // ones fill (measured at nvariables = 24: 9.7 against 9.0 ms at B <= 4096, 9.7 against 11.7 ms at 8192).  CNF_COOPD=0: never,
 // =2: at any batch size.
 static bool plan_uses_coopd(const MfmaPlan* p, long long B) {
-    if (!p || p->kind != 2 || p->KP != 1 || p->CR != 0 || p->cfg.ncond != 0) return false;
+    if (!p || p->kind != 2 || p->KP != 1) return false;
     const bool exact = p->cfg.mode == CNF_MODE_EXACT;
     if (!(p->cfg.mode == CNF_MODE_HUTCH_VJP || (exact && p->L == 2 && p->q_extra > 0))) return false;
     const int env = env_int("CNF_COOPD", 1);
     if (env == 0 || (env != 2 && B <= 16LL * (p->num_cus > 0 ? p->num_cus : 256))) return false;
     int hmax = 0;
     for (int l = 1; l < p->cfg.n_layers; ++l) hmax = p->cfg.widths[l] > hmax ? p->cfg.widths[l] : hmax;
-    return coopd_supported(hmax, p->cfg.nvars + p->cfg.naug, p->L, p->ACT, p->HT, p->ZR, exact ? 1 : 0);
+    return coopd_supported(hmax, p->cfg.nvars + p->cfg.naug, p->L, p->ACT, p->HT, p->ZR, exact ? 1 : 0, p->cfg.ncond);
 }
 
 long long mfma_plan_ckpt_tiles(const MfmaPlan* p, long long B, bool on_grid) {
@@ -526,7 +526,7 @@ hipError_t mfma_solve(MfmaPlan* p, const float* packed_dev, const SolveArgs& s, 
         if (plan_uses_coopd(p, s.B)) {
             int hmax = 0;
             for (int l = 1; l < p->cfg.n_layers; ++l) hmax = p->cfg.widths[l] > hmax ? p->cfg.widths[l] : hmax;
-            return coopd_launch(hmax, a.D, p->L, p->ACT, p->HT, p->ZR, a, mp->num_cus, st);
+            return coopd_launch(hmax, a.D, p->L, p->ACT, p->HT, p->ZR, p->CR, a, mp->num_cus, st);
         }
         return coopx_launch(p->HT, p->L, p->ZR, p->CR, p->ACT, a, mp->num_cus, st);
     }

@@ -191,6 +191,10 @@ COOPD_CASES = [
     (dict(nvars=19, naug=20, hidden=[160, 160], act=2, mode=2), 70, 0, 5),                                    # 10 tiles (b = 2), RK4
     (dict(nvars=22, naug=23, hidden=[184, 184], act=2, mode=2, autonomous=True), 90, 1, 4),                   # 12 tiles: A = 3; no time column
     (dict(nvars=40, hidden=[176, 176], act=2, mode=2), 33, 0, 4),                                             # 11 tiles (b = 3), D = 40
+    # conditioned flows (CondICNF: the condition rows of layer 1, src/layers/cond_layer.jl:7-31, src/core/base_icnf.jl:272-296)
+    (dict(nvars=16, naug=17, ncond=5, hidden=[156, 156], act=2, reg_z=True, reg_j=True, reg_aug=True), 120, 1, 5),   # default architecture with 5 conditions: 10 tiles
+    (dict(nvars=20, naug=21, ncond=16, hidden=[232, 232], act=2, autonomous=True), 64, 0, 4),                # 16 conditions, D = 41, 15 tiles, autonomous
+    (dict(nvars=18, naug=19, ncond=3, hidden=[164, 164], act=2, mode=2), 70, 1, 4),                          # TestMode, 3 conditions
 ]
 
 
@@ -219,7 +223,8 @@ def test_dealt_cooperative_kernel_matches_the_oracles(kw, B, alg, nsteps, pkg, o
         du = pkg.augmented_f(icnf, mode, dev(u), dev(p), 0.37, dev(eps), dev(ys)).cpu().numpy()
         assert np.max(np.abs(du - o64.aug_f(spec, p, u, 0.37, eps, ys)) / (1.0 + np.abs(o64.aug_f(spec, p, u, 0.37, eps, ys)))) < TOL_CALL, tag
         # generate: the reversed solve from a given state (cnf_integrate_fixed: u0 in, u1 out)
-        gen = pkg.generate(icnf, mode, dev(p), {}, B, z0=dev(out[tag][2][:spec.D]), eps=dev(eps)) if spec.mode == 0 else dev(xs)
+        gen = (pkg.generate(icnf, mode, *(((dev(ys),) if spec.ncond else ()) + (dev(p), {}, B)), z0=dev(out[tag][2][:spec.D]), eps=dev(eps))
+               if spec.mode == 0 else dev(xs))
         out[tag] += (gen.cpu().numpy(),)
     assert np.max(np.abs(out["dealt"][0] - out["extended"][0])) < 5e-5
     assert np.max(np.abs(out["dealt"][2] - out["extended"][2])) < 5e-5
@@ -262,6 +267,7 @@ def test_dealt_cooperative_kernel_at_full_size(pkg, oracles, monkeypatch):
     (dict(nvars=20, naug=21, hidden=[168, 168], act=2, reg_z=True, reg_j=True, reg_aug=True), (0.01, 0.01, 0.01), 70, 0, 3, False),
     (dict(nvars=24, naug=25, hidden=[200, 200], act=2, reg_z=True, reg_j=True, reg_aug=True), (0.01, 0.01, 0.01), 80, 1, 2, False),
     (dict(nvars=18, naug=19, hidden=[152, 152], act=2), (0.0, 0.0, 0.0), 100, 1, 3, True),      # on a non-uniform grid (device-resident step times)
+    (dict(nvars=16, naug=17, ncond=5, hidden=[156, 156], act=2, reg_z=True, reg_j=True, reg_aug=True), (0.01, 0.01, 0.01), 90, 1, 2, False),   # conditioned
 ])
 def test_cooperative_gradient_on_the_dealt_forward_solve(kw, lam, B, alg, nsteps, grid, pkg, oracles, monkeypatch):
     """The checkpointing forward half of the cooperative gradient on the dealt kernel (z per step, zdot and g = eps^T J per stage in
@@ -292,7 +298,8 @@ def test_cooperative_gradient_on_the_dealt_forward_solve(kw, lam, B, alg, nsteps
         assert int(h.lib.cnf_grad_path_for(h.ptr, B, alg, 1)) == 3
         val, g, gx = float(sums[0]) / B, g / B, (gx / B).t()
     else:
-        val, g, gx = pkg.loss_and_gradient(icnf, mode, dev(xs), dev(p), {}, eps=dev(eps), wrt_x=True)
+        args = (dev(xs),) + ((dev(ys),) if spec.ncond else ()) + (dev(p), {})
+        val, g, gx = pkg.loss_and_gradient(icnf, mode, *args, eps=dev(eps), wrt_x=True)
         assert icnf.grad_path(mode, B=B, alg=alg) == 3
     assert abs(float(val) - L) < 1e-4 + 2e-6 * abs(L)
     assert np.max(np.abs(g.cpu().numpy() - gref)) < 5e-5 * np.abs(gref).max() + 1e-6
