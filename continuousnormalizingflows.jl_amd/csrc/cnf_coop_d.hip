@@ -97,6 +97,14 @@ __device__ __forceinline__ float unpark(float a) {
     asm("v_accvgpr_read_b32 %0, %1" : "=v"(x) : "a"(a));
     return x;
 }
+// An MFMA's result may be read by a VALU instruction only 11 wait states after an 8-pass v_mfma_f32_16x16x4_f32 (MI300 / MI350 ISA,
+// "manually inserted wait states"); the compiler's hazard recogniser provides them for instructions it selected, but it does not
+// look inside inline asm - so wherever accumulator tiles go STRAIGHT from a product into park(), this goes in between.
+// The wait states are tied to the tiles themselves ("+v": the parked values are the asm's outputs), so neither the products'
+// MFMAs can sink below them nor the parks rise above them.
+__device__ __forceinline__ void mfma_results_fence(f32x4& t0, f32x4& t1, f32x4& t2, f32x4& t3) {
+    asm volatile("s_nop 7\n\ts_nop 3" : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3));
+}
 __device__ __forceinline__ f32x4 park4(const f32x4& v) { return f32x4{park(v[0]), park(v[1]), park(v[2]), park(v[3])}; }
 __device__ __forceinline__ f32x4 unpark4(const f32x4& v) { return f32x4{unpark(v[0]), unpark(v[1]), unpark(v[2]), unpark(v[3])}; }
 
@@ -113,6 +121,13 @@ __device__ __forceinline__ void uacc_fill(UAcc<A>& u, const f32x4 (&vS)[A], cons
         for (int q = 0; q < 4; ++q) u.S[m][q] = vS[m];
 #pragma unroll
     for (int r = 0; r < 3; ++r) u.R[r] = vR[r];
+}
+template <int A>
+__device__ __forceinline__ void uacc_mfma_fence(UAcc<A>& u) {   // before accumulator tiles of a product go straight into park()
+#pragma unroll
+    for (int m = 0; m < A; ++m) mfma_results_fence(u.S[m][0], u.S[m][1], u.S[m][2], u.S[m][3]);
+    f32x4 dummy = u.R[0];
+    mfma_results_fence(u.R[0], u.R[1], u.R[2], dummy);
 }
 template <int A>
 __device__ __forceinline__ void uacc_zero(UAcc<A>& u) {
@@ -639,6 +654,7 @@ __device__ __forceinline__ void coopd_eval_exact(const DRs& R, const float* __re
     // ---- Q act'_1 FIRST (act'_1 as the B image), the pre-activations a_2 parked meanwhile: the trace then meets act'_2 the
     //      moment it is computed, and neither act' has to outlive a product ----
     dealt_load_a<A>(R, TH, QI, 0, aS, aR);
+    uacc_mfma_fence<A>(acc);
 #pragma unroll
     for (int m = 0; m < A; ++m)
 #pragma unroll
@@ -709,6 +725,7 @@ __device__ __forceinline__ void coopd_hoist_c(const DRs& R, const DImg& G, const
     uacc_zero<A>(acc);
     dealt_load_a<A>(R, TZ, (unsigned)G.bN * 4u, 0, aS, aR);
     dealt_gemm<A>(R, TZ, (unsigned)G.bN * 4u, G.KGZ, G.remZ, b, ebuf, wave, lane, aS, aR, acc);
+    uacc_mfma_fence<A>(acc);
 #pragma unroll
     for (int m = 0; m < A; ++m)
 #pragma unroll
