@@ -262,6 +262,33 @@ def test_dealt_cooperative_kernel_at_full_size(pkg, oracles, monkeypatch):
         assert np.array_equal(np.concatenate([la, lb]), logp)
 
 
+@pytest.mark.parametrize("solver", ["tsit5", "vcabm"])
+def test_adaptive_solvers_on_the_dealt_kernel(solver, pkg, oracles, monkeypatch):
+    """The reference's default configuration above 4096 columns: ICNF(nvariables = 16) under the adaptive solvers (default VCABM,
+    or Tsit5, at 1e-4).  Every attempt is a single dynamics call (boundary A) of 5000 columns - on the dealt kernel; the loss, the
+    accepted / rejected counts and the training step on the frozen grid agree with the same solves on the extended kernel
+    (CNF_COOPD=0), which differ from it by summation order only."""
+    o64, _ = oracles
+    spec = o64.make_spec(nvars=16, naug=17, hidden=[136, 136], act=2, reg_z=True, reg_j=True, reg_aug=True)
+    B = 5000
+    p, xs, eps, _ = o64.synth_inputs(spec, B, 1234, bias_scale=0.2)
+    out = {}
+    for tag, env in (("dealt", "1"), ("extended", "0")):
+        monkeypatch.setenv("CNF_COOPD", env)
+        icnf = make_icnf(pkg, spec, 1, 1, lambdas=(0.01, 0.01, 0.01))
+        icnf.sol_kwargs = dict(alg=pkg.VCABM() if solver == "vcabm" else pkg.Tsit5(), reltol=1e-4, abstol=1e-4)
+        mode = pkg.TrainMode(True)
+        assert icnf.kernel_family(mode, B=B, whole_solve=False) == ("coopd" if tag == "dealt" else "coopx")
+        val = float(pkg.loss(icnf, mode, dev(xs), dev(p), {}, eps=dev(eps)))
+        stats = dict(icnf.last_solve_stats)
+        gval, g = pkg.loss_and_gradient(icnf, mode, dev(xs), dev(p), {}, eps=dev(eps))
+        out[tag] = (val, stats.get("naccept"), stats.get("nreject"), float(gval), g.cpu().numpy())
+    assert abs(out["dealt"][0] - out["extended"][0]) < 1e-4
+    assert out["dealt"][1:3] == out["extended"][1:3], (out["dealt"][1:3], out["extended"][1:3])
+    assert abs(out["dealt"][3] - out["extended"][3]) < 1e-4
+    assert np.max(np.abs(out["dealt"][4] - out["extended"][4])) < 1e-4 * np.abs(out["extended"][4]).max() + 1e-6
+
+
 @pytest.mark.parametrize("kw,lam,B,alg,nsteps,grid", [
     (dict(nvars=16, naug=17, hidden=[136, 136], act=2, reg_z=True, reg_j=True, reg_aug=True), (0.01, 0.01, 0.01), 150, 1, 2, False),
     (dict(nvars=20, naug=21, hidden=[168, 168], act=2, reg_z=True, reg_j=True, reg_aug=True), (0.01, 0.01, 0.01), 70, 0, 3, False),
