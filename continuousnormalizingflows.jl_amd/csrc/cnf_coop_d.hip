@@ -945,6 +945,10 @@ struct CoopDInst {
 #define CD_SHAPES(L, ACT) CD_INST(2, L, 12, ACT), CD_INST(3, L, 12, ACT), CD_INST(3, L, 16, ACT)
 static const CoopDInst kCoopD[] = {
     CD_SHAPES(2, CNF_ACT_SOFTPLUS),
+    // other flows of 8 .. 15 hidden tiles: tanh, three hidden layers (A = 2: act' of two layers parked), D <= 32
+    CD_INST(2, 2, 8, CNF_ACT_SOFTPLUS), CD_INST(3, 2, 8, CNF_ACT_SOFTPLUS), CD_INST(2, 3, 8, CNF_ACT_SOFTPLUS), CD_INST(2, 3, 12, CNF_ACT_SOFTPLUS),
+    CD_INST(2, 2, 8, CNF_ACT_TANH_PRESCALED), CD_INST(3, 2, 8, CNF_ACT_TANH_PRESCALED), CD_SHAPES(2, CNF_ACT_TANH_PRESCALED),
+    CD_INST(2, 3, 8, CNF_ACT_TANH_PRESCALED), CD_INST(3, 3, 8, CNF_ACT_TANH_PRESCALED), CD_INST(2, 3, 12, CNF_ACT_TANH_PRESCALED),
     CD_EXACT(2, 12, CNF_ACT_SOFTPLUS), CD_EXACT(3, 12, CNF_ACT_SOFTPLUS), CD_EXACT(3, 16, CNF_ACT_SOFTPLUS),   // TestMode of the same flows
 };
 

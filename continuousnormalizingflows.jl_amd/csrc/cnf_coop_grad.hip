@@ -183,6 +183,9 @@ coop_grad_step_kernel(CGArgs a) {
     };
     // this wave's tiles of chain `ch` in exchange buffer `buf` -> rows [16 mt0, 16 (mt0 + MTW)) of a column-major operand array
     auto gstore = [&](int buf, int ch, const __amdgpu_buffer_rsrc_t& rs, const unsigned (&voff)[NT][2], unsigned soff0) {
+#ifdef CG_EXP_NOSTORE   // timing-only build (wrong gradients): what the operand stores cost
+        return;
+#endif
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         typedef float __attribute__((may_alias)) float_a;
         const float_a* xb = reinterpret_cast<const float_a*>(xbuf + buf * XB);

@@ -421,13 +421,16 @@ static hipError_t plan_ensure_cus(MfmaPlan* mp) {
 // ones fill (measured at nvariables = 24: 9.7 against 9.0 ms at B <= 4096, 9.7 against 11.7 ms at 8192).  CNF_COOPD=0: never,
 // =2: at any batch size.
 static bool plan_uses_coopd(const MfmaPlan* p, long long B) {
-    if (!p || p->kind != 2 || p->KP != 1) return false;
+    if (!p || (p->kind != 2 && p->kind != 1) || p->KP != 1) return false;   // extended plans, and cooperative ones (one probe, VJP, no conditions)
     const bool exact = p->cfg.mode == CNF_MODE_EXACT;
     if (!(p->cfg.mode == CNF_MODE_HUTCH_VJP || (exact && p->L == 2 && p->q_extra > 0))) return false;
     const int env = env_int("CNF_COOPD", 1);
     if (env == 0 || (env != 2 && B <= 16LL * (p->num_cus > 0 ? p->num_cus : 256))) return false;
     int hmax = 0;
     for (int l = 1; l < p->cfg.n_layers; ++l) hmax = p->cfg.widths[l] > hmax ? p->cfg.widths[l] : hmax;
+    // a cooperative plan whose hidden width fills whole quads of tiles stays on its own, exact, tuned kernel (3 x 192, D = 20:
+    // 20.5 against 22.4 ms); one that it pads - 13 tiles run as 16 - is dealt (3 x 200: 31.0 -> 24.5 ms)
+    if (p->kind == 1 && ((hmax + 15) / 16) % 4 == 0) return false;
     return coopd_supported(hmax, p->cfg.nvars + p->cfg.naug, p->L, p->ACT, p->HT, p->ZR, exact ? 1 : 0, p->cfg.ncond);
 }
 
@@ -483,7 +486,7 @@ static bool plan_takes_tile_split(MfmaPlan* p, long long B) {
 
 // CNF_FAMILY_* of the kernel that serves a whole fixed-step solve of B columns (whole_solve) or a single dynamics call
 int mfma_plan_family_for(MfmaPlan* p, long long B, bool whole_solve) {
-    if (p->kind == 1) return CNF_FAMILY_COOP;
+    if (p->kind == 1) return (B > 0 && plan_ensure_cus(p) == hipSuccess && plan_uses_coopd(p, B)) ? CNF_FAMILY_COOPD : CNF_FAMILY_COOP;
     if (p->kind == 2) return (B > 0 && plan_ensure_cus(p) == hipSuccess && plan_uses_coopd(p, B)) ? CNF_FAMILY_COOPD : CNF_FAMILY_COOPX;
     return (whole_solve && B > 0 && plan_takes_tile_split(p, B)) ? CNF_FAMILY_TILE_SPLIT : CNF_FAMILY_PER_WAVE;
 }
@@ -529,6 +532,11 @@ hipError_t mfma_solve(MfmaPlan* p, const float* packed_dev, const SolveArgs& s, 
             return coopd_launch(hmax, a.D, p->L, p->ACT, p->HT, p->ZR, p->CR, a, mp->num_cus, st);
         }
         return coopx_launch(p->HT, p->L, p->ZR, p->CR, p->ACT, a, mp->num_cus, st);
+    }
+    if (p->kind == 1 && plan_uses_coopd(p, s.B)) {
+        int hmax = 0;
+        for (int l = 1; l < p->cfg.n_layers; ++l) hmax = p->cfg.widths[l] > hmax ? p->cfg.widths[l] : hmax;
+        return coopd_launch(hmax, a.D, p->L, p->ACT, p->HT, p->ZR, 0, a, mp->num_cus, st);
     }
     if (p->kind == 1) {
         // with checkpoint buffers: the checkpointing form of the cooperative solve (the forward half of cnf_coop_grad.hip)

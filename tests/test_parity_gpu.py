@@ -191,6 +191,13 @@ COOPD_CASES = [
     (dict(nvars=19, naug=20, hidden=[160, 160], act=2, mode=2), 70, 0, 5),                                    # 10 tiles (b = 2), RK4
     (dict(nvars=22, naug=23, hidden=[184, 184], act=2, mode=2, autonomous=True), 90, 1, 4),                   # 12 tiles: A = 3; no time column
     (dict(nvars=40, hidden=[176, 176], act=2, mode=2), 33, 0, 4),                                             # 11 tiles (b = 3), D = 40
+    # other flows of these sizes: tanh (pre-scaled forward images), three hidden layers, D <= 32 (cooperative plans whose width
+    # the cooperative kernel would pad to a whole quad of tiles)
+    (dict(nvars=20, hidden=[200, 200, 200], reg_z=True, reg_j=True), 130, 1, 4),                              # 13 tiles, three tanh layers (two exchange buffers)
+    (dict(nvars=10, hidden=[176, 176]), 77, 0, 5),                                                            # 11 tiles, two tanh layers
+    (dict(nvars=30, naug=2, hidden=[144, 144, 144], reg_aug=True), 64, 1, 3),                                 # 9 tiles, D = 32 exactly
+    (dict(nvars=12, hidden=[160, 160, 150], act=2, reg_j=True), 50, 0, 4),                                    # softplus, three layers, unequal widths
+    (dict(nvars=40, hidden=[232, 232]), 45, 1, 4),                                                            # tanh, D = 40, 15 tiles (an extended-kernel plan)
     # conditioned flows (CondICNF: the condition rows of layer 1, src/layers/cond_layer.jl:7-31, src/core/base_icnf.jl:272-296)
     (dict(nvars=16, naug=17, ncond=5, hidden=[156, 156], act=2, reg_z=True, reg_j=True, reg_aug=True), 120, 1, 5),   # default architecture with 5 conditions: 10 tiles
     (dict(nvars=20, naug=21, ncond=16, hidden=[232, 232], act=2, autonomous=True), 64, 0, 4),                # 16 conditions, D = 41, 15 tiles, autonomous
@@ -213,7 +220,8 @@ def test_dealt_cooperative_kernel_matches_the_oracles(kw, B, alg, nsteps, pkg, o
     for tag, env in (("dealt", "2"), ("extended", "0")):
         monkeypatch.setenv("CNF_COOPD", env)
         icnf = make_icnf(pkg, spec, alg, nsteps, path=2)
-        assert icnf.kernel_family(mode, B=B) == ("coopd" if tag == "dealt" else "coopx")
+        assert icnf.kernel_family(mode, B=B) == ("coopd" if tag == "dealt" else icnf.kernel_family(mode))   # (else the plan's own: coopx / coop)
+        assert icnf.kernel_family(mode) in ("coopx", "coop")
         logp, regs, u1 = run_inference(pkg, icnf, spec, p, xs, eps, ys, return_state=True)
         out[tag] = (logp.cpu().numpy(), [r.cpu().numpy() for r in regs], u1.cpu().numpy())
         assert np.max(np.abs(out[tag][0] - ref[0])) < TOL_SOLVE, tag
@@ -295,6 +303,7 @@ def test_adaptive_solvers_on_the_dealt_kernel(solver, pkg, oracles, monkeypatch)
     (dict(nvars=24, naug=25, hidden=[200, 200], act=2, reg_z=True, reg_j=True, reg_aug=True), (0.01, 0.01, 0.01), 80, 1, 2, False),
     (dict(nvars=18, naug=19, hidden=[152, 152], act=2), (0.0, 0.0, 0.0), 100, 1, 3, True),      # on a non-uniform grid (device-resident step times)
     (dict(nvars=16, naug=17, ncond=5, hidden=[156, 156], act=2, reg_z=True, reg_j=True, reg_aug=True), (0.01, 0.01, 0.01), 90, 1, 2, False),   # conditioned
+    (dict(nvars=20, hidden=[200, 200, 200], reg_z=True, reg_j=True), (0.02, 0.03, 0.0), 70, 0, 2, False),      # a cooperative (tanh, 3-layer) plan's forward on the dealt kernel
 ])
 def test_cooperative_gradient_on_the_dealt_forward_solve(kw, lam, B, alg, nsteps, grid, pkg, oracles, monkeypatch):
     """The checkpointing forward half of the cooperative gradient on the dealt kernel (z per step, zdot and g = eps^T J per stage in
