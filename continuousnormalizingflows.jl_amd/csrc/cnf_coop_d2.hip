@@ -1,0 +1,631 @@
+// cnf_coop_d2.hip — the dealt cooperative kernel for 16 .. 24 hidden tiles (round 4): 32-sample super-tiles.
+//
+// cnf_coop_d.hip gives every wave a sample tile of a 64-sample super-tile; at A = HT / 4 >= 4 its per-wave footprint - 16 A + 12
+// registers each for the accumulators, act' of the lower layers and c = W_N^T eps, plus six rows of up to 24 state registers -
+// exceeds the 256 architectural + 256 accumulation registers of a wave.  Here a workgroup owns TWO sample tiles: the same dealing
+// of the hidden M-tiles (wave w: tiles [w A, (w + 1) A) for both sample tiles; the 2 b left-over (tile, sample) units one each to
+// the waves in order), the same K-split-by-ownership D-row products, real k-steps, parked act' and Runge-Kutta sums - at half the
+// registers per wave.  Waves 0 and 1 own the two sample tiles (state, Runge-Kutta update, reductions); because the D-row
+// products are split by K-ownership, not by sample ownership, the other two waves carry the same MFMA load.  A weight fragment
+// feeds 8 MFMAs instead of 16 - the fragment traffic per MFMA of the 64-sample form at A = 2 .. 3.
+// Serves the one-probe VJP solves of extended-kernel plans with 16 .. 24 hidden tiles (the reference's default architecture at
+// nvariables = 30 .. 47: D = 61 .. 95, H = 248 .. 384), two hidden layers, softplus or tanh, on the plan's own packed image.
+// Same math and reference map as cnf_coop_d.hip (src/core/icnf.jl:517-559, src/core/utils.jl:150-159).
+#define CNF_NO_PK_ASM 1
+#define CNF_NO_PHASE_FENCE 1
+#include "cnf_coop_d_dev.h"
+
+namespace cnf {
+
+template <int A>
+struct UAcc2 {
+    f32x4 S[A][2];   // tiles [w A, (w + 1) A) x the two sample tiles
+    f32x4 R[2];      // left-over units w and w + 4 of the 2 b (tile, sample) units: tile 4 A + (w >> 1) + 2 s, sample w & 1
+};
+template <int A>
+struct TileOff2 { unsigned S[A]; unsigned Rr[2]; };
+
+// this wave's left-over units: slot s is live when w + 4 s < 2 b; its tile (clamped for the loads) and its sample tile
+struct RUnits {
+    bool v0, v1;
+    int t0, t1, q;
+};
+__device__ __forceinline__ RUnits runits(int A, int b, int wave) {
+    RUnits u;
+    u.v0 = wave < 2 * b; u.v1 = wave + 4 < 2 * b;
+    const int tmax = 4 * A + b - 1;   // (b = 0: tile 4 A - 1, loaded and never multiplied)
+    const int r0 = 4 * A + (wave >> 1), r1 = r0 + 2;
+    u.t0 = r0 < tmax ? r0 : tmax; u.t1 = r1 < tmax ? r1 : tmax;
+    u.q = wave & 1;
+    return u;
+}
+
+template <int A>
+__device__ __forceinline__ TileOff2<A> tile_offsets2(const DRs& R, int KP, int mtS0, const RUnits& U) {
+    TileOff2<A> t;
+#pragma unroll
+    for (int m = 0; m < A; ++m) { t.S[m] = R.lane16 + (unsigned)((mtS0 + m) * KP) * 1024u; asm volatile("" : "+v"(t.S[m])); }
+    t.Rr[0] = R.lane16 + (unsigned)(U.t0 * KP) * 1024u; asm volatile("" : "+v"(t.Rr[0]));
+    t.Rr[1] = R.lane16 + (unsigned)(U.t1 * KP) * 1024u; asm volatile("" : "+v"(t.Rr[1]));
+    return t;
+}
+template <int A>
+__device__ __forceinline__ void d2_load_a(const DRs& R, const TileOff2<A>& T, unsigned img, int kg, f32x4 (&aS)[A], f32x4 (&aR)[2]) {
+    const unsigned so = img + (unsigned)kg * 1024u;
+#pragma unroll
+    for (int m = 0; m < A; ++m) aS[m] = dloadv(R, T.S[m], so);
+    aR[0] = dloadv(R, T.Rr[0], so);
+    aR[1] = dloadv(R, T.Rr[1], so);
+}
+__device__ __forceinline__ void d2_load_b(const f32x4* __restrict__ bimg, int kg, int qr, int lane, f32x4 (&bq)[2], f32x4& bo) {
+    bq[0] = bimg[(kg * 2 + 0) * 64 + lane];
+    bq[1] = bimg[(kg * 2 + 1) * 64 + lane];
+    int qv = qr;
+    asm volatile("" : "+s"(qv));   // (rebuilt from the scalar per call: see dealt_load_b)
+    bo = bimg[(kg * 2 + qv) * 64 + lane];
+}
+template <int A, int JN>
+__device__ __forceinline__ void d2_mfma(const f32x4 (&aS)[A], const f32x4 (&aR)[2], const f32x4 (&bq)[2], const f32x4& bo, const RUnits& U,
+                                        UAcc2<A>& u) {
+#pragma unroll
+    for (int j = 0; j < JN; ++j)
+#pragma unroll
+        for (int m = 0; m < A; ++m)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) u.S[m][q] = mfma4(aS[m][j], bq[q][j], u.S[m][q]);
+    if (U.v0) {
+#pragma unroll
+        for (int j = 0; j < JN; ++j) u.R[0] = mfma4(aR[0][j], bo[j], u.R[0]);
+    }
+    if (U.v1) {
+#pragma unroll
+        for (int j = 0; j < JN; ++j) u.R[1] = mfma4(aR[1][j], bo[j], u.R[1]);
+    }
+}
+template <int A>
+__device__ __forceinline__ void d2_mfma_rem(const f32x4 (&aS)[A], const f32x4 (&aR)[2], const f32x4 (&bq)[2], const f32x4& bo, const RUnits& U,
+                                            int rem, UAcc2<A>& u) {
+    if (rem == 4) d2_mfma<A, 4>(aS, aR, bq, bo, U, u);
+    else if (rem == 3) d2_mfma<A, 3>(aS, aR, bq, bo, U, u);
+    else if (rem == 2) d2_mfma<A, 2>(aS, aR, bq, bo, U, u);
+    else d2_mfma<A, 1>(aS, aR, bq, bo, U, u);
+}
+// u += A(image) * B(LDS image) over KG k-groups, the last one with `rem` k-steps (structure of dealt_gemm)
+template <int A>
+__device__ __forceinline__ void d2_gemm(const DRs& R, const TileOff2<A>& T, unsigned img, int KG, int rem, const RUnits& U,
+                                        const f32x4* __restrict__ bimg, int lane, f32x4 (&aS0)[A], f32x4 (&aR0)[2], UAcc2<A>& u) {
+    f32x4 aS1[A], aR1[2], bq0[2], bq1[2], bo0, bo1;
+    d2_load_b(bimg, 0, U.q, lane, bq0, bo0);
+    const int KGf = KG - 1;
+    int kg = 0;
+#pragma clang loop unroll(disable)
+    for (; kg + 2 <= KGf; kg += 2) {
+        d2_load_a<A>(R, T, img, kg + 1, aS1, aR1);
+        d2_load_b(bimg, kg + 1, U.q, lane, bq1, bo1);
+        d2_mfma<A, 4>(aS0, aR0, bq0, bo0, U, u);
+        d2_load_a<A>(R, T, img, kg + 2, aS0, aR0);
+        d2_load_b(bimg, kg + 2, U.q, lane, bq0, bo0);
+        d2_mfma<A, 4>(aS1, aR1, bq1, bo1, U, u);
+    }
+    if (kg < KGf) {
+        d2_load_a<A>(R, T, img, KG - 1, aS1, aR1);
+        d2_load_b(bimg, KG - 1, U.q, lane, bq1, bo1);
+        d2_mfma<A, 4>(aS0, aR0, bq0, bo0, U, u);
+        d2_mfma_rem<A>(aS1, aR1, bq1, bo1, U, rem, u);
+    } else {
+        d2_mfma_rem<A>(aS0, aR0, bq0, bo0, U, rem, u);
+    }
+}
+
+// K-split D-row product by ownership: this wave's partial tiles over its shared k-groups (both sample tiles) go to pw[dm][0..1],
+// the partial over its left-over units' k-groups (sample tile w & 1) to pw[dm][2].  f0 arrives holding the fragments of k-group kgS0.
+template <int A, int DT>
+__device__ __forceinline__ void d2_drow(const DRs& R, const unsigned (&vd)[DT], unsigned img, int kgS0, int KG, int rem, const RUnits& U,
+                                        const UAcc2<A>& x, f32x4 (&f0)[DT], f32x4* __restrict__ pw, int lane) {
+    f32x4 f1[DT], part[DT][2], own[DT];
+#pragma unroll
+    for (int dm = 0; dm < DT; ++dm) {
+        own[dm] = f32x4{0.f, 0.f, 0.f, 0.f};
+        part[dm][0] = part[dm][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int m = 0; m < A + 2; ++m) {
+        f32x4(&cur)[DT] = (m & 1) ? f1 : f0;
+        f32x4(&nxt)[DT] = (m & 1) ? f0 : f1;
+        if (m + 1 < A + 2) {
+            const int kgn = m + 1 < A ? kgS0 + m + 1 : (m + 1 == A ? U.t0 : U.t1);
+#pragma unroll
+            for (int dm = 0; dm < DT; ++dm) nxt[dm] = dloadv(R, vd[dm], img + (unsigned)kgn * 1024u);
+        }
+        if (m < A) {
+            const bool last = kgS0 + m == KG - 1;
+            if (!last || rem == 4) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int dm = 0; dm < DT; ++dm)
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) part[dm][q] = mfma4(cur[dm][j], x.S[m][q][j], part[dm][q]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (j < rem) {
+#pragma unroll
+                        for (int dm = 0; dm < DT; ++dm)
+#pragma unroll
+                            for (int q = 0; q < 2; ++q) part[dm][q] = mfma4(cur[dm][j], x.S[m][q][j], part[dm][q]);
+                    }
+            }
+        } else {
+            const int s = m - A;
+            if (s == 0 ? U.v0 : U.v1) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int dm = 0; dm < DT; ++dm) own[dm] = mfma4(cur[dm][j], x.R[s][j], own[dm]);
+            }
+        }
+    }
+#pragma unroll
+    for (int dm = 0; dm < DT; ++dm) {
+        pw[(dm * 3 + 0) * 64 + lane] = part[dm][0];
+        pw[(dm * 3 + 1) * 64 + lane] = part[dm][1];
+        pw[(dm * 3 + 2) * 64 + lane] = own[dm];
+    }
+}
+// the owner of sample tile q adds the partial tiles of one D tile: the four waves' shared parts in wave order, then the left-over
+// parts of the waves whose units belong to sample tile q (waves q and q + 2)
+template <int DT>
+__device__ __forceinline__ f32x4 d2_reduce(const f32x4* __restrict__ pbuf, int dm, int q, int lane, f32x4 v) {
+#pragma unroll
+    for (int w = 0; w < 4; ++w) v += pbuf[((w * DT + dm) * 3 + q) * 64 + lane];
+    v += pbuf[((q * DT + dm) * 3 + 2) * 64 + lane];
+    v += pbuf[(((q + 2) * DT + dm) * 3 + 2) * 64 + lane];
+    return v;
+}
+
+template <int A>
+__device__ __forceinline__ void u2_fill(UAcc2<A>& u, const f32x4 (&vS)[A], const f32x4 (&vR)[2]) {
+#pragma unroll
+    for (int m = 0; m < A; ++m) { u.S[m][0] = vS[m]; u.S[m][1] = vS[m]; }
+    u.R[0] = vR[0]; u.R[1] = vR[1];
+}
+template <int A>
+__device__ __forceinline__ void u2_zero(UAcc2<A>& u) {
+#pragma unroll
+    for (int m = 0; m < A; ++m) { u.S[m][0] = f32x4{0.f, 0.f, 0.f, 0.f}; u.S[m][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    u.R[0] = f32x4{0.f, 0.f, 0.f, 0.f}; u.R[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+template <int A>
+__device__ __forceinline__ void u2_mfma_fence(UAcc2<A>& u) {
+#pragma unroll
+    for (int m = 0; m < A; ++m) mfma_results_fence(u.S[m][0], u.S[m][1], u.R[0], u.R[1]);
+}
+
+// One dynamics evaluation for a 32-sample super-tile (two hidden layers).  HOIST: c = W_N^T eps arrives parked in cP (taken once
+// per super-tile); otherwise it is taken here, per evaluation (the instances whose accumulation registers do not hold it).
+template <int A, int ZR, int ACT, bool HOIST>
+__device__ __forceinline__ void coopd2_eval(const DRs& R, const float* __restrict__ CV, const DImg& Gin, f32x4* __restrict__ xbuf,
+                                            f32x4* __restrict__ zbuf, const f32x4* __restrict__ ebuf, f32x4* __restrict__ pbuf,
+                                            const f32x4* __restrict__ ybuf, int lane, int wave, float t, bool autonomous, bool reg_z, bool reg_j,
+                                            const float (&zs)[ZR], float (&zd)[ZR], float& ld, float& ed, float& nd,
+                                            float* __restrict__ gout, const UAcc2<A>& cP, f32x4 (&aS)[A], f32x4 (&aR)[2]) {
+    constexpr int DT = ZR / 4;
+    static_assert(ZR % 4 == 0, "state registers in whole M-tiles");
+    int opq = 0;
+    asm volatile("" : "+s"(opq));
+    DImg G = Gin;
+    G.f1z += opq; G.fh += opq; G.fN += opq; G.bN += opq; G.bh += opq; G.b1 += opq; G.f1y += opq;
+    const float* __restrict__ P = CV - G.v_b1;
+    const int g = lane >> 4;
+    const bool owner = wave < 2;
+    const RUnits U = runits(A, G.b, wave);
+    const int mtS0 = wave * A;
+    const unsigned F1Z = (unsigned)G.f1z * 4u, FH = (unsigned)G.fh * 4u, FN = (unsigned)G.fN * 4u, BN = (unsigned)G.bN * 4u,
+                   BH = (unsigned)G.bh * 4u, B1 = (unsigned)G.b1 * 4u;
+    UAcc2<A> acc, h, d0;   // d0: act'_1 of this wave's units, parked
+    const TileOff2<A> TZ = tile_offsets2<A>(R, G.KPZ, mtS0, U);
+    const TileOff2<A> TH = tile_offsets2<A>(R, G.HTP, mtS0, U);
+    unsigned vd[DT];
+#pragma unroll
+    for (int dm = 0; dm < DT; ++dm) { vd[dm] = R.lane16 + (unsigned)(dm * G.HTP) * 1024u; asm volatile("" : "+v"(vd[dm])); }
+    auto cvec_units = [&](const float* __restrict__ vec, f32x4 (&vS)[A], f32x4 (&vR)[2]) {
+#pragma unroll
+        for (int m = 0; m < A; ++m) vS[m] = *reinterpret_cast<const f32x4*>(vec + ((mtS0 + m) * 4 + g) * 4);
+        vR[0] = *reinterpret_cast<const f32x4*>(vec + (U.t0 * 4 + g) * 4);
+        vR[1] = *reinterpret_cast<const f32x4*>(vec + (U.t1 * 4 + g) * 4);
+    };
+    auto publish = [&](const UAcc2<A>& v) {
+#pragma unroll
+        for (int m = 0; m < A; ++m) {
+            xbuf[((mtS0 + m) * 2 + 0) * 64 + lane] = v.S[m][0];
+            xbuf[((mtS0 + m) * 2 + 1) * 64 + lane] = v.S[m][1];
+        }
+        if (U.v0) xbuf[(U.t0 * 2 + U.q) * 64 + lane] = v.R[0];
+        if (U.v1) xbuf[(U.t1 * 2 + U.q) * 64 + lane] = v.R[1];
+    };
+    // ---- layer 1 ----
+    {
+        f32x4 bS[A], bR[2], wS[A], wR[2];
+        cvec_units(P + G.v_b1, bS, bR);
+        cvec_units(P + G.v_w1t, wS, wR);
+        if (owner) {
+#pragma unroll
+            for (int kg = 0; kg < DT; ++kg) {
+                f32x4 v;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = zs[4 * kg + j];
+                zbuf[(kg * 2 + wave) * 64 + lane] = v;
+            }
+        }
+        if (!autonomous) {
+#pragma unroll
+            for (int m = 0; m < A; ++m) bS[m] = tile_fma(wS[m], t, bS[m]);
+            bR[0] = tile_fma(wR[0], t, bR[0]);
+            bR[1] = tile_fma(wR[1], t, bR[1]);
+        }
+        u2_fill<A>(acc, bS, bR);
+        __syncthreads();
+        d2_gemm<A>(R, TZ, F1Z, G.KGZ, G.remZ, U, zbuf, lane, aS, aR, acc);
+        if (G.remC > 0) {
+            const TileOff2<A> TC = tile_offsets2<A>(R, G.KPC, mtS0, U);
+            d2_load_a<A>(R, TC, (unsigned)G.f1y * 4u, 0, aS, aR);
+            d2_gemm<A>(R, TC, (unsigned)G.f1y * 4u, 1, G.remC, U, ybuf, lane, aS, aR, acc);
+        }
+    }
+    // ---- hidden layer 1: publish h_1, park act'_1; hidden layer 2 ----
+    d2_load_a<A>(R, TH, FH, 0, aS, aR);
+#pragma unroll
+    for (int m = 0; m < A; ++m)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            f32x4 dd;
+            act_pair<ACT>(acc.S[m][q], h.S[m][q], dd);
+            d0.S[m][q] = park4(dd);
+        }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        f32x4 dd;
+        act_pair<ACT>(acc.R[s], h.R[s], dd);
+        d0.R[s] = park4(dd);
+    }
+    publish(h);
+    {
+        f32x4 bS[A], bR[2];
+        cvec_units(P + G.v_bh, bS, bR);
+        u2_fill<A>(acc, bS, bR);
+    }
+    __syncthreads();
+    d2_gemm<A>(R, TH, FH, G.KGH, G.remH, U, xbuf, lane, aS, aR, acc);
+    f32x4 fd[DT];
+#pragma unroll
+    for (int dm = 0; dm < DT; ++dm) fd[dm] = dloadv(R, vd[dm], FN + (unsigned)mtS0 * 1024u);
+#pragma unroll
+    for (int m = 0; m < A; ++m)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) h.S[m][q] = act_only<ACT>(acc.S[m][q]);
+    h.R[0] = act_only<ACT>(acc.R[0]);
+    h.R[1] = act_only<ACT>(acc.R[1]);
+    // ---- zdot: partials over this wave's own k-groups, from registers ----
+    f32x4* __restrict__ pw = pbuf + (wave * DT) * 3 * 64;
+    if (G.xalias) __syncthreads();
+    d2_drow<A, DT>(R, vd, FN, mtS0, G.KGH, G.remH, U, h, fd, pw, lane);
+    if constexpr (HOIST) {
+        d2_load_a<A>(R, TH, BH, 0, aS, aR);   // the pullback's first product
+#pragma unroll
+        for (int m = 0; m < A; ++m)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) h.S[m][q] = unpark4(cP.S[m][q]) * dact_from_h<ACT>(h.S[m][q]);
+        h.R[0] = unpark4(cP.R[0]) * dact_from_h<ACT>(h.R[0]);
+        h.R[1] = unpark4(cP.R[1]) * dact_from_h<ACT>(h.R[1]);
+    } else {
+        // c = W_N^T eps of this wave's units, per evaluation; delta_2 = c .* act'_2 with act'_2 rebuilt from h_2
+        d2_load_a<A>(R, TZ, BN, 0, aS, aR);
+        u2_zero<A>(acc);
+        d2_gemm<A>(R, TZ, BN, G.KGZ, G.remZ, U, ebuf, lane, aS, aR, acc);
+        d2_load_a<A>(R, TH, BH, 0, aS, aR);
+#pragma unroll
+        for (int m = 0; m < A; ++m)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) h.S[m][q] = acc.S[m][q] * dact_from_h<ACT>(h.S[m][q]);
+        h.R[0] = acc.R[0] * dact_from_h<ACT>(h.R[0]);
+        h.R[1] = acc.R[1] * dact_from_h<ACT>(h.R[1]);
+    }
+    __syncthreads();
+    ed = 0.f;
+    if (owner) {
+        f32x4 zacc[DT];
+#pragma unroll
+        for (int dm = 0; dm < DT; ++dm)
+            zacc[dm] = d2_reduce<DT>(pbuf, dm, wave, lane, *reinterpret_cast<const f32x4*>(P + G.v_bN + (dm * 4 + g) * 4));
+#pragma unroll
+        for (int s = 0; s < ZR; ++s) zd[s] = zacc[s >> 2][s & 3];
+        if (reg_z) {
+            float e2 = 0.f;
+#pragma unroll
+            for (int s = 0; s < ZR; ++s) e2 = fmaf(zd[s], zd[s], e2);
+            ed = sqrtf(group_sum(e2));   // Edot = |zdot|_2   (src/core/icnf.jl:184-199)
+        }
+    }
+    // ---- pullback: delta_2 into the exchange buffer (h_1's readers passed the barrier above), u_1 = W_2^T delta_2 ----
+    if (G.xalias) __syncthreads();   // the owners have read the zdot partials out of this buffer
+    publish(h);
+    u2_zero<A>(acc);
+    __syncthreads();
+    d2_gemm<A>(R, TH, BH, G.KGH, G.remH, U, xbuf, lane, aS, aR, acc);
+#pragma unroll
+    for (int dm = 0; dm < DT; ++dm) fd[dm] = dloadv(R, vd[dm], B1 + (unsigned)mtS0 * 1024u);
+    // delta_1 = u_1 .* act'_1
+#pragma unroll
+    for (int m = 0; m < A; ++m) {
+        f32x4 dd[2] = {unpark4(d0.S[m][0]), unpark4(d0.S[m][1])};
+        tiles_mul<2>(acc.S[m], dd, h.S[m]);
+    }
+    {
+        f32x4 dd[2] = {unpark4(d0.R[0]), unpark4(d0.R[1])};
+        tiles_mul<2>(acc.R, dd, h.R);
+    }
+    // ---- g = W_1[:,0:D]^T delta_1 = eps^T J: partials from registers ----
+    if (G.xalias) __syncthreads();
+    d2_drow<A, DT>(R, vd, B1, mtS0, G.KGH, G.remH, U, h, fd, pw, lane);
+    d2_load_a<A>(R, TZ, F1Z, 0, aS, aR);   // the next evaluation's layer-1 fragments
+    __syncthreads();
+    ld = 0.f; nd = 0.f;
+    if (owner) {
+        float dot = 0.f, n2 = 0.f;
+#pragma unroll
+        for (int dm = 0; dm < DT; ++dm) {
+            const f32x4 ga = d2_reduce<DT>(pbuf, dm, wave, lane, f32x4{0.f, 0.f, 0.f, 0.f});
+            const f32x4 ev = ebuf[(dm * 2 + wave) * 64 + lane];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                dot = fmaf(ga[j], ev[j], dot);   // <eps^T J, eps>
+                n2 = fmaf(ga[j], ga[j], n2);
+                if (gout) gout[4 * dm + j] = ga[j];
+            }
+        }
+        ld = -group_sum(dot);
+        nd = reg_j ? sqrtf(group_sum(n2)) : 0.f;   // ndot = |eps^T J|_2 (src/core/icnf.jl:229-245)
+    }
+}
+
+constexpr int coopd2_lds_bytes(int HT, int DT, bool alias, int cvn, bool cond) {
+    return (HT * 2 * 64 + 2 * DT * 2 * 64 + (alias ? 0 : 4 * DT * 3 * 64) + (cond ? 2 * 64 : 0)) * 16 + (cvn + 3) / 4 * 16;
+}
+
+template <int A, int ZR, int ACT, bool HOIST>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+coopd2_solve_kernel(DArgs da) {
+    const KArgs& a = da.k;
+    const DImg& G = da.g;
+    constexpr int DT = ZR / 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int HT = 4 * A + G.b;
+    f32x4* xbuf = reinterpret_cast<f32x4*>(smem);      // [HT][2 sample tiles][64 lanes]
+    f32x4* zbuf = xbuf + HT * 2 * 64;                   // [DT][2][64]
+    f32x4* ebuf = zbuf + DT * 2 * 64;                   // [DT][2][64]
+    f32x4* pbuf = G.xalias ? xbuf : ebuf + DT * 2 * 64; // [4 waves][DT][3][64] partial tiles of the D-row products
+    f32x4* ybuf = ebuf + DT * 2 * 64 + (G.xalias ? 0 : 4 * DT * 3 * 64);   // [2][64]: conditions
+    float* cbuf = reinterpret_cast<float*>(ybuf + (G.remC > 0 ? 2 * 64 : 0));
+    for (int i = threadIdx.x; i < G.cvn; i += 256) cbuf[i] = a.packed[G.v_b1 + i];
+    const int lane = threadIdx.x & 63, g = lane >> 4, n = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool owner = wave < 2;
+    const int D = a.D, S = D + 3;
+    const bool reg_z = a.reg_z, reg_j = a.reg_j, autonomous = a.autonomous;
+    const long long nst = (a.B + 31) / 32;
+    DRs R{__builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.packed), 0, 0x7fffffff, 0x00020000), (unsigned)lane * 16u};
+
+    for (long long st = blockIdx.x; st < nst; st += gridDim.x) {
+        const long long smp = st * 32 + (owner ? wave : 0) * 16 + n;
+        const bool valid = owner && smp < a.B;
+        const long long sc = smp < a.B ? smp : a.B - 1;
+        float zs[ZR], zp[ZR], pk[5][ZR];   // stage state; z and the running sums, parked (owner waves)
+        float lacc = 0.f, eacc = 0.f, nacc = 0.f;
+        __syncthreads();   // the previous super-tile's readers of the LDS images are done
+#pragma unroll
+        for (int kg = 0; kg < DT; ++kg) {
+            f32x4 v;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int s = 4 * kg + j, f = 4 * s + g;
+                if (a.x) zs[s] = f < a.nvars ? a.x[sc * a.nvars + f] : 0.f;
+                else zs[s] = f < D ? a.u0[sc * S + f] : 0.f;
+                zp[s] = park(zs[s]);
+                v[j] = f < D ? a.eps[sc * D + f] : 0.f;
+            }
+            if (owner) ebuf[(kg * 2 + wave) * 64 + lane] = v;
+        }
+        if (G.remC > 0 && owner) {
+            f32x4 v;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const int f = 4 * j + g; v[j] = f < a.C ? a.ys[sc * a.C + f] : 0.f; }
+            ybuf[wave * 64 + lane] = v;
+        }
+        if (!a.x) { lacc = a.u0[sc * S + D]; eacc = a.u0[sc * S + D + 1]; nacc = a.u0[sc * S + D + 2]; }
+        UAcc2<A> cP;
+        f32x4 aS[A], aR[2];
+        {
+            const RUnits U = runits(A, G.b, wave);
+            const TileOff2<A> TZ = tile_offsets2<A>(R, G.KPZ, wave * A, U);
+            if constexpr (HOIST) {
+                __syncthreads();
+                UAcc2<A> acc;
+                u2_zero<A>(acc);
+                d2_load_a<A>(R, TZ, (unsigned)G.bN * 4u, 0, aS, aR);
+                d2_gemm<A>(R, TZ, (unsigned)G.bN * 4u, G.KGZ, G.remZ, U, ebuf, lane, aS, aR, acc);
+                u2_mfma_fence<A>(acc);
+#pragma unroll
+                for (int m = 0; m < A; ++m) { cP.S[m][0] = park4(acc.S[m][0]); cP.S[m][1] = park4(acc.S[m][1]); }
+                cP.R[0] = park4(acc.R[0]); cP.R[1] = park4(acc.R[1]);
+            }
+            d2_load_a<A>(R, TZ, (unsigned)G.f1z * 4u, 0, aS, aR);
+        }
+
+        float zd[ZR], ld = 0.f, ed = 0.f, nd = 0.f;
+#pragma unroll
+        for (int s = 0; s < ZR; ++s) zd[s] = 0.f;
+        const float dt0 = a.dt;
+        const bool single = a.nsteps == 0;
+        const int ns = single ? 1 : (a.T.ns < 6 ? a.T.ns : 6);
+        const int nsteps = single ? 1 : a.nsteps;
+        const long long cktile = st * 2 + (owner ? wave : 0), ckntp = nst * 2;
+        const int ckzr = G.ckzr;
+#pragma clang loop unroll(disable)
+        for (int step = 0; step < nsteps; ++step) {
+            const float tn = a.tgrid ? a.tgrid[step] : a.t0 + (float)step * dt0;
+            const float dt = a.tgrid ? a.tgrid[step + 1] - tn : dt0;
+            if (a.ckpt && !single && owner) {
+                float* c = a.ckpt + (((long long)step * ckntp + cktile) * 64 + lane) * ckzr;
+#pragma unroll
+                for (int s = 0; s < ZR; ++s) c[s] = zs[s];
+                for (int s = ZR; s < ckzr; ++s) c[s] = 0.f;
+            }
+            float lsum = 0.f, esum = 0.f, nsum = 0.f;
+#pragma clang loop unroll(disable)
+            for (int sg = 0; sg < ns; ++sg) {
+                const long long ckrow = ((((long long)step * ns + sg) * ckntp + cktile) * 64 + lane) * ckzr;
+                float* gout = (a.ckpt_g && !single && owner) ? a.ckpt_g + ckrow : nullptr;
+                coopd2_eval<A, ZR, ACT, HOIST>(R, cbuf, G, xbuf, zbuf, ebuf, pbuf, ybuf, lane, wave, tn + a.T.c[sg] * dt, autonomous, reg_z, reg_j,
+                                               zs, zd, ld, ed, nd, gout, cP, aS, aR);
+                if (gout)
+                    for (int s = ZR; s < ckzr; ++s) gout[s] = 0.f;
+                if (a.ckpt_k && !single && owner) {
+                    float* c = a.ckpt_k + ckrow;
+#pragma unroll
+                    for (int s = 0; s < ZR; ++s) c[s] = zd[s];
+                    for (int s = ZR; s < ckzr; ++s) c[s] = 0.f;
+                }
+                const float bst = a.T.b[sg];
+                lsum = fmaf(bst, ld, lsum); esum = fmaf(bst, ed, esum); nsum = fmaf(bst, nd, nsum);
+                if (single) break;
+                if (owner) {
+                    // running sums (parked rows pk[0..3] = P_1 .. P_4, pk[4] = the step sum), as cnf_coop_d.hip
+                    const float c0 = a.acol[sg][0], c1 = a.acol[sg][1], c2 = a.acol[sg][2], c3 = a.acol[sg][3], c4 = a.acol[sg][4];
+                    const bool first = sg == 0, lastst = sg == ns - 1;
+#pragma unroll
+                    for (int s = 0; s < ZR; ++s) {
+                        const float k = zd[s];
+                        const float o1 = first ? 0.f : unpark(pk[0][s]), o2 = first ? 0.f : unpark(pk[1][s]),
+                                    o3 = first ? 0.f : unpark(pk[2][s]), o4 = first ? 0.f : unpark(pk[3][s]),
+                                    os = first ? 0.f : unpark(pk[4][s]);
+                        const float zz = unpark(zp[s]);
+                        const float p0 = fmaf(c0, k, o1);
+                        pk[0][s] = park(fmaf(c1, k, o2));
+                        pk[1][s] = park(fmaf(c2, k, o3));
+                        pk[2][s] = park(fmaf(c3, k, o4));
+                        pk[3][s] = park(c4 * k);
+                        const float nsu = fmaf(bst, k, os);
+                        pk[4][s] = park(nsu);
+                        zs[s] = fmaf(dt, p0, zz);
+                        if (lastst) { const float zn = fmaf(dt, nsu, zz); zp[s] = park(zn); zs[s] = zn; }
+                    }
+                }
+            }
+            if (single) break;
+            lacc = fmaf(dt, lsum, lacc); eacc = fmaf(dt, esum, eacc); nacc = fmaf(dt, nsum, nacc);
+        }
+        if (a.ckpt && !single && owner) {
+            float* c = a.ckpt + (((long long)nsteps * ckntp + cktile) * 64 + lane) * ckzr;
+#pragma unroll
+            for (int s = 0; s < ZR; ++s) c[s] = zs[s];
+            for (int s = ZR; s < ckzr; ++s) c[s] = 0.f;
+        }
+        if (single) {
+            if (valid) {
+#pragma unroll
+                for (int s = 0; s < ZR; ++s) { const int f = 4 * s + g; if (f < D) a.u_out[smp * S + f] = zd[s]; }
+                if (g == 0) { a.u_out[smp * S + D] = ld; a.u_out[smp * S + D + 1] = ed; a.u_out[smp * S + D + 2] = nd; }
+            }
+            continue;
+        }
+        // ---- epilogue: inference_sol (src/core/base_icnf.jl:158-172) ----
+        float ss = 0.f, sa = 0.f;
+#pragma unroll
+        for (int s = 0; s < ZR; ++s) {
+            const int f = 4 * s + g;
+            const float v2 = zs[s] * zs[s];
+            ss += v2;
+            if (f >= a.nvars) sa += v2;
+        }
+        ss = group_sum(ss);
+        sa = group_sum(sa);
+        if (valid) {
+            if (a.u_out) {
+#pragma unroll
+                for (int s = 0; s < ZR; ++s) { const int f = 4 * s + g; if (f < D) a.u_out[smp * S + f] = zs[s]; }
+                if (g == 0) { a.u_out[smp * S + D] = lacc; a.u_out[smp * S + D + 1] = eacc; a.u_out[smp * S + D + 2] = nacc; }
+            }
+            if (g == 0) {
+                if (a.logp) a.logp[smp] = (-0.5f * (float)D * kLog2Pi - 0.5f * ss) - lacc;
+                if (a.regs) {
+                    a.regs[smp] = eacc;
+                    a.regs[a.B + smp] = nacc;
+                    a.regs[2 * a.B + smp] = a.reg_aug ? sqrtf(sa) : 0.f;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------
+template <int A, int ZR, int ACT, bool HOIST>
+static hipError_t launch_coopd2(const DArgs& a, int lds, int nblocks, hipStream_t st) {
+    auto kern = coopd2_solve_kernel<A, ZR, ACT, HOIST>;
+    static DeviceOnce once;
+    int dev = 0;
+    hipError_t e0 = hipGetDevice(&dev);
+    if (e0 != hipSuccess) return e0;
+    if (!once.done(dev)) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        once.set(dev);
+    }
+    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(256), lds, st, a);
+    return hipGetLastError();
+}
+
+struct CoopD2Inst {
+    int A, ZR, ACT;
+    hipError_t (*fn)(const DArgs&, int, int, hipStream_t);
+};
+// c = W_N^T eps is hoisted where the accumulation registers hold it beside act'_1 and the seven state rows:
+// (8 A + 8) x 2 + 7 ZR <= 256
+#define CD2_INST(A, ZR, ACT) CoopD2Inst { A, ZR, ACT, &launch_coopd2<A, ZR, ACT, ((8 * A + 8) * 2 + 7 * ZR <= 250)> }
+#define CD2_SHAPES(ACT) CD2_INST(4, 16, ACT), CD2_INST(4, 20, ACT), CD2_INST(5, 20, ACT), CD2_INST(5, 24, ACT), CD2_INST(6, 24, ACT)
+static const CoopD2Inst kCoopD2[] = {
+    CD2_SHAPES(CNF_ACT_SOFTPLUS),
+};
+static const CoopD2Inst* cd2_find(int HT_real, int KZ, int ACT) {
+    const int A = HT_real / 4;
+    const CoopD2Inst* best = nullptr;
+    for (const CoopD2Inst& c : kCoopD2) {
+        const bool act_ok = c.ACT == ACT || (c.ACT == CNF_ACT_TANH_PRESCALED && ACT == CNF_ACT_TANH);
+        if (c.A == A && c.ZR >= KZ && act_ok && (!best || c.ZR < best->ZR)) best = &c;
+    }
+    return best;
+}
+
+bool coopd2_supported(int HT_real, int L, int KZ, int ACT, int C) {
+    if (L != 2 || C < 0 || C > 16) return false;
+    return cd2_find(HT_real, KZ, ACT) != nullptr;
+}
+
+// `a` arrives with the image view filled in by coopd_launch (cnf_coop_d.hip); the LDS decision is made here
+hipError_t coopd2_launch(int HT_real, int L, int KZ, int ACT, DArgs& a, int num_cus, hipStream_t st) {
+    const CoopD2Inst* c = cd2_find(HT_real, KZ, ACT);
+    if (!c || L != 2) return hipErrorNotSupported;
+    const int DT = c->ZR / 4;
+    // the instance's state registers must not read image k-groups the plan's layout does not have
+    if (DT > a.g.KPZ) return hipErrorNotSupported;
+    a.g.xalias = coopd2_lds_bytes(HT_real, DT, false, a.g.cvn, a.k.C > 0) <= 160 * 1024 ? 0 : 1;
+    const int lds = coopd2_lds_bytes(HT_real, DT, a.g.xalias != 0, a.g.cvn, a.k.C > 0);
+    if (lds > 160 * 1024 || (a.g.xalias && 4 * DT * 3 > HT_real * 2)) return hipErrorNotSupported;
+    const long long nst = (a.k.B + 31) / 32;
+    const int nblocks = (int)(nst < num_cus ? nst : num_cus);
+    return c->fn(a, lds, nblocks, st);
+}
+
+}  // namespace cnf

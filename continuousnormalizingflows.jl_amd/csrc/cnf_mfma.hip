@@ -436,7 +436,11 @@ static bool plan_uses_coopd(const MfmaPlan* p, long long B) {
 
 long long mfma_plan_ckpt_tiles(const MfmaPlan* p, long long B, bool on_grid) {
     (void)plan_ensure_cus(const_cast<MfmaPlan*>(p));   // (the batch threshold of the dealt kernel counts compute units)
-    if (plan_uses_coopd(p, B)) return (B + 63) / 64 * 4;
+    if (plan_uses_coopd(p, B)) {
+        int hmax = 0;
+        for (int l = 1; l < p->cfg.n_layers; ++l) hmax = p->cfg.widths[l] > hmax ? p->cfg.widths[l] : hmax;
+        return coopd_supertile(hmax, p->cfg.nvars + p->cfg.naug, p->L, p->ACT, 0) == 64 ? (B + 63) / 64 * 4 : (B + 31) / 32 * 2;
+    }
     const bool x = p->kind == 2 || on_grid || !coop_ckpt_supported(p->HT, p->L, p->ZR, p->ACT);   // which kernel checkpoints: see mfma_solve
     return x ? (B + 31) / 32 * 2 : (B + 63) / 64 * 4;
 }

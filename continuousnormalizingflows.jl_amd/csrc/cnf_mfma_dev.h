@@ -96,6 +96,7 @@ hipError_t coopx_launch_exact(int HT, int L, int ZR, int CR, int ACT, const KArg
 // the cooperative kernel with its tiles dealt exactly over four owner waves (cnf_coop_d.hip): one-probe VJP solves of extended-kernel
 // plans, on the plan's own image (layout MfmaLayout(HT_lay, L, ZR_lay, 0, true)); H / D = the configuration's widest hidden layer / state rows
 bool coopd_supported(int H, int D, int L, int ACT, int HT_lay, int ZR_lay, int exact, int C);   // exact: the TestMode form (two hidden layers, Q product)
+int coopd_supertile(int H, int D, int L, int ACT, int exact);   // 64 or 32 samples per super-tile (the checkpoint arrays' tile count)
 hipError_t coopd_launch(int H, int D, int L, int ACT, int HT_lay, int ZR_lay, int CR_lay, const KArgs& a, int num_cus, hipStream_t st);
 // the same kernel with ONE sample tile per workgroup and the images in LDS: the tile-split form for small batches
 bool coop_split_supported(int HT, int L, int ZR, int ACT);

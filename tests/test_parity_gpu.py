@@ -198,6 +198,13 @@ COOPD_CASES = [
     (dict(nvars=30, naug=2, hidden=[144, 144, 144], reg_aug=True), 64, 1, 3),                                 # 9 tiles, D = 32 exactly
     (dict(nvars=12, hidden=[160, 160, 150], act=2, reg_j=True), 50, 0, 4),                                    # softplus, three layers, unequal widths
     (dict(nvars=40, hidden=[232, 232]), 45, 1, 4),                                                            # tanh, D = 40, 15 tiles (an extended-kernel plan)
+    # 16 .. 24 hidden tiles: the 32-sample form (csrc/cnf_coop_d2.hip) - the default architecture at nvariables = 30 .. 47
+    (dict(nvars=30, naug=31, hidden=[248, 248], act=2, reg_z=True, reg_j=True, reg_aug=True), 100, 1, 4),    # ICNF(nvariables = 30): 16 tiles (A = 4, b = 0), D = 61
+    (dict(nvars=32, naug=33, hidden=[264, 264], act=2, reg_z=True, reg_j=True, reg_aug=True), 70, 0, 4),     # nvariables = 32: 17 tiles (one left-over tile: 2 units on waves 0, 1), D = 65
+    (dict(nvars=36, naug=37, hidden=[296, 296], act=2, reg_z=True, reg_j=True, reg_aug=True), 45, 1, 3),     # 19 tiles (b = 3: six left-over units), D = 73
+    (dict(nvars=43, naug=44, hidden=[352, 352], act=2, reg_j=True), 40, 0, 3),                                # nvariables = 43 (MiniBooNE's dimension): 22 tiles, D = 87: c per evaluation
+    (dict(nvars=47, naug=48, hidden=[384, 384], act=2, reg_z=True, reg_j=True, reg_aug=True), 33, 1, 2),     # the largest: 24 x 24 tiles
+    (dict(nvars=30, naug=31, ncond=6, hidden=[248, 248], act=2, reg_z=True, reg_j=True, reg_aug=True), 50, 1, 3),   # conditioned, 16 tiles (wider conditioned flows have no fused plan)
     # conditioned flows (CondICNF: the condition rows of layer 1, src/layers/cond_layer.jl:7-31, src/core/base_icnf.jl:272-296)
     (dict(nvars=16, naug=17, ncond=5, hidden=[156, 156], act=2, reg_z=True, reg_j=True, reg_aug=True), 120, 1, 5),   # default architecture with 5 conditions: 10 tiles
     (dict(nvars=20, naug=21, ncond=16, hidden=[232, 232], act=2, autonomous=True), 64, 0, 4),                # 16 conditions, D = 41, 15 tiles, autonomous
@@ -234,8 +241,9 @@ def test_dealt_cooperative_kernel_matches_the_oracles(kw, B, alg, nsteps, pkg, o
         gen = (pkg.generate(icnf, mode, *(((dev(ys),) if spec.ncond else ()) + (dev(p), {}, B)), z0=dev(out[tag][2][:spec.D]), eps=dev(eps))
                if spec.mode == 0 else dev(xs))
         out[tag] += (gen.cpu().numpy(),)
-    assert np.max(np.abs(out["dealt"][0] - out["extended"][0])) < 5e-5
-    assert np.max(np.abs(out["dealt"][2] - out["extended"][2])) < 5e-5
+    tol = 5e-5 + 2e-6 * float(np.abs(out["extended"][0]).max())       # (|logp| ~ 150 at D = 73 has a Float32 ulp of 1.5e-5)
+    assert np.max(np.abs(out["dealt"][0] - out["extended"][0])) < tol
+    assert np.max(np.abs(out["dealt"][2] - out["extended"][2])) < tol
     assert np.max(np.abs(out["dealt"][3] - out["extended"][3])) < 5e-5
 
 
@@ -304,6 +312,8 @@ def test_adaptive_solvers_on_the_dealt_kernel(solver, pkg, oracles, monkeypatch)
     (dict(nvars=18, naug=19, hidden=[152, 152], act=2), (0.0, 0.0, 0.0), 100, 1, 3, True),      # on a non-uniform grid (device-resident step times)
     (dict(nvars=16, naug=17, ncond=5, hidden=[156, 156], act=2, reg_z=True, reg_j=True, reg_aug=True), (0.01, 0.01, 0.01), 90, 1, 2, False),   # conditioned
     (dict(nvars=20, hidden=[200, 200, 200], reg_z=True, reg_j=True), (0.02, 0.03, 0.0), 70, 0, 2, False),      # a cooperative (tanh, 3-layer) plan's forward on the dealt kernel
+    (dict(nvars=32, naug=33, hidden=[264, 264], act=2, reg_z=True, reg_j=True, reg_aug=True), (0.01, 0.01, 0.01), 60, 1, 2, False),   # the 32-sample form (17 tiles)
+    (dict(nvars=40, naug=41, hidden=[328, 328], act=2), (0.0, 0.0, 0.0), 40, 0, 2, True),                        # ... 21 tiles, on a grid
 ])
 def test_cooperative_gradient_on_the_dealt_forward_solve(kw, lam, B, alg, nsteps, grid, pkg, oracles, monkeypatch):
     """The checkpointing forward half of the cooperative gradient on the dealt kernel (z per step, zdot and g = eps^T J per stage in
@@ -317,7 +327,7 @@ def test_cooperative_gradient_on_the_dealt_forward_solve(kw, lam, B, alg, nsteps
     icnf = make_icnf(pkg, spec, alg, nsteps, lambdas=lam)
     tg = None
     if grid:
-        tg = np.cumsum([0.0, 0.13, 0.31, 0.2, 0.36]).astype(np.float32)
+        tg = np.cumsum([0.0, 0.13, 0.31, 0.2, 0.36] if B > 50 else [0.0, 0.4, 0.6]).astype(np.float32)
         tg[-1] = 1.0
         nsteps = len(tg) - 1
     L, gref, gxref = o64.loss_and_grad(spec, p, xs, 0.0, 1.0, nsteps, alg, eps, ys, lam, wrt_x=True, tgrid=None if tg is None else [float(v) for v in tg])
