@@ -593,7 +593,7 @@ struct CoopD2Inst {
 };
 // c = W_N^T eps is hoisted where the accumulation registers hold it beside act'_1 and the seven state rows:
 // (8 A + 8) x 2 + 7 ZR <= 256
-#define CD2_INST(A, ZR, ACT) CoopD2Inst { A, ZR, ACT, &launch_coopd2<A, ZR, ACT, ((8 * A + 8) * 2 + 7 * ZR <= 250)> }
+#define CD2_INST(A, ZR, ACT) CoopD2Inst { A, ZR, ACT, &launch_coopd2<A, ZR, ACT, ((8 * A + 8) * 2 + 7 * ZR <= 200)> }
 #define CD2_SHAPES(ACT) CD2_INST(4, 16, ACT), CD2_INST(4, 20, ACT), CD2_INST(5, 20, ACT), CD2_INST(5, 24, ACT), CD2_INST(6, 24, ACT)
 static const CoopD2Inst kCoopD2[] = {
     CD2_SHAPES(CNF_ACT_SOFTPLUS),
