@@ -866,18 +866,11 @@ int coopd_supertile(int H, int D, int L, int ACT, int exact) {
     return cd_find(HT_real, L, KZ, ACT, exact ? 1 : 0) ? 64 : 32;
 }
 
-hipError_t coopd_launch(int H, int D, int L, int ACT, int HT_lay, int ZR_lay, int CR_lay, const KArgs& k, int num_cus, hipStream_t st) {
+// the run-time view of a plan's packed image (layout (HT_lay, L, ZR_lay, CR_lay), backward images included) for a configuration with
+// H hidden units and D state rows whose hidden tiles are dealt as 4 A + b
+void dimg_fill(DImg& G, int H, int D, int L, int HT_lay, int ZR_lay, int CR_lay, int A_inst, int C) {
     const int HT_real = (H + 15) / 16, KZ = (D + 3) / 4;
-    const bool exact = k.exact == 1;
-    if (exact && k.q_off <= 0) return hipErrorNotSupported;
-    const CoopDInst* c = cd_find(HT_real, L, KZ, ACT, exact ? 1 : 0);
-    const bool form32 = !c && !exact && coopd2_supported(HT_real, L, KZ, ACT, k.C);
-    if (!c && !form32) return hipErrorNotSupported;
-    const int A_inst = c ? c->A : HT_real / 4;
     const MfmaLayout Y(HT_lay, L, ZR_lay, CR_lay, true);
-    DArgs a{};
-    a.k = k;
-    DImg& G = a.g;
     G.f1z = Y.f1z; G.fh = Y.fh; G.fN = Y.fN; G.bN = Y.bN; G.bh = Y.bh; G.b1 = Y.b1;
     G.v_b1 = Y.v_b1; G.v_w1t = Y.v_w1t; G.v_bh = Y.v_bh; G.v_bN = Y.v_bN;
     G.KPZ = Y.KGZ; G.HTP = Y.HT; G.imgH = MfmaLayout::imgA(Y.HT, Y.HT); G.vecH = MfmaLayout::vecC(Y.HT);
@@ -886,13 +879,28 @@ hipError_t coopd_launch(int H, int D, int L, int ACT, int HT_lay, int ZR_lay, in
     G.KGH = HT_real; G.remH = ksH - 4 * (HT_real - 1);
     G.KGZ = (KZ + 3) / 4; G.remZ = KZ - 4 * (G.KGZ - 1);
     G.ckzr = ZR_lay;
-    G.q_off = exact ? k.q_off : 0;
-    G.f1y = Y.f1y; G.KPC = Y.KGC > 0 ? Y.KGC : 1; G.remC = (k.C + 3) / 4;   // condition k-steps (<= 4)
-    if (k.C > 16 || (k.C > 0 && CR_lay < G.remC)) return hipErrorNotSupported;
+    G.q_off = 0;
+    G.f1y = Y.f1y; G.KPC = Y.KGC > 0 ? Y.KGC : 1; G.remC = (C + 3) / 4;   // condition k-steps (<= 4)
     G.cvn = Y.v_bN + MfmaLayout::vecC(Y.DT) - Y.v_b1;
+    G.xalias = 0;
+}
+
+hipError_t coopd_launch(int H, int D, int L, int ACT, int HT_lay, int ZR_lay, int CR_lay, const KArgs& k, int num_cus, hipStream_t st) {
+    const int HT_real = (H + 15) / 16, KZ = (D + 3) / 4;
+    const bool exact = k.exact == 1;
+    if (exact && k.q_off <= 0) return hipErrorNotSupported;
+    const CoopDInst* c = cd_find(HT_real, L, KZ, ACT, exact ? 1 : 0);
+    const bool form32 = !c && !exact && coopd2_supported(HT_real, L, KZ, ACT, k.C);
+    if (!c && !form32) return hipErrorNotSupported;
+    const int A_inst = c ? c->A : HT_real / 4;
+    DArgs a{};
+    a.k = k;
+    DImg& G = a.g;
+    dimg_fill(G, H, D, L, HT_lay, ZR_lay, CR_lay, A_inst, k.C);
+    G.q_off = exact ? k.q_off : 0;
+    if (k.C > 16 || (k.C > 0 && CR_lay < G.remC)) return hipErrorNotSupported;
     if (form32) return coopd2_launch(HT_real, L, KZ, ACT, a, num_cus, st);
     const int DT = c->ZR / 4;
-    G.cvn = Y.v_bN + MfmaLayout::vecC(Y.DT) - Y.v_b1;
     G.xalias = coopd_lds_bytes(HT_real, L, DT, false, G.cvn, k.C > 0) <= 160 * 1024 ? 0 : 1;
     const int lds = coopd_lds_bytes(HT_real, L, DT, G.xalias != 0, G.cvn, k.C > 0);
     if (lds > 160 * 1024 || (G.xalias && 4 * DT * 4 > (L == 2 ? 1 : 2) * HT_real * 4)) return hipErrorNotSupported;

@@ -125,6 +125,7 @@ __device__ __forceinline__ f32x4 dact_from_h(const f32x4& h) {
 template <int ACT>
 __device__ __forceinline__ void act_pair(const f32x4& a, f32x4& h, f32x4& d) { act_tile<ACT>(a, h, d); }
 
+void dimg_fill(DImg& G, int H, int D, int L, int HT_lay, int ZR_lay, int CR_lay, int A_inst, int C);   // cnf_coop_d.hip
 // host side of the 32-sample form (cnf_coop_d2.hip): (A, ZR) instances for 16 .. 24 hidden tiles
 bool coopd2_supported(int HT_real, int L, int KZ, int ACT, int C);
 hipError_t coopd2_launch(int HT_real, int L, int KZ, int ACT, DArgs& a, int num_cus, hipStream_t st);

@@ -51,6 +51,10 @@ int coop_grad_scratch_slots(int L);   // one chain's tile set ([HT] tiles) each,
 int coop_grad_nblocks(long long B, int num_cus, int HT, int ZR, int CR = 0, int NT = 1);
 int coop_grad_nt(int HT, int L, int ZR, int CR, int ACT);   // sample tiles per super-tile of the instance that serves the shape   // workgroups of a launch (each owns `scratch_stride` floats of scratch)
 hipError_t coop_grad_step_launch(int HT, int L, int ZR, int CR, int ACT, const CGArgs& a, int num_cus, hipStream_t st);
+// the dealt form of the sweep (cnf_coop_dgrad.hip): same arguments, for the flows whose forward solve runs on cnf_coop_d.hip's kernels
+// (H hidden units, D state rows, L hidden layers; (HT_lay, ZR_lay, CR_lay) = the plan's layout)
+bool coopd_grad_supported(int H, int D, int L, int ACT, int HT_lay, int ZR_lay, int CR_lay);
+hipError_t coopd_grad_step_launch(int H, int D, int L, int ACT, int HT_lay, int ZR_lay, const CGArgs& a, int num_cus, hipStream_t st);
 // the cooperative forward solve with step / stage checkpoints in tile layout (cnf_coop.hip)
 bool coop_ckpt_supported(int HT, int L, int ZR, int ACT);
 hipError_t coop_launch_ckpt(int HT, int L, int ZR, int ACT, const KArgs& a, int num_cus, hipStream_t st);

@@ -1086,11 +1086,13 @@ hipError_t coop_grad(LayeredGrad** ctx, const cnf_config& c, MfmaPlan* plan, con
     for (int l = 0; l < Lh; ++l) { a.xh[l] = W + o_xh[l]; a.yh[l] = W + o_yh[l]; }
     a.y1 = W + o_y1; a.xN = W + o_xN; a.ld_y1 = n_in + 1; a.ldy = ldy;
     a.B = B; a.ntiles_pad = ntp; a.nsteps = nsteps; a.D = D; a.nvars = c.nvars; a.H = H; a.autonomous = c.autonomous; a.lam1 = lam[0]; a.lam2 = lam[1]; a.lam3 = lam[2]; a.T = T;
+    const bool dealt = coopd_grad_supported(H, D, Lh, ACT, HT, ZR, CR);   // the dealt sweep (cnf_coop_dgrad.hip) where it has an instance
     const float dt = (t1 - t0) / (float)nsteps;
     for (int n = nsteps - 1; n >= 0; --n) {
         a.step = n; a.tn = t0 + (float)n * dt; a.dt = dt;
         if (tgrid) { a.tn = tgrid[n]; a.dt = tgrid[n + 1] - tgrid[n]; }
-        LG_HIP(coop_grad_step_launch(HT, Lh, ZR, CR, ACT, a, G.num_cus, st));
+        if (dealt) LG_HIP(coopd_grad_step_launch(H, D, Lh, ACT, HT, ZR, a, G.num_cus, st));
+        else LG_HIP(coop_grad_step_launch(HT, Lh, ZR, CR, ACT, a, G.num_cus, st));
         LG_HIP(lg_wgrad(slabs + L.pa_off[0], npa_pad, kc, nslab, H, n_in + 1, a.xh[0], H, a.y1, n_in + 1, B2, st));
         for (int l = 1; l < Lh; ++l)
             LG_HIP(lg_wgrad(slabs + L.pa_off[l], npa_pad, kc, nslab, H, H + 1, a.xh[l], H, a.yh[l - 1], ldy, B2, st));

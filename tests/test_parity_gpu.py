@@ -352,6 +352,32 @@ def test_cooperative_gradient_on_the_dealt_forward_solve(kw, lam, B, alg, nsteps
     assert np.max(np.abs(gx.cpu().numpy() - gxref)) < 5e-5 * np.abs(gxref).max() + 1e-7
 
 
+@pytest.mark.parametrize("nv,alg", [(16, 1), (18, 0), (22, 1), (29, 1)])
+def test_dealt_reverse_sweep_matches_the_cooperative_sweep(nv, alg, pkg, oracles, monkeypatch):
+    """The dealt form of the reverse sweep (cnf_coop_dgrad.hip) against the sweep of cnf_coop_grad.hip on the same plan, the same
+    checkpoints and the same operand arrays (CNF_COOPD_GRAD=0 selects the latter): default architecture at 9, 10, 12 and 15 hidden
+    tiles (left-over units 1, 2, 0, 3 of a wave's two slots), 3000 columns (ragged last super-tile), default lambdas.  The two differ by
+    summation order only - and they do differ in the last bits, which is how the test knows both ran."""
+    o64, _ = oracles
+    D = 2 * nv + 1
+    spec = o64.make_spec(nvars=nv, naug=nv + 1, hidden=[4 * (D + 1)] * 2, act=2, reg_z=True, reg_j=True, reg_aug=True)
+    B = 3000
+    p, xs, eps, _ = o64.synth_inputs(spec, B, 99 + nv, bias_scale=0.2)
+    out = {}
+    for tag, env in (("dealt", "1"), ("coop", "0")):
+        monkeypatch.setenv("CNF_COOPD_GRAD", env)
+        icnf = make_icnf(pkg, spec, alg, 3, lambdas=(0.01, 0.01, 0.01))
+        mode = pkg.TrainMode(True)
+        val, g, gx = pkg.loss_and_gradient(icnf, mode, dev(xs), dev(p), {}, eps=dev(eps), wrt_x=True)
+        assert icnf.grad_path(mode, B=B, alg=alg) == 3
+        out[tag] = (float(val), g.cpu().numpy(), gx.cpu().numpy())
+    assert out["dealt"][0] == out["coop"][0]                      # the loss comes from the forward solve both share
+    for k in (1, 2):
+        a, b = out["dealt"][k], out["coop"][k]
+        assert np.max(np.abs(a - b)) < 2e-5 * np.abs(b).max() + 1e-7
+    assert not np.array_equal(out["dealt"][1], out["coop"][1])
+
+
 @pytest.mark.parametrize("kw,B,alg,nsteps", GENERIC_MFMA_CASES)
 def test_generic_instances_resolve_to_the_mfma_path(kw, B, alg, nsteps, pkg, oracles):
     o64, _ = oracles
