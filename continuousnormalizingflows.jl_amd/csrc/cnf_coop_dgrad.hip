@@ -47,7 +47,7 @@
 #endif
 
 #ifdef DG_TRACE
-#define DG_T(k) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); tr[k] = __builtin_amdgcn_s_memtime(); } while (0)
+#define DG_T(k) do { asm volatile("" ::: "memory"); tr[k] = __builtin_amdgcn_s_memtime(); asm volatile("" ::: "memory"); } while (0)
 #else
 #define DG_T(k)
 #endif
@@ -57,7 +57,6 @@ namespace cnf {
 struct DGArgs {
     CGArgs c;
     DImg g;
-    int dbg;
 };
 
 namespace {
@@ -72,7 +71,7 @@ __device__ __forceinline__ f32x4 dg_act_dd(const f32x4& h, const f32x4& d) {
 template <int A>
 struct GAcc {
     f32x4 S[A][4];    // tiles [w A, (w + 1) A) x (chain 0: sample tiles 0, 1 | chain 1: sample tiles 0, 1)
-    f32x4 R[2][2];    // left-over units w and w + 4 of the 2 b (tile, sample) units: [slot][chain]
+    f32x4 R[2][2];    // this wave's left-over (tile, sample) units (see gunits): [slot][chain]
 };
 template <int A>
 struct GHalf {        // one chain's worth of this wave's units
@@ -82,18 +81,22 @@ struct GHalf {        // one chain's worth of this wave's units
 template <int A>
 struct GOff { unsigned S[A]; unsigned Rr[2]; };
 
-// this wave's left-over units: slot s is live when w + 4 s < 2 b; its tile (clamped for the loads) and its sample tile
+// this wave's left-over units.  They are dealt from the LAST wave down (unit u = 3 - w and u + 4 of the 2 b (tile, sample) units:
+// tile 4 A + (u >> 1) + 2 s, sample tile u & 1): waves 0 and 1 own the sample tiles - the dense phase that opens every stage is
+// theirs while the other two wait - so the extra products go to waves 3 and 2 first.  Slot s is live when u + 4 s < 2 b; the tile
+// is clamped for the loads.
 struct GUnits {
     bool v0, v1;
     int t0, t1, q;
 };
 __device__ __forceinline__ GUnits gunits(int A, int b, int wave) {
     GUnits u;
-    u.v0 = wave < 2 * b; u.v1 = wave + 4 < 2 * b;
+    const int un = 3 - wave;
+    u.v0 = un < 2 * b; u.v1 = un + 4 < 2 * b;
     const int tmax = 4 * A + b - 1;
-    const int r0 = 4 * A + (wave >> 1), r1 = r0 + 2;
+    const int r0 = 4 * A + (un >> 1), r1 = r0 + 2;
     u.t0 = r0 < tmax ? r0 : tmax; u.t1 = r1 < tmax ? r1 : tmax;
-    u.q = wave & 1;
+    u.q = un & 1;
     return u;
 }
 template <int A>
@@ -320,7 +323,9 @@ coopd_grad_step_kernel(DGArgs da) {
     // lanes cover 32 consecutive rows (two row tiles) of one sample (bank assignment: see gstore of cnf_coop_grad.hip)
     const int mm = (lane >> 2) & 1, gg = lane & 3, s8 = (lane >> 3) ^ (4 * mm);
     auto gstore = [&](const f32x4* __restrict__ xb4, const __amdgpu_buffer_rsrc_t& rs, const unsigned (&vo)[2], unsigned so_c0, unsigned so_c1) {
-        if (da.dbg & 1) return;
+#ifdef DG_EXP_NOSTORE   // timing-only build (wrong gradients): what the operand stores cost
+        return;
+#endif
         typedef float __attribute__((may_alias)) float_a;
         const float_a* xb = reinterpret_cast<const float_a*>(xb4);
         const unsigned so0 = (wave >> 1) ? so_c1 : so_c0;
@@ -401,12 +406,13 @@ coopd_grad_step_kernel(DGArgs da) {
             unsigned long long tr[18];
 #endif
             DG_T(0);
-            // The image's buffer resource is rebuilt from the kernel argument in every stage (behind an opaque scalar zero): kept
-            // live across the whole kernel it lost its scalar registers to the allocator and every fragment load of the first build
-            // sat in a waterfall loop (4 v_readfirstlane + compare + branch per load: 304 of them, each load its own basic block).
-            int opq = 0;
-            asm volatile("" : "+s"(opq));
-            const DRs R{__builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.packed) + opq, 0, 0x7fffffff, 0x00020000), R0.lane16};
+            // The image's buffer resource is rebuilt in every stage from the kernel argument, made scalar BY HAND: the kernel's scalar
+            // registers overflow (kernel arguments, four operand-array resources, tableau coefficients), and whenever the allocator
+            // parked the image pointer in a vector register every fragment load sat in a waterfall loop (4 v_readfirstlane +
+            // compare + branch per load, each load its own basic block: an H x H product took 15.5 k cycles for 10.9 k of MFMAs).
+            const unsigned long long pimg = (unsigned long long)a.packed;
+            const unsigned plo = __builtin_amdgcn_readfirstlane((unsigned)pimg), phi = __builtin_amdgcn_readfirstlane((unsigned)(pimg >> 32));
+            const DRs R{__builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(((unsigned long long)phi << 32) | plo), 0, 0x7fffffff, 0x00020000), R0.lane16};
             float zs[KZ], kbar[KZ], gbar[KZ];
             const float bi = a.T.b[i];
             const float cl = valid ? dt * bi : 0.f;      // cotangent of ldot (dL/d dlogp = +1 per column); zero for padding columns
@@ -470,17 +476,6 @@ coopd_grad_step_kernel(DGArgs da) {
                 }
                 publish_dense(zebuf, wave, zs); publish_dense(zebuf, 2 + wave, gbar);
                 publish_dense(ekbuf, wave, eps); publish_dense(ekbuf, 2 + wave, kbar);
-                if (valid && !(da.dbg & 2)) {
-                    dense_store(a.y1, a.ld_y1, c1 + smp, gbar);
-                    dense_store(a.y1, a.ld_y1, c2 + smp, zs);
-                    if (g == 0) {
-                        float* col = a.y1 + (c2 + smp) * (long long)a.ld_y1;
-                        if (!a.autonomous) col[D] = tt;
-                        col[a.ld_y1 - 1] = 1.f;
-                    }
-                    dense_store(a.xN, D, c1 + smp, eps);
-                    dense_store(a.xN, D, c2 + smp, kbar);
-                }
             }
             GAcc<A> acc, out;
             GHalf<A> d1P, db1P, h1P;      // act'_1, dbar_1 (and h_1 for tanh) of this wave's units, parked until the way down
@@ -500,6 +495,34 @@ coopd_grad_step_kernel(DGArgs da) {
             g_load_a<A>(R, TZ, F1Z, 0, aS, aR);
             DG_T(1);
             DG_SYNC();                                                                     // B0
+            if (!owner) {
+                // The dense operands of Wbar_1 and Wbar_N ([gbar; 0 | z; t; 1] and [eps | kbar]: rows of 4-byte stores, an exec mask per
+                // row) leave through waves 2 and 3, which have waited for the owners: lane l of wave 2 + q reads back from the
+                // images what lane l of owner q has just published.
+                const int q = wave - 2;
+                const long long sm2 = smp0 + q * 16 + n;
+                if (sm2 < B) {
+                    float v0[KZ], v1[KZ];
+                    auto fetch = [&](const f32x4* img, int ct, float (&v)[KZ]) {
+#pragma unroll
+                        for (int kg = 0; kg < DT; ++kg) {
+                            const f32x4 t4 = img[(kg * 4 + ct) * 64 + lane];
+                            v[4 * kg] = t4[0]; v[4 * kg + 1] = t4[1]; v[4 * kg + 2] = t4[2]; v[4 * kg + 3] = t4[3];
+                        }
+                    };
+                    fetch(zebuf, 2 + q, v0); fetch(zebuf, q, v1);
+                    dense_store(a.y1, a.ld_y1, c1 + sm2, v0);
+                    dense_store(a.y1, a.ld_y1, c2 + sm2, v1);
+                    if (g == 0) {
+                        float* col = a.y1 + (c2 + sm2) * (long long)a.ld_y1;
+                        if (!a.autonomous) col[D] = tt;
+                        col[a.ld_y1 - 1] = 1.f;
+                    }
+                    fetch(ekbuf, q, v0); fetch(ekbuf, 2 + q, v1);
+                    dense_store(a.xN, D, c1 + sm2, v0);
+                    dense_store(a.xN, D, c2 + sm2, v1);
+                }
+            }
             DG_T(2);
             g_gemm<A>(R, TZ, F1Z, G.KGZ, G.remZ, U, zebuf, lane, aS, aR, acc);
             DG_T(3);
@@ -615,24 +638,25 @@ coopd_grad_step_kernel(DGArgs da) {
             DG_SYNC();                                                                     // B5
             DG_T(16);
             if (owner) {
-                const bool lo0 = wave < 2 * G.b, lo2 = wave + 2 < 2 * G.b;   // waves q and q + 2 hold left-over units of sample tile q
+                // waves 3 - q and 1 - q hold the left-over units of sample tile q (units q, q + 4 and q + 2, q + 6)
+                const bool lo0 = wave < 2 * G.b, lo2 = wave + 2 < 2 * G.b;
 #pragma unroll
                 for (int dm = 0; dm < DT; ++dm) {
                     f32x4 v = pbuf[((wave * 4 + 0) * DT + dm) * 64 + lane];
 #pragma unroll
                     for (int w = 1; w < 4; ++w) v += pbuf[((wave * 4 + w) * DT + dm) * 64 + lane];
-                    if (lo0) v += pbuf[((2 * 4 + wave) * DT + dm) * 64 + lane];
-                    if (lo2) v += pbuf[((2 * 4 + wave + 2) * DT + dm) * 64 + lane];
+                    if (lo0) v += pbuf[((2 * 4 + 3 - wave) * DT + dm) * 64 + lane];
+                    if (lo2) v += pbuf[((2 * 4 + 1 - wave) * DT + dm) * 64 + lane];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) zbt[i * KZ + 4 * dm + j] = v[j];
                 }
             }
 #ifdef DG_TRACE
             DG_T(17);
-            if (blockIdx.x == 3 && st == 3 && a.step == 5 && i == 2 && lane == 0 && (wave == 0 || wave == 3)) {
-                printf("w%d:", wave);
-                for (int k = 1; k < 18; ++k) printf(" %d", (int)(tr[k] - tr[k - 1]));
-                printf("\n");
+            if (blockIdx.x == 3 && st == 3 && a.step == 5 && i == 2 && lane == 0) {
+#define DG_D(k) (int)(tr[k] - tr[k - 1])
+                printf("w%d: dense %d B0 %d up1 %d ew1 %d B1 %d up2 %d ew2 %d B2 %d top %d ew3 %d B3 %d dn2 %d ew4 %d B4 %d gst %d B5 %d red %d\n", wave, DG_D(1), DG_D(2),
+                       DG_D(3), DG_D(4), DG_D(5), DG_D(6), DG_D(7), DG_D(8), DG_D(9), DG_D(10), DG_D(11), DG_D(12), DG_D(13), DG_D(14), DG_D(15), DG_D(16), DG_D(17));
             }
 #endif
             // (the next stage's first LDS writes - the [z | gbar] image in X1, [eps | kbar] - follow the stores of X1 this wave has
@@ -685,6 +709,7 @@ struct DGradInst {
 static const DGradInst kDGrad[] = {
     DG_INST(2, 8, CNF_ACT_SOFTPLUS), DG_INST(3, 8, CNF_ACT_SOFTPLUS),
     DG_INST(2, 12, CNF_ACT_SOFTPLUS), DG_INST(3, 12, CNF_ACT_SOFTPLUS), DG_INST(3, 16, CNF_ACT_SOFTPLUS),
+    DG_INST(2, 8, CNF_ACT_TANH_PRESCALED), DG_INST(2, 12, CNF_ACT_TANH_PRESCALED),   // tanh keeps h_1 as well: 8 .. 11 hidden tiles
 };
 static const DGradInst* dg_find(int HT_real, int KZ, int ACT) {
     const int A = HT_real / 4;
@@ -723,7 +748,6 @@ hipError_t coopd_grad_step_launch(int H, int D, int L, int ACT, int HT_lay, int 
     if (!c) return hipErrorNotSupported;
     DGArgs da{};
     da.c = a;
-    if (const char* e = getenv("CNF_DG_DBG")) da.dbg = atoi(e);
     dimg_fill(da.g, H, D, L, HT_lay, ZR_lay, 0, c->A, 0);
     const int DT = c->KZ / 4;
     if (!dg_fits(HT_real, DT, c->A, da.g.cvn)) return hipErrorNotSupported;

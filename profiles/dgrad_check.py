@@ -14,8 +14,8 @@ for nv in [int(v) for v in os.environ.get("DG_NV", "16,20,24,28").split(",")]:
     E = torch.randn(B, icnf.D, device=dev).t()
     m = pkg.TrainMode(True)
     res = {}
-    for tag, env, dbg in (("old", "0", "0"), ("dealt", "1", "0")) + tuple((f"dbg{d}", "1", str(d)) for d in os.environ.get("DG_DBG", "").split(",") if d):
-        os.environ["CNF_COOPD_GRAD"] = env; os.environ["CNF_DG_DBG"] = dbg
+    for tag, env in (("old", "0"), ("dealt", "1")):
+        os.environ["CNF_COOPD_GRAD"] = env
         for _ in range(2): l, gr = pkg.loss_and_gradient(icnf, m, X, P, st, eps=E)[:2]
         torch.cuda.synchronize()
         t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -25,5 +25,5 @@ for nv in [int(v) for v in os.environ.get("DG_NV", "16,20,24,28").split(",")]:
         res[tag] = (float(l), gr.double().cpu(), t0.elapsed_time(t1) / 3)
     go, gd = res["old"][1], res["dealt"][1]
     out[f"nv{nv}"] = dict(widths=icnf.nn.widths, loss_old=res["old"][0], loss_dealt=res["dealt"][0], ms_old=res["old"][2], ms_dealt=res["dealt"][2],
-                          ms_dbg={k: v[2] for k, v in res.items() if k.startswith("dbg")}, grad_rel=float((go - gd).norm() / go.norm()), grad_maxabs=float((go - gd).abs().max()), gnorm=float(go.norm()))
+                          grad_rel=float((go - gd).norm() / go.norm()), grad_maxabs=float((go - gd).abs().max()), gnorm=float(go.norm()))
     print(json.dumps({f"nv{nv}": out[f"nv{nv}"]}), flush=True)

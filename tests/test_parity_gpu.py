@@ -312,6 +312,8 @@ def test_adaptive_solvers_on_the_dealt_kernel(solver, pkg, oracles, monkeypatch)
     (dict(nvars=18, naug=19, hidden=[152, 152], act=2), (0.0, 0.0, 0.0), 100, 1, 3, True),      # on a non-uniform grid (device-resident step times)
     (dict(nvars=16, naug=17, ncond=5, hidden=[156, 156], act=2, reg_z=True, reg_j=True, reg_aug=True), (0.01, 0.01, 0.01), 90, 1, 2, False),   # conditioned
     (dict(nvars=20, hidden=[200, 200, 200], reg_z=True, reg_j=True), (0.02, 0.03, 0.0), 70, 0, 2, False),      # a cooperative (tanh, 3-layer) plan's forward on the dealt kernel
+    (dict(nvars=14, naug=6, hidden=[152, 152], reg_z=True, reg_j=True), (0.02, 0.03, 0.0), 90, 1, 2, False),     # tanh, two layers, 10 tiles: the dealt sweep keeps h_1 too
+    (dict(nvars=30, naug=11, hidden=[172, 172], reg_z=True, reg_j=True, reg_aug=True), (0.01, 0.02, 0.03), 50, 0, 3, False),   # tanh, 11 tiles, 12 state registers
     (dict(nvars=32, naug=33, hidden=[264, 264], act=2, reg_z=True, reg_j=True, reg_aug=True), (0.01, 0.01, 0.01), 60, 1, 2, False),   # the 32-sample form (17 tiles)
     (dict(nvars=40, naug=41, hidden=[328, 328], act=2), (0.0, 0.0, 0.0), 40, 0, 2, True),                        # ... 21 tiles, on a grid
 ])
