@@ -448,7 +448,7 @@ coopd_grad_step_kernel(DGArgs da) {
 #pragma unroll
                     for (int j = 0; j < NS - 1; ++j) {
                         acc = fmaf(a.T.a[i][j], kr[j][s >> 2][s & 3], acc);                         // a[i][j] = 0 for j >= i
-                        kb = fmaf(a.T.a[j + 1][i], j + 1 > i ? zr[j][s >> 2][s & 3] : 0.f, kb);    // Zbar_j exists for j > i only
+                        kb = fmaf(a.T.a[j + 1][i], (j + 1 > i && j + 1 < ns) ? zr[j][s >> 2][s & 3] : 0.f, kb);    // Zbar_j exists for i < j < ns only
                     }
                     zs[s] = fmaf(dt, acc, zn[s]);
                     kbar[s] = valid ? dt * kb : 0.f;
@@ -477,7 +477,7 @@ coopd_grad_step_kernel(DGArgs da) {
                 publish_dense(zebuf, wave, zs); publish_dense(zebuf, 2 + wave, gbar);
                 publish_dense(ekbuf, wave, eps); publish_dense(ekbuf, 2 + wave, kbar);
             }
-            GAcc<A> acc, out;
+            GAcc<A> acc;   // (the elementwise phases work in place: results replace the accumulators they come from)
             GHalf<A> d1P, db1P, h1P;      // act'_1, dbar_1 (and h_1 for tanh) of this wave's units, parked until the way down
             // ================= up 1: [a_1 | dbar_1] = W_1[:,0:D] [z | gbar] (+ bias and time column on the first chain) =================
             {
@@ -538,18 +538,18 @@ coopd_grad_step_kernel(DGArgs da) {
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
                     f32x4 hk, dk, dbk;
-                    up_unit(acc.S[m][q], acc.S[m][2 + q], out.S[m][q], out.S[m][2 + q], hk, dk, dbk);
+                    up_unit(acc.S[m][q], acc.S[m][2 + q], acc.S[m][q], acc.S[m][2 + q], hk, dk, dbk);
                     d1P.S[m][q] = park4(dk); db1P.S[m][q] = park4(dbk);
                     if constexpr (KEEP_H) h1P.S[m][q] = park4(hk);
                 }
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 f32x4 hk, dk, dbk;
-                up_unit(acc.R[s][0], acc.R[s][1], out.R[s][0], out.R[s][1], hk, dk, dbk);
+                up_unit(acc.R[s][0], acc.R[s][1], acc.R[s][0], acc.R[s][1], hk, dk, dbk);
                 d1P.R[s] = park4(dk); db1P.R[s] = park4(dbk);
                 if constexpr (KEEP_H) h1P.R[s] = park4(hk);
             }
-            publish(X0, out);
+            publish(X0, acc);
             {
                 f32x4 bS[A], bR[2];
                 cvec_units(P + G.v_bh, bS, bR);
@@ -569,10 +569,10 @@ coopd_grad_step_kernel(DGArgs da) {
 #pragma unroll
             for (int m = 0; m < A; ++m)
 #pragma unroll
-                for (int q = 0; q < 2; ++q) up_unit(acc.S[m][q], acc.S[m][2 + q], out.S[m][q], out.S[m][2 + q], h2.S[m][q], d2.S[m][q], db2.S[m][q]);
+                for (int q = 0; q < 2; ++q) up_unit(acc.S[m][q], acc.S[m][2 + q], acc.S[m][q], acc.S[m][2 + q], h2.S[m][q], d2.S[m][q], db2.S[m][q]);
 #pragma unroll
-            for (int s = 0; s < 2; ++s) up_unit(acc.R[s][0], acc.R[s][1], out.R[s][0], out.R[s][1], h2.R[s], d2.R[s], db2.R[s]);
-            publish(X1, out);
+            for (int s = 0; s < 2; ++s) up_unit(acc.R[s][0], acc.R[s][1], acc.R[s][0], acc.R[s][1], h2.R[s], d2.R[s], db2.R[s]);
+            publish(X1, acc);
             acc_zero(acc);
             DG_T(7);
             DG_SYNC();                                                                     // B2
@@ -584,16 +584,17 @@ coopd_grad_step_kernel(DGArgs da) {
             gstore(X1, ry[1], voy, sy2, sy1);                                              // Y_2 = [cbar; 0 | h_2; 1]
             // delta = u .* act', a2 = dbar .* u, sbar = hbar .* act' + a2 .* act''
             auto down_unit = [&](const f32x4& u, const f32x4& hb, const f32x4& h, const f32x4& d, const f32x4& db, f32x4& o0, f32x4& o1) {
+                const f32x4 sbar = hb * d + (db * u) * dg_act_dd<ACT>(h, d);   // (o0 / o1 may be u / hb themselves)
                 o0 = u * d;
-                o1 = hb * d + (db * u) * dg_act_dd<ACT>(h, d);
+                o1 = sbar;
             };
 #pragma unroll
             for (int m = 0; m < A; ++m)
 #pragma unroll
-                for (int q = 0; q < 2; ++q) down_unit(acc.S[m][q], acc.S[m][2 + q], h2.S[m][q], d2.S[m][q], db2.S[m][q], out.S[m][q], out.S[m][2 + q]);
+                for (int q = 0; q < 2; ++q) down_unit(acc.S[m][q], acc.S[m][2 + q], h2.S[m][q], d2.S[m][q], db2.S[m][q], acc.S[m][q], acc.S[m][2 + q]);
 #pragma unroll
-            for (int s = 0; s < 2; ++s) down_unit(acc.R[s][0], acc.R[s][1], h2.R[s], d2.R[s], db2.R[s], out.R[s][0], out.R[s][1]);
-            publish(X0, out);
+            for (int s = 0; s < 2; ++s) down_unit(acc.R[s][0], acc.R[s][1], h2.R[s], d2.R[s], db2.R[s], acc.R[s][0], acc.R[s][1]);
+            publish(X0, acc);
             acc_zero(acc);
             DG_T(10);
             DG_SYNC();                                                                     // B3
@@ -611,16 +612,16 @@ coopd_grad_step_kernel(DGArgs da) {
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
                     const f32x4 hk = KEEP_H ? unpark4(h1P.S[m][q]) : f32x4{0.f, 0.f, 0.f, 0.f};
-                    down_unit(acc.S[m][q], acc.S[m][2 + q], hk, unpark4(d1P.S[m][q]), unpark4(db1P.S[m][q]), out.S[m][q], out.S[m][2 + q]);
-                    sb.S[m][q] = out.S[m][2 + q];
+                    down_unit(acc.S[m][q], acc.S[m][2 + q], hk, unpark4(d1P.S[m][q]), unpark4(db1P.S[m][q]), acc.S[m][q], acc.S[m][2 + q]);
+                    sb.S[m][q] = acc.S[m][2 + q];
                 }
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 const f32x4 hk = KEEP_H ? unpark4(h1P.R[s]) : f32x4{0.f, 0.f, 0.f, 0.f};
-                down_unit(acc.R[s][0], acc.R[s][1], hk, unpark4(d1P.R[s]), unpark4(db1P.R[s]), out.R[s][0], out.R[s][1]);
-                sb.R[s] = out.R[s][1];
+                down_unit(acc.R[s][0], acc.R[s][1], hk, unpark4(d1P.R[s]), unpark4(db1P.R[s]), acc.R[s][0], acc.R[s][1]);
+                sb.R[s] = acc.R[s][1];
             }
-            publish(X1, out);
+            publish(X1, acc);
             // ================= Zbar_i = W_1[:,0:D]^T sbar_1: partial tiles over this wave's own k-groups, from registers =================
             f32x4 part[DT][2], own[DT];
             g_drow<A, DT>(R, vd, B1, mtS0, G.KGH, G.remH, U, sb, fd, part, own);
