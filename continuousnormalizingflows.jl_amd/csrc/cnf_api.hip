@@ -85,23 +85,23 @@ void free_pack_map(PackMap& m) {
 
 
 static int ensure_ws(cnf_handle* h, int64_t B) {
-    if (B <= h->ws_B) return CNF_OK;
-    if (h->ws) HIP_TRY(hipFree(h->ws));
-    h->ws = nullptr;
-    h->ws_B = 0;
+    if (B <= h->simt.ws_B) return CNF_OK;
+    if (h->simt.ws) HIP_TRY(hipFree(h->simt.ws));
+    h->simt.ws = nullptr;
+    h->simt.ws_B = 0;
     const int64_t Bp = (B + 255) / 256 * 256;
-    HIP_TRY(hipMalloc((void**)&h->ws, simt_ws_rows(h->net) * (size_t)Bp * sizeof(float)));
-    h->ws_B = Bp;
+    HIP_TRY(hipMalloc((void**)&h->simt.ws, simt_ws_rows(h->net) * (size_t)Bp * sizeof(float)));
+    h->simt.ws_B = Bp;
     return CNF_OK;
 }
 
 static int ensure_kbuf(cnf_handle* h, int64_t B) {
-    if (B <= h->kbuf_B) return CNF_OK;
-    if (h->kbuf) HIP_TRY(hipFree(h->kbuf));
-    h->kbuf = nullptr;
-    h->kbuf_B = 0;
-    HIP_TRY(hipMalloc((void**)&h->kbuf, 7 * (size_t)h->S * (size_t)B * sizeof(float)));
-    h->kbuf_B = B;
+    if (B <= h->simt.kbuf_B) return CNF_OK;
+    if (h->simt.kbuf) HIP_TRY(hipFree(h->simt.kbuf));
+    h->simt.kbuf = nullptr;
+    h->simt.kbuf_B = 0;
+    HIP_TRY(hipMalloc((void**)&h->simt.kbuf, 7 * (size_t)h->S * (size_t)B * sizeof(float)));
+    h->simt.kbuf_B = B;
     return CNF_OK;
 }
 
@@ -193,30 +193,30 @@ int cnf_create(cnf_handle** out, const cnf_config* cfg) {
 int cnf_destroy(cnf_handle* h) {
     if (!h) return CNF_OK;
     DeviceGuard g(h->cfg.device_id);
-    if (h->P_dev) (void)hipFree(h->P_dev);
-    if (h->packed_dev) (void)hipFree(h->packed_dev);
-    if (h->ws) (void)hipFree(h->ws);
-    if (h->kbuf) (void)hipFree(h->kbuf);
+    if (h->par.P_dev) (void)hipFree(h->par.P_dev);
+    if (h->par.packed_dev) (void)hipFree(h->par.packed_dev);
+    if (h->simt.ws) (void)hipFree(h->simt.ws);
+    if (h->simt.kbuf) (void)hipFree(h->simt.kbuf);
     if (h->loss_partial) (void)hipFree(h->loss_partial);
-    if (h->grad_packed) (void)hipFree(h->grad_packed);
-    if (h->grad_ws) (void)hipFree(h->grad_ws);
-    if (h->p_stage) (void)hipFree(h->p_stage);
-    if (h->ebuf) (void)hipFree(h->ebuf);
-    if (h->err_partial) (void)hipFree(h->err_partial);
-    if (h->vc_buf) (void)hipFree(h->vc_buf);
-    if (h->tgrid_dev) (void)hipFree(h->tgrid_dev);
-    if (h->ad_buf) (void)hipFree(h->ad_buf);
-    if (h->dc_buf) (void)hipFree(h->dc_buf);
-    if (h->vc_partial) (void)hipFree(h->vc_partial);
-    layered_grad_destroy(h->layered);
-    free_pack_map(h->map_fwd);
-    free_pack_map(h->map_grad);
-    free_pack_map(h->map_slab);
-    if (h->slab_packed) (void)hipFree(h->slab_packed);
-    if (h->slab_ws) (void)hipFree(h->slab_ws);
-    free_pack_map(h->map_cg);
-    if (h->cg_packed) (void)hipFree(h->cg_packed);
-    if (h->plan_cg) mfma_plan_destroy(h->plan_cg);
+    if (h->grad.packed) (void)hipFree(h->grad.packed);
+    if (h->grad.ws) (void)hipFree(h->grad.ws);
+    if (h->par.stage) (void)hipFree(h->par.stage);
+    if (h->emb.buf) (void)hipFree(h->emb.buf);
+    if (h->emb.err_partial) (void)hipFree(h->emb.err_partial);
+    if (h->vc.buf) (void)hipFree(h->vc.buf);
+    if (h->grad.tgrid_dev) (void)hipFree(h->grad.tgrid_dev);
+    if (h->adp.buf) (void)hipFree(h->adp.buf);
+    if (h->adp.dc_buf) (void)hipFree(h->adp.dc_buf);
+    if (h->vc.partial) (void)hipFree(h->vc.partial);
+    layered_grad_destroy(h->grad.layered);
+    free_pack_map(h->par.map_fwd);
+    free_pack_map(h->grad.map);
+    free_pack_map(h->grad.map_slab);
+    if (h->grad.slab_packed) (void)hipFree(h->grad.slab_packed);
+    if (h->grad.slab_ws) (void)hipFree(h->grad.slab_ws);
+    free_pack_map(h->grad.map_cg);
+    if (h->grad.cg_packed) (void)hipFree(h->grad.cg_packed);
+    if (h->grad.plan_cg) mfma_plan_destroy(h->grad.plan_cg);
     if (h->plan) mfma_plan_destroy(h->plan);
     delete h;
     return CNF_OK;
@@ -242,12 +242,12 @@ const char* cnf_kernel_name(const cnf_handle* h) {
     if (h->path == CNF_PATH_MFMA) return mfma_plan_name(h->plan);
     return h->path == CNF_PATH_LAYERED ? "layered" : "simt";
 }
-int cnf_solve_controller(const cnf_handle* h) { return (h && h->last_controller >= 0) ? h->last_controller : CNF_ERR_INVALID; }
+int cnf_solve_controller(const cnf_handle* h) { return (h && h->adp.last_controller >= 0) ? h->adp.last_controller : CNF_ERR_INVALID; }
 
 int cnf_repack_on_device(const cnf_handle* h) {
     if (!h) return CNF_ERR_INVALID;
-    if (!h->have_params) return CNF_ERR_NO_PARAMS;
-    return h->repack_on_device ? 1 : 0;
+    if (!h->par.have) return CNF_ERR_NO_PARAMS;
+    return h->par.repack_on_device ? 1 : 0;
 }
 
 int cnf_set_params(cnf_handle* h, const float* p, size_t n, const size_t* w_off,
@@ -265,52 +265,52 @@ int cnf_set_params(cnf_handle* h, const float* p, size_t n, const size_t* w_off,
     const bool mfma = h->path == CNF_PATH_MFMA;
     const cnf_config gc = api_grad_cfg(h);
     const bool want_grad = mfma && mfma_plan_is_per_wave(h->plan) && grad_supported(gc);
-    const bool same_layout = h->have_params && h->nparams == n &&
-                             std::equal(w_off, w_off + c.n_layers, h->w_off.begin()) &&
-                             std::equal(b_off, b_off + c.n_layers, h->b_off.begin());
+    const bool same_layout = h->par.have && h->par.n == n &&
+                             std::equal(w_off, w_off + c.n_layers, h->par.w_off.begin()) &&
+                             std::equal(b_off, b_off + c.n_layers, h->par.b_off.begin());
     if (!same_layout) {
-        h->w_off.assign(w_off, w_off + c.n_layers);
-        h->b_off.assign(b_off, b_off + c.n_layers);
-        h->maps_built = false;
+        h->par.w_off.assign(w_off, w_off + c.n_layers);
+        h->par.b_off.assign(b_off, b_off + c.n_layers);
+        h->par.maps_built = false;
     }
-    if (mfma && !h->packed_dev) HIP_TRY(hipMalloc((void**)&h->packed_dev, mfma_packed_bytes(h->plan)));
-    if (want_grad && !h->grad_packed) HIP_TRY(hipMalloc((void**)&h->grad_packed, grad_packed_bytes(gc)));
-    if (mfma && !h->maps_built) {
+    if (mfma && !h->par.packed_dev) HIP_TRY(hipMalloc((void**)&h->par.packed_dev, mfma_packed_bytes(h->plan)));
+    if (want_grad && !h->grad.packed) HIP_TRY(hipMalloc((void**)&h->grad.packed, grad_packed_bytes(gc)));
+    if (mfma && !h->par.maps_built) {
         // one-time (per layout): derive and verify the gather maps from the host packers
         size_t qo = 0, ql = 0;
         (void)mfma_plan_q_region(h->plan, &qo, &ql);
-        build_pack_map(h->map_fwd, n, mfma_packed_bytes(h->plan) / sizeof(float),
+        build_pack_map(h->par.map_fwd, n, mfma_packed_bytes(h->plan) / sizeof(float),
                        [&](const float* src, float* dst) { mfma_pack(h->plan, src, w_off, b_off, dst); }, qo, ql);
         if (want_grad)
-            build_pack_map(h->map_grad, n, grad_packed_bytes(gc) / sizeof(float),
+            build_pack_map(h->grad.map, n, grad_packed_bytes(gc) / sizeof(float),
                            [&](const float* src, float* dst) { grad_pack(gc, src, w_off, b_off, dst); });
-        h->maps_built = true;
+        h->par.maps_built = true;
     }
-    const bool dev_pack = mfma && h->map_fwd.valid && (!want_grad || h->map_grad.valid);
-    h->repack_on_device = dev_pack;
+    const bool dev_pack = mfma && h->par.map_fwd.valid && (!want_grad || h->grad.map.valid);
+    h->par.repack_on_device = dev_pack;
     if (mfma && dev_pack) {
         // device path: (host p: one H2D copy into the staging buffer, then) gather kernels on `stream`
         const float* src = p;
         if (!p_is_device) {
-            if (h->p_stage_n < n) {
-                if (h->p_stage) HIP_TRY(hipFree(h->p_stage));
-                h->p_stage = nullptr; h->p_stage_n = 0;
-                HIP_TRY(hipMalloc((void**)&h->p_stage, n * sizeof(float)));
-                h->p_stage_n = n;
+            if (h->par.stage_n < n) {
+                if (h->par.stage) HIP_TRY(hipFree(h->par.stage));
+                h->par.stage = nullptr; h->par.stage_n = 0;
+                HIP_TRY(hipMalloc((void**)&h->par.stage, n * sizeof(float)));
+                h->par.stage_n = n;
             }
-            HIP_TRY(hipMemcpyAsync(h->p_stage, p, n * sizeof(float), hipMemcpyHostToDevice, st));
+            HIP_TRY(hipMemcpyAsync(h->par.stage, p, n * sizeof(float), hipMemcpyHostToDevice, st));
             HIP_TRY(hipStreamSynchronize(st));   // the caller may reuse its host buffer on return
-            src = h->p_stage;
+            src = h->par.stage;
         }
         // Lux-layout device copy (the layer-wise gradient reads the plain parameters)
-        if (h->P_dev && h->nparams != n) {
-            HIP_TRY(hipFree(h->P_dev));
-            h->P_dev = nullptr;
+        if (h->par.P_dev && h->par.n != n) {
+            HIP_TRY(hipFree(h->par.P_dev));
+            h->par.P_dev = nullptr;
         }
-        if (!h->P_dev) HIP_TRY(hipMalloc((void**)&h->P_dev, n * sizeof(float)));
-        HIP_TRY(hipMemcpyAsync(h->P_dev, src, n * sizeof(float), hipMemcpyDeviceToDevice, st));
-        const PackMap* maps[2] = {&h->map_fwd, want_grad ? &h->map_grad : nullptr};
-        float* outs[2] = {h->packed_dev, h->grad_packed};
+        if (!h->par.P_dev) HIP_TRY(hipMalloc((void**)&h->par.P_dev, n * sizeof(float)));
+        HIP_TRY(hipMemcpyAsync(h->par.P_dev, src, n * sizeof(float), hipMemcpyDeviceToDevice, st));
+        const PackMap* maps[2] = {&h->par.map_fwd, want_grad ? &h->grad.map : nullptr};
+        float* outs[2] = {h->par.packed_dev, h->grad.packed};
         for (int i = 0; i < 2; ++i) {
             if (!maps[i]) continue;
             const size_t np = maps[i]->n;
@@ -319,7 +319,7 @@ int cnf_set_params(cnf_handle* h, const float* p, size_t n, const size_t* w_off,
             HIP_TRY(hipGetLastError());
         }
         size_t qo = 0, ql = 0;
-        if (mfma_plan_q_region(h->plan, &qo, &ql)) HIP_TRY(mfma_pack_q_device(h->plan, src, w_off, h->packed_dev, st));
+        if (mfma_plan_q_region(h->plan, &qo, &ql)) HIP_TRY(mfma_pack_q_device(h->plan, src, w_off, h->par.packed_dev, st));
     } else {
         // host path: SIMT parameters (plain copy) and images that are not a gather (split-bf16)
         std::vector<float> host(n);
@@ -330,31 +330,31 @@ int cnf_set_params(cnf_handle* h, const float* p, size_t n, const size_t* w_off,
             std::memcpy(host.data(), p, n * sizeof(float));
         }
         if (mfma) {
-            if (h->P_dev && h->nparams != n) {
-                HIP_TRY(hipFree(h->P_dev));
-                h->P_dev = nullptr;
+            if (h->par.P_dev && h->par.n != n) {
+                HIP_TRY(hipFree(h->par.P_dev));
+                h->par.P_dev = nullptr;
             }
-            if (!h->P_dev) HIP_TRY(hipMalloc((void**)&h->P_dev, n * sizeof(float)));
-            HIP_TRY(hipMemcpyAsync(h->P_dev, host.data(), n * sizeof(float), hipMemcpyHostToDevice, st));
+            if (!h->par.P_dev) HIP_TRY(hipMalloc((void**)&h->par.P_dev, n * sizeof(float)));
+            HIP_TRY(hipMemcpyAsync(h->par.P_dev, host.data(), n * sizeof(float), hipMemcpyHostToDevice, st));
             const size_t bytes = mfma_packed_bytes(h->plan);
             std::vector<float> packed(bytes / sizeof(float), 0.f);
             mfma_pack(h->plan, host.data(), w_off, b_off, packed.data());
-            HIP_TRY(hipMemcpyAsync(h->packed_dev, packed.data(), bytes, hipMemcpyHostToDevice, st));
+            HIP_TRY(hipMemcpyAsync(h->par.packed_dev, packed.data(), bytes, hipMemcpyHostToDevice, st));
             HIP_TRY(hipStreamSynchronize(st));
             if (want_grad) {
                 const size_t gb = grad_packed_bytes(gc);
                 std::vector<float> gp(gb / sizeof(float), 0.f);
                 grad_pack(gc, host.data(), w_off, b_off, gp.data());
-                HIP_TRY(hipMemcpyAsync(h->grad_packed, gp.data(), gb, hipMemcpyHostToDevice, st));
+                HIP_TRY(hipMemcpyAsync(h->grad.packed, gp.data(), gb, hipMemcpyHostToDevice, st));
                 HIP_TRY(hipStreamSynchronize(st));
             }
         } else {
-            if (h->P_dev && h->nparams != n) {
-                HIP_TRY(hipFree(h->P_dev));
-                h->P_dev = nullptr;
+            if (h->par.P_dev && h->par.n != n) {
+                HIP_TRY(hipFree(h->par.P_dev));
+                h->par.P_dev = nullptr;
             }
-            if (!h->P_dev) HIP_TRY(hipMalloc((void**)&h->P_dev, n * sizeof(float)));
-            HIP_TRY(hipMemcpyAsync(h->P_dev, host.data(), n * sizeof(float), hipMemcpyHostToDevice, st));
+            if (!h->par.P_dev) HIP_TRY(hipMalloc((void**)&h->par.P_dev, n * sizeof(float)));
+            HIP_TRY(hipMemcpyAsync(h->par.P_dev, host.data(), n * sizeof(float), hipMemcpyHostToDevice, st));
             HIP_TRY(hipStreamSynchronize(st));
             for (int l = 0; l < c.n_layers; ++l) {
                 h->net.w_off[l] = (int)w_off[l];
@@ -365,47 +365,47 @@ int cnf_set_params(cnf_handle* h, const float* p, size_t n, const size_t* w_off,
     // image of the slab-accumulator gradient kernel: a gather from the Lux-layout device copy kept above
     if (grad_slab_supported(c) && !(mfma && want_grad)) {
         const size_t sb = grad_slab_packed_bytes(c);
-        if (!h->slab_packed) HIP_TRY(hipMalloc((void**)&h->slab_packed, sb));
-        if (!h->map_slab.valid || !same_layout)
-            build_pack_map(h->map_slab, n, sb / sizeof(float),
+        if (!h->grad.slab_packed) HIP_TRY(hipMalloc((void**)&h->grad.slab_packed, sb));
+        if (!h->grad.map_slab.valid || !same_layout)
+            build_pack_map(h->grad.map_slab, n, sb / sizeof(float),
                            [&](const float* src, float* dst) { grad_slab_pack(c, src, w_off, b_off, dst); });
-        if (h->map_slab.valid) {
-            const size_t np = h->map_slab.n;
-            hipLaunchKernelGGL(gather_pack_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, st, h->P_dev,
-                               h->map_slab.idx, h->map_slab.scale, h->slab_packed, np);
+        if (h->grad.map_slab.valid) {
+            const size_t np = h->grad.map_slab.n;
+            hipLaunchKernelGGL(gather_pack_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, st, h->par.P_dev,
+                               h->grad.map_slab.idx, h->grad.map_slab.scale, h->grad.slab_packed, np);
             HIP_TRY(hipGetLastError());
         } else {
-            HIP_TRY(hipFree(h->slab_packed));
-            h->slab_packed = nullptr;
+            HIP_TRY(hipFree(h->grad.slab_packed));
+            h->grad.slab_packed = nullptr;
         }
     }
     // image of the auxiliary cooperative plan (see cnf_handle::plan_cg): wide two-layer slab shapes, one-probe VJP, no conditions
     if (grad_slab_supported(c) && !(mfma && want_grad) && c.mode == CNF_MODE_HUTCH_VJP && c.nprobes == 1 && c.ncond == 0 &&
         c.widths[1] > 96 && c.widths[1] == c.widths[2] && c.widths[1] % 4 == 0) {
-        if (!h->cg_tried) {
-            h->cg_tried = true;
+        if (!h->grad.cg_tried) {
+            h->grad.cg_tried = true;
             const char* e = getenv("CNF_COOP_GRAD_MID");
-            if (!(e && *e == '0')) h->plan_cg = mfma_plan_create(c, true);
+            if (!(e && *e == '0')) h->grad.plan_cg = mfma_plan_create(c, true);
         }
-        if (h->plan_cg) {
-            const size_t cb = mfma_packed_bytes(h->plan_cg);
-            if (!h->cg_packed) HIP_TRY(hipMalloc((void**)&h->cg_packed, cb));
-            if (!h->map_cg.valid || !same_layout)
-                build_pack_map(h->map_cg, n, cb / sizeof(float),
-                               [&](const float* src, float* dst) { mfma_pack(h->plan_cg, src, w_off, b_off, dst); });
-            if (h->map_cg.valid) {
-                const size_t np = h->map_cg.n;
-                hipLaunchKernelGGL(gather_pack_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, st, h->P_dev,
-                                   h->map_cg.idx, h->map_cg.scale, h->cg_packed, np);
+        if (h->grad.plan_cg) {
+            const size_t cb = mfma_packed_bytes(h->grad.plan_cg);
+            if (!h->grad.cg_packed) HIP_TRY(hipMalloc((void**)&h->grad.cg_packed, cb));
+            if (!h->grad.map_cg.valid || !same_layout)
+                build_pack_map(h->grad.map_cg, n, cb / sizeof(float),
+                               [&](const float* src, float* dst) { mfma_pack(h->grad.plan_cg, src, w_off, b_off, dst); });
+            if (h->grad.map_cg.valid) {
+                const size_t np = h->grad.map_cg.n;
+                hipLaunchKernelGGL(gather_pack_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, st, h->par.P_dev,
+                                   h->grad.map_cg.idx, h->grad.map_cg.scale, h->grad.cg_packed, np);
                 HIP_TRY(hipGetLastError());
             } else {
-                HIP_TRY(hipFree(h->cg_packed));
-                h->cg_packed = nullptr;
+                HIP_TRY(hipFree(h->grad.cg_packed));
+                h->grad.cg_packed = nullptr;
             }
         }
     }
-    h->nparams = n;
-    h->have_params = true;
+    h->par.n = n;
+    h->par.have = true;
     return CNF_OK;
 }
 
@@ -416,7 +416,7 @@ static int generic_aug_f(cnf_handle* h, const StageIn& in, float t, const float*
                          float* du, bool first_of_solve, hipStream_t st) {
     if (h->path == CNF_PATH_LAYERED && (h->layered_forced || B >= layered_min_batch())) {
         std::string msg;
-        hipError_t e = layered_aug_f(&h->layered, h->cfg, h->P_dev, h->w_off.data(), h->b_off.data(), first_of_solve, in, t,
+        hipError_t e = layered_aug_f(&h->grad.layered, h->cfg, h->par.P_dev, h->par.w_off.data(), h->par.b_off.data(), first_of_solve, in, t,
                                      eps, ys, B, du, st, &msg);
         if (e == hipErrorNotSupported) return fail(CNF_ERR_UNSUPPORTED, msg);
         if (e != hipSuccess) return fail(CNF_ERR_HIP, msg);
@@ -424,14 +424,14 @@ static int generic_aug_f(cnf_handle* h, const StageIn& in, float t, const float*
     }
     int rc = ensure_ws(h, B);
     if (rc) return rc;
-    HIP_TRY(simt_aug_f(h->net, h->P_dev, in, t, eps, ys, B, du, h->ws, h->ws_B, st));
+    HIP_TRY(simt_aug_f(h->net, h->par.P_dev, in, t, eps, ys, B, du, h->simt.ws, h->simt.ws_B, st));
     return CNF_OK;
 }
 
 extern "C++" {
 int cnf::api_check_call(cnf_handle* h, const float* eps, const float* ys, int64_t B, const char* who) {
     if (!h) return fail(CNF_ERR_INVALID, std::string(who) + ": null handle");
-    if (!h->have_params) return fail(CNF_ERR_NO_PARAMS, std::string(who) + ": cnf_set_params not called");
+    if (!h->par.have) return fail(CNF_ERR_NO_PARAMS, std::string(who) + ": cnf_set_params not called");
     if (B < 0) return fail(CNF_ERR_INVALID, std::string(who) + ": negative batch");
     if (h->cfg.mode != CNF_MODE_EXACT && !eps && B > 0)
         return fail(CNF_ERR_INVALID, std::string(who) + ": eps is required in Hutchinson modes");
@@ -454,7 +454,7 @@ int cnf_aug_f(cnf_handle* h, float* du, const float* u, float t, const float* ep
         SolveArgs a{};
         a.u0 = u; a.eps = eps; a.ys = ys; a.B = B; a.nsteps = 0; a.alg = 0; a.t0 = t; a.t1 = t;
         a.u_out = du; a.nvars = h->cfg.nvars; a.reg_aug = 0;
-        HIP_TRY(mfma_solve(h->plan, h->packed_dev, a, st));
+        HIP_TRY(mfma_solve(h->plan, h->par.packed_dev, a, st));
         return CNF_OK;
     }
     StageIn in{};
@@ -470,7 +470,7 @@ static int simt_integrate(cnf_handle* h, int alg, int nsteps, float t0, float t1
     const Tableau T = make_tableau(alg);
     const size_t n = (size_t)h->S * (size_t)B;
     float* k[6];
-    for (int i = 0; i < 6; ++i) k[i] = h->kbuf + (size_t)i * n;
+    for (int i = 0; i < 6; ++i) k[i] = h->simt.kbuf + (size_t)i * n;
     const float dt = (t1 - t0) / (float)nsteps;
     for (int step = 0; step < nsteps; ++step) {
         const float tn = t0 + (float)step * dt;
@@ -504,7 +504,7 @@ int cnf_integrate_fixed(cnf_handle* h, int alg, int nsteps, float t0, float t1, 
         SolveArgs a{};
         a.u0 = u0; a.eps = eps; a.ys = ys; a.B = B; a.nsteps = nsteps; a.alg = alg;
         a.t0 = t0; a.t1 = t1; a.u_out = u1; a.nvars = h->cfg.nvars; a.reg_aug = 0;
-        HIP_TRY(mfma_solve(h->plan, h->packed_dev, a, st));
+        HIP_TRY(mfma_solve(h->plan, h->par.packed_dev, a, st));
         return CNF_OK;
     }
     if (u1 != u0)
@@ -530,12 +530,12 @@ int cnf_inference_fixed(cnf_handle* h, int alg, int nsteps, float t0, float t1, 
         a.x = x; a.eps = eps; a.ys = ys; a.B = B; a.nsteps = nsteps; a.alg = alg;
         a.t0 = t0; a.t1 = t1; a.u_out = u_final; a.logp = logp; a.regs = regs;
         a.nvars = h->cfg.nvars; a.reg_aug = reg_aug;
-        HIP_TRY(mfma_solve(h->plan, h->packed_dev, a, st));
+        HIP_TRY(mfma_solve(h->plan, h->par.packed_dev, a, st));
         return CNF_OK;
     }
     rc = ensure_kbuf(h, B);
     if (rc) return rc;
-    float* u = u_final ? u_final : h->kbuf + 6 * (size_t)h->S * (size_t)h->kbuf_B;
+    float* u = u_final ? u_final : h->simt.kbuf + 6 * (size_t)h->S * (size_t)h->simt.kbuf_B;
     HIP_TRY(assemble_u0(x, h->cfg.nvars, h->S, B, u, st));
     rc = simt_integrate(h, alg, nsteps, t0, t1, u, eps, ys, B, st);
     if (rc) return rc;
@@ -603,7 +603,7 @@ int cnf_inference_fixed_dt(cnf_handle* h, int alg, float dt, float t0, float t1,
     if (!u) {
         rc = api_ensure_adaptive_buf(h, B);
         if (rc) return rc;
-        u = h->ad_buf;
+        u = h->adp.buf;
     }
     HIP_TRY(assemble_u0(x, h->cfg.nvars, h->S, B, u, st));
     if (p.n_full > 0) {
@@ -631,7 +631,7 @@ int cnf::api_eval_dynamics(cnf_handle* h, const StageIn& in, float t, const floa
         SolveArgs a{};
         a.u0 = uin; a.eps = eps; a.ys = ys; a.B = B; a.nsteps = 0; a.alg = 0; a.t0 = t; a.t1 = t;
         a.u_out = du; a.nvars = h->cfg.nvars; a.reg_aug = 0;
-        HIP_TRY(mfma_solve(h->plan, h->packed_dev, a, st));
+        HIP_TRY(mfma_solve(h->plan, h->par.packed_dev, a, st));
         return CNF_OK;
     }
     return generic_aug_f(h, in, t, eps, ys, B, du, first, st);
@@ -642,16 +642,16 @@ extern "C++" {
 int cnf::api_integrate_grid(cnf_handle* h, int alg, int nsteps, const float* tgrid, float* u, const float* eps, const float* ys,
                             int64_t B, hipStream_t st) {
     const size_t n = (size_t)h->S * (size_t)B;
-    if (B > h->ebuf_B) {
-        if (h->ebuf) HIP_TRY(hipFree(h->ebuf));
-        h->ebuf = nullptr; h->ebuf_B = 0;
-        HIP_TRY(hipMalloc((void**)&h->ebuf, 8 * n * sizeof(float)));
-        h->ebuf_B = B;
+    if (B > h->emb.B) {
+        if (h->emb.buf) HIP_TRY(hipFree(h->emb.buf));
+        h->emb.buf = nullptr; h->emb.B = 0;
+        HIP_TRY(hipMalloc((void**)&h->emb.buf, 8 * n * sizeof(float)));
+        h->emb.B = B;
     }
-    const size_t slot = (size_t)h->S * (size_t)h->ebuf_B;
-    float* stage = h->ebuf + 7 * slot;
+    const size_t slot = (size_t)h->S * (size_t)h->emb.B;
+    float* stage = h->emb.buf + 7 * slot;
     float* k[6];
-    for (int i = 0; i < 6; ++i) k[i] = h->ebuf + (size_t)i * slot;
+    for (int i = 0; i < 6; ++i) k[i] = h->emb.buf + (size_t)i * slot;
     const Tableau T = make_tableau(alg);
     for (int s = 0; s < nsteps; ++s) {
         const float tn = tgrid[s], dt = tgrid[s + 1] - tgrid[s];

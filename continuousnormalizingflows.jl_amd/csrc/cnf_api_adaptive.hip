@@ -25,19 +25,19 @@ int cnf_step_embedded(cnf_handle* h, int alg, int flags, float t, float dt, cons
     DeviceGuard g(h->cfg.device_id);
     hipStream_t st = (hipStream_t)stream;
     const size_t n = (size_t)h->S * (size_t)B;
-    if (B > h->ebuf_B) {
-        if (h->ebuf) HIP_TRY(hipFree(h->ebuf));
-        h->ebuf = nullptr; h->ebuf_B = 0;
-        HIP_TRY(hipMalloc((void**)&h->ebuf, 8 * n * sizeof(float)));
-        h->ebuf_B = B;
+    if (B > h->emb.B) {
+        if (h->emb.buf) HIP_TRY(hipFree(h->emb.buf));
+        h->emb.buf = nullptr; h->emb.B = 0;
+        HIP_TRY(hipMalloc((void**)&h->emb.buf, 8 * n * sizeof(float)));
+        h->emb.B = B;
         flags = 0;   // the cached stages went with the old buffer
     }
-    if (!h->err_partial) HIP_TRY(hipMalloc((void**)&h->err_partial, kErrBlocks * sizeof(double)));
-    const size_t slot = (size_t)h->S * (size_t)h->ebuf_B;
-    float* stage = h->ebuf + 7 * slot;
-    if (flags & CNF_STEP_FSAL) { const int tmp = h->ek[0]; h->ek[0] = h->ek[6]; h->ek[6] = tmp; }
+    if (!h->emb.err_partial) HIP_TRY(hipMalloc((void**)&h->emb.err_partial, kErrBlocks * sizeof(double)));
+    const size_t slot = (size_t)h->S * (size_t)h->emb.B;
+    float* stage = h->emb.buf + 7 * slot;
+    if (flags & CNF_STEP_FSAL) { const int tmp = h->emb.k[0]; h->emb.k[0] = h->emb.k[6]; h->emb.k[6] = tmp; }
     float* k[7];
-    for (int i = 0; i < 7; ++i) k[i] = h->ebuf + (size_t)h->ek[i] * slot;
+    for (int i = 0; i < 7; ++i) k[i] = h->emb.buf + (size_t)h->emb.k[i] * slot;
     const Tableau T = make_tableau(CNF_ALG_TSIT5);
     // b - bhat of the embedded 4th-order solution (Tsitouras 2011); satisfies the order-4 conditions to 1e-15
     static const float btilde[7] = {-0.00178001105222577714f, -0.0008164344596567469f, 0.007880878010261995f,
@@ -47,17 +47,17 @@ int cnf_step_embedded(cnf_handle* h, int alg, int flags, float t, float dt, cons
         // fused attempt: the six stages and the update in ONE launch of the solve kernel (nsteps = 1), which also
         // writes every stage derivative; then the 7th stage at u_new and the error reduction.  (The fused step
         // evaluates its own first stage, so the FSAL / RETRY hints save nothing here; 3 launches instead of 14.)
-        for (int i = 0; i < 7; ++i) k[i] = h->ebuf + (size_t)i * n;   // [stage][B][S], packed for this B
+        for (int i = 0; i < 7; ++i) k[i] = h->emb.buf + (size_t)i * n;   // [stage][B][S], packed for this B
         SolveArgs a{};
         a.u0 = u; a.eps = eps; a.ys = ys; a.B = B; a.nsteps = 1; a.alg = CNF_ALG_TSIT5; a.t0 = t; a.t1 = t + dt;
-        a.u_out = u_new; a.nvars = h->cfg.nvars; a.reg_aug = 0; a.kfull = h->ebuf;
+        a.u_out = u_new; a.nvars = h->cfg.nvars; a.reg_aug = 0; a.kfull = h->emb.buf;
         a.dt_exact = dt;   // the step the error estimate is scaled with, not fl(fl(t + dt) - t)
-        HIP_TRY(mfma_solve(h->plan, h->packed_dev, a, st));
+        HIP_TRY(mfma_solve(h->plan, h->par.packed_dev, a, st));
         StageIn last{};
         last.u = u_new; last.nprev = 0; last.dt = 0.f;
         rc = api_eval_dynamics(h, last, t + dt, eps, ys, B, k[6], stage, false, st);
         if (rc) return rc;
-        HIP_TRY(embedded_error(u, u_new, k, btilde, 7, dt, abstol, reltol, (int64_t)n, h->err_partial, err_sumsq, st));
+        HIP_TRY(embedded_error(u, u_new, k, btilde, 7, dt, abstol, reltol, (int64_t)n, h->emb.err_partial, err_sumsq, st));
         return CNF_OK;
     }
     if (!(flags & (CNF_STEP_FSAL | CNF_STEP_RETRY))) {
@@ -81,19 +81,19 @@ int cnf_step_embedded(cnf_handle* h, int alg, int flags, float t, float dt, cons
     last.u = u_new; last.nprev = 0; last.dt = 0.f;
     rc = api_eval_dynamics(h, last, t + dt, eps, ys, B, k[6], stage, false, st);   // 7th stage = first stage of the next step
     if (rc) return rc;
-    HIP_TRY(embedded_error(u, u_new, k, btilde, 7, dt, abstol, reltol, (int64_t)n, h->err_partial, err_sumsq, st));
+    HIP_TRY(embedded_error(u, u_new, k, btilde, 7, dt, abstol, reltol, (int64_t)n, h->emb.err_partial, err_sumsq, st));
     return CNF_OK;
 }
 
 // ---- variable-step variable-order Adams PECE: the reference's default alg = VCABM() ----
 
-static inline float* vc_vec(cnf_handle* h, int i) { return h->vc_buf + (size_t)i * (size_t)h->S * (size_t)h->vc_B; }
+static inline float* vc_vec(cnf_handle* h, int i) { return h->vc.buf + (size_t)i * (size_t)h->S * (size_t)h->vc.B; }
 static inline float* vc_diffs(cnf_handle* h, int half) { return vc_vec(h, 6 + half * kVcSlots); }
 
 static int vc_check(cnf_handle* h, const float* eps, const float* ys, int64_t B, const char* who) {
     int rc = api_check_call(h, eps, ys, B, who);
     if (rc) return rc;
-    if (h->vc_B < 0 || B != h->vc_B) return fail(CNF_ERR_INVALID, std::string(who) + ": cnf_vcabm_begin was not called for this batch");
+    if (h->vc.B < 0 || B != h->vc.B) return fail(CNF_ERR_INVALID, std::string(who) + ": cnf_vcabm_begin was not called for this batch");
     return CNF_OK;
 }
 
@@ -103,32 +103,32 @@ int cnf_vcabm_begin(cnf_handle* h, float t0, const float* u0, const float* eps, 
     if (B > 0 && !u0) return fail(CNF_ERR_INVALID, "cnf_vcabm_begin: null u0");
     DeviceGuard g(h->cfg.device_id);
     hipStream_t st = (hipStream_t)stream;
-    if (B > h->vc_cap) {   // grown on demand only: alternating batch sizes (a shorter last mini-batch) reuse the allocation
-        if (h->vc_buf) HIP_TRY(hipFree(h->vc_buf));
-        h->vc_buf = nullptr; h->vc_cap = 0; h->vc_B = -1;
-        HIP_TRY(hipMalloc((void**)&h->vc_buf, (6 + 2 * kVcSlots) * (size_t)h->S * (size_t)B * sizeof(float)));
-        h->vc_cap = B;
+    if (B > h->vc.cap) {   // grown on demand only: alternating batch sizes (a shorter last mini-batch) reuse the allocation
+        if (h->vc.buf) HIP_TRY(hipFree(h->vc.buf));
+        h->vc.buf = nullptr; h->vc.cap = 0; h->vc.B = -1;
+        HIP_TRY(hipMalloc((void**)&h->vc.buf, (6 + 2 * kVcSlots) * (size_t)h->S * (size_t)B * sizeof(float)));
+        h->vc.cap = B;
     }
-    h->vc_B = B;   // the vectors of this solve are packed at stride S x B inside the allocation
-    if (!h->vc_partial) HIP_TRY(hipMalloc((void**)&h->vc_partial, (vcabm_partial_doubles() + 8) * sizeof(double)));   // + result slots of cnf_solve_vcabm
-    h->vc_iu = 0; h->vc_iun = 2; h->vc_if = 3; h->vc_ifn = 5; h->vc_cur = 0;
-    h->vc_nhist = 0; h->vc_k = 0; h->vc_avail = 0; h->vc_m = 0; h->vc_t = t0; h->vc_dt = 0.0;
-    for (double& d : h->vc_hist) d = 0.0;
+    h->vc.B = B;   // the vectors of this solve are packed at stride S x B inside the allocation
+    if (!h->vc.partial) HIP_TRY(hipMalloc((void**)&h->vc.partial, (vcabm_partial_doubles() + 8) * sizeof(double)));   // + result slots of cnf_solve_vcabm
+    h->vc.iu = 0; h->vc.iun = 2; h->vc.ifn0 = 3; h->vc.ifn1 = 5; h->vc.cur = 0;
+    h->vc.nhist = 0; h->vc.k = 0; h->vc.avail = 0; h->vc.m = 0; h->vc.t = t0; h->vc.dt = 0.0;
+    for (double& d : h->vc.hist) d = 0.0;
     if (B == 0) return CNF_OK;
     const size_t n = (size_t)h->S * (size_t)B;
-    HIP_TRY(hipMemcpyAsync(vc_vec(h, h->vc_iu), u0, n * sizeof(float), hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(vc_vec(h, h->vc.iu), u0, n * sizeof(float), hipMemcpyDeviceToDevice, st));
     StageIn in{};
-    in.u = vc_vec(h, h->vc_iu); in.nprev = 0; in.dt = 0.f;
-    return api_eval_dynamics(h, in, t0, eps, ys, B, vc_vec(h, h->vc_if), nullptr, true, st);
+    in.u = vc_vec(h, h->vc.iu); in.nprev = 0; in.dt = 0.f;
+    return api_eval_dynamics(h, in, t0, eps, ys, B, vc_vec(h, h->vc.ifn0), nullptr, true, st);
 }
 
 int cnf_vcabm_attempt(cnf_handle* h, int order, float dt, const float* eps, const float* ys, int64_t B, float abstol,
                       float reltol, double* err3, void* stream) {
     int rc = vc_check(h, eps, ys, B, "cnf_vcabm_attempt");
     if (rc) return rc;
-    if (order < 1 || order > CNF_VCABM_MAX_ORDER || order > h->vc_nhist + 1)
+    if (order < 1 || order > CNF_VCABM_MAX_ORDER || order > h->vc.nhist + 1)
         return fail(CNF_ERR_INVALID, "cnf_vcabm_attempt: order must be in 1..12 and at most one more than the accepted steps");
-    if (std::min(order, h->vc_nhist) > h->vc_avail)
+    if (std::min(order, h->vc.nhist) > h->vc.avail)
         return fail(CNF_ERR_INVALID, "cnf_vcabm_attempt: the order can rise by at most one per accepted step (the stored differences end there)");
     if (!(abstol >= 0.f) || !(reltol >= 0.f) || (abstol == 0.f && reltol == 0.f))
         return fail(CNF_ERR_INVALID, "cnf_vcabm_attempt: tolerances must be non-negative and not both zero");
@@ -138,14 +138,14 @@ int cnf_vcabm_attempt(cnf_handle* h, int order, float dt, const float* eps, cons
     DeviceGuard g(h->cfg.device_id);
     hipStream_t st = (hipStream_t)stream;
     const int k = order;
-    const int m = std::min(k + 1, h->vc_nhist + 1);
+    const int m = std::min(k + 1, h->vc.nhist + 1);
     // step sizes newest first, the candidate in front (Hairer, Noersett, Wanner I, III.5: t_{n+1} - t_{n-j+1} = sum of the j newest)
     double dts[kVcSlots + 2];
     dts[0] = dt;
-    for (int i = 0; i <= kVcSlots; ++i) dts[i + 1] = h->vc_hist[i];
+    for (int i = 0; i <= kVcSlots; ++i) dts[i + 1] = h->vc.hist[i];
     VcCoef c{};
-    c.ps_old = vc_diffs(h, h->vc_cur);
-    c.ps_new = vc_diffs(h, h->vc_cur ^ 1);
+    c.ps_old = vc_diffs(h, h->vc.cur);
+    c.ps_new = vc_diffs(h, h->vc.cur ^ 1);
     c.ld = (size_t)h->S * (size_t)B;
     c.k = k; c.m = m; c.dt = dt;
     double beta = 1.0, num = 0.0, den = 0.0;
@@ -174,14 +174,14 @@ int cnf_vcabm_attempt(cnf_handle* h, int order, float dt, const float* eps, cons
     c.e1 = k >= 2 ? (float)((double)dt * (gd[k - 1] - gd[k - 2])) : 0.f;
     c.e2 = k >= 3 ? (float)((double)dt * (gd[k - 2] - gd[k - 3])) : 0.f;
     const int64_t n = (int64_t)c.ld;
-    float *u = vc_vec(h, h->vc_iu), *p = vc_vec(h, 1), *un = vc_vec(h, h->vc_iun), *d = vc_vec(h, 4);
-    HIP_TRY(vcabm_predict(vc_vec(h, h->vc_if), u, c, n, p, st));                                    // P
+    float *u = vc_vec(h, h->vc.iu), *p = vc_vec(h, 1), *un = vc_vec(h, h->vc.iun), *d = vc_vec(h, 4);
+    HIP_TRY(vcabm_predict(vc_vec(h, h->vc.ifn0), u, c, n, p, st));                                    // P
     StageIn in{};
     in.u = p; in.nprev = 0; in.dt = 0.f;
-    rc = api_eval_dynamics(h, in, (float)(h->vc_t + (double)dt), eps, ys, B, d, nullptr, false, st);   // E
+    rc = api_eval_dynamics(h, in, (float)(h->vc.t + (double)dt), eps, ys, B, d, nullptr, false, st);   // E
     if (rc) return rc;
-    HIP_TRY(vcabm_correct(d, p, u, c, abstol, reltol, n, un, h->vc_partial, err3, st));             // C
-    h->vc_k = k; h->vc_m = m; h->vc_dt = dt;
+    HIP_TRY(vcabm_correct(d, p, u, c, abstol, reltol, n, un, h->vc.partial, err3, st));             // C
+    h->vc.k = k; h->vc.m = m; h->vc.dt = dt;
     return CNF_OK;
 }
 
@@ -190,17 +190,17 @@ int cnf_vcabm_accept(cnf_handle* h, const float* eps, const float* ys, int64_t B
     int rc = vc_check(h, eps, ys, B, "cnf_vcabm_accept");
     if (rc) return rc;
     if (B == 0) return CNF_OK;
-    if (h->vc_k == 0) return fail(CNF_ERR_INVALID, "cnf_vcabm_accept: no pending attempt");
-    const int k = h->vc_k;
-    if (err_up && (k >= CNF_VCABM_MAX_ORDER || h->vc_nhist < k))
+    if (h->vc.k == 0) return fail(CNF_ERR_INVALID, "cnf_vcabm_accept: no pending attempt");
+    const int k = h->vc.k;
+    if (err_up && (k >= CNF_VCABM_MAX_ORDER || h->vc.nhist < k))
         return fail(CNF_ERR_INVALID, "cnf_vcabm_accept: the order k+1 estimate needs k accepted steps and k < 12");
     DeviceGuard g(h->cfg.device_id);
     hipStream_t st = (hipStream_t)stream;
     const size_t n = (size_t)h->S * (size_t)B;
-    float *u = vc_vec(h, h->vc_iu), *un = vc_vec(h, h->vc_iun), *fnew = vc_vec(h, h->vc_ifn);
+    float *u = vc_vec(h, h->vc.iu), *un = vc_vec(h, h->vc.iun), *fnew = vc_vec(h, h->vc.ifn1);
     StageIn in{};
     in.u = un; in.nprev = 0; in.dt = 0.f;
-    rc = api_eval_dynamics(h, in, (float)(h->vc_t + h->vc_dt), eps, ys, B, fnew, nullptr, false, st);   // E
+    rc = api_eval_dynamics(h, in, (float)(h->vc.t + h->vc.dt), eps, ys, B, fnew, nullptr, false, st);   // E
     if (rc) return rc;
     if (err_up) {
         // gamma*_j of the Adams-Moulton family: sum_{i<=j} gamma*_i / (j - i + 1) = [j == 0]
@@ -212,30 +212,30 @@ int cnf_vcabm_accept(cnf_handle* h, const float* eps, const float* ys, int64_t B
             gs[j] = -a;
         }
         VcCoef c{};
-        c.ps_new = vc_diffs(h, h->vc_cur ^ 1);
+        c.ps_new = vc_diffs(h, h->vc.cur ^ 1);
         c.ld = n; c.k = k;
-        c.e0 = (float)(h->vc_dt * gs[k + 1]);
-        HIP_TRY(vcabm_errup(fnew, u, un, c, abstol, reltol, (int64_t)n, h->vc_partial, err_up, st));
+        c.e0 = (float)(h->vc.dt * gs[k + 1]);
+        HIP_TRY(vcabm_errup(fnew, u, un, c, abstol, reltol, (int64_t)n, h->vc.partial, err_up, st));
     }
-    std::swap(h->vc_iu, h->vc_iun);
-    std::swap(h->vc_if, h->vc_ifn);
-    h->vc_cur ^= 1;
-    for (int i = kVcSlots; i > 0; --i) h->vc_hist[i] = h->vc_hist[i - 1];
-    h->vc_hist[0] = h->vc_dt;
-    h->vc_t += h->vc_dt;
-    h->vc_nhist += 1;
-    h->vc_avail = h->vc_m;
-    h->vc_k = 0;
+    std::swap(h->vc.iu, h->vc.iun);
+    std::swap(h->vc.ifn0, h->vc.ifn1);
+    h->vc.cur ^= 1;
+    for (int i = kVcSlots; i > 0; --i) h->vc.hist[i] = h->vc.hist[i - 1];
+    h->vc.hist[0] = h->vc.dt;
+    h->vc.t += h->vc.dt;
+    h->vc.nhist += 1;
+    h->vc.avail = h->vc.m;
+    h->vc.k = 0;
     return CNF_OK;
 }
 
 int cnf_vcabm_state(cnf_handle* h, int64_t B, float* u_out, double* t_out, void* stream) {
     if (!h) return fail(CNF_ERR_INVALID, "cnf_vcabm_state: null handle");
-    if (h->vc_B < 0 || B != h->vc_B) return fail(CNF_ERR_INVALID, "cnf_vcabm_state: cnf_vcabm_begin was not called for this batch");
-    if (t_out) *t_out = h->vc_t;
+    if (h->vc.B < 0 || B != h->vc.B) return fail(CNF_ERR_INVALID, "cnf_vcabm_state: cnf_vcabm_begin was not called for this batch");
+    if (t_out) *t_out = h->vc.t;
     if (u_out && B > 0) {
         DeviceGuard g(h->cfg.device_id);
-        HIP_TRY(hipMemcpyAsync(u_out, vc_vec(h, h->vc_iu), (size_t)h->S * (size_t)B * sizeof(float), hipMemcpyDeviceToDevice,
+        HIP_TRY(hipMemcpyAsync(u_out, vc_vec(h, h->vc.iu), (size_t)h->S * (size_t)B * sizeof(float), hipMemcpyDeviceToDevice,
                                (hipStream_t)stream));
     }
     return CNF_OK;
@@ -256,23 +256,23 @@ int cnf_solve_vcabm(cnf_handle* h, float t0, float t1, const float* u0, const fl
     if (maxiters < 1) return fail(CNF_ERR_INVALID, "cnf_solve_vcabm: maxiters >= 1 required");
     if (B > 0 && t1 != t0 && h->path == CNF_PATH_MFMA && h->plan && B <= mfma_vcabm_capacity(h->plan)) {
         // the batch fits the chip's wave slots: passes, error norms and the step / order policy in one launch
-        h->last_controller = 1;
+        h->adp.last_controller = 1;
         DeviceGuard g(h->cfg.device_id);
         hipStream_t st = (hipStream_t)stream;
         const int dts_cap = maxiters < (1 << 20) ? maxiters : (1 << 20);
         const size_t need = mfma_adaptive_scratch_bytes(B, dts_cap);
-        if (need > h->dc_bytes) {
-            if (h->dc_buf) HIP_TRY(hipFree(h->dc_buf));
-            h->dc_buf = nullptr; h->dc_bytes = 0;
-            HIP_TRY(hipMalloc(&h->dc_buf, need));
-            h->dc_bytes = need;
+        if (need > h->adp.dc_bytes) {
+            if (h->adp.dc_buf) HIP_TRY(hipFree(h->adp.dc_buf));
+            h->adp.dc_buf = nullptr; h->adp.dc_bytes = 0;
+            HIP_TRY(hipMalloc(&h->adp.dc_buf, need));
+            h->adp.dc_bytes = need;
         }
         SolveArgs a{};
         a.u0 = u0; a.eps = eps; a.ys = ys; a.B = B; a.nsteps = 1; a.alg = CNF_ALG_TSIT5; a.t0 = t0; a.t1 = t1;
         a.u_out = u1; a.nvars = h->cfg.nvars; a.reg_aug = 0;
         int *stats_dev = nullptr, *orders_dev = nullptr;
         float* dts_dev = nullptr;
-        const hipError_t le = mfma_solve_vcabm(h->plan, h->packed_dev, a, abstol, reltol, dt_init, maxiters, h->dc_buf, dts_cap,
+        const hipError_t le = mfma_solve_vcabm(h->plan, h->par.packed_dev, a, abstol, reltol, dt_init, maxiters, h->adp.dc_buf, dts_cap,
                                                &stats_dev, &dts_dev, &orders_dev, st);
         if (le != hipSuccess) {
             (void)hipGetLastError();
@@ -290,10 +290,10 @@ int cnf_solve_vcabm(cnf_handle* h, float t0, float t1, const float* u0, const fl
         if (na > 0 && dts_out) HIP_TRY(hipMemcpyAsync(dts_out, dts_dev, (size_t)na * sizeof(float), hipMemcpyDeviceToHost, st));
         if (na > 0 && orders_out) HIP_TRY(hipMemcpyAsync(orders_out, orders_dev, (size_t)na * sizeof(int32_t), hipMemcpyDeviceToHost, st));
         if (na > 0 && (dts_out || orders_out)) HIP_TRY(hipStreamSynchronize(st));
-        h->vc_B = -1;   // the step-wise entry points have no state from this solve
+        h->vc.B = -1;   // the step-wise entry points have no state from this solve
         return CNF_OK;
     }
-    h->last_controller = 0;
+    h->adp.last_controller = 0;
     rc = cnf_vcabm_begin(h, t0, u0, eps, ys, B, stream);
     if (rc) return rc;
     int nf = B > 0 ? 1 : 0, naccept = 0, nreject = 0, max_order = 0;
@@ -306,7 +306,7 @@ int cnf_solve_vcabm(cnf_handle* h, float t0, float t1, const float* u0, const fl
     hipStream_t st = (hipStream_t)stream;
     const size_t n = (size_t)h->S * (size_t)B;
     const double ntot = (double)n;
-    double* res = h->vc_partial + vcabm_partial_doubles();   // device result slots
+    double* res = h->vc.partial + vcabm_partial_doubles();   // device result slots
     double host[4];
     auto fetch = [&](int cnt) -> int {
         HIP_TRY(hipMemcpyAsync(host, res, cnt * sizeof(double), hipMemcpyDeviceToHost, st));
@@ -317,9 +317,9 @@ int cnf_solve_vcabm(cnf_handle* h, float t0, float t1, const float* u0, const fl
     if (dt_init != 0.f) {
         dt = std::min((double)std::fabs(dt_init), span);
     } else {   // ode_determine_initdt (Hairer, Noersett, Wanner I, II.4), RMS norm over all S*B entries; the exponent is 1 / get_current_alg_order = 1 / (the cache's current order) = 1 at the start of a VCABM solve (recalled, not read)
-        float *u = vc_vec(h, h->vc_iu), *f0 = vc_vec(h, h->vc_if), *ue = vc_vec(h, 1), *f1 = vc_vec(h, 4);
-        HIP_TRY(vcabm_scaled_sumsq(u, nullptr, u, abstol, reltol, (int64_t)n, h->vc_partial, res, st));
-        HIP_TRY(vcabm_scaled_sumsq(f0, nullptr, u, abstol, reltol, (int64_t)n, h->vc_partial, res + 1, st));
+        float *u = vc_vec(h, h->vc.iu), *f0 = vc_vec(h, h->vc.ifn0), *ue = vc_vec(h, 1), *f1 = vc_vec(h, 4);
+        HIP_TRY(vcabm_scaled_sumsq(u, nullptr, u, abstol, reltol, (int64_t)n, h->vc.partial, res, st));
+        HIP_TRY(vcabm_scaled_sumsq(f0, nullptr, u, abstol, reltol, (int64_t)n, h->vc.partial, res + 1, st));
         rc = fetch(2);
         if (rc) return rc;
         const double d0 = std::sqrt(host[0] / ntot), d1 = std::sqrt(host[1] / ntot);
@@ -333,7 +333,7 @@ int cnf_solve_vcabm(cnf_handle* h, float t0, float t1, const float* u0, const fl
         rc = api_eval_dynamics(h, in, (float)((double)t0 + tdir * h0), eps, ys, B, f1, nullptr, false, st);
         if (rc) return rc;
         ++nf;
-        HIP_TRY(vcabm_scaled_sumsq(f1, f0, u, abstol, reltol, (int64_t)n, h->vc_partial, res, st));
+        HIP_TRY(vcabm_scaled_sumsq(f1, f0, u, abstol, reltol, (int64_t)n, h->vc.partial, res, st));
         rc = fetch(1);
         if (rc) return rc;
         const double d2 = std::sqrt(host[0] / ntot) / h0, dmax = std::max(d1, d2);
@@ -394,11 +394,11 @@ int cnf_solve_vcabm(cnf_handle* h, float t0, float t1, const float* u0, const fl
 // solvers._adaptive_integrate restated inside the library (single process).  Synchronises `stream`.
 extern "C++" {
 int cnf::api_ensure_adaptive_buf(cnf_handle* h, int64_t B) {
-    if (B <= h->ad_B) return CNF_OK;
-    if (h->ad_buf) HIP_TRY(hipFree(h->ad_buf));
-    h->ad_buf = nullptr; h->ad_B = 0;
-    HIP_TRY(hipMalloc((void**)&h->ad_buf, 6 * (size_t)h->S * (size_t)B * sizeof(float)));   // 4 for the solve, 2 for cnf_loss_grad_adaptive
-    h->ad_B = B;
+    if (B <= h->adp.B) return CNF_OK;
+    if (h->adp.buf) HIP_TRY(hipFree(h->adp.buf));
+    h->adp.buf = nullptr; h->adp.B = 0;
+    HIP_TRY(hipMalloc((void**)&h->adp.buf, 6 * (size_t)h->S * (size_t)B * sizeof(float)));   // 4 for the solve, 2 for cnf_loss_grad_adaptive
+    h->adp.B = B;
     return CNF_OK;
 }
 }  // extern "C++"
@@ -425,21 +425,21 @@ int cnf::api_solve_tsit5(cnf_handle* h, float t0, float t1, const float* u0, con
     }
     if (h->path == CNF_PATH_MFMA && h->plan && B <= mfma_adaptive_capacity(h->plan)) {
         // the batch fits the chip's wave slots: the whole solve, step controller included, in one launch
-        h->last_controller = 1;
+        h->adp.last_controller = 1;
         const int dts_cap = maxiters < (1 << 20) ? maxiters : (1 << 20);
         const size_t need = mfma_adaptive_scratch_bytes(B, dts_cap);
-        if (need > h->dc_bytes) {
-            if (h->dc_buf) HIP_TRY(hipFree(h->dc_buf));
-            h->dc_buf = nullptr; h->dc_bytes = 0;
-            HIP_TRY(hipMalloc(&h->dc_buf, need));
-            h->dc_bytes = need;
+        if (need > h->adp.dc_bytes) {
+            if (h->adp.dc_buf) HIP_TRY(hipFree(h->adp.dc_buf));
+            h->adp.dc_buf = nullptr; h->adp.dc_bytes = 0;
+            HIP_TRY(hipMalloc(&h->adp.dc_buf, need));
+            h->adp.dc_bytes = need;
         }
         SolveArgs a{};
         a.u0 = u0; a.eps = eps; a.ys = ys; a.B = B; a.nsteps = 1; a.alg = CNF_ALG_TSIT5; a.t0 = t0; a.t1 = t1;
         a.u_out = u1; a.nvars = h->cfg.nvars; a.reg_aug = 0;
         int* stats_dev = nullptr;
         float* dts_dev = nullptr;
-        const hipError_t le = mfma_solve_adaptive(h->plan, h->packed_dev, a, abstol, reltol, dt_init, maxiters, h->dc_buf, dts_cap, &stats_dev, &dts_dev, st);
+        const hipError_t le = mfma_solve_adaptive(h->plan, h->par.packed_dev, a, abstol, reltol, dt_init, maxiters, h->adp.dc_buf, dts_cap, &stats_dev, &dts_dev, st);
         if (le != hipSuccess) {
             (void)hipGetLastError();   // not sticky: nothing was launched
             return fail(CNF_ERR_HIP, std::string("cnf_solve_tsit5: launch of the device-controlled solve failed: ") + hipGetErrorString(le));
@@ -468,14 +468,14 @@ int cnf::api_solve_tsit5(cnf_handle* h, float t0, float t1, const float* u0, con
         }
         return CNF_OK;
     }
-    h->last_controller = 0;
+    h->adp.last_controller = 0;
     rc = api_ensure_adaptive_buf(h, B);
     if (rc) return rc;
-    if (!h->vc_partial) HIP_TRY(hipMalloc((void**)&h->vc_partial, (vcabm_partial_doubles() + 8) * sizeof(double)));
-    const size_t slot = (size_t)h->S * (size_t)h->ad_B;
-    float *ua = h->ad_buf, *ub = ua + slot, *f0 = ub + slot, *f1 = f0 + slot;
+    if (!h->vc.partial) HIP_TRY(hipMalloc((void**)&h->vc.partial, (vcabm_partial_doubles() + 8) * sizeof(double)));
+    const size_t slot = (size_t)h->S * (size_t)h->adp.B;
+    float *ua = h->adp.buf, *ub = ua + slot, *f0 = ub + slot, *f1 = f0 + slot;
     HIP_TRY(hipMemcpyAsync(ua, u0, n * sizeof(float), hipMemcpyDeviceToDevice, st));
-    double* res = h->vc_partial + vcabm_partial_doubles();
+    double* res = h->vc.partial + vcabm_partial_doubles();
     double host[2];
     auto fetch = [&](int cnt) -> int {
         HIP_TRY(hipMemcpyAsync(host, res, cnt * sizeof(double), hipMemcpyDeviceToHost, st));
@@ -492,8 +492,8 @@ int cnf::api_solve_tsit5(cnf_handle* h, float t0, float t1, const float* u0, con
         rc = api_eval_dynamics(h, in, t0, eps, ys, B, f0, nullptr, true, st);
         if (rc) return rc;
         ++nf;
-        HIP_TRY(vcabm_scaled_sumsq(ua, nullptr, ua, abstol, reltol, (int64_t)n, h->vc_partial, res, st));
-        HIP_TRY(vcabm_scaled_sumsq(f0, nullptr, ua, abstol, reltol, (int64_t)n, h->vc_partial, res + 1, st));
+        HIP_TRY(vcabm_scaled_sumsq(ua, nullptr, ua, abstol, reltol, (int64_t)n, h->vc.partial, res, st));
+        HIP_TRY(vcabm_scaled_sumsq(f0, nullptr, ua, abstol, reltol, (int64_t)n, h->vc.partial, res + 1, st));
         rc = fetch(2);
         if (rc) return rc;
         const double d0 = std::sqrt(host[0] / ntot), d1 = std::sqrt(host[1] / ntot);
@@ -508,7 +508,7 @@ int cnf::api_solve_tsit5(cnf_handle* h, float t0, float t1, const float* u0, con
         rc = api_eval_dynamics(h, in1, (float)((double)t0 + tdir * h0), eps, ys, B, f1, nullptr, false, st);
         if (rc) return rc;
         ++nf;
-        HIP_TRY(vcabm_scaled_sumsq(f1, f0, ua, abstol, reltol, (int64_t)n, h->vc_partial, res, st));
+        HIP_TRY(vcabm_scaled_sumsq(f1, f0, ua, abstol, reltol, (int64_t)n, h->vc.partial, res, st));
         rc = fetch(1);
         if (rc) return rc;
         const double d2 = std::sqrt(host[0] / ntot) / h0, dmax = std::max(d1, d2);

@@ -46,11 +46,11 @@ bool cnf::api_grad_is_fused(const cnf_handle* h) {
 extern "C++" {
 // batches from which the cooperative reverse sweep beats the slab kernel on the shapes that have both (86 -> 80 ms at 2 x 104,
 // 106 -> 84 ms at 2 x 128, B = 65 536; the sweep's 40 + 160 launches per gradient need columns to amortise)
-bool cnf::api_grad_uses_coop_aux(const cnf_handle* h, int64_t B) { return h->plan_cg && h->cg_packed && B >= 4096; }
+bool cnf::api_grad_uses_coop_aux(const cnf_handle* h, int64_t B) { return h->grad.plan_cg && h->grad.cg_packed && B >= 4096; }
 
 bool cnf::api_grad_uses_slab(const cnf_handle* h) {
     const char* force = getenv("CNF_GRAD_LAYERED");
-    return (h->slab_packed || !h->have_params) && grad_slab_supported(h->cfg) && !(force && *force && *force != '0');
+    return (h->grad.slab_packed || !h->par.have) && grad_slab_supported(h->cfg) && !(force && *force && *force != '0');
 }
 }  // extern "C++"
 
@@ -59,17 +59,17 @@ bool cnf::api_grad_uses_slab(const cnf_handle* h) {
 extern "C++" {
 cnf::GradRoute cnf::api_grad_route(const cnf_handle* h, int64_t B, int alg, bool on_grid) {
     GradRoute r{};
-    if (api_grad_is_fused(h) && (h->grad_packed || !h->have_params)) { r.path = 1; return r; }
+    if (api_grad_is_fused(h) && (h->grad.packed || !h->par.have)) { r.path = 1; return r; }
     const bool slab = api_grad_uses_slab(h);
     // B < 0: "the batch is not known" - the auxiliary cooperative plan of a slab shape is not counted (cnf_grad_path)
     const bool fits = B < 0 || B <= coop_grad_max_columns(h->cfg, alg);
     const float lam0[3] = {0.f, 0.f, 0.f};
-    if (B >= 0 && api_grad_uses_coop_aux(h, B) && fits && coop_grad_eligible(h->cfg, h->plan_cg, lam0, on_grid)) {
+    if (B >= 0 && api_grad_uses_coop_aux(h, B) && fits && coop_grad_eligible(h->cfg, h->grad.plan_cg, lam0, on_grid)) {
         r.path = 3; r.use_cg_aux = true; return r;
     }
     if (slab) { r.path = 1; r.slab = true; return r; }
     // CNF_LAYERED_LOSS_BY_SOLVE (A/B switch of the layer-wise path: loss from a separate solve) keeps the call layer-wise
-    if (fits && !getenv("CNF_LAYERED_LOSS_BY_SOLVE") && (h->packed_dev || !h->have_params) && coop_grad_eligible(h->cfg, h->plan, lam0, on_grid)) {
+    if (fits && !getenv("CNF_LAYERED_LOSS_BY_SOLVE") && (h->par.packed_dev || !h->par.have) && coop_grad_eligible(h->cfg, h->plan, lam0, on_grid)) {
         r.path = 3; return r;
     }
     r.path = layered_grad_supported(h->cfg) ? 2 : 0;
@@ -105,7 +105,7 @@ static int loss_grad_impl(cnf_handle* h, const char* who, int alg, int nsteps, f
     if (route.path == 0) return fail(CNF_ERR_UNSUPPORTED, w + ": no gradient path for this configuration");
     DeviceGuard g(h->cfg.device_id);
     hipStream_t st = (hipStream_t)stream;
-    HIP_TRY(zero_async(grad, h->nparams * sizeof(float), st));
+    HIP_TRY(zero_async(grad, h->par.n * sizeof(float), st));
     if (B == 0) {
         if (sums4) HIP_TRY(zero_async(sums4, 4 * sizeof(float), st));
         return CNF_OK;
@@ -113,15 +113,15 @@ static int loss_grad_impl(cnf_handle* h, const char* who, int alg, int nsteps, f
     const float* tgrid_dev = nullptr;
     if (tgrid) {   // the fused kernels read the step times from device memory (uniform loads, once per step)
         t0 = tgrid[0]; t1 = tgrid[nsteps];
-        if ((size_t)nsteps + 1 > h->tgrid_cap) {
-            if (h->tgrid_dev) HIP_TRY(hipFree(h->tgrid_dev));
-            h->tgrid_dev = nullptr; h->tgrid_cap = 0;
+        if ((size_t)nsteps + 1 > h->grad.tgrid_cap) {
+            if (h->grad.tgrid_dev) HIP_TRY(hipFree(h->grad.tgrid_dev));
+            h->grad.tgrid_dev = nullptr; h->grad.tgrid_cap = 0;
             const size_t cap = ((size_t)nsteps + 1 + 63) / 64 * 64;
-            HIP_TRY(hipMalloc((void**)&h->tgrid_dev, cap * sizeof(float)));
-            h->tgrid_cap = cap;
+            HIP_TRY(hipMalloc((void**)&h->grad.tgrid_dev, cap * sizeof(float)));
+            h->grad.tgrid_cap = cap;
         }
-        HIP_TRY(hipMemcpyAsync(h->tgrid_dev, tgrid, ((size_t)nsteps + 1) * sizeof(float), hipMemcpyHostToDevice, st));
-        tgrid_dev = h->tgrid_dev;
+        HIP_TRY(hipMemcpyAsync(h->grad.tgrid_dev, tgrid, ((size_t)nsteps + 1) * sizeof(float), hipMemcpyHostToDevice, st));
+        tgrid_dev = h->grad.tgrid_dev;
     }
     if (!fused) {
         // the loss sums come from the regular solve on whichever family serves the handle
@@ -131,13 +131,13 @@ static int loss_grad_impl(cnf_handle* h, const char* who, int alg, int nsteps, f
         const bool loss_in_sweep = sums4 && (route.path == 3 || (route.path == 2 && !getenv("CNF_LAYERED_LOSS_BY_SOLVE")));
         if (sums4) {
             const size_t need = ((size_t)h->S + 4) * (size_t)B * sizeof(float);
-            if (need > h->grad_ws_bytes) {
-                if (h->grad_ws) HIP_TRY(hipFree(h->grad_ws));
-                h->grad_ws = nullptr; h->grad_ws_bytes = 0;
-                HIP_TRY(hipMalloc((void**)&h->grad_ws, need));
-                h->grad_ws_bytes = need;
+            if (need > h->grad.ws_bytes) {
+                if (h->grad.ws) HIP_TRY(hipFree(h->grad.ws));
+                h->grad.ws = nullptr; h->grad.ws_bytes = 0;
+                HIP_TRY(hipMalloc((void**)&h->grad.ws, need));
+                h->grad.ws_bytes = need;
             }
-            float* logp = h->grad_ws;
+            float* logp = h->grad.ws;
             float* regs = logp + B;
             if (loss_in_sweep) {
                 // the layer-wise reverse sweep accumulates the loss terms of the solve it differentiates (below)
@@ -166,32 +166,32 @@ static int loss_grad_impl(cnf_handle* h, const char* who, int alg, int nsteps, f
                 h->num_cus = prop.multiProcessorCount;
             }
             const size_t need = grad_slab_ws_floats(h->cfg, alg, nsteps, B, h->num_cus);
-            if (need > h->slab_ws_floats) {
-                if (h->slab_ws) HIP_TRY(hipFree(h->slab_ws));
-                h->slab_ws = nullptr; h->slab_ws_floats = 0;
-                HIP_TRY(hipMalloc((void**)&h->slab_ws, need * sizeof(float)));
-                h->slab_ws_floats = need;
+            if (need > h->grad.slab_ws_floats) {
+                if (h->grad.slab_ws) HIP_TRY(hipFree(h->grad.slab_ws));
+                h->grad.slab_ws = nullptr; h->grad.slab_ws_floats = 0;
+                HIP_TRY(hipMalloc((void**)&h->grad.slab_ws, need * sizeof(float)));
+                h->grad.slab_ws_floats = need;
             }
-            HIP_TRY(grad_slab_launch(h->cfg, h->slab_packed, x, eps, ys, h->w_off.data(), h->b_off.data(), alg, nsteps, t0, t1, tgrid_dev, B, lam,
-                                     h->slab_ws, grad, grad_x, h->num_cus, st));
+            HIP_TRY(grad_slab_launch(h->cfg, h->grad.slab_packed, x, eps, ys, h->par.w_off.data(), h->par.b_off.data(), alg, nsteps, t0, t1, tgrid_dev, B, lam,
+                                     h->grad.slab_ws, grad, grad_x, h->num_cus, st));
             return CNF_OK;
         }
         std::string msg;
-        MfmaPlan* cgp = use_cg ? h->plan_cg : h->plan;
-        const float* cgi = use_cg ? h->cg_packed : h->packed_dev;
+        MfmaPlan* cgp = use_cg ? h->grad.plan_cg : h->plan;
+        const float* cgi = use_cg ? h->grad.cg_packed : h->par.packed_dev;
         if (route.path == 3) {
             if (!cgi) return fail(CNF_ERR_NO_PARAMS, w + ": cnf_set_params has not been called");
             // wide hidden layers on the cooperative kernels: checkpointing forward solve (which also yields the loss terms),
             // one reverse-sweep launch per step, deferred weight-cotangent products (cnf_coop_grad.hip)
-            float* cg_logp = sums4 ? h->grad_ws : nullptr;
-            hipError_t e = coop_grad(&h->layered, h->cfg, cgp, cgi, h->w_off.data(), h->b_off.data(), x, eps, ys, alg, nsteps,
+            float* cg_logp = sums4 ? h->grad.ws : nullptr;
+            hipError_t e = coop_grad(&h->grad.layered, h->cfg, cgp, cgi, h->par.w_off.data(), h->par.b_off.data(), x, eps, ys, alg, nsteps,
                                      t0, t1, tgrid, tgrid_dev, B, lam, grad, grad_x, cg_logp, cg_logp ? cg_logp + B : nullptr, st, &msg);
             if (e != hipSuccess) return fail(CNF_ERR_HIP, w + ": " + msg);
             if (sums4) HIP_TRY(loss_sums(cg_logp, cg_logp + B, B, h->loss_partial, sums4, st));
             return CNF_OK;
         }
-        float* lg_logp = loss_in_sweep ? h->grad_ws : nullptr;
-        hipError_t e = layered_grad(&h->layered, h->cfg, h->P_dev, h->w_off.data(), h->b_off.data(), x, eps, ys, alg, nsteps,
+        float* lg_logp = loss_in_sweep ? h->grad.ws : nullptr;
+        hipError_t e = layered_grad(&h->grad.layered, h->cfg, h->par.P_dev, h->par.w_off.data(), h->par.b_off.data(), x, eps, ys, alg, nsteps,
                                     t0, t1, tgrid, B, lam, grad, grad_x, st, &msg, lg_logp, lg_logp ? lg_logp + B : nullptr);
         if (e == hipErrorNotSupported) return fail(CNF_ERR_UNSUPPORTED, w + ": " + msg);
         if (e != hipSuccess) return fail(CNF_ERR_HIP, w + ": " + msg);
@@ -215,13 +215,13 @@ static int loss_grad_impl(cnf_handle* h, const char* who, int alg, int nsteps, f
     const size_t state_floats = tgrid ? 2 * (size_t)h->S * (size_t)B : 0;   // ping-pong states of the step-by-step forward pass
     const size_t unit_floats = exact ? (size_t)h->D * (size_t)h->D * (size_t)B : 0;   // the D unit probes of every column
     const size_t need = (ckpt_floats + 4 * (size_t)B + slab_floats + state_floats + unit_floats) * sizeof(float);
-    if (need > h->grad_ws_bytes) {
-        if (h->grad_ws) HIP_TRY(hipFree(h->grad_ws));
-        h->grad_ws = nullptr; h->grad_ws_bytes = 0;
-        HIP_TRY(hipMalloc((void**)&h->grad_ws, need));
-        h->grad_ws_bytes = need;
+    if (need > h->grad.ws_bytes) {
+        if (h->grad.ws) HIP_TRY(hipFree(h->grad.ws));
+        h->grad.ws = nullptr; h->grad.ws_bytes = 0;
+        HIP_TRY(hipMalloc((void**)&h->grad.ws, need));
+        h->grad.ws_bytes = need;
     }
-    float* ckpt = h->grad_ws;
+    float* ckpt = h->grad.ws;
     float* ckpt_k = ckpt + ckpt_z_floats;
     float* logp = ckpt + ckpt_floats;
     float* regs = logp + B;
@@ -231,7 +231,7 @@ static int loss_grad_impl(cnf_handle* h, const char* who, int alg, int nsteps, f
         SolveArgs a{};
         a.x = x; a.eps = eps; a.ys = ys; a.B = B; a.nsteps = nsteps; a.alg = alg; a.t0 = t0; a.t1 = t1;
         a.logp = logp; a.regs = regs; a.nvars = h->cfg.nvars; a.reg_aug = reg_aug; a.ckpt = ckpt; a.ckpt_k = ckpt_k;
-        HIP_TRY(mfma_solve(h->plan, h->packed_dev, a, st));
+        HIP_TRY(mfma_solve(h->plan, h->par.packed_dev, a, st));
     } else {
         // non-uniform grid: the checkpointing forward pass is one launch of the (unchanged) solve kernel per step - the metric
         // kernel keeps its loop-invariant step size; step n writes checkpoint slots n and n + 1 and its stage derivatives
@@ -245,7 +245,7 @@ static int loss_grad_impl(cnf_handle* h, const char* who, int alg, int nsteps, f
             a.nvars = h->cfg.nvars; a.reg_aug = reg_aug;
             a.ckpt = ckpt + (size_t)n * zslot; a.ckpt_k = ckpt_k + (size_t)n * nstages * zslot;
             if (n == nsteps - 1) { a.logp = logp; a.regs = regs; }
-            HIP_TRY(mfma_solve(h->plan, h->packed_dev, a, st));
+            HIP_TRY(mfma_solve(h->plan, h->par.packed_dev, a, st));
             float* tmp = ua; ua = ub; ub = tmp;
         }
     }
@@ -262,7 +262,7 @@ static int loss_grad_impl(cnf_handle* h, const char* who, int alg, int nsteps, f
         HIP_TRY(hipGetLastError());
         probes = unit;
     }
-    HIP_TRY(grad_launch(gc, h->grad_packed, ckpt, ckpt_k, ckpt_zr, probes, ys, h->w_off.data(), h->b_off.data(), alg, nsteps, t0, t1,
+    HIP_TRY(grad_launch(gc, h->grad.packed, ckpt, ckpt_k, ckpt_zr, probes, ys, h->par.w_off.data(), h->par.b_off.data(), alg, nsteps, t0, t1,
                         tgrid_dev, exact ? 1.f : 0.f, B, lam, slab, grad, grad_x, h->num_cus, st));
     return CNF_OK;
 }
@@ -300,8 +300,8 @@ int cnf_loss_grad_adaptive(cnf_handle* h, float t0, float t1, const float* x, co
         DeviceGuard g(h->cfg.device_id);
         rc = api_ensure_adaptive_buf(h, B);
         if (rc) return rc;
-        const size_t slot = (size_t)h->S * (size_t)h->ad_B;
-        float* u = h->ad_buf + 4 * slot;
+        const size_t slot = (size_t)h->S * (size_t)h->adp.B;
+        float* u = h->adp.buf + 4 * slot;
         HIP_TRY(assemble_u0(x, h->cfg.nvars, h->S, B, u, (hipStream_t)stream));
         std::vector<double> steps;
         rc = api_solve_tsit5(h, t0, t1, u, eps, ys, B, abstol, reltol, dt_init, maxiters, u + slot, stats, &steps, stream);

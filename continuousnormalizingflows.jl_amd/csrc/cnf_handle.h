@@ -51,68 +51,95 @@ struct DeviceGuard {
 
 }  // namespace cnf
 
+// The handle is one configuration + its parameters + the state each kernel family keeps beside them, grouped by who owns it
+// (the flat struct had grown to ~60 fields across six families).
+namespace cnf {
+
+// parameters as the host handed them over and as the kernels read them
+struct HandleParams {
+    size_t n = 0;
+    bool have = false;
+    float* P_dev = nullptr;              // Lux layout (SIMT path)
+    float* packed_dev = nullptr;         // MFMA operand image of the forward plan
+    std::vector<size_t> w_off, b_off;    // Lux offsets given to cnf_set_params
+    // device-side repacking (see PackMap): the map of the solve image, rebuilt when the layout handed to cnf_set_params changes;
+    // `stage` holds host-supplied parameters
+    PackMap map_fwd;
+    bool maps_built = false;
+    bool repack_on_device = false;
+    float* stage = nullptr;
+    size_t stage_n = 0;
+};
+// thread-per-sample family: workspaces grown on demand
+struct HandleSimt {
+    float* ws = nullptr;
+    int64_t ws_B = 0;
+    float* kbuf = nullptr;               // 6 stage derivatives + 1 state, each S x kbuf_B
+    int64_t kbuf_B = 0;
+};
+// parameter gradient (cnf_loss_grad_*): operand images, checkpoints, the auxiliary cooperative plan
+struct HandleGrad {
+    float* packed = nullptr;             // plain f32 operand image for the register-accumulator reverse sweep
+    float* ws = nullptr;                 // checkpoints + logp + regs
+    size_t ws_bytes = 0;
+    PackMap map, map_slab;
+    float* slab_packed = nullptr;        // operand image of the slab-accumulator gradient kernel (cnf_grad_slab.hip)
+    float* slab_ws = nullptr;            // its checkpoints + slabs
+    size_t slab_ws_floats = 0;
+    // Two-hidden-layer nets of 7 .. 8 hidden tiles keep their per-wave forward plan (the one-launch adaptive solvers hang off it),
+    // but at large batches their gradient is faster on the cooperative reverse sweep: a second, cooperative plan + image for it
+    MfmaPlan* plan_cg = nullptr;
+    float* cg_packed = nullptr;
+    PackMap map_cg;
+    bool cg_tried = false;
+    LayeredGrad* layered = nullptr;      // operand images + workspaces of the layer-wise evaluation / gradient and of the cooperative gradient
+    float* tgrid_dev = nullptr;          // step times of a non-uniform grid for the fused gradient kernels
+    size_t tgrid_cap = 0;
+};
+// embedded-step workspace (cnf_step_embedded): 7 stage derivatives + 1 stage state, each S x B
+struct HandleEmbedded {
+    float* buf = nullptr;
+    int64_t B = 0;
+    int k[7] = {0, 1, 2, 3, 4, 5, 6};    // which slot holds k_1 .. k_7 (first-same-as-last swaps slots 0 and 6)
+    double* err_partial = nullptr;
+};
+// multistep solve (cnf_vcabm_*): 6 state-size vectors + 2 x kVcSlots difference vectors, each S x B
+struct HandleVcabm {
+    float* buf = nullptr;
+    double* partial = nullptr;
+    int64_t B = -1, cap = 0;             // columns of the solve in progress; columns the allocation holds
+    int iu = 0, iun = 2, ifn0 = 3, ifn1 = 5, cur = 0;   // which vector holds u, u_new, f_n, f_{n+1}; live difference half
+    int nhist = 0, k = 0;                // accepted steps since begin; order of the pending attempt (0 = none)
+    int avail = 0, m = 0;                // differences Phi*_j(n-1) the last accepted step stored; those the pending attempt stores
+    double hist[kVcSlots + 1] = {};      // signed sizes of the accepted steps, newest first
+    double t = 0.0, dt = 0.0;
+};
+// adaptive whole solves (cnf_solve_controller, cnf_solve_tsit5)
+struct HandleAdaptive {
+    int last_controller = -1;
+    void* dc_buf = nullptr;              // device-controlled adaptive solve: slots, counter, stats, accepted steps
+    size_t dc_bytes = 0;
+    float* buf = nullptr;                // adaptive Tsit5 whole solve: two states + two derivative scratch vectors
+    int64_t B = 0;
+};
+
+}  // namespace cnf
+
 struct cnf_handle {
     cnf_config cfg{};
     int D = 0, S = 0;
     cnf::NetDev net{};
-    size_t nparams = 0;
-    bool have_params = false;
     int path = CNF_PATH_SIMT;
-    // device copies of the parameters
-    float* P_dev = nullptr;       // Lux layout (SIMT path)
-    cnf::MfmaPlan* plan = nullptr;
-    float* packed_dev = nullptr;  // MFMA operand image
-    // SIMT workspaces, grown on demand
-    float* ws = nullptr;
-    int64_t ws_B = 0;
-    float* kbuf = nullptr;        // 6 stage derivatives + 1 state, each S x kbuf_B
-    int64_t kbuf_B = 0;
-    float* loss_partial = nullptr;
-    // parameter gradient (cnf_loss_grad_fixed)
-    std::vector<size_t> w_off, b_off;   // Lux offsets given to cnf_set_params
-    float* grad_packed = nullptr;        // plain f32 operand image for the reverse sweep
-    float* grad_ws = nullptr;            // checkpoints + logp + regs
-    size_t grad_ws_bytes = 0;
     int num_cus = 0;
-    // device-side repacking (see PackMap): maps for the solve image and the gradient image, rebuilt
-    // when the layout handed to cnf_set_params changes; p_stage holds host-supplied parameters
-    cnf::PackMap map_fwd, map_grad, map_slab;
-    float* slab_packed = nullptr;        // operand image of the slab-accumulator gradient kernel (cnf_grad_slab.hip)
-    // Two-hidden-layer nets of 7 .. 8 hidden tiles keep their per-wave forward plan (the one-launch adaptive solvers hang off it),
-    // but at large batches their gradient is faster on the cooperative reverse sweep: a second, cooperative plan + image for it
-    cnf::MfmaPlan* plan_cg = nullptr;
-    float* cg_packed = nullptr;
-    cnf::PackMap map_cg;
-    bool cg_tried = false;
-    float* slab_ws = nullptr;            // its checkpoints + slabs
-    size_t slab_ws_floats = 0;
-    cnf::LayeredGrad* layered = nullptr;      // operand images + workspaces of the layer-wise evaluation / gradient and of the cooperative gradient
-    // embedded-step workspace (cnf_step_embedded): 7 stage derivatives + 1 stage state, each S x ebuf_B
-    float* ebuf = nullptr;
-    int64_t ebuf_B = 0;
-    int ek[7] = {0, 1, 2, 3, 4, 5, 6};   // which slot holds k_1 .. k_7 (first-same-as-last swaps slots 0 and 6)
-    double* err_partial = nullptr;
-    // multistep solve (cnf_vcabm_*): 6 state-size vectors + 2 x cnf::kVcSlots difference vectors, each S x vc_B
-    float* vc_buf = nullptr;
-    double* vc_partial = nullptr;
-    int64_t vc_B = -1, vc_cap = 0;       // columns of the solve in progress; columns the allocation holds
-    int vc_iu = 0, vc_iun = 2, vc_if = 3, vc_ifn = 5, vc_cur = 0;   // which vector holds u, u_new, f_n, f_{n+1}; live difference half
-    int vc_nhist = 0, vc_k = 0;          // accepted steps since begin; order of the pending attempt (0 = none)
-    int vc_avail = 0, vc_m = 0;          // differences Phi*_j(n-1) the last accepted step stored; those the pending attempt stores
-    double vc_hist[cnf::kVcSlots + 1] = {};   // signed sizes of the accepted steps, newest first
-    double vc_t = 0.0, vc_dt = 0.0;
-    int last_controller = -1;            // cnf_solve_controller
-    void* dc_buf = nullptr;              // device-controlled adaptive solve: slots, counter, stats, accepted steps
-    size_t dc_bytes = 0;
-    float* ad_buf = nullptr;             // adaptive Tsit5 whole solve (cnf_solve_tsit5): two states + two derivative scratch vectors
-    int64_t ad_B = 0;
-    float* tgrid_dev = nullptr;          // step times of a non-uniform grid for the fused gradient kernels
-    size_t tgrid_cap = 0;
+    cnf::MfmaPlan* plan = nullptr;       // the fused forward plan (null on the SIMT / layer-wise paths)
     bool layered_forced = false;         // kernel_path = CNF_PATH_LAYERED given explicitly: GEMM path for every batch
-    bool maps_built = false;
-    bool repack_on_device = false;
-    float* p_stage = nullptr;
-    size_t p_stage_n = 0;
+    float* loss_partial = nullptr;       // partial sums of the loss reduction (every family)
+    cnf::HandleParams par;
+    cnf::HandleSimt simt;
+    cnf::HandleGrad grad;
+    cnf::HandleEmbedded emb;
+    cnf::HandleVcabm vc;
+    cnf::HandleAdaptive adp;
 };
 
 namespace cnf {
