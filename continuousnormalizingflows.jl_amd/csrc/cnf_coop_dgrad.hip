@@ -399,6 +399,29 @@ coopd_grad_step_kernel(DGArgs da) {
         __syncthreads();                 // the previous super-tile's readers of the LDS images are done
         float* zbt = a.zb + (tile * 64 + lane) * (long long)(NS * KZ);
         f32x4 aS[A], aR[2];
+        // stage-derivative checkpoints of stage `is` (rows j < ns - 1 for the stage state, row `is` of zdot and of g = eps^T J): one
+        // batch of 16-byte loads, requested a stage ahead of their use
+        f32x4 kr[NS - 1][DT], ki[DT], gi[DT];
+        auto load_rows = [&](int is) {
+            const long long rowb = (long long)a.step * ns * ntp + tile, rstride = ntp * 64 * (long long)ckzr;
+            const float* kbase = a.ckpt_k + (rowb * 64 + lane) * ckzr;
+            const float* gbase = (a.lam2 != 0.f ? a.ckpt_g : a.ckpt_k) + (rowb * 64 + lane) * ckzr;
+#pragma unroll
+            for (int j = 0; j < NS - 1; ++j) {
+                const int jj = j < ns ? j : ns - 1;
+#pragma unroll
+                for (int q = 0; q < DT; ++q) kr[j][q] = *reinterpret_cast<const f32x4*>(kbase + jj * rstride + 4 * q);
+            }
+#pragma unroll
+            for (int q = 0; q < DT; ++q) {
+                ki[q] = *reinterpret_cast<const f32x4*>(kbase + is * rstride + 4 * q);
+                gi[q] = *reinterpret_cast<const f32x4*>(gbase + is * rstride + 4 * q);
+            }
+        };
+        // (A = 3: the rows would stay live across the loop's back edge beside 24 more accumulator registers, and this compiler's
+        // AGPR-copy rewrite pass crashes instead of spilling: those instances request them in the dense phase itself)
+        constexpr bool PREF = A == 2;
+        if (PREF && owner) load_rows(ns - 1);
 
 #pragma clang loop unroll(disable)
         for (int i = ns - 1; i >= 0; --i) {
@@ -424,24 +447,14 @@ coopd_grad_step_kernel(DGArgs da) {
                 // chain of dependent global round trips: everything this phase reads is requested in ONE batch of 16-byte loads
                 // (straight-line code; rows the stage does not use are loaded and dropped).  (First build: per-row loops of dword
                 // loads run by all four waves - 576 load instructions per stage through one address unit, a fifth of the kernel.)
-                f32x4 kr[NS - 1][DT], zr[NS - 1][DT], ki[DT], gi[DT];
-                const long long rowb = (long long)a.step * ns * ntp + tile, rstride = ntp * 64 * (long long)ckzr;
-                const float* kbase = a.ckpt_k + (rowb * 64 + lane) * ckzr;
-                const float* gbase = (a.lam2 != 0.f ? a.ckpt_g : a.ckpt_k) + (rowb * 64 + lane) * ckzr;
+                // The checkpoint rows (HBM) of this stage were requested one stage ago, behind the last barrier but one (load_rows
+                // below): only the Zbar rows of the running step - written by this wave, L2 hits - are read here.
+                f32x4 zr[NS - 1][DT];
+                if constexpr (!PREF) load_rows(i);
 #pragma unroll
-                for (int j = 0; j < NS - 1; ++j) {
-                    const int jj = j < ns ? j : ns - 1;
+                for (int j = 0; j < NS - 1; ++j)
 #pragma unroll
-                    for (int q = 0; q < DT; ++q) {
-                        kr[j][q] = *reinterpret_cast<const f32x4*>(kbase + jj * rstride + 4 * q);
-                        zr[j][q] = *reinterpret_cast<const f32x4*>(zbt + (j + 1) * KZ + 4 * q);
-                    }
-                }
-#pragma unroll
-                for (int q = 0; q < DT; ++q) {
-                    ki[q] = *reinterpret_cast<const f32x4*>(kbase + i * rstride + 4 * q);
-                    gi[q] = *reinterpret_cast<const f32x4*>(gbase + i * rstride + 4 * q);
-                }
+                    for (int q = 0; q < DT; ++q) zr[j][q] = *reinterpret_cast<const f32x4*>(zbt + (j + 1) * KZ + 4 * q);
 #pragma unroll
                 for (int s = 0; s < KZ; ++s) {
                     float acc = 0.f, kb = bi * lam[s];
@@ -629,6 +642,7 @@ coopd_grad_step_kernel(DGArgs da) {
             DG_SYNC();                                                                     // B4 (every reader of X0 is through)
             DG_T(14);
             gstore(X1, rx[0], vox, sx1, sx2);                                              // X_1 = [delta_1 | sbar_1]
+            if (PREF && owner && i > 0) load_rows(i - 1);   // the next stage's checkpoint rows: they arrive under the stores, the barrier and the reduction
 #pragma unroll
             for (int dm = 0; dm < DT; ++dm) {
                 pbuf[((0 * 4 + wave) * DT + dm) * 64 + lane] = part[dm][0];
