@@ -597,6 +597,7 @@ struct CoopD2Inst {
 #define CD2_SHAPES(ACT) CD2_INST(4, 16, ACT), CD2_INST(4, 20, ACT), CD2_INST(5, 20, ACT), CD2_INST(5, 24, ACT), CD2_INST(6, 24, ACT)
 static const CoopD2Inst kCoopD2[] = {
     CD2_SHAPES(CNF_ACT_SOFTPLUS),
+    CD2_INST(4, 16, CNF_ACT_TANH_PRESCALED), CD2_INST(5, 20, CNF_ACT_TANH_PRESCALED), CD2_INST(6, 24, CNF_ACT_TANH_PRESCALED),   // tanh flows of 16 .. 24 hidden tiles
 };
 static const CoopD2Inst* cd2_find(int HT_real, int KZ, int ACT) {
     const int A = HT_real / 4;

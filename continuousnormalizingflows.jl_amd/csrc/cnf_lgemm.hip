@@ -625,7 +625,13 @@ lg_wgrad_kernel(LgWgradArgs a) {
     // The last column group of a strip may have one tile less than NTN (257 columns = 9 + 8 tiles): its waves skip that
     // tile's MFMAs (wave-uniform branch) instead of multiplying padding - 1 / 18 of the 256 x 257 product.
     const bool last_tile = (Nc + 15) / 16 >= NTN;
+    // A wave whose 16-row strip lies wholly behind the last row of C (136 rows = 9 strips in three row blocks: three of the last
+    // block's four waves) fetches and parks its share of every slice like the others, but multiplies nothing: its SIMD's MFMA
+    // pipe is then free for the waves of the other workgroups resident on it (the MFMAs it used to issue on clamped rows took
+    // a quarter of the pipe time of a 136 x 137 product for results that were never stored).
+    const bool strip_live = 16 * mt < a.M;
     auto multiply = [&](int buf) {
+        if (!strip_live) return;
         const f32x4* y4 = reinterpret_cast<const f32x4*>(smem + buf * (YS + XS)) + lane;
         const f32x4 av = reinterpret_cast<const f32x4*>(smem + buf * (YS + XS) + YS)[wave * 64 + lane];
         f32x4 bv[NTN];

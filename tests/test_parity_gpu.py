@@ -205,6 +205,8 @@ COOPD_CASES = [
     (dict(nvars=43, naug=44, hidden=[352, 352], act=2, reg_j=True), 40, 0, 3),                                # nvariables = 43 (MiniBooNE's dimension): 22 tiles, D = 87: c per evaluation
     (dict(nvars=47, naug=48, hidden=[384, 384], act=2, reg_z=True, reg_j=True, reg_aug=True), 33, 1, 2),     # the largest: 24 x 24 tiles
     (dict(nvars=30, naug=31, ncond=6, hidden=[248, 248], act=2, reg_z=True, reg_j=True, reg_aug=True), 50, 1, 3),   # conditioned, 16 tiles (wider conditioned flows have no fused plan)
+    (dict(nvars=48, hidden=[264, 264], reg_z=True, reg_j=True), 60, 1, 3),                                    # tanh on the 32-sample form: 17 tiles, D = 48
+    (dict(nvars=60, naug=20, hidden=[340, 340], reg_aug=True), 40, 0, 3),                                     # tanh, 22 tiles, D = 80
     # conditioned flows (CondICNF: the condition rows of layer 1, src/layers/cond_layer.jl:7-31, src/core/base_icnf.jl:272-296)
     (dict(nvars=16, naug=17, ncond=5, hidden=[156, 156], act=2, reg_z=True, reg_j=True, reg_aug=True), 120, 1, 5),   # default architecture with 5 conditions: 10 tiles
     (dict(nvars=20, naug=21, ncond=16, hidden=[232, 232], act=2, autonomous=True), 64, 0, 4),                # 16 conditions, D = 41, 15 tiles, autonomous
