@@ -885,6 +885,12 @@ void dimg_fill(DImg& G, int H, int D, int L, int HT_lay, int ZR_lay, int CR_lay,
     G.xalias = 0;
 }
 
+size_t coopd_rk_floats(int H, int D, int L, int ACT, int exact, int num_cus) {
+    const int HT_real = (H + 15) / 16, KZ = (D + 3) / 4;
+    if (exact || L != 2 || cd_find(HT_real, L, KZ, ACT, 0)) return 0;
+    return coopd2_rk_floats(HT_real, KZ, ACT, num_cus);
+}
+
 hipError_t coopd_launch(int H, int D, int L, int ACT, int HT_lay, int ZR_lay, int CR_lay, const KArgs& k, int num_cus, hipStream_t st) {
     const int HT_real = (H + 15) / 16, KZ = (D + 3) / 4;
     const bool exact = k.exact == 1;

@@ -17,6 +17,9 @@
 
 namespace cnf {
 
+// instances whose Runge-Kutta sums live in the global ring (KArgs::rk) instead of accumulation registers: see the kernel
+constexpr bool d2_rk_in_ring(int A, int ZR) { return A >= 5 || ZR >= 20; }
+
 template <int A>
 struct UAcc2 {
     f32x4 S[A][2];   // tiles [w A, (w + 1) A) x the two sample tiles
@@ -420,7 +423,14 @@ coopd2_solve_kernel(DArgs da) {
         const long long smp = st * 32 + (owner ? wave : 0) * 16 + n;
         const bool valid = owner && smp < a.B;
         const long long sc = smp < a.B ? smp : a.B - 1;
-        float zs[ZR], zp[ZR], pk[5][ZR];   // stage state; z and the running sums, parked (owner waves)
+        // RKG (20 .. 24 hidden tiles, or 20 and more state registers): z and the five running sums live in a per-workgroup ring in global memory (L2-resident:
+        // 2 x 6 rows x ZR x 256 B per workgroup) instead of 6 ZR accumulation registers - with them parked, act'_1 and the
+        // accumulators of five or six tile rows no longer fit and the allocator spilled 146 - 411 registers to scratch at
+        // places of its own choosing, k-loops included.  The ring is read and written ONCE per stage, behind the evaluation's last
+        // product and behind the next evaluation's first fragment requests.
+        constexpr bool RKG = d2_rk_in_ring(A, ZR);
+        f32x4* __restrict__ rk = RKG ? reinterpret_cast<f32x4*>(a.rk) + ((long long)(blockIdx.x * 2 + (owner ? wave : 0)) * 6 * DT) * 64 + lane : nullptr;
+        float zs[ZR], zp[RKG ? 1 : ZR], pk[RKG ? 1 : 5][RKG ? 1 : ZR];   // stage state; z and the running sums, parked (owner waves)
         float lacc = 0.f, eacc = 0.f, nacc = 0.f;
         __syncthreads();   // the previous super-tile's readers of the LDS images are done
 #pragma unroll
@@ -431,7 +441,7 @@ coopd2_solve_kernel(DArgs da) {
                 const int s = 4 * kg + j, f = 4 * s + g;
                 if (a.x) zs[s] = f < a.nvars ? a.x[sc * a.nvars + f] : 0.f;
                 else zs[s] = f < D ? a.u0[sc * S + f] : 0.f;
-                zp[s] = park(zs[s]);
+                if constexpr (!RKG) zp[s] = park(zs[s]);
                 v[j] = f < D ? a.eps[sc * D + f] : 0.f;
             }
             if (owner) ebuf[(kg * 2 + wave) * 64 + lane] = v;
@@ -441,6 +451,12 @@ coopd2_solve_kernel(DArgs da) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) { const int f = 4 * j + g; v[j] = f < a.C ? a.ys[sc * a.C + f] : 0.f; }
             ybuf[wave * 64 + lane] = v;
+        }
+        if constexpr (RKG) {
+            if (owner) {
+#pragma unroll
+                for (int q = 0; q < DT; ++q) rk[(5 * DT + q) * 64] = f32x4{zs[4 * q], zs[4 * q + 1], zs[4 * q + 2], zs[4 * q + 3]};
+            }
         }
         if (!a.x) { lacc = a.u0[sc * S + D]; eacc = a.u0[sc * S + D + 1]; nacc = a.u0[sc * S + D + 2]; }
         UAcc2<A> cP;
@@ -500,9 +516,32 @@ coopd2_solve_kernel(DArgs da) {
                 lsum = fmaf(bst, ld, lsum); esum = fmaf(bst, ed, esum); nsum = fmaf(bst, nd, nsum);
                 if (single) break;
                 if (owner) {
-                    // running sums (parked rows pk[0..3] = P_1 .. P_4, pk[4] = the step sum), as cnf_coop_d.hip
+                    // running sums (rows 0..3 = P_1 .. P_4, row 4 = the step sum, row 5 = z), as cnf_coop_d.hip
                     const float c0 = a.acol[sg][0], c1 = a.acol[sg][1], c2 = a.acol[sg][2], c3 = a.acol[sg][3], c4 = a.acol[sg][4];
                     const bool first = sg == 0, lastst = sg == ns - 1;
+                    if constexpr (RKG) {
+                        f32x4 o[5][DT], zz[DT];
+#pragma unroll
+                        for (int q = 0; q < DT; ++q) {
+#pragma unroll
+                            for (int r = 0; r < 5; ++r) o[r][q] = first ? f32x4{0.f, 0.f, 0.f, 0.f} : rk[(r * DT + q) * 64];
+                            zz[q] = rk[(5 * DT + q) * 64];
+                        }
+#pragma unroll
+                        for (int q = 0; q < DT; ++q) {
+                            const f32x4 k = {zd[4 * q], zd[4 * q + 1], zd[4 * q + 2], zd[4 * q + 3]};
+                            const f32x4 p0 = k * c0 + o[0][q], nsu = k * bst + o[4][q];
+                            rk[(0 * DT + q) * 64] = k * c1 + o[1][q];
+                            rk[(1 * DT + q) * 64] = k * c2 + o[2][q];
+                            rk[(2 * DT + q) * 64] = k * c3 + o[3][q];
+                            rk[(3 * DT + q) * 64] = k * c4;
+                            rk[(4 * DT + q) * 64] = nsu;
+                            f32x4 zn4 = p0 * dt + zz[q];
+                            if (lastst) { zn4 = nsu * dt + zz[q]; rk[(5 * DT + q) * 64] = zn4; }
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) zs[4 * q + j] = zn4[j];
+                        }
+                    } else {
 #pragma unroll
                     for (int s = 0; s < ZR; ++s) {
                         const float k = zd[s];
@@ -519,6 +558,7 @@ coopd2_solve_kernel(DArgs da) {
                         pk[4][s] = park(nsu);
                         zs[s] = fmaf(dt, p0, zz);
                         if (lastst) { const float zn = fmaf(dt, nsu, zz); zp[s] = park(zn); zs[s] = zn; }
+                    }
                     }
                 }
             }
@@ -591,9 +631,10 @@ struct CoopD2Inst {
     int A, ZR, ACT;
     hipError_t (*fn)(const DArgs&, int, int, hipStream_t);
 };
-// c = W_N^T eps is hoisted where the accumulation registers hold it beside act'_1 and the seven state rows:
-// (8 A + 8) x 2 + 7 ZR <= 256
-#define CD2_INST(A, ZR, ACT) CoopD2Inst { A, ZR, ACT, &launch_coopd2<A, ZR, ACT, ((8 * A + 8) * 2 + 7 * ZR <= 200)> }
+// c = W_N^T eps is hoisted where the accumulation registers hold it beside act'_1 and the seven state rows
+// ((8 A + 8) x 2 + 7 ZR <= 256), and where the state rows live in the global ring - except at A = 6, where parking it costs 54 more
+// spilled registers than it saves MFMAs (nvariables = 47: 60.4 against 62.0 ms)
+#define CD2_INST(A, ZR, ACT) CoopD2Inst { A, ZR, ACT, &launch_coopd2<A, ZR, ACT, ((d2_rk_in_ring(A, ZR) && A <= 5) || (8 * A + 8) * 2 + 7 * ZR <= 200)> }
 #define CD2_SHAPES(ACT) CD2_INST(4, 16, ACT), CD2_INST(4, 20, ACT), CD2_INST(5, 20, ACT), CD2_INST(5, 24, ACT), CD2_INST(6, 24, ACT)
 static const CoopD2Inst kCoopD2[] = {
     CD2_SHAPES(CNF_ACT_SOFTPLUS),
@@ -624,9 +665,16 @@ hipError_t coopd2_launch(int HT_real, int L, int KZ, int ACT, DArgs& a, int num_
     a.g.xalias = coopd2_lds_bytes(HT_real, DT, false, a.g.cvn, a.k.C > 0) <= 160 * 1024 ? 0 : 1;
     const int lds = coopd2_lds_bytes(HT_real, DT, a.g.xalias != 0, a.g.cvn, a.k.C > 0);
     if (lds > 160 * 1024 || (a.g.xalias && 4 * DT * 3 > HT_real * 2)) return hipErrorNotSupported;
+    if (d2_rk_in_ring(c->A, c->ZR) && !a.k.rk) return hipErrorNotSupported;   // the ring of the Runge-Kutta sums (coopd2_rk_floats: plan-owned)
     const long long nst = (a.k.B + 31) / 32;
     const int nblocks = (int)(nst < num_cus ? nst : num_cus);
     return c->fn(a, lds, nblocks, st);
+}
+
+// floats of the per-workgroup ring the instance serving the shape keeps its Runge-Kutta sums in (0: registers)
+size_t coopd2_rk_floats(int HT_real, int KZ, int ACT, int num_cus) {
+    const CoopD2Inst* c = cd2_find(HT_real, KZ, ACT);
+    return (c && d2_rk_in_ring(c->A, c->ZR)) ? (size_t)num_cus * 2 * 6 * c->ZR * 64 : 0;
 }
 
 }  // namespace cnf

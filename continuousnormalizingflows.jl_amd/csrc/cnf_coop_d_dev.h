@@ -129,5 +129,6 @@ void dimg_fill(DImg& G, int H, int D, int L, int HT_lay, int ZR_lay, int CR_lay,
 // host side of the 32-sample form (cnf_coop_d2.hip): (A, ZR) instances for 16 .. 24 hidden tiles
 bool coopd2_supported(int HT_real, int L, int KZ, int ACT, int C);
 hipError_t coopd2_launch(int HT_real, int L, int KZ, int ACT, DArgs& a, int num_cus, hipStream_t st);
+size_t coopd2_rk_floats(int HT_real, int KZ, int ACT, int num_cus);
 
 }  // namespace cnf

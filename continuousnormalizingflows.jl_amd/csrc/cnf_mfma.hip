@@ -48,6 +48,7 @@ struct MfmaPlan {
     int prio_mode;      // see KArgs
     int use_queue;
     int* queue_dev;     // one int per plan, zeroed on the stream before every launch
+    float* rk_dev = nullptr;   // ring of the Runge-Kutta sums of cnf_coop_d2.hip's 20 .. 24-tile instances (KArgs::rk), allocated on first use
     int q_extra = 0;    // extended cooperative plans of two-hidden-layer exact-trace flows: float offset of the Q image appended
                         // behind the layout (0 = none); per-wave plans carry theirs inside the layout (lay.qtr)
 
@@ -231,6 +232,7 @@ MfmaPlan* mfma_plan_create(const cnf_config& c, bool coop_only) {
 
 void mfma_plan_destroy(MfmaPlan* p) {
     if (p && p->queue_dev) (void)hipFree(p->queue_dev);
+    if (p && p->rk_dev) (void)hipFree(p->rk_dev);
     delete p;
 }
 size_t mfma_packed_bytes(const MfmaPlan* p) {
@@ -533,6 +535,12 @@ hipError_t mfma_solve(MfmaPlan* p, const float* packed_dev, const SolveArgs& s, 
         if (plan_uses_coopd(p, s.B)) {
             int hmax = 0;
             for (int l = 1; l < p->cfg.n_layers; ++l) hmax = p->cfg.widths[l] > hmax ? p->cfg.widths[l] : hmax;
+            const size_t rkf = coopd_rk_floats(hmax, a.D, p->L, p->ACT, a.exact == 1, mp->num_cus);
+            if (rkf && !mp->rk_dev) {
+                hipError_t e = hipMalloc((void**)&mp->rk_dev, rkf * sizeof(float));
+                if (e != hipSuccess) return e;
+            }
+            a.rk = mp->rk_dev;
             return coopd_launch(hmax, a.D, p->L, p->ACT, p->HT, p->ZR, p->CR, a, mp->num_cus, st);
         }
         return coopx_launch(p->HT, p->L, p->ZR, p->CR, p->ACT, a, mp->num_cus, st);

@@ -33,6 +33,7 @@ struct KArgs {
     int q_off;          // extended cooperative kernel, exact trace of a two-hidden-layer flow: float offset of the Q image in `packed` (0: none)
     const float* tgrid; // extended cooperative kernel: nsteps + 1 step times on the device (non-uniform grid) or null
     int KH;             // extended cooperative kernel: 16-row tiles the widest hidden layer really fills (<= the instance's HT; 0: all)
+    float* rk;          // cnf_coop_d2.hip, 20 .. 24 hidden tiles: per-workgroup ring of the Runge-Kutta running sums (plan-owned) or null
 };
 
 // Device-side step controller (mfma_adaptive_kernel): the whole adaptive Tsit5 solve of a batch that fits the chip's wave
@@ -98,6 +99,7 @@ hipError_t coopx_launch_exact(int HT, int L, int ZR, int CR, int ACT, const KArg
 bool coopd_supported(int H, int D, int L, int ACT, int HT_lay, int ZR_lay, int exact, int C);   // exact: the TestMode form (two hidden layers, Q product)
 int coopd_supertile(int H, int D, int L, int ACT, int exact);   // 64 or 32 samples per super-tile (the checkpoint arrays' tile count)
 hipError_t coopd_launch(int H, int D, int L, int ACT, int HT_lay, int ZR_lay, int CR_lay, const KArgs& a, int num_cus, hipStream_t st);
+size_t coopd_rk_floats(int H, int D, int L, int ACT, int exact, int num_cus);   // floats of the KArgs::rk ring the serving instance needs (0: none)
 // the same kernel with ONE sample tile per workgroup and the images in LDS: the tile-split form for small batches
 bool coop_split_supported(int HT, int L, int ZR, int ACT);
 hipError_t coop_split_launch(int HT, int L, int ZR, int ACT, const KArgs& a, hipStream_t st);
