@@ -849,7 +849,7 @@ bool coopd_supported(int H, int D, int L, int ACT, int HT_lay, int ZR_lay, int e
     const int HT_real = (H + 15) / 16, KZ = (D + 3) / 4;
     if (HT_real < 8 || HT_real > HT_lay || KZ > ZR_lay) return false;
     const CoopDInst* c = cd_find(HT_real, L, KZ, ACT, exact ? 1 : 0);
-    if (!c) return !exact && coopd2_supported(HT_real, L, KZ, ACT, C);   // 16 .. 24 hidden tiles: the 32-sample form (cnf_coop_d2.hip)
+    if (!c) return coopd2_supported(HT_real, L, KZ, ACT, C, exact);   // 16 .. 24 hidden tiles: the 32-sample form (cnf_coop_d2.hip)
     // state registers beyond the plan's k-steps would read image k-groups that do not exist
     if ((c->ZR + 3) / 4 > (ZR_lay + 3) / 4) return false;
     // LDS: exchange buffer(s) + state / probe images + partial tiles (+ conditions) + C vectors; when that exceeds 160 KB the partial
@@ -887,8 +887,8 @@ void dimg_fill(DImg& G, int H, int D, int L, int HT_lay, int ZR_lay, int CR_lay,
 
 size_t coopd_rk_floats(int H, int D, int L, int ACT, int exact, int num_cus) {
     const int HT_real = (H + 15) / 16, KZ = (D + 3) / 4;
-    if (exact || L != 2 || cd_find(HT_real, L, KZ, ACT, 0)) return 0;
-    return coopd2_rk_floats(HT_real, KZ, ACT, num_cus);
+    if (L != 2 || cd_find(HT_real, L, KZ, ACT, exact ? 1 : 0)) return 0;
+    return coopd2_rk_floats(HT_real, KZ, ACT, num_cus, exact);
 }
 
 hipError_t coopd_launch(int H, int D, int L, int ACT, int HT_lay, int ZR_lay, int CR_lay, const KArgs& k, int num_cus, hipStream_t st) {
@@ -896,7 +896,7 @@ hipError_t coopd_launch(int H, int D, int L, int ACT, int HT_lay, int ZR_lay, in
     const bool exact = k.exact == 1;
     if (exact && k.q_off <= 0) return hipErrorNotSupported;
     const CoopDInst* c = cd_find(HT_real, L, KZ, ACT, exact ? 1 : 0);
-    const bool form32 = !c && !exact && coopd2_supported(HT_real, L, KZ, ACT, k.C);
+    const bool form32 = !c && coopd2_supported(HT_real, L, KZ, ACT, k.C, exact);
     if (!c && !form32) return hipErrorNotSupported;
     const int A_inst = c ? c->A : HT_real / 4;
     DArgs a{};

@@ -18,7 +18,7 @@
 namespace cnf {
 
 // instances whose Runge-Kutta sums live in the global ring (KArgs::rk) instead of accumulation registers: see the kernel
-constexpr bool d2_rk_in_ring(int A, int ZR) { return A >= 5 || ZR >= 20; }
+constexpr bool d2_rk_in_ring(int A, int ZR, int MODE = 0) { return MODE == 1 || A >= 5 || ZR >= 20; }
 
 template <int A>
 struct UAcc2 {
@@ -392,13 +392,168 @@ __device__ __forceinline__ void coopd2_eval(const DRs& R, const float* __restric
     }
 }
 
+// TestMode (exact trace of a two-hidden-layer flow: tr J = act'_2^T Q act'_1 with the constant Q packed behind the layout,
+// src/core/utils.jl:79-88, icnf.jl:312) for a 32-sample super-tile: the forward chain, then Q act'_1 FIRST (act'_1 as the B image,
+// the second layer's pre-activations parked meanwhile), so that the trace meets act'_2 the moment it is computed - the scheme of
+// coopd_eval_exact (cnf_coop_d.hip) on this form's units.  `red`: [4 waves][3][64] floats of LDS for the trace partials (the probe
+// image's place: TestMode has no probes).
+template <int A, int ZR, int ACT>
+__device__ __forceinline__ void coopd2_eval_exact(const DRs& R, const float* __restrict__ CV, const DImg& Gin, f32x4* __restrict__ xbuf,
+                                                  f32x4* __restrict__ zbuf, f32x4* __restrict__ pbuf, float* __restrict__ red,
+                                                  const f32x4* __restrict__ ybuf, int lane, int wave, float t, bool autonomous,
+                                                  const float (&zs)[ZR], float (&zd)[ZR], float& ld, f32x4 (&aS)[A], f32x4 (&aR)[2]) {
+    constexpr int DT = ZR / 4;
+    int opq = 0;
+    asm volatile("" : "+s"(opq));
+    DImg G = Gin;
+    G.f1z += opq; G.fh += opq; G.fN += opq; G.q_off += opq; G.f1y += opq;
+    const float* __restrict__ P = CV - G.v_b1;
+    const int g = lane >> 4;
+    const bool owner = wave < 2;
+    const RUnits U = runits(A, G.b, wave);
+    const int mtS0 = wave * A;
+    const unsigned F1Z = (unsigned)G.f1z * 4u, FH = (unsigned)G.fh * 4u, FN = (unsigned)G.fN * 4u, QI = (unsigned)G.q_off * 4u;
+    UAcc2<A> acc, h, d1p, a2p;   // d1p: act'_1, a2p: the second layer's pre-activations of this wave's units - parked
+    const TileOff2<A> TZ = tile_offsets2<A>(R, G.KPZ, mtS0, U);
+    const TileOff2<A> TH = tile_offsets2<A>(R, G.HTP, mtS0, U);
+    unsigned vd[DT];
+#pragma unroll
+    for (int dm = 0; dm < DT; ++dm) { vd[dm] = R.lane16 + (unsigned)(dm * G.HTP) * 1024u; asm volatile("" : "+v"(vd[dm])); }
+    auto cvec_units = [&](const float* __restrict__ vec, f32x4 (&vS)[A], f32x4 (&vR)[2]) {
+#pragma unroll
+        for (int m = 0; m < A; ++m) vS[m] = *reinterpret_cast<const f32x4*>(vec + ((mtS0 + m) * 4 + g) * 4);
+        vR[0] = *reinterpret_cast<const f32x4*>(vec + (U.t0 * 4 + g) * 4);
+        vR[1] = *reinterpret_cast<const f32x4*>(vec + (U.t1 * 4 + g) * 4);
+    };
+    auto publish = [&](const UAcc2<A>& v) {
+#pragma unroll
+        for (int m = 0; m < A; ++m) {
+            xbuf[((mtS0 + m) * 2 + 0) * 64 + lane] = v.S[m][0];
+            xbuf[((mtS0 + m) * 2 + 1) * 64 + lane] = v.S[m][1];
+        }
+        if (U.v0) xbuf[(U.t0 * 2 + U.q) * 64 + lane] = v.R[0];
+        if (U.v1) xbuf[(U.t1 * 2 + U.q) * 64 + lane] = v.R[1];
+    };
+    // ---- layer 1 ----
+    {
+        f32x4 bS[A], bR[2], wS[A], wR[2];
+        cvec_units(P + G.v_b1, bS, bR);
+        cvec_units(P + G.v_w1t, wS, wR);
+        if (owner) {
+#pragma unroll
+            for (int kg = 0; kg < DT; ++kg) {
+                f32x4 v;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = zs[4 * kg + j];
+                zbuf[(kg * 2 + wave) * 64 + lane] = v;
+            }
+        }
+        if (!autonomous) {
+#pragma unroll
+            for (int m = 0; m < A; ++m) bS[m] = tile_fma(wS[m], t, bS[m]);
+            bR[0] = tile_fma(wR[0], t, bR[0]);
+            bR[1] = tile_fma(wR[1], t, bR[1]);
+        }
+        u2_fill<A>(acc, bS, bR);
+        __syncthreads();
+        d2_gemm<A>(R, TZ, F1Z, G.KGZ, G.remZ, U, zbuf, lane, aS, aR, acc);
+        if (G.remC > 0) {
+            const TileOff2<A> TC = tile_offsets2<A>(R, G.KPC, mtS0, U);
+            d2_load_a<A>(R, TC, (unsigned)G.f1y * 4u, 0, aS, aR);
+            d2_gemm<A>(R, TC, (unsigned)G.f1y * 4u, 1, G.remC, U, ybuf, lane, aS, aR, acc);
+        }
+    }
+    // ---- hidden layer 1: publish h_1; act'_1 waits (parked) for the exchange buffer ----
+    d2_load_a<A>(R, TH, FH, 0, aS, aR);
+#pragma unroll
+    for (int m = 0; m < A; ++m)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            f32x4 dd;
+            act_pair<ACT>(acc.S[m][q], h.S[m][q], dd);
+            d1p.S[m][q] = park4(dd);
+        }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        f32x4 dd;
+        act_pair<ACT>(acc.R[s], h.R[s], dd);
+        d1p.R[s] = park4(dd);
+    }
+    publish(h);
+    {
+        f32x4 bS[A], bR[2];
+        cvec_units(P + G.v_bh, bS, bR);
+        u2_fill<A>(acc, bS, bR);
+    }
+    __syncthreads();
+    d2_gemm<A>(R, TH, FH, G.KGH, G.remH, U, xbuf, lane, aS, aR, acc);   // a_2 = W_2 h_1 + b_2
+    // ---- Q act'_1 (act'_1 as the B image), a_2 parked meanwhile ----
+    d2_load_a<A>(R, TH, QI, 0, aS, aR);
+    u2_mfma_fence<A>(acc);
+#pragma unroll
+    for (int m = 0; m < A; ++m)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) { a2p.S[m][q] = park4(acc.S[m][q]); h.S[m][q] = unpark4(d1p.S[m][q]); }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) { a2p.R[s] = park4(acc.R[s]); h.R[s] = unpark4(d1p.R[s]); }
+    __syncthreads();   // every wave is done reading h_1
+    publish(h);
+    u2_zero<A>(acc);
+    __syncthreads();
+    d2_gemm<A>(R, TH, QI, G.KGH, G.remH, U, xbuf, lane, aS, aR, acc);   // Q act'_1
+    // ---- hidden layer 2: h_2 feeds zdot from registers; act'_2 meets Q act'_1 ----
+    f32x4 fd[DT];
+#pragma unroll
+    for (int dm = 0; dm < DT; ++dm) fd[dm] = dloadv(R, vd[dm], FN + (unsigned)mtS0 * 1024u);
+    float tr[2] = {0.f, 0.f}, trown = 0.f;
+#pragma unroll
+    for (int m = 0; m < A; ++m)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            f32x4 dd;
+            act_pair<ACT>(unpark4(a2p.S[m][q]), h.S[m][q], dd);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) tr[q] = fmaf(acc.S[m][q][r], dd[r], tr[q]);
+        }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        f32x4 dd;
+        act_pair<ACT>(unpark4(a2p.R[s]), h.R[s], dd);
+        if (s == 0 ? U.v0 : U.v1) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) trown = fmaf(acc.R[s][j], dd[j], trown);
+        }
+    }
+    f32x4* __restrict__ pw = pbuf + (wave * DT) * 3 * 64;
+    if (G.xalias) __syncthreads();            // the partial tiles share the exchange buffer: the Q product's readers are done
+    d2_drow<A, DT>(R, vd, FN, mtS0, G.KGH, G.remH, U, h, fd, pw, lane);
+    d2_load_a<A>(R, TZ, F1Z, 0, aS, aR);   // the next evaluation's layer-1 fragments
+    red[(wave * 3 + 0) * 64 + lane] = group_sum(tr[0]);
+    red[(wave * 3 + 1) * 64 + lane] = group_sum(tr[1]);
+    red[(wave * 3 + 2) * 64 + lane] = group_sum(trown);
+    __syncthreads();
+    ld = 0.f;
+    if (owner) {
+        f32x4 zacc[DT];
+#pragma unroll
+        for (int dm = 0; dm < DT; ++dm)
+            zacc[dm] = d2_reduce<DT>(pbuf, dm, wave, lane, *reinterpret_cast<const f32x4*>(P + G.v_bN + (dm * 4 + g) * 4));
+#pragma unroll
+        for (int s = 0; s < ZR; ++s) zd[s] = zacc[s >> 2][s & 3];
+        // shared parts of the four waves for this sample tile, then the left-over units of waves q and q + 2
+        ld = -((((red[(0 * 3 + wave) * 64 + lane] + red[(1 * 3 + wave) * 64 + lane]) + red[(2 * 3 + wave) * 64 + lane]) +
+                red[(3 * 3 + wave) * 64 + lane]) + (red[(wave * 3 + 2) * 64 + lane] + red[((wave + 2) * 3 + 2) * 64 + lane]));
+    }
+}
+
 constexpr int coopd2_lds_bytes(int HT, int DT, bool alias, int cvn, bool cond) {
     return (HT * 2 * 64 + 2 * DT * 2 * 64 + (alias ? 0 : 4 * DT * 3 * 64) + (cond ? 2 * 64 : 0)) * 16 + (cvn + 3) / 4 * 16;
 }
 
-template <int A, int ZR, int ACT, bool HOIST>
+template <int A, int ZR, int ACT, bool HOIST, int MODE>   // MODE 0: Hutchinson VJP; 1: exact trace (TestMode, no probes, no regularisers)
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 coopd2_solve_kernel(DArgs da) {
+    static_assert(MODE == 0 || !HOIST, "no probe image in TestMode");
     const KArgs& a = da.k;
     const DImg& G = da.g;
     constexpr int DT = ZR / 4;
@@ -428,7 +583,7 @@ coopd2_solve_kernel(DArgs da) {
         // accumulators of five or six tile rows no longer fit and the allocator spilled 146 - 411 registers to scratch at
         // places of its own choosing, k-loops included.  The ring is read and written ONCE per stage, behind the evaluation's last
         // product and behind the next evaluation's first fragment requests.
-        constexpr bool RKG = d2_rk_in_ring(A, ZR);
+        constexpr bool RKG = d2_rk_in_ring(A, ZR, MODE);
         f32x4* __restrict__ rk = RKG ? reinterpret_cast<f32x4*>(a.rk) + ((long long)(blockIdx.x * 2 + (owner ? wave : 0)) * 6 * DT) * 64 + lane : nullptr;
         float zs[ZR], zp[RKG ? 1 : ZR], pk[RKG ? 1 : 5][RKG ? 1 : ZR];   // stage state; z and the running sums, parked (owner waves)
         float lacc = 0.f, eacc = 0.f, nacc = 0.f;
@@ -442,9 +597,9 @@ coopd2_solve_kernel(DArgs da) {
                 if (a.x) zs[s] = f < a.nvars ? a.x[sc * a.nvars + f] : 0.f;
                 else zs[s] = f < D ? a.u0[sc * S + f] : 0.f;
                 if constexpr (!RKG) zp[s] = park(zs[s]);
-                v[j] = f < D ? a.eps[sc * D + f] : 0.f;
+                v[j] = (MODE == 0 && f < D) ? a.eps[sc * D + f] : 0.f;
             }
-            if (owner) ebuf[(kg * 2 + wave) * 64 + lane] = v;
+            if (MODE == 0 && owner) ebuf[(kg * 2 + wave) * 64 + lane] = v;
         }
         if (G.remC > 0 && owner) {
             f32x4 v;
@@ -502,6 +657,10 @@ coopd2_solve_kernel(DArgs da) {
             for (int sg = 0; sg < ns; ++sg) {
                 const long long ckrow = ((((long long)step * ns + sg) * ckntp + cktile) * 64 + lane) * ckzr;
                 float* gout = (a.ckpt_g && !single && owner) ? a.ckpt_g + ckrow : nullptr;
+                if constexpr (MODE == 1)
+                    coopd2_eval_exact<A, ZR, ACT>(R, cbuf, G, xbuf, zbuf, pbuf, reinterpret_cast<float*>(ebuf), ybuf, lane, wave, tn + a.T.c[sg] * dt,
+                                                  autonomous, zs, zd, ld, aS, aR);
+                else
                 coopd2_eval<A, ZR, ACT, HOIST>(R, cbuf, G, xbuf, zbuf, ebuf, pbuf, ybuf, lane, wave, tn + a.T.c[sg] * dt, autonomous, reg_z, reg_j,
                                                zs, zd, ld, ed, nd, gout, cP, aS, aR);
                 if (gout)
@@ -611,9 +770,9 @@ coopd2_solve_kernel(DArgs da) {
 // ---------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------
-template <int A, int ZR, int ACT, bool HOIST>
+template <int A, int ZR, int ACT, bool HOIST, int MODE>
 static hipError_t launch_coopd2(const DArgs& a, int lds, int nblocks, hipStream_t st) {
-    auto kern = coopd2_solve_kernel<A, ZR, ACT, HOIST>;
+    auto kern = coopd2_solve_kernel<A, ZR, ACT, HOIST, MODE>;
     static DeviceOnce once;
     int dev = 0;
     hipError_t e0 = hipGetDevice(&dev);
@@ -628,36 +787,41 @@ static hipError_t launch_coopd2(const DArgs& a, int lds, int nblocks, hipStream_
 }
 
 struct CoopD2Inst {
-    int A, ZR, ACT;
+    int A, ZR, ACT, MODE;
     hipError_t (*fn)(const DArgs&, int, int, hipStream_t);
 };
 // c = W_N^T eps is hoisted where the accumulation registers hold it beside act'_1 and the seven state rows
 // ((8 A + 8) x 2 + 7 ZR <= 256), and where the state rows live in the global ring - except at A = 6, where parking it costs 54 more
 // spilled registers than it saves MFMAs (nvariables = 47: 60.4 against 62.0 ms)
-#define CD2_INST(A, ZR, ACT) CoopD2Inst { A, ZR, ACT, &launch_coopd2<A, ZR, ACT, ((d2_rk_in_ring(A, ZR) && A <= 5) || (8 * A + 8) * 2 + 7 * ZR <= 200)> }
+#define CD2_INST(A, ZR, ACT) CoopD2Inst { A, ZR, ACT, 0, &launch_coopd2<A, ZR, ACT, ((d2_rk_in_ring(A, ZR) && A <= 5) || (8 * A + 8) * 2 + 7 * ZR <= 200), 0> }
+#define CD2_EXACT(A, ZR, ACT) CoopD2Inst { A, ZR, ACT, 1, &launch_coopd2<A, ZR, ACT, false, 1> }
 #define CD2_SHAPES(ACT) CD2_INST(4, 16, ACT), CD2_INST(4, 20, ACT), CD2_INST(5, 20, ACT), CD2_INST(5, 24, ACT), CD2_INST(6, 24, ACT)
 static const CoopD2Inst kCoopD2[] = {
     CD2_SHAPES(CNF_ACT_SOFTPLUS),
     CD2_INST(4, 16, CNF_ACT_TANH_PRESCALED), CD2_INST(5, 20, CNF_ACT_TANH_PRESCALED), CD2_INST(6, 24, CNF_ACT_TANH_PRESCALED),   // tanh flows of 16 .. 24 hidden tiles
+    // TestMode of the default architecture at nvariables = 30 .. 39 (Runge-Kutta sums always in the ring).  (5, 24) and (6, 24): act'_1
+    // and the parked pre-activations of 12 - 14 tiles beside the accumulators of the Q product crash this compiler's register
+    // rewrite pass - nvariables = 40 .. 47 keep TestMode on the extended kernel
+    CD2_EXACT(4, 16, CNF_ACT_SOFTPLUS), CD2_EXACT(4, 20, CNF_ACT_SOFTPLUS), CD2_EXACT(5, 20, CNF_ACT_SOFTPLUS),
 };
-static const CoopD2Inst* cd2_find(int HT_real, int KZ, int ACT) {
+static const CoopD2Inst* cd2_find(int HT_real, int KZ, int ACT, int MODE = 0) {
     const int A = HT_real / 4;
     const CoopD2Inst* best = nullptr;
     for (const CoopD2Inst& c : kCoopD2) {
         const bool act_ok = c.ACT == ACT || (c.ACT == CNF_ACT_TANH_PRESCALED && ACT == CNF_ACT_TANH);
-        if (c.A == A && c.ZR >= KZ && act_ok && (!best || c.ZR < best->ZR)) best = &c;
+        if (c.A == A && c.MODE == MODE && c.ZR >= KZ && act_ok && (!best || c.ZR < best->ZR)) best = &c;
     }
     return best;
 }
 
-bool coopd2_supported(int HT_real, int L, int KZ, int ACT, int C) {
+bool coopd2_supported(int HT_real, int L, int KZ, int ACT, int C, int exact) {
     if (L != 2 || C < 0 || C > 16) return false;
-    return cd2_find(HT_real, KZ, ACT) != nullptr;
+    return cd2_find(HT_real, KZ, ACT, exact ? 1 : 0) != nullptr;
 }
 
 // `a` arrives with the image view filled in by coopd_launch (cnf_coop_d.hip); the LDS decision is made here
 hipError_t coopd2_launch(int HT_real, int L, int KZ, int ACT, DArgs& a, int num_cus, hipStream_t st) {
-    const CoopD2Inst* c = cd2_find(HT_real, KZ, ACT);
+    const CoopD2Inst* c = cd2_find(HT_real, KZ, ACT, a.k.exact == 1 ? 1 : 0);
     if (!c || L != 2) return hipErrorNotSupported;
     const int DT = c->ZR / 4;
     // the instance's state registers must not read image k-groups the plan's layout does not have
@@ -665,16 +829,16 @@ hipError_t coopd2_launch(int HT_real, int L, int KZ, int ACT, DArgs& a, int num_
     a.g.xalias = coopd2_lds_bytes(HT_real, DT, false, a.g.cvn, a.k.C > 0) <= 160 * 1024 ? 0 : 1;
     const int lds = coopd2_lds_bytes(HT_real, DT, a.g.xalias != 0, a.g.cvn, a.k.C > 0);
     if (lds > 160 * 1024 || (a.g.xalias && 4 * DT * 3 > HT_real * 2)) return hipErrorNotSupported;
-    if (d2_rk_in_ring(c->A, c->ZR) && !a.k.rk) return hipErrorNotSupported;   // the ring of the Runge-Kutta sums (coopd2_rk_floats: plan-owned)
+    if (d2_rk_in_ring(c->A, c->ZR, c->MODE) && !a.k.rk) return hipErrorNotSupported;   // the ring of the Runge-Kutta sums (coopd2_rk_floats: plan-owned)
     const long long nst = (a.k.B + 31) / 32;
     const int nblocks = (int)(nst < num_cus ? nst : num_cus);
     return c->fn(a, lds, nblocks, st);
 }
 
 // floats of the per-workgroup ring the instance serving the shape keeps its Runge-Kutta sums in (0: registers)
-size_t coopd2_rk_floats(int HT_real, int KZ, int ACT, int num_cus) {
-    const CoopD2Inst* c = cd2_find(HT_real, KZ, ACT);
-    return (c && d2_rk_in_ring(c->A, c->ZR)) ? (size_t)num_cus * 2 * 6 * c->ZR * 64 : 0;
+size_t coopd2_rk_floats(int HT_real, int KZ, int ACT, int num_cus, int exact) {
+    const CoopD2Inst* c = cd2_find(HT_real, KZ, ACT, exact ? 1 : 0);
+    return (c && d2_rk_in_ring(c->A, c->ZR, c->MODE)) ? (size_t)num_cus * 2 * 6 * c->ZR * 64 : 0;
 }
 
 }  // namespace cnf

@@ -127,8 +127,8 @@ __device__ __forceinline__ void act_pair(const f32x4& a, f32x4& h, f32x4& d) { a
 
 void dimg_fill(DImg& G, int H, int D, int L, int HT_lay, int ZR_lay, int CR_lay, int A_inst, int C);   // cnf_coop_d.hip
 // host side of the 32-sample form (cnf_coop_d2.hip): (A, ZR) instances for 16 .. 24 hidden tiles
-bool coopd2_supported(int HT_real, int L, int KZ, int ACT, int C);
+bool coopd2_supported(int HT_real, int L, int KZ, int ACT, int C, int exact = 0);
 hipError_t coopd2_launch(int HT_real, int L, int KZ, int ACT, DArgs& a, int num_cus, hipStream_t st);
-size_t coopd2_rk_floats(int HT_real, int KZ, int ACT, int num_cus);
+size_t coopd2_rk_floats(int HT_real, int KZ, int ACT, int num_cus, int exact = 0);
 
 }  // namespace cnf
