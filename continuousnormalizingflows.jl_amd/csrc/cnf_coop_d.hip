@@ -31,6 +31,10 @@
 
 namespace cnf {
 
+// instances whose Runge-Kutta sums live in the plan's global ring (KArgs::rk) instead of accumulation registers: the ones that
+// spilled with them parked (12 and more state registers: 28 - 167 registers; three hidden layers at A = 3: 56)
+constexpr bool cd_rk_in_ring(int A, int L, int ZR) { return ZR >= 12 || (A == 3 && L == 3); }
+
 template <int A>
 struct UAcc {
     f32x4 S[A][4];   // tiles [w A, (w+1) A) x the four sample tiles
@@ -654,7 +658,12 @@ coopd_solve_kernel(DArgs da) {
         const long long smp = st * 64 + wave * 16 + n;
         const bool valid = smp < a.B;
         const long long sc = valid ? smp : a.B - 1;
-        float zs[ZR], zp[ZR], pk[5][ZR];   // stage state; z and the running sums, parked
+        // RKG: z and the five running sums in a per-wave slice of the plan's global ring (L2-resident; read and written once per
+        // stage as 16-byte accesses, behind the evaluation's last product and the next evaluation's first fragment requests) -
+        // see cnf_coop_d2.hip, where the same move took the 20 .. 24-tile instances from 77 to 110 TFLOP/s
+        constexpr bool RKG = cd_rk_in_ring(A, L, ZR);
+        f32x4* __restrict__ rk = RKG ? reinterpret_cast<f32x4*>(a.rk) + ((long long)(blockIdx.x * 4 + wave) * 6 * DT) * 64 + lane : nullptr;
+        float zs[ZR], zp[RKG ? 1 : ZR], pk[RKG ? 1 : 5][RKG ? 1 : ZR];   // stage state; z and the running sums, parked
         float lacc = 0.f, eacc = 0.f, nacc = 0.f;
         __syncthreads();   // the previous super-tile's readers of the LDS images are done
 #pragma unroll
@@ -665,7 +674,7 @@ coopd_solve_kernel(DArgs da) {
                 const int s = 4 * kg + j, f = 4 * s + g;
                 if (a.x) zs[s] = f < a.nvars ? a.x[sc * a.nvars + f] : 0.f;
                 else zs[s] = f < D ? a.u0[sc * S + f] : 0.f;
-                zp[s] = park(zs[s]);
+                if constexpr (!RKG) zp[s] = park(zs[s]);
                 v[j] = (MODE == 0 && f < D) ? a.eps[sc * D + f] : 0.f;
             }
             if constexpr (MODE == 0) ebuf[(kg * 4 + wave) * 64 + lane] = v;   // the probe of this wave's sample tile as a B image, for the whole solve
@@ -675,6 +684,10 @@ coopd_solve_kernel(DArgs da) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) { const int f = 4 * j + g; v[j] = f < a.C ? a.ys[sc * a.C + f] : 0.f; }
             ybuf[wave * 64 + lane] = v;
+        }
+        if constexpr (RKG) {
+#pragma unroll
+            for (int q = 0; q < DT; ++q) rk[(5 * DT + q) * 64] = f32x4{zs[4 * q], zs[4 * q + 1], zs[4 * q + 2], zs[4 * q + 3]};
         }
         if (!a.x) { lacc = a.u0[sc * S + D]; eacc = a.u0[sc * S + D + 1]; nacc = a.u0[sc * S + D + 2]; }
         UAcc<A> cP;
@@ -732,6 +745,29 @@ coopd_solve_kernel(DArgs da) {
                 // P_4 <- acol[sg][4] zdot, step sum <- fma(b, zdot, step sum); the next stage state is z + dt P_0
                 const float c0 = a.acol[sg][0], c1 = a.acol[sg][1], c2 = a.acol[sg][2], c3 = a.acol[sg][3], c4 = a.acol[sg][4];
                 const bool first = sg == 0, lastst = sg == ns - 1;
+                if constexpr (RKG) {
+                    f32x4 o[5][DT], zz[DT];
+#pragma unroll
+                    for (int q = 0; q < DT; ++q) {
+#pragma unroll
+                        for (int r = 0; r < 5; ++r) o[r][q] = first ? f32x4{0.f, 0.f, 0.f, 0.f} : rk[(r * DT + q) * 64];
+                        zz[q] = rk[(5 * DT + q) * 64];
+                    }
+#pragma unroll
+                    for (int q = 0; q < DT; ++q) {
+                        const f32x4 k = {zd[4 * q], zd[4 * q + 1], zd[4 * q + 2], zd[4 * q + 3]};
+                        const f32x4 p0 = k * c0 + o[0][q], nsu = k * bst + o[4][q];
+                        rk[(0 * DT + q) * 64] = k * c1 + o[1][q];
+                        rk[(1 * DT + q) * 64] = k * c2 + o[2][q];
+                        rk[(2 * DT + q) * 64] = k * c3 + o[3][q];
+                        rk[(3 * DT + q) * 64] = k * c4;
+                        rk[(4 * DT + q) * 64] = nsu;
+                        f32x4 zn4 = p0 * dt + zz[q];
+                        if (lastst) { zn4 = nsu * dt + zz[q]; rk[(5 * DT + q) * 64] = zn4; }
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) zs[4 * q + j] = zn4[j];
+                    }
+                } else {
 #pragma unroll
                 for (int s = 0; s < ZR; ++s) {
                     const float k = zd[s];
@@ -748,6 +784,7 @@ coopd_solve_kernel(DArgs da) {
                     pk[4][s] = park(nsu);
                     zs[s] = fmaf(dt, p0, zz);
                     if (lastst) { const float zn = fmaf(dt, nsu, zz); zp[s] = park(zn); zs[s] = zn; }
+                }
                 }
             }
             if (single) break;
@@ -887,8 +924,8 @@ void dimg_fill(DImg& G, int H, int D, int L, int HT_lay, int ZR_lay, int CR_lay,
 
 size_t coopd_rk_floats(int H, int D, int L, int ACT, int exact, int num_cus) {
     const int HT_real = (H + 15) / 16, KZ = (D + 3) / 4;
-    if (L != 2 || cd_find(HT_real, L, KZ, ACT, exact ? 1 : 0)) return 0;
-    return coopd2_rk_floats(HT_real, KZ, ACT, num_cus, exact);
+    if (const CoopDInst* c = cd_find(HT_real, L, KZ, ACT, exact ? 1 : 0)) return cd_rk_in_ring(c->A, c->L, c->ZR) ? (size_t)num_cus * 4 * 6 * c->ZR * 64 : 0;
+    return L == 2 ? coopd2_rk_floats(HT_real, KZ, ACT, num_cus, exact) : 0;
 }
 
 hipError_t coopd_launch(int H, int D, int L, int ACT, int HT_lay, int ZR_lay, int CR_lay, const KArgs& k, int num_cus, hipStream_t st) {
@@ -910,6 +947,7 @@ hipError_t coopd_launch(int H, int D, int L, int ACT, int HT_lay, int ZR_lay, in
     G.xalias = coopd_lds_bytes(HT_real, L, DT, false, G.cvn, k.C > 0) <= 160 * 1024 ? 0 : 1;
     const int lds = coopd_lds_bytes(HT_real, L, DT, G.xalias != 0, G.cvn, k.C > 0);
     if (lds > 160 * 1024 || (G.xalias && 4 * DT * 4 > (L == 2 ? 1 : 2) * HT_real * 4)) return hipErrorNotSupported;
+    if (cd_rk_in_ring(c->A, c->L, c->ZR) && !k.rk) return hipErrorNotSupported;   // the ring of the Runge-Kutta sums (coopd_rk_floats: plan-owned)
     const long long nst = (k.B + 63) / 64;
     const int nblocks = (int)(nst < num_cus ? nst : num_cus);
     return c->fn(a, lds, nblocks, st);

@@ -548,6 +548,12 @@ hipError_t mfma_solve(MfmaPlan* p, const float* packed_dev, const SolveArgs& s, 
     if (p->kind == 1 && plan_uses_coopd(p, s.B)) {
         int hmax = 0;
         for (int l = 1; l < p->cfg.n_layers; ++l) hmax = p->cfg.widths[l] > hmax ? p->cfg.widths[l] : hmax;
+        const size_t rkf = coopd_rk_floats(hmax, a.D, p->L, p->ACT, 0, mp->num_cus);
+        if (rkf && !mp->rk_dev) {
+            hipError_t e = hipMalloc((void**)&mp->rk_dev, rkf * sizeof(float));
+            if (e != hipSuccess) return e;
+        }
+        a.rk = mp->rk_dev;
         return coopd_launch(hmax, a.D, p->L, p->ACT, p->HT, p->ZR, 0, a, mp->num_cus, st);
     }
     if (p->kind == 1) {
