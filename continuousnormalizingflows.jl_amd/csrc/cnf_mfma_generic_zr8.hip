@@ -31,8 +31,14 @@ namespace cnf {
 #define GEN8_TAN7(ACT) MFMA_INST(7, 2, 8, 0, ACT, ENG_TAN, 1, 0, 256), MFMA_INST(7, 2, 8, 4, ACT, ENG_TAN, 1, 0, 256)
 #define GEN8_TAN7_DEF(ACT) MFMA_INST_AD(7, 2, 8, 0, ACT, ENG_TAN, 1, 0, 256), MFMA_INST(7, 2, 8, 4, ACT, ENG_TAN, 1, 0, 256)
 
+// 5 and 7 hidden tiles for the reference's default nets at nvariables = 8, 9 (H = 72, 80) and 12, 13 (H = 104, 112): on the 6- / 8-tile
+// instances their H x H products multiplied 1.4 - 1.8 x / 1.3 - 1.5 x the tiles they have (round 4: nvariables = 12 TrainMode 14.3 ms,
+// the same as nvariables = 15)
+#define GEN8_DEF57 MFMA_INST_AD(5, 2, 8, 0, CNF_ACT_SOFTPLUS, ENG_VJP, 1, 1, 256), MFMA_INST_AD(5, 2, 8, 0, CNF_ACT_SOFTPLUS, ENG_TAN, 1, 0, 256), \
+                   MFMA_INST_AD(7, 2, 8, 0, CNF_ACT_SOFTPLUS, ENG_VJP, 1, 1, 256)
+
 static const Inst kGenericZr8[] = {
-    GEN8_TAN7(CNF_ACT_TANH), GEN8_TAN7_DEF(CNF_ACT_SOFTPLUS),
+    GEN8_TAN7(CNF_ACT_TANH), GEN8_TAN7_DEF(CNF_ACT_SOFTPLUS), GEN8_DEF57,
     GEN8_ACT(2, 512), GEN8_ACT(4, 256), GEN8_ACT(6, 256), GEN8_ACT(8, 256),   // HT = 4 spills at 2 waves/SIMD (8 state k-steps)
 };
 

@@ -4,7 +4,7 @@ import __graft_entry__ as entry
 pkg = entry.load_package(); o64, oc = entry.load_oracle()
 dev = torch.device("cuda:0")
 out = {}
-for nv in (1, 2, 4, 8, 12, 15):
+for nv in [int(v) for v in os.environ.get("NVS", "1,2,4,8,12,15").split(",")]:
     icnf = pkg.ICNF(nvariables=nv, device=dev, steer_rate=0.0, sol_kwargs=dict(alg=pkg.Tsit5(), adaptive=False, nsteps=40))
     ps, st = pkg.setup(torch.Generator().manual_seed(0), icnf)
     B = 65536

@@ -112,7 +112,7 @@ CASES = [
     (dict(nvars=6, naug=2, hidden=[256, 256, 256], reg_z=True, reg_j=True, reg_aug=True), 100, 0, 8),  # D=8, 3x256
     (dict(nvars=30, hidden=[128, 128], autonomous=True), 65, 1, 6),                         # D=30, 2x128 autonomous
     # 8 state k-steps (csrc/cnf_mfma_generic_zr8.hip): the reference's default nets for nvariables = 8 .. 15
-    (dict(nvars=8, naug=9, hidden=[72, 72], act=2, reg_z=True, reg_j=True, reg_aug=True), 70, 1, 8),     # ICNF(nvariables=8): D=17, H=72 (5 tiles -> 6)
+    (dict(nvars=8, naug=9, hidden=[72, 72], act=2, reg_z=True, reg_j=True, reg_aug=True), 70, 1, 8),     # ICNF(nvariables=8): D=17, H=72 (5 tiles: its own instance since round 4)
     (dict(nvars=12, naug=13, hidden=[104, 104], act=2, reg_z=True, reg_j=True, reg_aug=True), 50, 0, 6),  # ICNF(nvariables=12): D=25, H=104
     (dict(nvars=15, naug=16, hidden=[128, 128], act=2, mode=1, reg_z=True, reg_j=True, reg_aug=True), 40, 1, 5),  # nvariables=15, JVP mode: D=31, H=128
     (dict(nvars=8, naug=9, ncond=4, hidden=[88, 88], act=2, reg_z=True, reg_j=True, reg_aug=True), 45, 1, 6),   # CondICNF default, 4 conditions
