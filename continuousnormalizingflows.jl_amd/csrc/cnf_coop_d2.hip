@@ -489,13 +489,27 @@ __device__ __forceinline__ void coopd2_eval_exact(const DRs& R, const float* __r
     d2_gemm<A>(R, TH, FH, G.KGH, G.remH, U, xbuf, lane, aS, aR, acc);   // a_2 = W_2 h_1 + b_2
     // ---- Q act'_1 (act'_1 as the B image), a_2 parked meanwhile ----
     d2_load_a<A>(R, TH, QI, 0, aS, aR);
+    // (A >= 5: the pre-activations wait in this wave's slice of the partial-tile buffer - 2 A + 2 tiles of the 3 DT it holds, free
+    // until the zdot partials are written - instead of accumulation registers: with act'_1 AND them parked beside the accumulators
+    // of the Q product this compiler's register-rewrite pass crashes)
+    constexpr bool A2LDS = A >= 5;
+    f32x4* __restrict__ pw = pbuf + (wave * DT) * 3 * 64;
+    static_assert(!A2LDS || 2 * A + 2 <= 3 * DT, "the pre-activations fit the wave's partial-tile slice");
     u2_mfma_fence<A>(acc);
 #pragma unroll
     for (int m = 0; m < A; ++m)
 #pragma unroll
-        for (int q = 0; q < 2; ++q) { a2p.S[m][q] = park4(acc.S[m][q]); h.S[m][q] = unpark4(d1p.S[m][q]); }
+        for (int q = 0; q < 2; ++q) {
+            if constexpr (A2LDS) pw[(m * 2 + q) * 64 + lane] = acc.S[m][q];
+            else a2p.S[m][q] = park4(acc.S[m][q]);
+            h.S[m][q] = unpark4(d1p.S[m][q]);
+        }
 #pragma unroll
-    for (int s = 0; s < 2; ++s) { a2p.R[s] = park4(acc.R[s]); h.R[s] = unpark4(d1p.R[s]); }
+    for (int s = 0; s < 2; ++s) {
+        if constexpr (A2LDS) pw[(2 * A + s) * 64 + lane] = acc.R[s];
+        else a2p.R[s] = park4(acc.R[s]);
+        h.R[s] = unpark4(d1p.R[s]);
+    }
     __syncthreads();   // every wave is done reading h_1
     publish(h);
     u2_zero<A>(acc);
@@ -511,20 +525,21 @@ __device__ __forceinline__ void coopd2_eval_exact(const DRs& R, const float* __r
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             f32x4 dd;
-            act_pair<ACT>(unpark4(a2p.S[m][q]), h.S[m][q], dd);
+            const f32x4 a2 = A2LDS ? pw[(m * 2 + q) * 64 + lane] : unpark4(a2p.S[m][q]);
+            act_pair<ACT>(a2, h.S[m][q], dd);
 #pragma unroll
             for (int r = 0; r < 4; ++r) tr[q] = fmaf(acc.S[m][q][r], dd[r], tr[q]);
         }
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
         f32x4 dd;
-        act_pair<ACT>(unpark4(a2p.R[s]), h.R[s], dd);
+        const f32x4 a2 = A2LDS ? pw[(2 * A + s) * 64 + lane] : unpark4(a2p.R[s]);
+        act_pair<ACT>(a2, h.R[s], dd);
         if (s == 0 ? U.v0 : U.v1) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) trown = fmaf(acc.R[s][j], dd[j], trown);
         }
     }
-    f32x4* __restrict__ pw = pbuf + (wave * DT) * 3 * 64;
     if (G.xalias) __syncthreads();            // the partial tiles share the exchange buffer: the Q product's readers are done
     d2_drow<A, DT>(R, vd, FN, mtS0, G.KGH, G.remH, U, h, fd, pw, lane);
     d2_load_a<A>(R, TZ, F1Z, 0, aS, aR);   // the next evaluation's layer-1 fragments
@@ -799,10 +814,10 @@ struct CoopD2Inst {
 static const CoopD2Inst kCoopD2[] = {
     CD2_SHAPES(CNF_ACT_SOFTPLUS),
     CD2_INST(4, 16, CNF_ACT_TANH_PRESCALED), CD2_INST(5, 20, CNF_ACT_TANH_PRESCALED), CD2_INST(6, 24, CNF_ACT_TANH_PRESCALED),   // tanh flows of 16 .. 24 hidden tiles
-    // TestMode of the default architecture at nvariables = 30 .. 39 (Runge-Kutta sums always in the ring).  (5, 24) and (6, 24): act'_1
-    // and the parked pre-activations of 12 - 14 tiles beside the accumulators of the Q product crash this compiler's register
-    // rewrite pass - nvariables = 40 .. 47 keep TestMode on the extended kernel
-    CD2_EXACT(4, 16, CNF_ACT_SOFTPLUS), CD2_EXACT(4, 20, CNF_ACT_SOFTPLUS), CD2_EXACT(5, 20, CNF_ACT_SOFTPLUS),
+    // TestMode of the default architecture at nvariables = 30 .. 45 (Runge-Kutta sums always in the ring; from A = 5 on the parked
+    // pre-activations wait in LDS).  (6, 24) still crashes this compiler's register-rewrite pass: 24 hidden tiles (nvariables = 46, 47)
+    // keep TestMode on the extended kernel
+    CD2_EXACT(4, 16, CNF_ACT_SOFTPLUS), CD2_EXACT(4, 20, CNF_ACT_SOFTPLUS), CD2_EXACT(5, 20, CNF_ACT_SOFTPLUS), CD2_EXACT(5, 24, CNF_ACT_SOFTPLUS),
 };
 static const CoopD2Inst* cd2_find(int HT_real, int KZ, int ACT, int MODE = 0) {
     const int A = HT_real / 4;

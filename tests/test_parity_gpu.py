@@ -210,6 +210,7 @@ COOPD_CASES = [
     (dict(nvars=33, naug=34, hidden=[272, 272], act=2, mode=2), 50, 0, 3),                                    # 17 tiles, D = 67: 20 state registers, RK4
     (dict(nvars=38, naug=39, hidden=[312, 312], act=2, mode=2, autonomous=True), 40, 1, 2),                   # 20 tiles (A = 5), D = 77, no time column
     (dict(nvars=30, naug=31, ncond=4, hidden=[248, 248], act=2, mode=2), 33, 1, 2),                           # conditioned TestMode, 16 tiles
+    (dict(nvars=42, naug=43, hidden=[344, 344], act=2, mode=2), 40, 1, 2),                                    # TestMode at 22 tiles, D = 85 (24 state registers): pre-activations parked in LDS
     (dict(nvars=60, naug=20, hidden=[340, 340], reg_aug=True), 40, 0, 3),                                     # tanh, 22 tiles, D = 80
     # conditioned flows (CondICNF: the condition rows of layer 1, src/layers/cond_layer.jl:7-31, src/core/base_icnf.jl:272-296)
     (dict(nvars=16, naug=17, ncond=5, hidden=[156, 156], act=2, reg_z=True, reg_j=True, reg_aug=True), 120, 1, 5),   # default architecture with 5 conditions: 10 tiles
