@@ -68,14 +68,16 @@ __device__ __forceinline__ f32x4 dg_act_dd(const f32x4& h, const f32x4& d) {
     else return h * d * -2.f;
 }
 
-template <int A>
+// NSAMP: sample tiles of a super-tile (2: 32 samples, four column tiles per product; 1: 16 samples, two - the form for 16 .. 24
+// hidden tiles, whose four-column exchange buffers would not fit the LDS)
+template <int A, int NSAMP>
 struct GAcc {
-    f32x4 S[A][4];    // tiles [w A, (w + 1) A) x (chain 0: sample tiles 0, 1 | chain 1: sample tiles 0, 1)
-    f32x4 R[2][2];    // this wave's left-over (tile, sample) units (see gunits): [slot][chain]
+    f32x4 S[A][2 * NSAMP];   // tiles [w A, (w + 1) A) x (chain 0: the sample tiles | chain 1: the sample tiles)
+    f32x4 R[2][2];           // this wave's left-over (tile, sample) units (see gunits): [slot][chain]
 };
-template <int A>
-struct GHalf {        // one chain's worth of this wave's units
-    f32x4 S[A][2];
+template <int A, int NSAMP>
+struct GHalf {               // one chain's worth of this wave's units
+    f32x4 S[A][NSAMP];
     f32x4 R[2];
 };
 template <int A>
@@ -89,14 +91,22 @@ struct GUnits {
     bool v0, v1;
     int t0, t1, q;
 };
+template <int NSAMP>
 __device__ __forceinline__ GUnits gunits(int A, int b, int wave) {
     GUnits u;
     const int un = 3 - wave;
-    u.v0 = un < 2 * b; u.v1 = un + 4 < 2 * b;
     const int tmax = 4 * A + b - 1;
-    const int r0 = 4 * A + (un >> 1), r1 = r0 + 2;
-    u.t0 = r0 < tmax ? r0 : tmax; u.t1 = r1 < tmax ? r1 : tmax;
-    u.q = un & 1;
+    if constexpr (NSAMP == 2) {
+        u.v0 = un < 2 * b; u.v1 = un + 4 < 2 * b;
+        const int r0 = 4 * A + (un >> 1), r1 = r0 + 2;
+        u.t0 = r0 < tmax ? r0 : tmax; u.t1 = r1 < tmax ? r1 : tmax;
+        u.q = un & 1;
+    } else {   // one sample tile: the b left-over tiles are the units, one each to waves 3, 2, 1
+        u.v0 = un < b; u.v1 = false;
+        const int r0 = 4 * A + un;
+        u.t0 = r0 < tmax ? r0 : tmax; u.t1 = tmax;
+        u.q = 0;
+    }
     return u;
 }
 template <int A>
@@ -118,23 +128,25 @@ __device__ __forceinline__ void g_load_a(const DRs& R, const GOff<A>& T, unsigne
 }
 // B fragments of k-group kg: the four column tiles, and again the two columns of this wave's left-over sample tile (the column
 // index is a scalar the compiler must not fold into per-column code paths)
-__device__ __forceinline__ void g_load_b(const f32x4* __restrict__ bimg, int kg, int qr, int lane, f32x4 (&bq)[4], f32x4 (&bo)[2]) {
+template <int NSAMP>
+__device__ __forceinline__ void g_load_b(const f32x4* __restrict__ bimg, int kg, int qr, int lane, f32x4 (&bq)[2 * NSAMP], f32x4 (&bo)[2]) {
+    constexpr int NC = 2 * NSAMP;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) bq[c] = bimg[(kg * 4 + c) * 64 + lane];
+    for (int c = 0; c < NC; ++c) bq[c] = bimg[(kg * NC + c) * 64 + lane];
     int qv = qr;
     asm volatile("" : "+s"(qv));
-    bo[0] = bimg[(kg * 4 + qv) * 64 + lane];
-    bo[1] = bimg[(kg * 4 + 2 + qv) * 64 + lane];
+    bo[0] = bimg[(kg * NC + qv) * 64 + lane];
+    bo[1] = bimg[(kg * NC + NSAMP + qv) * 64 + lane];
 }
-template <int A, int JN>
-__device__ __forceinline__ void g_mfma(const f32x4 (&aS)[A], const f32x4 (&aR)[2], const f32x4 (&bq)[4], const f32x4 (&bo)[2], const GUnits& U,
-                                       GAcc<A>& u) {
+template <int A, int NSAMP, int JN>
+__device__ __forceinline__ void g_mfma(const f32x4 (&aS)[A], const f32x4 (&aR)[2], const f32x4 (&bq)[2 * NSAMP], const f32x4 (&bo)[2], const GUnits& U,
+                                       GAcc<A, NSAMP>& u) {
 #pragma unroll
     for (int j = 0; j < JN; ++j)
 #pragma unroll
         for (int m = 0; m < A; ++m)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) u.S[m][c] = mfma4(aS[m][j], bq[c][j], u.S[m][c]);
+            for (int c = 0; c < 2 * NSAMP; ++c) u.S[m][c] = mfma4(aS[m][j], bq[c][j], u.S[m][c]);
     if (U.v0) {
 #pragma unroll
         for (int j = 0; j < JN; ++j)
@@ -148,53 +160,54 @@ __device__ __forceinline__ void g_mfma(const f32x4 (&aS)[A], const f32x4 (&aR)[2
             for (int ch = 0; ch < 2; ++ch) u.R[1][ch] = mfma4(aR[1][j], bo[ch][j], u.R[1][ch]);
     }
 }
-template <int A>
-__device__ __forceinline__ void g_mfma_rem(const f32x4 (&aS)[A], const f32x4 (&aR)[2], const f32x4 (&bq)[4], const f32x4 (&bo)[2], const GUnits& U,
-                                           int rem, GAcc<A>& u) {
-    if (rem == 4) g_mfma<A, 4>(aS, aR, bq, bo, U, u);
-    else if (rem == 3) g_mfma<A, 3>(aS, aR, bq, bo, U, u);
-    else if (rem == 2) g_mfma<A, 2>(aS, aR, bq, bo, U, u);
-    else g_mfma<A, 1>(aS, aR, bq, bo, U, u);
+template <int A, int NSAMP>
+__device__ __forceinline__ void g_mfma_rem(const f32x4 (&aS)[A], const f32x4 (&aR)[2], const f32x4 (&bq)[2 * NSAMP], const f32x4 (&bo)[2], const GUnits& U,
+                                           int rem, GAcc<A, NSAMP>& u) {
+    if (rem == 4) g_mfma<A, NSAMP, 4>(aS, aR, bq, bo, U, u);
+    else if (rem == 3) g_mfma<A, NSAMP, 3>(aS, aR, bq, bo, U, u);
+    else if (rem == 2) g_mfma<A, NSAMP, 2>(aS, aR, bq, bo, U, u);
+    else g_mfma<A, NSAMP, 1>(aS, aR, bq, bo, U, u);
 }
 // u += A(image) * B(LDS image, four column tiles) over KG k-groups, the last one with `rem` k-steps; aS0 / aR0 arrive holding the
 // fragments of k-group 0 (structure of dealt_gemm, cnf_coop_d.hip: two fragment sets ping-pong, one k-group of lead - a third set
 // and two k-groups of lead were measured with s_memtime: no difference)
-template <int A>
+template <int A, int NSAMP>
 __device__ __forceinline__ void g_gemm(const DRs& R, const GOff<A>& T, unsigned img, int KG, int rem, const GUnits& U,
-                                       const f32x4* __restrict__ bimg, int lane, f32x4 (&aS0)[A], f32x4 (&aR0)[2], GAcc<A>& u) {
-    f32x4 aS1[A], aR1[2], bq0[4], bq1[4], bo0[2], bo1[2];
-    g_load_b(bimg, 0, U.q, lane, bq0, bo0);
+                                       const f32x4* __restrict__ bimg, int lane, f32x4 (&aS0)[A], f32x4 (&aR0)[2], GAcc<A, NSAMP>& u) {
+    f32x4 aS1[A], aR1[2], bq0[2 * NSAMP], bq1[2 * NSAMP], bo0[2], bo1[2];
+    g_load_b<NSAMP>(bimg, 0, U.q, lane, bq0, bo0);
     const int KGf = KG - 1;
     int kg = 0;
 #pragma clang loop unroll(disable)
     for (; kg + 2 <= KGf; kg += 2) {
         g_load_a<A>(R, T, img, kg + 1, aS1, aR1);
-        g_load_b(bimg, kg + 1, U.q, lane, bq1, bo1);
-        g_mfma<A, 4>(aS0, aR0, bq0, bo0, U, u);
+        g_load_b<NSAMP>(bimg, kg + 1, U.q, lane, bq1, bo1);
+        g_mfma<A, NSAMP, 4>(aS0, aR0, bq0, bo0, U, u);
         g_load_a<A>(R, T, img, kg + 2, aS0, aR0);
-        g_load_b(bimg, kg + 2, U.q, lane, bq0, bo0);
-        g_mfma<A, 4>(aS1, aR1, bq1, bo1, U, u);
+        g_load_b<NSAMP>(bimg, kg + 2, U.q, lane, bq0, bo0);
+        g_mfma<A, NSAMP, 4>(aS1, aR1, bq1, bo1, U, u);
     }
     if (kg < KGf) {
         g_load_a<A>(R, T, img, KG - 1, aS1, aR1);
-        g_load_b(bimg, KG - 1, U.q, lane, bq1, bo1);
-        g_mfma<A, 4>(aS0, aR0, bq0, bo0, U, u);
-        g_mfma_rem<A>(aS1, aR1, bq1, bo1, U, rem, u);
+        g_load_b<NSAMP>(bimg, KG - 1, U.q, lane, bq1, bo1);
+        g_mfma<A, NSAMP, 4>(aS0, aR0, bq0, bo0, U, u);
+        g_mfma_rem<A, NSAMP>(aS1, aR1, bq1, bo1, U, rem, u);
     } else {
-        g_mfma_rem<A>(aS0, aR0, bq0, bo0, U, rem, u);
+        g_mfma_rem<A, NSAMP>(aS0, aR0, bq0, bo0, U, rem, u);
     }
 }
 
 // K-split D-row product by ownership, one chain: part[dm][q] = partial over this wave's shared k-groups for sample tile q,
 // own[dm] = partial over its left-over units' k-groups (sample tile w & 1).  f0 arrives holding the fragments of k-group kgS0.
-template <int A, int DT>
+template <int A, int NSAMP, int DT>
 __device__ __forceinline__ void g_drow(const DRs& R, const unsigned (&vd)[DT], unsigned img, int kgS0, int KG, int rem, const GUnits& U,
-                                       const GHalf<A>& x, f32x4 (&f0)[DT], f32x4 (&part)[DT][2], f32x4 (&own)[DT]) {
+                                       const GHalf<A, NSAMP>& x, f32x4 (&f0)[DT], f32x4 (&part)[DT][NSAMP], f32x4 (&own)[DT]) {
     f32x4 f1[DT];
 #pragma unroll
     for (int dm = 0; dm < DT; ++dm) {
         own[dm] = f32x4{0.f, 0.f, 0.f, 0.f};
-        part[dm][0] = part[dm][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < NSAMP; ++q) part[dm][q] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 #pragma unroll
     for (int m = 0; m < A + 2; ++m) {
@@ -213,7 +226,7 @@ __device__ __forceinline__ void g_drow(const DRs& R, const unsigned (&vd)[DT], u
 #pragma unroll
                     for (int dm = 0; dm < DT; ++dm)
 #pragma unroll
-                        for (int q = 0; q < 2; ++q) part[dm][q] = mfma4(cur[dm][j], x.S[m][q][j], part[dm][q]);
+                        for (int q = 0; q < NSAMP; ++q) part[dm][q] = mfma4(cur[dm][j], x.S[m][q][j], part[dm][q]);
             } else {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
@@ -221,7 +234,7 @@ __device__ __forceinline__ void g_drow(const DRs& R, const unsigned (&vd)[DT], u
 #pragma unroll
                         for (int dm = 0; dm < DT; ++dm)
 #pragma unroll
-                            for (int q = 0; q < 2; ++q) part[dm][q] = mfma4(cur[dm][j], x.S[m][q][j], part[dm][q]);
+                            for (int q = 0; q < NSAMP; ++q) part[dm][q] = mfma4(cur[dm][j], x.S[m][q][j], part[dm][q]);
                     }
             }
         } else {
@@ -239,13 +252,15 @@ __device__ __forceinline__ void g_drow(const DRs& R, const unsigned (&vd)[DT], u
 
 }  // namespace
 
-constexpr int coopd_grad_lds_bytes(int HT, int DT, int cvn) {
-    return (2 * ((HT + 1) / 2 * 2) * 4 * 64 + DT * 4 * 64) * 16 + (cvn + 3) / 4 * 16;
+// two exchange buffers + the [eps | kbar] image (+ the partial tiles when they do not alias the first exchange buffer) + C vectors
+constexpr int coopd_grad_lds_bytes(int HT, int DT, int cvn, int NSAMP = 2, bool palias = true) {
+    return (2 * ((HT + 1) / 2 * 2) * 2 * NSAMP * 64 + DT * 2 * NSAMP * 64 + (palias ? 0 : (NSAMP + 1) * 4 * DT * 64)) * 16 + (cvn + 3) / 4 * 16;
 }
 
-template <int A, int KZ, int ACT, int NS>
+template <int A, int KZ, int ACT, int NS, int NSAMP>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 coopd_grad_step_kernel(DGArgs da) {
+    constexpr int NC = 2 * NSAMP, SUP = 16 * NSAMP;
     static_assert(ACT == CNF_ACT_TANH_PRESCALED || ACT == CNF_ACT_SOFTPLUS, "act'' is rebuilt from h and act': tanh and softplus");
     static_assert(KZ % 4 == 0, "state registers in whole M-tiles");
     const CGArgs& a = da.c;
@@ -254,27 +269,27 @@ coopd_grad_step_kernel(DGArgs da) {
     constexpr bool KEEP_H = ACT != CNF_ACT_SOFTPLUS;   // tanh's act'' needs h as well
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int HT = 4 * A + G.b, HTE = (HT + 1) & ~1;
-    f32x4* X0 = reinterpret_cast<f32x4*>(smem);        // [HTE][4][64]: exchange buffer; the partial tiles of Zbar alias it
-    f32x4* X1 = X0 + HTE * 256;                        // [HTE][4][64]: exchange buffer; the [z | gbar] image aliases it
-    f32x4* ekbuf = X1 + HTE * 256;                     // [DT][4][64]: [eps | kbar]
-    float* cbuf = reinterpret_cast<float*>(ekbuf + DT * 256);
+    f32x4* X0 = reinterpret_cast<f32x4*>(smem);        // [HTE][NC][64]: exchange buffer; the partial tiles of Zbar alias it (G.xalias)
+    f32x4* X1 = X0 + HTE * NC * 64;                    // [HTE][NC][64]: exchange buffer; the [z | gbar] image aliases it
+    f32x4* ekbuf = X1 + HTE * NC * 64;                 // [DT][NC][64]: [eps | kbar]
     f32x4* zebuf = X1;
-    f32x4* pbuf = X0;                                  // [3 slots][4 waves][DT][64]
+    f32x4* pbuf = G.xalias ? X0 : ekbuf + DT * NC * 64;   // [NSAMP + 1 slots][4 waves][DT][64]
+    float* cbuf = reinterpret_cast<float*>(ekbuf + DT * NC * 64 + (G.xalias ? 0 : (NSAMP + 1) * 4 * DT * 64));
     for (int i = threadIdx.x; i < G.cvn; i += 256) cbuf[i] = a.packed[G.v_b1 + i];
     const float* __restrict__ P = cbuf - G.v_b1;
     const int lane = threadIdx.x & 63, g = lane >> 4, n = lane & 15;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const bool owner = wave < 2;
+    const bool owner = wave < NSAMP;
     const int D = a.D, H = a.H;
     const long long B = a.B;
-    const long long nst = (B + 31) / 32;
+    const long long nst = (B + SUP - 1) / SUP;
     const DRs R0{__builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.packed), 0, 0x7fffffff, 0x00020000), (unsigned)lane * 16u};
     const float inv_fs = ACT == CNF_ACT_TANH_PRESCALED ? 1.f / kTanhPrescale : 1.f;   // the forward images of tanh nets carry the pre-scale
     const int ns = a.T.ns < NS ? a.T.ns : NS;
     const float dt = a.dt, tn = a.tn;
     const long long nsB = (long long)ns * B;
     const int ckzr = G.ckzr;
-    const GUnits U = gunits(A, G.b, wave);
+    const GUnits U = gunits<NSAMP>(A, G.b, wave);
     const int mtS0 = wave * A;
     const GOff<A> TZ = g_offsets<A>(R0, G.KPZ, mtS0, U);
     const GOff<A> TH = g_offsets<A>(R0, G.HTP, mtS0, U);
@@ -296,47 +311,52 @@ coopd_grad_step_kernel(DGArgs da) {
         vR[0] = *reinterpret_cast<const f32x4*>(vec + (U.t0 * 4 + g) * 4);
         vR[1] = *reinterpret_cast<const f32x4*>(vec + (U.t1 * 4 + g) * 4);
     };
-    auto publish = [&](f32x4* __restrict__ xb, const GAcc<A>& v) {
+    auto publish = [&](f32x4* __restrict__ xb, const GAcc<A, NSAMP>& v) {
 #pragma unroll
         for (int m = 0; m < A; ++m)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) xb[((mtS0 + m) * 4 + c) * 64 + lane] = v.S[m][c];
-        if (U.v0) { xb[(U.t0 * 4 + U.q) * 64 + lane] = v.R[0][0]; xb[(U.t0 * 4 + 2 + U.q) * 64 + lane] = v.R[0][1]; }
-        if (U.v1) { xb[(U.t1 * 4 + U.q) * 64 + lane] = v.R[1][0]; xb[(U.t1 * 4 + 2 + U.q) * 64 + lane] = v.R[1][1]; }
+            for (int c = 0; c < NC; ++c) xb[((mtS0 + m) * NC + c) * 64 + lane] = v.S[m][c];
+        if (U.v0) { xb[(U.t0 * NC + U.q) * 64 + lane] = v.R[0][0]; xb[(U.t0 * NC + NSAMP + U.q) * 64 + lane] = v.R[0][1]; }
+        if (U.v1) { xb[(U.t1 * NC + U.q) * 64 + lane] = v.R[1][0]; xb[(U.t1 * NC + NSAMP + U.q) * 64 + lane] = v.R[1][1]; }
     };
     // chain 0 <- the C vector of this wave's units, chain 1 <- 0
-    auto acc_init = [&](GAcc<A>& u, const f32x4 (&vS)[A], const f32x4 (&vR)[2]) {
-        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int m = 0; m < A; ++m) { u.S[m][0] = vS[m]; u.S[m][1] = vS[m]; u.S[m][2] = z; u.S[m][3] = z; }
-        u.R[0][0] = vR[0]; u.R[0][1] = z; u.R[1][0] = vR[1]; u.R[1][1] = z;
-    };
-    auto acc_zero = [&](GAcc<A>& u) {
+    auto acc_init = [&](GAcc<A, NSAMP>& u, const f32x4 (&vS)[A], const f32x4 (&vR)[2]) {
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int m = 0; m < A; ++m)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) u.S[m][c] = z;
+            for (int q = 0; q < NSAMP; ++q) { u.S[m][q] = vS[m]; u.S[m][NSAMP + q] = z; }
+        u.R[0][0] = vR[0]; u.R[0][1] = z; u.R[1][0] = vR[1]; u.R[1][1] = z;
+    };
+    auto acc_zero = [&](GAcc<A, NSAMP>& u) {
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int m = 0; m < A; ++m)
+#pragma unroll
+            for (int c = 0; c < NC; ++c) u.S[m][c] = z;
         u.R[0][0] = z; u.R[0][1] = z; u.R[1][0] = z; u.R[1][1] = z;
     };
-    // column `wave` of every tile pair of an exchange buffer -> rows of a column-major operand array, as full 128-byte lines: eight
-    // lanes cover 32 consecutive rows (two row tiles) of one sample (bank assignment: see gstore of cnf_coop_grad.hip)
+    // this wave's share of an exchange buffer -> rows of a column-major operand array, as full 128-byte lines: eight lanes cover 32
+    // consecutive rows (two row tiles) of one sample (bank assignment: see gstore of cnf_coop_grad.hip).  Four columns: column
+    // `wave` of every tile pair; two columns: column wave & 1 of every other tile pair
     const int mm = (lane >> 2) & 1, gg = lane & 3, s8 = (lane >> 3) ^ (4 * mm);
+    const int gcol = NSAMP == 2 ? wave : (wave & 1), gpar = wave >> 1;
     auto gstore = [&](const f32x4* __restrict__ xb4, const __amdgpu_buffer_rsrc_t& rs, const unsigned (&vo)[2], unsigned so_c0, unsigned so_c1) {
 #ifdef DG_EXP_NOSTORE   // timing-only build (wrong gradients): what the operand stores cost
         return;
 #endif
         typedef float __attribute__((may_alias)) float_a;
         const float_a* xb = reinterpret_cast<const float_a*>(xb4);
-        const unsigned so0 = (wave >> 1) ? so_c1 : so_c0;
+        const unsigned so0 = gcol >= NSAMP ? so_c1 : so_c0;
         // all pairs an instance can have (HT <= 4 A + 3), requested in one batch; pairs beyond the real tiles read the last tile
         // and are dropped by the store's out-of-range offset
 #pragma unroll
         for (int p = 0; p < 2 * A + 2; ++p) {
+            if (NSAMP == 1 && (p & 1) != gpar) continue;
             const int t = 2 * p + mm < HTE ? 2 * p + mm : HTE - 1;
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf) {
-                const int base = ((t * 4 + wave) * 64 + s8 + 8 * hf) * 4 + gg;
+                const int base = ((t * NC + gcol) * 64 + s8 + 8 * hf) * 4 + gg;
                 f32x4 v;
                 v[0] = xb[base]; v[1] = xb[base + 64]; v[2] = xb[base + 128]; v[3] = xb[base + 192];
                 const unsigned so = so0 + (unsigned)(32 * p) * 4u;
@@ -347,7 +367,7 @@ coopd_grad_step_kernel(DGArgs da) {
     };
     auto publish_dense = [&](f32x4* img, int ct, const float (&v)[KZ]) {
 #pragma unroll
-        for (int kg = 0; kg < DT; ++kg) img[(kg * 4 + ct) * 64 + lane] = f32x4{v[4 * kg], v[4 * kg + 1], v[4 * kg + 2], v[4 * kg + 3]};
+        for (int kg = 0; kg < DT; ++kg) img[(kg * NC + ct) * 64 + lane] = f32x4{v[4 * kg], v[4 * kg + 1], v[4 * kg + 2], v[4 * kg + 3]};
     };
     auto dense_store = [&](float* arr, int ld, long long col, const float (&v)[KZ]) {
 #pragma unroll
@@ -355,11 +375,11 @@ coopd_grad_step_kernel(DGArgs da) {
     };
 
     for (long long st = blockIdx.x; st < nst; st += gridDim.x) {
-        const long long smp0 = st * 32;
+        const long long smp0 = st * SUP;
         const long long smp = smp0 + (owner ? wave : 0) * 16 + n;
         const bool valid = owner && smp < B;
         const long long sc = smp < B ? smp : B - 1;
-        const long long tile = st * 2 + (owner ? wave : 0), ntp = a.ntiles_pad;
+        const long long tile = st * NSAMP + (owner ? wave : 0), ntp = a.ntiles_pad;
         float eps[KZ], zn[KZ], lam[KZ];
 #pragma unroll
         for (int s = 0; s < KZ; ++s) { eps[s] = 0.f; zn[s] = 0.f; lam[s] = 0.f; }
@@ -391,7 +411,7 @@ coopd_grad_step_kernel(DGArgs da) {
         unsigned vox[2], voy[2];
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
-            const long long sq = smp0 + (wave & 1) * 16 + s8 + 8 * hf;
+            const long long sq = smp0 + (gcol % NSAMP) * 16 + s8 + 8 * hf;
             const unsigned ro = 16u * (unsigned)gg + 64u * (unsigned)mm;
             vox[hf] = sq < B ? (unsigned)sq * ldx + ro : 0xffffffffu;
             voy[hf] = sq < B ? (unsigned)sq * ldy + ro : 0xffffffffu;
@@ -420,7 +440,7 @@ coopd_grad_step_kernel(DGArgs da) {
         };
         // (A = 3: the rows would stay live across the loop's back edge beside 24 more accumulator registers, and this compiler's
         // AGPR-copy rewrite pass crashes instead of spilling: those instances request them in the dense phase itself)
-        constexpr bool PREF = A == 2;
+        constexpr bool PREF = A == 2 && NSAMP == 2;
         if (PREF && owner) load_rows(ns - 1);
 
 #pragma clang loop unroll(disable)
@@ -487,11 +507,11 @@ coopd_grad_step_kernel(DGArgs da) {
 #pragma unroll
                     for (int s = 0; s < KZ; ++s) gbar[s] = fmaf(inv, gi[s >> 2][s & 3], gbar[s]);
                 }
-                publish_dense(zebuf, wave, zs); publish_dense(zebuf, 2 + wave, gbar);
-                publish_dense(ekbuf, wave, eps); publish_dense(ekbuf, 2 + wave, kbar);
+                publish_dense(zebuf, wave, zs); publish_dense(zebuf, NSAMP + wave, gbar);
+                publish_dense(ekbuf, wave, eps); publish_dense(ekbuf, NSAMP + wave, kbar);
             }
-            GAcc<A> acc;   // (the elementwise phases work in place: results replace the accumulators they come from)
-            GHalf<A> d1P, db1P, h1P;      // act'_1, dbar_1 (and h_1 for tanh) of this wave's units, parked until the way down
+            GAcc<A, NSAMP> acc;   // (the elementwise phases work in place: results replace the accumulators they come from)
+            GHalf<A, NSAMP> d1P, db1P, h1P;      // act'_1, dbar_1 (and h_1 for tanh) of this wave's units, parked until the way down
             // ================= up 1: [a_1 | dbar_1] = W_1[:,0:D] [z | gbar] (+ bias and time column on the first chain) =================
             {
                 f32x4 bS[A], bR[2], wS[A], wR[2];
@@ -508,22 +528,22 @@ coopd_grad_step_kernel(DGArgs da) {
             g_load_a<A>(R, TZ, F1Z, 0, aS, aR);
             DG_T(1);
             DG_SYNC();                                                                     // B0
-            if (!owner) {
+            if (NSAMP == 2 ? wave >= 2 : wave == 1) {
                 // The dense operands of Wbar_1 and Wbar_N ([gbar; 0 | z; t; 1] and [eps | kbar]: rows of 4-byte stores, an exec mask per
                 // row) leave through waves 2 and 3, which have waited for the owners: lane l of wave 2 + q reads back from the
-                // images what lane l of owner q has just published.
-                const int q = wave - 2;
+                // images what lane l of owner q has just published.  (One sample tile: through wave 1, the last to get a left-over unit.)
+                const int q = NSAMP == 2 ? wave - 2 : 0;
                 const long long sm2 = smp0 + q * 16 + n;
                 if (sm2 < B) {
                     float v0[KZ], v1[KZ];
                     auto fetch = [&](const f32x4* img, int ct, float (&v)[KZ]) {
 #pragma unroll
                         for (int kg = 0; kg < DT; ++kg) {
-                            const f32x4 t4 = img[(kg * 4 + ct) * 64 + lane];
+                            const f32x4 t4 = img[(kg * NC + ct) * 64 + lane];
                             v[4 * kg] = t4[0]; v[4 * kg + 1] = t4[1]; v[4 * kg + 2] = t4[2]; v[4 * kg + 3] = t4[3];
                         }
                     };
-                    fetch(zebuf, 2 + q, v0); fetch(zebuf, q, v1);
+                    fetch(zebuf, NSAMP + q, v0); fetch(zebuf, q, v1);
                     dense_store(a.y1, a.ld_y1, c1 + sm2, v0);
                     dense_store(a.y1, a.ld_y1, c2 + sm2, v1);
                     if (g == 0) {
@@ -531,13 +551,13 @@ coopd_grad_step_kernel(DGArgs da) {
                         if (!a.autonomous) col[D] = tt;
                         col[a.ld_y1 - 1] = 1.f;
                     }
-                    fetch(ekbuf, q, v0); fetch(ekbuf, 2 + q, v1);
+                    fetch(ekbuf, q, v0); fetch(ekbuf, NSAMP + q, v1);
                     dense_store(a.xN, D, c1 + sm2, v0);
                     dense_store(a.xN, D, c2 + sm2, v1);
                 }
             }
             DG_T(2);
-            g_gemm<A>(R, TZ, F1Z, G.KGZ, G.remZ, U, zebuf, lane, aS, aR, acc);
+            g_gemm<A, NSAMP>(R, TZ, F1Z, G.KGZ, G.remZ, U, zebuf, lane, aS, aR, acc);
             DG_T(3);
             g_load_a<A>(R, TH, FH, 0, aS, aR);
             auto up_unit = [&](const f32x4& a0, const f32x4& a1, f32x4& o0, f32x4& o1, f32x4& hk, f32x4& dk, f32x4& dbk) {
@@ -549,9 +569,9 @@ coopd_grad_step_kernel(DGArgs da) {
 #pragma unroll
             for (int m = 0; m < A; ++m)
 #pragma unroll
-                for (int q = 0; q < 2; ++q) {
+                for (int q = 0; q < NSAMP; ++q) {
                     f32x4 hk, dk, dbk;
-                    up_unit(acc.S[m][q], acc.S[m][2 + q], acc.S[m][q], acc.S[m][2 + q], hk, dk, dbk);
+                    up_unit(acc.S[m][q], acc.S[m][NSAMP + q], acc.S[m][q], acc.S[m][NSAMP + q], hk, dk, dbk);
                     d1P.S[m][q] = park4(dk); db1P.S[m][q] = park4(dbk);
                     if constexpr (KEEP_H) h1P.S[m][q] = park4(hk);
                 }
@@ -572,17 +592,17 @@ coopd_grad_step_kernel(DGArgs da) {
             DG_SYNC();                                                                     // B1
             DG_T(5);
             // ================= up 2: [a_2 | dbar_2] = W_2 [h_1 | vbar_1] =================
-            g_gemm<A>(R, TH, FH, G.KGH, G.remH, U, X0, lane, aS, aR, acc);
+            g_gemm<A, NSAMP>(R, TH, FH, G.KGH, G.remH, U, X0, lane, aS, aR, acc);
             DG_T(6);
             g_load_a<A>(R, TZ, BN, 0, aS, aR);
             // (the operand stores go BEHIND the product and the next product's first fragment requests: the memory counter
             // retires in order, and a fragment wait behind twelve streaming stores waits for their acknowledgements)
             gstore(X0, ry[0], voy, sy2, sy1);                                              // Y_1 = [vbar_1; 0 | h_1; 1]
-            GHalf<A> d2, db2, h2;
+            GHalf<A, NSAMP> d2, db2, h2;
 #pragma unroll
             for (int m = 0; m < A; ++m)
 #pragma unroll
-                for (int q = 0; q < 2; ++q) up_unit(acc.S[m][q], acc.S[m][2 + q], acc.S[m][q], acc.S[m][2 + q], h2.S[m][q], d2.S[m][q], db2.S[m][q]);
+                for (int q = 0; q < NSAMP; ++q) up_unit(acc.S[m][q], acc.S[m][NSAMP + q], acc.S[m][q], acc.S[m][NSAMP + q], h2.S[m][q], d2.S[m][q], db2.S[m][q]);
 #pragma unroll
             for (int s = 0; s < 2; ++s) up_unit(acc.R[s][0], acc.R[s][1], acc.R[s][0], acc.R[s][1], h2.R[s], d2.R[s], db2.R[s]);
             publish(X1, acc);
@@ -591,7 +611,7 @@ coopd_grad_step_kernel(DGArgs da) {
             DG_SYNC();                                                                     // B2
             DG_T(8);
             // ================= the top: [c | hbar_2] = W_N^T [eps | kbar] =================
-            g_gemm<A>(R, TZ, BN, G.KGZ, G.remZ, U, ekbuf, lane, aS, aR, acc);
+            g_gemm<A, NSAMP>(R, TZ, BN, G.KGZ, G.remZ, U, ekbuf, lane, aS, aR, acc);
             DG_T(9);
             g_load_a<A>(R, TH, BH, 0, aS, aR);
             gstore(X1, ry[1], voy, sy2, sy1);                                              // Y_2 = [cbar; 0 | h_2; 1]
@@ -604,7 +624,7 @@ coopd_grad_step_kernel(DGArgs da) {
 #pragma unroll
             for (int m = 0; m < A; ++m)
 #pragma unroll
-                for (int q = 0; q < 2; ++q) down_unit(acc.S[m][q], acc.S[m][2 + q], h2.S[m][q], d2.S[m][q], db2.S[m][q], acc.S[m][q], acc.S[m][2 + q]);
+                for (int q = 0; q < NSAMP; ++q) down_unit(acc.S[m][q], acc.S[m][NSAMP + q], h2.S[m][q], d2.S[m][q], db2.S[m][q], acc.S[m][q], acc.S[m][NSAMP + q]);
 #pragma unroll
             for (int s = 0; s < 2; ++s) down_unit(acc.R[s][0], acc.R[s][1], h2.R[s], d2.R[s], db2.R[s], acc.R[s][0], acc.R[s][1]);
             publish(X0, acc);
@@ -613,20 +633,20 @@ coopd_grad_step_kernel(DGArgs da) {
             DG_SYNC();                                                                     // B3
             DG_T(11);
             // ================= down 2: [u_1 | hbar_1] = W_2^T [delta_2 | sbar_2] =================
-            g_gemm<A>(R, TH, BH, G.KGH, G.remH, U, X0, lane, aS, aR, acc);
+            g_gemm<A, NSAMP>(R, TH, BH, G.KGH, G.remH, U, X0, lane, aS, aR, acc);
             DG_T(12);
             f32x4 fd[DT];
 #pragma unroll
             for (int dm = 0; dm < DT; ++dm) fd[dm] = dloadv(R, vd[dm], B1 + (unsigned)mtS0 * 1024u);
             gstore(X0, rx[1], vox, sx1, sx2);                                              // X_2 = [delta_2 | sbar_2]
-            GHalf<A> sb;
+            GHalf<A, NSAMP> sb;
 #pragma unroll
             for (int m = 0; m < A; ++m)
 #pragma unroll
-                for (int q = 0; q < 2; ++q) {
+                for (int q = 0; q < NSAMP; ++q) {
                     const f32x4 hk = KEEP_H ? unpark4(h1P.S[m][q]) : f32x4{0.f, 0.f, 0.f, 0.f};
-                    down_unit(acc.S[m][q], acc.S[m][2 + q], hk, unpark4(d1P.S[m][q]), unpark4(db1P.S[m][q]), acc.S[m][q], acc.S[m][2 + q]);
-                    sb.S[m][q] = acc.S[m][2 + q];
+                    down_unit(acc.S[m][q], acc.S[m][NSAMP + q], hk, unpark4(d1P.S[m][q]), unpark4(db1P.S[m][q]), acc.S[m][q], acc.S[m][NSAMP + q]);
+                    sb.S[m][q] = acc.S[m][NSAMP + q];
                 }
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
@@ -636,8 +656,8 @@ coopd_grad_step_kernel(DGArgs da) {
             }
             publish(X1, acc);
             // ================= Zbar_i = W_1[:,0:D]^T sbar_1: partial tiles over this wave's own k-groups, from registers =================
-            f32x4 part[DT][2], own[DT];
-            g_drow<A, DT>(R, vd, B1, mtS0, G.KGH, G.remH, U, sb, fd, part, own);
+            f32x4 part[DT][NSAMP], own[DT];
+            g_drow<A, NSAMP, DT>(R, vd, B1, mtS0, G.KGH, G.remH, U, sb, fd, part, own);
             DG_T(13);
             DG_SYNC();                                                                     // B4 (every reader of X0 is through)
             DG_T(14);
@@ -645,23 +665,30 @@ coopd_grad_step_kernel(DGArgs da) {
             if (PREF && owner && i > 0) load_rows(i - 1);   // the next stage's checkpoint rows: they arrive under the stores, the barrier and the reduction
 #pragma unroll
             for (int dm = 0; dm < DT; ++dm) {
-                pbuf[((0 * 4 + wave) * DT + dm) * 64 + lane] = part[dm][0];
-                pbuf[((1 * 4 + wave) * DT + dm) * 64 + lane] = part[dm][1];
-                if (U.v0 || U.v1) pbuf[((2 * 4 + wave) * DT + dm) * 64 + lane] = own[dm];
+#pragma unroll
+                for (int q = 0; q < NSAMP; ++q) pbuf[((q * 4 + wave) * DT + dm) * 64 + lane] = part[dm][q];
+                if (U.v0 || U.v1) pbuf[((NSAMP * 4 + wave) * DT + dm) * 64 + lane] = own[dm];
             }
             DG_T(15);
             DG_SYNC();                                                                     // B5
             DG_T(16);
             if (owner) {
-                // waves 3 - q and 1 - q hold the left-over units of sample tile q (units q, q + 4 and q + 2, q + 6)
+                // waves 3 - q and 1 - q hold the left-over units of sample tile q (units q, q + 4 and q + 2, q + 6); with one sample tile
+                // the b left-over tiles sit on waves 3, 2, 1
                 const bool lo0 = wave < 2 * G.b, lo2 = wave + 2 < 2 * G.b;
 #pragma unroll
                 for (int dm = 0; dm < DT; ++dm) {
                     f32x4 v = pbuf[((wave * 4 + 0) * DT + dm) * 64 + lane];
 #pragma unroll
                     for (int w = 1; w < 4; ++w) v += pbuf[((wave * 4 + w) * DT + dm) * 64 + lane];
-                    if (lo0) v += pbuf[((2 * 4 + 3 - wave) * DT + dm) * 64 + lane];
-                    if (lo2) v += pbuf[((2 * 4 + 1 - wave) * DT + dm) * 64 + lane];
+                    if constexpr (NSAMP == 2) {
+                        if (lo0) v += pbuf[((2 * 4 + 3 - wave) * DT + dm) * 64 + lane];
+                        if (lo2) v += pbuf[((2 * 4 + 1 - wave) * DT + dm) * 64 + lane];
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < 3; ++u)
+                            if (u < G.b) v += pbuf[((1 * 4 + 3 - u) * DT + dm) * 64 + lane];
+                    }
 #pragma unroll
                     for (int j = 0; j < 4; ++j) zbt[i * KZ + 4 * dm + j] = v[j];
                 }
@@ -699,9 +726,9 @@ coopd_grad_step_kernel(DGArgs da) {
 // ---------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------
-template <int A, int KZ, int ACT, int NS>
+template <int A, int KZ, int ACT, int NS, int NSAMP>
 static hipError_t launch_dgrad(const DGArgs& a, int lds, int nblocks, hipStream_t st) {
-    auto kern = coopd_grad_step_kernel<A, KZ, ACT, NS>;
+    auto kern = coopd_grad_step_kernel<A, KZ, ACT, NS, NSAMP>;
     static DeviceOnce once;
     int dev = 0;
     hipError_t e0 = hipGetDevice(&dev);
@@ -716,15 +743,19 @@ static hipError_t launch_dgrad(const DGArgs& a, int lds, int nblocks, hipStream_
 }
 
 struct DGradInst {
-    int A, KZ, ACT;
+    int A, KZ, ACT, NSAMP;
     hipError_t (*fn[2])(const DGArgs&, int, int, hipStream_t);   // [0] RK4 (4 stages), [1] Tsit5 (6 stages)
 };
-#define DG_INST(A, KZ, ACT) DGradInst { A, KZ, ACT, { &launch_dgrad<A, KZ, ACT, 4>, &launch_dgrad<A, KZ, ACT, 6> } }
+#define DG_INST(A, KZ, ACT) DGradInst { A, KZ, ACT, 2, { &launch_dgrad<A, KZ, ACT, 4, 2>, &launch_dgrad<A, KZ, ACT, 6, 2> } }
+// 16 .. 24 hidden tiles: one sample tile per super-tile (two column tiles per product)
+#define DG1_INST(A, KZ, ACT) DGradInst { A, KZ, ACT, 1, { &launch_dgrad<A, KZ, ACT, 4, 1>, &launch_dgrad<A, KZ, ACT, 6, 1> } }
 // the (A, KZ) pairs of cnf_coop_d.hip's forward instances
 static const DGradInst kDGrad[] = {
     DG_INST(2, 8, CNF_ACT_SOFTPLUS), DG_INST(3, 8, CNF_ACT_SOFTPLUS),
     DG_INST(2, 12, CNF_ACT_SOFTPLUS), DG_INST(3, 12, CNF_ACT_SOFTPLUS), DG_INST(3, 16, CNF_ACT_SOFTPLUS),
     DG_INST(2, 8, CNF_ACT_TANH_PRESCALED), DG_INST(2, 12, CNF_ACT_TANH_PRESCALED),   // tanh keeps h_1 as well: 8 .. 11 hidden tiles
+    // the (A, KZ) pairs of cnf_coop_d2.hip's forward instances (the default architecture at nvariables = 30 .. 47)
+    DG1_INST(4, 16, CNF_ACT_SOFTPLUS), DG1_INST(4, 20, CNF_ACT_SOFTPLUS), DG1_INST(5, 20, CNF_ACT_SOFTPLUS), DG1_INST(5, 24, CNF_ACT_SOFTPLUS), DG1_INST(6, 24, CNF_ACT_SOFTPLUS),
 };
 static const DGradInst* dg_find(int HT_real, int KZ, int ACT) {
     const int A = HT_real / 4;
@@ -736,10 +767,14 @@ static const DGradInst* dg_find(int HT_real, int KZ, int ACT) {
     return best;
 }
 
-static bool dg_fits(int HT_real, int DT, int A, int cvn) {
-    const int HTE = (HT_real + 1) / 2 * 2, b = HT_real - 4 * A;
-    // the [z | gbar] image and the partial tiles alias the exchange buffers
-    return DT <= HTE && (b > 0 ? 3 : 2) * DT <= HTE && coopd_grad_lds_bytes(HT_real, DT, cvn) <= 160 * 1024;
+// the [z | gbar] image aliases the second exchange buffer; the partial tiles alias the first where they fit it (*palias), else
+// they get their own region if the LDS has room
+static bool dg_fits(int HT_real, int DT, int A, int cvn, int NSAMP, bool* palias) {
+    const int HTE = (HT_real + 1) / 2 * 2, b = HT_real - 4 * A, NC = 2 * NSAMP;
+    if (DT > HTE) return false;
+    const bool al = (NSAMP + (b > 0 ? 1 : 0)) * 4 * DT <= HTE * NC;
+    if (palias) *palias = al;
+    return coopd_grad_lds_bytes(HT_real, DT, cvn, NSAMP, al) <= 160 * 1024;
 }
 
 // H hidden units, D state rows, L hidden layers; (HT, ZR, CR) = the plan's layout
@@ -754,7 +789,7 @@ bool coopd_grad_supported(int H, int D, int L, int ACT, int HT_lay, int ZR_lay, 
     // multiplies no padding and runs two workgroups per CU: it keeps those shapes
     if (HT_real % 4 == 0 && HT_real == HT_lay && c->KZ >= ZR_lay) return false;
     const int cvn = (1 + L) * 16 * HT_lay + 16 * ((ZR_lay + 3) / 4);
-    return dg_fits(HT_real, c->KZ / 4, c->A, cvn);
+    return dg_fits(HT_real, c->KZ / 4, c->A, cvn, c->NSAMP, nullptr);
 }
 
 hipError_t coopd_grad_step_launch(int H, int D, int L, int ACT, int HT_lay, int ZR_lay, const CGArgs& a, int num_cus, hipStream_t st) {
@@ -765,9 +800,11 @@ hipError_t coopd_grad_step_launch(int H, int D, int L, int ACT, int HT_lay, int 
     da.c = a;
     dimg_fill(da.g, H, D, L, HT_lay, ZR_lay, 0, c->A, 0);
     const int DT = c->KZ / 4;
-    if (!dg_fits(HT_real, DT, c->A, da.g.cvn)) return hipErrorNotSupported;
-    const int lds = coopd_grad_lds_bytes(HT_real, DT, da.g.cvn);
-    const long long nst = (a.B + 31) / 32;
+    bool palias = true;
+    if (!dg_fits(HT_real, DT, c->A, da.g.cvn, c->NSAMP, &palias)) return hipErrorNotSupported;
+    da.g.xalias = palias ? 1 : 0;
+    const int lds = coopd_grad_lds_bytes(HT_real, DT, da.g.cvn, c->NSAMP, palias);
+    const long long nst = (a.B + 16 * c->NSAMP - 1) / (16 * c->NSAMP);
     const int nblocks = (int)(nst < num_cus ? nst : num_cus);
     return c->fn[a.T.ns <= 4 ? 0 : 1](da, lds, nblocks, st);
 }
