@@ -780,14 +780,16 @@ static bool dg_fits(int HT_real, int DT, int A, int cvn, int NSAMP, bool* palias
 // H hidden units, D state rows, L hidden layers; (HT, ZR, CR) = the plan's layout
 bool coopd_grad_supported(int H, int D, int L, int ACT, int HT_lay, int ZR_lay, int CR_lay) {
     if (L != 2 || CR_lay != 0) return false;
-    if (const char* e = getenv("CNF_COOPD_GRAD")) { if (*e == '0') return false; }
+    bool force = false;
+    if (const char* e = getenv("CNF_COOPD_GRAD")) { if (*e == '0') return false; force = *e == '2'; }
     const int HT_real = (H + 15) / 16, KZ = (D + 3) / 4;
     if (HT_real < 8 || HT_real > HT_lay || KZ > ZR_lay) return false;
     const DGradInst* c = dg_find(HT_real, KZ, ACT);
     if (!c || (c->KZ + 3) / 4 > (ZR_lay + 3) / 4) return false;
     // where the plan's layout IS the configuration (hidden tiles a multiple of four, state k-steps as laid out) cnf_coop_grad.hip
     // multiplies no padding and runs two workgroups per CU: it keeps those shapes
-    if (HT_real % 4 == 0 && HT_real == HT_lay && c->KZ >= ZR_lay) return false;
+    // (8 hidden tiles: the 8-tile instances of cnf_coop_grad.hip are not used any more - see coop_grad_eligible)
+    if (!force && HT_lay != 8 && HT_real % 4 == 0 && HT_real == HT_lay && c->KZ >= ZR_lay) return false;
     const int cvn = (1 + L) * 16 * HT_lay + 16 * ((ZR_lay + 3) / 4);
     return dg_fits(HT_real, c->KZ / 4, c->A, cvn, c->NSAMP, nullptr);
 }

@@ -194,7 +194,11 @@ coop_grad_step_kernel(CGArgs a) {
             // row tiles are a multiple of 32 words apart - the lanes of the second row tile therefore take the samples 4 further
             // on (s8 ^ 4: banks + 16), which made 2-way conflicts of every one of these reads (22 % of the kernel's LDS cycles,
             // profiles/r3/r3T_cfg4_grad_pmc_summary.txt); the store offsets vox / voy follow the same assignment
+#ifdef CG_NO_SWIZZLE
+            const int mm = (lane >> 2) & 1, gg = lane & 3, s8 = (lane >> 3);
+#else
             const int mm = (lane >> 2) & 1, gg = lane & 3, s8 = (lane >> 3) ^ (4 * mm);
+#endif
 #pragma unroll
             for (int m = 0; m < MTW; m += 2)
 #pragma unroll
@@ -204,6 +208,9 @@ coop_grad_step_kernel(CGArgs a) {
                         const int base = (((mt0 + m + mm) * CT + ch * NT + q) * 64 + s8 + 8 * hf) * 4 + gg;
                         f32x4 v;
                         v[0] = xb[base]; v[1] = xb[base + 64]; v[2] = xb[base + 128]; v[3] = xb[base + 192];
+#ifdef CG_DBG_SENTINEL
+                        if (v[3] == 0.f) v[3] = 123.f;
+#endif
                         const unsigned so = soff0 + (unsigned)(16 * (mt0 + m)) * 4u;
                         const unsigned vo = (16 * (mt0 + m + mm) + 4 * gg < H) ? voff[q][hf] : 0xffffffffu;
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rs, (int)vo, (int)so, CG_NT_AUX);
@@ -315,7 +322,11 @@ coop_grad_step_kernel(CGArgs a) {
         for (int q = 0; q < NT; ++q) {
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf) {
+#ifdef CG_NO_SWIZZLE
+                const long long sq = GS ? smp0 + q * 16 + (lane >> 3) + 8 * hf : smp0 + q * 16 + n;
+#else
                 const long long sq = GS ? smp0 + q * 16 + ((lane >> 3) ^ (4 * ((lane >> 2) & 1))) + 8 * hf : smp0 + q * 16 + n;
+#endif
                 const unsigned ro = GS ? 16u * (unsigned)(lane & 3) + 64u * (unsigned)((lane >> 2) & 1) : 16u * (unsigned)g;
                 vox[q][hf] = sq < B ? (unsigned)sq * ldx + ro : 0xffffffffu;
                 voy[q][hf] = sq < B ? (unsigned)sq * ldy + ro : 0xffffffffu;
@@ -662,7 +673,8 @@ int coop_grad_scratch_slots(int L) { return 2 * L - 3; }   // h_1 .. h_{L-1}, db
 // workgroups of a launch (16-sample super-tiles; two workgroups per CU where two sets of exchange buffers fit): the host sizes
 // the per-workgroup scratch with it
 int coop_grad_nblocks(long long B, int num_cus, int HT, int ZR, int CR, int NT) {
-    const long long nst = (B + 16 * NT - 1) / (16 * NT), cap = (long long)num_cus * (2 * coop_grad_lds_bytes(HT, ZR, NT, CR) <= 160 * 1024 ? 2 : 1);
+    static const int one = [] { const char* v = getenv("CNF_CG_ONE_PER_CU"); return v && *v == '1' ? 1 : 0; }();
+    const long long nst = (B + 16 * NT - 1) / (16 * NT), cap = (long long)num_cus * ((!one && 2 * coop_grad_lds_bytes(HT, ZR, NT, CR) <= 160 * 1024) ? 2 : 1);
     return (int)(nst < cap ? nst : cap);
 }
 
