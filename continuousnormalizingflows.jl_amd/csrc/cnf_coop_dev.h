@@ -4,6 +4,15 @@
 #pragma once
 #include "cnf_mfma_kernel.h"   // act_tile, tiles_mul, tile_fma: shared with the per-wave kernel
 
+// A 128-bit buffer store with its offset in a scalar register reads its data registers AFTER it has issued; a VALU write to one of
+// them needs wait states in between (GCN / CDNA "VMEM store more than 8 bytes followed by a write of the VGPRs holding the write
+// data").  This compiler does not provide them on gfx950: in the 8-tile instances of cnf_coop_grad.hip the instruction behind the
+// last operand store zeroed an accumulator that shared the store's fourth data register, and - rarely, under memory back-pressure
+// (two workgroups per CU) - the store wrote that zero: 3 000 of 12.6 M entries of X_1, the layer-1 cotangent off by 1e-3
+// (found through profiles/nv15_three_way.py, the array comparison of -DCNF_CG_COMPARE_BUILD and the ISA).  The stored vector is an
+// input of the asm, so its registers stay allocated across the wait states.
+#define CNF_STORE_DATA_HAZARD(v) asm volatile("s_nop 1" ::"v"(v))
+
 namespace cnf {
 
 // A fragments of k-group kg for M-tiles mt0 .. mt0 + M - 1 (global image, 16 B per lane, coalesced); A already points at the lane

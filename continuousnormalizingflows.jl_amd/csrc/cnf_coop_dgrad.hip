@@ -362,6 +362,7 @@ coopd_grad_step_kernel(DGArgs da) {
                 const unsigned so = so0 + (unsigned)(32 * p) * 4u;
                 const unsigned vof = (16 * (2 * p + mm) + 4 * gg < H) ? vo[hf] : 0xffffffffu;
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rs, (int)vof, (int)so, DG_NT_AUX);
+                CNF_STORE_DATA_HAZARD(v);
             }
         }
     };
@@ -788,8 +789,7 @@ bool coopd_grad_supported(int H, int D, int L, int ACT, int HT_lay, int ZR_lay, 
     if (!c || (c->KZ + 3) / 4 > (ZR_lay + 3) / 4) return false;
     // where the plan's layout IS the configuration (hidden tiles a multiple of four, state k-steps as laid out) cnf_coop_grad.hip
     // multiplies no padding and runs two workgroups per CU: it keeps those shapes
-    // (8 hidden tiles: the 8-tile instances of cnf_coop_grad.hip are not used any more - see coop_grad_eligible)
-    if (!force && HT_lay != 8 && HT_real % 4 == 0 && HT_real == HT_lay && c->KZ >= ZR_lay) return false;
+    if (!force && HT_real % 4 == 0 && HT_real == HT_lay && c->KZ >= ZR_lay) return false;
     const int cvn = (1 + L) * 16 * HT_lay + 16 * ((ZR_lay + 3) / 4);
     return dg_fits(HT_real, c->KZ / 4, c->A, cvn, c->NSAMP, nullptr);
 }

@@ -208,12 +208,10 @@ coop_grad_step_kernel(CGArgs a) {
                         const int base = (((mt0 + m + mm) * CT + ch * NT + q) * 64 + s8 + 8 * hf) * 4 + gg;
                         f32x4 v;
                         v[0] = xb[base]; v[1] = xb[base + 64]; v[2] = xb[base + 128]; v[3] = xb[base + 192];
-#ifdef CG_DBG_SENTINEL
-                        if (v[3] == 0.f) v[3] = 123.f;
-#endif
                         const unsigned so = soff0 + (unsigned)(16 * (mt0 + m)) * 4u;
                         const unsigned vo = (16 * (mt0 + m + mm) + 4 * gg < H) ? voff[q][hf] : 0xffffffffu;
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rs, (int)vo, (int)so, CG_NT_AUX);
+                        CNF_STORE_DATA_HAZARD(v);
                     }
         } else {
 #pragma unroll
@@ -226,6 +224,7 @@ coop_grad_step_kernel(CGArgs a) {
                     const unsigned so = soff0 + (unsigned)(16 * (mt0 + m)) * 4u;
                     const unsigned vo = (16 * (mt0 + m) + 4 * g < H) ? voff[q][0] : 0xffffffffu;
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rs, (int)vo, (int)so, CG_NT_AUX);
+                    CNF_STORE_DATA_HAZARD(v);
                 }
         }
         asm volatile("" ::: "memory");

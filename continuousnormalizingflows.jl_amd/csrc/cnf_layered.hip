@@ -1006,13 +1006,6 @@ bool coop_grad_eligible(const cnf_config& c, const MfmaPlan* plan, const float l
         if ((c.acts[l] != CNF_ACT_TANH && c.acts[l] != CNF_ACT_SOFTPLUS) || c.acts[l] != c.acts[0] || c.widths[l + 1] != c.widths[1]) return false;
     if (c.acts[L] != CNF_ACT_IDENTITY) return false;
     if (c.widths[1] % 4 != 0) return false;                   // 16-byte row quads of the operand arrays
-    // KNOWN DEFECT (found at the end of round 4, not root-caused): the 8-tile instances of coop_grad_step_kernel (two row tiles per
-    // wave) drop entries of X_1 = [delta_1 | sbar_1] once a launch has more workgroups than compute units (B > 4096): the layer-1
-    // cotangent is then off by 1e-3 relative (profiles/coop_sweep_two_per_cu_check.py, profiles/nv15_three_way.py; every other layer
-    // and every other instance agree with the layer-wise path and the slab kernel to 3e-7).  Until that is understood, plans of 8
-    // hidden tiles take the cooperative gradient only where the dealt sweep (cnf_coop_dgrad.hip: verified against both) serves them.
-    // (CNF_COOP_GRAD_8TILE=1 re-admits them: the parity cases of those instances, all below 4096 columns, still run them)
-    if (HT <= 8 && !getenv("CNF_COOP_GRAD_8TILE")) return coopd_grad_supported(c.widths[1], c.nvars + c.naug, L, ACT, HT, ZR, CR) && lg_wgrad_supported(c.widths[1], c.widths[1] + 1);
     return coop_grad_supported(HT, L, ZR, CR, ACT) && lg_wgrad_supported(c.widths[1], c.widths[1] + 1);
 }
 

@@ -915,9 +915,6 @@ def test_parameter_gradient_cooperative_reverse_sweep(kw, B, alg, nsteps, env, p
     lam = env.pop("lam", None)
     for k, v in env.items():
         monkeypatch.setenv(k, v)
-    # (plans of <= 8 hidden tiles no longer take this kernel by default - its 8-tile instances drop entries of X_1 once a launch has
-    # more workgroups than compute units, see coop_grad_eligible; below 4096 columns they are exact, and these cases keep them covered)
-    monkeypatch.setenv("CNF_COOP_GRAD_8TILE", "1")
     spec = o64.make_spec(**kw)
     if lam is None:
         lam = (0.0, 0.0, 0.03 if spec.reg_aug else 0.0)
@@ -965,12 +962,7 @@ def test_mid_width_gradient_takes_the_cooperative_sweep_at_large_batches(kw, pkg
         assert abs(out[tag][0] - L) < 1e-4 + 2e-6 * abs(L), tag
         assert np.max(np.abs(out[tag][1] - gref)) < 5e-5 * np.abs(gref).max() + 1e-6, tag
         assert np.max(np.abs(out[tag][2] - gxref)) < 5e-5 * np.abs(gxref).max() + 1e-7, tag
-    if -(-spec.widths[1] // 16) == 8 and spec.acts[0] == 2:
-        assert np.max(np.abs(out["aux"][1] - out["slab"][1])) > 0.0      # two implementations (the dealt sweep, the slab kernel), two summation orders
-    else:
-        # 7 hidden tiles (and tanh): only the 8-tile instances of cnf_coop_grad.hip serve these through the auxiliary plan, and they are
-        # not used any more (coop_grad_eligible: a defect at more workgroups than compute units) - both runs take the slab kernel
-        assert np.array_equal(out["aux"][1], out["slab"][1])
+    assert np.max(np.abs(out["aux"][1] - out["slab"][1])) > 0.0      # two implementations, two summation orders
     # below the threshold the same handle serves the slab kernel
     monkeypatch.setenv("CNF_COOP_GRAD_MID", "1")
     icnf = make_icnf(pkg, spec, alg, nsteps, path=0, lambdas=lam)
@@ -991,8 +983,9 @@ def test_fused_gradient_routes_agree_when_a_launch_has_more_workgroups_than_comp
     """The gradient of a batch that gives the sweep kernels more workgroups than the chip has compute units (two workgroups resident
     per CU) against the route the configuration takes with the cooperative sweep switched off (CNF_COOP_GRAD=0: layer-wise, or the
     slab-accumulator kernel).  Added when the 8-tile instances of cnf_coop_grad.hip were found to drop entries of X_1 in exactly this
-    regime (layer-1 cotangent off by 1e-3 relative; every parity case until then ran at most one workgroup per CU): plans of 8 hidden
-    tiles no longer take those instances (coop_grad_eligible), and every route has to agree here to summation order."""
+    regime (layer-1 cotangent off by 1e-3 relative; every parity case until then ran at most one workgroup per CU): a 128-bit
+    buffer store whose fourth data register the next VALU instruction overwrote before the store had read it - a wait-state hazard the
+    compiler does not cover on gfx950 (CNF_STORE_DATA_HAZARD, csrc/cnf_coop_dev.h).  Every route has to agree here to summation order."""
     o64, _ = oracles
     spec = o64.make_spec(**kw)
     p, xs, eps, _ = o64.synth_inputs(spec, B, 4242, bias_scale=0.2)
@@ -2080,12 +2073,11 @@ def test_adaptive_tsit5_follows_the_oracle_restatement(kw, tol, pkg, oracles):
     (dict(nvars=7, hidden=[120, 128, 100], reg_z=True, reg_j=True), (0.02, 0.03, 0.0), 2),   # unequal widths: layer-wise
     (dict(nvars=5, naug=2, hidden=[128, 128, 128], reg_z=True, reg_j=True, reg_aug=True), (0.02, 0.03, 0.04), 3),
 ])
-def test_gradient_of_the_adaptive_solve_on_its_frozen_grid(kw, lam, gpath, pkg, oracles, monkeypatch):
+def test_gradient_of_the_adaptive_solve_on_its_frozen_grid(kw, lam, gpath, pkg, oracles):
     """loss_and_gradient with the adaptive solver: the accepted steps are frozen and the discrete solve on that
     non-uniform grid is reversed (cnf_loss_grad_grid; the fused reverse-sweep kernels read the step times from device
     memory, the layer-wise path takes them from the host) - against fp64 autograd on the same grid."""
     o64, _ = oracles
-    monkeypatch.setenv("CNF_COOP_GRAD_8TILE", "1")   # (the 3 x 128 cases: 8-tile sweep instances, exact at this batch size - see coop_grad_eligible)
     spec = o64.make_spec(**kw)
     if gpath != 3:   # (the cooperative path answers once parameters are bound: checked behind the call below)
         assert _adaptive_icnf(pkg, spec, 1e-4).grad_path(pkg.TrainMode(True)) == gpath
