@@ -260,9 +260,11 @@ def test_dealt_cooperative_kernel_at_full_size(pkg, oracles, monkeypatch):
     sample of columns with the C restatement; column shards concatenate bit-identically within the kernel."""
     o64, oc = oracles
     monkeypatch.delenv("CNF_COOPD", raising=False)
-    for nv, H in ((16, 136), (24, 200)):
+    # (nvariables = 32, 40: the 32-sample form with its Runge-Kutta sums in the plan's global ring - every workgroup walks four
+    # super-tiles through the same ring slice; 40 on 16 384 columns to bound the C restatement's time)
+    for nv, H in ((16, 136), (24, 200), (32, 264), (40, 328)):
         spec = o64.make_spec(nvars=nv, naug=nv + 1, hidden=[H, H], act=2, reg_z=True, reg_j=True, reg_aug=True)
-        B = 32768
+        B = 32768 if nv < 40 else 16384
         p, xs, eps, _ = o64.synth_inputs(spec, B, 7 + nv, bias_scale=0.1)
         mode = mode_of(pkg, spec)
         icnf = make_icnf(pkg, spec, 1, 40)
@@ -272,14 +274,15 @@ def test_dealt_cooperative_kernel_at_full_size(pkg, oracles, monkeypatch):
         monkeypatch.setenv("CNF_COOPD", "0")
         lx, rx = run_inference(pkg, icnf, spec, p, xs, eps, None)
         monkeypatch.delenv("CNF_COOPD")
-        assert np.max(np.abs(logp - lx.cpu().numpy())) < 1e-4
+        tol = 1e-4 + 2e-6 * float(np.abs(logp).max())      # (|logp| ~ 200 at D = 81 has a Float32 ulp of 1.5e-5)
+        assert np.max(np.abs(logp - lx.cpu().numpy())) < tol
         for a_, b_ in zip(regs, rx):
-            assert np.max(np.abs(a_.cpu().numpy() - b_.cpu().numpy())) < 1e-4
-        idx = np.arange(0, B, 257)
+            assert np.max(np.abs(a_.cpu().numpy() - b_.cpu().numpy())) < tol
+        idx = np.arange(0, B, 257 if nv < 32 else 1031)
         ref = oc.inference_fixed(spec, p, xs[:, idx], 0.0, 1.0, 40, 1, eps[:, idx], None, nthreads=8)
-        assert np.max(np.abs(logp[idx] - ref[0])) < TOL_SOLVE
+        assert np.max(np.abs(logp[idx] - ref[0])) < max(TOL_SOLVE, tol)
         # two shards, both above the 4096-column threshold: the same kernel, the same bits
-        cut = 12288 + 64 * 3 + 5
+        cut = (12288 if nv < 40 else 6144) + 64 * 3 + 5
         la = run_inference(pkg, icnf, spec, p, xs[:, :cut], eps[:, :cut], None)[0].cpu().numpy()
         lb = run_inference(pkg, icnf, spec, p, xs[:, cut:], eps[:, cut:], None)[0].cpu().numpy()
         assert np.array_equal(np.concatenate([la, lb]), logp)
