@@ -96,7 +96,7 @@ static int env_int(const char* name, int dflt) {
     return (v && *v) ? atoi(v) : dflt;
 }
 
-MfmaPlan* mfma_plan_create(const cnf_config& c, bool coop_only) {
+static MfmaPlan* mfma_plan_create_impl(const cnf_config& c, bool coop_only) {
     const int N = c.n_layers, L = N - 1;
     if (L < 1) return nullptr;
     // hidden layers may have different widths: every one is zero-padded to the widest (act(0) of a padded
@@ -227,6 +227,22 @@ MfmaPlan* mfma_plan_create(const cnf_config& c, bool coop_only) {
     p->fwd_scale = c.acts[0] == CNF_ACT_TANH ? kTanhPrescale : 1.f;
     snprintf(p->name, sizeof(p->name), "coopx<HT=%d,L=%d,ZR=%d,CR=%d,act=%d,%s>", hti, L, zri, cri, c.acts[0],
              exact ? (L == 2 ? "exact (Q product)" : "exact (unit probes)") : c.mode == CNF_MODE_HUTCH_JVP ? "jvp" : "vjp");
+    return p;
+}
+
+static hipError_t plan_ensure_cus(MfmaPlan* mp);
+// The ring of the Runge-Kutta sums some dealt instances keep in device memory (KArgs::rk) is allocated with the plan where a
+// device is current, so that the first solve - which may run under stream capture, where hipMalloc is not allowed - finds it;
+// mfma_solve still allocates it on first use otherwise.
+MfmaPlan* mfma_plan_create(const cnf_config& c, bool coop_only) {
+    MfmaPlan* p = mfma_plan_create_impl(c, coop_only);
+    if (p && (p->kind == 1 || p->kind == 2) && p->KP == 1 && plan_ensure_cus(p) == hipSuccess) {
+        int hmax = 0;
+        for (int l = 1; l < c.n_layers; ++l) hmax = c.widths[l] > hmax ? c.widths[l] : hmax;
+        const size_t a = coopd_rk_floats(hmax, c.nvars + c.naug, p->L, p->ACT, 0, p->num_cus), b = coopd_rk_floats(hmax, c.nvars + c.naug, p->L, p->ACT, 1, p->num_cus);
+        const size_t rkf = a > b ? a : b;
+        if (rkf && hipMalloc((void**)&p->rk_dev, rkf * sizeof(float)) != hipSuccess) { p->rk_dev = nullptr; (void)hipGetLastError(); }
+    }
     return p;
 }
 

@@ -1346,6 +1346,8 @@ def test_kernel_family_is_reported_by_the_library(pkg, oracles, monkeypatch):
     (dict(nvars=8, ncond=8, hidden=[128, 128, 128], mode=2), 1500, 0),      # tangent engine, conditioned (cfg5's)
     (dict(nvars=16, naug=17, hidden=[136, 136], act=2, reg_z=True, reg_j=True), 1000, 1),   # extended cooperative kernel
     (dict(nvars=8, hidden=[64] * 5), 1200, 1),                              # layer-wise path
+    (dict(nvars=24, naug=25, hidden=[200, 200], act=2, reg_z=True, reg_j=True, reg_aug=True), 4500, 1),   # dealt kernel + dealt sweep, Runge-Kutta sums in the plan's global ring
+    (dict(nvars=32, naug=33, hidden=[264, 264], act=2, reg_z=True, reg_j=True, reg_aug=True), 4200, 1),   # ... the 32-sample form, the 16-sample sweep
 ])
 def test_hot_path_is_hip_graph_capturable_on_a_side_stream(kw, B, alg, pkg, oracles):
     """after the first call has sized the workspaces, every entry point only enqueues work on the caller's
