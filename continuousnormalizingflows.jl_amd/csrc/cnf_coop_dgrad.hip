@@ -529,34 +529,6 @@ coopd_grad_step_kernel(DGArgs da) {
             g_load_a<A>(R, TZ, F1Z, 0, aS, aR);
             DG_T(1);
             DG_SYNC();                                                                     // B0
-            if (NSAMP == 2 ? wave >= 2 : wave == 1) {
-                // The dense operands of Wbar_1 and Wbar_N ([gbar; 0 | z; t; 1] and [eps | kbar]: rows of 4-byte stores, an exec mask per
-                // row) leave through waves 2 and 3, which have waited for the owners: lane l of wave 2 + q reads back from the
-                // images what lane l of owner q has just published.  (One sample tile: through wave 1, the last to get a left-over unit.)
-                const int q = NSAMP == 2 ? wave - 2 : 0;
-                const long long sm2 = smp0 + q * 16 + n;
-                if (sm2 < B) {
-                    float v0[KZ], v1[KZ];
-                    auto fetch = [&](const f32x4* img, int ct, float (&v)[KZ]) {
-#pragma unroll
-                        for (int kg = 0; kg < DT; ++kg) {
-                            const f32x4 t4 = img[(kg * NC + ct) * 64 + lane];
-                            v[4 * kg] = t4[0]; v[4 * kg + 1] = t4[1]; v[4 * kg + 2] = t4[2]; v[4 * kg + 3] = t4[3];
-                        }
-                    };
-                    fetch(zebuf, NSAMP + q, v0); fetch(zebuf, q, v1);
-                    dense_store(a.y1, a.ld_y1, c1 + sm2, v0);
-                    dense_store(a.y1, a.ld_y1, c2 + sm2, v1);
-                    if (g == 0) {
-                        float* col = a.y1 + (c2 + sm2) * (long long)a.ld_y1;
-                        if (!a.autonomous) col[D] = tt;
-                        col[a.ld_y1 - 1] = 1.f;
-                    }
-                    fetch(ekbuf, q, v0); fetch(ekbuf, NSAMP + q, v1);
-                    dense_store(a.xN, D, c1 + sm2, v0);
-                    dense_store(a.xN, D, c2 + sm2, v1);
-                }
-            }
             DG_T(2);
             g_gemm<A, NSAMP>(R, TZ, F1Z, G.KGZ, G.remZ, U, zebuf, lane, aS, aR, acc);
             DG_T(3);
@@ -592,6 +564,41 @@ coopd_grad_step_kernel(DGArgs da) {
             DG_T(4);
             DG_SYNC();                                                                     // B1
             DG_T(5);
+            {
+                // The dense operands of Wbar_1 and Wbar_N ([gbar; 0 | z; t; 1] and [eps | kbar]: rows of 4-byte stores, an exec mask per
+                // row) leave HERE, behind the second barrier of the stage, read back from the LDS images ([z | gbar] lives in the second
+                // exchange buffer until this stage's second publish) by the waves that wait longest at the NEXT barrier - the ones
+                // without left-over units: the owners with two sample tiles (s_memtime: they waited 4.2 k cycles at this barrier
+                // for the two other waves to finish these stores), waves 1 and 2 with one (wave 3 carries the left-over tile).
+                const bool st_y = NSAMP == 2 ? wave < 2 : wave == 1, st_x = NSAMP == 2 ? wave < 2 : wave == 2;
+                const int q = NSAMP == 2 ? wave : 0;
+                const long long sm2 = smp0 + q * 16 + n;
+                if ((st_y || st_x) && sm2 < B) {
+                    float v0[KZ], v1[KZ];
+                    auto fetch = [&](const f32x4* img, int ct, float (&v)[KZ]) {
+#pragma unroll
+                        for (int kg = 0; kg < DT; ++kg) {
+                            const f32x4 t4 = img[(kg * NC + ct) * 64 + lane];
+                            v[4 * kg] = t4[0]; v[4 * kg + 1] = t4[1]; v[4 * kg + 2] = t4[2]; v[4 * kg + 3] = t4[3];
+                        }
+                    };
+                    if (st_y) {
+                        fetch(zebuf, NSAMP + q, v0); fetch(zebuf, q, v1);
+                        dense_store(a.y1, a.ld_y1, c1 + sm2, v0);
+                        dense_store(a.y1, a.ld_y1, c2 + sm2, v1);
+                        if (g == 0) {
+                            float* col = a.y1 + (c2 + sm2) * (long long)a.ld_y1;
+                            if (!a.autonomous) col[D] = tt;
+                            col[a.ld_y1 - 1] = 1.f;
+                        }
+                    }
+                    if (st_x) {
+                        fetch(ekbuf, q, v0); fetch(ekbuf, NSAMP + q, v1);
+                        dense_store(a.xN, D, c1 + sm2, v0);
+                        dense_store(a.xN, D, c2 + sm2, v1);
+                    }
+                }
+            }
             // ================= up 2: [a_2 | dbar_2] = W_2 [h_1 | vbar_1] =================
             g_gemm<A, NSAMP>(R, TH, FH, G.KGH, G.remH, U, X0, lane, aS, aR, acc);
             DG_T(6);
