@@ -759,6 +759,7 @@ struct DGradInst {
 #define DG1_INST(A, KZ, ACT) DGradInst { A, KZ, ACT, 1, { &launch_dgrad<A, KZ, ACT, 4, 1>, &launch_dgrad<A, KZ, ACT, 6, 1> } }
 // the (A, KZ) pairs of cnf_coop_d.hip's forward instances
 static const DGradInst kDGrad[] = {
+    DG_INST(1, 8, CNF_ACT_SOFTPLUS),   // 5 .. 7 hidden tiles (the auxiliary cooperative plans of the default architecture at nvariables = 12, 13)
     DG_INST(2, 8, CNF_ACT_SOFTPLUS), DG_INST(3, 8, CNF_ACT_SOFTPLUS),
     DG_INST(2, 12, CNF_ACT_SOFTPLUS), DG_INST(3, 12, CNF_ACT_SOFTPLUS), DG_INST(3, 16, CNF_ACT_SOFTPLUS),
     DG_INST(2, 8, CNF_ACT_TANH_PRESCALED), DG_INST(2, 12, CNF_ACT_TANH_PRESCALED),   // tanh keeps h_1 as well: 8 .. 11 hidden tiles
@@ -791,7 +792,7 @@ bool coopd_grad_supported(int H, int D, int L, int ACT, int HT_lay, int ZR_lay, 
     bool force = false;
     if (const char* e = getenv("CNF_COOPD_GRAD")) { if (*e == '0') return false; force = *e == '2'; }
     const int HT_real = (H + 15) / 16, KZ = (D + 3) / 4;
-    if (HT_real < 8 || HT_real > HT_lay || KZ > ZR_lay) return false;
+    if (HT_real < 5 || HT_real > HT_lay || KZ > ZR_lay) return false;
     const DGradInst* c = dg_find(HT_real, KZ, ACT);
     if (!c || (c->KZ + 3) / 4 > (ZR_lay + 3) / 4) return false;
     // (where the plan's layout IS the configuration - hidden tiles a multiple of four, state k-steps as laid out - cnf_coop_grad.hip

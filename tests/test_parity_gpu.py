@@ -364,17 +364,18 @@ def test_cooperative_gradient_on_the_dealt_forward_solve(kw, lam, B, alg, nsteps
     assert np.max(np.abs(gx.cpu().numpy() - gxref)) < 5e-5 * np.abs(gxref).max() + 1e-7
 
 
-@pytest.mark.parametrize("nv,alg", [(16, 1), (18, 0), (22, 1), (29, 1), (32, 1), (38, 0), (43, 1)])
+@pytest.mark.parametrize("nv,alg", [(12, 1), (16, 1), (18, 0), (22, 1), (29, 1), (32, 1), (38, 0), (43, 1)])
 def test_dealt_reverse_sweep_matches_the_cooperative_sweep(nv, alg, pkg, oracles, monkeypatch):
     """The dealt form of the reverse sweep (cnf_coop_dgrad.hip) against the sweep of cnf_coop_grad.hip on the same plan, the same
-    checkpoints and the same operand arrays (CNF_COOPD_GRAD=0 selects the latter): default architecture at 9, 10, 12 and 15 hidden
+    checkpoints and the same operand arrays (CNF_COOPD_GRAD=0 selects the latter): default architecture at 7 (through the auxiliary
+    cooperative plan: one shared tile per wave + six left-over units), 9, 10, 12 and 15 hidden
     tiles (left-over units 1, 2, 0, 3 of a wave's two slots) on 32-sample super-tiles, 17, 20 and 22 tiles on 16-sample ones (one, no,
     two left-over tiles), 3000 columns (ragged last super-tile), default lambdas.  The two differ by
     summation order only - and they do differ in the last bits, which is how the test knows both ran."""
     o64, _ = oracles
     D = 2 * nv + 1
     spec = o64.make_spec(nvars=nv, naug=nv + 1, hidden=[4 * (D + 1)] * 2, act=2, reg_z=True, reg_j=True, reg_aug=True)
-    B = 3000
+    B = 3000 if nv >= 16 else 4500     # (7 .. 8 tiles take the cooperative route from 4096 columns on)
     p, xs, eps, _ = o64.synth_inputs(spec, B, 99 + nv, bias_scale=0.2)
     out = {}
     for tag, env in (("dealt", "1"), ("coop", "0")):
