@@ -257,7 +257,7 @@ mfma_grad_kernel(GArgs a) {
                     tiles_store<HT>(xmine + 2 * TS, lane, cb);
                     tiles_store<HT>(xmine + (2 + HT) * TS, lane, h[L - 1]);
                     __syncthreads();
-                    if (wave < HT) {
+                    if (HT >= 4 || wave < HT) {
 #pragma unroll
                         for (int v = 0; v < 4; ++v) {
                             const float* xv = xch + v * G::XCH_W;
@@ -294,7 +294,7 @@ mfma_grad_kernel(GArgs a) {
                         tiles_store<HT>(xmine + 2 * HT * TS, lane, dl[l]);        // A2 = delta_l
                         tiles_store<HT>(xmine + 3 * HT * TS, lane, ubs[l - 1]);   // B2 = ubar_{l-1}
                         __syncthreads();
-                        if (wave < HT) {
+                        if (HT >= 4 || wave < HT) {
 #pragma unroll
                             for (int v = 0; v < 4; ++v) {
                                 const float* xv = xch + v * G::XCH_W;
@@ -333,7 +333,7 @@ mfma_grad_kernel(GArgs a) {
                         tile_store(xmine + (2 * HT + 1) * TS, lane, gb_tile[0]);
                         if constexpr (CR > 0) tile_store(xmine + (2 * HT + 2) * TS, lane, y_tile[0]);
                         __syncthreads();
-                        if (wave < HT) {
+                        if (HT >= 4 || wave < HT) {
 #pragma unroll
                             for (int v = 0; v < 4; ++v) {
                                 const float* xv = xch + v * G::XCH_W;
@@ -381,7 +381,7 @@ mfma_grad_kernel(GArgs a) {
         }
     }
     // every wave deposits the tiles it owns in its own (zeroed) slab; grad_reduce_kernel sums the slabs
-    if (wave < HT) {
+    if (HT >= 4 || wave < HT) {
 #pragma unroll
         for (int l = 0; l < L - 1; ++l) {
 #pragma unroll

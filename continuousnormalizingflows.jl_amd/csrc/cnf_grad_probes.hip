@@ -26,7 +26,7 @@ __device__ __forceinline__ void exchange_hidden(float* __restrict__ xch, int xch
     tiles_store<HT>(xmine, lane, A);
     tiles_store<HT>(xmine + HT * TS, lane, Bt);
     __syncthreads();
-    if (wave < HT) {
+    if (HT >= 4 || wave < HT) {
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
             const float* xv = xch + v * xch_w;
@@ -233,7 +233,7 @@ mfma_grad_probes_kernel(GArgs a) {
                         tiles_store<HT>(xmine + 2 * TS, lane, cb);
                         tiles_store<HT>(xmine + (2 + HT) * TS, lane, dl0);
                         __syncthreads();
-                        if (wave < HT) {
+                        if (HT >= 4 || wave < HT) {
 #pragma unroll
                             for (int v = 0; v < 4; ++v) {
                                 const float* xv = xch + v * G::XCH_W;
@@ -255,7 +255,7 @@ mfma_grad_probes_kernel(GArgs a) {
                     tile_store(xmine + 0 * TS, lane, dense_tile<ZR>(kbar));
                     tiles_store<HT>(xmine + 1 * TS, lane, h[L - 1]);
                     __syncthreads();
-                    if (wave < HT) {
+                    if (HT >= 4 || wave < HT) {
 #pragma unroll
                         for (int v = 0; v < 4; ++v) {
                             const float* xv = xch + v * G::XCH_W;
@@ -285,7 +285,7 @@ mfma_grad_probes_kernel(GArgs a) {
                         tiles_store<HT>(xmine + 0 * HT * TS, lane, ab);
                         tiles_store<HT>(xmine + 1 * HT * TS, lane, h[l - 1]);
                         __syncthreads();
-                        if (wave < HT) {
+                        if (HT >= 4 || wave < HT) {
 #pragma unroll
                             for (int v = 0; v < 4; ++v) {
                                 const float* xv = xch + v * G::XCH_W;
@@ -318,7 +318,7 @@ mfma_grad_probes_kernel(GArgs a) {
                         tile_store(xmine + (HT + 0) * TS, lane, in_tile);
                         if constexpr (CR > 0) tile_store(xmine + (HT + 1) * TS, lane, y_tile[0]);
                         __syncthreads();
-                        if (wave < HT) {
+                        if (HT >= 4 || wave < HT) {
 #pragma unroll
                             for (int v = 0; v < 4; ++v) {
                                 const float* xv = xch + v * G::XCH_W;
@@ -362,7 +362,7 @@ mfma_grad_probes_kernel(GArgs a) {
             }
         }
     }
-    if (wave < HT) {
+    if (HT >= 4 || wave < HT) {
 #pragma unroll
         for (int l = 0; l < L - 1; ++l) {
 #pragma unroll
