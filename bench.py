@@ -6,7 +6,7 @@ cnf_inference_fixed (fused fixed-step solve + log-density epilogue) + cnf_loss_m
 RCCL all-reduce of the loss scalars when N > 1), with inputs already resident in HBM.
 Metric (BASELINE.json): log-density evaluations counted as samples·steps per second.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg2|cfg2p|cfg3|cfg5|cfg1]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg1|cfg2|cfg2p|cfg3|cfg4|cfg4r|cfg5|nv20] [--mode infer|grad]
 
 N > 1 is launched by the driver as `python -m torch.distributed.run --nproc-per-node N ...`;
 the batch columns are sharded by rank (weak scaling: 65 536 columns per GPU), no data-path
@@ -30,6 +30,8 @@ The JSON line also carries
                  ≥ 97 flop/B); its HBM figure is reported beside it.
   secondary    — the north_star's target configuration (cfg2p: the same flow under Tsit5 x 40)
                  measured by the same protocol in the same process, with its own roofline.
+  secondaries  — (default one-GPU line only) every other BASELINE configuration, the loss + gradient of cfg2 and cfg4 and the
+                 reference's default architecture at nvariables = 20 (inference and loss + gradient), compactly, same protocol.
   cpu_baseline — CPU fp32 restatements of the same algorithm on this host's cores (rank 0, N = 1):
                  the C port (oracle/cnf_oracle.c, cache-blocked register-tiled products, AVX-512 when
                  the CPU has it) and a whole-batch BLAS leg (torch.mm on every host thread at the full
