@@ -443,9 +443,13 @@ static bool plan_uses_coopd(const MfmaPlan* p, long long B) {
     const bool exact = p->cfg.mode == CNF_MODE_EXACT;
     if (!(p->cfg.mode == CNF_MODE_HUTCH_VJP || (exact && p->L == 2 && p->q_extra > 0))) return false;
     const int env = env_int("CNF_COOPD", 1);
-    if (env == 0 || (env != 2 && B <= 16LL * (p->num_cus > 0 ? p->num_cus : 256))) return false;
+    if (env == 0) return false;
     int hmax = 0;
     for (int l = 1; l < p->cfg.n_layers; ++l) hmax = p->cfg.widths[l] > hmax ? p->cfg.widths[l] : hmax;
+    // the batch threshold belongs to the 64-sample form; the 32-sample form (16 .. 24 hidden tiles) has the extended kernel's
+    // super-tile size and beats it at every batch size (nvariables = 32: 7.7 against 11.6 ms at B = 1024 .. 4096; 40: 11.1 against 15.9)
+    if (env != 2 && B <= 16LL * (p->num_cus > 0 ? p->num_cus : 256) &&
+        coopd_supertile(hmax, p->cfg.nvars + p->cfg.naug, p->L, p->ACT, exact ? 1 : 0) == 64) return false;
     // a cooperative plan whose hidden width fills whole quads of tiles stays on its own, exact, tuned kernel (3 x 192, D = 20:
     // 20.5 against 22.4 ms); one that it pads - 13 tiles run as 16 - is dealt (3 x 200: 31.0 -> 24.5 ms)
     if (p->kind == 1 && ((hmax + 15) / 16) % 4 == 0) return false;

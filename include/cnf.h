@@ -212,7 +212,8 @@ int cnf_kernel_path(const cnf_handle* h);
  * Results of two families differ by summation order only (<= 2e-5 in logp); within one family a column's result does not depend
  * on which other columns are in the call - SHARD CONCATENATION IS THEREFORE BIT-IDENTICAL ONLY WHEN EVERY SHARD AND THE
  * UNSHARDED CALL TAKE THE SAME FAMILY: per-wave shapes switch to TILE_SPLIT at B <= 16 x (compute units) = 4096 columns
- * (CNF_TILE_SPLIT=0 in the environment keeps PER_WAVE at every size); every BASELINE shard is larger. */
+ * (CNF_TILE_SPLIT=0 in the environment keeps PER_WAVE at every size), extended-kernel shapes of 5 .. 15 hidden tiles to COOPD
+ * above it (CNF_COOPD=0 keeps COOPX; 16 .. 24 hidden tiles take COOPD at every size); every BASELINE shard is larger. */
 enum { CNF_FAMILY_SIMT = 0, CNF_FAMILY_PER_WAVE = 1, CNF_FAMILY_COOP = 2, CNF_FAMILY_COOPX = 3, CNF_FAMILY_TILE_SPLIT = 4, CNF_FAMILY_LAYERED = 5,
        CNF_FAMILY_COOPD = 6 };
 int cnf_kernel_family(const cnf_handle* h);

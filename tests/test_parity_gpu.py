@@ -268,7 +268,8 @@ def test_dealt_cooperative_kernel_at_full_size(pkg, oracles, monkeypatch):
         p, xs, eps, _ = o64.synth_inputs(spec, B, 7 + nv, bias_scale=0.1)
         mode = mode_of(pkg, spec)
         icnf = make_icnf(pkg, spec, 1, 40)
-        assert icnf.kernel_family(mode) == "coopx" and icnf.kernel_family(mode, B=B) == "coopd" and icnf.kernel_family(mode, B=4096) == "coopx"
+        # (the 4096-column threshold belongs to the 64-sample form: the 32-sample one serves every batch size)
+        assert icnf.kernel_family(mode) == "coopx" and icnf.kernel_family(mode, B=B) == "coopd" and icnf.kernel_family(mode, B=4096) == ("coopx" if nv < 30 else "coopd")
         logp, regs = run_inference(pkg, icnf, spec, p, xs, eps, None)
         logp = logp.cpu().numpy()
         monkeypatch.setenv("CNF_COOPD", "0")
