@@ -434,10 +434,10 @@ static hipError_t plan_ensure_cus(MfmaPlan* mp) {
     return hipSuccess;
 }
 
-// an extended-kernel plan whose one-probe VJP solves of B columns run on the dealt cooperative kernel (cnf_coop_d.hip): from 16
-// columns per compute unit on (4096) - below that its 64-sample super-tiles leave CUs empty that the extended kernel's 32-sample
-// ones fill (measured at nvariables = 24: 9.7 against 9.0 ms at B <= 4096, 9.7 against 11.7 ms at 8192).  CNF_COOPD=0: never,
-// =2: at any batch size.
+// an extended-kernel plan whose one-probe VJP solves of B columns run on the dealt cooperative kernel (cnf_coop_d.hip): its
+// 64-sample form from 16 columns per compute unit on (4096) - below that its super-tiles leave CUs empty that the extended
+// kernel's 32-sample ones fill (measured at nvariables = 24: 9.7 against 9.0 ms at B <= 4096, 9.7 against 11.7 ms at 8192) -
+// its 32-sample form (cnf_coop_d2.hip) at every batch size.  CNF_COOPD=0: never, =2: both forms at any batch size.
 static bool plan_uses_coopd(const MfmaPlan* p, long long B) {
     if (!p || (p->kind != 2 && p->kind != 1) || p->KP != 1) return false;   // extended plans, and cooperative ones (one probe, VJP, no conditions)
     const bool exact = p->cfg.mode == CNF_MODE_EXACT;
