@@ -221,7 +221,7 @@ COOPD_CASES = [
 
 @pytest.mark.parametrize("kw,B,alg,nsteps", COOPD_CASES)
 def test_dealt_cooperative_kernel_matches_the_oracles(kw, B, alg, nsteps, pkg, oracles, monkeypatch):
-    """csrc/cnf_coop_d.hip (forced at these batch sizes with CNF_COOPD=2; it takes over on its own above 4096 columns) is the
+    """csrc/cnf_coop_d.hip (forced at these batch sizes with CNF_COOPD=2; on its own the 64-sample form takes over above 4096 columns, the 32-sample form serves every size) is the
     same augmented_f / solve (src/core/icnf.jl:517-559, src/core/base_icnf.jl:158-172): whole solves against the C restatement,
     logp / regularisers / final state; a single dynamics call against the fp64 oracle; and against the extended kernel
     (CNF_COOPD=0) on the same inputs - the two differ by summation order only."""
