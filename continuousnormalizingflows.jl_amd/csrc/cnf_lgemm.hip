@@ -721,7 +721,15 @@ int lg_wgrad_chunks(int M, long long B, int num_cus, long long* chunk_out, int p
     // workgroups per CU: 2 for the per-stage calls of the layer-wise path (B columns), 4 for the per-step calls of the
     // cooperative gradient (2 x stages x B columns: cfg4 loss + gradient 139.9 -> 133.3 ms; 1: 162, 3: 135, 8: 135)
     static const int per_cu_env = [] { const char* v = getenv("CNF_LG_WGRAD_PER_CU"); return v && *v ? atoi(v) : 0; }();
-    const int per_cu = per_cu_env > 0 ? per_cu_env : per_cu_dflt;
+    // (three workgroups are resident per CU.  The per-step calls' workgroups per CU grow with the number of workgroups that
+    // share a chunk: their costs differ - dead strips, a short last column group - and more, smaller chunks even the CUs out.
+    // Loss + gradient of the default architecture, B = 32 768, against 4 per CU for all: nvariables = 16: 50.1 -> 47.7 ms,
+    // 20: 63.1 -> 59.9, 28: 100.6 -> 96.5, 32: 152.9 -> 146.0, 40: 218.2 -> 206.0; profiles/r4/r4u_wgrad_chunking.txt)
+    static const int t1 = [] { const char* v = getenv("CNF_LG_WGRAD_T1"); return v && *v ? atoi(v) : 5; }();
+    static const int t2 = [] { const char* v = getenv("CNF_LG_WGRAD_T2"); return v && *v ? atoi(v) : 8; }();
+    const bool uneven = M % 64 != 0;   // (256 x 257 has no dead strip: 6 and 12 tie there, 108.3 against 108.5 ms at cfg4)
+    const int by_rule = per_cu_dflt != 4 ? per_cu_dflt : (RB * groups >= t2 + (uneven ? 0 : 1)) ? 12 : RB * groups >= t1 ? 6 : 3;
+    const int per_cu = per_cu_env > 0 ? per_cu_env : by_rule;
     long long want = ((long long)per_cu * num_cus + RB * groups - 1) / (RB * groups);   // workgroups per CU
     if (want < 1) want = 1;
     long long chunk = (B + want - 1) / want;
