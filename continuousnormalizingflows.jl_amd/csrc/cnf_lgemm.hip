@@ -295,14 +295,16 @@ __device__ __forceinline__ void lg_epilogue_tile(const LgGemmArgs& a, f32x4 v, i
     }
 }
 
-constexpr int LG2_KQ_MAX = 17;                        // K <= 272: 2 buffers x 17 x 2 KB = 68 KB of LDS
+constexpr int LG2_KQ_MAX = 17;                        // K <= 272: 2 buffers x 17 x 2 KB = 68 KB of LDS, two workgroups per CU
+constexpr int LG2_KQ_WIDE = 32;                       // K <= 512: up to 128 KB, one workgroup of eight waves per CU (KQM = 32 instances)
 
 // NW waves per workgroup (4 or 8): with 8, a wave owns half as many row tiles, needs ~110 registers, and four waves share a
 // SIMD (two workgroups per CU) - twice the memory latency covered per SIMD
-template <int MTW, int EPI, int NW>
+// KQM: the most k-groups of 16 an instance stages (sizes the staging registers; the LDS need follows the call's own KQ)
+template <int MTW, int EPI, int NW, int KQM = LG2_KQ_MAX>
 __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 2, NW / 2)))
 lg_gemm2_kernel(LgGemmArgs a) {
-    constexpr int LG2_UNITS = (2 * LG2_KQ_MAX + NW - 1) / NW;   // staging units (1 KB: one (kq, q) tile) per wave and sub-panel
+    constexpr int LG2_UNITS = (2 * KQM + NW - 1) / NW;   // staging units (1 KB: one (kq, q) tile) per wave and sub-panel
     extern __shared__ __attribute__((aligned(16))) float smem[];
     f32x4* bimg = reinterpret_cast<f32x4*>(smem);                 // [2 buffers][KQ][2 sample tiles][64 lanes]
     const int lane = threadIdx.x & 63, g = lane >> 4, n = lane & 15;
@@ -415,16 +417,16 @@ lg_gemm2_kernel(LgGemmArgs a) {
     }
 }
 
-template <int MTW, int EPI, int NW = 4>
+template <int MTW, int EPI, int NW = 4, int KQM = LG2_KQ_MAX>
 static hipError_t lg_gemm2_launch(const LgGemmArgs& a, hipStream_t st) {
     const int lds = 2 * a.KQ * 2 * 64 * 16;
-    auto kern = lg_gemm2_kernel<MTW, EPI, NW>;
+    auto kern = lg_gemm2_kernel<MTW, EPI, NW, KQM>;
     static DeviceOnce once;
     int dev = 0;
     hipError_t e0 = hipGetDevice(&dev);
     if (e0 != hipSuccess) return e0;
     if (lds > 64 * 1024 && !once.done(dev)) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * KQM * 2 * 64 * 16 > 80 * 1024 ? 2 * KQM * 2 * 64 * 16 : 80 * 1024);
         if (e != hipSuccess) return e;
         once.set(dev);
     }
@@ -475,6 +477,18 @@ static hipError_t lg_gemm_dispatch(LgGemmArgs a, hipStream_t st) {
         if (a.mts <= 4) return lg_gemm2_launch<1, EPI>(a, st);
         if (a.mts <= 8) return lg_gemm2_launch<2, EPI>(a, st);
         return lg_gemm2_launch<4, EPI>(a, st);
+    }
+    // K = 273 .. 512 (the default architecture from nvariables = 33 on, where it runs layer-wise): the same pipeline, one workgroup
+    // of eight waves per CU (the 392 x 392 products of nvariables = 48: 193 - 214 us on lg_gemm_kernel, 50 TFLOP/s)
+    static const int wide2 = [] { const char* v = getenv("CNF_LG_GEMM2_WIDE"); return v && *v ? atoi(v) : 1; }();
+    if (variant == 2 && wide2 && a.KQ <= LG2_KQ_WIDE) {
+        const long long nsub = (a.N + 31) / 32;
+        long long spw = nsub * splits / 256;
+        if (spw < 1) spw = 1;
+        if (spw > 8) spw = 8;
+        a.spw = (int)spw;
+        if (a.mts <= 8) return lg_gemm2_launch<1, EPI, 8, LG2_KQ_WIDE>(a, st);
+        return lg_gemm2_launch<2, EPI, 8, LG2_KQ_WIDE>(a, st);
     }
     const bool wide = variant != 3 && a.KQ * 8 * 1024 <= 160 * 1024 && a.N * splits >= 128 * 192;
     if (a.mts <= 4) return wide ? lg_gemm_launch<1, 8, EPI>(a, st) : lg_gemm_launch<1, 4, EPI>(a, st);

@@ -854,6 +854,7 @@ LAYERED_GRAD_SHAPES = [
     (dict(nvars=3, naug=2, hidden=[24, 40, 16, 32, 24], act=2, reg_z=True, reg_j=True, reg_aug=True), (0.01, 0.02, 0.03), 50, 1, 3),  # five unequal hidden layers (SIMT forward)
     (dict(nvars=20, hidden=[64, 64], nprobes=3, reg_j=True), (0.0, 0.05, 0.0), 33, 0, 3),                 # D = 20, three probes
     (dict(nvars=4, hidden=[96], autonomous=True), (0.0, 0.0, 0.0), 25, 1, 2),                              # one hidden layer
+    (dict(nvars=48, naug=49, hidden=[392, 392], act=2, reg_z=True, reg_j=True, reg_aug=True), (0.01, 0.01, 0.01), 40, 1, 2),   # ICNF(nvariables = 48): the first default net past the fused kernels (25 hidden tiles; products of K = 392 on lg_gemm2's wide-K instances)
 ]
 
 
@@ -1294,6 +1295,24 @@ def test_randomised_shapes_layerwise_vs_generic_kernels(pkg, oracles):
         assert float((a[2] - b[2]).abs().max()) < 1e-4 * max(1.0, float(b[2].abs().max()) / 32.0), kw
         for u, v in zip(a[1], b[1]):
             assert float((u - v).abs().max()) < 1e-4, kw
+
+
+@pytest.mark.parametrize("nv,alg,B", [(48, 1, 70), (56, 0, 33), (63, 1, 45)])
+def test_default_architecture_past_the_fused_kernels_runs_layerwise(nv, alg, B, pkg, oracles):
+    """ICNF(nvariables >= 48) - two softplus layers of 4 (D + 1) >= 392 units, more than the 24 hidden tiles the cooperative kernels
+    hold - runs layer-wise (src/core/icnf.jl:53-103, 517-559): whole solves against the C restatement, TrainMode and TestMode."""
+    o64, oc = oracles
+    D = 2 * nv + 1
+    for kw in (dict(reg_z=True, reg_j=True, reg_aug=True), dict(mode=2)):
+        spec = o64.make_spec(nvars=nv, naug=nv + 1, hidden=[4 * (D + 1)] * 2, act=2, **kw)
+        p, xs, eps, ys = o64.synth_inputs(spec, B, 900 + nv, bias_scale=0.2)
+        icnf = make_icnf(pkg, spec, alg, 3, path=0)
+        assert icnf.kernel_family(mode_of(pkg, spec), B=B) == "layered"
+        ref = oc.inference_fixed(spec, p, xs, 0.0, 1.0, 3, alg, eps, ys, nthreads=8)
+        logp, regs, _ = run_inference(pkg, icnf, spec, p, xs, eps, ys, return_state=True)
+        assert np.max(np.abs(logp.cpu().numpy() - ref[0])) < TOL_SOLVE * max(1.0, float(np.abs(ref[0]).max()) / 32.0)
+        for a_, b_ in zip(regs, ref[1]):
+            assert np.max(np.abs(a_.cpu().numpy() - b_)) < TOL_SOLVE
 
 
 def test_auto_path_prefers_fused_then_layerwise(pkg, oracles):
