@@ -742,7 +742,9 @@ int lg_wgrad_chunks(int M, long long B, int num_cus, long long* chunk_out, int p
     static const int t1 = [] { const char* v = getenv("CNF_LG_WGRAD_T1"); return v && *v ? atoi(v) : 5; }();
     static const int t2 = [] { const char* v = getenv("CNF_LG_WGRAD_T2"); return v && *v ? atoi(v) : 8; }();
     const bool uneven = M % 64 != 0;   // (256 x 257 has no dead strip: 6 and 12 tie there, 108.3 against 108.5 ms at cfg4)
-    const int by_rule = per_cu_dflt != 4 ? per_cu_dflt : (RB * groups >= t2 + (uneven ? 0 : 1)) ? 12 : RB * groups >= t1 ? 6 : 3;
+    // (the layer-wise path's per-stage calls, 2 per CU: 6 from 12 sharers on - nvariables = 48: 645 -> 627 ms, 56: 780 -> 735)
+    const int by_rule = per_cu_dflt == 2 ? (RB * groups >= 12 ? 6 : 2)
+                      : per_cu_dflt != 4 ? per_cu_dflt : (RB * groups >= t2 + (uneven ? 0 : 1)) ? 12 : RB * groups >= t1 ? 6 : 3;
     const int per_cu = per_cu_env > 0 ? per_cu_env : by_rule;
     long long want = ((long long)per_cu * num_cus + RB * groups - 1) / (RB * groups);   // workgroups per CU
     if (want < 1) want = 1;
