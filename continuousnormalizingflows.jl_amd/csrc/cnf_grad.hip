@@ -30,6 +30,12 @@
 // wave-private slabs updated by load/MFMA/store - 64 GB of fabric traffic per gradient - 19 ms.)
 #include "cnf_grad_dev.h"
 
+#ifdef G_TRACE
+#define G_T(k) do { asm volatile("" ::: "memory"); tr[k] = __builtin_amdgcn_s_memtime(); asm volatile("" ::: "memory"); } while (0)
+#else
+#define G_T(k)
+#endif
+
 namespace cnf {
 
 template <int HT, int L, int ZR, int CR, int ACT>
@@ -168,6 +174,10 @@ mfma_grad_kernel(GArgs a) {
                 for (int s = 0; s < ZR; ++s) Zb[j][s] = 0.f;
 #pragma clang loop unroll(disable)
             for (int st = ns - 1; st >= 0; --st) {
+#ifdef G_TRACE
+                unsigned long long tr[28];
+#endif
+                G_T(0);
                 float zs[ZR], kbar[ZR];
                 const float bi = a.T.b[st];
 #pragma unroll
@@ -191,6 +201,7 @@ mfma_grad_kernel(GArgs a) {
                 // (1) recompute, (2) first-order pullback
                 f32x4 h[L][HT], d[L][HT], dl[L][HT], u[L][HT];
                 grad_forward<HT, L, ZR, CR, ACT>(sm, lane, tt, autonomous, zs, y, h, d);
+                G_T(1);
 #pragma unroll
                 for (int mt = 0; mt < HT; ++mt) { u[L - 1][mt] = cvec[mt]; dl[L - 1][mt] = cvec[mt] * d[L - 1][mt]; }
 #pragma unroll
@@ -200,6 +211,7 @@ mfma_grad_kernel(GArgs a) {
 #pragma unroll
                     for (int mt = 0; mt < HT; ++mt) dl[l - 1][mt] = u[l - 1][mt] * d[l - 1][mt];
                 }
+                G_T(2);
                 // (3) bottom-up through the pullback: dbar, second-order terms, Wbar_{l+1} += delta_{l+1} ubar_l^T
                 if (regz) {   // Edot = |zdot|: kbar += c_E zdot / |zdot|
                     f32x4 zacc[DT];
@@ -248,6 +260,7 @@ mfma_grad_kernel(GArgs a) {
                 f32x4 cb[HT];   // cbar = dbar_L .* act'_L: Wbar_N[i, f] += eps_i cbar_f
 #pragma unroll
                 for (int mt = 0; mt < HT; ++mt) { cb[mt] = db[mt] * d[L - 1][mt]; a2[L - 1][mt] = db[mt] * cvec[mt]; }
+                G_T(3);
                 // (4) top-down through the forward chain
                 f32x4 kb_tile[1];
                 kb_tile[0] = dense_tile<ZR>(kbar);
@@ -256,7 +269,9 @@ mfma_grad_kernel(GArgs a) {
                     tile_store(xmine + 1 * TS, lane, kb_tile[0]);
                     tiles_store<HT>(xmine + 2 * TS, lane, cb);
                     tiles_store<HT>(xmine + (2 + HT) * TS, lane, h[L - 1]);
+                    G_T(4);
                     __syncthreads();
+                    G_T(5);
                     if (HT >= 4 || wave < HT) {
 #pragma unroll
                         for (int v = 0; v < 4; ++v) {
@@ -271,11 +286,14 @@ mfma_grad_kernel(GArgs a) {
                             if (wave == 0) BNacc = outer4(a2f, onesf, BNacc);
                         }
                     }
+                    G_T(6);
                     __syncthreads();
+                    G_T(7);
                 }
                 f32x4 hb[HT];
                 zero_tiles<HT>(hb);
                 gemm_tiles<HT, ZR>(sm + LAY.bN, lane, RegIn<ZR>{kbar}, hb);   // W_N^T kbar
+                G_T(8);
                 float Zbar[ZR];
 #pragma unroll
                 for (int l = L - 1; l >= 0; --l) {
@@ -286,6 +304,7 @@ mfma_grad_kernel(GArgs a) {
                         const f32x4 d2 = ACT == CNF_ACT_TANH ? h[l][mt] * d[l][mt] * -2.f : d[l][mt] * (1.f - d[l][mt]);
                         ab[mt] = hb[mt] * d[l][mt] + a2[l][mt] * d2;
                     }
+                    G_T(9 + 6 * (L - 1 - l));
                     if (l > 0) {
                         // Wbar_{l+1} += abar_l h_{l-1}^T + delta_l ubar_{l-1}^T ;  bbar_{l+1} += abar_l x ones.
                         // Publish this wave's operand tiles; wave w accumulates row block w over all 4 waves.
@@ -293,7 +312,9 @@ mfma_grad_kernel(GArgs a) {
                         tiles_store<HT>(xmine + 1 * HT * TS, lane, h[l - 1]);     // B1 = h_{l-1}
                         tiles_store<HT>(xmine + 2 * HT * TS, lane, dl[l]);        // A2 = delta_l
                         tiles_store<HT>(xmine + 3 * HT * TS, lane, ubs[l - 1]);   // B2 = ubar_{l-1}
+                        G_T(10 + 6 * (L - 1 - l));
                         __syncthreads();
+                        G_T(11 + 6 * (L - 1 - l));
                         if (HT >= 4 || wave < HT) {
 #pragma unroll
                             for (int v = 0; v < 4; ++v) {
@@ -312,9 +333,12 @@ mfma_grad_kernel(GArgs a) {
                                 }
                             }
                         }
+                        G_T(12 + 6 * (L - 1 - l));
                         __syncthreads();   // exchange buffer is reused by the next hidden matrix / stage
+                        G_T(13 + 6 * (L - 1 - l));
                         zero_tiles<HT>(hb);
                         gemm_tiles<HT, 4 * HT>(sm + LAY.bh + (l - 1) * MfmaLayout::imgA(HT, HT), lane, TileIn<HT>{ab}, hb);   // W_{l+1}^T abar
+                        G_T(14 + 6 * (L - 1 - l));
                     } else {
                         // input pseudo tile [z (D rows); t; ...; 1 at feature 15]: feature j <-> (register j>>2, lane group j&3)
                         f32x4 in_tile;
@@ -332,7 +356,9 @@ mfma_grad_kernel(GArgs a) {
                         tile_store(xmine + (2 * HT + 0) * TS, lane, in_tile);
                         tile_store(xmine + (2 * HT + 1) * TS, lane, gb_tile[0]);
                         if constexpr (CR > 0) tile_store(xmine + (2 * HT + 2) * TS, lane, y_tile[0]);
+                        G_T(10 + 6 * (L - 1 - l));
                         __syncthreads();
+                        G_T(11 + 6 * (L - 1 - l));
                         if (HT >= 4 || wave < HT) {
 #pragma unroll
                             for (int v = 0; v < 4; ++v) {
@@ -351,7 +377,9 @@ mfma_grad_kernel(GArgs a) {
                                 }
                             }
                         }
+                        G_T(12 + 6 * (L - 1 - l));
                         __syncthreads();
+                        G_T(13 + 6 * (L - 1 - l));
                         f32x4 zb[DT];
                         zero_tiles<DT>(zb);
                         gemm_tiles<DT, 4 * HT>(sm + LAY.b1, lane, TileIn<HT>{ab}, zb);   // W_1[:,0:D]^T abar_1
@@ -363,6 +391,14 @@ mfma_grad_kernel(GArgs a) {
                 for (int j = 0; j < 6; ++j)
 #pragma unroll
                     for (int s = 0; s < ZR; ++s) Zb[j][s] = (j == st) ? Zbar[s] : Zb[j][s];
+#ifdef G_TRACE
+                G_T(14 + 6 * (L - 1));
+                if (blockIdx.x == 3 && step == 5 && st == 1 && lane == 0 && tg == blockIdx.x) {
+                    printf("w%d:", wave);
+                    for (int k = 1; k <= 14 + 6 * (L - 1); ++k) printf(" %d", (int)(tr[k] - tr[k - 1]));
+                    printf(" | total %d\n", (int)(tr[14 + 6 * (L - 1)] - tr[0]));
+                }
+#endif
             }
 #pragma unroll
             for (int s = 0; s < ZR; ++s) {
@@ -505,7 +541,14 @@ hipError_t grad_launch(const cnf_config& c, const float* packed_dev, const float
         if (!kern || !ckpt_k) return hipErrorNotSupported;
     }
     static DeviceOnce done_probes[sizeof(kGrad) / sizeof(kGrad[0])];
-    DeviceOnce& done = (c.nprobes > 1 ? done_probes : done_mask)[idx];
+    // one probe with stage checkpoints: the barrier-free form (cnf_grad2.hip) where it has an instance; CNF_GRAD_V1=1 keeps the
+    // exchange form above (A/B switch)
+    static DeviceOnce done_v2[sizeof(kGrad) / sizeof(kGrad[0])];
+    bool v2 = false;
+    if (c.nprobes == 1 && ckpt_k && !getenv("CNF_GRAD_V1")) {
+        if (GradKernel k2 = grad2_kernel(gi->HT, gi->L, gi->ZR, gi->CR, gi->ACT)) { kern = k2; v2 = true; }
+    }
+    DeviceOnce& done = (v2 ? done_v2 : c.nprobes > 1 ? done_probes : done_mask)[idx];
     if (!done.done(dev)) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, gi->lds_bytes);
         if (e != hipSuccess) return e;

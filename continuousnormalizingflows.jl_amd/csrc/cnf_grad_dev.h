@@ -135,5 +135,7 @@ __device__ __forceinline__ void grad_forward(const float* __restrict__ smem, int
 // kernel for K > 1 probes (cnf_grad_probes.hip); same slab layout and reduce kernel as the K = 1 one
 typedef void (*GradKernel)(GArgs);
 GradKernel grad_probes_kernel(int HT, int L, int ZR, int CR, int ACT);
+// barrier-free form for one probe (cnf_grad2.hip): every wave keeps the whole gradient of its own sample tiles; null = no instance
+GradKernel grad2_kernel(int HT, int L, int ZR, int CR, int ACT);
 
 }  // namespace cnf
