@@ -43,43 +43,43 @@ namespace {
 #define G2_MF(acc, a, b) "v_mfma_f32_16x16x4_f32 %" #acc ", %" #a ", %" #b ", %" #acc "\n\t"
 // row form: W[nt] += sum_s fa[s] fb[nt][s] - one A fragment (row tile), NT B fragments
 __device__ __forceinline__ void cot_row(const float (&fa)[4], const float (&fb)[1][4], f32x4 (&W)[1]) {
-    asm("s_nop 1\n\t" G2_MF(0, 1, 5) G2_MF(0, 2, 6) G2_MF(0, 3, 7) G2_MF(0, 4, 8)
+    asm volatile("s_nop 1\n\t" G2_MF(0, 1, 5) G2_MF(0, 2, 6) G2_MF(0, 3, 7) G2_MF(0, 4, 8)
         : "+a"(W[0])
         : "v"(fa[0]), "v"(fa[1]), "v"(fa[2]), "v"(fa[3]), "v"(fb[0][0]), "v"(fb[0][1]), "v"(fb[0][2]), "v"(fb[0][3]));
 }
 __device__ __forceinline__ void cot_row(const float (&fa)[4], const float (&fb)[2][4], f32x4 (&W)[2]) {
-    asm("s_nop 1\n\t" G2_MF(0, 2, 6) G2_MF(1, 2, 10) G2_MF(0, 3, 7) G2_MF(1, 3, 11) G2_MF(0, 4, 8) G2_MF(1, 4, 12) G2_MF(0, 5, 9) G2_MF(1, 5, 13)
+    asm volatile("s_nop 1\n\t" G2_MF(0, 2, 6) G2_MF(1, 2, 10) G2_MF(0, 3, 7) G2_MF(1, 3, 11) G2_MF(0, 4, 8) G2_MF(1, 4, 12) G2_MF(0, 5, 9) G2_MF(1, 5, 13)
         : "+a"(W[0]), "+a"(W[1])
         : "v"(fa[0]), "v"(fa[1]), "v"(fa[2]), "v"(fa[3]), "v"(fb[0][0]), "v"(fb[0][1]), "v"(fb[0][2]), "v"(fb[0][3]), "v"(fb[1][0]), "v"(fb[1][1]), "v"(fb[1][2]), "v"(fb[1][3]));
 }
 __device__ __forceinline__ void cot_row(const float (&fa)[4], const float (&fb)[3][4], f32x4 (&W)[3]) {
-    asm("s_nop 1\n\t" G2_MF(0, 3, 7) G2_MF(1, 3, 11) G2_MF(2, 3, 15) G2_MF(0, 4, 8) G2_MF(1, 4, 12) G2_MF(2, 4, 16) G2_MF(0, 5, 9) G2_MF(1, 5, 13) G2_MF(2, 5, 17) G2_MF(0, 6, 10) G2_MF(1, 6, 14) G2_MF(2, 6, 18)
+    asm volatile("s_nop 1\n\t" G2_MF(0, 3, 7) G2_MF(1, 3, 11) G2_MF(2, 3, 15) G2_MF(0, 4, 8) G2_MF(1, 4, 12) G2_MF(2, 4, 16) G2_MF(0, 5, 9) G2_MF(1, 5, 13) G2_MF(2, 5, 17) G2_MF(0, 6, 10) G2_MF(1, 6, 14) G2_MF(2, 6, 18)
         : "+a"(W[0]), "+a"(W[1]), "+a"(W[2])
         : "v"(fa[0]), "v"(fa[1]), "v"(fa[2]), "v"(fa[3]), "v"(fb[0][0]), "v"(fb[0][1]), "v"(fb[0][2]), "v"(fb[0][3]), "v"(fb[1][0]), "v"(fb[1][1]), "v"(fb[1][2]), "v"(fb[1][3]), "v"(fb[2][0]), "v"(fb[2][1]), "v"(fb[2][2]), "v"(fb[2][3]));
 }
 __device__ __forceinline__ void cot_row(const float (&fa)[4], const float (&fb)[4][4], f32x4 (&W)[4]) {
-    asm("s_nop 1\n\t" G2_MF(0, 4, 8) G2_MF(1, 4, 12) G2_MF(2, 4, 16) G2_MF(3, 4, 20) G2_MF(0, 5, 9) G2_MF(1, 5, 13) G2_MF(2, 5, 17) G2_MF(3, 5, 21) G2_MF(0, 6, 10) G2_MF(1, 6, 14) G2_MF(2, 6, 18) G2_MF(3, 6, 22) G2_MF(0, 7, 11) G2_MF(1, 7, 15) G2_MF(2, 7, 19) G2_MF(3, 7, 23)
+    asm volatile("s_nop 1\n\t" G2_MF(0, 4, 8) G2_MF(1, 4, 12) G2_MF(2, 4, 16) G2_MF(3, 4, 20) G2_MF(0, 5, 9) G2_MF(1, 5, 13) G2_MF(2, 5, 17) G2_MF(3, 5, 21) G2_MF(0, 6, 10) G2_MF(1, 6, 14) G2_MF(2, 6, 18) G2_MF(3, 6, 22) G2_MF(0, 7, 11) G2_MF(1, 7, 15) G2_MF(2, 7, 19) G2_MF(3, 7, 23)
         : "+a"(W[0]), "+a"(W[1]), "+a"(W[2]), "+a"(W[3])
         : "v"(fa[0]), "v"(fa[1]), "v"(fa[2]), "v"(fa[3]), "v"(fb[0][0]), "v"(fb[0][1]), "v"(fb[0][2]), "v"(fb[0][3]), "v"(fb[1][0]), "v"(fb[1][1]), "v"(fb[1][2]), "v"(fb[1][3]), "v"(fb[2][0]), "v"(fb[2][1]), "v"(fb[2][2]), "v"(fb[2][3]), "v"(fb[3][0]), "v"(fb[3][1]), "v"(fb[3][2]), "v"(fb[3][3]));
 }
 // column form: W[mt] += sum_s fa[mt][s] fb[s] - MT A fragments, one B fragment (column tile)
 __device__ __forceinline__ void cot_col(const float (&fa)[1][4], const float (&fb)[4], f32x4 (&W)[1]) {
-    asm("s_nop 1\n\t" G2_MF(0, 5, 1) G2_MF(0, 6, 2) G2_MF(0, 7, 3) G2_MF(0, 8, 4)
+    asm volatile("s_nop 1\n\t" G2_MF(0, 5, 1) G2_MF(0, 6, 2) G2_MF(0, 7, 3) G2_MF(0, 8, 4)
         : "+a"(W[0])
         : "v"(fb[0]), "v"(fb[1]), "v"(fb[2]), "v"(fb[3]), "v"(fa[0][0]), "v"(fa[0][1]), "v"(fa[0][2]), "v"(fa[0][3]));
 }
 __device__ __forceinline__ void cot_col(const float (&fa)[2][4], const float (&fb)[4], f32x4 (&W)[2]) {
-    asm("s_nop 1\n\t" G2_MF(0, 6, 2) G2_MF(1, 10, 2) G2_MF(0, 7, 3) G2_MF(1, 11, 3) G2_MF(0, 8, 4) G2_MF(1, 12, 4) G2_MF(0, 9, 5) G2_MF(1, 13, 5)
+    asm volatile("s_nop 1\n\t" G2_MF(0, 6, 2) G2_MF(1, 10, 2) G2_MF(0, 7, 3) G2_MF(1, 11, 3) G2_MF(0, 8, 4) G2_MF(1, 12, 4) G2_MF(0, 9, 5) G2_MF(1, 13, 5)
         : "+a"(W[0]), "+a"(W[1])
         : "v"(fb[0]), "v"(fb[1]), "v"(fb[2]), "v"(fb[3]), "v"(fa[0][0]), "v"(fa[0][1]), "v"(fa[0][2]), "v"(fa[0][3]), "v"(fa[1][0]), "v"(fa[1][1]), "v"(fa[1][2]), "v"(fa[1][3]));
 }
 __device__ __forceinline__ void cot_col(const float (&fa)[3][4], const float (&fb)[4], f32x4 (&W)[3]) {
-    asm("s_nop 1\n\t" G2_MF(0, 7, 3) G2_MF(1, 11, 3) G2_MF(2, 15, 3) G2_MF(0, 8, 4) G2_MF(1, 12, 4) G2_MF(2, 16, 4) G2_MF(0, 9, 5) G2_MF(1, 13, 5) G2_MF(2, 17, 5) G2_MF(0, 10, 6) G2_MF(1, 14, 6) G2_MF(2, 18, 6)
+    asm volatile("s_nop 1\n\t" G2_MF(0, 7, 3) G2_MF(1, 11, 3) G2_MF(2, 15, 3) G2_MF(0, 8, 4) G2_MF(1, 12, 4) G2_MF(2, 16, 4) G2_MF(0, 9, 5) G2_MF(1, 13, 5) G2_MF(2, 17, 5) G2_MF(0, 10, 6) G2_MF(1, 14, 6) G2_MF(2, 18, 6)
         : "+a"(W[0]), "+a"(W[1]), "+a"(W[2])
         : "v"(fb[0]), "v"(fb[1]), "v"(fb[2]), "v"(fb[3]), "v"(fa[0][0]), "v"(fa[0][1]), "v"(fa[0][2]), "v"(fa[0][3]), "v"(fa[1][0]), "v"(fa[1][1]), "v"(fa[1][2]), "v"(fa[1][3]), "v"(fa[2][0]), "v"(fa[2][1]), "v"(fa[2][2]), "v"(fa[2][3]));
 }
 __device__ __forceinline__ void cot_col(const float (&fa)[4][4], const float (&fb)[4], f32x4 (&W)[4]) {
-    asm("s_nop 1\n\t" G2_MF(0, 8, 4) G2_MF(1, 12, 4) G2_MF(2, 16, 4) G2_MF(3, 20, 4) G2_MF(0, 9, 5) G2_MF(1, 13, 5) G2_MF(2, 17, 5) G2_MF(3, 21, 5) G2_MF(0, 10, 6) G2_MF(1, 14, 6) G2_MF(2, 18, 6) G2_MF(3, 22, 6) G2_MF(0, 11, 7) G2_MF(1, 15, 7) G2_MF(2, 19, 7) G2_MF(3, 23, 7)
+    asm volatile("s_nop 1\n\t" G2_MF(0, 8, 4) G2_MF(1, 12, 4) G2_MF(2, 16, 4) G2_MF(3, 20, 4) G2_MF(0, 9, 5) G2_MF(1, 13, 5) G2_MF(2, 17, 5) G2_MF(3, 21, 5) G2_MF(0, 10, 6) G2_MF(1, 14, 6) G2_MF(2, 18, 6) G2_MF(3, 22, 6) G2_MF(0, 11, 7) G2_MF(1, 15, 7) G2_MF(2, 19, 7) G2_MF(3, 23, 7)
         : "+a"(W[0]), "+a"(W[1]), "+a"(W[2]), "+a"(W[3])
         : "v"(fb[0]), "v"(fb[1]), "v"(fb[2]), "v"(fb[3]), "v"(fa[0][0]), "v"(fa[0][1]), "v"(fa[0][2]), "v"(fa[0][3]), "v"(fa[1][0]), "v"(fa[1][1]), "v"(fa[1][2]), "v"(fa[1][3]), "v"(fa[2][0]), "v"(fa[2][1]), "v"(fa[2][2]), "v"(fa[2][3]), "v"(fa[3][0]), "v"(fa[3][1]), "v"(fa[3][2]), "v"(fa[3][3]));
 }
@@ -89,6 +89,23 @@ __device__ __forceinline__ void cot_block(const float (&fa)[MT][4], const float 
     for (int mt = 0; mt < MT; ++mt) cot_row(fa[mt], fb, W[mt]);
 }
 
+// The transposed fragment reads of cnf_grad_dev.h as four single-dword reads from ONE lane base (a register per access pattern,
+// computed once) with the tile's offset in the 16-bit immediate.  Left to the load/store optimiser they become two ds_read2_b32 whose
+// 8-bit dword offsets cannot reach the next tile, i.e. one v_add per fragment - a VALU instruction in the middle of an MFMA run costs
+// its issue plus a ~9-cycle round trip on gfx950, an LDS instruction in the MFMA's shadow nothing.  (volatile: not merged.)
+typedef __attribute__((address_space(3))) float LdsF;
+__device__ __forceinline__ void read_frag_A1(const float* tile, int lane, float (&f)[4]) {
+    const int i = lane & 15, g = lane >> 4;
+    const volatile LdsF* p = (const volatile LdsF*)(tile + (i >> 2) * 72 + 4 * g + (i & 3));
+#pragma unroll
+    for (int s = 0; s < 4; ++s) f[s] = p[16 * s];
+}
+__device__ __forceinline__ void read_frag_B1(const float* tile, int lane, float (&f)[4]) {
+    const int j = lane & 15, g = lane >> 4;
+    const volatile LdsF* p = (const volatile LdsF*)(tile + (j & 3) * 72 + 4 * g + (j >> 2));
+#pragma unroll
+    for (int s = 0; s < 4; ++s) f[s] = p[16 * s];
+}
 template <int MT>
 __device__ __forceinline__ void frags_A(const float* tiles, int lane, float (&f)[MT][4]) {
 #pragma unroll
@@ -98,6 +115,89 @@ template <int NT>
 __device__ __forceinline__ void frags_B(const float* tiles, int lane, float (&f)[NT][4]) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) read_frag_B(tiles + nt * TS, lane, f[nt]);
+}
+
+
+// what stage st reads of the Runge-Kutta tableau: b_st, c_st, row st of a (its stage state) and column st (the adjoint of the later stages)
+struct StageCoef {
+    float b, c, arow[5], acol[5];
+};
+__device__ __forceinline__ StageCoef stage_coef(const float* tab, int st) {   // tab: the LDS table [6][16] (three uniform ds_read_b128)
+    const f32x4* t = reinterpret_cast<const f32x4*>(tab + st * 16);
+    const f32x4 t0 = t[0], t1 = t[1], t2 = t[2];
+    StageCoef s;
+    s.b = t0[0]; s.c = t0[1];
+    s.arow[0] = t0[2]; s.arow[1] = t0[3]; s.arow[2] = t1[0]; s.arow[3] = t1[1]; s.arow[4] = t1[2];
+    s.acol[0] = t1[3]; s.acol[1] = t2[0]; s.acol[2] = t2[1]; s.acol[3] = t2[2]; s.acol[4] = t2[3];
+    return s;
+}
+
+// Scheduling fence: nothing crosses.  The stage below is laid out by hand as MFMA runs / VALU phases / LDS bursts; left to itself the
+// scheduler sank every fragment load to its first use (one exposed LDS round trip per 16 MFMAs: ~5 k of the 36 k cycles of a stage in
+// the first build of this file, profiles/r5/r5b_cfg2_grad2_phase_trace.txt) and interleaved the activations with the products (f32
+// MFMAs hide no VALU work on gfx950 and every MFMA -> VALU -> MFMA round trip costs ~9 issue cycles, cnf_mfma_kernel.h::phase_fence).
+#define G2_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+// fragments of k-group kg of an A image with KG k-groups: one ds_read_b128 per M-tile - one ds_read_b64 where only NJ <= 2 of the
+// group's k-steps are multiplied (D <= 8: with the full read the compiler overlaps the destination registers of consecutive tiles
+// in their unused halves and serialises the reads behind lgkmcnt(0))
+template <int MT, int NJ = 4>
+__device__ __forceinline__ void afrag(const float* img, int lane, int KG, int kg, f32x4 (&a)[MT]) {
+    const f32x4* A = reinterpret_cast<const f32x4*>(img) + lane;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        if constexpr (NJ <= 2) {
+            const f32x2 v = *reinterpret_cast<const f32x2*>(&A[(mt * KG + kg) * 64]);
+            a[mt] = f32x4{v[0], v[1], 0.f, 0.f};
+        } else {
+            a[mt] = A[(mt * KG + kg) * 64];
+        }
+    }
+}
+
+// gemm_tiles with the fragment loads one k-group AHEAD of the MFMAs that use them: `pre` holds k-group 0 on entry (requested by the
+// previous product); behind the first k-step of the last k-group, k-group 0 of the NEXT product (image nimg, NKG k-groups, NMT tiles)
+// is requested into `npre`.  One wave per SIMD: there is no other wave to cover an LDS round trip.
+// `hook(q)` runs behind the MT MFMAs of k-step q: the place for the few LDS instructions a phase needs besides the fragments - the
+// cotangent operands' tile stores and transposed fragment reads.  A wave issues in order, and the matrix pipe stays busy for 32 cycles
+// behind an MFMA: an LDS or scalar instruction issued in that shadow is free (two ds_read_b128 per gap, MI355X_MICROARCH.md), the same
+// instructions in one burst between two products stop the pipe (40 of them per product in the second build: LDS issue 2.1 k of a
+// stage's 37 k cycles, profiles/r5/r5c_cfg2_grad2_pmc.txt).
+struct NoHook {
+    template <int Q>
+    __device__ __forceinline__ void operator()(std::integral_constant<int, Q>) const {}
+};
+template <int MT, int KS, int NMT, int NKS = 4, typename InT, typename Hook = NoHook>
+__device__ __forceinline__ void gemm_pf(const float* img, int lane, const InT& in, const f32x4 (&pre)[MT], f32x4 (&acc)[MT],
+                                        const float* nimg, int NKG, f32x4 (&npre)[NMT], Hook&& hook = NoHook{}) {
+    constexpr int KG = (KS + 3) / 4;
+    constexpr int LASTJ = KS - 4 * (KG - 1);   // k-steps of the last k-group
+    f32x4 cur[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) cur[mt] = pre[mt];
+    static_for<0, KG>([&](auto kgc) {
+        constexpr int kg = decltype(kgc)::value;
+        f32x4 nxt[MT];
+        static_for<0, 4>([&](auto jc) {
+            constexpr int j = decltype(jc)::value, q = kg * 4 + j;
+            if constexpr (q < KS) {
+                const float b = in(q);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acc[mt] = mfma4(cur[mt][j], b, acc[mt]);
+                G2_FENCE();
+                if constexpr (j == 0) {
+                    if constexpr (kg + 1 < KG) afrag<MT, (kg + 2 == KG ? LASTJ : 4)>(img, lane, KG, kg + 1, nxt);
+                    else if (nimg) afrag<NMT, (NKS < 4 ? NKS : 4)>(nimg, lane, NKG, 0, npre);
+                }
+                hook(std::integral_constant<int, q>{});
+                G2_FENCE();
+            }
+        });
+        if constexpr (kg + 1 < KG) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) cur[mt] = nxt[mt];
+        }
+    });
 }
 
 }  // namespace
@@ -116,6 +216,18 @@ mfma_grad2_kernel(GArgs a) {
         const f32x4* src = reinterpret_cast<const f32x4*>(a.packed);
         f32x4* dst = reinterpret_cast<f32x4*>(smem);
         for (int i = threadIdx.x; i < LAY.total / 4; i += 256) dst[i] = src[i];
+    }
+    // The tableau by stage - [b_st, c_st, a[st][0..4], a[1..5][st]] - in LDS: read per stage at a run-time index, and as SCALAR loads
+    // (kernel-argument segment) those shared the out-of-order lgkmcnt counter with every LDS read of the stage's prologue: each
+    // fragment wait became lgkmcnt(0) and the prologue's twelve LDS reads ran one round trip after the other.
+    if (threadIdx.x < 6 * 16) {
+        const int st = threadIdx.x >> 4, k = threadIdx.x & 15;
+        float v = 0.f;
+        if (k == 0) v = a.T.b[st];
+        else if (k == 1) v = a.T.c[st];
+        else if (k < 7) v = a.T.a[st][k - 2];
+        else if (k < 12) v = a.T.a[k - 6][st];
+        smem[G::TAB + threadIdx.x] = v;
     }
     __syncthreads();   // the only barrier of the kernel
     const int lane = threadIdx.x & 63, g = lane >> 4, n = lane & 15;
@@ -168,67 +280,127 @@ mfma_grad2_kernel(GArgs a) {
 #pragma unroll
             for (int s = 0; s < CR; ++s) { const int f = 4 * s + g; y[s] = f < a.C ? a.ys[sc * a.C + f] : 0.f; }
         }
-        f32x4 cvec[HT], qvec[HT];   // c = W_N^T eps, q = W_1[:,0:D] eps: constant over the solve
+        // c = W_N^T eps: constant over the solve.  (q = W_1[:,0:D] eps is too, but 16 more registers live across every stage spill:
+        // dbar_1 = W_1[:,0:D] gbar is multiplied per stage instead - HT x ZR MFMAs of ~870)
+        f32x4 cvec[HT];
         zero_tiles<HT>(cvec);
-        zero_tiles<HT>(qvec);
         gemm_tiles<HT, ZR>(smem + LAY.bN, lane, RegIn<ZR>{eps}, cvec);
-        gemm_tiles<HT, ZR>(smem + LAY.f1z, lane, RegIn<ZR>{eps}, qvec);
+        // constant over the solve too: the A fragment of eps (Wbar_N += eps cbar^T) and the B fragment of the conditions (Wbar_1's y columns)
+        float fe[1][4], fy[1][4];
+        {
+            f32x4 et = dense_tile<ZR>(eps);
+            tile_store(scr, lane, et);
+            frags_A<1>(scr, lane, fe);
+            fy[0][0] = fy[0][1] = fy[0][2] = fy[0][3] = 0.f;
+            if constexpr (CR > 0) {
+                f32x4 yt = dense_tile<(CR > 0 ? CR : 1)>(y);
+                tile_store(scr + TS, lane, yt);
+                frags_B<1>(scr + TS, lane, fy);
+            }
+        }
 
+        // step checkpoints (z_n and the stage derivatives kz_i, z rows, written by the forward kernel): requested one STEP ahead -
+        // a step opened with an exposed HBM round trip otherwise
+        float zn[ZR], kz[6][ZR];
+        auto load_ckpt = [&](int step, float (&z)[ZR], float (&k)[6][ZR]) {
+#pragma unroll
+            for (int s = 0; s < ZR; ++s) z[s] = a.ckpt[(((long long)step * ntiles + tile) * 64 + lane) * a.ckpt_zr + s];
+#pragma unroll
+            for (int j = 0; j < 6; ++j)
+#pragma unroll
+                for (int s = 0; s < ZR; ++s)
+                    k[j][s] = j < ns ? a.ckpt_k[((((long long)step * ns + j) * ntiles + tile) * 64 + lane) * a.ckpt_zr + s] : 0.f;
+        };
+        load_ckpt(a.nsteps - 1, zn, kz);
 #pragma clang loop unroll(disable)
         for (int step = a.nsteps - 1; step >= 0; --step) {
             float tn = a.t0 + (float)step * dt0, dt = dt0;
             if (a.tgrid) { tn = a.tgrid[step]; dt = a.tgrid[step + 1] - tn; }
-            float zn[ZR];
-#pragma unroll
-            for (int s = 0; s < ZR; ++s) zn[s] = a.ckpt[(((long long)step * ntiles + tile) * 64 + lane) * a.ckpt_zr + s];
-            // stage derivatives kz_i (z rows), checkpointed by the forward kernel
-            float kz[6][ZR];
-#pragma unroll
-            for (int j = 0; j < 6; ++j)
-#pragma unroll
-                for (int s = 0; s < ZR; ++s) kz[j][s] = 0.f;
-#pragma unroll
-            for (int j = 0; j < 6; ++j)
-                if (j < ns) {
-#pragma unroll
-                    for (int s = 0; s < ZR; ++s)
-                        kz[j][s] = a.ckpt_k[((((long long)step * ns + j) * ntiles + tile) * 64 + lane) * a.ckpt_zr + s];
-                }
+            float zn_nx[ZR], kz_nx[6][ZR];
+            load_ckpt(step > 0 ? step - 1 : 0, zn_nx, kz_nx);
             float Zb[6][ZR];
 #pragma unroll
             for (int j = 0; j < 6; ++j)
 #pragma unroll
                 for (int s = 0; s < ZR; ++s) Zb[j][s] = 0.f;
+            // the tableau entries of a stage are read at a run-time index: requested one stage ahead
+            StageCoef sc_cur = stage_coef(smem + G::TAB, ns - 1);
 #pragma clang loop unroll(disable)
             for (int st = ns - 1; st >= 0; --st) {
 #ifdef G2_TRACE
                 unsigned long long tr[16];
 #endif
                 G2_T(0);
+                const StageCoef sc_nxt = stage_coef(smem + G::TAB, st > 0 ? st - 1 : 0);
                 float zs[ZR], kbar[ZR];
-                const float bi = a.T.b[st];
+                const float bi = sc_cur.b;
 #pragma unroll
                 for (int s = 0; s < ZR; ++s) {
                     float acc = 0.f, kb = bi * lam[s];
 #pragma unroll
-                    for (int j = 0; j < 5; ++j) acc = fmaf(a.T.a[st][j], kz[j][s], acc);
+                    for (int j = 0; j < 5; ++j) acc = fmaf(sc_cur.arow[j], kz[j][s], acc);
 #pragma unroll
-                    for (int j = 1; j < 6; ++j) kb = fmaf(a.T.a[j][st], Zb[j][s], kb);   // a[j][st] != 0 only for j > st
+                    for (int j = 1; j < 6; ++j) kb = fmaf(sc_cur.acol[j - 1], Zb[j][s], kb);   // a[j][st] != 0 only for j > st
                     zs[s] = fmaf(dt, acc, zn[s]);
                     kbar[s] = dt * kb;
                 }
                 const float cl = valid ? dt * bi : 0.f;   // cotangent of ldot: dL/d(dlogp) = +1
                 const float cE = cl * a.lam1, cn = cl * a.lam2;   // cotangents of Edot, ndot
                 const bool regz = a.lam1 != 0.f, regj = a.lam2 != 0.f;   // wave-uniform
-                const float tt = tn + a.T.c[st] * dt;
+                const float tt = tn + sc_cur.c * dt;
                 int opaque = 0;
                 asm volatile("" : "+v"(opaque));
                 const float* sm = smem + opaque;
                 float* sc0 = scr + opaque;
+                float* const sE = sc0 + (NH + 1) * HT * TS;   // the "early" slots behind delta_{l+1} (NH groups of HT tiles) and ubar (HT)
+                auto IMG_F = [&](int l) { return sm + LAY.fh + l * MfmaLayout::imgA(HT, HT); };   // W_{l+2}
+                auto IMG_B = [&](int l) { return sm + LAY.bh + l * MfmaLayout::imgA(HT, HT); };   // W_{l+2}^T
+                const float* const no_img = nullptr;
 
-                // (1) recompute the forward chain
-                f32x4 h[L][HT], d[L][HT];
-                grad_forward<HT, L, ZR, CR, ACT>(sm, lane, tt, autonomous, zs, y, h, d);
+                // ---- prologue: layer-1 fragments and bias requested
+                f32x4 nf[HT], nz[1], acc[HT];
+                afrag<HT, (ZR < 4 ? ZR : 4)>(sm + LAY.f1z, lane, LAY.KGZ, 0, nf);
+                load_cvec<HT>(sm + LAY.v_b1, g, acc);
+                f32x4 wt[HT];
+                if (!autonomous) load_cvec<HT>(sm + LAY.v_w1t, g, wt);
+                if (!autonomous) {
+#pragma unroll
+                    for (int mt = 0; mt < HT; ++mt) acc[mt] += wt[mt] * tt;
+                }
+                G2_FENCE();
+                // ---- (1) recompute the forward chain: h_l, act'_l
+                // (tanh: act' = 1 - h^2 is re-derived from h at each of its three uses - 24 packed FMAs a stage for 48 registers that
+                //  otherwise spill around the bottom-up products; softplus keeps its act' = sigmoid)
+                constexpr bool KEEP_D = ACT != CNF_ACT_TANH;
+                f32x4 h[L][HT], d[KEEP_D ? L : 1][HT];
+                // (`one` is an opaque 1.0 of the calling phase: with a literal the three derivations are one common subexpression
+                //  and the value is kept alive after all)
+                auto dact = [&](int l, int mt, float one) -> f32x4 {
+                    if constexpr (KEEP_D) return d[l][mt];
+                    else return __builtin_elementwise_fma(-h[l][mt], h[l][mt], f32x4{one, one, one, one});
+                };
+                auto opaque_one = [&]() { float o = 1.f; asm volatile("" : "+v"(o)); return o; };
+                gemm_pf<HT, ZR, HT>(sm + LAY.f1z, lane, RegIn<ZR>{zs}, nf, acc, no_img, 0, nf);
+                if constexpr (CR > 0) gemm_tiles<HT, CR>(sm + LAY.f1y, lane, RegIn<CR>{y}, acc);
+                static_for<0, L>([&](auto lc) {
+                    constexpr int l = decltype(lc)::value;
+                    f32x4 accn[HT];
+                    if constexpr (l + 1 < L) { afrag<HT>(IMG_F(l), lane, HT, 0, nf); load_cvec<HT>(sm + LAY.v_bh + l * MfmaLayout::vecC(HT), g, accn); }
+                    else afrag<HT>(IMG_B(NH - 1), lane, HT, 0, nf);   // the first pullback product
+                    G2_FENCE();
+#pragma unroll
+                    for (int mt = 0; mt < HT; ++mt) {
+                        f32x4 dd;
+                        act_tile<ACT>(acc[mt], h[l][mt], dd);
+                        if constexpr (KEEP_D) d[l][mt] = dd;
+                    }
+                    G2_FENCE();
+                    if constexpr (l + 1 < L) {
+                        gemm_pf<HT, 4 * HT, HT>(IMG_F(l), lane, TileIn<HT>{h[l]}, nf, accn, no_img, 0, nf);
+#pragma unroll
+                        for (int mt = 0; mt < HT; ++mt) acc[mt] = accn[mt];
+                    }
+                });
                 G2_T(1);
                 if (regz) {   // Edot = |zdot|: kbar += c_E zdot / |zdot|
                     f32x4 zacc[DT];
@@ -242,19 +414,39 @@ mfma_grad2_kernel(GArgs a) {
 #pragma unroll
                     for (int s = 0; s < ZR; ++s) kbar[s] = fmaf(inv, zacc[s >> 2][s & 3], kbar[s]);
                 }
-                // (2) first-order pullback; delta_{l+1} (l >= 1) goes to scratch slot group l - 1 as it appears: the A operand of
-                //     Wbar_{l+1}'s second term
-                f32x4 u[NH > 0 ? NH : 1][HT], dl[HT];
+                // ---- (2) first-order pullback.  LDS traffic in the products' shadows: delta_{l+1} (l >= 1) goes to scratch group l - 1 while
+                //      it is being multiplied (the A operand of Wbar_{l+1}'s second term); the first product also carries h_L and kbar
+                //      out and their fragments back, and Wbar_N += kbar h_L^T rides behind it
+                float fhL[HT][4], fk[1][4];
+                f32x4 u[NH][HT], dl[HT];
+                const float one_p = opaque_one();
 #pragma unroll
-                for (int mt = 0; mt < HT; ++mt) dl[mt] = cvec[mt] * d[L - 1][mt];
-#pragma unroll
-                for (int l = L - 1; l >= 1; --l) {
-                    tiles_store<HT>(sc0 + (l - 1) * HT * TS, lane, dl);
+                for (int mt = 0; mt < HT; ++mt) dl[mt] = cvec[mt] * dact(L - 1, mt, one_p);
+                const f32x4 kt = dense_tile<ZR>(kbar);
+                static_for<0, NH>([&](auto lc) {
+                    constexpr int l = L - 1 - decltype(lc)::value;   // L-1 .. 1
+                    G2_FENCE();
                     zero_tiles<HT>(u[l - 1]);
-                    gemm_tiles<HT, 4 * HT>(sm + LAY.bh + (l - 1) * MfmaLayout::imgA(HT, HT), lane, TileIn<HT>{dl}, u[l - 1]);
+                    gemm_pf<HT, 4 * HT, HT, (l > 1 ? 4 : ZR)>(IMG_B(l - 1), lane, TileIn<HT>{dl}, nf, u[l - 1], l > 1 ? IMG_B(l > 1 ? l - 2 : 0) : sm + LAY.f1z, l > 1 ? HT : LAY.KGZ, nf,
+                                            [&](auto qc) {
+                                                constexpr int q = decltype(qc)::value;
+                                                if constexpr (q < HT) tile_store(sc0 + ((l - 1) * HT + q) * TS, lane, dl[q]);
+                                                if constexpr (l == L - 1) {
+                                                    if constexpr (q >= HT && q < 2 * HT) tile_store(sE + (q - HT) * TS, lane, h[L - 1][q - HT]);
+                                                    if constexpr (q >= 2 * HT && q < 3 * HT) read_frag_B1(sE + (q - 2 * HT) * TS, lane, fhL[q - 2 * HT]);
+                                                    if constexpr (q == HT) tile_store(sc0 + NH * HT * TS, lane, kt);   // (ubar's slot: free until the bottom-up pass)
+                                                    if constexpr (q == 2 * HT) read_frag_A1(sc0 + NH * HT * TS, lane, fk[0]);
+                                                }
+                                            });
+                    if constexpr (l == L - 1) {
+                        cot_row(fk[0], fhL, WNacc[0]);
 #pragma unroll
-                    for (int mt = 0; mt < HT; ++mt) dl[mt] = u[l - 1][mt] * d[l - 1][mt];
-                }
+                        for (int s = 0; s < ZR; ++s) bN[s] += kbar[s];
+                    }
+                    G2_FENCE();
+#pragma unroll
+                    for (int mt = 0; mt < HT; ++mt) dl[mt] = u[l - 1][mt] * dact(l - 1, mt, one_p);
+                });
                 G2_T(2);
                 // gbar = cotangent of g = eps^T J (dense layout): -c_l eps (+ c_n g/|g|);  dbar_1 = W_1[:,0:D] gbar
                 float gbar[ZR];
@@ -272,130 +464,138 @@ mfma_grad2_kernel(GArgs a) {
                     const float inv = n2 > 0.f ? cn * rsqrtf(n2) : 0.f;
 #pragma unroll
                     for (int s = 0; s < ZR; ++s) gbar[s] = fmaf(inv, gacc[s >> 2][s & 3], gbar[s]);
-                    zero_tiles<HT>(db);
-                    gemm_tiles<HT, ZR>(sm + LAY.f1z, lane, RegIn<ZR>{gbar}, db);
-                } else {
-#pragma unroll
-                    for (int mt = 0; mt < HT; ++mt) db[mt] = qvec[mt] * (-cl);                // = W_1[:,0:D] (-c_l eps)
                 }
-                // (3) bottom-up through the pullback; Wbar_{l+2} += delta_{l+1} ubar_l^T beside the product that consumes ubar_l
-                f32x4 dl0[HT];
-#pragma unroll
-                for (int mt = 0; mt < HT; ++mt) dl0[mt] = dl[mt];
-#pragma unroll
-                for (int l = 0; l < NH; ++l) {
+                // ---- (3) bottom-up through the pullback; Wbar_{l+2} += delta_{l+2} ubar_l^T behind the product that consumes ubar_l.
+                //      delta_1 waits in the early slots for the stage's last phase (Wbar_1 += delta_1 [gbar; 0]^T)
+                const float one_b = opaque_one();
+                tiles_store<HT>(sE, lane, dl);
+                G2_FENCE();
+                zero_tiles<HT>(db);
+                gemm_pf<HT, ZR, HT>(sm + LAY.f1z, lane, RegIn<ZR>{gbar}, nf, db, IMG_F(0), HT, nf);   // dbar_1 = W_1[:,0:D] gbar
+                float* const sU = sc0 + NH * HT * TS;   // ubar_l, then cbar
+                static_for<0, NH>([&](auto lc) {
+                    constexpr int l = decltype(lc)::value;
                     f32x4 ubs[HT];
 #pragma unroll
-                    for (int mt = 0; mt < HT; ++mt) { ubs[mt] = db[mt] * d[l][mt]; a2[l][mt] = db[mt] * u[l][mt]; }
-                    float* sb = sc0 + NH * HT * TS;
-                    tiles_store<HT>(sb, lane, ubs);
+                    for (int mt = 0; mt < HT; ++mt) { ubs[mt] = db[mt] * dact(l, mt, one_b); a2[l][mt] = db[mt] * u[l][mt]; }
                     float fa[HT][4], fb[HT][4];
-                    frags_A<HT>(sc0 + l * HT * TS, lane, fa);
-                    frags_B<HT>(sb, lane, fb);
+                    G2_FENCE();
                     zero_tiles<HT>(db);
-                    gemm_tiles<HT, 4 * HT>(sm + LAY.fh + l * MfmaLayout::imgA(HT, HT), lane, TileIn<HT>{ubs}, db);   // W_{l+2} ubar_l
+                    gemm_pf<HT, 4 * HT, HT, (l + 1 < NH ? 4 : ZR)>(IMG_F(l), lane, TileIn<HT>{ubs}, nf, db, l + 1 < NH ? IMG_F(l + 1 < NH ? l + 1 : 0) : sm + LAY.bN, l + 1 < NH ? HT : LAY.KGZ, nf,
+                                            [&](auto qc) {
+                                                constexpr int q = decltype(qc)::value;
+                                                if constexpr (q >= 1 && q <= HT) tile_store(sU + (q - 1) * TS, lane, ubs[q - 1]);
+                                                if constexpr (q > HT && q <= 2 * HT) read_frag_A1(sc0 + (l * HT + q - HT - 1) * TS, lane, fa[q - HT - 1]);
+                                                if constexpr (q > 2 * HT && q <= 3 * HT) read_frag_B1(sU + (q - 2 * HT - 1) * TS, lane, fb[q - 2 * HT - 1]);
+                                            });
                     cot_block<HT, HT>(fa, fb, Wh[l]);
-                }
+                    G2_FENCE();
+                });
                 G2_T(3);
-                f32x4 cb[HT];   // cbar = dbar_L .* act'_L: Wbar_N[i, f] += eps_i cbar_f
-#pragma unroll
-                for (int mt = 0; mt < HT; ++mt) { cb[mt] = db[mt] * d[L - 1][mt]; a2[L - 1][mt] = db[mt] * cvec[mt]; }
-                // (4) top-down through the forward chain
-                {   // Wbar_N += eps cbar^T + kbar h_L^T;  bbar_N += kbar
-                    f32x4 et[1], kt[1];
-                    et[0] = dense_tile<ZR>(eps);
-                    kt[0] = dense_tile<ZR>(kbar);
-                    tile_store(sc0 + 0 * TS, lane, et[0]);
-                    tile_store(sc0 + 1 * TS, lane, kt[0]);
-                    tiles_store<HT>(sc0 + 2 * TS, lane, cb);
-                    tiles_store<HT>(sc0 + (2 + HT) * TS, lane, h[L - 1]);
-                    float fe[1][4], fk[1][4], fc[HT][4], fh[HT][4];
-                    frags_A<1>(sc0 + 0 * TS, lane, fe);
-                    frags_A<1>(sc0 + 1 * TS, lane, fk);
-                    frags_B<HT>(sc0 + 2 * TS, lane, fc);
-                    frags_B<HT>(sc0 + (2 + HT) * TS, lane, fh);
-                    cot_row(fe[0], fc, WNacc[0]);
-                    cot_row(fk[0], fh, WNacc[0]);
-#pragma unroll
-                    for (int s = 0; s < ZR; ++s) bN[s] += kbar[s];
-                }
+                // ---- (4) top-down through the forward chain
                 f32x4 hb[HT];
-                zero_tiles<HT>(hb);
-                gemm_tiles<HT, ZR>(sm + LAY.bN, lane, RegIn<ZR>{kbar}, hb);   // W_N^T kbar
+                float fc[HT][4];
+                {   // cbar = dbar_L .* act'_L;  hbar_L = W_N^T kbar carries cbar out; Wbar_N += eps cbar^T is taken behind the next product
+                    f32x4 cb[HT];
+#pragma unroll
+                    for (int mt = 0; mt < HT; ++mt) { cb[mt] = db[mt] * dact(L - 1, mt, one_b); a2[L - 1][mt] = db[mt] * cvec[mt]; }
+                    G2_FENCE();
+                    zero_tiles<HT>(hb);
+                    gemm_pf<HT, ZR, HT>(sm + LAY.bN, lane, RegIn<ZR>{kbar}, nf, hb, IMG_B(NH - 1), HT, nf,
+                                        [&](auto qc) {
+                                            constexpr int q = decltype(qc)::value;
+                                            constexpr int per = (HT + ZR - 1) / ZR;   // cbar's HT tiles over the product's ZR k-steps
+#pragma unroll
+                                            for (int mt = q * per; mt < (q + 1) * per && mt < HT; ++mt) tile_store(sU + mt * TS, lane, cb[mt]);
+                                        });
+                }
                 G2_T(4);
                 float Zbar[ZR];
-#pragma unroll
-                for (int l = L - 1; l >= 0; --l) {
+                const float one_t = opaque_one();
+                static_for<0, L>([&](auto lc) {
+                    constexpr int l = L - 1 - decltype(lc)::value;   // L-1 .. 0
                     f32x4 ab[HT];
 #pragma unroll
                     for (int mt = 0; mt < HT; ++mt) {
-                        // act'': tanh -> -2 h (1 - h^2);  softplus -> s (1 - s) with s = act' = sigmoid(a)
-                        const f32x4 d2 = ACT == CNF_ACT_TANH ? h[l][mt] * d[l][mt] * -2.f : d[l][mt] * (1.f - d[l][mt]);
-                        ab[mt] = hb[mt] * d[l][mt] + a2[l][mt] * d2;
+                        // abar = hbar .* act' + a2 .* act'';  act'': tanh -> -2 h act', so abar = act' .* (hbar - 2 h .* a2);
+                        // softplus -> s (1 - s) with s = act' = sigmoid(a)
+                        const f32x4 d1 = dact(l, mt, one_t);
+                        if constexpr (ACT == CNF_ACT_TANH) ab[mt] = d1 * __builtin_elementwise_fma(h[l][mt] * a2[l][mt], f32x4{-2.f, -2.f, -2.f, -2.f}, hb[mt]);
+                        else ab[mt] = hb[mt] * d1 + a2[l][mt] * (d1 * (1.f - d1));
                     }
-                    if (l > 0) {
+                    if constexpr (l > 0) {
                         // Wbar_{l+1} += abar_l h_{l-1}^T;  bbar_{l+1} += row sums of abar_l;  hbar_{l-1} = W_{l+1}^T abar_l
-                        tiles_store<HT>(sc0, lane, ab);
-                        tiles_store<HT>(sc0 + HT * TS, lane, h[l - 1]);
+                        if constexpr (l == L - 1) G2_T(10);
                         float fa[HT][4], fb[HT][4];
-                        frags_A<HT>(sc0, lane, fa);
-                        frags_B<HT>(sc0 + HT * TS, lane, fb);
+                        auto operands = [&](auto qc) {
+                            constexpr int q = decltype(qc)::value;
+                            if constexpr (q < HT) tile_store(sc0 + q * TS, lane, ab[q]);
+                            else if constexpr (q < 2 * HT) tile_store(sc0 + q * TS, lane, h[l - 1][q - HT]);
+                            else if constexpr (q < 3 * HT) read_frag_A1(sc0 + (q - 2 * HT) * TS, lane, fa[q - 2 * HT]);
+                            else read_frag_B1(sc0 + (q - 2 * HT) * TS, lane, fb[q - 3 * HT]);
+                            if constexpr (l == L - 1 && q >= 2 * HT && q < 3 * HT) read_frag_B1(sU + (q - 2 * HT) * TS, lane, fc[q - 2 * HT]);
+                        };
+                        G2_FENCE();
                         zero_tiles<HT>(hb);
-                        gemm_tiles<HT, 4 * HT>(sm + LAY.bh + (l - 1) * MfmaLayout::imgA(HT, HT), lane, TileIn<HT>{ab}, hb);
+                        if constexpr (l > 1) gemm_pf<HT, 4 * HT, HT>(IMG_B(l - 1), lane, TileIn<HT>{ab}, nf, hb, IMG_B(l > 1 ? l - 2 : 0), HT, nf, operands);
+                        else gemm_pf<HT, 4 * HT, 1>(IMG_B(l - 1), lane, TileIn<HT>{ab}, nf, hb, sm + LAY.b1, HT, nz, operands);
+                        if constexpr (l == L - 1) G2_T(11);
+                        cot_block<HT, HT>(fa, fb, Wh[l - 1]);
+                        if constexpr (l == L - 1) cot_row(fe[0], fc, WNacc[0]);   // Wbar_N += eps cbar^T
+                        G2_FENCE();
+                        if constexpr (l == L - 1) G2_T(12);
 #pragma unroll
                         for (int mt = 0; mt < HT; ++mt) bh[l - 1][mt] += (fa[mt][0] + fa[mt][1]) + (fa[mt][2] + fa[mt][3]);
-                        cot_block<HT, HT>(fa, fb, Wh[l - 1]);
                     } else {
-                        // input pseudo tile [z (D rows); t; ...; 1 at feature 15]: feature j <-> (register j>>2, lane group j&3)
+                        // Wbar_1 += abar_1 [z; t; 1]^T + delta_1 [gbar; 0]^T (+ abar_1 y^T);  Zbar = W_1[:,0:D]^T abar_1
+                        // input pseudo tile [z (D rows); t; 0 ...; 1 at feature 15]: feature j <-> (register j>>2, lane group j&3)
                         f32x4 in_tile;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            float v = r < ZR ? zs[r < ZR ? r : 0] : 0.f;
-                            if (!autonomous && 4 * r + g == D) v = tt;
-                            if (4 * r + g > D || (autonomous && 4 * r + g == D)) v = 0.f;
-                            if (4 * r + g == 15) v = 1.f;
-                            in_tile[r] = v;
+                            const int f = 4 * r + g;
+                            const float zv = r < ZR ? zs[r < ZR ? r : 0] : 0.f;
+                            const float tv = (!autonomous && f == D) ? tt : (f == 15 ? 1.f : 0.f);
+                            in_tile[r] = f < D ? zv : tv;
                         }
-                        // Wbar_1 += abar_1 [z; t; 1]^T + delta_1 [gbar; 0]^T (+ abar_1 y^T)
-                        f32x4 gt[1];
-                        gt[0] = dense_tile<ZR>(gbar);
-                        tiles_store<HT>(sc0, lane, ab);
-                        tiles_store<HT>(sc0 + HT * TS, lane, dl0);
-                        tile_store(sc0 + (2 * HT + 0) * TS, lane, in_tile);
-                        tile_store(sc0 + (2 * HT + 1) * TS, lane, gt[0]);
+                        const f32x4 gt = dense_tile<ZR>(gbar);
+                        // free slots by now: [HT, 2 HT) of the top-down pair; with one hidden tile ubar's slot (three hidden layers) or the
+                        // early slot behind delta_1 (two)
+                        constexpr int GT_SLOT = HT >= 2 ? HT + 1 : (NH == 2 ? 2 : 3);
                         float fa[HT][4], fd[HT][4], fi[1][4], fg[1][4];
-                        frags_A<HT>(sc0, lane, fa);
-                        frags_A<HT>(sc0 + HT * TS, lane, fd);
-                        frags_B<1>(sc0 + (2 * HT + 0) * TS, lane, fi);
-                        frags_B<1>(sc0 + (2 * HT + 1) * TS, lane, fg);
+                        G2_FENCE();
                         f32x4 zb[DT];
                         zero_tiles<DT>(zb);
-                        gemm_tiles<DT, 4 * HT>(sm + LAY.b1, lane, TileIn<HT>{ab}, zb);   // W_1[:,0:D]^T abar_1
-                        cot_col(fa, fi[0], W1in);
+                        // 4 HT k-steps of one MFMA each: abar_1 out (HT), in_tile and gbar out, then the fragments of abar_1, delta_1 (early
+                        // slots), in_tile and gbar
+                        gemm_pf<DT, 4 * HT, 1>(sm + LAY.b1, lane, TileIn<HT>{ab}, nz, zb, no_img, 0, nz,
+                                               [&](auto qc) {
+                                                   constexpr int q = decltype(qc)::value;
+                                                   if constexpr (q < HT) tile_store(sc0 + q * TS, lane, ab[q]);
+                                                   if constexpr (q == HT) { tile_store(sc0 + HT * TS, lane, in_tile); tile_store(sc0 + GT_SLOT * TS, lane, gt); }
+                                                   if constexpr (q > HT && q <= 2 * HT) read_frag_A1(sE + (q - HT - 1) * TS, lane, fd[q - HT - 1]);
+                                                   if constexpr (q > 2 * HT && q <= 3 * HT) read_frag_A1(sc0 + (q - 2 * HT - 1) * TS, lane, fa[q - 2 * HT - 1]);
+                                                   if constexpr (q == (HT >= 2 ? 3 * HT + 1 : 3 * HT)) { read_frag_B1(sc0 + HT * TS, lane, fi[0]); read_frag_B1(sc0 + GT_SLOT * TS, lane, fg[0]); }
+                                               });
                         cot_col(fd, fg[0], W1in);
-                        if constexpr (CR > 0) {
-                            f32x4 yt[1];
-                            yt[0] = dense_tile<(CR > 0 ? CR : 1)>(y);
-                            tile_store(sc0 + (2 * HT + 2) * TS, lane, yt[0]);
-                            float fy[1][4];
-                            frags_B<1>(sc0 + (2 * HT + 2) * TS, lane, fy);
-                            cot_col(fa, fy[0], W1y);
-                        }
+                        cot_col(fa, fi[0], W1in);
+                        if constexpr (CR > 0) cot_col(fa, fy[0], W1y);
+                        G2_FENCE();
 #pragma unroll
                         for (int s = 0; s < ZR; ++s) Zbar[s] = zb[s >> 2][s & 3];
                     }
                     G2_T(5 + (L - 1 - l));
-                }
+                });
 #pragma unroll
                 for (int j = 0; j < 6; ++j)
 #pragma unroll
                     for (int s = 0; s < ZR; ++s) Zb[j][s] = (j == st) ? Zbar[s] : Zb[j][s];
+                sc_cur = sc_nxt;
 #ifdef G2_TRACE
                 G2_T(5 + L);
                 if (blockIdx.x == 3 && step == 5 && st == 1 && lane == 0 && tile == (long long)blockIdx.x * 4 + wave) {
                     printf("w%d: fwd %d pull %d up %d WN %d", wave, (int)(tr[1] - tr[0]), (int)(tr[2] - tr[1]), (int)(tr[3] - tr[2]), (int)(tr[4] - tr[3]));
                     for (int k = 5; k <= 5 + L; ++k) printf(" %d", (int)(tr[k] - tr[k - 1]));
-                    printf(" | total %d\n", (int)(tr[5 + L] - tr[0]));
+                    printf(" | total %d | top: ew %d prod %d cot %d\n", (int)(tr[5 + L] - tr[0]), (int)(tr[10] - tr[4]), (int)(tr[11] - tr[10]), (int)(tr[12] - tr[11]));
                 }
 #endif
             }
@@ -405,6 +605,9 @@ mfma_grad2_kernel(GArgs a) {
 #pragma unroll
                 for (int j = 0; j < 6; ++j) acc += Zb[j][s];
                 lam[s] = acc;
+                zn[s] = zn_nx[s];
+#pragma unroll
+                for (int j = 0; j < 6; ++j) kz[j][s] = kz_nx[j][s];
             }
         }
         if (a.grad_x && valid) {   // costate at t0 = dL/dz_0; its first nvars rows are dL/dx

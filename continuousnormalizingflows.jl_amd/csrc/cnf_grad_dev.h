@@ -84,7 +84,8 @@ struct GradLds {   // float offsets inside dynamic LDS: operand image, then per-
     static constexpr int XCH = SCR;
     static constexpr int XCH_TILES = 4 * HT > 2 * HT + 3 ? 4 * HT : 2 * HT + 3;
     static constexpr int XCH_W = XCH_TILES * TS;
-    static constexpr int TOTAL = XCH + 4 * XCH_W;
+    static constexpr int TAB = XCH + 4 * XCH_W;     // cnf_grad2.hip: the Runge-Kutta tableau by stage, 6 x 16 floats
+    static constexpr int TOTAL = TAB + 6 * 16;
 };
 template <int HT, int L, int ZR, int CR>
 struct GradSlab {  // float offsets inside one wave's slab; every image is [mt][nt][lane][4] (accumulator layout)
