@@ -93,6 +93,30 @@ __device__ __forceinline__ void cot_block(const float (&fa)[MT][4], const float 
 // computed once) with the tile's offset in the 16-bit immediate.  Left to the load/store optimiser they become two ds_read2_b32 whose
 // 8-bit dword offsets cannot reach the next tile, i.e. one v_add per fragment - a VALU instruction in the middle of an MFMA run costs
 // its issue plus a ~9-cycle round trip on gfx950, an LDS instruction in the MFMA's shadow nothing.  (volatile: not merged.)
+// tanh of one accumulator tile WITHOUT its derivative (act_tile's asm always computes both; this kernel re-derives act' = 1 - h^2
+// where it is used): 2 / (1 + exp(-2 a)) - 1 with bare v_exp / v_rcp and the affine steps on register pairs
+__device__ __forceinline__ void tanh_tile_h(const f32x4& a, f32x4& h) {
+    const f32x2 x0 = f32x2{a[0], a[1]} * kTanhPrescale, x1 = f32x2{a[2], a[3]} * kTanhPrescale;
+    f32x2 e0 = {__builtin_amdgcn_exp2f(x0[0]), __builtin_amdgcn_exp2f(x0[1])};
+    f32x2 e1 = {__builtin_amdgcn_exp2f(x1[0]), __builtin_amdgcn_exp2f(x1[1])};
+    pk_add1(e0, e1);
+    const f32x2 r0 = {fast_rcp(e0[0]), fast_rcp(e0[1])}, r1 = {fast_rcp(e1[0]), fast_rcp(e1[1])};
+    f32x2 h0, h1;
+    asm volatile("s_nop 0\n\t"
+                 "v_pk_fma_f32 %0, %2, 2.0, -1.0 op_sel_hi:[1,0,0]\n\t"
+                 "v_pk_fma_f32 %1, %3, 2.0, -1.0 op_sel_hi:[1,0,0]"
+                 : "=&v"(h0), "=&v"(h1) : "v"(r0), "v"(r1));
+    h = f32x4{h0[0], h0[1], h1[0], h1[1]};
+}
+// one - h .* h on register pairs, the negation as an operand modifier (the vector expression compiled to a v_xor per pair)
+__device__ __forceinline__ f32x4 one_minus_sq(const f32x4& h, float one) {
+    const f32x2 lo = {h[0], h[1]}, hi = {h[2], h[3]}, o = {one, one};
+    f32x2 d0, d1;
+    asm("v_pk_fma_f32 %0, %2, %2, %4 neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+        "v_pk_fma_f32 %1, %3, %3, %4 neg_lo:[1,0,0] neg_hi:[1,0,0]"
+        : "=&v"(d0), "=&v"(d1) : "v"(lo), "v"(hi), "v"(o));
+    return f32x4{d0[0], d0[1], d1[0], d1[1]};
+}
 typedef __attribute__((address_space(3))) float LdsF;
 __device__ __forceinline__ void read_frag_A1(const float* tile, int lane, float (&f)[4]) {
     const int i = lane & 15, g = lane >> 4;
@@ -377,7 +401,7 @@ mfma_grad2_kernel(GArgs a) {
                 //  and the value is kept alive after all)
                 auto dact = [&](int l, int mt, float one) -> f32x4 {
                     if constexpr (KEEP_D) return d[l][mt];
-                    else return __builtin_elementwise_fma(-h[l][mt], h[l][mt], f32x4{one, one, one, one});
+                    else return one_minus_sq(h[l][mt], one);
                 };
                 auto opaque_one = [&]() { float o = 1.f; asm volatile("" : "+v"(o)); return o; };
                 gemm_pf<HT, ZR, HT>(sm + LAY.f1z, lane, RegIn<ZR>{zs}, nf, acc, no_img, 0, nf);
@@ -390,9 +414,8 @@ mfma_grad2_kernel(GArgs a) {
                     G2_FENCE();
 #pragma unroll
                     for (int mt = 0; mt < HT; ++mt) {
-                        f32x4 dd;
-                        act_tile<ACT>(acc[mt], h[l][mt], dd);
-                        if constexpr (KEEP_D) d[l][mt] = dd;
+                        if constexpr (KEEP_D) act_tile<ACT>(acc[mt], h[l][mt], d[l][mt]);
+                        else tanh_tile_h(acc[mt], h[l][mt]);
                     }
                     G2_FENCE();
                     if constexpr (l + 1 < L) {
@@ -533,7 +556,8 @@ mfma_grad2_kernel(GArgs a) {
                             else if constexpr (q < 2 * HT) tile_store(sc0 + q * TS, lane, h[l - 1][q - HT]);
                             else if constexpr (q < 3 * HT) read_frag_A1(sc0 + (q - 2 * HT) * TS, lane, fa[q - 2 * HT]);
                             else read_frag_B1(sc0 + (q - 2 * HT) * TS, lane, fb[q - 3 * HT]);
-                            if constexpr (l == L - 1 && q >= 2 * HT && q < 3 * HT) read_frag_B1(sU + (q - 2 * HT) * TS, lane, fc[q - 2 * HT]);
+                            // cbar's fragments first: with one hidden matrix its slot is the one h_{l-1} is about to take
+                            if constexpr (l == L - 1 && q < HT) read_frag_B1(sU + q * TS, lane, fc[q]);
                         };
                         G2_FENCE();
                         zero_tiles<HT>(hb);
@@ -656,9 +680,20 @@ struct Grad2Inst {
     GradKernel kern;
 };
 #define G2_INST(HT, L, ZR, CR, ACT) Grad2Inst { HT, L, ZR, CR, ACT, &mfma_grad2_kernel<HT, L, ZR, CR, ACT> }
-static const Grad2Inst kGrad2[] = {
-    G2_INST(4, 3, 2, 0, CNF_ACT_TANH),
-};
+// the shapes of cnf_grad.hip's table (kGrad): 1 .. 4 hidden tiles, 2 / 3 hidden layers, D <= 8 / 16, with and without conditions
+#define G2_HT(HT, CR, ACT) G2_INST(HT, 3, 2, CR, ACT), G2_INST(HT, 2, 2, CR, ACT), G2_INST(HT, 3, 4, CR, ACT), G2_INST(HT, 2, 4, CR, ACT)
+#define G2_SHAPES(CR, ACT) G2_HT(1, CR, ACT), G2_HT(2, CR, ACT), G2_HT(3, CR, ACT), G2_HT(4, CR, ACT)
+#ifdef G2_ONLY
+static const Grad2Inst kGrad2[] = {G2_ONLY};
+#else
+// (4 tiles, 3 layers, D > 8, softplus, no conditions) crashes this compiler's AGPR-copy rewrite pass (softplus keeps act' beside h:
+// the most registers of the table) and stays on cnf_grad.hip's kernel; the other (4, 3, ..) instances with D > 8 or softplus spill
+// 7 .. 84 registers outside the products' inner loops (per-instance audit: profiles/r5/r5g_grad2_instances.txt)
+#define G2_HT4_SOFTPLUS_NOCOND G2_INST(4, 3, 2, 0, CNF_ACT_SOFTPLUS), G2_INST(4, 2, 2, 0, CNF_ACT_SOFTPLUS), G2_INST(4, 2, 4, 0, CNF_ACT_SOFTPLUS)
+static const Grad2Inst kGrad2[] = {G2_SHAPES(0, CNF_ACT_TANH),
+                                   G2_HT(1, 0, CNF_ACT_SOFTPLUS), G2_HT(2, 0, CNF_ACT_SOFTPLUS), G2_HT(3, 0, CNF_ACT_SOFTPLUS), G2_HT4_SOFTPLUS_NOCOND,
+                                   G2_SHAPES(4, CNF_ACT_TANH), G2_SHAPES(4, CNF_ACT_SOFTPLUS)};
+#endif
 
 GradKernel grad2_kernel(int HT, int L, int ZR, int CR, int ACT) {
     for (const Grad2Inst& g : kGrad2)
