@@ -554,10 +554,12 @@ hipError_t grad_launch(const cnf_config& c, const float* packed_dev, const float
     // exchange form above (A/B switch)
     static DeviceOnce done_v2[sizeof(kGrad) / sizeof(kGrad[0])];
     bool v2 = false;
-    if (c.nprobes == 1 && ckpt_k && !getenv("CNF_GRAD_V1")) {
-        if (GradKernel k2 = grad2_kernel(gi->HT, gi->L, gi->ZR, gi->CR, gi->ACT)) { kern = k2; v2 = true; }
+    static DeviceOnce done_v2p[sizeof(kGrad) / sizeof(kGrad[0])];
+    if (ckpt_k && !getenv("CNF_GRAD_V1")) {
+        GradKernel k2 = c.nprobes == 1 ? grad2_kernel(gi->HT, gi->L, gi->ZR, gi->CR, gi->ACT) : grad2_probes_kernel(gi->HT, gi->L, gi->ZR, gi->CR, gi->ACT);
+        if (k2) { kern = k2; v2 = true; }
     }
-    DeviceOnce& done = (v2 ? done_v2 : c.nprobes > 1 ? done_probes : done_mask)[idx];
+    DeviceOnce& done = (v2 ? (c.nprobes > 1 ? done_v2p : done_v2) : c.nprobes > 1 ? done_probes : done_mask)[idx];
     if (!done.done(dev)) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, gi->lds_bytes);
         if (e != hipSuccess) return e;

@@ -22,6 +22,11 @@
 // MFMAs per stage per tile at cfg2: 864 (was 900 + 16 on wave 0).
 #include "cnf_grad_dev.h"
 
+// compiled twice: cnf_grad2.hip (one probe) and cnf_grad2_probes.hip (-DG2_MULTI=true: several probes)
+#ifndef G2_FIND
+#define G2_FIND grad2_kernel
+#endif
+
 #ifdef G2_TRACE
 #define G2_T(k) do { asm volatile("" ::: "memory"); tr[k] = __builtin_amdgcn_s_memtime(); asm volatile("" ::: "memory"); } while (0)
 #else
@@ -226,7 +231,10 @@ __device__ __forceinline__ void gemm_pf(const float* img, int lane, const InT& i
 
 }  // namespace
 
-template <int HT, int L, int ZR, int CR, int ACT>
+// MULTI: several Hutchinson probes (a.K of them; cnf_grad_probes.hip's objective: the probes share the forward chain and the top-down
+// pass, the pullback and its bottom-up reverse run once per probe and a2_l = sum_k dbar_l^k .* u_l^k).  The probe loop is rolled:
+// eps_k is read from global memory one probe ahead, c_k = W_N^T eps_k is multiplied per probe (HT x ZR MFMAs of ~450 per probe).
+template <int HT, int L, int ZR, int CR, int ACT, bool MULTI>
 __global__ void __launch_bounds__(256)
 mfma_grad2_kernel(GArgs a) {
     using G = GradLds<HT, L, ZR, CR, ACT>;
@@ -259,7 +267,8 @@ mfma_grad2_kernel(GArgs a) {
     float* slab = a.slab + ((long long)blockIdx.x * 4 + wave) * SL::TOTAL;
     float* scr = smem + G::XCH + wave * G::XCH_W;   // wave-private transpose scratch: XCH_TILES padded tiles
     const long long ntiles = (a.B + 15) / 16;
-    const int D = a.D;
+    const int D = a.D, K = MULTI ? a.K : 1;
+    const float invK = MULTI ? (a.probe_w > 0.f ? a.probe_w : 1.f / (float)K) : 1.f;
     const bool autonomous = a.autonomous;
     const float dt0 = a.dt;
     const int ns = a.T.ns;
@@ -285,7 +294,7 @@ mfma_grad2_kernel(GArgs a) {
 #pragma unroll
         for (int s = 0; s < ZR; ++s) {
             const int f = 4 * s + g;
-            eps[s] = f < D ? a.eps[sc * D + f] : 0.f;
+            eps[s] = f < D ? a.eps[sc * K * D + f] : 0.f;   // probe 0
             // dL/dz_N = z_N  (L = sum_j -logp_j, -log N(z) = |z|^2/2 + const); zero for padding columns
             lam[s] = valid ? a.ckpt[(((long long)a.nsteps * ntiles + tile) * 64 + lane) * a.ckpt_zr + s] : 0.f;
         }
@@ -308,13 +317,16 @@ mfma_grad2_kernel(GArgs a) {
         // dbar_1 = W_1[:,0:D] gbar is multiplied per stage instead - HT x ZR MFMAs of ~870)
         f32x4 cvec[HT];
         zero_tiles<HT>(cvec);
-        gemm_tiles<HT, ZR>(smem + LAY.bN, lane, RegIn<ZR>{eps}, cvec);
+        if constexpr (!MULTI) gemm_tiles<HT, ZR>(smem + LAY.bN, lane, RegIn<ZR>{eps}, cvec);
         // constant over the solve too: the A fragment of eps (Wbar_N += eps cbar^T) and the B fragment of the conditions (Wbar_1's y columns)
         float fe[1][4], fy[1][4];
         {
-            f32x4 et = dense_tile<ZR>(eps);
-            tile_store(scr, lane, et);
-            frags_A<1>(scr, lane, fe);
+            fe[0][0] = fe[0][1] = fe[0][2] = fe[0][3] = 0.f;
+            if constexpr (!MULTI) {
+                f32x4 et = dense_tile<ZR>(eps);
+                tile_store(scr, lane, et);
+                frags_A<1>(scr, lane, fe);
+            }
             fy[0][0] = fy[0][1] = fy[0][2] = fy[0][3] = 0.f;
             if constexpr (CR > 0) {
                 f32x4 yt = dense_tile<(CR > 0 ? CR : 1)>(y);
@@ -410,6 +422,7 @@ mfma_grad2_kernel(GArgs a) {
                     constexpr int l = decltype(lc)::value;
                     f32x4 accn[HT];
                     if constexpr (l + 1 < L) { afrag<HT>(IMG_F(l), lane, HT, 0, nf); load_cvec<HT>(sm + LAY.v_bh + l * MfmaLayout::vecC(HT), g, accn); }
+                    else if constexpr (MULTI) afrag<HT, (ZR < 4 ? ZR : 4)>(sm + LAY.bN, lane, LAY.KGZ, 0, nf);   // c_0 = W_N^T eps_0
                     else afrag<HT>(IMG_B(NH - 1), lane, HT, 0, nf);   // the first pullback product
                     G2_FENCE();
 #pragma unroll
@@ -441,11 +454,49 @@ mfma_grad2_kernel(GArgs a) {
                 //      it is being multiplied (the A operand of Wbar_{l+1}'s second term); the first product also carries h_L and kbar
                 //      out and their fragments back, and Wbar_N += kbar h_L^T rides behind it
                 float fhL[HT][4], fk[1][4];
-                f32x4 u[NH][HT], dl[HT];
+                f32x4 db[HT], a2[L][HT];   // a2_l = (sum over the probes of) dbar_l .* u_l  (multiplies act''_l later)
+                float gbar[ZR];
+                float* const sU = sc0 + NH * HT * TS;   // ubar_l, then cbar (several probes: eps_k and gbar_k pass through its first tile)
+                const f32x4 kt = dense_tile<ZR>(kbar);
+                if constexpr (MULTI) {
+#pragma unroll
+                    for (int l = 0; l < L; ++l) zero_tiles<HT>(a2[l]);
+                }
+                float epsk[ZR];   // the running probe (one probe: eps)
+#pragma unroll
+                for (int s = 0; s < ZR; ++s) epsk[s] = eps[s];
+#pragma clang loop unroll(disable)
+                for (int k = 0; k < K; ++k) {
+                f32x4 u[NH][HT], dl[HT], ck[HT];
+                float eps_nx[ZR];   // several probes: the next one, requested now
+                float fek[1][4];
+                if constexpr (MULTI) {
+                    const int kn = k + 1 < K ? k + 1 : 0;
+#pragma unroll
+                    for (int s = 0; s < ZR; ++s) {
+                        const int f = 4 * s + g;
+                        eps_nx[s] = f < D ? a.eps[(sc * K + kn) * D + f] : 0.f;
+                    }
+                    // c_k = W_N^T eps_k; eps_k out and its A fragment back in the product's shadow (Wbar_N += eps_k cbar_k^T)
+                    const f32x4 et = dense_tile<ZR>(epsk);
+                    G2_FENCE();
+                    zero_tiles<HT>(ck);
+                    gemm_pf<HT, ZR, HT>(sm + LAY.bN, lane, RegIn<ZR>{epsk}, nf, ck, IMG_B(NH - 1), HT, nf,
+                                        [&](auto qc) {
+                                            constexpr int q = decltype(qc)::value;
+                                            if constexpr (q == 0) tile_store(sU, lane, et);
+                                            if constexpr (q == 1) read_frag_A1(sU, lane, fek[0]);
+                                        });
+                    G2_FENCE();
+                } else {
+#pragma unroll
+                    for (int mt = 0; mt < HT; ++mt) ck[mt] = cvec[mt];
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) fek[0][s] = fe[0][s];
+                }
                 const float one_p = opaque_one();
 #pragma unroll
-                for (int mt = 0; mt < HT; ++mt) dl[mt] = cvec[mt] * dact(L - 1, mt, one_p);
-                const f32x4 kt = dense_tile<ZR>(kbar);
+                for (int mt = 0; mt < HT; ++mt) dl[mt] = ck[mt] * dact(L - 1, mt, one_p);
                 static_for<0, NH>([&](auto lc) {
                     constexpr int l = L - 1 - decltype(lc)::value;   // L-1 .. 1
                     G2_FENCE();
@@ -454,14 +505,14 @@ mfma_grad2_kernel(GArgs a) {
                                             [&](auto qc) {
                                                 constexpr int q = decltype(qc)::value;
                                                 if constexpr (q < HT) tile_store(sc0 + ((l - 1) * HT + q) * TS, lane, dl[q]);
-                                                if constexpr (l == L - 1) {
+                                                if constexpr (l == L - 1 && !MULTI) {
                                                     if constexpr (q >= HT && q < 2 * HT) tile_store(sE + (q - HT) * TS, lane, h[L - 1][q - HT]);
                                                     if constexpr (q >= 2 * HT && q < 3 * HT) read_frag_B1(sE + (q - 2 * HT) * TS, lane, fhL[q - 2 * HT]);
                                                     if constexpr (q == HT) tile_store(sc0 + NH * HT * TS, lane, kt);   // (ubar's slot: free until the bottom-up pass)
                                                     if constexpr (q == 2 * HT) read_frag_A1(sc0 + NH * HT * TS, lane, fk[0]);
                                                 }
                                             });
-                    if constexpr (l == L - 1) {
+                    if constexpr (l == L - 1 && !MULTI) {
                         cot_row(fk[0], fhL, WNacc[0]);
 #pragma unroll
                         for (int s = 0; s < ZR; ++s) bN[s] += kbar[s];
@@ -472,10 +523,9 @@ mfma_grad2_kernel(GArgs a) {
                 });
                 G2_T(2);
                 // gbar = cotangent of g = eps^T J (dense layout): -c_l eps (+ c_n g/|g|);  dbar_1 = W_1[:,0:D] gbar
-                float gbar[ZR];
+                const float clk = cl * invK, cnk = cn * invK;   // (several probes: each carries 1 / K of the trace terms)
 #pragma unroll
-                for (int s = 0; s < ZR; ++s) gbar[s] = -cl * eps[s];
-                f32x4 db[HT], a2[L][HT];   // a2_l = dbar_l .* u_l  (multiplies act''_l later)
+                for (int s = 0; s < ZR; ++s) gbar[s] = -clk * epsk[s];
                 if (regj) {
                     f32x4 gacc[DT];
                     zero_tiles<DT>(gacc);
@@ -484,7 +534,7 @@ mfma_grad2_kernel(GArgs a) {
 #pragma unroll
                     for (int s = 0; s < ZR; ++s) n2 = fmaf(gacc[s >> 2][s & 3], gacc[s >> 2][s & 3], n2);
                     n2 = group_sum(n2);
-                    const float inv = n2 > 0.f ? cn * rsqrtf(n2) : 0.f;
+                    const float inv = n2 > 0.f ? cnk * rsqrtf(n2) : 0.f;
 #pragma unroll
                     for (int s = 0; s < ZR; ++s) gbar[s] = fmaf(inv, gacc[s >> 2][s & 3], gbar[s]);
                 }
@@ -492,15 +542,25 @@ mfma_grad2_kernel(GArgs a) {
                 //      delta_1 waits in the early slots for the stage's last phase (Wbar_1 += delta_1 [gbar; 0]^T)
                 const float one_b = opaque_one();
                 tiles_store<HT>(sE, lane, dl);
+                float fd[HT][4], fg[1][4];   // several probes: delta_1^k and gbar_k, Wbar_1 += delta_1^k [gbar_k; 0]^T behind the bottom-up pass
+                const f32x4 gtk = dense_tile<ZR>(gbar);
                 G2_FENCE();
                 zero_tiles<HT>(db);
-                gemm_pf<HT, ZR, HT>(sm + LAY.f1z, lane, RegIn<ZR>{gbar}, nf, db, IMG_F(0), HT, nf);   // dbar_1 = W_1[:,0:D] gbar
-                float* const sU = sc0 + NH * HT * TS;   // ubar_l, then cbar
+                gemm_pf<HT, ZR, HT>(sm + LAY.f1z, lane, RegIn<ZR>{gbar}, nf, db, IMG_F(0), HT, nf,   // dbar_1 = W_1[:,0:D] gbar
+                                    [&](auto qc) {
+                                        constexpr int q = decltype(qc)::value;
+                                        if constexpr (MULTI && q == 0) tile_store(sU, lane, gtk);
+                                        if constexpr (MULTI && q == 1) read_frag_B1(sU, lane, fg[0]);
+                                    });
                 static_for<0, NH>([&](auto lc) {
                     constexpr int l = decltype(lc)::value;
                     f32x4 ubs[HT];
 #pragma unroll
-                    for (int mt = 0; mt < HT; ++mt) { ubs[mt] = db[mt] * dact(l, mt, one_b); a2[l][mt] = db[mt] * u[l][mt]; }
+                    for (int mt = 0; mt < HT; ++mt) {
+                        ubs[mt] = db[mt] * dact(l, mt, one_b);
+                        if constexpr (MULTI) a2[l][mt] += db[mt] * u[l][mt];
+                        else a2[l][mt] = db[mt] * u[l][mt];
+                    }
                     float fa[HT][4], fb[HT][4];
                     G2_FENCE();
                     zero_tiles<HT>(db);
@@ -510,18 +570,39 @@ mfma_grad2_kernel(GArgs a) {
                                                 if constexpr (q >= 1 && q <= HT) tile_store(sU + (q - 1) * TS, lane, ubs[q - 1]);
                                                 if constexpr (q > HT && q <= 2 * HT) read_frag_A1(sc0 + (l * HT + q - HT - 1) * TS, lane, fa[q - HT - 1]);
                                                 if constexpr (q > 2 * HT && q <= 3 * HT) read_frag_B1(sU + (q - 2 * HT - 1) * TS, lane, fb[q - 2 * HT - 1]);
+                                                if constexpr (MULTI && l == NH - 1 && q >= 3 * HT) read_frag_A1(sE + (q - 3 * HT) * TS, lane, fd[q - 3 * HT]);
                                             });
                     cot_block<HT, HT>(fa, fb, Wh[l]);
                     G2_FENCE();
                 });
+                if constexpr (MULTI) {
+                    // cbar_k = dbar_L^k .* act'_L out and its fragments back, behind them Wbar_1 += delta_1^k [gbar_k; 0]^T (covers the round
+                    // trip), then Wbar_N += eps_k cbar_k^T
+                    f32x4 cb[HT];
+                    float fck[HT][4];
+#pragma unroll
+                    for (int mt = 0; mt < HT; ++mt) { cb[mt] = db[mt] * dact(L - 1, mt, one_b); a2[L - 1][mt] += db[mt] * ck[mt]; }
+                    G2_FENCE();
+                    tiles_store<HT>(sU, lane, cb);
+#pragma unroll
+                    for (int mt = 0; mt < HT; ++mt) read_frag_B1(sU + mt * TS, lane, fck[mt]);
+                    G2_FENCE();
+                    cot_col(fd, fg[0], W1in);
+                    cot_row(fek[0], fck, WNacc[0]);
+                    G2_FENCE();
+#pragma unroll
+                    for (int s = 0; s < ZR; ++s) epsk[s] = eps_nx[s];
+                }
+                }   // probes
                 G2_T(3);
                 // ---- (4) top-down through the forward chain
                 f32x4 hb[HT];
                 float fc[HT][4];
-                {   // cbar = dbar_L .* act'_L;  hbar_L = W_N^T kbar carries cbar out; Wbar_N += eps cbar^T is taken behind the next product
+                if constexpr (!MULTI) {   // cbar = dbar_L .* act'_L;  hbar_L = W_N^T kbar carries cbar out; Wbar_N += eps cbar^T is taken behind the next product
+                    const float one_c = opaque_one();
                     f32x4 cb[HT];
 #pragma unroll
-                    for (int mt = 0; mt < HT; ++mt) { cb[mt] = db[mt] * dact(L - 1, mt, one_b); a2[L - 1][mt] = db[mt] * cvec[mt]; }
+                    for (int mt = 0; mt < HT; ++mt) { cb[mt] = db[mt] * dact(L - 1, mt, one_c); a2[L - 1][mt] = db[mt] * cvec[mt]; }
                     G2_FENCE();
                     zero_tiles<HT>(hb);
                     gemm_pf<HT, ZR, HT>(sm + LAY.bN, lane, RegIn<ZR>{kbar}, nf, hb, IMG_B(NH - 1), HT, nf,
@@ -530,6 +611,15 @@ mfma_grad2_kernel(GArgs a) {
                                             constexpr int per = (HT + ZR - 1) / ZR;   // cbar's HT tiles over the product's ZR k-steps
 #pragma unroll
                                             for (int mt = q * per; mt < (q + 1) * per && mt < HT; ++mt) tile_store(sU + mt * TS, lane, cb[mt]);
+                                        });
+                } else {   // several probes: hbar_L = W_N^T kbar carries kbar out (Wbar_N += kbar h_L^T is taken behind the next product)
+                    G2_FENCE();
+                    zero_tiles<HT>(hb);
+                    gemm_pf<HT, ZR, HT>(sm + LAY.bN, lane, RegIn<ZR>{kbar}, nf, hb, IMG_B(NH - 1), HT, nf,
+                                        [&](auto qc) {
+                                            constexpr int q = decltype(qc)::value;
+                                            if constexpr (q == 0) tile_store(sU, lane, kt);
+                                            if constexpr (q == 1) read_frag_A1(sU, lane, fk[0]);
                                         });
                 }
                 G2_T(4);
@@ -557,7 +647,10 @@ mfma_grad2_kernel(GArgs a) {
                             else if constexpr (q < 3 * HT) read_frag_A1(sc0 + (q - 2 * HT) * TS, lane, fa[q - 2 * HT]);
                             else read_frag_B1(sc0 + (q - 2 * HT) * TS, lane, fb[q - 3 * HT]);
                             // cbar's fragments first: with one hidden matrix its slot is the one h_{l-1} is about to take
-                            if constexpr (l == L - 1 && q < HT) read_frag_B1(sU + q * TS, lane, fc[q]);
+                            if constexpr (!MULTI && l == L - 1 && q < HT) read_frag_B1(sU + q * TS, lane, fc[q]);
+                            // several probes: h_L out to the early slots and its fragments back (delta_1^k's reads are long issued)
+                            if constexpr (MULTI && l == L - 1 && q < HT) tile_store(sE + q * TS, lane, h[L - 1][q]);
+                            if constexpr (MULTI && l == L - 1 && q >= 2 * HT && q < 3 * HT) read_frag_B1(sE + (q - 2 * HT) * TS, lane, fhL[q - 2 * HT]);
                         };
                         G2_FENCE();
                         zero_tiles<HT>(hb);
@@ -565,7 +658,12 @@ mfma_grad2_kernel(GArgs a) {
                         else gemm_pf<HT, 4 * HT, 1>(IMG_B(l - 1), lane, TileIn<HT>{ab}, nf, hb, sm + LAY.b1, HT, nz, operands);
                         if constexpr (l == L - 1) G2_T(11);
                         cot_block<HT, HT>(fa, fb, Wh[l - 1]);
-                        if constexpr (l == L - 1) cot_row(fe[0], fc, WNacc[0]);   // Wbar_N += eps cbar^T
+                        if constexpr (l == L - 1 && !MULTI) cot_row(fe[0], fc, WNacc[0]);   // Wbar_N += eps cbar^T
+                        if constexpr (l == L - 1 && MULTI) {                               // Wbar_N += kbar h_L^T;  bbar_N += kbar
+                            cot_row(fk[0], fhL, WNacc[0]);
+#pragma unroll
+                            for (int s = 0; s < ZR; ++s) bN[s] += kbar[s];
+                        }
                         G2_FENCE();
                         if constexpr (l == L - 1) G2_T(12);
 #pragma unroll
@@ -596,11 +694,11 @@ mfma_grad2_kernel(GArgs a) {
                                                    constexpr int q = decltype(qc)::value;
                                                    if constexpr (q < HT) tile_store(sc0 + q * TS, lane, ab[q]);
                                                    if constexpr (q == HT) { tile_store(sc0 + HT * TS, lane, in_tile); tile_store(sc0 + GT_SLOT * TS, lane, gt); }
-                                                   if constexpr (q > HT && q <= 2 * HT) read_frag_A1(sE + (q - HT - 1) * TS, lane, fd[q - HT - 1]);
+                                                   if constexpr (!MULTI && q > HT && q <= 2 * HT) read_frag_A1(sE + (q - HT - 1) * TS, lane, fd[q - HT - 1]);
                                                    if constexpr (q > 2 * HT && q <= 3 * HT) read_frag_A1(sc0 + (q - 2 * HT - 1) * TS, lane, fa[q - 2 * HT - 1]);
                                                    if constexpr (q == (HT >= 2 ? 3 * HT + 1 : 3 * HT)) { read_frag_B1(sc0 + HT * TS, lane, fi[0]); read_frag_B1(sc0 + GT_SLOT * TS, lane, fg[0]); }
                                                });
-                        cot_col(fd, fg[0], W1in);
+                        if constexpr (!MULTI) cot_col(fd, fg[0], W1in);
                         cot_col(fa, fi[0], W1in);
                         if constexpr (CR > 0) cot_col(fa, fy[0], W1y);
                         G2_FENCE();
@@ -679,7 +777,10 @@ struct Grad2Inst {
     int HT, L, ZR, CR, ACT;
     GradKernel kern;
 };
-#define G2_INST(HT, L, ZR, CR, ACT) Grad2Inst { HT, L, ZR, CR, ACT, &mfma_grad2_kernel<HT, L, ZR, CR, ACT> }
+#ifndef G2_MULTI
+#define G2_MULTI false
+#endif
+#define G2_INST(HT, L, ZR, CR, ACT) Grad2Inst { HT, L, ZR, CR, ACT, &mfma_grad2_kernel<HT, L, ZR, CR, ACT, G2_MULTI> }
 // the shapes of cnf_grad.hip's table (kGrad): 1 .. 4 hidden tiles, 2 / 3 hidden layers, D <= 8 / 16, with and without conditions
 #define G2_HT(HT, CR, ACT) G2_INST(HT, 3, 2, CR, ACT), G2_INST(HT, 2, 2, CR, ACT), G2_INST(HT, 3, 4, CR, ACT), G2_INST(HT, 2, 4, CR, ACT)
 #define G2_SHAPES(CR, ACT) G2_HT(1, CR, ACT), G2_HT(2, CR, ACT), G2_HT(3, CR, ACT), G2_HT(4, CR, ACT)
@@ -695,7 +796,7 @@ static const Grad2Inst kGrad2[] = {G2_SHAPES(0, CNF_ACT_TANH),
                                    G2_SHAPES(4, CNF_ACT_TANH), G2_SHAPES(4, CNF_ACT_SOFTPLUS)};
 #endif
 
-GradKernel grad2_kernel(int HT, int L, int ZR, int CR, int ACT) {
+GradKernel G2_FIND(int HT, int L, int ZR, int CR, int ACT) {
     for (const Grad2Inst& g : kGrad2)
         if (g.HT == HT && g.L == L && g.ZR == ZR && g.CR == CR && g.ACT == ACT) return g.kern;
     return nullptr;

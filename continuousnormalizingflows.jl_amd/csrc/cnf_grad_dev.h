@@ -138,5 +138,6 @@ typedef void (*GradKernel)(GArgs);
 GradKernel grad_probes_kernel(int HT, int L, int ZR, int CR, int ACT);
 // barrier-free form for one probe (cnf_grad2.hip): every wave keeps the whole gradient of its own sample tiles; null = no instance
 GradKernel grad2_kernel(int HT, int L, int ZR, int CR, int ACT);
+GradKernel grad2_probes_kernel(int HT, int L, int ZR, int CR, int ACT);   // the same for several probes (cnf_grad2_probes.hip)
 
 }  // namespace cnf
