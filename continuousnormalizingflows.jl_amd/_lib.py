@@ -29,7 +29,7 @@ ERR_COMM = -6
 COMM_ID_BYTES = 128
 DTYPE_F32, DTYPE_F64 = 0, 1
 
-EXPORTS = ("cnf_version", "cnf_last_error", "cnf_create", "cnf_destroy", "cnf_set_params",
+EXPORTS = ("cnf_version", "cnf_build_info", "cnf_last_error", "cnf_create", "cnf_destroy", "cnf_set_params",
            "cnf_kernel_path", "cnf_solve_controller", "cnf_repack_on_device", "cnf_aug_f", "cnf_integrate_fixed", "cnf_inference_fixed",
            "cnf_loss_sums", "cnf_loss_mean", "cnf_loss_grad_fixed", "cnf_loss_grad_grid", "cnf_grad_path", "cnf_step_embedded", "cnf_assemble_u0",
            "cnf_epilogue", "cnf_vcabm_begin", "cnf_vcabm_attempt", "cnf_vcabm_accept", "cnf_vcabm_state", "cnf_solve_vcabm", "cnf_solve_tsit5", "cnf_loss_grad_adaptive",
@@ -101,6 +101,8 @@ def load():
     lib.cnf_kernel_family_for.argtypes = [vp, C.c_int64, C.c_int]
     lib.cnf_kernel_name.argtypes = [vp]
     lib.cnf_kernel_name.restype = C.c_char_p
+    lib.cnf_build_info.argtypes = []
+    lib.cnf_build_info.restype = C.c_char_p
     lib.cnf_loss_grad_grid.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_float), fp, fp, fp, C.c_int64,
                                        C.POINTER(C.c_float), fp, fp, fp, vp]
     lib.cnf_step_embedded.argtypes = [vp, C.c_int, C.c_int, C.c_float, C.c_float, fp, fp, fp, C.c_int64, C.c_float,

@@ -33,7 +33,7 @@
  *   training                 cnf_loss_grad_fixed, cnf_loss_grad_grid, cnf_loss_grad_adaptive  (dloss/dps, optionally dloss/dxs)
  *   column shards (RCCL)     cnf_comm_unique_id, cnf_comm_init, cnf_comm_init_all, cnf_comm_destroy, cnf_comm_rank, cnf_comm_size,
  *                            cnf_allreduce_loss (the mean in `loss`), cnf_allreduce_sum, cnf_comm_group_start / _end
- *   introspection            cnf_version, cnf_last_error, cnf_kernel_path, cnf_kernel_family, cnf_grad_path, cnf_grad_path_for, cnf_repack_on_device, cnf_solve_controller
+ *   introspection            cnf_version, cnf_build_info, cnf_last_error, cnf_kernel_path, cnf_kernel_family, cnf_grad_path, cnf_grad_path_for, cnf_repack_on_device, cnf_solve_controller
  */
 #ifndef CNF_H
 #define CNF_H
@@ -110,6 +110,9 @@ typedef struct cnf_handle cnf_handle;
 
 int cnf_version(void);
 const char* cnf_last_error(void);
+/* Which compiler made this library: "hipcc <version line>; clang <version>; flags ..." recorded at build time (a log can then say
+ * which compiler produced the code objects whose hand-placed wait states tests/test_isa_hazards.py audits).  Never NULL. */
+const char* cnf_build_info(void);
 
 /* ICNF(; ...) constructor (src/core/icnf.jl:53-141): validates and binds a config to a device. */
 int cnf_create(cnf_handle** out, const cnf_config* cfg);

@@ -174,3 +174,23 @@ is_adaptive_tsit5(icnf::ICNF) = haskey(icnf.sol_kwargs, :alg) && nameof(typeof(i
     get(icnf.sol_kwargs, :adaptive, true)
 
 solver_maxiters(icnf::ICNF) = Cint(min(get(icnf.sol_kwargs, :maxiters, 100_000), typemax(Cint)))
+
+
+# ---- introspection (include/cnf.h: which kernel organisation serves a handle / a call, which gradient implementation) --------
+
+"`kernel_family(h)`: CNF_FAMILY_* of the handle (simt 0, per_wave 1, coop 2, coopx 3, tile_split 4, layered 5, coopd 6)."
+kernel_family(h::Handle) = Int(ccall((:cnf_kernel_family, libcnf), Cint, (Ptr{Cvoid},), h.ptr))
+
+"`kernel_family(h, B; whole_solve = true)`: the family a call of `B` columns takes (a fused solve, or one dynamics call)."
+kernel_family(h::Handle, B::Integer; whole_solve::Bool = true) =
+    Int(ccall((:cnf_kernel_family_for, libcnf), Cint, (Ptr{Cvoid}, Int64, Cint), h.ptr, B, whole_solve ? 1 : 0))
+
+"`kernel_name(h)`: the kernel instance serving the handle, e.g. `mfma_vjp<HT=4,L=3,...>`."
+kernel_name(h::Handle) = unsafe_string(ccall((:cnf_kernel_name, libcnf), Cstring, (Ptr{Cvoid},), h.ptr))
+
+"`grad_path(h, B, alg_id; on_grid = false)`: 1 fused register-accumulator sweep, 2 layer-wise, 3 cooperative sweep (0: none)."
+grad_path(h::Handle, B::Integer, alg_id::Integer; on_grid::Bool = false) =
+    Int(ccall((:cnf_grad_path_for, libcnf), Cint, (Ptr{Cvoid}, Int64, Cint, Cint), h.ptr, B, alg_id, on_grid ? 1 : 0))
+
+"`build_info()`: the compiler and flags the loaded library was built with."
+build_info() = unsafe_string(ccall((:cnf_build_info, libcnf), Cstring, ()))

@@ -30,6 +30,8 @@ def test_library_exports_every_declared_symbol(pkg):
         assert hasattr(lib, s), s
     assert set(pkg._lib.EXPORTS) == set(declared_symbols())
     assert lib.cnf_version() == 1
+    info = lib.cnf_build_info().decode()          # which compiler made the code objects (recorded by the Makefile)
+    assert "clang" in info.lower() and "gfx950" in info, info
 
 
 def test_config_struct_matches_header(pkg):

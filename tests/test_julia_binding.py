@@ -29,7 +29,9 @@ def header_protos():
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
     protos = {m.group(1): [a.strip() for a in m.group(2).split(",")]
               for m in re.finditer(r"\bint\s+(cnf_\w+)\s*\(([^;{]*?)\)\s*;", hdr)}
-    protos["cnf_last_error"] = ["void"]
+    for m in re.finditer(r"\bconst\s+char\s*\*\s*(cnf_\w+)\s*\(([^;{]*?)\)\s*;", hdr):   # the entry points that return a string
+        protos[m.group(1)] = [a.strip() for a in m.group(2).split(",")]
+    assert protos["cnf_last_error"] == ["void"]
     return protos
 
 
@@ -63,7 +65,7 @@ def test_every_ccall_matches_the_header():
             assert name in protos, f"{f}: ccall of an unknown entry point {name}"
             params = [] if protos[name] == ["void"] else protos[name]
             assert len(types) == len(params), (f, name, types, params)
-            assert ret == ("Cstring" if name == "cnf_last_error" else "Cint"), (name, ret)
+            assert ret == ("Cstring" if name in ("cnf_last_error", "cnf_kernel_name", "cnf_build_info") else "Cint"), (name, ret)
             for jt, cp in zip(types, params):
                 if jt in ("Cint", "Int32"):
                     assert re.match(r"(int|int32_t)\s+\w+$", cp), (name, jt, cp)
@@ -82,7 +84,8 @@ def test_every_ccall_matches_the_header():
             seen.add(name)
     need = {"cnf_create", "cnf_destroy", "cnf_set_params", "cnf_aug_f", "cnf_integrate_fixed_dt", "cnf_inference_fixed_dt",
             "cnf_solve_vcabm", "cnf_solve_tsit5", "cnf_loss_grad_grid", "cnf_loss_grad_adaptive", "cnf_last_error",
-            "cnf_comm_init", "cnf_comm_unique_id", "cnf_comm_destroy", "cnf_allreduce_loss"}
+            "cnf_comm_init", "cnf_comm_unique_id", "cnf_comm_destroy", "cnf_allreduce_loss",
+            "cnf_kernel_family", "cnf_kernel_family_for", "cnf_kernel_name", "cnf_grad_path_for", "cnf_build_info"}
     assert need <= seen, need - seen
 
 
