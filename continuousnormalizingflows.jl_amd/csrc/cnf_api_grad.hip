@@ -77,14 +77,24 @@ cnf::GradRoute cnf::api_grad_route(const cnf_handle* h, int64_t B, int alg, bool
 }
 }  // extern "C++"
 
+// JVP mode without the Jacobian regulariser (cnf_handle::grad_twin): the call is served by the VJP-mode twin when that one has a
+// fused implementation (1 or 3) for it
+static const cnf_handle* grad_server(const cnf_handle* h, int64_t B, int alg, bool on_grid) {
+    if (h && h->grad_twin) {
+        const int tp = api_grad_route(h->grad_twin, B, alg, on_grid).path;
+        if (tp == 1 || tp == 3) return h->grad_twin;
+    }
+    return h;
+}
+
 int cnf_grad_path(const cnf_handle* h) {
     if (!h) return CNF_ERR_INVALID;
-    return api_grad_route(h, -1, CNF_ALG_TSIT5, false).path;
+    return api_grad_route(grad_server(h, -1, CNF_ALG_TSIT5, false), -1, CNF_ALG_TSIT5, false).path;
 }
 
 int cnf_grad_path_for(const cnf_handle* h, int64_t B, int alg, int on_grid) {
     if (!h || B < 0 || (alg != CNF_ALG_RK4 && alg != CNF_ALG_TSIT5)) return CNF_ERR_INVALID;
-    return api_grad_route(h, B, alg, on_grid != 0).path;
+    return api_grad_route(grad_server(h, B, alg, on_grid != 0), B, alg, on_grid != 0).path;
 }
 
 }  // extern "C"
@@ -96,6 +106,10 @@ static int loss_grad_impl(cnf_handle* h, const char* who, int alg, int nsteps, f
                           float* grad, float* grad_x, float* sums4, void* stream) {
     int rc = api_check_call(h, eps, ys, B, who);
     if (rc) return rc;
+    if (alg == CNF_ALG_RK4 || alg == CNF_ALG_TSIT5) {
+        const cnf_handle* srv = grad_server(h, B, alg, tgrid != nullptr);
+        if (srv != h) return loss_grad_impl(const_cast<cnf_handle*>(srv), who, alg, nsteps, t0, t1, tgrid, x, eps, ys, B, lambdas, grad, grad_x, sums4, stream);
+    }
     const std::string w(who);
     if (nsteps < 1) return fail(CNF_ERR_INVALID, w + ": nsteps >= 1 required");
     if (alg != CNF_ALG_RK4 && alg != CNF_ALG_TSIT5) return fail(CNF_ERR_INVALID, w + ": unknown alg");

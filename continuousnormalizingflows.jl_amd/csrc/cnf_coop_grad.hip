@@ -472,8 +472,13 @@ coop_grad_step_kernel(CGArgs a) {
                     sstore(SLOT_H + l, h);
                     if (l > 0) sstore(SLOT_DB + l - 1, db);
                 }
+                // The operand stores of a published pair are issued INSIDE the product that reads it, behind its last fragment
+                // requests (round 5): vmcnt retires in order, so in front of the product (round 3) its first fragment wait drained
+                // 8 KB of HBM stores per wave, six times a stage (CG_STORES_FIRST restores that order for an A/B).
+#ifdef CG_STORES_FIRST
                 gstore(cur, 0, ry[l], voy, sy2);                              // [h_{l+1}; 1] half of Y_{l+1}
                 gstore(cur, 1, ry[l], voy, sy1);                              // [vbar_{l+1}; 0] half
+#endif
                 if (l + 1 < L) {
                     f32x4 bnx[MTW];
                     gload_cvec<MTW>(P + LAY.v_bh + l * MfmaLayout::vecC(HT), mt0, g, bnx);
@@ -482,9 +487,20 @@ coop_grad_step_kernel(CGArgs a) {
 #pragma unroll
                         for (int q = 0; q < NT; ++q) { acc[m][q] = bnx[m]; acc[m][NT + q] = f32x4{0.f, 0.f, 0.f, 0.f}; }
                     CG_SYNC();
+#ifdef CG_STORES_FIRST
                     run2(LAY.fh + l * IMG, HT, xbuf + cur * XB, afr, acc);
+#else
+                    head2(LAY.fh + l * IMG, HT, xbuf + cur * XB, afr, acc);
+                    gstore(cur, 0, ry[l], voy, sy2);                          // [h_{l+1}; 1] half of Y_{l+1}
+                    gstore(cur, 1, ry[l], voy, sy1);                          // [vbar_{l+1}; 0] half
+                    tail2(HT, afr, acc);
+#endif
                     cur ^= 1;
                 } else {
+#ifndef CG_STORES_FIRST
+                    gstore(cur, 0, ry[l], voy, sy2);                          // (the top: the pair is overwritten below)
+                    gstore(cur, 1, ry[l], voy, sy1);
+#endif
                     // ===== the top: [c | hbar_L] = W_N^T [eps | kbar]; delta_L = c .* act'_L, a2_L = dbar_L .* c,
                     //       sbar_L = hbar_L .* act'_L + a2_L .* act''_L - all while h_L and dbar_L are in registers =====
                     T2 t;
@@ -502,8 +518,10 @@ coop_grad_step_kernel(CGArgs a) {
                         }
                     // own tiles of the Y_L pair have been stored by this wave (gstore waits for its LDS reads): overwrite them
                     publish2(cur, dl, sb);
+#ifdef CG_STORES_FIRST
                     gstore(cur, 0, rx[L - 1], vox, sx1);                      // delta_L half of X_L
                     gstore(cur, 1, rx[L - 1], vox, sx2);                      // sbar_L half
+#endif
                     CG_SYNC();
                 }
             }
@@ -526,6 +544,10 @@ coop_grad_step_kernel(CGArgs a) {
                     coop_gemm<MTW, NT, NT>(AIMG(LAY.f1z), mt0, DT, gbuf, 0, lane, afq, dbl);
                 }
                 head2(LAY.bh + (l - 1) * IMG, HT, xbuf + cur * XB, afr, t);
+#ifndef CG_STORES_FIRST
+                gstore(cur, 0, rx[l], vox, sx1);                              // delta_{l+1} half of X_{l+1}: the pair this product reads
+                gstore(cur, 1, rx[l], vox, sx2);                              // sbar_{l+1} half
+#endif
                 sload(SLOT_H + l - 1, hl);
                 if (l > 1) sload(SLOT_DB + l - 2, dbl);
                 tail2(HT, afr, t);
@@ -542,8 +564,10 @@ coop_grad_step_kernel(CGArgs a) {
                         sb[m][q] = t[m][NT + q] * d + (dbv * u) * act_dd<ACT>(hl[m][q], d);
                     }
                 publish2(cur, dl, sb);
+#ifdef CG_STORES_FIRST
                 gstore(cur, 0, rx[l - 1], vox, sx1);                          // delta_l half of X_l
                 gstore(cur, 1, rx[l - 1], vox, sx2);                          // sbar_l half
+#endif
                 CG_SYNC();
             }
             // Zbar_i = W_1[:,0:D]^T sbar_1: D rows x the sample tiles, K = H.  SPLIT ALONG K over the four waves (wave w: k-groups
@@ -571,6 +595,10 @@ coop_grad_step_kernel(CGArgs a) {
 #pragma unroll
                     for (int q = 0; q < NT; ++q) bz[q] = bn[q];
                 }
+#ifndef CG_STORES_FIRST
+                gstore(cur, 0, rx[0], vox, sx1);                              // X_1 = [delta_1 | sbar_1], behind the product that read it
+                gstore(cur, 1, rx[0], vox, sx2);
+#endif
                 f32x4* pz = xbuf + (cur ^ 1) * XB;        // [wave][DT][NT][64] partial tiles
 #pragma unroll
                 for (int m = 0; m < DT; ++m)

@@ -140,6 +140,10 @@ struct cnf_handle {
     cnf::HandleEmbedded emb;
     cnf::HandleVcabm vc;
     cnf::HandleAdaptive adp;
+    // Hutchinson JVP mode without the Jacobian regulariser: eps^T (J eps) and (eps^T J) eps are the same number, so the loss is the
+    // VJP mode's loss and its parameter gradient is served by the VJP mode's fused reverse sweeps through this internal handle of
+    // the same configuration with mode = CNF_MODE_HUTCH_VJP (the JVP-specific gradient kernels are layer-wise only).  Null otherwise.
+    cnf_handle* grad_twin = nullptr;
 };
 
 namespace cnf {

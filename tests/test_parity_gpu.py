@@ -1099,26 +1099,50 @@ JVP_GRAD_SHAPES = [
     (dict(nvars=8, hidden=[64, 64, 64], mode=1, reg_z=True, reg_j=True), (0.02, 0.05, 0.0), 60, 0, 3),
     (dict(nvars=5, naug=2, ncond=4, hidden=[48, 96], act=2, mode=1, nprobes=2, reg_z=True, reg_j=True, reg_aug=True), (0.01, 0.03, 0.02), 41, 1, 2),
     (dict(nvars=32, hidden=[256, 256, 256], mode=1, reg_j=True), (0.0, 0.04, 0.0), 24, 0, 2),
+    (dict(nvars=32, hidden=[256, 256, 256], mode=1, reg_z=True), (0.03, 0.0, 0.0), 24, 0, 2),      # no |J eps| term: the VJP twin's cooperative sweep
+    (dict(nvars=20, naug=21, hidden=[168, 168], act=2, mode=1, reg_z=True, reg_aug=True), (0.01, 0.0, 0.01), 40, 1, 2),   # default architecture, dealt sweep
 ]
 
 
 @pytest.mark.parametrize("kw,lam,B,alg,nsteps", JVP_GRAD_SHAPES)
 def test_parameter_gradient_in_jvp_mode(kw, lam, B, alg, nsteps, pkg, oracles):
-    """The gradient in Hutchinson JVP mode (layer-wise path: pushforward, its reverse, shared top-down
-    pass) against the fp64 autograd oracle."""
+    """The gradient in Hutchinson JVP mode against the fp64 autograd oracle.  With the |J eps| regulariser: the layer-wise path
+    (pushforward, its reverse, shared top-down pass).  Without it eps^T (J eps) = (eps^T J) eps, the loss is the VJP mode's and the
+    library serves the gradient from the VJP mode's fused reverse sweeps (cnf_handle::grad_twin, round 5)."""
     o64, _ = oracles
     spec = o64.make_spec(**kw)
     p, xs, eps, ys = o64.synth_inputs(spec, B, 321, bias_scale=0.2)
     L, gref = o64.loss_and_grad(spec, p, xs, 0.0, 1.0, nsteps, alg, eps, ys, lam)
     icnf = make_icnf(pkg, spec, alg, nsteps, path=0, lambdas=lam)
     mode = pkg.TrainMode(bool(spec.reg_z or spec.reg_j or spec.reg_aug))
-    assert icnf.grad_path(mode) == 2
+    assert icnf.grad_path(mode) == (2 if spec.reg_j else (1 if max(spec.widths[1:-1]) <= 64 else 3))
     args = (dev(xs),) + ((dev(ys),) if spec.ncond else ()) + (dev(p), {})
     val, g = pkg.loss_and_gradient(icnf, mode, *args, eps=dev(eps))
     g = g.cpu().numpy().astype(np.float64)
     assert abs(float(val) - L) < 1e-4
     scale = np.abs(gref).max()
     assert np.max(np.abs(g - gref)) < 5e-5 * scale + 1e-6, np.max(np.abs(g - gref)) / scale
+
+
+def test_jvp_mode_gradient_through_the_vjp_twin_agrees_with_its_own_layerwise_gradient(pkg, oracles, monkeypatch):
+    """JVP mode without the Jacobian regulariser: the fused VJP-twin gradient against the mode's own layer-wise gradient
+    (CNF_JVP_GRAD_TWIN=0), same inputs - and the speed-up that motivates the route, at a batch that fills the chip."""
+    o64, _ = oracles
+    spec = o64.make_spec(nvars=8, hidden=[64, 64, 64], mode=1, reg_z=True)
+    B, alg, nsteps, lam = 4096, 1, 4, (0.02, 0.0, 0.0)
+    p, xs, eps, _ = o64.synth_inputs(spec, B, 55, bias_scale=0.2)
+    out = {}
+    for tag, env in (("twin", "1"), ("own", "0")):
+        monkeypatch.setenv("CNF_JVP_GRAD_TWIN", env)
+        icnf = make_icnf(pkg, spec, alg, nsteps, path=0, lambdas=lam)
+        mode = pkg.TrainMode(True)
+        assert icnf.grad_path(mode, B=B, alg=alg) == (1 if tag == "twin" else 2)
+        val, g, gx = pkg.loss_and_gradient(icnf, mode, dev(xs), dev(p), {}, eps=dev(eps), wrt_x=True)
+        out[tag] = (float(val), g.cpu().numpy().astype(np.float64), gx.cpu().numpy().astype(np.float64))
+    assert abs(out["twin"][0] - out["own"][0]) < 2e-5 * (1 + abs(out["own"][0]))
+    for k in (1, 2):
+        a, b = out["twin"][k], out["own"][k]
+        assert np.max(np.abs(a - b)) < 5e-5 * np.abs(b).max() + 1e-6
 
 
 @pytest.mark.parametrize("kw,lam", [
