@@ -346,7 +346,7 @@ def make_workload(pkg, o64, name, a, rank, dev, torch, arith=None, grad=None, ba
     P = torch.tensor(p, device=dev)
     args = (X,) + ((Y,) if Y is not None else ()) + (P, {})
     return dict(name=name, spec=spec, alg=alg, B=B, flop_ss=flop_ss, bytes_call_ss=bytes_call_ss,
-                bytes_fused=bytes_fused, desc=desc, icnf=icnf, mode=mode, args=args, E=E,
+                bytes_fused=bytes_fused, desc=desc, icnf=icnf, mode=mode, args=args, E=E, nparams=int(len(p)),
                 host=(p, xs, eps, ys), grad=(a.mode == "grad") if grad is None else bool(grad))
 
 
@@ -476,9 +476,12 @@ def report(w, m, a, steps, warmup, world):
     ach = flops_launch / (m["kern_ms"] * 1e-3) / 1e12
     roof = {
         "bound": "mfma", "achieved": ach, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-        "frac": ach / F32_MFMA_PEAK_TFLOPS, "traffic": measured_traffic(w["name"])[0],
-        "traffic_source": (f"committed PMC pass {measured_traffic(w['name'])[1]} (not collected by this run: bench.py "
-                           "cannot run rocprofv3 on itself)" if measured_traffic(w["name"])[1] else None),
+        "frac": ach / F32_MFMA_PEAK_TFLOPS, "traffic": measured_traffic(w["name"] + (":grad" if grad else ""))[0],
+        "traffic_source": (f"committed PMC pass {measured_traffic(w['name'] + (':grad' if grad else ''))[1]} (HBM bytes per step of the "
+                           "whole workload; not collected by this run: bench.py cannot run rocprofv3 on itself)"
+                           if measured_traffic(w["name"] + (":grad" if grad else ""))[1] else None),
+        # algorithmic bytes of a step: inputs read once, outputs written once (a gradient step also writes dloss/dps)
+        "algorithmic_bytes": w["bytes_fused"] * B + (4 * w["nparams"] if grad else 0),
         "kernel_ms": m["kern_ms"], "kernel_ms_median": m["kern_ms_median"], "kernel_ms_min": m["kern_ms_min"],
         "kernel_ms_max": m["kern_ms_max"], "flop_per_sample_step": flop_ss, "flop_per_launch": flops_launch,
         **extra,
@@ -490,6 +493,7 @@ def report(w, m, a, steps, warmup, world):
             "per_call_abi_frac_of_8TBps": w["bytes_call_ss"] * B * NSTEPS / (m["kern_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "stages_per_step": stages},
     }
+    roof["traffic_over_algorithmic"] = (roof["traffic"] / roof["algorithmic_bytes"]) if roof["traffic"] else None
     s = m["sustained"]
     if s:
         s = dict(s)
@@ -698,6 +702,8 @@ def main():
                     "roofline": {"kernel_ms": rf["kernel_ms"], "kernel_ms_median": rf["kernel_ms_median"], "frac": rf["frac"],
                                  "achieved": rf["achieved"], "peak": rf["peak"], "unit": rf["unit"],
                                  "flop_per_sample_step": rf["flop_per_sample_step"],
+                                 "traffic": rf["traffic"], "algorithmic_bytes": rf["algorithmic_bytes"],
+                                 "traffic_over_algorithmic": rf["traffic_over_algorithmic"], "traffic_source": rf["traffic_source"],
                                  **({"executed_frac": rf["executed_frac"]} if "executed_frac" in rf else {}),
                                  "what": ("loss + gradient (forward with checkpoints + reverse sweep), 3 F convention" if wi["grad"]
                                           else "the fused solve kernel")}}
