@@ -6,6 +6,7 @@ The directory name follows the repository contract (`continuousnormalizingflows.
 not a valid Python identifier; `__graft_entry__.load_package()` registers it as `cnf_amd`.
 """
 from . import _lib
+from ._lib import get_tuning, reload_tuning, set_tuning  # noqa: F401
 from .icnf import *  # noqa: F401,F403
 from .icnf import loss_sums, loss_mean  # noqa: F401
 from .icnf import loss_and_gradient  # noqa: F401

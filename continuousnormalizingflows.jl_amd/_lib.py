@@ -29,7 +29,7 @@ ERR_COMM = -6
 COMM_ID_BYTES = 128
 DTYPE_F32, DTYPE_F64 = 0, 1
 
-EXPORTS = ("cnf_version", "cnf_build_info", "cnf_last_error", "cnf_create", "cnf_destroy", "cnf_set_params",
+EXPORTS = ("cnf_version", "cnf_build_info", "cnf_get_tuning", "cnf_set_tuning", "cnf_last_error", "cnf_create", "cnf_destroy", "cnf_set_params",
            "cnf_kernel_path", "cnf_solve_controller", "cnf_repack_on_device", "cnf_aug_f", "cnf_integrate_fixed", "cnf_inference_fixed",
            "cnf_loss_sums", "cnf_loss_mean", "cnf_loss_grad_fixed", "cnf_loss_grad_grid", "cnf_grad_path", "cnf_step_embedded", "cnf_assemble_u0",
            "cnf_epilogue", "cnf_vcabm_begin", "cnf_vcabm_attempt", "cnf_vcabm_accept", "cnf_vcabm_state", "cnf_solve_vcabm", "cnf_solve_tsit5", "cnf_loss_grad_adaptive",
@@ -48,6 +48,14 @@ class CnfConfig(C.Structure):
                 ("mode", C.c_int32), ("nprobes", C.c_int32),
                 ("reg_z", C.c_int32), ("reg_j", C.c_int32), ("reg_aug", C.c_int32),
                 ("device_id", C.c_int32), ("kernel_path", C.c_int32), ("arith", C.c_int32)]
+
+
+TUNING_FIELDS = ("tile_split", "coopd", "coopd_grad", "coop_grad", "coop_grad_mid", "grad_layered", "grad_v1", "jvp_grad_twin", "layered_loss_by_solve", "device_controller", "dc_per_cu", "mfma_coop", "mfma_coopx", "mfma_nt", "mfma_pre", "mfma_prio", "mfma_queue", "coop_nt", "cg_one_per_cu", "cg_compare", "layered_min_b", "layered_kc", "layered_no_kckpt", "layered_act_gib", "lg_gemm", "lg_spw", "lg_nw", "lg_gemm2_wide", "lg_wgrad_per_cu", "lg_wgrad_t1", "lg_wgrad_t2")
+
+
+class CnfTuning(C.Structure):
+    """cnf_tuning (include/cnf.h): the library's switchboard, one int32 per switch."""
+    _fields_ = [(f, C.c_int32) for f in TUNING_FIELDS]
 
 
 class SolveStats(C.Structure):
@@ -101,6 +109,8 @@ def load():
     lib.cnf_kernel_family_for.argtypes = [vp, C.c_int64, C.c_int]
     lib.cnf_kernel_name.argtypes = [vp]
     lib.cnf_kernel_name.restype = C.c_char_p
+    lib.cnf_get_tuning.argtypes = [C.POINTER(CnfTuning)]
+    lib.cnf_set_tuning.argtypes = [C.POINTER(CnfTuning)]
     lib.cnf_build_info.argtypes = []
     lib.cnf_build_info.restype = C.c_char_p
     lib.cnf_loss_grad_grid.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_float), fp, fp, fp, C.c_int64,
@@ -163,3 +173,41 @@ def ptr(t) -> C.c_void_p:
 def clamp_maxiters(sol_kwargs) -> int:
     """sol_kwargs.maxiters as the C int the ABI takes (the reference's usage example passes typemax(Int))."""
     return min(int(sol_kwargs.get("maxiters", 100000)), 2 ** 31 - 1)
+
+
+def get_tuning() -> dict:
+    """The switchboard's current values (cnf_get_tuning)."""
+    t = CnfTuning()
+    rc = load().cnf_get_tuning(C.byref(t))
+    if rc:
+        raise CnfError(rc, "cnf_get_tuning")
+    return {f: int(getattr(t, f)) for f in TUNING_FIELDS}
+
+
+def set_tuning(**kw) -> dict:
+    """Change switches of the library's process-wide switchboard (cnf_set_tuning); returns the previous values of the ones
+    changed.  Note that cnf_create re-reads the CNF_* environment variables: set switches AFTER the handles they concern exist."""
+    t = CnfTuning()
+    lib = load()
+    rc = lib.cnf_get_tuning(C.byref(t))
+    if rc:
+        raise CnfError(rc, "cnf_get_tuning")
+    old = {}
+    for k, v in kw.items():
+        if k not in TUNING_FIELDS:
+            raise KeyError(f"cnf_tuning has no field {k!r}")
+        old[k] = int(getattr(t, k))
+        setattr(t, k, int(v))
+    rc = lib.cnf_set_tuning(C.byref(t))
+    if rc:
+        raise CnfError(rc, "cnf_set_tuning")
+    return old
+
+
+def reload_tuning() -> dict:
+    """Re-read the switchboard from its defaults and the CNF_* environment variables (cnf_set_tuning(NULL): what cnf_create does),
+    so that a variable changed after a handle was created takes effect for it too."""
+    rc = load().cnf_set_tuning(None)
+    if rc:
+        raise CnfError(rc, "cnf_set_tuning")
+    return get_tuning()

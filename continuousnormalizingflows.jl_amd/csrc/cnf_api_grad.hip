@@ -36,9 +36,7 @@ extern "C" {
 // fused reverse-sweep kernel, unless CNF_GRAD_LAYERED=1 forces the layer-wise path (tests, A/B timing)
 extern "C++" {
 bool cnf::api_grad_is_fused(const cnf_handle* h) {
-    const char* force = getenv("CNF_GRAD_LAYERED");
-    return h->path == CNF_PATH_MFMA && grad_supported(api_grad_cfg(h)) && mfma_plan_is_per_wave(h->plan) &&
-           !(force && *force && *force != '0');
+    return h->path == CNF_PATH_MFMA && grad_supported(api_grad_cfg(h)) && mfma_plan_is_per_wave(h->plan) && tuning().grad_layered == 0;
 }
 }  // extern "C++"
 
@@ -49,8 +47,7 @@ extern "C++" {
 bool cnf::api_grad_uses_coop_aux(const cnf_handle* h, int64_t B) { return h->grad.plan_cg && h->grad.cg_packed && B >= 4096; }
 
 bool cnf::api_grad_uses_slab(const cnf_handle* h) {
-    const char* force = getenv("CNF_GRAD_LAYERED");
-    return (h->grad.slab_packed || !h->par.have) && grad_slab_supported(h->cfg) && !(force && *force && *force != '0');
+    return (h->grad.slab_packed || !h->par.have) && grad_slab_supported(h->cfg) && tuning().grad_layered == 0;
 }
 }  // extern "C++"
 
@@ -69,7 +66,7 @@ cnf::GradRoute cnf::api_grad_route(const cnf_handle* h, int64_t B, int alg, bool
     }
     if (slab) { r.path = 1; r.slab = true; return r; }
     // CNF_LAYERED_LOSS_BY_SOLVE (A/B switch of the layer-wise path: loss from a separate solve) keeps the call layer-wise
-    if (fits && !getenv("CNF_LAYERED_LOSS_BY_SOLVE") && (h->par.packed_dev || !h->par.have) && coop_grad_eligible(h->cfg, h->plan, lam0, on_grid)) {
+    if (fits && !tuning().layered_loss_by_solve && (h->par.packed_dev || !h->par.have) && coop_grad_eligible(h->cfg, h->plan, lam0, on_grid)) {
         r.path = 3; return r;
     }
     r.path = layered_grad_supported(h->cfg) ? 2 : 0;
@@ -142,7 +139,7 @@ static int loss_grad_impl(cnf_handle* h, const char* who, int alg, int nsteps, f
         // (the cooperative sweep's checkpointing forward solve always yields the loss terms; the layer-wise sweep accumulates
         // them unless CNF_LAYERED_LOSS_BY_SOLVE asks for a separate solve; the slab kernel needs that solve)
         const bool use_cg = route.use_cg_aux;
-        const bool loss_in_sweep = sums4 && (route.path == 3 || (route.path == 2 && !getenv("CNF_LAYERED_LOSS_BY_SOLVE")));
+        const bool loss_in_sweep = sums4 && (route.path == 3 || (route.path == 2 && !tuning().layered_loss_by_solve));
         if (sums4) {
             const size_t need = ((size_t)h->S + 4) * (size_t)B * sizeof(float);
             if (need > h->grad.ws_bytes) {

@@ -570,7 +570,7 @@ hipError_t coop_launch(int HT, int L, int ZR, int ACT, const KArgs& a, int num_c
     const CoopInst* c = coop_find(HT, L, ZR, ACT);
     if (!c) return hipErrorNotSupported;
     // sample tiles per super-tile: 4 (one workgroup per CU); CNF_COOP_NT=2 in a -DCNF_COOP_NT2 build picks the two-workgroup form
-    static const int nt_env = [] { const char* e = getenv("CNF_COOP_NT"); return (e && *e) ? atoi(e) : 0; }();
+    const int nt_env = tuning().coop_nt;
     const int NT = (nt_env == 2 && c->fn[2]) ? 2 : 4;
     const long long nst = (a.B + 16 * NT - 1) / (16 * NT);
     const long long cap = (long long)num_cus * (NT == 4 ? 1 : 2);

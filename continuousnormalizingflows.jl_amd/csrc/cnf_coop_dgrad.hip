@@ -790,7 +790,8 @@ static bool dg_fits(int HT_real, int DT, int A, int cvn, int NSAMP, bool* palias
 bool coopd_grad_supported(int H, int D, int L, int ACT, int HT_lay, int ZR_lay, int CR_lay) {
     if (L != 2 || CR_lay != 0) return false;
     bool force = false;
-    if (const char* e = getenv("CNF_COOPD_GRAD")) { if (*e == '0') return false; force = *e == '2'; }
+    if (tuning().coopd_grad == 0) return false;
+    force = tuning().coopd_grad == 2;
     const int HT_real = (H + 15) / 16, KZ = (D + 3) / 4;
     if (HT_real < 5 || HT_real > HT_lay || KZ > ZR_lay) return false;
     const DGradInst* c = dg_find(HT_real, KZ, ACT);

@@ -700,7 +700,7 @@ int coop_grad_scratch_slots(int L) { return 2 * L - 3; }   // h_1 .. h_{L-1}, db
 // workgroups of a launch (16-sample super-tiles; two workgroups per CU where two sets of exchange buffers fit): the host sizes
 // the per-workgroup scratch with it
 int coop_grad_nblocks(long long B, int num_cus, int HT, int ZR, int CR, int NT) {
-    static const int one = [] { const char* v = getenv("CNF_CG_ONE_PER_CU"); return v && *v == '1' ? 1 : 0; }();
+    const int one = tuning().cg_one_per_cu == 1 ? 1 : 0;
     const long long nst = (B + 16 * NT - 1) / (16 * NT), cap = (long long)num_cus * ((!one && 2 * coop_grad_lds_bytes(HT, ZR, NT, CR) <= 160 * 1024) ? 2 : 1);
     return (int)(nst < cap ? nst : cap);
 }

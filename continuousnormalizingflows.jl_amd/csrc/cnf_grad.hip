@@ -555,7 +555,7 @@ hipError_t grad_launch(const cnf_config& c, const float* packed_dev, const float
     static DeviceOnce done_v2[sizeof(kGrad) / sizeof(kGrad[0])];
     bool v2 = false;
     static DeviceOnce done_v2p[sizeof(kGrad) / sizeof(kGrad[0])];
-    if (ckpt_k && !getenv("CNF_GRAD_V1")) {
+    if (ckpt_k && !tuning().grad_v1) {
         GradKernel k2 = c.nprobes == 1 ? grad2_kernel(gi->HT, gi->L, gi->ZR, gi->CR, gi->ACT) : grad2_probes_kernel(gi->HT, gi->L, gi->ZR, gi->CR, gi->ACT);
         if (k2) { kern = k2; v2 = true; }
     }

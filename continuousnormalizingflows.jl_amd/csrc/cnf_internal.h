@@ -6,6 +6,11 @@
 
 namespace cnf {
 
+// the switchboard (cnf_tuning.hip): current values; re-read from the CNF_* environment variables by cnf_create
+const cnf_tuning& tuning();
+void tuning_from_env();
+
+
 // Device-side description of the Dense chain (passed by value as a kernel argument).
 struct NetDev {
     int D, C, autonomous, n_layers, maxw;

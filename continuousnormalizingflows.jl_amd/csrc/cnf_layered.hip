@@ -679,9 +679,7 @@ hipError_t layered_grad(LayeredGrad** ctx, const cnf_config& c, const float* P_d
     // (cnf_lgemm.hip); CNF_LAYERED_KC overrides the chunk length
     long long kc = 0;
     int nslab = lg_wgrad_chunks(maxw, B, G.num_cus, &kc);
-    if (const char* e = getenv("CNF_LAYERED_KC")) {
-        if (atoll(e) >= 16) { kc = (atoll(e) + 3) / 4 * 4; nslab = (int)((B + kc - 1) / kc); }
-    }
+    if (tuning().layered_kc >= 16) { kc = ((long long)tuning().layered_kc + 3) / 4 * 4; nslab = (int)((B + kc - 1) / kc); }
 
     // ---- workspace ----
     const long long DB = (long long)D * B;
@@ -690,15 +688,14 @@ hipError_t layered_grad(LayeredGrad** ctx, const cnf_config& c, const float* P_d
     const long long o_PA = take(npa_pad), o_slab = take(npa_pad * nslab), o_zck = take(DB * (nsteps + 1));
     // stage derivatives of every step are kept when they fit 4 GiB, otherwise recomputed in the reverse sweep
     const int nst = alg == CNF_ALG_RK4 ? 4 : 6;
-    const bool keep_k = (double)DB * nst * nsteps * sizeof(float) <= 4.0 * 1024 * 1024 * 1024 && !getenv("CNF_LAYERED_NO_KCKPT");
+    const bool keep_k = (double)DB * nst * nsteps * sizeof(float) <= 4.0 * 1024 * 1024 * 1024 && !tuning().layered_no_kckpt;
     const long long o_kck = keep_k ? take(DB * nst * nsteps) : 0;
     // the activations of every stage (a_l with its ones row, act'_l) are kept too when they fit the budget (default 48 GiB of
     // the 288; CNF_LAYERED_ACT_GIB): the reverse sweep then reads them instead of recomputing the forward chain of the stage
     long long act_stage = (long long)(c.widths[0] + 1) * B;
     for (int l = 0; l < N; ++l) act_stage += (long long)(L.wout[l] + 1) * B + (long long)L.wout[l] * B;
     act_stage = (act_stage + 63) / 64 * 64 + 64 * (N + 2) * 2;
-    double act_gib = 48.0;
-    if (const char* e = getenv("CNF_LAYERED_ACT_GIB")) act_gib = atof(e);
+    const double act_gib = (double)tuning().layered_act_gib;
     bool keep_act = keep_k && (double)act_stage * nst * nsteps * sizeof(float) <= act_gib * 1024.0 * 1024.0 * 1024.0;
     if (keep_act) {   // ... and half of what the device has free (counting the workspace this context already holds)
         size_t mfree = 0, mtotal = 0;
@@ -996,7 +993,7 @@ long long coop_grad_max_columns(const cnf_config& c, int alg) {
 bool coop_grad_eligible(const cnf_config& c, const MfmaPlan* plan, const float lam[3], bool on_grid) {
     int HT, L, ZR, ACT, CR;
     if (!mfma_plan_coop_grad_shape(plan, &HT, &L, &ZR, &ACT, &CR)) return false;
-    if (const char* e = getenv("CNF_COOP_GRAD")) { if (*e == '0') return false; }
+    if (tuning().coop_grad == 0) return false;
     if (c.mode != CNF_MODE_HUTCH_VJP || c.nprobes != 1 || (c.ncond != 0) != (CR != 0)) return false;
     // the forward solve must be able to checkpoint: on a non-uniform grid (the frozen steps of an adaptive solve) a cooperative
     // plan does so through the extended kernel's instance of exactly its own layout, if there is one
@@ -1102,7 +1099,7 @@ hipError_t coop_grad(LayeredGrad** ctx, const cnf_config& c, MfmaPlan* plan, con
         a.step = n; a.tn = t0 + (float)n * dt; a.dt = dt;
         if (tgrid) { a.tn = tgrid[n]; a.dt = tgrid[n + 1] - tgrid[n]; }
 #ifdef CNF_CG_COMPARE_BUILD
-        if (getenv("CNF_CG_COMPARE") && Lh == 2 && CR == 0) {
+        if (tuning().cg_compare && Lh == 2 && CR == 0) {
             // debug: both sweeps on the same inputs, operand arrays compared
             const size_t nl = (size_t)ntp * 64 * ZR, nz = (size_t)ntp * 64 * 6 * ZR;
             const size_t sz[6] = {(size_t)H * B2, (size_t)H * B2, (size_t)ldy * B2, (size_t)ldy * B2, (size_t)(n_in + 1) * B2, (size_t)D * B2};

@@ -462,17 +462,17 @@ static hipError_t lg_gemm_dispatch(LgGemmArgs a, hipStream_t st) {
     // fits LDS and there are enough samples to fill the chip that way
     const int splits = (a.MT + 15) / 16;
     a.mts = (a.MT + splits - 1) / splits;
-    static const int variant = [] { const char* v = getenv("CNF_LG_GEMM"); return v && *v ? atoi(v) : 2; }();
+    const int variant = tuning().lg_gemm;
     if (variant == 2 && a.KQ <= LG2_KQ_MAX) {
         // enough sub-panels per workgroup for the pipeline to pay (>= 4 where the batch allows), at least ~2 workgroups per CU
-        static const int spw_env = [] { const char* v = getenv("CNF_LG_SPW"); return v && *v ? atoi(v) : 0; }();
+        const int spw_env = tuning().lg_spw;
         const long long nsub = (a.N + 31) / 32;
         long long spw = nsub * splits / 512;
         if (spw < 1) spw = 1;
         if (spw > 8) spw = 8;
         if (spw_env > 0) spw = spw_env;
         a.spw = (int)spw;
-        static const int nw = [] { const char* v = getenv("CNF_LG_NW"); return v && *v ? atoi(v) : 4; }();
+        const int nw = tuning().lg_nw;
         if (nw == 8 && a.mts > 8) return lg_gemm2_launch<2, EPI, 8>(a, st);   // 9..16 row tiles over 8 waves
         if (a.mts <= 4) return lg_gemm2_launch<1, EPI>(a, st);
         if (a.mts <= 8) return lg_gemm2_launch<2, EPI>(a, st);
@@ -480,7 +480,7 @@ static hipError_t lg_gemm_dispatch(LgGemmArgs a, hipStream_t st) {
     }
     // K = 273 .. 512 (the default architecture from nvariables = 33 on, where it runs layer-wise): the same pipeline, one workgroup
     // of eight waves per CU (the 392 x 392 products of nvariables = 48: 193 - 214 us on lg_gemm_kernel, 50 TFLOP/s)
-    static const int wide2 = [] { const char* v = getenv("CNF_LG_GEMM2_WIDE"); return v && *v ? atoi(v) : 1; }();
+    const int wide2 = tuning().lg_gemm2_wide;
     if (variant == 2 && wide2 && a.KQ <= LG2_KQ_WIDE) {
         const long long nsub = (a.N + 31) / 32;
         long long spw = nsub * splits / 256;
@@ -734,13 +734,12 @@ int lg_wgrad_chunks(int M, long long B, int num_cus, long long* chunk_out, int p
     const int groups = ((Nc + 15) / 16 + 8) / 9;      // column groups (lg_wgrad)
     // workgroups per CU: 2 for the per-stage calls of the layer-wise path (B columns), 4 for the per-step calls of the
     // cooperative gradient (2 x stages x B columns: cfg4 loss + gradient 139.9 -> 133.3 ms; 1: 162, 3: 135, 8: 135)
-    static const int per_cu_env = [] { const char* v = getenv("CNF_LG_WGRAD_PER_CU"); return v && *v ? atoi(v) : 0; }();
+    const int per_cu_env = tuning().lg_wgrad_per_cu;
     // (three workgroups are resident per CU.  The per-step calls' workgroups per CU grow with the number of workgroups that
     // share a chunk: their costs differ - dead strips, a short last column group - and more, smaller chunks even the CUs out.
     // Loss + gradient of the default architecture, B = 32 768, against 4 per CU for all: nvariables = 16: 50.1 -> 47.7 ms,
     // 20: 63.1 -> 59.9, 28: 100.6 -> 96.5, 32: 152.9 -> 146.0, 40: 218.2 -> 206.0; profiles/r4/r4u_wgrad_chunking.txt)
-    static const int t1 = [] { const char* v = getenv("CNF_LG_WGRAD_T1"); return v && *v ? atoi(v) : 5; }();
-    static const int t2 = [] { const char* v = getenv("CNF_LG_WGRAD_T2"); return v && *v ? atoi(v) : 8; }();
+    const int t1 = tuning().lg_wgrad_t1, t2 = tuning().lg_wgrad_t2;
     const bool uneven = M % 64 != 0;   // (256 x 257 has no dead strip: 6 and 12 tie there, 108.3 against 108.5 ms at cfg4)
     // (the layer-wise path's per-stage calls, 2 per CU: 6 from 12 sharers on - nvariables = 48: 645 -> 627 ms, 56: 780 -> 735)
     const int by_rule = per_cu_dflt == 2 ? (RB * groups >= 12 ? 6 : 2)

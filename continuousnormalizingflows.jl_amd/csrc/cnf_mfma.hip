@@ -91,11 +91,6 @@ static bool act_matches(int inst_act, int cfg_act) {
     return inst_act == cfg_act || (inst_act == CNF_ACT_TANH_PRESCALED && cfg_act == CNF_ACT_TANH);
 }
 
-static int env_int(const char* name, int dflt) {
-    const char* v = getenv(name);
-    return (v && *v) ? atoi(v) : dflt;
-}
-
 static MfmaPlan* mfma_plan_create_impl(const cnf_config& c, bool coop_only) {
     const int N = c.n_layers, L = N - 1;
     if (L < 1) return nullptr;
@@ -111,9 +106,9 @@ static MfmaPlan* mfma_plan_create_impl(const cnf_config& c, bool coop_only) {
     const int HT = (H + 15) / 16, ZR = (D + 3) / 4, CR = (c.ncond + 3) / 4;
     const int engine = c.mode == CNF_MODE_HUTCH_VJP ? ENG_VJP : ENG_TAN;
     const int KP = c.mode == CNF_MODE_EXACT ? 1 : c.nprobes;
-    const int want_nt = env_int("CNF_MFMA_NT", 0);
-    const int want_pre = env_int("CNF_MFMA_PRE", -1);
-    const bool force_coop = coop_only || env_int("CNF_MFMA_COOP", 0) != 0;
+    const int want_nt = tuning().mfma_nt;
+    const int want_pre = tuning().mfma_pre;
+    const bool force_coop = coop_only || tuning().mfma_coop != 0;
     auto make_coop = [&]() -> MfmaPlan* {
         int zr_inst = ZR, ht_inst = HT;
         if (!coop_supported(HT, L, ZR, CR, c.acts[0], engine, KP, &zr_inst, &ht_inst)) return nullptr;
@@ -151,8 +146,8 @@ static MfmaPlan* mfma_plan_create_impl(const cnf_config& c, bool coop_only) {
         p->cfg = c;
         p->nthreads = in.nthreads;
         p->num_cus = 0;
-        p->prio_mode = env_int("CNF_MFMA_PRIO", 0);
-        p->use_queue = env_int("CNF_MFMA_QUEUE", 0);
+        p->prio_mode = tuning().mfma_prio;
+        p->use_queue = tuning().mfma_queue;
         p->queue_dev = nullptr;
         p->kind = 0;
         snprintf(p->name, sizeof(p->name), "mfma_%s<HT=%d,L=%d,ZR=%d,CR=%d,act=%d,K=%d,pre=%d,nt=%d,%s>",
@@ -208,7 +203,7 @@ static MfmaPlan* mfma_plan_create_impl(const cnf_config& c, bool coop_only) {
     if (MfmaPlan* p = make_coop()) return p;
     // 4. ... and its extended form: conditions, several probes, the exact trace as D unit probes (three hidden layers: with two
     //    the layer-wise path's single Q product is cheaper than D pullbacks), Hutchinson JVP (probes pushed through the forward images).
-    if (c.arith != CNF_ARITH_F32 || env_int("CNF_MFMA_COOPX", 1) == 0) return nullptr;
+    if (c.arith != CNF_ARITH_F32 || tuning().mfma_coopx == 0) return nullptr;
     const bool exact = c.mode == CNF_MODE_EXACT;
     if (!(c.mode == CNF_MODE_HUTCH_VJP || c.mode == CNF_MODE_HUTCH_JVP || (exact && (L == 3 || L == 2)))) return nullptr;
     if (!exact && (c.nprobes < 1 || c.nprobes > 64)) return nullptr;
@@ -442,7 +437,7 @@ static bool plan_uses_coopd(const MfmaPlan* p, long long B) {
     if (!p || (p->kind != 2 && p->kind != 1) || p->KP != 1) return false;   // extended plans, and cooperative ones (one probe, VJP, no conditions)
     const bool exact = p->cfg.mode == CNF_MODE_EXACT;
     if (!(p->cfg.mode == CNF_MODE_HUTCH_VJP || (exact && p->L == 2 && p->q_extra > 0))) return false;
-    const int env = env_int("CNF_COOPD", 1);
+    const int env = tuning().coopd;
     if (env == 0) return false;
     int hmax = 0;
     for (int l = 1; l < p->cfg.n_layers; ++l) hmax = p->cfg.widths[l] > hmax ? p->cfg.widths[l] : hmax;
@@ -503,7 +498,7 @@ void grad_pack(const cnf_config& c, const float* lux, const size_t* w_off, const
 // for bit.  CNF_TILE_SPLIT=0 keeps the per-wave kernel everywhere, =2 forces the split form at any batch size.
 static bool plan_takes_tile_split(MfmaPlan* p, long long B) {
     if (p->kind != 0 || plan_ensure_cus(p) != hipSuccess) return false;
-    const int split_env = env_int("CNF_TILE_SPLIT", 1);   // read per call: tests and A/B runs switch it inside one process
+    const int split_env = tuning().tile_split;   // (cnf_set_tuning switches it inside one process: tests and A/B runs)
     const long long ntiles = (B + 15) / 16;
     const int D = p->cfg.nvars + p->cfg.naug;
     return split_env > 0 && p->ENGINE == ENG_VJP && p->KP == 1 && p->CR == 0 && p->arith == 0 && p->with_bwd && !p->use_queue &&
@@ -602,7 +597,7 @@ hipError_t mfma_solve(MfmaPlan* p, const float* packed_dev, const SolveArgs& s, 
 // no such kernel.
 int64_t mfma_adaptive_capacity(MfmaPlan* p) {
     if (!p || p->kind != 0 || !p->launch_adapt) return 0;
-    if (env_int("CNF_DEVICE_CONTROLLER", 1) == 0) return 0;
+    if (tuning().device_controller == 0) return 0;
     if (p->num_cus == 0) {
         int dev = 0;
         hipDeviceProp_t prop;
@@ -615,7 +610,7 @@ int64_t mfma_adaptive_capacity(MfmaPlan* p) {
         if (e != hipSuccess) { (void)hipGetLastError(); occ = 0; }
         // one workgroup per CU: what the kernel is compiled for (waves_per_eu) and what the tests cover; a second resident
         // workgroup (possible when the register count happens to allow it) only halves the active waves per workgroup
-        const int cap_env = env_int("CNF_DC_PER_CU", 1);
+        const int cap_env = tuning().dc_per_cu;
         p->adapt_per_cu = occ < cap_env ? occ : cap_env;
     }
     return (int64_t)p->num_cus * p->adapt_per_cu * (p->nthreads / 64) * 16;
@@ -686,7 +681,7 @@ hipError_t mfma_solve_adaptive(MfmaPlan* p, const float* packed_dev, const Solve
 // Largest batch the device-resident VCABM kernel takes (256-thread workgroups, one tile per wave), 0 if the plan has none.
 int64_t mfma_vcabm_capacity(MfmaPlan* p) {
     if (!p || p->kind != 0 || !p->launch_vcabm) return 0;
-    if (env_int("CNF_DEVICE_CONTROLLER", 1) == 0) return 0;
+    if (tuning().device_controller == 0) return 0;
     if (p->num_cus == 0) {
         int dev = 0;
         hipDeviceProp_t prop;
@@ -697,7 +692,7 @@ int64_t mfma_vcabm_capacity(MfmaPlan* p) {
         int occ = 0;
         const hipError_t e = p->launch_vcabm(KArgs{}, AArgs{}, p->lay.lds_total * (int)sizeof(float), 0, nullptr, &occ);
         if (e != hipSuccess) { (void)hipGetLastError(); occ = 0; }
-        const int cap_env = env_int("CNF_DC_PER_CU", 1);
+        const int cap_env = tuning().dc_per_cu;
         p->vcabm_per_cu = occ < cap_env ? occ : cap_env;
     }
     return (int64_t)p->num_cus * p->vcabm_per_cu * 4 * 16;

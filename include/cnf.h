@@ -33,6 +33,7 @@
  *   training                 cnf_loss_grad_fixed, cnf_loss_grad_grid, cnf_loss_grad_adaptive  (dloss/dps, optionally dloss/dxs)
  *   column shards (RCCL)     cnf_comm_unique_id, cnf_comm_init, cnf_comm_init_all, cnf_comm_destroy, cnf_comm_rank, cnf_comm_size,
  *                            cnf_allreduce_loss (the mean in `loss`), cnf_allreduce_sum, cnf_comm_group_start / _end
+ *   tuning (A/B, tests)      cnf_get_tuning, cnf_set_tuning
  *   introspection            cnf_version, cnf_build_info, cnf_last_error, cnf_kernel_path, cnf_kernel_family, cnf_grad_path, cnf_grad_path_for, cnf_repack_on_device, cnf_solve_controller
  */
 #ifndef CNF_H
@@ -107,6 +108,46 @@ typedef struct {
 } cnf_config;
 
 typedef struct cnf_handle cnf_handle;
+
+/* Tuning switchboard: every A/B and test switch of the library in one place.  The defaults are what ships; the environment
+ * variable CNF_<FIELD IN CAPITALS> overrides a field when a handle is created (cnf_create re-reads the environment - a test hook,
+ * not configuration), cnf_set_tuning replaces the whole board afterwards.  Process-wide: the switches select among kernels that
+ * compute the same thing (parity tests cross-check them), so they are not part of a handle's identity. */
+typedef struct cnf_tuning {
+    int32_t tile_split;            /* CNF_TILE_SPLIT, default 1: 1: whole fixed-step solves of per-wave shapes with at most one 16-sample tile per CU take the tile-split kernel; 0: never; 2: always */
+    int32_t coopd;                 /* CNF_COOPD, default 1: dealt cooperative kernels (csrc/cnf_coop_d*.hip): 1 above 4096 columns where they serve the plan; 0 off; 2 at every batch */
+    int32_t coopd_grad;            /* CNF_COOPD_GRAD, default 1: dealt reverse sweep (csrc/cnf_coop_dgrad.hip): 1 where it has an instance; 0 off (section 8.4's sweep); 2 forced */
+    int32_t coop_grad;             /* CNF_COOP_GRAD, default 1: cooperative reverse sweep (gradient path 3); 0: those shapes train layer-wise */
+    int32_t coop_grad_mid;         /* CNF_COOP_GRAD_MID, default 1: auxiliary cooperative plan for the gradient of 7-8-tile slab shapes from 4096 columns on; 0 off */
+    int32_t grad_layered;          /* CNF_GRAD_LAYERED, default 0: 1: every gradient takes the layer-wise path (A/B, cross-checks) */
+    int32_t grad_v1;               /* CNF_GRAD_V1, default 0: 1: the narrow gradient runs on the exchange kernels of rounds 2-4 (cnf_grad.hip / cnf_grad_probes.hip) instead of cnf_grad2.hip */
+    int32_t jvp_grad_twin;         /* CNF_JVP_GRAD_TWIN, default 1: JVP mode without the |J eps| regulariser trains through the VJP mode's fused sweeps; 0: its own layer-wise gradient */
+    int32_t layered_loss_by_solve; /* CNF_LAYERED_LOSS_BY_SOLVE, default 0: 1: the layer-wise gradient takes its loss from a separate solve instead of accumulating it in the sweep */
+    int32_t device_controller;     /* CNF_DEVICE_CONTROLLER, default 1: one-launch adaptive Tsit5 / VCABM with the step controller on the device where the batch fits; 0: host loop */
+    int32_t dc_per_cu;             /* CNF_DC_PER_CU, default 1: workgroups per CU of the one-launch adaptive kernels */
+    int32_t mfma_coop;             /* CNF_MFMA_COOP, default 0: 1: cnf_create prefers the cooperative kernel where a per-wave instance also fits (tests) */
+    int32_t mfma_coopx;            /* CNF_MFMA_COOPX, default 1: extended cooperative kernel (csrc/cnf_coop_x.hip); 0 off */
+    int32_t mfma_nt;               /* CNF_MFMA_NT, default 0: threads per workgroup of the per-wave solve kernel (0: the instance's own) */
+    int32_t mfma_pre;              /* CNF_MFMA_PRE, default -1: hoisting level of the per-wave solve kernel (-1: the best instance) */
+    int32_t mfma_prio;             /* CNF_MFMA_PRIO, default 0: s_setprio scheme of the per-wave solve kernel (A/B; no scheme won) */
+    int32_t mfma_queue;            /* CNF_MFMA_QUEUE, default 0: 1: dynamic tile queue instead of the static stride (A/B) */
+    int32_t coop_nt;               /* CNF_COOP_NT, default 0: sample tiles per super-tile of the cooperative solve kernel (0: the instance's own) */
+    int32_t cg_one_per_cu;         /* CNF_CG_ONE_PER_CU, default 0: 1: one workgroup per CU for the cooperative reverse sweep (A/B) */
+    int32_t cg_compare;            /* CNF_CG_COMPARE, default 0: debug builds (-DCNF_CG_COMPARE_BUILD) only: run both sweeps and compare their operand arrays */
+    int32_t layered_min_b;         /* CNF_LAYERED_MIN_B, default 0: batches below this of an AUTO-resolved layer-wise handle take the SIMT kernels (0: never) */
+    int32_t layered_kc;            /* CNF_LAYERED_KC, default 0: column chunk of the layer-wise weight-cotangent products (0: lg_wgrad_chunks' choice) */
+    int32_t layered_no_kckpt;      /* CNF_LAYERED_NO_KCKPT, default 0: 1: the layer-wise reverse sweep recomputes the stage derivatives instead of keeping them */
+    int32_t layered_act_gib;       /* CNF_LAYERED_ACT_GIB, default 48: GiB of stage activations the layer-wise gradient may keep (of the 288 GB of HBM) */
+    int32_t lg_gemm;               /* CNF_LG_GEMM, default 2: generic product kernel: 2 = lg_gemm2 (double-buffered sub-panels), 1 = the round-1 kernel */
+    int32_t lg_spw;                /* CNF_LG_SPW, default 0: lg_gemm2: sub-panels per workgroup (0: by shape) */
+    int32_t lg_nw;                 /* CNF_LG_NW, default 4: lg_gemm2: waves per workgroup for K <= 272 */
+    int32_t lg_gemm2_wide;         /* CNF_LG_GEMM2_WIDE, default 1: lg_gemm2's eight-wave instance for K = 273 .. 512; 0: the round-1 kernel */
+    int32_t lg_wgrad_per_cu;       /* CNF_LG_WGRAD_PER_CU, default 0: lg_wgrad workgroups per CU (0: 3 / 6 / 12 by the number of workgroups sharing a chunk) */
+    int32_t lg_wgrad_t1;           /* CNF_LG_WGRAD_T1, default 5: lg_wgrad: chunk-sharing threshold for 6 per CU */
+    int32_t lg_wgrad_t2;           /* CNF_LG_WGRAD_T2, default 8: lg_wgrad: chunk-sharing threshold for 12 per CU */
+} cnf_tuning;
+int cnf_get_tuning(cnf_tuning* out);
+int cnf_set_tuning(const cnf_tuning* in);   /* NULL: defaults + environment again, as cnf_create does */
 
 int cnf_version(void);
 const char* cnf_last_error(void);

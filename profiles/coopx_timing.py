@@ -20,7 +20,7 @@ for name, kw, B, alg in CASES:
     X, E, Y, P = t(xs), t(eps), t(ys), torch.tensor(p, device=dev)
     r = {}
     for tag, env in (("coopx", "1"), ("layered", "0")):
-        os.environ["CNF_MFMA_COOPX"] = env
+        os.environ["CNF_MFMA_COOPX"] = env; pkg.reload_tuning()
         layers = [pkg.Dense(spec.widths[i], spec.widths[i + 1], ["identity", "tanh", "softplus"][spec.acts[i]]) for i in range(len(spec.acts))]
         reg = bool(spec.reg_z or spec.reg_j)
         icnf = pkg.ICNF(nvariables=spec.nvars, naugments=0, nconditions=spec.ncond, nn=pkg.Chain(*layers), compute_mode=pkg.HIPVecJacMatrixMode(),
@@ -41,5 +41,5 @@ for name, kw, B, alg in CASES:
     r["speedup"] = round(r["layered_ms"] / r["coopx_ms"], 2)
     r["max_abs_dlogp_between_paths"] = abs(r["coopx_logp0"] - r["layered_logp0"])
     out[name] = r
-del os.environ["CNF_MFMA_COOPX"]
+del os.environ["CNF_MFMA_COOPX"]; pkg.reload_tuning()
 print(json.dumps(out, indent=1))

@@ -15,7 +15,7 @@ for nv in [int(v) for v in os.environ.get("DG_NV", "16,20,24,28").split(",")]:
     m = pkg.TrainMode(True)
     res = {}
     for tag, env in (("old", "0"), ("dealt", os.environ.get("DG_FORCE", "1"))):
-        os.environ["CNF_COOPD_GRAD"] = env
+        os.environ["CNF_COOPD_GRAD"] = env; pkg.reload_tuning()
         for _ in range(2): l, gr = pkg.loss_and_gradient(icnf, m, X, P, st, eps=E)[:2]
         torch.cuda.synchronize()
         t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

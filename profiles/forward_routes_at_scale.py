@@ -24,7 +24,7 @@ for kind, n, mode in cases:
     m = pkg.TrainMode(True) if mode == "train" else pkg.TestMode()
     out = {}
     for tag, env in (("dealt", "1"), ("extended", "0")):
-        os.environ["CNF_COOPD"] = env
+        os.environ["CNF_COOPD"] = env; pkg.reload_tuning()
         ic2 = mk()
         r = pkg.inference(ic2, m, X, P, st, eps=E)
         out[tag] = (r[0].double().cpu(), ic2.kernel_family(m, B=B))

@@ -22,7 +22,7 @@ for name, nv, na, hid, act, K in shapes:
     X = torch.randn(B, nv, device=dev).t(); E = torch.randn(B, K * D, device=dev).t()
     res, P = {}, None
     for tag, env in (("default", "0"), ("layered", "1")):
-        os.environ["CNF_GRAD_LAYERED"] = env; os.environ["CNF_COOP_GRAD"] = "0" if env == "1" else "1"
+        os.environ["CNF_GRAD_LAYERED"] = env; os.environ["CNF_COOP_GRAD"] = "0" if env == "1" else "1"; pkg.reload_tuning()
         ic = pkg.ICNF(nvariables=nv, naugments=na, nn=pkg.Chain(*layers), device=dev, steer_rate=0.0, lambda1=0.01, lambda2=0.01, lambda3=0.01 if na else 0.0,
                       nprobes=K, sol_kwargs=dict(alg=pkg.Tsit5(), adaptive=False, nsteps=2))
         if P is None:

@@ -17,7 +17,7 @@ for name, (kw, B) in CASES.items():
     X, E, P = (torch.tensor(np.ascontiguousarray(a), device=dev) for a in (xs, eps, p))
     row = {}
     for tag, env in (("twin", "1"), ("layerwise", "0")):
-        os.environ["CNF_JVP_GRAD_TWIN"] = env
+        os.environ["CNF_JVP_GRAD_TWIN"] = env; pkg.reload_tuning()
         layers = [pkg.Dense(spec.widths[i], spec.widths[i + 1], ACTS[spec.acts[i]]) for i in range(len(spec.acts))]
         icnf = pkg.ICNF(nvariables=spec.nvars, naugments=spec.naug, nn=pkg.Chain(*layers), compute_mode=pkg.HIPJacVecMatrixMode(),
                         steer_rate=0.0, lambda1=0.01 if spec.reg_z else 0.0, lambda2=0.0, lambda3=0.01 if spec.reg_aug else 0.0, device=dev,

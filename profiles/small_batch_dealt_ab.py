@@ -20,7 +20,7 @@ for nv in (20, 32, 40):
     for B in (256, 1024, 4096):
         res = {}
         for env in ("1", "2", "0"):
-            os.environ["CNF_COOPD"] = env
+            os.environ["CNF_COOPD"] = env; pkg.reload_tuning()
             ic = pkg.ICNF(nvariables=nv, device=dev, steer_rate=0.0, sol_kwargs=dict(alg=pkg.Tsit5(), adaptive=False, nsteps=40))
             ps, st = pkg.setup(torch.Generator().manual_seed(0), ic); P = ps.to(dev)
             X = torch.randn(B, nv, device=dev).t(); E = torch.randn(B, ic.D, device=dev).t()

@@ -35,7 +35,7 @@ for name, kw in nets:
                 st = getattr(icnf, "last_solve_stats", None) or {}
                 r[tag + "_steps"] = st.get("naccept"), st.get("nreject")
         if os.environ.get("CNF_DEVICE_CONTROLLER", "1") != "0":     # the host-loop twin of the adaptive Tsit5 solve
-            os.environ["CNF_DEVICE_CONTROLLER"] = "0"
+            os.environ["CNF_DEVICE_CONTROLLER"] = "0"; pkg.reload_tuning()
             icnf = pkg.ICNF(nvariables=spec.nvars, naugments=0, nn=pkg.Chain(*layers), compute_mode=pkg.HIPVecJacMatrixMode(), steer_rate=0.0,
                             lambda1=0.0, lambda2=0.0, lambda3=0.0, device=dev, sol_kwargs=dict(alg=pkg.Tsit5(), adaptive=True, reltol=1e-4, abstol=1e-4))
             fn = lambda: pkg.inference(icnf, m, X, P, {}, eps=E)
@@ -45,6 +45,6 @@ for name, kw in nets:
             for _ in range(30): fn()
             torch.cuda.synchronize()
             r["adaptive_hostloop_ms"] = round((time.perf_counter() - t0) / 30 * 1e3, 4)
-            del os.environ["CNF_DEVICE_CONTROLLER"]
+            del os.environ["CNF_DEVICE_CONTROLLER"]; pkg.reload_tuning()
         out[name][str(B)] = r
 print(json.dumps(out))

@@ -17,7 +17,7 @@ for name, kw, alg in (("d8_3x64_tsit5", dict(nvars=8, hidden=[64] * 3), "tsit5")
                         device=dev, sol_kwargs=dict(alg=pkg.Tsit5() if alg == "tsit5" else pkg.RK4(), adaptive=False, nsteps=40))
         r = {}
         for tag, env in (("wave", "0"), ("split", "2")):
-            os.environ["CNF_TILE_SPLIT"] = env
+            os.environ["CNF_TILE_SPLIT"] = env; pkg.reload_tuning()
             fn = lambda: pkg.inference(icnf, m, X, P, {}, eps=E, _raw=True)
             for _ in range(5): fn()
             torch.cuda.synchronize()

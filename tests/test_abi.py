@@ -108,3 +108,30 @@ def test_cpp_host_example_compiles_against_the_header(tmp_path):
         pytest.skip("hipcc not available")
     subprocess.run([hipcc, "-O1", "--offload-arch=gfx950", "-I", os.path.join(ROOT, "include"), "-c",
                     os.path.join(ROOT, "examples", "abi_demo.cpp"), "-o", str(tmp_path / "abi_demo.o")], check=True, timeout=300)
+
+
+def test_the_switchboard_is_the_only_reader_of_the_environment(pkg, monkeypatch):
+    """include/cnf.h: cnf_tuning - every A/B and test switch in one documented struct, read from the CNF_* variables in ONE place
+    (csrc/cnf_tuning.hip; cnf_create calls it) and changed through cnf_set_tuning (VERDICT r4 next #5)."""
+    import glob
+    import os
+    csrc = os.path.join(os.path.dirname(pkg._lib.LIB_PATH), "csrc")
+    readers = [os.path.basename(f) for f in glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h"))
+               if "getenv" in open(f).read()]
+    assert sorted(readers) == ["cnf_tuning.hip"], readers
+    # every field of the header's struct is bound, documented with its variable, and round-trips (no GPU needed)
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(csrc)), "include", "cnf.h")).read()
+    body = re.search(r"typedef struct cnf_tuning \{(.*?)\} cnf_tuning;", hdr, re.S).group(1)
+    fields = re.findall(r"int32_t (\w+);\s*/\* (CNF_[A-Z0-9_]+), default (-?\d+):", body)
+    assert [f for f, _, _ in fields] == list(pkg._lib.TUNING_FIELDS) and len(fields) >= 30
+    for f, env, _ in fields:
+        assert env == "CNF_" + f.upper(), (f, env)
+        monkeypatch.delenv(env, raising=False)
+    base = pkg.reload_tuning()
+    assert base == {f: int(d) for f, _, d in fields}
+    old = pkg.set_tuning(tile_split=0, lg_nw=8)
+    assert old == {"tile_split": 1, "lg_nw": 4} and pkg.get_tuning()["tile_split"] == 0 and pkg.get_tuning()["lg_nw"] == 8
+    monkeypatch.setenv("CNF_COOPD", "2")
+    assert pkg.reload_tuning()["coopd"] == 2 and pkg.get_tuning()["tile_split"] == 1      # reload = defaults + environment
+    monkeypatch.delenv("CNF_COOPD")
+    assert pkg.reload_tuning() == base

@@ -35,6 +35,18 @@ def make_icnf(pkg, spec, alg, nsteps, path=0, lambdas=(0.01, 0.01, 0.01)):
                                     nsteps=nsteps))
 
 
+def setsw(pkg, monkeypatch, var, val):
+    """A CNF_* switch for this test: the environment (read by cnf_create for handles made from here on) AND the library's
+    switchboard (include/cnf.h: cnf_tuning) for the handles that already exist."""
+    monkeypatch.setenv(var, str(val))
+    pkg.reload_tuning()
+
+
+def delsw(pkg, monkeypatch, var):
+    monkeypatch.delenv(var, raising=False)
+    pkg.reload_tuning()
+
+
 def mode_of(pkg, spec):
     if spec.mode == 2:
         return pkg.TestMode()
@@ -167,10 +179,12 @@ def test_wide_conditioned_probe_and_exact_flows_take_the_extended_cooperative_ke
     ref = o64.aug_f(spec, p, u, 0.41, eps, ys)
     assert np.max(np.abs(du - ref) / (1.0 + np.abs(ref))) < TOL_CALL
     os.environ["CNF_MFMA_COOPX"] = "0"
+    pkg.reload_tuning()
     try:
         assert make_icnf(pkg, spec, alg, nsteps, path=0).kernel_path(mode) == 3
     finally:
         del os.environ["CNF_MFMA_COOPX"]
+        pkg.reload_tuning()
 
 
 # the cooperative kernel with its tiles dealt exactly over four owner waves (csrc/cnf_coop_d.hip): one-probe VJP solves of two-layer
@@ -232,7 +246,7 @@ def test_dealt_cooperative_kernel_matches_the_oracles(kw, B, alg, nsteps, pkg, o
     ref = oc.inference_fixed(spec, p, xs, 0.0, 1.0, nsteps, alg, eps, ys, nthreads=8)
     out = {}
     for tag, env in (("dealt", "2"), ("extended", "0")):
-        monkeypatch.setenv("CNF_COOPD", env)
+        setsw(pkg, monkeypatch, "CNF_COOPD", env)
         icnf = make_icnf(pkg, spec, alg, nsteps, path=2)
         assert icnf.kernel_family(mode, B=B) == ("coopd" if tag == "dealt" else icnf.kernel_family(mode))   # (else the plan's own: coopx / coop)
         assert icnf.kernel_family(mode) in ("coopx", "coop")
@@ -259,7 +273,7 @@ def test_dealt_cooperative_kernel_at_full_size(pkg, oracles, monkeypatch):
     Tsit5 x 40: the dealt kernel serves it on its own, every column agrees with the extended kernel (summation order only) and a
     sample of columns with the C restatement; column shards concatenate bit-identically within the kernel."""
     o64, oc = oracles
-    monkeypatch.delenv("CNF_COOPD", raising=False)
+    delsw(pkg, monkeypatch, "CNF_COOPD")
     # (nvariables = 32, 40: the 32-sample form with its Runge-Kutta sums in the plan's global ring - every workgroup walks four
     # super-tiles through the same ring slice; 40 on 16 384 columns to bound the C restatement's time)
     for nv, H in ((16, 136), (24, 200), (32, 264), (40, 328)):
@@ -272,9 +286,9 @@ def test_dealt_cooperative_kernel_at_full_size(pkg, oracles, monkeypatch):
         assert icnf.kernel_family(mode) == "coopx" and icnf.kernel_family(mode, B=B) == "coopd" and icnf.kernel_family(mode, B=4096) == ("coopx" if nv < 30 else "coopd")
         logp, regs = run_inference(pkg, icnf, spec, p, xs, eps, None)
         logp = logp.cpu().numpy()
-        monkeypatch.setenv("CNF_COOPD", "0")
+        setsw(pkg, monkeypatch, "CNF_COOPD", "0")
         lx, rx = run_inference(pkg, icnf, spec, p, xs, eps, None)
-        monkeypatch.delenv("CNF_COOPD")
+        delsw(pkg, monkeypatch, "CNF_COOPD")
         tol = 1e-4 + 2e-6 * float(np.abs(logp).max())      # (|logp| ~ 200 at D = 81 has a Float32 ulp of 1.5e-5)
         assert np.max(np.abs(logp - lx.cpu().numpy())) < tol
         for a_, b_ in zip(regs, rx):
@@ -301,7 +315,7 @@ def test_adaptive_solvers_on_the_dealt_kernel(solver, pkg, oracles, monkeypatch)
     p, xs, eps, _ = o64.synth_inputs(spec, B, 1234, bias_scale=0.2)
     out = {}
     for tag, env in (("dealt", "1"), ("extended", "0")):
-        monkeypatch.setenv("CNF_COOPD", env)
+        setsw(pkg, monkeypatch, "CNF_COOPD", env)
         icnf = make_icnf(pkg, spec, 1, 1, lambdas=(0.01, 0.01, 0.01))
         icnf.sol_kwargs = dict(alg=pkg.VCABM() if solver == "vcabm" else pkg.Tsit5(), reltol=1e-4, abstol=1e-4)
         mode = pkg.TrainMode(True)
@@ -333,7 +347,7 @@ def test_cooperative_gradient_on_the_dealt_forward_solve(kw, lam, B, alg, nsteps
     the tile layout and stride the reverse sweep reads): loss, dloss/dps, dloss/dxs against fp64 autograd (CNF_COOPD=2 forces it
     at this batch size; src/core/icnf.jl:90-99)."""
     o64, _ = oracles
-    monkeypatch.setenv("CNF_COOPD", "2")
+    setsw(pkg, monkeypatch, "CNF_COOPD", "2")
     spec = o64.make_spec(**kw)
     p, xs, eps, ys = o64.synth_inputs(spec, B, 77 + B, bias_scale=0.2)
     mode = mode_of(pkg, spec)
@@ -380,7 +394,7 @@ def test_dealt_reverse_sweep_matches_the_cooperative_sweep(nv, alg, pkg, oracles
     p, xs, eps, _ = o64.synth_inputs(spec, B, 99 + nv, bias_scale=0.2)
     out = {}
     for tag, env in (("dealt", "1"), ("coop", "0")):
-        monkeypatch.setenv("CNF_COOPD_GRAD", env)
+        setsw(pkg, monkeypatch, "CNF_COOPD_GRAD", env)
         icnf = make_icnf(pkg, spec, alg, 3, lambdas=(0.01, 0.01, 0.01))
         mode = pkg.TrainMode(True)
         val, g, gx = pkg.loss_and_gradient(icnf, mode, dev(xs), dev(p), {}, eps=dev(eps), wrt_x=True)
@@ -429,7 +443,7 @@ def test_extended_cooperative_kernel_at_full_size(pkg, oracles, monkeypatch):
     assert icnf.kernel_path(mode_of(pkg, spec)) == 2
     lp = run_inference(pkg, icnf, spec, p, xs, eps, ys)[0].cpu().numpy()
     assert np.all(np.isfinite(lp))
-    monkeypatch.setenv("CNF_MFMA_COOPX", "0")
+    setsw(pkg, monkeypatch, "CNF_MFMA_COOPX", "0")
     lay = make_icnf(pkg, spec, 0, 40, path=0)
     assert lay.kernel_path(mode_of(pkg, spec)) == 3
     lp2 = run_inference(pkg, lay, spec, p, xs, eps, ys)[0].cpu().numpy()
@@ -447,9 +461,9 @@ def test_cooperative_wide_layer_kernel_matches_per_wave_kernel(pkg, oracles, mon
     B = 1000                                        # ragged: 15 full super-tiles + 40 columns
     p, xs, eps, _ = o64.synth_inputs(spec, B, 77, bias_scale=0.1)
     base = run_inference(pkg, make_icnf(pkg, spec, 1, 40, path=2), spec, p, xs, eps, None, return_state=True)
-    monkeypatch.setenv("CNF_MFMA_COOP", "1")
+    setsw(pkg, monkeypatch, "CNF_MFMA_COOP", "1")
     coop = run_inference(pkg, make_icnf(pkg, spec, 1, 40, path=2), spec, p, xs, eps, None, return_state=True)
-    monkeypatch.delenv("CNF_MFMA_COOP")
+    delsw(pkg, monkeypatch, "CNF_MFMA_COOP")
     ref = oc.inference_fixed(spec, p, xs, 0.0, 1.0, 40, 1, eps, nthreads=4)
     assert np.max(np.abs(coop[0].cpu().numpy() - ref[0])) < TOL_SOLVE
     assert np.max(np.abs(coop[0].cpu().numpy() - base[0].cpu().numpy())) < 2e-5
@@ -483,6 +497,7 @@ def test_tile_split_kernel_for_small_batches(kw, alg, pkg, oracles):
             out = {}
             for tag, env in (("wave", "0"), ("split", "2")):
                 os.environ["CNF_TILE_SPLIT"] = env
+                pkg.reload_tuning()
                 logp, regs, u1 = run_inference(pkg, icnf, spec, p, xs, eps, ys, return_state=True)
                 assert icnf.kernel_family(mode, B=B) == ("per_wave" if tag == "wave" else "tile_split")
                 assert icnf.kernel_family(mode, B=B, whole_solve=False) == "per_wave"   # single dynamics calls never split
@@ -494,6 +509,7 @@ def test_tile_split_kernel_for_small_batches(kw, alg, pkg, oracles):
             assert np.max(np.abs(out["wave"][2] - out["split"][2])) < 2e-5
         # generate (the reversed solve) on the split form inverts the forward solve
         os.environ["CNF_TILE_SPLIT"] = "2"
+        pkg.reload_tuning()
         if not spec.ncond:
             B = 333
             p, xs, eps, ys = o64.synth_inputs(spec, B, 77, bias_scale=0.2)
@@ -503,8 +519,10 @@ def test_tile_split_kernel_for_small_batches(kw, alg, pkg, oracles):
     finally:
         if old is None:
             os.environ.pop("CNF_TILE_SPLIT", None)
+            pkg.reload_tuning()
         else:
             os.environ["CNF_TILE_SPLIT"] = old
+            pkg.reload_tuning()
 
 
 def make_icnf_bf16x6(pkg, spec, alg, nsteps):
@@ -920,7 +938,7 @@ def test_parameter_gradient_cooperative_reverse_sweep(kw, B, alg, nsteps, env, p
     env = dict(env)
     lam = env.pop("lam", None)
     for k, v in env.items():
-        monkeypatch.setenv(k, v)
+        setsw(pkg, monkeypatch, k, v)
     spec = o64.make_spec(**kw)
     if lam is None:
         lam = (0.0, 0.0, 0.03 if spec.reg_aug else 0.0)
@@ -929,7 +947,7 @@ def test_parameter_gradient_cooperative_reverse_sweep(kw, B, alg, nsteps, env, p
     mode = mode_of(pkg, spec)
     out = {}
     for tag, flag in (("coop", "1"), ("layered", "0")):
-        monkeypatch.setenv("CNF_COOP_GRAD", flag)
+        setsw(pkg, monkeypatch, "CNF_COOP_GRAD", flag)
         icnf = make_icnf(pkg, spec, alg, nsteps, path=0, lambdas=lam)
         args = (dev(xs),) + ((dev(ys),) if spec.ncond else ()) + (dev(p), {})
         val, g, gx = pkg.loss_and_gradient(icnf, mode, *args, eps=dev(eps), wrt_x=True)
@@ -960,7 +978,7 @@ def test_mid_width_gradient_takes_the_cooperative_sweep_at_large_batches(kw, pkg
     mode = mode_of(pkg, spec)
     out = {}
     for tag, flag in (("aux", "1"), ("slab", "0")):
-        monkeypatch.setenv("CNF_COOP_GRAD_MID", flag)
+        setsw(pkg, monkeypatch, "CNF_COOP_GRAD_MID", flag)
         icnf = make_icnf(pkg, spec, alg, nsteps, path=0, lambdas=lam)
         val, g, gx = pkg.loss_and_gradient(icnf, mode, dev(xs), dev(p), {}, eps=dev(eps), wrt_x=True)
         assert icnf.kernel_path(mode) == 2 and icnf.grad_path(mode) == 1
@@ -970,10 +988,10 @@ def test_mid_width_gradient_takes_the_cooperative_sweep_at_large_batches(kw, pkg
         assert np.max(np.abs(out[tag][2] - gxref)) < 5e-5 * np.abs(gxref).max() + 1e-7, tag
     assert np.max(np.abs(out["aux"][1] - out["slab"][1])) > 0.0      # two implementations, two summation orders
     # below the threshold the same handle serves the slab kernel
-    monkeypatch.setenv("CNF_COOP_GRAD_MID", "1")
+    setsw(pkg, monkeypatch, "CNF_COOP_GRAD_MID", "1")
     icnf = make_icnf(pkg, spec, alg, nsteps, path=0, lambdas=lam)
     val, g = pkg.loss_and_gradient(icnf, mode, dev(xs[:, :300]), dev(p), {}, eps=dev(eps[:, :300]))
-    monkeypatch.setenv("CNF_COOP_GRAD_MID", "0")
+    setsw(pkg, monkeypatch, "CNF_COOP_GRAD_MID", "0")
     icnf0 = make_icnf(pkg, spec, alg, nsteps, path=0, lambdas=lam)
     val0, g0 = pkg.loss_and_gradient(icnf0, mode, dev(xs[:, :300]), dev(p), {}, eps=dev(eps[:, :300]))
     assert float(val) == float(val0) and torch.equal(g, g0)
@@ -998,7 +1016,7 @@ def test_fused_gradient_routes_agree_when_a_launch_has_more_workgroups_than_comp
     lam = (0.01, 0.01, 0.01 if spec.reg_aug else 0.0)
     out = {}
     for tag, env in (("default", "1"), ("no_coop", "0")):
-        monkeypatch.setenv("CNF_COOP_GRAD", env)
+        setsw(pkg, monkeypatch, "CNF_COOP_GRAD", env)
         icnf = make_icnf(pkg, spec, 1, 2, lambdas=lam)
         val, g = pkg.loss_and_gradient(icnf, mode_of(pkg, spec), dev(xs), dev(p), {}, eps=dev(eps))
         out[tag] = (float(val), g.double().cpu().numpy())
@@ -1019,7 +1037,7 @@ def test_cooperative_gradient_at_full_size_agrees_with_the_layerwise_path(pkg, o
     p, xs, eps, _ = o64.synth_inputs(spec, B, 20240615)
     out = {}
     for tag, flag in (("coop", "1"), ("layered", "0")):
-        monkeypatch.setenv("CNF_COOP_GRAD", flag)
+        setsw(pkg, monkeypatch, "CNF_COOP_GRAD", flag)
         icnf = make_icnf(pkg, spec, 0, 40, path=0, lambdas=(0.0, 0.0, 0.0))
         val, g, gx = pkg.loss_and_gradient(icnf, pkg.TrainMode(False), dev(xs), dev(p), {}, eps=dev(eps), wrt_x=True)
         assert icnf.grad_path(pkg.TrainMode(False)) == (3 if tag == "coop" else 2)
@@ -1067,9 +1085,9 @@ def test_parameter_gradient_slab_kernel(kw, lam, B, alg, nsteps, pkg, oracles, m
     assert np.max(np.abs(gx.cpu().numpy() - gxref)) < 5e-5 * np.abs(gxref).max() + 1e-7
     again = pkg.loss_and_gradient(icnf, mode, *cargs, eps=dev(eps))[1]
     assert torch.equal(g, again)                                                                      # no atomics
-    monkeypatch.setenv("CNF_GRAD_LAYERED", "1")
+    setsw(pkg, monkeypatch, "CNF_GRAD_LAYERED", "1")
     g2 = pkg.loss_and_gradient(icnf, mode, *cargs, eps=dev(eps))[1]
-    monkeypatch.delenv("CNF_GRAD_LAYERED")
+    delsw(pkg, monkeypatch, "CNF_GRAD_LAYERED")
     assert float((g - g2).abs().max()) < 5e-5 * float(g.abs().max())
 
 
@@ -1083,10 +1101,10 @@ def test_layerwise_gradient_agrees_with_the_fused_kernel(pkg, oracles, monkeypat
     p, xs, eps, _ = o64.synth_inputs(spec, B, 9, bias_scale=0.1)
     icnf = make_icnf(pkg, spec, 1, 6, path=2, lambdas=lam)
     v1, g1 = pkg.loss_and_gradient(icnf, pkg.TrainMode(True), dev(xs), dev(p), {}, eps=dev(eps))
-    monkeypatch.setenv("CNF_GRAD_LAYERED", "1")
+    setsw(pkg, monkeypatch, "CNF_GRAD_LAYERED", "1")
     v2, g2 = pkg.loss_and_gradient(icnf, pkg.TrainMode(True), dev(xs), dev(p), {}, eps=dev(eps))
     g2b = pkg.loss_and_gradient(icnf, pkg.TrainMode(True), dev(xs), dev(p), {}, eps=dev(eps))[1]
-    monkeypatch.delenv("CNF_GRAD_LAYERED")
+    delsw(pkg, monkeypatch, "CNF_GRAD_LAYERED")
     assert abs(float(v1) - float(v2)) < 1e-5
     scale = float(g1.abs().max())
     assert float((g1 - g2).abs().max()) < 2e-5 * scale
@@ -1133,7 +1151,7 @@ def test_jvp_mode_gradient_through_the_vjp_twin_agrees_with_its_own_layerwise_gr
     p, xs, eps, _ = o64.synth_inputs(spec, B, 55, bias_scale=0.2)
     out = {}
     for tag, env in (("twin", "1"), ("own", "0")):
-        monkeypatch.setenv("CNF_JVP_GRAD_TWIN", env)
+        setsw(pkg, monkeypatch, "CNF_JVP_GRAD_TWIN", env)
         icnf = make_icnf(pkg, spec, alg, nsteps, path=0, lambdas=lam)
         mode = pkg.TrainMode(True)
         assert icnf.grad_path(mode, B=B, alg=alg) == (1 if tag == "twin" else 2)
@@ -1360,7 +1378,7 @@ def test_kernel_family_is_reported_by_the_library(pkg, oracles, monkeypatch):
     """cnf_kernel_family / cnf_kernel_family_for / cnf_kernel_name: a host asks the library which kernel organisation serves a
     handle and a call instead of inferring it from CNF_* environment variables (VERDICT r3 weak #9)."""
     o64, _ = oracles
-    monkeypatch.delenv("CNF_TILE_SPLIT", raising=False)
+    delsw(pkg, monkeypatch, "CNF_TILE_SPLIT")
     T = pkg.TrainMode(False)
     cases = [
         (dict(nvars=8, hidden=[64, 64, 64]), 0, T, "per_wave", "mfma_vjp<HT=4"),
@@ -1380,7 +1398,7 @@ def test_kernel_family_is_reported_by_the_library(pkg, oracles, monkeypatch):
     small = make_icnf(pkg, o64.make_spec(nvars=8, hidden=[64, 64, 64]), 0, 4)
     assert small.kernel_family(T, B=4096) == "tile_split" and small.kernel_family(T, B=4097) == "per_wave"
     assert small.kernel_family(T, B=4096, whole_solve=False) == "per_wave"
-    monkeypatch.setenv("CNF_TILE_SPLIT", "0")
+    setsw(pkg, monkeypatch, "CNF_TILE_SPLIT", "0")
     assert small.kernel_family(T, B=4096) == "per_wave"
 
 
@@ -1546,6 +1564,7 @@ def test_shard_concatenation_is_bit_identical_and_deterministic(pkg, oracles):
     try:
         for env, exact in (("0", True), ("1", False)):
             os.environ["CNF_TILE_SPLIT"] = env
+            pkg.reload_tuning()
             parts = []
             for r in range(8):
                 lo, hi = pkg.shard_columns(B, r, 8)
@@ -1560,8 +1579,10 @@ def test_shard_concatenation_is_bit_identical_and_deterministic(pkg, oracles):
     finally:
         if old is None:
             os.environ.pop("CNF_TILE_SPLIT", None)
+            pkg.reload_tuning()
         else:
             os.environ["CNF_TILE_SPLIT"] = old
+            pkg.reload_tuning()
 
 
 def test_full_size_headline_properties(pkg, oracles):
@@ -2626,7 +2647,7 @@ def test_adaptive_tsit5_library_policy_is_the_host_loop(pkg, oracles, monkeypatc
     accepted steps, state, loss and gradient bit for bit; with Hairer's initial step the same counts and a gradient
     within 1e-5 (the two initial-step computations round differently).  (The library's HOST loop: the device-side
     controller, which this batch would otherwise get, is compared with it in the next test.)"""
-    monkeypatch.setenv("CNF_DEVICE_CONTROLLER", "0")
+    setsw(pkg, monkeypatch, "CNF_DEVICE_CONTROLLER", "0")
     o64, _ = oracles
     spec = o64.make_spec(nvars=8, hidden=[64, 64, 64], reg_z=True, reg_j=True)
     B = 48
@@ -2686,7 +2707,7 @@ def test_device_side_step_controller_is_the_host_loop(kw, B, tol, dt0, pkg, orac
     icnf = _adaptive_icnf(pkg, spec, tol, **extra)
     res = {}
     for ctl in ("1", "0"):
-        monkeypatch.setenv("CNF_DEVICE_CONTROLLER", ctl)
+        setsw(pkg, monkeypatch, "CNF_DEVICE_CONTROLLER", ctl)
         logp, regs, u1 = run_inference(pkg, icnf, spec, p, xs, eps, ys, return_state=True)
         res[ctl] = (logp, u1, dict(icnf.last_solve_stats))
     dev_st, host_st = res["1"][2], res["0"][2]
@@ -2741,7 +2762,7 @@ def test_default_solver_on_the_device_is_the_host_policy(kw, B, tol, dt0, pkg, o
     icnf.sol_kwargs = dict(reltol=tol, abstol=tol, **({} if dt0 is None else dict(dt=dt0)))   # alg defaults to VCABM()
     res = {}
     for ctl in ("1", "0"):
-        monkeypatch.setenv("CNF_DEVICE_CONTROLLER", ctl)
+        setsw(pkg, monkeypatch, "CNF_DEVICE_CONTROLLER", ctl)
         logp, regs, u1 = run_inference(pkg, icnf, spec, p, xs, eps, ys, return_state=True)
         res[ctl] = (logp, u1, dict(icnf.last_solve_stats))
     d, h = res["1"][2], res["0"][2]
@@ -2827,11 +2848,11 @@ def test_randomised_shapes_under_the_adaptive_solvers(pkg, oracles, monkeypatch)
         args = (dev(xs),) + ((dev(ys),) if spec.ncond else ()) + (dev(p), {})
         icnf.sol_kwargs["dt"] = 2.0 ** -5
         res = {}
-        monkeypatch.setenv("CNF_DEVICE_CONTROLLER", "0")        # bit for bit: the library's HOST loop is the Python loop
+        setsw(pkg, monkeypatch, "CNF_DEVICE_CONTROLLER", "0")        # bit for bit: the library's HOST loop is the Python loop
         for pol in ("library", "python"):
             icnf.adaptive_policy = pol
             res[pol] = pkg.loss_and_gradient(icnf, mode_obj, *args, eps=dev(eps), wrt_x=True)
-        monkeypatch.delenv("CNF_DEVICE_CONTROLLER")
+        delsw(pkg, monkeypatch, "CNF_DEVICE_CONTROLLER")
         for a, b in zip(res["library"], res["python"]):
             assert torch.equal(torch.as_tensor(a), torch.as_tensor(b)), (kw, B)
         assert bool(torch.isfinite(res["library"][1]).all())
