@@ -11,7 +11,7 @@ int fail(int code, const std::string& msg) { return cnf::api_fail(code, msg); }
 
 // The configuration the fused gradient kernels are selected and packed for.  TestMode (exact trace): -tr J is the sum over
 // the D unit vectors e_k of -e_k^T J e_k, i.e. the several-probe reverse sweep with K = D one-hot probes of weight 1 and no
-// regularisers (the probe loop of cnf_grad_probes.hip has no capacity limit; shapes outside the fused kernels take the
+// regularisers (the probe loop of cnf_grad2_probes.hip has no capacity limit; shapes outside the fused kernels take the
 // layer-wise path).
 cnf_config cnf::api_grad_cfg(const cnf_handle* h) {
     cnf_config c = h->cfg;

@@ -231,7 +231,7 @@ __device__ __forceinline__ void gemm_pf(const float* img, int lane, const InT& i
 
 }  // namespace
 
-// MULTI: several Hutchinson probes (a.K of them; cnf_grad_probes.hip's objective: the probes share the forward chain and the top-down
+// MULTI: several Hutchinson probes (a.K of them; the probes share the forward chain and the top-down
 // pass, the pullback and its bottom-up reverse run once per probe and a2_l = sum_k dbar_l^k .* u_l^k).  The probe loop is rolled:
 // eps_k is read from global memory one probe ahead, c_k = W_N^T eps_k is multiplied per probe (HT x ZR MFMAs of ~450 per probe).
 template <int HT, int L, int ZR, int CR, int ACT, bool MULTI>
@@ -407,13 +407,19 @@ mfma_grad2_kernel(GArgs a) {
                 // ---- (1) recompute the forward chain: h_l, act'_l
                 // (tanh: act' = 1 - h^2 is re-derived from h at each of its three uses - 24 packed FMAs a stage for 48 registers that
                 //  otherwise spill around the bottom-up products; softplus keeps its act' = sigmoid)
-                constexpr bool KEEP_D = ACT != CNF_ACT_TANH;
+                // (softplus: act' = sigmoid(a) = 1 - e^-h costs a transcendental per element to re-derive, so it is kept - except in the
+                //  widest instances, 4 tiles x 3 layers, where keeping it spills up to 127 registers and one instance does not compile)
+                constexpr bool KEEP_D = ACT != CNF_ACT_TANH && !(HT == 4 && L == 3);
                 f32x4 h[L][HT], d[KEEP_D ? L : 1][HT];
                 // (`one` is an opaque 1.0 of the calling phase: with a literal the three derivations are one common subexpression
                 //  and the value is kept alive after all)
                 auto dact = [&](int l, int mt, float one) -> f32x4 {
                     if constexpr (KEEP_D) return d[l][mt];
-                    else return one_minus_sq(h[l][mt], one);
+                    else if constexpr (ACT == CNF_ACT_TANH) return one_minus_sq(h[l][mt], one);
+                    else {   // softplus: 1 - exp(-h) with the bare v_exp (h >= 0: the argument is <= 0)
+                        const f32x4 x = h[l][mt] * (-1.4426950408889634f * one);
+                        return f32x4{one - __builtin_amdgcn_exp2f(x[0]), one - __builtin_amdgcn_exp2f(x[1]), one - __builtin_amdgcn_exp2f(x[2]), one - __builtin_amdgcn_exp2f(x[3])};
+                    }
                 };
                 auto opaque_one = [&]() { float o = 1.f; asm volatile("" : "+v"(o)); return o; };
                 gemm_pf<HT, ZR, HT>(sm + LAY.f1z, lane, RegIn<ZR>{zs}, nf, acc, no_img, 0, nf);
@@ -428,7 +434,8 @@ mfma_grad2_kernel(GArgs a) {
 #pragma unroll
                     for (int mt = 0; mt < HT; ++mt) {
                         if constexpr (KEEP_D) act_tile<ACT>(acc[mt], h[l][mt], d[l][mt]);
-                        else tanh_tile_h(acc[mt], h[l][mt]);
+                        else if constexpr (ACT == CNF_ACT_TANH) tanh_tile_h(acc[mt], h[l][mt]);
+                        else { f32x4 dd; act_tile<ACT>(acc[mt], h[l][mt], dd); }
                     }
                     G2_FENCE();
                     if constexpr (l + 1 < L) {
@@ -787,13 +794,7 @@ struct Grad2Inst {
 #ifdef G2_ONLY
 static const Grad2Inst kGrad2[] = {G2_ONLY};
 #else
-// (4 tiles, 3 layers, D > 8, softplus, no conditions) crashes this compiler's AGPR-copy rewrite pass (softplus keeps act' beside h:
-// the most registers of the table) and stays on cnf_grad.hip's kernel; the other (4, 3, ..) instances with D > 8 or softplus spill
-// 7 .. 84 registers outside the products' inner loops (per-instance audit: profiles/r5/r5g_grad2_instances.txt)
-#define G2_HT4_SOFTPLUS_NOCOND G2_INST(4, 3, 2, 0, CNF_ACT_SOFTPLUS), G2_INST(4, 2, 2, 0, CNF_ACT_SOFTPLUS), G2_INST(4, 2, 4, 0, CNF_ACT_SOFTPLUS)
-static const Grad2Inst kGrad2[] = {G2_SHAPES(0, CNF_ACT_TANH),
-                                   G2_HT(1, 0, CNF_ACT_SOFTPLUS), G2_HT(2, 0, CNF_ACT_SOFTPLUS), G2_HT(3, 0, CNF_ACT_SOFTPLUS), G2_HT4_SOFTPLUS_NOCOND,
-                                   G2_SHAPES(4, CNF_ACT_TANH), G2_SHAPES(4, CNF_ACT_SOFTPLUS)};
+static const Grad2Inst kGrad2[] = {G2_SHAPES(0, CNF_ACT_TANH), G2_SHAPES(0, CNF_ACT_SOFTPLUS), G2_SHAPES(4, CNF_ACT_TANH), G2_SHAPES(4, CNF_ACT_SOFTPLUS)};
 #endif
 
 GradKernel G2_FIND(int HT, int L, int ZR, int CR, int ACT) {

@@ -1,6 +1,6 @@
-// cnf_grad_dev.h — device helpers shared by the parameter-gradient kernels (cnf_grad.hip: one probe,
-// cnf_grad_probes.hip: several probes): argument block, padded exchange tiles, LDS / slab layouts and
-// the forward recompute.  See cnf_grad.hip for the method.
+// cnf_grad_dev.h — what the register-accumulator gradient shares between its host side (cnf_grad.hip) and its reverse-sweep kernel
+// (cnf_grad2.hip, compiled for one probe and - cnf_grad2_probes.hip - for several): argument block, padded transpose tiles,
+// LDS / slab layouts.  See cnf_grad.hip for the method, cnf_grad2.hip for the kernel.
 #pragma once
 #include "cnf_mfma_kernel.h"
 
@@ -12,7 +12,7 @@ struct GArgs {
     int ckpt_zr;
     const float* ckpt_k;   // stage derivatives [step * ns + stage][ntiles][64][ckpt_zr] or null (re-sweep)
     const float* eps;      // (K D) x B: probe k occupies rows k D .. k D + D - 1
-    int K;                 // Hutchinson probes (cnf_grad_probes.hip; cnf_grad.hip is K = 1)
+    int K;                 // Hutchinson probes
     const float* ys;       // C x B or null
     int C;
     float* slab;           // [waves][GradSlab::TOTAL] floats, zeroed by the host
@@ -133,10 +133,8 @@ __device__ __forceinline__ void grad_forward(const float* __restrict__ smem, int
     }
 }
 
-// kernel for K > 1 probes (cnf_grad_probes.hip); same slab layout and reduce kernel as the K = 1 one
+// the reverse-sweep kernel (cnf_grad2.hip): every wave keeps the whole gradient of its own sample tiles; null = no instance
 typedef void (*GradKernel)(GArgs);
-GradKernel grad_probes_kernel(int HT, int L, int ZR, int CR, int ACT);
-// barrier-free form for one probe (cnf_grad2.hip): every wave keeps the whole gradient of its own sample tiles; null = no instance
 GradKernel grad2_kernel(int HT, int L, int ZR, int CR, int ACT);
 GradKernel grad2_probes_kernel(int HT, int L, int ZR, int CR, int ACT);   // the same for several probes (cnf_grad2_probes.hip)
 

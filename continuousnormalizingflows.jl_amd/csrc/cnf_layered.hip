@@ -5,7 +5,7 @@
 //     JVP probes — in all three trace modes.  It has the signature of simt_aug_f and plugs into the same
 //     RK driver (cnf_api.hip), replacing the thread-per-sample kernels when the batch is large.
 // (2) layered_grad: the parameter gradient for every Hutchinson-VJP configuration the fused
-//     reverse-sweep kernels (cnf_grad.hip, cnf_grad_probes.hip) do not cover: wide layers (BASELINE cfg4,
+//     reverse-sweep kernels (cnf_grad2.hip, cnf_grad2_probes.hip) do not cover: wide layers (BASELINE cfg4,
 //     3x256), more than three hidden layers, unequal widths, mixed activations, D > 14.
 //
 // Same mathematics as cnf_grad.hip (discretise-then-optimise reverse sweep through the fixed-step RK

@@ -768,7 +768,7 @@ def test_parameter_gradient_other_shapes_and_softplus(kw, lam, B, alg, nsteps, p
 
 
 PROBE_GRAD_SHAPES = [
-    # (make_spec kwargs, lambdas, B, alg, nsteps): several Hutchinson probes (csrc/cnf_grad_probes.hip)
+    # (make_spec kwargs, lambdas, B, alg, nsteps): several Hutchinson probes (csrc/cnf_grad2_probes.hip)
     (dict(nvars=8, hidden=[64, 64, 64], nprobes=4, reg_z=True, reg_j=True), (0.01, 0.01, 0.0), 70, 1, 3),   # BASELINE cfg3 shape (RNODE, K = 4)
     (dict(nvars=8, hidden=[64, 64, 64], nprobes=2), (0.0, 0.0, 0.0), 37, 0, 4),                              # FFJORD, K = 2, no regularisers
     (dict(nvars=2, naug=3, hidden=[24, 24], act=2, nprobes=3, reg_z=True, reg_j=True, reg_aug=True), (0.02, 0.03, 0.01), 21, 1, 3),
@@ -800,7 +800,7 @@ def test_parameter_gradient_with_several_probes(kw, lam, B, alg, nsteps, pkg, or
 
 def test_probe_gradient_kernel_agrees_with_the_single_probe_kernel(pkg, oracles):
     """K identical probes have the same loss and gradient as one probe: the two gradient kernels
-    (cnf_grad.hip, cnf_grad_probes.hip) are independent implementations of the reverse sweep."""
+    (cnf_grad2.hip compiled for one probe and, with a rolled probe loop, for several) must agree."""
     o64, _ = oracles
     kw = dict(nvars=8, hidden=[64, 64, 64], reg_z=True, reg_j=True)
     lam = (0.02, 0.03, 0.0)
