@@ -24,4 +24,15 @@ python profiles/tile_split_timing.py > $OUT/${TAG}_tile_split.json 2>/dev/null
 python profiles/small_batch_latency.py > $OUT/${TAG}_small_batch_latency.json 2>/dev/null
 python profiles/reference_suite_timing.py > $OUT/${TAG}_reference_suite.json 2>/dev/null
 python profiles/coopx_timing.py > $OUT/${TAG}_coopx_timing.json 2>/dev/null
+python profiles/jvp_twin_timing.py 2>/dev/null | tail -1 > $OUT/${TAG}_jvp_twin_timing.json
+python profiles/probes_wide_timing.py 2>/dev/null | tail -1 > $OUT/${TAG}_probes_wide_timing.json
+# PMC of the narrow gradient kernels (one probe, four probes) and of the default architecture's gradient
+bash profiles/pmc_target.sh ${TAG}_cfg2_grad profiles/grad_profile_target.py CFG=cfg2 REPS=4 > $OUT/${TAG}_cfg2_grad_pmc.txt 2>&1
+bash profiles/pmc_target.sh ${TAG}_cfg3_grad profiles/grad_profile_target.py CFG=cfg3 REPS=3 > $OUT/${TAG}_cfg3_grad_pmc.txt 2>&1
+bash profiles/pmc_target.sh ${TAG}_nv20_grad profiles/default_net_grad_profile_target.py NV=20 > $OUT/${TAG}_nv20_grad_pmc.txt 2>&1
+# HBM traffic per step of every workload of the default line
+bash profiles/traffic_all.sh ${TAG}t > $OUT/traffic.log 2>&1
+cp $ROOT/gpurun_out/${TAG}t/traffic.json $OUT/${TAG}_traffic.json 2>/dev/null
+cd $ROOT
+python -m pytest tests -q -m gpu > $OUT/${TAG}_pytest_gpu.log 2>&1
 python profiles/brief.py $OUT/${TAG}_bench_*.json
