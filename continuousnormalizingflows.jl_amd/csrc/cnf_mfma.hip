@@ -582,6 +582,10 @@ hipError_t mfma_solve(MfmaPlan* p, const float* packed_dev, const SolveArgs& s, 
     const long long ntiles = (s.B + 15) / 16;
     if (s.nsteps > 0 && !s.ckpt && !s.ckpt_k && !s.kfull && plan_takes_tile_split(mp, s.B))
         return coop_split_launch(p->HT, p->L, p->ZR, p->ACT, a, st);
+    // one-probe VJP solves without conditions: the hand-scheduled form of the same kernel (cnf_mfma2.hip), bit-identical results
+    if (p->ENGINE == ENG_VJP && p->KP == 1 && p->CR == 0 && p->arith == CNF_ARITH_F32 && s.nsteps > 0 && !s.kfull && !mp->use_queue &&
+        tuning().solve2 != 0 && solve2_supported(p->HT, p->L, p->ZR, p->ACT))
+        return solve2_launch(p->HT, p->L, p->ZR, p->ACT, tuning().solve2 == 2 ? 512 : 256, a, mp->num_cus, st);
     const int wpb = p->nthreads / 64;
     long long want = ntiles;   // tile t runs on workgroup t % nblocks (cnf_mfma_kernel.h): small batches spread over the CUs
     (void)wpb;

@@ -100,6 +100,9 @@ bool coopd_supported(int H, int D, int L, int ACT, int HT_lay, int ZR_lay, int e
 int coopd_supertile(int H, int D, int L, int ACT, int exact);   // 64 or 32 samples per super-tile (the checkpoint arrays' tile count)
 hipError_t coopd_launch(int H, int D, int L, int ACT, int HT_lay, int ZR_lay, int CR_lay, const KArgs& a, int num_cus, hipStream_t st);
 size_t coopd_rk_floats(int H, int D, int L, int ACT, int exact, int num_cus);   // floats of the KArgs::rk ring the serving instance needs (0: none)
+// hand-scheduled form of the per-wave solve kernel for one-probe VJP flows without conditions (cnf_mfma2.hip)
+bool solve2_supported(int HT, int L, int ZR, int ACT);
+hipError_t solve2_launch(int HT, int L, int ZR, int ACT, int nthreads, const KArgs& a, int num_cus, hipStream_t st);
 // the same kernel with ONE sample tile per workgroup and the images in LDS: the tile-split form for small batches
 bool coop_split_supported(int HT, int L, int ZR, int ACT);
 hipError_t coop_split_launch(int HT, int L, int ZR, int ACT, const KArgs& a, hipStream_t st);

@@ -525,6 +525,38 @@ def test_tile_split_kernel_for_small_batches(kw, alg, pkg, oracles):
             pkg.reload_tuning()
 
 
+@pytest.mark.parametrize("alg,nsteps,kw", [
+    (0, 7, dict(nvars=8, hidden=[64, 64, 64])),                           # cfg2's flow, RK4
+    (1, 5, dict(nvars=8, hidden=[64, 64, 64])),                           # cfg2', Tsit5
+    (1, 4, dict(nvars=6, naug=2, hidden=[64, 64, 64], reg_z=True, reg_j=True, reg_aug=True)),   # regularised, augmented
+    (0, 3, dict(nvars=8, hidden=[64, 64, 64], autonomous=True)),
+])
+def test_hand_scheduled_solve_is_bit_identical_to_the_per_wave_kernel(alg, nsteps, kw, pkg, oracles, monkeypatch):
+    """csrc/cnf_mfma2.hip (round 5) is mfma_solve_kernel's one-probe VJP solve with its instruction order laid out by hand: same
+    fragments, same products in the same order, same elementwise expressions - so the same bits, at one and at two waves per SIMD,
+    for the outputs, the final state and (through the checkpoints of its forward pass) the parameter gradient."""
+    o64, oc = oracles
+    spec = o64.make_spec(**kw)
+    B = 5003                                                             # above the tile-split threshold, ragged last tile
+    p, xs, eps, ys = o64.synth_inputs(spec, B, 41, bias_scale=0.2)
+    lam = (0.02, 0.03, 0.01)
+    out = {}
+    for tag, sw in (("old", "0"), ("one", "1"), ("two", "2")):
+        setsw(pkg, monkeypatch, "CNF_SOLVE2", sw)
+        icnf = make_icnf(pkg, spec, alg, nsteps, path=2, lambdas=lam)
+        mode = mode_of(pkg, spec)
+        logp, regs, u1 = run_inference(pkg, icnf, spec, p, xs, eps, ys, return_state=True)
+        val, g, gx = pkg.loss_and_gradient(icnf, mode, dev(xs), dev(p), {}, eps=dev(eps), wrt_x=True)
+        out[tag] = (logp, regs, u1, val, g, gx)
+    ref = oc.inference_fixed(spec, p, xs, 0.0, 1.0, nsteps, alg, eps, ys, nthreads=8)
+    assert np.max(np.abs(out["one"][0].cpu().numpy() - ref[0])) < TOL_SOLVE
+    for tag in ("one", "two"):
+        assert torch.equal(out[tag][0], out["old"][0]) and torch.equal(out[tag][2], out["old"][2]), tag
+        for a_, b_ in zip(out[tag][1], out["old"][1]):
+            assert torch.equal(a_, b_), tag
+        assert float(out[tag][3]) == float(out["old"][3]) and torch.equal(out[tag][4], out["old"][4]) and torch.equal(out[tag][5], out["old"][5]), tag
+
+
 def make_icnf_bf16x6(pkg, spec, alg, nsteps):
     icnf = make_icnf(pkg, spec, alg, nsteps, path=2)
     icnf.compute_mode.arith = pkg._lib.ARITH_BF16X6
