@@ -329,9 +329,12 @@ mfma_grad2_kernel(GArgs a) {
                 // ---- prologue: layer-1 fragments and bias requested
                 f32x4 nf[HT], nz[1], acc[HT];
                 afrag<HT, (ZR < 4 ? ZR : 4)>(sm + LAY.f1z, lane, LAY.KGZ, 0, nf);
-                load_cvec<HT>(sm + LAY.v_b1, g, acc);
+                // C vectors: one lane base a stage, at the vectors' own region (the image is larger than a 16-bit immediate reaches)
+                const float* smg = sm + 4 * g + LAY.v_b1;
+                asm volatile("" : "+v"(smg));
+                load_cvec_g<HT>(smg, 0, acc);
                 f32x4 wt[HT];
-                if (!autonomous) load_cvec<HT>(sm + LAY.v_w1t, g, wt);
+                if (!autonomous) load_cvec_g<HT>(smg, LAY.v_w1t - LAY.v_b1, wt);
                 if (!autonomous) {
 #pragma unroll
                     for (int mt = 0; mt < HT; ++mt) acc[mt] += wt[mt] * tt;
@@ -360,15 +363,20 @@ mfma_grad2_kernel(GArgs a) {
                 static_for<0, L>([&](auto lc) {
                     constexpr int l = decltype(lc)::value;
                     f32x4 accn[HT];
-                    if constexpr (l + 1 < L) { afrag<HT>(IMG_F(l), lane, HT, 0, nf); load_cvec<HT>(sm + LAY.v_bh + l * MfmaLayout::vecC(HT), g, accn); }
+                    if constexpr (l + 1 < L) { afrag<HT>(IMG_F(l), lane, HT, 0, nf); load_cvec_g<HT>(smg, LAY.v_bh - LAY.v_b1 + l * MfmaLayout::vecC(HT), accn); }
                     else if constexpr (MULTI) afrag<HT, (ZR < 4 ? ZR : 4)>(sm + LAY.bN, lane, LAY.KGZ, 0, nf);   // c_0 = W_N^T eps_0
                     else afrag<HT>(IMG_B(NH - 1), lane, HT, 0, nf);   // the first pullback product
                     G2_FENCE();
+                    if constexpr (HT == 4 && ACT == CNF_ACT_TANH) {
+                        f32x4 dd[4];
+                        tanh_tiles4<false, false>(acc, h[l], dd);   // all four tiles stage by stage: one wait-state statement per packed step
+                    } else {
 #pragma unroll
-                    for (int mt = 0; mt < HT; ++mt) {
-                        if constexpr (KEEP_D) act_tile<ACT>(acc[mt], h[l][mt], d[l][mt]);
-                        else if constexpr (ACT == CNF_ACT_TANH) tanh_tile_h(acc[mt], h[l][mt]);
-                        else { f32x4 dd; act_tile<ACT>(acc[mt], h[l][mt], dd); }
+                        for (int mt = 0; mt < HT; ++mt) {
+                            if constexpr (KEEP_D) act_tile<ACT>(acc[mt], h[l][mt], d[l][mt]);
+                            else if constexpr (ACT == CNF_ACT_TANH) tanh_tile_h(acc[mt], h[l][mt]);
+                            else { f32x4 dd; act_tile<ACT>(acc[mt], h[l][mt], dd); }
+                        }
                     }
                     G2_FENCE();
                     if constexpr (l + 1 < L) {

@@ -153,6 +153,11 @@ static MfmaPlan* mfma_plan_create_impl(const cnf_config& c, bool coop_only) {
         snprintf(p->name, sizeof(p->name), "mfma_%s<HT=%d,L=%d,ZR=%d,CR=%d,act=%d,K=%d,pre=%d,nt=%d,%s>",
                  engine == ENG_VJP ? "vjp" : "tan", HT, L, in.ZR, in.CR, in.ACT, KP, in.PRE, in.nthreads,
                  in.arith ? "bf16x6" : "f32");
+        // whole fixed-step solves of this plan run on the hand-scheduled form of the same kernel (mfma_solve, cnf_mfma2.hip)
+        if (engine == ENG_VJP && KP == 1 && in.CR == 0 && !in.arith && tuning().solve2 != 0 && solve2_supported(HT, L, in.ZR, in.ACT)) {
+            const size_t n = strlen(p->name);
+            snprintf(p->name + n, sizeof(p->name) - n, " | solves: mfma_solve2<nt=%d>", tuning().solve2 == 1 ? 256 : 512);
+        }
         return p;
     };
     // 1. specialised instances: exact state / condition k-steps
@@ -585,7 +590,7 @@ hipError_t mfma_solve(MfmaPlan* p, const float* packed_dev, const SolveArgs& s, 
     // one-probe VJP solves without conditions: the hand-scheduled form of the same kernel (cnf_mfma2.hip), bit-identical results
     if (p->ENGINE == ENG_VJP && p->KP == 1 && p->CR == 0 && p->arith == CNF_ARITH_F32 && s.nsteps > 0 && !s.kfull && !mp->use_queue &&
         tuning().solve2 != 0 && solve2_supported(p->HT, p->L, p->ZR, p->ACT))
-        return solve2_launch(p->HT, p->L, p->ZR, p->ACT, tuning().solve2 == 2 ? 512 : 256, a, mp->num_cus, st);
+        return solve2_launch(p->HT, p->L, p->ZR, p->ACT, tuning().solve2 == 1 ? 256 : 512, a, mp->num_cus, st);
     const int wpb = p->nthreads / 64;
     long long want = ntiles;   // tile t runs on workgroup t % nblocks (cnf_mfma_kernel.h): small batches spread over the CUs
     (void)wpb;

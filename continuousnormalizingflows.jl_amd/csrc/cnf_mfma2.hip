@@ -70,6 +70,16 @@ mfma_solve2_kernel(KArgs a) {
         }
         f32x4 nf[HT], nz[1];   // first fragments of the next product (across stages)
         afrag<HT, ZJ>(smem + LAY.f1z, lane, LAY.KGZ, 0, nf);
+        // layer 1's bias and time column are the same in every stage: kept (32 registers) instead of read back per stage in front
+        // of the first product; the tableau entries of a stage are requested one stage ahead
+        // (one wave per SIMD only: with two, the partner wave covers those reads and the registers cost more than they save)
+        constexpr bool KEEP_B1 = NTHREADS == 256;
+        f32x4 b1v[HT], w1tv[HT];
+        if constexpr (KEEP_B1) {
+            load_cvec<HT>(smem + LAY.v_b1, g, b1v);
+            load_cvec<HT>(smem + LAY.v_w1t, g, w1tv);
+        }
+        f32x4 tq0 = reinterpret_cast<const f32x4*>(smem + TAB)[0], tq1 = reinterpret_cast<const f32x4*>(smem + TAB)[1];
 
         float P[5][ZR], zsum[ZR], lsum, esum, nsum;
 #pragma clang loop unroll(disable)
@@ -94,9 +104,13 @@ mfma_solve2_kernel(KArgs a) {
                 auto IMG_F = [&](int l) { return sm + LAY.fh + l * MfmaLayout::imgA(HT, HT); };   // W_{l+2}
                 auto IMG_B = [&](int l) { return sm + LAY.bh + l * MfmaLayout::imgA(HT, HT); };   // W_{l+2}^T
                 const float* const no_img = nullptr;
-                // the stage's tableau entries (LDS table: two uniform 16-byte reads)
-                const f32x4* tb = reinterpret_cast<const f32x4*>(sm + TAB + st * 8);
-                const f32x4 t0 = tb[0], t1 = tb[1];
+                // the stage's tableau entries (LDS table: two uniform 16-byte reads, requested a stage ahead)
+                const f32x4 t0 = tq0, t1 = tq1;
+                {
+                    const int sn = st + 1 < ns ? st + 1 : 0;
+                    const f32x4* tb = reinterpret_cast<const f32x4*>(sm + TAB + sn * 8);
+                    tq0 = tb[0]; tq1 = tb[1];
+                }
                 const float cst = t0[0], bst = t0[1];
                 const float acol[5] = {t0[2], t0[3], t1[0], t1[1], t1[2]};
                 float zs[ZR];
@@ -105,23 +119,35 @@ mfma_solve2_kernel(KArgs a) {
                 const float t = tn + cst * dt;
                 // ---- layer 1: a = W1z z + w1t t + b1 ----
                 f32x4 acc[HT], h[HT], d[L][HT];
-                load_cvec<HT>(sm + LAY.v_b1, g, acc);
-                if (!autonomous) {
-                    f32x4 wt[HT];
-                    load_cvec<HT>(sm + LAY.v_w1t, g, wt);
+                // C vectors: one lane base a stage, at the vectors' own region (the image is larger than a 16-bit immediate reaches)
+                const float* smg = sm + 4 * g + LAY.v_b1;
+                asm volatile("" : "+v"(smg));
+                if constexpr (KEEP_B1) {
 #pragma unroll
-                    for (int mt = 0; mt < HT; ++mt) acc[mt] = tile_fma(wt[mt], t, acc[mt]);
+                    for (int mt = 0; mt < HT; ++mt) acc[mt] = autonomous ? b1v[mt] : tile_fma(w1tv[mt], t, b1v[mt]);
+                } else {
+                    load_cvec_g<HT>(smg, 0, acc);
+                    if (!autonomous) {
+                        f32x4 wt[HT];
+                        load_cvec_g<HT>(smg, LAY.v_w1t - LAY.v_b1, wt);
+#pragma unroll
+                        for (int mt = 0; mt < HT; ++mt) acc[mt] = tile_fma(wt[mt], t, acc[mt]);
+                    }
                 }
                 G2_FENCE();
                 gemm_pf<HT, ZR, HT>(sm + LAY.f1z, lane, RegIn<ZR>{zs}, nf, acc, no_img, 0, nf);
                 static_for<0, L>([&](auto lc) {
                     constexpr int l = decltype(lc)::value;
                     f32x4 accn[HT], accz[DT];
-                    if constexpr (l + 1 < L) { afrag<HT>(IMG_F(l), lane, HT, 0, nf); load_cvec<HT>(sm + LAY.v_bh + l * MfmaLayout::vecC(HT), g, accn); }
-                    else { afrag<DT>(sm + LAY.fN, lane, HT, 0, nz); load_cvec<DT>(sm + LAY.v_bN, g, accz); }
+                    if constexpr (l + 1 < L) { afrag<HT>(IMG_F(l), lane, HT, 0, nf); load_cvec_g<HT>(smg, LAY.v_bh - LAY.v_b1 + l * MfmaLayout::vecC(HT), accn); }
+                    else { afrag<DT>(sm + LAY.fN, lane, HT, 0, nz); load_cvec_g<DT>(smg, LAY.v_bN - LAY.v_b1, accz); }
                     G2_FENCE();
+                    if constexpr (HT == 4 && ACT == CNF_ACT_TANH_PRESCALED) {
+                        tanh_tiles4<true, true>(acc, h, d[l]);
+                    } else {
 #pragma unroll
-                    for (int mt = 0; mt < HT; ++mt) act_tile<ACT>(acc[mt], h[mt], d[l][mt]);
+                        for (int mt = 0; mt < HT; ++mt) act_tile<ACT>(acc[mt], h[mt], d[l][mt]);
+                    }
                     G2_FENCE();
                     if constexpr (l + 1 < L) {
                         gemm_pf<HT, 4 * HT, HT>(IMG_F(l), lane, TileIn<HT>{h}, nf, accn, no_img, 0, nf);

@@ -75,4 +75,54 @@ __device__ __forceinline__ void gemm_pf(const float* img, int lane, const InT& i
 }
 
 
+// C vectors (bias, time column) of a stage from ONE lane base: smg = (image base) + 4 g floats, computed once per stage; the vector's
+// and the tile's offsets ride in the instruction's immediate (load_cvec's address is re-derived per tile: four VALU adds per vector)
+template <int MT>
+__device__ __forceinline__ void load_cvec_g(const float* smg, int vec_off, f32x4 (&out)[MT]) {
+    const f32x4* v = reinterpret_cast<const f32x4*>(smg);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) out[mt] = v[vec_off / 4 + mt * 4];
+}
+
+// tanh (and optionally tanh' = 1 - h^2) of FOUR accumulator tiles, stage by stage over all 16 values - 16 v_exp, the +1 on register
+// pairs, 16 v_rcp, h = 2 r - 1 and d = 1 - h^2 on register pairs - with ONE wait-state statement per packed step instead of one per
+// tile (act_tile: 2 x 4 per layer): the same operations on the same values, so the same bits.  PRESCALED: the pre-activation
+// arrives multiplied by -2 log2(e) (folded into the forward images).
+template <bool PRESCALED, bool WITH_D>
+__device__ __forceinline__ void tanh_tiles4(const f32x4 (&a)[4], f32x4 (&h)[4], f32x4 (&d)[4]) {
+    f32x2 e[8];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        f32x2 x0 = {a[mt][0], a[mt][1]}, x1 = {a[mt][2], a[mt][3]};
+        if constexpr (!PRESCALED) { x0 = x0 * kTanhPrescale; x1 = x1 * kTanhPrescale; }
+        e[2 * mt] = f32x2{__builtin_amdgcn_exp2f(x0[0]), __builtin_amdgcn_exp2f(x0[1])};
+        e[2 * mt + 1] = f32x2{__builtin_amdgcn_exp2f(x1[0]), __builtin_amdgcn_exp2f(x1[1])};
+    }
+#define CNF_PKADD1(i) "v_pk_add_f32 %" #i ", %" #i ", 1.0 op_sel_hi:[1,0]\n\t"
+    asm volatile("s_nop 0\n\t" CNF_PKADD1(0) CNF_PKADD1(1) CNF_PKADD1(2) CNF_PKADD1(3) CNF_PKADD1(4) CNF_PKADD1(5) CNF_PKADD1(6) CNF_PKADD1(7)
+                 : "+v"(e[0]), "+v"(e[1]), "+v"(e[2]), "+v"(e[3]), "+v"(e[4]), "+v"(e[5]), "+v"(e[6]), "+v"(e[7]));
+#undef CNF_PKADD1
+    f32x2 r[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r[i] = f32x2{fast_rcp(e[i][0]), fast_rcp(e[i][1])};
+    f32x2 hh[8];
+#define CNF_PKH(o, i) "v_pk_fma_f32 %" #o ", %" #i ", 2.0, -1.0 op_sel_hi:[1,0,0]\n\t"
+    asm volatile("s_nop 0\n\t" CNF_PKH(0, 8) CNF_PKH(1, 9) CNF_PKH(2, 10) CNF_PKH(3, 11) CNF_PKH(4, 12) CNF_PKH(5, 13) CNF_PKH(6, 14) CNF_PKH(7, 15)
+                 : "=&v"(hh[0]), "=&v"(hh[1]), "=&v"(hh[2]), "=&v"(hh[3]), "=&v"(hh[4]), "=&v"(hh[5]), "=&v"(hh[6]), "=&v"(hh[7])
+                 : "v"(r[0]), "v"(r[1]), "v"(r[2]), "v"(r[3]), "v"(r[4]), "v"(r[5]), "v"(r[6]), "v"(r[7]));
+#undef CNF_PKH
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) h[mt] = f32x4{hh[2 * mt][0], hh[2 * mt][1], hh[2 * mt + 1][0], hh[2 * mt + 1][1]};
+    if constexpr (WITH_D) {
+        f32x2 dd[8];
+#define CNF_PKD(o, i) "v_pk_fma_f32 %" #o ", %" #i ", %" #i ", 1.0 op_sel_hi:[1,1,0] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+        asm volatile(CNF_PKD(0, 8) CNF_PKD(1, 9) CNF_PKD(2, 10) CNF_PKD(3, 11) CNF_PKD(4, 12) CNF_PKD(5, 13) CNF_PKD(6, 14) CNF_PKD(7, 15)
+                     : "=&v"(dd[0]), "=&v"(dd[1]), "=&v"(dd[2]), "=&v"(dd[3]), "=&v"(dd[4]), "=&v"(dd[5]), "=&v"(dd[6]), "=&v"(dd[7])
+                     : "v"(hh[0]), "v"(hh[1]), "v"(hh[2]), "v"(hh[3]), "v"(hh[4]), "v"(hh[5]), "v"(hh[6]), "v"(hh[7]));
+#undef CNF_PKD
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) d[mt] = f32x4{dd[2 * mt][0], dd[2 * mt][1], dd[2 * mt + 1][0], dd[2 * mt + 1][1]};
+    }
+}
+
 }  // namespace cnf
