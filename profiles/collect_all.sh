@@ -35,4 +35,7 @@ bash profiles/traffic_all.sh ${TAG}t > $OUT/traffic.log 2>&1
 cp $ROOT/gpurun_out/${TAG}t/traffic.json $OUT/${TAG}_traffic.json 2>/dev/null
 cd $ROOT
 python -m pytest tests -q -m gpu > $OUT/${TAG}_pytest_gpu.log 2>&1
+# gpurun copies at most 64 MiB back: the raw rocprofv3 directories (kernel traces of several hundred launches, one per PMC pass) have
+# been summarised above - only the summaries travel
+rm -rf $ROOT/gpurun_out/prof_${TAG}_* $ROOT/gpurun_out/prof_${TAG}g_* $ROOT/gpurun_out/pmc_${TAG}_* $ROOT/gpurun_out/${TAG}t
 python profiles/brief.py $OUT/${TAG}_bench_*.json
