@@ -279,6 +279,8 @@ struct Solve2Inst { int HT, L, ZR, ACT, NT; Solve2Launch fn; };
 const Solve2Inst kSolve2[] = {
     S2_INST(4, 3, 2, CNF_ACT_TANH_PRESCALED, 256),   // cfg2 / cfg2': D = 8, 3 x 64, one wave per SIMD
     S2_INST(4, 3, 2, CNF_ACT_TANH_PRESCALED, 512),   // ... two
+    S2_INST(2, 2, 1, CNF_ACT_TANH_PRESCALED, 256),   // cfg1: D = 2, 2 x 32 (B = 1024: one tile per CU, latency-bound)
+    S2_INST(2, 2, 1, CNF_ACT_TANH_PRESCALED, 512),
 };
 const Solve2Inst* s2_find(int HT, int L, int ZR, int ACT, int NT) {
     for (const Solve2Inst& s : kSolve2)

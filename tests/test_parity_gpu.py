@@ -530,6 +530,8 @@ def test_tile_split_kernel_for_small_batches(kw, alg, pkg, oracles):
     (1, 5, dict(nvars=8, hidden=[64, 64, 64])),                           # cfg2', Tsit5
     (1, 4, dict(nvars=6, naug=2, hidden=[64, 64, 64], reg_z=True, reg_j=True, reg_aug=True)),   # regularised, augmented
     (0, 3, dict(nvars=8, hidden=[64, 64, 64], autonomous=True)),
+    (1, 6, dict(nvars=2, hidden=[32, 32])),                               # cfg1's flow: the (2 tiles, 2 layers, D <= 4) instance
+    (0, 5, dict(nvars=3, naug=1, hidden=[32, 32], reg_z=True, reg_j=True, reg_aug=True)),
 ])
 def test_hand_scheduled_solve_is_bit_identical_to_the_per_wave_kernel(alg, nsteps, kw, pkg, oracles, monkeypatch):
     """csrc/cnf_mfma2.hip (round 5) is mfma_solve_kernel's one-probe VJP solve with its instruction order laid out by hand: same
@@ -547,6 +549,7 @@ def test_hand_scheduled_solve_is_bit_identical_to_the_per_wave_kernel(alg, nstep
         mode = mode_of(pkg, spec)
         logp, regs, u1 = run_inference(pkg, icnf, spec, p, xs, eps, ys, return_state=True)
         val, g, gx = pkg.loss_and_gradient(icnf, mode, dev(xs), dev(p), {}, eps=dev(eps), wrt_x=True)
+        assert ("mfma_solve2" in icnf.kernel_name(mode)) == (sw != "0"), icnf.kernel_name(mode)
         out[tag] = (logp, regs, u1, val, g, gx)
     ref = oc.inference_fixed(spec, p, xs, 0.0, 1.0, nsteps, alg, eps, ys, nthreads=8)
     assert np.max(np.abs(out["one"][0].cpu().numpy() - ref[0])) < TOL_SOLVE
