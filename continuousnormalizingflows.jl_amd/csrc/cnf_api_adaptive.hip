@@ -1,6 +1,8 @@
 // cnf_api_adaptive.hip — the adaptive solves of the C ABI (include/cnf.h): cnf_step_embedded (one Tsit5 attempt),
 // cnf_vcabm_begin / _attempt / _accept / _state (the passes of the reference's default solver), and the whole solves
 // cnf_solve_vcabm / cnf_solve_tsit5 with the solvers' step-size (and order) policies restated on the host side.
+#include <cstring>
+
 #include "cnf_handle.h"
 
 using namespace cnf;
@@ -263,7 +265,7 @@ int cnf_solve_vcabm(cnf_handle* h, float t0, float t1, const float* u0, const fl
         const size_t need = mfma_adaptive_scratch_bytes(B, dts_cap);
         if (need > h->adp.dc_bytes) {
             if (h->adp.dc_buf) HIP_TRY(hipFree(h->adp.dc_buf));
-            h->adp.dc_buf = nullptr; h->adp.dc_bytes = 0;
+            h->adp.dc_buf = nullptr; h->adp.dc_bytes = 0; h->adp.dc_epoch = 0;
             HIP_TRY(hipMalloc(&h->adp.dc_buf, need));
             h->adp.dc_bytes = need;
         }
@@ -272,24 +274,32 @@ int cnf_solve_vcabm(cnf_handle* h, float t0, float t1, const float* u0, const fl
         a.u_out = u1; a.nvars = h->cfg.nvars; a.reg_aug = 0;
         int *stats_dev = nullptr, *orders_dev = nullptr;
         float* dts_dev = nullptr;
-        const hipError_t le = mfma_solve_vcabm(h->plan, h->par.packed_dev, a, abstol, reltol, dt_init, maxiters, h->adp.dc_buf, dts_cap,
-                                               &stats_dev, &dts_dev, &orders_dev, st);
+        if (!h->adp.host_rec) HIP_TRY(hipHostMalloc((void**)&h->adp.host_rec, (8 + 2 * kHostRec) * sizeof(int), hipHostMallocDefault));
+        const hipError_t le = mfma_solve_vcabm(h->plan, h->par.packed_dev, a, abstol, reltol, dt_init, maxiters, h->adp.dc_buf, &h->adp.dc_epoch, dts_cap,
+                                               &stats_dev, &dts_dev, &orders_dev, h->adp.host_rec, st);
         if (le != hipSuccess) {
             (void)hipGetLastError();
             return fail(CNF_ERR_HIP, std::string("cnf_solve_vcabm: launch of the device-resident solve failed: ") + hipGetErrorString(le));
         }
-        int hs[8];
-        HIP_TRY(hipMemcpyAsync(hs, stats_dev, sizeof(hs), hipMemcpyDeviceToHost, st));
+        // the kernel wrote its status words and first accepted steps into pinned host memory: no copy, one synchronisation
         HIP_TRY(hipStreamSynchronize(st));
+        const int* hs = h->adp.host_rec;
         if (stats) { stats->naccept = hs[0]; stats->nreject = hs[1]; stats->nf = hs[2]; stats->max_order = hs[4]; }
         if (hs[3] == 1) return fail(CNF_ERR_INVALID, "cnf_solve_vcabm: non-finite error estimate (unstable dynamics)");
         if (hs[3] == 2) return fail(CNF_ERR_INVALID, "cnf_solve_vcabm: maxiters reached");
         if (hs[3] == 3) return fail(CNF_ERR_INVALID, "cnf_solve_vcabm: non-finite state or dynamics at t0 (no initial step)");
         if (hs[3] == 4 || hs[5] != 0) return fail(CNF_ERR_HIP, "cnf_solve_vcabm: the grid-wide sum of the one-launch solve timed out (workgroups not all resident); CNF_DEVICE_CONTROLLER=0 selects the host loop");
         const int na = std::min(std::min(hs[0], dts_cap), (int)record_cap);
-        if (na > 0 && dts_out) HIP_TRY(hipMemcpyAsync(dts_out, dts_dev, (size_t)na * sizeof(float), hipMemcpyDeviceToHost, st));
-        if (na > 0 && orders_out) HIP_TRY(hipMemcpyAsync(orders_out, orders_dev, (size_t)na * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-        if (na > 0 && (dts_out || orders_out)) HIP_TRY(hipStreamSynchronize(st));
+        if (na <= kHostRec) {
+            for (int i = 0; i < na; ++i) {
+                if (dts_out) memcpy(dts_out + i, hs + 8 + 2 * i, sizeof(float));
+                if (orders_out) orders_out[i] = hs[9 + 2 * i];
+            }
+        } else {
+            if (dts_out) HIP_TRY(hipMemcpyAsync(dts_out, dts_dev, (size_t)na * sizeof(float), hipMemcpyDeviceToHost, st));
+            if (orders_out) HIP_TRY(hipMemcpyAsync(orders_out, orders_dev, (size_t)na * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+            if (dts_out || orders_out) HIP_TRY(hipStreamSynchronize(st));
+        }
         h->vc.B = -1;   // the step-wise entry points have no state from this solve
         return CNF_OK;
     }
@@ -430,7 +440,7 @@ int cnf::api_solve_tsit5(cnf_handle* h, float t0, float t1, const float* u0, con
         const size_t need = mfma_adaptive_scratch_bytes(B, dts_cap);
         if (need > h->adp.dc_bytes) {
             if (h->adp.dc_buf) HIP_TRY(hipFree(h->adp.dc_buf));
-            h->adp.dc_buf = nullptr; h->adp.dc_bytes = 0;
+            h->adp.dc_buf = nullptr; h->adp.dc_bytes = 0; h->adp.dc_epoch = 0;
             HIP_TRY(hipMalloc(&h->adp.dc_buf, need));
             h->adp.dc_bytes = need;
         }
@@ -439,17 +449,16 @@ int cnf::api_solve_tsit5(cnf_handle* h, float t0, float t1, const float* u0, con
         a.u_out = u1; a.nvars = h->cfg.nvars; a.reg_aug = 0;
         int* stats_dev = nullptr;
         float* dts_dev = nullptr;
-        const hipError_t le = mfma_solve_adaptive(h->plan, h->par.packed_dev, a, abstol, reltol, dt_init, maxiters, h->adp.dc_buf, dts_cap, &stats_dev, &dts_dev, st);
+        if (!h->adp.host_rec) HIP_TRY(hipHostMalloc((void**)&h->adp.host_rec, (8 + 2 * kHostRec) * sizeof(int), hipHostMallocDefault));
+        const hipError_t le = mfma_solve_adaptive(h->plan, h->par.packed_dev, a, abstol, reltol, dt_init, maxiters, h->adp.dc_buf, &h->adp.dc_epoch, dts_cap, &stats_dev, &dts_dev,
+                                                  h->adp.host_rec, st);
         if (le != hipSuccess) {
             (void)hipGetLastError();   // not sticky: nothing was launched
             return fail(CNF_ERR_HIP, std::string("cnf_solve_tsit5: launch of the device-controlled solve failed: ") + hipGetErrorString(le));
         }
-        // stats and the first accepted steps sit side by side: one copy serves the usual solve
-        constexpr int kInline = 56;
-        int host[8 + kInline];
-        const int first = dts_cap < kInline ? dts_cap : kInline;
-        HIP_TRY(hipMemcpyAsync(host, stats_dev, (8 + first) * sizeof(int), hipMemcpyDeviceToHost, st));
+        // the kernel wrote its status words and first accepted steps into pinned host memory: no copy, one synchronisation
         HIP_TRY(hipStreamSynchronize(st));
+        const int* host = h->adp.host_rec;
         if (stats) { stats->naccept = host[0]; stats->nreject = host[1]; stats->nf = host[2]; stats->max_order = 5; }
         if (host[3] == 1) return fail(CNF_ERR_INVALID, "cnf_solve_tsit5: non-finite error estimate (unstable dynamics)");
         if (host[3] == 2) return fail(CNF_ERR_INVALID, "cnf_solve_tsit5: maxiters reached");
@@ -458,10 +467,10 @@ int cnf::api_solve_tsit5(cnf_handle* h, float t0, float t1, const float* u0, con
         if (steps) {
             const int na = host[0] < dts_cap ? host[0] : dts_cap;
             std::vector<float> all((size_t)na);
-            const float* inl = reinterpret_cast<const float*>(host + 8);
-            for (int i = 0; i < na && i < first; ++i) all[i] = inl[i];
-            if (na > first) {
-                HIP_TRY(hipMemcpyAsync(all.data() + first, dts_dev + first, (size_t)(na - first) * sizeof(float), hipMemcpyDeviceToHost, st));
+            if (na <= kHostRec) {
+                for (int i = 0; i < na; ++i) memcpy(&all[i], host + 8 + 2 * i, sizeof(float));
+            } else {
+                HIP_TRY(hipMemcpyAsync(all.data(), dts_dev, (size_t)na * sizeof(float), hipMemcpyDeviceToHost, st));
                 HIP_TRY(hipStreamSynchronize(st));
             }
             for (int i = 0; i < na; ++i) steps->push_back((double)all[i]);

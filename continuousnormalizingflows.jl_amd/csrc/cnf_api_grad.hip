@@ -74,27 +74,96 @@ cnf::GradRoute cnf::api_grad_route(const cnf_handle* h, int64_t B, int alg, bool
 }
 }  // extern "C++"
 
-// JVP mode without the Jacobian regulariser (cnf_handle::grad_twin): the call is served by the VJP-mode twin when that one has a
-// fused implementation (1 or 3) for it
-static const cnf_handle* grad_server(const cnf_handle* h, int64_t B, int alg, bool on_grid) {
-    if (h && h->grad_twin) {
-        const int tp = api_grad_route(h->grad_twin, B, alg, on_grid).path;
-        if (tp == 1 || tp == 3) return h->grad_twin;
+// Who serves a gradient call (cnf_handle::grad_twin): the handle itself; for JVP mode without the Jacobian regulariser its VJP-mode
+// twin when that one has a fused implementation (1 or 3) for the call; for several probes without a fused implementation of their
+// own the one-probe twin, once per probe (`nloop` = K), when that one runs on the cooperative reverse sweep.
+struct GradServe { const cnf_handle* srv; int path; int nloop; };
+static GradServe grad_serve(const cnf_handle* h, int64_t B, int alg, bool on_grid) {
+    const int own = api_grad_route(h, B, alg, on_grid).path;
+    if (h->grad_twin) {
+        if (h->cfg.mode == CNF_MODE_HUTCH_JVP) {
+            const GradServe t = grad_serve(h->grad_twin, B, alg, on_grid);
+            if (t.path == 1 || t.path == 3) return t;
+        } else if (own != 1 && own != 3 && api_grad_route(h->grad_twin, B, alg, on_grid).path == 3 &&
+                   (h->cfg.n_layers == 3 || tuning().probe_grad_twin == 2)) {
+            // measured at K = 4, B = 32 768 (profiles/probes_wide_timing.py): 1.39 - 1.48 x the layer-wise path on two hidden layers
+            // (the reference's default architecture), 0.96 x on 3 x 256 - so three hidden layers keep their layer-wise gradient
+            // unless CNF_PROBE_GRAD_TWIN=2 asks for the loop
+            return GradServe{h->grad_twin, 3, h->cfg.nprobes};
+        }
     }
-    return h;
+    return GradServe{h, own, 1};
 }
 
 int cnf_grad_path(const cnf_handle* h) {
     if (!h) return CNF_ERR_INVALID;
-    return api_grad_route(grad_server(h, -1, CNF_ALG_TSIT5, false), -1, CNF_ALG_TSIT5, false).path;
+    return grad_serve(h, -1, CNF_ALG_TSIT5, false).path;
 }
 
 int cnf_grad_path_for(const cnf_handle* h, int64_t B, int alg, int on_grid) {
     if (!h || B < 0 || (alg != CNF_ALG_RK4 && alg != CNF_ALG_TSIT5)) return CNF_ERR_INVALID;
-    return api_grad_route(grad_server(h, B, alg, on_grid != 0), B, alg, on_grid != 0).path;
+    return grad_serve(h, B, alg, on_grid != 0).path;
 }
 
 }  // extern "C"
+
+static int loss_grad_impl(cnf_handle* h, const char* who, int alg, int nsteps, float t0, float t1, const float* tgrid,
+                          const float* x, const float* eps, const float* ys, int64_t B, const float* lambdas,
+                          float* grad, float* grad_x, float* sums4, void* stream);
+
+// rows p D .. p D + D - 1 of every column of the (K D) x B probe array: probe p as a D x B array
+__global__ void probe_slice_kernel(const float* __restrict__ eps, int K, int D, int p, long long B, float* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)D * B) return;
+    const long long b = i / D;
+    out[i] = eps[b * (long long)K * D + (long long)p * D + (i - b * D)];
+}
+
+// acc = first ? w v : acc + w v
+__global__ void probe_accum_kernel(float* __restrict__ acc, const float* __restrict__ v, float w, int first, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) acc[i] = first ? w * v[i] : fmaf(w, v[i], acc[i]);
+}
+
+// Several probes through the one-probe handle `one` (cnf_handle::grad_twin): loss sums and gradients of the K one-probe calls,
+// averaged in probe order.  Every call is a whole forward solve + reverse sweep of the cooperative path.
+static int loss_grad_probe_loop(cnf_handle* h, cnf_handle* one, int K, const char* who, int alg, int nsteps, float t0, float t1,
+                                const float* tgrid, const float* x, const float* eps, const float* ys, int64_t B,
+                                const float* lambdas, float* grad, float* grad_x, float* sums4, void* stream) {
+    if ((B > 0 && (!x || !eps)) || !grad || !lambdas) return fail(CNF_ERR_INVALID, std::string(who) + ": null x/eps/grad/lambdas");
+    DeviceGuard g(h->cfg.device_id);
+    hipStream_t st = (hipStream_t)stream;
+    const size_t D = (size_t)h->D, n = h->par.n, nx = grad_x ? (size_t)B * (size_t)h->cfg.nvars : 0;
+    const size_t need = D * (size_t)B + n + nx + 4 + 16;
+    if (need > h->grad.probe_ws_floats) {
+        if (h->grad.probe_ws) HIP_TRY(hipFree(h->grad.probe_ws));
+        h->grad.probe_ws = nullptr; h->grad.probe_ws_floats = 0;
+        HIP_TRY(hipMalloc((void**)&h->grad.probe_ws, need * sizeof(float)));
+        h->grad.probe_ws_floats = need;
+    }
+    float* eps_p = h->grad.probe_ws;
+    float* grad_p = eps_p + (D * (size_t)B + 3) / 4 * 4;
+    float* gx_p = grad_x ? grad_p + (n + 3) / 4 * 4 : nullptr;
+    float* sums_p = grad_p + (n + 3) / 4 * 4 + (nx + 3) / 4 * 4;
+    const float w = 1.f / (float)K;
+    auto accum = [&](float* acc, const float* v, size_t cnt, int first) -> hipError_t {
+        if (!cnt) return hipSuccess;
+        hipLaunchKernelGGL(probe_accum_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, acc, v, w, first, (long long)cnt);
+        return hipGetLastError();
+    };
+    if (B == 0) return loss_grad_impl(one, who, alg, nsteps, t0, t1, tgrid, x, eps, ys, B, lambdas, grad, grad_x, sums4, stream);
+    for (int p = 0; p < K; ++p) {
+        const long long cnt = (long long)D * B;
+        hipLaunchKernelGGL(probe_slice_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, eps, K, (int)D, p, (long long)B, eps_p);
+        HIP_TRY(hipGetLastError());
+        const int rc = loss_grad_impl(one, who, alg, nsteps, t0, t1, tgrid, x, eps_p, ys, B, lambdas, grad_p, gx_p, sums4 ? sums_p : nullptr, stream);
+        if (rc) return rc;
+        HIP_TRY(accum(grad, grad_p, n, p == 0));
+        if (grad_x) HIP_TRY(accum(grad_x, gx_p, nx, p == 0));
+        if (sums4) HIP_TRY(accum(sums4, sums_p, 4, p == 0));
+    }
+    return CNF_OK;
+}
 
 // loss sums + gradient on a uniform grid (tgrid == nullptr: nsteps steps from t0 to t1) or on the caller's non-uniform
 // grid (tgrid: host, nsteps + 1 times; t0 / t1 ignored).  The same three gradient implementations serve both.
@@ -104,8 +173,10 @@ static int loss_grad_impl(cnf_handle* h, const char* who, int alg, int nsteps, f
     int rc = api_check_call(h, eps, ys, B, who);
     if (rc) return rc;
     if (alg == CNF_ALG_RK4 || alg == CNF_ALG_TSIT5) {
-        const cnf_handle* srv = grad_server(h, B, alg, tgrid != nullptr);
-        if (srv != h) return loss_grad_impl(const_cast<cnf_handle*>(srv), who, alg, nsteps, t0, t1, tgrid, x, eps, ys, B, lambdas, grad, grad_x, sums4, stream);
+        const GradServe gs = grad_serve(h, B, alg, tgrid != nullptr);
+        cnf_handle* srv = const_cast<cnf_handle*>(gs.srv);
+        if (gs.nloop > 1) return loss_grad_probe_loop(h, srv, gs.nloop, who, alg, nsteps, t0, t1, tgrid, x, eps, ys, B, lambdas, grad, grad_x, sums4, stream);
+        if (srv != h) return loss_grad_impl(srv, who, alg, nsteps, t0, t1, tgrid, x, eps, ys, B, lambdas, grad, grad_x, sums4, stream);
     }
     const std::string w(who);
     if (nsteps < 1) return fail(CNF_ERR_INVALID, w + ": nsteps >= 1 required");

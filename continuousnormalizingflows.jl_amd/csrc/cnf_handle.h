@@ -95,6 +95,8 @@ struct HandleGrad {
     LayeredGrad* layered = nullptr;      // operand images + workspaces of the layer-wise evaluation / gradient and of the cooperative gradient
     float* tgrid_dev = nullptr;          // step times of a non-uniform grid for the fused gradient kernels
     size_t tgrid_cap = 0;
+    float* probe_ws = nullptr;           // several probes served probe by probe through the one-probe twin: one probe's columns, its
+    size_t probe_ws_floats = 0;          // gradient, data gradient and loss sums (cnf_api_grad.hip::loss_grad_probe_loop)
 };
 // embedded-step workspace (cnf_step_embedded): 7 stage derivatives + 1 stage state, each S x B
 struct HandleEmbedded {
@@ -119,6 +121,8 @@ struct HandleAdaptive {
     int last_controller = -1;
     void* dc_buf = nullptr;              // device-controlled adaptive solve: slots, counter, stats, accepted steps
     size_t dc_bytes = 0;
+    unsigned dc_epoch = 0;               // launches on dc_buf since it was allocated / last zeroed (mfma.hip::fill_aargs_scratch)
+    int* host_rec = nullptr;             // pinned host memory the one-launch solves write their status words and first steps into (AArgs::host_rec)
     float* buf = nullptr;                // adaptive Tsit5 whole solve: two states + two derivative scratch vectors
     int64_t B = 0;
 };
@@ -142,7 +146,11 @@ struct cnf_handle {
     cnf::HandleAdaptive adp;
     // Hutchinson JVP mode without the Jacobian regulariser: eps^T (J eps) and (eps^T J) eps are the same number, so the loss is the
     // VJP mode's loss and its parameter gradient is served by the VJP mode's fused reverse sweeps through this internal handle of
-    // the same configuration with mode = CNF_MODE_HUTCH_VJP (the JVP-specific gradient kernels are layer-wise only).  Null otherwise.
+    // the same configuration with mode = CNF_MODE_HUTCH_VJP (the JVP-specific gradient kernels are layer-wise only).
+    // Hutchinson VJP mode with K > 1 probes: the loss is the mean over the probes of the one-probe losses (-eps_k^T J eps_k and
+    // |eps_k^T J| enter it as means over k, the state does not depend on eps), so where the K-probe configuration itself has no fused
+    // gradient and the one-probe configuration runs on the cooperative reverse sweep, the gradient is K calls of this internal
+    // one-probe handle, averaged in a fixed order.  Null otherwise.
     cnf_handle* grad_twin = nullptr;
 };
 

@@ -93,15 +93,16 @@ struct SolveArgs {
     const float* tgrid_dev;   // optional, cooperative checkpointing solve only: nsteps + 1 step times on the device
 };
 hipError_t mfma_solve(MfmaPlan* p, const float* packed_dev, const SolveArgs& a, hipStream_t st);
+constexpr int kHostRec = 120;   // accepted steps the one-launch solves also record in pinned host memory (AArgs::host_rec)
 // adaptive Tsit5 with the step controller on the device (cnf_mfma_kernel.h: mfma_adaptive_kernel): u0 -> u_out over [t0, t1]
 int64_t mfma_adaptive_capacity(MfmaPlan* p);
 size_t mfma_adaptive_scratch_bytes(int64_t B, int dts_cap);
 hipError_t mfma_solve_adaptive(MfmaPlan* p, const float* packed_dev, const SolveArgs& s, float abstol, float reltol, float dt_init,
-                               int maxiters, void* scratch, int dts_cap, int** stats_dev, float** dts_dev, hipStream_t st);
+                               int maxiters, void* scratch, unsigned* epoch, int dts_cap, int** stats_dev, float** dts_dev, int* host_rec, hipStream_t st);
 // the default solver VCABM with its passes and its step / order policy on the device (mfma_vcabm_kernel)
 int64_t mfma_vcabm_capacity(MfmaPlan* p);
 hipError_t mfma_solve_vcabm(MfmaPlan* p, const float* packed_dev, const SolveArgs& s, float abstol, float reltol, float dt_init,
-                            int maxiters, void* scratch, int dts_cap, int** stats_dev, float** dts_dev, int** orders_dev, hipStream_t st);
+                            int maxiters, void* scratch, unsigned* epoch, int dts_cap, int** stats_dev, float** dts_dev, int** orders_dev, int* host_rec, hipStream_t st);
 
 // ---- parameter gradient (cnf_grad.hip) ----
 bool grad_supported(const cnf_config& c);

@@ -628,7 +628,7 @@ int64_t mfma_adaptive_capacity(MfmaPlan* p) {
 // scratch of one device-controlled solve: [2][3][ntiles] doubles, then counter (4 ints) + 8 stats, dts_cap floats, dts_cap orders
 size_t mfma_adaptive_scratch_bytes(int64_t B, int dts_cap) {
     const size_t ntiles = (size_t)((B + 15) / 16);
-    return 6 * ntiles * sizeof(double) + 12 * sizeof(int) + (size_t)dts_cap * (sizeof(float) + sizeof(int));
+    return 12 * ntiles * sizeof(double) + 12 * sizeof(int) + (size_t)dts_cap * (sizeof(float) + sizeof(int));
 }
 
 static void fill_kargs_adaptive(const MfmaPlan* p, const float* packed_dev, const SolveArgs& s, KArgs& a) {
@@ -641,11 +641,15 @@ static void fill_kargs_adaptive(const MfmaPlan* p, const float* packed_dev, cons
     a.K = p->KP;
 }
 
+// `epoch`: the caller's launch counter for this scratch buffer (0 after it was allocated).  The slots and the abort flag are tagged
+// with the launch's epoch (AArgs::epoch), so the buffer is zeroed only for the first launch on it and when the 16-bit epoch wraps.
 static hipError_t fill_aargs_scratch(AArgs& q, void* scratch, long long ntiles, int dts_cap, int** stats_dev, float** dts_dev,
-                                     int** orders_dev, hipStream_t st) {
+                                     int** orders_dev, unsigned* epoch, hipStream_t st) {
     char* base = (char*)scratch;
     q.slots = (double*)base;
-    int* ints = (int*)(base + 6 * (size_t)ntiles * sizeof(double));
+    // grid_sum3's slots: [2 (round parity)][workgroups <= tiles][6] tagged words
+    const size_t slot_bytes = 12 * (size_t)ntiles * sizeof(double);
+    int* ints = (int*)(base + slot_bytes);
     q.counter = (unsigned*)ints;
     q.stats = ints + 4;
     q.dts = (float*)(ints + 12);
@@ -653,15 +657,22 @@ static hipError_t fill_aargs_scratch(AArgs& q, void* scratch, long long ntiles, 
     *stats_dev = q.stats;
     *dts_dev = q.dts;
     if (orders_dev) *orders_dev = q.orders;
-    return zero_async(ints, 12 * sizeof(int), st);
+    hipError_t e = hipSuccess;
+    if (*epoch == 0 || *epoch >= 0xffffu) {
+        e = zero_async(base, slot_bytes + 12 * sizeof(int), st);
+        *epoch = 0;
+    }
+    q.epoch = ++*epoch;
+    return e;
 }
 
 hipError_t mfma_solve_adaptive(MfmaPlan* p, const float* packed_dev, const SolveArgs& s, float abstol, float reltol, float dt_init,
-                               int maxiters, void* scratch, int dts_cap, int** stats_dev, float** dts_dev, hipStream_t st) {
+                               int maxiters, void* scratch, unsigned* epoch, int dts_cap, int** stats_dev, float** dts_dev, int* host_rec, hipStream_t st) {
     const long long ntiles = (s.B + 15) / 16;
     KArgs a{};
     fill_kargs_adaptive(p, packed_dev, s, a);
     AArgs q{};
+    q.host_rec = host_rec;
     q.abstol = abstol; q.reltol = reltol; q.t1 = s.t1; q.dt_init = dt_init; q.maxiters = maxiters; q.dts_cap = dts_cap;
     const Tableau T = make_tableau(CNF_ALG_TSIT5);
     // b - bhat of the embedded 4th-order solution (Tsitouras 2011); the same constants as cnf_step_embedded
@@ -676,7 +687,7 @@ hipError_t mfma_solve_adaptive(MfmaPlan* p, const float* packed_dev, const Solve
             q.acol[j][i] = row < 6 ? T.a[row][j] : (row == 6 ? T.b[j] : 0.f);
         }
     }
-    hipError_t e = fill_aargs_scratch(q, scratch, ntiles, dts_cap, stats_dev, dts_dev, nullptr, st);
+    hipError_t e = fill_aargs_scratch(q, scratch, ntiles, dts_cap, stats_dev, dts_dev, nullptr, epoch, st);
     if (e != hipSuccess) return e;
     const int wpb = p->nthreads / 64;
     const int lds = p->lay.lds_total * (int)sizeof(float);
@@ -708,13 +719,14 @@ int64_t mfma_vcabm_capacity(MfmaPlan* p) {
 }
 
 hipError_t mfma_solve_vcabm(MfmaPlan* p, const float* packed_dev, const SolveArgs& s, float abstol, float reltol, float dt_init,
-                            int maxiters, void* scratch, int dts_cap, int** stats_dev, float** dts_dev, int** orders_dev, hipStream_t st) {
+                            int maxiters, void* scratch, unsigned* epoch, int dts_cap, int** stats_dev, float** dts_dev, int** orders_dev, int* host_rec, hipStream_t st) {
     const long long ntiles = (s.B + 15) / 16;
     KArgs a{};
     fill_kargs_adaptive(p, packed_dev, s, a);
     AArgs q{};
+    q.host_rec = host_rec;
     q.abstol = abstol; q.reltol = reltol; q.t1 = s.t1; q.dt_init = dt_init; q.maxiters = maxiters; q.dts_cap = dts_cap;
-    hipError_t e = fill_aargs_scratch(q, scratch, ntiles, dts_cap, stats_dev, dts_dev, orders_dev, st);
+    hipError_t e = fill_aargs_scratch(q, scratch, ntiles, dts_cap, stats_dev, dts_dev, orders_dev, epoch, st);
     if (e != hipSuccess) return e;
     const int lds = p->lay.lds_total * (int)sizeof(float);
     const long long cap = (long long)p->num_cus * (p->vcabm_per_cu > 0 ? p->vcabm_per_cu : 0);

@@ -47,12 +47,18 @@ struct AArgs {
     float b[6];         // weights of the 5th-order solution
     float bt[7];        // b - bhat: the embedded error estimate
     float c[7];
-    double* slots;      // [2 (round parity)][3][workgroups]
-    unsigned* counter;  // arrivals, zeroed on the stream before the launch
+    double* slots;      // grid_sum3: [2 (round parity)][workgroups][6] tagged words
+    unsigned epoch;     // 1 .. 65535, a different one for every launch on this scratch buffer: the upper half of a slot's tag and
+                        // the value of the abort flag, so that nothing has to be cleared between launches (the host zeroes the
+                        // buffer when it is allocated and when the epoch wraps)
+    unsigned* counter;  // (unused since the tagged slots; keeps the status words where they were)
     float* dts;         // accepted steps, dts_cap entries
     int* stats;         // naccept, nreject, nf, status (0 ok, 1 non-finite error estimate, 2 maxiters, 3 no initial step, 4 grid sum
                         // timed out), max order, [5] = abort flag raised by the first workgroup whose wait timed out
     int* orders;        // VCABM: order of every accepted step, dts_cap entries
+    int* host_rec;      // pinned host memory (or null): the eight status words, then the first kHostRec accepted steps as {step size
+                        // bits, order} pairs - written by the kernel itself, so the host reads its answer after one stream
+                        // synchronisation instead of two or three small device-to-host copies (15 - 40 us each at these sizes)
 };
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {

@@ -865,15 +865,22 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
 }
 #endif
 
-// Grid-wide sums of three per-lane values over all tiles, in two levels: the waves of a workgroup meet in LDS, wave 0 of every
-// workgroup publishes the workgroup's partial, arrives at the counter, waits for the other workgroups, and adds the
-// partials up in workgroup order.  Every wave ends with the same three doubles (same partials, same order).  `round` counts
-// the calls (the same in every wave): its parity picks the slot set, its value the arrival target.  One poller per
-// workgroup: with a poller per wave the 1024 pollers of a 16 K batch cost ~70 us per sum on one counter word.
+// Grid-wide sums of three per-lane values over all tiles, in two levels: the waves of a workgroup meet in LDS; wave 0 of every
+// workgroup publishes the workgroup's partials, waits for the partials of all workgroups and adds them up in workgroup order.  Every
+// wave ends with the same three doubles (same partials, same order).  `round` counts the calls (the same in every wave): its parity
+// picks the slot set, round + 1 is the tag.
+// A partial travels as 8-byte words {tag, half of the double} written with agent-scope atomic stores (write-through) and read
+// with agent-scope atomic loads (past the XCD's L2): a word is there or not, and a reader that sees the tag in all six words of a
+// slot has the three doubles - ONE trip to the coherence point for the writer (not waited for) and one for the reader.  The first
+// form of this function (partials, then a release increment of an arrival counter, a poll of it, an acquire fence, the partials)
+// was four dependent trips and two whole-L2 write-backs / invalidations: ~10 us per sum, 2/3 of a small-batch VCABM solve.
+// The tag is {launch epoch, round + 1 (mod 2^16)}: what an earlier launch left in a slot carries another epoch, what this launch left
+// there two rounds ago another round, so nothing is cleared between launches (AArgs::epoch).  A slot set is reused two rounds
+// later, which its owner reaches only after every workgroup has published the round in between, i.e. has finished reading this one.
 // (Spare waves of a workgroup have left the kernel; the hardware barrier counts the waves still running.)
 // Returns false when the other workgroups did not arrive within ~2^22 polls (seconds): a safety net, not a code path - a
 // grid whose workgroups are not all resident would otherwise spin for ever (and take the GPU with it).  The first workgroup
-// to give up raises q.stats[5]; every poller watches that word too, so the whole grid leaves within one poll.
+// to give up raises q.stats[5] (to the launch's epoch); every poller watches that word too, so the whole grid leaves within one poll.
 __device__ __forceinline__ bool grid_sum3(const AArgs& q, unsigned& round, int wave, int nact, int lane, double& v0, double& v1, double& v2) {
     __shared__ double wg_part[3][16];
     __shared__ double wg_tot[3];
@@ -885,34 +892,56 @@ __device__ __forceinline__ bool grid_sum3(const AArgs& q, unsigned& round, int w
     __syncthreads();
     if (wave == 0) {
         const unsigned nb = gridDim.x;
-        double* sl = q.slots + (size_t)(round & 1u) * 3u * (size_t)nb;
-        int ok = 1;
-        if (lane == 0) {
-            double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+        if (lane == 0)
             for (int w = 0; w < nact; ++w) { a0 += wg_part[0][w]; a1 += wg_part[1][w]; a2 += wg_part[2][w]; }
-            sl[blockIdx.x] = a0;
-            sl[nb + blockIdx.x] = a1;
-            sl[2 * nb + blockIdx.x] = a2;
-            __hip_atomic_fetch_add(q.counter, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned target = (round + 1u) * nb;
+        int ok = 1;
+        if (nb > 1) {   // (a single workgroup has its sums already)
+            typedef unsigned long long u64;
+            const u64 tag = (u64)((q.epoch << 16) | ((round + 1u) & 0xffffu)) << 32;
+            u64* sl = (u64*)q.slots + (size_t)(round & 1u) * 6u * (size_t)nb;
+            if (lane == 0) {
+                u64* mine = sl + 6u * (size_t)blockIdx.x;
+                const u64 b0 = (u64)__double_as_longlong(a0), b1 = (u64)__double_as_longlong(a1), b2 = (u64)__double_as_longlong(a2);
+                __hip_atomic_store(mine + 0, tag | (b0 & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(mine + 1, tag | (b0 >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(mine + 2, tag | (b1 & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(mine + 3, tag | (b1 >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(mine + 4, tag | (b2 & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(mine + 5, tag | (b2 >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            a0 = a1 = a2 = 0.0;
             unsigned polls = 0;
-            while (__hip_atomic_load(q.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-                __builtin_amdgcn_s_sleep(1);
-                if ((++polls & 63u) == 0u &&
-                    (polls > (1u << 22) || __hip_atomic_load(q.stats + 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
-                    __hip_atomic_store(q.stats + 5, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    ok = 0;
-                    break;
+            for (unsigned i = lane; i < nb && ok; i += 64) {
+                const u64* s = sl + 6u * (size_t)i;
+                u64 w[6];
+                for (;;) {
+                    bool ready = true;
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) {
+                        w[j] = __hip_atomic_load(s + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        ready = ready && (w[j] & 0xffffffff00000000ull) == tag;
+                    }
+                    if (ready) break;
+                    __builtin_amdgcn_s_sleep(1);
+                    if ((++polls & 63u) == 0u &&
+                        (polls > (1u << 22) || __hip_atomic_load(q.stats + 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)q.epoch)) {
+                        __hip_atomic_store(q.stats + 5, (int)q.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        ok = 0;
+                        break;
+                    }
+                }
+                if (ok) {
+                    a0 += __longlong_as_double((long long)((w[0] & 0xffffffffull) | (w[1] << 32)));
+                    a1 += __longlong_as_double((long long)((w[2] & 0xffffffffull) | (w[3] << 32)));
+                    a2 += __longlong_as_double((long long)((w[4] & 0xffffffffull) | (w[5] << 32)));
                 }
             }
+            ok = __builtin_amdgcn_ballot_w64(ok == 0) == 0ull ? 1 : 0;
+            a0 = wave_sum_f64(a0);
+            a1 = wave_sum_f64(a1);
+            a2 = wave_sum_f64(a2);
         }
-        ok = __builtin_amdgcn_readfirstlane(ok);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        double a0 = 0.0, a1 = 0.0, a2 = 0.0;
-        for (unsigned i = lane; i < nb; i += 64) { a0 += sl[i]; a1 += sl[nb + i]; a2 += sl[2 * nb + i]; }
-        a0 = wave_sum_f64(a0);
-        a1 = wave_sum_f64(a1);
-        a2 = wave_sum_f64(a2);
         if (lane == 0) { wg_tot[0] = a0; wg_tot[1] = a1; wg_tot[2] = a2; wg_ok = ok; }
     }
     __syncthreads();
@@ -1126,7 +1155,10 @@ mfma_adaptive_kernel(KArgs a, AArgs q) {
                 for (int s = 0; s < ZR; ++s) { z[s] = zs[s]; k1z[s] = zd[s]; }
                 la = ln; ea = en; na = nn;
                 k1l = ld; k1e = ed; k1n = nd;
-                if (tile == 0 && lane == 0 && naccept < q.dts_cap) q.dts[naccept] = (float)(tdir * step);
+                if (tile == 0 && lane == 0) {
+                    if (naccept < q.dts_cap) q.dts[naccept] = (float)(tdir * step);
+                    if (q.host_rec && naccept < kHostRec) { q.host_rec[8 + 2 * naccept] = __float_as_int((float)(tdir * step)); q.host_rec[9 + 2 * naccept] = 5; }
+                }
                 ++naccept;
                 qold = fmax(eest, 1e-4);
                 dt = step / qq;
@@ -1164,7 +1196,13 @@ mfma_adaptive_kernel(KArgs a, AArgs q) {
         for (int s = 0; s < ZR; ++s) { const int f = 4 * s + g; if (f < D) a.u_out[smp * S + f] = z[s]; }
         if (g == 0) { a.u_out[smp * S + D] = la; a.u_out[smp * S + D + 1] = ea; a.u_out[smp * S + D + 2] = na; }
     }
-    if (tile == 0 && lane == 0) { q.stats[0] = naccept; q.stats[1] = nreject; q.stats[2] = nf; q.stats[3] = status; q.stats[4] = 5; }
+    if (tile == 0 && lane == 0) {
+        q.stats[0] = naccept; q.stats[1] = nreject; q.stats[2] = nf; q.stats[3] = status; q.stats[4] = 5;
+        if (q.host_rec) {
+            q.host_rec[0] = naccept; q.host_rec[1] = nreject; q.host_rec[2] = nf; q.host_rec[3] = status; q.host_rec[4] = 5;
+            q.host_rec[5] = status == 4; q.host_rec[6] = 0; q.host_rec[7] = 0;
+        }
+    }
 }
 
 // occ_out != null: only report how many workgroups of this kernel one compute unit holds (registers and LDS considered)
@@ -1295,11 +1333,21 @@ mfma_vcabm_kernel(KArgs a, AArgs q) {
     // scaled squared norm pieces: r = v / (abstol + |ref| reltol)
     auto sk_of = [&](float ref) { return fmaf(fabsf(ref), reltol, abstol); };
 
+#ifdef VC_TRACE
+    unsigned long long vc_t[6] = {0, 0, 0, 0, 0, 0}, vc_s = 0, vc_k0 = __builtin_amdgcn_s_memtime();   // dyn, sums, begin, phase 2, phase 3, rest
+#define VC_ON() do { asm volatile("" ::: "memory"); vc_s = __builtin_amdgcn_s_memtime(); } while (0)
+#define VC_OFF(k) do { asm volatile("" ::: "memory"); vc_t[k] += __builtin_amdgcn_s_memtime() - vc_s; } while (0)
+#else
+#define VC_ON() do {} while (0)
+#define VC_OFF(k) do {} while (0)
+#endif
     for (;;) {
         int opaque = 0;
         asm volatile("" : "+v"(opaque));
+        VC_ON();
         dyn_eval<HT, L, ZR, CR, ACT, ENGINE, KP, PRE, ARITH>(smem + opaque, a.packed + opaque, lane, tcur, autonomous, reg_z, reg_j, exact,
                                                       D, K, zs, y, eps, pre_c, pre_q, zd, ld, ed, nd, pre_ck);
+        VC_OFF(0);
         ++nf;
 #pragma unroll
         for (int s = 0; s < ZR; ++s) X[s] = zd[s];
@@ -1320,7 +1368,10 @@ mfma_vcabm_kernel(KArgs a, AArgs q) {
                         s0 += (double)r0 * (double)r0; s1 += (double)r1 * (double)r1;
                     }
                 }
-                if (!grid_sum3(q, round, wave, nact, lane, s0, s1, s2)) { status = 4; break; }
+                VC_ON();
+                const bool gs_ok = grid_sum3(q, round, wave, nact, lane, s0, s1, s2);
+                VC_OFF(1);
+                if (!gs_ok) { status = 4; break; }
                 const double d0 = sqrt(s0 / ntot);
                 d1 = sqrt(s1 / ntot);
                 h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
@@ -1338,7 +1389,10 @@ mfma_vcabm_kernel(KArgs a, AArgs q) {
             for (int r = 0; r < NR; ++r) {
                 if (live[r]) { const float rr = (X[r] - F[r]) / sk_of(U[r]); s0 += (double)rr * (double)rr; }
             }
-            if (!grid_sum3(q, round, wave, nact, lane, s0, s1, s2)) { status = 4; break; }
+            VC_ON();
+            const bool gs_ok = grid_sum3(q, round, wave, nact, lane, s0, s1, s2);
+            VC_OFF(1);
+            if (!gs_ok) { status = 4; break; }
             const double d2 = sqrt(s0 / ntot) / h0, dmax = fmax(d1, d2);
             const double h1 = dmax <= 1e-15 ? fmax(1e-6, h0 * 1e-3) : pow(10.0, -(2.0 + log10(dmax)) / 1.0);
             dt = fmin(fmin(100.0 * h0, h1), span);
@@ -1346,6 +1400,7 @@ mfma_vcabm_kernel(KArgs a, AArgs q) {
             begin = true;
         } else if (phase == 2) {
             // C: Phi_j(n+1) from d = f(p, t + dt); u_new = p + dt g_k Phi_k(n+1); error sums of orders k, k-1, k-2
+            VC_ON();
             double s0 = 0.0, s1 = 0.0, s2 = 0.0;
             const float dg = dtf * gg[k];
 #pragma unroll
@@ -1365,7 +1420,11 @@ mfma_vcabm_kernel(KArgs a, AArgs q) {
                     s0 += (double)r0 * (double)r0; s1 += (double)r1 * (double)r1; s2 += (double)r2 * (double)r2;
                 }
             }
-            if (!grid_sum3(q, round, wave, nact, lane, s0, s1, s2)) { status = 4; break; }
+            VC_OFF(3);
+            VC_ON();
+            const bool gs_ok = grid_sum3(q, round, wave, nact, lane, s0, s1, s2);
+            VC_OFF(1);
+            if (!gs_ok) { status = 4; break; }
             eest = sqrt(s0 / ntot);
             if (!isfinite(eest)) { status = 1; break; }
             if (eest > 1.0) {   // reject: same state, smaller step, same order (nothing was stored)
@@ -1384,6 +1443,7 @@ mfma_vcabm_kernel(KArgs a, AArgs q) {
             }
         } else {
             // accepted: X = f(u_new, t + dt).  Order k + 1 estimate, then commit Phi*(n), u, f, the history
+            VC_ON();
             int knew = k;
             if (!select) knew = k + 1 < 3 ? k + 1 : 3;
             else if (lower) knew = k - 1;
@@ -1411,8 +1471,13 @@ mfma_vcabm_kernel(KArgs a, AArgs q) {
                         s0 += (double)rr * (double)rr;
                     }
                 }
-                if (!grid_sum3(q, round, wave, nact, lane, s0, s1, s2)) { status = 4; break; }
+                VC_OFF(4);
+                VC_ON();
+                const bool gs_ok = grid_sum3(q, round, wave, nact, lane, s0, s1, s2);
+                VC_OFF(1);
+                if (!gs_ok) { status = 4; break; }
                 if (sqrt(s0 / ntot) < eest) { knew = k + 1; eest = 1.0; }
+                VC_ON();
             }
 #pragma unroll
             for (int r = 0; r < NR; ++r) {
@@ -1431,14 +1496,19 @@ mfma_vcabm_kernel(KArgs a, AArgs q) {
             nhist += 1;
             const double qq = eest == 0.0 ? 1.0 / qmax : fmax(1.0 / qmax, fmin(1.0 / qmin, pow(eest, 1.0 / (double)(knew + 1)) / gamma));
             tpol = last ? t1 : tpol + tdir * hstep;
-            if (tile == 0 && lane == 0 && naccept < q.dts_cap) { q.dts[naccept] = dtf; q.orders[naccept] = k; }
+            if (tile == 0 && lane == 0) {
+                if (naccept < q.dts_cap) { q.dts[naccept] = dtf; q.orders[naccept] = k; }
+                if (q.host_rec && naccept < kHostRec) { q.host_rec[8 + 2 * naccept] = __float_as_int(dtf); q.host_rec[9 + 2 * naccept] = k; }
+            }
             ++naccept;
             if (k > max_order) max_order = k;
             k = knew; ++step;
             dt = hstep / qq;
             begin = true;
+            VC_OFF(4);
         }
         if (begin) {
+            VC_ON();
             if (fabs(t1 - tpol) <= 1e-7 * fmax(1.0, span)) break;
             if (it >= q.maxiters) { status = 2; break; }
             ++it;
@@ -1485,15 +1555,29 @@ mfma_vcabm_kernel(KArgs a, AArgs q) {
             for (int s = 0; s < ZR; ++s) zs[s] = Pp[s];
             tcur = (float)(tvc + (double)dtf);
             phase = 2;
+            VC_OFF(2);
         }
     }
+#ifdef VC_TRACE
+    if (tile == 0 && lane == 0) {
+        const unsigned long long tot = __builtin_amdgcn_s_memtime() - vc_k0;
+        printf("VC_TRACE steps %d nf %d total %llu | dyn %llu sums %llu begin %llu ph2 %llu ph3 %llu rest %llu\n", naccept, nf, tot, vc_t[0], vc_t[1], vc_t[2], vc_t[3], vc_t[4],
+               tot - vc_t[0] - vc_t[1] - vc_t[2] - vc_t[3] - vc_t[4]);
+    }
+#endif
 
     if (valid && a.u_out) {
 #pragma unroll
         for (int s = 0; s < ZR; ++s) { const int f = 4 * s + g; if (f < D) a.u_out[smp * S + f] = U[s]; }
         if (g == 0) { a.u_out[smp * S + D] = U[ZR]; a.u_out[smp * S + D + 1] = U[ZR + 1]; a.u_out[smp * S + D + 2] = U[ZR + 2]; }
     }
-    if (tile == 0 && lane == 0) { q.stats[0] = naccept; q.stats[1] = nreject; q.stats[2] = nf; q.stats[3] = status; q.stats[4] = max_order; }
+    if (tile == 0 && lane == 0) {
+        q.stats[0] = naccept; q.stats[1] = nreject; q.stats[2] = nf; q.stats[3] = status; q.stats[4] = max_order;
+        if (q.host_rec) {
+            q.host_rec[0] = naccept; q.host_rec[1] = nreject; q.host_rec[2] = nf; q.host_rec[3] = status; q.host_rec[4] = max_order;
+            q.host_rec[5] = status == 4; q.host_rec[6] = 0; q.host_rec[7] = 0;
+        }
+    }
 }
 
 template <int HT, int L, int ZR, int CR, int ACT, int ENGINE, int KP, int PRE, int NTHREADS, int ARITH = 0>

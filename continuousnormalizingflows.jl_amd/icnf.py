@@ -570,7 +570,7 @@ def _split_args(icnf: ICNF, args, what: str):
 
 
 def inference(icnf: ICNF, mode: Mode, *args, eps: Optional[torch.Tensor] = None,
-              return_state: bool = False, _raw: bool = False, group=None):
+              return_state: bool = False, _raw: bool = False, group=None, _sp=None):
     """inference(icnf, mode, xs[, ys], ps, st) -> (logp̂x (B,), (Ė, ṅ, Ȧ)).
 
     `eps` ((K*D, B)) pins the Hutchinson probes; by default they are drawn from icnf.rng as
@@ -602,22 +602,23 @@ def inference(icnf: ICNF, mode: Mode, *args, eps: Optional[torch.Tensor] = None,
     logp = torch.empty(B, device=dev, dtype=torch.float32)
     regs = torch.empty(3, B, device=dev, dtype=torch.float32)
     want_state = return_state or icnf.basedist is not None
+    sp = _sp if _sp is not None else _stream_ptr(dev)   # torch's current stream, looked up once per call (5 us a lookup; a small-batch solve is 200)
     if icnf.adaptive:
         u0 = torch.empty(B, icnf.S, device=dev, dtype=torch.float32)
         if B:
-            _lib.check(h.lib.cnf_assemble_u0(h.ptr, _ptr(x), B, _ptr(u0), _stream_ptr(dev)))
-        uf = _adaptive_integrate(icnf, h, u0, t0, t1, e, y, group=group)
+            _lib.check(h.lib.cnf_assemble_u0(h.ptr, _ptr(x), B, _ptr(u0), sp))
+        uf = _adaptive_integrate(icnf, h, u0, t0, t1, e, y, group=group, _sp=sp)
         if B:
-            _lib.check(h.lib.cnf_epilogue(h.ptr, _ptr(uf), B, _ptr(logp), _ptr(regs), _stream_ptr(dev)))
+            _lib.check(h.lib.cnf_epilogue(h.ptr, _ptr(uf), B, _ptr(logp), _ptr(regs), sp))
     else:
         uf = torch.empty(B, icnf.S, device=dev, dtype=torch.float32) if want_state else None
         dt = icnf._fixed_dt()
         if dt is not None:
             _lib.check(h.lib.cnf_inference_fixed_dt(h.ptr, alg, dt, t0, t1, _ptr(x), _ptr(e), _ptr(y), B,
-                                                    _ptr(logp), _ptr(regs), _ptr(uf), _stream_ptr(dev)))
+                                                    _ptr(logp), _ptr(regs), _ptr(uf), sp))
         else:
             _lib.check(h.lib.cnf_inference_fixed(h.ptr, alg, icnf._nsteps(t0, t1), t0, t1, _ptr(x), _ptr(e), _ptr(y), B,
-                                                 _ptr(logp), _ptr(regs), _ptr(uf), _stream_ptr(dev)))
+                                                 _ptr(logp), _ptr(regs), _ptr(uf), sp))
     if icnf.basedist is not None:   # logp̂x = logpdf(basedist, z) - Δlogp (base_icnf.jl:168-169)
         logp = (icnf.basedist.log_prob(uf[:, :icnf.D]) - uf[:, icnf.D]).to(torch.float32)
     if _raw:   # internal: the (3, B) regulariser block as one tensor (no copies on the loss path)
@@ -705,7 +706,7 @@ def loss_sums(icnf: ICNF, mode: Mode, logp: torch.Tensor, regs) -> torch.Tensor:
     return sums
 
 
-def loss_mean(icnf: ICNF, mode: Mode, logp: torch.Tensor, regs) -> torch.Tensor:
+def loss_mean(icnf: ICNF, mode: Mode, logp: torch.Tensor, regs, _sp=None) -> torch.Tensor:
     """The scalar loss of an UNSHARDED batch from (logp, regs) in the library's two reduction kernels
     (`cnf_loss_mean`): mean(-logp + λ₁Ė + λ₂ṅ + λ₃Ȧ), combined in float64, returned as a 0-dim float32 tensor."""
     import ctypes as C
@@ -717,7 +718,8 @@ def loss_mean(icnf: ICNF, mode: Mode, logp: torch.Tensor, regs) -> torch.Tensor:
         isinstance(regs, torch.Tensor) and regs.is_contiguous()) else regs
     out = torch.empty(1, device=icnf.device, dtype=torch.float32)
     lam = (C.c_double * 3)(float(icnf.lambda1), float(icnf.lambda2), float(icnf.lambda3))
-    _lib.check(h.lib.cnf_loss_mean(h.ptr, _ptr(logp.contiguous()), _ptr(r), B, lam, None, _ptr(out), _stream_ptr(icnf.device)))
+    _lib.check(h.lib.cnf_loss_mean(h.ptr, _ptr(logp.contiguous()), _ptr(r), B, lam, None, _ptr(out),
+                                   _sp if _sp is not None else _stream_ptr(icnf.device)))
     return out[0]
 
 
@@ -729,9 +731,10 @@ def loss(icnf: ICNF, mode: Mode, *args, eps: Optional[torch.Tensor] = None, grou
     from .sharding import reduce_loss
     group = icnf._group(group)
     from .sharding import is_sharded
-    logp, regs = inference(icnf, mode, *args, eps=eps, _raw=True, group=group)
+    sp = _stream_ptr(icnf.device)
+    logp, regs = inference(icnf, mode, *args, eps=eps, _raw=True, group=group, _sp=sp)
     if not is_sharded(group) and logp.numel():
-        return loss_mean(icnf, mode, logp, regs)       # one process: the mean comes out of the reduction kernels themselves
+        return loss_mean(icnf, mode, logp, regs, _sp=sp)       # one process: the mean comes out of the reduction kernels themselves
     sums = loss_sums(icnf, mode, logp, regs)
     return reduce_loss(sums, logp.numel(), (icnf.lambda1, icnf.lambda2, icnf.lambda3), group=group)
 

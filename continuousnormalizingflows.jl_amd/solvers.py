@@ -32,7 +32,7 @@ def _solve_errors(call):
 
 
 def _adaptive_integrate(icnf, h, u0: torch.Tensor, t0: float, t1: float,
-                        e: Optional[torch.Tensor], y: Optional[torch.Tensor], group=None, _tsit5: bool = False) -> torch.Tensor:
+                        e: Optional[torch.Tensor], y: Optional[torch.Tensor], group=None, _tsit5: bool = False, _sp=None) -> torch.Tensor:
     """Adaptive Tsit5 from t0 to t1 (either direction) on the (B, S) state u0: what `SciMLBase.solve(prob, Tsit5();
     reltol, abstol)` does in `base_sol` (src/core/base_icnf.jl:134-140), restated from OrdinaryDiffEq's documented
     algorithm — Hairer's initial step, embedded 4th-order error estimate scaled by `abstol + reltol max(|u_prev|, |u|)`
@@ -44,13 +44,13 @@ def _adaptive_integrate(icnf, h, u0: torch.Tensor, t0: float, t1: float,
     of the same algorithm and against fine fixed-step solves."""
     from .sharding import allsum as _allsum, is_sharded
     if icnf._solver() == _lib.ALG_VCABM and not _tsit5:
-        return _vcabm_integrate(icnf, h, u0, t0, t1, e, y, group=group)
+        return _vcabm_integrate(icnf, h, u0, t0, t1, e, y, group=group, _sp=_sp)
     kw = icnf.sol_kwargs
     reltol, abstol = float(kw.get("reltol", 1e-4)), float(kw.get("abstol", 1e-4))
     maxiters = _lib.clamp_maxiters(kw)
     dev = icnf.device
     B, S = u0.shape
-    lib, st = h.lib, _stream_ptr(dev)
+    lib, st = h.lib, (_sp if _sp is not None else _stream_ptr(dev))
     sharded = is_sharded(group)     # group=False: a rank-local solve, no collectives
     tdir = 1.0 if t1 >= t0 else -1.0
     span = abs(t1 - t0)
@@ -63,7 +63,9 @@ def _adaptive_integrate(icnf, h, u0: torch.Tensor, t0: float, t1: float,
     if not sharded and getattr(icnf, "adaptive_policy", "library") == "library":
         # single process: the same controller restated inside the library (cnf_solve_tsit5), one call per solve
         cap = 4096
-        ss, dts = _lib.SolveStats(), (C.c_float * cap)()
+        if getattr(icnf, "_ts_records", None) is None:      # the record array of the call, made once
+            icnf._ts_records = (_lib.SolveStats(), (C.c_float * cap)())
+        ss, dts = icnf._ts_records
         u0 = u0.contiguous()
         out = torch.empty_like(u0)
         _solve_errors(lambda: lib.cnf_solve_tsit5(h.ptr, t0, t1, _ptr(u0), _ptr(e), _ptr(y), B, abstol, reltol,
@@ -140,7 +142,7 @@ def _adaptive_integrate(icnf, h, u0: torch.Tensor, t0: float, t1: float,
 
 
 def _vcabm_integrate(icnf, h, u0: torch.Tensor, t0: float, t1: float,
-                     e: Optional[torch.Tensor], y: Optional[torch.Tensor], group=None) -> torch.Tensor:
+                     e: Optional[torch.Tensor], y: Optional[torch.Tensor], group=None, _sp=None) -> torch.Tensor:
     """`SciMLBase.solve(prob, VCABM(); reltol, abstol)` of `base_sol` (src/core/base_icnf.jl:134-140) - the reference's
     default solver - from t0 to t1 (either direction) on the (B, S) state u0.  The device keeps the multistep state and
     does the PECE passes (`cnf_vcabm_*`, csrc/cnf_vcabm.hip); this loop is the host side of the solver: order ramp
@@ -158,7 +160,7 @@ def _vcabm_integrate(icnf, h, u0: torch.Tensor, t0: float, t1: float,
     maxiters = _lib.clamp_maxiters(kw)
     dev = icnf.device
     B, S = u0.shape
-    lib, st = h.lib, _stream_ptr(dev)
+    lib, st = h.lib, (_sp if _sp is not None else _stream_ptr(dev))
     sharded = is_sharded(group)     # group=False: a rank-local solve, no collectives
     tdir = 1.0 if t1 >= t0 else -1.0
     span = abs(t1 - t0)
@@ -175,7 +177,9 @@ def _vcabm_integrate(icnf, h, u0: torch.Tensor, t0: float, t1: float,
     if not sharded and getattr(icnf, "adaptive_policy", "library") == "library":
         # single process: the same policy restated inside the library (cnf_solve_vcabm), one call per solve
         cap = 4096
-        ss, dts, orders = _lib.SolveStats(), (C.c_float * cap)(), (C.c_int32 * cap)()
+        if getattr(icnf, "_vc_records", None) is None:      # the record arrays of the call, made once (two 16 KB ctypes arrays cost 10 us)
+            icnf._vc_records = (_lib.SolveStats(), (C.c_float * cap)(), (C.c_int32 * cap)())
+        ss, dts, orders = icnf._vc_records
         out = torch.empty_like(u0)
         _solve_errors(lambda: lib.cnf_solve_vcabm(h.ptr, t0, t1, _ptr(u0), _ptr(e), _ptr(y), B, abstol, reltol,
                                                   float(kw["dt"]) if "dt" in kw else 0.0, maxiters, _ptr(out), C.byref(ss), dts, orders, cap, st))

@@ -122,6 +122,7 @@ typedef struct cnf_tuning {
     int32_t coop_grad_mid;         /* CNF_COOP_GRAD_MID, default 1: auxiliary cooperative plan for the gradient of 7-8-tile slab shapes from 4096 columns on; 0 off */
     int32_t grad_layered;          /* CNF_GRAD_LAYERED, default 0: 1: every gradient takes the layer-wise path (A/B, cross-checks) */
     int32_t jvp_grad_twin;         /* CNF_JVP_GRAD_TWIN, default 1: JVP mode without the |J eps| regulariser trains through the VJP mode's fused sweeps; 0: its own layer-wise gradient */
+    int32_t probe_grad_twin;       /* CNF_PROBE_GRAD_TWIN, default 1: K > 1 probes on two hidden layers whose own gradient is layer-wise train probe by probe on the one-probe cooperative sweep; 2: three hidden layers too (slower there); 0: never */
     int32_t layered_loss_by_solve; /* CNF_LAYERED_LOSS_BY_SOLVE, default 0: 1: the layer-wise gradient takes its loss from a separate solve instead of accumulating it in the sweep */
     int32_t device_controller;     /* CNF_DEVICE_CONTROLLER, default 1: one-launch adaptive Tsit5 / VCABM with the step controller on the device where the batch fits; 0: host loop */
     int32_t dc_per_cu;             /* CNF_DC_PER_CU, default 1: workgroups per CU of the one-launch adaptive kernels */

@@ -1198,6 +1198,44 @@ def test_jvp_mode_gradient_through_the_vjp_twin_agrees_with_its_own_layerwise_gr
         assert np.max(np.abs(a - b)) < 5e-5 * np.abs(b).max() + 1e-6
 
 
+PROBE_LOOP_SHAPES = [
+    # several probes on shapes whose one-probe gradient runs on the cooperative / dealt reverse sweep
+    (dict(nvars=32, hidden=[256, 256, 256], nprobes=3, reg_z=True, reg_j=True), (0.02, 0.03, 0.0), 40, 0, 2),
+    (dict(nvars=20, naug=21, hidden=[168, 168], act=2, nprobes=2, reg_z=True, reg_j=True, reg_aug=True), (0.01, 0.01, 0.01), 37, 1, 2),   # default architecture
+    (dict(nvars=12, hidden=[192, 192, 192], nprobes=4, mode=1, reg_z=True), (0.02, 0.0, 0.0), 33, 1, 2),                           # JVP -> K-probe VJP -> one-probe twin
+]
+
+
+@pytest.mark.parametrize("kw,lam,B,alg,nsteps", PROBE_LOOP_SHAPES)
+def test_several_probes_train_probe_by_probe_on_the_cooperative_sweep(kw, lam, B, alg, nsteps, pkg, oracles, monkeypatch):
+    """K > 1 probes on wide nets (round 5): the loss is the mean over the probes of the one-probe losses, so the gradient is K
+    calls of the one-probe configuration's cooperative reverse sweep (cnf_handle::grad_twin), averaged in probe order - against fp64
+    autograd of the K-probe loss and against the configuration's own layer-wise gradient (CNF_PROBE_GRAD_TWIN=0)."""
+    o64, _ = oracles
+    spec = o64.make_spec(**kw)
+    p, xs, eps, ys = o64.synth_inputs(spec, B, 77, bias_scale=0.2)
+    L, gref = o64.loss_and_grad(spec, p, xs, 0.0, 1.0, nsteps, alg, eps, ys, lam)
+    out = {}
+    two_hidden = len(spec.widths) == 4
+    for tag, env in (("default", "1"), ("loop", "2"), ("own", "0")):
+        setsw(pkg, monkeypatch, "CNF_PROBE_GRAD_TWIN", env)
+        icnf = make_icnf(pkg, spec, alg, nsteps, path=0, lambdas=lam)
+        mode = pkg.TrainMode(bool(spec.reg_z or spec.reg_j or spec.reg_aug))
+        # by default only two hidden layers take the loop (three: 0.96 x the layer-wise path at K = 4, B = 32 768)
+        assert icnf.grad_path(mode, B=B, alg=alg) == (3 if tag == "loop" or (tag == "default" and two_hidden) else 2)
+        if tag == "default":
+            continue
+        val, g, gx = pkg.loss_and_gradient(icnf, mode, dev(xs), dev(p), {}, eps=dev(eps), wrt_x=True)
+        out[tag] = (float(val), g.cpu().numpy().astype(np.float64), gx.cpu().numpy().astype(np.float64))
+    scale = np.abs(gref).max()
+    assert abs(out["loop"][0] - L) < 1e-4
+    assert np.max(np.abs(out["loop"][1] - gref)) < 5e-5 * scale + 1e-6, np.max(np.abs(out["loop"][1] - gref)) / scale
+    assert abs(out["loop"][0] - out["own"][0]) < 2e-5 * (1 + abs(L))
+    for k in (1, 2):
+        a, b = out["loop"][k], out["own"][k]
+        assert np.max(np.abs(a - b)) < 5e-5 * np.abs(b).max() + 1e-6
+
+
 @pytest.mark.parametrize("kw,lam", [
     (dict(nvars=8, hidden=[64, 64, 64]), (0.0, 0.0, 0.0)),                                                  # fused kernel, one probe
     (dict(nvars=6, naug=2, hidden=[64, 64, 64], nprobes=3, reg_z=True, reg_j=True, reg_aug=True), (0.02, 0.03, 0.01)),   # fused probes kernel, augmented
