@@ -1332,6 +1332,9 @@ mfma_vcabm_kernel(KArgs a, AArgs q) {
 
     // scaled squared norm pieces: r = v / (abstol + |ref| reltol)
     auto sk_of = [&](float ref) { return fmaf(fabsf(ref), reltol, abstol); };
+    // x^y for x > 0 as exp(y log x): a third of the instructions of pow() (no special cases, no extended-precision logarithm), a few
+    // ulp - the step-size factor it feeds is clamped to [1/qmax, 1/qmin] and the step it scales rounded to float
+    auto pow_pos = [](double x, double y) { return exp(y * log(x)); };
 
 #ifdef VC_TRACE
     unsigned long long vc_t[6] = {0, 0, 0, 0, 0, 0}, vc_s = 0, vc_k0 = __builtin_amdgcn_s_memtime();   // dyn, sums, begin, phase 2, phase 3, rest
@@ -1429,7 +1432,7 @@ mfma_vcabm_kernel(KArgs a, AArgs q) {
             if (!isfinite(eest)) { status = 1; break; }
             if (eest > 1.0) {   // reject: same state, smaller step, same order (nothing was stored)
                 ++nreject;
-                dt = hstep / fmax(1.0 / qmax, fmin(1.0 / qmin, pow(eest, 1.0 / (double)(k + 1)) / gamma));
+                dt = hstep / fmax(1.0 / qmax, fmin(1.0 / qmin, pow_pos(eest, 1.0 / (double)(k + 1)) / gamma));
                 begin = true;
             } else {
                 select = step > 4 && k >= 3;
@@ -1448,13 +1451,31 @@ mfma_vcabm_kernel(KArgs a, AArgs q) {
             if (!select) knew = k + 1 < 3 ? k + 1 : 3;
             else if (lower) knew = k - 1;
             else if (want_up) {
-                gs[0] = 1.0;
-                for (int j = 1; j <= k + 1; ++j) {
-                    double acc = 0.0;
-                    for (int i = 0; i < j; ++i) acc += gs[i] / (double)(j - i + 1);
-                    gs[j] = -acc;
+                double gs_up;
+                if (k <= 4) {   // register form of the loop below (see the step coefficients further down)
+                    double gr[6];
+                    gr[0] = 1.0;
+#pragma unroll
+                    for (int j = 1; j <= 5; ++j) {
+                        gr[j] = 0.0;
+                        if (j <= k + 1) {
+                            double acc = 0.0;
+#pragma unroll
+                            for (int i = 0; i < j; ++i) acc += gr[i] / (double)(j - i + 1);
+                            gr[j] = -acc;
+                        }
+                    }
+                    gs_up = k == 4 ? gr[5] : (k == 3 ? gr[4] : (k == 2 ? gr[3] : (k == 1 ? gr[2] : gr[1])));
+                } else {
+                    gs[0] = 1.0;
+                    for (int j = 1; j <= k + 1; ++j) {
+                        double acc = 0.0;
+                        for (int i = 0; i < j; ++i) acc += gs[i] / (double)(j - i + 1);
+                        gs[j] = -acc;
+                    }
+                    gs_up = gs[k + 1];
                 }
-                const float eu = (float)((double)dtf * gs[k + 1]);
+                const float eu = (float)((double)dtf * gs_up);
                 double s0 = 0.0, s1 = 0.0, s2 = 0.0;
 #pragma unroll
                 for (int r = 0; r < NR; ++r) {
@@ -1494,7 +1515,7 @@ mfma_vcabm_kernel(KArgs a, AArgs q) {
             hist[0] = (double)dtf;
             tvc += (double)dtf;
             nhist += 1;
-            const double qq = eest == 0.0 ? 1.0 / qmax : fmax(1.0 / qmax, fmin(1.0 / qmin, pow(eest, 1.0 / (double)(knew + 1)) / gamma));
+            const double qq = eest == 0.0 ? 1.0 / qmax : fmax(1.0 / qmax, fmin(1.0 / qmin, pow_pos(eest, 1.0 / (double)(knew + 1)) / gamma));
             tpol = last ? t1 : tpol + tdir * hstep;
             if (tile == 0 && lane == 0) {
                 if (naccept < q.dts_cap) { q.dts[naccept] = dtf; q.orders[naccept] = k; }
@@ -1516,27 +1537,70 @@ mfma_vcabm_kernel(KArgs a, AArgs q) {
             hstep = last ? fabs(t1 - tpol) : dt;      // tstop: never step over t1
             dtf = (float)(tdir * hstep);
             m = k + 1 < nhist + 1 ? k + 1 : nhist + 1;
-            // step sizes newest first, the candidate in front
-            dtsv[0] = (double)dtf;
-            for (int i = 0; i <= KS; ++i) dtsv[i + 1] = hist[i];
-            double bb = 1.0, num = 0.0, den = 0.0;
-            beta[0] = 1.f;
-            for (int j = 1; j < m; ++j) { num += dtsv[j - 1]; den += dtsv[j]; bb *= num / den; beta[j] = (float)bb; }
             const int ng = k + 1;
-            gd[0] = 1.0;
-            for (int qi = 1; qi <= ng; ++qi) cq[qi - 1] = 1.0 / ((double)qi * (double)(qi + 1));
-            double xi = dtsv[0];
-            for (int j = 1; j < ng; ++j) {
-                if (j > 1) {
-                    xi += dtsv[j - 1];
-                    for (int qi = 0; qi < ng - j + 1; ++qi) cq[qi] = cq[qi] - cq[qi + 1] * (double)dtf / xi;
+            if (k <= 4) {
+                // Orders 1 .. 4 (what a default-tolerance solve runs at): the recurrences of the general form below, operation for
+                // operation, on register arrays - static indices, wave-uniform branches.  The run-time indexed LDS loops cost a
+                // one-wave kernel ~6 k cycles per step (every access a round trip nothing covers), a third of the step.
+                const double hh[5] = {(double)dtf, hist[0], hist[1], hist[2], hist[3]};   // step sizes newest first, the candidate in front
+                double bb = 1.0, num = 0.0, den = 0.0;
+                beta[0] = 1.f;
+#pragma unroll
+                for (int j = 1; j < 5; ++j) {
+                    if (j < m) { num += hh[j - 1]; den += hh[j]; bb *= num / den; beta[j] = (float)bb; }
                 }
-                gd[j] = cq[0];
+                double c[5], gr[5];
+#pragma unroll
+                for (int qi = 1; qi <= 5; ++qi) c[qi - 1] = 1.0 / ((double)qi * (double)(qi + 1));
+                gr[0] = 1.0;
+                double xi = hh[0];
+#pragma unroll
+                for (int j = 1; j < 5; ++j) {
+                    gr[j] = 0.0;
+                    if (j < ng) {
+                        if (j > 1) {
+                            xi += hh[j - 1];
+#pragma unroll
+                            for (int qi = 0; qi < 6 - j; ++qi) {
+                                if (qi < ng - j + 1) c[qi] = c[qi] - c[qi + 1] * (double)dtf / xi;
+                            }
+                        }
+                        gr[j] = c[0];
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 5; ++j) {
+                    if (j < ng) gg[j] = (float)gr[j];
+                }
+                const double gk = k == 4 ? gr[4] : (k == 3 ? gr[3] : (k == 2 ? gr[2] : gr[1]));
+                const double gk1 = k == 4 ? gr[3] : (k == 3 ? gr[2] : (k == 2 ? gr[1] : gr[0]));
+                const double gk2 = k == 4 ? gr[2] : (k == 3 ? gr[1] : gr[0]);
+                const double gk3 = k == 4 ? gr[1] : gr[0];
+                e0 = (float)((double)dtf * (gk - gk1));
+                e1 = k >= 2 ? (float)((double)dtf * (gk1 - gk2)) : 0.f;
+                e2 = k >= 3 ? (float)((double)dtf * (gk2 - gk3)) : 0.f;
+            } else {
+                // step sizes newest first, the candidate in front
+                dtsv[0] = (double)dtf;
+                for (int i = 0; i <= KS; ++i) dtsv[i + 1] = hist[i];
+                double bb = 1.0, num = 0.0, den = 0.0;
+                beta[0] = 1.f;
+                for (int j = 1; j < m; ++j) { num += dtsv[j - 1]; den += dtsv[j]; bb *= num / den; beta[j] = (float)bb; }
+                gd[0] = 1.0;
+                for (int qi = 1; qi <= ng; ++qi) cq[qi - 1] = 1.0 / ((double)qi * (double)(qi + 1));
+                double xi = dtsv[0];
+                for (int j = 1; j < ng; ++j) {
+                    if (j > 1) {
+                        xi += dtsv[j - 1];
+                        for (int qi = 0; qi < ng - j + 1; ++qi) cq[qi] = cq[qi] - cq[qi + 1] * (double)dtf / xi;
+                    }
+                    gd[j] = cq[0];
+                }
+                for (int j = 0; j < ng; ++j) gg[j] = (float)gd[j];
+                e0 = (float)((double)dtf * (gd[k] - gd[k - 1]));
+                e1 = k >= 2 ? (float)((double)dtf * (gd[k - 1] - gd[k - 2])) : 0.f;
+                e2 = k >= 3 ? (float)((double)dtf * (gd[k - 2] - gd[k - 3])) : 0.f;
             }
-            for (int j = 0; j < ng; ++j) gg[j] = (float)gd[j];
-            e0 = (float)((double)dtf * (gd[k] - gd[k - 1]));
-            e1 = k >= 2 ? (float)((double)dtf * (gd[k - 1] - gd[k - 2])) : 0.f;
-            e2 = k >= 3 ? (float)((double)dtf * (gd[k - 2] - gd[k - 3])) : 0.f;
             // P: p = u + dt sum_{j<k} g_j Phi*_j(n)
 #pragma unroll
             for (int r = 0; r < NR; ++r) {
