@@ -32,6 +32,8 @@ The JSON line also carries
                  measured by the same protocol in the same process, with its own roofline.
   secondaries  — (default one-GPU line only) every other BASELINE configuration, the loss + gradient of cfg2, cfg3 and cfg4 and the
                  reference's default architecture at nvariables = 20 (inference and loss + gradient), compactly, same protocol.
+  small_batch  — (default one-GPU line only) wall time of one call at the reference's own batch size, host side included: its
+                 PkgBenchmark scenario (ICNF(nvariables = 1), VCABM, 2^10 samples; `loss` in TrainMode and TestMode) and cfg1.
   cpu_baseline — CPU fp32 restatements of the same algorithm on this host's cores (rank 0, N = 1):
                  the C port (oracle/cnf_oracle.c, cache-blocked register-tiled products, AVX-512 when
                  the CPU has it) and a whole-batch BLAS leg (torch.mm on every host thread at the full
@@ -350,6 +352,43 @@ def make_workload(pkg, o64, name, a, rank, dev, torch, arith=None, grad=None, ba
                 host=(p, xs, eps, ys), grad=(a.mode == "grad") if grad is None else bool(grad))
 
 
+def small_batch_latency(pkg, o64, a, dev, torch):
+    """Wall time of one call at the reference's own batch size (2^10 samples), host side included - what its PkgBenchmark suite
+    measures (benchmark/benchmarks.jl:11-19: ICNF(; nvariables = 1), every default: the default net, VCABM at 1e-4, default lambdas):
+    `loss` in TrainMode{true} and TestMode; and BASELINE's CPU-runnable configuration cfg1 (D = 2, 2 x 32, Tsit5 x 40) as one
+    `inference` call.  The adaptive solves synchronise the stream (the host reads the step count), so calls do not pipeline."""
+    import time
+    out = {"what": "ms per call at B = 1024, Python + library + kernels; PkgBenchmark scenario = ICNF(nvariables = 1) defaults (VCABM, 1e-4)", "batch": 1024}
+    r = torch.distributions.Beta(2.0, 4.0).sample((1, 1024)).float().to(dev)
+    icnf = pkg.ICNF(nvariables=1, device=dev)
+    ps, st = pkg.setup(torch.Generator().manual_seed(0), icnf)
+    ps = ps.to(dev)
+    for key, mode in (("pkgbenchmark_loss_train_ms", pkg.TrainMode(True)), ("pkgbenchmark_loss_test_ms", pkg.TestMode())):
+        for _ in range(20):
+            pkg.loss(icnf, mode, r, ps, st)
+        torch.cuda.synchronize()
+        n = 300
+        t0 = time.perf_counter()
+        for _ in range(n):
+            pkg.loss(icnf, mode, r, ps, st)
+        torch.cuda.synchronize()
+        out[key] = round(1e3 * (time.perf_counter() - t0) / n, 4)
+        out[key.replace("_ms", "_steps")] = int(icnf.last_solve_stats["naccept"])
+    w = make_workload(pkg, o64, "cfg1", a, 0, dev, torch, grad=False, batch=1024)
+    fn = lambda: pkg.inference(w["icnf"], w["mode"], *w["args"], eps=w["E"])
+    for _ in range(20):
+        fn()
+    torch.cuda.synchronize()
+    n = 300
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    out["cfg1_inference_ms"] = round(1e3 * (time.perf_counter() - t0) / n, 4)
+    out["cfg1_kernel"] = w["icnf"].kernel_name(w["mode"])
+    return out
+
+
 def _quarters(ms):
     n = len(ms)
     q = max(1, n // 4)
@@ -660,6 +699,13 @@ def main():
                 wi = None
                 torch.cuda.empty_cache()
 
+    small = None
+    if default_line and a.secondaries == "auto":
+        try:
+            small = small_batch_latency(pkg, o64, a, dev, torch)
+        except Exception as ex:  # pragma: no cover
+            small = {"error": str(ex)[:200]}
+
     ranks_seen = None
     if sharded:
         # what every rank bound and what the communicator it reduced on reports: the driver's log then proves that RCCL saw N ranks
@@ -707,6 +753,8 @@ def main():
                                  **({"executed_frac": rf["executed_frac"]} if "executed_frac" in rf else {}),
                                  "what": ("loss + gradient (forward with checkpoints + reverse sweep), 3 F convention" if wi["grad"]
                                           else "the fused solve kernel")}}
+        if small is not None:
+            out["small_batch"] = small
         if sec is not None:
             r2 = report(sec[0], sec[1], a, a.steps, a.warmup, world)
             out["secondary"] = {"metric": out["metric"], "unit": out["unit"], "steps": a.steps,
