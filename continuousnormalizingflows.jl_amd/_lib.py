@@ -20,7 +20,7 @@ OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_NO_PARAMS, ERR_HIP, ERR_NO_DEVICE = 0, -1,
 ACT_IDENTITY, ACT_TANH, ACT_SOFTPLUS = 0, 1, 2
 MODE_HUTCH_VJP, MODE_HUTCH_JVP, MODE_EXACT = 0, 1, 2
 ALG_RK4, ALG_TSIT5 = 0, 1
-ALG_VCABM = 2   # host-side id only: the multistep solve has its own entry points (cnf_vcabm_*)
+ALG_VCABM = 2   # CNF_ALG_VCABM: taken by cnf_loss_adaptive only - the multistep solve has its own entry points (cnf_vcabm_*, cnf_solve_vcabm)
 VCABM_MAX_ORDER = 12
 PATH_AUTO, PATH_SIMT, PATH_MFMA, PATH_LAYERED = 0, 1, 2, 3
 STEP_FSAL, STEP_RETRY = 1, 2
@@ -32,7 +32,7 @@ DTYPE_F32, DTYPE_F64 = 0, 1
 EXPORTS = ("cnf_version", "cnf_build_info", "cnf_get_tuning", "cnf_set_tuning", "cnf_last_error", "cnf_create", "cnf_destroy", "cnf_set_params",
            "cnf_kernel_path", "cnf_solve_controller", "cnf_repack_on_device", "cnf_aug_f", "cnf_integrate_fixed", "cnf_inference_fixed",
            "cnf_loss_sums", "cnf_loss_mean", "cnf_loss_grad_fixed", "cnf_loss_grad_grid", "cnf_grad_path", "cnf_step_embedded", "cnf_assemble_u0",
-           "cnf_epilogue", "cnf_vcabm_begin", "cnf_vcabm_attempt", "cnf_vcabm_accept", "cnf_vcabm_state", "cnf_solve_vcabm", "cnf_solve_tsit5", "cnf_loss_grad_adaptive",
+           "cnf_epilogue", "cnf_vcabm_begin", "cnf_vcabm_attempt", "cnf_vcabm_accept", "cnf_vcabm_state", "cnf_solve_vcabm", "cnf_solve_tsit5", "cnf_loss_adaptive", "cnf_loss_grad_adaptive",
            "cnf_integrate_fixed_dt", "cnf_inference_fixed_dt",
            "cnf_comm_unique_id", "cnf_comm_init", "cnf_comm_init_all", "cnf_comm_destroy", "cnf_comm_rank", "cnf_comm_size",
            "cnf_comm_group_start", "cnf_comm_group_end", "cnf_allreduce_loss", "cnf_allreduce_sum",
@@ -129,6 +129,9 @@ def load():
                                            C.POINTER(C.c_float), fp, fp, fp, C.POINTER(SolveStats), C.POINTER(C.c_float), C.c_int32, vp]
     lib.cnf_solve_vcabm.argtypes = [vp, C.c_float, C.c_float, fp, fp, fp, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_int,
                                     fp, C.POINTER(SolveStats), C.POINTER(C.c_float), C.POINTER(C.c_int32), C.c_int32, vp]
+    lib.cnf_loss_adaptive.argtypes = [vp, C.c_int, C.c_float, C.c_float, fp, fp, fp, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_int,
+                                      C.POINTER(C.c_double), fp, fp, fp, fp, C.POINTER(SolveStats), C.POINTER(C.c_float), C.POINTER(C.c_int32),
+                                      C.c_int32, vp]
     lib.cnf_aug_f.argtypes = [vp, fp, fp, C.c_float, fp, fp, C.c_int64, vp]
     lib.cnf_integrate_fixed.argtypes = [vp, C.c_int, C.c_int, C.c_float, C.c_float, fp, fp, fp,
                                         C.c_int64, fp, vp]

@@ -562,6 +562,40 @@ int cnf::api_solve_tsit5(cnf_handle* h, float t0, float t1, const float* u0, con
 }
 }  // extern "C++"
 
+int cnf_loss_adaptive(cnf_handle* h, int alg, float t0, float t1, const float* x, const float* eps, const float* ys, int64_t B,
+                      float abstol, float reltol, float dt_init, int maxiters, const double* lambdas, float* loss, float* sums4,
+                      float* logp_out, float* regs_out, cnf_solve_stats* stats, float* dts_out, int32_t* orders_out,
+                      int32_t record_cap, void* stream) {
+    if (stats) *stats = cnf_solve_stats{};
+    int rc = api_check_call(h, eps, ys, B, "cnf_loss_adaptive");
+    if (rc) return rc;
+    if (alg != CNF_ALG_VCABM && alg != CNF_ALG_TSIT5) return fail(CNF_ERR_INVALID, "cnf_loss_adaptive: alg must be CNF_ALG_VCABM or CNF_ALG_TSIT5");
+    if (B < 1) return fail(CNF_ERR_INVALID, "cnf_loss_adaptive: the mean of an empty batch is undefined");
+    if (!x || !lambdas || !loss) return fail(CNF_ERR_INVALID, "cnf_loss_adaptive: null x/lambdas/loss");
+    DeviceGuard g(h->cfg.device_id);
+    hipStream_t st = (hipStream_t)stream;
+    rc = api_ensure_adaptive_buf(h, B);
+    if (rc) return rc;
+    const size_t slot = (size_t)h->S * (size_t)h->adp.B;
+    float* u0 = h->adp.buf + 4 * slot;     // the two slots the solves themselves do not use (as cnf_loss_grad_adaptive)
+    float* u1 = u0 + slot;
+    HIP_TRY(assemble_u0(x, h->cfg.nvars, h->S, B, u0, st));
+    if (alg == CNF_ALG_VCABM) {
+        rc = cnf_solve_vcabm(h, t0, t1, u0, eps, ys, B, abstol, reltol, dt_init, maxiters, u1, stats, dts_out, orders_out, record_cap, stream);
+    } else {
+        rc = cnf_solve_tsit5(h, t0, t1, u0, eps, ys, B, abstol, reltol, dt_init, maxiters, u1, stats, dts_out, record_cap, stream);
+    }
+    if (rc) return rc;
+    // u0 is spent: its slot (S >= 4 floats per column) takes the per-sample outputs the caller did not ask for
+    float* logp = logp_out ? logp_out : u0;
+    float* regs = regs_out ? regs_out : u0 + B;
+    const int reg_aug = (h->cfg.reg_aug && h->cfg.naug > 0 && h->cfg.mode != CNF_MODE_EXACT) ? 1 : 0;
+    HIP_TRY(epilogue(u1, h->cfg.nvars, h->D, reg_aug, B, logp, regs, st));
+    if (!h->loss_partial) HIP_TRY(hipMalloc((void**)&h->loss_partial, 256 * 4 * sizeof(float)));
+    HIP_TRY(loss_mean(logp, regs, B, h->loss_partial, sums4, loss, lambdas, st));
+    return CNF_OK;
+}
+
 int cnf_solve_tsit5(cnf_handle* h, float t0, float t1, const float* u0, const float* eps, const float* ys, int64_t B,
                     float abstol, float reltol, float dt_init, int maxiters, float* u1, cnf_solve_stats* stats,
                     float* dts_out, int32_t record_cap, void* stream) {

@@ -723,6 +723,52 @@ def loss_mean(icnf: ICNF, mode: Mode, logp: torch.Tensor, regs, _sp=None) -> tor
     return out[0]
 
 
+def _loss_adaptive_one_call(icnf: ICNF, mode: Mode, args, eps, sp):
+    """`loss` of an unsharded batch under an adaptive solver as ONE library call (cnf_loss_adaptive: u0 assembly, the VCABM or
+    adaptive Tsit5 solve, the epilogue, the mean - the same kernels `inference` + `loss_mean` enqueue, so the same bits).  What it
+    saves is host time: at the reference's own batch size (2^10 samples, its PkgBenchmark suite) a solve is ~0.13 ms of kernel and
+    the Python / ctypes side of four calls another ~0.03.  Returns None for an empty batch (the general path raises / returns NaN)."""
+    xs, ys, ps, st = _split_args(icnf, args, "loss")
+    h = icnf._handle(mode)
+    icnf._bind_params(h, ps)
+    dev = icnf.device
+    x = _colmajor(xs, icnf.nvariables, "xs", dev)
+    B = x.shape[0]
+    if B == 0:
+        return None
+    y = _colmajor(ys, icnf.nconditions, "ys", dev) if icnf.conditioned else None
+    if y is not None and y.shape[0] != B:
+        raise ValueError("DimensionMismatch: xs and ys must have the same number of columns")
+    K = icnf.nprobes if isinstance(mode, TrainMode) else 1
+    if eps is None:
+        e = _draw_eps(icnf, K, B)
+    else:
+        e = _colmajor(eps, K * icnf.D, "eps", dev)
+        if e.shape[0] != B:
+            raise ValueError("DimensionMismatch: eps must have B columns")
+    t0, t1 = icnf._steer_tspan(mode)
+    kw = icnf.sol_kwargs
+    vcabm = icnf._solver() == _lib.ALG_VCABM
+    cap = 4096
+    rec = getattr(icnf, "_loss_records", None)
+    if rec is None:
+        rec = icnf._loss_records = (_lib.SolveStats(), (C.c_float * cap)(), (C.c_int32 * cap)(), (C.c_double * 3)())
+    ss, dts, orders, lam = rec
+    lam[0], lam[1], lam[2] = float(icnf.lambda1), float(icnf.lambda2), float(icnf.lambda3)
+    out = torch.empty(1, device=dev, dtype=torch.float32)
+    _solve_errors(lambda: h.lib.cnf_loss_adaptive(
+        h.ptr, _lib.ALG_VCABM if vcabm else _lib.ALG_TSIT5, t0, t1, _ptr(x), _ptr(e), _ptr(y), B, float(kw.get("abstol", 1e-4)),
+        float(kw.get("reltol", 1e-4)), float(kw["dt"]) if "dt" in kw else 0.0, _lib.clamp_maxiters(kw), lam, _ptr(out), None, None, None,
+        C.byref(ss), dts, orders, cap, sp))
+    m = min(ss.naccept, cap)
+    stats = {"naccept": ss.naccept, "nreject": ss.nreject, "nf": ss.nf, "dts": [float(v) for v in dts[:m]],
+             "alg_used": "VCABM" if vcabm else "Tsit5", "controller": "device" if h.lib.cnf_solve_controller(h.ptr) == 1 else "host"}
+    if vcabm:
+        stats["orders"] = [int(v) for v in orders[:m]]
+    icnf.last_solve_stats = stats
+    return out[0]
+
+
 def loss(icnf: ICNF, mode: Mode, *args, eps: Optional[torch.Tensor] = None, group=None):
     """loss(icnf, mode, xs[, ys], ps, st) = mean(-logp̂x + λ₁Ė + λ₂ṅ + λ₃Ȧ)
     (src/core/icnf.jl:628-649).  When torch.distributed is initialised the batch columns are
@@ -732,6 +778,10 @@ def loss(icnf: ICNF, mode: Mode, *args, eps: Optional[torch.Tensor] = None, grou
     group = icnf._group(group)
     from .sharding import is_sharded
     sp = _stream_ptr(icnf.device)
+    if (icnf.adaptive and not is_sharded(group) and icnf.basedist is None and getattr(icnf, "adaptive_policy", "library") == "library"):
+        out = _loss_adaptive_one_call(icnf, mode, args, eps, sp)
+        if out is not None:
+            return out
     logp, regs = inference(icnf, mode, *args, eps=eps, _raw=True, group=group, _sp=sp)
     if not is_sharded(group) and logp.numel():
         return loss_mean(icnf, mode, logp, regs, _sp=sp)       # one process: the mean comes out of the reduction kernels themselves

@@ -29,7 +29,8 @@
  *   boundary A (per call)    cnf_aug_f                      du = augmented_f(u, p, t)
  *   boundary B (whole solve) cnf_integrate_fixed, cnf_inference_fixed, cnf_integrate_fixed_dt, cnf_inference_fixed_dt, cnf_loss_sums, cnf_loss_mean
  *   caller-driven solves     cnf_assemble_u0, cnf_step_embedded (adaptive Tsit5 attempt), cnf_epilogue,
- *                            cnf_vcabm_begin / _attempt / _accept / _state, cnf_solve_vcabm (the reference's default alg VCABM), cnf_solve_tsit5
+ *                            cnf_vcabm_begin / _attempt / _accept / _state, cnf_solve_vcabm (the reference's default alg VCABM), cnf_solve_tsit5,
+ *                            cnf_loss_adaptive (the whole `loss` call under either)
  *   training                 cnf_loss_grad_fixed, cnf_loss_grad_grid, cnf_loss_grad_adaptive  (dloss/dps, optionally dloss/dxs)
  *   column shards (RCCL)     cnf_comm_unique_id, cnf_comm_init, cnf_comm_init_all, cnf_comm_destroy, cnf_comm_rank, cnf_comm_size,
  *                            cnf_allreduce_loss (the mean in `loss`), cnf_allreduce_sum, cnf_comm_group_start / _end
@@ -69,7 +70,7 @@ enum { CNF_MODE_HUTCH_VJP = 0, CNF_MODE_HUTCH_JVP = 1, CNF_MODE_EXACT = 2 };
 
 /* fixed-step integrators a user selects through sol_kwargs=(alg, adaptive=false, dt)
  * (src/core/base_icnf.jl:138) */
-enum { CNF_ALG_RK4 = 0, CNF_ALG_TSIT5 = 1 };
+enum { CNF_ALG_RK4 = 0, CNF_ALG_TSIT5 = 1, CNF_ALG_VCABM = 2 /* cnf_loss_adaptive only: the multistep solve has its own entry points */ };
 
 /* arithmetic of the hidden-layer products (cnf_config.arith).  Both accumulate in f32.
  *   F32       exact f32 MFMA (v_mfma_f32_16x16x4_f32 = fmaf chain) — default, the validated path
@@ -242,6 +243,20 @@ int cnf_solve_vcabm(cnf_handle* h, float t0, float t1, const float* u0, const fl
 int cnf_solve_tsit5(cnf_handle* h, float t0, float t1, const float* u0, const float* eps, const float* ys, int64_t B,
                     float abstol, float reltol, float dt_init, int maxiters, float* u1, cnf_solve_stats* stats,
                     float* dts_out, int32_t record_cap, void* stream);
+
+/* `loss(icnf, mode, xs, ps, st)` under an adaptive solver in ONE call (src/core/icnf.jl:628-649 over src/core/base_icnf.jl:134-172,
+ * 256-266): u0 = vcat(xs, 0), the solve (alg = CNF_ALG_VCABM, the reference's default: cnf_solve_vcabm; CNF_ALG_TSIT5:
+ * cnf_solve_tsit5), the inference epilogue and mean(-logp + l1 E + l2 n + l3 A) - the same kernels in the same order as
+ * cnf_assemble_u0 / cnf_solve_* / cnf_epilogue / cnf_loss_mean, so the same bits; what it saves is the host side of four calls,
+ * which at the reference's own batch sizes (2^10 samples, benchmark/benchmarks.jl) is a sixth of the call.
+ * x: nvars x B; lambdas: 3 doubles (host); loss: 1 float (device); sums4 (device, may be NULL): the four column sums;
+ * logp / regs (device, B and 3 B floats, may be NULL): the per-sample outputs of the epilogue; stats, dts_out, orders_out
+ * (host, may be NULL; orders_out is not written under CNF_ALG_TSIT5) as in cnf_solve_vcabm.  B >= 1.  Single process;
+ * synchronises `stream` (the solve does). */
+int cnf_loss_adaptive(cnf_handle* h, int alg, float t0, float t1, const float* x, const float* eps, const float* ys, int64_t B,
+                      float abstol, float reltol, float dt_init, int maxiters, const double* lambdas, float* loss, float* sums4,
+                      float* logp, float* regs, cnf_solve_stats* stats, float* dts_out, int32_t* orders_out, int32_t record_cap,
+                      void* stream);
 
 /* Which kernel family the handle resolved to (CNF_PATH_SIMT, CNF_PATH_MFMA or CNF_PATH_LAYERED). */
 int cnf_kernel_path(const cnf_handle* h);

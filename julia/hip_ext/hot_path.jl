@@ -189,6 +189,40 @@ function inference_sol(
 ) where {T <: AbstractFloat, INPLACE}
     f = prob.f.f
     fixed = fixed_step_args(icnf)
+    if f isa HIPODEFunc && fixed === nothing && is_std_normal(icnf.basedist) && (is_default_vcabm(icnf) || is_adaptive_tsit5(icnf)) &&
+       size(prob.u0, 2) > 0
+        # adaptive solver (the reference's default sol_kwargs): u0 assembly, the solve and the epilogue in ONE call - cnf_loss_adaptive
+        # also leaves mean(-logp + λ₁Ė + λ₂ṅ + λ₃Ȧ) in `lossv`; the reference's `loss` recomputes it from these outputs
+        t0, t1 = prob.tspan
+        xs = prob.u0[1:(icnf.nvariables), :]
+        B = size(xs, 2)
+        logp = similar(xs, B)
+        regs = similar(xs, B, 3)
+        lossv = similar(xs, 1)
+        h = cached_handle(icnf, mode, prob.p)
+        d_x = DeviceArg(xs)
+        d_e = DeviceArg(f.ϵ)
+        d_y = DeviceArg(conditions_of(f.nn))
+        d_l = DeviceArg(logp; out = true)
+        d_r = DeviceArg(regs; out = true)
+        d_v = DeviceArg(lossv; out = true)
+        kw = icnf.sol_kwargs
+        lambdas = Float64[icnf.λ₁, icnf.λ₂, icnf.λ₃]
+        stats = Ref(CnfSolveStats(0, 0, 0, 0))
+        GC.@preserve xs logp regs lossv lambdas f d_x d_e d_y d_l d_r d_v cnf_check(
+            ccall(
+                (:cnf_loss_adaptive, libcnf),
+                Cint,
+                (Ptr{Cvoid}, Cint, Cfloat, Cfloat, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}, Int64, Cfloat, Cfloat, Cfloat, Cint, Ptr{Float64}, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}, Ref{CnfSolveStats}, Ptr{Float32}, Ptr{Int32}, Int32, Ptr{Cvoid}),
+                h.ptr, is_default_vcabm(icnf) ? Cint(2) : Cint(1), Float32(t0), Float32(t1), d_x.ptr, d_e.ptr, d_y.ptr, B,
+                Float32(get(kw, :abstol, 1.0f-4)), Float32(get(kw, :reltol, 1.0f-4)), Float32(get(kw, :dt, 0.0f0)), solver_maxiters(icnf),
+                pointer(lambdas), d_v.ptr, C_NULL, d_l.ptr, d_r.ptr, stats, C_NULL, C_NULL, 0, current_stream(xs),
+            ),
+        )
+        finish!(d_l)
+        finish!(d_r)
+        return (logp, eachcol(regs))
+    end
     if !(f isa HIPODEFunc) || fixed === nothing || !is_std_normal(icnf.basedist)
         # the reference's own epilogue on the final state of `base_sol` (src/core/base_icnf.jl:158-172)
         n_aug = n_augments(icnf, mode)

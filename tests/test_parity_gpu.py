@@ -1198,6 +1198,34 @@ def test_jvp_mode_gradient_through_the_vjp_twin_agrees_with_its_own_layerwise_gr
         assert np.max(np.abs(a - b)) < 5e-5 * np.abs(b).max() + 1e-6
 
 
+@pytest.mark.parametrize("solver", ["vcabm", "tsit5"])
+@pytest.mark.parametrize("kw,B", [
+    (dict(nvars=1, naug=2, hidden=[16, 16], act=2, reg_z=True, reg_j=True, reg_aug=True), 1024),      # the reference's PkgBenchmark scenario
+    (dict(nvars=8, hidden=[64, 64, 64], mode=2), 777),                                                # TestMode: exact trace
+    (dict(nvars=5, ncond=3, hidden=[32, 48, 32, 16], act=2, reg_z=True), 300),                         # generic family, host-loop controller
+])
+def test_loss_under_an_adaptive_solver_in_one_library_call_is_the_four_calls(solver, kw, B, pkg, oracles):
+    """cnf_loss_adaptive (round 5): `loss` of an unsharded batch under VCABM / adaptive Tsit5 as one library call - the same kernels
+    in the same order as cnf_assemble_u0 + cnf_solve_* + cnf_epilogue + cnf_loss_mean, so the same bits, the same step record."""
+    o64, _ = oracles
+    spec = o64.make_spec(**kw)
+    p, xs, eps, ys = o64.synth_inputs(spec, B, 91, bias_scale=0.2)
+    icnf = make_icnf(pkg, spec, 1, 8, path=0, lambdas=(0.01, 0.01, 0.01))
+    icnf.sol_kwargs = dict(alg=pkg.VCABM() if solver == "vcabm" else pkg.Tsit5(), reltol=1e-4, abstol=1e-4)
+    mode = mode_of(pkg, spec)
+    args = (dev(xs),) + ((dev(ys),) if spec.ncond else ()) + (dev(p), {})
+    val = pkg.loss(icnf, mode, *args, eps=dev(eps))
+    st_one = dict(icnf.last_solve_stats)
+    logp, regs = pkg.inference(icnf, mode, *args, eps=dev(eps), _raw=True)
+    st_four = dict(icnf.last_solve_stats)
+    ref = pkg.loss_mean(icnf, mode, logp, regs)
+    assert icnf.adaptive and torch.equal(val, ref), (float(val), float(ref))
+    for k in ("naccept", "nreject", "nf", "dts", "alg_used", "controller"):
+        assert st_one[k] == st_four[k], k
+    if solver == "vcabm":
+        assert st_one["orders"] == st_four["orders"]
+
+
 PROBE_LOOP_SHAPES = [
     # several probes on shapes whose one-probe gradient runs on the cooperative / dealt reverse sweep
     (dict(nvars=32, hidden=[256, 256, 256], nprobes=3, reg_z=True, reg_j=True), (0.02, 0.03, 0.0), 40, 0, 2),
