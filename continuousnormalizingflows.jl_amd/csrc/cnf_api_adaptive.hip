@@ -316,11 +316,12 @@ int cnf_solve_vcabm(cnf_handle* h, float t0, float t1, const float* u0, const fl
     hipStream_t st = (hipStream_t)stream;
     const size_t n = (size_t)h->S * (size_t)B;
     const double ntot = (double)n;
-    double* res = h->vc.partial + vcabm_partial_doubles();   // device result slots
+    if (!h->vc.host_res) HIP_TRY(hipHostMalloc((void**)&h->vc.host_res, 8 * sizeof(double), hipHostMallocDefault));
+    double* res = h->vc.host_res;   // result slots in pinned host memory: the reduction kernels write them, the loop synchronises and reads
     double host[4];
     auto fetch = [&](int cnt) -> int {
-        HIP_TRY(hipMemcpyAsync(host, res, cnt * sizeof(double), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
+        for (int i = 0; i < cnt; ++i) host[i] = res[i];
         return CNF_OK;
     };
     double dt;
@@ -484,11 +485,12 @@ int cnf::api_solve_tsit5(cnf_handle* h, float t0, float t1, const float* u0, con
     const size_t slot = (size_t)h->S * (size_t)h->adp.B;
     float *ua = h->adp.buf, *ub = ua + slot, *f0 = ub + slot, *f1 = f0 + slot;
     HIP_TRY(hipMemcpyAsync(ua, u0, n * sizeof(float), hipMemcpyDeviceToDevice, st));
-    double* res = h->vc.partial + vcabm_partial_doubles();
+    if (!h->vc.host_res) HIP_TRY(hipHostMalloc((void**)&h->vc.host_res, 8 * sizeof(double), hipHostMallocDefault));
+    double* res = h->vc.host_res;   // pinned host memory, as in cnf_solve_vcabm
     double host[2];
     auto fetch = [&](int cnt) -> int {
-        HIP_TRY(hipMemcpyAsync(host, res, cnt * sizeof(double), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
+        for (int i = 0; i < cnt; ++i) host[i] = res[i];
         return CNF_OK;
     };
     int nf = 0, naccept = 0, nreject = 0;

@@ -109,6 +109,8 @@ struct HandleEmbedded {
 struct HandleVcabm {
     float* buf = nullptr;
     double* partial = nullptr;
+    double* host_res = nullptr;          // 8 doubles of pinned host memory: the reduction kernels of the library's own policy loops write their
+                                         // sums there, so the loop synchronises and reads instead of copying (a small copy costs 25 us)
     int64_t B = -1, cap = 0;             // columns of the solve in progress; columns the allocation holds
     int iu = 0, iun = 2, ifn0 = 3, ifn1 = 5, cur = 0;   // which vector holds u, u_new, f_n, f_{n+1}; live difference half
     int nhist = 0, k = 0;                // accepted steps since begin; order of the pending attempt (0 = none)
