@@ -729,7 +729,11 @@ hipError_t mfma_solve_vcabm(MfmaPlan* p, const float* packed_dev, const SolveArg
     hipError_t e = fill_aargs_scratch(q, scratch, ntiles, dts_cap, stats_dev, dts_dev, orders_dev, epoch, st);
     if (e != hipSuccess) return e;
     const int lds = p->lay.lds_total * (int)sizeof(float);
-    const long long cap = (long long)p->num_cus * (p->vcabm_per_cu > 0 ? p->vcabm_per_cu : 0);
+    // one workgroup per CU as long as the batch fits that way (fewer workgroups to sum over: 0.233 against 0.267 ms per solve at
+    // 16 384 samples); the second one the small-net instances allow only beyond (<= 32 768 samples: 0.27 ms against the host
+    // loop's 0.51, profiles/dc_per_cu_ab.py)
+    const long long cap1 = (long long)p->num_cus * (p->vcabm_per_cu > 0 ? 1 : 0);
+    const long long cap = ntiles <= cap1 * 4 ? cap1 : (long long)p->num_cus * (p->vcabm_per_cu > 0 ? p->vcabm_per_cu : 0);
     long long nblocks = ntiles < cap ? ntiles : cap;
     if (nblocks * 4 < ntiles) return hipErrorInvalidValue;
     return p->launch_vcabm(a, q, lds, (int)nblocks, st, nullptr);

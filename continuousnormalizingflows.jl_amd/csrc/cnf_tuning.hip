@@ -20,7 +20,7 @@ const Knob kKnobs[] = {
     {"CNF_PROBE_GRAD_TWIN", &cnf_tuning::probe_grad_twin, 1},
     {"CNF_LAYERED_LOSS_BY_SOLVE", &cnf_tuning::layered_loss_by_solve, 0},
     {"CNF_DEVICE_CONTROLLER", &cnf_tuning::device_controller, 1},
-    {"CNF_DC_PER_CU", &cnf_tuning::dc_per_cu, 1},
+    {"CNF_DC_PER_CU", &cnf_tuning::dc_per_cu, 2},
     {"CNF_MFMA_COOP", &cnf_tuning::mfma_coop, 0},
     {"CNF_MFMA_COOPX", &cnf_tuning::mfma_coopx, 1},
     {"CNF_MFMA_NT", &cnf_tuning::mfma_nt, 0},

@@ -2847,7 +2847,9 @@ def test_device_side_step_controller_is_the_host_loop(kw, B, tol, dt0, pkg, orac
     (dict(nvars=2, naug=3, ncond=2, hidden=[32, 32], act=2), 300, 1e-4, None),              # conditioned default-style net
     (dict(nvars=2, naug=3, ncond=2, hidden=[32, 32], act=2, mode=2), 64, 1e-5, None),       # ... TestMode
     (dict(nvars=2, hidden=[32, 32]), 6000, 1e-4, None),                                     # 375 tiles on 256 workgroups: one or two of the four waves own a tile
-    (dict(nvars=2, hidden=[32, 32]), 16384, 1e-4, None),                                    # a small net at the kernel's capacity (one workgroup per CU)
+    (dict(nvars=2, hidden=[32, 32]), 16384, 1e-4, None),                                    # a small net at the kernel's capacity at one workgroup per CU
+    (dict(nvars=2, hidden=[32, 32]), 32768, 1e-4, None),                                    # ... and at two (nets of <= 2 hidden tiles, round 5)
+    (dict(nvars=1, naug=2, hidden=[16, 16], act=2, reg_z=True, reg_j=True, reg_aug=True), 24001, 1e-4, None),   # default net, three of four waves own a tile
 ])
 def test_default_solver_on_the_device_is_the_host_policy(kw, B, tol, dt0, pkg, oracles, monkeypatch):
     """The reference's default solver VCABM in ONE launch (mfma_vcabm_kernel: predictor, corrector and order-raising passes per
