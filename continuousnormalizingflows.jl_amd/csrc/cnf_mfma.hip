@@ -49,6 +49,7 @@ struct MfmaPlan {
     int use_queue;
     int* queue_dev;     // one int per plan, zeroed on the stream before every launch
     float* rk_dev = nullptr;   // ring of the Runge-Kutta sums of cnf_coop_d2.hip's 20 .. 24-tile instances (KArgs::rk), allocated on first use
+    int pre = 0;        // the instance's hoisting level (2: the trace term as a dot with q = W_1 eps where |eps^T J| is not asked for)
     int q_extra = 0;    // extended cooperative plans of two-hidden-layer exact-trace flows: float offset of the Q image appended
                         // behind the layout (0 = none); per-wave plans carry theirs inside the layout (lay.qtr)
 
@@ -145,6 +146,7 @@ static MfmaPlan* mfma_plan_create_impl(const cnf_config& c, bool coop_only) {
         p->launch_vcabm = in.fn_vcabm;
         p->cfg = c;
         p->nthreads = in.nthreads;
+        p->pre = in.PRE;
         p->num_cus = 0;
         p->prio_mode = tuning().mfma_prio;
         p->use_queue = tuning().mfma_queue;
@@ -154,9 +156,12 @@ static MfmaPlan* mfma_plan_create_impl(const cnf_config& c, bool coop_only) {
                  engine == ENG_VJP ? "vjp" : "tan", HT, L, in.ZR, in.CR, in.ACT, KP, in.PRE, in.nthreads,
                  in.arith ? "bf16x6" : "f32");
         // whole fixed-step solves of this plan run on the hand-scheduled form of the same kernel (mfma_solve, cnf_mfma2.hip)
-        if (engine == ENG_VJP && KP == 1 && in.CR == 0 && !in.arith && tuning().solve2 != 0 && solve2_supported(HT, L, in.ZR, in.ACT)) {
+        if (engine == ENG_VJP && KP == 1 && in.CR == 0 && !in.arith) {
+            const bool s2 = tuning().solve2 != 0 && solve2_supported(HT, L, in.ZR, in.ACT);
+            const bool s2p = tuning().solve2_pair != 0 && solve2p_supported(HT, L, in.ZR, in.ACT, 0, 1);
             const size_t n = strlen(p->name);
-            snprintf(p->name + n, sizeof(p->name) - n, " | solves: mfma_solve2<nt=%d>", tuning().solve2 == 1 ? 256 : 512);
+            if (s2) snprintf(p->name + n, sizeof(p->name) - n, " | solves: mfma_solve2<nt=%d>%s", tuning().solve2 == 1 ? 256 : 512, s2p ? ", mfma_solve2p up to 2 tiles per CU" : "");
+            else if (s2p) snprintf(p->name + n, sizeof(p->name) - n, " | solves of up to 2 tiles per CU: mfma_solve2p");
         }
         return p;
     };
@@ -587,10 +592,16 @@ hipError_t mfma_solve(MfmaPlan* p, const float* packed_dev, const SolveArgs& s, 
     const long long ntiles = (s.B + 15) / 16;
     if (s.nsteps > 0 && !s.ckpt && !s.ckpt_k && !s.kfull && plan_takes_tile_split(mp, s.B))
         return coop_split_launch(p->HT, p->L, p->ZR, p->ACT, a, st);
-    // one-probe VJP solves without conditions: the hand-scheduled form of the same kernel (cnf_mfma2.hip), bit-identical results
-    if (p->ENGINE == ENG_VJP && p->KP == 1 && p->CR == 0 && p->arith == CNF_ARITH_F32 && s.nsteps > 0 && !s.kfull && !mp->use_queue &&
-        tuning().solve2 != 0 && solve2_supported(p->HT, p->L, p->ZR, p->ACT))
-        return solve2_launch(p->HT, p->L, p->ZR, p->ACT, tuning().solve2 == 1 ? 256 : 512, a, mp->num_cus, st);
+    // one-probe VJP solves without conditions: the hand-scheduled forms of the same kernel (cnf_mfma2.hip), bit-identical results
+    if (p->ENGINE == ENG_VJP && p->KP == 1 && p->CR == 0 && p->arith == CNF_ARITH_F32 && s.nsteps > 0 && !s.kfull && !mp->use_queue) {
+        // small batches of two-tile nets: two waves per tile (forward chain / pullback)
+        if (tuning().solve2_pair != 0 && solve2p_supported(p->HT, p->L, p->ZR, p->ACT, ntiles, mp->num_cus)) {
+            a.use_q = p->pre == 2;   // the plan's own arithmetic for the trace term
+            return solve2p_launch(p->HT, p->L, p->ZR, p->ACT, a, st);
+        }
+        if (tuning().solve2 != 0 && solve2_supported(p->HT, p->L, p->ZR, p->ACT))
+            return solve2_launch(p->HT, p->L, p->ZR, p->ACT, tuning().solve2 == 1 ? 256 : 512, a, mp->num_cus, st);
+    }
     const int wpb = p->nthreads / 64;
     long long want = ntiles;   // tile t runs on workgroup t % nblocks (cnf_mfma_kernel.h): small batches spread over the CUs
     (void)wpb;

@@ -34,6 +34,8 @@ struct KArgs {
     const float* tgrid; // extended cooperative kernel: nsteps + 1 step times on the device (non-uniform grid) or null
     int KH;             // extended cooperative kernel: 16-row tiles the widest hidden layer really fills (<= the instance's HT; 0: all)
     float* rk;          // cnf_coop_d2.hip, 20 .. 24 hidden tiles: per-workgroup ring of the Runge-Kutta running sums (plan-owned) or null
+    int use_q;          // mfma_solve2p_kernel: <eps^T J, eps> as a dot with q = W_1[:,0:D] eps where |eps^T J| is not asked for (the plan's
+                        // instance hoists q: PRE = 2); 0: through the last product, as the PRE <= 1 instances do
 };
 
 // Device-side step controller (mfma_adaptive_kernel): the whole adaptive Tsit5 solve of a batch that fits the chip's wave
@@ -109,6 +111,9 @@ size_t coopd_rk_floats(int H, int D, int L, int ACT, int exact, int num_cus);   
 // hand-scheduled form of the per-wave solve kernel for one-probe VJP flows without conditions (cnf_mfma2.hip)
 bool solve2_supported(int HT, int L, int ZR, int ACT);
 hipError_t solve2_launch(int HT, int L, int ZR, int ACT, int nthreads, const KArgs& a, int num_cus, hipStream_t st);
+// ... and its two-waves-per-tile form for small batches (mfma_solve2p_kernel)
+bool solve2p_supported(int HT, int L, int ZR, int ACT, long long ntiles, int num_cus);
+hipError_t solve2p_launch(int HT, int L, int ZR, int ACT, const KArgs& a, hipStream_t st);
 // the same kernel with ONE sample tile per workgroup and the images in LDS: the tile-split form for small batches
 bool coop_split_supported(int HT, int L, int ZR, int ACT);
 hipError_t coop_split_launch(int HT, int L, int ZR, int ACT, const KArgs& a, hipStream_t st);

@@ -11,6 +11,7 @@ struct Knob { const char* env; int32_t cnf_tuning::*field; int32_t dflt; };
 const Knob kKnobs[] = {
     {"CNF_TILE_SPLIT", &cnf_tuning::tile_split, 1},
     {"CNF_SOLVE2", &cnf_tuning::solve2, 2},
+    {"CNF_SOLVE2_PAIR", &cnf_tuning::solve2_pair, 1},
     {"CNF_COOPD", &cnf_tuning::coopd, 1},
     {"CNF_COOPD_GRAD", &cnf_tuning::coopd_grad, 1},
     {"CNF_COOP_GRAD", &cnf_tuning::coop_grad, 1},

@@ -13,7 +13,7 @@ for name, kw, B in (("d32_3x256_rk4", dict(nvars=32, hidden=[256, 256, 256], reg
                     ("nv16", dict(nvars=16, naug=17, hidden=[136, 136], act=2, reg_z=True, reg_j=True, reg_aug=True), 32768),
                     ("nv20", dict(nvars=20, naug=21, hidden=[168, 168], act=2, reg_z=True, reg_j=True, reg_aug=True), 32768)):
     res = {}
-    for tag, K, env in (("k1", 1, "1"), ("k4_probe_by_probe", 4, "1"), ("k4_layerwise", 4, "0")):
+    for tag, K, env in (("k1", 1, "1"), ("k4_probe_by_probe", 4, "2"), ("k4_layerwise", 4, "0")):   # 2: the loop on three hidden layers too
         os.environ["CNF_PROBE_GRAD_TWIN"] = env; pkg.reload_tuning()
         spec = o64.make_spec(nprobes=K, **kw)
         p, xs, eps, _ = o64.synth_inputs(spec, B, 3, bias_scale=0.1)

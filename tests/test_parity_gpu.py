@@ -543,6 +543,7 @@ def test_hand_scheduled_solve_is_bit_identical_to_the_per_wave_kernel(alg, nstep
     p, xs, eps, ys = o64.synth_inputs(spec, B, 41, bias_scale=0.2)
     lam = (0.02, 0.03, 0.01)
     out = {}
+    setsw(pkg, monkeypatch, "CNF_SOLVE2_PAIR", "0")                      # (the two-waves-per-tile form has its own test below)
     for tag, sw in (("old", "0"), ("one", "1"), ("two", "2")):
         setsw(pkg, monkeypatch, "CNF_SOLVE2", sw)
         icnf = make_icnf(pkg, spec, alg, nsteps, path=2, lambdas=lam)
@@ -558,6 +559,49 @@ def test_hand_scheduled_solve_is_bit_identical_to_the_per_wave_kernel(alg, nstep
         for a_, b_ in zip(out[tag][1], out["old"][1]):
             assert torch.equal(a_, b_), tag
         assert float(out[tag][3]) == float(out["old"][3]) and torch.equal(out[tag][4], out["old"][4]) and torch.equal(out[tag][5], out["old"][5]), tag
+
+
+@pytest.mark.parametrize("alg,nsteps,kw,B", [
+    (1, 6, dict(nvars=2, hidden=[32, 32]), 1024),                                                  # cfg1's flow at its own batch
+    (0, 5, dict(nvars=3, naug=1, hidden=[32, 32], reg_z=True, reg_j=True, reg_aug=True), 1000),    # regularised, augmented, ragged tile
+    (1, 3, dict(nvars=8, hidden=[32, 32], autonomous=True), 8192),                                 # D = 8 (the zero-padded layout); two tiles per CU: the largest batch it takes
+    (1, 4, dict(nvars=2, hidden=[32, 32], reg_z=True), 7),                                         # less than a tile
+    (1, 4, dict(nvars=3, naug=4, hidden=[32, 32], act=2, reg_z=True, reg_j=True, reg_aug=True), 2048),   # softplus: the default architecture at nvariables = 3
+])
+def test_two_waves_per_tile_solve_is_bit_identical_to_the_per_wave_kernel(alg, nsteps, kw, B, pkg, oracles, monkeypatch):
+    """mfma_solve2p_kernel (round 5): small batches of two-tile nets run the forward chain and the pullback of a tile on two waves, one
+    stage apart - the same products and expressions as mfma_solve2_kernel / mfma_solve_kernel, so the same bits for the outputs, the
+    final state and (through the checkpoints its forward wave writes) the parameter gradient; beyond two tiles per CU the per-wave
+    form takes over."""
+    o64, oc = oracles
+    spec = o64.make_spec(**kw)
+    p, xs, eps, ys = o64.synth_inputs(spec, B, 43, bias_scale=0.2)
+    lam = (0.02, 0.03, 0.01)
+    out = {}
+    for tag, sw in (("pair", "1"), ("one", "0")):
+        setsw(pkg, monkeypatch, "CNF_SOLVE2_PAIR", sw)
+        icnf = make_icnf(pkg, spec, alg, nsteps, path=2, lambdas=lam)
+        mode = mode_of(pkg, spec)
+        logp, regs, u1 = run_inference(pkg, icnf, spec, p, xs, eps, ys, return_state=True)
+        val, g, gx = pkg.loss_and_gradient(icnf, mode, dev(xs), dev(p), {}, eps=dev(eps), wrt_x=True)
+        assert ("mfma_solve2p" in icnf.kernel_name(mode)) == (sw == "1"), icnf.kernel_name(mode)
+        out[tag] = (logp, regs, u1, val, g, gx)
+    ref = oc.inference_fixed(spec, p, xs, 0.0, 1.0, nsteps, alg, eps, ys, nthreads=8)
+    assert np.max(np.abs(out["pair"][0].cpu().numpy() - ref[0])) < TOL_SOLVE
+    assert torch.equal(out["pair"][0], out["one"][0]) and torch.equal(out["pair"][2], out["one"][2])
+    for a_, b_ in zip(out["pair"][1], out["one"][1]):
+        assert torch.equal(a_, b_)
+    assert float(out["pair"][3]) == float(out["one"][3]) and torch.equal(out["pair"][4], out["one"][4]) and torch.equal(out["pair"][5], out["one"][5])
+    # a batch of more than two tiles per CU stays on the per-wave form and still agrees with it
+    if B == 8192:
+        setsw(pkg, monkeypatch, "CNF_SOLVE2_PAIR", "1")
+        p2, xs2, eps2, ys2 = o64.synth_inputs(spec, 8192 + 16, 44, bias_scale=0.2)
+        icnf = make_icnf(pkg, spec, alg, nsteps, path=2, lambdas=lam)
+        a1 = run_inference(pkg, icnf, spec, p2, xs2, eps2, ys2)[0]
+        setsw(pkg, monkeypatch, "CNF_SOLVE2_PAIR", "0")
+        icnf = make_icnf(pkg, spec, alg, nsteps, path=2, lambdas=lam)
+        a0 = run_inference(pkg, icnf, spec, p2, xs2, eps2, ys2)[0]
+        assert torch.equal(a1, a0)
 
 
 def make_icnf_bf16x6(pkg, spec, alg, nsteps):
@@ -1195,6 +1239,31 @@ def test_jvp_mode_gradient_through_the_vjp_twin_agrees_with_its_own_layerwise_gr
     assert abs(out["twin"][0] - out["own"][0]) < 2e-5 * (1 + abs(out["own"][0]))
     for k in (1, 2):
         a, b = out["twin"][k], out["own"][k]
+        assert np.max(np.abs(a - b)) < 5e-5 * np.abs(b).max() + 1e-6
+
+
+def test_several_probes_on_the_frozen_grid_of_an_adaptive_solve(pkg, oracles, monkeypatch):
+    """The training step under the reference's default sol_kwargs with K = 2 probes on the default architecture: the adaptive solve runs
+    with both probes (their trace estimates enter the error norm), its accepted steps are frozen, and the gradient on that grid is the
+    two one-probe dealt sweeps (cnf_grad_path_for(.., on_grid = 1) = 3) - against the layer-wise gradient on the same grid."""
+    o64, _ = oracles
+    spec = o64.make_spec(nvars=16, naug=17, hidden=[136, 136], act=2, nprobes=2, reg_z=True, reg_j=True, reg_aug=True)
+    B, lam = 4100, (0.01, 0.01, 0.01)
+    p, xs, eps, _ = o64.synth_inputs(spec, B, 12, bias_scale=0.2)
+    out = {}
+    for tag, env in (("loop", "1"), ("own", "0")):
+        setsw(pkg, monkeypatch, "CNF_PROBE_GRAD_TWIN", env)
+        icnf = make_icnf(pkg, spec, 1, 4, path=0, lambdas=lam)
+        icnf.sol_kwargs = dict(alg=pkg.Tsit5(), reltol=1e-3, abstol=1e-3)
+        mode = pkg.TrainMode(True)
+        h = icnf._handle(mode)
+        assert h.lib.cnf_grad_path_for(h.ptr, B, 1, 1) == (3 if tag == "loop" else 2)
+        val, g, gx = pkg.loss_and_gradient(icnf, mode, dev(xs), dev(p), {}, eps=dev(eps), wrt_x=True)
+        out[tag] = (float(val), g.cpu().numpy().astype(np.float64), gx.cpu().numpy().astype(np.float64), list(icnf.last_solve_stats["tgrid"]))
+    assert out["loop"][3] == out["own"][3] and len(out["loop"][3]) >= 3          # the same frozen grid
+    assert abs(out["loop"][0] - out["own"][0]) < 2e-5 * (1 + abs(out["own"][0]))
+    for k in (1, 2):
+        a, b = out["loop"][k], out["own"][k]
         assert np.max(np.abs(a - b)) < 5e-5 * np.abs(b).max() + 1e-6
 
 
