@@ -1238,9 +1238,11 @@ inline hipError_t launch_adapt_inst(const KArgs& a, const AArgs& q, int lds_byte
 // evaluation (f at t0, Hairer's Euler point, the predictor, the corrected state).  256-thread workgroups: one wave per SIMD,
 // the whole register file (the difference table alone is 13 x (ZR + 3) registers).
 template <int HT, int L, int ZR, int CR, int ACT, int ENGINE, int KP, int PRE, int NTHREADS, int ARITH = 0>
-// (nets of at most two hidden tiles keep the whole difference table within 256 registers: their instances may share a SIMD, which
-// doubles the batch the one-launch solve takes - 32 768 samples at two workgroups per CU, CNF_DC_PER_CU)
-__global__ void __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(HT <= 2 ? 2 : 1, HT <= 2 ? 2 : (NTHREADS + 255) / 256)))
+// (the exact-shape instances of nets of at most two hidden tiles - D <= 4, no conditions: four state rows per lane - keep the whole
+// difference table within 256 registers: they may share a SIMD, which doubles the batch the one-launch solve takes - 32 768 samples
+// at two workgroups per CU, CNF_DC_PER_CU.  The zero-padded instances (16 state rows) spill 110 - 130 registers under that limit.)
+__global__ void __launch_bounds__(NTHREADS)
+    __attribute__((amdgpu_waves_per_eu((HT <= 2 && ZR == 1 && CR == 0) ? 2 : 1, (HT <= 2 && ZR == 1 && CR == 0) ? 2 : (NTHREADS + 255) / 256)))
 mfma_vcabm_kernel(KArgs a, AArgs q) {
     constexpr MfmaLayout LAY(HT, L, ZR, CR, ENGINE == ENG_VJP, ARITH);
     constexpr int NR = ZR + 3;        // rows of the state a lane holds: ZR of z, then dlogp, E, n

@@ -127,7 +127,7 @@ typedef struct cnf_tuning {
     int32_t probe_grad_twin;       /* CNF_PROBE_GRAD_TWIN, default 1: K > 1 probes on two hidden layers whose own gradient is layer-wise train probe by probe on the one-probe cooperative sweep; 2: three hidden layers too (slower there); 0: never */
     int32_t layered_loss_by_solve; /* CNF_LAYERED_LOSS_BY_SOLVE, default 0: 1: the layer-wise gradient takes its loss from a separate solve instead of accumulating it in the sweep */
     int32_t device_controller;     /* CNF_DEVICE_CONTROLLER, default 1: one-launch adaptive Tsit5 / VCABM with the step controller on the device where the batch fits; 0: host loop */
-    int32_t dc_per_cu;             /* CNF_DC_PER_CU, default 2: most workgroups per CU of the one-launch adaptive kernels (the occupancy query bounds it: 2 only for the VCABM instances of nets of <= 2 hidden tiles, and only for batches that do not fit one per CU) */
+    int32_t dc_per_cu;             /* CNF_DC_PER_CU, default 2: most workgroups per CU of the one-launch adaptive kernels (the occupancy query bounds it: 2 only for the exact-shape VCABM instances of nets of <= 2 hidden tiles with D <= 4, and only for batches that do not fit one per CU) */
     int32_t mfma_coop;             /* CNF_MFMA_COOP, default 0: 1: cnf_create prefers the cooperative kernel where a per-wave instance also fits (tests) */
     int32_t mfma_coopx;            /* CNF_MFMA_COOPX, default 1: extended cooperative kernel (csrc/cnf_coop_x.hip); 0 off */
     int32_t mfma_nt;               /* CNF_MFMA_NT, default 0: threads per workgroup of the per-wave solve kernel (0: the instance's own) */
