@@ -2948,6 +2948,35 @@ def test_default_solver_on_the_device_is_the_host_policy(kw, B, tol, dt0, pkg, o
         assert max(d["orders"]) >= 6, d["orders"]
 
 
+@pytest.mark.parametrize("solver", ["tsit5", "vcabm"])
+def test_one_launch_solves_longer_than_the_pinned_record(solver, pkg, oracles, monkeypatch):
+    """The one-launch kernels write their status words and the first 120 accepted steps into pinned host memory (round 5); a longer
+    solve's record comes from the device arrays.  A stiff small flow at 1e-6 takes 140 (Tsit5) / 420 (VCABM) steps: the record is
+    complete, the steps add up to the span, and the solve is the library's host loop's to the first steps' last digit."""
+    o64, _ = oracles
+    spec = o64.make_spec(nvars=2, hidden=[32, 32], autonomous=True)      # (autonomous: the two Tsit5 paths then differ in summation order only)
+    p, xs, eps, ys = o64.synth_inputs(spec, 64, 5, bias_scale=0.3)
+    p = (p * 8.0).astype(np.float32)
+    icnf = make_icnf(pkg, spec, 1, 1)
+    icnf.sol_kwargs = dict(alg=pkg.Tsit5() if solver == "tsit5" else pkg.VCABM(), reltol=1e-6, abstol=1e-6)
+    res = {}
+    for ctl in ("1", "0"):
+        setsw(pkg, monkeypatch, "CNF_DEVICE_CONTROLLER", ctl)
+        logp, regs, u1 = run_inference(pkg, icnf, spec, p, xs, eps, ys, return_state=True)
+        res[ctl] = (logp, u1, dict(icnf.last_solve_stats))
+    d, h = res["1"][2], res["0"][2]
+    assert d["controller"] == "device" and h["controller"] == "host"
+    assert d["naccept"] > 130 and len(d["dts"]) == d["naccept"], (d["naccept"], len(d["dts"]))
+    assert abs(sum(d["dts"]) - 1.0) < 1e-4
+    if solver == "vcabm":
+        assert len(d["orders"]) == d["naccept"] and 1 <= min(d["orders"]) and max(d["orders"]) <= 12
+        assert d["orders"][:40] == h["orders"][:40]
+    assert np.allclose(d["dts"][:40], h["dts"][:40], rtol=1e-4), (d["dts"][:40], h["dts"][:40])
+    assert abs(d["naccept"] - h["naccept"]) <= 0.05 * h["naccept"], (d["naccept"], h["naccept"])
+    scale = max(1.0, float(res["0"][0].abs().max()))
+    assert float((res["1"][0] - res["0"][0]).abs().max()) < 1e-3 * scale
+
+
 def test_device_side_step_controller_reports_failures(pkg, oracles):
     """The one-launch adaptive solve fails as loudly as the host loop: maxiters, a non-finite error estimate."""
     o64, _ = oracles
