@@ -417,8 +417,9 @@ int cnf::api_ensure_adaptive_buf(cnf_handle* h, int64_t B) {
 extern "C++" {
 int cnf::api_solve_tsit5(cnf_handle* h, float t0, float t1, const float* u0, const float* eps, const float* ys, int64_t B,
                          float abstol, float reltol, float dt_init, int maxiters, float* u1, cnf_solve_stats* stats,
-                         std::vector<double>* steps, void* stream) {
+                         std::vector<double>* steps, void* stream, TsitCkpt* ck) {
     if (stats) *stats = cnf_solve_stats{};
+    if (ck) ck->ok = false;
     int rc = api_check_call(h, eps, ys, B, "cnf_solve_tsit5");
     if (rc) return rc;
     if (!(abstol >= 0.f) || !(reltol >= 0.f) || (abstol == 0.f && reltol == 0.f))
@@ -448,11 +449,12 @@ int cnf::api_solve_tsit5(cnf_handle* h, float t0, float t1, const float* u0, con
         SolveArgs a{};
         a.u0 = u0; a.eps = eps; a.ys = ys; a.B = B; a.nsteps = 1; a.alg = CNF_ALG_TSIT5; a.t0 = t0; a.t1 = t1;
         a.u_out = u1; a.nvars = h->cfg.nvars; a.reg_aug = 0;
+        if (ck && ck->cap > 0) { a.ckpt = ck->ckpt; a.ckpt_k = ck->ckpt_k; }
         int* stats_dev = nullptr;
         float* dts_dev = nullptr;
         if (!h->adp.host_rec) HIP_TRY(hipHostMalloc((void**)&h->adp.host_rec, (8 + 2 * kHostRec) * sizeof(int), hipHostMallocDefault));
         const hipError_t le = mfma_solve_adaptive(h->plan, h->par.packed_dev, a, abstol, reltol, dt_init, maxiters, h->adp.dc_buf, &h->adp.dc_epoch, dts_cap, &stats_dev, &dts_dev,
-                                                  h->adp.host_rec, st);
+                                                  h->adp.host_rec, ck ? ck->cap : 0, st);
         if (le != hipSuccess) {
             (void)hipGetLastError();   // not sticky: nothing was launched
             return fail(CNF_ERR_HIP, std::string("cnf_solve_tsit5: launch of the device-controlled solve failed: ") + hipGetErrorString(le));
@@ -465,6 +467,7 @@ int cnf::api_solve_tsit5(cnf_handle* h, float t0, float t1, const float* u0, con
         if (host[3] == 2) return fail(CNF_ERR_INVALID, "cnf_solve_tsit5: maxiters reached");
         if (host[3] == 3) return fail(CNF_ERR_INVALID, "cnf_solve_tsit5: non-finite state or dynamics at t0 (no initial step)");
         if (host[3] == 4 || host[5] != 0) return fail(CNF_ERR_HIP, "cnf_solve_tsit5: the grid-wide sum of the one-launch solve timed out (workgroups not all resident); CNF_DEVICE_CONTROLLER=0 selects the host loop");
+        if (ck) ck->ok = ck->cap > 0 && host[6] == 1;
         if (steps) {
             const int na = host[0] < dts_cap ? host[0] : dts_cap;
             std::vector<float> all((size_t)na);

@@ -107,9 +107,30 @@ int cnf_grad_path_for(const cnf_handle* h, int64_t B, int alg, int on_grid) {
 
 }  // extern "C"
 
+// Layout of the fused per-wave gradient's workspace (cnf_handle::grad.ws) for `steps` steps: z checkpoints (steps + 1 slots), stage
+// derivatives (steps x stages slots), logp + regs (4 B), the gradient slabs, the ping-pong states of a grid's step-by-step forward
+// pass, the unit probes of TestMode.
+struct FusedWs { size_t ckpt_z_floats, ckpt_k_floats, slab_floats, state_floats, unit_floats, need; };
+static FusedWs fused_ws(cnf_handle* h, int alg, int steps, int64_t B, bool on_grid) {
+    FusedWs W{};
+    const size_t ntiles = (size_t)((B + 15) / 16);
+    const size_t zslot = ntiles * 64 * (size_t)mfma_plan_zr(h->plan);
+    const int nstages = alg == CNF_ALG_RK4 ? 4 : 6;
+    W.ckpt_z_floats = (size_t)(steps + 1) * zslot;
+    W.ckpt_k_floats = (size_t)steps * nstages * zslot;
+    W.slab_floats = grad_slab_floats(api_grad_cfg(h), h->num_cus);
+    W.state_floats = on_grid ? 2 * (size_t)h->S * (size_t)B : 0;
+    W.unit_floats = h->cfg.mode == CNF_MODE_EXACT ? (size_t)h->D * (size_t)h->D * (size_t)B : 0;
+    W.need = (W.ckpt_z_floats + W.ckpt_k_floats + 4 * (size_t)B + W.slab_floats + W.state_floats + W.unit_floats) * sizeof(float);
+    return W;
+}
+
+// Checkpoints the adaptive solve that found the grid has already written (api_solve_tsit5's TsitCkpt): arrays laid out for `cap`
+// steps at the head of the handle's gradient workspace (fused_ws below), and the solve's final state for the loss terms.
+struct PreparedCkpt { int cap; const float* u_final; };
 static int loss_grad_impl(cnf_handle* h, const char* who, int alg, int nsteps, float t0, float t1, const float* tgrid,
                           const float* x, const float* eps, const float* ys, int64_t B, const float* lambdas,
-                          float* grad, float* grad_x, float* sums4, void* stream);
+                          float* grad, float* grad_x, float* sums4, void* stream, const PreparedCkpt* pc = nullptr);
 
 // rows p D .. p D + D - 1 of every column of the (K D) x B probe array: probe p as a D x B array
 __global__ void probe_slice_kernel(const float* __restrict__ eps, int K, int D, int p, long long B, float* __restrict__ out) {
@@ -169,7 +190,7 @@ static int loss_grad_probe_loop(cnf_handle* h, cnf_handle* one, int K, const cha
 // grid (tgrid: host, nsteps + 1 times; t0 / t1 ignored).  The same three gradient implementations serve both.
 static int loss_grad_impl(cnf_handle* h, const char* who, int alg, int nsteps, float t0, float t1, const float* tgrid,
                           const float* x, const float* eps, const float* ys, int64_t B, const float* lambdas,
-                          float* grad, float* grad_x, float* sums4, void* stream) {
+                          float* grad, float* grad_x, float* sums4, void* stream, const PreparedCkpt* pc) {
     int rc = api_check_call(h, eps, ys, B, who);
     if (rc) return rc;
     if (alg == CNF_ALG_RK4 || alg == CNF_ALG_TSIT5) {
@@ -288,28 +309,30 @@ static int loss_grad_impl(cnf_handle* h, const char* who, int alg, int nsteps, f
     const long long ntiles = (B + 15) / 16;
     const int ckpt_zr = mfma_plan_zr(h->plan);
     const int nstages = alg == CNF_ALG_RK4 ? 4 : 6;
-    const size_t ckpt_z_floats = (size_t)(nsteps + 1) * (size_t)ntiles * 64 * (size_t)ckpt_zr;
-    const size_t ckpt_k_floats = (size_t)nsteps * nstages * (size_t)ntiles * 64 * (size_t)ckpt_zr;
-    const size_t ckpt_floats = ckpt_z_floats + ckpt_k_floats;
     const cnf_config gc = api_grad_cfg(h);
     const bool exact = h->cfg.mode == CNF_MODE_EXACT;
-    const size_t slab_floats = grad_slab_floats(gc, h->num_cus);
-    const size_t state_floats = tgrid ? 2 * (size_t)h->S * (size_t)B : 0;   // ping-pong states of the step-by-step forward pass
-    const size_t unit_floats = exact ? (size_t)h->D * (size_t)h->D * (size_t)B : 0;   // the D unit probes of every column
-    const size_t need = (ckpt_floats + 4 * (size_t)B + slab_floats + state_floats + unit_floats) * sizeof(float);
-    if (need > h->grad.ws_bytes) {
+    // (checkpoints an adaptive solve has written sit in arrays laid out for pc->cap steps, of which the first nsteps are filled)
+    const FusedWs W = fused_ws(h, alg, pc ? pc->cap : nsteps, B, tgrid != nullptr);
+    if (W.need > h->grad.ws_bytes) {
+        if (pc) return fail(CNF_ERR_INVALID, w + ": prepared checkpoints without their workspace");
         if (h->grad.ws) HIP_TRY(hipFree(h->grad.ws));
         h->grad.ws = nullptr; h->grad.ws_bytes = 0;
-        HIP_TRY(hipMalloc((void**)&h->grad.ws, need));
-        h->grad.ws_bytes = need;
+        HIP_TRY(hipMalloc((void**)&h->grad.ws, W.need));
+        h->grad.ws_bytes = W.need;
     }
+    const size_t slab_floats = W.slab_floats, state_floats = W.state_floats, unit_floats = W.unit_floats;
     float* ckpt = h->grad.ws;
-    float* ckpt_k = ckpt + ckpt_z_floats;
-    float* logp = ckpt + ckpt_floats;
+    float* ckpt_k = ckpt + W.ckpt_z_floats;
+    float* logp = ckpt + W.ckpt_z_floats + W.ckpt_k_floats;
     float* regs = logp + B;
     float* slab = regs + 3 * (size_t)B;
+    (void)unit_floats;
     const int reg_aug = (!exact && h->cfg.reg_aug && h->cfg.naug > 0) ? 1 : 0;
-    if (!tgrid) {
+    if (pc) {
+        // the solve that found the grid has left z_n and the stage derivatives of its accepted steps in ckpt / ckpt_k: no forward
+        // pass; the loss terms are those of its final state
+        HIP_TRY(epilogue(pc->u_final, h->cfg.nvars, h->D, reg_aug, B, logp, regs, st));
+    } else if (!tgrid) {
         SolveArgs a{};
         a.x = x; a.eps = eps; a.ys = ys; a.B = B; a.nsteps = nsteps; a.alg = alg; a.t0 = t0; a.t1 = t1;
         a.logp = logp; a.regs = regs; a.nvars = h->cfg.nvars; a.reg_aug = reg_aug; a.ckpt = ckpt; a.ckpt_k = ckpt_k;
@@ -378,25 +401,50 @@ int cnf_loss_grad_adaptive(cnf_handle* h, float t0, float t1, const float* x, co
     if (B == 0) {   // nothing to step over: the fixed entry zeroes grad / sums4
         return loss_grad_impl(h, "cnf_loss_grad_adaptive", CNF_ALG_TSIT5, 1, t0, t1, nullptr, x, eps, ys, B, lambdas, grad, grad_x, sums4, stream);
     }
+    TsitCkpt ck{};
+    PreparedCkpt pc{};
     {
         DeviceGuard g(h->cfg.device_id);
         rc = api_ensure_adaptive_buf(h, B);
         if (rc) return rc;
         const size_t slot = (size_t)h->S * (size_t)h->adp.B;
         float* u = h->adp.buf + 4 * slot;
+        // Where the gradient on the frozen grid is the fused per-wave sweep of this very handle, the solve that finds the grid also
+        // writes the sweep's checkpoints (z_n and the stage derivatives of every accepted step: the one-launch kernel has them in
+        // registers) - the gradient then needs no forward pass of its own.  Up to kAdaptiveCkptSteps steps; a longer solve, a batch
+        // beyond the one-launch kernel or CNF_ADAPTIVE_CKPT=0 take the step-by-step forward pass of loss_grad_impl.
+        constexpr int kAdaptiveCkptSteps = 32;
+        const GradServe gs = grad_serve(h, B, CNF_ALG_TSIT5, true);
+        const GradRoute route = api_grad_route(h, B, CNF_ALG_TSIT5, true);
+        if (gs.srv == h && gs.nloop == 1 && route.path == 1 && !route.slab && tuning().adaptive_ckpt != 0 && h->path == CNF_PATH_MFMA && h->plan) {
+            if (h->num_cus == 0) {
+                hipDeviceProp_t prop;
+                HIP_TRY(hipGetDeviceProperties(&prop, h->cfg.device_id));
+                h->num_cus = prop.multiProcessorCount;
+            }
+            const FusedWs W = fused_ws(h, CNF_ALG_TSIT5, kAdaptiveCkptSteps, B, true);
+            if (W.need > h->grad.ws_bytes) {
+                if (h->grad.ws) HIP_TRY(hipFree(h->grad.ws));
+                h->grad.ws = nullptr; h->grad.ws_bytes = 0;
+                HIP_TRY(hipMalloc((void**)&h->grad.ws, W.need));
+                h->grad.ws_bytes = W.need;
+            }
+            ck.ckpt = h->grad.ws; ck.ckpt_k = h->grad.ws + W.ckpt_z_floats; ck.cap = kAdaptiveCkptSteps;
+        }
         HIP_TRY(assemble_u0(x, h->cfg.nvars, h->S, B, u, (hipStream_t)stream));
         std::vector<double> steps;
-        rc = api_solve_tsit5(h, t0, t1, u, eps, ys, B, abstol, reltol, dt_init, maxiters, u + slot, stats, &steps, stream);
+        rc = api_solve_tsit5(h, t0, t1, u, eps, ys, B, abstol, reltol, dt_init, maxiters, u + slot, stats, &steps, stream, &ck);
         if (rc) return rc;
         double t = t0;
         grid.push_back(t0);
         for (double d : steps) { t += d; grid.push_back((float)t); }
         grid.back() = t1;
+        if (ck.ok && (int)steps.size() <= ck.cap) { pc.cap = ck.cap; pc.u_final = u + slot; }
     }
     if (tgrid_out)
         for (size_t i = 0; i < grid.size() && (int64_t)i < grid_cap; ++i) tgrid_out[i] = grid[i];
     return loss_grad_impl(h, "cnf_loss_grad_adaptive", CNF_ALG_TSIT5, (int)grid.size() - 1, 0.f, 0.f, grid.data(), x, eps, ys, B,
-                          lambdas, grad, grad_x, sums4, stream);
+                          lambdas, grad, grad_x, sums4, stream, pc.cap > 0 ? &pc : nullptr);
 }
 
 }  // extern "C"

@@ -181,8 +181,12 @@ struct GradRoute {
 GradRoute api_grad_route(const cnf_handle* h, int64_t B, int alg, bool on_grid);
 // cnf_api_adaptive.hip
 int api_ensure_adaptive_buf(cnf_handle* h, int64_t B);
+// `ck` (may be null): checkpoint arrays the one-launch solve fills for its accepted steps - z_n per step (cap + 1 slots), the six stage
+// derivatives per step (6 cap slots), each slot [tile][lane][ZR of the plan] - so that the frozen-grid gradient needs no forward pass
+// of its own; ok = the solve ran in one launch and took at most `cap` steps (otherwise the arrays are not to be used)
+struct TsitCkpt { float* ckpt; float* ckpt_k; int cap; bool ok; };
 int api_solve_tsit5(cnf_handle* h, float t0, float t1, const float* u0, const float* eps, const float* ys, int64_t B,
                     float abstol, float reltol, float dt_init, int maxiters, float* u1, cnf_solve_stats* stats,
-                    std::vector<double>* steps, void* stream);
+                    std::vector<double>* steps, void* stream, TsitCkpt* ck = nullptr);
 
 }  // namespace cnf

@@ -98,7 +98,8 @@ constexpr int kHostRec = 120;   // accepted steps the one-launch solves also rec
 int64_t mfma_adaptive_capacity(MfmaPlan* p);
 size_t mfma_adaptive_scratch_bytes(int64_t B, int dts_cap);
 hipError_t mfma_solve_adaptive(MfmaPlan* p, const float* packed_dev, const SolveArgs& s, float abstol, float reltol, float dt_init,
-                               int maxiters, void* scratch, unsigned* epoch, int dts_cap, int** stats_dev, float** dts_dev, int* host_rec, hipStream_t st);
+                               int maxiters, void* scratch, unsigned* epoch, int dts_cap, int** stats_dev, float** dts_dev, int* host_rec, int ckpt_cap,
+                               hipStream_t st);   // s.ckpt / s.ckpt_k with ckpt_cap > 0: the accepted steps' checkpoints (host_rec[6] = 1: complete)
 // the default solver VCABM with its passes and its step / order policy on the device (mfma_vcabm_kernel)
 int64_t mfma_vcabm_capacity(MfmaPlan* p);
 hipError_t mfma_solve_vcabm(MfmaPlan* p, const float* packed_dev, const SolveArgs& s, float abstol, float reltol, float dt_init,

@@ -645,6 +645,7 @@ size_t mfma_adaptive_scratch_bytes(int64_t B, int dts_cap) {
 static void fill_kargs_adaptive(const MfmaPlan* p, const float* packed_dev, const SolveArgs& s, KArgs& a) {
     a.packed = packed_dev;
     a.u0 = s.u0; a.eps = s.eps; a.ys = s.ys; a.u_out = s.u_out;
+    a.ckpt = s.ckpt; a.ckpt_k = s.ckpt_k;   // adaptive Tsit5 only: the accepted steps' checkpoints (AArgs::ckpt_cap of them)
     a.B = s.B; a.nsteps = 1; a.t0 = s.t0; a.dt = 0.f;
     a.nvars = s.nvars; a.D = p->cfg.nvars + p->cfg.naug; a.C = p->cfg.ncond;
     a.reg_z = p->cfg.reg_z; a.reg_j = p->cfg.reg_j; a.reg_aug = s.reg_aug; a.autonomous = p->cfg.autonomous;
@@ -678,12 +679,15 @@ static hipError_t fill_aargs_scratch(AArgs& q, void* scratch, long long ntiles, 
 }
 
 hipError_t mfma_solve_adaptive(MfmaPlan* p, const float* packed_dev, const SolveArgs& s, float abstol, float reltol, float dt_init,
-                               int maxiters, void* scratch, unsigned* epoch, int dts_cap, int** stats_dev, float** dts_dev, int* host_rec, hipStream_t st) {
+                               int maxiters, void* scratch, unsigned* epoch, int dts_cap, int** stats_dev, float** dts_dev, int* host_rec, int ckpt_cap,
+                               hipStream_t st) {
     const long long ntiles = (s.B + 15) / 16;
     KArgs a{};
     fill_kargs_adaptive(p, packed_dev, s, a);
     AArgs q{};
     q.host_rec = host_rec;
+    q.ckpt_cap = (s.ckpt && s.ckpt_k) ? ckpt_cap : 0;
+    if (!q.ckpt_cap) a.ckpt = a.ckpt_k = nullptr;
     q.abstol = abstol; q.reltol = reltol; q.t1 = s.t1; q.dt_init = dt_init; q.maxiters = maxiters; q.dts_cap = dts_cap;
     const Tableau T = make_tableau(CNF_ALG_TSIT5);
     // b - bhat of the embedded 4th-order solution (Tsitouras 2011); the same constants as cnf_step_embedded
@@ -734,6 +738,7 @@ hipError_t mfma_solve_vcabm(MfmaPlan* p, const float* packed_dev, const SolveArg
     const long long ntiles = (s.B + 15) / 16;
     KArgs a{};
     fill_kargs_adaptive(p, packed_dev, s, a);
+    a.ckpt = a.ckpt_k = nullptr;
     AArgs q{};
     q.host_rec = host_rec;
     q.abstol = abstol; q.reltol = reltol; q.t1 = s.t1; q.dt_init = dt_init; q.maxiters = maxiters; q.dts_cap = dts_cap;

@@ -58,6 +58,9 @@ struct AArgs {
     int* stats;         // naccept, nreject, nf, status (0 ok, 1 non-finite error estimate, 2 maxiters, 3 no initial step, 4 grid sum
                         // timed out), max order, [5] = abort flag raised by the first workgroup whose wait timed out
     int* orders;        // VCABM: order of every accepted step, dts_cap entries
+    int ckpt_cap;       // mfma_adaptive_kernel with KArgs::ckpt / ckpt_k: accepted steps the checkpoint arrays hold (step n: z_n in slot n of
+                        // ckpt, its six stage derivatives in slots 6 n .. 6 n + 5 of ckpt_k; z at t1 in slot naccept) - the forward half of
+                        // the frozen-grid gradient, written by the solve that finds the grid (host_rec[6] = 1: complete)
     int* host_rec;      // pinned host memory (or null): the eight status words, then the first kHostRec accepted steps as {step size
                         // bits, order} pairs - written by the kernel itself, so the host reads its answer after one stream
                         // synchronisation instead of two or three small device-to-host copies (15 - 40 us each at these sizes)

@@ -1108,6 +1108,11 @@ mfma_adaptive_kernel(KArgs a, AArgs q) {
             begin = true;
         } else {
             // stage st (1..6) of the attempt has been evaluated
+            if (a.ckpt_k && st < 6 && naccept < q.ckpt_cap) {   // k_{st+1} of step `naccept` (a retry of the step overwrites it)
+#pragma unroll
+                for (int s = 0; s < ZR; ++s)
+                    a.ckpt_k[((((long long)naccept * 6 + st) * ntiles + tile) * 64 + lane) * ZR + s] = zd[s];
+            }
             erl = fmaf(q.bt[st], ld, erl); ere = fmaf(q.bt[st], ed, ere); ern = fmaf(q.bt[st], nd, ern);
 #pragma unroll
             for (int s = 0; s < ZR; ++s) erz[s] = fmaf(q.bt[st], zd[s], erz[s]);
@@ -1185,10 +1190,21 @@ mfma_adaptive_kernel(KArgs a, AArgs q) {
                 for (int i = 0; i < 6; ++i) P[i][s] = q.acol[0][i] * k1z[s];
                 zs[s] = fmaf(dtf, P[0][s], z[s]);
             }
+            if (a.ckpt && naccept < q.ckpt_cap) {   // the step's start state and first stage derivative (first-same-as-last)
+#pragma unroll
+                for (int s = 0; s < ZR; ++s) {
+                    a.ckpt[(((long long)naccept * ntiles + tile) * 64 + lane) * ZR + s] = z[s];
+                    if (a.ckpt_k) a.ckpt_k[((((long long)naccept * 6) * ntiles + tile) * 64 + lane) * ZR + s] = k1z[s];
+                }
+            }
             st = 1;
             phase = 2;
             tcur = tf + q.c[1] * dtf;
         }
+    }
+    if (a.ckpt && naccept <= q.ckpt_cap && status == 0) {   // the final state closes the checkpoint list
+#pragma unroll
+        for (int s = 0; s < ZR; ++s) a.ckpt[(((long long)naccept * ntiles + tile) * 64 + lane) * ZR + s] = z[s];
     }
 
     if (valid && a.u_out) {
@@ -1200,7 +1216,7 @@ mfma_adaptive_kernel(KArgs a, AArgs q) {
         q.stats[0] = naccept; q.stats[1] = nreject; q.stats[2] = nf; q.stats[3] = status; q.stats[4] = 5;
         if (q.host_rec) {
             q.host_rec[0] = naccept; q.host_rec[1] = nreject; q.host_rec[2] = nf; q.host_rec[3] = status; q.host_rec[4] = 5;
-            q.host_rec[5] = status == 4; q.host_rec[6] = 0; q.host_rec[7] = 0;
+            q.host_rec[5] = status == 4; q.host_rec[6] = (a.ckpt && naccept <= q.ckpt_cap && status == 0) ? 1 : 0; q.host_rec[7] = 0;
         }
     }
 }

@@ -19,6 +19,7 @@ const Knob kKnobs[] = {
     {"CNF_GRAD_LAYERED", &cnf_tuning::grad_layered, 0},
     {"CNF_JVP_GRAD_TWIN", &cnf_tuning::jvp_grad_twin, 1},
     {"CNF_PROBE_GRAD_TWIN", &cnf_tuning::probe_grad_twin, 1},
+    {"CNF_ADAPTIVE_CKPT", &cnf_tuning::adaptive_ckpt, 1},
     {"CNF_LAYERED_LOSS_BY_SOLVE", &cnf_tuning::layered_loss_by_solve, 0},
     {"CNF_DEVICE_CONTROLLER", &cnf_tuning::device_controller, 1},
     {"CNF_DC_PER_CU", &cnf_tuning::dc_per_cu, 2},

@@ -27,6 +27,7 @@ python profiles/coopx_timing.py > $OUT/${TAG}_coopx_timing.json 2>/dev/null
 python profiles/jvp_twin_timing.py 2>/dev/null | tail -1 > $OUT/${TAG}_jvp_twin_timing.json
 python profiles/probes_wide_timing.py 2>/dev/null | tail -1 > $OUT/${TAG}_probes_wide_timing.json
 python profiles/dc_per_cu_ab.py 2>/dev/null | tail -1 > $OUT/${TAG}_dc_per_cu_ab.json
+python profiles/adaptive_ckpt_ab.py 2>/dev/null | tail -1 > $OUT/${TAG}_adaptive_ckpt_ab.json
 # PMC of the narrow gradient kernels (one probe, four probes) and of the default architecture's gradient
 bash profiles/pmc_target.sh ${TAG}_cfg2_grad profiles/grad_profile_target.py CFG=cfg2 REPS=4 > $OUT/${TAG}_cfg2_grad_pmc.txt 2>&1
 bash profiles/pmc_target.sh ${TAG}_cfg3_grad profiles/grad_profile_target.py CFG=cfg3 REPS=3 > $OUT/${TAG}_cfg3_grad_pmc.txt 2>&1

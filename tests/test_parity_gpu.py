@@ -2948,6 +2948,40 @@ def test_default_solver_on_the_device_is_the_host_policy(kw, B, tol, dt0, pkg, o
         assert max(d["orders"]) >= 6, d["orders"]
 
 
+@pytest.mark.parametrize("kw,B,tol", [
+    (dict(nvars=1, naug=2, hidden=[16, 16], act=2, reg_z=True, reg_j=True, reg_aug=True), 1024, 1e-4),      # the reference's benchmark flow
+    (dict(nvars=8, hidden=[64, 64, 64], reg_z=True, reg_j=True), 1000, 1e-5),                               # cfg2's kernel, ragged tile
+    (dict(nvars=8, hidden=[64, 64, 64], nprobes=4, reg_z=True, reg_j=True), 500, 1e-4),                     # cfg3: four probes
+    (dict(nvars=3, hidden=[24, 24], act=2, mode=2), 200, 1e-5),                                             # TestMode (unit probes in the sweep)
+    (dict(nvars=5, naug=2, ncond=3, hidden=[32, 32], act=2, reg_z=True), 300, 1e-4),                        # conditioned, zero-padded instance
+    (dict(nvars=2, hidden=[32, 32]), 20000, 1e-4),                                                          # 1250 tiles: several waves per workgroup
+])
+def test_adaptive_solve_writes_the_checkpoints_of_its_own_gradient(kw, B, tol, pkg, oracles, monkeypatch):
+    """cnf_loss_grad_adaptive (round 5): where the frozen-grid gradient is the fused per-wave sweep, the one-launch adaptive Tsit5
+    solve that finds the grid also writes the sweep's checkpoints - z_n and the six stage derivatives of every accepted step - so the
+    gradient needs no forward pass of its own.  Against the same call with its own step-by-step forward pass (CNF_ADAPTIVE_CKPT=0):
+    the same grid; the two forward passes differ by an ulp in t and dt per step, so loss and gradient agree to 1e-5."""
+    o64, _ = oracles
+    spec = o64.make_spec(**kw)
+    p, xs, eps, ys = o64.synth_inputs(spec, B, 17, bias_scale=0.2)
+    out = {}
+    for tag, env in (("solve", "1"), ("own", "0")):
+        setsw(pkg, monkeypatch, "CNF_ADAPTIVE_CKPT", env)
+        icnf = make_icnf(pkg, spec, 1, 4, path=0, lambdas=(0.01, 0.01, 0.01))
+        icnf.sol_kwargs = dict(alg=pkg.Tsit5(), reltol=tol, abstol=tol)
+        mode = mode_of(pkg, spec)
+        assert icnf.grad_path(mode, B=B, alg=1, on_grid=True) == 1
+        args = (dev(xs),) + ((dev(ys),) if spec.ncond else ()) + (dev(p), {})
+        val, g, gx = pkg.loss_and_gradient(icnf, mode, *args, eps=dev(eps), wrt_x=True)
+        st = icnf.last_solve_stats
+        out[tag] = (float(val), g.cpu().numpy().astype(np.float64), gx.cpu().numpy().astype(np.float64), list(st["tgrid"]))
+    assert out["solve"][3] == out["own"][3] and len(out["solve"][3]) >= 3
+    assert abs(out["solve"][0] - out["own"][0]) < 1e-5 * (1 + abs(out["own"][0]))
+    for k in (1, 2):
+        a, b = out["solve"][k], out["own"][k]
+        assert np.max(np.abs(a - b)) < 1e-5 * np.abs(b).max() + 1e-7, np.max(np.abs(a - b)) / np.abs(b).max()
+
+
 @pytest.mark.parametrize("solver", ["tsit5", "vcabm"])
 def test_one_launch_solves_longer_than_the_pinned_record(solver, pkg, oracles, monkeypatch):
     """The one-launch kernels write their status words and the first 120 accepted steps into pinned host memory (round 5); a longer
