@@ -13,9 +13,23 @@ int fail(int code, const std::string& msg) { return cnf::api_fail(code, msg); }
 
 extern "C" {
 
+// ckpt / ckpt_k (may be null; per-wave plans only): slots of the frozen-grid gradient's checkpoint arrays for this step - the fused
+// attempt then also writes the step's start state, its six stage derivatives and the state it arrives at (api_solve_tsit5's TsitCkpt)
+static int step_embedded_impl(cnf_handle* h, int alg, int flags, float t, float dt, const float* u, const float* eps,
+                              const float* ys, int64_t B, float abstol, float reltol, float* u_new, double* err_sumsq,
+                              void* stream, float* ckpt, float* ckpt_k);
+
 int cnf_step_embedded(cnf_handle* h, int alg, int flags, float t, float dt, const float* u, const float* eps,
                       const float* ys, int64_t B, float abstol, float reltol, float* u_new, double* err_sumsq,
                       void* stream) {
+    return step_embedded_impl(h, alg, flags, t, dt, u, eps, ys, B, abstol, reltol, u_new, err_sumsq, stream, nullptr, nullptr);
+}
+
+}  // extern "C"
+
+static int step_embedded_impl(cnf_handle* h, int alg, int flags, float t, float dt, const float* u, const float* eps,
+                              const float* ys, int64_t B, float abstol, float reltol, float* u_new, double* err_sumsq,
+                              void* stream, float* ckpt, float* ckpt_k) {
     int rc = api_check_call(h, eps, ys, B, "cnf_step_embedded");
     if (rc) return rc;
     if (alg != CNF_ALG_TSIT5) return fail(CNF_ERR_INVALID, "cnf_step_embedded: the embedded pair is Tsit5 (alg = CNF_ALG_TSIT5)");
@@ -54,6 +68,7 @@ int cnf_step_embedded(cnf_handle* h, int alg, int flags, float t, float dt, cons
         a.u0 = u; a.eps = eps; a.ys = ys; a.B = B; a.nsteps = 1; a.alg = CNF_ALG_TSIT5; a.t0 = t; a.t1 = t + dt;
         a.u_out = u_new; a.nvars = h->cfg.nvars; a.reg_aug = 0; a.kfull = h->emb.buf;
         a.dt_exact = dt;   // the step the error estimate is scaled with, not fl(fl(t + dt) - t)
+        a.ckpt = ckpt; a.ckpt_k = ckpt_k;
         HIP_TRY(mfma_solve(h->plan, h->par.packed_dev, a, st));
         StageIn last{};
         last.u = u_new; last.nprev = 0; last.dt = 0.f;
@@ -86,6 +101,8 @@ int cnf_step_embedded(cnf_handle* h, int alg, int flags, float t, float dt, cons
     HIP_TRY(embedded_error(u, u_new, k, btilde, 7, dt, abstol, reltol, (int64_t)n, h->emb.err_partial, err_sumsq, st));
     return CNF_OK;
 }
+
+extern "C" {
 
 // ---- variable-step variable-order Adams PECE: the reference's default alg = VCABM() ----
 
@@ -533,11 +550,17 @@ int cnf::api_solve_tsit5(cnf_handle* h, float t0, float t1, const float* u0, con
     const double beta1 = 7.0 / 50.0, beta2 = 2.0 / 25.0, gamma = 0.9, qmin = 0.2, qmax = 10.0;
     double qold = 1e-4, t = t0;
     int flags = 0, it = 0;
+    const bool ck_live = ck && ck->cap > 0 && ck->ckpt && ck->ckpt_k && h->path == CNF_PATH_MFMA && mfma_plan_is_per_wave(h->plan);
+    const size_t ck_slot = ck_live ? (size_t)((B + 15) / 16) * 64 * (size_t)mfma_plan_zr(h->plan) : 0;
     for (; it < maxiters; ++it) {
         if (std::fabs((double)t1 - t) <= 1e-7 * std::max(1.0, span)) break;
         const bool last = dt >= std::fabs((double)t1 - t) * (1.0 - 1e-6);
         const double step = last ? std::fabs((double)t1 - t) : dt;     // tstop: never step over t1
-        rc = cnf_step_embedded(h, CNF_ALG_TSIT5, flags, (float)t, (float)(tdir * step), ua, eps, ys, B, abstol, reltol, ub, res, stream);
+        // (per-wave plans: the fused attempt of step `naccept` also fills that step's checkpoint slots - z_n, the six stage
+        // derivatives, z_{n+1}; a retry overwrites them)
+        float *cz = nullptr, *ckk = nullptr;
+        if (ck_live && naccept < ck->cap) { cz = ck->ckpt + (size_t)naccept * ck_slot; ckk = ck->ckpt_k + (size_t)naccept * 6 * ck_slot; }
+        rc = step_embedded_impl(h, CNF_ALG_TSIT5, flags, (float)t, (float)(tdir * step), ua, eps, ys, B, abstol, reltol, ub, res, stream, cz, ckk);
         if (rc) return rc;
         nf += flags ? 6 : 7;
         rc = fetch(1);
@@ -563,6 +586,7 @@ int cnf::api_solve_tsit5(cnf_handle* h, float t0, float t1, const float* u0, con
     if (stats) { stats->naccept = naccept; stats->nreject = nreject; stats->nf = nf; stats->max_order = 5; }
     if (it == maxiters) return fail(CNF_ERR_INVALID, "cnf_solve_tsit5: maxiters reached");
     HIP_TRY(hipMemcpyAsync(u1, ua, n * sizeof(float), hipMemcpyDeviceToDevice, st));
+    if (ck) ck->ok = ck_live && naccept <= ck->cap;
     return CNF_OK;
 }
 }  // extern "C++"

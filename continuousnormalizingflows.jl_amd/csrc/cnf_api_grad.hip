@@ -411,9 +411,10 @@ int cnf_loss_grad_adaptive(cnf_handle* h, float t0, float t1, const float* x, co
         float* u = h->adp.buf + 4 * slot;
         // Where the gradient on the frozen grid is the fused per-wave sweep of this very handle, the solve that finds the grid also
         // writes the sweep's checkpoints (z_n and the stage derivatives of every accepted step: the one-launch kernel has them in
-        // registers) - the gradient then needs no forward pass of its own.  Up to kAdaptiveCkptSteps steps; a longer solve, a batch
-        // beyond the one-launch kernel or CNF_ADAPTIVE_CKPT=0 take the step-by-step forward pass of loss_grad_impl.
-        constexpr int kAdaptiveCkptSteps = 32;
+        // registers; beyond its capacity the library's host loop lets every fused attempt fill the slots of its step) - the gradient
+        // then needs no forward pass of its own.  Up to kAdaptiveCkptSteps steps; a longer solve or CNF_ADAPTIVE_CKPT=0 take the
+        // step-by-step forward pass of loss_grad_impl.
+        const int kAdaptiveCkptSteps = B <= 32768 ? 32 : 16;   // (7 slots of tiles x 64 x ZR floats a step: 225 MB at 32 768 samples, D <= 8)
         const GradServe gs = grad_serve(h, B, CNF_ALG_TSIT5, true);
         const GradRoute route = api_grad_route(h, B, CNF_ALG_TSIT5, true);
         if (gs.srv == h && gs.nloop == 1 && route.path == 1 && !route.slab && tuning().adaptive_ckpt != 0 && h->path == CNF_PATH_MFMA && h->plan) {

@@ -1,6 +1,6 @@
 """Loss + gradient under an adaptive solver (cnf_loss_grad_adaptive) with the checkpoints of the frozen-grid sweep written by the
 adaptive solve itself (default) against the sweep's own step-by-step forward pass (CNF_ADAPTIVE_CKPT=0): the reference's benchmark flow
-at 2^10 samples and cfg2's flow at 1024 ... 32 768 samples, tolerance 1e-4.  Best of three runs of 20 calls."""
+at 2^10 samples and cfg2's flow at 1024 ... 65 536 samples (the last one beyond the one-launch kernel: the library's host loop), tolerance 1e-4.  Best of three runs of 20 calls."""
 import json, os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -24,7 +24,7 @@ for env in ("1", "0"):
     icnf = pkg.ICNF(nvariables=1, device=dev)
     ps, st = pkg.setup(torch.Generator().manual_seed(0), icnf); ps = ps.to(dev)
     res["pkgbenchmark_1024"] = dict(ms=timed(lambda: pkg.loss_and_gradient(icnf, pkg.TrainMode(True), r, ps, st)), steps=icnf.last_solve_stats["naccept"])
-    for B in (1024, 8192, 32768):
+    for B in (1024, 8192, 32768, 65536):
         spec = o64.make_spec(nvars=8, hidden=[64, 64, 64])
         p, xs, eps, _ = o64.synth_inputs(spec, B, 3)
         X = torch.tensor(xs.T.copy(), device=dev).t(); P = torch.tensor(p, device=dev); E = torch.tensor(eps.T.copy(), device=dev).t()

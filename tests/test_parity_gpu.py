@@ -2827,16 +2827,21 @@ def test_adaptive_tsit5_library_policy_is_the_host_loop(pkg, oracles, monkeypatc
     icnf.lambda1, icnf.lambda2 = 0.02, 0.03
     mode = pkg.TrainMode(True)
     out = {}
-    for pol in ("python", "library"):
-        icnf.adaptive_policy = pol
+    # (library0: the gradient's own forward pass on the frozen grid, as the Python loop runs it - bit for bit; library: the default, the
+    # solve's fused attempts fill the sweep's checkpoints themselves, an ulp of t and dt per step away)
+    for pol in ("python", "library0", "library"):
+        icnf.adaptive_policy = pol.rstrip("0")
+        setsw(pkg, monkeypatch, "CNF_ADAPTIVE_CKPT", "0" if pol == "library0" else "1")
         lp, _, u1 = pkg.inference(icnf, mode, dev(xs), dev(p), {}, eps=dev(eps), return_state=True)
         st = dict(icnf.last_solve_stats)
         val, g, gx = pkg.loss_and_gradient(icnf, mode, dev(xs), dev(p), {}, eps=dev(eps), wrt_x=True)
         out[pol] = (u1, st, float(val), g, gx, list(icnf.last_solve_stats["tgrid"]))
-    a, b = out["python"], out["library"]
+    a, b, c = out["python"], out["library0"], out["library"]
     assert (a[1]["naccept"], a[1]["nreject"], a[1]["nf"]) == (b[1]["naccept"], b[1]["nreject"], b[1]["nf"]) and a[1]["naccept"] >= 6
     assert np.array_equal(np.float32(a[1]["dts"]), np.float32(b[1]["dts"])) and torch.equal(a[0], b[0])
     assert np.array_equal(np.float32(a[5]), np.float32(b[5])) and a[2] == b[2] and torch.equal(a[3], b[3]) and torch.equal(a[4], b[4])
+    assert np.array_equal(np.float32(b[5]), np.float32(c[5])) and abs(b[2] - c[2]) < 2e-6 * abs(b[2])
+    assert float((b[3] - c[3]).abs().max()) < 1e-5 * float(b[3].abs().max()) and float((b[4] - c[4]).abs().max()) < 1e-5 * float(b[4].abs().max())
     del icnf.sol_kwargs["dt"]
     res = {}
     for pol in ("python", "library"):
@@ -2955,6 +2960,7 @@ def test_default_solver_on_the_device_is_the_host_policy(kw, B, tol, dt0, pkg, o
     (dict(nvars=3, hidden=[24, 24], act=2, mode=2), 200, 1e-5),                                             # TestMode (unit probes in the sweep)
     (dict(nvars=5, naug=2, ncond=3, hidden=[32, 32], act=2, reg_z=True), 300, 1e-4),                        # conditioned, zero-padded instance
     (dict(nvars=2, hidden=[32, 32]), 20000, 1e-4),                                                          # 1250 tiles: several waves per workgroup
+    (dict(nvars=8, hidden=[64, 64, 64]), 40000, 1e-4),                                                      # beyond the one-launch kernel: the host loop's fused attempts fill the slots
 ])
 def test_adaptive_solve_writes_the_checkpoints_of_its_own_gradient(kw, B, tol, pkg, oracles, monkeypatch):
     """cnf_loss_grad_adaptive (round 5): where the frozen-grid gradient is the fused per-wave sweep, the one-launch adaptive Tsit5
@@ -3083,13 +3089,20 @@ def test_randomised_shapes_under_the_adaptive_solvers(pkg, oracles, monkeypatch)
         args = (dev(xs),) + ((dev(ys),) if spec.ncond else ()) + (dev(p), {})
         icnf.sol_kwargs["dt"] = 2.0 ** -5
         res = {}
-        setsw(pkg, monkeypatch, "CNF_DEVICE_CONTROLLER", "0")        # bit for bit: the library's HOST loop is the Python loop
+        setsw(pkg, monkeypatch, "CNF_DEVICE_CONTROLLER", "0")        # bit for bit: the library's HOST loop is the Python loop,
+        setsw(pkg, monkeypatch, "CNF_ADAPTIVE_CKPT", "0")            # with the gradient's own forward pass on the frozen grid
         for pol in ("library", "python"):
             icnf.adaptive_policy = pol
             res[pol] = pkg.loss_and_gradient(icnf, mode_obj, *args, eps=dev(eps), wrt_x=True)
+        delsw(pkg, monkeypatch, "CNF_ADAPTIVE_CKPT")
+        icnf.adaptive_policy = "library"                             # the default: the solve's attempts fill the sweep's checkpoints
+        res["ckpt"] = pkg.loss_and_gradient(icnf, mode_obj, *args, eps=dev(eps), wrt_x=True)
         delsw(pkg, monkeypatch, "CNF_DEVICE_CONTROLLER")
         for a, b in zip(res["library"], res["python"]):
             assert torch.equal(torch.as_tensor(a), torch.as_tensor(b)), (kw, B)
+        for a, b in zip(res["ckpt"], res["library"]):
+            a, b = torch.as_tensor(a).double(), torch.as_tensor(b).double()
+            assert float((a - b).abs().max()) < 2e-5 * float(b.abs().max()) + 1e-7, (kw, B)
         assert bool(torch.isfinite(res["library"][1]).all())
         icnf.adaptive_policy = "library"                        # and the one-launch solve under the same training step
         one = pkg.loss_and_gradient(icnf, mode_obj, *args, eps=dev(eps), wrt_x=True)
