@@ -124,8 +124,10 @@ def test_the_switchboard_is_the_only_reader_of_the_environment(pkg, monkeypatch)
     body = re.search(r"typedef struct cnf_tuning \{(.*?)\} cnf_tuning;", hdr, re.S).group(1)
     fields = re.findall(r"int32_t (\w+);\s*/\* (CNF_[A-Z0-9_]+), default (-?\d+):", body)
     assert [f for f, _, _ in fields] == list(pkg._lib.TUNING_FIELDS) and len(fields) >= 30
+    integration = open(os.path.join(os.path.dirname(os.path.dirname(csrc)), "INTEGRATION.md")).read()
     for f, env, _ in fields:
         assert env == "CNF_" + f.upper(), (f, env)
+        assert env in integration, f"{env} is not described in INTEGRATION.md"
         monkeypatch.delenv(env, raising=False)
     base = pkg.reload_tuning()
     assert base == {f: int(d) for f, _, d in fields}
