@@ -244,6 +244,10 @@ static int loss_grad_impl(cnf_handle* h, const char* who, int alg, int nsteps, f
             float* regs = logp + B;
             if (loss_in_sweep) {
                 // the layer-wise reverse sweep accumulates the loss terms of the solve it differentiates (below)
+            } else if (tgrid && pc && pc->u_final) {
+                // the adaptive solve that found the grid has the state at t1: its loss terms, no second solve over the grid
+                const int ra0 = (h->cfg.mode != CNF_MODE_EXACT && h->cfg.reg_aug && h->cfg.naug > 0) ? 1 : 0;
+                HIP_TRY(epilogue(pc->u_final, h->cfg.nvars, h->D, ra0, B, logp, regs, st));
             } else if (tgrid) {   // the loss of the same discrete solve: augmented state advanced over the grid, then the epilogue
                 float* u = regs + 3 * (size_t)B;
                 const int ra0 = (h->cfg.mode != CNF_MODE_EXACT && h->cfg.reg_aug && h->cfg.naug > 0) ? 1 : 0;
@@ -312,6 +316,7 @@ static int loss_grad_impl(cnf_handle* h, const char* who, int alg, int nsteps, f
     const cnf_config gc = api_grad_cfg(h);
     const bool exact = h->cfg.mode == CNF_MODE_EXACT;
     // (checkpoints an adaptive solve has written sit in arrays laid out for pc->cap steps, of which the first nsteps are filled)
+    if (pc && pc->cap <= 0) pc = nullptr;   // (a final state without checkpoints serves the other implementations' loss terms only)
     const FusedWs W = fused_ws(h, alg, pc ? pc->cap : nsteps, B, tgrid != nullptr);
     if (W.need > h->grad.ws_bytes) {
         if (pc) return fail(CNF_ERR_INVALID, w + ": prepared checkpoints without their workspace");
@@ -440,12 +445,13 @@ int cnf_loss_grad_adaptive(cnf_handle* h, float t0, float t1, const float* x, co
         grid.push_back(t0);
         for (double d : steps) { t += d; grid.push_back((float)t); }
         grid.back() = t1;
-        if (ck.ok && (int)steps.size() <= ck.cap) { pc.cap = ck.cap; pc.u_final = u + slot; }
+        if (ck.ok && (int)steps.size() <= ck.cap) pc.cap = ck.cap;
+        if (tuning().adaptive_ckpt != 0 && gs.srv == h && gs.nloop == 1) pc.u_final = u + slot;   // the state at t1: the loss terms of every implementation
     }
     if (tgrid_out)
         for (size_t i = 0; i < grid.size() && (int64_t)i < grid_cap; ++i) tgrid_out[i] = grid[i];
     return loss_grad_impl(h, "cnf_loss_grad_adaptive", CNF_ALG_TSIT5, (int)grid.size() - 1, 0.f, 0.f, grid.data(), x, eps, ys, B,
-                          lambdas, grad, grad_x, sums4, stream, pc.cap > 0 ? &pc : nullptr);
+                          lambdas, grad, grad_x, sums4, stream, pc.u_final ? &pc : nullptr);
 }
 
 }  // extern "C"
