@@ -127,7 +127,9 @@ static FusedWs fused_ws(cnf_handle* h, int alg, int steps, int64_t B, bool on_gr
 
 // Checkpoints the adaptive solve that found the grid has already written (api_solve_tsit5's TsitCkpt): arrays laid out for `cap`
 // steps at the head of the handle's gradient workspace (fused_ws below), and the solve's final state for the loss terms.
-struct PreparedCkpt { int cap; const float* u_final; };
+// (ckpt / ckpt_k / zr: where the slab-accumulator kernel finds them - behind the loss workspace - and their stride; the fused per-wave
+// path derives its own from fused_ws)
+struct PreparedCkpt { int cap; const float* u_final; const float* ckpt; const float* ckpt_k; int zr; };
 static int loss_grad_impl(cnf_handle* h, const char* who, int alg, int nsteps, float t0, float t1, const float* tgrid,
                           const float* x, const float* eps, const float* ys, int64_t B, const float* lambdas,
                           float* grad, float* grad_x, float* sums4, void* stream, const PreparedCkpt* pc = nullptr);
@@ -279,8 +281,9 @@ static int loss_grad_impl(cnf_handle* h, const char* who, int alg, int nsteps, f
                 HIP_TRY(hipMalloc((void**)&h->grad.slab_ws, need * sizeof(float)));
                 h->grad.slab_ws_floats = need;
             }
+            const bool pre = pc && pc->cap > 0 && pc->ckpt && pc->ckpt_k && tgrid;
             HIP_TRY(grad_slab_launch(h->cfg, h->grad.slab_packed, x, eps, ys, h->par.w_off.data(), h->par.b_off.data(), alg, nsteps, t0, t1, tgrid_dev, B, lam,
-                                     h->grad.slab_ws, grad, grad_x, h->num_cus, st));
+                                     h->grad.slab_ws, grad, grad_x, h->num_cus, st, pre ? pc->ckpt : nullptr, pre ? pc->ckpt_k : nullptr, pre ? pc->zr : 0));
             return CNF_OK;
         }
         std::string msg;
@@ -408,6 +411,7 @@ int cnf_loss_grad_adaptive(cnf_handle* h, float t0, float t1, const float* x, co
     }
     TsitCkpt ck{};
     PreparedCkpt pc{};
+    bool slab_route = false;
     {
         DeviceGuard g(h->cfg.device_id);
         rc = api_ensure_adaptive_buf(h, B);
@@ -436,6 +440,21 @@ int cnf_loss_grad_adaptive(cnf_handle* h, float t0, float t1, const float* x, co
                 h->grad.ws_bytes = W.need;
             }
             ck.ckpt = h->grad.ws; ck.ckpt_k = h->grad.ws + W.ckpt_z_floats; ck.cap = kAdaptiveCkptSteps;
+        } else if (gs.srv == h && gs.nloop == 1 && route.path == 1 && route.slab && tuning().adaptive_ckpt != 0 && h->path == CNF_PATH_MFMA && h->plan &&
+                   mfma_plan_is_per_wave(h->plan)) {
+            // slab-accumulator gradient (its forward sweep is inside the kernel): the arrays sit behind the loss workspace of the
+            // non-fused branch of loss_grad_impl, in the forward instance's layout, which the kernel reads with that stride
+            const size_t zslot = (size_t)((B + 15) / 16) * 64 * (size_t)mfma_plan_zr(h->plan);
+            const size_t head = ((size_t)h->S + 4) * (size_t)B;
+            const size_t need = (head + (size_t)(7 * kAdaptiveCkptSteps + 1) * zslot) * sizeof(float);
+            if (need > h->grad.ws_bytes) {
+                if (h->grad.ws) HIP_TRY(hipFree(h->grad.ws));
+                h->grad.ws = nullptr; h->grad.ws_bytes = 0;
+                HIP_TRY(hipMalloc((void**)&h->grad.ws, need));
+                h->grad.ws_bytes = need;
+            }
+            ck.ckpt = h->grad.ws + head; ck.ckpt_k = ck.ckpt + (size_t)(kAdaptiveCkptSteps + 1) * zslot; ck.cap = kAdaptiveCkptSteps;
+            slab_route = true;
         }
         HIP_TRY(assemble_u0(x, h->cfg.nvars, h->S, B, u, (hipStream_t)stream));
         std::vector<double> steps;
@@ -445,7 +464,10 @@ int cnf_loss_grad_adaptive(cnf_handle* h, float t0, float t1, const float* x, co
         grid.push_back(t0);
         for (double d : steps) { t += d; grid.push_back((float)t); }
         grid.back() = t1;
-        if (ck.ok && (int)steps.size() <= ck.cap) pc.cap = ck.cap;
+        if (ck.ok && (int)steps.size() <= ck.cap) {
+            pc.cap = ck.cap;
+            if (slab_route) { pc.ckpt = ck.ckpt; pc.ckpt_k = ck.ckpt_k; pc.zr = mfma_plan_zr(h->plan); }
+        }
         if (tuning().adaptive_ckpt != 0 && gs.srv == h && gs.nloop == 1) pc.u_final = u + slot;   // the state at t1: the loss terms of every implementation
     }
     if (tgrid_out)

@@ -179,8 +179,20 @@ grad_slab_kernel(GArgs a, const float* __restrict__ x, float* __restrict__ ckz, 
 #pragma unroll
             for (int s = 0; s < CR; ++s) { const int f = 4 * s + g; y[s] = f < a.C ? a.ys[sc * a.C + f] : 0.f; }
         }
-        // ---------------- forward sweep: checkpoints z_n and the stage derivatives ----------------
-        {
+        // checkpoints: the kernel's own (forward sweep below), or - a.ckpt - those the adaptive solve that found the grid has written, in
+        // the forward instance's layout (a.ckpt_zr state k-steps per lane, cnf_api_grad.hip::PreparedCkpt): no forward sweep then
+        const float* const rz = a.ckpt ? a.ckpt : ckz;
+        const float* const rk = a.ckpt ? a.ckpt_k : ckk;
+        const int czr = a.ckpt ? a.ckpt_zr : ZR;
+        if (a.ckpt) {
+#pragma unroll
+            for (int s = 0; s < ZR; ++s) {
+                const int f = 4 * s + g;
+                eps[s] = f < D ? a.eps[sc * D + f] : 0.f;
+                lam[s] = valid ? rz[(((long long)a.nsteps * ntiles + tile) * 64 + lane) * czr + s] : 0.f;   // dL/dz_N = z_N
+            }
+        } else {
+            // ---------------- forward sweep: checkpoints z_n and the stage derivatives ----------------
             float z[ZR];
 #pragma unroll
             for (int s = 0; s < ZR; ++s) {
@@ -263,12 +275,12 @@ grad_slab_kernel(GArgs a, const float* __restrict__ x, float* __restrict__ ckz, 
             if (a.tgrid) { tn = a.tgrid[step]; dt = a.tgrid[step + 1] - tn; }
             float zn[ZR], kz[6][ZR], Zb[6][ZR];
 #pragma unroll
-            for (int s = 0; s < ZR; ++s) zn[s] = ckz[(((long long)step * ntiles + tile) * 64 + lane) * ZR + s];
+            for (int s = 0; s < ZR; ++s) zn[s] = rz[(((long long)step * ntiles + tile) * 64 + lane) * czr + s];
 #pragma unroll
             for (int j = 0; j < 6; ++j)
 #pragma unroll
                 for (int s = 0; s < ZR; ++s) {
-                    kz[j][s] = j < ns ? ckk[((((long long)step * ns + j) * ntiles + tile) * 64 + lane) * ZR + s] : 0.f;
+                    kz[j][s] = j < ns ? rk[((((long long)step * ns + j) * ntiles + tile) * 64 + lane) * czr + s] : 0.f;
                     Zb[j][s] = 0.f;
                 }
 #pragma clang loop unroll(disable)
@@ -541,7 +553,8 @@ size_t grad_slab_ws_floats(const cnf_config& c, int alg, int nsteps, long long B
 
 hipError_t grad_slab_launch(const cnf_config& c, const float* packed_dev, const float* x, const float* eps, const float* ys,
                             const size_t* w_off, const size_t* b_off, int alg, int nsteps, float t0, float t1,
-                            const float* tgrid_dev, long long B, const float lam[3], float* ws, float* grad, float* grad_x, int num_cus, hipStream_t st) {
+                            const float* tgrid_dev, long long B, const float lam[3], float* ws, float* grad, float* grad_x, int num_cus, hipStream_t st,
+                            const float* pre_ckpt, const float* pre_ckpt_k, int pre_zr) {
     const SlabInst* si = slab_find(c);
     if (!si) return hipErrorNotSupported;
     static DeviceOnce once[sizeof(kSlab) / sizeof(kSlab[0])];
@@ -562,6 +575,7 @@ hipError_t grad_slab_launch(const cnf_config& c, const float* packed_dev, const 
     GArgs a{};
     a.packed = packed_dev; a.eps = eps; a.K = 1; a.ys = ys; a.C = c.ncond; a.slab = slab; a.grad_x = grad_x; a.B = B;
     a.nsteps = nsteps; a.t0 = t0; a.dt = (t1 - t0) / (float)nsteps; a.tgrid = tgrid_dev;
+    if (pre_ckpt && pre_ckpt_k && pre_zr >= si->ZR) { a.ckpt = pre_ckpt; a.ckpt_k = pre_ckpt_k; a.ckpt_zr = pre_zr; }   // (else: its own forward sweep)
     a.D = c.nvars + c.naug; a.H = c.widths[1]; a.n_in = c.widths[2] /* second hidden width for the reduce kernel */;
     a.autonomous = c.autonomous; a.nvars = c.nvars;
     a.lam1 = lam[0]; a.lam2 = lam[1]; a.lam3 = lam[2];

@@ -139,7 +139,8 @@ void grad_slab_pack(const cnf_config& c, const float* lux, const size_t* w_off, 
 size_t grad_slab_ws_floats(const cnf_config& c, int alg, int nsteps, long long B, int num_cus);
 hipError_t grad_slab_launch(const cnf_config& c, const float* packed_dev, const float* x, const float* eps, const float* ys,
                             const size_t* w_off, const size_t* b_off, int alg, int nsteps, float t0, float t1,
-                            const float* tgrid_dev, long long B, const float lam[3], float* ws, float* grad, float* grad_x, int num_cus, hipStream_t st);
+                            const float* tgrid_dev, long long B, const float lam[3], float* ws, float* grad, float* grad_x, int num_cus, hipStream_t st,
+                            const float* pre_ckpt = nullptr, const float* pre_ckpt_k = nullptr, int pre_zr = 0);   // checkpoints an adaptive solve wrote (forward instance's layout, pre_zr state k-steps): no forward sweep
 int mfma_plan_zr(const MfmaPlan* p);   // state k-steps of the forward instance (checkpoint stride)
 bool mfma_plan_is_per_wave(const MfmaPlan* p);
 int mfma_plan_family_for(MfmaPlan* p, long long B, bool whole_solve);   // CNF_FAMILY_*
