@@ -412,6 +412,7 @@ int cnf_loss_grad_adaptive(cnf_handle* h, float t0, float t1, const float* x, co
     TsitCkpt ck{};
     PreparedCkpt pc{};
     bool slab_route = false;
+    cnf_handle* srv = nullptr;   // the handle whose gradient implementation takes the prepared state (h or its twin)
     {
         DeviceGuard g(h->cfg.device_id);
         rc = api_ensure_adaptive_buf(h, B);
@@ -424,36 +425,41 @@ int cnf_loss_grad_adaptive(cnf_handle* h, float t0, float t1, const float* x, co
         // then needs no forward pass of its own.  Up to kAdaptiveCkptSteps steps; a longer solve or CNF_ADAPTIVE_CKPT=0 take the
         // step-by-step forward pass of loss_grad_impl.
         const int kAdaptiveCkptSteps = B <= 32768 ? 32 : 16;   // (7 slots of tiles x 64 x ZR floats a step: 225 MB at 32 768 samples, D <= 8)
+        // (gh: the handle whose gradient implementation serves the call - h itself, or its VJP twin for a JVP-mode handle: the solve
+        // runs on h either way, and z_n / the stage derivatives do not depend on the trace engine)
         const GradServe gs = grad_serve(h, B, CNF_ALG_TSIT5, true);
-        const GradRoute route = api_grad_route(h, B, CNF_ALG_TSIT5, true);
-        if (gs.srv == h && gs.nloop == 1 && route.path == 1 && !route.slab && tuning().adaptive_ckpt != 0 && h->path == CNF_PATH_MFMA && h->plan) {
-            if (h->num_cus == 0) {
+        cnf_handle* const gh = const_cast<cnf_handle*>(gs.srv);
+        const GradRoute route = api_grad_route(gh, B, CNF_ALG_TSIT5, true);
+        const bool eligible = gs.nloop == 1 && route.path == 1 && tuning().adaptive_ckpt != 0 && h->path == CNF_PATH_MFMA && h->plan &&
+                              mfma_plan_is_per_wave(h->plan) && gh->path == CNF_PATH_MFMA && gh->plan;
+        srv = eligible ? gh : nullptr;
+        if (eligible && !route.slab && mfma_plan_zr(h->plan) == mfma_plan_zr(gh->plan)) {
+            if (gh->num_cus == 0) {
                 hipDeviceProp_t prop;
-                HIP_TRY(hipGetDeviceProperties(&prop, h->cfg.device_id));
-                h->num_cus = prop.multiProcessorCount;
+                HIP_TRY(hipGetDeviceProperties(&prop, gh->cfg.device_id));
+                gh->num_cus = prop.multiProcessorCount;
             }
-            const FusedWs W = fused_ws(h, CNF_ALG_TSIT5, kAdaptiveCkptSteps, B, true);
-            if (W.need > h->grad.ws_bytes) {
-                if (h->grad.ws) HIP_TRY(hipFree(h->grad.ws));
-                h->grad.ws = nullptr; h->grad.ws_bytes = 0;
-                HIP_TRY(hipMalloc((void**)&h->grad.ws, W.need));
-                h->grad.ws_bytes = W.need;
+            const FusedWs W = fused_ws(gh, CNF_ALG_TSIT5, kAdaptiveCkptSteps, B, true);
+            if (W.need > gh->grad.ws_bytes) {
+                if (gh->grad.ws) HIP_TRY(hipFree(gh->grad.ws));
+                gh->grad.ws = nullptr; gh->grad.ws_bytes = 0;
+                HIP_TRY(hipMalloc((void**)&gh->grad.ws, W.need));
+                gh->grad.ws_bytes = W.need;
             }
-            ck.ckpt = h->grad.ws; ck.ckpt_k = h->grad.ws + W.ckpt_z_floats; ck.cap = kAdaptiveCkptSteps;
-        } else if (gs.srv == h && gs.nloop == 1 && route.path == 1 && route.slab && tuning().adaptive_ckpt != 0 && h->path == CNF_PATH_MFMA && h->plan &&
-                   mfma_plan_is_per_wave(h->plan)) {
+            ck.ckpt = gh->grad.ws; ck.ckpt_k = gh->grad.ws + W.ckpt_z_floats; ck.cap = kAdaptiveCkptSteps;
+        } else if (eligible && route.slab) {
             // slab-accumulator gradient (its forward sweep is inside the kernel): the arrays sit behind the loss workspace of the
             // non-fused branch of loss_grad_impl, in the forward instance's layout, which the kernel reads with that stride
             const size_t zslot = (size_t)((B + 15) / 16) * 64 * (size_t)mfma_plan_zr(h->plan);
-            const size_t head = ((size_t)h->S + 4) * (size_t)B;
+            const size_t head = ((size_t)gh->S + 4) * (size_t)B;
             const size_t need = (head + (size_t)(7 * kAdaptiveCkptSteps + 1) * zslot) * sizeof(float);
-            if (need > h->grad.ws_bytes) {
-                if (h->grad.ws) HIP_TRY(hipFree(h->grad.ws));
-                h->grad.ws = nullptr; h->grad.ws_bytes = 0;
-                HIP_TRY(hipMalloc((void**)&h->grad.ws, need));
-                h->grad.ws_bytes = need;
+            if (need > gh->grad.ws_bytes) {
+                if (gh->grad.ws) HIP_TRY(hipFree(gh->grad.ws));
+                gh->grad.ws = nullptr; gh->grad.ws_bytes = 0;
+                HIP_TRY(hipMalloc((void**)&gh->grad.ws, need));
+                gh->grad.ws_bytes = need;
             }
-            ck.ckpt = h->grad.ws + head; ck.ckpt_k = ck.ckpt + (size_t)(kAdaptiveCkptSteps + 1) * zslot; ck.cap = kAdaptiveCkptSteps;
+            ck.ckpt = gh->grad.ws + head; ck.ckpt_k = ck.ckpt + (size_t)(kAdaptiveCkptSteps + 1) * zslot; ck.cap = kAdaptiveCkptSteps;
             slab_route = true;
         }
         HIP_TRY(assemble_u0(x, h->cfg.nvars, h->S, B, u, (hipStream_t)stream));
@@ -468,12 +474,15 @@ int cnf_loss_grad_adaptive(cnf_handle* h, float t0, float t1, const float* x, co
             pc.cap = ck.cap;
             if (slab_route) { pc.ckpt = ck.ckpt; pc.ckpt_k = ck.ckpt_k; pc.zr = mfma_plan_zr(h->plan); }
         }
-        if (tuning().adaptive_ckpt != 0 && gs.srv == h && gs.nloop == 1) pc.u_final = u + slot;   // the state at t1: the loss terms of every implementation
+        if (tuning().adaptive_ckpt != 0 && gs.nloop == 1) pc.u_final = u + slot;   // the state at t1: the loss terms of every implementation
+        if (!pc.u_final || gs.nloop != 1) srv = nullptr;
+        else if (!srv) srv = gh;   // (a route without checkpoints still takes the final state for its loss terms - on the handle that serves it)
     }
     if (tgrid_out)
         for (size_t i = 0; i < grid.size() && (int64_t)i < grid_cap; ++i) tgrid_out[i] = grid[i];
-    return loss_grad_impl(h, "cnf_loss_grad_adaptive", CNF_ALG_TSIT5, (int)grid.size() - 1, 0.f, 0.f, grid.data(), x, eps, ys, B,
-                          lambdas, grad, grad_x, sums4, stream, pc.u_final ? &pc : nullptr);
+    // (with prepared state / checkpoints the serving handle is called directly: loss_grad_impl's own delegation carries none)
+    return loss_grad_impl(srv ? srv : h, "cnf_loss_grad_adaptive", CNF_ALG_TSIT5, (int)grid.size() - 1, 0.f, 0.f, grid.data(), x, eps, ys, B,
+                          lambdas, grad, grad_x, sums4, stream, (srv && pc.u_final) ? &pc : nullptr);
 }
 
 }  // extern "C"

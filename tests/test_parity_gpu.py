@@ -2961,7 +2961,8 @@ def test_default_solver_on_the_device_is_the_host_policy(kw, B, tol, dt0, pkg, o
     (dict(nvars=5, naug=2, ncond=3, hidden=[32, 32], act=2, reg_z=True), 300, 1e-4),                        # conditioned, zero-padded instance
     (dict(nvars=2, hidden=[32, 32]), 20000, 1e-4),                                                          # 1250 tiles: several waves per workgroup
     (dict(nvars=8, hidden=[64, 64, 64]), 40000, 1e-4),                                                      # beyond the one-launch kernel: the host loop's fused attempts fill the slots
-    (dict(nvars=10, naug=11, hidden=[88, 88], act=2, reg_z=True, reg_j=True, reg_aug=True), 500, 1e-4),     # slab-accumulator kernel (default architecture, nvariables = 10): the loss terms from the solve's final state
+    (dict(nvars=10, naug=11, hidden=[88, 88], act=2, reg_z=True, reg_j=True, reg_aug=True), 500, 1e-4),     # slab-accumulator kernel (default architecture, nvariables = 10): it reads the solve's checkpoints, 8 state k-steps wide
+    (dict(nvars=8, hidden=[64, 64, 64], mode=1, reg_z=True), 700, 1e-4),                                    # JVP mode: the solve on the tangent engine, the sweep on the VJP twin
 ])
 def test_adaptive_solve_writes_the_checkpoints_of_its_own_gradient(kw, B, tol, pkg, oracles, monkeypatch):
     """cnf_loss_grad_adaptive (round 5): where the frozen-grid gradient is the fused per-wave sweep, the one-launch adaptive Tsit5
