@@ -234,8 +234,16 @@ static int loss_grad_impl(cnf_handle* h, const char* who, int alg, int nsteps, f
         // them unless CNF_LAYERED_LOSS_BY_SOLVE asks for a separate solve; the slab kernel needs that solve)
         const bool use_cg = route.use_cg_aux;
         const bool loss_in_sweep = sums4 && (route.path == 3 || (route.path == 2 && !tuning().layered_loss_by_solve));
+        // slab-accumulator kernel on uniform steps: ONE forward solve serves both the loss terms and - through its checkpoints, in the
+        // forward instance's layout, kept behind the loss workspace - the kernel, which then runs no forward sweep of its own
+        const bool slab_shared = route.slab && !tgrid && sums4 && tuning().adaptive_ckpt != 0 && h->path == CNF_PATH_MFMA && h->plan &&
+                                 mfma_plan_is_per_wave(h->plan) && h->par.packed_dev;
+        const size_t sh_zslot = slab_shared ? (size_t)((B + 15) / 16) * 64 * (size_t)mfma_plan_zr(h->plan) : 0;
+        const int sh_stages = alg == CNF_ALG_RK4 ? 4 : 6;
+        const size_t sh_head = ((size_t)h->S + 4) * (size_t)B;
+        const float *sh_ckpt = nullptr, *sh_ckpt_k = nullptr;
         if (sums4) {
-            const size_t need = ((size_t)h->S + 4) * (size_t)B * sizeof(float);
+            const size_t need = (sh_head + (slab_shared ? (size_t)((sh_stages + 1) * nsteps + 1) * sh_zslot : 0)) * sizeof(float);
             if (need > h->grad.ws_bytes) {
                 if (h->grad.ws) HIP_TRY(hipFree(h->grad.ws));
                 h->grad.ws = nullptr; h->grad.ws_bytes = 0;
@@ -257,6 +265,16 @@ static int loss_grad_impl(cnf_handle* h, const char* who, int alg, int nsteps, f
                 rc = api_integrate_grid(h, alg, nsteps, tgrid, u, eps, ys, B, st);
                 if (rc) return rc;
                 HIP_TRY(epilogue(u, h->cfg.nvars, h->D, ra0, B, logp, regs, st));
+            } else if (slab_shared) {
+                float* ck = h->grad.ws + sh_head;
+                float* ckk = ck + (size_t)(nsteps + 1) * sh_zslot;
+                SolveArgs a{};
+                a.x = x; a.eps = eps; a.ys = ys; a.B = B; a.nsteps = nsteps; a.alg = alg; a.t0 = t0; a.t1 = t1;
+                a.logp = logp; a.regs = regs; a.nvars = h->cfg.nvars;
+                a.reg_aug = (h->cfg.mode != CNF_MODE_EXACT && h->cfg.reg_aug && h->cfg.naug > 0) ? 1 : 0;
+                a.ckpt = ck; a.ckpt_k = ckk;
+                HIP_TRY(mfma_solve(h->plan, h->par.packed_dev, a, st));
+                sh_ckpt = ck; sh_ckpt_k = ckk;
             } else {
                 rc = cnf_inference_fixed(h, alg, nsteps, t0, t1, x, eps, ys, B, logp, regs, nullptr, stream);
                 if (rc) return rc;
@@ -282,8 +300,11 @@ static int loss_grad_impl(cnf_handle* h, const char* who, int alg, int nsteps, f
                 h->grad.slab_ws_floats = need;
             }
             const bool pre = pc && pc->cap > 0 && pc->ckpt && pc->ckpt_k && tgrid;
+            const float* pk = pre ? pc->ckpt : sh_ckpt;
+            const float* pkk = pre ? pc->ckpt_k : sh_ckpt_k;
+            const int pzr = pre ? pc->zr : (sh_ckpt ? mfma_plan_zr(h->plan) : 0);
             HIP_TRY(grad_slab_launch(h->cfg, h->grad.slab_packed, x, eps, ys, h->par.w_off.data(), h->par.b_off.data(), alg, nsteps, t0, t1, tgrid_dev, B, lam,
-                                     h->grad.slab_ws, grad, grad_x, h->num_cus, st, pre ? pc->ckpt : nullptr, pre ? pc->ckpt_k : nullptr, pre ? pc->zr : 0));
+                                     h->grad.slab_ws, grad, grad_x, h->num_cus, st, pk, pkk, pzr));
             return CNF_OK;
         }
         std::string msg;

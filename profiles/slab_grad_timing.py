@@ -12,15 +12,17 @@ for nv in (7, 8, 10, 12, 15):
         X = torch.randn(B, nv, device=dev).t(); P = ps.to(dev); E = torch.randn(B, icnf.D, device=dev).t()
         m = pkg.TrainMode(True)
         r = {}
-        for name, env in (("slab", None), ("layered", "1")):
-            if env: os.environ["CNF_GRAD_LAYERED"] = env; pkg.reload_tuning()
-            else: os.environ.pop("CNF_GRAD_LAYERED", None); pkg.reload_tuning()
+        for name, env in (("slab", None), ("slab_own_forward", "ckpt0"), ("layered", "1")):   # slab: one forward solve for loss terms and checkpoints (round 5)
+            os.environ.pop("CNF_GRAD_LAYERED", None); os.environ.pop("CNF_ADAPTIVE_CKPT", None)
+            if env == "1": os.environ["CNF_GRAD_LAYERED"] = "1"
+            if env == "ckpt0": os.environ["CNF_ADAPTIVE_CKPT"] = "0"
+            pkg.reload_tuning()
             fn = lambda: pkg.loss_and_gradient(icnf, m, X, P, st, eps=E)
             fn(); torch.cuda.synchronize()
             t0 = time.perf_counter()
             for _ in range(3): v, g = fn()
             torch.cuda.synchronize()
             r[name + "_ms"] = round(1e3 * (time.perf_counter() - t0) / 3, 2)
-        os.environ.pop("CNF_GRAD_LAYERED", None); pkg.reload_tuning()
+        os.environ.pop("CNF_GRAD_LAYERED", None); os.environ.pop("CNF_ADAPTIVE_CKPT", None); pkg.reload_tuning()
         out[f"nv{nv}_B{B}"] = r
 print(json.dumps(out))
