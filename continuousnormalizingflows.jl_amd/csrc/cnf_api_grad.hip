@@ -42,9 +42,14 @@ bool cnf::api_grad_is_fused(const cnf_handle* h) {
 
 // slab-accumulator kernel for the mid-width two-hidden-layer nets (CNF_GRAD_LAYERED=1 skips it too)
 extern "C++" {
-// batches from which the cooperative reverse sweep beats the slab kernel on the shapes that have both (86 -> 80 ms at 2 x 104,
-// 106 -> 84 ms at 2 x 128, B = 65 536; the sweep's 40 + 160 launches per gradient need columns to amortise)
-bool cnf::api_grad_uses_coop_aux(const cnf_handle* h, int64_t B) { return h->grad.plan_cg && h->grad.cg_packed && B >= 4096; }
+// the cooperative reverse sweep beats the slab kernel on the shapes that have both at every batch size: 86 -> 80 ms at 2 x 104,
+// 106 -> 84 ms at 2 x 128, B = 65 536 (round 3, which set a threshold of 4096 columns for the sweep's 40 + 160 launches to
+// amortise) - and, measured in round 5, 12.4 -> 7.4 ms at nvariables = 12 / 13 and 18.2 -> 8.4 ms at 14 / 15 at B = 1024 (64 ... 4000
+// columns alike: the slab kernel is one wave per 16-sample tile, a latency chain; profiles/r5/r5y_mid_width_small_batches.json)
+bool cnf::api_grad_uses_coop_aux(const cnf_handle* h, int64_t B) {
+    const int sw = tuning().coop_grad_mid;   // > 1: a threshold in columns (A/B runs, tests of the slab kernel below it)
+    return h->grad.plan_cg && h->grad.cg_packed && B >= (sw > 1 ? sw : 1);
+}
 
 bool cnf::api_grad_uses_slab(const cnf_handle* h) {
     return (h->grad.slab_packed || !h->par.have) && grad_slab_supported(h->cfg) && tuning().grad_layered == 0;

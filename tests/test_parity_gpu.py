@@ -1066,8 +1066,8 @@ def test_mid_width_gradient_takes_the_cooperative_sweep_at_large_batches(kw, pkg
         assert np.max(np.abs(out[tag][1] - gref)) < 5e-5 * np.abs(gref).max() + 1e-6, tag
         assert np.max(np.abs(out[tag][2] - gxref)) < 5e-5 * np.abs(gxref).max() + 1e-7, tag
     assert np.max(np.abs(out["aux"][1] - out["slab"][1])) > 0.0      # two implementations, two summation orders
-    # below the threshold the same handle serves the slab kernel
-    setsw(pkg, monkeypatch, "CNF_COOP_GRAD_MID", "1")
+    # below a threshold given in columns (round 5: the default is every batch size) the same handle serves the slab kernel
+    setsw(pkg, monkeypatch, "CNF_COOP_GRAD_MID", "4096")
     icnf = make_icnf(pkg, spec, alg, nsteps, path=0, lambdas=lam)
     val, g = pkg.loss_and_gradient(icnf, mode, dev(xs[:, :300]), dev(p), {}, eps=dev(eps[:, :300]))
     setsw(pkg, monkeypatch, "CNF_COOP_GRAD_MID", "0")
@@ -1150,12 +1150,13 @@ def test_parameter_gradient_slab_kernel(kw, lam, B, alg, nsteps, pkg, oracles, m
     """The mid-width two-hidden-layer nets (the reference's default architecture for 7..11 variables): parameters and
     data gradients against fp64 autograd, and against the layer-wise path on the same inputs."""
     o64, _ = oracles
+    setsw(pkg, monkeypatch, "CNF_COOP_GRAD_MID", "0")       # (7 - 8 hidden tiles otherwise take the auxiliary cooperative sweep: round 5)
     spec = o64.make_spec(**kw)
     p, xs, eps, ys = o64.synth_inputs(spec, B, 222, bias_scale=0.2)
     L, gref, gxref = o64.loss_and_grad(spec, p, xs, 0.0, 1.0, nsteps, alg, eps, ys, lam, wrt_x=True)
     icnf = make_icnf(pkg, spec, alg, nsteps, path=0, lambdas=lam)
     mode = pkg.TrainMode(bool(spec.reg_z or spec.reg_j or spec.reg_aug))
-    assert icnf.grad_path(mode) == 1
+    assert icnf.grad_path(mode) == 1 and icnf.grad_path(mode, B=B, alg=alg) == 1
     cargs = (dev(xs),) + ((dev(ys),) if spec.ncond else ()) + (dev(p), {})
     val, g, gx = pkg.loss_and_gradient(icnf, mode, *cargs, eps=dev(eps), wrt_x=True)
     assert abs(float(val) - L) < 1e-4
