@@ -2303,7 +2303,7 @@ def test_adaptive_tsit5_follows_the_oracle_restatement(kw, tol, pkg, oracles):
     (dict(nvars=8, hidden=[64, 64, 64], reg_z=True, reg_j=True), (0.02, 0.03, 0.0), 1),     # register-accumulator kernel
     (dict(nvars=8, hidden=[64, 64, 64], nprobes=3, reg_j=True), (0.0, 0.03, 0.0), 1),       # several-probe kernel
     (dict(nvars=4, naug=5, ncond=2, hidden=[40, 40], act=2, reg_z=True), (0.02, 0.0, 0.0), 1),   # default-style net, conditioned
-    (dict(nvars=10, hidden=[72, 72], act=2, reg_z=True, reg_j=True), (0.02, 0.03, 0.0), 1),  # slab-accumulator kernel
+    (dict(nvars=10, hidden=[72, 72], act=2, reg_z=True, reg_j=True), (0.02, 0.03, 0.0), 1),  # slab shape (at this batch size: its auxiliary cooperative sweep)
     (dict(nvars=3, naug=2, ncond=2, hidden=[24, 48, 24], act=2, nprobes=2, reg_aug=True), (0.0, 0.0, 0.05), 2),   # layer-wise path
     # the cooperative gradient on a frozen grid: the extended kernel checkpoints on the caller's step times
     (dict(nvars=16, naug=17, hidden=[136, 136], act=2, reg_z=True, reg_j=True, reg_aug=True), (0.01, 0.01, 0.01), 3),   # ICNF(nvariables = 16), default lambdas
@@ -2333,7 +2333,8 @@ def test_gradient_of_the_adaptive_solve_on_its_frozen_grid(kw, lam, gpath, pkg, 
     val, g, gx = pkg.loss_and_gradient(icnf, mode, *args, eps=dev(eps), wrt_x=True)
     assert icnf.grad_path(mode) == gpath
     ts = icnf.last_solve_stats["tgrid"]
-    assert icnf.grad_path(mode, B=B, alg=1, on_grid=True) == gpath   # cnf_grad_path_for: what this call took
+    # cnf_grad_path_for: what this call took (the slab shape of 5 hidden tiles: the auxiliary cooperative sweep up to 4096 columns, round 5)
+    assert icnf.grad_path(mode, B=B, alg=1, on_grid=True) == (3 if kw["hidden"] == [72, 72] else gpath)
     assert len(ts) >= 5 and ts[0] == 0.0 and ts[-1] == 1.0 and len(set(np.round(np.diff(ts), 6))) > 1   # non-uniform
     L, gref, gxref = o64.loss_and_grad(spec, p, xs, 0.0, 1.0, len(ts) - 1, 1, eps, ys, lam, wrt_x=True, tgrid=ts)
     assert abs(float(val) - L) < 1e-4 + 2e-6 * abs(L)       # (a loss of 300 has a Float32 ulp of 3e-5)
@@ -2971,6 +2972,7 @@ def test_adaptive_solve_writes_the_checkpoints_of_its_own_gradient(kw, B, tol, p
     gradient needs no forward pass of its own.  Against the same call with its own step-by-step forward pass (CNF_ADAPTIVE_CKPT=0):
     the same grid; the two forward passes differ by an ulp in t and dt per step, so loss and gradient agree to 1e-5."""
     o64, _ = oracles
+    setsw(pkg, monkeypatch, "CNF_COOP_GRAD_MID", "0")       # (the slab case: 5 - 8 hidden tiles otherwise take the auxiliary cooperative sweep)
     spec = o64.make_spec(**kw)
     p, xs, eps, ys = o64.synth_inputs(spec, B, 17, bias_scale=0.2)
     out = {}
