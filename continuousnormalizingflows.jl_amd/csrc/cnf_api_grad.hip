@@ -46,13 +46,14 @@ extern "C++" {
 // 106 -> 84 ms at 2 x 128, B = 65 536 (round 3, which set a threshold of 4096 columns for the sweep's 40 + 160 launches to
 // amortise) - and, measured in round 5, 12.4 -> 7.4 ms at nvariables = 12 / 13 and 18.2 -> 8.4 ms at 14 / 15 at B = 1024 (64 ... 4000
 // columns alike: the slab kernel is one wave per 16-sample tile, a latency chain; profiles/r5/r5y_mid_width_small_batches.json)
-// 5 - 6 hidden tiles (nvariables = 8 ... 11, on the 8-tile instance): the sweep wins up to ~8 k columns (B = 1024: 9.0 -> 6.4 ms at
-// nvariables = 10), the slab kernel beyond (B = 65 536: 47.7 against 55.1 ms) - the auxiliary plan serves them up to 4096 columns.
+// 5 - 6 hidden tiles (nvariables = 8 ... 11, on the 8-tile instance): the sweep wins up to 8192 columns = two 16-sample super-tiles per
+// CU (B = 1024: 9.0 -> 6.4 ms at nvariables = 10; 8192: 11.4 -> 8.3), the slab kernel beyond (10 240: 11.6 against 13.1 ms; 65 536:
+// 47.7 against 55.1) - the auxiliary plan serves them up to 8192 columns.
 bool cnf::api_grad_uses_coop_aux(const cnf_handle* h, int64_t B) {
     if (!h->grad.plan_cg || !h->grad.cg_packed || B < 1) return false;
     const int sw = tuning().coop_grad_mid;   // > 1: "from sw columns on" (A/B runs, tests of the slab kernel below it)
     if (sw > 1) return B >= sw;
-    return h->cfg.widths[1] > 96 || B <= 4096;
+    return h->cfg.widths[1] > 96 || B <= 8192;
 }
 
 bool cnf::api_grad_uses_slab(const cnf_handle* h) {

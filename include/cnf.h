@@ -121,7 +121,7 @@ typedef struct cnf_tuning {
     int32_t coopd;                 /* CNF_COOPD, default 1: dealt cooperative kernels (csrc/cnf_coop_d*.hip): 1 above 4096 columns where they serve the plan; 0 off; 2 at every batch */
     int32_t coopd_grad;            /* CNF_COOPD_GRAD, default 1: dealt reverse sweep (csrc/cnf_coop_dgrad.hip): 1 where it has an instance; 0 off (section 8.4's sweep); 2 forced */
     int32_t coop_grad;             /* CNF_COOP_GRAD, default 1: cooperative reverse sweep (gradient path 3); 0: those shapes train layer-wise */
-    int32_t coop_grad_mid;         /* CNF_COOP_GRAD_MID, default 1: auxiliary cooperative plan for the gradient of the slab shapes of 5 - 8 hidden tiles (7 - 8: every batch size, 5 - 6: up to 4096 columns); N > 1: from N columns on; 0 off */
+    int32_t coop_grad_mid;         /* CNF_COOP_GRAD_MID, default 1: auxiliary cooperative plan for the gradient of the slab shapes of 5 - 8 hidden tiles (7 - 8: every batch size, 5 - 6: up to 8192 columns); N > 1: from N columns on; 0 off */
     int32_t grad_layered;          /* CNF_GRAD_LAYERED, default 0: 1: every gradient takes the layer-wise path (A/B, cross-checks) */
     int32_t jvp_grad_twin;         /* CNF_JVP_GRAD_TWIN, default 1: JVP mode without the |J eps| regulariser trains through the VJP mode's fused sweeps; 0: its own layer-wise gradient */
     int32_t probe_grad_twin;       /* CNF_PROBE_GRAD_TWIN, default 1: K > 1 probes on two hidden layers whose own gradient is layer-wise train probe by probe on the one-probe cooperative sweep; 2: three hidden layers too (slower there); 0: never */

@@ -33,11 +33,13 @@ for env in ("1", "0"):
                       device=dev, sol_kwargs=dict(alg=pkg.Tsit5(), reltol=1e-4, abstol=1e-4))
         res[f"d8_3x64_{B}"] = dict(ms=timed(lambda: pkg.loss_and_gradient(ic, pkg.TrainMode(False), X, P, {}, eps=E)), steps=ic.last_solve_stats["naccept"])
     # default architecture at nvariables = 10 (slab-accumulator gradient: only the separate loss solve over the grid goes)
+    os.environ["CNF_COOP_GRAD_MID"] = "0"; pkg.reload_tuning()     # (the slab kernel itself: at this size the default is the auxiliary cooperative sweep)
     r10 = torch.randn(10, 8192, device=dev)
     ic10 = pkg.ICNF(nvariables=10, device=dev, sol_kwargs=dict(alg=pkg.Tsit5(), reltol=1e-4, abstol=1e-4))
     ps10, st10 = pkg.setup(torch.Generator().manual_seed(0), ic10); ps10 = ps10.to(dev)
     res["default_nv10_8192"] = dict(ms=timed(lambda: pkg.loss_and_gradient(ic10, pkg.TrainMode(True), r10, ps10, st10)), steps=ic10.last_solve_stats["naccept"],
                                     grad_path=ic10.grad_path(pkg.TrainMode(True), B=8192, alg=1, on_grid=True))
+    os.environ.pop("CNF_COOP_GRAD_MID", None); pkg.reload_tuning()
     out["solve_writes_checkpoints" if env == "1" else "own_forward_pass"] = res
 os.environ.pop("CNF_ADAPTIVE_CKPT", None)
 print(json.dumps(out))

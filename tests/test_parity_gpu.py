@@ -2333,7 +2333,7 @@ def test_gradient_of_the_adaptive_solve_on_its_frozen_grid(kw, lam, gpath, pkg, 
     val, g, gx = pkg.loss_and_gradient(icnf, mode, *args, eps=dev(eps), wrt_x=True)
     assert icnf.grad_path(mode) == gpath
     ts = icnf.last_solve_stats["tgrid"]
-    # cnf_grad_path_for: what this call took (the slab shape of 5 hidden tiles: the auxiliary cooperative sweep up to 4096 columns, round 5)
+    # cnf_grad_path_for: what this call took (the slab shape of 5 hidden tiles: the auxiliary cooperative sweep up to 8192 columns, round 5)
     assert icnf.grad_path(mode, B=B, alg=1, on_grid=True) == (3 if kw["hidden"] == [72, 72] else gpath)
     assert len(ts) >= 5 and ts[0] == 0.0 and ts[-1] == 1.0 and len(set(np.round(np.diff(ts), 6))) > 1   # non-uniform
     L, gref, gxref = o64.loss_and_grad(spec, p, xs, 0.0, 1.0, len(ts) - 1, 1, eps, ys, lam, wrt_x=True, tgrid=ts)
