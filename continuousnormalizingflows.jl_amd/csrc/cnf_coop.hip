@@ -46,7 +46,11 @@ __device__ __forceinline__ void coop_eval(const float* __restrict__ P, const flo
                                           f32x4* __restrict__ zbuf, const f32x4* __restrict__ ebuf, f32x4* __restrict__ pbuf,
                                           int lane, int wave, float t, bool autonomous, bool reg_z,
                                           bool reg_j, const float (&zs)[ZR],
-                                          float (&zd)[ZR], float& ld, float& ed, float& nd, float* __restrict__ gout = nullptr, int KHa = 0) {
+                                          float (&zd)[ZR], float& ld, float& ed, float& nd, float* __restrict__ gout = nullptr, int KHa = 0,
+                                          f32x4* __restrict__ fsb = nullptr, long long fsl = 0) {
+    // fsb (checkpointing form, round 6): the stage store of the second-order reverse sweep (cnf_tiles.h) - every h_l and delta_l tile
+    // of this stage leaves for HBM as the wave that computed it holds it (tile-native: one 16-byte store per lane); fsb points at
+    // this super-tile's first tile of (kind h, layer 0), `fsl` f32x4 separate consecutive (kind, layer) arrays
     constexpr MfmaLayout LAY(HT, L, ZR, 0, true);
     // hidden k-groups that are not zero padding (even): a width that fills fewer 16-row tiles than the instance has skips the rest
     const int KH = (KHa > 0 && KHa < HT) ? ((KHa + 1) & ~1) : HT;
@@ -116,6 +120,9 @@ __device__ __forceinline__ void coop_eval(const float* __restrict__ P, const flo
                 if (!(D_FROM_H && l == L - 1 && L > 1)) d[l < LD ? l : 0][m][q] = dd;
                 if (SPLITK && l == L - 1) hown[SPLITK ? m : 0] = h;
                 else xbuf[cur * XB + ((mt0 + m) * NT + q) * 64 + lane] = h;
+                if constexpr (GOUT) {
+                    if (fsb) __builtin_nontemporal_store(h, &fsb[(long long)l * fsl + (q * HT + mt0 + m) * 64 + lane]);
+                }
             }
         if constexpr (SPLITK) {
             if (l == L - 1) {   // partial of zdot over this wave's own k-groups
@@ -225,6 +232,12 @@ __device__ __forceinline__ void coop_eval(const float* __restrict__ P, const flo
             }
 #pragma unroll
             for (int q = 0; q < NT; ++q) xbuf[wbuf * XB + ((mt0 + m) * NT + q) * 64 + lane] = dl[q];
+            if constexpr (GOUT) {
+                if (fsb) {
+#pragma unroll
+                    for (int q = 0; q < NT; ++q) __builtin_nontemporal_store(dl[q], &fsb[(long long)(L + l) * fsl + (q * HT + mt0 + m) * 64 + lane]);
+                }
+            }
         }
         if (l == 0 && owner && !SPLITK) coop_load_a<DT>(AIMG(LAY.b1), 0, HT, 0, afd);
         __syncthreads();
@@ -373,8 +386,16 @@ coop_vjp_solve_kernel(KArgs a) {
                 if constexpr (CK) {
                     if (a.ckpt_g) gout = a.ckpt_g + ((((long long)step * ns + sg) * nst * NT + st * NT + wave) * 64 + lane) * ZR;
                 }
+                f32x4* fsb = nullptr;
+                long long fsl = 0;
+                if constexpr (CK) {
+                    if (a.kfull) {   // (the checkpointing form's use of KArgs::kfull: base of the stage store, cnf_tiles.h)
+                        fsl = (long long)nsteps * ns * nst * NT * HT * 64;
+                        fsb = reinterpret_cast<f32x4*>(a.kfull) + ((((long long)step * ns + sg) * nst + st) * NT) * HT * 64;
+                    }
+                }
                 coop_eval<HT, L, ZR, ACT, NT, WL, CK>(a.packed, wl, xbuf, zbuf, ebuf, pbuf, lane, wave, tn + a.T.c[sg] * dt, autonomous,
-                                          reg_z, reg_j, zs, zd, ld, ed, nd, gout, a.KH);
+                                          reg_z, reg_j, zs, zd, ld, ed, nd, gout, a.KH, fsb, fsl);
                 if constexpr (CK) {
                     if (owner) {
 #pragma unroll

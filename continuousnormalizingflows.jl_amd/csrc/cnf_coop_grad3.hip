@@ -1,0 +1,615 @@
+// cnf_coop_grad3.hip - the SECOND-ORDER reverse sweep of the cooperative gradient (round 6).
+//
+// Reference: the parameter gradient of `loss` through the fixed-step solve (Zygote through SciMLBase.solve with QuadratureAdjoint +
+// ZygoteVJP, src/core/icnf.jl:90-99, driven by src/exts/mlj_ext/core_icnf.jl:42-51); the mathematics is DESIGN.md section 8 /
+// cnf_coop_grad.hip's header.
+//
+// The sweeps of rounds 3 - 5 (cnf_coop_grad.hip, cnf_coop_dgrad.hip) RECOMPUTE, per stage, the forward chain h_l and the
+// first-order pullback delta_l - the two chains the forward solve has just run - beside the two second-order chains that need
+// them: half of a stage's H x H products are repeats, and every operand of the deferred weight-cotangent products (X_l =
+// [delta_l | sbar_l], Y_l = [vbar_l | h_l]) leaves through an LDS transposition.  Here the forward solve STORES h_l and delta_l of
+// every stage as it computes them (tile-native, cnf_tiles.h: 2 L H floats per sample and stage - 32 GB at cfg4, a sixth of one
+// GPU's HBM, written under a compute-bound kernel), and this kernel runs the second-order chains alone:
+//     up:    dbar_1 = W_1[:,0:D] gbar,   vbar_l = dbar_l .* act'(h_l),   dbar_{l+1} = W_{l+1} vbar_l
+//     top:   hbar_L = W_N^T kbar
+//     down:  sbar_l = hbar_l .* act'_l + dbar_l .* G(h_l, delta_l),   hbar_{l-1} = W_l^T sbar_l,   Zbar = W_1[:,0:D]^T sbar_1
+//            (G = delta act'' / act':  tanh -2 h delta,  softplus delta (1 - act'))
+// Every product is ONE chain over a 32-sample super-tile (two column tiles per weight fragment, as the two-chain products of the
+// older sweeps), no activation is evaluated (act' comes from h: an FMA for tanh, one v_exp for softplus), vbar_l and sbar_l leave
+// for the cotangent products straight from the registers that hold them (cnf_wgrad_tiles.hip reads tiles), and the other half of
+// those products' operands is the forward solve's store.  Per stage and sample: 4 (L - 1) H^2 + 8 H D multiply-adds instead of
+// 8 (L - 1) H^2 + 16 H D.
+//
+// Organisation (cnf_coop_dgrad.hip's): a workgroup of four waves, one per SIMD with the whole register file, owns a super-tile;
+// the real hidden tiles HT = 4 A + b are dealt - wave w takes tiles [w A, (w + 1) A) with both column tiles, the b left-over
+// tiles go one each to waves 3, 2, 1; waves 0 and 1 own the two sample tiles (dense D-row state, Runge-Kutta adjoint); Zbar is
+// split along K by ownership (every wave multiplies the sbar_1 tiles it has just produced); h_l and dbar_l of the lower layers wait
+// in accumulation registers between the way up and the way down.  Barriers order LDS traffic only.
+#define CNF_NO_PK_ASM 1
+#define CNF_NO_PHASE_FENCE 1
+#include "cnf_coop_d_dev.h"
+#include "cnf_tiles.h"
+
+#define G3_SYNC()                                                       \
+    do {                                                                \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local"); \
+        __builtin_amdgcn_s_barrier();                                   \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local"); \
+    } while (0)
+
+namespace cnf {
+
+struct G3Args {
+    CG3Args c;
+    DImg g;
+};
+
+namespace {
+
+template <int A>
+struct G3U {                 // this wave's units of one chain: shared tiles x 2 sample tiles, the left-over tile x 2 sample tiles
+    f32x4 S[A][2];
+    f32x4 R[2];
+};
+template <int A>
+struct G3Off { unsigned S[A]; unsigned Rr; };
+
+template <int A>
+__device__ __forceinline__ G3Off<A> g3_offsets(const DRs& R, int KP, int mtS0, int tR) {
+    G3Off<A> t;
+#pragma unroll
+    for (int m = 0; m < A; ++m) { t.S[m] = R.lane16 + (unsigned)((mtS0 + m) * KP) * 1024u; asm volatile("" : "+v"(t.S[m])); }
+    t.Rr = R.lane16 + (unsigned)(tR * KP) * 1024u; asm volatile("" : "+v"(t.Rr));
+    return t;
+}
+template <int A, bool LO>
+__device__ __forceinline__ void g3_load_a(const DRs& R, const G3Off<A>& T, unsigned img, int kg, f32x4 (&aS)[A], f32x4& aR) {
+    const unsigned so = img + (unsigned)kg * 1024u;
+#pragma unroll
+    for (int m = 0; m < A; ++m) aS[m] = dloadv(R, T.S[m], so);
+    if constexpr (LO) aR = dloadv(R, T.Rr, so);
+}
+__device__ __forceinline__ void g3_load_b(const f32x4* __restrict__ bimg, int kg, int lane, f32x4 (&bq)[2]) {
+    bq[0] = bimg[(kg * 2 + 0) * 64 + lane];
+    bq[1] = bimg[(kg * 2 + 1) * 64 + lane];
+}
+template <int A, bool LO, int JN>
+__device__ __forceinline__ void g3_mfma(const f32x4 (&aS)[A], const f32x4& aR, const f32x4 (&bq)[2], bool v0, G3U<A>& u) {
+#pragma unroll
+    for (int j = 0; j < JN; ++j)
+#pragma unroll
+        for (int m = 0; m < A; ++m)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) u.S[m][c] = mfma4(aS[m][j], bq[c][j], u.S[m][c]);
+    if constexpr (LO) {
+        if (v0) {
+#pragma unroll
+            for (int j = 0; j < JN; ++j)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) u.R[c] = mfma4(aR[j], bq[c][j], u.R[c]);
+        }
+    }
+}
+template <int A, bool LO>
+__device__ __forceinline__ void g3_mfma_rem(const f32x4 (&aS)[A], const f32x4& aR, const f32x4 (&bq)[2], bool v0, int rem, G3U<A>& u) {
+    if (rem == 4) g3_mfma<A, LO, 4>(aS, aR, bq, v0, u);
+    else if (rem == 3) g3_mfma<A, LO, 3>(aS, aR, bq, v0, u);
+    else if (rem == 2) g3_mfma<A, LO, 2>(aS, aR, bq, v0, u);
+    else g3_mfma<A, LO, 1>(aS, aR, bq, v0, u);
+}
+// u += A(image) * B(LDS image: [k-group][2 column tiles][64 lanes]) over KG k-groups, the last one with `rem` k-steps; aS0 / aR0
+// arrive holding the fragments of k-group 0.  Two fragment sets ping-pong, one k-group of lead.
+template <int A, bool LO>
+__device__ __forceinline__ void g3_gemm(const DRs& R, const G3Off<A>& T, unsigned img, int KG, int rem, bool v0,
+                                        const f32x4* __restrict__ bimg, int lane, f32x4 (&aS0)[A], f32x4& aR0, G3U<A>& u) {
+    f32x4 aS1[A], aR1 = {0.f, 0.f, 0.f, 0.f}, bq0[2], bq1[2];
+    g3_load_b(bimg, 0, lane, bq0);
+    const int KGf = KG - 1;
+    int kg = 0;
+#pragma clang loop unroll(disable)
+    for (; kg + 2 <= KGf; kg += 2) {
+        g3_load_a<A, LO>(R, T, img, kg + 1, aS1, aR1);
+        g3_load_b(bimg, kg + 1, lane, bq1);
+        g3_mfma<A, LO, 4>(aS0, aR0, bq0, v0, u);
+        g3_load_a<A, LO>(R, T, img, kg + 2, aS0, aR0);
+        g3_load_b(bimg, kg + 2, lane, bq0);
+        g3_mfma<A, LO, 4>(aS1, aR1, bq1, v0, u);
+    }
+    if (kg < KGf) {
+        g3_load_a<A, LO>(R, T, img, KG - 1, aS1, aR1);
+        g3_load_b(bimg, KG - 1, lane, bq1);
+        g3_mfma<A, LO, 4>(aS0, aR0, bq0, v0, u);
+        g3_mfma_rem<A, LO>(aS1, aR1, bq1, v0, rem, u);
+    } else {
+        g3_mfma_rem<A, LO>(aS0, aR0, bq0, v0, rem, u);
+    }
+}
+
+// G = delta act'' / act'  (so that  a2 .* act'' = dbar .* u .* act'' = dbar .* G  with delta = u .* act'):  tanh: act'' = -2 h act';
+// softplus: act'' = act' (1 - act')
+template <int ACT>
+__device__ __forceinline__ f32x4 g3_G(const f32x4& h, const f32x4& dl, const f32x4& d) {
+    if constexpr (ACT == CNF_ACT_SOFTPLUS) return dl * (1.f - d);
+    else return h * dl * -2.f;
+}
+
+}  // namespace
+
+// LDS: two exchange buffers [HT][2][64] (the partial tiles of Zbar alias the first), the gbar and kbar images [DT][2][64], C vectors
+// are not needed (no bias enters a second-order chain)
+constexpr int coop_grad3_lds_bytes(int HT, int DT) {
+    const int part = 4 * DT * 2;                       // [4 waves][DT][2] partial tiles
+    const int x0 = HT * 2 > part ? HT * 2 : part;
+    return (x0 + HT * 2 + 2 * DT * 2) * 64 * 16;
+}
+
+// A: shared hidden tiles per wave; LO: the instance serves left-over tiles (HT = 4 A + b, b run-time); L: hidden layers;
+// KZ: state registers per lane (D <= 4 KZ, whole M-tiles); NS: stages of the instance
+template <int A, bool LO, int L, int KZ, int ACT, int NS>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+coop_grad3_step_kernel(G3Args ga) {
+    static_assert(ACT == CNF_ACT_TANH_PRESCALED || ACT == CNF_ACT_SOFTPLUS, "act' and act'' are rebuilt from h: tanh and softplus");
+    static_assert(KZ % 4 == 0, "state registers in whole M-tiles");
+    static_assert(L == 2 || L == 3, "two or three hidden layers");
+    const CGArgs& a = ga.c.c;
+    const CG3Args& q3 = ga.c;
+    const DImg& G = ga.g;
+    constexpr int DT = KZ / 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int HT = 4 * A + G.b;
+    const int X0N = (HT * 2 > 4 * DT * 2 ? HT * 2 : 4 * DT * 2) * 64;
+    f32x4* X0 = reinterpret_cast<f32x4*>(smem);        // [HT][2][64]; the partial tiles [4 waves][DT][2][64] alias it
+    f32x4* X1 = X0 + X0N;                              // [HT][2][64]
+    f32x4* gbuf = X1 + HT * 2 * 64;                    // [DT][2][64]: gbar
+    f32x4* kbuf = gbuf + DT * 2 * 64;                  // [DT][2][64]: kbar
+    f32x4* pbuf = X0;
+    const int lane = threadIdx.x & 63, g = lane >> 4, n = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool owner = wave < 2;
+    const int D = a.D;
+    const long long B = a.B;
+    const long long nst = a.ntiles_pad / 2;   // every 32-sample pair of the checkpoint arrays' tiles: the pairs behind the batch write zeros the cotangent products read
+    const DRs R0{__builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.packed), 0, 0x7fffffff, 0x00020000), (unsigned)lane * 16u};
+    const float inv_fs = ACT == CNF_ACT_TANH_PRESCALED ? 1.f / kTanhPrescale : 1.f;   // the forward images of tanh nets carry the pre-scale
+    const int ns = a.T.ns < NS ? a.T.ns : NS;
+    const float dt = a.dt, tn = a.tn;
+    const int ckzr = G.ckzr;
+    // this wave's left-over tile (b of them, one each to waves 3, 2, 1; clamped for the loads)
+    const int un = 3 - wave;
+    const bool v0 = LO && un < G.b;
+    const int tR = (4 * A + un < HT - 1) ? 4 * A + un : HT - 1;
+    const int mtS0 = wave * A;
+    const G3Off<A> TZ = g3_offsets<A>(R0, G.KPZ, mtS0, tR);
+    const G3Off<A> TH = g3_offsets<A>(R0, G.HTP, mtS0, tR);
+    unsigned vd[DT];
+#pragma unroll
+    for (int dm = 0; dm < DT; ++dm) { vd[dm] = R0.lane16 + (unsigned)(dm * G.HTP) * 1024u; asm volatile("" : "+v"(vd[dm])); }
+    const unsigned F1Z = (unsigned)G.f1z * 4u, FH = (unsigned)G.fh * 4u, BN = (unsigned)G.bN * 4u, BH = (unsigned)G.bh * 4u, B1 = (unsigned)G.b1 * 4u;
+    const unsigned IMGH = (unsigned)G.imgH * 4u;
+    const int HTs = q3.HTs, DTZ = q3.DTZ;
+    const long long ntp = a.ntiles_pad;
+    // byte offsets of this wave's units inside a column-tile PAIR of an [..][ntp][HTs] tile array (sample tile q, hidden tile mt)
+    unsigned uo[A][2], uoR[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+#pragma unroll
+        for (int m = 0; m < A; ++m) { uo[m][c] = (unsigned)lane * 16u + (unsigned)((c * HTs + mtS0 + m) * 1024); asm volatile("" : "+v"(uo[m][c])); }
+        uoR[c] = (unsigned)lane * 16u + (unsigned)((c * HTs + tR) * 1024); asm volatile("" : "+v"(uoR[c]));
+    }
+    const unsigned arr_bytes = (unsigned)((long long)ns * ntp * HTs * 1024);
+    auto rsrc = [&](const float* p) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, (int)arr_bytes, 0x00020000); };
+    auto load_units = [&](const float* arr, unsigned so, G3U<A>& u) {
+        const __amdgpu_buffer_rsrc_t r = rsrc(arr);
+#pragma unroll
+        for (int m = 0; m < A; ++m)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) u.S[m][c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)uo[m][c], (int)so, 0));
+        if constexpr (LO) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c) u.R[c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)uoR[c], (int)so, 0));
+        }
+    };
+    auto store_units = [&](float* arr, unsigned so, const G3U<A>& u) {
+        const __amdgpu_buffer_rsrc_t r = rsrc(arr);
+#pragma unroll
+        for (int m = 0; m < A; ++m)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, u.S[m][c]), r, (int)uo[m][c], (int)so, 2);
+                CNF_STORE_DATA_HAZARD(u.S[m][c]);
+            }
+        if constexpr (LO) {
+            if (v0) {
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, u.R[c]), r, (int)uoR[c], (int)so, 2);
+                    CNF_STORE_DATA_HAZARD(u.R[c]);
+                }
+            }
+        }
+    };
+    auto publish = [&](f32x4* __restrict__ xb, const G3U<A>& v) {
+#pragma unroll
+        for (int m = 0; m < A; ++m)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) xb[((mtS0 + m) * 2 + c) * 64 + lane] = v.S[m][c];
+        if constexpr (LO) {
+            if (v0) { xb[(tR * 2 + 0) * 64 + lane] = v.R[0]; xb[(tR * 2 + 1) * 64 + lane] = v.R[1]; }
+        }
+    };
+    auto zero_u = [&](G3U<A>& u) {
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int m = 0; m < A; ++m) { u.S[m][0] = z; u.S[m][1] = z; }
+        u.R[0] = z; u.R[1] = z;
+    };
+    auto park_u = [&](const G3U<A>& u, G3U<A>& p) {
+#pragma unroll
+        for (int m = 0; m < A; ++m) { p.S[m][0] = park4(u.S[m][0]); p.S[m][1] = park4(u.S[m][1]); }
+        if constexpr (LO) { p.R[0] = park4(u.R[0]); p.R[1] = park4(u.R[1]); }
+    };
+    auto unpark_u = [&](const G3U<A>& p, G3U<A>& u) {
+#pragma unroll
+        for (int m = 0; m < A; ++m) { u.S[m][0] = unpark4(p.S[m][0]); u.S[m][1] = unpark4(p.S[m][1]); }
+        if constexpr (LO) { u.R[0] = unpark4(p.R[0]); u.R[1] = unpark4(p.R[1]); }
+    };
+    // vbar = (acc / fs) .* act'(h); acc <- dbar
+    auto up_ew = [&](G3U<A>& acc, const G3U<A>& h, G3U<A>& vb) {
+        auto one = [&](f32x4& ac, const f32x4& hh, f32x4& v) {
+            ac = ac * inv_fs;
+            v = ac * dact_from_h<ACT>(hh);
+        };
+#pragma unroll
+        for (int m = 0; m < A; ++m) { one(acc.S[m][0], h.S[m][0], vb.S[m][0]); one(acc.S[m][1], h.S[m][1], vb.S[m][1]); }
+        if constexpr (LO) { one(acc.R[0], h.R[0], vb.R[0]); one(acc.R[1], h.R[1], vb.R[1]); }
+    };
+    // sbar = hbar .* act' + dbar .* G(h, delta): in place of hbar
+    auto down_ew = [&](G3U<A>& hb, const G3U<A>& h, const G3U<A>& dl, const G3U<A>& db) {
+        auto one = [&](f32x4& x, const f32x4& hh, const f32x4& dd, const f32x4& bb) {
+            const f32x4 d = dact_from_h<ACT>(hh);
+            x = x * d + bb * g3_G<ACT>(hh, dd, d);
+        };
+#pragma unroll
+        for (int m = 0; m < A; ++m) { one(hb.S[m][0], h.S[m][0], dl.S[m][0], db.S[m][0]); one(hb.S[m][1], h.S[m][1], dl.S[m][1], db.S[m][1]); }
+        if constexpr (LO) { one(hb.R[0], h.R[0], dl.R[0], db.R[0]); one(hb.R[1], h.R[1], dl.R[1], db.R[1]); }
+    };
+    auto publish_dense = [&](f32x4* img, int ct, const float (&v)[KZ]) {
+#pragma unroll
+        for (int kg = 0; kg < DT; ++kg) img[(kg * 2 + ct) * 64 + lane] = f32x4{v[4 * kg], v[4 * kg + 1], v[4 * kg + 2], v[4 * kg + 3]};
+    };
+
+    for (long long st = blockIdx.x; st < nst; st += gridDim.x) {
+        const long long smp0 = st * 32;
+        const long long smp = smp0 + (owner ? wave : 0) * 16 + n;
+        const bool valid = owner && smp < B;
+        const long long sc = smp < B ? smp : B - 1;
+        const long long tile = st * 2 + (owner ? wave : 0);
+        float eps[KZ], zn[KZ], lam[KZ];
+#pragma unroll
+        for (int s = 0; s < KZ; ++s) { eps[s] = 0.f; zn[s] = 0.f; lam[s] = 0.f; }
+        if (owner) {
+#pragma unroll
+            for (int s = 0; s < KZ; ++s) {
+                const int f = 4 * s + g;
+                eps[s] = f < D ? a.eps[sc * D + f] : 0.f;
+                zn[s] = a.ckpt[(((long long)a.step * ntp + tile) * 64 + lane) * ckzr + s];
+            }
+            if (a.step == a.nsteps - 1) {
+#pragma unroll
+                for (int s = 0; s < KZ; ++s) lam[s] = valid ? a.ckpt[(((long long)a.nsteps * ntp + tile) * 64 + lane) * ckzr + s] : 0.f;
+                if (a.lam3 != 0.f) {
+                    float sa = 0.f;
+#pragma unroll
+                    for (int s = 0; s < KZ; ++s) { const int f = 4 * s + g; if (f >= a.nvars && f < D) sa = fmaf(lam[s], lam[s], sa); }
+                    sa = group_sum(sa);
+                    const float inv = sa > 0.f ? a.lam3 * rsqrtf(sa) : 0.f;
+#pragma unroll
+                    for (int s = 0; s < KZ; ++s) { const int f = 4 * s + g; if (f >= a.nvars && f < D) lam[s] = fmaf(inv, lam[s], lam[s]); }
+                }
+            } else {
+#pragma unroll
+                for (int s = 0; s < KZ; ++s) lam[s] = a.lam[(tile * 64 + lane) * KZ + s];
+            }
+        }
+        __syncthreads();                 // the previous super-tile's readers of the LDS images are done
+        float* zbt = a.zb + (tile * 64 + lane) * (long long)(NS * KZ);
+        f32x4 aS[A], aR = {0.f, 0.f, 0.f, 0.f};
+
+#pragma clang loop unroll(disable)
+        for (int i = ns - 1; i >= 0; --i) {
+            // (the image's buffer resource is rebuilt per stage from the kernel argument made scalar by hand: see cnf_coop_dgrad.hip)
+            const unsigned long long pimg = (unsigned long long)a.packed;
+            const unsigned plo = __builtin_amdgcn_readfirstlane((unsigned)pimg), phi = __builtin_amdgcn_readfirstlane((unsigned)(pimg >> 32));
+            const DRs R{__builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(((unsigned long long)phi << 32) | plo), 0, 0x7fffffff, 0x00020000), R0.lane16};
+            const float bi = a.T.b[i];
+            const float cl = valid ? dt * bi : 0.f;      // cotangent of ldot (dL/d dlogp = +1 per column); zero for padding columns
+            const float tt = tn + a.T.c[i] * dt;
+            // byte offset of this super-tile's column-tile pair of stage i in every [ns][ntp][tiles] array
+            const unsigned soH = (unsigned)(((long long)i * ntp + st * 2) * HTs * 1024);
+            G3U<A> hcur;
+            load_units(q3.fh[0], soH, hcur);             // h_1: arrives under the dense phase and the first product
+            if (owner) {
+                // ---- dense phase: stage state, kbar, gbar (cnf_coop_dgrad.hip's, one batch of 16-byte loads) ----
+                float zs[KZ], kbar[KZ], gbar[KZ];
+                f32x4 kr[NS - 1][DT], ki[DT], gi[DT], zr[NS - 1][DT];
+                {
+                    const long long rowb = (long long)a.step * ns * ntp + tile, rstride = ntp * 64 * (long long)ckzr;
+                    const float* kbase = a.ckpt_k + (rowb * 64 + lane) * ckzr;
+                    const float* gbase = (a.lam2 != 0.f ? a.ckpt_g : a.ckpt_k) + (rowb * 64 + lane) * ckzr;
+#pragma unroll
+                    for (int j = 0; j < NS - 1; ++j) {
+                        const int jj = j < ns ? j : ns - 1;
+#pragma unroll
+                        for (int q = 0; q < DT; ++q) kr[j][q] = *reinterpret_cast<const f32x4*>(kbase + jj * rstride + 4 * q);
+                    }
+#pragma unroll
+                    for (int q = 0; q < DT; ++q) {
+                        ki[q] = *reinterpret_cast<const f32x4*>(kbase + i * rstride + 4 * q);
+                        gi[q] = *reinterpret_cast<const f32x4*>(gbase + i * rstride + 4 * q);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < NS - 1; ++j)
+#pragma unroll
+                    for (int q = 0; q < DT; ++q) zr[j][q] = *reinterpret_cast<const f32x4*>(zbt + (j + 1) * KZ + 4 * q);
+#pragma unroll
+                for (int s = 0; s < KZ; ++s) {
+                    float acc = 0.f, kb = bi * lam[s];
+#pragma unroll
+                    for (int j = 0; j < NS - 1; ++j) {
+                        acc = fmaf(a.T.a[i][j], kr[j][s >> 2][s & 3], acc);                         // a[i][j] = 0 for j >= i
+                        kb = fmaf(a.T.a[j + 1][i], (j + 1 > i && j + 1 < ns) ? zr[j][s >> 2][s & 3] : 0.f, kb);    // Zbar_j exists for i < j < ns only
+                    }
+                    zs[s] = fmaf(dt, acc, zn[s]);
+                    kbar[s] = valid ? dt * kb : 0.f;
+                    gbar[s] = -cl * eps[s];
+                }
+                // gbar = cotangent of g = eps^T J: -c_l eps (+ c_n g / |g|);  kbar += c_E zdot / |zdot|  (src/core/icnf.jl:184-251)
+                if (a.lam1 != 0.f) {
+                    float e2 = 0.f;
+#pragma unroll
+                    for (int s = 0; s < KZ; ++s) e2 = fmaf(ki[s >> 2][s & 3], ki[s >> 2][s & 3], e2);
+                    e2 = group_sum(e2);
+                    const float inv = e2 > 0.f ? cl * a.lam1 * rsqrtf(e2) : 0.f;
+#pragma unroll
+                    for (int s = 0; s < KZ; ++s) kbar[s] = fmaf(inv, ki[s >> 2][s & 3], kbar[s]);
+                }
+                if (a.lam2 != 0.f) {
+                    float n2 = 0.f;
+#pragma unroll
+                    for (int s = 0; s < KZ; ++s) n2 = fmaf(gi[s >> 2][s & 3], gi[s >> 2][s & 3], n2);
+                    n2 = group_sum(n2);
+                    const float inv = n2 > 0.f ? cl * a.lam2 * rsqrtf(n2) : 0.f;
+#pragma unroll
+                    for (int s = 0; s < KZ; ++s) gbar[s] = fmaf(inv, gi[s >> 2][s & 3], gbar[s]);
+                }
+                publish_dense(gbuf, wave, gbar);
+                publish_dense(kbuf, wave, kbar);
+                // the D-row operands of Wbar_1 (= delta_1 gbar^T + sbar_1 [z; t]^T) and Wbar_N (= eps cbar^T + kbar h_L^T) as tiles
+                {
+                    const long long ctile = (long long)i * ntp + tile;
+                    f32x4* gbp = reinterpret_cast<f32x4*>(q3.gb) + (ctile * DTZ) * 64 + lane;
+                    f32x4* ztp = reinterpret_cast<f32x4*>(q3.zt) + (ctile * DTZ) * 64 + lane;
+                    f32x4* epp = reinterpret_cast<f32x4*>(q3.ep) + (ctile * DT) * 64 + lane;
+                    f32x4* kbp = reinterpret_cast<f32x4*>(q3.kb) + (ctile * DT) * 64 + lane;
+                    const int kt = D >> 4, et = (D & 15) >> 2, gt = D & 3;   // where the time row (feature D) sits
+                    for (int kg = 0; kg < DTZ; ++kg) {
+                        f32x4 zv = {0.f, 0.f, 0.f, 0.f}, gv = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int k2 = 0; k2 < DT; ++k2)
+                            if (k2 == kg) {
+                                zv = f32x4{zs[4 * k2], zs[4 * k2 + 1], zs[4 * k2 + 2], zs[4 * k2 + 3]};
+                                gv = f32x4{gbar[4 * k2], gbar[4 * k2 + 1], gbar[4 * k2 + 2], gbar[4 * k2 + 3]};
+                            }
+                        if (!a.autonomous && kg == kt && g == gt) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) if (e == et) zv[e] = tt;
+                        }
+                        if (!valid) zv = f32x4{0.f, 0.f, 0.f, 0.f};
+                        gbp[kg * 64] = gv;
+                        ztp[kg * 64] = zv;
+                    }
+#pragma unroll
+                    for (int kg = 0; kg < DT; ++kg) {
+                        epp[kg * 64] = f32x4{eps[4 * kg], eps[4 * kg + 1], eps[4 * kg + 2], eps[4 * kg + 3]};
+                        kbp[kg * 64] = f32x4{kbar[4 * kg], kbar[4 * kg + 1], kbar[4 * kg + 2], kbar[4 * kg + 3]};
+                    }
+                }
+            }
+            G3U<A> acc;
+            G3U<A> hP[L - 1], dbP[L - 1];               // h_l and dbar_l of the lower layers, parked until the way down
+            zero_u(acc);
+            g3_load_a<A, LO>(R, TZ, F1Z, 0, aS, aR);
+            G3_SYNC();                                                                     // gbar / kbar published
+            // ================= up 1: dbar_1 = W_1[:,0:D] gbar =================
+            g3_gemm<A, LO>(R, TZ, F1Z, G.KGZ, G.remZ, v0, gbuf, lane, aS, aR, acc);
+            g3_load_a<A, LO>(R, TH, FH, 0, aS, aR);
+            G3U<A> hlast, dblast;                        // h_L, dbar_L: used at the top, in registers
+#pragma unroll
+            for (int l = 0; l < L; ++l) {
+                G3U<A> vb;
+                up_ew(acc, hcur, vb);                    // acc <- dbar_{l+1} (1-based), vb <- vbar_{l+1}
+                store_units(q3.sv[l], soH, vb);
+                if (l + 1 < L) {
+                    publish((l & 1) ? X1 : X0, vb);
+                    park_u(hcur, hP[l]);
+                    park_u(acc, dbP[l]);
+                    load_units(q3.fh[l + 1], soH, hcur); // the next layer's h: arrives under the product
+                    zero_u(acc);
+                    G3_SYNC();
+                    // ================= up l + 2: dbar = W_{l+2} vbar_{l+1} =================
+                    g3_gemm<A, LO>(R, TH, FH + (unsigned)l * IMGH, G.KGH, G.remH, v0, (l & 1) ? X1 : X0, lane, aS, aR, acc);
+                    if (l + 2 < L) g3_load_a<A, LO>(R, TH, FH + (unsigned)(l + 1) * IMGH, 0, aS, aR);
+                    else g3_load_a<A, LO>(R, TZ, BN, 0, aS, aR);
+                } else {
+                    hlast = hcur;
+                    dblast = acc;
+                }
+            }
+            // ================= the top: hbar_L = W_N^T kbar =================
+            G3U<A> dlt;
+            load_units(q3.fd[L - 1], soH, dlt);
+            zero_u(acc);
+            g3_gemm<A, LO>(R, TZ, BN, G.KGZ, G.remZ, v0, kbuf, lane, aS, aR, acc);
+            g3_load_a<A, LO>(R, TH, BH + (unsigned)(L - 2) * IMGH, 0, aS, aR);
+            down_ew(acc, hlast, dlt, dblast);            // acc <- sbar_L
+            store_units(q3.ss[L - 1], soH, acc);
+            // buffers: vbar_1 -> X0, (vbar_2 -> X1,) sbar_L -> the buffer the last up product did not read, alternating downwards
+            constexpr int topbuf = (L - 1) & 1;          // L = 2: X1; L = 3: X0
+            publish(topbuf ? X1 : X0, acc);
+            f32x4 fd[DT];
+#pragma unroll
+            for (int l = L - 1; l >= 1; --l) {           // hbar_l = W_{l+1}^T sbar_{l+1}  (1-based l)
+                const int rb = ((L - 1 - l) & 1) ^ topbuf;   // the buffer sbar_{l+1} was published in
+                load_units(q3.fd[l - 1], soH, dlt);
+                zero_u(acc);
+                G3_SYNC();
+                g3_gemm<A, LO>(R, TH, BH + (unsigned)(l - 1) * IMGH, G.KGH, G.remH, v0, rb ? X1 : X0, lane, aS, aR, acc);
+                if (l > 1) g3_load_a<A, LO>(R, TH, BH + (unsigned)(l - 2) * IMGH, 0, aS, aR);
+                else {
+#pragma unroll
+                    for (int dm = 0; dm < DT; ++dm) fd[dm] = dloadv(R, vd[dm], B1 + (unsigned)mtS0 * 1024u);
+                }
+                G3U<A> hh, db;
+                unpark_u(hP[l - 1], hh);
+                unpark_u(dbP[l - 1], db);
+                down_ew(acc, hh, dlt, db);               // acc <- sbar_l
+                store_units(q3.ss[l - 1], soH, acc);
+                if (l > 1) publish(rb ? X0 : X1, acc);
+            }
+            // ================= Zbar_i = W_1[:,0:D]^T sbar_1: partial tiles over this wave's own k-groups, from registers =================
+            f32x4 part[DT][2];
+#pragma unroll
+            for (int dm = 0; dm < DT; ++dm) { part[dm][0] = f32x4{0.f, 0.f, 0.f, 0.f}; part[dm][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+            {
+                f32x4 f1[DT];
+#pragma unroll
+                for (int m = 0; m < A + (LO ? 1 : 0); ++m) {
+                    f32x4(&cur)[DT] = (m & 1) ? f1 : fd;
+                    f32x4(&nxt)[DT] = (m & 1) ? fd : f1;
+                    if (m + 1 < A + (LO ? 1 : 0)) {
+                        const int kgn = m + 1 < A ? mtS0 + m + 1 : tR;
+#pragma unroll
+                        for (int dm = 0; dm < DT; ++dm) nxt[dm] = dloadv(R, vd[dm], B1 + (unsigned)kgn * 1024u);
+                    }
+                    if (m < A) {
+                        const int js = (mtS0 + m == G.KGH - 1) ? G.remH : 4;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (j < js) {
+#pragma unroll
+                                for (int dm = 0; dm < DT; ++dm)
+#pragma unroll
+                                    for (int c = 0; c < 2; ++c) part[dm][c] = mfma4(cur[dm][j], acc.S[m][c][j], part[dm][c]);
+                            }
+                    } else if (v0) {
+                        // (a left-over tile may be the last k-group: its k-steps beyond `rem` multiply zero columns of the image)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+#pragma unroll
+                            for (int dm = 0; dm < DT; ++dm)
+#pragma unroll
+                                for (int c = 0; c < 2; ++c) part[dm][c] = mfma4(cur[dm][j], acc.R[c][j], part[dm][c]);
+                    }
+                }
+            }
+            G3_SYNC();                                                                     // every reader of X0 is through
+#pragma unroll
+            for (int dm = 0; dm < DT; ++dm)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) pbuf[((wave * DT + dm) * 2 + c) * 64 + lane] = part[dm][c];
+            G3_SYNC();
+            if (owner) {
+#pragma unroll
+                for (int dm = 0; dm < DT; ++dm) {
+                    f32x4 v = pbuf[((0 * DT + dm) * 2 + wave) * 64 + lane];
+#pragma unroll
+                    for (int w = 1; w < 4; ++w) v += pbuf[((w * DT + dm) * 2 + wave) * 64 + lane];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) zbt[i * KZ + 4 * dm + j] = v[j];
+                }
+            }
+            // (the next stage's first LDS writes - gbar / kbar images - touch neither exchange buffer; its first publish into X0 comes
+            // behind its first barrier, which the owners reach after this sum)
+        }
+        if (owner) {
+#pragma unroll
+            for (int s = 0; s < KZ; ++s) {
+                float acc = lam[s];
+                for (int j = 0; j < ns; ++j) acc += zbt[j * KZ + s];
+                lam[s] = acc;
+                a.lam[(tile * 64 + lane) * KZ + s] = acc;
+            }
+        }
+        if (a.step == 0 && a.grad_x && valid) {
+#pragma unroll
+            for (int s = 0; s < KZ; ++s) {
+                const int f = 4 * s + g;
+                if (f < a.nvars) a.grad_x[smp * a.nvars + f] = lam[s];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------
+template <int A, bool LO, int L, int KZ, int ACT, int NS>
+static hipError_t launch_g3(const G3Args& a, int lds, int nblocks, hipStream_t st) {
+    auto kern = coop_grad3_step_kernel<A, LO, L, KZ, ACT, NS>;
+    static DeviceOnce once;
+    int dev = 0;
+    hipError_t e0 = hipGetDevice(&dev);
+    if (e0 != hipSuccess) return e0;
+    if (!once.done(dev)) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        once.set(dev);
+    }
+    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(256), lds, st, a);
+    return hipGetLastError();
+}
+
+struct G3Inst {
+    int A, LO, L, KZ, ACT;
+    hipError_t (*fn[2])(const G3Args&, int, int, hipStream_t);   // [0] RK4 (4 stages), [1] Tsit5 (6 stages)
+};
+#define G3_INST(A, LO, L, KZ, ACT) G3Inst { A, LO, L, KZ, ACT, { &launch_g3<A, LO, L, KZ, ACT, 4>, &launch_g3<A, LO, L, KZ, ACT, 6> } }
+static const G3Inst kG3[] = {
+    G3_INST(4, false, 3, 8, CNF_ACT_TANH_PRESCALED),   // cfg4: 3 x 256, D <= 32
+    G3_INST(2, false, 3, 8, CNF_ACT_TANH_PRESCALED),   // 3 x 128
+};
+static const G3Inst* g3_find(int HT_real, int L, int KZ, int ACT) {
+    const int A = HT_real / 4, b = HT_real - 4 * A;
+    const G3Inst* best = nullptr;
+    for (const G3Inst& c : kG3) {
+        const bool act_ok = c.ACT == ACT || (c.ACT == CNF_ACT_TANH_PRESCALED && ACT == CNF_ACT_TANH);
+        if (c.A == A && (c.LO || b == 0) && c.L == L && c.KZ >= KZ && act_ok && (!best || c.KZ < best->KZ || (c.KZ == best->KZ && !c.LO && best->LO))) best = &c;
+    }
+    return best;
+}
+
+bool coop_grad3_supported(int H, int D, int L, int ACT, int HT_lay, int ZR_lay, int CR_lay) {
+    if (CR_lay != 0) return false;
+    const int HT_real = (H + 15) / 16, KZ = (D + 3) / 4;
+    if (HT_real > HT_lay || KZ > ZR_lay) return false;
+    const G3Inst* c = g3_find(HT_real, L, KZ, ACT);
+    if (!c || c->KZ > ZR_lay) return false;   // the checkpoint rows are read KZ registers wide
+    return coop_grad3_lds_bytes(HT_real, c->KZ / 4) <= 160 * 1024;
+}
+
+hipError_t coop_grad3_step_launch(int H, int D, int L, int ACT, int HT_lay, int ZR_lay, const CG3Args& a, int num_cus, hipStream_t st) {
+    const int HT_real = (H + 15) / 16, KZ = (D + 3) / 4;
+    const G3Inst* c = g3_find(HT_real, L, KZ, ACT);
+    if (!c) return hipErrorNotSupported;
+    G3Args ga{};
+    ga.c = a;
+    dimg_fill(ga.g, H, D, L, HT_lay, ZR_lay, 0, c->A, 0);
+    const int lds = coop_grad3_lds_bytes(HT_real, c->KZ / 4);
+    if (lds > 160 * 1024) return hipErrorNotSupported;
+    const long long nst = a.c.ntiles_pad / 2;
+    const int nblocks = (int)(nst < num_cus ? nst : num_cus);
+    return c->fn[a.c.T.ns <= 4 ? 0 : 1](ga, lds, nblocks, st);
+}
+
+}  // namespace cnf

@@ -152,6 +152,7 @@ long long mfma_plan_ckpt_tiles(const MfmaPlan* p, long long B, bool on_grid = fa
 // cnf_layered.hip): loss terms from the checkpointing forward solve, gradient in the Lux layout, dL/dx
 bool coop_grad_eligible(const cnf_config& c, const MfmaPlan* plan, const float lam[3], bool on_grid);
 long long coop_grad_max_columns(const cnf_config& c, int alg);   // batches beyond it take the layer-wise path (32-bit operand addressing)
+int mfma_plan_stage_store_tiles(const MfmaPlan* p, long long B, bool on_grid);   // cnf_mfma.hip: 0 = the forward solve writes no stage store
 hipError_t coop_grad(LayeredGrad** ctx, const cnf_config& c, MfmaPlan* plan, const float* packed_dev, const size_t* w_off,
                      const size_t* b_off, const float* x, const float* eps, const float* ys, int alg, int nsteps, float t0, float t1,
                      const float* tgrid, const float* tgrid_dev, long long B, const float lam[3], float* grad, float* grad_x, float* logp_out, float* regs_out, hipStream_t st, std::string* err);

@@ -37,6 +37,7 @@
 
 #include "cnf_internal.h"
 #include "cnf_coop_grad.h"
+#include "cnf_tiles.h"
 #include <map>
 
 namespace cnf {
@@ -441,6 +442,8 @@ struct LayeredGrad {
     size_t ws_floats = 0;
     float* ws_fwd = nullptr;      // forward-evaluation workspace (the gradient calls the forward for the loss)
     size_t ws_fwd_floats = 0;
+    float* ws_store = nullptr;    // the stage store of the cooperative gradient's second form (cnf_tiles.h): h_l, delta_l of every stage
+    size_t ws_store_floats = 0;
 };
 
 void layered_grad_destroy(LayeredGrad* g) {
@@ -449,6 +452,7 @@ void layered_grad_destroy(LayeredGrad* g) {
         if (im.img) (void)hipFree(im.img);
     if (g->ws) (void)hipFree(g->ws);
     if (g->ws_fwd) (void)hipFree(g->ws_fwd);
+    if (g->ws_store) (void)hipFree(g->ws_store);
     delete g;
 }
 
@@ -1006,6 +1010,111 @@ bool coop_grad_eligible(const cnf_config& c, const MfmaPlan* plan, const float l
     return coop_grad_supported(HT, L, ZR, CR, ACT) && lg_wgrad_supported(c.widths[1], c.widths[1] + 1);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The cooperative gradient in its SECOND FORM (round 6): the checkpointing forward solve also stores h_l
+// and delta_l of every stage (tile-native, cnf_tiles.h), the sweep (cnf_coop_grad3.hip) runs the second-order chains alone
+// and leaves vbar_l / sbar_l as tiles, and the weight cotangents are products over tiles (cnf_wgrad_tiles.hip) whose other
+// operands are the forward solve's store.  Same checkpoints, same costate algebra, same slabs and final reduction as coop_grad.
+// ---------------------------------------------------------------------------------------------------------------------
+static bool coop_grad3_fits(const cnf_config& c, int HTs, int Lh, int alg, int nsteps, long long ntp) {
+    const long long ns = make_tableau(alg).ns;
+    StageStore S{Lh, nsteps, (int)ns, HTs, ntp};
+    const long long gib = tuning().coop_grad3_gib > 0 ? tuning().coop_grad3_gib : 0;
+    if (S.total() * 4 > (gib << 30)) return false;
+    const int D = c.nvars + c.naug;
+    const long long dtz = (c.widths[0] + 15) / 16 > (D + 15) / 16 ? (c.widths[0] + 15) / 16 : (D + 15) / 16;
+    // the sweep addresses a step's arrays through 32-bit byte offsets
+    return ns * ntp * (HTs > dtz ? HTs : dtz) * 1024 < 0x7fffffffLL;
+}
+
+static hipError_t coop_grad3_run(LayeredGrad& G, const cnf_config& c, MfmaPlan* plan, const float* packed_dev, const size_t* w_off, const size_t* b_off,
+                                 const float* x, const float* eps, const float* ys, int alg, int nsteps, float t0, float t1, long long B, const float lam[3],
+                                 float* grad, float* grad_x, float* logp_out, float* regs_out, int HT, int Lh, int ZR, int ACT, int HTs, hipStream_t st, std::string* err) {
+    const int N = c.n_layers, D = c.nvars + c.naug, H = c.widths[1], n_in = c.widths[0];
+    LDesc L{};
+    L.n_layers = N;
+    long long npa = 0;
+    for (int l = 0; l < N; ++l) {
+        L.win[l] = c.widths[l]; L.wout[l] = c.widths[l + 1]; L.act[l] = c.acts[l];
+        L.pa_off[l] = npa; L.w_off[l] = (long long)w_off[l]; L.b_off[l] = (long long)b_off[l];
+        npa += (long long)L.wout[l] * (L.win[l] + 1);
+    }
+    L.npa = npa;
+    const long long npa_pad = (npa + 63) / 64 * 64;
+    const Tableau T = make_tableau(alg);
+    const int ns = T.ns;
+    const long long ntp = mfma_plan_ckpt_tiles(plan, B, false);
+    const long long nct = (long long)ns * ntp;              // column tiles of a step
+    const int DT = (D + 15) / 16, DTZ = (n_in + 15) / 16 > DT ? (n_in + 15) / 16 : DT;
+    // chunks (= slabs) of the three kinds of product
+    long long ch1 = 0, chH = 0, chN = 0;
+    const int nc1 = wgrad_tiles_chunks(H, n_in, nct, G.num_cus, &ch1), ncH = wgrad_tiles_chunks(H, H, nct, G.num_cus, &chH),
+              ncN = wgrad_tiles_chunks(D, H, nct, G.num_cus, &chN);
+    const int nslab = std::max(nc1, std::max(ncH, ncN));
+    StageStore S{Lh, nsteps, ns, HTs, ntp};
+    if ((size_t)S.total() > G.ws_store_floats) {
+        if (G.ws_store) LG_HIP(hipFree(G.ws_store));
+        G.ws_store = nullptr; G.ws_store_floats = 0;
+        LG_HIP(hipMalloc((void**)&G.ws_store, (size_t)S.total() * sizeof(float)));
+        G.ws_store_floats = (size_t)S.total();
+    }
+    long long off = 0;
+    auto take = [&](long long n) { const long long o = off; off += (n + 63) / 64 * 64; return o; };
+    const long long o_slab = take(npa_pad * nslab);
+    const long long o_zck = take((long long)(nsteps + 1) * ntp * 64 * ZR), o_kck = take((long long)nsteps * ns * ntp * 64 * ZR);
+    const long long o_gck = lam[1] != 0.f ? take((long long)nsteps * ns * ntp * 64 * ZR) : 0;
+    const int KZ = (ZR + 3) / 4 * 4;
+    const long long o_lam = take(ntp * 64 * KZ), o_zb = take(ntp * 64 * 6 * KZ);
+    long long o_sv[3], o_ss[3];
+    for (int l = 0; l < Lh; ++l) { o_sv[l] = take(nct * HTs * 256); o_ss[l] = take(nct * HTs * 256); }
+    const long long o_gb = take(nct * DTZ * 256), o_zt = take(nct * DTZ * 256), o_ep = take(nct * DT * 256), o_kb = take(nct * DT * 256);
+    if ((size_t)off > G.ws_floats) {
+        if (G.ws) LG_HIP(hipFree(G.ws));
+        G.ws = nullptr; G.ws_floats = 0;
+        LG_HIP(hipMalloc((void**)&G.ws, (size_t)off * sizeof(float)));
+        G.ws_floats = (size_t)off;
+    }
+    float* W = G.ws;
+    float* slabs = W + o_slab;
+    LG_HIP(zero_async(slabs, (size_t)npa_pad * nslab * sizeof(float), st));
+
+    // ---- forward: the cooperative solve, checkpointing z_n and the stage derivatives AND storing h_l / delta_l of every stage ----
+    SolveArgs sa{};
+    sa.x = x; sa.eps = eps; sa.ys = ys; sa.B = B; sa.nsteps = nsteps; sa.alg = alg; sa.t0 = t0; sa.t1 = t1;
+    sa.logp = logp_out; sa.regs = regs_out; sa.nvars = c.nvars; sa.reg_aug = (c.reg_aug && c.naug > 0) ? 1 : 0;
+    sa.ckpt = W + o_zck; sa.ckpt_k = W + o_kck; sa.ckpt_g = lam[1] != 0.f ? W + o_gck : nullptr;
+    sa.kfull = G.ws_store;
+    LG_HIP(mfma_solve(plan, packed_dev, sa, st));
+
+    // ---- reverse: one sweep launch per step, then the step's weight-cotangent products over tiles ----
+    CG3Args a{};
+    a.c.packed = packed_dev; a.c.eps = eps; a.c.ys = ys; a.c.C = 0; a.c.ckpt = W + o_zck; a.c.ckpt_k = W + o_kck; a.c.ckpt_g = sa.ckpt_g;
+    a.c.lam = W + o_lam; a.c.zb = W + o_zb; a.c.grad_x = grad_x;
+    a.c.B = B; a.c.ntiles_pad = ntp; a.c.nsteps = nsteps; a.c.D = D; a.c.nvars = c.nvars; a.c.H = H; a.c.autonomous = c.autonomous;
+    a.c.lam1 = lam[0]; a.c.lam2 = lam[1]; a.c.lam3 = lam[2]; a.c.T = T;
+    for (int l = 0; l < Lh; ++l) { a.sv[l] = W + o_sv[l]; a.ss[l] = W + o_ss[l]; }
+    a.gb = W + o_gb; a.zt = W + o_zt; a.ep = W + o_ep; a.kb = W + o_kb;
+    a.HTs = HTs; a.DTZ = DTZ;
+    const float dt = (t1 - t0) / (float)nsteps;
+    for (int n = nsteps - 1; n >= 0; --n) {
+        a.c.step = n; a.c.tn = t0 + (float)n * dt; a.c.dt = dt;
+        for (int l = 0; l < Lh; ++l) { a.fh[l] = G.ws_store + S.at(0, l, n, 0); a.fd[l] = G.ws_store + S.at(1, l, n, 0); }
+        LG_HIP(coop_grad3_step_launch(H, D, Lh, ACT, HT, ZR, a, G.num_cus, st));
+        // Wbar_1 += delta_1 gbar^T + sbar_1 [z; t]^T  (bias: row sums of sbar_1)
+        LG_HIP(wgrad_tiles(slabs + L.pa_off[0], npa_pad, ch1, nc1, H, n_in, WTTerm{a.fd[0], a.gb, HTs, DTZ}, WTTerm{a.ss[0], a.zt, HTs, DTZ}, nct, 1, st));
+        // Wbar_{l+1} += delta_{l+1} vbar_l^T + sbar_{l+1} h_l^T
+        for (int l = 1; l < Lh; ++l)
+            LG_HIP(wgrad_tiles(slabs + L.pa_off[l], npa_pad, chH, ncH, H, H, WTTerm{a.fd[l], a.sv[l - 1], HTs, HTs}, WTTerm{a.ss[l], a.fh[l - 1], HTs, HTs}, nct, 1, st));
+        // Wbar_N += eps cbar^T + kbar h_L^T  (bias: row sums of kbar)
+        LG_HIP(wgrad_tiles(slabs + L.pa_off[Lh], npa_pad, chN, ncN, D, H, WTTerm{a.ep, a.sv[Lh - 1], DT, HTs}, WTTerm{a.kb, a.fh[Lh - 1], DT, HTs}, nct, 1, st));
+    }
+    hipLaunchKernelGGL(reduce_slabs_kernel, grid_for(npa), dim3(TPB), 0, st, slabs, nslab, npa_pad, L, grad);
+    LG_HIP(hipGetLastError());
+    (void)err;
+    return hipSuccess;
+}
+
 hipError_t coop_grad(LayeredGrad** ctx, const cnf_config& c, MfmaPlan* plan, const float* packed_dev, const size_t* w_off,
                      const size_t* b_off, const float* x, const float* eps, const float* ys, int alg, int nsteps, float t0, float t1,
                      const float* tgrid, const float* tgrid_dev, long long B, const float lam[3], float* grad, float* grad_x, float* logp_out, float* regs_out, hipStream_t st, std::string* err) {
@@ -1019,6 +1128,12 @@ hipError_t coop_grad(LayeredGrad** ctx, const cnf_config& c, MfmaPlan* plan, con
         LG_HIP(hipGetDevice(&dev));
         LG_HIP(hipGetDeviceProperties(&prop, dev));
         G.num_cus = prop.multiProcessorCount;
+    }
+    if (!tgrid && tuning().coop_grad3 != 0 && CR == 0 && coop_grad3_supported(c.widths[1], c.nvars + c.naug, Lh, ACT, HT, ZR, CR)) {
+        // the second form (section 8.6) where the forward solve's kernel writes the stage store and HBM has room for it
+        const int HTs = mfma_plan_stage_store_tiles(plan, B, false);
+        if (HTs > 0 && coop_grad3_fits(c, HTs, Lh, alg, nsteps, mfma_plan_ckpt_tiles(plan, B, false)))
+            return coop_grad3_run(G, c, plan, packed_dev, w_off, b_off, x, eps, ys, alg, nsteps, t0, t1, B, lam, grad, grad_x, logp_out, regs_out, HT, Lh, ZR, ACT, HTs, st, err);
     }
     const int N = c.n_layers, D = c.nvars + c.naug, H = c.widths[1], n_in = c.widths[0];
     LDesc L{};

@@ -471,6 +471,16 @@ long long mfma_plan_ckpt_tiles(const MfmaPlan* p, long long B, bool on_grid) {
     const bool x = p->kind == 2 || on_grid || !coop_ckpt_supported(p->HT, p->L, p->ZR, p->ACT);   // which kernel checkpoints: see mfma_solve
     return x ? (B + 31) / 32 * 2 : (B + 63) / 64 * 4;
 }
+// hidden tiles per sample tile of the STAGE STORE (cnf_tiles.h) the plan's checkpointing forward solve writes when SolveArgs::kfull
+// is set - h_l and delta_l of every stage, for the second-order reverse sweep - or 0 when the kernel that would serve the solve
+// does not write one (then the older sweeps recompute both chains)
+int mfma_plan_stage_store_tiles(const MfmaPlan* p, long long B, bool on_grid) {
+    if (!p || on_grid) return 0;
+    (void)plan_ensure_cus(const_cast<MfmaPlan*>(p));
+    if (plan_uses_coopd(p, B)) return 0;
+    if (p->kind == 1 && coop_ckpt_supported(p->HT, p->L, p->ZR, p->ACT)) return p->HT;
+    return 0;
+}
 bool mfma_plan_is_per_wave(const MfmaPlan* p) { return p->kind == 0; }
 // can this plan's forward solve checkpoint for the cooperative gradient (on the caller's grid when `on_grid`)?  Extended-kernel
 // plans always do (run-time switch); cooperative plans through their CK instance on uniform steps, otherwise through the

@@ -16,6 +16,8 @@ const Knob kKnobs[] = {
     {"CNF_COOPD_GRAD", &cnf_tuning::coopd_grad, 1},
     {"CNF_COOP_GRAD", &cnf_tuning::coop_grad, 1},
     {"CNF_COOP_GRAD_MID", &cnf_tuning::coop_grad_mid, 1},
+    {"CNF_COOP_GRAD3", &cnf_tuning::coop_grad3, 1},
+    {"CNF_COOP_GRAD3_GIB", &cnf_tuning::coop_grad3_gib, 96},
     {"CNF_GRAD_LAYERED", &cnf_tuning::grad_layered, 0},
     {"CNF_JVP_GRAD_TWIN", &cnf_tuning::jvp_grad_twin, 1},
     {"CNF_PROBE_GRAD_TWIN", &cnf_tuning::probe_grad_twin, 1},
