@@ -36,7 +36,7 @@ EXPORTS = ("cnf_version", "cnf_build_info", "cnf_get_tuning", "cnf_set_tuning", 
            "cnf_integrate_fixed_dt", "cnf_inference_fixed_dt",
            "cnf_comm_unique_id", "cnf_comm_init", "cnf_comm_init_all", "cnf_comm_destroy", "cnf_comm_rank", "cnf_comm_size",
            "cnf_comm_group_start", "cnf_comm_group_end", "cnf_allreduce_loss", "cnf_allreduce_sum",
-           "cnf_kernel_family", "cnf_kernel_family_for", "cnf_kernel_name", "cnf_grad_path_for")
+           "cnf_kernel_family", "cnf_kernel_family_for", "cnf_kernel_name", "cnf_grad_path_for", "cnf_grad_form_for")
 FAMILY_SIMT, FAMILY_PER_WAVE, FAMILY_COOP, FAMILY_COOPX, FAMILY_TILE_SPLIT, FAMILY_LAYERED, FAMILY_COOPD = 0, 1, 2, 3, 4, 5, 6
 FAMILY_NAMES = ("simt", "per_wave", "coop", "coopx", "tile_split", "layered", "coopd")
 
@@ -105,6 +105,7 @@ def load():
     lib.cnf_repack_on_device.argtypes = [vp]
     lib.cnf_grad_path.argtypes = [vp]
     lib.cnf_grad_path_for.argtypes = [vp, C.c_int64, C.c_int, C.c_int]
+    lib.cnf_grad_form_for.argtypes = [vp, C.c_int64, C.c_int, C.c_int, C.c_int]
     lib.cnf_kernel_family.argtypes = [vp]
     lib.cnf_kernel_family_for.argtypes = [vp, C.c_int64, C.c_int]
     lib.cnf_kernel_name.argtypes = [vp]
@@ -208,7 +209,7 @@ def set_tuning(**kw) -> dict:
 
 
 def reload_tuning() -> dict:
-    """Re-read the switchboard from its defaults and the CNF_* environment variables (cnf_set_tuning(NULL): what cnf_create does),
+    """Re-read the switchboard from its defaults and the CNF_* environment variables (cnf_set_tuning(NULL); creating a handle does not),
     so that a variable changed after a handle was created takes effect for it too."""
     rc = load().cnf_set_tuning(None)
     if rc:

@@ -115,6 +115,15 @@ int cnf_grad_path_for(const cnf_handle* h, int64_t B, int alg, int on_grid) {
     return grad_serve(h, B, alg, on_grid != 0).path;
 }
 
+int cnf_grad_form_for(const cnf_handle* h, int64_t B, int alg, int nsteps, int on_grid) {
+    if (!h || B < 0 || nsteps < 1 || (alg != CNF_ALG_RK4 && alg != CNF_ALG_TSIT5)) return CNF_ERR_INVALID;
+    const GradServe s = grad_serve(h, B, alg, on_grid != 0);
+    if (s.path != 3) return 0;
+    const GradRoute r = api_grad_route(s.srv, B, alg, on_grid != 0);
+    MfmaPlan* plan = r.use_cg_aux ? s.srv->grad.plan_cg : s.srv->plan;
+    return coop_grad_stage_store_tiles(s.srv->cfg, plan, B, alg, nsteps, on_grid != 0) > 0 ? 2 : 1;
+}
+
 }  // extern "C"
 
 // Layout of the fused per-wave gradient's workspace (cnf_handle::grad.ws) for `steps` steps: z checkpoints (steps + 1 slots), stage

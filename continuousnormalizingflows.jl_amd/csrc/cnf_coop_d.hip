@@ -233,7 +233,12 @@ __device__ __forceinline__ void coopd_eval(const DRs& R, const float* __restrict
                                            f32x4* __restrict__ zbuf, const f32x4* __restrict__ ebuf, f32x4* __restrict__ pbuf,
                                            const f32x4* __restrict__ ybuf, int lane, int wave, float t, bool autonomous, bool reg_z, bool reg_j,
                                            const float (&zs)[ZR], float (&zd)[ZR], float& ld, float& ed, float& nd,
-                                           float* __restrict__ gout, const UAcc<A>& cP, f32x4 (&aS)[A], f32x4 (&aR)[3]) {
+                                           float* __restrict__ gout, const UAcc<A>& cP, f32x4 (&aS)[A], f32x4 (&aR)[3],
+                                           float* __restrict__ fsb = nullptr, long long fsl = 0) {
+    // fsb (checkpointing solves, round 6): the stage store of the second-order reverse sweep (cnf_tiles.h) - every h_l and delta_l
+    // tile of this evaluation leaves for HBM from the registers of the wave that computed it, tile-native (one 16-byte store per
+    // lane; HTs = 4 A + b tiles per sample tile).  fsb: float pointer at this super-tile's first tile of (kind h, layer 0) for this
+    // stage; `fsl` floats separate consecutive (kind, layer) arrays.
     // cP: c = W_N^T eps of this wave's units, PARKED - eps is fixed for the whole solve (src/core/base_icnf.jl:258-259), so the
     //     product is taken once per super-tile (coopd_hoist_c), and delta_L = c .* act'_L falls out of the last activation pass;
     // aS / aR arrive holding the layer-1 fragments of k-group 0 and leave holding them again for the next evaluation (requested
@@ -269,6 +274,27 @@ __device__ __forceinline__ void coopd_eval(const DRs& R, const float* __restrict
             const int mt = mtR0 + r < mtRmax ? mtR0 + r : mtRmax;
             vR[r] = *reinterpret_cast<const f32x4*>(vec + (mt * 4 + g) * 4);
         }
+    };
+    auto fs_store = [&](int kl, const UAcc<A>& v) {
+        if (!fsb) return;
+        // (the array's address is made scalar by hand: a buffer resource in vector registers would put every store in a waterfall loop)
+        const unsigned long long pa = (unsigned long long)(fsb + (long long)kl * fsl);
+        const unsigned plo = __builtin_amdgcn_readfirstlane((unsigned)pa), phi = __builtin_amdgcn_readfirstlane((unsigned)(pa >> 32));
+        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(((unsigned long long)phi << 32) | plo), 0, 0x7fffffff, 0x00020000);
+        const int HTs = 4 * A + b;
+#pragma unroll
+        for (int m = 0; m < A; ++m)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v.S[m][q]), r, (int)R.lane16, (q * HTs + mtS0 + m) * 1024, 2);
+                CNF_STORE_DATA_HAZARD(v.S[m][q]);
+            }
+#pragma unroll
+        for (int rr = 0; rr < 3; ++rr)
+            if (rr < b) {
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v.R[rr]), r, (int)R.lane16, (wave * HTs + mtR0 + rr) * 1024, 2);
+                CNF_STORE_DATA_HAZARD(v.R[rr]);
+            }
     };
     // ---- layer 1: a = W1z z + w1t t + b1 ----
     {
@@ -326,6 +352,7 @@ __device__ __forceinline__ void coopd_eval(const DRs& R, const float* __restrict
                 h.R[r] = act_only<ACT>(acc.R[r]);
             }
         }
+        fs_store(l, h);                          // h_{l+1} (1-based) of this stage
         if (l + 1 < L) {
 #pragma unroll
             for (int m = 0; m < A; ++m)
@@ -395,6 +422,7 @@ __device__ __forceinline__ void coopd_eval(const DRs& R, const float* __restrict
             for (int r = 0; r < 3; ++r) dd[r] = unpark4(d[l].R[r]);
             tiles_mul<3>(acc.R, dd, h.R);
         }
+        fs_store(L + l, h);                      // delta_{l+1} (1-based)
         if (l > 0) {
             // exchange buffer: h_l sat in buffer (l - 1) & 1; every reader passed a barrier since.  L = 2: buffer 0 again.
             const int wbuf = (L == 2) ? 0 : ((l - 1) & 1) ^ 1;
@@ -724,9 +752,16 @@ coopd_solve_kernel(DArgs da) {
             for (int sg = 0; sg < ns; ++sg) {
                 const long long ckrow = ((((long long)step * ns + sg) * ckntp + cktile) * 64 + lane) * ckzr;
                 float* gout = (a.ckpt_g && !single) ? a.ckpt_g + ckrow : nullptr;
-                if constexpr (MODE == 0)
+                if constexpr (MODE == 0) {
+                    float* fsb = nullptr;
+                    long long fsl = 0;
+                    if (a.kfull && !single) {   // (the checkpointing solve's use of KArgs::kfull: base of the stage store, cnf_tiles.h)
+                        fsl = (long long)nsteps * ns * ckntp * HT * 256;
+                        fsb = a.kfull + ((((long long)step * ns + sg) * ckntp + st * 4) * HT) * 256;
+                    }
                     coopd_eval<A, L, ZR, ACT>(R, cbuf, G, xbuf, XB, zbuf, ebuf, pbuf, ybuf, lane, wave, tn + a.T.c[sg] * dt, autonomous, reg_z, reg_j,
-                                              zs, zd, ld, ed, nd, gout, cP, aS, aR);
+                                              zs, zd, ld, ed, nd, gout, cP, aS, aR, fsb, fsl);
+                }
                 else
                     coopd_eval_exact<A, ZR, ACT>(R, cbuf, G, xbuf, zbuf, pbuf, reinterpret_cast<float*>(ebuf), ybuf, lane, wave, tn + a.T.c[sg] * dt,
                                                  autonomous, zs, zd, ld, aS, aR);   // (the probe image's LDS holds the partial traces)

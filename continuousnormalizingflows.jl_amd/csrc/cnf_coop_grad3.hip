@@ -578,6 +578,14 @@ struct G3Inst {
 static const G3Inst kG3[] = {
     G3_INST(4, false, 3, 8, CNF_ACT_TANH_PRESCALED),   // cfg4: 3 x 256, D <= 32
     G3_INST(2, false, 3, 8, CNF_ACT_TANH_PRESCALED),   // 3 x 128
+    // the flows whose forward solve runs on the dealt kernel (cnf_coop_d.hip: 8 .. 15 hidden tiles): the reference's default
+    // architecture at nvariables = 16 .. 29 (two softplus layers), tanh nets of those widths
+    G3_INST(2, true, 2, 8, CNF_ACT_SOFTPLUS), G3_INST(2, true, 2, 12, CNF_ACT_SOFTPLUS), G3_INST(3, true, 2, 12, CNF_ACT_SOFTPLUS), G3_INST(3, true, 2, 16, CNF_ACT_SOFTPLUS),
+    G3_INST(3, true, 2, 8, CNF_ACT_SOFTPLUS),
+    G3_INST(2, true, 2, 8, CNF_ACT_TANH_PRESCALED), G3_INST(2, true, 2, 12, CNF_ACT_TANH_PRESCALED), G3_INST(3, true, 2, 8, CNF_ACT_TANH_PRESCALED),
+    G3_INST(3, true, 2, 12, CNF_ACT_TANH_PRESCALED), G3_INST(3, true, 2, 16, CNF_ACT_TANH_PRESCALED),
+    G3_INST(2, true, 3, 8, CNF_ACT_TANH_PRESCALED), G3_INST(3, true, 3, 8, CNF_ACT_TANH_PRESCALED), G3_INST(2, true, 3, 12, CNF_ACT_TANH_PRESCALED),
+    G3_INST(2, true, 3, 8, CNF_ACT_SOFTPLUS), G3_INST(2, true, 3, 12, CNF_ACT_SOFTPLUS),
 };
 static const G3Inst* g3_find(int HT_real, int L, int KZ, int ACT) {
     const int A = HT_real / 4, b = HT_real - 4 * A;

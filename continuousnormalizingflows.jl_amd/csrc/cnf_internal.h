@@ -151,6 +151,7 @@ long long mfma_plan_ckpt_tiles(const MfmaPlan* p, long long B, bool on_grid = fa
 // cooperative gradient for wide layers (cnf_coop_grad.hip + the deferred weight-cotangent products of cnf_lgemm.hip; host side in
 // cnf_layered.hip): loss terms from the checkpointing forward solve, gradient in the Lux layout, dL/dx
 bool coop_grad_eligible(const cnf_config& c, const MfmaPlan* plan, const float lam[3], bool on_grid);
+int coop_grad_stage_store_tiles(const cnf_config& c, MfmaPlan* plan, long long B, int alg, int nsteps, bool on_grid);   // > 0: the cooperative gradient's second form
 long long coop_grad_max_columns(const cnf_config& c, int alg);   // batches beyond it take the layer-wise path (32-bit operand addressing)
 int mfma_plan_stage_store_tiles(const MfmaPlan* p, long long B, bool on_grid);   // cnf_mfma.hip: 0 = the forward solve writes no stage store
 hipError_t coop_grad(LayeredGrad** ctx, const cnf_config& c, MfmaPlan* plan, const float* packed_dev, const size_t* w_off,

@@ -1028,6 +1028,18 @@ static bool coop_grad3_fits(const cnf_config& c, int HTs, int Lh, int alg, int n
     return ns * ntp * (HTs > dtz ? HTs : dtz) * 1024 < 0x7fffffffLL;
 }
 
+// Does a cooperative gradient call of B columns, `nsteps` steps of `alg`, take the second form - and with how many hidden tiles per
+// sample tile in its stage store (0: no, the recomputing sweeps serve it)?  Uniform steps only; the sweep must have an instance
+// for the shape, the forward solve's kernel must write the store, and HBM must have room for it (CNF_COOP_GRAD3_GIB).
+int coop_grad_stage_store_tiles(const cnf_config& c, MfmaPlan* plan, long long B, int alg, int nsteps, bool on_grid) {
+    int HT, Lh, ZR, ACT, CR;
+    if (on_grid || tuning().coop_grad3 == 0 || nsteps < 1 || !mfma_plan_coop_grad_shape(plan, &HT, &Lh, &ZR, &ACT, &CR) || CR != 0) return 0;
+    if (!coop_grad3_supported(c.widths[1], c.nvars + c.naug, Lh, ACT, HT, ZR, CR)) return 0;
+    const int HTs = mfma_plan_stage_store_tiles(plan, B, false);
+    if (HTs <= 0 || !coop_grad3_fits(c, HTs, Lh, alg, nsteps, mfma_plan_ckpt_tiles(plan, B, false))) return 0;
+    return HTs;
+}
+
 static hipError_t coop_grad3_run(LayeredGrad& G, const cnf_config& c, MfmaPlan* plan, const float* packed_dev, const size_t* w_off, const size_t* b_off,
                                  const float* x, const float* eps, const float* ys, int alg, int nsteps, float t0, float t1, long long B, const float lam[3],
                                  float* grad, float* grad_x, float* logp_out, float* regs_out, int HT, int Lh, int ZR, int ACT, int HTs, hipStream_t st, std::string* err) {
@@ -1129,12 +1141,8 @@ hipError_t coop_grad(LayeredGrad** ctx, const cnf_config& c, MfmaPlan* plan, con
         LG_HIP(hipGetDeviceProperties(&prop, dev));
         G.num_cus = prop.multiProcessorCount;
     }
-    if (!tgrid && tuning().coop_grad3 != 0 && CR == 0 && coop_grad3_supported(c.widths[1], c.nvars + c.naug, Lh, ACT, HT, ZR, CR)) {
-        // the second form (section 8.6) where the forward solve's kernel writes the stage store and HBM has room for it
-        const int HTs = mfma_plan_stage_store_tiles(plan, B, false);
-        if (HTs > 0 && coop_grad3_fits(c, HTs, Lh, alg, nsteps, mfma_plan_ckpt_tiles(plan, B, false)))
-            return coop_grad3_run(G, c, plan, packed_dev, w_off, b_off, x, eps, ys, alg, nsteps, t0, t1, B, lam, grad, grad_x, logp_out, regs_out, HT, Lh, ZR, ACT, HTs, st, err);
-    }
+    if (const int HTs = coop_grad_stage_store_tiles(c, plan, B, alg, nsteps, tgrid != nullptr))
+        return coop_grad3_run(G, c, plan, packed_dev, w_off, b_off, x, eps, ys, alg, nsteps, t0, t1, B, lam, grad, grad_x, logp_out, regs_out, HT, Lh, ZR, ACT, HTs, st, err);
     const int N = c.n_layers, D = c.nvars + c.naug, H = c.widths[1], n_in = c.widths[0];
     LDesc L{};
     L.n_layers = N;

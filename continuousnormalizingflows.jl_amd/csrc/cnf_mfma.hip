@@ -477,7 +477,12 @@ long long mfma_plan_ckpt_tiles(const MfmaPlan* p, long long B, bool on_grid) {
 int mfma_plan_stage_store_tiles(const MfmaPlan* p, long long B, bool on_grid) {
     if (!p || on_grid) return 0;
     (void)plan_ensure_cus(const_cast<MfmaPlan*>(p));
-    if (plan_uses_coopd(p, B)) return 0;
+    if (plan_uses_coopd(p, B)) {   // the dealt kernel in its 64-sample form (cnf_coop_d.hip) stores the real tiles
+        int hmax = 0;
+        for (int l = 1; l < p->cfg.n_layers; ++l) hmax = p->cfg.widths[l] > hmax ? p->cfg.widths[l] : hmax;
+        if (p->cfg.ncond != 0 || coopd_supertile(hmax, p->cfg.nvars + p->cfg.naug, p->L, p->ACT, 0) != 64) return 0;
+        return (hmax + 15) / 16;
+    }
     if (p->kind == 1 && coop_ckpt_supported(p->HT, p->L, p->ZR, p->ACT)) return p->HT;
     return 0;
 }

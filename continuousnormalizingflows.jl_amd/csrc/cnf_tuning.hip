@@ -1,6 +1,8 @@
 // cnf_tuning.hip - the library's ONE switchboard (include/cnf.h: cnf_tuning): defaults, the CNF_* environment variables that
-// override them when a handle is created, cnf_get_tuning / cnf_set_tuning.  No other file of the library reads the environment.
+// override them at the first use of the board (and again on cnf_set_tuning(NULL)), cnf_get_tuning / cnf_set_tuning.  No other file of the library reads the environment.
+#include <atomic>
 #include <cstdlib>
+#include <mutex>
 
 #include "cnf_internal.h"
 
@@ -46,21 +48,42 @@ const Knob kKnobs[] = {
     {"CNF_LG_WGRAD_T1", &cnf_tuning::lg_wgrad_t1, 5},
     {"CNF_LG_WGRAD_T2", &cnf_tuning::lg_wgrad_t2, 8},
 };
-cnf_tuning g_tuning = [] {
+cnf_tuning board_defaults() {
     cnf_tuning t{};
     for (const Knob& k : kKnobs) t.*(k.field) = k.dflt;
     return t;
-}();
-}  // namespace
-
-const cnf_tuning& tuning() { return g_tuning; }
-
-// defaults, then every variable that is set and not empty (integers; "1"-style flags read as their number)
-void tuning_from_env() {
+}
+// defaults, then every CNF_* variable that is set and not empty (integers; "1"-style flags read as their number)
+cnf_tuning board_from_env() {
+    cnf_tuning t = board_defaults();
     for (const Knob& k : kKnobs) {
         const char* v = getenv(k.env);
-        g_tuning.*(k.field) = (v && *v) ? (int32_t)atoi(v) : k.dflt;
+        if (v && *v) t.*(k.field) = (int32_t)atoi(v);
     }
+    return t;
+}
+// The board is published as an immutable snapshot behind one atomic pointer: a reader - any call of the library, on
+// any thread, on any handle - sees one consistent board for as long as it holds the reference, and a writer never edits a board
+// somebody reads.  Superseded snapshots are not freed (a reader may still hold one; ~150 bytes per change).
+std::atomic<const cnf_tuning*> g_board{nullptr};
+std::mutex g_board_mu;
+std::once_flag g_board_once;
+void publish(const cnf_tuning& t) {
+    std::lock_guard<std::mutex> lk(g_board_mu);
+    g_board.store(new cnf_tuning(t), std::memory_order_release);
+}
+}  // namespace
+
+// The environment is read ONCE, at the first use of the board, and again only on request (cnf_set_tuning(NULL)): creating a
+// handle - the library itself creates internal ones - never reverts what cnf_set_tuning set.
+const cnf_tuning& tuning() {
+    std::call_once(g_board_once, [] { publish(board_from_env()); });
+    return *g_board.load(std::memory_order_acquire);
+}
+
+void tuning_from_env() {
+    (void)tuning();
+    publish(board_from_env());
 }
 
 }  // namespace cnf
@@ -68,12 +91,12 @@ void tuning_from_env() {
 extern "C" {
 int cnf_get_tuning(cnf_tuning* out) {
     if (!out) return CNF_ERR_INVALID;
-    *out = cnf::g_tuning;
+    *out = cnf::tuning();
     return CNF_OK;
 }
 int cnf_set_tuning(const cnf_tuning* in) {
-    if (!in) cnf::tuning_from_env();   // NULL: the defaults + the CNF_* variables again (what cnf_create does)
-    else cnf::g_tuning = *in;
+    if (!in) cnf::tuning_from_env();   // NULL: the defaults + the CNF_* variables again
+    else { (void)cnf::tuning(); cnf::publish(*in); }
     return CNF_OK;
 }
 }

@@ -483,6 +483,12 @@ class ICNF:
             return int(h.lib.cnf_grad_path(h.ptr))
         return int(h.lib.cnf_grad_path_for(h.ptr, int(B), int(alg), int(on_grid)))
 
+    def grad_form(self, mode: Mode, B: int, alg: int = _lib.ALG_TSIT5, nsteps: int = 40, on_grid: bool = False) -> int:
+        """Which form of the cooperative reverse sweep a call takes (cnf_grad_form_for): 0 none, 1 the sweeps that recompute both
+        first-order chains, 2 the second form (the forward solve's stage store + the second-order sweep + products over tiles)."""
+        h = self._handle(mode)
+        return int(h.lib.cnf_grad_form_for(h.ptr, int(B), int(alg), int(nsteps), int(on_grid)))
+
     def kernel_family(self, mode: Mode, B: Optional[int] = None, whole_solve: bool = True) -> str:
         """Which kernel organisation serves this mode's handle ("per_wave", "coop", "coopx", "layered", "simt"), or - with `B` -
         a call of B columns ("tile_split" for small whole solves of per-wave shapes): cnf_kernel_family / cnf_kernel_family_for."""

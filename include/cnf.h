@@ -35,7 +35,7 @@
  *   column shards (RCCL)     cnf_comm_unique_id, cnf_comm_init, cnf_comm_init_all, cnf_comm_destroy, cnf_comm_rank, cnf_comm_size,
  *                            cnf_allreduce_loss (the mean in `loss`), cnf_allreduce_sum, cnf_comm_group_start / _end
  *   tuning (A/B, tests)      cnf_get_tuning, cnf_set_tuning
- *   introspection            cnf_version, cnf_build_info, cnf_last_error, cnf_kernel_path, cnf_kernel_family, cnf_grad_path, cnf_grad_path_for, cnf_repack_on_device, cnf_solve_controller
+ *   introspection            cnf_version, cnf_build_info, cnf_last_error, cnf_kernel_path, cnf_kernel_family, cnf_grad_path, cnf_grad_path_for, cnf_grad_form_for, cnf_repack_on_device, cnf_solve_controller
  */
 #ifndef CNF_H
 #define CNF_H
@@ -111,9 +111,12 @@ typedef struct {
 typedef struct cnf_handle cnf_handle;
 
 /* Tuning switchboard: every A/B and test switch of the library in one place.  The defaults are what ships; the environment
- * variable CNF_<FIELD IN CAPITALS> overrides a field when a handle is created (cnf_create re-reads the environment - a test hook,
- * not configuration), cnf_set_tuning replaces the whole board afterwards.  Process-wide: the switches select among kernels that
- * compute the same thing (parity tests cross-check them), so they are not part of a handle's identity. */
+ * variable CNF_<FIELD IN CAPITALS> overrides a field when the library first consults the board and again on cnf_set_tuning(NULL)
+ * - a hook for tests and A/B runs, not configuration; cnf_set_tuning replaces the whole board.  Creating a handle never touches
+ * it (the library creates internal handles itself).  Process-wide: the switches select among kernels that compute the same
+ * thing (parity tests cross-check them), so they are not part of a handle's identity.  Thread safety: the board is published
+ * as an immutable snapshot behind one atomic pointer, so cnf_get_tuning / cnf_set_tuning may be called from any thread; a call
+ * of the library that is in flight on another thread while the board changes may run under the old board or the new one. */
 typedef struct cnf_tuning {
     int32_t tile_split;            /* CNF_TILE_SPLIT, default 1: 1: whole fixed-step solves of per-wave shapes with at most one 16-sample tile per CU take the tile-split kernel; 0: never; 2: always */
     int32_t solve2;                /* CNF_SOLVE2, default 2: whole fixed-step solves of one-probe VJP flows without conditions on the hand-scheduled per-wave kernel (csrc/cnf_mfma2.hip; same bits) with two waves per SIMD; 1: one wave per SIMD; 0: mfma_solve_kernel */
@@ -153,7 +156,7 @@ typedef struct cnf_tuning {
     int32_t lg_wgrad_t2;           /* CNF_LG_WGRAD_T2, default 8: lg_wgrad: chunk-sharing threshold for 12 per CU */
 } cnf_tuning;
 int cnf_get_tuning(cnf_tuning* out);
-int cnf_set_tuning(const cnf_tuning* in);   /* NULL: defaults + environment again, as cnf_create does */
+int cnf_set_tuning(const cnf_tuning* in);   /* NULL: defaults + the CNF_* environment variables, read again */
 
 int cnf_version(void);
 const char* cnf_last_error(void);
@@ -404,6 +407,14 @@ int cnf_grad_path(const cnf_handle* h);
  * what cnf_loss_grad_fixed (on_grid = 0) / cnf_loss_grad_grid, cnf_loss_grad_adaptive (on_grid = 1) WILL take for B columns
  * with `alg` (CNF_ALG_RK4 / CNF_ALG_TSIT5); same codes. */
 int cnf_grad_path_for(const cnf_handle* h, int64_t B, int alg, int on_grid);
+
+/* Which FORM of the cooperative reverse sweep (code 3 above) a call of B columns and `nsteps` steps of `alg` takes: 0 = the call
+ * does not take the cooperative sweep; 1 = the sweeps that recompute the forward chain and the first-order pullback per stage
+ * (cnf_coop_grad.hip, cnf_coop_dgrad.hip; operands of the weight cotangents as column-major arrays); 2 = the second form
+ * (round 6): the checkpointing forward solve stores h_l and delta_l of every stage (2 L H floats per
+ * sample and stage of HBM, bounded by cnf_tuning.coop_grad3_gib), the sweep (cnf_coop_grad3.hip) runs the second-order chains
+ * alone, the weight cotangents are products over tiles (cnf_wgrad_tiles.hip).  Same gradient to rounding. */
+int cnf_grad_form_for(const cnf_handle* h, int64_t B, int alg, int nsteps, int on_grid);
 
 /* ---- column shards: the one exchange step of the path -----------------------------------------
  * Under fixed-step integration every column (sample) is independent (src/core/icnf.jl:530-535 is column-wise), so rank r

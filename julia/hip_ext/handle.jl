@@ -192,5 +192,9 @@ kernel_name(h::Handle) = unsafe_string(ccall((:cnf_kernel_name, libcnf), Cstring
 grad_path(h::Handle, B::Integer, alg_id::Integer; on_grid::Bool = false) =
     Int(ccall((:cnf_grad_path_for, libcnf), Cint, (Ptr{Cvoid}, Int64, Cint, Cint), h.ptr, B, alg_id, on_grid ? 1 : 0))
 
+"`grad_form(h, B, alg_id, nsteps; on_grid = false)`: the form of the cooperative sweep a call takes - 0 none, 1 recomputing sweeps, 2 stage store + second-order sweep."
+grad_form(h::Handle, B::Integer, alg_id::Integer, nsteps::Integer; on_grid::Bool = false) =
+    Int(ccall((:cnf_grad_form_for, libcnf), Cint, (Ptr{Cvoid}, Int64, Cint, Cint, Cint), h.ptr, B, alg_id, nsteps, on_grid ? 1 : 0))
+
 "`build_info()`: the compiler and flags the loaded library was built with."
 build_info() = unsafe_string(ccall((:cnf_build_info, libcnf), Cstring, ()))

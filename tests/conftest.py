@@ -22,6 +22,18 @@ def pkg():
     return entry.load_package()
 
 
+@pytest.fixture(autouse=True)
+def _switchboard_back_to_the_environment():
+    """The library's switchboard (include/cnf.h: cnf_tuning) is process-wide and creating a handle no longer re-reads it:
+    monkeypatch restores the environment after a test, this restores the board (autouse fixtures are torn down last, i.e. after
+    monkeypatch has put the variables back), so no switch leaks into the next test."""
+    yield
+    try:
+        entry.load_package().reload_tuning()
+    except Exception:
+        pass   # no library built: nothing to restore
+
+
 @pytest.fixture(scope="session")
 def oracles():
     # the fp64 oracle issues thousands of tiny autograd calls; on a many-core host torch's default intra-op

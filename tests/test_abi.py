@@ -112,7 +112,7 @@ def test_cpp_host_example_compiles_against_the_header(tmp_path):
 
 def test_the_switchboard_is_the_only_reader_of_the_environment(pkg, monkeypatch):
     """include/cnf.h: cnf_tuning - every A/B and test switch in one documented struct, read from the CNF_* variables in ONE place
-    (csrc/cnf_tuning.hip; cnf_create calls it) and changed through cnf_set_tuning (VERDICT r4 next #5)."""
+    (csrc/cnf_tuning.hip: once, at the board's first use, and on cnf_set_tuning(NULL) - creating a handle never touches the board, ADVICE r5) and changed through cnf_set_tuning (VERDICT r4 next #5)."""
     import glob
     import os
     csrc = os.path.join(os.path.dirname(pkg._lib.LIB_PATH), "csrc")

@@ -85,7 +85,7 @@ def test_every_ccall_matches_the_header():
     need = {"cnf_create", "cnf_destroy", "cnf_set_params", "cnf_aug_f", "cnf_integrate_fixed_dt", "cnf_inference_fixed_dt",
             "cnf_solve_vcabm", "cnf_solve_tsit5", "cnf_loss_adaptive", "cnf_loss_grad_grid", "cnf_loss_grad_adaptive", "cnf_last_error",
             "cnf_comm_init", "cnf_comm_unique_id", "cnf_comm_destroy", "cnf_allreduce_loss",
-            "cnf_kernel_family", "cnf_kernel_family_for", "cnf_kernel_name", "cnf_grad_path_for", "cnf_build_info"}
+            "cnf_kernel_family", "cnf_kernel_family_for", "cnf_kernel_name", "cnf_grad_path_for", "cnf_grad_form_for", "cnf_build_info"}
     assert need <= seen, need - seen
 
 
