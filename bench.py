@@ -158,6 +158,20 @@ def coop_grad_flop_per_stage(spec):
     return solve + chain + wgrad
 
 
+def coop_grad3_flop_per_stage(spec):
+    """Product flop per sample per RK stage of the cooperative gradient's second form: the checkpointing forward
+    solve (chain + pullback + g), the sweep's second-order chains alone (dbar_1 = W_1 gbar, the H x H products up and down,
+    W_N^T kbar, Zbar = W_1^T sbar_1) and the weight cotangents over tiles (two terms per matrix)."""
+    w, D = spec.widths, spec.D
+    N = len(w) - 1
+    fwd = sum(2 * w[l + 1] * w[l] for l in range(N))
+    hid = sum(2 * w[l + 1] * w[l] for l in range(1, N - 1))
+    solve = fwd + hid + 2 * D * w[1] + 2 * D * w[1]                    # chain, pullback (c hoisted or not: counted), g
+    sweep = 2 * hid + 4 * (2 * D * w[1])                               # up, down; dbar_1, W_N^T kbar, Zbar (+ nothing else)
+    wgrad = sum(2 * 2 * w[l + 1] * w[l] for l in range(N))
+    return solve + sweep + wgrad
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -506,7 +520,10 @@ def report(w, m, a, steps, warmup, world):
         # instructions (2048 flop) per stage per 16-sample tile, recomputation included; (ii) the algorithmic figure:
         # reverse mode of a function costing F is 2F on top of F (each product once forwards, twice backwards) = 3 F
         gpath = icnf.grad_path(mode, B=B, alg=alg)      # the implementation THIS call took (cnf_grad_path_for), not the handle's hint
-        exec_ss = (grad_mfma_per_stage(spec) * 2048 / 16 if gpath == 1 else coop_grad_flop_per_stage(spec) if gpath == 3
+        gform = icnf.grad_form(mode, B, alg, NSTEPS) if gpath == 3 else 0
+        extra["gradient_form"] = gform
+        exec_ss = (grad_mfma_per_stage(spec) * 2048 / 16 if gpath == 1 else
+                   (coop_grad3_flop_per_stage(spec) if gform == 2 else coop_grad_flop_per_stage(spec)) if gpath == 3
                    else layered_flop_per_stage(spec)) * stages
         extra["executed_flop_per_sample_step"] = exec_ss
         extra["executed_frac"] = exec_ss * B * NSTEPS / (m["kern_ms"] * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS
@@ -555,7 +572,9 @@ def report(w, m, a, steps, warmup, world):
                    "mode": "grad" if grad else "infer",
                    **({"gradient_path": {1: "fused reverse-sweep kernel", 2: "layer-wise (hand-written MFMA product kernels)",
                                               3: "cooperative reverse sweep + deferred weight-cotangent products"}.get(
-                       icnf.grad_path(mode, B=B, alg=alg), "none")} if grad else {}),
+                       icnf.grad_path(mode, B=B, alg=alg), "none") +
+                       (" (second form: the forward solve stores h_l / delta_l, second-order sweep, products over tiles)"
+                        if extra.get("gradient_form") == 2 else "")} if grad else {}),
                    "collective": w.get("collective", ""),
                    "parallelism": f"column-shard x{world}, loss all-reduce (5 scalars)"
                    + (" + gradient all-reduce (nparams floats)" if grad else "")},

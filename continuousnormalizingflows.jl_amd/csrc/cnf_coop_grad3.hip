@@ -46,10 +46,10 @@ struct G3Args {
 
 namespace {
 
-template <int A>
-struct G3U {                 // this wave's units of one chain: shared tiles x 2 sample tiles, the left-over tile x 2 sample tiles
-    f32x4 S[A][2];
-    f32x4 R[2];
+template <int A, int NC>
+struct G3U {                 // this wave's units of one chain: shared tiles x NC sample tiles, the left-over tile x NC sample tiles
+    f32x4 S[A][NC];
+    f32x4 R[NC];
 };
 template <int A>
 struct G3Off { unsigned S[A]; unsigned Rr; };
@@ -69,59 +69,60 @@ __device__ __forceinline__ void g3_load_a(const DRs& R, const G3Off<A>& T, unsig
     for (int m = 0; m < A; ++m) aS[m] = dloadv(R, T.S[m], so);
     if constexpr (LO) aR = dloadv(R, T.Rr, so);
 }
-__device__ __forceinline__ void g3_load_b(const f32x4* __restrict__ bimg, int kg, int lane, f32x4 (&bq)[2]) {
-    bq[0] = bimg[(kg * 2 + 0) * 64 + lane];
-    bq[1] = bimg[(kg * 2 + 1) * 64 + lane];
+template <int NC>
+__device__ __forceinline__ void g3_load_b(const f32x4* __restrict__ bimg, int kg, int lane, f32x4 (&bq)[NC]) {
+#pragma unroll
+    for (int c = 0; c < NC; ++c) bq[c] = bimg[(kg * NC + c) * 64 + lane];
 }
-template <int A, bool LO, int JN>
-__device__ __forceinline__ void g3_mfma(const f32x4 (&aS)[A], const f32x4& aR, const f32x4 (&bq)[2], bool v0, G3U<A>& u) {
+template <int A, bool LO, int JN, int NC>
+__device__ __forceinline__ void g3_mfma(const f32x4 (&aS)[A], const f32x4& aR, const f32x4 (&bq)[NC], bool v0, G3U<A, NC>& u) {
 #pragma unroll
     for (int j = 0; j < JN; ++j)
 #pragma unroll
         for (int m = 0; m < A; ++m)
 #pragma unroll
-            for (int c = 0; c < 2; ++c) u.S[m][c] = mfma4(aS[m][j], bq[c][j], u.S[m][c]);
+            for (int c = 0; c < NC; ++c) u.S[m][c] = mfma4(aS[m][j], bq[c][j], u.S[m][c]);
     if constexpr (LO) {
         if (v0) {
 #pragma unroll
             for (int j = 0; j < JN; ++j)
 #pragma unroll
-                for (int c = 0; c < 2; ++c) u.R[c] = mfma4(aR[j], bq[c][j], u.R[c]);
+                for (int c = 0; c < NC; ++c) u.R[c] = mfma4(aR[j], bq[c][j], u.R[c]);
         }
     }
 }
-template <int A, bool LO>
-__device__ __forceinline__ void g3_mfma_rem(const f32x4 (&aS)[A], const f32x4& aR, const f32x4 (&bq)[2], bool v0, int rem, G3U<A>& u) {
-    if (rem == 4) g3_mfma<A, LO, 4>(aS, aR, bq, v0, u);
-    else if (rem == 3) g3_mfma<A, LO, 3>(aS, aR, bq, v0, u);
-    else if (rem == 2) g3_mfma<A, LO, 2>(aS, aR, bq, v0, u);
-    else g3_mfma<A, LO, 1>(aS, aR, bq, v0, u);
+template <int A, bool LO, int NC>
+__device__ __forceinline__ void g3_mfma_rem(const f32x4 (&aS)[A], const f32x4& aR, const f32x4 (&bq)[NC], bool v0, int rem, G3U<A, NC>& u) {
+    if (rem == 4) g3_mfma<A, LO, 4, NC>(aS, aR, bq, v0, u);
+    else if (rem == 3) g3_mfma<A, LO, 3, NC>(aS, aR, bq, v0, u);
+    else if (rem == 2) g3_mfma<A, LO, 2, NC>(aS, aR, bq, v0, u);
+    else g3_mfma<A, LO, 1, NC>(aS, aR, bq, v0, u);
 }
-// u += A(image) * B(LDS image: [k-group][2 column tiles][64 lanes]) over KG k-groups, the last one with `rem` k-steps; aS0 / aR0
+// u += A(image) * B(LDS image: [k-group][NC column tiles][64 lanes]) over KG k-groups, the last one with `rem` k-steps; aS0 / aR0
 // arrive holding the fragments of k-group 0.  Two fragment sets ping-pong, one k-group of lead.
-template <int A, bool LO>
+template <int A, bool LO, int NC>
 __device__ __forceinline__ void g3_gemm(const DRs& R, const G3Off<A>& T, unsigned img, int KG, int rem, bool v0,
-                                        const f32x4* __restrict__ bimg, int lane, f32x4 (&aS0)[A], f32x4& aR0, G3U<A>& u) {
-    f32x4 aS1[A], aR1 = {0.f, 0.f, 0.f, 0.f}, bq0[2], bq1[2];
-    g3_load_b(bimg, 0, lane, bq0);
+                                        const f32x4* __restrict__ bimg, int lane, f32x4 (&aS0)[A], f32x4& aR0, G3U<A, NC>& u) {
+    f32x4 aS1[A], aR1 = {0.f, 0.f, 0.f, 0.f}, bq0[NC], bq1[NC];
+    g3_load_b<NC>(bimg, 0, lane, bq0);
     const int KGf = KG - 1;
     int kg = 0;
 #pragma clang loop unroll(disable)
     for (; kg + 2 <= KGf; kg += 2) {
         g3_load_a<A, LO>(R, T, img, kg + 1, aS1, aR1);
-        g3_load_b(bimg, kg + 1, lane, bq1);
-        g3_mfma<A, LO, 4>(aS0, aR0, bq0, v0, u);
+        g3_load_b<NC>(bimg, kg + 1, lane, bq1);
+        g3_mfma<A, LO, 4, NC>(aS0, aR0, bq0, v0, u);
         g3_load_a<A, LO>(R, T, img, kg + 2, aS0, aR0);
-        g3_load_b(bimg, kg + 2, lane, bq0);
-        g3_mfma<A, LO, 4>(aS1, aR1, bq1, v0, u);
+        g3_load_b<NC>(bimg, kg + 2, lane, bq0);
+        g3_mfma<A, LO, 4, NC>(aS1, aR1, bq1, v0, u);
     }
     if (kg < KGf) {
         g3_load_a<A, LO>(R, T, img, KG - 1, aS1, aR1);
-        g3_load_b(bimg, KG - 1, lane, bq1);
-        g3_mfma<A, LO, 4>(aS0, aR0, bq0, v0, u);
-        g3_mfma_rem<A, LO>(aS1, aR1, bq1, v0, rem, u);
+        g3_load_b<NC>(bimg, KG - 1, lane, bq1);
+        g3_mfma<A, LO, 4, NC>(aS0, aR0, bq0, v0, u);
+        g3_mfma_rem<A, LO, NC>(aS1, aR1, bq1, v0, rem, u);
     } else {
-        g3_mfma_rem<A, LO>(aS0, aR0, bq0, v0, rem, u);
+        g3_mfma_rem<A, LO, NC>(aS0, aR0, bq0, v0, rem, u);
     }
 }
 
@@ -137,17 +138,24 @@ __device__ __forceinline__ f32x4 g3_G(const f32x4& h, const f32x4& dl, const f32
 
 // LDS: two exchange buffers [HT][2][64] (the partial tiles of Zbar alias the first), the gbar and kbar images [DT][2][64], C vectors
 // are not needed (no bias enters a second-order chain)
-constexpr int coop_grad3_lds_bytes(int HT, int DT) {
-    const int part = 4 * DT * 2;                       // [4 waves][DT][2] partial tiles
-    const int x0 = HT * 2 > part ? HT * 2 : part;
-    return (x0 + HT * 2 + 2 * DT * 2) * 64 * 16;
+constexpr int coop_grad3_lds_bytes(int HT, int DT, int NC, int NS = 6) {
+    const int part = 4 * DT * NC;                      // [4 waves][DT][NC] partial tiles
+    const int x0 = HT * NC > part ? HT * NC : part;
+    return (x0 + HT * NC + 2 * DT * NC + (NC == 2 ? 2 * NS * DT : 0)) * 64 * 16;   // ... + (NC = 2) Zbar_j of the running step: [2 owners][NS][DT]
 }
 
 // A: shared hidden tiles per wave; LO: the instance serves left-over tiles (HT = 4 A + b, b run-time); L: hidden layers;
 // KZ: state registers per lane (D <= 4 KZ, whole M-tiles); NS: stages of the instance
-template <int A, bool LO, int L, int KZ, int ACT, int NS>
+// PF: what a stage needs from HBM at its start (h_1, delta_L, the checkpoint rows) is requested a stage ahead (the A = 4, L = 3 instance
+// has no registers for it: 472 -> 512 with spills, 0.77 -> 0.86 ms per launch at cfg4; two hidden layers gain 11 %)
+// NC: sample tiles of a super-tile = column tiles of every product (2: 32 samples, waves 0 and 1 own the sample tiles; 4: 64 samples,
+// every wave owns one - a stage's fixed costs (barriers, the dense phase, prologues of the short products) are paid per twice the
+// MFMAs, and no wave idles through the dense phase: the form of the two-hidden-layer nets, whose stages are short)
+template <int A, bool LO, int L, int KZ, int ACT, int NS, int NC, bool PF>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 coop_grad3_step_kernel(G3Args ga) {
+    using U = G3U<A, NC>;
+    constexpr bool ZL = NC == 2;                     // Zbar_j of the running step in LDS (else in the global scratch CGArgs::zb: L2)
     static_assert(ACT == CNF_ACT_TANH_PRESCALED || ACT == CNF_ACT_SOFTPLUS, "act' and act'' are rebuilt from h: tanh and softplus");
     static_assert(KZ % 4 == 0, "state registers in whole M-tiles");
     static_assert(L == 2 || L == 3, "two or three hidden layers");
@@ -157,18 +165,19 @@ coop_grad3_step_kernel(G3Args ga) {
     constexpr int DT = KZ / 4;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int HT = 4 * A + G.b;
-    const int X0N = (HT * 2 > 4 * DT * 2 ? HT * 2 : 4 * DT * 2) * 64;
-    f32x4* X0 = reinterpret_cast<f32x4*>(smem);        // [HT][2][64]; the partial tiles [4 waves][DT][2][64] alias it
-    f32x4* X1 = X0 + X0N;                              // [HT][2][64]
-    f32x4* gbuf = X1 + HT * 2 * 64;                    // [DT][2][64]: gbar
-    f32x4* kbuf = gbuf + DT * 2 * 64;                  // [DT][2][64]: kbar
+    const int X0N = (HT * NC > 4 * DT * NC ? HT * NC : 4 * DT * NC) * 64;
+    f32x4* X0 = reinterpret_cast<f32x4*>(smem);        // [HT][NC][64]; the partial tiles [4 waves][DT][NC][64] alias it
+    f32x4* X1 = X0 + X0N;                              // [HT][NC][64]
+    f32x4* gbuf = X1 + HT * NC * 64;                   // [DT][NC][64]: gbar
+    f32x4* kbuf = gbuf + DT * NC * 64;                 // [DT][NC][64]: kbar
+    f32x4* zbL = kbuf + DT * NC * 64;                  // (ZL) [2 owners][NS][DT][64]: Zbar_j of the running step's stages (owner-private)
     f32x4* pbuf = X0;
     const int lane = threadIdx.x & 63, g = lane >> 4, n = lane & 15;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const bool owner = wave < 2;
+    const bool owner = wave < NC;
     const int D = a.D;
     const long long B = a.B;
-    const long long nst = a.ntiles_pad / 2;   // every 32-sample pair of the checkpoint arrays' tiles: the pairs behind the batch write zeros the cotangent products read
+    const long long nst = a.ntiles_pad / NC;   // every group of NC of the checkpoint arrays' tiles: the groups behind the batch write zeros the cotangent products read
     const DRs R0{__builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.packed), 0, 0x7fffffff, 0x00020000), (unsigned)lane * 16u};
     const float inv_fs = ACT == CNF_ACT_TANH_PRESCALED ? 1.f / kTanhPrescale : 1.f;   // the forward images of tanh nets carry the pre-scale
     const int ns = a.T.ns < NS ? a.T.ns : NS;
@@ -189,101 +198,127 @@ coop_grad3_step_kernel(G3Args ga) {
     const int HTs = q3.HTs, DTZ = q3.DTZ;
     const long long ntp = a.ntiles_pad;
     // byte offsets of this wave's units inside a column-tile PAIR of an [..][ntp][HTs] tile array (sample tile q, hidden tile mt)
-    unsigned uo[A][2], uoR[2];
+    unsigned uo[A][NC], uoR[NC];
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
+    for (int c = 0; c < NC; ++c) {
 #pragma unroll
         for (int m = 0; m < A; ++m) { uo[m][c] = (unsigned)lane * 16u + (unsigned)((c * HTs + mtS0 + m) * 1024); asm volatile("" : "+v"(uo[m][c])); }
         uoR[c] = (unsigned)lane * 16u + (unsigned)((c * HTs + tR) * 1024); asm volatile("" : "+v"(uoR[c]));
     }
     const unsigned arr_bytes = (unsigned)((long long)ns * ntp * HTs * 1024);
     auto rsrc = [&](const float* p) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, (int)arr_bytes, 0x00020000); };
-    auto load_units = [&](const float* arr, unsigned so, G3U<A>& u) {
+    auto load_units = [&](const float* arr, unsigned so, U& u) {
         const __amdgpu_buffer_rsrc_t r = rsrc(arr);
 #pragma unroll
         for (int m = 0; m < A; ++m)
 #pragma unroll
-            for (int c = 0; c < 2; ++c) u.S[m][c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)uo[m][c], (int)so, 0));
+            for (int c = 0; c < NC; ++c) u.S[m][c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)uo[m][c], (int)so, 0));
         if constexpr (LO) {
 #pragma unroll
-            for (int c = 0; c < 2; ++c) u.R[c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)uoR[c], (int)so, 0));
+            for (int c = 0; c < NC; ++c) u.R[c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)uoR[c], (int)so, 0));
         }
     };
-    auto store_units = [&](float* arr, unsigned so, const G3U<A>& u) {
+    auto store_units = [&](float* arr, unsigned so, const U& u) {
         const __amdgpu_buffer_rsrc_t r = rsrc(arr);
 #pragma unroll
         for (int m = 0; m < A; ++m)
 #pragma unroll
-            for (int c = 0; c < 2; ++c) {
+            for (int c = 0; c < NC; ++c) {
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, u.S[m][c]), r, (int)uo[m][c], (int)so, 2);
                 CNF_STORE_DATA_HAZARD(u.S[m][c]);
             }
         if constexpr (LO) {
             if (v0) {
 #pragma unroll
-                for (int c = 0; c < 2; ++c) {
+                for (int c = 0; c < NC; ++c) {
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, u.R[c]), r, (int)uoR[c], (int)so, 2);
                     CNF_STORE_DATA_HAZARD(u.R[c]);
                 }
             }
         }
     };
-    auto publish = [&](f32x4* __restrict__ xb, const G3U<A>& v) {
+    auto publish = [&](f32x4* __restrict__ xb, const U& v) {
 #pragma unroll
         for (int m = 0; m < A; ++m)
 #pragma unroll
-            for (int c = 0; c < 2; ++c) xb[((mtS0 + m) * 2 + c) * 64 + lane] = v.S[m][c];
+            for (int c = 0; c < NC; ++c) xb[((mtS0 + m) * NC + c) * 64 + lane] = v.S[m][c];
         if constexpr (LO) {
-            if (v0) { xb[(tR * 2 + 0) * 64 + lane] = v.R[0]; xb[(tR * 2 + 1) * 64 + lane] = v.R[1]; }
+            if (v0) {
+#pragma unroll
+                for (int c = 0; c < NC; ++c) xb[(tR * NC + c) * 64 + lane] = v.R[c];
+            }
         }
     };
-    auto zero_u = [&](G3U<A>& u) {
+    auto zero_u = [&](U& u) {
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int m = 0; m < A; ++m) { u.S[m][0] = z; u.S[m][1] = z; }
-        u.R[0] = z; u.R[1] = z;
-    };
-    auto park_u = [&](const G3U<A>& u, G3U<A>& p) {
+        for (int m = 0; m < A; ++m)
 #pragma unroll
-        for (int m = 0; m < A; ++m) { p.S[m][0] = park4(u.S[m][0]); p.S[m][1] = park4(u.S[m][1]); }
-        if constexpr (LO) { p.R[0] = park4(u.R[0]); p.R[1] = park4(u.R[1]); }
-    };
-    auto unpark_u = [&](const G3U<A>& p, G3U<A>& u) {
+            for (int c = 0; c < NC; ++c) u.S[m][c] = z;
 #pragma unroll
-        for (int m = 0; m < A; ++m) { u.S[m][0] = unpark4(p.S[m][0]); u.S[m][1] = unpark4(p.S[m][1]); }
-        if constexpr (LO) { u.R[0] = unpark4(p.R[0]); u.R[1] = unpark4(p.R[1]); }
+        for (int c = 0; c < NC; ++c) u.R[c] = z;
+    };
+    auto park_u = [&](const U& u, U& p) {
+#pragma unroll
+        for (int m = 0; m < A; ++m)
+#pragma unroll
+            for (int c = 0; c < NC; ++c) p.S[m][c] = park4(u.S[m][c]);
+        if constexpr (LO) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) p.R[c] = park4(u.R[c]);
+        }
+    };
+    auto unpark_u = [&](const U& p, U& u) {
+#pragma unroll
+        for (int m = 0; m < A; ++m)
+#pragma unroll
+            for (int c = 0; c < NC; ++c) u.S[m][c] = unpark4(p.S[m][c]);
+        if constexpr (LO) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) u.R[c] = unpark4(p.R[c]);
+        }
     };
     // vbar = (acc / fs) .* act'(h); acc <- dbar
-    auto up_ew = [&](G3U<A>& acc, const G3U<A>& h, G3U<A>& vb) {
+    auto up_ew = [&](U& acc, const U& h, U& vb) {
         auto one = [&](f32x4& ac, const f32x4& hh, f32x4& v) {
             ac = ac * inv_fs;
             v = ac * dact_from_h<ACT>(hh);
         };
 #pragma unroll
-        for (int m = 0; m < A; ++m) { one(acc.S[m][0], h.S[m][0], vb.S[m][0]); one(acc.S[m][1], h.S[m][1], vb.S[m][1]); }
-        if constexpr (LO) { one(acc.R[0], h.R[0], vb.R[0]); one(acc.R[1], h.R[1], vb.R[1]); }
+        for (int m = 0; m < A; ++m)
+#pragma unroll
+            for (int c = 0; c < NC; ++c) one(acc.S[m][c], h.S[m][c], vb.S[m][c]);
+        if constexpr (LO) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) one(acc.R[c], h.R[c], vb.R[c]);
+        }
     };
     // sbar = hbar .* act' + dbar .* G(h, delta): in place of hbar
-    auto down_ew = [&](G3U<A>& hb, const G3U<A>& h, const G3U<A>& dl, const G3U<A>& db) {
+    auto down_ew = [&](U& hb, const U& h, const U& dl, const U& db) {
         auto one = [&](f32x4& x, const f32x4& hh, const f32x4& dd, const f32x4& bb) {
             const f32x4 d = dact_from_h<ACT>(hh);
             x = x * d + bb * g3_G<ACT>(hh, dd, d);
         };
 #pragma unroll
-        for (int m = 0; m < A; ++m) { one(hb.S[m][0], h.S[m][0], dl.S[m][0], db.S[m][0]); one(hb.S[m][1], h.S[m][1], dl.S[m][1], db.S[m][1]); }
-        if constexpr (LO) { one(hb.R[0], h.R[0], dl.R[0], db.R[0]); one(hb.R[1], h.R[1], dl.R[1], db.R[1]); }
+        for (int m = 0; m < A; ++m)
+#pragma unroll
+            for (int c = 0; c < NC; ++c) one(hb.S[m][c], h.S[m][c], dl.S[m][c], db.S[m][c]);
+        if constexpr (LO) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) one(hb.R[c], h.R[c], dl.R[c], db.R[c]);
+        }
     };
     auto publish_dense = [&](f32x4* img, int ct, const float (&v)[KZ]) {
 #pragma unroll
-        for (int kg = 0; kg < DT; ++kg) img[(kg * 2 + ct) * 64 + lane] = f32x4{v[4 * kg], v[4 * kg + 1], v[4 * kg + 2], v[4 * kg + 3]};
+        for (int kg = 0; kg < DT; ++kg) img[(kg * NC + ct) * 64 + lane] = f32x4{v[4 * kg], v[4 * kg + 1], v[4 * kg + 2], v[4 * kg + 3]};
     };
 
     for (long long st = blockIdx.x; st < nst; st += gridDim.x) {
-        const long long smp0 = st * 32;
+        const long long smp0 = st * (16 * NC);
         const long long smp = smp0 + (owner ? wave : 0) * 16 + n;
         const bool valid = owner && smp < B;
         const long long sc = smp < B ? smp : B - 1;
-        const long long tile = st * 2 + (owner ? wave : 0);
+        const long long tile = st * NC + (owner ? wave : 0);
         float eps[KZ], zn[KZ], lam[KZ];
 #pragma unroll
         for (int s = 0; s < KZ; ++s) { eps[s] = 0.f; zn[s] = 0.f; lam[s] = 0.f; }
@@ -312,8 +347,37 @@ coop_grad3_step_kernel(G3Args ga) {
             }
         }
         __syncthreads();                 // the previous super-tile's readers of the LDS images are done
-        float* zbt = a.zb + (tile * 64 + lane) * (long long)(NS * KZ);
+        // Zbar_j of this wave's sample tile: [NS][DT] f32x4 per lane - LDS, or (NC = 4: no room) the kernel's global scratch, L2-resident
+        f32x4* zbt = ZL ? zbL + ((owner ? wave : 0) * NS * DT) * 64 + lane
+                        : reinterpret_cast<f32x4*>(a.zb) + ((tile * NS * DT) * 64 + lane);
         f32x4 aS[A], aR = {0.f, 0.f, 0.f, 0.f};
+        // What a stage needs from HBM at its very start - h_1 and delta_L of the stage (stage store), the checkpoint rows of the dense
+        // phase - is requested one stage AHEAD, under the previous stage's last H x H product: with one wave per SIMD nothing else
+        // hides a round trip to HBM, and the two D-sized products these loads used to sit in front of are a tenth of its length.
+        U hN, dN;
+        f32x4 krN[NS - 1][DT], kiN[DT], giN[DT];
+        auto load_rows = [&](int is) {
+            const long long rowb = (long long)a.step * ns * ntp + tile, rstride = ntp * 64 * (long long)ckzr;
+            const float* kbase = a.ckpt_k + (rowb * 64 + lane) * ckzr;
+            const float* gbase = (a.lam2 != 0.f ? a.ckpt_g : a.ckpt_k) + (rowb * 64 + lane) * ckzr;
+#pragma unroll
+            for (int j = 0; j < NS - 1; ++j) {
+                const int jj = j < ns ? j : ns - 1;
+#pragma unroll
+                for (int q = 0; q < DT; ++q) krN[j][q] = *reinterpret_cast<const f32x4*>(kbase + jj * rstride + 4 * q);
+            }
+#pragma unroll
+            for (int q = 0; q < DT; ++q) {
+                kiN[q] = *reinterpret_cast<const f32x4*>(kbase + is * rstride + 4 * q);
+                giN[q] = *reinterpret_cast<const f32x4*>(gbase + is * rstride + 4 * q);
+            }
+        };
+        auto stage_off = [&](int is) { return (unsigned)(((long long)is * ntp + st * NC) * HTs * 1024); };
+        if constexpr (PF) {
+            load_units(q3.fh[0], stage_off(ns - 1), hN);
+            load_units(q3.fd[L - 1], stage_off(ns - 1), dN);
+            if (owner) load_rows(ns - 1);
+        }
 
 #pragma clang loop unroll(disable)
         for (int i = ns - 1; i >= 0; --i) {
@@ -325,33 +389,22 @@ coop_grad3_step_kernel(G3Args ga) {
             const float cl = valid ? dt * bi : 0.f;      // cotangent of ldot (dL/d dlogp = +1 per column); zero for padding columns
             const float tt = tn + a.T.c[i] * dt;
             // byte offset of this super-tile's column-tile pair of stage i in every [ns][ntp][tiles] array
-            const unsigned soH = (unsigned)(((long long)i * ntp + st * 2) * HTs * 1024);
-            G3U<A> hcur;
-            load_units(q3.fh[0], soH, hcur);             // h_1: arrives under the dense phase and the first product
+            const unsigned soH = stage_off(i);
+            if constexpr (!PF) {
+                load_units(q3.fh[0], soH, hN);
+                if (owner) load_rows(i);
+            }
+            U hcur = hN;                            // h_1 of this stage (PF: requested a stage ago)
             if (owner) {
-                // ---- dense phase: stage state, kbar, gbar (cnf_coop_dgrad.hip's, one batch of 16-byte loads) ----
+                // ---- dense phase: stage state, kbar, gbar (cnf_coop_dgrad.hip's) on rows requested a stage ago ----
                 float zs[KZ], kbar[KZ], gbar[KZ];
                 f32x4 kr[NS - 1][DT], ki[DT], gi[DT], zr[NS - 1][DT];
-                {
-                    const long long rowb = (long long)a.step * ns * ntp + tile, rstride = ntp * 64 * (long long)ckzr;
-                    const float* kbase = a.ckpt_k + (rowb * 64 + lane) * ckzr;
-                    const float* gbase = (a.lam2 != 0.f ? a.ckpt_g : a.ckpt_k) + (rowb * 64 + lane) * ckzr;
-#pragma unroll
-                    for (int j = 0; j < NS - 1; ++j) {
-                        const int jj = j < ns ? j : ns - 1;
-#pragma unroll
-                        for (int q = 0; q < DT; ++q) kr[j][q] = *reinterpret_cast<const f32x4*>(kbase + jj * rstride + 4 * q);
-                    }
-#pragma unroll
-                    for (int q = 0; q < DT; ++q) {
-                        ki[q] = *reinterpret_cast<const f32x4*>(kbase + i * rstride + 4 * q);
-                        gi[q] = *reinterpret_cast<const f32x4*>(gbase + i * rstride + 4 * q);
-                    }
-                }
 #pragma unroll
                 for (int j = 0; j < NS - 1; ++j)
 #pragma unroll
-                    for (int q = 0; q < DT; ++q) zr[j][q] = *reinterpret_cast<const f32x4*>(zbt + (j + 1) * KZ + 4 * q);
+                    for (int q = 0; q < DT; ++q) { kr[j][q] = krN[j][q]; zr[j][q] = zbt[((j + 1) * DT + q) * 64]; }
+#pragma unroll
+                for (int q = 0; q < DT; ++q) { ki[q] = kiN[q]; gi[q] = giN[q]; }
 #pragma unroll
                 for (int s = 0; s < KZ; ++s) {
                     float acc = 0.f, kb = bi * lam[s];
@@ -416,18 +469,18 @@ coop_grad3_step_kernel(G3Args ga) {
                     }
                 }
             }
-            G3U<A> acc;
-            G3U<A> hP[L - 1], dbP[L - 1];               // h_l and dbar_l of the lower layers, parked until the way down
+            U acc;
+            U hP[L - 1], dbP[L - 1];               // h_l and dbar_l of the lower layers, parked until the way down
             zero_u(acc);
             g3_load_a<A, LO>(R, TZ, F1Z, 0, aS, aR);
             G3_SYNC();                                                                     // gbar / kbar published
             // ================= up 1: dbar_1 = W_1[:,0:D] gbar =================
-            g3_gemm<A, LO>(R, TZ, F1Z, G.KGZ, G.remZ, v0, gbuf, lane, aS, aR, acc);
+            g3_gemm<A, LO, NC>(R, TZ, F1Z, G.KGZ, G.remZ, v0, gbuf, lane, aS, aR, acc);
             g3_load_a<A, LO>(R, TH, FH, 0, aS, aR);
-            G3U<A> hlast, dblast;                        // h_L, dbar_L: used at the top, in registers
+            U hlast, dblast;                        // h_L, dbar_L: used at the top, in registers
 #pragma unroll
             for (int l = 0; l < L; ++l) {
-                G3U<A> vb;
+                U vb;
                 up_ew(acc, hcur, vb);                    // acc <- dbar_{l+1} (1-based), vb <- vbar_{l+1}
                 store_units(q3.sv[l], soH, vb);
                 if (l + 1 < L) {
@@ -438,7 +491,7 @@ coop_grad3_step_kernel(G3Args ga) {
                     zero_u(acc);
                     G3_SYNC();
                     // ================= up l + 2: dbar = W_{l+2} vbar_{l+1} =================
-                    g3_gemm<A, LO>(R, TH, FH + (unsigned)l * IMGH, G.KGH, G.remH, v0, (l & 1) ? X1 : X0, lane, aS, aR, acc);
+                    g3_gemm<A, LO, NC>(R, TH, FH + (unsigned)l * IMGH, G.KGH, G.remH, v0, (l & 1) ? X1 : X0, lane, aS, aR, acc);
                     if (l + 2 < L) g3_load_a<A, LO>(R, TH, FH + (unsigned)(l + 1) * IMGH, 0, aS, aR);
                     else g3_load_a<A, LO>(R, TZ, BN, 0, aS, aR);
                 } else {
@@ -447,12 +500,12 @@ coop_grad3_step_kernel(G3Args ga) {
                 }
             }
             // ================= the top: hbar_L = W_N^T kbar =================
-            G3U<A> dlt;
-            load_units(q3.fd[L - 1], soH, dlt);
+            U dlt;
+            if constexpr (!PF) load_units(q3.fd[L - 1], soH, dN);
             zero_u(acc);
-            g3_gemm<A, LO>(R, TZ, BN, G.KGZ, G.remZ, v0, kbuf, lane, aS, aR, acc);
+            g3_gemm<A, LO, NC>(R, TZ, BN, G.KGZ, G.remZ, v0, kbuf, lane, aS, aR, acc);
             g3_load_a<A, LO>(R, TH, BH + (unsigned)(L - 2) * IMGH, 0, aS, aR);
-            down_ew(acc, hlast, dlt, dblast);            // acc <- sbar_L
+            down_ew(acc, hlast, dN, dblast);             // acc <- sbar_L  (dN: delta_L of this stage)
             store_units(q3.ss[L - 1], soH, acc);
             // buffers: vbar_1 -> X0, (vbar_2 -> X1,) sbar_L -> the buffer the last up product did not read, alternating downwards
             constexpr int topbuf = (L - 1) & 1;          // L = 2: X1; L = 3: X0
@@ -462,15 +515,21 @@ coop_grad3_step_kernel(G3Args ga) {
             for (int l = L - 1; l >= 1; --l) {           // hbar_l = W_{l+1}^T sbar_{l+1}  (1-based l)
                 const int rb = ((L - 1 - l) & 1) ^ topbuf;   // the buffer sbar_{l+1} was published in
                 load_units(q3.fd[l - 1], soH, dlt);
+                if (PF && l == 1) {                      // the next stage's (i - 1) first needs, under this stage's last H x H product
+                    const int inx = i > 0 ? i - 1 : 0;
+                    load_units(q3.fh[0], stage_off(inx), hN);
+                    load_units(q3.fd[L - 1], stage_off(inx), dN);
+                    if (owner) load_rows(inx);
+                }
                 zero_u(acc);
                 G3_SYNC();
-                g3_gemm<A, LO>(R, TH, BH + (unsigned)(l - 1) * IMGH, G.KGH, G.remH, v0, rb ? X1 : X0, lane, aS, aR, acc);
+                g3_gemm<A, LO, NC>(R, TH, BH + (unsigned)(l - 1) * IMGH, G.KGH, G.remH, v0, rb ? X1 : X0, lane, aS, aR, acc);
                 if (l > 1) g3_load_a<A, LO>(R, TH, BH + (unsigned)(l - 2) * IMGH, 0, aS, aR);
                 else {
 #pragma unroll
                     for (int dm = 0; dm < DT; ++dm) fd[dm] = dloadv(R, vd[dm], B1 + (unsigned)mtS0 * 1024u);
                 }
-                G3U<A> hh, db;
+                U hh, db;
                 unpark_u(hP[l - 1], hh);
                 unpark_u(dbP[l - 1], db);
                 down_ew(acc, hh, dlt, db);               // acc <- sbar_l
@@ -478,9 +537,11 @@ coop_grad3_step_kernel(G3Args ga) {
                 if (l > 1) publish(rb ? X0 : X1, acc);
             }
             // ================= Zbar_i = W_1[:,0:D]^T sbar_1: partial tiles over this wave's own k-groups, from registers =================
-            f32x4 part[DT][2];
+            f32x4 part[DT][NC];
 #pragma unroll
-            for (int dm = 0; dm < DT; ++dm) { part[dm][0] = f32x4{0.f, 0.f, 0.f, 0.f}; part[dm][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+            for (int dm = 0; dm < DT; ++dm)
+#pragma unroll
+                for (int c = 0; c < NC; ++c) part[dm][c] = f32x4{0.f, 0.f, 0.f, 0.f};
             {
                 f32x4 f1[DT];
 #pragma unroll
@@ -500,7 +561,7 @@ coop_grad3_step_kernel(G3Args ga) {
 #pragma unroll
                                 for (int dm = 0; dm < DT; ++dm)
 #pragma unroll
-                                    for (int c = 0; c < 2; ++c) part[dm][c] = mfma4(cur[dm][j], acc.S[m][c][j], part[dm][c]);
+                                    for (int c = 0; c < NC; ++c) part[dm][c] = mfma4(cur[dm][j], acc.S[m][c][j], part[dm][c]);
                             }
                     } else if (v0) {
                         // (a left-over tile may be the last k-group: its k-steps beyond `rem` multiply zero columns of the image)
@@ -509,24 +570,24 @@ coop_grad3_step_kernel(G3Args ga) {
 #pragma unroll
                             for (int dm = 0; dm < DT; ++dm)
 #pragma unroll
-                                for (int c = 0; c < 2; ++c) part[dm][c] = mfma4(cur[dm][j], acc.R[c][j], part[dm][c]);
+                                for (int c = 0; c < NC; ++c) part[dm][c] = mfma4(cur[dm][j], acc.R[c][j], part[dm][c]);
                     }
                 }
             }
-            G3_SYNC();                                                                     // every reader of X0 is through
+            // (X0 - the partial tiles alias it - was last read by the product before the last one of the stage, and every wave has passed
+            // the barrier in front of the last one since: no barrier here)
 #pragma unroll
             for (int dm = 0; dm < DT; ++dm)
 #pragma unroll
-                for (int c = 0; c < 2; ++c) pbuf[((wave * DT + dm) * 2 + c) * 64 + lane] = part[dm][c];
+                for (int c = 0; c < NC; ++c) pbuf[((wave * DT + dm) * NC + c) * 64 + lane] = part[dm][c];
             G3_SYNC();
             if (owner) {
 #pragma unroll
                 for (int dm = 0; dm < DT; ++dm) {
-                    f32x4 v = pbuf[((0 * DT + dm) * 2 + wave) * 64 + lane];
+                    f32x4 v = pbuf[((0 * DT + dm) * NC + wave) * 64 + lane];
 #pragma unroll
-                    for (int w = 1; w < 4; ++w) v += pbuf[((w * DT + dm) * 2 + wave) * 64 + lane];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) zbt[i * KZ + 4 * dm + j] = v[j];
+                    for (int w = 1; w < 4; ++w) v += pbuf[((w * DT + dm) * NC + wave) * 64 + lane];
+                    zbt[(i * DT + dm) * 64] = v;
                 }
             }
             // (the next stage's first LDS writes - gbar / kbar images - touch neither exchange buffer; its first publish into X0 comes
@@ -536,7 +597,7 @@ coop_grad3_step_kernel(G3Args ga) {
 #pragma unroll
             for (int s = 0; s < KZ; ++s) {
                 float acc = lam[s];
-                for (int j = 0; j < ns; ++j) acc += zbt[j * KZ + s];
+                for (int j = 0; j < ns; ++j) acc += zbt[(j * DT + (s >> 2)) * 64][s & 3];
                 lam[s] = acc;
                 a.lam[(tile * 64 + lane) * KZ + s] = acc;
             }
@@ -554,9 +615,9 @@ coop_grad3_step_kernel(G3Args ga) {
 // ---------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------
-template <int A, bool LO, int L, int KZ, int ACT, int NS>
+template <int A, bool LO, int L, int KZ, int ACT, int NS, int NC, bool PF>
 static hipError_t launch_g3(const G3Args& a, int lds, int nblocks, hipStream_t st) {
-    auto kern = coop_grad3_step_kernel<A, LO, L, KZ, ACT, NS>;
+    auto kern = coop_grad3_step_kernel<A, LO, L, KZ, ACT, NS, NC, PF>;
     static DeviceOnce once;
     int dev = 0;
     hipError_t e0 = hipGetDevice(&dev);
@@ -571,10 +632,15 @@ static hipError_t launch_g3(const G3Args& a, int lds, int nblocks, hipStream_t s
 }
 
 struct G3Inst {
-    int A, LO, L, KZ, ACT;
+    int A, LO, L, KZ, ACT, NC;
     hipError_t (*fn[2])(const G3Args&, int, int, hipStream_t);   // [0] RK4 (4 stages), [1] Tsit5 (6 stages)
 };
-#define G3_INST(A, LO, L, KZ, ACT) G3Inst { A, LO, L, KZ, ACT, { &launch_g3<A, LO, L, KZ, ACT, 4>, &launch_g3<A, LO, L, KZ, ACT, 6> } }
+// three hidden layers: nothing requested ahead (the registers hold h_l and dbar_l of two layers); two: the next stage's first needs
+// requested a stage ahead.  Every instance runs 32-sample super-tiles: the 64-sample form (NC = 4: every wave an owner, a stage's
+// fixed costs per twice the MFMAs) is written, but its two-hidden-layer instances either crash this compiler's AGPR-copy rewrite
+// pass (A = 3; A = 2 with 8 state registers) or, built without -amdgpu-mfma-vgpr-form, spill 68 registers to scratch.
+#define G3_INSTX(A, LO, L, KZ, ACT, NC, PF) G3Inst { A, LO, L, KZ, ACT, NC, { &launch_g3<A, LO, L, KZ, ACT, 4, NC, PF>, &launch_g3<A, LO, L, KZ, ACT, 6, NC, PF> } }
+#define G3_INST(A, LO, L, KZ, ACT) G3_INSTX(A, LO, L, KZ, ACT, 2, (L == 2))
 static const G3Inst kG3[] = {
     G3_INST(4, false, 3, 8, CNF_ACT_TANH_PRESCALED),   // cfg4: 3 x 256, D <= 32
     G3_INST(2, false, 3, 8, CNF_ACT_TANH_PRESCALED),   // 3 x 128
@@ -603,7 +669,7 @@ bool coop_grad3_supported(int H, int D, int L, int ACT, int HT_lay, int ZR_lay, 
     if (HT_real > HT_lay || KZ > ZR_lay) return false;
     const G3Inst* c = g3_find(HT_real, L, KZ, ACT);
     if (!c || c->KZ > ZR_lay) return false;   // the checkpoint rows are read KZ registers wide
-    return coop_grad3_lds_bytes(HT_real, c->KZ / 4) <= 160 * 1024;
+    return coop_grad3_lds_bytes(HT_real, c->KZ / 4, c->NC) <= 160 * 1024;   // (sized for six stages)
 }
 
 hipError_t coop_grad3_step_launch(int H, int D, int L, int ACT, int HT_lay, int ZR_lay, const CG3Args& a, int num_cus, hipStream_t st) {
@@ -613,9 +679,9 @@ hipError_t coop_grad3_step_launch(int H, int D, int L, int ACT, int HT_lay, int 
     G3Args ga{};
     ga.c = a;
     dimg_fill(ga.g, H, D, L, HT_lay, ZR_lay, 0, c->A, 0);
-    const int lds = coop_grad3_lds_bytes(HT_real, c->KZ / 4);
+    const int lds = coop_grad3_lds_bytes(HT_real, c->KZ / 4, c->NC);
     if (lds > 160 * 1024) return hipErrorNotSupported;
-    const long long nst = a.c.ntiles_pad / 2;
+    const long long nst = a.c.ntiles_pad / c->NC;
     const int nblocks = (int)(nst < num_cus ? nst : num_cus);
     return c->fn[a.c.T.ns <= 4 ? 0 : 1](ga, lds, nblocks, st);
 }

@@ -1109,15 +1109,19 @@ static hipError_t coop_grad3_run(LayeredGrad& G, const cnf_config& c, MfmaPlan* 
     a.gb = W + o_gb; a.zt = W + o_zt; a.ep = W + o_ep; a.kb = W + o_kb;
     a.HTs = HTs; a.DTZ = DTZ;
     const float dt = (t1 - t0) / (float)nsteps;
+    // (Tried, round 6: the three kinds of product of a step - disjoint slab regions, disjoint operands; the D-sized ones bound by
+    // reading their H-row operand once, the H x H ones by the matrix pipe - side by side on three library-owned streams, joined
+    // before the next sweep: cfg4 86.4 -> 88.7 ms, default architecture nv = 20 / 28 52.2 -> 53.9 / 83.6 -> 86.9 ms.  Concurrent
+    // kernels slow each other down by more than the overlap gains, as round 3 found for the older form.  One stream.)
     for (int n = nsteps - 1; n >= 0; --n) {
         a.c.step = n; a.c.tn = t0 + (float)n * dt; a.c.dt = dt;
         for (int l = 0; l < Lh; ++l) { a.fh[l] = G.ws_store + S.at(0, l, n, 0); a.fd[l] = G.ws_store + S.at(1, l, n, 0); }
         LG_HIP(coop_grad3_step_launch(H, D, Lh, ACT, HT, ZR, a, G.num_cus, st));
-        // Wbar_1 += delta_1 gbar^T + sbar_1 [z; t]^T  (bias: row sums of sbar_1)
-        LG_HIP(wgrad_tiles(slabs + L.pa_off[0], npa_pad, ch1, nc1, H, n_in, WTTerm{a.fd[0], a.gb, HTs, DTZ}, WTTerm{a.ss[0], a.zt, HTs, DTZ}, nct, 1, st));
         // Wbar_{l+1} += delta_{l+1} vbar_l^T + sbar_{l+1} h_l^T
         for (int l = 1; l < Lh; ++l)
             LG_HIP(wgrad_tiles(slabs + L.pa_off[l], npa_pad, chH, ncH, H, H, WTTerm{a.fd[l], a.sv[l - 1], HTs, HTs}, WTTerm{a.ss[l], a.fh[l - 1], HTs, HTs}, nct, 1, st));
+        // Wbar_1 += delta_1 gbar^T + sbar_1 [z; t]^T  (bias: row sums of sbar_1)
+        LG_HIP(wgrad_tiles(slabs + L.pa_off[0], npa_pad, ch1, nc1, H, n_in, WTTerm{a.fd[0], a.gb, HTs, DTZ}, WTTerm{a.ss[0], a.zt, HTs, DTZ}, nct, 1, st));
         // Wbar_N += eps cbar^T + kbar h_L^T  (bias: row sums of kbar)
         LG_HIP(wgrad_tiles(slabs + L.pa_off[Lh], npa_pad, chN, ncN, D, H, WTTerm{a.ep, a.sv[Lh - 1], DT, HTs}, WTTerm{a.kb, a.fh[Lh - 1], DT, HTs}, nct, 1, st));
     }

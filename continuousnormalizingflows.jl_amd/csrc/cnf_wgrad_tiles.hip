@@ -21,6 +21,10 @@ namespace {
 
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 constexpr int kTileWords = 4 * 72;   // a parked tile: four lane groups, 64 + 8 words each
+// 16-column tiles of C a wave keeps at most: a strip of up to 12 tiles (H <= 192: the default architecture up to nvariables = 23) is ONE
+// column group - its X operand is read once, and an iteration carries 4 NTN MFMAs per wave against a fixed cost (a barrier, the
+// fetches, the parks); wider strips are dealt evenly over groups of <= 12 (16 tiles = 8 + 8)
+constexpr int kMaxNTN = 12;
 
 // NTN: 16-column tiles of C a wave keeps (one column group).  Four waves = four 16-row strips of C, sharing every Y tile.
 template <int NTN>
@@ -187,7 +191,7 @@ hipError_t launch_wt(const WTArgs& a, dim3 grid, hipStream_t st) {
 // asked for when five or more workgroups share a chunk (uneven strips even out), as lg_wgrad_chunks found for the same loop shape
 int wgrad_tiles_chunks(int M, int Nc, long long nct, int num_cus, long long* chunk_out) {
     const int RB = ((M + 15) / 16 + 3) / 4;
-    const int groups = ((Nc + 15) / 16 + 8) / 9;
+    const int groups = ((Nc + 15) / 16 + kMaxNTN - 1) / kMaxNTN;
     const int sharers = RB * groups;
     const int per_cu = sharers >= 5 ? 6 : 3;
     long long want = ((long long)per_cu * num_cus + sharers - 1) / sharers;
@@ -206,7 +210,7 @@ hipError_t wgrad_tiles(float* slabs, long long slab_stride, long long chunk, int
     a.slabs = slabs; a.slab_stride = slab_stride; a.t[0] = t0; a.t[1] = t1; a.nct = nct; a.chunk = chunk;
     a.M = M; a.Nc = Nc; a.bias = bias;
     const int MT = (M + 15) / 16, NT = (Nc + 15) / 16;
-    const int groups = (NT + 8) / 9;
+    const int groups = (NT + kMaxNTN - 1) / kMaxNTN;
     a.nchunks = nchunks; a.rblocks = (MT + 3) / 4; a.groups = groups;
     const dim3 grid((unsigned)(((nchunks + 7) / 8) * 8 * a.rblocks * a.groups));
     const int ntn = (NT + groups - 1) / groups;   // the strip's tiles dealt evenly over its groups
@@ -219,7 +223,10 @@ hipError_t wgrad_tiles(float* slabs, long long slab_stride, long long chunk, int
         case 6: return launch_wt<6>(a, grid, st);
         case 7: return launch_wt<7>(a, grid, st);
         case 8: return launch_wt<8>(a, grid, st);
-        default: return launch_wt<9>(a, grid, st);
+        case 9: return launch_wt<9>(a, grid, st);
+        case 10: return launch_wt<10>(a, grid, st);
+        case 11: return launch_wt<11>(a, grid, st);
+        default: return launch_wt<12>(a, grid, st);
     }
 }
 

@@ -6,8 +6,8 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp && cd $ROOT
 mkdir -p gpurun_out
 for kv in "$@"; do export "$kv"; done
-rocprofv3 --kernel-trace --stats -d gpurun_out/prof_$TAG -- python3 $TARGET > gpurun_out/${TAG}_prof.log 2>&1
-f=$(ls gpurun_out/prof_$TAG/*/*_kernel_stats.csv 2>/dev/null | head -1)
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$TAG -- python3 $TARGET > gpurun_out/${TAG}_prof.log 2>&1
+f=$(find gpurun_out/prof_$TAG -name "*_kernel_stats.csv" | head -1)
 [ -n "$f" ] && cp $f gpurun_out/${TAG}_kernel_stats.csv
 rm -rf gpurun_out/prof_$TAG
 head -14 gpurun_out/${TAG}_kernel_stats.csv | cut -c1-200

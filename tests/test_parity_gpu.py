@@ -1128,6 +1128,79 @@ def test_cooperative_gradient_at_full_size_agrees_with_the_layerwise_path(pkg, o
     assert np.all(np.isfinite(a[1])) and np.all(np.isfinite(a[2]))
 
 
+STAGE_STORE_GRAD_SHAPES = [
+    # (make_spec kwargs, B, alg, nsteps, lam, force the dealt forward kernel at this batch): the cooperative gradient's SECOND FORM
+    (dict(nvars=32, hidden=[256, 256, 256]), 40, 0, 2, None, False),                                   # BASELINE cfg4's shape, RK4, one ragged super-tile
+    (dict(nvars=32, hidden=[256, 256, 256]), 333, 1, 2, None, False),                                  # Tsit5, several super-tiles, tiles behind the batch
+    (dict(nvars=32, hidden=[256, 256, 256], reg_z=True, reg_j=True), 77, 0, 2, (0.02, 0.03, 0.0), False),   # |zdot| and |eps^T J| cotangents
+    (dict(nvars=30, naug=2, hidden=[250, 250, 250], autonomous=True, reg_aug=True), 65, 1, 2, (0.0, 0.0, 0.02), False),   # zero-padded width, no time row, |z_aug|
+    (dict(nvars=32, hidden=[256, 256, 256], reg_z=True, reg_j=True), 1, 0, 1, (0.01, 0.01, 0.0), False),    # one column, one step
+    # the forward solve on the dealt kernel (8 .. 15 hidden tiles; CNF_COOPD=2 takes it below 4096 columns): the real tiles are stored
+    (dict(nvars=16, naug=17, hidden=[136, 136], act=2, reg_z=True, reg_j=True, reg_aug=True), 70, 1, 2, (0.01, 0.01, 0.01), True),   # ICNF(nvariables = 16): 9 tiles (A = 2, one left-over), 12 state registers
+    (dict(nvars=20, naug=21, hidden=[168, 168], act=2, reg_z=True, reg_j=True, reg_aug=True), 130, 1, 2, (0.01, 0.01, 0.01), True),  # ICNF(nvariables = 20): 11 tiles (three left-over)
+    (dict(nvars=24, naug=25, hidden=[200, 200], act=2, reg_z=True, reg_j=True, reg_aug=True), 45, 0, 2, (0.01, 0.01, 0.01), True),   # ICNF(nvariables = 24): 13 tiles (A = 3), 16 state registers
+    (dict(nvars=12, hidden=[160, 160], act=2), 60, 1, 2, None, True),                                   # softplus, 10 tiles, D <= 32
+    (dict(nvars=10, hidden=[176, 176]), 40, 0, 3, None, True),                                          # tanh, two layers
+    (dict(nvars=20, naug=5, hidden=[200, 200, 200], reg_aug=True), 150, 0, 3, None, True),              # tanh, three layers, 13 of 16 tiles
+    (dict(nvars=8, hidden=[136, 136, 136], act=2), 90, 1, 2, None, True),                               # softplus, three layers (A = 2)
+]
+
+
+@pytest.mark.parametrize("kw,B,alg,nsteps,lam,dealt", STAGE_STORE_GRAD_SHAPES)
+def test_cooperative_gradient_second_form(kw, B, alg, nsteps, lam, dealt, pkg, oracles, monkeypatch):
+    """Round 6: the checkpointing forward solve stores h_l and delta_l of every stage as tiles, the sweep of
+    csrc/cnf_coop_grad3.hip runs the second-order chains alone and the weight cotangents are products over tiles
+    (csrc/cnf_wgrad_tiles.hip).  dloss/dps, dloss/dxs and the loss against fp64 autograd through the same discrete solve
+    (src/core/icnf.jl:90-99 differentiates `loss` through the solve), and against the sweeps that recompute both first-order
+    chains (CNF_COOP_GRAD3=0) on the same handle configuration; cnf_grad_form_for says which one a call takes."""
+    o64, _ = oracles
+    if dealt:
+        setsw(pkg, monkeypatch, "CNF_COOPD", "2")
+    spec = o64.make_spec(**kw)
+    if lam is None:
+        lam = (0.0, 0.0, 0.03 if spec.reg_aug else 0.0)
+    p, xs, eps, ys = o64.synth_inputs(spec, B, 654, bias_scale=0.2)
+    L, gref, gxref = o64.loss_and_grad(spec, p, xs, 0.0, 1.0, nsteps, alg, eps, ys, lam, wrt_x=True)
+    mode = mode_of(pkg, spec)
+    out = {}
+    for tag, flag in (("store", "1"), ("recompute", "0")):
+        setsw(pkg, monkeypatch, "CNF_COOP_GRAD3", flag)
+        icnf = make_icnf(pkg, spec, alg, nsteps, path=0, lambdas=lam)
+        val, g, gx = pkg.loss_and_gradient(icnf, mode, dev(xs), dev(p), {}, eps=dev(eps), wrt_x=True)
+        assert icnf.grad_path(mode, B=B, alg=alg) == 3
+        assert icnf.grad_form(mode, B, alg, nsteps) == (2 if tag == "store" else 1), (tag, icnf.grad_form(mode, B, alg, nsteps))
+        out[tag] = (float(val), g.cpu().numpy().astype(np.float64), gx.cpu().numpy().astype(np.float64))
+        assert abs(out[tag][0] - L) < 1e-4 + 2e-6 * abs(L), tag
+        scale = np.abs(gref).max()
+        assert np.max(np.abs(out[tag][1] - gref)) < 5e-5 * scale + 1e-6, (tag, np.max(np.abs(out[tag][1] - gref)) / scale)
+        assert np.max(np.abs(out[tag][2] - gxref)) < 5e-5 * np.abs(gxref).max() + 1e-7, tag
+    assert np.max(np.abs(out["store"][1] - out["recompute"][1])) < 2e-5 * np.abs(gref).max() + 1e-6
+
+
+def test_second_form_is_deterministic_and_falls_back_when_the_store_does_not_fit(pkg, oracles, monkeypatch):
+    """The stage store is bounded (cnf_tuning.coop_grad3_gib): a call whose store would not fit takes the recomputing sweeps, and
+    says so through cnf_grad_form_for.  Two calls of the second form on one handle return the same bits (fixed summation order)."""
+    o64, _ = oracles
+    spec = o64.make_spec(nvars=32, hidden=[256, 256, 256])
+    B, nsteps, alg = 2048, 3, 0
+    p, xs, eps, _ = o64.synth_inputs(spec, B, 11, bias_scale=0.2)
+    mode = pkg.TrainMode(False)
+    icnf = make_icnf(pkg, spec, alg, nsteps, path=0, lambdas=(0.0, 0.0, 0.0))
+    assert icnf.grad_form(mode, B, alg, nsteps) == 2
+    v1, g1 = pkg.loss_and_gradient(icnf, mode, dev(xs), dev(p), {}, eps=dev(eps))[:2]
+    v2, g2 = pkg.loss_and_gradient(icnf, mode, dev(xs), dev(p), {}, eps=dev(eps))[:2]
+    assert float(v1) == float(v2) and torch.equal(g1, g2)
+    # 2 kinds x 3 layers x nsteps x 4 stages x 128 tiles x 16 KB = 302 MB: does not fit 0 GiB
+    old = pkg.set_tuning(coop_grad3_gib=0)
+    try:
+        assert icnf.grad_form(mode, B, alg, nsteps) == 1
+        v3, g3 = pkg.loss_and_gradient(icnf, mode, dev(xs), dev(p), {}, eps=dev(eps))[:2]
+    finally:
+        pkg.set_tuning(**old)
+    assert abs(float(v3) - float(v1)) < 1e-6 * abs(float(v1)) + 1e-6
+    assert float((g3 - g1).abs().max()) < 2e-5 * float(g1.abs().max())
+
+
 SLAB_GRAD_SHAPES = [
     # two hidden layers, 4..7 hidden tiles: tile-fused reverse sweep with slab accumulators (csrc/cnf_grad_slab.hip)
     (dict(nvars=7, naug=8, hidden=[64, 64], act=2, reg_z=True, reg_j=True, reg_aug=True), (0.01, 0.01, 0.01), 45, 1, 3),   # ICNF(nvariables=7): D=15, two input tiles
