@@ -443,8 +443,9 @@ coop_grad3_step_kernel(G3Args ga) {
                     const long long ctile = (long long)i * ntp + tile;
                     f32x4* gbp = reinterpret_cast<f32x4*>(q3.gb) + (ctile * DTZ) * 64 + lane;
                     f32x4* ztp = reinterpret_cast<f32x4*>(q3.zt) + (ctile * DTZ) * 64 + lane;
-                    f32x4* epp = reinterpret_cast<f32x4*>(q3.ep) + (ctile * DT) * 64 + lane;
-                    f32x4* kbp = reinterpret_cast<f32x4*>(q3.kb) + (ctile * DT) * 64 + lane;
+                    const int DTs = q3.DTs;              // tiles of the D-row arrays: the configuration's (<= the instance's DT)
+                    f32x4* epp = reinterpret_cast<f32x4*>(q3.ep) + (ctile * DTs) * 64 + lane;
+                    f32x4* kbp = reinterpret_cast<f32x4*>(q3.kb) + (ctile * DTs) * 64 + lane;
                     const int kt = D >> 4, et = (D & 15) >> 2, gt = D & 3;   // where the time row (feature D) sits
                     for (int kg = 0; kg < DTZ; ++kg) {
                         f32x4 zv = {0.f, 0.f, 0.f, 0.f}, gv = {0.f, 0.f, 0.f, 0.f};
@@ -463,10 +464,11 @@ coop_grad3_step_kernel(G3Args ga) {
                         ztp[kg * 64] = zv;
                     }
 #pragma unroll
-                    for (int kg = 0; kg < DT; ++kg) {
-                        epp[kg * 64] = f32x4{eps[4 * kg], eps[4 * kg + 1], eps[4 * kg + 2], eps[4 * kg + 3]};
-                        kbp[kg * 64] = f32x4{kbar[4 * kg], kbar[4 * kg + 1], kbar[4 * kg + 2], kbar[4 * kg + 3]};
-                    }
+                    for (int kg = 0; kg < DT; ++kg)
+                        if (kg < DTs) {
+                            epp[kg * 64] = f32x4{eps[4 * kg], eps[4 * kg + 1], eps[4 * kg + 2], eps[4 * kg + 3]};
+                            kbp[kg * 64] = f32x4{kbar[4 * kg], kbar[4 * kg + 1], kbar[4 * kg + 2], kbar[4 * kg + 3]};
+                        }
                 }
             }
             U acc;

@@ -1107,7 +1107,7 @@ static hipError_t coop_grad3_run(LayeredGrad& G, const cnf_config& c, MfmaPlan* 
     a.c.lam1 = lam[0]; a.c.lam2 = lam[1]; a.c.lam3 = lam[2]; a.c.T = T;
     for (int l = 0; l < Lh; ++l) { a.sv[l] = W + o_sv[l]; a.ss[l] = W + o_ss[l]; }
     a.gb = W + o_gb; a.zt = W + o_zt; a.ep = W + o_ep; a.kb = W + o_kb;
-    a.HTs = HTs; a.DTZ = DTZ;
+    a.HTs = HTs; a.DTZ = DTZ; a.DTs = DT;
     const float dt = (t1 - t0) / (float)nsteps;
     // (Tried, round 6: the three kinds of product of a step - disjoint slab regions, disjoint operands; the D-sized ones bound by
     // reading their H-row operand once, the H x H ones by the matrix pipe - side by side on three library-owned streams, joined

@@ -1133,7 +1133,7 @@ STAGE_STORE_GRAD_SHAPES = [
     (dict(nvars=32, hidden=[256, 256, 256]), 40, 0, 2, None, False),                                   # BASELINE cfg4's shape, RK4, one ragged super-tile
     (dict(nvars=32, hidden=[256, 256, 256]), 333, 1, 2, None, False),                                  # Tsit5, several super-tiles, tiles behind the batch
     (dict(nvars=32, hidden=[256, 256, 256], reg_z=True, reg_j=True), 77, 0, 2, (0.02, 0.03, 0.0), False),   # |zdot| and |eps^T J| cotangents
-    (dict(nvars=30, naug=2, hidden=[250, 250, 250], autonomous=True, reg_aug=True), 65, 1, 2, (0.0, 0.0, 0.02), False),   # zero-padded width, no time row, |z_aug|
+    (dict(nvars=30, naug=2, hidden=[252, 252, 252], autonomous=True, reg_aug=True), 65, 1, 2, (0.0, 0.0, 0.02), False),   # zero-padded width (rows of four), no time row, |z_aug|
     (dict(nvars=32, hidden=[256, 256, 256], reg_z=True, reg_j=True), 1, 0, 1, (0.01, 0.01, 0.0), False),    # one column, one step
     # the forward solve on the dealt kernel (8 .. 15 hidden tiles; CNF_COOPD=2 takes it below 4096 columns): the real tiles are stored
     (dict(nvars=16, naug=17, hidden=[136, 136], act=2, reg_z=True, reg_j=True, reg_aug=True), 70, 1, 2, (0.01, 0.01, 0.01), True),   # ICNF(nvariables = 16): 9 tiles (A = 2, one left-over), 12 state registers
