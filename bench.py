@@ -331,17 +331,22 @@ class ClockProbe:
 # ---------------------------------------------------------------------------------------------------
 # workloads
 # ---------------------------------------------------------------------------------------------------
-def make_workload(pkg, o64, name, a, rank, dev, torch, arith=None, grad=None, batch=None):
-    kw, alg, Bdef, flop_ss, bytes_call_ss, bytes_fused, desc = CONFIGS[name]
-    B = batch or a.batch or Bdef
-    spec = o64.make_spec(**kw)
-    # weights are shared by all ranks; the batch is generated per global column block so an
-    # N-GPU run evaluates N different shards (weak scaling).
+def host_inputs(o64, name, rank, B):
+    """The synthetic inputs of a workload on the host: weights shared by all ranks; the batch generated per global
+    column block so that an N-GPU run evaluates N different shards (weak scaling)."""
+    spec = o64.make_spec(**CONFIGS[name][0])
     p = o64.glorot_params(spec, np.random.default_rng(20240612))
     rng = np.random.default_rng(20240612 + 1000 * (rank + 1))
     xs = rng.standard_normal((spec.nvars, B)).astype(np.float32)
     eps = rng.standard_normal((spec.nprobes * spec.D, B)).astype(np.float32)
     ys = rng.standard_normal((spec.ncond, B)).astype(np.float32) if spec.ncond else None
+    return spec, p, xs, eps, ys
+
+
+def make_workload(pkg, o64, name, a, rank, dev, torch, arith=None, grad=None, batch=None):
+    kw, alg, Bdef, flop_ss, bytes_call_ss, bytes_fused, desc = CONFIGS[name]
+    B = batch or a.batch or Bdef
+    spec, p, xs, eps, ys = host_inputs(o64, name, rank, B)
 
     acts = {0: "identity", 1: "tanh", 2: "softplus"}
     layers = [pkg.Dense(spec.widths[i], spec.widths[i + 1], acts[spec.acts[i]])
@@ -738,6 +743,22 @@ def main():
 
     if rank == 0:
         r = report(w, m, a, a.steps, a.warmup, world)
+        rf = r["roofline"]
+        # ---- the full record of the run: ONE line on stderr (prefix "bench.py detail: "); the stdout line below is its digest ----
+        detail = {"config": r["config"], "roofline": rf, "protocol": {"preroll_seconds": a.preroll_seconds}}
+
+        def digest(ri, grad):
+            q = ri["roofline"]
+            d = {"ms": round(ri["ms_per_step"], 4), "frac": round(q["frac"], 4), "value": round(ri["value"], 1),
+                 "family": ri["config"]["kernel_family"]}
+            if "executed_frac" in q:
+                d["exec"] = round(q["executed_frac"], 4)
+            if q.get("traffic_over_algorithmic"):
+                d["traffic_ratio"] = round(q["traffic_over_algorithmic"], 1)
+            if grad:
+                d["form"] = q.get("gradient_form", 0)
+            return d
+
         out = {
             "metric": "log-density evals (samples*steps)/sec" if a.mode == "infer"
             else "training-step evals (samples*steps)/sec: loss + dloss/dp",
@@ -745,55 +766,70 @@ def main():
             "warmup": a.warmup, "ms_per_step": r["ms_per_step"], "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if a.arith == "f32" else "f32 via 3-way bf16 split (6 bf16 MFMAs per hidden product)",
-            "data": "synthetic", "config": r["config"], "loss": r["loss"], "roofline": r["roofline"],
-            "protocol": {"preroll_seconds": a.preroll_seconds,
-                         "note": "W warm-up steps, an untimed pre-roll to the sustained clock, then exactly K timed "
-                                 "steps between barrier+synchronize; roofline from HIP events around each solve launch"},
+            "data": "synthetic",
+            "config": {k: r["config"][k] for k in ("workload", "name", "columns_per_gpu", "global_columns", "nsteps", "integrator", "kernel_family",
+                                                   "kernel", "mode", "parallelism") if k in r["config"]},
+            "loss": r["loss"],
+            "roofline": {"bound": "mfma", "achieved": rf["achieved"], "peak": rf["peak"], "unit": rf["unit"], "frac": rf["frac"],
+                         "traffic": rf["traffic"], "algorithmic_bytes": rf["algorithmic_bytes"], "traffic_over_algorithmic": rf["traffic_over_algorithmic"],
+                         "kernel_ms": rf["kernel_ms"], "kernel_ms_median": rf["kernel_ms_median"], "flop_per_sample_step": rf["flop_per_sample_step"],
+                         "per_call_abi_frac_of_8TBps": rf["hbm_model"]["per_call_abi_frac_of_8TBps"],
+                         **({"sustained_frac_last_quarter": rf["sustained"]["frac_last_quarter"],
+                             "clock_mhz": (rf["sustained"].get("clock_mhz") or {}).get("last_quarter")} if rf.get("sustained") else {}),
+                         **({k: rf[k] for k in ("executed_frac", "gradient_form") if k in rf}),
+                         "traffic_src": "profiles/pmc_traffic.json (committed PMC passes; bench.py cannot run rocprofv3 on itself)"},
         }
+        if "gradient_path" in r["config"]:
+            out["config"]["gradient_path"] = r["config"]["gradient_path"]
+        if r["config"].get("collective"):
+            out["config"]["collective"] = r["config"]["collective"]
         if ranks_seen is not None:
             out["ranks_seen"] = ranks_seen
         if more:
-            out["secondaries"] = {}
+            out["secondaries"] = {"_": "ms per step; frac of the f32 MFMA peak (gradients: 3 F convention), exec = executed flops; traffic_ratio = HBM bytes / algorithmic; form 2 = stage-store gradient"}
+            detail["secondaries"] = {}
             for item, wi, mi, ki in more:
                 if wi is None:
                     out["secondaries"][item] = {"error": mi}
                     continue
                 ri = report(wi, mi, a, ki, a.warmup, world)
-                rf = ri["roofline"]
-                out["secondaries"][item] = {
-                    "workload": ri["config"]["workload"], "mode": ri["config"]["mode"], "columns_per_gpu": ri["config"]["columns_per_gpu"],
-                    "kernel_family": ri["config"]["kernel_family"], **({"gradient_path": ri["config"]["gradient_path"]} if wi["grad"] else {}),
-                    "value": ri["value"], "unit": "samples*steps/s", "steps": ki, "ms_per_step": ri["ms_per_step"], "loss": ri["loss"],
-                    "roofline": {"kernel_ms": rf["kernel_ms"], "kernel_ms_median": rf["kernel_ms_median"], "frac": rf["frac"],
-                                 "achieved": rf["achieved"], "peak": rf["peak"], "unit": rf["unit"],
-                                 "flop_per_sample_step": rf["flop_per_sample_step"],
-                                 "traffic": rf["traffic"], "algorithmic_bytes": rf["algorithmic_bytes"],
-                                 "traffic_over_algorithmic": rf["traffic_over_algorithmic"], "traffic_source": rf["traffic_source"],
-                                 **({"executed_frac": rf["executed_frac"]} if "executed_frac" in rf else {}),
-                                 "what": ("loss + gradient (forward with checkpoints + reverse sweep), 3 F convention" if wi["grad"]
-                                          else "the fused solve kernel")}}
+                out["secondaries"][item] = digest(ri, wi["grad"])
+                detail["secondaries"][item] = ri
         if small is not None:
-            out["small_batch"] = small
+            out["small_batch"] = {k: v for k, v in small.items() if k != "what"}
         if sec is not None:
             r2 = report(sec[0], sec[1], a, a.steps, a.warmup, world)
-            out["secondary"] = {"metric": out["metric"], "unit": out["unit"], "steps": a.steps,
-                                "why": "the north_star's target configuration (Tsit5 x 40) by the same protocol", **r2}
+            out["secondary"] = {"name": sec[0]["name"], "why": "north_star's target (Tsit5 x 40), same protocol", "kernel_ms": r2["roofline"]["kernel_ms"],
+                                **digest(r2, sec[0]["grad"])}
+            detail["secondary"] = r2
         if bf is not None and bf[0] != "error":
             r3 = report(bf[0], bf[1], a, a.steps, a.warmup, world)
             out["secondary_bf16x6"] = {
-                "what": "the same workload with the hidden H x H products on six v_mfma_f32_16x16x32_bf16 per tile over an exact 3-way "
-                        "bf16 split of both operands (cnf_config.arith = CNF_ARITH_BF16X6; DESIGN.md section 4.1b): opt-in, not the headline",
-                "value": r3["value"], "unit": out["unit"], "ms_per_step": r3["ms_per_step"], "kernel_ms": r3["roofline"]["kernel_ms"],
-                "speedup_vs_f32": r3["value"] / r["value"], "loss": r3["loss"],
-                "dtype": "f32 via 3-way bf16 split (6 bf16 MFMAs per hidden product)",
-                "max_abs_dlogp_f32_vs_bf16x6": float(np.max(np.abs(bf[2]["f32"] - bf[2]["bf16x6"]))),
-                "note": "the MFMA-roofline fraction is not meaningful for this kernel (VALU / issue-bound, not MFMA-bound)"}
+                "what": "opt-in split-bf16 hidden products (cnf_config.arith = CNF_ARITH_BF16X6), not the headline",
+                "value": r3["value"], "ms_per_step": r3["ms_per_step"], "speedup_vs_f32": r3["value"] / r["value"],
+                "max_abs_dlogp_f32_vs_bf16x6": float(np.max(np.abs(bf[2]["f32"] - bf[2]["bf16x6"])))}
+            detail["secondary_bf16x6"] = r3
         elif bf is not None:
             out["secondary_bf16x6"] = {"error": bf[1]}
         if world == 1 and not a.no_cpu_baseline and not a.force_dist:
             p, xs, eps, ys = w["host"]
-            out["cpu_baseline"] = cpu_baseline(o64, oc, w["spec"], w["alg"], p, xs, eps, ys, a.cpu_seconds)
-            out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+            cb = cpu_baseline(o64, oc, w["spec"], w["alg"], p, xs, eps, ys, a.cpu_seconds)
+            detail["cpu_baseline"] = cb
+            out["cpu_baseline"] = {k: cb[k] for k in ("value", "unit", "cores", "kind", "sample", "host_threads", "julia_available")}
+            out["cpu_baseline"]["legs"] = {k: round(v["value"], 1) for k, v in cb["legs"].items() if "value" in v}
+            out["gpu_over_cpu"] = out["value"] / cb["value"]
+            # the legs BASELINE.md section 2 promises beside the headline: cfg2' (the north_star's target) and cfg1 (BASELINE config 1:
+            # "CPU MatrixMode (reference, no GPU)") on the C port, bounded samples
+            if default_line:
+                for nm in ("cfg2p", "cfg1"):
+                    try:
+                        sp, pp, xx, ee, yy = host_inputs(o64, nm, rank, CONFIGS[nm][2])
+                        leg = _cpu_leg_c_port(oc, sp, CONFIGS[nm][1], pp, xx, ee, yy, min(a.cpu_seconds, 5.0))
+                        out["cpu_baseline"][nm] = {"value": round(leg["value"], 1), "cores": leg["threads"], "sample": leg["sample"]}
+                    except Exception as ex:  # pragma: no cover
+                        out["cpu_baseline"][nm] = {"error": str(ex)[:120]}
+                if sec is not None and "value" in out["cpu_baseline"].get("cfg2p", {}):
+                    out["secondary"]["gpu_over_cpu"] = out["secondary"]["value"] / out["cpu_baseline"]["cfg2p"]["value"]
             if bf is not None and bf[0] != "error":
                 # the checker on the same 64 columns: the fp64 oracle (full 40-step solves), both arithmetics against it
                 idx = bf[2]["idx"]
@@ -801,8 +837,8 @@ def main():
                                             None if ys is None else ys[:, idx])[0]
                 out["secondary_bf16x6"]["max_abs_dlogp_vs_fp64"] = {
                     "columns": int(len(idx)), "f32": float(np.max(np.abs(bf[2]["f32"] - ref64))),
-                    "bf16x6": float(np.max(np.abs(bf[2]["bf16x6"] - ref64))), "tolerance": 1e-4,
-                    "oracle": "oracle/cnf_oracle64.py (float64 autograd), run in the cpu_baseline leg"}
+                    "bf16x6": float(np.max(np.abs(bf[2]["bf16x6"] - ref64))), "tolerance": 1e-4}
+        print("bench.py detail: " + json.dumps(detail), file=sys.stderr, flush=True)
         print(json.dumps(out))
     if sharded:
         c = pkg.get_comm()

@@ -387,7 +387,14 @@ int cnf_loss_grad_grid(cnf_handle* h, int alg, int nsteps, const float* tgrid, c
  * steps frozen into a grid, then cnf_loss_grad_grid on that grid.  This is what serves `Zygote.gradient` of a loss evaluated
  * with the reference's default sol_kwargs (VCABM at 1e-4: a multistep recurrence has no one-step discrete adjoint, so the
  * adaptive Tsit5 discretisation at the same tolerances is differentiated; the reference's own QuadratureAdjoint gradient is
- * likewise a separate solve that matches the forward pass to tolerance).  tgrid_out (host, may be NULL): the first grid_cap
+ * likewise a separate solve that matches the forward pass to tolerance).  HOW FAR this gradient is from the gradient of the
+ * exact flow's loss - what both it and the reference's adjoint approximate - is measured in the fp64 oracle
+ * (profiles/adaptive_gradient_gap.py -> profiles/r6/r6f_adaptive_gradient_gap.json, bounded by
+ * tests/test_oracle_gradient.py::test_frozen_grid_gradient_against_the_exact_flow): along random directions, against central
+ * differences of the loss on a VCABM solve at tolerance 1e-10, the frozen-grid gradient at 1e-4 is off by 1e-8 / 7e-8 relative for the
+ * reference's default architecture at nvariables = 1 / 8 with freshly initialised weights (four Tsit5 steps resolve that flow) and
+ * by 3e-5 / 2e-3 with the weights scaled threefold (22 / 39 steps) - while differences of the VCABM solve at its own 1e-4
+ * (step decisions moving with the parameters) are off by 1e-4 / 2.5e-2.  tgrid_out (host, may be NULL): the first grid_cap
  * grid times; stats (host, may be NULL).  Single process; synchronises `stream`. */
 int cnf_loss_grad_adaptive(cnf_handle* h, float t0, float t1, const float* x, const float* eps, const float* ys, int64_t B,
                            float abstol, float reltol, float dt_init, int maxiters, const float* lambdas, float* grad,

@@ -315,3 +315,36 @@ def test_reference_signature_fixture_is_current():
     spec.loader.exec_module(mod)
     assert mod.derive() == reference_table()
     assert mod.constructor_keywords() == json.load(open(os.path.join(ROOT, "tests", "golden", "reference_constructor_keywords.json")))
+
+
+def test_julia_environment_carries_the_references_bounds():
+    """julia/Project.toml: the compat bounds INTEGRATION.md states in prose, as a file Pkg can resolve - every
+    entry is the reference's own UUID and bound (checked against /root/reference/Project.toml where that tree exists), and every
+    package the recipe and the binding import is either listed, a standard library, the reference itself, or one of the four that
+    julia/setup_env.jl adds by name."""
+    import tomli
+    root = os.path.dirname(JL_DIR)
+    proj = tomli.load(open(os.path.join(root, "Project.toml"), "rb"))
+    deps, compat = proj["deps"], proj["compat"]
+    assert set(deps) | {"julia"} == set(compat) and compat["julia"] == "1.10"
+    ref = "/root/reference/Project.toml"
+    if os.path.exists(ref):
+        r = tomli.load(open(ref, "rb"))
+        for name, uuid in deps.items():
+            assert r["deps"][name] == uuid and r["compat"][name] == compat[name], name
+        assert r["compat"]["julia"] == compat["julia"]
+    imported = set()
+    for f in [os.path.join(root, "make_reference_golden.jl")] + [os.path.join(JL_DIR, n) for n in os.listdir(JL_DIR) if n.endswith(".jl")]:
+        for line in open(f):
+            m = re.match(r"\s*(?:import|using)\s+([A-Za-z0-9_., :]+)", line)
+            if m:
+                for part in m.group(1).split(","):
+                    name = part.strip().split(":")[0].split(".")[0].strip()
+                    if name:
+                        imported.add(name)
+    by_name = {"OrdinaryDiffEqTsit5", "OrdinaryDiffEqLowOrderRK", "NPZ", "JSON"}
+    setup = open(os.path.join(root, "setup_env.jl")).read()
+    assert all(n in setup for n in by_name)
+    known = set(deps) | by_name | {"ContinuousNormalizingFlows", "Libdl", "LinearAlgebra", "Random", "Pkg", "CNF"}
+    optional = {"AMDGPU", "MPI"}            # weak dependencies of the binding's device / multi-process glue, loaded by the user
+    assert imported - known - optional == set(), imported - known - optional

@@ -37,3 +37,27 @@ def test_gradient_fixture_is_reproducible(oracles):
     L, g = o64.loss_and_grad(spec, f["p"], f["xs"], 0.0, 1.0, int(f["nsteps"]), o64.ALG_TSIT5, f["eps"])
     assert abs(L - float(f["loss"])) < 1e-12
     assert np.max(np.abs(g - f["grad"])) < 1e-12
+
+
+def test_frozen_grid_gradient_against_the_exact_flow():
+    """What cnf_loss_grad_adaptive differs from (include/cnf.h): under the reference's default sol_kwargs it trains with
+    QuadratureAdjoint on the VCABM solution (src/core/icnf.jl:84-99); the library returns the exact gradient of the Tsit5 solve on the
+    frozen accepted steps.  Both approximate the gradient of the exact flow's loss: central differences of the loss on a VCABM solve
+    at 1e-10 along random directions.  Bounds for the default architecture at nvariables = 1 (nvariables = 8 and both weight scales:
+    profiles/r6/r6f_adaptive_gradient_gap.json, same script)."""
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "adaptive_gradient_gap.py")
+    spec = importlib.util.spec_from_file_location("adaptive_gradient_gap", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    fresh = mod.run(1, 1.0, ndir=3)
+    assert fresh["tsit5_steps"] <= 6 and fresh["rel_gap_frozen_vs_tight"] < 1e-6, fresh["rel_gap_frozen_vs_tight"]
+    stiff = mod.run(1, 3.0, ndir=3)
+    assert stiff["tsit5_steps"] > 10
+    # within the solver tolerance's own accuracy, and no worse than differentiating the adaptive VCABM solve itself
+    assert stiff["rel_gap_frozen_vs_tight"] < 2e-4, stiff["rel_gap_frozen_vs_tight"]
+    assert stiff["rel_loss_gap_frozen_vs_tight"] < 1e-4
+    committed = __import__("json").load(open(os.path.join(os.path.dirname(path), "r6", "r6f_adaptive_gradient_gap.json")))
+    worst = max(r["rel_gap_frozen_vs_tight"] for r in committed)
+    assert worst < 5e-3 and {(r["nvariables"], r["weight_scale"]) for r in committed} == {(1, 1.0), (1, 3.0), (8, 1.0), (8, 3.0)}

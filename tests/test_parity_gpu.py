@@ -2282,6 +2282,113 @@ def test_conditioned_fit_and_distribution_wrapper(pkg):
         d.logpdf(torch.zeros(1, 3))
 
 
+def _adapter_flow(pkg, o64, nvars, naug=0, ncond=0, hidden=(24, 24), act="softplus", nsteps=10, lambdas=(0.01, 0.01, 0.01), epsdist=None):
+    """A small flow for the adapter tests, its Spec for the fp64 oracle (TrainMode: Hutchinson VJP with the regularisers the
+    lambdas switch on; TestMode: exact trace) and the parameters LuxCore.setup would give it from a fixed generator."""
+    D = nvars + naug
+    widths = [D + 1 + ncond] + list(hidden) + [D]
+    layers = [pkg.Dense(widths[i], widths[i + 1], act if i + 1 < len(widths) - 1 else "identity") for i in range(len(widths) - 1)]
+    icnf = pkg.ICNF(nvariables=nvars, naugments=naug, nconditions=ncond, nn=pkg.Chain(*layers), steer_rate=0.0,
+                    lambda1=lambdas[0], lambda2=lambdas[1], lambda3=lambdas[2], device="cuda:0", epsdist=epsdist,
+                    sol_kwargs=dict(alg=pkg.Tsit5(), adaptive=False, nsteps=nsteps) if nsteps else None)
+    kw = dict(nvars=nvars, naug=naug, ncond=ncond, hidden=list(hidden), act=2 if act == "softplus" else 1)
+    train = o64.make_spec(reg_z=lambdas[0] != 0, reg_j=lambdas[1] != 0, reg_aug=lambdas[2] != 0 and naug > 0, **kw)
+    test = o64.make_spec(mode=2, **kw)
+    return icnf, train, test
+
+
+def test_distribution_wrappers_logpdf_against_the_oracle(pkg, oracles):
+    """ICNFDist / CondICNFDist (src/exts/dist_ext/core_icnf.jl:36-75, core_cond_icnf.jl:45): `logpdf(d, A)` is `inference` on
+    the wrapped flow - TestMode (exact trace) against the fp64 oracle on the same parameters, fixed-step and under the
+    reference's DEFAULT sol_kwargs (VCABM at 1e-4: the restatement of oracle/cnf_oracle64.py and a fine fixed-step solve);
+    a point given as a vector is the one-column matrix; the conditioned wrapper takes the FIRST n condition columns."""
+    o64, _ = oracles
+    rng = np.random.default_rng(31)
+    # ---- unconditioned, augmented, fixed-step ----
+    icnf, _, spec = _adapter_flow(pkg, o64, nvars=3, naug=2)
+    ps, st = pkg.setup(torch.Generator().manual_seed(7), icnf)
+    p = ps.numpy().astype(np.float32)
+    A = rng.standard_normal((3, 37)).astype(np.float32)
+    d = pkg.ICNFDist(icnf, pkg.TestMode(), ps.to("cuda:0"), st)
+    got = d.logpdf(torch.tensor(A)).cpu().numpy()
+    ref = o64.inference_fixed(spec, p, A, 0.0, 1.0, 10, 1, None)[0]
+    assert len(d) == 3 and got.shape == (37,) and np.max(np.abs(got - ref)) < TOL_SOLVE, np.max(np.abs(got - ref))
+    assert abs(float(d.logpdf(torch.tensor(A[:, 5]))) - ref[5]) < TOL_SOLVE                 # a vector: one point
+    assert np.max(np.abs(d.pdf(torch.tensor(A)).cpu().numpy() - np.exp(ref))) < 2e-4 * np.exp(ref).max()
+    # ---- the reference's default sol_kwargs: VCABM, reltol = abstol = 1e-4 (src/core/icnf.jl:84-89) ----
+    icnf_d, _, spec_d = _adapter_flow(pkg, o64, nvars=2, naug=3, nsteps=0)
+    ps_d, st_d = pkg.setup(torch.Generator().manual_seed(8), icnf_d)
+    p_d = ps_d.numpy().astype(np.float32)
+    A2 = rng.standard_normal((2, 24)).astype(np.float32)
+    got_d = pkg.ICNFDist(icnf_d, pkg.TestMode(), ps_d.to("cuda:0"), st_d).logpdf(torch.tensor(A2)).cpu().numpy()
+    assert icnf_d.adaptive and isinstance(icnf_d.sol_kwargs["alg"], pkg.VCABM)
+    u0 = np.vstack([A2.astype(np.float64), np.zeros((3 + 3, 24))])
+    u1, _ = o64.integrate_vcabm(spec_d, p_d, u0, 0.0, 1.0, 1e-4, 1e-4, None, None)
+    ref_v = o64.std_normal_logpdf(u1[:5]) - u1[5]
+    ref_fine = o64.inference_fixed(spec_d, p_d, A2, 0.0, 1.0, 200, 1, None)[0]
+    assert np.max(np.abs(got_d - ref_v)) < 200 * 1e-4 and np.max(np.abs(got_d - ref_fine)) < 100 * 1e-4, (np.max(np.abs(got_d - ref_v)), np.max(np.abs(got_d - ref_fine)))
+    # ---- conditioned: CondICNFDist(icnf, mode, ys, ps, st) uses ys[:, 1:n] ----
+    icnf_c, _, spec_c = _adapter_flow(pkg, o64, nvars=2, ncond=3, hidden=(32, 32), act="tanh")
+    ps_c, st_c = pkg.setup(torch.Generator().manual_seed(9), icnf_c)
+    p_c = ps_c.numpy().astype(np.float32)
+    Y = rng.standard_normal((3, 20)).astype(np.float32)
+    A3 = rng.standard_normal((2, 12)).astype(np.float32)
+    dc = pkg.CondICNFDist(icnf_c, pkg.TestMode(), torch.tensor(Y), ps_c.to("cuda:0"), st_c)
+    ref_c = o64.inference_fixed(spec_c, p_c, A3, 0.0, 1.0, 10, 1, None, Y[:, :12])[0]
+    assert np.max(np.abs(dc.logpdf(torch.tensor(A3)).cpu().numpy() - ref_c)) < TOL_SOLVE
+
+
+def test_mlj_model_fit_steps_and_transform_against_the_oracle(pkg, oracles):
+    """ICNFModel.fit (src/exts/mlj_ext/core_icnf.jl:32-57): two full-batch steps of OptimiserChain(WeightDecay, Adam) on
+    loss(icnf, TrainMode{true}(), xs, ps, st) - the parameters after them against the SAME optimiser arithmetic in numpy driven by
+    the fp64 oracle's loss_and_grad (probes pinned through `epsdist`, the shuffle replayed from the same generator); and
+    `transform` (core_icnf.jl:59-68) = exp.(logp̂x) in TestMode against the oracle on the fitted parameters."""
+    o64, _ = oracles
+    n, nvars, naug, nsteps = 48, 2, 1, 6
+    rng = np.random.default_rng(77)
+    X = rng.standard_normal((n, nvars)).astype(np.float32) * 0.7 + 0.3
+    probes = [rng.standard_normal((nvars + naug, n)).astype(np.float32) for _ in range(2)]
+    calls = []
+
+    def epsdist(gen, shape, device):                                    # rand!(rng, epsdist, eps): call k returns the k-th pinned array
+        e = probes[len(calls)]                                          # (the library asks for the Julia memory layout: (B, D) contiguous)
+        calls.append(shape)
+        assert shape == (e.shape[1], e.shape[0])
+        return torch.tensor(np.ascontiguousarray(e.T), device=device)
+
+    lam = (0.01, 0.02, 0.03)
+    icnf, spec, spec_test = _adapter_flow(pkg, o64, nvars, naug, nsteps=nsteps, lambdas=lam, epsdist=epsdist)
+    eta, wd, b1, b2, ee = 2e-3, 1e-4, 0.9, 0.999, 1e-8
+    model = pkg.ICNFModel(icnf=icnf, batchsize=0, epochs=2, eta=eta, weight_decay=wd, callback=None,
+                          shuffle_rng=torch.Generator().manual_seed(4), init_rng=torch.Generator().manual_seed(5))
+    (ps_fit, st), _, report = model.fit(X)
+    assert report["stats"]["iterations"] == 2 and len(calls) == 2
+    # ---- the same two steps in numpy on the oracle's gradients ----
+    p = pkg.setup(torch.Generator().manual_seed(5), icnf)[0].numpy().astype(np.float64)
+    g_sh = torch.Generator().manual_seed(4)
+    m = np.zeros_like(p); v = np.zeros_like(p)
+    sens = []
+    for k in range(2):
+        idx = torch.randperm(n, generator=g_sh).numpy()                  # MLUtils.DataLoader(shuffle = true): a fresh permutation per epoch
+        L, g = o64.loss_and_grad(spec, p.astype(np.float32), X.T[:, idx], 0.0, 1.0, nsteps, 1, probes[k], None, lam)
+        g = g + wd * p                                                   # WeightDecay in front of Adam
+        m = b1 * m + (1 - b1) * g; v = b2 * v + (1 - b2) * g * g
+        step = eta * (m / (1 - b1 ** (k + 1))) / (np.sqrt(v / (1 - b2 ** (k + 1))) + ee)
+        sens.append(np.abs(g) > 1e-3 * np.abs(g).max())                  # where the update is not the sign of rounding noise
+        p = p - step
+    got = ps_fit.cpu().numpy().astype(np.float64)
+    ok = sens[0] & sens[1]
+    assert ok.mean() > 0.8, ok.mean()
+    assert np.max(np.abs(got[ok] - p[ok])) < 2e-6, np.max(np.abs(got[ok] - p[ok]))          # two steps of 2e-3 each
+    assert np.max(np.abs(got - p)) <= 2.001 * 2 * eta                                       # the rest moved by at most a step per epoch
+    assert abs(report["stats"]["final_loss"] - L) < 1e-4 + 2e-6 * abs(L)
+    # ---- transform: exp.(logp̂x), TestMode, on the fitted parameters ----
+    Xn = rng.standard_normal((9, nvars)).astype(np.float32)
+    px = np.asarray(model.transform((ps_fit, st), Xn)["px"])
+    ref = np.exp(o64.inference_fixed(spec_test, got.astype(np.float32), Xn.T, 0.0, 1.0, nsteps, 1, None)[0])
+    assert np.max(np.abs(px - ref)) < 2e-4 * ref.max()
+
+
 def test_custom_base_and_probe_distributions(pkg, oracles):
     """ICNF(; basedist, epsdist) (src/core/icnf.jl:76-83): a non-default base density is evaluated on the host
     from the final state (logp̂x = logpdf(basedist, z) - Δlogp, base_icnf.jl:168) and sampled in generate;
