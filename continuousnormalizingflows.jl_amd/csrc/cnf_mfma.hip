@@ -654,7 +654,7 @@ int64_t mfma_adaptive_capacity(MfmaPlan* p) {
 // scratch of one device-controlled solve: [2][3][ntiles] doubles, then counter (4 ints) + 8 stats, dts_cap floats, dts_cap orders
 size_t mfma_adaptive_scratch_bytes(int64_t B, int dts_cap) {
     const size_t ntiles = (size_t)((B + 15) / 16);
-    return 12 * ntiles * sizeof(double) + 12 * sizeof(int) + (size_t)dts_cap * (sizeof(float) + sizeof(int));
+    return 64 + 12 * ntiles * sizeof(double) + (size_t)dts_cap * (sizeof(float) + sizeof(int));   // status words (fixed, at the head), slots, steps + orders
 }
 
 static void fill_kargs_adaptive(const MfmaPlan* p, const float* packed_dev, const SolveArgs& s, KArgs& a) {
@@ -668,28 +668,34 @@ static void fill_kargs_adaptive(const MfmaPlan* p, const float* packed_dev, cons
     a.K = p->KP;
 }
 
-// `epoch`: the caller's launch counter for this scratch buffer (0 after it was allocated).  The slots and the abort flag are tagged
-// with the launch's epoch (AArgs::epoch), so the buffer is zeroed only for the first launch on it and when the 16-bit epoch wraps.
+// `epoch`: the caller's opaque launch state for this scratch buffer (0 after it was allocated): low half = the launch counter the slots
+// and the abort flag are tagged with (AArgs::epoch), so the buffer is zeroed only for the first launch on it and when the 16-bit
+// counter wraps; high half = a key of the layout (tiles, step capacity) of the previous launch - the slots' extent moves with the
+// batch size, so a launch with another layout could otherwise find stale steps / orders words where it expects tagged slots, one of
+// which might carry the current epoch.  The status words (counter, stats, abort flag) sit at a FIXED offset at the head.
 static hipError_t fill_aargs_scratch(AArgs& q, void* scratch, long long ntiles, int dts_cap, int** stats_dev, float** dts_dev,
                                      int** orders_dev, unsigned* epoch, hipStream_t st) {
     char* base = (char*)scratch;
-    q.slots = (double*)base;
-    // grid_sum3's slots: [2 (round parity)][workgroups <= tiles][6] tagged words
-    const size_t slot_bytes = 12 * (size_t)ntiles * sizeof(double);
-    int* ints = (int*)(base + slot_bytes);
+    int* ints = (int*)base;                       // 16 status words
     q.counter = (unsigned*)ints;
     q.stats = ints + 4;
-    q.dts = (float*)(ints + 12);
-    q.orders = ints + 12 + dts_cap;
+    q.slots = (double*)(base + 64);
+    // grid_sum3's slots: [2 (round parity)][workgroups <= tiles][6] tagged words
+    const size_t slot_bytes = 12 * (size_t)ntiles * sizeof(double);
+    q.dts = (float*)(base + 64 + slot_bytes);
+    q.orders = (int*)(q.dts + dts_cap);
     *stats_dev = q.stats;
     *dts_dev = q.dts;
     if (orders_dev) *orders_dev = q.orders;
     hipError_t e = hipSuccess;
-    if (*epoch == 0 || *epoch >= 0xffffu) {
-        e = zero_async(base, slot_bytes + 12 * sizeof(int), st);
-        *epoch = 0;
+    const unsigned key = ((((unsigned)ntiles * 2654435761u) ^ ((unsigned)dts_cap * 40503u)) >> 13) & 0xffffu;
+    unsigned ep = *epoch & 0xffffu;
+    if (ep == 0 || ep >= 0xfffeu || (*epoch >> 16) != key) {
+        e = zero_async(base, 64 + slot_bytes, st);
+        ep = 0;
     }
-    q.epoch = ++*epoch;
+    q.epoch = ++ep;
+    *epoch = (key << 16) | ep;
     return e;
 }
 

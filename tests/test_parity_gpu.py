@@ -2351,8 +2351,11 @@ def test_mlj_model_fit_steps_and_transform_against_the_oracle(pkg, oracles):
     calls = []
 
     def epsdist(gen, shape, device):                                    # rand!(rng, epsdist, eps): call k returns the k-th pinned array
-        e = probes[len(calls)]                                          # (the library asks for the Julia memory layout: (B, D) contiguous)
+        k = len(calls)                                                  # (the library asks for the Julia memory layout: (B, D) contiguous)
         calls.append(shape)
+        if k >= len(probes):                                            # transform / TestMode draws probes too and ignores them (base_icnf.jl:258-259)
+            return torch.zeros(shape, device=device)
+        e = probes[k]
         assert shape == (e.shape[1], e.shape[0])
         return torch.tensor(np.ascontiguousarray(e.T), device=device)
 
@@ -2362,7 +2365,7 @@ def test_mlj_model_fit_steps_and_transform_against_the_oracle(pkg, oracles):
     model = pkg.ICNFModel(icnf=icnf, batchsize=0, epochs=2, eta=eta, weight_decay=wd, callback=None,
                           shuffle_rng=torch.Generator().manual_seed(4), init_rng=torch.Generator().manual_seed(5))
     (ps_fit, st), _, report = model.fit(X)
-    assert report["stats"]["iterations"] == 2 and len(calls) == 2
+    assert report["stats"]["iterations"] == 2 and len(calls) == 2          # one draw per optimiser step
     # ---- the same two steps in numpy on the oracle's gradients ----
     p = pkg.setup(torch.Generator().manual_seed(5), icnf)[0].numpy().astype(np.float64)
     g_sh = torch.Generator().manual_seed(4)
