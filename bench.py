@@ -222,14 +222,15 @@ def _cpu_leg_c_port(oc, spec, alg, p, xs, eps, ys, target_s):
     nt = os.cpu_count() or 1
     nt = min(nt, oc.max_threads()) if oc.max_threads() > 0 else nt
     oc.set_fast_tanh(True)   # the arithmetic Lux's CPU path runs (NNlib.tanh_fast); vectorises
-    B0 = 64 * nt
+    ncols = xs.shape[1]
+    B0 = min(64 * nt, ncols)        # (cfg1 has 1024 columns: fewer than 64 per thread of a 128-core host)
     t = time.perf_counter()
     oc.inference_fixed(spec, p, xs[:, :B0], 0.0, 1.0, NSTEPS, alg, eps[:, :B0],
                        None if ys is None else ys[:, :B0], nthreads=nt)
     dt0 = time.perf_counter() - t
     rate0 = B0 * NSTEPS / dt0
-    Bs = int(min(xs.shape[1], max(B0, rate0 * target_s / NSTEPS)))
-    Bs = max(B0, Bs // (64 * nt) * (64 * nt))
+    Bs = int(min(ncols, max(B0, rate0 * target_s / NSTEPS)))
+    Bs = min(ncols, max(B0, Bs // (64 * nt) * (64 * nt)))
     # a fast host finishes the whole batch in well under the target: repeat the solve until the sample is ~target_s long
     reps = int(max(1, min(64, round(rate0 * target_s / (Bs * NSTEPS)))))
     run = lambda: oc.inference_fixed(spec, p, xs[:, :Bs], 0.0, 1.0, NSTEPS, alg, eps[:, :Bs],
