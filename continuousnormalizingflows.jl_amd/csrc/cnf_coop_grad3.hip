@@ -37,6 +37,13 @@
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local"); \
     } while (0)
 
+// -DG3_TRACE: s_memtime at every phase boundary of one stage of one workgroup, printed by every wave (a measuring build)
+#ifdef G3_TRACE
+#define G3_T(k) do { asm volatile("" ::: "memory"); tr[k] = __builtin_amdgcn_s_memtime(); asm volatile("" ::: "memory"); } while (0)
+#else
+#define G3_T(k)
+#endif
+
 namespace cnf {
 
 struct G3Args {
@@ -100,9 +107,11 @@ __device__ __forceinline__ void g3_mfma_rem(const f32x4 (&aS)[A], const f32x4& a
 }
 // u += A(image) * B(LDS image: [k-group][NC column tiles][64 lanes]) over KG k-groups, the last one with `rem` k-steps; aS0 / aR0
 // arrive holding the fragments of k-group 0.  Two fragment sets ping-pong, one k-group of lead.
-template <int A, bool LO, int NC>
+// `hook()` runs right behind the product's LAST fragment request: what is issued there has nothing younger of this product waiting
+// behind it in the in-order memory counter, and travels under the product's last k-groups and the phase that follows.
+template <int A, bool LO, int NC, class Hook>
 __device__ __forceinline__ void g3_gemm(const DRs& R, const G3Off<A>& T, unsigned img, int KG, int rem, bool v0,
-                                        const f32x4* __restrict__ bimg, int lane, f32x4 (&aS0)[A], f32x4& aR0, G3U<A, NC>& u) {
+                                        const f32x4* __restrict__ bimg, int lane, f32x4 (&aS0)[A], f32x4& aR0, G3U<A, NC>& u, Hook&& hook) {
     f32x4 aS1[A], aR1 = {0.f, 0.f, 0.f, 0.f}, bq0[NC], bq1[NC];
     g3_load_b<NC>(bimg, 0, lane, bq0);
     const int KGf = KG - 1;
@@ -119,9 +128,11 @@ __device__ __forceinline__ void g3_gemm(const DRs& R, const G3Off<A>& T, unsigne
     if (kg < KGf) {
         g3_load_a<A, LO>(R, T, img, KG - 1, aS1, aR1);
         g3_load_b<NC>(bimg, KG - 1, lane, bq1);
+        hook();
         g3_mfma<A, LO, 4, NC>(aS0, aR0, bq0, v0, u);
         g3_mfma_rem<A, LO, NC>(aS1, aR1, bq1, v0, rem, u);
     } else {
+        hook();
         g3_mfma_rem<A, LO, NC>(aS0, aR0, bq0, v0, rem, u);
     }
 }
@@ -376,8 +387,8 @@ coop_grad3_step_kernel(G3Args ga) {
         if constexpr (PF) {
             load_units(q3.fh[0], stage_off(ns - 1), hN);
             load_units(q3.fd[L - 1], stage_off(ns - 1), dN);
-            if (owner) load_rows(ns - 1);
         }
+        if (owner) load_rows(ns - 1);   // (the rows: every instance)
 
 #pragma clang loop unroll(disable)
         for (int i = ns - 1; i >= 0; --i) {
@@ -390,10 +401,11 @@ coop_grad3_step_kernel(G3Args ga) {
             const float tt = tn + a.T.c[i] * dt;
             // byte offset of this super-tile's column-tile pair of stage i in every [ns][ntp][tiles] array
             const unsigned soH = stage_off(i);
-            if constexpr (!PF) {
-                load_units(q3.fh[0], soH, hN);
-                if (owner) load_rows(i);
-            }
+#ifdef G3_TRACE
+            unsigned long long tr[16];
+#endif
+            G3_T(0);
+            if constexpr (!PF) load_units(q3.fh[0], soH, hN);
             U hcur = hN;                            // h_1 of this stage (PF: requested a stage ago)
             if (owner) {
                 // ---- dense phase: stage state, kbar, gbar (cnf_coop_dgrad.hip's) on rows requested a stage ago ----
@@ -475,114 +487,143 @@ coop_grad3_step_kernel(G3Args ga) {
             U hP[L - 1], dbP[L - 1];               // h_l and dbar_l of the lower layers, parked until the way down
             zero_u(acc);
             g3_load_a<A, LO>(R, TZ, F1Z, 0, aS, aR);
+            G3_T(1);
             G3_SYNC();                                                                     // gbar / kbar published
+            G3_T(2);
+            // Every global access of the stage is PLACED (s_memtime trace of the first build, profiles/r6/r6i_sweep_phase_trace.txt: the
+            // memory counter retires in order, so eight tile stores or loads issued in FRONT of a product made its second k-group wait
+            // for their acknowledgements / round trips to HBM - the D-sized product at the top took 7.8 k cycles for 2.1 k of MFMAs,
+            // every H x H product 23 - 24 k for 16.4 k at cfg4): a tile set is LOADED behind the last fragment request of the product
+            // before the one whose elementwise phase needs it, and STORED behind the product that follows the phase that made it.
             // ================= up 1: dbar_1 = W_1[:,0:D] gbar =================
-            g3_gemm<A, LO, NC>(R, TZ, F1Z, G.KGZ, G.remZ, v0, gbuf, lane, aS, aR, acc);
+            U hnext;
+            g3_gemm<A, LO, NC>(R, TZ, F1Z, G.KGZ, G.remZ, v0, gbuf, lane, aS, aR, acc, [&]() { if constexpr (L > 1) load_units(q3.fh[1], soH, hnext); });
+            G3_T(3);
             g3_load_a<A, LO>(R, TH, FH, 0, aS, aR);
             U hlast, dblast;                        // h_L, dbar_L: used at the top, in registers
+            U vbl;                                   // vbar of the layer just finished, until the product behind it has been issued
 #pragma unroll
             for (int l = 0; l < L; ++l) {
-                U vb;
-                up_ew(acc, hcur, vb);                    // acc <- dbar_{l+1} (1-based), vb <- vbar_{l+1}
-                store_units(q3.sv[l], soH, vb);
+                up_ew(acc, hcur, vbl);                   // acc <- dbar_{l+1} (1-based), vbl <- vbar_{l+1}
                 if (l + 1 < L) {
-                    publish((l & 1) ? X1 : X0, vb);
+                    publish((l & 1) ? X1 : X0, vbl);
                     park_u(hcur, hP[l]);
                     park_u(acc, dbP[l]);
-                    load_units(q3.fh[l + 1], soH, hcur); // the next layer's h: arrives under the product
+                    hcur = hnext;
                     zero_u(acc);
+                    if (l == 0) G3_T(4);
                     G3_SYNC();
+                    if (l == 0) G3_T(5);
                     // ================= up l + 2: dbar = W_{l+2} vbar_{l+1} =================
-                    g3_gemm<A, LO, NC>(R, TH, FH + (unsigned)l * IMGH, G.KGH, G.remH, v0, (l & 1) ? X1 : X0, lane, aS, aR, acc);
+                    g3_gemm<A, LO, NC>(R, TH, FH + (unsigned)l * IMGH, G.KGH, G.remH, v0, (l & 1) ? X1 : X0, lane, aS, aR, acc,
+                                       [&]() {
+                                           if (l + 2 < L) load_units(q3.fh[l + 2 < L ? l + 2 : 0], soH, hnext);
+                                           else if (!PF) load_units(q3.fd[L - 1], soH, dN);      // delta_L for the top
+                                       });
+                    if (l == 0) G3_T(6);
                     if (l + 2 < L) g3_load_a<A, LO>(R, TH, FH + (unsigned)(l + 1) * IMGH, 0, aS, aR);
                     else g3_load_a<A, LO>(R, TZ, BN, 0, aS, aR);
+                    store_units(q3.sv[l], soH, vbl);
                 } else {
                     hlast = hcur;
                     dblast = acc;
                 }
             }
             // ================= the top: hbar_L = W_N^T kbar =================
-            U dlt;
-            if constexpr (!PF) load_units(q3.fd[L - 1], soH, dN);
+            G3_T(7);
+            U dlt, dln;
             zero_u(acc);
-            g3_gemm<A, LO, NC>(R, TZ, BN, G.KGZ, G.remZ, v0, kbuf, lane, aS, aR, acc);
+            g3_gemm<A, LO, NC>(R, TZ, BN, G.KGZ, G.remZ, v0, kbuf, lane, aS, aR, acc, [&]() { load_units(q3.fd[L - 2], soH, dln); });
+            G3_T(8);
             g3_load_a<A, LO>(R, TH, BH + (unsigned)(L - 2) * IMGH, 0, aS, aR);
+            store_units(q3.sv[L - 1], soH, vbl);
             down_ew(acc, hlast, dN, dblast);             // acc <- sbar_L  (dN: delta_L of this stage)
-            store_units(q3.ss[L - 1], soH, acc);
             // buffers: vbar_1 -> X0, (vbar_2 -> X1,) sbar_L -> the buffer the last up product did not read, alternating downwards
             constexpr int topbuf = (L - 1) & 1;          // L = 2: X1; L = 3: X0
             publish(topbuf ? X1 : X0, acc);
-            f32x4 fd[DT];
+            U sprev = acc;                               // sbar_{l+1}: stored behind the product that reads it
+            // the fragments of the Zbar product: ALL requested behind the last H x H product where they are few (<= 12 f32x4), else the first
+            // k-group's there and the others one k-group ahead inside the product
+            constexpr int NZ = A + (LO ? 1 : 0);
+            constexpr bool ZALL = NZ * DT <= 12;
+            f32x4 fz[ZALL ? NZ : 2][DT];
 #pragma unroll
             for (int l = L - 1; l >= 1; --l) {           // hbar_l = W_{l+1}^T sbar_{l+1}  (1-based l)
                 const int rb = ((L - 1 - l) & 1) ^ topbuf;   // the buffer sbar_{l+1} was published in
-                load_units(q3.fd[l - 1], soH, dlt);
-                if (PF && l == 1) {                      // the next stage's (i - 1) first needs, under this stage's last H x H product
-                    const int inx = i > 0 ? i - 1 : 0;
-                    load_units(q3.fh[0], stage_off(inx), hN);
-                    load_units(q3.fd[L - 1], stage_off(inx), dN);
-                    if (owner) load_rows(inx);
-                }
+                dlt = dln;
                 zero_u(acc);
+                if (l == 1) G3_T(9);
                 G3_SYNC();
-                g3_gemm<A, LO, NC>(R, TH, BH + (unsigned)(l - 1) * IMGH, G.KGH, G.remH, v0, rb ? X1 : X0, lane, aS, aR, acc);
+                if (l == 1) G3_T(10);
+                g3_gemm<A, LO, NC>(R, TH, BH + (unsigned)(l - 1) * IMGH, G.KGH, G.remH, v0, rb ? X1 : X0, lane, aS, aR, acc,
+                                   [&]() { if (l > 1) load_units(q3.fd[l > 1 ? l - 2 : 0], soH, dln); });
+                if (l == 1) G3_T(11);
                 if (l > 1) g3_load_a<A, LO>(R, TH, BH + (unsigned)(l - 2) * IMGH, 0, aS, aR);
                 else {
 #pragma unroll
-                    for (int dm = 0; dm < DT; ++dm) fd[dm] = dloadv(R, vd[dm], B1 + (unsigned)mtS0 * 1024u);
+                    for (int m = 0; m < (ZALL ? NZ : 1); ++m)
+#pragma unroll
+                        for (int dm = 0; dm < DT; ++dm) fz[m][dm] = dloadv(R, vd[dm], B1 + (unsigned)(m < A ? mtS0 + m : tR) * 1024u);
+                }
+                store_units(q3.ss[l], soH, sprev);
+                if (l == 1) {                            // the next stage's (i - 1) first needs: they travel under the rest of this stage
+                    const int inx = i > 0 ? i - 1 : 0;
+                    if constexpr (PF) {
+                        load_units(q3.fh[0], stage_off(inx), hN);
+                        load_units(q3.fd[L - 1], stage_off(inx), dN);
+                    }
+                    if (owner) load_rows(inx);
                 }
                 U hh, db;
                 unpark_u(hP[l - 1], hh);
                 unpark_u(dbP[l - 1], db);
                 down_ew(acc, hh, dlt, db);               // acc <- sbar_l
-                store_units(q3.ss[l - 1], soH, acc);
-                if (l > 1) publish(rb ? X0 : X1, acc);
+                if (l > 1) { publish(rb ? X0 : X1, acc); sprev = acc; }
             }
             // ================= Zbar_i = W_1[:,0:D]^T sbar_1: partial tiles over this wave's own k-groups, from registers =================
+            G3_T(12);
             f32x4 part[DT][NC];
 #pragma unroll
             for (int dm = 0; dm < DT; ++dm)
 #pragma unroll
                 for (int c = 0; c < NC; ++c) part[dm][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-            {
-                f32x4 f1[DT];
 #pragma unroll
-                for (int m = 0; m < A + (LO ? 1 : 0); ++m) {
-                    f32x4(&cur)[DT] = (m & 1) ? f1 : fd;
-                    f32x4(&nxt)[DT] = (m & 1) ? fd : f1;
-                    if (m + 1 < A + (LO ? 1 : 0)) {
-                        const int kgn = m + 1 < A ? mtS0 + m + 1 : tR;
+            for (int m = 0; m < NZ; ++m) {
+                f32x4(&cur)[DT] = fz[ZALL ? m : (m & 1)];
+                if (!ZALL && m + 1 < NZ) {
 #pragma unroll
-                        for (int dm = 0; dm < DT; ++dm) nxt[dm] = dloadv(R, vd[dm], B1 + (unsigned)kgn * 1024u);
-                    }
-                    if (m < A) {
-                        const int js = (mtS0 + m == G.KGH - 1) ? G.remH : 4;
+                    for (int dm = 0; dm < DT; ++dm) fz[(m + 1) & 1][dm] = dloadv(R, vd[dm], B1 + (unsigned)(m + 1 < A ? mtS0 + m + 1 : tR) * 1024u);
+                }
+                if (m < A) {
+                    const int js = (mtS0 + m == G.KGH - 1) ? G.remH : 4;
 #pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            if (j < js) {
-#pragma unroll
-                                for (int dm = 0; dm < DT; ++dm)
-#pragma unroll
-                                    for (int c = 0; c < NC; ++c) part[dm][c] = mfma4(cur[dm][j], acc.S[m][c][j], part[dm][c]);
-                            }
-                    } else if (v0) {
-                        // (a left-over tile may be the last k-group: its k-steps beyond `rem` multiply zero columns of the image)
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
+                    for (int j = 0; j < 4; ++j)
+                        if (j < js) {
 #pragma unroll
                             for (int dm = 0; dm < DT; ++dm)
 #pragma unroll
-                                for (int c = 0; c < NC; ++c) part[dm][c] = mfma4(cur[dm][j], acc.R[c][j], part[dm][c]);
-                    }
+                                for (int c = 0; c < NC; ++c) part[dm][c] = mfma4(cur[dm][j], acc.S[m][c][j], part[dm][c]);
+                        }
+                } else if (v0) {
+                    // (a left-over tile may be the last k-group: its k-steps beyond `rem` multiply zero columns of the image)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int dm = 0; dm < DT; ++dm)
+#pragma unroll
+                            for (int c = 0; c < NC; ++c) part[dm][c] = mfma4(cur[dm][j], acc.R[c][j], part[dm][c]);
                 }
             }
+            store_units(q3.ss[0], soH, acc);
             // (X0 - the partial tiles alias it - was last read by the product before the last one of the stage, and every wave has passed
             // the barrier in front of the last one since: no barrier here)
 #pragma unroll
             for (int dm = 0; dm < DT; ++dm)
 #pragma unroll
                 for (int c = 0; c < NC; ++c) pbuf[((wave * DT + dm) * NC + c) * 64 + lane] = part[dm][c];
+            G3_T(13);
             G3_SYNC();
+            G3_T(14);
             if (owner) {
 #pragma unroll
                 for (int dm = 0; dm < DT; ++dm) {
@@ -592,6 +633,14 @@ coop_grad3_step_kernel(G3Args ga) {
                     zbt[(i * DT + dm) * 64] = v;
                 }
             }
+#ifdef G3_TRACE
+            G3_T(15);
+            if (blockIdx.x == 3 && st == 3 && a.step == 5 && i == 2 && lane == 0) {
+#define G3_D(k) (int)(tr[k] - tr[k - 1])
+                printf("w%d: dense %d B0 %d up1 %d ew1 %d B1 %d up2 %d ew2(+up3) %d top %d ewtop %d B %d down %d ewdown %d zbar %d B %d red %d | stage %d\n", wave, G3_D(1), G3_D(2), G3_D(3),
+                       G3_D(4), G3_D(5), G3_D(6), G3_D(7), G3_D(8), G3_D(9), G3_D(10), G3_D(11), G3_D(12), G3_D(13), G3_D(14), G3_D(15), (int)(tr[15] - tr[0]));
+            }
+#endif
             // (the next stage's first LDS writes - gbar / kbar images - touch neither exchange buffer; its first publish into X0 comes
             // behind its first barrier, which the owners reach after this sum)
         }
