@@ -357,7 +357,11 @@ __device__ __forceinline__ void coopd_eval(const DRs& R, const float* __restrict
                 h.R[r] = act_only<ACT>(acc.R[r]);
             }
         }
-        fs_store(l, h);                          // h_{l+1} (1-based) of this stage
+        // (the stage-store writes are PLACED behind the product that follows the phase that made the tiles: the memory counter
+        // retires in order, and a store burst in front of a product makes its second k-group wait for the acknowledgements.  The
+        // tiles then stay live across that product: the A = 3 instances have no registers for it - 39 / 64 spilled - and store in front)
+        constexpr bool FSP = A <= 2;
+        if constexpr (!FSP) fs_store(l, h);
         if (l + 1 < L) {
 #pragma unroll
             for (int m = 0; m < A; ++m)
@@ -371,6 +375,7 @@ __device__ __forceinline__ void coopd_eval(const DRs& R, const float* __restrict
             uacc_fill<A>(acc, bS, bR);
             __syncthreads();
             dealt_gemm<A>(R, TH, FH + (unsigned)l * IMGH, G.KGH, G.remH, b, xbuf + cur * XB, wave, lane, aS, aR, acc);
+            if constexpr (FSP) fs_store(l, h);   // h_{l+1} (1-based) of this stage
         }
     }
     // ---- zdot = W_N h_L + b_N: partials over this wave's own k-groups, from registers ----
@@ -380,6 +385,7 @@ __device__ __forceinline__ void coopd_eval(const DRs& R, const float* __restrict
     dealt_drow<A, DT, QH>(R, vd, FN, mtS0, mtR0, G.KGH, G.remH, b, h, fd, pw, lane, own);
     // the first fragments of the pullback's first product are requested before the barrier
     if (L > 1) dealt_load_a<A>(R, TH, BH + (unsigned)(L - 2) * IMGH, 0, aS, aR);
+    if constexpr (A <= 2) fs_store(L - 1, h);    // h_L
     // delta_L = c .* act'_L, act'_L rebuilt from h_L (which the product above has consumed)
 #pragma unroll
     for (int m = 0; m < A; ++m)
@@ -427,7 +433,7 @@ __device__ __forceinline__ void coopd_eval(const DRs& R, const float* __restrict
             for (int r = 0; r < 3; ++r) dd[r] = unpark4(d[l].R[r]);
             tiles_mul<3>(acc.R, dd, h.R);
         }
-        fs_store(L + l, h);                      // delta_{l+1} (1-based)
+        if constexpr (A > 2) fs_store(L + l, h); // delta_{l+1} (1-based): in front (see above)
         if (l > 0) {
             // exchange buffer: h_l sat in buffer (l - 1) & 1; every reader passed a barrier since.  L = 2: buffer 0 again.
             const int wbuf = (L == 2) ? 0 : ((l - 1) & 1) ^ 1;
@@ -443,12 +449,14 @@ __device__ __forceinline__ void coopd_eval(const DRs& R, const float* __restrict
             uacc_zero<A>(acc);
             __syncthreads();
             dealt_gemm<A>(R, TH, BH + (unsigned)(l - 1) * IMGH, G.KGH, G.remH, b, xbuf + wbuf * XB, wave, lane, aS, aR, acc);
+            if constexpr (A <= 2) fs_store(L + l, h);   // delta_{l+1} (1-based), behind the product that read it
         }
     }
     // ---- g = W_1[:,0:D]^T delta_1 = eps^T J: partials from registers ----
     if (G.xalias) __syncthreads();
     dealt_drow<A, DT, QH>(R, vd, B1, mtS0, mtR0, G.KGH, G.remH, b, h, fd, pw, lane, own);
     dealt_load_a<A>(R, TZ, F1Z, 0, aS, aR);   // the next evaluation's layer-1 fragments
+    if constexpr (A <= 2) fs_store(L, h);        // delta_1
     __syncthreads();
     {
         float dot = 0.f, n2 = 0.f;

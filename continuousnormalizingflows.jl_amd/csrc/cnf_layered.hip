@@ -1112,7 +1112,10 @@ static hipError_t coop_grad3_run(LayeredGrad& G, const cnf_config& c, MfmaPlan* 
     // (Tried, round 6: the three kinds of product of a step - disjoint slab regions, disjoint operands; the D-sized ones bound by
     // reading their H-row operand once, the H x H ones by the matrix pipe - side by side on three library-owned streams, joined
     // before the next sweep: cfg4 86.4 -> 88.7 ms, default architecture nv = 20 / 28 52.2 -> 53.9 / 83.6 -> 86.9 ms.  Concurrent
-    // kernels slow each other down by more than the overlap gains, as round 3 found for the older form.  One stream.)
+    // kernels slow each other down by more than the overlap gains, as round 3 found for the older form.  Also tried: the two D-sized
+    // products (bound by reading their H-row operand once) on a second stream beside the NEXT step's sweep, launched on 8 / 16 / 32
+    // fewer CUs, their inputs double-buffered: cfg4 85.7 -> 93.3 ms (1024 super-tiles on 240 workgroups are five rounds, not four),
+    // nv = 20 50.9 -> 51.4.  One stream.)
     for (int n = nsteps - 1; n >= 0; --n) {
         a.c.step = n; a.c.tn = t0 + (float)n * dt; a.c.dt = dt;
         for (int l = 0; l < Lh; ++l) { a.fh[l] = G.ws_store + S.at(0, l, n, 0); a.fd[l] = G.ws_store + S.at(1, l, n, 0); }

@@ -102,5 +102,5 @@ def run(case):
     print(json.dumps(out), flush=True)
 
 
-for case in os.environ.get("G3_CASE", "cfg4").split(","):
+for case in os.environ.get("G3_CASE", "cfg4,cfg4r,nv16,nv20,nv24,nv28").split(","):
     run(case)
