@@ -50,7 +50,7 @@ class CnfConfig(C.Structure):
                 ("device_id", C.c_int32), ("kernel_path", C.c_int32), ("arith", C.c_int32)]
 
 
-TUNING_FIELDS = ("tile_split", "solve2", "solve2_pair", "coopd", "coopd_grad", "coop_grad", "coop_grad_mid", "coop_grad3", "coop_grad3_gib", "grad_layered", "jvp_grad_twin", "probe_grad_twin", "adaptive_ckpt", "layered_loss_by_solve", "device_controller", "dc_per_cu", "mfma_coop", "mfma_coopx", "mfma_nt", "mfma_pre", "mfma_prio", "mfma_queue", "coop_nt", "cg_one_per_cu", "cg_compare", "layered_min_b", "layered_kc", "layered_no_kckpt", "layered_act_gib", "lg_gemm", "lg_spw", "lg_nw", "lg_gemm2_wide", "lg_wgrad_per_cu", "lg_wgrad_t1", "lg_wgrad_t2")
+TUNING_FIELDS = ("tile_split", "solve2", "solve2_pair", "coopd", "coopd_grad", "coop_grad", "coop_grad_mid", "coop_grad3", "coop_grad3_gib", "grad_layered", "jvp_grad_twin", "probe_grad_twin", "adaptive_ckpt", "layered_loss_by_solve", "device_controller", "dc_per_cu", "mfma_coop", "mfma_coopx", "mfma_nt", "mfma_pre", "mfma_prio", "mfma_queue", "cg_one_per_cu", "layered_min_b", "layered_kc", "layered_no_kckpt", "layered_act_gib", "lg_gemm", "lg_spw", "lg_nw", "lg_gemm2_wide", "lg_wgrad_per_cu", "lg_wgrad_t1", "lg_wgrad_t2")
 
 
 class CnfTuning(C.Structure):

@@ -485,20 +485,13 @@ static hipError_t launch_coop(const KArgs& a, int nblocks, hipStream_t st) {
 
 struct CoopInst {
     int HT, L, ZR, ACT;
-    // [0] RK4, [1] Tsit5 with 64-sample super-tiles (one workgroup per CU); with -DCNF_COOP_NT2 also [2], [3]: the same with
-    // 32-sample super-tiles (two workgroups per CU, two waves per SIMD; CNF_COOP_NT=2 selects them).  Measured at cfg4 on one
-    // box: 28.8 ms against 25.4 ms - each weight fragment then feeds 2 sample tiles instead of 4 and the second wave on the
-    // SIMD hides less than that costs - so the default build does not carry them.
-    hipError_t (*fn[4])(const KArgs&, int, hipStream_t);
+    // [0] RK4, [1] Tsit5, 64-sample super-tiles (one workgroup per CU).  (32-sample super-tiles - two workgroups per CU, two waves per
+    // SIMD - were measured at cfg4: 28.8 ms against 25.4 ms; each weight fragment then feeds 2 sample tiles instead of 4 and the second
+    // wave on the SIMD hides less than that costs.  The A/B build was deleted in round 6.)
+    hipError_t (*fn[2])(const KArgs&, int, hipStream_t);
 };
-#ifdef CNF_COOP_NT2
-#define COOP_INST(HT, L, ZR, ACT)                                                                        \
-    CoopInst { HT, L, ZR, ACT, { &launch_coop<HT, L, ZR, ACT, 4, 4>, &launch_coop<HT, L, ZR, ACT, 6, 4>,  \
-                                 &launch_coop<HT, L, ZR, ACT, 4, 2>, &launch_coop<HT, L, ZR, ACT, 6, 2> } }
-#else
 #define COOP_INST(HT, L, ZR, ACT) \
-    CoopInst { HT, L, ZR, ACT, { &launch_coop<HT, L, ZR, ACT, 4, 4>, &launch_coop<HT, L, ZR, ACT, 6, 4>, nullptr, nullptr } }
-#endif
+    CoopInst { HT, L, ZR, ACT, { &launch_coop<HT, L, ZR, ACT, 4, 4>, &launch_coop<HT, L, ZR, ACT, 6, 4> } }
 // tanh instances are compiled for pre-scaled pre-activations (mfma_pack folds -2 log2 e into the
 // forward images); they are matched against CNF_ACT_TANH configurations.  First the exact shapes,
 // then zero-padded ones (state k-steps padded to 8: D <= 32).
@@ -590,13 +583,9 @@ bool coop_supported(int HT, int L, int ZR, int CR, int ACT, int engine, int KP, 
 hipError_t coop_launch(int HT, int L, int ZR, int ACT, const KArgs& a, int num_cus, hipStream_t st) {
     const CoopInst* c = coop_find(HT, L, ZR, ACT);
     if (!c) return hipErrorNotSupported;
-    // sample tiles per super-tile: 4 (one workgroup per CU); CNF_COOP_NT=2 in a -DCNF_COOP_NT2 build picks the two-workgroup form
-    const int nt_env = tuning().coop_nt;
-    const int NT = (nt_env == 2 && c->fn[2]) ? 2 : 4;
-    const long long nst = (a.B + 16 * NT - 1) / (16 * NT);
-    const long long cap = (long long)num_cus * (NT == 4 ? 1 : 2);
-    const int nblocks = (int)(nst < cap ? nst : cap);
-    return c->fn[(a.T.ns <= 4 ? 0 : 1) + (NT == 4 ? 0 : 2)](a, nblocks, st);
+    const long long nst = (a.B + 63) / 64;
+    const int nblocks = (int)(nst < num_cus ? nst : num_cus);
+    return c->fn[a.T.ns <= 4 ? 0 : 1](a, nblocks, st);
 }
 
 }  // namespace cnf

@@ -29,11 +29,6 @@
 #define CNF_NO_PHASE_FENCE 1
 #include "cnf_coop_d_dev.h"
 
-// cache policy of the stage-store writes (cnf_tiles.h): 0 = plain (write-back L2), 2 = non-temporal
-#ifndef CD_FS_AUX
-#define CD_FS_AUX 0
-#endif
-
 namespace cnf {
 
 // instances whose Runge-Kutta sums live in the plan's global ring (KArgs::rk) instead of accumulation registers: the ones that
@@ -291,13 +286,13 @@ __device__ __forceinline__ void coopd_eval(const DRs& R, const float* __restrict
         for (int m = 0; m < A; ++m)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v.S[m][q]), r, (int)R.lane16, (q * HTs + mtS0 + m) * 1024, CD_FS_AUX);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v.S[m][q]), r, (int)R.lane16, (q * HTs + mtS0 + m) * 1024, 0 /* plain stores: non-temporal ones measured the same */);
                 CNF_STORE_DATA_HAZARD(v.S[m][q]);
             }
 #pragma unroll
         for (int rr = 0; rr < 3; ++rr)
             if (rr < b) {
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v.R[rr]), r, (int)R.lane16, (wave * HTs + mtR0 + rr) * 1024, CD_FS_AUX);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v.R[rr]), r, (int)R.lane16, (wave * HTs + mtR0 + rr) * 1024, 0 /* plain stores: non-temporal ones measured the same */);
                 CNF_STORE_DATA_HAZARD(v.R[rr]);
             }
     };

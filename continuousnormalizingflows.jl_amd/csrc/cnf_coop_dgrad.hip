@@ -34,17 +34,13 @@
 #endif
 
 // The kernel's barriers order LDS traffic only (the exchange images); no wave reads global memory another wave of the launch
-// wrote.  __syncthreads() also waits for every outstanding global store; -DDG_FULL_SYNC restores it for an A/B.
-#ifndef DG_FULL_SYNC
+// wrote (__syncthreads() would also wait for every outstanding global store).
 #define DG_SYNC()                                                       \
     do {                                                                \
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local"); \
         __builtin_amdgcn_s_barrier();                                   \
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local"); \
     } while (0)
-#else
-#define DG_SYNC() __syncthreads()
-#endif
 
 #ifdef DG_TRACE
 #define DG_T(k) do { asm volatile("" ::: "memory"); tr[k] = __builtin_amdgcn_s_memtime(); asm volatile("" ::: "memory"); } while (0)
@@ -342,9 +338,6 @@ coopd_grad_step_kernel(DGArgs da) {
     const int mm = (lane >> 2) & 1, gg = lane & 3, s8 = (lane >> 3) ^ (4 * mm);
     const int gcol = NSAMP == 2 ? wave : (wave & 1), gpar = wave >> 1;
     auto gstore = [&](const f32x4* __restrict__ xb4, const __amdgpu_buffer_rsrc_t& rs, const unsigned (&vo)[2], unsigned so_c0, unsigned so_c1) {
-#ifdef DG_EXP_NOSTORE   // timing-only build (wrong gradients): what the operand stores cost
-        return;
-#endif
         typedef float __attribute__((may_alias)) float_a;
         const float_a* xb = reinterpret_cast<const float_a*>(xb4);
         const unsigned so0 = gcol >= NSAMP ? so_c1 : so_c0;

@@ -69,18 +69,9 @@
 
 // The kernel's barriers order LDS traffic only (the exchange images); no wave reads global memory another wave of the launch
 // wrote.  __syncthreads() also waits for every outstanding global store (vmcnt(0): the operand and scratch streams) at each of
-// the ~7 barriers of a stage; -DCG_LDS_SYNC waits for the LDS queue alone.  Measured at cfg4: no difference (112.7 vs 112.4 ms;
+// the ~7 barriers of a stage; a barrier that waits for the LDS queue alone was measured at cfg4: no difference (112.7 vs 112.4 ms;
 // vmcnt retires in order, so the next product's first fragment wait drains the stores anyway) - the plain form stays.
-#ifdef CG_LDS_SYNC
-#define CG_SYNC()                                                     \
-    do {                                                              \
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local"); \
-        __builtin_amdgcn_s_barrier();                                 \
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local"); \
-    } while (0)
-#else
 #define CG_SYNC() __syncthreads()
-#endif
 
 namespace cnf {
 
@@ -183,9 +174,6 @@ coop_grad_step_kernel(CGArgs a) {
     };
     // this wave's tiles of chain `ch` in exchange buffer `buf` -> rows [16 mt0, 16 (mt0 + MTW)) of a column-major operand array
     auto gstore = [&](int buf, int ch, const __amdgpu_buffer_rsrc_t& rs, const unsigned (&voff)[NT][2], unsigned soff0) {
-#ifdef CG_EXP_NOSTORE   // timing-only build (wrong gradients): what the operand stores cost
-        return;
-#endif
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         typedef float __attribute__((may_alias)) float_a;
         const float_a* xb = reinterpret_cast<const float_a*>(xbuf + buf * XB);
@@ -194,11 +182,7 @@ coop_grad_step_kernel(CGArgs a) {
             // row tiles are a multiple of 32 words apart - the lanes of the second row tile therefore take the samples 4 further
             // on (s8 ^ 4: banks + 16), which made 2-way conflicts of every one of these reads (22 % of the kernel's LDS cycles,
             // profiles/r3/r3T_cfg4_grad_pmc_summary.txt); the store offsets vox / voy follow the same assignment
-#ifdef CG_NO_SWIZZLE
-            const int mm = (lane >> 2) & 1, gg = lane & 3, s8 = (lane >> 3);
-#else
             const int mm = (lane >> 2) & 1, gg = lane & 3, s8 = (lane >> 3) ^ (4 * mm);
-#endif
 #pragma unroll
             for (int m = 0; m < MTW; m += 2)
 #pragma unroll
@@ -321,11 +305,7 @@ coop_grad_step_kernel(CGArgs a) {
         for (int q = 0; q < NT; ++q) {
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf) {
-#ifdef CG_NO_SWIZZLE
-                const long long sq = GS ? smp0 + q * 16 + (lane >> 3) + 8 * hf : smp0 + q * 16 + n;
-#else
                 const long long sq = GS ? smp0 + q * 16 + ((lane >> 3) ^ (4 * ((lane >> 2) & 1))) + 8 * hf : smp0 + q * 16 + n;
-#endif
                 const unsigned ro = GS ? 16u * (unsigned)(lane & 3) + 64u * (unsigned)((lane >> 2) & 1) : 16u * (unsigned)g;
                 vox[q][hf] = sq < B ? (unsigned)sq * ldx + ro : 0xffffffffu;
                 voy[q][hf] = sq < B ? (unsigned)sq * ldy + ro : 0xffffffffu;
@@ -474,11 +454,7 @@ coop_grad_step_kernel(CGArgs a) {
                 }
                 // The operand stores of a published pair are issued INSIDE the product that reads it, behind its last fragment
                 // requests (round 5): vmcnt retires in order, so in front of the product (round 3) its first fragment wait drained
-                // 8 KB of HBM stores per wave, six times a stage (CG_STORES_FIRST restores that order for an A/B).
-#ifdef CG_STORES_FIRST
-                gstore(cur, 0, ry[l], voy, sy2);                              // [h_{l+1}; 1] half of Y_{l+1}
-                gstore(cur, 1, ry[l], voy, sy1);                              // [vbar_{l+1}; 0] half
-#endif
+                // 8 KB of HBM stores per wave, six times a stage (108.4 against 108.2 ms at cfg4: the A/B build was deleted in round 6).
                 if (l + 1 < L) {
                     f32x4 bnx[MTW];
                     gload_cvec<MTW>(P + LAY.v_bh + l * MfmaLayout::vecC(HT), mt0, g, bnx);
@@ -487,20 +463,14 @@ coop_grad_step_kernel(CGArgs a) {
 #pragma unroll
                         for (int q = 0; q < NT; ++q) { acc[m][q] = bnx[m]; acc[m][NT + q] = f32x4{0.f, 0.f, 0.f, 0.f}; }
                     CG_SYNC();
-#ifdef CG_STORES_FIRST
-                    run2(LAY.fh + l * IMG, HT, xbuf + cur * XB, afr, acc);
-#else
                     head2(LAY.fh + l * IMG, HT, xbuf + cur * XB, afr, acc);
                     gstore(cur, 0, ry[l], voy, sy2);                          // [h_{l+1}; 1] half of Y_{l+1}
                     gstore(cur, 1, ry[l], voy, sy1);                          // [vbar_{l+1}; 0] half
                     tail2(HT, afr, acc);
-#endif
                     cur ^= 1;
                 } else {
-#ifndef CG_STORES_FIRST
                     gstore(cur, 0, ry[l], voy, sy2);                          // (the top: the pair is overwritten below)
                     gstore(cur, 1, ry[l], voy, sy1);
-#endif
                     // ===== the top: [c | hbar_L] = W_N^T [eps | kbar]; delta_L = c .* act'_L, a2_L = dbar_L .* c,
                     //       sbar_L = hbar_L .* act'_L + a2_L .* act''_L - all while h_L and dbar_L are in registers =====
                     T2 t;
@@ -518,10 +488,6 @@ coop_grad_step_kernel(CGArgs a) {
                         }
                     // own tiles of the Y_L pair have been stored by this wave (gstore waits for its LDS reads): overwrite them
                     publish2(cur, dl, sb);
-#ifdef CG_STORES_FIRST
-                    gstore(cur, 0, rx[L - 1], vox, sx1);                      // delta_L half of X_L
-                    gstore(cur, 1, rx[L - 1], vox, sx2);                      // sbar_L half
-#endif
                     CG_SYNC();
                 }
             }
@@ -544,10 +510,8 @@ coop_grad_step_kernel(CGArgs a) {
                     coop_gemm<MTW, NT, NT>(AIMG(LAY.f1z), mt0, DT, gbuf, 0, lane, afq, dbl);
                 }
                 head2(LAY.bh + (l - 1) * IMG, HT, xbuf + cur * XB, afr, t);
-#ifndef CG_STORES_FIRST
                 gstore(cur, 0, rx[l], vox, sx1);                              // delta_{l+1} half of X_{l+1}: the pair this product reads
                 gstore(cur, 1, rx[l], vox, sx2);                              // sbar_{l+1} half
-#endif
                 sload(SLOT_H + l - 1, hl);
                 if (l > 1) sload(SLOT_DB + l - 2, dbl);
                 tail2(HT, afr, t);
@@ -564,10 +528,6 @@ coop_grad_step_kernel(CGArgs a) {
                         sb[m][q] = t[m][NT + q] * d + (dbv * u) * act_dd<ACT>(hl[m][q], d);
                     }
                 publish2(cur, dl, sb);
-#ifdef CG_STORES_FIRST
-                gstore(cur, 0, rx[l - 1], vox, sx1);                          // delta_l half of X_l
-                gstore(cur, 1, rx[l - 1], vox, sx2);                          // sbar_l half
-#endif
                 CG_SYNC();
             }
             // Zbar_i = W_1[:,0:D]^T sbar_1: D rows x the sample tiles, K = H.  SPLIT ALONG K over the four waves (wave w: k-groups
@@ -595,10 +555,8 @@ coop_grad_step_kernel(CGArgs a) {
 #pragma unroll
                     for (int q = 0; q < NT; ++q) bz[q] = bn[q];
                 }
-#ifndef CG_STORES_FIRST
                 gstore(cur, 0, rx[0], vox, sx1);                              // X_1 = [delta_1 | sbar_1], behind the product that read it
                 gstore(cur, 1, rx[0], vox, sx2);
-#endif
                 f32x4* pz = xbuf + (cur ^ 1) * XB;        // [wave][DT][NT][64] partial tiles
 #pragma unroll
                 for (int m = 0; m < DT; ++m)

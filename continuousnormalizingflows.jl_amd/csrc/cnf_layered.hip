@@ -38,7 +38,6 @@
 #include "cnf_internal.h"
 #include "cnf_coop_grad.h"
 #include "cnf_tiles.h"
-#include <map>
 
 namespace cnf {
 
@@ -970,15 +969,6 @@ __global__ void fold_slabs_kernel(float* __restrict__ dst, const float* __restri
     dst[e] += ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
 }
 
-#ifdef CNF_CG_COMPARE_BUILD
-__global__ void dbg_compare_kernel(const float* __restrict__ x, const float* __restrict__ y, long long n, unsigned* out) {
-    const long long i = (long long)blockIdx.x * TPB + threadIdx.x;
-    if (i >= n) return;
-    const float d = fabsf(x[i] - y[i]);
-    if (d > 0.f) atomicMax(&out[0], __float_as_uint(d));
-    if (d > 1e-3f) { const unsigned k = atomicAdd(&out[1], 1u); atomicMax(&out[2], ~(unsigned)i); if (k < 2000) out[4 + k] = (unsigned)i; }
-}
-#endif
 // rows [row0, rows) of columns [c0, c1) of a column-major array <- val
 __global__ void fill_rows_kernel(float* __restrict__ a, int ld, int row0, int rows, long long c0, long long c1, float val) {
     const long long i = (long long)blockIdx.x * TPB + threadIdx.x;
@@ -1228,54 +1218,6 @@ hipError_t coop_grad(LayeredGrad** ctx, const cnf_config& c, MfmaPlan* plan, con
     for (int n = nsteps - 1; n >= 0; --n) {
         a.step = n; a.tn = t0 + (float)n * dt; a.dt = dt;
         if (tgrid) { a.tn = tgrid[n]; a.dt = tgrid[n + 1] - tgrid[n]; }
-#ifdef CNF_CG_COMPARE_BUILD
-        if (tuning().cg_compare && Lh == 2 && CR == 0) {
-            // debug: both sweeps on the same inputs, operand arrays compared
-            const size_t nl = (size_t)ntp * 64 * ZR, nz = (size_t)ntp * 64 * 6 * ZR;
-            const size_t sz[6] = {(size_t)H * B2, (size_t)H * B2, (size_t)ldy * B2, (size_t)ldy * B2, (size_t)(n_in + 1) * B2, (size_t)D * B2};
-            float* arr[6] = {a.xh[0], a.xh[1], a.yh[0], a.yh[1], a.y1, a.xN};
-            const char* nm[6] = {"X_1", "X_2", "Y_1", "Y_2", "y1", "xN"};
-            float *bl, *bz, *cp[6]; unsigned* out;
-            hipMalloc((void**)&bl, nl * 4); hipMalloc((void**)&bz, nz * 4); hipMalloc((void**)&out, 8192 + 64);
-            for (int k = 0; k < 6; ++k) hipMalloc((void**)&cp[k], sz[k] * 4);
-            copy_async(bl, a.lam, nl * 4, st); copy_async(bz, a.zb, nz * 4, st);
-            coop_grad_step_launch(HT, Lh, ZR, CR, ACT, a, G.num_cus, st);
-            for (int k = 0; k < 6; ++k) copy_async(cp[k], arr[k], sz[k] * 4, st);
-            copy_async(a.lam, bl, nl * 4, st); copy_async(a.zb, bz, nz * 4, st);
-            coopd_grad_step_launch(H, D, Lh, ACT, HT, ZR, a, G.num_cus, st);
-            for (int k = 0; k < 6; ++k) {
-                zero_async(out, 8192 + 64, st);
-                hipLaunchKernelGGL(dbg_compare_kernel, grid_for((long long)sz[k]), dim3(TPB), 0, st, cp[k], arr[k], (long long)sz[k], out);
-                unsigned h[4]; hipMemcpyAsync(h, out, 16, hipMemcpyDeviceToHost, st); hipStreamSynchronize(st);
-                float mx; __builtin_memcpy(&mx, &h[0], 4); h[2] = ~h[2];
-                if (k == 0 && h[1] > 0) {
-                    static unsigned idx[2000]; hipMemcpy(idx, out + 4, sizeof(idx), hipMemcpyDeviceToHost);
-                    for (unsigned t = 0; t < 24 && t < h[1]; ++t) {
-                        float vo, vn; hipMemcpy(&vo, cp[0] + idx[t], 4, hipMemcpyDeviceToHost); hipMemcpy(&vn, arr[0] + idx[t], 4, hipMemcpyDeviceToHost);
-                        fprintf(stderr, "   entry row %u col %u: coop %.6f dealt %.6f\n", idx[t] % (unsigned)H, idx[t] / (unsigned)H, vo, vn);
-                    }
-                    {
-                        int nz = 0, big = 0, half0 = 0; unsigned lanes[16] = {0}, rmod[4] = {0};
-                        for (unsigned t = 0; t < (h[1] < 2000 ? h[1] : 2000); ++t) {
-                            float vo, vn; hipMemcpy(&vo, cp[0] + idx[t], 4, hipMemcpyDeviceToHost); hipMemcpy(&vn, arr[0] + idx[t], 4, hipMemcpyDeviceToHost);
-                            nz += vo == 0.f; big += fabsf(vo - vn) > 0.1f; const long long col = idx[t] / (unsigned)H; half0 += col < (long long)ns * B;
-                            lanes[(col % B) % 16]++; rmod[(idx[t] % (unsigned)H) % 4]++;
-                        }
-                        fprintf(stderr, "   of the first 2000 bad entries: %d are exact zeros in the coop array, %d differ by > 0.1, %d in the delta half; by sample-in-tile:", nz, big, half0);
-                        for (int t = 0; t < 16; ++t) fprintf(stderr, " %u", lanes[t]);
-                        fprintf(stderr, "; by row mod 4: %u %u %u %u\n", rmod[0], rmod[1], rmod[2], rmod[3]);
-                    }
-                    std::map<long long, int> cols;
-                    for (unsigned t = 0; t < (h[1] < 2000 ? h[1] : 2000); ++t) cols[idx[t] / (unsigned)H]++;
-                    for (auto& c : cols) fprintf(stderr, "   col %lld: half %lld stage %lld sample %lld (tile %lld, lane-sample %lld) rows bad %d\n", c.first, c.first / ((long long)ns * B),
-                                                 (c.first % ((long long)ns * B)) / B, c.first % B, (c.first % B) / 16, (c.first % B) % 16, c.second);
-                }
-                fprintf(stderr, "step %d %s: max|diff| %.3e, %u entries differ by > 1e-5, first at %u (row %u col %u)\n", n, nm[k], mx, h[1], h[2],
-                        h[2] % (unsigned)(k < 2 ? H : k < 4 ? ldy : k == 4 ? n_in + 1 : D), h[2] / (unsigned)(k < 2 ? H : k < 4 ? ldy : k == 4 ? n_in + 1 : D));
-            }
-            hipFree(bl); hipFree(bz); hipFree(out); for (int k = 0; k < 6; ++k) hipFree(cp[k]);
-        } else
-#endif
         if (dealt) LG_HIP(coopd_grad_step_launch(H, D, Lh, ACT, HT, ZR, a, G.num_cus, st));
         else LG_HIP(coop_grad_step_launch(HT, Lh, ZR, CR, ACT, a, G.num_cus, st));
         LG_HIP(lg_wgrad(slabs + L.pa_off[0], npa_pad, kc, nslab, H, n_in + 1, a.xh[0], H, a.y1, n_in + 1, B2, st));

@@ -736,9 +736,6 @@ mfma_solve_kernel(KArgs a) {
                 // The weight image is loop-invariant, and LLVM would hoist all ~300 operand reads out
                 // of the RK loops (and spill them).  An opaque zero offset pins the reads per stage.
                 int opaque = 0;
-#ifdef CNF_HOIST_SMALL
-                if constexpr (!(HT <= 2 && KP == 1))
-#endif
                 asm volatile("" : "+v"(opaque));
                 dyn_eval<HT, L, ZR, CR, ACT, ENGINE, KP, PRE, ARITH>(smem + opaque, a.packed + opaque, lane, tn + a.T.c[st] * dt, autonomous,
                                                               reg_z, reg_j, exact, D, K, zs, y, eps, pre_c, pre_q, zd,
@@ -828,13 +825,6 @@ mfma_solve_kernel(KArgs a) {
 // half-row and row mirrors), across rows from the gfx950 row / half swaps - all VALU-speed; the shuffle form
 // (`__shfl_xor` on a double = two ds_bpermute_b32 + an LDS round trip per step, six steps) cost ~2 us per call, and a
 // grid-wide sum makes two calls for each of its three values.
-#ifdef CNF_WAVE_SUM_SHFL
-__device__ __forceinline__ double wave_sum_f64(double v) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
-#else
 __device__ __forceinline__ double wave_sum_f64(double v) {
     auto halves = [](double x, unsigned& lo, unsigned& hi) {
         const unsigned long long b = __builtin_bit_cast(unsigned long long, x);
@@ -863,7 +853,6 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
     }
     return v;
 }
-#endif
 
 // Grid-wide sums of three per-lane values over all tiles, in two levels: the waves of a workgroup meet in LDS; wave 0 of every
 // workgroup publishes the workgroup's partials, waits for the partials of all workgroups and adds them up in workgroup order.  Every

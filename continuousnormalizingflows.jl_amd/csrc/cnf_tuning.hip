@@ -33,9 +33,7 @@ const Knob kKnobs[] = {
     {"CNF_MFMA_PRE", &cnf_tuning::mfma_pre, -1},
     {"CNF_MFMA_PRIO", &cnf_tuning::mfma_prio, 0},
     {"CNF_MFMA_QUEUE", &cnf_tuning::mfma_queue, 0},
-    {"CNF_COOP_NT", &cnf_tuning::coop_nt, 0},
     {"CNF_CG_ONE_PER_CU", &cnf_tuning::cg_one_per_cu, 0},
-    {"CNF_CG_COMPARE", &cnf_tuning::cg_compare, 0},
     {"CNF_LAYERED_MIN_B", &cnf_tuning::layered_min_b, 0},
     {"CNF_LAYERED_KC", &cnf_tuning::layered_kc, 0},
     {"CNF_LAYERED_NO_KCKPT", &cnf_tuning::layered_no_kckpt, 0},

@@ -140,9 +140,7 @@ typedef struct cnf_tuning {
     int32_t mfma_pre;              /* CNF_MFMA_PRE, default -1: hoisting level of the per-wave solve kernel (-1: the best instance) */
     int32_t mfma_prio;             /* CNF_MFMA_PRIO, default 0: s_setprio scheme of the per-wave solve kernel (A/B; no scheme won) */
     int32_t mfma_queue;            /* CNF_MFMA_QUEUE, default 0: 1: dynamic tile queue instead of the static stride (A/B) */
-    int32_t coop_nt;               /* CNF_COOP_NT, default 0: sample tiles per super-tile of the cooperative solve kernel (0: the instance's own) */
     int32_t cg_one_per_cu;         /* CNF_CG_ONE_PER_CU, default 0: 1: one workgroup per CU for the cooperative reverse sweep (A/B) */
-    int32_t cg_compare;            /* CNF_CG_COMPARE, default 0: debug builds (-DCNF_CG_COMPARE_BUILD) only: run both sweeps and compare their operand arrays */
     int32_t layered_min_b;         /* CNF_LAYERED_MIN_B, default 0: batches below this of an AUTO-resolved layer-wise handle take the SIMT kernels (0: never) */
     int32_t layered_kc;            /* CNF_LAYERED_KC, default 0: column chunk of the layer-wise weight-cotangent products (0: lg_wgrad_chunks' choice) */
     int32_t layered_no_kckpt;      /* CNF_LAYERED_NO_KCKPT, default 0: 1: the layer-wise reverse sweep recomputes the stage derivatives instead of keeping them */
