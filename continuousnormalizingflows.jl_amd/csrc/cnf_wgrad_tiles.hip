@@ -25,6 +25,10 @@ constexpr int kTileWords = 4 * 72;   // a parked tile: four lane groups, 64 + 8 
 // column group - its X operand is read once, and an iteration carries 4 NTN MFMAs per wave against a fixed cost (a barrier, the
 // fetches, the parks); wider strips are dealt evenly over groups of <= 12 (16 tiles = 8 + 8)
 constexpr int kMaxNTN = 12;
+// (Measured and dropped, round 6 - PMC of this kernel at cfg4: 67 % MFMA-busy, waves waiting 31 % of their cycles, no LDS bank conflict,
+// HBM traffic = every operand once: four slices in flight instead of two: 0.2195 against 0.2185 ms per 256 x 256 call, and at twelve
+// tiles per group, where the registers then allow two waves per SIMD instead of three, 0.193 against 0.155 ms - occupancy, not prefetch
+// depth, is what hides the round trips; LDS-only barriers instead of __syncthreads: no difference.)
 
 // NTN: 16-column tiles of C a wave keeps (one column group).  Four waves = four 16-row strips of C, sharing every Y tile.
 template <int NTN>
