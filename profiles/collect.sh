@@ -18,7 +18,9 @@ cd /tmp && export TMPDIR=/tmp
 BENCH="python3 $ROOT/bench.py --config $CFG --steps 40 --warmup 3 --no-cpu-baseline --secondary none $*"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/trace.log 2>&1
 # PMC passes: a short pre-roll is enough (counters are per launch), 24 launches each
-PBENCH="python3 $ROOT/bench.py --config $CFG --steps 20 --warmup 2 --preroll-seconds 0.5 --no-cpu-baseline --secondary none $*"
+# (--secondaries none: the default cfg2 line would otherwise run every secondary workload under every counter pass - serialised
+# launches - and the passes ran into their time limit: rounds 5's cfg2 summary had lost its SQ / WRITE passes that way)
+PBENCH="python3 $ROOT/bench.py --config $CFG --steps 20 --warmup 2 --preroll-seconds 0.5 --no-cpu-baseline --secondary none --secondaries none --bf16x6-secondary off $*"
 i=0
 for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVES" \
            "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_VALU" \
