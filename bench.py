@@ -85,6 +85,24 @@ CONFIGS = {
 NSTEPS = 40
 
 
+def traffic_is_stale():
+    """True when a kernel source changed after profiles/pmc_traffic.json was collected (its `_csrc_sha16` = sha256 over csrc/*.hip, *.h
+    at collection time, profiles/make_pmc_traffic.py): the committed traffic figures then describe an older build (VERDICT r5 weak #11)."""
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "profiles"))
+        import hashlib, glob
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            want = json.load(f).get("_csrc_sha16")
+        h = hashlib.sha256()
+        d = os.path.join(ROOT, "continuousnormalizingflows.jl_amd", "csrc")
+        for fn in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.h"))):
+            h.update(os.path.basename(fn).encode())
+            h.update(open(fn, "rb").read())
+        return want is None or h.hexdigest()[:16] != want
+    except Exception:
+        return True
+
+
 def measured_traffic(name):
     """HBM bytes per launch of the solve kernel from the PMC passes of profiles/collect.sh
     (FETCH_SIZE and WRITE_SIZE in separate runs; FETCH_SIZE doubled per the gfx950 note in
@@ -778,7 +796,8 @@ def main():
                          **({"sustained_frac_last_quarter": rf["sustained"]["frac_last_quarter"],
                              "clock_mhz": (rf["sustained"].get("clock_mhz") or {}).get("last_quarter")} if rf.get("sustained") else {}),
                          **({k: rf[k] for k in ("executed_frac", "gradient_form") if k in rf}),
-                         "traffic_src": "profiles/pmc_traffic.json (committed PMC passes; bench.py cannot run rocprofv3 on itself)"},
+                         "traffic_src": "profiles/pmc_traffic.json (committed PMC passes; bench.py cannot run rocprofv3 on itself)",
+                         "traffic_stale": traffic_is_stale()},
         }
         if "gradient_path" in r["config"]:
             out["config"]["gradient_path"] = r["config"]["gradient_path"]
