@@ -1106,10 +1106,13 @@ static hipError_t coop_grad3_run(LayeredGrad& G, const cnf_config& c, MfmaPlan* 
     // products (bound by reading their H-row operand once) on a second stream beside the NEXT step's sweep, launched on 8 / 16 / 32
     // fewer CUs, their inputs double-buffered: cfg4 85.7 -> 93.3 ms (1024 super-tiles on 240 workgroups are five rounds, not four),
     // nv = 20 50.9 -> 51.4.  One stream.)
+    // two hidden layers: the sweep with two workgroups per CU (cnf_coop_grad3w.hip); CNF_COOP_GRAD3=2 keeps the one-per-CU sweep (A/B)
+    const bool paired = tuning().coop_grad3 != 2 && coop_grad3w_supported(H, D, Lh, ACT, HT, ZR, 0);
     for (int n = nsteps - 1; n >= 0; --n) {
         a.c.step = n; a.c.tn = t0 + (float)n * dt; a.c.dt = dt;
         for (int l = 0; l < Lh; ++l) { a.fh[l] = G.ws_store + S.at(0, l, n, 0); a.fd[l] = G.ws_store + S.at(1, l, n, 0); }
-        LG_HIP(coop_grad3_step_launch(H, D, Lh, ACT, HT, ZR, a, G.num_cus, st));
+        if (paired) LG_HIP(coop_grad3w_step_launch(H, D, Lh, ACT, HT, ZR, a, G.num_cus, st));
+        else LG_HIP(coop_grad3_step_launch(H, D, Lh, ACT, HT, ZR, a, G.num_cus, st));
         // Wbar_{l+1} += delta_{l+1} vbar_l^T + sbar_{l+1} h_l^T
         for (int l = 1; l < Lh; ++l)
             LG_HIP(wgrad_tiles(slabs + L.pa_off[l], npa_pad, chH, ncH, H, H, WTTerm{a.fd[l], a.sv[l - 1], HTs, HTs}, WTTerm{a.ss[l], a.fh[l - 1], HTs, HTs}, nct, 1, st));

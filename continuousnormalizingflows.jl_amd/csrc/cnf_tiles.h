@@ -68,5 +68,8 @@ struct CG3Args {
 };
 bool coop_grad3_supported(int H, int D, int L, int ACT, int HT_lay, int ZR_lay, int CR_lay);
 hipError_t coop_grad3_step_launch(int H, int D, int L, int ACT, int HT_lay, int ZR_lay, const CG3Args& a, int num_cus, hipStream_t st);
+// the same step with two workgroups per CU (cnf_coop_grad3w.hip: two hidden layers, at most 256 registers per wave and 80 KB of LDS)
+bool coop_grad3w_supported(int H, int D, int L, int ACT, int HT_lay, int ZR_lay, int CR_lay);
+hipError_t coop_grad3w_step_launch(int H, int D, int L, int ACT, int HT_lay, int ZR_lay, const CG3Args& a, int num_cus, hipStream_t st);
 
 }  // namespace cnf

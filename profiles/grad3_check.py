@@ -1,6 +1,6 @@
 # The cooperative gradient's second form (stage store + second-order sweep + products over tiles, CNF_COOP_GRAD3=1)
 # against the recomputing sweeps (CNF_COOP_GRAD3=0) on the same handle configuration: per-layer gradient agreement, the fp64 oracle
-# at a small batch, and loss + gradient time at full size.   G3_CASE = cfg4 | nv16 | nv20 | nv24 ..., G3_B, G3_ORACLE_B
+# at a small batch, and loss + gradient time at full size (CNF_COOP_GRAD3=2: the second form with the one-workgroup-per-CU sweep for every shape).   G3_CASE = cfg4 | nv16 | nv20 | nv24 ..., G3_B, G3_ORACLE_B
 import json
 import os
 import sys
@@ -81,7 +81,7 @@ def run(case):
     E = torch.randn(spec.nvars + spec.naug, B, generator=g).to(dev)
     P = t(p)
     full = {}
-    for tag, sw in (("new", "1"), ("old", "0")):
+    for tag, sw in (("new", "1"), ("one_per_cu", "2"), ("old", "0")):
         os.environ["CNF_COOP_GRAD3"] = sw
         pkg.reload_tuning()
         icnf = make_icnf(spec, alg, ns, lam)
@@ -96,7 +96,9 @@ def run(case):
         torch.cuda.synchronize()
         full[tag] = (float(val), gr.double().cpu().numpy(), e0.elapsed_time(e1) / 3)
     gn, go = full["new"][1], full["old"][1]
-    out = dict(case=case, B=B, ms_new=full["new"][2], ms_old=full["old"][2], loss_new=full["new"][0], loss_old=full["old"][0],
+    g1 = full["one_per_cu"][1]
+    out = dict(case=case, B=B, ms_new=full["new"][2], ms_one_per_cu=full["one_per_cu"][2], ms_old=full["old"][2],
+               grad_maxabs_rel_new_vs_one_per_cu=float(np.abs(gn - g1).max() / np.abs(g1).max()), loss_new=full["new"][0], loss_old=full["old"][0],
                grad_rel=float(np.linalg.norm(gn - go) / np.linalg.norm(go)), grad_maxabs_rel=float(np.abs(gn - go).max() / np.abs(go).max()),
                per_layer={nm: float(np.abs(gn[a:b] - go[a:b]).max() / (np.abs(go[a:b]).max() + 1e-30)) for nm, a, b in layer_slices(spec)})
     print(json.dumps(out), flush=True)

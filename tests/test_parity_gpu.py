@@ -1152,7 +1152,9 @@ def test_cooperative_gradient_second_form(kw, B, alg, nsteps, lam, dealt, pkg, o
     csrc/cnf_coop_grad3.hip runs the second-order chains alone and the weight cotangents are products over tiles
     (csrc/cnf_wgrad_tiles.hip).  dloss/dps, dloss/dxs and the loss against fp64 autograd through the same discrete solve
     (src/core/icnf.jl:90-99 differentiates `loss` through the solve), and against the sweeps that recompute both first-order
-    chains (CNF_COOP_GRAD3=0) on the same handle configuration; cnf_grad_form_for says which one a call takes."""
+    chains (CNF_COOP_GRAD3=0) on the same handle configuration; cnf_grad_form_for says which one a call takes.  Two hidden layers
+    run the sweep with two workgroups per CU (csrc/cnf_coop_grad3w.hip); CNF_COOP_GRAD3=2 keeps the one-per-CU sweep for every
+    shape: same chains, same summation order - the two must agree bit for bit."""
     o64, _ = oracles
     if dealt:
         setsw(pkg, monkeypatch, "CNF_COOPD", "2")
@@ -1163,18 +1165,19 @@ def test_cooperative_gradient_second_form(kw, B, alg, nsteps, lam, dealt, pkg, o
     L, gref, gxref = o64.loss_and_grad(spec, p, xs, 0.0, 1.0, nsteps, alg, eps, ys, lam, wrt_x=True)
     mode = mode_of(pkg, spec)
     out = {}
-    for tag, flag in (("store", "1"), ("recompute", "0")):
+    for tag, flag in (("store", "1"), ("store_one_per_cu", "2"), ("recompute", "0")):
         setsw(pkg, monkeypatch, "CNF_COOP_GRAD3", flag)
         icnf = make_icnf(pkg, spec, alg, nsteps, path=0, lambdas=lam)
         val, g, gx = pkg.loss_and_gradient(icnf, mode, dev(xs), dev(p), {}, eps=dev(eps), wrt_x=True)
         assert icnf.grad_path(mode, B=B, alg=alg) == 3
-        assert icnf.grad_form(mode, B, alg, nsteps) == (2 if tag == "store" else 1), (tag, icnf.grad_form(mode, B, alg, nsteps))
+        assert icnf.grad_form(mode, B, alg, nsteps) == (1 if tag == "recompute" else 2), (tag, icnf.grad_form(mode, B, alg, nsteps))
         out[tag] = (float(val), g.cpu().numpy().astype(np.float64), gx.cpu().numpy().astype(np.float64))
         assert abs(out[tag][0] - L) < 1e-4 + 2e-6 * abs(L), tag
         scale = np.abs(gref).max()
         assert np.max(np.abs(out[tag][1] - gref)) < 5e-5 * scale + 1e-6, (tag, np.max(np.abs(out[tag][1] - gref)) / scale)
         assert np.max(np.abs(out[tag][2] - gxref)) < 5e-5 * np.abs(gxref).max() + 1e-7, tag
     assert np.max(np.abs(out["store"][1] - out["recompute"][1])) < 2e-5 * np.abs(gref).max() + 1e-6
+    assert np.array_equal(out["store"][1], out["store_one_per_cu"][1]) and np.array_equal(out["store"][2], out["store_one_per_cu"][2])
 
 
 def test_second_form_is_deterministic_and_falls_back_when_the_store_does_not_fit(pkg, oracles, monkeypatch):
