@@ -665,7 +665,11 @@ constexpr int coopd_lds_bytes(int HT, int L, int DT, bool alias, int cvn, bool c
 // same fma chains in the same order, so the numbers are the same; 72 - 96 of the 256 architectural registers stay free for the
 // 4 A + b accumulator tiles and two fragment sets of the k-loops.
 // MODE 0: one Hutchinson probe, VJP (TrainMode); 1: exact trace through the Q product (TestMode, two hidden layers)
-template <int A, int L, int ZR, int ACT, int MODE>
+// NL: rows of the Runge-Kutta state (P_1 .. P_4, the step sum, z) kept in a per-wave LDS slice, the other 6 - NL parked in
+// accumulation registers (0: all parked, or all in the global ring where cd_rk_in_ring says so).  The (2, 12) instance - the
+// reference's default architecture at nvariables = 16 .. 21 - is 28 registers short with six rows parked and has 36 KB of LDS to
+// spare: three rows there, three parked, and the 6.9 GB per solve the global ring moved through L2 and HBM are gone.
+template <int A, int L, int ZR, int ACT, int MODE, int NL>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 coopd_solve_kernel(DArgs da) {
     static_assert(MODE == 0 || L == 2, "the exact-trace form is the two-hidden-layer Q product");
@@ -681,6 +685,7 @@ coopd_solve_kernel(DArgs da) {
     f32x4* pbuf = G.xalias ? xbuf : ebuf + DT * 4 * 64;       // [4 waves][DT][4][64] partial tiles of the D-row products
     f32x4* ybuf = ebuf + DT * 4 * 64 + (G.xalias ? 0 : 4 * DT * 4 * 64);   // [1][4][64]: conditions (constant over the solve)
     float* cbuf = reinterpret_cast<float*>(ybuf + (G.remC > 0 ? 4 * 64 : 0));   // C vectors (biases, time column)
+    f32x4* lrk0 = reinterpret_cast<f32x4*>(cbuf + (G.cvn + 3) / 4 * 4);         // (NL > 0) [4 waves][NL][DT][64]: rows of the Runge-Kutta state
     for (int i = threadIdx.x; i < G.cvn; i += 256) cbuf[i] = a.packed[G.v_b1 + i];
     // (the first __syncthreads of the super-tile loop orders these writes before any read)
     const int lane = threadIdx.x & 63, g = lane >> 4, n = lane & 15;
@@ -697,9 +702,12 @@ coopd_solve_kernel(DArgs da) {
         // RKG: z and the five running sums in a per-wave slice of the plan's global ring (L2-resident; read and written once per
         // stage as 16-byte accesses, behind the evaluation's last product and the next evaluation's first fragment requests) -
         // see cnf_coop_d2.hip, where the same move took the 20 .. 24-tile instances from 77 to 110 TFLOP/s
-        constexpr bool RKG = cd_rk_in_ring(A, L, ZR);
+        constexpr bool RKL = NL > 0;
+        constexpr bool RKG = !RKL && cd_rk_in_ring(A, L, ZR);
         f32x4* __restrict__ rk = RKG ? reinterpret_cast<f32x4*>(a.rk) + ((long long)(blockIdx.x * 4 + wave) * 6 * DT) * 64 + lane : nullptr;
-        float zs[ZR], zp[RKG ? 1 : ZR], pk[RKG ? 1 : 5][RKG ? 1 : ZR];   // stage state; z and the running sums, parked
+        f32x4* lrk = lrk0 + (wave * (RKL ? NL : 1) * DT) * 64 + lane;
+        float zs[ZR], zp[RKG || RKL ? 1 : ZR], pk[RKG || RKL ? 1 : 5][RKG || RKL ? 1 : ZR];   // stage state; z and the running sums, parked
+        f32x4 pkv[RKL ? 6 - NL : 1][RKL ? DT : 1];                                            // (RKL) rows NL .. 5, parked
         float lacc = 0.f, eacc = 0.f, nacc = 0.f;
         __syncthreads();   // the previous super-tile's readers of the LDS images are done
 #pragma unroll
@@ -710,7 +718,7 @@ coopd_solve_kernel(DArgs da) {
                 const int s = 4 * kg + j, f = 4 * s + g;
                 if (a.x) zs[s] = f < a.nvars ? a.x[sc * a.nvars + f] : 0.f;
                 else zs[s] = f < D ? a.u0[sc * S + f] : 0.f;
-                if constexpr (!RKG) zp[s] = park(zs[s]);
+                if constexpr (!RKG && !RKL) zp[s] = park(zs[s]);
                 v[j] = (MODE == 0 && f < D) ? a.eps[sc * D + f] : 0.f;
             }
             if constexpr (MODE == 0) ebuf[(kg * 4 + wave) * 64 + lane] = v;   // the probe of this wave's sample tile as a B image, for the whole solve
@@ -724,6 +732,11 @@ coopd_solve_kernel(DArgs da) {
         if constexpr (RKG) {
 #pragma unroll
             for (int q = 0; q < DT; ++q) rk[(5 * DT + q) * 64] = f32x4{zs[4 * q], zs[4 * q + 1], zs[4 * q + 2], zs[4 * q + 3]};
+        }
+        if constexpr (RKL) {
+            static_assert(NL <= 5, "z stays parked");
+#pragma unroll
+            for (int q = 0; q < DT; ++q) pkv[5 - NL][q] = park4(f32x4{zs[4 * q], zs[4 * q + 1], zs[4 * q + 2], zs[4 * q + 3]});
         }
         if (!a.x) { lacc = a.u0[sc * S + D]; eacc = a.u0[sc * S + D + 1]; nacc = a.u0[sc * S + D + 2]; }
         UAcc<A> cP;
@@ -810,6 +823,34 @@ coopd_solve_kernel(DArgs da) {
 #pragma unroll
                         for (int j = 0; j < 4; ++j) zs[4 * q + j] = zn4[j];
                     }
+                } else if constexpr (RKL) {
+                    // the same expressions as the ring's path, row r from LDS (r < NL) or from its parked registers
+                    auto get = [&](int r, int q) -> f32x4 { return r < NL ? lrk[(r * DT + q) * 64] : unpark4(pkv[r < NL ? 0 : r - NL][q]); };
+                    auto put = [&](int r, int q, const f32x4& v) {
+                        if (r < NL) lrk[(r * DT + q) * 64] = v;
+                        else pkv[r < NL ? 0 : r - NL][q] = park4(v);
+                    };
+                    f32x4 o[5][DT], zz[DT];
+#pragma unroll
+                    for (int q = 0; q < DT; ++q) {
+#pragma unroll
+                        for (int r = 0; r < 5; ++r) o[r][q] = first ? f32x4{0.f, 0.f, 0.f, 0.f} : get(r, q);
+                        zz[q] = get(5, q);
+                    }
+#pragma unroll
+                    for (int q = 0; q < DT; ++q) {
+                        const f32x4 k = {zd[4 * q], zd[4 * q + 1], zd[4 * q + 2], zd[4 * q + 3]};
+                        const f32x4 p0 = k * c0 + o[0][q], nsu = k * bst + o[4][q];
+                        put(0, q, k * c1 + o[1][q]);
+                        put(1, q, k * c2 + o[2][q]);
+                        put(2, q, k * c3 + o[3][q]);
+                        put(3, q, k * c4);
+                        put(4, q, nsu);
+                        f32x4 zn4 = p0 * dt + zz[q];
+                        if (lastst) { zn4 = nsu * dt + zz[q]; put(5, q, zn4); }
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) zs[4 * q + j] = zn4[j];
+                    }
                 } else {
 #pragma unroll
                 for (int s = 0; s < ZR; ++s) {
@@ -879,9 +920,9 @@ coopd_solve_kernel(DArgs da) {
 // ---------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------
-template <int A, int L, int ZR, int ACT, int MODE>
+template <int A, int L, int ZR, int ACT, int MODE, int NL = 0>
 static hipError_t launch_coopd(const DArgs& a, int lds, int nblocks, hipStream_t st) {
-    auto kern = coopd_solve_kernel<A, L, ZR, ACT, MODE>;
+    auto kern = coopd_solve_kernel<A, L, ZR, ACT, MODE, NL>;
     static DeviceOnce once;
     int dev = 0;
     hipError_t e0 = hipGetDevice(&dev);
@@ -898,12 +939,16 @@ static hipError_t launch_coopd(const DArgs& a, int lds, int nblocks, hipStream_t
 struct CoopDInst {
     int A, L, ZR, ACT, MODE;
     hipError_t (*fn)(const DArgs&, int, int, hipStream_t);
+    int NL;                                                      // rows of the Runge-Kutta state in LDS of the form below (0: none)
+    hipError_t (*fn_lds)(const DArgs&, int, int, hipStream_t);   // the same instance with NL rows of the Runge-Kutta state in LDS, or null
 };
-#define CD_INST(A, L, ZR, ACT) CoopDInst { A, L, ZR, ACT, 0, &launch_coopd<A, L, ZR, ACT, 0> }
-#define CD_EXACT(A, ZR, ACT) CoopDInst { A, 2, ZR, ACT, 1, &launch_coopd<A, 2, ZR, ACT, 1> }
+constexpr int kCdLdsRows = 3;
+#define CD_INST(A, L, ZR, ACT) CoopDInst { A, L, ZR, ACT, 0, &launch_coopd<A, L, ZR, ACT, 0>, 0, nullptr }
+#define CD_INST_LDS(A, L, ZR, ACT) CoopDInst { A, L, ZR, ACT, 0, &launch_coopd<A, L, ZR, ACT, 0>, kCdLdsRows, &launch_coopd<A, L, ZR, ACT, 0, kCdLdsRows> }
+#define CD_EXACT(A, ZR, ACT) CoopDInst { A, 2, ZR, ACT, 1, &launch_coopd<A, 2, ZR, ACT, 1>, 0, nullptr }
 // (A, ZR) pairs of the reference's default architecture H = 4 (D + 1): D <= 48 with 9 .. 12 hidden tiles (nvariables 16 .. 23),
 // D <= 64 with 13 .. 16 (nvariables 24 .. 31); the same pairs serve any flow of those sizes
-#define CD_SHAPES(L, ACT) CD_INST(2, L, 12, ACT), CD_INST(3, L, 12, ACT), CD_INST(3, L, 16, ACT)
+#define CD_SHAPES(L, ACT) CD_INST_LDS(2, L, 12, ACT), CD_INST(3, L, 12, ACT), CD_INST(3, L, 16, ACT)
 static const CoopDInst kCoopD[] = {
     CD_SHAPES(2, CNF_ACT_SOFTPLUS),
     // other flows of 8 .. 15 hidden tiles: tanh, three hidden layers (A = 2: act' of two layers parked), D <= 32
@@ -990,9 +1035,14 @@ hipError_t coopd_launch(int H, int D, int L, int ACT, int HT_lay, int ZR_lay, in
     G.xalias = coopd_lds_bytes(HT_real, L, DT, false, G.cvn, k.C > 0) <= 160 * 1024 ? 0 : 1;
     const int lds = coopd_lds_bytes(HT_real, L, DT, G.xalias != 0, G.cvn, k.C > 0);
     if (lds > 160 * 1024 || (G.xalias && 4 * DT * 4 > (L == 2 ? 1 : 2) * HT_real * 4)) return hipErrorNotSupported;
-    if (cd_rk_in_ring(c->A, c->L, c->ZR) && !k.rk) return hipErrorNotSupported;   // the ring of the Runge-Kutta sums (coopd_rk_floats: plan-owned)
     const long long nst = (k.B + 63) / 64;
     const int nblocks = (int)(nst < num_cus ? nst : num_cus);
+    // rows of the Runge-Kutta state in LDS where the instance has the form and the configuration's images leave the room
+    if (c->fn_lds && !G.xalias && tuning().coopd != 3) {
+        const int lds2 = (lds + 15) / 16 * 16 + c->NL * DT * 4 * 64 * 16;
+        if (lds2 <= 160 * 1024) return c->fn_lds(a, lds2, nblocks, st);
+    }
+    if (cd_rk_in_ring(c->A, c->L, c->ZR) && !k.rk) return hipErrorNotSupported;   // the ring of the Runge-Kutta sums (coopd_rk_floats: plan-owned)
     return c->fn(a, lds, nblocks, st);
 }
 

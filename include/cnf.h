@@ -121,7 +121,7 @@ typedef struct cnf_tuning {
     int32_t tile_split;            /* CNF_TILE_SPLIT, default 1: 1: whole fixed-step solves of per-wave shapes with at most one 16-sample tile per CU take the tile-split kernel; 0: never; 2: always */
     int32_t solve2;                /* CNF_SOLVE2, default 2: whole fixed-step solves of one-probe VJP flows without conditions on the hand-scheduled per-wave kernel (csrc/cnf_mfma2.hip; same bits) with two waves per SIMD; 1: one wave per SIMD; 0: mfma_solve_kernel */
     int32_t solve2_pair;           /* CNF_SOLVE2_PAIR, default 1: batches of at most two 16-sample tiles per CU of two-tile nets (cfg1) run two waves per tile (forward chain / pullback: csrc/cnf_mfma2.hip); 0: one */
-    int32_t coopd;                 /* CNF_COOPD, default 1: dealt cooperative kernels (csrc/cnf_coop_d*.hip): 1 above 4096 columns where they serve the plan; 0 off; 2 at every batch */
+    int32_t coopd;                 /* CNF_COOPD, default 1: dealt cooperative kernels (csrc/cnf_coop_d*.hip): 1 above 4096 columns where they serve the plan; 0 off; 2 at every batch; 3 as 1 with the Runge-Kutta rows of the (2, 12) instance in the plan's global ring instead of LDS (A/B, bit-identical) */
     int32_t coopd_grad;            /* CNF_COOPD_GRAD, default 1: dealt reverse sweep (csrc/cnf_coop_dgrad.hip): 1 where it has an instance; 0 off (section 8.4's sweep); 2 forced */
     int32_t coop_grad;             /* CNF_COOP_GRAD, default 1: cooperative reverse sweep (gradient path 3); 0: those shapes train layer-wise */
     int32_t coop_grad_mid;         /* CNF_COOP_GRAD_MID, default 1: auxiliary cooperative plan for the gradient of the slab shapes of 5 - 8 hidden tiles (7 - 8: every batch size, 5 - 6: up to 8192 columns); N > 1: from N columns on; 0 off */
