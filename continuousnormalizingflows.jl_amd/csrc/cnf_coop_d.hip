@@ -234,7 +234,7 @@ __device__ __forceinline__ void coopd_eval(const DRs& R, const float* __restrict
                                            const f32x4* __restrict__ ybuf, int lane, int wave, float t, bool autonomous, bool reg_z, bool reg_j,
                                            const float (&zs)[ZR], float (&zd)[ZR], float& ld, float& ed, float& nd,
                                            float* __restrict__ gout, const UAcc<A>& cP, f32x4 (&aS)[A], f32x4 (&aR)[3],
-                                           float* __restrict__ fsb = nullptr, long long fsl = 0) {
+                                           float* __restrict__ fsb = nullptr, long long fsl = 0, int gqs = 4) {
     // fsb (checkpointing solves, round 6): the stage store of the second-order reverse sweep (cnf_tiles.h) - every h_l and delta_l
     // tile of this evaluation leaves for HBM from the registers of the wave that computed it, tile-native (one 16-byte store per
     // lane; HTs = 4 A + b tiles per sample tile).  fsb: float pointer at this super-tile's first tile of (kind h, layer 0) for this
@@ -466,7 +466,7 @@ __device__ __forceinline__ void coopd_eval(const DRs& R, const float* __restrict
             for (int j = 0; j < 4; ++j) {
                 dot = fmaf(ga[j], ev[j], dot);   // <eps^T J, eps>
                 n2 = fmaf(ga[j], ga[j], n2);
-                if (gout) gout[4 * dm + j] = ga[j];       // checkpointing solve: g of this stage for the reverse sweep
+                if (gout) gout[gqs * dm + j] = ga[j];     // checkpointing solve: g of this stage for the reverse sweep (gqs: floats between 16-row groups)
             }
         }
         ld = -group_sum(dot);
@@ -755,23 +755,27 @@ coopd_solve_kernel(DArgs da) {
         const bool single = a.nsteps == 0;
         const int ns = single ? 1 : (a.T.ns < 6 ? a.T.ns : 6);
         const int nsteps = single ? 1 : a.nsteps;
-        // checkpoints for the cooperative gradient: [..][16-sample tile][lane][ckzr]
+        // checkpoints for the cooperative gradient: [..][16-sample tile][lane][ckzr], or (KArgs::ck_tiles) [..][tile][16-row group][lane][4]:
+        // state register s of this lane sits at lane * ckls + (s >> 2) * ckqs + (s & 3) inside the tile's 64 ckzr floats
         const long long cktile = st * 4 + wave, ckntp = nst * 4;
         const int ckzr = G.ckzr;
+        const int ckls = a.ck_tiles ? 4 : ckzr, ckqs = a.ck_tiles ? 256 : 4;
+        auto ck_put = [&](float* c, const float (&v)[ZR]) {
+#pragma unroll
+            for (int q = 0; q < ZR / 4; ++q) *reinterpret_cast<f32x4*>(c + q * ckqs) = f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+            for (int q = ZR / 4; q < ckzr / 4; ++q) *reinterpret_cast<f32x4*>(c + q * ckqs) = f32x4{0.f, 0.f, 0.f, 0.f};
+        };
 #pragma clang loop unroll(disable)
         for (int step = 0; step < nsteps; ++step) {
             const float tn = a.tgrid ? a.tgrid[step] : a.t0 + (float)step * dt0;
             const float dt = a.tgrid ? a.tgrid[step + 1] - tn : dt0;
             if (a.ckpt && !single) {
-                float* c = a.ckpt + (((long long)step * ckntp + cktile) * 64 + lane) * ckzr;
-#pragma unroll
-                for (int s = 0; s < ZR; ++s) c[s] = zs[s];   // (at a step's start the stage state IS z)
-                for (int s = ZR; s < ckzr; ++s) c[s] = 0.f;
+                ck_put(a.ckpt + ((long long)step * ckntp + cktile) * 64 * ckzr + lane * ckls, zs);   // (at a step's start the stage state IS z)
             }
             float lsum = 0.f, esum = 0.f, nsum = 0.f;
 #pragma clang loop unroll(disable)
             for (int sg = 0; sg < ns; ++sg) {
-                const long long ckrow = ((((long long)step * ns + sg) * ckntp + cktile) * 64 + lane) * ckzr;
+                const long long ckrow = (((long long)step * ns + sg) * ckntp + cktile) * 64 * ckzr + lane * ckls;
                 float* gout = (a.ckpt_g && !single) ? a.ckpt_g + ckrow : nullptr;
                 if constexpr (MODE == 0) {
                     float* fsb = nullptr;
@@ -781,19 +785,14 @@ coopd_solve_kernel(DArgs da) {
                         fsb = a.kfull + ((((long long)step * ns + sg) * ckntp + st * 4) * HT) * 256;
                     }
                     coopd_eval<A, L, ZR, ACT>(R, cbuf, G, xbuf, XB, zbuf, ebuf, pbuf, ybuf, lane, wave, tn + a.T.c[sg] * dt, autonomous, reg_z, reg_j,
-                                              zs, zd, ld, ed, nd, gout, cP, aS, aR, fsb, fsl);
+                                              zs, zd, ld, ed, nd, gout, cP, aS, aR, fsb, fsl, ckqs);
                 }
                 else
                     coopd_eval_exact<A, ZR, ACT>(R, cbuf, G, xbuf, zbuf, pbuf, reinterpret_cast<float*>(ebuf), ybuf, lane, wave, tn + a.T.c[sg] * dt,
                                                  autonomous, zs, zd, ld, aS, aR);   // (the probe image's LDS holds the partial traces)
                 if (gout)
-                    for (int s = ZR; s < ckzr; ++s) gout[s] = 0.f;
-                if (a.ckpt_k && !single) {
-                    float* c = a.ckpt_k + ckrow;
-#pragma unroll
-                    for (int s = 0; s < ZR; ++s) c[s] = zd[s];
-                    for (int s = ZR; s < ckzr; ++s) c[s] = 0.f;
-                }
+                    for (int q = ZR / 4; q < ckzr / 4; ++q) *reinterpret_cast<f32x4*>(gout + q * ckqs) = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (a.ckpt_k && !single) ck_put(a.ckpt_k + ckrow, zd);
                 const float bst = a.T.b[sg];
                 lsum = fmaf(bst, ld, lsum); esum = fmaf(bst, ed, esum); nsum = fmaf(bst, nd, nsum);
                 if (single) break;
@@ -875,10 +874,7 @@ coopd_solve_kernel(DArgs da) {
             lacc = fmaf(dt, lsum, lacc); eacc = fmaf(dt, esum, eacc); nacc = fmaf(dt, nsum, nacc);
         }
         if (a.ckpt && !single) {
-            float* c = a.ckpt + (((long long)nsteps * ckntp + cktile) * 64 + lane) * ckzr;
-#pragma unroll
-            for (int s = 0; s < ZR; ++s) c[s] = zs[s];
-            for (int s = ZR; s < ckzr; ++s) c[s] = 0.f;
+            ck_put(a.ckpt + ((long long)nsteps * ckntp + cktile) * 64 * ckzr + lane * ckls, zs);
         }
         if (single) {
             if (valid) {
@@ -1004,6 +1000,7 @@ void dimg_fill(DImg& G, int H, int D, int L, int HT_lay, int ZR_lay, int CR_lay,
     G.KGH = HT_real; G.remH = ksH - 4 * (HT_real - 1);
     G.KGZ = (KZ + 3) / 4; G.remZ = KZ - 4 * (G.KGZ - 1);
     G.ckzr = ZR_lay;
+    G.ck_ls = ZR_lay; G.ck_qs = 4;
     G.q_off = 0;
     G.f1y = Y.f1y; G.KPC = Y.KGC > 0 ? Y.KGC : 1; G.remC = (C + 3) / 4;   // condition k-steps (<= 4)
     G.cvn = Y.v_bN + MfmaLayout::vecC(Y.DT) - Y.v_b1;
@@ -1030,6 +1027,8 @@ hipError_t coopd_launch(int H, int D, int L, int ACT, int HT_lay, int ZR_lay, in
     dimg_fill(G, H, D, L, HT_lay, ZR_lay, CR_lay, A_inst, k.C);
     G.q_off = exact ? k.q_off : 0;
     if (k.C > 16 || (k.C > 0 && CR_lay < G.remC)) return hipErrorNotSupported;
+    if ((k.ckpt || k.ckpt_k) && ZR_lay % 4 != 0) return hipErrorNotSupported;   // (checkpoint rows leave as 16-byte stores)
+    if (form32 && k.ck_tiles) return hipErrorNotSupported;   // (the 32-sample form writes [tile][lane][ZR] rows only)
     if (form32) return coopd2_launch(HT_real, L, KZ, ACT, a, num_cus, st);
     const int DT = c->ZR / 4;
     G.xalias = coopd_lds_bytes(HT_real, L, DT, false, G.cvn, k.C > 0) <= 160 * 1024 ? 0 : 1;

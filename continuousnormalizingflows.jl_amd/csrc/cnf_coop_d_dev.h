@@ -17,6 +17,8 @@ struct DImg {
     int KGZ, remZ;    // real state k-groups and k-steps of the last one
     int xalias;       // the partial tiles alias the exchange buffer (LDS is short): one more barrier per D-row product
     int ckzr;         // floats per lane of the checkpoint arrays (the plan's ZR: what the reverse sweep strides by)
+    int ck_ls, ck_qs; // checkpoint rows: floats between lanes / between a lane's 16-row groups inside a tile of 64 ckzr floats - (ckzr, 4): [tile][lane][ckzr];
+                      // (4, 256): [tile][group][lane][4] (KArgs::ck_tiles, written by the dealt forward kernel for the second form's sweeps)
     int f1y, KPC, remC;   // conditioned flows (C <= 16: one k-group): the condition columns' image of layer 1, its k-group pitch, real k-steps (0: none)
     int q_off;        // exact-trace instances: float offset of the Q image (two hidden layers: tr J = act'_2^T Q act'_1), else 0
     int cvn;          // floats of the C-vector section [v_b1, end of v_bN) of the image: staged into LDS once per workgroup

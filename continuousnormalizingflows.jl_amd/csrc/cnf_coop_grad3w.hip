@@ -65,7 +65,7 @@ coop_grad3w_step_kernel(G3Args ga) {
     const float inv_fs = ACT == CNF_ACT_TANH_PRESCALED ? 1.f / kTanhPrescale : 1.f;   // the forward images of tanh nets carry the pre-scale
     const int ns = a.T.ns < NS ? a.T.ns : NS;
     const float dt = a.dt, tn = a.tn;
-    const int ckzr = G.ckzr;
+    const int ckzr = G.ckzr, ckls = G.ck_ls, ckqs = G.ck_qs;   // (cnf_coop_d_dev.h: the two layouts of the checkpoint rows)
     const int un = 3 - wave;
     const bool v0 = LO && un < G.b;
     const int tR = (4 * A + un < HT - 1) ? 4 * A + un : HT - 1;
@@ -170,7 +170,7 @@ coop_grad3w_step_kernel(G3Args ga) {
         float eps[KZ];
 #pragma unroll
         for (int s = 0; s < KZ; ++s) eps[s] = 0.f;
-        const f32x4* znp = reinterpret_cast<const f32x4*>(a.ckpt + (((long long)a.step * ntp + tile) * 64 + lane) * ckzr);
+        const float* znp = a.ckpt + ((long long)a.step * ntp + tile) * 64 * ckzr + lane * ckls;
         f32x4* lamp = reinterpret_cast<f32x4*>(a.lam + (tile * 64 + lane) * KZ);
         // Zbar_j of this wave's sample tile: [NS][DT] f32x4 per lane in the kernel's global scratch (L2; written and read by the same lane)
         f32x4* zbt = reinterpret_cast<f32x4*>(a.zb) + ((tile * NS * DT) * 64 + lane);
@@ -184,7 +184,7 @@ coop_grad3w_step_kernel(G3Args ga) {
                 // the costate at t_1 (cotangent of the loss terms of the final state): made here, kept where every later step keeps it
                 float lam[KZ];
 #pragma unroll
-                for (int s = 0; s < KZ; ++s) lam[s] = valid ? a.ckpt[(((long long)a.nsteps * ntp + tile) * 64 + lane) * ckzr + s] : 0.f;
+                for (int s = 0; s < KZ; ++s) lam[s] = valid ? a.ckpt[((long long)a.nsteps * ntp + tile) * 64 * ckzr + lane * ckls + (s >> 2) * ckqs + (s & 3)] : 0.f;
                 if (a.lam3 != 0.f) {
                     float sa = 0.f;
 #pragma unroll
@@ -223,8 +223,8 @@ coop_grad3w_step_kernel(G3Args ga) {
                 // cycles that way): slot j of a 16-row group is the stage derivative k_j where the tableau's a[i][j] multiplies it
                 // (j < i) and Zbar_{j+1} where a[j+1][i] does (j >= i) - NS - 1 rows, not 2 (NS - 1).
                 const long long rowb = (long long)a.step * ns * ntp + tile, rstride = ntp * 64 * (long long)ckzr;
-                const float* kbase = a.ckpt_k + (rowb * 64 + lane) * ckzr;
-                const float* gbase = (a.lam2 != 0.f ? a.ckpt_g : a.ckpt_k) + (rowb * 64 + lane) * ckzr;
+                const float* kbase = a.ckpt_k + rowb * 64 * ckzr + lane * ckls;
+                const float* gbase = (a.lam2 != 0.f ? a.ckpt_g : a.ckpt_k) + rowb * 64 * ckzr + lane * ckls;
                 f32x4 row[NS - 1][DT], zn[DT], lm[DT], ki[DT], gi[DT];
                 float ca[NS - 1], ck[NS - 1];
 #pragma unroll
@@ -234,16 +234,16 @@ coop_grad3w_step_kernel(G3Args ga) {
                     ca[j] = lower ? a.T.a[i][j] : 0.f;
                     ck[j] = upper ? a.T.a[j + 1][i] : 0.f;
                     const f32x4* src = upper ? zbt + ((j + 1) * DT) * 64 : reinterpret_cast<const f32x4*>(kbase + (j < ns ? j : ns - 1) * rstride);
-                    const int qs = upper ? 64 : 1;                    // f32x4 stride between the 16-row groups of the source
+                    const int qs = upper ? 64 : (ckqs >> 2);          // f32x4 stride between the 16-row groups of the source
 #pragma unroll
                     for (int q = 0; q < DT; ++q) row[j][q] = src[q * qs];
                 }
 #pragma unroll
                 for (int q = 0; q < DT; ++q) {
-                    zn[q] = znp[q];
+                    zn[q] = *reinterpret_cast<const f32x4*>(znp + q * ckqs);
                     lm[q] = lamp[q];
-                    ki[q] = *reinterpret_cast<const f32x4*>(kbase + i * rstride + 4 * q);
-                    gi[q] = *reinterpret_cast<const f32x4*>(gbase + i * rstride + 4 * q);
+                    ki[q] = *reinterpret_cast<const f32x4*>(kbase + i * rstride + q * ckqs);
+                    gi[q] = *reinterpret_cast<const f32x4*>(gbase + i * rstride + q * ckqs);
                 }
                 load_units(q3.fh[0], soH, h1);               // h_1 of this stage: needed behind the first product
                 // gbar = cotangent of g = eps^T J: -c_l eps (+ c_n g / |g|);  kbar += c_E zdot / |zdot|  (src/core/icnf.jl:184-251)
@@ -524,6 +524,7 @@ hipError_t coop_grad3w_step_launch(int H, int D, int L, int ACT, int HT_lay, int
     G3Args ga{};
     ga.c = a;
     dimg_fill(ga.g, H, D, L, HT_lay, ZR_lay, 0, c->A, 0);
+    if (a.ck_tiles) { ga.g.ck_ls = 4; ga.g.ck_qs = 256; }
     const int lds = coop_grad3w_lds_bytes(HT_real, c->KZ / 4);
     if (lds > 80 * 1024) return hipErrorNotSupported;
     const long long nst = a.c.ntiles_pad / 2;

@@ -91,6 +91,7 @@ struct SolveArgs {
     float dt_exact;  // != 0: the step itself (nsteps = 1 attempts: (t0 + dt) - t0 is not dt in float32); 0: (t1 - t0) / nsteps
     float* ckpt_g;   // optional, cooperative checkpointing solve only (KArgs::ckpt_g)
     const float* tgrid_dev;   // optional, cooperative checkpointing solve only: nsteps + 1 step times on the device
+    int ck_tiles;    // 1: checkpoint rows in tile layout (KArgs::ck_tiles) - only where mfma_plan_ckpt_rows_as_tiles(plan, B) says the solve's kernel writes it
 };
 hipError_t mfma_solve(MfmaPlan* p, const float* packed_dev, const SolveArgs& a, hipStream_t st);
 constexpr int kHostRec = 120;   // accepted steps the one-launch solves also record in pinned host memory (AArgs::host_rec)
@@ -153,6 +154,7 @@ long long mfma_plan_ckpt_tiles(const MfmaPlan* p, long long B, bool on_grid = fa
 bool coop_grad_eligible(const cnf_config& c, const MfmaPlan* plan, const float lam[3], bool on_grid);
 int coop_grad_stage_store_tiles(const cnf_config& c, MfmaPlan* plan, long long B, int alg, int nsteps, bool on_grid);   // > 0: the cooperative gradient's second form
 long long coop_grad_max_columns(const cnf_config& c, int alg);   // batches beyond it take the layer-wise path (32-bit operand addressing)
+bool mfma_plan_ckpt_rows_as_tiles(const MfmaPlan* p, long long B, bool on_grid);   // cnf_mfma.hip: the checkpointing solve of B columns runs on the dealt kernel's 64-sample form, which can write KArgs::ck_tiles
 int mfma_plan_stage_store_tiles(const MfmaPlan* p, long long B, bool on_grid);   // cnf_mfma.hip: 0 = the forward solve writes no stage store
 hipError_t coop_grad(LayeredGrad** ctx, const cnf_config& c, MfmaPlan* plan, const float* packed_dev, const size_t* w_off,
                      const size_t* b_off, const float* x, const float* eps, const float* ys, int alg, int nsteps, float t0, float t1,

@@ -1087,6 +1087,9 @@ static hipError_t coop_grad3_run(LayeredGrad& G, const cnf_config& c, MfmaPlan* 
     sa.logp = logp_out; sa.regs = regs_out; sa.nvars = c.nvars; sa.reg_aug = (c.reg_aug && c.naug > 0) ? 1 : 0;
     sa.ckpt = W + o_zck; sa.ckpt_k = W + o_kck; sa.ckpt_g = lam[1] != 0.f ? W + o_gck : nullptr;
     sa.kfull = G.ws_store;
+    // the checkpoint rows as tiles where the forward solve's kernel writes that layout (the dealt 64-sample form): the sweeps' row reads coalesce
+    const bool ck_tiles = mfma_plan_ckpt_rows_as_tiles(plan, B, false);
+    sa.ck_tiles = ck_tiles ? 1 : 0;
     LG_HIP(mfma_solve(plan, packed_dev, sa, st));
 
     // ---- reverse: one sweep launch per step, then the step's weight-cotangent products over tiles ----
@@ -1097,7 +1100,7 @@ static hipError_t coop_grad3_run(LayeredGrad& G, const cnf_config& c, MfmaPlan* 
     a.c.lam1 = lam[0]; a.c.lam2 = lam[1]; a.c.lam3 = lam[2]; a.c.T = T;
     for (int l = 0; l < Lh; ++l) { a.sv[l] = W + o_sv[l]; a.ss[l] = W + o_ss[l]; }
     a.gb = W + o_gb; a.zt = W + o_zt; a.ep = W + o_ep; a.kb = W + o_kb;
-    a.HTs = HTs; a.DTZ = DTZ; a.DTs = DT;
+    a.HTs = HTs; a.DTZ = DTZ; a.DTs = DT; a.ck_tiles = ck_tiles ? 1 : 0;
     const float dt = (t1 - t0) / (float)nsteps;
     // (Tried, round 6: the three kinds of product of a step - disjoint slab regions, disjoint operands; the D-sized ones bound by
     // reading their H-row operand once, the H x H ones by the matrix pipe - side by side on three library-owned streams, joined

@@ -486,6 +486,14 @@ int mfma_plan_stage_store_tiles(const MfmaPlan* p, long long B, bool on_grid) {
     if (p->kind == 1 && coop_ckpt_supported(p->HT, p->L, p->ZR, p->ACT)) return p->HT;
     return 0;
 }
+bool mfma_plan_ckpt_rows_as_tiles(const MfmaPlan* p, long long B, bool on_grid) {
+    if (!p || on_grid || p->ZR % 4 != 0) return false;
+    (void)plan_ensure_cus(const_cast<MfmaPlan*>(p));
+    if (!plan_uses_coopd(p, B)) return false;
+    int hmax = 0;
+    for (int l = 1; l < p->cfg.n_layers; ++l) hmax = p->cfg.widths[l] > hmax ? p->cfg.widths[l] : hmax;
+    return coopd_supertile(hmax, p->cfg.nvars + p->cfg.naug, p->L, p->ACT, 0) == 64;
+}
 bool mfma_plan_is_per_wave(const MfmaPlan* p) { return p->kind == 0; }
 // can this plan's forward solve checkpoint for the cooperative gradient (on the caller's grid when `on_grid`)?  Extended-kernel
 // plans always do (run-time switch); cooperative plans through their CK instance on uniform steps, otherwise through the
@@ -548,6 +556,8 @@ hipError_t mfma_solve(MfmaPlan* p, const float* packed_dev, const SolveArgs& s, 
     a.packed = packed_dev;
     a.x = s.x; a.u0 = s.u0; a.eps = s.eps; a.ys = s.ys;
     a.u_out = s.u_out; a.logp = s.logp; a.regs = s.regs; a.ckpt = s.ckpt; a.ckpt_k = s.ckpt_k; a.kfull = s.kfull; a.ckpt_g = s.ckpt_g; a.tgrid = s.tgrid_dev;
+    a.ck_tiles = s.ck_tiles;
+    if (s.ck_tiles && !mfma_plan_ckpt_rows_as_tiles(p, s.B, s.tgrid_dev != nullptr)) return hipErrorNotSupported;   // (only that kernel writes the layout)
     a.B = s.B; a.nsteps = s.nsteps; a.t0 = s.t0;
     a.dt = s.nsteps > 0 ? (s.dt_exact != 0.f ? s.dt_exact : (s.t1 - s.t0) / (float)s.nsteps) : 0.f;
     a.nvars = s.nvars; a.D = p->cfg.nvars + p->cfg.naug; a.C = p->cfg.ncond;

@@ -65,6 +65,7 @@ struct CG3Args {
     float* ep;                // out: [eps]
     float* kb;                // out: [kbar]
     int HTs, DTZ, DTs;        // tiles per column tile of the H-row arrays, of gb / zt, of ep / kb
+    int ck_tiles;             // 1: the checkpoint rows (c.ckpt, c.ckpt_k, c.ckpt_g) are in tile layout (KArgs::ck_tiles)
 };
 bool coop_grad3_supported(int H, int D, int L, int ACT, int HT_lay, int ZR_lay, int CR_lay);
 hipError_t coop_grad3_step_launch(int H, int D, int L, int ACT, int HT_lay, int ZR_lay, const CG3Args& a, int num_cus, hipStream_t st);
