@@ -1140,6 +1140,9 @@ STAGE_STORE_GRAD_SHAPES = [
     (dict(nvars=20, naug=21, hidden=[168, 168], act=2, reg_z=True, reg_j=True, reg_aug=True), 130, 1, 2, (0.01, 0.01, 0.01), True),  # ICNF(nvariables = 20): 11 tiles (three left-over)
     (dict(nvars=24, naug=25, hidden=[200, 200], act=2, reg_z=True, reg_j=True, reg_aug=True), 45, 0, 2, (0.01, 0.01, 0.01), True),   # ICNF(nvariables = 24): 13 tiles (A = 3), 16 state registers
     (dict(nvars=12, hidden=[160, 160], act=2), 60, 1, 2, None, True),                                   # softplus, 10 tiles, D <= 32
+    (dict(nvars=48, hidden=[168, 168], act=2), 37, 1, 2, None, True),                                   # D = 48: the time row opens a fourth 16-row group of the input side (DTZ > DT)
+    (dict(nvars=20, naug=4, hidden=[136, 136], autonomous=True, reg_aug=True), 100, 0, 2, (0.0, 0.0, 0.02), True),   # tanh, two layers, autonomous (no time row), RK4, |z_aug|
+    (dict(nvars=28, naug=29, hidden=[232, 232], act=2, reg_z=True, reg_j=True, reg_aug=True), 33, 1, 1, (0.01, 0.01, 0.01), True),   # ICNF(nvariables = 28): 15 tiles (A = 3, three left-over), one step
     (dict(nvars=10, hidden=[176, 176]), 40, 0, 3, None, True),                                          # tanh, two layers
     (dict(nvars=20, naug=5, hidden=[200, 200, 200], reg_aug=True), 150, 0, 3, None, True),              # tanh, three layers, 13 of 16 tiles
     (dict(nvars=8, hidden=[136, 136, 136], act=2), 90, 1, 2, None, True),                               # softplus, three layers (A = 2)
