@@ -16,11 +16,14 @@
 // trips run under the other's products:
 //   * h_1 is read twice per stage from the stage store (at the start for vbar_1, behind the last H x H product's fragment
 //     requests for sbar_1) instead of being parked; dbar_1 and dbar_2 stay in architectural registers;
-//   * the owners keep no rows: z_n and the costate of the step are re-read per stage from the checkpoint / costate arrays (L2),
-//     Zbar_j of the running step's stages lives in the kernel's global scratch (CGArgs::zb, L2), the dense phase works one
-//     16-row group at a time;
+//   * the owners keep no rows: z_n and the costate of the step are re-read per stage from the checkpoint / costate arrays (L2;
+//     coalesced where the forward solve wrote them as tiles, KArgs::ck_tiles), Zbar_j of the running step's stages lives in the
+//     kernel's global scratch (CGArgs::zb, L2); every row of a stage's dense phase is requested up front, unconditionally;
 //   * nothing is requested a stage ahead: the other workgroup's products cover the round trips.
-// Two hidden layers, HT = 4 A + b real hidden tiles (A = 2, 3), 32-sample super-tiles, tanh and softplus.
+// Two hidden layers, HT = 4 A + b real hidden tiles (A = 2, 3), 32-sample super-tiles, tanh and softplus.  Same chains and the same
+// summation order as cnf_coop_grad3.hip: the two sweeps agree bit for bit (tests/test_parity_gpu.py).
+// Measured (default architecture, B = 32 768, 40 Tsit5 steps; profiles/r6/): 0.512 -> 0.451 ms per launch at nvariables = 20,
+// 45.7 % MFMA-busy (39.8 % one per CU); what was tried on top of it and lost is in DESIGN.md section 8.6.
 #include "cnf_coop_grad3_dev.h"
 
 namespace cnf {
