@@ -125,7 +125,7 @@ typedef struct cnf_tuning {
     int32_t coopd_grad;            /* CNF_COOPD_GRAD, default 1: dealt reverse sweep (csrc/cnf_coop_dgrad.hip): 1 where it has an instance; 0 off (section 8.4's sweep); 2 forced */
     int32_t coop_grad;             /* CNF_COOP_GRAD, default 1: cooperative reverse sweep (gradient path 3); 0: those shapes train layer-wise */
     int32_t coop_grad_mid;         /* CNF_COOP_GRAD_MID, default 1: auxiliary cooperative plan for the gradient of the slab shapes of 5 - 8 hidden tiles (7 - 8: every batch size, 5 - 6: up to 8192 columns); N > 1: from N columns on; 0 off */
-    int32_t coop_grad3;            /* CNF_COOP_GRAD3, default 1: the cooperative gradient in its second form: the forward solve stores h_l and delta_l of every stage, the sweep (csrc/cnf_coop_grad3.hip) runs the second-order chains alone - with two workgroups per CU on two hidden layers (csrc/cnf_coop_grad3w.hip); 2: the one-workgroup-per-CU sweep for every shape (A/B); 0: the sweeps that recompute both chains */
+    int32_t coop_grad3;            /* CNF_COOP_GRAD3, default 1: the cooperative gradient in its second form: the forward solve stores h_l and delta_l of every stage, the sweep (csrc/cnf_coop_grad3.hip) runs the second-order chains alone - with two workgroups per CU on two hidden layers once there are more 32-sample super-tiles than CUs (csrc/cnf_coop_grad3w.hip); 2: the one-workgroup-per-CU sweep for every shape and size, 3: the two-per-CU sweep at every size (A/B, tests; the two agree bit for bit); 0: the sweeps that recompute both chains */
     int32_t coop_grad3_gib;        /* CNF_COOP_GRAD3_GIB, default 96: GiB of HBM the stage store of that form may take (of 288); larger batches take the recomputing sweeps */
     int32_t grad_layered;          /* CNF_GRAD_LAYERED, default 0: 1: every gradient takes the layer-wise path (A/B, cross-checks) */
     int32_t jvp_grad_twin;         /* CNF_JVP_GRAD_TWIN, default 1: JVP mode without the |J eps| regulariser trains through the VJP mode's fused sweeps; 0: its own layer-wise gradient */

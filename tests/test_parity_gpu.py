@@ -1156,8 +1156,8 @@ def test_cooperative_gradient_second_form(kw, B, alg, nsteps, lam, dealt, pkg, o
     (csrc/cnf_wgrad_tiles.hip).  dloss/dps, dloss/dxs and the loss against fp64 autograd through the same discrete solve
     (src/core/icnf.jl:90-99 differentiates `loss` through the solve), and against the sweeps that recompute both first-order
     chains (CNF_COOP_GRAD3=0) on the same handle configuration; cnf_grad_form_for says which one a call takes.  Two hidden layers
-    run the sweep with two workgroups per CU (csrc/cnf_coop_grad3w.hip); CNF_COOP_GRAD3=2 keeps the one-per-CU sweep for every
-    shape: same chains, same summation order - the two must agree bit for bit."""
+    run the sweep with two workgroups per CU (csrc/cnf_coop_grad3w.hip; CNF_COOP_GRAD3=3 takes it at these small batches too);
+    CNF_COOP_GRAD3=2 keeps the one-per-CU sweep for every shape: same chains, same summation order - the two must agree bit for bit."""
     o64, _ = oracles
     if dealt:
         setsw(pkg, monkeypatch, "CNF_COOPD", "2")
@@ -1168,7 +1168,7 @@ def test_cooperative_gradient_second_form(kw, B, alg, nsteps, lam, dealt, pkg, o
     L, gref, gxref = o64.loss_and_grad(spec, p, xs, 0.0, 1.0, nsteps, alg, eps, ys, lam, wrt_x=True)
     mode = mode_of(pkg, spec)
     out = {}
-    for tag, flag in (("store", "1"), ("store_one_per_cu", "2"), ("recompute", "0")):
+    for tag, flag in (("store", "3"), ("store_one_per_cu", "2"), ("recompute", "0")):
         setsw(pkg, monkeypatch, "CNF_COOP_GRAD3", flag)
         icnf = make_icnf(pkg, spec, alg, nsteps, path=0, lambdas=lam)
         val, g, gx = pkg.loss_and_gradient(icnf, mode, dev(xs), dev(p), {}, eps=dev(eps), wrt_x=True)
