@@ -25,6 +25,8 @@ for tag, line in lines():
     r = d["roofline"]
     out = [tag, d["config"]["name"], f"{d['value']:.4g}", f"frac={r['frac']:.4f}", f"kernel_ms={r['kernel_ms']:.4f}", f"loss={d['loss']:.6f}"]
     if "secondary" in d:
-        s = d["secondary"]
-        out += ["|", s["config"]["name"], f"{s['value']:.4g}", f"frac={s['roofline']['frac']:.4f}"]
+        s = d["secondary"]   # (round 6: the stdout digest carries {name, ms, frac, value, ...}; the full record has config / roofline)
+        name = s["config"]["name"] if "config" in s else s.get("name", "?")
+        frac = s["roofline"]["frac"] if "roofline" in s else s.get("frac", float("nan"))
+        out += ["|", name, f"{s['value']:.4g}", f"frac={frac:.4f}"]
     print(" ".join(str(x) for x in out))
