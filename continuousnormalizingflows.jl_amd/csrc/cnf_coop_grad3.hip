@@ -190,7 +190,7 @@ coop_grad3_step_kernel(G3Args ga) {
     auto down_ew = [&](U& hb, const U& h, const U& dl, const U& db) {
         auto one = [&](f32x4& x, const f32x4& hh, const f32x4& dd, const f32x4& bb) {
             const f32x4 d = dact_from_h<ACT>(hh);
-            x = x * d + bb * g3_G<ACT>(hh, dd, d);
+            x = g3_sbar(x, d, bb, g3_G<ACT>(hh, dd, d));
         };
 #pragma unroll
         for (int m = 0; m < A; ++m)

@@ -114,6 +114,17 @@ __device__ __forceinline__ void g3_gemm(const DRs& R, const G3Off<A>& T, unsigne
     }
 }
 
+// sbar = hbar .* act' + dbar .* G as ONE spelled-out sequence - the product dbar .* G rounded, then a fused multiply-add - so that every
+// instantiation of both sweeps (cnf_coop_grad3.hip, cnf_coop_grad3w.hip) rounds alike: left to -ffp-contract=fast the compiler fused one
+// product or the other depending on the code around it, and the two sweeps - which a call is routed to by its size - differed in the
+// last bit (3e-7 of the gradient) the day one of them changed shape
+__device__ __forceinline__ f32x4 g3_sbar(const f32x4& hbar, const f32x4& d, const f32x4& dbar, const f32x4& G) {
+    f32x4 t;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) t[e] = __fmul_rn(dbar[e], G[e]);
+    return __builtin_elementwise_fma(hbar, d, t);
+}
+
 // G = delta act'' / act'  (so that  a2 .* act'' = dbar .* u .* act'' = dbar .* G  with delta = u .* act'):  tanh: act'' = -2 h act';
 // softplus: act'' = act' (1 - act')
 template <int ACT>

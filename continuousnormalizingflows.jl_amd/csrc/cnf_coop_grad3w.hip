@@ -38,7 +38,9 @@ constexpr int coop_grad3w_lds_bytes(int HT, int DT) {
 
 // A: shared hidden tiles per wave (HT = 4 A + b, b run-time: the left-over tiles go one each to waves 3, 2, 1);
 // KZ: state registers per lane (D <= 4 KZ, whole M-tiles); NS: stages of the instance
-template <int A, int KZ, int ACT, int NS>
+// H1L: h_1 of the stage waits in LDS between its two uses (this wave's own units: no barrier) where 80 KB have the room - A = 2 -
+// instead of being read from the stage store a second time (one of a stage's five tile-set reads)
+template <int A, int KZ, int ACT, int NS, bool H1L>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 coop_grad3w_step_kernel(G3Args ga) {
     constexpr int NC = 2;
@@ -57,6 +59,7 @@ coop_grad3w_step_kernel(G3Args ga) {
     f32x4* X1 = X0 + X0N;                              // [HT][NC][64]
     f32x4* gbuf = X1 + HT * NC * 64;                   // [DT][NC][64]: gbar
     f32x4* kbuf = gbuf + DT * NC * 64;                 // [DT][NC][64]: kbar
+    f32x4* hbuf = kbuf + DT * NC * 64;                 // (H1L) [HT][NC][64]: h_1 of the stage
     f32x4* pbuf = X0;
     const int lane = threadIdx.x & 63, g = lane >> 4, n = lane & 15;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -153,7 +156,7 @@ coop_grad3w_step_kernel(G3Args ga) {
     auto down_ew = [&](U& hb, const U& h, const U& dl, const U& db) {
         auto one = [&](f32x4& x, const f32x4& hh, const f32x4& dd, const f32x4& bb) {
             const f32x4 d = dact_from_h<ACT>(hh);
-            x = x * d + bb * g3_G<ACT>(hh, dd, d);
+            x = g3_sbar(x, d, bb, g3_G<ACT>(hh, dd, d));
         };
 #pragma unroll
         for (int m = 0; m < A; ++m)
@@ -344,6 +347,14 @@ coop_grad3w_step_kernel(G3Args ga) {
                 U vb;
                 up_ew(acc, h1, vb);                      // acc <- dbar_1, vb <- vbar_1
                 publish(X0, vb);
+                if constexpr (H1L) {
+#pragma unroll
+                    for (int m = 0; m < A; ++m)
+#pragma unroll
+                        for (int c = 0; c < NC; ++c) hbuf[((mtS0 + m) * NC + c) * 64 + lane] = h1.S[m][c];
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) hbuf[(tR * NC + c) * 64 + lane] = h1.R[c];   // (a wave without a left-over tile holds a clamped copy of another wave's: the same values into the same slot)
+                }
                 d1 = acc;
                 zero_u(acc);
                 G3_T(4);
@@ -378,7 +389,15 @@ coop_grad3w_step_kernel(G3Args ga) {
             // ================= down: hbar_1 = W_2^T sbar_2 =================
             U dl1;
             g3_gemm<A, LO, NC>(R, TH, BH, G.KGH, G.remH, v0, X1, lane, aS, aR, acc,
-                               [&]() { load_units(q3.fh[0], soH, h1); load_units(q3.fd[0], soH, dl1); });
+                               [&]() { if constexpr (!H1L) load_units(q3.fh[0], soH, h1); load_units(q3.fd[0], soH, dl1); });
+            if constexpr (H1L) {
+#pragma unroll
+                for (int m = 0; m < A; ++m)
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) h1.S[m][c] = hbuf[((mtS0 + m) * NC + c) * 64 + lane];
+#pragma unroll
+                for (int c = 0; c < NC; ++c) h1.R[c] = hbuf[(tR * NC + c) * 64 + lane];
+            }
             G3_T(11);
             // the fragments of the Zbar product (this wave's own k-groups of W_1[:,0:D]^T)
             constexpr int NZ = A + 1;
@@ -472,9 +491,9 @@ coop_grad3w_step_kernel(G3Args ga) {
 // ---------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------
-template <int A, int KZ, int ACT, int NS>
+template <int A, int KZ, int ACT, int NS, bool H1L>
 static hipError_t launch_g3w(const G3Args& a, int lds, int nblocks, hipStream_t st) {
-    auto kern = coop_grad3w_step_kernel<A, KZ, ACT, NS>;
+    auto kern = coop_grad3w_step_kernel<A, KZ, ACT, NS, H1L>;
     static DeviceOnce once;
     int dev = 0;
     hipError_t e0 = hipGetDevice(&dev);
@@ -491,8 +510,10 @@ static hipError_t launch_g3w(const G3Args& a, int lds, int nblocks, hipStream_t 
 struct G3WInst {
     int A, KZ, ACT;
     hipError_t (*fn[2])(const G3Args&, int, int, hipStream_t);   // [0] RK4 (4 stages), [1] Tsit5 (6 stages)
+    hipError_t (*fn_h1l[2])(const G3Args&, int, int, hipStream_t);   // the same with h_1 kept in LDS (A = 2), or null
 };
-#define G3W_INST(A, KZ, ACT) G3WInst { A, KZ, ACT, { &launch_g3w<A, KZ, ACT, 4>, &launch_g3w<A, KZ, ACT, 6> } }
+#define G3W_INST(A, KZ, ACT) G3WInst { A, KZ, ACT, { &launch_g3w<A, KZ, ACT, 4, false>, &launch_g3w<A, KZ, ACT, 6, false> }, \
+                                       { A == 2 ? &launch_g3w<2, KZ, ACT, 4, true> : nullptr, A == 2 ? &launch_g3w<2, KZ, ACT, 6, true> : nullptr } }
 static const G3WInst kG3W[] = {
     G3W_INST(2, 8, CNF_ACT_SOFTPLUS), G3W_INST(2, 12, CNF_ACT_SOFTPLUS),
     G3W_INST(2, 8, CNF_ACT_TANH_PRESCALED), G3W_INST(2, 12, CNF_ACT_TANH_PRESCALED),
@@ -532,7 +553,10 @@ hipError_t coop_grad3w_step_launch(int H, int D, int L, int ACT, int HT_lay, int
     if (lds > 80 * 1024) return hipErrorNotSupported;
     const long long nst = a.c.ntiles_pad / 2;
     const int nblocks = (int)(nst < 2LL * num_cus ? nst : 2LL * num_cus);
-    return c->fn[a.c.T.ns <= 4 ? 0 : 1](ga, lds, nblocks, st);
+    const int si = a.c.T.ns <= 4 ? 0 : 1;
+    const int lds_h1 = lds + HT_real * 2 * 64 * 16;
+    if (c->fn_h1l[si] && lds_h1 <= 80 * 1024) return c->fn_h1l[si](ga, lds_h1, nblocks, st);
+    return c->fn[si](ga, lds, nblocks, st);
 }
 
 }  // namespace cnf

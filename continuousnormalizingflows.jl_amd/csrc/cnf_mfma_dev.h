@@ -38,8 +38,8 @@ struct KArgs {
                         // instance hoists q: PRE = 2); 0: through the last product, as the PRE <= 1 instances do
     int ck_tiles;       // the dealt forward kernel's 64-sample form (cnf_coop_d.hip) only: 1 = the checkpoint rows (ckpt, ckpt_k, ckpt_g) in TILE layout
                         // [row][tile][16-row group][lane][4] - one coalesced 1 KB access per group for the wave that owns the tile - instead of
-                        // [row][tile][lane][ZR] (48-byte lane stride at 12 state registers: three to five times the cache-line lookups per
-                        // access, and the rows are the sweep owners' whole dense phase); same bytes per tile either way
+                        // [row][tile][lane][ZR] (64 bytes between lanes at the default architecture's 16 state registers: every 16-byte access
+                        // of a wave touches 32 cache lines instead of 8, and the rows are the sweep owners' whole dense phase); same bytes per tile
 };
 
 // Device-side step controller (mfma_adaptive_kernel): the whole adaptive Tsit5 solve of a batch that fits the chip's wave
