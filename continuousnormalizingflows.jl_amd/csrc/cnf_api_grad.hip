@@ -94,12 +94,19 @@ static GradServe grad_serve(const cnf_handle* h, int64_t B, int alg, bool on_gri
         if (h->cfg.mode == CNF_MODE_HUTCH_JVP) {
             const GradServe t = grad_serve(h->grad_twin, B, alg, on_grid);
             if (t.path == 1 || t.path == 3) return t;
-        } else if (own != 1 && own != 3 && api_grad_route(h->grad_twin, B, alg, on_grid).path == 3 &&
-                   (h->cfg.n_layers == 3 || tuning().probe_grad_twin == 2)) {
-            // measured at K = 4, B = 32 768 (profiles/probes_wide_timing.py): 1.39 - 1.48 x the layer-wise path on two hidden layers
-            // (the reference's default architecture), 0.96 x on 3 x 256 - so three hidden layers keep their layer-wise gradient
-            // unless CNF_PROBE_GRAD_TWIN=2 asks for the loop
-            return GradServe{h->grad_twin, 3, h->cfg.nprobes};
+        } else if (own != 1 && own != 3) {
+            const GradRoute tr = api_grad_route(h->grad_twin, B, alg, on_grid);
+            // measured at K = 4, B = 32 768 (profiles/probes_wide_timing.py, profiles/r6/r6z_probes_wide_timing.json): 1.76 - 1.78 x the
+            // layer-wise path on two hidden layers (the reference's default architecture); on 3 x 256 0.96 x with the recomputing sweeps
+            // of round 5 and 1.22 x with the cooperative gradient's second form (345 against 420 ms) - so three hidden layers take the
+            // loop where the twin's call takes that form (asked with one step: a store that does not fit HBM falls back to the older
+            // sweeps inside the loop), else keep their layer-wise gradient unless CNF_PROBE_GRAD_TWIN=2 asks for the loop
+            bool loop = tr.path == 3 && (h->cfg.n_layers == 3 || tuning().probe_grad_twin == 2);
+            if (tr.path == 3 && !loop && tuning().probe_grad_twin == 1 && B > 0) {
+                const cnf_handle* t = h->grad_twin;
+                loop = coop_grad_stage_store_tiles(t->cfg, tr.use_cg_aux ? t->grad.plan_cg : t->plan, B, alg, 1, on_grid) > 0;
+            }
+            if (loop) return GradServe{h->grad_twin, 3, h->cfg.nprobes};
         }
     }
     return GradServe{h, own, 1};

@@ -129,7 +129,7 @@ typedef struct cnf_tuning {
     int32_t coop_grad3_gib;        /* CNF_COOP_GRAD3_GIB, default 96: GiB of HBM the stage store of that form may take (of 288); larger batches take the recomputing sweeps */
     int32_t grad_layered;          /* CNF_GRAD_LAYERED, default 0: 1: every gradient takes the layer-wise path (A/B, cross-checks) */
     int32_t jvp_grad_twin;         /* CNF_JVP_GRAD_TWIN, default 1: JVP mode without the |J eps| regulariser trains through the VJP mode's fused sweeps; 0: its own layer-wise gradient */
-    int32_t probe_grad_twin;       /* CNF_PROBE_GRAD_TWIN, default 1: K > 1 probes on two hidden layers whose own gradient is layer-wise train probe by probe on the one-probe cooperative sweep; 2: three hidden layers too (slower there); 0: never */
+    int32_t probe_grad_twin;       /* CNF_PROBE_GRAD_TWIN, default 1: K > 1 probes whose own gradient is layer-wise train probe by probe on the one-probe cooperative sweep - two hidden layers always, three where the one-probe call takes the second form (1.22 x at 3 x 256, K = 4); 2: three hidden layers always (0.96 x on the recomputing sweeps); 0: never */
     int32_t adaptive_ckpt;         /* CNF_ADAPTIVE_CKPT, default 1: the adaptive Tsit5 solve of cnf_loss_grad_adaptive writes the checkpoints of the frozen-grid gradient itself, and the slab-accumulator gradient reads those of the loss solve (no second forward pass); 0: every gradient runs its own */
     int32_t layered_loss_by_solve; /* CNF_LAYERED_LOSS_BY_SOLVE, default 0: 1: the layer-wise gradient takes its loss from a separate solve instead of accumulating it in the sweep */
     int32_t device_controller;     /* CNF_DEVICE_CONTROLLER, default 1: one-launch adaptive Tsit5 / VCABM with the step controller on the device where the batch fits; 0: host loop */

@@ -1398,8 +1398,10 @@ def test_several_probes_train_probe_by_probe_on_the_cooperative_sweep(kw, lam, B
         setsw(pkg, monkeypatch, "CNF_PROBE_GRAD_TWIN", env)
         icnf = make_icnf(pkg, spec, alg, nsteps, path=0, lambdas=lam)
         mode = pkg.TrainMode(bool(spec.reg_z or spec.reg_j or spec.reg_aug))
-        # by default only two hidden layers take the loop (three: 0.96 x the layer-wise path at K = 4, B = 32 768)
-        assert icnf.grad_path(mode, B=B, alg=alg) == (3 if tag == "loop" or (tag == "default" and two_hidden) else 2)
+        # by default two hidden layers take the loop, and three where the one-probe call runs the cooperative gradient's second form
+        # (cfg4's 3 x 256: 1.22 x the layer-wise path at K = 4, B = 32 768; with the recomputing sweeps - 3 x 192 - 0.96 x: layer-wise)
+        second_form = spec.widths[1:-1] == [256, 256, 256]
+        assert icnf.grad_path(mode, B=B, alg=alg) == (3 if tag == "loop" or (tag == "default" and (two_hidden or second_form)) else 2)
         if tag == "default":
             continue
         val, g, gx = pkg.loss_and_gradient(icnf, mode, dev(xs), dev(p), {}, eps=dev(eps), wrt_x=True)
