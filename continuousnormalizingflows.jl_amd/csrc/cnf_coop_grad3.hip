@@ -75,7 +75,7 @@ coop_grad3_step_kernel(G3Args ga) {
     const float inv_fs = ACT == CNF_ACT_TANH_PRESCALED ? 1.f / kTanhPrescale : 1.f;   // the forward images of tanh nets carry the pre-scale
     const int ns = a.T.ns < NS ? a.T.ns : NS;
     const float dt = a.dt, tn = a.tn;
-    const int ckzr = G.ckzr, ckls = G.ck_ls, ckqs = G.ck_qs;   // (cnf_coop_d_dev.h: the two layouts of the checkpoint rows)
+    const int ckzr = G.ckzr;   // (lane-major checkpoint rows only: the tile layout of KArgs::ck_tiles is the two-per-CU sweep's - its two run-time strides cost the 512-register instances here 14 ... 42 spilled registers)
     // this wave's left-over tile (b of them, one each to waves 3, 2, 1; clamped for the loads)
     const int un = 3 - wave;
     const bool v0 = LO && un < G.b;
@@ -220,11 +220,11 @@ coop_grad3_step_kernel(G3Args ga) {
             for (int s = 0; s < KZ; ++s) {
                 const int f = 4 * s + g;
                 eps[s] = f < D ? a.eps[sc * D + f] : 0.f;
-                zn[s] = a.ckpt[((long long)a.step * ntp + tile) * 64 * ckzr + lane * ckls + (s >> 2) * ckqs + (s & 3)];
+                zn[s] = a.ckpt[(((long long)a.step * ntp + tile) * 64 + lane) * ckzr + s];
             }
             if (a.step == a.nsteps - 1) {
 #pragma unroll
-                for (int s = 0; s < KZ; ++s) lam[s] = valid ? a.ckpt[((long long)a.nsteps * ntp + tile) * 64 * ckzr + lane * ckls + (s >> 2) * ckqs + (s & 3)] : 0.f;
+                for (int s = 0; s < KZ; ++s) lam[s] = valid ? a.ckpt[(((long long)a.nsteps * ntp + tile) * 64 + lane) * ckzr + s] : 0.f;
                 if (a.lam3 != 0.f) {
                     float sa = 0.f;
 #pragma unroll
@@ -251,18 +251,18 @@ coop_grad3_step_kernel(G3Args ga) {
         f32x4 krN[NS - 1][DT], kiN[DT], giN[DT];
         auto load_rows = [&](int is) {
             const long long rowb = (long long)a.step * ns * ntp + tile, rstride = ntp * 64 * (long long)ckzr;
-            const float* kbase = a.ckpt_k + rowb * 64 * ckzr + lane * ckls;
-            const float* gbase = (a.lam2 != 0.f ? a.ckpt_g : a.ckpt_k) + rowb * 64 * ckzr + lane * ckls;
+            const float* kbase = a.ckpt_k + (rowb * 64 + lane) * ckzr;
+            const float* gbase = (a.lam2 != 0.f ? a.ckpt_g : a.ckpt_k) + (rowb * 64 + lane) * ckzr;
 #pragma unroll
             for (int j = 0; j < NS - 1; ++j) {
                 const int jj = j < ns ? j : ns - 1;
 #pragma unroll
-                for (int q = 0; q < DT; ++q) krN[j][q] = *reinterpret_cast<const f32x4*>(kbase + jj * rstride + q * ckqs);
+                for (int q = 0; q < DT; ++q) krN[j][q] = *reinterpret_cast<const f32x4*>(kbase + jj * rstride + 4 * q);
             }
 #pragma unroll
             for (int q = 0; q < DT; ++q) {
-                kiN[q] = *reinterpret_cast<const f32x4*>(kbase + is * rstride + q * ckqs);
-                giN[q] = *reinterpret_cast<const f32x4*>(gbase + is * rstride + q * ckqs);
+                kiN[q] = *reinterpret_cast<const f32x4*>(kbase + is * rstride + 4 * q);
+                giN[q] = *reinterpret_cast<const f32x4*>(gbase + is * rstride + 4 * q);
             }
         };
         auto stage_off = [&](int is) { return (unsigned)(((long long)is * ntp + st * NC) * HTs * 1024); };
@@ -612,7 +612,7 @@ hipError_t coop_grad3_step_launch(int H, int D, int L, int ACT, int HT_lay, int 
     G3Args ga{};
     ga.c = a;
     dimg_fill(ga.g, H, D, L, HT_lay, ZR_lay, 0, c->A, 0);
-    if (a.ck_tiles) { ga.g.ck_ls = 4; ga.g.ck_qs = 256; }
+    if (a.ck_tiles) return hipErrorNotSupported;   // (this sweep reads lane-major checkpoint rows)
     const int lds = coop_grad3_lds_bytes(HT_real, c->KZ / 4, c->NC);
     if (lds > 160 * 1024) return hipErrorNotSupported;
     const long long nst = a.c.ntiles_pad / c->NC;

@@ -1087,8 +1087,16 @@ static hipError_t coop_grad3_run(LayeredGrad& G, const cnf_config& c, MfmaPlan* 
     sa.logp = logp_out; sa.regs = regs_out; sa.nvars = c.nvars; sa.reg_aug = (c.reg_aug && c.naug > 0) ? 1 : 0;
     sa.ckpt = W + o_zck; sa.ckpt_k = W + o_kck; sa.ckpt_g = lam[1] != 0.f ? W + o_gck : nullptr;
     sa.kfull = G.ws_store;
-    // the checkpoint rows as tiles where the forward solve's kernel writes that layout (the dealt 64-sample form): the sweeps' row reads coalesce
-    const bool ck_tiles = mfma_plan_ckpt_rows_as_tiles(plan, B, false);
+    // two hidden layers: the sweep with two workgroups per CU (cnf_coop_grad3w.hip) once there are more 32-sample super-tiles than CUs - with
+    // one workgroup per CU anyway the one-per-CU sweep, which requests a stage ahead, is the faster of the two (0.51 against 0.55 ms per
+    // launch at nvariables = 20); the two agree bit for bit, so the choice moves no number.  CNF_COOP_GRAD3=2 keeps the one-per-CU sweep, =3
+    // takes the two-per-CU one at every size (A/B, tests)
+    const int g3sw = tuning().coop_grad3;
+    const bool paired = g3sw != 2 && (g3sw == 3 || ntp / 2 > G.num_cus) && coop_grad3w_supported(H, D, Lh, ACT, HT, ZR, 0);
+    // the checkpoint rows as tiles where the forward solve's kernel writes that layout (the dealt 64-sample form) and the two-per-CU sweep
+    // reads them: up to 12 state registers - D <= 48 - a sweep reads three of a lane's four 16-byte groups and the layout pays (nvariables =
+    // 20: 48.8 -> 47.7 ms); with 16 every line is used either way
+    const bool ck_tiles = paired && D <= 48 && mfma_plan_ckpt_rows_as_tiles(plan, B, false);
     sa.ck_tiles = ck_tiles ? 1 : 0;
     LG_HIP(mfma_solve(plan, packed_dev, sa, st));
 
@@ -1109,11 +1117,6 @@ static hipError_t coop_grad3_run(LayeredGrad& G, const cnf_config& c, MfmaPlan* 
     // products (bound by reading their H-row operand once) on a second stream beside the NEXT step's sweep, launched on 8 / 16 / 32
     // fewer CUs, their inputs double-buffered: cfg4 85.7 -> 93.3 ms (1024 super-tiles on 240 workgroups are five rounds, not four),
     // nv = 20 50.9 -> 51.4.  One stream.)
-    // two hidden layers: the sweep with two workgroups per CU (cnf_coop_grad3w.hip) once there are more 32-sample super-tiles than CUs - with
-    // one workgroup per CU anyway the one-per-CU sweep, which requests a stage ahead, is the faster of the two (0.51 against 0.55 ms per
-    // launch at nvariables = 20); the two agree bit for bit, so the choice moves no number.  CNF_COOP_GRAD3=2 keeps the one-per-CU sweep, =3 takes the two-per-CU one at every size (A/B, tests)
-    const int g3sw = tuning().coop_grad3;
-    const bool paired = g3sw != 2 && (g3sw == 3 || ntp / 2 > G.num_cus) && coop_grad3w_supported(H, D, Lh, ACT, HT, ZR, 0);
     for (int n = nsteps - 1; n >= 0; --n) {
         a.c.step = n; a.c.tn = t0 + (float)n * dt; a.c.dt = dt;
         for (int l = 0; l < Lh; ++l) { a.fh[l] = G.ws_store + S.at(0, l, n, 0); a.fd[l] = G.ws_store + S.at(1, l, n, 0); }
