@@ -83,8 +83,16 @@ __global__ void reduce_slabs_kernel(const float* __restrict__ slabs, int nslab, 
                                     float* __restrict__ grad) {
     const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= L.npa) return;
-    float acc = 0.f;
-    for (int s = 0; s < nslab; ++s) acc += slabs[(long long)s * stride + e];
+    // eight independent partial sums (slabs s = k mod 8) keep eight loads in flight; combined in a fixed order (one dependent chain over
+    // several hundred slabs took 0.29 ms for the 37 k parameters of the default architecture at nvariables = 20)
+    float p8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int s = 0;
+    for (; s + 8 <= nslab; s += 8) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) p8[k] += slabs[(long long)(s + k) * stride + e];
+    }
+    for (int k = 0; s < nslab; ++s, ++k) p8[k] += slabs[(long long)s * stride + e];
+    const float acc = ((p8[0] + p8[1]) + (p8[2] + p8[3])) + ((p8[4] + p8[5]) + (p8[6] + p8[7]));
     int l = 0;
     while (l + 1 < L.n_layers && e >= L.pa_off[l + 1]) ++l;
     const long long r = e - L.pa_off[l];
